@@ -1,0 +1,172 @@
+/* kao.h -- C ABI of libkao.so, the MI355X (gfx950) solver for the Kafka partition-assignment
+ * 0-1 model of killerwhile/kafka-assignment-optimizer.
+ *
+ * What this boundary replaces.  The reference snapshot (/root/reference = README.md + one
+ * image) contains no code, hence no FFI declaration to copy.  Its only solver seam is
+ * "lp_solve is used behind the scene to solve the generated linear equation"
+ * (README.md:135-136): the generated 0-1 model (README.md:144-185) goes in, one 0/1 value per
+ * variable plus the objective comes out.  libkao.so replaces exactly that seam; each entry
+ * point below cites the README lines it stands in for.  The structured instance (kao_topic)
+ * is the compact form of the same model: variable t<T>b<B>p<P>[_l] (README.md:146,
+ * README.md:182-184) == "broker B holds a replica of partition P of topic T [as leader]"
+ * == assignment[P*rf + k] == B with k == 0 for the `_l` variable.
+ *
+ * Conventions: plain C, little-endian integers, caller owns every buffer, the library never
+ * frees caller memory, no exceptions cross the ABI, return 0 = success / negative = error
+ * (kao_strerror).  One process drives one GPU (kao_init(device)); sessions are independent.
+ * Every compute entry point runs on the GPU; there is no CPU fallback -- without a usable
+ * device the calls fail with KAO_ERR_NO_DEVICE.
+ */
+#ifndef KAO_H
+#define KAO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAO_VERSION 100 /* 0.1.0 */
+#define KAO_NONE 0xFFFFu /* "no broker": replica on a broker outside the target set / empty slot */
+#define KAO_MAX_RF 4     /* replica slots per partition supported by the gfx950 kernels */
+#define KAO_MAX_RACKS 64
+
+enum {
+    KAO_OK = 0,
+    KAO_ERR_INVALID = -1,     /* bad argument */
+    KAO_ERR_UNSUPPORTED = -2, /* RF > KAO_MAX_RF, racks > KAO_MAX_RACKS, topic too large for LDS */
+    KAO_ERR_NO_DEVICE = -3,   /* no gfx950 device / HIP runtime failure at init */
+    KAO_ERR_HIP = -4,         /* HIP runtime error (message via kao_last_error) */
+    KAO_ERR_NOMEM = -5,
+    KAO_ERR_NOT_INIT = -6
+};
+
+enum { /* kao_result.status */
+    KAO_STATUS_OPTIMAL_PROVEN = 0,    /* feasible and objective == upper_bound */
+    KAO_STATUS_FEASIBLE_BOUND_GAP = 1,/* feasible, objective < upper_bound (bound not tight or not optimal) */
+    KAO_STATUS_NO_FEASIBLE = 2,       /* search found no feasible assignment (lp_solve would say "infeasible"
+                                         only if truly so; this is not a proof) */
+    KAO_STATUS_TIME_LIMIT = 3         /* feasible, stopped by the time limit before target_objective */
+};
+
+/* One topic's sub-problem.  Topics are independent in the README model: every variable and
+ * row carries the topic prefix t1... (README.md:146-184). */
+typedef struct kao_topic {
+    int32_t n_brokers;        /* B: size of the TARGET broker set (--broker-list, README.md:48) */
+    int32_t n_racks;          /* R <= KAO_MAX_RACKS */
+    int32_t n_partitions;     /* P */
+    int32_t rf;               /* target replication factor (README.md:148-151), <= KAO_MAX_RF */
+    int32_t rf_cur;           /* replication factor of `current` (README.md:9: RF may change) */
+    const uint8_t *rack_of;   /* [B] dense rack index of each target broker (README.md:27-29) */
+    const uint16_t *current;  /* [P*rf_cur] dense broker index, slot 0 = preferred leader
+                                 (README.md:52-63); KAO_NONE = broker not in the target set */
+    int32_t w[2][2];          /* objective weights w[cur_role][new_role], role 0 leader, 1 follower
+                                 (README.md:145-146); default {{4,1},{2,2}} */
+    /* band right-hand sides; -1 = derive floor/ceil of the average (README.md:159-160,
+       164-165, 174-175, 179) */
+    int32_t rep_lo, rep_hi;     /* C3 replicas per broker   (README.md:158-161) */
+    int32_t lead_lo, lead_hi;   /* C4 leaders per broker    (README.md:163-166) */
+    int32_t rack_lo, rack_hi;   /* C6 replicas per rack     (README.md:173-176) */
+    int32_t prack_lo, prack_hi; /* C7 replicas per partition per rack (README.md:178-180) */
+} kao_topic;
+
+typedef struct kao_opts {
+    uint64_t seed;            /* search is deterministic in (seed, restarts, iters_per_launch) */
+    double time_limit_s;      /* kao_solve: wall-clock limit; <= 0 = default 10 s */
+    int32_t restarts;         /* parallel restarts (wavefronts) per topic; <= 0 = auto */
+    int32_t iters_per_launch; /* local-search iterations per K-search launch; <= 0 = 512 */
+    int32_t max_launches;     /* kao_solve: stop after this many launches; <= 0 = unlimited */
+    int32_t obj_scale;        /* S in cost = lam*violation - S*objective; <= 0 = 4 */
+    int32_t lam_min, lam_max; /* penalty sawtooth bounds; <= 0 = 1 / 40 */
+    int32_t period_log2;      /* sawtooth period = 2^(period_log2 + (restart & 3)); <= 0 = 8 */
+    int32_t stop_at_bound;    /* kao_solve: 1 = stop as soon as every topic is OPTIMAL_PROVEN */
+    int32_t profile;          /* 1 = bracket every kernel with HIP events (kao_session_stats) */
+} kao_opts;
+
+typedef struct kao_result {
+    int32_t status;            /* KAO_STATUS_* */
+    int32_t best_restart;      /* which restart produced the answer */
+    int64_t objective;         /* value of the README objective (README.md:145-146) */
+    int64_t upper_bound;       /* combinatorial bound (coupling constraints ignored) */
+    int32_t violations[8];     /* [0] total, [1..7] = C1..C7 magnitudes of the returned assignment */
+    double seconds_to_best;    /* wall time from entry to the launch that produced `objective` */
+    uint16_t *assignment;      /* [P*rf] caller-allocated; dense broker index, slot 0 = leader */
+} kao_result;
+
+typedef struct kao_stats {
+    uint64_t launches;          /* K-search launches */
+    uint64_t delta_candidates;  /* neighbours delta-evaluated by K-search (64 per iteration per restart) */
+    uint64_t full_candidates;   /* complete candidates fully evaluated by K-eval */
+    double ms_search;           /* HIP-event time of K-search launches (profile=1) */
+    double ms_eval;             /* HIP-event time of K-eval launches (profile=1) */
+    uint64_t search_bytes_algo; /* algorithmic bytes of the K-search launches */
+    uint64_t eval_bytes_algo;   /* algorithmic bytes of the K-eval launches */
+    int32_t n_restarts_total;
+    int32_t lds_bytes_search;   /* dynamic LDS per K-search workgroup */
+    int32_t blocks_search;      /* workgroups per K-search launch */
+    int32_t drift;              /* restarts whose incrementally tracked (V, objective) disagreed with the
+                                   from-scratch recount at the end of a launch; must be 0 */
+} kao_stats;
+
+typedef struct kao_session kao_session;
+typedef struct kao_eval_plan kao_eval_plan;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+int kao_init(int device);            /* select the HIP device of this process; idempotent */
+void kao_shutdown(void);
+int kao_version(void);
+const char *kao_strerror(int code);  /* static storage */
+const char *kao_last_error(void);    /* thread-local detail of the last failure */
+int kao_device_name(char *buf, int len);
+
+/* ---- host-side model helpers (no device work) ------------------------------------------ */
+/* Fill the derived band values (out[0..7] = rep_lo,rep_hi,lead_lo,lead_hi,rack_lo,rack_hi,
+ * prack_lo,prack_hi), honouring overrides >= 0.  README.md:158-180. */
+int kao_derive_bounds(const kao_topic *t, int32_t out[8]);
+/* Upper bound on the objective with every coupling row (C3,C4,C6,C7) dropped. */
+int kao_upper_bound(const kao_topic *t, int64_t *ub);
+/* Canonical tie-break among equal-objective feasible assignments (lowest broker index for newly
+ * placed replicas, retained followers keep their order): reproduces README.md:88 `[8,1]`.
+ * Uses kao_evaluate (GPU) for every feasibility check. */
+int kao_canonicalize(const kao_topic *t, uint16_t *assignment);
+
+/* ---- K-eval: full evaluation of complete candidates (README.md:145-180 in one pass) ---- */
+/* One candidate from host memory.  Stands in for "substitute the 0/1 vector into every row of
+ * the generated model". */
+int kao_evaluate(const kao_topic *t, const uint16_t *assignment, int64_t *objective, int32_t violations[8]);
+/* n candidates [n][P*rf] from host memory; objective[n], violations[n*8]. */
+int kao_evaluate_batch(const kao_topic *t, const uint16_t *candidates, int64_t n, int32_t *objective,
+                       int32_t *violations);
+/* Device-resident batches: tables uploaded once, candidates/outputs are DEVICE pointers. */
+int kao_eval_plan_create(const kao_topic *t, kao_eval_plan **out);
+int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, void *d_objective /* int32[n] */,
+                      void *d_violations /* int32[n*8] or NULL */, void *d_best_key /* uint64[1] or NULL */);
+int kao_eval_plan_sync(kao_eval_plan *p, double *ms_last /* HIP-event ms of the last run, or NULL */);
+void kao_eval_plan_destroy(kao_eval_plan *p);
+
+/* ---- K-search sessions: resident parallel-restart local search ------------------------- */
+/* Replaces lp_solve's solve() (README.md:135-136) for a batch of topics. */
+int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_session **out);
+/* One step = one K-search launch (iters_per_launch iterations for every restart of every topic)
+ * + one K-eval launch over every restart's best snapshot with the wavefront/block min-reduce
+ * into one packed key per topic.  Asynchronous on the session's stream. */
+int kao_session_step(kao_session *s);
+int kao_session_sync(kao_session *s);
+/* Copy back per-topic bests (results[n_topics], assignment buffers caller-allocated). */
+int kao_session_best(kao_session *s, kao_result *results);
+/* Per-topic packed best keys as the device holds them (uint64[n_topics]); the value a
+ * min-allreduce across GPUs operates on: viol(20b) << 44 | (0xFFFFFF - objective) << 20 | restart. */
+int kao_session_best_keys(kao_session *s, uint64_t *keys);
+int kao_session_stats(kao_session *s, kao_stats *out);
+/* Test hook: state of one restart -- final[P*rf], best[P*rf] (dense), info = {best_obj, V, obj, accepted}. */
+int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, uint16_t *final_state,
+                              uint16_t *best_state, int32_t info[4]);
+void kao_session_destroy(kao_session *s);
+
+/* Whole job: create, step until target/time limit, read back, destroy. */
+int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAO_H */

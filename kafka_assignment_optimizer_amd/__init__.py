@@ -1,0 +1,13 @@
+"""kafka_assignment_optimizer_amd -- MI355X (gfx950) solver for the Kafka partition-assignment
+0-1 model of killerwhile/kafka-assignment-optimizer (reference: /root/reference/README.md).
+
+The package is a thin host layer over the C ABI of ``libkao.so`` (include/kao.h): reassignment
+JSON in/out (README.md:52-63, README.md:67-78), instance preparation, and ctypes bindings.  All
+evaluation and search runs in the hand-written HIP kernels (csrc/kao_kernels.hip); there is no CPU
+fallback -- importing works anywhere, computing needs the GPU and the built library.
+"""
+from .model import DEFAULT_WEIGHTS, NONE, Topic, assignment_to_json, topics_from_json  # noqa: F401
+from .solver import (EvalPlan, KaoError, Result, Session, canonicalize, derive_bounds, device_name, evaluate,  # noqa: F401
+                     evaluate_batch, init, library_path, solve, upper_bound)
+
+__version__ = "0.1.0"

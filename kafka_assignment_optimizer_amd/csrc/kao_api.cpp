@@ -1,0 +1,768 @@
+// kao_api.cpp -- host side of libkao.so: the C ABI declared in include/kao.h.
+//
+// Everything that computes runs in the gfx950 kernels of kao_kernels.hip; this file only prepares
+// instances (dense -> rack-major internal broker index), owns the device pools, launches, and reads
+// results back.  There is deliberately no CPU evaluation or search path here: if the HIP device is
+// missing every compute entry point fails with KAO_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kao.h"
+#include "kao_internal.h"
+
+using namespace kao;
+
+namespace {
+
+thread_local std::string g_err;
+int g_device = -1;
+bool g_init = false;
+int g_num_cu = 256;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(KAO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+double now_s() {
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+void floor_ceil(int64_t num, int64_t den, int32_t &lo, int32_t &hi) {
+    lo = (int32_t)(num / den);
+    hi = (int32_t)((num + den - 1) / den);
+}
+
+int validate(const kao_topic *t) {
+    if (!t) return fail(KAO_ERR_INVALID, "null topic");
+    if (t->n_brokers < 1 || t->n_brokers > 65534) return fail(KAO_ERR_INVALID, "n_brokers out of range");
+    if (t->n_racks < 1) return fail(KAO_ERR_INVALID, "n_racks < 1");
+    if (t->n_racks > KAO_MAX_RACKS) return fail(KAO_ERR_UNSUPPORTED, "more than 64 racks");
+    if (t->n_partitions < 1) return fail(KAO_ERR_INVALID, "n_partitions < 1");
+    if (t->rf < 1 || t->rf_cur < 1) return fail(KAO_ERR_INVALID, "rf < 1");
+    if (t->rf > KAO_MAX_RF || t->rf_cur > KAO_MAX_RF) return fail(KAO_ERR_UNSUPPORTED, "replication factor > 4");
+    if (t->rf > t->n_brokers) return fail(KAO_ERR_INVALID, "rf > n_brokers");
+    if (!t->rack_of || !t->current) return fail(KAO_ERR_INVALID, "null rack_of/current");
+    for (int b = 0; b < t->n_brokers; ++b)
+        if (t->rack_of[b] >= t->n_racks) return fail(KAO_ERR_INVALID, "rack_of entry >= n_racks");
+    if ((int64_t)t->n_partitions * t->rf * 4 > (int64_t)kObjCap) return fail(KAO_ERR_UNSUPPORTED, "topic too large");
+    return KAO_OK;
+}
+
+void derive_bounds(const kao_topic *t, int32_t o[8]) {
+    const int64_t B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
+    floor_ceil(P * RF, B, o[0], o[1]);  // C3 README.md:158-161
+    floor_ceil(P, B, o[2], o[3]);       // C4 README.md:163-166
+    floor_ceil(P * RF, R, o[4], o[5]);  // C6 README.md:173-176
+    floor_ceil(RF, R, o[6], o[7]);      // C7 README.md:178-180
+    const int32_t ov[8] = {t->rep_lo, t->rep_hi, t->lead_lo, t->lead_hi, t->rack_lo, t->rack_hi, t->prack_lo, t->prack_hi};
+    for (int i = 0; i < 8; ++i)
+        if (ov[i] >= 0) o[i] = ov[i];
+}
+
+// Host-side image of one topic in both index spaces.
+struct PreparedTopic {
+    TopicDev d{};
+    std::vector<uint16_t> int_of;   // dense -> internal
+    std::vector<uint16_t> ext_of;   // internal -> dense
+    std::vector<int32_t> rack_size; // [R]
+    std::vector<uint16_t> cur_int;  // [P*4] internal
+    std::vector<uint8_t> rack_of;   // [B]
+    std::vector<uint16_t> cur_dense;// [P*rf_cur]
+};
+
+int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
+    int rc = validate(t);
+    if (rc) return rc;
+    const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    pt.rack_size.assign(R, 0);
+    for (int b = 0; b < B; ++b) pt.rack_size[t->rack_of[b]]++;
+    int m = 0;
+    for (int r = 0; r < R; ++r) m = std::max(m, pt.rack_size[r]);
+    const int64_t Bx = (int64_t)R * m;
+    if (Bx > 65534) return fail(KAO_ERR_UNSUPPORTED, "racks x largest-rack exceeds the 16-bit internal index");
+    pt.int_of.assign(B, 0);
+    pt.ext_of.assign((size_t)Bx, (uint16_t)KAO_NONE);
+    std::vector<int> fill(R, 0);
+    for (int b = 0; b < B; ++b) {  // dense order inside each rack is preserved
+        const int r = t->rack_of[b];
+        const int x = r * m + fill[r]++;
+        pt.int_of[b] = (uint16_t)x;
+        pt.ext_of[x] = (uint16_t)b;
+    }
+    pt.cur_int.assign((size_t)P * kRFP, (uint16_t)KAO_NONE);
+    for (int p = 0; p < P; ++p)
+        for (int k = 0; k < t->rf_cur; ++k) {
+            const unsigned b = t->current[(size_t)p * t->rf_cur + k];
+            if (b < (unsigned)B) pt.cur_int[(size_t)p * kRFP + k] = pt.int_of[b];
+        }
+    pt.rack_of.assign(t->rack_of, t->rack_of + B);
+    pt.cur_dense.assign(t->current, t->current + (size_t)P * t->rf_cur);
+    TopicDev &d = pt.d;
+    d.P = P; d.RF = t->rf; d.R = R; d.m = m; d.Bx = (int32_t)Bx;
+    d.magic = (uint32_t)(0x100000000ull / (uint64_t)m) + 1u;
+    d.rep_lo = bd[0]; d.rep_hi = bd[1]; d.lead_lo = bd[2]; d.lead_hi = bd[3];
+    d.rack_lo = bd[4]; d.rack_hi = bd[5]; d.prack_lo = bd[6]; d.prack_hi = bd[7];
+    d.w00 = t->w[0][0]; d.w01 = t->w[0][1]; d.w10 = t->w[1][0]; d.w11 = t->w[1][1];
+    d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
+    d.B = B; d.rf_cur = t->rf_cur;
+    return KAO_OK;
+}
+
+int64_t upper_bound(const kao_topic *t) {
+    // each partition keeps its best surviving replicas in their best roles; coupling rows dropped
+    int64_t total = 0;
+    const int B = t->n_brokers;
+    for (int p = 0; p < t->n_partitions; ++p) {
+        const uint16_t *c = t->current + (size_t)p * t->rf_cur;
+        const bool lead_alive = c[0] < (unsigned)B;
+        int n_fol = 0;
+        for (int k = 1; k < t->rf_cur; ++k) n_fol += c[k] < (unsigned)B;
+        int64_t best = 0;
+        struct Opt { int lead_gain, fol_avail; bool old_leader_fol; };
+        std::vector<Opt> opts;
+        if (lead_alive) opts.push_back({t->w[0][0], n_fol, false});
+        if (n_fol) opts.push_back({t->w[1][0], n_fol - 1, lead_alive});
+        opts.push_back({0, n_fol, lead_alive});
+        for (const Opt &o : opts) {
+            std::vector<int> gains((size_t)o.fol_avail, t->w[1][1]);
+            if (o.old_leader_fol) gains.push_back(t->w[0][1]);
+            std::sort(gains.rbegin(), gains.rend());
+            int64_t v = o.lead_gain;
+            for (int i = 0; i < (int)gains.size() && i < t->rf - 1; ++i)
+                if (gains[i] > 0) v += gains[i];
+            best = std::max(best, v);
+        }
+        total += best;
+    }
+    return total;
+}
+
+template <typename T>
+int dev_alloc_copy(T **dst, const std::vector<T> &src) {
+    *dst = nullptr;
+    const size_t n = std::max<size_t>(src.size(), 1);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return KAO_OK;
+}
+
+// Physical workgroup order: the dispatcher places workgroup b on XCD b % 8 (observed, used for L2
+// affinity only), so the workgroups of one topic -- which read the same tables -- are dealt to one XCD.
+template <typename Item>
+std::vector<Item> xcd_order(const std::vector<Item> &items, const std::vector<int> &topic_of) {
+    const size_t n = items.size();
+    std::vector<std::vector<size_t>> q(8);
+    for (size_t i = 0; i < n; ++i) q[(size_t)topic_of[i] % 8].push_back(i);
+    std::vector<size_t> head(8, 0);
+    std::vector<Item> out;
+    out.reserve(n);
+    for (size_t b = 0; b < n; ++b) {
+        size_t x = b % 8;
+        if (head[x] >= q[x].size()) {  // this XCD's queue ran dry: steal from the longest remaining one
+            size_t bestx = 0, bestlen = 0;
+            for (size_t y = 0; y < 8; ++y)
+                if (q[y].size() - head[y] > bestlen) { bestlen = q[y].size() - head[y]; bestx = y; }
+            x = bestx;
+            out.push_back(items[q[x].back()]);
+            q[x].pop_back();
+            continue;
+        }
+        out.push_back(items[q[x][head[x]++]]);
+    }
+    return out;
+}
+
+}  // namespace
+
+// =================================================================================================
+struct kao_eval_plan {
+    PreparedTopic pt;
+    TopicDev *d_topic = nullptr;
+    uint8_t *d_rackof = nullptr;
+    uint16_t *d_curd = nullptr;
+    int4 *d_map = nullptr;
+    int64_t map_n = -1;
+    int map_blocks = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int cands_per_block = 32;
+};
+
+struct kao_session {
+    int n_topics = 0;
+    kao_opts opts{};
+    std::vector<PreparedTopic> pts;
+    std::vector<kao_topic> topics;  // shallow copies (pointers not retained for device work)
+    std::vector<int64_t> ub;
+    int total_restarts = 0;
+    int maxP = 0, maxBx = 0, maxB = 0;
+    int blocks_search = 0, blocks_eval = 0;
+    // device pools
+    TopicDev *d_topics = nullptr;
+    int2 *d_smap = nullptr;
+    int4 *d_emap = nullptr;
+    uint2 *d_cur = nullptr;
+    uint16_t *d_ext = nullptr;
+    int32_t *d_rsz = nullptr;
+    uint2 *d_state = nullptr;
+    uint16_t *d_best = nullptr;
+    int32_t *d_info = nullptr;
+    int32_t *d_drift = nullptr;
+    uint8_t *d_rackof = nullptr;
+    uint16_t *d_curd = nullptr;
+    int32_t *d_obj = nullptr;
+    int32_t *d_viol = nullptr;
+    unsigned long long *d_keys = nullptr;
+    hipStream_t stream = nullptr;
+    uint32_t launch = 0;
+    // profiling
+    std::vector<hipEvent_t> ev;  // triples
+    int ev_pending = 0;
+    double ms_search = 0, ms_eval = 0;
+    uint64_t search_bytes_per_launch = 0, eval_bytes_per_launch = 0;
+};
+
+namespace {
+
+constexpr int kEvRing = 32;
+
+int session_drain_events(kao_session *s) {
+    for (int i = 0; i < s->ev_pending; ++i) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventSynchronize(s->ev[i * 3 + 2]));
+        HIP_TRY(hipEventElapsedTime(&a, s->ev[i * 3 + 0], s->ev[i * 3 + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, s->ev[i * 3 + 1], s->ev[i * 3 + 2]));
+        s->ms_search += a;
+        s->ms_eval += b;
+    }
+    s->ev_pending = 0;
+    return KAO_OK;
+}
+
+int require_init() {
+    if (!g_init) {
+        int rc = kao_init(g_device < 0 ? 0 : g_device);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipSetDevice(g_device));
+    return KAO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kao_version(void) { return KAO_VERSION; }
+
+const char *kao_strerror(int code) {
+    switch (code) {
+        case KAO_OK: return "ok";
+        case KAO_ERR_INVALID: return "invalid argument";
+        case KAO_ERR_UNSUPPORTED: return "instance not supported by the gfx950 kernels";
+        case KAO_ERR_NO_DEVICE: return "no usable HIP device (libkao has no CPU fallback)";
+        case KAO_ERR_HIP: return "HIP runtime error";
+        case KAO_ERR_NOMEM: return "out of memory";
+        case KAO_ERR_NOT_INIT: return "kao_init not called";
+        default: return "unknown error";
+    }
+}
+
+const char *kao_last_error(void) { return g_err.c_str(); }
+
+int kao_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(KAO_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(KAO_ERR_INVALID, "device ordinal out of range");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(KAO_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_device = device;
+    g_init = true;
+    return KAO_OK;
+}
+
+void kao_shutdown(void) { g_init = false; }
+
+int kao_device_name(char *buf, int len) {
+    int rc = require_init();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    std::snprintf(buf, (size_t)len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return KAO_OK;
+}
+
+int kao_derive_bounds(const kao_topic *t, int32_t out[8]) {
+    int rc = validate(t);
+    if (rc) return rc;
+    derive_bounds(t, out);
+    return KAO_OK;
+}
+
+int kao_upper_bound(const kao_topic *t, int64_t *ub) {
+    int rc = validate(t);
+    if (rc) return rc;
+    *ub = upper_bound(t);
+    return KAO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-eval plans
+// ------------------------------------------------------------------------------------------------
+int kao_eval_plan_create(const kao_topic *t, kao_eval_plan **out) {
+    if (!out) return fail(KAO_ERR_INVALID, "null out");
+    *out = nullptr;
+    int rc = require_init();
+    if (rc) return rc;
+    kao_eval_plan *p = new kao_eval_plan();
+    rc = prepare(t, 0, p->pt);
+    if (rc) { delete p; return rc; }
+    if (eval_lds_bytes(p->pt.d.P, p->pt.d.B) > 160 * 1024) { delete p; return fail(KAO_ERR_UNSUPPORTED, "topic tables exceed 160 KiB of LDS"); }
+    p->pt.d.best_off = 0; p->pt.d.rackof_off = 0; p->pt.d.curd_off = 0;
+    std::vector<TopicDev> td(1, p->pt.d);
+    if ((rc = dev_alloc_copy(&p->d_topic, td)) || (rc = dev_alloc_copy(&p->d_rackof, p->pt.rack_of)) ||
+        (rc = dev_alloc_copy(&p->d_curd, p->pt.cur_dense))) { kao_eval_plan_destroy(p); return rc; }
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&p->ev0));
+    HIP_TRY(hipEventCreate(&p->ev1));
+    *out = p;
+    return KAO_OK;
+}
+
+int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, void *d_objective, void *d_violations,
+                      void *d_best_key) {
+    if (!p || !d_candidates || n < 1) return fail(KAO_ERR_INVALID, "bad plan/candidates");
+    if (n > (1 << 20)) return fail(KAO_ERR_INVALID, "at most 2^20 candidates per run (packed key id width)");
+    HIP_TRY(hipSetDevice(g_device));
+    if (n != p->map_n) {
+        const int cpb = p->cands_per_block;
+        const int nb = (int)((n + cpb - 1) / cpb);
+        std::vector<int4> map((size_t)nb);
+        for (int b = 0; b < nb; ++b) {
+            const int first = b * cpb;
+            map[b] = make_int4(0, first, (int)std::min<int64_t>(cpb, n - first), first);
+        }
+        if (p->d_map) HIP_TRY(hipFree(p->d_map));
+        p->d_map = nullptr;
+        int rc = dev_alloc_copy(&p->d_map, map);
+        if (rc) return rc;
+        p->map_n = n;
+        p->map_blocks = nb;
+    }
+    EvalPools pl{};
+    pl.topics = p->d_topic; pl.block_map = p->d_map; pl.rackof_pool = p->d_rackof; pl.curd_pool = p->d_curd;
+    pl.cand = static_cast<const uint16_t *>(d_candidates);
+    pl.objective = static_cast<int32_t *>(d_objective);
+    pl.violations = static_cast<int32_t *>(d_violations);
+    pl.best_key = static_cast<unsigned long long *>(d_best_key);
+    pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B;
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    launch_eval(pl, p->map_blocks, p->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    p->timed = true;
+    return KAO_OK;
+}
+
+int kao_eval_plan_sync(kao_eval_plan *p, double *ms_last) {
+    if (!p) return fail(KAO_ERR_INVALID, "null plan");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (ms_last) {
+        float ms = 0;
+        if (p->timed) HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+        *ms_last = ms;
+    }
+    return KAO_OK;
+}
+
+void kao_eval_plan_destroy(kao_eval_plan *p) {
+    if (!p) return;
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(p->d_topic); (void)hipFree(p->d_rackof); (void)hipFree(p->d_curd); (void)hipFree(p->d_map);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int kao_evaluate_batch(const kao_topic *t, const uint16_t *candidates, int64_t n, int32_t *objective, int32_t *violations) {
+    if (!candidates || !objective || !violations || n < 1) return fail(KAO_ERR_INVALID, "null buffers");
+    kao_eval_plan *p = nullptr;
+    int rc = kao_eval_plan_create(t, &p);
+    if (rc) return rc;
+    const size_t per = (size_t)t->n_partitions * t->rf;
+    uint16_t *d_c = nullptr; int32_t *d_o = nullptr, *d_v = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_c); (void)hipFree(d_o); (void)hipFree(d_v); kao_eval_plan_destroy(p); };
+    const int64_t chunk_max = 1 << 20;
+    for (int64_t done = 0; done < n; done += chunk_max) {
+        const int64_t c = std::min(chunk_max, n - done);
+        if (!d_c) {
+            const size_t cap = (size_t)std::min(chunk_max, n);
+            if (hipMalloc(reinterpret_cast<void **>(&d_c), cap * per * 2) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void **>(&d_o), cap * 4) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void **>(&d_v), cap * 32) != hipSuccess) { cleanup(); return fail(KAO_ERR_NOMEM, "hipMalloc"); }
+        }
+        if (hipMemcpy(d_c, candidates + (size_t)done * per, (size_t)c * per * 2, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(KAO_ERR_HIP, "H2D"); }
+        rc = kao_eval_plan_run(p, d_c, c, d_o, d_v, nullptr);
+        if (!rc) rc = kao_eval_plan_sync(p, nullptr);
+        if (rc) { cleanup(); return rc; }
+        if (hipMemcpy(objective + done, d_o, (size_t)c * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(violations + done * 8, d_v, (size_t)c * 32, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(KAO_ERR_HIP, "D2H"); }
+    }
+    cleanup();
+    return KAO_OK;
+}
+
+int kao_evaluate(const kao_topic *t, const uint16_t *assignment, int64_t *objective, int32_t violations[8]) {
+    int32_t obj = 0;
+    int rc = kao_evaluate_batch(t, assignment, 1, &obj, violations);
+    if (!rc && objective) *objective = obj;
+    return rc;
+}
+
+int kao_canonicalize(const kao_topic *t, uint16_t *a) {
+    int rc = validate(t);
+    if (rc) return rc;
+    const int P = t->n_partitions, RF = t->rf, B = t->n_brokers;
+    const size_t per = (size_t)P * RF;
+    int64_t obj0 = 0; int32_t v[8];
+    if ((rc = kao_evaluate(t, a, &obj0, v))) return rc;
+    if (v[0] != 0) return KAO_OK;  // only feasible assignments are polished
+    auto is_cur = [&](int p, unsigned b) {
+        for (int k = 0; k < t->rf_cur; ++k) if (t->current[(size_t)p * t->rf_cur + k] == b) return true;
+        return false;
+    };
+    std::vector<uint16_t> batch; std::vector<int> cand_b; std::vector<int32_t> bo, bv;
+    bool changed = true;
+    while (changed) {
+        changed = false;
+        for (int p = 0; p < P; ++p)
+            for (int k = 0; k < RF; ++k) {
+                const unsigned b = a[(size_t)p * RF + k];
+                if (b >= (unsigned)B || is_cur(p, b)) continue;
+                batch.clear(); cand_b.clear();
+                for (unsigned nb = 0; nb < b; ++nb) {  // every lower broker index, one K-eval batch
+                    bool used = is_cur(p, nb);
+                    for (int j = 0; j < RF && !used; ++j) used = a[(size_t)p * RF + j] == nb;
+                    if (used) continue;
+                    batch.insert(batch.end(), a, a + per);
+                    batch[batch.size() - per + (size_t)p * RF + k] = (uint16_t)nb;
+                    cand_b.push_back((int)nb);
+                }
+                if (cand_b.empty()) continue;
+                bo.resize(cand_b.size()); bv.resize(cand_b.size() * 8);
+                if ((rc = kao_evaluate_batch(t, batch.data(), (int64_t)cand_b.size(), bo.data(), bv.data()))) return rc;
+                for (size_t i = 0; i < cand_b.size(); ++i)
+                    if (bv[i * 8] == 0 && bo[i] == obj0) { a[(size_t)p * RF + k] = (uint16_t)cand_b[i]; changed = true; break; }
+            }
+    }
+    for (int p = 0; p < P; ++p) {  // followers: retained ones in their current order, then new ones ascending
+        std::vector<uint16_t> fol(a + (size_t)p * RF + 1, a + (size_t)p * RF + RF), kept, fresh;
+        for (int k = 0; k < t->rf_cur; ++k) {
+            const uint16_t c = t->current[(size_t)p * t->rf_cur + k];
+            if (std::find(fol.begin(), fol.end(), c) != fol.end() && std::find(kept.begin(), kept.end(), c) == kept.end()) kept.push_back(c);
+        }
+        for (uint16_t f : fol) if (std::find(kept.begin(), kept.end(), f) == kept.end()) fresh.push_back(f);
+        std::sort(fresh.begin(), fresh.end());
+        kept.insert(kept.end(), fresh.begin(), fresh.end());
+        std::copy(kept.begin(), kept.end(), a + (size_t)p * RF + 1);
+    }
+    return KAO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sessions
+// ------------------------------------------------------------------------------------------------
+void kao_session_destroy(kao_session *s) {
+    if (!s) return;
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    (void)hipFree(s->d_topics); (void)hipFree(s->d_smap); (void)hipFree(s->d_emap); (void)hipFree(s->d_cur);
+    (void)hipFree(s->d_ext); (void)hipFree(s->d_rsz); (void)hipFree(s->d_state); (void)hipFree(s->d_best);
+    (void)hipFree(s->d_info); (void)hipFree(s->d_drift); (void)hipFree(s->d_rackof); (void)hipFree(s->d_curd);
+    (void)hipFree(s->d_obj); (void)hipFree(s->d_viol); (void)hipFree(s->d_keys);
+    for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts *opts_in, kao_session **out) {
+    if (!out) return fail(KAO_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (!topics || n_topics < 1) return fail(KAO_ERR_INVALID, "no topics");
+    int rc = require_init();
+    if (rc) return rc;
+    kao_session *s = new kao_session();
+    s->n_topics = n_topics;
+    kao_opts o{};
+    if (opts_in) o = *opts_in;
+    if (o.iters_per_launch <= 0) o.iters_per_launch = 512;
+    if (o.obj_scale <= 0) o.obj_scale = 4;
+    if (o.lam_min <= 0) o.lam_min = 1;
+    if (o.lam_max <= 0) o.lam_max = 40;
+    if (o.lam_max < o.lam_min) o.lam_max = o.lam_min;
+    if (o.period_log2 <= 0) o.period_log2 = 8;
+    if (o.period_log2 > 20) o.period_log2 = 20;
+    if (o.time_limit_s <= 0) o.time_limit_s = 10.0;
+    if (o.restarts <= 0) {  // fill the chip: ~24 wavefronts per CU across all topics
+        const int want = g_num_cu * 24;
+        int r = (want + n_topics - 1) / n_topics;
+        r = ((r + kWaves - 1) / kWaves) * kWaves;
+        o.restarts = std::min(std::max(r, 8), 8192);
+    }
+    if (o.restarts > (1 << 20)) o.restarts = 1 << 20;
+    s->opts = o;
+    s->pts.resize((size_t)n_topics);
+    s->topics.assign(topics, topics + n_topics);
+    s->ub.resize((size_t)n_topics);
+
+    std::vector<uint2> cur_pool; std::vector<uint16_t> ext_pool, curd_pool; std::vector<int32_t> rsz_pool;
+    std::vector<uint8_t> rackof_pool;
+    uint64_t state_parts = 0, best_u16 = 0;
+    int restart_base = 0;
+    for (int t = 0; t < n_topics; ++t) {
+        PreparedTopic &pt = s->pts[(size_t)t];
+        const uint64_t seed = o.seed ^ ((uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull);
+        rc = prepare(&topics[t], seed, pt);
+        if (rc) { kao_session_destroy(s); return rc; }
+        s->ub[(size_t)t] = upper_bound(&topics[t]);
+        TopicDev &d = pt.d;
+        d.n_restarts = o.restarts;
+        d.restart_base = restart_base;
+        restart_base += o.restarts;
+        d.cur_off = (uint32_t)cur_pool.size();
+        for (int p = 0; p < d.P; ++p) {
+            const uint16_t *c = &pt.cur_int[(size_t)p * kRFP];
+            cur_pool.push_back(make_uint2((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)c[2] | ((uint32_t)c[3] << 16)));
+        }
+        d.ext_off = (uint32_t)ext_pool.size();
+        ext_pool.insert(ext_pool.end(), pt.ext_of.begin(), pt.ext_of.end());
+        d.rsz_off = (uint32_t)rsz_pool.size();
+        rsz_pool.insert(rsz_pool.end(), pt.rack_size.begin(), pt.rack_size.end());
+        d.state_off = state_parts;
+        state_parts += (uint64_t)o.restarts * d.P;
+        d.best_off = best_u16;
+        best_u16 += (uint64_t)o.restarts * d.P * d.RF;
+        d.rackof_off = (uint32_t)rackof_pool.size();
+        rackof_pool.insert(rackof_pool.end(), pt.rack_of.begin(), pt.rack_of.end());
+        d.curd_off = (uint32_t)curd_pool.size();
+        curd_pool.insert(curd_pool.end(), pt.cur_dense.begin(), pt.cur_dense.end());
+        s->maxP = std::max(s->maxP, d.P); s->maxBx = std::max(s->maxBx, d.Bx); s->maxB = std::max(s->maxB, d.B);
+        // algorithmic bytes: delta = 8*RF+10 per neighbour; full = 2*RF*P + 2*rf_cur*P + B per candidate
+        s->search_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)o.iters_per_launch * 64ull * (uint64_t)(8 * d.RF + 10);
+        s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
+    }
+    s->total_restarts = restart_base;
+    if (search_lds_bytes(s->maxP, s->maxBx) > 160 * 1024 || eval_lds_bytes(s->maxP, s->maxB) > 160 * 1024) {
+        kao_session_destroy(s);
+        return fail(KAO_ERR_UNSUPPORTED, "topic state exceeds 160 KiB of LDS per workgroup (partitions x 16 B x 5 + brokers x 16 B)");
+    }
+    // workgroup maps
+    std::vector<int2> smap; std::vector<int> smap_topic;
+    std::vector<int4> emap; std::vector<int> emap_topic;
+    const int cpb = 32;  // candidates per K-eval workgroup
+    for (int t = 0; t < n_topics; ++t) {
+        const TopicDev &d = s->pts[(size_t)t].d;
+        for (int r = 0; r < d.n_restarts; r += kWaves) { smap.push_back(make_int2(t, r)); smap_topic.push_back(t); }
+        for (int r = 0; r < d.n_restarts; r += cpb) {
+            emap.push_back(make_int4(t, r, std::min(cpb, d.n_restarts - r), d.restart_base + r));
+            emap_topic.push_back(t);
+        }
+    }
+    smap = xcd_order(smap, smap_topic);
+    emap = xcd_order(emap, emap_topic);
+    s->blocks_search = (int)smap.size();
+    s->blocks_eval = (int)emap.size();
+
+    std::vector<TopicDev> tds;
+    for (auto &pt : s->pts) tds.push_back(pt.d);
+    if ((rc = dev_alloc_copy(&s->d_topics, tds)) || (rc = dev_alloc_copy(&s->d_smap, smap)) || (rc = dev_alloc_copy(&s->d_emap, emap)) ||
+        (rc = dev_alloc_copy(&s->d_cur, cur_pool)) || (rc = dev_alloc_copy(&s->d_ext, ext_pool)) || (rc = dev_alloc_copy(&s->d_rsz, rsz_pool)) ||
+        (rc = dev_alloc_copy(&s->d_rackof, rackof_pool)) || (rc = dev_alloc_copy(&s->d_curd, curd_pool))) { kao_session_destroy(s); return rc; }
+    auto alloc = [&](void **p, size_t bytes, int fillbyte) -> int {
+        HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 16)));
+        HIP_TRY(hipMemset(*p, fillbyte, std::max<size_t>(bytes, 16)));
+        return KAO_OK;
+    };
+    if ((rc = alloc(reinterpret_cast<void **>(&s->d_state), state_parts * sizeof(uint2), 0xFF)) ||
+        (rc = alloc(reinterpret_cast<void **>(&s->d_best), best_u16 * 2, 0xFF)) ||  // "no snapshot" = all KAO_NONE
+        (rc = alloc(reinterpret_cast<void **>(&s->d_info), (size_t)s->total_restarts * 16, 0)) ||
+        (rc = alloc(reinterpret_cast<void **>(&s->d_drift), 16, 0)) ||
+        (rc = alloc(reinterpret_cast<void **>(&s->d_obj), (size_t)s->total_restarts * 4, 0)) ||
+        (rc = alloc(reinterpret_cast<void **>(&s->d_viol), (size_t)s->total_restarts * 32, 0)) ||
+        (rc = alloc(reinterpret_cast<void **>(&s->d_keys), (size_t)n_topics * 8, 0xFF))) { kao_session_destroy(s); return rc; }
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { kao_session_destroy(s); return fail(KAO_ERR_HIP, "hipStreamCreate"); }
+    if (o.profile) {
+        s->ev.resize(kEvRing * 3);
+        for (auto &e : s->ev) if (hipEventCreate(&e) != hipSuccess) { kao_session_destroy(s); return fail(KAO_ERR_HIP, "hipEventCreate"); }
+    }
+    *out = s;
+    return KAO_OK;
+}
+
+int kao_session_step(kao_session *s) {
+    if (!s) return fail(KAO_ERR_INVALID, "null session");
+    HIP_TRY(hipSetDevice(g_device));
+    const bool prof = s->opts.profile != 0;
+    if (prof && s->ev_pending == kEvRing) {
+        int rc = session_drain_events(s);
+        if (rc) return rc;
+    }
+    SearchPools sp{};
+    sp.topics = s->d_topics; sp.block_map = s->d_smap; sp.cur_pool = s->d_cur; sp.ext_pool = s->d_ext; sp.rsz_pool = s->d_rsz;
+    sp.state_pool = s->d_state; sp.best_pool = s->d_best; sp.restart_info = s->d_info; sp.drift = s->d_drift;
+    SearchParams prm{};
+    prm.obj_scale = s->opts.obj_scale; prm.lam_min = s->opts.lam_min; prm.lam_max = s->opts.lam_max; prm.period_log2 = s->opts.period_log2;
+    prm.launch = s->launch; prm.iters = (uint32_t)s->opts.iters_per_launch; prm.init = s->launch == 0 ? 1 : 0;
+    prm.maxP = s->maxP; prm.maxBx = s->maxBx;
+    EvalPools ep{};
+    ep.topics = s->d_topics; ep.block_map = s->d_emap; ep.rackof_pool = s->d_rackof; ep.curd_pool = s->d_curd;
+    ep.cand = s->d_best; ep.objective = s->d_obj; ep.violations = s->d_viol; ep.best_key = s->d_keys;
+    ep.maxP = s->maxP; ep.maxB = s->maxB;
+    hipEvent_t *e = prof ? &s->ev[(size_t)s->ev_pending * 3] : nullptr;
+    if (prof) HIP_TRY(hipEventRecord(e[0], s->stream));
+    launch_search(sp, prm, s->blocks_search, s->stream);
+    HIP_TRY(hipGetLastError());
+    if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
+    launch_eval(ep, s->blocks_eval, s->stream);
+    HIP_TRY(hipGetLastError());
+    if (prof) { HIP_TRY(hipEventRecord(e[2], s->stream)); s->ev_pending++; }
+    s->launch++;
+    return KAO_OK;
+}
+
+int kao_session_sync(kao_session *s) {
+    if (!s) return fail(KAO_ERR_INVALID, "null session");
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->opts.profile) return session_drain_events(s);
+    return KAO_OK;
+}
+
+int kao_session_best_keys(kao_session *s, uint64_t *keys) {
+    if (!s || !keys) return fail(KAO_ERR_INVALID, "null argument");
+    HIP_TRY(hipMemcpyAsync(keys, s->d_keys, (size_t)s->n_topics * 8, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return KAO_OK;
+}
+
+int kao_session_best(kao_session *s, kao_result *results) {
+    if (!s || !results) return fail(KAO_ERR_INVALID, "null argument");
+    int rc = kao_session_sync(s);
+    if (rc) return rc;
+    std::vector<uint64_t> keys((size_t)s->n_topics);
+    HIP_TRY(hipMemcpy(keys.data(), s->d_keys, keys.size() * 8, hipMemcpyDeviceToHost));
+    for (int t = 0; t < s->n_topics; ++t) {
+        const TopicDev &d = s->pts[(size_t)t].d;
+        kao_result &r = results[t];
+        r.upper_bound = s->ub[(size_t)t];
+        const uint64_t key = keys[(size_t)t];
+        if (key == ~0ull) {  // no step has run yet
+            r.status = KAO_STATUS_NO_FEASIBLE; r.best_restart = -1; r.objective = -1;
+            std::memset(r.violations, 0, sizeof r.violations);
+            continue;
+        }
+        const int rho = (int)(key & 0xFFFFF);
+        r.best_restart = rho;
+        r.objective = (int64_t)kObjCap - (int64_t)((key >> 20) & 0xFFFFFF);
+        HIP_TRY(hipMemcpy(r.violations, s->d_viol + (size_t)(d.restart_base + rho) * 8, 32, hipMemcpyDeviceToHost));
+        if (r.assignment)
+            HIP_TRY(hipMemcpy(r.assignment, s->d_best + d.best_off + (uint64_t)rho * d.P * d.RF, (size_t)d.P * d.RF * 2, hipMemcpyDeviceToHost));
+        if (r.violations[0] != 0) { r.status = KAO_STATUS_NO_FEASIBLE; r.objective = -1; }
+        else r.status = r.objective >= r.upper_bound ? KAO_STATUS_OPTIMAL_PROVEN : KAO_STATUS_FEASIBLE_BOUND_GAP;
+    }
+    return KAO_OK;
+}
+
+int kao_session_stats(kao_session *s, kao_stats *out) {
+    if (!s || !out) return fail(KAO_ERR_INVALID, "null argument");
+    int rc = kao_session_sync(s);
+    if (rc) return rc;
+    std::memset(out, 0, sizeof *out);
+    out->launches = s->launch;
+    out->delta_candidates = (uint64_t)s->launch * (uint64_t)s->total_restarts * (uint64_t)s->opts.iters_per_launch * 64ull;
+    out->full_candidates = (uint64_t)s->launch * (uint64_t)s->total_restarts;
+    out->ms_search = s->ms_search; out->ms_eval = s->ms_eval;
+    out->search_bytes_algo = s->search_bytes_per_launch * s->launch;
+    out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
+    out->n_restarts_total = s->total_restarts;
+    out->lds_bytes_search = (int32_t)search_lds_bytes(s->maxP, s->maxBx);
+    out->blocks_search = s->blocks_search;
+    HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));
+    return KAO_OK;
+}
+
+int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, uint16_t *final_state, uint16_t *best_state,
+                              int32_t info[4]) {
+    if (!s || topic < 0 || topic >= s->n_topics) return fail(KAO_ERR_INVALID, "bad topic");
+    const PreparedTopic &pt = s->pts[(size_t)topic];
+    const TopicDev &d = pt.d;
+    if (restart < 0 || restart >= d.n_restarts) return fail(KAO_ERR_INVALID, "bad restart");
+    int rc = kao_session_sync(s);
+    if (rc) return rc;
+    if (final_state) {
+        std::vector<uint2> st((size_t)d.P);
+        HIP_TRY(hipMemcpy(st.data(), s->d_state + d.state_off + (uint64_t)restart * d.P, st.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+        for (int p = 0; p < d.P; ++p) {
+            const uint16_t x[4] = {(uint16_t)(st[p].x & 0xFFFF), (uint16_t)(st[p].x >> 16), (uint16_t)(st[p].y & 0xFFFF), (uint16_t)(st[p].y >> 16)};
+            for (int k = 0; k < d.RF; ++k) final_state[(size_t)p * d.RF + k] = x[k] < pt.ext_of.size() ? pt.ext_of[x[k]] : (uint16_t)KAO_NONE;
+        }
+    }
+    if (best_state)
+        HIP_TRY(hipMemcpy(best_state, s->d_best + d.best_off + (uint64_t)restart * d.P * d.RF, (size_t)d.P * d.RF * 2, hipMemcpyDeviceToHost));
+    if (info) HIP_TRY(hipMemcpy(info, s->d_info + (size_t)(d.restart_base + restart) * 4, 16, hipMemcpyDeviceToHost));
+    return KAO_OK;
+}
+
+int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results) {
+    const double t0 = now_s();
+    if (!results) return fail(KAO_ERR_INVALID, "null results");
+    kao_session *s = nullptr;
+    int rc = kao_session_create(topics, n_topics, opts, &s);
+    if (rc) return rc;
+    const kao_opts &o = s->opts;
+    std::vector<uint64_t> keys((size_t)n_topics), prev((size_t)n_topics, ~0ull);
+    std::vector<double> t_best((size_t)n_topics, 0.0);
+    bool hit_time = false;
+    for (int launch = 0;; ++launch) {
+        if ((rc = kao_session_step(s)) || (rc = kao_session_best_keys(s, keys.data()))) { kao_session_destroy(s); return rc; }
+        const double t = now_s() - t0;
+        bool all_proven = true;
+        for (int i = 0; i < n_topics; ++i) {
+            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; }
+            const bool feasible = (keys[(size_t)i] >> 44) == 0;
+            const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
+            if (!(feasible && obj >= s->ub[(size_t)i])) all_proven = false;
+        }
+        if (o.stop_at_bound && all_proven) break;
+        if (o.max_launches > 0 && launch + 1 >= o.max_launches) break;
+        if (t >= o.time_limit_s) { hit_time = true; break; }
+    }
+    rc = kao_session_best(s, results);
+    if (!rc)
+        for (int i = 0; i < n_topics; ++i) {
+            results[i].seconds_to_best = t_best[(size_t)i];
+            if (hit_time && results[i].status == KAO_STATUS_FEASIBLE_BOUND_GAP) results[i].status = KAO_STATUS_TIME_LIMIT;
+        }
+    kao_session_destroy(s);
+    return rc;
+}
+
+}  // extern "C"

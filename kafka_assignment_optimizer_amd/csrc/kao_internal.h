@@ -1,0 +1,74 @@
+// kao_internal.h -- structures shared by the host API (kao_api.cpp) and the gfx950 kernels
+// (kao_kernels.hip).  Not part of the C ABI.
+#pragma once
+#include <stdint.h>
+
+namespace kao {
+
+constexpr int kRFP = 4;          // padded replica slots per partition
+constexpr int kWaves = 4;        // wavefronts (restarts) per K-search workgroup
+constexpr int kMaxRacks = 64;
+constexpr uint32_t kNoneW = 0xFFFFFFFFu;  // empty slot in the LDS word layout (x | rack << 16)
+constexpr uint32_t kKeyNull = 0xFFFFFFFFu;
+constexpr int kDBias = 32768;
+constexpr uint32_t kObjCap = 0xFFFFFFu;   // packed best key: viol(20) << 44 | (kObjCap - obj) << 20 | restart(20)
+
+// Device-side descriptor of one topic.  Read once per workgroup (wave-uniform -> SGPRs).
+struct TopicDev {
+    // ---- internal (rack-major padded) index space, used by K-search -------------------
+    int32_t P, RF, R, m, Bx;     // m = largest rack; x = rack*m + j, j < rack_size[rack]
+    uint32_t magic;              // floor(2^32/m)+1 : rack(x) = mulhi(x, magic), exact for x < 2^16
+    int32_t rep_lo, rep_hi, lead_lo, lead_hi, rack_lo, rack_hi, prack_lo, prack_hi;
+    int32_t w00, w01, w10, w11;  // w[cur_role][new_role]
+    uint32_t seed_lo, seed_hi;   // per-topic seed
+    int32_t n_restarts;          // restarts (wavefronts) searching this topic
+    int32_t restart_base;        // index of restart 0 in the per-restart arrays
+    uint32_t cur_off;            // cur_pool   : first partition (uint2 = 4 x u16 internal idx per partition)
+    uint32_t ext_off;            // ext_pool   : internal -> dense (u16[Bx])
+    uint32_t rsz_off;            // rsz_pool   : rack sizes (int32[R])
+    uint64_t state_off;          // state_pool : first partition of restart 0 (uint2 per partition)
+    uint64_t best_off;           // best_pool  : first u16 of restart 0's dense snapshot ([P*RF] per restart)
+    // ---- dense index space, used by K-eval ---------------------------------------------
+    int32_t B, rf_cur;
+    uint32_t rackof_off;         // rackof_pool: u8[B]
+    uint32_t curd_off;           // curd_pool  : u16[P*rf_cur] dense current assignment
+};
+
+struct SearchParams {
+    int32_t obj_scale, lam_min, lam_max, period_log2;
+    uint32_t launch;             // launch number (global iteration = launch*iters + i)
+    uint32_t iters;
+    int32_t init;                // 1 = build the initial state of every restart first
+    int32_t maxP, maxBx;         // LDS carve sizes
+};
+
+struct SearchPools {
+    const TopicDev *topics;
+    const int2 *block_map;       // per workgroup: {topic, first restart}
+    const uint2 *cur_pool;
+    const uint16_t *ext_pool;
+    const int32_t *rsz_pool;
+    uint2 *state_pool;
+    uint16_t *best_pool;
+    int32_t *restart_info;       // [n_restarts_total][4] = {best_obj, V, obj, accepted}
+    int32_t *drift;              // [1] counter
+};
+
+struct EvalPools {
+    const TopicDev *topics;
+    const int4 *block_map;       // per workgroup: {topic, first candidate (within topic), n candidates, out base}
+    const uint8_t *rackof_pool;
+    const uint16_t *curd_pool;
+    const uint16_t *cand;        // candidates; topic t's candidate c at cand + best_off(t) + c*P*RF
+    int32_t *objective;          // [n] or nullptr
+    int32_t *violations;         // [n*8] or nullptr
+    unsigned long long *best_key;// [n_topics] or nullptr (atomicMin of the packed key)
+    int32_t maxP, maxB;
+};
+
+size_t search_lds_bytes(int maxP, int maxBx);
+size_t eval_lds_bytes(int maxP, int maxB);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, void *stream);
+void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
+
+}  // namespace kao

@@ -1,0 +1,560 @@
+// kao_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the Kafka partition-assignment solver.
+//
+//   k_search : parallel-restart local search "KAO-LS" (DESIGN.md section 4).  One wavefront owns one
+//              restart; each of its 64 lanes proposes one neighbour per iteration and delta-evaluates
+//              feasibility (C3,C4,C6,C7; C1,C2,C5 hold by construction) and move cost against broker /
+//              rack tables staged in LDS; a DPP min-reduce over the wavefront picks the move.
+//   k_eval   : full evaluation (objective README.md:145-146 and rows C1..C7 README.md:148-180) of
+//              complete compact candidates streamed from HBM, one wavefront per candidate, ending in
+//              the wavefront -> workgroup -> atomicMin reduce of the packed (violation, cost, id) key.
+//
+// Integer-only (no floating point on the device path); wave64 throughout; no MFMA (nothing here is a
+// dense contraction).  The scalar CPU restatement used by the tests is oracle/kao_port.c.
+#include <hip/hip_runtime.h>
+
+#include "kao_internal.h"
+
+namespace kao {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t xs32(uint32_t &s) {
+    s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+    return s;
+}
+__device__ __forceinline__ uint32_t mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+__device__ __forceinline__ int band(int c, int lo, int hi) { return max(c - hi, 0) + max(lo - c, 0); }
+// band(c+1)-band(c) and band(c-1)-band(c)
+__device__ __forceinline__ int dinc(int c, int lo, int hi) { return (int)(c >= hi) - (int)(c < lo); }
+__device__ __forceinline__ int ddec(int c, int lo, int hi) { return (int)(c <= lo) - (int)(c > hi); }
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+// Wavefront min (all 64 lanes active): butterfly inside each row of 16 with DPP (quad_perm xor1, xor2,
+// row_half_mirror, row_mirror), then the four row minima are read with v_readlane and combined on
+// the scalar unit.  Result is wave-uniform.
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
+    v = min(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = min(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = min(v, dpp_mov<0x141>(v));  // row_half_mirror
+    v = min(v, dpp_mov<0x140>(v));  // row_mirror
+    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+    uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ int wave_sum(int v) {
+    v += (int)dpp_mov<0xB1>((uint32_t)v);
+    v += (int)dpp_mov<0x4E>((uint32_t)v);
+    v += (int)dpp_mov<0x141>((uint32_t)v);
+    v += (int)dpp_mov<0x140>((uint32_t)v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+__device__ __forceinline__ uint32_t sel4(const uint4 &a, int k) {
+    return k == 0 ? a.x : (k == 1 ? a.y : (k == 2 ? a.z : a.w));
+}
+__device__ __forceinline__ bool in4(const uint4 &a, uint32_t w) {
+    return (a.x == w) | (a.y == w) | (a.z == w) | (a.w == w);
+}
+// replicas of the partition that sit in rack r (empty slots carry rack 0xFFFF and never match)
+__device__ __forceinline__ int cnt4(const uint4 &a, uint32_t r) {
+    return (int)((a.x >> 16) == r) + (int)((a.y >> 16) == r) + (int)((a.z >> 16) == r) + (int)((a.w >> 16) == r);
+}
+
+struct TopicRegs {  // wave-uniform copy of the fields the inner loop needs
+    int P, RF, R, m, Bx;
+    uint32_t magic;
+    int rep_lo, rep_hi, lead_lo, lead_hi, rack_lo, rack_hi, prack_lo, prack_hi;
+    int w00, w01, w10, w11;
+};
+
+// objective weight of broker word w on a partition whose current replicas are c, in new role nr
+__device__ __forceinline__ int role_w(const TopicRegs &T, const uint4 &c, uint32_t w, int nr) {
+    const int wl = nr ? T.w01 : T.w00;
+    const int wf = nr ? T.w11 : T.w10;
+    return (c.x == w) ? wl : (((c.y == w) | (c.z == w) | (c.w == w)) ? wf : 0);
+}
+// internal index -> LDS word (x | rack << 16); 0xFFFF -> empty
+__device__ __forceinline__ uint32_t to_word(const TopicRegs &T, uint32_t x) {
+    return x == 0xFFFFu ? kNoneW : (x | (mulhi(x, T.magic) << 16));
+}
+__device__ __forceinline__ uint4 expand(const TopicRegs &T, uint2 s) {
+    return make_uint4(to_word(T, s.x & 0xFFFFu), to_word(T, s.x >> 16), to_word(T, s.y & 0xFFFFu), to_word(T, s.y >> 16));
+}
+__device__ __forceinline__ uint2 pack(const uint4 &a) {
+    return make_uint2((a.x & 0xFFFFu) | (a.y << 16), (a.z & 0xFFFFu) | (a.w << 16));
+}
+// sum over all R racks of band(#replicas of the partition in the rack)
+__device__ __forceinline__ int part_rack_viol(const TopicRegs &T, const uint4 &a) {
+    int s = 0, touched = 0;
+    const uint32_t r0 = a.x >> 16, r1 = a.y >> 16, r2 = a.z >> 16, r3 = a.w >> 16;
+    if (a.x != kNoneW) { s += band(cnt4(a, r0), T.prack_lo, T.prack_hi); touched++; }
+    if (a.y != kNoneW && r1 != r0) { s += band(cnt4(a, r1), T.prack_lo, T.prack_hi); touched++; }
+    if (a.z != kNoneW && r2 != r0 && r2 != r1) { s += band(cnt4(a, r2), T.prack_lo, T.prack_hi); touched++; }
+    if (a.w != kNoneW && r3 != r0 && r3 != r1 && r3 != r2) { s += band(cnt4(a, r3), T.prack_lo, T.prack_hi); touched++; }
+    return s + (T.R - touched) * T.prack_lo;  // band(0, lo, hi) == lo
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-search
+// ------------------------------------------------------------------------------------------------
+struct WaveLds {
+    uint4 *A;     // [P] this restart's assignment, 4 words per partition
+    uint32_t *C;  // [Bx] replicas | leaders << 16 per broker
+    int *K;       // [64] replicas per rack
+};
+
+// rebuild C and K from A (lanes stride partitions; LDS atomics)
+__device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds &L, int lane) {
+    for (int x = lane; x < T.Bx; x += 64) L.C[x] = 0;
+    L.K[lane] = 0;
+    for (int p = lane; p < T.P; p += 64) {
+        const uint4 a = L.A[p];
+        if (a.x != kNoneW) { atomicAdd(&L.C[a.x & 0xFFFFu], 0x10001u); atomicAdd(&L.K[a.x >> 16], 1); }
+        if (a.y != kNoneW) { atomicAdd(&L.C[a.y & 0xFFFFu], 1u); atomicAdd(&L.K[a.y >> 16], 1); }
+        if (a.z != kNoneW) { atomicAdd(&L.C[a.z & 0xFFFFu], 1u); atomicAdd(&L.K[a.z >> 16], 1); }
+        if (a.w != kNoneW) { atomicAdd(&L.C[a.w & 0xFFFFu], 1u); atomicAdd(&L.K[a.w >> 16], 1); }
+    }
+}
+
+// total violation magnitude and objective of the state in LDS (C, K must be current)
+__device__ __forceinline__ void full_cost(const TopicRegs &T, const WaveLds &L, const uint4 *CUR, const int *RSZ,
+                                          int lane, int &V, int &obj) {
+    int v = 0, o = 0;
+    for (int p = lane; p < T.P; p += 64) {
+        const uint4 a = L.A[p];
+        const uint4 c = CUR[p];
+        if (a.x != kNoneW) o += role_w(T, c, a.x, 0);
+        if (a.y != kNoneW) o += role_w(T, c, a.y, 1);
+        if (a.z != kNoneW) o += role_w(T, c, a.z, 1);
+        if (a.w != kNoneW) o += role_w(T, c, a.w, 1);
+        v += part_rack_viol(T, a);
+    }
+    for (int x = lane; x < T.Bx; x += 64) {
+        const int r = (int)mulhi((uint32_t)x, T.magic);
+        if (x - r * T.m < RSZ[r]) {
+            const uint32_t c = L.C[x];
+            v += band((int)(c & 0xFFFFu), T.rep_lo, T.rep_hi) + band((int)(c >> 16), T.lead_lo, T.lead_hi);
+        }
+    }
+    if (lane < T.R) v += band(L.K[lane], T.rack_lo, T.rack_hi);
+    V = wave_sum(v);
+    obj = wave_sum(o);
+}
+
+__device__ __forceinline__ void snapshot(const TopicRegs &T, const WaveLds &L, const uint16_t *ext, uint16_t *best, int lane) {
+    for (int p = lane; p < T.P; p += 64) {
+        const uint4 a = L.A[p];
+        uint16_t *o = best + p * T.RF;
+        o[0] = ext[a.x & 0xFFFFu];
+        if (T.RF > 1) o[1] = ext[a.y & 0xFFFFu];
+        if (T.RF > 2) o[2] = ext[a.z & 0xFFFFu];
+        if (T.RF > 3) o[3] = ext[a.w & 0xFFFFu];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int2 bm = pl.block_map[blockIdx.x];
+    const TopicDev *TD = pl.topics + bm.x;
+
+    TopicRegs T;
+    T.P = TD->P; T.RF = TD->RF; T.R = TD->R; T.m = TD->m; T.Bx = TD->Bx; T.magic = TD->magic;
+    T.rep_lo = TD->rep_lo; T.rep_hi = TD->rep_hi; T.lead_lo = TD->lead_lo; T.lead_hi = TD->lead_hi;
+    T.rack_lo = TD->rack_lo; T.rack_hi = TD->rack_hi; T.prack_lo = TD->prack_lo; T.prack_hi = TD->prack_hi;
+    T.w00 = TD->w00; T.w01 = TD->w01; T.w10 = TD->w10; T.w11 = TD->w11;
+
+    // ---- LDS carve: [CUR uint4[maxP]] [RSZ int[64]] then per wave [A uint4[maxP]] [C u32[maxBx~]] [K int[64]]
+    const int a_bytes = prm.maxP * 16;
+    const int c_bytes = (prm.maxBx * 4 + 15) & ~15;
+    uint4 *CUR = reinterpret_cast<uint4 *>(smem);
+    int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
+    unsigned char *wb = smem + a_bytes + 256 + wave * (a_bytes + c_bytes + 256);
+    WaveLds L;
+    L.A = reinterpret_cast<uint4 *>(wb);
+    L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
+    L.K = reinterpret_cast<int *>(wb + a_bytes + c_bytes);
+
+    // ---- stage the topic's current-assignment table and rack sizes (shared by the 4 restarts) ----
+    for (int p = threadIdx.x; p < T.P; p += 256) CUR[p] = expand(T, pl.cur_pool[TD->cur_off + p]);
+    if (threadIdx.x < 64) RSZ[threadIdx.x] = (int)threadIdx.x < T.R ? pl.rsz_pool[TD->rsz_off + threadIdx.x] : 0;
+    __syncthreads();
+
+    const int rho = bm.y + wave;
+    if (rho >= TD->n_restarts) return;  // no block-level barrier below this point
+    const int g = TD->restart_base + rho;
+    uint2 *state = pl.state_pool + TD->state_off + (uint64_t)rho * T.P;
+    uint16_t *best = pl.best_pool + TD->best_off + (uint64_t)rho * T.P * T.RF;
+    const uint16_t *ext = pl.ext_pool + TD->ext_off;
+    const uint32_t slo = TD->seed_lo, shi = TD->seed_hi;
+    const int S = prm.obj_scale;
+
+    int best_obj, accepted;
+    if (prm.init) {
+        // surviving current replicas stay in their slots
+        for (int p = lane; p < T.P; p += 64) {
+            uint4 c = CUR[p];
+            if (T.RF < 4) c.w = kNoneW;
+            if (T.RF < 3) c.z = kNoneW;
+            if (T.RF < 2) c.y = kNoneW;
+            L.A[p] = c;
+        }
+        best_obj = -1; accepted = 0;
+    } else {
+        for (int p = lane; p < T.P; p += 64) L.A[p] = expand(T, state[p]);
+        best_obj = pl.restart_info[g * 4 + 0];
+        accepted = pl.restart_info[g * 4 + 3];
+    }
+    recount(T, L, lane);
+
+    if (prm.init) {
+        // ---- greedy hole filling: holes in (p,k) order, best of 64 hashed tries (one per lane) ----
+        for (int p = 0; p < T.P; ++p) {
+            uint4 a = L.A[p];  // same address in every lane: LDS broadcast
+            const uint4 c = CUR[p];
+#pragma unroll
+            for (int k = 0; k < kRFP; ++k) {
+                if (k >= T.RF) break;
+                if (sel4(a, k) != kNoneW) continue;  // wave-uniform
+                const uint32_t u = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * kRFP + k) * 0x27D4EB2Fu +
+                                                       (uint32_t)lane * 0x165667B1u + 0x5BD1E995u));
+                const uint32_t x = mulhi(u, (uint32_t)T.Bx);
+                const uint32_t rn = mulhi(x, T.magic);
+                const uint32_t xw = x | (rn << 16);
+                const bool ok = ((int)(x - rn * T.m) < RSZ[rn]) && !in4(a, xw);
+                uint32_t key = kKeyNull;
+                if (ok) {
+                    const uint32_t cn = L.C[x];
+                    int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[rn], T.rack_lo, T.rack_hi) +
+                             dinc(cnt4(a, rn), T.prack_lo, T.prack_hi);
+                    if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+                    int delta = prm.lam_max * dV - S * role_w(T, c, xw, k == 0 ? 0 : 1);
+                    delta = max(delta, -kDBias);
+                    delta = min(delta, kDBias - 2);
+                    key = ((uint32_t)(delta + kDBias) << 16) | (uint32_t)lane;
+                }
+                const uint32_t kmin = wave_umin(key);
+                uint32_t xw_win;
+                if (kmin != kKeyNull) {
+                    xw_win = (uint32_t)__builtin_amdgcn_readlane((int)xw, (int)(kmin & 63u));
+                } else {  // all 64 tries invalid: lowest valid x not in the partition
+                    xw_win = kNoneW;
+                    for (int base = 0; base < T.Bx; base += 64) {
+                        const uint32_t y = (uint32_t)(base + lane);
+                        const uint32_t ry = mulhi(y, T.magic);
+                        const uint32_t yw = y | (ry << 16);
+                        const bool oky = (int)y < T.Bx && ((int)(y - ry * T.m) < RSZ[ry < 64 ? ry : 0]) && !in4(a, yw);
+                        const unsigned long long bal = __ballot(oky);
+                        if (bal) {
+                            xw_win = (uint32_t)__builtin_amdgcn_readlane((int)yw, __ffsll((long long)bal) - 1);
+                            break;
+                        }
+                    }
+                }
+                if (k == 0) a.x = xw_win; else if (k == 1) a.y = xw_win; else if (k == 2) a.z = xw_win; else a.w = xw_win;
+                if (lane == 0) {
+                    reinterpret_cast<uint32_t *>(&L.A[p])[k] = xw_win;
+                    L.C[xw_win & 0xFFFFu] += (k == 0) ? 0x10001u : 1u;
+                    L.K[xw_win >> 16] += 1;
+                }
+            }
+        }
+    }
+
+    int V, obj;
+    full_cost(T, L, CUR, RSZ, lane, V, obj);
+    if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
+
+    // ---- per-lane RNG stream of this launch ----
+    uint32_t rng = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + prm.launch * 0x85EBCA77u + (uint32_t)lane * 0xC2B2AE3Du));
+    if (rng == 0) rng = 0x6D2B79F5u;
+
+    const int plog = prm.period_log2 + (rho & 3);
+    const uint32_t pmask = (1u << plog) - 1u;
+    const uint32_t lrange = (uint32_t)(prm.lam_max - prm.lam_min + 1);
+
+    for (uint32_t i = 0; i < prm.iters; ++i) {
+        const uint32_t it = prm.launch * prm.iters + i;
+        const int type = (int)((0x1210u >> ((it & 7u) * 2u)) & 3u);  // pattern R R X R L R X R
+        const uint32_t ph = it & pmask;
+        const int lam = min(prm.lam_max, prm.lam_min + (int)((2u * ph * lrange) >> plog));
+
+        const uint32_t r1 = xs32(rng), r2 = xs32(rng), r3 = xs32(rng);
+        const int p = (int)mulhi(r1, (uint32_t)T.P);
+        const uint4 a = L.A[p];
+        const uint4 c = CUR[p];
+        bool ok;
+        int dV = 0, dObj = 0;
+        // proposal registers (meaning depends on the move type)
+        int k = 0, q = 0, j = 0;
+        uint32_t uw = 0, vw = 0;
+
+        if (type == 0) {  // REPLACE (p,k) <- x
+            k = (int)(((r1 & 0xFFFFu) * (uint32_t)T.RF) >> 16);
+            const uint32_t x = mulhi(r2, (uint32_t)T.Bx);
+            const uint32_t rn = mulhi(x, T.magic);
+            vw = x | (rn << 16);
+            ok = ((int)(x - rn * T.m) < RSZ[rn]) && !in4(a, vw);
+            uw = sel4(a, k);
+            const uint32_t ro = uw >> 16;
+            const int nr = k != 0;
+            dObj = role_w(T, c, vw, nr) - role_w(T, c, uw, nr);
+            const uint32_t co = L.C[uw & 0xFFFFu], cn = L.C[x];
+            dV = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi);
+            if (k == 0) dV += ddec((int)(co >> 16), T.lead_lo, T.lead_hi) + dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+            if (ro != rn) {
+                dV += ddec(L.K[ro], T.rack_lo, T.rack_hi) + dinc(L.K[rn], T.rack_lo, T.rack_hi);
+                dV += ddec(cnt4(a, ro), T.prack_lo, T.prack_hi) + dinc(cnt4(a, rn), T.prack_lo, T.prack_hi);
+            }
+        } else if (type == 1) {  // EXCHANGE (p,k) <-> (q,j)
+            k = (int)(((r1 & 0xFFFFu) * (uint32_t)T.RF) >> 16);
+            q = (int)mulhi(r2, (uint32_t)T.P);
+            j = (int)(((r2 & 0xFFFFu) * (uint32_t)T.RF) >> 16);
+            const uint4 b = L.A[q];
+            const uint4 cb = CUR[q];
+            uw = sel4(a, k);
+            vw = sel4(b, j);
+            ok = (p != q) && (uw != vw) && !in4(a, vw) && !in4(b, uw);
+            const int nrp = k != 0, nrq = j != 0;
+            dObj = role_w(T, c, vw, nrp) + role_w(T, cb, uw, nrq) - role_w(T, c, uw, nrp) - role_w(T, cb, vw, nrq);
+            if ((k == 0) != (j == 0)) {
+                const uint32_t lose = (k == 0) ? uw : vw, gain = (k == 0) ? vw : uw;
+                dV += ddec((int)(L.C[lose & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi) +
+                      dinc((int)(L.C[gain & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+            }
+            const uint32_t ru = uw >> 16, rv = vw >> 16;
+            if (ru != rv) {
+                dV += ddec(cnt4(a, ru), T.prack_lo, T.prack_hi) + dinc(cnt4(a, rv), T.prack_lo, T.prack_hi) +
+                      ddec(cnt4(b, rv), T.prack_lo, T.prack_hi) + dinc(cnt4(b, ru), T.prack_lo, T.prack_hi);
+            }
+        } else {  // LEADER SWAP inside p: slot 0 <-> slot k
+            ok = T.RF >= 2;
+            k = 1 + (int)(((r1 & 0xFFFFu) * (uint32_t)(T.RF - 1)) >> 16);
+            uw = a.x;
+            vw = sel4(a, k);
+            dObj = role_w(T, c, vw, 0) + role_w(T, c, uw, 1) - role_w(T, c, uw, 0) - role_w(T, c, vw, 1);
+            if (ok)
+                dV = ddec((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi) +
+                     dinc((int)(L.C[vw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+        }
+
+        int delta = lam * dV - S * dObj;
+        delta = max(delta, -kDBias);
+        delta = min(delta, kDBias - 2);
+        const uint32_t key = ok ? (((uint32_t)(delta + kDBias) << 16) | ((r3 >> 22) << 6) | (uint32_t)lane) : kKeyNull;
+        const uint32_t kmin = wave_umin(key);  // wavefront min-scan: best of the 64 proposals
+        if (kmin == kKeyNull) continue;
+        if ((int)(kmin >> 16) - kDBias > 0) continue;  // accept only non-worsening moves (cost under current lam)
+        const int win = (int)(kmin & 63u);
+
+        if (lane == win) {  // the winning lane applies its own proposal
+            uint32_t *ap = reinterpret_cast<uint32_t *>(&L.A[p]);
+            if (type == 0) {
+                const uint32_t d = (k == 0) ? 0x10001u : 1u;
+                L.C[uw & 0xFFFFu] -= d;
+                L.C[vw & 0xFFFFu] += d;
+                L.K[uw >> 16] -= 1;
+                L.K[vw >> 16] += 1;
+                ap[k] = vw;
+            } else if (type == 1) {
+                uint32_t *bp = reinterpret_cast<uint32_t *>(&L.A[q]);
+                if ((k == 0) != (j == 0)) {
+                    const uint32_t lose = (k == 0) ? uw : vw, gain = (k == 0) ? vw : uw;
+                    L.C[lose & 0xFFFFu] -= 0x10000u;
+                    L.C[gain & 0xFFFFu] += 0x10000u;
+                }
+                ap[k] = vw;
+                bp[j] = uw;
+            } else {
+                L.C[uw & 0xFFFFu] -= 0x10000u;
+                L.C[vw & 0xFFFFu] += 0x10000u;
+                ap[0] = vw;
+                ap[k] = uw;
+            }
+        }
+        V += __builtin_amdgcn_readlane(dV, win);
+        obj += __builtin_amdgcn_readlane(dObj, win);
+        accepted++;
+        if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
+    }
+
+    // ---- end of launch: verify the incremental bookkeeping against a from-scratch recount ----
+    recount(T, L, lane);
+    int V2, obj2;
+    full_cost(T, L, CUR, RSZ, lane, V2, obj2);
+    if ((V2 != V || obj2 != obj) && lane == 0) atomicAdd(pl.drift, 1);
+    for (int p = lane; p < T.P; p += 64) state[p] = pack(L.A[p]);
+    if (lane == 0) {
+        pl.restart_info[g * 4 + 0] = best_obj;
+        pl.restart_info[g * 4 + 1] = V2;
+        pl.restart_info[g * 4 + 2] = obj2;
+        pl.restart_info[g * 4 + 3] = accepted;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-eval
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    unsigned long long *wave_key = reinterpret_cast<unsigned long long *>(smem_all);  // [kWaves], 32 B
+    unsigned char *smem = smem_all + 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int4 bm = pl.block_map[blockIdx.x];
+    const TopicDev *TD = pl.topics + bm.x;
+    const int B = TD->B, R = TD->R, P = TD->P, RF = TD->RF, rf_cur = TD->rf_cur;
+    const int rep_lo = TD->rep_lo, rep_hi = TD->rep_hi, lead_lo = TD->lead_lo, lead_hi = TD->lead_hi;
+    const int rack_lo = TD->rack_lo, rack_hi = TD->rack_hi, prack_lo = TD->prack_lo, prack_hi = TD->prack_hi;
+    const int w00 = TD->w00, w01 = TD->w01, w10 = TD->w10, w11 = TD->w11;
+
+    // ---- LDS carve: [wave_key 32 B] [RACK u8[maxB~]] [CURD uint2[maxP]] then per wave [C u32[maxB~]] [K int[64]]
+    const int r_bytes = (pl.maxB + 15) & ~15;
+    const int d_bytes = pl.maxP * 8;
+    const int c_bytes = (pl.maxB * 4 + 15) & ~15;
+    uint8_t *RACK = smem;
+    uint2 *CURD = reinterpret_cast<uint2 *>(smem + r_bytes);
+    unsigned char *wb = smem + r_bytes + ((d_bytes + 15) & ~15) + wave * (c_bytes + 256);
+    uint32_t *C = reinterpret_cast<uint32_t *>(wb);
+    int *K = reinterpret_cast<int *>(wb + c_bytes);
+
+    // ---- stage the broker->rack table and the current assignment (padded to 4 slots) ----
+    for (int b = threadIdx.x; b < B; b += 256) RACK[b] = pl.rackof_pool[TD->rackof_off + b];
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const uint16_t *cp = pl.curd_pool + TD->curd_off + (size_t)p * rf_cur;
+        const uint32_t c0 = cp[0];
+        const uint32_t c1 = rf_cur > 1 ? cp[1] : 0xFFFFu;
+        const uint32_t c2 = rf_cur > 2 ? cp[2] : 0xFFFFu;
+        const uint32_t c3 = rf_cur > 3 ? cp[3] : 0xFFFFu;
+        CURD[p] = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+    }
+    __syncthreads();
+
+    unsigned long long my_key = ~0ull;
+    for (int ci = bm.y + wave; ci < bm.y + bm.z; ci += kWaves) {
+        const uint16_t *cand = pl.cand + TD->best_off + (uint64_t)ci * P * RF;
+        for (int b = lane; b < B; b += 64) C[b] = 0;
+        K[lane] = 0;
+        int obj = 0, v1 = 0, v2 = 0, v5 = 0, v7 = 0;
+        for (int p = lane; p < P; p += 64) {
+            const uint16_t *ap = cand + (size_t)p * RF;  // a wavefront reads 64*RF consecutive u16: coalesced
+            uint32_t b0 = ap[0], b1 = 0xFFFFu, b2 = 0xFFFFu, b3 = 0xFFFFu;
+            if (RF > 1) b1 = ap[1];
+            if (RF > 2) b2 = ap[2];
+            if (RF > 3) b3 = ap[3];
+            const bool ok0 = b0 < (uint32_t)B, ok1 = b1 < (uint32_t)B, ok2 = b2 < (uint32_t)B, ok3 = b3 < (uint32_t)B;
+            const int missing = (int)!ok0 + (RF > 1 ? (int)!ok1 : 0) + (RF > 2 ? (int)!ok2 : 0) + (RF > 3 ? (int)!ok3 : 0);
+            v1 += missing;             // C1: sum_b (f+l) = RF
+            v2 += (int)!ok0;           // C2: exactly one leader
+            const uint2 cu = CURD[p];
+            const uint32_t c0 = cu.x & 0xFFFFu, c1 = cu.x >> 16, c2 = cu.y & 0xFFFFu, c3 = cu.y >> 16;
+            uint32_t r0 = 0xFFu, r1 = 0xFFu, r2 = 0xFFu, r3 = 0xFFu;
+            if (ok0) {
+                r0 = RACK[b0]; atomicAdd(&C[b0], 0x10001u); atomicAdd(&K[r0], 1);
+                obj += (c0 == b0) ? w00 : (((c1 == b0) | (c2 == b0) | (c3 == b0)) ? w10 : 0);
+            }
+            if (ok1) {
+                r1 = RACK[b1]; atomicAdd(&C[b1], 1u); atomicAdd(&K[r1], 1);
+                obj += (c0 == b1) ? w01 : (((c1 == b1) | (c2 == b1) | (c3 == b1)) ? w11 : 0);
+                v5 += (int)(b1 == b0);  // C5: f+l <= 1 (an earlier slot holds the same broker)
+            }
+            if (ok2) {
+                r2 = RACK[b2]; atomicAdd(&C[b2], 1u); atomicAdd(&K[r2], 1);
+                obj += (c0 == b2) ? w01 : (((c1 == b2) | (c2 == b2) | (c3 == b2)) ? w11 : 0);
+                v5 += (int)((b2 == b0) | (b2 == b1));
+            }
+            if (ok3) {
+                r3 = RACK[b3]; atomicAdd(&C[b3], 1u); atomicAdd(&K[r3], 1);
+                obj += (c0 == b3) ? w01 : (((c1 == b3) | (c2 == b3) | (c3 == b3)) ? w11 : 0);
+                v5 += (int)((b3 == b0) | (b3 == b1) | (b3 == b2));
+            }
+            // C7: replicas per partition per rack, over all R racks
+            int touched = 0, s7 = 0;
+            if (ok0) { s7 += band(1 + (int)(r1 == r0) + (int)(r2 == r0) + (int)(r3 == r0), prack_lo, prack_hi); touched++; }
+            if (ok1 && r1 != r0) { s7 += band(1 + (int)(r2 == r1) + (int)(r3 == r1), prack_lo, prack_hi); touched++; }
+            if (ok2 && r2 != r0 && r2 != r1) { s7 += band(1 + (int)(r3 == r2), prack_lo, prack_hi); touched++; }
+            if (ok3 && r3 != r0 && r3 != r1 && r3 != r2) { s7 += band(1, prack_lo, prack_hi); touched++; }
+            v7 += s7 + (R - touched) * prack_lo;
+        }
+        int v3 = 0, v4 = 0, v6 = 0;
+        for (int b = lane; b < B; b += 64) {
+            const uint32_t c = C[b];
+            v3 += band((int)(c & 0xFFFFu), rep_lo, rep_hi);   // C3
+            v4 += band((int)(c >> 16), lead_lo, lead_hi);     // C4
+        }
+        if (lane < R) v6 = band(K[lane], rack_lo, rack_hi);   // C6
+        obj = wave_sum(obj);
+        v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
+        v5 = wave_sum(v5); v6 = wave_sum(v6); v7 = wave_sum(v7);
+        const int v0 = v1 + v2 + v3 + v4 + v5 + v6 + v7;
+        const int out = bm.w + (ci - bm.y);
+        if (lane == 0) {
+            if (pl.objective) pl.objective[out] = obj;
+            if (pl.violations) {
+                int4 *vo = reinterpret_cast<int4 *>(pl.violations + (size_t)out * 8);
+                vo[0] = make_int4(v0, v1, v2, v3);
+                vo[1] = make_int4(v4, v5, v6, v7);
+            }
+        }
+        const unsigned long long key = ((unsigned long long)min(v0, 0xFFFFF) << 44) |
+                                       ((unsigned long long)(kObjCap - (uint32_t)min(obj, (int)kObjCap)) << 20) |
+                                       (unsigned long long)(ci & 0xFFFFF);
+        my_key = key < my_key ? key : my_key;
+    }
+    if (pl.best_key) {  // workgroup reduce of the wave-uniform keys, one atomicMin per workgroup
+        if (lane == 0) wave_key[wave] = my_key;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long k = wave_key[0];
+            for (int w = 1; w < kWaves; ++w) k = wave_key[w] < k ? wave_key[w] : k;
+            if (k != ~0ull) atomicMin(pl.best_key + bm.x, k);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+size_t search_lds_bytes(int maxP, int maxBx) {
+    const size_t a = (size_t)maxP * 16, c = ((size_t)maxBx * 4 + 15) & ~(size_t)15;
+    return a + 256 + kWaves * (a + c + 256);
+}
+size_t eval_lds_bytes(int maxP, int maxB) {
+    const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = ((size_t)maxP * 8 + 15) & ~(size_t)15;
+    const size_t c = ((size_t)maxB * 4 + 15) & ~(size_t)15;
+    return 32 + r + d + kWaves * (c + 256);
+}
+
+static int g_attr_search = 0, g_attr_eval = 0;
+
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, void *stream) {
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx);
+    if ((int)lds > g_attr_search) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        g_attr_search = (int)lds;
+    }
+    hipLaunchKernelGGL(k_search, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools, prm);
+}
+
+void launch_eval(const EvalPools &pools, int n_blocks, void *stream) {
+    const size_t lds = eval_lds_bytes(pools.maxP, pools.maxB);
+    if ((int)lds > g_attr_eval) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        g_attr_eval = (int)lds;
+    }
+    hipLaunchKernelGGL(k_eval, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools);
+}
+
+}  // namespace kao

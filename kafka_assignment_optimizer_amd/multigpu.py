@@ -1,0 +1,86 @@
+"""Topic sharding across the GPUs of one node (one process per GPU, torch.distributed).
+
+Topics are independent sub-problems (every variable and row of the README model carries the topic
+prefix, README.md:146-184), so the data path needs no collective: each rank searches its own
+topics.  The one exchange step is the result merge -- a min-allreduce of the packed per-topic best
+keys (RCCL `ncclMin` on int64 when the backend is "nccl"; gloo on CPU in the tests) followed by a
+broadcast-free gather of the winners' assignments (each topic has exactly one owner unless topics
+are replicated, in which case the allreduce picks the global best and the winning rank supplies it).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+
+KEY_NONE = (1 << 63) - 1  # int64 max: "this rank has no result for the topic"
+RANK_BITS = 4             # up to 16 ranks per node folded into the key's low bits
+
+
+def shard_topics(sizes: Sequence[int], world: int) -> List[List[int]]:
+    """Longest-processing-time deal: topics sorted by size (B*P) descending, each to the least
+    loaded rank (ties -> lowest rank).  Returns the topic indices of every rank."""
+    order = sorted(range(len(sizes)), key=lambda i: (-int(sizes[i]), i))
+    load = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += int(sizes[i])
+    for r in range(world):
+        out[r].sort()
+    return out
+
+
+def pack_for_allreduce(keys_u64: np.ndarray, rank: int) -> np.ndarray:
+    """Device key (viol 20b | cost 24b | restart 20b) -> int64 whose minimum also identifies the
+    rank: the restart id keeps its 20 bits, the rank takes the low RANK_BITS of a left-shifted key.
+    The top bits stay clear (20+24+20+4 = 68 > 63), so the violation field is saturated to 15 bits."""
+    k = np.asarray(keys_u64, dtype=np.uint64)
+    viol = np.minimum(k >> np.uint64(44), np.uint64(0x7FFF))
+    rest = k & np.uint64((1 << 44) - 1)
+    packed = (viol << np.uint64(44 + RANK_BITS)) | (rest << np.uint64(RANK_BITS)) | np.uint64(rank)
+    return packed.astype(np.int64)
+
+
+def unpack_allreduced(v: int):
+    """-> (violation, objective, restart, rank)"""
+    v = int(v)
+    rank = v & ((1 << RANK_BITS) - 1)
+    v >>= RANK_BITS
+    return v >> 44, 0xFFFFFF - ((v >> 20) & 0xFFFFFF), v & 0xFFFFF, rank
+
+
+def allreduce_best(local_keys_u64: np.ndarray, owned: Sequence[int], n_topics: int, rank: int, device=None):
+    """Min-allreduce of the packed best keys over all ranks.
+
+    local_keys_u64[i] is this rank's key for topic owned[i].  Returns an int64 numpy array
+    [n_topics] holding, for every topic, the globally best (violation, cost, restart, rank)."""
+    import torch
+    import torch.distributed as dist
+
+    full = np.full(n_topics, KEY_NONE, dtype=np.int64)
+    if len(owned):
+        full[np.asarray(owned, dtype=np.int64)] = pack_for_allreduce(local_keys_u64, rank)
+    t = torch.from_numpy(full)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t.cpu().numpy()
+
+
+def gather_assignments(best: np.ndarray, owned: Sequence[int], local_assignments: Sequence[np.ndarray],
+                       rank: int, world: int) -> List[np.ndarray]:
+    """Every rank contributes the assignments of the topics it won; rank 0 receives all of them."""
+    import torch.distributed as dist
+
+    mine = {}
+    for i, t in enumerate(owned):
+        if unpack_allreduced(best[t])[3] == rank and best[t] != KEY_NONE:
+            mine[int(t)] = np.asarray(local_assignments[i])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    merged = {}
+    for d in gathered:
+        merged.update(d)
+    return [merged.get(t) for t in range(len(best))]

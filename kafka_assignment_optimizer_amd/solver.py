@@ -1,0 +1,267 @@
+"""Python face of the C ABI (include/kao.h).  Everything here forwards to libkao.so; the numbers
+come from the gfx950 kernels."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .model import BOUND_KEYS, Topic
+
+STATUS_NAMES = {0: "OPTIMAL_PROVEN", 1: "FEASIBLE_BOUND_GAP", 2: "NO_FEASIBLE", 3: "TIME_LIMIT"}
+
+
+class KaoError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        lib = _ffi.load()
+        detail = lib.kao_last_error().decode(errors="replace")
+        super().__init__(f"{where}: {lib.kao_strerror(code).decode()} ({code}) {detail}")
+        self.code = code
+
+
+def _check(rc: int, where: str):
+    if rc != 0:
+        raise KaoError(rc, where)
+
+
+def library_path() -> str:
+    return _ffi.LIB_PATH
+
+
+def init(device: int = 0):
+    _check(_ffi.load().kao_init(int(device)), "kao_init")
+
+
+def device_name() -> str:
+    buf = C.create_string_buffer(256)
+    _check(_ffi.load().kao_device_name(buf, 256), "kao_device_name")
+    return buf.value.decode()
+
+
+class _CTopics:
+    """C array of kao_topic plus the numpy buffers it points into."""
+
+    def __init__(self, topics: Sequence[Topic]):
+        self.keep = []
+        self.arr = (_ffi.KaoTopic * len(topics))()
+        for i, t in enumerate(topics):
+            s = self.arr[i]
+            rack = np.ascontiguousarray(t.rack_of, dtype=np.uint8)
+            cur = np.ascontiguousarray(t.current, dtype=np.uint16)
+            self.keep += [rack, cur]
+            s.n_brokers, s.n_racks, s.n_partitions = t.n_brokers, int(t.n_racks), int(t.n_partitions)
+            s.rf, s.rf_cur = int(t.rf), int(cur.shape[1])
+            s.rack_of = rack.ctypes.data_as(C.POINTER(C.c_uint8))
+            s.current = cur.ctypes.data_as(C.POINTER(C.c_uint16))
+            for a in range(2):
+                for b in range(2):
+                    s.w[a][b] = int(t.weights[a][b])
+            for k in BOUND_KEYS:
+                v = t.bounds_override.get(k, -1) if t.bounds_override else -1
+                setattr(s, k, -1 if v is None else int(v))
+
+    def ptr(self, i: int = 0):
+        return C.byref(self.arr[i]) if i else self.arr
+
+
+def derive_bounds(topic: Topic) -> dict:
+    ct = _CTopics([topic])
+    out = (C.c_int32 * 8)()
+    _check(_ffi.load().kao_derive_bounds(ct.arr, out), "kao_derive_bounds")
+    return dict(zip(BOUND_KEYS, [int(v) for v in out]))
+
+
+def upper_bound(topic: Topic) -> int:
+    ct = _CTopics([topic])
+    ub = C.c_int64()
+    _check(_ffi.load().kao_upper_bound(ct.arr, C.byref(ub)), "kao_upper_bound")
+    return int(ub.value)
+
+
+def evaluate(topic: Topic, assign) -> tuple:
+    """(objective, viol[8]) of one compact candidate, computed by K-eval on the GPU."""
+    ct = _CTopics([topic])
+    a = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1)
+    if a.size != topic.n_partitions * topic.rf:
+        raise ValueError("assignment must have P*rf entries")
+    obj = C.c_int64()
+    viol = (C.c_int32 * 8)()
+    _check(_ffi.load().kao_evaluate(ct.arr, a.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(obj), viol),
+           "kao_evaluate")
+    return int(obj.value), np.array(list(viol), dtype=np.int64)
+
+
+def evaluate_batch(topic: Topic, candidates) -> tuple:
+    """candidates [n, P*rf] -> (objective[n] int32, violations[n, 8] int32)."""
+    ct = _CTopics([topic])
+    c = np.ascontiguousarray(candidates, dtype=np.uint16).reshape(-1, topic.n_partitions * topic.rf)
+    n = c.shape[0]
+    obj = np.zeros(n, dtype=np.int32)
+    viol = np.zeros((n, 8), dtype=np.int32)
+    _check(_ffi.load().kao_evaluate_batch(ct.arr, c.ctypes.data_as(C.POINTER(C.c_uint16)), n,
+                                          obj.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          viol.ctypes.data_as(C.POINTER(C.c_int32))), "kao_evaluate_batch")
+    return obj, viol
+
+
+def canonicalize(topic: Topic, assign) -> np.ndarray:
+    ct = _CTopics([topic])
+    a = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1).copy()
+    _check(_ffi.load().kao_canonicalize(ct.arr, a.ctypes.data_as(C.POINTER(C.c_uint16))), "kao_canonicalize")
+    return a.reshape(topic.n_partitions, topic.rf)
+
+
+class EvalPlan:
+    """Device-resident K-eval: tables uploaded once; candidates / outputs are device pointers
+    (e.g. ``torch.Tensor.data_ptr()``)."""
+
+    def __init__(self, topic: Topic):
+        self.topic = topic
+        self._ct = _CTopics([topic])
+        self._h = C.c_void_p()
+        _check(_ffi.load().kao_eval_plan_create(self._ct.arr, C.byref(self._h)), "kao_eval_plan_create")
+
+    def run(self, d_candidates: int, n: int, d_objective: int, d_violations: int = 0, d_best_key: int = 0):
+        _check(_ffi.load().kao_eval_plan_run(self._h, C.c_void_p(d_candidates), int(n), C.c_void_p(d_objective),
+                                             C.c_void_p(d_violations or None), C.c_void_p(d_best_key or None)),
+               "kao_eval_plan_run")
+
+    def sync(self) -> float:
+        ms = C.c_double()
+        _check(_ffi.load().kao_eval_plan_sync(self._h, C.byref(ms)), "kao_eval_plan_sync")
+        return float(ms.value)
+
+    def close(self):
+        if self._h:
+            _ffi.load().kao_eval_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class Result:
+    status: str
+    objective: int
+    upper_bound: int
+    violations: np.ndarray
+    assignment: np.ndarray
+    best_restart: int
+    seconds_to_best: float
+
+
+def _make_opts(**kw) -> _ffi.KaoOpts:
+    o = _ffi.KaoOpts()
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown option {k}")
+        setattr(o, k, v)
+    return o
+
+
+def _results_buffers(topics: Sequence[Topic]):
+    res = (_ffi.KaoResult * len(topics))()
+    bufs = []
+    for i, t in enumerate(topics):
+        b = np.full(t.n_partitions * t.rf, 0xFFFF, dtype=np.uint16)
+        bufs.append(b)
+        res[i].assignment = b.ctypes.data_as(C.POINTER(C.c_uint16))
+    return res, bufs
+
+
+def _unpack(topics, res, bufs) -> List[Result]:
+    out = []
+    for i, t in enumerate(topics):
+        r = res[i]
+        out.append(Result(STATUS_NAMES.get(r.status, str(r.status)), int(r.objective), int(r.upper_bound),
+                          np.array(list(r.violations), dtype=np.int64), bufs[i].reshape(t.n_partitions, t.rf).copy(),
+                          int(r.best_restart), float(r.seconds_to_best)))
+    return out
+
+
+class Session:
+    """Resident parallel-restart search over a batch of topics (kao_session_*)."""
+
+    def __init__(self, topics: Sequence[Topic], **opts):
+        self.topics = list(topics)
+        self._ct = _CTopics(self.topics)
+        self._opts = _make_opts(**opts)
+        self._h = C.c_void_p()
+        _check(_ffi.load().kao_session_create(self._ct.arr, len(self.topics), C.byref(self._opts), C.byref(self._h)),
+               "kao_session_create")
+
+    def step(self, n: int = 1):
+        lib = _ffi.load()
+        for _ in range(n):
+            _check(lib.kao_session_step(self._h), "kao_session_step")
+
+    def sync(self):
+        _check(_ffi.load().kao_session_sync(self._h), "kao_session_sync")
+
+    def best(self) -> List[Result]:
+        res, bufs = _results_buffers(self.topics)
+        _check(_ffi.load().kao_session_best(self._h, res), "kao_session_best")
+        return _unpack(self.topics, res, bufs)
+
+    def best_keys(self) -> np.ndarray:
+        keys = np.zeros(len(self.topics), dtype=np.uint64)
+        _check(_ffi.load().kao_session_best_keys(self._h, keys.ctypes.data_as(C.POINTER(C.c_uint64))),
+               "kao_session_best_keys")
+        return keys
+
+    def stats(self) -> dict:
+        st = _ffi.KaoStats()
+        _check(_ffi.load().kao_session_stats(self._h, C.byref(st)), "kao_session_stats")
+        return {k: getattr(st, k) for k, _ in _ffi.KaoStats._fields_}
+
+    def restart_state(self, topic: int, restart: int) -> dict:
+        t = self.topics[topic]
+        n = t.n_partitions * t.rf
+        fin = np.zeros(n, dtype=np.uint16)
+        best = np.zeros(n, dtype=np.uint16)
+        info = (C.c_int32 * 4)()
+        _check(_ffi.load().kao_session_restart_state(self._h, topic, restart, fin.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                     best.ctypes.data_as(C.POINTER(C.c_uint16)), info),
+               "kao_session_restart_state")
+        return dict(final=fin.reshape(t.n_partitions, t.rf), best=best.reshape(t.n_partitions, t.rf),
+                    best_obj=int(info[0]), V=int(info[1]), obj=int(info[2]), n_accept=int(info[3]))
+
+    def close(self):
+        if self._h:
+            _ffi.load().kao_session_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_key(key: int) -> tuple:
+    """packed best key -> (violation, objective, restart)"""
+    key = int(key)
+    return key >> 44, 0xFFFFFF - ((key >> 20) & 0xFFFFFF), key & 0xFFFFF
+
+
+def solve(topics: Sequence[Topic], **opts) -> List[Result]:
+    """Whole job (kao_solve): search every topic until proven optimal / time limit."""
+    topics = list(topics)
+    ct = _CTopics(topics)
+    o = _make_opts(**opts)
+    res, bufs = _results_buffers(topics)
+    _check(_ffi.load().kao_solve(ct.arr, len(topics), C.byref(o), res), "kao_solve")
+    return _unpack(topics, res, bufs)

@@ -1,0 +1,112 @@
+"""Synthetic clusters for the BASELINE.json configs, product side.
+
+Old cluster: brokers 0..B0-1 with rack(b) = b mod R (generalises README.md:28-29); every topic gets
+a deterministic rack-aware balanced assignment; then a seeded change set (splitmix64, seed
+0x4B414F00 + config number) removes and/or adds brokers.  tests/test_synthetic.py checks these
+arrays against the oracle's independent generator.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .model import DEFAULT_WEIGHTS, NONE, Topic
+
+CONFIG_SEED = 0x4B414F00
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+WORKLOADS = {
+    1: "cfg1: README example, 20 brokers / 2 AZ, 1 topic x 10 partitions RF 2, remove broker 19",
+    2: "cfg2: 100 brokers / 4 racks, 1 topic x 256 partitions RF 3, remove 1 broker",
+    3: "cfg3: 200 brokers / 6 racks, 50 topics x 64 partitions RF 3, add 20 brokers",
+    4: "cfg4: 500 brokers / 10 racks, 200 topics x 50 partitions (10k partitions) RF 3, rolling replace 50 brokers",
+    5: "cfg5: 1000 brokers / 20 racks, 1000 topics x 100 partitions (100k partitions) RF 3, remove 50 + add 50, per-broker cap ceil(avg)+1",
+}
+
+
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.s = seed & _M64
+
+    def next(self) -> int:
+        self.s = (self.s + 0x9E3779B97F4A7C15) & _M64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+        return z ^ (z >> 31)
+
+    def below(self, n: int) -> int:
+        return self.next() % n
+
+    def sample(self, items: Sequence[int], k: int) -> List[int]:
+        pool = list(items)
+        return [pool.pop(self.below(len(pool))) for _ in range(k)]
+
+
+def balanced_fill(n_brokers: int, n_racks: int, n_partitions: int, rf: int, t: int, rack_of: np.ndarray) -> np.ndarray:
+    """Slot k of partition p -> rack (t+p+k) mod R, least-loaded broker of that rack not already in
+    p; leaders ordered by (leaders, replicas, id), followers by (replicas, id)."""
+    members = [np.nonzero(rack_of == r)[0] for r in range(n_racks)]
+    cnt_r = np.zeros(n_brokers, dtype=np.int64)
+    cnt_l = np.zeros(n_brokers, dtype=np.int64)
+    out = np.full((n_partitions, rf), NONE, dtype=np.uint16)
+    big = 1 << 60
+    for p in range(n_partitions):
+        used: List[int] = []
+        for k in range(rf):
+            mem = members[(t + p + k) % n_racks]
+            key = (cnt_l[mem] << 40) + (cnt_r[mem] << 20) + mem if k == 0 else (cnt_r[mem] << 20) + mem
+            if used:
+                key = np.where(np.isin(mem, used), big, key)
+            b = int(mem[int(np.argmin(key))])
+            if k == 0:
+                cnt_l[b] += 1
+            cnt_r[b] += 1
+            used.append(b)
+            out[p, k] = b
+    return out
+
+
+def make_cluster(n_brokers0: int, n_racks: int, n_topics: int, n_partitions: int, rf: int, removed: Sequence[int],
+                 added: Sequence[Tuple[int, int]], weights=DEFAULT_WEIGHTS, bounds_override=None,
+                 new_rf: Optional[int] = None) -> List[Topic]:
+    rack0 = np.arange(n_brokers0) % n_racks
+    gone = set(int(b) for b in removed)
+    target = [b for b in range(n_brokers0) if b not in gone] + [int(b) for b, _ in added]
+    rack_t = [int(rack0[b]) for b in range(n_brokers0) if b not in gone] + [int(r) for _, r in added]
+    lut = np.full(n_brokers0, NONE, dtype=np.uint16)
+    for i, b in enumerate(target):
+        if b < n_brokers0:
+            lut[b] = i
+    topics = []
+    for t in range(n_topics):
+        cur_old = balanced_fill(n_brokers0, n_racks, n_partitions, rf, t, rack0)
+        topics.append(Topic(name=f"topic-{t:04d}", broker_ids=np.array(target, dtype=np.int32),
+                            rack_of=np.array(rack_t, dtype=np.uint8), n_racks=n_racks, n_partitions=n_partitions,
+                            rf=new_rf or rf, current=lut[cur_old], weights=weights,
+                            bounds_override=dict(bounds_override or {})))
+    return topics
+
+
+def make_config(n: int, n_topics: Optional[int] = None) -> List[Topic]:
+    """Topics of BASELINE.json config `n` (2..5); `n_topics` truncates."""
+    rng = SplitMix64(CONFIG_SEED + n)
+    if n == 2:
+        return make_cluster(100, 4, n_topics or 1, 256, 3, [rng.below(100)], [])
+    if n == 3:
+        return make_cluster(200, 6, n_topics or 50, 64, 3, [], [(b, b % 6) for b in range(200, 220)])
+    if n == 4:
+        rm, add, nid = [], [], 500
+        for r in range(10):
+            for b in rng.sample([b for b in range(500) if b % 10 == r], 5):
+                rm.append(b)
+                add.append((nid, r))
+                nid += 1
+        return make_cluster(500, 10, n_topics or 200, 50, 3, rm, add)
+    if n == 5:
+        rm = rng.sample(list(range(1000)), 50)
+        add = [(1000 + i, rng.below(20)) for i in range(50)]
+        cap = -((-100 * 3) // 1000) + 1
+        return make_cluster(1000, 20, n_topics or 1000, 100, 3, rm, add, bounds_override={"rep_hi": cap})
+    raise ValueError("config must be 2..5 (config 1 is the README example: use topics_from_json)")

@@ -1,0 +1,426 @@
+/* kao_port.c -- CPU restatement (plain C) of the hot path -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Two things live here, both used only by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg (never by the product library):
+ *
+ *  1. kao_port_eval(): full evaluation of one compact candidate against the README model
+ *     (objective README.md:145-146; C1 README.md:148-151; C2 153-156; C3 158-161;
+ *     C4 163-166; C5 168-171; C6 173-176; C7 178-180).  Same definition as
+ *     oracle/kao_oracle.py::verify(), checked against it in tests.
+ *
+ *  2. kao_port_search(): a scalar replay of the device's parallel-restart local search
+ *     ("KAO-LS", specified in DESIGN.md section 4): 64 proposals per iteration (one per
+ *     wavefront lane on the GPU, a plain loop here), delta-evaluated against the same
+ *     state, arg-min by packed key, accept rule, best-feasible snapshot.  Given the same
+ *     seed it must produce bit-identical states to the HIP kernel.
+ *
+ * PARITY STATUS: parity unpinned beyond KAT-1 -- the reference's solver (lp_solve 5.5,
+ * README.md:135-136) is absent; see oracle/kao_oracle.py header.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NONE16 0xFFFFu
+#define RFP 4 /* padded replica slots per partition */
+#define LANES 64
+
+typedef struct {
+    int32_t n_brokers, n_racks, n_partitions, rf, rf_cur;
+    const uint8_t *rack_of;   /* [B] */
+    const uint16_t *current;  /* [P*rf_cur] dense index or NONE16 */
+    int32_t w[2][2];          /* w[cur_role][new_role] */
+    int32_t rep_lo, rep_hi, lead_lo, lead_hi, rack_lo, rack_hi, prack_lo, prack_hi;
+} port_topic;
+
+typedef struct {
+    uint64_t seed;      /* per-topic seed */
+    int32_t obj_scale;  /* S: objective weights are multiplied by S inside the search cost */
+    int32_t lam_min;    /* penalty per unit of violation: sawtooth lam_min..lam_max */
+    int32_t lam_max;
+    int32_t period_log2;/* sawtooth period of restart rho = 2^(period_log2 + (rho & 3)) iterations: the first
+                           half ramps lam_min -> lam_max, the second half holds lam_max */
+} port_params;
+
+static inline int band(int c, int lo, int hi) {
+    int a = c - hi, b = lo - c;
+    return (a > 0 ? a : 0) + (b > 0 ? b : 0);
+}
+
+/* ------------------------------------------------------------------ full evaluation */
+int kao_port_eval(const port_topic *t, const uint16_t *assign, int64_t *objective, int32_t viol[8]) {
+    const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
+    int32_t *cr = (int32_t *)calloc((size_t)B, sizeof(int32_t));
+    int32_t *cl = (int32_t *)calloc((size_t)B, sizeof(int32_t));
+    int32_t *rk = (int32_t *)calloc((size_t)R, sizeof(int32_t));
+    int32_t *pr = (int32_t *)calloc((size_t)R, sizeof(int32_t));
+    if (!cr || !cl || !rk || !pr) { free(cr); free(cl); free(rk); free(pr); return -1; }
+    int64_t obj = 0;
+    memset(viol, 0, 8 * sizeof(int32_t));
+    for (int p = 0; p < P; ++p) {
+        memset(pr, 0, (size_t)R * sizeof(int32_t));
+        for (int k = 0; k < RF; ++k) {
+            unsigned b = assign[p * RF + k];
+            if (b >= (unsigned)B) {
+                viol[1] += 1;
+                if (k == 0) viol[2] += 1;
+                continue;
+            }
+            cr[b] += 1;
+            if (k == 0) cl[b] += 1;
+            rk[t->rack_of[b]] += 1;
+            pr[t->rack_of[b]] += 1;
+            for (int j = 0; j < k; ++j)
+                if (assign[p * RF + j] == b) { viol[5] += 1; break; }
+            const uint16_t *cur = t->current + (size_t)p * t->rf_cur;
+            int nr = k == 0 ? 0 : 1;
+            for (int j = 0; j < t->rf_cur; ++j)
+                if (cur[j] == b) { obj += t->w[j == 0 ? 0 : 1][nr]; break; }
+        }
+        for (int r = 0; r < R; ++r) viol[7] += band(pr[r], t->prack_lo, t->prack_hi);
+    }
+    for (int b = 0; b < B; ++b) {
+        viol[3] += band(cr[b], t->rep_lo, t->rep_hi);
+        viol[4] += band(cl[b], t->lead_lo, t->lead_hi);
+    }
+    for (int r = 0; r < R; ++r) viol[6] += band(rk[r], t->rack_lo, t->rack_hi);
+    viol[0] = viol[1] + viol[2] + viol[3] + viol[4] + viol[5] + viol[6] + viol[7];
+    *objective = obj;
+    free(cr); free(cl); free(rk); free(pr);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ KAO-LS replay */
+typedef struct {
+    int P, RF, R, m, Bx; /* m = max rack size; internal index x = rack*m + j */
+    uint32_t magic;      /* floor(2^32/m)+1: rack(x) = mulhi(x, magic) */
+    int rack_size[64];
+    uint16_t *int_of;    /* [B] dense -> internal */
+    uint16_t *ext_of;    /* [Bx] internal -> dense (NONE16 for padding) */
+    uint16_t *cur;       /* [P*RFP] internal */
+    int w[2][2];
+    int rep_lo, rep_hi, lead_lo, lead_hi, rack_lo, rack_hi, prack_lo, prack_hi;
+} ls_topic;
+
+typedef struct {
+    uint16_t *A;   /* [P*RFP] internal, slots >= RF are NONE16 */
+    uint32_t *C;   /* [Bx] cntR | cntL << 16 */
+    int K[64];     /* replicas per rack */
+    int V, obj;    /* current total violation magnitude, objective */
+    int best_obj;  /* best feasible objective seen, -1 if none */
+    uint16_t *best;/* [P*RF] dense snapshot */
+    uint64_t n_eval, n_accept;
+} ls_state;
+
+static inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+static inline uint32_t mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static inline uint32_t xs32(uint32_t *s) {
+    uint32_t x = *s; x ^= x << 13; x ^= x >> 17; x ^= x << 5; *s = x; return x;
+}
+static inline int rack_of_x(const ls_topic *t, unsigned x) { return (int)mulhi(x, t->magic); }
+static inline int valid_x(const ls_topic *t, unsigned x) {
+    int r = rack_of_x(t, x);
+    return (int)(x - (unsigned)(r * t->m)) < t->rack_size[r];
+}
+static inline int role_w(const ls_topic *t, int p, unsigned x, int nr) {
+    const uint16_t *c = t->cur + p * RFP;
+    if (c[0] == x) return t->w[0][nr];
+    if (c[1] == x || c[2] == x || c[3] == x) return t->w[1][nr];
+    return 0;
+}
+static inline int in_part(const uint16_t *a, unsigned x) {
+    return a[0] == x || a[1] == x || a[2] == x || a[3] == x;
+}
+static inline int rack_count(const ls_topic *t, const uint16_t *a, int r) {
+    int c = 0;
+    for (int s = 0; s < RFP; ++s) c += (a[s] != NONE16 && rack_of_x(t, a[s]) == r);
+    return c;
+}
+
+void *kao_port_ls_create(const port_topic *pt) {
+    ls_topic *t = (ls_topic *)calloc(1, sizeof(ls_topic));
+    const int B = pt->n_brokers;
+    t->P = pt->n_partitions; t->RF = pt->rf; t->R = pt->n_racks;
+    if (t->RF > RFP || pt->rf_cur > RFP || t->R > 64) { free(t); return NULL; }
+    for (int b = 0; b < B; ++b) t->rack_size[pt->rack_of[b]] += 1;
+    for (int r = 0; r < t->R; ++r) if (t->rack_size[r] > t->m) t->m = t->rack_size[r];
+    t->Bx = t->R * t->m;
+    t->magic = (uint32_t)(0x100000000ull / (uint64_t)t->m) + 1u;
+    t->int_of = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B);
+    t->ext_of = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->Bx);
+    memset(t->ext_of, 0xFF, sizeof(uint16_t) * (size_t)t->Bx);
+    int fill[64] = {0};
+    for (int b = 0; b < B; ++b) { /* dense order inside each rack is preserved */
+        int r = pt->rack_of[b];
+        int x = r * t->m + fill[r]++;
+        t->int_of[b] = (uint16_t)x; t->ext_of[x] = (uint16_t)b;
+    }
+    t->cur = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * RFP);
+    memset(t->cur, 0xFF, sizeof(uint16_t) * (size_t)t->P * RFP);
+    for (int p = 0; p < t->P; ++p)
+        for (int k = 0; k < pt->rf_cur; ++k) {
+            unsigned b = pt->current[p * pt->rf_cur + k];
+            if (b < (unsigned)B) t->cur[p * RFP + k] = t->int_of[b];
+        }
+    memcpy(t->w, pt->w, sizeof(t->w));
+    t->rep_lo = pt->rep_lo; t->rep_hi = pt->rep_hi; t->lead_lo = pt->lead_lo; t->lead_hi = pt->lead_hi;
+    t->rack_lo = pt->rack_lo; t->rack_hi = pt->rack_hi; t->prack_lo = pt->prack_lo; t->prack_hi = pt->prack_hi;
+    return t;
+}
+
+void kao_port_ls_destroy(void *h) {
+    ls_topic *t = (ls_topic *)h;
+    if (!t) return;
+    free(t->int_of); free(t->ext_of); free(t->cur); free(t);
+}
+
+/* rebuild counters, V and obj from A (the device does this wave-parallel at every launch) */
+static void ls_recount(const ls_topic *t, ls_state *s) {
+    memset(s->C, 0, sizeof(uint32_t) * (size_t)t->Bx);
+    memset(s->K, 0, sizeof(s->K));
+    int V = 0, obj = 0;
+    for (int p = 0; p < t->P; ++p) {
+        const uint16_t *a = s->A + p * RFP;
+        for (int k = 0; k < t->RF; ++k) {
+            unsigned x = a[k];
+            s->C[x] += (k == 0) ? 0x10001u : 1u;
+            s->K[rack_of_x(t, x)] += 1;
+            obj += role_w(t, p, x, k == 0 ? 0 : 1);
+        }
+        for (int r = 0; r < t->R; ++r) V += band(rack_count(t, a, r), t->prack_lo, t->prack_hi);
+    }
+    for (int x = 0; x < t->Bx; ++x) {
+        if (!valid_x(t, (unsigned)x)) continue;
+        V += band((int)(s->C[x] & 0xFFFF), t->rep_lo, t->rep_hi);
+        V += band((int)(s->C[x] >> 16), t->lead_lo, t->lead_hi);
+    }
+    for (int r = 0; r < t->R; ++r) V += band(s->K[r], t->rack_lo, t->rack_hi);
+    s->V = V; s->obj = obj;
+}
+
+static void ls_snapshot(const ls_topic *t, ls_state *s) {
+    for (int p = 0; p < t->P; ++p)
+        for (int k = 0; k < t->RF; ++k) s->best[p * t->RF + k] = t->ext_of[s->A[p * RFP + k]];
+}
+
+#define KEY_NULL 0xFFFFFFFFu
+#define DBIAS 32768
+static inline int d_band(int c, int d, int lo, int hi) { return band(c + d, lo, hi) - band(c, lo, hi); }
+
+/* rebuild counters from A, skipping empty (NONE16) slots; V / obj are not meaningful while
+ * holes remain, so they are left to ls_recount */
+static void ls_count_partial(const ls_topic *t, ls_state *s) {
+    memset(s->C, 0, sizeof(uint32_t) * (size_t)t->Bx);
+    memset(s->K, 0, sizeof(s->K));
+    for (int p = 0; p < t->P; ++p)
+        for (int k = 0; k < t->RF; ++k) {
+            unsigned x = s->A[p * RFP + k];
+            if (x == NONE16) continue;
+            s->C[x] += (k == 0) ? 0x10001u : 1u;
+            s->K[rack_of_x(t, x)] += 1;
+        }
+}
+
+/* initial state of restart `rho`: surviving current replicas stay in their slots; every hole
+ * (replica on a removed broker, or a slot added by an RF increase) is filled, in (p,k) order,
+ * by the best of 64 hashed tries (one per lane on the GPU): minimal lam_max*dV - S*dObj of
+ * the insertion, ties to the lowest try index; if all 64 tries are invalid, the lowest valid
+ * x not in the partition. */
+static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho) {
+    const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
+    for (int p = 0; p < t->P; ++p)
+        for (int k = 0; k < RFP; ++k) s->A[p * RFP + k] = (k < t->RF) ? t->cur[p * RFP + k] : NONE16;
+    ls_count_partial(t, s);
+    for (int p = 0; p < t->P; ++p) {
+        uint16_t *a = s->A + p * RFP;
+        for (int k = 0; k < t->RF; ++k) {
+            if (a[k] != NONE16) continue;
+            uint32_t best_key = KEY_NULL; int found = -1;
+            for (uint32_t i = 0; i < LANES; ++i) {
+                uint32_t u = fmix32(slo ^ fmix32(shi + rho * 0x9E3779B1u + (uint32_t)(p * RFP + k) * 0x27D4EB2Fu
+                                                 + i * 0x165667B1u + 0x5BD1E995u));
+                unsigned x = mulhi(u, (uint32_t)t->Bx);
+                if (!valid_x(t, x) || in_part(a, x)) continue;
+                int rn = rack_of_x(t, x);
+                int dV = d_band((int)(s->C[x] & 0xFFFF), +1, t->rep_lo, t->rep_hi)
+                       + d_band(s->K[rn], +1, t->rack_lo, t->rack_hi)
+                       + d_band(rack_count(t, a, rn), +1, t->prack_lo, t->prack_hi);
+                if (k == 0) dV += d_band((int)(s->C[x] >> 16), +1, t->lead_lo, t->lead_hi);
+                int delta = pp->lam_max * dV - pp->obj_scale * role_w(t, p, x, k == 0 ? 0 : 1);
+                if (delta < -DBIAS) delta = -DBIAS;
+                if (delta > DBIAS - 2) delta = DBIAS - 2;
+                uint32_t key = ((uint32_t)(delta + DBIAS) << 16) | i;
+                if (key < best_key) { best_key = key; found = (int)x; }
+            }
+            for (int x = 0; x < t->Bx && found < 0; ++x)
+                if (valid_x(t, (unsigned)x) && !in_part(a, (unsigned)x)) found = x;
+            a[k] = (uint16_t)found; /* found >= 0 whenever B >= RF */
+            s->C[found] += (k == 0) ? 0x10001u : 1u;
+            s->K[rack_of_x(t, (unsigned)found)] += 1;
+        }
+    }
+    s->best_obj = -1; s->n_eval = 0; s->n_accept = 0;
+}
+
+typedef struct { int type, p, k, q, j; unsigned x; int dV, dObj; } proposal;
+
+/* move type of global iteration `it` (wave-uniform on the GPU) */
+static inline int move_type(uint32_t it) {
+    static const uint8_t pat[8] = {0, 0, 1, 0, 2, 0, 1, 0}; /* 0 replace, 1 exchange, 2 leader swap */
+    return pat[it & 7];
+}
+
+/* one lane's proposal and its delta; returns 0 for a null proposal */
+static int ls_propose(const ls_topic *t, const ls_state *s, int type, uint32_t r1, uint32_t r2, proposal *o) {
+    const int P = t->P, RF = t->RF;
+    o->type = type;
+    int p = (int)mulhi(r1, (uint32_t)P);
+    const uint16_t *a = s->A + p * RFP;
+    o->p = p;
+    if (type == 0) { /* replace (p,k) by x */
+        int k = (int)(((r1 & 0xFFFFu) * (uint32_t)RF) >> 16);
+        unsigned x = mulhi(r2, (uint32_t)t->Bx);
+        o->k = k; o->x = x;
+        if (!valid_x(t, x) || in_part(a, x)) return 0;
+        unsigned old = a[k];
+        int nr = k == 0 ? 0 : 1;
+        int dObj = role_w(t, p, x, nr) - role_w(t, p, old, nr);
+        uint32_t co = s->C[old], cn = s->C[x];
+        int dV = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi) + d_band((int)(cn & 0xFFFF), +1, t->rep_lo, t->rep_hi);
+        if (k == 0)
+            dV += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
+        int ro = rack_of_x(t, old), rn = rack_of_x(t, x);
+        if (ro != rn) {
+            dV += d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(s->K[rn], +1, t->rack_lo, t->rack_hi);
+            dV += d_band(rack_count(t, a, ro), -1, t->prack_lo, t->prack_hi)
+                + d_band(rack_count(t, a, rn), +1, t->prack_lo, t->prack_hi);
+        }
+        o->dV = dV; o->dObj = dObj;
+        return 1;
+    }
+    if (type == 1) { /* exchange (p,k) <-> (q,j) */
+        int k = (int)(((r1 & 0xFFFFu) * (uint32_t)RF) >> 16);
+        int q = (int)mulhi(r2, (uint32_t)P);
+        int j = (int)(((r2 & 0xFFFFu) * (uint32_t)RF) >> 16);
+        o->k = k; o->q = q; o->j = j;
+        if (p == q) return 0;
+        const uint16_t *b = s->A + q * RFP;
+        unsigned u = a[k], v = b[j];
+        if (u == v || in_part(a, v) || in_part(b, u)) return 0;
+        int nrp = k == 0 ? 0 : 1, nrq = j == 0 ? 0 : 1;
+        int dObj = role_w(t, p, v, nrp) + role_w(t, q, u, nrq) - role_w(t, p, u, nrp) - role_w(t, q, v, nrq);
+        int dV = 0;
+        if ((k == 0) != (j == 0)) {
+            unsigned lose = (k == 0) ? u : v, gain = (k == 0) ? v : u;
+            dV += d_band((int)(s->C[lose] >> 16), -1, t->lead_lo, t->lead_hi)
+                + d_band((int)(s->C[gain] >> 16), +1, t->lead_lo, t->lead_hi);
+        }
+        int ru = rack_of_x(t, u), rv = rack_of_x(t, v);
+        if (ru != rv) {
+            dV += d_band(rack_count(t, a, ru), -1, t->prack_lo, t->prack_hi)
+                + d_band(rack_count(t, a, rv), +1, t->prack_lo, t->prack_hi)
+                + d_band(rack_count(t, b, rv), -1, t->prack_lo, t->prack_hi)
+                + d_band(rack_count(t, b, ru), +1, t->prack_lo, t->prack_hi);
+        }
+        o->dV = dV; o->dObj = dObj;
+        return 1;
+    }
+    /* leader swap inside p: slot 0 <-> slot k (k >= 1) */
+    if (RF < 2) return 0;
+    int k = 1 + (int)(((r1 & 0xFFFFu) * (uint32_t)(RF - 1)) >> 16);
+    o->k = k;
+    unsigned u = a[0], v = a[k];
+    o->dObj = role_w(t, p, v, 0) + role_w(t, p, u, 1) - role_w(t, p, u, 0) - role_w(t, p, v, 1);
+    o->dV = d_band((int)(s->C[u] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[v] >> 16), +1, t->lead_lo, t->lead_hi);
+    return 1;
+}
+
+static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
+    uint16_t *a = s->A + o->p * RFP;
+    if (o->type == 0) {
+        unsigned old = a[o->k];
+        uint32_t d = (o->k == 0) ? 0x10001u : 1u;
+        s->C[old] -= d; s->C[o->x] += d;
+        s->K[rack_of_x(t, old)] -= 1; s->K[rack_of_x(t, o->x)] += 1;
+        a[o->k] = (uint16_t)o->x;
+    } else if (o->type == 1) {
+        uint16_t *b = s->A + o->q * RFP;
+        unsigned u = a[o->k], v = b[o->j];
+        if ((o->k == 0) != (o->j == 0)) {
+            unsigned lose = (o->k == 0) ? u : v, gain = (o->k == 0) ? v : u;
+            s->C[lose] -= 0x10000u; s->C[gain] += 0x10000u;
+        }
+        a[o->k] = (uint16_t)v; b[o->j] = (uint16_t)u;
+    } else {
+        unsigned u = a[0], v = a[o->k];
+        s->C[u] -= 0x10000u; s->C[v] += 0x10000u;
+        a[0] = (uint16_t)v; a[o->k] = (uint16_t)u;
+    }
+    s->V += o->dV; s->obj += o->dObj;
+}
+
+/* run `iters` iterations of launch number `launch` (global iteration = launch*iters + i) */
+static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho, uint32_t launch, uint32_t iters) {
+    const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
+    uint32_t rng[LANES];
+    for (uint32_t l = 0; l < LANES; ++l) {
+        uint32_t v = fmix32(slo ^ fmix32(shi + rho * 0x9E3779B1u + launch * 0x85EBCA77u + l * 0xC2B2AE3Du));
+        rng[l] = v ? v : 0x6D2B79F5u;
+    }
+    ls_recount(t, s);
+    if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
+    const uint32_t plog = (uint32_t)pp->period_log2 + (rho & 3u);
+    const uint32_t pmask = (1u << plog) - 1u;
+    for (uint32_t i = 0; i < iters; ++i) {
+        const uint32_t it = launch * iters + i;
+        const int type = move_type(it);
+        const uint32_t ph = it & pmask;
+        int lam = pp->lam_min + (int)((2u * ph * (uint32_t)(pp->lam_max - pp->lam_min + 1)) >> plog);
+        if (lam > pp->lam_max) lam = pp->lam_max;
+        uint32_t best_key = KEY_NULL;
+        proposal best_prop; memset(&best_prop, 0, sizeof best_prop);
+        for (uint32_t l = 0; l < LANES; ++l) {
+            uint32_t r1 = xs32(&rng[l]), r2 = xs32(&rng[l]), r3 = xs32(&rng[l]);
+            proposal o;
+            if (!ls_propose(t, s, type, r1, r2, &o)) continue;
+            int delta = lam * o.dV - pp->obj_scale * o.dObj;
+            if (delta < -DBIAS) delta = -DBIAS;
+            if (delta > DBIAS - 2) delta = DBIAS - 2;
+            uint32_t key = ((uint32_t)(delta + DBIAS) << 16) | ((r3 >> 22) << 6) | l;
+            if (key < best_key) { best_key = key; best_prop = o; }
+        }
+        s->n_eval += LANES;
+        if (best_key == KEY_NULL) continue;
+        int delta = (int)(best_key >> 16) - DBIAS;
+        if (delta > 0) continue;
+        ls_apply(t, s, &best_prop);
+        s->n_accept++;
+        if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
+    }
+}
+
+/* Search one restart from scratch: `launches` launches of `iters` iterations each.
+ * Outputs: final state (dense, [P*RF]), best snapshot (dense, [P*RF]), stats[6] =
+ * {best_obj, V, obj, n_eval lo, n_eval hi, n_accept}. */
+int kao_port_search(void *h, const port_params *pp, uint32_t rho, uint32_t launches, uint32_t iters,
+                    uint16_t *final_dense, uint16_t *best_dense, int64_t stats[6]) {
+    const ls_topic *t = (const ls_topic *)h;
+    ls_state s; memset(&s, 0, sizeof s);
+    s.A = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * RFP);
+    s.C = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)t->Bx);
+    s.best = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * t->RF);
+    memset(s.best, 0xFF, sizeof(uint16_t) * (size_t)t->P * t->RF);
+    ls_init(t, &s, pp, rho);
+    for (uint32_t L = 0; L < launches; ++L) ls_run(t, &s, pp, rho, L, iters);
+    ls_recount(t, &s);
+    for (int p = 0; p < t->P; ++p)
+        for (int k = 0; k < t->RF; ++k) final_dense[p * t->RF + k] = t->ext_of[s.A[p * RFP + k]];
+    memcpy(best_dense, s.best, sizeof(uint16_t) * (size_t)t->P * t->RF);
+    stats[0] = s.best_obj; stats[1] = s.V; stats[2] = s.obj;
+    stats[3] = (int64_t)(s.n_eval & 0xFFFFFFFFu); stats[4] = (int64_t)(s.n_eval >> 32); stats[5] = (int64_t)s.n_accept;
+    free(s.A); free(s.C); free(s.best);
+    return 0;
+}

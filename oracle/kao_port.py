@@ -1,0 +1,109 @@
+"""ctypes wrapper of oracle/libkao_port.so (CPU restatement in C) -- TEST INFRASTRUCTURE ONLY.
+See oracle/kao_port.c.  Never imported by the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class PortTopic(C.Structure):
+    _fields_ = [("n_brokers", C.c_int32), ("n_racks", C.c_int32), ("n_partitions", C.c_int32),
+                ("rf", C.c_int32), ("rf_cur", C.c_int32),
+                ("rack_of", C.POINTER(C.c_uint8)), ("current", C.POINTER(C.c_uint16)),
+                ("w", (C.c_int32 * 2) * 2),
+                ("rep_lo", C.c_int32), ("rep_hi", C.c_int32), ("lead_lo", C.c_int32), ("lead_hi", C.c_int32),
+                ("rack_lo", C.c_int32), ("rack_hi", C.c_int32), ("prack_lo", C.c_int32), ("prack_hi", C.c_int32)]
+
+
+class PortParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("obj_scale", C.c_int32), ("lam_min", C.c_int32),
+                ("lam_max", C.c_int32), ("period_log2", C.c_int32)]
+
+
+def build() -> str:
+    so = os.path.join(_HERE, "libkao_port.so")
+    src = os.path.join(_HERE, "kao_port.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libkao_port.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.kao_port_eval.argtypes = [C.POINTER(PortTopic), C.POINTER(C.c_uint16), C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int32)]
+        _LIB.kao_port_eval.restype = C.c_int
+        _LIB.kao_port_ls_create.argtypes = [C.POINTER(PortTopic)]
+        _LIB.kao_port_ls_create.restype = C.c_void_p
+        _LIB.kao_port_ls_destroy.argtypes = [C.c_void_p]
+        _LIB.kao_port_search.argtypes = [C.c_void_p, C.POINTER(PortParams), C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int64)]
+        _LIB.kao_port_search.restype = C.c_int
+    return _LIB
+
+
+class CTopic:
+    """Keeps the numpy buffers alive next to the C struct."""
+
+    def __init__(self, topic):
+        bd = topic.bounds()
+        self.rack = np.ascontiguousarray(topic.rack_of, dtype=np.uint8)
+        self.cur = np.ascontiguousarray(topic.current, dtype=np.uint16)
+        s = PortTopic()
+        s.n_brokers, s.n_racks, s.n_partitions = topic.n_brokers, topic.n_racks, topic.n_partitions
+        s.rf, s.rf_cur = topic.rf, topic.rf_cur
+        s.rack_of = self.rack.ctypes.data_as(C.POINTER(C.c_uint8))
+        s.current = self.cur.ctypes.data_as(C.POINTER(C.c_uint16))
+        for i in range(2):
+            for j in range(2):
+                s.w[i][j] = int(topic.weights[i][j])
+        for k in ("rep_lo", "rep_hi", "lead_lo", "lead_hi", "rack_lo", "rack_hi", "prack_lo", "prack_hi"):
+            setattr(s, k, bd[k])
+        self.s = s
+        self.topic = topic
+
+
+def port_eval(topic, assign) -> Tuple[int, np.ndarray]:
+    ct = CTopic(topic)
+    a = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1)
+    obj = C.c_int64()
+    viol = (C.c_int32 * 8)()
+    rc = lib().kao_port_eval(C.byref(ct.s), a.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(obj), viol)
+    assert rc == 0
+    return int(obj.value), np.array(list(viol), dtype=np.int64)
+
+
+DEFAULT_PARAMS = dict(obj_scale=4, lam_min=1, lam_max=40, period_log2=8)
+
+
+def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params):
+    """Replay restart `rho`.  Returns dict(final, best, best_obj, V, obj, n_eval, n_accept)."""
+    ct = CTopic(topic)
+    h = lib().kao_port_ls_create(C.byref(ct.s))
+    if not h:
+        raise ValueError("unsupported instance (RF > 4 or racks > 64)")
+    try:
+        pr = dict(DEFAULT_PARAMS)
+        pr.update(params)
+        pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
+                        lam_max=pr["lam_max"], period_log2=pr["period_log2"])
+        n = topic.n_partitions * topic.rf
+        fin = np.zeros(n, dtype=np.uint16)
+        best = np.zeros(n, dtype=np.uint16)
+        st = (C.c_int64 * 6)()
+        lib().kao_port_search(h, C.byref(pp), rho, launches, iters, fin.ctypes.data_as(C.POINTER(C.c_uint16)),
+                              best.ctypes.data_as(C.POINTER(C.c_uint16)), st)
+        return dict(final=fin.reshape(topic.n_partitions, topic.rf), best=best.reshape(topic.n_partitions, topic.rf),
+                    best_obj=int(st[0]), V=int(st[1]), obj=int(st[2]), n_eval=int(st[3]) | (int(st[4]) << 32),
+                    n_accept=int(st[5]))
+    finally:
+        lib().kao_port_ls_destroy(h)

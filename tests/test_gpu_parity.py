@@ -1,0 +1,222 @@
+"""GPU parity tests (run on the MI355X box with -m gpu).  Everything goes through the C ABI of
+libkao.so; the oracle (numpy verifier, C port, HiGHS golden optima) is only the checker.
+
+  * K-eval  vs oracle verifier: bit-exact (objective, viol[8]) -- golden vectors, seeded random
+    candidates at every BASELINE config's topic size, edge cases (empty slots, out-of-range ids,
+    duplicates, RF change).
+  * K-search vs the scalar replay (oracle/kao_port.c): bit-identical final state, best snapshot and
+    counters per restart, for the same seed.
+  * K-search vs exact optimum (HiGHS golden): equal objective; README KAT-1 reproduced bit-exactly
+    after the canonical tie-break; unique optima reproduced bit-exactly.
+  * size-independent properties at full BASELINE sizes: every returned assignment feasible under the
+    independent verifier, objective == verifier objective, objective <= upper bound, idempotence
+    (re-solving the solution moves nothing), drift counter == 0.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, random_candidates, to_product_topic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kao():
+    import kafka_assignment_optimizer_amd as k
+    k.init(0)
+    assert "gfx950" in k.device_name(), k.device_name()
+    return k
+
+
+# ------------------------------------------------------------------------------- K-eval
+def test_eval_golden_vectors(kao, ko):
+    g = load_golden("kat1.json")
+    ot = ko.topic_from_dict(g["topic"])
+    pt = to_product_topic(ot)
+    cands = np.array([e["assignment"] for e in g["eval_vectors"]], dtype=np.uint16)
+    obj, viol = kao.evaluate_batch(pt, cands)
+    assert obj.tolist() == [e["objective"] for e in g["eval_vectors"]]
+    assert viol.tolist() == [e["viol"] for e in g["eval_vectors"]]
+    o1, v1 = kao.evaluate(pt, np.array(g["expected_assignment"], dtype=np.uint16))
+    assert (o1, v1.tolist()) == (58, [0] * 8)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_eval_random_candidates_match_oracle(kao, ko, kp, cfg):
+    ot = ko.gen_config(cfg, n_topics=1).topics[0]
+    pt = to_product_topic(ot)
+    n = 200 if cfg != 2 else 96
+    cands = random_candidates(ot, n, seed=100 + cfg)
+    obj, viol = kao.evaluate_batch(pt, cands)
+    for i in range(n):
+        o, v = kp.port_eval(ot, cands[i])
+        assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist()), (cfg, i)
+    for i in range(0, n, 17):  # and the numpy restatement on a subset
+        o, v = ko.verify(ot, cands[i])
+        assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist())
+
+
+def test_eval_edge_cases(kao, ko, kp):
+    # RF change, single rack, RF 1, RF 4, ragged sizes (P not a multiple of 64, B < 64 and > 64)
+    seeds = [s for s in range(60) if ko.random_case(s).rf <= 4 and ko.random_case(s).rf_cur <= 4][:30]
+    for s in seeds:
+        ot = ko.random_case(s, max_b=14, max_p=10)
+        pt = to_product_topic(ot)
+        cands = random_candidates(ot, 9, seed=s, p_mut=0.3, p_none=0.1)
+        obj, viol = kao.evaluate_batch(pt, cands)
+        for i in range(len(cands)):
+            o, v = kp.port_eval(ot, cands[i])
+            assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist()), (s, i)
+    c = ko.make_cluster("rf4", 70, 5, 1, 130, 4, [1, 2, 3], [(70, 0), (71, 4)])
+    ot = c.topics[0]
+    cands = random_candidates(ot, 40, seed=9)
+    cands[1][:] = 0xFFFF  # a completely empty candidate
+    obj, viol = kao.evaluate_batch(to_product_topic(ot), cands)
+    for i in range(len(cands)):
+        o, v = kp.port_eval(ot, cands[i])
+        assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist())
+    assert viol[1][1] == 130 * 4 and viol[1][2] == 130
+
+
+# ------------------------------------------------------------------------------- K-search replay
+@pytest.mark.parametrize("cfg,launches,iters", [(1, 2, 96), (2, 2, 160), (4, 3, 128), (5, 1, 200)])
+def test_search_replay_bit_exact(kao, ko, kp, cfg, launches, iters):
+    """Same seed -> the device restart and the scalar replay agree bit for bit."""
+    ots = ko.gen_config(cfg, n_topics=2).topics
+    pts = [to_product_topic(t) for t in ots]
+    seed = 0xABCDEF12345 + cfg
+    with kao.Session(pts, seed=seed, restarts=8, iters_per_launch=iters) as s:
+        s.step(launches)
+        s.sync()
+        assert s.stats()["drift"] == 0
+        for ti, ot in enumerate(ots):
+            tseed = seed ^ (((ti + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+            for rho in (0, 3, 7):
+                dev = s.restart_state(ti, rho)
+                ref = kp.port_search(ot, tseed, rho, launches, iters)
+                assert dev["final"].tolist() == ref["final"].tolist(), (cfg, ti, rho)
+                assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == \
+                       (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"]), (cfg, ti, rho)
+                if ref["best_obj"] >= 0:
+                    assert dev["best"].tolist() == ref["best"].tolist()
+
+
+def test_search_replay_random_small(kao, ko, kp):
+    cases = [c for c in load_golden("random_small.json")["cases"]][:16]
+    ots = [ko.topic_from_dict(c["topic"]) for c in cases]
+    seed = 77
+    with kao.Session([to_product_topic(t) for t in ots], seed=seed, restarts=4, iters_per_launch=300) as s:
+        s.step(2)
+        for ti, ot in enumerate(ots):
+            tseed = seed ^ (((ti + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+            for rho in range(4):
+                dev = s.restart_state(ti, rho)
+                ref = kp.port_search(ot, tseed, rho, 2, 300)
+                assert dev["final"].tolist() == ref["final"].tolist(), (ti, rho)
+                assert (dev["best_obj"], dev["V"], dev["obj"]) == (ref["best_obj"], ref["V"], ref["obj"])
+        assert s.stats()["drift"] == 0
+
+
+# ------------------------------------------------------------------------------- optimum parity
+def test_kat1_end_to_end(kao, ko):
+    """README.md:52-63 in -> README.md:88 out ([8,19] -> [8,1], nothing else moves)."""
+    import kafka_assignment_optimizer_amd as k
+    racks = {b: ("a" if b % 2 == 0 else "b") for b in range(20)}
+    topics = k.topics_from_json(ko.README_CURRENT, list(range(19)), racks)
+    res = k.solve(topics, seed=1, time_limit_s=5.0, stop_at_bound=1, restarts=64, iters_per_launch=128)
+    r = res[0]
+    assert r.status == "OPTIMAL_PROVEN" and r.objective == 58 and r.upper_bound == 58
+    canon = k.canonicalize(topics[0], r.assignment)
+    g = load_golden("kat1.json")
+    assert canon.tolist() == g["expected_assignment"]
+    assert k.assignment_to_json(topics, [canon]) == g["expected_json"]
+    assert ko.count_moves(ko.readme_example(), canon) == (1, 0)
+
+
+def test_golden_optima_random_small(kao, ko):
+    cases = [c for c in load_golden("random_small.json")["cases"]]
+    ots = [ko.topic_from_dict(c["topic"]) for c in cases]
+    pts = [to_product_topic(t) for t in ots]
+    res = kao.solve(pts, seed=5, restarts=32, iters_per_launch=512, max_launches=8, time_limit_s=30.0)
+    n_unique = 0
+    for c, ot, pt, r in zip(cases, ots, pts, res):
+        if c["status"] == "infeasible":
+            assert r.status == "NO_FEASIBLE", c["seed"]
+            continue
+        assert r.objective == c["objective"], (c["seed"], r.objective, c["objective"])
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == r.objective
+        assert r.violations.tolist() == [0] * 8 and r.objective <= r.upper_bound
+        if c.get("unique"):
+            # unique optimum: the 0/1 vector is determined -> leader and follower SET bit-exact;
+            # follower order is fixed by the canonical form
+            canon = kao.canonicalize(pt, r.assignment)
+            want = ko.canonicalize(ot, np.array(c["assignment"]))
+            assert canon.tolist() == want.tolist(), c["seed"]
+            n_unique += 1
+    assert n_unique >= 5
+
+
+@pytest.mark.parametrize("name", ["cfg2.json", "cfg3.json", "cfg4.json"])
+def test_golden_optima_configs(kao, ko, name):
+    g = load_golden(name)
+    ots = [ko.topic_from_dict(e["topic"]) for e in g["topics"]]
+    res = kao.solve([to_product_topic(t) for t in ots], seed=11, iters_per_launch=512, max_launches=12,
+                    time_limit_s=30.0)
+    for e, ot, r in zip(g["topics"], ots, res):
+        assert r.objective == e["objective"], (name, r.objective, e["objective"], r.status)
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == e["objective"]
+        assert ko.count_moves(ot, r.assignment)[0] == e["moves"][0]
+
+
+# ------------------------------------------------------------------------------- full-size properties
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_full_config_properties(kao, ko, kp, cfg):
+    case = ko.gen_config(cfg)
+    ots = case.topics
+    pts = [to_product_topic(t) for t in ots]
+    with kao.Session(pts, seed=2024, iters_per_launch=512) as s:
+        s.step(6)
+        res = s.best()
+        st = s.stats()
+    assert st["drift"] == 0 and st["launches"] == 6
+    golden = {i: e["objective"] for i, e in enumerate(load_golden(f"cfg{cfg}.json")["topics"])}
+    again = []
+    for i, (ot, r) in enumerate(zip(ots, res)):
+        obj, viol = kp.port_eval(ot, r.assignment)
+        assert viol[0] == 0, (cfg, i, viol)           # feasible under the independent verifier
+        assert obj == r.objective <= r.upper_bound    # reported objective is the true objective
+        if i in golden:
+            assert r.objective == golden[i]
+        if i < 8:  # idempotence: the solution, fed back as the current assignment, is a fixed point
+            t2 = to_product_topic(ot)
+            t2.current = r.assignment.copy()
+            again.append((t2, r))
+    res2 = kao.solve([t for t, _ in again], seed=3, iters_per_launch=256, max_launches=4, stop_at_bound=1, time_limit_s=20)
+    for (t2, r), r2 in zip(again, res2):
+        assert r2.status == "OPTIMAL_PROVEN"
+        moved = sum(len(set(a) - set(b)) for a, b in zip(r2.assignment.tolist(), r.assignment.tolist()))
+        assert moved == 0 and r2.assignment[:, 0].tolist() == r.assignment[:, 0].tolist()
+
+
+def test_config5_sample_and_caps(kao, ko, kp):
+    """cfg5 (1000 brokers, 20 racks, per-broker load caps): 64 of the 1000 topics."""
+    ots = ko.gen_config(5, n_topics=64).topics
+    assert ots[0].bounds()["rep_hi"] == 2  # cap = ceil(avg)+1
+    res = kao.solve([to_product_topic(t) for t in ots], seed=9, iters_per_launch=512, max_launches=6, time_limit_s=30)
+    for ot, r in zip(ots, res):
+        obj, viol = kp.port_eval(ot, r.assignment)
+        assert viol[0] == 0 and obj == r.objective
+    ex = ko.solve_exact(ots[0], 120)
+    assert ex.status == "optimal" and res[0].objective == ex.objective
+
+
+def test_determinism(kao, ko):
+    pts = [to_product_topic(t) for t in ko.gen_config(4, n_topics=4).topics]
+    outs = []
+    for _ in range(2):
+        with kao.Session(pts, seed=99, restarts=16, iters_per_launch=200) as s:
+            s.step(3)
+            outs.append(([r.assignment.tolist() for r in s.best()], s.best_keys().tolist()))
+    assert outs[0] == outs[1]

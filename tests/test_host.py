@@ -1,0 +1,107 @@
+"""CPU tests of the host layer: the C-ABI library loads and exports every symbol include/kao.h
+declares, the host-only helpers agree with the oracle, JSON I/O matches the reassignment format, and
+compute entry points fail loudly (no CPU fallback) when there is no GPU."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, have_gpu, to_product_topic
+
+
+def test_library_exports_every_declared_symbol():
+    from kafka_assignment_optimizer_amd import _ffi
+    header = open(os.path.join(ROOT, "include", "kao.h")).read()
+    declared = set(re.findall(r"\b(kao_[a-z_]+)\s*\(", header))
+    declared -= {"kao_init(device", "kao_strerror"} - {"kao_strerror"}
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    lib = _ffi.load()  # raises if the .so is missing or lacks a symbol
+    assert lib.kao_version() == 100
+    assert lib.kao_strerror(-3).decode().startswith("no usable HIP device")
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    from kafka_assignment_optimizer_amd import _ffi
+    assert C.sizeof(_ffi.KaoTopic) == 5 * 4 + 4 + 2 * 8 + 16 + 8 * 4  # 5 ints, pad, 2 pointers, w[2][2], 8 bounds
+    assert C.sizeof(_ffi.KaoOpts) == 8 + 8 + 9 * 4 + 4
+    assert C.sizeof(_ffi.KaoResult) == 4 + 4 + 8 + 8 + 32 + 8 + 8
+    assert C.sizeof(_ffi.KaoStats) == 3 * 8 + 2 * 8 + 2 * 8 + 4 * 4
+
+
+def test_host_helpers_match_oracle(ko):
+    import kafka_assignment_optimizer_amd as kao
+    cases = [ko.readme_example(), ko.gen_config(2).topics[0], ko.gen_config(3, n_topics=1).topics[0],
+             ko.gen_config(5, n_topics=1).topics[0]] + [ko.random_case(s) for s in range(12)]
+    for ot in cases:
+        if ot.rf > 4 or ot.rf_cur > 4:
+            continue
+        pt = to_product_topic(ot)
+        assert kao.derive_bounds(pt) == ot.bounds()
+        assert kao.upper_bound(pt) == ko.upper_bound_simple(ot)
+
+
+def test_validation_errors(ko):
+    import kafka_assignment_optimizer_amd as kao
+    pt = to_product_topic(ko.readme_example())
+    pt.rf = 5
+    with pytest.raises(kao.KaoError) as e:
+        kao.derive_bounds(pt)
+    assert e.value.code == -2  # KAO_ERR_UNSUPPORTED
+    pt = to_product_topic(ko.readme_example())
+    pt.rack_of = pt.rack_of.copy()
+    pt.rack_of[3] = 9
+    with pytest.raises(kao.KaoError) as e:
+        kao.upper_bound(pt)
+    assert e.value.code == -1
+
+
+def test_json_roundtrip_readme():
+    """README.md:52-63 in, README.md:67-78-shaped JSON out."""
+    import kafka_assignment_optimizer_amd as kao
+    cur = {"version": 1, "partitions": [
+        {"topic": "x.y.z.t", "partition": 1, "replicas": [8, 19]},
+        {"topic": "x.y.z.t", "partition": 0, "replicas": [7, 18]},
+        {"topic": "a", "partition": 0, "replicas": [1, 2]}]}
+    racks = {str(b): ("a" if b % 2 == 0 else "b") for b in range(20)}
+    topics = kao.topics_from_json(cur, list(range(19)), racks)
+    assert [t.name for t in topics] == ["a", "x.y.z.t"]
+    t = topics[1]
+    assert t.current.tolist() == [[7, 18], [8, 0xFFFF]]  # broker 19 is not in the target list
+    assert t.rack_of.tolist() == [b % 2 for b in range(19)]
+    out = kao.assignment_to_json(topics, [np.array([[1, 2]]), np.array([[7, 18], [8, 1]])])
+    assert out == {"version": 1, "partitions": [
+        {"topic": "a", "partition": 0, "replicas": [1, 2]},
+        {"topic": "x.y.z.t", "partition": 0, "replicas": [7, 18]},
+        {"topic": "x.y.z.t", "partition": 1, "replicas": [8, 1]}]}
+    json.dumps(out)
+    with pytest.raises(ValueError):
+        kao.topics_from_json(cur, [0, 1, 1], racks)
+
+
+@pytest.mark.skipif(have_gpu(), reason="checks the no-device failure mode")
+def test_compute_fails_loudly_without_gpu(ko):
+    """The product has no CPU fallback: without a device every compute call raises."""
+    import kafka_assignment_optimizer_amd as kao
+    pt = to_product_topic(ko.readme_example())
+    with pytest.raises(kao.KaoError) as e:
+        kao.evaluate(pt, pt.current)
+    assert e.value.code == -3
+    with pytest.raises(kao.KaoError):
+        kao.solve([pt], max_launches=1)
+    with pytest.raises(kao.KaoError):
+        kao.Session([pt])
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under the package may reference it."""
+    pkg = os.path.join(ROOT, "kafka_assignment_optimizer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"import\s+kao_(oracle|port)", r"from\s+(oracle|kao_oracle|kao_port)\b", r"libkao_port",
+                            r"#include\s+[\"<][^\n]*oracle", r"sys\.path[^\n]*oracle", r"dlopen[^\n]*oracle"):
+                    assert not re.search(pat, src), (f, pat)

@@ -1,0 +1,147 @@
+"""CPU tests of the oracle itself (no GPU): the restatement is pinned against the README worked
+example (KAT-1, the only result the reference pins) and cross-checked three ways -- HiGHS on the
+materialised model, HiGHS on the emitted lp_solve text, brute force on tiny instances -- and the C
+port is checked against the numpy verifier and against the exact optimum."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, random_candidates
+
+
+def test_kat1_readme_example(ko):
+    """README.md:52-63 -> README.md:85-91: only partition 1 changes, [8,19] -> [8,1]."""
+    t = ko.readme_example()
+    assert (t.n_brokers, t.n_racks, t.n_partitions, t.rf) == (19, 2, 10, 2)
+    bd = t.bounds()
+    assert (bd["rep_lo"], bd["rep_hi"]) == (1, 2)      # README.md:159-160
+    assert (bd["lead_lo"], bd["lead_hi"]) == (0, 1)    # README.md:164-165
+    assert (bd["rack_lo"], bd["rack_hi"]) == (10, 10)  # README.md:174-175
+    assert bd["prack_hi"] == 1                         # README.md:179
+    ex = ko.solve_exact(t)
+    assert ex.status == "optimal" and ex.objective == 58
+    assert ko.count_moves(t, ex.assign) == (1, 0)
+    canon = ko.canonicalize(t, ex.assign)
+    doc = ko.assignment_to_json([t], [canon])
+    want = {p["partition"]: p["replicas"] for p in ko.README_CURRENT["partitions"]}
+    want[1] = [8, 1]  # README.md:88
+    assert {p["partition"]: p["replicas"] for p in doc["partitions"]} == want
+    g = load_golden("kat1.json")
+    assert g["objective"] == 58 and g["expected_assignment"] == canon.tolist()
+
+
+def test_kat1_alt_weights_and_cooptimal(ko):
+    t = ko.readme_example()
+    t.weights = ((4, 2), (2, 1))
+    assert ko.solve_exact(t).objective == 49
+    t = ko.readme_example()
+    # forcing p1's follower onto each broker: optimal exactly for the odd brokers 1..17 (9 co-optima)
+    good = []
+    for b in range(19):
+        a = np.array(t.current, dtype=np.int64)
+        a[1, 1] = b
+        obj, viol = ko.verify(t, a)
+        if viol[0] == 0 and obj == 58:
+            good.append(b)
+    assert good == [1, 3, 5, 7, 9, 11, 13, 15, 17]
+
+
+def test_kafka_tool_proposal_is_worse(ko):
+    """README.md:67-78: kafka-reassign-partitions' own proposal moves 20/20 replicas, 10/10 leaders
+    and puts partition 2 ([16,0]) in a single AZ."""
+    t = ko.readme_example()
+    prop = [[14, 17], [15, 18], [16, 0], [17, 1], [18, 2], [0, 3], [1, 4], [2, 5], [3, 6], [4, 7]]
+    a = np.array(prop)
+    assert ko.count_moves(t, a) == (20, 10)
+    obj, viol = ko.verify(t, a)
+    assert obj == 0 and viol[7] > 0  # C7: two replicas of p2 in rack a, none in b
+
+
+def test_lp_text_roundtrip(ko):
+    """The emitted lp_solve LP text (README.md:144-185) encodes the same model."""
+    t = ko.readme_example()
+    txt = ko.write_lp(t)
+    assert txt.startswith("// Optimization function") and "\nbin\n" in txt
+    first_bin = txt.split("\nbin\n")[1].split(",")[:4]
+    assert [s.strip() for s in first_bin] == ["t1b0p0", "t1b0p0_l", "t1b0p1", "t1b0p1_l"]  # README.md:184 order
+    status, obj, vals = ko.solve_lp_text(txt)
+    assert status == "optimal" and obj == 58
+    assert vals["t1b8p1_l"] == 1 and vals["t1b7p0_l"] == 1 and vals["t1b18p0"] == 1
+    assert sum(vals.values()) == 20
+    rows = ko.build_rows(t)
+    assert len(rows) == 2 * 10 + 2 * 19 + 19 * 10 + 2 + 10 * 2  # ranged-row count
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bruteforce_matches_highs(ko, seed):
+    t = ko.random_case(500 + seed, max_b=5, max_p=3)
+    if t.n_brokers > 6 or t.n_partitions > 3:
+        pytest.skip("too large for brute force")
+    best, _ = ko.brute_force(t)
+    ex = ko.solve_exact(t)
+    if best is None:
+        assert ex.status == "infeasible"
+    else:
+        assert ex.status == "optimal" and ex.objective == best
+
+
+def test_port_eval_matches_verifier(ko, kp):
+    for t in [ko.readme_example(), ko.gen_config(2).topics[0], ko.gen_config(4, n_topics=1).topics[0],
+              ko.random_case(3), ko.random_case(11)]:
+        for a in random_candidates(t, 12, 5):
+            o1, v1 = ko.verify(t, a)
+            o2, v2 = kp.port_eval(t, a)
+            assert o1 == o2 and v1.tolist() == v2.tolist()
+
+
+def test_golden_eval_vectors(ko, kp):
+    g = load_golden("kat1.json")
+    t = ko.topic_from_dict(g["topic"])
+    for e in g["eval_vectors"]:
+        a = np.array(e["assignment"], dtype=np.uint16)
+        o, v = kp.port_eval(t, a)
+        assert o == e["objective"] and v.tolist() == e["viol"]
+        o, v = ko.verify(t, a)
+        assert o == e["objective"] and v.tolist() == e["viol"]
+
+
+def test_port_search_reaches_golden_optimum(ko, kp):
+    """The scalar replay of the device search finds the exact optimum on the golden instances."""
+    cases = load_golden("random_small.json")["cases"]
+    n = 0
+    for c in cases:
+        if c["status"] != "optimal":
+            continue
+        t = ko.topic_from_dict(c["topic"])
+        best = max(kp.port_search(t, 7, rho, 1, 2048)["best_obj"] for rho in range(8))
+        assert best == c["objective"], c["seed"]
+        n += 1
+    assert n >= 25
+    for name in ("cfg3.json", "cfg4.json"):
+        e = load_golden(name)["topics"][0]
+        t = ko.topic_from_dict(e["topic"])
+        best = max(kp.port_search(t, 3, rho, 2, 1024)["best_obj"] for rho in range(4))
+        assert best == e["objective"]
+
+
+def test_port_search_deterministic_and_sound(ko, kp):
+    t = ko.gen_config(4, n_topics=1).topics[0]
+    r1 = kp.port_search(t, 42, 5, 3, 200)
+    r2 = kp.port_search(t, 42, 5, 3, 200)
+    assert r1["final"].tolist() == r2["final"].tolist() and r1["best_obj"] == r2["best_obj"]
+    r3 = kp.port_search(t, 43, 5, 3, 200)
+    assert r3["final"].tolist() != r1["final"].tolist()
+    obj, viol = ko.verify(t, r1["final"])
+    assert (obj, int(viol[0])) == (r1["obj"], r1["V"])  # incremental bookkeeping == full evaluation
+    if r1["best_obj"] >= 0:
+        obj, viol = ko.verify(t, r1["best"])
+        assert viol[0] == 0 and obj == r1["best_obj"]
+
+
+def test_infeasible_instance_detected(ko, kp):
+    """rigid floor/ceil bands can be jointly infeasible; the exact oracle says so and
+    the search reports no feasible state."""
+    c = ko.make_cluster("h5", 100, 4, 1, 64, 3, [3, 17, 42, 77, 99], [])
+    t = c.topics[0]
+    assert ko.solve_exact(t, 60).status == "infeasible"
+    r = kp.port_search(t, 1, 0, 1, 2000)
+    assert r["best_obj"] == -1
