@@ -57,7 +57,7 @@ def cpu_baseline(topics, restarts, iters, budget_s=15.0):
     ex = ko.solve_exact(ots[0], 120)
     exact_s = time.perf_counter() - te
     return {"value": n_eval / dt, "unit": "candidates/s", "cores": 1, "kind": "port",
-            "sample": f"{done_topics} of {len(ots)} topics x {restarts} restarts x {iters} iterations x 64 neighbours, "
+            "sample": f"{done_topics} of {len(ots)} topics x {restarts} restarts x {iters} iterations, "
                       f"oracle/kao_port.c scalar replay of the same search, {dt:.1f} s",
             "exact_solver": "HiGHS (scipy.optimize.milp) on the README model; lp_solve 5.5 not installed",
             "exact_seconds_per_topic": exact_s, "exact_objective_topic0": ex.objective}
@@ -187,7 +187,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": synthetic.WORKLOADS[args.config], "topics_total": n_topics,
                    "topics_per_rank": [len(s) for s in shards], "restarts_per_topic_rank0": st1["n_restarts_total"] // max(1, len(topics)),
-                   "iters_per_launch": args.iters, "neighbours_per_iteration": 64,
+                   "iters_per_launch": args.iters,
+                   "neighbours_per_iteration": "64 lanes x (4 REPLACE | 1 EXCHANGE | rf-1 LEADER-SWAP), pattern RRXRLRXR",
                    "parallelism": f"topic-sharded x{world}" if world > 1 else "single GPU"},
         "delta_candidates_per_s": tot_delta / dt_max,
         "full_candidates_per_s": tot_full / dt_max,

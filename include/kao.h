@@ -95,7 +95,8 @@ typedef struct kao_result {
 
 typedef struct kao_stats {
     uint64_t launches;          /* K-search launches */
-    uint64_t delta_candidates;  /* neighbours delta-evaluated by K-search (64 per iteration per restart) */
+    uint64_t delta_candidates;  /* neighbours delta-evaluated by K-search: per iteration per restart 64 lanes x
+                                   (4 REPLACE | 1 EXCHANGE | rf-1 LEADER-SWAP candidates) */
     uint64_t full_candidates;   /* complete candidates fully evaluated by K-eval */
     double ms_search;           /* HIP-event time of K-search launches (profile=1) */
     double ms_eval;             /* HIP-event time of K-eval launches (profile=1) */

@@ -153,6 +153,17 @@ int64_t upper_bound(const kao_topic *t) {
     return total;
 }
 
+// Neighbours delta-evaluated by ONE restart over iterations [it0, it0+iters): per iteration 64 lanes x
+// (4 REPLACE candidates | 1 EXCHANGE | RF-1 LEADER-SWAPs), move pattern R R X R L R X R (kao_kernels.hip).
+uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf) {
+    static const uint8_t pat[8] = {0, 0, 1, 0, 2, 0, 1, 0};
+    const uint64_t per_type[3] = {64ull * 4, 64ull, 64ull * (uint64_t)(rf > 1 ? rf - 1 : 0)};
+    const uint64_t per8 = 5 * per_type[0] + 2 * per_type[1] + per_type[2];
+    uint64_t n = (uint64_t)(iters / 8) * per8;
+    for (uint32_t i = (iters / 8) * 8; i < iters; ++i) n += per_type[pat[(it0 + i) & 7]];
+    return n;
+}
+
 template <typename T>
 int dev_alloc_copy(T **dst, const std::vector<T> &src) {
     *dst = nullptr;
@@ -236,7 +247,8 @@ struct kao_session {
     std::vector<hipEvent_t> ev;  // triples
     int ev_pending = 0;
     double ms_search = 0, ms_eval = 0;
-    uint64_t search_bytes_per_launch = 0, eval_bytes_per_launch = 0;
+    uint64_t eval_bytes_per_launch = 0;
+    uint64_t delta_total = 0, search_bytes_total = 0;
 };
 
 namespace {
@@ -567,7 +579,6 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         curd_pool.insert(curd_pool.end(), pt.cur_dense.begin(), pt.cur_dense.end());
         s->maxP = std::max(s->maxP, d.P); s->maxBx = std::max(s->maxBx, d.Bx); s->maxB = std::max(s->maxB, d.B);
         // algorithmic bytes: delta = 8*RF+10 per neighbour; full = 2*RF*P + 2*rf_cur*P + B per candidate
-        s->search_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)o.iters_per_launch * 64ull * (uint64_t)(8 * d.RF + 10);
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
     }
     s->total_restarts = restart_base;
@@ -645,6 +656,11 @@ int kao_session_step(kao_session *s) {
     launch_eval(ep, s->blocks_eval, s->stream);
     HIP_TRY(hipGetLastError());
     if (prof) { HIP_TRY(hipEventRecord(e[2], s->stream)); s->ev_pending++; }
+    for (const PreparedTopic &pt : s->pts) {
+        const uint64_t n = neighbours_in_range(prm.launch * prm.iters, prm.iters, pt.d.RF) * (uint64_t)pt.d.n_restarts;
+        s->delta_total += n;
+        s->search_bytes_total += n * (uint64_t)(8 * pt.d.RF + 10);
+    }
     s->launch++;
     return KAO_OK;
 }
@@ -697,10 +713,10 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     if (rc) return rc;
     std::memset(out, 0, sizeof *out);
     out->launches = s->launch;
-    out->delta_candidates = (uint64_t)s->launch * (uint64_t)s->total_restarts * (uint64_t)s->opts.iters_per_launch * 64ull;
+    out->delta_candidates = s->delta_total;
     out->full_candidates = (uint64_t)s->launch * (uint64_t)s->total_restarts;
     out->ms_search = s->ms_search; out->ms_eval = s->ms_eval;
-    out->search_bytes_algo = s->search_bytes_per_launch * s->launch;
+    out->search_bytes_algo = s->search_bytes_total;
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
     out->lds_bytes_search = (int32_t)search_lds_bytes(s->maxP, s->maxBx);

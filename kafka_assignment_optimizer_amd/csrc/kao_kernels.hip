@@ -60,8 +60,26 @@ __device__ __forceinline__ int wave_sum(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
+// slot k of a partition, as two independent selects (keeps the compiler from building a switch)
 __device__ __forceinline__ uint32_t sel4(const uint4 &a, int k) {
-    return k == 0 ? a.x : (k == 1 ? a.y : (k == 2 ? a.z : a.w));
+    const uint32_t lo = (k & 2) ? a.z : a.x;
+    const uint32_t hi = (k & 2) ? a.w : a.y;
+    return (k & 1) ? hi : lo;
+}
+// per-lane LCG modulo 2^24: one v_mad_u32_u24 (only the low 24 bits of the state are ever read)
+__device__ __forceinline__ uint32_t lcg24(uint32_t &s) {
+    s = __umul24(s, 0x6D2B79u) + 0x3C6EF3u;
+    return s;
+}
+// uniform-ish draw on [0, n) from the high bits of a 24x24-bit product: one v_mul_hi_u32_u24.  n8 = n << 8.
+__device__ __forceinline__ uint32_t rnd24(uint32_t &s, uint32_t n8) {
+    const uint32_t v = lcg24(s);
+    return (uint32_t)(((unsigned long long)(v & 0xFFFFFFu) * (unsigned long long)(n8 & 0xFFFFFFu)) >> 32);
+}
+__device__ __forceinline__ uint32_t make_key(int lam, int S, int dV, int dObj, int lane) {
+    int delta = __mul24(lam, dV) - __mul24(S, dObj);
+    delta = min(max(delta, -kDBias), kDBias - 2);
+    return ((uint32_t)(delta + kDBias) << 8) | (uint32_t)lane;
 }
 __device__ __forceinline__ bool in4(const uint4 &a, uint32_t w) {
     return (a.x == w) | (a.y == w) | (a.z == w) | (a.w == w);
@@ -79,10 +97,11 @@ struct TopicRegs {  // wave-uniform copy of the fields the inner loop needs
 };
 
 // objective weight of broker word w on a partition whose current replicas are c, in new role nr
-__device__ __forceinline__ int role_w(const TopicRegs &T, const uint4 &c, uint32_t w, int nr) {
-    const int wl = nr ? T.w01 : T.w00;
-    const int wf = nr ? T.w11 : T.w10;
+__device__ __forceinline__ int role_w2(const uint4 &c, uint32_t w, int wl, int wf) {
     return (c.x == w) ? wl : (((c.y == w) | (c.z == w) | (c.w == w)) ? wf : 0);
+}
+__device__ __forceinline__ int role_w(const TopicRegs &T, const uint4 &c, uint32_t w, int nr) {
+    return role_w2(c, w, nr ? T.w01 : T.w00, nr ? T.w11 : T.w10);
 }
 // internal index -> LDS word (x | rack << 16); 0xFFFF -> empty
 __device__ __forceinline__ uint32_t to_word(const TopicRegs &T, uint32_t x) {
@@ -277,13 +296,13 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     full_cost(T, L, CUR, RSZ, lane, V, obj);
     if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
 
-    // ---- per-lane RNG stream of this launch ----
+    // ---- per-lane RNG stream of this launch (LCG mod 2^24, re-keyed every launch) ----
     uint32_t rng = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + prm.launch * 0x85EBCA77u + (uint32_t)lane * 0xC2B2AE3Du));
-    if (rng == 0) rng = 0x6D2B79F5u;
 
     const int plog = prm.period_log2 + (rho & 3);
     const uint32_t pmask = (1u << plog) - 1u;
     const uint32_t lrange = (uint32_t)(prm.lam_max - prm.lam_min + 1);
+    const uint32_t P8 = (uint32_t)T.P << 8, RF8 = (uint32_t)T.RF << 8, R8 = (uint32_t)T.R << 8, m8 = (uint32_t)T.m << 8;
 
     for (uint32_t i = 0; i < prm.iters; ++i) {
         const uint32_t it = prm.launch * prm.iters + i;
@@ -291,42 +310,62 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         const uint32_t ph = it & pmask;
         const int lam = min(prm.lam_max, prm.lam_min + (int)((2u * ph * lrange) >> plog));
 
-        const uint32_t r1 = xs32(rng), r2 = xs32(rng), r3 = xs32(rng);
-        const int p = (int)mulhi(r1, (uint32_t)T.P);
+        const int p = (int)rnd24(rng, P8);
         const uint4 a = L.A[p];
         const uint4 c = CUR[p];
-        bool ok;
-        int dV = 0, dObj = 0;
-        // proposal registers (meaning depends on the move type)
-        int k = 0, q = 0, j = 0;
+        // this lane's best proposal of the iteration
+        uint32_t key = kKeyNull;
+        int dV = 0, dObj = 0, k = 0, q = 0, j = 0;
         uint32_t uw = 0, vw = 0;
 
-        if (type == 0) {  // REPLACE (p,k) <- x
-            k = (int)(((r1 & 0xFFFFu) * (uint32_t)T.RF) >> 16);
-            const uint32_t x = mulhi(r2, (uint32_t)T.Bx);
-            const uint32_t rn = mulhi(x, T.magic);
-            vw = x | (rn << 16);
-            ok = ((int)(x - rn * T.m) < RSZ[rn]) && !in4(a, vw);
+        if (type == 0) {  // REPLACE (p,k) <- x_g: 2 candidates of any rack, 2 of the old broker's rack
+            k = (int)rnd24(rng, RF8);
             uw = sel4(a, k);
             const uint32_t ro = uw >> 16;
-            const int nr = k != 0;
-            dObj = role_w(T, c, vw, nr) - role_w(T, c, uw, nr);
-            const uint32_t co = L.C[uw & 0xFFFFu], cn = L.C[x];
-            dV = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi);
-            if (k == 0) dV += ddec((int)(co >> 16), T.lead_lo, T.lead_hi) + dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
-            if (ro != rn) {
-                dV += ddec(L.K[ro], T.rack_lo, T.rack_hi) + dinc(L.K[rn], T.rack_lo, T.rack_hi);
-                dV += ddec(cnt4(a, ro), T.prack_lo, T.prack_hi) + dinc(cnt4(a, rn), T.prack_lo, T.prack_hi);
+            const bool lead = k == 0;
+            const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
+            const int g_old = role_w2(c, uw, wl, wf);
+            const uint32_t co = L.C[uw & 0xFFFFu];
+            int dV_old = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
+            if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+            const int dV_rack_old = ddec(L.K[ro], T.rack_lo, T.rack_hi) + ddec(cnt4(a, ro), T.prack_lo, T.prack_hi);
+            const int rsz_ro = RSZ[ro];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t r, jj;
+                bool okg;
+                if (g < 2) {
+                    r = rnd24(rng, R8);
+                    jj = rnd24(rng, m8);
+                    okg = (int)jj < RSZ[r];
+                } else {
+                    r = ro;
+                    jj = rnd24(rng, (uint32_t)rsz_ro << 8);
+                    okg = true;
+                }
+                const uint32_t x = __umul24(r, (uint32_t)T.m) + jj;
+                const uint32_t xw = x | (r << 16);
+                okg = okg && !in4(a, xw);
+                const uint32_t cn = L.C[x];
+                int dVg = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi);
+                if (lead) dVg += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+                if (g < 2) {
+                    if (r != ro)
+                        dVg += dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
+                }
+                const int dObjg = role_w2(c, xw, wl, wf) - g_old;
+                const uint32_t keyg = okg ? make_key(lam, S, dVg, dObjg, lane) : kKeyNull;
+                if (keyg < key) { key = keyg; vw = xw; dV = dVg; dObj = dObjg; }
             }
         } else if (type == 1) {  // EXCHANGE (p,k) <-> (q,j)
-            k = (int)(((r1 & 0xFFFFu) * (uint32_t)T.RF) >> 16);
-            q = (int)mulhi(r2, (uint32_t)T.P);
-            j = (int)(((r2 & 0xFFFFu) * (uint32_t)T.RF) >> 16);
+            k = (int)rnd24(rng, RF8);
+            q = (int)rnd24(rng, P8);
+            j = (int)rnd24(rng, RF8);
             const uint4 b = L.A[q];
             const uint4 cb = CUR[q];
             uw = sel4(a, k);
             vw = sel4(b, j);
-            ok = (p != q) && (uw != vw) && !in4(a, vw) && !in4(b, uw);
+            const bool ok = (p != q) && (uw != vw) && !in4(a, vw) && !in4(b, uw);
             const int nrp = k != 0, nrq = j != 0;
             dObj = role_w(T, c, vw, nrp) + role_w(T, cb, uw, nrq) - role_w(T, c, uw, nrp) - role_w(T, cb, vw, nrq);
             if ((k == 0) != (j == 0)) {
@@ -339,24 +378,25 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 dV += ddec(cnt4(a, ru), T.prack_lo, T.prack_hi) + dinc(cnt4(a, rv), T.prack_lo, T.prack_hi) +
                       ddec(cnt4(b, rv), T.prack_lo, T.prack_hi) + dinc(cnt4(b, ru), T.prack_lo, T.prack_hi);
             }
-        } else {  // LEADER SWAP inside p: slot 0 <-> slot k
-            ok = T.RF >= 2;
-            k = 1 + (int)(((r1 & 0xFFFFu) * (uint32_t)(T.RF - 1)) >> 16);
+            key = ok ? make_key(lam, S, dV, dObj, lane) : kKeyNull;
+        } else {  // LEADER SWAP inside p: slot 0 <-> slot k, every k = 1..RF-1 is a candidate
             uw = a.x;
-            vw = sel4(a, k);
-            dObj = role_w(T, c, vw, 0) + role_w(T, c, uw, 1) - role_w(T, c, uw, 0) - role_w(T, c, vw, 1);
-            if (ok)
-                dV = ddec((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi) +
-                     dinc((int)(L.C[vw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+            const int u_lead = role_w2(c, uw, T.w00, T.w10), u_fol = role_w2(c, uw, T.w01, T.w11);
+            const int dV_u = ddec((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+#pragma unroll
+            for (int kk = 1; kk < kRFP; ++kk) {
+                if (kk >= T.RF) break;
+                const uint32_t xw = kk == 1 ? a.y : (kk == 2 ? a.z : a.w);
+                const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11);
+                const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+                const uint32_t keyg = make_key(lam, S, dVg, dObjg, lane);
+                if (keyg < key) { key = keyg; vw = xw; k = kk; dV = dVg; dObj = dObjg; }
+            }
         }
 
-        int delta = lam * dV - S * dObj;
-        delta = max(delta, -kDBias);
-        delta = min(delta, kDBias - 2);
-        const uint32_t key = ok ? (((uint32_t)(delta + kDBias) << 16) | ((r3 >> 22) << 6) | (uint32_t)lane) : kKeyNull;
-        const uint32_t kmin = wave_umin(key);  // wavefront min-scan: best of the 64 proposals
+        const uint32_t kmin = wave_umin(key);  // wavefront min-scan: best of all lanes' proposals
         if (kmin == kKeyNull) continue;
-        if ((int)(kmin >> 16) - kDBias > 0) continue;  // accept only non-worsening moves (cost under current lam)
+        if ((int)(kmin >> 8) - kDBias > 0) continue;  // accept only non-worsening moves (cost under current lam)
         const int win = (int)(kmin & 63u);
 
         if (lane == win) {  // the winning lane applies its own proposal

@@ -273,69 +273,93 @@ static inline int move_type(uint32_t it) {
     return pat[it & 7];
 }
 
-/* one lane's proposal and its delta; returns 0 for a null proposal */
-static int ls_propose(const ls_topic *t, const ls_state *s, int type, uint32_t r1, uint32_t r2, proposal *o) {
+/* per-lane LCG modulo 2^24 (one v_mad_u32_u24 on the GPU) and range reduction by the high bits of
+ * a 24x24-bit product (one v_mul_hi_u32_u24): rnd(n) is uniform-ish on [0, n), n < 65536 */
+static inline uint32_t lcg24(uint32_t *s) { *s = (*s & 0xFFFFFFu) * 0x6D2B79u + 0x3C6EF3u; return *s; }
+static inline uint32_t rnd24(uint32_t *s, uint32_t n) {
+    const uint32_t v = lcg24(s);
+    return (uint32_t)(((uint64_t)(v & 0xFFFFFFu) * (uint64_t)((n << 8) & 0xFFFFFFu)) >> 32);
+}
+#define REPL_G 4 /* candidate brokers per lane in a REPLACE iteration: 2 of any rack, 2 of the old broker's rack */
+
+static inline uint32_t make_key(int lam, int S, int dV, int dObj, uint32_t lane) {
+    int delta = lam * dV - S * dObj;
+    if (delta < -DBIAS) delta = -DBIAS;
+    if (delta > DBIAS - 2) delta = DBIAS - 2;
+    return ((uint32_t)(delta + DBIAS) << 8) | lane;
+}
+
+/* One lane's proposals of one iteration: draws from the lane's stream, delta-evaluates every candidate
+ * against the current state and returns the lane's smallest key (KEY_NULL if none is valid), with the
+ * matching proposal in *o.  Ties inside a lane go to the earlier candidate. */
+static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t *rng, int lam, int S, uint32_t lane,
+                        proposal *o, uint64_t *n_eval) {
     const int P = t->P, RF = t->RF;
-    o->type = type;
-    int p = (int)mulhi(r1, (uint32_t)P);
+    uint32_t best = KEY_NULL;
+    const int p = (int)rnd24(rng, (uint32_t)P);
     const uint16_t *a = s->A + p * RFP;
-    o->p = p;
-    if (type == 0) { /* replace (p,k) by x */
-        int k = (int)(((r1 & 0xFFFFu) * (uint32_t)RF) >> 16);
-        unsigned x = mulhi(r2, (uint32_t)t->Bx);
-        o->k = k; o->x = x;
-        if (!valid_x(t, x) || in_part(a, x)) return 0;
-        unsigned old = a[k];
-        int nr = k == 0 ? 0 : 1;
-        int dObj = role_w(t, p, x, nr) - role_w(t, p, old, nr);
-        uint32_t co = s->C[old], cn = s->C[x];
-        int dV = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi) + d_band((int)(cn & 0xFFFF), +1, t->rep_lo, t->rep_hi);
-        if (k == 0)
-            dV += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
-        int ro = rack_of_x(t, old), rn = rack_of_x(t, x);
-        if (ro != rn) {
-            dV += d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(s->K[rn], +1, t->rack_lo, t->rack_hi);
-            dV += d_band(rack_count(t, a, ro), -1, t->prack_lo, t->prack_hi)
-                + d_band(rack_count(t, a, rn), +1, t->prack_lo, t->prack_hi);
+    if (type == 0) { /* REPLACE (p,k) <- x_g, g = 0..3 */
+        const int k = (int)rnd24(rng, (uint32_t)RF);
+        const unsigned old = a[k];
+        const int nr = k == 0 ? 0 : 1;
+        const int ro = rack_of_x(t, old);
+        const int g_old = role_w(t, p, old, nr);
+        const uint32_t co = s->C[old];
+        int dV_old = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
+        if (k == 0) dV_old += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
+        const int dV_rack_old = d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, ro), -1, t->prack_lo, t->prack_hi);
+        for (int g = 0; g < REPL_G; ++g) {
+            int r, j;
+            if (g < 2) { r = (int)rnd24(rng, (uint32_t)t->R); j = (int)rnd24(rng, (uint32_t)t->m); }
+            else { r = ro; j = (int)rnd24(rng, (uint32_t)t->rack_size[ro]); }
+            const unsigned x = (unsigned)(r * t->m + j);
+            *n_eval += 1;
+            if (j >= t->rack_size[r] || in_part(a, x)) continue;
+            const uint32_t cn = s->C[x];
+            int dV = dV_old + d_band((int)(cn & 0xFFFF), +1, t->rep_lo, t->rep_hi);
+            if (k == 0) dV += d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
+            if (r != ro)
+                dV += dV_rack_old + d_band(s->K[r], +1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, r), +1, t->prack_lo, t->prack_hi);
+            const int dObj = role_w(t, p, x, nr) - g_old;
+            const uint32_t key = make_key(lam, S, dV, dObj, lane);
+            if (key < best) { best = key; o->type = 0; o->p = p; o->k = k; o->x = x; o->dV = dV; o->dObj = dObj; }
         }
-        o->dV = dV; o->dObj = dObj;
-        return 1;
+        return best;
     }
-    if (type == 1) { /* exchange (p,k) <-> (q,j) */
-        int k = (int)(((r1 & 0xFFFFu) * (uint32_t)RF) >> 16);
-        int q = (int)mulhi(r2, (uint32_t)P);
-        int j = (int)(((r2 & 0xFFFFu) * (uint32_t)RF) >> 16);
-        o->k = k; o->q = q; o->j = j;
-        if (p == q) return 0;
+    if (type == 1) { /* EXCHANGE (p,k) <-> (q,j) */
+        const int k = (int)rnd24(rng, (uint32_t)RF);
+        const int q = (int)rnd24(rng, (uint32_t)P);
+        const int j = (int)rnd24(rng, (uint32_t)RF);
+        *n_eval += 1;
+        if (p == q) return best;
         const uint16_t *b = s->A + q * RFP;
-        unsigned u = a[k], v = b[j];
-        if (u == v || in_part(a, v) || in_part(b, u)) return 0;
-        int nrp = k == 0 ? 0 : 1, nrq = j == 0 ? 0 : 1;
-        int dObj = role_w(t, p, v, nrp) + role_w(t, q, u, nrq) - role_w(t, p, u, nrp) - role_w(t, q, v, nrq);
+        const unsigned u = a[k], v = b[j];
+        if (u == v || in_part(a, v) || in_part(b, u)) return best;
+        const int nrp = k == 0 ? 0 : 1, nrq = j == 0 ? 0 : 1;
+        const int dObj = role_w(t, p, v, nrp) + role_w(t, q, u, nrq) - role_w(t, p, u, nrp) - role_w(t, q, v, nrq);
         int dV = 0;
         if ((k == 0) != (j == 0)) {
-            unsigned lose = (k == 0) ? u : v, gain = (k == 0) ? v : u;
-            dV += d_band((int)(s->C[lose] >> 16), -1, t->lead_lo, t->lead_hi)
-                + d_band((int)(s->C[gain] >> 16), +1, t->lead_lo, t->lead_hi);
+            const unsigned lose = (k == 0) ? u : v, gain = (k == 0) ? v : u;
+            dV += d_band((int)(s->C[lose] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[gain] >> 16), +1, t->lead_lo, t->lead_hi);
         }
-        int ru = rack_of_x(t, u), rv = rack_of_x(t, v);
-        if (ru != rv) {
-            dV += d_band(rack_count(t, a, ru), -1, t->prack_lo, t->prack_hi)
-                + d_band(rack_count(t, a, rv), +1, t->prack_lo, t->prack_hi)
-                + d_band(rack_count(t, b, rv), -1, t->prack_lo, t->prack_hi)
-                + d_band(rack_count(t, b, ru), +1, t->prack_lo, t->prack_hi);
-        }
-        o->dV = dV; o->dObj = dObj;
-        return 1;
+        const int ru = rack_of_x(t, u), rv = rack_of_x(t, v);
+        if (ru != rv)
+            dV += d_band(rack_count(t, a, ru), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, a, rv), +1, t->prack_lo, t->prack_hi)
+                + d_band(rack_count(t, b, rv), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, b, ru), +1, t->prack_lo, t->prack_hi);
+        o->type = 1; o->p = p; o->k = k; o->q = q; o->j = j; o->dV = dV; o->dObj = dObj;
+        return make_key(lam, S, dV, dObj, lane);
     }
-    /* leader swap inside p: slot 0 <-> slot k (k >= 1) */
-    if (RF < 2) return 0;
-    int k = 1 + (int)(((r1 & 0xFFFFu) * (uint32_t)(RF - 1)) >> 16);
-    o->k = k;
-    unsigned u = a[0], v = a[k];
-    o->dObj = role_w(t, p, v, 0) + role_w(t, p, u, 1) - role_w(t, p, u, 0) - role_w(t, p, v, 1);
-    o->dV = d_band((int)(s->C[u] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[v] >> 16), +1, t->lead_lo, t->lead_hi);
-    return 1;
+    /* LEADER SWAP inside p: slot 0 <-> slot k, every k = 1..RF-1 is a candidate */
+    const unsigned u = a[0];
+    for (int k = 1; k < RF; ++k) {
+        const unsigned v = a[k];
+        *n_eval += 1;
+        const int dObj = role_w(t, p, v, 0) + role_w(t, p, u, 1) - role_w(t, p, u, 0) - role_w(t, p, v, 1);
+        const int dV = d_band((int)(s->C[u] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[v] >> 16), +1, t->lead_lo, t->lead_hi);
+        const uint32_t key = make_key(lam, S, dV, dObj, lane);
+        if (key < best) { best = key; o->type = 2; o->p = p; o->k = k; o->dV = dV; o->dObj = dObj; }
+    }
+    return best;
 }
 
 static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
@@ -366,10 +390,8 @@ static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
 static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho, uint32_t launch, uint32_t iters) {
     const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
     uint32_t rng[LANES];
-    for (uint32_t l = 0; l < LANES; ++l) {
-        uint32_t v = fmix32(slo ^ fmix32(shi + rho * 0x9E3779B1u + launch * 0x85EBCA77u + l * 0xC2B2AE3Du));
-        rng[l] = v ? v : 0x6D2B79F5u;
-    }
+    for (uint32_t l = 0; l < LANES; ++l)
+        rng[l] = fmix32(slo ^ fmix32(shi + rho * 0x9E3779B1u + launch * 0x85EBCA77u + l * 0xC2B2AE3Du));
     ls_recount(t, s);
     if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
     const uint32_t plog = (uint32_t)pp->period_log2 + (rho & 3u);
@@ -383,19 +405,12 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
         uint32_t best_key = KEY_NULL;
         proposal best_prop; memset(&best_prop, 0, sizeof best_prop);
         for (uint32_t l = 0; l < LANES; ++l) {
-            uint32_t r1 = xs32(&rng[l]), r2 = xs32(&rng[l]), r3 = xs32(&rng[l]);
-            proposal o;
-            if (!ls_propose(t, s, type, r1, r2, &o)) continue;
-            int delta = lam * o.dV - pp->obj_scale * o.dObj;
-            if (delta < -DBIAS) delta = -DBIAS;
-            if (delta > DBIAS - 2) delta = DBIAS - 2;
-            uint32_t key = ((uint32_t)(delta + DBIAS) << 16) | ((r3 >> 22) << 6) | l;
+            proposal o; memset(&o, 0, sizeof o);
+            const uint32_t key = ls_lane(t, s, type, &rng[l], lam, pp->obj_scale, l, &o, &s->n_eval);
             if (key < best_key) { best_key = key; best_prop = o; }
         }
-        s->n_eval += LANES;
         if (best_key == KEY_NULL) continue;
-        int delta = (int)(best_key >> 16) - DBIAS;
-        if (delta > 0) continue;
+        if ((int)(best_key >> 8) - DBIAS > 0) continue; /* accept only non-worsening moves under the current lam */
         ls_apply(t, s, &best_prop);
         s->n_accept++;
         if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }

@@ -88,17 +88,21 @@ def test_search_replay_bit_exact(kao, ko, kp, cfg, launches, iters):
     with kao.Session(pts, seed=seed, restarts=8, iters_per_launch=iters) as s:
         s.step(launches)
         s.sync()
-        assert s.stats()["drift"] == 0
+        st = s.stats()
+        assert st["drift"] == 0
+        n_eval = 0
         for ti, ot in enumerate(ots):
             tseed = seed ^ (((ti + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
             for rho in (0, 3, 7):
                 dev = s.restart_state(ti, rho)
                 ref = kp.port_search(ot, tseed, rho, launches, iters)
+                n_eval += ref["n_eval"] * 8 // 3
                 assert dev["final"].tolist() == ref["final"].tolist(), (cfg, ti, rho)
                 assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == \
                        (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"]), (cfg, ti, rho)
                 if ref["best_obj"] >= 0:
                     assert dev["best"].tolist() == ref["best"].tolist()
+        assert st["delta_candidates"] == n_eval  # the host's neighbour count is the replay's count
 
 
 def test_search_replay_random_small(kao, ko, kp):
