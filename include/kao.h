@@ -81,6 +81,9 @@ typedef struct kao_opts {
     int32_t period_log2;      /* sawtooth period = 2^(period_log2 + (restart & 3)); <= 0 = 8 */
     int32_t stop_at_bound;    /* kao_solve: 1 = stop as soon as every topic is OPTIMAL_PROVEN */
     int32_t profile;          /* 1 = bracket every kernel with HIP events (kao_session_stats) */
+    int32_t reserved;
+    const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
+                                        objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;
 
 typedef struct kao_result {
@@ -166,6 +169,10 @@ void kao_session_destroy(kao_session *s);
 
 /* Whole job: create, step until target/time limit, read back, destroy. */
 int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results);
+/* Wall-clock breakdown of this thread's last kao_solve, seconds from its entry:
+ * out[0] session ready (instance prepared + uploaded), out[1] last improving launch finished (time-to-best),
+ * out[2] results read back, out[3] returned (buffers released); out[4] = launches run. */
+int kao_last_solve_timing(double out[5]);
 
 #ifdef __cplusplus
 }

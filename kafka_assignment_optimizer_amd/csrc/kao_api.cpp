@@ -58,7 +58,7 @@ int validate(const kao_topic *t) {
     if (!t->rack_of || !t->current) return fail(KAO_ERR_INVALID, "null rack_of/current");
     for (int b = 0; b < t->n_brokers; ++b)
         if (t->rack_of[b] >= t->n_racks) return fail(KAO_ERR_INVALID, "rack_of entry >= n_racks");
-    if ((int64_t)t->n_partitions * t->rf * 4 > (int64_t)kObjCap) return fail(KAO_ERR_UNSUPPORTED, "topic too large");
+    if ((int64_t)t->n_partitions * t->rf > 32767) return fail(KAO_ERR_UNSUPPORTED, "more than 32767 replicas in one topic (16-bit packed counters)");
     return KAO_OK;
 }
 
@@ -127,27 +127,26 @@ int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
 int64_t upper_bound(const kao_topic *t) {
     // each partition keeps its best surviving replicas in their best roles; coupling rows dropped
     int64_t total = 0;
-    const int B = t->n_brokers;
+    const int B = t->n_brokers, slots = t->rf - 1;
+    const int wLL = t->w[0][0], wLF = t->w[0][1], wFL = t->w[1][0], wFF = t->w[1][1];
+    auto fol_sum = [&](int n_ff, bool old_leader) {  // best `slots` follower gains among n_ff x wFF (+ wLF)
+        int64_t v = 0;
+        int left = slots;
+        const bool lf_first = old_leader && wLF > wFF;
+        if (lf_first && left > 0 && wLF > 0) { v += wLF; --left; }
+        const int take = std::min(left, n_ff);
+        if (wFF > 0) { v += (int64_t)take * wFF; left -= take; }
+        if (old_leader && !lf_first && left > 0 && wLF > 0) v += wLF;
+        return v;
+    };
     for (int p = 0; p < t->n_partitions; ++p) {
         const uint16_t *c = t->current + (size_t)p * t->rf_cur;
         const bool lead_alive = c[0] < (unsigned)B;
         int n_fol = 0;
         for (int k = 1; k < t->rf_cur; ++k) n_fol += c[k] < (unsigned)B;
-        int64_t best = 0;
-        struct Opt { int lead_gain, fol_avail; bool old_leader_fol; };
-        std::vector<Opt> opts;
-        if (lead_alive) opts.push_back({t->w[0][0], n_fol, false});
-        if (n_fol) opts.push_back({t->w[1][0], n_fol - 1, lead_alive});
-        opts.push_back({0, n_fol, lead_alive});
-        for (const Opt &o : opts) {
-            std::vector<int> gains((size_t)o.fol_avail, t->w[1][1]);
-            if (o.old_leader_fol) gains.push_back(t->w[0][1]);
-            std::sort(gains.rbegin(), gains.rend());
-            int64_t v = o.lead_gain;
-            for (int i = 0; i < (int)gains.size() && i < t->rf - 1; ++i)
-                if (gains[i] > 0) v += gains[i];
-            best = std::max(best, v);
-        }
+        int64_t best = fol_sum(n_fol, lead_alive);                               // a new broker leads
+        if (lead_alive) best = std::max(best, wLL + fol_sum(n_fol, false));      // the current leader stays leader
+        if (n_fol) best = std::max(best, wFL + fol_sum(n_fol - 1, lead_alive));  // a current follower is promoted
         total += best;
     }
     return total;
@@ -225,22 +224,31 @@ struct kao_session {
     int total_restarts = 0;
     int maxP = 0, maxBx = 0, maxB = 0;
     int blocks_search = 0, blocks_eval = 0;
-    // device pools
+    // device memory: one read-only arena (instance tables, uploaded with ONE H2D copy) and one mutable
+    // arena (restart states, snapshots, results); the pointers below are carved from them
+    void *arena_ro = nullptr, *arena_rw = nullptr;
+    size_t arena_ro_bytes = 0, arena_rw_bytes = 0;
     TopicDev *d_topics = nullptr;
     int2 *d_smap = nullptr;
     int4 *d_emap = nullptr;
     uint2 *d_cur = nullptr;
     uint16_t *d_ext = nullptr;
     int32_t *d_rsz = nullptr;
+    uint8_t *d_rackof = nullptr;
+    uint16_t *d_curd = nullptr;
     uint2 *d_state = nullptr;
     uint16_t *d_best = nullptr;
     int32_t *d_info = nullptr;
-    int32_t *d_drift = nullptr;
-    uint8_t *d_rackof = nullptr;
-    uint16_t *d_curd = nullptr;
     int32_t *d_obj = nullptr;
     int32_t *d_viol = nullptr;
+    // read-back block (contiguous): [keys u64[T]] [drift i32 (16 B)] [win_viol i32[8T]] [win_assign u16[sum P*RF]]
+    unsigned char *d_readback = nullptr;
+    size_t readback_bytes = 0, rb_viol_off = 0, rb_assign_off = 0;
     unsigned long long *d_keys = nullptr;
+    int32_t *d_drift = nullptr;
+    int32_t *d_win_viol = nullptr;
+    uint16_t *d_win_assign = nullptr;
+    std::vector<unsigned char> h_readback;
     hipStream_t stream = nullptr;
     uint32_t launch = 0;
     // profiling
@@ -254,6 +262,56 @@ struct kao_session {
 namespace {
 
 constexpr int kEvRing = 32;
+
+// hipMalloc / hipFree cost 0.1-1 ms each; a finished session parks its arenas here for the next one
+struct Parked { void *p; size_t bytes; };
+std::vector<Parked> g_parked;
+constexpr size_t kParkMax = 4;
+
+int arena_get(size_t bytes, void **out, size_t *cap) {
+    size_t best = g_parked.size();
+    for (size_t i = 0; i < g_parked.size(); ++i)
+        if (g_parked[i].bytes >= bytes && g_parked[i].bytes <= 4 * bytes + (1u << 20) &&
+            (best == g_parked.size() || g_parked[i].bytes < g_parked[best].bytes)) best = i;
+    if (best < g_parked.size()) {
+        *out = g_parked[best].p; *cap = g_parked[best].bytes;
+        g_parked.erase(g_parked.begin() + (long)best);
+        return KAO_OK;
+    }
+    const size_t want = ((bytes + (1u << 16)) + 4095) & ~(size_t)4095;
+    HIP_TRY(hipMalloc(out, want));
+    *cap = want;
+    return KAO_OK;
+}
+void arena_put(void *p, size_t bytes) {
+    if (!p) return;
+    if (g_parked.size() >= kParkMax) {
+        size_t small = 0;
+        for (size_t i = 1; i < g_parked.size(); ++i) if (g_parked[i].bytes < g_parked[small].bytes) small = i;
+        if (g_parked[small].bytes >= bytes) { (void)hipFree(p); return; }
+        (void)hipFree(g_parked[small].p);
+        g_parked.erase(g_parked.begin() + (long)small);
+    }
+    g_parked.push_back({p, bytes});
+}
+std::vector<hipStream_t> g_streams;  // parked streams (create/destroy cost ~1 ms)
+int stream_get(hipStream_t *out) {
+    if (!g_streams.empty()) { *out = g_streams.back(); g_streams.pop_back(); return KAO_OK; }
+    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return KAO_OK;
+}
+void stream_put(hipStream_t st) {
+    if (!st) return;
+    if (g_streams.size() < 4) g_streams.push_back(st); else (void)hipStreamDestroy(st);
+}
+void arena_drop_all() {
+    for (auto &a : g_parked) (void)hipFree(a.p);
+    g_parked.clear();
+    for (hipStream_t st : g_streams) (void)hipStreamDestroy(st);
+    g_streams.clear();
+}
+thread_local double g_timing[5] = {0, 0, 0, 0, 0};
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 int session_drain_events(kao_session *s) {
     for (int i = 0; i < s->ev_pending; ++i) {
@@ -312,7 +370,10 @@ int kao_init(int device) {
     return KAO_OK;
 }
 
-void kao_shutdown(void) { g_init = false; }
+void kao_shutdown(void) {
+    if (g_init) { (void)hipSetDevice(g_device); arena_drop_all(); }
+    g_init = false;
+}
 
 int kao_device_name(char *buf, int len) {
     int rc = require_init();
@@ -416,32 +477,47 @@ void kao_eval_plan_destroy(kao_eval_plan *p) {
     delete p;
 }
 
+namespace {
+// a plan plus growable device buffers, reused across batches (kao_canonicalize issues many small ones)
+struct EvalCtx {
+    kao_eval_plan *plan = nullptr;
+    size_t per = 0, cap = 0;
+    uint16_t *d_c = nullptr; int32_t *d_o = nullptr, *d_v = nullptr;
+    ~EvalCtx() { (void)hipFree(d_c); (void)hipFree(d_o); (void)hipFree(d_v); kao_eval_plan_destroy(plan); }
+    int open(const kao_topic *t) {
+        per = (size_t)t->n_partitions * t->rf;
+        return kao_eval_plan_create(t, &plan);
+    }
+    int run(const uint16_t *candidates, int64_t n, int32_t *objective, int32_t *violations) {
+        const int64_t chunk_max = 1 << 20;
+        for (int64_t done = 0; done < n; done += chunk_max) {
+            const int64_t c = std::min(chunk_max, n - done);
+            if ((size_t)c > cap) {
+                (void)hipFree(d_c); (void)hipFree(d_o); (void)hipFree(d_v);
+                d_c = nullptr; d_o = d_v = nullptr;
+                cap = std::max<size_t>((size_t)c, std::min<size_t>(2 * cap + 64, (size_t)chunk_max));
+                if (hipMalloc(reinterpret_cast<void **>(&d_c), cap * per * 2) != hipSuccess ||
+                    hipMalloc(reinterpret_cast<void **>(&d_o), cap * 4) != hipSuccess ||
+                    hipMalloc(reinterpret_cast<void **>(&d_v), cap * 32) != hipSuccess) { cap = 0; return fail(KAO_ERR_NOMEM, "hipMalloc"); }
+            }
+            HIP_TRY(hipMemcpy(d_c, candidates + (size_t)done * per, (size_t)c * per * 2, hipMemcpyHostToDevice));
+            int rc = kao_eval_plan_run(plan, d_c, c, d_o, d_v, nullptr);
+            if (!rc) rc = kao_eval_plan_sync(plan, nullptr);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(objective + done, d_o, (size_t)c * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(violations + done * 8, d_v, (size_t)c * 32, hipMemcpyDeviceToHost));
+        }
+        return KAO_OK;
+    }
+};
+}  // namespace
+
 int kao_evaluate_batch(const kao_topic *t, const uint16_t *candidates, int64_t n, int32_t *objective, int32_t *violations) {
     if (!candidates || !objective || !violations || n < 1) return fail(KAO_ERR_INVALID, "null buffers");
-    kao_eval_plan *p = nullptr;
-    int rc = kao_eval_plan_create(t, &p);
+    EvalCtx ctx;
+    int rc = ctx.open(t);
     if (rc) return rc;
-    const size_t per = (size_t)t->n_partitions * t->rf;
-    uint16_t *d_c = nullptr; int32_t *d_o = nullptr, *d_v = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_c); (void)hipFree(d_o); (void)hipFree(d_v); kao_eval_plan_destroy(p); };
-    const int64_t chunk_max = 1 << 20;
-    for (int64_t done = 0; done < n; done += chunk_max) {
-        const int64_t c = std::min(chunk_max, n - done);
-        if (!d_c) {
-            const size_t cap = (size_t)std::min(chunk_max, n);
-            if (hipMalloc(reinterpret_cast<void **>(&d_c), cap * per * 2) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void **>(&d_o), cap * 4) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void **>(&d_v), cap * 32) != hipSuccess) { cleanup(); return fail(KAO_ERR_NOMEM, "hipMalloc"); }
-        }
-        if (hipMemcpy(d_c, candidates + (size_t)done * per, (size_t)c * per * 2, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(KAO_ERR_HIP, "H2D"); }
-        rc = kao_eval_plan_run(p, d_c, c, d_o, d_v, nullptr);
-        if (!rc) rc = kao_eval_plan_sync(p, nullptr);
-        if (rc) { cleanup(); return rc; }
-        if (hipMemcpy(objective + done, d_o, (size_t)c * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(violations + done * 8, d_v, (size_t)c * 32, hipMemcpyDeviceToHost) != hipSuccess) { cleanup(); return fail(KAO_ERR_HIP, "D2H"); }
-    }
-    cleanup();
-    return KAO_OK;
+    return ctx.run(candidates, n, objective, violations);
 }
 
 int kao_evaluate(const kao_topic *t, const uint16_t *assignment, int64_t *objective, int32_t violations[8]) {
@@ -456,8 +532,10 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
     if (rc) return rc;
     const int P = t->n_partitions, RF = t->rf, B = t->n_brokers;
     const size_t per = (size_t)P * RF;
-    int64_t obj0 = 0; int32_t v[8];
-    if ((rc = kao_evaluate(t, a, &obj0, v))) return rc;
+    EvalCtx ctx;
+    if ((rc = ctx.open(t))) return rc;
+    int32_t obj0 = 0; int32_t v[8];
+    if ((rc = ctx.run(a, 1, &obj0, v))) return rc;
     if (v[0] != 0) return KAO_OK;  // only feasible assignments are polished
     auto is_cur = [&](int p, unsigned b) {
         for (int k = 0; k < t->rf_cur; ++k) if (t->current[(size_t)p * t->rf_cur + k] == b) return true;
@@ -482,7 +560,7 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
                 }
                 if (cand_b.empty()) continue;
                 bo.resize(cand_b.size()); bv.resize(cand_b.size() * 8);
-                if ((rc = kao_evaluate_batch(t, batch.data(), (int64_t)cand_b.size(), bo.data(), bv.data()))) return rc;
+                if ((rc = ctx.run(batch.data(), (int64_t)cand_b.size(), bo.data(), bv.data()))) return rc;
                 for (size_t i = 0; i < cand_b.size(); ++i)
                     if (bv[i * 8] == 0 && bo[i] == obj0) { a[(size_t)p * RF + k] = (uint16_t)cand_b[i]; changed = true; break; }
             }
@@ -507,12 +585,10 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
 void kao_session_destroy(kao_session *s) {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    (void)hipFree(s->d_topics); (void)hipFree(s->d_smap); (void)hipFree(s->d_emap); (void)hipFree(s->d_cur);
-    (void)hipFree(s->d_ext); (void)hipFree(s->d_rsz); (void)hipFree(s->d_state); (void)hipFree(s->d_best);
-    (void)hipFree(s->d_info); (void)hipFree(s->d_drift); (void)hipFree(s->d_rackof); (void)hipFree(s->d_curd);
-    (void)hipFree(s->d_obj); (void)hipFree(s->d_viol); (void)hipFree(s->d_keys);
+    arena_put(s->arena_ro, s->arena_ro_bytes);
+    arena_put(s->arena_rw, s->arena_rw_bytes);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    stream_put(s->stream);
     delete s;
 }
 
@@ -548,7 +624,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
 
     std::vector<uint2> cur_pool; std::vector<uint16_t> ext_pool, curd_pool; std::vector<int32_t> rsz_pool;
     std::vector<uint8_t> rackof_pool;
-    uint64_t state_parts = 0, best_u16 = 0;
+    uint64_t state_parts = 0, best_u16 = 0, win_u16 = 0;
     int restart_base = 0;
     for (int t = 0; t < n_topics; ++t) {
         PreparedTopic &pt = s->pts[(size_t)t];
@@ -573,12 +649,14 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         state_parts += (uint64_t)o.restarts * d.P;
         d.best_off = best_u16;
         best_u16 += (uint64_t)o.restarts * d.P * d.RF;
+        d.win_off = (uint32_t)win_u16;
+        win_u16 += (uint64_t)d.P * d.RF;
         d.rackof_off = (uint32_t)rackof_pool.size();
         rackof_pool.insert(rackof_pool.end(), pt.rack_of.begin(), pt.rack_of.end());
         d.curd_off = (uint32_t)curd_pool.size();
         curd_pool.insert(curd_pool.end(), pt.cur_dense.begin(), pt.cur_dense.end());
         s->maxP = std::max(s->maxP, d.P); s->maxBx = std::max(s->maxBx, d.Bx); s->maxB = std::max(s->maxB, d.B);
-        // algorithmic bytes: delta = 8*RF+10 per neighbour; full = 2*RF*P + 2*rf_cur*P + B per candidate
+        // algorithmic bytes: full evaluation = 2*RF*P + 2*rf_cur*P + B per candidate
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
     }
     s->total_restarts = restart_base;
@@ -602,25 +680,64 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     emap = xcd_order(emap, emap_topic);
     s->blocks_search = (int)smap.size();
     s->blocks_eval = (int)emap.size();
-
     std::vector<TopicDev> tds;
     for (auto &pt : s->pts) tds.push_back(pt.d);
-    if ((rc = dev_alloc_copy(&s->d_topics, tds)) || (rc = dev_alloc_copy(&s->d_smap, smap)) || (rc = dev_alloc_copy(&s->d_emap, emap)) ||
-        (rc = dev_alloc_copy(&s->d_cur, cur_pool)) || (rc = dev_alloc_copy(&s->d_ext, ext_pool)) || (rc = dev_alloc_copy(&s->d_rsz, rsz_pool)) ||
-        (rc = dev_alloc_copy(&s->d_rackof, rackof_pool)) || (rc = dev_alloc_copy(&s->d_curd, curd_pool))) { kao_session_destroy(s); return rc; }
-    auto alloc = [&](void **p, size_t bytes, int fillbyte) -> int {
-        HIP_TRY(hipMalloc(p, std::max<size_t>(bytes, 16)));
-        HIP_TRY(hipMemset(*p, fillbyte, std::max<size_t>(bytes, 16)));
-        return KAO_OK;
-    };
-    if ((rc = alloc(reinterpret_cast<void **>(&s->d_state), state_parts * sizeof(uint2), 0xFF)) ||
-        (rc = alloc(reinterpret_cast<void **>(&s->d_best), best_u16 * 2, 0xFF)) ||  // "no snapshot" = all KAO_NONE
-        (rc = alloc(reinterpret_cast<void **>(&s->d_info), (size_t)s->total_restarts * 16, 0)) ||
-        (rc = alloc(reinterpret_cast<void **>(&s->d_drift), 16, 0)) ||
-        (rc = alloc(reinterpret_cast<void **>(&s->d_obj), (size_t)s->total_restarts * 4, 0)) ||
-        (rc = alloc(reinterpret_cast<void **>(&s->d_viol), (size_t)s->total_restarts * 32, 0)) ||
-        (rc = alloc(reinterpret_cast<void **>(&s->d_keys), (size_t)n_topics * 8, 0xFF))) { kao_session_destroy(s); return rc; }
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { kao_session_destroy(s); return fail(KAO_ERR_HIP, "hipStreamCreate"); }
+
+    // ---- read-only arena: stage everything on the host, ONE hipMalloc (or a parked arena), ONE H2D copy ----
+    struct Sec { const void *src; size_t bytes; size_t off; };
+    Sec secs[8] = {{tds.data(), tds.size() * sizeof(TopicDev), 0}, {smap.data(), smap.size() * sizeof(int2), 0},
+                   {emap.data(), emap.size() * sizeof(int4), 0}, {cur_pool.data(), cur_pool.size() * sizeof(uint2), 0},
+                   {ext_pool.data(), ext_pool.size() * 2, 0}, {rsz_pool.data(), rsz_pool.size() * 4, 0},
+                   {rackof_pool.data(), rackof_pool.size(), 0}, {curd_pool.data(), curd_pool.size() * 2, 0}};
+    size_t ro_bytes = 0;
+    for (Sec &sec : secs) { sec.off = ro_bytes; ro_bytes += align_up(sec.bytes); }
+    std::vector<unsigned char> stage(ro_bytes);
+    for (const Sec &sec : secs) if (sec.bytes) std::memcpy(stage.data() + sec.off, sec.src, sec.bytes);
+    if ((rc = arena_get(ro_bytes, &s->arena_ro, &s->arena_ro_bytes))) { kao_session_destroy(s); return rc; }
+    unsigned char *ro = static_cast<unsigned char *>(s->arena_ro);
+    s->d_topics = reinterpret_cast<TopicDev *>(ro + secs[0].off);
+    s->d_smap = reinterpret_cast<int2 *>(ro + secs[1].off);
+    s->d_emap = reinterpret_cast<int4 *>(ro + secs[2].off);
+    s->d_cur = reinterpret_cast<uint2 *>(ro + secs[3].off);
+    s->d_ext = reinterpret_cast<uint16_t *>(ro + secs[4].off);
+    s->d_rsz = reinterpret_cast<int32_t *>(ro + secs[5].off);
+    s->d_rackof = reinterpret_cast<uint8_t *>(ro + secs[6].off);
+    s->d_curd = reinterpret_cast<uint16_t *>(ro + secs[7].off);
+
+    // ---- mutable arena ----
+    const size_t state_b = align_up(state_parts * sizeof(uint2)), best_b = align_up(best_u16 * 2);
+    const size_t info_b = align_up((size_t)s->total_restarts * 16), obj_b = align_up((size_t)s->total_restarts * 4);
+    const size_t viol_b = align_up((size_t)s->total_restarts * 32);
+    s->rb_viol_off = align_up((size_t)n_topics * 8 + 16, 16);
+    s->rb_assign_off = s->rb_viol_off + (size_t)n_topics * 32;
+    s->readback_bytes = s->rb_assign_off + win_u16 * 2;
+    const size_t rw_bytes = state_b + best_b + info_b + obj_b + viol_b + align_up(s->readback_bytes);
+    if ((rc = arena_get(rw_bytes, &s->arena_rw, &s->arena_rw_bytes))) { kao_session_destroy(s); return rc; }
+    unsigned char *rw = static_cast<unsigned char *>(s->arena_rw);
+    s->d_state = reinterpret_cast<uint2 *>(rw);
+    s->d_best = reinterpret_cast<uint16_t *>(rw + state_b);
+    s->d_info = reinterpret_cast<int32_t *>(rw + state_b + best_b);
+    s->d_obj = reinterpret_cast<int32_t *>(rw + state_b + best_b + info_b);
+    s->d_viol = reinterpret_cast<int32_t *>(rw + state_b + best_b + info_b + obj_b);
+    s->d_readback = rw + state_b + best_b + info_b + obj_b + viol_b;
+    s->d_keys = reinterpret_cast<unsigned long long *>(s->d_readback);
+    s->d_drift = reinterpret_cast<int32_t *>(s->d_readback + (size_t)n_topics * 8);
+    s->d_win_viol = reinterpret_cast<int32_t *>(s->d_readback + s->rb_viol_off);
+    s->d_win_assign = reinterpret_cast<uint16_t *>(s->d_readback + s->rb_assign_off);
+    s->h_readback.assign(s->readback_bytes, 0);
+
+    if ((rc = stream_get(&s->stream))) { kao_session_destroy(s); return rc; }
+    // restart states / info / obj / viol are fully written by launch 0 (init) and the first K-eval; only the
+    // snapshots ("no snapshot" = all KAO_NONE), the keys (all ones) and the drift counter need initial values
+    hipError_t e1 = hipMemcpyAsync(ro, stage.data(), ro_bytes, hipMemcpyHostToDevice, s->stream);
+    hipError_t e2 = hipMemsetAsync(s->d_best, 0xFF, best_u16 * 2 ? best_u16 * 2 : 2, s->stream);
+    hipError_t e3 = hipMemsetAsync(s->d_readback, 0xFF, (size_t)n_topics * 8, s->stream);
+    hipError_t e4 = hipMemsetAsync(s->d_drift, 0, 16, s->stream);
+    hipError_t e5 = hipStreamSynchronize(s->stream);  // `stage` is pageable host memory and goes out of scope
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
+        kao_session_destroy(s);
+        return fail(KAO_ERR_HIP, "session upload failed");
+    }
     if (o.profile) {
         s->ev.resize(kEvRing * 3);
         for (auto &e : s->ev) if (hipEventCreate(&e) != hipSuccess) { kao_session_destroy(s); return fail(KAO_ERR_HIP, "hipEventCreate"); }
@@ -681,26 +798,29 @@ int kao_session_best_keys(kao_session *s, uint64_t *keys) {
 
 int kao_session_best(kao_session *s, kao_result *results) {
     if (!s || !results) return fail(KAO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(g_device));
+    launch_gather(s->d_topics, s->n_topics, s->d_keys, s->d_best, s->d_viol, s->d_win_assign, s->d_win_viol, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s->h_readback.data(), s->d_readback, s->readback_bytes, hipMemcpyDeviceToHost, s->stream));
     int rc = kao_session_sync(s);
     if (rc) return rc;
-    std::vector<uint64_t> keys((size_t)s->n_topics);
-    HIP_TRY(hipMemcpy(keys.data(), s->d_keys, keys.size() * 8, hipMemcpyDeviceToHost));
+    const uint64_t *keys = reinterpret_cast<const uint64_t *>(s->h_readback.data());
+    const int32_t *wv = reinterpret_cast<const int32_t *>(s->h_readback.data() + s->rb_viol_off);
+    const uint16_t *wa = reinterpret_cast<const uint16_t *>(s->h_readback.data() + s->rb_assign_off);
     for (int t = 0; t < s->n_topics; ++t) {
         const TopicDev &d = s->pts[(size_t)t].d;
         kao_result &r = results[t];
         r.upper_bound = s->ub[(size_t)t];
-        const uint64_t key = keys[(size_t)t];
+        const uint64_t key = keys[t];
         if (key == ~0ull) {  // no step has run yet
             r.status = KAO_STATUS_NO_FEASIBLE; r.best_restart = -1; r.objective = -1;
             std::memset(r.violations, 0, sizeof r.violations);
             continue;
         }
-        const int rho = (int)(key & 0xFFFFF);
-        r.best_restart = rho;
+        r.best_restart = (int)(key & 0xFFFFF);
         r.objective = (int64_t)kObjCap - (int64_t)((key >> 20) & 0xFFFFFF);
-        HIP_TRY(hipMemcpy(r.violations, s->d_viol + (size_t)(d.restart_base + rho) * 8, 32, hipMemcpyDeviceToHost));
-        if (r.assignment)
-            HIP_TRY(hipMemcpy(r.assignment, s->d_best + d.best_off + (uint64_t)rho * d.P * d.RF, (size_t)d.P * d.RF * 2, hipMemcpyDeviceToHost));
+        std::memcpy(r.violations, wv + (size_t)t * 8, 32);
+        if (r.assignment) std::memcpy(r.assignment, wa + d.win_off, (size_t)d.P * d.RF * 2);
         if (r.violations[0] != 0) { r.status = KAO_STATUS_NO_FEASIBLE; r.objective = -1; }
         else r.status = r.objective >= r.upper_bound ? KAO_STATUS_OPTIMAL_PROVEN : KAO_STATUS_FEASIBLE_BOUND_GAP;
     }
@@ -753,32 +873,48 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     kao_session *s = nullptr;
     int rc = kao_session_create(topics, n_topics, opts, &s);
     if (rc) return rc;
+    g_timing[0] = now_s() - t0;
     const kao_opts &o = s->opts;
+    const int64_t *target = opts ? opts->target_objective : nullptr;
     std::vector<uint64_t> keys((size_t)n_topics), prev((size_t)n_topics, ~0ull);
     std::vector<double> t_best((size_t)n_topics, 0.0);
     bool hit_time = false;
-    for (int launch = 0;; ++launch) {
+    int launches = 0;
+    double t_last_improve = 0;
+    for (;;) {
         if ((rc = kao_session_step(s)) || (rc = kao_session_best_keys(s, keys.data()))) { kao_session_destroy(s); return rc; }
+        ++launches;
         const double t = now_s() - t0;
-        bool all_proven = true;
+        bool all_done = true;
         for (int i = 0; i < n_topics; ++i) {
-            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; }
+            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; }
             const bool feasible = (keys[(size_t)i] >> 44) == 0;
             const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
-            if (!(feasible && obj >= s->ub[(size_t)i])) all_proven = false;
+            const int64_t goal = target ? target[i] : s->ub[(size_t)i];
+            if (!(feasible && obj >= goal)) all_done = false;
         }
-        if (o.stop_at_bound && all_proven) break;
-        if (o.max_launches > 0 && launch + 1 >= o.max_launches) break;
+        if (o.stop_at_bound && all_done) break;
+        if (o.max_launches > 0 && launches >= o.max_launches) break;
         if (t >= o.time_limit_s) { hit_time = true; break; }
     }
+    g_timing[1] = t_last_improve;
     rc = kao_session_best(s, results);
+    g_timing[2] = now_s() - t0;
     if (!rc)
         for (int i = 0; i < n_topics; ++i) {
             results[i].seconds_to_best = t_best[(size_t)i];
             if (hit_time && results[i].status == KAO_STATUS_FEASIBLE_BOUND_GAP) results[i].status = KAO_STATUS_TIME_LIMIT;
         }
     kao_session_destroy(s);
+    g_timing[3] = now_s() - t0;
+    g_timing[4] = launches;
     return rc;
+}
+
+int kao_last_solve_timing(double out[5]) {
+    if (!out) return fail(KAO_ERR_INVALID, "null out");
+    for (int i = 0; i < 5; ++i) out[i] = g_timing[i];
+    return KAO_OK;
 }
 
 }  // extern "C"

@@ -32,6 +32,8 @@ struct TopicDev {
     int32_t B, rf_cur;
     uint32_t rackof_off;         // rackof_pool: u8[B]
     uint32_t curd_off;           // curd_pool  : u16[P*rf_cur] dense current assignment
+    uint32_t win_off;            // winners    : first u16 of this topic's winning assignment ([P*RF])
+    uint32_t pad_;
 };
 
 struct SearchParams {
@@ -70,5 +72,9 @@ size_t search_lds_bytes(int maxP, int maxBx);
 size_t eval_lds_bytes(int maxP, int maxB);
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, void *stream);
 void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
+// copy every topic's winning snapshot (restart id in its packed key) and violation row into contiguous
+// read-back buffers: one D2H instead of two per topic
+void launch_gather(const TopicDev *topics, int n_topics, const unsigned long long *keys, const uint16_t *best_pool,
+                   const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream);
 
 }  // namespace kao

@@ -483,11 +483,18 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     __syncthreads();
 
     unsigned long long my_key = ~0ull;
+    const int nB4 = (B + 3) >> 2;  // counters zeroed 16 bytes per lane per store (C is 16-byte aligned and padded)
     for (int ci = bm.y + wave; ci < bm.y + bm.z; ci += kWaves) {
         const uint16_t *cand = pl.cand + TD->best_off + (uint64_t)ci * P * RF;
-        for (int b = lane; b < B; b += 64) C[b] = 0;
+        for (int b4 = lane; b4 < nB4; b4 += 64) reinterpret_cast<uint4 *>(C)[b4] = make_uint4(0, 0, 0, 0);
         K[lane] = 0;
-        int obj = 0, v1 = 0, v2 = 0, v5 = 0, v7 = 0;
+        // Band violations are accumulated from the value each LDS atomic RETURNS: adding a replica to a
+        // broker whose count was c changes band(c) by (c >= hi) - (c < lo), and sum_b band(0) = B*lo, so
+        // no pass over all brokers is needed.  Packed partial sums: low half = #(old >= hi), high = #(old < lo).
+        int obj = 0;
+        uint32_t s12 = 0;  // v1 | v2 << 16
+        uint32_t s3 = 0, s4 = 0, s6 = 0;
+        uint32_t s57 = 0;  // v5 | v7 << 16
         for (int p = lane; p < P; p += 64) {
             const uint16_t *ap = cand + (size_t)p * RF;  // a wavefront reads 64*RF consecutive u16: coalesced
             uint32_t b0 = ap[0], b1 = 0xFFFFu, b2 = 0xFFFFu, b3 = 0xFFFFu;
@@ -496,29 +503,46 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             if (RF > 3) b3 = ap[3];
             const bool ok0 = b0 < (uint32_t)B, ok1 = b1 < (uint32_t)B, ok2 = b2 < (uint32_t)B, ok3 = b3 < (uint32_t)B;
             const int missing = (int)!ok0 + (RF > 1 ? (int)!ok1 : 0) + (RF > 2 ? (int)!ok2 : 0) + (RF > 3 ? (int)!ok3 : 0);
-            v1 += missing;             // C1: sum_b (f+l) = RF
-            v2 += (int)!ok0;           // C2: exactly one leader
+            s12 += (uint32_t)missing + ((uint32_t)!ok0 << 16);  // C1: sum_b (f+l) = RF ; C2: exactly one leader
             const uint2 cu = CURD[p];
             const uint32_t c0 = cu.x & 0xFFFFu, c1 = cu.x >> 16, c2 = cu.y & 0xFFFFu, c3 = cu.y >> 16;
             uint32_t r0 = 0xFFu, r1 = 0xFFu, r2 = 0xFFu, r3 = 0xFFu;
             if (ok0) {
-                r0 = RACK[b0]; atomicAdd(&C[b0], 0x10001u); atomicAdd(&K[r0], 1);
+                r0 = RACK[b0];
+                const uint32_t oc = atomicAdd(&C[b0], 0x10001u);
+                const int ok = atomicAdd(&K[r0], 1);
+                const int cr = (int)(oc & 0xFFFFu), cl = (int)(oc >> 16);
+                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);     // C3
+                s4 += (uint32_t)(cl >= lead_hi) + ((uint32_t)(cl < lead_lo) << 16);   // C4
+                s6 += (uint32_t)(ok >= rack_hi) + ((uint32_t)(ok < rack_lo) << 16);   // C6
                 obj += (c0 == b0) ? w00 : (((c1 == b0) | (c2 == b0) | (c3 == b0)) ? w10 : 0);
             }
             if (ok1) {
-                r1 = RACK[b1]; atomicAdd(&C[b1], 1u); atomicAdd(&K[r1], 1);
+                r1 = RACK[b1];
+                const int cr = (int)(atomicAdd(&C[b1], 1u) & 0xFFFFu);
+                const int ok = atomicAdd(&K[r1], 1);
+                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
+                s6 += (uint32_t)(ok >= rack_hi) + ((uint32_t)(ok < rack_lo) << 16);
                 obj += (c0 == b1) ? w01 : (((c1 == b1) | (c2 == b1) | (c3 == b1)) ? w11 : 0);
-                v5 += (int)(b1 == b0);  // C5: f+l <= 1 (an earlier slot holds the same broker)
+                s57 += (uint32_t)(b1 == b0);  // C5: f+l <= 1 (an earlier slot holds the same broker)
             }
             if (ok2) {
-                r2 = RACK[b2]; atomicAdd(&C[b2], 1u); atomicAdd(&K[r2], 1);
+                r2 = RACK[b2];
+                const int cr = (int)(atomicAdd(&C[b2], 1u) & 0xFFFFu);
+                const int ok = atomicAdd(&K[r2], 1);
+                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
+                s6 += (uint32_t)(ok >= rack_hi) + ((uint32_t)(ok < rack_lo) << 16);
                 obj += (c0 == b2) ? w01 : (((c1 == b2) | (c2 == b2) | (c3 == b2)) ? w11 : 0);
-                v5 += (int)((b2 == b0) | (b2 == b1));
+                s57 += (uint32_t)((b2 == b0) | (b2 == b1));
             }
             if (ok3) {
-                r3 = RACK[b3]; atomicAdd(&C[b3], 1u); atomicAdd(&K[r3], 1);
+                r3 = RACK[b3];
+                const int cr = (int)(atomicAdd(&C[b3], 1u) & 0xFFFFu);
+                const int ok = atomicAdd(&K[r3], 1);
+                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
+                s6 += (uint32_t)(ok >= rack_hi) + ((uint32_t)(ok < rack_lo) << 16);
                 obj += (c0 == b3) ? w01 : (((c1 == b3) | (c2 == b3) | (c3 == b3)) ? w11 : 0);
-                v5 += (int)((b3 == b0) | (b3 == b1) | (b3 == b2));
+                s57 += (uint32_t)((b3 == b0) | (b3 == b1) | (b3 == b2));
             }
             // C7: replicas per partition per rack, over all R racks
             int touched = 0, s7 = 0;
@@ -526,18 +550,16 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             if (ok1 && r1 != r0) { s7 += band(1 + (int)(r2 == r1) + (int)(r3 == r1), prack_lo, prack_hi); touched++; }
             if (ok2 && r2 != r0 && r2 != r1) { s7 += band(1 + (int)(r3 == r2), prack_lo, prack_hi); touched++; }
             if (ok3 && r3 != r0 && r3 != r1 && r3 != r2) { s7 += band(1, prack_lo, prack_hi); touched++; }
-            v7 += s7 + (R - touched) * prack_lo;
+            s57 += (uint32_t)(s7 + (R - touched) * prack_lo) << 16;
         }
-        int v3 = 0, v4 = 0, v6 = 0;
-        for (int b = lane; b < B; b += 64) {
-            const uint32_t c = C[b];
-            v3 += band((int)(c & 0xFFFFu), rep_lo, rep_hi);   // C3
-            v4 += band((int)(c >> 16), lead_lo, lead_hi);     // C4
-        }
-        if (lane < R) v6 = band(K[lane], rack_lo, rack_hi);   // C6
         obj = wave_sum(obj);
-        v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
-        v5 = wave_sum(v5); v6 = wave_sum(v6); v7 = wave_sum(v7);
+        const uint32_t t12 = (uint32_t)wave_sum((int)s12), t3 = (uint32_t)wave_sum((int)s3), t4 = (uint32_t)wave_sum((int)s4);
+        const uint32_t t6 = (uint32_t)wave_sum((int)s6), t57 = (uint32_t)wave_sum((int)s57);
+        const int v1 = (int)(t12 & 0xFFFFu), v2 = (int)(t12 >> 16);
+        const int v3 = B * rep_lo + (int)(t3 & 0xFFFFu) - (int)(t3 >> 16);
+        const int v4 = B * lead_lo + (int)(t4 & 0xFFFFu) - (int)(t4 >> 16);
+        const int v6 = R * rack_lo + (int)(t6 & 0xFFFFu) - (int)(t6 >> 16);
+        const int v5 = (int)(t57 & 0xFFFFu), v7 = (int)(t57 >> 16);
         const int v0 = v1 + v2 + v3 + v4 + v5 + v6 + v7;
         const int out = bm.w + (ci - bm.y);
         if (lane == 0) {
@@ -562,6 +584,22 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             if (k != ~0ull) atomicMin(pl.best_key + bm.x, k);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-gather: winners -> contiguous read-back buffers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_gather(const TopicDev *topics, const unsigned long long *keys, const uint16_t *best_pool,
+                                               const int32_t *viol, uint16_t *win_assign, int32_t *win_viol) {
+    const TopicDev *TD = topics + blockIdx.x;
+    const unsigned long long key = keys[blockIdx.x];
+    if (key == ~0ull) return;
+    const int rho = (int)(key & 0xFFFFFull);
+    const int n = TD->P * TD->RF;
+    const uint16_t *src = best_pool + TD->best_off + (uint64_t)rho * n;
+    uint16_t *dst = win_assign + TD->win_off;
+    for (int i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
+    if (threadIdx.x < 8) win_viol[blockIdx.x * 8 + threadIdx.x] = viol[(size_t)(TD->restart_base + rho) * 8 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -595,6 +633,12 @@ void launch_eval(const EvalPools &pools, int n_blocks, void *stream) {
         g_attr_eval = (int)lds;
     }
     hipLaunchKernelGGL(k_eval, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools);
+}
+
+void launch_gather(const TopicDev *topics, int n_topics, const unsigned long long *keys, const uint16_t *best_pool,
+                   const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream) {
+    hipLaunchKernelGGL(k_gather, dim3(n_topics), dim3(64), 0, static_cast<hipStream_t>(stream), topics, keys, best_pool, viol,
+                       win_assign, win_viol);
 }
 
 }  // namespace kao

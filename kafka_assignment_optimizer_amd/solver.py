@@ -257,11 +257,22 @@ def decode_key(key: int) -> tuple:
     return key >> 44, 0xFFFFFF - ((key >> 20) & 0xFFFFFF), key & 0xFFFFF
 
 
-def solve(topics: Sequence[Topic], **opts) -> List[Result]:
-    """Whole job (kao_solve): search every topic until proven optimal / time limit."""
+def solve(topics: Sequence[Topic], target_objective: Optional[Sequence[int]] = None, **opts) -> List[Result]:
+    """Whole job (kao_solve): search every topic until proven optimal (or `target_objective[i]` reached,
+    with stop_at_bound=1) / time limit."""
     topics = list(topics)
     ct = _CTopics(topics)
     o = _make_opts(**opts)
+    if target_objective is not None:
+        tgt = (C.c_int64 * len(topics))(*[int(v) for v in target_objective])
+        o.target_objective = tgt
     res, bufs = _results_buffers(topics)
     _check(_ffi.load().kao_solve(ct.arr, len(topics), C.byref(o), res), "kao_solve")
     return _unpack(topics, res, bufs)
+
+
+def last_solve_timing() -> dict:
+    """C-side wall-clock breakdown of the last kao_solve (seconds from its entry)."""
+    out = (C.c_double * 5)()
+    _check(_ffi.load().kao_last_solve_timing(out), "kao_last_solve_timing")
+    return dict(session_ready=out[0], time_to_best=out[1], results_read_back=out[2], returned=out[3], launches=int(out[4]))
