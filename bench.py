@@ -63,6 +63,20 @@ def cpu_baseline(topics, restarts, iters, budget_s=15.0):
             "exact_seconds_per_topic": exact_s, "exact_objective_topic0": ex.objective}
 
 
+def load_profile_constants(config, iters, restarts_total):
+    """Per-launch PMC figures of the committed rocprofv3 run of THIS command (profiles/pmc_constants.json);
+    returned only when workload, iterations and restart count match, else None (-> traffic: null)."""
+    path = os.path.join(ROOT, "profiles", "pmc_constants.json")
+    try:
+        with open(path) as f:
+            for e in json.load(f):
+                if e["config"] == config and e["iters_per_launch"] == iters and e["restarts_total"] == restarts_total:
+                    return e
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,12 +106,19 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solver has no CPU path")
-    torch.cuda.set_device(local_rank)
-    kao.init(local_rank)
+    # KAO_BENCH_SHARE_DEVICE=1 (test mode for a 1-GPU box): every rank uses device 0 and the collective runs
+    # over gloo, so the N > 1 code path can be exercised without N GPUs.  Never set by the driver.
+    share = os.environ.get("KAO_BENCH_SHARE_DEVICE", "0") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    kao.init(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    dev = torch.device("cuda", dev_index)
 
     def barrier():
         if world > 1:
@@ -210,6 +231,18 @@ def main():
                        "avg_launch_ms": ms_search / max(1, launches),
                        "note": "algorithmic bytes = neighbours x (8*RF+10) B (SURVEY.md 8d); the working set is "
                                "LDS-resident, so this kernel is VALU/LDS-issue bound, not HBM bound (DESIGN.md section 6)"}
+    prof = load_profile_constants(args.config, args.iters, st1["n_restarts_total"])
+    if prof:
+        out["roofline"]["traffic"] = prof["k_search_hbm_bytes_per_launch"]
+        out["roofline"]["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE (x2 gfx950 wide-read correction) + WRITE_SIZE per launch, "
+                                           "separate passes, from " + prof["source"])
+        valu = prof["k_search_valu_insts_per_launch"]
+        peak = 256 * 4 * 2.4e9 / 4  # wave64 integer VALU instructions/s: 1024 SIMDs, one issue per 4 cycles, 2.4 GHz
+        out["roofline_valu_issue"] = {"kernel": "k_search", "bound": "valu-issue", "insts_per_launch": valu,
+                                      "achieved": valu / (ms_search / max(1, launches) * 1e-3) / 1e9, "peak": peak / 1e9,
+                                      "unit": "G wave-instructions/s",
+                                      "frac": valu / (ms_search / max(1, launches) * 1e-3) / peak,
+                                      "note": "SQ_INSTS_VALU per launch from " + prof["source"] + "; this, not HBM, is the binding roof"}
     ach_e = eb / (ms_eval * 1e-3) / 1e9 if ms_eval > 0 else None
     out["roofline_eval_in_step"] = {"kernel": "k_eval", "achieved": ach_e, "unit": "GB/s", "avg_launch_ms": ms_eval / max(1, launches),
                                     "algorithmic_bytes_per_launch": eb // max(1, launches)}

@@ -121,6 +121,51 @@ def test_search_replay_random_small(kao, ko, kp):
         assert s.stats()["drift"] == 0
 
 
+def test_search_replay_varied_shapes(kao, ko, kp):
+    """One session holding heterogeneous topics: RF 1/2/4, an RF increase and decrease, a single rack,
+    uneven racks (padding slots in the internal index), P not a multiple of 64, B < 64 and B > 64."""
+    mk = ko.make_cluster
+    ots = [
+        mk("rf1", 10, 2, 1, 7, 1, [3], [(10, 0)]).topics[0],
+        mk("rf2", 30, 3, 1, 70, 2, [0, 1, 2, 3], []).topics[0],
+        mk("rf4", 70, 5, 1, 130, 4, [1, 2, 3], [(70, 0), (71, 4)]).topics[0],
+        mk("rf2to3", 24, 4, 1, 40, 2, [5], [(24, 1), (25, 1), (26, 1)], new_rf=3).topics[0],
+        mk("rf3to2", 24, 4, 1, 33, 3, [], [(24, 0)], new_rf=2).topics[0],
+        mk("onerack", 9, 1, 1, 12, 3, [4], []).topics[0],
+        mk("uneven", 40, 4, 1, 65, 3, [0, 4, 8, 12, 16, 1], []).topics[0],
+    ]
+    seed = 424242
+    with kao.Session([to_product_topic(t) for t in ots], seed=seed, restarts=8, iters_per_launch=96) as s:
+        s.step(3)
+        assert s.stats()["drift"] == 0
+        for ti, ot in enumerate(ots):
+            tseed = seed ^ (((ti + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+            for rho in (0, 1, 2, 5):
+                dev = s.restart_state(ti, rho)
+                ref = kp.port_search(ot, tseed, rho, 3, 96)
+                assert dev["final"].tolist() == ref["final"].tolist(), (ot.name, rho)
+                assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == \
+                       (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"]), (ot.name, rho)
+                if ref["best_obj"] >= 0:
+                    assert dev["best"].tolist() == ref["best"].tolist()
+        res = s.best()
+    for ot, r in zip(ots, res):
+        if r.status != "NO_FEASIBLE":
+            obj, viol = ko.verify(ot, r.assignment)
+            assert viol[0] == 0 and obj == r.objective, ot.name
+
+
+def test_unsupported_instances_are_rejected(kao, ko):
+    ot = ko.make_cluster("big", 100, 4, 1, 11000, 3, [], []).topics[0]
+    with pytest.raises(kao.KaoError) as e:
+        kao.Session([to_product_topic(ot)])
+    assert e.value.code == -2  # 33000 replicas > 32767
+    ot = ko.make_cluster("lds", 1000, 20, 1, 3000, 3, [], []).topics[0]
+    with pytest.raises(kao.KaoError) as e:
+        kao.Session([to_product_topic(ot)])
+    assert e.value.code == -2  # state does not fit 160 KiB of LDS per workgroup
+
+
 # ------------------------------------------------------------------------------- optimum parity
 def test_kat1_end_to_end(kao, ko):
     """README.md:52-63 in -> README.md:88 out ([8,19] -> [8,1], nothing else moves)."""

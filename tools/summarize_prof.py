@@ -60,3 +60,45 @@ for db in dbs("pmc_sq"):
             groups[(short(name), gs // wg)][cn].append(val)
     for (name, blocks), d in sorted(groups.items()):
         print(f"{name} workgroups={blocks}: " + ", ".join(f"{k}={sum(v)/len(v):.4g}" for k, v in sorted(d.items())))
+
+# ---- machine-readable per-launch constants of the full-size K-search launch (largest duration group) ----
+import json
+try:
+    const = {}
+    c = sqlite3.connect(dbs("trace")[0])
+    rows = c.execute("select name, grid_x, workgroup_x, duration from kernels").fetchall()
+    ks = [(gx // wx, dur) for name, gx, wx, dur in rows if "k_search" in name]
+    blocks = max(b for b, _ in ks)
+    durs = sorted(d for b, d in ks if b == blocks)
+    full = [d for d in durs if d > 0.7 * durs[-1]]  # drop the short kao_solve launches
+    const["k_search_workgroups"] = blocks
+    const["k_search_avg_us_trace"] = sum(full) / len(full) / 1e3
+
+    def per_launch(sub, ctr):
+        cc = sqlite3.connect(dbs(sub)[0])
+        v = [val for name, val in cc.execute("select kernel_name, value from counters_collection where counter_name=?", (ctr,)) if "k_search" in name]
+        v = sorted(v)
+        big = [x for x in v if x > 0.7 * v[-1]]
+        return sum(big) / len(big)
+    fetch = per_launch("pmc_fetch", "FETCH_SIZE") * 1024 * 2
+    write = per_launch("pmc_write", "WRITE_SIZE") * 1024
+    const["k_search_hbm_bytes_per_launch"] = int(fetch + write)
+    const["k_search_valu_insts_per_launch"] = int(per_launch("pmc_sq", "SQ_INSTS_VALU"))
+    const["k_search_lds_insts_per_launch"] = int(per_launch("pmc_sq", "SQ_INSTS_LDS"))
+    meta = {}
+    try:
+        with open(os.path.join(out, "bench_trace.json")) as f:
+            b = json.loads(f.read().strip().splitlines()[-1])
+        meta = {"config": int(b["config"]["workload"][3]), "iters_per_launch": b["config"]["iters_per_launch"],
+                "restarts_total": b["config"]["restarts_per_topic_rank0"] * b["config"]["topics_per_rank"][0],
+                "bench_hip_event_avg_launch_ms": b["roofline"]["avg_launch_ms"]}
+    except Exception as e:  # noqa: BLE001
+        print("bench json unavailable:", e)
+    const.update(meta)
+    const["source"] = "profiles/" + os.path.basename(out.rstrip("/")) + " (tools/profile.sh)"
+    print("== constants ==")
+    print(json.dumps(const))
+    with open(os.path.join(out, "pmc_constants.json"), "w") as f:
+        json.dump([const], f)
+except Exception as e:  # noqa: BLE001
+    print("constants unavailable:", e)
