@@ -211,7 +211,8 @@ def main():
         "config": {"workload": synthetic.WORKLOADS[args.config], "topics_total": n_topics,
                    "topics_per_rank": [len(s) for s in shards], "restarts_per_topic_rank0": st1["n_restarts_total"] // max(1, len(topics)),
                    "iters_per_launch": args.iters,
-                   "neighbours_per_iteration": "64 lanes x (4 REPLACE | 1 EXCHANGE | rf-1 LEADER-SWAP), pattern RRXRLRXR",
+                   "neighbours_per_iteration": "REPLACE: B brokers of one slot (scan) or 64x4 (sample), EXCHANGE: P*rf partner slots, "
+                                               "LEADER-SWAP: 64x(rf-1); pattern RRXRLRXR",
                    "parallelism": f"topic-sharded x{world}" if world > 1 else "single GPU"},
         "delta_candidates_per_s": tot_delta / dt_max,
         "full_candidates_per_s": tot_full / dt_max,

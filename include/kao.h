@@ -98,8 +98,9 @@ typedef struct kao_result {
 
 typedef struct kao_stats {
     uint64_t launches;          /* K-search launches */
-    uint64_t delta_candidates;  /* neighbours delta-evaluated by K-search: per iteration per restart 64 lanes x
-                                   (4 REPLACE | 1 EXCHANGE | rf-1 LEADER-SWAP candidates) */
+    uint64_t delta_candidates;  /* neighbours delta-evaluated by K-search, per restart and iteration: REPLACE = all B
+                                   brokers of one slot (scan blocks) or 64 lanes x 4 (sample blocks), EXCHANGE = all
+                                   P*rf partner slots, LEADER-SWAP = 64 x (rf-1) */
     uint64_t full_candidates;   /* complete candidates fully evaluated by K-eval */
     double ms_search;           /* HIP-event time of K-search launches (profile=1) */
     double ms_eval;             /* HIP-event time of K-eval launches (profile=1) */

@@ -152,14 +152,19 @@ int64_t upper_bound(const kao_topic *t) {
     return total;
 }
 
-// Neighbours delta-evaluated by ONE restart over iterations [it0, it0+iters): per iteration 64 lanes x
-// (4 REPLACE candidates | 1 EXCHANGE | RF-1 LEADER-SWAPs), move pattern R R X R L R X R (kao_kernels.hip).
-uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf) {
+// Neighbours delta-evaluated by ONE restart over iterations [it0, it0+iters) (kao_kernels.hip, KAO-LS):
+// move pattern R R X R L R X R; REPLACE scans all B brokers of one slot in even blocks of 8 iterations and
+// samples 64 lanes x 4 brokers in odd blocks; EXCHANGE scans all P*RF partner slots; LEADER-SWAP 64 x (RF-1).
+uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers, int n_partitions) {
     static const uint8_t pat[8] = {0, 0, 1, 0, 2, 0, 1, 0};
-    const uint64_t per_type[3] = {64ull * 4, 64ull, 64ull * (uint64_t)(rf > 1 ? rf - 1 : 0)};
-    const uint64_t per8 = 5 * per_type[0] + 2 * per_type[1] + per_type[2];
-    uint64_t n = (uint64_t)(iters / 8) * per8;
-    for (uint32_t i = (iters / 8) * 8; i < iters; ++i) n += per_type[pat[(it0 + i) & 7]];
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < iters; ++i) {
+        const uint32_t it = it0 + i;
+        const int type = pat[it & 7];
+        if (type == 0) n += ((it >> 3) & 1u) ? 256ull : (uint64_t)n_brokers;
+        else if (type == 1) n += (uint64_t)n_partitions * (uint64_t)rf;
+        else n += 64ull * (uint64_t)(rf > 1 ? rf - 1 : 0);
+    }
     return n;
 }
 
@@ -224,6 +229,7 @@ struct kao_session {
     int total_restarts = 0;
     int maxP = 0, maxBx = 0, maxB = 0;
     int blocks_search = 0, blocks_eval = 0;
+    int search_waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
     // device memory: one read-only arena (instance tables, uploaded with ONE H2D copy) and one mutable
     // arena (restart states, snapshots, results); the pointers below are carved from them
     void *arena_ro = nullptr, *arena_rw = nullptr;
@@ -660,9 +666,12 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
     }
     s->total_restarts = restart_base;
-    if (search_lds_bytes(s->maxP, s->maxBx) > 160 * 1024 || eval_lds_bytes(s->maxP, s->maxB) > 160 * 1024) {
+    s->search_waves = kWaves;
+    while (s->search_waves > 1 && search_lds_bytes(s->maxP, s->maxBx, s->search_waves) > 160 * 1024) s->search_waves /= 2;
+    if (search_lds_bytes(s->maxP, s->maxBx, s->search_waves) > 160 * 1024 || eval_lds_bytes(s->maxP, s->maxB) > 160 * 1024) {
         kao_session_destroy(s);
-        return fail(KAO_ERR_UNSUPPORTED, "topic state exceeds 160 KiB of LDS per workgroup (partitions x 16 B x 5 + brokers x 16 B)");
+        return fail(KAO_ERR_UNSUPPORTED, "topic state exceeds 160 KiB of LDS even with one restart per workgroup "
+                                         "(32 B x partitions + 4 B x padded brokers)");
     }
     // workgroup maps
     std::vector<int2> smap; std::vector<int> smap_topic;
@@ -670,7 +679,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     const int cpb = 32;  // candidates per K-eval workgroup
     for (int t = 0; t < n_topics; ++t) {
         const TopicDev &d = s->pts[(size_t)t].d;
-        for (int r = 0; r < d.n_restarts; r += kWaves) { smap.push_back(make_int2(t, r)); smap_topic.push_back(t); }
+        for (int r = 0; r < d.n_restarts; r += s->search_waves) { smap.push_back(make_int2(t, r)); smap_topic.push_back(t); }
         for (int r = 0; r < d.n_restarts; r += cpb) {
             emap.push_back(make_int4(t, r, std::min(cpb, d.n_restarts - r), d.restart_base + r));
             emap_topic.push_back(t);
@@ -767,14 +776,14 @@ int kao_session_step(kao_session *s) {
     ep.maxP = s->maxP; ep.maxB = s->maxB;
     hipEvent_t *e = prof ? &s->ev[(size_t)s->ev_pending * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(e[0], s->stream));
-    launch_search(sp, prm, s->blocks_search, s->stream);
+    launch_search(sp, prm, s->blocks_search, s->search_waves, s->stream);
     HIP_TRY(hipGetLastError());
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
     launch_eval(ep, s->blocks_eval, s->stream);
     HIP_TRY(hipGetLastError());
     if (prof) { HIP_TRY(hipEventRecord(e[2], s->stream)); s->ev_pending++; }
     for (const PreparedTopic &pt : s->pts) {
-        const uint64_t n = neighbours_in_range(prm.launch * prm.iters, prm.iters, pt.d.RF) * (uint64_t)pt.d.n_restarts;
+        const uint64_t n = neighbours_in_range(prm.launch * prm.iters, prm.iters, pt.d.RF, pt.d.B, pt.d.P) * (uint64_t)pt.d.n_restarts;
         s->delta_total += n;
         s->search_bytes_total += n * (uint64_t)(8 * pt.d.RF + 10);
     }
@@ -839,7 +848,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->search_bytes_algo = s->search_bytes_total;
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
-    out->lds_bytes_search = (int32_t)search_lds_bytes(s->maxP, s->maxBx);
+    out->lds_bytes_search = (int32_t)search_lds_bytes(s->maxP, s->maxBx, s->search_waves);
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));
     return KAO_OK;

@@ -6,7 +6,7 @@
 namespace kao {
 
 constexpr int kRFP = 4;          // padded replica slots per partition
-constexpr int kWaves = 4;        // wavefronts (restarts) per K-search workgroup
+constexpr int kWaves = 4;        // wavefronts per K-eval workgroup; K-search uses 4, 2 or 1 (largest that fits LDS)
 constexpr int kMaxRacks = 64;
 constexpr uint32_t kNoneW = 0xFFFFFFFFu;  // empty slot in the LDS word layout (x | rack << 16)
 constexpr uint32_t kKeyNull = 0xFFFFFFFFu;
@@ -68,9 +68,9 @@ struct EvalPools {
     int32_t maxP, maxB;
 };
 
-size_t search_lds_bytes(int maxP, int maxBx);
+size_t search_lds_bytes(int maxP, int maxBx, int waves);
 size_t eval_lds_bytes(int maxP, int maxB);
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, void *stream);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, void *stream);
 void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
 // copy every topic's winning snapshot (restart id in its packed key) and violation row into contiguous
 // read-back buffers: one D2H instead of two per topic

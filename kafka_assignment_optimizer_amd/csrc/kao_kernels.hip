@@ -37,14 +37,17 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
-// Wavefront min (all 64 lanes active): butterfly inside each row of 16 with DPP (quad_perm xor1, xor2,
-// row_half_mirror, row_mirror), then the four row minima are read with v_readlane and combined on
-// the scalar unit.  Result is wave-uniform.
+// Wavefront min (all 64 lanes active): butterfly inside each row of 16 with four fused v_min_u32_dpp
+// (quad_perm xor1, xor2, row_half_mirror, row_mirror; hipcc emits mov_dpp + min pairs for the builtin form),
+// then the four row minima are read with v_readlane and combined on the scalar unit.  Result is wave-uniform.
+// s_nop 1 = the 2 wait states a DPP read needs after the VALU write of its source.
 __device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
-    v = min(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
-    v = min(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
-    v = min(v, dpp_mov<0x141>(v));  // row_half_mirror
-    v = min(v, dpp_mov<0x140>(v));  // row_mirror
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
     uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
     uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
@@ -68,7 +71,9 @@ __device__ __forceinline__ uint32_t sel4(const uint4 &a, int k) {
 }
 // per-lane LCG modulo 2^24: one v_mad_u32_u24 (only the low 24 bits of the state are ever read)
 __device__ __forceinline__ uint32_t lcg24(uint32_t &s) {
-    s = __umul24(s, 0x6D2B79u) + 0x3C6EF3u;
+    // s = (s & 0xFFFFFF) * 0x6D2B79 + 0x3C6EF3; forced to the full-rate 24-bit multiply-add (hipcc otherwise
+    // picks the quarter-rate v_mul_lo_u32 for some call sites)
+    asm("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(s) : "s"(0x6D2B79u), "v"(0x3C6EF3u));
     return s;
 }
 // uniform-ish draw on [0, n) from the high bits of a 24x24-bit product: one v_mul_hi_u32_u24.  n8 = n << 8.
@@ -87,6 +92,12 @@ __device__ __forceinline__ bool in4(const uint4 &a, uint32_t w) {
 // replicas of the partition that sit in rack r (empty slots carry rack 0xFFFF and never match)
 __device__ __forceinline__ int cnt4(const uint4 &a, uint32_t r) {
     return (int)((a.x >> 16) == r) + (int)((a.y >> 16) == r) + (int)((a.z >> 16) == r) + (int)((a.w >> 16) == r);
+}
+
+__device__ __forceinline__ uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t tie) {
+    int delta = __mul24(lam, dV) - __mul24(S, dObj);
+    delta = min(max(delta, -kDBias), kDBias - 2);
+    return ((uint32_t)(delta + kDBias) << 8) | (tie & 0xFFu);
 }
 
 struct TopicRegs {  // wave-uniform copy of the fields the inner loop needs
@@ -131,11 +142,12 @@ struct WaveLds {
     uint4 *A;     // [P] this restart's assignment, 4 words per partition
     uint32_t *C;  // [Bx] replicas | leaders << 16 per broker
     int *K;       // [64] replicas per rack
+    int *RT;      // [64] scratch: rack-dependent part of a REPLACE delta for the slot being scanned
 };
 
 // rebuild C and K from A (lanes stride partitions; LDS atomics)
 __device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds &L, int lane) {
-    for (int x = lane; x < T.Bx; x += 64) L.C[x] = 0;
+    for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) L.C[x] = 0;
     L.K[lane] = 0;
     for (int p = lane; p < T.P; p += 64) {
         const uint4 a = L.A[p];
@@ -195,20 +207,29 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     T.rack_lo = TD->rack_lo; T.rack_hi = TD->rack_hi; T.prack_lo = TD->prack_lo; T.prack_hi = TD->prack_hi;
     T.w00 = TD->w00; T.w01 = TD->w01; T.w10 = TD->w10; T.w11 = TD->w11;
 
-    // ---- LDS carve: [CUR uint4[maxP]] [RSZ int[64]] then per wave [A uint4[maxP]] [C u32[maxBx~]] [K int[64]]
+    // ---- LDS carve: [CUR uint4[maxP]] [RSZ int[64]] [XR u8[Bx rounded to 64]] then per wave
+    //      [A uint4[maxP]] [C u32[Bx rounded to 64]] [K int[64]] [RT int[64]]
     const int a_bytes = prm.maxP * 16;
-    const int c_bytes = (prm.maxBx * 4 + 15) & ~15;
+    const int bx64 = (prm.maxBx + 63) & ~63;
+    const int c_bytes = bx64 * 4;
     uint4 *CUR = reinterpret_cast<uint4 *>(smem);
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
-    unsigned char *wb = smem + a_bytes + 256 + wave * (a_bytes + c_bytes + 256);
+    uint8_t *XR = smem + a_bytes + 256;  // rack of internal index x, 0xFF = padding slot / beyond Bx
+    unsigned char *wb = smem + a_bytes + 256 + bx64 + wave * (a_bytes + c_bytes + 512);  // blockDim.x / 64 waves
     WaveLds L;
     L.A = reinterpret_cast<uint4 *>(wb);
     L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
     L.K = reinterpret_cast<int *>(wb + a_bytes + c_bytes);
+    L.RT = L.K + 64;
 
     // ---- stage the topic's current-assignment table and rack sizes (shared by the 4 restarts) ----
-    for (int p = threadIdx.x; p < T.P; p += 256) CUR[p] = expand(T, pl.cur_pool[TD->cur_off + p]);
+    for (int p = threadIdx.x; p < T.P; p += blockDim.x) CUR[p] = expand(T, pl.cur_pool[TD->cur_off + p]);
     if (threadIdx.x < 64) RSZ[threadIdx.x] = (int)threadIdx.x < T.R ? pl.rsz_pool[TD->rsz_off + threadIdx.x] : 0;
+    __syncthreads();
+    for (int x = threadIdx.x; x < ((T.Bx + 63) & ~63); x += blockDim.x) {
+        const uint32_t r = mulhi((uint32_t)x, T.magic);
+        XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < 64 ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
+    }
     __syncthreads();
 
     const int rho = bm.y + wave;
@@ -304,100 +325,182 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const uint32_t lrange = (uint32_t)(prm.lam_max - prm.lam_min + 1);
     const uint32_t P8 = (uint32_t)T.P << 8, RF8 = (uint32_t)T.RF << 8, R8 = (uint32_t)T.R << 8, m8 = (uint32_t)T.m << 8;
 
+    const int T_tour = min(64, max(4, (T.P * T.RF) >> 2));  // tournament size of the slot choice
+
     for (uint32_t i = 0; i < prm.iters; ++i) {
         const uint32_t it = prm.launch * prm.iters + i;
         const int type = (int)((0x1210u >> ((it & 7u) * 2u)) & 3u);  // pattern R R X R L R X R
         const uint32_t ph = it & pmask;
         const int lam = min(prm.lam_max, prm.lam_min + (int)((2u * ph * lrange) >> plog));
+        // REPLACE alternates, in blocks of 8 iterations, between "scan" (one slot, every broker) and "sample"
+        // (every lane its own slot, 4 brokers); EXCHANGE always scans; LEADER-SWAP always samples
+        const bool sampled = (type == 2) || (type == 0 && ((it >> 3) & 1u));
 
-        const int p = (int)rnd24(rng, P8);
-        const uint4 a = L.A[p];
-        const uint4 c = CUR[p];
         // this lane's best proposal of the iteration
         uint32_t key = kKeyNull;
-        int dV = 0, dObj = 0, k = 0, q = 0, j = 0;
+        int dV = 0, dObj = 0, p = 0, k = 0, q = 0, j = 0;
         uint32_t uw = 0, vw = 0;
+        uint32_t kmin;
+        int win;
 
-        if (type == 0) {  // REPLACE (p,k) <- x_g: 2 candidates of any rack, 2 of the old broker's rack
-            k = (int)rnd24(rng, RF8);
-            uw = sel4(a, k);
+        if (sampled) {
+            p = (int)rnd24(rng, P8);
+            const uint4 a = L.A[p];
+            const uint4 c = CUR[p];
+            if (type == 0) {  // REPLACE (p,k) <- x_g: 2 candidates of any rack, 2 of the old broker's rack
+                k = (int)rnd24(rng, RF8);
+                uw = sel4(a, k);
+                const uint32_t ro = uw >> 16;
+                const bool lead = k == 0;
+                const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
+                const int g_old = role_w2(c, uw, wl, wf);
+                const uint32_t co = L.C[uw & 0xFFFFu];
+                int dV_old = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
+                if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+                const int dV_rack_old = ddec(L.K[ro], T.rack_lo, T.rack_hi) + ddec(cnt4(a, ro), T.prack_lo, T.prack_hi);
+                const int rsz_ro = RSZ[ro];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint32_t r, jj;
+                    bool okg;
+                    if (g < 2) {
+                        r = rnd24(rng, R8);
+                        jj = rnd24(rng, m8);
+                        okg = (int)jj < RSZ[r];
+                    } else {
+                        r = ro;
+                        jj = rnd24(rng, (uint32_t)rsz_ro << 8);
+                        okg = true;
+                    }
+                    const uint32_t x = __umul24(r, (uint32_t)T.m) + jj;
+                    const uint32_t xw = x | (r << 16);
+                    okg = okg && !in4(a, xw);
+                    const uint32_t cn = L.C[x];
+                    int dVg = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi);
+                    if (lead) dVg += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+                    if (g < 2) {
+                        if (r != ro)
+                            dVg += dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
+                    }
+                    const int dObjg = role_w2(c, xw, wl, wf) - g_old;
+                    const uint32_t keyg = okg ? make_key(lam, S, dVg, dObjg, lane) : kKeyNull;
+                    if (keyg < key) { key = keyg; vw = xw; dV = dVg; dObj = dObjg; }
+                }
+            } else {  // LEADER SWAP inside p: slot 0 <-> slot k, every k = 1..RF-1 is a candidate
+                uw = a.x;
+                const int u_lead = role_w2(c, uw, T.w00, T.w10), u_fol = role_w2(c, uw, T.w01, T.w11);
+                const int dV_u = ddec((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+#pragma unroll
+                for (int kk = 1; kk < kRFP; ++kk) {
+                    if (kk >= T.RF) break;
+                    const uint32_t xw = kk == 1 ? a.y : (kk == 2 ? a.z : a.w);
+                    const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11);
+                    const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+                    const uint32_t keyg = make_key(lam, S, dVg, dObjg, lane);
+                    if (keyg < key) { key = keyg; vw = xw; k = kk; dV = dVg; dObj = dObjg; }
+                }
+            }
+            kmin = wave_umin(key);  // wavefront min-scan over the lanes' best proposals
+            win = (int)(kmin & 63u);
+        } else {
+            // ---- phase A: tournament over T_tour random slots; lowest removal score wins the iteration ----
+            const int pl_ = (int)rnd24(rng, P8);
+            const int kl_ = (int)rnd24(rng, RF8);
+            uint32_t keyA = kKeyNull;
+            uint32_t oldw_l = 0;
+            int g_old_l = 0, dvo_l = 0, dvr_l = 0;
+            {
+                const uint4 al = L.A[pl_];
+                const uint4 cl = CUR[pl_];
+                oldw_l = sel4(al, kl_);
+                const uint32_t rol = oldw_l >> 16;
+                const bool leadl = kl_ == 0;
+                g_old_l = role_w2(cl, oldw_l, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
+                const uint32_t co = L.C[oldw_l & 0xFFFFu];
+                dvo_l = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
+                if (leadl) dvo_l += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+                dvr_l = ddec(L.K[rol], T.rack_lo, T.rack_hi) + ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
+                if (lane < T_tour) keyA = make_key(lam, S, dvo_l + min(dvr_l, 0), -g_old_l, lane);
+            }
+            const int wA = (int)(wave_umin(keyA) & 63u);
+            p = __builtin_amdgcn_readlane(pl_, wA);
+            k = __builtin_amdgcn_readlane(kl_, wA);
+            uw = (uint32_t)__builtin_amdgcn_readlane((int)oldw_l, wA);
+            const int g_old = __builtin_amdgcn_readlane(g_old_l, wA);
+            const int dV_old = __builtin_amdgcn_readlane(dvo_l, wA);
+            const int dV_rack_old = __builtin_amdgcn_readlane(dvr_l, wA);
+            const uint4 a = L.A[p];   // same address in every lane: LDS broadcast
+            const uint4 c = CUR[p];
+            const bool lead = k == 0;  // wave-uniform
             const uint32_t ro = uw >> 16;
-            const bool lead = k == 0;
-            const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
-            const int g_old = role_w2(c, uw, wl, wf);
-            const uint32_t co = L.C[uw & 0xFFFFu];
-            int dV_old = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
-            if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
-            const int dV_rack_old = ddec(L.K[ro], T.rack_lo, T.rack_hi) + ddec(cnt4(a, ro), T.prack_lo, T.prack_hi);
-            const int rsz_ro = RSZ[ro];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint32_t r, jj;
-                bool okg;
-                if (g < 2) {
-                    r = rnd24(rng, R8);
-                    jj = rnd24(rng, m8);
-                    okg = (int)jj < RSZ[r];
-                } else {
-                    r = ro;
-                    jj = rnd24(rng, (uint32_t)rsz_ro << 8);
-                    okg = true;
+            if (type == 0) {
+                // ---- phase B (REPLACE): every target broker for slot (p,k), 64 per round ----
+                {   // rack-dependent part of the delta, one rack per lane
+                    int v = 0;
+                    if (lane < T.R && (uint32_t)lane != ro)
+                        v = dV_rack_old + dinc(L.K[lane], T.rack_lo, T.rack_hi) + dinc(cnt4(a, (uint32_t)lane), T.prack_lo, T.prack_hi);
+                    L.RT[lane] = v;
                 }
-                const uint32_t x = __umul24(r, (uint32_t)T.m) + jj;
-                const uint32_t xw = x | (r << 16);
-                okg = okg && !in4(a, xw);
-                const uint32_t cn = L.C[x];
-                int dVg = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi);
-                if (lead) dVg += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
-                if (g < 2) {
-                    if (r != ro)
-                        dVg += dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
+                const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
+                // a displaced current replica (in c, not in a) is the only broker with a non-zero weight here
+                const bool hm_l = (c.x != kNoneW && !in4(a, c.x)) || (c.y != kNoneW && !in4(a, c.y)) ||
+                                  (c.z != kNoneW && !in4(a, c.z)) || (c.w != kNoneW && !in4(a, c.w));
+                const int has_missing = __builtin_amdgcn_readfirstlane((int)hm_l);
+                for (int base = 0; base < T.Bx; base += 64) {
+                    const uint32_t tie = lcg24(rng) >> 8;
+                    const uint32_t x = (uint32_t)(base + lane);
+                    const uint32_t r = XR[x];
+                    const uint32_t xw = x | (r << 16);
+                    const bool okx = (r != 0xFFu) & !in4(a, xw);
+                    const uint32_t cn = L.C[x];
+                    int dVx = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + L.RT[r & 63u];
+                    if (lead) dVx += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+                    int dObjx = -g_old;
+                    if (has_missing) dObjx += role_w2(c, xw, wl, wf);
+                    const uint32_t keyx = okx ? make_key_tie(lam, S, dVx, dObjx, tie) : kKeyNull;
+                    if (keyx < key) { key = keyx; vw = xw; dV = dVx; dObj = dObjx; }
                 }
-                const int dObjg = role_w2(c, xw, wl, wf) - g_old;
-                const uint32_t keyg = okg ? make_key(lam, S, dVg, dObjg, lane) : kKeyNull;
-                if (keyg < key) { key = keyg; vw = xw; dV = dVg; dObj = dObjg; }
-            }
-        } else if (type == 1) {  // EXCHANGE (p,k) <-> (q,j)
-            k = (int)rnd24(rng, RF8);
-            q = (int)rnd24(rng, P8);
-            j = (int)rnd24(rng, RF8);
-            const uint4 b = L.A[q];
-            const uint4 cb = CUR[q];
-            uw = sel4(a, k);
-            vw = sel4(b, j);
-            const bool ok = (p != q) && (uw != vw) && !in4(a, vw) && !in4(b, uw);
-            const int nrp = k != 0, nrq = j != 0;
-            dObj = role_w(T, c, vw, nrp) + role_w(T, cb, uw, nrq) - role_w(T, c, uw, nrp) - role_w(T, cb, vw, nrq);
-            if ((k == 0) != (j == 0)) {
-                const uint32_t lose = (k == 0) ? uw : vw, gain = (k == 0) ? vw : uw;
-                dV += ddec((int)(L.C[lose & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi) +
-                      dinc((int)(L.C[gain & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
-            }
-            const uint32_t ru = uw >> 16, rv = vw >> 16;
-            if (ru != rv) {
-                dV += ddec(cnt4(a, ru), T.prack_lo, T.prack_hi) + dinc(cnt4(a, rv), T.prack_lo, T.prack_hi) +
-                      ddec(cnt4(b, rv), T.prack_lo, T.prack_hi) + dinc(cnt4(b, ru), T.prack_lo, T.prack_hi);
-            }
-            key = ok ? make_key(lam, S, dV, dObj, lane) : kKeyNull;
-        } else {  // LEADER SWAP inside p: slot 0 <-> slot k, every k = 1..RF-1 is a candidate
-            uw = a.x;
-            const int u_lead = role_w2(c, uw, T.w00, T.w10), u_fol = role_w2(c, uw, T.w01, T.w11);
-            const int dV_u = ddec((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+            } else {
+                // ---- phase B (EXCHANGE): every partner slot (q,j) for slot (p,k), 64 partitions per round ----
+                const int nrp = lead ? 0 : 1;
+                const int cnt_a_ru = cnt4(a, ro);
+                const int cu = (int)(L.C[uw & 0xFFFFu] >> 16);
+                for (int base = 0; base < T.P; base += 64) {
+                    const uint32_t tie0 = lcg24(rng) >> 8;
+                    const int qq = base + lane;
+                    const bool okq = qq < T.P && qq != p;
+                    const int qc = min(qq, T.P - 1);
+                    const uint4 b = L.A[qc];
+                    const uint4 cb = CUR[qc];
+                    const bool u_in_b = in4(b, uw);
 #pragma unroll
-            for (int kk = 1; kk < kRFP; ++kk) {
-                if (kk >= T.RF) break;
-                const uint32_t xw = kk == 1 ? a.y : (kk == 2 ? a.z : a.w);
-                const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11);
-                const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
-                const uint32_t keyg = make_key(lam, S, dVg, dObjg, lane);
-                if (keyg < key) { key = keyg; vw = xw; k = kk; dV = dVg; dObj = dObjg; }
+                    for (int jj = 0; jj < kRFP; ++jj) {
+                        if (jj >= T.RF) break;
+                        const uint32_t v = jj == 0 ? b.x : (jj == 1 ? b.y : (jj == 2 ? b.z : b.w));
+                        const bool ok = okq & (v != uw) & !in4(a, v) & !u_in_b;
+                        const int nrq = jj != 0;
+                        const int dObjx = role_w(T, c, v, nrp) + role_w(T, cb, uw, nrq) - g_old - role_w(T, cb, v, nrq);
+                        int dVx = 0;
+                        if (lead != (jj == 0)) {  // wave-uniform: exactly one of the two slots is a leader slot
+                            const int cv = (int)(L.C[v & 0xFFFFu] >> 16);
+                            dVx += lead ? (ddec(cu, T.lead_lo, T.lead_hi) + dinc(cv, T.lead_lo, T.lead_hi))
+                                        : (ddec(cv, T.lead_lo, T.lead_hi) + dinc(cu, T.lead_lo, T.lead_hi));
+                        }
+                        const uint32_t rv = v >> 16;
+                        if (rv != ro)
+                            dVx += ddec(cnt_a_ru, T.prack_lo, T.prack_hi) + dinc(cnt4(a, rv), T.prack_lo, T.prack_hi) +
+                                   ddec(cnt4(b, rv), T.prack_lo, T.prack_hi) + dinc(cnt4(b, ro), T.prack_lo, T.prack_hi);
+                        const uint32_t keyx = ok ? make_key_tie(lam, S, dVx, dObjx, tie0 + (uint32_t)jj * 0x55u) : kKeyNull;
+                        if (keyx < key) { key = keyx; vw = v; q = qq; j = jj; dV = dVx; dObj = dObjx; }
+                    }
+                }
             }
+            kmin = wave_umin(key);
+            const unsigned long long bal = __ballot(key == kmin);
+            win = __ffsll((long long)bal) - 1;  // ties inside the wave go to the lowest lane
         }
-
-        const uint32_t kmin = wave_umin(key);  // wavefront min-scan: best of all lanes' proposals
         if (kmin == kKeyNull) continue;
         if ((int)(kmin >> 8) - kDBias > 0) continue;  // accept only non-worsening moves (cost under current lam)
-        const int win = (int)(kmin & 63u);
 
         if (lane == win) {  // the winning lane applies its own proposal
             uint32_t *ap = reinterpret_cast<uint32_t *>(&L.A[p]);
@@ -605,9 +708,9 @@ __global__ __launch_bounds__(64) void k_gather(const TopicDev *topics, const uns
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t search_lds_bytes(int maxP, int maxBx) {
-    const size_t a = (size_t)maxP * 16, c = ((size_t)maxBx * 4 + 15) & ~(size_t)15;
-    return a + 256 + kWaves * (a + c + 256);
+size_t search_lds_bytes(int maxP, int maxBx, int waves) {
+    const size_t a = (size_t)maxP * 16, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
+    return a + 256 + bx64 + (size_t)waves * (a + bx64 * 4 + 512);
 }
 size_t eval_lds_bytes(int maxP, int maxB) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = ((size_t)maxP * 8 + 15) & ~(size_t)15;
@@ -617,13 +720,13 @@ size_t eval_lds_bytes(int maxP, int maxB) {
 
 static int g_attr_search = 0, g_attr_eval = 0;
 
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, void *stream) {
-    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, void *stream) {
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves);
     if ((int)lds > g_attr_search) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_search = (int)lds;
     }
-    hipLaunchKernelGGL(k_search, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools, prm);
+    hipLaunchKernelGGL(k_search, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools, prm);
 }
 
 void launch_eval(const EvalPools &pools, int n_blocks, void *stream) {

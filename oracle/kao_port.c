@@ -289,7 +289,7 @@ static inline uint32_t make_key(int lam, int S, int dV, int dObj, uint32_t lane)
     return ((uint32_t)(delta + DBIAS) << 8) | lane;
 }
 
-/* One lane's proposals of one iteration: draws from the lane's stream, delta-evaluates every candidate
+/* One lane's proposals of a sampled REPLACE (type 0) or LEADER-SWAP (type 2) iteration: draws from the lane's stream, delta-evaluates every candidate
  * against the current state and returns the lane's smallest key (KEY_NULL if none is valid), with the
  * matching proposal in *o.  Ties inside a lane go to the earlier candidate. */
 static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t *rng, int lam, int S, uint32_t lane,
@@ -325,29 +325,6 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
             if (key < best) { best = key; o->type = 0; o->p = p; o->k = k; o->x = x; o->dV = dV; o->dObj = dObj; }
         }
         return best;
-    }
-    if (type == 1) { /* EXCHANGE (p,k) <-> (q,j) */
-        const int k = (int)rnd24(rng, (uint32_t)RF);
-        const int q = (int)rnd24(rng, (uint32_t)P);
-        const int j = (int)rnd24(rng, (uint32_t)RF);
-        *n_eval += 1;
-        if (p == q) return best;
-        const uint16_t *b = s->A + q * RFP;
-        const unsigned u = a[k], v = b[j];
-        if (u == v || in_part(a, v) || in_part(b, u)) return best;
-        const int nrp = k == 0 ? 0 : 1, nrq = j == 0 ? 0 : 1;
-        const int dObj = role_w(t, p, v, nrp) + role_w(t, q, u, nrq) - role_w(t, p, u, nrp) - role_w(t, q, v, nrq);
-        int dV = 0;
-        if ((k == 0) != (j == 0)) {
-            const unsigned lose = (k == 0) ? u : v, gain = (k == 0) ? v : u;
-            dV += d_band((int)(s->C[lose] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[gain] >> 16), +1, t->lead_lo, t->lead_hi);
-        }
-        const int ru = rack_of_x(t, u), rv = rack_of_x(t, v);
-        if (ru != rv)
-            dV += d_band(rack_count(t, a, ru), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, a, rv), +1, t->prack_lo, t->prack_hi)
-                + d_band(rack_count(t, b, rv), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, b, ru), +1, t->prack_lo, t->prack_hi);
-        o->type = 1; o->p = p; o->k = k; o->q = q; o->j = j; o->dV = dV; o->dObj = dObj;
-        return make_key(lam, S, dV, dObj, lane);
     }
     /* LEADER SWAP inside p: slot 0 <-> slot k, every k = 1..RF-1 is a candidate */
     const unsigned u = a[0];
@@ -386,9 +363,25 @@ static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
     s->V += o->dV; s->obj += o->dObj;
 }
 
-/* run `iters` iterations of launch number `launch` (global iteration = launch*iters + i) */
+/* ---------------------------------------------------------------------------------------------
+ * One launch of KAO-LS.  Move type of iteration `it`: pattern R R X R L R X R.
+ *   REPLACE, blocks of 8 iterations alternate between two styles ((it >> 3) & 1):
+ *     scan   : a tournament over T random slots (lowest "removal score") picks ONE slot (p,k); every
+ *              target broker is then delta-evaluated for it, 64 per round (lane = internal index);
+ *     sample : every lane proposes its own random slot and 4 candidate brokers (ls_lane).
+ *   EXCHANGE : tournament slot (p,k), then every partner slot (q,j) is scanned (lane = partition q).
+ *   LEADER-SWAP : every lane a random partition, all RF-1 swaps (ls_lane).
+ * --------------------------------------------------------------------------------------------- */
+static inline uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t tie) {
+    int delta = lam * dV - S * dObj;
+    if (delta < -DBIAS) delta = -DBIAS;
+    if (delta > DBIAS - 2) delta = DBIAS - 2;
+    return ((uint32_t)(delta + DBIAS) << 8) | (tie & 0xFFu);
+}
+
 static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho, uint32_t launch, uint32_t iters) {
     const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
+    const int P = t->P, RF = t->RF, S = pp->obj_scale;
     uint32_t rng[LANES];
     for (uint32_t l = 0; l < LANES; ++l)
         rng[l] = fmix32(slo ^ fmix32(shi + rho * 0x9E3779B1u + launch * 0x85EBCA77u + l * 0xC2B2AE3Du));
@@ -396,6 +389,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
     if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
     const uint32_t plog = (uint32_t)pp->period_log2 + (rho & 3u);
     const uint32_t pmask = (1u << plog) - 1u;
+    int T = (P * RF) / 4; if (T < 4) T = 4; if (T > LANES) T = LANES; /* tournament size */
     for (uint32_t i = 0; i < iters; ++i) {
         const uint32_t it = launch * iters + i;
         const int type = move_type(it);
@@ -403,15 +397,99 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
         int lam = pp->lam_min + (int)((2u * ph * (uint32_t)(pp->lam_max - pp->lam_min + 1)) >> plog);
         if (lam > pp->lam_max) lam = pp->lam_max;
         uint32_t best_key = KEY_NULL;
-        proposal best_prop; memset(&best_prop, 0, sizeof best_prop);
-        for (uint32_t l = 0; l < LANES; ++l) {
-            proposal o; memset(&o, 0, sizeof o);
-            const uint32_t key = ls_lane(t, s, type, &rng[l], lam, pp->obj_scale, l, &o, &s->n_eval);
-            if (key < best_key) { best_key = key; best_prop = o; }
+        proposal bp; memset(&bp, 0, sizeof bp);
+        if (type == 2 || (type == 0 && ((it >> 3) & 1))) { /* per-lane proposals: LEADER SWAP, sampled REPLACE */
+            for (uint32_t l = 0; l < LANES; ++l) {
+                proposal o; memset(&o, 0, sizeof o);
+                const uint32_t key = ls_lane(t, s, type, &rng[l], lam, S, l, &o, &s->n_eval);
+                if (key < best_key) { best_key = key; bp = o; }
+            }
+        } else {
+            /* ---- phase A: tournament over T random slots, lowest removal score wins ---- */
+            uint32_t keyA = KEY_NULL; int p = 0, k = 0;
+            for (uint32_t l = 0; l < LANES; ++l) {
+                const int pl = (int)rnd24(&rng[l], (uint32_t)P);
+                const int kl = (int)rnd24(&rng[l], (uint32_t)RF);
+                if ((int)l >= T) continue;
+                const uint16_t *al = s->A + pl * RFP;
+                const unsigned old = al[kl];
+                const int ro = rack_of_x(t, old);
+                const uint32_t co = s->C[old];
+                int dvo = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
+                if (kl == 0) dvo += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
+                const int dvr = d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, al, ro), -1, t->prack_lo, t->prack_hi);
+                const uint32_t key = make_key(lam, S, dvo + (dvr < 0 ? dvr : 0), -role_w(t, pl, old, kl == 0 ? 0 : 1), l);
+                if (key < keyA) { keyA = key; p = pl; k = kl; }
+            }
+            const uint16_t *a = s->A + p * RFP;
+            const unsigned old = a[k];
+            const int nr = k == 0 ? 0 : 1;
+            if (type == 0) { /* ---- phase B: scan every target broker for slot (p,k) ---- */
+                const int ro = rack_of_x(t, old);
+                const int g_old = role_w(t, p, old, nr);
+                const uint32_t co = s->C[old];
+                int dV_old = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
+                if (k == 0) dV_old += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
+                const int dV_rack_old = d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, ro), -1, t->prack_lo, t->prack_hi);
+                int RT[64];
+                for (int r = 0; r < t->R; ++r)
+                    RT[r] = (r == ro) ? 0 : dV_rack_old + d_band(s->K[r], +1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, r), +1, t->prack_lo, t->prack_hi);
+                uint32_t lane_key[LANES]; unsigned lane_x[LANES]; int lane_dV[LANES], lane_dO[LANES];
+                for (uint32_t l = 0; l < LANES; ++l) lane_key[l] = KEY_NULL;
+                for (int base = 0; base < t->Bx; base += LANES)
+                    for (uint32_t l = 0; l < LANES; ++l) {
+                        const uint32_t tie = lcg24(&rng[l]) >> 8;
+                        const unsigned x = (unsigned)base + l;
+                        if ((int)x >= t->Bx || !valid_x(t, x)) continue;
+                        s->n_eval += 1;
+                        if (in_part(a, x)) continue;
+                        const uint32_t cn = s->C[x];
+                        int dV = dV_old + d_band((int)(cn & 0xFFFF), +1, t->rep_lo, t->rep_hi) + RT[rack_of_x(t, x)];
+                        if (k == 0) dV += d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
+                        const int dObj = role_w(t, p, x, nr) - g_old;
+                        const uint32_t key = make_key_tie(lam, S, dV, dObj, tie);
+                        if (key < lane_key[l]) { lane_key[l] = key; lane_x[l] = x; lane_dV[l] = dV; lane_dO[l] = dObj; }
+                    }
+                for (uint32_t l = 0; l < LANES; ++l)
+                    if (lane_key[l] < best_key) { best_key = lane_key[l]; bp.type = 0; bp.p = p; bp.k = k; bp.x = lane_x[l]; bp.dV = lane_dV[l]; bp.dObj = lane_dO[l]; }
+            } else { /* ---- phase B: scan every partner slot (q,j) for an exchange with (p,k) ---- */
+                const unsigned u = old;
+                const int ru = rack_of_x(t, u);
+                const int gu_p = role_w(t, p, u, nr);
+                uint32_t lane_key[LANES]; int lane_q[LANES], lane_j[LANES], lane_dV[LANES], lane_dO[LANES];
+                for (uint32_t l = 0; l < LANES; ++l) lane_key[l] = KEY_NULL;
+                for (int base = 0; base < P; base += LANES)
+                    for (uint32_t l = 0; l < LANES; ++l) {
+                        const uint32_t tie0 = lcg24(&rng[l]) >> 8;
+                        const int q = base + (int)l;
+                        if (q >= P) continue;
+                        const uint16_t *b = s->A + q * RFP;
+                        for (int j = 0; j < RF; ++j) {
+                            s->n_eval += 1;
+                            const unsigned v = b[j];
+                            if (q == p || u == v || in_part(a, v) || in_part(b, u)) continue;
+                            const int nrq = j == 0 ? 0 : 1;
+                            const int dObj = role_w(t, p, v, nr) + role_w(t, q, u, nrq) - gu_p - role_w(t, q, v, nrq);
+                            int dV = 0;
+                            if ((k == 0) != (j == 0)) {
+                                const unsigned lose = (k == 0) ? u : v, gain = (k == 0) ? v : u;
+                                dV += d_band((int)(s->C[lose] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[gain] >> 16), +1, t->lead_lo, t->lead_hi);
+                            }
+                            const int rv = rack_of_x(t, v);
+                            if (ru != rv)
+                                dV += d_band(rack_count(t, a, ru), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, a, rv), +1, t->prack_lo, t->prack_hi)
+                                    + d_band(rack_count(t, b, rv), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, b, ru), +1, t->prack_lo, t->prack_hi);
+                            const uint32_t key = make_key_tie(lam, S, dV, dObj, tie0 + (uint32_t)j * 0x55u);
+                            if (key < lane_key[l]) { lane_key[l] = key; lane_q[l] = q; lane_j[l] = j; lane_dV[l] = dV; lane_dO[l] = dObj; }
+                        }
+                    }
+                for (uint32_t l = 0; l < LANES; ++l)
+                    if (lane_key[l] < best_key) { best_key = lane_key[l]; bp.type = 1; bp.p = p; bp.k = k; bp.q = lane_q[l]; bp.j = lane_j[l]; bp.dV = lane_dV[l]; bp.dObj = lane_dO[l]; }
+            }
         }
         if (best_key == KEY_NULL) continue;
-        if ((int)(best_key >> 8) - DBIAS > 0) continue; /* accept only non-worsening moves under the current lam */
-        ls_apply(t, s, &best_prop);
+        if ((int)(best_key >> 8) - DBIAS > 0) continue;
+        ls_apply(t, s, &bp);
         s->n_accept++;
         if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
     }
