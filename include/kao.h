@@ -90,7 +90,7 @@ typedef struct kao_result {
     int32_t status;            /* KAO_STATUS_* */
     int32_t best_restart;      /* which restart produced the answer */
     int64_t objective;         /* value of the README objective (README.md:145-146) */
-    int64_t upper_bound;       /* combinatorial bound (coupling constraints ignored) */
+    int64_t upper_bound;       /* combinatorial bound (kao_upper_bound) */
     int32_t violations[8];     /* [0] total, [1..7] = C1..C7 magnitudes of the returned assignment */
     double seconds_to_best;    /* wall time from entry to the launch that produced `objective` */
     uint16_t *assignment;      /* [P*rf] caller-allocated; dense broker index, slot 0 = leader */
@@ -128,7 +128,8 @@ int kao_device_name(char *buf, int len);
 /* Fill the derived band values (out[0..7] = rep_lo,rep_hi,lead_lo,lead_hi,rack_lo,rack_hi,
  * prack_lo,prack_hi), honouring overrides >= 0.  README.md:158-180. */
 int kao_derive_bounds(const kao_topic *t, int32_t out[8]);
-/* Upper bound on the objective with every coupling row (C3,C4,C6,C7) dropped. */
+/* Upper bound on the objective: every partition keeps its best surviving replicas (coupling rows dropped),
+ * minus the cheapest way to perform the evictions / leader changes the bands force (kao_api.cpp). */
 int kao_upper_bound(const kao_topic *t, int64_t *ub);
 /* Canonical tie-break among equal-objective feasible assignments (lowest broker index for newly
  * placed replicas, retained followers keep their order): reproduces README.md:88 `[8,1]`.

@@ -124,10 +124,10 @@ int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
     return KAO_OK;
 }
 
-int64_t upper_bound(const kao_topic *t) {
-    // each partition keeps its best surviving replicas in their best roles; coupling rows dropped
-    int64_t total = 0;
-    const int B = t->n_brokers, slots = t->rf - 1;
+// Best value one partition can collect from a kept set: its current leader (if kept) and n_fol kept current
+// followers, at most rf replicas, exactly one leader; coupling rows (C3, C4, C6, C7) ignored.
+int64_t partition_value(const kao_topic *t, bool lead_kept, int n_fol, bool leader_may_lead = true) {
+    const int slots = t->rf - 1;
     const int wLL = t->w[0][0], wLF = t->w[0][1], wFL = t->w[1][0], wFF = t->w[1][1];
     auto fol_sum = [&](int n_ff, bool old_leader) {  // best `slots` follower gains among n_ff x wFF (+ wLF)
         int64_t v = 0;
@@ -135,21 +135,105 @@ int64_t upper_bound(const kao_topic *t) {
         const bool lf_first = old_leader && wLF > wFF;
         if (lf_first && left > 0 && wLF > 0) { v += wLF; --left; }
         const int take = std::min(left, n_ff);
-        if (wFF > 0) { v += (int64_t)take * wFF; left -= take; }
+        if (wFF > 0 && take > 0) { v += (int64_t)take * wFF; left -= take; }
         if (old_leader && !lf_first && left > 0 && wLF > 0) v += wLF;
         return v;
     };
-    for (int p = 0; p < t->n_partitions; ++p) {
+    int64_t best = fol_sum(n_fol, lead_kept);                                         // a new broker leads
+    if (lead_kept && leader_may_lead) best = std::max(best, wLL + fol_sum(n_fol, false));  // current leader stays leader
+    if (n_fol) best = std::max(best, wFL + fol_sum(n_fol - 1, lead_kept));            // a current follower is promoted
+    return best;
+}
+
+// Upper bound on the objective (kao_upper_bound): every partition keeps its best surviving replicas in
+// their best roles, minus the cheapest way to perform the evictions / leader changes that EVERY feasible
+// assignment must perform.  f_p(K) = partition_value of a kept subset K.  With s_b / s_r / s_(p,r) the
+// surviving replicas per broker / rack / (partition, rack) cell, at least
+//   k = max( sum_b (s_b - rep_hi)+, sum_r (s_r - rack_hi)+, sum_cells (s - prack_hi)+,
+//            n_surv + sum_b (rep_lo - s_b)+ - P*RF,  n_surv + sum_r (rack_lo - s_r)+ - P*RF )
+// replicas cannot be kept (one eviction lowers one broker, one rack and one cell count; lower bands need
+// arrivals and only P*RF - kept slots can take them).  g_p(j) = f_p(all) - max_{|K| = n_p - j} f_p(K); the
+// total loss is at least the k smallest marginals of the lower convex envelopes of the g_p.  Brokers with
+// more current leaders than lead_hi force leader changes, each costing f_p(all) - f_p(leader not leading).
+// Both losses may hit the same partitions, so the larger is subtracted.  Restated (and checked against the
+// exact optimum) in oracle/kao_oracle.py::upper_bound_forced.
+int64_t upper_bound(const kao_topic *t) {
+    const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    const int rep_lo = bd[0], rep_hi = bd[1], lead_hi = bd[3], rack_lo = bd[4], rack_hi = bd[5], prack_hi = bd[7];
+    std::vector<int> s_b((size_t)B, 0), s_r((size_t)R, 0), lead_b((size_t)B, 0);
+    std::vector<int64_t> marginals;
+    std::vector<std::pair<int, int64_t>> lead_losses;  // (broker, loss if this partition's leader stops leading)
+    int64_t total = 0, n_surv = 0, cell_excess = 0;
+    for (int p = 0; p < P; ++p) {
         const uint16_t *c = t->current + (size_t)p * t->rf_cur;
         const bool lead_alive = c[0] < (unsigned)B;
-        int n_fol = 0;
-        for (int k = 1; k < t->rf_cur; ++k) n_fol += c[k] < (unsigned)B;
-        int64_t best = fol_sum(n_fol, lead_alive);                               // a new broker leads
-        if (lead_alive) best = std::max(best, wLL + fol_sum(n_fol, false));      // the current leader stays leader
-        if (n_fol) best = std::max(best, wFL + fol_sum(n_fol - 1, lead_alive));  // a current follower is promoted
-        total += best;
+        int n_fol = 0, racks[KAO_MAX_RF], n_in = 0;
+        for (int k = 0; k < t->rf_cur; ++k) {
+            if (c[k] >= (unsigned)B) continue;
+            if (k > 0) ++n_fol;
+            s_b[c[k]]++;
+            s_r[t->rack_of[c[k]]]++;
+            racks[n_in++] = t->rack_of[c[k]];
+        }
+        const int n_p = n_fol + (lead_alive ? 1 : 0);
+        n_surv += n_p;
+        for (int i = 0; i < n_in; ++i) {  // cells: count each rack once
+            bool first = true;
+            int cnt = 0;
+            for (int j = 0; j < n_in; ++j) { if (racks[j] == racks[i]) { ++cnt; if (j < i) first = false; } }
+            if (first) cell_excess += std::max(0, cnt - prack_hi);
+        }
+        const int64_t f_all = partition_value(t, lead_alive, n_fol);
+        total += f_all;
+        int64_t g[KAO_MAX_RF + 1];
+        for (int j = 0; j <= n_p; ++j) {  // cheapest loss of evicting j replicas (followers are interchangeable)
+            int64_t best = -1;
+            for (int drop_lead = 0; drop_lead <= (lead_alive ? 1 : 0); ++drop_lead) {
+                const int df = j - drop_lead;
+                if (df >= 0 && df <= n_fol) best = std::max(best, partition_value(t, lead_alive && !drop_lead, n_fol - df));
+            }
+            g[j] = f_all - best;
+        }
+        int hx[KAO_MAX_RF + 1]; int64_t hy[KAO_MAX_RF + 1]; int hn = 0;  // lower convex envelope of (j, g[j])
+        for (int j = 0; j <= n_p; ++j) {
+            hx[hn] = j; hy[hn] = g[j]; ++hn;
+            while (hn >= 3 && (hy[hn - 2] - hy[hn - 3]) * (hx[hn - 1] - hx[hn - 3]) >= (hy[hn - 1] - hy[hn - 3]) * (hx[hn - 2] - hx[hn - 3])) {
+                hx[hn - 2] = hx[hn - 1]; hy[hn - 2] = hy[hn - 1]; --hn;
+            }
+        }
+        for (int i = 0; i + 1 < hn; ++i)
+            for (int x = hx[i] + 1; x <= hx[i + 1]; ++x) {  // integer floor of the envelope stays a lower bound
+                const int64_t dy = hy[i + 1] - hy[i], dx = hx[i + 1] - hx[i];
+                const int64_t prev = hy[i] + (dy * (x - 1 - hx[i])) / dx, now = hy[i] + (dy * (x - hx[i])) / dx;
+                marginals.push_back(now - prev);
+            }
+        if (lead_alive) {
+            lead_b[c[0]]++;
+            const int64_t alt = std::max(partition_value(t, false, n_fol), partition_value(t, true, n_fol, false));
+            lead_losses.emplace_back((int)c[0], std::max<int64_t>(0, f_all - alt));
+        }
     }
-    return total;
+    int64_t ex_b = 0, ex_r = 0, need_b = 0, need_r = 0;
+    for (int b = 0; b < B; ++b) { ex_b += std::max(0, s_b[b] - rep_hi); need_b += std::max(0, rep_lo - s_b[b]); }
+    for (int r = 0; r < R; ++r) { ex_r += std::max(0, s_r[r] - rack_hi); need_r += std::max(0, rack_lo - s_r[r]); }
+    const int64_t slots = (int64_t)P * RF;
+    int64_t k = std::max<int64_t>({ex_b, ex_r, cell_excess, n_surv + need_b - slots, n_surv + need_r - slots, 0});
+    k = std::min<int64_t>(k, (int64_t)marginals.size());
+    std::sort(marginals.begin(), marginals.end());
+    int64_t evict_loss = 0;
+    for (int64_t i = 0; i < k; ++i) evict_loss += marginals[(size_t)i];
+    int64_t lead_loss = 0;
+    std::sort(lead_losses.begin(), lead_losses.end());
+    for (size_t i = 0; i < lead_losses.size();) {
+        size_t j = i;
+        while (j < lead_losses.size() && lead_losses[j].first == lead_losses[i].first) ++j;
+        const int ex = lead_b[(size_t)lead_losses[i].first] - lead_hi;
+        for (size_t q = i; q < j && (int)(q - i) < ex; ++q) lead_loss += lead_losses[q].second;  // sorted by loss within a broker
+        i = j;
+    }
+    return total - std::max(evict_loss, lead_loss);
 }
 
 // Neighbours delta-evaluated by ONE restart over iterations [it0, it0+iters) (kao_kernels.hip, KAO-LS):

@@ -784,3 +784,109 @@ if __name__ == "__main__":
     r = solve_exact(t)
     print(r.status, r.objective, count_moves(t, r.assign), r.seconds)
     print(json.dumps(assignment_to_json([t], [canonicalize(t, r.assign)])))
+
+
+def _partition_value(w, rf: int, lead_kept: bool, n_fol: int, leader_may_lead: bool = True) -> int:
+    """Best objective one partition can collect from a kept set: its current leader (if kept) and n_fol
+    kept current followers, at most rf replicas, exactly one leader (coupling rows ignored).  With
+    leader_may_lead=False the current leader may only stay as a follower."""
+    slots = rf - 1
+
+    def fol_sum(n_ff: int, old_leader: bool) -> int:
+        gains = [w[1][1]] * n_ff + ([w[0][1]] if old_leader else [])
+        gains.sort(reverse=True)
+        return sum(g for g in gains[:slots] if g > 0)
+
+    best = fol_sum(n_fol, lead_kept)  # a new broker leads
+    if lead_kept and leader_may_lead:
+        best = max(best, w[0][0] + fol_sum(n_fol, False))
+    if n_fol:
+        best = max(best, w[1][0] + fol_sum(n_fol - 1, lead_kept))
+    return best
+
+
+def upper_bound_forced(topic: Topic) -> int:
+    """Tighter combinatorial bound = upper_bound_simple minus the cheapest way to perform the evictions
+    (and leader changes) that EVERY feasible assignment must perform.
+
+    f_p(K) = best value partition p can collect from a kept subset K of its surviving current replicas
+    (_partition_value).  Any assignment keeps some K_p per partition and scores at most sum_p f_p(K_p).
+      * evictions: with s_b / s_r / s_(p,r) the surviving replicas per broker / rack / (partition, rack)
+        cell, at least k = max(sum_b (s_b - rep_hi)+, sum_r (s_r - rack_hi)+, sum_cells (s - prack_hi)+,
+        n_surv + sum_b (rep_lo - s_b)+ - P*RF, n_surv + sum_r (rack_lo - s_r)+ - P*RF) replicas cannot be
+        kept (one eviction lowers one broker, one rack and one cell count by one; lower bands need arrivals,
+        and only P*RF - kept slots can take them).  g_p(j) = f_p(all) - max_{|K| = n_p - j} f_p(K) is the
+        cheapest loss of evicting j replicas of p; relaxing "which replicas" to "any", the total loss is
+        at least the minimum of sum_p g_p(j_p) over sum_p j_p >= k, bounded below by the k smallest
+        marginals of the lower convex envelopes of the g_p.
+      * leader changes: brokers holding more current leaders than lead_hi force that many partitions to
+        change leader; each costs at least f_p(all) - f_p(all, current leader not leading).
+    The two losses may fall on the same partitions, so the larger one is subtracted."""
+    B, R, P, RF = topic.n_brokers, topic.n_racks, topic.n_partitions, topic.rf
+    w = topic.weights
+    bd = topic.bounds()
+    rack = [int(r) for r in topic.rack_of]
+    s_b = [0] * B
+    s_r = [0] * R
+    lead_b = [0] * B
+    cell_excess = 0
+    n_surv = 0
+    total = 0
+    marginals: List[int] = []
+    lead_losses: List[Tuple[int, int]] = []  # (broker, loss if this partition's leader stops leading)
+    for p in range(P):
+        cur = [int(v) for v in topic.current[p]]
+        lead_alive = cur[0] != NONE
+        fol = [b for b in cur[1:] if b != NONE]
+        n_p = len(fol) + (1 if lead_alive else 0)
+        n_surv += n_p
+        cell: Dict[int, int] = {}
+        for b in fol + ([cur[0]] if lead_alive else []):
+            s_b[b] += 1
+            s_r[rack[b]] += 1
+            cell[rack[b]] = cell.get(rack[b], 0) + 1
+        cell_excess += sum(max(0, c - bd["prack_hi"]) for c in cell.values())
+        f_all = _partition_value(w, RF, lead_alive, len(fol))
+        total += f_all
+        # g_p(j): cheapest loss of evicting j replicas (followers are interchangeable)
+        g = []
+        for j in range(n_p + 1):
+            best = -1
+            for drop_lead in ((False, True) if lead_alive else (False,)):
+                df = j - (1 if drop_lead else 0)
+                if 0 <= df <= len(fol):
+                    best = max(best, _partition_value(w, RF, lead_alive and not drop_lead, len(fol) - df))
+            g.append(f_all - best)
+        # lower convex envelope of (j, g[j]) -> non-decreasing marginals
+        hull = [(0, g[0])]
+        for j in range(1, n_p + 1):
+            hull.append((j, g[j]))
+            while len(hull) >= 3:
+                (x0, y0), (x1, y1), (x2, y2) = hull[-3], hull[-2], hull[-1]
+                if (y1 - y0) * (x2 - x0) >= (y2 - y0) * (x1 - x0):  # middle point on or above the chord
+                    hull.pop(-2)
+                else:
+                    break
+        for (x0, y0), (x1, y1) in zip(hull, hull[1:]):
+            # integer-valued relaxation of the envelope: floor of the running total keeps it a lower bound
+            for t in range(x0 + 1, x1 + 1):
+                lo_prev = y0 + ((y1 - y0) * (t - 1 - x0)) // (x1 - x0)
+                lo_now = y0 + ((y1 - y0) * (t - x0)) // (x1 - x0)
+                marginals.append(lo_now - lo_prev)
+        if lead_alive:
+            lead_b[cur[0]] += 1
+            # value when the current leader may stay only as a follower, or leaves
+            alt = max(_partition_value(w, RF, False, len(fol)), _partition_value(w, RF, True, len(fol), leader_may_lead=False))
+            lead_losses.append((cur[0], max(0, f_all - alt)))
+    need_b = sum(max(0, bd["rep_lo"] - c) for c in s_b)
+    need_r = sum(max(0, bd["rack_lo"] - c) for c in s_r)
+    k = max(sum(max(0, c - bd["rep_hi"]) for c in s_b), sum(max(0, c - bd["rack_hi"]) for c in s_r), cell_excess,
+            n_surv + need_b - P * RF, n_surv + need_r - P * RF, 0)
+    marginals.sort()
+    evict_loss = sum(marginals[:k])
+    lead_loss = 0
+    for b in range(B):
+        ex = lead_b[b] - bd["lead_hi"]
+        if ex > 0:
+            lead_loss += sum(sorted(l for bb, l in lead_losses if bb == b)[:ex])
+    return total - max(evict_loss, lead_loss)

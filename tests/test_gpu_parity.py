@@ -236,6 +236,7 @@ def test_golden_optima_configs(kao, ko, name):
                     time_limit_s=30.0)
     for e, ot, r in zip(g["topics"], ots, res):
         assert r.objective == e["objective"], (name, r.objective, e["objective"], r.status)
+        assert r.status == "OPTIMAL_PROVEN" and r.upper_bound == e["objective"]  # the bound certificate is tight here
         obj, viol = ko.verify(ot, r.assignment)
         assert viol[0] == 0 and obj == e["objective"]
         assert ko.count_moves(ot, r.assignment)[0] == e["moves"][0]

@@ -145,3 +145,25 @@ def test_infeasible_instance_detected(ko, kp):
     assert ko.solve_exact(t, 60).status == "infeasible"
     r = kp.port_search(t, 1, 0, 1, 2000)
     assert r["best_obj"] == -1
+
+
+def test_upper_bound_is_valid_and_often_tight(ko):
+    """upper_bound_forced (restated by the library's kao_upper_bound) never undercuts the exact optimum and
+    closes the gap on BASELINE config 3, where the simple bound is loose (2 forced moves per topic)."""
+    n = tight = 0
+    for name in ("cfg2.json", "cfg3.json", "cfg4.json"):
+        for e in load_golden(name)["topics"]:
+            t = ko.topic_from_dict(e["topic"])
+            ub = ko.upper_bound_forced(t)
+            assert e["objective"] <= ub <= ko.upper_bound_simple(t)
+            if name == "cfg3.json":
+                assert ub == e["objective"] < ko.upper_bound_simple(t)
+    for c in load_golden("random_small.json")["cases"]:
+        if c["status"] != "optimal":
+            continue
+        t = ko.topic_from_dict(c["topic"])
+        ub = ko.upper_bound_forced(t)
+        assert c["objective"] <= ub <= ko.upper_bound_simple(t), c["seed"]
+        n += 1
+        tight += ub == c["objective"]
+    assert tight >= n // 2
