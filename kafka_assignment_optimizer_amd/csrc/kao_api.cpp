@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -94,6 +95,7 @@ int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
     for (int b = 0; b < B; ++b) pt.rack_size[t->rack_of[b]]++;
     int m = 0;
     for (int r = 0; r < R; ++r) m = std::max(m, pt.rack_size[r]);
+    m = std::max(m, 2);  // floor(2^32/m)+1 must fit 32 bits: single-broker racks get a stride of 2
     const int64_t Bx = (int64_t)R * m;
     if (Bx > 65534) return fail(KAO_ERR_UNSUPPORTED, "racks x largest-rack exceeds the 16-bit internal index");
     pt.int_of.assign(B, 0);
@@ -357,8 +359,10 @@ constexpr int kEvRing = 32;
 struct Parked { void *p; size_t bytes; };
 std::vector<Parked> g_parked;
 constexpr size_t kParkMax = 4;
+std::mutex g_cache_mu;  // guards g_parked / g_streams (sessions may be created from several host threads)
 
 int arena_get(size_t bytes, void **out, size_t *cap) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     size_t best = g_parked.size();
     for (size_t i = 0; i < g_parked.size(); ++i)
         if (g_parked[i].bytes >= bytes && g_parked[i].bytes <= 4 * bytes + (1u << 20) &&
@@ -375,6 +379,7 @@ int arena_get(size_t bytes, void **out, size_t *cap) {
 }
 void arena_put(void *p, size_t bytes) {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     if (g_parked.size() >= kParkMax) {
         size_t small = 0;
         for (size_t i = 1; i < g_parked.size(); ++i) if (g_parked[i].bytes < g_parked[small].bytes) small = i;
@@ -386,15 +391,18 @@ void arena_put(void *p, size_t bytes) {
 }
 std::vector<hipStream_t> g_streams;  // parked streams (create/destroy cost ~1 ms)
 int stream_get(hipStream_t *out) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     if (!g_streams.empty()) { *out = g_streams.back(); g_streams.pop_back(); return KAO_OK; }
     HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
     return KAO_OK;
 }
 void stream_put(hipStream_t st) {
     if (!st) return;
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     if (g_streams.size() < 4) g_streams.push_back(st); else (void)hipStreamDestroy(st);
 }
 void arena_drop_all() {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
     for (auto &a : g_parked) (void)hipFree(a.p);
     g_parked.clear();
     for (hipStream_t st : g_streams) (void)hipStreamDestroy(st);
@@ -451,6 +459,7 @@ int kao_init(int device) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(KAO_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(KAO_ERR_INVALID, "device ordinal out of range");
+    if (g_init && device != g_device) { (void)hipSetDevice(g_device); arena_drop_all(); }  // parked memory belongs to the old device
     e = hipSetDevice(device);
     if (e != hipSuccess) return fail(KAO_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
     hipDeviceProp_t prop;

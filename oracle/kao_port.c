@@ -147,6 +147,7 @@ void *kao_port_ls_create(const port_topic *pt) {
     if (t->RF > RFP || pt->rf_cur > RFP || t->R > 64) { free(t); return NULL; }
     for (int b = 0; b < B; ++b) t->rack_size[pt->rack_of[b]] += 1;
     for (int r = 0; r < t->R; ++r) if (t->rack_size[r] > t->m) t->m = t->rack_size[r];
+    if (t->m < 2) t->m = 2; /* floor(2^32/m)+1 must fit 32 bits: single-broker racks get a stride of 2 */
     t->Bx = t->R * t->m;
     t->magic = (uint32_t)(0x100000000ull / (uint64_t)t->m) + 1u;
     t->int_of = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B);

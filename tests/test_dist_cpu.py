@@ -4,7 +4,6 @@ import os
 import socket
 
 import numpy as np
-import pytest
 
 from kafka_assignment_optimizer_amd import multigpu as mg
 

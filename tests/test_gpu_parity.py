@@ -155,6 +155,65 @@ def test_search_replay_varied_shapes(kao, ko, kp):
             assert viol[0] == 0 and obj == r.objective, ot.name
 
 
+def test_empty_and_degenerate_inputs(kao, ko):
+    import ctypes as C
+    from kafka_assignment_optimizer_amd import _ffi
+    lib = _ffi.load()
+    h = C.c_void_p()
+    assert lib.kao_session_create(None, 0, None, C.byref(h)) == -1          # no topics
+    pt = to_product_topic(ko.readme_example())
+    with pytest.raises(ValueError):
+        kao.evaluate(pt, pt.current[:3])                                     # ragged candidate
+    one = ko.make_cluster("one", 3, 1, 1, 1, 1, [], []).topics[0]            # 1 partition, RF 1, 1 rack
+    r = kao.solve([to_product_topic(one)], max_launches=2, restarts=4, iters_per_launch=16)[0]
+    assert r.status == "OPTIMAL_PROVEN" and r.assignment.tolist() == one.current.tolist()
+    full = ko.make_cluster("full", 3, 3, 1, 5, 3, [], []).topics[0]          # RF == B: every broker in every partition
+    r = kao.solve([to_product_topic(full)], max_launches=4, restarts=4, iters_per_launch=64)[0]
+    obj, viol = ko.verify(full, r.assignment)
+    assert viol[0] == 0 and obj == r.objective == ko.solve_exact(full).objective
+
+
+def test_device_bookkeeping_matches_verifier_on_edge_shapes(kao, ko):
+    """Device restarts' tracked (objective, violation) equal the independent numpy verifier of their final
+    state on structured edge shapes (single-broker racks, one rack, RF 1, RF = B - 1, tiny P)."""
+    import itertools
+    ots = []
+    for B0, R, P, rf in itertools.product((2, 3, 4, 5, 7), (1, 2, 3, 4, 5), (1, 2, 5), (1, 2, 3)):
+        if rf < B0 and R <= B0:
+            ots.append(ko.make_cluster("e", B0, R, 1, P, rf, [], []).topics[0])
+    with kao.Session([to_product_topic(t) for t in ots], seed=11, restarts=4, iters_per_launch=40) as s:
+        s.step(2)
+        assert s.stats()["drift"] == 0
+        for ti, ot in enumerate(ots):
+            st = s.restart_state(ti, ti % 4)
+            obj, viol = ko.verify(ot, st["final"])
+            assert (obj, int(viol[0])) == (st["obj"], st["V"]), (ti, ot.n_brokers, ot.n_racks, ot.n_partitions, ot.rf)
+        for ot, r in zip(ots, s.best()):
+            if r.status != "NO_FEASIBLE":
+                obj, viol = ko.verify(ot, r.assignment)
+                assert viol[0] == 0 and obj == r.objective
+
+
+def test_maximum_size_topic(kao, ko, kp):
+    """Near the LDS limit: 4800 partitions x RF 3 = 14400 replicas on 40 brokers, one restart per workgroup."""
+    ot = ko.make_cluster("max", 40, 4, 1, 4800, 3, [5], [(40, 1)]).topics[0]
+    pt = to_product_topic(ot)
+    cands = random_candidates(ot, 6, seed=3)
+    obj, viol = kao.evaluate_batch(pt, cands)
+    for i in range(len(cands)):
+        o, v = kp.port_eval(ot, cands[i])
+        assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist())
+    seed = 7
+    with kao.Session([pt], seed=seed, restarts=4, iters_per_launch=48) as s:
+        assert s.stats()["blocks_search"] == 4  # 1 wave per workgroup
+        s.step(1)
+        assert s.stats()["drift"] == 0
+        dev = s.restart_state(0, 2)
+        ref = kp.port_search(ot, seed ^ 0x9E3779B97F4A7C15, 2, 1, 48)
+        assert dev["final"].tolist() == ref["final"].tolist()
+        assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
+
+
 def test_unsupported_instances_are_rejected(kao, ko):
     ot = ko.make_cluster("big", 100, 4, 1, 11000, 3, [], []).topics[0]
     with pytest.raises(kao.KaoError) as e:

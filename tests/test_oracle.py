@@ -167,3 +167,22 @@ def test_upper_bound_is_valid_and_often_tight(ko):
         n += 1
         tight += ub == c["objective"]
     assert tight >= n // 2
+
+
+def test_port_bookkeeping_matches_verifier_on_edge_shapes(ko, kp):
+    """The replay's incremental (objective, violation) equals the independent numpy verifier on structured
+    edge shapes: single-broker racks (rack stride padding), one rack, RF 1, RF = B - 1, tiny P."""
+    import itertools
+    n = 0
+    for B0, R, P, rf in itertools.product((2, 3, 4, 5, 7), (1, 2, 3, 4, 5), (1, 2, 5), (1, 2, 3)):
+        if rf >= B0 or R > B0:
+            continue
+        t = ko.make_cluster("e", B0, R, 1, P, rf, [], []).topics[0]
+        r = kp.port_search(t, 3, 0, 1, 32)
+        obj, viol = ko.verify(t, r["final"])
+        assert (obj, int(viol[0])) == (r["obj"], r["V"]), (B0, R, P, rf)
+        n += 1
+    assert n > 80
+    full = ko.make_cluster("full", 3, 3, 1, 5, 3, [], []).topics[0]  # RF == B, every rack a single broker
+    r = kp.port_search(full, 1, 0, 1, 16)
+    assert (r["best_obj"], r["V"]) == (40, 0)
