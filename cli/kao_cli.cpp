@@ -9,6 +9,9 @@
 //
 //   kao-cli --current cur.json --broker-list 0,1,2 --racks racks.json [--rf N] [--weights 4,1,2,2]
 //           [--seed S] [--time-limit SEC] [--device D] [--no-canonical] [--out out.json] [--report]
+//           [--emit-lp PREFIX [--lp-only]]
+// --emit-lp writes the generated 0-1 model of every topic as lp_solve LP text (README.md:144-185) to
+// PREFIX<topic#>.lp -- no GPU needed -- so the answer can be cross-checked with real lp_solve 5.5.
 #include <algorithm>
 #include <cctype>
 #include <cstdio>
@@ -123,8 +126,61 @@ struct TopicData {
     std::fprintf(stderr,
         "usage: kao-cli --current <reassignment.json|-> --broker-list <id,id,...> --racks <racks.json | id:rack,...>\n"
         "               [--rf N] [--weights LL,LF,FL,FF] [--seed S] [--time-limit SEC] [--device D]\n"
-        "               [--no-canonical] [--out <file>] [--report]\n");
+        "               [--no-canonical] [--out <file>] [--report] [--emit-lp <prefix> [--lp-only]]\n");
     std::exit(2);
+}
+
+// lp_solve LP-format text of one topic's model (README.md:144-185): `max:` objective over the current
+// placements, rows C1..C7 in README order, `bin` section in the declared variable order broker-major /
+// partition-minor / follower-then-leader (README.md:184).  Same text as oracle/kao_oracle.py::write_lp.
+std::string lp_text(const kao_topic &t, const TopicData &td, const std::vector<int> &brokers, int t_index) {
+    const int B = t.n_brokers, R = t.n_racks, P = t.n_partitions;
+    int32_t bd[8];
+    if (kao_derive_bounds(&t, bd) != 0) throw std::runtime_error(std::string("kao_derive_bounds: ") + kao_last_error());
+    auto name = [&](int b, int p, bool leader) {
+        return "t" + std::to_string(t_index) + "b" + std::to_string(brokers[(size_t)b]) + "p" + std::to_string(td.partition_ids[(size_t)p]) + (leader ? "_l" : "");
+    };
+    std::ostringstream os;
+    os << "// Optimization function, based on current assignment\nmax: ";
+    bool first = true;
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < P; ++p) {
+            int role = -1;  // current role of b on p
+            for (int k = 0; k < t.rf_cur; ++k) if (t.current[(size_t)p * t.rf_cur + k] == b) { role = k == 0 ? 0 : 1; break; }
+            if (role < 0) continue;
+            const int cf = t.w[role][1], cl = t.w[role][0];
+            if (cf != 0) { os << (first ? "" : " + ") << cf << " " << name(b, p, false); first = false; }
+            if (cl != 0) { os << (first ? "" : " + ") << cl << " " << name(b, p, true); first = false; }
+        }
+    if (first) os << "0";
+    os << ";\n";
+    auto row = [&](const std::vector<std::string> &vars, long lo, long hi, bool has_lo, bool has_hi) {
+        std::string lhs;
+        for (size_t i = 0; i < vars.size(); ++i) { if (i) lhs += " + "; lhs += vars[i]; }
+        if (has_lo && has_hi && lo == hi) { os << lhs << " = " << lo << ";\n"; return; }
+        if (has_hi) os << lhs << " <= " << hi << ";\n";
+        if (has_lo) os << lhs << " >= " << lo << ";\n";
+    };
+    std::vector<std::string> v;
+    os << "\n// Constrain on replication factor for every partition\n";
+    for (int p = 0; p < P; ++p) { v.clear(); for (int b = 0; b < B; ++b) { v.push_back(name(b, p, false)); v.push_back(name(b, p, true)); } row(v, t.rf, t.rf, true, true); }
+    os << "\n// Constraint on having one and only one leader per partition\n";
+    for (int p = 0; p < P; ++p) { v.clear(); for (int b = 0; b < B; ++b) v.push_back(name(b, p, true)); row(v, 1, 1, true, true); }
+    os << "\n// Constraint on min/max replicas per broker\n";
+    for (int b = 0; b < B; ++b) { v.clear(); for (int p = 0; p < P; ++p) { v.push_back(name(b, p, false)); v.push_back(name(b, p, true)); } row(v, bd[0], bd[1], true, true); }
+    os << "\n// Constraint on min/max leaders per broker\n";
+    for (int b = 0; b < B; ++b) { v.clear(); for (int p = 0; p < P; ++p) v.push_back(name(b, p, true)); row(v, bd[2], bd[3], true, true); }
+    os << "\n// Constraint on no leader and replicas on the same broker\n";
+    for (int b = 0; b < B; ++b) for (int p = 0; p < P; ++p) { v = {name(b, p, false), name(b, p, true)}; row(v, 0, 1, false, true); }
+    os << "\n// Constrain on min/max total replicas per racks\n";
+    for (int r = 0; r < R; ++r) { v.clear(); for (int b = 0; b < B; ++b) if (t.rack_of[b] == r) for (int p = 0; p < P; ++p) { v.push_back(name(b, p, false)); v.push_back(name(b, p, true)); } row(v, bd[4], bd[5], true, true); }
+    os << "\n// Constrain on min/max replicas per partitions per racks\n";
+    for (int p = 0; p < P; ++p) for (int r = 0; r < R; ++r) { v.clear(); for (int b = 0; b < B; ++b) if (t.rack_of[b] == r) { v.push_back(name(b, p, false)); v.push_back(name(b, p, true)); } if (!v.empty()) row(v, bd[6], bd[7], true, true); }
+    os << "\n// All variables are binary\nbin\n";
+    first = true;
+    for (int b = 0; b < B; ++b) for (int p = 0; p < P; ++p) { os << (first ? "" : ", ") << name(b, p, false) << ", " << name(b, p, true); first = false; }
+    os << ";\n";
+    return os.str();
 }
 
 }  // namespace
@@ -135,7 +191,8 @@ int main(int argc, char **argv) {
     int w[4] = {4, 1, 2, 2};
     unsigned long long seed = 1;
     double time_limit = 10.0;
-    bool canonical = true, report = false;
+    bool canonical = true, report = false, lp_only = false;
+    std::string lp_prefix;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto need = [&](const char *flag) -> std::string { if (i + 1 >= argc) usage((std::string(flag) + " needs a value").c_str()); return argv[++i]; };
@@ -150,6 +207,8 @@ int main(int argc, char **argv) {
         else if (a == "--no-canonical") canonical = false;
         else if (a == "--out") out_path = need("--out");
         else if (a == "--report") report = true;
+        else if (a == "--emit-lp") lp_prefix = need("--emit-lp");
+        else if (a == "--lp-only") lp_only = true;
         else if (a == "-h" || a == "--help") usage(nullptr);
         else usage(("unknown flag " + a).c_str());
     }
@@ -202,9 +261,6 @@ int main(int argc, char **argv) {
             }
             tds.push_back(std::move(td));
         }
-        // ---- solve on the GPU ------------------------------------------------------------------
-        int rc = kao_init(device);
-        if (rc) throw std::runtime_error(std::string("kao_init: ") + kao_strerror(rc) + " " + kao_last_error());
         std::vector<kao_topic> topics(tds.size());
         std::vector<std::vector<uint16_t>> assigns(tds.size());
         std::vector<kao_result> results(tds.size());
@@ -218,6 +274,17 @@ int main(int argc, char **argv) {
             results[i] = kao_result{};
             results[i].assignment = assigns[i].data();
         }
+        if (!lp_prefix.empty()) {  // the generated model as lp_solve LP text; host only
+            for (size_t i = 0; i < tds.size(); ++i) {
+                std::ofstream f(lp_prefix + std::to_string(i + 1) + ".lp");
+                if (!f) throw std::runtime_error("cannot write " + lp_prefix + std::to_string(i + 1) + ".lp");
+                f << lp_text(topics[i], tds[i], brokers, (int)i + 1);
+            }
+            if (lp_only) return 0;
+        }
+        // ---- solve on the GPU ------------------------------------------------------------------
+        int rc = kao_init(device);
+        if (rc) throw std::runtime_error(std::string("kao_init: ") + kao_strerror(rc) + " " + kao_last_error());
         kao_opts opts{};
         opts.seed = seed; opts.time_limit_s = time_limit; opts.stop_at_bound = 0; opts.iters_per_launch = 256;
         // stop early when every topic is proven optimal; otherwise search until the time limit

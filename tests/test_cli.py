@@ -24,6 +24,32 @@ def test_cli_usage_errors():
     assert r.returncode == 1 and b"cannot open" in r.stderr
 
 
+def test_cli_emits_lp_solve_text(tmp_path, ko):
+    """--emit-lp (host only, no GPU): the generated model as lp_solve LP text (README.md:144-185), byte-identical
+    to the oracle's writer -- whose text re-solves to the README answer (test_oracle.test_lp_text_roundtrip)."""
+    _build()
+    prefix = str(tmp_path / "m")
+    r = subprocess.run([CLI] + ARGS + ["--emit-lp", prefix, "--lp-only"], capture_output=True)
+    assert r.returncode == 0 and r.stdout == b"", r.stderr
+    txt = open(prefix + "1.lp").read()
+    assert txt == ko.write_lp(ko.readme_example())
+    assert "max: 1 t1b0p3 + 4 t1b0p3_l" in txt and txt.rstrip().endswith("t1b18p9, t1b18p9_l;")
+    # two topics, an RF increase (2 -> 3), racks given as CSV
+    cur = {"version": 1, "partitions": [
+        {"topic": "a", "partition": 0, "replicas": [0, 1]}, {"topic": "a", "partition": 1, "replicas": [2, 9]},
+        {"topic": "b", "partition": 7, "replicas": [3, 0]}]}
+    cur_path = tmp_path / "cur.json"
+    cur_path.write_text(json.dumps(cur))
+    racks = {b: "r%d" % (b % 2) for b in range(10)}
+    r = subprocess.run([CLI, "--current", str(cur_path), "--broker-list", "0,1,2,3,4", "--racks",
+                        ",".join(f"{b}:{v}" for b, v in racks.items()), "--rf", "3", "--emit-lp", prefix, "--lp-only"],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr
+    topics = ko.topics_from_json(cur, [0, 1, 2, 3, 4], racks, rf=3)
+    for i, t in enumerate(topics):
+        assert open(f"{prefix}{i + 1}.lp").read() == ko.write_lp(t, t_index=i + 1)
+
+
 @pytest.mark.skipif(have_gpu(), reason="checks the no-device failure mode")
 def test_cli_fails_loudly_without_gpu():
     _build()
