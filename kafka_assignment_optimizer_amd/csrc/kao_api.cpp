@@ -240,7 +240,8 @@ int64_t upper_bound(const kao_topic *t) {
 
 // Neighbours delta-evaluated by ONE restart over iterations [it0, it0+iters) (kao_kernels.hip, KAO-LS):
 // move pattern R R X R L R X R; REPLACE scans all B brokers of one slot in even blocks of 8 iterations and
-// samples 64 lanes x 4 brokers in odd blocks; EXCHANGE scans all P*RF partner slots; LEADER-SWAP 64 x (RF-1).
+// samples 64 lanes x 4 brokers in odd blocks; EXCHANGE scans all P*RF partner slots (a window of 512 partitions
+// when P > 512); LEADER-SWAP 64 x (RF-1).
 uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers, int n_partitions) {
     static const uint8_t pat[8] = {0, 0, 1, 0, 2, 0, 1, 0};
     uint64_t n = 0;
@@ -248,7 +249,7 @@ uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers
         const uint32_t it = it0 + i;
         const int type = pat[it & 7];
         if (type == 0) n += ((it >> 3) & 1u) ? 256ull : (uint64_t)n_brokers;
-        else if (type == 1) n += (uint64_t)n_partitions * (uint64_t)rf;
+        else if (type == 1) n += (uint64_t)std::min(n_partitions, n_partitions > 512 ? 512 : n_partitions) * (uint64_t)rf;
         else n += 64ull * (uint64_t)(rf > 1 ? rf - 1 : 0);
     }
     return n;

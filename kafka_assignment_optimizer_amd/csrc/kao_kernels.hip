@@ -325,7 +325,10 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const uint32_t lrange = (uint32_t)(prm.lam_max - prm.lam_min + 1);
     const uint32_t P8 = (uint32_t)T.P << 8, RF8 = (uint32_t)T.RF << 8, R8 = (uint32_t)T.R << 8, m8 = (uint32_t)T.m << 8;
 
-    const int T_tour = min(64, max(4, (T.P * T.RF) >> 2));  // tournament size of the slot choice
+    const int T_tour = min(64, max(4, (T.P * T.RF) >> 2));  // lanes taking part in the slot tournament
+    const int GA = min(4, max(1, (T.P * T.RF) >> 8));        // random slots scored per lane
+    const int x_rounds_full = (T.P + 63) >> 6;
+    const bool x_windowed = x_rounds_full > 8;               // EXCHANGE scans at most 8 rounds of 64 partitions
 
     for (uint32_t i = 0; i < prm.iters; ++i) {
         const uint32_t it = prm.launch * prm.iters + i;
@@ -404,23 +407,24 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             win = (int)(kmin & 63u);
         } else {
             // ---- phase A: tournament over T_tour random slots; lowest removal score wins the iteration ----
-            const int pl_ = (int)rnd24(rng, P8);
-            const int kl_ = (int)rnd24(rng, RF8);
             uint32_t keyA = kKeyNull;
             uint32_t oldw_l = 0;
-            int g_old_l = 0, dvo_l = 0, dvr_l = 0;
-            {
-                const uint4 al = L.A[pl_];
-                const uint4 cl = CUR[pl_];
-                oldw_l = sel4(al, kl_);
-                const uint32_t rol = oldw_l >> 16;
-                const bool leadl = kl_ == 0;
-                g_old_l = role_w2(cl, oldw_l, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
-                const uint32_t co = L.C[oldw_l & 0xFFFFu];
-                dvo_l = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
-                if (leadl) dvo_l += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
-                dvr_l = ddec(L.K[rol], T.rack_lo, T.rack_hi) + ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
-                if (lane < T_tour) keyA = make_key(lam, S, dvo_l + min(dvr_l, 0), -g_old_l, lane);
+            int pl_ = 0, kl_ = 0, g_old_l = 0, dvo_l = 0, dvr_l = 0;
+            for (int ga = 0; ga < GA; ++ga) {
+                const int pg = (int)rnd24(rng, P8);
+                const int kg = (int)rnd24(rng, RF8);
+                const uint4 al = L.A[pg];
+                const uint4 cl = CUR[pg];
+                const uint32_t oldw = sel4(al, kg);
+                const uint32_t rol = oldw >> 16;
+                const bool leadl = kg == 0;
+                const int g_old_g = role_w2(cl, oldw, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
+                const uint32_t co = L.C[oldw & 0xFFFFu];
+                int dvo = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
+                if (leadl) dvo += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+                const int dvr = ddec(L.K[rol], T.rack_lo, T.rack_hi) + ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
+                const uint32_t keyg = lane < T_tour ? make_key(lam, S, dvo + min(dvr, 0), -g_old_g, lane) : kKeyNull;
+                if (keyg < keyA) { keyA = keyg; pl_ = pg; kl_ = kg; oldw_l = oldw; g_old_l = g_old_g; dvo_l = dvo; dvr_l = dvr; }
             }
             const int wA = (int)(wave_umin(keyA) & 63u);
             p = __builtin_amdgcn_readlane(pl_, wA);
@@ -465,10 +469,16 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const int nrp = lead ? 0 : 1;
                 const int cnt_a_ru = cnt4(a, ro);
                 const int cu = (int)(L.C[uw & 0xFFFFu] >> 16);
-                for (int base = 0; base < T.P; base += 64) {
+                // every lane draws; lane 0's value places the window when the topic has more than 512 partitions
+                const int q_draw = (int)rnd24(rng, P8);
+                const int q0 = x_windowed ? __builtin_amdgcn_readfirstlane(q_draw) : 0;
+                const int x_rounds = x_windowed ? 8 : x_rounds_full;
+                for (int rd = 0; rd < x_rounds; ++rd) {
                     const uint32_t tie0 = lcg24(rng) >> 8;
-                    const int qq = base + lane;
-                    const bool okq = qq < T.P && qq != p;
+                    int qq = q0 + rd * 64 + lane;
+                    bool okq = true;
+                    if (qq >= T.P) { if (x_windowed) qq -= T.P; else okq = false; }
+                    okq = okq & (qq != p);
                     const int qc = min(qq, T.P - 1);
                     const uint4 b = L.A[qc];
                     const uint4 cb = CUR[qc];

@@ -370,7 +370,9 @@ static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
  *     scan   : a tournament over T random slots (lowest "removal score") picks ONE slot (p,k); every
  *              target broker is then delta-evaluated for it, 64 per round (lane = internal index);
  *     sample : every lane proposes its own random slot and 4 candidate brokers (ls_lane).
- *   EXCHANGE : tournament slot (p,k), then every partner slot (q,j) is scanned (lane = partition q).
+ *   EXCHANGE : tournament slot (p,k), then every partner slot (q,j) is scanned (lane = partition q); topics with
+ *              more than 512 partitions scan a random window of 512 (8 rounds).
+ *   The tournament scores clamp(P*RF/256, 1, 4) random slots per lane on the first T lanes.
  *   LEADER-SWAP : every lane a random partition, all RF-1 swaps (ls_lane).
  * --------------------------------------------------------------------------------------------- */
 static inline uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t tie) {
@@ -391,6 +393,8 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
     const uint32_t plog = (uint32_t)pp->period_log2 + (rho & 3u);
     const uint32_t pmask = (1u << plog) - 1u;
     int T = (P * RF) / 4; if (T < 4) T = 4; if (T > LANES) T = LANES; /* tournament size */
+    int GA = (P * RF) / 256; if (GA < 1) GA = 1; if (GA > 4) GA = 4; /* slots scored per lane in the tournament */
+    const int XW = 8; /* an EXCHANGE scans at most XW rounds of 64 partitions (a random window when P is larger) */
     for (uint32_t i = 0; i < iters; ++i) {
         const uint32_t it = launch * iters + i;
         const int type = move_type(it);
@@ -408,7 +412,8 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
         } else {
             /* ---- phase A: tournament over T random slots, lowest removal score wins ---- */
             uint32_t keyA = KEY_NULL; int p = 0, k = 0;
-            for (uint32_t l = 0; l < LANES; ++l) {
+            for (uint32_t l = 0; l < LANES; ++l)
+              for (int ga = 0; ga < GA; ++ga) {
                 const int pl = (int)rnd24(&rng[l], (uint32_t)P);
                 const int kl = (int)rnd24(&rng[l], (uint32_t)RF);
                 if ((int)l >= T) continue;
@@ -421,7 +426,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 const int dvr = d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, al, ro), -1, t->prack_lo, t->prack_hi);
                 const uint32_t key = make_key(lam, S, dvo + (dvr < 0 ? dvr : 0), -role_w(t, pl, old, kl == 0 ? 0 : 1), l);
                 if (key < keyA) { keyA = key; p = pl; k = kl; }
-            }
+              }
             const uint16_t *a = s->A + p * RFP;
             const unsigned old = a[k];
             const int nr = k == 0 ? 0 : 1;
@@ -459,11 +464,18 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 const int gu_p = role_w(t, p, u, nr);
                 uint32_t lane_key[LANES]; int lane_q[LANES], lane_j[LANES], lane_dV[LANES], lane_dO[LANES];
                 for (uint32_t l = 0; l < LANES; ++l) lane_key[l] = KEY_NULL;
-                for (int base = 0; base < P; base += LANES)
+                int nrounds = (P + LANES - 1) / LANES, q0 = 0;
+                const int windowed = nrounds > XW;
+                for (uint32_t l = 0; l < LANES; ++l) { /* every lane draws; lane 0's value places the window */
+                    const int d = (int)rnd24(&rng[l], (uint32_t)P);
+                    if (l == 0 && windowed) q0 = d;
+                }
+                if (windowed) nrounds = XW;
+                for (int rd = 0; rd < nrounds; ++rd)
                     for (uint32_t l = 0; l < LANES; ++l) {
                         const uint32_t tie0 = lcg24(&rng[l]) >> 8;
-                        const int q = base + (int)l;
-                        if (q >= P) continue;
+                        int q = q0 + rd * LANES + (int)l;
+                        if (q >= P) { if (!windowed) continue; q -= P; }
                         const uint16_t *b = s->A + q * RFP;
                         for (int j = 0; j < RF; ++j) {
                             s->n_eval += 1;
