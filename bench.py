@@ -126,7 +126,10 @@ def main():
     # ---- workload: identical synthetic instance on every rank, topics sharded (LPT) -------------
     topics_all = synthetic.make_config(args.config, n_topics=args.topics or None)
     sizes = [t.n_brokers * t.n_partitions for t in topics_all]
-    shards = multigpu.shard_topics(sizes, world)
+    if len(topics_all) >= world:
+        shards = multigpu.shard_topics(sizes, world)
+    else:  # fewer topics than GPUs: every rank searches every topic with its own seed; the min-allreduce picks the best
+        shards = [list(range(len(topics_all))) for _ in range(world)]
     owned = shards[rank]
     topics = [topics_all[i] for i in owned]
     n_topics = len(topics_all)

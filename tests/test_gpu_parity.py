@@ -263,6 +263,29 @@ def test_kat1_end_to_end(kao, ko):
     assert ko.count_moves(ko.readme_example(), canon) == (1, 0)
 
 
+def test_alternative_weight_scheme(kao, ko):
+    """the README fixes only the weight multiset {1,2,2,4}; scheme C (LL=4, LF=2, FL=2, FF=1)
+    gives 49 on KAT-1 and must be honoured end to end (objective, evaluation, bound)."""
+    ot = ko.readme_example()
+    ot.weights = ((4, 2), (2, 1))
+    pt = to_product_topic(ot)
+    r = kao.solve([pt], seed=2, restarts=64, iters_per_launch=128, stop_at_bound=1, time_limit_s=5)[0]
+    assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", 49, 49)
+    obj, viol = ko.verify(ot, r.assignment)
+    assert viol[0] == 0 and obj == 49 and ko.count_moves(ot, r.assignment) == (1, 0)
+    for s in range(20, 40):  # random instances under scheme C: exact objective parity
+        o2 = ko.random_case(s, max_b=12, max_p=8)
+        if o2.rf > 4 or o2.rf_cur > 4:
+            continue
+        o2.weights = ((4, 2), (2, 1))
+        ex = ko.solve_exact(o2, 30)
+        r = kao.solve([to_product_topic(o2)], seed=s, restarts=32, iters_per_launch=256, max_launches=6, time_limit_s=10)[0]
+        if ex.status == "infeasible":
+            assert r.status == "NO_FEASIBLE"
+        else:
+            assert r.objective == ex.objective <= r.upper_bound, s
+
+
 def test_golden_optima_random_small(kao, ko):
     cases = [c for c in load_golden("random_small.json")["cases"]]
     ots = [ko.topic_from_dict(c["topic"]) for c in cases]
