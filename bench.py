@@ -85,7 +85,8 @@ def main():
     ap.add_argument("--config", type=int, default=4, help="BASELINE config (2..5); the metric is quoted on 4")
     ap.add_argument("--topics", type=int, default=0, help="truncate the topic list (debug)")
     ap.add_argument("--iters", type=int, default=512, help="local-search iterations per K-search launch")
-    ap.add_argument("--restarts", type=int, default=0, help="restarts per topic (0 = fill the GPU)")
+    ap.add_argument("--restarts", type=int, default=0,
+                    help="restarts per topic (0 = four full rounds of resident wavefronts: 256 CUs x 32 x 4 / topics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-bench", type=int, default=1, help="also time K-eval alone on a resident batch")
     args = ap.parse_args()
@@ -134,7 +135,14 @@ def main():
     topics = [topics_all[i] for i in owned]
     n_topics = len(topics_all)
 
-    sess = kao.Session(topics, seed=0xB0B + rank, restarts=args.restarts, iters_per_launch=args.iters, profile=1)
+    restarts = args.restarts
+    if restarts <= 0:
+        # throughput batch: ~4 rounds of resident wavefronts, so that fill/drain and the per-launch prologue/epilogue
+        # amortize (measured: 3.8e11 cand/s at one partial round, 5.1e11 at three rounds)
+        cus = torch.cuda.get_device_properties(dev_index).multi_processor_count
+        restarts = max(8, (cus * 32 * 4 // max(1, len(topics))) // 4 * 4)
+        restarts = min(restarts, 8192)
+    sess = kao.Session(topics, seed=0xB0B + rank, restarts=restarts, iters_per_launch=args.iters, profile=1)
 
     def one_step():
         sess.step(1)
@@ -239,12 +247,15 @@ def main():
         out["roofline"]["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE (x2 gfx950 wide-read correction) + WRITE_SIZE per launch, "
                                            "separate passes, from " + prof["source"])
         valu = prof["k_search_valu_insts_per_launch"]
-        peak = 256 * 4 * 2.4e9 / 4  # wave64 integer VALU instructions/s: 1024 SIMDs, one issue per 4 cycles, 2.4 GHz
+        # integer VALU issue peak, MEASURED on this chip (tools/microbench/valu_rate.hip, profiles/r01_valu_issue_microbench.txt):
+        # 540-671 G wave64-instructions/s depending on the op (~4 cycles per instruction per SIMD); best class used as the roof
+        peak = 671.3e9
         out["roofline_valu_issue"] = {"kernel": "k_search", "bound": "valu-issue", "insts_per_launch": valu,
                                       "achieved": valu / (ms_search / max(1, launches) * 1e-3) / 1e9, "peak": peak / 1e9,
                                       "unit": "G wave-instructions/s",
                                       "frac": valu / (ms_search / max(1, launches) * 1e-3) / peak,
-                                      "note": "SQ_INSTS_VALU per launch from " + prof["source"] + "; this, not HBM, is the binding roof"}
+                                      "note": "SQ_INSTS_VALU per launch from " + prof["source"] + "; peak = best measured integer-VALU class "
+                                              "(profiles/r01_valu_issue_microbench.txt); this, not HBM, is the binding roof"}
     ach_e = eb / (ms_eval * 1e-3) / 1e9 if ms_eval > 0 else None
     out["roofline_eval_in_step"] = {"kernel": "k_eval", "achieved": ach_e, "unit": "GB/s", "avg_launch_ms": ms_eval / max(1, launches),
                                     "algorithmic_bytes_per_launch": eb // max(1, launches)}

@@ -710,10 +710,10 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     if (o.period_log2 <= 0) o.period_log2 = 8;
     if (o.period_log2 > 20) o.period_log2 = 20;
     if (o.time_limit_s <= 0) o.time_limit_s = 10.0;
-    if (o.restarts <= 0) {  // fill the chip: ~24 wavefronts per CU across all topics
-        const int want = g_num_cu * 24;
-        int r = (want + n_topics - 1) / n_topics;
-        r = ((r + kWaves - 1) / kWaves) * kWaves;
+    if (o.restarts <= 0) {  // one full round of resident wavefronts (8 per SIMD = 32 per CU) across all topics
+        const int want = g_num_cu * 32;
+        int r = want / n_topics;
+        r = (r / kWaves) * kWaves;
         o.restarts = std::min(std::max(r, 8), 8192);
     }
     if (o.restarts > (1 << 20)) o.restarts = 1 << 20;

@@ -1,0 +1,90 @@
+// Integer-VALU issue-rate microbenchmark for gfx950: how many wave64 instructions per second can the chip
+// issue for the instruction kinds k_search is made of?  (measure, don't guess: anchors roofline_valu_issue)
+//   hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip && ./valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define REP 64
+template <int KIND>
+__global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t s0, uint32_t s1) {
+    uint32_t a = threadIdx.x * 2654435761u + s0, b = a ^ s1, c = a + 7, d = b + 11, e = a ^ 0x1234567u, f = b * 3u, g = c + d, h = e ^ f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) {
+            if (KIND == 0) {  // v_add_u32, 8 independent chains
+                asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                             "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(s1));
+            } else if (KIND == 1) {  // v_cmp_eq_u32 (to vcc) + v_cndmask_b32
+                asm volatile("v_cmp_eq_u32 vcc, %0, %1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_eq_u32 vcc, %4, %5\n v_cndmask_b32 %6, %6, %7, vcc\n"
+                             "v_cmp_eq_u32 vcc, %1, %2\n v_cndmask_b32 %0, %0, %3, vcc\n v_cmp_eq_u32 vcc, %5, %6\n v_cndmask_b32 %4, %4, %7, vcc\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "vcc");
+            } else if (KIND == 2) {  // v_mad_u32_u24
+                asm volatile("v_mad_u32_u24 %0, %0, %8, %1\n v_mad_u32_u24 %1, %1, %8, %2\n v_mad_u32_u24 %2, %2, %8, %3\n v_mad_u32_u24 %3, %3, %8, %4\n"
+                             "v_mad_u32_u24 %4, %4, %8, %5\n v_mad_u32_u24 %5, %5, %8, %6\n v_mad_u32_u24 %6, %6, %8, %7\n v_mad_u32_u24 %7, %7, %8, %0\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(s1));
+            } else if (KIND == 3) {  // v_mul_hi_u32_u24
+                asm volatile("v_mul_hi_u32_u24 %0, %1, %8\n v_mul_hi_u32_u24 %1, %2, %8\n v_mul_hi_u32_u24 %2, %3, %8\n v_mul_hi_u32_u24 %3, %4, %8\n"
+                             "v_mul_hi_u32_u24 %4, %5, %8\n v_mul_hi_u32_u24 %5, %6, %8\n v_mul_hi_u32_u24 %6, %7, %8\n v_mul_hi_u32_u24 %7, %0, %8\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(s1));
+            } else if (KIND == 4) {  // v_cmp_eq_u32_sdwa (WORD_1) + v_addc_co_u32
+                asm volatile("v_cmp_eq_u32_sdwa vcc, %0, %1 src0_sel:WORD_1 src1_sel:DWORD\n v_addc_co_u32 %2, vcc, 0, %2, vcc\n"
+                             "v_cmp_eq_u32_sdwa vcc, %3, %4 src0_sel:WORD_1 src1_sel:DWORD\n v_addc_co_u32 %5, vcc, 0, %5, vcc\n"
+                             "v_cmp_eq_u32_sdwa vcc, %6, %7 src0_sel:WORD_1 src1_sel:DWORD\n v_addc_co_u32 %0, vcc, 0, %0, vcc\n"
+                             "v_cmp_eq_u32_sdwa vcc, %1, %2 src0_sel:WORD_1 src1_sel:DWORD\n v_addc_co_u32 %3, vcc, 0, %3, vcc\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : : "vcc");
+            } else if (KIND == 5) {  // v_mul_lo_u32 (full 32-bit multiply)
+                asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                             "v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(s1));
+            } else if (KIND == 6) {  // v_min_u32 with DPP
+                asm volatile("v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             "v_min_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             "v_min_u32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             "v_min_u32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+            } else {  // v_and_b32 / v_xor_b32 / v_lshl_or_b32 mix
+                asm volatile("v_and_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_lshl_or_b32 %2, %3, 16, %2\n v_and_b32 %3, %3, %4\n"
+                             "v_xor_b32 %4, %4, %5\n v_lshl_or_b32 %5, %6, 16, %5\n v_and_b32 %6, %6, %7\n v_xor_b32 %7, %7, %0\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h;
+}
+
+template <int KIND>
+double run(const char *name, uint32_t *d_out, int blocks) {
+    const int iters = 4000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 10, 1u, 3u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1u, 3u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double winst = (double)blocks * 4 * iters * REP;  // wave-instructions
+    const double rate = winst / (ms * 1e-3);
+    printf("%-44s %8.1f G wave-instr/s  = %.2f cycles per wave64 instruction per SIMD @2.4 GHz (1024 SIMDs)\n", name, rate / 1e9,
+           1024.0 * 2.4e9 / rate);
+    return rate;
+}
+
+int main() {
+    uint32_t *d_out;
+    const int blocks = 256 * 8;  // 8 waves per SIMD
+    hipMalloc(&d_out, (size_t)blocks * 256 * 4);
+    run<0>("v_add_u32", d_out, blocks);
+    run<7>("v_and / v_xor / v_lshl_or", d_out, blocks);
+    run<1>("v_cmp_eq_u32 + v_cndmask_b32", d_out, blocks);
+    run<4>("v_cmp_eq_u32_sdwa + v_addc_co_u32", d_out, blocks);
+    run<2>("v_mad_u32_u24", d_out, blocks);
+    run<3>("v_mul_hi_u32_u24", d_out, blocks);
+    run<5>("v_mul_lo_u32", d_out, blocks);
+    run<6>("v_min_u32_dpp", d_out, blocks);
+    return 0;
+}
