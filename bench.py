@@ -108,7 +108,8 @@ def main():
     # KAO_BENCH_SHARE_DEVICE=1 (test mode for a 1-GPU box): every rank uses device 0 and the collective runs
     # over gloo, so the N > 1 code path can be exercised without N GPUs.  Never set by the driver.
     share = os.environ.get("KAO_BENCH_SHARE_DEVICE", "0") == "1"
-    dev_index = 0 if share else local_rank
+    # a launcher may mask devices per rank (HIP_VISIBLE_DEVICES): then every rank sees one device, index 0
+    dev_index = 0 if share else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     kao.init(dev_index)
     if world > 1:
