@@ -74,7 +74,7 @@ typedef struct kao_opts {
     uint64_t seed;            /* search is deterministic in (seed, restarts, iters_per_launch) */
     double time_limit_s;      /* kao_solve: wall-clock limit; <= 0 = default 10 s */
     int32_t restarts;         /* parallel restarts (wavefronts) per topic; <= 0 = auto */
-    int32_t iters_per_launch; /* local-search iterations per K-search launch; <= 0 = 512 */
+    int32_t iters_per_launch; /* local-search iterations per K-search launch; <= 0 = 512 (sessions) / 128 (kao_solve) */
     int32_t max_launches;     /* kao_solve: stop after this many launches; <= 0 = unlimited */
     int32_t obj_scale;        /* S in cost = lam*violation - S*objective; <= 0 = 4 */
     int32_t lam_min, lam_max; /* penalty sawtooth bounds; <= 0 = 1 / 40 */
@@ -107,10 +107,12 @@ typedef struct kao_stats {
     uint64_t search_bytes_algo; /* algorithmic bytes of the K-search launches */
     uint64_t eval_bytes_algo;   /* algorithmic bytes of the K-eval launches */
     int32_t n_restarts_total;
-    int32_t lds_bytes_search;   /* dynamic LDS per K-search workgroup */
+    int32_t lds_bytes_search;   /* dynamic LDS per K-search workgroup (largest launch group) */
     int32_t blocks_search;      /* workgroups per K-search launch */
     int32_t drift;              /* restarts whose incrementally tracked (V, objective) disagreed with the
                                    from-scratch recount at the end of a launch; must be 0 */
+    int32_t launch_groups;      /* topics are bucketed by LDS footprint; one K-search + K-eval launch per group */
+    int32_t reserved;
 } kao_stats;
 
 typedef struct kao_session kao_session;

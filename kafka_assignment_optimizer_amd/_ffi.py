@@ -35,7 +35,7 @@ class KaoStats(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("delta_candidates", C.c_uint64), ("full_candidates", C.c_uint64),
                 ("ms_search", C.c_double), ("ms_eval", C.c_double), ("search_bytes_algo", C.c_uint64),
                 ("eval_bytes_algo", C.c_uint64), ("n_restarts_total", C.c_int32), ("lds_bytes_search", C.c_int32),
-                ("blocks_search", C.c_int32), ("drift", C.c_int32)]
+                ("blocks_search", C.c_int32), ("drift", C.c_int32), ("launch_groups", C.c_int32), ("reserved", C.c_int32)]
 
 
 # every symbol include/kao.h declares: name -> (restype, argtypes)

@@ -314,9 +314,15 @@ struct kao_session {
     std::vector<kao_topic> topics;  // shallow copies (pointers not retained for device work)
     std::vector<int64_t> ub;
     int total_restarts = 0;
-    int maxP = 0, maxBx = 0, maxB = 0;
+    // Topics are bucketed by LDS footprint into launch groups (a 3000-partition topic must not impose its LDS carve
+    // and its 2 waves per workgroup on 200 small topics); one K-search + one K-eval launch per group per step.
+    struct LaunchGroup {
+        int maxP = 0, maxBx = 0, maxB = 0;
+        int waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
+        int smap_off = 0, smap_n = 0, emap_off = 0, emap_n = 0;
+    };
+    std::vector<LaunchGroup> groups;
     int blocks_search = 0, blocks_eval = 0;
-    int search_waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
     // device memory: one read-only arena (instance tables, uploaded with ONE H2D copy) and one mutable
     // arena (restart states, snapshots, results); the pointers below are carved from them
     void *arena_ro = nullptr, *arena_rw = nullptr;
@@ -755,32 +761,53 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         rackof_pool.insert(rackof_pool.end(), pt.rack_of.begin(), pt.rack_of.end());
         d.curd_off = (uint32_t)curd_pool.size();
         curd_pool.insert(curd_pool.end(), pt.cur_dense.begin(), pt.cur_dense.end());
-        s->maxP = std::max(s->maxP, d.P); s->maxBx = std::max(s->maxBx, d.Bx); s->maxB = std::max(s->maxB, d.B);
         // algorithmic bytes: full evaluation = 2*RF*P + 2*rf_cur*P + B per candidate
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
     }
     s->total_restarts = restart_base;
-    s->search_waves = kWaves;
-    while (s->search_waves > 1 && search_lds_bytes(s->maxP, s->maxBx, s->search_waves) > 160 * 1024) s->search_waves /= 2;
-    if (search_lds_bytes(s->maxP, s->maxBx, s->search_waves) > 160 * 1024 || eval_lds_bytes(s->maxP, s->maxB) > 160 * 1024) {
-        kao_session_destroy(s);
-        return fail(KAO_ERR_UNSUPPORTED, "topic state exceeds 160 KiB of LDS even with one restart per workgroup "
-                                         "(32 B x partitions + 4 B x padded brokers)");
+    // ---- launch groups: topics sorted by single-wave LDS need, a new group whenever the need doubles (<= 8 groups) ----
+    std::vector<int> order((size_t)n_topics);
+    for (int t = 0; t < n_topics; ++t) order[(size_t)t] = t;
+    auto need1 = [&](int t) { const TopicDev &d = s->pts[(size_t)t].d; return search_lds_bytes(d.P, d.Bx, 1); };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need1(x) < need1(y); });
+    std::vector<std::vector<int>> members;
+    size_t group_base = 0;
+    for (int t : order) {
+        if (members.empty() || (need1(t) > 2 * group_base && members.size() < 8)) { members.emplace_back(); group_base = need1(t); }
+        members.back().push_back(t);
     }
-    // workgroup maps
-    std::vector<int2> smap; std::vector<int> smap_topic;
-    std::vector<int4> emap; std::vector<int> emap_topic;
+    std::vector<int2> smap; std::vector<int4> emap;
     const int cpb = 32;  // candidates per K-eval workgroup
-    for (int t = 0; t < n_topics; ++t) {
-        const TopicDev &d = s->pts[(size_t)t].d;
-        for (int r = 0; r < d.n_restarts; r += s->search_waves) { smap.push_back(make_int2(t, r)); smap_topic.push_back(t); }
-        for (int r = 0; r < d.n_restarts; r += cpb) {
-            emap.push_back(make_int4(t, r, std::min(cpb, d.n_restarts - r), d.restart_base + r));
-            emap_topic.push_back(t);
+    for (const std::vector<int> &mem : members) {
+        kao_session::LaunchGroup g;
+        for (int t : mem) {
+            const TopicDev &d = s->pts[(size_t)t].d;
+            g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B);
         }
+        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves) > 160 * 1024) g.waves /= 2;
+        if (search_lds_bytes(g.maxP, g.maxBx, g.waves) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB) > 160 * 1024) {
+            kao_session_destroy(s);
+            return fail(KAO_ERR_UNSUPPORTED, "topic state exceeds 160 KiB of LDS even with one restart per workgroup "
+                                             "(32 B x partitions + 5 B x padded brokers)");
+        }
+        std::vector<int2> gs; std::vector<int> gs_topic;
+        std::vector<int4> ge; std::vector<int> ge_topic;
+        for (int t : mem) {
+            const TopicDev &d = s->pts[(size_t)t].d;
+            for (int r = 0; r < d.n_restarts; r += g.waves) { gs.push_back(make_int2(t, r)); gs_topic.push_back(t); }
+            for (int r = 0; r < d.n_restarts; r += cpb) {
+                ge.push_back(make_int4(t, r, std::min(cpb, d.n_restarts - r), d.restart_base + r));
+                ge_topic.push_back(t);
+            }
+        }
+        gs = xcd_order(gs, gs_topic);
+        ge = xcd_order(ge, ge_topic);
+        g.smap_off = (int)smap.size(); g.smap_n = (int)gs.size();
+        g.emap_off = (int)emap.size(); g.emap_n = (int)ge.size();
+        smap.insert(smap.end(), gs.begin(), gs.end());
+        emap.insert(emap.end(), ge.begin(), ge.end());
+        s->groups.push_back(g);
     }
-    smap = xcd_order(smap, smap_topic);
-    emap = xcd_order(emap, emap_topic);
     s->blocks_search = (int)smap.size();
     s->blocks_eval = (int)emap.size();
     std::vector<TopicDev> tds;
@@ -863,18 +890,24 @@ int kao_session_step(kao_session *s) {
     SearchParams prm{};
     prm.obj_scale = s->opts.obj_scale; prm.lam_min = s->opts.lam_min; prm.lam_max = s->opts.lam_max; prm.period_log2 = s->opts.period_log2;
     prm.launch = s->launch; prm.iters = (uint32_t)s->opts.iters_per_launch; prm.init = s->launch == 0 ? 1 : 0;
-    prm.maxP = s->maxP; prm.maxBx = s->maxBx;
     EvalPools ep{};
-    ep.topics = s->d_topics; ep.block_map = s->d_emap; ep.rackof_pool = s->d_rackof; ep.curd_pool = s->d_curd;
+    ep.topics = s->d_topics; ep.rackof_pool = s->d_rackof; ep.curd_pool = s->d_curd;
     ep.cand = s->d_best; ep.objective = s->d_obj; ep.violations = s->d_viol; ep.best_key = s->d_keys;
-    ep.maxP = s->maxP; ep.maxB = s->maxB;
     hipEvent_t *e = prof ? &s->ev[(size_t)s->ev_pending * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(e[0], s->stream));
-    launch_search(sp, prm, s->blocks_search, s->search_waves, s->stream);
-    HIP_TRY(hipGetLastError());
+    for (const kao_session::LaunchGroup &g : s->groups) {
+        sp.block_map = s->d_smap + g.smap_off;
+        prm.maxP = g.maxP; prm.maxBx = g.maxBx;
+        launch_search(sp, prm, g.smap_n, g.waves, s->stream);
+        HIP_TRY(hipGetLastError());
+    }
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
-    launch_eval(ep, s->blocks_eval, s->stream);
-    HIP_TRY(hipGetLastError());
+    for (const kao_session::LaunchGroup &g : s->groups) {
+        ep.block_map = s->d_emap + g.emap_off;
+        ep.maxP = g.maxP; ep.maxB = g.maxB;
+        launch_eval(ep, g.emap_n, s->stream);
+        HIP_TRY(hipGetLastError());
+    }
     if (prof) { HIP_TRY(hipEventRecord(e[2], s->stream)); s->ev_pending++; }
     for (const PreparedTopic &pt : s->pts) {
         const uint64_t n = neighbours_in_range(prm.launch * prm.iters, prm.iters, pt.d.RF, pt.d.B, pt.d.P) * (uint64_t)pt.d.n_restarts;
@@ -942,7 +975,9 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->search_bytes_algo = s->search_bytes_total;
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
-    out->lds_bytes_search = (int32_t)search_lds_bytes(s->maxP, s->maxBx, s->search_waves);
+    for (const kao_session::LaunchGroup &g : s->groups)
+        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves));
+    out->launch_groups = (int32_t)s->groups.size();
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));
     return KAO_OK;
@@ -974,7 +1009,10 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     const double t0 = now_s();
     if (!results) return fail(KAO_ERR_INVALID, "null results");
     kao_session *s = nullptr;
-    int rc = kao_session_create(topics, n_topics, opts, &s);
+    kao_opts so{};
+    if (opts) so = *opts;
+    if (so.iters_per_launch <= 0) so.iters_per_launch = 128;  // latency first: the host checks the bound after every launch
+    int rc = kao_session_create(topics, n_topics, &so, &s);
     if (rc) return rc;
     g_timing[0] = now_s() - t0;
     const kao_opts &o = s->opts;

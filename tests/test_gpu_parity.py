@@ -155,6 +155,33 @@ def test_search_replay_varied_shapes(kao, ko, kp):
             assert viol[0] == 0 and obj == r.objective, ot.name
 
 
+def test_heterogeneous_session_uses_launch_groups(kao, ko, kp):
+    """A 3000-partition topic next to small ones: topics are bucketed by LDS footprint into separate launches, so the
+    small topics keep 4 restarts per workgroup; replay parity holds in every group."""
+    big = ko.make_cluster("big3000", 1000, 20, 1, 3000, 3, [7, 77, 777], [(1000, 7), (1001, 17), (1002, 17)]).topics[0]
+    small = ko.gen_config(4, n_topics=6).topics
+    mid = ko.gen_config(2).topics[0]
+    ots = [small[0], big, small[1], mid] + small[2:]
+    seed = 555
+    with kao.Session([to_product_topic(t) for t in ots], seed=seed, restarts=8, iters_per_launch=64) as s:
+        st = s.stats()
+        assert st["launch_groups"] >= 2
+        # 6 small + 1 mid topics at 4 waves per workgroup (2 workgroups each), the big one at 2 waves (4 workgroups)
+        assert st["blocks_search"] == 7 * 2 + 4
+        s.step(2)
+        assert s.stats()["drift"] == 0
+        for ti, ot in enumerate(ots):
+            tseed = seed ^ (((ti + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+            dev = s.restart_state(ti, 5)
+            ref = kp.port_search(ot, tseed, 5, 2, 64)
+            assert dev["final"].tolist() == ref["final"].tolist(), ot.name
+            assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
+        for ot, r in zip(ots, s.best()):
+            if r.status != "NO_FEASIBLE":
+                obj, viol = kp.port_eval(ot, r.assignment)
+                assert viol[0] == 0 and obj == r.objective
+
+
 def test_empty_and_degenerate_inputs(kao, ko):
     import ctypes as C
     from kafka_assignment_optimizer_amd import _ffi

@@ -28,7 +28,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.KaoTopic) == 5 * 4 + 4 + 2 * 8 + 16 + 8 * 4  # 5 ints, pad, 2 pointers, w[2][2], 8 bounds
     assert C.sizeof(_ffi.KaoOpts) == 8 + 8 + 10 * 4 + 8
     assert C.sizeof(_ffi.KaoResult) == 4 + 4 + 8 + 8 + 32 + 8 + 8
-    assert C.sizeof(_ffi.KaoStats) == 3 * 8 + 2 * 8 + 2 * 8 + 4 * 4
+    assert C.sizeof(_ffi.KaoStats) == 3 * 8 + 2 * 8 + 2 * 8 + 6 * 4
 
 
 def test_host_helpers_match_oracle(ko):
