@@ -157,14 +157,16 @@ int64_t partition_value(const kao_topic *t, bool lead_kept, int n_fol, bool lead
 // arrivals and only P*RF - kept slots can take them).  g_p(j) = f_p(all) - max_{|K| = n_p - j} f_p(K); the
 // total loss is at least the k smallest marginals of the lower convex envelopes of the g_p.  Brokers with
 // more current leaders than lead_hi force leader changes, each costing f_p(all) - f_p(leader not leading).
-// Both losses may hit the same partitions, so the larger is subtracted.  Restated (and checked against the
-// exact optimum) in oracle/kao_oracle.py::upper_bound_forced.
+// Both losses may hit the same partitions, so the larger is subtracted; the result is then capped by the
+// per-broker capacity bound below.  Restated (and checked against the exact optimum) in
+// oracle/kao_oracle.py::upper_bound_forced / upper_bound_broker.
 int64_t upper_bound(const kao_topic *t) {
     const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
     int32_t bd[8];
     derive_bounds(t, bd);
     const int rep_lo = bd[0], rep_hi = bd[1], lead_hi = bd[3], rack_lo = bd[4], rack_hi = bd[5], prack_hi = bd[7];
     std::vector<int> s_b((size_t)B, 0), s_r((size_t)R, 0), lead_b((size_t)B, 0);
+    std::vector<int> nl_b((size_t)B, 0);  // surviving current LEADER replicas per broker (followers = s_b - nl_b)
     std::vector<int64_t> marginals;
     std::vector<std::pair<int, int64_t>> lead_losses;  // (broker, loss if this partition's leader stops leading)
     int64_t total = 0, n_surv = 0, cell_excess = 0;
@@ -212,6 +214,7 @@ int64_t upper_bound(const kao_topic *t) {
                 marginals.push_back(now - prev);
             }
         if (lead_alive) {
+            nl_b[c[0]]++;
             lead_b[c[0]]++;
             const int64_t alt = std::max(partition_value(t, false, n_fol), partition_value(t, true, n_fol, false));
             lead_losses.emplace_back((int)c[0], std::max<int64_t>(0, f_all - alt));
@@ -235,7 +238,30 @@ int64_t upper_bound(const kao_topic *t) {
         for (size_t q = i; q < j && (int)(q - i) < ex; ++q) lead_loss += lead_losses[q].second;  // sorted by loss within a broker
         i = j;
     }
-    return total - std::max(evict_loss, lead_loss);
+    // Per-broker capacity bound: a broker keeps at most rep_hi of its surviving replicas and at most lead_hi of them
+    // lead; a replica that leads is worth w[cur_role][0], one that follows w[cur_role][1] (one-leader-per-partition
+    // and rack rows relaxed).  Charges forced evictions AND forced leader changes together.
+    const int wLL = t->w[0][0], wLF = t->w[0][1], wFL = t->w[1][0], wFF = t->w[1][1];
+    int64_t broker_bound = 0;
+    for (int b = 0; b < B; ++b) {
+        const int n_l = nl_b[(size_t)b], n_f = s_b[(size_t)b] - n_l;
+        int64_t best = 0;
+        for (int x = 0; x <= std::min(n_l, std::min(lead_hi, rep_hi)); ++x)
+            for (int y = 0; y <= std::min(n_f, std::min(lead_hi - x, rep_hi - x)); ++y) {
+                int64_t val = (int64_t)x * wLL + (int64_t)y * wFL;
+                int slots = rep_hi - x - y;
+                const int ga = n_l - x, gb = n_f - y;  // ga replicas worth wLF as followers, gb worth wFF
+                const int hi_w = std::max(wLF, wFF), lo_w = std::min(wLF, wFF);
+                const int hi_n = wLF >= wFF ? ga : gb, lo_n = wLF >= wFF ? gb : ga;
+                const int t1 = std::min(hi_n, slots);
+                if (hi_w > 0) val += (int64_t)t1 * hi_w;
+                slots -= t1;
+                if (lo_w > 0) val += (int64_t)std::min(lo_n, slots) * lo_w;
+                best = std::max(best, val);
+            }
+        broker_bound += best;
+    }
+    return std::min(total - std::max(evict_loss, lead_loss), broker_bound);
 }
 
 // Neighbours delta-evaluated by ONE restart over iterations [it0, it0+iters) (kao_kernels.hip, KAO-LS):

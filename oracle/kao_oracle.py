@@ -889,4 +889,37 @@ def upper_bound_forced(topic: Topic) -> int:
         ex = lead_b[b] - bd["lead_hi"]
         if ex > 0:
             lead_loss += sum(sorted(l for bb, l in lead_losses if bb == b)[:ex])
-    return total - max(evict_loss, lead_loss)
+    return min(total - max(evict_loss, lead_loss), upper_bound_broker(topic))
+
+
+def upper_bound_broker(topic: Topic) -> int:
+    """Per-broker capacity bound: a broker keeps at most rep_hi of its surviving replicas and at most lead_hi of
+    them can be leading; a replica that leads is worth w[cur_role][0], one that follows w[cur_role][1].  The
+    sum over brokers of the best such selection bounds the objective (the one-leader-per-partition and rack rows
+    are relaxed).  Unlike the eviction bound it charges forced evictions AND forced leader changes together."""
+    B = topic.n_brokers
+    w = topic.weights
+    bd = topic.bounds()
+    on_b: List[List[int]] = [[] for _ in range(B)]  # per broker: current roles (0 leader, 1 follower) of surviving replicas
+    for p in range(topic.n_partitions):
+        for k in range(topic.rf_cur):
+            b = int(topic.current[p, k])
+            if b != NONE:
+                on_b[b].append(0 if k == 0 else 1)
+    total = 0
+    for roles in on_b:
+        n_l = sum(1 for r in roles if r == 0)
+        n_f = len(roles) - n_l
+        best = 0
+        # x current leaders and y current followers lead (x + y <= lead_hi); the rest of the kept ones follow
+        for x in range(0, min(n_l, bd["lead_hi"]) + 1):
+            for y in range(0, min(n_f, bd["lead_hi"] - x) + 1):
+                val = x * w[0][0] + y * w[1][0]
+                slots = bd["rep_hi"] - x - y
+                if slots < 0:
+                    continue
+                gains = sorted([w[0][1]] * (n_l - x) + [w[1][1]] * (n_f - y), reverse=True)
+                val += sum(g for g in gains[:slots] if g > 0)
+                best = max(best, val)
+        total += best
+    return total
