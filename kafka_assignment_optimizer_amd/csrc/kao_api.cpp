@@ -169,7 +169,7 @@ int64_t upper_bound(const kao_topic *t) {
     std::vector<int> nl_b((size_t)B, 0);  // surviving current LEADER replicas per broker (followers = s_b - nl_b)
     std::vector<int64_t> marginals;
     std::vector<std::pair<int, int64_t>> lead_losses;  // (broker, loss if this partition's leader stops leading)
-    int64_t total = 0, n_surv = 0, cell_excess = 0;
+    int64_t total = 0, n_surv = 0, cell_excess = 0, parts_with_survivor = 0;
     for (int p = 0; p < P; ++p) {
         const uint16_t *c = t->current + (size_t)p * t->rf_cur;
         const bool lead_alive = c[0] < (unsigned)B;
@@ -183,6 +183,7 @@ int64_t upper_bound(const kao_topic *t) {
         }
         const int n_p = n_fol + (lead_alive ? 1 : 0);
         n_surv += n_p;
+        parts_with_survivor += n_p > 0;
         for (int i = 0; i < n_in; ++i) {  // cells: count each rack once
             bool first = true;
             int cnt = 0;
@@ -238,16 +239,27 @@ int64_t upper_bound(const kao_topic *t) {
         for (size_t q = i; q < j && (int)(q - i) < ex; ++q) lead_loss += lead_losses[q].second;  // sorted by loss within a broker
         i = j;
     }
-    // Per-broker capacity bound: a broker keeps at most rep_hi of its surviving replicas and at most lead_hi of them
-    // lead; a replica that leads is worth w[cur_role][0], one that follows w[cur_role][1] (one-leader-per-partition
-    // and rack rows relaxed).  Charges forced evictions AND forced leader changes together.
+    // Per-broker capacity bound with a global cap on leading survivors.  A broker keeps at most rep_hi of its
+    // surviving replicas and at most lead_hi of them lead; a replica that leads is worth w[cur_role][0], one that
+    // follows w[cur_role][1] (one-leader-per-partition and rack rows relaxed).  v_b(L) = best value on broker b with
+    // at most L survivors leading.  Brokers with fewer than lead_lo survivors must receive lead_lo - s_b NEW leaders,
+    // so at most Lcap = min(#partitions with a survivor, P - sum_b (lead_lo - s_b)+) partitions keep a surviving
+    // replica as leader: bound = sum_b v_b(0) + the Lcap largest marginals of the upper concave envelopes of the v_b.
+    // Charges forced evictions AND forced leader changes together.
     const int wLL = t->w[0][0], wLF = t->w[0][1], wFL = t->w[1][0], wFF = t->w[1][1];
-    int64_t broker_bound = 0;
+    const int lead_lo = bd[2];
+    int64_t lcap = P;
+    for (int b = 0; b < B; ++b) lcap -= std::max(0, lead_lo - s_b[(size_t)b]);
+    lcap = std::min<int64_t>(lcap, parts_with_survivor);
+    int64_t broker_base = 0;
+    std::vector<int64_t> lead_marg;
+    std::vector<int64_t> v, hx, hy;
     for (int b = 0; b < B; ++b) {
         const int n_l = nl_b[(size_t)b], n_f = s_b[(size_t)b] - n_l;
-        int64_t best = 0;
-        for (int x = 0; x <= std::min(n_l, std::min(lead_hi, rep_hi)); ++x)
-            for (int y = 0; y <= std::min(n_f, std::min(lead_hi - x, rep_hi - x)); ++y) {
+        const int lmax = std::min(std::min(lead_hi, rep_hi), n_l + n_f);
+        v.assign((size_t)lmax + 1, -1);
+        for (int x = 0; x <= std::min(n_l, lmax); ++x)
+            for (int y = 0; y <= std::min(n_f, lmax - x); ++y) {
                 int64_t val = (int64_t)x * wLL + (int64_t)y * wFL;
                 int slots = rep_hi - x - y;
                 const int ga = n_l - x, gb = n_f - y;  // ga replicas worth wLF as followers, gb worth wFF
@@ -257,10 +269,31 @@ int64_t upper_bound(const kao_topic *t) {
                 if (hi_w > 0) val += (int64_t)t1 * hi_w;
                 slots -= t1;
                 if (lo_w > 0) val += (int64_t)std::min(lo_n, slots) * lo_w;
-                best = std::max(best, val);
+                v[(size_t)(x + y)] = std::max(v[(size_t)(x + y)], val);
             }
-        broker_bound += best;
+        for (int i = 1; i <= lmax; ++i) v[(size_t)i] = std::max(v[(size_t)i], v[(size_t)i - 1]);  // "at most L leading"
+        broker_base += v[0];
+        hx.clear(); hy.clear();  // upper concave envelope of (L, v[L]) -> non-increasing marginals
+        for (int i = 0; i <= lmax; ++i) {
+            hx.push_back(i); hy.push_back(v[(size_t)i]);
+            while (hx.size() >= 3) {
+                const size_t n = hx.size();
+                if ((hy[n - 2] - hy[n - 3]) * (hx[n - 1] - hx[n - 3]) <= (hy[n - 1] - hy[n - 3]) * (hx[n - 2] - hx[n - 3])) {
+                    hx[n - 2] = hx[n - 1]; hy[n - 2] = hy[n - 1]; hx.pop_back(); hy.pop_back();
+                } else break;
+            }
+        }
+        for (size_t i = 0; i + 1 < hx.size(); ++i)
+            for (int64_t x = hx[i] + 1; x <= hx[i + 1]; ++x) {  // ceil of the running total keeps it an upper bound
+                const int64_t dy = hy[i + 1] - hy[i], dx = hx[i + 1] - hx[i];
+                auto up = [&](int64_t k) { const int64_t num = dy * k; return hy[i] + (num >= 0 ? (num + dx - 1) / dx : -((-num) / dx)); };
+                lead_marg.push_back(up(x - hx[i]) - up(x - 1 - hx[i]));
+            }
     }
+    std::sort(lead_marg.begin(), lead_marg.end(), [](int64_t p, int64_t q) { return p > q; });
+    int64_t broker_bound = broker_base;
+    for (int64_t i = 0; i < lcap && i < (int64_t)lead_marg.size(); ++i)
+        if (lead_marg[(size_t)i] > 0) broker_bound += lead_marg[(size_t)i];
     return std::min(total - std::max(evict_loss, lead_loss), broker_bound);
 }
 

@@ -893,33 +893,62 @@ def upper_bound_forced(topic: Topic) -> int:
 
 
 def upper_bound_broker(topic: Topic) -> int:
-    """Per-broker capacity bound: a broker keeps at most rep_hi of its surviving replicas and at most lead_hi of
-    them can be leading; a replica that leads is worth w[cur_role][0], one that follows w[cur_role][1].  The
-    sum over brokers of the best such selection bounds the objective (the one-leader-per-partition and rack rows
-    are relaxed).  Unlike the eviction bound it charges forced evictions AND forced leader changes together."""
-    B = topic.n_brokers
+    """Per-broker capacity bound with a global cap on leading survivors.
+
+    A broker keeps at most rep_hi of its surviving replicas and at most lead_hi of them can be leading; a replica
+    that leads is worth w[cur_role][0], one that follows w[cur_role][1] (one-leader-per-partition and rack rows
+    relaxed).  v_b(L) = best value on broker b with at most L survivors leading.  Brokers with fewer than lead_lo
+    survivors must receive lead_lo - s_b NEW leaders, so at most Lcap = min(#partitions with a survivor,
+    P - sum_b (lead_lo - s_b)+) partitions keep a surviving replica as leader: the bound is
+    sum_b v_b(0) + the Lcap largest marginals of the (upper concave envelopes of the) v_b.  Unlike the eviction
+    bound it charges forced evictions AND forced leader changes together."""
+    B, P = topic.n_brokers, topic.n_partitions
     w = topic.weights
     bd = topic.bounds()
-    on_b: List[List[int]] = [[] for _ in range(B)]  # per broker: current roles (0 leader, 1 follower) of surviving replicas
-    for p in range(topic.n_partitions):
+    n_l = [0] * B
+    n_f = [0] * B
+    with_survivor = 0
+    for p in range(P):
+        alive = False
         for k in range(topic.rf_cur):
             b = int(topic.current[p, k])
             if b != NONE:
-                on_b[b].append(0 if k == 0 else 1)
-    total = 0
-    for roles in on_b:
-        n_l = sum(1 for r in roles if r == 0)
-        n_f = len(roles) - n_l
-        best = 0
-        # x current leaders and y current followers lead (x + y <= lead_hi); the rest of the kept ones follow
-        for x in range(0, min(n_l, bd["lead_hi"]) + 1):
-            for y in range(0, min(n_f, bd["lead_hi"] - x) + 1):
+                alive = True
+                if k == 0:
+                    n_l[b] += 1
+                else:
+                    n_f[b] += 1
+        with_survivor += alive
+    lcap = min(with_survivor, P - sum(max(0, bd["lead_lo"] - (n_l[b] + n_f[b])) for b in range(B)))
+    base = 0
+    marginals: List[int] = []
+    for b in range(B):
+        lmax = min(bd["lead_hi"], bd["rep_hi"], n_l[b] + n_f[b])
+        v = [-1] * (lmax + 1)
+        for x in range(0, min(n_l[b], lmax) + 1):
+            for y in range(0, min(n_f[b], lmax - x) + 1):
                 val = x * w[0][0] + y * w[1][0]
                 slots = bd["rep_hi"] - x - y
-                if slots < 0:
-                    continue
-                gains = sorted([w[0][1]] * (n_l - x) + [w[1][1]] * (n_f - y), reverse=True)
+                gains = sorted([w[0][1]] * (n_l[b] - x) + [w[1][1]] * (n_f[b] - y), reverse=True)
                 val += sum(g for g in gains[:slots] if g > 0)
-                best = max(best, val)
-        total += best
-    return total
+                v[x + y] = max(v[x + y], val)
+        for i in range(1, lmax + 1):  # "at most L leading"
+            v[i] = max(v[i], v[i - 1])
+        base += v[0]
+        # upper concave envelope -> non-increasing marginals (a relaxation: envelope >= v)
+        hull = [(0, v[0])]
+        for i in range(1, lmax + 1):
+            hull.append((i, v[i]))
+            while len(hull) >= 3:
+                (x0, y0), (x1, y1), (x2, y2) = hull[-3], hull[-2], hull[-1]
+                if (y1 - y0) * (x2 - x0) <= (y2 - y0) * (x1 - x0):  # middle point on or below the chord
+                    hull.pop(-2)
+                else:
+                    break
+        for (x0, y0), (x1, y1) in zip(hull, hull[1:]):
+            for t in range(x0 + 1, x1 + 1):  # ceil of the running total keeps it an upper bound
+                up_prev = y0 + -((-(y1 - y0) * (t - 1 - x0)) // (x1 - x0))
+                up_now = y0 + -((-(y1 - y0) * (t - x0)) // (x1 - x0))
+                marginals.append(up_now - up_prev)
+    marginals.sort(reverse=True)
+    return base + sum(m for m in marginals[: max(0, lcap)] if m > 0)
