@@ -31,6 +31,22 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_ffi.KaoStats) == 3 * 8 + 2 * 8 + 2 * 8 + 6 * 4
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/kao.h compiles as pedantic C99 (the JNI shim of INTEGRATION.md is C), its struct sizes are the ones
+    the ctypes binding uses, and a C program can call the host-only entry points."""
+    import ctypes as C
+    import subprocess
+    from kafka_assignment_optimizer_amd import _ffi
+    assert (C.sizeof(_ffi.KaoTopic), C.sizeof(_ffi.KaoOpts), C.sizeof(_ffi.KaoResult), C.sizeof(_ffi.KaoStats)) == (88, 64, 72, 80)
+    exe = str(tmp_path / "abi_check")
+    libdir = os.path.join(ROOT, "kafka_assignment_optimizer_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_check.c"), "-o", exe, "-L", libdir, "-lkao",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    out = subprocess.run([exe], capture_output=True)
+    assert out.returncode == 0 and out.stdout.strip() == b"abi ok", (out.returncode, out.stdout, out.stderr)
+
+
 def test_host_helpers_match_oracle(ko):
     import kafka_assignment_optimizer_amd as kao
     cases = [ko.readme_example(), ko.gen_config(2).topics[0], ko.gen_config(3, n_topics=1).topics[0],
