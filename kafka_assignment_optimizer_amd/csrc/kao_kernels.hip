@@ -33,10 +33,6 @@ __device__ __forceinline__ int band(int c, int lo, int hi) { return max(c - hi, 
 __device__ __forceinline__ int dinc(int c, int lo, int hi) { return (int)(c >= hi) - (int)(c < lo); }
 __device__ __forceinline__ int ddec(int c, int lo, int hi) { return (int)(c <= lo) - (int)(c > hi); }
 
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
 // Wavefront min (all 64 lanes active): butterfly inside each row of 16 with four fused v_min_u32_dpp
 // (quad_perm xor1, xor2, row_half_mirror, row_mirror; hipcc emits mov_dpp + min pairs for the builtin form),
 // then the four row minima are read with v_readlane and combined on the scalar unit.  Result is wave-uniform.
@@ -54,11 +50,14 @@ __device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
     uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
     return min(min(a, b), min(c, d));
 }
+// Wavefront sum, same structure with fused v_add_u32_dpp.
 __device__ __forceinline__ int wave_sum(int v) {
-    v += (int)dpp_mov<0xB1>((uint32_t)v);
-    v += (int)dpp_mov<0x4E>((uint32_t)v);
-    v += (int)dpp_mov<0x141>((uint32_t)v);
-    v += (int)dpp_mov<0x140>((uint32_t)v);
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }

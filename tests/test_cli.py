@@ -70,3 +70,13 @@ def test_cli_readme_example():
     racks = ",".join(f"{b}:{'a' if b % 2 == 0 else 'b'}" for b in range(20))
     r2 = subprocess.run([CLI] + ARGS[:4] + ["--racks", racks], capture_output=True, timeout=120)
     assert json.loads(r2.stdout) == out
+
+
+@pytest.mark.gpu
+def test_python_cli_matches_cpp_cli():
+    import sys
+    _build()
+    r1 = subprocess.run([CLI] + ARGS, capture_output=True, timeout=120)
+    r2 = subprocess.run([sys.executable, "-m", "kafka_assignment_optimizer_amd.cli"] + ARGS, capture_output=True, timeout=120, cwd=ROOT)
+    assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+    assert json.loads(r1.stdout) == json.loads(r2.stdout) == load_golden("kat1.json")["expected_json"]
