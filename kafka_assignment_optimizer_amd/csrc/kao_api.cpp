@@ -59,7 +59,9 @@ int validate(const kao_topic *t) {
     if (!t->rack_of || !t->current) return fail(KAO_ERR_INVALID, "null rack_of/current");
     for (int b = 0; b < t->n_brokers; ++b)
         if (t->rack_of[b] >= t->n_racks) return fail(KAO_ERR_INVALID, "rack_of entry >= n_racks");
-    if ((int64_t)t->n_partitions * t->rf > 32767) return fail(KAO_ERR_UNSUPPORTED, "more than 32767 replicas in one topic (16-bit packed counters)");
+    if ((int64_t)t->n_partitions * t->rf > 4000000) return fail(KAO_ERR_UNSUPPORTED, "more than 4,000,000 replicas in one topic");
+    if (((int64_t)t->n_partitions * t->rf + t->n_brokers - 1) / t->n_brokers > 30000)
+        return fail(KAO_ERR_UNSUPPORTED, "more than 30,000 replicas per broker on average (16-bit per-broker counters)");
     return KAO_OK;
 }
 
@@ -364,6 +366,7 @@ struct kao_eval_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int cands_per_block = 32;
+    bool cur_in_lds = true;
 };
 
 struct kao_session {
@@ -372,12 +375,15 @@ struct kao_session {
     std::vector<PreparedTopic> pts;
     std::vector<kao_topic> topics;  // shallow copies (pointers not retained for device work)
     std::vector<int64_t> ub;
+    std::vector<char> topic_global;  // per topic: runs with its assignment in global memory
     int total_restarts = 0;
     // Topics are bucketed by LDS footprint into launch groups (a 3000-partition topic must not impose its LDS carve
     // and its 2 waves per workgroup on 200 small topics); one K-search + one K-eval launch per group per step.
     struct LaunchGroup {
         int maxP = 0, maxBx = 0, maxB = 0;
         int waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
+        bool global_a = false;   // topic too large for LDS: assignment + current words stay in global memory
+        bool cur_in_lds = true;  // K-eval stages the current assignment in LDS (false: reads it from global)
         int smap_off = 0, smap_n = 0, emap_off = 0, emap_n = 0;
     };
     std::vector<LaunchGroup> groups;
@@ -389,12 +395,12 @@ struct kao_session {
     TopicDev *d_topics = nullptr;
     int2 *d_smap = nullptr;
     int4 *d_emap = nullptr;
-    uint2 *d_cur = nullptr;
+    uint4 *d_cur = nullptr;
     uint16_t *d_ext = nullptr;
     int32_t *d_rsz = nullptr;
     uint8_t *d_rackof = nullptr;
     uint16_t *d_curd = nullptr;
-    uint2 *d_state = nullptr;
+    unsigned char *d_state = nullptr;
     uint16_t *d_best = nullptr;
     int32_t *d_info = nullptr;
     int32_t *d_obj = nullptr;
@@ -574,7 +580,8 @@ int kao_eval_plan_create(const kao_topic *t, kao_eval_plan **out) {
     kao_eval_plan *p = new kao_eval_plan();
     rc = prepare(t, 0, p->pt);
     if (rc) { delete p; return rc; }
-    if (eval_lds_bytes(p->pt.d.P, p->pt.d.B) > 160 * 1024) { delete p; return fail(KAO_ERR_UNSUPPORTED, "topic tables exceed 160 KiB of LDS"); }
+    p->cur_in_lds = eval_lds_bytes(p->pt.d.P, p->pt.d.B, true) <= 160 * 1024;
+    if (eval_lds_bytes(p->pt.d.P, p->pt.d.B, p->cur_in_lds) > 160 * 1024) { delete p; return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS"); }
     p->pt.d.best_off = 0; p->pt.d.rackof_off = 0; p->pt.d.curd_off = 0;
     std::vector<TopicDev> td(1, p->pt.d);
     if ((rc = dev_alloc_copy(&p->d_topic, td)) || (rc = dev_alloc_copy(&p->d_rackof, p->pt.rack_of)) ||
@@ -612,7 +619,7 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
     pl.objective = static_cast<int32_t *>(d_objective);
     pl.violations = static_cast<int32_t *>(d_violations);
     pl.best_key = static_cast<unsigned long long *>(d_best_key);
-    pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B;
+    pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B; pl.cur_in_lds = p->cur_in_lds ? 1 : 0;
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     launch_eval(pl, p->map_blocks, p->stream);
     HIP_TRY(hipGetLastError());
@@ -782,14 +789,21 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         o.restarts = std::min(std::max(r, 8), 8192);
     }
     if (o.restarts > (1 << 20)) o.restarts = 1 << 20;
+    {   // huge topics: keep the per-restart state (16 B working words + snapshot per partition) within ~8 GB of HBM
+        uint64_t per_restart = 0;
+        for (int t = 0; t < n_topics; ++t) per_restart += (uint64_t)topics[t].n_partitions * (16 + 2 * (uint64_t)std::max(topics[t].rf, 1));
+        const uint64_t cap = (8ull << 30) / std::max<uint64_t>(per_restart, 1);
+        if ((uint64_t)o.restarts > cap) o.restarts = (int)std::max<uint64_t>(cap / kWaves * kWaves, kWaves);
+    }
     s->opts = o;
     s->pts.resize((size_t)n_topics);
     s->topics.assign(topics, topics + n_topics);
     s->ub.resize((size_t)n_topics);
 
-    std::vector<uint2> cur_pool; std::vector<uint16_t> ext_pool, curd_pool; std::vector<int32_t> rsz_pool;
+    std::vector<uint4> cur_pool; std::vector<uint16_t> ext_pool, curd_pool; std::vector<int32_t> rsz_pool;
     std::vector<uint8_t> rackof_pool;
-    uint64_t state_parts = 0, best_u16 = 0, win_u16 = 0;
+    uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0;
+    s->topic_global.assign((size_t)n_topics, 0);
     int restart_base = 0;
     for (int t = 0; t < n_topics; ++t) {
         PreparedTopic &pt = s->pts[(size_t)t];
@@ -802,16 +816,19 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         d.restart_base = restart_base;
         restart_base += o.restarts;
         d.cur_off = (uint32_t)cur_pool.size();
-        for (int p = 0; p < d.P; ++p) {
+        auto word = [&](uint16_t x) { return x == KAO_NONE ? kNoneW : ((uint32_t)x | ((uint32_t)(x / d.m) << 16)); };
+        for (int p = 0; p < d.P; ++p) {  // LDS / register form of a replica: internal index | rack << 16
             const uint16_t *c = &pt.cur_int[(size_t)p * kRFP];
-            cur_pool.push_back(make_uint2((uint32_t)c[0] | ((uint32_t)c[1] << 16), (uint32_t)c[2] | ((uint32_t)c[3] << 16)));
+            cur_pool.push_back(make_uint4(word(c[0]), word(c[1]), word(c[2]), word(c[3])));
         }
+        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false) > 160 * 1024;
+        s->topic_global[(size_t)t] = global_a;
         d.ext_off = (uint32_t)ext_pool.size();
         ext_pool.insert(ext_pool.end(), pt.ext_of.begin(), pt.ext_of.end());
         d.rsz_off = (uint32_t)rsz_pool.size();
         rsz_pool.insert(rsz_pool.end(), pt.rack_size.begin(), pt.rack_size.end());
-        d.state_off = state_parts;
-        state_parts += (uint64_t)o.restarts * d.P;
+        d.state_off = state_bytes;  // bytes: 8 per partition (packed, LDS path) or 16 (working words, global path)
+        state_bytes += align_up((uint64_t)o.restarts * d.P * (global_a ? 16 : 8));
         d.best_off = best_u16;
         best_u16 += (uint64_t)o.restarts * d.P * d.RF;
         d.win_off = (uint32_t)win_u16;
@@ -827,7 +844,11 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     // ---- launch groups: topics sorted by single-wave LDS need, a new group whenever the need doubles (<= 8 groups) ----
     std::vector<int> order((size_t)n_topics);
     for (int t = 0; t < n_topics; ++t) order[(size_t)t] = t;
-    auto need1 = [&](int t) { const TopicDev &d = s->pts[(size_t)t].d; return search_lds_bytes(d.P, d.Bx, 1); };
+    auto need1 = [&](int t) {  // topics kept in global memory sort last (their LDS need is tiny but they form their own groups)
+        const TopicDev &d = s->pts[(size_t)t].d;
+        const bool ga = s->topic_global[(size_t)t] != 0;
+        return (ga ? ((size_t)1 << 40) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga);
+    };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need1(x) < need1(y); });
     std::vector<std::vector<int>> members;
     size_t group_base = 0;
@@ -843,11 +864,12 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
             const TopicDev &d = s->pts[(size_t)t].d;
             g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B);
         }
-        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves) > 160 * 1024) g.waves /= 2;
-        if (search_lds_bytes(g.maxP, g.maxBx, g.waves) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB) > 160 * 1024) {
+        g.global_a = s->topic_global[(size_t)mem[0]] != 0;
+        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a) > 160 * 1024) g.waves /= 2;
+        g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true) <= 160 * 1024;
+        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds) > 160 * 1024) {
             kao_session_destroy(s);
-            return fail(KAO_ERR_UNSUPPORTED, "topic state exceeds 160 KiB of LDS even with one restart per workgroup "
-                                             "(32 B x partitions + 5 B x padded brokers)");
+            return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS (about 30,000 padded brokers)");
         }
         std::vector<int2> gs; std::vector<int> gs_topic;
         std::vector<int4> ge; std::vector<int> ge_topic;
@@ -875,7 +897,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     // ---- read-only arena: stage everything on the host, ONE hipMalloc (or a parked arena), ONE H2D copy ----
     struct Sec { const void *src; size_t bytes; size_t off; };
     Sec secs[8] = {{tds.data(), tds.size() * sizeof(TopicDev), 0}, {smap.data(), smap.size() * sizeof(int2), 0},
-                   {emap.data(), emap.size() * sizeof(int4), 0}, {cur_pool.data(), cur_pool.size() * sizeof(uint2), 0},
+                   {emap.data(), emap.size() * sizeof(int4), 0}, {cur_pool.data(), cur_pool.size() * sizeof(uint4), 0},
                    {ext_pool.data(), ext_pool.size() * 2, 0}, {rsz_pool.data(), rsz_pool.size() * 4, 0},
                    {rackof_pool.data(), rackof_pool.size(), 0}, {curd_pool.data(), curd_pool.size() * 2, 0}};
     size_t ro_bytes = 0;
@@ -887,14 +909,14 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->d_topics = reinterpret_cast<TopicDev *>(ro + secs[0].off);
     s->d_smap = reinterpret_cast<int2 *>(ro + secs[1].off);
     s->d_emap = reinterpret_cast<int4 *>(ro + secs[2].off);
-    s->d_cur = reinterpret_cast<uint2 *>(ro + secs[3].off);
+    s->d_cur = reinterpret_cast<uint4 *>(ro + secs[3].off);
     s->d_ext = reinterpret_cast<uint16_t *>(ro + secs[4].off);
     s->d_rsz = reinterpret_cast<int32_t *>(ro + secs[5].off);
     s->d_rackof = reinterpret_cast<uint8_t *>(ro + secs[6].off);
     s->d_curd = reinterpret_cast<uint16_t *>(ro + secs[7].off);
 
     // ---- mutable arena ----
-    const size_t state_b = align_up(state_parts * sizeof(uint2)), best_b = align_up(best_u16 * 2);
+    const size_t state_b = align_up(state_bytes), best_b = align_up(best_u16 * 2);
     const size_t info_b = align_up((size_t)s->total_restarts * 16), obj_b = align_up((size_t)s->total_restarts * 4);
     const size_t viol_b = align_up((size_t)s->total_restarts * 32);
     s->rb_viol_off = align_up((size_t)n_topics * 8 + 16, 16);
@@ -903,7 +925,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     const size_t rw_bytes = state_b + best_b + info_b + obj_b + viol_b + align_up(s->readback_bytes);
     if ((rc = arena_get(rw_bytes, &s->arena_rw, &s->arena_rw_bytes))) { kao_session_destroy(s); return rc; }
     unsigned char *rw = static_cast<unsigned char *>(s->arena_rw);
-    s->d_state = reinterpret_cast<uint2 *>(rw);
+    s->d_state = rw;
     s->d_best = reinterpret_cast<uint16_t *>(rw + state_b);
     s->d_info = reinterpret_cast<int32_t *>(rw + state_b + best_b);
     s->d_obj = reinterpret_cast<int32_t *>(rw + state_b + best_b + info_b);
@@ -957,13 +979,13 @@ int kao_session_step(kao_session *s) {
     for (const kao_session::LaunchGroup &g : s->groups) {
         sp.block_map = s->d_smap + g.smap_off;
         prm.maxP = g.maxP; prm.maxBx = g.maxBx;
-        launch_search(sp, prm, g.smap_n, g.waves, s->stream);
+        launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->stream);
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
     for (const kao_session::LaunchGroup &g : s->groups) {
         ep.block_map = s->d_emap + g.emap_off;
-        ep.maxP = g.maxP; ep.maxB = g.maxB;
+        ep.maxP = g.maxP; ep.maxB = g.maxB; ep.cur_in_lds = g.cur_in_lds ? 1 : 0;
         launch_eval(ep, g.emap_n, s->stream);
         HIP_TRY(hipGetLastError());
     }
@@ -1035,7 +1057,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
     for (const kao_session::LaunchGroup &g : s->groups)
-        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves));
+        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a));
     out->launch_groups = (int32_t)s->groups.size();
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));
@@ -1051,10 +1073,14 @@ int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, ui
     int rc = kao_session_sync(s);
     if (rc) return rc;
     if (final_state) {
-        std::vector<uint2> st((size_t)d.P);
-        HIP_TRY(hipMemcpy(st.data(), s->d_state + d.state_off + (uint64_t)restart * d.P, st.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+        const bool ga = s->topic_global[(size_t)topic] != 0;
+        std::vector<uint32_t> raw((size_t)d.P * (ga ? 4 : 2));
+        HIP_TRY(hipMemcpy(raw.data(), s->d_state + d.state_off + (uint64_t)restart * d.P * (ga ? 16 : 8), raw.size() * 4, hipMemcpyDeviceToHost));
         for (int p = 0; p < d.P; ++p) {
-            const uint16_t x[4] = {(uint16_t)(st[p].x & 0xFFFF), (uint16_t)(st[p].x >> 16), (uint16_t)(st[p].y & 0xFFFF), (uint16_t)(st[p].y >> 16)};
+            uint16_t x[4];
+            if (ga) for (int k = 0; k < 4; ++k) x[k] = (uint16_t)(raw[(size_t)p * 4 + k] & 0xFFFF);  // word = x | rack << 16 (none: all ones)
+            else { x[0] = (uint16_t)(raw[(size_t)p * 2] & 0xFFFF); x[1] = (uint16_t)(raw[(size_t)p * 2] >> 16);
+                   x[2] = (uint16_t)(raw[(size_t)p * 2 + 1] & 0xFFFF); x[3] = (uint16_t)(raw[(size_t)p * 2 + 1] >> 16); }
             for (int k = 0; k < d.RF; ++k) final_state[(size_t)p * d.RF + k] = x[k] < pt.ext_of.size() ? pt.ext_of[x[k]] : (uint16_t)KAO_NONE;
         }
     }

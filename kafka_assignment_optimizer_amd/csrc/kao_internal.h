@@ -23,10 +23,11 @@ struct TopicDev {
     uint32_t seed_lo, seed_hi;   // per-topic seed
     int32_t n_restarts;          // restarts (wavefronts) searching this topic
     int32_t restart_base;        // index of restart 0 in the per-restart arrays
-    uint32_t cur_off;            // cur_pool   : first partition (uint2 = 4 x u16 internal idx per partition)
+    uint32_t cur_off;            // cur_pool   : first partition (uint4 = 4 words x | rack << 16 per partition)
     uint32_t ext_off;            // ext_pool   : internal -> dense (u16[Bx])
     uint32_t rsz_off;            // rsz_pool   : rack sizes (int32[R])
-    uint64_t state_off;          // state_pool : first partition of restart 0 (uint2 per partition)
+    uint64_t state_off;          // state_pool : BYTE offset of restart 0 (uint2 per partition, or uint4 words when the
+                                 //              topic runs with its assignment in global memory)
     uint64_t best_off;           // best_pool  : first u16 of restart 0's dense snapshot ([P*RF] per restart)
     // ---- dense index space, used by K-eval ---------------------------------------------
     int32_t B, rf_cur;
@@ -47,10 +48,10 @@ struct SearchParams {
 struct SearchPools {
     const TopicDev *topics;
     const int2 *block_map;       // per workgroup: {topic, first restart}
-    const uint2 *cur_pool;
+    const uint4 *cur_pool;
     const uint16_t *ext_pool;
     const int32_t *rsz_pool;
-    uint2 *state_pool;
+    unsigned char *state_pool;
     uint16_t *best_pool;
     int32_t *restart_info;       // [n_restarts_total][4] = {best_obj, V, obj, accepted}
     int32_t *drift;              // [1] counter
@@ -66,11 +67,12 @@ struct EvalPools {
     int32_t *violations;         // [n*8] or nullptr
     unsigned long long *best_key;// [n_topics] or nullptr (atomicMin of the packed key)
     int32_t maxP, maxB;
+    int32_t cur_in_lds;          // 1 = stage the current assignment in LDS (fits); 0 = read it from global memory
 };
 
-size_t search_lds_bytes(int maxP, int maxBx, int waves);
-size_t eval_lds_bytes(int maxP, int maxB);
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, void *stream);
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a);
+size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, void *stream);
 void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
 // copy every topic's winning snapshot (restart id in its packed key) and violation row into contiguous
 // read-back buffers: one D2H instead of two per topic

@@ -193,6 +193,12 @@ __device__ __forceinline__ void snapshot(const TopicRegs &T, const WaveLds &L, c
     }
 }
 
+// kGlobalA = false: the restart's assignment words and the topic's current-assignment words are staged in LDS
+//                   (topics that fit: the fast path).
+// kGlobalA = true : they stay in global memory (HBM / L2) -- 16 B per partition per restart, updated in place --
+//                   and only the broker / rack tables live in LDS.  Same algorithm, same results; this is what
+//                   lets a single 100k-partition topic run.
+template <bool kGlobalA>
 __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -206,23 +212,27 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     T.rack_lo = TD->rack_lo; T.rack_hi = TD->rack_hi; T.prack_lo = TD->prack_lo; T.prack_hi = TD->prack_hi;
     T.w00 = TD->w00; T.w01 = TD->w01; T.w10 = TD->w10; T.w11 = TD->w11;
 
-    // ---- LDS carve: [CUR uint4[maxP]] [RSZ int[64]] [XR u8[Bx rounded to 64]] then per wave
-    //      [A uint4[maxP]] [C u32[Bx rounded to 64]] [K int[64]] [RT int[64]]
-    const int a_bytes = prm.maxP * 16;
+    // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[64]] [XR u8[Bx rounded to 64]] then per wave
+    //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [K int[64]] [RT int[64]]          (* only when !kGlobalA)
+    const int a_bytes = kGlobalA ? 0 : prm.maxP * 16;
     const int bx64 = (prm.maxBx + 63) & ~63;
     const int c_bytes = bx64 * 4;
-    uint4 *CUR = reinterpret_cast<uint4 *>(smem);
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
     uint8_t *XR = smem + a_bytes + 256;  // rack of internal index x, 0xFF = padding slot / beyond Bx
     unsigned char *wb = smem + a_bytes + 256 + bx64 + wave * (a_bytes + c_bytes + 512);  // blockDim.x / 64 waves
+    const uint4 *cur_words = pl.cur_pool + TD->cur_off;  // host-prepared words x | rack << 16 (0xFFFFFFFF = none)
+    const uint4 *CUR;
+    if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const uint4 *>(smem);
     WaveLds L;
-    L.A = reinterpret_cast<uint4 *>(wb);
     L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
     L.K = reinterpret_cast<int *>(wb + a_bytes + c_bytes);
     L.RT = L.K + 64;
 
-    // ---- stage the topic's current-assignment table and rack sizes (shared by the 4 restarts) ----
-    for (int p = threadIdx.x; p < T.P; p += blockDim.x) CUR[p] = expand(T, pl.cur_pool[TD->cur_off + p]);
+    // ---- stage the rack sizes / rack-of-index table (and, when it fits, the current-assignment words) ----
+    if (!kGlobalA) {
+        uint4 *cur_lds = reinterpret_cast<uint4 *>(smem);
+        for (int p = threadIdx.x; p < T.P; p += blockDim.x) cur_lds[p] = cur_words[p];
+    }
     if (threadIdx.x < 64) RSZ[threadIdx.x] = (int)threadIdx.x < T.R ? pl.rsz_pool[TD->rsz_off + threadIdx.x] : 0;
     __syncthreads();
     for (int x = threadIdx.x; x < ((T.Bx + 63) & ~63); x += blockDim.x) {
@@ -234,7 +244,11 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const int rho = bm.y + wave;
     if (rho >= TD->n_restarts) return;  // no block-level barrier below this point
     const int g = TD->restart_base + rho;
-    uint2 *state = pl.state_pool + TD->state_off + (uint64_t)rho * T.P;
+    // restart state in HBM: packed 4 x u16 per partition (LDS path, loaded / stored around the launch) or the
+    // working words themselves, 16 B per partition, updated in place (global path)
+    uint2 *state_packed = reinterpret_cast<uint2 *>(pl.state_pool + TD->state_off) + (uint64_t)rho * T.P;
+    if (kGlobalA) L.A = reinterpret_cast<uint4 *>(pl.state_pool + TD->state_off) + (uint64_t)rho * T.P;
+    else L.A = reinterpret_cast<uint4 *>(wb);
     uint16_t *best = pl.best_pool + TD->best_off + (uint64_t)rho * T.P * T.RF;
     const uint16_t *ext = pl.ext_pool + TD->ext_off;
     const uint32_t slo = TD->seed_lo, shi = TD->seed_hi;
@@ -252,64 +266,63 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         }
         best_obj = -1; accepted = 0;
     } else {
-        for (int p = lane; p < T.P; p += 64) L.A[p] = expand(T, state[p]);
+        if (!kGlobalA)
+            for (int p = lane; p < T.P; p += 64) L.A[p] = expand(T, state_packed[p]);
         best_obj = pl.restart_info[g * 4 + 0];
         accepted = pl.restart_info[g * 4 + 3];
     }
+    if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own stores visible to every lane's loads
     recount(T, L, lane);
 
     if (prm.init) {
-        // ---- greedy hole filling: holes in (p,k) order, best of 64 hashed tries (one per lane) ----
-        for (int p = 0; p < T.P; ++p) {
-            uint4 a = L.A[p];  // same address in every lane: LDS broadcast
-            const uint4 c = CUR[p];
+        // ---- hole filling by best insertion, holes in (p,k) order.  Partitions are inspected 64 at a time (one per
+        //      lane); only those with a hole are visited, in ascending order. ----
+        for (int pbase = 0; pbase < T.P; pbase += 64) {
+            bool has_hole = false;
+            if (pbase + lane < T.P) {
+                const uint4 al = L.A[pbase + lane];
+                has_hole = (al.x == kNoneW) || (T.RF > 1 && al.y == kNoneW) || (T.RF > 2 && al.z == kNoneW) || (T.RF > 3 && al.w == kNoneW);
+            }
+            unsigned long long todo = __ballot(has_hole);
+            while (todo) {
+                const int p = pbase + __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                uint4 a = L.A[p];  // same address in every lane: broadcast
+                const uint4 c = CUR[p];
 #pragma unroll
-            for (int k = 0; k < kRFP; ++k) {
-                if (k >= T.RF) break;
-                if (sel4(a, k) != kNoneW) continue;  // wave-uniform
-                const uint32_t u = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * kRFP + k) * 0x27D4EB2Fu +
-                                                       (uint32_t)lane * 0x165667B1u + 0x5BD1E995u));
-                const uint32_t x = mulhi(u, (uint32_t)T.Bx);
-                const uint32_t rn = mulhi(x, T.magic);
-                const uint32_t xw = x | (rn << 16);
-                const bool ok = ((int)(x - rn * T.m) < RSZ[rn]) && !in4(a, xw);
-                uint32_t key = kKeyNull;
-                if (ok) {
-                    const uint32_t cn = L.C[x];
-                    int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[rn], T.rack_lo, T.rack_hi) +
-                             dinc(cnt4(a, rn), T.prack_lo, T.prack_hi);
-                    if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
-                    int delta = prm.lam_max * dV - S * role_w(T, c, xw, k == 0 ? 0 : 1);
-                    delta = max(delta, -kDBias);
-                    delta = min(delta, kDBias - 2);
-                    key = ((uint32_t)(delta + kDBias) << 16) | (uint32_t)lane;
-                }
-                const uint32_t kmin = wave_umin(key);
-                uint32_t xw_win;
-                if (kmin != kKeyNull) {
-                    xw_win = (uint32_t)__builtin_amdgcn_readlane((int)xw, (int)(kmin & 63u));
-                } else {  // all 64 tries invalid: lowest valid x not in the partition
-                    xw_win = kNoneW;
+                for (int k = 0; k < kRFP; ++k) {
+                    if (k >= T.RF) break;
+                    if (sel4(a, k) != kNoneW) continue;  // wave-uniform
+                    // best insertion: every valid broker not in the partition, 64 per round (lane = internal index)
+                    const uint32_t hmix = slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * kRFP + k) * 0x27D4EB2Fu + 0x5BD1E995u);
+                    const int wl = k == 0 ? T.w00 : T.w01, wf = k == 0 ? T.w10 : T.w11;
+                    uint32_t key = kKeyNull, xw_l = kNoneW;
                     for (int base = 0; base < T.Bx; base += 64) {
-                        const uint32_t y = (uint32_t)(base + lane);
-                        const uint32_t ry = mulhi(y, T.magic);
-                        const uint32_t yw = y | (ry << 16);
-                        const bool oky = (int)y < T.Bx && ((int)(y - ry * T.m) < RSZ[ry < 64 ? ry : 0]) && !in4(a, yw);
-                        const unsigned long long bal = __ballot(oky);
-                        if (bal) {
-                            xw_win = (uint32_t)__builtin_amdgcn_readlane((int)yw, __ffsll((long long)bal) - 1);
-                            break;
-                        }
+                        const uint32_t x = (uint32_t)(base + lane);
+                        const uint32_t r = XR[x];
+                        const uint32_t xw = x | (r << 16);
+                        const bool okx = (r != 0xFFu) & !in4(a, xw);
+                        const uint32_t cn = L.C[x];
+                        int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[r & 63u], T.rack_lo, T.rack_hi) +
+                                 dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
+                        if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+                        const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
+                        const uint32_t keyx = okx ? make_key_tie(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), tie) : kKeyNull;
+                        if (keyx < key) { key = keyx; xw_l = xw; }
                     }
-                }
-                if (k == 0) a.x = xw_win; else if (k == 1) a.y = xw_win; else if (k == 2) a.z = xw_win; else a.w = xw_win;
-                if (lane == 0) {
-                    reinterpret_cast<uint32_t *>(&L.A[p])[k] = xw_win;
-                    L.C[xw_win & 0xFFFFu] += (k == 0) ? 0x10001u : 1u;
-                    L.K[xw_win >> 16] += 1;
+                    const uint32_t kmin = wave_umin(key);
+                    const unsigned long long bal = __ballot(key == kmin);
+                    const uint32_t xw_win = (uint32_t)__builtin_amdgcn_readlane((int)xw_l, __ffsll((long long)bal) - 1);  // ties: lowest lane
+                    if (k == 0) a.x = xw_win; else if (k == 1) a.y = xw_win; else if (k == 2) a.z = xw_win; else a.w = xw_win;
+                    if (lane == 0) {
+                        reinterpret_cast<uint32_t *>(&L.A[p])[k] = xw_win;
+                        L.C[xw_win & 0xFFFFu] += (k == 0) ? 0x10001u : 1u;
+                        L.K[xw_win >> 16] += 1;
+                    }
                 }
             }
         }
+        if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 
     int V, obj;
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const uint32_t P8 = (uint32_t)T.P << 8, RF8 = (uint32_t)T.RF << 8, R8 = (uint32_t)T.R << 8, m8 = (uint32_t)T.m << 8;
 
     const int T_tour = min(64, max(4, (T.P * T.RF) >> 2));  // lanes taking part in the slot tournament
-    const int GA = min(4, max(1, (T.P * T.RF) >> 8));        // random slots scored per lane
+    const int GA = min(16, max(1, (T.P * T.RF) >> 8));       // random slots scored per lane
     const int x_rounds_full = (T.P + 63) >> 6;
     const bool x_windowed = x_rounds_full > 8;               // EXCHANGE scans at most 8 rounds of 64 partitions
 
@@ -333,7 +346,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         const uint32_t it = prm.launch * prm.iters + i;
         const int type = (int)((0x1210u >> ((it & 7u) * 2u)) & 3u);  // pattern R R X R L R X R
         const uint32_t ph = it & pmask;
-        const int lam = min(prm.lam_max, prm.lam_min + (int)((2u * ph * lrange) >> plog));
+        // no oscillation before the restart has been feasible once (best_obj < 0): the penalty stays at lam_max
+        const int lam = best_obj < 0 ? prm.lam_max : min(prm.lam_max, prm.lam_min + (int)((2u * ph * lrange) >> plog));
         // REPLACE alternates, in blocks of 8 iterations, between "scan" (one slot, every broker) and "sample"
         // (every lane its own slot, 4 brokers); EXCHANGE always scans; LEADER-SWAP always samples
         const bool sampled = (type == 2) || (type == 0 && ((it >> 3) & 1u));
@@ -421,8 +435,12 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t co = L.C[oldw & 0xFFFFu];
                 int dvo = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
                 if (leadl) dvo += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
-                const int dvr = ddec(L.K[rol], T.rack_lo, T.rack_hi) + ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
-                const uint32_t keyg = lane < T_tour ? make_key(lam, S, dvo + min(dvr, 0), -g_old_g, lane) : kKeyNull;
+                const int dv7 = ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
+                const int dvr = ddec(L.K[rol], T.rack_lo, T.rack_hi) + dv7;
+                // removal score.  REPLACE: the replica leaves its broker and (at best) its rack.  EXCHANGE: broker and
+                // rack totals do not change, only the partition's own rack spread (C7) can improve.
+                const int sc = (type == 0) ? dvo + min(dvr, 0) : min(dv7, 0);
+                const uint32_t keyg = lane < T_tour ? make_key(lam, S, sc, -g_old_g, lane) : kKeyNull;
                 if (keyg < keyA) { keyA = keyg; pl_ = pg; kl_ = kg; oldw_l = oldw; g_old_l = g_old_g; dvo_l = dvo; dvr_l = dvr; }
             }
             const int wA = (int)(wave_umin(keyA) & 63u);
@@ -536,6 +554,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 ap[k] = uw;
             }
         }
+        if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the winner's stores before the next loads
         V += __builtin_amdgcn_readlane(dV, win);
         obj += __builtin_amdgcn_readlane(dObj, win);
         accepted++;
@@ -547,7 +566,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     int V2, obj2;
     full_cost(T, L, CUR, RSZ, lane, V2, obj2);
     if ((V2 != V || obj2 != obj) && lane == 0) atomicAdd(pl.drift, 1);
-    for (int p = lane; p < T.P; p += 64) state[p] = pack(L.A[p]);
+    if (!kGlobalA)
+        for (int p = lane; p < T.P; p += 64) state_packed[p] = pack(L.A[p]);
     if (lane == 0) {
         pl.restart_info[g * 4 + 0] = best_obj;
         pl.restart_info[g * 4 + 1] = V2;
@@ -574,7 +594,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
 
     // ---- LDS carve: [wave_key 32 B] [RACK u8[maxB~]] [CURD uint2[maxP]] then per wave [C u32[maxB~]] [K int[64]]
     const int r_bytes = (pl.maxB + 15) & ~15;
-    const int d_bytes = pl.maxP * 8;
+    const int d_bytes = pl.cur_in_lds ? pl.maxP * 8 : 0;  // huge topics read the current assignment from global memory
     const int c_bytes = (pl.maxB * 4 + 15) & ~15;
     uint8_t *RACK = smem;
     uint2 *CURD = reinterpret_cast<uint2 *>(smem + r_bytes);
@@ -584,14 +604,17 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
 
     // ---- stage the broker->rack table and the current assignment (padded to 4 slots) ----
     for (int b = threadIdx.x; b < B; b += 256) RACK[b] = pl.rackof_pool[TD->rackof_off + b];
-    for (int p = threadIdx.x; p < P; p += 256) {
-        const uint16_t *cp = pl.curd_pool + TD->curd_off + (size_t)p * rf_cur;
+    const uint16_t *curd = pl.curd_pool + TD->curd_off;
+    auto load_cur = [&](int p) {  // current replicas of partition p, padded to 4 slots with 0xFFFF
+        const uint16_t *cp = curd + (size_t)p * rf_cur;
         const uint32_t c0 = cp[0];
         const uint32_t c1 = rf_cur > 1 ? cp[1] : 0xFFFFu;
         const uint32_t c2 = rf_cur > 2 ? cp[2] : 0xFFFFu;
         const uint32_t c3 = rf_cur > 3 ? cp[3] : 0xFFFFu;
-        CURD[p] = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
-    }
+        return make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+    };
+    if (pl.cur_in_lds)
+        for (int p = threadIdx.x; p < P; p += 256) CURD[p] = load_cur(p);
     __syncthreads();
 
     unsigned long long my_key = ~0ull;
@@ -616,7 +639,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             const bool ok0 = b0 < (uint32_t)B, ok1 = b1 < (uint32_t)B, ok2 = b2 < (uint32_t)B, ok3 = b3 < (uint32_t)B;
             const int missing = (int)!ok0 + (RF > 1 ? (int)!ok1 : 0) + (RF > 2 ? (int)!ok2 : 0) + (RF > 3 ? (int)!ok3 : 0);
             s12 += (uint32_t)missing + ((uint32_t)!ok0 << 16);  // C1: sum_b (f+l) = RF ; C2: exactly one leader
-            const uint2 cu = CURD[p];
+            const uint2 cu = pl.cur_in_lds ? CURD[p] : load_cur(p);
             const uint32_t c0 = cu.x & 0xFFFFu, c1 = cu.x >> 16, c2 = cu.y & 0xFFFFu, c3 = cu.y >> 16;
             uint32_t r0 = 0xFFu, r1 = 0xFFu, r2 = 0xFFu, r3 = 0xFFu;
             if (ok0) {
@@ -665,13 +688,22 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             s57 += (uint32_t)(s7 + (R - touched) * prack_lo) << 16;
         }
         obj = wave_sum(obj);
-        const uint32_t t12 = (uint32_t)wave_sum((int)s12), t3 = (uint32_t)wave_sum((int)s3), t4 = (uint32_t)wave_sum((int)s4);
-        const uint32_t t6 = (uint32_t)wave_sum((int)s6), t57 = (uint32_t)wave_sum((int)s57);
-        const int v1 = (int)(t12 & 0xFFFFu), v2 = (int)(t12 >> 16);
-        const int v3 = B * rep_lo + (int)(t3 & 0xFFFFu) - (int)(t3 >> 16);
-        const int v4 = B * lead_lo + (int)(t4 & 0xFFFFu) - (int)(t4 >> 16);
-        const int v6 = R * rack_lo + (int)(t6 & 0xFFFFu) - (int)(t6 >> 16);
-        const int v5 = (int)(t57 & 0xFFFFu), v7 = (int)(t57 >> 16);
+        int v1, v2, v3, v4, v5, v6, v7;
+        if (P * RF <= 32767) {  // packed halves cannot carry: every count is at most P*RF
+            const uint32_t t12 = (uint32_t)wave_sum((int)s12), t3 = (uint32_t)wave_sum((int)s3), t4 = (uint32_t)wave_sum((int)s4);
+            const uint32_t t6 = (uint32_t)wave_sum((int)s6), t57 = (uint32_t)wave_sum((int)s57);
+            v1 = (int)(t12 & 0xFFFFu); v2 = (int)(t12 >> 16);
+            v3 = B * rep_lo + (int)(t3 & 0xFFFFu) - (int)(t3 >> 16);
+            v4 = B * lead_lo + (int)(t4 & 0xFFFFu) - (int)(t4 >> 16);
+            v6 = R * rack_lo + (int)(t6 & 0xFFFFu) - (int)(t6 >> 16);
+            v5 = (int)(t57 & 0xFFFFu); v7 = (int)(t57 >> 16);
+        } else {  // huge topic: per-lane halves still fit 16 bits, the wavefront totals do not -> sum them unpacked
+            v1 = wave_sum((int)(s12 & 0xFFFFu)); v2 = wave_sum((int)(s12 >> 16));
+            v3 = B * rep_lo + wave_sum((int)(s3 & 0xFFFFu)) - wave_sum((int)(s3 >> 16));
+            v4 = B * lead_lo + wave_sum((int)(s4 & 0xFFFFu)) - wave_sum((int)(s4 >> 16));
+            v6 = R * rack_lo + wave_sum((int)(s6 & 0xFFFFu)) - wave_sum((int)(s6 >> 16));
+            v5 = wave_sum((int)(s57 & 0xFFFFu)); v7 = wave_sum((int)(s57 >> 16));
+        }
         const int v0 = v1 + v2 + v3 + v4 + v5 + v6 + v7;
         const int out = bm.w + (ci - bm.y);
         if (lane == 0) {
@@ -717,29 +749,33 @@ __global__ __launch_bounds__(64) void k_gather(const TopicDev *topics, const uns
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t search_lds_bytes(int maxP, int maxBx, int waves) {
-    const size_t a = (size_t)maxP * 16, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a) {
+    const size_t a = global_a ? 0 : (size_t)maxP * 16, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
     return a + 256 + bx64 + (size_t)waves * (a + bx64 * 4 + 512);
 }
-size_t eval_lds_bytes(int maxP, int maxB) {
-    const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = ((size_t)maxP * 8 + 15) & ~(size_t)15;
+size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds) {
+    const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 8 + 15) & ~(size_t)15 : 0;
     const size_t c = ((size_t)maxB * 4 + 15) & ~(size_t)15;
     return 32 + r + d + kWaves * (c + 256);
 }
 
 static int g_attr_search = 0, g_attr_eval = 0;
 
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, void *stream) {
-    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, void *stream) {
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a);
     if ((int)lds > g_attr_search) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_search = (int)lds;
     }
-    hipLaunchKernelGGL(k_search, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools, prm);
+    if (global_a)
+        hipLaunchKernelGGL(k_search<true>, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools, prm);
+    else
+        hipLaunchKernelGGL(k_search<false>, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools, prm);
 }
 
 void launch_eval(const EvalPools &pools, int n_blocks, void *stream) {
-    const size_t lds = eval_lds_bytes(pools.maxP, pools.maxB);
+    const size_t lds = eval_lds_bytes(pools.maxP, pools.maxB, pools.cur_in_lds != 0);
     if ((int)lds > g_attr_eval) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_eval = (int)lds;

@@ -225,11 +225,17 @@ static void ls_count_partial(const ls_topic *t, ls_state *s) {
         }
 }
 
-/* initial state of restart `rho`: surviving current replicas stay in their slots; every hole
- * (replica on a removed broker, or a slot added by an RF increase) is filled, in (p,k) order,
- * by the best of 64 hashed tries (one per lane on the GPU): minimal lam_max*dV - S*dObj of
- * the insertion, ties to the lowest try index; if all 64 tries are invalid, the lowest valid
- * x not in the partition. */
+static inline uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t tie) {
+    int delta = lam * dV - S * dObj;
+    if (delta < -DBIAS) delta = -DBIAS;
+    if (delta > DBIAS - 2) delta = DBIAS - 2;
+    return ((uint32_t)(delta + DBIAS) << 8) | (tie & 0xFFu);
+}
+
+/* initial state of restart `rho`: surviving current replicas stay in their slots; every hole (replica on a removed
+ * broker, or a slot added by an RF increase) is filled, in (p,k) order, by BEST INSERTION: every valid broker not in
+ * the partition is scored lam_max*dV - S*dObj of the insertion (64 per round on the GPU, lane = internal index), ties
+ * broken by 8 hashed bits (per restart, hole and broker), then by the lowest lane. */
 static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho) {
     const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
     for (int p = 0; p < t->P; ++p)
@@ -239,25 +245,25 @@ static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint3
         uint16_t *a = s->A + p * RFP;
         for (int k = 0; k < t->RF; ++k) {
             if (a[k] != NONE16) continue;
+            const uint32_t hmix = slo ^ fmix32(shi + rho * 0x9E3779B1u + (uint32_t)(p * RFP + k) * 0x27D4EB2Fu + 0x5BD1E995u);
+            uint32_t lane_key[LANES]; int lane_x[LANES];
+            for (uint32_t l = 0; l < LANES; ++l) lane_key[l] = KEY_NULL;
+            for (int base = 0; base < t->Bx; base += LANES)
+                for (uint32_t l = 0; l < LANES; ++l) {
+                    const unsigned x = (unsigned)base + l;
+                    if ((int)x >= t->Bx || !valid_x(t, x) || in_part(a, x)) continue;
+                    const int rn = rack_of_x(t, x);
+                    int dV = d_band((int)(s->C[x] & 0xFFFF), +1, t->rep_lo, t->rep_hi)
+                           + d_band(s->K[rn], +1, t->rack_lo, t->rack_hi)
+                           + d_band(rack_count(t, a, rn), +1, t->prack_lo, t->prack_hi);
+                    if (k == 0) dV += d_band((int)(s->C[x] >> 16), +1, t->lead_lo, t->lead_hi);
+                    const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
+                    const uint32_t key = make_key_tie(pp->lam_max, pp->obj_scale, dV, role_w(t, p, x, k == 0 ? 0 : 1), tie);
+                    if (key < lane_key[l]) { lane_key[l] = key; lane_x[l] = (int)x; }
+                }
             uint32_t best_key = KEY_NULL; int found = -1;
-            for (uint32_t i = 0; i < LANES; ++i) {
-                uint32_t u = fmix32(slo ^ fmix32(shi + rho * 0x9E3779B1u + (uint32_t)(p * RFP + k) * 0x27D4EB2Fu
-                                                 + i * 0x165667B1u + 0x5BD1E995u));
-                unsigned x = mulhi(u, (uint32_t)t->Bx);
-                if (!valid_x(t, x) || in_part(a, x)) continue;
-                int rn = rack_of_x(t, x);
-                int dV = d_band((int)(s->C[x] & 0xFFFF), +1, t->rep_lo, t->rep_hi)
-                       + d_band(s->K[rn], +1, t->rack_lo, t->rack_hi)
-                       + d_band(rack_count(t, a, rn), +1, t->prack_lo, t->prack_hi);
-                if (k == 0) dV += d_band((int)(s->C[x] >> 16), +1, t->lead_lo, t->lead_hi);
-                int delta = pp->lam_max * dV - pp->obj_scale * role_w(t, p, x, k == 0 ? 0 : 1);
-                if (delta < -DBIAS) delta = -DBIAS;
-                if (delta > DBIAS - 2) delta = DBIAS - 2;
-                uint32_t key = ((uint32_t)(delta + DBIAS) << 16) | i;
-                if (key < best_key) { best_key = key; found = (int)x; }
-            }
-            for (int x = 0; x < t->Bx && found < 0; ++x)
-                if (valid_x(t, (unsigned)x) && !in_part(a, (unsigned)x)) found = x;
+            for (uint32_t l = 0; l < LANES; ++l)
+                if (lane_key[l] < best_key) { best_key = lane_key[l]; found = lane_x[l]; }
             a[k] = (uint16_t)found; /* found >= 0 whenever B >= RF */
             s->C[found] += (k == 0) ? 0x10001u : 1u;
             s->K[rack_of_x(t, (unsigned)found)] += 1;
@@ -372,15 +378,10 @@ static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
  *     sample : every lane proposes its own random slot and 4 candidate brokers (ls_lane).
  *   EXCHANGE : tournament slot (p,k), then every partner slot (q,j) is scanned (lane = partition q); topics with
  *              more than 512 partitions scan a random window of 512 (8 rounds).
- *   The tournament scores clamp(P*RF/256, 1, 4) random slots per lane on the first T lanes.
+ *   The tournament scores clamp(P*RF/256, 1, 16) random slots per lane on the first T lanes; the score is the cost of
+ *   taking the replica out of its slot under the current penalty (for an EXCHANGE only the partition's rack spread counts).
  *   LEADER-SWAP : every lane a random partition, all RF-1 swaps (ls_lane).
  * --------------------------------------------------------------------------------------------- */
-static inline uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t tie) {
-    int delta = lam * dV - S * dObj;
-    if (delta < -DBIAS) delta = -DBIAS;
-    if (delta > DBIAS - 2) delta = DBIAS - 2;
-    return ((uint32_t)(delta + DBIAS) << 8) | (tie & 0xFFu);
-}
 
 static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho, uint32_t launch, uint32_t iters) {
     const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
@@ -393,7 +394,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
     const uint32_t plog = (uint32_t)pp->period_log2 + (rho & 3u);
     const uint32_t pmask = (1u << plog) - 1u;
     int T = (P * RF) / 4; if (T < 4) T = 4; if (T > LANES) T = LANES; /* tournament size */
-    int GA = (P * RF) / 256; if (GA < 1) GA = 1; if (GA > 4) GA = 4; /* slots scored per lane in the tournament */
+    int GA = (P * RF) / 256; if (GA < 1) GA = 1; if (GA > 16) GA = 16; /* slots scored per lane in the tournament */
     const int XW = 8; /* an EXCHANGE scans at most XW rounds of 64 partitions (a random window when P is larger) */
     for (uint32_t i = 0; i < iters; ++i) {
         const uint32_t it = launch * iters + i;
@@ -401,6 +402,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
         const uint32_t ph = it & pmask;
         int lam = pp->lam_min + (int)((2u * ph * (uint32_t)(pp->lam_max - pp->lam_min + 1)) >> plog);
         if (lam > pp->lam_max) lam = pp->lam_max;
+        if (s->best_obj < 0) lam = pp->lam_max; /* no oscillation before the restart has been feasible once */
         uint32_t best_key = KEY_NULL;
         proposal bp; memset(&bp, 0, sizeof bp);
         if (type == 2 || (type == 0 && ((it >> 3) & 1))) { /* per-lane proposals: LEADER SWAP, sampled REPLACE */
@@ -424,7 +426,11 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 int dvo = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
                 if (kl == 0) dvo += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
                 const int dvr = d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, al, ro), -1, t->prack_lo, t->prack_hi);
-                const uint32_t key = make_key(lam, S, dvo + (dvr < 0 ? dvr : 0), -role_w(t, pl, old, kl == 0 ? 0 : 1), l);
+                /* removal score of the slot.  REPLACE: the replica leaves its broker and (at best) its rack.  EXCHANGE:
+                 * broker and rack totals do not change, only the partition's own rack spread (C7) can improve. */
+                const int dv7 = d_band(rack_count(t, al, ro), -1, t->prack_lo, t->prack_hi);
+                const int sc = (type == 0) ? dvo + (dvr < 0 ? dvr : 0) : (dv7 < 0 ? dv7 : 0);
+                const uint32_t key = make_key(lam, S, sc, -role_w(t, pl, old, kl == 0 ? 0 : 1), l);
                 if (key < keyA) { keyA = key; p = pl; k = kl; }
               }
             const uint16_t *a = s->A + p * RFP;

@@ -242,14 +242,79 @@ def test_maximum_size_topic(kao, ko, kp):
 
 
 def test_unsupported_instances_are_rejected(kao, ko):
-    ot = ko.make_cluster("big", 100, 4, 1, 11000, 3, [], []).topics[0]
+    from kafka_assignment_optimizer_amd import Topic
+    huge = Topic(name="huge", broker_ids=np.arange(100), rack_of=np.zeros(100, dtype=np.uint8), n_racks=1,
+                 n_partitions=1_400_000, rf=3, current=np.zeros((1_400_000, 1), dtype=np.uint16))
     with pytest.raises(kao.KaoError) as e:
-        kao.Session([to_product_topic(ot)])
-    assert e.value.code == -2  # 33000 replicas > 32767
-    ot = ko.make_cluster("lds", 1000, 20, 1, 5200, 2, [], []).topics[0]
+        kao.derive_bounds(huge)
+    assert e.value.code == -2  # 4.2 M replicas > 4,000,000
+    dense = Topic(name="dense", broker_ids=np.arange(2), rack_of=np.zeros(2, dtype=np.uint8), n_racks=1,
+                  n_partitions=70_000, rf=1, current=np.zeros((70_000, 1), dtype=np.uint16))
     with pytest.raises(kao.KaoError) as e:
-        kao.Session([to_product_topic(ot)])
-    assert e.value.code == -2  # state does not fit 160 KiB of LDS even with one restart per workgroup
+        kao.derive_bounds(dense)
+    assert e.value.code == -2  # 35,000 replicas per broker on average: 16-bit per-broker counters
+
+
+def _oracle_topic(ko, pt):
+    return ko.Topic(name=pt.name, broker_ids=pt.broker_ids, rack_of=pt.rack_of, n_racks=pt.n_racks, n_partitions=pt.n_partitions,
+                    rf=pt.rf, current=pt.current, weights=pt.weights, bounds_override=dict(pt.bounds_override))
+
+
+def test_topic_in_global_memory_replay_and_eval(kao, ko, kp):
+    """6000 partitions x 1000 brokers does not fit LDS even with one restart per workgroup: the kernel keeps the
+    assignment words in global memory (k_search<true>).  Same spec: bit-exact against the scalar replay; K-eval
+    on 12000 x 3 = 36000 replicas (> 32767: unpacked wave sums) bit-exact against the C evaluator."""
+    from kafka_assignment_optimizer_amd import synthetic
+    pt = synthetic.make_cluster(1000, 20, 1, 6000, 3, [7, 77, 777], [(1000, 7), (1001, 17), (1002, 17)])[0]
+    ot = _oracle_topic(ko, pt)
+    seed = 2718
+    with kao.Session([pt], seed=seed, restarts=4, iters_per_launch=40) as s:
+        st = s.stats()
+        assert st["lds_bytes_search"] < 40 * 1024  # only broker / rack tables in LDS
+        s.step(2)
+        assert s.stats()["drift"] == 0
+        tseed = seed ^ 0x9E3779B97F4A7C15
+        for rho in (0, 3):
+            dev = s.restart_state(0, rho)
+            ref = kp.port_search(ot, tseed, rho, 2, 40)
+            assert dev["final"].tolist() == ref["final"].tolist()
+            assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
+            obj, viol = kp.port_eval(ot, dev["final"])
+            assert (obj, int(viol[0])) == (dev["obj"], dev["V"])
+    big = synthetic.make_cluster(400, 8, 1, 12000, 3, [5], [(400, 5)])[0]
+    ob = _oracle_topic(ko, big)
+    cands = random_candidates(ob, 5, seed=4, p_mut=0.2, p_none=0.02)
+    obj, viol = kao.evaluate_batch(big, cands)
+    for i in range(len(cands)):
+        o, v = kp.port_eval(ob, cands[i])
+        assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist())
+
+
+def test_config5_as_one_topic(kao, ko, kp):
+    """BASELINE config 5 taken literally as ONE topic: 1000 brokers, 20 racks, 100,000 partitions, RF 3, 50 brokers
+    replaced, per-broker cap ceil(avg)+1, solved with a 1 s budget (north_star's time target).  The topic (1.6 MB of
+    assignment words per restart) runs on the global-memory path; measured: first feasible at ~0.24 s, within 0.01 % of
+    the bound at 1 s (as 1000 topics x 100 partitions the same cluster is proven optimal in 3.9 ms)."""
+    from kafka_assignment_optimizer_amd import synthetic
+    rng = synthetic.SplitMix64(synthetic.CONFIG_SEED + 5)
+    rm = rng.sample(list(range(1000)), 50)
+    add = [(1000 + i, b % 20) for i, b in enumerate(rm)]  # each new broker joins the rack of a removed one: with uneven
+    # racks the single-topic rack band (exactly 15,000 per rack) would be infeasible (SURVEY.md H5)
+    pt = synthetic.make_cluster(1000, 20, 1, 100_000, 3, rm, add, bounds_override={"rep_hi": 301})[0]
+    ot = _oracle_topic(ko, pt)
+    kao.solve([pt], seed=1, restarts=64, iters_per_launch=16, max_launches=1)  # warm allocation of the big arenas
+    import time
+    t0 = time.perf_counter()
+    r = kao.solve([pt], seed=5, restarts=64, iters_per_launch=128, stop_at_bound=1, time_limit_s=1.0)[0]
+    dt = time.perf_counter() - t0
+    tm = kao.last_solve_timing()
+    print(f"cfg5 as one topic: {r.status} objective {r.objective} bound {r.upper_bound} launches {tm['launches']} "
+          f"time_to_best {tm['time_to_best']:.3f}s total {dt:.3f}s")
+    obj, viol = kp.port_eval(ot, r.assignment)
+    assert viol[0] == 0 and obj == r.objective <= r.upper_bound          # feasible under the independent evaluator
+    assert r.status in ("OPTIMAL_PROVEN", "TIME_LIMIT")
+    assert r.objective >= r.upper_bound * 0.9995                         # within 0.05 % of the bound inside the 1 s budget
+    assert dt < 2.5
 
 
 def test_large_topic_fewer_waves_per_workgroup(kao, ko, kp):
