@@ -80,6 +80,11 @@ __device__ __forceinline__ uint32_t rnd24(uint32_t &s, uint32_t n8) {
     const uint32_t v = lcg24(s);
     return (uint32_t)(((unsigned long long)(v & 0xFFFFFFu) * (unsigned long long)(n8 & 0xFFFFFFu)) >> 32);
 }
+// same draw for ranges that may exceed 65535 (partition indices): floor(v24 * n / 2^24) = mulhi(v24 << 8, n)
+__device__ __forceinline__ uint32_t rnd24_wide(uint32_t &s, uint32_t n) {
+    const uint32_t v = lcg24(s);
+    return __umulhi((v & 0xFFFFFFu) << 8, n);
+}
 __device__ __forceinline__ uint32_t make_key(int lam, int S, int dV, int dObj, int lane) {
     int delta = __mul24(lam, dV) - __mul24(S, dObj);
     delta = min(max(delta, -kDBias), kDBias - 2);
@@ -277,11 +282,14 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     if (prm.init) {
         // ---- hole filling by best insertion, holes in (p,k) order.  Partitions are inspected 64 at a time (one per
         //      lane); only those with a hole are visited, in ascending order. ----
+        // Two passes: leader holes of all partitions first, then follower holes (leaders are the scarcer resource).
+        for (int pass = 0; pass < 2; ++pass)
         for (int pbase = 0; pbase < T.P; pbase += 64) {
             bool has_hole = false;
             if (pbase + lane < T.P) {
                 const uint4 al = L.A[pbase + lane];
-                has_hole = (al.x == kNoneW) || (T.RF > 1 && al.y == kNoneW) || (T.RF > 2 && al.z == kNoneW) || (T.RF > 3 && al.w == kNoneW);
+                has_hole = pass == 0 ? (al.x == kNoneW)
+                                     : ((T.RF > 1 && al.y == kNoneW) || (T.RF > 2 && al.z == kNoneW) || (T.RF > 3 && al.w == kNoneW));
             }
             unsigned long long todo = __ballot(has_hole);
             while (todo) {
@@ -292,6 +300,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
 #pragma unroll
                 for (int k = 0; k < kRFP; ++k) {
                     if (k >= T.RF) break;
+                    if ((k == 0) != (pass == 0)) continue;  // this pass handles the other kind of slot
                     if (sel4(a, k) != kNoneW) continue;  // wave-uniform
                     // best insertion: every valid broker not in the partition, 64 per round (lane = internal index)
                     const uint32_t hmix = slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * kRFP + k) * 0x27D4EB2Fu + 0x5BD1E995u);
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const int plog = prm.period_log2 + (rho & 3);
     const uint32_t pmask = (1u << plog) - 1u;
     const uint32_t lrange = (uint32_t)(prm.lam_max - prm.lam_min + 1);
-    const uint32_t P8 = (uint32_t)T.P << 8, RF8 = (uint32_t)T.RF << 8, R8 = (uint32_t)T.R << 8, m8 = (uint32_t)T.m << 8;
+    const uint32_t RF8 = (uint32_t)T.RF << 8, R8 = (uint32_t)T.R << 8, m8 = (uint32_t)T.m << 8;  // all < 65536
 
     const int T_tour = min(64, max(4, (T.P * T.RF) >> 2));  // lanes taking part in the slot tournament
     const int GA = min(16, max(1, (T.P * T.RF) >> 8));       // random slots scored per lane
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         int win;
 
         if (sampled) {
-            p = (int)rnd24(rng, P8);
+            p = (int)rnd24_wide(rng, (uint32_t)T.P);
             const uint4 a = L.A[p];
             const uint4 c = CUR[p];
             if (type == 0) {  // REPLACE (p,k) <- x_g: 2 candidates of any rack, 2 of the old broker's rack
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             uint32_t oldw_l = 0;
             int pl_ = 0, kl_ = 0, g_old_l = 0, dvo_l = 0, dvr_l = 0;
             for (int ga = 0; ga < GA; ++ga) {
-                const int pg = (int)rnd24(rng, P8);
+                const int pg = (int)rnd24_wide(rng, (uint32_t)T.P);
                 const int kg = (int)rnd24(rng, RF8);
                 const uint4 al = L.A[pg];
                 const uint4 cl = CUR[pg];
@@ -439,7 +448,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const int dvr = ddec(L.K[rol], T.rack_lo, T.rack_hi) + dv7;
                 // removal score.  REPLACE: the replica leaves its broker and (at best) its rack.  EXCHANGE: broker and
                 // rack totals do not change, only the partition's own rack spread (C7) can improve.
-                const int sc = (type == 0) ? dvo + min(dvr, 0) : min(dv7, 0);
+                // (an exchange can also change who leads: a leader slot may shed a leader, a follower slot may gain one)
+                const int dvl = leadl ? ddec((int)(co >> 16), T.lead_lo, T.lead_hi) : dinc((int)(co >> 16), T.lead_lo, T.lead_hi);
+                const int sc = (type == 0) ? dvo + min(dvr, 0) : min(dv7, 0) + min(dvl, 0);
                 const uint32_t keyg = lane < T_tour ? make_key(lam, S, sc, -g_old_g, lane) : kKeyNull;
                 if (keyg < keyA) { keyA = keyg; pl_ = pg; kl_ = kg; oldw_l = oldw; g_old_l = g_old_g; dvo_l = dvo; dvr_l = dvr; }
             }
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const int cnt_a_ru = cnt4(a, ro);
                 const int cu = (int)(L.C[uw & 0xFFFFu] >> 16);
                 // every lane draws; lane 0's value places the window when the topic has more than 512 partitions
-                const int q_draw = (int)rnd24(rng, P8);
+                const int q_draw = (int)rnd24_wide(rng, (uint32_t)T.P);
                 const int q0 = x_windowed ? __builtin_amdgcn_readfirstlane(q_draw) : 0;
                 const int x_rounds = x_windowed ? 8 : x_rounds_full;
                 for (int rd = 0; rd < x_rounds; ++rd) {

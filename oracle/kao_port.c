@@ -235,15 +235,17 @@ static inline uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t t
 /* initial state of restart `rho`: surviving current replicas stay in their slots; every hole (replica on a removed
  * broker, or a slot added by an RF increase) is filled, in (p,k) order, by BEST INSERTION: every valid broker not in
  * the partition is scored lam_max*dV - S*dObj of the insertion (64 per round on the GPU, lane = internal index), ties
- * broken by 8 hashed bits (per restart, hole and broker), then by the lowest lane. */
+ * broken by 8 hashed bits (per restart, hole and broker), then by the lowest lane.  Two passes: leader holes of all
+ * partitions first, then follower holes. */
 static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho) {
     const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
     for (int p = 0; p < t->P; ++p)
         for (int k = 0; k < RFP; ++k) s->A[p * RFP + k] = (k < t->RF) ? t->cur[p * RFP + k] : NONE16;
     ls_count_partial(t, s);
+    for (int pass = 0; pass < 2; ++pass) /* leader holes first (pass 0), then follower holes: leaders are the scarcer resource */
     for (int p = 0; p < t->P; ++p) {
         uint16_t *a = s->A + p * RFP;
-        for (int k = 0; k < t->RF; ++k) {
+        for (int k = (pass == 0 ? 0 : 1); k < (pass == 0 ? 1 : t->RF); ++k) {
             if (a[k] != NONE16) continue;
             const uint32_t hmix = slo ^ fmix32(shi + rho * 0x9E3779B1u + (uint32_t)(p * RFP + k) * 0x27D4EB2Fu + 0x5BD1E995u);
             uint32_t lane_key[LANES]; int lane_x[LANES];
@@ -281,11 +283,11 @@ static inline int move_type(uint32_t it) {
 }
 
 /* per-lane LCG modulo 2^24 (one v_mad_u32_u24 on the GPU) and range reduction by the high bits of
- * a 24x24-bit product (one v_mul_hi_u32_u24): rnd(n) is uniform-ish on [0, n), n < 65536 */
+ * a 24x24-bit product (one v_mul_hi_u32_u24 when n < 65536; mulhi(v24 << 8, n) in general): uniform-ish on [0, n) */
 static inline uint32_t lcg24(uint32_t *s) { *s = (*s & 0xFFFFFFu) * 0x6D2B79u + 0x3C6EF3u; return *s; }
 static inline uint32_t rnd24(uint32_t *s, uint32_t n) {
     const uint32_t v = lcg24(s);
-    return (uint32_t)(((uint64_t)(v & 0xFFFFFFu) * (uint64_t)((n << 8) & 0xFFFFFFu)) >> 32);
+    return (uint32_t)(((uint64_t)((v & 0xFFFFFFu) << 8) * (uint64_t)n) >> 32); /* floor(v24 * n / 2^24), any n < 2^32 */
 }
 #define REPL_G 4 /* candidate brokers per lane in a REPLACE iteration: 2 of any rack, 2 of the old broker's rack */
 
@@ -429,7 +431,9 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 /* removal score of the slot.  REPLACE: the replica leaves its broker and (at best) its rack.  EXCHANGE:
                  * broker and rack totals do not change, only the partition's own rack spread (C7) can improve. */
                 const int dv7 = d_band(rack_count(t, al, ro), -1, t->prack_lo, t->prack_hi);
-                const int sc = (type == 0) ? dvo + (dvr < 0 ? dvr : 0) : (dv7 < 0 ? dv7 : 0);
+                /* an exchange can also change who leads: a leader slot may shed a leader, a follower slot may gain one */
+                const int dvl = d_band((int)(co >> 16), kl == 0 ? -1 : +1, t->lead_lo, t->lead_hi);
+                const int sc = (type == 0) ? dvo + (dvr < 0 ? dvr : 0) : (dv7 < 0 ? dv7 : 0) + (dvl < 0 ? dvl : 0);
                 const uint32_t key = make_key(lam, S, sc, -role_w(t, pl, old, kl == 0 ? 0 : 1), l);
                 if (key < keyA) { keyA = key; p = pl; k = kl; }
               }

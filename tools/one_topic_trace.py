@@ -16,7 +16,7 @@ for L in range(40):
     s.step(1); k = s.best_keys()[0]
     st = s.restart_state(0, 0)
     print(L, f"{time.perf_counter()-t0:.3f}s key viol/obj/rho", decode_key(k), "restart0 V", st["V"], "obj", st["obj"], "acc", st["n_accept"], flush=True)
-    if L % 8 == 7:
+    if L % 8 == 7 or L == 0:
         print("   viol breakdown [total,C1..C7]:", kao.evaluate(pt, st["final"])[1].tolist(), flush=True)
     if decode_key(k)[0] == 0 and decode_key(k)[1] >= kao.upper_bound(pt): break
 print(s.stats())
