@@ -782,17 +782,19 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     if (o.period_log2 <= 0) o.period_log2 = 8;
     if (o.period_log2 > 20) o.period_log2 = 20;
     if (o.time_limit_s <= 0) o.time_limit_s = 10.0;
-    if (o.restarts <= 0) {  // one full round of resident wavefronts (8 per SIMD = 32 per CU) across all topics
+    const bool auto_restarts = o.restarts <= 0;
+    if (auto_restarts) {  // one full round of resident wavefronts (8 per SIMD = 32 per CU) across all topics
         const int want = g_num_cu * 32;
         int r = want / n_topics;
         r = (r / kWaves) * kWaves;
         o.restarts = std::min(std::max(r, 8), 8192);
     }
     if (o.restarts > (1 << 20)) o.restarts = 1 << 20;
-    {   // huge topics: keep the per-restart state (16 B working words + snapshot per partition) within ~8 GB of HBM
+    {   // huge topics: bound the per-restart state in HBM (16 B of working words + the snapshot per partition):
+        // 1 GB when the count was chosen automatically, 8 GB for an explicit request
         uint64_t per_restart = 0;
         for (int t = 0; t < n_topics; ++t) per_restart += (uint64_t)topics[t].n_partitions * (16 + 2 * (uint64_t)std::max(topics[t].rf, 1));
-        const uint64_t cap = (8ull << 30) / std::max<uint64_t>(per_restart, 1);
+        const uint64_t cap = ((auto_restarts ? 1ull : 8ull) << 30) / std::max<uint64_t>(per_restart, 1);
         if ((uint64_t)o.restarts > cap) o.restarts = (int)std::max<uint64_t>(cap / kWaves * kWaves, kWaves);
     }
     s->opts = o;

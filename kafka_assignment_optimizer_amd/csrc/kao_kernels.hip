@@ -429,30 +429,42 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             win = (int)(kmin & 63u);
         } else {
             // ---- phase A: tournament over T_tour random slots; lowest removal score wins the iteration ----
-            uint32_t keyA = kKeyNull;
-            uint32_t oldw_l = 0;
-            int pl_ = 0, kl_ = 0, g_old_l = 0, dvo_l = 0, dvr_l = 0;
-            for (int ga = 0; ga < GA; ++ga) {
-                const int pg = (int)rnd24_wide(rng, (uint32_t)T.P);
-                const int kg = (int)rnd24(rng, RF8);
-                const uint4 al = L.A[pg];
-                const uint4 cl = CUR[pg];
-                const uint32_t oldw = sel4(al, kg);
-                const uint32_t rol = oldw >> 16;
-                const bool leadl = kg == 0;
-                const int g_old_g = role_w2(cl, oldw, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
-                const uint32_t co = L.C[oldw & 0xFFFFu];
-                int dvo = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
-                if (leadl) dvo += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+            // Score one random slot: the cost of taking its replica out under the current penalty.  REPLACE: the replica
+            // leaves its broker and (at best) its rack.  EXCHANGE: broker and rack totals do not change; only the
+            // partition's own rack spread (C7) and who leads (a leader slot may shed a leader, a follower slot may
+            // gain one) can improve.  `type` is wave-uniform, so only one branch is ever executed.
+            uint32_t keyA, oldw_l;
+            int pl_, kl_, g_old_l, dvo_l = 0, dvr_l = 0;
+            auto score_slot = [&](uint32_t &key_o, int &p_o, int &k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
+                p_o = (int)rnd24_wide(rng, (uint32_t)T.P);
+                k_o = (int)rnd24(rng, RF8);
+                const uint4 al = L.A[p_o];
+                const uint4 cl = CUR[p_o];
+                oldw_o = sel4(al, k_o);
+                const uint32_t rol = oldw_o >> 16;
+                const bool leadl = k_o == 0;
+                g_o = role_w2(cl, oldw_o, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
+                const uint32_t co = L.C[oldw_o & 0xFFFFu];
                 const int dv7 = ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
-                const int dvr = ddec(L.K[rol], T.rack_lo, T.rack_hi) + dv7;
-                // removal score.  REPLACE: the replica leaves its broker and (at best) its rack.  EXCHANGE: broker and
-                // rack totals do not change, only the partition's own rack spread (C7) can improve.
-                // (an exchange can also change who leads: a leader slot may shed a leader, a follower slot may gain one)
-                const int dvl = leadl ? ddec((int)(co >> 16), T.lead_lo, T.lead_hi) : dinc((int)(co >> 16), T.lead_lo, T.lead_hi);
-                const int sc = (type == 0) ? dvo + min(dvr, 0) : min(dv7, 0) + min(dvl, 0);
-                const uint32_t keyg = lane < T_tour ? make_key(lam, S, sc, -g_old_g, lane) : kKeyNull;
-                if (keyg < keyA) { keyA = keyg; pl_ = pg; kl_ = kg; oldw_l = oldw; g_old_l = g_old_g; dvo_l = dvo; dvr_l = dvr; }
+                int sc;
+                if (type == 0) {
+                    dvo_o = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
+                    if (leadl) dvo_o += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+                    dvr_o = ddec(L.K[rol], T.rack_lo, T.rack_hi) + dv7;
+                    sc = dvo_o + min(dvr_o, 0);
+                } else {
+                    const int cl16 = (int)(co >> 16);
+                    const int dvl = leadl ? ddec(cl16, T.lead_lo, T.lead_hi) : dinc(cl16, T.lead_lo, T.lead_hi);
+                    sc = min(dv7, 0) + min(dvl, 0);
+                }
+                key_o = lane < T_tour ? make_key(lam, S, sc, -g_o, lane) : kKeyNull;
+            };
+            score_slot(keyA, pl_, kl_, oldw_l, g_old_l, dvo_l, dvr_l);
+            for (int ga = 1; ga < GA; ++ga) {  // large topics: up to 16 slots per lane, the lane keeps its best
+                uint32_t kg, ow;
+                int pg, kk, gg, d1 = 0, d2 = 0;
+                score_slot(kg, pg, kk, ow, gg, d1, d2);
+                if (kg < keyA) { keyA = kg; pl_ = pg; kl_ = kk; oldw_l = ow; g_old_l = gg; dvo_l = d1; dvr_l = d2; }
             }
             const int wA = (int)(wave_umin(keyA) & 63u);
             p = __builtin_amdgcn_readlane(pl_, wA);

@@ -70,7 +70,7 @@ try:
     ks = [(gx // wx, dur) for name, gx, wx, dur in rows if "k_search" in name]
     blocks = max(b for b, _ in ks)
     durs = sorted(d for b, d in ks if b == blocks)
-    full = [d for d in durs if d > 0.7 * durs[-1]]  # drop the short kao_solve launches
+    full = [d for d in durs if d > 0.7 * durs[len(durs) // 2]]  # drop the short kao_solve launches
     const["k_search_workgroups"] = blocks
     const["k_search_avg_us_trace"] = sum(full) / len(full) / 1e3
 
@@ -78,8 +78,7 @@ try:
         cc = sqlite3.connect(dbs(sub)[0])
         v = [val for name, val in cc.execute("select kernel_name, value from counters_collection where counter_name=?", (ctr,)) if "k_search" in name]
         v = sorted(v)
-        big = [x for x in v if x > 0.7 * v[-1]]
-        return sum(big) / len(big)
+        return v[len(v) // 2]  # median: the first launch (init) and the short kao_solve launches are outliers
     fetch = per_launch("pmc_fetch", "FETCH_SIZE") * 1024 * 2
     write = per_launch("pmc_write", "WRITE_SIZE") * 1024
     const["k_search_hbm_bytes_per_launch"] = int(fetch + write)
