@@ -1,9 +1,12 @@
 // kao_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the Kafka partition-assignment solver.
 //
 //   k_search : parallel-restart local search "KAO-LS" (DESIGN.md section 4).  One wavefront owns one
-//              restart; each of its 64 lanes proposes one neighbour per iteration and delta-evaluates
-//              feasibility (C3,C4,C6,C7; C1,C2,C5 hold by construction) and move cost against broker /
-//              rack tables staged in LDS; a DPP min-reduce over the wavefront picks the move.
+//              restart.  Per iteration its 64 lanes either score random slots (tournament) and then scan
+//              every target broker / partner slot for the winning slot, or sample their own proposals;
+//              every neighbour is delta-evaluated for feasibility (C3,C4,C6,C7; C1,C2,C5 hold by
+//              construction) and move cost against broker / rack tables staged in LDS; a DPP min-reduce
+//              over the wavefront picks the move.  k_search<false> also keeps the assignment words in
+//              LDS; k_search<true> leaves them in HBM/L2 for topics that do not fit.
 //   k_eval   : full evaluation (objective README.md:145-146 and rows C1..C7 README.md:148-180) of
 //              complete compact candidates streamed from HBM, one wavefront per candidate, ending in
 //              the wavefront -> workgroup -> atomicMin reduce of the packed (violation, cost, id) key.

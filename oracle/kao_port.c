@@ -9,10 +9,11 @@
  *     oracle/kao_oracle.py::verify(), checked against it in tests.
  *
  *  2. kao_port_search(): a scalar replay of the device's parallel-restart local search
- *     ("KAO-LS", specified in DESIGN.md section 4): 64 proposals per iteration (one per
- *     wavefront lane on the GPU, a plain loop here), delta-evaluated against the same
- *     state, arg-min by packed key, accept rule, best-feasible snapshot.  Given the same
- *     seed it must produce bit-identical states to the HIP kernel.
+ *     ("KAO-LS", specified in DESIGN.md section 4): per iteration the 64 wavefront lanes of the
+ *     GPU (a plain loop here) score slots / scan brokers or partner slots / sample proposals,
+ *     delta-evaluated against the same state, arg-min by packed key, accept rule,
+ *     best-feasible snapshot.  Given the same seed it must produce bit-identical states to
+ *     the HIP kernel.
  *
  * PARITY STATUS: parity unpinned beyond KAT-1 -- the reference's solver (lp_solve 5.5,
  * README.md:135-136) is absent; see oracle/kao_oracle.py header.
