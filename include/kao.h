@@ -135,7 +135,7 @@ int kao_derive_bounds(const kao_topic *t, int32_t out[8]);
 int kao_upper_bound(const kao_topic *t, int64_t *ub);
 /* Canonical tie-break among equal-objective feasible assignments (lowest broker index for newly
  * placed replicas, retained followers keep their order): reproduces README.md:88 `[8,1]`.
- * Uses kao_evaluate (GPU) for every feasibility check. */
+ * Runs on the GPU (k_canon: the REPLACE scan with "violation delta == 0" as the filter); any topic size. */
 int kao_canonicalize(const kao_topic *t, uint16_t *assignment);
 
 /* ---- K-eval: full evaluation of complete candidates (README.md:145-180 in one pass) ---- */

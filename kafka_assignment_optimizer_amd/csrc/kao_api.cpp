@@ -700,42 +700,60 @@ int kao_evaluate(const kao_topic *t, const uint16_t *assignment, int64_t *object
 }
 
 int kao_canonicalize(const kao_topic *t, uint16_t *a) {
-    int rc = validate(t);
+    if (!a) return fail(KAO_ERR_INVALID, "null assignment");
+    int rc = require_init();
     if (rc) return rc;
-    const int P = t->n_partitions, RF = t->rf, B = t->n_brokers;
-    const size_t per = (size_t)P * RF;
-    EvalCtx ctx;
-    if ((rc = ctx.open(t))) return rc;
-    int32_t obj0 = 0; int32_t v[8];
-    if ((rc = ctx.run(a, 1, &obj0, v))) return rc;
-    if (v[0] != 0) return KAO_OK;  // only feasible assignments are polished
-    auto is_cur = [&](int p, unsigned b) {
-        for (int k = 0; k < t->rf_cur; ++k) if (t->current[(size_t)p * t->rf_cur + k] == b) return true;
-        return false;
-    };
-    std::vector<uint16_t> batch; std::vector<int> cand_b; std::vector<int32_t> bo, bv;
-    bool changed = true;
-    while (changed) {
-        changed = false;
-        for (int p = 0; p < P; ++p)
-            for (int k = 0; k < RF; ++k) {
-                const unsigned b = a[(size_t)p * RF + k];
-                if (b >= (unsigned)B || is_cur(p, b)) continue;
-                batch.clear(); cand_b.clear();
-                for (unsigned nb = 0; nb < b; ++nb) {  // every lower broker index, one K-eval batch
-                    bool used = is_cur(p, nb);
-                    for (int j = 0; j < RF && !used; ++j) used = a[(size_t)p * RF + j] == nb;
-                    if (used) continue;
-                    batch.insert(batch.end(), a, a + per);
-                    batch[batch.size() - per + (size_t)p * RF + k] = (uint16_t)nb;
-                    cand_b.push_back((int)nb);
-                }
-                if (cand_b.empty()) continue;
-                bo.resize(cand_b.size()); bv.resize(cand_b.size() * 8);
-                if ((rc = ctx.run(batch.data(), (int64_t)cand_b.size(), bo.data(), bv.data()))) return rc;
-                for (size_t i = 0; i < cand_b.size(); ++i)
-                    if (bv[i * 8] == 0 && bo[i] == obj0) { a[(size_t)p * RF + k] = (uint16_t)cand_b[i]; changed = true; break; }
-            }
+    PreparedTopic pt;
+    if ((rc = prepare(t, 0, pt))) return rc;
+    const TopicDev &d = pt.d;
+    const int P = d.P, RF = d.RF, B = d.B;
+    if (canon_lds_bytes(d.Bx) > 160 * 1024) return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS");
+    auto word = [&](uint16_t x) { return x == KAO_NONE ? kNoneW : ((uint32_t)x | ((uint32_t)(x / d.m) << 16)); };
+    std::vector<uint4> cur_words((size_t)P), a_words((size_t)P);
+    for (int p = 0; p < P; ++p) {
+        const uint16_t *c = &pt.cur_int[(size_t)p * kRFP];
+        cur_words[(size_t)p] = make_uint4(word(c[0]), word(c[1]), word(c[2]), word(c[3]));
+        uint32_t w[4] = {kNoneW, kNoneW, kNoneW, kNoneW};
+        for (int k = 0; k < RF; ++k) {
+            const unsigned b = a[(size_t)p * RF + k];
+            if (b >= (unsigned)B) return KAO_OK;  // an empty slot: infeasible, nothing to polish
+            w[k] = word(pt.int_of[b]);
+        }
+        a_words[(size_t)p] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    // one device buffer: [TopicDev][status 16 B][cur words][A words][ext][rsz]
+    const size_t o_status = align_up(sizeof(TopicDev)), o_cur = o_status + 256, o_a = o_cur + align_up((size_t)P * 16);
+    const size_t o_ext = o_a + align_up((size_t)P * 16), o_rsz = o_ext + align_up(pt.ext_of.size() * 2);
+    const size_t total = o_rsz + align_up(pt.rack_size.size() * 4);
+    std::vector<unsigned char> stage(total, 0);
+    std::memcpy(stage.data(), &d, sizeof(TopicDev));
+    std::memcpy(stage.data() + o_cur, cur_words.data(), (size_t)P * 16);
+    std::memcpy(stage.data() + o_a, a_words.data(), (size_t)P * 16);
+    std::memcpy(stage.data() + o_ext, pt.ext_of.data(), pt.ext_of.size() * 2);
+    std::memcpy(stage.data() + o_rsz, pt.rack_size.data(), pt.rack_size.size() * 4);
+    void *dev = nullptr; size_t cap = 0;
+    if ((rc = arena_get(total, &dev, &cap))) return rc;
+    unsigned char *db = static_cast<unsigned char *>(dev);
+    hipStream_t st = nullptr;
+    if ((rc = stream_get(&st))) { arena_put(dev, cap); return rc; }
+    int32_t status[2] = {0, 0};
+    hipError_t e = hipMemcpyAsync(db, stage.data(), total, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        launch_canon(reinterpret_cast<const TopicDev *>(db), reinterpret_cast<const uint4 *>(db + o_cur),
+                     reinterpret_cast<const uint16_t *>(db + o_ext), reinterpret_cast<const int32_t *>(db + o_rsz),
+                     reinterpret_cast<uint4 *>(db + o_a), d.Bx, reinterpret_cast<int32_t *>(db + o_status), st);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(a_words.data(), db + o_a, (size_t)P * 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(status, db + o_status, sizeof status, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    stream_put(st);
+    arena_put(dev, cap);
+    if (e != hipSuccess) return fail(KAO_ERR_HIP, std::string("kao_canonicalize: ") + hipGetErrorString(e));
+    if (!status[0]) return KAO_OK;  // only feasible assignments are polished
+    for (int p = 0; p < P; ++p) {
+        const uint32_t w[4] = {a_words[(size_t)p].x, a_words[(size_t)p].y, a_words[(size_t)p].z, a_words[(size_t)p].w};
+        for (int k = 0; k < RF; ++k) a[(size_t)p * RF + k] = pt.ext_of[w[k] & 0xFFFFu];
     }
     for (int p = 0; p < P; ++p) {  // followers: retained ones in their current order, then new ones ascending
         std::vector<uint16_t> fol(a + (size_t)p * RF + 1, a + (size_t)p * RF + RF), kept, fresh;

@@ -79,4 +79,9 @@ void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
 void launch_gather(const TopicDev *topics, int n_topics, const unsigned long long *keys, const uint16_t *best_pool,
                    const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream);
 
+// canonical tie-break on the device (kao_canonicalize): one wavefront, assignment words in global memory
+size_t canon_lds_bytes(int maxBx);
+void launch_canon(const TopicDev *topic, const uint4 *cur_words, const uint16_t *ext, const int32_t *rsz, uint4 *A, int maxBx,
+                  int32_t *status, void *stream);
+
 }  // namespace kao

@@ -773,6 +773,114 @@ __global__ __launch_bounds__(64) void k_gather(const TopicDev *topics, const uns
 }
 
 // ------------------------------------------------------------------------------------------------
+// K-canon: canonical tie-break among equal-objective feasible assignments (kao_canonicalize)
+// ------------------------------------------------------------------------------------------------
+// Scanning partitions and slots in order, every NEWLY placed replica (its broker is not a current replica of the
+// partition) moves to the lowest DENSE broker index that keeps the assignment feasible; repeated to a fixpoint.
+// Such a move never changes the objective (neither broker carries weight on that partition) and, the state being
+// feasible, it stays feasible iff the move's violation delta is 0 -- so this is the REPLACE scan of k_search with
+// "delta == 0" as the filter and the dense index as the key.  One wavefront; the assignment and current-assignment
+// words stay in global memory (any topic size); broker / rack tables in LDS.  status = {input feasible, #moves}.
+__global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *cur_words, const uint16_t *ext, const int32_t *rsz,
+                                              uint4 *A, int maxBx, int32_t *status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    TopicRegs T;
+    T.P = TD->P; T.RF = TD->RF; T.R = TD->R; T.m = TD->m; T.Bx = TD->Bx; T.magic = TD->magic;
+    T.rep_lo = TD->rep_lo; T.rep_hi = TD->rep_hi; T.lead_lo = TD->lead_lo; T.lead_hi = TD->lead_hi;
+    T.rack_lo = TD->rack_lo; T.rack_hi = TD->rack_hi; T.prack_lo = TD->prack_lo; T.prack_hi = TD->prack_hi;
+    T.w00 = TD->w00; T.w01 = TD->w01; T.w10 = TD->w10; T.w11 = TD->w11;
+    const int bx64 = (maxBx + 63) & ~63;
+    int *RSZ = reinterpret_cast<int *>(smem);
+    uint8_t *XR = smem + 256;
+    WaveLds L;
+    L.A = A;
+    L.C = reinterpret_cast<uint32_t *>(smem + 256 + bx64);
+    L.K = reinterpret_cast<int *>(smem + 256 + bx64 + bx64 * 4);
+    L.RT = L.K;  // unused here
+    RSZ[lane] = lane < T.R ? rsz[lane] : 0;
+    __syncthreads();
+    for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) {
+        const uint32_t r = mulhi((uint32_t)x, T.magic);
+        XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < 64 ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
+    }
+    __syncthreads();
+    recount(T, L, lane);
+    int V, obj;
+    full_cost(T, L, cur_words, RSZ, lane, V, obj);
+    if (V != 0) {  // only feasible assignments are polished
+        if (lane == 0) { status[0] = 0; status[1] = 0; }
+        return;
+    }
+    int moves = 0;
+    bool changed = true;
+    while (changed) {
+        changed = false;
+        for (int pbase = 0; pbase < T.P; pbase += 64) {
+            bool has_new = false;
+            if (pbase + lane < T.P) {
+                const uint4 al = L.A[pbase + lane];
+                const uint4 cl = cur_words[pbase + lane];
+                has_new = !in4(cl, al.x) || (T.RF > 1 && !in4(cl, al.y)) || (T.RF > 2 && !in4(cl, al.z)) || (T.RF > 3 && !in4(cl, al.w));
+            }
+            unsigned long long todo = __ballot(has_new);
+            while (todo) {
+                const int p = pbase + __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                uint4 a = L.A[p];
+                const uint4 c = cur_words[p];
+#pragma unroll
+                for (int k = 0; k < kRFP; ++k) {
+                    if (k >= T.RF) break;
+                    const uint32_t uw = sel4(a, k);
+                    if (in4(c, uw)) continue;  // a retained current replica stays where it is (wave-uniform)
+                    const uint32_t old_dense = ext[uw & 0xFFFFu];
+                    const uint32_t ro = uw >> 16;
+                    const bool lead = k == 0;
+                    const uint32_t co = L.C[uw & 0xFFFFu];
+                    int dV_old = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
+                    if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+                    const int dV_rack_old = ddec(L.K[ro], T.rack_lo, T.rack_hi) + ddec(cnt4(a, ro), T.prack_lo, T.prack_hi);
+                    uint32_t key = kKeyNull;
+                    for (int base = 0; base < T.Bx; base += 64) {
+                        const uint32_t x = (uint32_t)(base + lane);
+                        const uint32_t r = XR[x];
+                        const uint32_t xw = x | (r << 16);
+                        bool ok = (r != 0xFFu) && !in4(a, xw) && !in4(c, xw);
+                        const uint32_t dense = ok ? (uint32_t)ext[x] : 0xFFFFu;
+                        ok = ok & (dense < old_dense);
+                        const uint32_t cn = L.C[x];
+                        int dV = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi);
+                        if (lead) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+                        if (r != ro) dV += dV_rack_old + dinc(L.K[r & 63u], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
+                        const uint32_t kx = (ok & (dV == 0)) ? ((dense << 16) | x) : kKeyNull;
+                        key = min(key, kx);
+                    }
+                    const uint32_t kmin = wave_umin(key);
+                    if (kmin == kKeyNull) continue;
+                    const uint32_t xn = kmin & 0xFFFFu;
+                    const uint32_t rn = XR[xn];
+                    const uint32_t xw_new = xn | (rn << 16);
+                    if (k == 0) a.x = xw_new; else if (k == 1) a.y = xw_new; else if (k == 2) a.z = xw_new; else a.w = xw_new;
+                    if (lane == 0) {
+                        const uint32_t d = lead ? 0x10001u : 1u;
+                        reinterpret_cast<uint32_t *>(&L.A[p])[k] = xw_new;
+                        L.C[uw & 0xFFFFu] -= d;
+                        L.C[xn] += d;
+                        L.K[ro] -= 1;
+                        L.K[rn] += 1;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    changed = true;
+                    ++moves;
+                }
+            }
+        }
+    }
+    if (lane == 0) { status[0] = 1; status[1] = moves; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a) {
@@ -813,6 +921,18 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
                    const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream) {
     hipLaunchKernelGGL(k_gather, dim3(n_topics), dim3(64), 0, static_cast<hipStream_t>(stream), topics, keys, best_pool, viol,
                        win_assign, win_viol);
+}
+
+size_t canon_lds_bytes(int maxBx) {
+    const size_t bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
+    return 256 + bx64 + bx64 * 4 + 256;
+}
+
+void launch_canon(const TopicDev *topic, const uint4 *cur_words, const uint16_t *ext, const int32_t *rsz, uint4 *A, int maxBx,
+                  int32_t *status, void *stream) {
+    const size_t lds = canon_lds_bytes(maxBx);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_canon), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_canon, dim3(1), dim3(64), lds, static_cast<hipStream_t>(stream), topic, cur_words, ext, rsz, A, maxBx, status);
 }
 
 }  // namespace kao

@@ -377,6 +377,33 @@ def test_alternative_weight_scheme(kao, ko):
             assert r.objective == ex.objective <= r.upper_bound, s
 
 
+def test_canonicalize_matches_oracle(kao, ko):
+    """kao_canonicalize (k_canon on the device) == the oracle's canonicalize on solved instances: golden random cases,
+    BASELINE config topics, and a larger topic (many new placements, several passes)."""
+    ots = [ko.topic_from_dict(c["topic"]) for c in load_golden("random_small.json")["cases"] if c["status"] == "optimal"]
+    ots += [ko.gen_config(n, n_topics=2).topics[1] for n in (2, 3, 4)]
+    ots.append(ko.make_cluster("rf2to3", 40, 4, 1, 90, 2, [5, 6], [(40, 1), (41, 1), (42, 2)], new_rf=3).topics[0])
+    pts = [to_product_topic(t) for t in ots]
+    res = kao.solve(pts, seed=17, iters_per_launch=256, max_launches=6, stop_at_bound=1, time_limit_s=20)
+    n = 0
+    for ot, pt, r in zip(ots, pts, res):
+        if r.status == "NO_FEASIBLE":
+            continue
+        got = kao.canonicalize(pt, r.assignment)
+        want = ko.canonicalize(ot, r.assignment)
+        assert got.tolist() == want.tolist(), ot.name
+        obj, viol = ko.verify(ot, got)
+        assert viol[0] == 0 and obj == r.objective
+        again = kao.canonicalize(pt, got)
+        assert again.tolist() == got.tolist()  # idempotent
+        n += 1
+    assert n >= 30
+    bad = res[0].assignment.copy()
+    bad[0, 0] = bad[0, -1] if ots[0].rf > 1 else 0xFFFF  # infeasible input is returned untouched
+    if ko.verify(ots[0], bad)[1][0] != 0:
+        assert kao.canonicalize(pts[0], bad).tolist() == bad.tolist()
+
+
 def test_golden_optima_random_small(kao, ko):
     cases = [c for c in load_golden("random_small.json")["cases"]]
     ots = [ko.topic_from_dict(c["topic"]) for c in cases]

@@ -12,3 +12,7 @@ for rep in range(3):
     r = kao.solve([pt], seed=rep, stop_at_bound=1, time_limit_s=5.0)[0]
     dt = time.perf_counter() - t0
     print(rep, r.status, r.objective, r.upper_bound, kao.last_solve_timing(), f"python wall {dt:.3f}s")
+t0 = time.perf_counter()
+c = kao.canonicalize(pt, r.assignment)
+print(f"canonicalize (k_canon, 100k partitions): {time.perf_counter() - t0:.3f}s, changed slots: {int((c != r.assignment).sum())}")
+print("still optimal after tie-break:", kao.evaluate(pt, c))
