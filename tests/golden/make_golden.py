@@ -75,6 +75,21 @@ def main():
         rnd.append(e)
     dump("random_small.json", {"cases": rnd})
 
+    # medium random instances (up to 40 brokers x 40 partitions): exact optimum, uniqueness flagged
+    med = []
+    seed = 1000
+    while len(med) < 100:
+        tp = ko.random_case(seed, max_b=40, max_p=40)
+        seed += 1
+        if tp.rf > 4 or tp.rf_cur > 4:
+            continue
+        e = exact_entry(tp, uniq=True)
+        if e["status"] not in ("optimal", "infeasible"):
+            continue
+        e["seed"] = seed - 1
+        med.append(e)
+    dump("random_medium.json", {"cases": med})
+
 
 if __name__ == "__main__":
     main()

@@ -428,6 +428,31 @@ def test_golden_optima_random_small(kao, ko):
     assert n_unique >= 5
 
 
+def test_golden_optima_random_medium(kao, ko):
+    """100 medium random instances (up to 40 brokers x 40 partitions, RF changes, adds and removals): the device
+    objective equals the HiGHS optimum, infeasible instances are reported as such, the bound never undercuts the
+    optimum, and unique optima are reproduced bit for bit (after the canonical follower order)."""
+    cases = load_golden("random_medium.json")["cases"]
+    ots = [ko.topic_from_dict(c["topic"]) for c in cases]
+    pts = [to_product_topic(t) for t in ots]
+    res = kao.solve(pts, seed=23, restarts=64, iters_per_launch=512, max_launches=10, time_limit_s=60.0)
+    n_opt = n_unique = n_proven = 0
+    for c, ot, pt, r in zip(cases, ots, pts, res):
+        if c["status"] == "infeasible":
+            assert r.status == "NO_FEASIBLE", c["seed"]
+            continue
+        assert r.objective == c["objective"], (c["seed"], r.objective, c["objective"])
+        assert c["objective"] <= r.upper_bound
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == r.objective
+        n_opt += 1
+        n_proven += r.status == "OPTIMAL_PROVEN"
+        if c.get("unique"):
+            assert kao.canonicalize(pt, r.assignment).tolist() == ko.canonicalize(ot, np.array(c["assignment"])).tolist(), c["seed"]
+            n_unique += 1
+    assert n_opt >= 70 and n_unique >= 5 and n_proven >= n_opt // 2
+
+
 @pytest.mark.parametrize("name", ["cfg2.json", "cfg3.json", "cfg4.json"])
 def test_golden_optima_configs(kao, ko, name):
     g = load_golden(name)
