@@ -29,12 +29,12 @@ extern "C" {
 #define KAO_VERSION 100 /* 0.1.0 */
 #define KAO_NONE 0xFFFFu /* "no broker": replica on a broker outside the target set / empty slot */
 #define KAO_MAX_RF 4     /* replica slots per partition supported by the gfx950 kernels */
-#define KAO_MAX_RACKS 64
+#define KAO_MAX_RACKS 255
 
 enum {
     KAO_OK = 0,
     KAO_ERR_INVALID = -1,     /* bad argument */
-    KAO_ERR_UNSUPPORTED = -2, /* RF > KAO_MAX_RF, racks > KAO_MAX_RACKS, topic too large for LDS */
+    KAO_ERR_UNSUPPORTED = -2, /* RF > KAO_MAX_RF, racks > KAO_MAX_RACKS, broker tables too large for LDS */
     KAO_ERR_NO_DEVICE = -3,   /* no gfx950 device / HIP runtime failure at init */
     KAO_ERR_HIP = -4,         /* HIP runtime error (message via kao_last_error) */
     KAO_ERR_NOMEM = -5,

@@ -51,7 +51,7 @@ int validate(const kao_topic *t) {
     if (!t) return fail(KAO_ERR_INVALID, "null topic");
     if (t->n_brokers < 1 || t->n_brokers > 65534) return fail(KAO_ERR_INVALID, "n_brokers out of range");
     if (t->n_racks < 1) return fail(KAO_ERR_INVALID, "n_racks < 1");
-    if (t->n_racks > KAO_MAX_RACKS) return fail(KAO_ERR_UNSUPPORTED, "more than 64 racks");
+    if (t->n_racks > KAO_MAX_RACKS) return fail(KAO_ERR_UNSUPPORTED, "more than 255 racks");
     if (t->n_partitions < 1) return fail(KAO_ERR_INVALID, "n_partitions < 1");
     if (t->rf < 1 || t->rf_cur < 1) return fail(KAO_ERR_INVALID, "rf < 1");
     if (t->rf > KAO_MAX_RF || t->rf_cur > KAO_MAX_RF) return fail(KAO_ERR_UNSUPPORTED, "replication factor > 4");

@@ -7,7 +7,8 @@ namespace kao {
 
 constexpr int kRFP = 4;          // padded replica slots per partition
 constexpr int kWaves = 4;        // wavefronts per K-eval workgroup; K-search uses 4, 2 or 1 (largest that fits LDS)
-constexpr int kMaxRacks = 64;
+constexpr int kMaxRacks = 255;   // rack ids are u8, 0xFF marks a padding slot
+constexpr int kRackTab = 256;    // entries of the per-rack LDS tables (rack sizes, K, RT)
 constexpr uint32_t kNoneW = 0xFFFFFFFFu;  // empty slot in the LDS word layout (x | rack << 16)
 constexpr uint32_t kKeyNull = 0xFFFFFFFFu;
 constexpr int kDBias = 32768;

@@ -148,14 +148,14 @@ __device__ __forceinline__ int part_rack_viol(const TopicRegs &T, const uint4 &a
 struct WaveLds {
     uint4 *A;     // [P] this restart's assignment, 4 words per partition
     uint32_t *C;  // [Bx] replicas | leaders << 16 per broker
-    int *K;       // [64] replicas per rack
-    int *RT;      // [64] scratch: rack-dependent part of a REPLACE delta for the slot being scanned
+    int *K;       // [kRackTab] replicas per rack
+    int *RT;      // [kRackTab] scratch: rack-dependent part of a REPLACE delta for the slot being scanned
 };
 
 // rebuild C and K from A (lanes stride partitions; LDS atomics)
 __device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds &L, int lane) {
     for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) L.C[x] = 0;
-    L.K[lane] = 0;
+    for (int r = lane; r < kRackTab; r += 64) L.K[r] = 0;
     for (int p = lane; p < T.P; p += 64) {
         const uint4 a = L.A[p];
         if (a.x != kNoneW) { atomicAdd(&L.C[a.x & 0xFFFFu], 0x10001u); atomicAdd(&L.K[a.x >> 16], 1); }
@@ -185,7 +185,7 @@ __device__ __forceinline__ void full_cost(const TopicRegs &T, const WaveLds &L, 
             v += band((int)(c & 0xFFFFu), T.rep_lo, T.rep_hi) + band((int)(c >> 16), T.lead_lo, T.lead_hi);
         }
     }
-    if (lane < T.R) v += band(L.K[lane], T.rack_lo, T.rack_hi);
+    for (int r = lane; r < T.R; r += 64) v += band(L.K[r], T.rack_lo, T.rack_hi);
     V = wave_sum(v);
     obj = wave_sum(o);
 }
@@ -220,32 +220,32 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     T.rack_lo = TD->rack_lo; T.rack_hi = TD->rack_hi; T.prack_lo = TD->prack_lo; T.prack_hi = TD->prack_hi;
     T.w00 = TD->w00; T.w01 = TD->w01; T.w10 = TD->w10; T.w11 = TD->w11;
 
-    // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[64]] [XR u8[Bx rounded to 64]] then per wave
-    //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [K int[64]] [RT int[64]]          (* only when !kGlobalA)
+    // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[256]] [XR u8[Bx rounded to 64]] then per wave
+    //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [K int[256]] [RT int[256]]        (* only when !kGlobalA)
     const int a_bytes = kGlobalA ? 0 : prm.maxP * 16;
     const int bx64 = (prm.maxBx + 63) & ~63;
     const int c_bytes = bx64 * 4;
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
-    uint8_t *XR = smem + a_bytes + 256;  // rack of internal index x, 0xFF = padding slot / beyond Bx
-    unsigned char *wb = smem + a_bytes + 256 + bx64 + wave * (a_bytes + c_bytes + 512);  // blockDim.x / 64 waves
+    uint8_t *XR = smem + a_bytes + kRackTab * 4;  // rack of internal index x, 0xFF = padding slot / beyond Bx
+    unsigned char *wb = smem + a_bytes + kRackTab * 4 + bx64 + wave * (a_bytes + c_bytes + kRackTab * 8);  // blockDim.x / 64 waves
     const uint4 *cur_words = pl.cur_pool + TD->cur_off;  // host-prepared words x | rack << 16 (0xFFFFFFFF = none)
     const uint4 *CUR;
     if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const uint4 *>(smem);
     WaveLds L;
     L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
     L.K = reinterpret_cast<int *>(wb + a_bytes + c_bytes);
-    L.RT = L.K + 64;
+    L.RT = L.K + kRackTab;
 
     // ---- stage the rack sizes / rack-of-index table (and, when it fits, the current-assignment words) ----
     if (!kGlobalA) {
         uint4 *cur_lds = reinterpret_cast<uint4 *>(smem);
         for (int p = threadIdx.x; p < T.P; p += blockDim.x) cur_lds[p] = cur_words[p];
     }
-    if (threadIdx.x < 64) RSZ[threadIdx.x] = (int)threadIdx.x < T.R ? pl.rsz_pool[TD->rsz_off + threadIdx.x] : 0;
+    for (int r = threadIdx.x; r < kRackTab; r += blockDim.x) RSZ[r] = r < T.R ? pl.rsz_pool[TD->rsz_off + r] : 0;
     __syncthreads();
     for (int x = threadIdx.x; x < ((T.Bx + 63) & ~63); x += blockDim.x) {
         const uint32_t r = mulhi((uint32_t)x, T.magic);
-        XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < 64 ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
+        XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)kRackTab ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
     }
     __syncthreads();
 
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         const uint32_t xw = x | (r << 16);
                         const bool okx = (r != 0xFFu) & !in4(a, xw);
                         const uint32_t cn = L.C[x];
-                        int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[r & 63u], T.rack_lo, T.rack_hi) +
+                        int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[r & 255u], T.rack_lo, T.rack_hi) +
                                  dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
                         if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                         const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
@@ -482,11 +482,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             const uint32_t ro = uw >> 16;
             if (type == 0) {
                 // ---- phase B (REPLACE): every target broker for slot (p,k), 64 per round ----
-                {   // rack-dependent part of the delta, one rack per lane
-                    int v = 0;
-                    if (lane < T.R && (uint32_t)lane != ro)
-                        v = dV_rack_old + dinc(L.K[lane], T.rack_lo, T.rack_hi) + dinc(cnt4(a, (uint32_t)lane), T.prack_lo, T.prack_hi);
-                    L.RT[lane] = v;
+                {   // rack-dependent part of the delta, racks strided over the lanes
+                    for (int r = lane; r < T.R; r += 64)
+                        L.RT[r] = ((uint32_t)r != ro) ? dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, (uint32_t)r), T.prack_lo, T.prack_hi) : 0;
                 }
                 const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
                 // a displaced current replica (in c, not in a) is the only broker with a non-zero weight here
@@ -500,7 +498,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const uint32_t xw = x | (r << 16);
                     const bool okx = (r != 0xFFu) & !in4(a, xw);
                     const uint32_t cn = L.C[x];
-                    int dVx = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + L.RT[r & 63u];
+                    int dVx = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + L.RT[r & 255u];
                     if (lead) dVx += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                     int dObjx = -g_old;
                     if (has_missing) dObjx += role_w2(c, xw, wl, wf);
@@ -618,13 +616,13 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     const int rack_lo = TD->rack_lo, rack_hi = TD->rack_hi, prack_lo = TD->prack_lo, prack_hi = TD->prack_hi;
     const int w00 = TD->w00, w01 = TD->w01, w10 = TD->w10, w11 = TD->w11;
 
-    // ---- LDS carve: [wave_key 32 B] [RACK u8[maxB~]] [CURD uint2[maxP]] then per wave [C u32[maxB~]] [K int[64]]
+    // ---- LDS carve: [wave_key 32 B] [RACK u8[maxB~]] [CURD uint2[maxP]] then per wave [C u32[maxB~]] [K int[256]]
     const int r_bytes = (pl.maxB + 15) & ~15;
     const int d_bytes = pl.cur_in_lds ? pl.maxP * 8 : 0;  // huge topics read the current assignment from global memory
     const int c_bytes = (pl.maxB * 4 + 15) & ~15;
     uint8_t *RACK = smem;
     uint2 *CURD = reinterpret_cast<uint2 *>(smem + r_bytes);
-    unsigned char *wb = smem + r_bytes + ((d_bytes + 15) & ~15) + wave * (c_bytes + 256);
+    unsigned char *wb = smem + r_bytes + ((d_bytes + 15) & ~15) + wave * (c_bytes + kRackTab * 4);
     uint32_t *C = reinterpret_cast<uint32_t *>(wb);
     int *K = reinterpret_cast<int *>(wb + c_bytes);
 
@@ -648,7 +646,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     for (int ci = bm.y + wave; ci < bm.y + bm.z; ci += kWaves) {
         const uint16_t *cand = pl.cand + TD->best_off + (uint64_t)ci * P * RF;
         for (int b4 = lane; b4 < nB4; b4 += 64) reinterpret_cast<uint4 *>(C)[b4] = make_uint4(0, 0, 0, 0);
-        K[lane] = 0;
+        for (int r = lane; r < kRackTab; r += 64) K[r] = 0;
         // Band violations are accumulated from the value each LDS atomic RETURNS: adding a replica to a
         // broker whose count was c changes band(c) by (c >= hi) - (c < lo), and sum_b band(0) = B*lo, so
         // no pass over all brokers is needed.  Packed partial sums: low half = #(old >= hi), high = #(old < lo).
@@ -792,17 +790,17 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *c
     T.w00 = TD->w00; T.w01 = TD->w01; T.w10 = TD->w10; T.w11 = TD->w11;
     const int bx64 = (maxBx + 63) & ~63;
     int *RSZ = reinterpret_cast<int *>(smem);
-    uint8_t *XR = smem + 256;
+    uint8_t *XR = smem + kRackTab * 4;
     WaveLds L;
     L.A = A;
-    L.C = reinterpret_cast<uint32_t *>(smem + 256 + bx64);
-    L.K = reinterpret_cast<int *>(smem + 256 + bx64 + bx64 * 4);
+    L.C = reinterpret_cast<uint32_t *>(smem + kRackTab * 4 + bx64);
+    L.K = reinterpret_cast<int *>(smem + kRackTab * 4 + bx64 + bx64 * 4);
     L.RT = L.K;  // unused here
-    RSZ[lane] = lane < T.R ? rsz[lane] : 0;
+    for (int r = lane; r < kRackTab; r += 64) RSZ[r] = r < T.R ? rsz[r] : 0;
     __syncthreads();
     for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) {
         const uint32_t r = mulhi((uint32_t)x, T.magic);
-        XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < 64 ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
+        XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)kRackTab ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
     }
     __syncthreads();
     recount(T, L, lane);
@@ -852,7 +850,7 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *c
                         const uint32_t cn = L.C[x];
                         int dV = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi);
                         if (lead) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
-                        if (r != ro) dV += dV_rack_old + dinc(L.K[r & 63u], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
+                        if (r != ro) dV += dV_rack_old + dinc(L.K[r & 255u], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
                         const uint32_t kx = (ok & (dV == 0)) ? ((dense << 16) | x) : kKeyNull;
                         key = min(key, kx);
                     }
@@ -885,12 +883,12 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *c
 // ------------------------------------------------------------------------------------------------
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a) {
     const size_t a = global_a ? 0 : (size_t)maxP * 16, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
-    return a + 256 + bx64 + (size_t)waves * (a + bx64 * 4 + 512);
+    return a + kRackTab * 4 + bx64 + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
 }
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 8 + 15) & ~(size_t)15 : 0;
     const size_t c = ((size_t)maxB * 4 + 15) & ~(size_t)15;
-    return 32 + r + d + kWaves * (c + 256);
+    return 32 + r + d + kWaves * (c + kRackTab * 4);
 }
 
 static int g_attr_search = 0, g_attr_eval = 0;
@@ -925,7 +923,7 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
 
 size_t canon_lds_bytes(int maxBx) {
     const size_t bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
-    return 256 + bx64 + bx64 * 4 + 256;
+    return kRackTab * 4 + bx64 + bx64 * 4 + kRackTab * 4;
 }
 
 void launch_canon(const TopicDev *topic, const uint4 *cur_words, const uint16_t *ext, const int32_t *rsz, uint4 *A, int maxBx,

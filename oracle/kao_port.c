@@ -95,7 +95,7 @@ int kao_port_eval(const port_topic *t, const uint16_t *assign, int64_t *objectiv
 typedef struct {
     int P, RF, R, m, Bx; /* m = max rack size; internal index x = rack*m + j */
     uint32_t magic;      /* floor(2^32/m)+1: rack(x) = mulhi(x, magic) */
-    int rack_size[64];
+    int rack_size[256];
     uint16_t *int_of;    /* [B] dense -> internal */
     uint16_t *ext_of;    /* [Bx] internal -> dense (NONE16 for padding) */
     uint16_t *cur;       /* [P*RFP] internal */
@@ -106,7 +106,7 @@ typedef struct {
 typedef struct {
     uint16_t *A;   /* [P*RFP] internal, slots >= RF are NONE16 */
     uint32_t *C;   /* [Bx] cntR | cntL << 16 */
-    int K[64];     /* replicas per rack */
+    int K[256];    /* replicas per rack */
     int V, obj;    /* current total violation magnitude, objective */
     int best_obj;  /* best feasible objective seen, -1 if none */
     uint16_t *best;/* [P*RF] dense snapshot */
@@ -145,7 +145,7 @@ void *kao_port_ls_create(const port_topic *pt) {
     ls_topic *t = (ls_topic *)calloc(1, sizeof(ls_topic));
     const int B = pt->n_brokers;
     t->P = pt->n_partitions; t->RF = pt->rf; t->R = pt->n_racks;
-    if (t->RF > RFP || pt->rf_cur > RFP || t->R > 64) { free(t); return NULL; }
+    if (t->RF > RFP || pt->rf_cur > RFP || t->R > 255) { free(t); return NULL; }
     for (int b = 0; b < B; ++b) t->rack_size[pt->rack_of[b]] += 1;
     for (int r = 0; r < t->R; ++r) if (t->rack_size[r] > t->m) t->m = t->rack_size[r];
     if (t->m < 2) t->m = 2; /* floor(2^32/m)+1 must fit 32 bits: single-broker racks get a stride of 2 */
@@ -154,7 +154,7 @@ void *kao_port_ls_create(const port_topic *pt) {
     t->int_of = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)B);
     t->ext_of = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->Bx);
     memset(t->ext_of, 0xFF, sizeof(uint16_t) * (size_t)t->Bx);
-    int fill[64] = {0};
+    int fill[256] = {0};
     for (int b = 0; b < B; ++b) { /* dense order inside each rack is preserved */
         int r = pt->rack_of[b];
         int x = r * t->m + fill[r]++;
@@ -448,7 +448,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 int dV_old = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
                 if (k == 0) dV_old += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
                 const int dV_rack_old = d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, ro), -1, t->prack_lo, t->prack_hi);
-                int RT[64];
+                int RT[256];
                 for (int r = 0; r < t->R; ++r)
                     RT[r] = (r == ro) ? 0 : dV_rack_old + d_band(s->K[r], +1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, r), +1, t->prack_lo, t->prack_hi);
                 uint32_t lane_key[LANES]; unsigned lane_x[LANES]; int lane_dV[LANES], lane_dO[LANES];

@@ -90,7 +90,7 @@ def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params)
     ct = CTopic(topic)
     h = lib().kao_port_ls_create(C.byref(ct.s))
     if not h:
-        raise ValueError("unsupported instance (RF > 4 or racks > 64)")
+        raise ValueError("unsupported instance (RF > 4 or racks > 255)")
     try:
         pr = dict(DEFAULT_PARAMS)
         pr.update(params)

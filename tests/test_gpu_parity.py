@@ -67,6 +67,13 @@ def test_eval_edge_cases(kao, ko, kp):
         for i in range(len(cands)):
             o, v = kp.port_eval(ot, cands[i])
             assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist()), (s, i)
+    for R, B0 in ((100, 300), (200, 400)):  # more racks than lanes
+        ot = ko.make_cluster("r", B0, R, 1, 77, 3, [5], [(B0, 5)]).topics[0]
+        cands = random_candidates(ot, 12, seed=R, p_mut=0.3)
+        obj, viol = kao.evaluate_batch(to_product_topic(ot), cands)
+        for i in range(len(cands)):
+            o, v = kp.port_eval(ot, cands[i])
+            assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist()), (R, i)
     c = ko.make_cluster("rf4", 70, 5, 1, 130, 4, [1, 2, 3], [(70, 0), (71, 4)])
     ot = c.topics[0]
     cands = random_candidates(ot, 40, seed=9)
@@ -123,7 +130,8 @@ def test_search_replay_random_small(kao, ko, kp):
 
 def test_search_replay_varied_shapes(kao, ko, kp):
     """One session holding heterogeneous topics: RF 1/2/4, an RF increase and decrease, a single rack,
-    uneven racks (padding slots in the internal index), P not a multiple of 64, B < 64 and B > 64."""
+    uneven racks (padding slots in the internal index), P not a multiple of 64, B < 64 and B > 64, 100 and 200 racks
+    (more racks than wavefront lanes)."""
     mk = ko.make_cluster
     ots = [
         mk("rf1", 10, 2, 1, 7, 1, [3], [(10, 0)]).topics[0],
@@ -133,6 +141,8 @@ def test_search_replay_varied_shapes(kao, ko, kp):
         mk("rf3to2", 24, 4, 1, 33, 3, [], [(24, 0)], new_rf=2).topics[0],
         mk("onerack", 9, 1, 1, 12, 3, [4], []).topics[0],
         mk("uneven", 40, 4, 1, 65, 3, [0, 4, 8, 12, 16, 1], []).topics[0],
+        mk("racks100", 300, 100, 1, 120, 3, [1, 2, 3], [(300, 1), (301, 2), (302, 3)]).topics[0],   # more racks than lanes
+        mk("racks200", 400, 200, 1, 90, 2, [7], [(400, 7)]).topics[0],
     ]
     seed = 424242
     with kao.Session([to_product_topic(t) for t in ots], seed=seed, restarts=8, iters_per_launch=96) as s:
