@@ -488,9 +488,10 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 }
                 const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
                 // a displaced current replica (in c, not in a) is the only broker with a non-zero weight here
-                const bool hm_l = (c.x != kNoneW && !in4(a, c.x)) || (c.y != kNoneW && !in4(a, c.y)) ||
-                                  (c.z != kNoneW && !in4(a, c.z)) || (c.w != kNoneW && !in4(a, c.w));
-                const int has_missing = __builtin_amdgcn_readfirstlane((int)hm_l);
+                // (lane i < 4 checks current replica i; one ballot instead of every lane checking all four)
+                const uint32_t ci = sel4(c, lane & 3);
+                const bool hm_l = (lane < 4) & (ci != kNoneW) & !in4(a, ci);
+                const bool has_missing = __ballot(hm_l) != 0ull;
                 for (int base = 0; base < T.Bx; base += 64) {
                     const uint32_t tie = lcg24(rng) >> 8;
                     const uint32_t x = (uint32_t)(base + lane);
@@ -524,13 +525,16 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const uint4 b = L.A[qc];
                     const uint4 cb = CUR[qc];
                     const bool u_in_b = in4(b, uw);
+                    // independent of the partner slot j: what u would be worth in q, and q's replicas in u's rack
+                    const int u_in_q_lead = role_w2(cb, uw, T.w00, T.w10), u_in_q_fol = role_w2(cb, uw, T.w01, T.w11);
+                    const int cnt_b_ro = cnt4(b, ro);
 #pragma unroll
                     for (int jj = 0; jj < kRFP; ++jj) {
                         if (jj >= T.RF) break;
                         const uint32_t v = jj == 0 ? b.x : (jj == 1 ? b.y : (jj == 2 ? b.z : b.w));
                         const bool ok = okq & (v != uw) & !in4(a, v) & !u_in_b;
                         const int nrq = jj != 0;
-                        const int dObjx = role_w(T, c, v, nrp) + role_w(T, cb, uw, nrq) - g_old - role_w(T, cb, v, nrq);
+                        const int dObjx = role_w(T, c, v, nrp) + (jj == 0 ? u_in_q_lead : u_in_q_fol) - g_old - role_w(T, cb, v, nrq);
                         int dVx = 0;
                         if (lead != (jj == 0)) {  // wave-uniform: exactly one of the two slots is a leader slot
                             const int cv = (int)(L.C[v & 0xFFFFu] >> 16);
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         const uint32_t rv = v >> 16;
                         if (rv != ro)
                             dVx += ddec(cnt_a_ru, T.prack_lo, T.prack_hi) + dinc(cnt4(a, rv), T.prack_lo, T.prack_hi) +
-                                   ddec(cnt4(b, rv), T.prack_lo, T.prack_hi) + dinc(cnt4(b, ro), T.prack_lo, T.prack_hi);
+                                   ddec(cnt4(b, rv), T.prack_lo, T.prack_hi) + dinc(cnt_b_ro, T.prack_lo, T.prack_hi);
                         const uint32_t keyx = ok ? make_key_tie(lam, S, dVx, dObjx, tie0 + (uint32_t)jj * 0x55u) : kKeyNull;
                         if (keyx < key) { key = keyx; vw = v; q = qq; j = jj; dV = dVx; dObj = dObjx; }
                     }

@@ -11,12 +11,16 @@ from conftest import to_product_topic, random_candidates
 kao.init(0)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big_every = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # every n-th topic is large
+launches = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 rng = ko._Rng(0xF022 + seed0)
 topics = []
 while len(topics) < n_cases:
     R = 1 + rng.below(12)
     B0 = max(R + 1, 3 + rng.below(180))
     P = 1 + rng.below(300)
+    if big_every and len(topics) % big_every == big_every - 1:
+        P = 2500 + rng.below(6000)  # large topic: 2 or 1 restarts per workgroup, or the global-memory path
     rf = 1 + rng.below(min(4, B0 - 1))
     n_rm = rng.below(max(1, B0 // 4))
     n_add = rng.below(1 + B0 // 8)
@@ -25,7 +29,7 @@ while len(topics) < n_cases:
     new_rf = rf
     if rng.below(3) == 0:
         new_rf = max(1, min(4, rf + (1 if rng.below(2) else -1), B0 - n_rm + n_add - 1))
-    if B0 - n_rm + n_add < max(new_rf, 1) + 0 or P * max(rf, new_rf) > 32767:
+    if B0 - n_rm + n_add < max(new_rf, 1) + 0:
         continue
     try:
         t = ko.make_cluster(f"f{len(topics)}", B0, R, 1, P, rf, rm, add, new_rf=new_rf).topics[0]
@@ -33,6 +37,17 @@ while len(topics) < n_cases:
         continue
     if t.n_brokers < t.rf:
         continue
+    if rng.below(4) == 0:  # random objective weights (leader weight stays the largest)
+        lf, fl, ff = 1 + rng.below(3), 1 + rng.below(3), 1 + rng.below(3)
+        t.weights = ((max(lf, fl, ff) + 1 + rng.below(3), lf), (fl, ff))
+    if rng.below(4) == 0:  # random band overrides (caps / floors), kept satisfiable on average
+        bd = t.bounds()
+        t.bounds_override = {"rep_hi": bd["rep_hi"] + rng.below(3), "lead_hi": bd["lead_hi"] + rng.below(2)}
+        if rng.below(2):
+            t.bounds_override["rack_hi"] = bd["rack_hi"] + rng.below(4)
+            t.bounds_override["rack_lo"] = max(0, bd["rack_lo"] - rng.below(4))
+        if rng.below(3) == 0:
+            t.bounds_override["prack_hi"] = bd["prack_hi"] + 1
     if rng.below(3) == 0:  # scramble part of the start
         cur = t.current.copy()
         for _ in range(rng.below(P + 1)):
@@ -50,14 +65,14 @@ for lo in range(0, len(topics), 50):
     pts = [to_product_topic(t) for t in batch]
     seed = 1000 + lo
     with kao.Session(pts, seed=seed, restarts=8, iters_per_launch=80) as s:
-        s.step(2)
+        s.step(launches)
         if s.stats()["drift"] != 0:
             bad += 1; print("DRIFT", lo)
         for ti, ot in enumerate(batch):
             tseed = seed ^ (((ti + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
             rho = (ti * 3) % 8
             dev = s.restart_state(ti, rho)
-            ref = kp.port_search(ot, tseed, rho, 2, 80)
+            ref = kp.port_search(ot, tseed, rho, launches, 80)
             if dev["final"].tolist() != ref["final"].tolist() or (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) != (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"]):
                 bad += 1; print("REPLAY MISMATCH", lo + ti, ot.n_brokers, ot.n_racks, ot.n_partitions, ot.rf_cur, ot.rf)
             obj, viol = ko.verify(ot, dev["final"])
