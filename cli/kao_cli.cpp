@@ -293,8 +293,15 @@ int main(int argc, char **argv) {
         if (rc) throw std::runtime_error(std::string("kao_solve: ") + kao_strerror(rc) + " " + kao_last_error());
         int exit_code = 0;
         for (size_t i = 0; i < tds.size(); ++i) {
+            if (results[i].status == KAO_STATUS_INFEASIBLE_PROVEN) {
+                char why[256] = "";
+                (void)kao_check_infeasible(&topics[i], why, (int)sizeof why);
+                std::fprintf(stderr, "kao-cli: topic %s: This problem is infeasible (%s)\n", tds[i].name.c_str(), why);
+                exit_code = 3;
+                continue;
+            }
             if (results[i].status == KAO_STATUS_NO_FEASIBLE) {
-                std::fprintf(stderr, "kao-cli: topic %s: no feasible assignment found (lp_solve would report: This problem is infeasible)\n", tds[i].name.c_str());
+                std::fprintf(stderr, "kao-cli: topic %s: no feasible assignment found within the time limit (not a proof of infeasibility)\n", tds[i].name.c_str());
                 exit_code = 3;
                 continue;
             }
@@ -308,7 +315,7 @@ int main(int argc, char **argv) {
         os << "{\"version\":1,\"partitions\":[";
         bool first = true;
         for (size_t i = 0; i < tds.size(); ++i) {
-            if (results[i].status == KAO_STATUS_NO_FEASIBLE) continue;
+            if (results[i].status == KAO_STATUS_NO_FEASIBLE || results[i].status == KAO_STATUS_INFEASIBLE_PROVEN) continue;
             const int P = topics[i].n_partitions, RF = topics[i].rf;
             for (int p = 0; p < P; ++p) {
                 os << (first ? "\n" : ",\n") << "    {\"topic\":\"" << tds[i].name << "\",\"partition\":" << tds[i].partition_ids[p] << ",\"replicas\":[";
@@ -321,11 +328,11 @@ int main(int argc, char **argv) {
         if (out_path.empty()) std::fputs(os.str().c_str(), stdout);
         else { std::ofstream f(out_path); f << os.str(); }
         if (report) {
-            static const char *st[] = {"OPTIMAL_PROVEN", "FEASIBLE_BOUND_GAP", "NO_FEASIBLE", "TIME_LIMIT"};
+            static const char *st[] = {"OPTIMAL_PROVEN", "FEASIBLE_BOUND_GAP", "NO_FEASIBLE", "TIME_LIMIT", "INFEASIBLE_PROVEN", "?", "?", "?"};
             for (size_t i = 0; i < tds.size(); ++i) {
                 int moves = 0, lead = 0;
                 const int P = topics[i].n_partitions, RF = topics[i].rf, RC = topics[i].rf_cur;
-                if (results[i].status != KAO_STATUS_NO_FEASIBLE)
+                if (results[i].status != KAO_STATUS_NO_FEASIBLE && results[i].status != KAO_STATUS_INFEASIBLE_PROVEN)
                     for (int p = 0; p < P; ++p) {
                         for (int k = 0; k < RF; ++k) {
                             bool kept = false;
@@ -335,7 +342,7 @@ int main(int argc, char **argv) {
                         lead += tds[i].current[(size_t)p * RC] != assigns[i][(size_t)p * RF];
                     }
                 std::fprintf(stderr, "topic %s: status=%s objective=%lld bound=%lld replica_moves=%d leader_changes=%d seconds_to_best=%.4f\n",
-                             tds[i].name.c_str(), st[results[i].status & 3], (long long)results[i].objective, (long long)results[i].upper_bound,
+                             tds[i].name.c_str(), st[results[i].status & 7], (long long)results[i].objective, (long long)results[i].upper_bound,
                              moves, lead, results[i].seconds_to_best);
             }
         }

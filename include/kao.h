@@ -46,7 +46,9 @@ enum { /* kao_result.status */
     KAO_STATUS_FEASIBLE_BOUND_GAP = 1,/* feasible, objective < upper_bound (bound not tight or not optimal) */
     KAO_STATUS_NO_FEASIBLE = 2,       /* search found no feasible assignment (lp_solve would say "infeasible"
                                          only if truly so; this is not a proof) */
-    KAO_STATUS_TIME_LIMIT = 3         /* feasible, stopped by the time limit before target_objective */
+    KAO_STATUS_TIME_LIMIT = 3,        /* feasible, stopped by the time limit before target_objective */
+    KAO_STATUS_INFEASIBLE_PROVEN = 4  /* a counting argument (kao_check_infeasible) shows that no assignment satisfies
+                                         the rows: what lp_solve reports as "This problem is infeasible" */
 };
 
 /* One topic's sub-problem.  Topics are independent in the README model: every variable and
@@ -133,6 +135,10 @@ int kao_derive_bounds(const kao_topic *t, int32_t out[8]);
 /* Upper bound on the objective: every partition keeps its best surviving replicas (coupling rows dropped),
  * minus the cheapest way to perform the evictions / leader changes the bands force (kao_api.cpp). */
 int kao_upper_bound(const kao_topic *t, int64_t *ub);
+/* Necessary conditions of the model checked by counting (band capacities per broker / rack / partition).  Returns 1
+ * and a reason in `why` (may be NULL) if the topic is provably infeasible, 0 if no condition fails (it may still be
+ * infeasible for subtler reasons), < 0 on error. */
+int kao_check_infeasible(const kao_topic *t, char *why, int why_len);
 /* Canonical tie-break among equal-objective feasible assignments (lowest broker index for newly
  * placed replicas, retained followers keep their order): reproduces README.md:88 `[8,1]`.
  * Runs on the GPU (k_canon: the REPLACE scan with "violation delta == 0" as the filter); any topic size. */

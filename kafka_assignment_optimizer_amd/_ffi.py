@@ -50,6 +50,7 @@ SIGNATURES = {
     "kao_derive_bounds": (C.c_int, [_P(KaoTopic), _P(C.c_int32)]),
     "kao_upper_bound": (C.c_int, [_P(KaoTopic), _P(C.c_int64)]),
     "kao_canonicalize": (C.c_int, [_P(KaoTopic), _P(C.c_uint16)]),
+    "kao_check_infeasible": (C.c_int, [_P(KaoTopic), C.c_char_p, C.c_int]),
     "kao_evaluate": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), _P(C.c_int64), _P(C.c_int32)]),
     "kao_evaluate_batch": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int64, _P(C.c_int32), _P(C.c_int32)]),
     "kao_eval_plan_create": (C.c_int, [_P(KaoTopic), _P(C.c_void_p)]),

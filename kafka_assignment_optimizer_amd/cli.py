@@ -38,8 +38,9 @@ def main(argv=None) -> int:
     res = solve(topics, seed=a.seed, time_limit_s=a.time_limit, stop_at_bound=1, iters_per_launch=256)
     ok_topics, assigns, rc = [], [], 0
     for t, r in zip(topics, res):
-        if r.status == "NO_FEASIBLE":
-            print(f"topic {t.name}: no feasible assignment found", file=sys.stderr)
+        if r.status in ("NO_FEASIBLE", "INFEASIBLE_PROVEN"):
+            print(f"topic {t.name}: " + ("This problem is infeasible" if r.status == "INFEASIBLE_PROVEN"
+                                          else "no feasible assignment found within the time limit"), file=sys.stderr)
             rc = 3
             continue
         ok_topics.append(t)

@@ -128,6 +128,34 @@ int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
     return KAO_OK;
 }
 
+// Necessary conditions checked by counting; empty string = not provably infeasible (kao_check_infeasible).
+std::string infeasible_reason(const kao_topic *t) {
+    const int64_t B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf, n = P * RF;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    const int64_t rep_lo = bd[0], rep_hi = bd[1], lead_lo = bd[2], lead_hi = bd[3], rack_lo = bd[4], rack_hi = bd[5], prack_lo = bd[6], prack_hi = bd[7];
+    std::vector<int64_t> rs((size_t)R, 0);
+    for (int b = 0; b < t->n_brokers; ++b) rs[t->rack_of[b]]++;
+    if (RF > B) return "rf > brokers";
+    if (!(B * rep_lo <= n && n <= B * rep_hi)) return "replicas per broker band cannot hold P*RF replicas";
+    if (!(B * lead_lo <= P && P <= B * lead_hi)) return "leaders per broker band cannot hold P leaders";
+    if (!(R * rack_lo <= n && n <= R * rack_hi)) return "replicas per rack band cannot hold P*RF replicas";
+    int64_t sum_hi = 0, sum_lo = 0, spread = 0;
+    for (int r = 0; r < t->n_racks; ++r) {
+        const int64_t hi = std::min(rack_hi, std::min(rs[(size_t)r] * rep_hi, P * std::min(prack_hi, rs[(size_t)r])));
+        const int64_t lo = std::max(rack_lo, std::max(rs[(size_t)r] * rep_lo, P * prack_lo));
+        if (lo > hi) return "rack " + std::to_string(r) + ": needs at least " + std::to_string(lo) + " replicas but can hold at most " + std::to_string(hi);
+        sum_hi += hi; sum_lo += lo;
+        spread += std::min(prack_hi, rs[(size_t)r]);
+        if (prack_lo > rs[(size_t)r]) return "per-partition rack floor cannot be met";
+    }
+    if (sum_hi < n) return "rack capacities sum below P*RF";
+    if (sum_lo > n) return "rack floors sum above P*RF";
+    if (spread < RF) return "a partition cannot spread RF replicas over the racks";
+    if (R * prack_lo > RF) return "per-partition rack floor cannot be met";
+    return "";
+}
+
 // Best value one partition can collect from a kept set: its current leader (if kept) and n_fol kept current
 // followers, at most rf replicas, exactly one leader; coupling rows (C3, C4, C6, C7) ignored.
 int64_t partition_value(const kao_topic *t, bool lead_kept, int n_fol, bool leader_may_lead = true) {
@@ -376,6 +404,7 @@ struct kao_session {
     std::vector<kao_topic> topics;  // shallow copies (pointers not retained for device work)
     std::vector<int64_t> ub;
     std::vector<char> topic_global;  // per topic: runs with its assignment in global memory
+    std::vector<char> topic_infeasible;  // per topic: proven infeasible by counting (kao_check_infeasible)
     int total_restarts = 0;
     // Topics are bucketed by LDS footprint into launch groups (a 3000-partition topic must not impose its LDS carve
     // and its 2 waves per workgroup on 200 small topics); one K-search + one K-eval launch per group per step.
@@ -560,6 +589,14 @@ int kao_derive_bounds(const kao_topic *t, int32_t out[8]) {
     if (rc) return rc;
     derive_bounds(t, out);
     return KAO_OK;
+}
+
+int kao_check_infeasible(const kao_topic *t, char *why, int why_len) {
+    int rc = validate(t);
+    if (rc) return rc;
+    const std::string r = infeasible_reason(t);
+    if (why && why_len > 0) std::snprintf(why, (size_t)why_len, "%s", r.c_str());
+    return r.empty() ? 0 : 1;
 }
 
 int kao_upper_bound(const kao_topic *t, int64_t *ub) {
@@ -831,6 +868,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         rc = prepare(&topics[t], seed, pt);
         if (rc) { kao_session_destroy(s); return rc; }
         s->ub[(size_t)t] = upper_bound(&topics[t]);
+        s->topic_infeasible.push_back(infeasible_reason(&topics[t]).empty() ? 0 : 1);
         TopicDev &d = pt.d;
         d.n_restarts = o.restarts;
         d.restart_base = restart_base;
@@ -1050,7 +1088,7 @@ int kao_session_best(kao_session *s, kao_result *results) {
         r.upper_bound = s->ub[(size_t)t];
         const uint64_t key = keys[t];
         if (key == ~0ull) {  // no step has run yet
-            r.status = KAO_STATUS_NO_FEASIBLE; r.best_restart = -1; r.objective = -1;
+            r.status = s->topic_infeasible[(size_t)t] ? KAO_STATUS_INFEASIBLE_PROVEN : KAO_STATUS_NO_FEASIBLE; r.best_restart = -1; r.objective = -1;
             std::memset(r.violations, 0, sizeof r.violations);
             continue;
         }
@@ -1058,7 +1096,7 @@ int kao_session_best(kao_session *s, kao_result *results) {
         r.objective = (int64_t)kObjCap - (int64_t)((key >> 20) & 0xFFFFFF);
         std::memcpy(r.violations, wv + (size_t)t * 8, 32);
         if (r.assignment) std::memcpy(r.assignment, wa + d.win_off, (size_t)d.P * d.RF * 2);
-        if (r.violations[0] != 0) { r.status = KAO_STATUS_NO_FEASIBLE; r.objective = -1; }
+        if (r.violations[0] != 0) { r.status = s->topic_infeasible[(size_t)t] ? KAO_STATUS_INFEASIBLE_PROVEN : KAO_STATUS_NO_FEASIBLE; r.objective = -1; }
         else r.status = r.objective >= r.upper_bound ? KAO_STATUS_OPTIMAL_PROVEN : KAO_STATUS_FEASIBLE_BOUND_GAP;
     }
     return KAO_OK;
@@ -1137,6 +1175,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
             const bool feasible = (keys[(size_t)i] >> 44) == 0;
             const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
             const int64_t goal = target ? target[i] : s->ub[(size_t)i];
+            if (s->topic_infeasible[(size_t)i]) continue;  // proven infeasible: nothing to wait for
             if (!(feasible && obj >= goal)) all_done = false;
         }
         if (o.stop_at_bound && all_done) break;

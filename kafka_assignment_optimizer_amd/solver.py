@@ -11,7 +11,7 @@ import numpy as np
 from . import _ffi
 from .model import BOUND_KEYS, Topic
 
-STATUS_NAMES = {0: "OPTIMAL_PROVEN", 1: "FEASIBLE_BOUND_GAP", 2: "NO_FEASIBLE", 3: "TIME_LIMIT"}
+STATUS_NAMES = {0: "OPTIMAL_PROVEN", 1: "FEASIBLE_BOUND_GAP", 2: "NO_FEASIBLE", 3: "TIME_LIMIT", 4: "INFEASIBLE_PROVEN"}
 
 
 class KaoError(RuntimeError):
@@ -79,6 +79,16 @@ def upper_bound(topic: Topic) -> int:
     ub = C.c_int64()
     _check(_ffi.load().kao_upper_bound(ct.arr, C.byref(ub)), "kao_upper_bound")
     return int(ub.value)
+
+
+def check_infeasible(topic: Topic) -> str:
+    """'' if no counting argument fails, else the reason the topic is provably infeasible (host only)."""
+    ct = _CTopics([topic])
+    buf = C.create_string_buffer(256)
+    rc = _ffi.load().kao_check_infeasible(ct.arr, buf, 256)
+    if rc < 0:
+        raise KaoError(rc, "kao_check_infeasible")
+    return buf.value.decode() if rc == 1 else ""
 
 
 def evaluate(topic: Topic, assign) -> tuple:

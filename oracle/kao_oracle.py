@@ -374,6 +374,41 @@ def brute_force(topic: Topic) -> Tuple[Optional[int], int]:
     return best, n_best
 
 
+def provably_infeasible(topic: Topic) -> List[str]:
+    """Necessary conditions of the README model that can be checked by counting: if any fails, no 0/1
+    point satisfies the rows and lp_solve would print "This problem is infeasible".  Returns the failed conditions
+    (empty list = not provably infeasible; the instance may still be infeasible for subtler reasons)."""
+    B, R, P, RF = topic.n_brokers, topic.n_racks, topic.n_partitions, topic.rf
+    bd = topic.bounds()
+    n = P * RF
+    rs = [0] * R
+    for r in topic.rack_of:
+        rs[int(r)] += 1
+    why = []
+    if RF > B:
+        why.append("rf > brokers")
+    if not B * bd["rep_lo"] <= n <= B * bd["rep_hi"]:
+        why.append("replicas per broker band cannot hold P*RF replicas")
+    if not B * bd["lead_lo"] <= P <= B * bd["lead_hi"]:
+        why.append("leaders per broker band cannot hold P leaders")
+    if not R * bd["rack_lo"] <= n <= R * bd["rack_hi"]:
+        why.append("replicas per rack band cannot hold P*RF replicas")
+    caps_hi = [min(bd["rack_hi"], rs[r] * bd["rep_hi"], P * min(bd["prack_hi"], rs[r])) for r in range(R)]
+    caps_lo = [max(bd["rack_lo"], rs[r] * bd["rep_lo"], P * bd["prack_lo"]) for r in range(R)]
+    for r in range(R):
+        if caps_lo[r] > caps_hi[r]:
+            why.append(f"rack {r}: needs at least {caps_lo[r]} replicas but can hold at most {caps_hi[r]}")
+    if sum(caps_hi) < n:
+        why.append("rack capacities sum below P*RF")
+    if sum(caps_lo) > n:
+        why.append("rack floors sum above P*RF")
+    if sum(min(bd["prack_hi"], x) for x in rs) < RF:
+        why.append("a partition cannot spread RF replicas over the racks")
+    if R * bd["prack_lo"] > RF or any(bd["prack_lo"] > x for x in rs):
+        why.append("per-partition rack floor cannot be met")
+    return why
+
+
 def upper_bound_simple(topic: Topic) -> int:
     """Combinatorial bound: each partition keeps its best RF surviving replicas in their best
     roles, ignoring every coupling constraint (C3, C4, C6, C7)."""

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT, have_gpu, to_product_topic
+from conftest import ROOT, have_gpu, load_golden, to_product_topic
 
 
 def test_library_exports_every_declared_symbol():
@@ -58,6 +58,28 @@ def test_host_helpers_match_oracle(ko):
         pt = to_product_topic(ot)
         assert kao.derive_bounds(pt) == ot.bounds()
         assert kao.upper_bound(pt) == ko.upper_bound_forced(ot) <= ko.upper_bound_simple(ot)
+
+
+def test_infeasibility_proofs_match_oracle_and_highs(ko):
+    """kao_check_infeasible (counting arguments) agrees with the oracle's restatement, never fires on an instance
+    HiGHS solved, and catches every golden instance HiGHS proved infeasible (what lp_solve reports as "This problem is
+    infeasible")."""
+    import kafka_assignment_optimizer_amd as kao
+    n_inf = 0
+    for name in ("random_small.json", "random_medium.json"):
+        for c in load_golden(name)["cases"]:
+            ot = ko.topic_from_dict(c["topic"])
+            why = kao.check_infeasible(to_product_topic(ot))
+            assert bool(why) == bool(ko.provably_infeasible(ot)), c["seed"]
+            if c["status"] == "infeasible":
+                assert why, c["seed"]
+                n_inf += 1
+            else:
+                assert not why, (c["seed"], why)
+    assert n_inf >= 30
+    h5 = ko.make_cluster("h5", 100, 4, 1, 64, 3, [3, 17, 42, 77, 99], []).topics[0]
+    assert "rack" in kao.check_infeasible(to_product_topic(h5))
+    assert not kao.check_infeasible(to_product_topic(ko.readme_example()))
 
 
 def test_validation_errors(ko):
