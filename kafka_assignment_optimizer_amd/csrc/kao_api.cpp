@@ -195,10 +195,44 @@ int64_t upper_bound(const kao_topic *t) {
     int32_t bd[8];
     derive_bounds(t, bd);
     const int rep_lo = bd[0], rep_hi = bd[1], lead_hi = bd[3], rack_lo = bd[4], rack_hi = bd[5], prack_hi = bd[7];
+    // Everything per partition depends only on (current leader survives, number of surviving followers): 2 x 4 combos.
+    struct Combo { int64_t f_all = 0, lead_loss = 0; int n_marg = 0; int64_t marg[KAO_MAX_RF + 1] = {0}; int64_t count = 0; } combo[8];
+    for (int la = 0; la < 2; ++la)
+        for (int n_fol = 0; n_fol <= 3; ++n_fol) {
+            Combo &c = combo[la * 4 + n_fol];
+            const bool lead_alive = la != 0;
+            const int n_p = n_fol + la;
+            c.f_all = partition_value(t, lead_alive, n_fol);
+            int64_t g[KAO_MAX_RF + 1];
+            for (int j = 0; j <= n_p; ++j) {  // cheapest loss of evicting j replicas (followers are interchangeable)
+                int64_t best = -1;
+                for (int drop_lead = 0; drop_lead <= la; ++drop_lead) {
+                    const int df = j - drop_lead;
+                    if (df >= 0 && df <= n_fol) best = std::max(best, partition_value(t, lead_alive && !drop_lead, n_fol - df));
+                }
+                g[j] = c.f_all - best;
+            }
+            int hx[KAO_MAX_RF + 1]; int64_t hy[KAO_MAX_RF + 1]; int hn = 0;  // lower convex envelope of (j, g[j])
+            for (int j = 0; j <= n_p; ++j) {
+                hx[hn] = j; hy[hn] = g[j]; ++hn;
+                while (hn >= 3 && (hy[hn - 2] - hy[hn - 3]) * (hx[hn - 1] - hx[hn - 3]) >= (hy[hn - 1] - hy[hn - 3]) * (hx[hn - 2] - hx[hn - 3])) {
+                    hx[hn - 2] = hx[hn - 1]; hy[hn - 2] = hy[hn - 1]; --hn;
+                }
+            }
+            for (int i = 0; i + 1 < hn; ++i)
+                for (int x = hx[i] + 1; x <= hx[i + 1]; ++x) {  // integer floor of the envelope stays a lower bound
+                    const int64_t dy = hy[i + 1] - hy[i], dx = hx[i + 1] - hx[i];
+                    const int64_t prev = hy[i] + (dy * (x - 1 - hx[i])) / dx, now = hy[i] + (dy * (x - hx[i])) / dx;
+                    c.marg[c.n_marg++] = now - prev;
+                }
+            if (lead_alive) {
+                const int64_t alt = std::max(partition_value(t, false, n_fol), partition_value(t, true, n_fol, false));
+                c.lead_loss = std::max<int64_t>(0, c.f_all - alt);
+            }
+        }
     std::vector<int> s_b((size_t)B, 0), s_r((size_t)R, 0), lead_b((size_t)B, 0);
     std::vector<int> nl_b((size_t)B, 0);  // surviving current LEADER replicas per broker (followers = s_b - nl_b)
-    std::vector<int64_t> marginals;
-    std::vector<std::pair<int, int64_t>> lead_losses;  // (broker, loss if this partition's leader stops leading)
+    std::vector<int> touched;             // brokers holding at least one surviving replica
     int64_t total = 0, n_surv = 0, cell_excess = 0, parts_with_survivor = 0;
     for (int p = 0; p < P; ++p) {
         const uint16_t *c = t->current + (size_t)p * t->rf_cur;
@@ -207,67 +241,62 @@ int64_t upper_bound(const kao_topic *t) {
         for (int k = 0; k < t->rf_cur; ++k) {
             if (c[k] >= (unsigned)B) continue;
             if (k > 0) ++n_fol;
-            s_b[c[k]]++;
+            if (s_b[c[k]]++ == 0) touched.push_back((int)c[k]);
             s_r[t->rack_of[c[k]]]++;
             racks[n_in++] = t->rack_of[c[k]];
         }
-        const int n_p = n_fol + (lead_alive ? 1 : 0);
-        n_surv += n_p;
-        parts_with_survivor += n_p > 0;
+        n_surv += n_in;
+        parts_with_survivor += n_in > 0;
         for (int i = 0; i < n_in; ++i) {  // cells: count each rack once
             bool first = true;
             int cnt = 0;
             for (int j = 0; j < n_in; ++j) { if (racks[j] == racks[i]) { ++cnt; if (j < i) first = false; } }
             if (first) cell_excess += std::max(0, cnt - prack_hi);
         }
-        const int64_t f_all = partition_value(t, lead_alive, n_fol);
-        total += f_all;
-        int64_t g[KAO_MAX_RF + 1];
-        for (int j = 0; j <= n_p; ++j) {  // cheapest loss of evicting j replicas (followers are interchangeable)
-            int64_t best = -1;
-            for (int drop_lead = 0; drop_lead <= (lead_alive ? 1 : 0); ++drop_lead) {
-                const int df = j - drop_lead;
-                if (df >= 0 && df <= n_fol) best = std::max(best, partition_value(t, lead_alive && !drop_lead, n_fol - df));
-            }
-            g[j] = f_all - best;
-        }
-        int hx[KAO_MAX_RF + 1]; int64_t hy[KAO_MAX_RF + 1]; int hn = 0;  // lower convex envelope of (j, g[j])
-        for (int j = 0; j <= n_p; ++j) {
-            hx[hn] = j; hy[hn] = g[j]; ++hn;
-            while (hn >= 3 && (hy[hn - 2] - hy[hn - 3]) * (hx[hn - 1] - hx[hn - 3]) >= (hy[hn - 1] - hy[hn - 3]) * (hx[hn - 2] - hx[hn - 3])) {
-                hx[hn - 2] = hx[hn - 1]; hy[hn - 2] = hy[hn - 1]; --hn;
-            }
-        }
-        for (int i = 0; i + 1 < hn; ++i)
-            for (int x = hx[i] + 1; x <= hx[i + 1]; ++x) {  // integer floor of the envelope stays a lower bound
-                const int64_t dy = hy[i + 1] - hy[i], dx = hx[i + 1] - hx[i];
-                const int64_t prev = hy[i] + (dy * (x - 1 - hx[i])) / dx, now = hy[i] + (dy * (x - hx[i])) / dx;
-                marginals.push_back(now - prev);
-            }
-        if (lead_alive) {
-            nl_b[c[0]]++;
-            lead_b[c[0]]++;
-            const int64_t alt = std::max(partition_value(t, false, n_fol), partition_value(t, true, n_fol, false));
-            lead_losses.emplace_back((int)c[0], std::max<int64_t>(0, f_all - alt));
-        }
+        Combo &cb = combo[(lead_alive ? 4 : 0) + n_fol];
+        total += cb.f_all;
+        cb.count++;
+        if (lead_alive) { nl_b[c[0]]++; lead_b[c[0]]++; }
     }
     int64_t ex_b = 0, ex_r = 0, need_b = 0, need_r = 0;
-    for (int b = 0; b < B; ++b) { ex_b += std::max(0, s_b[b] - rep_hi); need_b += std::max(0, rep_lo - s_b[b]); }
+    need_b = (int64_t)std::max(0, rep_lo) * ((int64_t)B - (int64_t)touched.size());  // untouched brokers hold nothing
+    for (int b : touched) { ex_b += std::max(0, s_b[(size_t)b] - rep_hi); need_b += std::max(0, rep_lo - s_b[(size_t)b]); }
     for (int r = 0; r < R; ++r) { ex_r += std::max(0, s_r[r] - rack_hi); need_r += std::max(0, rack_lo - s_r[r]); }
     const int64_t slots = (int64_t)P * RF;
     int64_t k = std::max<int64_t>({ex_b, ex_r, cell_excess, n_surv + need_b - slots, n_surv + need_r - slots, 0});
-    k = std::min<int64_t>(k, (int64_t)marginals.size());
-    std::sort(marginals.begin(), marginals.end());
-    int64_t evict_loss = 0;
-    for (int64_t i = 0; i < k; ++i) evict_loss += marginals[(size_t)i];
+    // the k smallest marginals over all partitions, taken combo by combo (value, multiplicity)
+    std::vector<std::pair<int64_t, int64_t>> vm;
+    for (const Combo &c : combo)
+        for (int i = 0; i < c.n_marg; ++i)
+            if (c.count) vm.emplace_back(c.marg[i], c.count);
+    std::sort(vm.begin(), vm.end());
+    int64_t evict_loss = 0, left = k;
+    for (const auto &e : vm) {
+        if (left <= 0) break;
+        const int64_t take = std::min(left, e.second);
+        evict_loss += take * e.first;
+        left -= take;
+    }
     int64_t lead_loss = 0;
-    std::sort(lead_losses.begin(), lead_losses.end());
-    for (size_t i = 0; i < lead_losses.size();) {
-        size_t j = i;
-        while (j < lead_losses.size() && lead_losses[j].first == lead_losses[i].first) ++j;
-        const int ex = lead_b[(size_t)lead_losses[i].first] - lead_hi;
-        for (size_t q = i; q < j && (int)(q - i) < ex; ++q) lead_loss += lead_losses[q].second;  // sorted by loss within a broker
-        i = j;
+    bool over_led = false;
+    for (int b : touched) over_led |= lead_b[(size_t)b] > lead_hi;
+    if (over_led) {  // rare: collect the per-partition losses only for brokers holding too many current leaders
+        std::vector<std::pair<int, int64_t>> lead_losses;
+        for (int p = 0; p < P; ++p) {
+            const uint16_t *c = t->current + (size_t)p * t->rf_cur;
+            if (c[0] >= (unsigned)B || lead_b[c[0]] <= lead_hi) continue;
+            int n_fol = 0;
+            for (int q = 1; q < t->rf_cur; ++q) n_fol += c[q] < (unsigned)B;
+            lead_losses.emplace_back((int)c[0], combo[4 + n_fol].lead_loss);
+        }
+        std::sort(lead_losses.begin(), lead_losses.end());
+        for (size_t i = 0; i < lead_losses.size();) {
+            size_t j = i;
+            while (j < lead_losses.size() && lead_losses[j].first == lead_losses[i].first) ++j;
+            const int ex = lead_b[(size_t)lead_losses[i].first] - lead_hi;
+            for (size_t q = i; q < j && (int)(q - i) < ex; ++q) lead_loss += lead_losses[q].second;  // sorted by loss within a broker
+            i = j;
+        }
     }
     // Per-broker capacity bound with a global cap on leading survivors.  A broker keeps at most rep_hi of its
     // surviving replicas and at most lead_hi of them lead; a replica that leads is worth w[cur_role][0], one that
@@ -278,14 +307,26 @@ int64_t upper_bound(const kao_topic *t) {
     // Charges forced evictions AND forced leader changes together.
     const int wLL = t->w[0][0], wLF = t->w[0][1], wFL = t->w[1][0], wFF = t->w[1][1];
     const int lead_lo = bd[2];
-    int64_t lcap = P;
-    for (int b = 0; b < B; ++b) lcap -= std::max(0, lead_lo - s_b[(size_t)b]);
+    int64_t lcap = P - (int64_t)std::max(0, lead_lo) * ((int64_t)B - (int64_t)touched.size());
+    for (int b : touched) lcap -= std::max(0, lead_lo - s_b[(size_t)b]);
     lcap = std::min<int64_t>(lcap, parts_with_survivor);
+    // brokers with the same (surviving leaders, surviving followers) share v_b: evaluate each distinct pair once
+    // (only brokers that hold a surviving replica are visited; all others are the kind (0, 0))
+    std::vector<std::pair<std::pair<int, int>, int64_t>> kinds;  // ((n_l, n_f), number of brokers)
+    kinds.push_back({{0, 0}, (int64_t)B - (int64_t)touched.size()});
+    for (int b : touched) {
+        const std::pair<int, int> key{nl_b[(size_t)b], s_b[(size_t)b] - nl_b[(size_t)b]};
+        size_t i = 0;
+        while (i < kinds.size() && kinds[i].first != key) ++i;
+        if (i == kinds.size()) kinds.push_back({key, 0});
+        kinds[i].second++;
+    }
     int64_t broker_base = 0;
-    std::vector<int64_t> lead_marg;
+    std::vector<std::pair<int64_t, int64_t>> lead_marg;  // (marginal value, multiplicity)
     std::vector<int64_t> v, hx, hy;
-    for (int b = 0; b < B; ++b) {
-        const int n_l = nl_b[(size_t)b], n_f = s_b[(size_t)b] - n_l;
+    for (const auto &kind : kinds) {
+        const int n_l = kind.first.first, n_f = kind.first.second;
+        const int64_t mult = kind.second;
         const int lmax = std::min(std::min(lead_hi, rep_hi), n_l + n_f);
         v.assign((size_t)lmax + 1, -1);
         for (int x = 0; x <= std::min(n_l, lmax); ++x)
@@ -302,7 +343,7 @@ int64_t upper_bound(const kao_topic *t) {
                 v[(size_t)(x + y)] = std::max(v[(size_t)(x + y)], val);
             }
         for (int i = 1; i <= lmax; ++i) v[(size_t)i] = std::max(v[(size_t)i], v[(size_t)i - 1]);  // "at most L leading"
-        broker_base += v[0];
+        broker_base += v[0] * mult;
         hx.clear(); hy.clear();  // upper concave envelope of (L, v[L]) -> non-increasing marginals
         for (int i = 0; i <= lmax; ++i) {
             hx.push_back(i); hy.push_back(v[(size_t)i]);
@@ -317,13 +358,18 @@ int64_t upper_bound(const kao_topic *t) {
             for (int64_t x = hx[i] + 1; x <= hx[i + 1]; ++x) {  // ceil of the running total keeps it an upper bound
                 const int64_t dy = hy[i + 1] - hy[i], dx = hx[i + 1] - hx[i];
                 auto up = [&](int64_t k) { const int64_t num = dy * k; return hy[i] + (num >= 0 ? (num + dx - 1) / dx : -((-num) / dx)); };
-                lead_marg.push_back(up(x - hx[i]) - up(x - 1 - hx[i]));
+                const int64_t m = up(x - hx[i]) - up(x - 1 - hx[i]);
+                if (m > 0) lead_marg.emplace_back(m, mult);
             }
     }
-    std::sort(lead_marg.begin(), lead_marg.end(), [](int64_t p, int64_t q) { return p > q; });
-    int64_t broker_bound = broker_base;
-    for (int64_t i = 0; i < lcap && i < (int64_t)lead_marg.size(); ++i)
-        if (lead_marg[(size_t)i] > 0) broker_bound += lead_marg[(size_t)i];
+    std::sort(lead_marg.begin(), lead_marg.end(), [](const std::pair<int64_t, int64_t> &p, const std::pair<int64_t, int64_t> &q) { return p.first > q.first; });
+    int64_t broker_bound = broker_base, cap_left = std::max<int64_t>(lcap, 0);
+    for (const auto &e : lead_marg) {
+        if (cap_left <= 0) break;
+        const int64_t take = std::min(cap_left, e.second);
+        broker_bound += take * e.first;
+        cap_left -= take;
+    }
     return std::min(total - std::max(evict_loss, lead_loss), broker_bound);
 }
 
