@@ -797,6 +797,42 @@ def random_case(seed: int, max_b: int = 12, max_p: int = 8) -> Topic:
     return t
 
 
+def random_case_wide(seed: int, max_b: int = 60, max_p: int = 96) -> Topic:
+    """Wider random family than random_case: up to 8 racks of uneven size (added brokers land in random
+    racks), RF up to 4 with RF changes, random objective weights (README.md:116-120 allows any scheme with
+    the leader weight largest), heavier scrambling of the start.  May be infeasible."""
+    rng = _Rng(0x51DE0000 + seed)
+    R = 1 + rng.below(8)
+    B0 = max(R + 2, 6 + rng.below(max_b - 5))
+    P = 4 + rng.below(max_p - 3)
+    rf = 1 + rng.below(min(4, B0 - 1))
+    n_rm = rng.below(max(1, B0 // 3))
+    n_add = rng.below(1 + B0 // 6)
+    rm = rng.sample(list(range(B0)), n_rm)
+    add = [(B0 + i, rng.below(R)) for i in range(n_add)]
+    new_rf = rf
+    if rng.below(3) == 0:
+        new_rf = max(1, min(4, rf + (1 if rng.below(2) else -1), B0 - n_rm + n_add - 1))
+    weights = DEFAULT_WEIGHTS
+    k = rng.below(4)
+    if k == 1:
+        weights = ((4, 2), (2, 1))      # the README's prose scheme (README.md:116-120)
+    elif k == 2:
+        ll = 3 + rng.below(6)
+        weights = ((ll, rng.below(ll)), (rng.below(ll), 1 + rng.below(ll - 1)))
+    c = make_cluster(f"wide{seed}", B0, R, 1, P, rf, rm, add, weights=weights, new_rf=new_rf)
+    t = c.topics[0]
+    cur = t.current.copy()
+    for _ in range(rng.below(2 * P + 1)):
+        p = rng.below(P)
+        kk = rng.below(cur.shape[1])
+        nb = rng.below(t.n_brokers)
+        if nb not in cur[p]:
+            cur[p, kk] = nb
+    t.current = cur
+    return t
+
+
 def topic_to_dict(t: Topic) -> dict:
     return {"name": t.name, "broker_ids": [int(x) for x in t.broker_ids],
             "rack_of": [int(x) for x in t.rack_of], "n_racks": t.n_racks,

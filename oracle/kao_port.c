@@ -541,3 +541,160 @@ int kao_port_search(void *h, const port_params *pp, uint32_t rho, uint32_t launc
     free(s.A); free(s.C); free(s.best);
     return 0;
 }
+
+/* ------------------------------------------------------------------ KAO-DB: Lagrangian dual bound
+ *
+ * Scalar replay of the device's dual-bound kernel (k_bound).  lp_solve proves optimality by
+ * branch-and-bound on the LP relaxation (README.md:135-136); here the certificate is a Lagrangian dual of the same
+ * 0-1 model (README.md:144-185): the coupling rows -- replicas per broker (C3, README.md:158-161), leaders per
+ * broker (C4, README.md:163-166), replicas per rack (C6, README.md:173-176) -- are priced with integer multipliers
+ * a[b], l[b], g[r] (fixed point, DB_SCALE = 1), the rows local to a partition (C1, C2, C5, C7) stay in a
+ * per-partition subproblem that is solved exactly, and
+ *     L(a,l,g) = sum_p max{priced value of one partition's leader + followers} + sum (multiplier x band end)
+ * is an upper bound on the optimum for ANY multipliers; floor(min L / DB_SCALE) is the certificate.  The multipliers
+ * move along a deflected subgradient d = 16*s + 3/4 d_prev with the Polyak step (L - target*DB_SCALE) / |d|^2 towards
+ * the incumbent `target` (a known feasible objective), all in integers so that the device and this replay agree bit
+ * for bit. */
+#define DB_SCALE 4096
+#define DB_CLAMP (1 << 26)
+
+typedef struct { int b[RFP]; int f[RFP]; int r[RFP]; int n; } db_set;
+
+static inline int db_wcur(const port_topic *t, const uint16_t *cur, unsigned b, int new_role) {
+    for (int j = 0; j < t->rf_cur; ++j)
+        if (cur[j] == b) return t->w[j == 0 ? 0 : 1][new_role];
+    return 0;
+}
+
+/* One partition's priced subproblem.  Returns 0 and fills S (the chosen brokers, leader first) and *val, or -1 if
+ * no set of RF brokers satisfies the per-partition rack band. */
+static int db_partition(const port_topic *t, int p, const int32_t *a, const int32_t *l, const int32_t *g, int *S, int32_t *val) {
+    const int B = t->n_brokers, R = t->n_racks, RF = t->rf, plo = t->prack_lo, phi = t->prack_hi;
+    const uint16_t *cur = t->current + (size_t)p * t->rf_cur;
+    db_set G; G.n = 0;
+    int cnt[256]; memset(cnt, 0, sizeof(int) * (size_t)R);
+    /* greedy: plo best followers of every rack first, then the best remaining under the cap; ties -> lowest b */
+    for (int round = 0; round < RF; ++round) {
+        const int forced_rack = round < R * plo ? round / plo : -1;
+        int bb = -1; int32_t bv = 0;
+        for (int b = 0; b < B; ++b) {
+            const int rb = t->rack_of[b];
+            if (forced_rack >= 0 ? rb != forced_rack : cnt[rb] >= phi) continue;
+            int in = 0;
+            for (int j = 0; j < G.n; ++j) in |= G.b[j] == b;
+            if (in) continue;
+            const int32_t fv = db_wcur(t, cur, (unsigned)b, 1) * DB_SCALE - a[b] - g[rb];
+            if (bb < 0 || fv > bv) { bb = b; bv = fv; }
+        }
+        if (bb < 0) return -1;
+        G.b[G.n] = bb; G.f[G.n] = bv; G.r[G.n] = t->rack_of[bb]; G.n++;
+        cnt[t->rack_of[bb]]++;
+    }
+    int32_t fG = 0;
+    for (int j = 0; j < RF; ++j) fG += G.f[j];
+    /* leader: every broker b0; outside G it displaces the cheapest element whose removal keeps the rack band */
+    int best_b0 = -1, best_e = -1; int32_t best_v = 0;
+    for (int b0 = 0; b0 < B; ++b0) {
+        const int r0 = t->rack_of[b0];
+        const int32_t lv = db_wcur(t, cur, (unsigned)b0, 0) * DB_SCALE - a[b0] - g[r0] - l[b0];
+        int pos = -1;
+        for (int j = 0; j < RF; ++j) if (G.b[j] == b0) pos = j;
+        int e = -1; int32_t v;
+        if (pos >= 0) { v = fG - G.f[pos] + lv; e = pos; }
+        else {
+            for (int j = 0; j < RF; ++j) {
+                const int ok = cnt[r0] >= phi ? G.r[j] == r0 : (G.r[j] == r0 || cnt[G.r[j]] > plo);
+                if (ok && (e < 0 || G.f[j] <= G.f[e])) e = j;   /* cheapest; ties -> the latest picked */
+            }
+            if (e < 0) continue;
+            v = fG - G.f[e] + lv;
+        }
+        if (best_b0 < 0 || v > best_v) { best_b0 = b0; best_v = v; best_e = e; }
+    }
+    if (best_b0 < 0) return -1;
+    int n = 0;
+    S[n++] = best_b0;
+    for (int j = 0; j < RF; ++j) if (j != best_e) S[n++] = G.b[j];
+    *val = best_v;
+    return 0;
+}
+
+static inline int32_t db_sub(int32_t m, int n, int lo, int hi) {   /* element of the subdifferential closest to 0 */
+    if (m > 0) return hi - n;
+    if (m < 0) return lo - n;
+    return n < lo ? lo - n : n > hi ? hi - n : 0;
+}
+static inline int32_t db_dir(int32_t d_prev, int32_t s) {         /* d = 16 s + floor(3 d_prev / 4) */
+    return 16 * s + (int32_t)(((int64_t)d_prev * 3) >> 2);
+}
+static inline int32_t db_move(int32_t m, int64_t step, int32_t d) {
+    const int64_t mag = (step * (d < 0 ? -(int64_t)d : (int64_t)d)) >> 16;
+    int64_t v = (int64_t)m - (d < 0 ? -mag : mag);
+    if (v > DB_CLAMP) v = DB_CLAMP;
+    if (v < -DB_CLAMP) v = -DB_CLAMP;
+    return (int32_t)v;
+}
+
+/* Runs up to `iters` dual iterations from the state (a[B], l[B], g[R] multipliers; da[B], dl[B], dg[R] previous
+ * direction; *best_L), all in/out (zeros and INT64_MAX to start).  Needs P*RF <= 2^17 and P*RF*max(w) <= 2^19 (32-bit
+ * headroom of the priced values).  flags: 1 = closed (best_L < (target+1)*DB_SCALE), 2 = zero subgradient (dual optimum reached),
+ * 4 = a partition subproblem is infeasible (no bound).  Returns the number of iterations performed. */
+int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int32_t *a, int32_t *l, int32_t *g,
+                        int32_t *da, int32_t *dl, int32_t *dg, int64_t *best_L, int32_t *flags) {
+    const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
+    int32_t *nrep = (int32_t *)malloc(sizeof(int32_t) * (size_t)B), *nlead = (int32_t *)malloc(sizeof(int32_t) * (size_t)B);
+    int32_t nrack[256];
+    *flags = 0;
+    int it = 0;
+    for (; it < iters; ++it) {
+        memset(nrep, 0, sizeof(int32_t) * (size_t)B); memset(nlead, 0, sizeof(int32_t) * (size_t)B);
+        memset(nrack, 0, sizeof nrack);
+        int64_t L = 0;
+        for (int p = 0; p < P; ++p) {
+            int S[RFP]; int32_t v;
+            if (db_partition(t, p, a, l, g, S, &v)) { *flags |= 4; goto done; }
+            L += v;
+            nlead[S[0]]++;
+            for (int j = 0; j < RF; ++j) { nrep[S[j]]++; nrack[t->rack_of[S[j]]]++; }
+        }
+        int64_t nrm = 0;
+        for (int b = 0; b < B; ++b) {
+            L += (int64_t)a[b] * (a[b] > 0 ? t->rep_hi : t->rep_lo) + (int64_t)l[b] * (l[b] > 0 ? t->lead_hi : t->lead_lo);
+            const int64_t sa = db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi), sl = db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi);
+            nrm += sa * sa + sl * sl;
+        }
+        for (int r = 0; r < R; ++r) {
+            L += (int64_t)g[r] * (g[r] > 0 ? t->rack_hi : t->rack_lo);
+            const int64_t sg = db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi);
+            nrm += sg * sg;
+        }
+        if (L < *best_L) *best_L = L;
+        if (*best_L < (target + 1) * DB_SCALE) { *flags |= 1; ++it; break; }
+        if (nrm == 0) { *flags |= 2; ++it; break; }
+        const int64_t gap = L - target * DB_SCALE;       /* >= DB_SCALE here */
+        int64_t dn = 0;
+        for (int b = 0; b < B; ++b) {
+            da[b] = db_dir(da[b], db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi));
+            dl[b] = db_dir(dl[b], db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi));
+            dn += (int64_t)da[b] * da[b] + (int64_t)dl[b] * dl[b];
+        }
+        for (int r = 0; r < R; ++r) {
+            dg[r] = db_dir(dg[r], db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi));
+            dn += (int64_t)dg[r] * dg[r];
+        }
+        if (dn == 0) {                                    /* the memory cancelled the subgradient: restart from it */
+            for (int b = 0; b < B; ++b) {
+                da[b] = 16 * db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi);
+                dl[b] = 16 * db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi);
+            }
+            for (int r = 0; r < R; ++r) dg[r] = 16 * db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi);
+            dn = 256 * nrm;
+        }
+        const int64_t step = (gap << 20) / dn;           /* multiplier change = gap * 16 d / |d|^2, 16 fractional bits */
+        for (int b = 0; b < B; ++b) { a[b] = db_move(a[b], step, da[b]); l[b] = db_move(l[b], step, dl[b]); }
+        for (int r = 0; r < R; ++r) g[r] = db_move(g[r], step, dg[r]);
+    }
+done:
+    free(nrep); free(nlead);
+    return it;
+}

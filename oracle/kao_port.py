@@ -48,6 +48,9 @@ def lib():
         _LIB.kao_port_search.argtypes = [C.c_void_p, C.POINTER(PortParams), C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int64)]
         _LIB.kao_port_search.restype = C.c_int
+        _LIB.kao_port_dual_bound.argtypes = [C.POINTER(PortTopic), C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 6 + [
+            C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        _LIB.kao_port_dual_bound.restype = C.c_int
     return _LIB
 
 
@@ -107,3 +110,42 @@ def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params)
                     n_accept=int(st[5]))
     finally:
         lib().kao_port_ls_destroy(h)
+
+
+DB_SCALE = 4096
+INT64_MAX = (1 << 63) - 1
+
+
+class DualState:
+    """Multipliers + best dual value of one topic (KAO-DB, oracle/kao_port.c::kao_port_dual_bound)."""
+
+    def __init__(self, topic):
+        self.a = np.zeros(topic.n_brokers, dtype=np.int32)
+        self.l = np.zeros(topic.n_brokers, dtype=np.int32)
+        self.g = np.zeros(max(1, topic.n_racks), dtype=np.int32)
+        self.da = np.zeros_like(self.a)   # previous direction (deflected subgradient)
+        self.dl = np.zeros_like(self.l)
+        self.dg = np.zeros_like(self.g)
+        self.best_L = INT64_MAX
+        self.iters = 0
+        self.flags = 0
+
+    @property
+    def bound(self):
+        """floor(best_L / DB_SCALE): an upper bound on the optimum (None before the first iteration)."""
+        return None if self.best_L == INT64_MAX else self.best_L // DB_SCALE
+
+
+def port_dual_bound(topic, target: int, iters: int, state: DualState = None) -> DualState:
+    st = state or DualState(topic)
+    ct = CTopic(topic)
+    bl = C.c_int64(st.best_L)
+    fl = C.c_int32(0)
+    p32 = C.POINTER(C.c_int32)
+    n = lib().kao_port_dual_bound(C.byref(ct.s), int(target), int(iters), st.a.ctypes.data_as(p32), st.l.ctypes.data_as(p32),
+                                  st.g.ctypes.data_as(p32), st.da.ctypes.data_as(p32), st.dl.ctypes.data_as(p32),
+                                  st.dg.ctypes.data_as(p32), C.byref(bl), C.byref(fl))
+    st.best_L = int(bl.value)
+    st.iters += int(n)
+    st.flags = int(fl.value)
+    return st
