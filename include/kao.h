@@ -83,7 +83,8 @@ typedef struct kao_opts {
     int32_t period_log2;      /* sawtooth period = 2^(period_log2 + (restart & 3)); <= 0 = 8 */
     int32_t stop_at_bound;    /* kao_solve: 1 = stop as soon as every topic is OPTIMAL_PROVEN */
     int32_t profile;          /* 1 = bracket every kernel with HIP events (kao_session_stats) */
-    int32_t reserved;
+    int32_t dual_iters;       /* kao_solve: K-bound (Lagrangian dual bound) iterations per launch for topics whose
+                                 feasible incumbent is below the bound; 0 = 512, < 0 = never run K-bound */
     const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
                                         objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;
@@ -92,7 +93,7 @@ typedef struct kao_result {
     int32_t status;            /* KAO_STATUS_* */
     int32_t best_restart;      /* which restart produced the answer */
     int64_t objective;         /* value of the README objective (README.md:145-146) */
-    int64_t upper_bound;       /* combinatorial bound (kao_upper_bound) */
+    int64_t upper_bound;       /* min(closed-form bound (kao_upper_bound), K-bound dual certificate) */
     int32_t violations[8];     /* [0] total, [1..7] = C1..C7 magnitudes of the returned assignment */
     double seconds_to_best;    /* wall time from entry to the launch that produced `objective` */
     uint16_t *assignment;      /* [P*rf] caller-allocated; dense broker index, slot 0 = leader */
@@ -172,6 +173,28 @@ int kao_session_best(kao_session *s, kao_result *results);
  * min-allreduce across GPUs operates on: viol(20b) << 44 | (0xFFFFFF - objective) << 20 | restart. */
 int kao_session_best_keys(kao_session *s, uint64_t *keys);
 int kao_session_stats(kao_session *s, kao_stats *out);
+/* K-bound: the optimality certificate beyond the closed-form bound (kao_upper_bound).  lp_solve proves optimality
+ * by branch-and-bound over the LP relaxation (README.md:135-136); K-bound instead minimises the Lagrangian dual of
+ * the same 0-1 model (README.md:144-185) on the device: rows C3, C4, C6 priced with integer multipliers, rows
+ * C1, C2, C5, C7 kept in an exactly solved per-partition subproblem.  Every dual value is an upper bound on the
+ * optimum, so floor(min dual) is a certificate whatever the multipliers.
+ * One launch runs up to `iters` iterations for every topic i with target[i] >= 0 (the incumbent objective the
+ * step length aims at; pass -1 to skip a topic).  Topics outside K-bound's limits (n_brokers > 8192,
+ * n_partitions*rf > 131072, a weight outside 0..255) are skipped.  Asynchronous on the session's stream. */
+int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters);
+/* Synchronise and read the certificates back: upper_bound[i] = min(closed-form bound, floor(best dual value));
+ * flags[i]: 1 = the last K-bound launch closed the gap to its target, 2 = dual optimum reached (zero subgradient),
+ * 4 = no bound (a partition subproblem is infeasible), 8 = topic outside K-bound's limits; iters[i] = K-bound
+ * iterations so far.  Any output pointer may be NULL. */
+int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int32_t *iters);
+/* Test hook: K-bound state of one topic -- multipliers a[n_brokers], l[n_brokers], g[n_racks] (fixed point, 4096 = 1)
+ * and the smallest dual value so far in the same fixed point (INT64_MAX-like before the first iteration). */
+int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l, int32_t *g, int64_t *best_dual);
+/* One-shot K-bound on one topic: `launches` launches of `iters` iterations towards `target`.
+ * *bound = floor(best dual / 4096) (not combined with kao_upper_bound); multipliers, if not NULL, receives
+ * a[n_brokers], l[n_brokers], g[n_racks]. */
+int kao_dual_bound(const kao_topic *t, int64_t target, int32_t iters, int32_t launches, int64_t *bound,
+                   int64_t *best_dual, int32_t *iters_done, int32_t *flags, int32_t *multipliers);
 /* Test hook: state of one restart -- final[P*rf], best[P*rf] (dense), info = {best_obj, V, obj, accepted}. */
 int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, uint16_t *final_state,
                               uint16_t *best_state, int32_t info[4]);

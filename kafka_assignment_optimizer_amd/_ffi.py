@@ -21,7 +21,7 @@ class KaoOpts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("time_limit_s", C.c_double), ("restarts", C.c_int32),
                 ("iters_per_launch", C.c_int32), ("max_launches", C.c_int32), ("obj_scale", C.c_int32),
                 ("lam_min", C.c_int32), ("lam_max", C.c_int32), ("period_log2", C.c_int32),
-                ("stop_at_bound", C.c_int32), ("profile", C.c_int32), ("reserved", C.c_int32),
+                ("stop_at_bound", C.c_int32), ("profile", C.c_int32), ("dual_iters", C.c_int32),
                 ("target_objective", C.POINTER(C.c_int64))]
 
 
@@ -65,6 +65,11 @@ SIGNATURES = {
     "kao_session_stats": (C.c_int, [C.c_void_p, _P(KaoStats)]),
     "kao_session_restart_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_uint16), _P(C.c_uint16),
                                             _P(C.c_int32)]),
+    "kao_session_bound_step": (C.c_int, [C.c_void_p, _P(C.c_int64), C.c_int32]),
+    "kao_session_bounds": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32)]),
+    "kao_session_dual_state": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
+    "kao_dual_bound": (C.c_int, [_P(KaoTopic), C.c_int64, C.c_int32, C.c_int32, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32),
+                                 _P(C.c_int32), _P(C.c_int32)]),
     "kao_session_destroy": (None, [C.c_void_p]),
     "kao_solve": (C.c_int, [_P(KaoTopic), C.c_int32, _P(KaoOpts), _P(KaoResult)]),
     "kao_last_solve_timing": (C.c_int, [_P(C.c_double)]),

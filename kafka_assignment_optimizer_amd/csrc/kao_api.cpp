@@ -390,6 +390,17 @@ uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers
     return n;
 }
 
+// K-bound limits: 17 B of LDS per broker; 32-bit headroom of the priced values (weights x 4096, P*RF subgradients)
+bool dual_supported(const kao_topic *t) {
+    if (t->n_brokers > kDualMaxB) return false;
+    const int64_t n = (int64_t)t->n_partitions * t->rf;
+    if (n > 131072) return false;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (t->w[i][j] < 0 || t->w[i][j] > 255) return false;
+    return true;
+}
+
 template <typename T>
 int dev_alloc_copy(T **dst, const std::vector<T> &src) {
     *dst = nullptr;
@@ -451,6 +462,10 @@ struct kao_session {
     std::vector<int64_t> ub;
     std::vector<char> topic_global;  // per topic: runs with its assignment in global memory
     std::vector<char> topic_infeasible;  // per topic: proven infeasible by counting (kao_check_infeasible)
+    std::vector<char> dual_ok;           // per topic: within K-bound's limits
+    std::vector<int64_t> h_dual_target;  // staging for kao_session_bound_step
+    std::vector<int32_t> h_dual_ids;
+    std::vector<int32_t> dual_flags, dual_iters;
     int total_restarts = 0;
     // Topics are bucketed by LDS footprint into launch groups (a 3000-partition topic must not impose its LDS carve
     // and its 2 waves per workgroup on 200 small topics); one K-search + one K-eval launch per group per step.
@@ -483,6 +498,14 @@ struct kao_session {
     // read-back block (contiguous): [keys u64[T]] [drift i32 (16 B)] [win_viol i32[8T]] [win_assign u16[sum P*RF]]
     unsigned char *d_readback = nullptr;
     size_t readback_bytes = 0, rb_viol_off = 0, rb_assign_off = 0;
+    // K-bound: multipliers + directions per topic; targets and workgroup->topic ids (host-written before a launch);
+    // read-back block [best_L i64[T]] [info i32[4T]]
+    int32_t *d_dual = nullptr;
+    long long *d_dual_target = nullptr;
+    int32_t *d_dual_ids = nullptr;
+    unsigned char *d_dual_rb = nullptr;
+    size_t dual_rb_bytes = 0;
+    uint64_t bound_launches = 0;
     unsigned long long *d_keys = nullptr;
     int32_t *d_drift = nullptr;
     int32_t *d_win_viol = nullptr;
@@ -905,7 +928,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
 
     std::vector<uint4> cur_pool; std::vector<uint16_t> ext_pool, curd_pool; std::vector<int32_t> rsz_pool;
     std::vector<uint8_t> rackof_pool;
-    uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0;
+    uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0, dual_i32 = 0;
     s->topic_global.assign((size_t)n_topics, 0);
     int restart_base = 0;
     for (int t = 0; t < n_topics; ++t) {
@@ -941,6 +964,9 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         rackof_pool.insert(rackof_pool.end(), pt.rack_of.begin(), pt.rack_of.end());
         d.curd_off = (uint32_t)curd_pool.size();
         curd_pool.insert(curd_pool.end(), pt.cur_dense.begin(), pt.cur_dense.end());
+        d.dual_off = (uint32_t)dual_i32;
+        dual_i32 += 4 * (uint64_t)d.B + 2 * kRackTab;
+        s->dual_ok.push_back(dual_supported(&topics[t]) ? 1 : 0);
         // algorithmic bytes: full evaluation = 2*RF*P + 2*rf_cur*P + B per candidate
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
     }
@@ -1026,7 +1052,10 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->rb_viol_off = align_up((size_t)n_topics * 8 + 16, 16);
     s->rb_assign_off = s->rb_viol_off + (size_t)n_topics * 32;
     s->readback_bytes = s->rb_assign_off + win_u16 * 2;
-    const size_t rw_bytes = state_b + best_b + info_b + obj_b + viol_b + align_up(s->readback_bytes);
+    const size_t dual_b = align_up(dual_i32 * 4), dtarget_b = align_up((size_t)n_topics * 8), dids_b = align_up((size_t)n_topics * 4);
+    s->dual_rb_bytes = (size_t)n_topics * 24;
+    const size_t rw_bytes = state_b + best_b + info_b + obj_b + viol_b + align_up(s->readback_bytes) + dual_b + dtarget_b + dids_b +
+                            align_up(s->dual_rb_bytes);
     if ((rc = arena_get(rw_bytes, &s->arena_rw, &s->arena_rw_bytes))) { kao_session_destroy(s); return rc; }
     unsigned char *rw = static_cast<unsigned char *>(s->arena_rw);
     s->d_state = rw;
@@ -1040,6 +1069,16 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->d_win_viol = reinterpret_cast<int32_t *>(s->d_readback + s->rb_viol_off);
     s->d_win_assign = reinterpret_cast<uint16_t *>(s->d_readback + s->rb_assign_off);
     s->h_readback.assign(s->readback_bytes, 0);
+    {
+        unsigned char *q = s->d_readback + align_up(s->readback_bytes);
+        s->d_dual = reinterpret_cast<int32_t *>(q); q += dual_b;
+        s->d_dual_target = reinterpret_cast<long long *>(q); q += dtarget_b;
+        s->d_dual_ids = reinterpret_cast<int32_t *>(q); q += dids_b;
+        s->d_dual_rb = q;
+        s->dual_flags.assign((size_t)n_topics, 0);
+        s->dual_iters.assign((size_t)n_topics, 0);
+        for (int t = 0; t < n_topics; ++t) if (!s->dual_ok[(size_t)t]) s->dual_flags[(size_t)t] = 8;
+    }
 
     if ((rc = stream_get(&s->stream))) { kao_session_destroy(s); return rc; }
     // restart states / info / obj / viol are fully written by launch 0 (init) and the first K-eval; only the
@@ -1048,6 +1087,10 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     hipError_t e2 = hipMemsetAsync(s->d_best, 0xFF, best_u16 * 2 ? best_u16 * 2 : 2, s->stream);
     hipError_t e3 = hipMemsetAsync(s->d_readback, 0xFF, (size_t)n_topics * 8, s->stream);
     hipError_t e4 = hipMemsetAsync(s->d_drift, 0, 16, s->stream);
+    // K-bound state: multipliers and directions 0, best dual value "infinite" (0x7F7F...), info 0
+    if (e4 == hipSuccess) e4 = hipMemsetAsync(s->d_dual, 0, dual_b, s->stream);
+    if (e4 == hipSuccess) e4 = hipMemsetAsync(s->d_dual_rb, 0x7F, (size_t)n_topics * 8, s->stream);
+    if (e4 == hipSuccess) e4 = hipMemsetAsync(s->d_dual_rb + (size_t)n_topics * 8, 0, (size_t)n_topics * 16, s->stream);
     hipError_t e5 = hipStreamSynchronize(s->stream);  // `stage` is pageable host memory and goes out of scope
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
         kao_session_destroy(s);
@@ -1168,6 +1211,105 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     return KAO_OK;
 }
 
+int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters) {
+    if (!s || !target) return fail(KAO_ERR_INVALID, "null argument");
+    if (iters < 1) return fail(KAO_ERR_INVALID, "iters < 1");
+    HIP_TRY(hipSetDevice(g_device));
+    s->h_dual_ids.clear();
+    s->h_dual_target.assign((size_t)s->n_topics, -1);
+    int maxB = 0, maxP = 0;
+    for (int t = 0; t < s->n_topics; ++t) {
+        if (target[t] < 0 || !s->dual_ok[(size_t)t] || s->topic_infeasible[(size_t)t]) continue;
+        if (target[t] > (int64_t)1 << 40) return fail(KAO_ERR_INVALID, "target out of range");
+        s->h_dual_ids.push_back(t);
+        s->h_dual_target[(size_t)t] = target[t];
+        maxB = std::max(maxB, s->pts[(size_t)t].d.B);
+        maxP = std::max(maxP, s->pts[(size_t)t].d.P);
+    }
+    if (s->h_dual_ids.empty()) return KAO_OK;
+    // the staging vectors are pageable: make sure the previous launch's copies are done before they are rewritten
+    HIP_TRY(hipMemcpyAsync(s->d_dual_target, s->h_dual_target.data(), (size_t)s->n_topics * 8, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_dual_ids, s->h_dual_ids.data(), s->h_dual_ids.size() * 4, hipMemcpyHostToDevice, s->stream));
+    BoundPools bp{};
+    bp.topics = s->d_topics; bp.ids = s->d_dual_ids; bp.rackof_pool = s->d_rackof; bp.curd_pool = s->d_curd;
+    bp.dual_pool = s->d_dual; bp.target = s->d_dual_target;
+    bp.best_L = reinterpret_cast<long long *>(s->d_dual_rb);
+    bp.info = reinterpret_cast<int32_t *>(s->d_dual_rb + (size_t)s->n_topics * 8);
+    bp.iters = iters; bp.maxB = maxB;
+    const int waves = std::min(16, std::max(1, maxP));  // one wavefront per partition, at most 16 per workgroup
+    launch_bound(bp, (int)s->h_dual_ids.size(), waves, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));  // pageable staging above; K-bound launches are rare and short
+    s->bound_launches++;
+    return KAO_OK;
+}
+
+int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int32_t *iters) {
+    if (!s) return fail(KAO_ERR_INVALID, "null session");
+    if (s->bound_launches) {
+        std::vector<unsigned char> rb(s->dual_rb_bytes);
+        HIP_TRY(hipMemcpyAsync(rb.data(), s->d_dual_rb, s->dual_rb_bytes, hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        const int64_t *best = reinterpret_cast<const int64_t *>(rb.data());
+        const int32_t *info = reinterpret_cast<const int32_t *>(rb.data() + (size_t)s->n_topics * 8);
+        for (int t = 0; t < s->n_topics; ++t) {
+            if (!s->dual_ok[(size_t)t]) continue;
+            s->dual_iters[(size_t)t] = info[t * 4 + 0];
+            s->dual_flags[(size_t)t] = info[t * 4 + 1];
+            if ((info[t * 4 + 1] & 4) || info[t * 4 + 0] == 0 || best[t] >= (int64_t)0x7F7F7F7F7F7F7F7Fll) continue;
+            const int64_t b = best[t] >= 0 ? best[t] / kDualScale : -((-best[t] + kDualScale - 1) / kDualScale);  // floor
+            s->ub[(size_t)t] = std::min(s->ub[(size_t)t], b);
+        }
+    }
+    for (int t = 0; t < s->n_topics; ++t) {
+        if (upper_bound) upper_bound[t] = s->ub[(size_t)t];
+        if (flags) flags[t] = s->dual_flags[(size_t)t];
+        if (iters) iters[t] = s->dual_iters[(size_t)t];
+    }
+    return KAO_OK;
+}
+
+int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l, int32_t *g, int64_t *best_dual) {
+    if (!s || topic < 0 || topic >= s->n_topics) return fail(KAO_ERR_INVALID, "bad argument");
+    const TopicDev &d = s->pts[(size_t)topic].d;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int32_t *base = s->d_dual + d.dual_off;
+    if (a) HIP_TRY(hipMemcpy(a, base, (size_t)d.B * 4, hipMemcpyDeviceToHost));
+    if (l) HIP_TRY(hipMemcpy(l, base + d.B, (size_t)d.B * 4, hipMemcpyDeviceToHost));
+    if (g) HIP_TRY(hipMemcpy(g, base + 4 * (size_t)d.B, (size_t)d.R * 4, hipMemcpyDeviceToHost));
+    if (best_dual) HIP_TRY(hipMemcpy(best_dual, s->d_dual_rb + (size_t)topic * 8, 8, hipMemcpyDeviceToHost));
+    return KAO_OK;
+}
+
+int kao_dual_bound(const kao_topic *t, int64_t target, int32_t iters, int32_t launches, int64_t *bound, int64_t *best_dual,
+                   int32_t *iters_done, int32_t *flags, int32_t *multipliers) {
+    if (!t) return fail(KAO_ERR_INVALID, "null topic");
+    if (target < 0 || iters < 1 || launches < 1) return fail(KAO_ERR_INVALID, "bad target / iters / launches");
+    kao_opts o{};
+    o.restarts = kWaves;  // no search is run: the smallest session there is
+    kao_session *s = nullptr;
+    int rc = kao_session_create(t, 1, &o, &s);
+    if (rc) return rc;
+    if (!s->dual_ok[0]) { kao_session_destroy(s); return fail(KAO_ERR_UNSUPPORTED, "topic outside K-bound's limits"); }
+    int32_t fl = 0, itn = 0;
+    for (int i = 0; i < launches && !rc; ++i) {
+        rc = kao_session_bound_step(s, &target, iters);
+        if (!rc) rc = kao_session_bounds(s, nullptr, &fl, &itn);
+        if (fl & 7) break;
+    }
+    int64_t bd = 0;
+    if (!rc) rc = kao_session_dual_state(s, 0, multipliers, multipliers ? multipliers + t->n_brokers : nullptr,
+                                         multipliers ? multipliers + 2 * (size_t)t->n_brokers : nullptr, &bd);
+    if (!rc) {
+        if (best_dual) *best_dual = bd;
+        if (bound) *bound = (fl & 4) || itn == 0 ? INT64_MAX : (bd >= 0 ? bd / kDualScale : -((-bd + kDualScale - 1) / kDualScale));
+        if (iters_done) *iters_done = itn;
+        if (flags) *flags = fl;
+    }
+    kao_session_destroy(s);
+    return rc;
+}
+
 int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, uint16_t *final_state, uint16_t *best_state,
                               int32_t info[4]) {
     if (!s || topic < 0 || topic >= s->n_topics) return fail(KAO_ERR_INVALID, "bad topic");
@@ -1211,6 +1353,8 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     bool hit_time = false;
     int launches = 0;
     double t_last_improve = 0;
+    const int dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 512 : o.dual_iters);
+    std::vector<int64_t> dual_target((size_t)n_topics);
     for (;;) {
         if ((rc = kao_session_step(s)) || (rc = kao_session_best_keys(s, keys.data()))) { kao_session_destroy(s); return rc; }
         ++launches;
@@ -1223,6 +1367,30 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
             const int64_t goal = target ? target[i] : s->ub[(size_t)i];
             if (s->topic_infeasible[(size_t)i]) continue;  // proven infeasible: nothing to wait for
             if (!(feasible && obj >= goal)) all_done = false;
+        }
+        if (!all_done && !target && dual_iters > 0) {
+            // a feasible incumbent below the closed-form bound: tighten the certificate with K-bound (Lagrangian dual)
+            bool any = false;
+            for (int i = 0; i < n_topics; ++i) {
+                const bool feasible = (keys[(size_t)i] >> 44) == 0;
+                const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
+                const bool want = feasible && obj < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !(s->dual_flags[(size_t)i] & 6);
+                dual_target[(size_t)i] = want ? obj : -1;
+                any |= want;
+            }
+            if (any) {
+                if ((rc = kao_session_bound_step(s, dual_target.data(), dual_iters)) || (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) {
+                    kao_session_destroy(s);
+                    return rc;
+                }
+                all_done = true;
+                for (int i = 0; i < n_topics; ++i) {
+                    if (s->topic_infeasible[(size_t)i]) continue;
+                    const bool feasible = (keys[(size_t)i] >> 44) == 0;
+                    const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
+                    if (!(feasible && obj >= s->ub[(size_t)i])) all_done = false;
+                }
+            }
         }
         if (o.stop_at_bound && all_done) break;
         if (o.max_launches > 0 && launches >= o.max_launches) break;

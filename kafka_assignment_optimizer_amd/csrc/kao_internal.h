@@ -12,6 +12,9 @@ constexpr int kRackTab = 256;    // entries of the per-rack LDS tables (rack siz
 constexpr uint32_t kNoneW = 0xFFFFFFFFu;  // empty slot in the LDS word layout (x | rack << 16)
 constexpr uint32_t kKeyNull = 0xFFFFFFFFu;
 constexpr int kDBias = 32768;
+constexpr int kDualScale = 4096;          // fixed point of the dual multipliers (K-bound)
+constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
+constexpr int kDualMaxB = 8192;           // K-bound keeps 17 B per broker in LDS
 constexpr uint32_t kObjCap = 0xFFFFFFu;   // packed best key: viol(20) << 44 | (kObjCap - obj) << 20 | restart(20)
 
 // Device-side descriptor of one topic.  Read once per workgroup (wave-uniform -> SGPRs).
@@ -35,7 +38,7 @@ struct TopicDev {
     uint32_t rackof_off;         // rackof_pool: u8[B]
     uint32_t curd_off;           // curd_pool  : u16[P*rf_cur] dense current assignment
     uint32_t win_off;            // winners    : first u16 of this topic's winning assignment ([P*RF])
-    uint32_t pad_;
+    uint32_t dual_off;           // dual_pool  : first int32 of a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
 };
 
 struct SearchParams {
@@ -71,6 +74,19 @@ struct EvalPools {
     int32_t cur_in_lds;          // 1 = stage the current assignment in LDS (fits); 0 = read it from global memory
 };
 
+struct BoundPools {
+    const TopicDev *topics;
+    const int32_t *ids;          // per workgroup: topic
+    const uint8_t *rackof_pool;
+    const uint16_t *curd_pool;
+    int32_t *dual_pool;          // multipliers and previous directions, see TopicDev::dual_off
+    const long long *target;     // [n_topics] incumbent objective the Polyak step aims at
+    long long *best_L;           // [n_topics] smallest dual value so far (fixed point, kDualScale)
+    int32_t *info;               // [n_topics][4] = {iterations so far, flags of the last launch, -, -}
+    int32_t iters;               // iterations this launch
+    int32_t maxB;                // LDS carve size
+};
+
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a);
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds);
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, void *stream);
@@ -79,6 +95,10 @@ void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
 // read-back buffers: one D2H instead of two per topic
 void launch_gather(const TopicDev *topics, int n_topics, const unsigned long long *keys, const uint16_t *best_pool,
                    const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream);
+
+// K-bound: Lagrangian dual bound, one workgroup (`waves` wavefronts) per listed topic
+size_t bound_lds_bytes(int maxB);
+void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream);
 
 // canonical tie-break on the device (kao_canonicalize): one wavefront, assignment words in global memory
 size_t canon_lds_bytes(int maxBx);

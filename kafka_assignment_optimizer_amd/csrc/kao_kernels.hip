@@ -7,6 +7,9 @@
 //              construction) and move cost against broker / rack tables staged in LDS; a DPP min-reduce
 //              over the wavefront picks the move.  k_search<false> also keeps the assignment words in
 //              LDS; k_search<true> leaves them in HBM/L2 for topics that do not fit.
+//   k_bound  : Lagrangian dual bound "KAO-DB" (the optimality certificate): one workgroup per topic prices the
+//              coupling rows, one wavefront per partition solves the priced subproblem exactly, deflected Polyak
+//              subgradient steps in integer fixed point.
 //   k_eval   : full evaluation (objective README.md:145-146 and rows C1..C7 README.md:148-180) of
 //              complete compact candidates streamed from HBM, one wavefront per candidate, ending in
 //              the wavefront -> workgroup -> atomicMin reduce of the packed (violation, cost, id) key.
@@ -883,6 +886,221 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *c
 }
 
 // ------------------------------------------------------------------------------------------------
+// K-bound : Lagrangian dual bound "KAO-DB" (scalar replay oracle/kao_port.c::kao_port_dual_bound).
+// lp_solve certifies optimality by branch-and-bound over the LP relaxation (README.md:135-136); here the certificate
+// is the Lagrangian dual of the same 0-1 model: the coupling rows C3 (README.md:158-161), C4 (163-166) and C6 (173-176)
+// are priced with integer fixed-point multipliers a[b], l[b], g[r]; the rows local to a partition (C1, C2, C5, C7) stay
+// in a per-partition subproblem solved exactly by one wavefront (greedy follower set under the per-partition rack
+// band + one exchange for the leader).  L(a,l,g) bounds the optimum from above for ANY multipliers, so
+// floor(min L / kDualScale) is a valid certificate; a deflected Polyak subgradient step towards the incumbent
+// objective drives it down.  One workgroup per topic, persistent over the iterations of a launch; multipliers, counters
+// and the rack table live in LDS; integer-only so that the replay agrees bit for bit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) { return ~wave_umin(~v); }
+__device__ __forceinline__ long long wave_sum64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int db_sub(int m, int n, int lo, int hi) {  // element of the subdifferential closest to 0
+    return m > 0 ? hi - n : (m < 0 ? lo - n : (n < lo ? lo - n : (n > hi ? hi - n : 0)));
+}
+__device__ __forceinline__ int db_dir(int d_prev, int s) { return 16 * s + (int)(((long long)d_prev * 3) >> 2); }
+__device__ __forceinline__ int db_move(int m, long long step, int d) {
+    const long long mag = (step * (d < 0 ? -(long long)d : (long long)d)) >> 16;
+    long long v = (long long)m - (d < 0 ? -mag : mag);
+    v = v > kDualClamp ? kDualClamp : (v < -kDualClamp ? -kDualClamp : v);
+    return (int)v;
+}
+__device__ __forceinline__ int pick4(int x0, int x1, int x2, int x3, int k) {
+    const int lo = (k & 2) ? x2 : x0, hi = (k & 2) ? x3 : x1;
+    return (k & 1) ? hi : lo;
+}
+
+__global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
+    const int topic = pl.ids[blockIdx.x];
+    const TopicDev &T = pl.topics[topic];
+    const int B = T.B, R = T.R, P = T.P, RF = T.RF, rfc = T.rf_cur;
+    const int rep_lo = T.rep_lo, rep_hi = T.rep_hi, lead_lo = T.lead_lo, lead_hi = T.lead_hi;
+    const int rack_lo = T.rack_lo, rack_hi = T.rack_hi, plo = T.prack_lo, phi = T.prack_hi;
+    const int w00 = T.w00 * kDualScale, w01 = T.w01 * kDualScale, w10 = T.w10 * kDualScale, w11 = T.w11 * kDualScale;
+    // ---- LDS carve ----
+    long long *acc = reinterpret_cast<long long *>(smem_b);             // [2][4] : L, |s|^2, |d|^2, -
+    int *ctl = reinterpret_cast<int *>(smem_b + 64);                    // [4]
+    int *G = reinterpret_cast<int *>(smem_b + 80);                      // g[kRackTab]
+    int *DG = G + kRackTab;                                             // dg[kRackTab]
+    int *NK = DG + kRackTab;                                            // replicas per rack in the subproblem solutions
+    int *A = NK + kRackTab;                                             // a[maxB]
+    int *LM = A + pl.maxB;                                              // l[maxB]
+    int *NR = LM + pl.maxB;                                             // replicas per broker
+    int *NL = NR + pl.maxB;                                             // leaders per broker
+    const uint8_t *rk_g = pl.rackof_pool + T.rackof_off;
+    uint8_t *RK = reinterpret_cast<uint8_t *>(NL + pl.maxB);            // rack of broker
+    int *gp = pl.dual_pool + T.dual_off;                                // a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
+    int *g_a = gp, *g_l = gp + B, *g_da = gp + 2 * B, *g_dl = gp + 3 * B, *g_g = gp + 4 * B, *g_dg = gp + 4 * B + kRackTab;
+    for (int b = tid; b < B; b += nt) { A[b] = g_a[b]; LM[b] = g_l[b]; NR[b] = 0; NL[b] = 0; RK[b] = rk_g[b]; }
+    for (int r = tid; r < kRackTab; r += nt) { G[r] = r < R ? g_g[r] : 0; DG[r] = r < R ? g_dg[r] : 0; NK[r] = 0; }
+    if (tid < 8) acc[tid] = 0;
+    if (tid < 4) ctl[tid] = 0;
+    __syncthreads();
+    long long best = pl.best_L[topic];
+    const long long target = pl.target[topic];
+    const uint16_t *curd = pl.curd_pool + T.curd_off;
+    int flags = 0, it = 0;
+    for (; it < pl.iters; ++it) {
+        const int par = it & 1;
+        // ---- phase A: one wavefront per partition solves the priced subproblem ----
+        long long wsum = 0;
+        bool bad = false;
+        for (int pp = wave; pp < P; pp += nw) {
+            const int p = __builtin_amdgcn_readfirstlane(pp);
+            const uint16_t *cur = curd + (size_t)p * rfc;
+            const int c0 = cur[0], c1 = rfc > 1 ? (int)cur[1] : -1, c2 = rfc > 2 ? (int)cur[2] : -1, c3 = rfc > 3 ? (int)cur[3] : -1;
+            int Gb0 = -1, Gb1 = -1, Gb2 = -1, Gb3 = -1, Gf0 = 0, Gf1 = 0, Gf2 = 0, Gf3 = 0, Gr0 = -1, Gr1 = -1, Gr2 = -1, Gr3 = -1;
+            // greedy follower set: prack_lo best of every rack first, then the best remaining under the cap; ties -> lowest b
+            for (int j = 0; j < RF; ++j) {
+                const int forced = j < R * plo ? j / plo : -1;
+                uint32_t bkey = 0, bb = 0xFFFFFFFFu;
+                for (int b = lane; b < B; b += 64) {
+                    const int rb = RK[b];
+                    const int cnt = (int)(Gr0 == rb) + (int)(Gr1 == rb) + (int)(Gr2 == rb);
+                    const bool in = (Gb0 == b) | (Gb1 == b) | (Gb2 == b);
+                    const bool ok = (forced >= 0 ? rb == forced : cnt < phi) & !in;
+                    const int wf = (b == c0) ? w01 : (((b == c1) | (b == c2) | (b == c3)) ? w11 : 0);
+                    const uint32_t key = (uint32_t)(wf - A[b] - G[rb]) + 0x80000000u;
+                    if (ok && key > bkey) { bkey = key; bb = (uint32_t)b; }
+                }
+                const uint32_t mx = wave_umax(bkey);
+                if (mx == 0) { bad = true; break; }
+                const int sel = (int)wave_umin(bkey == mx ? bb : 0xFFFFFFFFu);
+                const int fv = (int)(mx - 0x80000000u), rs = RK[sel];
+                if (j == 0) { Gb0 = sel; Gf0 = fv; Gr0 = rs; }
+                else if (j == 1) { Gb1 = sel; Gf1 = fv; Gr1 = rs; }
+                else if (j == 2) { Gb2 = sel; Gf2 = fv; Gr2 = rs; }
+                else { Gb3 = sel; Gf3 = fv; Gr3 = rs; }
+            }
+            if (bad) break;
+            // leader: every broker b0; outside the set it displaces the cheapest element whose removal keeps the rack band
+            const int fG = Gf0 + Gf1 + Gf2 + Gf3;
+            const int cg0 = 1 + (int)(Gr1 == Gr0) + (int)(Gr2 == Gr0) + (int)(Gr3 == Gr0);
+            const int cg1 = (int)(Gr0 == Gr1) + 1 + (int)(Gr2 == Gr1) + (int)(Gr3 == Gr1);
+            const int cg2 = (int)(Gr0 == Gr2) + (int)(Gr1 == Gr2) + 1 + (int)(Gr3 == Gr2);
+            const int cg3 = (int)(Gr0 == Gr3) + (int)(Gr1 == Gr3) + (int)(Gr2 == Gr3) + 1;
+            uint32_t bkey = 0, bb = 0xFFFFFFFFu;
+            int be = 0;
+            for (int b0 = lane; b0 < B; b0 += 64) {
+                const int r0 = RK[b0];
+                const int wl = (b0 == c0) ? w00 : (((b0 == c1) | (b0 == c2) | (b0 == c3)) ? w10 : 0);
+                const int lv = wl - A[b0] - G[r0] - LM[b0];
+                const int c0cnt = (int)(Gr0 == r0) + (int)(Gr1 == r0) + (int)(Gr2 == r0) + (int)(Gr3 == r0);
+                int e = -1, fe = 0;
+                if (Gb0 == b0) { e = 0; fe = Gf0; }
+                else if (Gb1 == b0) { e = 1; fe = Gf1; }
+                else if (Gb2 == b0) { e = 2; fe = Gf2; }
+                else if (Gb3 == b0) { e = 3; fe = Gf3; }
+                else {
+                    const bool full = c0cnt >= phi;
+                    const bool ok0 = full ? Gr0 == r0 : ((Gr0 == r0) | (cg0 > plo));
+                    const bool ok1 = (RF > 1) & (full ? Gr1 == r0 : ((Gr1 == r0) | (cg1 > plo)));
+                    const bool ok2 = (RF > 2) & (full ? Gr2 == r0 : ((Gr2 == r0) | (cg2 > plo)));
+                    const bool ok3 = (RF > 3) & (full ? Gr3 == r0 : ((Gr3 == r0) | (cg3 > plo)));
+                    if (ok0) { e = 0; fe = Gf0; }                        // cheapest; ties -> the latest picked
+                    if (ok1 && (e < 0 || Gf1 <= fe)) { e = 1; fe = Gf1; }
+                    if (ok2 && (e < 0 || Gf2 <= fe)) { e = 2; fe = Gf2; }
+                    if (ok3 && (e < 0 || Gf3 <= fe)) { e = 3; fe = Gf3; }
+                }
+                const uint32_t key = (uint32_t)(fG - fe + lv) + 0x80000000u;
+                if (e >= 0 && key > bkey) { bkey = key; bb = (uint32_t)b0; be = e; }
+            }
+            const uint32_t mx = wave_umax(bkey);
+            if (mx == 0) { bad = true; break; }
+            const int sel = (int)wave_umin(bkey == mx ? bb : 0xFFFFFFFFu);
+            const unsigned long long own = __ballot(bkey == mx && bb == (uint32_t)sel);
+            const int esel = __builtin_amdgcn_readlane(be, (int)__builtin_ctzll(own));
+            wsum += (int)(mx - 0x80000000u);
+            // counts of the chosen set: lanes 0..RF-1 the kept followers, lane 4 the leader
+            if (lane < RF && lane != esel) {
+                atomicAdd(&NR[pick4(Gb0, Gb1, Gb2, Gb3, lane)], 1);
+                atomicAdd(&NK[pick4(Gr0, Gr1, Gr2, Gr3, lane)], 1);
+            } else if (lane == 4) {
+                atomicAdd(&NR[sel], 1);
+                atomicAdd(&NL[sel], 1);
+                atomicAdd(&NK[RK[sel]], 1);
+            }
+        }
+        if (lane == 0) {
+            if (wsum) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 0]), (unsigned long long)wsum);
+            if (bad) atomicOr(&ctl[0], 4);
+        }
+        __syncthreads();
+        if (ctl[0] & 4) { flags |= 4; break; }
+        // ---- phase B: band terms of L, subgradient s, new direction d = 16 s + floor(3 d_prev / 4) ----
+        long long cL = 0, cN = 0, cD = 0;
+        for (int b = tid; b < B; b += nt) {
+            const int a_ = A[b], l_ = LM[b];
+            const int sa = db_sub(a_, NR[b], rep_lo, rep_hi), sl = db_sub(l_, NL[b], lead_lo, lead_hi);
+            cL += (long long)a_ * (a_ > 0 ? rep_hi : rep_lo) + (long long)l_ * (l_ > 0 ? lead_hi : lead_lo);
+            cN += (long long)sa * sa + (long long)sl * sl;
+            const int da = db_dir(g_da[b], sa), dl = db_dir(g_dl[b], sl);
+            g_da[b] = da; g_dl[b] = dl;
+            cD += (long long)da * da + (long long)dl * dl;
+        }
+        if (tid < R) {
+            const int g_ = G[tid], sg = db_sub(g_, NK[tid], rack_lo, rack_hi);
+            cL += (long long)g_ * (g_ > 0 ? rack_hi : rack_lo);
+            cN += (long long)sg * sg;
+            const int dg = db_dir(DG[tid], sg);
+            DG[tid] = dg;
+            cD += (long long)dg * dg;
+        }
+        cL = wave_sum64(cL); cN = wave_sum64(cN); cD = wave_sum64(cD);
+        if (lane == 0) {
+            if (cL) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 0]), (unsigned long long)cL);
+            if (cN) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 1]), (unsigned long long)cN);
+            if (cD) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 2]), (unsigned long long)cD);
+        }
+        __syncthreads();
+        // ---- phase C: stop tests, Polyak step along d, reset the counters ----
+        const long long Lv = acc[par * 4 + 0], nrm = acc[par * 4 + 1];
+        long long dn = acc[par * 4 + 2];
+        if (Lv < best) best = Lv;
+        if (best < (target + 1) * kDualScale) { flags |= 1; ++it; break; }
+        if (nrm == 0) { flags |= 2; ++it; break; }
+        const bool reset = dn == 0;  // the memory cancelled the subgradient: restart from it
+        if (reset) dn = 256 * nrm;
+        const long long step = ((Lv - target * kDualScale) << 20) / dn;
+        for (int b = tid; b < B; b += nt) {
+            int da = g_da[b], dl = g_dl[b];
+            if (reset) {
+                da = 16 * db_sub(A[b], NR[b], rep_lo, rep_hi); dl = 16 * db_sub(LM[b], NL[b], lead_lo, lead_hi);
+                g_da[b] = da; g_dl[b] = dl;
+            }
+            A[b] = db_move(A[b], step, da);
+            LM[b] = db_move(LM[b], step, dl);
+            NR[b] = 0; NL[b] = 0;
+        }
+        if (tid < R) {
+            int dg = DG[tid];
+            if (reset) { dg = 16 * db_sub(G[tid], NK[tid], rack_lo, rack_hi); DG[tid] = dg; }
+            G[tid] = db_move(G[tid], step, dg);
+            NK[tid] = 0;
+        }
+        if (tid < 4) acc[(par ^ 1) * 4 + tid] = 0;
+        __syncthreads();
+    }
+    // ---- epilogue: multipliers and the best dual value go back to HBM for the next launch ----
+    for (int b = tid; b < B; b += nt) { g_a[b] = A[b]; g_l[b] = LM[b]; }
+    if (tid < R) { g_g[tid] = G[tid]; g_dg[tid] = DG[tid]; }
+    if (tid == 0) {
+        pl.best_L[topic] = best;
+        pl.info[topic * 4 + 0] += it;
+        pl.info[topic * 4 + 1] = flags;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a) {
@@ -923,6 +1141,21 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
                    const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream) {
     hipLaunchKernelGGL(k_gather, dim3(n_topics), dim3(64), 0, static_cast<hipStream_t>(stream), topics, keys, best_pool, viol,
                        win_assign, win_viol);
+}
+
+size_t bound_lds_bytes(int maxB) {
+    return 80 + 3 * (size_t)kRackTab * 4 + 16 * (size_t)maxB + (((size_t)maxB + 15) & ~(size_t)15);
+}
+
+static int g_attr_bound = 0;
+
+void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream) {
+    const size_t lds = bound_lds_bytes(pools.maxB);
+    if ((int)lds > g_attr_bound) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bound), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        g_attr_bound = (int)lds;
+    }
+    hipLaunchKernelGGL(k_bound, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools);
 }
 
 size_t canon_lds_bytes(int maxBx) {

@@ -243,6 +243,36 @@ class Session:
         return dict(final=fin.reshape(t.n_partitions, t.rf), best=best.reshape(t.n_partitions, t.rf),
                     best_obj=int(info[0]), V=int(info[1]), obj=int(info[2]), n_accept=int(info[3]))
 
+    def bound_step(self, targets: Sequence[int], iters: int = 512):
+        """One K-bound launch (Lagrangian dual bound) for every topic whose target (incumbent objective) is >= 0."""
+        tg = np.ascontiguousarray(targets, dtype=np.int64)
+        if tg.shape != (len(self.topics),):
+            raise ValueError("one target per topic")
+        _check(_ffi.load().kao_session_bound_step(self._h, tg.ctypes.data_as(C.POINTER(C.c_int64)), int(iters)),
+               "kao_session_bound_step")
+
+    def bounds(self) -> dict:
+        """Certificates: upper_bound = min(closed-form bound, floor(best dual value)); flags / iters per topic."""
+        n = len(self.topics)
+        ub = np.zeros(n, dtype=np.int64)
+        fl = np.zeros(n, dtype=np.int32)
+        it = np.zeros(n, dtype=np.int32)
+        _check(_ffi.load().kao_session_bounds(self._h, ub.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              fl.ctypes.data_as(C.POINTER(C.c_int32)), it.ctypes.data_as(C.POINTER(C.c_int32))),
+               "kao_session_bounds")
+        return dict(upper_bound=ub, flags=fl, iters=it)
+
+    def dual_state(self, topic: int) -> dict:
+        t = self.topics[topic]
+        a = np.zeros(t.n_brokers, dtype=np.int32)
+        l = np.zeros(t.n_brokers, dtype=np.int32)
+        g = np.zeros(t.n_racks, dtype=np.int32)
+        best = C.c_int64()
+        p32 = C.POINTER(C.c_int32)
+        _check(_ffi.load().kao_session_dual_state(self._h, topic, a.ctypes.data_as(p32), l.ctypes.data_as(p32),
+                                                  g.ctypes.data_as(p32), C.byref(best)), "kao_session_dual_state")
+        return dict(a=a, l=l, g=g, best_dual=int(best.value))
+
     def close(self):
         if self._h:
             _ffi.load().kao_session_destroy(self._h)
@@ -259,6 +289,19 @@ class Session:
             self.close()
         except Exception:
             pass
+
+
+def dual_bound(topic: Topic, target: int, iters: int = 512, launches: int = 1) -> dict:
+    """One-shot K-bound (kao_dual_bound): Lagrangian dual certificate of one topic towards the incumbent `target`."""
+    ct = _CTopics([topic])
+    bound, best = C.c_int64(), C.c_int64()
+    itn, fl = C.c_int32(), C.c_int32()
+    mult = np.zeros(2 * topic.n_brokers + topic.n_racks, dtype=np.int32)
+    _check(_ffi.load().kao_dual_bound(ct.ptr(0), int(target), int(iters), int(launches), C.byref(bound), C.byref(best),
+                                      C.byref(itn), C.byref(fl), mult.ctypes.data_as(C.POINTER(C.c_int32))), "kao_dual_bound")
+    B = topic.n_brokers
+    return dict(bound=int(bound.value), best_dual=int(best.value), iters=int(itn.value), flags=int(fl.value),
+                a=mult[:B].copy(), l=mult[B:2 * B].copy(), g=mult[2 * B:].copy())
 
 
 def decode_key(key: int) -> tuple:

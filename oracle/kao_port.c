@@ -657,31 +657,26 @@ int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int3
             nlead[S[0]]++;
             for (int j = 0; j < RF; ++j) { nrep[S[j]]++; nrack[t->rack_of[S[j]]]++; }
         }
-        int64_t nrm = 0;
+        /* band terms of L, subgradient s, new direction d = 16 s + floor(3 d_prev / 4) (kept even when this iteration stops) */
+        int64_t nrm = 0, dn = 0;
         for (int b = 0; b < B; ++b) {
             L += (int64_t)a[b] * (a[b] > 0 ? t->rep_hi : t->rep_lo) + (int64_t)l[b] * (l[b] > 0 ? t->lead_hi : t->lead_lo);
-            const int64_t sa = db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi), sl = db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi);
-            nrm += sa * sa + sl * sl;
+            const int32_t sa = db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi), sl = db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi);
+            nrm += (int64_t)sa * sa + (int64_t)sl * sl;
+            da[b] = db_dir(da[b], sa);
+            dl[b] = db_dir(dl[b], sl);
+            dn += (int64_t)da[b] * da[b] + (int64_t)dl[b] * dl[b];
         }
         for (int r = 0; r < R; ++r) {
             L += (int64_t)g[r] * (g[r] > 0 ? t->rack_hi : t->rack_lo);
-            const int64_t sg = db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi);
-            nrm += sg * sg;
+            const int32_t sg = db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi);
+            nrm += (int64_t)sg * sg;
+            dg[r] = db_dir(dg[r], sg);
+            dn += (int64_t)dg[r] * dg[r];
         }
         if (L < *best_L) *best_L = L;
         if (*best_L < (target + 1) * DB_SCALE) { *flags |= 1; ++it; break; }
         if (nrm == 0) { *flags |= 2; ++it; break; }
-        const int64_t gap = L - target * DB_SCALE;       /* >= DB_SCALE here */
-        int64_t dn = 0;
-        for (int b = 0; b < B; ++b) {
-            da[b] = db_dir(da[b], db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi));
-            dl[b] = db_dir(dl[b], db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi));
-            dn += (int64_t)da[b] * da[b] + (int64_t)dl[b] * dl[b];
-        }
-        for (int r = 0; r < R; ++r) {
-            dg[r] = db_dir(dg[r], db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi));
-            dn += (int64_t)dg[r] * dg[r];
-        }
         if (dn == 0) {                                    /* the memory cancelled the subgradient: restart from it */
             for (int b = 0; b < B; ++b) {
                 da[b] = 16 * db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi);
@@ -690,6 +685,7 @@ int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int3
             for (int r = 0; r < R; ++r) dg[r] = 16 * db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi);
             dn = 256 * nrm;
         }
+        const int64_t gap = L - target * DB_SCALE;       /* >= DB_SCALE here */
         const int64_t step = (gap << 20) / dn;           /* multiplier change = gap * 16 d / |d|^2, 16 fractional bits */
         for (int b = 0; b < B; ++b) { a[b] = db_move(a[b], step, da[b]); l[b] = db_move(l[b], step, dl[b]); }
         for (int r = 0; r < R; ++r) g[r] = db_move(g[r], step, dg[r]);

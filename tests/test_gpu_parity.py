@@ -527,3 +527,81 @@ def test_determinism(kao, ko):
             s.step(3)
             outs.append(([r.assignment.tolist() for r in s.best()], s.best_keys().tolist()))
     assert outs[0] == outs[1]
+
+
+# ------------------------------------------------------------------------------- K-bound (Lagrangian dual certificate)
+def _wide_cases(ko, status="optimal"):
+    return [(c, ko.random_case_wide(c["seed"])) for c in load_golden("random_wide.json")["cases"] if c["status"] == status]
+
+
+def test_dual_bound_replay_bit_exact(kao, ko, kp):
+    """K-bound vs its scalar replay (oracle/kao_port.c::kao_port_dual_bound): identical multipliers, best dual value,
+    iteration count and stop flags -- one launch, and several launches that continue from the state in HBM."""
+    picked = [(c, t) for c, t in _wide_cases(ko) if c["upper_bound"] != c["objective"]][:40]
+    picked += [(e, ko.topic_from_dict(e["topic"])) for n in ("cfg2.json", "cfg3.json", "cfg4.json") for e in load_golden(n)["topics"][:1]]
+    assert len(picked) >= 40
+    for i, (c, ot) in enumerate(picked):
+        target = c["objective"] - (i % 3 == 2) * 2      # every third case aims at a suboptimal incumbent
+        iters, launches = (37, 3) if i % 2 else (120, 1)
+        got = kao.dual_bound(to_product_topic(ot), target, iters=iters, launches=launches)
+        st = kp.DualState(ot)
+        for _ in range(launches):
+            st = kp.port_dual_bound(ot, target, iters, st)
+            if st.flags & 7:
+                break
+        tag = (i, c.get("seed"), ot.n_brokers, ot.n_partitions)
+        assert (got["iters"], got["flags"]) == (st.iters, st.flags), tag
+        assert got["best_dual"] == st.best_L, tag
+        assert got["a"].tolist() == st.a.tolist() and got["l"].tolist() == st.l.tolist() and got["g"].tolist() == st.g[:ot.n_racks].tolist(), tag
+        assert got["bound"] == st.bound >= c["objective"], tag
+
+
+def test_dual_bound_is_valid_and_closes_wide_family(kao, ko):
+    """Every feasible instance of the wide family: floor(dual) never undercuts the HiGHS optimum and, aimed at the
+    optimum, equals it on all but a few (the closed-form bound is tight on fewer than half)."""
+    cases = _wide_cases(ko)
+    closed = 0
+    for c, ot in cases:
+        got = kao.dual_bound(to_product_topic(ot), c["objective"], iters=1500)
+        assert not got["flags"] & 4 and got["bound"] >= c["objective"], c["seed"]
+        closed += got["bound"] == c["objective"]
+    assert closed >= len(cases) - 4, (closed, len(cases))
+
+
+def test_solve_proves_wide_family(kao, ko):
+    """kao_solve end to end on the 400-instance wide family in ONE call (heterogeneous topics): feasible instances
+    reach the HiGHS optimum and are PROVEN optimal (closed-form bound or K-bound) on all but a few; instances HiGHS
+    found infeasible come back INFEASIBLE_PROVEN."""
+    cases = load_golden("random_wide.json")["cases"]
+    ots = [ko.random_case_wide(c["seed"]) for c in cases]
+    res = kao.solve([to_product_topic(t) for t in ots], seed=31, restarts=32, iters_per_launch=256, time_limit_s=20.0, stop_at_bound=1)
+    n_opt = n_proven = n_equal = 0
+    for c, ot, r in zip(cases, ots, res):
+        if c["status"] == "infeasible":
+            assert r.status == "INFEASIBLE_PROVEN", c["seed"]
+            continue
+        n_opt += 1
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == r.objective <= c["objective"] <= r.upper_bound, (c["seed"], r.objective, c["objective"], r.upper_bound)
+        n_equal += r.objective == c["objective"]
+        if r.status == "OPTIMAL_PROVEN":
+            assert r.objective == c["objective"], c["seed"]
+            n_proven += 1
+    assert n_equal >= n_opt - 2 and n_proven >= n_opt - 6, (n_opt, n_equal, n_proven)
+
+
+def test_dual_bound_limits_and_errors(kao, ko):
+    ot = ko.readme_example()
+    pt = to_product_topic(ot)
+    got = kao.dual_bound(pt, 58, iters=200)
+    assert got["bound"] == 58 and got["flags"] & 1                       # KAT-1: certificate == README optimum
+    with pytest.raises(kao.KaoError):
+        kao.dual_bound(pt, -1)
+    big = to_product_topic(ko.make_cluster("big", 9000, 10, 1, 64, 3, [], []).topics[0])    # > 8192 brokers: outside K-bound
+    with pytest.raises(kao.KaoError):
+        kao.dual_bound(big, 10)
+    with kao.Session([big, pt], restarts=8, iters_per_launch=64) as s:   # skipped silently inside a session, flag 8
+        s.step(1)
+        s.bound_step([100, 58], 100)
+        b = s.bounds()
+        assert b["flags"][0] == 8 and b["iters"][0] == 0 and b["upper_bound"][1] == 58

@@ -82,6 +82,30 @@ def test_infeasibility_proofs_match_oracle_and_highs(ko):
     assert not kao.check_infeasible(to_product_topic(ko.readme_example()))
 
 
+def test_wide_family_host_bound_and_infeasibility(ko):
+    """tests/golden/random_wide.json (400 instances: uneven racks, RF <= 4 with RF changes, random weights): the
+    generator still produces the fingerprinted instances; the host's closed-form bound equals the oracle's and never
+    undercuts the HiGHS optimum; every instance HiGHS found infeasible is proven infeasible by counting."""
+    import zlib
+    import kafka_assignment_optimizer_amd as kao
+    n_opt = n_inf = 0
+    for c in load_golden("random_wide.json")["cases"]:
+        ot = ko.random_case_wide(c["seed"])
+        assert [ot.n_brokers, ot.n_racks, ot.n_partitions, ot.rf_cur, ot.rf] == c["shape"]
+        assert zlib.crc32(ot.current.astype("<u2").tobytes()) == c["current_crc"]
+        pt = to_product_topic(ot)
+        why = kao.check_infeasible(pt)
+        assert bool(why) == c["proven_infeasible_by_counting"] == bool(ko.provably_infeasible(ot))
+        if c["status"] == "infeasible":
+            assert why, c["seed"]
+            n_inf += 1
+        else:
+            assert not why
+            assert kao.upper_bound(pt) == c["upper_bound"] >= c["objective"], c["seed"]
+            n_opt += 1
+    assert n_opt >= 150 and n_inf >= 150
+
+
 def test_validation_errors(ko):
     import kafka_assignment_optimizer_amd as kao
     pt = to_product_topic(ko.readme_example())

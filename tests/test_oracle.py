@@ -187,3 +187,37 @@ def test_port_bookkeeping_matches_verifier_on_edge_shapes(ko, kp):
     full = ko.make_cluster("full", 3, 3, 1, 5, 3, [], []).topics[0]  # RF == B, every rack a single broker
     r = kp.port_search(full, 1, 0, 1, 16)
     assert (r["best_obj"], r["V"]) == (40, 0)
+
+
+def test_port_dual_bound_is_valid_and_closes_the_gap(ko, kp):
+    """KAO-DB (oracle/kao_port.c::kao_port_dual_bound, the replay of K-bound): on every feasible instance of the wide
+    golden family the Lagrangian dual value never undercuts the HiGHS optimum -- also when the step aims at a
+    suboptimal incumbent -- and with the optimum as target it closes the gap (floor(dual) == optimum) on all but a
+    few; the closed-form bound alone is tight on fewer than half of them."""
+    cases = [c for c in load_golden("random_wide.json")["cases"] if c["status"] == "optimal"]
+    closed = tight_closed_form = 0
+    for c in cases:
+        t = ko.random_case_wide(c["seed"])
+        st = kp.port_dual_bound(t, c["objective"], 1500)
+        assert not st.flags & 4
+        assert st.bound >= c["objective"], c["seed"]
+        closed += st.bound == c["objective"]
+        tight_closed_form += c["upper_bound"] == c["objective"]
+        if c["seed"] % 7 == 0:  # a suboptimal incumbent as target: still a valid bound; continuation == one long run
+            lo = kp.port_dual_bound(t, max(0, c["objective"] - 5), 60)
+            assert lo.bound >= c["objective"]
+            one = kp.port_dual_bound(t, c["objective"], 80)
+            two = kp.port_dual_bound(t, c["objective"], 30)
+            if not two.flags & 3:
+                two = kp.port_dual_bound(t, c["objective"], 50, two)
+            assert (one.best_L, one.a.tolist(), one.l.tolist(), one.g.tolist()) == (two.best_L, two.a.tolist(), two.l.tolist(), two.g.tolist())
+    assert closed >= len(cases) - 4 and tight_closed_form < len(cases) // 2 + 5, (closed, tight_closed_form, len(cases))
+
+
+def test_port_dual_bound_golden_configs(ko, kp):
+    for name in ("kat1.json", "cfg2.json", "cfg3.json", "cfg4.json"):
+        g = load_golden(name)
+        for e in (g["topics"] if "topics" in g else [g]):
+            t = ko.topic_from_dict(e["topic"])
+            st = kp.port_dual_bound(t, e["objective"], 400)
+            assert st.bound == e["objective"] and st.flags & 1
