@@ -180,9 +180,13 @@ int kao_session_stats(kao_session *s, kao_stats *out);
  * optimum, so floor(min dual) is a certificate whatever the multipliers.
  * One launch runs up to `iters` iterations for every topic i with target[i] >= 0 (the incumbent objective the
  * step length aims at; pass -1 to skip a topic).  Topics outside K-bound's limits (n_brokers > 8192,
- * n_partitions*rf > 131072, a weight outside 0..255) are skipped.  Asynchronous on the session's stream. */
+ * n_partitions*rf > 131072, a weight outside 0..255) are skipped.  Asynchronous, on a stream of its own: K-bound
+ * occupies one compute unit per topic and runs beside K-search (kao_session_step); a new launch first waits for the
+ * previous K-bound launch (it continues from the multipliers that one left in HBM). */
 int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters);
-/* Synchronise and read the certificates back: upper_bound[i] = min(closed-form bound, floor(best dual value));
+/* 1 while a K-bound launch is still running, 0 when none is (its results can be read without waiting), < 0 = error. */
+int kao_session_bound_busy(kao_session *s);
+/* Wait for the K-bound launch in flight (if any) and read the certificates back: upper_bound[i] = min(closed-form bound, floor(best dual value));
  * flags[i]: 1 = the last K-bound launch closed the gap to its target, 2 = dual optimum reached (zero subgradient),
  * 4 = no bound (a partition subproblem is infeasible), 8 = topic outside K-bound's limits; iters[i] = K-bound
  * iterations so far.  Any output pointer may be NULL. */

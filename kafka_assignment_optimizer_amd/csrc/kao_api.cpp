@@ -506,6 +506,11 @@ struct kao_session {
     unsigned char *d_dual_rb = nullptr;
     size_t dual_rb_bytes = 0;
     uint64_t bound_launches = 0;
+    hipStream_t stream_bound = nullptr;   // K-bound runs beside K-search on its own stream (it occupies one CU per topic)
+    hipEvent_t ev_bound0 = nullptr, ev_bound1 = nullptr;
+    bool bound_inflight = false;
+    int bound_iters_last = 0;
+    double bound_ms_last = 0;
     unsigned long long *d_keys = nullptr;
     int32_t *d_drift = nullptr;
     int32_t *d_win_viol = nullptr;
@@ -881,6 +886,10 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
 void kao_session_destroy(kao_session *s) {
     if (!s) return;
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream_bound) (void)hipStreamSynchronize(s->stream_bound);
+    if (s->ev_bound0) (void)hipEventDestroy(s->ev_bound0);
+    if (s->ev_bound1) (void)hipEventDestroy(s->ev_bound1);
+    if (s->stream_bound) stream_put(s->stream_bound);
     arena_put(s->arena_ro, s->arena_ro_bytes);
     arena_put(s->arena_rw, s->arena_rw_bytes);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
@@ -1227,29 +1236,56 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
         maxP = std::max(maxP, s->pts[(size_t)t].d.P);
     }
     if (s->h_dual_ids.empty()) return KAO_OK;
-    // the staging vectors are pageable: make sure the previous launch's copies are done before they are rewritten
-    HIP_TRY(hipMemcpyAsync(s->d_dual_target, s->h_dual_target.data(), (size_t)s->n_topics * 8, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->d_dual_ids, s->h_dual_ids.data(), s->h_dual_ids.size() * 4, hipMemcpyHostToDevice, s->stream));
+    if (!s->stream_bound) {
+        int rc = stream_get(&s->stream_bound);
+        if (rc) return rc;
+        HIP_TRY(hipEventCreate(&s->ev_bound0));
+        HIP_TRY(hipEventCreate(&s->ev_bound1));
+    }
+    // one K-bound launch in flight at a time (it continues from the state the previous one left in HBM); the session
+    // upload was synchronised at creation, K-search and K-bound share read-only tables only
+    HIP_TRY(hipStreamSynchronize(s->stream_bound));
+    // pageable staging: hipMemcpyAsync returns once the host buffers have been consumed
+    HIP_TRY(hipMemcpyAsync(s->d_dual_target, s->h_dual_target.data(), (size_t)s->n_topics * 8, hipMemcpyHostToDevice, s->stream_bound));
+    HIP_TRY(hipMemcpyAsync(s->d_dual_ids, s->h_dual_ids.data(), s->h_dual_ids.size() * 4, hipMemcpyHostToDevice, s->stream_bound));
     BoundPools bp{};
     bp.topics = s->d_topics; bp.ids = s->d_dual_ids; bp.rackof_pool = s->d_rackof; bp.curd_pool = s->d_curd;
     bp.dual_pool = s->d_dual; bp.target = s->d_dual_target;
     bp.best_L = reinterpret_cast<long long *>(s->d_dual_rb);
     bp.info = reinterpret_cast<int32_t *>(s->d_dual_rb + (size_t)s->n_topics * 8);
-    bp.iters = iters; bp.maxB = maxB;
+    bp.iters = iters; bp.maxB = maxB; bp.maxP = maxP;
+    bp.cur_in_lds = bound_lds_bytes(maxB, maxP, true) <= 160 * 1024 ? 1 : 0;
     const int waves = std::min(16, std::max(1, maxP));  // one wavefront per partition, at most 16 per workgroup
-    launch_bound(bp, (int)s->h_dual_ids.size(), waves, s->stream);
+    HIP_TRY(hipEventRecord(s->ev_bound0, s->stream_bound));
+    launch_bound(bp, (int)s->h_dual_ids.size(), waves, s->stream_bound);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s->stream));  // pageable staging above; K-bound launches are rare and short
+    HIP_TRY(hipEventRecord(s->ev_bound1, s->stream_bound));
+    s->bound_inflight = true;
+    s->bound_iters_last = iters;
     s->bound_launches++;
     return KAO_OK;
+}
+
+int kao_session_bound_busy(kao_session *s) {
+    if (!s) return fail(KAO_ERR_INVALID, "null session");
+    if (!s->bound_inflight) return 0;
+    const hipError_t e = hipEventQuery(s->ev_bound1);
+    if (e == hipErrorNotReady) return 1;
+    if (e != hipSuccess) return fail(KAO_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+    return 0;
 }
 
 int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int32_t *iters) {
     if (!s) return fail(KAO_ERR_INVALID, "null session");
     if (s->bound_launches) {
         std::vector<unsigned char> rb(s->dual_rb_bytes);
-        HIP_TRY(hipMemcpyAsync(rb.data(), s->d_dual_rb, s->dual_rb_bytes, hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpyAsync(rb.data(), s->d_dual_rb, s->dual_rb_bytes, hipMemcpyDeviceToHost, s->stream_bound));
+        HIP_TRY(hipStreamSynchronize(s->stream_bound));
+        if (s->bound_inflight) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, s->ev_bound0, s->ev_bound1) == hipSuccess) s->bound_ms_last = ms;
+            s->bound_inflight = false;
+        }
         const int64_t *best = reinterpret_cast<const int64_t *>(rb.data());
         const int32_t *info = reinterpret_cast<const int32_t *>(rb.data() + (size_t)s->n_topics * 8);
         for (int t = 0; t < s->n_topics; ++t) {
@@ -1273,6 +1309,7 @@ int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l
     if (!s || topic < 0 || topic >= s->n_topics) return fail(KAO_ERR_INVALID, "bad argument");
     const TopicDev &d = s->pts[(size_t)topic].d;
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->stream_bound) HIP_TRY(hipStreamSynchronize(s->stream_bound));
     const int32_t *base = s->d_dual + d.dual_off;
     if (a) HIP_TRY(hipMemcpy(a, base, (size_t)d.B * 4, hipMemcpyDeviceToHost));
     if (l) HIP_TRY(hipMemcpy(l, base + d.B, (size_t)d.B * 4, hipMemcpyDeviceToHost));
@@ -1355,6 +1392,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     double t_last_improve = 0;
     const int dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 512 : o.dual_iters);
     std::vector<int64_t> dual_target((size_t)n_topics);
+    int dual_now = dual_iters;
     for (;;) {
         if ((rc = kao_session_step(s)) || (rc = kao_session_best_keys(s, keys.data()))) { kao_session_destroy(s); return rc; }
         ++launches;
@@ -1368,28 +1406,37 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
             if (s->topic_infeasible[(size_t)i]) continue;  // proven infeasible: nothing to wait for
             if (!(feasible && obj >= goal)) all_done = false;
         }
-        if (!all_done && !target && dual_iters > 0) {
-            // a feasible incumbent below the closed-form bound: tighten the certificate with K-bound (Lagrangian dual)
-            bool any = false;
-            for (int i = 0; i < n_topics; ++i) {
-                const bool feasible = (keys[(size_t)i] >> 44) == 0;
-                const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
-                const bool want = feasible && obj < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !(s->dual_flags[(size_t)i] & 6);
-                dual_target[(size_t)i] = want ? obj : -1;
-                any |= want;
-            }
-            if (any) {
-                if ((rc = kao_session_bound_step(s, dual_target.data(), dual_iters)) || (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) {
-                    kao_session_destroy(s);
-                    return rc;
+        if (!target && dual_iters > 0) {
+            // K-bound runs beside the search on its own stream; when a launch has finished its certificates are merged
+            // and, while some feasible incumbent is still below its bound, the next launch starts (aimed at the new
+            // incumbents).  Launch length adapts so that one launch takes about 10 ms.
+            const int busy = kao_session_bound_busy(s);
+            if (busy < 0) { kao_session_destroy(s); return busy; }
+            if (!busy) {
+                if (s->bound_inflight) {
+                    if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) { kao_session_destroy(s); return rc; }
+                    if (s->bound_ms_last > 0) {
+                        const double scale = 10.0 / s->bound_ms_last;
+                        dual_now = (int)std::min(4096.0, std::max(32.0, s->bound_iters_last * std::min(4.0, std::max(0.25, scale))));
+                    }
+                    all_done = true;
+                    for (int i = 0; i < n_topics; ++i) {
+                        if (s->topic_infeasible[(size_t)i]) continue;
+                        const bool feasible = (keys[(size_t)i] >> 44) == 0;
+                        const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
+                        if (!(feasible && obj >= s->ub[(size_t)i])) all_done = false;
+                    }
                 }
-                all_done = true;
-                for (int i = 0; i < n_topics; ++i) {
-                    if (s->topic_infeasible[(size_t)i]) continue;
+                bool any = false;
+                for (int i = 0; i < n_topics && !all_done; ++i) {
                     const bool feasible = (keys[(size_t)i] >> 44) == 0;
                     const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
-                    if (!(feasible && obj >= s->ub[(size_t)i])) all_done = false;
+                    const bool want = feasible && obj < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
+                                      !(s->dual_flags[(size_t)i] & 6);
+                    dual_target[(size_t)i] = want ? obj : -1;
+                    any |= want;
                 }
+                if (any && (rc = kao_session_bound_step(s, dual_target.data(), dual_now))) { kao_session_destroy(s); return rc; }
             }
         }
         if (o.stop_at_bound && all_done) break;
@@ -1397,6 +1444,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
         if (t >= o.time_limit_s) { hit_time = true; break; }
     }
     g_timing[1] = t_last_improve;
+    if (s->bound_inflight && (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) { kao_session_destroy(s); return rc; }  // last K-bound launch
     rc = kao_session_best(s, results);
     g_timing[2] = now_s() - t0;
     if (!rc)

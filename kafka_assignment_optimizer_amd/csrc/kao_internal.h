@@ -84,7 +84,8 @@ struct BoundPools {
     long long *best_L;           // [n_topics] smallest dual value so far (fixed point, kDualScale)
     int32_t *info;               // [n_topics][4] = {iterations so far, flags of the last launch, -, -}
     int32_t iters;               // iterations this launch
-    int32_t maxB;                // LDS carve size
+    int32_t maxB, maxP;          // LDS carve sizes
+    int32_t cur_in_lds;          // 1 = the current assignment (8 B per partition) is staged in LDS too
 };
 
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a);
@@ -97,7 +98,7 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
                    const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream);
 
 // K-bound: Lagrangian dual bound, one workgroup (`waves` wavefronts) per listed topic
-size_t bound_lds_bytes(int maxB);
+size_t bound_lds_bytes(int maxB, int maxP, bool cur_in_lds);
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream);
 
 // canonical tie-break on the device (kao_canonicalize): one wavefront, assignment words in global memory

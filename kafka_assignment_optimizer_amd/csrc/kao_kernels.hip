@@ -917,6 +917,19 @@ __device__ __forceinline__ int pick4(int x0, int x1, int x2, int x3, int k) {
     return (k & 1) ? hi : lo;
 }
 
+template <int NCH, typename Fn>
+__device__ __forceinline__ void for_chunks(int nch, Fn &&fn) {
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) fn(c);
+    } else {
+        for (int c = 0; c < nch; ++c) fn(c);
+    }
+}
+
+// NCH > 0: the topic's brokers fit NCH x 64 lanes and every lane keeps its brokers' priced values in registers for the
+// whole iteration; NCH == 0: any broker count, values recomputed from LDS per round.
+template <int NCH>
 __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
@@ -938,44 +951,88 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     int *NL = NR + pl.maxB;                                             // leaders per broker
     const uint8_t *rk_g = pl.rackof_pool + T.rackof_off;
     uint8_t *RK = reinterpret_cast<uint8_t *>(NL + pl.maxB);            // rack of broker
+    // current assignment, 4 x u16 per partition (0xFFFF = none), when it fits next to the broker tables
+    uint2 *CURP = reinterpret_cast<uint2 *>(smem_b + 80 + 3 * kRackTab * 4 + 16 * (size_t)pl.maxB + (((size_t)pl.maxB + 15) & ~(size_t)15));
     int *gp = pl.dual_pool + T.dual_off;                                // a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
     int *g_a = gp, *g_l = gp + B, *g_da = gp + 2 * B, *g_dl = gp + 3 * B, *g_g = gp + 4 * B, *g_dg = gp + 4 * B + kRackTab;
     for (int b = tid; b < B; b += nt) { A[b] = g_a[b]; LM[b] = g_l[b]; NR[b] = 0; NL[b] = 0; RK[b] = rk_g[b]; }
     for (int r = tid; r < kRackTab; r += nt) { G[r] = r < R ? g_g[r] : 0; DG[r] = r < R ? g_dg[r] : 0; NK[r] = 0; }
     if (tid < 8) acc[tid] = 0;
     if (tid < 4) ctl[tid] = 0;
+    const uint16_t *curd = pl.curd_pool + T.curd_off;
+    auto load_cur = [&](int p) -> uint2 {  // 4 independent loads (index clamped to the last valid slot), then masked
+        const uint16_t *cur = curd + (size_t)p * rfc;
+        const uint32_t v0 = cur[0], v1 = cur[min(1, rfc - 1)], v2 = cur[min(2, rfc - 1)], v3 = cur[min(3, rfc - 1)];
+        return make_uint2(v0 | ((rfc > 1 ? v1 : 0xFFFFu) << 16), (rfc > 2 ? v2 : 0xFFFFu) | ((rfc > 3 ? v3 : 0xFFFFu) << 16));
+    };
+    if (pl.cur_in_lds)
+        for (int p = tid; p < P; p += nt) CURP[p] = load_cur(p);
     __syncthreads();
     long long best = pl.best_L[topic];
     const long long target = pl.target[topic];
-    const uint16_t *curd = pl.curd_pool + T.curd_off;
     int flags = 0, it = 0;
+    constexpr int NR_ = NCH > 0 ? NCH : 1;
+    int rkr[NR_], Fr[NR_], FLr[NR_];
+    if constexpr (NCH > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) rkr[c] = lane + 64 * c < B ? (int)RK[lane + 64 * c] : 0;
+    }
+    const int nch = NCH > 0 ? NCH : (B + 63) >> 6;
+    // priced follower / leader value of the generic (weight 0) broker in chunk c of this lane
+    auto elem = [&](int c, int &b, int &rk, int &F, int &FL) -> bool {
+        b = lane + 64 * c;
+        if constexpr (NCH > 0) { rk = rkr[c]; F = Fr[c]; FL = FLr[c]; return b < B; }
+        else {
+            if (b >= B) return false;
+            rk = RK[b]; F = -A[b] - G[rk]; FL = F - LM[b];
+            return true;
+        }
+    };
+    // lane of the wavefront maximum of `key`; ties -> the lowest broker index `bb`
+    auto arg_lane = [&](uint32_t key, uint32_t mx, uint32_t bb) -> int {
+        const unsigned long long ties = __ballot(key == mx);
+        if (NCH == 1 || __popcll(ties) == 1) return (int)__builtin_ctzll(ties);
+        const uint32_t sb = wave_umin(key == mx ? bb : 0xFFFFFFFFu);
+        return (int)__builtin_ctzll(__ballot(key == mx && bb == sb));
+    };
     for (; it < pl.iters; ++it) {
         const int par = it & 1;
         // ---- phase A: one wavefront per partition solves the priced subproblem ----
+        if constexpr (NCH > 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int b = lane + 64 * c;
+                Fr[c] = b < B ? -A[b] - G[rkr[c]] : 0;
+                FLr[c] = b < B ? Fr[c] - LM[b] : 0;
+            }
+        }
         long long wsum = 0;
         bool bad = false;
         for (int pp = wave; pp < P; pp += nw) {
             const int p = __builtin_amdgcn_readfirstlane(pp);
-            const uint16_t *cur = curd + (size_t)p * rfc;
-            const int c0 = cur[0], c1 = rfc > 1 ? (int)cur[1] : -1, c2 = rfc > 2 ? (int)cur[2] : -1, c3 = rfc > 3 ? (int)cur[3] : -1;
+            const uint2 cw = pl.cur_in_lds ? CURP[p] : load_cur(p);   // 0xFFFF (none) never equals a broker index
+            const int c0 = (int)(cw.x & 0xFFFFu), c1 = (int)(cw.x >> 16), c2 = (int)(cw.y & 0xFFFFu), c3 = (int)(cw.y >> 16);
             int Gb0 = -1, Gb1 = -1, Gb2 = -1, Gb3 = -1, Gf0 = 0, Gf1 = 0, Gf2 = 0, Gf3 = 0, Gr0 = -1, Gr1 = -1, Gr2 = -1, Gr3 = -1;
             // greedy follower set: prack_lo best of every rack first, then the best remaining under the cap; ties -> lowest b
             for (int j = 0; j < RF; ++j) {
                 const int forced = j < R * plo ? j / plo : -1;
                 uint32_t bkey = 0, bb = 0xFFFFFFFFu;
-                for (int b = lane; b < B; b += 64) {
-                    const int rb = RK[b];
+                int brk = 0;
+                for_chunks<NCH>(nch, [&](int c) {
+                    int b, rb, F, FL;
+                    if (!elem(c, b, rb, F, FL)) return;
                     const int cnt = (int)(Gr0 == rb) + (int)(Gr1 == rb) + (int)(Gr2 == rb);
                     const bool in = (Gb0 == b) | (Gb1 == b) | (Gb2 == b);
                     const bool ok = (forced >= 0 ? rb == forced : cnt < phi) & !in;
                     const int wf = (b == c0) ? w01 : (((b == c1) | (b == c2) | (b == c3)) ? w11 : 0);
-                    const uint32_t key = (uint32_t)(wf - A[b] - G[rb]) + 0x80000000u;
-                    if (ok && key > bkey) { bkey = key; bb = (uint32_t)b; }
-                }
+                    const uint32_t key = (uint32_t)(wf + F) + 0x80000000u;
+                    if (ok && key > bkey) { bkey = key; bb = (uint32_t)b; brk = rb; }
+                });
                 const uint32_t mx = wave_umax(bkey);
                 if (mx == 0) { bad = true; break; }
-                const int sel = (int)wave_umin(bkey == mx ? bb : 0xFFFFFFFFu);
-                const int fv = (int)(mx - 0x80000000u), rs = RK[sel];
+                const int wl_ = arg_lane(bkey, mx, bb);
+                const int sel = __builtin_amdgcn_readlane((int)bb, wl_), rs = __builtin_amdgcn_readlane(brk, wl_);
+                const int fv = (int)(mx - 0x80000000u);
                 if (j == 0) { Gb0 = sel; Gf0 = fv; Gr0 = rs; }
                 else if (j == 1) { Gb1 = sel; Gf1 = fv; Gr1 = rs; }
                 else if (j == 2) { Gb2 = sel; Gf2 = fv; Gr2 = rs; }
@@ -989,11 +1046,12 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
             const int cg2 = (int)(Gr0 == Gr2) + (int)(Gr1 == Gr2) + 1 + (int)(Gr3 == Gr2);
             const int cg3 = (int)(Gr0 == Gr3) + (int)(Gr1 == Gr3) + (int)(Gr2 == Gr3) + 1;
             uint32_t bkey = 0, bb = 0xFFFFFFFFu;
-            int be = 0;
-            for (int b0 = lane; b0 < B; b0 += 64) {
-                const int r0 = RK[b0];
+            int be = 0, brk = 0;
+            for_chunks<NCH>(nch, [&](int c) {
+                int b0, r0, F, FL;
+                if (!elem(c, b0, r0, F, FL)) return;
                 const int wl = (b0 == c0) ? w00 : (((b0 == c1) | (b0 == c2) | (b0 == c3)) ? w10 : 0);
-                const int lv = wl - A[b0] - G[r0] - LM[b0];
+                const int lv = wl + FL;
                 const int c0cnt = (int)(Gr0 == r0) + (int)(Gr1 == r0) + (int)(Gr2 == r0) + (int)(Gr3 == r0);
                 int e = -1, fe = 0;
                 if (Gb0 == b0) { e = 0; fe = Gf0; }
@@ -1012,13 +1070,13 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
                     if (ok3 && (e < 0 || Gf3 <= fe)) { e = 3; fe = Gf3; }
                 }
                 const uint32_t key = (uint32_t)(fG - fe + lv) + 0x80000000u;
-                if (e >= 0 && key > bkey) { bkey = key; bb = (uint32_t)b0; be = e; }
-            }
+                if (e >= 0 && key > bkey) { bkey = key; bb = (uint32_t)b0; be = e; brk = r0; }
+            });
             const uint32_t mx = wave_umax(bkey);
             if (mx == 0) { bad = true; break; }
-            const int sel = (int)wave_umin(bkey == mx ? bb : 0xFFFFFFFFu);
-            const unsigned long long own = __ballot(bkey == mx && bb == (uint32_t)sel);
-            const int esel = __builtin_amdgcn_readlane(be, (int)__builtin_ctzll(own));
+            const int wl_ = arg_lane(bkey, mx, bb);
+            const int sel = __builtin_amdgcn_readlane((int)bb, wl_), esel = __builtin_amdgcn_readlane(be, wl_);
+            const int rsel = __builtin_amdgcn_readlane(brk, wl_);
             wsum += (int)(mx - 0x80000000u);
             // counts of the chosen set: lanes 0..RF-1 the kept followers, lane 4 the leader
             if (lane < RF && lane != esel) {
@@ -1027,7 +1085,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
             } else if (lane == 4) {
                 atomicAdd(&NR[sel], 1);
                 atomicAdd(&NL[sel], 1);
-                atomicAdd(&NK[RK[sel]], 1);
+                atomicAdd(&NK[rsel], 1);
             }
         }
         if (lane == 0) {
@@ -1055,8 +1113,9 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
             DG[tid] = dg;
             cD += (long long)dg * dg;
         }
-        cL = wave_sum64(cL); cN = wave_sum64(cN); cD = wave_sum64(cD);
-        if (lane == 0) {
+        const bool owns = wave * 64 < max(B, R);  // wavefronts without a broker or rack skip the 64-bit reductions
+        if (owns) { cL = wave_sum64(cL); cN = wave_sum64(cN); cD = wave_sum64(cD); }
+        if (lane == 0 && owns) {
             if (cL) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 0]), (unsigned long long)cL);
             if (cN) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 1]), (unsigned long long)cN);
             if (cD) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 2]), (unsigned long long)cD);
@@ -1143,19 +1202,30 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
                        win_assign, win_viol);
 }
 
-size_t bound_lds_bytes(int maxB) {
-    return 80 + 3 * (size_t)kRackTab * 4 + 16 * (size_t)maxB + (((size_t)maxB + 15) & ~(size_t)15);
+size_t bound_lds_bytes(int maxB, int maxP, bool cur_in_lds) {
+    return 80 + 3 * (size_t)kRackTab * 4 + 16 * (size_t)maxB + (((size_t)maxB + 15) & ~(size_t)15) + (cur_in_lds ? 8 * (size_t)maxP : 0);
 }
 
 static int g_attr_bound = 0;
 
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream) {
-    const size_t lds = bound_lds_bytes(pools.maxB);
+    const size_t lds = bound_lds_bytes(pools.maxB, pools.maxP, pools.cur_in_lds != 0);
     if ((int)lds > g_attr_bound) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bound), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const void *fns[5] = {reinterpret_cast<const void *>(k_bound<0>), reinterpret_cast<const void *>(k_bound<1>),
+                              reinterpret_cast<const void *>(k_bound<2>), reinterpret_cast<const void *>(k_bound<3>),
+                              reinterpret_cast<const void *>(k_bound<4>)};
+        for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_bound = (int)lds;
     }
-    hipLaunchKernelGGL(k_bound, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools);
+    const dim3 grid(n_blocks), block(64 * waves);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (pools.maxB <= 256 ? (pools.maxB + 63) / 64 : 0) {  // brokers per lane kept in registers, or the LDS path
+        case 1: hipLaunchKernelGGL(k_bound<1>, grid, block, lds, st, pools); break;
+        case 2: hipLaunchKernelGGL(k_bound<2>, grid, block, lds, st, pools); break;
+        case 3: hipLaunchKernelGGL(k_bound<3>, grid, block, lds, st, pools); break;
+        case 4: hipLaunchKernelGGL(k_bound<4>, grid, block, lds, st, pools); break;
+        default: hipLaunchKernelGGL(k_bound<0>, grid, block, lds, st, pools); break;
+    }
 }
 
 size_t canon_lds_bytes(int maxBx) {

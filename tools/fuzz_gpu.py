@@ -79,10 +79,26 @@ for lo in range(0, len(topics), 50):
             if (obj, int(viol[0])) != (dev["obj"], dev["V"]):
                 bad += 1; print("VERIFIER MISMATCH", lo + ti, (obj, int(viol[0])), (dev["obj"], dev["V"]))
         for ot, r in zip(batch, s.best()):
-            if r.status != "NO_FEASIBLE":
+            if r.status not in ("NO_FEASIBLE", "INFEASIBLE_PROVEN"):
                 obj, viol = ko.verify(ot, r.assignment)
                 if viol[0] != 0 or obj != r.objective or r.objective > r.upper_bound:
                     bad += 1; print("BEST MISMATCH", ot.name, obj, viol.tolist(), r.objective, r.upper_bound)
+    for ti, (ot, pt) in enumerate(zip(batch, pts)):  # K-bound vs its replay: multipliers and dual value, two launches
+        if ti % 3 or ko.provably_infeasible(ot) or ot.n_brokers > 8192 or max(max(w) for w in ot.weights) > 255:
+            continue
+        target = max(0, ko.upper_bound_simple(ot) - 3 - (ti % 5))
+        try:
+            dv = kao.dual_bound(pt, target, iters=25, launches=2)
+        except kao.KaoError as e:
+            bad += 1; print("DUAL ERROR", ot.name, e); continue
+        st = kp.DualState(ot)
+        for _ in range(2):
+            st = kp.port_dual_bound(ot, target, 25, st)
+            if st.flags & 7:
+                break
+        if (dv["iters"], dv["flags"], dv["best_dual"] if dv["iters"] else 0) != (st.iters, st.flags, st.best_L if st.iters else 0) or \
+                dv["a"].tolist() != st.a.tolist() or dv["l"].tolist() != st.l.tolist() or dv["g"].tolist() != st.g[:ot.n_racks].tolist():
+            bad += 1; print("DUAL MISMATCH", lo + ti, ot.n_brokers, ot.n_racks, ot.n_partitions, ot.rf_cur, ot.rf, dv["iters"], st.iters, dv["flags"], st.flags)
     for ot, pt in list(zip(batch, pts))[:10]:  # K-eval on mutated candidates
         cands = random_candidates(ot, 5, seed=lo, p_mut=0.3, p_none=0.05)
         o, v = kao.evaluate_batch(pt, cands)
