@@ -75,12 +75,14 @@ typedef struct kao_topic {
 typedef struct kao_opts {
     uint64_t seed;            /* search is deterministic in (seed, restarts, iters_per_launch) */
     double time_limit_s;      /* kao_solve: wall-clock limit; <= 0 = default 10 s */
-    int32_t restarts;         /* parallel restarts (wavefronts) per topic; <= 0 = auto */
+    int32_t restarts;         /* parallel restarts (wavefronts) per topic; <= 0 = auto: one round of resident wavefronts
+                                 over all topics, fewer for very large topics (depth over breadth) */
     int32_t iters_per_launch; /* local-search iterations per K-search launch; <= 0 = 512 (sessions) / 128 (kao_solve) */
     int32_t max_launches;     /* kao_solve: stop after this many launches; <= 0 = unlimited */
     int32_t obj_scale;        /* S in cost = lam*violation - S*objective; <= 0 = 4 */
     int32_t lam_min, lam_max; /* penalty sawtooth bounds; <= 0 = 1 / 40 */
-    int32_t period_log2;      /* sawtooth period = 2^(period_log2 + (restart & 3)); <= 0 = 8 */
+    int32_t period_log2;      /* sawtooth period = 2^(period_log2 + (restart & 3)); <= 0 = per topic by size:
+                                 floor(log2(2 * n_partitions * rf)) clamped to 8..16 */
     int32_t stop_at_bound;    /* kao_solve: 1 = stop as soon as every topic is OPTIMAL_PROVEN */
     int32_t profile;          /* 1 = bracket every kernel with HIP events (kao_session_stats) */
     int32_t dual_iters;       /* kao_solve: K-bound (Lagrangian dual bound) iterations per launch for topics whose

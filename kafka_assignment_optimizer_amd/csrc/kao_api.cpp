@@ -390,6 +390,16 @@ uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers
     return n;
 }
 
+// Sawtooth period by topic size: one ramp should span about 2 * P * RF iterations (every slot gets a chance to move
+// while the penalty is low).  Measured on a drifted 2000-partition topic (optimum 14812): 2^8 -> 14777, 2^11 -> 14794,
+// 2^14 -> 14801..14806; small topics keep the 2^8 they were tuned with.
+int auto_period_log2(int P, int RF) {
+    int64_t n = 2 * (int64_t)P * RF;
+    int lg = 0;
+    while (n > 1) { n >>= 1; ++lg; }
+    return std::min(16, std::max(8, lg));
+}
+
 // K-bound limits: 17 B of LDS per broker; 32-bit headroom of the priced values (weights x 4096, P*RF subgradients)
 bool dual_supported(const kao_topic *t) {
     if (t->n_brokers > kDualMaxB) return false;
@@ -506,6 +516,7 @@ struct kao_session {
     unsigned char *d_dual_rb = nullptr;
     size_t dual_rb_bytes = 0;
     uint64_t bound_launches = 0;
+    size_t dual_bytes = 0;
     hipStream_t stream_bound = nullptr;   // K-bound runs beside K-search on its own stream (it occupies one CU per topic)
     hipEvent_t ev_bound0 = nullptr, ev_bound1 = nullptr;
     bool bound_inflight = false;
@@ -912,7 +923,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     if (o.lam_min <= 0) o.lam_min = 1;
     if (o.lam_max <= 0) o.lam_max = 40;
     if (o.lam_max < o.lam_min) o.lam_max = o.lam_min;
-    if (o.period_log2 <= 0) o.period_log2 = 8;
+    if (o.period_log2 < 0) o.period_log2 = 0;    // 0 = per topic, by size (auto_period_log2)
     if (o.period_log2 > 20) o.period_log2 = 20;
     if (o.time_limit_s <= 0) o.time_limit_s = 10.0;
     const bool auto_restarts = o.restarts <= 0;
@@ -921,6 +932,12 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         int r = want / n_topics;
         r = (r / kWaves) * kWaves;
         o.restarts = std::min(std::max(r, 8), 8192);
+        // large topics need depth (iterations per second) more than breadth: at most 2^22 replica slots over all the
+        // restarts of the largest topic, but never fewer than one restart per compute unit
+        int64_t slots = 1;
+        for (int t = 0; t < n_topics; ++t) slots = std::max<int64_t>(slots, (int64_t)topics[t].n_partitions * std::max(topics[t].rf, 1));
+        const int cap = (int)std::max<int64_t>(g_num_cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves);
+        o.restarts = std::min(o.restarts, cap);
     }
     if (o.restarts > (1 << 20)) o.restarts = 1 << 20;
     {   // huge topics: bound the per-restart state in HBM (16 B of working words + the snapshot per partition):
@@ -949,6 +966,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         s->topic_infeasible.push_back(infeasible_reason(&topics[t]).empty() ? 0 : 1);
         TopicDev &d = pt.d;
         d.n_restarts = o.restarts;
+        d.period_log2 = o.period_log2 > 0 ? o.period_log2 : auto_period_log2(d.P, d.RF);
         d.restart_base = restart_base;
         restart_base += o.restarts;
         d.cur_off = (uint32_t)cur_pool.size();
@@ -1084,6 +1102,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         s->d_dual_target = reinterpret_cast<long long *>(q); q += dtarget_b;
         s->d_dual_ids = reinterpret_cast<int32_t *>(q); q += dids_b;
         s->d_dual_rb = q;
+        s->dual_bytes = dual_b;
         s->dual_flags.assign((size_t)n_topics, 0);
         s->dual_iters.assign((size_t)n_topics, 0);
         for (int t = 0; t < n_topics; ++t) if (!s->dual_ok[(size_t)t]) s->dual_flags[(size_t)t] = 8;
@@ -1096,10 +1115,6 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     hipError_t e2 = hipMemsetAsync(s->d_best, 0xFF, best_u16 * 2 ? best_u16 * 2 : 2, s->stream);
     hipError_t e3 = hipMemsetAsync(s->d_readback, 0xFF, (size_t)n_topics * 8, s->stream);
     hipError_t e4 = hipMemsetAsync(s->d_drift, 0, 16, s->stream);
-    // K-bound state: multipliers and directions 0, best dual value "infinite" (0x7F7F...), info 0
-    if (e4 == hipSuccess) e4 = hipMemsetAsync(s->d_dual, 0, dual_b, s->stream);
-    if (e4 == hipSuccess) e4 = hipMemsetAsync(s->d_dual_rb, 0x7F, (size_t)n_topics * 8, s->stream);
-    if (e4 == hipSuccess) e4 = hipMemsetAsync(s->d_dual_rb + (size_t)n_topics * 8, 0, (size_t)n_topics * 16, s->stream);
     hipError_t e5 = hipStreamSynchronize(s->stream);  // `stage` is pageable host memory and goes out of scope
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
         kao_session_destroy(s);
@@ -1125,7 +1140,7 @@ int kao_session_step(kao_session *s) {
     sp.topics = s->d_topics; sp.block_map = s->d_smap; sp.cur_pool = s->d_cur; sp.ext_pool = s->d_ext; sp.rsz_pool = s->d_rsz;
     sp.state_pool = s->d_state; sp.best_pool = s->d_best; sp.restart_info = s->d_info; sp.drift = s->d_drift;
     SearchParams prm{};
-    prm.obj_scale = s->opts.obj_scale; prm.lam_min = s->opts.lam_min; prm.lam_max = s->opts.lam_max; prm.period_log2 = s->opts.period_log2;
+    prm.obj_scale = s->opts.obj_scale; prm.lam_min = s->opts.lam_min; prm.lam_max = s->opts.lam_max;
     prm.launch = s->launch; prm.iters = (uint32_t)s->opts.iters_per_launch; prm.init = s->launch == 0 ? 1 : 0;
     EvalPools ep{};
     ep.topics = s->d_topics; ep.rackof_pool = s->d_rackof; ep.curd_pool = s->d_curd;
@@ -1245,6 +1260,13 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     // one K-bound launch in flight at a time (it continues from the state the previous one left in HBM); the session
     // upload was synchronised at creation, K-search and K-bound share read-only tables only
     HIP_TRY(hipStreamSynchronize(s->stream_bound));
+    if (s->bound_launches == 0) {
+        // K-bound state is initialised by the first launch only (most sessions never need K-bound): multipliers and
+        // directions 0, best dual value "infinite" (0x7F7F...), info 0
+        HIP_TRY(hipMemsetAsync(s->d_dual, 0, s->dual_bytes, s->stream_bound));
+        HIP_TRY(hipMemsetAsync(s->d_dual_rb, 0x7F, (size_t)s->n_topics * 8, s->stream_bound));
+        HIP_TRY(hipMemsetAsync(s->d_dual_rb + (size_t)s->n_topics * 8, 0, (size_t)s->n_topics * 16, s->stream_bound));
+    }
     // pageable staging: hipMemcpyAsync returns once the host buffers have been consumed
     HIP_TRY(hipMemcpyAsync(s->d_dual_target, s->h_dual_target.data(), (size_t)s->n_topics * 8, hipMemcpyHostToDevice, s->stream_bound));
     HIP_TRY(hipMemcpyAsync(s->d_dual_ids, s->h_dual_ids.data(), s->h_dual_ids.size() * 4, hipMemcpyHostToDevice, s->stream_bound));
@@ -1311,6 +1333,13 @@ int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->stream_bound) HIP_TRY(hipStreamSynchronize(s->stream_bound));
     const int32_t *base = s->d_dual + d.dual_off;
+    if (s->bound_launches == 0) {  // no K-bound launch yet: the initial state
+        if (a) std::memset(a, 0, (size_t)d.B * 4);
+        if (l) std::memset(l, 0, (size_t)d.B * 4);
+        if (g) std::memset(g, 0, (size_t)d.R * 4);
+        if (best_dual) *best_dual = (int64_t)0x7F7F7F7F7F7F7F7Fll;
+        return KAO_OK;
+    }
     if (a) HIP_TRY(hipMemcpy(a, base, (size_t)d.B * 4, hipMemcpyDeviceToHost));
     if (l) HIP_TRY(hipMemcpy(l, base + d.B, (size_t)d.B * 4, hipMemcpyDeviceToHost));
     if (g) HIP_TRY(hipMemcpy(g, base + 4 * (size_t)d.B, (size_t)d.R * 4, hipMemcpyDeviceToHost));

@@ -39,10 +39,12 @@ struct TopicDev {
     uint32_t curd_off;           // curd_pool  : u16[P*rf_cur] dense current assignment
     uint32_t win_off;            // winners    : first u16 of this topic's winning assignment ([P*RF])
     uint32_t dual_off;           // dual_pool  : first int32 of a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
+    int32_t period_log2;         // penalty sawtooth: restart rho has period 2^(period_log2 + (rho & 3)) iterations
+    int32_t pad_;
 };
 
 struct SearchParams {
-    int32_t obj_scale, lam_min, lam_max, period_log2;
+    int32_t obj_scale, lam_min, lam_max, pad_;   // (the sawtooth period is per topic: TopicDev::period_log2)
     uint32_t launch;             // launch number (global iteration = launch*iters + i)
     uint32_t iters;
     int32_t init;                // 1 = build the initial state of every restart first

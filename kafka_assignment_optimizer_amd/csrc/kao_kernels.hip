@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     // ---- per-lane RNG stream of this launch (LCG mod 2^24, re-keyed every launch) ----
     uint32_t rng = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + prm.launch * 0x85EBCA77u + (uint32_t)lane * 0xC2B2AE3Du));
 
-    const int plog = prm.period_log2 + (rho & 3);
+    const int plog = TD->period_log2 + (rho & 3);
     const uint32_t pmask = (1u << plog) - 1u;
     const uint32_t lrange = (uint32_t)(prm.lam_max - prm.lam_min + 1);
     const uint32_t RF8 = (uint32_t)T.RF << 8, R8 = (uint32_t)T.R << 8, m8 = (uint32_t)T.m << 8;  // all < 65536

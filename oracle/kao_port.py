@@ -85,7 +85,12 @@ def port_eval(topic, assign) -> Tuple[int, np.ndarray]:
     return int(obj.value), np.array(list(viol), dtype=np.int64)
 
 
-DEFAULT_PARAMS = dict(obj_scale=4, lam_min=1, lam_max=40, period_log2=8)
+DEFAULT_PARAMS = dict(obj_scale=4, lam_min=1, lam_max=40, period_log2=None)  # None = by topic size, see below
+
+
+def auto_period_log2(topic) -> int:
+    """Sawtooth period chosen by topic size: floor(log2(2 * P * RF)) clamped to 8..16."""
+    return min(16, max(8, (2 * topic.n_partitions * topic.rf).bit_length() - 1))
 
 
 def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params):
@@ -97,6 +102,8 @@ def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params)
     try:
         pr = dict(DEFAULT_PARAMS)
         pr.update(params)
+        if pr["period_log2"] is None:
+            pr["period_log2"] = auto_period_log2(topic)
         pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
                         lam_max=pr["lam_max"], period_log2=pr["period_log2"])
         n = topic.n_partitions * topic.rf
