@@ -400,9 +400,10 @@ int auto_period_log2(int P, int RF) {
     return std::min(16, std::max(8, lg));
 }
 
-// K-bound limits: 17 B of LDS per broker; 32-bit headroom of the priced values (weights x 4096, P*RF subgradients)
+// K-bound limits: 19 B of LDS per broker + 72 B per rack; 32-bit headroom of the priced values (weights x 4096,
+// P*RF subgradients)
 bool dual_supported(const kao_topic *t) {
-    if (t->n_brokers > kDualMaxB) return false;
+    if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false) > 160 * 1024) return false;
     const int64_t n = (int64_t)t->n_partitions * t->rf;
     if (n > 131072) return false;
     for (int i = 0; i < 2; ++i)
@@ -991,8 +992,9 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         rackof_pool.insert(rackof_pool.end(), pt.rack_of.begin(), pt.rack_of.end());
         d.curd_off = (uint32_t)curd_pool.size();
         curd_pool.insert(curd_pool.end(), pt.cur_dense.begin(), pt.cur_dense.end());
+        dual_i32 = (dual_i32 + 1) & ~(uint64_t)1;  // the level-control words are 64-bit
         d.dual_off = (uint32_t)dual_i32;
-        dual_i32 += 4 * (uint64_t)d.B + 2 * kRackTab;
+        dual_i32 += 4 * (uint64_t)d.B + 2 * kRackTab + 8;
         s->dual_ok.push_back(dual_supported(&topics[t]) ? 1 : 0);
         // algorithmic bytes: full evaluation = 2*RF*P + 2*rf_cur*P + B per candidate
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
@@ -1241,7 +1243,7 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     HIP_TRY(hipSetDevice(g_device));
     s->h_dual_ids.clear();
     s->h_dual_target.assign((size_t)s->n_topics, -1);
-    int maxB = 0, maxP = 0;
+    int maxB = 0, maxP = 0, maxR = 0;
     for (int t = 0; t < s->n_topics; ++t) {
         if (target[t] < 0 || !s->dual_ok[(size_t)t] || s->topic_infeasible[(size_t)t]) continue;
         if (target[t] > (int64_t)1 << 40) return fail(KAO_ERR_INVALID, "target out of range");
@@ -1249,6 +1251,7 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
         s->h_dual_target[(size_t)t] = target[t];
         maxB = std::max(maxB, s->pts[(size_t)t].d.B);
         maxP = std::max(maxP, s->pts[(size_t)t].d.P);
+        maxR = std::max(maxR, s->pts[(size_t)t].d.R);
     }
     if (s->h_dual_ids.empty()) return KAO_OK;
     if (!s->stream_bound) {
@@ -1275,9 +1278,11 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     bp.dual_pool = s->d_dual; bp.target = s->d_dual_target;
     bp.best_L = reinterpret_cast<long long *>(s->d_dual_rb);
     bp.info = reinterpret_cast<int32_t *>(s->d_dual_rb + (size_t)s->n_topics * 8);
-    bp.iters = iters; bp.maxB = maxB; bp.maxP = maxP;
-    bp.cur_in_lds = bound_lds_bytes(maxB, maxP, true) <= 160 * 1024 ? 1 : 0;
-    const int waves = std::min(16, std::max(1, maxP));  // one wavefront per partition, at most 16 per workgroup
+    bp.ext_pool = s->d_ext; bp.rsz_pool = s->d_rsz;
+    bp.iters = iters; bp.maxB = maxB; bp.maxP = maxP; bp.maxR = maxR;
+    bp.cur_in_lds = bound_lds_bytes(maxB, maxP, maxR, true) <= 160 * 1024 ? 1 : 0;
+    // lanes own partitions, wavefronts own racks when the pools are rebuilt: enough wavefronts for either, at most 16
+    const int waves = std::min(16, std::max({1, (maxP + 63) / 64, std::min(maxR, 8)}));
     HIP_TRY(hipEventRecord(s->ev_bound0, s->stream_bound));
     launch_bound(bp, (int)s->h_dual_ids.size(), waves, s->stream_bound);
     HIP_TRY(hipGetLastError());

@@ -13,8 +13,8 @@ constexpr uint32_t kNoneW = 0xFFFFFFFFu;  // empty slot in the LDS word layout (
 constexpr uint32_t kKeyNull = 0xFFFFFFFFu;
 constexpr int kDBias = 32768;
 constexpr int kDualScale = 4096;          // fixed point of the dual multipliers (K-bound)
+constexpr int kDualStage = 100;           // level control: iterations per stage (K-bound)
 constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
-constexpr int kDualMaxB = 8192;           // K-bound keeps 17 B per broker in LDS
 constexpr uint32_t kObjCap = 0xFFFFFFu;   // packed best key: viol(20) << 44 | (kObjCap - obj) << 20 | restart(20)
 
 // Device-side descriptor of one topic.  Read once per workgroup (wave-uniform -> SGPRs).
@@ -38,7 +38,7 @@ struct TopicDev {
     uint32_t rackof_off;         // rackof_pool: u8[B]
     uint32_t curd_off;           // curd_pool  : u16[P*rf_cur] dense current assignment
     uint32_t win_off;            // winners    : first u16 of this topic's winning assignment ([P*RF])
-    uint32_t dual_off;           // dual_pool  : first int32 of a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
+    uint32_t dual_off;           // dual_pool  : first int32 of a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab] lv[8]
     int32_t period_log2;         // penalty sawtooth: restart rho has period 2^(period_log2 + (rho & 3)) iterations
     int32_t pad_;
 };
@@ -81,12 +81,14 @@ struct BoundPools {
     const int32_t *ids;          // per workgroup: topic
     const uint8_t *rackof_pool;
     const uint16_t *curd_pool;
+    const uint16_t *ext_pool;    // rack-major internal index -> dense broker (members of every rack)
+    const int32_t *rsz_pool;     // rack sizes
     int32_t *dual_pool;          // multipliers and previous directions, see TopicDev::dual_off
     const long long *target;     // [n_topics] incumbent objective the Polyak step aims at
     long long *best_L;           // [n_topics] smallest dual value so far (fixed point, kDualScale)
     int32_t *info;               // [n_topics][4] = {iterations so far, flags of the last launch, -, -}
     int32_t iters;               // iterations this launch
-    int32_t maxB, maxP;          // LDS carve sizes
+    int32_t maxB, maxP, maxR;    // LDS carve sizes
     int32_t cur_in_lds;          // 1 = the current assignment (8 B per partition) is staged in LDS too
 };
 
@@ -100,7 +102,7 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
                    const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream);
 
 // K-bound: Lagrangian dual bound, one workgroup (`waves` wavefronts) per listed topic
-size_t bound_lds_bytes(int maxB, int maxP, bool cur_in_lds);
+size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds);
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream);
 
 // canonical tie-break on the device (kao_canonicalize): one wavefront, assignment words in global memory

@@ -917,19 +917,29 @@ __device__ __forceinline__ int pick4(int x0, int x1, int x2, int x3, int k) {
     return (k & 1) ? hi : lo;
 }
 
-template <int NCH, typename Fn>
-__device__ __forceinline__ void for_chunks(int nch, Fn &&fn) {
-    if constexpr (NCH > 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) fn(c);
-    } else {
-        for (int c = 0; c < nch; ++c) fn(c);
-    }
+// Wavefront arg-max of (value, lowest id): lanes hold their best (key = biased value, 0 = none; id).  Returns the lane
+// that owns the winner.  `mx` receives the maximum key (0 = no lane had a candidate).
+__device__ __forceinline__ int wave_argmax(uint32_t key, uint32_t id, uint32_t &mx) {
+    mx = wave_umax(key);
+    const unsigned long long ties = __ballot(key == mx);
+    if (__popcll(ties) == 1) return (int)__builtin_ctzll(ties);
+    const uint32_t sid = wave_umin(key == mx ? id : 0xFFFFFFFFu);
+    return (int)__builtin_ctzll(__ballot(key == mx && id == sid));
 }
 
-// NCH > 0: the topic's brokers fit NCH x 64 lanes and every lane keeps its brokers' priced values in registers for the
-// whole iteration; NCH == 0: any broker count, values recomputed from LDS per round.
-template <int NCH>
+constexpr int kTF = 4;   // follower candidates kept per rack (RF needed)
+constexpr int kTL = 5;   // leader candidates kept per rack (RF + 1 needed)
+
+// Phase A works on candidate pools instead of all brokers.  With values "priced weight + bonus for the partition's own
+// current brokers (bonus >= 0)" and the rule "largest value, ties -> lowest broker index", the greedy pick of a round
+// is always (i) one of the partition's current brokers, or (ii) one of the RF best brokers (by generic value F, then
+// index) of one of the RF best racks (racks ranked by their best broker): fewer than RF picks exist before any round,
+// so a better-or-equal unpicked broker of the same rack, or the best broker of a still empty better rack, would win
+// otherwise.  Likewise the leader is a set member, a current broker, one of the RF+1 best brokers (by generic leader
+// value FL) of a rack that holds a set member, or the best broker of one of the RF+1 best racks by FL (at least one
+// of them holds no set member, and brokers of member-free racks all displace the same element).  The pools are rebuilt
+// once per iteration by the workgroup; a LANE then solves a partition over <= 20 + 33 candidates, independent of B,
+// with results identical to the brute-force scan of the scalar replay (oracle/kao_port.c).
 __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
@@ -939,26 +949,41 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     const int rep_lo = T.rep_lo, rep_hi = T.rep_hi, lead_lo = T.lead_lo, lead_hi = T.lead_hi;
     const int rack_lo = T.rack_lo, rack_hi = T.rack_hi, plo = T.prack_lo, phi = T.prack_hi;
     const int w00 = T.w00 * kDualScale, w01 = T.w01 * kDualScale, w10 = T.w10 * kDualScale, w11 = T.w11 * kDualScale;
-    // ---- LDS carve ----
+    // ---- LDS carve (bound_lds_bytes) ----
     long long *acc = reinterpret_cast<long long *>(smem_b);             // [2][4] : L, |s|^2, |d|^2, -
     int *ctl = reinterpret_cast<int *>(smem_b + 64);                    // [4]
     int *G = reinterpret_cast<int *>(smem_b + 80);                      // g[kRackTab]
     int *DG = G + kRackTab;                                             // dg[kRackTab]
     int *NK = DG + kRackTab;                                            // replicas per rack in the subproblem solutions
-    int *A = NK + kRackTab;                                             // a[maxB]
+    int *RO = NK + kRackTab;                                            // first member of rack r in XB ([kRackTab + 2])
+    int *PFb = RO + kRackTab + 2;                                       // follower pool: broker, rack, generic value [16] each
+    int *PFr = PFb + 16, *PFv = PFr + 16;
+    int *PLb = PFv + 16;                                                // best leader of the RF+1 best racks [8] each
+    int *PLr = PLb + 8, *PLv = PLr + 8;
+    int *TFb = PLv + 8;                                                 // per rack: kTF best followers (broker, value)
+    int *TFv = TFb + pl.maxR * kTF;
+    int *TLb = TFv + pl.maxR * kTF;                                     // per rack: kTL best leaders
+    int *TLv = TLb + pl.maxR * kTL;
+    int *A = TLv + pl.maxR * kTL;                                       // a[maxB]
     int *LM = A + pl.maxB;                                              // l[maxB]
     int *NR = LM + pl.maxB;                                             // replicas per broker
     int *NL = NR + pl.maxB;                                             // leaders per broker
-    const uint8_t *rk_g = pl.rackof_pool + T.rackof_off;
-    uint8_t *RK = reinterpret_cast<uint8_t *>(NL + pl.maxB);            // rack of broker
+    uint16_t *XB = reinterpret_cast<uint16_t *>(NL + pl.maxB);          // brokers grouped by rack (ascending inside a rack)
+    uint8_t *RK = reinterpret_cast<uint8_t *>(XB + ((pl.maxB + 7) & ~7)); // rack of broker
     // current assignment, 4 x u16 per partition (0xFFFF = none), when it fits next to the broker tables
-    uint2 *CURP = reinterpret_cast<uint2 *>(smem_b + 80 + 3 * kRackTab * 4 + 16 * (size_t)pl.maxB + (((size_t)pl.maxB + 15) & ~(size_t)15));
+    uint2 *CURP = reinterpret_cast<uint2 *>(RK + ((pl.maxB + 15) & ~15));
+    const uint8_t *rk_g = pl.rackof_pool + T.rackof_off;
     int *gp = pl.dual_pool + T.dual_off;                                // a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
     int *g_a = gp, *g_l = gp + B, *g_da = gp + 2 * B, *g_dl = gp + 3 * B, *g_g = gp + 4 * B, *g_dg = gp + 4 * B + kRackTab;
     for (int b = tid; b < B; b += nt) { A[b] = g_a[b]; LM[b] = g_l[b]; NR[b] = 0; NL[b] = 0; RK[b] = rk_g[b]; }
     for (int r = tid; r < kRackTab; r += nt) { G[r] = r < R ? g_g[r] : 0; DG[r] = r < R ? g_dg[r] : 0; NK[r] = 0; }
     if (tid < 8) acc[tid] = 0;
     if (tid < 4) ctl[tid] = 0;
+    if (tid == 0) {  // rack offsets (R <= 255)
+        int o = 0;
+        for (int r = 0; r < R; ++r) { RO[r] = o; o += pl.rsz_pool[T.rsz_off + r]; }
+        RO[R] = o;
+    }
     const uint16_t *curd = pl.curd_pool + T.curd_off;
     auto load_cur = [&](int p) -> uint2 {  // 4 independent loads (index clamped to the last valid slot), then masked
         const uint16_t *cur = curd + (size_t)p * rfc;
@@ -968,126 +993,185 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     if (pl.cur_in_lds)
         for (int p = tid; p < P; p += nt) CURP[p] = load_cur(p);
     __syncthreads();
+    {   // members of every rack, from the rack-major internal index (x = rack * m + j; dense order kept inside a rack)
+        const uint16_t *ext = pl.ext_pool + T.ext_off;
+        for (int x = tid; x < T.Bx; x += nt) {
+            const int r = x / T.m, jj = x - r * T.m;
+            if (jj < RO[r + 1] - RO[r]) XB[RO[r] + jj] = ext[x];
+        }
+    }
+    __syncthreads();
     long long best = pl.best_L[topic];
     const long long target = pl.target[topic];
+    // level control (every thread keeps the same copy): distance record -> level, record at stage start, iterations in stage
+    long long *g_lv = reinterpret_cast<long long *>(gp + 4 * B + 2 * kRackTab);
+    long long lv_delta = g_lv[0], lv_rec = g_lv[1];
+    int lv_since = (int)g_lv[2];
     int flags = 0, it = 0;
-    constexpr int NR_ = NCH > 0 ? NCH : 1;
-    int rkr[NR_], Fr[NR_], FLr[NR_];
-    if constexpr (NCH > 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) rkr[c] = lane + 64 * c < B ? (int)RK[lane + 64 * c] : 0;
-    }
-    const int nch = NCH > 0 ? NCH : (B + 63) >> 6;
-    // priced follower / leader value of the generic (weight 0) broker in chunk c of this lane
-    auto elem = [&](int c, int &b, int &rk, int &F, int &FL) -> bool {
-        b = lane + 64 * c;
-        if constexpr (NCH > 0) { rk = rkr[c]; F = Fr[c]; FL = FLr[c]; return b < B; }
-        else {
-            if (b >= B) return false;
-            rk = RK[b]; F = -A[b] - G[rk]; FL = F - LM[b];
-            return true;
-        }
-    };
-    // lane of the wavefront maximum of `key`; ties -> the lowest broker index `bb`
-    auto arg_lane = [&](uint32_t key, uint32_t mx, uint32_t bb) -> int {
-        const unsigned long long ties = __ballot(key == mx);
-        if (NCH == 1 || __popcll(ties) == 1) return (int)__builtin_ctzll(ties);
-        const uint32_t sb = wave_umin(key == mx ? bb : 0xFFFFFFFFu);
-        return (int)__builtin_ctzll(__ballot(key == mx && bb == sb));
-    };
     for (; it < pl.iters; ++it) {
         const int par = it & 1;
-        // ---- phase A: one wavefront per partition solves the priced subproblem ----
-        if constexpr (NCH > 0) {
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int b = lane + 64 * c;
-                Fr[c] = b < B ? -A[b] - G[rkr[c]] : 0;
-                FLr[c] = b < B ? Fr[c] - LM[b] : 0;
+        // ---- phase T: per rack, the kTF best followers and kTL best leaders by generic value (one wavefront per rack) ----
+        for (int rr = wave; rr < R; rr += nw) {
+            const int r = __builtin_amdgcn_readfirstlane(rr);
+            const int x0 = RO[r], n = RO[r + 1] - x0, gr = G[r];
+            for (int pass = 0; pass < 2; ++pass) {   // 0: followers (F), 1: leaders (FL = F - l)
+                const int want = pass == 0 ? RF : RF + 1, stride = pass == 0 ? kTF : kTL;
+                int *ob = pass == 0 ? TFb + r * kTF : TLb + r * kTL, *ov = pass == 0 ? TFv + r * kTF : TLv + r * kTL;
+                int s0 = -1, s1 = -1, s2 = -1, s3 = -1;
+                for (int k = 0; k < stride; ++k) {
+                    int selb = -1, selv = 0;
+                    if (k < want && k < n) {
+                        uint32_t bkey = 0, bb = 0xFFFFFFFFu;
+                        for (int jj = lane; jj < n; jj += 64) {
+                            const int b = XB[x0 + jj];
+                            const int v = -A[b] - gr - (pass ? LM[b] : 0);
+                            const uint32_t key = (uint32_t)v + 0x80000000u;
+                            const bool ok = (b != s0) & (b != s1) & (b != s2) & (b != s3);
+                            if (ok && key > bkey) { bkey = key; bb = (uint32_t)b; }
+                        }
+                        uint32_t mx;
+                        const int wl_ = wave_argmax(bkey, bb, mx);
+                        selb = __builtin_amdgcn_readlane((int)bb, wl_);
+                        selv = (int)(mx - 0x80000000u);
+                        if (k == 0) s0 = selb; else if (k == 1) s1 = selb; else if (k == 2) s2 = selb; else s3 = selb;
+                    }
+                    if (lane == 0) { ob[k] = selb; ov[k] = selv; }
+                }
             }
         }
+        __syncthreads();
+        // ---- phase R (wavefront 0): the RF best racks for followers -> pool PF, the RF+1 best racks for leaders -> PL ----
+        if (wave == 0) {
+            for (int pass = 0; pass < 2; ++pass) {
+                const int want = pass == 0 ? RF : RF + 1;
+                const int *tb = pass == 0 ? TFb : TLb, *tv = pass == 0 ? TFv : TLv;
+                const int stride = pass == 0 ? kTF : kTL;
+                int s0 = -1, s1 = -1, s2 = -1, s3 = -1, s4 = -1;
+                for (int k = 0; k < want; ++k) {
+                    uint32_t bkey = 0, bid = 0xFFFFFFFFu;
+                    int brk = -1;
+                    for (int r = lane; r < R; r += 64) {
+                        const int b = tb[r * stride];
+                        const bool ok = (b >= 0) & (r != s0) & (r != s1) & (r != s2) & (r != s3) & (r != s4);
+                        const uint32_t key = (uint32_t)tv[r * stride] + 0x80000000u;
+                        if (ok && (key > bkey || (key == bkey && (uint32_t)b < bid))) { bkey = key; bid = (uint32_t)b; brk = r; }
+                    }
+                    uint32_t mx;
+                    int selr = -1;
+                    if (__ballot(bkey != 0) != 0ull) {
+                        const int wl_ = wave_argmax(bkey, bid, mx);
+                        selr = __builtin_amdgcn_readlane(brk, wl_);
+                    }
+                    if (k == 0) s0 = selr; else if (k == 1) s1 = selr; else if (k == 2) s2 = selr; else if (k == 3) s3 = selr; else s4 = selr;
+                    if (pass == 0) {
+                        if (lane < kTF) {
+                            const bool have = selr >= 0 && lane < RF;
+                            PFb[k * kTF + lane] = have ? TFb[selr * kTF + lane] : -1;
+                            PFr[k * kTF + lane] = selr;
+                            PFv[k * kTF + lane] = have ? TFv[selr * kTF + lane] : 0;
+                        }
+                    } else if (lane == 0) {
+                        PLb[k] = selr >= 0 ? TLb[selr * kTL] : -1;
+                        PLr[k] = selr;
+                        PLv[k] = selr >= 0 ? TLv[selr * kTL] : 0;
+                    }
+                }
+                if (pass == 0) { for (int k = RF; k < 4; ++k) if (lane < kTF) PFb[k * kTF + lane] = -1; }
+                else if (lane == 0) for (int k = RF + 1; k < 8; ++k) PLb[k] = -1;
+            }
+        }
+        __syncthreads();
+        // ---- phase A: one LANE per partition solves the priced subproblem over the pools ----
         long long wsum = 0;
         bool bad = false;
-        for (int pp = wave; pp < P; pp += nw) {
-            const int p = __builtin_amdgcn_readfirstlane(pp);
-            const uint2 cw = pl.cur_in_lds ? CURP[p] : load_cur(p);   // 0xFFFF (none) never equals a broker index
-            const int c0 = (int)(cw.x & 0xFFFFu), c1 = (int)(cw.x >> 16), c2 = (int)(cw.y & 0xFFFFu), c3 = (int)(cw.y >> 16);
-            int Gb0 = -1, Gb1 = -1, Gb2 = -1, Gb3 = -1, Gf0 = 0, Gf1 = 0, Gf2 = 0, Gf3 = 0, Gr0 = -1, Gr1 = -1, Gr2 = -1, Gr3 = -1;
-            // greedy follower set: prack_lo best of every rack first, then the best remaining under the cap; ties -> lowest b
-            for (int j = 0; j < RF; ++j) {
-                const int forced = j < R * plo ? j / plo : -1;
-                uint32_t bkey = 0, bb = 0xFFFFFFFFu;
-                int brk = 0;
-                for_chunks<NCH>(nch, [&](int c) {
-                    int b, rb, F, FL;
-                    if (!elem(c, b, rb, F, FL)) return;
-                    const int cnt = (int)(Gr0 == rb) + (int)(Gr1 == rb) + (int)(Gr2 == rb);
-                    const bool in = (Gb0 == b) | (Gb1 == b) | (Gb2 == b);
-                    const bool ok = (forced >= 0 ? rb == forced : cnt < phi) & !in;
-                    const int wf = (b == c0) ? w01 : (((b == c1) | (b == c2) | (b == c3)) ? w11 : 0);
-                    const uint32_t key = (uint32_t)(wf + F) + 0x80000000u;
-                    if (ok && key > bkey) { bkey = key; bb = (uint32_t)b; brk = rb; }
-                });
-                const uint32_t mx = wave_umax(bkey);
-                if (mx == 0) { bad = true; break; }
-                const int wl_ = arg_lane(bkey, mx, bb);
-                const int sel = __builtin_amdgcn_readlane((int)bb, wl_), rs = __builtin_amdgcn_readlane(brk, wl_);
-                const int fv = (int)(mx - 0x80000000u);
-                if (j == 0) { Gb0 = sel; Gf0 = fv; Gr0 = rs; }
-                else if (j == 1) { Gb1 = sel; Gf1 = fv; Gr1 = rs; }
-                else if (j == 2) { Gb2 = sel; Gf2 = fv; Gr2 = rs; }
-                else { Gb3 = sel; Gf3 = fv; Gr3 = rs; }
+        for (int base = wave * 64; base < P; base += nw * 64) {
+            const int p = base + lane;
+            const bool act = p < P;
+            const uint2 cw = pl.cur_in_lds ? CURP[min(p, P - 1)] : load_cur(min(p, P - 1));
+            int cb[4] = {(int)(cw.x & 0xFFFFu), (int)(cw.x >> 16), (int)(cw.y & 0xFFFFu), (int)(cw.y >> 16)};
+            int cr[4], cF[4], cFL[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool v = cb[i] < B;
+                const int b = v ? cb[i] : 0;
+                cr[i] = RK[b];
+                cF[i] = -A[b] - G[cr[i]];
+                cFL[i] = cF[i] - LM[b];
+                if (!v) cb[i] = -1;
             }
-            if (bad) break;
-            // leader: every broker b0; outside the set it displaces the cheapest element whose removal keeps the rack band
-            const int fG = Gf0 + Gf1 + Gf2 + Gf3;
-            const int cg0 = 1 + (int)(Gr1 == Gr0) + (int)(Gr2 == Gr0) + (int)(Gr3 == Gr0);
-            const int cg1 = (int)(Gr0 == Gr1) + 1 + (int)(Gr2 == Gr1) + (int)(Gr3 == Gr1);
-            const int cg2 = (int)(Gr0 == Gr2) + (int)(Gr1 == Gr2) + 1 + (int)(Gr3 == Gr2);
-            const int cg3 = (int)(Gr0 == Gr3) + (int)(Gr1 == Gr3) + (int)(Gr2 == Gr3) + 1;
-            uint32_t bkey = 0, bb = 0xFFFFFFFFu;
-            int be = 0, brk = 0;
-            for_chunks<NCH>(nch, [&](int c) {
-                int b0, r0, F, FL;
-                if (!elem(c, b0, r0, F, FL)) return;
-                const int wl = (b0 == c0) ? w00 : (((b0 == c1) | (b0 == c2) | (b0 == c3)) ? w10 : 0);
-                const int lv = wl + FL;
-                const int c0cnt = (int)(Gr0 == r0) + (int)(Gr1 == r0) + (int)(Gr2 == r0) + (int)(Gr3 == r0);
+            const int c0 = cb[0], c1 = cb[1], c2 = cb[2], c3 = cb[3];
+            int Gb[4] = {-1, -1, -1, -1}, Gf[4] = {0, 0, 0, 0}, Gr[4] = {-1, -1, -1, -1};
+            bool fail = false;
+            // greedy follower set: prack_lo best of every rack first, then the best remaining under the cap; ties -> lowest b
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= RF) break;
+                const int forced = j < R * plo ? j / plo : -1;
+                int bf = INT_MIN, bb = INT_MAX, br = -1;
+                auto consider = [&](int b, int r, int F) {
+                    const int f = F + ((b == c0) ? w01 : (((b == c1) | (b == c2) | (b == c3)) ? w11 : 0));
+                    const int cnt = (int)(Gr[0] == r) + (int)(Gr[1] == r) + (int)(Gr[2] == r);
+                    const bool in = (Gb[0] == b) | (Gb[1] == b) | (Gb[2] == b);
+                    const bool ok = (b >= 0) & (forced >= 0 ? r == forced : cnt < phi) & !in;
+                    if (ok && (f > bf || (f == bf && b < bb))) { bf = f; bb = b; br = r; }
+                };
+                for (int i = 0; i < RF * kTF; ++i) consider(PFb[i], PFr[i], PFv[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) consider(cb[i], cr[i], cF[i]);
+                if (bb == INT_MAX) { fail = true; bb = -1; bf = 0; }
+                Gb[j] = bb; Gf[j] = bf; Gr[j] = br;
+            }
+            // leader: outside the set it displaces the cheapest element whose removal keeps the rack band
+            const int fG = Gf[0] + Gf[1] + Gf[2] + Gf[3];
+            int cg[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cg[j] = (int)(Gr[0] == Gr[j]) + (int)(Gr[1] == Gr[j]) + (int)(Gr[2] == Gr[j]) + (int)(Gr[3] == Gr[j]);
+            int bv = INT_MIN, b0 = INT_MAX, be = -1, b0r = -1;
+            auto lead = [&](int b, int r, int FL) {
+                const int lv = FL + ((b == c0) ? w00 : (((b == c1) | (b == c2) | (b == c3)) ? w10 : 0));
                 int e = -1, fe = 0;
-                if (Gb0 == b0) { e = 0; fe = Gf0; }
-                else if (Gb1 == b0) { e = 1; fe = Gf1; }
-                else if (Gb2 == b0) { e = 2; fe = Gf2; }
-                else if (Gb3 == b0) { e = 3; fe = Gf3; }
+                if (Gb[0] == b) { e = 0; fe = Gf[0]; }
+                else if (Gb[1] == b) { e = 1; fe = Gf[1]; }
+                else if (Gb[2] == b) { e = 2; fe = Gf[2]; }
+                else if (Gb[3] == b) { e = 3; fe = Gf[3]; }
                 else {
-                    const bool full = c0cnt >= phi;
-                    const bool ok0 = full ? Gr0 == r0 : ((Gr0 == r0) | (cg0 > plo));
-                    const bool ok1 = (RF > 1) & (full ? Gr1 == r0 : ((Gr1 == r0) | (cg1 > plo)));
-                    const bool ok2 = (RF > 2) & (full ? Gr2 == r0 : ((Gr2 == r0) | (cg2 > plo)));
-                    const bool ok3 = (RF > 3) & (full ? Gr3 == r0 : ((Gr3 == r0) | (cg3 > plo)));
-                    if (ok0) { e = 0; fe = Gf0; }                        // cheapest; ties -> the latest picked
-                    if (ok1 && (e < 0 || Gf1 <= fe)) { e = 1; fe = Gf1; }
-                    if (ok2 && (e < 0 || Gf2 <= fe)) { e = 2; fe = Gf2; }
-                    if (ok3 && (e < 0 || Gf3 <= fe)) { e = 3; fe = Gf3; }
+                    const int rc = (int)(Gr[0] == r) + (int)(Gr[1] == r) + (int)(Gr[2] == r) + (int)(Gr[3] == r);
+                    const bool full = rc >= phi;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = (j < RF) & (full ? Gr[j] == r : ((Gr[j] == r) | (cg[j] > plo)));
+                        if (ok && (e < 0 || Gf[j] <= fe)) { e = j; fe = Gf[j]; }     // cheapest; ties -> the latest picked
+                    }
                 }
-                const uint32_t key = (uint32_t)(fG - fe + lv) + 0x80000000u;
-                if (e >= 0 && key > bkey) { bkey = key; bb = (uint32_t)b0; be = e; brk = r0; }
-            });
-            const uint32_t mx = wave_umax(bkey);
-            if (mx == 0) { bad = true; break; }
-            const int wl_ = arg_lane(bkey, mx, bb);
-            const int sel = __builtin_amdgcn_readlane((int)bb, wl_), esel = __builtin_amdgcn_readlane(be, wl_);
-            const int rsel = __builtin_amdgcn_readlane(brk, wl_);
-            wsum += (int)(mx - 0x80000000u);
-            // counts of the chosen set: lanes 0..RF-1 the kept followers, lane 4 the leader
-            if (lane < RF && lane != esel) {
-                atomicAdd(&NR[pick4(Gb0, Gb1, Gb2, Gb3, lane)], 1);
-                atomicAdd(&NK[pick4(Gr0, Gr1, Gr2, Gr3, lane)], 1);
-            } else if (lane == 4) {
-                atomicAdd(&NR[sel], 1);
-                atomicAdd(&NL[sel], 1);
-                atomicAdd(&NK[rsel], 1);
+                const int v = fG - fe + lv;
+                if (b >= 0 && e >= 0 && (v > bv || (v == bv && b < b0))) { bv = v; b0 = b; be = e; b0r = r; }
+            };
+            if (!fail) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= RF) break;
+                    const int b = Gb[j], r = Gr[j];
+                    lead(b, r, -A[b] - G[r] - LM[b]);                                 // a set member leads
+                    for (int k = 0; k <= RF; ++k) lead(TLb[r * kTL + k], r, TLv[r * kTL + k]);   // best leaders of its rack
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) lead(cb[i], cr[i], cFL[i]);               // the partition's current brokers
+                for (int i = 0; i <= RF; ++i) lead(PLb[i], PLr[i], PLv[i]);           // best leader of the best racks
+            }
+            if (b0 == INT_MAX) fail = true;
+            if (act && fail) bad = true;
+            if (act && !fail) {
+                wsum += bv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < RF && j != be) { atomicAdd(&NR[Gb[j]], 1); atomicAdd(&NK[Gr[j]], 1); }
+                atomicAdd(&NR[b0], 1);
+                atomicAdd(&NL[b0], 1);
+                atomicAdd(&NK[b0r], 1);
             }
         }
+        bad = __ballot(bad) != 0ull;
+        wsum = wave_sum64(wsum);
         if (lane == 0) {
             if (wsum) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 0]), (unsigned long long)wsum);
             if (bad) atomicOr(&ctl[0], 4);
@@ -1129,7 +1213,19 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
         if (nrm == 0) { flags |= 2; ++it; break; }
         const bool reset = dn == 0;  // the memory cancelled the subgradient: restart from it
         if (reset) dn = 256 * nrm;
-        const long long step = ((Lv - target * kDualScale) << 20) / dn;
+        // level control: aim at the incumbent while the record keeps falling; every kDualStage iterations without half a
+        // unit of progress the distance between record and level is halved (an incumbent below the optimum is an
+        // unreachable level: steps too long, the record stalls far above the optimum)
+        long long level = target * kDualScale;
+        if (lv_delta <= 0) { lv_delta = best - level; lv_rec = best; lv_since = 0; }
+        if (++lv_since >= kDualStage) {
+            if (lv_rec - best < kDualScale / 2) { lv_delta /= 2; if (lv_delta < kDualScale / 16) lv_delta = kDualScale / 16; }
+            lv_rec = best; lv_since = 0;
+        }
+        if (best - lv_delta > level) level = best - lv_delta;
+        long long gap = Lv - level;
+        if (gap < 1) gap = 1;
+        const long long step = (gap << 20) / dn;
         for (int b = tid; b < B; b += nt) {
             int da = g_da[b], dl = g_dl[b];
             if (reset) {
@@ -1153,6 +1249,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     for (int b = tid; b < B; b += nt) { g_a[b] = A[b]; g_l[b] = LM[b]; }
     if (tid < R) { g_g[tid] = G[tid]; g_dg[tid] = DG[tid]; }
     if (tid == 0) {
+        g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since;
         pl.best_L[topic] = best;
         pl.info[topic * 4 + 0] += it;
         pl.info[topic * 4 + 1] = flags;
@@ -1202,30 +1299,22 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
                        win_assign, win_viol);
 }
 
-size_t bound_lds_bytes(int maxB, int maxP, bool cur_in_lds) {
-    return 80 + 3 * (size_t)kRackTab * 4 + 16 * (size_t)maxB + (((size_t)maxB + 15) & ~(size_t)15) + (cur_in_lds ? 8 * (size_t)maxP : 0);
+size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds) {
+    size_t n = 80 + (3 * (size_t)kRackTab + kRackTab + 2 + 48 + 24) * 4 + (size_t)maxR * (2 * 4 + 2 * 5) * 4;
+    n += 16 * (size_t)maxB + 2 * (((size_t)maxB + 7) & ~(size_t)7) + (((size_t)maxB + 15) & ~(size_t)15);
+    n = (n + 7) & ~(size_t)7;
+    return n + (cur_in_lds ? 8 * (size_t)maxP : 0);
 }
 
 static int g_attr_bound = 0;
 
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream) {
-    const size_t lds = bound_lds_bytes(pools.maxB, pools.maxP, pools.cur_in_lds != 0);
+    const size_t lds = bound_lds_bytes(pools.maxB, pools.maxP, pools.maxR, pools.cur_in_lds != 0);
     if ((int)lds > g_attr_bound) {
-        const void *fns[5] = {reinterpret_cast<const void *>(k_bound<0>), reinterpret_cast<const void *>(k_bound<1>),
-                              reinterpret_cast<const void *>(k_bound<2>), reinterpret_cast<const void *>(k_bound<3>),
-                              reinterpret_cast<const void *>(k_bound<4>)};
-        for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bound), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_bound = (int)lds;
     }
-    const dim3 grid(n_blocks), block(64 * waves);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (pools.maxB <= 256 ? (pools.maxB + 63) / 64 : 0) {  // brokers per lane kept in registers, or the LDS path
-        case 1: hipLaunchKernelGGL(k_bound<1>, grid, block, lds, st, pools); break;
-        case 2: hipLaunchKernelGGL(k_bound<2>, grid, block, lds, st, pools); break;
-        case 3: hipLaunchKernelGGL(k_bound<3>, grid, block, lds, st, pools); break;
-        case 4: hipLaunchKernelGGL(k_bound<4>, grid, block, lds, st, pools); break;
-        default: hipLaunchKernelGGL(k_bound<0>, grid, block, lds, st, pools); break;
-    }
+    hipLaunchKernelGGL(k_bound, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools);
 }
 
 size_t canon_lds_bytes(int maxBx) {

@@ -552,11 +552,13 @@ int kao_port_search(void *h, const port_params *pp, uint32_t rho, uint32_t launc
  * per-partition subproblem that is solved exactly, and
  *     L(a,l,g) = sum_p max{priced value of one partition's leader + followers} + sum (multiplier x band end)
  * is an upper bound on the optimum for ANY multipliers; floor(min L / DB_SCALE) is the certificate.  The multipliers
- * move along a deflected subgradient d = 16*s + 3/4 d_prev with the Polyak step (L - target*DB_SCALE) / |d|^2 towards
- * the incumbent `target` (a known feasible objective), all in integers so that the device and this replay agree bit
- * for bit. */
+ * move along a deflected subgradient d = 16*s + 3/4 d_prev with the Polyak step (L - level) / |d|^2, where the level is
+ * the incumbent `target` (a known feasible objective) while that keeps working and moves up towards the record dual
+ * value when it does not (level control below), all in integers so that the device and this replay agree bit for
+ * bit. */
 #define DB_SCALE 4096
 #define DB_CLAMP (1 << 26)
+#define DB_STAGE 100
 
 typedef struct { int b[RFP]; int f[RFP]; int r[RFP]; int n; } db_set;
 
@@ -636,11 +638,11 @@ static inline int32_t db_move(int32_t m, int64_t step, int32_t d) {
 }
 
 /* Runs up to `iters` dual iterations from the state (a[B], l[B], g[R] multipliers; da[B], dl[B], dg[R] previous
- * direction; *best_L), all in/out (zeros and INT64_MAX to start).  Needs P*RF <= 2^17 and P*RF*max(w) <= 2^19 (32-bit
+ * direction; lv[3] level-control state, zeros to start; *best_L), all in/out (zeros and INT64_MAX to start).  Needs P*RF <= 2^17 and P*RF*max(w) <= 2^19 (32-bit
  * headroom of the priced values).  flags: 1 = closed (best_L < (target+1)*DB_SCALE), 2 = zero subgradient (dual optimum reached),
  * 4 = a partition subproblem is infeasible (no bound).  Returns the number of iterations performed. */
 int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int32_t *a, int32_t *l, int32_t *g,
-                        int32_t *da, int32_t *dl, int32_t *dg, int64_t *best_L, int32_t *flags) {
+                        int32_t *da, int32_t *dl, int32_t *dg, int64_t *lv, int64_t *best_L, int32_t *flags) {
     const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
     int32_t *nrep = (int32_t *)malloc(sizeof(int32_t) * (size_t)B), *nlead = (int32_t *)malloc(sizeof(int32_t) * (size_t)B);
     int32_t nrack[256];
@@ -685,7 +687,19 @@ int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int3
             for (int r = 0; r < R; ++r) dg[r] = 16 * db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi);
             dn = 256 * nrm;
         }
-        const int64_t gap = L - target * DB_SCALE;       /* >= DB_SCALE here */
+        /* Level control: the Polyak step aims at `level`, the incumbent while the record keeps falling.  An incumbent
+         * below the optimum is an unreachable level (steps too long, the record stalls far above the optimum): every
+         * DB_STAGE iterations without half a unit of progress the distance delta between record and level is halved.
+         * lv = {delta (0 = not started), record at the start of the stage, iterations in the stage}. */
+        int64_t level = target * DB_SCALE;
+        if (lv[0] <= 0) { lv[0] = *best_L - level; lv[1] = *best_L; lv[2] = 0; }
+        if (++lv[2] >= DB_STAGE) {
+            if (lv[1] - *best_L < DB_SCALE / 2) { lv[0] /= 2; if (lv[0] < DB_SCALE / 16) lv[0] = DB_SCALE / 16; }
+            lv[1] = *best_L; lv[2] = 0;
+        }
+        if (*best_L - lv[0] > level) level = *best_L - lv[0];
+        int64_t gap = L - level;
+        if (gap < 1) gap = 1;
         const int64_t step = (gap << 20) / dn;           /* multiplier change = gap * 16 d / |d|^2, 16 fractional bits */
         for (int b = 0; b < B; ++b) { a[b] = db_move(a[b], step, da[b]); l[b] = db_move(l[b], step, dl[b]); }
         for (int r = 0; r < R; ++r) g[r] = db_move(g[r], step, dg[r]);

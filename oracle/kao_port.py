@@ -49,7 +49,7 @@ def lib():
                                          C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int64)]
         _LIB.kao_port_search.restype = C.c_int
         _LIB.kao_port_dual_bound.argtypes = [C.POINTER(PortTopic), C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 6 + [
-            C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+            C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         _LIB.kao_port_dual_bound.restype = C.c_int
     return _LIB
 
@@ -133,6 +133,7 @@ class DualState:
         self.da = np.zeros_like(self.a)   # previous direction (deflected subgradient)
         self.dl = np.zeros_like(self.l)
         self.dg = np.zeros_like(self.g)
+        self.lv = np.zeros(3, dtype=np.int64)   # level control: delta, record at stage start, iterations in stage
         self.best_L = INT64_MAX
         self.iters = 0
         self.flags = 0
@@ -151,7 +152,7 @@ def port_dual_bound(topic, target: int, iters: int, state: DualState = None) -> 
     p32 = C.POINTER(C.c_int32)
     n = lib().kao_port_dual_bound(C.byref(ct.s), int(target), int(iters), st.a.ctypes.data_as(p32), st.l.ctypes.data_as(p32),
                                   st.g.ctypes.data_as(p32), st.da.ctypes.data_as(p32), st.dl.ctypes.data_as(p32),
-                                  st.dg.ctypes.data_as(p32), C.byref(bl), C.byref(fl))
+                                  st.dg.ctypes.data_as(p32), st.lv.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(bl), C.byref(fl))
     st.best_L = int(bl.value)
     st.iters += int(n)
     st.flags = int(fl.value)

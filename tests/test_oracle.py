@@ -211,7 +211,16 @@ def test_port_dual_bound_is_valid_and_closes_the_gap(ko, kp):
             if not two.flags & 3:
                 two = kp.port_dual_bound(t, c["objective"], 50, two)
             assert (one.best_L, one.a.tolist(), one.l.tolist(), one.g.tolist()) == (two.best_L, two.a.tolist(), two.l.tolist(), two.g.tolist())
-    assert closed >= len(cases) - 4 and tight_closed_form < len(cases) // 2 + 5, (closed, tight_closed_form, len(cases))
+    assert closed >= len(cases) - 2 and tight_closed_form < len(cases) // 2 + 5, (closed, tight_closed_form, len(cases))
+    # an incumbent BELOW the optimum as target (what K-search hands over on hard instances): the level control keeps the
+    # certificate close to the optimum anyway (a plain Polyak step stalls 6.5 units above it on average, 25 at worst)
+    excess = []
+    for c in cases[::3]:
+        t = ko.random_case_wide(c["seed"])
+        st = kp.port_dual_bound(t, max(0, c["objective"] - max(3, c["objective"] // 50)), 2000)
+        assert st.bound >= c["objective"]
+        excess.append(st.bound - c["objective"])
+    assert sum(excess) <= len(excess) // 4 and max(excess) <= 2, (sum(excess), max(excess))
 
 
 def test_port_dual_bound_golden_configs(ko, kp):
