@@ -181,8 +181,8 @@ int kao_session_stats(kao_session *s, kao_stats *out);
  * C1, C2, C5, C7 kept in an exactly solved per-partition subproblem.  Every dual value is an upper bound on the
  * optimum, so floor(min dual) is a certificate whatever the multipliers.
  * One launch runs up to `iters` iterations for every topic i with target[i] >= 0 (the incumbent objective the
- * step length aims at; pass -1 to skip a topic).  Topics outside K-bound's limits (n_brokers > 8192,
- * n_partitions*rf > 131072, a weight outside 0..255) are skipped.  Asynchronous, on a stream of its own: K-bound
+ * step length aims at; pass -1 to skip a topic).  Topics outside K-bound's limits (broker and rack tables
+ * beyond 160 KiB of LDS: about 8,000 brokers; n_partitions*rf > 131072; a weight outside 0..255) are skipped.  Asynchronous, on a stream of its own: K-bound
  * occupies one compute unit per topic and runs beside K-search (kao_session_step); a new launch first waits for the
  * previous K-bound launch (it continues from the multipliers that one left in HBM). */
 int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters);
