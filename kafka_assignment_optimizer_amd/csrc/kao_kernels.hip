@@ -8,8 +8,8 @@
 //              over the wavefront picks the move.  k_search<false> also keeps the assignment words in
 //              LDS; k_search<true> leaves them in HBM/L2 for topics that do not fit.
 //   k_bound  : Lagrangian dual bound "KAO-DB" (the optimality certificate): one workgroup per topic prices the
-//              coupling rows, one wavefront per partition solves the priced subproblem exactly, deflected Polyak
-//              subgradient steps in integer fixed point.
+//              coupling rows, rebuilds the candidate pools (wavefront arg-max per rack), one lane per partition solves
+//              the priced subproblem exactly, deflected level-controlled Polyak steps in integer fixed point.
 //   k_eval   : full evaluation (objective README.md:145-146 and rows C1..C7 README.md:148-180) of
 //              complete compact candidates streamed from HBM, one wavefront per candidate, ending in
 //              the wavefront -> workgroup -> atomicMin reduce of the packed (violation, cost, id) key.
@@ -890,11 +890,11 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *c
 // lp_solve certifies optimality by branch-and-bound over the LP relaxation (README.md:135-136); here the certificate
 // is the Lagrangian dual of the same 0-1 model: the coupling rows C3 (README.md:158-161), C4 (163-166) and C6 (173-176)
 // are priced with integer fixed-point multipliers a[b], l[b], g[r]; the rows local to a partition (C1, C2, C5, C7) stay
-// in a per-partition subproblem solved exactly by one wavefront (greedy follower set under the per-partition rack
-// band + one exchange for the leader).  L(a,l,g) bounds the optimum from above for ANY multipliers, so
-// floor(min L / kDualScale) is a valid certificate; a deflected Polyak subgradient step towards the incumbent
-// objective drives it down.  One workgroup per topic, persistent over the iterations of a launch; multipliers, counters
-// and the rack table live in LDS; integer-only so that the replay agrees bit for bit.
+// in a per-partition subproblem solved exactly (greedy follower set under the per-partition rack band + one exchange
+// for the leader) by one lane over per-iteration candidate pools.  L(a,l,g) bounds the optimum from above for ANY
+// multipliers, so floor(min L / kDualScale) is a valid certificate; a deflected, level-controlled Polyak subgradient
+// step towards the incumbent objective drives it down.  One workgroup per topic, persistent over the iterations of a
+// launch; multipliers, counters, rack tables and pools live in LDS; integer-only so that the replay agrees bit for bit.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v) { return ~wave_umin(~v); }
 __device__ __forceinline__ long long wave_sum64(long long v) {
@@ -911,10 +911,6 @@ __device__ __forceinline__ int db_move(int m, long long step, int d) {
     long long v = (long long)m - (d < 0 ? -mag : mag);
     v = v > kDualClamp ? kDualClamp : (v < -kDualClamp ? -kDualClamp : v);
     return (int)v;
-}
-__device__ __forceinline__ int pick4(int x0, int x1, int x2, int x3, int k) {
-    const int lo = (k & 2) ? x2 : x0, hi = (k & 2) ? x3 : x1;
-    return (k & 1) ? hi : lo;
 }
 
 // Wavefront arg-max of (value, lowest id): lanes hold their best (key = biased value, 0 = none; id).  Returns the lane
