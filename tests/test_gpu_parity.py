@@ -556,6 +556,34 @@ def test_dual_bound_replay_bit_exact(kao, ko, kp):
         assert got["bound"] == st.bound >= c["objective"], tag
 
 
+def test_dual_bound_replay_large_shapes(kao, ko, kp):
+    """K-bound paths the small families do not reach: the current assignment read from global memory (8 B per
+    partition no longer fits LDS), hundreds of brokers in few racks (long per-rack scans), many racks (rack ranking
+    over several 64-lane rounds), RF 4 with an RF change; multipliers and dual value still equal the replay's."""
+    shapes = [  # (brokers, racks, partitions, rf, removed, added, new_rf, target offset)
+        (50, 5, 20000, 3, [3, 7], [(50, 1)], None, 40),
+        (900, 3, 300, 3, list(range(0, 90, 7)), [(900 + i, i % 3) for i in range(5)], None, 25),
+        (400, 200, 150, 2, [5, 6, 7], [(400, 3)], None, 1),
+        (64, 4, 500, 4, [1], [(64, 2), (65, 3)], 3, 3),
+        (130, 1, 257, 1, [0, 129], [], 2, 5),
+    ]
+    for i, (B, R, P, rf, rm, add, new_rf, off) in enumerate(shapes):
+        ot = ko.make_cluster(f"shape{i}", B, R, 1, P, rf, rm, add, new_rf=new_rf).topics[0]
+        if ko.provably_infeasible(ot):   # rigid bands on uneven racks: relax the rack bands, keep the rest
+            bd = ot.bounds()
+            ot.bounds_override = {"rack_lo": 0, "rack_hi": bd["rack_hi"] + P, "prack_hi": bd["prack_hi"] + 1, "rep_hi": bd["rep_hi"] + 1}
+            assert not ko.provably_infeasible(ot), i
+        target = max(0, ko.upper_bound_simple(ot) - off)
+        got = kao.dual_bound(to_product_topic(ot), target, iters=12, launches=2)
+        st = kp.DualState(ot)
+        for _ in range(2):
+            st = kp.port_dual_bound(ot, target, 12, st)
+            if st.flags & 7:
+                break
+        assert (got["iters"], got["flags"], got["best_dual"]) == (st.iters, st.flags, st.best_L), (i, got["iters"], st.iters, got["flags"], st.flags)
+        assert got["a"].tolist() == st.a.tolist() and got["l"].tolist() == st.l.tolist() and got["g"].tolist() == st.g[:ot.n_racks].tolist(), i
+
+
 def test_dual_bound_is_valid_and_closes_wide_family(kao, ko):
     """Every feasible instance of the wide family: floor(dual) never undercuts the HiGHS optimum and, aimed at the
     optimum, equals it on all but a few (the closed-form bound is tight on fewer than half)."""
