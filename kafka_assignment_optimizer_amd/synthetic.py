@@ -89,6 +89,26 @@ def make_cluster(n_brokers0: int, n_racks: int, n_topics: int, n_partitions: int
     return topics
 
 
+def drift(topics: Sequence[Topic], frac: float = 0.2, seed: int = 1) -> List[Topic]:
+    """The same topics after the cluster has drifted: `frac` of every topic's replica slots moved to a random target
+    broker (never one already holding the partition).  The bands do not depend on the current assignment, so the
+    instances stay feasible; what changes is that the optimum is no longer "keep everything that survived", i.e. the
+    closed-form bound has a gap and the certificate has to come from K-bound."""
+    out = []
+    for ti, t in enumerate(topics):
+        rng = SplitMix64(0xD21F7000 + seed * 1000003 + ti)
+        cur = np.array(t.current).copy()
+        P, rfc, B = cur.shape[0], cur.shape[1], len(t.broker_ids)
+        for _ in range(int(P * rfc * frac)):
+            p, k, nb = rng.below(P), rng.below(rfc), rng.below(B)
+            if nb not in cur[p]:
+                cur[p, k] = nb
+        out.append(Topic(name=t.name + "-drift", broker_ids=t.broker_ids, rack_of=t.rack_of, n_racks=t.n_racks,
+                         n_partitions=t.n_partitions, rf=t.rf, current=cur, weights=t.weights,
+                         partition_ids=t.partition_ids, bounds_override=dict(t.bounds_override)))
+    return out
+
+
 def make_config(n: int, n_topics: Optional[int] = None) -> List[Topic]:
     """Topics of BASELINE.json config `n` (2..5); `n_topics` truncates."""
     rng = SplitMix64(CONFIG_SEED + n)

@@ -618,6 +618,18 @@ def test_solve_proves_wide_family(kao, ko):
     assert n_equal >= n_opt - 2 and n_proven >= n_opt - 6, (n_opt, n_equal, n_proven)
 
 
+def test_golden_optima_config4_drifted(kao, ko):
+    """BASELINE config 4 after a 20 % drift (bench.py's second time-to-optimal workload): HiGHS optimum reached and
+    PROVEN -- the closed-form bound has a gap on each of these topics, so the proof is K-bound's."""
+    g = load_golden("cfg4_drift.json")["topics"]
+    ots = [ko.topic_from_dict(e["topic"]) for e in g]
+    res = kao.solve([to_product_topic(t) for t in ots], seed=9, time_limit_s=20.0, stop_at_bound=1)
+    for e, ot, r in zip(g, ots, res):
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == r.objective == e["objective"], (ot.name, r.objective, e["objective"])
+        assert r.status == "OPTIMAL_PROVEN" and r.upper_bound == e["objective"] < e["upper_bound_closed_form"], (ot.name, r.status, r.upper_bound)
+
+
 def test_dual_bound_limits_and_errors(kao, ko):
     ot = ko.readme_example()
     pt = to_product_topic(ot)
