@@ -13,6 +13,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big_every = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # every n-th topic is large
 launches = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+dual_iters = int(sys.argv[5]) if len(sys.argv) > 5 else 25   # K-bound iterations per launch (2 launches)
 rng = ko._Rng(0xF022 + seed0)
 topics = []
 while len(topics) < n_cases:
@@ -88,12 +89,12 @@ for lo in range(0, len(topics), 50):
             continue
         target = max(0, ko.upper_bound_simple(ot) - 3 - (ti % 5))
         try:
-            dv = kao.dual_bound(pt, target, iters=25, launches=2)
+            dv = kao.dual_bound(pt, target, iters=dual_iters, launches=2)
         except kao.KaoError as e:
             bad += 1; print("DUAL ERROR", ot.name, e); continue
         st = kp.DualState(ot)
         for _ in range(2):
-            st = kp.port_dual_bound(ot, target, 25, st)
+            st = kp.port_dual_bound(ot, target, dual_iters, st)
             if st.flags & 7:
                 break
         if (dv["iters"], dv["flags"], dv["best_dual"] if dv["iters"] else 0) != (st.iters, st.flags, st.best_L if st.iters else 0) or \
