@@ -618,10 +618,11 @@ def test_solve_proves_wide_family(kao, ko):
     assert n_equal >= n_opt - 2 and n_proven >= n_opt - 6, (n_opt, n_equal, n_proven)
 
 
-def test_golden_optima_config4_drifted(kao, ko):
-    """BASELINE config 4 after a 20 % drift (bench.py's second time-to-optimal workload): HiGHS optimum reached and
-    PROVEN -- the closed-form bound has a gap on each of these topics, so the proof is K-bound's."""
-    g = load_golden("cfg4_drift.json")["topics"]
+@pytest.mark.parametrize("name", ["cfg2_drift.json", "cfg3_drift.json", "cfg4_drift.json"])
+def test_golden_optima_configs_drifted(kao, ko, name):
+    """BASELINE configs 2-4 after a 20 % drift (config 4: bench.py's second time-to-optimal workload): HiGHS optimum
+    reached and PROVEN -- the closed-form bound has a gap on each of these topics, so the proof is K-bound's."""
+    g = load_golden(name)["topics"]
     ots = [ko.topic_from_dict(e["topic"]) for e in g]
     res = kao.solve([to_product_topic(t) for t in ots], seed=9, time_limit_s=20.0, stop_at_bound=1)
     for e, ot, r in zip(g, ots, res):
