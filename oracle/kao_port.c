@@ -542,6 +542,38 @@ int kao_port_search(void *h, const port_params *pp, uint32_t rho, uint32_t launc
     return 0;
 }
 
+/* Throughput driver for bench.py's cpu_baseline leg: restarts rho0 .. rho0+n-1 of one topic replayed on `threads`
+ * native threads (restarts are independent; no Python in the loop).  Returns the number of neighbours evaluated. */
+#include <pthread.h>
+typedef struct { void *h; const port_params *pp; uint32_t rho0, n, stride, first, launches, iters; uint64_t n_eval; } many_job;
+static void *many_worker(void *arg) {
+    many_job *j = (many_job *)arg;
+    const ls_topic *t = (const ls_topic *)j->h;
+    uint16_t *fin = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * t->RF), *best = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * t->RF);
+    for (uint32_t r = j->first; r < j->n; r += j->stride) {
+        int64_t st[6];
+        kao_port_search(j->h, j->pp, j->rho0 + r, j->launches, j->iters, fin, best, st);
+        j->n_eval += (uint64_t)st[3] | ((uint64_t)st[4] << 32);
+    }
+    free(fin); free(best);
+    return NULL;
+}
+uint64_t kao_port_search_many(void *h, const port_params *pp, uint32_t rho0, uint32_t n, uint32_t launches, uint32_t iters, uint32_t threads) {
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    many_job *jobs = (many_job *)calloc(threads, sizeof(many_job));
+    for (uint32_t i = 0; i < threads; ++i) {
+        jobs[i].h = h; jobs[i].pp = pp; jobs[i].rho0 = rho0; jobs[i].n = n; jobs[i].stride = threads; jobs[i].first = i;
+        jobs[i].launches = launches; jobs[i].iters = iters;
+        pthread_create(&th[i], NULL, many_worker, &jobs[i]);
+    }
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < threads; ++i) { pthread_join(th[i], NULL); total += jobs[i].n_eval; }
+    free(th); free(jobs);
+    return total;
+}
+
 /* ------------------------------------------------------------------ KAO-DB: Lagrangian dual bound
  *
  * Scalar replay of the device's dual-bound kernel (k_bound).  lp_solve proves optimality by

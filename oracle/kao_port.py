@@ -48,6 +48,8 @@ def lib():
         _LIB.kao_port_search.argtypes = [C.c_void_p, C.POINTER(PortParams), C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int64)]
         _LIB.kao_port_search.restype = C.c_int
+        _LIB.kao_port_search_many.argtypes = [C.c_void_p, C.POINTER(PortParams)] + [C.c_uint32] * 5
+        _LIB.kao_port_search_many.restype = C.c_uint64
         _LIB.kao_port_dual_bound.argtypes = [C.POINTER(PortTopic), C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 6 + [
             C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         _LIB.kao_port_dual_bound.restype = C.c_int
@@ -115,6 +117,25 @@ def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params)
         return dict(final=fin.reshape(topic.n_partitions, topic.rf), best=best.reshape(topic.n_partitions, topic.rf),
                     best_obj=int(st[0]), V=int(st[1]), obj=int(st[2]), n_eval=int(st[3]) | (int(st[4]) << 32),
                     n_accept=int(st[5]))
+    finally:
+        lib().kao_port_ls_destroy(h)
+
+
+def port_search_throughput(topic, seed: int, n_restarts: int, launches: int, iters: int, threads: int, **params) -> int:
+    """Replays restarts 0..n_restarts-1 of `topic` on `threads` native threads; returns the neighbours evaluated
+    (bench.py's cpu_baseline leg)."""
+    ct = CTopic(topic)
+    h = lib().kao_port_ls_create(C.byref(ct.s))
+    if not h:
+        raise ValueError("unsupported instance (RF > 4 or racks > 255)")
+    try:
+        pr = dict(DEFAULT_PARAMS)
+        pr.update(params)
+        if pr["period_log2"] is None:
+            pr["period_log2"] = auto_period_log2(topic)
+        pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
+                        lam_max=pr["lam_max"], period_log2=pr["period_log2"])
+        return int(lib().kao_port_search_many(h, C.byref(pp), 0, n_restarts, launches, iters, threads))
     finally:
         lib().kao_port_ls_destroy(h)
 
