@@ -30,6 +30,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
+def host_cores() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box with 256 hardware
+    threads may grant the container 16 CPUs' worth of time)."""
+    n = max(1, len(os.sched_getaffinity(0)))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:        # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(topics, restarts, iters, budget_s=15.0):
     """The oracle's scalar C port of the same search (oracle/kao_port.c), on every host core, on a
     bounded sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
@@ -50,10 +70,10 @@ def cpu_baseline(topics, restarts, iters, budget_s=15.0):
         n1 += kp.port_search(ots[0], 1, k1 & 1023, 1, iters)["n_eval"]
         k1 += 1
     rate1 = n1 / (time.perf_counter() - t0)
-    cores = max(1, len(os.sched_getaffinity(0)))
+    cores = host_cores()
     n_eval = 0
     done_topics = 0
-    per_call = restarts * max(1, -(-cores // restarts))   # at least one restart per thread in every call
+    per_call = max(4 * cores, -(-restarts // cores) * cores)   # a multiple of the thread count, >= 4 restarts per thread
     t0 = time.perf_counter()
     while True:   # whole passes over the topic list until the budget is used (a 256-thread host finishes one pass in ~1 s)
         for ot in ots:
