@@ -901,7 +901,7 @@ void kao_session_destroy(kao_session *s) {
     if (s->stream_bound) (void)hipStreamSynchronize(s->stream_bound);
     if (s->ev_bound0) (void)hipEventDestroy(s->ev_bound0);
     if (s->ev_bound1) (void)hipEventDestroy(s->ev_bound1);
-    if (s->stream_bound) stream_put(s->stream_bound);
+    if (s->stream_bound) (void)hipStreamDestroy(s->stream_bound);
     arena_put(s->arena_ro, s->arena_ro_bytes);
     arena_put(s->arena_rw, s->arena_rw_bytes);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
@@ -1255,8 +1255,10 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     }
     if (s->h_dual_ids.empty()) return KAO_OK;
     if (!s->stream_bound) {
-        int rc = stream_get(&s->stream_bound);
-        if (rc) return rc;
+        // highest priority: a K-bound launch is a handful of workgroups that should not queue behind a full K-search grid
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&s->stream_bound, hipStreamNonBlocking, hi));
         HIP_TRY(hipEventCreate(&s->ev_bound0));
         HIP_TRY(hipEventCreate(&s->ev_bound1));
     }
