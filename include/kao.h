@@ -86,7 +86,8 @@ typedef struct kao_opts {
     int32_t stop_at_bound;    /* kao_solve: 1 = stop as soon as every topic is OPTIMAL_PROVEN */
     int32_t profile;          /* 1 = bracket every kernel with HIP events (kao_session_stats) */
     int32_t dual_iters;       /* kao_solve: K-bound (Lagrangian dual bound) iterations per launch for topics whose
-                                 feasible incumbent is below the bound; 0 = 512, < 0 = never run K-bound */
+                                 feasible incumbent is below the bound; 0 = 128 for the first launch, then adapted to
+                                 about 10 ms per launch; < 0 = never run K-bound */
     const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
                                         objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;

@@ -1426,7 +1426,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     bool hit_time = false;
     int launches = 0;
     double t_last_improve = 0;
-    const int dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 512 : o.dual_iters);
+    const int dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 128 : o.dual_iters);
     std::vector<int64_t> dual_target((size_t)n_topics);
     int dual_now = dual_iters;
     for (;;) {
