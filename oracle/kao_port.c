@@ -602,7 +602,7 @@ static inline int db_wcur(const port_topic *t, const uint16_t *cur, unsigned b, 
 
 /* One partition's priced subproblem.  Returns 0 and fills S (the chosen brokers, leader first) and *val, or -1 if
  * no set of RF brokers satisfies the per-partition rack band. */
-static int db_partition(const port_topic *t, int p, const int32_t *a, const int32_t *l, const int32_t *g, int *S, int32_t *val) {
+static int db_partition_g(const port_topic *t, int p, const int32_t *a, const int32_t *l, const int32_t *g, int *S, int32_t *val, int *Gout) {
     const int B = t->n_brokers, R = t->n_racks, RF = t->rf, plo = t->prack_lo, phi = t->prack_hi;
     const uint16_t *cur = t->current + (size_t)p * t->rf_cur;
     db_set G; G.n = 0;
@@ -626,6 +626,7 @@ static int db_partition(const port_topic *t, int p, const int32_t *a, const int3
     }
     int32_t fG = 0;
     for (int j = 0; j < RF; ++j) fG += G.f[j];
+    if (Gout) for (int j = 0; j < RF; ++j) Gout[j] = G.b[j];
     /* leader: every broker b0; outside G it displaces the cheapest element whose removal keeps the rack band */
     int best_b0 = -1, best_e = -1; int32_t best_v = 0;
     for (int b0 = 0; b0 < B; ++b0) {
@@ -651,6 +652,20 @@ static int db_partition(const port_topic *t, int p, const int32_t *a, const int3
     for (int j = 0; j < RF; ++j) if (j != best_e) S[n++] = G.b[j];
     *val = best_v;
     return 0;
+}
+
+/* Test hook: the brute-force subproblem solution of one partition (S: leader first; G: the greedy follower set the
+ * leader was then fitted into) under given multipliers. */
+int kao_port_dual_partition(const port_topic *t, int p, const int32_t *a, const int32_t *l, const int32_t *g, int32_t *S, int32_t *G,
+                            int32_t *val) {
+    int s[RFP], gg[RFP];
+    const int rc = db_partition_g(t, p, a, l, g, s, val, gg);
+    if (!rc) for (int j = 0; j < t->rf; ++j) { S[j] = s[j]; G[j] = gg[j]; }
+    return rc;
+}
+
+static int db_partition(const port_topic *t, int p, const int32_t *a, const int32_t *l, const int32_t *g, int *S, int32_t *val) {
+    return db_partition_g(t, p, a, l, g, S, val, NULL);
 }
 
 static inline int32_t db_sub(int32_t m, int n, int lo, int hi) {   /* element of the subdifferential closest to 0 */

@@ -50,6 +50,8 @@ def lib():
         _LIB.kao_port_search.restype = C.c_int
         _LIB.kao_port_search_many.argtypes = [C.c_void_p, C.POINTER(PortParams)] + [C.c_uint32] * 5
         _LIB.kao_port_search_many.restype = C.c_uint64
+        _LIB.kao_port_dual_partition.argtypes = [C.POINTER(PortTopic), C.c_int] + [C.POINTER(C.c_int32)] * 6
+        _LIB.kao_port_dual_partition.restype = C.c_int
         _LIB.kao_port_dual_bound.argtypes = [C.POINTER(PortTopic), C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 6 + [
             C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         _LIB.kao_port_dual_bound.restype = C.c_int
@@ -178,3 +180,16 @@ def port_dual_bound(topic, target: int, iters: int, state: DualState = None) -> 
     st.iters += int(n)
     st.flags = int(fl.value)
     return st
+
+
+def port_dual_partition(topic, p: int, a, l, g):
+    """Brute-force priced subproblem of partition p: (brokers leader first, greedy follower set, value) or None."""
+    ct = CTopic(topic)
+    a = np.ascontiguousarray(a, dtype=np.int32); l = np.ascontiguousarray(l, dtype=np.int32); g = np.ascontiguousarray(g, dtype=np.int32)
+    S = np.zeros(4, dtype=np.int32)
+    G = np.zeros(4, dtype=np.int32)
+    val = C.c_int32()
+    p32 = C.POINTER(C.c_int32)
+    rc = lib().kao_port_dual_partition(C.byref(ct.s), int(p), a.ctypes.data_as(p32), l.ctypes.data_as(p32), g.ctypes.data_as(p32),
+                                       S.ctypes.data_as(p32), G.ctypes.data_as(p32), C.byref(val))
+    return None if rc else (S[:topic.rf].tolist(), G[:topic.rf].tolist(), int(val.value))

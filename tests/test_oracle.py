@@ -230,3 +230,46 @@ def test_port_dual_bound_golden_configs(ko, kp):
             t = ko.topic_from_dict(e["topic"])
             st = kp.port_dual_bound(t, e["objective"], 400)
             assert st.bound == e["objective"] and st.flags & 1
+
+
+def test_dual_subproblem_picks_lie_in_the_candidate_pools(ko, kp):
+    """The lemma K-bound's kernel relies on (k_bound): under "largest priced value, ties -> lowest
+    broker index" every follower the brute-force subproblem picks is one of the partition's current brokers or one of the
+    RF best brokers (by generic value F, then index) of one of the RF best racks; the leader is a set member, a current
+    broker, one of the RF+1 best brokers (by generic leader value FL) of a rack holding a set member, or the best broker of
+    one of the RF+1 best racks by FL.  Checked against the brute-force scan with random multipliers, heavy on ties."""
+    rng = np.random.default_rng(7)
+    checked = 0
+    for seed in range(0, 120, 3):
+        t = ko.random_case_wide(seed)
+        if ko.provably_infeasible(t):
+            continue
+        B, R, RF = t.n_brokers, t.n_racks, t.rf
+        rack = t.rack_of.astype(int)
+        for trial in range(3):
+            step = [1, 512, 4096][trial]          # coarse multipliers -> many exact ties
+            a = (rng.integers(-3, 4, B) * step).astype(np.int32)
+            l = (rng.integers(-2, 3, B) * step).astype(np.int32)
+            g = (rng.integers(-2, 3, max(1, R)) * step).astype(np.int32)
+            F = -a.astype(np.int64) - g[rack]
+            FL = F - l
+            topF = {r: sorted(np.flatnonzero(rack == r), key=lambda b: (-F[b], b))[:RF] for r in range(R)}
+            topL = {r: sorted(np.flatnonzero(rack == r), key=lambda b: (-FL[b], b))[:RF + 1] for r in range(R)}
+            racksF = sorted((r for r in range(R) if topF[r]), key=lambda r: (-F[topF[r][0]], topF[r][0]))[:RF]
+            racksL = sorted((r for r in range(R) if topL[r]), key=lambda r: (-FL[topL[r][0]], topL[r][0]))[:RF + 1]
+            poolF = {int(b) for r in racksF for b in topF[r]}
+            for p in range(0, t.n_partitions, max(1, t.n_partitions // 12)):
+                got = kp.port_dual_partition(t, p, a, l, g)
+                if got is None:
+                    continue
+                S, G, _ = got
+                cur = {int(b) for b in t.current[p] if b < B}
+                for b in G:       # every greedy pick: a current broker or in the follower pool
+                    assert b in cur or b in poolF, (seed, trial, p, b)
+                poolL = set(G) | cur | {int(topL[r][0]) for r in racksL}
+                for b in G:       # RF+1 best leaders of every rack that holds a set member
+                    poolL |= {int(x) for x in topL[rack[b]]}
+                assert S[0] in poolL, (seed, trial, p, S[0])
+                assert set(S[1:]) <= set(G)
+                checked += 1
+    assert checked > 300
