@@ -106,6 +106,21 @@ def test_wide_family_host_bound_and_infeasibility(ko):
     assert n_opt >= 150 and n_inf >= 150
 
 
+def test_jni_shim_in_integration_md_compiles(tmp_path):
+    """The JNI shim shown in INTEGRATION.md is real C against include/kao.h: it compiles (no JDK here, so against
+    tests/jni_stub/jni.h, which declares the JNIEnv members it uses with their real signatures) with -Wall -Werror."""
+    import re
+    import subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```c\n(.*?)```", text, flags=re.S)
+    shim = [b for b in blocks if "Java_io_sqooba_kao_Kao_solve" in b]
+    assert len(shim) == 1
+    src = tmp_path / "kao_jni.c"
+    src.write_text(shim[0])
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I", os.path.join(ROOT, "include"), str(src)])
+
+
 def test_validation_errors(ko):
     import kafka_assignment_optimizer_amd as kao
     pt = to_product_topic(ko.readme_example())
