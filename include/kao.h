@@ -61,7 +61,8 @@ typedef struct kao_topic {
     int32_t rf_cur;           /* replication factor of `current` (README.md:9: RF may change) */
     const uint8_t *rack_of;   /* [B] dense rack index of each target broker (README.md:27-29) */
     const uint16_t *current;  /* [P*rf_cur] dense broker index, slot 0 = preferred leader
-                                 (README.md:52-63); KAO_NONE = broker not in the target set */
+                                 (README.md:52-63); KAO_NONE = broker not in the target set; a broker may not
+                                 appear twice in one partition (KAO_ERR_INVALID) */
     int32_t w[2][2];          /* objective weights w[cur_role][new_role], role 0 leader, 1 follower
                                  (README.md:145-146); default {{4,1},{2,2}} */
     /* band right-hand sides; -1 = derive floor/ceil of the average (README.md:159-160,

@@ -59,6 +59,13 @@ int validate(const kao_topic *t) {
     if (!t->rack_of || !t->current) return fail(KAO_ERR_INVALID, "null rack_of/current");
     for (int b = 0; b < t->n_brokers; ++b)
         if (t->rack_of[b] >= t->n_racks) return fail(KAO_ERR_INVALID, "rack_of entry >= n_racks");
+    for (int p = 0; p < t->n_partitions; ++p) {  // one LP variable per (broker, partition) (README.md:146): a broker cannot be listed twice
+        const uint16_t *c = t->current + (size_t)p * t->rf_cur;
+        for (int k = 1; k < t->rf_cur; ++k)
+            for (int j = 0; j < k; ++j)
+                if (c[k] == c[j] && c[k] < t->n_brokers)
+                    return fail(KAO_ERR_INVALID, "current assignment lists a broker twice in partition " + std::to_string(p));
+    }
     if ((int64_t)t->n_partitions * t->rf > 4000000) return fail(KAO_ERR_UNSUPPORTED, "more than 4,000,000 replicas in one topic");
     if (((int64_t)t->n_partitions * t->rf + t->n_brokers - 1) / t->n_brokers > 30000)
         return fail(KAO_ERR_UNSUPPORTED, "more than 30,000 replicas per broker on average (16-bit per-broker counters)");

@@ -134,6 +134,15 @@ def test_validation_errors(ko):
     with pytest.raises(kao.KaoError) as e:
         kao.upper_bound(pt)
     assert e.value.code == -1
+    pt = to_product_topic(ko.readme_example())     # a broker listed twice in one partition of the current assignment
+    pt.current = pt.current.copy()
+    pt.current[4, 1] = pt.current[4, 0]
+    with pytest.raises(kao.KaoError) as e:
+        kao.upper_bound(pt)
+    assert e.value.code == -1 and "twice" in str(e.value)
+    pt.current[4, 1] = 0xFFFF                      # two empty slots are fine
+    pt.current[4, 0] = 0xFFFF
+    kao.upper_bound(pt)
 
 
 def test_json_roundtrip_readme():
