@@ -64,7 +64,8 @@ typedef struct kao_topic {
                                  (README.md:52-63); KAO_NONE = broker not in the target set; a broker may not
                                  appear twice in one partition (KAO_ERR_INVALID) */
     int32_t w[2][2];          /* objective weights w[cur_role][new_role], role 0 leader, 1 follower
-                                 (README.md:145-146); default {{4,1},{2,2}} */
+                                 (README.md:145-146); default {{4,1},{2,2}}; each 0..1023 and
+                                 n_partitions * rf * largest weight < 2^24 */
     /* band right-hand sides; -1 = derive floor/ceil of the average (README.md:159-160,
        164-165, 174-175, 179) */
     int32_t rep_lo, rep_hi;     /* C3 replicas per broker   (README.md:158-161) */

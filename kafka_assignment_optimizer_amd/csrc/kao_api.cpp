@@ -59,6 +59,14 @@ int validate(const kao_topic *t) {
     if (!t->rack_of || !t->current) return fail(KAO_ERR_INVALID, "null rack_of/current");
     for (int b = 0; b < t->n_brokers; ++b)
         if (t->rack_of[b] >= t->n_racks) return fail(KAO_ERR_INVALID, "rack_of entry >= n_racks");
+    int wmax = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            if (t->w[i][j] < 0 || t->w[i][j] > 1023) return fail(KAO_ERR_INVALID, "objective weights must be 0..1023");
+            wmax = std::max(wmax, t->w[i][j]);
+        }
+    if ((int64_t)t->n_partitions * t->rf * wmax > 0xFFFFFE)
+        return fail(KAO_ERR_UNSUPPORTED, "objective can exceed 24 bits (n_partitions * rf * largest weight)");
     for (int p = 0; p < t->n_partitions; ++p) {  // one LP variable per (broker, partition) (README.md:146): a broker cannot be listed twice
         const uint16_t *c = t->current + (size_t)p * t->rf_cur;
         for (int k = 1; k < t->rf_cur; ++k)

@@ -140,6 +140,14 @@ def test_validation_errors(ko):
     with pytest.raises(kao.KaoError) as e:
         kao.upper_bound(pt)
     assert e.value.code == -1 and "twice" in str(e.value)
+    pw = to_product_topic(ko.readme_example())
+    pw.weights = ((4, -1), (2, 2))                 # negative / oversized objective weights
+    with pytest.raises(kao.KaoError) as e:
+        kao.upper_bound(pw)
+    assert e.value.code == -1
+    pw.weights = ((5000, 1), (2, 2))
+    with pytest.raises(kao.KaoError):
+        kao.upper_bound(pw)
     pt.current[4, 1] = 0xFFFF                      # two empty slots are fine
     pt.current[4, 0] = 0xFFFF
     kao.upper_bound(pt)
