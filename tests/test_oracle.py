@@ -273,3 +273,30 @@ def test_dual_subproblem_picks_lie_in_the_candidate_pools(ko, kp):
                 assert set(S[1:]) <= set(G)
                 checked += 1
     assert checked > 300
+
+
+def test_dual_value_is_an_upper_bound_for_any_multipliers(ko, kp):
+    """Weak duality, the claim the certificate rests on: for ARBITRARY multipliers (not ones the iteration produced) the
+    dual value L(a,l,g) = sum of the exact partition subproblems + multiplier x priced band end is >= the HiGHS optimum."""
+    rng = np.random.default_rng(11)
+    cases = [c for c in load_golden("random_wide.json")["cases"] if c["status"] == "optimal"][::5]
+    cases += [c for c in load_golden("random_small.json")["cases"] if c["status"] == "optimal"][::4]
+    n = 0
+    for c in cases:
+        t = ko.random_case_wide(c["seed"]) if "shape" in c else ko.topic_from_dict(c["topic"])
+        bd = t.bounds()
+        B, R = t.n_brokers, t.n_racks
+        for scale in (0, 300, 4096, 20000):
+            a = rng.integers(-scale, scale + 1, B).astype(np.int32)
+            l = rng.integers(-scale, scale + 1, B).astype(np.int32)
+            g = rng.integers(-scale, scale + 1, max(1, R)).astype(np.int32)
+            L = 0
+            for p in range(t.n_partitions):
+                S, G, v = kp.port_dual_partition(t, p, a, l, g)
+                L += v
+            L += int(np.where(a > 0, a.astype(np.int64) * bd["rep_hi"], a.astype(np.int64) * bd["rep_lo"]).sum())
+            L += int(np.where(l > 0, l.astype(np.int64) * bd["lead_hi"], l.astype(np.int64) * bd["lead_lo"]).sum())
+            L += int(np.where(g[:R] > 0, g[:R].astype(np.int64) * bd["rack_hi"], g[:R].astype(np.int64) * bd["rack_lo"]).sum())
+            assert L >= c["objective"] * kp.DB_SCALE, (c["seed"], scale, L / kp.DB_SCALE, c["objective"])
+            n += 1
+    assert n >= 150
