@@ -69,6 +69,24 @@ def allreduce_best(local_keys_u64: np.ndarray, owned: Sequence[int], n_topics: i
     return t.cpu().numpy()
 
 
+def allreduce_bounds(local_bounds: Sequence[int], owned: Sequence[int], n_topics: int, device=None) -> np.ndarray:
+    """Min-allreduce of the per-topic certificates (kao_result.upper_bound).  Every rank's value is a valid upper bound
+    on the topic's optimum (closed-form bound or a Lagrangian dual value), so the smallest one is the best certificate --
+    this matters when a topic is replicated over several GPUs, whose K-bound runs aim at different incumbents.
+    Returns int64 [n_topics] (KEY_NONE where no rank owns the topic)."""
+    import torch
+    import torch.distributed as dist
+
+    full = np.full(n_topics, KEY_NONE, dtype=np.int64)
+    if len(owned):
+        full[np.asarray(owned, dtype=np.int64)] = np.asarray(local_bounds, dtype=np.int64)
+    t = torch.from_numpy(full)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return t.cpu().numpy()
+
+
 def gather_assignments(best: np.ndarray, owned: Sequence[int], local_assignments: Sequence[np.ndarray],
                        rank: int, world: int) -> List[np.ndarray]:
     """Every rank contributes the assignments of the topics it won; rank 0 receives all of them."""
