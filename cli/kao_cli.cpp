@@ -126,7 +126,10 @@ struct TopicData {
     std::fprintf(stderr,
         "usage: kao-cli --current <reassignment.json|-> --broker-list <id,id,...> --racks <racks.json | id:rack,...>\n"
         "               [--rf N] [--weights LL,LF,FL,FF] [--seed S] [--time-limit SEC] [--device D]\n"
-        "               [--no-canonical] [--out <file>] [--report] [--emit-lp <prefix> [--lp-only]]\n");
+        "               [--no-canonical] [--out <file>] [--report] [--require-optimal] [--emit-lp <prefix> [--lp-only]]\n"
+        "exit status: 0 = every topic solved (a warning on stderr marks any plan that is feasible but not PROVEN optimal),\n"
+        "             3 = a topic is infeasible / no feasible plan found, 4 = --require-optimal and a plan was not proven\n"
+        "             optimal (that topic is withheld from the output), 1 = error, 2 = usage\n");
     std::exit(2);
 }
 
@@ -191,7 +194,7 @@ int main(int argc, char **argv) {
     int w[4] = {4, 1, 2, 2};
     unsigned long long seed = 1;
     double time_limit = 10.0;
-    bool canonical = true, report = false, lp_only = false;
+    bool canonical = true, report = false, lp_only = false, require_optimal = false;
     std::string lp_prefix;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -207,6 +210,7 @@ int main(int argc, char **argv) {
         else if (a == "--no-canonical") canonical = false;
         else if (a == "--out") out_path = need("--out");
         else if (a == "--report") report = true;
+        else if (a == "--require-optimal") require_optimal = true;
         else if (a == "--emit-lp") lp_prefix = need("--emit-lp");
         else if (a == "--lp-only") lp_only = true;
         else if (a == "-h" || a == "--help") usage(nullptr);
@@ -292,6 +296,7 @@ int main(int argc, char **argv) {
         rc = kao_solve(topics.data(), (int)topics.size(), &opts, results.data());
         if (rc) throw std::runtime_error(std::string("kao_solve: ") + kao_strerror(rc) + " " + kao_last_error());
         int exit_code = 0;
+        std::vector<char> withheld(tds.size(), 0);
         for (size_t i = 0; i < tds.size(); ++i) {
             if (results[i].status == KAO_STATUS_INFEASIBLE_PROVEN) {
                 char why[256] = "";
@@ -305,6 +310,16 @@ int main(int argc, char **argv) {
                 exit_code = 3;
                 continue;
             }
+            if (results[i].status != KAO_STATUS_OPTIMAL_PROVEN) {
+                // lp_solve only ever returns the exact optimum (README.md:135-136); a plan that is not proven optimal may
+                // move more replicas than necessary, so it is never emitted silently
+                const long long gap = (long long)(results[i].upper_bound - results[i].objective);
+                std::fprintf(stderr, "kao-cli: warning: topic %s: plan is feasible but NOT proven optimal (%s): objective=%lld bound=%lld gap=%lld%s\n",
+                             tds[i].name.c_str(), results[i].status == KAO_STATUS_TIME_LIMIT ? "time limit" : "bound gap",
+                             (long long)results[i].objective, (long long)results[i].upper_bound, gap,
+                             require_optimal ? "; withheld (--require-optimal)" : "");
+                if (require_optimal) { exit_code = exit_code ? exit_code : 4; withheld[i] = 1; continue; }
+            }
             if (canonical) {
                 rc = kao_canonicalize(&topics[i], assigns[i].data());
                 if (rc) throw std::runtime_error(std::string("kao_canonicalize: ") + kao_strerror(rc));
@@ -315,7 +330,7 @@ int main(int argc, char **argv) {
         os << "{\"version\":1,\"partitions\":[";
         bool first = true;
         for (size_t i = 0; i < tds.size(); ++i) {
-            if (results[i].status == KAO_STATUS_NO_FEASIBLE || results[i].status == KAO_STATUS_INFEASIBLE_PROVEN) continue;
+            if (results[i].status == KAO_STATUS_NO_FEASIBLE || results[i].status == KAO_STATUS_INFEASIBLE_PROVEN || withheld[i]) continue;
             const int P = topics[i].n_partitions, RF = topics[i].rf;
             for (int p = 0; p < P; ++p) {
                 os << (first ? "\n" : ",\n") << "    {\"topic\":\"" << tds[i].name << "\",\"partition\":" << tds[i].partition_ids[p] << ",\"replicas\":[";

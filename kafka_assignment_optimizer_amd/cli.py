@@ -29,6 +29,9 @@ def main(argv=None) -> int:
     ap.add_argument("--no-canonical", action="store_true")
     ap.add_argument("--out", default="")
     ap.add_argument("--report", action="store_true")
+    ap.add_argument("--require-optimal", action="store_true",
+                    help="withhold (exit status 4) any topic whose plan is feasible but not PROVEN optimal; "
+                         "without it such plans are emitted with a warning on stderr")
     a = ap.parse_args(argv)
     doc = json.load(sys.stdin if a.current == "-" else open(a.current))
     w = [int(x) for x in a.weights.split(",")]
@@ -43,6 +46,14 @@ def main(argv=None) -> int:
                                           else "no feasible assignment found within the time limit"), file=sys.stderr)
             rc = 3
             continue
+        if r.status != "OPTIMAL_PROVEN":
+            # lp_solve only returns the exact optimum (README.md:135-136): never emit a possibly suboptimal plan silently
+            print(f"warning: topic {t.name}: plan is feasible but NOT proven optimal ({r.status}): objective={r.objective} "
+                  f"bound={r.upper_bound} gap={r.upper_bound - r.objective}"
+                  + ("; withheld (--require-optimal)" if a.require_optimal else ""), file=sys.stderr)
+            if a.require_optimal:
+                rc = rc or 4
+                continue
         ok_topics.append(t)
         assigns.append(r.assignment if a.no_canonical else canonicalize(t, r.assignment))
         if a.report:

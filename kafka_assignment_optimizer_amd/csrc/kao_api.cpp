@@ -75,6 +75,12 @@ int validate(const kao_topic *t) {
                     return fail(KAO_ERR_INVALID, "current assignment lists a broker twice in partition " + std::to_string(p));
     }
     if ((int64_t)t->n_partitions * t->rf > 4000000) return fail(KAO_ERR_UNSUPPORTED, "more than 4,000,000 replicas in one topic");
+    if ((int64_t)t->n_partitions * t->rf_cur > 65535) {  // per-broker counters are 16 + 16 bits (replicas | leaders)
+        std::vector<int32_t> cnt((size_t)t->n_brokers, 0);
+        for (int64_t i = 0, n = (int64_t)t->n_partitions * t->rf_cur; i < n; ++i)
+            if (t->current[i] < t->n_brokers && ++cnt[t->current[i]] > 65535)
+                return fail(KAO_ERR_UNSUPPORTED, "current assignment puts more than 65,535 replicas on one broker (16-bit per-broker counters)");
+    }
     if (((int64_t)t->n_partitions * t->rf + t->n_brokers - 1) / t->n_brokers > 30000)
         return fail(KAO_ERR_UNSUPPORTED, "more than 30,000 replicas per broker on average (16-bit per-broker counters)");
     return KAO_OK;
@@ -724,9 +730,10 @@ int kao_eval_plan_create(const kao_topic *t, kao_eval_plan **out) {
     std::vector<TopicDev> td(1, p->pt.d);
     if ((rc = dev_alloc_copy(&p->d_topic, td)) || (rc = dev_alloc_copy(&p->d_rackof, p->pt.rack_of)) ||
         (rc = dev_alloc_copy(&p->d_curd, p->pt.cur_dense))) { kao_eval_plan_destroy(p); return rc; }
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&p->ev0));
-    HIP_TRY(hipEventCreate(&p->ev1));
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&p->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&p->ev1);
+    if (e != hipSuccess) { kao_eval_plan_destroy(p); return fail(KAO_ERR_HIP, std::string("kao_eval_plan_create: ") + hipGetErrorString(e)); }
     *out = p;
     return KAO_OK;
 }
@@ -744,8 +751,8 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
             const int first = b * cpb;
             map[b] = make_int4(0, first, (int)std::min<int64_t>(cpb, n - first), first);
         }
-        if (p->d_map) HIP_TRY(hipFree(p->d_map));
-        p->d_map = nullptr;
+        p->map_n = -1;  // no valid map until the new one is uploaded
+        if (p->d_map) { int4 *old_map = p->d_map; p->d_map = nullptr; HIP_TRY(hipFree(old_map)); }
         int rc = dev_alloc_copy(&p->d_map, map);
         if (rc) return rc;
         p->map_n = n;
@@ -1256,6 +1263,8 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     if (!s || !target) return fail(KAO_ERR_INVALID, "null argument");
     if (iters < 1) return fail(KAO_ERR_INVALID, "iters < 1");
     HIP_TRY(hipSetDevice(g_device));
+    // the previous launch's H2D copies read the staging vectors below: wait for them before rewriting
+    if (s->stream_bound) HIP_TRY(hipStreamSynchronize(s->stream_bound));
     s->h_dual_ids.clear();
     s->h_dual_target.assign((size_t)s->n_topics, -1);
     int maxB = 0, maxP = 0, maxR = 0;

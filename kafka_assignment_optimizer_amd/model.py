@@ -80,6 +80,9 @@ def assignment_to_json(topics: Sequence[Topic], assigns: Sequence[np.ndarray]) -
     parts = []
     for t, a in zip(topics, assigns):
         a = np.asarray(a).reshape(t.n_partitions, t.rf)
+        if a.size and int(a.max()) >= t.n_brokers:
+            raise ValueError(f"topic {t.name}: assignment has empty / out-of-range slots (a NO_FEASIBLE or "
+                             "INFEASIBLE_PROVEN result carries no plan)")
         for p in range(t.n_partitions):
             pid = p if t.partition_ids is None else int(t.partition_ids[p])
             parts.append({"topic": t.name, "partition": pid,

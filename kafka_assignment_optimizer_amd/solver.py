@@ -311,10 +311,17 @@ def decode_key(key: int) -> tuple:
 
 
 def solve(topics: Sequence[Topic], target_objective: Optional[Sequence[int]] = None, **opts) -> List[Result]:
-    """Whole job (kao_solve): search every topic until proven optimal (or `target_objective[i]` reached,
-    with stop_at_bound=1) / time limit."""
+    """Whole job (kao_solve): search every topic until it is proven optimal (or `target_objective[i]` is reached) or the
+    time limit / `max_launches` runs out.  `stop_at_bound` defaults to 1 here (return as soon as every topic is proven);
+    pass stop_at_bound=0 to keep searching until the limit.
+
+    Result.status: "OPTIMAL_PROVEN" (objective == upper_bound: the answer lp_solve would give, README.md:135-136),
+    "FEASIBLE_BOUND_GAP" / "TIME_LIMIT" (feasible plan, possibly suboptimal: upper_bound - objective is the certified
+    gap), "NO_FEASIBLE" (no plan found; not a proof), "INFEASIBLE_PROVEN" (counting argument: lp_solve's "This problem
+    is infeasible")."""
     topics = list(topics)
     ct = _CTopics(topics)
+    opts.setdefault("stop_at_bound", 1)
     o = _make_opts(**opts)
     if target_objective is not None:
         tgt = (C.c_int64 * len(topics))(*[int(v) for v in target_objective])
