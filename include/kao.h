@@ -90,6 +90,11 @@ typedef struct kao_opts {
     int32_t dual_iters;       /* kao_solve: K-bound (Lagrangian dual bound) iterations per launch for topics whose
                                  feasible incumbent is below the bound; 0 = 128 for the first launch, then adapted to
                                  about 10 ms per launch; < 0 = never run K-bound */
+    int32_t elite_period;     /* every elite_period-th K-search launch, restarts that trail their topic's best feasible
+                                 objective re-seed from that assignment with probability 1/2 ("go with the winners");
+                                 0 = kao_solve: about one penalty period of the largest topic, sessions: never; < 0 = never */
+    int32_t use_prices;       /* kao_solve: feed K-bound's multipliers (rounded to quarters) back into K-search as Lagrangian
+                                 prices of the broker / rack rows (augmented-Lagrangian search); 0 = yes, < 0 = no */
     const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
                                         objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;
@@ -189,6 +194,15 @@ int kao_session_stats(kao_session *s, kao_stats *out);
  * occupies one compute unit per topic and runs beside K-search (kao_session_step); a new launch first waits for the
  * previous K-bound launch (it continues from the multipliers that one left in HBM). */
 int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters);
+/* Search prices.  K-search can carry Lagrangian prices of the coupling rows in its move cost: delta = lam * dViolation
+ * - S * dObjective + S * dPrice, where dPrice is the change of sum_b price_rep[b] * replicas(b) + price_lead[b] * leaders(b)
+ * (price_rep[b] = a[b] + g[rack(b)]).  With near-optimal multipliers the chain steps an improvement needs become neutral.
+ * kao_session_set_prices: a[n_brokers], l[n_brokers], g[n_racks] of one topic from the host (fixed point, 4096 = 1; any
+ * values are valid -- prices steer the search, they never change what is reported).  kao_session_adopt_prices: use what
+ * the last finished K-bound launch exported (its multipliers rounded to the quarter grid) for every topic it covered;
+ * waits for the K-bound launch in flight.  Both take effect from the next kao_session_step. */
+int kao_session_set_prices(kao_session *s, int32_t topic, const int32_t *a, const int32_t *l, const int32_t *g);
+int kao_session_adopt_prices(kao_session *s);
 /* 1 while a K-bound launch is still running, 0 when none is (its results can be read without waiting), < 0 = error. */
 int kao_session_bound_busy(kao_session *s);
 /* Wait for the K-bound launch in flight (if any) and read the certificates back: upper_bound[i] = min(closed-form bound, floor(best dual value));

@@ -22,6 +22,7 @@ class KaoOpts(C.Structure):
                 ("iters_per_launch", C.c_int32), ("max_launches", C.c_int32), ("obj_scale", C.c_int32),
                 ("lam_min", C.c_int32), ("lam_max", C.c_int32), ("period_log2", C.c_int32),
                 ("stop_at_bound", C.c_int32), ("profile", C.c_int32), ("dual_iters", C.c_int32),
+                ("elite_period", C.c_int32), ("use_prices", C.c_int32),
                 ("target_objective", C.POINTER(C.c_int64))]
 
 
@@ -66,6 +67,8 @@ SIGNATURES = {
     "kao_session_restart_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_uint16), _P(C.c_uint16),
                                             _P(C.c_int32)]),
     "kao_session_bound_step": (C.c_int, [C.c_void_p, _P(C.c_int64), C.c_int32]),
+    "kao_session_set_prices": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "kao_session_adopt_prices": (C.c_int, [C.c_void_p]),
     "kao_session_bound_busy": (C.c_int, [C.c_void_p]),
     "kao_session_bounds": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32)]),
     "kao_session_dual_state": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),

@@ -533,6 +533,14 @@ struct kao_session {
     // K-bound: multipliers + directions per topic; targets and workgroup->topic ids (host-written before a launch);
     // read-back block [best_L i64[T]] [info i32[4T]]
     int32_t *d_dual = nullptr;
+    // search prices, double buffered: K-bound launch n exports into half (n & 1) while K-search reads the half of the last
+    // launch whose results the host has merged (price_read); topics K-bound never covered read zeros
+    int32_t *d_price = nullptr;
+    size_t price_half_i32 = 0;
+    int price_read = 0;          // half K-search reads
+    int price_write_last = -1;   // half the K-bound launch in flight (or the last finished one) writes
+    bool priced = false;         // K-search launches carry prices
+    uint16_t *d_int = nullptr;   // dense -> internal broker index per topic
     long long *d_dual_target = nullptr;
     int32_t *d_dual_ids = nullptr;
     unsigned char *d_dual_rb = nullptr;
@@ -540,7 +548,7 @@ struct kao_session {
     uint64_t bound_launches = 0;
     size_t dual_bytes = 0;
     hipStream_t stream_bound = nullptr;   // K-bound runs beside K-search on its own stream (it occupies one CU per topic)
-    hipEvent_t ev_bound0 = nullptr, ev_bound1 = nullptr;
+    hipEvent_t ev_bound0 = nullptr, ev_bound1 = nullptr, ev_search = nullptr;
     bool bound_inflight = false;
     int bound_iters_last = 0;
     double bound_ms_last = 0;
@@ -923,6 +931,7 @@ void kao_session_destroy(kao_session *s) {
     if (s->stream_bound) (void)hipStreamSynchronize(s->stream_bound);
     if (s->ev_bound0) (void)hipEventDestroy(s->ev_bound0);
     if (s->ev_bound1) (void)hipEventDestroy(s->ev_bound1);
+    if (s->ev_search) (void)hipEventDestroy(s->ev_search);
     if (s->stream_bound) (void)hipStreamDestroy(s->stream_bound);
     arena_put(s->arena_ro, s->arena_ro_bytes);
     arena_put(s->arena_rw, s->arena_rw_bytes);
@@ -949,6 +958,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     if (o.period_log2 < 0) o.period_log2 = 0;    // 0 = per topic, by size (auto_period_log2)
     if (o.period_log2 > 20) o.period_log2 = 20;
     if (o.time_limit_s <= 0) o.time_limit_s = 10.0;
+    if (o.elite_period < 0) o.elite_period = 0;  // sessions: 0 = never (kao_solve picks its own default before creating the session)
     const bool auto_restarts = o.restarts <= 0;
     if (auto_restarts) {  // one full round of resident wavefronts (8 per SIMD = 32 per CU) across all topics
         const int want = g_num_cu * 32;
@@ -975,7 +985,8 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->topics.assign(topics, topics + n_topics);
     s->ub.resize((size_t)n_topics);
 
-    std::vector<uint4> cur_pool; std::vector<uint16_t> ext_pool, curd_pool; std::vector<int32_t> rsz_pool;
+    std::vector<uint4> cur_pool; std::vector<uint16_t> ext_pool, curd_pool, int_pool; std::vector<int32_t> rsz_pool;
+    uint64_t price_i32 = 0;
     std::vector<uint8_t> rackof_pool;
     uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0, dual_i32 = 0;
     s->topic_global.assign((size_t)n_topics, 0);
@@ -998,7 +1009,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
             const uint16_t *c = &pt.cur_int[(size_t)p * kRFP];
             cur_pool.push_back(make_uint4(word(c[0]), word(c[1]), word(c[2]), word(c[3])));
         }
-        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false) > 160 * 1024;
+        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true) > 160 * 1024;
         s->topic_global[(size_t)t] = global_a;
         d.ext_off = (uint32_t)ext_pool.size();
         ext_pool.insert(ext_pool.end(), pt.ext_of.begin(), pt.ext_of.end());
@@ -1014,6 +1025,10 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         rackof_pool.insert(rackof_pool.end(), pt.rack_of.begin(), pt.rack_of.end());
         d.curd_off = (uint32_t)curd_pool.size();
         curd_pool.insert(curd_pool.end(), pt.cur_dense.begin(), pt.cur_dense.end());
+        d.int_off = (uint32_t)int_pool.size();
+        int_pool.insert(int_pool.end(), pt.int_of.begin(), pt.int_of.end());
+        d.price_off = (uint32_t)price_i32;
+        price_i32 += 2 * (uint64_t)d.B + kRackTab;
         dual_i32 = (dual_i32 + 1) & ~(uint64_t)1;  // the level-control words are 64-bit
         d.dual_off = (uint32_t)dual_i32;
         dual_i32 += 4 * (uint64_t)d.B + 2 * kRackTab + 8;
@@ -1028,7 +1043,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     auto need1 = [&](int t) {  // topics kept in global memory sort last (their LDS need is tiny but they form their own groups)
         const TopicDev &d = s->pts[(size_t)t].d;
         const bool ga = s->topic_global[(size_t)t] != 0;
-        return (ga ? ((size_t)1 << 40) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga);
+        return (ga ? ((size_t)1 << 40) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true);
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need1(x) < need1(y); });
     std::vector<std::vector<int>> members;
@@ -1046,9 +1061,9 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
             g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B);
         }
         g.global_a = s->topic_global[(size_t)mem[0]] != 0;
-        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a) > 160 * 1024) g.waves /= 2;
+        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true) > 160 * 1024) g.waves /= 2;
         g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true) <= 160 * 1024;
-        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds) > 160 * 1024) {
+        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds) > 160 * 1024) {
             kao_session_destroy(s);
             return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS (about 30,000 padded brokers)");
         }
@@ -1077,10 +1092,11 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
 
     // ---- read-only arena: stage everything on the host, ONE hipMalloc (or a parked arena), ONE H2D copy ----
     struct Sec { const void *src; size_t bytes; size_t off; };
-    Sec secs[8] = {{tds.data(), tds.size() * sizeof(TopicDev), 0}, {smap.data(), smap.size() * sizeof(int2), 0},
+    Sec secs[9] = {{tds.data(), tds.size() * sizeof(TopicDev), 0}, {smap.data(), smap.size() * sizeof(int2), 0},
                    {emap.data(), emap.size() * sizeof(int4), 0}, {cur_pool.data(), cur_pool.size() * sizeof(uint4), 0},
                    {ext_pool.data(), ext_pool.size() * 2, 0}, {rsz_pool.data(), rsz_pool.size() * 4, 0},
-                   {rackof_pool.data(), rackof_pool.size(), 0}, {curd_pool.data(), curd_pool.size() * 2, 0}};
+                   {rackof_pool.data(), rackof_pool.size(), 0}, {curd_pool.data(), curd_pool.size() * 2, 0},
+                   {int_pool.data(), int_pool.size() * 2, 0}};
     size_t ro_bytes = 0;
     for (Sec &sec : secs) { sec.off = ro_bytes; ro_bytes += align_up(sec.bytes); }
     std::vector<unsigned char> stage(ro_bytes);
@@ -1095,6 +1111,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->d_rsz = reinterpret_cast<int32_t *>(ro + secs[5].off);
     s->d_rackof = reinterpret_cast<uint8_t *>(ro + secs[6].off);
     s->d_curd = reinterpret_cast<uint16_t *>(ro + secs[7].off);
+    s->d_int = reinterpret_cast<uint16_t *>(ro + secs[8].off);
 
     // ---- mutable arena ----
     const size_t state_b = align_up(state_bytes), best_b = align_up(best_u16 * 2);
@@ -1105,8 +1122,10 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->readback_bytes = s->rb_assign_off + win_u16 * 2;
     const size_t dual_b = align_up(dual_i32 * 4), dtarget_b = align_up((size_t)n_topics * 8), dids_b = align_up((size_t)n_topics * 4);
     s->dual_rb_bytes = (size_t)n_topics * 24;
+    s->price_half_i32 = align_up(price_i32 * 4) / 4;
+    const size_t price_b = 2 * s->price_half_i32 * 4;
     const size_t rw_bytes = state_b + best_b + info_b + obj_b + viol_b + align_up(s->readback_bytes) + dual_b + dtarget_b + dids_b +
-                            align_up(s->dual_rb_bytes);
+                            align_up(s->dual_rb_bytes) + price_b;
     if ((rc = arena_get(rw_bytes, &s->arena_rw, &s->arena_rw_bytes))) { kao_session_destroy(s); return rc; }
     unsigned char *rw = static_cast<unsigned char *>(s->arena_rw);
     s->d_state = rw;
@@ -1125,7 +1144,8 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         s->d_dual = reinterpret_cast<int32_t *>(q); q += dual_b;
         s->d_dual_target = reinterpret_cast<long long *>(q); q += dtarget_b;
         s->d_dual_ids = reinterpret_cast<int32_t *>(q); q += dids_b;
-        s->d_dual_rb = q;
+        s->d_dual_rb = q; q += align_up(s->dual_rb_bytes);
+        s->d_price = reinterpret_cast<int32_t *>(q);
         s->dual_bytes = dual_b;
         s->dual_flags.assign((size_t)n_topics, 0);
         s->dual_iters.assign((size_t)n_topics, 0);
@@ -1139,6 +1159,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     hipError_t e2 = hipMemsetAsync(s->d_best, 0xFF, best_u16 * 2 ? best_u16 * 2 : 2, s->stream);
     hipError_t e3 = hipMemsetAsync(s->d_readback, 0xFF, (size_t)n_topics * 8, s->stream);
     hipError_t e4 = hipMemsetAsync(s->d_drift, 0, 16, s->stream);
+    if (e4 == hipSuccess) e4 = hipMemsetAsync(s->d_price, 0, price_b ? price_b : 4, s->stream);  // no prices yet
     hipError_t e5 = hipStreamSynchronize(s->stream);  // `stage` is pageable host memory and goes out of scope
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
         kao_session_destroy(s);
@@ -1166,6 +1187,10 @@ int kao_session_step(kao_session *s) {
     SearchParams prm{};
     prm.obj_scale = s->opts.obj_scale; prm.lam_min = s->opts.lam_min; prm.lam_max = s->opts.lam_max;
     prm.launch = s->launch; prm.iters = (uint32_t)s->opts.iters_per_launch; prm.init = s->launch == 0 ? 1 : 0;
+    const int eper = s->opts.elite_period;
+    prm.elite = (eper > 0 && s->launch > 0 && s->launch % (uint32_t)eper == 0) ? 1 : 0;
+    sp.price_pool = s->d_price + (size_t)s->price_read * s->price_half_i32;
+    sp.int_pool = s->d_int; sp.elite_assign = s->d_win_assign; sp.elite_key = s->d_keys;
     EvalPools ep{};
     ep.topics = s->d_topics; ep.rackof_pool = s->d_rackof; ep.curd_pool = s->d_curd;
     ep.cand = s->d_best; ep.objective = s->d_obj; ep.violations = s->d_viol; ep.best_key = s->d_keys;
@@ -1174,7 +1199,7 @@ int kao_session_step(kao_session *s) {
     for (const kao_session::LaunchGroup &g : s->groups) {
         sp.block_map = s->d_smap + g.smap_off;
         prm.maxP = g.maxP; prm.maxBx = g.maxBx;
-        launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->stream);
+        launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, s->stream);
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
@@ -1185,6 +1210,10 @@ int kao_session_step(kao_session *s) {
         HIP_TRY(hipGetLastError());
     }
     if (prof) { HIP_TRY(hipEventRecord(e[2], s->stream)); s->ev_pending++; }
+    if (eper > 0 && (s->launch + 1) % (uint32_t)eper == 0) {  // the next launch is an elite launch: stage every topic's best assignment
+        launch_gather(s->d_topics, s->n_topics, s->d_keys, s->d_best, s->d_viol, s->d_win_assign, s->d_win_viol, s->stream);
+        HIP_TRY(hipGetLastError());
+    }
     for (const PreparedTopic &pt : s->pts) {
         const uint64_t n = neighbours_in_range(prm.launch * prm.iters, prm.iters, pt.d.RF, pt.d.B, pt.d.P) * (uint64_t)pt.d.n_restarts;
         s->delta_total += n;
@@ -1252,7 +1281,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
     for (const kao_session::LaunchGroup &g : s->groups)
-        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a));
+        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced));
     out->launch_groups = (int32_t)s->groups.size();
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));
@@ -1307,6 +1336,19 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     bp.ext_pool = s->d_ext; bp.rsz_pool = s->d_rsz;
     bp.iters = iters; bp.maxB = maxB; bp.maxP = maxP; bp.maxR = maxR;
     bp.cur_in_lds = bound_lds_bytes(maxB, maxP, maxR, true) <= 160 * 1024 ? 1 : 0;
+    if (s->priced) {  // K-search launches already enqueued may still read the half this launch is about to overwrite
+        if (!s->ev_search) HIP_TRY(hipEventCreateWithFlags(&s->ev_search, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(s->ev_search, s->stream));
+        HIP_TRY(hipStreamWaitEvent(s->stream_bound, s->ev_search, 0));
+    }
+    // prices go into the half K-search is NOT reading; kao_session_adopt_prices flips the halves once this launch is done
+    const int wh = s->price_read ^ 1;
+    if (s->price_write_last >= 0 && s->price_write_last != wh)  // keep the prices of topics this launch does not cover
+        HIP_TRY(hipMemcpyAsync(s->d_price + (size_t)wh * s->price_half_i32, s->d_price + (size_t)(wh ^ 1) * s->price_half_i32,
+                               s->price_half_i32 * 4, hipMemcpyDeviceToDevice, s->stream_bound));
+    bp.price_pool = s->d_price + (size_t)wh * s->price_half_i32;
+    bp.export_prices = 1;
+    s->price_write_last = wh;
     // lanes own partitions, wavefronts own racks when the pools are rebuilt: enough wavefronts for either, at most 16
     const int waves = std::min(16, std::max({1, (maxP + 63) / 64, std::min(maxR, 8)}));
     HIP_TRY(hipEventRecord(s->ev_bound0, s->stream_bound));
@@ -1316,6 +1358,33 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     s->bound_inflight = true;
     s->bound_iters_last = iters;
     s->bound_launches++;
+    return KAO_OK;
+}
+
+int kao_session_set_prices(kao_session *s, int32_t topic, const int32_t *a, const int32_t *l, const int32_t *g) {
+    if (!s || topic < 0 || topic >= s->n_topics || !a || !l || !g) return fail(KAO_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(g_device));
+    const TopicDev &d = s->pts[(size_t)topic].d;
+    std::vector<int32_t> buf(2 * (size_t)d.B + kRackTab, 0);
+    std::memcpy(buf.data(), a, (size_t)d.B * 4);
+    std::memcpy(buf.data() + d.B, l, (size_t)d.B * 4);
+    std::memcpy(buf.data() + 2 * (size_t)d.B, g, (size_t)d.R * 4);
+    // both halves, so that a later adopt (which flips them) keeps host-set prices of topics K-bound does not cover
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->stream_bound) HIP_TRY(hipStreamSynchronize(s->stream_bound));
+    for (int h = 0; h < 2; ++h)
+        HIP_TRY(hipMemcpy(s->d_price + (size_t)h * s->price_half_i32 + d.price_off, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+    s->priced = true;
+    return KAO_OK;
+}
+
+int kao_session_adopt_prices(kao_session *s) {
+    if (!s) return fail(KAO_ERR_INVALID, "null session");
+    if (s->price_write_last < 0) return KAO_OK;  // K-bound has not run: nothing to adopt
+    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipStreamSynchronize(s->stream_bound));
+    s->price_read = s->price_write_last;
+    s->priced = true;
     return KAO_OK;
 }
 
@@ -1440,6 +1509,13 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     kao_opts so{};
     if (opts) so = *opts;
     if (so.iters_per_launch <= 0) so.iters_per_launch = 128;  // latency first: the host checks the bound after every launch
+    if (so.elite_period == 0 && topics && n_topics > 0) {  // about one penalty period of the largest topic between elite launches
+        int lg = 8;
+        for (int i = 0; i < n_topics; ++i)
+            lg = std::max(lg, so.period_log2 > 0 ? so.period_log2 : auto_period_log2(topics[i].n_partitions, std::max(topics[i].rf, 1)));
+        so.elite_period = std::max(1, (1 << std::min(lg, 20)) / so.iters_per_launch);
+    }
+    const bool use_prices = so.use_prices >= 0;
     int rc = kao_session_create(topics, n_topics, &so, &s);
     if (rc) return rc;
     g_timing[0] = now_s() - t0;
@@ -1475,6 +1551,8 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
             if (!busy) {
                 if (s->bound_inflight) {
                     if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) { kao_session_destroy(s); return rc; }
+                    // the finished launch's multipliers (rounded to quarters) become the prices of the next K-search launches
+                    if (use_prices && (rc = kao_session_adopt_prices(s))) { kao_session_destroy(s); return rc; }
                     if (s->bound_ms_last > 0) {
                         const double scale = 10.0 / s->bound_ms_last;
                         dual_now = (int)std::min(4096.0, std::max(32.0, s->bound_iters_last * std::min(4.0, std::max(0.25, scale))));

@@ -15,6 +15,8 @@ constexpr int kDBias = 32768;
 constexpr int kDualScale = 4096;          // fixed point of the dual multipliers (K-bound)
 constexpr int kDualStage = 100;           // level control: iterations per stage (K-bound)
 constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
+constexpr int kDualQuarterLog2 = 10;      // kDualScale / 4 = 2^10: the quarter grid of the rounding probes and the search prices
+constexpr int kDualProbes = 2;            // probes per K-bound launch: multipliers rounded to the quarter grid, then the half grid
 constexpr uint32_t kObjCap = 0xFFFFFFu;   // packed best key: viol(20) << 44 | (kObjCap - obj) << 20 | restart(20)
 
 // Device-side descriptor of one topic.  Read once per workgroup (wave-uniform -> SGPRs).
@@ -40,7 +42,10 @@ struct TopicDev {
     uint32_t win_off;            // winners    : first u16 of this topic's winning assignment ([P*RF])
     uint32_t dual_off;           // dual_pool  : first int32 of a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab] lv[8]
     int32_t period_log2;         // penalty sawtooth: restart rho has period 2^(period_log2 + (rho & 3)) iterations
-    int32_t pad_;
+    uint32_t price_off;          // price_pool : first int32 of this topic's search prices pa[B] pl[B] pg[kRackTab] (fixed point
+                                 //              kDualScale, dense broker index); K-bound's epilogue or the host writes them
+    uint32_t int_off;            // int_pool   : dense -> internal broker index (u16[B]); elite re-seeding reads dense snapshots
+    int32_t pad_[3];
 };
 
 struct SearchParams {
@@ -49,6 +54,8 @@ struct SearchParams {
     uint32_t iters;
     int32_t init;                // 1 = build the initial state of every restart first
     int32_t maxP, maxBx;         // LDS carve sizes
+    int32_t elite;               // 1 = restarts that trail their topic's best feasible objective may re-seed from it (KAO-LS
+                                 //     "elite" rule)
 };
 
 struct SearchPools {
@@ -61,6 +68,10 @@ struct SearchPools {
     uint16_t *best_pool;
     int32_t *restart_info;       // [n_restarts_total][4] = {best_obj, V, obj, accepted}
     int32_t *drift;              // [1] counter
+    const int32_t *price_pool;   // search prices (k_search<*, true> only), see TopicDev::price_off
+    const uint16_t *int_pool;    // dense -> internal broker index per topic
+    const uint16_t *elite_assign;// [sum P*RF] every topic's best feasible assignment so far (dense; k_gather's output), at win_off
+    const unsigned long long *elite_key;  // [n_topics] packed key of that assignment as of the previous step (~0 = none)
 };
 
 struct EvalPools {
@@ -90,11 +101,13 @@ struct BoundPools {
     int32_t iters;               // iterations this launch
     int32_t maxB, maxP, maxR;    // LDS carve sizes
     int32_t cur_in_lds;          // 1 = the current assignment (8 B per partition) is staged in LDS too
+    int32_t *price_pool;         // K-bound's epilogue exports the multipliers, rounded to the quarter grid, as search prices
+    int32_t export_prices;       // 1 = do so
 };
 
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a);
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false);
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds);
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, void *stream);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, void *stream);
 void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
 // copy every topic's winning snapshot (restart id in its packed key) and violation row into contiguous
 // read-back buffers: one D2H instead of two per topic

@@ -96,6 +96,24 @@ __device__ __forceinline__ uint32_t make_key(int lam, int S, int dV, int dObj, i
     delta = min(max(delta, -kDBias), kDBias - 2);
     return ((uint32_t)(delta + kDBias) << 8) | (uint32_t)lane;
 }
+// the same keys with a price term dP (Lagrangian prices of the broker rows, already in key units) added to the cost
+__device__ __forceinline__ uint32_t make_key_p(int lam, int S, int dV, int dObj, int dP, int lane) {
+    int delta = __mul24(lam, dV) - __mul24(S, dObj) + dP;
+    delta = min(max(delta, -kDBias), kDBias - 2);
+    return ((uint32_t)(delta + kDBias) << 8) | (uint32_t)lane;
+}
+__device__ __forceinline__ uint32_t make_key_tie_p(int lam, int S, int dV, int dObj, int dP, uint32_t tie) {
+    int delta = __mul24(lam, dV) - __mul24(S, dObj) + dP;
+    delta = min(max(delta, -kDBias), kDBias - 2);
+    return ((uint32_t)(delta + kDBias) << 8) | (tie & 0xFFu);
+}
+// packed search prices of one broker: low half = replica price (a[b] + g[rack]), high half = leader price l[b], key units
+__device__ __forceinline__ int price_rep(uint32_t pr) { return (int)(short)(pr & 0xFFFFu); }
+__device__ __forceinline__ int price_lead(uint32_t pr) { return (int)pr >> 16; }
+__device__ __forceinline__ int price_of(uint32_t pr, bool lead) { return price_rep(pr) + (lead ? price_lead(pr) : 0); }
+// fixed point (kDualScale) -> key units (obj_scale per objective unit), rounded half up, clamped to 16 bits
+__device__ __forceinline__ int price_units(int v, int S) { return min(max((S * v + kDualScale / 2) >> 12, -32767), 32767); }
+
 __device__ __forceinline__ bool in4(const uint4 &a, uint32_t w) {
     return (a.x == w) | (a.y == w) | (a.z == w) | (a.w == w);
 }
@@ -209,7 +227,10 @@ __device__ __forceinline__ void snapshot(const TopicRegs &T, const WaveLds &L, c
 // kGlobalA = true : they stay in global memory (HBM / L2) -- 16 B per partition per restart, updated in place --
 //                   and only the broker / rack tables live in LDS.  Same algorithm, same results; this is what
 //                   lets a single 100k-partition topic run.
-template <bool kGlobalA>
+// kPriced = true : the cost of a move also carries Lagrangian PRICES of the coupling rows (K-bound's multipliers: replicas
+//                   per broker / rack, leaders per broker) -- an augmented-Lagrangian search: with near-optimal prices the
+//                   chain steps an improvement needs (objective down a little, violation unchanged) become neutral moves.
+template <bool kGlobalA, bool kPriced>
 __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -230,7 +251,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const int c_bytes = bx64 * 4;
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
     uint8_t *XR = smem + a_bytes + kRackTab * 4;  // rack of internal index x, 0xFF = padding slot / beyond Bx
-    unsigned char *wb = smem + a_bytes + kRackTab * 4 + bx64 + wave * (a_bytes + c_bytes + kRackTab * 8);  // blockDim.x / 64 waves
+    uint32_t *PR = reinterpret_cast<uint32_t *>(smem + a_bytes + kRackTab * 4 + bx64);  // [bx64] packed prices (kPriced only)
+    const int pr_bytes = kPriced ? c_bytes : 0;
+    unsigned char *wb = smem + a_bytes + kRackTab * 4 + bx64 + pr_bytes + wave * (a_bytes + c_bytes + kRackTab * 8);  // blockDim.x / 64 waves
     const uint4 *cur_words = pl.cur_pool + TD->cur_off;  // host-prepared words x | rack << 16 (0xFFFFFFFF = none)
     const uint4 *CUR;
     if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const uint4 *>(smem);
@@ -248,7 +271,18 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     __syncthreads();
     for (int x = threadIdx.x; x < ((T.Bx + 63) & ~63); x += blockDim.x) {
         const uint32_t r = mulhi((uint32_t)x, T.magic);
-        XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)kRackTab ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
+        const bool valid = x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)kRackTab ? r : 0];
+        XR[x] = valid ? (uint8_t)r : (uint8_t)0xFF;
+        if (kPriced) {  // prices of broker x in key units: replica price a[b] + g[rack] | leader price l[b] << 16
+            uint32_t pr = 0;
+            if (valid) {
+                const int32_t *pp = pl.price_pool + TD->price_off;
+                const int b = pl.ext_pool[TD->ext_off + x];
+                pr = ((uint32_t)price_units(pp[b] + pp[2 * TD->B + (int)r], prm.obj_scale) & 0xFFFFu) |
+                     ((uint32_t)price_units(pp[TD->B + b], prm.obj_scale) << 16);
+            }
+            PR[x] = pr;
+        }
     }
     __syncthreads();
 
@@ -277,10 +311,31 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         }
         best_obj = -1; accepted = 0;
     } else {
-        if (!kGlobalA)
-            for (int p = lane; p < T.P; p += 64) L.A[p] = expand(T, state_packed[p]);
         best_obj = pl.restart_info[g * 4 + 0];
         accepted = pl.restart_info[g * 4 + 3];
+        // Elite rule: a restart whose best feasible objective trails the topic's best (as of the previous step) re-seeds
+        // its state from that assignment with probability 1/2 (hash of seed, restart, launch); the elite's own restart and
+        // the restarts that tie with it keep going, so the population stays diverse.
+        bool reseed = false;
+        if (prm.elite) {
+            const unsigned long long ek = pl.elite_key[bm.x];
+            const int e_obj = (int)kObjCap - (int)((ek >> 20) & 0xFFFFFFull);
+            reseed = ek != ~0ull && (ek >> 44) == 0 && (int)(ek & 0xFFFFFull) != rho && best_obj < e_obj &&
+                     (fmix32(slo ^ ((uint32_t)rho * 0x9E3779B1u) ^ (prm.launch * 0x85EBCA77u) ^ 0xE117Eu) & 1u);
+        }
+        if (reseed) {
+            const uint16_t *ea = pl.elite_assign + TD->win_off;
+            const uint16_t *io = pl.int_pool + TD->int_off;
+            for (int p = lane; p < T.P; p += 64) {
+                uint32_t w[4] = {kNoneW, kNoneW, kNoneW, kNoneW};
+#pragma unroll
+                for (int k = 0; k < kRFP; ++k)
+                    if (k < T.RF) w[k] = to_word(T, io[ea[p * T.RF + k]]);
+                L.A[p] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        } else if (!kGlobalA) {
+            for (int p = lane; p < T.P; p += 64) L.A[p] = expand(T, state_packed[p]);
+        }
     }
     if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own stores visible to every lane's loads
     recount(T, L, lane);
@@ -322,7 +377,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                                  dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
                         if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                         const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
-                        const uint32_t keyx = okx ? make_key_tie(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), tie) : kKeyNull;
+                        uint32_t keyx;
+                        if (kPriced) keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), price_of(PR[x], k == 0), tie) : kKeyNull;
+                        else keyx = okx ? make_key_tie(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), tie) : kKeyNull;
                         if (keyx < key) { key = keyx; xw_l = xw; }
                     }
                     const uint32_t kmin = wave_umin(key);
@@ -390,6 +447,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
                 const int dV_rack_old = ddec(L.K[ro], T.rack_lo, T.rack_hi) + ddec(cnt4(a, ro), T.prack_lo, T.prack_hi);
                 const int rsz_ro = RSZ[ro];
+                const int p_old = kPriced ? price_of(PR[uw & 0xFFFFu], lead) : 0;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint32_t r, jj;
@@ -414,7 +472,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                             dVg += dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
                     }
                     const int dObjg = role_w2(c, xw, wl, wf) - g_old;
-                    const uint32_t keyg = okg ? make_key(lam, S, dVg, dObjg, lane) : kKeyNull;
+                    uint32_t keyg;
+                    if (kPriced) keyg = okg ? make_key_p(lam, S, dVg, dObjg, price_of(PR[x], lead) - p_old, lane) : kKeyNull;
+                    else keyg = okg ? make_key(lam, S, dVg, dObjg, lane) : kKeyNull;
                     if (keyg < key) { key = keyg; vw = xw; dV = dVg; dObj = dObjg; }
                 }
             } else {  // LEADER SWAP inside p: slot 0 <-> slot k, every k = 1..RF-1 is a candidate
@@ -427,7 +487,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const uint32_t xw = kk == 1 ? a.y : (kk == 2 ? a.z : a.w);
                     const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11);
                     const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
-                    const uint32_t keyg = make_key(lam, S, dVg, dObjg, lane);
+                    uint32_t keyg;
+                    if (kPriced) keyg = make_key_p(lam, S, dVg, dObjg, price_lead(PR[xw & 0xFFFFu]) - price_lead(PR[uw & 0xFFFFu]), lane);
+                    else keyg = make_key(lam, S, dVg, dObjg, lane);
                     if (keyg < key) { key = keyg; vw = xw; k = kk; dV = dVg; dObj = dObjg; }
                 }
             }
@@ -463,7 +525,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const int dvl = leadl ? ddec(cl16, T.lead_lo, T.lead_hi) : dinc(cl16, T.lead_lo, T.lead_hi);
                     sc = min(dv7, 0) + min(dvl, 0);
                 }
-                key_o = lane < T_tour ? make_key(lam, S, sc, -g_o, lane) : kKeyNull;
+                if (kPriced) key_o = lane < T_tour ? make_key_p(lam, S, sc, -g_o, type == 0 ? -price_of(PR[oldw_o & 0xFFFFu], leadl) : 0, lane) : kKeyNull;
+                else key_o = lane < T_tour ? make_key(lam, S, sc, -g_o, lane) : kKeyNull;
             };
             score_slot(keyA, pl_, kl_, oldw_l, g_old_l, dvo_l, dvr_l);
             for (int ga = 1; ga < GA; ++ga) {  // large topics: up to 16 slots per lane, the lane keeps its best
@@ -495,6 +558,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t ci = sel4(c, lane & 3);
                 const bool hm_l = (lane < 4) & (ci != kNoneW) & !in4(a, ci);
                 const bool has_missing = __ballot(hm_l) != 0ull;
+                const int p_old = kPriced ? price_of(PR[uw & 0xFFFFu], lead) : 0;
                 for (int base = 0; base < T.Bx; base += 64) {
                     const uint32_t tie = lcg24(rng) >> 8;
                     const uint32_t x = (uint32_t)(base + lane);
@@ -506,7 +570,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     if (lead) dVx += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                     int dObjx = -g_old;
                     if (has_missing) dObjx += role_w2(c, xw, wl, wf);
-                    const uint32_t keyx = okx ? make_key_tie(lam, S, dVx, dObjx, tie) : kKeyNull;
+                    uint32_t keyx;
+                    if (kPriced) keyx = okx ? make_key_tie_p(lam, S, dVx, dObjx, price_of(PR[x], lead) - p_old, tie) : kKeyNull;
+                    else keyx = okx ? make_key_tie(lam, S, dVx, dObjx, tie) : kKeyNull;
                     if (keyx < key) { key = keyx; vw = xw; dV = dVx; dObj = dObjx; }
                 }
             } else {
@@ -514,6 +580,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const int nrp = lead ? 0 : 1;
                 const int cnt_a_ru = cnt4(a, ro);
                 const int cu = (int)(L.C[uw & 0xFFFFu] >> 16);
+                const int pl_u = kPriced ? price_lead(PR[uw & 0xFFFFu]) : 0;
                 // every lane draws; lane 0's value places the window when the topic has more than 512 partitions
                 const int q_draw = (int)rnd24_wide(rng, (uint32_t)T.P);
                 const int q0 = x_windowed ? __builtin_amdgcn_readfirstlane(q_draw) : 0;
@@ -538,17 +605,20 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         const bool ok = okq & (v != uw) & !in4(a, v) & !u_in_b;
                         const int nrq = jj != 0;
                         const int dObjx = role_w(T, c, v, nrp) + (jj == 0 ? u_in_q_lead : u_in_q_fol) - g_old - role_w(T, cb, v, nrq);
-                        int dVx = 0;
+                        int dVx = 0, dPx = 0;
                         if (lead != (jj == 0)) {  // wave-uniform: exactly one of the two slots is a leader slot
                             const int cv = (int)(L.C[v & 0xFFFFu] >> 16);
                             dVx += lead ? (ddec(cu, T.lead_lo, T.lead_hi) + dinc(cv, T.lead_lo, T.lead_hi))
                                         : (ddec(cv, T.lead_lo, T.lead_hi) + dinc(cu, T.lead_lo, T.lead_hi));
+                            if (kPriced) { const int dl = price_lead(PR[v & 0xFFFFu]) - pl_u; dPx = lead ? dl : -dl; }  // the leader moves u -> v or v -> u
                         }
                         const uint32_t rv = v >> 16;
                         if (rv != ro)
                             dVx += ddec(cnt_a_ru, T.prack_lo, T.prack_hi) + dinc(cnt4(a, rv), T.prack_lo, T.prack_hi) +
                                    ddec(cnt4(b, rv), T.prack_lo, T.prack_hi) + dinc(cnt_b_ro, T.prack_lo, T.prack_hi);
-                        const uint32_t keyx = ok ? make_key_tie(lam, S, dVx, dObjx, tie0 + (uint32_t)jj * 0x55u) : kKeyNull;
+                        uint32_t keyx;
+                        if (kPriced) keyx = ok ? make_key_tie_p(lam, S, dVx, dObjx, dPx, tie0 + (uint32_t)jj * 0x55u) : kKeyNull;
+                        else keyx = ok ? make_key_tie(lam, S, dVx, dObjx, tie0 + (uint32_t)jj * 0x55u) : kKeyNull;
                         if (keyx < key) { key = keyx; vw = v; q = qq; j = jj; dV = dVx; dObj = dObjx; }
                     }
                 }
@@ -905,6 +975,8 @@ __device__ __forceinline__ long long wave_sum64(long long v) {
 __device__ __forceinline__ int db_sub(int m, int n, int lo, int hi) {  // element of the subdifferential closest to 0
     return m > 0 ? hi - n : (m < 0 ? lo - n : (n < lo ? lo - n : (n > hi ? hi - n : 0)));
 }
+// nearest multiple of 2^sh (half up; arithmetic shift)
+__device__ __forceinline__ int dual_round(int v, int sh) { return ((v + (1 << (sh - 1))) >> sh) << sh; }
 __device__ __forceinline__ int db_dir(int d_prev, int s) { return 16 * s + (int)(((long long)d_prev * 3) >> 2); }
 __device__ __forceinline__ int db_move(int m, long long step, int d) {
     const long long mag = (step * (d < 0 ? -(long long)d : (long long)d)) >> 16;
@@ -1004,8 +1076,24 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     long long lv_delta = g_lv[0], lv_rec = g_lv[1];
     int lv_since = (int)g_lv[2];
     int flags = 0, it = 0;
-    for (; it < pl.iters; ++it) {
-        const int par = it & 1;
+    // After the last iteration of a launch the dual function is also PROBED at the multipliers rounded to the quarter and to
+    // the half grid (optimal multipliers of this model tend to be small fractions: a subgradient iterate hovers a few
+    // thousandths around them, the rounded point hits them exactly -- drifted 100 x 1000 topic: iterate 7430.6, rounded 7430.0
+    // = the LP optimum).  A probe evaluates L only: no direction update, no step; the iterate is restored afterwards.
+    const int n_steps = pl.iters + kDualProbes;
+    for (int stp = 0; stp < n_steps; ++stp) {
+        const int par = stp & 1;
+        const bool probe = stp >= pl.iters;
+        if (probe) {
+            if (stp == pl.iters) {  // park the iterate in HBM (the epilogue writes the same values again)
+                for (int b = tid; b < B; b += nt) { g_a[b] = A[b]; g_l[b] = LM[b]; }
+                if (tid < R) g_g[tid] = G[tid];
+            }
+            const int sh = stp == pl.iters ? kDualQuarterLog2 : kDualQuarterLog2 + 1;
+            for (int b = tid; b < B; b += nt) { A[b] = dual_round(g_a[b], sh); LM[b] = dual_round(g_l[b], sh); }
+            if (tid < R) G[tid] = dual_round(g_g[tid], sh);
+            __syncthreads();
+        }
         // ---- phase T: per rack, the kTF best followers and kTL best leaders by generic value (one wavefront per rack) ----
         for (int rr = wave; rr < R; rr += nw) {
             const int r = __builtin_amdgcn_readfirstlane(rr);
@@ -1173,7 +1261,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
             if (bad) atomicOr(&ctl[0], 4);
         }
         __syncthreads();
-        if (ctl[0] & 4) { flags |= 4; break; }
+        if (ctl[0] & 4) { if (!probe) flags |= 4; break; }
         // ---- phase B: band terms of L, subgradient s, new direction d = 16 s + floor(3 d_prev / 4) ----
         long long cL = 0, cN = 0, cD = 0;
         for (int b = tid; b < B; b += nt) {
@@ -1181,17 +1269,21 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
             const int sa = db_sub(a_, NR[b], rep_lo, rep_hi), sl = db_sub(l_, NL[b], lead_lo, lead_hi);
             cL += (long long)a_ * (a_ > 0 ? rep_hi : rep_lo) + (long long)l_ * (l_ > 0 ? lead_hi : lead_lo);
             cN += (long long)sa * sa + (long long)sl * sl;
-            const int da = db_dir(g_da[b], sa), dl = db_dir(g_dl[b], sl);
-            g_da[b] = da; g_dl[b] = dl;
-            cD += (long long)da * da + (long long)dl * dl;
+            if (!probe) {
+                const int da = db_dir(g_da[b], sa), dl = db_dir(g_dl[b], sl);
+                g_da[b] = da; g_dl[b] = dl;
+                cD += (long long)da * da + (long long)dl * dl;
+            }
         }
         if (tid < R) {
             const int g_ = G[tid], sg = db_sub(g_, NK[tid], rack_lo, rack_hi);
             cL += (long long)g_ * (g_ > 0 ? rack_hi : rack_lo);
             cN += (long long)sg * sg;
-            const int dg = db_dir(DG[tid], sg);
-            DG[tid] = dg;
-            cD += (long long)dg * dg;
+            if (!probe) {
+                const int dg = db_dir(DG[tid], sg);
+                DG[tid] = dg;
+                cD += (long long)dg * dg;
+            }
         }
         const bool owns = wave * 64 < max(B, R);  // wavefronts without a broker or rack skip the 64-bit reductions
         if (owns) { cL = wave_sum64(cL); cN = wave_sum64(cN); cD = wave_sum64(cD); }
@@ -1205,8 +1297,17 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
         const long long Lv = acc[par * 4 + 0], nrm = acc[par * 4 + 1];
         long long dn = acc[par * 4 + 2];
         if (Lv < best) best = Lv;
-        if (best < (target + 1) * kDualScale) { flags |= 1; ++it; break; }
-        if (nrm == 0) { flags |= 2; ++it; break; }
+        if (probe) {  // a probe only records the value; back to the iterate, counters cleared for the next evaluation
+            for (int b = tid; b < B; b += nt) { A[b] = g_a[b]; LM[b] = g_l[b]; NR[b] = 0; NL[b] = 0; }
+            if (tid < R) { G[tid] = g_g[tid]; NK[tid] = 0; }
+            if (tid < 4) acc[(par ^ 1) * 4 + tid] = 0;
+            if (best < (target + 1) * kDualScale) flags |= 1;
+            __syncthreads();
+            continue;
+        }
+        ++it;
+        if (best < (target + 1) * kDualScale) { flags |= 1; break; }
+        if (nrm == 0) { flags |= 2; break; }
         const bool reset = dn == 0;  // the memory cancelled the subgradient: restart from it
         if (reset) dn = 256 * nrm;
         // level control: aim at the incumbent while the record keeps falling; every kDualStage iterations without half a
@@ -1244,6 +1345,11 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     // ---- epilogue: multipliers and the best dual value go back to HBM for the next launch ----
     for (int b = tid; b < B; b += nt) { g_a[b] = A[b]; g_l[b] = LM[b]; }
     if (tid < R) { g_g[tid] = G[tid]; g_dg[tid] = DG[tid]; }
+    if (pl.export_prices) {  // search prices for K-search: the multipliers on the quarter grid (exact ties between equally priced brokers)
+        int *pp = pl.price_pool + T.price_off;
+        for (int b = tid; b < B; b += nt) { pp[b] = dual_round(A[b], kDualQuarterLog2); pp[B + b] = dual_round(LM[b], kDualQuarterLog2); }
+        if (tid < kRackTab) pp[2 * B + tid] = tid < R ? dual_round(G[tid], kDualQuarterLog2) : 0;
+    }
     if (tid == 0) {
         g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since;
         pl.best_L[topic] = best;
@@ -1255,9 +1361,9 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a) {
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced) {
     const size_t a = global_a ? 0 : (size_t)maxP * 16, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
-    return a + kRackTab * 4 + bx64 + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
+    return a + kRackTab * 4 + bx64 + (priced ? bx64 * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
 }
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 8 + 15) & ~(size_t)15 : 0;
@@ -1267,17 +1373,21 @@ size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds) {
 
 static int g_attr_search = 0, g_attr_eval = 0;
 
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, void *stream) {
-    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, void *stream) {
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced);
     if ((int)lds > g_attr_search) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_search = (int)lds;
     }
-    if (global_a)
-        hipLaunchKernelGGL(k_search<true>, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools, prm);
-    else
-        hipLaunchKernelGGL(k_search<false>, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools, prm);
+    const dim3 grid(n_blocks), block(64 * waves);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (global_a && priced) hipLaunchKernelGGL((k_search<true, true>), grid, block, lds, st, pools, prm);
+    else if (global_a) hipLaunchKernelGGL((k_search<true, false>), grid, block, lds, st, pools, prm);
+    else if (priced) hipLaunchKernelGGL((k_search<false, true>), grid, block, lds, st, pools, prm);
+    else hipLaunchKernelGGL((k_search<false, false>), grid, block, lds, st, pools, prm);
 }
 
 void launch_eval(const EvalPools &pools, int n_blocks, void *stream) {

@@ -251,6 +251,20 @@ class Session:
         _check(_ffi.load().kao_session_bound_step(self._h, tg.ctypes.data_as(C.POINTER(C.c_int64)), int(iters)),
                "kao_session_bound_step")
 
+    def set_prices(self, topic: int, a, l, g):
+        """Search prices of one topic from the host (fixed point, 4096 = 1): a[n_brokers], l[n_brokers], g[n_racks]."""
+        t = self.topics[topic]
+        a = np.ascontiguousarray(a, dtype=np.int32); l = np.ascontiguousarray(l, dtype=np.int32); g = np.ascontiguousarray(g, dtype=np.int32)
+        if a.shape != (t.n_brokers,) or l.shape != (t.n_brokers,) or g.shape[0] < t.n_racks:
+            raise ValueError("a[n_brokers], l[n_brokers], g[n_racks] expected")
+        p32 = C.POINTER(C.c_int32)
+        _check(_ffi.load().kao_session_set_prices(self._h, topic, a.ctypes.data_as(p32), l.ctypes.data_as(p32), g.ctypes.data_as(p32)),
+               "kao_session_set_prices")
+
+    def adopt_prices(self):
+        """From the next step on, K-search carries the prices the last finished K-bound launch exported."""
+        _check(_ffi.load().kao_session_adopt_prices(self._h), "kao_session_adopt_prices")
+
     def bounds(self) -> dict:
         """Certificates: upper_bound = min(closed-form bound, floor(best dual value)); flags / iters per topic."""
         n = len(self.topics)

@@ -111,7 +111,11 @@ typedef struct {
     int best_obj;  /* best feasible objective seen, -1 if none */
     uint16_t *best;/* [P*RF] dense snapshot */
     uint64_t n_eval, n_accept;
+    const int *PA, *PL; /* [Bx] search prices in key units (replica price a[b] + g[rack], leader price l[b]); NULL = unpriced */
 } ls_state;
+static inline int PAx(const ls_state *s, unsigned x) { return s->PA ? s->PA[x] : 0; }
+static inline int PLx(const ls_state *s, unsigned x) { return s->PL ? s->PL[x] : 0; }
+static inline int Pof(const ls_state *s, unsigned x, int lead) { return PAx(s, x) + (lead ? PLx(s, x) : 0); }
 
 static inline uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -226,8 +230,8 @@ static void ls_count_partial(const ls_topic *t, ls_state *s) {
         }
 }
 
-static inline uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t tie) {
-    int delta = lam * dV - S * dObj;
+static inline uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t tie, int dP) {
+    int delta = lam * dV - S * dObj + dP;
     if (delta < -DBIAS) delta = -DBIAS;
     if (delta > DBIAS - 2) delta = DBIAS - 2;
     return ((uint32_t)(delta + DBIAS) << 8) | (tie & 0xFFu);
@@ -261,7 +265,7 @@ static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint3
                            + d_band(rack_count(t, a, rn), +1, t->prack_lo, t->prack_hi);
                     if (k == 0) dV += d_band((int)(s->C[x] >> 16), +1, t->lead_lo, t->lead_hi);
                     const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
-                    const uint32_t key = make_key_tie(pp->lam_max, pp->obj_scale, dV, role_w(t, p, x, k == 0 ? 0 : 1), tie);
+                    const uint32_t key = make_key_tie(pp->lam_max, pp->obj_scale, dV, role_w(t, p, x, k == 0 ? 0 : 1), tie, Pof(s, x, k == 0));
                     if (key < lane_key[l]) { lane_key[l] = key; lane_x[l] = (int)x; }
                 }
             uint32_t best_key = KEY_NULL; int found = -1;
@@ -292,8 +296,8 @@ static inline uint32_t rnd24(uint32_t *s, uint32_t n) {
 }
 #define REPL_G 4 /* candidate brokers per lane in a REPLACE iteration: 2 of any rack, 2 of the old broker's rack */
 
-static inline uint32_t make_key(int lam, int S, int dV, int dObj, uint32_t lane) {
-    int delta = lam * dV - S * dObj;
+static inline uint32_t make_key(int lam, int S, int dV, int dObj, uint32_t lane, int dP) {
+    int delta = lam * dV - S * dObj + dP;
     if (delta < -DBIAS) delta = -DBIAS;
     if (delta > DBIAS - 2) delta = DBIAS - 2;
     return ((uint32_t)(delta + DBIAS) << 8) | lane;
@@ -331,7 +335,7 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
             if (r != ro)
                 dV += dV_rack_old + d_band(s->K[r], +1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, r), +1, t->prack_lo, t->prack_hi);
             const int dObj = role_w(t, p, x, nr) - g_old;
-            const uint32_t key = make_key(lam, S, dV, dObj, lane);
+            const uint32_t key = make_key(lam, S, dV, dObj, lane, Pof(s, x, k == 0) - Pof(s, old, k == 0));
             if (key < best) { best = key; o->type = 0; o->p = p; o->k = k; o->x = x; o->dV = dV; o->dObj = dObj; }
         }
         return best;
@@ -343,7 +347,7 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
         *n_eval += 1;
         const int dObj = role_w(t, p, v, 0) + role_w(t, p, u, 1) - role_w(t, p, u, 0) - role_w(t, p, v, 1);
         const int dV = d_band((int)(s->C[u] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[v] >> 16), +1, t->lead_lo, t->lead_hi);
-        const uint32_t key = make_key(lam, S, dV, dObj, lane);
+        const uint32_t key = make_key(lam, S, dV, dObj, lane, PLx(s, v) - PLx(s, u));
         if (key < best) { best = key; o->type = 2; o->p = p; o->k = k; o->dV = dV; o->dObj = dObj; }
     }
     return best;
@@ -435,7 +439,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 /* an exchange can also change who leads: a leader slot may shed a leader, a follower slot may gain one */
                 const int dvl = d_band((int)(co >> 16), kl == 0 ? -1 : +1, t->lead_lo, t->lead_hi);
                 const int sc = (type == 0) ? dvo + (dvr < 0 ? dvr : 0) : (dv7 < 0 ? dv7 : 0) + (dvl < 0 ? dvl : 0);
-                const uint32_t key = make_key(lam, S, sc, -role_w(t, pl, old, kl == 0 ? 0 : 1), l);
+                const uint32_t key = make_key(lam, S, sc, -role_w(t, pl, old, kl == 0 ? 0 : 1), l, type == 0 ? -Pof(s, old, kl == 0) : 0);
                 if (key < keyA) { keyA = key; p = pl; k = kl; }
               }
             const uint16_t *a = s->A + p * RFP;
@@ -464,7 +468,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                         int dV = dV_old + d_band((int)(cn & 0xFFFF), +1, t->rep_lo, t->rep_hi) + RT[rack_of_x(t, x)];
                         if (k == 0) dV += d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
                         const int dObj = role_w(t, p, x, nr) - g_old;
-                        const uint32_t key = make_key_tie(lam, S, dV, dObj, tie);
+                        const uint32_t key = make_key_tie(lam, S, dV, dObj, tie, Pof(s, x, k == 0) - Pof(s, old, k == 0));
                         if (key < lane_key[l]) { lane_key[l] = key; lane_x[l] = x; lane_dV[l] = dV; lane_dO[l] = dObj; }
                     }
                 for (uint32_t l = 0; l < LANES; ++l)
@@ -503,7 +507,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                             if (ru != rv)
                                 dV += d_band(rack_count(t, a, ru), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, a, rv), +1, t->prack_lo, t->prack_hi)
                                     + d_band(rack_count(t, b, rv), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, b, ru), +1, t->prack_lo, t->prack_hi);
-                            const uint32_t key = make_key_tie(lam, S, dV, dObj, tie0 + (uint32_t)j * 0x55u);
+                            const uint32_t key = make_key_tie(lam, S, dV, dObj, tie0 + (uint32_t)j * 0x55u, ((k == 0) != (j == 0)) ? ((k == 0) ? PLx(s, v) - PLx(s, u) : PLx(s, u) - PLx(s, v)) : 0);
                             if (key < lane_key[l]) { lane_key[l] = key; lane_q[l] = q; lane_j[l] = j; lane_dV[l] = dV; lane_dO[l] = dObj; }
                         }
                     }
@@ -517,6 +521,87 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
         s->n_accept++;
         if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
     }
+}
+
+/* ---- launch-by-launch replay of one restart (sessions with search prices and elite launches) ----
+ * port_extra carries what the device reads at the start of a launch besides the restart's own state:
+ *   search prices (K-bound's multipliers on the quarter grid, or host-set): dense index, fixed point 4096; key units are
+ *   (obj_scale * v + 2048) >> 12 clamped to 16 bits -- replica price a[b] + g[rack(b)], leader price l[b];
+ *   the elite: the topic's best feasible assignment as of the previous step, its objective and its restart.  Elite rule:
+ *   a restart other than the elite's whose best feasible objective is below the elite's re-seeds its state from it when
+ *   bit 0 of fmix32(seed_lo ^ rho * 0x9E3779B1 ^ launch * 0x85EBCA77 ^ 0xE117E) is set. */
+typedef struct {
+    const int32_t *pa, *pl, *pg;
+    const uint16_t *elite;
+    int32_t elite_obj, elite_rho;
+} port_extra;
+typedef struct { const ls_topic *t; ls_state s; port_params pp; uint32_t rho; int *PA, *PL; } ls_runner;
+
+static inline int price_units(int v, int S) {
+    int u = (S * v + 2048) >> 12; /* arithmetic shift: floor */
+    if (u < -32767) u = -32767;
+    if (u > 32767) u = 32767;
+    return u;
+}
+
+void *kao_port_run_create(void *h, const port_params *pp, uint32_t rho) {
+    const ls_topic *t = (const ls_topic *)h;
+    ls_runner *r = (ls_runner *)calloc(1, sizeof(ls_runner));
+    r->t = t; r->pp = *pp; r->rho = rho;
+    r->s.A = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * RFP);
+    r->s.C = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)t->Bx);
+    r->s.best = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * t->RF);
+    memset(r->s.best, 0xFF, sizeof(uint16_t) * (size_t)t->P * t->RF);
+    r->PA = (int *)calloc((size_t)t->Bx, sizeof(int));
+    r->PL = (int *)calloc((size_t)t->Bx, sizeof(int));
+    return r;
+}
+
+void kao_port_run_destroy(void *run) {
+    ls_runner *r = (ls_runner *)run;
+    if (!r) return;
+    free(r->s.A); free(r->s.C); free(r->s.best); free(r->PA); free(r->PL); free(r);
+}
+
+/* One launch (launch 0 builds the initial state first).  n_brokers = dense broker count (length of pa / pl). */
+int kao_port_run_launch(void *run, uint32_t launch, uint32_t iters, const port_extra *ex, int32_t n_brokers) {
+    ls_runner *r = (ls_runner *)run;
+    const ls_topic *t = r->t;
+    ls_state *s = &r->s;
+    s->PA = NULL; s->PL = NULL;
+    if (ex && ex->pa && ex->pl && ex->pg) {
+        for (int b = 0; b < n_brokers; ++b) {
+            const unsigned x = t->int_of[b];
+            r->PA[x] = price_units(ex->pa[b] + ex->pg[rack_of_x(t, x)], r->pp.obj_scale);
+            r->PL[x] = price_units(ex->pl[b], r->pp.obj_scale);
+        }
+        s->PA = r->PA; s->PL = r->PL;
+    }
+    if (launch == 0) ls_init(t, s, &r->pp, r->rho);
+    else if (ex && ex->elite) {
+        const uint32_t slo = (uint32_t)r->pp.seed;
+        const int go = (uint32_t)ex->elite_rho != r->rho && s->best_obj < ex->elite_obj &&
+                       (fmix32(slo ^ (r->rho * 0x9E3779B1u) ^ (launch * 0x85EBCA77u) ^ 0xE117Eu) & 1u);
+        if (go)
+            for (int p = 0; p < t->P; ++p)
+                for (int k = 0; k < RFP; ++k) s->A[p * RFP + k] = k < t->RF ? t->int_of[ex->elite[p * t->RF + k]] : NONE16;
+    }
+    ls_run(t, s, &r->pp, r->rho, launch, iters);
+    return 0;
+}
+
+/* final state (dense, [P*RF]), best snapshot (dense), stats[6] = {best_obj, V, obj, n_eval lo, n_eval hi, n_accept} */
+int kao_port_run_read(void *run, uint16_t *final_dense, uint16_t *best_dense, int64_t stats[6]) {
+    ls_runner *r = (ls_runner *)run;
+    const ls_topic *t = r->t;
+    ls_state *s = &r->s;
+    ls_recount(t, s);
+    for (int p = 0; p < t->P; ++p)
+        for (int k = 0; k < t->RF; ++k) final_dense[p * t->RF + k] = t->ext_of[s->A[p * RFP + k]];
+    memcpy(best_dense, s->best, sizeof(uint16_t) * (size_t)t->P * t->RF);
+    stats[0] = s->best_obj; stats[1] = s->V; stats[2] = s->obj;
+    stats[3] = (int64_t)(s->n_eval & 0xFFFFFFFFu); stats[4] = (int64_t)(s->n_eval >> 32); stats[5] = (int64_t)s->n_accept;
+    return 0;
 }
 
 /* Search one restart from scratch: `launches` launches of `iters` iterations each.
@@ -591,6 +676,8 @@ uint64_t kao_port_search_many(void *h, const port_params *pp, uint32_t rho0, uin
 #define DB_SCALE 4096
 #define DB_CLAMP (1 << 26)
 #define DB_STAGE 100
+#define DB_QUARTER_LOG2 10 /* DB_SCALE / 4: the quarter grid of the rounding probes and of the search prices */
+static inline int32_t db_round(int32_t v, int sh) { return (int32_t)(((v + (1 << (sh - 1))) >> sh) << sh); } /* nearest multiple, half up */
 
 typedef struct { int b[RFP]; int f[RFP]; int r[RFP]; int n; } db_set;
 
@@ -750,6 +837,31 @@ int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int3
         const int64_t step = (gap << 20) / dn;           /* multiplier change = gap * 16 d / |d|^2, 16 fractional bits */
         for (int b = 0; b < B; ++b) { a[b] = db_move(a[b], step, da[b]); l[b] = db_move(l[b], step, dl[b]); }
         for (int r = 0; r < R; ++r) g[r] = db_move(g[r], step, dg[r]);
+    }
+    /* Rounding probes (only when the launch ran all its iterations): the dual function is also evaluated at the
+     * multipliers rounded to the quarter grid and to the half grid -- optimal multipliers of this model tend to be small
+     * fractions, and the rounded point hits them exactly while the subgradient iterate hovers around them.  A probe only
+     * lowers *best_L (any multipliers give a valid bound); the iterate and the directions are left alone. */
+    if (it == iters && !(*flags & 7)) {
+        int32_t *ra = (int32_t *)malloc(sizeof(int32_t) * (size_t)B), *rl = (int32_t *)malloc(sizeof(int32_t) * (size_t)B);
+        int32_t rg[256];
+        for (int sh = DB_QUARTER_LOG2; sh <= DB_QUARTER_LOG2 + 1; ++sh) {
+            for (int b = 0; b < B; ++b) { ra[b] = db_round(a[b], sh); rl[b] = db_round(l[b], sh); }
+            for (int r = 0; r < R; ++r) rg[r] = db_round(g[r], sh);
+            int64_t L = 0;
+            int bad = 0;
+            for (int p = 0; p < P && !bad; ++p) {
+                int S[RFP]; int32_t v;
+                if (db_partition(t, p, ra, rl, rg, S, &v)) bad = 1; else L += v;
+            }
+            if (bad) break;
+            for (int b = 0; b < B; ++b)
+                L += (int64_t)ra[b] * (ra[b] > 0 ? t->rep_hi : t->rep_lo) + (int64_t)rl[b] * (rl[b] > 0 ? t->lead_hi : t->lead_lo);
+            for (int r = 0; r < R; ++r) L += (int64_t)rg[r] * (rg[r] > 0 ? t->rack_hi : t->rack_lo);
+            if (L < *best_L) *best_L = L;
+            if (*best_L < (target + 1) * DB_SCALE) *flags |= 1;
+        }
+        free(ra); free(rl);
     }
 done:
     free(nrep); free(nlead);

@@ -27,6 +27,11 @@ class PortParams(C.Structure):
                 ("lam_max", C.c_int32), ("period_log2", C.c_int32)]
 
 
+class PortExtra(C.Structure):
+    _fields_ = [("pa", C.POINTER(C.c_int32)), ("pl", C.POINTER(C.c_int32)), ("pg", C.POINTER(C.c_int32)),
+                ("elite", C.POINTER(C.c_uint16)), ("elite_obj", C.c_int32), ("elite_rho", C.c_int32)]
+
+
 def build() -> str:
     so = os.path.join(_HERE, "libkao_port.so")
     src = os.path.join(_HERE, "kao_port.c")
@@ -48,6 +53,13 @@ def lib():
         _LIB.kao_port_search.argtypes = [C.c_void_p, C.POINTER(PortParams), C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int64)]
         _LIB.kao_port_search.restype = C.c_int
+        _LIB.kao_port_run_create.argtypes = [C.c_void_p, C.POINTER(PortParams), C.c_uint32]
+        _LIB.kao_port_run_create.restype = C.c_void_p
+        _LIB.kao_port_run_destroy.argtypes = [C.c_void_p]
+        _LIB.kao_port_run_launch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(PortExtra), C.c_int32]
+        _LIB.kao_port_run_launch.restype = C.c_int
+        _LIB.kao_port_run_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int64)]
+        _LIB.kao_port_run_read.restype = C.c_int
         _LIB.kao_port_search_many.argtypes = [C.c_void_p, C.POINTER(PortParams)] + [C.c_uint32] * 5
         _LIB.kao_port_search_many.restype = C.c_uint64
         _LIB.kao_port_dual_partition.argtypes = [C.POINTER(PortTopic), C.c_int] + [C.POINTER(C.c_int32)] * 6
@@ -121,6 +133,72 @@ def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params)
                     n_accept=int(st[5]))
     finally:
         lib().kao_port_ls_destroy(h)
+
+
+class PortRun:
+    """Launch-by-launch replay of one restart (sessions with search prices and elite launches):
+    run = PortRun(topic, seed, rho); run.launch(0, iters, prices=(a, l, g)); run.launch(1, iters, elite=(assign, obj, rho)); run.read()"""
+
+    def __init__(self, topic, seed: int, rho: int, **params):
+        self.topic = topic
+        self._ct = CTopic(topic)
+        self._h = lib().kao_port_ls_create(C.byref(self._ct.s))
+        if not self._h:
+            raise ValueError("unsupported instance (RF > 4 or racks > 255)")
+        pr = dict(DEFAULT_PARAMS)
+        pr.update(params)
+        if pr["period_log2"] is None:
+            pr["period_log2"] = auto_period_log2(topic)
+        self._pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
+                              lam_max=pr["lam_max"], period_log2=pr["period_log2"])
+        self._run = lib().kao_port_run_create(self._h, C.byref(self._pp), rho)
+
+    def launch(self, launch: int, iters: int, prices=None, elite=None):
+        ex = PortExtra()
+        keep = []
+        if prices is not None:
+            a, l, g = (np.ascontiguousarray(v, dtype=np.int32) for v in prices)
+            g = np.concatenate([g, np.zeros(max(0, 256 - len(g)), dtype=np.int32)])
+            keep += [a, l, g]
+            p32 = C.POINTER(C.c_int32)
+            ex.pa, ex.pl, ex.pg = a.ctypes.data_as(p32), l.ctypes.data_as(p32), g.ctypes.data_as(p32)
+        if elite is not None:
+            assign, obj, rho = elite
+            e = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1)
+            keep.append(e)
+            ex.elite = e.ctypes.data_as(C.POINTER(C.c_uint16))
+            ex.elite_obj, ex.elite_rho = int(obj), int(rho)
+        lib().kao_port_run_launch(self._run, launch, iters, C.byref(ex), self.topic.n_brokers)
+
+    def read(self) -> dict:
+        t = self.topic
+        n = t.n_partitions * t.rf
+        fin = np.zeros(n, dtype=np.uint16)
+        best = np.zeros(n, dtype=np.uint16)
+        st = (C.c_int64 * 6)()
+        lib().kao_port_run_read(self._run, fin.ctypes.data_as(C.POINTER(C.c_uint16)), best.ctypes.data_as(C.POINTER(C.c_uint16)), st)
+        return dict(final=fin.reshape(t.n_partitions, t.rf), best=best.reshape(t.n_partitions, t.rf), best_obj=int(st[0]),
+                    V=int(st[1]), obj=int(st[2]), n_eval=int(st[3]) | (int(st[4]) << 32), n_accept=int(st[5]))
+
+    def close(self):
+        if self._run:
+            lib().kao_port_run_destroy(self._run)
+            self._run = None
+        if self._h:
+            lib().kao_port_ls_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def quarter_round(v):
+    """Multipliers on the quarter grid (what K-bound exports as search prices): nearest multiple of 1024, half up."""
+    v = np.asarray(v, dtype=np.int64)
+    return (((v + 512) >> 10) << 10).astype(np.int32)
 
 
 def port_search_throughput(topic, seed: int, n_restarts: int, launches: int, iters: int, threads: int, **params) -> int:

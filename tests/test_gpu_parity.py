@@ -112,6 +112,118 @@ def test_search_replay_bit_exact(kao, ko, kp, cfg, launches, iters):
         assert st["delta_candidates"] * 3 == n_eval * 8  # the host's neighbour count is the replay's count
 
 
+def _tseed(seed, ti):
+    return seed ^ (((ti + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+
+
+def _drifted(ko, cfg, n):
+    """First n topics of BASELINE config `cfg` after a 20 % drift (the instances where prices and elites matter)."""
+    from kafka_assignment_optimizer_amd import synthetic
+    out = []
+    for pt in synthetic.drift(synthetic.make_config(cfg, n_topics=n), 0.2, 1):
+        out.append(ko.Topic(name=pt.name, broker_ids=np.array(pt.broker_ids), rack_of=np.array(pt.rack_of), n_racks=pt.n_racks,
+                            n_partitions=pt.n_partitions, rf=pt.rf, current=np.array(pt.current), weights=pt.weights,
+                            bounds_override=dict(pt.bounds_override)))
+    return out
+
+
+@pytest.mark.parametrize("cfg", [2, 4])
+def test_search_replay_with_prices_bit_exact(kao, ko, kp, cfg):
+    """K-search with Lagrangian prices in the move cost (k_search<*, true>): host-set prices -- random multiples of a
+    quarter, and odd values that exercise the rounding to key units -- replayed bit for bit by the port, init included."""
+    ots = _drifted(ko, cfg, 2)
+    pts = [to_product_topic(t) for t in ots]
+    rng = np.random.default_rng(cfg)
+    prices = []
+    for t in ots:
+        a = rng.integers(-8, 9, t.n_brokers) * 1024
+        l = rng.integers(-4, 5, t.n_brokers) * 1024 + rng.integers(-300, 300, t.n_brokers)   # off-grid on purpose
+        g = rng.integers(-2, 3, t.n_racks) * 1024
+        prices.append((a.astype(np.int32), l.astype(np.int32), g.astype(np.int32)))
+    seed = 0x51CE + cfg
+    with kao.Session(pts, seed=seed, restarts=8, iters_per_launch=150) as s:
+        for ti, pr in enumerate(prices):
+            s.set_prices(ti, *pr)
+        s.step(2)
+        assert s.stats()["drift"] == 0
+        for ti, ot in enumerate(ots):
+            for rho in (0, 5):
+                run = kp.PortRun(ot, _tseed(seed, ti), rho)
+                run.launch(0, 150, prices=prices[ti])
+                run.launch(1, 150, prices=prices[ti])
+                ref = run.read()
+                dev = s.restart_state(ti, rho)
+                assert dev["final"].tolist() == ref["final"].tolist(), (cfg, ti, rho)
+                assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
+                # prices steer the search but never change what is reported: V / obj are the true values
+                obj, viol = ko.verify(ot, dev["final"])
+                assert (obj, int(viol[0])) == (dev["obj"], dev["V"])
+    # zero prices == the unpriced kernel
+    with kao.Session(pts, seed=seed, restarts=8, iters_per_launch=150) as s0, kao.Session(pts, seed=seed, restarts=8, iters_per_launch=150) as s1:
+        for ti, t in enumerate(ots):
+            s1.set_prices(ti, np.zeros(t.n_brokers, np.int32), np.zeros(t.n_brokers, np.int32), np.zeros(t.n_racks, np.int32))
+        s0.step(2); s1.step(2)
+        for ti in range(len(ots)):
+            assert s0.restart_state(ti, 3)["final"].tolist() == s1.restart_state(ti, 3)["final"].tolist()
+
+
+def test_adopted_prices_are_the_rounded_multipliers(kao, ko, kp):
+    """kao_session_adopt_prices: K-search then carries K-bound's multipliers rounded to the quarter grid -- replayed by the
+    port from the multipliers the device reports."""
+    ots = _drifted(ko, 4, 2)
+    pts = [to_product_topic(t) for t in ots]
+    seed = 99
+    with kao.Session(pts, seed=seed, restarts=8, iters_per_launch=100) as s:
+        s.step(1)
+        res = s.best()
+        s.bound_step([max(0, r.objective) for r in res], 60)
+        s.bounds()
+        s.adopt_prices()
+        duals = [s.dual_state(ti) for ti in range(len(ots))]
+        s.step(1)
+        for ti, ot in enumerate(ots):
+            d = duals[ti]
+            pr = (kp.quarter_round(d["a"]), kp.quarter_round(d["l"]), kp.quarter_round(d["g"]))
+            assert np.any(pr[0] != 0) or np.any(pr[1] != 0)
+            run = kp.PortRun(ot, _tseed(seed, ti), 2)
+            run.launch(0, 100)
+            run.launch(1, 100, prices=pr)
+            ref = run.read()
+            dev = s.restart_state(ti, 2)
+            assert dev["final"].tolist() == ref["final"].tolist(), ti
+            assert (dev["best_obj"], dev["V"], dev["obj"]) == (ref["best_obj"], ref["V"], ref["obj"])
+
+
+def test_elite_launch_replay_bit_exact(kao, ko, kp):
+    """Elite launches (every elite_period-th launch trailing restarts may re-seed from the topic's best assignment):
+    the port replays the rule from the best assignment the device reported before that launch."""
+    ots = _drifted(ko, 4, 3)
+    pts = [to_product_topic(t) for t in ots]
+    seed = 4242
+    iters = 120
+    with kao.Session(pts, seed=seed, restarts=16, iters_per_launch=iters, elite_period=2) as s:
+        s.step(2)                      # launches 0, 1
+        res = s.best()                 # what launch 2 (an elite launch) re-seeds from
+        s.step(1)
+        assert s.stats()["drift"] == 0
+        reseeded = 0
+        for ti, ot in enumerate(ots):
+            r = res[ti]
+            assert r.status != "NO_FEASIBLE"
+            for rho in range(16):
+                run = kp.PortRun(ot, _tseed(seed, ti), rho)
+                run.launch(0, iters)
+                run.launch(1, iters)
+                before = run.read()
+                run.launch(2, iters, elite=(r.assignment, r.objective, r.best_restart))
+                ref = run.read()
+                dev = s.restart_state(ti, rho)
+                assert dev["final"].tolist() == ref["final"].tolist(), (ti, rho)
+                assert (dev["best_obj"], dev["V"], dev["obj"]) == (ref["best_obj"], ref["V"], ref["obj"])
+                reseeded += before["best_obj"] < r.objective and ref["best_obj"] >= r.objective
+        assert reseeded > 0            # the rule fired somewhere
+
+
 def test_search_replay_random_small(kao, ko, kp):
     cases = [c for c in load_golden("random_small.json")["cases"]][:16]
     ots = [ko.topic_from_dict(c["topic"]) for c in cases]
@@ -488,14 +600,19 @@ def test_full_config_properties(kao, ko, kp, cfg):
         res = s.best()
         st = s.stats()
     assert st["drift"] == 0 and st["launches"] == 6
-    golden = {i: e["objective"] for i, e in enumerate(load_golden(f"cfg{cfg}.json")["topics"])}
+    full = load_golden(f"cfg{cfg}_full.json")["topics"]   # HiGHS optimum of EVERY topic (tests/golden/make_golden_full.py)
+    assert len(full) == len(ots)
+    for i, e in enumerate(load_golden(f"cfg{cfg}.json")["topics"]):
+        assert e["objective"] == full[i]["objective"]     # the two golden files agree
     again = []
     for i, (ot, r) in enumerate(zip(ots, res)):
         obj, viol = kp.port_eval(ot, r.assignment)
         assert viol[0] == 0, (cfg, i, viol)           # feasible under the independent verifier
         assert obj == r.objective <= r.upper_bound    # reported objective is the true objective
-        if i in golden:
-            assert r.objective == golden[i]
+        assert r.objective == full[i]["objective"], (cfg, i, r.objective, full[i]["objective"])   # == exact optimum, all topics
+        assert r.upper_bound >= full[i]["objective"]  # the certificate never undercuts the exact optimum
+        assert r.status == "OPTIMAL_PROVEN" and r.upper_bound == full[i]["objective"]
+        assert ko.count_moves(ot, r.assignment)[0] == full[i]["moves"][0]   # as few replica moves as the exact solver
         if i < 8:  # idempotence: the solution, fed back as the current assignment, is a fixed point
             t2 = to_product_topic(ot)
             t2.current = r.assignment.copy()
@@ -515,8 +632,12 @@ def test_config5_sample_and_caps(kao, ko, kp):
     for ot, r in zip(ots, res):
         obj, viol = kp.port_eval(ot, r.assignment)
         assert viol[0] == 0 and obj == r.objective
-    ex = ko.solve_exact(ots[0], 120)
-    assert ex.status == "optimal" and res[0].objective == ex.objective
+    full = load_golden("cfg5_full.json")["topics"]        # HiGHS optimum of each of the 64 topics
+    assert len(full) == len(ots)
+    for i, (ot, r) in enumerate(zip(ots, res)):
+        assert r.objective == full[i]["objective"], (i, r.objective, full[i]["objective"])
+        assert r.upper_bound >= full[i]["objective"]
+        assert r.status == "OPTIMAL_PROVEN"
 
 
 def test_determinism(kao, ko):
