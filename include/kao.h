@@ -199,10 +199,12 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
  * (price_rep[b] = a[b] + g[rack(b)]).  With near-optimal multipliers the chain steps an improvement needs become neutral.
  * kao_session_set_prices: a[n_brokers], l[n_brokers], g[n_racks] of one topic from the host (fixed point, 4096 = 1; any
  * values are valid -- prices steer the search, they never change what is reported).  kao_session_adopt_prices: use what
- * the last finished K-bound launch exported (its multipliers rounded to the quarter grid) for every topic it covered;
+ * the last finished K-bound launch exported (the multipliers of its record dual value, rounded to the quarter grid) for every topic it covered;
  * waits for the K-bound launch in flight.  Both take effect from the next kao_session_step. */
 int kao_session_set_prices(kao_session *s, int32_t topic, const int32_t *a, const int32_t *l, const int32_t *g);
 int kao_session_adopt_prices(kao_session *s);
+/* Test hook: the prices K-search currently carries for one topic (zeros until set or adopted); outputs may be NULL. */
+int kao_session_prices(kao_session *s, int32_t topic, int32_t *a, int32_t *l, int32_t *g);
 /* 1 while a K-bound launch is still running, 0 when none is (its results can be read without waiting), < 0 = error. */
 int kao_session_bound_busy(kao_session *s);
 /* Wait for the K-bound launch in flight (if any) and read the certificates back: upper_bound[i] = min(closed-form bound, floor(best dual value));

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -1031,7 +1032,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         price_i32 += 2 * (uint64_t)d.B + kRackTab;
         dual_i32 = (dual_i32 + 1) & ~(uint64_t)1;  // the level-control words are 64-bit
         d.dual_off = (uint32_t)dual_i32;
-        dual_i32 += 4 * (uint64_t)d.B + 2 * kRackTab + 8;
+        dual_i32 += 6 * (uint64_t)d.B + 3 * kRackTab + 8;
         s->dual_ok.push_back(dual_supported(&topics[t]) ? 1 : 0);
         // algorithmic bytes: full evaluation = 2*RF*P + 2*rf_cur*P + B per candidate
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
@@ -1348,6 +1349,7 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
                                s->price_half_i32 * 4, hipMemcpyDeviceToDevice, s->stream_bound));
     bp.price_pool = s->d_price + (size_t)wh * s->price_half_i32;
     bp.export_prices = 1;
+    if (const char *e = std::getenv("KAO_X_PRICE_SRC")) bp.export_prices = std::atoi(e);  // experiment knob
     s->price_write_last = wh;
     // lanes own partitions, wavefronts own racks when the pools are rebuilt: enough wavefronts for either, at most 16
     const int waves = std::min(16, std::max({1, (maxP + 63) / 64, std::min(maxR, 8)}));
@@ -1375,6 +1377,18 @@ int kao_session_set_prices(kao_session *s, int32_t topic, const int32_t *a, cons
     for (int h = 0; h < 2; ++h)
         HIP_TRY(hipMemcpy(s->d_price + (size_t)h * s->price_half_i32 + d.price_off, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
     s->priced = true;
+    return KAO_OK;
+}
+
+int kao_session_prices(kao_session *s, int32_t topic, int32_t *a, int32_t *l, int32_t *g) {
+    if (!s || topic < 0 || topic >= s->n_topics) return fail(KAO_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(g_device));
+    const TopicDev &d = s->pts[(size_t)topic].d;
+    const int32_t *base = s->d_price + (size_t)s->price_read * s->price_half_i32 + d.price_off;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (a) HIP_TRY(hipMemcpy(a, base, (size_t)d.B * 4, hipMemcpyDeviceToHost));
+    if (l) HIP_TRY(hipMemcpy(l, base + d.B, (size_t)d.B * 4, hipMemcpyDeviceToHost));
+    if (g) HIP_TRY(hipMemcpy(g, base + 2 * (size_t)d.B, (size_t)d.R * 4, hipMemcpyDeviceToHost));
     return KAO_OK;
 }
 

@@ -40,7 +40,7 @@ struct TopicDev {
     uint32_t rackof_off;         // rackof_pool: u8[B]
     uint32_t curd_off;           // curd_pool  : u16[P*rf_cur] dense current assignment
     uint32_t win_off;            // winners    : first u16 of this topic's winning assignment ([P*RF])
-    uint32_t dual_off;           // dual_pool  : first int32 of a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab] lv[8]
+    uint32_t dual_off;           // dual_pool  : first int32 of a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab] lv[8] ra[B] rl[B] rg[kRackTab]
     int32_t period_log2;         // penalty sawtooth: restart rho has period 2^(period_log2 + (rho & 3)) iterations
     uint32_t price_off;          // price_pool : first int32 of this topic's search prices pa[B] pl[B] pg[kRackTab] (fixed point
                                  //              kDualScale, dense broker index); K-bound's epilogue or the host writes them
@@ -102,7 +102,7 @@ struct BoundPools {
     int32_t maxB, maxP, maxR;    // LDS carve sizes
     int32_t cur_in_lds;          // 1 = the current assignment (8 B per partition) is staged in LDS too
     int32_t *price_pool;         // K-bound's epilogue exports the multipliers, rounded to the quarter grid, as search prices
-    int32_t export_prices;       // 1 = do so
+    int32_t export_prices;       // 1 = the multipliers of the record dual value, 2 = the last iterate, 0 = no export
 };
 
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false);

@@ -1073,6 +1073,8 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     const long long target = pl.target[topic];
     // level control (every thread keeps the same copy): distance record -> level, record at stage start, iterations in stage
     long long *g_lv = reinterpret_cast<long long *>(gp + 4 * B + 2 * kRackTab);
+    // the multipliers of the record (smallest) dual value: what the search prices are taken from
+    int *g_ra = gp + 4 * B + 2 * kRackTab + 8, *g_rl = g_ra + B, *g_rg = g_rl + B;
     long long lv_delta = g_lv[0], lv_rec = g_lv[1];
     int lv_since = (int)g_lv[2];
     int flags = 0, it = 0;
@@ -1296,7 +1298,11 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
         // ---- phase C: stop tests, Polyak step along d, reset the counters ----
         const long long Lv = acc[par * 4 + 0], nrm = acc[par * 4 + 1];
         long long dn = acc[par * 4 + 2];
-        if (Lv < best) best = Lv;
+        if (Lv < best) {  // a new record (same decision in every thread): keep its multipliers
+            best = Lv;
+            for (int b = tid; b < B; b += nt) { g_ra[b] = A[b]; g_rl[b] = LM[b]; }
+            if (tid < R) g_rg[tid] = G[tid];
+        }
         if (probe) {  // a probe only records the value; back to the iterate, counters cleared for the next evaluation
             for (int b = tid; b < B; b += nt) { A[b] = g_a[b]; LM[b] = g_l[b]; NR[b] = 0; NL[b] = 0; }
             if (tid < R) { G[tid] = g_g[tid]; NK[tid] = 0; }
@@ -1346,9 +1352,14 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     for (int b = tid; b < B; b += nt) { g_a[b] = A[b]; g_l[b] = LM[b]; }
     if (tid < R) { g_g[tid] = G[tid]; g_dg[tid] = DG[tid]; }
     if (pl.export_prices) {  // search prices for K-search: the multipliers on the quarter grid (exact ties between equally priced brokers)
+        // export_prices 1: the record multipliers (own stores of this thread, or of an earlier launch); 2: the last iterate
         int *pp = pl.price_pool + T.price_off;
-        for (int b = tid; b < B; b += nt) { pp[b] = dual_round(A[b], kDualQuarterLog2); pp[B + b] = dual_round(LM[b], kDualQuarterLog2); }
-        if (tid < kRackTab) pp[2 * B + tid] = tid < R ? dual_round(G[tid], kDualQuarterLog2) : 0;
+        const bool rec = pl.export_prices == 1;
+        for (int b = tid; b < B; b += nt) {
+            pp[b] = dual_round(rec ? g_ra[b] : A[b], kDualQuarterLog2);
+            pp[B + b] = dual_round(rec ? g_rl[b] : LM[b], kDualQuarterLog2);
+        }
+        if (tid < kRackTab) pp[2 * B + tid] = tid < R ? dual_round(rec ? g_rg[tid] : G[tid], kDualQuarterLog2) : 0;
     }
     if (tid == 0) {
         g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since;

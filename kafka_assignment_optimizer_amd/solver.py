@@ -261,6 +261,15 @@ class Session:
         _check(_ffi.load().kao_session_set_prices(self._h, topic, a.ctypes.data_as(p32), l.ctypes.data_as(p32), g.ctypes.data_as(p32)),
                "kao_session_set_prices")
 
+    def prices(self, topic: int) -> tuple:
+        """(a, l, g): the search prices K-search currently carries for one topic."""
+        t = self.topics[topic]
+        a = np.zeros(t.n_brokers, dtype=np.int32); l = np.zeros(t.n_brokers, dtype=np.int32); g = np.zeros(t.n_racks, dtype=np.int32)
+        p32 = C.POINTER(C.c_int32)
+        _check(_ffi.load().kao_session_prices(self._h, topic, a.ctypes.data_as(p32), l.ctypes.data_as(p32), g.ctypes.data_as(p32)),
+               "kao_session_prices")
+        return a, l, g
+
     def adopt_prices(self):
         """From the next step on, K-search carries the prices the last finished K-bound launch exported."""
         _check(_ffi.load().kao_session_adopt_prices(self._h), "kao_session_adopt_prices")

@@ -775,8 +775,18 @@ static inline int32_t db_move(int32_t m, int64_t step, int32_t d) {
  * direction; lv[3] level-control state, zeros to start; *best_L), all in/out (zeros and INT64_MAX to start).  Needs P*RF <= 2^17 and P*RF*max(w) <= 2^19 (32-bit
  * headroom of the priced values).  flags: 1 = closed (best_L < (target+1)*DB_SCALE), 2 = zero subgradient (dual optimum reached),
  * 4 = a partition subproblem is infeasible (no bound).  Returns the number of iterations performed. */
+int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, int32_t *a, int32_t *l, int32_t *g,
+                            int32_t *da, int32_t *dl, int32_t *dg, int64_t *lv, int64_t *best_L, int32_t *flags,
+                            int32_t *ra, int32_t *rl_, int32_t *rg_);
 int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int32_t *a, int32_t *l, int32_t *g,
                         int32_t *da, int32_t *dl, int32_t *dg, int64_t *lv, int64_t *best_L, int32_t *flags) {
+    return kao_port_dual_bound_rec(t, target, iters, a, l, g, da, dl, dg, lv, best_L, flags, NULL, NULL, NULL);
+}
+/* ra / rl_ / rg_ (may be NULL): the multipliers at the record (smallest) dual value, in/out -- what the device exports,
+ * rounded to the quarter grid, as search prices. */
+int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, int32_t *a, int32_t *l, int32_t *g,
+                            int32_t *da, int32_t *dl, int32_t *dg, int64_t *lv, int64_t *best_L, int32_t *flags,
+                            int32_t *ra, int32_t *rl_, int32_t *rg_) {
     const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
     int32_t *nrep = (int32_t *)malloc(sizeof(int32_t) * (size_t)B), *nlead = (int32_t *)malloc(sizeof(int32_t) * (size_t)B);
     int32_t nrack[256];
@@ -810,7 +820,10 @@ int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int3
             dg[r] = db_dir(dg[r], sg);
             dn += (int64_t)dg[r] * dg[r];
         }
-        if (L < *best_L) *best_L = L;
+        if (L < *best_L) {
+            *best_L = L;
+            if (ra) { memcpy(ra, a, sizeof(int32_t) * (size_t)B); memcpy(rl_, l, sizeof(int32_t) * (size_t)B); memcpy(rg_, g, sizeof(int32_t) * (size_t)R); }
+        }
         if (*best_L < (target + 1) * DB_SCALE) { *flags |= 1; ++it; break; }
         if (nrm == 0) { *flags |= 2; ++it; break; }
         if (dn == 0) {                                    /* the memory cancelled the subgradient: restart from it */
@@ -843,25 +856,28 @@ int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int3
      * fractions, and the rounded point hits them exactly while the subgradient iterate hovers around them.  A probe only
      * lowers *best_L (any multipliers give a valid bound); the iterate and the directions are left alone. */
     if (it == iters && !(*flags & 7)) {
-        int32_t *ra = (int32_t *)malloc(sizeof(int32_t) * (size_t)B), *rl = (int32_t *)malloc(sizeof(int32_t) * (size_t)B);
+        int32_t *qa = (int32_t *)malloc(sizeof(int32_t) * (size_t)B), *ql = (int32_t *)malloc(sizeof(int32_t) * (size_t)B);
         int32_t rg[256];
         for (int sh = DB_QUARTER_LOG2; sh <= DB_QUARTER_LOG2 + 1; ++sh) {
-            for (int b = 0; b < B; ++b) { ra[b] = db_round(a[b], sh); rl[b] = db_round(l[b], sh); }
+            for (int b = 0; b < B; ++b) { qa[b] = db_round(a[b], sh); ql[b] = db_round(l[b], sh); }
             for (int r = 0; r < R; ++r) rg[r] = db_round(g[r], sh);
             int64_t L = 0;
             int bad = 0;
             for (int p = 0; p < P && !bad; ++p) {
                 int S[RFP]; int32_t v;
-                if (db_partition(t, p, ra, rl, rg, S, &v)) bad = 1; else L += v;
+                if (db_partition(t, p, qa, ql, rg, S, &v)) bad = 1; else L += v;
             }
             if (bad) break;
             for (int b = 0; b < B; ++b)
-                L += (int64_t)ra[b] * (ra[b] > 0 ? t->rep_hi : t->rep_lo) + (int64_t)rl[b] * (rl[b] > 0 ? t->lead_hi : t->lead_lo);
+                L += (int64_t)qa[b] * (qa[b] > 0 ? t->rep_hi : t->rep_lo) + (int64_t)ql[b] * (ql[b] > 0 ? t->lead_hi : t->lead_lo);
             for (int r = 0; r < R; ++r) L += (int64_t)rg[r] * (rg[r] > 0 ? t->rack_hi : t->rack_lo);
-            if (L < *best_L) *best_L = L;
+            if (L < *best_L) {
+                *best_L = L;
+                if (ra) { memcpy(ra, qa, sizeof(int32_t) * (size_t)B); memcpy(rl_, ql, sizeof(int32_t) * (size_t)B); memcpy(rg_, rg, sizeof(int32_t) * (size_t)R); }
+            }
             if (*best_L < (target + 1) * DB_SCALE) *flags |= 1;
         }
-        free(ra); free(rl);
+        free(qa); free(ql);
     }
 done:
     free(nrep); free(nlead);

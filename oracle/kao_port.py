@@ -67,6 +67,8 @@ def lib():
         _LIB.kao_port_dual_bound.argtypes = [C.POINTER(PortTopic), C.c_int64, C.c_int32] + [C.POINTER(C.c_int32)] * 6 + [
             C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         _LIB.kao_port_dual_bound.restype = C.c_int
+        _LIB.kao_port_dual_bound_rec.argtypes = _LIB.kao_port_dual_bound.argtypes + [C.POINTER(C.c_int32)] * 3
+        _LIB.kao_port_dual_bound_rec.restype = C.c_int
     return _LIB
 
 
@@ -235,6 +237,9 @@ class DualState:
         self.dl = np.zeros_like(self.l)
         self.dg = np.zeros_like(self.g)
         self.lv = np.zeros(3, dtype=np.int64)   # level control: delta, record at stage start, iterations in stage
+        self.ra = np.zeros_like(self.a)         # multipliers at the record dual value (exported, rounded, as search prices)
+        self.rl = np.zeros_like(self.l)
+        self.rg = np.zeros_like(self.g)
         self.best_L = INT64_MAX
         self.iters = 0
         self.flags = 0
@@ -251,9 +256,10 @@ def port_dual_bound(topic, target: int, iters: int, state: DualState = None) -> 
     bl = C.c_int64(st.best_L)
     fl = C.c_int32(0)
     p32 = C.POINTER(C.c_int32)
-    n = lib().kao_port_dual_bound(C.byref(ct.s), int(target), int(iters), st.a.ctypes.data_as(p32), st.l.ctypes.data_as(p32),
-                                  st.g.ctypes.data_as(p32), st.da.ctypes.data_as(p32), st.dl.ctypes.data_as(p32),
-                                  st.dg.ctypes.data_as(p32), st.lv.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(bl), C.byref(fl))
+    n = lib().kao_port_dual_bound_rec(C.byref(ct.s), int(target), int(iters), st.a.ctypes.data_as(p32), st.l.ctypes.data_as(p32),
+                                      st.g.ctypes.data_as(p32), st.da.ctypes.data_as(p32), st.dl.ctypes.data_as(p32),
+                                      st.dg.ctypes.data_as(p32), st.lv.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(bl), C.byref(fl),
+                                      st.ra.ctypes.data_as(p32), st.rl.ctypes.data_as(p32), st.rg.ctypes.data_as(p32))
     st.best_L = int(bl.value)
     st.iters += int(n)
     st.flags = int(fl.value)

@@ -1,5 +1,5 @@
-/* Minimal stand-in for <jni.h>: just enough declarations to COMPILE-CHECK the JNI shim printed in INTEGRATION.md
- * (tests/test_host.py::test_jni_shim_in_integration_md_compiles).  No JDK exists in the build image; this is test
+/* Minimal stand-in for <jni.h>: just enough declarations to COMPILE-CHECK the JNI shim cli/java/kao_jni.c
+ * (tests/test_host.py::test_jni_shim_compiles).  No JDK exists in the build image; this is test
  * scaffolding, not a JNI implementation -- types and the few JNIEnv members the shim uses, with their real signatures. */
 #ifndef KAO_TEST_JNI_STUB_H
 #define KAO_TEST_JNI_STUB_H
@@ -15,6 +15,7 @@ typedef void *jobject;
 typedef jobject jclass;
 typedef jobject jarray;
 typedef jarray jintArray, jlongArray, jbyteArray, jshortArray;
+typedef jobject jstring;
 #define JNIEXPORT
 #define JNICALL
 struct JNINativeInterface_;
@@ -24,6 +25,8 @@ struct JNINativeInterface_ {
     jint (*ThrowNew)(JNIEnv *, jclass, const char *);
     jsize (*GetArrayLength)(JNIEnv *, jarray);
     jintArray (*NewIntArray)(JNIEnv *, jsize);
+    jlongArray (*NewLongArray)(JNIEnv *, jsize);
+    jstring (*NewStringUTF)(JNIEnv *, const char *);
     void (*GetByteArrayRegion)(JNIEnv *, jbyteArray, jsize, jsize, jbyte *);
     void (*GetShortArrayRegion)(JNIEnv *, jshortArray, jsize, jsize, jshort *);
     void (*GetIntArrayRegion)(JNIEnv *, jintArray, jsize, jsize, jint *);

@@ -168,8 +168,8 @@ def test_search_replay_with_prices_bit_exact(kao, ko, kp, cfg):
 
 
 def test_adopted_prices_are_the_rounded_multipliers(kao, ko, kp):
-    """kao_session_adopt_prices: K-search then carries K-bound's multipliers rounded to the quarter grid -- replayed by the
-    port from the multipliers the device reports."""
+    """kao_session_adopt_prices: K-search then carries the multipliers of K-bound's record dual value rounded to the quarter
+    grid (checked against the port's replay of that K-bound launch), and the priced launch is replayed by the port."""
     ots = _drifted(ko, 4, 2)
     pts = [to_product_topic(t) for t in ots]
     seed = 99
@@ -179,12 +179,14 @@ def test_adopted_prices_are_the_rounded_multipliers(kao, ko, kp):
         s.bound_step([max(0, r.objective) for r in res], 60)
         s.bounds()
         s.adopt_prices()
-        duals = [s.dual_state(ti) for ti in range(len(ots))]
         s.step(1)
         for ti, ot in enumerate(ots):
-            d = duals[ti]
-            pr = (kp.quarter_round(d["a"]), kp.quarter_round(d["l"]), kp.quarter_round(d["g"]))
+            st = kp.port_dual_bound(ot, max(0, res[ti].objective), 60)   # the port's replay of the same K-bound launch
+            pr = s.prices(ti)
             assert np.any(pr[0] != 0) or np.any(pr[1] != 0)
+            # exported = the multipliers of the record dual value, rounded to the quarter grid
+            assert (pr[0].tolist(), pr[1].tolist(), pr[2].tolist()) == \
+                   (kp.quarter_round(st.ra).tolist(), kp.quarter_round(st.rl).tolist(), kp.quarter_round(st.rg)[:ot.n_racks].tolist())
             run = kp.PortRun(ot, _tseed(seed, ti), 2)
             run.launch(0, 100)
             run.launch(1, 100, prices=pr)

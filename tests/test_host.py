@@ -106,19 +106,31 @@ def test_wide_family_host_bound_and_infeasibility(ko):
     assert n_opt >= 150 and n_inf >= 150
 
 
-def test_jni_shim_in_integration_md_compiles(tmp_path):
-    """The JNI shim shown in INTEGRATION.md is real C against include/kao.h: it compiles (no JDK here, so against
-    tests/jni_stub/jni.h, which declares the JNIEnv members it uses with their real signatures) with -Wall -Werror."""
+def test_jni_shim_compiles():
+    """cli/java/kao_jni.c is real C against include/kao.h: it compiles (no JDK here, so against tests/jni_stub/jni.h, which
+    declares the JNIEnv members it uses with their real signatures) with -Wall -Wextra -Werror, and it exports one
+    Java_io_sqooba_kao_Kao_<name> per native method io/sqooba/kao/Kao.java declares."""
     import re
     import subprocess
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    blocks = re.findall(r"```c\n(.*?)```", text, flags=re.S)
-    shim = [b for b in blocks if "Java_io_sqooba_kao_Kao_solve" in b]
-    assert len(shim) == 1
-    src = tmp_path / "kao_jni.c"
-    src.write_text(shim[0])
-    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-fsyntax-only",
-                           "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I", os.path.join(ROOT, "include"), str(src)])
+    src = os.path.join(ROOT, "cli", "java", "kao_jni.c")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                           "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I", os.path.join(ROOT, "include"), src])
+    java = open(os.path.join(ROOT, "cli", "java", "io", "sqooba", "kao", "Kao.java")).read()
+    natives = set(re.findall(r"public static native [\w\[\]]+ (\w+)\(", java))
+    exported = set(re.findall(r"Java_io_sqooba_kao_Kao_(\w+)\(", open(src).read()))
+    assert natives == exported == {"init", "solve", "evaluate", "canonicalize", "checkInfeasible"}
+
+
+def test_java_cli_mirrors_the_cpp_cli_flags():
+    """The Java CLI cannot be compiled here (no JDK); at least its flag set is held to the C++ CLI's (minus the host-only
+    LP export) and its JSON output statement to the README shape (README.md:67-78)."""
+    import re
+    cpp = open(os.path.join(ROOT, "cli", "kao_cli.cpp")).read()
+    java = open(os.path.join(ROOT, "cli", "java", "io", "sqooba", "kao", "KaoCli.java")).read()
+    cpp_flags = set(re.findall(r'a == "(--[a-z-]+)"', cpp))
+    java_flags = set(re.findall(r'case "(--[a-z-]+)"', java))
+    assert cpp_flags - java_flags == {"--emit-lp", "--lp-only"} and java_flags <= cpp_flags
+    assert '{\\"version\\":1,\\"partitions\\":[' in java and "Kao.solve(" in java and "Kao.canonicalize(" in java
 
 
 def test_validation_errors(ko):
