@@ -7,27 +7,33 @@ of 50 brokers), at 1/2/4/8 GPUs.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over this rank's topics: one K-search launch (iters_per_launch
-local-search iterations x 64 neighbours for every restart of every topic) + one K-eval launch (full
-evaluation of every restart's best snapshot, wavefront/workgroup min-reduce into one packed key per
-topic) + the host read-back of those keys [+ for N > 1 the RCCL min-allreduce of the global best].
-Topics shard across ranks (independent sub-problems, README.md:146-184) and every rank fills its
-own GPU with restarts, so per-GPU work is fixed as N grows: "scaling": "weak".
+One step = one pass of the hot path over ONE FRESH BATCH of synthetic input: the config-4 cluster after a 20 % drift
+(synthetic.drift, a different drift seed for every step), i.e. 200 reassignment problems nobody has solved yet, all
+resident in HBM before the timed region.  A step runs, for this rank's topics, one K-search launch (best-insertion init +
+iters_per_launch local-search iterations for every restart of every topic) + one K-eval launch (full evaluation of every
+restart's best snapshot, wavefront/workgroup min-reduce into one packed key per topic) + the host read-back of those keys
+[+ for N > 1 the min-allreduce of the global best over RCCL].  (Round 1 timed 20 launches on ONE batch, i.e. mostly on
+topics that were already solved; that figure is still reported, as `steady_state`.)
+Topics shard across ranks (independent sub-problems, README.md:146-184) and every rank fills its own GPU with
+restarts, so per-GPU work is fixed as N grows: "scaling": "weak".
 
-value = (delta-evaluated neighbours + fully evaluated candidates) of ALL ranks / wall time of the K
-timed steps (max over ranks).  Inputs (instance tables, restart states) are resident in HBM before
-the timed region.  Prints ONE JSON line on rank 0.
+value = (delta-evaluated neighbours + fully evaluated candidates) of ALL ranks / wall time of the K timed steps (max over
+ranks); `value_non_null` discounts the null proposals (same proposals as the scalar replay, which counts them).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+LDS_PEAK_GBS = 256 * 128 * 2.4   # 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s for ds_read_b128-class accesses (guide, LDS table)
 
 
 def host_cores() -> int:
@@ -50,10 +56,23 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(topics, restarts, iters, budget_s=15.0):
-    """The oracle's scalar C port of the same search (oracle/kao_port.c), on every host core, on a
-    bounded sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
+def _exact_one(args):
+    """(process-pool worker) HiGHS on the README model of one topic; returns (seconds, objective or None)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import kao_oracle as ko
+    d, limit = args
+    t = ko.topic_from_dict(d)
+    t0 = time.perf_counter()
+    ex = ko.solve_exact(t, limit)
+    return time.perf_counter() - t0, ex.objective if ex.status == "optimal" else None
+
+
+def cpu_baseline(topics, restarts, iters, budget_s=12.0, exact_budget_s=45.0):
+    """The oracle's scalar C port of the same search (oracle/kao_port.c), on every host core, on a bounded sample of the
+    same workload, and the exact CPU solver (HiGHS; lp_solve is not installed) over the bench topics with a process pool.
+    This is the ONLY place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import multiprocessing as mp
     import kao_oracle as ko
     import kao_port as kp
 
@@ -70,6 +89,7 @@ def cpu_baseline(topics, restarts, iters, budget_s=15.0):
         n1 += kp.port_search(ots[0], 1, k1 & 1023, 1, iters)["n_eval"]
         k1 += 1
     rate1 = n1 / (time.perf_counter() - t0)
+    non_null = sum(kp.port_valid_fraction(ots[i % len(ots)], 1, i, 1, iters) for i in range(8)) / 8
     cores = host_cores()
     n_eval = 0
     done_topics = 0
@@ -84,30 +104,76 @@ def cpu_baseline(topics, restarts, iters, budget_s=15.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    # exact CPU solve (HiGHS on the README model; lp_solve itself is not installed) of one topic
+    # exact CPU solve of the bench topics: HiGHS (scipy.optimize.milp) on the README model, one process per core
     te = time.perf_counter()
-    ex = ko.solve_exact(ots[0], 120)
-    exact_s = time.perf_counter() - te
+    secs, objs, n_done = [], [], 0
+    with mp.Pool(min(cores, len(ots))) as pool:
+        it = pool.imap(_exact_one, [(ko.topic_to_dict(t), 120.0) for t in ots])
+        for _ in range(len(ots)):
+            try:
+                s, o = it.next(timeout=max(1.0, exact_budget_s - (time.perf_counter() - te)))
+            except mp.TimeoutError:
+                break
+            secs.append(s); objs.append(o); n_done += 1
+        pool.terminate()
+    exact_wall = time.perf_counter() - te
     return {"value": n_eval / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
             "sample": f"{done_topics} topic passes (of the {len(ots)}-topic list, repeated) x {per_call} restarts x {iters} iterations, "
                       f"oracle/kao_port.c scalar replay of the same search on {cores} native host threads, {dt:.1f} s",
-            "value_one_thread": rate1,
+            "value_one_thread": rate1, "non_null_fraction": non_null,
             "exact_solver": "HiGHS (scipy.optimize.milp) on the README model; lp_solve 5.5 not installed",
-            "exact_seconds_per_topic": exact_s, "exact_objective_topic0": ex.objective}
+            "exact_topics_solved": n_done, "exact_topics_total": len(ots), "exact_pool_processes": min(cores, len(ots)),
+            "exact_wall_seconds": exact_wall, "exact_cpu_seconds_sum": sum(secs),
+            "exact_cpu_seconds_per_topic_mean": (sum(secs) / n_done) if n_done else None,
+            "exact_seconds_total_all_topics_est": (sum(secs) / n_done * len(ots) / min(cores, len(ots))) if n_done else None,
+            "exact_objectives": objs}
 
 
-def load_profile_constants(config, iters, restarts_total):
+def load_profile_constants(tag, iters, restarts_total):
     """Per-launch PMC figures of the committed rocprofv3 run of THIS command (profiles/pmc_constants.json);
     returned only when workload, iterations and restart count match, else None (-> traffic: null)."""
     path = os.path.join(ROOT, "profiles", "pmc_constants.json")
     try:
         with open(path) as f:
             for e in json.load(f):
-                if e["config"] == config and e["iters_per_launch"] == iters and e["restarts_total"] == restarts_total:
+                if e.get("workload_tag") == tag and e["iters_per_launch"] == iters and e["restarts_total"] == restarts_total:
                     return e
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def write_cli_inputs(topics, path_prefix):
+    """current.json / racks.json / broker list for cli/kao-cli from product topics (replicas on removed brokers get ids
+    outside the target list, as in README.md:52-63 where broker 19 is about to be removed)."""
+    t0 = topics[0]
+    parts = []
+    for t in topics:
+        for p in range(t.n_partitions):
+            reps = [int(t.broker_ids[b]) if b != 0xFFFF else 900000 + k for k, b in enumerate(t.current[p].tolist())]
+            parts.append({"topic": t.name, "partition": p, "replicas": reps})
+    with open(path_prefix + "current.json", "w") as f:
+        json.dump({"version": 1, "partitions": parts}, f)
+    with open(path_prefix + "racks.json", "w") as f:
+        json.dump({str(int(b)): f"r{int(r)}" for b, r in zip(t0.broker_ids, t0.rack_of)}, f)
+    return ",".join(str(int(b)) for b in t0.broker_ids)
+
+
+def cold_cli(topics, device):
+    """Wall time of a COLD cli/kao-cli process (exec + HIP init + first hipMalloc + solve + JSON out) on the workload."""
+    exe = os.path.join(ROOT, "cli", "kao-cli")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        pre = os.path.join(d, "b_")
+        brokers = write_cli_inputs(topics, pre)
+        t0 = time.perf_counter()
+        out = subprocess.run([exe, "--current", pre + "current.json", "--broker-list", brokers, "--racks", pre + "racks.json",
+                              "--device", str(device), "--time-limit", "20", "--out", pre + "out.json", "--no-canonical"],
+                             capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        warn = sum(1 for ln in out.stderr.splitlines() if "NOT proven optimal" in ln)
+        return {"wall_s": wall, "exit_code": out.returncode, "topics_not_proven": warn}
 
 
 def main():
@@ -121,6 +187,7 @@ def main():
     ap.add_argument("--restarts", type=int, default=0,
                     help="restarts per topic (0 = four full rounds of resident wavefronts: 256 CUs x 32 x 4 / topics)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="timed steps only (what tools/profile.sh wraps in rocprofv3)")
     ap.add_argument("--eval-bench", type=int, default=1, help="also time K-eval alone on a resident batch")
     args = ap.parse_args()
 
@@ -176,32 +243,39 @@ def main():
         cus = torch.cuda.get_device_properties(dev_index).multi_processor_count
         restarts = max(8, (cus * 32 * 4 // max(1, len(topics))) // 4 * 4)
         restarts = min(restarts, 8192)
-    sess = kao.Session(topics, seed=0xB0B + rank, restarts=restarts, iters_per_launch=args.iters, profile=1)
 
-    def one_step():
+    # one FRESH drifted batch per step (warm-up steps included), every session resident in HBM before the clock starts
+    n_batches = args.warmup + args.steps
+    batches = [synthetic.drift(topics, 0.2, 1 + i) for i in range(n_batches)]
+    sessions = [kao.Session(b, seed=0xB0B + rank + 7919 * i, restarts=restarts, iters_per_launch=args.iters, profile=1)
+                for i, b in enumerate(batches)]
+
+    def one_step(sess):
         sess.step(1)
         keys = sess.best_keys()  # syncs the session stream
         if world > 1:
             return multigpu.allreduce_best(keys, owned, n_topics, rank, device=dev)
         return keys
 
-    for _ in range(args.warmup):
-        one_step()
-    st0 = sess.stats()
+    for i in range(args.warmup):
+        one_step(sessions[i])
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    for i in range(args.warmup, n_batches):
+        one_step(sessions[i])
     barrier()
     dt = time.perf_counter() - t0
-    st1 = sess.stats()
+    timed = sessions[args.warmup:]
+    stats = [s.stats() for s in timed]
 
-    d_delta = st1["delta_candidates"] - st0["delta_candidates"]
-    d_full = st1["full_candidates"] - st0["full_candidates"]
-    ms_search = st1["ms_search"] - st0["ms_search"]
-    ms_eval = st1["ms_eval"] - st0["ms_eval"]
-    sb = st1["search_bytes_algo"] - st0["search_bytes_algo"]
-    eb = st1["eval_bytes_algo"] - st0["eval_bytes_algo"]
+    def tot(k):
+        return sum(st[k] for st in stats)
+    d_delta, d_full = tot("delta_candidates"), tot("full_candidates")
+    ms_search, ms_eval = tot("ms_search"), tot("ms_eval")
+    sb, eb = tot("search_bytes_algo"), tot("eval_bytes_algo")
+    launches = tot("launches")
+    drift_ctr = tot("drift")
+    restarts_total = stats[0]["n_restarts_total"]
 
     # aggregate over ranks: max time, summed candidates
     agg = torch.tensor([dt, float(d_delta), float(d_full)], dtype=torch.float64, device=dev)
@@ -212,45 +286,64 @@ def main():
         agg[0] = tmax[0]
     dt_max, tot_delta, tot_full = (float(x) for x in agg.cpu())
 
-    # ---- solution quality after the timed steps (all ranks' topics) -----------------------------
-    res = sess.best()
-    feasible = sum(1 for r in res if r.violations[0] == 0 and r.objective >= 0)
-    proven = sum(1 for r in res if r.status == "OPTIMAL_PROVEN")
-    drift = st1["drift"]
-    sess.close()
+    # ---- what the timed steps achieved: every batch's topics after its ONE step ------------------
+    feasible = n_res = 0
+    obj_after_step = []
+    for s in timed:
+        res = s.best()
+        n_res += len(res)
+        feasible += sum(1 for r in res if r.violations[0] == 0 and r.objective >= 0)
+        obj_after_step.append(sum(int(r.objective) for r in res))
 
-    # ---- time-to-optimal: a fresh whole job (create + H2D + launches until every topic is proven
-    #      optimal + D2H), wall clock from kao_solve entry
-    barrier()
-    t1 = time.perf_counter()
-    sol = kao.solve(topics, seed=0x5EED + rank, iters_per_launch=64, stop_at_bound=1, time_limit_s=20.0)
-    tto_wall = time.perf_counter() - t1
-    tm = kao.last_solve_timing()
-    all_proven = all(r.status == "OPTIMAL_PROVEN" for r in sol)
-    tto = torch.tensor([tm["results_read_back"], 0.0 if all_proven else 1.0, tto_wall, tm["time_to_best"], float(tm["launches"])],
-                       dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tto, op=dist.ReduceOp.MAX)
-    tto_s, tto_fail, tto_wall_s, tto_best_s, tto_launches = (float(x) for x in tto.cpu())
+    out_extra = {}
+    if not args.no_extras:
+        # ---- steady state (round 1's figure): more launches on a batch that is already solved ----
+        ss = timed[-1]
+        sa = ss.stats()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            one_step(ss)
+        barrier()
+        dts = time.perf_counter() - t1
+        sbb = ss.stats()
+        out_extra["steady_state"] = {
+            "candidates_per_s_rank0": (sbb["delta_candidates"] - sa["delta_candidates"] + sbb["full_candidates"] - sa["full_candidates"]) / dts,
+            "note": "5 further launches on the last batch, whose topics are at or near their optimum already: machinery "
+                    "throughput, not useful work (this is what round 1 reported as `value`)"}
+    for s in sessions:
+        s.close()
 
-    # ---- the same reassign after the cluster has drifted (20 % of the slots on random brokers): the closed-form bound
-    #      has a gap on every topic, so "optimal" is proven by the Lagrangian dual kernel (K-bound) running beside K-search
-    drifted = synthetic.drift(topics, 0.2, 1)
-    barrier()
-    kao.solve(drifted[:1], seed=1, iters_per_launch=64, max_launches=1)  # warm-up of the K-bound code path
-    sold = kao.solve(drifted, seed=0xD21F + rank, iters_per_launch=64, stop_at_bound=1, time_limit_s=20.0)
-    tmd = kao.last_solve_timing()
-    dr = torch.tensor([tmd["results_read_back"], float(sum(r.status != "OPTIMAL_PROVEN" for r in sold)), float(tmd["launches"])],
-                      dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(dr, op=dist.ReduceOp.MAX)
-    dr_s, dr_unproven, dr_launches = (float(x) for x in dr.cpu())
+    tto = {}
+    if not args.no_extras:
+        # ---- time-to-optimal: fresh whole jobs (create + H2D + launches until every topic is PROVEN optimal + D2H),
+        #      wall clock from kao_solve entry.  (a) the drifted batch of the first timed step: the closed-form bound has a
+        #      gap on every topic, optimality is proven by K-bound beside K-search; (b) the balanced config as generated.
+        def run_solve(tp, seed):
+            barrier()
+            t1 = time.perf_counter()
+            sol = kao.solve(tp, seed=seed, stop_at_bound=1, time_limit_s=20.0)
+            wall = time.perf_counter() - t1
+            tm = kao.last_solve_timing()
+            unproven = sum(r.status != "OPTIMAL_PROVEN" for r in sol)
+            v = torch.tensor([tm["results_read_back"], float(unproven), wall, tm["time_to_best"], float(tm["launches"]),
+                              float(tm["delta_candidates"]), float(sum(int(r.objective) for r in sol))], dtype=torch.float64, device=dev)
+            if world > 1:
+                vmax = v.clone(); dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+                vsum = v.clone(); dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+                v = vmax; v[5] = vsum[5]; v[6] = vsum[6]; v[1] = vsum[1]
+            return [float(x) for x in v.cpu()]
+        kao.solve(batches[0][:1], seed=1, max_launches=1)  # warm-up of the K-bound code path / arena cache
+        d = run_solve(batches[args.warmup], 0xD21F + rank)
+        b = run_solve(topics, 0x5EED + rank)
+        tto = {"drifted": d, "balanced": b}
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    non_null = None
     out = {
         "metric": "candidate assignments/sec (+ time_to_optimal_s), 10k-partition reassign",
         "value": (tot_delta + tot_full) / dt_max,
@@ -264,54 +357,73 @@ def main():
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic",
-        "config": {"workload": synthetic.WORKLOADS[args.config], "topics_total": n_topics,
-                   "topics_per_rank": [len(s) for s in shards], "restarts_per_topic_rank0": st1["n_restarts_total"] // max(1, len(topics)),
-                   "iters_per_launch": args.iters,
+        "config": {"workload": synthetic.WORKLOADS[args.config] + "; every step a FRESH batch: the cluster after a 20 % drift "
+                               "(synthetic.drift, seed 1 + step), all batches resident in HBM before the timed region",
+                   "topics_total": n_topics, "topics_per_rank": [len(s) for s in shards],
+                   "restarts_per_topic_rank0": restarts_total // max(1, len(topics)), "iters_per_launch": args.iters,
                    "neighbours_per_iteration": "REPLACE: B brokers of one slot (scan) or 64x4 (sample), EXCHANGE: P*rf partner slots, "
                                                "LEADER-SWAP: 64x(rf-1); pattern RRXRLRXR",
                    "parallelism": f"topic-sharded x{world}" if world > 1 else "single GPU"},
         "delta_candidates_per_s": tot_delta / dt_max,
         "full_candidates_per_s": tot_full / dt_max,
-        "time_to_optimal_s": None if tto_fail else tto_s,
-        "time_to_optimal_note": "seconds from kao_solve entry (instance in host memory) to results in host memory: instance "
-                                "preparation + H2D + K-search/K-eval launches until every topic's objective equals its upper "
-                                "bound (OPTIMAL_PROVEN) + gather + D2H; max over ranks",
-        "time_to_optimal_detail": {"python_wall_s": tto_wall_s, "last_improving_launch_done_s": tto_best_s, "launches": int(tto_launches)},
-        "time_to_optimal_drifted": {"workload": "the same topics after a 20 % drift (synthetic.drift): every topic has a "
-                                                "closed-form bound gap, optimality is proven by K-bound (Lagrangian dual) on its own stream",
-                                    "seconds": dr_s, "unproven_topics_max_over_ranks": int(dr_unproven), "launches": int(dr_launches)},
-        "quality_after_timed_steps": {"topics_rank0": len(res), "feasible": feasible, "proven_optimal": proven, "drift": drift},
+        "quality_after_one_step": {"batches": len(timed), "topics_rank0": n_res, "feasible": feasible, "drift": drift_ctr,
+                                   "objective_sum_per_batch_rank0": obj_after_step},
     }
-    # ---- roofline of the dominant kernel (K-search), from HIP events on the session stream -------
-    launches = st1["launches"] - st0["launches"]
-    achieved = sb / (ms_search * 1e-3) / 1e9 if ms_search > 0 else None
-    out["roofline"] = {"kernel": "k_search", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
-                       "algorithmic_bytes_per_launch": sb // max(1, launches),
-                       "avg_launch_ms": ms_search / max(1, launches),
-                       "note": "algorithmic bytes = neighbours x (8*RF+10) B (SURVEY.md 8d); the working set is "
-                               "LDS-resident, so this kernel is VALU/LDS-issue bound, not HBM bound (DESIGN.md section 6)"}
-    prof = load_profile_constants(args.config, args.iters, st1["n_restarts_total"])
+    out.update(out_extra)
+    if tto:
+        d, b = tto["drifted"], tto["balanced"]
+        out["time_to_optimal_s"] = None if d[1] else d[0]
+        out["time_to_optimal_note"] = ("seconds from kao_solve entry (instance in host memory) to results in host memory: instance "
+                                       "preparation + H2D + K-search/K-eval launches (+ K-bound on its own stream) until every topic's "
+                                       "objective equals its certificate (OPTIMAL_PROVEN) + gather + D2H; max over ranks; workload = "
+                                       "the drifted batch of the first timed step (no topic is solved by the initial state)")
+        out["time_to_optimal_detail"] = {"unproven_topics": int(d[1]), "python_wall_s": d[2], "last_improving_launch_done_s": d[3],
+                                         "launches": int(d[4]), "delta_candidates": d[5], "objective_sum": d[6],
+                                         "useful_candidates_per_s": d[5] / d[0] if d[0] > 0 else None,
+                                         "objective_sum_after_one_timed_step_rank0": obj_after_step[0]}
+        out["time_to_optimal_balanced"] = {"workload": "config 4 as generated (balanced start: the best-insertion init is optimal, "
+                                                       "proof by the closed-form bound)", "seconds": None if b[1] else b[0],
+                                           "python_wall_s": b[2], "launches": int(b[4]), "delta_candidates": b[5]}
+        out["cold_cli"] = {"balanced": cold_cli(topics, dev_index), "drifted": cold_cli(batches[args.warmup], dev_index),
+                           "note": "cli/kao-cli process start -> JSON written (exec, HIP init, first hipMalloc, JSON parse, solve, JSON out), "
+                                   "rank 0's topics"}
+
+    # ---- roofline of the dominant kernel (K-search), duration from HIP events on the session stream -------
+    avg_ms = ms_search / max(1, launches)
+    algo_per_launch = sb // max(1, launches)
+    prof = load_profile_constants("cfg%d-drift-fresh" % args.config, args.iters, restarts_total)
+    roof = {"kernel": "k_search", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": avg_ms,
+            "achieved": None, "frac": None, "traffic": None,
+            "algorithmic_lds_served": {"bytes_per_launch": algo_per_launch, "gbps": algo_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
+                                       "note": "SURVEY.md 8(d) algorithmic bytes = neighbours x (8*RF+10) B; they are served from LDS (the "
+                                               "restart state is LDS-resident), NOT from HBM, so they are not priced against the HBM peak"},
+            "note": "achieved = HBM bytes per launch from the PMC counters / HIP-event launch time: the kernel touches HBM only to load and "
+                    "store restart states; it is bound by VALU issue (see roofline_valu_issue), not by HBM"}
     if prof:
-        out["roofline"]["traffic"] = prof["k_search_hbm_bytes_per_launch"]
-        out["roofline"]["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE (x2 gfx950 wide-read correction) + WRITE_SIZE per launch, "
-                                           "separate passes, from " + prof["source"])
+        roof["traffic"] = prof["k_search_hbm_bytes_per_launch"]
+        roof["achieved"] = prof["k_search_hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE (x2 gfx950 wide-read correction) + WRITE_SIZE per launch, separate passes, from "
+                                + prof["source"])
         valu = prof["k_search_valu_insts_per_launch"]
-        # integer VALU issue peak, MEASURED on this chip (tools/microbench/valu_rate.hip, profiles/r01_valu_issue_microbench.txt):
-        # 540-671 G wave64-instructions/s depending on the op (~4 cycles per instruction per SIMD); best class used as the roof
-        peak = 671.3e9
+        peak = prof.get("valu_issue_peak_winst_per_s", 671.3e9)
         out["roofline_valu_issue"] = {"kernel": "k_search", "bound": "valu-issue", "insts_per_launch": valu,
-                                      "achieved": valu / (ms_search / max(1, launches) * 1e-3) / 1e9, "peak": peak / 1e9,
-                                      "unit": "G wave-instructions/s",
-                                      "frac": valu / (ms_search / max(1, launches) * 1e-3) / peak,
-                                      "note": "SQ_INSTS_VALU per launch from " + prof["source"] + "; peak = best measured integer-VALU class "
-                                              "(profiles/r01_valu_issue_microbench.txt); this, not HBM, is the binding roof"}
+                                      "achieved": valu / (avg_ms * 1e-3) / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
+                                      "frac": valu / (avg_ms * 1e-3) / peak,
+                                      "valu_insts_per_neighbour": valu / max(1.0, d_delta / max(1, launches)),
+                                      "note": "SQ_INSTS_VALU per launch from " + prof["source"] + "; peak: " + prof.get("valu_issue_peak_note", "")}
+        if "k_search_lds_insts_per_launch" in prof:
+            lds_b = prof["k_search_lds_insts_per_launch"] * 64 * prof.get("lds_bytes_per_lane_avg", 4)
+            out["roofline_lds"] = {"kernel": "k_search", "bound": "lds", "achieved": lds_b / (avg_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS,
+                                   "unit": "GB/s", "frac": lds_b / (avg_ms * 1e-3) / 1e9 / LDS_PEAK_GBS,
+                                   "note": "SQ_INSTS_LDS x 64 lanes x average access width; peak 128 B/clk/CU"}
+    out["roofline"] = roof
     ach_e = eb / (ms_eval * 1e-3) / 1e9 if ms_eval > 0 else None
     out["roofline_eval_in_step"] = {"kernel": "k_eval", "achieved": ach_e, "unit": "GB/s", "avg_launch_ms": ms_eval / max(1, launches),
                                     "algorithmic_bytes_per_launch": eb // max(1, launches)}
 
     # ---- K-eval alone on a large resident batch: the genuinely HBM-streaming kernel ----------------
-    if args.eval_bench:
+    if args.eval_bench and not args.no_extras:
         t = topics[0]
         n = 1 << 18
         per = t.n_partitions * t.rf
@@ -336,9 +448,15 @@ def main():
                                        "frac": bytes_e / (ms_e * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        "full_candidates_per_s": n / (ms_e * 1e-3)}
 
-    if world == 1 and not args.no_cpu_baseline:
-        rpt = st1["n_restarts_total"] // max(1, len(topics))
-        out["cpu_baseline"] = cpu_baseline(topics, rpt, args.iters)
+    if world == 1 and not args.no_cpu_baseline and not args.no_extras:
+        rpt = restarts_total // max(1, len(topics))
+        cb = cpu_baseline(batches[args.warmup], rpt, args.iters)
+        out["cpu_baseline"] = cb
+        non_null = cb["non_null_fraction"]
+        out["value_non_null"] = out["value"] * non_null
+        objs = [o for o in cb.pop("exact_objectives") if o is not None]
+        if tto and objs and len(objs) == len(topics):   # the exact solver finished every topic: the certified optimum agrees
+            out["time_to_optimal_detail"]["objective_sum_exact_cpu"] = sum(objs)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -195,8 +195,11 @@ int kao_session_stats(kao_session *s, kao_stats *out);
  * previous K-bound launch (it continues from the multipliers that one left in HBM). */
 int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters);
 /* Search prices.  K-search can carry Lagrangian prices of the coupling rows in its move cost: delta = lam * dViolation
- * - S * dObjective + S * dPrice, where dPrice is the change of sum_b price_rep[b] * replicas(b) + price_lead[b] * leaders(b)
- * (price_rep[b] = a[b] + g[rack(b)]).  With near-optimal multipliers the chain steps an improvement needs become neutral.
+ * - S * dObjective + S * dPrice.  A row's multiplier (a[b]: replicas on broker b, l[b]: leaders on b, g[r]: replicas in rack
+ * r) is charged for a unit that enters the row and refunded for one that leaves, but only where the row's count leaves or
+ * re-enters its band -- exactly where the violation changes (inside a slack band a unit is free): broker-, rack- and
+ * direction-specific penalty weights lam +- multiplier.  With near-optimal multipliers the chain steps an improvement
+ * needs (objective down a little, excess moved to another broker) become neutral moves.
  * kao_session_set_prices: a[n_brokers], l[n_brokers], g[n_racks] of one topic from the host (fixed point, 4096 = 1; any
  * values are valid -- prices steer the search, they never change what is reported).  kao_session_adopt_prices: use what
  * the last finished K-bound launch exported (the multipliers of its record dual value, rounded to the quarter grid) for every topic it covered;
@@ -229,8 +232,9 @@ void kao_session_destroy(kao_session *s);
 int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results);
 /* Wall-clock breakdown of this thread's last kao_solve, seconds from its entry:
  * out[0] session ready (instance prepared + uploaded), out[1] last improving launch finished (time-to-best),
- * out[2] results read back, out[3] returned (buffers released); out[4] = launches run. */
-int kao_last_solve_timing(double out[5]);
+ * out[2] results read back, out[3] returned (buffers released); out[4] = launches run; out[5] = neighbours K-search
+ * delta-evaluated in those launches (kao_stats.delta_candidates), out[6] = K-bound launches, out[7] = reserved. */
+int kao_last_solve_timing(double out[8]);
 
 #ifdef __cplusplus
 }

@@ -625,7 +625,7 @@ void arena_drop_all() {
     for (hipStream_t st : g_streams) (void)hipStreamDestroy(st);
     g_streams.clear();
 }
-thread_local double g_timing[5] = {0, 0, 0, 0, 0};
+thread_local double g_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 int session_drain_events(kao_session *s) {
@@ -1522,7 +1522,14 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     kao_session *s = nullptr;
     kao_opts so{};
     if (opts) so = *opts;
-    if (so.iters_per_launch <= 0) so.iters_per_launch = 128;  // latency first: the host checks the bound after every launch
+    if (so.iters_per_launch <= 0) {
+        // latency first (the host checks the bound after every launch): 128 iterations; large topics pay O(P) per launch
+        // for loading, recounting and storing a restart (drifted 500 x 5000 topic: 40 % more iterations per second with
+        // 512 per launch), so they get longer launches
+        int64_t slots = 0;
+        for (int i = 0; topics && i < n_topics; ++i) slots = std::max<int64_t>(slots, (int64_t)topics[i].n_partitions * std::max(topics[i].rf, 1));
+        so.iters_per_launch = slots <= 4096 ? 128 : (slots <= 8192 ? 256 : 512);
+    }
     if (so.elite_period == 0 && topics && n_topics > 0) {  // about one penalty period of the largest topic between elite launches
         int lg = 8;
         for (int i = 0; i < n_topics; ++i)
@@ -1599,6 +1606,8 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     if (s->bound_inflight && (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) { kao_session_destroy(s); return rc; }  // last K-bound launch
     rc = kao_session_best(s, results);
     g_timing[2] = now_s() - t0;
+    g_timing[5] = (double)s->delta_total;
+    g_timing[6] = (double)s->bound_launches;
     if (!rc)
         for (int i = 0; i < n_topics; ++i) {
             results[i].seconds_to_best = t_best[(size_t)i];
@@ -1610,9 +1619,9 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     return rc;
 }
 
-int kao_last_solve_timing(double out[5]) {
+int kao_last_solve_timing(double out[8]) {
     if (!out) return fail(KAO_ERR_INVALID, "null out");
-    for (int i = 0; i < 5; ++i) out[i] = g_timing[i];
+    for (int i = 0; i < 8; ++i) out[i] = g_timing[i];
     return KAO_OK;
 }
 

@@ -107,10 +107,14 @@ __device__ __forceinline__ uint32_t make_key_tie_p(int lam, int S, int dV, int d
     delta = min(max(delta, -kDBias), kDBias - 2);
     return ((uint32_t)(delta + kDBias) << 8) | (tie & 0xFFu);
 }
-// packed search prices of one broker: low half = replica price (a[b] + g[rack]), high half = leader price l[b], key units
+// packed search prices of one broker: low half = replica price a[b], high half = leader price l[b], key units
 __device__ __forceinline__ int price_rep(uint32_t pr) { return (int)(short)(pr & 0xFFFFu); }
 __device__ __forceinline__ int price_lead(uint32_t pr) { return (int)pr >> 16; }
-__device__ __forceinline__ int price_of(uint32_t pr, bool lead) { return price_rep(pr) + (lead ? price_lead(pr) : 0); }
+// Price of one more (p_in) / one fewer (p_out) unit on a priced row whose count is c: the multiplier applies only where the
+// count leaves or re-enters its band [lo, hi], i.e. exactly where the violation changes; inside a slack band a unit costs
+// nothing (a plain linear term would push the counts of rows with a positive multiplier down to the lower band end).
+__device__ __forceinline__ int p_in(int c, int lo, int hi, int price) { return ((c >= hi) | (c < lo)) ? price : 0; }
+__device__ __forceinline__ int p_out(int c, int lo, int hi, int price) { return ((c > hi) | (c <= lo)) ? -price : 0; }
 // fixed point (kDualScale) -> key units (obj_scale per objective unit), rounded half up, clamped to 16 bits
 __device__ __forceinline__ int price_units(int v, int S) { return min(max((S * v + kDualScale / 2) >> 12, -32767), 32767); }
 
@@ -252,7 +256,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
     uint8_t *XR = smem + a_bytes + kRackTab * 4;  // rack of internal index x, 0xFF = padding slot / beyond Bx
     uint32_t *PR = reinterpret_cast<uint32_t *>(smem + a_bytes + kRackTab * 4 + bx64);  // [bx64] packed prices (kPriced only)
-    const int pr_bytes = kPriced ? c_bytes : 0;
+    const int pr_bytes = kPriced ? c_bytes + kRackTab * 4 : 0;
+    int *PG = reinterpret_cast<int *>(smem + a_bytes + kRackTab * 4 + bx64 + c_bytes);  // [kRackTab] rack prices (kPriced only)
     unsigned char *wb = smem + a_bytes + kRackTab * 4 + bx64 + pr_bytes + wave * (a_bytes + c_bytes + kRackTab * 8);  // blockDim.x / 64 waves
     const uint4 *cur_words = pl.cur_pool + TD->cur_off;  // host-prepared words x | rack << 16 (0xFFFFFFFF = none)
     const uint4 *CUR;
@@ -267,19 +272,21 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         uint4 *cur_lds = reinterpret_cast<uint4 *>(smem);
         for (int p = threadIdx.x; p < T.P; p += blockDim.x) cur_lds[p] = cur_words[p];
     }
-    for (int r = threadIdx.x; r < kRackTab; r += blockDim.x) RSZ[r] = r < T.R ? pl.rsz_pool[TD->rsz_off + r] : 0;
+    for (int r = threadIdx.x; r < kRackTab; r += blockDim.x) {
+        RSZ[r] = r < T.R ? pl.rsz_pool[TD->rsz_off + r] : 0;
+        if (kPriced) PG[r] = r < T.R ? price_units(pl.price_pool[TD->price_off + 2 * TD->B + r], prm.obj_scale) : 0;
+    }
     __syncthreads();
     for (int x = threadIdx.x; x < ((T.Bx + 63) & ~63); x += blockDim.x) {
         const uint32_t r = mulhi((uint32_t)x, T.magic);
         const bool valid = x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)kRackTab ? r : 0];
         XR[x] = valid ? (uint8_t)r : (uint8_t)0xFF;
-        if (kPriced) {  // prices of broker x in key units: replica price a[b] + g[rack] | leader price l[b] << 16
+        if (kPriced) {  // prices of broker x in key units: replica price a[b] | leader price l[b] << 16
             uint32_t pr = 0;
             if (valid) {
                 const int32_t *pp = pl.price_pool + TD->price_off;
                 const int b = pl.ext_pool[TD->ext_off + x];
-                pr = ((uint32_t)price_units(pp[b] + pp[2 * TD->B + (int)r], prm.obj_scale) & 0xFFFFu) |
-                     ((uint32_t)price_units(pp[TD->B + b], prm.obj_scale) << 16);
+                pr = ((uint32_t)price_units(pp[b], prm.obj_scale) & 0xFFFFu) | ((uint32_t)price_units(pp[TD->B + b], prm.obj_scale) << 16);
             }
             PR[x] = pr;
         }
@@ -378,7 +385,12 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                         const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
                         uint32_t keyx;
-                        if (kPriced) keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), price_of(PR[x], k == 0), tie) : kKeyNull;
+                        if (kPriced) {
+                            const uint32_t prx = PR[x];
+                            int dP = p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx)) + p_in(L.K[r & 255u], T.rack_lo, T.rack_hi, PG[r & 255u]);
+                            if (k == 0) dP += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
+                            keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), dP, tie) : kKeyNull;
+                        }
                         else keyx = okx ? make_key_tie(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), tie) : kKeyNull;
                         if (keyx < key) { key = keyx; xw_l = xw; }
                     }
@@ -447,7 +459,13 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
                 const int dV_rack_old = ddec(L.K[ro], T.rack_lo, T.rack_hi) + ddec(cnt4(a, ro), T.prack_lo, T.prack_hi);
                 const int rsz_ro = RSZ[ro];
-                const int p_old = kPriced ? price_of(PR[uw & 0xFFFFu], lead) : 0;
+                int dP_old = 0, dP_rack_old = 0;
+                if (kPriced) {
+                    const uint32_t pro = PR[uw & 0xFFFFu];
+                    dP_old = p_out((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(pro));
+                    if (lead) dP_old += p_out((int)(co >> 16), T.lead_lo, T.lead_hi, price_lead(pro));
+                    dP_rack_old = p_out(L.K[ro], T.rack_lo, T.rack_hi, PG[ro]);
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint32_t r, jj;
@@ -473,7 +491,13 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     }
                     const int dObjg = role_w2(c, xw, wl, wf) - g_old;
                     uint32_t keyg;
-                    if (kPriced) keyg = okg ? make_key_p(lam, S, dVg, dObjg, price_of(PR[x], lead) - p_old, lane) : kKeyNull;
+                    if (kPriced) {
+                        const uint32_t prx = PR[x];
+                        int dPg = dP_old + p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx));
+                        if (lead) dPg += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
+                        if (g < 2 && r != ro) dPg += dP_rack_old + p_in(L.K[r], T.rack_lo, T.rack_hi, PG[r]);
+                        keyg = okg ? make_key_p(lam, S, dVg, dObjg, dPg, lane) : kKeyNull;
+                    }
                     else keyg = okg ? make_key(lam, S, dVg, dObjg, lane) : kKeyNull;
                     if (keyg < key) { key = keyg; vw = xw; dV = dVg; dObj = dObjg; }
                 }
@@ -481,6 +505,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 uw = a.x;
                 const int u_lead = role_w2(c, uw, T.w00, T.w10), u_fol = role_w2(c, uw, T.w01, T.w11);
                 const int dV_u = ddec((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+                const int dP_u = kPriced ? p_out((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi, price_lead(PR[uw & 0xFFFFu])) : 0;
 #pragma unroll
                 for (int kk = 1; kk < kRFP; ++kk) {
                     if (kk >= T.RF) break;
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11);
                     const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
                     uint32_t keyg;
-                    if (kPriced) keyg = make_key_p(lam, S, dVg, dObjg, price_lead(PR[xw & 0xFFFFu]) - price_lead(PR[uw & 0xFFFFu]), lane);
+                    if (kPriced) keyg = make_key_p(lam, S, dVg, dObjg, dP_u + p_in((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi, price_lead(PR[xw & 0xFFFFu])), lane);
                     else keyg = make_key(lam, S, dVg, dObjg, lane);
                     if (keyg < key) { key = keyg; vw = xw; k = kk; dV = dVg; dObj = dObjg; }
                 }
@@ -525,7 +550,15 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const int dvl = leadl ? ddec(cl16, T.lead_lo, T.lead_hi) : dinc(cl16, T.lead_lo, T.lead_hi);
                     sc = min(dv7, 0) + min(dvl, 0);
                 }
-                if (kPriced) key_o = lane < T_tour ? make_key_p(lam, S, sc, -g_o, type == 0 ? -price_of(PR[oldw_o & 0xFFFFu], leadl) : 0, lane) : kKeyNull;
+                if (kPriced) {
+                    int dPs = 0;
+                    if (type == 0) {
+                        const uint32_t pro = PR[oldw_o & 0xFFFFu];
+                        dPs = p_out((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(pro));
+                        if (leadl) dPs += p_out((int)(co >> 16), T.lead_lo, T.lead_hi, price_lead(pro));
+                    }
+                    key_o = lane < T_tour ? make_key_p(lam, S, sc, -g_o, dPs, lane) : kKeyNull;
+                }
                 else key_o = lane < T_tour ? make_key(lam, S, sc, -g_o, lane) : kKeyNull;
             };
             score_slot(keyA, pl_, kl_, oldw_l, g_old_l, dvo_l, dvr_l);
@@ -549,8 +582,13 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             if (type == 0) {
                 // ---- phase B (REPLACE): every target broker for slot (p,k), 64 per round ----
                 {   // rack-dependent part of the delta, racks strided over the lanes
-                    for (int r = lane; r < T.R; r += 64)
-                        L.RT[r] = ((uint32_t)r != ro) ? dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, (uint32_t)r), T.prack_lo, T.prack_hi) : 0;
+                    const int dP_rack_old = kPriced ? p_out(L.K[ro], T.rack_lo, T.rack_hi, PG[ro]) : 0;
+                    for (int r = lane; r < T.R; r += 64) {
+                        int v = ((uint32_t)r != ro) ? dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, (uint32_t)r), T.prack_lo, T.prack_hi) : 0;
+                        if (kPriced)  // rack part of the price delta rides in the upper 24 bits (the violation delta is within -8..8)
+                            v = (v & 0xFF) | ((((uint32_t)r != ro) ? dP_rack_old + p_in(L.K[r], T.rack_lo, T.rack_hi, PG[r]) : 0) * 256);
+                        L.RT[r] = v;
+                    }
                 }
                 const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
                 // a displaced current replica (in c, not in a) is the only broker with a non-zero weight here
@@ -558,7 +596,13 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t ci = sel4(c, lane & 3);
                 const bool hm_l = (lane < 4) & (ci != kNoneW) & !in4(a, ci);
                 const bool has_missing = __ballot(hm_l) != 0ull;
-                const int p_old = kPriced ? price_of(PR[uw & 0xFFFFu], lead) : 0;
+                int dP_old = 0;
+                if (kPriced) {
+                    const uint32_t pro = PR[uw & 0xFFFFu];
+                    const uint32_t co = L.C[uw & 0xFFFFu];
+                    dP_old = p_out((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(pro));
+                    if (lead) dP_old += p_out((int)(co >> 16), T.lead_lo, T.lead_hi, price_lead(pro));
+                }
                 for (int base = 0; base < T.Bx; base += 64) {
                     const uint32_t tie = lcg24(rng) >> 8;
                     const uint32_t x = (uint32_t)(base + lane);
@@ -566,12 +610,18 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const uint32_t xw = x | (r << 16);
                     const bool okx = (r != 0xFFu) & !in4(a, xw);
                     const uint32_t cn = L.C[x];
-                    int dVx = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + L.RT[r & 255u];
+                    const int rt = L.RT[r & 255u];
+                    int dVx = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + (kPriced ? (int)(signed char)(rt & 0xFF) : rt);
                     if (lead) dVx += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                     int dObjx = -g_old;
                     if (has_missing) dObjx += role_w2(c, xw, wl, wf);
                     uint32_t keyx;
-                    if (kPriced) keyx = okx ? make_key_tie_p(lam, S, dVx, dObjx, price_of(PR[x], lead) - p_old, tie) : kKeyNull;
+                    if (kPriced) {
+                        const uint32_t prx = PR[x];
+                        int dPx = dP_old + p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx)) + (rt >> 8);
+                        if (lead) dPx += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
+                        keyx = okx ? make_key_tie_p(lam, S, dVx, dObjx, dPx, tie) : kKeyNull;
+                    }
                     else keyx = okx ? make_key_tie(lam, S, dVx, dObjx, tie) : kKeyNull;
                     if (keyx < key) { key = keyx; vw = xw; dV = dVx; dObj = dObjx; }
                 }
@@ -610,7 +660,11 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                             const int cv = (int)(L.C[v & 0xFFFFu] >> 16);
                             dVx += lead ? (ddec(cu, T.lead_lo, T.lead_hi) + dinc(cv, T.lead_lo, T.lead_hi))
                                         : (ddec(cv, T.lead_lo, T.lead_hi) + dinc(cu, T.lead_lo, T.lead_hi));
-                            if (kPriced) { const int dl = price_lead(PR[v & 0xFFFFu]) - pl_u; dPx = lead ? dl : -dl; }  // the leader moves u -> v or v -> u
+                            if (kPriced) {  // the leader moves u -> v or v -> u
+                                const int plv = price_lead(PR[v & 0xFFFFu]);
+                                dPx = lead ? (p_out(cu, T.lead_lo, T.lead_hi, pl_u) + p_in(cv, T.lead_lo, T.lead_hi, plv))
+                                           : (p_out(cv, T.lead_lo, T.lead_hi, plv) + p_in(cu, T.lead_lo, T.lead_hi, pl_u));
+                            }
                         }
                         const uint32_t rv = v >> 16;
                         if (rv != ro)
@@ -1374,7 +1428,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
 // ------------------------------------------------------------------------------------------------
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced) {
     const size_t a = global_a ? 0 : (size_t)maxP * 16, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
-    return a + kRackTab * 4 + bx64 + (priced ? bx64 * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
+    return a + kRackTab * 4 + bx64 + (priced ? bx64 * 4 + kRackTab * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
 }
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 8 + 15) & ~(size_t)15 : 0;

@@ -356,6 +356,7 @@ def solve(topics: Sequence[Topic], target_objective: Optional[Sequence[int]] = N
 
 def last_solve_timing() -> dict:
     """C-side wall-clock breakdown of the last kao_solve (seconds from its entry)."""
-    out = (C.c_double * 5)()
+    out = (C.c_double * 8)()
     _check(_ffi.load().kao_last_solve_timing(out), "kao_last_solve_timing")
-    return dict(session_ready=out[0], time_to_best=out[1], results_read_back=out[2], returned=out[3], launches=int(out[4]))
+    return dict(session_ready=out[0], time_to_best=out[1], results_read_back=out[2], returned=out[3], launches=int(out[4]),
+                delta_candidates=int(out[5]), bound_launches=int(out[6]))

@@ -111,11 +111,18 @@ typedef struct {
     int best_obj;  /* best feasible objective seen, -1 if none */
     uint16_t *best;/* [P*RF] dense snapshot */
     uint64_t n_eval, n_accept;
-    const int *PA, *PL; /* [Bx] search prices in key units (replica price a[b] + g[rack], leader price l[b]); NULL = unpriced */
+    uint64_t n_valid; /* neighbours that were real proposals (not null: broker already in the partition, padding slot, ...) */
+    const int *PA, *PL, *PG; /* search prices in key units: replica price a[b] and leader price l[b] per internal index [Bx],
+                                rack price g[r] [256]; NULL = unpriced */
 } ls_state;
 static inline int PAx(const ls_state *s, unsigned x) { return s->PA ? s->PA[x] : 0; }
 static inline int PLx(const ls_state *s, unsigned x) { return s->PL ? s->PL[x] : 0; }
-static inline int Pof(const ls_state *s, unsigned x, int lead) { return PAx(s, x) + (lead ? PLx(s, x) : 0); }
+static inline int PGx(const ls_state *s, int r) { return s->PG ? s->PG[r] : 0; }
+/* Price of one more (p_in) / one fewer (p_out) unit on a priced row whose count is c.  The multiplier applies only where
+ * the count leaves or re-enters its band [lo, hi] -- i.e. exactly where the violation changes; inside a slack band a unit
+ * costs nothing (a plain linear term would push counts of rows with a positive multiplier down to the lower band end). */
+static inline int p_in(int c, int lo, int hi, int price) { return (c >= hi || c < lo) ? price : 0; }
+static inline int p_out(int c, int lo, int hi, int price) { return (c > hi || c <= lo) ? -price : 0; }
 
 static inline uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -265,7 +272,9 @@ static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint3
                            + d_band(rack_count(t, a, rn), +1, t->prack_lo, t->prack_hi);
                     if (k == 0) dV += d_band((int)(s->C[x] >> 16), +1, t->lead_lo, t->lead_hi);
                     const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
-                    const uint32_t key = make_key_tie(pp->lam_max, pp->obj_scale, dV, role_w(t, p, x, k == 0 ? 0 : 1), tie, Pof(s, x, k == 0));
+                    const uint32_t key = make_key_tie(pp->lam_max, pp->obj_scale, dV, role_w(t, p, x, k == 0 ? 0 : 1), tie,
+                                                          p_in((int)(s->C[x] & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, x)) + p_in(s->K[rn], t->rack_lo, t->rack_hi, PGx(s, rn)) +
+                                                          (k == 0 ? p_in((int)(s->C[x] >> 16), t->lead_lo, t->lead_hi, PLx(s, x)) : 0));
                     if (key < lane_key[l]) { lane_key[l] = key; lane_x[l] = (int)x; }
                 }
             uint32_t best_key = KEY_NULL; int found = -1;
@@ -276,7 +285,7 @@ static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint3
             s->K[rack_of_x(t, (unsigned)found)] += 1;
         }
     }
-    s->best_obj = -1; s->n_eval = 0; s->n_accept = 0;
+    s->best_obj = -1; s->n_eval = 0; s->n_accept = 0; s->n_valid = 0;
 }
 
 typedef struct { int type, p, k, q, j; unsigned x; int dV, dObj; } proposal;
@@ -322,6 +331,9 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
         int dV_old = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
         if (k == 0) dV_old += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
         const int dV_rack_old = d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, ro), -1, t->prack_lo, t->prack_hi);
+        int dP_old = p_out((int)(co & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, old));
+        if (k == 0) dP_old += p_out((int)(co >> 16), t->lead_lo, t->lead_hi, PLx(s, old));
+        const int dP_rack_old = p_out(s->K[ro], t->rack_lo, t->rack_hi, PGx(s, ro));
         for (int g = 0; g < REPL_G; ++g) {
             int r, j;
             if (g < 2) { r = (int)rnd24(rng, (uint32_t)t->R); j = (int)rnd24(rng, (uint32_t)t->m); }
@@ -329,13 +341,17 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
             const unsigned x = (unsigned)(r * t->m + j);
             *n_eval += 1;
             if (j >= t->rack_size[r] || in_part(a, x)) continue;
+            ((ls_state *)s)->n_valid += 1;
             const uint32_t cn = s->C[x];
             int dV = dV_old + d_band((int)(cn & 0xFFFF), +1, t->rep_lo, t->rep_hi);
             if (k == 0) dV += d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
             if (r != ro)
                 dV += dV_rack_old + d_band(s->K[r], +1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, r), +1, t->prack_lo, t->prack_hi);
             const int dObj = role_w(t, p, x, nr) - g_old;
-            const uint32_t key = make_key(lam, S, dV, dObj, lane, Pof(s, x, k == 0) - Pof(s, old, k == 0));
+            int dP = dP_old + p_in((int)(cn & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, x));
+            if (k == 0) dP += p_in((int)(cn >> 16), t->lead_lo, t->lead_hi, PLx(s, x));
+            if (r != ro) dP += dP_rack_old + p_in(s->K[r], t->rack_lo, t->rack_hi, PGx(s, r));
+            const uint32_t key = make_key(lam, S, dV, dObj, lane, dP);
             if (key < best) { best = key; o->type = 0; o->p = p; o->k = k; o->x = x; o->dV = dV; o->dObj = dObj; }
         }
         return best;
@@ -345,9 +361,11 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
     for (int k = 1; k < RF; ++k) {
         const unsigned v = a[k];
         *n_eval += 1;
+        ((ls_state *)s)->n_valid += 1;
         const int dObj = role_w(t, p, v, 0) + role_w(t, p, u, 1) - role_w(t, p, u, 0) - role_w(t, p, v, 1);
         const int dV = d_band((int)(s->C[u] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[v] >> 16), +1, t->lead_lo, t->lead_hi);
-        const uint32_t key = make_key(lam, S, dV, dObj, lane, PLx(s, v) - PLx(s, u));
+        const uint32_t key = make_key(lam, S, dV, dObj, lane, p_out((int)(s->C[u] >> 16), t->lead_lo, t->lead_hi, PLx(s, u)) +
+                                                                 p_in((int)(s->C[v] >> 16), t->lead_lo, t->lead_hi, PLx(s, v)));
         if (key < best) { best = key; o->type = 2; o->p = p; o->k = k; o->dV = dV; o->dObj = dObj; }
     }
     return best;
@@ -439,7 +457,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 /* an exchange can also change who leads: a leader slot may shed a leader, a follower slot may gain one */
                 const int dvl = d_band((int)(co >> 16), kl == 0 ? -1 : +1, t->lead_lo, t->lead_hi);
                 const int sc = (type == 0) ? dvo + (dvr < 0 ? dvr : 0) : (dv7 < 0 ? dv7 : 0) + (dvl < 0 ? dvl : 0);
-                const uint32_t key = make_key(lam, S, sc, -role_w(t, pl, old, kl == 0 ? 0 : 1), l, type == 0 ? -Pof(s, old, kl == 0) : 0);
+                const uint32_t key = make_key(lam, S, sc, -role_w(t, pl, old, kl == 0 ? 0 : 1), l, type == 0 ? p_out((int)(co & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, old)) + (kl == 0 ? p_out((int)(co >> 16), t->lead_lo, t->lead_hi, PLx(s, old)) : 0) : 0);
                 if (key < keyA) { keyA = key; p = pl; k = kl; }
               }
             const uint16_t *a = s->A + p * RFP;
@@ -452,9 +470,13 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 int dV_old = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
                 if (k == 0) dV_old += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
                 const int dV_rack_old = d_band(s->K[ro], -1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, ro), -1, t->prack_lo, t->prack_hi);
-                int RT[256];
-                for (int r = 0; r < t->R; ++r)
+                int RT[256], RTP[256];
+                int dP_old = p_out((int)(co & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, old));
+                if (k == 0) dP_old += p_out((int)(co >> 16), t->lead_lo, t->lead_hi, PLx(s, old));
+                for (int r = 0; r < t->R; ++r) {
                     RT[r] = (r == ro) ? 0 : dV_rack_old + d_band(s->K[r], +1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, r), +1, t->prack_lo, t->prack_hi);
+                    RTP[r] = (r == ro) ? 0 : p_out(s->K[ro], t->rack_lo, t->rack_hi, PGx(s, ro)) + p_in(s->K[r], t->rack_lo, t->rack_hi, PGx(s, r));
+                }
                 uint32_t lane_key[LANES]; unsigned lane_x[LANES]; int lane_dV[LANES], lane_dO[LANES];
                 for (uint32_t l = 0; l < LANES; ++l) lane_key[l] = KEY_NULL;
                 for (int base = 0; base < t->Bx; base += LANES)
@@ -464,11 +486,14 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                         if ((int)x >= t->Bx || !valid_x(t, x)) continue;
                         s->n_eval += 1;
                         if (in_part(a, x)) continue;
+                        s->n_valid += 1;
                         const uint32_t cn = s->C[x];
                         int dV = dV_old + d_band((int)(cn & 0xFFFF), +1, t->rep_lo, t->rep_hi) + RT[rack_of_x(t, x)];
                         if (k == 0) dV += d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
                         const int dObj = role_w(t, p, x, nr) - g_old;
-                        const uint32_t key = make_key_tie(lam, S, dV, dObj, tie, Pof(s, x, k == 0) - Pof(s, old, k == 0));
+                        int dP = dP_old + p_in((int)(cn & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, x)) + RTP[rack_of_x(t, x)];
+                        if (k == 0) dP += p_in((int)(cn >> 16), t->lead_lo, t->lead_hi, PLx(s, x));
+                        const uint32_t key = make_key_tie(lam, S, dV, dObj, tie, dP);
                         if (key < lane_key[l]) { lane_key[l] = key; lane_x[l] = x; lane_dV[l] = dV; lane_dO[l] = dObj; }
                     }
                 for (uint32_t l = 0; l < LANES; ++l)
@@ -496,18 +521,20 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                             s->n_eval += 1;
                             const unsigned v = b[j];
                             if (q == p || u == v || in_part(a, v) || in_part(b, u)) continue;
+                            s->n_valid += 1;
                             const int nrq = j == 0 ? 0 : 1;
                             const int dObj = role_w(t, p, v, nr) + role_w(t, q, u, nrq) - gu_p - role_w(t, q, v, nrq);
-                            int dV = 0;
+                            int dV = 0, dP = 0;
                             if ((k == 0) != (j == 0)) {
                                 const unsigned lose = (k == 0) ? u : v, gain = (k == 0) ? v : u;
                                 dV += d_band((int)(s->C[lose] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[gain] >> 16), +1, t->lead_lo, t->lead_hi);
+                                dP = p_out((int)(s->C[lose] >> 16), t->lead_lo, t->lead_hi, PLx(s, lose)) + p_in((int)(s->C[gain] >> 16), t->lead_lo, t->lead_hi, PLx(s, gain));
                             }
                             const int rv = rack_of_x(t, v);
                             if (ru != rv)
                                 dV += d_band(rack_count(t, a, ru), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, a, rv), +1, t->prack_lo, t->prack_hi)
                                     + d_band(rack_count(t, b, rv), -1, t->prack_lo, t->prack_hi) + d_band(rack_count(t, b, ru), +1, t->prack_lo, t->prack_hi);
-                            const uint32_t key = make_key_tie(lam, S, dV, dObj, tie0 + (uint32_t)j * 0x55u, ((k == 0) != (j == 0)) ? ((k == 0) ? PLx(s, v) - PLx(s, u) : PLx(s, u) - PLx(s, v)) : 0);
+                            const uint32_t key = make_key_tie(lam, S, dV, dObj, tie0 + (uint32_t)j * 0x55u, dP);
                             if (key < lane_key[l]) { lane_key[l] = key; lane_q[l] = q; lane_j[l] = j; lane_dV[l] = dV; lane_dO[l] = dObj; }
                         }
                     }
@@ -526,7 +553,8 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
 /* ---- launch-by-launch replay of one restart (sessions with search prices and elite launches) ----
  * port_extra carries what the device reads at the start of a launch besides the restart's own state:
  *   search prices (K-bound's multipliers on the quarter grid, or host-set): dense index, fixed point 4096; key units are
- *   (obj_scale * v + 2048) >> 12 clamped to 16 bits -- replica price a[b] + g[rack(b)], leader price l[b];
+ *   (obj_scale * v + 2048) >> 12 clamped to 16 bits -- replica price a[b], leader price l[b], rack price g[r]; a price
+ *   enters the cost of a move only where the row's count leaves or re-enters its band (p_in / p_out above);
  *   the elite: the topic's best feasible assignment as of the previous step, its objective and its restart.  Elite rule:
  *   a restart other than the elite's whose best feasible objective is below the elite's re-seeds its state from it when
  *   bit 0 of fmix32(seed_lo ^ rho * 0x9E3779B1 ^ launch * 0x85EBCA77 ^ 0xE117E) is set. */
@@ -535,7 +563,7 @@ typedef struct {
     const uint16_t *elite;
     int32_t elite_obj, elite_rho;
 } port_extra;
-typedef struct { const ls_topic *t; ls_state s; port_params pp; uint32_t rho; int *PA, *PL; } ls_runner;
+typedef struct { const ls_topic *t; ls_state s; port_params pp; uint32_t rho; int *PA, *PL; int PG[256]; } ls_runner;
 
 static inline int price_units(int v, int S) {
     int u = (S * v + 2048) >> 12; /* arithmetic shift: floor */
@@ -568,14 +596,15 @@ int kao_port_run_launch(void *run, uint32_t launch, uint32_t iters, const port_e
     ls_runner *r = (ls_runner *)run;
     const ls_topic *t = r->t;
     ls_state *s = &r->s;
-    s->PA = NULL; s->PL = NULL;
+    s->PA = NULL; s->PL = NULL; s->PG = NULL;
     if (ex && ex->pa && ex->pl && ex->pg) {
         for (int b = 0; b < n_brokers; ++b) {
             const unsigned x = t->int_of[b];
-            r->PA[x] = price_units(ex->pa[b] + ex->pg[rack_of_x(t, x)], r->pp.obj_scale);
+            r->PA[x] = price_units(ex->pa[b], r->pp.obj_scale);
             r->PL[x] = price_units(ex->pl[b], r->pp.obj_scale);
         }
-        s->PA = r->PA; s->PL = r->PL;
+        for (int q = 0; q < 256; ++q) r->PG[q] = q < t->R ? price_units(ex->pg[q], r->pp.obj_scale) : 0;
+        s->PA = r->PA; s->PL = r->PL; s->PG = r->PG;
     }
     if (launch == 0) ls_init(t, s, &r->pp, r->rho);
     else if (ex && ex->elite) {
@@ -625,6 +654,21 @@ int kao_port_search(void *h, const port_params *pp, uint32_t rho, uint32_t launc
     stats[3] = (int64_t)(s.n_eval & 0xFFFFFFFFu); stats[4] = (int64_t)(s.n_eval >> 32); stats[5] = (int64_t)s.n_accept;
     free(s.A); free(s.C); free(s.best);
     return 0;
+}
+
+/* Fraction of the delta-evaluated neighbours of one restart that were real (non-null) proposals: bench.py multiplies the
+ * device's neighbour count by it (the device evaluates the same proposals, null ones included, and does not count them apart). */
+double kao_port_valid_fraction(void *h, const port_params *pp, uint32_t rho, uint32_t launches, uint32_t iters) {
+    const ls_topic *t = (const ls_topic *)h;
+    ls_state s; memset(&s, 0, sizeof s);
+    s.A = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * RFP);
+    s.C = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)t->Bx);
+    s.best = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * t->RF);
+    ls_init(t, &s, pp, rho);
+    for (uint32_t L = 0; L < launches; ++L) ls_run(t, &s, pp, rho, L, iters);
+    const double f = s.n_eval ? (double)s.n_valid / (double)s.n_eval : 0.0;
+    free(s.A); free(s.C); free(s.best);
+    return f;
 }
 
 /* Throughput driver for bench.py's cpu_baseline leg: restarts rho0 .. rho0+n-1 of one topic replayed on `threads`

@@ -60,6 +60,8 @@ def lib():
         _LIB.kao_port_run_launch.restype = C.c_int
         _LIB.kao_port_run_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_int64)]
         _LIB.kao_port_run_read.restype = C.c_int
+        _LIB.kao_port_valid_fraction.argtypes = [C.c_void_p, C.POINTER(PortParams), C.c_uint32, C.c_uint32, C.c_uint32]
+        _LIB.kao_port_valid_fraction.restype = C.c_double
         _LIB.kao_port_search_many.argtypes = [C.c_void_p, C.POINTER(PortParams)] + [C.c_uint32] * 5
         _LIB.kao_port_search_many.restype = C.c_uint64
         _LIB.kao_port_dual_partition.argtypes = [C.POINTER(PortTopic), C.c_int] + [C.POINTER(C.c_int32)] * 6
@@ -201,6 +203,24 @@ def quarter_round(v):
     """Multipliers on the quarter grid (what K-bound exports as search prices): nearest multiple of 1024, half up."""
     v = np.asarray(v, dtype=np.int64)
     return (((v + 512) >> 10) << 10).astype(np.int32)
+
+
+def port_valid_fraction(topic, seed: int, rho: int, launches: int, iters: int, **params) -> float:
+    """Share of one restart's delta-evaluated neighbours that were real (non-null) proposals."""
+    ct = CTopic(topic)
+    h = lib().kao_port_ls_create(C.byref(ct.s))
+    if not h:
+        raise ValueError("unsupported instance (RF > 4 or racks > 255)")
+    try:
+        pr = dict(DEFAULT_PARAMS)
+        pr.update(params)
+        if pr["period_log2"] is None:
+            pr["period_log2"] = auto_period_log2(topic)
+        pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
+                        lam_max=pr["lam_max"], period_log2=pr["period_log2"])
+        return float(lib().kao_port_valid_fraction(h, C.byref(pp), rho, launches, iters))
+    finally:
+        lib().kao_port_ls_destroy(h)
 
 
 def port_search_throughput(topic, seed: int, n_restarts: int, launches: int, iters: int, threads: int, **params) -> int:

@@ -23,6 +23,10 @@ for key in pick:
         "both-rec": (dict(), {"KAO_X_PRICE_SRC": "1"}),
         "both-last": (dict(), {"KAO_X_PRICE_SRC": "2"}),
         "both-rec/4": (dict(elite_period=max(1, ep // 4)), {"KAO_X_PRICE_SRC": "1"}),
+        "r128": (dict(restarts=128), {}), "r256": (dict(restarts=256), {}), "r512": (dict(restarts=512), {}),
+        "r1024": (dict(restarts=1024), {}), "r2048": (dict(restarts=2048), {}),
+        "i512": (dict(iters_per_launch=512), {}), "r512i512": (dict(restarts=512, iters_per_launch=512), {}),
+        "default": (dict(), {}),
     }
     t = sy.drift(sy.make_cluster(B, R, 1, P, 3, [], []), 0.2, 1)[0]
     kao.solve([t], seed=1, max_launches=1)  # warm the arena cache

@@ -9,6 +9,8 @@
 template <int KIND>
 __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t s0, uint32_t s1) {
     uint32_t a = threadIdx.x * 2654435761u + s0, b = a ^ s1, c = a + 7, d = b + 11, e = a ^ 0x1234567u, f = b * 3u, g = c + d, h = e ^ f;
+    unsigned long long p0 = ((unsigned long long)a << 32) | b, p1 = ((unsigned long long)c << 32) | d, p2 = ((unsigned long long)e << 32) | f,
+                       p3 = ((unsigned long long)g << 32) | h;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
         for (int r = 0; r < REP / 8; ++r) {
@@ -44,6 +46,18 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t s0, 
                              "v_min_u32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
                              "v_min_u32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_min_u32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
                              : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+            } else if (KIND == 8) {  // CONTROL: v_fma_f32 (the guide's table quotes 2 cycles per wave64 instruction for it)
+                asm volatile("v_fma_f32 %0, %0, %8, %1\n v_fma_f32 %1, %1, %8, %2\n v_fma_f32 %2, %2, %8, %3\n v_fma_f32 %3, %3, %8, %4\n"
+                             "v_fma_f32 %4, %4, %8, %5\n v_fma_f32 %5, %5, %8, %6\n v_fma_f32 %6, %6, %8, %7\n v_fma_f32 %7, %7, %8, %0\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(s1));
+            } else if (KIND == 9) {  // CONTROL: v_pk_fma_f32 (two fp32 FMAs per lane per instruction), 4 register pairs
+                asm volatile("v_pk_fma_f32 %0, %0, %2, %1\n v_pk_fma_f32 %1, %1, %3, %2\n v_pk_fma_f32 %2, %2, %0, %3\n v_pk_fma_f32 %3, %3, %1, %0\n"
+                             "v_pk_fma_f32 %0, %0, %2, %1\n v_pk_fma_f32 %1, %1, %3, %2\n v_pk_fma_f32 %2, %2, %0, %3\n v_pk_fma_f32 %3, %3, %1, %0\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+            } else if (KIND == 10) {  // CONTROL: fp32 FMA and integer add interleaved (do the two share one issue port?)
+                asm volatile("v_fma_f32 %0, %0, %8, %1\n v_add_u32 %1, %1, %8\n v_fma_f32 %2, %2, %8, %3\n v_add_u32 %3, %3, %8\n"
+                             "v_fma_f32 %4, %4, %8, %5\n v_add_u32 %5, %5, %8\n v_fma_f32 %6, %6, %8, %7\n v_add_u32 %7, %7, %8\n"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "s"(s1));
             } else {  // v_and_b32 / v_xor_b32 / v_lshl_or_b32 mix
                 asm volatile("v_and_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_lshl_or_b32 %2, %3, 16, %2\n v_and_b32 %3, %3, %4\n"
                              "v_xor_b32 %4, %4, %5\n v_lshl_or_b32 %5, %6, 16, %5\n v_and_b32 %6, %6, %7\n v_xor_b32 %7, %7, %0\n"
@@ -51,23 +65,23 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t s0, 
             }
         }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h ^ (uint32_t)(p0 ^ p1 ^ p2 ^ p3) ^ (uint32_t)((p0 ^ p1 ^ p2 ^ p3) >> 32);
 }
 
 template <int KIND>
-double run(const char *name, uint32_t *d_out, int blocks) {
+double run(const char *name, uint32_t *d_out, int blocks, int threads = 256) {
     const int iters = 4000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 10, 1u, 3u);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 10, 1u, 3u);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 1u, 3u);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 1u, 3u);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    const double winst = (double)blocks * 4 * iters * REP;  // wave-instructions
+    const double winst = (double)blocks * (threads / 64) * iters * REP;  // wave-instructions
     const double rate = winst / (ms * 1e-3);
     printf("%-44s %8.1f G wave-instr/s  = %.2f cycles per wave64 instruction per SIMD @2.4 GHz (1024 SIMDs)\n", name, rate / 1e9,
            1024.0 * 2.4e9 / rate);
@@ -86,5 +100,13 @@ int main() {
     run<3>("v_mul_hi_u32_u24", d_out, blocks);
     run<5>("v_mul_lo_u32", d_out, blocks);
     run<6>("v_min_u32_dpp", d_out, blocks);
+    // controls: does this harness reproduce the guide's 2-cycle figure for the fp32 FMA path?
+    run<8>("CONTROL v_fma_f32", d_out, blocks);
+    run<9>("CONTROL v_pk_fma_f32 (2 FMAs per lane)", d_out, blocks);
+    run<10>("CONTROL v_fma_f32 / v_add_u32 interleaved", d_out, blocks);
+    run<8>("CONTROL v_fma_f32, 1 wave per SIMD", d_out, 256, 256);
+    run<0>("v_add_u32, 1 wave per SIMD", d_out, 256, 256);
+    run<8>("CONTROL v_fma_f32, 2 waves per SIMD", d_out, 512, 256);
+    run<0>("v_add_u32, 2 waves per SIMD", d_out, 512, 256);
     return 0;
 }

@@ -5,14 +5,14 @@
 #   3. --pmc WRITE_SIZE       : HBM write traffic per dispatch  (separate pass)
 # Outputs land in gpurun_out/prof_<tag>/ ; copy the summaries into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 STEPS=${2:-10}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps $STEPS --warmup 2 --no-extras"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o bench -- $BENCH > "$OUT/bench_write.json" 2> "$OUT/write.err"

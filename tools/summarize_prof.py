@@ -88,7 +88,8 @@ try:
     try:
         with open(os.path.join(out, "bench_trace.json")) as f:
             b = json.loads(f.read().strip().splitlines()[-1])
-        meta = {"config": int(b["config"]["workload"][3]), "iters_per_launch": b["config"]["iters_per_launch"],
+        meta = {"config": int(b["config"]["workload"][3]), "workload_tag": "cfg%d-drift-fresh" % int(b["config"]["workload"][3]),
+                "iters_per_launch": b["config"]["iters_per_launch"],
                 "restarts_total": b["config"]["restarts_per_topic_rank0"] * b["config"]["topics_per_rank"][0],
                 "bench_hip_event_avg_launch_ms": b["roofline"]["avg_launch_ms"]}
     except Exception as e:  # noqa: BLE001
