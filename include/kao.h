@@ -101,7 +101,7 @@ typedef struct kao_opts {
 
 typedef struct kao_result {
     int32_t status;            /* KAO_STATUS_* */
-    int32_t best_restart;      /* which restart produced the answer */
+    int32_t best_restart;      /* which restart produced the answer (-1: adopted from another GPU, kao_solve_multi) */
     int64_t objective;         /* value of the README objective (README.md:145-146) */
     int64_t upper_bound;       /* min(closed-form bound (kao_upper_bound), K-bound dual certificate) */
     int32_t violations[8];     /* [0] total, [1..7] = C1..C7 magnitudes of the returned assignment */
@@ -230,10 +230,26 @@ void kao_session_destroy(kao_session *s);
 
 /* Whole job: create, step until target/time limit, read back, destroy. */
 int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results);
-/* Wall-clock breakdown of this thread's last kao_solve, seconds from its entry:
+/* Whole job on several GPUs of ONE process (one host thread drives all of them; launches of every device are enqueued
+ * before any is waited for).  devices[n_dev] = HIP device ordinals.
+ *   n_topics >= n_dev: topics are independent sub-problems (README.md:146-184) and are dealt to the devices (longest
+ *     processing time first by brokers x partitions); no exchange on the data path.
+ *   n_topics <  n_dev: every device searches every topic with its own seed; every elite_period launches the packed best
+ *     keys are min-allreduced on the device-resident buffers (ncclAllReduce, ncclUint64, ncclMin over xGMI) and each topic's
+ *     winning assignment is broadcast (ncclBroadcast), so that trailing restarts on EVERY device re-seed from the global
+ *     best; certificates are shared (any device's bound is valid).  K-bound runs on the first device only.
+ * Listing a device twice gives logical shards on one device (the same flow through plain copies; for tests on one GPU).
+ * librccl.so is loaded on first use.  Results as kao_solve. */
+int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *devices, int32_t n_dev, const kao_opts *opts,
+                    kao_result *results);
+/* Diagnostic: runs the two collectives kao_solve_multi uses (ncclAllReduce(ncclUint64, ncclMin) and ncclBroadcast) on
+ * small resident buffers of the listed distinct devices and checks the results.  0 = ok. */
+int kao_rccl_selftest(const int32_t *devices, int32_t n_dev);
+/* Wall-clock breakdown of this thread's last kao_solve / kao_solve_multi, seconds from its entry:
  * out[0] session ready (instance prepared + uploaded), out[1] last improving launch finished (time-to-best),
  * out[2] results read back, out[3] returned (buffers released); out[4] = launches run; out[5] = neighbours K-search
- * delta-evaluated in those launches (kao_stats.delta_candidates), out[6] = K-bound launches, out[7] = reserved. */
+ * delta-evaluated in those launches (kao_stats.delta_candidates, all devices), out[6] = K-bound launches, out[7] = elite
+ * exchanges between GPUs (kao_solve_multi). */
 int kao_last_solve_timing(double out[8]);
 
 #ifdef __cplusplus

@@ -77,6 +77,8 @@ SIGNATURES = {
                                  _P(C.c_int32), _P(C.c_int32)]),
     "kao_session_destroy": (None, [C.c_void_p]),
     "kao_solve": (C.c_int, [_P(KaoTopic), C.c_int32, _P(KaoOpts), _P(KaoResult)]),
+    "kao_solve_multi": (C.c_int, [_P(KaoTopic), C.c_int32, _P(C.c_int32), C.c_int32, _P(KaoOpts), _P(KaoResult)]),
+    "kao_rccl_selftest": (C.c_int, [_P(C.c_int32), C.c_int32]),
     "kao_last_solve_timing": (C.c_int, [_P(C.c_double)]),
 }
 

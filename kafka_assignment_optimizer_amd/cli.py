@@ -6,7 +6,7 @@ import argparse
 import json
 import sys
 
-from . import assignment_to_json, canonicalize, init, solve, topics_from_json
+from . import assignment_to_json, canonicalize, init, solve, solve_multi, topics_from_json
 
 
 def _racks(arg: str) -> dict:
@@ -26,6 +26,7 @@ def main(argv=None) -> int:
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--time-limit", type=float, default=10.0)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=1, help="solve on devices device .. device+gpus-1 (kao_solve_multi)")
     ap.add_argument("--no-canonical", action="store_true")
     ap.add_argument("--out", default="")
     ap.add_argument("--report", action="store_true")
@@ -38,7 +39,10 @@ def main(argv=None) -> int:
     topics = topics_from_json(doc, [int(b) for b in a.broker_list.split(",") if b], _racks(a.racks), rf=a.rf or None,
                               weights=((w[0], w[1]), (w[2], w[3])))
     init(a.device)
-    res = solve(topics, seed=a.seed, time_limit_s=a.time_limit, stop_at_bound=1, iters_per_launch=256)
+    if a.gpus > 1:
+        res = solve_multi(topics, list(range(a.device, a.device + a.gpus)), seed=a.seed, time_limit_s=a.time_limit, stop_at_bound=1)
+    else:
+        res = solve(topics, seed=a.seed, time_limit_s=a.time_limit, stop_at_bound=1)
     ok_topics, assigns, rc = [], [], 0
     for t, r in zip(topics, res):
         if r.status in ("NO_FEASIBLE", "INFEASIBLE_PROVEN"):

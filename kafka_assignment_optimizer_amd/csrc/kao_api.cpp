@@ -5,6 +5,8 @@
 // results back.  There is deliberately no CPU evaluation or search path here: if the HIP device is
 // missing every compute entry point fails with KAO_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is loaded on first use (kao_solve_multi), see Rccl below
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -23,9 +25,22 @@ using namespace kao;
 namespace {
 
 thread_local std::string g_err;
-int g_device = -1;
+int g_device = -1;           // the process default (kao_init)
 bool g_init = false;
-int g_num_cu = 256;
+thread_local int t_device = -1;  // per-thread override: kao_solve_multi drives several devices from one process
+constexpr int kMaxDevices = 64;
+int g_num_cu_of[kMaxDevices] = {0};
+
+int cur_device() { return t_device >= 0 ? t_device : g_device; }
+int num_cu(int device) {
+    if (device < 0 || device >= kMaxDevices) return 256;
+    if (!g_num_cu_of[device]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 256;
+        g_num_cu_of[device] = v;
+    }
+    return g_num_cu_of[device];
+}
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -485,9 +500,11 @@ struct kao_eval_plan {
     bool timed = false;
     int cands_per_block = 32;
     bool cur_in_lds = true;
+    int device = 0;
 };
 
 struct kao_session {
+    int device = 0;              // HIP device this session lives on
     int n_topics = 0;
     kao_opts opts{};
     std::vector<PreparedTopic> pts;
@@ -554,6 +571,7 @@ struct kao_session {
     int bound_iters_last = 0;
     double bound_ms_last = 0;
     unsigned long long *d_keys = nullptr;
+    unsigned long long *d_keys_glob = nullptr;  // receive buffer of the cross-GPU min-allreduce (kao_solve_multi)
     int32_t *d_drift = nullptr;
     int32_t *d_win_viol = nullptr;
     uint16_t *d_win_assign = nullptr;
@@ -573,16 +591,17 @@ namespace {
 constexpr int kEvRing = 32;
 
 // hipMalloc / hipFree cost 0.1-1 ms each; a finished session parks its arenas here for the next one
-struct Parked { void *p; size_t bytes; };
+struct Parked { void *p; size_t bytes; int device; };
 std::vector<Parked> g_parked;
 constexpr size_t kParkMax = 4;
 std::mutex g_cache_mu;  // guards g_parked / g_streams (sessions may be created from several host threads)
 
 int arena_get(size_t bytes, void **out, size_t *cap) {
     std::lock_guard<std::mutex> lock(g_cache_mu);
+    const int dev = cur_device();
     size_t best = g_parked.size();
     for (size_t i = 0; i < g_parked.size(); ++i)
-        if (g_parked[i].bytes >= bytes && g_parked[i].bytes <= 4 * bytes + (1u << 20) &&
+        if (g_parked[i].device == dev && g_parked[i].bytes >= bytes && g_parked[i].bytes <= 4 * bytes + (1u << 20) &&
             (best == g_parked.size() || g_parked[i].bytes < g_parked[best].bytes)) best = i;
     if (best < g_parked.size()) {
         *out = g_parked[best].p; *cap = g_parked[best].bytes;
@@ -594,36 +613,42 @@ int arena_get(size_t bytes, void **out, size_t *cap) {
     *cap = want;
     return KAO_OK;
 }
-void arena_put(void *p, size_t bytes) {
+void arena_put(void *p, size_t bytes, int device) {
     if (!p) return;
     std::lock_guard<std::mutex> lock(g_cache_mu);
+    (void)hipSetDevice(device);
     if (g_parked.size() >= kParkMax) {
         size_t small = 0;
         for (size_t i = 1; i < g_parked.size(); ++i) if (g_parked[i].bytes < g_parked[small].bytes) small = i;
         if (g_parked[small].bytes >= bytes) { (void)hipFree(p); return; }
+        (void)hipSetDevice(g_parked[small].device);
         (void)hipFree(g_parked[small].p);
+        (void)hipSetDevice(device);
         g_parked.erase(g_parked.begin() + (long)small);
     }
-    g_parked.push_back({p, bytes});
+    g_parked.push_back({p, bytes, device});
 }
-std::vector<hipStream_t> g_streams;  // parked streams (create/destroy cost ~1 ms)
+std::vector<std::pair<hipStream_t, int>> g_streams;  // parked streams with their device (create/destroy cost ~1 ms)
 int stream_get(hipStream_t *out) {
     std::lock_guard<std::mutex> lock(g_cache_mu);
-    if (!g_streams.empty()) { *out = g_streams.back(); g_streams.pop_back(); return KAO_OK; }
+    const int dev = cur_device();
+    for (size_t i = 0; i < g_streams.size(); ++i)
+        if (g_streams[i].second == dev) { *out = g_streams[i].first; g_streams.erase(g_streams.begin() + (long)i); return KAO_OK; }
     HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
     return KAO_OK;
 }
-void stream_put(hipStream_t st) {
+void stream_put(hipStream_t st, int device) {
     if (!st) return;
     std::lock_guard<std::mutex> lock(g_cache_mu);
-    if (g_streams.size() < 4) g_streams.push_back(st); else (void)hipStreamDestroy(st);
+    if (g_streams.size() < 16) g_streams.push_back({st, device}); else { (void)hipSetDevice(device); (void)hipStreamDestroy(st); }
 }
 void arena_drop_all() {
     std::lock_guard<std::mutex> lock(g_cache_mu);
-    for (auto &a : g_parked) (void)hipFree(a.p);
+    for (auto &a : g_parked) { (void)hipSetDevice(a.device); (void)hipFree(a.p); }
     g_parked.clear();
-    for (hipStream_t st : g_streams) (void)hipStreamDestroy(st);
+    for (auto &st : g_streams) { (void)hipSetDevice(st.second); (void)hipStreamDestroy(st.first); }
     g_streams.clear();
+    if (g_device >= 0) (void)hipSetDevice(g_device);
 }
 thread_local double g_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
@@ -646,7 +671,7 @@ int require_init() {
         int rc = kao_init(g_device < 0 ? 0 : g_device);
         if (rc) return rc;
     }
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(cur_device()));
     return KAO_OK;
 }
 
@@ -676,18 +701,19 @@ int kao_init(int device) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(KAO_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(KAO_ERR_INVALID, "device ordinal out of range");
-    if (g_init && device != g_device) { (void)hipSetDevice(g_device); arena_drop_all(); }  // parked memory belongs to the old device
     e = hipSetDevice(device);
     if (e != hipSuccess) return fail(KAO_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    (void)num_cu(device);
     g_device = device;
     g_init = true;
     return KAO_OK;
 }
 
+void kao_multi_shutdown_comms(void);
+
 void kao_shutdown(void) {
-    if (g_init) { (void)hipSetDevice(g_device); arena_drop_all(); }
+    kao_multi_shutdown_comms();
+    if (g_init) arena_drop_all();
     g_init = false;
 }
 
@@ -695,7 +721,7 @@ int kao_device_name(char *buf, int len) {
     int rc = require_init();
     if (rc) return rc;
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, g_device));
+    HIP_TRY(hipGetDeviceProperties(&prop, cur_device()));
     std::snprintf(buf, (size_t)len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     return KAO_OK;
 }
@@ -731,6 +757,7 @@ int kao_eval_plan_create(const kao_topic *t, kao_eval_plan **out) {
     int rc = require_init();
     if (rc) return rc;
     kao_eval_plan *p = new kao_eval_plan();
+    p->device = cur_device();
     rc = prepare(t, 0, p->pt);
     if (rc) { delete p; return rc; }
     p->cur_in_lds = eval_lds_bytes(p->pt.d.P, p->pt.d.B, true) <= 160 * 1024;
@@ -751,7 +778,7 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
                       void *d_best_key) {
     if (!p || !d_candidates || n < 1) return fail(KAO_ERR_INVALID, "bad plan/candidates");
     if (n > (1 << 20)) return fail(KAO_ERR_INVALID, "at most 2^20 candidates per run (packed key id width)");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(p->device));
     if (n != p->map_n) {
         const int cpb = p->cands_per_block;
         const int nb = (int)((n + cpb - 1) / cpb);
@@ -795,6 +822,7 @@ int kao_eval_plan_sync(kao_eval_plan *p, double *ms_last) {
 
 void kao_eval_plan_destroy(kao_eval_plan *p) {
     if (!p) return;
+    (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     (void)hipFree(p->d_topic); (void)hipFree(p->d_rackof); (void)hipFree(p->d_curd); (void)hipFree(p->d_map);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
@@ -889,7 +917,7 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
     if ((rc = arena_get(total, &dev, &cap))) return rc;
     unsigned char *db = static_cast<unsigned char *>(dev);
     hipStream_t st = nullptr;
-    if ((rc = stream_get(&st))) { arena_put(dev, cap); return rc; }
+    if ((rc = stream_get(&st))) { arena_put(dev, cap, cur_device()); return rc; }
     int32_t status[2] = {0, 0};
     hipError_t e = hipMemcpyAsync(db, stage.data(), total, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
@@ -901,8 +929,8 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
     if (e == hipSuccess) e = hipMemcpyAsync(a_words.data(), db + o_a, (size_t)P * 16, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(status, db + o_status, sizeof status, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    stream_put(st);
-    arena_put(dev, cap);
+    stream_put(st, cur_device());
+    arena_put(dev, cap, cur_device());
     if (e != hipSuccess) return fail(KAO_ERR_HIP, std::string("kao_canonicalize: ") + hipGetErrorString(e));
     if (!status[0]) return KAO_OK;  // only feasible assignments are polished
     for (int p = 0; p < P; ++p) {
@@ -928,16 +956,17 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
 // ------------------------------------------------------------------------------------------------
 void kao_session_destroy(kao_session *s) {
     if (!s) return;
+    (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->stream_bound) (void)hipStreamSynchronize(s->stream_bound);
     if (s->ev_bound0) (void)hipEventDestroy(s->ev_bound0);
     if (s->ev_bound1) (void)hipEventDestroy(s->ev_bound1);
     if (s->ev_search) (void)hipEventDestroy(s->ev_search);
     if (s->stream_bound) (void)hipStreamDestroy(s->stream_bound);
-    arena_put(s->arena_ro, s->arena_ro_bytes);
-    arena_put(s->arena_rw, s->arena_rw_bytes);
+    arena_put(s->arena_ro, s->arena_ro_bytes, s->device);
+    arena_put(s->arena_rw, s->arena_rw_bytes, s->device);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
-    stream_put(s->stream);
+    stream_put(s->stream, s->device);
     delete s;
 }
 
@@ -948,7 +977,9 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     int rc = require_init();
     if (rc) return rc;
     kao_session *s = new kao_session();
+    s->device = cur_device();
     s->n_topics = n_topics;
+    const int g_num_cu = num_cu(s->device);
     kao_opts o{};
     if (opts_in) o = *opts_in;
     if (o.iters_per_launch <= 0) o.iters_per_launch = 512;
@@ -973,7 +1004,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         const int cap = (int)std::max<int64_t>(g_num_cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves);
         o.restarts = std::min(o.restarts, cap);
     }
-    if (o.restarts > (1 << 20)) o.restarts = 1 << 20;
+    if (o.restarts > (1 << 20) - 2) o.restarts = (1 << 20) - 2;  // id 0xFFFFF is reserved (kExternalRestart)
     {   // huge topics: bound the per-restart state in HBM (16 B of working words + the snapshot per partition):
         // 1 GB when the count was chosen automatically, 8 GB for an explicit request
         uint64_t per_restart = 0;
@@ -1126,7 +1157,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->price_half_i32 = align_up(price_i32 * 4) / 4;
     const size_t price_b = 2 * s->price_half_i32 * 4;
     const size_t rw_bytes = state_b + best_b + info_b + obj_b + viol_b + align_up(s->readback_bytes) + dual_b + dtarget_b + dids_b +
-                            align_up(s->dual_rb_bytes) + price_b;
+                            align_up(s->dual_rb_bytes) + price_b + align_up((size_t)n_topics * 8);
     if ((rc = arena_get(rw_bytes, &s->arena_rw, &s->arena_rw_bytes))) { kao_session_destroy(s); return rc; }
     unsigned char *rw = static_cast<unsigned char *>(s->arena_rw);
     s->d_state = rw;
@@ -1146,7 +1177,8 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         s->d_dual_target = reinterpret_cast<long long *>(q); q += dtarget_b;
         s->d_dual_ids = reinterpret_cast<int32_t *>(q); q += dids_b;
         s->d_dual_rb = q; q += align_up(s->dual_rb_bytes);
-        s->d_price = reinterpret_cast<int32_t *>(q);
+        s->d_price = reinterpret_cast<int32_t *>(q); q += price_b;
+        s->d_keys_glob = reinterpret_cast<unsigned long long *>(q);
         s->dual_bytes = dual_b;
         s->dual_flags.assign((size_t)n_topics, 0);
         s->dual_iters.assign((size_t)n_topics, 0);
@@ -1176,7 +1208,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
 
 int kao_session_step(kao_session *s) {
     if (!s) return fail(KAO_ERR_INVALID, "null session");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(s->device));
     const bool prof = s->opts.profile != 0;
     if (prof && s->ev_pending == kEvRing) {
         int rc = session_drain_events(s);
@@ -1226,6 +1258,7 @@ int kao_session_step(kao_session *s) {
 
 int kao_session_sync(kao_session *s) {
     if (!s) return fail(KAO_ERR_INVALID, "null session");
+    HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->opts.profile) return session_drain_events(s);
     return KAO_OK;
@@ -1233,6 +1266,7 @@ int kao_session_sync(kao_session *s) {
 
 int kao_session_best_keys(kao_session *s, uint64_t *keys) {
     if (!s || !keys) return fail(KAO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpyAsync(keys, s->d_keys, (size_t)s->n_topics * 8, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return KAO_OK;
@@ -1240,7 +1274,7 @@ int kao_session_best_keys(kao_session *s, uint64_t *keys) {
 
 int kao_session_best(kao_session *s, kao_result *results) {
     if (!s || !results) return fail(KAO_ERR_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(s->device));
     launch_gather(s->d_topics, s->n_topics, s->d_keys, s->d_best, s->d_viol, s->d_win_assign, s->d_win_viol, s->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(s->h_readback.data(), s->d_readback, s->readback_bytes, hipMemcpyDeviceToHost, s->stream));
@@ -1259,7 +1293,7 @@ int kao_session_best(kao_session *s, kao_result *results) {
             std::memset(r.violations, 0, sizeof r.violations);
             continue;
         }
-        r.best_restart = (int)(key & 0xFFFFF);
+        r.best_restart = (key & 0xFFFFF) == kExternalRestart ? -1 : (int)(key & 0xFFFFF);  // -1: adopted from another GPU
         r.objective = (int64_t)kObjCap - (int64_t)((key >> 20) & 0xFFFFFF);
         std::memcpy(r.violations, wv + (size_t)t * 8, 32);
         if (r.assignment) std::memcpy(r.assignment, wa + d.win_off, (size_t)d.P * d.RF * 2);
@@ -1292,7 +1326,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
 int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters) {
     if (!s || !target) return fail(KAO_ERR_INVALID, "null argument");
     if (iters < 1) return fail(KAO_ERR_INVALID, "iters < 1");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(s->device));
     // the previous launch's H2D copies read the staging vectors below: wait for them before rewriting
     if (s->stream_bound) HIP_TRY(hipStreamSynchronize(s->stream_bound));
     s->h_dual_ids.clear();
@@ -1365,7 +1399,7 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
 
 int kao_session_set_prices(kao_session *s, int32_t topic, const int32_t *a, const int32_t *l, const int32_t *g) {
     if (!s || topic < 0 || topic >= s->n_topics || !a || !l || !g) return fail(KAO_ERR_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(s->device));
     const TopicDev &d = s->pts[(size_t)topic].d;
     std::vector<int32_t> buf(2 * (size_t)d.B + kRackTab, 0);
     std::memcpy(buf.data(), a, (size_t)d.B * 4);
@@ -1382,7 +1416,7 @@ int kao_session_set_prices(kao_session *s, int32_t topic, const int32_t *a, cons
 
 int kao_session_prices(kao_session *s, int32_t topic, int32_t *a, int32_t *l, int32_t *g) {
     if (!s || topic < 0 || topic >= s->n_topics) return fail(KAO_ERR_INVALID, "bad argument");
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(s->device));
     const TopicDev &d = s->pts[(size_t)topic].d;
     const int32_t *base = s->d_price + (size_t)s->price_read * s->price_half_i32 + d.price_off;
     HIP_TRY(hipStreamSynchronize(s->stream));
@@ -1395,7 +1429,7 @@ int kao_session_prices(kao_session *s, int32_t topic, int32_t *a, int32_t *l, in
 int kao_session_adopt_prices(kao_session *s) {
     if (!s) return fail(KAO_ERR_INVALID, "null session");
     if (s->price_write_last < 0) return KAO_OK;  // K-bound has not run: nothing to adopt
-    HIP_TRY(hipSetDevice(g_device));
+    HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream_bound));
     s->price_read = s->price_write_last;
     s->priced = true;
@@ -1404,6 +1438,7 @@ int kao_session_adopt_prices(kao_session *s) {
 
 int kao_session_bound_busy(kao_session *s) {
     if (!s) return fail(KAO_ERR_INVALID, "null session");
+    HIP_TRY(hipSetDevice(s->device));
     if (!s->bound_inflight) return 0;
     const hipError_t e = hipEventQuery(s->ev_bound1);
     if (e == hipErrorNotReady) return 1;
@@ -1413,6 +1448,7 @@ int kao_session_bound_busy(kao_session *s) {
 
 int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int32_t *iters) {
     if (!s) return fail(KAO_ERR_INVALID, "null session");
+    HIP_TRY(hipSetDevice(s->device));
     if (s->bound_launches) {
         std::vector<unsigned char> rb(s->dual_rb_bytes);
         HIP_TRY(hipMemcpyAsync(rb.data(), s->d_dual_rb, s->dual_rb_bytes, hipMemcpyDeviceToHost, s->stream_bound));
@@ -1443,6 +1479,7 @@ int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int
 
 int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l, int32_t *g, int64_t *best_dual) {
     if (!s || topic < 0 || topic >= s->n_topics) return fail(KAO_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(s->device));
     const TopicDev &d = s->pts[(size_t)topic].d;
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->stream_bound) HIP_TRY(hipStreamSynchronize(s->stream_bound));
@@ -1496,6 +1533,7 @@ int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, ui
     const PreparedTopic &pt = s->pts[(size_t)topic];
     const TopicDev &d = pt.d;
     if (restart < 0 || restart >= d.n_restarts) return fail(KAO_ERR_INVALID, "bad restart");
+    HIP_TRY(hipSetDevice(s->device));
     int rc = kao_session_sync(s);
     if (rc) return rc;
     if (final_state) {
@@ -1516,10 +1554,104 @@ int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, ui
     return KAO_OK;
 }
 
-int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results) {
-    const double t0 = now_s();
-    if (!results) return fail(KAO_ERR_INVALID, "null results");
+}  // extern "C"
+
+namespace {
+
+// One whole job on one device: the kao_solve loop, cut into steps so that kao_solve_multi can drive several of them in
+// lockstep from one host thread (launches of all devices are enqueued before any of them is waited for).
+struct SolveRun {
     kao_session *s = nullptr;
+    int n = 0;
+    bool has_target = false;
+    std::vector<int64_t> target;
+    std::vector<uint64_t> keys, prev;
+    std::vector<double> t_best;
+    std::vector<int64_t> dual_target;
+    double t0 = 0, t_last_improve = 0;
+    int launches = 0, dual_iters = 0, dual_now = 0;
+    bool use_prices = true, all_done = false;
+
+    ~SolveRun() { if (s) kao_session_destroy(s); }
+
+    // `so` is the caller's options with kao_solve's defaults applied; the session is created on the calling thread's device
+    int begin(const kao_topic *topics, int n_topics, const kao_opts &so, const int64_t *tgt, double t_start) {
+        n = n_topics; t0 = t_start;
+        int rc = kao_session_create(topics, n_topics, &so, &s);
+        if (rc) return rc;
+        has_target = tgt != nullptr;
+        if (tgt) target.assign(tgt, tgt + n_topics);
+        keys.assign((size_t)n, 0); prev.assign((size_t)n, ~0ull); t_best.assign((size_t)n, 0.0); dual_target.assign((size_t)n, -1);
+        const kao_opts &o = s->opts;
+        dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 128 : o.dual_iters);
+        dual_now = dual_iters;
+        use_prices = so.use_prices >= 0;
+        return KAO_OK;
+    }
+    int launch() { return kao_session_step(s); }   // asynchronous
+    bool feasible(int i) const { return (keys[(size_t)i] >> 44) == 0; }
+    int64_t objective(int i) const { return (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF); }
+    bool check_done() const {
+        for (int i = 0; i < n; ++i) {
+            if (s->topic_infeasible[(size_t)i]) continue;  // proven infeasible: nothing to wait for
+            const int64_t goal = has_target ? target[(size_t)i] : s->ub[(size_t)i];
+            if (!(feasible(i) && objective(i) >= goal)) return false;
+        }
+        return true;
+    }
+    // waits for the launch, books improvements, merges a finished K-bound launch and starts the next one
+    int after_launch() {
+        int rc = kao_session_best_keys(s, keys.data());
+        if (rc) return rc;
+        ++launches;
+        const double t = now_s() - t0;
+        for (int i = 0; i < n; ++i)
+            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; }
+        all_done = check_done();
+        if (!has_target && dual_iters > 0) {
+            // K-bound runs beside the search on its own stream; when a launch has finished its certificates are merged
+            // and, while some feasible incumbent is still below its bound, the next launch starts (aimed at the new
+            // incumbents).  Launch length adapts so that one launch takes about 10 ms.
+            const int busy = kao_session_bound_busy(s);
+            if (busy < 0) return busy;
+            if (!busy) {
+                if (s->bound_inflight) {
+                    if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
+                    // the finished launch's multipliers (rounded to quarters) become the prices of the next K-search launches
+                    if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
+                    if (s->bound_ms_last > 0) {
+                        const double scale = 10.0 / s->bound_ms_last;
+                        dual_now = (int)std::min(4096.0, std::max(32.0, s->bound_iters_last * std::min(4.0, std::max(0.25, scale))));
+                    }
+                    all_done = check_done();
+                }
+                bool any = false;
+                for (int i = 0; i < n && !all_done; ++i) {
+                    const bool want = feasible(i) && objective(i) < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
+                                      !(s->dual_flags[(size_t)i] & 6);
+                    dual_target[(size_t)i] = want ? objective(i) : -1;
+                    any |= want;
+                }
+                if (any && (rc = kao_session_bound_step(s, dual_target.data(), dual_now))) return rc;
+            }
+        }
+        return KAO_OK;
+    }
+    int finish(kao_result *results, bool hit_time) {
+        int rc = KAO_OK;
+        if (s->bound_inflight && (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;  // last K-bound launch
+        rc = kao_session_best(s, results);
+        if (!rc)
+            for (int i = 0; i < n; ++i) {
+                results[i].seconds_to_best = t_best[(size_t)i];
+                if (hit_time && results[i].status == KAO_STATUS_FEASIBLE_BOUND_GAP) results[i].status = KAO_STATUS_TIME_LIMIT;
+            }
+        return rc;
+    }
+};
+
+// kao_solve's defaults on top of the caller's options
+kao_opts solve_defaults(const kao_topic *topics, int32_t n_topics, const kao_opts *opts) {
     kao_opts so{};
     if (opts) so = *opts;
     if (so.iters_per_launch <= 0) {
@@ -1536,86 +1668,338 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
             lg = std::max(lg, so.period_log2 > 0 ? so.period_log2 : auto_period_log2(topics[i].n_partitions, std::max(topics[i].rf, 1)));
         so.elite_period = std::max(1, (1 << std::min(lg, 20)) / so.iters_per_launch);
     }
-    const bool use_prices = so.use_prices >= 0;
-    int rc = kao_session_create(topics, n_topics, &so, &s);
+    return so;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results) {
+    const double t0 = now_s();
+    if (!results) return fail(KAO_ERR_INVALID, "null results");
+    const kao_opts so = solve_defaults(topics, n_topics, opts);
+    SolveRun run;
+    int rc = run.begin(topics, n_topics, so, opts ? opts->target_objective : nullptr, t0);
     if (rc) return rc;
     g_timing[0] = now_s() - t0;
-    const kao_opts &o = s->opts;
-    const int64_t *target = opts ? opts->target_objective : nullptr;
-    std::vector<uint64_t> keys((size_t)n_topics), prev((size_t)n_topics, ~0ull);
-    std::vector<double> t_best((size_t)n_topics, 0.0);
+    const kao_opts &o = run.s->opts;
     bool hit_time = false;
-    int launches = 0;
-    double t_last_improve = 0;
-    const int dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 128 : o.dual_iters);
-    std::vector<int64_t> dual_target((size_t)n_topics);
-    int dual_now = dual_iters;
     for (;;) {
-        if ((rc = kao_session_step(s)) || (rc = kao_session_best_keys(s, keys.data()))) { kao_session_destroy(s); return rc; }
-        ++launches;
-        const double t = now_s() - t0;
-        bool all_done = true;
-        for (int i = 0; i < n_topics; ++i) {
-            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; }
-            const bool feasible = (keys[(size_t)i] >> 44) == 0;
-            const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
-            const int64_t goal = target ? target[i] : s->ub[(size_t)i];
-            if (s->topic_infeasible[(size_t)i]) continue;  // proven infeasible: nothing to wait for
-            if (!(feasible && obj >= goal)) all_done = false;
+        if ((rc = run.launch()) || (rc = run.after_launch())) return rc;
+        if (o.stop_at_bound && run.all_done) break;
+        if (o.max_launches > 0 && run.launches >= o.max_launches) break;
+        if (now_s() - t0 >= o.time_limit_s) { hit_time = true; break; }
+    }
+    g_timing[1] = run.t_last_improve;
+    rc = run.finish(results, hit_time);
+    g_timing[2] = now_s() - t0;
+    g_timing[5] = (double)run.s->delta_total;
+    g_timing[6] = (double)run.s->bound_launches;
+    kao_session_destroy(run.s);
+    run.s = nullptr;
+    g_timing[3] = now_s() - t0;
+    g_timing[4] = run.launches;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kao_solve_multi: one process, several GPUs
+// ------------------------------------------------------------------------------------------------
+namespace {
+// librccl.so is half a gigabyte of code objects; linking it would make every process that loads libkao.so (the CLI, a JVM)
+// pay for registering them.  It is opened on the first multi-GPU exchange instead.
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    bool load() {
+        if (h) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
         }
-        if (!target && dual_iters > 0) {
-            // K-bound runs beside the search on its own stream; when a launch has finished its certificates are merged
-            // and, while some feasible incumbent is still below its bound, the next launch starts (aimed at the new
-            // incumbents).  Launch length adapts so that one launch takes about 10 ms.
-            const int busy = kao_session_bound_busy(s);
-            if (busy < 0) { kao_session_destroy(s); return busy; }
-            if (!busy) {
-                if (s->bound_inflight) {
-                    if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) { kao_session_destroy(s); return rc; }
-                    // the finished launch's multipliers (rounded to quarters) become the prices of the next K-search launches
-                    if (use_prices && (rc = kao_session_adopt_prices(s))) { kao_session_destroy(s); return rc; }
-                    if (s->bound_ms_last > 0) {
-                        const double scale = 10.0 / s->bound_ms_last;
-                        dual_now = (int)std::min(4096.0, std::max(32.0, s->bound_iters_last * std::min(4.0, std::max(0.25, scale))));
+        if (!h) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(h, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(h, "ncclAllReduce"));
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(h, "ncclBroadcast"));
+        return CommInitAll && CommDestroy && GetErrorString && GroupStart && GroupEnd && AllReduce && Broadcast;
+    }
+} g_rccl;
+struct CommSet { std::vector<int> devices; std::vector<ncclComm_t> comms; };
+std::vector<CommSet> g_comms;   // RCCL communicators per device list (creation costs ~100 ms; kept until kao_shutdown)
+std::mutex g_comm_mu;
+int comms_for(const std::vector<int> &devices, std::vector<ncclComm_t> &out) {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    for (const CommSet &c : g_comms) if (c.devices == devices) { out = c.comms; return KAO_OK; }
+    if (!g_rccl.load()) return fail(KAO_ERR_HIP, std::string("librccl.so not available: ") + (dlerror() ? dlerror() : "missing symbol"));
+    CommSet c; c.devices = devices; c.comms.resize(devices.size());
+    const ncclResult_t r = g_rccl.CommInitAll(c.comms.data(), (int)devices.size(), devices.data());
+    if (r != ncclSuccess) return fail(KAO_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+    g_comms.push_back(c);
+    out = c.comms;
+    return KAO_OK;
+}
+}  // namespace
+
+void kao_multi_shutdown_comms(void) {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    for (CommSet &c : g_comms) for (ncclComm_t cm : c.comms) (void)g_rccl.CommDestroy(cm);
+    g_comms.clear();
+}
+
+// Diagnostic: the collectives kao_solve_multi uses, on small resident buffers of the listed (distinct) devices -- rank r holds
+// keys {100 - r, 7 + r, ~0, r}; after ncclAllReduce(ncclUint64, ncclMin) every rank must hold {101 - n, 7, ~0, 0}, and after
+// ncclBroadcast from the last rank every rank holds that rank's 64-byte pattern.  0 = ok.
+int kao_rccl_selftest(const int32_t *devices, int32_t n_dev) {
+    if (!devices || n_dev < 1 || n_dev > kMaxDevices) return fail(KAO_ERR_INVALID, "bad device list");
+    std::vector<int> devs(devices, devices + n_dev);
+    std::vector<ncclComm_t> comms;
+    int rc = comms_for(devs, comms);
+    if (rc) return rc;
+    std::vector<unsigned long long *> keys((size_t)n_dev, nullptr), out((size_t)n_dev, nullptr);
+    std::vector<unsigned char *> pat((size_t)n_dev, nullptr);
+    std::vector<hipStream_t> st((size_t)n_dev, nullptr);
+    bool ok = true;
+    for (int d = 0; d < n_dev && ok; ++d) {
+        ok = hipSetDevice(devs[(size_t)d]) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&keys[(size_t)d]), 32) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&out[(size_t)d]), 32) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&pat[(size_t)d]), 64) == hipSuccess &&
+             hipStreamCreateWithFlags(&st[(size_t)d], hipStreamNonBlocking) == hipSuccess;
+        const unsigned long long h[4] = {100ull - (unsigned)d, 7ull + (unsigned)d, ~0ull, (unsigned long long)d};
+        unsigned char p[64];
+        for (int i = 0; i < 64; ++i) p[i] = (unsigned char)(d * 64 + i);
+        ok = ok && hipMemcpy(keys[(size_t)d], h, 32, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pat[(size_t)d], p, 64, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    ncclResult_t nr = ok ? g_rccl.GroupStart() : ncclSystemError;
+    for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) nr = g_rccl.AllReduce(keys[(size_t)d], out[(size_t)d], 4, ncclUint64, ncclMin, comms[(size_t)d], st[(size_t)d]);
+    if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = g_rccl.GroupStart();
+    for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) nr = g_rccl.Broadcast(pat[(size_t)d], pat[(size_t)d], 64, ncclUint8, n_dev - 1, comms[(size_t)d], st[(size_t)d]);
+    if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+    ok = ok && nr == ncclSuccess;
+    for (int d = 0; d < n_dev && ok; ++d) {
+        unsigned long long h[4]; unsigned char p[64];
+        ok = hipSetDevice(devs[(size_t)d]) == hipSuccess && hipStreamSynchronize(st[(size_t)d]) == hipSuccess &&
+             hipMemcpy(h, out[(size_t)d], 32, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(p, pat[(size_t)d], 64, hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && h[0] == 101ull - (unsigned)n_dev && h[1] == 7ull && h[2] == ~0ull && h[3] == 0ull;
+        for (int i = 0; i < 64 && ok; ++i) ok = p[i] == (unsigned char)((n_dev - 1) * 64 + i);
+    }
+    for (int d = 0; d < n_dev; ++d) {
+        (void)hipSetDevice(devs[(size_t)d]);
+        (void)hipFree(keys[(size_t)d]); (void)hipFree(out[(size_t)d]); (void)hipFree(pat[(size_t)d]);
+        if (st[(size_t)d]) (void)hipStreamDestroy(st[(size_t)d]);
+    }
+    if (cur_device() >= 0) (void)hipSetDevice(cur_device());
+    if (!ok) return fail(KAO_ERR_HIP, nr != ncclSuccess ? std::string("RCCL: ") + g_rccl.GetErrorString(nr) : std::string("RCCL self-test: wrong result"));
+    return KAO_OK;
+}
+
+int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *devices, int32_t n_dev, const kao_opts *opts,
+                    kao_result *results) {
+    const double t0 = now_s();
+    if (!topics || n_topics < 1 || !results) return fail(KAO_ERR_INVALID, "no topics / null results");
+    if (!devices || n_dev < 1 || n_dev > kMaxDevices) return fail(KAO_ERR_INVALID, "bad device list");
+    int n_hw = 0;
+    if (hipGetDeviceCount(&n_hw) != hipSuccess || n_hw <= 0) return fail(KAO_ERR_NO_DEVICE, "no HIP device");
+    std::vector<int> devs(devices, devices + n_dev);
+    bool distinct = true;
+    for (int i = 0; i < n_dev; ++i) {
+        if (devs[(size_t)i] < 0 || devs[(size_t)i] >= n_hw) return fail(KAO_ERR_INVALID, "device ordinal out of range");
+        for (int j = 0; j < i; ++j) distinct &= devs[(size_t)j] != devs[(size_t)i];
+    }
+    if (!g_init) { int rc0 = kao_init(devs[0]); if (rc0) return rc0; }
+    const kao_opts so = solve_defaults(topics, n_topics, opts);
+    const bool replicated = n_topics < n_dev;   // fewer topics than GPUs: every GPU searches every topic, elites are exchanged
+    // ---- shards: LPT by brokers x partitions (independent sub-problems, README.md:146-184) ----
+    std::vector<std::vector<int>> shard((size_t)n_dev);
+    if (replicated) for (auto &sh : shard) for (int i = 0; i < n_topics; ++i) sh.push_back(i);
+    else {
+        std::vector<int> order((size_t)n_topics);
+        for (int i = 0; i < n_topics; ++i) order[(size_t)i] = i;
+        auto size_of = [&](int i) { return (int64_t)topics[i].n_brokers * topics[i].n_partitions; };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return size_of(a) > size_of(b); });
+        std::vector<int64_t> load((size_t)n_dev, 0);
+        for (int i : order) {
+            int best = 0;
+            for (int d = 1; d < n_dev; ++d) if (load[(size_t)d] < load[(size_t)best]) best = d;
+            shard[(size_t)best].push_back(i);
+            load[(size_t)best] += size_of(i);
+        }
+    }
+    std::vector<ncclComm_t> comms;
+    const bool use_rccl = replicated && distinct;   // logical shards on one device (tests) merge through the host instead
+    if (use_rccl) { int rc0 = comms_for(devs, comms); if (rc0) return rc0; }
+
+    struct Dev { SolveRun run; std::vector<kao_topic> tp; std::vector<kao_result> res; std::vector<int64_t> tgt; };
+    std::vector<Dev> D((size_t)n_dev);
+    const int saved_t_device = t_device;
+    auto cleanup = [&]() { t_device = saved_t_device; if (cur_device() >= 0) (void)hipSetDevice(cur_device()); };
+    int rc = KAO_OK;
+    for (int d = 0; d < n_dev && !rc; ++d) {
+        Dev &x = D[(size_t)d];
+        for (int i : shard[(size_t)d]) { x.tp.push_back(topics[i]); if (opts && opts->target_objective) x.tgt.push_back(opts->target_objective[i]); }
+        if (x.tp.empty()) continue;
+        kao_opts o = so;
+        o.seed = so.seed + 0x9E3779B97F4A7C15ull * (uint64_t)d;            // replicated topics: a different seed per GPU
+        if (replicated && d > 0) o.dual_iters = -1;                        // one certificate per topic is enough: device 0 runs K-bound
+        t_device = devs[(size_t)d];
+        if (hipSetDevice(t_device) != hipSuccess) { rc = fail(KAO_ERR_NO_DEVICE, "hipSetDevice"); break; }
+        rc = x.run.begin(x.tp.data(), (int)x.tp.size(), o, x.tgt.empty() ? nullptr : x.tgt.data(), t0);
+    }
+    if (rc) { cleanup(); return rc; }
+    g_timing[0] = now_s() - t0;
+    const int exch = std::max(1, so.elite_period);
+    bool hit_time = false;
+    int rounds = 0;
+    uint64_t exchanges = 0;
+    std::vector<uint64_t> gmin((size_t)n_topics);
+    std::vector<int> root((size_t)n_topics);
+    for (;;) {
+        for (int d = 0; d < n_dev && !rc; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; rc = D[(size_t)d].run.launch(); }
+        for (int d = 0; d < n_dev && !rc; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; rc = D[(size_t)d].run.after_launch(); }
+        if (rc) break;
+        ++rounds;
+        if (replicated) {
+            // certificates: any GPU's bound is valid for the topic
+            for (int i = 0; i < n_topics; ++i) {
+                int64_t ub = INT64_MAX;
+                for (Dev &x : D) ub = std::min(ub, x.run.s->ub[(size_t)i]);
+                for (Dev &x : D) x.run.s->ub[(size_t)i] = ub;
+            }
+            if (rounds % exch == 0 || so.stop_at_bound) {
+                // ---- elite exchange: min-allreduce of the packed best keys on the resident buffers, winners broadcast ----
+                bool differ = false;
+                for (int i = 0; i < n_topics; ++i) {
+                    gmin[(size_t)i] = ~0ull; root[(size_t)i] = 0;
+                    for (int d = 0; d < n_dev; ++d) {
+                        const uint64_t k = D[(size_t)d].run.keys[(size_t)i] | 0;  // host copy read by after_launch
+                        if (k < gmin[(size_t)i]) { gmin[(size_t)i] = k; root[(size_t)i] = d; }
                     }
-                    all_done = true;
-                    for (int i = 0; i < n_topics; ++i) {
-                        if (s->topic_infeasible[(size_t)i]) continue;
-                        const bool feasible = (keys[(size_t)i] >> 44) == 0;
-                        const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
-                        if (!(feasible && obj >= s->ub[(size_t)i])) all_done = false;
+                    for (int d = 0; d < n_dev; ++d) differ |= (D[(size_t)d].run.keys[(size_t)i] >> 20) != (gmin[(size_t)i] >> 20);
+                }
+                if (differ && rounds % exch == 0) {
+                    ++exchanges;
+                    for (int d = 0; d < n_dev && !rc; ++d) {   // stage every GPU's current winners
+                        kao_session *s = D[(size_t)d].run.s;
+                        if (hipSetDevice(s->device) != hipSuccess) { rc = fail(KAO_ERR_HIP, "hipSetDevice"); break; }
+                        launch_gather(s->d_topics, s->n_topics, s->d_keys, s->d_best, s->d_viol, s->d_win_assign, s->d_win_viol, s->stream);
                     }
+                    if (!rc && use_rccl) {
+                        ncclResult_t nr = g_rccl.GroupStart();
+                        for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) {
+                            kao_session *s = D[(size_t)d].run.s;
+                            nr = g_rccl.AllReduce(s->d_keys, s->d_keys_glob, (size_t)n_topics, ncclUint64, ncclMin, comms[(size_t)d], s->stream);
+                        }
+                        if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+                        for (int i = 0; i < n_topics && nr == ncclSuccess; ++i) {
+                            if ((gmin[(size_t)i] >> 44) != 0) continue;   // no feasible assignment anywhere yet
+                            nr = g_rccl.GroupStart();
+                            for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) {
+                                kao_session *s = D[(size_t)d].run.s;
+                                const TopicDev &td = s->pts[(size_t)i].d;
+                                uint16_t *buf = s->d_win_assign + td.win_off;
+                                nr = g_rccl.Broadcast(buf, buf, (size_t)td.P * td.RF * 2, ncclUint8, root[(size_t)i], comms[(size_t)d], s->stream);
+                            }
+                            if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+                        }
+                        if (nr != ncclSuccess) rc = fail(KAO_ERR_HIP, std::string("RCCL elite exchange: ") + g_rccl.GetErrorString(nr));
+                    } else if (!rc) {   // logical shards on one device: same data movement through plain copies
+                        for (int d = 0; d < n_dev && !rc; ++d) {
+                            kao_session *s = D[(size_t)d].run.s;
+                            if (hipSetDevice(s->device) != hipSuccess) { rc = fail(KAO_ERR_HIP, "hipSetDevice"); break; }
+                            for (int r2 = 0; r2 < n_dev; ++r2) (void)hipStreamSynchronize(D[(size_t)r2].run.s->stream);
+                            if (hipMemcpyAsync(s->d_keys_glob, gmin.data(), (size_t)n_topics * 8, hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = fail(KAO_ERR_HIP, "hipMemcpyAsync");
+                            for (int i = 0; i < n_topics && !rc; ++i) {
+                                if ((gmin[(size_t)i] >> 44) != 0 || root[(size_t)i] == d) continue;
+                                kao_session *sr = D[(size_t)root[(size_t)i]].run.s;
+                                const TopicDev &td = s->pts[(size_t)i].d;
+                                if (hipMemcpyAsync(s->d_win_assign + td.win_off, sr->d_win_assign + td.win_off, (size_t)td.P * td.RF * 2,
+                                                   hipMemcpyDeviceToDevice, s->stream) != hipSuccess) rc = fail(KAO_ERR_HIP, "hipMemcpyAsync");
+                            }
+                            if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(KAO_ERR_HIP, "hipStreamSynchronize");  // gmin is reused
+                        }
+                    }
+                    for (int d = 0; d < n_dev && !rc; ++d) {
+                        kao_session *s = D[(size_t)d].run.s;
+                        if (hipSetDevice(s->device) != hipSuccess) { rc = fail(KAO_ERR_HIP, "hipSetDevice"); break; }
+                        launch_adopt_global(s->d_keys, s->d_keys_glob, n_topics, s->stream);
+                        if (hipGetLastError() != hipSuccess) rc = fail(KAO_ERR_HIP, "k_adopt_global");
+                    }
+                    if (rc) break;
                 }
-                bool any = false;
-                for (int i = 0; i < n_topics && !all_done; ++i) {
-                    const bool feasible = (keys[(size_t)i] >> 44) == 0;
-                    const int64_t obj = (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF);
-                    const bool want = feasible && obj < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
-                                      !(s->dual_flags[(size_t)i] & 6);
-                    dual_target[(size_t)i] = want ? obj : -1;
-                    any |= want;
-                }
-                if (any && (rc = kao_session_bound_step(s, dual_target.data(), dual_now))) { kao_session_destroy(s); return rc; }
+                for (Dev &x : D)   // every run now judges "done" against the global incumbents
+                    for (int i = 0; i < n_topics; ++i) if (gmin[(size_t)i] < x.run.keys[(size_t)i]) x.run.keys[(size_t)i] = gmin[(size_t)i];
+                for (Dev &x : D) x.run.all_done = x.run.check_done();
             }
         }
-        if (o.stop_at_bound && all_done) break;
-        if (o.max_launches > 0 && launches >= o.max_launches) break;
-        if (t >= o.time_limit_s) { hit_time = true; break; }
+        bool all = true;
+        for (Dev &x : D) if (x.run.s) all &= x.run.all_done;
+        if (replicated) { all = false; for (Dev &x : D) all |= x.run.all_done; }   // one GPU holding proven optima for every topic suffices
+        if (so.stop_at_bound && all) break;
+        if (so.max_launches > 0 && rounds >= so.max_launches) break;
+        const double tl = so.time_limit_s > 0 ? so.time_limit_s : 10.0;
+        if (now_s() - t0 >= tl) { hit_time = true; break; }
     }
-    g_timing[1] = t_last_improve;
-    if (s->bound_inflight && (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) { kao_session_destroy(s); return rc; }  // last K-bound launch
-    rc = kao_session_best(s, results);
-    g_timing[2] = now_s() - t0;
-    g_timing[5] = (double)s->delta_total;
-    g_timing[6] = (double)s->bound_launches;
-    if (!rc)
-        for (int i = 0; i < n_topics; ++i) {
-            results[i].seconds_to_best = t_best[(size_t)i];
-            if (hit_time && results[i].status == KAO_STATUS_FEASIBLE_BOUND_GAP) results[i].status = KAO_STATUS_TIME_LIMIT;
+    // ---- results ----
+    double t_improve = 0, cand = 0, bl = 0;
+    if (!rc) {
+        if (replicated) {   // per topic: the GPU holding the best key answers
+            std::vector<std::vector<kao_result>> rs((size_t)n_dev, std::vector<kao_result>((size_t)n_topics));
+            std::vector<std::vector<std::vector<uint16_t>>> bufs((size_t)n_dev);
+            for (int d = 0; d < n_dev && !rc; ++d) {
+                bufs[(size_t)d].resize((size_t)n_topics);
+                for (int i = 0; i < n_topics; ++i) {
+                    bufs[(size_t)d][(size_t)i].assign((size_t)topics[i].n_partitions * topics[i].rf, (uint16_t)KAO_NONE);
+                    rs[(size_t)d][(size_t)i] = kao_result{};
+                    rs[(size_t)d][(size_t)i].assignment = bufs[(size_t)d][(size_t)i].data();
+                }
+                t_device = devs[(size_t)d];
+                rc = D[(size_t)d].run.finish(rs[(size_t)d].data(), hit_time);
+            }
+            for (int i = 0; i < n_topics && !rc; ++i) {
+                int best = 0;
+                auto better = [&](const kao_result &a, const kao_result &b) {   // feasible first, then objective
+                    const bool fa = a.status != KAO_STATUS_NO_FEASIBLE && a.status != KAO_STATUS_INFEASIBLE_PROVEN;
+                    const bool fb = b.status != KAO_STATUS_NO_FEASIBLE && b.status != KAO_STATUS_INFEASIBLE_PROVEN;
+                    return fa != fb ? fa : a.objective > b.objective;
+                };
+                for (int d = 1; d < n_dev; ++d) if (better(rs[(size_t)d][(size_t)i], rs[(size_t)best][(size_t)i])) best = d;
+                uint16_t *dst = results[i].assignment;
+                results[i] = rs[(size_t)best][(size_t)i];
+                results[i].assignment = dst;
+                if (dst) std::memcpy(dst, bufs[(size_t)best][(size_t)i].data(), bufs[(size_t)best][(size_t)i].size() * 2);
+                int64_t ub = INT64_MAX;
+                for (int d = 0; d < n_dev; ++d) ub = std::min(ub, rs[(size_t)d][(size_t)i].upper_bound);
+                results[i].upper_bound = ub;
+                if (results[i].status == KAO_STATUS_FEASIBLE_BOUND_GAP || results[i].status == KAO_STATUS_TIME_LIMIT || results[i].status == KAO_STATUS_OPTIMAL_PROVEN)
+                    results[i].status = results[i].objective >= ub ? KAO_STATUS_OPTIMAL_PROVEN : (hit_time ? KAO_STATUS_TIME_LIMIT : KAO_STATUS_FEASIBLE_BOUND_GAP);
+            }
+        } else {
+            for (int d = 0; d < n_dev && !rc; ++d) {
+                Dev &x = D[(size_t)d];
+                if (!x.run.s) continue;
+                x.res.assign(x.tp.size(), kao_result{});
+                for (size_t k = 0; k < x.tp.size(); ++k) x.res[k].assignment = results[shard[(size_t)d][k]].assignment;
+                t_device = devs[(size_t)d];
+                rc = x.run.finish(x.res.data(), hit_time);
+                for (size_t k = 0; k < x.tp.size() && !rc; ++k) results[shard[(size_t)d][k]] = x.res[k];
+            }
         }
-    kao_session_destroy(s);
-    g_timing[3] = now_s() - t0;
-    g_timing[4] = launches;
+    }
+    g_timing[2] = now_s() - t0;
+    for (Dev &x : D) if (x.run.s) { t_improve = std::max(t_improve, x.run.t_last_improve); cand += (double)x.run.s->delta_total; bl += (double)x.run.s->bound_launches; }
+    for (int d = 0; d < n_dev; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; kao_session_destroy(D[(size_t)d].run.s); D[(size_t)d].run.s = nullptr; }
+    cleanup();
+    g_timing[1] = t_improve; g_timing[3] = now_s() - t0; g_timing[4] = rounds; g_timing[5] = cand; g_timing[6] = bl; g_timing[7] = (double)exchanges;
     return rc;
 }
 

@@ -17,6 +17,7 @@ constexpr int kDualStage = 100;           // level control: iterations per stage
 constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
 constexpr int kDualQuarterLog2 = 10;      // kDualScale / 4 = 2^10: the quarter grid of the rounding probes and the search prices
 constexpr int kDualProbes = 2;            // probes per K-bound launch: multipliers rounded to the quarter grid, then the half grid
+constexpr uint32_t kExternalRestart = 0xFFFFFu;  // restart id of a best key adopted from another GPU (kao_solve_multi)
 constexpr uint32_t kObjCap = 0xFFFFFFu;   // packed best key: viol(20) << 44 | (kObjCap - obj) << 20 | restart(20)
 
 // Device-side descriptor of one topic.  Read once per workgroup (wave-uniform -> SGPRs).
@@ -113,6 +114,8 @@ void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
 // read-back buffers: one D2H instead of two per topic
 void launch_gather(const TopicDev *topics, int n_topics, const unsigned long long *keys, const uint16_t *best_pool,
                    const int32_t *viol, uint16_t *win_assign, int32_t *win_viol, void *stream);
+
+void launch_adopt_global(unsigned long long *keys, const unsigned long long *glob, int n, void *stream);
 
 // K-bound: Lagrangian dual bound, one workgroup (`waves` wavefronts) per listed topic
 size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds);

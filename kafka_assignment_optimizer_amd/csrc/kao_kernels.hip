@@ -894,11 +894,24 @@ __global__ __launch_bounds__(64) void k_gather(const TopicDev *topics, const uns
     const unsigned long long key = keys[blockIdx.x];
     if (key == ~0ull) return;
     const int rho = (int)(key & 0xFFFFFull);
+    if (rho == (int)kExternalRestart) {  // the topic's best came from another GPU (kao_solve_multi): win_assign already holds it
+        if (threadIdx.x < 8) win_viol[blockIdx.x * 8 + threadIdx.x] = 0;  // only feasible assignments are exchanged
+        return;
+    }
     const int n = TD->P * TD->RF;
     const uint16_t *src = best_pool + TD->best_off + (uint64_t)rho * n;
     uint16_t *dst = win_assign + TD->win_off;
     for (int i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
     if (threadIdx.x < 8) win_viol[blockIdx.x * 8 + threadIdx.x] = viol[(size_t)(TD->restart_base + rho) * 8 + threadIdx.x];
+}
+
+// After the min-allreduce of the packed best keys across GPUs (kao_solve_multi, replicated topics): where another GPU's key
+// beats the local one, adopt it with the reserved restart id kExternalRestart (its assignment arrives by broadcast).
+__global__ __launch_bounds__(64) void k_adopt_global(unsigned long long *keys, const unsigned long long *glob, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long g = glob[i];
+    if (g < keys[i] && (g >> 44) == 0) keys[i] = g | (unsigned long long)kExternalRestart;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1436,10 +1449,14 @@ size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds) {
     return 32 + r + d + kWaves * (c + kRackTab * 4);
 }
 
-static int g_attr_search = 0, g_attr_eval = 0;
+// largest dynamic-LDS size each kernel has been enabled for, per device (function attributes are per device)
+constexpr int kAttrDevices = 64;
+static int g_attr_search_dev[kAttrDevices] = {0}, g_attr_eval_dev[kAttrDevices] = {0}, g_attr_bound_dev[kAttrDevices] = {0};
+static int attr_slot() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kAttrDevices) ? d : 0; }
 
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, void *stream) {
     const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced);
+    int &g_attr_search = g_attr_search_dev[attr_slot()];
     if ((int)lds > g_attr_search) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1457,6 +1474,7 @@ void launch_search(const SearchPools &pools, const SearchParams &prm, int n_bloc
 
 void launch_eval(const EvalPools &pools, int n_blocks, void *stream) {
     const size_t lds = eval_lds_bytes(pools.maxP, pools.maxB, pools.cur_in_lds != 0);
+    int &g_attr_eval = g_attr_eval_dev[attr_slot()];
     if ((int)lds > g_attr_eval) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_eval = (int)lds;
@@ -1470,6 +1488,10 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
                        win_assign, win_viol);
 }
 
+void launch_adopt_global(unsigned long long *keys, const unsigned long long *glob, int n, void *stream) {
+    hipLaunchKernelGGL(k_adopt_global, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), keys, glob, n);
+}
+
 size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds) {
     size_t n = 80 + (3 * (size_t)kRackTab + kRackTab + 2 + 48 + 24) * 4 + (size_t)maxR * (2 * 4 + 2 * 5) * 4;
     n += 16 * (size_t)maxB + 2 * (((size_t)maxB + 7) & ~(size_t)7) + (((size_t)maxB + 15) & ~(size_t)15);
@@ -1477,10 +1499,10 @@ size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds) {
     return n + (cur_in_lds ? 8 * (size_t)maxP : 0);
 }
 
-static int g_attr_bound = 0;
 
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream) {
     const size_t lds = bound_lds_bytes(pools.maxB, pools.maxP, pools.maxR, pools.cur_in_lds != 0);
+    int &g_attr_bound = g_attr_bound_dev[attr_slot()];
     if ((int)lds > g_attr_bound) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bound), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_bound = (int)lds;

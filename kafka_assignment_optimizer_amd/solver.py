@@ -354,9 +354,32 @@ def solve(topics: Sequence[Topic], target_objective: Optional[Sequence[int]] = N
     return _unpack(topics, res, bufs)
 
 
+def solve_multi(topics: Sequence[Topic], devices: Sequence[int], target_objective: Optional[Sequence[int]] = None, **opts) -> List[Result]:
+    """Whole job on several GPUs of this process (kao_solve_multi): topics are dealt to the devices; with fewer topics
+    than devices every device searches every topic and the elites are exchanged over RCCL (min-allreduce of the packed
+    best keys + broadcast of the winner)."""
+    topics = list(topics)
+    ct = _CTopics(topics)
+    opts.setdefault("stop_at_bound", 1)
+    o = _make_opts(**opts)
+    if target_objective is not None:
+        tgt = (C.c_int64 * len(topics))(*[int(v) for v in target_objective])
+        o.target_objective = tgt
+    dev = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    res, bufs = _results_buffers(topics)
+    _check(_ffi.load().kao_solve_multi(ct.arr, len(topics), dev, len(devices), C.byref(o), res), "kao_solve_multi")
+    return _unpack(topics, res, bufs)
+
+
+def rccl_selftest(devices: Sequence[int]) -> None:
+    """Runs the collectives of kao_solve_multi (min-allreduce of uint64 keys, broadcast) on the listed devices; raises on failure."""
+    dev = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    _check(_ffi.load().kao_rccl_selftest(dev, len(devices)), "kao_rccl_selftest")
+
+
 def last_solve_timing() -> dict:
     """C-side wall-clock breakdown of the last kao_solve (seconds from its entry)."""
     out = (C.c_double * 8)()
     _check(_ffi.load().kao_last_solve_timing(out), "kao_last_solve_timing")
     return dict(session_ready=out[0], time_to_best=out[1], results_read_back=out[2], returned=out[3], launches=int(out[4]),
-                delta_candidates=int(out[5]), bound_launches=int(out[6]))
+                delta_candidates=int(out[5]), bound_launches=int(out[6]), elite_exchanges=int(out[7]))

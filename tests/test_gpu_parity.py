@@ -769,3 +769,41 @@ def test_dual_bound_limits_and_errors(kao, ko):
         s.bound_step([100, 58], 100)
         b = s.bounds()
         assert b["flags"][0] == 8 and b["iters"][0] == 0 and b["upper_bound"][1] == 58
+
+
+# ------------------------------------------------------------------------------- several GPUs in one process (kao_solve_multi)
+def test_solve_multi_sharded_matches_single_device(kao, ko):
+    """Topics dealt to two logical shards on device 0 through the C ABI: the same proven optima as kao_solve."""
+    ots = ko.gen_config(4, n_topics=9).topics
+    pts = [to_product_topic(t) for t in ots]
+    one = kao.solve(pts, seed=5, time_limit_s=20)
+    two = kao.solve_multi(pts, [0, 0], seed=5, time_limit_s=20)
+    full = load_golden("cfg4_full.json")["topics"]
+    for i, (ot, a, b) in enumerate(zip(ots, one, two)):
+        assert a.status == b.status == "OPTIMAL_PROVEN"
+        assert a.objective == b.objective == full[i]["objective"]
+        obj, viol = ko.verify(ot, b.assignment)
+        assert viol[0] == 0 and obj == b.objective
+
+
+def test_solve_multi_replicated_exchanges_elites(kao, ko):
+    """Fewer topics than devices: every (logical) device searches the topic, the best keys are min-reduced and the winner's
+    assignment travels to the others (host copies for logical shards; one device alone goes through RCCL, world size 1)."""
+    ot = _drifted(ko, 2, 1)[0]
+    pt = to_product_topic(ot)
+    g = load_golden("cfg2_drift.json")["topics"][0]
+    for devices in ([0, 0, 0], [0]):
+        r = kao.solve_multi([pt], devices, seed=21, time_limit_s=20, elite_period=2)[0]
+        tm = kao.last_solve_timing()
+        assert r.status == "OPTIMAL_PROVEN" and r.objective == g["objective"], (devices, r.status, r.objective)
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == r.objective
+        if len(devices) > 1:
+            assert tm["elite_exchanges"] >= 0
+
+
+def test_rccl_collectives_on_the_resident_buffers(kao):
+    """The RCCL path of kao_solve_multi (librccl.so opened on first use, ncclCommInitAll, ncclAllReduce(ncclUint64, ncclMin),
+    ncclBroadcast) on the devices this box has -- one here, so a world of one; the same entry point checks 8 on a full node."""
+    import torch
+    kao.rccl_selftest(list(range(torch.cuda.device_count())))

@@ -129,7 +129,7 @@ def test_java_cli_mirrors_the_cpp_cli_flags():
     java = open(os.path.join(ROOT, "cli", "java", "io", "sqooba", "kao", "KaoCli.java")).read()
     cpp_flags = set(re.findall(r'a == "(--[a-z-]+)"', cpp))
     java_flags = set(re.findall(r'case "(--[a-z-]+)"', java))
-    assert cpp_flags - java_flags == {"--emit-lp", "--lp-only"} and java_flags <= cpp_flags
+    assert cpp_flags - java_flags == {"--emit-lp", "--lp-only", "--gpus"} and java_flags <= cpp_flags   # (multi-GPU: C++ CLI only)
     assert '{\\"version\\":1,\\"partitions\\":[' in java and "Kao.solve(" in java and "Kao.canonicalize(" in java
 
 
