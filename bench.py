@@ -252,6 +252,8 @@ def main():
 
     def one_step(sess):
         sess.step(1)
+        if world > 1 and not share:   # min-allreduce on the resident key buffer (RCCL), no host round trip
+            return multigpu.allreduce_best_resident(sess, owned, n_topics, rank)
         keys = sess.best_keys()  # syncs the session stream
         if world > 1:
             return multigpu.allreduce_best(keys, owned, n_topics, rank, device=dev)

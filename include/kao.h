@@ -157,7 +157,8 @@ int kao_canonicalize(const kao_topic *t, uint16_t *assignment);
 
 /* ---- K-eval: full evaluation of complete candidates (README.md:145-180 in one pass) ---- */
 /* One candidate from host memory.  Stands in for "substitute the 0/1 vector into every row of
- * the generated model". */
+ * the generated model".  Per-broker counters are 16 + 16 bits (replicas | leaders): a candidate that puts more than
+ * 65,535 replicas on one broker (possible only when P*RF > 65535) is reported as KAO_ERR_UNSUPPORTED, never mis-counted. */
 int kao_evaluate(const kao_topic *t, const uint16_t *assignment, int64_t *objective, int32_t violations[8]);
 /* n candidates [n][P*rf] from host memory; objective[n], violations[n*8]. */
 int kao_evaluate_batch(const kao_topic *t, const uint16_t *candidates, int64_t n, int32_t *objective,
@@ -182,6 +183,10 @@ int kao_session_best(kao_session *s, kao_result *results);
 /* Per-topic packed best keys as the device holds them (uint64[n_topics]); the value a
  * min-allreduce across GPUs operates on: viol(20b) << 44 | (0xFFFFFF - objective) << 20 | restart. */
 int kao_session_best_keys(kao_session *s, uint64_t *keys);
+/* The same keys where they live: DEVICE pointer to uint64[n_topics] (valid for the session's lifetime; written by K-eval on
+ * the session's stream -- kao_session_sync first).  What a one-process-per-GPU host hands to ncclAllReduce(..., ncclMin)
+ * without a host round trip (kafka_assignment_optimizer_amd/multigpu.py::allreduce_best_resident). */
+int kao_session_device_keys(kao_session *s, void **d_keys);
 int kao_session_stats(kao_session *s, kao_stats *out);
 /* K-bound: the optimality certificate beyond the closed-form bound (kao_upper_bound).  lp_solve proves optimality
  * by branch-and-bound over the LP relaxation (README.md:135-136); K-bound instead minimises the Lagrangian dual of

@@ -63,6 +63,7 @@ SIGNATURES = {
     "kao_session_sync": (C.c_int, [C.c_void_p]),
     "kao_session_best": (C.c_int, [C.c_void_p, _P(KaoResult)]),
     "kao_session_best_keys": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    "kao_session_device_keys": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),
     "kao_session_stats": (C.c_int, [C.c_void_p, _P(KaoStats)]),
     "kao_session_restart_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_uint16), _P(C.c_uint16),
                                             _P(C.c_int32)]),

@@ -493,6 +493,7 @@ struct kao_eval_plan {
     uint8_t *d_rackof = nullptr;
     uint16_t *d_curd = nullptr;
     int4 *d_map = nullptr;
+    int32_t *d_overflow = nullptr;  // set by K-eval when a candidate overflows a 16-bit per-broker counter (P*RF > 65535 only)
     int64_t map_n = -1;
     int map_blocks = 0;
     hipStream_t stream = nullptr;
@@ -767,6 +768,10 @@ int kao_eval_plan_create(const kao_topic *t, kao_eval_plan **out) {
     if ((rc = dev_alloc_copy(&p->d_topic, td)) || (rc = dev_alloc_copy(&p->d_rackof, p->pt.rack_of)) ||
         (rc = dev_alloc_copy(&p->d_curd, p->pt.cur_dense))) { kao_eval_plan_destroy(p); return rc; }
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && (int64_t)p->pt.d.P * p->pt.d.RF > 65535) {
+        e = hipMalloc(reinterpret_cast<void **>(&p->d_overflow), 4);
+        if (e == hipSuccess) e = hipMemset(p->d_overflow, 0, 4);
+    }
     if (e == hipSuccess) e = hipEventCreate(&p->ev0);
     if (e == hipSuccess) e = hipEventCreate(&p->ev1);
     if (e != hipSuccess) { kao_eval_plan_destroy(p); return fail(KAO_ERR_HIP, std::string("kao_eval_plan_create: ") + hipGetErrorString(e)); }
@@ -801,6 +806,7 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
     pl.violations = static_cast<int32_t *>(d_violations);
     pl.best_key = static_cast<unsigned long long *>(d_best_key);
     pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B; pl.cur_in_lds = p->cur_in_lds ? 1 : 0;
+    pl.overflow = p->d_overflow;
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     launch_eval(pl, p->map_blocks, p->stream);
     HIP_TRY(hipGetLastError());
@@ -812,6 +818,14 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
 int kao_eval_plan_sync(kao_eval_plan *p, double *ms_last) {
     if (!p) return fail(KAO_ERR_INVALID, "null plan");
     HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->d_overflow) {
+        int32_t flag = 0;
+        HIP_TRY(hipMemcpy(&flag, p->d_overflow, 4, hipMemcpyDeviceToHost));
+        if (flag) {
+            HIP_TRY(hipMemset(p->d_overflow, 0, 4));
+            return fail(KAO_ERR_UNSUPPORTED, "a candidate puts more than 65,535 replicas on one broker (16-bit per-broker counters)");
+        }
+    }
     if (ms_last) {
         float ms = 0;
         if (p->timed) HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
@@ -824,7 +838,7 @@ void kao_eval_plan_destroy(kao_eval_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->d_topic); (void)hipFree(p->d_rackof); (void)hipFree(p->d_curd); (void)hipFree(p->d_map);
+    (void)hipFree(p->d_topic); (void)hipFree(p->d_rackof); (void)hipFree(p->d_curd); (void)hipFree(p->d_map); (void)hipFree(p->d_overflow);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1269,6 +1283,12 @@ int kao_session_best_keys(kao_session *s, uint64_t *keys) {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpyAsync(keys, s->d_keys, (size_t)s->n_topics * 8, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    return KAO_OK;
+}
+
+int kao_session_device_keys(kao_session *s, void **d_keys) {
+    if (!s || !d_keys) return fail(KAO_ERR_INVALID, "null argument");
+    *d_keys = s->d_keys;
     return KAO_OK;
 }
 
@@ -1720,8 +1740,18 @@ struct Rccl {
     decltype(&ncclBroadcast) Broadcast = nullptr;
     bool load() {
         if (h) return true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // RCCL must sit on the SAME HIP / HSA runtime instance this library runs on (a process may hold two: PyTorch wheels
+        // bundle their own next to /opt/rocm's): look for librccl next to the libamdhip64 that serves our HIP calls first
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) { dir.resize(slash); names.push_back(dir + "/librccl.so.1"); names.push_back(dir + "/librccl.so"); }
+        }
+        names.push_back("librccl.so.1"); names.push_back("librccl.so"); names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const std::string &name : names) {
+            h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (h) break;
         }
         if (!h) return false;
@@ -1742,6 +1772,12 @@ int comms_for(const std::vector<int> &devices, std::vector<ncclComm_t> &out) {
     std::lock_guard<std::mutex> lock(g_comm_mu);
     for (const CommSet &c : g_comms) if (c.devices == devices) { out = c.comms; return KAO_OK; }
     if (!g_rccl.load()) return fail(KAO_ERR_HIP, std::string("librccl.so not available: ") + (dlerror() ? dlerror() : "missing symbol"));
+    for (int d : devices) {  // RCCL expects every device's primary context to exist already
+        if (hipSetDevice(d) != hipSuccess || hipFree(nullptr) != hipSuccess) return fail(KAO_ERR_HIP, "cannot initialise device " + std::to_string(d));
+        void *probe = nullptr;
+        if (hipMalloc(&probe, 256) == hipSuccess) (void)hipFree(probe);
+    }
+    if (cur_device() >= 0) (void)hipSetDevice(cur_device());
     CommSet c; c.devices = devices; c.comms.resize(devices.size());
     const ncclResult_t r = g_rccl.CommInitAll(c.comms.data(), (int)devices.size(), devices.data());
     if (r != ncclSuccess) return fail(KAO_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));

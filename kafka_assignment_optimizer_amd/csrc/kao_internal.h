@@ -86,6 +86,8 @@ struct EvalPools {
     unsigned long long *best_key;// [n_topics] or nullptr (atomicMin of the packed key)
     int32_t maxP, maxB;
     int32_t cur_in_lds;          // 1 = stage the current assignment in LDS (fits); 0 = read it from global memory
+    int32_t *overflow;           // [1] or nullptr: set when a candidate puts more than 65,535 replicas on one broker (the 16-bit
+                                 //     halves of the per-broker counters would carry; only possible when P*RF > 65535)
 };
 
 struct BoundPools {

@@ -774,17 +774,25 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
 
     unsigned long long my_key = ~0ull;
     const int nB4 = (B + 3) >> 2;  // counters zeroed 16 bytes per lane per store (C is 16-byte aligned and padded)
+    // Rack counters: the 64 lanes of a wavefront hit only R addresses, so one LDS atomic per replica would serialise (10 racks:
+    // ~5 lanes per address).  They are privatised per 16-lane row -- 4 copies inside the same 256-entry table when R <= 64 --
+    // added without return value, and the band rows C6 are evaluated from the totals in one pass at the end.
+    const int KR = (R + 15) & ~15;
+    const int kcopy = 4 * KR <= kRackTab ? (lane >> 4) * KR : 0;
+    const bool k4 = 4 * KR <= kRackTab;
+    const bool big = P * RF > 65535;   // only then can a 16-bit per-broker counter overflow
     for (int ci = bm.y + wave; ci < bm.y + bm.z; ci += kWaves) {
         const uint16_t *cand = pl.cand + TD->best_off + (uint64_t)ci * P * RF;
         for (int b4 = lane; b4 < nB4; b4 += 64) reinterpret_cast<uint4 *>(C)[b4] = make_uint4(0, 0, 0, 0);
         for (int r = lane; r < kRackTab; r += 64) K[r] = 0;
-        // Band violations are accumulated from the value each LDS atomic RETURNS: adding a replica to a
+        // Broker band violations are accumulated from the value each LDS atomic RETURNS: adding a replica to a
         // broker whose count was c changes band(c) by (c >= hi) - (c < lo), and sum_b band(0) = B*lo, so
         // no pass over all brokers is needed.  Packed partial sums: low half = #(old >= hi), high = #(old < lo).
         int obj = 0;
         uint32_t s12 = 0;  // v1 | v2 << 16
-        uint32_t s3 = 0, s4 = 0, s6 = 0;
+        uint32_t s3 = 0, s4 = 0;
         uint32_t s57 = 0;  // v5 | v7 << 16
+        bool ovf = false;
         for (int p = lane; p < P; p += 64) {
             const uint16_t *ap = cand + (size_t)p * RF;  // a wavefront reads 64*RF consecutive u16: coalesced
             uint32_t b0 = ap[0], b1 = 0xFFFFu, b2 = 0xFFFFu, b3 = 0xFFFFu;
@@ -800,37 +808,37 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             if (ok0) {
                 r0 = RACK[b0];
                 const uint32_t oc = atomicAdd(&C[b0], 0x10001u);
-                const int ok = atomicAdd(&K[r0], 1);
+                __hip_atomic_fetch_add(&K[kcopy + r0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int cr = (int)(oc & 0xFFFFu), cl = (int)(oc >> 16);
                 s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);     // C3
                 s4 += (uint32_t)(cl >= lead_hi) + ((uint32_t)(cl < lead_lo) << 16);   // C4
-                s6 += (uint32_t)(ok >= rack_hi) + ((uint32_t)(ok < rack_lo) << 16);   // C6
+                if (big) ovf |= cr == 0xFFFF;
                 obj += (c0 == b0) ? w00 : (((c1 == b0) | (c2 == b0) | (c3 == b0)) ? w10 : 0);
             }
             if (ok1) {
                 r1 = RACK[b1];
                 const int cr = (int)(atomicAdd(&C[b1], 1u) & 0xFFFFu);
-                const int ok = atomicAdd(&K[r1], 1);
+                __hip_atomic_fetch_add(&K[kcopy + r1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
-                s6 += (uint32_t)(ok >= rack_hi) + ((uint32_t)(ok < rack_lo) << 16);
+                if (big) ovf |= cr == 0xFFFF;
                 obj += (c0 == b1) ? w01 : (((c1 == b1) | (c2 == b1) | (c3 == b1)) ? w11 : 0);
                 s57 += (uint32_t)(b1 == b0);  // C5: f+l <= 1 (an earlier slot holds the same broker)
             }
             if (ok2) {
                 r2 = RACK[b2];
                 const int cr = (int)(atomicAdd(&C[b2], 1u) & 0xFFFFu);
-                const int ok = atomicAdd(&K[r2], 1);
+                __hip_atomic_fetch_add(&K[kcopy + r2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
-                s6 += (uint32_t)(ok >= rack_hi) + ((uint32_t)(ok < rack_lo) << 16);
+                if (big) ovf |= cr == 0xFFFF;
                 obj += (c0 == b2) ? w01 : (((c1 == b2) | (c2 == b2) | (c3 == b2)) ? w11 : 0);
                 s57 += (uint32_t)((b2 == b0) | (b2 == b1));
             }
             if (ok3) {
                 r3 = RACK[b3];
                 const int cr = (int)(atomicAdd(&C[b3], 1u) & 0xFFFFu);
-                const int ok = atomicAdd(&K[r3], 1);
+                __hip_atomic_fetch_add(&K[kcopy + r3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
-                s6 += (uint32_t)(ok >= rack_hi) + ((uint32_t)(ok < rack_lo) << 16);
+                if (big) ovf |= cr == 0xFFFF;
                 obj += (c0 == b3) ? w01 : (((c1 == b3) | (c2 == b3) | (c3 == b3)) ? w11 : 0);
                 s57 += (uint32_t)((b3 == b0) | (b3 == b1) | (b3 == b2));
             }
@@ -842,23 +850,29 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             if (ok3 && r3 != r0 && r3 != r1 && r3 != r2) { s7 += band(1, prack_lo, prack_hi); touched++; }
             s57 += (uint32_t)(s7 + (R - touched) * prack_lo) << 16;
         }
+        // C6 from the rack totals (the wavefront's own LDS operations complete in order: no barrier needed)
+        int s6 = 0;
+        for (int r = lane; r < R; r += 64) {
+            const int tot = k4 ? K[r] + K[KR + r] + K[2 * KR + r] + K[3 * KR + r] : K[r];
+            s6 += band(tot, rack_lo, rack_hi);
+        }
+        if (big && __ballot(ovf) != 0ull && pl.overflow && lane == 0) atomicOr(pl.overflow, 1);
         obj = wave_sum(obj);
         int v1, v2, v3, v4, v5, v6, v7;
         if (P * RF <= 32767) {  // packed halves cannot carry: every count is at most P*RF
             const uint32_t t12 = (uint32_t)wave_sum((int)s12), t3 = (uint32_t)wave_sum((int)s3), t4 = (uint32_t)wave_sum((int)s4);
-            const uint32_t t6 = (uint32_t)wave_sum((int)s6), t57 = (uint32_t)wave_sum((int)s57);
+            const uint32_t t57 = (uint32_t)wave_sum((int)s57);
             v1 = (int)(t12 & 0xFFFFu); v2 = (int)(t12 >> 16);
             v3 = B * rep_lo + (int)(t3 & 0xFFFFu) - (int)(t3 >> 16);
             v4 = B * lead_lo + (int)(t4 & 0xFFFFu) - (int)(t4 >> 16);
-            v6 = R * rack_lo + (int)(t6 & 0xFFFFu) - (int)(t6 >> 16);
             v5 = (int)(t57 & 0xFFFFu); v7 = (int)(t57 >> 16);
         } else {  // huge topic: per-lane halves still fit 16 bits, the wavefront totals do not -> sum them unpacked
             v1 = wave_sum((int)(s12 & 0xFFFFu)); v2 = wave_sum((int)(s12 >> 16));
             v3 = B * rep_lo + wave_sum((int)(s3 & 0xFFFFu)) - wave_sum((int)(s3 >> 16));
             v4 = B * lead_lo + wave_sum((int)(s4 & 0xFFFFu)) - wave_sum((int)(s4 >> 16));
-            v6 = R * rack_lo + wave_sum((int)(s6 & 0xFFFFu)) - wave_sum((int)(s6 >> 16));
             v5 = wave_sum((int)(s57 & 0xFFFFu)); v7 = wave_sum((int)(s57 >> 16));
         }
+        v6 = wave_sum(s6);
         const int v0 = v1 + v2 + v3 + v4 + v5 + v6 + v7;
         const int out = bm.w + (ci - bm.y);
         if (lane == 0) {

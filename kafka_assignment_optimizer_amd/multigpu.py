@@ -69,6 +69,32 @@ def allreduce_best(local_keys_u64: np.ndarray, owned: Sequence[int], n_topics: i
     return t.cpu().numpy()
 
 
+class _DevKeys:
+    """Exposes a session's resident key buffer to torch (no copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 3}
+
+
+def allreduce_best_resident(sess, owned: Sequence[int], n_topics: int, rank: int):
+    """The same min-allreduce without leaving the GPU: the session's packed keys are read where K-eval wrote them (zero-copy
+    view), re-packed with the rank on the device, scattered into a [n_topics] int64 tensor and all-reduced (RCCL ncclMin over
+    xGMI when the backend is "nccl").  Returns the DEVICE tensor (same encoding as allreduce_best)."""
+    import torch
+    import torch.distributed as dist
+
+    sess.sync()                                   # K-eval wrote the keys on the session's own stream
+    dev = torch.device("cuda", torch.cuda.current_device())
+    full = torch.full((n_topics,), KEY_NONE, dtype=torch.int64, device=dev)
+    if len(owned):
+        k = torch.as_tensor(_DevKeys(sess.device_keys_ptr(), len(owned)), device=dev)
+        viol = torch.clamp((k >> 44) & 0xFFFFF, max=0x7FFF)
+        rest = k & ((1 << 44) - 1)
+        full[torch.as_tensor(list(owned), dtype=torch.int64, device=dev)] = (viol << (44 + RANK_BITS)) | (rest << RANK_BITS) | rank
+    dist.all_reduce(full, op=dist.ReduceOp.MIN)
+    return full
+
+
 def allreduce_bounds(local_bounds: Sequence[int], owned: Sequence[int], n_topics: int, device=None) -> np.ndarray:
     """Min-allreduce of the per-topic certificates (kao_result.upper_bound).  Every rank's value is a valid upper bound
     on the topic's optimum (closed-form bound or a Lagrangian dual value), so the smallest one is the best certificate --

@@ -220,6 +220,12 @@ class Session:
         _check(_ffi.load().kao_session_best(self._h, res), "kao_session_best")
         return _unpack(self.topics, res, bufs)
 
+    def device_keys_ptr(self) -> int:
+        """DEVICE address of the packed best keys (uint64[n_topics]); sync() before reading them from another stream."""
+        p = C.c_void_p()
+        _check(_ffi.load().kao_session_device_keys(self._h, C.byref(p)), "kao_session_device_keys")
+        return int(p.value)
+
     def best_keys(self) -> np.ndarray:
         keys = np.zeros(len(self.topics), dtype=np.uint64)
         _check(_ffi.load().kao_session_best_keys(self._h, keys.ctypes.data_as(C.POINTER(C.c_uint64))),

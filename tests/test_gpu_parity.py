@@ -15,7 +15,7 @@ libkao.so; the oracle (numpy verifier, C port, HiGHS golden optima) is only the 
 import numpy as np
 import pytest
 
-from conftest import load_golden, random_candidates, to_product_topic
+from conftest import ROOT as ROOT_DIR, load_golden, random_candidates, to_product_topic
 
 pytestmark = pytest.mark.gpu
 
@@ -807,3 +807,46 @@ def test_rccl_collectives_on_the_resident_buffers(kao):
     ncclBroadcast) on the devices this box has -- one here, so a world of one; the same entry point checks 8 on a full node."""
     import torch
     kao.rccl_selftest(list(range(torch.cuda.device_count())))
+
+
+def test_allreduce_best_resident_matches_host_packing(kao, ko):
+    """multigpu.allreduce_best_resident (zero-copy view of the session's key buffer, packed and all-reduced on the GPU) ==
+    multigpu.allreduce_best (host packing) -- RCCL world of one here."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle"))
+        import numpy as np, torch, torch.distributed as dist
+        import kafka_assignment_optimizer_amd as kao
+        from kafka_assignment_optimizer_amd import multigpu, synthetic
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(0); kao.init(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        topics = synthetic.drift(synthetic.make_config(4, n_topics=6), 0.2, 1)
+        owned = [1, 3, 4, 6, 7, 9]
+        with kao.Session(topics, seed=5, restarts=8, iters_per_launch=64) as s:
+            s.step(2)
+            a = multigpu.allreduce_best_resident(s, owned, 10, 0).cpu().numpy()
+            b = multigpu.allreduce_best(s.best_keys(), owned, 10, 0, device=torch.device("cuda", 0))
+        assert a.tolist() == b.tolist(), (a, b)
+        assert (a[[0, 2, 5, 8]] == multigpu.KEY_NONE).all() and (a[owned] != multigpu.KEY_NONE).all()
+        dist.destroy_process_group()
+        print("resident-ok")
+    """) % (ROOT_DIR, ROOT_DIR)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "resident-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_eval_counter_overflow_is_reported(kao, ko):
+    """a candidate with more than 65,535 replicas on one broker would carry out of the 16-bit counter half --
+    K-eval reports it (KAO_ERR_UNSUPPORTED) instead of returning wrong violation counts."""
+    from kafka_assignment_optimizer_amd import Topic
+    B, P = 8, 70000
+    ok = (np.arange(P) % B).astype(np.uint16).reshape(P, 1)
+    t = Topic(name="big", broker_ids=np.arange(B), rack_of=np.arange(B) % 2, n_racks=2, n_partitions=P, rf=1, current=ok.copy())
+    obj, viol = kao.evaluate(t, ok)                      # 8750 per broker: fine
+    assert viol[3] == 0
+    bad = np.zeros((P, 1), dtype=np.uint16)              # 70,000 replicas on broker 0
+    with pytest.raises(kao.KaoError) as e:
+        kao.evaluate(t, bad)
+    assert e.value.code == -2
