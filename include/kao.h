@@ -28,7 +28,8 @@ extern "C" {
 
 #define KAO_VERSION 100 /* 0.1.0 */
 #define KAO_NONE 0xFFFFu /* "no broker": replica on a broker outside the target set / empty slot */
-#define KAO_MAX_RF 4     /* replica slots per partition supported by the gfx950 kernels */
+#define KAO_MAX_RF 8     /* replica slots per partition supported by the gfx950 kernels (RF <= 4: one 128-bit word group per
+                            partition; 5..8: two) */
 #define KAO_MAX_RACKS 255
 
 enum {

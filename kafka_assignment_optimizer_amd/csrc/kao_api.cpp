@@ -70,7 +70,7 @@ int validate(const kao_topic *t) {
     if (t->n_racks > KAO_MAX_RACKS) return fail(KAO_ERR_UNSUPPORTED, "more than 255 racks");
     if (t->n_partitions < 1) return fail(KAO_ERR_INVALID, "n_partitions < 1");
     if (t->rf < 1 || t->rf_cur < 1) return fail(KAO_ERR_INVALID, "rf < 1");
-    if (t->rf > KAO_MAX_RF || t->rf_cur > KAO_MAX_RF) return fail(KAO_ERR_UNSUPPORTED, "replication factor > 4");
+    if (t->rf > KAO_MAX_RF || t->rf_cur > KAO_MAX_RF) return fail(KAO_ERR_UNSUPPORTED, "replication factor > 8");
     if (t->rf > t->n_brokers) return fail(KAO_ERR_INVALID, "rf > n_brokers");
     if (!t->rack_of || !t->current) return fail(KAO_ERR_INVALID, "null rack_of/current");
     for (int b = 0; b < t->n_brokers; ++b)
@@ -146,11 +146,12 @@ int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
         pt.int_of[b] = (uint16_t)x;
         pt.ext_of[x] = (uint16_t)b;
     }
-    pt.cur_int.assign((size_t)P * kRFP, (uint16_t)KAO_NONE);
+    const int nw = (t->rf > kRFP || t->rf_cur > kRFP) ? kMaxRF : kRFP;   // replica words per partition in K-search / K-canon / K-eval
+    pt.cur_int.assign((size_t)P * nw, (uint16_t)KAO_NONE);
     for (int p = 0; p < P; ++p)
         for (int k = 0; k < t->rf_cur; ++k) {
             const unsigned b = t->current[(size_t)p * t->rf_cur + k];
-            if (b < (unsigned)B) pt.cur_int[(size_t)p * kRFP + k] = pt.int_of[b];
+            if (b < (unsigned)B) pt.cur_int[(size_t)p * nw + k] = pt.int_of[b];
         }
     pt.rack_of.assign(t->rack_of, t->rack_of + B);
     pt.cur_dense.assign(t->current, t->current + (size_t)P * t->rf_cur);
@@ -161,7 +162,7 @@ int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
     d.rack_lo = bd[4]; d.rack_hi = bd[5]; d.prack_lo = bd[6]; d.prack_hi = bd[7];
     d.w00 = t->w[0][0]; d.w01 = t->w[0][1]; d.w10 = t->w[1][0]; d.w11 = t->w[1][1];
     d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
-    d.B = B; d.rf_cur = t->rf_cur;
+    d.B = B; d.rf_cur = t->rf_cur; d.nw = nw;
     return KAO_OK;
 }
 
@@ -233,10 +234,10 @@ int64_t upper_bound(const kao_topic *t) {
     derive_bounds(t, bd);
     const int rep_lo = bd[0], rep_hi = bd[1], lead_hi = bd[3], rack_lo = bd[4], rack_hi = bd[5], prack_hi = bd[7];
     // Everything per partition depends only on (current leader survives, number of surviving followers): 2 x 4 combos.
-    struct Combo { int64_t f_all = 0, lead_loss = 0; int n_marg = 0; int64_t marg[KAO_MAX_RF + 1] = {0}; int64_t count = 0; } combo[8];
+    struct Combo { int64_t f_all = 0, lead_loss = 0; int n_marg = 0; int64_t marg[KAO_MAX_RF + 1] = {0}; int64_t count = 0; } combo[2 * KAO_MAX_RF];
     for (int la = 0; la < 2; ++la)
-        for (int n_fol = 0; n_fol <= 3; ++n_fol) {
-            Combo &c = combo[la * 4 + n_fol];
+        for (int n_fol = 0; n_fol < KAO_MAX_RF; ++n_fol) {
+            Combo &c = combo[la * KAO_MAX_RF + n_fol];
             const bool lead_alive = la != 0;
             const int n_p = n_fol + la;
             c.f_all = partition_value(t, lead_alive, n_fol);
@@ -290,7 +291,7 @@ int64_t upper_bound(const kao_topic *t) {
             for (int j = 0; j < n_in; ++j) { if (racks[j] == racks[i]) { ++cnt; if (j < i) first = false; } }
             if (first) cell_excess += std::max(0, cnt - prack_hi);
         }
-        Combo &cb = combo[(lead_alive ? 4 : 0) + n_fol];
+        Combo &cb = combo[(lead_alive ? KAO_MAX_RF : 0) + n_fol];
         total += cb.f_all;
         cb.count++;
         if (lead_alive) { nl_b[c[0]]++; lead_b[c[0]]++; }
@@ -324,7 +325,7 @@ int64_t upper_bound(const kao_topic *t) {
             if (c[0] >= (unsigned)B || lead_b[c[0]] <= lead_hi) continue;
             int n_fol = 0;
             for (int q = 1; q < t->rf_cur; ++q) n_fol += c[q] < (unsigned)B;
-            lead_losses.emplace_back((int)c[0], combo[4 + n_fol].lead_loss);
+            lead_losses.emplace_back((int)c[0], combo[KAO_MAX_RF + n_fol].lead_loss);
         }
         std::sort(lead_losses.begin(), lead_losses.end());
         for (size_t i = 0; i < lead_losses.size();) {
@@ -440,6 +441,7 @@ int auto_period_log2(int P, int RF) {
 // K-bound limits: 19 B of LDS per broker + 72 B per rack; 32-bit headroom of the priced values (weights x 4096,
 // P*RF subgradients)
 bool dual_supported(const kao_topic *t) {
+    if (t->rf > kRFP || t->rf_cur > kRFP) return false;   // K-bound's per-lane subproblem holds 4 replicas
     if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false) > 160 * 1024) return false;
     const int64_t n = (int64_t)t->n_partitions * t->rf;
     if (n > 131072) return false;
@@ -523,6 +525,7 @@ struct kao_session {
     struct LaunchGroup {
         int maxP = 0, maxBx = 0, maxB = 0;
         int waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
+        int nw = kRFP;       // replica words per partition of the group's topics: 4 or 8 (template instantiation)
         bool global_a = false;   // topic too large for LDS: assignment + current words stay in global memory
         bool cur_in_lds = true;  // K-eval stages the current assignment in LDS (false: reads it from global)
         int smap_off = 0, smap_n = 0, emap_off = 0, emap_n = 0;
@@ -536,7 +539,7 @@ struct kao_session {
     TopicDev *d_topics = nullptr;
     int2 *d_smap = nullptr;
     int4 *d_emap = nullptr;
-    uint4 *d_cur = nullptr;
+    uint32_t *d_cur = nullptr;
     uint16_t *d_ext = nullptr;
     int32_t *d_rsz = nullptr;
     uint8_t *d_rackof = nullptr;
@@ -761,8 +764,8 @@ int kao_eval_plan_create(const kao_topic *t, kao_eval_plan **out) {
     p->device = cur_device();
     rc = prepare(t, 0, p->pt);
     if (rc) { delete p; return rc; }
-    p->cur_in_lds = eval_lds_bytes(p->pt.d.P, p->pt.d.B, true) <= 160 * 1024;
-    if (eval_lds_bytes(p->pt.d.P, p->pt.d.B, p->cur_in_lds) > 160 * 1024) { delete p; return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS"); }
+    p->cur_in_lds = eval_lds_bytes(p->pt.d.P, p->pt.d.B, true, p->pt.d.nw) <= 160 * 1024;
+    if (eval_lds_bytes(p->pt.d.P, p->pt.d.B, p->cur_in_lds, p->pt.d.nw) > 160 * 1024) { delete p; return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS"); }
     p->pt.d.best_off = 0; p->pt.d.rackof_off = 0; p->pt.d.curd_off = 0;
     std::vector<TopicDev> td(1, p->pt.d);
     if ((rc = dev_alloc_copy(&p->d_topic, td)) || (rc = dev_alloc_copy(&p->d_rackof, p->pt.rack_of)) ||
@@ -808,7 +811,7 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
     pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B; pl.cur_in_lds = p->cur_in_lds ? 1 : 0;
     pl.overflow = p->d_overflow;
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
-    launch_eval(pl, p->map_blocks, p->stream);
+    launch_eval(pl, p->map_blocks, p->pt.d.nw, p->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     p->timed = true;
@@ -905,26 +908,26 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
     const int P = d.P, RF = d.RF, B = d.B;
     if (canon_lds_bytes(d.Bx) > 160 * 1024) return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS");
     auto word = [&](uint16_t x) { return x == KAO_NONE ? kNoneW : ((uint32_t)x | ((uint32_t)(x / d.m) << 16)); };
-    std::vector<uint4> cur_words((size_t)P), a_words((size_t)P);
+    const int nw = d.nw;
+    std::vector<uint32_t> cur_words((size_t)P * nw), a_words((size_t)P * nw, kNoneW);
     for (int p = 0; p < P; ++p) {
-        const uint16_t *c = &pt.cur_int[(size_t)p * kRFP];
-        cur_words[(size_t)p] = make_uint4(word(c[0]), word(c[1]), word(c[2]), word(c[3]));
-        uint32_t w[4] = {kNoneW, kNoneW, kNoneW, kNoneW};
+        const uint16_t *c = &pt.cur_int[(size_t)p * nw];
+        for (int k = 0; k < nw; ++k) cur_words[(size_t)p * nw + k] = word(c[k]);
         for (int k = 0; k < RF; ++k) {
             const unsigned b = a[(size_t)p * RF + k];
             if (b >= (unsigned)B) return KAO_OK;  // an empty slot: infeasible, nothing to polish
-            w[k] = word(pt.int_of[b]);
+            a_words[(size_t)p * nw + k] = word(pt.int_of[b]);
         }
-        a_words[(size_t)p] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     // one device buffer: [TopicDev][status 16 B][cur words][A words][ext][rsz]
-    const size_t o_status = align_up(sizeof(TopicDev)), o_cur = o_status + 256, o_a = o_cur + align_up((size_t)P * 16);
-    const size_t o_ext = o_a + align_up((size_t)P * 16), o_rsz = o_ext + align_up(pt.ext_of.size() * 2);
+    const size_t wbytes = (size_t)P * nw * 4;
+    const size_t o_status = align_up(sizeof(TopicDev)), o_cur = o_status + 256, o_a = o_cur + align_up(wbytes);
+    const size_t o_ext = o_a + align_up(wbytes), o_rsz = o_ext + align_up(pt.ext_of.size() * 2);
     const size_t total = o_rsz + align_up(pt.rack_size.size() * 4);
     std::vector<unsigned char> stage(total, 0);
     std::memcpy(stage.data(), &d, sizeof(TopicDev));
-    std::memcpy(stage.data() + o_cur, cur_words.data(), (size_t)P * 16);
-    std::memcpy(stage.data() + o_a, a_words.data(), (size_t)P * 16);
+    std::memcpy(stage.data() + o_cur, cur_words.data(), wbytes);
+    std::memcpy(stage.data() + o_a, a_words.data(), wbytes);
     std::memcpy(stage.data() + o_ext, pt.ext_of.data(), pt.ext_of.size() * 2);
     std::memcpy(stage.data() + o_rsz, pt.rack_size.data(), pt.rack_size.size() * 4);
     void *dev = nullptr; size_t cap = 0;
@@ -935,12 +938,12 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
     int32_t status[2] = {0, 0};
     hipError_t e = hipMemcpyAsync(db, stage.data(), total, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        launch_canon(reinterpret_cast<const TopicDev *>(db), reinterpret_cast<const uint4 *>(db + o_cur),
+        launch_canon(reinterpret_cast<const TopicDev *>(db), reinterpret_cast<const uint32_t *>(db + o_cur),
                      reinterpret_cast<const uint16_t *>(db + o_ext), reinterpret_cast<const int32_t *>(db + o_rsz),
-                     reinterpret_cast<uint4 *>(db + o_a), d.Bx, reinterpret_cast<int32_t *>(db + o_status), st);
+                     reinterpret_cast<uint32_t *>(db + o_a), d.Bx, nw, reinterpret_cast<int32_t *>(db + o_status), st);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(a_words.data(), db + o_a, (size_t)P * 16, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(a_words.data(), db + o_a, wbytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(status, db + o_status, sizeof status, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     stream_put(st, cur_device());
@@ -948,8 +951,7 @@ int kao_canonicalize(const kao_topic *t, uint16_t *a) {
     if (e != hipSuccess) return fail(KAO_ERR_HIP, std::string("kao_canonicalize: ") + hipGetErrorString(e));
     if (!status[0]) return KAO_OK;  // only feasible assignments are polished
     for (int p = 0; p < P; ++p) {
-        const uint32_t w[4] = {a_words[(size_t)p].x, a_words[(size_t)p].y, a_words[(size_t)p].z, a_words[(size_t)p].w};
-        for (int k = 0; k < RF; ++k) a[(size_t)p * RF + k] = pt.ext_of[w[k] & 0xFFFFu];
+        for (int k = 0; k < RF; ++k) a[(size_t)p * RF + k] = pt.ext_of[a_words[(size_t)p * nw + k] & 0xFFFFu];
     }
     for (int p = 0; p < P; ++p) {  // followers: retained ones in their current order, then new ones ascending
         std::vector<uint16_t> fol(a + (size_t)p * RF + 1, a + (size_t)p * RF + RF), kept, fresh;
@@ -1022,7 +1024,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     {   // huge topics: bound the per-restart state in HBM (16 B of working words + the snapshot per partition):
         // 1 GB when the count was chosen automatically, 8 GB for an explicit request
         uint64_t per_restart = 0;
-        for (int t = 0; t < n_topics; ++t) per_restart += (uint64_t)topics[t].n_partitions * (16 + 2 * (uint64_t)std::max(topics[t].rf, 1));
+        for (int t = 0; t < n_topics; ++t) per_restart += (uint64_t)topics[t].n_partitions * (32 + 2 * (uint64_t)std::max(topics[t].rf, 1));
         const uint64_t cap = ((auto_restarts ? 1ull : 8ull) << 30) / std::max<uint64_t>(per_restart, 1);
         if ((uint64_t)o.restarts > cap) o.restarts = (int)std::max<uint64_t>(cap / kWaves * kWaves, kWaves);
     }
@@ -1031,7 +1033,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->topics.assign(topics, topics + n_topics);
     s->ub.resize((size_t)n_topics);
 
-    std::vector<uint4> cur_pool; std::vector<uint16_t> ext_pool, curd_pool, int_pool; std::vector<int32_t> rsz_pool;
+    std::vector<uint32_t> cur_pool; std::vector<uint16_t> ext_pool, curd_pool, int_pool; std::vector<int32_t> rsz_pool;
     uint64_t price_i32 = 0;
     std::vector<uint8_t> rackof_pool;
     uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0, dual_i32 = 0;
@@ -1049,20 +1051,18 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         d.period_log2 = o.period_log2 > 0 ? o.period_log2 : auto_period_log2(d.P, d.RF);
         d.restart_base = restart_base;
         restart_base += o.restarts;
-        d.cur_off = (uint32_t)cur_pool.size();
         auto word = [&](uint16_t x) { return x == KAO_NONE ? kNoneW : ((uint32_t)x | ((uint32_t)(x / d.m) << 16)); };
-        for (int p = 0; p < d.P; ++p) {  // LDS / register form of a replica: internal index | rack << 16
-            const uint16_t *c = &pt.cur_int[(size_t)p * kRFP];
-            cur_pool.push_back(make_uint4(word(c[0]), word(c[1]), word(c[2]), word(c[3])));
-        }
-        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true) > 160 * 1024;
+        while (cur_pool.size() % 4) cur_pool.push_back(kNoneW);   // every topic's words start 16-byte aligned
+        d.cur_off = (uint32_t)cur_pool.size();
+        for (size_t i = 0; i < (size_t)d.P * d.nw; ++i) cur_pool.push_back(word(pt.cur_int[i]));  // LDS / register form of a replica: internal index | rack << 16
+        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw) > 160 * 1024;
         s->topic_global[(size_t)t] = global_a;
         d.ext_off = (uint32_t)ext_pool.size();
         ext_pool.insert(ext_pool.end(), pt.ext_of.begin(), pt.ext_of.end());
         d.rsz_off = (uint32_t)rsz_pool.size();
         rsz_pool.insert(rsz_pool.end(), pt.rack_size.begin(), pt.rack_size.end());
         d.state_off = state_bytes;  // bytes: 8 per partition (packed, LDS path) or 16 (working words, global path)
-        state_bytes += align_up((uint64_t)o.restarts * d.P * (global_a ? 16 : 8));
+        state_bytes += align_up((uint64_t)o.restarts * d.P * d.nw * (global_a ? 4 : 2));
         d.best_off = best_u16;
         best_u16 += (uint64_t)o.restarts * d.P * d.RF;
         d.win_off = (uint32_t)win_u16;
@@ -1089,7 +1089,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     auto need1 = [&](int t) {  // topics kept in global memory sort last (their LDS need is tiny but they form their own groups)
         const TopicDev &d = s->pts[(size_t)t].d;
         const bool ga = s->topic_global[(size_t)t] != 0;
-        return (ga ? ((size_t)1 << 40) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true);
+        return (ga ? ((size_t)1 << 40) : 0) + (d.nw > kRFP ? ((size_t)1 << 41) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true, d.nw);
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need1(x) < need1(y); });
     std::vector<std::vector<int>> members;
@@ -1107,9 +1107,10 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
             g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B);
         }
         g.global_a = s->topic_global[(size_t)mem[0]] != 0;
-        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true) > 160 * 1024) g.waves /= 2;
-        g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true) <= 160 * 1024;
-        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds) > 160 * 1024) {
+        g.nw = s->pts[(size_t)mem[0]].d.nw;
+        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw) > 160 * 1024) g.waves /= 2;
+        g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true, g.nw) <= 160 * 1024;
+        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
             kao_session_destroy(s);
             return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS (about 30,000 padded brokers)");
         }
@@ -1139,7 +1140,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     // ---- read-only arena: stage everything on the host, ONE hipMalloc (or a parked arena), ONE H2D copy ----
     struct Sec { const void *src; size_t bytes; size_t off; };
     Sec secs[9] = {{tds.data(), tds.size() * sizeof(TopicDev), 0}, {smap.data(), smap.size() * sizeof(int2), 0},
-                   {emap.data(), emap.size() * sizeof(int4), 0}, {cur_pool.data(), cur_pool.size() * sizeof(uint4), 0},
+                   {emap.data(), emap.size() * sizeof(int4), 0}, {cur_pool.data(), cur_pool.size() * sizeof(uint32_t), 0},
                    {ext_pool.data(), ext_pool.size() * 2, 0}, {rsz_pool.data(), rsz_pool.size() * 4, 0},
                    {rackof_pool.data(), rackof_pool.size(), 0}, {curd_pool.data(), curd_pool.size() * 2, 0},
                    {int_pool.data(), int_pool.size() * 2, 0}};
@@ -1152,7 +1153,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->d_topics = reinterpret_cast<TopicDev *>(ro + secs[0].off);
     s->d_smap = reinterpret_cast<int2 *>(ro + secs[1].off);
     s->d_emap = reinterpret_cast<int4 *>(ro + secs[2].off);
-    s->d_cur = reinterpret_cast<uint4 *>(ro + secs[3].off);
+    s->d_cur = reinterpret_cast<uint32_t *>(ro + secs[3].off);
     s->d_ext = reinterpret_cast<uint16_t *>(ro + secs[4].off);
     s->d_rsz = reinterpret_cast<int32_t *>(ro + secs[5].off);
     s->d_rackof = reinterpret_cast<uint8_t *>(ro + secs[6].off);
@@ -1246,14 +1247,14 @@ int kao_session_step(kao_session *s) {
     for (const kao_session::LaunchGroup &g : s->groups) {
         sp.block_map = s->d_smap + g.smap_off;
         prm.maxP = g.maxP; prm.maxBx = g.maxBx;
-        launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, s->stream);
+        launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, g.nw, s->stream);
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
     for (const kao_session::LaunchGroup &g : s->groups) {
         ep.block_map = s->d_emap + g.emap_off;
         ep.maxP = g.maxP; ep.maxB = g.maxB; ep.cur_in_lds = g.cur_in_lds ? 1 : 0;
-        launch_eval(ep, g.emap_n, s->stream);
+        launch_eval(ep, g.emap_n, g.nw, s->stream);
         HIP_TRY(hipGetLastError());
     }
     if (prof) { HIP_TRY(hipEventRecord(e[2], s->stream)); s->ev_pending++; }
@@ -1336,7 +1337,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
     for (const kao_session::LaunchGroup &g : s->groups)
-        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced));
+        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw));
     out->launch_groups = (int32_t)s->groups.size();
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));
@@ -1558,15 +1559,15 @@ int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, ui
     if (rc) return rc;
     if (final_state) {
         const bool ga = s->topic_global[(size_t)topic] != 0;
-        std::vector<uint32_t> raw((size_t)d.P * (ga ? 4 : 2));
-        HIP_TRY(hipMemcpy(raw.data(), s->d_state + d.state_off + (uint64_t)restart * d.P * (ga ? 16 : 8), raw.size() * 4, hipMemcpyDeviceToHost));
-        for (int p = 0; p < d.P; ++p) {
-            uint16_t x[4];
-            if (ga) for (int k = 0; k < 4; ++k) x[k] = (uint16_t)(raw[(size_t)p * 4 + k] & 0xFFFF);  // word = x | rack << 16 (none: all ones)
-            else { x[0] = (uint16_t)(raw[(size_t)p * 2] & 0xFFFF); x[1] = (uint16_t)(raw[(size_t)p * 2] >> 16);
-                   x[2] = (uint16_t)(raw[(size_t)p * 2 + 1] & 0xFFFF); x[3] = (uint16_t)(raw[(size_t)p * 2 + 1] >> 16); }
-            for (int k = 0; k < d.RF; ++k) final_state[(size_t)p * d.RF + k] = x[k] < pt.ext_of.size() ? pt.ext_of[x[k]] : (uint16_t)KAO_NONE;
-        }
+        const int nw = d.nw;
+        std::vector<uint16_t> raw((size_t)d.P * nw * (ga ? 2 : 1));   // global path: nw words per partition; LDS path: nw x u16
+        HIP_TRY(hipMemcpy(raw.data(), s->d_state + d.state_off + (uint64_t)restart * d.P * nw * (ga ? 4 : 2), raw.size() * 2, hipMemcpyDeviceToHost));
+        for (int p = 0; p < d.P; ++p)
+            for (int k = 0; k < d.RF; ++k) {
+                // global path: word = x | rack << 16 (little endian: x is the low half; none = all ones); LDS path: the index itself
+                const uint16_t x = ga ? raw[((size_t)p * nw + k) * 2] : raw[(size_t)p * nw + k];
+                final_state[(size_t)p * d.RF + k] = x < pt.ext_of.size() ? pt.ext_of[x] : (uint16_t)KAO_NONE;
+            }
     }
     if (best_state)
         HIP_TRY(hipMemcpy(best_state, s->d_best + d.best_off + (uint64_t)restart * d.P * d.RF, (size_t)d.P * d.RF * 2, hipMemcpyDeviceToHost));

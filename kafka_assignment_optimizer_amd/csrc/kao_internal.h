@@ -5,7 +5,8 @@
 
 namespace kao {
 
-constexpr int kRFP = 4;          // padded replica slots per partition
+constexpr int kRFP = 4;          // replica words per partition of the common case (RF <= 4); topics with 5..8 replicas use 8 (kMaxRF)
+constexpr int kMaxRF = 8;
 constexpr int kWaves = 4;        // wavefronts per K-eval workgroup; K-search uses 4, 2 or 1 (largest that fits LDS)
 constexpr int kMaxRacks = 255;   // rack ids are u8, 0xFF marks a padding slot
 constexpr int kRackTab = 256;    // entries of the per-rack LDS tables (rack sizes, K, RT)
@@ -30,7 +31,7 @@ struct TopicDev {
     uint32_t seed_lo, seed_hi;   // per-topic seed
     int32_t n_restarts;          // restarts (wavefronts) searching this topic
     int32_t restart_base;        // index of restart 0 in the per-restart arrays
-    uint32_t cur_off;            // cur_pool   : first partition (uint4 = 4 words x | rack << 16 per partition)
+    uint32_t cur_off;            // cur_pool   : first WORD of the topic (nw words x | rack << 16 per partition, 16-byte aligned)
     uint32_t ext_off;            // ext_pool   : internal -> dense (u16[Bx])
     uint32_t rsz_off;            // rsz_pool   : rack sizes (int32[R])
     uint64_t state_off;          // state_pool : BYTE offset of restart 0 (uint2 per partition, or uint4 words when the
@@ -46,7 +47,8 @@ struct TopicDev {
     uint32_t price_off;          // price_pool : first int32 of this topic's search prices pa[B] pl[B] pg[kRackTab] (fixed point
                                  //              kDualScale, dense broker index); K-bound's epilogue or the host writes them
     uint32_t int_off;            // int_pool   : dense -> internal broker index (u16[B]); elite re-seeding reads dense snapshots
-    int32_t pad_[3];
+    int32_t nw;                  // replica words per partition in K-search / K-canon: 4 (RF, current RF <= 4) or 8
+    int32_t pad_[2];
 };
 
 struct SearchParams {
@@ -62,7 +64,7 @@ struct SearchParams {
 struct SearchPools {
     const TopicDev *topics;
     const int2 *block_map;       // per workgroup: {topic, first restart}
-    const uint4 *cur_pool;
+    const uint32_t *cur_pool;
     const uint16_t *ext_pool;
     const int32_t *rsz_pool;
     unsigned char *state_pool;
@@ -108,10 +110,10 @@ struct BoundPools {
     int32_t export_prices;       // 1 = the multipliers of the record dual value, 2 = the last iterate, 0 = no export
 };
 
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false);
-size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds);
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, void *stream);
-void launch_eval(const EvalPools &pools, int n_blocks, void *stream);
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4);
+size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne = 4);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream);
+void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream);
 // copy every topic's winning snapshot (restart id in its packed key) and violation row into contiguous
 // read-back buffers: one D2H instead of two per topic
 void launch_gather(const TopicDev *topics, int n_topics, const unsigned long long *keys, const uint16_t *best_pool,
@@ -125,7 +127,7 @@ void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream
 
 // canonical tie-break on the device (kao_canonicalize): one wavefront, assignment words in global memory
 size_t canon_lds_bytes(int maxBx);
-void launch_canon(const TopicDev *topic, const uint4 *cur_words, const uint16_t *ext, const int32_t *rsz, uint4 *A, int maxBx,
-                  int32_t *status, void *stream);
+void launch_canon(const TopicDev *topic, const uint32_t *cur_words, const uint16_t *ext, const int32_t *rsz, uint32_t *A, int maxBx,
+                  int nw, int32_t *status, void *stream);
 
 }  // namespace kao

@@ -68,11 +68,22 @@ __device__ __forceinline__ int wave_sum(int v) {
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
-// slot k of a partition, as two independent selects (keeps the compiler from building a switch)
-__device__ __forceinline__ uint32_t sel4(const uint4 &a, int k) {
-    const uint32_t lo = (k & 2) ? a.z : a.x;
-    const uint32_t hi = (k & 2) ? a.w : a.y;
+// A partition's replica slots as the kernels hold them: NW = 4 words (RF <= 4, one ds_read_b128) or 8 words (RF 5..8, two).
+template <int NW> struct alignas(16) Part { uint32_t w[NW]; };
+// slot k of a partition, as independent selects (keeps the compiler from building a switch)
+__device__ __forceinline__ uint32_t sel4(const Part<4> &a, int k) {
+    const uint32_t lo = (k & 2) ? a.w[2] : a.w[0];
+    const uint32_t hi = (k & 2) ? a.w[3] : a.w[1];
     return (k & 1) ? hi : lo;
+}
+__device__ __forceinline__ uint32_t sel4(const Part<8> &a, int k) {
+    const uint32_t q0 = (k & 4) ? a.w[4] : a.w[0], q1 = (k & 4) ? a.w[5] : a.w[1], q2 = (k & 4) ? a.w[6] : a.w[2], q3 = (k & 4) ? a.w[7] : a.w[3];
+    const uint32_t lo = (k & 2) ? q2 : q0, hi = (k & 2) ? q3 : q1;
+    return (k & 1) ? hi : lo;
+}
+template <int NW> __device__ __forceinline__ void set_slot(Part<NW> &a, int k, uint32_t v) {
+#pragma unroll
+    for (int i = 0; i < NW; ++i) a.w[i] = (i == k) ? v : a.w[i];
 }
 // per-lane LCG modulo 2^24: one v_mad_u32_u24 (only the low 24 bits of the state are ever read)
 __device__ __forceinline__ uint32_t lcg24(uint32_t &s) {
@@ -118,12 +129,18 @@ __device__ __forceinline__ int p_out(int c, int lo, int hi, int price) { return 
 // fixed point (kDualScale) -> key units (obj_scale per objective unit), rounded half up, clamped to 16 bits
 __device__ __forceinline__ int price_units(int v, int S) { return min(max((S * v + kDualScale / 2) >> 12, -32767), 32767); }
 
-__device__ __forceinline__ bool in4(const uint4 &a, uint32_t w) {
-    return (a.x == w) | (a.y == w) | (a.z == w) | (a.w == w);
+template <int NW> __device__ __forceinline__ bool in4(const Part<NW> &a, uint32_t w) {
+    bool r = false;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r |= a.w[i] == w;
+    return r;
 }
 // replicas of the partition that sit in rack r (empty slots carry rack 0xFFFF and never match)
-__device__ __forceinline__ int cnt4(const uint4 &a, uint32_t r) {
-    return (int)((a.x >> 16) == r) + (int)((a.y >> 16) == r) + (int)((a.z >> 16) == r) + (int)((a.w >> 16) == r);
+template <int NW> __device__ __forceinline__ int cnt4(const Part<NW> &a, uint32_t r) {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) n += (int)((a.w[i] >> 16) == r);
+    return n;
 }
 
 __device__ __forceinline__ uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t tie) {
@@ -140,67 +157,84 @@ struct TopicRegs {  // wave-uniform copy of the fields the inner loop needs
 };
 
 // objective weight of broker word w on a partition whose current replicas are c, in new role nr
-__device__ __forceinline__ int role_w2(const uint4 &c, uint32_t w, int wl, int wf) {
-    return (c.x == w) ? wl : (((c.y == w) | (c.z == w) | (c.w == w)) ? wf : 0);
+template <int NW> __device__ __forceinline__ int role_w2(const Part<NW> &c, uint32_t w, int wl, int wf) {
+    bool fol = false;
+#pragma unroll
+    for (int i = 1; i < NW; ++i) fol |= c.w[i] == w;
+    return (c.w[0] == w) ? wl : (fol ? wf : 0);
 }
-__device__ __forceinline__ int role_w(const TopicRegs &T, const uint4 &c, uint32_t w, int nr) {
+template <int NW> __device__ __forceinline__ int role_w(const TopicRegs &T, const Part<NW> &c, uint32_t w, int nr) {
     return role_w2(c, w, nr ? T.w01 : T.w00, nr ? T.w11 : T.w10);
 }
 // internal index -> LDS word (x | rack << 16); 0xFFFF -> empty
 __device__ __forceinline__ uint32_t to_word(const TopicRegs &T, uint32_t x) {
     return x == 0xFFFFu ? kNoneW : (x | (mulhi(x, T.magic) << 16));
 }
-__device__ __forceinline__ uint4 expand(const TopicRegs &T, uint2 s) {
-    return make_uint4(to_word(T, s.x & 0xFFFFu), to_word(T, s.x >> 16), to_word(T, s.y & 0xFFFFu), to_word(T, s.y >> 16));
+// a restart's state in HBM between launches (LDS path): NW x u16 internal indices per partition
+template <int NW> __device__ __forceinline__ Part<NW> load_packed(const TopicRegs &T, const unsigned char *base, int p) {
+    Part<NW> a;
+    if (NW == 4) {
+        const uint2 s = reinterpret_cast<const uint2 *>(base)[p];
+        a.w[0] = to_word(T, s.x & 0xFFFFu); a.w[1] = to_word(T, s.x >> 16); a.w[2] = to_word(T, s.y & 0xFFFFu); a.w[3] = to_word(T, s.y >> 16);
+    } else {
+        const uint4 s = reinterpret_cast<const uint4 *>(base)[p];
+        const uint32_t v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int i = 0; i < NW / 2; ++i) { a.w[2 * i] = to_word(T, v[i & 3] & 0xFFFFu); a.w[2 * i + 1] = to_word(T, v[i & 3] >> 16); }
+    }
+    return a;
 }
-__device__ __forceinline__ uint2 pack(const uint4 &a) {
-    return make_uint2((a.x & 0xFFFFu) | (a.y << 16), (a.z & 0xFFFFu) | (a.w << 16));
+template <int NW> __device__ __forceinline__ void store_packed(unsigned char *base, int p, const Part<NW> &a) {
+    if (NW == 4) reinterpret_cast<uint2 *>(base)[p] = make_uint2((a.w[0] & 0xFFFFu) | (a.w[1] << 16), (a.w[2] & 0xFFFFu) | (a.w[3] << 16));
+    else reinterpret_cast<uint4 *>(base)[p] = make_uint4((a.w[0] & 0xFFFFu) | (a.w[1] << 16), (a.w[2] & 0xFFFFu) | (a.w[3] << 16),
+                                                         (a.w[4 % NW] & 0xFFFFu) | (a.w[5 % NW] << 16), (a.w[6 % NW] & 0xFFFFu) | (a.w[7 % NW] << 16));
 }
 // sum over all R racks of band(#replicas of the partition in the rack)
-__device__ __forceinline__ int part_rack_viol(const TopicRegs &T, const uint4 &a) {
+template <int NW> __device__ __forceinline__ int part_rack_viol(const TopicRegs &T, const Part<NW> &a) {
     int s = 0, touched = 0;
-    const uint32_t r0 = a.x >> 16, r1 = a.y >> 16, r2 = a.z >> 16, r3 = a.w >> 16;
-    if (a.x != kNoneW) { s += band(cnt4(a, r0), T.prack_lo, T.prack_hi); touched++; }
-    if (a.y != kNoneW && r1 != r0) { s += band(cnt4(a, r1), T.prack_lo, T.prack_hi); touched++; }
-    if (a.z != kNoneW && r2 != r0 && r2 != r1) { s += band(cnt4(a, r2), T.prack_lo, T.prack_hi); touched++; }
-    if (a.w != kNoneW && r3 != r0 && r3 != r1 && r3 != r2) { s += band(cnt4(a, r3), T.prack_lo, T.prack_hi); touched++; }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const uint32_t rk = a.w[k] >> 16;
+        bool first = a.w[k] != kNoneW;
+#pragma unroll
+        for (int j = 0; j < k; ++j) first &= (a.w[j] >> 16) != rk;   // this rack has not been counted yet
+        if (first) { s += band(cnt4(a, rk), T.prack_lo, T.prack_hi); touched++; }
+    }
     return s + (T.R - touched) * T.prack_lo;  // band(0, lo, hi) == lo
 }
 
 // ------------------------------------------------------------------------------------------------
 // K-search
 // ------------------------------------------------------------------------------------------------
-struct WaveLds {
-    uint4 *A;     // [P] this restart's assignment, 4 words per partition
+template <int NW> struct WaveLds {
+    Part<NW> *A;  // [P] this restart's assignment, NW words per partition
     uint32_t *C;  // [Bx] replicas | leaders << 16 per broker
     int *K;       // [kRackTab] replicas per rack
     int *RT;      // [kRackTab] scratch: rack-dependent part of a REPLACE delta for the slot being scanned
 };
 
 // rebuild C and K from A (lanes stride partitions; LDS atomics)
-__device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds &L, int lane) {
+template <int NW> __device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds<NW> &L, int lane) {
     for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) L.C[x] = 0;
     for (int r = lane; r < kRackTab; r += 64) L.K[r] = 0;
     for (int p = lane; p < T.P; p += 64) {
-        const uint4 a = L.A[p];
-        if (a.x != kNoneW) { atomicAdd(&L.C[a.x & 0xFFFFu], 0x10001u); atomicAdd(&L.K[a.x >> 16], 1); }
-        if (a.y != kNoneW) { atomicAdd(&L.C[a.y & 0xFFFFu], 1u); atomicAdd(&L.K[a.y >> 16], 1); }
-        if (a.z != kNoneW) { atomicAdd(&L.C[a.z & 0xFFFFu], 1u); atomicAdd(&L.K[a.z >> 16], 1); }
-        if (a.w != kNoneW) { atomicAdd(&L.C[a.w & 0xFFFFu], 1u); atomicAdd(&L.K[a.w >> 16], 1); }
+        const Part<NW> a = L.A[p];
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            if (a.w[k] != kNoneW) { atomicAdd(&L.C[a.w[k] & 0xFFFFu], k == 0 ? 0x10001u : 1u); atomicAdd(&L.K[a.w[k] >> 16], 1); }
     }
 }
 
 // total violation magnitude and objective of the state in LDS (C, K must be current)
-__device__ __forceinline__ void full_cost(const TopicRegs &T, const WaveLds &L, const uint4 *CUR, const int *RSZ,
-                                          int lane, int &V, int &obj) {
+template <int NW> __device__ __forceinline__ void full_cost(const TopicRegs &T, const WaveLds<NW> &L, const Part<NW> *CUR, const int *RSZ,
+                                                            int lane, int &V, int &obj) {
     int v = 0, o = 0;
     for (int p = lane; p < T.P; p += 64) {
-        const uint4 a = L.A[p];
-        const uint4 c = CUR[p];
-        if (a.x != kNoneW) o += role_w(T, c, a.x, 0);
-        if (a.y != kNoneW) o += role_w(T, c, a.y, 1);
-        if (a.z != kNoneW) o += role_w(T, c, a.z, 1);
-        if (a.w != kNoneW) o += role_w(T, c, a.w, 1);
+        const Part<NW> a = L.A[p];
+        const Part<NW> c = CUR[p];
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            if (a.w[k] != kNoneW) o += role_w(T, c, a.w[k], k == 0 ? 0 : 1);
         v += part_rack_viol(T, a);
     }
     for (int x = lane; x < T.Bx; x += 64) {
@@ -215,14 +249,13 @@ __device__ __forceinline__ void full_cost(const TopicRegs &T, const WaveLds &L, 
     obj = wave_sum(o);
 }
 
-__device__ __forceinline__ void snapshot(const TopicRegs &T, const WaveLds &L, const uint16_t *ext, uint16_t *best, int lane) {
+template <int NW> __device__ __forceinline__ void snapshot(const TopicRegs &T, const WaveLds<NW> &L, const uint16_t *ext, uint16_t *best, int lane) {
     for (int p = lane; p < T.P; p += 64) {
-        const uint4 a = L.A[p];
+        const Part<NW> a = L.A[p];
         uint16_t *o = best + p * T.RF;
-        o[0] = ext[a.x & 0xFFFFu];
-        if (T.RF > 1) o[1] = ext[a.y & 0xFFFFu];
-        if (T.RF > 2) o[2] = ext[a.z & 0xFFFFu];
-        if (T.RF > 3) o[3] = ext[a.w & 0xFFFFu];
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+            if (k < T.RF) o[k] = ext[a.w[k] & 0xFFFFu];
     }
 }
 
@@ -234,7 +267,8 @@ __device__ __forceinline__ void snapshot(const TopicRegs &T, const WaveLds &L, c
 // kPriced = true : the cost of a move also carries Lagrangian PRICES of the coupling rows (K-bound's multipliers: replicas
 //                   per broker / rack, leaders per broker) -- an augmented-Lagrangian search: with near-optimal prices the
 //                   chain steps an improvement needs (objective down a little, violation unchanged) become neutral moves.
-template <bool kGlobalA, bool kPriced>
+// NW              : replica words per partition -- 4 (RF and current RF <= 4) or 8 (up to 8 replicas).
+template <bool kGlobalA, bool kPriced, int NW>
 __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
 
     // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[256]] [XR u8[Bx rounded to 64]] then per wave
     //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [K int[256]] [RT int[256]]        (* only when !kGlobalA)
-    const int a_bytes = kGlobalA ? 0 : prm.maxP * 16;
+    const int a_bytes = kGlobalA ? 0 : prm.maxP * NW * 4;
     const int bx64 = (prm.maxBx + 63) & ~63;
     const int c_bytes = bx64 * 4;
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
@@ -259,17 +293,17 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const int pr_bytes = kPriced ? c_bytes + kRackTab * 4 : 0;
     int *PG = reinterpret_cast<int *>(smem + a_bytes + kRackTab * 4 + bx64 + c_bytes);  // [kRackTab] rack prices (kPriced only)
     unsigned char *wb = smem + a_bytes + kRackTab * 4 + bx64 + pr_bytes + wave * (a_bytes + c_bytes + kRackTab * 8);  // blockDim.x / 64 waves
-    const uint4 *cur_words = pl.cur_pool + TD->cur_off;  // host-prepared words x | rack << 16 (0xFFFFFFFF = none)
-    const uint4 *CUR;
-    if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const uint4 *>(smem);
-    WaveLds L;
+    const Part<NW> *cur_words = reinterpret_cast<const Part<NW> *>(pl.cur_pool + TD->cur_off);  // host-prepared words x | rack << 16 (0xFFFFFFFF = none); cur_off counts words
+    const Part<NW> *CUR;
+    if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const Part<NW> *>(smem);
+    WaveLds<NW> L;
     L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
     L.K = reinterpret_cast<int *>(wb + a_bytes + c_bytes);
     L.RT = L.K + kRackTab;
 
     // ---- stage the rack sizes / rack-of-index table (and, when it fits, the current-assignment words) ----
     if (!kGlobalA) {
-        uint4 *cur_lds = reinterpret_cast<uint4 *>(smem);
+        Part<NW> *cur_lds = reinterpret_cast<Part<NW> *>(smem);
         for (int p = threadIdx.x; p < T.P; p += blockDim.x) cur_lds[p] = cur_words[p];
     }
     for (int r = threadIdx.x; r < kRackTab; r += blockDim.x) {
@@ -298,9 +332,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const int g = TD->restart_base + rho;
     // restart state in HBM: packed 4 x u16 per partition (LDS path, loaded / stored around the launch) or the
     // working words themselves, 16 B per partition, updated in place (global path)
-    uint2 *state_packed = reinterpret_cast<uint2 *>(pl.state_pool + TD->state_off) + (uint64_t)rho * T.P;
-    if (kGlobalA) L.A = reinterpret_cast<uint4 *>(pl.state_pool + TD->state_off) + (uint64_t)rho * T.P;
-    else L.A = reinterpret_cast<uint4 *>(wb);
+    unsigned char *state_packed = pl.state_pool + TD->state_off + (uint64_t)rho * T.P * (NW * 2);
+    if (kGlobalA) L.A = reinterpret_cast<Part<NW> *>(pl.state_pool + TD->state_off) + (uint64_t)rho * T.P;
+    else L.A = reinterpret_cast<Part<NW> *>(wb);
     uint16_t *best = pl.best_pool + TD->best_off + (uint64_t)rho * T.P * T.RF;
     const uint16_t *ext = pl.ext_pool + TD->ext_off;
     const uint32_t slo = TD->seed_lo, shi = TD->seed_hi;
@@ -310,10 +344,10 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     if (prm.init) {
         // surviving current replicas stay in their slots
         for (int p = lane; p < T.P; p += 64) {
-            uint4 c = CUR[p];
-            if (T.RF < 4) c.w = kNoneW;
-            if (T.RF < 3) c.z = kNoneW;
-            if (T.RF < 2) c.y = kNoneW;
+            Part<NW> c = CUR[p];
+#pragma unroll
+            for (int k = 1; k < NW; ++k)
+                if (k >= T.RF) c.w[k] = kNoneW;
             L.A[p] = c;
         }
         best_obj = -1; accepted = 0;
@@ -334,14 +368,13 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             const uint16_t *ea = pl.elite_assign + TD->win_off;
             const uint16_t *io = pl.int_pool + TD->int_off;
             for (int p = lane; p < T.P; p += 64) {
-                uint32_t w[4] = {kNoneW, kNoneW, kNoneW, kNoneW};
+                Part<NW> w;
 #pragma unroll
-                for (int k = 0; k < kRFP; ++k)
-                    if (k < T.RF) w[k] = to_word(T, io[ea[p * T.RF + k]]);
-                L.A[p] = make_uint4(w[0], w[1], w[2], w[3]);
+                for (int k = 0; k < NW; ++k) w.w[k] = k < T.RF ? to_word(T, io[ea[p * T.RF + k]]) : kNoneW;
+                L.A[p] = w;
             }
         } else if (!kGlobalA) {
-            for (int p = lane; p < T.P; p += 64) L.A[p] = expand(T, state_packed[p]);
+            for (int p = lane; p < T.P; p += 64) L.A[p] = load_packed<NW>(T, state_packed, p);
         }
     }
     if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own stores visible to every lane's loads
@@ -355,23 +388,25 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         for (int pbase = 0; pbase < T.P; pbase += 64) {
             bool has_hole = false;
             if (pbase + lane < T.P) {
-                const uint4 al = L.A[pbase + lane];
-                has_hole = pass == 0 ? (al.x == kNoneW)
-                                     : ((T.RF > 1 && al.y == kNoneW) || (T.RF > 2 && al.z == kNoneW) || (T.RF > 3 && al.w == kNoneW));
+                const Part<NW> al = L.A[pbase + lane];
+                bool fh = false;
+#pragma unroll
+                for (int k = 1; k < NW; ++k) fh |= (k < T.RF) & (al.w[k] == kNoneW);
+                has_hole = pass == 0 ? (al.w[0] == kNoneW) : fh;
             }
             unsigned long long todo = __ballot(has_hole);
             while (todo) {
                 const int p = pbase + __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                uint4 a = L.A[p];  // same address in every lane: broadcast
-                const uint4 c = CUR[p];
+                Part<NW> a = L.A[p];  // same address in every lane: broadcast
+                const Part<NW> c = CUR[p];
 #pragma unroll
-                for (int k = 0; k < kRFP; ++k) {
+                for (int k = 0; k < NW; ++k) {
                     if (k >= T.RF) break;
                     if ((k == 0) != (pass == 0)) continue;  // this pass handles the other kind of slot
-                    if (sel4(a, k) != kNoneW) continue;  // wave-uniform
+                    if (a.w[k] != kNoneW) continue;  // wave-uniform
                     // best insertion: every valid broker not in the partition, 64 per round (lane = internal index)
-                    const uint32_t hmix = slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * kRFP + k) * 0x27D4EB2Fu + 0x5BD1E995u);
+                    const uint32_t hmix = slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * NW + k) * 0x27D4EB2Fu + 0x5BD1E995u);
                     const int wl = k == 0 ? T.w00 : T.w01, wf = k == 0 ? T.w10 : T.w11;
                     uint32_t key = kKeyNull, xw_l = kNoneW;
                     for (int base = 0; base < T.Bx; base += 64) {
@@ -397,7 +432,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const uint32_t kmin = wave_umin(key);
                     const unsigned long long bal = __ballot(key == kmin);
                     const uint32_t xw_win = (uint32_t)__builtin_amdgcn_readlane((int)xw_l, __ffsll((long long)bal) - 1);  // ties: lowest lane
-                    if (k == 0) a.x = xw_win; else if (k == 1) a.y = xw_win; else if (k == 2) a.z = xw_win; else a.w = xw_win;
+                    a.w[k] = xw_win;
                     if (lane == 0) {
                         reinterpret_cast<uint32_t *>(&L.A[p])[k] = xw_win;
                         L.C[xw_win & 0xFFFFu] += (k == 0) ? 0x10001u : 1u;
@@ -445,8 +480,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
 
         if (sampled) {
             p = (int)rnd24_wide(rng, (uint32_t)T.P);
-            const uint4 a = L.A[p];
-            const uint4 c = CUR[p];
+            const Part<NW> a = L.A[p];
+            const Part<NW> c = CUR[p];
             if (type == 0) {  // REPLACE (p,k) <- x_g: 2 candidates of any rack, 2 of the old broker's rack
                 k = (int)rnd24(rng, RF8);
                 uw = sel4(a, k);
@@ -502,14 +537,14 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     if (keyg < key) { key = keyg; vw = xw; dV = dVg; dObj = dObjg; }
                 }
             } else {  // LEADER SWAP inside p: slot 0 <-> slot k, every k = 1..RF-1 is a candidate
-                uw = a.x;
+                uw = a.w[0];
                 const int u_lead = role_w2(c, uw, T.w00, T.w10), u_fol = role_w2(c, uw, T.w01, T.w11);
                 const int dV_u = ddec((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
                 const int dP_u = kPriced ? p_out((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi, price_lead(PR[uw & 0xFFFFu])) : 0;
 #pragma unroll
-                for (int kk = 1; kk < kRFP; ++kk) {
+                for (int kk = 1; kk < NW; ++kk) {
                     if (kk >= T.RF) break;
-                    const uint32_t xw = kk == 1 ? a.y : (kk == 2 ? a.z : a.w);
+                    const uint32_t xw = a.w[kk];
                     const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11);
                     const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
                     uint32_t keyg;
@@ -531,8 +566,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             auto score_slot = [&](uint32_t &key_o, int &p_o, int &k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
                 p_o = (int)rnd24_wide(rng, (uint32_t)T.P);
                 k_o = (int)rnd24(rng, RF8);
-                const uint4 al = L.A[p_o];
-                const uint4 cl = CUR[p_o];
+                const Part<NW> al = L.A[p_o];
+                const Part<NW> cl = CUR[p_o];
                 oldw_o = sel4(al, k_o);
                 const uint32_t rol = oldw_o >> 16;
                 const bool leadl = k_o == 0;
@@ -575,8 +610,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             const int g_old = __builtin_amdgcn_readlane(g_old_l, wA);
             const int dV_old = __builtin_amdgcn_readlane(dvo_l, wA);
             const int dV_rack_old = __builtin_amdgcn_readlane(dvr_l, wA);
-            const uint4 a = L.A[p];   // same address in every lane: LDS broadcast
-            const uint4 c = CUR[p];
+            const Part<NW> a = L.A[p];   // same address in every lane: LDS broadcast
+            const Part<NW> c = CUR[p];
             const bool lead = k == 0;  // wave-uniform
             const uint32_t ro = uw >> 16;
             if (type == 0) {
@@ -592,9 +627,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 }
                 const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
                 // a displaced current replica (in c, not in a) is the only broker with a non-zero weight here
-                // (lane i < 4 checks current replica i; one ballot instead of every lane checking all four)
-                const uint32_t ci = sel4(c, lane & 3);
-                const bool hm_l = (lane < 4) & (ci != kNoneW) & !in4(a, ci);
+                // (lane i < NW checks current replica i; one ballot instead of every lane checking all of them)
+                const uint32_t ci = sel4(c, lane & (NW - 1));
+                const bool hm_l = (lane < NW) & (ci != kNoneW) & !in4(a, ci);
                 const bool has_missing = __ballot(hm_l) != 0ull;
                 int dP_old = 0;
                 if (kPriced) {
@@ -642,16 +677,16 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     if (qq >= T.P) { if (x_windowed) qq -= T.P; else okq = false; }
                     okq = okq & (qq != p);
                     const int qc = min(qq, T.P - 1);
-                    const uint4 b = L.A[qc];
-                    const uint4 cb = CUR[qc];
+                    const Part<NW> b = L.A[qc];
+                    const Part<NW> cb = CUR[qc];
                     const bool u_in_b = in4(b, uw);
                     // independent of the partner slot j: what u would be worth in q, and q's replicas in u's rack
                     const int u_in_q_lead = role_w2(cb, uw, T.w00, T.w10), u_in_q_fol = role_w2(cb, uw, T.w01, T.w11);
                     const int cnt_b_ro = cnt4(b, ro);
 #pragma unroll
-                    for (int jj = 0; jj < kRFP; ++jj) {
+                    for (int jj = 0; jj < NW; ++jj) {
                         if (jj >= T.RF) break;
-                        const uint32_t v = jj == 0 ? b.x : (jj == 1 ? b.y : (jj == 2 ? b.z : b.w));
+                        const uint32_t v = b.w[jj];
                         const bool ok = okq & (v != uw) & !in4(a, v) & !u_in_b;
                         const int nrq = jj != 0;
                         const int dObjx = role_w(T, c, v, nrp) + (jj == 0 ? u_in_q_lead : u_in_q_fol) - g_old - role_w(T, cb, v, nrq);
@@ -722,7 +757,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     full_cost(T, L, CUR, RSZ, lane, V2, obj2);
     if ((V2 != V || obj2 != obj) && lane == 0) atomicAdd(pl.drift, 1);
     if (!kGlobalA)
-        for (int p = lane; p < T.P; p += 64) state_packed[p] = pack(L.A[p]);
+        for (int p = lane; p < T.P; p += 64) store_packed<NW>(state_packed, p, L.A[p]);
     if (lane == 0) {
         pl.restart_info[g * 4 + 0] = best_obj;
         pl.restart_info[g * 4 + 1] = V2;
@@ -734,6 +769,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
 // ------------------------------------------------------------------------------------------------
 // K-eval
 // ------------------------------------------------------------------------------------------------
+// NE = replica slots handled per partition: 4 (RF and current RF <= 4) or 8.
+template <int NE>
 __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     unsigned long long *wave_key = reinterpret_cast<unsigned long long *>(smem_all);  // [kWaves], 32 B
@@ -747,29 +784,24 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     const int rack_lo = TD->rack_lo, rack_hi = TD->rack_hi, prack_lo = TD->prack_lo, prack_hi = TD->prack_hi;
     const int w00 = TD->w00, w01 = TD->w01, w10 = TD->w10, w11 = TD->w11;
 
-    // ---- LDS carve: [wave_key 32 B] [RACK u8[maxB~]] [CURD uint2[maxP]] then per wave [C u32[maxB~]] [K int[256]]
+    // ---- LDS carve: [wave_key 32 B] [RACK u8[maxB~]] [CURD u16[maxP][NE]] then per wave [C u32[maxB~]] [K int[256]]
     const int r_bytes = (pl.maxB + 15) & ~15;
-    const int d_bytes = pl.cur_in_lds ? pl.maxP * 8 : 0;  // huge topics read the current assignment from global memory
+    const int d_bytes = pl.cur_in_lds ? pl.maxP * NE * 2 : 0;  // huge topics read the current assignment from global memory
     const int c_bytes = (pl.maxB * 4 + 15) & ~15;
     uint8_t *RACK = smem;
-    uint2 *CURD = reinterpret_cast<uint2 *>(smem + r_bytes);
+    uint16_t *CURD = reinterpret_cast<uint16_t *>(smem + r_bytes);
     unsigned char *wb = smem + r_bytes + ((d_bytes + 15) & ~15) + wave * (c_bytes + kRackTab * 4);
     uint32_t *C = reinterpret_cast<uint32_t *>(wb);
     int *K = reinterpret_cast<int *>(wb + c_bytes);
 
-    // ---- stage the broker->rack table and the current assignment (padded to 4 slots) ----
+    // ---- stage the broker->rack table and the current assignment (padded to NE slots with 0xFFFF) ----
     for (int b = threadIdx.x; b < B; b += 256) RACK[b] = pl.rackof_pool[TD->rackof_off + b];
     const uint16_t *curd = pl.curd_pool + TD->curd_off;
-    auto load_cur = [&](int p) {  // current replicas of partition p, padded to 4 slots with 0xFFFF
-        const uint16_t *cp = curd + (size_t)p * rf_cur;
-        const uint32_t c0 = cp[0];
-        const uint32_t c1 = rf_cur > 1 ? cp[1] : 0xFFFFu;
-        const uint32_t c2 = rf_cur > 2 ? cp[2] : 0xFFFFu;
-        const uint32_t c3 = rf_cur > 3 ? cp[3] : 0xFFFFu;
-        return make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
-    };
     if (pl.cur_in_lds)
-        for (int p = threadIdx.x; p < P; p += 256) CURD[p] = load_cur(p);
+        for (int i = threadIdx.x; i < P * NE; i += 256) {
+            const int p = i / NE, k = i - p * NE;
+            CURD[i] = k < rf_cur ? curd[(size_t)p * rf_cur + k] : (uint16_t)0xFFFFu;
+        }
     __syncthreads();
 
     unsigned long long my_key = ~0ull;
@@ -795,59 +827,48 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
         bool ovf = false;
         for (int p = lane; p < P; p += 64) {
             const uint16_t *ap = cand + (size_t)p * RF;  // a wavefront reads 64*RF consecutive u16: coalesced
-            uint32_t b0 = ap[0], b1 = 0xFFFFu, b2 = 0xFFFFu, b3 = 0xFFFFu;
-            if (RF > 1) b1 = ap[1];
-            if (RF > 2) b2 = ap[2];
-            if (RF > 3) b3 = ap[3];
-            const bool ok0 = b0 < (uint32_t)B, ok1 = b1 < (uint32_t)B, ok2 = b2 < (uint32_t)B, ok3 = b3 < (uint32_t)B;
-            const int missing = (int)!ok0 + (RF > 1 ? (int)!ok1 : 0) + (RF > 2 ? (int)!ok2 : 0) + (RF > 3 ? (int)!ok3 : 0);
-            s12 += (uint32_t)missing + ((uint32_t)!ok0 << 16);  // C1: sum_b (f+l) = RF ; C2: exactly one leader
-            const uint2 cu = pl.cur_in_lds ? CURD[p] : load_cur(p);
-            const uint32_t c0 = cu.x & 0xFFFFu, c1 = cu.x >> 16, c2 = cu.y & 0xFFFFu, c3 = cu.y >> 16;
-            uint32_t r0 = 0xFFu, r1 = 0xFFu, r2 = 0xFFu, r3 = 0xFFu;
-            if (ok0) {
-                r0 = RACK[b0];
-                const uint32_t oc = atomicAdd(&C[b0], 0x10001u);
-                __hip_atomic_fetch_add(&K[kcopy + r0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int cr = (int)(oc & 0xFFFFu), cl = (int)(oc >> 16);
-                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);     // C3
-                s4 += (uint32_t)(cl >= lead_hi) + ((uint32_t)(cl < lead_lo) << 16);   // C4
-                if (big) ovf |= cr == 0xFFFF;
-                obj += (c0 == b0) ? w00 : (((c1 == b0) | (c2 == b0) | (c3 == b0)) ? w10 : 0);
+            uint32_t bk[NE], rk[NE], ck[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                bk[k] = k < RF ? (uint32_t)ap[k < RF ? k : 0] : 0xFFFFu;
+                rk[k] = 0xFFu;
+                ck[k] = pl.cur_in_lds ? (uint32_t)CURD[p * NE + k] : (k < rf_cur ? (uint32_t)curd[(size_t)p * rf_cur + (k < rf_cur ? k : 0)] : 0xFFFFu);
             }
-            if (ok1) {
-                r1 = RACK[b1];
-                const int cr = (int)(atomicAdd(&C[b1], 1u) & 0xFFFFu);
-                __hip_atomic_fetch_add(&K[kcopy + r1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
+            int missing = 0;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                if (k >= RF) break;
+                const uint32_t b = bk[k];
+                if (b >= (uint32_t)B) { ++missing; continue; }   // empty / out-of-range slot
+                rk[k] = RACK[b];
+                const uint32_t oc = atomicAdd(&C[b], k == 0 ? 0x10001u : 1u);
+                __hip_atomic_fetch_add(&K[kcopy + rk[k]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int cr = (int)(oc & 0xFFFFu);
+                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);         // C3
+                if (k == 0) {
+                    const int cl = (int)(oc >> 16);
+                    s4 += (uint32_t)(cl >= lead_hi) + ((uint32_t)(cl < lead_lo) << 16);   // C4
+                }
                 if (big) ovf |= cr == 0xFFFF;
-                obj += (c0 == b1) ? w01 : (((c1 == b1) | (c2 == b1) | (c3 == b1)) ? w11 : 0);
-                s57 += (uint32_t)(b1 == b0);  // C5: f+l <= 1 (an earlier slot holds the same broker)
+                bool fol = false, dup = false;
+#pragma unroll
+                for (int j = 1; j < NE; ++j) fol |= ck[j] == b;
+#pragma unroll
+                for (int j = 0; j < k; ++j) dup |= bk[j] == b;
+                obj += (ck[0] == b) ? (k == 0 ? w00 : w01) : (fol ? (k == 0 ? w10 : w11) : 0);
+                s57 += (uint32_t)dup;  // C5: f+l <= 1 (an earlier slot holds the same broker)
             }
-            if (ok2) {
-                r2 = RACK[b2];
-                const int cr = (int)(atomicAdd(&C[b2], 1u) & 0xFFFFu);
-                __hip_atomic_fetch_add(&K[kcopy + r2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
-                if (big) ovf |= cr == 0xFFFF;
-                obj += (c0 == b2) ? w01 : (((c1 == b2) | (c2 == b2) | (c3 == b2)) ? w11 : 0);
-                s57 += (uint32_t)((b2 == b0) | (b2 == b1));
-            }
-            if (ok3) {
-                r3 = RACK[b3];
-                const int cr = (int)(atomicAdd(&C[b3], 1u) & 0xFFFFu);
-                __hip_atomic_fetch_add(&K[kcopy + r3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);
-                if (big) ovf |= cr == 0xFFFF;
-                obj += (c0 == b3) ? w01 : (((c1 == b3) | (c2 == b3) | (c3 == b3)) ? w11 : 0);
-                s57 += (uint32_t)((b3 == b0) | (b3 == b1) | (b3 == b2));
-            }
-            // C7: replicas per partition per rack, over all R racks
+            s12 += (uint32_t)missing + ((uint32_t)(bk[0] >= (uint32_t)B) << 16);  // C1: sum_b (f+l) = RF ; C2: exactly one leader
+            // C7: replicas per partition per rack, over all R racks (each rack counted at its first slot)
             int touched = 0, s7 = 0;
-            if (ok0) { s7 += band(1 + (int)(r1 == r0) + (int)(r2 == r0) + (int)(r3 == r0), prack_lo, prack_hi); touched++; }
-            if (ok1 && r1 != r0) { s7 += band(1 + (int)(r2 == r1) + (int)(r3 == r1), prack_lo, prack_hi); touched++; }
-            if (ok2 && r2 != r0 && r2 != r1) { s7 += band(1 + (int)(r3 == r2), prack_lo, prack_hi); touched++; }
-            if (ok3 && r3 != r0 && r3 != r1 && r3 != r2) { s7 += band(1, prack_lo, prack_hi); touched++; }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                bool first = rk[k] != 0xFFu;
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) { cnt += (int)(rk[j] == rk[k]); if (j < k) first &= rk[j] != rk[k]; }
+                if (first) { s7 += band(cnt, prack_lo, prack_hi); touched++; }
+            }
             s57 += (uint32_t)(s7 + (R - touched) * prack_lo) << 16;
         }
         // C6 from the rack totals (the wavefront's own LDS operations complete in order: no barrier needed)
@@ -888,7 +909,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
                                        (unsigned long long)(ci & 0xFFFFF);
         my_key = key < my_key ? key : my_key;
     }
-    if (pl.best_key) {  // workgroup reduce of the wave-uniform keys, one atomicMin per workgroup
+    if (pl.best_key) {  // workgroup reduce of the wave-uniform keys, one atomicMin per workgroup per topic
         if (lane == 0) wave_key[wave] = my_key;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -937,8 +958,9 @@ __global__ __launch_bounds__(64) void k_adopt_global(unsigned long long *keys, c
 // feasible, it stays feasible iff the move's violation delta is 0 -- so this is the REPLACE scan of k_search with
 // "delta == 0" as the filter and the dense index as the key.  One wavefront; the assignment and current-assignment
 // words stay in global memory (any topic size); broker / rack tables in LDS.  status = {input feasible, #moves}.
-__global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *cur_words, const uint16_t *ext, const int32_t *rsz,
-                                              uint4 *A, int maxBx, int32_t *status) {
+template <int NW>
+__global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW> *cur_words, const uint16_t *ext, const int32_t *rsz,
+                                              Part<NW> *A, int maxBx, int32_t *status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     TopicRegs T;
@@ -949,7 +971,7 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *c
     const int bx64 = (maxBx + 63) & ~63;
     int *RSZ = reinterpret_cast<int *>(smem);
     uint8_t *XR = smem + kRackTab * 4;
-    WaveLds L;
+    WaveLds<NW> L;
     L.A = A;
     L.C = reinterpret_cast<uint32_t *>(smem + kRackTab * 4 + bx64);
     L.K = reinterpret_cast<int *>(smem + kRackTab * 4 + bx64 + bx64 * 4);
@@ -975,20 +997,21 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *c
         for (int pbase = 0; pbase < T.P; pbase += 64) {
             bool has_new = false;
             if (pbase + lane < T.P) {
-                const uint4 al = L.A[pbase + lane];
-                const uint4 cl = cur_words[pbase + lane];
-                has_new = !in4(cl, al.x) || (T.RF > 1 && !in4(cl, al.y)) || (T.RF > 2 && !in4(cl, al.z)) || (T.RF > 3 && !in4(cl, al.w));
+                const Part<NW> al = L.A[pbase + lane];
+                const Part<NW> cl = cur_words[pbase + lane];
+#pragma unroll
+                for (int k = 0; k < NW; ++k) has_new |= (k < T.RF) & !in4(cl, al.w[k]);
             }
             unsigned long long todo = __ballot(has_new);
             while (todo) {
                 const int p = pbase + __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
-                uint4 a = L.A[p];
-                const uint4 c = cur_words[p];
+                Part<NW> a = L.A[p];
+                const Part<NW> c = cur_words[p];
 #pragma unroll
-                for (int k = 0; k < kRFP; ++k) {
+                for (int k = 0; k < NW; ++k) {
                     if (k >= T.RF) break;
-                    const uint32_t uw = sel4(a, k);
+                    const uint32_t uw = a.w[k];
                     if (in4(c, uw)) continue;  // a retained current replica stays where it is (wave-uniform)
                     const uint32_t old_dense = ext[uw & 0xFFFFu];
                     const uint32_t ro = uw >> 16;
@@ -1017,7 +1040,7 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const uint4 *c
                     const uint32_t xn = kmin & 0xFFFFu;
                     const uint32_t rn = XR[xn];
                     const uint32_t xw_new = xn | (rn << 16);
-                    if (k == 0) a.x = xw_new; else if (k == 1) a.y = xw_new; else if (k == 2) a.z = xw_new; else a.w = xw_new;
+                    a.w[k] = xw_new;
                     if (lane == 0) {
                         const uint32_t d = lead ? 0x10001u : 1u;
                         reinterpret_cast<uint32_t *>(&L.A[p])[k] = xw_new;
@@ -1453,47 +1476,57 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced) {
-    const size_t a = global_a ? 0 : (size_t)maxP * 16, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw) {
+    const size_t a = global_a ? 0 : (size_t)maxP * 4 * (size_t)nw, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
     return a + kRackTab * 4 + bx64 + (priced ? bx64 * 4 + kRackTab * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
 }
-size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds) {
-    const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 8 + 15) & ~(size_t)15 : 0;
+size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
+    const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 2 * (size_t)ne + 15) & ~(size_t)15 : 0;
     const size_t c = ((size_t)maxB * 4 + 15) & ~(size_t)15;
     return 32 + r + d + kWaves * (c + kRackTab * 4);
 }
 
 // largest dynamic-LDS size each kernel has been enabled for, per device (function attributes are per device)
 constexpr int kAttrDevices = 64;
-static int g_attr_search_dev[kAttrDevices] = {0}, g_attr_eval_dev[kAttrDevices] = {0}, g_attr_bound_dev[kAttrDevices] = {0};
+static int g_attr_eval_dev[kAttrDevices] = {0}, g_attr_bound_dev[kAttrDevices] = {0};
 static int attr_slot() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kAttrDevices) ? d : 0; }
 
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, void *stream) {
-    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced);
-    int &g_attr_search = g_attr_search_dev[attr_slot()];
-    if ((int)lds > g_attr_search) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        g_attr_search = (int)lds;
-    }
-    const dim3 grid(n_blocks), block(64 * waves);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (global_a && priced) hipLaunchKernelGGL((k_search<true, true>), grid, block, lds, st, pools, prm);
-    else if (global_a) hipLaunchKernelGGL((k_search<true, false>), grid, block, lds, st, pools, prm);
-    else if (priced) hipLaunchKernelGGL((k_search<false, true>), grid, block, lds, st, pools, prm);
-    else hipLaunchKernelGGL((k_search<false, false>), grid, block, lds, st, pools, prm);
+template <bool kGlobalA, bool kPriced, int NW>
+static void launch_search_t(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, size_t lds, int &attr, hipStream_t st) {
+    if ((int)lds > attr) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<kGlobalA, kPriced, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_search<kGlobalA, kPriced, NW>), dim3(n_blocks), dim3(64 * waves), lds, st, pools, prm);
 }
 
-void launch_eval(const EvalPools &pools, int n_blocks, void *stream) {
-    const size_t lds = eval_lds_bytes(pools.maxP, pools.maxB, pools.cur_in_lds != 0);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream) {
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw);
+    // largest dynamic-LDS size each of the 8 instantiations has been enabled for, per device
+    static int attr[kAttrDevices][8] = {{0}};
+    int &a = attr[attr_slot()][(global_a ? 4 : 0) + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (nw == 8) {
+        if (global_a && priced) launch_search_t<true, true, 8>(pools, prm, n_blocks, waves, lds, a, st);
+        else if (global_a) launch_search_t<true, false, 8>(pools, prm, n_blocks, waves, lds, a, st);
+        else if (priced) launch_search_t<false, true, 8>(pools, prm, n_blocks, waves, lds, a, st);
+        else launch_search_t<false, false, 8>(pools, prm, n_blocks, waves, lds, a, st);
+    } else {
+        if (global_a && priced) launch_search_t<true, true, 4>(pools, prm, n_blocks, waves, lds, a, st);
+        else if (global_a) launch_search_t<true, false, 4>(pools, prm, n_blocks, waves, lds, a, st);
+        else if (priced) launch_search_t<false, true, 4>(pools, prm, n_blocks, waves, lds, a, st);
+        else launch_search_t<false, false, 4>(pools, prm, n_blocks, waves, lds, a, st);
+    }
+    if ((int)lds > a) a = (int)lds;
+}
+
+void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream) {
+    const size_t lds = eval_lds_bytes(pools.maxP, pools.maxB, pools.cur_in_lds != 0, ne);
     int &g_attr_eval = g_attr_eval_dev[attr_slot()];
     if ((int)lds > g_attr_eval) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_eval = (int)lds;
     }
-    hipLaunchKernelGGL(k_eval, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools);
+    if (ne == 8) hipLaunchKernelGGL(k_eval<8>, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools);
+    else hipLaunchKernelGGL(k_eval<4>, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools);
 }
 
 void launch_gather(const TopicDev *topics, int n_topics, const unsigned long long *keys, const uint16_t *best_pool,
@@ -1529,11 +1562,18 @@ size_t canon_lds_bytes(int maxBx) {
     return kRackTab * 4 + bx64 + bx64 * 4 + kRackTab * 4;
 }
 
-void launch_canon(const TopicDev *topic, const uint4 *cur_words, const uint16_t *ext, const int32_t *rsz, uint4 *A, int maxBx,
-                  int32_t *status, void *stream) {
+void launch_canon(const TopicDev *topic, const uint32_t *cur_words, const uint16_t *ext, const int32_t *rsz, uint32_t *A, int maxBx,
+                  int nw, int32_t *status, void *stream) {
     const size_t lds = canon_lds_bytes(maxBx);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_canon), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_canon, dim3(1), dim3(64), lds, static_cast<hipStream_t>(stream), topic, cur_words, ext, rsz, A, maxBx, status);
+    if (nw == 8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_canon<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_canon<8>, dim3(1), dim3(64), lds, static_cast<hipStream_t>(stream), topic, reinterpret_cast<const Part<8> *>(cur_words), ext, rsz,
+                           reinterpret_cast<Part<8> *>(A), maxBx, status);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_canon<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_canon<4>, dim3(1), dim3(64), lds, static_cast<hipStream_t>(stream), topic, reinterpret_cast<const Part<4> *>(cur_words), ext, rsz,
+                           reinterpret_cast<Part<4> *>(A), maxBx, status);
+    }
 }
 
 }  // namespace kao

@@ -833,6 +833,42 @@ def random_case_wide(seed: int, max_b: int = 60, max_p: int = 96) -> Topic:
     return t
 
 
+def random_case_rf(seed: int, max_b: int = 26, max_p: int = 24) -> Topic:
+    """Random instances with HIGH replication factors (5..8 replicas, RF changes across the 4 / 5 boundary included):
+    README.md:148-151 puts no cap on the replication factor and README.md:9 lists an RF change as a use case.  May be
+    infeasible."""
+    rng = _Rng(0x8F000000 + seed)
+    R = 1 + rng.below(6)
+    rf = 4 + rng.below(5)                       # current RF 4..8
+    B0 = max(R * 2, rf + 2 + rng.below(max_b - rf))
+    P = 2 + rng.below(max_p - 1)
+    n_rm = rng.below(max(1, B0 // 5))
+    n_add = rng.below(3)
+    rm = rng.sample(list(range(B0)), n_rm)
+    add = [(B0 + i, rng.below(R)) for i in range(n_add)]
+    new_rf = rf
+    k = rng.below(3)
+    if k == 1:
+        new_rf = rf + 1
+    elif k == 2:
+        new_rf = rf - 1
+    new_rf = max(5 if rf <= 5 and k != 2 else 3, min(8, new_rf, B0 - n_rm + n_add - 1))
+    if rf <= 4 and new_rf <= 4:
+        new_rf = 5
+    weights = DEFAULT_WEIGHTS if rng.below(3) else ((4, 2), (2, 1))
+    c = make_cluster(f"rf{seed}", B0, R, 1, P, rf, rm, add, weights=weights, new_rf=new_rf)
+    t = c.topics[0]
+    cur = t.current.copy()
+    for _ in range(rng.below(P + 1)):
+        p = rng.below(P)
+        kk = rng.below(cur.shape[1])
+        nb = rng.below(t.n_brokers)
+        if nb not in cur[p]:
+            cur[p, kk] = nb
+    t.current = cur
+    return t
+
+
 def topic_to_dict(t: Topic) -> dict:
     return {"name": t.name, "broker_ids": [int(x) for x in t.broker_ids],
             "rack_of": [int(x) for x in t.rack_of], "n_racks": t.n_racks,

@@ -23,7 +23,8 @@
 #include <string.h>
 
 #define NONE16 0xFFFFu
-#define RFP 4 /* padded replica slots per partition */
+#define RFP 8 /* replica slots per partition held by the replay (the device holds 4 words per partition when RF and the
+                 current RF are <= 4, else 8: ls_topic.nw) */
 #define LANES 64
 
 typedef struct {
@@ -94,6 +95,7 @@ int kao_port_eval(const port_topic *t, const uint16_t *assign, int64_t *objectiv
 /* ------------------------------------------------------------------ KAO-LS replay */
 typedef struct {
     int P, RF, R, m, Bx; /* m = max rack size; internal index x = rack*m + j */
+    int nw;              /* replica words per partition on the device: 4, or 8 when RF or the current RF exceeds 4 (enters the hole hash) */
     uint32_t magic;      /* floor(2^32/m)+1: rack(x) = mulhi(x, magic) */
     int rack_size[256];
     uint16_t *int_of;    /* [B] dense -> internal */
@@ -140,11 +142,12 @@ static inline int valid_x(const ls_topic *t, unsigned x) {
 static inline int role_w(const ls_topic *t, int p, unsigned x, int nr) {
     const uint16_t *c = t->cur + p * RFP;
     if (c[0] == x) return t->w[0][nr];
-    if (c[1] == x || c[2] == x || c[3] == x) return t->w[1][nr];
+    for (int j = 1; j < RFP; ++j) if (c[j] == x) return t->w[1][nr];
     return 0;
 }
 static inline int in_part(const uint16_t *a, unsigned x) {
-    return a[0] == x || a[1] == x || a[2] == x || a[3] == x;
+    for (int j = 0; j < RFP; ++j) if (a[j] == x) return 1;
+    return 0;
 }
 static inline int rack_count(const ls_topic *t, const uint16_t *a, int r) {
     int c = 0;
@@ -157,6 +160,7 @@ void *kao_port_ls_create(const port_topic *pt) {
     const int B = pt->n_brokers;
     t->P = pt->n_partitions; t->RF = pt->rf; t->R = pt->n_racks;
     if (t->RF > RFP || pt->rf_cur > RFP || t->R > 255) { free(t); return NULL; }
+    t->nw = (t->RF > 4 || pt->rf_cur > 4) ? 8 : 4;
     for (int b = 0; b < B; ++b) t->rack_size[pt->rack_of[b]] += 1;
     for (int r = 0; r < t->R; ++r) if (t->rack_size[r] > t->m) t->m = t->rack_size[r];
     if (t->m < 2) t->m = 2; /* floor(2^32/m)+1 must fit 32 bits: single-broker racks get a stride of 2 */
@@ -259,7 +263,7 @@ static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint3
         uint16_t *a = s->A + p * RFP;
         for (int k = (pass == 0 ? 0 : 1); k < (pass == 0 ? 1 : t->RF); ++k) {
             if (a[k] != NONE16) continue;
-            const uint32_t hmix = slo ^ fmix32(shi + rho * 0x9E3779B1u + (uint32_t)(p * RFP + k) * 0x27D4EB2Fu + 0x5BD1E995u);
+            const uint32_t hmix = slo ^ fmix32(shi + rho * 0x9E3779B1u + (uint32_t)(p * t->nw + k) * 0x27D4EB2Fu + 0x5BD1E995u);
             uint32_t lane_key[LANES]; int lane_x[LANES];
             for (uint32_t l = 0; l < LANES; ++l) lane_key[l] = KEY_NULL;
             for (int base = 0; base < t->Bx; base += LANES)

@@ -118,7 +118,7 @@ def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params)
     ct = CTopic(topic)
     h = lib().kao_port_ls_create(C.byref(ct.s))
     if not h:
-        raise ValueError("unsupported instance (RF > 4 or racks > 255)")
+        raise ValueError("unsupported instance (RF > 8 or racks > 255)")
     try:
         pr = dict(DEFAULT_PARAMS)
         pr.update(params)
@@ -148,7 +148,7 @@ class PortRun:
         self._ct = CTopic(topic)
         self._h = lib().kao_port_ls_create(C.byref(self._ct.s))
         if not self._h:
-            raise ValueError("unsupported instance (RF > 4 or racks > 255)")
+            raise ValueError("unsupported instance (RF > 8 or racks > 255)")
         pr = dict(DEFAULT_PARAMS)
         pr.update(params)
         if pr["period_log2"] is None:
@@ -210,7 +210,7 @@ def port_valid_fraction(topic, seed: int, rho: int, launches: int, iters: int, *
     ct = CTopic(topic)
     h = lib().kao_port_ls_create(C.byref(ct.s))
     if not h:
-        raise ValueError("unsupported instance (RF > 4 or racks > 255)")
+        raise ValueError("unsupported instance (RF > 8 or racks > 255)")
     try:
         pr = dict(DEFAULT_PARAMS)
         pr.update(params)
@@ -229,7 +229,7 @@ def port_search_throughput(topic, seed: int, n_restarts: int, launches: int, ite
     ct = CTopic(topic)
     h = lib().kao_port_ls_create(C.byref(ct.s))
     if not h:
-        raise ValueError("unsupported instance (RF > 4 or racks > 255)")
+        raise ValueError("unsupported instance (RF > 8 or racks > 255)")
     try:
         pr = dict(DEFAULT_PARAMS)
         pr.update(params)

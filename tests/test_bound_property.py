@@ -47,7 +47,7 @@ KNOBS = st.tuples(st.integers(0, len(WEIGHTS) - 1),
 
 
 def _check(kao, ko, t, brute=False):
-    if t.rf > 4 or t.rf_cur > 4:
+    if t.rf > 8 or t.rf_cur > 8:
         return "skipped"
     pt = to_product_topic(t)
     ub = kao.upper_bound(pt)
@@ -87,6 +87,14 @@ def test_bound_never_undercuts_wide(ko, seed, knobs):
     t = ko.random_case_wide(seed, max_b=36, max_p=40)
     w_idx, band_key, band_delta, scramble, scr_seed = knobs
     _check(kao, ko, _perturb(ko, t, (w_idx if w_idx % 2 else 0, band_key, band_delta, scramble, scr_seed)))
+
+
+@settings(max_examples=150, derandomize=True, deadline=None, suppress_health_check=list(HealthCheck))
+@given(seed=st.integers(100000, 10**7), knobs=KNOBS)
+def test_bound_never_undercuts_high_rf(ko, seed, knobs):
+    """5..8 replicas (two word groups per partition on the device; the host bound's eviction tables grow with RF)."""
+    import kafka_assignment_optimizer_amd as kao
+    _check(kao, ko, _perturb(ko, ko.random_case_rf(seed, max_b=20, max_p=12), knobs))
 
 
 def test_bound_on_drifted_config_topics(ko):

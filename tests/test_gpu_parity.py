@@ -490,7 +490,7 @@ def test_alternative_weight_scheme(kao, ko):
     assert viol[0] == 0 and obj == 49 and ko.count_moves(ot, r.assignment) == (1, 0)
     for s in range(20, 40):  # random instances under scheme C: exact objective parity
         o2 = ko.random_case(s, max_b=12, max_p=8)
-        if o2.rf > 4 or o2.rf_cur > 4:
+        if o2.rf > 8 or o2.rf_cur > 8:
             continue
         o2.weights = ((4, 2), (2, 1))
         ex = ko.solve_exact(o2, 30)
@@ -850,3 +850,56 @@ def test_eval_counter_overflow_is_reported(kao, ko):
     with pytest.raises(kao.KaoError) as e:
         kao.evaluate(t, bad)
     assert e.value.code == -2
+
+
+# ------------------------------------------------------------------------------- replication factors 5..8 (two word groups per partition)
+def _rf_cases(ko):
+    return [(c, ko.random_case_rf(c["seed"])) for c in load_golden("random_rf.json")["cases"]]
+
+
+def test_high_rf_eval_and_replay_bit_exact(kao, ko, kp):
+    """K-eval (k_eval<8>) == the numpy verifier and K-search (k_search<*, *, 8>) == the scalar replay on topics with 5..8
+    replicas, RF changes across the 4 / 5 boundary included (README.md:148-151: no cap on RF; README.md:9: RF changes)."""
+    cases = [(c, t) for c, t in _rf_cases(ko) if c["status"] == "optimal"][:24]
+    ots = [t for _, t in cases]
+    assert max(t.rf for t in ots) == 8 and any(t.rf_cur <= 4 < t.rf for t in ots) and any(t.rf <= 4 < t.rf_cur for t in ots)
+    for ot in ots[:10]:
+        cands = random_candidates(ot, 12, seed=ot.n_partitions, p_mut=0.3, p_none=0.05)
+        o, v = kao.evaluate_batch(to_product_topic(ot), cands)
+        for i in range(len(cands)):
+            oo, vv = ko.verify(ot, cands[i])
+            assert (int(o[i]), v[i].tolist()) == (oo, vv.tolist()), (ot.name, i)
+    seed = 808
+    with kao.Session([to_product_topic(t) for t in ots], seed=seed, restarts=8, iters_per_launch=160) as s:
+        s.step(2)
+        assert s.stats()["drift"] == 0
+        for ti, ot in enumerate(ots):
+            for rho in (1, 6):
+                dev = s.restart_state(ti, rho)
+                ref = kp.port_search(ot, _tseed(seed, ti), rho, 2, 160)
+                assert dev["final"].tolist() == ref["final"].tolist(), (ot.name, rho)
+                assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
+                obj, viol = ko.verify(ot, dev["final"])
+                assert (obj, int(viol[0])) == (dev["obj"], dev["V"])
+
+
+def test_high_rf_golden_optima(kao, ko):
+    """kao_solve on the whole RF 5..8 family: the HiGHS optimum on every feasible instance, every HiGHS-infeasible one either
+    proven infeasible or left without a feasible plan, the canonical form of unique optima bit-exact."""
+    cases = _rf_cases(ko)
+    res = kao.solve([to_product_topic(t) for _, t in cases], seed=31, time_limit_s=30, max_launches=40)
+    n_opt = n_proven = n_unique = 0
+    for (c, ot), r in zip(cases, res):
+        if c["status"] != "optimal":
+            assert r.status in ("INFEASIBLE_PROVEN", "NO_FEASIBLE"), (c["seed"], r.status)
+            continue
+        assert r.objective == c["objective"], (c["seed"], r.objective, c["objective"], r.status)
+        assert r.upper_bound >= c["objective"]
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == c["objective"]
+        n_opt += 1
+        n_proven += r.status == "OPTIMAL_PROVEN"
+        if c.get("unique"):
+            assert kao.canonicalize(to_product_topic(ot), r.assignment).tolist() == ko.canonicalize(ot, np.array(c["assignment"])).tolist(), c["seed"]
+            n_unique += 1
+    assert n_opt >= 50 and n_proven >= n_opt // 3

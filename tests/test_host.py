@@ -53,7 +53,7 @@ def test_host_helpers_match_oracle(ko):
              ko.gen_config(5, n_topics=1).topics[0]] + [ko.random_case(s) for s in range(60)] + \
             [ko.random_case(s, max_b=40, max_p=40) for s in range(1000, 1040)]
     for ot in cases:
-        if ot.rf > 4 or ot.rf_cur > 4:
+        if ot.rf > 8 or ot.rf_cur > 8:
             continue
         pt = to_product_topic(ot)
         assert kao.derive_bounds(pt) == ot.bounds()
@@ -136,10 +136,10 @@ def test_java_cli_mirrors_the_cpp_cli_flags():
 def test_validation_errors(ko):
     import kafka_assignment_optimizer_amd as kao
     pt = to_product_topic(ko.readme_example())
-    pt.rf = 5
+    pt.rf = 9
     with pytest.raises(kao.KaoError) as e:
         kao.derive_bounds(pt)
-    assert e.value.code == -2  # KAO_ERR_UNSUPPORTED
+    assert e.value.code == -2  # KAO_ERR_UNSUPPORTED (more than KAO_MAX_RF = 8 replicas)
     pt = to_product_topic(ko.readme_example())
     pt.rack_of = pt.rack_of.copy()
     pt.rack_of[3] = 9
