@@ -73,6 +73,12 @@ typedef struct kao_topic {
     int32_t lead_lo, lead_hi;   /* C4 leaders per broker    (README.md:163-166) */
     int32_t rack_lo, rack_hi;   /* C6 replicas per rack     (README.md:173-176) */
     int32_t prack_lo, prack_hi; /* C7 replicas per partition per rack (README.md:178-180) */
+    /* Optional broker weights (NULL = none): extra objective coefficients on EVERY variable of a broker -- broker_w[b] on
+       each replica placed on b (t?b<b>p? and t?b<b>p?_l), broker_wl[b] on each leader (t?b<b>p?_l) -- i.e. plain
+       coefficients of the README's `max:` row (README.md:145-146).  0..1023 each.  kao_solve_capped uses them to price
+       cluster-wide per-broker caps; topics with broker weights get no K-bound certificate and are not canonicalised. */
+    const int32_t *broker_w;    /* [n_brokers] or NULL */
+    const int32_t *broker_wl;   /* [n_brokers] or NULL */
 } kao_topic;
 
 typedef struct kao_opts {
@@ -248,6 +254,19 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
  * librccl.so is loaded on first use.  Results as kao_solve. */
 int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *devices, int32_t n_dev, const kao_opts *opts,
                     kao_result *results);
+/* Cluster-wide per-broker load caps (BASELINE config 5; SURVEY.md section 8e "when it does NOT shard"): on top of every
+ * topic's own rows, sum over ALL topics of the replicas on broker b <= replica_cap[b] (-1 = no cap for b).  All topics must
+ * share one broker set (same n_brokers, same dense index).  The caps couple the topics; they are priced: every round solves
+ * the topics independently (kao_solve / kao_solve_multi when n_dev > 1) with broker weights M - mu[b], adds up the broker
+ * loads of the answers (the step that is an allreduce(SUM, int32[B]) when topics are sharded over processes) and raises mu[b]
+ * on overloaded brokers (projected subgradient with a diminishing step; once a round respects every cap its plan is kept as
+ * incumbent and the prices are relaxed again to look for a cheaper one).  results[i] = the best plan found that respects
+ * the caps (status FEASIBLE_BOUND_GAP / NO_FEASIBLE; objective = README objective without the weights);
+ * *lagrangian_bound (may be NULL) = smallest Lagrangian dual value seen (an upper bound on the capped optimum when every
+ * topic's priced sub-problem was proven optimal in that round, else INT64_MAX).  devices / n_dev as kao_solve_multi
+ * (NULL / 0 = the current device). */
+int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *replica_cap, const int32_t *devices, int32_t n_dev,
+                     const kao_opts *opts, int32_t max_rounds, kao_result *results, int64_t *lagrangian_bound);
 /* Diagnostic: runs the two collectives kao_solve_multi uses (ncclAllReduce(ncclUint64, ncclMin) and ncclBroadcast) on
  * small resident buffers of the listed distinct devices and checks the results.  0 = ok. */
 int kao_rccl_selftest(const int32_t *devices, int32_t n_dev);

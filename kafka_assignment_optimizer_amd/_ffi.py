@@ -14,7 +14,8 @@ class KaoTopic(C.Structure):
                 ("rack_of", C.POINTER(C.c_uint8)), ("current", C.POINTER(C.c_uint16)),
                 ("w", (C.c_int32 * 2) * 2),
                 ("rep_lo", C.c_int32), ("rep_hi", C.c_int32), ("lead_lo", C.c_int32), ("lead_hi", C.c_int32),
-                ("rack_lo", C.c_int32), ("rack_hi", C.c_int32), ("prack_lo", C.c_int32), ("prack_hi", C.c_int32)]
+                ("rack_lo", C.c_int32), ("rack_hi", C.c_int32), ("prack_lo", C.c_int32), ("prack_hi", C.c_int32),
+                ("broker_w", C.POINTER(C.c_int32)), ("broker_wl", C.POINTER(C.c_int32))]
 
 
 class KaoOpts(C.Structure):
@@ -79,6 +80,8 @@ SIGNATURES = {
     "kao_session_destroy": (None, [C.c_void_p]),
     "kao_solve": (C.c_int, [_P(KaoTopic), C.c_int32, _P(KaoOpts), _P(KaoResult)]),
     "kao_solve_multi": (C.c_int, [_P(KaoTopic), C.c_int32, _P(C.c_int32), C.c_int32, _P(KaoOpts), _P(KaoResult)]),
+    "kao_solve_capped": (C.c_int, [_P(KaoTopic), C.c_int32, _P(C.c_int32), _P(C.c_int32), C.c_int32, _P(KaoOpts), C.c_int32,
+                                  _P(KaoResult), _P(C.c_int64)]),
     "kao_rccl_selftest": (C.c_int, [_P(C.c_int32), C.c_int32]),
     "kao_last_solve_timing": (C.c_int, [_P(C.c_double)]),
 }

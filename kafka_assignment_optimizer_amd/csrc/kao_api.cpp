@@ -81,7 +81,13 @@ int validate(const kao_topic *t) {
             if (t->w[i][j] < 0 || t->w[i][j] > 1023) return fail(KAO_ERR_INVALID, "objective weights must be 0..1023");
             wmax = std::max(wmax, t->w[i][j]);
         }
-    if ((int64_t)t->n_partitions * t->rf * wmax > 0xFFFFFE)
+    int bwmax = 0, bwlmax = 0;
+    for (int b = 0; b < t->n_brokers; ++b) {
+        const int v = t->broker_w ? t->broker_w[b] : 0, vl = t->broker_wl ? t->broker_wl[b] : 0;
+        if (v < 0 || v > 1023 || vl < 0 || vl > 1023) return fail(KAO_ERR_INVALID, "broker weights must be 0..1023");
+        bwmax = std::max(bwmax, v); bwlmax = std::max(bwlmax, vl);
+    }
+    if ((int64_t)t->n_partitions * t->rf * (wmax + bwmax) + (int64_t)t->n_partitions * bwlmax > 0xFFFFFE)
         return fail(KAO_ERR_UNSUPPORTED, "objective can exceed 24 bits (n_partitions * rf * largest weight)");
     for (int p = 0; p < t->n_partitions; ++p) {  // one LP variable per (broker, partition) (README.md:146): a broker cannot be listed twice
         const uint16_t *c = t->current + (size_t)p * t->rf_cur;
@@ -122,6 +128,7 @@ struct PreparedTopic {
     std::vector<uint16_t> cur_int;  // [P*4] internal
     std::vector<uint8_t> rack_of;   // [B]
     std::vector<uint16_t> cur_dense;// [P*rf_cur]
+    std::vector<uint32_t> bw_int, bw_dense;  // broker weights bw | bwl << 16 per internal / dense index (empty = none)
 };
 
 int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
@@ -163,6 +170,16 @@ int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
     d.w00 = t->w[0][0]; d.w01 = t->w[0][1]; d.w10 = t->w[1][0]; d.w11 = t->w[1][1];
     d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
     d.B = B; d.rf_cur = t->rf_cur; d.nw = nw;
+    d.has_bw = (t->broker_w || t->broker_wl) ? 1 : 0;
+    if (d.has_bw) {
+        pt.bw_dense.assign((size_t)B, 0);
+        pt.bw_int.assign((size_t)Bx, 0);
+        for (int b = 0; b < B; ++b) {
+            const uint32_t v = (uint32_t)(t->broker_w ? t->broker_w[b] : 0) | ((uint32_t)(t->broker_wl ? t->broker_wl[b] : 0) << 16);
+            pt.bw_dense[(size_t)b] = v;
+            pt.bw_int[pt.int_of[(size_t)b]] = v;
+        }
+    }
     return KAO_OK;
 }
 
@@ -411,6 +428,31 @@ int64_t upper_bound(const kao_topic *t) {
     return std::min(total - std::max(evict_loss, lead_loss), broker_bound);
 }
 
+// Closed-form bound of a topic that may carry broker weights: the weights are bounded term by term -- the band rows allow at
+// most min(rep_hi, P) replicas and min(lead_hi, P) leaders on a broker, P*RF replicas and P leaders in all, so the
+// weight part is at most the greedy fill of those capacities in descending weight order.
+int64_t upper_bound_w(const kao_topic *t) {
+    int64_t ub = upper_bound(t);
+    if (!t->broker_w && !t->broker_wl) return ub;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    for (int kind = 0; kind < 2; ++kind) {
+        const int32_t *w = kind == 0 ? t->broker_w : t->broker_wl;
+        if (!w) continue;
+        std::vector<int> v(w, w + t->n_brokers);
+        std::sort(v.begin(), v.end(), std::greater<int>());
+        int64_t left = kind == 0 ? (int64_t)t->n_partitions * t->rf : t->n_partitions;
+        const int64_t per = std::min<int64_t>(kind == 0 ? bd[1] : bd[3], t->n_partitions);
+        for (int x : v) {
+            if (left <= 0) break;
+            const int64_t take = std::min(left, per);
+            ub += take * x;
+            left -= take;
+        }
+    }
+    return ub;
+}
+
 // Neighbours delta-evaluated by ONE restart over iterations [it0, it0+iters) (kao_kernels.hip, KAO-LS):
 // move pattern R R X R L R X R; REPLACE scans all B brokers of one slot in even blocks of 8 iterations and
 // samples 64 lanes x 4 brokers in odd blocks; EXCHANGE scans all P*RF partner slots (a window of 512 partitions
@@ -442,6 +484,7 @@ int auto_period_log2(int P, int RF) {
 // P*RF subgradients)
 bool dual_supported(const kao_topic *t) {
     if (t->rf > kRFP || t->rf_cur > kRFP) return false;   // K-bound's per-lane subproblem holds 4 replicas
+    if (t->broker_w || t->broker_wl) return false;        // K-bound prices the README rows only
     if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false) > 160 * 1024) return false;
     const int64_t n = (int64_t)t->n_partitions * t->rf;
     if (n > 131072) return false;
@@ -495,6 +538,7 @@ struct kao_eval_plan {
     uint8_t *d_rackof = nullptr;
     uint16_t *d_curd = nullptr;
     int4 *d_map = nullptr;
+    uint32_t *d_bwd = nullptr;      // broker weights (dense) when the topic has them
     int32_t *d_overflow = nullptr;  // set by K-eval when a candidate overflows a 16-bit per-broker counter (P*RF > 65535 only)
     int64_t map_n = -1;
     int map_blocks = 0;
@@ -563,6 +607,7 @@ struct kao_session {
     int price_write_last = -1;   // half the K-bound launch in flight (or the last finished one) writes
     bool priced = false;         // K-search launches carry prices
     uint16_t *d_int = nullptr;   // dense -> internal broker index per topic
+    uint32_t *d_bw = nullptr, *d_bwd = nullptr;   // broker weights per internal / dense index (topics with has_bw)
     long long *d_dual_target = nullptr;
     int32_t *d_dual_ids = nullptr;
     unsigned char *d_dual_rb = nullptr;
@@ -748,7 +793,7 @@ int kao_check_infeasible(const kao_topic *t, char *why, int why_len) {
 int kao_upper_bound(const kao_topic *t, int64_t *ub) {
     int rc = validate(t);
     if (rc) return rc;
-    *ub = upper_bound(t);
+    *ub = upper_bound_w(t);
     return KAO_OK;
 }
 
@@ -766,10 +811,10 @@ int kao_eval_plan_create(const kao_topic *t, kao_eval_plan **out) {
     if (rc) { delete p; return rc; }
     p->cur_in_lds = eval_lds_bytes(p->pt.d.P, p->pt.d.B, true, p->pt.d.nw) <= 160 * 1024;
     if (eval_lds_bytes(p->pt.d.P, p->pt.d.B, p->cur_in_lds, p->pt.d.nw) > 160 * 1024) { delete p; return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS"); }
-    p->pt.d.best_off = 0; p->pt.d.rackof_off = 0; p->pt.d.curd_off = 0;
+    p->pt.d.best_off = 0; p->pt.d.rackof_off = 0; p->pt.d.curd_off = 0; p->pt.d.bwd_off = 0;
     std::vector<TopicDev> td(1, p->pt.d);
     if ((rc = dev_alloc_copy(&p->d_topic, td)) || (rc = dev_alloc_copy(&p->d_rackof, p->pt.rack_of)) ||
-        (rc = dev_alloc_copy(&p->d_curd, p->pt.cur_dense))) { kao_eval_plan_destroy(p); return rc; }
+        (rc = dev_alloc_copy(&p->d_curd, p->pt.cur_dense)) || (p->pt.d.has_bw && (rc = dev_alloc_copy(&p->d_bwd, p->pt.bw_dense)))) { kao_eval_plan_destroy(p); return rc; }
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e == hipSuccess && (int64_t)p->pt.d.P * p->pt.d.RF > 65535) {
         e = hipMalloc(reinterpret_cast<void **>(&p->d_overflow), 4);
@@ -809,7 +854,7 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
     pl.violations = static_cast<int32_t *>(d_violations);
     pl.best_key = static_cast<unsigned long long *>(d_best_key);
     pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B; pl.cur_in_lds = p->cur_in_lds ? 1 : 0;
-    pl.overflow = p->d_overflow;
+    pl.overflow = p->d_overflow; pl.bwd_pool = p->d_bwd;
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     launch_eval(pl, p->map_blocks, p->pt.d.nw, p->stream);
     HIP_TRY(hipGetLastError());
@@ -841,7 +886,7 @@ void kao_eval_plan_destroy(kao_eval_plan *p) {
     if (!p) return;
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->d_topic); (void)hipFree(p->d_rackof); (void)hipFree(p->d_curd); (void)hipFree(p->d_map); (void)hipFree(p->d_overflow);
+    (void)hipFree(p->d_topic); (void)hipFree(p->d_rackof); (void)hipFree(p->d_curd); (void)hipFree(p->d_map); (void)hipFree(p->d_overflow); (void)hipFree(p->d_bwd);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -900,6 +945,7 @@ int kao_evaluate(const kao_topic *t, const uint16_t *assignment, int64_t *object
 
 int kao_canonicalize(const kao_topic *t, uint16_t *a) {
     if (!a) return fail(KAO_ERR_INVALID, "null assignment");
+    if (t && (t->broker_w || t->broker_wl)) return KAO_OK;   // moving a replica to another broker changes the objective: nothing to canonicalise
     int rc = require_init();
     if (rc) return rc;
     PreparedTopic pt;
@@ -1033,7 +1079,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->topics.assign(topics, topics + n_topics);
     s->ub.resize((size_t)n_topics);
 
-    std::vector<uint32_t> cur_pool; std::vector<uint16_t> ext_pool, curd_pool, int_pool; std::vector<int32_t> rsz_pool;
+    std::vector<uint32_t> cur_pool, bw_pool, bwd_pool; std::vector<uint16_t> ext_pool, curd_pool, int_pool; std::vector<int32_t> rsz_pool;
     uint64_t price_i32 = 0;
     std::vector<uint8_t> rackof_pool;
     uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0, dual_i32 = 0;
@@ -1044,7 +1090,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         const uint64_t seed = o.seed ^ ((uint64_t)(t + 1) * 0x9E3779B97F4A7C15ull);
         rc = prepare(&topics[t], seed, pt);
         if (rc) { kao_session_destroy(s); return rc; }
-        s->ub[(size_t)t] = upper_bound(&topics[t]);
+        s->ub[(size_t)t] = upper_bound_w(&topics[t]);
         s->topic_infeasible.push_back(infeasible_reason(&topics[t]).empty() ? 0 : 1);
         TopicDev &d = pt.d;
         d.n_restarts = o.restarts;
@@ -1071,6 +1117,11 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         rackof_pool.insert(rackof_pool.end(), pt.rack_of.begin(), pt.rack_of.end());
         d.curd_off = (uint32_t)curd_pool.size();
         curd_pool.insert(curd_pool.end(), pt.cur_dense.begin(), pt.cur_dense.end());
+        if (d.has_bw) {
+            d.bw_off = (uint32_t)bw_pool.size(); bw_pool.insert(bw_pool.end(), pt.bw_int.begin(), pt.bw_int.end());
+            d.bwd_off = (uint32_t)bwd_pool.size(); bwd_pool.insert(bwd_pool.end(), pt.bw_dense.begin(), pt.bw_dense.end());
+            s->priced = true;   // broker weights live in the tables of the priced K-search instantiation
+        }
         d.int_off = (uint32_t)int_pool.size();
         int_pool.insert(int_pool.end(), pt.int_of.begin(), pt.int_of.end());
         d.price_off = (uint32_t)price_i32;
@@ -1139,11 +1190,12 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
 
     // ---- read-only arena: stage everything on the host, ONE hipMalloc (or a parked arena), ONE H2D copy ----
     struct Sec { const void *src; size_t bytes; size_t off; };
-    Sec secs[9] = {{tds.data(), tds.size() * sizeof(TopicDev), 0}, {smap.data(), smap.size() * sizeof(int2), 0},
+    Sec secs[11] = {{tds.data(), tds.size() * sizeof(TopicDev), 0}, {smap.data(), smap.size() * sizeof(int2), 0},
                    {emap.data(), emap.size() * sizeof(int4), 0}, {cur_pool.data(), cur_pool.size() * sizeof(uint32_t), 0},
                    {ext_pool.data(), ext_pool.size() * 2, 0}, {rsz_pool.data(), rsz_pool.size() * 4, 0},
                    {rackof_pool.data(), rackof_pool.size(), 0}, {curd_pool.data(), curd_pool.size() * 2, 0},
-                   {int_pool.data(), int_pool.size() * 2, 0}};
+                   {int_pool.data(), int_pool.size() * 2, 0}, {bw_pool.data(), bw_pool.size() * 4, 0},
+                   {bwd_pool.data(), bwd_pool.size() * 4, 0}};
     size_t ro_bytes = 0;
     for (Sec &sec : secs) { sec.off = ro_bytes; ro_bytes += align_up(sec.bytes); }
     std::vector<unsigned char> stage(ro_bytes);
@@ -1159,6 +1211,8 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->d_rackof = reinterpret_cast<uint8_t *>(ro + secs[6].off);
     s->d_curd = reinterpret_cast<uint16_t *>(ro + secs[7].off);
     s->d_int = reinterpret_cast<uint16_t *>(ro + secs[8].off);
+    s->d_bw = reinterpret_cast<uint32_t *>(ro + secs[9].off);
+    s->d_bwd = reinterpret_cast<uint32_t *>(ro + secs[10].off);
 
     // ---- mutable arena ----
     const size_t state_b = align_up(state_bytes), best_b = align_up(best_u16 * 2);
@@ -1238,10 +1292,10 @@ int kao_session_step(kao_session *s) {
     const int eper = s->opts.elite_period;
     prm.elite = (eper > 0 && s->launch > 0 && s->launch % (uint32_t)eper == 0) ? 1 : 0;
     sp.price_pool = s->d_price + (size_t)s->price_read * s->price_half_i32;
-    sp.int_pool = s->d_int; sp.elite_assign = s->d_win_assign; sp.elite_key = s->d_keys;
+    sp.int_pool = s->d_int; sp.elite_assign = s->d_win_assign; sp.elite_key = s->d_keys; sp.bw_pool = s->d_bw;
     EvalPools ep{};
     ep.topics = s->d_topics; ep.rackof_pool = s->d_rackof; ep.curd_pool = s->d_curd;
-    ep.cand = s->d_best; ep.objective = s->d_obj; ep.violations = s->d_viol; ep.best_key = s->d_keys;
+    ep.cand = s->d_best; ep.objective = s->d_obj; ep.violations = s->d_viol; ep.best_key = s->d_keys; ep.bwd_pool = s->d_bwd;
     hipEvent_t *e = prof ? &s->ev[(size_t)s->ev_pending * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(e[0], s->stream));
     for (const kao_session::LaunchGroup &g : s->groups) {
@@ -2037,6 +2091,119 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
     for (int d = 0; d < n_dev; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; kao_session_destroy(D[(size_t)d].run.s); D[(size_t)d].run.s = nullptr; }
     cleanup();
     g_timing[1] = t_improve; g_timing[3] = now_s() - t0; g_timing[4] = rounds; g_timing[5] = cand; g_timing[6] = bl; g_timing[7] = (double)exchanges;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kao_solve_capped: cluster-wide per-broker load caps, priced (Lagrangian) over independent per-topic solves
+// ------------------------------------------------------------------------------------------------
+int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *replica_cap, const int32_t *devices, int32_t n_dev,
+                     const kao_opts *opts, int32_t max_rounds, kao_result *results, int64_t *lagrangian_bound) {
+    const double t0 = now_s();
+    if (!topics || n_topics < 1 || !replica_cap || !results) return fail(KAO_ERR_INVALID, "null argument");
+    const int B = topics[0].n_brokers;
+    int wmax = 1;
+    for (int i = 0; i < n_topics; ++i) {
+        if (topics[i].n_brokers != B) return fail(KAO_ERR_INVALID, "kao_solve_capped: every topic must use the same broker set");
+        if (topics[i].broker_w || topics[i].broker_wl) return fail(KAO_ERR_UNSUPPORTED, "kao_solve_capped: topics with their own broker weights");
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) wmax = std::max(wmax, topics[i].w[a][b]);
+    }
+    const int mu_max = std::min(1023, 4 * wmax);   // a price above every objective weight already repels every replica
+    kao_opts o{};
+    if (opts) o = *opts;
+    const double limit = o.time_limit_s > 0 ? o.time_limit_s : 10.0;
+    const int rounds = max_rounds > 0 ? max_rounds : 40;
+    if (o.max_launches <= 0) o.max_launches = 6;
+    o.stop_at_bound = 1;
+    o.target_objective = nullptr;
+    std::vector<int32_t> mu((size_t)B, 0), bw((size_t)B, 0);
+    std::vector<kao_topic> tp(topics, topics + n_topics);
+    std::vector<std::vector<uint16_t>> buf((size_t)n_topics), inc((size_t)n_topics);
+    std::vector<kao_result> res((size_t)n_topics), inc_res((size_t)n_topics);
+    for (int i = 0; i < n_topics; ++i) buf[(size_t)i].assign((size_t)topics[i].n_partitions * topics[i].rf, (uint16_t)KAO_NONE);
+    int64_t inc_total = -1, best_L = INT64_MAX, n_slots = 0;
+    for (int i = 0; i < n_topics; ++i) n_slots += (int64_t)topics[i].n_partitions * topics[i].rf;
+    std::vector<int64_t> load((size_t)B);
+    int rc = KAO_OK, r = 0;
+    for (; r < rounds; ++r) {
+        const double left = limit - (now_s() - t0);
+        if (r > 0 && left <= 0) break;
+        int M = 0;
+        for (int b = 0; b < B; ++b) M = std::max(M, mu[(size_t)b]);
+        for (int b = 0; b < B; ++b) bw[(size_t)b] = M - mu[(size_t)b];   // weights must be >= 0: a constant M per replica does not change any argmax
+        for (int i = 0; i < n_topics; ++i) {
+            tp[(size_t)i].broker_w = M ? bw.data() : nullptr;
+            res[(size_t)i] = kao_result{};
+            res[(size_t)i].assignment = buf[(size_t)i].data();
+        }
+        o.time_limit_s = std::max(0.05, left / std::max(1, std::min(rounds - r, 8)));
+        o.seed = (opts ? opts->seed : 0) + (uint64_t)r * 0x9E3779B97F4A7C15ull;
+        rc = (devices && n_dev > 1) ? kao_solve_multi(tp.data(), n_topics, devices, n_dev, &o, res.data())
+                                    : kao_solve(tp.data(), n_topics, &o, res.data());
+        if (rc) break;
+        // ---- broker loads over ALL topics (the allreduce(SUM) of a sharded deployment), objective without the weights ----
+        std::fill(load.begin(), load.end(), 0);
+        bool all_feasible = true, all_proven = true;
+        int64_t total = 0, total_w = 0;
+        for (int i = 0; i < n_topics; ++i) {
+            const kao_result &x = res[(size_t)i];
+            if (x.status == KAO_STATUS_NO_FEASIBLE || x.status == KAO_STATUS_INFEASIBLE_PROVEN) { all_feasible = false; continue; }
+            all_proven &= x.status == KAO_STATUS_OPTIMAL_PROVEN;
+            int64_t wsum = 0;
+            for (size_t k = 0; k < buf[(size_t)i].size(); ++k) { const uint16_t b = buf[(size_t)i][k]; load[b]++; wsum += M ? bw[b] : 0; }
+            total += x.objective - wsum;
+            total_w += x.upper_bound;
+        }
+        int64_t worst = 0, priced = 0;
+        for (int b = 0; b < B; ++b) {
+            if (replica_cap[b] < 0) continue;
+            worst = std::max<int64_t>(worst, load[(size_t)b] - replica_cap[b]);
+            priced += (int64_t)mu[(size_t)b] * replica_cap[b];
+        }
+        if (all_feasible && all_proven) best_L = std::min(best_L, total_w - (int64_t)M * n_slots + priced);   // L(mu) >= capped optimum
+        if (all_feasible && worst <= 0 && total > inc_total) {   // respects every cap: a candidate answer
+            inc_total = total;
+            for (int i = 0; i < n_topics; ++i) {
+                inc[(size_t)i] = buf[(size_t)i];
+                inc_res[(size_t)i] = res[(size_t)i];
+                int64_t wsum = 0;
+                for (uint16_t b : buf[(size_t)i]) wsum += M ? bw[b] : 0;
+                inc_res[(size_t)i].objective = res[(size_t)i].objective - wsum;
+            }
+        }
+        if (inc_total >= 0 && best_L != INT64_MAX && inc_total >= best_L) break;   // incumbent meets the Lagrangian bound: optimal
+        // ---- projected subgradient step on the prices, diminishing: alpha = 1 / (1 + r / 3) ----
+        const int den = 1 + r / 3;
+        bool moved = false;
+        for (int b = 0; b < B; ++b) {
+            if (replica_cap[b] < 0) continue;
+            const int64_t ex = load[(size_t)b] - replica_cap[b];
+            int d = 0;
+            if (ex > 0) d = (int)std::max<int64_t>(1, ex / den);
+            else if (ex < 0 && mu[(size_t)b] > 0) d = -(int)std::min<int64_t>(mu[(size_t)b], std::max<int64_t>(r >= 6 ? 0 : 1, (-ex) / (2 * den)));
+            const int nm = std::min(mu_max, std::max(0, mu[(size_t)b] + d));
+            moved |= nm != mu[(size_t)b];
+            mu[(size_t)b] = nm;
+        }
+        if (!moved) break;   // prices are stationary
+    }
+    if (!rc) {
+        for (int i = 0; i < n_topics; ++i) {
+            uint16_t *dst = results[i].assignment;
+            if (inc_total >= 0) {
+                results[i] = inc_res[(size_t)i];
+                results[i].status = (best_L != INT64_MAX && inc_total >= best_L) ? KAO_STATUS_OPTIMAL_PROVEN : KAO_STATUS_FEASIBLE_BOUND_GAP;
+                results[i].upper_bound = best_L != INT64_MAX ? best_L : INT64_MAX;   // a bound on the SUM over all topics
+                if (dst) std::memcpy(dst, inc[(size_t)i].data(), inc[(size_t)i].size() * 2);
+            } else {
+                results[i] = res[(size_t)i];
+                results[i].status = KAO_STATUS_NO_FEASIBLE; results[i].objective = -1;
+            }
+            results[i].assignment = dst;
+        }
+        if (lagrangian_bound) *lagrangian_bound = best_L;
+    }
+    g_timing[3] = now_s() - t0; g_timing[4] = r;
     return rc;
 }
 

@@ -48,7 +48,10 @@ struct TopicDev {
                                  //              kDualScale, dense broker index); K-bound's epilogue or the host writes them
     uint32_t int_off;            // int_pool   : dense -> internal broker index (u16[B]); elite re-seeding reads dense snapshots
     int32_t nw;                  // replica words per partition in K-search / K-canon: 4 (RF, current RF <= 4) or 8
-    int32_t pad_[2];
+    int32_t has_bw;              // 1 = the topic carries broker weights (kao_topic.broker_w / broker_wl)
+    uint32_t bw_off;             // bw_pool  : packed bw | bwl << 16 per INTERNAL index (u32[Bx])
+    uint32_t bwd_off;            // bwd_pool : the same per DENSE index (u32[B]) for K-eval
+    int32_t pad_[3];
 };
 
 struct SearchParams {
@@ -72,6 +75,7 @@ struct SearchPools {
     int32_t *restart_info;       // [n_restarts_total][4] = {best_obj, V, obj, accepted}
     int32_t *drift;              // [1] counter
     const int32_t *price_pool;   // search prices (k_search<*, true> only), see TopicDev::price_off
+    const uint32_t *bw_pool;     // broker weights per internal index (k_search<*, true> only)
     const uint16_t *int_pool;    // dense -> internal broker index per topic
     const uint16_t *elite_assign;// [sum P*RF] every topic's best feasible assignment so far (dense; k_gather's output), at win_off
     const unsigned long long *elite_key;  // [n_topics] packed key of that assignment as of the previous step (~0 = none)
@@ -88,6 +92,7 @@ struct EvalPools {
     unsigned long long *best_key;// [n_topics] or nullptr (atomicMin of the packed key)
     int32_t maxP, maxB;
     int32_t cur_in_lds;          // 1 = stage the current assignment in LDS (fits); 0 = read it from global memory
+    const uint32_t *bwd_pool;    // broker weights per dense index (topics with has_bw)
     int32_t *overflow;           // [1] or nullptr: set when a candidate puts more than 65,535 replicas on one broker (the 16-bit
                                  //     halves of the per-broker counters would carry; only possible when P*RF > 65535)
 };

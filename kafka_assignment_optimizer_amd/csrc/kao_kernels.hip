@@ -126,6 +126,8 @@ __device__ __forceinline__ int price_lead(uint32_t pr) { return (int)pr >> 16; }
 // nothing (a plain linear term would push the counts of rows with a positive multiplier down to the lower band end).
 __device__ __forceinline__ int p_in(int c, int lo, int hi, int price) { return ((c >= hi) | (c < lo)) ? price : 0; }
 __device__ __forceinline__ int p_out(int c, int lo, int hi, int price) { return ((c > hi) | (c <= lo)) ? -price : 0; }
+// packed broker weights (objective terms per replica / per leader on a broker, kao_topic.broker_w / broker_wl): low | high half
+__device__ __forceinline__ int bw_of(uint32_t bw, bool lead) { return (int)(bw & 0xFFFFu) + (lead ? (int)(bw >> 16) : 0); }
 // fixed point (kDualScale) -> key units (obj_scale per objective unit), rounded half up, clamped to 16 bits
 __device__ __forceinline__ int price_units(int v, int S) { return min(max((S * v + kDualScale / 2) >> 12, -32767), 32767); }
 
@@ -227,7 +229,7 @@ template <int NW> __device__ __forceinline__ void recount(const TopicRegs &T, co
 
 // total violation magnitude and objective of the state in LDS (C, K must be current)
 template <int NW> __device__ __forceinline__ void full_cost(const TopicRegs &T, const WaveLds<NW> &L, const Part<NW> *CUR, const int *RSZ,
-                                                            int lane, int &V, int &obj) {
+                                                            int lane, int &V, int &obj, const uint32_t *BW = nullptr) {
     int v = 0, o = 0;
     for (int p = lane; p < T.P; p += 64) {
         const Part<NW> a = L.A[p];
@@ -242,6 +244,7 @@ template <int NW> __device__ __forceinline__ void full_cost(const TopicRegs &T, 
         if (x - r * T.m < RSZ[r]) {
             const uint32_t c = L.C[x];
             v += band((int)(c & 0xFFFFu), T.rep_lo, T.rep_hi) + band((int)(c >> 16), T.lead_lo, T.lead_hi);
+            if (BW) { const uint32_t bw = BW[x]; o += (int)(c & 0xFFFFu) * (int)(bw & 0xFFFFu) + (int)(c >> 16) * (int)(bw >> 16); }
         }
     }
     for (int r = lane; r < T.R; r += 64) v += band(L.K[r], T.rack_lo, T.rack_hi);
@@ -290,8 +293,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
     uint8_t *XR = smem + a_bytes + kRackTab * 4;  // rack of internal index x, 0xFF = padding slot / beyond Bx
     uint32_t *PR = reinterpret_cast<uint32_t *>(smem + a_bytes + kRackTab * 4 + bx64);  // [bx64] packed prices (kPriced only)
-    const int pr_bytes = kPriced ? c_bytes + kRackTab * 4 : 0;
+    const int pr_bytes = kPriced ? 2 * c_bytes + kRackTab * 4 : 0;
     int *PG = reinterpret_cast<int *>(smem + a_bytes + kRackTab * 4 + bx64 + c_bytes);  // [kRackTab] rack prices (kPriced only)
+    uint32_t *BW = reinterpret_cast<uint32_t *>(smem + a_bytes + kRackTab * 4 + bx64 + c_bytes + kRackTab * 4);  // [bx64] broker weights (kPriced only)
     unsigned char *wb = smem + a_bytes + kRackTab * 4 + bx64 + pr_bytes + wave * (a_bytes + c_bytes + kRackTab * 8);  // blockDim.x / 64 waves
     const Part<NW> *cur_words = reinterpret_cast<const Part<NW> *>(pl.cur_pool + TD->cur_off);  // host-prepared words x | rack << 16 (0xFFFFFFFF = none); cur_off counts words
     const Part<NW> *CUR;
@@ -323,6 +327,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 pr = ((uint32_t)price_units(pp[b], prm.obj_scale) & 0xFFFFu) | ((uint32_t)price_units(pp[TD->B + b], prm.obj_scale) << 16);
             }
             PR[x] = pr;
+            BW[x] = (valid && TD->has_bw) ? pl.bw_pool[TD->bw_off + x] : 0u;
         }
     }
     __syncthreads();
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                             const uint32_t prx = PR[x];
                             int dP = p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx)) + p_in(L.K[r & 255u], T.rack_lo, T.rack_hi, PG[r & 255u]);
                             if (k == 0) dP += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
-                            keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), dP, tie) : kKeyNull;
+                            keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf) + bw_of(BW[x], k == 0), dP, tie) : kKeyNull;
                         }
                         else keyx = okx ? make_key_tie(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), tie) : kKeyNull;
                         if (keyx < key) { key = keyx; xw_l = xw; }
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     }
 
     int V, obj;
-    full_cost(T, L, CUR, RSZ, lane, V, obj);
+    full_cost(T, L, CUR, RSZ, lane, V, obj, kPriced ? BW : nullptr);
     if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
 
     // ---- per-lane RNG stream of this launch (LCG mod 2^24, re-keyed every launch) ----
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t ro = uw >> 16;
                 const bool lead = k == 0;
                 const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
-                const int g_old = role_w2(c, uw, wl, wf);
+                const int g_old = role_w2(c, uw, wl, wf) + (kPriced ? bw_of(BW[uw & 0xFFFFu], lead) : 0);
                 const uint32_t co = L.C[uw & 0xFFFFu];
                 int dV_old = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
                 if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         if (r != ro)
                             dVg += dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
                     }
-                    const int dObjg = role_w2(c, xw, wl, wf) - g_old;
+                    const int dObjg = role_w2(c, xw, wl, wf) + (kPriced ? bw_of(BW[x], lead) : 0) - g_old;
                     uint32_t keyg;
                     if (kPriced) {
                         const uint32_t prx = PR[x];
@@ -545,7 +550,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 for (int kk = 1; kk < NW; ++kk) {
                     if (kk >= T.RF) break;
                     const uint32_t xw = a.w[kk];
-                    const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11);
+                    const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11) +
+                                      (kPriced ? (int)(BW[xw & 0xFFFFu] >> 16) - (int)(BW[uw & 0xFFFFu] >> 16) : 0);
                     const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
                     uint32_t keyg;
                     if (kPriced) keyg = make_key_p(lam, S, dVg, dObjg, dP_u + p_in((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi, price_lead(PR[xw & 0xFFFFu])), lane);
@@ -572,6 +578,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t rol = oldw_o >> 16;
                 const bool leadl = k_o == 0;
                 g_o = role_w2(cl, oldw_o, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
+                if (kPriced && type == 0) g_o += bw_of(BW[oldw_o & 0xFFFFu], leadl);   // a REPLACE also gives up the broker's own weight
                 const uint32_t co = L.C[oldw_o & 0xFFFFu];
                 const int dv7 = ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
                 int sc;
@@ -650,6 +657,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     if (lead) dVx += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                     int dObjx = -g_old;
                     if (has_missing) dObjx += role_w2(c, xw, wl, wf);
+                    if (kPriced) dObjx += bw_of(BW[x], lead);
                     uint32_t keyx;
                     if (kPriced) {
                         const uint32_t prx = PR[x];
@@ -666,6 +674,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const int cnt_a_ru = cnt4(a, ro);
                 const int cu = (int)(L.C[uw & 0xFFFFu] >> 16);
                 const int pl_u = kPriced ? price_lead(PR[uw & 0xFFFFu]) : 0;
+                const int bwl_u = kPriced ? (int)(BW[uw & 0xFFFFu] >> 16) : 0;
                 // every lane draws; lane 0's value places the window when the topic has more than 512 partitions
                 const int q_draw = (int)rnd24_wide(rng, (uint32_t)T.P);
                 const int q0 = x_windowed ? __builtin_amdgcn_readfirstlane(q_draw) : 0;
@@ -689,13 +698,15 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         const uint32_t v = b.w[jj];
                         const bool ok = okq & (v != uw) & !in4(a, v) & !u_in_b;
                         const int nrq = jj != 0;
-                        const int dObjx = role_w(T, c, v, nrp) + (jj == 0 ? u_in_q_lead : u_in_q_fol) - g_old - role_w(T, cb, v, nrq);
+                        int dObjx = role_w(T, c, v, nrp) + (jj == 0 ? u_in_q_lead : u_in_q_fol) - g_old - role_w(T, cb, v, nrq);
                         int dVx = 0, dPx = 0;
                         if (lead != (jj == 0)) {  // wave-uniform: exactly one of the two slots is a leader slot
                             const int cv = (int)(L.C[v & 0xFFFFu] >> 16);
                             dVx += lead ? (ddec(cu, T.lead_lo, T.lead_hi) + dinc(cv, T.lead_lo, T.lead_hi))
                                         : (ddec(cv, T.lead_lo, T.lead_hi) + dinc(cu, T.lead_lo, T.lead_hi));
                             if (kPriced) {  // the leader moves u -> v or v -> u
+                                const int dbl = (int)(BW[v & 0xFFFFu] >> 16) - bwl_u;
+                                dObjx += lead ? dbl : -dbl;
                                 const int plv = price_lead(PR[v & 0xFFFFu]);
                                 dPx = lead ? (p_out(cu, T.lead_lo, T.lead_hi, pl_u) + p_in(cv, T.lead_lo, T.lead_hi, plv))
                                            : (p_out(cv, T.lead_lo, T.lead_hi, plv) + p_in(cu, T.lead_lo, T.lead_hi, pl_u));
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     // ---- end of launch: verify the incremental bookkeeping against a from-scratch recount ----
     recount(T, L, lane);
     int V2, obj2;
-    full_cost(T, L, CUR, RSZ, lane, V2, obj2);
+    full_cost(T, L, CUR, RSZ, lane, V2, obj2, kPriced ? BW : nullptr);
     if ((V2 != V || obj2 != obj) && lane == 0) atomicAdd(pl.drift, 1);
     if (!kGlobalA)
         for (int p = lane; p < T.P; p += 64) store_packed<NW>(state_packed, p, L.A[p]);
@@ -797,6 +808,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     // ---- stage the broker->rack table and the current assignment (padded to NE slots with 0xFFFF) ----
     for (int b = threadIdx.x; b < B; b += 256) RACK[b] = pl.rackof_pool[TD->rackof_off + b];
     const uint16_t *curd = pl.curd_pool + TD->curd_off;
+    const uint32_t *bwd = TD->has_bw ? pl.bwd_pool + TD->bwd_off : nullptr;   // broker weights, dense index (global memory / L2)
     if (pl.cur_in_lds)
         for (int i = threadIdx.x; i < P * NE; i += 256) {
             const int p = i / NE, k = i - p * NE;
@@ -856,6 +868,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
 #pragma unroll
                 for (int j = 0; j < k; ++j) dup |= bk[j] == b;
                 obj += (ck[0] == b) ? (k == 0 ? w00 : w01) : (fol ? (k == 0 ? w10 : w11) : 0);
+                if (bwd) { const uint32_t bw = bwd[b]; obj += (int)(bw & 0xFFFFu) + (k == 0 ? (int)(bw >> 16) : 0); }
                 s57 += (uint32_t)dup;  // C5: f+l <= 1 (an earlier slot holds the same broker)
             }
             s12 += (uint32_t)missing + ((uint32_t)(bk[0] >= (uint32_t)B) << 16);  // C1: sum_b (f+l) = RF ; C2: exactly one leader
@@ -1478,7 +1491,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
 // ------------------------------------------------------------------------------------------------
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw) {
     const size_t a = global_a ? 0 : (size_t)maxP * 4 * (size_t)nw, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
-    return a + kRackTab * 4 + bx64 + (priced ? bx64 * 4 + kRackTab * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
+    return a + kRackTab * 4 + bx64 + (priced ? 2 * bx64 * 4 + kRackTab * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
 }
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 2 * (size_t)ne + 15) & ~(size_t)15 : 0;

@@ -30,6 +30,8 @@ class Topic:
     weights: tuple = DEFAULT_WEIGHTS
     partition_ids: Optional[np.ndarray] = None
     bounds_override: Dict[str, int] = field(default_factory=dict)
+    broker_w: Optional[np.ndarray] = None    # [B] extra objective weight per replica on the broker (kao_topic.broker_w)
+    broker_wl: Optional[np.ndarray] = None   # [B] ... per leader on the broker
 
     def __post_init__(self):
         self.broker_ids = np.ascontiguousarray(self.broker_ids, dtype=np.int32)

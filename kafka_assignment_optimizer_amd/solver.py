@@ -62,6 +62,14 @@ class _CTopics:
             for k in BOUND_KEYS:
                 v = t.bounds_override.get(k, -1) if t.bounds_override else -1
                 setattr(s, k, -1 if v is None else int(v))
+            for name in ("broker_w", "broker_wl"):
+                v = getattr(t, name, None)
+                if v is not None:
+                    arr = np.ascontiguousarray(v, dtype=np.int32)
+                    if arr.shape != (t.n_brokers,):
+                        raise ValueError(f"{name}: one weight per broker expected")
+                    self.keep.append(arr)
+                    setattr(s, name, arr.ctypes.data_as(C.POINTER(C.c_int32)))
 
     def ptr(self, i: int = 0):
         return C.byref(self.arr[i]) if i else self.arr
@@ -375,6 +383,24 @@ def solve_multi(topics: Sequence[Topic], devices: Sequence[int], target_objectiv
     res, bufs = _results_buffers(topics)
     _check(_ffi.load().kao_solve_multi(ct.arr, len(topics), dev, len(devices), C.byref(o), res), "kao_solve_multi")
     return _unpack(topics, res, bufs)
+
+
+def solve_capped(topics: Sequence[Topic], replica_cap: Sequence[int], devices: Optional[Sequence[int]] = None, max_rounds: int = 0, **opts):
+    """Cluster-wide per-broker load caps (kao_solve_capped): sum over all topics of the replicas on broker b <= replica_cap[b]
+    (-1 = none).  Returns (results, lagrangian_bound or None)."""
+    topics = list(topics)
+    ct = _CTopics(topics)
+    o = _make_opts(**opts)
+    cap = np.ascontiguousarray(replica_cap, dtype=np.int32)
+    if cap.shape != (topics[0].n_brokers,):
+        raise ValueError("one cap per broker expected")
+    dev = (C.c_int32 * len(devices))(*[int(d) for d in devices]) if devices else None
+    res, bufs = _results_buffers(topics)
+    lb = C.c_int64()
+    _check(_ffi.load().kao_solve_capped(ct.arr, len(topics), cap.ctypes.data_as(C.POINTER(C.c_int32)), dev, len(devices) if devices else 0,
+                                        C.byref(o), int(max_rounds), res, C.byref(lb)), "kao_solve_capped")
+    out = _unpack(topics, res, bufs)
+    return out, (None if lb.value == (1 << 63) - 1 else int(lb.value))
 
 
 def rccl_selftest(devices: Sequence[int]) -> None:

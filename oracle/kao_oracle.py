@@ -64,6 +64,10 @@ class Topic:
     partition_ids: Optional[np.ndarray] = None  # external partition numbers (default 0..P-1)
     # band overrides; -1 = derive floor/ceil of the average (README.md:159-160 etc.)
     bounds_override: Dict[str, int] = field(default_factory=dict)
+    # optional broker weights: extra objective coefficients on every variable of a broker (kao_topic.broker_w / broker_wl):
+    # broker_w[b] on t?b<b>p? and t?b<b>p?_l, broker_wl[b] on t?b<b>p?_l -- plain coefficients of the `max:` row (README.md:145-146)
+    broker_w: Optional[np.ndarray] = None
+    broker_wl: Optional[np.ndarray] = None
 
     @property
     def n_brokers(self) -> int:
@@ -102,6 +106,10 @@ class Topic:
                 cr = 0 if k == 0 else 1
                 W[p, b, 0] = w[cr][0]
                 W[p, b, 1] = w[cr][1]
+        if self.broker_w is not None:
+            W += np.asarray(self.broker_w, dtype=np.int64)[None, :, None]
+        if self.broker_wl is not None:
+            W[:, :, 0] += np.asarray(self.broker_wl, dtype=np.int64)[None, :]
         return W
 
 
@@ -315,6 +323,43 @@ def solve_exact(topic: Topic, time_limit: float = 120.0, extra_cuts=None) -> Exa
     if res.status == 1:
         return ExactResult("time_limit", None, None, dt)
     return ExactResult("error", None, None, dt)
+
+
+def solve_exact_capped(topics: Sequence[Topic], replica_cap: Sequence[int], time_limit: float = 300.0):
+    """Exact optimum of SEVERAL topics under cluster-wide per-broker load caps (BASELINE config 5): the README model of
+    every topic (README.md:144-185; block diagonal, every variable and row carries its topic prefix) plus one coupling row
+    per capped broker b over all topics:  sum_t sum_p (t<t>b<b>p<p> + t<t>b<b>p<p>_l) <= replica_cap[b]   (-1 = no cap).
+    Returns (status, total objective, [assign per topic])."""
+    from scipy import sparse
+    from scipy.optimize import Bounds, LinearConstraint, milp
+
+    B = topics[0].n_brokers
+    blocks, los, his, cs, offs = [], [], [], [], [0]
+    for t in topics:
+        assert t.n_brokers == B
+        A, lo, hi = _sparse_model(t)
+        blocks.append(A); los.append(lo); his.append(hi); cs.append(objective_vector(t).astype(float))
+        offs.append(offs[-1] + A.shape[1])
+    A = sparse.block_diag(blocks, format="csr")
+    rows, cols = [], []
+    capped = [b for b in range(B) if replica_cap[b] >= 0]
+    for ri, b in enumerate(capped):
+        for ti, t in enumerate(topics):
+            for p in range(t.n_partitions):
+                for leader in (False, True):
+                    rows.append(ri); cols.append(offs[ti] + var_index(t, b, p, leader))
+    cons = [LinearConstraint(A, np.concatenate(los), np.concatenate(his))]
+    if capped:
+        C = sparse.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(len(capped), offs[-1]))
+        cons.append(LinearConstraint(C, -np.inf, np.array([replica_cap[b] for b in capped], dtype=float)))
+    c = np.concatenate(cs)
+    res = milp(-c, constraints=cons, integrality=np.ones(len(c)), bounds=Bounds(0, 1), options={"time_limit": time_limit, "mip_rel_gap": 0.0})
+    if res.status == 2:
+        return "infeasible", None, None
+    if res.status != 0 or res.x is None:
+        return "time_limit", None, None
+    assigns = [decode_solution(t, res.x[offs[i]:offs[i + 1]]) for i, t in enumerate(topics)]
+    return "optimal", int(round(-res.fun)), assigns
 
 
 def lp_bound(topic: Topic) -> Optional[float]:
@@ -874,7 +919,9 @@ def topic_to_dict(t: Topic) -> dict:
             "rack_of": [int(x) for x in t.rack_of], "n_racks": t.n_racks,
             "n_partitions": t.n_partitions, "rf": t.rf,
             "current": [[int(x) for x in row] for row in t.current],
-            "weights": [list(w) for w in t.weights], "bounds_override": dict(t.bounds_override)}
+            "weights": [list(w) for w in t.weights], "bounds_override": dict(t.bounds_override),
+            **({"broker_w": [int(x) for x in t.broker_w]} if t.broker_w is not None else {}),
+            **({"broker_wl": [int(x) for x in t.broker_wl]} if t.broker_wl is not None else {})}
 
 
 def topic_from_dict(d: dict) -> Topic:
@@ -883,7 +930,9 @@ def topic_from_dict(d: dict) -> Topic:
                  n_partitions=int(d["n_partitions"]), rf=int(d["rf"]),
                  current=np.array(d["current"], dtype=np.uint16).reshape(int(d["n_partitions"]), -1),
                  weights=tuple(tuple(w) for w in d["weights"]),
-                 bounds_override=dict(d.get("bounds_override", {})))
+                 bounds_override=dict(d.get("bounds_override", {})),
+                 broker_w=np.array(d["broker_w"], dtype=np.int32) if "broker_w" in d else None,
+                 broker_wl=np.array(d["broker_wl"], dtype=np.int32) if "broker_wl" in d else None)
 
 
 if __name__ == "__main__":

@@ -33,6 +33,8 @@ typedef struct {
     const uint16_t *current;  /* [P*rf_cur] dense index or NONE16 */
     int32_t w[2][2];          /* w[cur_role][new_role] */
     int32_t rep_lo, rep_hi, lead_lo, lead_hi, rack_lo, rack_hi, prack_lo, prack_hi;
+    const int32_t *broker_w;  /* [B] or NULL: extra objective weight of every replica on the broker (kao_topic.broker_w) */
+    const int32_t *broker_wl; /* [B] or NULL: ... of every leader on the broker */
 } port_topic;
 
 typedef struct {
@@ -78,6 +80,8 @@ int kao_port_eval(const port_topic *t, const uint16_t *assign, int64_t *objectiv
             int nr = k == 0 ? 0 : 1;
             for (int j = 0; j < t->rf_cur; ++j)
                 if (cur[j] == b) { obj += t->w[j == 0 ? 0 : 1][nr]; break; }
+            if (t->broker_w) obj += t->broker_w[b];
+            if (t->broker_wl && k == 0) obj += t->broker_wl[b];
         }
         for (int r = 0; r < R; ++r) viol[7] += band(pr[r], t->prack_lo, t->prack_hi);
     }
@@ -103,6 +107,7 @@ typedef struct {
     uint16_t *cur;       /* [P*RFP] internal */
     int w[2][2];
     int rep_lo, rep_hi, lead_lo, lead_hi, rack_lo, rack_hi, prack_lo, prack_hi;
+    int *bw, *bwl;       /* [Bx] broker weights per internal index (zeros when the topic has none) */
 } ls_topic;
 
 typedef struct {
@@ -145,6 +150,8 @@ static inline int role_w(const ls_topic *t, int p, unsigned x, int nr) {
     for (int j = 1; j < RFP; ++j) if (c[j] == x) return t->w[1][nr];
     return 0;
 }
+/* role weight plus the broker's own weights: what a replica of p on x in role nr adds to the objective */
+static inline int slot_w(const ls_topic *t, int p, unsigned x, int nr) { return role_w(t, p, x, nr) + t->bw[x] + (nr == 0 ? t->bwl[x] : 0); }
 static inline int in_part(const uint16_t *a, unsigned x) {
     for (int j = 0; j < RFP; ++j) if (a[j] == x) return 1;
     return 0;
@@ -182,6 +189,11 @@ void *kao_port_ls_create(const port_topic *pt) {
             unsigned b = pt->current[p * pt->rf_cur + k];
             if (b < (unsigned)B) t->cur[p * RFP + k] = t->int_of[b];
         }
+    t->bw = (int *)calloc((size_t)t->Bx, sizeof(int)); t->bwl = (int *)calloc((size_t)t->Bx, sizeof(int));
+    for (int b = 0; b < B; ++b) {
+        if (pt->broker_w) t->bw[t->int_of[b]] = pt->broker_w[b];
+        if (pt->broker_wl) t->bwl[t->int_of[b]] = pt->broker_wl[b];
+    }
     memcpy(t->w, pt->w, sizeof(t->w));
     t->rep_lo = pt->rep_lo; t->rep_hi = pt->rep_hi; t->lead_lo = pt->lead_lo; t->lead_hi = pt->lead_hi;
     t->rack_lo = pt->rack_lo; t->rack_hi = pt->rack_hi; t->prack_lo = pt->prack_lo; t->prack_hi = pt->prack_hi;
@@ -191,7 +203,7 @@ void *kao_port_ls_create(const port_topic *pt) {
 void kao_port_ls_destroy(void *h) {
     ls_topic *t = (ls_topic *)h;
     if (!t) return;
-    free(t->int_of); free(t->ext_of); free(t->cur); free(t);
+    free(t->int_of); free(t->ext_of); free(t->cur); free(t->bw); free(t->bwl); free(t);
 }
 
 /* rebuild counters, V and obj from A (the device does this wave-parallel at every launch) */
@@ -205,7 +217,7 @@ static void ls_recount(const ls_topic *t, ls_state *s) {
             unsigned x = a[k];
             s->C[x] += (k == 0) ? 0x10001u : 1u;
             s->K[rack_of_x(t, x)] += 1;
-            obj += role_w(t, p, x, k == 0 ? 0 : 1);
+            obj += slot_w(t, p, x, k == 0 ? 0 : 1);
         }
         for (int r = 0; r < t->R; ++r) V += band(rack_count(t, a, r), t->prack_lo, t->prack_hi);
     }
@@ -276,7 +288,7 @@ static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint3
                            + d_band(rack_count(t, a, rn), +1, t->prack_lo, t->prack_hi);
                     if (k == 0) dV += d_band((int)(s->C[x] >> 16), +1, t->lead_lo, t->lead_hi);
                     const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
-                    const uint32_t key = make_key_tie(pp->lam_max, pp->obj_scale, dV, role_w(t, p, x, k == 0 ? 0 : 1), tie,
+                    const uint32_t key = make_key_tie(pp->lam_max, pp->obj_scale, dV, slot_w(t, p, x, k == 0 ? 0 : 1), tie,
                                                           p_in((int)(s->C[x] & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, x)) + p_in(s->K[rn], t->rack_lo, t->rack_hi, PGx(s, rn)) +
                                                           (k == 0 ? p_in((int)(s->C[x] >> 16), t->lead_lo, t->lead_hi, PLx(s, x)) : 0));
                     if (key < lane_key[l]) { lane_key[l] = key; lane_x[l] = (int)x; }
@@ -330,7 +342,7 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
         const unsigned old = a[k];
         const int nr = k == 0 ? 0 : 1;
         const int ro = rack_of_x(t, old);
-        const int g_old = role_w(t, p, old, nr);
+        const int g_old = slot_w(t, p, old, nr);
         const uint32_t co = s->C[old];
         int dV_old = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
         if (k == 0) dV_old += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
@@ -351,7 +363,7 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
             if (k == 0) dV += d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
             if (r != ro)
                 dV += dV_rack_old + d_band(s->K[r], +1, t->rack_lo, t->rack_hi) + d_band(rack_count(t, a, r), +1, t->prack_lo, t->prack_hi);
-            const int dObj = role_w(t, p, x, nr) - g_old;
+            const int dObj = slot_w(t, p, x, nr) - g_old;
             int dP = dP_old + p_in((int)(cn & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, x));
             if (k == 0) dP += p_in((int)(cn >> 16), t->lead_lo, t->lead_hi, PLx(s, x));
             if (r != ro) dP += dP_rack_old + p_in(s->K[r], t->rack_lo, t->rack_hi, PGx(s, r));
@@ -366,7 +378,7 @@ static uint32_t ls_lane(const ls_topic *t, const ls_state *s, int type, uint32_t
         const unsigned v = a[k];
         *n_eval += 1;
         ((ls_state *)s)->n_valid += 1;
-        const int dObj = role_w(t, p, v, 0) + role_w(t, p, u, 1) - role_w(t, p, u, 0) - role_w(t, p, v, 1);
+        const int dObj = role_w(t, p, v, 0) + role_w(t, p, u, 1) - role_w(t, p, u, 0) - role_w(t, p, v, 1) + t->bwl[v] - t->bwl[u];
         const int dV = d_band((int)(s->C[u] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[v] >> 16), +1, t->lead_lo, t->lead_hi);
         const uint32_t key = make_key(lam, S, dV, dObj, lane, p_out((int)(s->C[u] >> 16), t->lead_lo, t->lead_hi, PLx(s, u)) +
                                                                  p_in((int)(s->C[v] >> 16), t->lead_lo, t->lead_hi, PLx(s, v)));
@@ -461,7 +473,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                 /* an exchange can also change who leads: a leader slot may shed a leader, a follower slot may gain one */
                 const int dvl = d_band((int)(co >> 16), kl == 0 ? -1 : +1, t->lead_lo, t->lead_hi);
                 const int sc = (type == 0) ? dvo + (dvr < 0 ? dvr : 0) : (dv7 < 0 ? dv7 : 0) + (dvl < 0 ? dvl : 0);
-                const uint32_t key = make_key(lam, S, sc, -role_w(t, pl, old, kl == 0 ? 0 : 1), l, type == 0 ? p_out((int)(co & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, old)) + (kl == 0 ? p_out((int)(co >> 16), t->lead_lo, t->lead_hi, PLx(s, old)) : 0) : 0);
+                const uint32_t key = make_key(lam, S, sc, -(type == 0 ? slot_w(t, pl, old, kl == 0 ? 0 : 1) : role_w(t, pl, old, kl == 0 ? 0 : 1)), l, type == 0 ? p_out((int)(co & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, old)) + (kl == 0 ? p_out((int)(co >> 16), t->lead_lo, t->lead_hi, PLx(s, old)) : 0) : 0);
                 if (key < keyA) { keyA = key; p = pl; k = kl; }
               }
             const uint16_t *a = s->A + p * RFP;
@@ -469,7 +481,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
             const int nr = k == 0 ? 0 : 1;
             if (type == 0) { /* ---- phase B: scan every target broker for slot (p,k) ---- */
                 const int ro = rack_of_x(t, old);
-                const int g_old = role_w(t, p, old, nr);
+                const int g_old = slot_w(t, p, old, nr);
                 const uint32_t co = s->C[old];
                 int dV_old = d_band((int)(co & 0xFFFF), -1, t->rep_lo, t->rep_hi);
                 if (k == 0) dV_old += d_band((int)(co >> 16), -1, t->lead_lo, t->lead_hi);
@@ -494,7 +506,7 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                         const uint32_t cn = s->C[x];
                         int dV = dV_old + d_band((int)(cn & 0xFFFF), +1, t->rep_lo, t->rep_hi) + RT[rack_of_x(t, x)];
                         if (k == 0) dV += d_band((int)(cn >> 16), +1, t->lead_lo, t->lead_hi);
-                        const int dObj = role_w(t, p, x, nr) - g_old;
+                        const int dObj = slot_w(t, p, x, nr) - g_old;
                         int dP = dP_old + p_in((int)(cn & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, x)) + RTP[rack_of_x(t, x)];
                         if (k == 0) dP += p_in((int)(cn >> 16), t->lead_lo, t->lead_hi, PLx(s, x));
                         const uint32_t key = make_key_tie(lam, S, dV, dObj, tie, dP);
@@ -527,10 +539,11 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                             if (q == p || u == v || in_part(a, v) || in_part(b, u)) continue;
                             s->n_valid += 1;
                             const int nrq = j == 0 ? 0 : 1;
-                            const int dObj = role_w(t, p, v, nr) + role_w(t, q, u, nrq) - gu_p - role_w(t, q, v, nrq);
+                            int dObj = role_w(t, p, v, nr) + role_w(t, q, u, nrq) - gu_p - role_w(t, q, v, nrq);
                             int dV = 0, dP = 0;
                             if ((k == 0) != (j == 0)) {
                                 const unsigned lose = (k == 0) ? u : v, gain = (k == 0) ? v : u;
+                                dObj += t->bwl[gain] - t->bwl[lose];   /* the leader (and its broker weight) moves */
                                 dV += d_band((int)(s->C[lose] >> 16), -1, t->lead_lo, t->lead_hi) + d_band((int)(s->C[gain] >> 16), +1, t->lead_lo, t->lead_hi);
                                 dP = p_out((int)(s->C[lose] >> 16), t->lead_lo, t->lead_hi, PLx(s, lose)) + p_in((int)(s->C[gain] >> 16), t->lead_lo, t->lead_hi, PLx(s, gain));
                             }

@@ -19,7 +19,8 @@ class PortTopic(C.Structure):
                 ("rack_of", C.POINTER(C.c_uint8)), ("current", C.POINTER(C.c_uint16)),
                 ("w", (C.c_int32 * 2) * 2),
                 ("rep_lo", C.c_int32), ("rep_hi", C.c_int32), ("lead_lo", C.c_int32), ("lead_hi", C.c_int32),
-                ("rack_lo", C.c_int32), ("rack_hi", C.c_int32), ("prack_lo", C.c_int32), ("prack_hi", C.c_int32)]
+                ("rack_lo", C.c_int32), ("rack_hi", C.c_int32), ("prack_lo", C.c_int32), ("prack_hi", C.c_int32),
+                ("broker_w", C.POINTER(C.c_int32)), ("broker_wl", C.POINTER(C.c_int32))]
 
 
 class PortParams(C.Structure):
@@ -91,6 +92,12 @@ class CTopic:
                 s.w[i][j] = int(topic.weights[i][j])
         for k in ("rep_lo", "rep_hi", "lead_lo", "lead_hi", "rack_lo", "rack_hi", "prack_lo", "prack_hi"):
             setattr(s, k, bd[k])
+        self.bw = None if getattr(topic, "broker_w", None) is None else np.ascontiguousarray(topic.broker_w, dtype=np.int32)
+        self.bwl = None if getattr(topic, "broker_wl", None) is None else np.ascontiguousarray(topic.broker_wl, dtype=np.int32)
+        if self.bw is not None:
+            s.broker_w = self.bw.ctypes.data_as(C.POINTER(C.c_int32))
+        if self.bwl is not None:
+            s.broker_wl = self.bwl.ctypes.data_as(C.POINTER(C.c_int32))
         self.s = s
         self.topic = topic
 

@@ -33,7 +33,9 @@ def to_product_topic(ot):
     from kafka_assignment_optimizer_amd import Topic
     return Topic(name=ot.name, broker_ids=np.array(ot.broker_ids), rack_of=np.array(ot.rack_of), n_racks=ot.n_racks,
                  n_partitions=ot.n_partitions, rf=ot.rf, current=np.array(ot.current), weights=ot.weights,
-                 partition_ids=ot.partition_ids, bounds_override=dict(ot.bounds_override))
+                 partition_ids=ot.partition_ids, bounds_override=dict(ot.bounds_override),
+                 broker_w=None if getattr(ot, "broker_w", None) is None else np.array(ot.broker_w),
+                 broker_wl=None if getattr(ot, "broker_wl", None) is None else np.array(ot.broker_wl))
 
 
 def random_candidates(ot, n, seed, p_mut=0.15, p_none=0.02):

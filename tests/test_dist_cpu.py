@@ -55,7 +55,8 @@ def _worker(rank, world, port, q):
         got = mg.gather_assignments(best, owned, assigns, rank, world)
         # certificates: every rank's upper bound is valid, the smallest wins (rank 0 holds the tighter one for topic 4)
         bounds = mg.allreduce_bounds([120 + t if t != 4 else 510 - 5 * (1 - rank) for t in owned], owned, n_topics)
-        q.put((rank, best.tolist(), [None if g is None else g.tolist() for g in got], bounds.tolist()))
+        loads = mg.allreduce_loads(np.array([rank + 1, 10 * rank, 5]))   # broker loads of this rank's topics -> cluster-wide loads
+        q.put((rank, best.tolist(), [None if g is None else g.tolist() for g in got], bounds.tolist(), loads.tolist()))
     finally:
         dist.destroy_process_group()
 
@@ -75,8 +76,9 @@ def test_allreduce_best_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, best0, got0, bounds0), (_, best1, got1, bounds1) = res
+    (_, best0, got0, bounds0, loads0), (_, best1, got1, bounds1, loads1) = res
     assert bounds0 == bounds1 == [120, 121, 122, 123, 505]
+    assert loads0 == loads1 == [3, 10, 10]  # allreduce(SUM) of the per-rank broker loads (cluster-wide caps)
     assert best0 == best1  # every rank holds the same global result
     dec = [mg.unpack_allreduced(v) for v in best0]
     shards = mg.shard_topics([3, 9, 4, 9, 1], 2)

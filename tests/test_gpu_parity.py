@@ -903,3 +903,75 @@ def test_high_rf_golden_optima(kao, ko):
             assert kao.canonicalize(to_product_topic(ot), r.assignment).tolist() == ko.canonicalize(ot, np.array(c["assignment"])).tolist(), c["seed"]
             n_unique += 1
     assert n_opt >= 50 and n_proven >= n_opt // 3
+
+
+# ------------------------------------------------------------------------------- broker weights and cluster-wide caps
+def test_broker_weights_eval_and_replay_bit_exact(kao, ko, kp):
+    """Broker weights (kao_topic.broker_w / broker_wl: plain extra coefficients of the `max:` row on every variable of a
+    broker): K-eval == the verifier, K-search (priced instantiation, which carries the weight table) == the scalar replay."""
+    ots = _drifted(ko, 4, 3) + [ko.random_case_rf(c["seed"]) for c in load_golden("random_rf.json")["cases"] if c["status"] == "optimal"][:2]
+    rng = np.random.default_rng(12)
+    for t in ots:
+        t.broker_w = rng.integers(0, 6, t.n_brokers).astype(np.int32)
+        t.broker_wl = rng.integers(0, 4, t.n_brokers).astype(np.int32)
+    pts = [to_product_topic(t) for t in ots]
+    for ot, pt in zip(ots, pts):
+        cands = random_candidates(ot, 8, seed=3, p_mut=0.3, p_none=0.05)
+        o, v = kao.evaluate_batch(pt, cands)
+        for i in range(len(cands)):
+            oo, vv = ko.verify(ot, cands[i])
+            assert (int(o[i]), v[i].tolist()) == (oo, vv.tolist())
+    seed = 515
+    with kao.Session(pts, seed=seed, restarts=8, iters_per_launch=140) as s:
+        s.step(2)
+        assert s.stats()["drift"] == 0
+        for ti, ot in enumerate(ots):
+            for rho in (0, 7):
+                dev = s.restart_state(ti, rho)
+                ref = kp.port_search(ot, _tseed(seed, ti), rho, 2, 140)
+                assert dev["final"].tolist() == ref["final"].tolist(), (ti, rho)
+                assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
+                obj, viol = ko.verify(ot, dev["final"])
+                assert (obj, int(viol[0])) == (dev["obj"], dev["V"])
+    # and the optimum of the weighted model (HiGHS) is what kao_solve returns; the certificate stays valid
+    small = [ko.random_case(s, max_b=14, max_p=10) for s in range(40, 52)]
+    for t in small:
+        t.broker_w = rng.integers(0, 4, t.n_brokers).astype(np.int32)
+        t.broker_wl = rng.integers(0, 3, t.n_brokers).astype(np.int32)
+    res = kao.solve([to_product_topic(t) for t in small], seed=2, time_limit_s=10, max_launches=16)
+    n = 0
+    for t, r in zip(small, res):
+        ex = ko.solve_exact(t, 60)
+        if ex.status != "optimal":
+            continue
+        assert r.objective == ex.objective <= r.upper_bound, (t.name, r.objective, ex.objective, r.upper_bound)
+        n += 1
+    assert n >= 5
+
+
+def test_solve_capped_matches_the_exact_joint_optimum_on_toys(kao, ko):
+    """Cluster-wide per-broker caps (kao_solve_capped) against HiGHS on the JOINT model (every topic's README rows + one
+    coupling row per capped broker over all topics; tests/golden/capped_toy.json): the plan respects every cap and every
+    topic's own rows, its objective is sandwiched incumbent <= exact optimum <= Lagrangian bound, and it is within 2 % of the
+    exact optimum (equal on most toys)."""
+    cases = load_golden("capped_toy.json")["cases"]
+    equal = 0
+    for c in cases:
+        ots = [ko.topic_from_dict(d) for d in c["topics"]]
+        cap = np.array(c["replica_cap"])
+        res, lb = kao.solve_capped([to_product_topic(t) for t in ots], cap, seed=c["seed"], time_limit_s=20, max_rounds=60)
+        load = np.zeros(len(cap), dtype=int)
+        total = 0
+        for ot, r in zip(ots, res):
+            assert r.status in ("FEASIBLE_BOUND_GAP", "OPTIMAL_PROVEN"), (c["seed"], r.status)
+            obj, viol = ko.verify(ot, r.assignment)
+            assert viol[0] == 0 and obj == r.objective
+            total += obj
+            np.add.at(load, r.assignment.reshape(-1).astype(int), 1)
+        assert (load <= cap).all(), (c["seed"], load.tolist(), cap.tolist())
+        assert total <= c["objective"] < c["objective_without_caps"]
+        if lb is not None:
+            assert lb >= c["objective"], (c["seed"], lb, c["objective"])
+        assert total >= 0.98 * c["objective"], (c["seed"], total, c["objective"])
+        equal += total == c["objective"]
+    assert equal >= len(cases) // 2, equal
