@@ -606,6 +606,7 @@ struct kao_session {
     int price_read = 0;          // half K-search reads
     int price_write_last = -1;   // half the K-bound launch in flight (or the last finished one) writes
     bool priced = false;         // K-search launches carry prices
+    bool any_bw = false;         // some topic carries broker weights (their LDS table is carved in every launch group)
     uint16_t *d_int = nullptr;   // dense -> internal broker index per topic
     uint32_t *d_bw = nullptr, *d_bwd = nullptr;   // broker weights per internal / dense index (topics with has_bw)
     long long *d_dual_target = nullptr;
@@ -1084,6 +1085,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     std::vector<uint8_t> rackof_pool;
     uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0, dual_i32 = 0;
     s->topic_global.assign((size_t)n_topics, 0);
+    for (int t = 0; t < n_topics; ++t) s->any_bw |= topics[t].broker_w || topics[t].broker_wl;
     int restart_base = 0;
     for (int t = 0; t < n_topics; ++t) {
         PreparedTopic &pt = s->pts[(size_t)t];
@@ -1101,7 +1103,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         while (cur_pool.size() % 4) cur_pool.push_back(kNoneW);   // every topic's words start 16-byte aligned
         d.cur_off = (uint32_t)cur_pool.size();
         for (size_t i = 0; i < (size_t)d.P * d.nw; ++i) cur_pool.push_back(word(pt.cur_int[i]));  // LDS / register form of a replica: internal index | rack << 16
-        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw) > 160 * 1024;
+        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw, s->any_bw) > 160 * 1024;
         s->topic_global[(size_t)t] = global_a;
         d.ext_off = (uint32_t)ext_pool.size();
         ext_pool.insert(ext_pool.end(), pt.ext_of.begin(), pt.ext_of.end());
@@ -1121,6 +1123,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
             d.bw_off = (uint32_t)bw_pool.size(); bw_pool.insert(bw_pool.end(), pt.bw_int.begin(), pt.bw_int.end());
             d.bwd_off = (uint32_t)bwd_pool.size(); bwd_pool.insert(bwd_pool.end(), pt.bw_dense.begin(), pt.bw_dense.end());
             s->priced = true;   // broker weights live in the tables of the priced K-search instantiation
+            s->any_bw = true;
         }
         d.int_off = (uint32_t)int_pool.size();
         int_pool.insert(int_pool.end(), pt.int_of.begin(), pt.int_of.end());
@@ -1140,7 +1143,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     auto need1 = [&](int t) {  // topics kept in global memory sort last (their LDS need is tiny but they form their own groups)
         const TopicDev &d = s->pts[(size_t)t].d;
         const bool ga = s->topic_global[(size_t)t] != 0;
-        return (ga ? ((size_t)1 << 40) : 0) + (d.nw > kRFP ? ((size_t)1 << 41) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true, d.nw);
+        return (ga ? ((size_t)1 << 40) : 0) + (d.nw > kRFP ? ((size_t)1 << 41) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true, d.nw, s->any_bw);
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need1(x) < need1(y); });
     std::vector<std::vector<int>> members;
@@ -1159,9 +1162,9 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         }
         g.global_a = s->topic_global[(size_t)mem[0]] != 0;
         g.nw = s->pts[(size_t)mem[0]].d.nw;
-        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw) > 160 * 1024) g.waves /= 2;
+        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw) > 160 * 1024) g.waves /= 2;
         g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true, g.nw) <= 160 * 1024;
-        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
+        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
             kao_session_destroy(s);
             return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS (about 30,000 padded brokers)");
         }
@@ -1290,6 +1293,7 @@ int kao_session_step(kao_session *s) {
     prm.obj_scale = s->opts.obj_scale; prm.lam_min = s->opts.lam_min; prm.lam_max = s->opts.lam_max;
     prm.launch = s->launch; prm.iters = (uint32_t)s->opts.iters_per_launch; prm.init = s->launch == 0 ? 1 : 0;
     const int eper = s->opts.elite_period;
+    prm.bw = s->any_bw ? 1 : 0;
     prm.elite = (eper > 0 && s->launch > 0 && s->launch % (uint32_t)eper == 0) ? 1 : 0;
     sp.price_pool = s->d_price + (size_t)s->price_read * s->price_half_i32;
     sp.int_pool = s->d_int; sp.elite_assign = s->d_win_assign; sp.elite_key = s->d_keys; sp.bw_pool = s->d_bw;
@@ -1391,7 +1395,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
     for (const kao_session::LaunchGroup &g : s->groups)
-        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw));
+        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw, s->any_bw));
     out->launch_groups = (int32_t)s->groups.size();
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));

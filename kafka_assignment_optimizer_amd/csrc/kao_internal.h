@@ -60,6 +60,7 @@ struct SearchParams {
     uint32_t iters;
     int32_t init;                // 1 = build the initial state of every restart first
     int32_t maxP, maxBx;         // LDS carve sizes
+    int32_t bw;                  // 1 = topics of this launch carry broker weights (priced instantiation: the weight table is carved)
     int32_t elite;               // 1 = restarts that trail their topic's best feasible objective may re-seed from it (KAO-LS
                                  //     "elite" rule)
 };
@@ -115,7 +116,7 @@ struct BoundPools {
     int32_t export_prices;       // 1 = the multipliers of the record dual value, 2 = the last iterate, 0 = no export
 };
 
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4);
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4, bool bw = false);
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne = 4);
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream);
 void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream);

@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
     uint8_t *XR = smem + a_bytes + kRackTab * 4;  // rack of internal index x, 0xFF = padding slot / beyond Bx
     uint32_t *PR = reinterpret_cast<uint32_t *>(smem + a_bytes + kRackTab * 4 + bx64);  // [bx64] packed prices (kPriced only)
-    const int pr_bytes = kPriced ? 2 * c_bytes + kRackTab * 4 : 0;
+    const bool hbw = kPriced && prm.bw != 0;   // the launch group carries broker weights (their table is carved only then)
+    const int pr_bytes = kPriced ? (hbw ? 2 : 1) * c_bytes + kRackTab * 4 : 0;
     int *PG = reinterpret_cast<int *>(smem + a_bytes + kRackTab * 4 + bx64 + c_bytes);  // [kRackTab] rack prices (kPriced only)
     uint32_t *BW = reinterpret_cast<uint32_t *>(smem + a_bytes + kRackTab * 4 + bx64 + c_bytes + kRackTab * 4);  // [bx64] broker weights (kPriced only)
     unsigned char *wb = smem + a_bytes + kRackTab * 4 + bx64 + pr_bytes + wave * (a_bytes + c_bytes + kRackTab * 8);  // blockDim.x / 64 waves
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 pr = ((uint32_t)price_units(pp[b], prm.obj_scale) & 0xFFFFu) | ((uint32_t)price_units(pp[TD->B + b], prm.obj_scale) << 16);
             }
             PR[x] = pr;
-            BW[x] = (valid && TD->has_bw) ? pl.bw_pool[TD->bw_off + x] : 0u;
+            if (hbw) BW[x] = (valid && TD->has_bw) ? pl.bw_pool[TD->bw_off + x] : 0u;
         }
     }
     __syncthreads();
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                             const uint32_t prx = PR[x];
                             int dP = p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx)) + p_in(L.K[r & 255u], T.rack_lo, T.rack_hi, PG[r & 255u]);
                             if (k == 0) dP += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
-                            keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf) + bw_of(BW[x], k == 0), dP, tie) : kKeyNull;
+                            keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf) + (hbw ? bw_of(BW[x], k == 0) : 0), dP, tie) : kKeyNull;
                         }
                         else keyx = okx ? make_key_tie(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), tie) : kKeyNull;
                         if (keyx < key) { key = keyx; xw_l = xw; }
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     }
 
     int V, obj;
-    full_cost(T, L, CUR, RSZ, lane, V, obj, kPriced ? BW : nullptr);
+    full_cost(T, L, CUR, RSZ, lane, V, obj, hbw ? BW : nullptr);
     if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
 
     // ---- per-lane RNG stream of this launch (LCG mod 2^24, re-keyed every launch) ----
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t ro = uw >> 16;
                 const bool lead = k == 0;
                 const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
-                const int g_old = role_w2(c, uw, wl, wf) + (kPriced ? bw_of(BW[uw & 0xFFFFu], lead) : 0);
+                const int g_old = role_w2(c, uw, wl, wf) + (hbw ? bw_of(BW[uw & 0xFFFFu], lead) : 0);
                 const uint32_t co = L.C[uw & 0xFFFFu];
                 int dV_old = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
                 if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         if (r != ro)
                             dVg += dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
                     }
-                    const int dObjg = role_w2(c, xw, wl, wf) + (kPriced ? bw_of(BW[x], lead) : 0) - g_old;
+                    const int dObjg = role_w2(c, xw, wl, wf) + (hbw ? bw_of(BW[x], lead) : 0) - g_old;
                     uint32_t keyg;
                     if (kPriced) {
                         const uint32_t prx = PR[x];
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     if (kk >= T.RF) break;
                     const uint32_t xw = a.w[kk];
                     const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11) +
-                                      (kPriced ? (int)(BW[xw & 0xFFFFu] >> 16) - (int)(BW[uw & 0xFFFFu] >> 16) : 0);
+                                      (hbw ? (int)(BW[xw & 0xFFFFu] >> 16) - (int)(BW[uw & 0xFFFFu] >> 16) : 0);
                     const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
                     uint32_t keyg;
                     if (kPriced) keyg = make_key_p(lam, S, dVg, dObjg, dP_u + p_in((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi, price_lead(PR[xw & 0xFFFFu])), lane);
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t rol = oldw_o >> 16;
                 const bool leadl = k_o == 0;
                 g_o = role_w2(cl, oldw_o, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
-                if (kPriced && type == 0) g_o += bw_of(BW[oldw_o & 0xFFFFu], leadl);   // a REPLACE also gives up the broker's own weight
+                if (hbw && type == 0) g_o += bw_of(BW[oldw_o & 0xFFFFu], leadl);   // a REPLACE also gives up the broker's own weight
                 const uint32_t co = L.C[oldw_o & 0xFFFFu];
                 const int dv7 = ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
                 int sc;
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     if (lead) dVx += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                     int dObjx = -g_old;
                     if (has_missing) dObjx += role_w2(c, xw, wl, wf);
-                    if (kPriced) dObjx += bw_of(BW[x], lead);
+                    if (hbw) dObjx += bw_of(BW[x], lead);
                     uint32_t keyx;
                     if (kPriced) {
                         const uint32_t prx = PR[x];
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const int cnt_a_ru = cnt4(a, ro);
                 const int cu = (int)(L.C[uw & 0xFFFFu] >> 16);
                 const int pl_u = kPriced ? price_lead(PR[uw & 0xFFFFu]) : 0;
-                const int bwl_u = kPriced ? (int)(BW[uw & 0xFFFFu] >> 16) : 0;
+                const int bwl_u = hbw ? (int)(BW[uw & 0xFFFFu] >> 16) : 0;
                 // every lane draws; lane 0's value places the window when the topic has more than 512 partitions
                 const int q_draw = (int)rnd24_wide(rng, (uint32_t)T.P);
                 const int q0 = x_windowed ? __builtin_amdgcn_readfirstlane(q_draw) : 0;
@@ -705,8 +706,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                             dVx += lead ? (ddec(cu, T.lead_lo, T.lead_hi) + dinc(cv, T.lead_lo, T.lead_hi))
                                         : (ddec(cv, T.lead_lo, T.lead_hi) + dinc(cu, T.lead_lo, T.lead_hi));
                             if (kPriced) {  // the leader moves u -> v or v -> u
-                                const int dbl = (int)(BW[v & 0xFFFFu] >> 16) - bwl_u;
-                                dObjx += lead ? dbl : -dbl;
+                                if (hbw) { const int dbl = (int)(BW[v & 0xFFFFu] >> 16) - bwl_u; dObjx += lead ? dbl : -dbl; }
                                 const int plv = price_lead(PR[v & 0xFFFFu]);
                                 dPx = lead ? (p_out(cu, T.lead_lo, T.lead_hi, pl_u) + p_in(cv, T.lead_lo, T.lead_hi, plv))
                                            : (p_out(cv, T.lead_lo, T.lead_hi, plv) + p_in(cu, T.lead_lo, T.lead_hi, pl_u));
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     // ---- end of launch: verify the incremental bookkeeping against a from-scratch recount ----
     recount(T, L, lane);
     int V2, obj2;
-    full_cost(T, L, CUR, RSZ, lane, V2, obj2, kPriced ? BW : nullptr);
+    full_cost(T, L, CUR, RSZ, lane, V2, obj2, hbw ? BW : nullptr);
     if ((V2 != V || obj2 != obj) && lane == 0) atomicAdd(pl.drift, 1);
     if (!kGlobalA)
         for (int p = lane; p < T.P; p += 64) store_packed<NW>(state_packed, p, L.A[p]);
@@ -1489,9 +1489,9 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw) {
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw) {
     const size_t a = global_a ? 0 : (size_t)maxP * 4 * (size_t)nw, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
-    return a + kRackTab * 4 + bx64 + (priced ? 2 * bx64 * 4 + kRackTab * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
+    return a + kRackTab * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + kRackTab * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
 }
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 2 * (size_t)ne + 15) & ~(size_t)15 : 0;
@@ -1511,7 +1511,7 @@ static void launch_search_t(const SearchPools &pools, const SearchParams &prm, i
 }
 
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream) {
-    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw);
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw, prm.bw != 0);
     // largest dynamic-LDS size each of the 8 instantiations has been enabled for, per device
     static int attr[kAttrDevices][8] = {{0}};
     int &a = attr[attr_slot()][(global_a ? 4 : 0) + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
