@@ -840,11 +840,17 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
         for (int p = lane; p < P; p += 64) {
             const uint16_t *ap = cand + (size_t)p * RF;  // a wavefront reads 64*RF consecutive u16: coalesced
             uint32_t bk[NE], rk[NE], ck[NE];
+            uint32_t cw[NE / 2];   // the partition's current replicas, two u16 per word: one ds_read_b64 / b128 when staged in LDS
+            if (pl.cur_in_lds) {
+                if (NE == 4) { const uint2 v = reinterpret_cast<const uint2 *>(CURD)[p]; cw[0] = v.x; cw[1] = v.y; }
+                else { const uint4 v = reinterpret_cast<const uint4 *>(CURD)[p]; cw[0] = v.x; cw[1] = v.y; cw[2 % (NE / 2)] = v.z; cw[3 % (NE / 2)] = v.w; }
+            }
 #pragma unroll
             for (int k = 0; k < NE; ++k) {
                 bk[k] = k < RF ? (uint32_t)ap[k < RF ? k : 0] : 0xFFFFu;
                 rk[k] = 0xFFu;
-                ck[k] = pl.cur_in_lds ? (uint32_t)CURD[p * NE + k] : (k < rf_cur ? (uint32_t)curd[(size_t)p * rf_cur + (k < rf_cur ? k : 0)] : 0xFFFFu);
+                ck[k] = pl.cur_in_lds ? ((k & 1) ? cw[k >> 1] >> 16 : cw[k >> 1] & 0xFFFFu)
+                                      : (k < rf_cur ? (uint32_t)curd[(size_t)p * rf_cur + (k < rf_cur ? k : 0)] : 0xFFFFu);
             }
             int missing = 0;
 #pragma unroll
