@@ -267,6 +267,26 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
  * (NULL / 0 = the current device). */
 int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *replica_cap, const int32_t *devices, int32_t n_dev,
                      const kao_opts *opts, int32_t max_rounds, kao_result *results, int64_t *lagrangian_bound);
+/* ---- KAO-CX: cyclic-exchange improvement of a feasible assignment --------------------------------
+ * Stands in for nothing in the reference (lp_solve returns the exact optimum, README.md:135-136): it is the intensification
+ * step that lets the device reach optima K-search's one- and two-slot moves do not -- on rigid instances (replicas per
+ * broker fixed exactly) the last improvements are cyclic exchanges over 4..10 partitions.  From a FEASIBLE `assignment`
+ * ([P*rf], overwritten by the improved one): transfer graphs on the brokers (follower moves, role swaps, band slack), cheapest
+ * paths of <= 8 edges by three min-plus squarings, improving cycles and seed rows priced by their closures, candidates
+ * unrolled into slot changes and scored exactly by K-eval; rounds until nothing improves or `max_rounds` (<= 0: no limit).
+ * kao_solve calls it for unproven topics whose search has stalled.  stats (may be NULL): [0] rounds, [1] improving rounds,
+ * [2] realisations evaluated, [3] improving ones, [4] candidates priced > 0, [5] compounds merged, [6] objective before,
+ * [7] objective after.  KAO_ERR_UNSUPPORTED: rf > 4, more than 2047 brokers, or broker weights. */
+int kao_improve_cycles(const kao_topic *t, uint16_t *assignment, int32_t max_rounds, int64_t *objective, int32_t stats[8]);
+/* Parity hooks of KAO-CX (tests): the cost matrix of `layer` (0 = follower moves, 1 = role swaps) after `level` squarings
+ * (0..3) as dist[(B+1)*(B+1)] (node B = slack; 1 << 17 = none), the midpoints mid[(B+1)*(B+1)] (level >= 1; may be NULL) and
+ * the slot p*rf+k behind every level-0 edge slot[(B+1)*(B+1)] (0xFFFFFFFF = none; may be NULL). */
+int kao_cycle_matrices(const kao_topic *t, const uint16_t *assignment, int32_t layer, int32_t level, int32_t *dist, int32_t *mid,
+                       uint32_t *slot);
+/* The seed table table[P * n_cfg * 2] = (total, completing broker) per partition and configuration (oracle/kao_cycle.py
+ * gives the numbering); *n_cfg is always set; table may be NULL to query n_cfg only. */
+int kao_cycle_seeds(const kao_topic *t, const uint16_t *assignment, int32_t *table, int32_t *n_cfg);
+
 /* Diagnostic: runs the two collectives kao_solve_multi uses (ncclAllReduce(ncclUint64, ncclMin) and ncclBroadcast) on
  * small resident buffers of the listed distinct devices and checks the results.  0 = ok. */
 int kao_rccl_selftest(const int32_t *devices, int32_t n_dev);

@@ -83,6 +83,9 @@ SIGNATURES = {
     "kao_solve_capped": (C.c_int, [_P(KaoTopic), C.c_int32, _P(C.c_int32), _P(C.c_int32), C.c_int32, _P(KaoOpts), C.c_int32,
                                   _P(KaoResult), _P(C.c_int64)]),
     "kao_rccl_selftest": (C.c_int, [_P(C.c_int32), C.c_int32]),
+    "kao_improve_cycles": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int32, _P(C.c_int64), _P(C.c_int32)]),
+    "kao_cycle_matrices": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_uint32)]),
+    "kao_cycle_seeds": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), _P(C.c_int32), _P(C.c_int32)]),
     "kao_last_solve_timing": (C.c_int, [_P(C.c_double)]),
 }
 

@@ -1752,6 +1752,12 @@ kao_opts solve_defaults(const kao_topic *topics, int32_t n_topics, const kao_opt
 
 }  // namespace
 
+namespace kao {
+int api_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+int api_require_init() { return require_init(); }
+double api_now_s() { return now_s(); }
+}  // namespace kao
+
 extern "C" {
 
 int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results) {

@@ -1,0 +1,693 @@
+// kao_cycle.hip -- KAO-CX: cyclic-exchange improvement of a feasible assignment, gfx950 only.
+//
+// K-search moves one or two slots at a time; on rigid instances (replicas per broker and per rack fixed exactly, as in
+// every drifted topic whose P*RF is a multiple of B) the last improvements are cyclic exchanges over 4..10 partitions whose
+// intermediate states are all infeasible.  KAO-CX finds them by shortest paths instead of by chance:
+//   k_cx_edges   : two transfer graphs on the brokers -- F (a follower slot takes another broker: one replica unit moves),
+//                  S (leader and follower of one partition swap roles: one leader unit moves) -- cheapest slot per broker
+//                  pair by 64-bit atomicMin of (cost, slot);
+//   k_cx_dist0   : edge keys -> cost matrices, slack node Z (brokers with room inside their band absorb / give a unit);
+//   k_cx_square  : min-plus squaring with the midpoint of every pair, three times: cheapest paths of <= 8 edges;
+//   k_cx_seeds   : for every partition every new row that replaces <= 2 replicas (one by a current replica) with any
+//                  leader, priced as gain - closure of its replica imbalance (F) - of its leader imbalance (S);
+// the host unrolls the best candidates into slot changes (a partition is used once), K-eval scores them exactly, and the
+// best -- or a merge of partition-disjoint ones -- becomes the next assignment.  Every definition follows
+// oracle/kao_cycle.py, which the parity tests compare with bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/kao.h"
+#include "kao_internal.h"
+
+namespace kao {
+namespace {
+
+constexpr int kCxInf = 1 << 17;
+constexpr int kCxBias = 1 << 16;
+constexpr int kCxLevels = 3;
+constexpr int kCxMaxEval = 512;
+constexpr int kCxMaxRF = 4;
+constexpr unsigned long long kNoEdge = ~0ull;
+
+struct CxParams {
+    int32_t B, R, P, RF, rfc, n, np;   // n = B + 1 (slack node Z = B), np = row stride of the matrices (multiple of 64)
+    int32_t rep_lo, rep_hi, lead_lo, lead_hi, prack_lo, prack_hi;
+    int32_t w00, w01, w10, w11;
+    int32_t ncfg;
+};
+
+// objective weight of broker b in role nr on a partition whose current replicas are cur[0..rfc) (README.md:145-146)
+__device__ __forceinline__ int cx_wt(const CxParams &q, const uint16_t *cur, int b, int nr) {
+    int w = 0;
+    for (int k = 0; k < q.rfc; ++k)
+        if ((int)cur[k] == b) w = k == 0 ? (nr == 0 ? q.w00 : q.w01) : (nr == 0 ? q.w10 : q.w11);
+    return w;
+}
+
+// C7 (README.md:178-180) of a row made of `base[0..nb)` plus one more broker of rack ry: nb <= 3
+struct CxBase {
+    int rk[kCxMaxRF];
+    int nb, ndef;
+    bool over;
+};
+__device__ __forceinline__ CxBase cx_base(const CxParams &q, const uint8_t *rack, const int *base, int nb) {
+    CxBase o;
+    o.nb = nb; o.over = false;
+    int distinct = 0, deficient_present = 0;
+    for (int i = 0; i < nb; ++i) o.rk[i] = rack[base[i]];
+    for (int i = 0; i < nb; ++i) {
+        int cnt = 0; bool first = true;
+        for (int j = 0; j < nb; ++j) { cnt += o.rk[j] == o.rk[i]; first = first && !(j < i && o.rk[j] == o.rk[i]); }
+        if (cnt > q.prack_hi) o.over = true;
+        if (first) { ++distinct; deficient_present += cnt < q.prack_lo; }
+    }
+    o.ndef = q.prack_lo > 0 ? (q.R - distinct) + deficient_present : 0;
+    return o;
+}
+__device__ __forceinline__ bool cx_completes(const CxParams &q, const CxBase &b, int ry) {
+    int cnt = 0;
+    for (int i = 0; i < b.nb; ++i) cnt += b.rk[i] == ry;
+    if (cnt + 1 > q.prack_hi) return false;
+    if (b.ndef == 0) return true;
+    return b.ndef == 1 && cnt < q.prack_lo && cnt + 1 >= q.prack_lo;
+}
+
+// ---- edges: one wavefront per partition -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cx_edges(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack,
+                                                  unsigned long long *EF, unsigned long long *ES) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= q.P) return;
+    int row[kCxMaxRF];
+    for (int k = 0; k < q.RF; ++k) row[k] = A[(size_t)p * q.RF + k];
+    const uint16_t *c = cur + (size_t)p * q.rfc;
+    for (int k = 1; k < q.RF; ++k) {
+        const int u = row[k];
+        int base[kCxMaxRF]; int nb = 0;
+        for (int j = 0; j < q.RF; ++j) if (j != k) base[nb++] = row[j];
+        const CxBase cb = cx_base(q, rack, base, nb);
+        if (!cb.over && cb.ndef <= 1) {
+            const int wu = cx_wt(q, c, u, 1);
+            for (int v = lane; v < q.B; v += 64) {
+                bool in = false;
+                for (int j = 0; j < q.RF; ++j) in = in || row[j] == v;
+                if (in || !cx_completes(q, cb, rack[v])) continue;
+                const int cost = wu - cx_wt(q, c, v, 1);
+                const unsigned long long key = ((unsigned long long)(unsigned)(cost + kCxBias) << 32) | (unsigned)(p * q.RF + k);
+                atomicMin(&EF[(size_t)u * q.np + v], key);
+            }
+        }
+        if (lane == 0) {
+            const int a = row[0];
+            const int cs = cx_wt(q, c, a, 0) + cx_wt(q, c, u, 1) - cx_wt(q, c, u, 0) - cx_wt(q, c, a, 1);
+            const unsigned long long key = ((unsigned long long)(unsigned)(cs + kCxBias) << 32) | (unsigned)(p * q.RF + k);
+            atomicMin(&ES[(size_t)a * q.np + u], key);
+        }
+    }
+}
+
+// ---- edge keys -> level-0 cost matrix (with the slack node) -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cx_dist0(CxParams q, const unsigned long long *E, const int32_t *cnt, int lo, int hi, int32_t *D) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= q.np) return;
+    int d = kCxInf;
+    if (i < q.n && j < q.n) {
+        if (i == j) d = 0;
+        else if (j == q.B) d = cnt[i] < hi ? 0 : kCxInf;
+        else if (i == q.B) d = cnt[j] > lo ? 0 : kCxInf;
+        else {
+            const unsigned long long key = E[(size_t)i * q.np + j];
+            d = key == kNoEdge ? kCxInf : (int)(key >> 32) - kCxBias;
+        }
+    }
+    D[(size_t)i * q.np + j] = d;
+}
+
+// ---- min-plus squaring with midpoints: 64 x 64 outputs per workgroup, 4 x 4 per lane, LDS tiles of 16 midpoints --------
+// composite key ((sum + 2^18) << 12) | prio, prio = 0 for k == i (the pair's own entry), k + 1 otherwise: the smallest key is
+// the cheapest midpoint, "no midpoint" preferred, then the lowest index -- the oracle's rule.
+__global__ __launch_bounds__(256) void k_cx_square(int np, const int32_t *__restrict__ D, int32_t *__restrict__ Dn, uint16_t *__restrict__ mid) {
+    __shared__ int32_t sa[64][17];   // D[i0 + r][k0 + kk]
+    __shared__ int32_t sb[16][64];   // D[k0 + kk][j0 + c]
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int tr = (threadIdx.x >> 4) * 4, tc = (threadIdx.x & 15) * 4;
+    uint32_t best[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) best[a][b] = 0xFFFFFFFFu;
+    for (int k0 = 0; k0 < np; k0 += 16) {
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int r = e >> 4, kk = e & 15;
+            sa[r][kk] = D[(size_t)(i0 + r) * np + k0 + kk];
+        }
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int kk = e >> 6, c = e & 63;
+            sb[kk][c] = D[(size_t)(k0 + kk) * np + j0 + c];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = k0 + kk;
+            int bv[4];
+            for (int b = 0; b < 4; ++b) bv[b] = sb[kk][tc + b];
+            for (int a = 0; a < 4; ++a) {
+                const int av = sa[tr + a][kk] + (1 << 18);
+                const uint32_t prio = (k == i0 + tr + a) ? 0u : (uint32_t)(k + 1);
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t key = ((uint32_t)(av + bv[b]) << 12) | prio;
+                    best[a][b] = key < best[a][b] ? key : best[a][b];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+            const int i = i0 + tr + a, j = j0 + tc + b;
+            const int sum = (int)(best[a][b] >> 12) - (1 << 18);
+            const uint32_t prio = best[a][b] & 0xFFFu;
+            Dn[(size_t)i * np + j] = sum < kCxInf ? sum : kCxInf;
+            mid[(size_t)i * np + j] = (uint16_t)(prio == 0 ? i : (int)prio - 1);
+        }
+}
+
+// ---- seeds: one wavefront per partition -------------------------------------------------------------------------------
+// table[p][cfg] = (total, y) of the best completion of configuration cfg (total <= 0: none).  Configuration numbering:
+//   [0, RF-1)                                      role swap with follower slot cfg + 1
+//   RF-1 + rmi*RF + li                             slot rmi replaced by y; leader = base[li] (li < RF-1) or y (li = RF-1)
+//   RF-1 + RF*RF + ((pair*rfc + ii)*RF + li)       slots of `pair` replaced by cur[p][ii] and y; base = kept + cur[p][ii]
+__device__ __forceinline__ long long cx_wave_max(long long v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_cx_seeds(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack,
+                                                  const int32_t *DF, const int32_t *DS, int2 *table) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= q.P) return;
+    const int RF = q.RF;
+    int row[kCxMaxRF];
+    for (int k = 0; k < RF; ++k) row[k] = A[(size_t)p * RF + k];
+    const uint16_t *c = cur + (size_t)p * q.rfc;
+    int w0 = cx_wt(q, c, row[0], 0);
+    for (int k = 1; k < RF; ++k) w0 += cx_wt(q, c, row[k], 1);
+    int2 *out = table + (size_t)p * q.ncfg;
+    if (lane > 0 && lane < RF) {   // role swaps
+        const int k = lane;
+        const int g = cx_wt(q, c, row[k], 0) + cx_wt(q, c, row[0], 1) - cx_wt(q, c, row[0], 0) - cx_wt(q, c, row[k], 1);
+        const int tot = g - DS[(size_t)row[k] * q.np + row[0]];
+        out[k - 1] = tot > 0 ? make_int2(tot, 0) : make_int2(0, 0);
+    }
+    const int n_single = RF, n_pair = RF * (RF - 1) / 2;
+    for (int bc = 0; bc < n_single + n_pair * q.rfc; ++bc) {
+        int base[kCxMaxRF], removed[2], nb = 0, nrm = 0, cfg0;
+        bool valid = true;
+        if (bc < n_single) {
+            for (int j = 0; j < RF; ++j) { if (j == bc) removed[nrm++] = row[j]; else base[nb++] = row[j]; }
+            cfg0 = (RF - 1) + bc * RF;
+        } else {
+            const int pi = (bc - n_single) / q.rfc, ii = (bc - n_single) % q.rfc;
+            int a = 0, b = 1;   // pi-th pair in lexicographic order
+            for (int t = 0; t < pi; ++t) { if (++b == RF) { ++a; b = a + 1; } }
+            for (int j = 0; j < RF; ++j) { if (j == a || j == b) removed[nrm++] = row[j]; else base[nb++] = row[j]; }
+            const int i = c[ii];
+            valid = i < q.B;
+            for (int j = 0; j < RF; ++j) valid = valid && row[j] != i;
+            base[nb++] = valid ? i : 0;
+            cfg0 = (RF - 1) + RF * RF + (pi * q.rfc + ii) * RF;
+        }
+        const CxBase cb = cx_base(q, rack, base, nb);
+        valid = valid && !cb.over && cb.ndef <= 1;
+        if (!valid) {
+            if (lane < RF) out[cfg0 + lane] = make_int2(0, 0);
+            continue;
+        }
+        int wl_base[kCxMaxRF], wf_sum = 0, cl_base[kCxMaxRF];
+        for (int i = 0; i < nb; ++i) {
+            wl_base[i] = cx_wt(q, c, base[i], 0);
+            wf_sum += cx_wt(q, c, base[i], 1);
+            cl_base[i] = DS[(size_t)base[i] * q.np + row[0]];
+        }
+        long long best[kCxMaxRF];
+        for (int li = 0; li < RF; ++li) best[li] = -1;
+        for (int y = lane; y < q.B; y += 64) {
+            bool ok = cx_completes(q, cb, rack[y]);
+            for (int j = 0; j < RF; ++j) ok = ok && row[j] != y;
+            for (int i = 0; i < nb; ++i) ok = ok && base[i] != y;
+            if (!ok) continue;
+            int cR;
+            if (nrm == 1) cR = DF[(size_t)y * q.np + removed[0]];
+            else {
+                const int i = base[nb - 1];
+                const int m0 = DF[(size_t)i * q.np + removed[0]] + DF[(size_t)y * q.np + removed[1]];
+                const int m1 = DF[(size_t)i * q.np + removed[1]] + DF[(size_t)y * q.np + removed[0]];
+                cR = m0 < m1 ? m0 : m1;
+            }
+            const int wfy = cx_wt(q, c, y, 1), wly = cx_wt(q, c, y, 0);
+            for (int li = 0; li < RF; ++li) {
+                int tot;
+                if (li < RF - 1) tot = wl_base[li] + wf_sum - cx_wt(q, c, base[li], 1) + wfy - w0 - cR - cl_base[li];
+                else tot = wly + wf_sum - w0 - cR - DS[(size_t)y * q.np + row[0]];
+                if (tot > 0) {
+                    const long long key = ((long long)tot << 12) | (long long)(4095 - y);   // larger total, then lower y
+                    best[li] = key > best[li] ? key : best[li];
+                }
+            }
+        }
+        for (int li = 0; li < RF; ++li) {
+            const long long m = cx_wave_max(best[li]);
+            if (lane == 0) out[cfg0 + li] = m > 0 ? make_int2((int)(m >> 12), 4095 - (int)(m & 4095)) : make_int2(0, 0);
+        }
+    }
+}
+
+#define CX_TRY(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return api_fail(KAO_ERR_HIP, (std::string(#expr) + ": " + hipGetErrorString(e_)).c_str()); \
+    } while (0)
+
+int cx_ncfg(int rf, int rfc) { return (rf - 1) + rf * rf + (rf * (rf - 1) / 2) * rfc * rf; }
+
+// Device buffers and host images of one topic's KAO-CX state
+struct Cx {
+    const kao_topic *t = nullptr;
+    CxParams q{};
+    hipStream_t stream = nullptr;
+    kao_eval_plan *plan = nullptr;
+    uint16_t *d_A = nullptr, *d_cur = nullptr; uint8_t *d_rack = nullptr;
+    int32_t *d_cnt = nullptr;                       // c[B] | l[B]
+    unsigned long long *d_E[2] = {nullptr, nullptr};
+    int32_t *d_D[2][kCxLevels + 1] = {};
+    uint16_t *d_M[2][kCxLevels + 1] = {};
+    int2 *d_table = nullptr;
+    uint16_t *d_cand = nullptr; int32_t *d_obj = nullptr, *d_viol = nullptr;
+    // host images of the current round
+    std::vector<uint16_t> A;
+    std::vector<unsigned long long> hE[2];
+    std::vector<int32_t> hD3[2];
+    std::vector<uint16_t> hM[2][kCxLevels + 1];
+    std::vector<int32_t> diag;
+    std::vector<int2> table;
+    bool have_paths = false;
+
+    ~Cx() {
+        (void)hipFree(d_A); (void)hipFree(d_cur); (void)hipFree(d_rack); (void)hipFree(d_cnt); (void)hipFree(d_table);
+        (void)hipFree(d_cand); (void)hipFree(d_obj); (void)hipFree(d_viol);
+        for (int l = 0; l < 2; ++l) {
+            (void)hipFree(d_E[l]);
+            for (int v = 0; v <= kCxLevels; ++v) { (void)hipFree(d_D[l][v]); (void)hipFree(d_M[l][v]); }
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+        kao_eval_plan_destroy(plan);
+    }
+
+    int open(const kao_topic *topic) {
+        t = topic;
+        int32_t bd[8];
+        int rc = kao_derive_bounds(t, bd);
+        if (rc) return rc;
+        if (t->rf > kCxMaxRF || t->rf_cur > 8 || t->n_brokers + 1 > 2048 || t->broker_w || t->broker_wl || t->rf < 2)
+            return api_fail(KAO_ERR_UNSUPPORTED, "KAO-CX: needs 2 <= RF <= 4, at most 2047 brokers and no broker weights");
+        q.B = t->n_brokers; q.R = t->n_racks; q.P = t->n_partitions; q.RF = t->rf; q.rfc = t->rf_cur;
+        q.n = q.B + 1; q.np = (q.n + 63) & ~63;
+        q.rep_lo = bd[0]; q.rep_hi = bd[1]; q.lead_lo = bd[2]; q.lead_hi = bd[3]; q.prack_lo = bd[6]; q.prack_hi = bd[7];
+        q.w00 = t->w[0][0]; q.w01 = t->w[0][1]; q.w10 = t->w[1][0]; q.w11 = t->w[1][1];
+        q.ncfg = cx_ncfg(q.RF, q.rfc);
+        if ((rc = api_require_init())) return rc;
+        if ((rc = kao_eval_plan_create(t, &plan))) return rc;
+        CX_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        const size_t nn = (size_t)q.np * q.np, slots = (size_t)q.P * q.RF;
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_A), slots * 2));
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_cur), (size_t)q.P * q.rfc * 2));
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_rack), (size_t)q.B));
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_cnt), (size_t)q.B * 8));
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_table), (size_t)q.P * q.ncfg * sizeof(int2)));
+        for (int l = 0; l < 2; ++l) {
+            CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_E[l]), nn * 8));
+            for (int v = 0; v <= kCxLevels; ++v) {
+                CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_D[l][v]), nn * 4));
+                if (v) CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_M[l][v]), nn * 2));
+            }
+        }
+        CX_TRY(hipMemcpy(d_cur, t->current, (size_t)q.P * q.rfc * 2, hipMemcpyHostToDevice));
+        CX_TRY(hipMemcpy(d_rack, t->rack_of, (size_t)q.B, hipMemcpyHostToDevice));
+        return KAO_OK;
+    }
+
+    // edges, closures (device); diagonals to the host
+    int build(const uint16_t *assign) {
+        const size_t nn = (size_t)q.np * q.np, slots = (size_t)q.P * q.RF;
+        A.assign(assign, assign + slots);
+        std::vector<int32_t> cnt((size_t)q.B * 2, 0);
+        for (int p = 0; p < q.P; ++p)
+            for (int k = 0; k < q.RF; ++k) {
+                const unsigned b = A[(size_t)p * q.RF + k];
+                if (b >= (unsigned)q.B) return api_fail(KAO_ERR_INVALID, "KAO-CX: the assignment has an empty or out-of-range slot");
+                ++cnt[b];
+                if (k == 0) ++cnt[(size_t)q.B + b];
+            }
+        CX_TRY(hipMemcpyAsync(d_A, A.data(), slots * 2, hipMemcpyHostToDevice, stream));
+        CX_TRY(hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
+        for (int l = 0; l < 2; ++l) CX_TRY(hipMemsetAsync(d_E[l], 0xFF, nn * 8, stream));
+        hipLaunchKernelGGL(k_cx_edges, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_E[0], d_E[1]);
+        const dim3 g0((q.np + 255) / 256, q.np);
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[0], d_cnt, q.rep_lo, q.rep_hi, d_D[0][0]);
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[1], d_cnt + q.B, q.lead_lo, q.lead_hi, d_D[1][0]);
+        const dim3 gs(q.np / 64, q.np / 64);
+        for (int v = 1; v <= kCxLevels; ++v)
+            for (int l = 0; l < 2; ++l)
+                hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[l][v - 1], d_D[l][v], d_M[l][v]);
+        CX_TRY(hipGetLastError());
+        diag.assign((size_t)2 * kCxLevels * q.B, 0);
+        for (int l = 0; l < 2; ++l)
+            for (int v = 1; v <= kCxLevels; ++v)
+                CX_TRY(hipMemcpy2DAsync(&diag[((size_t)l * kCxLevels + (v - 1)) * q.B], 4, d_D[l][v], ((size_t)q.np + 1) * 4, 4, (size_t)q.B,
+                                        hipMemcpyDeviceToHost, stream));
+        CX_TRY(hipStreamSynchronize(stream));
+        have_paths = false;
+        return KAO_OK;
+    }
+
+    int eval_buffers() {
+        if (d_cand) return KAO_OK;
+        const size_t slots = (size_t)q.P * q.RF;
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_cand), (size_t)(kCxMaxEval + 1) * slots * 2));
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_obj), (size_t)(kCxMaxEval + 1) * 4));
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_viol), (size_t)(kCxMaxEval + 1) * 32));
+        return KAO_OK;
+    }
+
+    int seeds() {
+        hipLaunchKernelGGL(k_cx_seeds, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_D[1][kCxLevels], d_table);
+        CX_TRY(hipGetLastError());
+        table.resize((size_t)q.P * q.ncfg);
+        CX_TRY(hipMemcpyAsync(table.data(), d_table, table.size() * sizeof(int2), hipMemcpyDeviceToHost, stream));
+        CX_TRY(hipStreamSynchronize(stream));
+        return KAO_OK;
+    }
+
+    int fetch_paths() {
+        if (have_paths) return KAO_OK;
+        const size_t nn = (size_t)q.np * q.np;
+        for (int l = 0; l < 2; ++l) {
+            hE[l].resize(nn); hD3[l].resize(nn);
+            CX_TRY(hipMemcpyAsync(hE[l].data(), d_E[l], nn * 8, hipMemcpyDeviceToHost, stream));
+            CX_TRY(hipMemcpyAsync(hD3[l].data(), d_D[l][kCxLevels], nn * 4, hipMemcpyDeviceToHost, stream));
+            for (int v = 1; v <= kCxLevels; ++v) {
+                hM[l][v].resize(nn);
+                CX_TRY(hipMemcpyAsync(hM[l][v].data(), d_M[l][v], nn * 2, hipMemcpyDeviceToHost, stream));
+            }
+        }
+        CX_TRY(hipStreamSynchronize(stream));
+        have_paths = true;
+        return KAO_OK;
+    }
+
+    // ---- realisation (host; mirrors oracle/kao_cycle.py Round._path / _walk / realise_*) ----
+    void path(int layer, int u, int v, int lev, std::vector<int> &out) const {   // appends the nodes after u
+        if (u == v) return;
+        if (lev == 0) { out.push_back(v); return; }
+        const int m = hM[layer][lev][(size_t)u * q.np + v];
+        path(layer, u, m, lev - 1, out);
+        path(layer, m, v, lev - 1, out);
+    }
+    bool walk(std::vector<uint16_t> &X, std::vector<int> &used, int layer, int from, const std::vector<int> &nodes) const {
+        int s = from;
+        for (int d : nodes) {
+            const int s0 = s;
+            s = d;
+            if (s0 == d || s0 == q.B || d == q.B) continue;
+            const unsigned long long key = hE[layer][(size_t)s0 * q.np + d];
+            if (key == kNoEdge) return false;
+            const unsigned slot = (unsigned)(key & 0xFFFFFFFFu);
+            const int qq = (int)(slot / (unsigned)q.RF), j = (int)(slot % (unsigned)q.RF);
+            if (std::find(used.begin(), used.end(), qq) != used.end()) return false;
+            used.push_back(qq);
+            uint16_t *r = &X[(size_t)qq * q.RF];
+            if (layer == 0) r[j] = (uint16_t)d;
+            else std::swap(r[0], r[j]);
+        }
+        return true;
+    }
+    void seed_row(int p, int cfg, int y, int *nr) const {
+        const int RF = q.RF;
+        const uint16_t *row = &A[(size_t)p * RF];
+        if (cfg < RF - 1) { for (int k = 0; k < RF; ++k) nr[k] = row[k]; std::swap(nr[0], nr[cfg + 1]); return; }
+        cfg -= RF - 1;
+        int full[kCxMaxRF], nf = 0, li;
+        if (cfg < RF * RF) {
+            const int rmi = cfg / RF; li = cfg % RF;
+            for (int j = 0; j < RF; ++j) if (j != rmi) full[nf++] = row[j];
+        } else {
+            cfg -= RF * RF;
+            li = cfg % RF;
+            const int qd = cfg / RF, pi = qd / q.rfc, ii = qd % q.rfc;
+            int a = 0, b = 1;
+            for (int tt = 0; tt < pi; ++tt) { if (++b == RF) { ++a; b = a + 1; } }
+            for (int j = 0; j < RF; ++j) if (j != a && j != b) full[nf++] = row[j];
+            full[nf++] = t->current[(size_t)p * q.rfc + ii];
+        }
+        full[nf++] = y;
+        nr[0] = full[li];
+        int o = 1;
+        for (int i = 0; i < nf; ++i) if (i != li) nr[o++] = full[i];
+    }
+};
+
+struct CxCand { int total, a, b, c; };   // seed: (total, p, cfg, y); cycle: (gain, layer, level, broker)
+
+struct CxReal { std::vector<uint16_t> X; std::vector<int> used; };
+
+// one round from `assign` (feasible, objective `base`): returns 1 and overwrites assign when it improved, 0 when nothing was found
+int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t stats[8]) {
+    const CxParams &q = cx.q;
+    int rc = cx.build(assign);
+    if (rc) return -rc;
+    // ---- candidates ----
+    std::vector<CxCand> cyc;
+    for (int l = 0; l < 2; ++l)
+        for (int v = 1; v <= kCxLevels; ++v) {
+            const int32_t *dg = &cx.diag[((size_t)l * kCxLevels + (v - 1)) * q.B];
+            bool any = false;
+            for (int b = 0; b < q.B; ++b) if (dg[b] < 0) { cyc.push_back({-dg[b], l, v, b}); any = true; }
+            if (any) break;
+        }
+    std::vector<CxCand> cands;
+    const bool cycles = !cyc.empty();
+    if (cycles) {
+        std::sort(cyc.begin(), cyc.end(), [](const CxCand &x, const CxCand &y) {
+            return x.total != y.total ? x.total > y.total : (x.a != y.a ? x.a < y.a : x.c < y.c); });
+        cands = cyc;
+    } else {
+        if ((rc = cx.seeds())) return -rc;
+        for (int p = 0; p < q.P; ++p)
+            for (int c = 0; c < q.ncfg; ++c) {
+                const int2 e = cx.table[(size_t)p * q.ncfg + c];
+                if (e.x > 0) cands.push_back({e.x, p, c, e.y});
+            }
+        std::sort(cands.begin(), cands.end(), [](const CxCand &x, const CxCand &y) {
+            return x.total != y.total ? x.total > y.total : (x.a != y.a ? x.a < y.a : x.b < y.b); });
+    }
+    stats[4] += (int32_t)cands.size();
+    if (cands.empty()) return 0;
+    if ((rc = cx.fetch_paths())) return -rc;
+    // ---- realisations ----
+    const size_t slots = (size_t)q.P * q.RF;
+    std::vector<CxReal> reals;
+    std::set<std::vector<int>> seen;
+    auto push = [&](CxReal &&r) {
+        std::vector<int> sig;
+        std::vector<int> us = r.used;
+        std::sort(us.begin(), us.end());
+        for (int u : us) { sig.push_back(u); for (int k = 0; k < q.RF; ++k) sig.push_back(r.X[(size_t)u * q.RF + k]); }
+        if (seen.insert(sig).second) reals.push_back(std::move(r));
+    };
+    for (const CxCand &cd : cands) {
+        if ((int)reals.size() >= kCxMaxEval) break;
+        if (cycles) {
+            const int layer = cd.a, lev = cd.b, b = cd.c;
+            const int m = cx.hM[layer][lev][(size_t)b * q.np + b];
+            std::vector<int> nodes;
+            cx.path(layer, b, m, lev - 1, nodes);
+            cx.path(layer, m, b, lev - 1, nodes);
+            CxReal r; r.X = cx.A;
+            if (cx.walk(r.X, r.used, layer, b, nodes)) push(std::move(r));
+        } else {
+            const int p = cd.a;
+            int nr[kCxMaxRF];
+            cx.seed_row(p, cd.b, cd.c, nr);
+            const uint16_t *row = &cx.A[(size_t)p * q.RF];
+            int Rm[kCxMaxRF] = {0, 0, 0, 0}, Ad[kCxMaxRF] = {0, 0, 0, 0}, nrm = 0, nad = 0;
+            for (int k = 0; k < q.RF; ++k) { bool in = false; for (int j = 0; j < q.RF; ++j) in = in || nr[j] == row[k]; if (!in) Rm[nrm++] = row[k]; }
+            for (int k = 0; k < q.RF; ++k) { bool in = false; for (int j = 0; j < q.RF; ++j) in = in || row[j] == nr[k]; if (!in) Ad[nad++] = nr[k]; }
+            int orders[2][2] = {{Rm[0], nrm > 1 ? Rm[1] : 0}, {nrm > 1 ? Rm[1] : 0, Rm[0]}};
+            int n_orders = nrm == 2 ? 2 : 1;
+            if (nrm == 2) {
+                const std::vector<int32_t> &D3 = cx.hD3[0];
+                const int m0 = D3[(size_t)Ad[0] * q.np + Rm[0]] + D3[(size_t)Ad[1] * q.np + Rm[1]];
+                const int m1 = D3[(size_t)Ad[0] * q.np + Rm[1]] + D3[(size_t)Ad[1] * q.np + Rm[0]];
+                if (!(m0 <= m1)) { std::swap(orders[0][0], orders[1][0]); std::swap(orders[0][1], orders[1][1]); }
+            }
+            for (int o = 0; o < n_orders && (int)reals.size() < kCxMaxEval; ++o) {
+                CxReal r; r.X = cx.A;
+                for (int k = 0; k < q.RF; ++k) r.X[(size_t)p * q.RF + k] = (uint16_t)nr[k];
+                r.used.push_back(p);
+                bool good = true;
+                for (int i = 0; i < nad && good; ++i) {
+                    std::vector<int> nodes;
+                    cx.path(0, Ad[i], orders[o][i], kCxLevels, nodes);
+                    good = cx.walk(r.X, r.used, 0, Ad[i], nodes);
+                }
+                if (good && nr[0] != row[0]) {
+                    std::vector<int> nodes;
+                    cx.path(1, nr[0], row[0], kCxLevels, nodes);
+                    good = cx.walk(r.X, r.used, 1, nr[0], nodes);
+                }
+                if (good) push(std::move(r));
+            }
+        }
+    }
+    stats[2] += (int32_t)reals.size();
+    if (reals.empty()) return 0;
+    // ---- exact evaluation by K-eval ----
+    const size_t n = reals.size();
+    if ((rc = cx.eval_buffers())) return -rc;
+    auto evaluate = [&](const std::vector<const uint16_t *> &xs, std::vector<int32_t> &obj, std::vector<int32_t> &viol) -> int {
+        for (size_t i = 0; i < xs.size(); ++i)
+            CX_TRY(hipMemcpyAsync(cx.d_cand + i * slots, xs[i], slots * 2, hipMemcpyHostToDevice, cx.stream));
+        CX_TRY(hipStreamSynchronize(cx.stream));
+        int r2 = kao_eval_plan_run(cx.plan, cx.d_cand, (int64_t)xs.size(), cx.d_obj, cx.d_viol, nullptr);
+        if (!r2) r2 = kao_eval_plan_sync(cx.plan, nullptr);
+        if (r2) return r2;
+        obj.resize(xs.size()); viol.resize(xs.size() * 8);
+        CX_TRY(hipMemcpy(obj.data(), cx.d_obj, xs.size() * 4, hipMemcpyDeviceToHost));
+        CX_TRY(hipMemcpy(viol.data(), cx.d_viol, xs.size() * 32, hipMemcpyDeviceToHost));
+        return KAO_OK;
+    };
+    std::vector<const uint16_t *> xs(n);
+    for (size_t i = 0; i < n; ++i) xs[i] = reals[i].X.data();
+    std::vector<int32_t> obj, viol;
+    if ((rc = evaluate(xs, obj, viol))) return -rc;
+    int best = -1, n_good = 0;
+    std::vector<uint16_t> merged = cx.A;
+    std::vector<char> taken((size_t)q.P, 0);
+    int n_taken = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (viol[i * 8] != 0 || obj[i] <= base) continue;
+        ++n_good;
+        if (best < 0 || obj[i] > obj[(size_t)best]) best = (int)i;
+        bool clash = false;
+        for (int u : reals[i].used) clash = clash || taken[(size_t)u];
+        if (clash) continue;
+        for (int u : reals[i].used) {
+            taken[(size_t)u] = 1;
+            std::memcpy(&merged[(size_t)u * q.RF], &reals[i].X[(size_t)u * q.RF], (size_t)q.RF * 2);
+        }
+        ++n_taken;
+    }
+    stats[3] += n_good;
+    if (best < 0) return 0;
+    const uint16_t *win = reals[(size_t)best].X.data();
+    int32_t win_obj = obj[(size_t)best];
+    if (n_taken > 1) {
+        std::vector<const uint16_t *> one{merged.data()};
+        std::vector<int32_t> o1, v1;
+        if ((rc = evaluate(one, o1, v1))) return -rc;
+        if (v1[0] == 0 && o1[0] >= win_obj) { win = merged.data(); win_obj = o1[0]; stats[5] += n_taken; }
+    }
+    std::memcpy(assign, win, slots * 2);
+    *new_obj = win_obj;
+    return 1;
+}
+
+}  // namespace
+
+// KAO-CX from a feasible assignment: rounds until nothing improves, `max_rounds` or the deadline (seconds on now_s()'s clock,
+// <= 0 = none).  stats: [0] rounds run, [1] rounds that improved, [2] realisations evaluated, [3] improving ones,
+// [4] candidates priced > 0, [5] compounds merged, [6] objective before, [7] objective after.
+int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8]) {
+    int32_t local[8];
+    if (!stats) stats = local;
+    for (int i = 0; i < 8; ++i) stats[i] = 0;
+    Cx cx;
+    int rc = cx.open(t);
+    if (rc) return rc;
+    int64_t obj0 = 0; int32_t viol[8];
+    if ((rc = kao_evaluate(t, assign, &obj0, viol))) return rc;
+    if (viol[0] != 0) return api_fail(KAO_ERR_INVALID, "KAO-CX starts from a feasible assignment");
+    int32_t cur = (int32_t)obj0;
+    stats[6] = cur;
+    for (int r = 0; max_rounds <= 0 || r < max_rounds; ++r) {
+        if (deadline > 0 && api_now_s() >= deadline) break;
+        int32_t next = cur;
+        const int got = cx_round(cx, assign, cur, &next, stats);
+        ++stats[0];
+        if (got < 0) return -got;
+        if (got == 0) break;
+        ++stats[1];
+        cur = next;
+    }
+    stats[7] = cur;
+    if (objective) *objective = cur;
+    return KAO_OK;
+}
+
+bool cycle_supported(const kao_topic *t) {
+    return t && t->rf >= 2 && t->rf <= kCxMaxRF && t->rf_cur <= 8 && t->n_brokers + 1 <= 2048 && !t->broker_w && !t->broker_wl;
+}
+
+}  // namespace kao
+
+extern "C" {
+
+int kao_improve_cycles(const kao_topic *t, uint16_t *assignment, int32_t max_rounds, int64_t *objective, int32_t stats[8]) {
+    if (!t || !assignment) return kao::api_fail(KAO_ERR_INVALID, "null topic or assignment");
+    return kao::cycle_improve(t, assignment, max_rounds, 0.0, objective, stats);
+}
+
+int kao_cycle_matrices(const kao_topic *t, const uint16_t *assignment, int32_t layer, int32_t level, int32_t *dist, int32_t *mid, uint32_t *slot) {
+    using namespace kao;
+    if (!t || !assignment || !dist || layer < 0 || layer > 1 || level < 0 || level > kCxLevels) return api_fail(KAO_ERR_INVALID, "bad arguments");
+    Cx cx;
+    int rc = cx.open(t);
+    if (rc) return rc;
+    if ((rc = cx.build(assignment))) return rc;
+    const CxParams &q = cx.q;
+    const size_t nn = (size_t)q.np * q.np;
+    std::vector<int32_t> D(nn);
+    CX_TRY(hipMemcpy(D.data(), cx.d_D[layer][level], nn * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < q.n; ++i) for (int j = 0; j < q.n; ++j) dist[(size_t)i * q.n + j] = D[(size_t)i * q.np + j];
+    if (mid && level >= 1) {
+        std::vector<uint16_t> M(nn);
+        CX_TRY(hipMemcpy(M.data(), cx.d_M[layer][level], nn * 2, hipMemcpyDeviceToHost));
+        for (int i = 0; i < q.n; ++i) for (int j = 0; j < q.n; ++j) mid[(size_t)i * q.n + j] = M[(size_t)i * q.np + j];
+    }
+    if (slot) {
+        std::vector<unsigned long long> E(nn);
+        CX_TRY(hipMemcpy(E.data(), cx.d_E[layer], nn * 8, hipMemcpyDeviceToHost));
+        for (int i = 0; i < q.n; ++i) for (int j = 0; j < q.n; ++j) slot[(size_t)i * q.n + j] = (uint32_t)(E[(size_t)i * q.np + j] & 0xFFFFFFFFu);
+    }
+    return KAO_OK;
+}
+
+int kao_cycle_seeds(const kao_topic *t, const uint16_t *assignment, int32_t *table, int32_t *n_cfg) {
+    using namespace kao;
+    if (!t || !assignment) return api_fail(KAO_ERR_INVALID, "bad arguments");
+    Cx cx;
+    int rc = cx.open(t);
+    if (rc) return rc;
+    if (n_cfg) *n_cfg = cx.q.ncfg;
+    if (!table) return KAO_OK;
+    if ((rc = cx.build(assignment)) || (rc = cx.seeds())) return rc;
+    for (size_t i = 0; i < cx.table.size(); ++i) { table[2 * i] = cx.table[i].x; table[2 * i + 1] = cx.table[i].y; }
+    return KAO_OK;
+}
+
+}  // extern "C"

@@ -3,6 +3,8 @@
 #pragma once
 #include <stdint.h>
 
+#include "../../include/kao.h"
+
 namespace kao {
 
 constexpr int kRFP = 4;          // replica words per partition of the common case (RF <= 4); topics with 5..8 replicas use 8 (kMaxRF)
@@ -135,5 +137,14 @@ void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream
 size_t canon_lds_bytes(int maxBx);
 void launch_canon(const TopicDev *topic, const uint32_t *cur_words, const uint16_t *ext, const int32_t *rsz, uint32_t *A, int maxBx,
                   int nw, int32_t *status, void *stream);
+
+
+// ---- KAO-CX (kao_cycle.hip): cyclic-exchange improvement of a feasible assignment ----
+bool cycle_supported(const kao_topic *t);
+int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8]);
+// helpers of the host API (kao_api.cpp) for the other translation units
+int api_fail(int code, const char *msg);
+int api_require_init();
+double api_now_s();
 
 }  // namespace kao

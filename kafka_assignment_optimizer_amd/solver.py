@@ -132,6 +132,47 @@ def canonicalize(topic: Topic, assign) -> np.ndarray:
     return a.reshape(topic.n_partitions, topic.rf)
 
 
+def improve_cycles(topic: Topic, assign, max_rounds: int = 0) -> tuple:
+    """KAO-CX (kao_improve_cycles): cyclic-exchange improvement of a FEASIBLE assignment on the GPU.
+    Returns (assignment [P, rf], objective, stats dict)."""
+    ct = _CTopics([topic])
+    a = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1).copy()
+    if a.size != topic.n_partitions * topic.rf:
+        raise ValueError("assignment must have P*rf entries")
+    obj = C.c_int64()
+    st = (C.c_int32 * 8)()
+    _check(_ffi.load().kao_improve_cycles(ct.arr, a.ctypes.data_as(C.POINTER(C.c_uint16)), int(max_rounds), C.byref(obj), st),
+           "kao_improve_cycles")
+    names = ("rounds", "improving_rounds", "realisations", "improving", "candidates", "merged", "objective_before", "objective_after")
+    return a.reshape(topic.n_partitions, topic.rf), int(obj.value), dict(zip(names, (int(v) for v in st)))
+
+
+def cycle_matrices(topic: Topic, assign, layer: int, level: int) -> tuple:
+    """Parity hook of KAO-CX: (dist, mid, slot), each [(B+1), (B+1)], of one layer (0 follower moves, 1 role swaps) and level."""
+    ct = _CTopics([topic])
+    a = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1)
+    n = len(topic.broker_ids) + 1
+    dist = np.zeros((n, n), dtype=np.int32)
+    mid = np.zeros((n, n), dtype=np.int32)
+    slot = np.zeros((n, n), dtype=np.uint32)
+    _check(_ffi.load().kao_cycle_matrices(ct.arr, a.ctypes.data_as(C.POINTER(C.c_uint16)), layer, level,
+                                          dist.ctypes.data_as(C.POINTER(C.c_int32)), mid.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          slot.ctypes.data_as(C.POINTER(C.c_uint32))), "kao_cycle_matrices")
+    return dist, mid, slot
+
+
+def cycle_seeds(topic: Topic, assign) -> np.ndarray:
+    """Parity hook of KAO-CX: the seed table [P, n_cfg, 2] = (total, completing broker)."""
+    ct = _CTopics([topic])
+    a = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1)
+    ncfg = C.c_int32()
+    _check(_ffi.load().kao_cycle_seeds(ct.arr, a.ctypes.data_as(C.POINTER(C.c_uint16)), None, C.byref(ncfg)), "kao_cycle_seeds")
+    tab = np.zeros((topic.n_partitions, ncfg.value, 2), dtype=np.int32)
+    _check(_ffi.load().kao_cycle_seeds(ct.arr, a.ctypes.data_as(C.POINTER(C.c_uint16)), tab.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ncfg)),
+           "kao_cycle_seeds")
+    return tab
+
+
 class EvalPlan:
     """Device-resident K-eval: tables uploaded once; candidates / outputs are device pointers
     (e.g. ``torch.Tensor.data_ptr()``)."""
