@@ -102,6 +102,9 @@ typedef struct kao_opts {
                                  0 = kao_solve: about one penalty period of the largest topic, sessions: never; < 0 = never */
     int32_t use_prices;       /* kao_solve: feed K-bound's multipliers (rounded to quarters) back into K-search as Lagrangian
                                  prices of the broker / rack rows (augmented-Lagrangian search); 0 = yes, < 0 = no */
+    int32_t use_cycles;       /* kao_solve: KAO-CX (kao_improve_cycles) on incumbents the search has stopped improving;
+                                 0 = yes, < 0 = no */
+    int32_t reserved_;
     const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
                                         objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;

@@ -1639,6 +1639,30 @@ namespace {
 
 // One whole job on one device: the kao_solve loop, cut into steps so that kao_solve_multi can drive several of them in
 // lockstep from one host thread (launches of all devices are enqueued before any of them is waited for).
+// the topic's winning assignment (dense [P*RF]) as of the last finished launch
+int session_topic_best(kao_session *s, int i, uint16_t *out) {
+    HIP_TRY(hipSetDevice(s->device));
+    launch_gather(s->d_topics, s->n_topics, s->d_keys, s->d_best, s->d_viol, s->d_win_assign, s->d_win_viol, s->stream);
+    HIP_TRY(hipGetLastError());
+    const TopicDev &d = s->pts[(size_t)i].d;
+    HIP_TRY(hipMemcpyAsync(out, s->d_win_assign + d.win_off, (size_t)d.P * d.RF * 2, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return KAO_OK;
+}
+// a feasible assignment found outside K-search (KAO-CX) becomes the topic's incumbent: winner buffer + packed key with the
+// reserved restart id, exactly as an assignment adopted from another GPU (k_gather leaves it alone, elite launches re-seed from it)
+int session_adopt_external(kao_session *s, int i, const uint16_t *assign, int64_t objective, uint64_t *key_out) {
+    HIP_TRY(hipSetDevice(s->device));
+    const TopicDev &d = s->pts[(size_t)i].d;
+    const uint64_t key = ((uint64_t)((int64_t)kObjCap - objective) << 20) | (uint64_t)kExternalRestart;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_win_assign + d.win_off, assign, (size_t)d.P * d.RF * 2, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_keys + i, &key, 8, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    *key_out = key;
+    return KAO_OK;
+}
+
 struct SolveRun {
     kao_session *s = nullptr;
     int n = 0;
@@ -1650,8 +1674,18 @@ struct SolveRun {
     double t0 = 0, t_last_improve = 0;
     int launches = 0, dual_iters = 0, dual_now = 0;
     bool use_prices = true, all_done = false;
+    // KAO-CX (kao_cycle.hip): cyclic-exchange improvement of incumbents K-search has stopped improving
+    const kao_topic *topics = nullptr;
+    bool cx_on = true;
+    double deadline = 0;
+    std::vector<double> t_improved, t_cx;         // per topic: last improvement, last KAO-CX call (seconds from t0)
+    std::vector<uint64_t> cx_seen;                // packed key KAO-CX last ran to a fixpoint on
+    std::vector<uint16_t> cx_buf;
+    std::vector<CycleCtx *> cx_ctx;
+    int cx_calls = 0, cx_gains = 0;
+    double cx_slice = 0.1;                        // seconds one KAO-CX call may take
 
-    ~SolveRun() { if (s) kao_session_destroy(s); }
+    ~SolveRun() { for (CycleCtx *c : cx_ctx) cycle_close(c); if (s) kao_session_destroy(s); }
 
     // `so` is the caller's options with kao_solve's defaults applied; the session is created on the calling thread's device
     int begin(const kao_topic *topics, int n_topics, const kao_opts &so, const int64_t *tgt, double t_start) {
@@ -1661,6 +1695,12 @@ struct SolveRun {
         has_target = tgt != nullptr;
         if (tgt) target.assign(tgt, tgt + n_topics);
         keys.assign((size_t)n, 0); prev.assign((size_t)n, ~0ull); t_best.assign((size_t)n, 0.0); dual_target.assign((size_t)n, -1);
+        this->topics = topics;
+        t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
+        cx_on = so.use_cycles >= 0;
+        cx_ctx.assign((size_t)n, nullptr);
+        cx_slice = std::max(0.1, 0.1 * (so.time_limit_s > 0 ? so.time_limit_s : 10.0));
+        deadline = t_start + (so.time_limit_s > 0 ? so.time_limit_s : 10.0);
         const kao_opts &o = s->opts;
         dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 128 : o.dual_iters);
         dual_now = dual_iters;
@@ -1685,35 +1725,76 @@ struct SolveRun {
         ++launches;
         const double t = now_s() - t0;
         for (int i = 0; i < n; ++i)
-            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; }
+            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; t_improved[(size_t)i] = t; }
         all_done = check_done();
-        if (!has_target && dual_iters > 0) {
-            // K-bound runs beside the search on its own stream; when a launch has finished its certificates are merged
-            // and, while some feasible incumbent is still below its bound, the next launch starts (aimed at the new
-            // incumbents).  Launch length adapts so that one launch takes about 10 ms.
-            const int busy = kao_session_bound_busy(s);
-            if (busy < 0) return busy;
-            if (!busy) {
-                if (s->bound_inflight) {
-                    if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
-                    // the finished launch's multipliers (rounded to quarters) become the prices of the next K-search launches
-                    if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
-                    if (s->bound_ms_last > 0) {
-                        const double scale = 10.0 / s->bound_ms_last;
-                        dual_now = (int)std::min(4096.0, std::max(32.0, s->bound_iters_last * std::min(4.0, std::max(0.25, scale))));
-                    }
-                    all_done = check_done();
-                }
-                bool any = false;
-                for (int i = 0; i < n && !all_done; ++i) {
-                    const bool want = feasible(i) && objective(i) < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
-                                      !(s->dual_flags[(size_t)i] & 6);
-                    dual_target[(size_t)i] = want ? objective(i) : -1;
-                    any |= want;
-                }
-                if (any && (rc = kao_session_bound_step(s, dual_target.data(), dual_now))) return rc;
+        if ((rc = service_bound())) return rc;
+        if (cx_on && !all_done && !has_target && (rc = cycles(t))) return rc;
+        return KAO_OK;
+    }
+    // K-bound runs beside the search on its own stream; when a launch has finished its certificates are merged and, while
+    // some feasible incumbent is still below its bound, the next launch starts (aimed at the new incumbents).  Launch length
+    // adapts so that one launch takes about 10 ms.  Called after every K-search launch and between the rounds of KAO-CX.
+    int service_bound() {
+        if (has_target || dual_iters <= 0) return KAO_OK;
+        int rc;
+        const int busy = kao_session_bound_busy(s);
+        if (busy < 0) return busy;
+        if (busy) return KAO_OK;
+        if (s->bound_inflight) {
+            if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
+            // the finished launch's multipliers (rounded to quarters) become the prices of the next K-search launches
+            if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
+            if (s->bound_ms_last > 0) {
+                const double scale = 10.0 / s->bound_ms_last;
+                dual_now = (int)std::min(4096.0, std::max(32.0, s->bound_iters_last * std::min(4.0, std::max(0.25, scale))));
             }
+            all_done = check_done();
         }
+        bool any = false;
+        for (int i = 0; i < n && !all_done; ++i) {
+            const bool want = feasible(i) && objective(i) < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
+                              !(s->dual_flags[(size_t)i] & 6);
+            dual_target[(size_t)i] = want ? objective(i) : -1;
+            any |= want;
+        }
+        if (any && (rc = kao_session_bound_step(s, dual_target.data(), dual_now))) return rc;
+        return KAO_OK;
+    }
+    static int poll_bound(void *self) { return static_cast<SolveRun *>(self)->service_bound(); }
+    // KAO-CX for feasible, unproven topics whose search has stalled (no improvement for 50 ms) or that have not been looked at
+    // for 250 ms: the incumbent goes through kao_cycle.hip to a fixpoint of the cyclic-exchange neighbourhood and, when that
+    // improved it, comes back as the topic's incumbent (elite launches re-seed the restarts from it)
+    int cycles(double t) {
+        for (int i = 0; i < n; ++i) {
+            if (s->topic_infeasible[(size_t)i] || !feasible(i) || objective(i) >= s->ub[(size_t)i]) continue;
+            if (!cycle_supported(&topics[i])) continue;
+            if ((keys[(size_t)i] >> 20) == (cx_seen[(size_t)i] >> 20)) continue;   // same incumbent as the last fixpoint
+            const bool stalled = t - t_improved[(size_t)i] >= 0.05, due = t - t_cx[(size_t)i] >= 2.0 * cx_slice;
+            if (t < 0.05 || !(stalled || due) || t - t_cx[(size_t)i] < 0.05) continue;
+            const size_t slots = (size_t)topics[i].n_partitions * topics[i].rf;
+            cx_buf.resize(slots);
+            int rc = session_topic_best(s, i, cx_buf.data());
+            if (rc) return rc;
+            int64_t obj = objective(i);
+            int32_t st[8];
+            if (!cx_ctx[(size_t)i] && !(cx_ctx[(size_t)i] = cycle_open(&topics[i], &rc))) return rc;
+            const double slice_end = std::min(deadline, now_s() + cx_slice);
+            rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), 0, slice_end, &obj, st, &SolveRun::poll_bound, this);
+            ++cx_calls;
+            if (rc) return rc;
+            const bool fixpoint = st[0] > st[1];   // the last round found nothing
+            const double t2 = now_s() - t0;
+            t_cx[(size_t)i] = t2;
+            if (obj > objective(i)) {
+                uint64_t key = 0;
+                if ((rc = session_adopt_external(s, i, cx_buf.data(), obj, &key))) return rc;
+                keys[(size_t)i] = prev[(size_t)i] = key;
+                t_best[(size_t)i] = t_improved[(size_t)i] = t_last_improve = t2;
+                ++cx_gains;
+            }
+            if (fixpoint) cx_seen[(size_t)i] = keys[(size_t)i];
+        }
+        all_done = check_done();
         return KAO_OK;
     }
     int finish(kao_result *results, bool hit_time) {

@@ -17,6 +17,8 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -384,6 +386,23 @@ struct Cx {
         return KAO_OK;
     }
 
+    // exact scores by K-eval (at most kCxMaxEval + 1 assignments)
+    int eval(const std::vector<const uint16_t *> &xs, std::vector<int32_t> &obj, std::vector<int32_t> &viol) {
+        int rc = eval_buffers();
+        if (rc) return rc;
+        const size_t slots = (size_t)q.P * q.RF;
+        for (size_t i = 0; i < xs.size(); ++i)
+            CX_TRY(hipMemcpyAsync(d_cand + i * slots, xs[i], slots * 2, hipMemcpyHostToDevice, stream));
+        CX_TRY(hipStreamSynchronize(stream));
+        rc = kao_eval_plan_run(plan, d_cand, (int64_t)xs.size(), d_obj, d_viol, nullptr);
+        if (!rc) rc = kao_eval_plan_sync(plan, nullptr);
+        if (rc) return rc;
+        obj.resize(xs.size()); viol.resize(xs.size() * 8);
+        CX_TRY(hipMemcpy(obj.data(), d_obj, xs.size() * 4, hipMemcpyDeviceToHost));
+        CX_TRY(hipMemcpy(viol.data(), d_viol, xs.size() * 32, hipMemcpyDeviceToHost));
+        return KAO_OK;
+    }
+
     int seeds() {
         hipLaunchKernelGGL(k_cx_seeds, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_D[1][kCxLevels], d_table);
         CX_TRY(hipGetLastError());
@@ -468,8 +487,11 @@ struct CxReal { std::vector<uint16_t> X; std::vector<int> used; };
 // one round from `assign` (feasible, objective `base`): returns 1 and overwrites assign when it improved, 0 when nothing was found
 int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t stats[8]) {
     const CxParams &q = cx.q;
+    static const bool trace = std::getenv("KAO_CX_TRACE") != nullptr;
+    const double tt0 = api_now_s();
     int rc = cx.build(assign);
     if (rc) return -rc;
+    const double tt1 = api_now_s();
     // ---- candidates ----
     std::vector<CxCand> cyc;
     for (int l = 0; l < 2; ++l)
@@ -497,7 +519,9 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     }
     stats[4] += (int32_t)cands.size();
     if (cands.empty()) return 0;
+    const double tt2 = api_now_s();
     if ((rc = cx.fetch_paths())) return -rc;
+    const double tt3 = api_now_s();
     // ---- realisations ----
     const size_t slots = (size_t)q.P * q.RF;
     std::vector<CxReal> reals;
@@ -556,29 +580,17 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     }
     stats[2] += (int32_t)reals.size();
     if (reals.empty()) return 0;
+    const double tt4 = api_now_s();
     // ---- exact evaluation by K-eval ----
     const size_t n = reals.size();
-    if ((rc = cx.eval_buffers())) return -rc;
-    auto evaluate = [&](const std::vector<const uint16_t *> &xs, std::vector<int32_t> &obj, std::vector<int32_t> &viol) -> int {
-        for (size_t i = 0; i < xs.size(); ++i)
-            CX_TRY(hipMemcpyAsync(cx.d_cand + i * slots, xs[i], slots * 2, hipMemcpyHostToDevice, cx.stream));
-        CX_TRY(hipStreamSynchronize(cx.stream));
-        int r2 = kao_eval_plan_run(cx.plan, cx.d_cand, (int64_t)xs.size(), cx.d_obj, cx.d_viol, nullptr);
-        if (!r2) r2 = kao_eval_plan_sync(cx.plan, nullptr);
-        if (r2) return r2;
-        obj.resize(xs.size()); viol.resize(xs.size() * 8);
-        CX_TRY(hipMemcpy(obj.data(), cx.d_obj, xs.size() * 4, hipMemcpyDeviceToHost));
-        CX_TRY(hipMemcpy(viol.data(), cx.d_viol, xs.size() * 32, hipMemcpyDeviceToHost));
-        return KAO_OK;
-    };
+    auto evaluate = [&](const std::vector<const uint16_t *> &xs, std::vector<int32_t> &obj, std::vector<int32_t> &viol) -> int { return cx.eval(xs, obj, viol); };
     std::vector<const uint16_t *> xs(n);
     for (size_t i = 0; i < n; ++i) xs[i] = reals[i].X.data();
     std::vector<int32_t> obj, viol;
     if ((rc = evaluate(xs, obj, viol))) return -rc;
     int best = -1, n_good = 0;
-    std::vector<uint16_t> merged = cx.A;
     std::vector<char> taken((size_t)q.P, 0);
-    int n_taken = 0;
+    std::vector<int> chosen;   // partition-disjoint improving realisations, candidate order
     for (size_t i = 0; i < n; ++i) {
         if (viol[i * 8] != 0 || obj[i] <= base) continue;
         ++n_good;
@@ -586,24 +598,39 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
         bool clash = false;
         for (int u : reals[i].used) clash = clash || taken[(size_t)u];
         if (clash) continue;
-        for (int u : reals[i].used) {
-            taken[(size_t)u] = 1;
-            std::memcpy(&merged[(size_t)u * q.RF], &reals[i].X[(size_t)u * q.RF], (size_t)q.RF * 2);
-        }
-        ++n_taken;
+        for (int u : reals[i].used) taken[(size_t)u] = 1;
+        chosen.push_back((int)i);
     }
     stats[3] += n_good;
     if (best < 0) return 0;
     const uint16_t *win = reals[(size_t)best].X.data();
     int32_t win_obj = obj[(size_t)best];
-    if (n_taken > 1) {
-        std::vector<const uint16_t *> one{merged.data()};
+    int n_taken = 1;
+    // merges of the first m, m/2, m/4, ... chosen ones (two compounds may still clash on a band's slack): the best feasible wins
+    std::vector<int> sizes;
+    for (int k = (int)chosen.size(); k >= 2; k /= 2) sizes.push_back(k);
+    std::vector<std::vector<uint16_t>> merges(sizes.size(), cx.A);
+    if (!sizes.empty()) {
+        std::vector<const uint16_t *> ms(sizes.size());
+        for (size_t m = 0; m < sizes.size(); ++m) {
+            for (int c = 0; c < sizes[m]; ++c) {
+                const CxReal &r = reals[(size_t)chosen[(size_t)c]];
+                for (int u : r.used) std::memcpy(&merges[m][(size_t)u * q.RF], &r.X[(size_t)u * q.RF], (size_t)q.RF * 2);
+            }
+            ms[m] = merges[m].data();
+        }
         std::vector<int32_t> o1, v1;
-        if ((rc = evaluate(one, o1, v1))) return -rc;
-        if (v1[0] == 0 && o1[0] >= win_obj) { win = merged.data(); win_obj = o1[0]; stats[5] += n_taken; }
+        if ((rc = evaluate(ms, o1, v1))) return -rc;
+        for (size_t m = 0; m < sizes.size(); ++m)
+            if (v1[m * 8] == 0 && o1[m] > win_obj) { win = merges[m].data(); win_obj = o1[m]; n_taken = sizes[m]; }
+        if (n_taken > 1) stats[5] += n_taken;
     }
     std::memcpy(assign, win, slots * 2);
     *new_obj = win_obj;
+    if (trace)
+        std::fprintf(stderr, "[kao-cx] %s build %.2f ms, candidates %zu in %.2f ms, paths %.2f ms, %zu realisations %.2f ms, eval+merge %.2f ms: %d -> %d (%d merged)\n",
+                     cycles ? "cycles" : "seeds", (tt1 - tt0) * 1e3, cands.size(), (tt2 - tt1) * 1e3, (tt3 - tt2) * 1e3, reals.size(), (tt4 - tt3) * 1e3,
+                     (api_now_s() - tt4) * 1e3, base, win_obj, n_taken);
     return 1;
 }
 
@@ -612,20 +639,33 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
 // KAO-CX from a feasible assignment: rounds until nothing improves, `max_rounds` or the deadline (seconds on now_s()'s clock,
 // <= 0 = none).  stats: [0] rounds run, [1] rounds that improved, [2] realisations evaluated, [3] improving ones,
 // [4] candidates priced > 0, [5] compounds merged, [6] objective before, [7] objective after.
-int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8]) {
+struct CycleCtx { Cx cx; };
+
+CycleCtx *cycle_open(const kao_topic *t, int *rc_out) {
+    CycleCtx *c = new CycleCtx();
+    const int rc = c->cx.open(t);
+    if (rc_out) *rc_out = rc;
+    if (rc) { delete c; return nullptr; }
+    return c;
+}
+void cycle_close(CycleCtx *c) { delete c; }
+
+int cycle_run(CycleCtx *c, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8],
+              int (*poll)(void *), void *poll_arg) {
     int32_t local[8];
     if (!stats) stats = local;
     for (int i = 0; i < 8; ++i) stats[i] = 0;
-    Cx cx;
-    int rc = cx.open(t);
+    Cx &cx = c->cx;
+    std::vector<const uint16_t *> one{assign};
+    std::vector<int32_t> o0, v0;
+    int rc = cx.eval(one, o0, v0);
     if (rc) return rc;
-    int64_t obj0 = 0; int32_t viol[8];
-    if ((rc = kao_evaluate(t, assign, &obj0, viol))) return rc;
-    if (viol[0] != 0) return api_fail(KAO_ERR_INVALID, "KAO-CX starts from a feasible assignment");
-    int32_t cur = (int32_t)obj0;
+    if (v0[0] != 0) return api_fail(KAO_ERR_INVALID, "KAO-CX starts from a feasible assignment");
+    int32_t cur = o0[0];
     stats[6] = cur;
     for (int r = 0; max_rounds <= 0 || r < max_rounds; ++r) {
         if (deadline > 0 && api_now_s() >= deadline) break;
+        if (poll && (rc = poll(poll_arg))) return rc;
         int32_t next = cur;
         const int got = cx_round(cx, assign, cur, &next, stats);
         ++stats[0];
@@ -637,6 +677,15 @@ int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, doub
     stats[7] = cur;
     if (objective) *objective = cur;
     return KAO_OK;
+}
+
+int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8]) {
+    int rc = KAO_OK;
+    CycleCtx *c = cycle_open(t, &rc);
+    if (!c) return rc;
+    rc = cycle_run(c, assign, max_rounds, deadline, objective, stats);
+    cycle_close(c);
+    return rc;
 }
 
 bool cycle_supported(const kao_topic *t) {

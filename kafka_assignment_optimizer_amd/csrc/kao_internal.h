@@ -142,6 +142,13 @@ void launch_canon(const TopicDev *topic, const uint32_t *cur_words, const uint16
 // ---- KAO-CX (kao_cycle.hip): cyclic-exchange improvement of a feasible assignment ----
 bool cycle_supported(const kao_topic *t);
 int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8]);
+// the same with the device buffers kept between calls (kao_solve); the topic must outlive the context
+struct CycleCtx;
+CycleCtx *cycle_open(const kao_topic *t, int *rc_out);
+// `poll` (may be null) is called between rounds: the caller keeps its other streams busy (kao_solve: K-bound)
+int cycle_run(CycleCtx *c, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8],
+              int (*poll)(void *) = nullptr, void *poll_arg = nullptr);
+void cycle_close(CycleCtx *c);
 // helpers of the host API (kao_api.cpp) for the other translation units
 int api_fail(int code, const char *msg);
 int api_require_init();

@@ -362,21 +362,28 @@ def round_step(t, A, evaluator=evaluate):
     if not good:
         return None, info
     best = max(good, key=lambda g: (g[0], -g[1]))
-    merged = rd.A.copy()
+    chosen = []                                        # partition-disjoint improving realisations, candidate order
     taken: set = set()
-    n_taken = 0
-    for o, idx, X, used in good:                      # candidate order
-        if used & taken:
+    for g in good:
+        if g[3] & taken:
             continue
-        for q in used:
-            merged[q] = X[q]
-        taken |= used
-        n_taken += 1
-    out, out_obj = best[2], best[0]
-    if n_taken > 1:
+        chosen.append(g)
+        taken |= g[3]
+    out, out_obj, n_taken = best[2], best[0], 1
+    # merges of the first m, m/2, m/4, ... chosen ones (two compounds may still clash on a band's slack): the best feasible wins
+    sizes = []
+    k = len(chosen)
+    while k >= 2:
+        sizes.append(k)
+        k //= 2
+    for k in sizes:
+        merged = rd.A.copy()
+        for o, idx, X, used in chosen[:k]:
+            for q in used:
+                merged[q] = X[q]
         o, v = evaluator(t, merged)
-        if v == 0 and o >= best[0]:
-            out, out_obj = merged, o
+        if v == 0 and o > out_obj:
+            out, out_obj, n_taken = merged, o, k
     info.update(objective=out_obj, merged=n_taken)
     return out.astype(np.uint16), info
 

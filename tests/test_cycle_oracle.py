@@ -1,0 +1,115 @@
+"""KAO-CX oracle (oracle/kao_cycle.py) on the CPU: the closures are shortest paths, a realised candidate changes the objective
+by exactly the value it was priced at, rounds only ever improve a feasible assignment, and the result never exceeds the exact
+optimum (HiGHS) of the golden instances."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def _incumbent(kp, t, launches=6, iters=256, rho=0):
+    r = kp.port_search(t, 3, rho, launches, iters)
+    return r["best"] if r["best_obj"] >= 0 else None
+
+
+def _wide_cases(ko, kp, seeds, need_rf=2, launches=6, iters=256):
+    for s in seeds:
+        t = ko.random_case_wide(s)
+        if t.rf < need_rf or t.rf > 4:
+            continue
+        a = _incumbent(kp, t, launches, iters)
+        if a is not None:
+            yield s, t, a
+
+
+def test_closure_is_the_bounded_shortest_path(ko, kp):
+    import kao_cycle as kc
+    n_checked = 0
+    for s, t, a in _wide_cases(ko, kp, range(40)):
+        rd = kc.Round(t, a)
+        for D, M in ((rd.DF, rd.MF), (rd.DS, rd.MS)):
+            ref = D[0].copy()
+            for _ in range(7):      # paths of <= 8 edges: seven more relaxations of the edge matrix
+                ref = np.minimum(ref, (ref[:, :, None] + D[0][None, :, :]).min(axis=1))
+            assert np.array_equal(np.minimum(ref, kc.CINF), D[3]), s
+            # the midpoints unroll into a walk of <= 8 edges whose edge costs add up to the entry (paths are only unrolled
+            # when no level has a negative cycle: otherwise the cycles themselves are the candidates)
+            if any((np.diag(D[lev]) < 0).any() for lev in range(1, 4)):
+                continue
+            n = D[0].shape[0]
+            for u in range(0, n, 3):
+                for v in range(0, n, 5):
+                    if D[3][u, v] >= kc.CINF or u == v:
+                        continue
+                    pth = rd._path(M, u, v, 3)
+                    assert pth[0] == u and pth[-1] == v and len(pth) - 1 <= 8
+                    assert sum(int(D[0][x, y]) for x, y in zip(pth[:-1], pth[1:]) if x != y) == D[3][u, v]
+        n_checked += 1
+    assert n_checked >= 10
+
+
+def test_realised_candidates_are_worth_their_price(ko, kp):
+    import kao_cycle as kc
+    seen_seed = seen_cycle = 0
+    for s, t, a in _wide_cases(ko, kp, range(60)):
+        rd = kc.Round(t, a)
+        base, v0 = kc.evaluate(t, rd.A)
+        assert v0 == 0
+        cyc = rd.cycle_candidates()
+        if cyc:
+            for c in cyc[:20]:
+                for X, used in rd.realise_cycle(c):
+                    o, _ = kc.evaluate(t, X)
+                    assert o - base == c[0], (s, c)
+                    seen_cycle += 1
+        else:
+            for c in rd.seed_candidates()[:40]:
+                for X, used in rd.realise_seed(c):
+                    o, _ = kc.evaluate(t, X)
+                    assert o - base == c[0], (s, c)
+                    seen_seed += 1
+    assert seen_seed > 0 and seen_cycle > 0
+
+
+def test_rounds_only_improve_and_stay_feasible(ko, kp):
+    import kao_cycle as kc
+    improved = 0
+    for s, t, a in _wide_cases(ko, kp, range(100, 160), launches=1, iters=48):
+        base, _ = kc.evaluate(t, a)
+        X, hist = kc.improve(t, a, 8)
+        o, v = kc.evaluate(t, X)
+        assert v == 0 and o >= base
+        objs = [h["objective"] for h in hist if "objective" in h]
+        assert objs == sorted(set(objs)) and (not objs or (objs[0] > base and objs[-1] == o))
+        improved += o > base
+    assert improved >= 3
+
+
+def test_never_above_the_exact_optimum(ko, kp):
+    import kao_cycle as kc
+    g = load_golden("random_wide.json")
+    n = 0
+    for case in g["cases"][:120]:
+        if case["status"] != "optimal":
+            continue
+        t = ko.random_case_wide(case["seed"])
+        if t.rf < 2 or t.rf > 4:
+            continue
+        a = _incumbent(kp, t, launches=2, iters=64)
+        if a is None:
+            continue
+        X, _ = kc.improve(t, a, 6)
+        o, v = kc.evaluate(t, X)
+        assert v == 0 and o <= case["objective"]
+        n += 1
+    assert n >= 10
+
+
+def test_config_numbering_round_trips(ko, kp):
+    import kao_cycle as kc
+    for s, t, a in _wide_cases(ko, kp, range(12)):
+        rd = kc.Round(t, a)
+        assert rd.seed_table().shape[1] == kc.n_cfg(t.rf, t.rf_cur)
+        for tot, p, cfg, y in rd.seed_candidates()[:50]:
+            row = rd.seed_row(p, cfg, y)
+            assert len(set(row)) == t.rf and max(row) < t.n_brokers

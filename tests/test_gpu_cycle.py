@@ -1,0 +1,134 @@
+"""KAO-CX on the MI355X through the C ABI (kao_improve_cycles / kao_cycle_matrices / kao_cycle_seeds) against
+oracle/kao_cycle.py: bit-exact transfer-graph edges, closures and midpoints, seed tables, whole rounds and fixpoints; the
+improved assignments stay feasible under the independent verifier; kao_solve with KAO-CX on a drifted 1000-partition topic."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, to_product_topic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kao():
+    import kafka_assignment_optimizer_amd as k
+    k.init(0)
+    return k
+
+
+def _cases(ko, kp, seeds, launches, iters):
+    for s in seeds:
+        t = ko.random_case_wide(s)
+        if t.rf < 2 or t.rf > 4:
+            continue
+        r = kp.port_search(t, 3, 0, launches, iters)
+        if r["best_obj"] >= 0:
+            yield s, t, r["best"]
+
+
+def _drifted(ko, B, R, P, rf=3, seed=1):
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    pt = sy.drift(sy.make_cluster(B, R, 1, P, rf, [], []), 0.2, seed)[0]
+    ot = ko.Topic(name=pt.name, broker_ids=np.array(pt.broker_ids), rack_of=np.array(pt.rack_of), n_racks=pt.n_racks,
+                  n_partitions=pt.n_partitions, rf=pt.rf, current=np.array(pt.current), weights=pt.weights)
+    return pt, ot
+
+
+def _same_matrices(kao, kc, pt, t, a):
+    rd = kc.Round(t, a)
+    B = t.n_brokers
+    for layer, (Ds, Ms, E) in enumerate(((rd.DF, rd.MF, rd.EF), (rd.DS, rd.MS, rd.ES))):
+        for lev in range(4):
+            d, m, s = kao.cycle_matrices(pt, a, layer, lev)
+            assert np.array_equal(d, Ds[lev]), (layer, lev)
+            if lev:
+                assert np.array_equal(m, Ms[lev]), (layer, lev)
+            else:
+                es = (E & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                assert np.array_equal(s[:B, :B], es[:B, :B]), layer
+    return rd
+
+
+def test_matrices_seeds_and_rounds_match_the_oracle_on_the_wide_family(kao, ko, kp):
+    import kao_cycle as kc
+    n = n_seed_tables = n_improved = 0
+    for launches, iters, seeds in ((6, 256, range(0, 50)), (1, 48, range(100, 160))):
+        for s, t, a in _cases(ko, kp, seeds, launches, iters):
+            pt = to_product_topic(t)
+            rd = _same_matrices(kao, kc, pt, t, a)
+            if not rd.cycle_candidates():
+                assert np.array_equal(kao.cycle_seeds(pt, a), rd.seed_table()), s
+                n_seed_tables += 1
+            Xo, hist = kc.improve(t, a, 64)
+            Xg, obj, st = kao.improve_cycles(pt, a, 64)
+            assert np.array_equal(np.asarray(Xo).reshape(-1), Xg.reshape(-1)), s
+            o, v = ko.verify(t, Xg)
+            assert int(np.asarray(v).sum()) == 0 and o == obj == st["objective_after"]
+            assert st["rounds"] == len(hist) and st["improving_rounds"] == sum("objective" in h for h in hist)
+            n += 1
+            n_improved += obj > st["objective_before"]
+    assert n >= 25 and n_seed_tables >= 10 and n_improved >= 5
+
+
+@pytest.mark.parametrize("shape", [(60, 3, 200, 3), (45, 5, 130, 2), (50, 2, 120, 3), (48, 6, 160, 4)])
+def test_drifted_topics_match_the_oracle(kao, ko, kp, shape):
+    """Rigid (60 x 200: every broker count fixed) and slack bands (45 brokers, RF 2), prack_lo = 1 (two racks, RF 3), RF 2 and 4."""
+    import kao_cycle as kc
+    B, R, P, rf = shape
+    pt, t = _drifted(ko, B, R, P, rf)
+    r = kp.port_search(t, 3, 0, 2, 64)
+    assert r["best_obj"] >= 0
+    a = r["best"]
+    rd = _same_matrices(kao, kc, pt, t, a)
+    if not rd.cycle_candidates():
+        assert np.array_equal(kao.cycle_seeds(pt, a), rd.seed_table())
+    Xo, hist = kc.improve(t, a, 64)
+    Xg, obj, st = kao.improve_cycles(pt, a, 64)
+    assert np.array_equal(np.asarray(Xo).reshape(-1), Xg.reshape(-1))
+    o, v = ko.verify(t, Xg)
+    assert int(np.asarray(v).sum()) == 0 and o == obj >= st["objective_before"]
+
+
+def test_fixpoint_on_a_1000_partition_topic_is_feasible_and_better(kao, ko, kp):
+    pt, t = _drifted(ko, 100, 5, 1000)
+    a = kp.port_search(t, 3, 0, 30, 512)["best"]
+    X, obj, st = kao.improve_cycles(pt, a, 0)
+    o, v = ko.verify(t, X)
+    assert int(np.asarray(v).sum()) == 0 and o == obj
+    assert obj > st["objective_before"] and st["improving_rounds"] >= 2
+    X2, obj2, st2 = kao.improve_cycles(pt, X, 0)           # a fixpoint stays a fixpoint
+    assert obj2 == obj and st2["improving_rounds"] == 0 and np.array_equal(X, X2)
+    assert obj <= load_golden("drift_scale.json")["rows"][0]["milp_objective"]
+
+
+def test_rejects_what_it_does_not_support(kao, ko, kp):
+    t = next(x for x in (ko.random_case_rf(s) for s in range(200)) if x.rf > 4)
+    pt = to_product_topic(t)
+    a = np.zeros((t.n_partitions, t.rf), dtype=np.uint16)
+    with pytest.raises(kao.KaoError):
+        kao.improve_cycles(pt, a, 1)
+    pt2, t2 = _drifted(ko, 30, 3, 60)
+    bad = np.zeros((60, 3), dtype=np.uint16)               # every replica on broker 0: infeasible start
+    with pytest.raises(kao.KaoError):
+        kao.improve_cycles(pt2, bad, 1)
+
+
+def test_solve_with_cycles_proves_the_drifted_1000_partition_topic(kao, ko):
+    pt, t = _drifted(ko, 100, 5, 1000)
+    want = load_golden("drift_scale.json")["rows"][0]["milp_objective"]
+    for cx in (0, -1):
+        r = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=5.0, use_cycles=cx)[0]
+        o, v = ko.verify(t, r.assignment)
+        assert int(np.asarray(v).sum()) == 0 and o == r.objective
+        if cx == 0:
+            assert r.objective == want == r.upper_bound
+
+
+def test_solve_with_cycles_beats_plain_search_on_a_large_drifted_topic(kao, ko):
+    pt, t = _drifted(ko, 500, 10, 10000)
+    with_cx = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=2.0)[0]
+    without = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=2.0, use_cycles=-1)[0]
+    o, v = ko.verify(t, with_cx.assignment)
+    assert int(np.asarray(v).sum()) == 0 and o == with_cx.objective
+    assert with_cx.objective > without.objective
+    assert with_cx.upper_bound >= with_cx.objective

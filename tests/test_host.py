@@ -26,7 +26,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from kafka_assignment_optimizer_amd import _ffi
     assert C.sizeof(_ffi.KaoTopic) == 5 * 4 + 4 + 2 * 8 + 16 + 8 * 4 + 2 * 8  # 5 ints, pad, 2 pointers, w[2][2], 8 bounds, 2 pointers
-    assert C.sizeof(_ffi.KaoOpts) == 8 + 8 + 12 * 4 + 8
+    assert C.sizeof(_ffi.KaoOpts) == 8 + 8 + 14 * 4 + 8
     assert C.sizeof(_ffi.KaoResult) == 4 + 4 + 8 + 8 + 32 + 8 + 8
     assert C.sizeof(_ffi.KaoStats) == 3 * 8 + 2 * 8 + 2 * 8 + 6 * 4
 
@@ -37,7 +37,7 @@ def test_header_is_plain_c(tmp_path):
     import ctypes as C
     import subprocess
     from kafka_assignment_optimizer_amd import _ffi
-    assert (C.sizeof(_ffi.KaoTopic), C.sizeof(_ffi.KaoOpts), C.sizeof(_ffi.KaoResult), C.sizeof(_ffi.KaoStats)) == (104, 72, 72, 80)
+    assert (C.sizeof(_ffi.KaoTopic), C.sizeof(_ffi.KaoOpts), C.sizeof(_ffi.KaoResult), C.sizeof(_ffi.KaoStats)) == (104, 80, 72, 80)
     exe = str(tmp_path / "abi_check")
     libdir = os.path.join(ROOT, "kafka_assignment_optimizer_amd")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
