@@ -269,6 +269,19 @@ __global__ __launch_bounds__(256) void k_cx_seeds(CxParams q, const uint16_t *A,
     }
 }
 
+// ---- candidates = the incumbent with a few rows rewritten: built on the device from (candidate, partition, row) patches ----
+__global__ __launch_bounds__(256) void k_cx_copy(const uint16_t *__restrict__ A, uint16_t *__restrict__ out, int slots) {
+    const size_t base = (size_t)blockIdx.y * (size_t)slots;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < slots; i += gridDim.x * 256) out[base + i] = A[i];
+}
+__global__ __launch_bounds__(256) void k_cx_patch(const int32_t *__restrict__ pq, const uint16_t *__restrict__ prow, int n_patches, int RF, int slots,
+                                                  uint16_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_patches * RF) return;
+    const int pi = i / RF, k = i - pi * RF;
+    out[(size_t)pq[2 * pi] * (size_t)slots + (size_t)pq[2 * pi + 1] * RF + k] = prow[i];
+}
+
 #define CX_TRY(expr)                                                                                        \
     do {                                                                                                    \
         hipError_t e_ = (expr);                                                                             \
@@ -276,6 +289,9 @@ __global__ __launch_bounds__(256) void k_cx_seeds(CxParams q, const uint16_t *A,
     } while (0)
 
 int cx_ncfg(int rf, int rfc) { return (rf - 1) + rf * rf + (rf * (rf - 1) / 2) * rfc * rf; }
+
+// a realisation = the partitions it rewrites (each at most once) and their new rows
+struct CxReal { std::vector<int> used; std::vector<uint16_t> rows; };
 
 // Device buffers and host images of one topic's KAO-CX state
 struct Cx {
@@ -290,6 +306,7 @@ struct Cx {
     uint16_t *d_M[2][kCxLevels + 1] = {};
     int2 *d_table = nullptr;
     uint16_t *d_cand = nullptr; int32_t *d_obj = nullptr, *d_viol = nullptr;
+    int32_t *d_pq = nullptr; uint16_t *d_prow = nullptr; size_t patch_cap = 0;   // patches of the candidates being built
     // host images of the current round
     std::vector<uint16_t> A;
     std::vector<unsigned long long> hE[2];
@@ -301,7 +318,7 @@ struct Cx {
 
     ~Cx() {
         (void)hipFree(d_A); (void)hipFree(d_cur); (void)hipFree(d_rack); (void)hipFree(d_cnt); (void)hipFree(d_table);
-        (void)hipFree(d_cand); (void)hipFree(d_obj); (void)hipFree(d_viol);
+        (void)hipFree(d_cand); (void)hipFree(d_obj); (void)hipFree(d_viol); (void)hipFree(d_pq); (void)hipFree(d_prow);
         for (int l = 0; l < 2; ++l) {
             (void)hipFree(d_E[l]);
             for (int v = 0; v <= kCxLevels; ++v) { (void)hipFree(d_D[l][v]); (void)hipFree(d_M[l][v]); }
@@ -437,7 +454,7 @@ struct Cx {
         path(layer, u, m, lev - 1, out);
         path(layer, m, v, lev - 1, out);
     }
-    bool walk(std::vector<uint16_t> &X, std::vector<int> &used, int layer, int from, const std::vector<int> &nodes) const {
+    bool walk(CxReal &r, int layer, int from, const std::vector<int> &nodes) const {
         int s = from;
         for (int d : nodes) {
             const int s0 = s;
@@ -447,14 +464,48 @@ struct Cx {
             if (key == kNoEdge) return false;
             const unsigned slot = (unsigned)(key & 0xFFFFFFFFu);
             const int qq = (int)(slot / (unsigned)q.RF), j = (int)(slot % (unsigned)q.RF);
-            if (std::find(used.begin(), used.end(), qq) != used.end()) return false;
-            used.push_back(qq);
-            uint16_t *r = &X[(size_t)qq * q.RF];
-            if (layer == 0) r[j] = (uint16_t)d;
-            else std::swap(r[0], r[j]);
+            if (std::find(r.used.begin(), r.used.end(), qq) != r.used.end()) return false;
+            r.used.push_back(qq);
+            const size_t o = r.rows.size();
+            r.rows.insert(r.rows.end(), &A[(size_t)qq * q.RF], &A[(size_t)qq * q.RF] + q.RF);
+            if (layer == 0) r.rows[o + (size_t)j] = (uint16_t)d;
+            else std::swap(r.rows[o], r.rows[o + (size_t)j]);
         }
         return true;
     }
+    // candidates on the device: `count` copies of A with the patches of reals[first + i] applied, then K-eval
+    int eval_patched(const std::vector<const CxReal *> &rs, std::vector<int32_t> &obj, std::vector<int32_t> &viol) {
+        int rc = eval_buffers();
+        if (rc) return rc;
+        const size_t n = rs.size();
+        std::vector<int32_t> pq;            // (candidate, partition) per patch
+        std::vector<uint16_t> prow;
+        for (size_t i = 0; i < n; ++i)
+            for (size_t u = 0; u < rs[i]->used.size(); ++u) {
+                pq.push_back((int32_t)i); pq.push_back(rs[i]->used[u]);
+                prow.insert(prow.end(), &rs[i]->rows[u * q.RF], &rs[i]->rows[u * q.RF] + q.RF);
+            }
+        const size_t np_ = pq.size() / 2;
+        if (np_ > patch_cap) {
+            (void)hipFree(d_pq); (void)hipFree(d_prow); d_pq = nullptr; d_prow = nullptr;
+            patch_cap = std::max<size_t>(2 * np_, 4096);
+            CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_pq), patch_cap * 8));
+            CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_prow), patch_cap * kCxMaxRF * 2));
+        }
+        CX_TRY(hipMemcpyAsync(d_pq, pq.data(), pq.size() * 4, hipMemcpyHostToDevice, stream));
+        CX_TRY(hipMemcpyAsync(d_prow, prow.data(), prow.size() * 2, hipMemcpyHostToDevice, stream));
+        launch_apply(n, np_);
+        CX_TRY(hipGetLastError());
+        CX_TRY(hipStreamSynchronize(stream));
+        rc = kao_eval_plan_run(plan, d_cand, (int64_t)n, d_obj, d_viol, nullptr);
+        if (!rc) rc = kao_eval_plan_sync(plan, nullptr);
+        if (rc) return rc;
+        obj.resize(n); viol.resize(n * 8);
+        CX_TRY(hipMemcpy(obj.data(), d_obj, n * 4, hipMemcpyDeviceToHost));
+        CX_TRY(hipMemcpy(viol.data(), d_viol, n * 32, hipMemcpyDeviceToHost));
+        return KAO_OK;
+    }
+    void launch_apply(size_t n, size_t n_patches);
     void seed_row(int p, int cfg, int y, int *nr) const {
         const int RF = q.RF;
         const uint16_t *row = &A[(size_t)p * RF];
@@ -480,9 +531,15 @@ struct Cx {
     }
 };
 
+void Cx::launch_apply(size_t n, size_t n_patches) {
+    const int slots = q.P * q.RF;
+    hipLaunchKernelGGL(k_cx_copy, dim3((unsigned)std::min(64, (slots + 255) / 256), (unsigned)n), dim3(256), 0, stream, d_A, d_cand, slots);
+    if (n_patches)
+        hipLaunchKernelGGL(k_cx_patch, dim3((unsigned)((n_patches * q.RF + 255) / 256)), dim3(256), 0, stream, d_pq, d_prow, (int)n_patches, q.RF, slots, d_cand);
+}
+
 struct CxCand { int total, a, b, c; };   // seed: (total, p, cfg, y); cycle: (gain, layer, level, broker)
 
-struct CxReal { std::vector<uint16_t> X; std::vector<int> used; };
 
 // one round from `assign` (feasible, objective `base`): returns 1 and overwrites assign when it improved, 0 when nothing was found
 int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t stats[8]) {
@@ -527,10 +584,11 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     std::vector<CxReal> reals;
     std::set<std::vector<int>> seen;
     auto push = [&](CxReal &&r) {
+        std::vector<size_t> order(r.used.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return r.used[x] < r.used[y]; });
         std::vector<int> sig;
-        std::vector<int> us = r.used;
-        std::sort(us.begin(), us.end());
-        for (int u : us) { sig.push_back(u); for (int k = 0; k < q.RF; ++k) sig.push_back(r.X[(size_t)u * q.RF + k]); }
+        for (size_t i : order) { sig.push_back(r.used[i]); for (int k = 0; k < q.RF; ++k) sig.push_back(r.rows[i * q.RF + k]); }
         if (seen.insert(sig).second) reals.push_back(std::move(r));
     };
     for (const CxCand &cd : cands) {
@@ -541,8 +599,8 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
             std::vector<int> nodes;
             cx.path(layer, b, m, lev - 1, nodes);
             cx.path(layer, m, b, lev - 1, nodes);
-            CxReal r; r.X = cx.A;
-            if (cx.walk(r.X, r.used, layer, b, nodes)) push(std::move(r));
+            CxReal r;
+            if (cx.walk(r, layer, b, nodes)) push(std::move(r));
         } else {
             const int p = cd.a;
             int nr[kCxMaxRF];
@@ -560,19 +618,19 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
                 if (!(m0 <= m1)) { std::swap(orders[0][0], orders[1][0]); std::swap(orders[0][1], orders[1][1]); }
             }
             for (int o = 0; o < n_orders && (int)reals.size() < kCxMaxEval; ++o) {
-                CxReal r; r.X = cx.A;
-                for (int k = 0; k < q.RF; ++k) r.X[(size_t)p * q.RF + k] = (uint16_t)nr[k];
+                CxReal r;
+                for (int k = 0; k < q.RF; ++k) r.rows.push_back((uint16_t)nr[k]);
                 r.used.push_back(p);
                 bool good = true;
                 for (int i = 0; i < nad && good; ++i) {
                     std::vector<int> nodes;
                     cx.path(0, Ad[i], orders[o][i], kCxLevels, nodes);
-                    good = cx.walk(r.X, r.used, 0, Ad[i], nodes);
+                    good = cx.walk(r, 0, Ad[i], nodes);
                 }
                 if (good && nr[0] != row[0]) {
                     std::vector<int> nodes;
                     cx.path(1, nr[0], row[0], kCxLevels, nodes);
-                    good = cx.walk(r.X, r.used, 1, nr[0], nodes);
+                    good = cx.walk(r, 1, nr[0], nodes);
                 }
                 if (good) push(std::move(r));
             }
@@ -583,11 +641,10 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     const double tt4 = api_now_s();
     // ---- exact evaluation by K-eval ----
     const size_t n = reals.size();
-    auto evaluate = [&](const std::vector<const uint16_t *> &xs, std::vector<int32_t> &obj, std::vector<int32_t> &viol) -> int { return cx.eval(xs, obj, viol); };
-    std::vector<const uint16_t *> xs(n);
-    for (size_t i = 0; i < n; ++i) xs[i] = reals[i].X.data();
+    std::vector<const CxReal *> rs(n);
+    for (size_t i = 0; i < n; ++i) rs[i] = &reals[i];
     std::vector<int32_t> obj, viol;
-    if ((rc = evaluate(xs, obj, viol))) return -rc;
+    if ((rc = cx.eval_patched(rs, obj, viol))) return -rc;
     int best = -1, n_good = 0;
     std::vector<char> taken((size_t)q.P, 0);
     std::vector<int> chosen;   // partition-disjoint improving realisations, candidate order
@@ -603,29 +660,32 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     }
     stats[3] += n_good;
     if (best < 0) return 0;
-    const uint16_t *win = reals[(size_t)best].X.data();
     int32_t win_obj = obj[(size_t)best];
     int n_taken = 1;
     // merges of the first m, m/2, m/4, ... chosen ones (two compounds may still clash on a band's slack): the best feasible wins
     std::vector<int> sizes;
     for (int k = (int)chosen.size(); k >= 2; k /= 2) sizes.push_back(k);
-    std::vector<std::vector<uint16_t>> merges(sizes.size(), cx.A);
+    std::vector<CxReal> merges(sizes.size());
     if (!sizes.empty()) {
-        std::vector<const uint16_t *> ms(sizes.size());
+        std::vector<const CxReal *> ms(sizes.size());
         for (size_t m = 0; m < sizes.size(); ++m) {
             for (int c = 0; c < sizes[m]; ++c) {
                 const CxReal &r = reals[(size_t)chosen[(size_t)c]];
-                for (int u : r.used) std::memcpy(&merges[m][(size_t)u * q.RF], &r.X[(size_t)u * q.RF], (size_t)q.RF * 2);
+                merges[m].used.insert(merges[m].used.end(), r.used.begin(), r.used.end());
+                merges[m].rows.insert(merges[m].rows.end(), r.rows.begin(), r.rows.end());
             }
-            ms[m] = merges[m].data();
+            ms[m] = &merges[m];
         }
         std::vector<int32_t> o1, v1;
-        if ((rc = evaluate(ms, o1, v1))) return -rc;
+        if ((rc = cx.eval_patched(ms, o1, v1))) return -rc;
         for (size_t m = 0; m < sizes.size(); ++m)
-            if (v1[m * 8] == 0 && o1[m] > win_obj) { win = merges[m].data(); win_obj = o1[m]; n_taken = sizes[m]; }
-        if (n_taken > 1) stats[5] += n_taken;
+            if (v1[m * 8] == 0 && o1[m] > win_obj) { win_obj = o1[m]; n_taken = -(int)(m + 1); }
     }
-    std::memcpy(assign, win, slots * 2);
+    const CxReal &winner = n_taken < 0 ? merges[(size_t)(-n_taken - 1)] : reals[(size_t)best];
+    if (n_taken < 0) { n_taken = sizes[(size_t)(-n_taken - 1)]; stats[5] += n_taken; }
+    std::memcpy(assign, cx.A.data(), slots * 2);
+    for (size_t u = 0; u < winner.used.size(); ++u)
+        std::memcpy(&assign[(size_t)winner.used[u] * q.RF], &winner.rows[u * q.RF], (size_t)q.RF * 2);
     *new_obj = win_obj;
     if (trace)
         std::fprintf(stderr, "[kao-cx] %s build %.2f ms, candidates %zu in %.2f ms, paths %.2f ms, %zu realisations %.2f ms, eval+merge %.2f ms: %d -> %d (%d merged)\n",
