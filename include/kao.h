@@ -215,7 +215,7 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
  * re-enters its band -- exactly where the violation changes (inside a slack band a unit is free): broker-, rack- and
  * direction-specific penalty weights lam +- multiplier.  With near-optimal multipliers the chain steps an improvement
  * needs (objective down a little, excess moved to another broker) become neutral moves.
- * kao_session_set_prices: a[n_brokers], l[n_brokers], g[n_racks] of one topic from the host (fixed point, 4096 = 1; any
+ * kao_session_set_prices: a[n_brokers], l[n_brokers], g[n_racks] of one topic from the host (fixed point, 65536 = 1; any
  * values are valid -- prices steer the search, they never change what is reported).  kao_session_adopt_prices: use what
  * the last finished K-bound launch exported (the multipliers of its record dual value, rounded to the quarter grid) for every topic it covered;
  * waits for the K-bound launch in flight.  Both take effect from the next kao_session_step. */
@@ -230,11 +230,11 @@ int kao_session_bound_busy(kao_session *s);
  * 4 = no bound (a partition subproblem is infeasible), 8 = topic outside K-bound's limits; iters[i] = K-bound
  * iterations so far.  Any output pointer may be NULL. */
 int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int32_t *iters);
-/* Test hook: K-bound state of one topic -- multipliers a[n_brokers], l[n_brokers], g[n_racks] (fixed point, 4096 = 1)
+/* Test hook: K-bound state of one topic -- multipliers a[n_brokers], l[n_brokers], g[n_racks] (fixed point, 65536 = 1)
  * and the smallest dual value so far in the same fixed point (INT64_MAX-like before the first iteration). */
 int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l, int32_t *g, int64_t *best_dual);
 /* One-shot K-bound on one topic: `launches` launches of `iters` iterations towards `target`.
- * *bound = floor(best dual / 4096) (not combined with kao_upper_bound); multipliers, if not NULL, receives
+ * *bound = floor(best dual / 65536) (not combined with kao_upper_bound); multipliers, if not NULL, receives
  * a[n_brokers], l[n_brokers], g[n_racks]. */
 int kao_dual_bound(const kao_topic *t, int64_t target, int32_t iters, int32_t launches, int64_t *bound,
                    int64_t *best_dual, int32_t *iters_done, int32_t *flags, int32_t *multipliers);

@@ -15,10 +15,13 @@ constexpr int kRackTab = 256;    // entries of the per-rack LDS tables (rack siz
 constexpr uint32_t kNoneW = 0xFFFFFFFFu;  // empty slot in the LDS word layout (x | rack << 16)
 constexpr uint32_t kKeyNull = 0xFFFFFFFFu;
 constexpr int kDBias = 32768;
-constexpr int kDualScale = 4096;          // fixed point of the dual multipliers (K-bound)
+constexpr int kDualLog2 = 16;
+constexpr int kDualScale = 1 << kDualLog2; // fixed point of the dual multipliers (K-bound): 65536 = 1.  (4096 until round 2: Polyak steps
+                                          // below one unit of the last place truncate to zero and the iterate freezes -- 300 x 2000: stuck at
+                                          // 14831.74 for 110,000 iterations; with 2^16 the same iteration reaches the LP optimum 14826.0)
 constexpr int kDualStage = 100;           // level control: iterations per stage (K-bound)
 constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
-constexpr int kDualQuarterLog2 = 10;      // kDualScale / 4 = 2^10: the quarter grid of the rounding probes and the search prices
+constexpr int kDualQuarterLog2 = kDualLog2 - 2;  // kDualScale / 4: the quarter grid of the rounding probes and the search prices
 constexpr int kDualProbes = 2;            // probes per K-bound launch: multipliers rounded to the quarter grid, then the half grid
 constexpr uint32_t kExternalRestart = 0xFFFFFu;  // restart id of a best key adopted from another GPU (kao_solve_multi)
 constexpr uint32_t kObjCap = 0xFFFFFFu;   // packed best key: viol(20) << 44 | (kObjCap - obj) << 20 | restart(20)

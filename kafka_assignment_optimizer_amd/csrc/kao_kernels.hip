@@ -129,7 +129,7 @@ __device__ __forceinline__ int p_out(int c, int lo, int hi, int price) { return 
 // packed broker weights (objective terms per replica / per leader on a broker, kao_topic.broker_w / broker_wl): low | high half
 __device__ __forceinline__ int bw_of(uint32_t bw, bool lead) { return (int)(bw & 0xFFFFu) + (lead ? (int)(bw >> 16) : 0); }
 // fixed point (kDualScale) -> key units (obj_scale per objective unit), rounded half up, clamped to 16 bits
-__device__ __forceinline__ int price_units(int v, int S) { return min(max((S * v + kDualScale / 2) >> 12, -32767), 32767); }
+__device__ __forceinline__ int price_units(int v, int S) { return min(max((S * v + kDualScale / 2) >> kDualLog2, -32767), 32767); }
 
 template <int NW> __device__ __forceinline__ bool in4(const Part<NW> &a, uint32_t w) {
     bool r = false;

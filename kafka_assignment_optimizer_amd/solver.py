@@ -307,7 +307,7 @@ class Session:
                "kao_session_bound_step")
 
     def set_prices(self, topic: int, a, l, g):
-        """Search prices of one topic from the host (fixed point, 4096 = 1): a[n_brokers], l[n_brokers], g[n_racks]."""
+        """Search prices of one topic from the host (fixed point, 65536 = 1): a[n_brokers], l[n_brokers], g[n_racks]."""
         t = self.topics[topic]
         a = np.ascontiguousarray(a, dtype=np.int32); l = np.ascontiguousarray(l, dtype=np.int32); g = np.ascontiguousarray(g, dtype=np.int32)
         if a.shape != (t.n_brokers,) or l.shape != (t.n_brokers,) or g.shape[0] < t.n_racks:

@@ -583,7 +583,7 @@ typedef struct {
 typedef struct { const ls_topic *t; ls_state s; port_params pp; uint32_t rho; int *PA, *PL; int PG[256]; } ls_runner;
 
 static inline int price_units(int v, int S) {
-    int u = (S * v + 2048) >> 12; /* arithmetic shift: floor */
+    int u = (S * v + (1 << 15)) >> 16; /* fixed point 65536 = 1 (DB_SCALE); arithmetic shift: floor */
     if (u < -32767) u = -32767;
     if (u > 32767) u = 32767;
     return u;
@@ -734,10 +734,11 @@ uint64_t kao_port_search_many(void *h, const port_params *pp, uint32_t rho0, uin
  * the incumbent `target` (a known feasible objective) while that keeps working and moves up towards the record dual
  * value when it does not (level control below), all in integers so that the device and this replay agree bit for
  * bit. */
-#define DB_SCALE 4096
+#define DB_LOG2 16
+#define DB_SCALE (1 << DB_LOG2)
 #define DB_CLAMP (1 << 26)
 #define DB_STAGE 100
-#define DB_QUARTER_LOG2 10 /* DB_SCALE / 4: the quarter grid of the rounding probes and of the search prices */
+#define DB_QUARTER_LOG2 (DB_LOG2 - 2) /* DB_SCALE / 4: the quarter grid of the rounding probes and of the search prices */
 static inline int32_t db_round(int32_t v, int sh) { return (int32_t)(((v + (1 << (sh - 1))) >> sh) << sh); } /* nearest multiple, half up */
 
 typedef struct { int b[RFP]; int f[RFP]; int r[RFP]; int n; } db_set;

@@ -207,9 +207,9 @@ class PortRun:
 
 
 def quarter_round(v):
-    """Multipliers on the quarter grid (what K-bound exports as search prices): nearest multiple of 1024, half up."""
+    """Multipliers on the quarter grid (what K-bound exports as search prices): nearest multiple of DB_SCALE / 4, half up."""
     v = np.asarray(v, dtype=np.int64)
-    return (((v + 512) >> 10) << 10).astype(np.int32)
+    return (((v + 8192) >> 14) << 14).astype(np.int32)
 
 
 def port_valid_fraction(topic, seed: int, rho: int, launches: int, iters: int, **params) -> float:
@@ -249,7 +249,7 @@ def port_search_throughput(topic, seed: int, n_restarts: int, launches: int, ite
         lib().kao_port_ls_destroy(h)
 
 
-DB_SCALE = 4096
+DB_SCALE = 65536
 INT64_MAX = (1 << 63) - 1
 
 

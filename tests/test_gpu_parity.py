@@ -136,9 +136,9 @@ def test_search_replay_with_prices_bit_exact(kao, ko, kp, cfg):
     rng = np.random.default_rng(cfg)
     prices = []
     for t in ots:
-        a = rng.integers(-8, 9, t.n_brokers) * 1024
-        l = rng.integers(-4, 5, t.n_brokers) * 1024 + rng.integers(-300, 300, t.n_brokers)   # off-grid on purpose
-        g = rng.integers(-2, 3, t.n_racks) * 1024
+        a = rng.integers(-8, 9, t.n_brokers) * 16384
+        l = rng.integers(-4, 5, t.n_brokers) * 16384 + rng.integers(-4800, 4800, t.n_brokers)   # off-grid on purpose
+        g = rng.integers(-2, 3, t.n_racks) * 16384
         prices.append((a.astype(np.int32), l.astype(np.int32), g.astype(np.int32)))
     seed = 0x51CE + cfg
     with kao.Session(pts, seed=seed, restarts=8, iters_per_launch=150) as s:

@@ -249,7 +249,7 @@ def test_dual_subproblem_picks_lie_in_the_candidate_pools(ko, kp):
         B, R, RF = t.n_brokers, t.n_racks, t.rf
         rack = t.rack_of.astype(int)
         for trial in range(3):
-            step = [1, 512, 4096][trial]          # coarse multipliers -> many exact ties
+            step = [1, kp.DB_SCALE // 8, kp.DB_SCALE][trial]          # coarse multipliers -> many exact ties
             a = (rng.integers(-3, 4, B) * step).astype(np.int32)
             l = (rng.integers(-2, 3, B) * step).astype(np.int32)
             g = (rng.integers(-2, 3, max(1, R)) * step).astype(np.int32)
@@ -288,7 +288,7 @@ def test_dual_value_is_an_upper_bound_for_any_multipliers(ko, kp):
         t = ko.random_case_wide(c["seed"]) if "shape" in c else ko.topic_from_dict(c["topic"])
         bd = t.bounds()
         B, R = t.n_brokers, t.n_racks
-        for scale in (0, 300, 4096, 20000):
+        for scale in (0, 300, kp.DB_SCALE, 5 * kp.DB_SCALE):
             a = rng.integers(-scale, scale + 1, B).astype(np.int32)
             l = rng.integers(-scale, scale + 1, B).astype(np.int32)
             g = rng.integers(-scale, scale + 1, max(1, R)).astype(np.int32)
