@@ -104,7 +104,9 @@ typedef struct kao_opts {
                                  prices of the broker / rack rows (augmented-Lagrangian search); 0 = yes, < 0 = no */
     int32_t use_cycles;       /* kao_solve: KAO-CX (kao_improve_cycles) on incumbents the search has stopped improving;
                                  0 = yes, < 0 = no */
-    int32_t reserved_;
+    int32_t islands;          /* kao_solve, experimental: > 1 = search every topic as this many independent copies (own seed,
+                                 restarts, elite, K-bound trajectory, KAO-CX) that share one copy's restart budget and answer
+                                 with the best; certificates are shared.  0 / 1 = off (measured: no gain) */
     const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
                                         objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;

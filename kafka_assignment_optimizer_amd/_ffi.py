@@ -23,7 +23,7 @@ class KaoOpts(C.Structure):
                 ("iters_per_launch", C.c_int32), ("max_launches", C.c_int32), ("obj_scale", C.c_int32),
                 ("lam_min", C.c_int32), ("lam_max", C.c_int32), ("period_log2", C.c_int32),
                 ("stop_at_bound", C.c_int32), ("profile", C.c_int32), ("dual_iters", C.c_int32),
-                ("elite_period", C.c_int32), ("use_prices", C.c_int32), ("use_cycles", C.c_int32), ("reserved_", C.c_int32),
+                ("elite_period", C.c_int32), ("use_prices", C.c_int32), ("use_cycles", C.c_int32), ("islands", C.c_int32),
                 ("target_objective", C.POINTER(C.c_int64))]
 
 
