@@ -390,6 +390,20 @@ def main():
                            "note": "cli/kao-cli process start -> JSON written (exec, HIP init, first hipMalloc, JSON parse, solve, JSON out), "
                                    "rank 0's topics"}
 
+    # ---- exactness at scale: single drifted topics of >= 1000 partitions, rank 0 only ----
+    if not args.no_extras and rank == 0:
+        probes = []
+        for (B_, R_, P_, budget, known) in ((100, 5, 1000, 3.0, 7430), (300, 6, 2000, 3.0, 14826)):
+            tp = synthetic.drift(synthetic.make_cluster(B_, R_, 1, P_, 3, [], []), 0.2, 1)[0]
+            t0 = time.perf_counter()
+            r = kao.solve([tp], seed=3, stop_at_bound=1, time_limit_s=budget)[0]
+            probes.append({"brokers": B_, "partitions": P_, "rf": 3, "status": str(r.status), "objective": int(r.objective),
+                           "certificate": int(r.upper_bound), "exact_optimum_highs": known, "seconds": time.perf_counter() - t0,
+                           "seconds_to_best": float(r.seconds_to_best)})
+        out["exactness_probe"] = {"topics": probes,
+                                  "note": "one kao_solve call per topic (K-search + K-bound + KAO-CX), 20 % drift, tools/drift_scale.py's "
+                                          "instances; exact optima from tests/golden/drift_scale.json (HiGHS LP = MILP)"}
+
     # ---- roofline of the dominant kernel (K-search), duration from HIP events on the session stream -------
     avg_ms = ms_search / max(1, launches)
     algo_per_launch = sb // max(1, launches)
