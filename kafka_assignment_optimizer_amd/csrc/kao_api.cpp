@@ -1680,6 +1680,7 @@ struct SolveRun {
     std::vector<int> origin;                      // session topic -> caller topic
     int n_user = 0;
     bool cx_on = true;
+    bool cx_eager = false;                        // test hook KAO_CX_EAGER=1: KAO-CX after every launch, whatever the clock says
     double deadline = 0;
     std::vector<double> t_improved, t_cx;         // per topic: last improvement, last KAO-CX call (seconds from t0)
     std::vector<uint64_t> cx_seen;                // packed key KAO-CX last ran to a fixpoint on
@@ -1723,6 +1724,7 @@ struct SolveRun {
         this->topics = topics;
         t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
         cx_on = so.use_cycles >= 0;
+        { const char *e = std::getenv("KAO_CX_EAGER"); cx_eager = e && e[0] == '1'; }
         cx_ctx.assign((size_t)n, nullptr);
         cx_slice = std::max(0.1, 0.1 * (so.time_limit_s > 0 ? so.time_limit_s : 10.0));
         deadline = t_start + (so.time_limit_s > 0 ? so.time_limit_s : 10.0);
@@ -1802,7 +1804,31 @@ struct SolveRun {
         if (any && (rc = kao_session_bound_step(s, dual_target.data(), dual_now))) return rc;
         return KAO_OK;
     }
-    static int poll_bound(void *self) { return static_cast<SolveRun *>(self)->service_bound(); }
+    // between the rounds of KAO-CX: K-bound is serviced and K-search keeps running -- whenever its stream has drained the next
+    // launch is enqueued (KAO-CX works on a snapshot of the incumbent, on its own stream)
+    int async_launches = 0;
+    static int poll_cx(void *self) {
+        SolveRun *r = static_cast<SolveRun *>(self);
+        int rc = r->service_bound();
+        if (rc) return rc;
+        if (r->s->opts.max_launches > 0 && r->launches + r->async_launches >= r->s->opts.max_launches) return KAO_OK;
+        const hipError_t q = hipStreamQuery(r->s->stream);
+        if (q == hipSuccess) { if ((rc = kao_session_step(r->s))) return rc; ++r->async_launches; }
+        else if (q != hipErrorNotReady) return fail(KAO_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        return KAO_OK;
+    }
+    // keys after the launches enqueued by poll_cx (waits for them)
+    int book_async() {
+        if (!async_launches) return KAO_OK;
+        int rc = kao_session_best_keys(s, keys.data());
+        if (rc) return rc;
+        launches += async_launches;
+        async_launches = 0;
+        const double t = now_s() - t0;
+        for (int i = 0; i < n; ++i)
+            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; t_improved[(size_t)i] = t; }
+        return KAO_OK;
+    }
     // KAO-CX for feasible, unproven topics whose search has stalled (no improvement for 50 ms) or that have not been looked at
     // for 250 ms: the incumbent goes through kao_cycle.hip to a fixpoint of the cyclic-exchange neighbourhood and, when that
     // improved it, comes back as the topic's incumbent (elite launches re-seed the restarts from it)
@@ -1812,7 +1838,7 @@ struct SolveRun {
             if (!cycle_supported(&topics[i])) continue;
             if ((keys[(size_t)i] >> 20) == (cx_seen[(size_t)i] >> 20)) continue;   // same incumbent as the last fixpoint
             const bool stalled = t - t_improved[(size_t)i] >= 0.05, due = t - t_cx[(size_t)i] >= 2.0 * cx_slice;
-            if (t < 0.05 || !(stalled || due) || t - t_cx[(size_t)i] < 0.05) continue;
+            if (!cx_eager && (t < 0.05 || !(stalled || due) || t - t_cx[(size_t)i] < 0.05)) continue;
             const size_t slots = (size_t)topics[i].n_partitions * topics[i].rf;
             cx_buf.resize(slots);
             int rc = session_topic_best(s, i, cx_buf.data());
@@ -1821,9 +1847,9 @@ struct SolveRun {
             int32_t st[8];
             if (!cx_ctx[(size_t)i] && !(cx_ctx[(size_t)i] = cycle_open(&topics[i], &rc))) return rc;
             const double slice_end = std::min(deadline, now_s() + cx_slice);
-            rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), 0, slice_end, &obj, st, &SolveRun::poll_bound, this);
+            rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), 0, slice_end, &obj, st, &SolveRun::poll_cx, this);
             ++cx_calls;
-            if (rc) return rc;
+            if (rc || (rc = book_async())) return rc;
             const bool fixpoint = st[0] > st[1];   // the last round found nothing
             const double t2 = now_s() - t0;
             t_cx[(size_t)i] = t2;

@@ -132,3 +132,39 @@ def test_solve_with_cycles_beats_plain_search_on_a_large_drifted_topic(kao, ko):
     assert int(np.asarray(v).sum()) == 0 and o == with_cx.objective
     assert with_cx.objective > without.objective
     assert with_cx.upper_bound >= with_cx.objective
+
+
+@pytest.mark.parametrize("name", ["cfg2_drift.json", "cfg3_drift.json", "cfg4_drift.json"])
+def test_solve_with_eager_cycles_keeps_the_golden_optima(kao, ko, name, monkeypatch):
+    """KAO-CX forced after EVERY launch (test hook KAO_CX_EAGER=1; normally only stalled topics get it): incumbents fetched from
+    the session, improved, adopted back as external elites, over and over on many topics at once -- the proven HiGHS optima
+    of the drifted configs must come out exactly as without it."""
+    monkeypatch.setenv("KAO_CX_EAGER", "1")
+    g = load_golden(name)["topics"]
+    ots = [ko.topic_from_dict(e["topic"]) for e in g]
+    res = kao.solve([to_product_topic(t) for t in ots], seed=9, time_limit_s=30.0, stop_at_bound=1)
+    for e, ot, r in zip(g, ots, res):
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == r.objective == e["objective"], (ot.name, r.objective, e["objective"])
+        assert r.status == "OPTIMAL_PROVEN" and r.upper_bound == e["objective"]
+
+
+def test_solve_with_eager_cycles_on_the_wide_family(kao, ko, monkeypatch):
+    """The 400-instance wide family (RF 1..4 incl. RF changes, empty current slots, uneven racks, odd weights) in one call with
+    KAO-CX after every launch: unsupported topics are skipped, every answer is feasible and never above the HiGHS optimum,
+    and the optimum is still reached and proven on all but a few."""
+    monkeypatch.setenv("KAO_CX_EAGER", "1")
+    cases = load_golden("random_wide.json")["cases"]
+    ots = [ko.random_case_wide(c["seed"]) for c in cases]
+    res = kao.solve([to_product_topic(t) for t in ots], seed=31, restarts=32, iters_per_launch=256, time_limit_s=30.0, stop_at_bound=1)
+    n_opt = n_equal = n_proven = 0
+    for c, ot, r in zip(cases, ots, res):
+        if c["status"] == "infeasible":
+            assert r.status == "INFEASIBLE_PROVEN", c["seed"]
+            continue
+        n_opt += 1
+        obj, viol = ko.verify(ot, r.assignment)
+        assert viol[0] == 0 and obj == r.objective <= c["objective"], c["seed"]
+        n_equal += r.objective == c["objective"]
+        n_proven += r.status == "OPTIMAL_PROVEN"
+    assert n_equal >= n_opt - 2 and n_proven >= n_opt - 6, (n_opt, n_equal, n_proven)
