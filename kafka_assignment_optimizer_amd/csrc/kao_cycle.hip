@@ -4,8 +4,8 @@
 // every drifted topic whose P*RF is a multiple of B) the last improvements are cyclic exchanges over 4..10 partitions whose
 // intermediate states are all infeasible.  KAO-CX finds them by shortest paths instead of by chance:
 //   k_cx_edges   : two transfer graphs on the brokers -- F (a follower slot takes another broker: one replica unit moves),
-//                  S (leader and follower of one partition swap roles: one leader unit moves) -- cheapest slot per broker
-//                  pair by 64-bit atomicMin of (cost, slot);
+//                  S (leader and follower of one partition swap roles: one leader unit moves), L (the leader slot takes
+//                  another broker: both units move) -- cheapest slot per broker pair by 64-bit atomicMin of (cost, slot);
 //   k_cx_dist0   : edge keys -> cost matrices, slack node Z (brokers with room inside their band absorb / give a unit);
 //   k_cx_square  : min-plus squaring with the midpoint of every pair, three times: cheapest paths of <= 8 edges;
 //   k_cx_seeds   : for every partition every new row that replaces <= 2 replicas (one by a current replica) with any
@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +34,7 @@ namespace {
 constexpr int kCxInf = 1 << 17;
 constexpr int kCxBias = 1 << 16;
 constexpr int kCxLevels = 3;
+constexpr int kCxLayers = 3;      // 0 F (follower moves), 1 S (role swaps), 2 L (leader replacements)
 constexpr int kCxMaxEval = 512;
 constexpr int kCxMaxRF = 4;
 constexpr unsigned long long kNoEdge = ~0ull;
@@ -82,12 +84,28 @@ __device__ __forceinline__ bool cx_completes(const CxParams &q, const CxBase &b,
 
 // ---- edges: one wavefront per partition -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cx_edges(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack,
-                                                  unsigned long long *EF, unsigned long long *ES) {
+                                                  unsigned long long *EF, unsigned long long *ES, unsigned long long *EL) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= q.P) return;
     int row[kCxMaxRF];
     for (int k = 0; k < q.RF; ++k) row[k] = A[(size_t)p * q.RF + k];
     const uint16_t *c = cur + (size_t)p * q.rfc;
+    {   // leader replacement: slot 0 takes v
+        int base[kCxMaxRF]; int nb = 0;
+        for (int j = 1; j < q.RF; ++j) base[nb++] = row[j];
+        const CxBase cb = cx_base(q, rack, base, nb);
+        if (!cb.over && cb.ndef <= 1) {
+            const int u = row[0], wu = cx_wt(q, c, u, 0);
+            for (int v = lane; v < q.B; v += 64) {
+                bool in = false;
+                for (int j = 0; j < q.RF; ++j) in = in || row[j] == v;
+                if (in || !cx_completes(q, cb, rack[v])) continue;
+                const int cost = wu - cx_wt(q, c, v, 0);
+                const unsigned long long key = ((unsigned long long)(unsigned)(cost + kCxBias) << 32) | (unsigned)(p * q.RF);
+                atomicMin(&EL[(size_t)u * q.np + v], key);
+            }
+        }
+    }
     for (int k = 1; k < q.RF; ++k) {
         const int u = row[k];
         int base[kCxMaxRF]; int nb = 0;
@@ -190,7 +208,7 @@ __device__ __forceinline__ long long cx_wave_max(long long v) {
 }
 
 __global__ __launch_bounds__(256) void k_cx_seeds(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack,
-                                                  const int32_t *DF, const int32_t *DS, int2 *table) {
+                                                  const int32_t *DF, const int32_t *DS, const int32_t *DL, int2 *table) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= q.P) return;
     const int RF = q.RF;
@@ -252,19 +270,35 @@ __global__ __launch_bounds__(256) void k_cx_seeds(CxParams q, const uint16_t *A,
                 cR = m0 < m1 ? m0 : m1;
             }
             const int wfy = cx_wt(q, c, y, 1), wly = cx_wt(q, c, y, 0);
+            // one-replica seeds may also close their replica imbalance through L (option 1): free when y replaces the leader as
+            // leader, plus a swap path r -> y when the leader stays
+            const int cRL = nrm == 1 ? DL[(size_t)y * q.np + removed[0]] : 0;
             for (int li = 0; li < RF; ++li) {
-                int tot;
-                if (li < RF - 1) tot = wl_base[li] + wf_sum - cx_wt(q, c, base[li], 1) + wfy - w0 - cR - cl_base[li];
-                else tot = wly + wf_sum - w0 - cR - DS[(size_t)y * q.np + row[0]];
+                int tot, opt = 0;
+                if (li < RF - 1) {
+                    const int gain = wl_base[li] + wf_sum - cx_wt(q, c, base[li], 1) + wfy - w0;
+                    tot = gain - cR - cl_base[li];
+                    if (nrm == 1 && base[li] == row[0]) {
+                        const int alt = gain - cRL - DS[(size_t)removed[0] * q.np + y];
+                        if (alt > tot) { tot = alt; opt = 1; }
+                    }
+                } else {
+                    const int gain = wly + wf_sum - w0;
+                    tot = gain - cR - DS[(size_t)y * q.np + row[0]];
+                    if (nrm == 1 && removed[0] == row[0]) {
+                        const int alt = gain - cRL;
+                        if (alt > tot) { tot = alt; opt = 1; }
+                    }
+                }
                 if (tot > 0) {
-                    const long long key = ((long long)tot << 12) | (long long)(4095 - y);   // larger total, then lower y
+                    const long long key = ((long long)tot << 13) | ((long long)(4095 - y) << 1) | (long long)opt;   // larger total, then lower y
                     best[li] = key > best[li] ? key : best[li];
                 }
             }
         }
         for (int li = 0; li < RF; ++li) {
             const long long m = cx_wave_max(best[li]);
-            if (lane == 0) out[cfg0 + li] = m > 0 ? make_int2((int)(m >> 12), 4095 - (int)(m & 4095)) : make_int2(0, 0);
+            if (lane == 0) out[cfg0 + li] = m > 0 ? make_int2((int)(m >> 13), 4095 - (int)((m >> 1) & 4095) + 4096 * (int)(m & 1)) : make_int2(0, 0);
         }
     }
 }
@@ -301,17 +335,17 @@ struct Cx {
     kao_eval_plan *plan = nullptr;
     uint16_t *d_A = nullptr, *d_cur = nullptr; uint8_t *d_rack = nullptr;
     int32_t *d_cnt = nullptr;                       // c[B] | l[B]
-    unsigned long long *d_E[2] = {nullptr, nullptr};
-    int32_t *d_D[2][kCxLevels + 1] = {};
-    uint16_t *d_M[2][kCxLevels + 1] = {};
+    unsigned long long *d_E[kCxLayers] = {};
+    int32_t *d_D[kCxLayers][kCxLevels + 1] = {};
+    uint16_t *d_M[kCxLayers][kCxLevels + 1] = {};
     int2 *d_table = nullptr;
     uint16_t *d_cand = nullptr; int32_t *d_obj = nullptr, *d_viol = nullptr;
     int32_t *d_pq = nullptr; uint16_t *d_prow = nullptr; size_t patch_cap = 0;   // patches of the candidates being built
     // host images of the current round
     std::vector<uint16_t> A;
-    std::vector<unsigned long long> hE[2];
-    std::vector<int32_t> hD3[2];
-    std::vector<uint16_t> hM[2][kCxLevels + 1];
+    std::vector<unsigned long long> hE[kCxLayers];
+    std::vector<int32_t> hD3[kCxLayers];
+    std::vector<uint16_t> hM[kCxLayers][kCxLevels + 1];
     std::vector<int32_t> diag;
     std::vector<int2> table;
     bool have_paths = false;
@@ -319,7 +353,7 @@ struct Cx {
     ~Cx() {
         (void)hipFree(d_A); (void)hipFree(d_cur); (void)hipFree(d_rack); (void)hipFree(d_cnt); (void)hipFree(d_table);
         (void)hipFree(d_cand); (void)hipFree(d_obj); (void)hipFree(d_viol); (void)hipFree(d_pq); (void)hipFree(d_prow);
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < kCxLayers; ++l) {
             (void)hipFree(d_E[l]);
             for (int v = 0; v <= kCxLevels; ++v) { (void)hipFree(d_D[l][v]); (void)hipFree(d_M[l][v]); }
         }
@@ -348,7 +382,7 @@ struct Cx {
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_rack), (size_t)q.B));
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_cnt), (size_t)q.B * 8));
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_table), (size_t)q.P * q.ncfg * sizeof(int2)));
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < kCxLayers; ++l) {
             CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_E[l]), nn * 8));
             for (int v = 0; v <= kCxLevels; ++v) {
                 CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_D[l][v]), nn * 4));
@@ -374,18 +408,19 @@ struct Cx {
             }
         CX_TRY(hipMemcpyAsync(d_A, A.data(), slots * 2, hipMemcpyHostToDevice, stream));
         CX_TRY(hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
-        for (int l = 0; l < 2; ++l) CX_TRY(hipMemsetAsync(d_E[l], 0xFF, nn * 8, stream));
-        hipLaunchKernelGGL(k_cx_edges, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_E[0], d_E[1]);
+        for (int l = 0; l < kCxLayers; ++l) CX_TRY(hipMemsetAsync(d_E[l], 0xFF, nn * 8, stream));
+        hipLaunchKernelGGL(k_cx_edges, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_E[0], d_E[1], d_E[2]);
         const dim3 g0((q.np + 255) / 256, q.np);
         hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[0], d_cnt, q.rep_lo, q.rep_hi, d_D[0][0]);
         hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[1], d_cnt + q.B, q.lead_lo, q.lead_hi, d_D[1][0]);
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[2], d_cnt, INT_MAX, INT_MIN, d_D[2][0]);   // L: no slack edges
         const dim3 gs(q.np / 64, q.np / 64);
         for (int v = 1; v <= kCxLevels; ++v)
-            for (int l = 0; l < 2; ++l)
+            for (int l = 0; l < kCxLayers; ++l)
                 hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[l][v - 1], d_D[l][v], d_M[l][v]);
         CX_TRY(hipGetLastError());
-        diag.assign((size_t)2 * kCxLevels * q.B, 0);
-        for (int l = 0; l < 2; ++l)
+        diag.assign((size_t)kCxLayers * kCxLevels * q.B, 0);
+        for (int l = 0; l < kCxLayers; ++l)
             for (int v = 1; v <= kCxLevels; ++v)
                 CX_TRY(hipMemcpy2DAsync(&diag[((size_t)l * kCxLevels + (v - 1)) * q.B], 4, d_D[l][v], ((size_t)q.np + 1) * 4, 4, (size_t)q.B,
                                         hipMemcpyDeviceToHost, stream));
@@ -421,7 +456,7 @@ struct Cx {
     }
 
     int seeds() {
-        hipLaunchKernelGGL(k_cx_seeds, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_D[1][kCxLevels], d_table);
+        hipLaunchKernelGGL(k_cx_seeds, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_D[1][kCxLevels], d_D[2][kCxLevels], d_table);
         CX_TRY(hipGetLastError());
         table.resize((size_t)q.P * q.ncfg);
         CX_TRY(hipMemcpyAsync(table.data(), d_table, table.size() * sizeof(int2), hipMemcpyDeviceToHost, stream));
@@ -432,7 +467,7 @@ struct Cx {
     int fetch_paths() {
         if (have_paths) return KAO_OK;
         const size_t nn = (size_t)q.np * q.np;
-        for (int l = 0; l < 2; ++l) {
+        for (int l = 0; l < kCxLayers; ++l) {
             hE[l].resize(nn); hD3[l].resize(nn);
             CX_TRY(hipMemcpyAsync(hE[l].data(), d_E[l], nn * 8, hipMemcpyDeviceToHost, stream));
             CX_TRY(hipMemcpyAsync(hD3[l].data(), d_D[l][kCxLevels], nn * 4, hipMemcpyDeviceToHost, stream));
@@ -468,8 +503,8 @@ struct Cx {
             r.used.push_back(qq);
             const size_t o = r.rows.size();
             r.rows.insert(r.rows.end(), &A[(size_t)qq * q.RF], &A[(size_t)qq * q.RF] + q.RF);
-            if (layer == 0) r.rows[o + (size_t)j] = (uint16_t)d;
-            else std::swap(r.rows[o], r.rows[o + (size_t)j]);
+            if (layer == 1) std::swap(r.rows[o], r.rows[o + (size_t)j]);
+            else r.rows[o + (size_t)j] = (uint16_t)d;
         }
         return true;
     }
@@ -551,7 +586,7 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     const double tt1 = api_now_s();
     // ---- candidates ----
     std::vector<CxCand> cyc;
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < kCxLayers; ++l)
         for (int v = 1; v <= kCxLevels; ++v) {
             const int32_t *dg = &cx.diag[((size_t)l * kCxLevels + (v - 1)) * q.B];
             bool any = false;
@@ -602,13 +637,28 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
             CxReal r;
             if (cx.walk(r, layer, b, nodes)) push(std::move(r));
         } else {
-            const int p = cd.a;
+            const int p = cd.a, opt = cd.c >> 12, y = cd.c & 4095;
             int nr[kCxMaxRF];
-            cx.seed_row(p, cd.b, cd.c, nr);
+            cx.seed_row(p, cd.b, y, nr);
             const uint16_t *row = &cx.A[(size_t)p * q.RF];
             int Rm[kCxMaxRF] = {0, 0, 0, 0}, Ad[kCxMaxRF] = {0, 0, 0, 0}, nrm = 0, nad = 0;
             for (int k = 0; k < q.RF; ++k) { bool in = false; for (int j = 0; j < q.RF; ++j) in = in || nr[j] == row[k]; if (!in) Rm[nrm++] = row[k]; }
             for (int k = 0; k < q.RF; ++k) { bool in = false; for (int j = 0; j < q.RF; ++j) in = in || row[j] == nr[k]; if (!in) Ad[nad++] = nr[k]; }
+            if (opt) {   // replica imbalance closed through L (and the leader imbalance, when the leader stayed, through S)
+                CxReal r;
+                for (int k = 0; k < q.RF; ++k) r.rows.push_back((uint16_t)nr[k]);
+                r.used.push_back(p);
+                std::vector<int> nodes;
+                cx.path(2, Ad[0], Rm[0], kCxLevels, nodes);
+                bool good = cx.walk(r, 2, Ad[0], nodes);
+                if (good && nr[0] == row[0]) {
+                    nodes.clear();
+                    cx.path(1, Rm[0], Ad[0], kCxLevels, nodes);
+                    good = cx.walk(r, 1, Rm[0], nodes);
+                }
+                if (good) push(std::move(r));
+                continue;
+            }
             int orders[2][2] = {{Rm[0], nrm > 1 ? Rm[1] : 0}, {nrm > 1 ? Rm[1] : 0, Rm[0]}};
             int n_orders = nrm == 2 ? 2 : 1;
             if (nrm == 2) {
@@ -763,7 +813,7 @@ int kao_improve_cycles(const kao_topic *t, uint16_t *assignment, int32_t max_rou
 
 int kao_cycle_matrices(const kao_topic *t, const uint16_t *assignment, int32_t layer, int32_t level, int32_t *dist, int32_t *mid, uint32_t *slot) {
     using namespace kao;
-    if (!t || !assignment || !dist || layer < 0 || layer > 1 || level < 0 || level > kCxLevels) return api_fail(KAO_ERR_INVALID, "bad arguments");
+    if (!t || !assignment || !dist || layer < 0 || layer >= kCxLayers || level < 0 || level > kCxLevels) return api_fail(KAO_ERR_INVALID, "bad arguments");
     Cx cx;
     int rc = cx.open(t);
     if (rc) return rc;

@@ -9,6 +9,7 @@ One round, from a FEASIBLE assignment A of one topic (model: README.md:144-185):
   * two transfer graphs on the brokers plus a slack node Z = B:
       F: edge u -> v = "some follower slot holding u takes v instead" (one replica unit moves u -> v), cheapest slot per pair;
       S: edge u -> v = "a partition led by u with follower v swaps the two roles" (one leader unit moves u -> v);
+      L: edge u -> v = "a partition led by u takes v as its leader instead" (a replica unit AND a leader unit move u -> v);
       u -> Z when u may take one more (replica / leader) inside its band, Z -> v when v may give one up;
   * bounded-hop closures by three min-plus squarings (paths of <= 8 edges), with the midpoint of every pair;
   * a negative diagonal entry is an improving cyclic exchange by itself; otherwise SEEDS are enumerated -- for every partition
@@ -94,11 +95,19 @@ class Round:
         n, B, P, RF = self.n, self.B, self.P, self.RF
         EF = np.full((n, n), NO_EDGE, dtype=np.uint64)
         ES = np.full((n, n), NO_EDGE, dtype=np.uint64)
+        EL = np.full((n, n), NO_EDGE, dtype=np.uint64)
         allb = np.arange(B)
         for p in range(P):
             row = [int(x) for x in self.A[p]]
             inrow = np.zeros(B, dtype=bool)
             inrow[row] = True
+            ok = self._completions(row[1:])
+            if ok is not None:      # leader replacement: slot 0 takes v
+                ok = ok & ~inrow
+                cost = int(self.WL[p, row[0]]) - self.WL[p]
+                key = ((cost + CB).astype(np.uint64) << np.uint64(32)) | np.uint64(p * RF)
+                vs = allb[ok]
+                EL[row[0], vs] = np.minimum(EL[row[0], vs], key[ok])
             for k in range(1, RF):
                 u = row[k]
                 ok = self._completions([row[j] for j in range(RF) if j != k])
@@ -119,7 +128,7 @@ class Round:
         EF[self.Z, :B][self.c > self.bd["rep_lo"]] = zkey
         ES[:B, self.Z][self.l < self.bd["lead_hi"]] = zkey
         ES[self.Z, :B][self.l > self.bd["lead_lo"]] = zkey
-        self.EF, self.ES = EF, ES
+        self.EF, self.ES, self.EL = EF, ES, EL    # L has no slack edges: it moves two kinds of units at once
 
     @staticmethod
     def _dist0(E):
@@ -151,7 +160,10 @@ class Round:
         self.DS = [self._dist0(self.ES)]
         self.MF: List[Optional[np.ndarray]] = [None]
         self.MS: List[Optional[np.ndarray]] = [None]
+        self.DL = [self._dist0(self.EL)]
+        self.ML: List[Optional[np.ndarray]] = [None]
         for _ in range(LEVELS):
+            d, m = self._square(self.DL[-1]); self.DL.append(d); self.ML.append(m)
             d, m = self._square(self.DF[-1]); self.DF.append(d); self.MF.append(m)
             d, m = self._square(self.DS[-1]); self.DS.append(d); self.MS.append(m)
 
@@ -159,7 +171,7 @@ class Round:
     def cycle_candidates(self) -> List[Tuple[int, int, int, int]]:
         """(gain, layer, level, b) of the lowest level of each layer that has a negative diagonal entry."""
         out = []
-        for layer, Ds in ((0, self.DF), (1, self.DS)):
+        for layer, Ds in ((0, self.DF), (1, self.DS), (2, self.DL)):
             for lev in range(1, LEVELS + 1):
                 dg = np.diag(Ds[lev])[: self.B]
                 if (dg < 0).any():
@@ -172,10 +184,12 @@ class Round:
         return int(self.WL[p, row[0]] + sum(self.WF[p, b] for b in row[1:]))
 
     def seed_table(self) -> np.ndarray:
-        """[P, n_cfg, 2] int64: (total, y) of the best completion y of every configuration (total <= 0: none)."""
+        """[P, n_cfg, 2] int64: (total, y + 4096 * option) of the best completion y of every configuration (total <= 0: none).
+        option 1 = the replica imbalance of a one-replica seed is closed through L (leader replacements) instead of F: free when
+        y replaces the leader AS leader (both units travel back together), plus a swap path r -> y when the leader stays."""
         P, RF, B = self.P, self.RF, self.B
         rfc = self.cur.shape[1]
-        DF3, DS3 = self.DF[LEVELS], self.DS[LEVELS]
+        DF3, DS3, DL3 = self.DF[LEVELS], self.DS[LEVELS], self.DL[LEVELS]
         tab = np.zeros((P, n_cfg(RF, rfc), 2), dtype=np.int64)
         pairs = list(itertools.combinations(range(RF), 2))
         ys = np.arange(B)
@@ -214,9 +228,20 @@ class Round:
                         gain = self.WL[p] + wf_base - w0
                         cL = DS3[:B, row[0]]
                     tot = np.where(ok, gain - cR - cL, -(1 << 40))
+                    opt = np.zeros(B, dtype=np.int64)
+                    if len(removed) == 1:
+                        alt = None
+                        if li == RF - 1 and removed[0] == row[0]:
+                            alt = gain - DL3[:B, removed[0]]
+                        elif li < RF - 1 and base[li] == row[0]:
+                            alt = gain - DL3[:B, removed[0]] - DS3[removed[0], :B]
+                        if alt is not None:
+                            alt = np.where(ok, alt, -(1 << 40))
+                            opt = (alt > tot).astype(np.int64)      # F closure preferred on ties
+                            tot = np.maximum(tot, alt)
                     y = int(tot.argmax())          # lowest y among equal totals
                     if tot[y] > 0:
-                        tab[p, cfg0 + li] = (int(tot[y]), y)
+                        tab[p, cfg0 + li] = (int(tot[y]), y + 4096 * int(opt[y]))
 
             for rmi in range(RF):
                 complete((RF - 1) + rmi * RF, [row[j] for j in range(RF) if j != rmi], [row[rmi]])
@@ -270,7 +295,7 @@ class Round:
         return a + b[1:]
 
     def _walk(self, X, used: set, layer: int, pth: List[int]) -> bool:
-        E = self.EF if layer == 0 else self.ES
+        E = (self.EF, self.ES, self.EL)[layer]
         RF = self.RF
         for s, d in zip(pth[:-1], pth[1:]):
             if s == d or s == self.Z or d == self.Z:
@@ -282,15 +307,15 @@ class Round:
             if q in used:
                 return False
             used.add(q)
-            if layer == 0:
-                X[q, j] = d
-            else:
+            if layer == 1:
                 X[q, 0], X[q, j] = X[q, j], X[q, 0]
+            else:
+                X[q, j] = d
         return True
 
     def realise_cycle(self, cand):
         _, layer, lev, b = cand
-        mids = self.MF if layer == 0 else self.MS
+        mids = (self.MF, self.MS, self.ML)[layer]
         m = int(mids[lev][b, b])
         pth = self._path(mids, b, m, lev - 1) + self._path(mids, m, b, lev - 1)[1:]
         X = self.A.copy()
@@ -299,10 +324,19 @@ class Round:
 
     def realise_seed(self, cand):
         _, p, cfg, y = cand
+        opt, y = divmod(y, 4096)
         row = [int(x) for x in self.A[p]]
         new = self.seed_row(p, cfg, y)
         Rm = [b for b in row if b not in new]
         Ad = [b for b in new if b not in row]
+        if opt:
+            X = self.A.copy()
+            X[p] = new
+            used = {p}
+            good = self._walk(X, used, 2, self._path(self.ML, Ad[0], Rm[0], LEVELS))
+            if good and new[0] == row[0]:
+                good = self._walk(X, used, 1, self._path(self.MS, Rm[0], Ad[0], LEVELS))
+            return [(X, used)] if good else []
         DF3 = self.DF[LEVELS]
         if len(Rm) == 2:
             m0 = DF3[Ad[0], Rm[0]] + DF3[Ad[1], Rm[1]]

@@ -37,7 +37,7 @@ def _drifted(ko, B, R, P, rf=3, seed=1):
 def _same_matrices(kao, kc, pt, t, a):
     rd = kc.Round(t, a)
     B = t.n_brokers
-    for layer, (Ds, Ms, E) in enumerate(((rd.DF, rd.MF, rd.EF), (rd.DS, rd.MS, rd.ES))):
+    for layer, (Ds, Ms, E) in enumerate(((rd.DF, rd.MF, rd.EF), (rd.DS, rd.MS, rd.ES), (rd.DL, rd.ML, rd.EL))):
         for lev in range(4):
             d, m, s = kao.cycle_matrices(pt, a, layer, lev)
             assert np.array_equal(d, Ds[lev]), (layer, lev)

@@ -17,7 +17,7 @@ A = kp.port_search(t, 3, 0, launches, 512)["best"]
 print("start", kc.evaluate(t, A))
 rd = kc.Round(t, A)
 ok = True
-for layer, (Ds, Ms, E) in enumerate(((rd.DF, rd.MF, rd.EF), (rd.DS, rd.MS, rd.ES))):
+for layer, (Ds, Ms, E) in enumerate(((rd.DF, rd.MF, rd.EF), (rd.DS, rd.MS, rd.ES), (rd.DL, rd.ML, rd.EL))):
     for lev in range(4):
         d, m, s = kao.cycle_matrices(pt, A, layer, lev)
         same = np.array_equal(d, Ds[lev])
