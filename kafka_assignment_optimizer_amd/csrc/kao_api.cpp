@@ -1839,6 +1839,10 @@ struct SolveRun {
                 ++cx_gains;
             }
             if (fixpoint) cx_seen[(size_t)i] = keys[(size_t)i];
+            // a context holds ~90 B per broker pair on the device and as much on the host: keep a handful, not one per topic
+            int open = 0;
+            for (CycleCtx *c : cx_ctx) open += c != nullptr;
+            if (open > 8) { cycle_close(cx_ctx[(size_t)i]); cx_ctx[(size_t)i] = nullptr; }
         }
         all_done = check_done();
         return KAO_OK;
