@@ -834,7 +834,11 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
     if (n > (1 << 20)) return fail(KAO_ERR_INVALID, "at most 2^20 candidates per run (packed key id width)");
     HIP_TRY(hipSetDevice(p->device));
     if (n != p->map_n) {
-        const int cpb = p->cands_per_block;
+        // small batches of large candidates (KAO-CX: <= 513 assignments of up to 10^5 slots) spread over the compute units: one
+        // candidate per wavefront instead of eight, as soon as 32 per workgroup would leave most of the chip idle
+        int cpb = p->cands_per_block;
+        const int64_t fill = 4 * (int64_t)std::max(num_cu(p->device), 1);
+        if (n < fill * 8) cpb = (int)std::min<int64_t>(cpb, std::max<int64_t>(kWaves, ((n + fill - 1) / fill) * kWaves));
         const int nb = (int)((n + cpb - 1) / cpb);
         std::vector<int4> map((size_t)nb);
         for (int b = 0; b < nb; ++b) {
