@@ -4,8 +4,10 @@
 // every drifted topic whose P*RF is a multiple of B) the last improvements are cyclic exchanges over 4..10 partitions whose
 // intermediate states are all infeasible.  KAO-CX finds them by shortest paths instead of by chance:
 //   k_cx_edges   : two transfer graphs on the brokers -- F (a follower slot takes another broker: one replica unit moves),
-//                  S (leader and follower of one partition swap roles: one leader unit moves), L (the leader slot takes
-//                  another broker: both units move) -- cheapest slot per broker pair by 64-bit atomicMin of (cost, slot);
+//                  S (leader and follower of one partition swap roles: one leader unit moves) -- cheapest slot per broker
+//                  pair by 64-bit atomicMin of (cost, slot);
+//   k_cx_edges_l : L, generalised leader transfers (five variants of "the partition led by u gets leader v", each priced with
+//                  the F path that compensates its replica effect), built on the closure of F;
 //   k_cx_dist0   : edge keys -> cost matrices, slack node Z (brokers with room inside their band absorb / give a unit);
 //   k_cx_square  : min-plus squaring with the midpoint of every pair, three times: cheapest paths of <= 8 edges;
 //   k_cx_seeds   : for every partition every new row that replaces <= 2 replicas (one by a current replica) with any
@@ -84,28 +86,12 @@ __device__ __forceinline__ bool cx_completes(const CxParams &q, const CxBase &b,
 
 // ---- edges: one wavefront per partition -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cx_edges(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack,
-                                                  unsigned long long *EF, unsigned long long *ES, unsigned long long *EL) {
+                                                  unsigned long long *EF, unsigned long long *ES) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= q.P) return;
     int row[kCxMaxRF];
     for (int k = 0; k < q.RF; ++k) row[k] = A[(size_t)p * q.RF + k];
     const uint16_t *c = cur + (size_t)p * q.rfc;
-    {   // leader replacement: slot 0 takes v
-        int base[kCxMaxRF]; int nb = 0;
-        for (int j = 1; j < q.RF; ++j) base[nb++] = row[j];
-        const CxBase cb = cx_base(q, rack, base, nb);
-        if (!cb.over && cb.ndef <= 1) {
-            const int u = row[0], wu = cx_wt(q, c, u, 0);
-            for (int v = lane; v < q.B; v += 64) {
-                bool in = false;
-                for (int j = 0; j < q.RF; ++j) in = in || row[j] == v;
-                if (in || !cx_completes(q, cb, rack[v])) continue;
-                const int cost = wu - cx_wt(q, c, v, 0);
-                const unsigned long long key = ((unsigned long long)(unsigned)(cost + kCxBias) << 32) | (unsigned)(p * q.RF);
-                atomicMin(&EL[(size_t)u * q.np + v], key);
-            }
-        }
-    }
     for (int k = 1; k < q.RF; ++k) {
         const int u = row[k];
         int base[kCxMaxRF]; int nb = 0;
@@ -131,8 +117,131 @@ __global__ __launch_bounds__(256) void k_cx_edges(CxParams q, const uint16_t *A,
     }
 }
 
+// ---- generalised leader-transfer edges (layer L), built on the level-3 closure of F: one wavefront per partition ------------
+// Edge u -> v = "the partition led by u gets leader v"; nominally a replica unit and a leader unit move u -> v.  Variants whose
+// replica effect differs carry the cost of the compensating F path:
+//   0 plain   : v replaces u                                                   1 demote : v enters, u stays as follower, slot k
+//   2 promote : slot k becomes leader, u leaves, y enters      (+ DF[y][v])               leaves            (+ DF[u][row[k]])
+//   3 swap    : slot k becomes leader, u follower              (+ DF[u][v])    4 double : v replaces u and slot k takes y, one of
+//                                                                                         them a current replica (+ DF[y][row[k]])
+// key = (cost + 2^16) << 44 | p << 20 | variant << 16 | k << 12 | y.  `plain_only`: F has improving cycles, nothing is priced on it.
+__device__ __forceinline__ unsigned long long cx_lkey(int cost, int p, int var, int k, int y) {
+    return ((unsigned long long)(unsigned)(cost + kCxBias) << 44) | ((unsigned long long)(unsigned)p << 20) | ((unsigned long long)var << 16) |
+           ((unsigned long long)k << 12) | (unsigned long long)y;
+}
+__device__ __forceinline__ long long cx_wave_min(long long v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack, const int32_t *DF,
+                                                    int plain_only, unsigned long long *EL) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= q.P) return;
+    const int RF = q.RF;
+    int row[kCxMaxRF];
+    for (int k = 0; k < RF; ++k) row[k] = A[(size_t)p * RF + k];
+    const uint16_t *c = cur + (size_t)p * q.rfc;
+    const int u = row[0];
+    int w0 = cx_wt(q, c, u, 0);
+    for (int k = 1; k < RF; ++k) w0 += cx_wt(q, c, row[k], 1);
+    const int wlu = cx_wt(q, c, u, 0), wfu = cx_wt(q, c, u, 1);
+    auto inrow = [&](int x) { bool in = false; for (int j = 0; j < RF; ++j) in = in || row[j] == x; return in; };
+    {   // 0 plain
+        int base[kCxMaxRF]; int nb = 0;
+        for (int j = 1; j < RF; ++j) base[nb++] = row[j];
+        const CxBase cb = cx_base(q, rack, base, nb);
+        if (!cb.over && cb.ndef <= 1)
+            for (int v = lane; v < q.B; v += 64) {
+                if (inrow(v) || !cx_completes(q, cb, rack[v])) continue;
+                const int cost = wlu - cx_wt(q, c, v, 0);
+                if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 0, 0, 0));
+            }
+    }
+    if (plain_only) return;
+    for (int k = 1; k < RF; ++k) {
+        const int b = row[k];
+        int others[kCxMaxRF], no = 0, osum = 0;
+        for (int j = 1; j < RF; ++j) if (j != k) { others[no++] = row[j]; osum += cx_wt(q, c, row[j], 1); }
+        {   // 1 demote: row' = (v; u, others)
+            int base[kCxMaxRF]; int nb = 0;
+            base[nb++] = u;
+            for (int j = 0; j < no; ++j) base[nb++] = others[j];
+            const CxBase cb = cx_base(q, rack, base, nb);
+            const int comp = DF[(size_t)u * q.np + b];
+            if (!cb.over && cb.ndef <= 1 && comp < kCxInf)
+                for (int v = lane; v < q.B; v += 64) {
+                    if (inrow(v) || !cx_completes(q, cb, rack[v])) continue;
+                    const int cost = w0 - (cx_wt(q, c, v, 0) + wfu + osum) + comp;
+                    if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 1, k, 0));
+                }
+        }
+        {   // 2 promote: v = row[k]; row' = (v; y, others), best y
+            int base[kCxMaxRF]; int nb = 0;
+            base[nb++] = b;
+            for (int j = 0; j < no; ++j) base[nb++] = others[j];
+            const CxBase cb = cx_base(q, rack, base, nb);
+            long long best = LLONG_MAX;
+            if (!cb.over && cb.ndef <= 1) {
+                const int wlv = cx_wt(q, c, b, 0);
+                for (int y = lane; y < q.B; y += 64) {
+                    if (inrow(y) || !cx_completes(q, cb, rack[y])) continue;
+                    const long long cost = (long long)w0 - (wlv + cx_wt(q, c, y, 1) + osum) + DF[(size_t)y * q.np + b];
+                    const long long key = (cost + (1ll << 30)) * 4096 + y;
+                    best = key < best ? key : best;
+                }
+            }
+            best = cx_wave_min(best);
+            if (lane == 0 && best != LLONG_MAX) {
+                const long long cost = best / 4096 - (1ll << 30);
+                if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + b], cx_lkey((int)cost, p, 2, k, (int)(best % 4096)));
+            }
+        }
+        if (lane == 0) {   // 3 swap
+            const int cost = wlu + cx_wt(q, c, b, 1) - cx_wt(q, c, b, 0) - wfu + DF[(size_t)u * q.np + b];
+            if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + b], cx_lkey(cost, p, 3, k, 0));
+        }
+        // 4 double: new leader v (not in the row) and slot k takes y; v or y is a current replica i of the partition
+        for (int ii = 0; ii < q.rfc; ++ii) {
+            const int i = c[ii];
+            if (i >= q.B || inrow(i)) continue;
+            int base[kCxMaxRF]; int nb = 0;
+            for (int j = 0; j < no; ++j) base[nb++] = others[j];
+            base[nb++] = i;
+            const CxBase cb = cx_base(q, rack, base, nb);
+            if (cb.over || cb.ndef > 1) continue;
+            const int compi = DF[(size_t)i * q.np + b];
+            if (compi < kCxInf) {   // (a) y = i, any v
+                const int wfi = cx_wt(q, c, i, 1);
+                for (int v = lane; v < q.B; v += 64) {
+                    if (inrow(v) || v == i || !cx_completes(q, cb, rack[v])) continue;
+                    const int cost = w0 - (cx_wt(q, c, v, 0) + wfi + osum) + compi;
+                    if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 4, k, i));
+                }
+            }
+            {   // (b) v = i, best y
+                long long best = LLONG_MAX;
+                const int wli = cx_wt(q, c, i, 0);
+                for (int y = lane; y < q.B; y += 64) {
+                    if (inrow(y) || y == i || !cx_completes(q, cb, rack[y])) continue;
+                    const long long cost = (long long)w0 - (wli + cx_wt(q, c, y, 1) + osum) + DF[(size_t)y * q.np + b];
+                    const long long key = (cost + (1ll << 30)) * 4096 + y;
+                    best = key < best ? key : best;
+                }
+                best = cx_wave_min(best);
+                if (lane == 0 && best != LLONG_MAX) {
+                    const long long cost = best / 4096 - (1ll << 30);
+                    if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + i], cx_lkey((int)cost, p, 4, k, (int)(best % 4096)));
+                }
+            }
+        }
+    }
+}
+
 // ---- edge keys -> level-0 cost matrix (with the slack node) -----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cx_dist0(CxParams q, const unsigned long long *E, const int32_t *cnt, int lo, int hi, int32_t *D) {
+__global__ __launch_bounds__(256) void k_cx_dist0(CxParams q, const unsigned long long *E, const int32_t *cnt, int lo, int hi, int shift, int32_t *D) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= q.np) return;
     int d = kCxInf;
@@ -142,7 +251,7 @@ __global__ __launch_bounds__(256) void k_cx_dist0(CxParams q, const unsigned lon
         else if (i == q.B) d = cnt[j] > lo ? 0 : kCxInf;
         else {
             const unsigned long long key = E[(size_t)i * q.np + j];
-            d = key == kNoEdge ? kCxInf : (int)(key >> 32) - kCxBias;
+            d = key == kNoEdge ? kCxInf : (int)(key >> shift) - kCxBias;
         }
     }
     D[(size_t)i * q.np + j] = d;
@@ -409,21 +518,34 @@ struct Cx {
         CX_TRY(hipMemcpyAsync(d_A, A.data(), slots * 2, hipMemcpyHostToDevice, stream));
         CX_TRY(hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
         for (int l = 0; l < kCxLayers; ++l) CX_TRY(hipMemsetAsync(d_E[l], 0xFF, nn * 8, stream));
-        hipLaunchKernelGGL(k_cx_edges, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_E[0], d_E[1], d_E[2]);
+        hipLaunchKernelGGL(k_cx_edges, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_E[0], d_E[1]);
         const dim3 g0((q.np + 255) / 256, q.np);
-        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[0], d_cnt, q.rep_lo, q.rep_hi, d_D[0][0]);
-        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[1], d_cnt + q.B, q.lead_lo, q.lead_hi, d_D[1][0]);
-        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[2], d_cnt, INT_MAX, INT_MIN, d_D[2][0]);   // L: no slack edges
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[0], d_cnt, q.rep_lo, q.rep_hi, 32, d_D[0][0]);
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[1], d_cnt + q.B, q.lead_lo, q.lead_hi, 32, d_D[1][0]);
         const dim3 gs(q.np / 64, q.np / 64);
         for (int v = 1; v <= kCxLevels; ++v)
-            for (int l = 0; l < kCxLayers; ++l)
+            for (int l = 0; l < 2; ++l)
                 hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[l][v - 1], d_D[l][v], d_M[l][v]);
         CX_TRY(hipGetLastError());
         diag.assign((size_t)kCxLayers * kCxLevels * q.B, 0);
-        for (int l = 0; l < kCxLayers; ++l)
+        auto fetch_diag = [&](int l) -> int {
             for (int v = 1; v <= kCxLevels; ++v)
                 CX_TRY(hipMemcpy2DAsync(&diag[((size_t)l * kCxLevels + (v - 1)) * q.B], 4, d_D[l][v], ((size_t)q.np + 1) * 4, 4, (size_t)q.B,
                                         hipMemcpyDeviceToHost, stream));
+            return KAO_OK;
+        };
+        int rc;
+        if ((rc = fetch_diag(0)) || (rc = fetch_diag(1))) return rc;
+        CX_TRY(hipStreamSynchronize(stream));
+        // the L graph prices its compensations on the F closure: only when F has no improving cycle of its own
+        int f_neg = 0;
+        for (size_t i = 0; i < (size_t)kCxLevels * q.B; ++i) f_neg |= diag[i] < 0;
+        hipLaunchKernelGGL(k_cx_edges_l, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], f_neg, d_E[2]);
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[2], d_cnt, INT_MAX, INT_MIN, 44, d_D[2][0]);   // L: no slack edges
+        for (int v = 1; v <= kCxLevels; ++v)
+            hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[2][v - 1], d_D[2][v], d_M[2][v]);
+        CX_TRY(hipGetLastError());
+        if ((rc = fetch_diag(2))) return rc;
         CX_TRY(hipStreamSynchronize(stream));
         have_paths = false;
         return KAO_OK;
@@ -497,6 +619,28 @@ struct Cx {
             if (s0 == d || s0 == q.B || d == q.B) continue;
             const unsigned long long key = hE[layer][(size_t)s0 * q.np + d];
             if (key == kNoEdge) return false;
+            if (layer == 2) {   // generalised leader transfer: the partition's row changes, then the compensating F path
+                const unsigned long long pay = key & ((1ull << 44) - 1);
+                const int qq = (int)(pay >> 20), var = (int)((pay >> 16) & 15), k = (int)((pay >> 12) & 15), y = (int)(pay & 4095);
+                if (std::find(r.used.begin(), r.used.end(), qq) != r.used.end()) return false;
+                r.used.push_back(qq);
+                const size_t o = r.rows.size();
+                const uint16_t *row = &A[(size_t)qq * q.RF];
+                r.rows.insert(r.rows.end(), row, row + q.RF);
+                const int u = row[0];
+                int c0 = -1, c1 = -1;
+                if (var == 0) r.rows[o] = (uint16_t)d;
+                else if (var == 1) { c0 = u; c1 = row[k]; r.rows[o] = (uint16_t)d; r.rows[o + (size_t)k] = (uint16_t)u; }
+                else if (var == 2) { c0 = y; c1 = d; r.rows[o] = (uint16_t)d; r.rows[o + (size_t)k] = (uint16_t)y; }
+                else if (var == 3) { c0 = u; c1 = d; r.rows[o] = row[k]; r.rows[o + (size_t)k] = (uint16_t)u; }
+                else { c0 = y; c1 = row[k]; r.rows[o] = (uint16_t)d; r.rows[o + (size_t)k] = (uint16_t)y; }
+                if (c0 >= 0 && c0 != c1) {
+                    std::vector<int> comp;
+                    path(0, c0, c1, kCxLevels, comp);
+                    if (!walk(r, 0, c0, comp)) return false;
+                }
+                continue;
+            }
             const unsigned slot = (unsigned)(key & 0xFFFFFFFFu);
             const int qq = (int)(slot / (unsigned)q.RF), j = (int)(slot % (unsigned)q.RF);
             if (std::find(r.used.begin(), r.used.end(), qq) != r.used.end()) return false;

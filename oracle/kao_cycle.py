@@ -9,12 +9,16 @@ One round, from a FEASIBLE assignment A of one topic (model: README.md:144-185):
   * two transfer graphs on the brokers plus a slack node Z = B:
       F: edge u -> v = "some follower slot holding u takes v instead" (one replica unit moves u -> v), cheapest slot per pair;
       S: edge u -> v = "a partition led by u with follower v swaps the two roles" (one leader unit moves u -> v);
-      L: edge u -> v = "a partition led by u takes v as its leader instead" (a replica unit AND a leader unit move u -> v);
+      L: edge u -> v = "a partition led by u gets leader v" -- nominally a replica unit AND a leader unit move u -> v; five
+         variants (plain replacement; v enters and u stays as follower while another follower leaves; a follower is promoted
+         and u leaves; role swap; replacement plus one follower replaced), each carrying the cost of the F path that
+         compensates the difference between its replica effect and u -> v -- built AFTER the F closure;
       u -> Z when u may take one more (replica / leader) inside its band, Z -> v when v may give one up;
   * bounded-hop closures by three min-plus squarings (paths of <= 8 edges), with the midpoint of every pair;
   * a negative diagonal entry is an improving cyclic exchange by itself; otherwise SEEDS are enumerated -- for every partition
     every new row that replaces at most two replicas (one of them by a current replica of the partition) and picks any
-    leader -- and priced as  gain(seed) - cheapest closure of its replica imbalance (F) - of its leader imbalance (S);
+    leader -- and priced as  gain(seed) - cheapest closure of its replica imbalance (F) - of its leader imbalance (S), or of both
+    at once through L;
   * candidates are realised (paths unrolled into slot changes, a partition may be used once), evaluated exactly, and the
     best one -- or a merge of partition-disjoint ones -- becomes the next assignment.
 """
@@ -101,13 +105,6 @@ class Round:
             row = [int(x) for x in self.A[p]]
             inrow = np.zeros(B, dtype=bool)
             inrow[row] = True
-            ok = self._completions(row[1:])
-            if ok is not None:      # leader replacement: slot 0 takes v
-                ok = ok & ~inrow
-                cost = int(self.WL[p, row[0]]) - self.WL[p]
-                key = ((cost + CB).astype(np.uint64) << np.uint64(32)) | np.uint64(p * RF)
-                vs = allb[ok]
-                EL[row[0], vs] = np.minimum(EL[row[0], vs], key[ok])
             for k in range(1, RF):
                 u = row[k]
                 ok = self._completions([row[j] for j in range(RF) if j != k])
@@ -160,13 +157,101 @@ class Round:
         self.DS = [self._dist0(self.ES)]
         self.MF: List[Optional[np.ndarray]] = [None]
         self.MS: List[Optional[np.ndarray]] = [None]
-        self.DL = [self._dist0(self.EL)]
+        for _ in range(LEVELS):
+            d, m = self._square(self.DF[-1]); self.DF.append(d); self.MF.append(m)
+            d, m = self._square(self.DS[-1]); self.DS.append(d); self.MS.append(m)
+        self._edges_L()
+        self.DL = [self._dist0L(self.EL)]
         self.ML: List[Optional[np.ndarray]] = [None]
         for _ in range(LEVELS):
             d, m = self._square(self.DL[-1]); self.DL.append(d); self.ML.append(m)
-            d, m = self._square(self.DF[-1]); self.DF.append(d); self.MF.append(m)
-            d, m = self._square(self.DS[-1]); self.DS.append(d); self.MS.append(m)
 
+    @staticmethod
+    def _dist0L(E):
+        D = np.where(E == np.uint64(NO_EDGE), CINF, (E >> np.uint64(44)).astype(np.int64) - CB).astype(np.int64)
+        np.fill_diagonal(D, 0)
+        return D
+
+    def _edges_L(self):
+        """Generalised leader-transfer edges u -> v (the leader unit AND, nominally, a replica unit move u -> v); variants whose
+        replica effect differs from u -> v carry the cost of the compensating F path (level-3 closure):
+          0 plain   : v replaces u as leader
+          1 demote  : v enters as leader, u stays as follower, follower slot k leaves        (+ F path u -> row[k])
+          2 promote : follower slot k becomes leader, u leaves, y enters as follower           (+ F path y -> v)
+          3 swap    : follower slot k becomes leader, u becomes follower                       (+ F path u -> v)
+          4 double  : v replaces u as leader and follower slot k takes y (v or y a current replica of the partition) (+ F path y -> row[k])
+        key = (cost + CB) << 44 | p << 20 | variant << 16 | k << 12 | y"""
+        n, B, P, RF = self.n, self.B, self.P, self.RF
+        EL = np.full((n, n), NO_EDGE, dtype=np.uint64)
+        DF3 = self.DF[LEVELS]
+        allb = np.arange(B)
+        neg = any((np.diag(self.DF[lev])[:B] < 0).any() for lev in range(1, LEVELS + 1))
+        def put(u, vs, cost, payload):
+            cost = np.asarray(cost, dtype=np.int64)
+            good = cost < CINF // 2
+            if not good.any(): return
+            key = ((cost + CB).astype(np.uint64) << np.uint64(44)) | payload.astype(np.uint64)
+            vs = np.asarray(vs)[good]; key = key[good]
+            EL[u, vs] = np.minimum(EL[u, vs], key)
+        for p in range(P):
+            row = [int(x) for x in self.A[p]]
+            u = row[0]
+            inrow = np.zeros(B, dtype=bool); inrow[row] = True
+            w0 = self.row_weight(p, row)
+            wl, wf = self.WL[p], self.WF[p]
+            pb = np.uint64(p << 20)
+            I = [int(b) for b in self.cur[p] if b < B and b not in row]
+            fsum = sum(int(wf[b]) for b in row[1:])
+            # 0 plain
+            ok = self._completions(row[1:])
+            if ok is not None:
+                ok = ok & ~inrow
+                vs = allb[ok]
+                put(u, vs, int(wl[u]) - wl[vs], np.full(len(vs), int(pb), dtype=np.uint64))
+            if neg:
+                continue          # compensations are only priced on a closure without negative cycles
+            for k in range(1, RF):
+                b = row[k]; others = [row[j] for j in range(1, RF) if j != k]
+                osum = sum(int(wf[x]) for x in others)
+                # 1 demote: row' = (v; u, others)
+                ok = self._completions([u] + others)
+                if ok is not None and DF3[u, b] < CINF:
+                    ok = ok & ~inrow
+                    vs = allb[ok]
+                    cost = w0 - (wl[vs] + int(wf[u]) + osum) + int(DF3[u, b])
+                    put(u, vs, cost, np.full(len(vs), int(pb) | (1 << 16) | (k << 12), dtype=np.uint64))
+                # 2 promote: v = row[k]; row' = (v; y, others)
+                v = b
+                ok = self._completions([v] + others)
+                if ok is not None:
+                    ok = ok & ~inrow
+                    if ok.any():
+                        cy = np.where(ok, w0 - (int(wl[v]) + wf + osum) + DF3[:B, v], 1 << 40)
+                        y = int(cy.argmin())
+                        put(u, [v], [int(cy[y])], np.array([int(pb) | (2 << 16) | (k << 12) | y], dtype=np.uint64))
+                # 3 swap
+                cs = int(wl[u] + wf[v] - wl[v] - wf[u])
+                put(u, [v], [cs + int(DF3[u, v])], np.array([int(pb) | (3 << 16) | (k << 12)], dtype=np.uint64))
+                # 4 double: new leader v (not in row) and follower slot k -> y; at least one of v, y a current replica
+                for i in I:
+                    # (a) y = i fixed, v generic
+                    okv = self._completions(others + [i])
+                    if okv is not None and DF3[i, b] < CINF:
+                        okv = okv & ~inrow
+                        okv[i] = False
+                        vs = allb[okv]
+                        cost = w0 - (wl[vs] + int(wf[i]) + osum) + int(DF3[i, b])
+                        put(u, vs, cost, np.full(len(vs), int(pb) | (4 << 16) | (k << 12) | i, dtype=np.uint64))
+                    # (b) v = i fixed, y generic
+                    oky = self._completions(others + [i])
+                    if oky is not None:
+                        oky = oky & ~inrow
+                        oky[i] = False
+                        if oky.any():
+                            cy = np.where(oky, w0 - (int(wl[i]) + wf + osum) + DF3[:B, b], 1 << 40)
+                            y = int(cy.argmin())
+                            put(u, [i], [int(cy[y])], np.array([int(pb) | (4 << 16) | (k << 12) | y], dtype=np.uint64))
+        self.EL = EL
     # ---- candidates ----
     def cycle_candidates(self) -> List[Tuple[int, int, int, int]]:
         """(gain, layer, level, b) of the lowest level of each layer that has a negative diagonal entry."""
@@ -303,6 +388,29 @@ class Round:
             key = int(E[s, d])
             if key == NO_EDGE:
                 return False
+            if layer == 2:
+                pay = key & ((1 << 44) - 1)
+                q, var, k, y = pay >> 20, (pay >> 16) & 15, (pay >> 12) & 15, pay & 4095
+                if q in used:
+                    return False
+                used.add(q)
+                row = [int(x) for x in self.A[q]]
+                u = row[0]
+                comp = None
+                if var == 0:
+                    X[q, 0] = d
+                elif var == 1:
+                    b = row[k]; X[q, 0] = d; X[q, k] = u; comp = (u, b)
+                elif var == 2:
+                    X[q, 0] = d; X[q, k] = y; comp = (y, d)
+                elif var == 3:
+                    X[q, 0], X[q, k] = row[k], u; comp = (u, d)
+                else:
+                    b = row[k]; X[q, 0] = d; X[q, k] = y; comp = (y, b)
+                if comp is not None and comp[0] != comp[1]:
+                    if not self._walk(X, used, 0, self._path(self.MF, comp[0], comp[1], LEVELS)):
+                        return False
+                continue
             q, j = divmod(key & 0xFFFFFFFF, RF)
             if q in used:
                 return False
