@@ -562,6 +562,8 @@ struct kao_session {
     std::vector<char> dual_ok;           // per topic: within K-bound's limits
     std::vector<int64_t> h_dual_target;  // staging for kao_session_bound_step
     std::vector<int32_t> h_dual_ids;
+    std::vector<int2> h_wide_map;        // sliced K-bound: {topic, slice} per workgroup (staging, like h_dual_ids)
+    uint64_t wide_ctl_i32 = 0, wide_map_i32 = 0;   // int32 offsets of the control blocks / the map inside d_dual
     std::vector<int32_t> dual_flags, dual_iters;
     int total_restarts = 0;
     // Topics are bucketed by LDS footprint into launch groups (a 3000-partition topic must not impose its LDS carve
@@ -1087,7 +1089,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     std::vector<uint32_t> cur_pool, bw_pool, bwd_pool; std::vector<uint16_t> ext_pool, curd_pool, int_pool; std::vector<int32_t> rsz_pool;
     uint64_t price_i32 = 0;
     std::vector<uint8_t> rackof_pool;
-    uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0, dual_i32 = 0;
+    uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0, dual_i32 = 0, wide_slices = 0;
     s->topic_global.assign((size_t)n_topics, 0);
     for (int t = 0; t < n_topics; ++t) s->any_bw |= topics[t].broker_w || topics[t].broker_wl;
     int restart_base = 0;
@@ -1136,6 +1138,9 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         dual_i32 = (dual_i32 + 1) & ~(uint64_t)1;  // the level-control words are 64-bit
         d.dual_off = (uint32_t)dual_i32;
         dual_i32 += 6 * (uint64_t)d.B + 3 * kRackTab + 8;
+        d.cnt_off = (uint32_t)dual_i32;             // counters of the sliced K-bound live in the same pool (zeroed with it)
+        dual_i32 += 2 * (uint64_t)d.B + kRackTab;
+        wide_slices += (uint64_t)(d.P + 63) / 64;
         s->dual_ok.push_back(dual_supported(&topics[t]) ? 1 : 0);
         // algorithmic bytes: full evaluation = 2*RF*P + 2*rf_cur*P + B per candidate
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
@@ -1228,6 +1233,10 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->rb_viol_off = align_up((size_t)n_topics * 8 + 16, 16);
     s->rb_assign_off = s->rb_viol_off + (size_t)n_topics * 32;
     s->readback_bytes = s->rb_assign_off + win_u16 * 2;
+    // behind the per-topic blocks: control blocks (8 x int64 per topic) and the workgroup map of the sliced K-bound
+    dual_i32 = (dual_i32 + 1) & ~(uint64_t)1;
+    s->wide_ctl_i32 = dual_i32; dual_i32 += 16 * (uint64_t)n_topics;
+    s->wide_map_i32 = dual_i32; dual_i32 += 2 * wide_slices;
     const size_t dual_b = align_up(dual_i32 * 4), dtarget_b = align_up((size_t)n_topics * 8), dids_b = align_up((size_t)n_topics * 4);
     s->dual_rb_bytes = (size_t)n_topics * 24;
     s->price_half_i32 = align_up(price_i32 * 4) / 4;
@@ -1470,8 +1479,26 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     s->price_write_last = wh;
     // lanes own partitions, wavefronts own racks when the pools are rebuilt: enough wavefronts for either, at most 16
     const int waves = std::min(16, std::max({1, (maxP + 63) / 64, std::min(maxR, 8)}));
+    // topics beyond a few thousand partitions: one iteration per launch, the partitions sliced over several workgroups
+    // (k_bound_step); a launch that holds such a topic runs all its topics that way.  KAO_BOUND_CHUNK = partitions per
+    // slice (test hook: small values slice small topics)
+    int chunk = maxP > 2048 ? 512 : 0;
+    if (const char *e = std::getenv("KAO_BOUND_CHUNK")) chunk = std::max(0, std::atoi(e)) / 64 * 64;
     HIP_TRY(hipEventRecord(s->ev_bound0, s->stream_bound));
-    launch_bound(bp, (int)s->h_dual_ids.size(), waves, s->stream_bound);
+    if (chunk > 0) {
+        s->h_wide_map.clear();
+        for (int t : s->h_dual_ids)
+            for (int sl = 0, n = (s->pts[(size_t)t].d.P + chunk - 1) / chunk; sl < n; ++sl) s->h_wide_map.push_back(make_int2(t, sl));
+        BoundWide wd{};
+        wd.map = reinterpret_cast<const int2 *>(s->d_dual + s->wide_map_i32);
+        wd.cnt_pool = s->d_dual;
+        wd.ctl = reinterpret_cast<long long *>(s->d_dual + s->wide_ctl_i32);
+        wd.chunk = chunk;
+        HIP_TRY(hipMemcpyAsync(s->d_dual + s->wide_map_i32, s->h_wide_map.data(), s->h_wide_map.size() * sizeof(int2), hipMemcpyHostToDevice,
+                               s->stream_bound));
+        launch_bound_wide(bp, wd, (int)s->h_dual_ids.size(), (int)s->h_wide_map.size(), 16, s->stream_bound);
+    } else
+        launch_bound(bp, (int)s->h_dual_ids.size(), waves, s->stream_bound);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_bound1, s->stream_bound));
     s->bound_inflight = true;

@@ -56,7 +56,8 @@ struct TopicDev {
     int32_t has_bw;              // 1 = the topic carries broker weights (kao_topic.broker_w / broker_wl)
     uint32_t bw_off;             // bw_pool  : packed bw | bwl << 16 per INTERNAL index (u32[Bx])
     uint32_t bwd_off;            // bwd_pool : the same per DENSE index (u32[B]) for K-eval
-    int32_t pad_[3];
+    uint32_t cnt_off;            // cnt_pool : NR[B] NL[B] NK[kRackTab] of the sliced K-bound (k_bound_step), zero between steps
+    int32_t pad_[2];
 };
 
 struct SearchParams {
@@ -121,6 +122,14 @@ struct BoundPools {
     int32_t export_prices;       // 1 = the multipliers of the record dual value, 2 = the last iterate, 0 = no export
 };
 
+// K-bound on several workgroups per topic (k_bound_step: one iteration per launch, partitions sliced over workgroups)
+struct BoundWide {
+    const int2 *map;             // per workgroup: {topic, slice}
+    int32_t *cnt_pool;           // subproblem counts meeting in HBM, see TopicDev::cnt_off
+    long long *ctl;              // [n_topics][8] control block: value sum, ticket, bad, stop (see kao_bound.hip)
+    int32_t chunk;               // partitions per slice (a multiple of 64)
+};
+
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4, bool bw = false);
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne = 4);
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream);
@@ -135,6 +144,9 @@ void launch_adopt_global(unsigned long long *keys, const unsigned long long *glo
 // K-bound: Lagrangian dual bound, one workgroup (`waves` wavefronts) per listed topic
 size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds);
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream);
+// the same iteration as a sequence of launches: begin, pools.iters x step, the probes, finish (n_blocks = all slices of the
+// n_topics listed topics)
+void launch_bound_wide(const BoundPools &pools, const BoundWide &wide, int n_topics, int n_blocks, int waves, void *stream);
 
 // canonical tie-break on the device (kao_canonicalize): one wavefront, assignment words in global memory
 size_t canon_lds_bytes(int maxBx);

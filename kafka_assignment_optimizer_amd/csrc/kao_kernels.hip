@@ -18,6 +18,7 @@
 // dense contraction).  The scalar CPU restatement used by the tests is oracle/kao_port.c.
 #include <hip/hip_runtime.h>
 
+#include "kao_device.h"
 #include "kao_internal.h"
 
 namespace kao {
@@ -38,35 +39,6 @@ __device__ __forceinline__ int band(int c, int lo, int hi) { return max(c - hi, 
 // band(c+1)-band(c) and band(c-1)-band(c)
 __device__ __forceinline__ int dinc(int c, int lo, int hi) { return (int)(c >= hi) - (int)(c < lo); }
 __device__ __forceinline__ int ddec(int c, int lo, int hi) { return (int)(c <= lo) - (int)(c > hi); }
-
-// Wavefront min (all 64 lanes active): butterfly inside each row of 16 with four fused v_min_u32_dpp
-// (quad_perm xor1, xor2, row_half_mirror, row_mirror; hipcc emits mov_dpp + min pairs for the builtin form),
-// then the four row minima are read with v_readlane and combined on the scalar unit.  Result is wave-uniform.
-// s_nop 1 = the 2 wait states a DPP read needs after the VALU write of its source.
-__device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
-    asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
-    uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-    uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
-    uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    return min(min(a, b), min(c, d));
-}
-// Wavefront sum, same structure with fused v_add_u32_dpp.
-__device__ __forceinline__ int wave_sum(int v) {
-    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(v));
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
-           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
-}
 
 // A partition's replica slots as the kernels hold them: NW = 4 words (RF <= 4, one ds_read_b128) or 8 words (RF 5..8, two).
 template <int NW> struct alignas(16) Part { uint32_t w[NW]; };
@@ -1079,420 +1051,6 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
 }
 
 // ------------------------------------------------------------------------------------------------
-// K-bound : Lagrangian dual bound "KAO-DB" (scalar replay oracle/kao_port.c::kao_port_dual_bound).
-// lp_solve certifies optimality by branch-and-bound over the LP relaxation (README.md:135-136); here the certificate
-// is the Lagrangian dual of the same 0-1 model: the coupling rows C3 (README.md:158-161), C4 (163-166) and C6 (173-176)
-// are priced with integer fixed-point multipliers a[b], l[b], g[r]; the rows local to a partition (C1, C2, C5, C7) stay
-// in a per-partition subproblem solved exactly (greedy follower set under the per-partition rack band + one exchange
-// for the leader) by one lane over per-iteration candidate pools.  L(a,l,g) bounds the optimum from above for ANY
-// multipliers, so floor(min L / kDualScale) is a valid certificate; a deflected, level-controlled Polyak subgradient
-// step towards the incumbent objective drives it down.  One workgroup per topic, persistent over the iterations of a
-// launch; multipliers, counters, rack tables and pools live in LDS; integer-only so that the replay agrees bit for bit.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_umax(uint32_t v) { return ~wave_umin(~v); }
-__device__ __forceinline__ long long wave_sum64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ int db_sub(int m, int n, int lo, int hi) {  // element of the subdifferential closest to 0
-    return m > 0 ? hi - n : (m < 0 ? lo - n : (n < lo ? lo - n : (n > hi ? hi - n : 0)));
-}
-// nearest multiple of 2^sh (half up; arithmetic shift)
-__device__ __forceinline__ int dual_round(int v, int sh) { return ((v + (1 << (sh - 1))) >> sh) << sh; }
-__device__ __forceinline__ int db_dir(int d_prev, int s) { return 16 * s + (int)(((long long)d_prev * 3) >> 2); }
-__device__ __forceinline__ int db_move(int m, long long step, int d) {
-    const long long mag = (step * (d < 0 ? -(long long)d : (long long)d)) >> 16;
-    long long v = (long long)m - (d < 0 ? -mag : mag);
-    v = v > kDualClamp ? kDualClamp : (v < -kDualClamp ? -kDualClamp : v);
-    return (int)v;
-}
-
-// Wavefront arg-max of (value, lowest id): lanes hold their best (key = biased value, 0 = none; id).  Returns the lane
-// that owns the winner.  `mx` receives the maximum key (0 = no lane had a candidate).
-__device__ __forceinline__ int wave_argmax(uint32_t key, uint32_t id, uint32_t &mx) {
-    mx = wave_umax(key);
-    const unsigned long long ties = __ballot(key == mx);
-    if (__popcll(ties) == 1) return (int)__builtin_ctzll(ties);
-    const uint32_t sid = wave_umin(key == mx ? id : 0xFFFFFFFFu);
-    return (int)__builtin_ctzll(__ballot(key == mx && id == sid));
-}
-
-constexpr int kTF = 4;   // follower candidates kept per rack (RF needed)
-constexpr int kTL = 5;   // leader candidates kept per rack (RF + 1 needed)
-
-// Phase A works on candidate pools instead of all brokers.  With values "priced weight + bonus for the partition's own
-// current brokers (bonus >= 0)" and the rule "largest value, ties -> lowest broker index", the greedy pick of a round
-// is always (i) one of the partition's current brokers, or (ii) one of the RF best brokers (by generic value F, then
-// index) of one of the RF best racks (racks ranked by their best broker): fewer than RF picks exist before any round,
-// so a better-or-equal unpicked broker of the same rack, or the best broker of a still empty better rack, would win
-// otherwise.  Likewise the leader is a set member, a current broker, one of the RF+1 best brokers (by generic leader
-// value FL) of a rack that holds a set member, or the best broker of one of the RF+1 best racks by FL (at least one
-// of them holds no set member, and brokers of member-free racks all displace the same element).  The pools are rebuilt
-// once per iteration by the workgroup; a LANE then solves a partition over <= 20 + 33 candidates, independent of B,
-// with results identical to the brute-force scan of the scalar replay (oracle/kao_port.c).
-__global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
-    const int topic = pl.ids[blockIdx.x];
-    const TopicDev &T = pl.topics[topic];
-    const int B = T.B, R = T.R, P = T.P, RF = T.RF, rfc = T.rf_cur;
-    const int rep_lo = T.rep_lo, rep_hi = T.rep_hi, lead_lo = T.lead_lo, lead_hi = T.lead_hi;
-    const int rack_lo = T.rack_lo, rack_hi = T.rack_hi, plo = T.prack_lo, phi = T.prack_hi;
-    const int w00 = T.w00 * kDualScale, w01 = T.w01 * kDualScale, w10 = T.w10 * kDualScale, w11 = T.w11 * kDualScale;
-    // ---- LDS carve (bound_lds_bytes) ----
-    long long *acc = reinterpret_cast<long long *>(smem_b);             // [2][4] : L, |s|^2, |d|^2, -
-    int *ctl = reinterpret_cast<int *>(smem_b + 64);                    // [4]
-    int *G = reinterpret_cast<int *>(smem_b + 80);                      // g[kRackTab]
-    int *DG = G + kRackTab;                                             // dg[kRackTab]
-    int *NK = DG + kRackTab;                                            // replicas per rack in the subproblem solutions
-    int *RO = NK + kRackTab;                                            // first member of rack r in XB ([kRackTab + 2])
-    int *PFb = RO + kRackTab + 2;                                       // follower pool: broker, rack, generic value [16] each
-    int *PFr = PFb + 16, *PFv = PFr + 16;
-    int *PLb = PFv + 16;                                                // best leader of the RF+1 best racks [8] each
-    int *PLr = PLb + 8, *PLv = PLr + 8;
-    int *TFb = PLv + 8;                                                 // per rack: kTF best followers (broker, value)
-    int *TFv = TFb + pl.maxR * kTF;
-    int *TLb = TFv + pl.maxR * kTF;                                     // per rack: kTL best leaders
-    int *TLv = TLb + pl.maxR * kTL;
-    int *A = TLv + pl.maxR * kTL;                                       // a[maxB]
-    int *LM = A + pl.maxB;                                              // l[maxB]
-    int *NR = LM + pl.maxB;                                             // replicas per broker
-    int *NL = NR + pl.maxB;                                             // leaders per broker
-    uint16_t *XB = reinterpret_cast<uint16_t *>(NL + pl.maxB);          // brokers grouped by rack (ascending inside a rack)
-    uint8_t *RK = reinterpret_cast<uint8_t *>(XB + ((pl.maxB + 7) & ~7)); // rack of broker
-    // current assignment, 4 x u16 per partition (0xFFFF = none), when it fits next to the broker tables
-    uint2 *CURP = reinterpret_cast<uint2 *>(RK + ((pl.maxB + 15) & ~15));
-    const uint8_t *rk_g = pl.rackof_pool + T.rackof_off;
-    int *gp = pl.dual_pool + T.dual_off;                                // a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
-    int *g_a = gp, *g_l = gp + B, *g_da = gp + 2 * B, *g_dl = gp + 3 * B, *g_g = gp + 4 * B, *g_dg = gp + 4 * B + kRackTab;
-    for (int b = tid; b < B; b += nt) { A[b] = g_a[b]; LM[b] = g_l[b]; NR[b] = 0; NL[b] = 0; RK[b] = rk_g[b]; }
-    for (int r = tid; r < kRackTab; r += nt) { G[r] = r < R ? g_g[r] : 0; DG[r] = r < R ? g_dg[r] : 0; NK[r] = 0; }
-    if (tid < 8) acc[tid] = 0;
-    if (tid < 4) ctl[tid] = 0;
-    if (tid == 0) {  // rack offsets (R <= 255)
-        int o = 0;
-        for (int r = 0; r < R; ++r) { RO[r] = o; o += pl.rsz_pool[T.rsz_off + r]; }
-        RO[R] = o;
-    }
-    const uint16_t *curd = pl.curd_pool + T.curd_off;
-    auto load_cur = [&](int p) -> uint2 {  // 4 independent loads (index clamped to the last valid slot), then masked
-        const uint16_t *cur = curd + (size_t)p * rfc;
-        const uint32_t v0 = cur[0], v1 = cur[min(1, rfc - 1)], v2 = cur[min(2, rfc - 1)], v3 = cur[min(3, rfc - 1)];
-        return make_uint2(v0 | ((rfc > 1 ? v1 : 0xFFFFu) << 16), (rfc > 2 ? v2 : 0xFFFFu) | ((rfc > 3 ? v3 : 0xFFFFu) << 16));
-    };
-    if (pl.cur_in_lds)
-        for (int p = tid; p < P; p += nt) CURP[p] = load_cur(p);
-    __syncthreads();
-    {   // members of every rack, from the rack-major internal index (x = rack * m + j; dense order kept inside a rack)
-        const uint16_t *ext = pl.ext_pool + T.ext_off;
-        for (int x = tid; x < T.Bx; x += nt) {
-            const int r = x / T.m, jj = x - r * T.m;
-            if (jj < RO[r + 1] - RO[r]) XB[RO[r] + jj] = ext[x];
-        }
-    }
-    __syncthreads();
-    long long best = pl.best_L[topic];
-    const long long target = pl.target[topic];
-    // level control (every thread keeps the same copy): distance record -> level, record at stage start, iterations in stage
-    long long *g_lv = reinterpret_cast<long long *>(gp + 4 * B + 2 * kRackTab);
-    // the multipliers of the record (smallest) dual value: what the search prices are taken from
-    int *g_ra = gp + 4 * B + 2 * kRackTab + 8, *g_rl = g_ra + B, *g_rg = g_rl + B;
-    long long lv_delta = g_lv[0], lv_rec = g_lv[1];
-    int lv_since = (int)g_lv[2];
-    int flags = 0, it = 0;
-    // After the last iteration of a launch the dual function is also PROBED at the multipliers rounded to the quarter and to
-    // the half grid (optimal multipliers of this model tend to be small fractions: a subgradient iterate hovers a few
-    // thousandths around them, the rounded point hits them exactly -- drifted 100 x 1000 topic: iterate 7430.6, rounded 7430.0
-    // = the LP optimum).  A probe evaluates L only: no direction update, no step; the iterate is restored afterwards.
-    const int n_steps = pl.iters + kDualProbes;
-    for (int stp = 0; stp < n_steps; ++stp) {
-        const int par = stp & 1;
-        const bool probe = stp >= pl.iters;
-        if (probe) {
-            if (stp == pl.iters) {  // park the iterate in HBM (the epilogue writes the same values again)
-                for (int b = tid; b < B; b += nt) { g_a[b] = A[b]; g_l[b] = LM[b]; }
-                if (tid < R) g_g[tid] = G[tid];
-            }
-            const int sh = stp == pl.iters ? kDualQuarterLog2 : kDualQuarterLog2 + 1;
-            for (int b = tid; b < B; b += nt) { A[b] = dual_round(g_a[b], sh); LM[b] = dual_round(g_l[b], sh); }
-            if (tid < R) G[tid] = dual_round(g_g[tid], sh);
-            __syncthreads();
-        }
-        // ---- phase T: per rack, the kTF best followers and kTL best leaders by generic value (one wavefront per rack) ----
-        for (int rr = wave; rr < R; rr += nw) {
-            const int r = __builtin_amdgcn_readfirstlane(rr);
-            const int x0 = RO[r], n = RO[r + 1] - x0, gr = G[r];
-            for (int pass = 0; pass < 2; ++pass) {   // 0: followers (F), 1: leaders (FL = F - l)
-                const int want = pass == 0 ? RF : RF + 1, stride = pass == 0 ? kTF : kTL;
-                int *ob = pass == 0 ? TFb + r * kTF : TLb + r * kTL, *ov = pass == 0 ? TFv + r * kTF : TLv + r * kTL;
-                int s0 = -1, s1 = -1, s2 = -1, s3 = -1;
-                for (int k = 0; k < stride; ++k) {
-                    int selb = -1, selv = 0;
-                    if (k < want && k < n) {
-                        uint32_t bkey = 0, bb = 0xFFFFFFFFu;
-                        for (int jj = lane; jj < n; jj += 64) {
-                            const int b = XB[x0 + jj];
-                            const int v = -A[b] - gr - (pass ? LM[b] : 0);
-                            const uint32_t key = (uint32_t)v + 0x80000000u;
-                            const bool ok = (b != s0) & (b != s1) & (b != s2) & (b != s3);
-                            if (ok && key > bkey) { bkey = key; bb = (uint32_t)b; }
-                        }
-                        uint32_t mx;
-                        const int wl_ = wave_argmax(bkey, bb, mx);
-                        selb = __builtin_amdgcn_readlane((int)bb, wl_);
-                        selv = (int)(mx - 0x80000000u);
-                        if (k == 0) s0 = selb; else if (k == 1) s1 = selb; else if (k == 2) s2 = selb; else s3 = selb;
-                    }
-                    if (lane == 0) { ob[k] = selb; ov[k] = selv; }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- phase R (wavefront 0): the RF best racks for followers -> pool PF, the RF+1 best racks for leaders -> PL ----
-        if (wave == 0) {
-            for (int pass = 0; pass < 2; ++pass) {
-                const int want = pass == 0 ? RF : RF + 1;
-                const int *tb = pass == 0 ? TFb : TLb, *tv = pass == 0 ? TFv : TLv;
-                const int stride = pass == 0 ? kTF : kTL;
-                int s0 = -1, s1 = -1, s2 = -1, s3 = -1, s4 = -1;
-                for (int k = 0; k < want; ++k) {
-                    uint32_t bkey = 0, bid = 0xFFFFFFFFu;
-                    int brk = -1;
-                    for (int r = lane; r < R; r += 64) {
-                        const int b = tb[r * stride];
-                        const bool ok = (b >= 0) & (r != s0) & (r != s1) & (r != s2) & (r != s3) & (r != s4);
-                        const uint32_t key = (uint32_t)tv[r * stride] + 0x80000000u;
-                        if (ok && (key > bkey || (key == bkey && (uint32_t)b < bid))) { bkey = key; bid = (uint32_t)b; brk = r; }
-                    }
-                    uint32_t mx;
-                    int selr = -1;
-                    if (__ballot(bkey != 0) != 0ull) {
-                        const int wl_ = wave_argmax(bkey, bid, mx);
-                        selr = __builtin_amdgcn_readlane(brk, wl_);
-                    }
-                    if (k == 0) s0 = selr; else if (k == 1) s1 = selr; else if (k == 2) s2 = selr; else if (k == 3) s3 = selr; else s4 = selr;
-                    if (pass == 0) {
-                        if (lane < kTF) {
-                            const bool have = selr >= 0 && lane < RF;
-                            PFb[k * kTF + lane] = have ? TFb[selr * kTF + lane] : -1;
-                            PFr[k * kTF + lane] = selr;
-                            PFv[k * kTF + lane] = have ? TFv[selr * kTF + lane] : 0;
-                        }
-                    } else if (lane == 0) {
-                        PLb[k] = selr >= 0 ? TLb[selr * kTL] : -1;
-                        PLr[k] = selr;
-                        PLv[k] = selr >= 0 ? TLv[selr * kTL] : 0;
-                    }
-                }
-                if (pass == 0) { for (int k = RF; k < 4; ++k) if (lane < kTF) PFb[k * kTF + lane] = -1; }
-                else if (lane == 0) for (int k = RF + 1; k < 8; ++k) PLb[k] = -1;
-            }
-        }
-        __syncthreads();
-        // ---- phase A: one LANE per partition solves the priced subproblem over the pools ----
-        long long wsum = 0;
-        bool bad = false;
-        for (int base = wave * 64; base < P; base += nw * 64) {
-            const int p = base + lane;
-            const bool act = p < P;
-            const uint2 cw = pl.cur_in_lds ? CURP[min(p, P - 1)] : load_cur(min(p, P - 1));
-            int cb[4] = {(int)(cw.x & 0xFFFFu), (int)(cw.x >> 16), (int)(cw.y & 0xFFFFu), (int)(cw.y >> 16)};
-            int cr[4], cF[4], cFL[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool v = cb[i] < B;
-                const int b = v ? cb[i] : 0;
-                cr[i] = RK[b];
-                cF[i] = -A[b] - G[cr[i]];
-                cFL[i] = cF[i] - LM[b];
-                if (!v) cb[i] = -1;
-            }
-            const int c0 = cb[0], c1 = cb[1], c2 = cb[2], c3 = cb[3];
-            int Gb[4] = {-1, -1, -1, -1}, Gf[4] = {0, 0, 0, 0}, Gr[4] = {-1, -1, -1, -1};
-            bool fail = false;
-            // greedy follower set: prack_lo best of every rack first, then the best remaining under the cap; ties -> lowest b
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j >= RF) break;
-                const int forced = j < R * plo ? j / plo : -1;
-                int bf = INT_MIN, bb = INT_MAX, br = -1;
-                auto consider = [&](int b, int r, int F) {
-                    const int f = F + ((b == c0) ? w01 : (((b == c1) | (b == c2) | (b == c3)) ? w11 : 0));
-                    const int cnt = (int)(Gr[0] == r) + (int)(Gr[1] == r) + (int)(Gr[2] == r);
-                    const bool in = (Gb[0] == b) | (Gb[1] == b) | (Gb[2] == b);
-                    const bool ok = (b >= 0) & (forced >= 0 ? r == forced : cnt < phi) & !in;
-                    if (ok && (f > bf || (f == bf && b < bb))) { bf = f; bb = b; br = r; }
-                };
-                for (int i = 0; i < RF * kTF; ++i) consider(PFb[i], PFr[i], PFv[i]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) consider(cb[i], cr[i], cF[i]);
-                if (bb == INT_MAX) { fail = true; bb = -1; bf = 0; }
-                Gb[j] = bb; Gf[j] = bf; Gr[j] = br;
-            }
-            // leader: outside the set it displaces the cheapest element whose removal keeps the rack band
-            const int fG = Gf[0] + Gf[1] + Gf[2] + Gf[3];
-            int cg[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) cg[j] = (int)(Gr[0] == Gr[j]) + (int)(Gr[1] == Gr[j]) + (int)(Gr[2] == Gr[j]) + (int)(Gr[3] == Gr[j]);
-            int bv = INT_MIN, b0 = INT_MAX, be = -1, b0r = -1;
-            auto lead = [&](int b, int r, int FL) {
-                const int lv = FL + ((b == c0) ? w00 : (((b == c1) | (b == c2) | (b == c3)) ? w10 : 0));
-                int e = -1, fe = 0;
-                if (Gb[0] == b) { e = 0; fe = Gf[0]; }
-                else if (Gb[1] == b) { e = 1; fe = Gf[1]; }
-                else if (Gb[2] == b) { e = 2; fe = Gf[2]; }
-                else if (Gb[3] == b) { e = 3; fe = Gf[3]; }
-                else {
-                    const int rc = (int)(Gr[0] == r) + (int)(Gr[1] == r) + (int)(Gr[2] == r) + (int)(Gr[3] == r);
-                    const bool full = rc >= phi;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool ok = (j < RF) & (full ? Gr[j] == r : ((Gr[j] == r) | (cg[j] > plo)));
-                        if (ok && (e < 0 || Gf[j] <= fe)) { e = j; fe = Gf[j]; }     // cheapest; ties -> the latest picked
-                    }
-                }
-                const int v = fG - fe + lv;
-                if (b >= 0 && e >= 0 && (v > bv || (v == bv && b < b0))) { bv = v; b0 = b; be = e; b0r = r; }
-            };
-            if (!fail) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j >= RF) break;
-                    const int b = Gb[j], r = Gr[j];
-                    lead(b, r, -A[b] - G[r] - LM[b]);                                 // a set member leads
-                    for (int k = 0; k <= RF; ++k) lead(TLb[r * kTL + k], r, TLv[r * kTL + k]);   // best leaders of its rack
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) lead(cb[i], cr[i], cFL[i]);               // the partition's current brokers
-                for (int i = 0; i <= RF; ++i) lead(PLb[i], PLr[i], PLv[i]);           // best leader of the best racks
-            }
-            if (b0 == INT_MAX) fail = true;
-            if (act && fail) bad = true;
-            if (act && !fail) {
-                wsum += bv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (j < RF && j != be) { atomicAdd(&NR[Gb[j]], 1); atomicAdd(&NK[Gr[j]], 1); }
-                atomicAdd(&NR[b0], 1);
-                atomicAdd(&NL[b0], 1);
-                atomicAdd(&NK[b0r], 1);
-            }
-        }
-        bad = __ballot(bad) != 0ull;
-        wsum = wave_sum64(wsum);
-        if (lane == 0) {
-            if (wsum) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 0]), (unsigned long long)wsum);
-            if (bad) atomicOr(&ctl[0], 4);
-        }
-        __syncthreads();
-        if (ctl[0] & 4) { if (!probe) flags |= 4; break; }
-        // ---- phase B: band terms of L, subgradient s, new direction d = 16 s + floor(3 d_prev / 4) ----
-        long long cL = 0, cN = 0, cD = 0;
-        for (int b = tid; b < B; b += nt) {
-            const int a_ = A[b], l_ = LM[b];
-            const int sa = db_sub(a_, NR[b], rep_lo, rep_hi), sl = db_sub(l_, NL[b], lead_lo, lead_hi);
-            cL += (long long)a_ * (a_ > 0 ? rep_hi : rep_lo) + (long long)l_ * (l_ > 0 ? lead_hi : lead_lo);
-            cN += (long long)sa * sa + (long long)sl * sl;
-            if (!probe) {
-                const int da = db_dir(g_da[b], sa), dl = db_dir(g_dl[b], sl);
-                g_da[b] = da; g_dl[b] = dl;
-                cD += (long long)da * da + (long long)dl * dl;
-            }
-        }
-        if (tid < R) {
-            const int g_ = G[tid], sg = db_sub(g_, NK[tid], rack_lo, rack_hi);
-            cL += (long long)g_ * (g_ > 0 ? rack_hi : rack_lo);
-            cN += (long long)sg * sg;
-            if (!probe) {
-                const int dg = db_dir(DG[tid], sg);
-                DG[tid] = dg;
-                cD += (long long)dg * dg;
-            }
-        }
-        const bool owns = wave * 64 < max(B, R);  // wavefronts without a broker or rack skip the 64-bit reductions
-        if (owns) { cL = wave_sum64(cL); cN = wave_sum64(cN); cD = wave_sum64(cD); }
-        if (lane == 0 && owns) {
-            if (cL) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 0]), (unsigned long long)cL);
-            if (cN) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 1]), (unsigned long long)cN);
-            if (cD) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[par * 4 + 2]), (unsigned long long)cD);
-        }
-        __syncthreads();
-        // ---- phase C: stop tests, Polyak step along d, reset the counters ----
-        const long long Lv = acc[par * 4 + 0], nrm = acc[par * 4 + 1];
-        long long dn = acc[par * 4 + 2];
-        if (Lv < best) {  // a new record (same decision in every thread): keep its multipliers
-            best = Lv;
-            for (int b = tid; b < B; b += nt) { g_ra[b] = A[b]; g_rl[b] = LM[b]; }
-            if (tid < R) g_rg[tid] = G[tid];
-        }
-        if (probe) {  // a probe only records the value; back to the iterate, counters cleared for the next evaluation
-            for (int b = tid; b < B; b += nt) { A[b] = g_a[b]; LM[b] = g_l[b]; NR[b] = 0; NL[b] = 0; }
-            if (tid < R) { G[tid] = g_g[tid]; NK[tid] = 0; }
-            if (tid < 4) acc[(par ^ 1) * 4 + tid] = 0;
-            if (best < (target + 1) * kDualScale) flags |= 1;
-            __syncthreads();
-            continue;
-        }
-        ++it;
-        if (best < (target + 1) * kDualScale) { flags |= 1; break; }
-        if (nrm == 0) { flags |= 2; break; }
-        const bool reset = dn == 0;  // the memory cancelled the subgradient: restart from it
-        if (reset) dn = 256 * nrm;
-        // level control: aim at the incumbent while the record keeps falling; every kDualStage iterations without half a
-        // unit of progress the distance between record and level is halved (an incumbent below the optimum is an
-        // unreachable level: steps too long, the record stalls far above the optimum)
-        long long level = target * kDualScale;
-        if (lv_delta <= 0) { lv_delta = best - level; lv_rec = best; lv_since = 0; }
-        if (++lv_since >= kDualStage) {
-            if (lv_rec - best < kDualScale / 2) { lv_delta /= 2; if (lv_delta < kDualScale / 16) lv_delta = kDualScale / 16; }
-            lv_rec = best; lv_since = 0;
-        }
-        if (best - lv_delta > level) level = best - lv_delta;
-        long long gap = Lv - level;
-        if (gap < 1) gap = 1;
-        const long long step = (gap << 20) / dn;
-        for (int b = tid; b < B; b += nt) {
-            int da = g_da[b], dl = g_dl[b];
-            if (reset) {
-                da = 16 * db_sub(A[b], NR[b], rep_lo, rep_hi); dl = 16 * db_sub(LM[b], NL[b], lead_lo, lead_hi);
-                g_da[b] = da; g_dl[b] = dl;
-            }
-            A[b] = db_move(A[b], step, da);
-            LM[b] = db_move(LM[b], step, dl);
-            NR[b] = 0; NL[b] = 0;
-        }
-        if (tid < R) {
-            int dg = DG[tid];
-            if (reset) { dg = 16 * db_sub(G[tid], NK[tid], rack_lo, rack_hi); DG[tid] = dg; }
-            G[tid] = db_move(G[tid], step, dg);
-            NK[tid] = 0;
-        }
-        if (tid < 4) acc[(par ^ 1) * 4 + tid] = 0;
-        __syncthreads();
-    }
-    // ---- epilogue: multipliers and the best dual value go back to HBM for the next launch ----
-    for (int b = tid; b < B; b += nt) { g_a[b] = A[b]; g_l[b] = LM[b]; }
-    if (tid < R) { g_g[tid] = G[tid]; g_dg[tid] = DG[tid]; }
-    if (pl.export_prices) {  // search prices for K-search: the multipliers on the quarter grid (exact ties between equally priced brokers)
-        // export_prices 1: the record multipliers (own stores of this thread, or of an earlier launch); 2: the last iterate
-        int *pp = pl.price_pool + T.price_off;
-        const bool rec = pl.export_prices == 1;
-        for (int b = tid; b < B; b += nt) {
-            pp[b] = dual_round(rec ? g_ra[b] : A[b], kDualQuarterLog2);
-            pp[B + b] = dual_round(rec ? g_rl[b] : LM[b], kDualQuarterLog2);
-        }
-        if (tid < kRackTab) pp[2 * B + tid] = tid < R ? dual_round(rec ? g_rg[tid] : G[tid], kDualQuarterLog2) : 0;
-    }
-    if (tid == 0) {
-        g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since;
-        pl.best_L[topic] = best;
-        pl.info[topic * 4 + 0] += it;
-        pl.info[topic * 4 + 1] = flags;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw) {
@@ -1506,9 +1064,7 @@ size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
 }
 
 // largest dynamic-LDS size each kernel has been enabled for, per device (function attributes are per device)
-constexpr int kAttrDevices = 64;
-static int g_attr_eval_dev[kAttrDevices] = {0}, g_attr_bound_dev[kAttrDevices] = {0};
-static int attr_slot() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < kAttrDevices) ? d : 0; }
+static int g_attr_eval_dev[kAttrDevices] = {0};
 
 template <bool kGlobalA, bool kPriced, int NW>
 static void launch_search_t(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, size_t lds, int &attr, hipStream_t st) {
@@ -1556,24 +1112,6 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
 
 void launch_adopt_global(unsigned long long *keys, const unsigned long long *glob, int n, void *stream) {
     hipLaunchKernelGGL(k_adopt_global, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), keys, glob, n);
-}
-
-size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds) {
-    size_t n = 80 + (3 * (size_t)kRackTab + kRackTab + 2 + 48 + 24) * 4 + (size_t)maxR * (2 * 4 + 2 * 5) * 4;
-    n += 16 * (size_t)maxB + 2 * (((size_t)maxB + 7) & ~(size_t)7) + (((size_t)maxB + 15) & ~(size_t)15);
-    n = (n + 7) & ~(size_t)7;
-    return n + (cur_in_lds ? 8 * (size_t)maxP : 0);
-}
-
-
-void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream) {
-    const size_t lds = bound_lds_bytes(pools.maxB, pools.maxP, pools.maxR, pools.cur_in_lds != 0);
-    int &g_attr_bound = g_attr_bound_dev[attr_slot()];
-    if ((int)lds > g_attr_bound) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bound), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        g_attr_bound = (int)lds;
-    }
-    hipLaunchKernelGGL(k_bound, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools);
 }
 
 size_t canon_lds_bytes(int maxBx) {

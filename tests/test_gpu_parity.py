@@ -657,9 +657,22 @@ def _wide_cases(ko, status="optimal"):
     return [(c, ko.random_case_wide(c["seed"])) for c in load_golden("random_wide.json")["cases"] if c["status"] == status]
 
 
-def test_dual_bound_replay_bit_exact(kao, ko, kp):
+def _bound_chunk(monkeypatch, chunk):
+    """KAO_BOUND_CHUNK (test hook): None = the library's own choice (one persistent workgroup per topic up to 2048 partitions,
+    k_bound_step with slices of 512 partitions beyond), "0" = always the persistent kernel, "64" / "192" = always k_bound_step
+    with slices that small (several workgroups even for the small families)."""
+    if chunk is None:
+        monkeypatch.delenv("KAO_BOUND_CHUNK", raising=False)
+    else:
+        monkeypatch.setenv("KAO_BOUND_CHUNK", chunk)
+
+
+@pytest.mark.parametrize("chunk", [None, "64", "192"])
+def test_dual_bound_replay_bit_exact(kao, ko, kp, monkeypatch, chunk):
     """K-bound vs its scalar replay (oracle/kao_port.c::kao_port_dual_bound): identical multipliers, best dual value,
-    iteration count and stop flags -- one launch, and several launches that continue from the state in HBM."""
+    iteration count and stop flags -- one launch, and several launches that continue from the state in HBM.  Both drivers:
+    the persistent workgroup and the sliced one-iteration-per-launch kernel."""
+    _bound_chunk(monkeypatch, chunk)
     picked = [(c, t) for c, t in _wide_cases(ko) if c["upper_bound"] != c["objective"]][:40]
     picked += [(e, ko.topic_from_dict(e["topic"])) for n in ("cfg2.json", "cfg3.json", "cfg4.json") for e in load_golden(n)["topics"][:1]]
     assert len(picked) >= 40
@@ -679,8 +692,10 @@ def test_dual_bound_replay_bit_exact(kao, ko, kp):
         assert got["bound"] == st.bound >= c["objective"], tag
 
 
-def test_dual_bound_replay_large_shapes(kao, ko, kp):
-    """K-bound paths the small families do not reach: the current assignment read from global memory (8 B per
+@pytest.mark.parametrize("chunk", [None, "0", "64"])
+def test_dual_bound_replay_large_shapes(kao, ko, kp, monkeypatch, chunk):
+    """(chunk None: the 20,000-partition shape runs sliced over 40 workgroups, the others persistent; "0": all persistent; "64":
+    all sliced.)  K-bound paths the small families do not reach: the current assignment read from global memory (8 B per
     partition no longer fits LDS), hundreds of brokers in few racks (long per-rack scans), many racks (rack ranking
     over several 64-lane rounds), RF 4 with an RF change; multipliers and dual value still equal the replay's."""
     shapes = [  # (brokers, racks, partitions, rf, removed, added, new_rf, target offset)
@@ -696,6 +711,7 @@ def test_dual_bound_replay_large_shapes(kao, ko, kp):
             bd = ot.bounds()
             ot.bounds_override = {"rack_lo": 0, "rack_hi": bd["rack_hi"] + P, "prack_hi": bd["prack_hi"] + 1, "rep_hi": bd["rep_hi"] + 1}
             assert not ko.provably_infeasible(ot), i
+        _bound_chunk(monkeypatch, chunk)
         target = max(0, ko.upper_bound_simple(ot) - off)
         got = kao.dual_bound(to_product_topic(ot), target, iters=12, launches=2)
         st = kp.DualState(ot)
