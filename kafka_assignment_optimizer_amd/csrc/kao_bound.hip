@@ -32,8 +32,18 @@ __device__ __forceinline__ int db_sub(int m, int n, int lo, int hi) {  // elemen
 // nearest multiple of 2^sh (half up; arithmetic shift)
 __device__ __forceinline__ int dual_round(int v, int sh) { return ((v + (1 << (sh - 1))) >> sh) << sh; }
 __device__ __forceinline__ int db_dir(int d_prev, int s) { return 16 * s + (int)(((long long)d_prev * 3) >> 2); }
-__device__ __forceinline__ int db_move(int m, long long step, int d) {
-    const long long mag = (step * (d < 0 ? -(long long)d : (long long)d)) >> 16;
+// The move |step * d| carries 16 fractional bits below the multipliers' unit of the last place.  Truncating them froze
+// the iterate on large topics (1000 x 30000: |d|^2 grows with the number of brokers, near the optimum every move fell below
+// one unit and NO multiplier changed for 50,000 iterations): the fraction is rounded up with probability equal to itself --
+// `h`, 16 bits hashed from the step number and the multiplier's index -- so the expected move is the exact one.
+__device__ __forceinline__ uint32_t db_dither(uint32_t seq, uint32_t idx) {
+    uint32_t h = seq * 0x9E3779B1u + idx * 0x85EBCA77u + 0x68E31DA4u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h >> 16;
+}
+// `step` = (gap << sh) / |d|^2 with sh in 20..40 (bound_step_length): the move is gap * 16 d / |d|^2.
+__device__ __forceinline__ int db_move(int m, long long step, int sh, int d, uint32_t h) {
+    const long long mag = (step * (d < 0 ? -(long long)d : (long long)d) + ((long long)h << (sh - 20))) >> (sh - 4);
     long long v = (long long)m - (d < 0 ? -mag : mag);
     v = v > kDualClamp ? kDualClamp : (v < -kDualClamp ? -kDualClamp : v);
     return (int)v;
@@ -348,8 +358,11 @@ __device__ __forceinline__ void bound_band_terms(const BoundLds &L, const BoundT
 // the record keeps falling; every kDualStage iterations without half a unit of progress the distance between record and
 // level is halved (an incumbent below the optimum is an unreachable level: steps too long, the record stalls far above
 // the optimum).  `dn` is |d|^2 (already replaced by 256 |s|^2 on a reset).
+// Returns (gap << sh) / |d|^2; the shift `sh` is as large as 62 bits allow, at most 40 (with the fixed 20 bits of the first
+// version the quotient was ZERO once |d|^2 > 2^32 at the smallest gap -- 1000 brokers whose counts are tens off -- and the
+// iterate stopped; gap < 2^42 by K-bound's limits on P * RF * weight, so sh >= 20).
 __device__ __forceinline__ long long bound_step_length(long long best, long long target, long long Lv, long long dn,
-                                                       long long &lv_delta, long long &lv_rec, int &lv_since) {
+                                                       long long &lv_delta, long long &lv_rec, int &lv_since, int &sh) {
     long long level = target * kDualScale;
     if (lv_delta <= 0) { lv_delta = best - level; lv_rec = best; lv_since = 0; }
     if (++lv_since >= kDualStage) {
@@ -359,26 +372,27 @@ __device__ __forceinline__ long long bound_step_length(long long best, long long
     if (best - lv_delta > level) level = best - lv_delta;
     long long gap = Lv - level;
     if (gap < 1) gap = 1;
-    return (gap << 20) / dn;
+    sh = min(40, max(20, __clzll(gap) - 2));
+    return (gap << sh) / dn;
 }
 
 // The step along d (on a reset: along the subgradient itself), counters cleared for the next evaluation.
 __device__ __forceinline__ void bound_take_step(const BoundLds &L, const BoundTopic &K, int *g_da, int *g_dl, bool reset, long long step,
-                                                int tid, int nt) {
+                                                int sh, uint32_t seq, int tid, int nt) {
     for (int b = tid; b < K.B; b += nt) {
         int da = g_da[b], dl = g_dl[b];
         if (reset) {
             da = 16 * db_sub(L.A[b], L.NR[b], K.rep_lo, K.rep_hi); dl = 16 * db_sub(L.LM[b], L.NL[b], K.lead_lo, K.lead_hi);
             g_da[b] = da; g_dl[b] = dl;
         }
-        L.A[b] = db_move(L.A[b], step, da);
-        L.LM[b] = db_move(L.LM[b], step, dl);
+        L.A[b] = db_move(L.A[b], step, sh, da, db_dither(seq, (uint32_t)b));
+        L.LM[b] = db_move(L.LM[b], step, sh, dl, db_dither(seq, (uint32_t)(K.B + b)));
         L.NR[b] = 0; L.NL[b] = 0;
     }
     if (tid < K.R) {
         int dg = L.DG[tid];
         if (reset) { dg = 16 * db_sub(L.G[tid], L.NK[tid], K.rack_lo, K.rack_hi); L.DG[tid] = dg; }
-        L.G[tid] = db_move(L.G[tid], step, dg);
+        L.G[tid] = db_move(L.G[tid], step, sh, dg, db_dither(seq, (uint32_t)(2 * K.B + tid)));
         L.NK[tid] = 0;
     }
 }
@@ -429,6 +443,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     int *g_ra = gp + 4 * B + 2 * kRackTab + 8, *g_rl = g_ra + B, *g_rg = g_rl + B;
     long long lv_delta = g_lv[0], lv_rec = g_lv[1];
     int lv_since = (int)g_lv[2];
+    uint32_t lv_seq = (uint32_t)g_lv[3];   // steps taken so far (over all launches): the dither sequence number
     int flags = 0, it = 0;
     // After the last iteration of a launch the dual function is also PROBED at the multipliers rounded to the quarter and to
     // the half grid (optimal multipliers of this model tend to be small fractions: a subgradient iterate hovers a few
@@ -492,8 +507,9 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
         if (nrm == 0) { flags |= 2; break; }
         const bool reset = dn == 0;  // the memory cancelled the subgradient: restart from it
         if (reset) dn = 256 * nrm;
-        const long long step = bound_step_length(best, target, Lv, dn, lv_delta, lv_rec, lv_since);
-        bound_take_step(L, K, g_da, g_dl, reset, step, tid, nt);
+        int sh;
+        const long long step = bound_step_length(best, target, Lv, dn, lv_delta, lv_rec, lv_since, sh);
+        bound_take_step(L, K, g_da, g_dl, reset, step, sh, lv_seq++, tid, nt);
         if (tid < 4) acc[(par ^ 1) * 4 + tid] = 0;
         __syncthreads();
     }
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     if (tid < R) { g_g[tid] = L.G[tid]; g_dg[tid] = L.DG[tid]; }
     if (pl.export_prices) bound_export_prices(pl, T, L.A, L.LM, L.G, g_ra, g_rl, g_rg, tid, nt);  // own stores or an earlier launch's
     if (tid == 0) {
-        g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since;
+        g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since; g_lv[3] = lv_seq;
         pl.best_L[topic] = best;
         pl.info[topic * 4 + 0] += it;
         pl.info[topic * 4 + 1] = flags;
@@ -543,15 +559,15 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
     const uint8_t *rk_g = pl.rackof_pool + T.rackof_off;
     int *gp = pl.dual_pool + T.dual_off;
     int *g_a = gp, *g_l = gp + B, *g_da = gp + 2 * B, *g_dl = gp + 3 * B, *g_g = gp + 4 * B, *g_dg = gp + 4 * B + kRackTab;
-    const int sh = mode == 1 ? kDualQuarterLog2 : kDualQuarterLog2 + 1;
+    const int rsh = mode == 1 ? kDualQuarterLog2 : kDualQuarterLog2 + 1;
     for (int b = tid; b < B; b += nt) {
         const int a_ = g_a[b], l_ = g_l[b];
-        L.A[b] = probe ? dual_round(a_, sh) : a_; L.LM[b] = probe ? dual_round(l_, sh) : l_;
+        L.A[b] = probe ? dual_round(a_, rsh) : a_; L.LM[b] = probe ? dual_round(l_, rsh) : l_;
         L.NR[b] = 0; L.NL[b] = 0; L.RK[b] = rk_g[b];
     }
     for (int r = tid; r < kRackTab; r += nt) {
         const int g_ = r < R ? g_g[r] : 0;
-        L.G[r] = probe ? dual_round(g_, sh) : g_; L.DG[r] = r < R ? g_dg[r] : 0; L.NK[r] = 0;
+        L.G[r] = probe ? dual_round(g_, rsh) : g_; L.DG[r] = r < R ? g_dg[r] : 0; L.NK[r] = 0;
     }
     if (tid < 8) L.acc[tid] = 0;
     bound_rack_members(L, pl, T, tid, nt);
@@ -624,6 +640,7 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
     const long long target = pl.target[topic];
     long long lv_delta = g_lv[0], lv_rec = g_lv[1];
     int lv_since = (int)g_lv[2];
+    const uint32_t lv_seq = (uint32_t)g_lv[3];
     __syncthreads();   // every thread holds the state of the previous step before thread 0 rewrites it
     if (Lv < best) {
         best = Lv;
@@ -643,11 +660,12 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
     }
     const bool reset = dn == 0;
     if (reset) dn = 256 * nrm;
-    const long long step = bound_step_length(best, target, Lv, dn, lv_delta, lv_rec, lv_since);
-    bound_take_step(L, K, g_da, g_dl, reset, step, tid, nt);
+    int sh;
+    const long long step = bound_step_length(best, target, Lv, dn, lv_delta, lv_rec, lv_since, sh);
+    bound_take_step(L, K, g_da, g_dl, reset, step, sh, lv_seq, tid, nt);
     for (int b = tid; b < B; b += nt) { g_a[b] = L.A[b]; g_l[b] = L.LM[b]; }
     if (tid < R) { g_g[tid] = L.G[tid]; g_dg[tid] = L.DG[tid]; }
-    if (tid == 0) { g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since; }
+    if (tid == 0) { g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since; g_lv[3] = (long long)lv_seq + 1; }
 }
 
 // end of a launch sequence: the search prices (k_bound's epilogue)

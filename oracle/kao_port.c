@@ -825,8 +825,15 @@ static inline int32_t db_sub(int32_t m, int n, int lo, int hi) {   /* element of
 static inline int32_t db_dir(int32_t d_prev, int32_t s) {         /* d = 16 s + floor(3 d_prev / 4) */
     return 16 * s + (int32_t)(((int64_t)d_prev * 3) >> 2);
 }
-static inline int32_t db_move(int32_t m, int64_t step, int32_t d) {
-    const int64_t mag = (step * (d < 0 ? -(int64_t)d : (int64_t)d)) >> 16;
+/* the 16 fractional bits of a move are rounded up with probability equal to the fraction (16 bits hashed from the step
+ * number and the multiplier's index): truncation froze the iterate on large topics, see kao_bound.hip */
+static inline uint32_t db_dither(uint32_t seq, uint32_t idx) {
+    uint32_t h = seq * 0x9E3779B1u + idx * 0x85EBCA77u + 0x68E31DA4u;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h >> 16;
+}
+static inline int32_t db_move(int32_t m, int64_t step, int sh, int32_t d, uint32_t h) {
+    const int64_t mag = (step * (d < 0 ? -(int64_t)d : (int64_t)d) + ((int64_t)h << (sh - 20))) >> (sh - 4);
     int64_t v = (int64_t)m - (d < 0 ? -mag : mag);
     if (v > DB_CLAMP) v = DB_CLAMP;
     if (v < -DB_CLAMP) v = -DB_CLAMP;
@@ -834,7 +841,7 @@ static inline int32_t db_move(int32_t m, int64_t step, int32_t d) {
 }
 
 /* Runs up to `iters` dual iterations from the state (a[B], l[B], g[R] multipliers; da[B], dl[B], dg[R] previous
- * direction; lv[3] level-control state, zeros to start; *best_L), all in/out (zeros and INT64_MAX to start).  Needs P*RF <= 2^17 and P*RF*max(w) <= 2^19 (32-bit
+ * direction; lv[4] level-control state and step counter, zeros to start; *best_L), all in/out (zeros and INT64_MAX to start).  Needs P*RF <= 2^17 and P*RF*max(w) <= 2^19 (32-bit
  * headroom of the priced values).  flags: 1 = closed (best_L < (target+1)*DB_SCALE), 2 = zero subgradient (dual optimum reached),
  * 4 = a partition subproblem is infeasible (no bound).  Returns the number of iterations performed. */
 int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, int32_t *a, int32_t *l, int32_t *g,
@@ -899,7 +906,7 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         /* Level control: the Polyak step aims at `level`, the incumbent while the record keeps falling.  An incumbent
          * below the optimum is an unreachable level (steps too long, the record stalls far above the optimum): every
          * DB_STAGE iterations without half a unit of progress the distance delta between record and level is halved.
-         * lv = {delta (0 = not started), record at the start of the stage, iterations in the stage}. */
+         * lv = {delta (0 = not started), record at the start of the stage, iterations in the stage, steps taken}. */
         int64_t level = target * DB_SCALE;
         if (lv[0] <= 0) { lv[0] = *best_L - level; lv[1] = *best_L; lv[2] = 0; }
         if (++lv[2] >= DB_STAGE) {
@@ -909,9 +916,17 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         if (*best_L - lv[0] > level) level = *best_L - lv[0];
         int64_t gap = L - level;
         if (gap < 1) gap = 1;
-        const int64_t step = (gap << 20) / dn;           /* multiplier change = gap * 16 d / |d|^2, 16 fractional bits */
-        for (int b = 0; b < B; ++b) { a[b] = db_move(a[b], step, da[b]); l[b] = db_move(l[b], step, dl[b]); }
-        for (int r = 0; r < R; ++r) g[r] = db_move(g[r], step, dg[r]);
+        /* multiplier change = gap * 16 d / |d|^2; step = (gap << sh) / |d|^2 with as many bits as 62 allow, at most 40
+         * (20 fixed bits gave a ZERO quotient once |d|^2 > 2^32 at the smallest gap; gap < 2^42 by the limits above) */
+        int sh = __builtin_clzll((unsigned long long)gap) - 2;
+        sh = sh > 40 ? 40 : (sh < 20 ? 20 : sh);
+        const int64_t step = (gap << sh) / dn;
+        const uint32_t seq = (uint32_t)lv[3]++;           /* steps taken so far, over all launches */
+        for (int b = 0; b < B; ++b) {
+            a[b] = db_move(a[b], step, sh, da[b], db_dither(seq, (uint32_t)b));
+            l[b] = db_move(l[b], step, sh, dl[b], db_dither(seq, (uint32_t)(B + b)));
+        }
+        for (int r = 0; r < R; ++r) g[r] = db_move(g[r], step, sh, dg[r], db_dither(seq, (uint32_t)(2 * B + r)));
     }
     /* Rounding probes (only when the launch ran all its iterations): the dual function is also evaluated at the
      * multipliers rounded to the quarter grid and to the half grid -- optimal multipliers of this model tend to be small
