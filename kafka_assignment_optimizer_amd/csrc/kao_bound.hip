@@ -357,19 +357,27 @@ __device__ __forceinline__ void bound_band_terms(const BoundLds &L, const BoundT
 // Level control and step length of the Polyak step (every thread computes the same values): aim at the incumbent while
 // the record keeps falling; every kDualStage iterations without half a unit of progress the distance between record and
 // level is halved (an incumbent below the optimum is an unreachable level: steps too long, the record stalls far above
-// the optimum).  `dn` is |d|^2 (already replaced by 256 |s|^2 on a reset).
+// the optimum); a stage that gained more than that distance doubles it again, up to the incumbent (the level had closed in
+// while the incumbent was poor -- inside kao_solve the early incumbents of large topics are -- and a better one makes
+// longer steps pay again).  The record that steers the level is the best value among the ITERATES, `bi` -- not the certificate record,
+// which the rounding probes also lower: a probe value the iterate cannot reach soon reads as "no progress", and with a probe
+// every 150 iterations (kao_solve's launches) the level control starved (drifted 500 x 5000: 37560.9 after 18,000 iterations
+// in launches of 150, 37559.6 in launches of 2000).  `dn` is |d|^2 (already replaced by 256 |s|^2 on a reset).
 // Returns (gap << sh) / |d|^2; the shift `sh` is as large as 62 bits allow, at most 40 (with the fixed 20 bits of the first
 // version the quotient was ZERO once |d|^2 > 2^32 at the smallest gap -- 1000 brokers whose counts are tens off -- and the
 // iterate stopped; gap < 2^42 by K-bound's limits on P * RF * weight, so sh >= 20).
-__device__ __forceinline__ long long bound_step_length(long long best, long long target, long long Lv, long long dn,
-                                                       long long &lv_delta, long long &lv_rec, int &lv_since, int &sh) {
+__device__ __forceinline__ long long bound_step_length(long long target, long long Lv, long long dn,
+                                                       long long &lv_delta, long long &lv_rec, int &lv_since, long long &bi, int &sh) {
     long long level = target * kDualScale;
-    if (lv_delta <= 0) { lv_delta = best - level; lv_rec = best; lv_since = 0; }
+    if (lv_delta <= 0) { bi = Lv; lv_delta = bi - level; lv_rec = bi; lv_since = 0; }
+    if (Lv < bi) bi = Lv;
     if (++lv_since >= kDualStage) {
-        if (lv_rec - best < kDualScale / 2) { lv_delta /= 2; if (lv_delta < kDualScale / 16) lv_delta = kDualScale / 16; }
-        lv_rec = best; lv_since = 0;
+        const long long prog = lv_rec - bi;
+        if (prog < kDualScale / 2) { lv_delta /= 2; if (lv_delta < kDualScale / 16) lv_delta = kDualScale / 16; }
+        else if (prog >= lv_delta && bi - 2 * lv_delta >= level) lv_delta *= 2;   // a stage that gained more than the distance: aim further
+        lv_rec = bi; lv_since = 0;
     }
-    if (best - lv_delta > level) level = best - lv_delta;
+    if (bi - lv_delta > level) level = bi - lv_delta;
     long long gap = Lv - level;
     if (gap < 1) gap = 1;
     sh = min(40, max(20, __clzll(gap) - 2));
@@ -436,14 +444,16 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
         for (int p = tid; p < P; p += nt) L.CURP[p] = bound_load_cur(curd, K.rfc, p);
     bound_rack_members(L, pl, T, tid, nt);
     long long best = pl.best_L[topic];
-    const long long target = pl.target[topic];
+    const long long target_raw = pl.target[topic], target = target_raw & ~kDualRelevel;
     // level control (every thread keeps the same copy): distance record -> level, record at stage start, iterations in stage
     long long *g_lv = reinterpret_cast<long long *>(gp + 4 * B + 2 * kRackTab);
     // the multipliers of the record (smallest) dual value: what the search prices are taken from
     int *g_ra = gp + 4 * B + 2 * kRackTab + 8, *g_rl = g_ra + B, *g_rg = g_rl + B;
-    long long lv_delta = g_lv[0], lv_rec = g_lv[1];
-    int lv_since = (int)g_lv[2];
-    uint32_t lv_seq = (uint32_t)g_lv[3];   // steps taken so far (over all launches): the dither sequence number
+    long long lv_delta = (target_raw & kDualRelevel) ? 0 : g_lv[0], lv_rec = g_lv[1];
+    // g_lv[2] = iterations in the stage | steps taken so far (over all launches: the dither sequence number) << 8
+    int lv_since = (int)(g_lv[2] & 0xFF);
+    uint32_t lv_seq = (uint32_t)(g_lv[2] >> 8);
+    long long lv_bi = g_lv[3];               // best dual value among the iterates (the probes do not count)
     int flags = 0, it = 0;
     // After the last iteration of a launch the dual function is also PROBED at the multipliers rounded to the quarter and to
     // the half grid (optimal multipliers of this model tend to be small fractions: a subgradient iterate hovers a few
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
         const bool reset = dn == 0;  // the memory cancelled the subgradient: restart from it
         if (reset) dn = 256 * nrm;
         int sh;
-        const long long step = bound_step_length(best, target, Lv, dn, lv_delta, lv_rec, lv_since, sh);
+        const long long step = bound_step_length(target, Lv, dn, lv_delta, lv_rec, lv_since, lv_bi, sh);
         bound_take_step(L, K, g_da, g_dl, reset, step, sh, lv_seq++, tid, nt);
         if (tid < 4) acc[(par ^ 1) * 4 + tid] = 0;
         __syncthreads();
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
     if (tid < R) { g_g[tid] = L.G[tid]; g_dg[tid] = L.DG[tid]; }
     if (pl.export_prices) bound_export_prices(pl, T, L.A, L.LM, L.G, g_ra, g_rl, g_rg, tid, nt);  // own stores or an earlier launch's
     if (tid == 0) {
-        g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since; g_lv[3] = lv_seq;
+        g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = (long long)lv_since | ((long long)lv_seq << 8); g_lv[3] = lv_bi;
         pl.best_L[topic] = best;
         pl.info[topic * 4 + 0] += it;
         pl.info[topic * 4 + 1] = flags;
@@ -539,6 +549,10 @@ __global__ __launch_bounds__(64) void k_bound_begin(BoundPools pl, BoundWide wd,
     const int topic = pl.ids[i];
     pl.info[topic * 4 + 1] = 0;
     reinterpret_cast<int *>(wd.ctl + (size_t)topic * 8)[4] = 0;
+    if (pl.target[topic] & kDualRelevel) {   // level control afresh: the first step of the sequence re-initialises it
+        const TopicDev &T = pl.topics[topic];
+        reinterpret_cast<long long *>(pl.dual_pool + T.dual_off + 4 * T.B + 2 * kRackTab)[0] = 0;
+    }
 }
 
 // mode 0: iteration; 1 / 2: probe at the multipliers rounded to the quarter / half grid
@@ -637,10 +651,11 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
     const long long Lv = L.acc[0], nrm = L.acc[1];
     long long dn = L.acc[2];
     long long best = pl.best_L[topic];
-    const long long target = pl.target[topic];
+    const long long target = pl.target[topic] & ~kDualRelevel;
     long long lv_delta = g_lv[0], lv_rec = g_lv[1];
-    int lv_since = (int)g_lv[2];
-    const uint32_t lv_seq = (uint32_t)g_lv[3];
+    int lv_since = (int)(g_lv[2] & 0xFF);
+    const uint32_t lv_seq = (uint32_t)(g_lv[2] >> 8);
+    long long lv_bi = g_lv[3];
     __syncthreads();   // every thread holds the state of the previous step before thread 0 rewrites it
     if (Lv < best) {
         best = Lv;
@@ -661,11 +676,11 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
     const bool reset = dn == 0;
     if (reset) dn = 256 * nrm;
     int sh;
-    const long long step = bound_step_length(best, target, Lv, dn, lv_delta, lv_rec, lv_since, sh);
+    const long long step = bound_step_length(target, Lv, dn, lv_delta, lv_rec, lv_since, lv_bi, sh);
     bound_take_step(L, K, g_da, g_dl, reset, step, sh, lv_seq, tid, nt);
     for (int b = tid; b < B; b += nt) { g_a[b] = L.A[b]; g_l[b] = L.LM[b]; }
     if (tid < R) { g_g[tid] = L.G[tid]; g_dg[tid] = L.DG[tid]; }
-    if (tid == 0) { g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = lv_since; g_lv[3] = (long long)lv_seq + 1; }
+    if (tid == 0) { g_lv[0] = lv_delta; g_lv[1] = lv_rec; g_lv[2] = (long long)lv_since | (((long long)lv_seq + 1) << 8); g_lv[3] = lv_bi; }
 }
 
 // end of a launch sequence: the search prices (k_bound's epilogue)

@@ -1,4 +1,4 @@
-// kao_internal.h -- structures shared by the host API (kao_api.cpp) and the gfx950 kernels
+// kao_internal.h -- structures shared by the host side (kao_model.cpp, kao_session.cpp, kao_solve.cpp; see kao_host.h) and the gfx950 kernels
 // (kao_kernels.hip).  Not part of the C ABI.
 #pragma once
 #include <stdint.h>
@@ -22,6 +22,7 @@ constexpr int kDualScale = 1 << kDualLog2; // fixed point of the dual multiplier
 constexpr int kDualStage = 100;           // level control: iterations per stage (K-bound)
 constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
 constexpr int kDualQuarterLog2 = kDualLog2 - 2;  // kDualScale / 4: the quarter grid of the rounding probes and the search prices
+constexpr long long kDualRelevel = 1ll << 62;  // bit of BoundPools::target: restart the level control at this launch (kao_session_bound_relevel)
 constexpr int kDualProbes = 2;            // probes per K-bound launch: multipliers rounded to the quarter grid, then the half grid
 constexpr uint32_t kExternalRestart = 0xFFFFFu;  // restart id of a best key adopted from another GPU (kao_solve_multi)
 constexpr uint32_t kObjCap = 0xFFFFFFu;   // packed best key: viol(20) << 44 | (kObjCap - obj) << 20 | restart(20)
@@ -112,7 +113,7 @@ struct BoundPools {
     const uint16_t *ext_pool;    // rack-major internal index -> dense broker (members of every rack)
     const int32_t *rsz_pool;     // rack sizes
     int32_t *dual_pool;          // multipliers and previous directions, see TopicDev::dual_off
-    const long long *target;     // [n_topics] incumbent objective the Polyak step aims at
+    const long long *target;     // [n_topics] incumbent objective the Polyak step aims at (| kDualRelevel)
     long long *best_L;           // [n_topics] smallest dual value so far (fixed point, kDualScale)
     int32_t *info;               // [n_topics][4] = {iterations so far, flags of the last launch, -, -}
     int32_t iters;               // iterations this launch
@@ -164,7 +165,7 @@ CycleCtx *cycle_open(const kao_topic *t, int *rc_out);
 int cycle_run(CycleCtx *c, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8],
               int (*poll)(void *) = nullptr, void *poll_arg = nullptr);
 void cycle_close(CycleCtx *c);
-// helpers of the host API (kao_api.cpp) for the other translation units
+// helpers of the host side (kao_solve.cpp) for the device translation units
 int api_fail(int code, const char *msg);
 int api_require_init();
 double api_now_s();

@@ -1,0 +1,463 @@
+// kao_model.cpp -- the Kafka partition-assignment model on the host: validation of a kao_topic at the C-ABI boundary, the
+// band rule (floor / ceil, README.md:158-180), the dense -> rack-major internal broker index the kernels use, proofs of
+// infeasibility, and the closed-form upper bound on the objective (kao_upper_bound) -- the certificate that needs no solver.
+// Restated by the oracle (oracle/kao_oracle.py::upper_bound_forced / upper_bound_broker / provably_infeasible), which the
+// tests hold against HiGHS.  No device code, no search: nothing here computes an assignment.
+#include <cstdio>
+#include <cstring>
+
+#include "kao_host.h"
+
+namespace kao {
+
+void floor_ceil(int64_t num, int64_t den, int32_t &lo, int32_t &hi) {
+    lo = (int32_t)(num / den);
+    hi = (int32_t)((num + den - 1) / den);
+}
+
+int validate(const kao_topic *t) {
+    if (!t) return fail(KAO_ERR_INVALID, "null topic");
+    if (t->n_brokers < 1 || t->n_brokers > 65534) return fail(KAO_ERR_INVALID, "n_brokers out of range");
+    if (t->n_racks < 1) return fail(KAO_ERR_INVALID, "n_racks < 1");
+    if (t->n_racks > KAO_MAX_RACKS) return fail(KAO_ERR_UNSUPPORTED, "more than 255 racks");
+    if (t->n_partitions < 1) return fail(KAO_ERR_INVALID, "n_partitions < 1");
+    if (t->rf < 1 || t->rf_cur < 1) return fail(KAO_ERR_INVALID, "rf < 1");
+    if (t->rf > KAO_MAX_RF || t->rf_cur > KAO_MAX_RF) return fail(KAO_ERR_UNSUPPORTED, "replication factor > 8");
+    if (t->rf > t->n_brokers) return fail(KAO_ERR_INVALID, "rf > n_brokers");
+    if (!t->rack_of || !t->current) return fail(KAO_ERR_INVALID, "null rack_of/current");
+    for (int b = 0; b < t->n_brokers; ++b)
+        if (t->rack_of[b] >= t->n_racks) return fail(KAO_ERR_INVALID, "rack_of entry >= n_racks");
+    int wmax = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            if (t->w[i][j] < 0 || t->w[i][j] > 1023) return fail(KAO_ERR_INVALID, "objective weights must be 0..1023");
+            wmax = std::max(wmax, t->w[i][j]);
+        }
+    int bwmax = 0, bwlmax = 0;
+    for (int b = 0; b < t->n_brokers; ++b) {
+        const int v = t->broker_w ? t->broker_w[b] : 0, vl = t->broker_wl ? t->broker_wl[b] : 0;
+        if (v < 0 || v > 1023 || vl < 0 || vl > 1023) return fail(KAO_ERR_INVALID, "broker weights must be 0..1023");
+        bwmax = std::max(bwmax, v); bwlmax = std::max(bwlmax, vl);
+    }
+    if ((int64_t)t->n_partitions * t->rf * (wmax + bwmax) + (int64_t)t->n_partitions * bwlmax > 0xFFFFFE)
+        return fail(KAO_ERR_UNSUPPORTED, "objective can exceed 24 bits (n_partitions * rf * largest weight)");
+    for (int p = 0; p < t->n_partitions; ++p) {  // one LP variable per (broker, partition) (README.md:146): a broker cannot be listed twice
+        const uint16_t *c = t->current + (size_t)p * t->rf_cur;
+        for (int k = 1; k < t->rf_cur; ++k)
+            for (int j = 0; j < k; ++j)
+                if (c[k] == c[j] && c[k] < t->n_brokers)
+                    return fail(KAO_ERR_INVALID, "current assignment lists a broker twice in partition " + std::to_string(p));
+    }
+    if ((int64_t)t->n_partitions * t->rf > 4000000) return fail(KAO_ERR_UNSUPPORTED, "more than 4,000,000 replicas in one topic");
+    if ((int64_t)t->n_partitions * t->rf_cur > 65535) {  // per-broker counters are 16 + 16 bits (replicas | leaders)
+        std::vector<int32_t> cnt((size_t)t->n_brokers, 0);
+        for (int64_t i = 0, n = (int64_t)t->n_partitions * t->rf_cur; i < n; ++i)
+            if (t->current[i] < t->n_brokers && ++cnt[t->current[i]] > 65535)
+                return fail(KAO_ERR_UNSUPPORTED, "current assignment puts more than 65,535 replicas on one broker (16-bit per-broker counters)");
+    }
+    if (((int64_t)t->n_partitions * t->rf + t->n_brokers - 1) / t->n_brokers > 30000)
+        return fail(KAO_ERR_UNSUPPORTED, "more than 30,000 replicas per broker on average (16-bit per-broker counters)");
+    return KAO_OK;
+}
+
+void derive_bounds(const kao_topic *t, int32_t o[8]) {
+    const int64_t B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
+    floor_ceil(P * RF, B, o[0], o[1]);  // C3 README.md:158-161
+    floor_ceil(P, B, o[2], o[3]);       // C4 README.md:163-166
+    floor_ceil(P * RF, R, o[4], o[5]);  // C6 README.md:173-176
+    floor_ceil(RF, R, o[6], o[7]);      // C7 README.md:178-180
+    const int32_t ov[8] = {t->rep_lo, t->rep_hi, t->lead_lo, t->lead_hi, t->rack_lo, t->rack_hi, t->prack_lo, t->prack_hi};
+    for (int i = 0; i < 8; ++i)
+        if (ov[i] >= 0) o[i] = ov[i];
+}
+
+int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt) {
+    int rc = validate(t);
+    if (rc) return rc;
+    const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    pt.rack_size.assign(R, 0);
+    for (int b = 0; b < B; ++b) pt.rack_size[t->rack_of[b]]++;
+    int m = 0;
+    for (int r = 0; r < R; ++r) m = std::max(m, pt.rack_size[r]);
+    m = std::max(m, 2);  // floor(2^32/m)+1 must fit 32 bits: single-broker racks get a stride of 2
+    const int64_t Bx = (int64_t)R * m;
+    if (Bx > 65534) return fail(KAO_ERR_UNSUPPORTED, "racks x largest-rack exceeds the 16-bit internal index");
+    pt.int_of.assign(B, 0);
+    pt.ext_of.assign((size_t)Bx, (uint16_t)KAO_NONE);
+    std::vector<int> fill(R, 0);
+    for (int b = 0; b < B; ++b) {  // dense order inside each rack is preserved
+        const int r = t->rack_of[b];
+        const int x = r * m + fill[r]++;
+        pt.int_of[b] = (uint16_t)x;
+        pt.ext_of[x] = (uint16_t)b;
+    }
+    const int nw = (t->rf > kRFP || t->rf_cur > kRFP) ? kMaxRF : kRFP;   // replica words per partition in K-search / K-canon / K-eval
+    pt.cur_int.assign((size_t)P * nw, (uint16_t)KAO_NONE);
+    for (int p = 0; p < P; ++p)
+        for (int k = 0; k < t->rf_cur; ++k) {
+            const unsigned b = t->current[(size_t)p * t->rf_cur + k];
+            if (b < (unsigned)B) pt.cur_int[(size_t)p * nw + k] = pt.int_of[b];
+        }
+    pt.rack_of.assign(t->rack_of, t->rack_of + B);
+    pt.cur_dense.assign(t->current, t->current + (size_t)P * t->rf_cur);
+    TopicDev &d = pt.d;
+    d.P = P; d.RF = t->rf; d.R = R; d.m = m; d.Bx = (int32_t)Bx;
+    d.magic = (uint32_t)(0x100000000ull / (uint64_t)m) + 1u;
+    d.rep_lo = bd[0]; d.rep_hi = bd[1]; d.lead_lo = bd[2]; d.lead_hi = bd[3];
+    d.rack_lo = bd[4]; d.rack_hi = bd[5]; d.prack_lo = bd[6]; d.prack_hi = bd[7];
+    d.w00 = t->w[0][0]; d.w01 = t->w[0][1]; d.w10 = t->w[1][0]; d.w11 = t->w[1][1];
+    d.seed_lo = (uint32_t)seed; d.seed_hi = (uint32_t)(seed >> 32);
+    d.B = B; d.rf_cur = t->rf_cur; d.nw = nw;
+    d.has_bw = (t->broker_w || t->broker_wl) ? 1 : 0;
+    if (d.has_bw) {
+        pt.bw_dense.assign((size_t)B, 0);
+        pt.bw_int.assign((size_t)Bx, 0);
+        for (int b = 0; b < B; ++b) {
+            const uint32_t v = (uint32_t)(t->broker_w ? t->broker_w[b] : 0) | ((uint32_t)(t->broker_wl ? t->broker_wl[b] : 0) << 16);
+            pt.bw_dense[(size_t)b] = v;
+            pt.bw_int[pt.int_of[(size_t)b]] = v;
+        }
+    }
+    return KAO_OK;
+}
+
+// Necessary conditions checked by counting; empty string = not provably infeasible (kao_check_infeasible).
+std::string infeasible_reason(const kao_topic *t) {
+    const int64_t B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf, n = P * RF;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    const int64_t rep_lo = bd[0], rep_hi = bd[1], lead_lo = bd[2], lead_hi = bd[3], rack_lo = bd[4], rack_hi = bd[5], prack_lo = bd[6], prack_hi = bd[7];
+    std::vector<int64_t> rs((size_t)R, 0);
+    for (int b = 0; b < t->n_brokers; ++b) rs[t->rack_of[b]]++;
+    if (RF > B) return "rf > brokers";
+    if (!(B * rep_lo <= n && n <= B * rep_hi)) return "replicas per broker band cannot hold P*RF replicas";
+    if (!(B * lead_lo <= P && P <= B * lead_hi)) return "leaders per broker band cannot hold P leaders";
+    if (!(R * rack_lo <= n && n <= R * rack_hi)) return "replicas per rack band cannot hold P*RF replicas";
+    int64_t sum_hi = 0, sum_lo = 0, spread = 0;
+    for (int r = 0; r < t->n_racks; ++r) {
+        const int64_t hi = std::min(rack_hi, std::min(rs[(size_t)r] * rep_hi, P * std::min(prack_hi, rs[(size_t)r])));
+        const int64_t lo = std::max(rack_lo, std::max(rs[(size_t)r] * rep_lo, P * prack_lo));
+        if (lo > hi) return "rack " + std::to_string(r) + ": needs at least " + std::to_string(lo) + " replicas but can hold at most " + std::to_string(hi);
+        sum_hi += hi; sum_lo += lo;
+        spread += std::min(prack_hi, rs[(size_t)r]);
+        if (prack_lo > rs[(size_t)r]) return "per-partition rack floor cannot be met";
+    }
+    if (sum_hi < n) return "rack capacities sum below P*RF";
+    if (sum_lo > n) return "rack floors sum above P*RF";
+    if (spread < RF) return "a partition cannot spread RF replicas over the racks";
+    if (R * prack_lo > RF) return "per-partition rack floor cannot be met";
+    return "";
+}
+
+// Best value one partition can collect from a kept set: its current leader (if kept) and n_fol kept current
+// followers, at most rf replicas, exactly one leader; coupling rows (C3, C4, C6, C7) ignored.
+int64_t partition_value(const kao_topic *t, bool lead_kept, int n_fol, bool leader_may_lead = true) {
+    const int slots = t->rf - 1;
+    const int wLL = t->w[0][0], wLF = t->w[0][1], wFL = t->w[1][0], wFF = t->w[1][1];
+    auto fol_sum = [&](int n_ff, bool old_leader) {  // best `slots` follower gains among n_ff x wFF (+ wLF)
+        int64_t v = 0;
+        int left = slots;
+        const bool lf_first = old_leader && wLF > wFF;
+        if (lf_first && left > 0 && wLF > 0) { v += wLF; --left; }
+        const int take = std::min(left, n_ff);
+        if (wFF > 0 && take > 0) { v += (int64_t)take * wFF; left -= take; }
+        if (old_leader && !lf_first && left > 0 && wLF > 0) v += wLF;
+        return v;
+    };
+    int64_t best = fol_sum(n_fol, lead_kept);                                         // a new broker leads
+    if (lead_kept && leader_may_lead) best = std::max(best, wLL + fol_sum(n_fol, false));  // current leader stays leader
+    if (n_fol) best = std::max(best, wFL + fol_sum(n_fol - 1, lead_kept));            // a current follower is promoted
+    return best;
+}
+
+// Upper bound on the objective (kao_upper_bound): every partition keeps its best surviving replicas in
+// their best roles, minus the cheapest way to perform the evictions / leader changes that EVERY feasible
+// assignment must perform.  f_p(K) = partition_value of a kept subset K.  With s_b / s_r / s_(p,r) the
+// surviving replicas per broker / rack / (partition, rack) cell, at least
+//   k = max( sum_b (s_b - rep_hi)+, sum_r (s_r - rack_hi)+, sum_cells (s - prack_hi)+,
+//            n_surv + sum_b (rep_lo - s_b)+ - P*RF,  n_surv + sum_r (rack_lo - s_r)+ - P*RF )
+// replicas cannot be kept (one eviction lowers one broker, one rack and one cell count; lower bands need
+// arrivals and only P*RF - kept slots can take them).  g_p(j) = f_p(all) - max_{|K| = n_p - j} f_p(K); the
+// total loss is at least the k smallest marginals of the lower convex envelopes of the g_p.  Brokers with
+// more current leaders than lead_hi force leader changes, each costing f_p(all) - f_p(leader not leading).
+// Both losses may hit the same partitions, so the larger is subtracted; the result is then capped by the
+// per-broker capacity bound below.  Restated (and checked against the exact optimum) in
+// oracle/kao_oracle.py::upper_bound_forced / upper_bound_broker.
+int64_t upper_bound(const kao_topic *t) {
+    const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    const int rep_lo = bd[0], rep_hi = bd[1], lead_hi = bd[3], rack_lo = bd[4], rack_hi = bd[5], prack_hi = bd[7];
+    // Everything per partition depends only on (current leader survives, number of surviving followers): 2 x 4 combos.
+    struct Combo { int64_t f_all = 0, lead_loss = 0; int n_marg = 0; int64_t marg[KAO_MAX_RF + 1] = {0}; int64_t count = 0; } combo[2 * KAO_MAX_RF];
+    for (int la = 0; la < 2; ++la)
+        for (int n_fol = 0; n_fol < KAO_MAX_RF; ++n_fol) {
+            Combo &c = combo[la * KAO_MAX_RF + n_fol];
+            const bool lead_alive = la != 0;
+            const int n_p = n_fol + la;
+            c.f_all = partition_value(t, lead_alive, n_fol);
+            int64_t g[KAO_MAX_RF + 1];
+            for (int j = 0; j <= n_p; ++j) {  // cheapest loss of evicting j replicas (followers are interchangeable)
+                int64_t best = -1;
+                for (int drop_lead = 0; drop_lead <= la; ++drop_lead) {
+                    const int df = j - drop_lead;
+                    if (df >= 0 && df <= n_fol) best = std::max(best, partition_value(t, lead_alive && !drop_lead, n_fol - df));
+                }
+                g[j] = c.f_all - best;
+            }
+            int hx[KAO_MAX_RF + 1]; int64_t hy[KAO_MAX_RF + 1]; int hn = 0;  // lower convex envelope of (j, g[j])
+            for (int j = 0; j <= n_p; ++j) {
+                hx[hn] = j; hy[hn] = g[j]; ++hn;
+                while (hn >= 3 && (hy[hn - 2] - hy[hn - 3]) * (hx[hn - 1] - hx[hn - 3]) >= (hy[hn - 1] - hy[hn - 3]) * (hx[hn - 2] - hx[hn - 3])) {
+                    hx[hn - 2] = hx[hn - 1]; hy[hn - 2] = hy[hn - 1]; --hn;
+                }
+            }
+            for (int i = 0; i + 1 < hn; ++i)
+                for (int x = hx[i] + 1; x <= hx[i + 1]; ++x) {  // integer floor of the envelope stays a lower bound
+                    const int64_t dy = hy[i + 1] - hy[i], dx = hx[i + 1] - hx[i];
+                    const int64_t prev = hy[i] + (dy * (x - 1 - hx[i])) / dx, now = hy[i] + (dy * (x - hx[i])) / dx;
+                    c.marg[c.n_marg++] = now - prev;
+                }
+            if (lead_alive) {
+                const int64_t alt = std::max(partition_value(t, false, n_fol), partition_value(t, true, n_fol, false));
+                c.lead_loss = std::max<int64_t>(0, c.f_all - alt);
+            }
+        }
+    std::vector<int> s_b((size_t)B, 0), s_r((size_t)R, 0), lead_b((size_t)B, 0);
+    std::vector<int> nl_b((size_t)B, 0);  // surviving current LEADER replicas per broker (followers = s_b - nl_b)
+    std::vector<int> touched;             // brokers holding at least one surviving replica
+    int64_t total = 0, n_surv = 0, cell_excess = 0, parts_with_survivor = 0;
+    for (int p = 0; p < P; ++p) {
+        const uint16_t *c = t->current + (size_t)p * t->rf_cur;
+        const bool lead_alive = c[0] < (unsigned)B;
+        int n_fol = 0, racks[KAO_MAX_RF], n_in = 0;
+        for (int k = 0; k < t->rf_cur; ++k) {
+            if (c[k] >= (unsigned)B) continue;
+            if (k > 0) ++n_fol;
+            if (s_b[c[k]]++ == 0) touched.push_back((int)c[k]);
+            s_r[t->rack_of[c[k]]]++;
+            racks[n_in++] = t->rack_of[c[k]];
+        }
+        n_surv += n_in;
+        parts_with_survivor += n_in > 0;
+        for (int i = 0; i < n_in; ++i) {  // cells: count each rack once
+            bool first = true;
+            int cnt = 0;
+            for (int j = 0; j < n_in; ++j) { if (racks[j] == racks[i]) { ++cnt; if (j < i) first = false; } }
+            if (first) cell_excess += std::max(0, cnt - prack_hi);
+        }
+        Combo &cb = combo[(lead_alive ? KAO_MAX_RF : 0) + n_fol];
+        total += cb.f_all;
+        cb.count++;
+        if (lead_alive) { nl_b[c[0]]++; lead_b[c[0]]++; }
+    }
+    int64_t ex_b = 0, ex_r = 0, need_b = 0, need_r = 0;
+    need_b = (int64_t)std::max(0, rep_lo) * ((int64_t)B - (int64_t)touched.size());  // untouched brokers hold nothing
+    for (int b : touched) { ex_b += std::max(0, s_b[(size_t)b] - rep_hi); need_b += std::max(0, rep_lo - s_b[(size_t)b]); }
+    for (int r = 0; r < R; ++r) { ex_r += std::max(0, s_r[r] - rack_hi); need_r += std::max(0, rack_lo - s_r[r]); }
+    const int64_t slots = (int64_t)P * RF;
+    int64_t k = std::max<int64_t>({ex_b, ex_r, cell_excess, n_surv + need_b - slots, n_surv + need_r - slots, 0});
+    // the k smallest marginals over all partitions, taken combo by combo (value, multiplicity)
+    std::vector<std::pair<int64_t, int64_t>> vm;
+    for (const Combo &c : combo)
+        for (int i = 0; i < c.n_marg; ++i)
+            if (c.count) vm.emplace_back(c.marg[i], c.count);
+    std::sort(vm.begin(), vm.end());
+    int64_t evict_loss = 0, left = k;
+    for (const auto &e : vm) {
+        if (left <= 0) break;
+        const int64_t take = std::min(left, e.second);
+        evict_loss += take * e.first;
+        left -= take;
+    }
+    int64_t lead_loss = 0;
+    bool over_led = false;
+    for (int b : touched) over_led |= lead_b[(size_t)b] > lead_hi;
+    if (over_led) {  // rare: collect the per-partition losses only for brokers holding too many current leaders
+        std::vector<std::pair<int, int64_t>> lead_losses;
+        for (int p = 0; p < P; ++p) {
+            const uint16_t *c = t->current + (size_t)p * t->rf_cur;
+            if (c[0] >= (unsigned)B || lead_b[c[0]] <= lead_hi) continue;
+            int n_fol = 0;
+            for (int q = 1; q < t->rf_cur; ++q) n_fol += c[q] < (unsigned)B;
+            lead_losses.emplace_back((int)c[0], combo[KAO_MAX_RF + n_fol].lead_loss);
+        }
+        std::sort(lead_losses.begin(), lead_losses.end());
+        for (size_t i = 0; i < lead_losses.size();) {
+            size_t j = i;
+            while (j < lead_losses.size() && lead_losses[j].first == lead_losses[i].first) ++j;
+            const int ex = lead_b[(size_t)lead_losses[i].first] - lead_hi;
+            for (size_t q = i; q < j && (int)(q - i) < ex; ++q) lead_loss += lead_losses[q].second;  // sorted by loss within a broker
+            i = j;
+        }
+    }
+    // Per-broker capacity bound with a global cap on leading survivors.  A broker keeps at most rep_hi of its
+    // surviving replicas and at most lead_hi of them lead; a replica that leads is worth w[cur_role][0], one that
+    // follows w[cur_role][1] (one-leader-per-partition and rack rows relaxed).  v_b(L) = best value on broker b with
+    // at most L survivors leading.  Brokers with fewer than lead_lo survivors must receive lead_lo - s_b NEW leaders,
+    // so at most Lcap = min(#partitions with a survivor, P - sum_b (lead_lo - s_b)+) partitions keep a surviving
+    // replica as leader: bound = sum_b v_b(0) + the Lcap largest marginals of the upper concave envelopes of the v_b.
+    // Charges forced evictions AND forced leader changes together.
+    const int wLL = t->w[0][0], wLF = t->w[0][1], wFL = t->w[1][0], wFF = t->w[1][1];
+    const int lead_lo = bd[2];
+    int64_t lcap = P - (int64_t)std::max(0, lead_lo) * ((int64_t)B - (int64_t)touched.size());
+    for (int b : touched) lcap -= std::max(0, lead_lo - s_b[(size_t)b]);
+    lcap = std::min<int64_t>(lcap, parts_with_survivor);
+    // brokers with the same (surviving leaders, surviving followers) share v_b: evaluate each distinct pair once
+    // (only brokers that hold a surviving replica are visited; all others are the kind (0, 0))
+    std::vector<std::pair<std::pair<int, int>, int64_t>> kinds;  // ((n_l, n_f), number of brokers)
+    kinds.push_back({{0, 0}, (int64_t)B - (int64_t)touched.size()});
+    for (int b : touched) {
+        const std::pair<int, int> key{nl_b[(size_t)b], s_b[(size_t)b] - nl_b[(size_t)b]};
+        size_t i = 0;
+        while (i < kinds.size() && kinds[i].first != key) ++i;
+        if (i == kinds.size()) kinds.push_back({key, 0});
+        kinds[i].second++;
+    }
+    int64_t broker_base = 0;
+    std::vector<std::pair<int64_t, int64_t>> lead_marg;  // (marginal value, multiplicity)
+    std::vector<int64_t> v, hx, hy;
+    for (const auto &kind : kinds) {
+        const int n_l = kind.first.first, n_f = kind.first.second;
+        const int64_t mult = kind.second;
+        const int lmax = std::min(std::min(lead_hi, rep_hi), n_l + n_f);
+        v.assign((size_t)lmax + 1, -1);
+        for (int x = 0; x <= std::min(n_l, lmax); ++x)
+            for (int y = 0; y <= std::min(n_f, lmax - x); ++y) {
+                int64_t val = (int64_t)x * wLL + (int64_t)y * wFL;
+                int slots = rep_hi - x - y;
+                const int ga = n_l - x, gb = n_f - y;  // ga replicas worth wLF as followers, gb worth wFF
+                const int hi_w = std::max(wLF, wFF), lo_w = std::min(wLF, wFF);
+                const int hi_n = wLF >= wFF ? ga : gb, lo_n = wLF >= wFF ? gb : ga;
+                const int t1 = std::min(hi_n, slots);
+                if (hi_w > 0) val += (int64_t)t1 * hi_w;
+                slots -= t1;
+                if (lo_w > 0) val += (int64_t)std::min(lo_n, slots) * lo_w;
+                v[(size_t)(x + y)] = std::max(v[(size_t)(x + y)], val);
+            }
+        for (int i = 1; i <= lmax; ++i) v[(size_t)i] = std::max(v[(size_t)i], v[(size_t)i - 1]);  // "at most L leading"
+        broker_base += v[0] * mult;
+        hx.clear(); hy.clear();  // upper concave envelope of (L, v[L]) -> non-increasing marginals
+        for (int i = 0; i <= lmax; ++i) {
+            hx.push_back(i); hy.push_back(v[(size_t)i]);
+            while (hx.size() >= 3) {
+                const size_t n = hx.size();
+                if ((hy[n - 2] - hy[n - 3]) * (hx[n - 1] - hx[n - 3]) <= (hy[n - 1] - hy[n - 3]) * (hx[n - 2] - hx[n - 3])) {
+                    hx[n - 2] = hx[n - 1]; hy[n - 2] = hy[n - 1]; hx.pop_back(); hy.pop_back();
+                } else break;
+            }
+        }
+        for (size_t i = 0; i + 1 < hx.size(); ++i)
+            for (int64_t x = hx[i] + 1; x <= hx[i + 1]; ++x) {  // ceil of the running total keeps it an upper bound
+                const int64_t dy = hy[i + 1] - hy[i], dx = hx[i + 1] - hx[i];
+                auto up = [&](int64_t k) { const int64_t num = dy * k; return hy[i] + (num >= 0 ? (num + dx - 1) / dx : -((-num) / dx)); };
+                const int64_t m = up(x - hx[i]) - up(x - 1 - hx[i]);
+                if (m > 0) lead_marg.emplace_back(m, mult);
+            }
+    }
+    std::sort(lead_marg.begin(), lead_marg.end(), [](const std::pair<int64_t, int64_t> &p, const std::pair<int64_t, int64_t> &q) { return p.first > q.first; });
+    int64_t broker_bound = broker_base, cap_left = std::max<int64_t>(lcap, 0);
+    for (const auto &e : lead_marg) {
+        if (cap_left <= 0) break;
+        const int64_t take = std::min(cap_left, e.second);
+        broker_bound += take * e.first;
+        cap_left -= take;
+    }
+    return std::min(total - std::max(evict_loss, lead_loss), broker_bound);
+}
+
+// Closed-form bound of a topic that may carry broker weights: the weights are bounded term by term -- the band rows allow at
+// most min(rep_hi, P) replicas and min(lead_hi, P) leaders on a broker, P*RF replicas and P leaders in all, so the
+// weight part is at most the greedy fill of those capacities in descending weight order.
+int64_t upper_bound_w(const kao_topic *t) {
+    int64_t ub = upper_bound(t);
+    if (!t->broker_w && !t->broker_wl) return ub;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    for (int kind = 0; kind < 2; ++kind) {
+        const int32_t *w = kind == 0 ? t->broker_w : t->broker_wl;
+        if (!w) continue;
+        std::vector<int> v(w, w + t->n_brokers);
+        std::sort(v.begin(), v.end(), std::greater<int>());
+        int64_t left = kind == 0 ? (int64_t)t->n_partitions * t->rf : t->n_partitions;
+        const int64_t per = std::min<int64_t>(kind == 0 ? bd[1] : bd[3], t->n_partitions);
+        for (int x : v) {
+            if (left <= 0) break;
+            const int64_t take = std::min(left, per);
+            ub += take * x;
+            left -= take;
+        }
+    }
+    return ub;
+}
+
+// Neighbours delta-evaluated by ONE restart over iterations [it0, it0+iters) (kao_kernels.hip, KAO-LS):
+// move pattern R R X R L R X R; REPLACE scans all B brokers of one slot in even blocks of 8 iterations and
+// samples 64 lanes x 4 brokers in odd blocks; EXCHANGE scans all P*RF partner slots (a window of 512 partitions
+// when P > 512); LEADER-SWAP 64 x (RF-1).
+uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers, int n_partitions) {
+    static const uint8_t pat[8] = {0, 0, 1, 0, 2, 0, 1, 0};
+    uint64_t n = 0;
+    for (uint32_t i = 0; i < iters; ++i) {
+        const uint32_t it = it0 + i;
+        const int type = pat[it & 7];
+        if (type == 0) n += ((it >> 3) & 1u) ? 256ull : (uint64_t)n_brokers;
+        else if (type == 1) n += (uint64_t)std::min(n_partitions, n_partitions > 512 ? 512 : n_partitions) * (uint64_t)rf;
+        else n += 64ull * (uint64_t)(rf > 1 ? rf - 1 : 0);
+    }
+    return n;
+}
+
+// Sawtooth period by topic size: one ramp should span about 2 * P * RF iterations (every slot gets a chance to move
+// while the penalty is low).  Measured on a drifted 2000-partition topic (optimum 14812): 2^8 -> 14777, 2^11 -> 14794,
+// 2^14 -> 14801..14806; small topics keep the 2^8 they were tuned with.
+int auto_period_log2(int P, int RF) {
+    int64_t n = 2 * (int64_t)P * RF;
+    int lg = 0;
+    while (n > 1) { n >>= 1; ++lg; }
+    return std::min(16, std::max(8, lg));
+}
+
+// K-bound limits: 19 B of LDS per broker + 72 B per rack; 32-bit headroom of the priced values (weights x 4096,
+// P*RF subgradients)
+bool dual_supported(const kao_topic *t) {
+    if (t->rf > kRFP || t->rf_cur > kRFP) return false;   // K-bound's per-lane subproblem holds 4 replicas
+    if (t->broker_w || t->broker_wl) return false;        // K-bound prices the README rows only
+    if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false) > 160 * 1024) return false;
+    const int64_t n = (int64_t)t->n_partitions * t->rf;
+    if (n > 131072) return false;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (t->w[i][j] < 0 || t->w[i][j] > 255) return false;
+    return true;
+}
+
+}  // namespace kao
+
+extern "C" {
+
+int kao_derive_bounds(const kao_topic *t, int32_t out[8]) {
+    int rc = validate(t);
+    if (rc) return rc;
+    derive_bounds(t, out);
+    return KAO_OK;
+}
+
+int kao_check_infeasible(const kao_topic *t, char *why, int why_len) {
+    int rc = validate(t);
+    if (rc) return rc;
+    const std::string r = infeasible_reason(t);
+    if (why && why_len > 0) std::snprintf(why, (size_t)why_len, "%s", r.c_str());
+    return r.empty() ? 0 : 1;
+}
+
+int kao_upper_bound(const kao_topic *t, int64_t *ub) {
+    int rc = validate(t);
+    if (rc) return rc;
+    *ub = upper_bound_w(t);
+    return KAO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,734 @@
+// kao_solve.cpp -- host side of libkao.so, part 3 of 3 (see kao_host.h): the solve loops on top of sessions.
+//   kao_solve         one device: K-search launches, K-bound beside them on its own stream, KAO-CX (kao_cycle.hip) for
+//                     incumbents the search has stopped improving, stop at the proof
+//   kao_solve_multi   several GPUs in one process: topics dealt LPT, or every GPU on every topic with the elites exchanged by
+//                     ncclAllReduce(min) / ncclBroadcast on the resident key buffers (librccl is opened on first use)
+//   kao_solve_capped  cluster-wide per-broker load caps: Lagrangian prices over independent per-topic solves
+#include <rccl/rccl.h>  // types and prototypes only: librccl.so is loaded on first use (kao_solve_multi), see Rccl below
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "kao_host.h"
+
+namespace {
+
+// One whole job on one device: the kao_solve loop, cut into steps so that kao_solve_multi can drive several of them in
+// lockstep from one host thread (launches of all devices are enqueued before any of them is waited for).
+struct SolveRun {
+    kao_session *s = nullptr;
+    int n = 0;
+    bool has_target = false;
+    std::vector<int64_t> target;
+    std::vector<uint64_t> keys, prev;
+    std::vector<double> t_best;
+    std::vector<int64_t> dual_target;
+    double t0 = 0, t_last_improve = 0;
+    int launches = 0, dual_iters = 0, dual_now = 0;
+    bool use_prices = true, all_done = false;
+    // KAO-CX (kao_cycle.hip): cyclic-exchange improvement of incumbents K-search has stopped improving
+    const kao_topic *topics = nullptr;
+    std::vector<kao_topic> xt;                    // the session's topics: every caller topic `islands` times
+    std::vector<int> origin;                      // session topic -> caller topic
+    int n_user = 0;
+    bool cx_on = true;
+    bool cx_eager = false;                        // test hook KAO_CX_EAGER=1: KAO-CX after every launch, whatever the clock says
+    double deadline = 0;
+    std::vector<double> t_improved, t_cx;         // per topic: last improvement, last KAO-CX call (seconds from t0)
+    std::vector<uint64_t> cx_seen;                // packed key KAO-CX last ran to a fixpoint on
+    std::vector<uint16_t> cx_buf;
+    std::vector<CycleCtx *> cx_ctx;
+    int cx_calls = 0, cx_gains = 0;
+    double cx_slice = 0.1;                        // seconds one KAO-CX call may take
+
+    ~SolveRun() { for (CycleCtx *c : cx_ctx) cycle_close(c); if (s) kao_session_destroy(s); }
+
+    // `so` is the caller's options with kao_solve's defaults applied; the session is created on the calling thread's device
+    int begin(const kao_topic *user_topics, int n_topics, const kao_opts &so, const int64_t *tgt, double t_start, bool allow_islands = false) {
+        t0 = t_start;
+        n_user = n_topics;
+        // Islands (kao_opts.islands > 1, off by default): every topic is searched as several independent copies (own seed,
+        // own restarts, own elite, own K-bound trajectory and prices, own KAO-CX) sharing one copy's restart budget;
+        // certificates are shared, the best copy answers.  Measured on the drifted 300 x 2000 topic (4 islands, 4 seeds,
+        // 8 s): 14825 / 14825 / 14824 / 14822 against 14825 / 14826 (proven) / ... without -- no gain, so not the default.
+        int k = 1;
+        if (allow_islands && user_topics && n_topics >= 1 && so.restarts <= 0 && so.islands > 1) k = std::min(so.islands, 8);
+        xt.clear(); origin.clear();
+        for (int i = 0; i < n_topics; ++i)
+            for (int c = 0; c < k; ++c) { xt.push_back(user_topics[i]); origin.push_back(i); }
+        const kao_topic *topics = xt.data();
+        kao_opts so_x = so;
+        if (k > 1) {   // the islands share what one copy would have got: same work per launch, k basins
+            int64_t slots = 1;
+            for (int i = 0; i < n_topics; ++i) slots = std::max<int64_t>(slots, (int64_t)user_topics[i].n_partitions * std::max(user_topics[i].rf, 1));
+            (void)require_init();
+            const int cu = std::max(num_cu(cur_device()), 1);
+            int r = std::min(std::max((cu * 32 / n_topics) / kWaves * kWaves, 8), 8192);
+            r = std::min<int>(r, (int)std::max<int64_t>(cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves));
+            so_x.restarts = std::max((r / k) / kWaves * kWaves, 2 * kWaves);
+        }
+        n = n_topics = (int)xt.size();
+        int rc = kao_session_create(topics, n_topics, &so_x, &s);
+        if (rc) return rc;
+        has_target = tgt != nullptr;
+        if (tgt) { target.resize((size_t)n); for (int i = 0; i < n; ++i) target[(size_t)i] = tgt[origin[(size_t)i]]; }
+        keys.assign((size_t)n, 0); prev.assign((size_t)n, ~0ull); t_best.assign((size_t)n, 0.0); dual_target.assign((size_t)n, -1);
+        this->topics = topics;
+        t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
+        cx_on = so.use_cycles >= 0;
+        { const char *e = std::getenv("KAO_CX_EAGER"); cx_eager = e && e[0] == '1'; }
+        cx_ctx.assign((size_t)n, nullptr);
+        cx_slice = std::max(0.1, 0.1 * (so.time_limit_s > 0 ? so.time_limit_s : 10.0));
+        deadline = t_start + (so.time_limit_s > 0 ? so.time_limit_s : 10.0);
+        const kao_opts &o = s->opts;
+        dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 128 : o.dual_iters);
+        dual_now = dual_iters;
+        use_prices = so.use_prices >= 0;
+        return KAO_OK;
+    }
+    int launch() { return kao_session_step(s); }   // asynchronous
+    bool feasible(int i) const { return (keys[(size_t)i] >> 44) == 0; }
+    int64_t objective(int i) const { return (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF); }
+    bool topic_done(int i) const {
+        if (s->topic_infeasible[(size_t)i]) return true;  // proven infeasible: nothing to wait for
+        const int64_t goal = has_target ? target[(size_t)i] : s->ub[(size_t)i];
+        return feasible(i) && objective(i) >= goal;
+    }
+    bool check_done() const {   // every caller topic has one island that is done
+        for (int i = 0; i < n;) {
+            bool any = false;
+            int j = i;
+            for (; j < n && origin[(size_t)j] == origin[(size_t)i]; ++j) any = any || topic_done(j);
+            if (!any) return false;
+            i = j;
+        }
+        return true;
+    }
+    void share_bounds() {       // a certificate of any island holds for its caller topic
+        for (int i = 0; i < n;) {
+            int64_t ub = INT64_MAX;
+            int j = i;
+            for (; j < n && origin[(size_t)j] == origin[(size_t)i]; ++j) ub = std::min(ub, s->ub[(size_t)j]);
+            for (int q = i; q < j; ++q) s->ub[(size_t)q] = ub;
+            i = j;
+        }
+    }
+    // waits for the launch, books improvements, merges a finished K-bound launch and starts the next one
+    int after_launch() {
+        int rc = kao_session_best_keys(s, keys.data());
+        if (rc) return rc;
+        ++launches;
+        const double t = now_s() - t0;
+        for (int i = 0; i < n; ++i)
+            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; t_improved[(size_t)i] = t; }
+        all_done = check_done();
+        if ((rc = service_bound())) return rc;
+        if (cx_on && !all_done && !has_target && (rc = cycles(t))) return rc;
+        return KAO_OK;
+    }
+    // K-bound runs beside the search on its own stream; when a launch has finished its certificates are merged and, while
+    // some feasible incumbent is still below its bound, the next launch starts (aimed at the new incumbents).  Launch length
+    // adapts so that one launch takes about 10 ms.  Called after every K-search launch and between the rounds of KAO-CX.
+    int service_bound() {
+        if (has_target || dual_iters <= 0) return KAO_OK;
+        int rc;
+        const int busy = kao_session_bound_busy(s);
+        if (busy < 0) return busy;
+        if (busy) return KAO_OK;
+        if (s->bound_inflight) {
+            if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
+            share_bounds();
+            // the finished launch's multipliers (rounded to quarters) become the prices of the next K-search launches
+            if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
+            if (s->bound_ms_last > 0) {
+                const double scale = 10.0 / s->bound_ms_last;
+                dual_now = (int)std::min(4096.0, std::max(32.0, s->bound_iters_last * std::min(4.0, std::max(0.25, scale))));
+            }
+            all_done = check_done();
+        }
+        bool any = false;
+        for (int i = 0; i < n && !all_done; ++i) {
+            const bool want = feasible(i) && objective(i) < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
+                              !(s->dual_flags[(size_t)i] & 6);
+            dual_target[(size_t)i] = want ? objective(i) : -1;
+            any |= want;
+        }
+        if (any && (rc = kao_session_bound_step(s, dual_target.data(), dual_now))) return rc;
+        return KAO_OK;
+    }
+    // between the rounds of KAO-CX K-bound is serviced.  (Keeping K-search running as well -- launches enqueued from here
+    // whenever its stream had drained -- was measured and dropped: 300 x 2000, 8 seeds, 3 s: mean 14823.5 with, 14824.4 without.)
+    static int poll_bound(void *self) { return static_cast<SolveRun *>(self)->service_bound(); }
+    // KAO-CX for feasible, unproven topics whose search has stalled (no improvement for 50 ms) or that have not been looked at
+    // for 250 ms: the incumbent goes through kao_cycle.hip to a fixpoint of the cyclic-exchange neighbourhood and, when that
+    // improved it, comes back as the topic's incumbent (elite launches re-seed the restarts from it)
+    int cycles(double t) {
+        for (int i = 0; i < n; ++i) {
+            if (s->topic_infeasible[(size_t)i] || !feasible(i) || objective(i) >= s->ub[(size_t)i]) continue;
+            if (!cycle_supported(&topics[i])) continue;
+            if ((keys[(size_t)i] >> 20) == (cx_seen[(size_t)i] >> 20)) continue;   // same incumbent as the last fixpoint
+            const bool stalled = t - t_improved[(size_t)i] >= 0.05, due = t - t_cx[(size_t)i] >= 2.0 * cx_slice;
+            if (!cx_eager && (t < 0.05 || !(stalled || due) || t - t_cx[(size_t)i] < 0.05)) continue;
+            const size_t slots = (size_t)topics[i].n_partitions * topics[i].rf;
+            cx_buf.resize(slots);
+            int rc = session_topic_best(s, i, cx_buf.data());
+            if (rc) return rc;
+            int64_t obj = objective(i);
+            int32_t st[8];
+            if (!cx_ctx[(size_t)i] && !(cx_ctx[(size_t)i] = cycle_open(&topics[i], &rc))) return rc;
+            const double slice_end = std::min(deadline, now_s() + cx_slice);
+            rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), 0, slice_end, &obj, st, &SolveRun::poll_bound, this);
+            ++cx_calls;
+            if (rc) return rc;
+            const bool fixpoint = st[0] > st[1];   // the last round found nothing
+            const double t2 = now_s() - t0;
+            t_cx[(size_t)i] = t2;
+            if (obj > objective(i)) {
+                uint64_t key = 0;
+                if ((rc = session_adopt_external(s, i, cx_buf.data(), obj, &key))) return rc;
+                keys[(size_t)i] = prev[(size_t)i] = key;
+                t_best[(size_t)i] = t_improved[(size_t)i] = t_last_improve = t2;
+                ++cx_gains;
+            }
+            if (fixpoint) cx_seen[(size_t)i] = keys[(size_t)i];
+            // a context holds ~90 B per broker pair on the device and as much on the host: keep a handful, not one per topic
+            int open = 0;
+            for (CycleCtx *c : cx_ctx) open += c != nullptr;
+            if (open > 8) { cycle_close(cx_ctx[(size_t)i]); cx_ctx[(size_t)i] = nullptr; }
+        }
+        all_done = check_done();
+        return KAO_OK;
+    }
+    int finish(kao_result *results, bool hit_time) {
+        int rc = KAO_OK;
+        if (s->bound_inflight && (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;  // last K-bound launch
+        share_bounds();
+        std::vector<kao_result> rs((size_t)n);
+        std::vector<std::vector<uint16_t>> bufs((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            rs[(size_t)i] = kao_result{};
+            bufs[(size_t)i].assign((size_t)xt[(size_t)i].n_partitions * std::max(xt[(size_t)i].rf, 1), (uint16_t)KAO_NONE);
+            rs[(size_t)i].assignment = bufs[(size_t)i].data();
+        }
+        if ((rc = kao_session_best(s, rs.data()))) return rc;
+        auto better = [](const kao_result &a, const kao_result &b) {   // feasible first, then objective
+            const bool fa = a.status != KAO_STATUS_NO_FEASIBLE && a.status != KAO_STATUS_INFEASIBLE_PROVEN;
+            const bool fb = b.status != KAO_STATUS_NO_FEASIBLE && b.status != KAO_STATUS_INFEASIBLE_PROVEN;
+            return fa != fb ? fa : a.objective > b.objective;
+        };
+        for (int i = 0; i < n;) {
+            int best = i, j = i + 1;
+            for (; j < n && origin[(size_t)j] == origin[(size_t)i]; ++j) if (better(rs[(size_t)j], rs[(size_t)best])) best = j;
+            kao_result &out = results[origin[(size_t)i]];
+            uint16_t *dst = out.assignment;
+            out = rs[(size_t)best];
+            out.assignment = dst;
+            if (dst) std::memcpy(dst, bufs[(size_t)best].data(), bufs[(size_t)best].size() * 2);
+            out.seconds_to_best = t_best[(size_t)best];
+            if (hit_time && out.status == KAO_STATUS_FEASIBLE_BOUND_GAP) out.status = KAO_STATUS_TIME_LIMIT;
+            i = j;
+        }
+        return rc;
+    }
+};
+
+// kao_solve's defaults on top of the caller's options
+kao_opts solve_defaults(const kao_topic *topics, int32_t n_topics, const kao_opts *opts) {
+    kao_opts so{};
+    if (opts) so = *opts;
+    if (so.iters_per_launch <= 0) {
+        // latency first (the host checks the bound after every launch): 128 iterations; large topics pay O(P) per launch
+        // for loading, recounting and storing a restart (drifted 500 x 5000 topic: 40 % more iterations per second with
+        // 512 per launch), so they get longer launches
+        int64_t slots = 0;
+        for (int i = 0; topics && i < n_topics; ++i) slots = std::max<int64_t>(slots, (int64_t)topics[i].n_partitions * std::max(topics[i].rf, 1));
+        so.iters_per_launch = slots <= 4096 ? 128 : (slots <= 8192 ? 256 : 512);
+    }
+    if (so.elite_period == 0 && topics && n_topics > 0) {  // about one penalty period of the largest topic between elite launches
+        int lg = 8;
+        for (int i = 0; i < n_topics; ++i)
+            lg = std::max(lg, so.period_log2 > 0 ? so.period_log2 : auto_period_log2(topics[i].n_partitions, std::max(topics[i].rf, 1)));
+        so.elite_period = std::max(1, (1 << std::min(lg, 20)) / so.iters_per_launch);
+    }
+    return so;
+}
+
+}  // namespace
+
+namespace kao {
+int api_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+int api_require_init() { return require_init(); }
+double api_now_s() { return now_s(); }
+}  // namespace kao
+
+extern "C" {
+
+int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results) {
+    const double t0 = now_s();
+    if (!results) return fail(KAO_ERR_INVALID, "null results");
+    const kao_opts so = solve_defaults(topics, n_topics, opts);
+    SolveRun run;
+    int rc = run.begin(topics, n_topics, so, opts ? opts->target_objective : nullptr, t0, true);
+    if (rc) return rc;
+    g_timing[0] = now_s() - t0;
+    const kao_opts &o = run.s->opts;
+    bool hit_time = false;
+    for (;;) {
+        if ((rc = run.launch()) || (rc = run.after_launch())) return rc;
+        if (o.stop_at_bound && run.all_done) break;
+        if (o.max_launches > 0 && run.launches >= o.max_launches) break;
+        if (now_s() - t0 >= o.time_limit_s) { hit_time = true; break; }
+    }
+    g_timing[1] = run.t_last_improve;
+    rc = run.finish(results, hit_time);
+    g_timing[2] = now_s() - t0;
+    g_timing[5] = (double)run.s->delta_total;
+    g_timing[6] = (double)run.s->bound_launches;
+    g_timing[7] = 0;   // K-bound iterations, summed over the topics
+    for (int32_t v : run.s->dual_iters) g_timing[7] += (double)v;
+    kao_session_destroy(run.s);
+    run.s = nullptr;
+    g_timing[3] = now_s() - t0;
+    g_timing[4] = run.launches;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kao_solve_multi: one process, several GPUs
+// ------------------------------------------------------------------------------------------------
+namespace {
+// librccl.so is half a gigabyte of code objects; linking it would make every process that loads libkao.so (the CLI, a JVM)
+// pay for registering them.  It is opened on the first multi-GPU exchange instead.
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    bool load() {
+        if (h) return true;
+        // RCCL must sit on the SAME HIP / HSA runtime instance this library runs on (a process may hold two: PyTorch wheels
+        // bundle their own next to /opt/rocm's): look for librccl next to the libamdhip64 that serves our HIP calls first
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) { dir.resize(slash); names.push_back(dir + "/librccl.so.1"); names.push_back(dir + "/librccl.so"); }
+        }
+        names.push_back("librccl.so.1"); names.push_back("librccl.so"); names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const std::string &name : names) {
+            h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(h, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(h, "ncclAllReduce"));
+        Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(h, "ncclBroadcast"));
+        return CommInitAll && CommDestroy && GetErrorString && GroupStart && GroupEnd && AllReduce && Broadcast;
+    }
+} g_rccl;
+struct CommSet { std::vector<int> devices; std::vector<ncclComm_t> comms; };
+std::vector<CommSet> g_comms;   // RCCL communicators per device list (creation costs ~100 ms; kept until kao_shutdown)
+std::mutex g_comm_mu;
+int comms_for(const std::vector<int> &devices, std::vector<ncclComm_t> &out) {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    for (const CommSet &c : g_comms) if (c.devices == devices) { out = c.comms; return KAO_OK; }
+    if (!g_rccl.load()) return fail(KAO_ERR_HIP, std::string("librccl.so not available: ") + (dlerror() ? dlerror() : "missing symbol"));
+    for (int d : devices) {  // RCCL expects every device's primary context to exist already
+        if (hipSetDevice(d) != hipSuccess || hipFree(nullptr) != hipSuccess) return fail(KAO_ERR_HIP, "cannot initialise device " + std::to_string(d));
+        void *probe = nullptr;
+        if (hipMalloc(&probe, 256) == hipSuccess) (void)hipFree(probe);
+    }
+    if (cur_device() >= 0) (void)hipSetDevice(cur_device());
+    CommSet c; c.devices = devices; c.comms.resize(devices.size());
+    const ncclResult_t r = g_rccl.CommInitAll(c.comms.data(), (int)devices.size(), devices.data());
+    if (r != ncclSuccess) return fail(KAO_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+    g_comms.push_back(c);
+    out = c.comms;
+    return KAO_OK;
+}
+}  // namespace
+
+void kao_multi_shutdown_comms(void) {
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    for (CommSet &c : g_comms) for (ncclComm_t cm : c.comms) (void)g_rccl.CommDestroy(cm);
+    g_comms.clear();
+}
+
+// Diagnostic: the collectives kao_solve_multi uses, on small resident buffers of the listed (distinct) devices -- rank r holds
+// keys {100 - r, 7 + r, ~0, r}; after ncclAllReduce(ncclUint64, ncclMin) every rank must hold {101 - n, 7, ~0, 0}, and after
+// ncclBroadcast from the last rank every rank holds that rank's 64-byte pattern.  0 = ok.
+int kao_rccl_selftest(const int32_t *devices, int32_t n_dev) {
+    if (!devices || n_dev < 1 || n_dev > kMaxDevices) return fail(KAO_ERR_INVALID, "bad device list");
+    std::vector<int> devs(devices, devices + n_dev);
+    std::vector<ncclComm_t> comms;
+    int rc = comms_for(devs, comms);
+    if (rc) return rc;
+    std::vector<unsigned long long *> keys((size_t)n_dev, nullptr), out((size_t)n_dev, nullptr);
+    std::vector<unsigned char *> pat((size_t)n_dev, nullptr);
+    std::vector<hipStream_t> st((size_t)n_dev, nullptr);
+    bool ok = true;
+    for (int d = 0; d < n_dev && ok; ++d) {
+        ok = hipSetDevice(devs[(size_t)d]) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&keys[(size_t)d]), 32) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void **>(&out[(size_t)d]), 32) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&pat[(size_t)d]), 64) == hipSuccess &&
+             hipStreamCreateWithFlags(&st[(size_t)d], hipStreamNonBlocking) == hipSuccess;
+        const unsigned long long h[4] = {100ull - (unsigned)d, 7ull + (unsigned)d, ~0ull, (unsigned long long)d};
+        unsigned char p[64];
+        for (int i = 0; i < 64; ++i) p[i] = (unsigned char)(d * 64 + i);
+        ok = ok && hipMemcpy(keys[(size_t)d], h, 32, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pat[(size_t)d], p, 64, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    ncclResult_t nr = ok ? g_rccl.GroupStart() : ncclSystemError;
+    for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) nr = g_rccl.AllReduce(keys[(size_t)d], out[(size_t)d], 4, ncclUint64, ncclMin, comms[(size_t)d], st[(size_t)d]);
+    if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+    if (nr == ncclSuccess) nr = g_rccl.GroupStart();
+    for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) nr = g_rccl.Broadcast(pat[(size_t)d], pat[(size_t)d], 64, ncclUint8, n_dev - 1, comms[(size_t)d], st[(size_t)d]);
+    if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+    ok = ok && nr == ncclSuccess;
+    for (int d = 0; d < n_dev && ok; ++d) {
+        unsigned long long h[4]; unsigned char p[64];
+        ok = hipSetDevice(devs[(size_t)d]) == hipSuccess && hipStreamSynchronize(st[(size_t)d]) == hipSuccess &&
+             hipMemcpy(h, out[(size_t)d], 32, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(p, pat[(size_t)d], 64, hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && h[0] == 101ull - (unsigned)n_dev && h[1] == 7ull && h[2] == ~0ull && h[3] == 0ull;
+        for (int i = 0; i < 64 && ok; ++i) ok = p[i] == (unsigned char)((n_dev - 1) * 64 + i);
+    }
+    for (int d = 0; d < n_dev; ++d) {
+        (void)hipSetDevice(devs[(size_t)d]);
+        (void)hipFree(keys[(size_t)d]); (void)hipFree(out[(size_t)d]); (void)hipFree(pat[(size_t)d]);
+        if (st[(size_t)d]) (void)hipStreamDestroy(st[(size_t)d]);
+    }
+    if (cur_device() >= 0) (void)hipSetDevice(cur_device());
+    if (!ok) return fail(KAO_ERR_HIP, nr != ncclSuccess ? std::string("RCCL: ") + g_rccl.GetErrorString(nr) : std::string("RCCL self-test: wrong result"));
+    return KAO_OK;
+}
+
+int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *devices, int32_t n_dev, const kao_opts *opts,
+                    kao_result *results) {
+    const double t0 = now_s();
+    if (!topics || n_topics < 1 || !results) return fail(KAO_ERR_INVALID, "no topics / null results");
+    if (!devices || n_dev < 1 || n_dev > kMaxDevices) return fail(KAO_ERR_INVALID, "bad device list");
+    int n_hw = 0;
+    if (hipGetDeviceCount(&n_hw) != hipSuccess || n_hw <= 0) return fail(KAO_ERR_NO_DEVICE, "no HIP device");
+    std::vector<int> devs(devices, devices + n_dev);
+    bool distinct = true;
+    for (int i = 0; i < n_dev; ++i) {
+        if (devs[(size_t)i] < 0 || devs[(size_t)i] >= n_hw) return fail(KAO_ERR_INVALID, "device ordinal out of range");
+        for (int j = 0; j < i; ++j) distinct &= devs[(size_t)j] != devs[(size_t)i];
+    }
+    if (!is_init()) { int rc0 = kao_init(devs[0]); if (rc0) return rc0; }
+    const kao_opts so = solve_defaults(topics, n_topics, opts);
+    const bool replicated = n_topics < n_dev;   // fewer topics than GPUs: every GPU searches every topic, elites are exchanged
+    // ---- shards: LPT by brokers x partitions (independent sub-problems, README.md:146-184) ----
+    std::vector<std::vector<int>> shard((size_t)n_dev);
+    if (replicated) for (auto &sh : shard) for (int i = 0; i < n_topics; ++i) sh.push_back(i);
+    else {
+        std::vector<int> order((size_t)n_topics);
+        for (int i = 0; i < n_topics; ++i) order[(size_t)i] = i;
+        auto size_of = [&](int i) { return (int64_t)topics[i].n_brokers * topics[i].n_partitions; };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return size_of(a) > size_of(b); });
+        std::vector<int64_t> load((size_t)n_dev, 0);
+        for (int i : order) {
+            int best = 0;
+            for (int d = 1; d < n_dev; ++d) if (load[(size_t)d] < load[(size_t)best]) best = d;
+            shard[(size_t)best].push_back(i);
+            load[(size_t)best] += size_of(i);
+        }
+    }
+    std::vector<ncclComm_t> comms;
+    const bool use_rccl = replicated && distinct;   // logical shards on one device (tests) merge through the host instead
+    if (use_rccl) { int rc0 = comms_for(devs, comms); if (rc0) return rc0; }
+
+    struct Dev { SolveRun run; std::vector<kao_topic> tp; std::vector<kao_result> res; std::vector<int64_t> tgt; };
+    std::vector<Dev> D((size_t)n_dev);
+    const int saved_t_device = t_device;
+    auto cleanup = [&]() { t_device = saved_t_device; if (cur_device() >= 0) (void)hipSetDevice(cur_device()); };
+    int rc = KAO_OK;
+    for (int d = 0; d < n_dev && !rc; ++d) {
+        Dev &x = D[(size_t)d];
+        for (int i : shard[(size_t)d]) { x.tp.push_back(topics[i]); if (opts && opts->target_objective) x.tgt.push_back(opts->target_objective[i]); }
+        if (x.tp.empty()) continue;
+        kao_opts o = so;
+        o.seed = so.seed + 0x9E3779B97F4A7C15ull * (uint64_t)d;            // replicated topics: a different seed per GPU
+        if (replicated && d > 0) o.dual_iters = -1;                        // one certificate per topic is enough: device 0 runs K-bound
+        t_device = devs[(size_t)d];
+        if (hipSetDevice(t_device) != hipSuccess) { rc = fail(KAO_ERR_NO_DEVICE, "hipSetDevice"); break; }
+        rc = x.run.begin(x.tp.data(), (int)x.tp.size(), o, x.tgt.empty() ? nullptr : x.tgt.data(), t0);
+    }
+    if (rc) { cleanup(); return rc; }
+    g_timing[0] = now_s() - t0;
+    const int exch = std::max(1, so.elite_period);
+    bool hit_time = false;
+    int rounds = 0;
+    uint64_t exchanges = 0;
+    std::vector<uint64_t> gmin((size_t)n_topics);
+    std::vector<int> root((size_t)n_topics);
+    for (;;) {
+        for (int d = 0; d < n_dev && !rc; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; rc = D[(size_t)d].run.launch(); }
+        for (int d = 0; d < n_dev && !rc; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; rc = D[(size_t)d].run.after_launch(); }
+        if (rc) break;
+        ++rounds;
+        if (replicated) {
+            // certificates: any GPU's bound is valid for the topic
+            for (int i = 0; i < n_topics; ++i) {
+                int64_t ub = INT64_MAX;
+                for (Dev &x : D) ub = std::min(ub, x.run.s->ub[(size_t)i]);
+                for (Dev &x : D) x.run.s->ub[(size_t)i] = ub;
+            }
+            if (rounds % exch == 0 || so.stop_at_bound) {
+                // ---- elite exchange: min-allreduce of the packed best keys on the resident buffers, winners broadcast ----
+                bool differ = false;
+                for (int i = 0; i < n_topics; ++i) {
+                    gmin[(size_t)i] = ~0ull; root[(size_t)i] = 0;
+                    for (int d = 0; d < n_dev; ++d) {
+                        const uint64_t k = D[(size_t)d].run.keys[(size_t)i] | 0;  // host copy read by after_launch
+                        if (k < gmin[(size_t)i]) { gmin[(size_t)i] = k; root[(size_t)i] = d; }
+                    }
+                    for (int d = 0; d < n_dev; ++d) differ |= (D[(size_t)d].run.keys[(size_t)i] >> 20) != (gmin[(size_t)i] >> 20);
+                }
+                if (differ && rounds % exch == 0) {
+                    ++exchanges;
+                    for (int d = 0; d < n_dev && !rc; ++d) {   // stage every GPU's current winners
+                        kao_session *s = D[(size_t)d].run.s;
+                        if (hipSetDevice(s->device) != hipSuccess) { rc = fail(KAO_ERR_HIP, "hipSetDevice"); break; }
+                        launch_gather(s->d_topics, s->n_topics, s->d_keys, s->d_best, s->d_viol, s->d_win_assign, s->d_win_viol, s->stream);
+                    }
+                    if (!rc && use_rccl) {
+                        ncclResult_t nr = g_rccl.GroupStart();
+                        for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) {
+                            kao_session *s = D[(size_t)d].run.s;
+                            nr = g_rccl.AllReduce(s->d_keys, s->d_keys_glob, (size_t)n_topics, ncclUint64, ncclMin, comms[(size_t)d], s->stream);
+                        }
+                        if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+                        for (int i = 0; i < n_topics && nr == ncclSuccess; ++i) {
+                            if ((gmin[(size_t)i] >> 44) != 0) continue;   // no feasible assignment anywhere yet
+                            nr = g_rccl.GroupStart();
+                            for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) {
+                                kao_session *s = D[(size_t)d].run.s;
+                                const TopicDev &td = s->pts[(size_t)i].d;
+                                uint16_t *buf = s->d_win_assign + td.win_off;
+                                nr = g_rccl.Broadcast(buf, buf, (size_t)td.P * td.RF * 2, ncclUint8, root[(size_t)i], comms[(size_t)d], s->stream);
+                            }
+                            if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+                        }
+                        if (nr != ncclSuccess) rc = fail(KAO_ERR_HIP, std::string("RCCL elite exchange: ") + g_rccl.GetErrorString(nr));
+                    } else if (!rc) {   // logical shards on one device: same data movement through plain copies
+                        for (int d = 0; d < n_dev && !rc; ++d) {
+                            kao_session *s = D[(size_t)d].run.s;
+                            if (hipSetDevice(s->device) != hipSuccess) { rc = fail(KAO_ERR_HIP, "hipSetDevice"); break; }
+                            for (int r2 = 0; r2 < n_dev; ++r2) (void)hipStreamSynchronize(D[(size_t)r2].run.s->stream);
+                            if (hipMemcpyAsync(s->d_keys_glob, gmin.data(), (size_t)n_topics * 8, hipMemcpyHostToDevice, s->stream) != hipSuccess) rc = fail(KAO_ERR_HIP, "hipMemcpyAsync");
+                            for (int i = 0; i < n_topics && !rc; ++i) {
+                                if ((gmin[(size_t)i] >> 44) != 0 || root[(size_t)i] == d) continue;
+                                kao_session *sr = D[(size_t)root[(size_t)i]].run.s;
+                                const TopicDev &td = s->pts[(size_t)i].d;
+                                if (hipMemcpyAsync(s->d_win_assign + td.win_off, sr->d_win_assign + td.win_off, (size_t)td.P * td.RF * 2,
+                                                   hipMemcpyDeviceToDevice, s->stream) != hipSuccess) rc = fail(KAO_ERR_HIP, "hipMemcpyAsync");
+                            }
+                            if (!rc && hipStreamSynchronize(s->stream) != hipSuccess) rc = fail(KAO_ERR_HIP, "hipStreamSynchronize");  // gmin is reused
+                        }
+                    }
+                    for (int d = 0; d < n_dev && !rc; ++d) {
+                        kao_session *s = D[(size_t)d].run.s;
+                        if (hipSetDevice(s->device) != hipSuccess) { rc = fail(KAO_ERR_HIP, "hipSetDevice"); break; }
+                        launch_adopt_global(s->d_keys, s->d_keys_glob, n_topics, s->stream);
+                        if (hipGetLastError() != hipSuccess) rc = fail(KAO_ERR_HIP, "k_adopt_global");
+                    }
+                    if (rc) break;
+                }
+                for (Dev &x : D)   // every run now judges "done" against the global incumbents
+                    for (int i = 0; i < n_topics; ++i) if (gmin[(size_t)i] < x.run.keys[(size_t)i]) x.run.keys[(size_t)i] = gmin[(size_t)i];
+                for (Dev &x : D) x.run.all_done = x.run.check_done();
+            }
+        }
+        bool all = true;
+        for (Dev &x : D) if (x.run.s) all &= x.run.all_done;
+        if (replicated) { all = false; for (Dev &x : D) all |= x.run.all_done; }   // one GPU holding proven optima for every topic suffices
+        if (so.stop_at_bound && all) break;
+        if (so.max_launches > 0 && rounds >= so.max_launches) break;
+        const double tl = so.time_limit_s > 0 ? so.time_limit_s : 10.0;
+        if (now_s() - t0 >= tl) { hit_time = true; break; }
+    }
+    // ---- results ----
+    double t_improve = 0, cand = 0, bl = 0;
+    if (!rc) {
+        if (replicated) {   // per topic: the GPU holding the best key answers
+            std::vector<std::vector<kao_result>> rs((size_t)n_dev, std::vector<kao_result>((size_t)n_topics));
+            std::vector<std::vector<std::vector<uint16_t>>> bufs((size_t)n_dev);
+            for (int d = 0; d < n_dev && !rc; ++d) {
+                bufs[(size_t)d].resize((size_t)n_topics);
+                for (int i = 0; i < n_topics; ++i) {
+                    bufs[(size_t)d][(size_t)i].assign((size_t)topics[i].n_partitions * topics[i].rf, (uint16_t)KAO_NONE);
+                    rs[(size_t)d][(size_t)i] = kao_result{};
+                    rs[(size_t)d][(size_t)i].assignment = bufs[(size_t)d][(size_t)i].data();
+                }
+                t_device = devs[(size_t)d];
+                rc = D[(size_t)d].run.finish(rs[(size_t)d].data(), hit_time);
+            }
+            for (int i = 0; i < n_topics && !rc; ++i) {
+                int best = 0;
+                auto better = [&](const kao_result &a, const kao_result &b) {   // feasible first, then objective
+                    const bool fa = a.status != KAO_STATUS_NO_FEASIBLE && a.status != KAO_STATUS_INFEASIBLE_PROVEN;
+                    const bool fb = b.status != KAO_STATUS_NO_FEASIBLE && b.status != KAO_STATUS_INFEASIBLE_PROVEN;
+                    return fa != fb ? fa : a.objective > b.objective;
+                };
+                for (int d = 1; d < n_dev; ++d) if (better(rs[(size_t)d][(size_t)i], rs[(size_t)best][(size_t)i])) best = d;
+                uint16_t *dst = results[i].assignment;
+                results[i] = rs[(size_t)best][(size_t)i];
+                results[i].assignment = dst;
+                if (dst) std::memcpy(dst, bufs[(size_t)best][(size_t)i].data(), bufs[(size_t)best][(size_t)i].size() * 2);
+                int64_t ub = INT64_MAX;
+                for (int d = 0; d < n_dev; ++d) ub = std::min(ub, rs[(size_t)d][(size_t)i].upper_bound);
+                results[i].upper_bound = ub;
+                if (results[i].status == KAO_STATUS_FEASIBLE_BOUND_GAP || results[i].status == KAO_STATUS_TIME_LIMIT || results[i].status == KAO_STATUS_OPTIMAL_PROVEN)
+                    results[i].status = results[i].objective >= ub ? KAO_STATUS_OPTIMAL_PROVEN : (hit_time ? KAO_STATUS_TIME_LIMIT : KAO_STATUS_FEASIBLE_BOUND_GAP);
+            }
+        } else {
+            for (int d = 0; d < n_dev && !rc; ++d) {
+                Dev &x = D[(size_t)d];
+                if (!x.run.s) continue;
+                x.res.assign(x.tp.size(), kao_result{});
+                for (size_t k = 0; k < x.tp.size(); ++k) x.res[k].assignment = results[shard[(size_t)d][k]].assignment;
+                t_device = devs[(size_t)d];
+                rc = x.run.finish(x.res.data(), hit_time);
+                for (size_t k = 0; k < x.tp.size() && !rc; ++k) results[shard[(size_t)d][k]] = x.res[k];
+            }
+        }
+    }
+    g_timing[2] = now_s() - t0;
+    for (Dev &x : D) if (x.run.s) { t_improve = std::max(t_improve, x.run.t_last_improve); cand += (double)x.run.s->delta_total; bl += (double)x.run.s->bound_launches; }
+    for (int d = 0; d < n_dev; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; kao_session_destroy(D[(size_t)d].run.s); D[(size_t)d].run.s = nullptr; }
+    cleanup();
+    g_timing[1] = t_improve; g_timing[3] = now_s() - t0; g_timing[4] = rounds; g_timing[5] = cand; g_timing[6] = bl; g_timing[7] = (double)exchanges;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kao_solve_capped: cluster-wide per-broker load caps, priced (Lagrangian) over independent per-topic solves
+// ------------------------------------------------------------------------------------------------
+int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *replica_cap, const int32_t *devices, int32_t n_dev,
+                     const kao_opts *opts, int32_t max_rounds, kao_result *results, int64_t *lagrangian_bound) {
+    const double t0 = now_s();
+    if (!topics || n_topics < 1 || !replica_cap || !results) return fail(KAO_ERR_INVALID, "null argument");
+    const int B = topics[0].n_brokers;
+    int wmax = 1;
+    for (int i = 0; i < n_topics; ++i) {
+        if (topics[i].n_brokers != B) return fail(KAO_ERR_INVALID, "kao_solve_capped: every topic must use the same broker set");
+        if (topics[i].broker_w || topics[i].broker_wl) return fail(KAO_ERR_UNSUPPORTED, "kao_solve_capped: topics with their own broker weights");
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) wmax = std::max(wmax, topics[i].w[a][b]);
+    }
+    const int mu_max = std::min(1023, 4 * wmax);   // a price above every objective weight already repels every replica
+    kao_opts o{};
+    if (opts) o = *opts;
+    const double limit = o.time_limit_s > 0 ? o.time_limit_s : 10.0;
+    const int rounds = max_rounds > 0 ? max_rounds : 40;
+    if (o.max_launches <= 0) o.max_launches = 6;
+    o.stop_at_bound = 1;
+    o.target_objective = nullptr;
+    std::vector<int32_t> mu((size_t)B, 0), bw((size_t)B, 0);
+    std::vector<kao_topic> tp(topics, topics + n_topics);
+    std::vector<std::vector<uint16_t>> buf((size_t)n_topics), inc((size_t)n_topics);
+    std::vector<kao_result> res((size_t)n_topics), inc_res((size_t)n_topics);
+    for (int i = 0; i < n_topics; ++i) buf[(size_t)i].assign((size_t)topics[i].n_partitions * topics[i].rf, (uint16_t)KAO_NONE);
+    int64_t inc_total = -1, best_L = INT64_MAX, n_slots = 0;
+    for (int i = 0; i < n_topics; ++i) n_slots += (int64_t)topics[i].n_partitions * topics[i].rf;
+    std::vector<int64_t> load((size_t)B);
+    int rc = KAO_OK, r = 0;
+    for (; r < rounds; ++r) {
+        const double left = limit - (now_s() - t0);
+        if (r > 0 && left <= 0) break;
+        int M = 0;
+        for (int b = 0; b < B; ++b) M = std::max(M, mu[(size_t)b]);
+        for (int b = 0; b < B; ++b) bw[(size_t)b] = M - mu[(size_t)b];   // weights must be >= 0: a constant M per replica does not change any argmax
+        for (int i = 0; i < n_topics; ++i) {
+            tp[(size_t)i].broker_w = M ? bw.data() : nullptr;
+            res[(size_t)i] = kao_result{};
+            res[(size_t)i].assignment = buf[(size_t)i].data();
+        }
+        o.time_limit_s = std::max(0.05, left / std::max(1, std::min(rounds - r, 8)));
+        o.seed = (opts ? opts->seed : 0) + (uint64_t)r * 0x9E3779B97F4A7C15ull;
+        rc = (devices && n_dev > 1) ? kao_solve_multi(tp.data(), n_topics, devices, n_dev, &o, res.data())
+                                    : kao_solve(tp.data(), n_topics, &o, res.data());
+        if (rc) break;
+        // ---- broker loads over ALL topics (the allreduce(SUM) of a sharded deployment), objective without the weights ----
+        std::fill(load.begin(), load.end(), 0);
+        bool all_feasible = true, all_proven = true;
+        int64_t total = 0, total_w = 0;
+        for (int i = 0; i < n_topics; ++i) {
+            const kao_result &x = res[(size_t)i];
+            if (x.status == KAO_STATUS_NO_FEASIBLE || x.status == KAO_STATUS_INFEASIBLE_PROVEN) { all_feasible = false; continue; }
+            all_proven &= x.status == KAO_STATUS_OPTIMAL_PROVEN;
+            int64_t wsum = 0;
+            for (size_t k = 0; k < buf[(size_t)i].size(); ++k) { const uint16_t b = buf[(size_t)i][k]; load[b]++; wsum += M ? bw[b] : 0; }
+            total += x.objective - wsum;
+            total_w += x.upper_bound;
+        }
+        int64_t worst = 0, priced = 0;
+        for (int b = 0; b < B; ++b) {
+            if (replica_cap[b] < 0) continue;
+            worst = std::max<int64_t>(worst, load[(size_t)b] - replica_cap[b]);
+            priced += (int64_t)mu[(size_t)b] * replica_cap[b];
+        }
+        if (all_feasible && all_proven) best_L = std::min(best_L, total_w - (int64_t)M * n_slots + priced);   // L(mu) >= capped optimum
+        if (all_feasible && worst <= 0 && total > inc_total) {   // respects every cap: a candidate answer
+            inc_total = total;
+            for (int i = 0; i < n_topics; ++i) {
+                inc[(size_t)i] = buf[(size_t)i];
+                inc_res[(size_t)i] = res[(size_t)i];
+                int64_t wsum = 0;
+                for (uint16_t b : buf[(size_t)i]) wsum += M ? bw[b] : 0;
+                inc_res[(size_t)i].objective = res[(size_t)i].objective - wsum;
+            }
+        }
+        if (inc_total >= 0 && best_L != INT64_MAX && inc_total >= best_L) break;   // incumbent meets the Lagrangian bound: optimal
+        // ---- projected subgradient step on the prices, diminishing: alpha = 1 / (1 + r / 3) ----
+        const int den = 1 + r / 3;
+        bool moved = false;
+        for (int b = 0; b < B; ++b) {
+            if (replica_cap[b] < 0) continue;
+            const int64_t ex = load[(size_t)b] - replica_cap[b];
+            int d = 0;
+            if (ex > 0) d = (int)std::max<int64_t>(1, ex / den);
+            else if (ex < 0 && mu[(size_t)b] > 0) d = -(int)std::min<int64_t>(mu[(size_t)b], std::max<int64_t>(r >= 6 ? 0 : 1, (-ex) / (2 * den)));
+            const int nm = std::min(mu_max, std::max(0, mu[(size_t)b] + d));
+            moved |= nm != mu[(size_t)b];
+            mu[(size_t)b] = nm;
+        }
+        if (!moved) break;   // prices are stationary
+    }
+    if (!rc) {
+        for (int i = 0; i < n_topics; ++i) {
+            uint16_t *dst = results[i].assignment;
+            if (inc_total >= 0) {
+                results[i] = inc_res[(size_t)i];
+                results[i].status = (best_L != INT64_MAX && inc_total >= best_L) ? KAO_STATUS_OPTIMAL_PROVEN : KAO_STATUS_FEASIBLE_BOUND_GAP;
+                results[i].upper_bound = best_L != INT64_MAX ? best_L : INT64_MAX;   // a bound on the SUM over all topics
+                if (dst) std::memcpy(dst, inc[(size_t)i].data(), inc[(size_t)i].size() * 2);
+            } else {
+                results[i] = res[(size_t)i];
+                results[i].status = KAO_STATUS_NO_FEASIBLE; results[i].objective = -1;
+            }
+            results[i].assignment = dst;
+        }
+        if (lagrangian_bound) *lagrangian_bound = best_L;
+    }
+    g_timing[3] = now_s() - t0; g_timing[4] = r;
+    return rc;
+}
+
+int kao_last_solve_timing(double out[8]) {
+    if (!out) return fail(KAO_ERR_INVALID, "null out");
+    for (int i = 0; i < 8; ++i) out[i] = g_timing[i];
+    return KAO_OK;
+}
+
+}  // extern "C"

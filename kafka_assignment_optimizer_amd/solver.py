@@ -306,6 +306,10 @@ class Session:
         _check(_ffi.load().kao_session_bound_step(self._h, tg.ctypes.data_as(C.POINTER(C.c_int64)), int(iters)),
                "kao_session_bound_step")
 
+    def bound_relevel(self, topic: int):
+        """The next K-bound launch of `topic` restarts its level control (the step length aims at the target again)."""
+        _check(_ffi.load().kao_session_bound_relevel(self._h, int(topic)), "kao_session_bound_relevel")
+
     def set_prices(self, topic: int, a, l, g):
         """Search prices of one topic from the host (fixed point, 65536 = 1): a[n_brokers], l[n_brokers], g[n_racks]."""
         t = self.topics[topic]
@@ -455,4 +459,4 @@ def last_solve_timing() -> dict:
     out = (C.c_double * 8)()
     _check(_ffi.load().kao_last_solve_timing(out), "kao_last_solve_timing")
     return dict(session_ready=out[0], time_to_best=out[1], results_read_back=out[2], returned=out[3], launches=int(out[4]),
-                delta_candidates=int(out[5]), bound_launches=int(out[6]), elite_exchanges=int(out[7]))
+                delta_candidates=int(out[5]), bound_launches=int(out[6]), elite_exchanges=int(out[7]), bound_iters=int(out[7]))

@@ -905,15 +905,21 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         }
         /* Level control: the Polyak step aims at `level`, the incumbent while the record keeps falling.  An incumbent
          * below the optimum is an unreachable level (steps too long, the record stalls far above the optimum): every
-         * DB_STAGE iterations without half a unit of progress the distance delta between record and level is halved.
-         * lv = {delta (0 = not started), record at the start of the stage, iterations in the stage, steps taken}. */
+         * DB_STAGE iterations without half a unit of progress the distance delta between record and level is halved; a stage
+         * that gained more than delta doubles it again (never beyond the incumbent).
+         * The record that steers the level is the best value among the ITERATES (lv[3]), not *best_L, which the rounding probes
+         * also lower (a probe value the iterate cannot reach soon would read as "no progress").
+         * lv = {delta (0 = not started), record at the start of the stage, iterations in the stage | steps taken << 8, best iterate value}. */
         int64_t level = target * DB_SCALE;
-        if (lv[0] <= 0) { lv[0] = *best_L - level; lv[1] = *best_L; lv[2] = 0; }
-        if (++lv[2] >= DB_STAGE) {
-            if (lv[1] - *best_L < DB_SCALE / 2) { lv[0] /= 2; if (lv[0] < DB_SCALE / 16) lv[0] = DB_SCALE / 16; }
-            lv[1] = *best_L; lv[2] = 0;
+        if (lv[0] <= 0) { lv[3] = L; lv[0] = lv[3] - level; lv[1] = lv[3]; lv[2] &= ~(int64_t)0xFF; }
+        if (L < lv[3]) lv[3] = L;
+        if (((++lv[2]) & 0xFF) >= DB_STAGE) {
+            const int64_t prog = lv[1] - lv[3];
+            if (prog < DB_SCALE / 2) { lv[0] /= 2; if (lv[0] < DB_SCALE / 16) lv[0] = DB_SCALE / 16; }
+            else if (prog >= lv[0] && lv[3] - 2 * lv[0] >= level) lv[0] *= 2;   /* a stage that gained more than the distance: aim further */
+            lv[1] = lv[3]; lv[2] &= ~(int64_t)0xFF;
         }
-        if (*best_L - lv[0] > level) level = *best_L - lv[0];
+        if (lv[3] - lv[0] > level) level = lv[3] - lv[0];
         int64_t gap = L - level;
         if (gap < 1) gap = 1;
         /* multiplier change = gap * 16 d / |d|^2; step = (gap << sh) / |d|^2 with as many bits as 62 allow, at most 40
@@ -921,7 +927,8 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         int sh = __builtin_clzll((unsigned long long)gap) - 2;
         sh = sh > 40 ? 40 : (sh < 20 ? 20 : sh);
         const int64_t step = (gap << sh) / dn;
-        const uint32_t seq = (uint32_t)lv[3]++;           /* steps taken so far, over all launches */
+        const uint32_t seq = (uint32_t)(lv[2] >> 8);      /* steps taken so far, over all launches */
+        lv[2] += 256;
         for (int b = 0; b < B; ++b) {
             a[b] = db_move(a[b], step, sh, da[b], db_dither(seq, (uint32_t)b));
             l[b] = db_move(l[b], step, sh, dl[b], db_dither(seq, (uint32_t)(B + b)));

@@ -263,7 +263,7 @@ class DualState:
         self.da = np.zeros_like(self.a)   # previous direction (deflected subgradient)
         self.dl = np.zeros_like(self.l)
         self.dg = np.zeros_like(self.g)
-        self.lv = np.zeros(4, dtype=np.int64)   # level control: delta, record at stage start, iterations in stage; steps taken
+        self.lv = np.zeros(4, dtype=np.int64)   # level control: delta, record at stage start, iterations in stage | steps << 8, best iterate value
         self.ra = np.zeros_like(self.a)         # multipliers at the record dual value (exported, rounded, as search prices)
         self.rl = np.zeros_like(self.l)
         self.rg = np.zeros_like(self.g)

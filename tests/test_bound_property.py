@@ -1,6 +1,6 @@
 """Property tests of the two host-side certificates libkao.so hands out without a solver behind them:
 
-  * kao_upper_bound (closed form, kao_api.cpp::upper_bound) must NEVER undercut the exact optimum -- one undercut
+  * kao_upper_bound (closed form, kao_model.cpp::upper_bound) must NEVER undercut the exact optimum -- one undercut
     is a false OPTIMAL_PROVEN;
   * kao_check_infeasible must never call a feasible instance infeasible.
 

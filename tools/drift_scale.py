@@ -13,4 +13,4 @@ for B, R, P in ((100, 5, 1000), (300, 6, 2000), (500, 10, 5000), (500, 10, 10000
     tm = kao.last_solve_timing()
     gap = r.upper_bound - r.objective
     print(f"B={B} R={R} P={P}: {r.status} objective {r.objective} certificate {r.upper_bound} gap {gap} ({100.0 * gap / max(1, r.upper_bound):.3f} %) "
-          f"closed-form {kao.upper_bound(t)} t_best {tm['time_to_best']:.2f}s launches {int(tm['launches'])} total {dt:.2f}s", flush=True)
+          f"closed-form {kao.upper_bound(t)} t_best {tm['time_to_best']:.2f}s launches {int(tm['launches'])} bound launches {tm['bound_launches']} iters {tm['bound_iters']} total {dt:.2f}s", flush=True)

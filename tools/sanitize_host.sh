@@ -6,7 +6,7 @@ REPO=$(pwd)
 OUT=/tmp/kao_san
 mkdir -p "$OUT"
 SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
-( cd kafka_assignment_optimizer_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -fPIC -shared $SAN -o "$OUT/libkao.so" kao_kernels.hip kao_bound.hip kao_cycle.hip -x hip kao_api.cpp -ldl )
+( cd kafka_assignment_optimizer_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -fPIC -shared $SAN -o "$OUT/libkao.so" kao_kernels.hip kao_bound.hip kao_cycle.hip -x hip kao_model.cpp kao_session.cpp kao_solve.cpp -ldl )
 ( cd cli && g++ -std=c++17 $SAN -o "$OUT/kao-cli" kao_cli.cpp -L"$OUT" -lkao -Wl,-rpath,"$OUT" -Wl,-rpath-link,/opt/rocm/lib -Wl,--allow-shlib-undefined )
 ASAN_LIB=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 cat > "$OUT/run.py" <<PY
