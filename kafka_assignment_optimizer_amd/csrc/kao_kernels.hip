@@ -256,6 +256,10 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     T.rep_lo = TD->rep_lo; T.rep_hi = TD->rep_hi; T.lead_lo = TD->lead_lo; T.lead_hi = TD->lead_hi;
     T.rack_lo = TD->rack_lo; T.rack_hi = TD->rack_hi; T.prack_lo = TD->prack_lo; T.prack_hi = TD->prack_hi;
     T.w00 = TD->w00; T.w01 = TD->w01; T.w10 = TD->w10; T.w11 = TD->w11;
+    // the broker band ends are operands of per-lane compares only: held in VGPRs.  The SGPR file is full (106 + 142 spilled
+    // in the plain instantiation) and every spilled scalar costs a v_readlane -- a VALU slot, the unit this kernel is bound
+    // by -- where it is used; VGPRs are plentiful (68 of the 72 that keep 7 waves per SIMD).
+    asm volatile("" : "+v"(T.rep_lo), "+v"(T.rep_hi), "+v"(T.lead_lo), "+v"(T.lead_hi));
 
     // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[256]] [XR u8[Bx rounded to 64]] then per wave
     //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [K int[256]] [RT int[256]]        (* only when !kGlobalA)
@@ -439,12 +443,22 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const int x_rounds_full = (T.P + 63) >> 6;
     const bool x_windowed = x_rounds_full > 8;               // EXCHANGE scans at most 8 rounds of 64 partitions
 
-    for (uint32_t i = 0; i < prm.iters; ++i) {
-        const uint32_t it = prm.launch * prm.iters + i;
+    // the launch parameters the loop needs, as scalars of their own: read straight from `prm` they stay one 8-dword register
+    // tuple (the kernarg load) that the allocator spills and restores WHOLE -- three times per iteration, 24 v_readlane
+    int lam_lo = prm.lam_min, lam_hi = prm.lam_max;
+    uint32_t n_iters = prm.iters, it_base = prm.launch * prm.iters;
+    {   // through a VGPR and back: a plain scalar copy is coalesced with the tuple again
+        uint32_t v0 = (uint32_t)lam_lo, v1 = (uint32_t)lam_hi, v2 = n_iters, v3 = it_base;
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+        lam_lo = (int)__builtin_amdgcn_readfirstlane(v0); lam_hi = (int)__builtin_amdgcn_readfirstlane(v1);
+        n_iters = __builtin_amdgcn_readfirstlane(v2); it_base = __builtin_amdgcn_readfirstlane(v3);
+    }
+    for (uint32_t i = 0; i < n_iters; ++i) {
+        const uint32_t it = it_base + i;
         const int type = (int)((0x1210u >> ((it & 7u) * 2u)) & 3u);  // pattern R R X R L R X R
         const uint32_t ph = it & pmask;
         // no oscillation before the restart has been feasible once (best_obj < 0): the penalty stays at lam_max
-        const int lam = best_obj < 0 ? prm.lam_max : min(prm.lam_max, prm.lam_min + (int)((2u * ph * lrange) >> plog));
+        const int lam = best_obj < 0 ? lam_hi : min(lam_hi, lam_lo + (int)((2u * ph * lrange) >> plog));
         // REPLACE alternates, in blocks of 8 iterations, between "scan" (one slot, every broker) and "sample"
         // (every lane its own slot, 4 brokers); EXCHANGE always scans; LEADER-SWAP always samples
         const bool sampled = (type == 2) || (type == 0 && ((it >> 3) & 1u));

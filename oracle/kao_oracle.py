@@ -362,8 +362,9 @@ def solve_exact_capped(topics: Sequence[Topic], replica_cap: Sequence[int], time
     return "optimal", int(round(-res.fun)), assigns
 
 
-def lp_bound(topic: Topic) -> Optional[float]:
-    """Value of the LP relaxation (an upper bound on the 0-1 optimum)."""
+def lp_bound(topic: Topic, method: str = "highs") -> Optional[float]:
+    """Value of the LP relaxation (an upper bound on the 0-1 optimum).  method: "highs" (HiGHS chooses, dual simplex here) or
+    "highs-ipm" (interior point + crossover: the only one that finishes on the 400 x 3000 topic within the hour)."""
     from scipy.optimize import linprog
 
     A, lo, hi = _sparse_model(topic)
@@ -375,7 +376,7 @@ def lp_bound(topic: Topic) -> Optional[float]:
 
     A_ub = sparse.vstack([A[fin_hi], -A[fin_lo]])
     b_ub = np.concatenate([hi[fin_hi], -lo[fin_lo]])
-    res = linprog(-c, A_ub=A_ub, b_ub=b_ub, A_eq=A[eq], b_eq=lo[eq], bounds=(0, 1), method="highs")
+    res = linprog(-c, A_ub=A_ub, b_ub=b_ub, A_eq=A[eq], b_eq=lo[eq], bounds=(0, 1), method=method)
     if res.status != 0:
         return None
     return float(-res.fun)
