@@ -31,7 +31,14 @@ __device__ __forceinline__ int db_sub(int m, int n, int lo, int hi) {  // elemen
 }
 // nearest multiple of 2^sh (half up; arithmetic shift)
 __device__ __forceinline__ int dual_round(int v, int sh) { return ((v + (1 << (sh - 1))) >> sh) << sh; }
-__device__ __forceinline__ int db_dir(int d_prev, int s) { return 16 * s + (int)(((long long)d_prev * 3) >> 2); }
+// Deflection d = 2^(6-k) s + floor((2^k - 1) d_prev / 2^k), a memory of about 2^k iterations: k = 2 (16 s + 3/4 d_prev) up to
+// kDualDeflP partitions, k = 4 (4 s + 15/16 d_prev) beyond.  With thousands of partitions a subproblem solution is bang-bang
+// (|s|^2 ~ 2e5 on the drifted 400 x 3000 topic: a price change of a thousandth flips hundreds of partitions), one subgradient
+// says little, and the average over 16 of them -- the residual of an averaged, nearly LP-feasible assignment -- is a far
+// better direction: that topic (LP optimum 22586) reaches 22588.8 after 4,200 iterations instead of stalling at 22601.4.
+// Small topics close faster with the short memory (wide family: 174 of 175 within 1,500 iterations, 166 with k = 4).
+__device__ __forceinline__ int db_defl(int n_partitions) { return n_partitions > kDualDeflP ? 4 : 2; }
+__device__ __forceinline__ int db_dir(int d_prev, int s, int k) { return s * (1 << (6 - k)) + (int)(((long long)d_prev * ((1 << k) - 1)) >> k); }
 // The move |step * d| carries 16 fractional bits below the multipliers' unit of the last place.  Truncating them froze
 // the iterate on large topics (1000 x 30000: |d|^2 grows with the number of brokers, near the optimum every move fell below
 // one unit and NO multiplier changed for 50,000 iterations): the fraction is rounded up with probability equal to itself --
@@ -41,9 +48,9 @@ __device__ __forceinline__ uint32_t db_dither(uint32_t seq, uint32_t idx) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h >> 16;
 }
-// `step` = (gap << sh) / |d|^2 with sh in 20..40 (bound_step_length): the move is gap * 16 d / |d|^2.
-__device__ __forceinline__ int db_move(int m, long long step, int sh, int d, uint32_t h) {
-    const long long mag = (step * (d < 0 ? -(long long)d : (long long)d) + ((long long)h << (sh - 20))) >> (sh - 4);
+// `step` = (gap << sh) / |d|^2 with sh in 20..40 (bound_step_length): the move is gap * 2^(6-k) d / |d|^2.
+__device__ __forceinline__ int db_move(int m, long long step, int sh, int k, int d, uint32_t h) {
+    const long long mag = (step * (d < 0 ? -(long long)d : (long long)d) + ((long long)h << (sh - 22 + k))) >> (sh - 6 + k);
     long long v = (long long)m - (d < 0 ? -mag : mag);
     v = v > kDualClamp ? kDualClamp : (v < -kDualClamp ? -kDualClamp : v);
     return (int)v;
@@ -67,6 +74,7 @@ struct BoundTopic {
     int B, R, P, RF, rfc;
     int rep_lo, rep_hi, lead_lo, lead_hi, rack_lo, rack_hi, plo, phi;
     int w00, w01, w10, w11;   // role weights in dual fixed point
+    int dk;                   // deflection memory log2 (db_defl)
 };
 __device__ __forceinline__ BoundTopic bound_topic(const TopicDev &T) {
     BoundTopic K;
@@ -74,6 +82,7 @@ __device__ __forceinline__ BoundTopic bound_topic(const TopicDev &T) {
     K.rep_lo = T.rep_lo; K.rep_hi = T.rep_hi; K.lead_lo = T.lead_lo; K.lead_hi = T.lead_hi;
     K.rack_lo = T.rack_lo; K.rack_hi = T.rack_hi; K.plo = T.prack_lo; K.phi = T.prack_hi;
     K.w00 = T.w00 * kDualScale; K.w01 = T.w01 * kDualScale; K.w10 = T.w10 * kDualScale; K.w11 = T.w11 * kDualScale;
+    K.dk = db_defl(T.P);
     return K;
 }
 
@@ -337,7 +346,7 @@ __device__ __forceinline__ void bound_band_terms(const BoundLds &L, const BoundT
         cL += (long long)a_ * (a_ > 0 ? K.rep_hi : K.rep_lo) + (long long)l_ * (l_ > 0 ? K.lead_hi : K.lead_lo);
         cN += (long long)sa * sa + (long long)sl * sl;
         if (!probe) {
-            const int da = db_dir(g_da[b], sa), dl = db_dir(g_dl[b], sl);
+            const int da = db_dir(g_da[b], sa, K.dk), dl = db_dir(g_dl[b], sl, K.dk);
             g_da[b] = da; g_dl[b] = dl;
             cD += (long long)da * da + (long long)dl * dl;
         }
@@ -347,22 +356,25 @@ __device__ __forceinline__ void bound_band_terms(const BoundLds &L, const BoundT
         cL += (long long)g_ * (g_ > 0 ? K.rack_hi : K.rack_lo);
         cN += (long long)sg * sg;
         if (!probe) {
-            const int dg = db_dir(L.DG[tid], sg);
+            const int dg = db_dir(L.DG[tid], sg, K.dk);
             L.DG[tid] = dg;
             cD += (long long)dg * dg;
         }
     }
 }
 
-// Level control and step length of the Polyak step (every thread computes the same values): aim at the incumbent while
-// the record keeps falling; every kDualStage iterations without half a unit of progress the distance between record and
-// level is halved (an incumbent below the optimum is an unreachable level: steps too long, the record stalls far above
-// the optimum); a stage that gained more than that distance doubles it again, up to the incumbent (the level had closed in
-// while the incumbent was poor -- inside kao_solve the early incumbents of large topics are -- and a better one makes
-// longer steps pay again).  The record that steers the level is the best value among the ITERATES, `bi` -- not the certificate record,
-// which the rounding probes also lower: a probe value the iterate cannot reach soon reads as "no progress", and with a probe
-// every 150 iterations (kao_solve's launches) the level control starved (drifted 500 x 5000: 37560.9 after 18,000 iterations
-// in launches of 150, 37559.6 in launches of 2000).  `dn` is |d|^2 (already replaced by 256 |s|^2 on a reset).
+// Level control and step length of the Polyak step (every thread computes the same values).  The step aims at `level` =
+// record - delta, never below the incumbent `target`; delta starts as the whole distance record -> incumbent (an incumbent
+// below the optimum is an unreachable level: steps too long, the record stalls far above the optimum).  Per stage of
+// kDualStage iterations the record's gain is held against delta: less than delta / 32 halves delta (floor 1/16), at least
+// delta / 8 doubles it (never beyond the incumbent).  The thresholds are RELATIVE because the gain per stage is itself
+// proportional to delta (step length ~ delta): the first rule halved whenever a stage gained less than half a unit, which
+// below delta ~ 2.5 is every stage -- delta collapsed to its floor wherever the record stood, and nothing ever widened it
+// again (drifted 400 x 3000, LP optimum 22586: frozen at 22601.4 aimed at a moving incumbent; now 22586.7, a probe at 22586.5).
+// The record that steers the level is the best value among the ITERATES, `bi` -- not the certificate record, which the
+// rounding probes also lower: a probe value the iterate cannot reach soon reads as "no progress", and with a probe every
+// 150 iterations (kao_solve's launches) the level control starved (drifted 500 x 5000: 37560.9 after 18,000 iterations in
+// launches of 150, 37559.6 in launches of 2000).  `dn` is |d|^2 (already replaced by the scaled |s|^2 on a reset).
 // Returns (gap << sh) / |d|^2; the shift `sh` is as large as 62 bits allow, at most 40 (with the fixed 20 bits of the first
 // version the quotient was ZERO once |d|^2 > 2^32 at the smallest gap -- 1000 brokers whose counts are tens off -- and the
 // iterate stopped; gap < 2^42 by K-bound's limits on P * RF * weight, so sh >= 20).
@@ -373,8 +385,8 @@ __device__ __forceinline__ long long bound_step_length(long long target, long lo
     if (Lv < bi) bi = Lv;
     if (++lv_since >= kDualStage) {
         const long long prog = lv_rec - bi;
-        if (prog < kDualScale / 2) { lv_delta /= 2; if (lv_delta < kDualScale / 16) lv_delta = kDualScale / 16; }
-        else if (prog >= lv_delta && bi - 2 * lv_delta >= level) lv_delta *= 2;   // a stage that gained more than the distance: aim further
+        if (prog < lv_delta / 32) { lv_delta /= 2; if (lv_delta < kDualScale / 16) lv_delta = kDualScale / 16; }
+        else if (prog >= lv_delta / 8 && bi - 2 * lv_delta >= level) lv_delta *= 2;
         lv_rec = bi; lv_since = 0;
     }
     if (bi - lv_delta > level) level = bi - lv_delta;
@@ -390,17 +402,17 @@ __device__ __forceinline__ void bound_take_step(const BoundLds &L, const BoundTo
     for (int b = tid; b < K.B; b += nt) {
         int da = g_da[b], dl = g_dl[b];
         if (reset) {
-            da = 16 * db_sub(L.A[b], L.NR[b], K.rep_lo, K.rep_hi); dl = 16 * db_sub(L.LM[b], L.NL[b], K.lead_lo, K.lead_hi);
+            da = db_sub(L.A[b], L.NR[b], K.rep_lo, K.rep_hi) * (1 << (6 - K.dk)); dl = db_sub(L.LM[b], L.NL[b], K.lead_lo, K.lead_hi) * (1 << (6 - K.dk));
             g_da[b] = da; g_dl[b] = dl;
         }
-        L.A[b] = db_move(L.A[b], step, sh, da, db_dither(seq, (uint32_t)b));
-        L.LM[b] = db_move(L.LM[b], step, sh, dl, db_dither(seq, (uint32_t)(K.B + b)));
+        L.A[b] = db_move(L.A[b], step, sh, K.dk, da, db_dither(seq, (uint32_t)b));
+        L.LM[b] = db_move(L.LM[b], step, sh, K.dk, dl, db_dither(seq, (uint32_t)(K.B + b)));
         L.NR[b] = 0; L.NL[b] = 0;
     }
     if (tid < K.R) {
         int dg = L.DG[tid];
-        if (reset) { dg = 16 * db_sub(L.G[tid], L.NK[tid], K.rack_lo, K.rack_hi); L.DG[tid] = dg; }
-        L.G[tid] = db_move(L.G[tid], step, sh, dg, db_dither(seq, (uint32_t)(2 * K.B + tid)));
+        if (reset) { dg = db_sub(L.G[tid], L.NK[tid], K.rack_lo, K.rack_hi) * (1 << (6 - K.dk)); L.DG[tid] = dg; }
+        L.G[tid] = db_move(L.G[tid], step, sh, K.dk, dg, db_dither(seq, (uint32_t)(2 * K.B + tid)));
         L.NK[tid] = 0;
     }
 }
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
         if (best < (target + 1) * kDualScale) { flags |= 1; break; }
         if (nrm == 0) { flags |= 2; break; }
         const bool reset = dn == 0;  // the memory cancelled the subgradient: restart from it
-        if (reset) dn = 256 * nrm;
+        if (reset) dn = nrm << (2 * (6 - K.dk));
         int sh;
         const long long step = bound_step_length(target, Lv, dn, lv_delta, lv_rec, lv_since, lv_bi, sh);
         bound_take_step(L, K, g_da, g_dl, reset, step, sh, lv_seq++, tid, nt);
@@ -674,7 +686,7 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
         return;
     }
     const bool reset = dn == 0;
-    if (reset) dn = 256 * nrm;
+    if (reset) dn = nrm << (2 * (6 - K.dk));
     int sh;
     const long long step = bound_step_length(target, Lv, dn, lv_delta, lv_rec, lv_since, lv_bi, sh);
     bound_take_step(L, K, g_da, g_dl, reset, step, sh, lv_seq, tid, nt);

@@ -20,6 +20,7 @@ constexpr int kDualScale = 1 << kDualLog2; // fixed point of the dual multiplier
                                           // below one unit of the last place truncate to zero and the iterate freezes -- 300 x 2000: stuck at
                                           // 14831.74 for 110,000 iterations; with 2^16 the same iteration reaches the LP optimum 14826.0)
 constexpr int kDualStage = 100;           // level control: iterations per stage (K-bound)
+constexpr int kDualDeflP = 2048;          // topics with more partitions use the long deflection memory (kao_bound.hip::db_defl)
 constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
 constexpr int kDualQuarterLog2 = kDualLog2 - 2;  // kDualScale / 4: the quarter grid of the rounding probes and the search prices
 constexpr long long kDualRelevel = 1ll << 62;  // bit of BoundPools::target: restart the level control at this launch (kao_session_bound_relevel)

@@ -738,6 +738,14 @@ uint64_t kao_port_search_many(void *h, const port_params *pp, uint32_t rho0, uin
 #define DB_SCALE (1 << DB_LOG2)
 #define DB_CLAMP (1 << 26)
 #define DB_STAGE 100
+/* Deflection d = 2^(6-k) s + floor((2^k - 1) d_prev / 2^k), a memory of about 2^k iterations: k = 2 (16 s + 3/4 d_prev) up to
+ * DB_DEFL_P partitions, k = 4 (4 s + 15/16 d_prev) beyond.  With thousands of partitions a subproblem solution is bang-bang
+ * (|s|^2 ~ 2e5 on the drifted 400 x 3000 topic: a price change of a thousandth flips hundreds of partitions), one subgradient
+ * says little, and the average over 16 of them -- the residual of an averaged, nearly LP-feasible assignment -- is a far
+ * better direction: that topic (LP optimum 22586) reaches 22588.8 after 4,200 iterations instead of stalling at 22601.4.
+ * Small topics close faster with the short memory (wide family: 174 of 175 within 1,500 iterations, 166 with k = 4). */
+#define DB_DEFL_P 2048
+static inline int db_defl(int n_partitions) { return n_partitions > DB_DEFL_P ? 4 : 2; }
 #define DB_QUARTER_LOG2 (DB_LOG2 - 2) /* DB_SCALE / 4: the quarter grid of the rounding probes and of the search prices */
 static inline int32_t db_round(int32_t v, int sh) { return (int32_t)(((v + (1 << (sh - 1))) >> sh) << sh); } /* nearest multiple, half up */
 
@@ -822,8 +830,8 @@ static inline int32_t db_sub(int32_t m, int n, int lo, int hi) {   /* element of
     if (m < 0) return lo - n;
     return n < lo ? lo - n : n > hi ? hi - n : 0;
 }
-static inline int32_t db_dir(int32_t d_prev, int32_t s) {         /* d = 16 s + floor(3 d_prev / 4) */
-    return 16 * s + (int32_t)(((int64_t)d_prev * 3) >> 2);
+static inline int32_t db_dir(int32_t d_prev, int32_t s, int k) {  /* d = 2^(6-k) s + floor((2^k - 1) d_prev / 2^k) */
+    return s * (1 << (6 - k)) + (int32_t)(((int64_t)d_prev * ((1 << k) - 1)) >> k);
 }
 /* the 16 fractional bits of a move are rounded up with probability equal to the fraction (16 bits hashed from the step
  * number and the multiplier's index): truncation froze the iterate on large topics, see kao_bound.hip */
@@ -832,8 +840,8 @@ static inline uint32_t db_dither(uint32_t seq, uint32_t idx) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h >> 16;
 }
-static inline int32_t db_move(int32_t m, int64_t step, int sh, int32_t d, uint32_t h) {
-    const int64_t mag = (step * (d < 0 ? -(int64_t)d : (int64_t)d) + ((int64_t)h << (sh - 20))) >> (sh - 4);
+static inline int32_t db_move(int32_t m, int64_t step, int sh, int k, int32_t d, uint32_t h) {
+    const int64_t mag = (step * (d < 0 ? -(int64_t)d : (int64_t)d) + ((int64_t)h << (sh - 22 + k))) >> (sh - 6 + k);
     int64_t v = (int64_t)m - (d < 0 ? -mag : mag);
     if (v > DB_CLAMP) v = DB_CLAMP;
     if (v < -DB_CLAMP) v = -DB_CLAMP;
@@ -856,7 +864,7 @@ int kao_port_dual_bound(const port_topic *t, int64_t target, int32_t iters, int3
 int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, int32_t *a, int32_t *l, int32_t *g,
                             int32_t *da, int32_t *dl, int32_t *dg, int64_t *lv, int64_t *best_L, int32_t *flags,
                             int32_t *ra, int32_t *rl_, int32_t *rg_) {
-    const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf;
+    const int B = t->n_brokers, R = t->n_racks, P = t->n_partitions, RF = t->rf, dk = db_defl(t->n_partitions);
     int32_t *nrep = (int32_t *)malloc(sizeof(int32_t) * (size_t)B), *nlead = (int32_t *)malloc(sizeof(int32_t) * (size_t)B);
     int32_t nrack[256];
     *flags = 0;
@@ -878,15 +886,15 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
             L += (int64_t)a[b] * (a[b] > 0 ? t->rep_hi : t->rep_lo) + (int64_t)l[b] * (l[b] > 0 ? t->lead_hi : t->lead_lo);
             const int32_t sa = db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi), sl = db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi);
             nrm += (int64_t)sa * sa + (int64_t)sl * sl;
-            da[b] = db_dir(da[b], sa);
-            dl[b] = db_dir(dl[b], sl);
+            da[b] = db_dir(da[b], sa, dk);
+            dl[b] = db_dir(dl[b], sl, dk);
             dn += (int64_t)da[b] * da[b] + (int64_t)dl[b] * dl[b];
         }
         for (int r = 0; r < R; ++r) {
             L += (int64_t)g[r] * (g[r] > 0 ? t->rack_hi : t->rack_lo);
             const int32_t sg = db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi);
             nrm += (int64_t)sg * sg;
-            dg[r] = db_dir(dg[r], sg);
+            dg[r] = db_dir(dg[r], sg, dk);
             dn += (int64_t)dg[r] * dg[r];
         }
         if (L < *best_L) {
@@ -897,16 +905,18 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         if (nrm == 0) { *flags |= 2; ++it; break; }
         if (dn == 0) {                                    /* the memory cancelled the subgradient: restart from it */
             for (int b = 0; b < B; ++b) {
-                da[b] = 16 * db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi);
-                dl[b] = 16 * db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi);
+                da[b] = db_sub(a[b], nrep[b], t->rep_lo, t->rep_hi) * (1 << (6 - dk));
+                dl[b] = db_sub(l[b], nlead[b], t->lead_lo, t->lead_hi) * (1 << (6 - dk));
             }
-            for (int r = 0; r < R; ++r) dg[r] = 16 * db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi);
-            dn = 256 * nrm;
+            for (int r = 0; r < R; ++r) dg[r] = db_sub(g[r], nrack[r], t->rack_lo, t->rack_hi) * (1 << (6 - dk));
+            dn = nrm << (2 * (6 - dk));
         }
-        /* Level control: the Polyak step aims at `level`, the incumbent while the record keeps falling.  An incumbent
-         * below the optimum is an unreachable level (steps too long, the record stalls far above the optimum): every
-         * DB_STAGE iterations without half a unit of progress the distance delta between record and level is halved; a stage
-         * that gained more than delta doubles it again (never beyond the incumbent).
+        /* Level control: the Polyak step aims at `level` = record - delta, never below the incumbent `target`; delta starts
+         * as the whole distance record -> incumbent (an incumbent below the optimum is an unreachable level: steps too long,
+         * the record stalls far above the optimum).  Per stage of DB_STAGE iterations the record's gain is held against delta:
+         * less than delta / 32 halves delta (floor 1/16), at least delta / 8 doubles it (never beyond the incumbent).  The
+         * thresholds are relative because the gain per stage is itself proportional to delta; an absolute one (half a unit, the
+         * first version) fails every stage once delta < ~2.5 and delta collapses wherever the record stands.
          * The record that steers the level is the best value among the ITERATES (lv[3]), not *best_L, which the rounding probes
          * also lower (a probe value the iterate cannot reach soon would read as "no progress").
          * lv = {delta (0 = not started), record at the start of the stage, iterations in the stage | steps taken << 8, best iterate value}. */
@@ -915,14 +925,14 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         if (L < lv[3]) lv[3] = L;
         if (((++lv[2]) & 0xFF) >= DB_STAGE) {
             const int64_t prog = lv[1] - lv[3];
-            if (prog < DB_SCALE / 2) { lv[0] /= 2; if (lv[0] < DB_SCALE / 16) lv[0] = DB_SCALE / 16; }
-            else if (prog >= lv[0] && lv[3] - 2 * lv[0] >= level) lv[0] *= 2;   /* a stage that gained more than the distance: aim further */
+            if (prog < lv[0] / 32) { lv[0] /= 2; if (lv[0] < DB_SCALE / 16) lv[0] = DB_SCALE / 16; }
+            else if (prog >= lv[0] / 8 && lv[3] - 2 * lv[0] >= level) lv[0] *= 2;
             lv[1] = lv[3]; lv[2] &= ~(int64_t)0xFF;
         }
         if (lv[3] - lv[0] > level) level = lv[3] - lv[0];
         int64_t gap = L - level;
         if (gap < 1) gap = 1;
-        /* multiplier change = gap * 16 d / |d|^2; step = (gap << sh) / |d|^2 with as many bits as 62 allow, at most 40
+        /* multiplier change = gap * 2^(6-k) d / |d|^2; step = (gap << sh) / |d|^2 with as many bits as 62 allow, at most 40
          * (20 fixed bits gave a ZERO quotient once |d|^2 > 2^32 at the smallest gap; gap < 2^42 by the limits above) */
         int sh = __builtin_clzll((unsigned long long)gap) - 2;
         sh = sh > 40 ? 40 : (sh < 20 ? 20 : sh);
@@ -930,10 +940,10 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         const uint32_t seq = (uint32_t)(lv[2] >> 8);      /* steps taken so far, over all launches */
         lv[2] += 256;
         for (int b = 0; b < B; ++b) {
-            a[b] = db_move(a[b], step, sh, da[b], db_dither(seq, (uint32_t)b));
-            l[b] = db_move(l[b], step, sh, dl[b], db_dither(seq, (uint32_t)(B + b)));
+            a[b] = db_move(a[b], step, sh, dk, da[b], db_dither(seq, (uint32_t)b));
+            l[b] = db_move(l[b], step, sh, dk, dl[b], db_dither(seq, (uint32_t)(B + b)));
         }
-        for (int r = 0; r < R; ++r) g[r] = db_move(g[r], step, sh, dg[r], db_dither(seq, (uint32_t)(2 * B + r)));
+        for (int r = 0; r < R; ++r) g[r] = db_move(g[r], step, sh, dk, dg[r], db_dither(seq, (uint32_t)(2 * B + r)));
     }
     /* Rounding probes (only when the launch ran all its iterations): the dual function is also evaluated at the
      * multipliers rounded to the quarter grid and to the half grid -- optimal multipliers of this model tend to be small
