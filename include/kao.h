@@ -211,11 +211,6 @@ int kao_session_stats(kao_session *s, kao_stats *out);
  * occupies one compute unit per topic and runs beside K-search (kao_session_step); a new launch first waits for the
  * previous K-bound launch (it continues from the multipliers that one left in HBM). */
 int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters);
-/* The next K-bound launch of `topic` starts its level control afresh: the step length aims at the target again (distance
- * record -> level = record - target) instead of at the level the earlier launches had closed in on.  For a target that has
- * risen by much since the level control started (kao_solve: an incumbent that moved by more than half of what separates it
- * from the certificate): aiming at a near-optimal incumbent is what makes the Polyak step converge fast. */
-int kao_session_bound_relevel(kao_session *s, int32_t topic);
 /* Search prices.  K-search can carry Lagrangian prices of the coupling rows in its move cost: delta = lam * dViolation
  * - S * dObjective + S * dPrice.  A row's multiplier (a[b]: replicas on broker b, l[b]: leaders on b, g[r]: replicas in rack
  * r) is charged for a unit that enters the row and refunded for one that leaves, but only where the row's count leaves or

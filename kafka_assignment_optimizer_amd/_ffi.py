@@ -69,7 +69,6 @@ SIGNATURES = {
     "kao_session_restart_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _P(C.c_uint16), _P(C.c_uint16),
                                             _P(C.c_int32)]),
     "kao_session_bound_step": (C.c_int, [C.c_void_p, _P(C.c_int64), C.c_int32]),
-    "kao_session_bound_relevel": (C.c_int, [C.c_void_p, C.c_int32]),
     "kao_session_set_prices": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "kao_session_adopt_prices": (C.c_int, [C.c_void_p]),
     "kao_session_prices": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),

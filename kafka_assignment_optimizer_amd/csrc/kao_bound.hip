@@ -456,12 +456,12 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
         for (int p = tid; p < P; p += nt) L.CURP[p] = bound_load_cur(curd, K.rfc, p);
     bound_rack_members(L, pl, T, tid, nt);
     long long best = pl.best_L[topic];
-    const long long target_raw = pl.target[topic], target = target_raw & ~kDualRelevel;
+    const long long target = pl.target[topic];
     // level control (every thread keeps the same copy): distance record -> level, record at stage start, iterations in stage
     long long *g_lv = reinterpret_cast<long long *>(gp + 4 * B + 2 * kRackTab);
     // the multipliers of the record (smallest) dual value: what the search prices are taken from
     int *g_ra = gp + 4 * B + 2 * kRackTab + 8, *g_rl = g_ra + B, *g_rg = g_rl + B;
-    long long lv_delta = (target_raw & kDualRelevel) ? 0 : g_lv[0], lv_rec = g_lv[1];
+    long long lv_delta = g_lv[0], lv_rec = g_lv[1];
     // g_lv[2] = iterations in the stage | steps taken so far (over all launches: the dither sequence number) << 8
     int lv_since = (int)(g_lv[2] & 0xFF);
     uint32_t lv_seq = (uint32_t)(g_lv[2] >> 8);
@@ -561,10 +561,6 @@ __global__ __launch_bounds__(64) void k_bound_begin(BoundPools pl, BoundWide wd,
     const int topic = pl.ids[i];
     pl.info[topic * 4 + 1] = 0;
     reinterpret_cast<int *>(wd.ctl + (size_t)topic * 8)[4] = 0;
-    if (pl.target[topic] & kDualRelevel) {   // level control afresh: the first step of the sequence re-initialises it
-        const TopicDev &T = pl.topics[topic];
-        reinterpret_cast<long long *>(pl.dual_pool + T.dual_off + 4 * T.B + 2 * kRackTab)[0] = 0;
-    }
 }
 
 // mode 0: iteration; 1 / 2: probe at the multipliers rounded to the quarter / half grid
@@ -663,7 +659,7 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
     const long long Lv = L.acc[0], nrm = L.acc[1];
     long long dn = L.acc[2];
     long long best = pl.best_L[topic];
-    const long long target = pl.target[topic] & ~kDualRelevel;
+    const long long target = pl.target[topic];
     long long lv_delta = g_lv[0], lv_rec = g_lv[1];
     int lv_since = (int)(g_lv[2] & 0xFF);
     const uint32_t lv_seq = (uint32_t)(g_lv[2] >> 8);

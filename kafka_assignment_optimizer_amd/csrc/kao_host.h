@@ -91,7 +91,6 @@ struct kao_session {
     std::vector<char> dual_ok;           // per topic: within K-bound's limits
     std::vector<int64_t> h_dual_target;  // staging for kao_session_bound_step
     std::vector<int32_t> h_dual_ids;
-    std::vector<char> dual_relevel;      // per topic: the next K-bound launch restarts its level control
     std::vector<int2> h_wide_map;        // sliced K-bound: {topic, slice} per workgroup (staging, like h_dual_ids)
     uint64_t wide_ctl_i32 = 0, wide_map_i32 = 0;   // int32 offsets of the control blocks / the map inside d_dual
     std::vector<int32_t> dual_flags, dual_iters;

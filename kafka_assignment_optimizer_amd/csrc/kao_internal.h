@@ -23,7 +23,6 @@ constexpr int kDualStage = 100;           // level control: iterations per stage
 constexpr int kDualDeflP = 2048;          // topics with more partitions use the long deflection memory (kao_bound.hip::db_defl)
 constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
 constexpr int kDualQuarterLog2 = kDualLog2 - 2;  // kDualScale / 4: the quarter grid of the rounding probes and the search prices
-constexpr long long kDualRelevel = 1ll << 62;  // bit of BoundPools::target: restart the level control at this launch (kao_session_bound_relevel)
 constexpr int kDualProbes = 2;            // probes per K-bound launch: multipliers rounded to the quarter grid, then the half grid
 constexpr uint32_t kExternalRestart = 0xFFFFFu;  // restart id of a best key adopted from another GPU (kao_solve_multi)
 constexpr uint32_t kObjCap = 0xFFFFFFu;   // packed best key: viol(20) << 44 | (kObjCap - obj) << 20 | restart(20)
@@ -114,7 +113,7 @@ struct BoundPools {
     const uint16_t *ext_pool;    // rack-major internal index -> dense broker (members of every rack)
     const int32_t *rsz_pool;     // rack sizes
     int32_t *dual_pool;          // multipliers and previous directions, see TopicDev::dual_off
-    const long long *target;     // [n_topics] incumbent objective the Polyak step aims at (| kDualRelevel)
+    const long long *target;     // [n_topics] incumbent objective the Polyak step aims at
     long long *best_L;           // [n_topics] smallest dual value so far (fixed point, kDualScale)
     int32_t *info;               // [n_topics][4] = {iterations so far, flags of the last launch, -, -}
     int32_t iters;               // iterations this launch

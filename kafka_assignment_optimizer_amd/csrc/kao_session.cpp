@@ -856,7 +856,6 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
         if (target[t] > (int64_t)1 << 40) return fail(KAO_ERR_INVALID, "target out of range");
         s->h_dual_ids.push_back(t);
         s->h_dual_target[(size_t)t] = target[t];
-        if (!s->dual_relevel.empty() && s->dual_relevel[(size_t)t]) { s->h_dual_target[(size_t)t] |= kDualRelevel; s->dual_relevel[(size_t)t] = 0; }
         maxB = std::max(maxB, s->pts[(size_t)t].d.B);
         maxP = std::max(maxP, s->pts[(size_t)t].d.P);
         maxR = std::max(maxR, s->pts[(size_t)t].d.R);
@@ -932,13 +931,6 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     s->bound_inflight = true;
     s->bound_iters_last = iters;
     s->bound_launches++;
-    return KAO_OK;
-}
-
-int kao_session_bound_relevel(kao_session *s, int32_t topic) {
-    if (!s || topic < 0 || topic >= s->n_topics) return fail(KAO_ERR_INVALID, "bad argument");
-    if (s->dual_relevel.empty()) s->dual_relevel.assign((size_t)s->n_topics, 0);
-    s->dual_relevel[(size_t)topic] = 1;
     return KAO_OK;
 }
 

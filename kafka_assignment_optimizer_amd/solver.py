@@ -306,10 +306,6 @@ class Session:
         _check(_ffi.load().kao_session_bound_step(self._h, tg.ctypes.data_as(C.POINTER(C.c_int64)), int(iters)),
                "kao_session_bound_step")
 
-    def bound_relevel(self, topic: int):
-        """The next K-bound launch of `topic` restarts its level control (the step length aims at the target again)."""
-        _check(_ffi.load().kao_session_bound_relevel(self._h, int(topic)), "kao_session_bound_relevel")
-
     def set_prices(self, topic: int, a, l, g):
         """Search prices of one topic from the host (fixed point, 65536 = 1): a[n_brokers], l[n_brokers], g[n_racks]."""
         t = self.topics[topic]

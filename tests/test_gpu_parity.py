@@ -723,39 +723,6 @@ def test_dual_bound_replay_large_shapes(kao, ko, kp, monkeypatch, chunk):
         assert got["a"].tolist() == st.a.tolist() and got["l"].tolist() == st.l.tolist() and got["g"].tolist() == st.g[:ot.n_racks].tolist(), i
 
 
-@pytest.mark.parametrize("chunk", [None, "64"])
-def test_dual_bound_relevel_replay(kao, ko, kp, monkeypatch, chunk):
-    """kao_session_bound_relevel: the next launch starts its level control afresh, aimed at the (risen) target -- the replay is
-    the port with the level distance zeroed (lv[0] = 0) before that launch.  Multipliers and dual value stay bit-exact, and the
-    re-levelled run differs from the one that carried on (the flag is not a no-op)."""
-    _bound_chunk(monkeypatch, chunk)
-    ots = _drifted(ko, 4, 2)
-    pts = [to_product_topic(t) for t in ots]
-    ubs = [kao.upper_bound(t) for t in pts]
-    low = [u - 60 for u in ubs]
-    high = [u - 4 for u in ubs]
-    with kao.Session(pts, seed=5, restarts=8, iters_per_launch=64) as s, kao.Session(pts, seed=5, restarts=8, iters_per_launch=64) as s2:
-        for ss in (s, s2):
-            ss.bound_step(low, 250)
-            ss.bounds()
-        for ti in range(len(ots)):
-            s.bound_relevel(ti)
-        s.bound_step(high, 90); s2.bound_step(high, 90)
-        s.bounds(); s2.bounds()
-        differs = 0
-        for ti, ot in enumerate(ots):
-            st = kp.port_dual_bound(ot, low[ti], 250)
-            if st.flags & 7:
-                continue
-            st.lv[0] = 0
-            st = kp.port_dual_bound(ot, high[ti], 90, st)
-            d = s.dual_state(ti)
-            assert d["best_dual"] == st.best_L, ti
-            assert d["a"].tolist() == st.a.tolist() and d["l"].tolist() == st.l.tolist() and d["g"].tolist() == st.g[:ot.n_racks].tolist(), ti
-            differs += d["a"].tolist() != s2.dual_state(ti)["a"].tolist()
-        assert differs >= 1
-
-
 def test_dual_bound_is_valid_and_closes_wide_family(kao, ko):
     """Every feasible instance of the wide family: floor(dual) never undercuts the HiGHS optimum and, aimed at the
     optimum, equals it on all but a few (the closed-form bound is tight on fewer than half)."""
