@@ -208,7 +208,9 @@ int kao_session_stats(kao_session *s, kao_stats *out);
  * One launch runs up to `iters` iterations for every topic i with target[i] >= 0 (the incumbent objective the
  * step length aims at; pass -1 to skip a topic).  Topics outside K-bound's limits (broker and rack tables
  * beyond 160 KiB of LDS: about 8,000 brokers; n_partitions*rf > 131072; a weight outside 0..255) are skipped.  Asynchronous, on a stream of its own: K-bound
- * occupies one compute unit per topic and runs beside K-search (kao_session_step); a new launch first waits for the
+ * occupies one compute unit per topic -- one per 512 partitions when a launch holds a topic of more than 2,048 partitions
+ * (then every iteration is a kernel launch of its own, see kao_bound.hip) -- and runs beside K-search (kao_session_step); a
+ * new launch first waits for the
  * previous K-bound launch (it continues from the multipliers that one left in HBM). */
 int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters);
 /* Search prices.  K-search can carry Lagrangian prices of the coupling rows in its move cost: delta = lam * dViolation
