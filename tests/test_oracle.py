@@ -2,6 +2,9 @@
 example (KAT-1, the only result the reference pins) and cross-checked three ways -- HiGHS on the
 materialised model, HiGHS on the emitted lp_solve text, brute force on tiny instances -- and the C
 port is checked against the numpy verifier and against the exact optimum."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -223,6 +226,24 @@ def test_port_dual_bound_is_valid_and_closes_the_gap(ko, kp):
         assert st.bound >= c["objective"]
         excess.append(st.bound - c["objective"])
     assert sum(excess) <= len(excess) // 4 and max(excess) <= 2, (sum(excess), max(excess))
+
+
+def test_port_dual_bound_follows_a_moving_incumbent(ko, kp):
+    """What kao_solve does to K-bound on a large topic: launches of 150 iterations aimed at incumbents that start far below
+    the optimum and close in.  The level control must neither collapse on the way (the first rule halved the distance record ->
+    level whenever a stage gained less than half a unit: below a distance of ~2.5 that is every stage) nor be starved by the
+    rounding probes; on the drifted 120 x 1200 topic (optimum 8834, proven on the device and equal to the LP value) the
+    certificate reaches the optimum although no target ever does."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_golden_drift_scale import oracle_topic
+    ot = oracle_topic(120, 4, 1200)
+    opt = 8834
+    st = None
+    for upto, target in ((600, opt - 300), (1200, opt - 50), (1800, opt - 8), (4200, opt - 2)):
+        while (st.iters if st else 0) < upto:
+            st = kp.port_dual_bound(ot, target, 150, st)
+            assert not st.flags & 6
+    assert st.bound == opt, (st.bound, st.best_L / kp.DB_SCALE)
 
 
 def test_port_dual_bound_golden_configs(ko, kp):
