@@ -16,7 +16,9 @@ public final class Kao {
     /** Selects the HIP device of this process (kao_init). */
     public static native void init(int device);
 
-    /** Solves nTopics topics sharing one broker set (kao_solve).  Arrays are flattened per topic, in order.
+    /** Solves nTopics topics sharing one broker set (kao_solve; kao_solve_multi when `devices` lists more than one HIP device
+     *  ordinal -- topics sharded over them, or replicated with an RCCL min-allreduce when there are fewer topics than
+     *  devices; null or one entry = the device selected by init()).  Arrays are flattened per topic, in order.
      *  @return status per topic; assignment (dense broker index, leader first) is written to outAssignment,
      *          objective and its certified upper bound to outObjective / outUpperBound. */
     public static native int[] solve(int nTopics, int nBrokers, int nRacks, byte[] rackOf,
@@ -24,6 +26,7 @@ public final class Kao {
                                      short[] current,          // concatenated [P*rfCur] per topic
                                      int[] weights,            // {LL, LF, FL, FF}  (README.md:145-146)
                                      long seed, double timeLimitSeconds,
+                                     int[] devices,            // null, or the HIP device ordinals to shard over
                                      short[] outAssignment,    // concatenated [P*rf] per topic
                                      long[] outObjective, long[] outUpperBound);
 

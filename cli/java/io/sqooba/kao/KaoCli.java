@@ -5,7 +5,7 @@
 //
 //   java -Djava.library.path=cli/java -cp cli/java io.sqooba.kao.KaoCli --current current.json \
 //        --broker-list 0,1,...,18 --racks racks.json [--rf N] [--weights LL,LF,FL,FF] [--seed S] [--time-limit SEC]
-//        [--device D] [--no-canonical] [--out FILE] [--report] [--require-optimal]
+//        [--device D] [--gpus N | d0,d1,...] [--no-canonical] [--out FILE] [--report] [--require-optimal]
 //
 // Exit status as kao-cli: 0 = every topic solved (a warning on stderr marks a plan that is feasible but not PROVEN
 // optimal), 3 = a topic is infeasible / no feasible plan found, 4 = --require-optimal and a plan was withheld, 1 = error,
@@ -99,7 +99,7 @@ public final class KaoCli {
     private static void usage(String msg) {
         if (msg != null) System.err.println("KaoCli: " + msg);
         System.err.println("usage: KaoCli --current <reassignment.json|-> --broker-list <id,id,...> --racks <racks.json | id:rack,...>\n"
-            + "              [--rf N] [--weights LL,LF,FL,FF] [--seed S] [--time-limit SEC] [--device D]\n"
+            + "              [--rf N] [--weights LL,LF,FL,FF] [--seed S] [--time-limit SEC] [--device D] [--gpus N]\n"
             + "              [--no-canonical] [--out <file>] [--report] [--require-optimal]");
         System.exit(2);
     }
@@ -114,7 +114,8 @@ public final class KaoCli {
     @SuppressWarnings("unchecked")
     public static void main(String[] argv) {
         String curPath = null, brokersCsv = null, racksArg = null, outPath = null;
-        int rfOverride = 0, device = 0;
+        int rfOverride = 0, device = 0, gpus = 1;
+        int[] gpuList = null;
         int[] w = {4, 1, 2, 2};
         long seed = 1;
         double timeLimit = 10.0;
@@ -137,6 +138,19 @@ public final class KaoCli {
                 case "--seed": if (!hasNext) usage(a + " needs a value"); seed = Long.decode(argv[++i]); break;
                 case "--time-limit": if (!hasNext) usage(a + " needs a value"); timeLimit = Double.parseDouble(argv[++i]); break;
                 case "--device": if (!hasNext) usage(a + " needs a value"); device = Integer.parseInt(argv[++i]); break;
+                case "--gpus": {   // N = devices device .. device+N-1; a,b,... = exactly these ordinals (as cli/kao-cli)
+                    if (!hasNext) usage(a + " needs a value");
+                    String v = argv[++i];
+                    if (v.indexOf(',') < 0) gpus = Integer.parseInt(v.trim());
+                    else {
+                        String[] p = v.split(",");
+                        gpuList = new int[p.length];
+                        for (int k = 0; k < p.length; ++k) gpuList[k] = Integer.parseInt(p[k].trim());
+                        gpus = p.length;
+                    }
+                    if (gpus < 1) usage("--gpus needs a count >= 1 or a device list");
+                    break;
+                }
                 case "--no-canonical": canonical = false; break;
                 case "--out": if (!hasNext) usage(a + " needs a value"); outPath = argv[++i]; break;
                 case "--report": report = true; break;
@@ -229,7 +243,11 @@ public final class KaoCli {
             Kao.init(device);
             short[] out = new short[outLen];
             long[] obj = new long[T], ub = new long[T];
-            int[] status = Kao.solve(T, B, R, rackOf, nP, rf, rfCur, current, w, seed, timeLimit, out, obj, ub);
+            // several GPUs of this node: topics sharded by kao_solve_multi (fewer topics than GPUs: every GPU searches every
+            // topic and the best is min-allreduced over RCCL); null = the one device selected by init()
+            int[] devices = gpuList;
+            if (devices == null && gpus > 1) { devices = new int[gpus]; for (int d = 0; d < gpus; ++d) devices[d] = device + d; }
+            int[] status = Kao.solve(T, B, R, rackOf, nP, rf, rfCur, current, w, seed, timeLimit, devices, out, obj, ub);
 
             int exit = 0;
             boolean[] emit = new boolean[T];

@@ -125,7 +125,7 @@ struct TopicData {
     if (msg) std::fprintf(stderr, "kao-cli: %s\n", msg);
     std::fprintf(stderr,
         "usage: kao-cli --current <reassignment.json|-> --broker-list <id,id,...> --racks <racks.json | id:rack,...>\n"
-        "               [--rf N] [--weights LL,LF,FL,FF] [--seed S] [--time-limit SEC] [--device D] [--gpus N]\n"
+        "               [--rf N] [--weights LL,LF,FL,FF] [--seed S] [--time-limit SEC] [--device D] [--gpus N | d0,d1,...]\n"
         "               [--no-canonical] [--out <file>] [--report] [--require-optimal] [--emit-lp <prefix> [--lp-only]]\n"
         "exit status: 0 = every topic solved (a warning on stderr marks any plan that is feasible but not PROVEN optimal),\n"
         "             3 = a topic is infeasible / no feasible plan found, 4 = --require-optimal and a plan was not proven\n"
@@ -191,6 +191,7 @@ std::string lp_text(const kao_topic &t, const TopicData &td, const std::vector<i
 int main(int argc, char **argv) {
     std::string cur_path, brokers_csv, racks_arg, out_path;
     int rf_override = 0, device = 0, gpus = 1;
+    std::vector<int32_t> gpu_list;
     int w[4] = {4, 1, 2, 2};
     unsigned long long seed = 1;
     double time_limit = 10.0;
@@ -207,7 +208,12 @@ int main(int argc, char **argv) {
         else if (a == "--seed") seed = std::strtoull(need("--seed").c_str(), nullptr, 0);
         else if (a == "--time-limit") time_limit = std::atof(need("--time-limit").c_str());
         else if (a == "--device") device = std::atoi(need("--device").c_str());
-        else if (a == "--gpus") gpus = std::atoi(need("--gpus").c_str());
+        else if (a == "--gpus") {   // N = devices device .. device+N-1; a,b,... = exactly these ordinals (one may repeat: logical shards)
+            const std::string v = need("--gpus");
+            if (v.find(',') == std::string::npos) gpus = std::atoi(v.c_str());
+            else { for (auto &t : split(v, ',')) if (!t.empty()) gpu_list.push_back(std::atoi(t.c_str())); gpus = (int)gpu_list.size(); }
+            if (gpus < 1) usage("--gpus needs a count >= 1 or a device list");
+        }
         else if (a == "--no-canonical") canonical = false;
         else if (a == "--out") out_path = need("--out");
         else if (a == "--report") report = true;
@@ -296,8 +302,8 @@ int main(int argc, char **argv) {
         opts.stop_at_bound = 1;
         if (gpus > 1) {  // devices device .. device+gpus-1 of this node: topics sharded (or, with fewer topics than GPUs, replicated with an
                          // RCCL min-allreduce of the global best between them)
-            std::vector<int32_t> devs;
-            for (int d = 0; d < gpus; ++d) devs.push_back(device + d);
+            std::vector<int32_t> devs = gpu_list;
+            if (devs.empty()) for (int d = 0; d < gpus; ++d) devs.push_back(device + d);
             rc = kao_solve_multi(topics.data(), (int)topics.size(), devs.data(), gpus, &opts, results.data());
         } else rc = kao_solve(topics.data(), (int)topics.size(), &opts, results.data());
         if (rc) throw std::runtime_error(std::string("kao_solve: ") + kao_strerror(rc) + " " + kao_last_error());

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KAO_VERSION 100 /* 0.1.0 */
+#define KAO_VERSION 101 /* 0.1.1: kao_opts.schedule, kao_last_solve_timing out[12] */
 #define KAO_NONE 0xFFFFu /* "no broker": replica on a broker outside the target set / empty slot */
 #define KAO_MAX_RF 8     /* replica slots per partition supported by the gfx950 kernels (RF <= 4: one 128-bit word group per
                             partition; 5..8: two) */
@@ -107,6 +107,15 @@ typedef struct kao_opts {
     int32_t islands;          /* kao_solve, experimental: > 1 = search every topic as this many independent copies (own seed,
                                  restarts, elite, K-bound trajectory, KAO-CX) that share one copy's restart budget and answer
                                  with the best; certificates are shared.  0 / 1 = off (measured: no gain) */
+    int32_t schedule;         /* kao_solve / kao_solve_multi: 0 = DETERMINISTIC (default): every decision of the solve loop -- which
+                                 incumbents K-bound is aimed at and for how many iterations, when its certificates and prices are
+                                 merged, when KAO-CX runs and for how many rounds, when elites are exchanged -- is keyed to counts
+                                 of launches / iterations / rounds, never to the clock, so the same (instance, options, seed, device
+                                 size) gives the same answer whatever the launch timing; the clock (time_limit_s) only decides when
+                                 to stop.  1 = wall-clock adaptive (round-2 behaviour: K-bound merged whenever it has finished,
+                                 launch lengths adapted to measured times, KAO-CX in time slices): a few percent more work per
+                                 second, answers on large topics vary by a unit or two between runs */
+    int32_t reserved0;        /* must be 0 */
     const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
                                         objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;
@@ -297,12 +306,19 @@ int kao_cycle_seeds(const kao_topic *t, const uint16_t *assignment, int32_t *tab
 /* Diagnostic: runs the two collectives kao_solve_multi uses (ncclAllReduce(ncclUint64, ncclMin) and ncclBroadcast) on
  * small resident buffers of the listed distinct devices and checks the results.  0 = ok. */
 int kao_rccl_selftest(const int32_t *devices, int32_t n_dev);
+/* Test hook.  With KAO_RCCL_LOOPBACK=1 in the environment kao_solve_multi and kao_rccl_selftest take their collectives from an
+ * in-process loop-back table instead of librccl: the device list may then name one device several times ("ranks" on one GPU)
+ * and the grouped ncclAllReduce(ncclUint64, ncclMin) / ncclBroadcast call sequence of the elite exchange runs exactly as it
+ * does between distinct GPUs, the data moving through plain copies when a group closes.  out[0] / out[1] = all-reduces /
+ * broadcasts the loop-back table has completed in this process. */
+int kao_rccl_loopback_counts(uint64_t out[2]);
 /* Wall-clock breakdown of this thread's last kao_solve / kao_solve_multi, seconds from its entry:
  * out[0] session ready (instance prepared + uploaded), out[1] last improving launch finished (time-to-best),
  * out[2] results read back, out[3] returned (buffers released); out[4] = launches run; out[5] = neighbours K-search
  * delta-evaluated in those launches (kao_stats.delta_candidates, all devices), out[6] = K-bound launches, out[7] = elite
- * exchanges between GPUs (kao_solve_multi). */
-int kao_last_solve_timing(double out[8]);
+ * exchanges between GPUs (kao_solve_multi), out[8] = K-bound iterations summed over the topics, out[9] = KAO-CX calls,
+ * out[10] = KAO-CX calls that improved an incumbent, out[11] = K-search iterations per restart. */
+int kao_last_solve_timing(double out[12]);
 
 #ifdef __cplusplus
 }

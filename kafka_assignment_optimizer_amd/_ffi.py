@@ -24,6 +24,7 @@ class KaoOpts(C.Structure):
                 ("lam_min", C.c_int32), ("lam_max", C.c_int32), ("period_log2", C.c_int32),
                 ("stop_at_bound", C.c_int32), ("profile", C.c_int32), ("dual_iters", C.c_int32),
                 ("elite_period", C.c_int32), ("use_prices", C.c_int32), ("use_cycles", C.c_int32), ("islands", C.c_int32),
+                ("schedule", C.c_int32), ("reserved0", C.c_int32),
                 ("target_objective", C.POINTER(C.c_int64))]
 
 
@@ -83,6 +84,7 @@ SIGNATURES = {
     "kao_solve_capped": (C.c_int, [_P(KaoTopic), C.c_int32, _P(C.c_int32), _P(C.c_int32), C.c_int32, _P(KaoOpts), C.c_int32,
                                   _P(KaoResult), _P(C.c_int64)]),
     "kao_rccl_selftest": (C.c_int, [_P(C.c_int32), C.c_int32]),
+    "kao_rccl_loopback_counts": (C.c_int, [_P(C.c_uint64)]),
     "kao_improve_cycles": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int32, _P(C.c_int64), _P(C.c_int32)]),
     "kao_cycle_matrices": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_uint32)]),
     "kao_cycle_seeds": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), _P(C.c_int32), _P(C.c_int32)]),

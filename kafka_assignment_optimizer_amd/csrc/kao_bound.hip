@@ -366,8 +366,10 @@ __device__ __forceinline__ void bound_band_terms(const BoundLds &L, const BoundT
 // Level control and step length of the Polyak step (every thread computes the same values).  The step aims at `level` =
 // record - delta, never below the incumbent `target`; delta starts as the whole distance record -> incumbent (an incumbent
 // below the optimum is an unreachable level: steps too long, the record stalls far above the optimum).  Per stage of
-// kDualStage iterations the record's gain is held against delta: less than delta / 32 halves delta (floor 1/16), at least
-// delta / 8 doubles it (never beyond the incumbent).  The thresholds are RELATIVE because the gain per stage is itself
+// kDualStage iterations the record's gain is held against delta: less than delta / 32 AND less than half a unit halves delta
+// (floor 1/16), at least delta / 8 doubles it (never beyond the incumbent).  The halving test is absolute while delta is large
+// and relative once delta < 16 (round 3: the purely relative test halved delta from 21 to 2.6 on the drifted 1000 x 30000
+// topic with 80 units still to go -- its gain per stage is ~0.05 delta, right at the delta / 32 threshold).  The thresholds are RELATIVE because the gain per stage is itself
 // proportional to delta (step length ~ delta): the first rule halved whenever a stage gained less than half a unit, which
 // below delta ~ 2.5 is every stage -- delta collapsed to its floor wherever the record stood, and nothing ever widened it
 // again (drifted 400 x 3000, LP optimum 22586: frozen at 22601.4 aimed at a moving incumbent; now 22586.7, a probe at 22586.5).
@@ -385,7 +387,7 @@ __device__ __forceinline__ long long bound_step_length(long long target, long lo
     if (Lv < bi) bi = Lv;
     if (++lv_since >= kDualStage) {
         const long long prog = lv_rec - bi;
-        if (prog < lv_delta / 32) { lv_delta /= 2; if (lv_delta < kDualScale / 16) lv_delta = kDualScale / 16; }
+        if (prog < lv_delta / 32 && prog < kDualScale / 2) { lv_delta /= 2; if (lv_delta < kDualScale / 16) lv_delta = kDualScale / 16; }
         else if (prog >= lv_delta / 8 && bi - 2 * lv_delta >= level) lv_delta *= 2;
         lv_rec = bi; lv_since = 0;
     }

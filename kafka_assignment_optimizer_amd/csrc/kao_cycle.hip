@@ -720,13 +720,14 @@ void Cx::launch_apply(size_t n, size_t n_patches) {
 struct CxCand { int total, a, b, c; };   // seed: (total, p, cfg, y); cycle: (gain, layer, level, broker)
 
 
-// one round from `assign` (feasible, objective `base`): returns 1 and overwrites assign when it improved, 0 when nothing was found
+// one round from `assign` (feasible, objective `base`): returns 1 and overwrites assign when it improved, 0 when nothing was found,
+// a negative KAO_ERR_* code on failure
 int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t stats[8]) {
     const CxParams &q = cx.q;
     static const bool trace = std::getenv("KAO_CX_TRACE") != nullptr;
     const double tt0 = api_now_s();
     int rc = cx.build(assign);
-    if (rc) return -rc;
+    if (rc) return rc;
     const double tt1 = api_now_s();
     // ---- candidates ----
     std::vector<CxCand> cyc;
@@ -744,7 +745,7 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
             return x.total != y.total ? x.total > y.total : (x.a != y.a ? x.a < y.a : x.c < y.c); });
         cands = cyc;
     } else {
-        if ((rc = cx.seeds())) return -rc;
+        if ((rc = cx.seeds())) return rc;
         for (int p = 0; p < q.P; ++p)
             for (int c = 0; c < q.ncfg; ++c) {
                 const int2 e = cx.table[(size_t)p * q.ncfg + c];
@@ -756,7 +757,7 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     stats[4] += (int32_t)cands.size();
     if (cands.empty()) return 0;
     const double tt2 = api_now_s();
-    if ((rc = cx.fetch_paths())) return -rc;
+    if ((rc = cx.fetch_paths())) return rc;
     const double tt3 = api_now_s();
     // ---- realisations ----
     const size_t slots = (size_t)q.P * q.RF;
@@ -838,7 +839,7 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     std::vector<const CxReal *> rs(n);
     for (size_t i = 0; i < n; ++i) rs[i] = &reals[i];
     std::vector<int32_t> obj, viol;
-    if ((rc = cx.eval_patched(rs, obj, viol))) return -rc;
+    if ((rc = cx.eval_patched(rs, obj, viol))) return rc;
     int best = -1, n_good = 0;
     std::vector<char> taken((size_t)q.P, 0);
     std::vector<int> chosen;   // partition-disjoint improving realisations, candidate order
@@ -871,7 +872,7 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
             ms[m] = &merges[m];
         }
         std::vector<int32_t> o1, v1;
-        if ((rc = cx.eval_patched(ms, o1, v1))) return -rc;
+        if ((rc = cx.eval_patched(ms, o1, v1))) return rc;
         for (size_t m = 0; m < sizes.size(); ++m)
             if (v1[m * 8] == 0 && o1[m] > win_obj) { win_obj = o1[m]; n_taken = -(int)(m + 1); }
     }
@@ -923,7 +924,7 @@ int cycle_run(CycleCtx *c, uint16_t *assign, int32_t max_rounds, double deadline
         int32_t next = cur;
         const int got = cx_round(cx, assign, cur, &next, stats);
         ++stats[0];
-        if (got < 0) return -got;
+        if (got < 0) return got;   // a KAO_ERR_* code (negative) from cx_round
         if (got == 0) break;
         ++stats[1];
         cur = next;

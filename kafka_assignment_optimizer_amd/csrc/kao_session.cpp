@@ -16,7 +16,7 @@
 namespace kao {
 
 thread_local int t_device = -1;
-thread_local double g_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_timing[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace {
 thread_local std::string g_err;
@@ -584,8 +584,17 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need1(x) < need1(y); });
     std::vector<std::vector<int>> members;
     size_t group_base = 0;
+    // K-search / K-eval are instantiated per (assignment words in HBM or LDS, words per partition): a launch group must be
+    // homogeneous in both, whatever the LDS sizes say -- so a change of either ALWAYS starts a group; the
+    // "at most 8 groups" cap only limits the splits by LDS footprint
+    auto kind = [&](int t) { return (s->topic_global[(size_t)t] ? 1 : 0) | (s->pts[(size_t)t].d.nw > kRFP ? 2 : 0); };
+    int lds_groups = 0, group_kind = -1;
     for (int t : order) {
-        if (members.empty() || (need1(t) > 2 * group_base && members.size() < 8)) { members.emplace_back(); group_base = need1(t); }
+        const bool new_kind = members.empty() || kind(t) != group_kind;
+        if (new_kind || (need1(t) > 2 * group_base && lds_groups < 8)) {
+            members.emplace_back(); group_base = need1(t); group_kind = kind(t);
+            if (new_kind) lds_groups = 1; else ++lds_groups;
+        }
         members.back().push_back(t);
     }
     std::vector<int2> smap; std::vector<int4> emap;

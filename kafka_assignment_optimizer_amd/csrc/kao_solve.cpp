@@ -16,6 +16,22 @@
 
 namespace {
 
+// The counts of the deterministic schedule (kao_opts.schedule == 0) for a session whose largest topic has `slots` replica
+// slots and `maxB` brokers.  Every value is a pure function of the instance and the options -- nothing measured at run time.
+struct DetPlan { int bound_iters; int64_t cx_stall_iters, cx_due_iters; int cx_rounds; };
+DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
+    DetPlan d;
+    (void)maxB; (void)n_topics;
+    // K-bound iterations per launch: about one K-search launch's worth of time (DESIGN.md section 4e has the measurements)
+    d.bound_iters = slots <= 8192 ? 128 : (slots <= 32768 ? 192 : 96);
+    // KAO-CX: a topic counts as stalled after ~50 ms without improvement and is revisited after ~250 ms
+    const int64_t it = std::max(iters_per_launch, 1);
+    d.cx_stall_iters = it * (slots <= 8192 ? 24 : 6);
+    d.cx_due_iters = d.cx_stall_iters * 6;
+    d.cx_rounds = slots <= 32768 ? 12 : 6;
+    return d;
+}
+
 // One whole job on one device: the kao_solve loop, cut into steps so that kao_solve_multi can drive several of them in
 // lockstep from one host thread (launches of all devices are enqueued before any of them is waited for).
 struct SolveRun {
@@ -42,7 +58,20 @@ struct SolveRun {
     std::vector<uint16_t> cx_buf;
     std::vector<CycleCtx *> cx_ctx;
     int cx_calls = 0, cx_gains = 0;
-    double cx_slice = 0.1;                        // seconds one KAO-CX call may take
+    double cx_slice = 0.1;                        // seconds one KAO-CX call may take (wall-clock schedule only)
+    // Deterministic schedule (kao_opts.schedule == 0, the default): every decision of the loop is keyed to COUNTS -- K-search
+    // launches and iterations, K-bound iterations, KAO-CX rounds -- never to the clock, so the same seed gives the same answer
+    // whatever the launch timing (the clock only decides when to stop).  K-bound launches have a fixed length and are merged
+    // (waiting for them if need be) after every K-search launch and after every KAO-CX round; KAO-CX is called for a topic that
+    // has not improved for `cx_stall_iters` search iterations or has not been through it for `cx_due_iters`, `cx_rounds` rounds
+    // per call.
+    bool det = true;
+    int64_t cx_stall_iters = 0, cx_due_iters = 0;
+    int cx_rounds = 0;
+    int64_t iters_done = 0;                       // K-search iterations so far (launches x iterations per launch)
+    std::vector<int64_t> i_improved, i_cx;        // per topic: iteration count at the last improvement / the last KAO-CX call
+    bool trace = false;                           // KAO_SOLVE_TRACE=1: one line per launch on stderr (timings; never read back)
+    double t_prev = 0;
 
     ~SolveRun() { for (CycleCtx *c : cx_ctx) cycle_close(c); if (s) kao_session_destroy(s); }
 
@@ -86,6 +115,26 @@ struct SolveRun {
         const kao_opts &o = s->opts;
         dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 128 : o.dual_iters);
         dual_now = dual_iters;
+        det = so.schedule == 0;
+        i_improved.assign((size_t)n, 0); i_cx.assign((size_t)n, 0);
+        {   // the counts of the deterministic schedule, from the size of the largest topic (constants measured on one MI355X so
+            // that a K-bound launch takes about as long as a K-search launch and KAO-CX gets about the share of the wall clock
+            // the time slices of the wall-clock schedule gave it).  Test / tuning hooks: KAO_DET_*.
+            int64_t slots = 1; int maxB = 1;
+            for (int i = 0; i < n; ++i) {
+                slots = std::max<int64_t>(slots, (int64_t)topics[i].n_partitions * std::max(topics[i].rf, 1));
+                maxB = std::max(maxB, topics[i].n_brokers);
+            }
+            const DetPlan dp = det_plan(slots, maxB, n, o.iters_per_launch);
+            if (det && o.dual_iters == 0) dual_now = dual_iters = dp.bound_iters;
+            cx_stall_iters = dp.cx_stall_iters; cx_due_iters = dp.cx_due_iters; cx_rounds = dp.cx_rounds;
+            auto env_i = [](const char *name, int64_t dflt) { const char *e = std::getenv(name); return e && *e ? (int64_t)std::atoll(e) : dflt; };
+            if (det) { dual_now = dual_iters = dual_iters > 0 ? (int)env_i("KAO_DET_BOUND_ITERS", dual_iters) : 0; }
+            cx_stall_iters = env_i("KAO_DET_CX_STALL", cx_stall_iters); cx_due_iters = env_i("KAO_DET_CX_DUE", cx_due_iters);
+            cx_rounds = (int)env_i("KAO_DET_CX_ROUNDS", cx_rounds);
+        }
+        { const char *e = std::getenv("KAO_SOLVE_TRACE"); trace = e && e[0] == '1'; }
+        t_prev = t_start;
         use_prices = so.use_prices >= 0;
         return KAO_OK;
     }
@@ -121,12 +170,26 @@ struct SolveRun {
         int rc = kao_session_best_keys(s, keys.data());
         if (rc) return rc;
         ++launches;
+        iters_done += s->opts.iters_per_launch;
         const double t = now_s() - t0;
         for (int i = 0; i < n; ++i)
-            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; t_improved[(size_t)i] = t; }
+            if (keys[(size_t)i] < prev[(size_t)i]) {
+                prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; t_improved[(size_t)i] = t; i_improved[(size_t)i] = iters_done;
+            }
         all_done = check_done();
+        const double t_search = now_s();
         if ((rc = service_bound())) return rc;
+        const double t_bound = now_s();
+        const int cx0 = cx_calls;
         if (cx_on && !all_done && !has_target && (rc = cycles(t))) return rc;
+        if (trace) {
+            const double t_end = now_s();
+            int64_t obj0 = feasible(0) ? objective(0) : -1;
+            std::fprintf(stderr, "[kao-solve] launch %d t %.4f search+sync %.3f ms, bound service %.3f ms (last K-bound launch %.3f ms / %d it, next %d it), cx %d calls %.3f ms | topic0 obj %lld ub %lld\n",
+                         launches, t_end - t0, (t_search - t_prev) * 1e3, (t_bound - t_search) * 1e3, s->bound_ms_last, s->bound_iters_last, dual_now,
+                         cx_calls - cx0, (t_end - t_bound) * 1e3, (long long)obj0, (long long)s->ub[0]);
+            t_prev = t_end;
+        }
         return KAO_OK;
     }
     // K-bound runs beside the search on its own stream; when a launch has finished its certificates are merged and, while
@@ -135,15 +198,17 @@ struct SolveRun {
     int service_bound() {
         if (has_target || dual_iters <= 0) return KAO_OK;
         int rc;
-        const int busy = kao_session_bound_busy(s);
-        if (busy < 0) return busy;
-        if (busy) return KAO_OK;
+        if (!det) {   // wall-clock schedule: a K-bound launch is merged whenever it happens to have finished
+            const int busy = kao_session_bound_busy(s);
+            if (busy < 0) return busy;
+            if (busy) return KAO_OK;
+        }
         if (s->bound_inflight) {
-            if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
+            if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;   // deterministic schedule: waits for the launch
             share_bounds();
             // the finished launch's multipliers (rounded to quarters) become the prices of the next K-search launches
             if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
-            if (s->bound_ms_last > 0) {
+            if (!det && s->bound_ms_last > 0) {
                 const double scale = 10.0 / s->bound_ms_last;
                 dual_now = (int)std::min(4096.0, std::max(32.0, s->bound_iters_last * std::min(4.0, std::max(0.25, scale))));
             }
@@ -170,8 +235,13 @@ struct SolveRun {
             if (s->topic_infeasible[(size_t)i] || !feasible(i) || objective(i) >= s->ub[(size_t)i]) continue;
             if (!cycle_supported(&topics[i])) continue;
             if ((keys[(size_t)i] >> 20) == (cx_seen[(size_t)i] >> 20)) continue;   // same incumbent as the last fixpoint
-            const bool stalled = t - t_improved[(size_t)i] >= 0.05, due = t - t_cx[(size_t)i] >= 2.0 * cx_slice;
-            if (!cx_eager && (t < 0.05 || !(stalled || due) || t - t_cx[(size_t)i] < 0.05)) continue;
+            if (det) {   // counts, not the clock: iterations since the last improvement / since the last call
+                const bool stalled = iters_done - i_improved[(size_t)i] >= cx_stall_iters, due = iters_done - i_cx[(size_t)i] >= cx_due_iters;
+                if (!cx_eager && (!(stalled || due) || iters_done - i_cx[(size_t)i] < cx_stall_iters)) continue;
+            } else {
+                const bool stalled = t - t_improved[(size_t)i] >= 0.05, due = t - t_cx[(size_t)i] >= 2.0 * cx_slice;
+                if (!cx_eager && (t < 0.05 || !(stalled || due) || t - t_cx[(size_t)i] < 0.05)) continue;
+            }
             const size_t slots = (size_t)topics[i].n_partitions * topics[i].rf;
             cx_buf.resize(slots);
             int rc = session_topic_best(s, i, cx_buf.data());
@@ -179,18 +249,21 @@ struct SolveRun {
             int64_t obj = objective(i);
             int32_t st[8];
             if (!cx_ctx[(size_t)i] && !(cx_ctx[(size_t)i] = cycle_open(&topics[i], &rc))) return rc;
-            const double slice_end = std::min(deadline, now_s() + cx_slice);
-            rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), 0, slice_end, &obj, st, &SolveRun::poll_bound, this);
+            // the clock only ends a deterministic call at the solve's own deadline (the stop condition)
+            const double slice_end = det ? deadline : std::min(deadline, now_s() + cx_slice);
+            rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), det ? cx_rounds : 0, slice_end, &obj, st, &SolveRun::poll_bound, this);
             ++cx_calls;
             if (rc) return rc;
             const bool fixpoint = st[0] > st[1];   // the last round found nothing
             const double t2 = now_s() - t0;
             t_cx[(size_t)i] = t2;
+            i_cx[(size_t)i] = iters_done;
             if (obj > objective(i)) {
                 uint64_t key = 0;
                 if ((rc = session_adopt_external(s, i, cx_buf.data(), obj, &key))) return rc;
                 keys[(size_t)i] = prev[(size_t)i] = key;
                 t_best[(size_t)i] = t_improved[(size_t)i] = t_last_improve = t2;
+                i_improved[(size_t)i] = iters_done;
                 ++cx_gains;
             }
             if (fixpoint) cx_seen[(size_t)i] = keys[(size_t)i];
@@ -287,8 +360,10 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     g_timing[2] = now_s() - t0;
     g_timing[5] = (double)run.s->delta_total;
     g_timing[6] = (double)run.s->bound_launches;
-    g_timing[7] = 0;   // K-bound iterations, summed over the topics
-    for (int32_t v : run.s->dual_iters) g_timing[7] += (double)v;
+    g_timing[7] = 0;   // elite exchanges between GPUs: none on one device
+    g_timing[8] = 0;   // K-bound iterations, summed over the topics
+    for (int32_t v : run.s->dual_iters) g_timing[8] += (double)v;
+    g_timing[9] = run.cx_calls; g_timing[10] = run.cx_gains; g_timing[11] = (double)run.iters_done;
     kao_session_destroy(run.s);
     run.s = nullptr;
     g_timing[3] = now_s() - t0;
@@ -304,6 +379,7 @@ namespace {
 // pay for registering them.  It is opened on the first multi-GPU exchange instead.
 struct Rccl {
     void *h = nullptr;
+    std::string why = "not found";   // text of the last dlopen / dlsym failure
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -326,6 +402,7 @@ struct Rccl {
         for (const std::string &name : names) {
             h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (h) break;
+            if (const char *e = dlerror()) why = e;   // dlerror() clears the message: read it once, here
         }
         if (!h) return false;
         CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
@@ -335,25 +412,106 @@ struct Rccl {
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(h, "ncclGroupEnd"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(h, "ncclAllReduce"));
         Broadcast = reinterpret_cast<decltype(Broadcast)>(dlsym(h, "ncclBroadcast"));
-        return CommInitAll && CommDestroy && GetErrorString && GroupStart && GroupEnd && AllReduce && Broadcast;
+        if (CommInitAll && CommDestroy && GetErrorString && GroupStart && GroupEnd && AllReduce && Broadcast) return true;
+        if (const char *e = dlerror()) why = e; else why = "missing symbol";
+        dlclose(h); h = nullptr;
+        return false;
     }
 } g_rccl;
-struct CommSet { std::vector<int> devices; std::vector<ncclComm_t> comms; };
-std::vector<CommSet> g_comms;   // RCCL communicators per device list (creation costs ~100 ms; kept until kao_shutdown)
+
+// ---- loop-back collectives (test hook KAO_RCCL_LOOPBACK=1) ----------------------------------------------------------------
+// The same function table filled with an in-process implementation: "ranks" are entries of the device list -- which may name
+// one device several times -- and the two collectives kao_solve_multi uses move the data with plain copies when the group
+// closes.  It exists so that the REAL control flow of the elite exchange (grouped ncclAllReduce(ncclUint64, ncclMin) on the
+// resident key buffers, then one grouped ncclBroadcast per topic from the winner's rank) runs with several communicators on a
+// box that has one GPU (the grouped sequence had never executed with more than one rank).  Never used unless the
+// environment asks for it; results are those RCCL would deliver.
+struct LoopComm { int rank, nranks, device; };
+struct LoopOp { int kind; const void *send; void *recv; size_t count; int dtype, root; LoopComm *comm; hipStream_t st; };
+thread_local std::vector<LoopOp> t_loop_ops;
+thread_local int t_loop_depth = 0;
+uint64_t g_loop_allreduces = 0, g_loop_broadcasts = 0;   // collectives completed (test hook kao_rccl_loopback_counts)
+size_t loop_elem(int dtype) { return dtype == ncclUint64 || dtype == ncclInt64 ? 8 : (dtype == ncclUint8 || dtype == ncclInt8 ? 1 : 4); }
+ncclResult_t loop_run() {
+    std::vector<LoopOp> ops;
+    ops.swap(t_loop_ops);
+    if (ops.empty()) return ncclSuccess;
+    const int n = ops[0].comm->nranks;
+    if ((int)ops.size() != n) return ncclInvalidUsage;            // every rank of the communicator must take part
+    std::vector<const LoopOp *> by_rank((size_t)n, nullptr);
+    for (const LoopOp &o : ops) {
+        if (o.kind != ops[0].kind || o.count != ops[0].count || o.dtype != ops[0].dtype || o.root != ops[0].root || o.comm->nranks != n) return ncclInvalidUsage;
+        if (o.comm->rank < 0 || o.comm->rank >= n || by_rank[(size_t)o.comm->rank]) return ncclInvalidUsage;
+        by_rank[(size_t)o.comm->rank] = &o;
+    }
+    const size_t bytes = ops[0].count * loop_elem(ops[0].dtype);
+    for (const LoopOp &o : ops)   // a collective is ordered behind the work already enqueued on each rank's stream
+        if (hipSetDevice(o.comm->device) != hipSuccess || hipStreamSynchronize(o.st) != hipSuccess) return ncclUnhandledCudaError;
+    if (ops[0].kind == 0) {   // all-reduce: uint64 / min is the only combination the solver uses
+        if (ops[0].dtype != ncclUint64) return ncclInvalidArgument;
+        std::vector<uint64_t> acc(ops[0].count, ~0ull), tmp(ops[0].count);
+        for (const LoopOp &o : ops) {
+            if (hipSetDevice(o.comm->device) != hipSuccess || hipMemcpy(tmp.data(), o.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+            for (size_t i = 0; i < acc.size(); ++i) acc[i] = std::min(acc[i], tmp[i]);
+        }
+        for (const LoopOp &o : ops)
+            if (hipSetDevice(o.comm->device) != hipSuccess || hipMemcpy(o.recv, acc.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        ++g_loop_allreduces;
+    } else {                  // broadcast from rank `root`
+        if (ops[0].root < 0 || ops[0].root >= n) return ncclInvalidArgument;
+        std::vector<unsigned char> buf(bytes);
+        const LoopOp &r = *by_rank[(size_t)ops[0].root];
+        if (hipSetDevice(r.comm->device) != hipSuccess || hipMemcpy(buf.data(), r.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+        for (const LoopOp &o : ops)
+            if (hipSetDevice(o.comm->device) != hipSuccess || hipMemcpy(o.recv, buf.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        ++g_loop_broadcasts;
+    }
+    return ncclSuccess;
+}
+ncclResult_t loop_CommInitAll(ncclComm_t *comms, int ndev, const int *devlist) {
+    for (int i = 0; i < ndev; ++i) comms[i] = reinterpret_cast<ncclComm_t>(new LoopComm{i, ndev, devlist ? devlist[i] : i});
+    return ncclSuccess;
+}
+ncclResult_t loop_CommDestroy(ncclComm_t c) { delete reinterpret_cast<LoopComm *>(c); return ncclSuccess; }
+const char *loop_GetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : (r == ncclInvalidUsage ? "loop-back: invalid usage (a rank is missing from the group)" : "loop-back: error"); }
+ncclResult_t loop_GroupStart() { ++t_loop_depth; return ncclSuccess; }
+ncclResult_t loop_GroupEnd() { if (t_loop_depth <= 0) return ncclInvalidUsage; return --t_loop_depth == 0 ? loop_run() : ncclSuccess; }
+ncclResult_t loop_AllReduce(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t c, hipStream_t st) {
+    if (op != ncclMin) return ncclInvalidArgument;
+    t_loop_ops.push_back(LoopOp{0, send, recv, count, (int)dt, 0, reinterpret_cast<LoopComm *>(c), st});
+    return t_loop_depth == 0 ? loop_run() : ncclSuccess;
+}
+ncclResult_t loop_Broadcast(const void *send, void *recv, size_t count, ncclDataType_t dt, int root, ncclComm_t c, hipStream_t st) {
+    t_loop_ops.push_back(LoopOp{1, send, recv, count, (int)dt, root, reinterpret_cast<LoopComm *>(c), st});
+    return t_loop_depth == 0 ? loop_run() : ncclSuccess;
+}
+struct LoopTable : Rccl {
+    LoopTable() {
+        CommInitAll = &loop_CommInitAll; CommDestroy = &loop_CommDestroy; GetErrorString = &loop_GetErrorString;
+        GroupStart = &loop_GroupStart; GroupEnd = &loop_GroupEnd; AllReduce = &loop_AllReduce; Broadcast = &loop_Broadcast;
+    }
+} g_loop;
+bool loopback_wanted() { const char *e = std::getenv("KAO_RCCL_LOOPBACK"); return e && e[0] == '1'; }
+
+struct CommSet { std::vector<int> devices; const Rccl *api; std::vector<ncclComm_t> comms; };
+std::vector<CommSet> g_comms;   // communicators per (device list, function table) (creation costs ~100 ms with RCCL; kept until kao_shutdown)
 std::mutex g_comm_mu;
-int comms_for(const std::vector<int> &devices, std::vector<ncclComm_t> &out) {
+int comms_for(const std::vector<int> &devices, std::vector<ncclComm_t> &out, const Rccl **api_out) {
     std::lock_guard<std::mutex> lock(g_comm_mu);
-    for (const CommSet &c : g_comms) if (c.devices == devices) { out = c.comms; return KAO_OK; }
-    if (!g_rccl.load()) return fail(KAO_ERR_HIP, std::string("librccl.so not available: ") + (dlerror() ? dlerror() : "missing symbol"));
+    const bool loop = loopback_wanted();
+    const Rccl *api = loop ? &g_loop : &g_rccl;
+    *api_out = api;
+    for (const CommSet &c : g_comms) if (c.devices == devices && c.api == api) { out = c.comms; return KAO_OK; }
+    if (!loop && !g_rccl.load()) return fail(KAO_ERR_HIP, std::string("librccl.so not available: ") + g_rccl.why);
     for (int d : devices) {  // RCCL expects every device's primary context to exist already
         if (hipSetDevice(d) != hipSuccess || hipFree(nullptr) != hipSuccess) return fail(KAO_ERR_HIP, "cannot initialise device " + std::to_string(d));
         void *probe = nullptr;
         if (hipMalloc(&probe, 256) == hipSuccess) (void)hipFree(probe);
     }
     if (cur_device() >= 0) (void)hipSetDevice(cur_device());
-    CommSet c; c.devices = devices; c.comms.resize(devices.size());
-    const ncclResult_t r = g_rccl.CommInitAll(c.comms.data(), (int)devices.size(), devices.data());
-    if (r != ncclSuccess) return fail(KAO_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
+    CommSet c; c.devices = devices; c.api = api; c.comms.resize(devices.size());
+    const ncclResult_t r = api->CommInitAll(c.comms.data(), (int)devices.size(), devices.data());
+    if (r != ncclSuccess) return fail(KAO_ERR_HIP, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
     g_comms.push_back(c);
     out = c.comms;
     return KAO_OK;
@@ -362,7 +520,7 @@ int comms_for(const std::vector<int> &devices, std::vector<ncclComm_t> &out) {
 
 void kao_multi_shutdown_comms(void) {
     std::lock_guard<std::mutex> lock(g_comm_mu);
-    for (CommSet &c : g_comms) for (ncclComm_t cm : c.comms) (void)g_rccl.CommDestroy(cm);
+    for (CommSet &c : g_comms) for (ncclComm_t cm : c.comms) (void)c.api->CommDestroy(cm);
     g_comms.clear();
 }
 
@@ -373,8 +531,10 @@ int kao_rccl_selftest(const int32_t *devices, int32_t n_dev) {
     if (!devices || n_dev < 1 || n_dev > kMaxDevices) return fail(KAO_ERR_INVALID, "bad device list");
     std::vector<int> devs(devices, devices + n_dev);
     std::vector<ncclComm_t> comms;
-    int rc = comms_for(devs, comms);
+    const Rccl *api = nullptr;
+    int rc = comms_for(devs, comms, &api);
     if (rc) return rc;
+    const Rccl &cc = *api;   // RCCL, or the loop-back table (KAO_RCCL_LOOPBACK=1: the list may then repeat a device)
     std::vector<unsigned long long *> keys((size_t)n_dev, nullptr), out((size_t)n_dev, nullptr);
     std::vector<unsigned char *> pat((size_t)n_dev, nullptr);
     std::vector<hipStream_t> st((size_t)n_dev, nullptr);
@@ -388,12 +548,12 @@ int kao_rccl_selftest(const int32_t *devices, int32_t n_dev) {
         for (int i = 0; i < 64; ++i) p[i] = (unsigned char)(d * 64 + i);
         ok = ok && hipMemcpy(keys[(size_t)d], h, 32, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(pat[(size_t)d], p, 64, hipMemcpyHostToDevice) == hipSuccess;
     }
-    ncclResult_t nr = ok ? g_rccl.GroupStart() : ncclSystemError;
-    for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) nr = g_rccl.AllReduce(keys[(size_t)d], out[(size_t)d], 4, ncclUint64, ncclMin, comms[(size_t)d], st[(size_t)d]);
-    if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
-    if (nr == ncclSuccess) nr = g_rccl.GroupStart();
-    for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) nr = g_rccl.Broadcast(pat[(size_t)d], pat[(size_t)d], 64, ncclUint8, n_dev - 1, comms[(size_t)d], st[(size_t)d]);
-    if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+    ncclResult_t nr = ok ? cc.GroupStart() : ncclSystemError;
+    for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) nr = cc.AllReduce(keys[(size_t)d], out[(size_t)d], 4, ncclUint64, ncclMin, comms[(size_t)d], st[(size_t)d]);
+    if (nr == ncclSuccess) nr = cc.GroupEnd();
+    if (nr == ncclSuccess) nr = cc.GroupStart();
+    for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) nr = cc.Broadcast(pat[(size_t)d], pat[(size_t)d], 64, ncclUint8, n_dev - 1, comms[(size_t)d], st[(size_t)d]);
+    if (nr == ncclSuccess) nr = cc.GroupEnd();
     ok = ok && nr == ncclSuccess;
     for (int d = 0; d < n_dev && ok; ++d) {
         unsigned long long h[4]; unsigned char p[64];
@@ -408,7 +568,7 @@ int kao_rccl_selftest(const int32_t *devices, int32_t n_dev) {
         if (st[(size_t)d]) (void)hipStreamDestroy(st[(size_t)d]);
     }
     if (cur_device() >= 0) (void)hipSetDevice(cur_device());
-    if (!ok) return fail(KAO_ERR_HIP, nr != ncclSuccess ? std::string("RCCL: ") + g_rccl.GetErrorString(nr) : std::string("RCCL self-test: wrong result"));
+    if (!ok) return fail(KAO_ERR_HIP, nr != ncclSuccess ? std::string("RCCL: ") + cc.GetErrorString(nr) : std::string("RCCL self-test: wrong result"));
     return KAO_OK;
 }
 
@@ -445,8 +605,11 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
         }
     }
     std::vector<ncclComm_t> comms;
-    const bool use_rccl = replicated && distinct;   // logical shards on one device (tests) merge through the host instead
-    if (use_rccl) { int rc0 = comms_for(devs, comms); if (rc0) return rc0; }
+    // logical shards on one device (tests) merge through plain copies -- or, with KAO_RCCL_LOOPBACK=1, through the same grouped
+    // collective calls as distinct devices, served by the in-process loop-back table
+    const bool use_rccl = replicated && (distinct || loopback_wanted());
+    const Rccl *api = nullptr;
+    if (use_rccl) { int rc0 = comms_for(devs, comms, &api); if (rc0) return rc0; }
 
     struct Dev { SolveRun run; std::vector<kao_topic> tp; std::vector<kao_result> res; std::vector<int64_t> tgt; };
     std::vector<Dev> D((size_t)n_dev);
@@ -503,24 +666,24 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
                         launch_gather(s->d_topics, s->n_topics, s->d_keys, s->d_best, s->d_viol, s->d_win_assign, s->d_win_viol, s->stream);
                     }
                     if (!rc && use_rccl) {
-                        ncclResult_t nr = g_rccl.GroupStart();
+                        ncclResult_t nr = api->GroupStart();
                         for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) {
                             kao_session *s = D[(size_t)d].run.s;
-                            nr = g_rccl.AllReduce(s->d_keys, s->d_keys_glob, (size_t)n_topics, ncclUint64, ncclMin, comms[(size_t)d], s->stream);
+                            nr = api->AllReduce(s->d_keys, s->d_keys_glob, (size_t)n_topics, ncclUint64, ncclMin, comms[(size_t)d], s->stream);
                         }
-                        if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+                        if (nr == ncclSuccess) nr = api->GroupEnd();
                         for (int i = 0; i < n_topics && nr == ncclSuccess; ++i) {
                             if ((gmin[(size_t)i] >> 44) != 0) continue;   // no feasible assignment anywhere yet
-                            nr = g_rccl.GroupStart();
+                            nr = api->GroupStart();
                             for (int d = 0; d < n_dev && nr == ncclSuccess; ++d) {
                                 kao_session *s = D[(size_t)d].run.s;
                                 const TopicDev &td = s->pts[(size_t)i].d;
                                 uint16_t *buf = s->d_win_assign + td.win_off;
-                                nr = g_rccl.Broadcast(buf, buf, (size_t)td.P * td.RF * 2, ncclUint8, root[(size_t)i], comms[(size_t)d], s->stream);
+                                nr = api->Broadcast(buf, buf, (size_t)td.P * td.RF * 2, ncclUint8, root[(size_t)i], comms[(size_t)d], s->stream);
                             }
-                            if (nr == ncclSuccess) nr = g_rccl.GroupEnd();
+                            if (nr == ncclSuccess) nr = api->GroupEnd();
                         }
-                        if (nr != ncclSuccess) rc = fail(KAO_ERR_HIP, std::string("RCCL elite exchange: ") + g_rccl.GetErrorString(nr));
+                        if (nr != ncclSuccess) rc = fail(KAO_ERR_HIP, std::string("RCCL elite exchange: ") + api->GetErrorString(nr));
                     } else if (!rc) {   // logical shards on one device: same data movement through plain copies
                         for (int d = 0; d < n_dev && !rc; ++d) {
                             kao_session *s = D[(size_t)d].run.s;
@@ -725,9 +888,15 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
     return rc;
 }
 
-int kao_last_solve_timing(double out[8]) {
+int kao_rccl_loopback_counts(uint64_t out[2]) {
     if (!out) return fail(KAO_ERR_INVALID, "null out");
-    for (int i = 0; i < 8; ++i) out[i] = g_timing[i];
+    out[0] = g_loop_allreduces; out[1] = g_loop_broadcasts;
+    return KAO_OK;
+}
+
+int kao_last_solve_timing(double out[12]) {
+    if (!out) return fail(KAO_ERR_INVALID, "null out");
+    for (int i = 0; i < 12; ++i) out[i] = g_timing[i];
     return KAO_OK;
 }
 

@@ -450,9 +450,17 @@ def rccl_selftest(devices: Sequence[int]) -> None:
     _check(_ffi.load().kao_rccl_selftest(dev, len(devices)), "kao_rccl_selftest")
 
 
+def rccl_loopback_counts() -> tuple:
+    """(all-reduces, broadcasts) completed by the in-process loop-back collectives (test hook KAO_RCCL_LOOPBACK=1)."""
+    out = (C.c_uint64 * 2)()
+    _check(_ffi.load().kao_rccl_loopback_counts(out), "kao_rccl_loopback_counts")
+    return int(out[0]), int(out[1])
+
+
 def last_solve_timing() -> dict:
     """C-side wall-clock breakdown of the last kao_solve (seconds from its entry)."""
-    out = (C.c_double * 8)()
+    out = (C.c_double * 12)()
     _check(_ffi.load().kao_last_solve_timing(out), "kao_last_solve_timing")
     return dict(session_ready=out[0], time_to_best=out[1], results_read_back=out[2], returned=out[3], launches=int(out[4]),
-                delta_candidates=int(out[5]), bound_launches=int(out[6]), elite_exchanges=int(out[7]), bound_iters=int(out[7]))
+                delta_candidates=int(out[5]), bound_launches=int(out[6]), elite_exchanges=int(out[7]), bound_iters=int(out[8]),
+                cx_calls=int(out[9]), cx_gains=int(out[10]), search_iters=int(out[11]))

@@ -914,7 +914,8 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         /* Level control: the Polyak step aims at `level` = record - delta, never below the incumbent `target`; delta starts
          * as the whole distance record -> incumbent (an incumbent below the optimum is an unreachable level: steps too long,
          * the record stalls far above the optimum).  Per stage of DB_STAGE iterations the record's gain is held against delta:
-         * less than delta / 32 halves delta (floor 1/16), at least delta / 8 doubles it (never beyond the incumbent).  The
+         * less than delta / 32 AND less than half a unit halves delta (floor 1/16), at least delta / 8 doubles it (never beyond
+         * the incumbent): absolute while delta is large, relative once delta < 16.  The
          * thresholds are relative because the gain per stage is itself proportional to delta; an absolute one (half a unit, the
          * first version) fails every stage once delta < ~2.5 and delta collapses wherever the record stands.
          * The record that steers the level is the best value among the ITERATES (lv[3]), not *best_L, which the rounding probes
@@ -925,7 +926,7 @@ int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, 
         if (L < lv[3]) lv[3] = L;
         if (((++lv[2]) & 0xFF) >= DB_STAGE) {
             const int64_t prog = lv[1] - lv[3];
-            if (prog < lv[0] / 32) { lv[0] /= 2; if (lv[0] < DB_SCALE / 16) lv[0] = DB_SCALE / 16; }
+            if (prog < lv[0] / 32 && prog < DB_SCALE / 2) { lv[0] /= 2; if (lv[0] < DB_SCALE / 16) lv[0] = DB_SCALE / 16; }
             else if (prog >= lv[0] / 8 && lv[3] - 2 * lv[0] >= level) lv[0] *= 2;
             lv[1] = lv[3]; lv[2] &= ~(int64_t)0xFF;
         }

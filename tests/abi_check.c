@@ -6,7 +6,7 @@
 #include "kao.h"
 
 typedef char assert_topic[(sizeof(kao_topic) == 104) ? 1 : -1];
-typedef char assert_opts[(sizeof(kao_opts) == 80) ? 1 : -1];
+typedef char assert_opts[(sizeof(kao_opts) == 88) ? 1 : -1];
 typedef char assert_result[(sizeof(kao_result) == 72) ? 1 : -1];
 typedef char assert_stats[(sizeof(kao_stats) == 80) ? 1 : -1];
 

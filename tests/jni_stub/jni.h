@@ -11,6 +11,7 @@ typedef int8_t jbyte;
 typedef int16_t jshort;
 typedef double jdouble;
 typedef jint jsize;
+typedef uint8_t jboolean;
 typedef void *jobject;
 typedef jobject jclass;
 typedef jobject jarray;
@@ -23,6 +24,7 @@ typedef const struct JNINativeInterface_ *JNIEnv;
 struct JNINativeInterface_ {
     jclass (*FindClass)(JNIEnv *, const char *);
     jint (*ThrowNew)(JNIEnv *, jclass, const char *);
+    jboolean (*ExceptionCheck)(JNIEnv *);
     jsize (*GetArrayLength)(JNIEnv *, jarray);
     jintArray (*NewIntArray)(JNIEnv *, jsize);
     jlongArray (*NewLongArray)(JNIEnv *, jsize);

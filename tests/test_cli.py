@@ -80,3 +80,74 @@ def test_python_cli_matches_cpp_cli():
     r2 = subprocess.run([sys.executable, "-m", "kafka_assignment_optimizer_amd.cli"] + ARGS, capture_output=True, timeout=120, cwd=ROOT)
     assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
     assert json.loads(r1.stdout) == json.loads(r2.stdout) == load_golden("kat1.json")["expected_json"]
+
+
+def _current_json(ots):
+    """The topics' current assignment in the reassignment-JSON shape (README.md:52-63); a replica on a broker outside the
+    target list gets an id the list does not hold."""
+    parts = []
+    for t in ots:
+        for i in range(t.n_partitions):
+            pid = i if t.partition_ids is None else int(t.partition_ids[i])
+            parts.append({"topic": t.name, "partition": pid,
+                          "replicas": [int(t.broker_ids[b]) if b < t.n_brokers else 1000000 + k for k, b in enumerate(t.current[i])]})
+    return {"version": 1, "partitions": parts}
+
+
+def _cli_args(ots, cur_path):
+    t0 = ots[0]
+    return ["--current", str(cur_path), "--broker-list", ",".join(str(int(b)) for b in t0.broker_ids),
+            "--racks", ",".join(f"{int(b)}:r{int(r):03d}" for b, r in zip(t0.broker_ids, t0.rack_of))]
+
+
+def test_cli_reads_synthetic_configs(tmp_path, ko):
+    """The JSON the multi-GPU CLI test feeds kao-cli describes the same topics the oracle generated (host only: the LP text
+    of every topic equals the oracle writer's)."""
+    _build()
+    ots = ko.gen_config(3, n_topics=2).topics + ko.gen_config(4, n_topics=2).topics[:0]
+    cur_path = tmp_path / "cur.json"
+    cur_path.write_text(json.dumps(_current_json(ots)))
+    prefix = str(tmp_path / "m")
+    r = subprocess.run([CLI] + _cli_args(ots, cur_path) + ["--emit-lp", prefix, "--lp-only"], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    for i, t in enumerate(sorted(ots, key=lambda t: t.name)):
+        assert open(f"{prefix}{i + 1}.lp").read() == ko.write_lp(t, t_index=i + 1)
+
+
+@pytest.mark.gpu
+def test_cli_gpus_on_logical_shards(tmp_path, ko):
+    """kao-cli --gpus with an explicit device list: two logical shards on device 0 (kao_solve_multi, topics dealt LPT) give the
+    same plan as one device; with ONE topic and three shards every shard searches it and the elites travel through the grouped
+    all-reduce / broadcast calls, served by the loop-back table (KAO_RCCL_LOOPBACK=1) since the box has one GPU."""
+    _build()
+    ots = ko.gen_config(3, n_topics=4).topics
+    cur = _current_json(ots)
+    cur_path = tmp_path / "cur.json"
+    cur_path.write_text(json.dumps(cur))
+    t0 = ots[0]
+    args = _cli_args(ots, cur_path) + ["--report", "--seed", "3"]
+    one = subprocess.run([CLI] + args, capture_output=True, timeout=300)
+    two = subprocess.run([CLI] + args + ["--gpus", "0,0"], capture_output=True, timeout=300)
+    assert one.returncode == 0 and two.returncode == 0, (one.stderr, two.stderr)
+    assert one.stderr.count(b"status=OPTIMAL_PROVEN") == two.stderr.count(b"status=OPTIMAL_PROVEN") == 4
+    assert json.loads(one.stdout) == json.loads(two.stdout)          # canonical tie-break: one plan per optimum
+    # one topic, three "ranks": replicated search + elite exchange through the loop-back collectives
+    single = {"version": 1, "partitions": [e for e in cur["partitions"] if e["topic"] == t0.name]}
+    cur_path.write_text(json.dumps(single))
+    env = dict(os.environ, KAO_RCCL_LOOPBACK="1")
+    three = subprocess.run([CLI] + args + ["--gpus", "0,0,0"], capture_output=True, timeout=300, env=env)
+    assert three.returncode == 0 and three.stderr.count(b"status=OPTIMAL_PROVEN") == 1, three.stderr
+    plan = {(e["topic"], e["partition"]): e["replicas"] for e in json.loads(one.stdout)["partitions"] if e["topic"] == t0.name}
+    assert {(e["topic"], e["partition"]): e["replicas"] for e in json.loads(three.stdout)["partitions"]} == plan
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["solve", "solve-multi"])
+def test_jni_shim_runs_the_readme_example(tmp_path, mode):
+    """cli/java/kao_jni.c executed (fake JNIEnv, tests/jni_stub/fake_env.c -- no JDK in the image): Kao.init, Kao.solve (one
+    device / two logical shards through the `devices` argument), Kao.canonicalize and Kao.evaluate on README.md:52-63 give
+    objective 58 = bound, one move, partition 1 -> [8,1] (README.md:88)."""
+    from test_host import build_jni_harness
+    out = subprocess.run([build_jni_harness(tmp_path), mode], capture_output=True, timeout=120)
+    assert out.returncode == 0 and b"jni_harness solve: ok" in out.stdout, (out.stdout, out.stderr)
+    assert b"status=0 objective=58 bound=58 eval_objective=58 eval_violation=0 p1=[8,1]" in out.stdout

@@ -652,6 +652,29 @@ def test_determinism(kao, ko):
     assert outs[0] == outs[1]
 
 
+def _drift_topic(B, R, P, dseed=1):
+    """The drifted single topics of tools/drift_scale.py / tests/golden/drift_scale.json (product-side generator)."""
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    return sy.drift(sy.make_cluster(B, R, 1, P, 3, [], []), 0.2, dseed)[0]
+
+
+def test_solve_is_deterministic(kao, ko):
+    """kao_solve under its default (deterministic) schedule: K-bound targets and launch lengths, price adoption, KAO-CX calls and
+    elite launches are keyed to launch / iteration / round counts, never to the clock (the answer on large topics
+    depended on launch timing).  Same seed => same assignment, certificate, launch count, K-bound iterations and KAO-CX calls --
+    on a topic that ends in a proof and on one stopped by max_launches with a gap left."""
+    for (B, R, P, ml) in ((100, 5, 1000, 0), (300, 6, 2000, 150)):
+        t = _drift_topic(B, R, P)
+        outs = []
+        for _ in range(3):
+            r = kao.solve([t], seed=11, time_limit_s=60.0, max_launches=ml)[0]
+            tm = kao.last_solve_timing()
+            outs.append((r.status, r.objective, r.upper_bound, r.assignment.tolist(), tm["launches"], tm["bound_launches"], tm["bound_iters"],
+                         tm["cx_calls"], tm["cx_gains"], tm["search_iters"]))
+        assert outs[0] == outs[1] == outs[2], [(o[:3], o[4:]) for o in outs]
+        assert outs[0][6] > 0 and (ml == 0 or outs[0][4] == ml)
+
+
 # ------------------------------------------------------------------------------- K-bound (Lagrangian dual certificate)
 def _wide_cases(ko, status="optimal"):
     return [(c, ko.random_case_wide(c["seed"])) for c in load_golden("random_wide.json")["cases"] if c["status"] == status]
@@ -814,8 +837,31 @@ def test_solve_multi_replicated_exchanges_elites(kao, ko):
         assert r.status == "OPTIMAL_PROVEN" and r.objective == g["objective"], (devices, r.status, r.objective)
         obj, viol = ko.verify(ot, r.assignment)
         assert viol[0] == 0 and obj == r.objective
-        if len(devices) > 1:
-            assert tm["elite_exchanges"] >= 0
+
+
+def test_solve_multi_replicated_runs_the_grouped_collectives(kao, ko, monkeypatch):
+    """The RCCL control flow of the elite exchange with MORE THAN ONE rank (it had only ever run with a world of
+    one): KAO_RCCL_LOOPBACK=1 serves ncclCommInitAll / ncclGroupStart / ncclAllReduce(ncclUint64, ncclMin) / ncclBroadcast /
+    ncclGroupEnd from an in-process table, so three "ranks" on device 0 drive exactly the call sequence distinct GPUs would --
+    one grouped all-reduce of the resident key buffers per exchange, one grouped broadcast per topic from the winner's rank."""
+    monkeypatch.setenv("KAO_RCCL_LOOPBACK", "1")
+    kao.rccl_selftest([0, 0, 0])                                  # both collectives, three communicators on one device
+    ar0, bc0 = kao.rccl_loopback_counts()
+    assert ar0 >= 1 and bc0 >= 1
+    t = _drift_topic(100, 5, 1000)                                # 0.3-0.6 s to the proof: many launches with differing elites
+    gold = [r for r in load_golden("drift_scale.json")["rows"] if (r["B"], r["P"]) == (100, 1000)][0]
+    r = kao.solve_multi([t], [0, 0, 0], seed=21, time_limit_s=30, elite_period=2)[0]
+    tm = kao.last_solve_timing()
+    ar1, bc1 = kao.rccl_loopback_counts()
+    assert r.status == "OPTIMAL_PROVEN" and r.objective == gold["milp_objective"], (r.status, r.objective)
+    obj, viol = ko.verify(ko.Topic(name=t.name, broker_ids=np.array(t.broker_ids), rack_of=np.array(t.rack_of), n_racks=t.n_racks,
+                                   n_partitions=t.n_partitions, rf=t.rf, current=np.array(t.current), weights=t.weights), r.assignment)
+    assert viol[0] == 0 and obj == r.objective
+    assert tm["elite_exchanges"] >= 1 and ar1 - ar0 == tm["elite_exchanges"] and 1 <= bc1 - bc0 <= tm["elite_exchanges"]
+    # the same solve through plain copies (the hook off) gives the same answer: the collectives moved the right data
+    monkeypatch.delenv("KAO_RCCL_LOOPBACK")
+    r2 = kao.solve_multi([t], [0, 0, 0], seed=21, time_limit_s=30, elite_period=2)[0]
+    assert (r2.status, r2.objective, r2.assignment.tolist()) == (r.status, r.objective, r.assignment.tolist())
 
 
 def test_rccl_collectives_on_the_resident_buffers(kao):

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"kao_init(device", "kao_strerror"} - {"kao_strerror"}
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     lib = _ffi.load()  # raises if the .so is missing or lacks a symbol
-    assert lib.kao_version() == 100
+    assert lib.kao_version() == 101
     assert lib.kao_strerror(-3).decode().startswith("no usable HIP device")
 
 
@@ -26,7 +26,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from kafka_assignment_optimizer_amd import _ffi
     assert C.sizeof(_ffi.KaoTopic) == 5 * 4 + 4 + 2 * 8 + 16 + 8 * 4 + 2 * 8  # 5 ints, pad, 2 pointers, w[2][2], 8 bounds, 2 pointers
-    assert C.sizeof(_ffi.KaoOpts) == 8 + 8 + 14 * 4 + 8
+    assert C.sizeof(_ffi.KaoOpts) == 8 + 8 + 16 * 4 + 8
     assert C.sizeof(_ffi.KaoResult) == 4 + 4 + 8 + 8 + 32 + 8 + 8
     assert C.sizeof(_ffi.KaoStats) == 3 * 8 + 2 * 8 + 2 * 8 + 6 * 4
 
@@ -37,7 +37,7 @@ def test_header_is_plain_c(tmp_path):
     import ctypes as C
     import subprocess
     from kafka_assignment_optimizer_amd import _ffi
-    assert (C.sizeof(_ffi.KaoTopic), C.sizeof(_ffi.KaoOpts), C.sizeof(_ffi.KaoResult), C.sizeof(_ffi.KaoStats)) == (104, 80, 72, 80)
+    assert (C.sizeof(_ffi.KaoTopic), C.sizeof(_ffi.KaoOpts), C.sizeof(_ffi.KaoResult), C.sizeof(_ffi.KaoStats)) == (104, 88, 72, 80)
     exe = str(tmp_path / "abi_check")
     libdir = os.path.join(ROOT, "kafka_assignment_optimizer_amd")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
@@ -121,6 +121,27 @@ def test_jni_shim_compiles():
     assert natives == exported == {"init", "solve", "evaluate", "canonicalize", "checkInfeasible"}
 
 
+def build_jni_harness(tmp_path):
+    """cli/java/kao_jni.c linked with the fake JNIEnv of tests/jni_stub/fake_env.c (no JDK in the image): the shim RUNS."""
+    import subprocess
+    exe = str(tmp_path / "jni_harness")
+    libdir = os.path.join(ROOT, "kafka_assignment_optimizer_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "tests", "jni_stub"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "jni_stub", "fake_env.c"),
+                           os.path.join(ROOT, "cli", "java", "kao_jni.c"), "-o", exe, "-L", libdir, "-lkao",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"])
+    return exe
+
+
+def test_jni_shim_validates_its_arguments(tmp_path):
+    """the shim sized native buffers from caller-supplied counts.  Run against a fake JNIEnv, every malformed call
+    (short `current` / `outAssignment` / `rackOf`, negative counts, null arrays, wrong assignment length, rf > 8) must raise
+    IllegalArgumentException before anything reaches the C ABI -- no GPU involved -- and a well-formed host-only call works."""
+    import subprocess
+    out = subprocess.run([build_jni_harness(tmp_path), "validate"], capture_output=True)
+    assert out.returncode == 0 and b"jni_harness validate: ok" in out.stdout, (out.stdout, out.stderr)
+
+
 def test_java_cli_mirrors_the_cpp_cli_flags():
     """The Java CLI cannot be compiled here (no JDK); at least its flag set is held to the C++ CLI's (minus the host-only
     LP export) and its JSON output statement to the README shape (README.md:67-78)."""
@@ -129,7 +150,8 @@ def test_java_cli_mirrors_the_cpp_cli_flags():
     java = open(os.path.join(ROOT, "cli", "java", "io", "sqooba", "kao", "KaoCli.java")).read()
     cpp_flags = set(re.findall(r'a == "(--[a-z-]+)"', cpp))
     java_flags = set(re.findall(r'case "(--[a-z-]+)"', java))
-    assert cpp_flags - java_flags == {"--emit-lp", "--lp-only", "--gpus"} and java_flags <= cpp_flags   # (multi-GPU: C++ CLI only)
+    assert cpp_flags - java_flags == {"--emit-lp", "--lp-only"} and java_flags <= cpp_flags and "--gpus" in java_flags
+    assert "devices" in open(os.path.join(ROOT, "cli", "java", "kao_jni.c")).read() and "kao_solve_multi" in open(os.path.join(ROOT, "cli", "java", "kao_jni.c")).read()
     assert '{\\"version\\":1,\\"partitions\\":[' in java and "Kao.solve(" in java and "Kao.canonicalize(" in java
 
 
