@@ -98,7 +98,7 @@ struct kao_session {
     // Topics are bucketed by LDS footprint into launch groups (a 3000-partition topic must not impose its LDS carve
     // and its 2 waves per workgroup on 200 small topics); one K-search + one K-eval launch per group per step.
     struct LaunchGroup {
-        int maxP = 0, maxBx = 0, maxB = 0;
+        int maxP = 0, maxBx = 0, maxB = 0, maxR = 0;
         int waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
         int nw = kRFP;       // replica words per partition of the group's topics: 4 or 8 (template instantiation)
         bool global_a = false;   // topic too large for LDS: assignment + current words stay in global memory

@@ -183,14 +183,63 @@ template <int NW> __device__ __forceinline__ int part_rack_viol(const TopicRegs 
 template <int NW> struct WaveLds {
     Part<NW> *A;  // [P] this restart's assignment, NW words per partition
     uint32_t *C;  // [Bx] replicas | leaders << 16 per broker
-    int *K;       // [kRackTab] replicas per rack
-    int *RT;      // [kRackTab] scratch: rack-dependent part of a REPLACE delta for the slot being scanned
+    uint32_t *W;  // [Bx] band state of every broker, derived from C and kept current with it (see band_fields)
+    int *K;       // [krt] replicas per rack (krt = search_rack_tab(largest rack count of the launch group))
+    int *RT;      // [krt] scratch: rack-dependent part of a REPLACE delta for the slot being scanned; RT[krt - 1] is the
+                  //       reserved "no candidate" slot (a delta no move survives)
 };
 
+// Band state of one broker, precomputed from its counter word c = replicas | leaders << 16 so that delta evaluation costs
+// one v_bfe_i32 per row instead of two compares, a select and a subtract.  Replica row (C3) in bits 5:0, leader row (C4) in
+// bits 11:6, each: signed 2-bit dinc = band(c + 1) - band(c), signed 2-bit ddec = band(c - 1) - band(c) (README.md:158-166),
+// and the two flags that say where a search price applies (p_in / p_out).  The upper half of the W word holds
+// the LDS address (>> 2) of the broker's rack entry in RT -- or of the reserved "no candidate" slot for padding indices and,
+// during a REPLACE scan, for the brokers already in the partition (row C5, README.md:168-171).
+constexpr int kWIncR = 0, kWDecR = 2, kWPinR = 4, kWPoutR = 5, kWIncL = 6, kWDecL = 8, kWPinL = 10, kWPoutL = 11;
+__device__ __forceinline__ int wfld(uint32_t w, int off) { return __builtin_amdgcn_sbfe((int)w, (unsigned)off, 2u); }
+__device__ __forceinline__ int wfldw(uint32_t w, int off, uint32_t width) { return __builtin_amdgcn_sbfe((int)w, (unsigned)off, width); }   // width 0 -> 0
+__device__ __forceinline__ int wflag(uint32_t w, int off) { return __builtin_amdgcn_sbfe((int)w, (unsigned)off, 1u); }                      // all ones / 0
+__device__ __forceinline__ int wflagw(uint32_t w, int off, uint32_t width) { return __builtin_amdgcn_sbfe((int)w, (unsigned)off, width); }
+// The six state bits of one band row as a function of where the count c stands: a = clamp(c - lo, -1, 1), b = clamp(c - hi, -1, 1)
+//   dinc = (c >= hi) - (c < lo) = (b >= 0) - (a < 0)        ddec = (c <= lo) - (c > hi) = (a <= 0) - (b > 0)
+//   pin  = (c >= hi) | (c < lo)   (one more unit leaves / re-enters the band: where a price applies, p_in)
+//   pout = (c > hi) | (c <= lo)   (one fewer unit, p_out)
+// entry = dinc & 3 | (ddec & 3) << 2 | pin << 4 | pout << 5, nine entries of 6 bits indexed by 3 * (a + 1) + (b + 1) in one 64-bit constant.
+constexpr unsigned long long band_entry_of(int a, int b) {
+    const int di = (b >= 0 ? 1 : 0) - (a < 0 ? 1 : 0), dd = (a <= 0 ? 1 : 0) - (b > 0 ? 1 : 0);
+    const int pin = (b >= 0 || a < 0) ? 1 : 0, pout = (b > 0 || a <= 0) ? 1 : 0;
+    return (unsigned long long)((di & 3) | ((dd & 3) << 2) | (pin << 4) | (pout << 5));
+}
+constexpr unsigned long long band_table() {
+    unsigned long long t = 0;
+    for (int a = -1; a <= 1; ++a) for (int b = -1; b <= 1; ++b) t |= band_entry_of(a, b) << (6 * (3 * (a + 1) + (b + 1)));
+    return t;
+}
+constexpr unsigned long long kBandTab = band_table();
+__device__ __forceinline__ uint32_t band_entry(int c, int lo, int hi) {
+    const int a = min(max(c - lo, -1), 1), b = min(max(c - hi, -1), 1);
+    return (uint32_t)(kBandTab >> (uint32_t)((__mul24(a, 3) + b + 4) * 6)) & 63u;
+}
+__device__ __forceinline__ uint32_t band_fields(const TopicRegs &T, uint32_t c) {
+    return band_entry((int)(c & 0xFFFFu), T.rep_lo, T.rep_hi) | (band_entry((int)(c >> 16), T.lead_lo, T.lead_hi) << 6);
+}
+// LDS byte address of a __shared__ object (the low 32 bits of its generic address are the LDS offset on gfx9)
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ int lds_read_i32(uint32_t byte_addr) { return *reinterpret_cast<const lds_int_t *>((uintptr_t)byte_addr); }
+// W[x] for every index of the topic: fields from the counters, RT entry of the broker's rack (XR: rack of x, 0xFF = padding)
+template <int NW> __device__ __forceinline__ void rebuild_band_state(const TopicRegs &T, const WaveLds<NW> &L, const uint8_t *XR, int krt, int lane) {
+    const uint32_t rt0 = lds_addr(L.RT) >> 2;
+    for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) {
+        const uint32_t r = XR[x];
+        L.W[x] = r == 0xFFu ? ((rt0 + (uint32_t)krt - 1u) << 16) : (((rt0 + r) << 16) | band_fields(T, L.C[x]));
+    }
+}
+
 // rebuild C and K from A (lanes stride partitions; LDS atomics)
-template <int NW> __device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds<NW> &L, int lane) {
+template <int NW> __device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds<NW> &L, int lane, int krt) {
     for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) L.C[x] = 0;
-    for (int r = lane; r < kRackTab; r += 64) L.K[r] = 0;
+    for (int r = lane; r < krt; r += 64) L.K[r] = 0;
     for (int p = lane; p < T.P; p += 64) {
         const Part<NW> a = L.A[p];
 #pragma unroll
@@ -261,40 +310,43 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     // by -- where it is used; VGPRs are plentiful (68 of the 72 that keep 7 waves per SIMD).
     asm volatile("" : "+v"(T.rep_lo), "+v"(T.rep_hi), "+v"(T.lead_lo), "+v"(T.lead_hi));
 
-    // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[256]] [XR u8[Bx rounded to 64]] then per wave
-    //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [K int[256]] [RT int[256]]        (* only when !kGlobalA)
+    // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[krt]] [XR u8[Bx rounded to 64]] then per wave
+    //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [W u32[same]] [K int[krt]] [RT int[krt]]        (* only when !kGlobalA)
+    //      krt = search_rack_tab(largest rack count of the launch group): the racks plus the reserved "no candidate" entry
     const int a_bytes = kGlobalA ? 0 : prm.maxP * NW * 4;
     const int bx64 = (prm.maxBx + 63) & ~63;
     const int c_bytes = bx64 * 4;
+    const int krt = search_rack_tab(prm.maxR);
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
-    uint8_t *XR = smem + a_bytes + kRackTab * 4;  // rack of internal index x, 0xFF = padding slot / beyond Bx
-    uint32_t *PR = reinterpret_cast<uint32_t *>(smem + a_bytes + kRackTab * 4 + bx64);  // [bx64] packed prices (kPriced only)
+    uint8_t *XR = smem + a_bytes + krt * 4;  // rack of internal index x, 0xFF = padding slot / beyond Bx
+    uint32_t *PR = reinterpret_cast<uint32_t *>(smem + a_bytes + krt * 4 + bx64);  // [bx64] packed prices (kPriced only)
     const bool hbw = kPriced && prm.bw != 0;   // the launch group carries broker weights (their table is carved only then)
-    const int pr_bytes = kPriced ? (hbw ? 2 : 1) * c_bytes + kRackTab * 4 : 0;
-    int *PG = reinterpret_cast<int *>(smem + a_bytes + kRackTab * 4 + bx64 + c_bytes);  // [kRackTab] rack prices (kPriced only)
-    uint32_t *BW = reinterpret_cast<uint32_t *>(smem + a_bytes + kRackTab * 4 + bx64 + c_bytes + kRackTab * 4);  // [bx64] broker weights (kPriced only)
-    unsigned char *wb = smem + a_bytes + kRackTab * 4 + bx64 + pr_bytes + wave * (a_bytes + c_bytes + kRackTab * 8);  // blockDim.x / 64 waves
+    const int pr_bytes = kPriced ? (hbw ? 2 : 1) * c_bytes + krt * 4 : 0;
+    int *PG = reinterpret_cast<int *>(smem + a_bytes + krt * 4 + bx64 + c_bytes);  // [krt] rack prices (kPriced only)
+    uint32_t *BW = reinterpret_cast<uint32_t *>(smem + a_bytes + krt * 4 + bx64 + c_bytes + krt * 4);  // [bx64] broker weights (kPriced only)
+    unsigned char *wb = smem + a_bytes + krt * 4 + bx64 + pr_bytes + wave * (a_bytes + 2 * c_bytes + krt * 8);  // blockDim.x / 64 waves
     const Part<NW> *cur_words = reinterpret_cast<const Part<NW> *>(pl.cur_pool + TD->cur_off);  // host-prepared words x | rack << 16 (0xFFFFFFFF = none); cur_off counts words
     const Part<NW> *CUR;
     if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const Part<NW> *>(smem);
     WaveLds<NW> L;
     L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
-    L.K = reinterpret_cast<int *>(wb + a_bytes + c_bytes);
-    L.RT = L.K + kRackTab;
+    L.W = reinterpret_cast<uint32_t *>(wb + a_bytes + c_bytes);
+    L.K = reinterpret_cast<int *>(wb + a_bytes + 2 * c_bytes);
+    L.RT = L.K + krt;
 
     // ---- stage the rack sizes / rack-of-index table (and, when it fits, the current-assignment words) ----
     if (!kGlobalA) {
         Part<NW> *cur_lds = reinterpret_cast<Part<NW> *>(smem);
         for (int p = threadIdx.x; p < T.P; p += blockDim.x) cur_lds[p] = cur_words[p];
     }
-    for (int r = threadIdx.x; r < kRackTab; r += blockDim.x) {
+    for (int r = threadIdx.x; r < krt; r += blockDim.x) {
         RSZ[r] = r < T.R ? pl.rsz_pool[TD->rsz_off + r] : 0;
         if (kPriced) PG[r] = r < T.R ? price_units(pl.price_pool[TD->price_off + 2 * TD->B + r], prm.obj_scale) : 0;
     }
     __syncthreads();
     for (int x = threadIdx.x; x < ((T.Bx + 63) & ~63); x += blockDim.x) {
         const uint32_t r = mulhi((uint32_t)x, T.magic);
-        const bool valid = x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)kRackTab ? r : 0];
+        const bool valid = x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)krt ? r : 0];
         XR[x] = valid ? (uint8_t)r : (uint8_t)0xFF;
         if (kPriced) {  // prices of broker x in key units: replica price a[b] | leader price l[b] << 16
             uint32_t pr = 0;
@@ -360,7 +412,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         }
     }
     if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own stores visible to every lane's loads
-    recount(T, L, lane);
+    recount(T, L, lane, krt);
 
     if (prm.init) {
         // ---- hole filling by best insertion, holes in (p,k) order.  Partitions are inspected 64 at a time (one per
@@ -397,14 +449,15 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         const uint32_t xw = x | (r << 16);
                         const bool okx = (r != 0xFFu) & !in4(a, xw);
                         const uint32_t cn = L.C[x];
-                        int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[r & 255u], T.rack_lo, T.rack_hi) +
+                        const uint32_t rk = r == 0xFFu ? 0u : r;   // padding lanes (no candidate anyway) read entry 0
+                        int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[rk], T.rack_lo, T.rack_hi) +
                                  dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
                         if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
                         const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
                         uint32_t keyx;
                         if (kPriced) {
                             const uint32_t prx = PR[x];
-                            int dP = p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx)) + p_in(L.K[r & 255u], T.rack_lo, T.rack_hi, PG[r & 255u]);
+                            int dP = p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx)) + p_in(L.K[rk], T.rack_lo, T.rack_hi, PG[rk]);
                             if (k == 0) dP += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
                             keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf) + (hbw ? bw_of(BW[x], k == 0) : 0), dP, tie) : kKeyNull;
                         }
@@ -429,6 +482,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     int V, obj;
     full_cost(T, L, CUR, RSZ, lane, V, obj, hbw ? BW : nullptr);
     if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
+    rebuild_band_state(T, L, XR, krt, lane);          // W from the counters; kept current by every accepted move below
+    // the reserved RT entry: a violation delta (unpriced) / a rack price above the violation byte (priced) that no move survives
+    if (lane == 0) L.RT[krt - 1] = kPriced ? (1 << 28) : kNoCand;
 
     // ---- per-lane RNG stream of this launch (LCG mod 2^24, re-keyed every launch) ----
     uint32_t rng = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + prm.launch * 0x85EBCA77u + (uint32_t)lane * 0xC2B2AE3Du));
@@ -470,6 +526,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         uint32_t kmin;
         int win;
 
+        // Every violation delta of the broker rows (C3, C4) below comes from the brokers' band state W (band_fields): a signed
+        // 2-bit field per (row, direction) instead of two compares, a select and a subtract on the counter word; the prices
+        // of the priced instantiation apply where the matching "count leaves / re-enters its band" flag is set.
         if (sampled) {
             p = (int)rnd24_wide(rng, (uint32_t)T.P);
             const Part<NW> a = L.A[p];
@@ -479,18 +538,18 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 uw = sel4(a, k);
                 const uint32_t ro = uw >> 16;
                 const bool lead = k == 0;
+                const uint32_t lw = lead ? 2u : 0u;   // width of a leader field: a zero-width extract yields 0 for follower slots
                 const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
                 const int g_old = role_w2(c, uw, wl, wf) + (hbw ? bw_of(BW[uw & 0xFFFFu], lead) : 0);
-                const uint32_t co = L.C[uw & 0xFFFFu];
-                int dV_old = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
-                if (lead) dV_old += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+                const uint32_t wo = L.W[uw & 0xFFFFu];
+                const int dV_old = wfld(wo, kWDecR) + wfldw(wo, kWDecL, lw);
                 const int dV_rack_old = ddec(L.K[ro], T.rack_lo, T.rack_hi) + ddec(cnt4(a, ro), T.prack_lo, T.prack_hi);
                 const int rsz_ro = RSZ[ro];
                 int dP_old = 0, dP_rack_old = 0;
                 if (kPriced) {
                     const uint32_t pro = PR[uw & 0xFFFFu];
-                    dP_old = p_out((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(pro));
-                    if (lead) dP_old += p_out((int)(co >> 16), T.lead_lo, T.lead_hi, price_lead(pro));
+                    dP_old = -(wflag(wo, kWPoutR) & price_rep(pro));
+                    if (lead) dP_old -= wflag(wo, kWPoutL) & price_lead(pro);
                     dP_rack_old = p_out(L.K[ro], T.rack_lo, T.rack_hi, PG[ro]);
                 }
 #pragma unroll
@@ -509,9 +568,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     const uint32_t x = __umul24(r, (uint32_t)T.m) + jj;
                     const uint32_t xw = x | (r << 16);
                     okg = okg && !in4(a, xw);
-                    const uint32_t cn = L.C[x];
-                    int dVg = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi);
-                    if (lead) dVg += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+                    const uint32_t wn = L.W[x];
+                    int dVg = dV_old + wfld(wn, kWIncR) + wfldw(wn, kWIncL, lw);
                     if (g < 2) {
                         if (r != ro)
                             dVg += dV_rack_old + dinc(L.K[r], T.rack_lo, T.rack_hi) + dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
@@ -520,8 +578,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     uint32_t keyg;
                     if (kPriced) {
                         const uint32_t prx = PR[x];
-                        int dPg = dP_old + p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx));
-                        if (lead) dPg += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
+                        int dPg = dP_old + (wflag(wn, kWPinR) & price_rep(prx));
+                        if (lead) dPg += wflag(wn, kWPinL) & price_lead(prx);
                         if (g < 2 && r != ro) dPg += dP_rack_old + p_in(L.K[r], T.rack_lo, T.rack_hi, PG[r]);
                         keyg = okg ? make_key_p(lam, S, dVg, dObjg, dPg, lane) : kKeyNull;
                     }
@@ -531,17 +589,19 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             } else {  // LEADER SWAP inside p: slot 0 <-> slot k, every k = 1..RF-1 is a candidate
                 uw = a.w[0];
                 const int u_lead = role_w2(c, uw, T.w00, T.w10), u_fol = role_w2(c, uw, T.w01, T.w11);
-                const int dV_u = ddec((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
-                const int dP_u = kPriced ? p_out((int)(L.C[uw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi, price_lead(PR[uw & 0xFFFFu])) : 0;
+                const uint32_t wu = L.W[uw & 0xFFFFu];
+                const int dV_u = wfld(wu, kWDecL);
+                const int dP_u = kPriced ? -(wflag(wu, kWPoutL) & price_lead(PR[uw & 0xFFFFu])) : 0;
 #pragma unroll
                 for (int kk = 1; kk < NW; ++kk) {
                     if (kk >= T.RF) break;
                     const uint32_t xw = a.w[kk];
                     const int dObjg = role_w2(c, xw, T.w00, T.w10) + u_fol - u_lead - role_w2(c, xw, T.w01, T.w11) +
                                       (hbw ? (int)(BW[xw & 0xFFFFu] >> 16) - (int)(BW[uw & 0xFFFFu] >> 16) : 0);
-                    const int dVg = dV_u + dinc((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi);
+                    const uint32_t wx = L.W[xw & 0xFFFFu];
+                    const int dVg = dV_u + wfld(wx, kWIncL);
                     uint32_t keyg;
-                    if (kPriced) keyg = make_key_p(lam, S, dVg, dObjg, dP_u + p_in((int)(L.C[xw & 0xFFFFu] >> 16), T.lead_lo, T.lead_hi, price_lead(PR[xw & 0xFFFFu])), lane);
+                    if (kPriced) keyg = make_key_p(lam, S, dVg, dObjg, dP_u + (wflag(wx, kWPinL) & price_lead(PR[xw & 0xFFFFu])), lane);
                     else keyg = make_key(lam, S, dVg, dObjg, lane);
                     if (keyg < key) { key = keyg; vw = xw; k = kk; dV = dVg; dObj = dObjg; }
                 }
@@ -566,25 +626,23 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const bool leadl = k_o == 0;
                 g_o = role_w2(cl, oldw_o, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
                 if (hbw && type == 0) g_o += bw_of(BW[oldw_o & 0xFFFFu], leadl);   // a REPLACE also gives up the broker's own weight
-                const uint32_t co = L.C[oldw_o & 0xFFFFu];
+                const uint32_t wo = L.W[oldw_o & 0xFFFFu];
                 const int dv7 = ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
                 int sc;
                 if (type == 0) {
-                    dvo_o = ddec((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi);
-                    if (leadl) dvo_o += ddec((int)(co >> 16), T.lead_lo, T.lead_hi);
+                    dvo_o = wfld(wo, kWDecR) + wfldw(wo, kWDecL, leadl ? 2u : 0u);
                     dvr_o = ddec(L.K[rol], T.rack_lo, T.rack_hi) + dv7;
                     sc = dvo_o + min(dvr_o, 0);
                 } else {
-                    const int cl16 = (int)(co >> 16);
-                    const int dvl = leadl ? ddec(cl16, T.lead_lo, T.lead_hi) : dinc(cl16, T.lead_lo, T.lead_hi);
+                    const int dvl = wfld(wo, leadl ? kWDecL : kWIncL);
                     sc = min(dv7, 0) + min(dvl, 0);
                 }
                 if (kPriced) {
                     int dPs = 0;
                     if (type == 0) {
                         const uint32_t pro = PR[oldw_o & 0xFFFFu];
-                        dPs = p_out((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(pro));
-                        if (leadl) dPs += p_out((int)(co >> 16), T.lead_lo, T.lead_hi, price_lead(pro));
+                        dPs = -(wflag(wo, kWPoutR) & price_rep(pro));
+                        if (leadl) dPs -= wflag(wo, kWPoutL) & price_lead(pro);
                     }
                     key_o = lane < T_tour ? make_key_p(lam, S, sc, -g_o, dPs, lane) : kKeyNull;
                 }
@@ -609,7 +667,11 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             const bool lead = k == 0;  // wave-uniform
             const uint32_t ro = uw >> 16;
             if (type == 0) {
-                // ---- phase B (REPLACE): every target broker for slot (p,k), 64 per round ----
+                // ---- phase B (REPLACE): every target broker for slot (p,k), 64 per round -- the band-state scan.  A candidate
+                //      costs one W read (band deltas + where its rack's entry of RT lives), one RT read, two bit-field
+                //      extracts, the cost and the key; the per-lane running minimum is a plain v_min_u32 because the key carries
+                //      the round number below the tie bits; only the winner's details are recomputed afterwards.  Same
+                //      candidates, same keys, same winner as the scalar restatement (oracle/kao_port.c).
                 {   // rack-dependent part of the delta, racks strided over the lanes
                     const int dP_rack_old = kPriced ? p_out(L.K[ro], T.rack_lo, T.rack_hi, PG[ro]) : 0;
                     for (int r = lane; r < T.R; r += 64) {
@@ -620,46 +682,88 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     }
                 }
                 const int wl = lead ? T.w00 : T.w01, wf = lead ? T.w10 : T.w11;
-                // a displaced current replica (in c, not in a) is the only broker with a non-zero weight here
-                // (lane i < NW checks current replica i; one ballot instead of every lane checking all of them)
-                const uint32_t ci = sel4(c, lane & (NW - 1));
+                // lane i < NW looks after slot i of the partition: (1) the broker it holds is no candidate (row C5) -- for the
+                // duration of the scan its W entry points at the reserved RT entry; (2) current replica i, when displaced (in c,
+                // not in a), is the only broker with a non-zero objective weight here: the round it falls into is scored with weights
+                const int li = lane & (NW - 1);
+                const uint32_t ai = sel4(a, li), ci = sel4(c, li);
+                const bool mine = (lane < NW) & (ai != kNoneW);
+                uint32_t w_keep = 0;
+                if (mine) {
+                    w_keep = L.W[ai & 0xFFFFu];
+                    L.W[ai & 0xFFFFu] = (w_keep & 0xFFFFu) | (((lds_addr(L.RT) >> 2) + (uint32_t)krt - 1u) << 16);
+                }
                 const bool hm_l = (lane < NW) & (ci != kNoneW) & !in4(a, ci);
-                const bool has_missing = __ballot(hm_l) != 0ull;
-                int dP_old = 0;
+                const int mr_l = hm_l ? (int)((ci & 0xFFFFu) >> 6) : -1;
+                int mr[NW];
+#pragma unroll
+                for (int i2 = 0; i2 < NW; ++i2) mr[i2] = __builtin_amdgcn_readlane(mr_l, i2);
+                bool has_missing = false;
+#pragma unroll
+                for (int i2 = 0; i2 < NW; ++i2) has_missing |= mr[i2] >= 0;
+                // cost + bias of a candidate = lam * (its own delta + dV_old) + S * g_old (+ prices) (- S * weight of a displaced
+                // current replica): everything that does not depend on the candidate is one wave-uniform constant
+                int K0 = __mul24(S, g_old) + kDBias + __mul24(lam, dV_old);
                 if (kPriced) {
                     const uint32_t pro = PR[uw & 0xFFFFu];
-                    const uint32_t co = L.C[uw & 0xFFFFu];
-                    dP_old = p_out((int)(co & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(pro));
-                    if (lead) dP_old += p_out((int)(co >> 16), T.lead_lo, T.lead_hi, price_lead(pro));
+                    const uint32_t wo = L.W[uw & 0xFFFFu];
+                    K0 -= wflag(wo, kWPoutR) & price_rep(pro);
+                    if (lead) K0 -= wflag(wo, kWPoutL) & price_lead(pro);
                 }
-                for (int base = 0; base < T.Bx; base += 64) {
-                    const uint32_t tie = lcg24(rng) >> 8;
-                    const uint32_t x = (uint32_t)(base + lane);
-                    const uint32_t r = XR[x];
-                    const uint32_t xw = x | (r << 16);
-                    const bool okx = (r != 0xFFu) & !in4(a, xw);
-                    const uint32_t cn = L.C[x];
-                    const int rt = L.RT[r & 255u];
-                    int dVx = dV_old + dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + (kPriced ? (int)(signed char)(rt & 0xFF) : rt);
-                    if (lead) dVx += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
-                    int dObjx = -g_old;
-                    if (has_missing) dObjx += role_w2(c, xw, wl, wf);
-                    if (hbw) dObjx += bw_of(BW[x], lead);
-                    uint32_t keyx;
-                    if (kPriced) {
-                        const uint32_t prx = PR[x];
-                        int dPx = dP_old + p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx)) + (rt >> 8);
-                        if (lead) dPx += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
-                        keyx = okx ? make_key_tie_p(lam, S, dVx, dObjx, dPx, tie) : kKeyNull;
+                const uint32_t lw = lead ? 2u : 0u, lf = lead ? 1u : 0u;   // widths of the leader fields / flags: zero for follower slots
+                uint32_t bestA = kKeyNull;   // (cost + bias) << 16 | tie << 8 | round within the chunk of 256 rounds
+                int chunkA = 0;
+                for (int cb = 0; cb < T.Bx; cb += 16384) {
+                    uint32_t bestc = kKeyNull;
+                    const int cend = min(T.Bx, cb + 16384);
+                    int rd = 0;
+                    for (int base = cb; base < cend; base += 64, ++rd) {
+                        const uint32_t st = lcg24(rng);   // tie bits = bits 8..15 of the draw, as make_key_tie(lcg24 >> 8)
+                        const uint32_t w = L.W[base + lane];
+                        const int rt = lds_read_i32((w >> 16) << 2);
+                        int dsc;
+                        if (kPriced) {   // RT entry: violation delta in the low byte, rack price above it
+                            const uint32_t prx = PR[base + lane];
+                            const int dVx = wfld(w, kWIncR) + wfldw(w, kWIncL, lw) + (int)(signed char)(rt & 0xFF);
+                            dsc = __mul24(lam, dVx) + K0 + (rt >> 8) + (wflag(w, kWPinR) & price_rep(prx)) + (wflagw(w, kWPinL, lf) & price_lead(prx));
+                            if (hbw) dsc -= __mul24(S, bw_of(BW[base + lane], lead));
+                        } else {
+                            const int dVx = wfld(w, kWIncR) + wfldw(w, kWIncL, lw) + rt;
+                            dsc = __mul24(lam, dVx) + K0;
+                        }
+                        bool weighted = false;   // wave-uniform: this round holds a displaced current replica of the partition
+                        const int rdg = (cb >> 6) + rd;
+#pragma unroll
+                        for (int i2 = 0; i2 < NW; ++i2) weighted |= mr[i2] == rdg;
+                        if (weighted) {
+                            const uint32_t x = (uint32_t)((rdg << 6) + lane);
+                            dsc -= __mul24(S, role_w2(c, x | ((uint32_t)XR[x] << 16), wl, wf));
+                        }
+                        dsc = min(max(dsc, 0), 2 * kDBias - 2);
+                        bestc = min(bestc, ((uint32_t)dsc << 16) | (st & 0xFF00u) | (uint32_t)rd);
                     }
-                    else keyx = okx ? make_key_tie(lam, S, dVx, dObjx, tie) : kKeyNull;
-                    if (keyx < key) { key = keyx; vw = xw; dV = dVx; dObj = dObjx; }
+                    if ((bestc >> 8) < (bestA >> 8)) { bestA = bestc; chunkA = cb; }   // strict: ties stay with the earlier round
+                }
+                if (mine) L.W[ai & 0xFFFFu] = w_keep;
+                key = bestA >> 8;   // (cost + bias) << 8 | tie: the key format of every other move type
+                kmin = wave_umin(key);
+                const unsigned long long bal = __ballot(key == kmin);
+                win = __ffsll((long long)bal) - 1;  // ties inside the wave go to the lowest lane
+                if ((int)(kmin >> 8) - kDBias <= 0) {   // will be accepted: the winner's move, wave-uniform
+                    const uint32_t bw_ = (uint32_t)__builtin_amdgcn_readlane((int)bestA, win);
+                    const uint32_t xs = (uint32_t)__builtin_amdgcn_readlane(chunkA, win) + ((bw_ & 255u) << 6) + (uint32_t)win;
+                    const uint32_t rs = XR[xs];
+                    const uint32_t ws = L.W[xs];
+                    const int rts = L.RT[rs];
+                    vw = xs | (rs << 16);
+                    dV = wfld(ws, kWIncR) + wfldw(ws, kWIncL, lw) + dV_old + (kPriced ? (int)(signed char)(rts & 0xFF) : rts);
+                    dObj = -g_old + (has_missing ? role_w2(c, vw, wl, wf) : 0) + (hbw ? bw_of(BW[xs], lead) : 0);
                 }
             } else {
                 // ---- phase B (EXCHANGE): every partner slot (q,j) for slot (p,k), 64 partitions per round ----
                 const int nrp = lead ? 0 : 1;
                 const int cnt_a_ru = cnt4(a, ro);
-                const int cu = (int)(L.C[uw & 0xFFFFu] >> 16);
+                const uint32_t wu = L.W[uw & 0xFFFFu];
                 const int pl_u = kPriced ? price_lead(PR[uw & 0xFFFFu]) : 0;
                 const int bwl_u = hbw ? (int)(BW[uw & 0xFFFFu] >> 16) : 0;
                 // every lane draws; lane 0's value places the window when the topic has more than 512 partitions
@@ -688,14 +792,13 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         int dObjx = role_w(T, c, v, nrp) + (jj == 0 ? u_in_q_lead : u_in_q_fol) - g_old - role_w(T, cb, v, nrq);
                         int dVx = 0, dPx = 0;
                         if (lead != (jj == 0)) {  // wave-uniform: exactly one of the two slots is a leader slot
-                            const int cv = (int)(L.C[v & 0xFFFFu] >> 16);
-                            dVx += lead ? (ddec(cu, T.lead_lo, T.lead_hi) + dinc(cv, T.lead_lo, T.lead_hi))
-                                        : (ddec(cv, T.lead_lo, T.lead_hi) + dinc(cu, T.lead_lo, T.lead_hi));
+                            const uint32_t wv = L.W[v & 0xFFFFu];
+                            dVx += lead ? (wfld(wu, kWDecL) + wfld(wv, kWIncL)) : (wfld(wv, kWDecL) + wfld(wu, kWIncL));
                             if (kPriced) {  // the leader moves u -> v or v -> u
                                 if (hbw) { const int dbl = (int)(BW[v & 0xFFFFu] >> 16) - bwl_u; dObjx += lead ? dbl : -dbl; }
                                 const int plv = price_lead(PR[v & 0xFFFFu]);
-                                dPx = lead ? (p_out(cu, T.lead_lo, T.lead_hi, pl_u) + p_in(cv, T.lead_lo, T.lead_hi, plv))
-                                           : (p_out(cv, T.lead_lo, T.lead_hi, plv) + p_in(cu, T.lead_lo, T.lead_hi, pl_u));
+                                dPx = lead ? ((wflag(wv, kWPinL) & plv) - (wflag(wu, kWPoutL) & pl_u))
+                                           : ((wflag(wu, kWPinL) & pl_u) - (wflag(wv, kWPoutL) & plv));
                             }
                         }
                         const uint32_t rv = v >> 16;
@@ -708,10 +811,10 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         if (keyx < key) { key = keyx; vw = v; q = qq; j = jj; dV = dVx; dObj = dObjx; }
                     }
                 }
+                kmin = wave_umin(key);
+                const unsigned long long bal = __ballot(key == kmin);
+                win = __ffsll((long long)bal) - 1;  // ties inside the wave go to the lowest lane
             }
-            kmin = wave_umin(key);
-            const unsigned long long bal = __ballot(key == kmin);
-            win = __ffsll((long long)bal) - 1;  // ties inside the wave go to the lowest lane
         }
         if (kmin == kKeyNull) continue;
         if ((int)(kmin >> 8) - kDBias > 0) continue;  // accept only non-worsening moves (cost under current lam)
@@ -741,6 +844,13 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 ap[k] = uw;
             }
         }
+        {   // band state of the two brokers whose counters may have changed: lane 0 the old broker, lane 1 the new one
+            const uint32_t xo = (uint32_t)__builtin_amdgcn_readlane((int)uw, win) & 0xFFFFu, xn = (uint32_t)__builtin_amdgcn_readlane((int)vw, win) & 0xFFFFu;
+            if (lane < 2) {
+                const uint32_t xx = lane ? xn : xo;
+                L.W[xx] = (L.W[xx] & 0xFFFF0000u) | band_fields(T, L.C[xx]);
+            }
+        }
         if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the winner's stores before the next loads
         V += __builtin_amdgcn_readlane(dV, win);
         obj += __builtin_amdgcn_readlane(dObj, win);
@@ -749,7 +859,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     }
 
     // ---- end of launch: verify the incremental bookkeeping against a from-scratch recount ----
-    recount(T, L, lane);
+    recount(T, L, lane, krt);
     int V2, obj2;
     full_cost(T, L, CUR, RSZ, lane, V2, obj2, hbw ? BW : nullptr);
     if ((V2 != V || obj2 != obj) && lane == 0) atomicAdd(pl.drift, 1);
@@ -981,6 +1091,7 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
     L.C = reinterpret_cast<uint32_t *>(smem + kRackTab * 4 + bx64);
     L.K = reinterpret_cast<int *>(smem + kRackTab * 4 + bx64 + bx64 * 4);
     L.RT = L.K;  // unused here
+    L.W = L.C;   // unused here
     for (int r = lane; r < kRackTab; r += 64) RSZ[r] = r < T.R ? rsz[r] : 0;
     __syncthreads();
     for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) {
@@ -988,7 +1099,7 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
         XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)kRackTab ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
     }
     __syncthreads();
-    recount(T, L, lane);
+    recount(T, L, lane, kRackTab);
     int V, obj;
     full_cost(T, L, cur_words, RSZ, lane, V, obj);
     if (V != 0) {  // only feasible assignments are polished
@@ -1067,9 +1178,9 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw) {
-    const size_t a = global_a ? 0 : (size_t)maxP * 4 * (size_t)nw, bx64 = ((size_t)maxBx + 63) & ~(size_t)63;
-    return a + kRackTab * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + kRackTab * 4 : 0) + (size_t)waves * (a + bx64 * 4 + kRackTab * 8);
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw, int maxR) {
+    const size_t a = global_a ? 0 : (size_t)maxP * 4 * (size_t)nw, bx64 = ((size_t)maxBx + 63) & ~(size_t)63, krt = (size_t)search_rack_tab(maxR);
+    return a + krt * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + krt * 4 : 0) + (size_t)waves * (a + bx64 * 8 + krt * 8);
 }
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 2 * (size_t)ne + 15) & ~(size_t)15 : 0;
@@ -1087,7 +1198,7 @@ static void launch_search_t(const SearchPools &pools, const SearchParams &prm, i
 }
 
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream) {
-    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw, prm.bw != 0);
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw, prm.bw != 0, prm.maxR);
     // largest dynamic-LDS size each of the 8 instantiations has been enabled for, per device
     static int attr[kAttrDevices][8] = {{0}};
     int &a = attr[attr_slot()][(global_a ? 4 : 0) + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];

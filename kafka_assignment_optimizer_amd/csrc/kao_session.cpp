@@ -536,7 +536,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         while (cur_pool.size() % 4) cur_pool.push_back(kNoneW);   // every topic's words start 16-byte aligned
         d.cur_off = (uint32_t)cur_pool.size();
         for (size_t i = 0; i < (size_t)d.P * d.nw; ++i) cur_pool.push_back(word(pt.cur_int[i]));  // LDS / register form of a replica: internal index | rack << 16
-        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw, s->any_bw) > 160 * 1024;
+        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw, s->any_bw, d.R) > 160 * 1024;
         s->topic_global[(size_t)t] = global_a;
         d.ext_off = (uint32_t)ext_pool.size();
         ext_pool.insert(ext_pool.end(), pt.ext_of.begin(), pt.ext_of.end());
@@ -579,7 +579,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     auto need1 = [&](int t) {  // topics kept in global memory sort last (their LDS need is tiny but they form their own groups)
         const TopicDev &d = s->pts[(size_t)t].d;
         const bool ga = s->topic_global[(size_t)t] != 0;
-        return (ga ? ((size_t)1 << 40) : 0) + (d.nw > kRFP ? ((size_t)1 << 41) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true, d.nw, s->any_bw);
+        return (ga ? ((size_t)1 << 40) : 0) + (d.nw > kRFP ? ((size_t)1 << 41) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true, d.nw, s->any_bw, d.R);
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need1(x) < need1(y); });
     std::vector<std::vector<int>> members;
@@ -603,13 +603,13 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         kao_session::LaunchGroup g;
         for (int t : mem) {
             const TopicDev &d = s->pts[(size_t)t].d;
-            g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B);
+            g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B); g.maxR = std::max(g.maxR, d.R);
         }
         g.global_a = s->topic_global[(size_t)mem[0]] != 0;
         g.nw = s->pts[(size_t)mem[0]].d.nw;
-        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw) > 160 * 1024) g.waves /= 2;
+        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR) > 160 * 1024) g.waves /= 2;
         g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true, g.nw) <= 160 * 1024;
-        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
+        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
             kao_session_destroy(s);
             return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS (about 30,000 padded brokers)");
         }
@@ -753,7 +753,7 @@ int kao_session_step(kao_session *s) {
     if (prof) HIP_TRY(hipEventRecord(e[0], s->stream));
     for (const kao_session::LaunchGroup &g : s->groups) {
         sp.block_map = s->d_smap + g.smap_off;
-        prm.maxP = g.maxP; prm.maxBx = g.maxBx;
+        prm.maxP = g.maxP; prm.maxBx = g.maxBx; prm.maxR = g.maxR;
         launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, g.nw, s->stream);
         HIP_TRY(hipGetLastError());
     }
@@ -844,7 +844,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
     for (const kao_session::LaunchGroup &g : s->groups)
-        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw, s->any_bw));
+        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw, s->any_bw, g.maxR));
     out->launch_groups = (int32_t)s->groups.size();
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));

@@ -22,12 +22,31 @@ struct DetPlan { int bound_iters; int64_t cx_stall_iters, cx_due_iters; int cx_r
 DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
     DetPlan d;
     (void)maxB; (void)n_topics;
-    // K-bound iterations per launch: about one K-search launch's worth of time (DESIGN.md section 4e has the measurements)
-    d.bound_iters = slots <= 8192 ? 128 : (slots <= 32768 ? 192 : 96);
-    // KAO-CX: a topic counts as stalled after ~50 ms without improvement and is revisited after ~250 ms
+    // K-bound iterations per launch = about one K-search launch's worth of time, so that neither stream waits for the other
+    // (measured on one MI355X, wall-clock schedule with KAO_SOLVE_TRACE=1, profiles/r03_schedule_trace.txt: drifted single
+    // topics of 1,000 / 2,000 / 5,000 / 10,000 / 30,000 partitions: K-search launch 1.6 / 4.5 / 5.2 / 7.6 / 14.2 ms, K-bound
+    // 29 / 49 / 43 / 48 / 77 us per iteration; the 200-topic config-4 batch: 1.0 ms and 9.5 us).  Interpolated on a log scale
+    // of the largest topic's replica slots and rounded down a little: K-bound finishing early costs it some idle time, K-bound
+    // finishing late stalls the search.
+    static const struct { int64_t slots; int iters; } tab[] = {{512, 128}, {3000, 56}, {6000, 88}, {15000, 112}, {30000, 144}, {90000, 176}};
+    const int nt = (int)(sizeof tab / sizeof tab[0]);
+    if (slots <= tab[0].slots) d.bound_iters = tab[0].iters;
+    else if (slots >= tab[nt - 1].slots) d.bound_iters = tab[nt - 1].iters;
+    else {
+        int i = 1;
+        while (tab[i].slots < slots) ++i;
+        // integer interpolation in log2(slots): position of `slots` between the two knots in 1/64 steps
+        auto lg64 = [](int64_t v) { int l = 63 - __builtin_clzll((unsigned long long)v); return (int64_t)l * 64 + (((v << 6) >> l) - 64); };
+        const int64_t a = lg64(tab[i - 1].slots), b = lg64(tab[i].slots), x = lg64(slots);
+        d.bound_iters = (int)(tab[i - 1].iters + (tab[i].iters - tab[i - 1].iters) * (x - a) / std::max<int64_t>(b - a, 1));
+    }
+    d.bound_iters = std::max(16, d.bound_iters / 8 * 8);
+    // KAO-CX: a topic counts as stalled after 8 launches without improvement and is revisited every 32 launches (a call is
+    // skipped anyway while the incumbent is the one KAO-CX last ran to a fixpoint on); a call runs at most 12 rounds (6 on
+    // topics beyond 30,000 slots, where a round costs as much as several launches)
     const int64_t it = std::max(iters_per_launch, 1);
-    d.cx_stall_iters = it * (slots <= 8192 ? 24 : 6);
-    d.cx_due_iters = d.cx_stall_iters * 6;
+    d.cx_stall_iters = it * 8;
+    d.cx_due_iters = it * 32;
     d.cx_rounds = slots <= 32768 ? 12 : 6;
     return d;
 }

@@ -9,6 +9,7 @@ from kafka_assignment_optimizer_amd import synthetic as sy
 
 what = set((sys.argv[1] if len(sys.argv) > 1 else "family").split(","))
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+SCHEDS = [int(v) for v in os.environ.get("R3_SCHEDS", "0,1").split(",")]
 kao.init(0)
 OUT = "gpurun_out"
 os.makedirs(OUT, exist_ok=True)
@@ -35,7 +36,7 @@ def line(tag, B, R, P, dseed, r, dt, tm):
 
 
 if "family" in what:
-    for sched in (0, 1):
+    for sched in SCHEDS:
         proven, gaps = 0, []
         for (B, R, P) in FAMILY:
             for dseed in (1, 2):
@@ -46,7 +47,7 @@ if "family" in what:
         print(f"family sched{sched}: proven {proven}/{len(gaps)}; gaps of the others {sorted(g for g in gaps if g)}", flush=True)
 
 if "scale" in what:
-    for sched in (0, 1):
+    for sched in SCHEDS:
         for (B, R, P) in SCALE:
             r, dt, tm = run(topic(B, R, P), seed=3, time_limit_s=budget, schedule=sched)
             print(line(f"scale sched{sched}", B, R, P, 1, r, dt, tm), flush=True)
