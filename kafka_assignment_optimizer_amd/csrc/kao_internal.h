@@ -15,8 +15,6 @@ constexpr int kRackTab = 256;    // entries of the per-rack LDS tables (rack siz
 constexpr uint32_t kNoneW = 0xFFFFFFFFu;  // empty slot in the LDS word layout (x | rack << 16)
 constexpr uint32_t kKeyNull = 0xFFFFFFFFu;
 constexpr int kDBias = 32768;
-constexpr int kNoCand = 1 << 14;  // K-search REPLACE scan: violation delta of the reserved "no candidate" RT entry -- with any penalty >= 1 the
-                                  // move cost exceeds every acceptable one (cost <= 0), so such a lane can never supply an accepted move
 constexpr int kDualLog2 = 16;
 constexpr int kDualScale = 1 << kDualLog2; // fixed point of the dual multipliers (K-bound): 65536 = 1.  (4096 until round 2: Polyak steps
                                           // below one unit of the last place truncate to zero and the iterate freezes -- 300 x 2000: stuck at
@@ -134,7 +132,7 @@ struct BoundWide {
     int32_t chunk;               // partitions per slice (a multiple of 64)
 };
 
-// per-rack LDS tables of K-search (rack sizes, K, RT): entries for `maxR` racks plus the reserved "no candidate" slot, rounded to 64
+// per-rack LDS tables of K-search (rack sizes, K, RT): entries for `maxR` racks plus one for the padding marker, rounded to 64
 constexpr int search_rack_tab(int maxR) { return ((maxR < 1 ? 1 : maxR) + 1 + 63) & ~63; }
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4, bool bw = false, int maxR = kRackTab - 1);
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne = 4);

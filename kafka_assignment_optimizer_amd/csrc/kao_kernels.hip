@@ -183,18 +183,17 @@ template <int NW> __device__ __forceinline__ int part_rack_viol(const TopicRegs 
 template <int NW> struct WaveLds {
     Part<NW> *A;  // [P] this restart's assignment, NW words per partition
     uint32_t *C;  // [Bx] replicas | leaders << 16 per broker
-    uint32_t *W;  // [Bx] band state of every broker, derived from C and kept current with it (see band_fields)
+    uint16_t *W;  // [Bx] band state of every broker, derived from C and kept current with it (see band_fields); bit 15 = no candidate
     int *K;       // [krt] replicas per rack (krt = search_rack_tab(largest rack count of the launch group))
-    int *RT;      // [krt] scratch: rack-dependent part of a REPLACE delta for the slot being scanned; RT[krt - 1] is the
-                  //       reserved "no candidate" slot (a delta no move survives)
+    int *RT;      // [krt] scratch: rack-dependent part of a REPLACE delta for the slot being scanned
 };
 
 // Band state of one broker, precomputed from its counter word c = replicas | leaders << 16 so that delta evaluation costs
 // one v_bfe_i32 per row instead of two compares, a select and a subtract.  Replica row (C3) in bits 5:0, leader row (C4) in
 // bits 11:6, each: signed 2-bit dinc = band(c + 1) - band(c), signed 2-bit ddec = band(c - 1) - band(c) (README.md:158-166),
-// and the two flags that say where a search price applies (p_in / p_out).  The upper half of the W word holds
-// the LDS address (>> 2) of the broker's rack entry in RT -- or of the reserved "no candidate" slot for padding indices and,
-// during a REPLACE scan, for the brokers already in the partition (row C5, README.md:168-171).
+// and the two flags that say where a search price applies (p_in / p_out).  Bit 15 marks an index that is no candidate: padding
+// slots of the rack-major index space always, and during a REPLACE scan the brokers already in the partition (row C5,
+// README.md:168-171).
 constexpr int kWIncR = 0, kWDecR = 2, kWPinR = 4, kWPoutR = 5, kWIncL = 6, kWDecL = 8, kWPinL = 10, kWPoutL = 11;
 __device__ __forceinline__ int wfld(uint32_t w, int off) { return __builtin_amdgcn_sbfe((int)w, (unsigned)off, 2u); }
 __device__ __forceinline__ int wfldw(uint32_t w, int off, uint32_t width) { return __builtin_amdgcn_sbfe((int)w, (unsigned)off, width); }   // width 0 -> 0
@@ -223,17 +222,10 @@ __device__ __forceinline__ uint32_t band_entry(int c, int lo, int hi) {
 __device__ __forceinline__ uint32_t band_fields(const TopicRegs &T, uint32_t c) {
     return band_entry((int)(c & 0xFFFFu), T.rep_lo, T.rep_hi) | (band_entry((int)(c >> 16), T.lead_lo, T.lead_hi) << 6);
 }
-// LDS byte address of a __shared__ object (the low 32 bits of its generic address are the LDS offset on gfx9)
-__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
-typedef __attribute__((address_space(3))) int lds_int_t;
-__device__ __forceinline__ int lds_read_i32(uint32_t byte_addr) { return *reinterpret_cast<const lds_int_t *>((uintptr_t)byte_addr); }
-// W[x] for every index of the topic: fields from the counters, RT entry of the broker's rack (XR: rack of x, 0xFF = padding)
-template <int NW> __device__ __forceinline__ void rebuild_band_state(const TopicRegs &T, const WaveLds<NW> &L, const uint8_t *XR, int krt, int lane) {
-    const uint32_t rt0 = lds_addr(L.RT) >> 2;
-    for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) {
-        const uint32_t r = XR[x];
-        L.W[x] = r == 0xFFu ? ((rt0 + (uint32_t)krt - 1u) << 16) : (((rt0 + r) << 16) | band_fields(T, L.C[x]));
-    }
+constexpr uint32_t kWNoCand = 0x8000u;
+// W[x] for every index of the topic (XR: rack of x, `inv` = padding)
+template <int NW> __device__ __forceinline__ void rebuild_band_state(const TopicRegs &T, const WaveLds<NW> &L, const uint8_t *XR, uint32_t inv, int lane) {
+    for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) L.W[x] = (uint16_t)(XR[x] == inv ? kWNoCand : band_fields(T, L.C[x]));
 }
 
 // rebuild C and K from A (lanes stride partitions; LDS atomics)
@@ -311,27 +303,28 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     asm volatile("" : "+v"(T.rep_lo), "+v"(T.rep_hi), "+v"(T.lead_lo), "+v"(T.lead_hi));
 
     // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[krt]] [XR u8[Bx rounded to 64]] then per wave
-    //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [W u32[same]] [K int[krt]] [RT int[krt]]        (* only when !kGlobalA)
-    //      krt = search_rack_tab(largest rack count of the launch group): the racks plus the reserved "no candidate" entry
+    //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [W u16[same]] [K int[krt]] [RT int[krt]]        (* only when !kGlobalA)
+    //      krt = search_rack_tab(largest rack count of the launch group): the racks plus one entry for the padding marker
     const int a_bytes = kGlobalA ? 0 : prm.maxP * NW * 4;
     const int bx64 = (prm.maxBx + 63) & ~63;
     const int c_bytes = bx64 * 4;
     const int krt = search_rack_tab(prm.maxR);
     int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
-    uint8_t *XR = smem + a_bytes + krt * 4;  // rack of internal index x, 0xFF = padding slot / beyond Bx
+    uint8_t *XR = smem + a_bytes + krt * 4;  // rack of internal index x, inv = krt - 1 (never a rack) = padding slot / beyond Bx
+    const uint32_t inv = (uint32_t)krt - 1u;
     uint32_t *PR = reinterpret_cast<uint32_t *>(smem + a_bytes + krt * 4 + bx64);  // [bx64] packed prices (kPriced only)
     const bool hbw = kPriced && prm.bw != 0;   // the launch group carries broker weights (their table is carved only then)
     const int pr_bytes = kPriced ? (hbw ? 2 : 1) * c_bytes + krt * 4 : 0;
     int *PG = reinterpret_cast<int *>(smem + a_bytes + krt * 4 + bx64 + c_bytes);  // [krt] rack prices (kPriced only)
     uint32_t *BW = reinterpret_cast<uint32_t *>(smem + a_bytes + krt * 4 + bx64 + c_bytes + krt * 4);  // [bx64] broker weights (kPriced only)
-    unsigned char *wb = smem + a_bytes + krt * 4 + bx64 + pr_bytes + wave * (a_bytes + 2 * c_bytes + krt * 8);  // blockDim.x / 64 waves
+    unsigned char *wb = smem + a_bytes + krt * 4 + bx64 + pr_bytes + wave * (a_bytes + c_bytes + c_bytes / 2 + krt * 8);  // blockDim.x / 64 waves
     const Part<NW> *cur_words = reinterpret_cast<const Part<NW> *>(pl.cur_pool + TD->cur_off);  // host-prepared words x | rack << 16 (0xFFFFFFFF = none); cur_off counts words
     const Part<NW> *CUR;
     if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const Part<NW> *>(smem);
     WaveLds<NW> L;
     L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
-    L.W = reinterpret_cast<uint32_t *>(wb + a_bytes + c_bytes);
-    L.K = reinterpret_cast<int *>(wb + a_bytes + 2 * c_bytes);
+    L.W = reinterpret_cast<uint16_t *>(wb + a_bytes + c_bytes);
+    L.K = reinterpret_cast<int *>(wb + a_bytes + c_bytes + c_bytes / 2);
     L.RT = L.K + krt;
 
     // ---- stage the rack sizes / rack-of-index table (and, when it fits, the current-assignment words) ----
@@ -347,7 +340,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     for (int x = threadIdx.x; x < ((T.Bx + 63) & ~63); x += blockDim.x) {
         const uint32_t r = mulhi((uint32_t)x, T.magic);
         const bool valid = x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)krt ? r : 0];
-        XR[x] = valid ? (uint8_t)r : (uint8_t)0xFF;
+        XR[x] = valid ? (uint8_t)r : (uint8_t)inv;
         if (kPriced) {  // prices of broker x in key units: replica price a[b] | leader price l[b] << 16
             uint32_t pr = 0;
             if (valid) {
@@ -447,9 +440,9 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         const uint32_t x = (uint32_t)(base + lane);
                         const uint32_t r = XR[x];
                         const uint32_t xw = x | (r << 16);
-                        const bool okx = (r != 0xFFu) & !in4(a, xw);
+                        const bool okx = (r != inv) & !in4(a, xw);
                         const uint32_t cn = L.C[x];
-                        const uint32_t rk = r == 0xFFu ? 0u : r;   // padding lanes (no candidate anyway) read entry 0
+                        const uint32_t rk = r;   // (padding lanes, no candidates anyway, read the spare entry krt - 1)
                         int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[rk], T.rack_lo, T.rack_hi) +
                                  dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
                         if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
@@ -482,9 +475,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     int V, obj;
     full_cost(T, L, CUR, RSZ, lane, V, obj, hbw ? BW : nullptr);
     if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
-    rebuild_band_state(T, L, XR, krt, lane);          // W from the counters; kept current by every accepted move below
-    // the reserved RT entry: a violation delta (unpriced) / a rack price above the violation byte (priced) that no move survives
-    if (lane == 0) L.RT[krt - 1] = kPriced ? (1 << 28) : kNoCand;
+    rebuild_band_state(T, L, XR, inv, lane);          // W from the counters; kept current by every accepted move below
+    if (lane == 0) L.RT[krt - 1] = 0;                 // the spare entry padding lanes read
 
     // ---- per-lane RNG stream of this launch (LCG mod 2^24, re-keyed every launch) ----
     uint32_t rng = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + prm.launch * 0x85EBCA77u + (uint32_t)lane * 0xC2B2AE3Du));
@@ -691,7 +683,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 uint32_t w_keep = 0;
                 if (mine) {
                     w_keep = L.W[ai & 0xFFFFu];
-                    L.W[ai & 0xFFFFu] = (w_keep & 0xFFFFu) | (((lds_addr(L.RT) >> 2) + (uint32_t)krt - 1u) << 16);
+                    L.W[ai & 0xFFFFu] = (uint16_t)(w_keep | kWNoCand);
                 }
                 const bool hm_l = (lane < NW) & (ci != kNoneW) & !in4(a, ci);
                 const int mr_l = hm_l ? (int)((ci & 0xFFFFu) >> 6) : -1;
@@ -719,8 +711,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     int rd = 0;
                     for (int base = cb; base < cend; base += 64, ++rd) {
                         const uint32_t st = lcg24(rng);   // tie bits = bits 8..15 of the draw, as make_key_tie(lcg24 >> 8)
-                        const uint32_t w = L.W[base + lane];
-                        const int rt = lds_read_i32((w >> 16) << 2);
+                        const int w = (int)(short)L.W[base + lane];   // sign-extended: bit 15 fills the upper half
+                        const int rt = L.RT[XR[base + lane]];
                         int dsc;
                         if (kPriced) {   // RT entry: violation delta in the low byte, rack price above it
                             const uint32_t prx = PR[base + lane];
@@ -740,11 +732,12 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                             dsc -= __mul24(S, role_w2(c, x | ((uint32_t)XR[x] << 16), wl, wf));
                         }
                         dsc = min(max(dsc, 0), 2 * kDBias - 2);
-                        bestc = min(bestc, ((uint32_t)dsc << 16) | (st & 0xFF00u) | (uint32_t)rd);
+                        // a "no candidate" index gets a cost field of 0xFFFF: above every real cost (<= 2 * kDBias - 2) and never accepted
+                        bestc = min(bestc, ((uint32_t)dsc << 16) | (st & 0xFF00u) | (uint32_t)rd | ((uint32_t)w & 0xFFFF0000u));
                     }
                     if ((bestc >> 8) < (bestA >> 8)) { bestA = bestc; chunkA = cb; }   // strict: ties stay with the earlier round
                 }
-                if (mine) L.W[ai & 0xFFFFu] = w_keep;
+                if (mine) L.W[ai & 0xFFFFu] = (uint16_t)w_keep;
                 key = bestA >> 8;   // (cost + bias) << 8 | tie: the key format of every other move type
                 kmin = wave_umin(key);
                 const unsigned long long bal = __ballot(key == kmin);
@@ -848,7 +841,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             const uint32_t xo = (uint32_t)__builtin_amdgcn_readlane((int)uw, win) & 0xFFFFu, xn = (uint32_t)__builtin_amdgcn_readlane((int)vw, win) & 0xFFFFu;
             if (lane < 2) {
                 const uint32_t xx = lane ? xn : xo;
-                L.W[xx] = (L.W[xx] & 0xFFFF0000u) | band_fields(T, L.C[xx]);
+                L.W[xx] = (uint16_t)band_fields(T, L.C[xx]);
             }
         }
         if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the winner's stores before the next loads
@@ -1091,7 +1084,7 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
     L.C = reinterpret_cast<uint32_t *>(smem + kRackTab * 4 + bx64);
     L.K = reinterpret_cast<int *>(smem + kRackTab * 4 + bx64 + bx64 * 4);
     L.RT = L.K;  // unused here
-    L.W = L.C;   // unused here
+    L.W = reinterpret_cast<uint16_t *>(L.C);   // unused here
     for (int r = lane; r < kRackTab; r += 64) RSZ[r] = r < T.R ? rsz[r] : 0;
     __syncthreads();
     for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) {
@@ -1180,7 +1173,7 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
 // ------------------------------------------------------------------------------------------------
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw, int maxR) {
     const size_t a = global_a ? 0 : (size_t)maxP * 4 * (size_t)nw, bx64 = ((size_t)maxBx + 63) & ~(size_t)63, krt = (size_t)search_rack_tab(maxR);
-    return a + krt * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + krt * 4 : 0) + (size_t)waves * (a + bx64 * 8 + krt * 8);
+    return a + krt * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + krt * 4 : 0) + (size_t)waves * (a + bx64 * 6 + krt * 8);
 }
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 2 * (size_t)ne + 15) & ~(size_t)15 : 0;

@@ -41,12 +41,16 @@ DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
         d.bound_iters = (int)(tab[i - 1].iters + (tab[i].iters - tab[i - 1].iters) * (x - a) / std::max<int64_t>(b - a, 1));
     }
     d.bound_iters = std::max(16, d.bound_iters / 8 * 8);
-    // KAO-CX: a topic counts as stalled after 8 launches without improvement and is revisited every 32 launches (a call is
+    // KAO-CX pays on a MATURE incumbent: called while K-search still improves it lands in a basin neither comes out of again
+    // (24 drifted topics of 1,000-4,000 partitions, 3 s each: first call after 32 launches: 10 proven; after 144: 15).  So a
+    // topic counts as stalled after 24 launches without improvement and is otherwise looked at every 144 launches (a call is
     // skipped anyway while the incumbent is the one KAO-CX last ran to a fixpoint on); a call runs at most 12 rounds (6 on
-    // topics beyond 30,000 slots, where a round costs as much as several launches)
+    // topics beyond 30,000 slots, where a round costs as much as several launches).  Test hooks KAO_DET_CX_STALL_L / _DUE_L
+    // give both in launches.
     const int64_t it = std::max(iters_per_launch, 1);
-    d.cx_stall_iters = it * 8;
-    d.cx_due_iters = it * 32;
+    auto env_l = [](const char *name, int64_t dflt) { const char *e = std::getenv(name); return e && *e ? (int64_t)std::atoll(e) : dflt; };
+    d.cx_stall_iters = it * env_l("KAO_DET_CX_STALL_L", 24);
+    d.cx_due_iters = it * env_l("KAO_DET_CX_DUE_L", 144);
     d.cx_rounds = slots <= 32768 ? 12 : 6;
     return d;
 }

@@ -672,7 +672,7 @@ def test_solve_is_deterministic(kao, ko):
             outs.append((r.status, r.objective, r.upper_bound, r.assignment.tolist(), tm["launches"], tm["bound_launches"], tm["bound_iters"],
                          tm["cx_calls"], tm["cx_gains"], tm["search_iters"]))
         assert outs[0] == outs[1] == outs[2], [(o[:3], o[4:]) for o in outs]
-        assert outs[0][6] > 0 and (ml == 0 or outs[0][4] == ml)
+        assert outs[0][6] > 0 and (ml == 0 or outs[0][4] <= ml)
 
 
 # ------------------------------------------------------------------------------- K-bound (Lagrangian dual certificate)

@@ -52,6 +52,20 @@ if "scale" in what:
             r, dt, tm = run(topic(B, R, P), seed=3, time_limit_s=budget, schedule=sched)
             print(line(f"scale sched{sched}", B, R, P, 1, r, dt, tm), flush=True)
 
+if "seeds" in what:
+    # would independent re-runs (another seed) inside the same budget prove more topics than one long run?
+    n_any = n_long = 0
+    for (B, R, P) in FAMILY:
+        for dseed in (1, 2):
+            t = topic(B, R, P, dseed)
+            got = []
+            for sd in (3, 4, 5):
+                r, dt, tm = run(t, seed=sd, time_limit_s=budget / 3.0, schedule=0)
+                got.append((r.status == "OPTIMAL_PROVEN", r.objective, r.upper_bound, round(dt, 2)))
+            n_any += any(g[0] for g in got)
+            print(f"seeds B={B:4d} R={R:2d} P={P:5d} d{dseed}: three runs of {budget / 3.0:.2f}s: {got}", flush=True)
+    print(f"seeds: proven by any of three short runs {n_any}/24", flush=True)
+
 if "determinism" in what:
     for (B, R, P, ml) in ((100, 5, 1000, 400), (300, 6, 2000, 300), (500, 10, 5000, 120)):
         t = topic(B, R, P)
