@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KAO_VERSION 101 /* 0.1.1: kao_opts.schedule, kao_last_solve_timing out[12] */
+#define KAO_VERSION 101 /* 0.1.1: kao_opts.schedule, kao_session_new_generation, kao_last_solve_timing out[16] */
 #define KAO_NONE 0xFFFFu /* "no broker": replica on a broker outside the target set / empty slot */
 #define KAO_MAX_RF 8     /* replica slots per partition supported by the gfx950 kernels (RF <= 4: one 128-bit word group per
                             partition; 5..8: two) */
@@ -199,6 +199,13 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
  * into one packed key per topic.  Asynchronous on the session's stream. */
 int kao_session_step(kao_session *s);
 int kao_session_sync(kao_session *s);
+/* Starts a new GENERATION of the population: the next kao_session_step re-initialises every restart of every topic from the
+ * current assignment (best insertion; the tie-break hash carries the generation number, so the new population differs from
+ * the first), and the best snapshots and packed best keys of the old generation are dropped -- read kao_session_best first.
+ * K-bound's state, the search prices and the launch counter carry on.  kao_solve does this when a population has converged
+ * on an incumbent it cannot prove optimal (the incumbent itself is kept on the host); also a test hook of the bit-exact
+ * replay (oracle/kao_port.c re-initialises the same way). */
+int kao_session_new_generation(kao_session *s);
 /* Copy back per-topic bests (results[n_topics], assignment buffers caller-allocated). */
 int kao_session_best(kao_session *s, kao_result *results);
 /* Per-topic packed best keys as the device holds them (uint64[n_topics]); the value a
@@ -317,8 +324,9 @@ int kao_rccl_loopback_counts(uint64_t out[2]);
  * out[2] results read back, out[3] returned (buffers released); out[4] = launches run; out[5] = neighbours K-search
  * delta-evaluated in those launches (kao_stats.delta_candidates, all devices), out[6] = K-bound launches, out[7] = elite
  * exchanges between GPUs (kao_solve_multi), out[8] = K-bound iterations summed over the topics, out[9] = KAO-CX calls,
- * out[10] = KAO-CX calls that improved an incumbent, out[11] = K-search iterations per restart. */
-int kao_last_solve_timing(double out[12]);
+ * out[10] = KAO-CX calls that improved an incumbent, out[11] = K-search iterations per restart, out[12] = generations started
+ * after the first (kao_session_new_generation), out[13..15] reserved (0). */
+int kao_last_solve_timing(double out[16]);
 
 #ifdef __cplusplus
 }

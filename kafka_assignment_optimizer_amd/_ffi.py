@@ -63,6 +63,7 @@ SIGNATURES = {
     "kao_session_create": (C.c_int, [_P(KaoTopic), C.c_int32, _P(KaoOpts), _P(C.c_void_p)]),
     "kao_session_step": (C.c_int, [C.c_void_p]),
     "kao_session_sync": (C.c_int, [C.c_void_p]),
+    "kao_session_new_generation": (C.c_int, [C.c_void_p]),
     "kao_session_best": (C.c_int, [C.c_void_p, _P(KaoResult)]),
     "kao_session_best_keys": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "kao_session_device_keys": (C.c_int, [C.c_void_p, _P(C.c_void_p)]),

@@ -33,7 +33,7 @@ int num_cu(int device);
 int require_init();               // kao_init on first use, then hipSetDevice(cur_device())
 bool is_init();
 extern thread_local int t_device; // per-thread override: kao_solve_multi drives several devices from one process
-extern thread_local double g_timing[12];   // wall-clock breakdown of the last solve (kao_last_solve_timing)
+extern thread_local double g_timing[16];   // wall-clock breakdown of the last solve (kao_last_solve_timing)
 
 // ---- the model on the host (kao_model.cpp) ----
 int validate(const kao_topic *t);
@@ -159,6 +159,9 @@ struct kao_session {
     std::vector<unsigned char> h_readback;
     hipStream_t stream = nullptr;
     uint32_t launch = 0;
+    uint32_t gen = 0;            // generation of the population (kao_session_new_generation)
+    bool reinit = false;         // the next step re-initialises every restart (first launch of a new generation)
+    size_t best_bytes = 0;       // size of the snapshot pool d_best
     // profiling
     std::vector<hipEvent_t> ev;  // triples
     int ev_pending = 0;

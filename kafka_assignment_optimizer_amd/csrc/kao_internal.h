@@ -69,6 +69,8 @@ struct SearchParams {
     int32_t init;                // 1 = build the initial state of every restart first
     int32_t maxP, maxBx;         // LDS carve sizes
     int32_t bw;                  // 1 = topics of this launch carry broker weights (priced instantiation: the weight table is carved)
+    uint32_t gen;                // generation of the population: salts the tie-break hash of the initial state (init = 1 with gen > 0 =
+                                 //     kao_solve re-initialises every restart after a population converged without a proof)
     int32_t elite;               // 1 = restarts that trail their topic's best feasible objective may re-seed from it (KAO-LS
                                  //     "elite" rule)
 };

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                     if ((k == 0) != (pass == 0)) continue;  // this pass handles the other kind of slot
                     if (a.w[k] != kNoneW) continue;  // wave-uniform
                     // best insertion: every valid broker not in the partition, 64 per round (lane = internal index)
-                    const uint32_t hmix = slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * NW + k) * 0x27D4EB2Fu + 0x5BD1E995u);
+                    const uint32_t hmix = slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * NW + k) * 0x27D4EB2Fu + 0x5BD1E995u + prm.gen * 0x632BE5ABu);
                     const int wl = k == 0 ? T.w00 : T.w01, wf = k == 0 ? T.w10 : T.w11;
                     uint32_t key = kKeyNull, xw_l = kNoneW;
                     for (int base = 0; base < T.Bx; base += 64) {

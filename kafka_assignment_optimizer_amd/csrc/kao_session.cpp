@@ -16,7 +16,7 @@
 namespace kao {
 
 thread_local int t_device = -1;
-thread_local double g_timing[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_timing[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace {
 thread_local std::string g_err;
@@ -710,7 +710,8 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     // restart states / info / obj / viol are fully written by launch 0 (init) and the first K-eval; only the
     // snapshots ("no snapshot" = all KAO_NONE), the keys (all ones) and the drift counter need initial values
     hipError_t e1 = hipMemcpyAsync(ro, stage.data(), ro_bytes, hipMemcpyHostToDevice, s->stream);
-    hipError_t e2 = hipMemsetAsync(s->d_best, 0xFF, best_u16 * 2 ? best_u16 * 2 : 2, s->stream);
+    s->best_bytes = best_u16 * 2 ? best_u16 * 2 : 2;
+    hipError_t e2 = hipMemsetAsync(s->d_best, 0xFF, s->best_bytes, s->stream);
     hipError_t e3 = hipMemsetAsync(s->d_readback, 0xFF, (size_t)n_topics * 8, s->stream);
     hipError_t e4 = hipMemsetAsync(s->d_drift, 0, 16, s->stream);
     if (e4 == hipSuccess) e4 = hipMemsetAsync(s->d_price, 0, price_b ? price_b : 4, s->stream);  // no prices yet
@@ -740,7 +741,9 @@ int kao_session_step(kao_session *s) {
     sp.state_pool = s->d_state; sp.best_pool = s->d_best; sp.restart_info = s->d_info; sp.drift = s->d_drift;
     SearchParams prm{};
     prm.obj_scale = s->opts.obj_scale; prm.lam_min = s->opts.lam_min; prm.lam_max = s->opts.lam_max;
-    prm.launch = s->launch; prm.iters = (uint32_t)s->opts.iters_per_launch; prm.init = s->launch == 0 ? 1 : 0;
+    prm.launch = s->launch; prm.iters = (uint32_t)s->opts.iters_per_launch; prm.init = (s->launch == 0 || s->reinit) ? 1 : 0;
+    prm.gen = s->gen;
+    s->reinit = false;
     const int eper = s->opts.elite_period;
     prm.bw = s->any_bw ? 1 : 0;
     prm.elite = (eper > 0 && s->launch > 0 && s->launch % (uint32_t)eper == 0) ? 1 : 0;
@@ -775,6 +778,20 @@ int kao_session_step(kao_session *s) {
         s->search_bytes_total += n * (uint64_t)(8 * pt.d.RF + 10);
     }
     s->launch++;
+    return KAO_OK;
+}
+
+// A new generation of the population: the next step re-initialises every restart from the current assignment (best
+// insertion, tie-break hash salted with the generation number), the snapshots and packed best keys of the old generation are
+// dropped -- the caller has read what it wants to keep (kao_solve keeps the incumbent on the host).  K-bound state, prices
+// and the launch / iteration counters carry on.
+int kao_session_new_generation(kao_session *s) {
+    if (!s) return fail(KAO_ERR_INVALID, "null session");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemsetAsync(s->d_best, 0xFF, s->best_bytes, s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_readback, 0xFF, (size_t)s->n_topics * 8, s->stream));   // packed best keys: none
+    s->gen++;
+    s->reinit = true;
     return KAO_OK;
 }
 

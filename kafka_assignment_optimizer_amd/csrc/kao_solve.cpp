@@ -95,11 +95,23 @@ struct SolveRun {
     std::vector<int64_t> i_improved, i_cx;        // per topic: iteration count at the last improvement / the last KAO-CX call
     bool trace = false;                           // KAO_SOLVE_TRACE=1: one line per launch on stderr (timings; never read back)
     double t_prev = 0;
+    // Generations (deterministic schedule, kao_solve): independent runs of the same topic end 1-2 units apart -- which basin a
+    // population converges to is decided early -- so a population that has converged (KAO-CX at a fixpoint of its best, nothing
+    // new for `gen_stall_iters`) without a proof is replaced: the incumbent moves to the host, every restart is re-initialised
+    // with the generation number in its tie-break hash (kao_session_new_generation), and K-bound, its certificate and its
+    // prices carry on, so later generations search under converged prices from their first launch.  The answer is the best
+    // incumbent of all generations.
+    bool gens_on = false;
+    int generations = 0;
+    int64_t gen_stall_iters = 0, gen_start = 0;
+    std::vector<uint64_t> dkeys, gprev;           // packed best keys of the CURRENT generation as the device holds them; their record
+    std::vector<uint64_t> inc_key;                // best incumbent of the earlier generations (host copy), ~0 = none
+    std::vector<std::vector<uint16_t>> inc_assign;
 
     ~SolveRun() { for (CycleCtx *c : cx_ctx) cycle_close(c); if (s) kao_session_destroy(s); }
 
     // `so` is the caller's options with kao_solve's defaults applied; the session is created on the calling thread's device
-    int begin(const kao_topic *user_topics, int n_topics, const kao_opts &so, const int64_t *tgt, double t_start, bool allow_islands = false) {
+    int begin(const kao_topic *user_topics, int n_topics, const kao_opts &so, const int64_t *tgt, double t_start, bool allow_islands = false, bool allow_gens = false) {
         t0 = t_start;
         n_user = n_topics;
         // Islands (kao_opts.islands > 1, off by default): every topic is searched as several independent copies (own seed,
@@ -128,6 +140,7 @@ struct SolveRun {
         has_target = tgt != nullptr;
         if (tgt) { target.resize((size_t)n); for (int i = 0; i < n; ++i) target[(size_t)i] = tgt[origin[(size_t)i]]; }
         keys.assign((size_t)n, 0); prev.assign((size_t)n, ~0ull); t_best.assign((size_t)n, 0.0); dual_target.assign((size_t)n, -1);
+        dkeys.assign((size_t)n, ~0ull); gprev.assign((size_t)n, ~0ull); inc_key.assign((size_t)n, ~0ull); inc_assign.assign((size_t)n, {});
         this->topics = topics;
         t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
         cx_on = so.use_cycles >= 0;
@@ -156,14 +169,21 @@ struct SolveRun {
             cx_stall_iters = env_i("KAO_DET_CX_STALL", cx_stall_iters); cx_due_iters = env_i("KAO_DET_CX_DUE", cx_due_iters);
             cx_rounds = (int)env_i("KAO_DET_CX_ROUNDS", cx_rounds);
         }
+        gens_on = allow_gens && det && cx_on && !has_target;
+        { const char *e = std::getenv("KAO_DET_GEN"); if (e && e[0] == '0') gens_on = false; }
+        gen_stall_iters = 32 * (int64_t)std::max(o.iters_per_launch, 1);
+        { const char *e = std::getenv("KAO_DET_GEN_STALL_L"); if (e && *e) gen_stall_iters = std::atoll(e) * (int64_t)std::max(o.iters_per_launch, 1); }
         { const char *e = std::getenv("KAO_SOLVE_TRACE"); trace = e && e[0] == '1'; }
         t_prev = t_start;
         use_prices = so.use_prices >= 0;
         return KAO_OK;
     }
     int launch() { return kao_session_step(s); }   // asynchronous
+    // keys = the best over all generations (what "done", the K-bound targets and the answer go by); dkeys = this generation's
     bool feasible(int i) const { return (keys[(size_t)i] >> 44) == 0; }
     int64_t objective(int i) const { return (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF); }
+    bool gfeasible(int i) const { return (dkeys[(size_t)i] >> 44) == 0; }
+    int64_t gobjective(int i) const { return (int64_t)kObjCap - (int64_t)((dkeys[(size_t)i] >> 20) & 0xFFFFFF); }
     bool topic_done(int i) const {
         if (s->topic_infeasible[(size_t)i]) return true;  // proven infeasible: nothing to wait for
         const int64_t goal = has_target ? target[(size_t)i] : s->ub[(size_t)i];
@@ -190,27 +210,30 @@ struct SolveRun {
     }
     // waits for the launch, books improvements, merges a finished K-bound launch and starts the next one
     int after_launch() {
-        int rc = kao_session_best_keys(s, keys.data());
+        int rc = kao_session_best_keys(s, dkeys.data());
         if (rc) return rc;
         ++launches;
         iters_done += s->opts.iters_per_launch;
         const double t = now_s() - t0;
-        for (int i = 0; i < n; ++i)
-            if (keys[(size_t)i] < prev[(size_t)i]) {
-                prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; t_improved[(size_t)i] = t; i_improved[(size_t)i] = iters_done;
-            }
+        for (int i = 0; i < n; ++i) {
+            if (dkeys[(size_t)i] < gprev[(size_t)i]) { gprev[(size_t)i] = dkeys[(size_t)i]; t_improved[(size_t)i] = t; i_improved[(size_t)i] = iters_done; }
+            keys[(size_t)i] = std::min(dkeys[(size_t)i], inc_key[(size_t)i]);
+            if (keys[(size_t)i] < prev[(size_t)i]) { prev[(size_t)i] = keys[(size_t)i]; t_best[(size_t)i] = t; t_last_improve = t; }
+        }
         all_done = check_done();
         const double t_search = now_s();
         if ((rc = service_bound())) return rc;
         const double t_bound = now_s();
         const int cx0 = cx_calls;
         if (cx_on && !all_done && !has_target && (rc = cycles(t))) return rc;
+        if (gens_on && !all_done && (rc = maybe_new_generation())) return rc;
         if (trace) {
             const double t_end = now_s();
             int64_t obj0 = feasible(0) ? objective(0) : -1;
             std::fprintf(stderr, "[kao-solve] launch %d t %.4f search+sync %.3f ms, bound service %.3f ms (last K-bound launch %.3f ms / %d it, next %d it), cx %d calls %.3f ms | topic0 obj %lld ub %lld\n",
                          launches, t_end - t0, (t_search - t_prev) * 1e3, (t_bound - t_search) * 1e3, s->bound_ms_last, s->bound_iters_last, dual_now,
                          cx_calls - cx0, (t_end - t_bound) * 1e3, (long long)obj0, (long long)s->ub[0]);
+            if (gens_on) std::fprintf(stderr, "[kao-solve]   generation %d, its best %lld\n", generations, gfeasible(0) ? (long long)gobjective(0) : -1ll);
             t_prev = t_end;
         }
         return KAO_OK;
@@ -255,9 +278,9 @@ struct SolveRun {
     // improved it, comes back as the topic's incumbent (elite launches re-seed the restarts from it)
     int cycles(double t) {
         for (int i = 0; i < n; ++i) {
-            if (s->topic_infeasible[(size_t)i] || !feasible(i) || objective(i) >= s->ub[(size_t)i]) continue;
+            if (s->topic_infeasible[(size_t)i] || !gfeasible(i) || (feasible(i) && objective(i) >= s->ub[(size_t)i])) continue;
             if (!cycle_supported(&topics[i])) continue;
-            if ((keys[(size_t)i] >> 20) == (cx_seen[(size_t)i] >> 20)) continue;   // same incumbent as the last fixpoint
+            if ((dkeys[(size_t)i] >> 20) == (cx_seen[(size_t)i] >> 20)) continue;   // same incumbent as the last fixpoint
             if (det) {   // counts, not the clock: iterations since the last improvement / since the last call
                 const bool stalled = iters_done - i_improved[(size_t)i] >= cx_stall_iters, due = iters_done - i_cx[(size_t)i] >= cx_due_iters;
                 if (!cx_eager && (!(stalled || due) || iters_done - i_cx[(size_t)i] < cx_stall_iters)) continue;
@@ -269,7 +292,7 @@ struct SolveRun {
             cx_buf.resize(slots);
             int rc = session_topic_best(s, i, cx_buf.data());
             if (rc) return rc;
-            int64_t obj = objective(i);
+            int64_t obj = gobjective(i);
             int32_t st[8];
             if (!cx_ctx[(size_t)i] && !(cx_ctx[(size_t)i] = cycle_open(&topics[i], &rc))) return rc;
             // the clock only ends a deterministic call at the solve's own deadline (the stop condition)
@@ -281,21 +304,47 @@ struct SolveRun {
             const double t2 = now_s() - t0;
             t_cx[(size_t)i] = t2;
             i_cx[(size_t)i] = iters_done;
-            if (obj > objective(i)) {
+            if (obj > gobjective(i)) {
                 uint64_t key = 0;
                 if ((rc = session_adopt_external(s, i, cx_buf.data(), obj, &key))) return rc;
-                keys[(size_t)i] = prev[(size_t)i] = key;
-                t_best[(size_t)i] = t_improved[(size_t)i] = t_last_improve = t2;
+                dkeys[(size_t)i] = gprev[(size_t)i] = key;
+                t_improved[(size_t)i] = t2;
                 i_improved[(size_t)i] = iters_done;
+                if (key < keys[(size_t)i]) { keys[(size_t)i] = prev[(size_t)i] = key; t_best[(size_t)i] = t_last_improve = t2; }
                 ++cx_gains;
             }
-            if (fixpoint) cx_seen[(size_t)i] = keys[(size_t)i];
+            if (fixpoint) cx_seen[(size_t)i] = dkeys[(size_t)i];
             // a context holds ~90 B per broker pair on the device and as much on the host: keep a handful, not one per topic
             int open = 0;
             for (CycleCtx *c : cx_ctx) open += c != nullptr;
             if (open > 8) { cycle_close(cx_ctx[(size_t)i]); cx_ctx[(size_t)i] = nullptr; }
         }
         all_done = check_done();
+        return KAO_OK;
+    }
+    // every open topic's population has converged (its best is a fixpoint of KAO-CX and nothing has improved since): bank the
+    // incumbents and start the next generation
+    int maybe_new_generation() {
+        bool any_open = false;
+        for (int i = 0; i < n; ++i) {
+            if (topic_done(i)) continue;
+            any_open = true;
+            const int64_t quiet = iters_done - std::max(i_improved[(size_t)i], gen_start);
+            const bool cx_ok = cycle_supported(&topics[i]) && gfeasible(i);
+            if (cx_ok ? !((dkeys[(size_t)i] >> 20) == (cx_seen[(size_t)i] >> 20) && quiet >= gen_stall_iters) : quiet < cx_due_iters + gen_stall_iters) return KAO_OK;
+        }
+        if (!any_open) return KAO_OK;
+        int rc;
+        for (int i = 0; i < n; ++i) {
+            if (dkeys[(size_t)i] >= inc_key[(size_t)i] || !gfeasible(i)) continue;
+            inc_assign[(size_t)i].resize((size_t)topics[i].n_partitions * topics[i].rf);
+            if ((rc = session_topic_best(s, i, inc_assign[(size_t)i].data()))) return rc;
+            inc_key[(size_t)i] = dkeys[(size_t)i];
+        }
+        if ((rc = kao_session_new_generation(s))) return rc;
+        ++generations;
+        gen_start = iters_done;
+        for (int i = 0; i < n; ++i) { dkeys[(size_t)i] = gprev[(size_t)i] = ~0ull; i_improved[(size_t)i] = i_cx[(size_t)i] = iters_done; cx_seen[(size_t)i] = ~0ull; }
         return KAO_OK;
     }
     int finish(kao_result *results, bool hit_time) {
@@ -310,6 +359,18 @@ struct SolveRun {
             rs[(size_t)i].assignment = bufs[(size_t)i].data();
         }
         if ((rc = kao_session_best(s, rs.data()))) return rc;
+        for (int i = 0; i < n; ++i) {   // an earlier generation's incumbent that the current one has not beaten is the answer
+            const bool cur_ok = rs[(size_t)i].status != KAO_STATUS_NO_FEASIBLE && rs[(size_t)i].status != KAO_STATUS_INFEASIBLE_PROVEN;
+            if (inc_key[(size_t)i] == ~0ull || (inc_key[(size_t)i] >> 44) != 0) continue;
+            const int64_t inc_obj = (int64_t)kObjCap - (int64_t)((inc_key[(size_t)i] >> 20) & 0xFFFFFF);
+            if (cur_ok && rs[(size_t)i].objective >= inc_obj) continue;
+            kao_result &r = rs[(size_t)i];
+            r.objective = inc_obj; r.best_restart = -1;
+            std::memset(r.violations, 0, sizeof r.violations);
+            bufs[(size_t)i] = inc_assign[(size_t)i];
+            r.assignment = bufs[(size_t)i].data();
+            r.status = r.objective >= r.upper_bound ? KAO_STATUS_OPTIMAL_PROVEN : KAO_STATUS_FEASIBLE_BOUND_GAP;
+        }
         auto better = [](const kao_result &a, const kao_result &b) {   // feasible first, then objective
             const bool fa = a.status != KAO_STATUS_NO_FEASIBLE && a.status != KAO_STATUS_INFEASIBLE_PROVEN;
             const bool fb = b.status != KAO_STATUS_NO_FEASIBLE && b.status != KAO_STATUS_INFEASIBLE_PROVEN;
@@ -367,7 +428,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     if (!results) return fail(KAO_ERR_INVALID, "null results");
     const kao_opts so = solve_defaults(topics, n_topics, opts);
     SolveRun run;
-    int rc = run.begin(topics, n_topics, so, opts ? opts->target_objective : nullptr, t0, true);
+    int rc = run.begin(topics, n_topics, so, opts ? opts->target_objective : nullptr, t0, true, true);
     if (rc) return rc;
     g_timing[0] = now_s() - t0;
     const kao_opts &o = run.s->opts;
@@ -386,7 +447,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     g_timing[7] = 0;   // elite exchanges between GPUs: none on one device
     g_timing[8] = 0;   // K-bound iterations, summed over the topics
     for (int32_t v : run.s->dual_iters) g_timing[8] += (double)v;
-    g_timing[9] = run.cx_calls; g_timing[10] = run.cx_gains; g_timing[11] = (double)run.iters_done;
+    g_timing[9] = run.cx_calls; g_timing[10] = run.cx_gains; g_timing[11] = (double)run.iters_done; g_timing[12] = run.generations;
     kao_session_destroy(run.s);
     run.s = nullptr;
     g_timing[3] = now_s() - t0;
@@ -917,9 +978,9 @@ int kao_rccl_loopback_counts(uint64_t out[2]) {
     return KAO_OK;
 }
 
-int kao_last_solve_timing(double out[12]) {
+int kao_last_solve_timing(double out[16]) {
     if (!out) return fail(KAO_ERR_INVALID, "null out");
-    for (int i = 0; i < 12; ++i) out[i] = g_timing[i];
+    for (int i = 0; i < 16; ++i) out[i] = g_timing[i];
     return KAO_OK;
 }
 

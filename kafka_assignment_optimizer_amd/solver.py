@@ -264,6 +264,10 @@ class Session:
     def sync(self):
         _check(_ffi.load().kao_session_sync(self._h), "kao_session_sync")
 
+    def new_generation(self):
+        """The next step re-initialises every restart (generation-salted best insertion); old snapshots and best keys are dropped."""
+        _check(_ffi.load().kao_session_new_generation(self._h), "kao_session_new_generation")
+
     def best(self) -> List[Result]:
         res, bufs = _results_buffers(self.topics)
         _check(_ffi.load().kao_session_best(self._h, res), "kao_session_best")
@@ -459,8 +463,8 @@ def rccl_loopback_counts() -> tuple:
 
 def last_solve_timing() -> dict:
     """C-side wall-clock breakdown of the last kao_solve (seconds from its entry)."""
-    out = (C.c_double * 12)()
+    out = (C.c_double * 16)()
     _check(_ffi.load().kao_last_solve_timing(out), "kao_last_solve_timing")
     return dict(session_ready=out[0], time_to_best=out[1], results_read_back=out[2], returned=out[3], launches=int(out[4]),
                 delta_candidates=int(out[5]), bound_launches=int(out[6]), elite_exchanges=int(out[7]), bound_iters=int(out[8]),
-                cx_calls=int(out[9]), cx_gains=int(out[10]), search_iters=int(out[11]))
+                cx_calls=int(out[9]), cx_gains=int(out[10]), search_iters=int(out[11]), generations=int(out[12]))

@@ -260,12 +260,14 @@ static inline uint32_t make_key_tie(int lam, int S, int dV, int dObj, uint32_t t
     return ((uint32_t)(delta + DBIAS) << 8) | (tie & 0xFFu);
 }
 
-/* initial state of restart `rho`: surviving current replicas stay in their slots; every hole (replica on a removed
+/* initial state of restart `rho` (generation `gen`: kao_solve starts a new generation -- every restart re-initialised, the
+ * tie-break hash salted with the generation number -- when a population has converged without a proof; 0 = the first):
+ * surviving current replicas stay in their slots; every hole (replica on a removed
  * broker, or a slot added by an RF increase) is filled, in (p,k) order, by BEST INSERTION: every valid broker not in
  * the partition is scored lam_max*dV - S*dObj of the insertion (64 per round on the GPU, lane = internal index), ties
  * broken by 8 hashed bits (per restart, hole and broker), then by the lowest lane.  Two passes: leader holes of all
  * partitions first, then follower holes. */
-static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho) {
+static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho, uint32_t gen) {
     const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
     for (int p = 0; p < t->P; ++p)
         for (int k = 0; k < RFP; ++k) s->A[p * RFP + k] = (k < t->RF) ? t->cur[p * RFP + k] : NONE16;
@@ -275,7 +277,7 @@ static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint3
         uint16_t *a = s->A + p * RFP;
         for (int k = (pass == 0 ? 0 : 1); k < (pass == 0 ? 1 : t->RF); ++k) {
             if (a[k] != NONE16) continue;
-            const uint32_t hmix = slo ^ fmix32(shi + rho * 0x9E3779B1u + (uint32_t)(p * t->nw + k) * 0x27D4EB2Fu + 0x5BD1E995u);
+            const uint32_t hmix = slo ^ fmix32(shi + rho * 0x9E3779B1u + (uint32_t)(p * t->nw + k) * 0x27D4EB2Fu + 0x5BD1E995u + gen * 0x632BE5ABu);
             uint32_t lane_key[LANES]; int lane_x[LANES];
             for (uint32_t l = 0; l < LANES; ++l) lane_key[l] = KEY_NULL;
             for (int base = 0; base < t->Bx; base += LANES)
@@ -579,6 +581,7 @@ typedef struct {
     const int32_t *pa, *pl, *pg;
     const uint16_t *elite;
     int32_t elite_obj, elite_rho;
+    int32_t gen;   /* > 0: this launch starts generation `gen`: the restart is re-initialised (ls_init with the generation salt) */
 } port_extra;
 typedef struct { const ls_topic *t; ls_state s; port_params pp; uint32_t rho; int *PA, *PL; int PG[256]; } ls_runner;
 
@@ -623,7 +626,11 @@ int kao_port_run_launch(void *run, uint32_t launch, uint32_t iters, const port_e
         for (int q = 0; q < 256; ++q) r->PG[q] = q < t->R ? price_units(ex->pg[q], r->pp.obj_scale) : 0;
         s->PA = r->PA; s->PL = r->PL; s->PG = r->PG;
     }
-    if (launch == 0) ls_init(t, s, &r->pp, r->rho);
+    if (launch == 0) ls_init(t, s, &r->pp, r->rho, 0);
+    else if (ex && ex->gen > 0) {
+        ls_init(t, s, &r->pp, r->rho, (uint32_t)ex->gen);
+        memset(s->best, 0xFF, sizeof(uint16_t) * (size_t)t->P * t->RF);   /* the snapshots of the old generation are dropped */
+    }
     else if (ex && ex->elite) {
         const uint32_t slo = (uint32_t)r->pp.seed;
         const int go = (uint32_t)ex->elite_rho != r->rho && s->best_obj < ex->elite_obj &&
@@ -661,7 +668,7 @@ int kao_port_search(void *h, const port_params *pp, uint32_t rho, uint32_t launc
     s.C = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)t->Bx);
     s.best = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * t->RF);
     memset(s.best, 0xFF, sizeof(uint16_t) * (size_t)t->P * t->RF);
-    ls_init(t, &s, pp, rho);
+    ls_init(t, &s, pp, rho, 0);
     for (uint32_t L = 0; L < launches; ++L) ls_run(t, &s, pp, rho, L, iters);
     ls_recount(t, &s);
     for (int p = 0; p < t->P; ++p)
@@ -681,7 +688,7 @@ double kao_port_valid_fraction(void *h, const port_params *pp, uint32_t rho, uin
     s.A = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * RFP);
     s.C = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)t->Bx);
     s.best = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)t->P * t->RF);
-    ls_init(t, &s, pp, rho);
+    ls_init(t, &s, pp, rho, 0);
     for (uint32_t L = 0; L < launches; ++L) ls_run(t, &s, pp, rho, L, iters);
     const double f = s.n_eval ? (double)s.n_valid / (double)s.n_eval : 0.0;
     free(s.A); free(s.C); free(s.best);

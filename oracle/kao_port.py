@@ -30,7 +30,7 @@ class PortParams(C.Structure):
 
 class PortExtra(C.Structure):
     _fields_ = [("pa", C.POINTER(C.c_int32)), ("pl", C.POINTER(C.c_int32)), ("pg", C.POINTER(C.c_int32)),
-                ("elite", C.POINTER(C.c_uint16)), ("elite_obj", C.c_int32), ("elite_rho", C.c_int32)]
+                ("elite", C.POINTER(C.c_uint16)), ("elite_obj", C.c_int32), ("elite_rho", C.c_int32), ("gen", C.c_int32)]
 
 
 def build() -> str:
@@ -164,8 +164,9 @@ class PortRun:
                               lam_max=pr["lam_max"], period_log2=pr["period_log2"])
         self._run = lib().kao_port_run_create(self._h, C.byref(self._pp), rho)
 
-    def launch(self, launch: int, iters: int, prices=None, elite=None):
+    def launch(self, launch: int, iters: int, prices=None, elite=None, gen: int = 0):
         ex = PortExtra()
+        ex.gen = int(gen)   # > 0: this launch starts generation `gen` (the restart is re-initialised)
         keep = []
         if prices is not None:
             a, l, g = (np.ascontiguousarray(v, dtype=np.int32) for v in prices)

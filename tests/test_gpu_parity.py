@@ -226,6 +226,34 @@ def test_elite_launch_replay_bit_exact(kao, ko, kp):
         assert reseeded > 0            # the rule fired somewhere
 
 
+def test_new_generation_replay_bit_exact(kao, ko, kp):
+    """kao_session_new_generation (what kao_solve does with a population that converged without a proof): the next launch
+    re-initialises every restart with the generation number in the tie-break hash, old snapshots and best keys are dropped, the
+    launch counter carries on -- the scalar restatement re-initialises the same way, restart by restart, bit for bit."""
+    ot = _drifted(ko, 2, 1)[0]
+    seed, iters = 0x6E47, 120
+    with kao.Session([to_product_topic(ot)], seed=seed, restarts=8, iters_per_launch=iters) as s:
+        s.step(2)
+        before = s.best()[0]
+        s.new_generation()
+        assert int(s.best_keys()[0]) == (1 << 64) - 1                       # nothing of the old generation is left on the device
+        s.step(2)
+        assert s.stats()["drift"] == 0
+        tseed = seed ^ (0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)
+        states = set()
+        for rho in (0, 3, 7):
+            dev = s.restart_state(0, rho)
+            run = kp.PortRun(ot, tseed, rho)
+            run.launch(0, iters); run.launch(1, iters); run.launch(2, iters, gen=1); run.launch(3, iters)
+            ref = run.read()
+            assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
+            assert np.array_equal(dev["final"], ref["final"]) and np.array_equal(dev["best"], ref["best"])
+            plain = kp.port_search(ot, tseed, rho, 4, iters)                 # the same restart without the new generation
+            assert not np.array_equal(plain["final"], ref["final"])
+            states.add(dev["final"].tobytes())
+        assert len(states) == 3 and before.status != "NO_FEASIBLE"
+
+
 def test_search_replay_random_small(kao, ko, kp):
     cases = [c for c in load_golden("random_small.json")["cases"]][:16]
     ots = [ko.topic_from_dict(c["topic"]) for c in cases]

@@ -323,3 +323,23 @@ def test_dual_value_is_an_upper_bound_for_any_multipliers(ko, kp):
             assert L >= c["objective"] * kp.DB_SCALE, (c["seed"], scale, L / kp.DB_SCALE, c["objective"])
             n += 1
     assert n >= 150
+
+
+def test_port_generations_differ_and_are_reproducible(ko, kp):
+    """The scalar restatement of a new generation (kao_port_run_launch with gen > 0): the restart is re-initialised with the
+    generation number in the tie-break hash -- reproducibly, and differently from generation 0 and from generation 2."""
+    ot = ko.gen_config(2).topics[0]
+
+    def run(gens):
+        r = kp.PortRun(ot, 0xABCDEF, 5)
+        for launch, g in enumerate(gens):
+            r.launch(launch, 60, gen=g)
+        out = r.read()
+        r.close()
+        return out
+    a, b = run([0, 0, 1, 0]), run([0, 0, 1, 0])
+    assert np.array_equal(a["final"], b["final"]) and a["obj"] == b["obj"]
+    c, d = run([0, 0, 0, 0]), run([0, 0, 2, 0])
+    assert not np.array_equal(a["final"], c["final"]) and not np.array_equal(a["final"], d["final"])
+    obj, viol = ko.verify(ot, a["final"])
+    assert obj == a["obj"] and int(viol[0]) == a["V"]

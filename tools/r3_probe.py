@@ -32,7 +32,7 @@ def run(t, **kw):
 def line(tag, B, R, P, dseed, r, dt, tm):
     gap = r.upper_bound - r.objective
     return (f"{tag} B={B:4d} R={R:2d} P={P:5d} d{dseed}: {r.status:15s} obj {r.objective} cert {r.upper_bound} gap {gap} {dt:.2f}s "
-            f"t_best {tm['time_to_best']:.2f} launches {tm['launches']} its {tm['search_iters']} K-bound {tm['bound_launches']}/{tm['bound_iters']} cx {tm['cx_calls']}/{tm['cx_gains']}")
+            f"t_best {tm['time_to_best']:.2f} launches {tm['launches']} its {tm['search_iters']} K-bound {tm['bound_launches']}/{tm['bound_iters']} cx {tm['cx_calls']}/{tm['cx_gains']} gens {tm['generations']}")
 
 
 if "family" in what:
@@ -65,6 +65,13 @@ if "seeds" in what:
             n_any += any(g[0] for g in got)
             print(f"seeds B={B:4d} R={R:2d} P={P:5d} d{dseed}: three runs of {budget / 3.0:.2f}s: {got}", flush=True)
     print(f"seeds: proven by any of three short runs {n_any}/24", flush=True)
+
+if "goldens" in what:
+    # the rows of tests/golden/drift_scale.json the GPU tests assert: time to the proof over three seeds
+    for (B, R, P, lim) in ((100, 5, 1000, 8.0), (200, 5, 2000, 8.0), (300, 6, 2000, 8.0), (400, 8, 3000, 3.0), (250, 5, 4000, 3.0)):
+        for sd in (1, 2, 3):
+            r, dt, tm = run(topic(B, R, P), seed=sd, time_limit_s=lim, schedule=0)
+            print(line(f"goldens seed {sd} gens {tm['generations']}", B, R, P, 1, r, dt, tm), flush=True)
 
 if "determinism" in what:
     for (B, R, P, ml) in ((100, 5, 1000, 400), (300, 6, 2000, 300), (500, 10, 5000, 120)):
