@@ -99,6 +99,7 @@ struct kao_session {
     // and its 2 waves per workgroup on 200 small topics); one K-search + one K-eval launch per group per step.
     struct LaunchGroup {
         int maxP = 0, maxBx = 0, maxB = 0, maxR = 0;
+        bool wide = false;   // some topic of the group has 512 replica slots or more (several tournament slots per lane)
         int waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
         int nw = kRFP;       // replica words per partition of the group's topics: 4 or 8 (template instantiation)
         bool global_a = false;   // topic too large for LDS: assignment + current words stay in global memory
@@ -149,6 +150,7 @@ struct kao_session {
     hipStream_t stream_bound = nullptr;   // K-bound runs beside K-search on its own stream (it occupies one CU per topic)
     hipEvent_t ev_bound0 = nullptr, ev_bound1 = nullptr, ev_search = nullptr;
     bool bound_inflight = false;
+    bool bound_no_wait = false;  // kao_solve's deterministic schedule: no event wait on the search stream before a K-bound launch
     int bound_iters_last = 0;
     double bound_ms_last = 0;
     unsigned long long *d_keys = nullptr;

@@ -64,6 +64,7 @@ struct TopicDev {
 struct SearchParams {
     int32_t obj_scale, lam_min, lam_max;         // (the sawtooth period is per topic: TopicDev::period_log2)
     int32_t maxR;                // largest rack count of the launch group (sizes the per-rack LDS tables)
+    int32_t wide;                // 1 = the group holds a topic of >= 512 replica slots (k_search<..., kWide = true>)
     uint32_t launch;             // launch number (global iteration = launch*iters + i)
     uint32_t iters;
     int32_t init;                // 1 = build the initial state of every restart first

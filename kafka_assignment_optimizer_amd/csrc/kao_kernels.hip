@@ -18,6 +18,8 @@
 // dense contraction).  The scalar CPU restatement used by the tests is oracle/kao_port.c.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kao_device.h"
 #include "kao_internal.h"
 
@@ -284,7 +286,10 @@ template <int NW> __device__ __forceinline__ void snapshot(const TopicRegs &T, c
 //                   per broker / rack, leaders per broker) -- an augmented-Lagrangian search: with near-optimal prices the
 //                   chain steps an improvement needs (objective down a little, violation unchanged) become neutral moves.
 // NW              : replica words per partition -- 4 (RF and current RF <= 4) or 8 (up to 8 replicas).
-template <bool kGlobalA, bool kPriced, int NW>
+// kWide          : the launch group holds topics of 512 replica slots or more: their tournament scores several slots per lane
+//                   and is issued two slots per trip, the REPLACE scan two rounds per trip (instruction-level parallelism for
+//                   the one-wavefront-per-SIMD regime of large topics; costs registers the small-topic instantiation keeps)
+template <bool kGlobalA, bool kPriced, int NW, bool kWide>
 __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -487,6 +492,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const uint32_t RF8 = (uint32_t)T.RF << 8, R8 = (uint32_t)T.R << 8, m8 = (uint32_t)T.m << 8;  // all < 65536
 
     const int T_tour = min(64, max(4, (T.P * T.RF) >> 2));  // lanes taking part in the slot tournament
+    uint32_t tour_off = lane < T_tour ? 0u : kKeyNull;       // OR-ed into a lane's tournament key (a select would put a branch between the slots of a trip)
+    asm volatile("" : "+v"(tour_off));
     const int GA = min(16, max(1, (T.P * T.RF) >> 8));       // random slots scored per lane
     const int x_rounds_full = (T.P + 63) >> 6;
     const bool x_windowed = x_rounds_full > 8;               // EXCHANGE scans at most 8 rounds of 64 partitions
@@ -608,7 +615,11 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             // gain one) can improve.  `type` is wave-uniform, so only one branch is ever executed.
             uint32_t keyA, oldw_l;
             int pl_, kl_, g_old_l, dvo_l = 0, dvr_l = 0;
-            auto score_slot = [&](uint32_t &key_o, int &p_o, int &k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
+            // `ty` is the (wave-uniform) move type as a compile-time constant: each instantiation is straight-line code, so the
+            // two slots of a trip below interleave -- a big topic runs one wavefront per SIMD and the LDS round trips of one
+            // slot (A[p], then W[x] / K[rack]) are hidden behind the other slot's, not behind other wavefronts
+            auto score_slot = [&](auto ty, uint32_t &key_o, int &p_o, int &k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
+                constexpr int TY = decltype(ty)::value;
                 p_o = (int)rnd24_wide(rng, (uint32_t)T.P);
                 k_o = (int)rnd24(rng, RF8);
                 const Part<NW> al = L.A[p_o];
@@ -617,11 +628,11 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t rol = oldw_o >> 16;
                 const bool leadl = k_o == 0;
                 g_o = role_w2(cl, oldw_o, leadl ? T.w00 : T.w01, leadl ? T.w10 : T.w11);
-                if (hbw && type == 0) g_o += bw_of(BW[oldw_o & 0xFFFFu], leadl);   // a REPLACE also gives up the broker's own weight
+                if (hbw && TY == 0) g_o += bw_of(BW[oldw_o & 0xFFFFu], leadl);   // a REPLACE also gives up the broker's own weight
                 const uint32_t wo = L.W[oldw_o & 0xFFFFu];
                 const int dv7 = ddec(cnt4(al, rol), T.prack_lo, T.prack_hi);
                 int sc;
-                if (type == 0) {
+                if (TY == 0) {
                     dvo_o = wfld(wo, kWDecR) + wfldw(wo, kWDecL, leadl ? 2u : 0u);
                     dvr_o = ddec(L.K[rol], T.rack_lo, T.rack_hi) + dv7;
                     sc = dvo_o + min(dvr_o, 0);
@@ -631,22 +642,36 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 }
                 if (kPriced) {
                     int dPs = 0;
-                    if (type == 0) {
+                    if (TY == 0) {
                         const uint32_t pro = PR[oldw_o & 0xFFFFu];
                         dPs = -(wflag(wo, kWPoutR) & price_rep(pro));
-                        if (leadl) dPs -= wflag(wo, kWPoutL) & price_lead(pro);
+                        dPs -= wflagw(wo, kWPoutL, leadl ? 1u : 0u) & price_lead(pro);
                     }
-                    key_o = lane < T_tour ? make_key_p(lam, S, sc, -g_o, dPs, lane) : kKeyNull;
+                    key_o = make_key_p(lam, S, sc, -g_o, dPs, lane) | tour_off;
                 }
-                else key_o = lane < T_tour ? make_key(lam, S, sc, -g_o, lane) : kKeyNull;
+                else key_o = make_key(lam, S, sc, -g_o, lane) | tour_off;   // lanes outside the tournament: all ones = kKeyNull
             };
-            score_slot(keyA, pl_, kl_, oldw_l, g_old_l, dvo_l, dvr_l);
-            for (int ga = 1; ga < GA; ++ga) {  // large topics: up to 16 slots per lane, the lane keeps its best
-                uint32_t kg, ow;
-                int pg, kk, gg, d1 = 0, d2 = 0;
-                score_slot(kg, pg, kk, ow, gg, d1, d2);
-                if (kg < keyA) { keyA = kg; pl_ = pg; kl_ = kk; oldw_l = ow; g_old_l = gg; dvo_l = d1; dvr_l = d2; }
-            }
+            // large topics: up to 16 slots per lane, the lane keeps its best; two slots per trip.  Draw and comparison order
+            // are those of a one-at-a-time loop.
+            auto tournament = [&](auto ty) {
+                score_slot(ty, keyA, pl_, kl_, oldw_l, g_old_l, dvo_l, dvr_l);
+                int ga = 1;
+                for (; kWide && ga + 1 < GA; ga += 2) {
+                    uint32_t kg0, ow0, kg1, ow1;
+                    int pg0, kk0, gg0, d10 = 0, d20 = 0, pg1, kk1, gg1, d11 = 0, d21 = 0;
+                    score_slot(ty, kg0, pg0, kk0, ow0, gg0, d10, d20);
+                    score_slot(ty, kg1, pg1, kk1, ow1, gg1, d11, d21);
+                    if (kg0 < keyA) { keyA = kg0; pl_ = pg0; kl_ = kk0; oldw_l = ow0; g_old_l = gg0; dvo_l = d10; dvr_l = d20; }
+                    if (kg1 < keyA) { keyA = kg1; pl_ = pg1; kl_ = kk1; oldw_l = ow1; g_old_l = gg1; dvo_l = d11; dvr_l = d21; }
+                }
+                for (; ga < GA; ++ga) {
+                    uint32_t kg, ow;
+                    int pg, kk, gg, d1 = 0, d2 = 0;
+                    score_slot(ty, kg, pg, kk, ow, gg, d1, d2);
+                    if (kg < keyA) { keyA = kg; pl_ = pg; kl_ = kk; oldw_l = ow; g_old_l = gg; dvo_l = d1; dvr_l = d2; }
+                }
+            };
+            if (type == 0) tournament(std::integral_constant<int, 0>{}); else tournament(std::integral_constant<int, 1>{});
             const int wA = (int)(wave_umin(keyA) & 63u);
             p = __builtin_amdgcn_readlane(pl_, wA);
             k = __builtin_amdgcn_readlane(kl_, wA);
@@ -705,36 +730,55 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 const uint32_t lw = lead ? 2u : 0u, lf = lead ? 1u : 0u;   // widths of the leader fields / flags: zero for follower slots
                 uint32_t bestA = kKeyNull;   // (cost + bias) << 16 | tie << 8 | round within the chunk of 256 rounds
                 int chunkA = 0;
+                // one round: 64 candidates x = base + lane, `rd` = round within the chunk of 256; `with_w` (compile time): the
+                // round holds a displaced current replica of the partition and is scored with objective weights
+                auto scan_round = [&](auto with_w, int base, int rd) -> uint32_t {
+                    const uint32_t st = lcg24(rng);   // tie bits = bits 8..15 of the draw, as make_key_tie(lcg24 >> 8)
+                    const int w = (int)(short)L.W[base + lane];   // sign-extended: bit 15 fills the upper half
+                    const int rt = L.RT[XR[base + lane]];
+                    int dsc;
+                    if (kPriced) {   // RT entry: violation delta in the low byte, rack price above it
+                        const uint32_t prx = PR[base + lane];
+                        const int dVx = wfld(w, kWIncR) + wfldw(w, kWIncL, lw) + (int)(signed char)(rt & 0xFF);
+                        dsc = __mul24(lam, dVx) + K0 + (rt >> 8) + (wflag(w, kWPinR) & price_rep(prx)) + (wflagw(w, kWPinL, lf) & price_lead(prx));
+                        if (hbw) dsc -= __mul24(S, bw_of(BW[base + lane], lead));
+                    } else {
+                        const int dVx = wfld(w, kWIncR) + wfldw(w, kWIncL, lw) + rt;
+                        dsc = __mul24(lam, dVx) + K0;
+                    }
+                    if (decltype(with_w)::value) {
+                        const uint32_t x = (uint32_t)(base + lane);
+                        dsc -= __mul24(S, role_w2(c, x | ((uint32_t)XR[x] << 16), wl, wf));
+                    }
+                    dsc = min(max(dsc, 0), 2 * kDBias - 2);
+                    // a "no candidate" index gets a cost field of 0xFFFF: above every real cost (<= 2 * kDBias - 2) and never accepted
+                    return ((uint32_t)dsc << 16) | (st & 0xFF00u) | (uint32_t)rd | ((uint32_t)w & 0xFFFF0000u);
+                };
+                auto is_weighted = [&](int rdg) {   // wave-uniform
+                    bool wgt = false;
+#pragma unroll
+                    for (int i2 = 0; i2 < NW; ++i2) wgt |= mr[i2] == rdg;
+                    return wgt;
+                };
                 for (int cb = 0; cb < T.Bx; cb += 16384) {
                     uint32_t bestc = kKeyNull;
                     const int cend = min(T.Bx, cb + 16384);
-                    int rd = 0;
-                    for (int base = cb; base < cend; base += 64, ++rd) {
-                        const uint32_t st = lcg24(rng);   // tie bits = bits 8..15 of the draw, as make_key_tie(lcg24 >> 8)
-                        const int w = (int)(short)L.W[base + lane];   // sign-extended: bit 15 fills the upper half
-                        const int rt = L.RT[XR[base + lane]];
-                        int dsc;
-                        if (kPriced) {   // RT entry: violation delta in the low byte, rack price above it
-                            const uint32_t prx = PR[base + lane];
-                            const int dVx = wfld(w, kWIncR) + wfldw(w, kWIncL, lw) + (int)(signed char)(rt & 0xFF);
-                            dsc = __mul24(lam, dVx) + K0 + (rt >> 8) + (wflag(w, kWPinR) & price_rep(prx)) + (wflagw(w, kWPinL, lf) & price_lead(prx));
-                            if (hbw) dsc -= __mul24(S, bw_of(BW[base + lane], lead));
-                        } else {
-                            const int dVx = wfld(w, kWIncR) + wfldw(w, kWIncL, lw) + rt;
-                            dsc = __mul24(lam, dVx) + K0;
+                    int rd = 0, base = cb;
+                    if (kWide) {   // two rounds per trip: straight-line code, the LDS round trips of one round hide behind the other's
+                        for (; base + 64 < cend; base += 128, rd += 2) {
+                            const int rdg = (cb >> 6) + rd;
+                            if (is_weighted(rdg) || is_weighted(rdg + 1)) {   // rare: at most NW rounds of a scan carry weights
+                                bestc = min(bestc, is_weighted(rdg) ? scan_round(std::true_type{}, base, rd) : scan_round(std::false_type{}, base, rd));
+                                bestc = min(bestc, is_weighted(rdg + 1) ? scan_round(std::true_type{}, base + 64, rd + 1) : scan_round(std::false_type{}, base + 64, rd + 1));
+                            } else {
+                                const uint32_t k0 = scan_round(std::false_type{}, base, rd);
+                                const uint32_t k1 = scan_round(std::false_type{}, base + 64, rd + 1);
+                                bestc = min(bestc, min(k0, k1));
+                            }
                         }
-                        bool weighted = false;   // wave-uniform: this round holds a displaced current replica of the partition
-                        const int rdg = (cb >> 6) + rd;
-#pragma unroll
-                        for (int i2 = 0; i2 < NW; ++i2) weighted |= mr[i2] == rdg;
-                        if (weighted) {
-                            const uint32_t x = (uint32_t)((rdg << 6) + lane);
-                            dsc -= __mul24(S, role_w2(c, x | ((uint32_t)XR[x] << 16), wl, wf));
-                        }
-                        dsc = min(max(dsc, 0), 2 * kDBias - 2);
-                        // a "no candidate" index gets a cost field of 0xFFFF: above every real cost (<= 2 * kDBias - 2) and never accepted
-                        bestc = min(bestc, ((uint32_t)dsc << 16) | (st & 0xFF00u) | (uint32_t)rd | ((uint32_t)w & 0xFFFF0000u));
                     }
+                    for (; base < cend; base += 64, ++rd)
+                        bestc = min(bestc, is_weighted((cb >> 6) + rd) ? scan_round(std::true_type{}, base, rd) : scan_round(std::false_type{}, base, rd));
                     if ((bestc >> 8) < (bestA >> 8)) { bestA = bestc; chunkA = cb; }   // strict: ties stay with the earlier round
                 }
                 if (mine) L.W[ai & 0xFFFFu] = (uint16_t)w_keep;
@@ -1184,28 +1228,34 @@ size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
 // largest dynamic-LDS size each kernel has been enabled for, per device (function attributes are per device)
 static int g_attr_eval_dev[kAttrDevices] = {0};
 
-template <bool kGlobalA, bool kPriced, int NW>
+template <bool kGlobalA, bool kPriced, int NW, bool kWide>
 static void launch_search_t(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, size_t lds, int &attr, hipStream_t st) {
-    if ((int)lds > attr) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<kGlobalA, kPriced, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_search<kGlobalA, kPriced, NW>), dim3(n_blocks), dim3(64 * waves), lds, st, pools, prm);
+    if ((int)lds > attr) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_search<kGlobalA, kPriced, NW, kWide>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_search<kGlobalA, kPriced, NW, kWide>), dim3(n_blocks), dim3(64 * waves), lds, st, pools, prm);
+}
+template <bool kGlobalA, bool kPriced, int NW>
+static void launch_search_w(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, size_t lds, int &attr, bool wide, hipStream_t st) {
+    if (wide || kGlobalA) launch_search_t<kGlobalA, kPriced, NW, true>(pools, prm, n_blocks, waves, lds, attr, st);   // (topics in global memory are always wide)
+    else launch_search_t<kGlobalA, kPriced, NW, kGlobalA>(pools, prm, n_blocks, waves, lds, attr, st);
 }
 
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream) {
     const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw, prm.bw != 0, prm.maxR);
-    // largest dynamic-LDS size each of the 8 instantiations has been enabled for, per device
-    static int attr[kAttrDevices][8] = {{0}};
-    int &a = attr[attr_slot()][(global_a ? 4 : 0) + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
+    // largest dynamic-LDS size each of the instantiations has been enabled for, per device
+    static int attr[kAttrDevices][16] = {{0}};
+    const bool wide = prm.wide != 0;
+    int &a = attr[attr_slot()][(wide || global_a ? 8 : 0) + (global_a ? 4 : 0) + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (nw == 8) {
-        if (global_a && priced) launch_search_t<true, true, 8>(pools, prm, n_blocks, waves, lds, a, st);
-        else if (global_a) launch_search_t<true, false, 8>(pools, prm, n_blocks, waves, lds, a, st);
-        else if (priced) launch_search_t<false, true, 8>(pools, prm, n_blocks, waves, lds, a, st);
-        else launch_search_t<false, false, 8>(pools, prm, n_blocks, waves, lds, a, st);
+        if (global_a && priced) launch_search_w<true, true, 8>(pools, prm, n_blocks, waves, lds, a, wide, st);
+        else if (global_a) launch_search_w<true, false, 8>(pools, prm, n_blocks, waves, lds, a, wide, st);
+        else if (priced) launch_search_w<false, true, 8>(pools, prm, n_blocks, waves, lds, a, wide, st);
+        else launch_search_w<false, false, 8>(pools, prm, n_blocks, waves, lds, a, wide, st);
     } else {
-        if (global_a && priced) launch_search_t<true, true, 4>(pools, prm, n_blocks, waves, lds, a, st);
-        else if (global_a) launch_search_t<true, false, 4>(pools, prm, n_blocks, waves, lds, a, st);
-        else if (priced) launch_search_t<false, true, 4>(pools, prm, n_blocks, waves, lds, a, st);
-        else launch_search_t<false, false, 4>(pools, prm, n_blocks, waves, lds, a, st);
+        if (global_a && priced) launch_search_w<true, true, 4>(pools, prm, n_blocks, waves, lds, a, wide, st);
+        else if (global_a) launch_search_w<true, false, 4>(pools, prm, n_blocks, waves, lds, a, wide, st);
+        else if (priced) launch_search_w<false, true, 4>(pools, prm, n_blocks, waves, lds, a, wide, st);
+        else launch_search_w<false, false, 4>(pools, prm, n_blocks, waves, lds, a, wide, st);
     }
     if ((int)lds > a) a = (int)lds;
 }

@@ -603,7 +603,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         kao_session::LaunchGroup g;
         for (int t : mem) {
             const TopicDev &d = s->pts[(size_t)t].d;
-            g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B); g.maxR = std::max(g.maxR, d.R);
+            g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B); g.maxR = std::max(g.maxR, d.R); g.wide = g.wide || (int64_t)d.P * d.RF >= 512;
         }
         g.global_a = s->topic_global[(size_t)mem[0]] != 0;
         g.nw = s->pts[(size_t)mem[0]].d.nw;
@@ -756,7 +756,7 @@ int kao_session_step(kao_session *s) {
     if (prof) HIP_TRY(hipEventRecord(e[0], s->stream));
     for (const kao_session::LaunchGroup &g : s->groups) {
         sp.block_map = s->d_smap + g.smap_off;
-        prm.maxP = g.maxP; prm.maxBx = g.maxBx; prm.maxR = g.maxR;
+        prm.maxP = g.maxP; prm.maxBx = g.maxBx; prm.maxR = g.maxR; prm.wide = g.wide ? 1 : 0;
         launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, g.nw, s->stream);
         HIP_TRY(hipGetLastError());
     }
@@ -916,7 +916,10 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     bp.ext_pool = s->d_ext; bp.rsz_pool = s->d_rsz;
     bp.iters = iters; bp.maxB = maxB; bp.maxP = maxP; bp.maxR = maxR;
     bp.cur_in_lds = bound_lds_bytes(maxB, maxP, maxR, true) <= 160 * 1024 ? 1 : 0;
-    if (s->priced) {  // K-search launches already enqueued may still read the half this launch is about to overwrite
+    // K-search launches already enqueued may still read the half this launch is about to overwrite -- except under kao_solve's
+    // deterministic schedule, which starts K-bound only when the enqueued K-search launches read the OTHER half (the launch
+    // that read this one has been waited for)
+    if (s->priced && !s->bound_no_wait) {
         if (!s->ev_search) HIP_TRY(hipEventCreateWithFlags(&s->ev_search, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(s->ev_search, s->stream));
         HIP_TRY(hipStreamWaitEvent(s->stream_bound, s->ev_search, 0));

@@ -49,8 +49,11 @@ DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
     // give both in launches.
     const int64_t it = std::max(iters_per_launch, 1);
     auto env_l = [](const char *name, int64_t dflt) { const char *e = std::getenv(name); return e && *e ? (int64_t)std::atoll(e) : dflt; };
-    d.cx_stall_iters = it * env_l("KAO_DET_CX_STALL_L", 24);
-    d.cx_due_iters = it * env_l("KAO_DET_CX_DUE_L", 144);
+    // Beyond a few thousand partitions a launch takes 5-15 ms and KAO-CX is what carries the incumbent (1000 x 30000, 3 s:
+    // 231,529 with a call every 6 / 36 launches, 231,159 with 24 / 144), so the counts shrink with the topic.
+    const int64_t stall_l = slots <= 16384 ? 24 : (slots <= 32768 ? 12 : 6);
+    d.cx_stall_iters = it * env_l("KAO_DET_CX_STALL_L", stall_l);
+    d.cx_due_iters = it * env_l("KAO_DET_CX_DUE_L", 6 * stall_l);
     d.cx_rounds = slots <= 32768 ? 12 : 6;
     return d;
 }
@@ -101,6 +104,7 @@ struct SolveRun {
     // with the generation number in its tie-break hash (kao_session_new_generation), and K-bound, its certificate and its
     // prices carry on, so later generations search under converged prices from their first launch.  The answer is the best
     // incumbent of all generations.
+    bool bound_pending = false;                   // a K-bound launch (dual_target, dual_now) waits for the next K-search launch
     bool gens_on = false;
     int generations = 0;
     int64_t gen_stall_iters = 0, gen_start = 0;
@@ -152,6 +156,7 @@ struct SolveRun {
         dual_iters = o.dual_iters < 0 ? 0 : (o.dual_iters == 0 ? 128 : o.dual_iters);
         dual_now = dual_iters;
         det = so.schedule == 0;
+        s->bound_no_wait = det;   // K-bound launches start at points where no K-search launch reads the price half they write
         i_improved.assign((size_t)n, 0); i_cx.assign((size_t)n, 0);
         {   // the counts of the deterministic schedule, from the size of the largest topic (constants measured on one MI355X so
             // that a K-bound launch takes about as long as a K-search launch and KAO-CX gets about the share of the wall clock
@@ -178,7 +183,14 @@ struct SolveRun {
         use_prices = so.use_prices >= 0;
         return KAO_OK;
     }
-    int launch() { return kao_session_step(s); }   // asynchronous
+    // asynchronous.  Deterministic schedule: the K-bound launch decided after the previous K-search launch is enqueued only
+    // now, behind the new K-search launch -- enqueueing up to 176 step kernels takes the host about a millisecond, which
+    // the search stream no longer spends idle
+    int launch() {
+        int rc = kao_session_step(s);
+        if (!rc && bound_pending) { bound_pending = false; rc = kao_session_bound_step(s, dual_target.data(), dual_now); }
+        return rc;
+    }
     // keys = the best over all generations (what "done", the K-bound targets and the answer go by); dkeys = this generation's
     bool feasible(int i) const { return (keys[(size_t)i] >> 44) == 0; }
     int64_t objective(int i) const { return (int64_t)kObjCap - (int64_t)((keys[(size_t)i] >> 20) & 0xFFFFFF); }
@@ -222,7 +234,7 @@ struct SolveRun {
         }
         all_done = check_done();
         const double t_search = now_s();
-        if ((rc = service_bound())) return rc;
+        if ((rc = service_bound(false))) return rc;
         const double t_bound = now_s();
         const int cx0 = cx_calls;
         if (cx_on && !all_done && !has_target && (rc = cycles(t))) return rc;
@@ -241,7 +253,7 @@ struct SolveRun {
     // K-bound runs beside the search on its own stream; when a launch has finished its certificates are merged and, while
     // some feasible incumbent is still below its bound, the next launch starts (aimed at the new incumbents).  Launch length
     // adapts so that one launch takes about 10 ms.  Called after every K-search launch and between the rounds of KAO-CX.
-    int service_bound() {
+    int service_bound(bool start_now = true) {
         if (has_target || dual_iters <= 0) return KAO_OK;
         int rc;
         if (!det) {   // wall-clock schedule: a K-bound launch is merged whenever it happens to have finished
@@ -267,7 +279,11 @@ struct SolveRun {
             dual_target[(size_t)i] = want ? objective(i) : -1;
             any |= want;
         }
-        if (any && (rc = kao_session_bound_step(s, dual_target.data(), dual_now))) return rc;
+        bound_pending = false;
+        if (any) {
+            if (det && !start_now) bound_pending = true;   // goes out behind the next K-search launch (launch())
+            else if ((rc = kao_session_bound_step(s, dual_target.data(), dual_now))) return rc;
+        }
         return KAO_OK;
     }
     // between the rounds of KAO-CX K-bound is serviced.  (Keeping K-search running as well -- launches enqueued from here

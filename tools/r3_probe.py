@@ -88,11 +88,11 @@ if "trace" in what:
     os.environ["KAO_SOLVE_TRACE"] = "1"
     for (B, R, P) in [(100, 5, 1000), (300, 6, 2000), (500, 10, 5000), (500, 10, 10000), (1000, 20, 30000)]:
         print(f"trace B={B} P={P}", file=sys.stderr, flush=True)
-        r, dt, tm = run(topic(B, R, P), seed=3, time_limit_s=1.0, schedule=1)
+        r, dt, tm = run(topic(B, R, P), seed=3, time_limit_s=1.0, schedule=SCHEDS[0])
         print(line("trace", B, R, P, 1, r, dt, tm), flush=True)
     ts = sy.drift(sy.make_config(4), 0.2, 1)
     print("trace cfg4 drifted batch", file=sys.stderr, flush=True)
-    t0 = time.perf_counter(); rs = kao.solve(ts, seed=3, time_limit_s=2.0, schedule=1); dt = time.perf_counter() - t0
+    t0 = time.perf_counter(); rs = kao.solve(ts, seed=3, time_limit_s=2.0, schedule=SCHEDS[0]); dt = time.perf_counter() - t0
     print(f"trace cfg4 batch: proven {sum(r.status == 'OPTIMAL_PROVEN' for r in rs)}/200 in {dt:.3f}s {kao.last_solve_timing()}", flush=True)
     del os.environ["KAO_SOLVE_TRACE"]
 
