@@ -28,7 +28,7 @@ DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
     // 29 / 49 / 43 / 48 / 77 us per iteration; the 200-topic config-4 batch: 1.0 ms and 9.5 us).  Interpolated on a log scale
     // of the largest topic's replica slots and rounded down a little: K-bound finishing early costs it some idle time, K-bound
     // finishing late stalls the search.
-    static const struct { int64_t slots; int iters; } tab[] = {{512, 128}, {3000, 56}, {6000, 88}, {15000, 112}, {30000, 144}, {90000, 176}};
+    static const struct { int64_t slots; int iters; } tab[] = {{512, 128}, {3000, 56}, {6000, 80}, {15000, 96}, {30000, 136}, {90000, 176}};
     const int nt = (int)(sizeof tab / sizeof tab[0]);
     if (slots <= tab[0].slots) d.bound_iters = tab[0].iters;
     else if (slots >= tab[nt - 1].slots) d.bound_iters = tab[nt - 1].iters;
