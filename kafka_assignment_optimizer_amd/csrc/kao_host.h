@@ -76,6 +76,7 @@ struct kao_eval_plan {
     bool timed = false;
     int cands_per_block = 32;
     bool cur_in_lds = true;
+    bool coop = false;            // the last batch ran one candidate per workgroup (k_eval<NE, true>)
     int device = 0;
 };
 
@@ -104,6 +105,7 @@ struct kao_session {
         int nw = kRFP;       // replica words per partition of the group's topics: 4 or 8 (template instantiation)
         bool global_a = false;   // topic too large for LDS: assignment + current words stay in global memory
         bool cur_in_lds = true;  // K-eval stages the current assignment in LDS (false: reads it from global)
+        bool eval_coop = false;  // K-eval: one candidate per workgroup, wavefronts cooperating (few large candidates)
         int smap_off = 0, smap_n = 0, emap_off = 0, emap_n = 0;
     };
     std::vector<LaunchGroup> groups;

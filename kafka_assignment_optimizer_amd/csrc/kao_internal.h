@@ -104,6 +104,7 @@ struct EvalPools {
     unsigned long long *best_key;// [n_topics] or nullptr (atomicMin of the packed key)
     int32_t maxP, maxB;
     int32_t cur_in_lds;          // 1 = stage the current assignment in LDS (fits); 0 = read it from global memory
+    int32_t coop;                // 1 = one candidate per workgroup, its wavefronts cooperating (k_eval<NE, true>): few large candidates
     const uint32_t *bwd_pool;    // broker weights per dense index (topics with has_bw)
     int32_t *overflow;           // [1] or nullptr: set when a candidate puts more than 65,535 replicas on one broker (the 16-bit
                                  //     halves of the per-broker counters would carry; only possible when P*RF > 65535)

@@ -618,9 +618,10 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             // `ty` is the (wave-uniform) move type as a compile-time constant: each instantiation is straight-line code, so the
             // two slots of a trip below interleave -- a big topic runs one wavefront per SIMD and the LDS round trips of one
             // slot (A[p], then W[x] / K[rack]) are hidden behind the other slot's, not behind other wavefronts
-            auto score_slot = [&](auto ty, uint32_t &key_o, int &p_o, int &k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
+            // (p_o comes in: the lane's first slot is in a random partition, its further slots in the partitions that follow it
+            //  cyclically -- on topics that live in HBM the slots of a lane then share two cache lines instead of touching 16)
+            auto score_slot = [&](auto ty, uint32_t &key_o, int p_o, int &k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
                 constexpr int TY = decltype(ty)::value;
-                p_o = (int)rnd24_wide(rng, (uint32_t)T.P);
                 k_o = (int)rnd24(rng, RF8);
                 const Part<NW> al = L.A[p_o];
                 const Part<NW> cl = CUR[p_o];
@@ -654,11 +655,15 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             // large topics: up to 16 slots per lane, the lane keeps its best; two slots per trip.  Draw and comparison order
             // are those of a one-at-a-time loop.
             auto tournament = [&](auto ty) {
-                score_slot(ty, keyA, pl_, kl_, oldw_l, g_old_l, dvo_l, dvr_l);
+                const int p0 = (int)rnd24_wide(rng, (uint32_t)T.P);
+                auto part = [&](int ga) { const int q2 = p0 + ga; return q2 < T.P ? q2 : q2 - T.P; };   // GA <= 16 <= P whenever GA > 1
+                pl_ = p0;
+                score_slot(ty, keyA, p0, kl_, oldw_l, g_old_l, dvo_l, dvr_l);
                 int ga = 1;
                 for (; kWide && ga + 1 < GA; ga += 2) {
                     uint32_t kg0, ow0, kg1, ow1;
-                    int pg0, kk0, gg0, d10 = 0, d20 = 0, pg1, kk1, gg1, d11 = 0, d21 = 0;
+                    int kk0, gg0, d10 = 0, d20 = 0, kk1, gg1, d11 = 0, d21 = 0;
+                    const int pg0 = part(ga), pg1 = part(ga + 1);
                     score_slot(ty, kg0, pg0, kk0, ow0, gg0, d10, d20);
                     score_slot(ty, kg1, pg1, kk1, ow1, gg1, d11, d21);
                     if (kg0 < keyA) { keyA = kg0; pl_ = pg0; kl_ = kk0; oldw_l = ow0; g_old_l = gg0; dvo_l = d10; dvr_l = d20; }
@@ -666,7 +671,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 }
                 for (; ga < GA; ++ga) {
                     uint32_t kg, ow;
-                    int pg, kk, gg, d1 = 0, d2 = 0;
+                    int kk, gg, d1 = 0, d2 = 0;
+                    const int pg = part(ga);
                     score_slot(ty, kg, pg, kk, ow, gg, d1, d2);
                     if (kg < keyA) { keyA = kg; pl_ = pg; kl_ = kk; oldw_l = ow; g_old_l = gg; dvo_l = d1; dvr_l = d2; }
                 }
@@ -914,7 +920,12 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
 // K-eval
 // ------------------------------------------------------------------------------------------------
 // NE = replica slots handled per partition: 4 (RF and current RF <= 4) or 8.
-template <int NE>
+// kCoop = false: one wavefront per candidate (4 candidates in flight per workgroup) -- batches that fill the device.
+// kCoop = true : the WHOLE workgroup evaluates one candidate, its four wavefronts striding the partitions over one shared set
+//                of LDS counters -- few large candidates (a 30,000-partition topic has 256 restarts; KAO-CX scores <= 513
+//                realisations): one wavefront per candidate left 3 of 4 SIMDs idle and took 469 dependent trips per candidate.
+//                All sums are integers, so the split changes no result.
+template <int NE, bool kCoop>
 __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     unsigned long long *wave_key = reinterpret_cast<unsigned long long *>(smem_all);  // [kWaves], 32 B
@@ -934,7 +945,9 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     const int c_bytes = (pl.maxB * 4 + 15) & ~15;
     uint8_t *RACK = smem;
     uint16_t *CURD = reinterpret_cast<uint16_t *>(smem + r_bytes);
-    unsigned char *wb = smem + r_bytes + ((d_bytes + 15) & ~15) + wave * (c_bytes + kRackTab * 4);
+    unsigned char *wb = smem + r_bytes + ((d_bytes + 15) & ~15) + (kCoop ? 0 : wave) * (c_bytes + kRackTab * 4);
+    int *red = reinterpret_cast<int *>(smem + r_bytes + ((d_bytes + 15) & ~15) + kWaves * (c_bytes + kRackTab * 4));   // [kWaves][8] (kCoop)
+    const int tid = kCoop ? (int)threadIdx.x : lane, tstride = kCoop ? 256 : 64;
     uint32_t *C = reinterpret_cast<uint32_t *>(wb);
     int *K = reinterpret_cast<int *>(wb + c_bytes);
 
@@ -958,10 +971,11 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     const int kcopy = 4 * KR <= kRackTab ? (lane >> 4) * KR : 0;
     const bool k4 = 4 * KR <= kRackTab;
     const bool big = P * RF > 65535;   // only then can a 16-bit per-broker counter overflow
-    for (int ci = bm.y + wave; ci < bm.y + bm.z; ci += kWaves) {
+    for (int ci = bm.y + (kCoop ? 0 : wave); ci < bm.y + bm.z; ci += (kCoop ? 1 : kWaves)) {
         const uint16_t *cand = pl.cand + TD->best_off + (uint64_t)ci * P * RF;
-        for (int b4 = lane; b4 < nB4; b4 += 64) reinterpret_cast<uint4 *>(C)[b4] = make_uint4(0, 0, 0, 0);
-        for (int r = lane; r < kRackTab; r += 64) K[r] = 0;
+        for (int b4 = tid; b4 < nB4; b4 += tstride) reinterpret_cast<uint4 *>(C)[b4] = make_uint4(0, 0, 0, 0);
+        for (int r = tid; r < kRackTab; r += tstride) K[r] = 0;
+        if (kCoop) __syncthreads();
         // Broker band violations are accumulated from the value each LDS atomic RETURNS: adding a replica to a
         // broker whose count was c changes band(c) by (c >= hi) - (c < lo), and sum_b band(0) = B*lo, so
         // no pass over all brokers is needed.  Packed partial sums: low half = #(old >= hi), high = #(old < lo).
@@ -970,7 +984,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
         uint32_t s3 = 0, s4 = 0;
         uint32_t s57 = 0;  // v5 | v7 << 16
         bool ovf = false;
-        for (int p = lane; p < P; p += 64) {
+        for (int p = tid; p < P; p += tstride) {
             const uint16_t *ap = cand + (size_t)p * RF;  // a wavefront reads 64*RF consecutive u16: coalesced
             uint32_t bk[NE], rk[NE], ck[NE];
             uint32_t cw[NE / 2];   // the partition's current replicas, two u16 per word: one ds_read_b64 / b128 when staged in LDS
@@ -1023,32 +1037,45 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             }
             s57 += (uint32_t)(s7 + (R - touched) * prack_lo) << 16;
         }
-        // C6 from the rack totals (the wavefront's own LDS operations complete in order: no barrier needed)
+        // C6 from the rack totals (the wavefront's own LDS operations complete in order: no barrier needed; the cooperating
+        // wavefronts of kCoop meet at one)
+        if (kCoop) __syncthreads();
         int s6 = 0;
-        for (int r = lane; r < R; r += 64) {
+        for (int r = tid; r < R; r += tstride) {
             const int tot = k4 ? K[r] + K[KR + r] + K[2 * KR + r] + K[3 * KR + r] : K[r];
             s6 += band(tot, rack_lo, rack_hi);
         }
         if (big && __ballot(ovf) != 0ull && pl.overflow && lane == 0) atomicOr(pl.overflow, 1);
         obj = wave_sum(obj);
-        int v1, v2, v3, v4, v5, v6, v7;
+        int v1, v2, v3, v4, v5, v6, v7;   // (v3, v4 without their constants B * lo until the partial sums have met)
         if (P * RF <= 32767) {  // packed halves cannot carry: every count is at most P*RF
             const uint32_t t12 = (uint32_t)wave_sum((int)s12), t3 = (uint32_t)wave_sum((int)s3), t4 = (uint32_t)wave_sum((int)s4);
             const uint32_t t57 = (uint32_t)wave_sum((int)s57);
             v1 = (int)(t12 & 0xFFFFu); v2 = (int)(t12 >> 16);
-            v3 = B * rep_lo + (int)(t3 & 0xFFFFu) - (int)(t3 >> 16);
-            v4 = B * lead_lo + (int)(t4 & 0xFFFFu) - (int)(t4 >> 16);
+            v3 = (int)(t3 & 0xFFFFu) - (int)(t3 >> 16);
+            v4 = (int)(t4 & 0xFFFFu) - (int)(t4 >> 16);
             v5 = (int)(t57 & 0xFFFFu); v7 = (int)(t57 >> 16);
         } else {  // huge topic: per-lane halves still fit 16 bits, the wavefront totals do not -> sum them unpacked
             v1 = wave_sum((int)(s12 & 0xFFFFu)); v2 = wave_sum((int)(s12 >> 16));
-            v3 = B * rep_lo + wave_sum((int)(s3 & 0xFFFFu)) - wave_sum((int)(s3 >> 16));
-            v4 = B * lead_lo + wave_sum((int)(s4 & 0xFFFFu)) - wave_sum((int)(s4 >> 16));
+            v3 = wave_sum((int)(s3 & 0xFFFFu)) - wave_sum((int)(s3 >> 16));
+            v4 = wave_sum((int)(s4 & 0xFFFFu)) - wave_sum((int)(s4 >> 16));
             v5 = wave_sum((int)(s57 & 0xFFFFu)); v7 = wave_sum((int)(s57 >> 16));
         }
         v6 = wave_sum(s6);
+        if (kCoop) {   // the four wavefronts' partial sums meet in LDS; every wavefront reads the totals
+            if (lane == 0) { int *q = red + wave * 8; q[0] = obj; q[1] = v1; q[2] = v2; q[3] = v3; q[4] = v4; q[5] = v5; q[6] = v6; q[7] = v7; }
+            __syncthreads();
+            obj = v1 = v2 = v3 = v4 = v5 = v6 = v7 = 0;
+            for (int w = 0; w < kWaves; ++w) {
+                const int *q = red + w * 8;
+                obj += q[0]; v1 += q[1]; v2 += q[2]; v3 += q[3]; v4 += q[4]; v5 += q[5]; v6 += q[6]; v7 += q[7];
+            }
+            __syncthreads();   // the counters and `red` are reused by the next candidate
+        }
+        v3 += B * rep_lo; v4 += B * lead_lo;
         const int v0 = v1 + v2 + v3 + v4 + v5 + v6 + v7;
         const int out = bm.w + (ci - bm.y);
-        if (lane == 0) {
+        if (lane == 0 && (!kCoop || wave == 0)) {
             if (pl.objective) pl.objective[out] = obj;
             if (pl.violations) {
                 int4 *vo = reinterpret_cast<int4 *>(pl.violations + (size_t)out * 8);
@@ -1222,7 +1249,7 @@ size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool pric
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 2 * (size_t)ne + 15) & ~(size_t)15 : 0;
     const size_t c = ((size_t)maxB * 4 + 15) & ~(size_t)15;
-    return 32 + r + d + kWaves * (c + kRackTab * 4);
+    return 32 + r + d + kWaves * (c + kRackTab * 4) + kWaves * 8 * 4;   // (+ the partial sums of the cooperative mode)
 }
 
 // largest dynamic-LDS size each kernel has been enabled for, per device (function attributes are per device)
@@ -1264,12 +1291,20 @@ void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream) {
     const size_t lds = eval_lds_bytes(pools.maxP, pools.maxB, pools.cur_in_lds != 0, ne);
     int &g_attr_eval = g_attr_eval_dev[attr_slot()];
     if ((int)lds > g_attr_eval) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_eval = (int)lds;
     }
-    if (ne == 8) hipLaunchKernelGGL(k_eval<8>, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools);
-    else hipLaunchKernelGGL(k_eval<4>, dim3(n_blocks), dim3(256), lds, static_cast<hipStream_t>(stream), pools);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (pools.coop) {
+        if (ne == 8) hipLaunchKernelGGL((k_eval<8, true>), dim3(n_blocks), dim3(256), lds, st, pools);
+        else hipLaunchKernelGGL((k_eval<4, true>), dim3(n_blocks), dim3(256), lds, st, pools);
+    } else {
+        if (ne == 8) hipLaunchKernelGGL((k_eval<8, false>), dim3(n_blocks), dim3(256), lds, st, pools);
+        else hipLaunchKernelGGL((k_eval<4, false>), dim3(n_blocks), dim3(256), lds, st, pools);
+    }
 }
 
 void launch_gather(const TopicDev *topics, int n_topics, const unsigned long long *keys, const uint16_t *best_pool,

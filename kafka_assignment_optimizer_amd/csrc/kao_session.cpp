@@ -268,6 +268,8 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
         int cpb = p->cands_per_block;
         const int64_t fill = 4 * (int64_t)std::max(num_cu(p->device), 1);
         if (n < fill * 8) cpb = (int)std::min<int64_t>(cpb, std::max<int64_t>(kWaves, ((n + fill - 1) / fill) * kWaves));
+        p->coop = n <= fill && p->pt.d.P >= 1024;   // few large candidates: one workgroup each, its wavefronts cooperating
+        if (p->coop) cpb = 1;
         const int nb = (int)((n + cpb - 1) / cpb);
         std::vector<int4> map((size_t)nb);
         for (int b = 0; b < nb; ++b) {
@@ -287,7 +289,7 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
     pl.objective = static_cast<int32_t *>(d_objective);
     pl.violations = static_cast<int32_t *>(d_violations);
     pl.best_key = static_cast<unsigned long long *>(d_best_key);
-    pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B; pl.cur_in_lds = p->cur_in_lds ? 1 : 0;
+    pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B; pl.cur_in_lds = p->cur_in_lds ? 1 : 0; pl.coop = p->coop ? 1 : 0;
     pl.overflow = p->d_overflow; pl.bwd_pool = p->d_bwd;
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     launch_eval(pl, p->map_blocks, p->pt.d.nw, p->stream);
@@ -598,15 +600,24 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         members.back().push_back(t);
     }
     std::vector<int2> smap; std::vector<int4> emap;
-    const int cpb = 32;  // candidates per K-eval workgroup
     for (const std::vector<int> &mem : members) {
         kao_session::LaunchGroup g;
+        // candidates (one best snapshot per restart) per K-eval workgroup: 32 when the group fills the device; fewer when it does
+        // not (a 30,000-partition topic has 256 restarts: at 32 per workgroup that was EIGHT workgroups, 2.9 ms per step --
+        // a third of the step); few large candidates get one workgroup each, its wavefronts cooperating (k_eval<NE, true>)
+        int64_t n_cand = 0;
+        for (int t : mem) n_cand += s->pts[(size_t)t].d.n_restarts;
+        const int64_t fill = 4 * (int64_t)std::max(g_num_cu, 1);
+        int cpb = 32;
+        if (n_cand < fill * 32) cpb = (int)std::min<int64_t>(32, std::max<int64_t>(kWaves, ((n_cand + fill - 1) / fill + kWaves - 1) / kWaves * kWaves));
         for (int t : mem) {
             const TopicDev &d = s->pts[(size_t)t].d;
             g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B); g.maxR = std::max(g.maxR, d.R); g.wide = g.wide || (int64_t)d.P * d.RF >= 512;
         }
         g.global_a = s->topic_global[(size_t)mem[0]] != 0;
         g.nw = s->pts[(size_t)mem[0]].d.nw;
+        g.eval_coop = n_cand <= fill && g.maxP >= 1024;
+        if (g.eval_coop) cpb = 1;
         while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR) > 160 * 1024) g.waves /= 2;
         g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true, g.nw) <= 160 * 1024;
         if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
@@ -763,7 +774,7 @@ int kao_session_step(kao_session *s) {
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
     for (const kao_session::LaunchGroup &g : s->groups) {
         ep.block_map = s->d_emap + g.emap_off;
-        ep.maxP = g.maxP; ep.maxB = g.maxB; ep.cur_in_lds = g.cur_in_lds ? 1 : 0;
+        ep.maxP = g.maxP; ep.maxB = g.maxB; ep.cur_in_lds = g.cur_in_lds ? 1 : 0; ep.coop = g.eval_coop ? 1 : 0;
         launch_eval(ep, g.emap_n, g.nw, s->stream);
         HIP_TRY(hipGetLastError());
     }

@@ -421,7 +421,8 @@ static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
  *     sample : every lane proposes its own random slot and 4 candidate brokers (ls_lane).
  *   EXCHANGE : tournament slot (p,k), then every partner slot (q,j) is scanned (lane = partition q); topics with
  *              more than 512 partitions scan a random window of 512 (8 rounds).
- *   The tournament scores clamp(P*RF/256, 1, 16) random slots per lane on the first T lanes; the score is the cost of
+ *   The tournament scores clamp(P*RF/256, 1, 16) slots per lane on the first T lanes -- a random partition and the ones that
+ *   follow it, a random slot of each; the score is the cost of
  *   taking the replica out of its slot under the current penalty (for an EXCHANGE only the partition's rack spread counts).
  *   LEADER-SWAP : every lane a random partition, all RF-1 swaps (ls_lane).
  * --------------------------------------------------------------------------------------------- */
@@ -458,8 +459,11 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
             /* ---- phase A: tournament over T random slots, lowest removal score wins ---- */
             uint32_t keyA = KEY_NULL; int p = 0, k = 0;
             for (uint32_t l = 0; l < LANES; ++l)
-              for (int ga = 0; ga < GA; ++ga) {
-                const int pl = (int)rnd24(&rng[l], (uint32_t)P);
+              for (int ga = 0, p0 = 0; ga < GA; ++ga) {
+                /* the lane draws ONE partition; its further slots come from the partitions that follow it (cyclically): on topics
+                 * that live in HBM the 16 slots of a lane then share two cache lines instead of touching 16 */
+                if (ga == 0) p0 = (int)rnd24(&rng[l], (uint32_t)P);
+                const int pl = p0 + ga < P ? p0 + ga : p0 + ga - P;
                 const int kl = (int)rnd24(&rng[l], (uint32_t)RF);
                 if ((int)l >= T) continue;
                 const uint16_t *al = s->A + pl * RFP;

@@ -234,3 +234,12 @@ def test_product_does_not_import_oracle():
                 for pat in (r"import\s+kao_(oracle|port)", r"from\s+(oracle|kao_oracle|kao_port)\b", r"libkao_port",
                             r"#include\s+[\"<][^\n]*oracle", r"sys\.path[^\n]*oracle", r"dlopen[^\n]*oracle"):
                     assert not re.search(pat, src), (f, pat)
+
+
+@pytest.mark.slow
+def test_host_code_under_asan_and_ubsan():
+    """tools/sanitize_host.sh: the host side (validation, bands, closed-form bound, infeasibility proofs, LP writer, CLI parsing)
+    rebuilt with -fsanitize=address,undefined and run over the golden families -- no GPU involved.  Minutes of hipcc: -m slow."""
+    import subprocess
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh")], cwd=ROOT, capture_output=True, timeout=1800)
+    assert out.returncode == 0 and b"sanitised host code: ok" in out.stdout and b"sanitised kao-cli --emit-lp: ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
