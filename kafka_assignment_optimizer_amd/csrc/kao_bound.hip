@@ -19,6 +19,11 @@
 //                 For topics of 10^4..10^5 partitions, where one compute unit per topic was what the certificate
 //                 waited for.  Same arithmetic, same order of decisions: the two agree bit for bit.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
 #include <limits.h>
 
 #include "kao_device.h"
@@ -725,6 +730,27 @@ void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream
     hipLaunchKernelGGL(k_bound, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools);
 }
 
+// The launch sequence of one sliced K-bound launch as a hipGraph: begin, `iters` x step, the probes, finish -- up to ~180 kernel
+// nodes with unchanged arguments from one launch to the next (the targets, the topic list and the slice map are device buffers
+// whose CONTENTS change; the two price halves alternate).  Instantiated graphs are cached per argument set; a replay is one
+// enqueue.  KAO_BOUND_GRAPH=0 falls back to plain stream launches (the two must agree: same kernels, same order).
+namespace {
+struct BoundGraphKey {
+    BoundPools p; BoundWide w; int n_topics, n_blocks, waves, device;
+    bool operator==(const BoundGraphKey &o) const { return std::memcmp(this, &o, sizeof *this) == 0; }
+};
+struct BoundGraph { BoundGraphKey key; hipGraphExec_t exec; };
+std::vector<BoundGraph> g_bound_graphs;   // a handful per process (sessions come and go; LRU of 16)
+std::mutex g_bound_graph_mu;
+bool bound_graph_wanted() { static const bool on = [] { const char *e = std::getenv("KAO_BOUND_GRAPH"); return !(e && e[0] == '0'); }(); return on; }
+void bound_wide_enqueue(const BoundPools &pools, const BoundWide &wide, int n_topics, int n_blocks, int waves, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL(k_bound_begin, dim3((n_topics + 63) / 64), dim3(64), 0, st, pools, wide, n_topics);
+    for (int i = 0; i < pools.iters; ++i) hipLaunchKernelGGL(k_bound_step, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, 0);
+    for (int m = 1; m <= kDualProbes; ++m) hipLaunchKernelGGL(k_bound_step, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, m);
+    hipLaunchKernelGGL(k_bound_finish, dim3(n_topics), dim3(256), 0, st, pools);
+}
+}  // namespace
+
 void launch_bound_wide(const BoundPools &pools, const BoundWide &wide, int n_topics, int n_blocks, int waves, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t lds = bound_lds_bytes(pools.maxB, 0, pools.maxR, false);
@@ -733,10 +759,35 @@ void launch_bound_wide(const BoundPools &pools, const BoundWide &wide, int n_top
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bound_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr = (int)lds;
     }
-    hipLaunchKernelGGL(k_bound_begin, dim3((n_topics + 63) / 64), dim3(64), 0, st, pools, wide, n_topics);
-    for (int i = 0; i < pools.iters; ++i) hipLaunchKernelGGL(k_bound_step, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, 0);
-    for (int m = 1; m <= kDualProbes; ++m) hipLaunchKernelGGL(k_bound_step, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, m);
-    hipLaunchKernelGGL(k_bound_finish, dim3(n_topics), dim3(256), 0, st, pools);
+    if (bound_graph_wanted() && pools.iters >= 8) {
+        BoundGraphKey key;
+        std::memset(&key, 0, sizeof key);   // (padding bytes take part in the comparison)
+        key.p = pools; key.w = wide; key.n_topics = n_topics; key.n_blocks = n_blocks; key.waves = waves; key.device = attr_slot();
+        std::lock_guard<std::mutex> lock(g_bound_graph_mu);
+        for (size_t i = 0; i < g_bound_graphs.size(); ++i)
+            if (g_bound_graphs[i].key == key) {
+                if (hipGraphLaunch(g_bound_graphs[i].exec, st) == hipSuccess) {
+                    if (i) std::swap(g_bound_graphs[i], g_bound_graphs[i - 1]);   // towards the front: recently used
+                    return;
+                }
+                (void)hipGetLastError();
+                break;
+            }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            bound_wide_enqueue(pools, wide, n_topics, n_blocks, waves, lds, st);
+            const hipError_t e = hipStreamEndCapture(st, &graph);
+            if (e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                (void)hipGraphDestroy(graph);
+                if (g_bound_graphs.size() >= 16) { (void)hipGraphExecDestroy(g_bound_graphs.back().exec); g_bound_graphs.pop_back(); }
+                g_bound_graphs.insert(g_bound_graphs.begin(), BoundGraph{key, exec});
+                if (hipGraphLaunch(exec, st) == hipSuccess) return;
+            } else if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+        } else (void)hipGetLastError();
+    }
+    bound_wide_enqueue(pools, wide, n_topics, n_blocks, waves, lds, st);
 }
 
 }  // namespace kao

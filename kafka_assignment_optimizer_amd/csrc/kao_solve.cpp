@@ -24,11 +24,11 @@ DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
     (void)maxB; (void)n_topics;
     // K-bound iterations per launch = about one K-search launch's worth of time, so that neither stream waits for the other
     // (measured on one MI355X, wall-clock schedule with KAO_SOLVE_TRACE=1, profiles/r03_schedule_trace.txt: drifted single
-    // topics of 1,000 / 2,000 / 5,000 / 10,000 / 30,000 partitions: K-search launch 1.6 / 4.5 / 5.2 / 7.6 / 14.2 ms, K-bound
-    // 29 / 49 / 43 / 48 / 77 us per iteration; the 200-topic config-4 batch: 1.0 ms and 9.5 us).  Interpolated on a log scale
+    // topics of 1,000 / 2,000 / 5,000 / 10,000 / 30,000 partitions: K-search launch 1.6 / 4.0 / 4.4 / 7.3 / 8.4 ms with prices, K-bound
+    // 29 / 49 / 43 / 48 / 60 us per iteration; the 200-topic config-4 batch: 1.0 ms and 9.5 us).  Interpolated on a log scale
     // of the largest topic's replica slots and rounded down a little: K-bound finishing early costs it some idle time, K-bound
     // finishing late stalls the search.
-    static const struct { int64_t slots; int iters; } tab[] = {{512, 128}, {3000, 56}, {6000, 80}, {15000, 96}, {30000, 136}, {90000, 176}};
+    static const struct { int64_t slots; int iters; } tab[] = {{512, 128}, {3000, 56}, {6000, 80}, {15000, 88}, {30000, 120}, {90000, 136}};
     const int nt = (int)(sizeof tab / sizeof tab[0]);
     if (slots <= tab[0].slots) d.bound_iters = tab[0].iters;
     else if (slots >= tab[nt - 1].slots) d.bound_iters = tab[nt - 1].iters;
