@@ -143,6 +143,21 @@ def load_profile_constants(tag, iters, restarts_total):
     return None
 
 
+def load_big_constants(which):
+    """Per-kernel counter figures of the north-star workloads (tools/profile_big.sh -> profiles/r03_big_<which>_constants.json)."""
+    path = os.path.join(ROOT, "profiles", "r03_big_%s_constants.json" % which)
+    try:
+        with open(path) as f:
+            c = json.load(f)
+    except (OSError, ValueError):
+        return None
+    out = {"source": "profiles/" + os.path.basename(path)}
+    for k, v in c.items():
+        if isinstance(v, dict) and "hbm_bytes" in v:
+            out["k_search" if k.startswith("k_search") else ("k_eval" if k.startswith("k_eval") else k)] = v
+    return out
+
+
 def write_cli_inputs(topics, path_prefix):
     """current.json / racks.json / broker list for cli/kao-cli from product topics (replicas on removed brokers get ids
     outside the target list, as in README.md:52-63 where broker 19 is about to be removed)."""
@@ -409,6 +424,34 @@ def main():
                                   "note": "one kao_solve call per topic (K-search + K-bound + KAO-CX), 20 % drift, tools/drift_scale.py's "
                                           "instances; exact references from tests/golden/drift_scale.json (HiGHS: MILP optimum where branch-and-"
                                           "bound finished, value of the LP relaxation where only that did; none for the largest)"}
+
+    # ---- the north-star regime (BASELINE config 5): one LARGE topic, assignment words in HBM/L2 -- the kernel variants that
+    #      run there (k_search<true, ...>, the cooperative k_eval) against the HBM peak; traffic from profiles/ (rocprofv3 --pmc) ----
+    if not args.no_extras and rank == 0:
+        big = []
+        for which in ("drift30k", "cfg5one"):
+            st = synthetic.north_star_steps(kao, which, launches=4)
+            prof_b = load_big_constants(which)
+            e = {"workload": which, "brokers": st["brokers"], "partitions": st["partitions"], "restarts": st["restarts"],
+                 "iters_per_launch": st["iters_per_launch"], "wall_ms_per_step": st["wall_ms_per_launch"], "drift": st["drift"]}
+            for kern, ms, algo in (("k_search", st["k_search_ms_per_launch"], st["k_search_algorithmic_bytes_per_launch"]),
+                                   ("k_eval", st["k_eval_ms_per_launch"], st["k_eval_algorithmic_bytes_per_launch"])):
+                r = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": ms, "algorithmic_bytes_per_launch": algo,
+                     "algorithmic_gbps": algo / (ms * 1e-3) / 1e9 if ms > 0 else None, "achieved": None, "frac": None, "traffic": None}
+                pk = prof_b.get(kern) if prof_b else None
+                if pk and ms > 0:
+                    r["traffic"] = pk["hbm_bytes"]
+                    r["achieved"] = pk["hbm_bytes"] / (ms * 1e-3) / 1e9
+                    r["frac"] = r["achieved"] / HBM_PEAK_GBS
+                    r["traffic_over_algorithmic"] = pk["hbm_bytes"] / algo if algo else None
+                    r["valu_insts_per_launch"] = pk.get("SQ_INSTS_VALU")
+                    r["traffic_note"] = "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 wide-read correction) + WRITE_SIZE per launch, separate passes, " + prof_b["source"]
+                e[kern] = r
+            big.append(e)
+        out["roofline_big_topic"] = {"topics": big,
+                                     "note": "K-search + K-eval steps of one session on a single large topic (synthetic.north_star_topic): "
+                                             "the assignment words live in HBM/L2 (16 B per partition per restart, updated in place); k_search<true,...> is "
+                                             "bound by the latency of dependent global loads at one wavefront per SIMD, not by bandwidth"}
 
     # ---- roofline of the dominant kernel (K-search), duration from HIP events on the session stream -------
     avg_ms = ms_search / max(1, launches)

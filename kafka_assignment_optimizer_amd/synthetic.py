@@ -130,3 +130,50 @@ def make_config(n: int, n_topics: Optional[int] = None) -> List[Topic]:
         cap = -((-100 * 3) // 1000) + 1
         return make_cluster(1000, 20, n_topics or 1000, 100, 3, rm, add, bounds_override={"rep_hi": cap})
     raise ValueError("config must be 2..5 (config 1 is the README example: use topics_from_json)")
+
+
+def north_star_topic(which: str) -> Topic:
+    """The single large topics of the north-star regime (BASELINE config 5 and its drifted relatives), shared by bench.py's
+    `roofline_big_topic` leg, tools/big_topic.py and the GPU tests:
+      cfg5one  = config 5 taken literally as ONE topic: 1000 brokers / 20 racks, 100,000 partitions RF 3, 50 brokers replaced
+                 (each new broker joins the rack of a removed one: with uneven racks the single-topic rack band would be
+                 infeasible, SURVEY.md H5), per-broker cap ceil(avg)+1;
+      drift30k = 1000 brokers / 20 racks x 30,000 partitions after a 20 % drift;   drift5k = 500 / 10 x 5,000 likewise."""
+    if which == "drift30k":
+        return drift(make_cluster(1000, 20, 1, 30000, 3, [], []), 0.2, 1)[0]
+    if which == "drift5k":
+        return drift(make_cluster(500, 10, 1, 5000, 3, [], []), 0.2, 1)[0]
+    if which == "cfg5one":
+        rng = SplitMix64(CONFIG_SEED + 5)
+        rm = rng.sample(list(range(1000)), 50)
+        add = [(1000 + i, b % 20) for i, b in enumerate(rm)]
+        return make_cluster(1000, 20, 1, 100_000, 3, rm, add, bounds_override={"rep_hi": 301})[0]
+    raise ValueError("north_star_topic: drift30k | drift5k | cfg5one")
+
+
+def north_star_steps(kao, which: str, launches: int = 6, iters: int = 512, restarts: int = 0) -> dict:
+    """`launches` K-search + K-eval steps of a session on north_star_topic(which) after the init launch: per-launch HIP-event
+    times and SURVEY.md 8(d)'s algorithmic bytes (`kao` = the package, initialised)."""
+    import time
+    t = north_star_topic(which)
+    opts = dict(seed=3, iters_per_launch=iters, profile=1)
+    if restarts:
+        opts["restarts"] = restarts
+    with kao.Session([t], **opts) as s:
+        s.step(1)                      # launch 0: best-insertion init + the first iterations (not timed)
+        s.sync()
+        a = s.stats()
+        t0 = time.perf_counter()
+        s.step(launches)
+        s.sync()
+        wall = time.perf_counter() - t0
+        b = s.stats()
+        best = s.best()[0]
+    n = launches
+    rf, P, B = t.rf, t.n_partitions, t.n_brokers
+    nb = (b["delta_candidates"] - a["delta_candidates"]) / n
+    return {"workload": which, "brokers": B, "partitions": P, "rf": rf, "restarts": b["n_restarts_total"], "iters_per_launch": iters,
+            "launches_timed": n, "k_search_ms_per_launch": (b["ms_search"] - a["ms_search"]) / n, "k_eval_ms_per_launch": (b["ms_eval"] - a["ms_eval"]) / n,
+            "wall_ms_per_launch": 1e3 * wall / n, "neighbours_per_launch": nb, "k_search_algorithmic_bytes_per_launch": nb * (8 * rf + 10),
+            "k_eval_algorithmic_bytes_per_launch": b["n_restarts_total"] * (4 * rf * P + B), "k_search_lds_bytes": b["lds_bytes_search"],
+            "k_search_workgroups": b["blocks_search"], "objective_after": int(best.objective), "violation_after": int(best.violations[0]), "drift": b["drift"]}

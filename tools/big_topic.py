@@ -10,42 +10,11 @@ from kafka_assignment_optimizer_amd import synthetic as sy
 
 
 def instance(which):
-    if which == "drift30k":
-        return sy.drift(sy.make_cluster(1000, 20, 1, 30000, 3, [], []), 0.2, 1)[0]
-    if which == "drift5k":
-        return sy.drift(sy.make_cluster(500, 10, 1, 5000, 3, [], []), 0.2, 1)[0]
-    if which == "cfg5one":
-        rng = sy.SplitMix64(sy.CONFIG_SEED + 5)
-        rm = rng.sample(list(range(1000)), 50)
-        add = [(1000 + i, b % 20) for i, b in enumerate(rm)]
-        return sy.make_cluster(1000, 20, 1, 100_000, 3, rm, add, bounds_override={"rep_hi": 301})[0]
-    raise SystemExit("which: drift30k | drift5k | cfg5one")
+    return sy.north_star_topic(which)
 
 
 def steps(which, launches=6, iters=512, restarts=0):
-    """`launches` K-search + K-eval steps after the init launch; returns the per-launch figures of the timed ones."""
-    t = instance(which)
-    opts = dict(seed=3, iters_per_launch=iters, profile=1)
-    if restarts:
-        opts["restarts"] = restarts
-    with kao.Session([t], **opts) as s:
-        s.step(1)                      # launch 0: best-insertion init + the first iterations (not timed)
-        s.sync()
-        a = s.stats()
-        t0 = time.perf_counter()
-        s.step(launches)
-        s.sync()
-        wall = time.perf_counter() - t0
-        b = s.stats()
-        best = s.best()[0]
-    n = launches
-    rf, P, B = t.rf, t.n_partitions, t.n_brokers
-    nb = (b["delta_candidates"] - a["delta_candidates"]) / n
-    return {"workload": which, "brokers": B, "partitions": P, "rf": rf, "restarts": b["n_restarts_total"], "iters_per_launch": iters,
-            "launches_timed": n, "k_search_ms_per_launch": (b["ms_search"] - a["ms_search"]) / n, "k_eval_ms_per_launch": (b["ms_eval"] - a["ms_eval"]) / n,
-            "wall_ms_per_launch": 1e3 * wall / n, "neighbours_per_launch": nb, "k_search_algorithmic_bytes_per_launch": nb * (8 * rf + 10),
-            "k_eval_algorithmic_bytes_per_launch": b["n_restarts_total"] * (4 * rf * P + B), "k_search_lds_bytes": b["lds_bytes_search"],
-            "k_search_workgroups": b["blocks_search"], "objective_after": int(best.objective), "violation_after": int(best.violations[0]), "drift": b["drift"]}
+    return sy.north_star_steps(kao, which, launches, iters, restarts)
 
 
 if __name__ == "__main__":

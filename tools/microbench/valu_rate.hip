@@ -6,8 +6,11 @@
 #include <cstdint>
 
 #define REP 64
+// clk[0] += shader-clock ticks (s_memtime), clk[1] += ticks of the constant 100 MHz reference (s_memrealtime) spent in the loop by
+// one wavefront: their ratio is the REAL shader clock during the run (the table assumed 2.4 GHz instead of measuring)
 template <int KIND>
-__global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t s0, uint32_t s1) {
+__global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t s0, uint32_t s1, unsigned long long *clk) {
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
     uint32_t a = threadIdx.x * 2654435761u + s0, b = a ^ s1, c = a + 7, d = b + 11, e = a ^ 0x1234567u, f = b * 3u, g = c + d, h = e ^ f;
     unsigned long long p0 = ((unsigned long long)a << 32) | b, p1 = ((unsigned long long)c << 32) | d, p2 = ((unsigned long long)e << 32) | f,
                        p3 = ((unsigned long long)g << 32) | h;
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int iters, uint32_t s0, 
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h ^ (uint32_t)(p0 ^ p1 ^ p2 ^ p3) ^ (uint32_t)((p0 ^ p1 ^ p2 ^ p3) >> 32);
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 
 template <int KIND>
@@ -73,18 +77,23 @@ double run(const char *name, uint32_t *d_out, int blocks, int threads = 256) {
     const int iters = 4000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 10, 1u, 3u);
+    static unsigned long long *d_clk = nullptr;
+    if (!d_clk) hipMalloc(reinterpret_cast<void **>(&d_clk), 16);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, 10, 1u, 3u, d_clk);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 1u, 3u);
+    hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), 0, 0, d_out, iters, 1u, 3u, d_clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long clk[2] = {0, 0};
+    hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost);
+    const double ghz = clk[1] ? (double)clk[0] / (double)clk[1] * 0.1 : 0.0;   // s_memtime ticks per s_memrealtime tick x 100 MHz
     const double winst = (double)blocks * (threads / 64) * iters * REP;  // wave-instructions
     const double rate = winst / (ms * 1e-3);
-    printf("%-44s %8.1f G wave-instr/s  = %.2f cycles per wave64 instruction per SIMD @2.4 GHz (1024 SIMDs)\n", name, rate / 1e9,
-           1024.0 * 2.4e9 / rate);
+    printf("%-44s %8.1f G wave-instr/s  = %.2f cycles per wave64 instruction per SIMD at the MEASURED shader clock %.3f GHz (%.2f at a nominal 2.4 GHz; 1024 SIMDs)\n",
+           name, rate / 1e9, ghz > 0 ? 1024.0 * ghz * 1e9 / rate : 0.0, ghz, 1024.0 * 2.4e9 / rate);
     return rate;
 }
 
