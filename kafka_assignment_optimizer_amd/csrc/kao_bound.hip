@@ -20,6 +20,7 @@
 //                 waited for.  Same arithmetic, same order of decisions: the two agree bit for bit.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -71,8 +72,12 @@ __device__ __forceinline__ int wave_argmax(uint32_t key, uint32_t id, uint32_t &
     return (int)__builtin_ctzll(__ballot(key == mx && id == sid));
 }
 
-constexpr int kTF = 4;   // follower candidates kept per rack (RF needed)
-constexpr int kTL = 5;   // leader candidates kept per rack (RF + 1 needed)
+// Every phase is instantiated for NE = 4 (RF and current RF <= 4: the README's range, 8 B of current assignment per partition)
+// and NE = 8 (RF 5..8, round 3).  Per rack the NE best follower candidates (RF needed) and the NE + 1 best leader candidates
+// (RF + 1 needed) are kept; the follower pool PF holds NE racks x NE brokers, the leader pool PL the best leader of NE + 1 racks.
+template <int NE> struct BoundDims {
+    static constexpr int kTF = NE, kTL = NE + 1, kPF = NE * NE, kPL = 2 * NE;
+};
 
 // wave-uniform copy of what the phases need from the topic descriptor
 struct BoundTopic {
@@ -97,17 +102,29 @@ struct BoundLds {
     int *ctl;            // [4]
     int *G, *DG, *NK;    // g[kRackTab], dg[kRackTab], replicas per rack in the subproblem solutions
     int *RO;             // first member of rack r in XB ([kRackTab + 2])
-    int *PFb, *PFr, *PFv;  // follower pool: broker, rack, generic value [16] each
-    int *PLb, *PLr, *PLv;  // best leader of the RF+1 best racks [8] each
+    int *PFb, *PFr, *PFv;  // follower pool: broker, rack, generic value [NE * NE] each
+    int *PLb, *PLr, *PLv;  // best leader of the RF+1 best racks [2 * NE] each
     int *TFb, *TFv;      // per rack: kTF best followers (broker, value)
     int *TLb, *TLv;      // per rack: kTL best leaders
     int *A, *LM;         // a[maxB], l[maxB]
     int *NR, *NL;        // replicas / leaders per broker in the subproblem solutions
     uint16_t *XB;        // brokers grouped by rack (ascending inside a rack)
     uint8_t *RK;         // rack of broker
-    uint2 *CURP;         // current assignment, 4 x u16 per partition (0xFFFF = none), when it fits next to the broker tables
+    uint32_t *BW;        // broker weights bw | bwl << 16 per dense broker (launches with weighted topics), else nullptr
+    uint32_t *CURP;      // current assignment, NE x u16 per partition (0xFFFF = none), when it fits next to the broker tables
 };
-__device__ __forceinline__ BoundLds bound_carve(unsigned char *smem_b, int maxB, int maxR) {
+// generic follower value F and leader value FL = F - l of broker b in rack r under the multipliers in LDS; broker weights are
+// plain objective coefficients (kao_topic.broker_w on every replica, broker_wl on top for the leader)
+__device__ __forceinline__ int bound_fval(const BoundLds &L, int b, int gr) {
+    return -L.A[b] - gr + (L.BW ? (int)(L.BW[b] & 0xFFFFu) * kDualScale : 0);
+}
+__device__ __forceinline__ int bound_lval(const BoundLds &L, int b, int gr) {
+    return -L.A[b] - gr - L.LM[b] + (L.BW ? (int)((L.BW[b] & 0xFFFFu) + (L.BW[b] >> 16)) * kDualScale : 0);
+}
+template <int NE>
+__device__ __forceinline__ BoundLds bound_carve(unsigned char *smem_b, int maxB, int maxR, bool hbw) {
+    using D = BoundDims<NE>;
+    constexpr int kTF = D::kTF, kTL = D::kTL;
     BoundLds L;
     L.acc = reinterpret_cast<long long *>(smem_b);
     L.ctl = reinterpret_cast<int *>(smem_b + 64);
@@ -116,10 +133,10 @@ __device__ __forceinline__ BoundLds bound_carve(unsigned char *smem_b, int maxB,
     L.NK = L.DG + kRackTab;
     L.RO = L.NK + kRackTab;
     L.PFb = L.RO + kRackTab + 2;
-    L.PFr = L.PFb + 16; L.PFv = L.PFr + 16;
-    L.PLb = L.PFv + 16;
-    L.PLr = L.PLb + 8; L.PLv = L.PLr + 8;
-    L.TFb = L.PLv + 8;
+    L.PFr = L.PFb + D::kPF; L.PFv = L.PFr + D::kPF;
+    L.PLb = L.PFv + D::kPF;
+    L.PLr = L.PLb + D::kPL; L.PLv = L.PLr + D::kPL;
+    L.TFb = L.PLv + D::kPL;
     L.TFv = L.TFb + maxR * kTF;
     L.TLb = L.TFv + maxR * kTF;
     L.TLv = L.TLb + maxR * kTL;
@@ -129,15 +146,35 @@ __device__ __forceinline__ BoundLds bound_carve(unsigned char *smem_b, int maxB,
     L.NL = L.NR + maxB;
     L.XB = reinterpret_cast<uint16_t *>(L.NL + maxB);
     L.RK = reinterpret_cast<uint8_t *>(L.XB + ((maxB + 7) & ~7));
-    L.CURP = reinterpret_cast<uint2 *>(L.RK + ((maxB + 15) & ~15));
+    unsigned char *tail = L.RK + ((maxB + 15) & ~15);
+    L.BW = hbw ? reinterpret_cast<uint32_t *>(tail) : nullptr;
+    if (hbw) tail += 4 * (size_t)((maxB + 3) & ~3);
+    L.CURP = reinterpret_cast<uint32_t *>(tail);
     return L;
 }
 
-__device__ __forceinline__ uint2 bound_load_cur(const uint16_t *curd, int rfc, int p) {
-    // 4 independent loads (index clamped to the last valid slot), then masked
+template <int NE> struct CurW { uint32_t w[NE / 2]; };   // NE x u16, slot i in bits 16 (i & 1) of word i / 2
+template <int NE>
+__device__ __forceinline__ CurW<NE> bound_load_cur(const uint16_t *curd, int rfc, int p) {
+    // NE independent loads (index clamped to the last valid slot), then masked
     const uint16_t *cur = curd + (size_t)p * rfc;
-    const uint32_t v0 = cur[0], v1 = cur[min(1, rfc - 1)], v2 = cur[min(2, rfc - 1)], v3 = cur[min(3, rfc - 1)];
-    return make_uint2(v0 | ((rfc > 1 ? v1 : 0xFFFFu) << 16), (rfc > 2 ? v2 : 0xFFFFu) | ((rfc > 3 ? v3 : 0xFFFFu) << 16));
+    uint32_t v[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) v[i] = cur[min(i, rfc - 1)];
+    CurW<NE> c;
+#pragma unroll
+    for (int i = 0; i < NE / 2; ++i) c.w[i] = (2 * i < rfc ? v[2 * i] : 0xFFFFu) | ((2 * i + 1 < rfc ? v[2 * i + 1] : 0xFFFFu) << 16);
+    return c;
+}
+template <int NE> __device__ __forceinline__ CurW<NE> bound_lds_cur(const uint32_t *curp, int p) {
+    CurW<NE> c;
+#pragma unroll
+    for (int i = 0; i < NE / 2; ++i) c.w[i] = curp[p * (NE / 2) + i];
+    return c;
+}
+template <int NE> __device__ __forceinline__ void bound_stage_cur(uint32_t *curp, int p, const CurW<NE> &c) {
+#pragma unroll
+    for (int i = 0; i < NE / 2; ++i) curp[p * (NE / 2) + i] = c.w[i];
 }
 
 // rack offsets RO (R <= 255) by thread 0, then the members of every rack from the rack-major internal index
@@ -169,7 +206,10 @@ __device__ __forceinline__ void bound_rack_members(const BoundLds &L, const Boun
 // with results identical to the brute-force scan of the scalar replay (oracle/kao_port.c).
 //
 // Phases T and R: the pools of this iteration.  Ends with a workgroup barrier.
+template <int NE>
 __device__ __forceinline__ void bound_pools(const BoundLds &L, const BoundTopic &K, int wave, int nw, int lane) {
+    using D = BoundDims<NE>;
+    constexpr int kTF = D::kTF, kTL = D::kTL;
     const int R = K.R, RF = K.RF;
     // ---- phase T: per rack, the kTF best followers and kTL best leaders by generic value (one wavefront per rack) ----
     for (int rr = wave; rr < R; rr += nw) {
@@ -178,23 +218,29 @@ __device__ __forceinline__ void bound_pools(const BoundLds &L, const BoundTopic 
         for (int pass = 0; pass < 2; ++pass) {   // 0: followers (F), 1: leaders (FL = F - l)
             const int want = pass == 0 ? RF : RF + 1, stride = pass == 0 ? kTF : kTL;
             int *ob = pass == 0 ? L.TFb + r * kTF : L.TLb + r * kTL, *ov = pass == 0 ? L.TFv + r * kTF : L.TLv + r * kTL;
-            int s0 = -1, s1 = -1, s2 = -1, s3 = -1;
-            for (int k = 0; k < stride; ++k) {
+            int sel[kTL];
+#pragma unroll
+            for (int i = 0; i < kTL; ++i) sel[i] = -1;
+#pragma unroll
+            for (int k = 0; k < kTL; ++k) {
+                if (k >= stride) continue;
                 int selb = -1, selv = 0;
                 if (k < want && k < n) {
                     uint32_t bkey = 0, bb = 0xFFFFFFFFu;
                     for (int jj = lane; jj < n; jj += 64) {
                         const int b = L.XB[x0 + jj];
-                        const int v = -L.A[b] - gr - (pass ? L.LM[b] : 0);
+                        const int v = pass ? bound_lval(L, b, gr) : bound_fval(L, b, gr);
                         const uint32_t key = (uint32_t)v + 0x80000000u;
-                        const bool ok = (b != s0) & (b != s1) & (b != s2) & (b != s3);
+                        bool ok = true;
+#pragma unroll
+                        for (int i = 0; i < kTL - 1; ++i) ok &= b != sel[i];
                         if (ok && key > bkey) { bkey = key; bb = (uint32_t)b; }
                     }
                     uint32_t mx;
                     const int wl_ = wave_argmax(bkey, bb, mx);
                     selb = __builtin_amdgcn_readlane((int)bb, wl_);
                     selv = (int)(mx - 0x80000000u);
-                    if (k == 0) s0 = selb; else if (k == 1) s1 = selb; else if (k == 2) s2 = selb; else s3 = selb;
+                    sel[k] = selb;
                 }
                 if (lane == 0) { ob[k] = selb; ov[k] = selv; }
             }
@@ -207,13 +253,19 @@ __device__ __forceinline__ void bound_pools(const BoundLds &L, const BoundTopic 
             const int want = pass == 0 ? RF : RF + 1;
             const int *tb = pass == 0 ? L.TFb : L.TLb, *tv = pass == 0 ? L.TFv : L.TLv;
             const int stride = pass == 0 ? kTF : kTL;
-            int s0 = -1, s1 = -1, s2 = -1, s3 = -1, s4 = -1;
-            for (int k = 0; k < want; ++k) {
+            int sel[kTL];
+#pragma unroll
+            for (int i = 0; i < kTL; ++i) sel[i] = -1;
+#pragma unroll
+            for (int k = 0; k < kTL; ++k) {
+                if (k >= want) continue;
                 uint32_t bkey = 0, bid = 0xFFFFFFFFu;
                 int brk = -1;
                 for (int r = lane; r < R; r += 64) {
                     const int b = tb[r * stride];
-                    const bool ok = (b >= 0) & (r != s0) & (r != s1) & (r != s2) & (r != s3) & (r != s4);
+                    bool ok = b >= 0;
+#pragma unroll
+                    for (int i = 0; i < kTL - 1; ++i) ok &= r != sel[i];
                     const uint32_t key = (uint32_t)tv[r * stride] + 0x80000000u;
                     if (ok && (key > bkey || (key == bkey && (uint32_t)b < bid))) { bkey = key; bid = (uint32_t)b; brk = r; }
                 }
@@ -223,7 +275,7 @@ __device__ __forceinline__ void bound_pools(const BoundLds &L, const BoundTopic 
                     const int wl_ = wave_argmax(bkey, bid, mx);
                     selr = __builtin_amdgcn_readlane(brk, wl_);
                 }
-                if (k == 0) s0 = selr; else if (k == 1) s1 = selr; else if (k == 2) s2 = selr; else if (k == 3) s3 = selr; else s4 = selr;
+                sel[k] = selr;
                 if (pass == 0) {
                     if (lane < kTF) {
                         const bool have = selr >= 0 && lane < RF;
@@ -237,8 +289,8 @@ __device__ __forceinline__ void bound_pools(const BoundLds &L, const BoundTopic 
                     L.PLv[k] = selr >= 0 ? L.TLv[selr * kTL] : 0;
                 }
             }
-            if (pass == 0) { for (int k = RF; k < 4; ++k) if (lane < kTF) L.PFb[k * kTF + lane] = -1; }
-            else if (lane == 0) for (int k = RF + 1; k < 8; ++k) L.PLb[k] = -1;
+            if (pass == 0) { for (int k = RF; k < NE; ++k) if (lane < kTF) L.PFb[k * kTF + lane] = -1; }
+            else if (lane == 0) for (int k = RF + 1; k < D::kPL; ++k) L.PLb[k] = -1;
         }
     }
     __syncthreads();
@@ -247,68 +299,84 @@ __device__ __forceinline__ void bound_pools(const BoundLds &L, const BoundTopic 
 // Phase A: one LANE per partition of [p_begin, p_end) solves the priced subproblem over the pools; the solutions are
 // counted into L.NR / L.NL / L.NK (LDS atomics), their values summed into `wsum` (per lane), `bad` = a partition without a
 // solution.  kCurLds: the current assignment is staged in L.CURP (indexed by partition), otherwise read from `curd`.
-template <bool kCurLds>
+template <int NE, bool kCurLds>
 __device__ __forceinline__ void bound_subproblems(const BoundLds &L, const BoundTopic &K, const uint16_t *curd, int p_begin, int p_end,
                                                   int wave, int nw, int lane, long long &wsum, bool &bad) {
+    using D = BoundDims<NE>;
+    constexpr int kTF = D::kTF, kTL = D::kTL;
     const int B = K.B, R = K.R, RF = K.RF, plo = K.plo, phi = K.phi;
     const int w00 = K.w00, w01 = K.w01, w10 = K.w10, w11 = K.w11;
     const int *PFb = L.PFb, *PFr = L.PFr, *PFv = L.PFv, *PLb = L.PLb, *PLr = L.PLr, *PLv = L.PLv, *TLb = L.TLb, *TLv = L.TLv;
-    const int *A = L.A, *LM = L.LM, *G = L.G;
+    const int *G = L.G;
     for (int base = p_begin + wave * 64; base < p_end; base += nw * 64) {
         const int p = base + lane;
         const bool act = p < p_end;
-        const uint2 cw = kCurLds ? L.CURP[min(p, p_end - 1)] : bound_load_cur(curd, K.rfc, min(p, p_end - 1));
-        int cb[4] = {(int)(cw.x & 0xFFFFu), (int)(cw.x >> 16), (int)(cw.y & 0xFFFFu), (int)(cw.y >> 16)};
-        int cr[4], cF[4], cFL[4];
+        const CurW<NE> cw = kCurLds ? bound_lds_cur<NE>(L.CURP, min(p, p_end - 1)) : bound_load_cur<NE>(curd, K.rfc, min(p, p_end - 1));
+        int cb[NE], cr[NE], cF[NE], cFL[NE];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NE; ++i) {
+            cb[i] = (int)((cw.w[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
             const bool v = cb[i] < B;
             const int b = v ? cb[i] : 0;
             cr[i] = L.RK[b];
-            cF[i] = -A[b] - G[cr[i]];
-            cFL[i] = cF[i] - LM[b];
+            cF[i] = bound_fval(L, b, G[cr[i]]);
+            cFL[i] = bound_lval(L, b, G[cr[i]]);
             if (!v) cb[i] = -1;
         }
-        const int c0 = cb[0], c1 = cb[1], c2 = cb[2], c3 = cb[3];
-        int Gb[4] = {-1, -1, -1, -1}, Gf[4] = {0, 0, 0, 0}, Gr[4] = {-1, -1, -1, -1};
+        // objective weight of broker b in this partition: current leader / current follower / newcomer
+        auto is_cur_f = [&](int b) { bool f = false;
+#pragma unroll
+            for (int i = 1; i < NE; ++i) f |= b == cb[i];
+            return f; };
+        int Gb[NE], Gf[NE], Gr[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { Gb[i] = -1; Gf[i] = 0; Gr[i] = -1; }
         bool fail = false;
         // greedy follower set: prack_lo best of every rack first, then the best remaining under the cap; ties -> lowest b
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NE; ++j) {
             if (j >= RF) break;
             const int forced = j < R * plo ? j / plo : -1;
             int bf = INT_MIN, bb = INT_MAX, br = -1;
             auto consider = [&](int b, int r, int F) {
-                const int f = F + ((b == c0) ? w01 : (((b == c1) | (b == c2) | (b == c3)) ? w11 : 0));
-                const int cnt = (int)(Gr[0] == r) + (int)(Gr[1] == r) + (int)(Gr[2] == r);
-                const bool in = (Gb[0] == b) | (Gb[1] == b) | (Gb[2] == b);
+                const int f = F + ((b == cb[0]) ? w01 : (is_cur_f(b) ? w11 : 0));
+                int cnt = 0;
+                bool in = false;
+#pragma unroll
+                for (int i = 0; i < NE - 1; ++i) { cnt += (int)(Gr[i] == r); in |= Gb[i] == b; }
                 const bool ok = (b >= 0) & (forced >= 0 ? r == forced : cnt < phi) & !in;
                 if (ok && (f > bf || (f == bf && b < bb))) { bf = f; bb = b; br = r; }
             };
             for (int i = 0; i < RF * kTF; ++i) consider(PFb[i], PFr[i], PFv[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) consider(cb[i], cr[i], cF[i]);
+            for (int i = 0; i < NE; ++i) consider(cb[i], cr[i], cF[i]);
             if (bb == INT_MAX) { fail = true; bb = -1; bf = 0; }
             Gb[j] = bb; Gf[j] = bf; Gr[j] = br;
         }
         // leader: outside the set it displaces the cheapest element whose removal keeps the rack band
-        const int fG = Gf[0] + Gf[1] + Gf[2] + Gf[3];
-        int cg[4];
+        int fG = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cg[j] = (int)(Gr[0] == Gr[j]) + (int)(Gr[1] == Gr[j]) + (int)(Gr[2] == Gr[j]) + (int)(Gr[3] == Gr[j]);
+        for (int j = 0; j < NE; ++j) fG += Gf[j];
+        int cg[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            cg[j] = 0;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) cg[j] += (int)(Gr[i] == Gr[j]);
+        }
         int bv = INT_MIN, b0 = INT_MAX, be = -1, b0r = -1;
         auto lead = [&](int b, int r, int FL) {
-            const int lv = FL + ((b == c0) ? w00 : (((b == c1) | (b == c2) | (b == c3)) ? w10 : 0));
+            const int lv = FL + ((b == cb[0]) ? w00 : (is_cur_f(b) ? w10 : 0));
             int e = -1, fe = 0;
-            if (Gb[0] == b) { e = 0; fe = Gf[0]; }
-            else if (Gb[1] == b) { e = 1; fe = Gf[1]; }
-            else if (Gb[2] == b) { e = 2; fe = Gf[2]; }
-            else if (Gb[3] == b) { e = 3; fe = Gf[3]; }
-            else {
-                const int rc = (int)(Gr[0] == r) + (int)(Gr[1] == r) + (int)(Gr[2] == r) + (int)(Gr[3] == r);
+#pragma unroll
+            for (int j = NE - 1; j >= 0; --j) if (Gb[j] == b) { e = j; fe = Gf[j]; }   // (a broker is in the set once)
+            if (e < 0) {
+                int rc = 0;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) rc += (int)(Gr[i] == r);
                 const bool full = rc >= phi;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NE; ++j) {
                     const bool ok = (j < RF) & (full ? Gr[j] == r : ((Gr[j] == r) | (cg[j] > plo)));
                     if (ok && (e < 0 || Gf[j] <= fe)) { e = j; fe = Gf[j]; }     // cheapest; ties -> the latest picked
                 }
@@ -318,14 +386,14 @@ __device__ __forceinline__ void bound_subproblems(const BoundLds &L, const Bound
         };
         if (!fail) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NE; ++j) {
                 if (j >= RF) break;
                 const int b = Gb[j], r = Gr[j];
-                lead(b, r, -A[b] - G[r] - LM[b]);                                 // a set member leads
+                lead(b, r, bound_lval(L, b, G[r]));                               // a set member leads
                 for (int k = 0; k <= RF; ++k) lead(TLb[r * kTL + k], r, TLv[r * kTL + k]);   // best leaders of its rack
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lead(cb[i], cr[i], cFL[i]);               // the partition's current brokers
+            for (int i = 0; i < NE; ++i) lead(cb[i], cr[i], cFL[i]);              // the partition's current brokers
             for (int i = 0; i <= RF; ++i) lead(PLb[i], PLr[i], PLv[i]);           // best leader of the best racks
         }
         if (b0 == INT_MAX) fail = true;
@@ -333,7 +401,7 @@ __device__ __forceinline__ void bound_subproblems(const BoundLds &L, const Bound
         if (act && !fail) {
             wsum += bv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NE; ++j)
                 if (j < RF && j != be) { atomicAdd(&L.NR[Gb[j]], 1); atomicAdd(&L.NK[Gr[j]], 1); }
             atomicAdd(&L.NR[b0], 1);
             atomicAdd(&L.NL[b0], 1);
@@ -441,26 +509,28 @@ __device__ __forceinline__ void bound_export_prices(const BoundPools &pl, const 
 // ------------------------------------------------------------------------------------------------
 // k_bound: one workgroup per topic, persistent over the iterations of a launch
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
+template <int NE>
+__global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound(BoundPools pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
     const int topic = pl.ids[blockIdx.x];
     const TopicDev &T = pl.topics[topic];
     const BoundTopic K = bound_topic(T);
     const int B = K.B, R = K.R, P = K.P;
-    const BoundLds L = bound_carve(smem_b, pl.maxB, pl.maxR);
+    const BoundLds L = bound_carve<NE>(smem_b, pl.maxB, pl.maxR, pl.bwd_pool != nullptr);
     long long *acc = L.acc;
     int *ctl = L.ctl;
     const uint8_t *rk_g = pl.rackof_pool + T.rackof_off;
     int *gp = pl.dual_pool + T.dual_off;                                // a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
     int *g_a = gp, *g_l = gp + B, *g_da = gp + 2 * B, *g_dl = gp + 3 * B, *g_g = gp + 4 * B, *g_dg = gp + 4 * B + kRackTab;
     for (int b = tid; b < B; b += nt) { L.A[b] = g_a[b]; L.LM[b] = g_l[b]; L.NR[b] = 0; L.NL[b] = 0; L.RK[b] = rk_g[b]; }
+    if (L.BW) for (int b = tid; b < B; b += nt) L.BW[b] = T.has_bw ? pl.bwd_pool[T.bwd_off + b] : 0u;
     for (int r = tid; r < kRackTab; r += nt) { L.G[r] = r < R ? g_g[r] : 0; L.DG[r] = r < R ? g_dg[r] : 0; L.NK[r] = 0; }
     if (tid < 8) acc[tid] = 0;
     if (tid < 4) ctl[tid] = 0;
     const uint16_t *curd = pl.curd_pool + T.curd_off;
     if (pl.cur_in_lds)
-        for (int p = tid; p < P; p += nt) L.CURP[p] = bound_load_cur(curd, K.rfc, p);
+        for (int p = tid; p < P; p += nt) bound_stage_cur<NE>(L.CURP, p, bound_load_cur<NE>(curd, K.rfc, p));
     bound_rack_members(L, pl, T, tid, nt);
     long long best = pl.best_L[topic];
     const long long target = pl.target[topic];
@@ -492,11 +562,11 @@ __global__ __launch_bounds__(1024) void k_bound(BoundPools pl) {
             if (tid < R) L.G[tid] = dual_round(g_g[tid], sh);
             __syncthreads();
         }
-        bound_pools(L, K, wave, nw, lane);
+        bound_pools<NE>(L, K, wave, nw, lane);
         long long wsum = 0;
         bool bad = false;
-        if (pl.cur_in_lds) bound_subproblems<true>(L, K, curd, 0, P, wave, nw, lane, wsum, bad);
-        else bound_subproblems<false>(L, K, curd, 0, P, wave, nw, lane, wsum, bad);
+        if (pl.cur_in_lds) bound_subproblems<NE, true>(L, K, curd, 0, P, wave, nw, lane, wsum, bad);
+        else bound_subproblems<NE, false>(L, K, curd, 0, P, wave, nw, lane, wsum, bad);
         bad = __ballot(bad) != 0ull;
         wsum = wave_sum64(wsum);
         if (lane == 0) {
@@ -571,7 +641,8 @@ __global__ __launch_bounds__(64) void k_bound_begin(BoundPools pl, BoundWide wd,
 }
 
 // mode 0: iteration; 1 / 2: probe at the multipliers rounded to the quarter / half grid
-__global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd, int mode) {
+template <int NE>
+__global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_step(BoundPools pl, BoundWide wd, int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
@@ -584,7 +655,7 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
     const BoundTopic K = bound_topic(T);
     const int B = K.B, R = K.R, P = K.P;
     const bool probe = mode != 0;
-    const BoundLds L = bound_carve(smem_b, pl.maxB, pl.maxR);
+    const BoundLds L = bound_carve<NE>(smem_b, pl.maxB, pl.maxR, pl.bwd_pool != nullptr);
     const uint8_t *rk_g = pl.rackof_pool + T.rackof_off;
     int *gp = pl.dual_pool + T.dual_off;
     int *g_a = gp, *g_l = gp + B, *g_da = gp + 2 * B, *g_dl = gp + 3 * B, *g_g = gp + 4 * B, *g_dg = gp + 4 * B + kRackTab;
@@ -593,6 +664,7 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
         const int a_ = g_a[b], l_ = g_l[b];
         L.A[b] = probe ? dual_round(a_, rsh) : a_; L.LM[b] = probe ? dual_round(l_, rsh) : l_;
         L.NR[b] = 0; L.NL[b] = 0; L.RK[b] = rk_g[b];
+        if (L.BW) L.BW[b] = T.has_bw ? pl.bwd_pool[T.bwd_off + b] : 0u;
     }
     for (int r = tid; r < kRackTab; r += nt) {
         const int g_ = r < R ? g_g[r] : 0;
@@ -600,14 +672,14 @@ __global__ __launch_bounds__(1024) void k_bound_step(BoundPools pl, BoundWide wd
     }
     if (tid < 8) L.acc[tid] = 0;
     bound_rack_members(L, pl, T, tid, nt);
-    bound_pools(L, K, wave, nw, lane);
+    bound_pools<NE>(L, K, wave, nw, lane);
     // ---- this workgroup's slice of the subproblems ----
     const int p_begin = slice * wd.chunk, p_end = min(P, p_begin + wd.chunk);
     const int n_slices = (P + wd.chunk - 1) / wd.chunk;
     long long wsum = 0;
     bool bad = false;
     // (a slice's upper end clamps the loads of its idle lanes, as P does in k_bound: the values are never used)
-    bound_subproblems<false>(L, K, pl.curd_pool + T.curd_off, p_begin, p_end, wave, nw, lane, wsum, bad);
+    bound_subproblems<NE, false>(L, K, pl.curd_pool + T.curd_off, p_begin, p_end, wave, nw, lane, wsum, bad);
     bad = __ballot(bad) != 0ull;
     wsum = wave_sum64(wsum);
     if (lane == 0) {
@@ -711,23 +783,28 @@ __global__ __launch_bounds__(256) void k_bound_finish(BoundPools pl) {
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds) {
-    size_t n = 80 + (3 * (size_t)kRackTab + kRackTab + 2 + 48 + 24) * 4 + (size_t)maxR * (2 * 4 + 2 * 5) * 4;
+size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds, int ne, bool hbw) {
+    const size_t pf = (size_t)ne * ne, pl = 2 * (size_t)ne, tf = (size_t)ne, tl = (size_t)ne + 1;
+    size_t n = 80 + (3 * (size_t)kRackTab + kRackTab + 2 + 3 * pf + 3 * pl) * 4 + (size_t)maxR * (2 * tf + 2 * tl) * 4;
     n += 16 * (size_t)maxB + 2 * (((size_t)maxB + 7) & ~(size_t)7) + (((size_t)maxB + 15) & ~(size_t)15);
+    if (hbw) n += 4 * (((size_t)maxB + 3) & ~(size_t)3);
     n = (n + 7) & ~(size_t)7;
-    return n + (cur_in_lds ? 8 * (size_t)maxP : 0);
+    return n + (cur_in_lds ? 2 * (size_t)ne * (size_t)maxP : 0);
 }
 
-static int g_attr_bound_dev[kAttrDevices] = {0}, g_attr_step_dev[kAttrDevices] = {0};
+static int g_attr_bound_dev[kAttrDevices][2] = {{0}}, g_attr_step_dev[kAttrDevices][2] = {{0}};
 
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream) {
-    const size_t lds = bound_lds_bytes(pools.maxB, pools.maxP, pools.maxR, pools.cur_in_lds != 0);
-    int &g_attr_bound = g_attr_bound_dev[attr_slot()];
+    const bool ne8 = pools.ne == 8;
+    const size_t lds = bound_lds_bytes(pools.maxB, pools.maxP, pools.maxR, pools.cur_in_lds != 0, pools.ne, pools.bwd_pool != nullptr);
+    int &g_attr_bound = g_attr_bound_dev[attr_slot()][ne8];
+    const void *fn = ne8 ? reinterpret_cast<const void *>(k_bound<8>) : reinterpret_cast<const void *>(k_bound<4>);
     if ((int)lds > g_attr_bound) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bound), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr_bound = (int)lds;
     }
-    hipLaunchKernelGGL(k_bound, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools);
+    if (ne8) hipLaunchKernelGGL(k_bound<8>, dim3(n_blocks), dim3(64 * std::min(waves, 8)), lds, static_cast<hipStream_t>(stream), pools);
+    else hipLaunchKernelGGL(k_bound<4>, dim3(n_blocks), dim3(64 * waves), lds, static_cast<hipStream_t>(stream), pools);
 }
 
 // The launch sequence of one sliced K-bound launch as a hipGraph: begin, `iters` x step, the probes, finish -- up to ~180 kernel
@@ -749,18 +826,26 @@ std::mutex g_bound_graph_mu;
 bool bound_graph_wanted() { static const bool on = [] { const char *e = std::getenv("KAO_BOUND_GRAPH"); return e && e[0] == '1'; }(); return on; }
 void bound_wide_enqueue(const BoundPools &pools, const BoundWide &wide, int n_topics, int n_blocks, int waves, size_t lds, hipStream_t st) {
     hipLaunchKernelGGL(k_bound_begin, dim3((n_topics + 63) / 64), dim3(64), 0, st, pools, wide, n_topics);
-    for (int i = 0; i < pools.iters; ++i) hipLaunchKernelGGL(k_bound_step, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, 0);
-    for (int m = 1; m <= kDualProbes; ++m) hipLaunchKernelGGL(k_bound_step, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, m);
+    if (pools.ne == 8) {
+        waves = std::min(waves, 8);
+        for (int i = 0; i < pools.iters; ++i) hipLaunchKernelGGL(k_bound_step<8>, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, 0);
+        for (int m = 1; m <= kDualProbes; ++m) hipLaunchKernelGGL(k_bound_step<8>, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, m);
+    } else {
+        for (int i = 0; i < pools.iters; ++i) hipLaunchKernelGGL(k_bound_step<4>, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, 0);
+        for (int m = 1; m <= kDualProbes; ++m) hipLaunchKernelGGL(k_bound_step<4>, dim3(n_blocks), dim3(64 * waves), lds, st, pools, wide, m);
+    }
     hipLaunchKernelGGL(k_bound_finish, dim3(n_topics), dim3(256), 0, st, pools);
 }
 }  // namespace
 
 void launch_bound_wide(const BoundPools &pools, const BoundWide &wide, int n_topics, int n_blocks, int waves, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = bound_lds_bytes(pools.maxB, 0, pools.maxR, false);
-    int &g_attr = g_attr_step_dev[attr_slot()];
+    const bool ne8 = pools.ne == 8;
+    const size_t lds = bound_lds_bytes(pools.maxB, 0, pools.maxR, false, pools.ne, pools.bwd_pool != nullptr);
+    int &g_attr = g_attr_step_dev[attr_slot()][ne8];
     if ((int)lds > g_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_bound_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(ne8 ? reinterpret_cast<const void *>(k_bound_step<8>) : reinterpret_cast<const void *>(k_bound_step<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         g_attr = (int)lds;
     }
     if (bound_graph_wanted() && pools.iters >= 8) {

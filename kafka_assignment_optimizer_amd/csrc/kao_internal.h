@@ -126,6 +126,8 @@ struct BoundPools {
     int32_t cur_in_lds;          // 1 = the current assignment (8 B per partition) is staged in LDS too
     int32_t *price_pool;         // K-bound's epilogue exports the multipliers, rounded to the quarter grid, as search prices
     int32_t export_prices;       // 1 = the multipliers of the record dual value, 2 = the last iterate, 0 = no export
+    int32_t ne;                  // 4 or 8: replica slots per partition the launch is instantiated for (k_bound<NE>)
+    const uint32_t *bwd_pool;    // broker weights per dense index (TopicDev::bwd_off), nullptr when no topic of the session has any
 };
 
 // K-bound on several workgroups per topic (k_bound_step: one iteration per launch, partitions sliced over workgroups)
@@ -150,7 +152,7 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
 void launch_adopt_global(unsigned long long *keys, const unsigned long long *glob, int n, void *stream);
 
 // K-bound: Lagrangian dual bound, one workgroup (`waves` wavefronts) per listed topic
-size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds);
+size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds, int ne = 4, bool hbw = false);
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream);
 // the same iteration as a sequence of launches: begin, pools.iters x step, the probes, finish (n_blocks = all slices of the
 // n_topics listed topics)

@@ -420,18 +420,24 @@ int auto_period_log2(int P, int RF) {
     return std::min(16, std::max(8, lg));
 }
 
-// K-bound limits: 19 B of LDS per broker + 72 B per rack; 32-bit headroom of the priced values (weights x 4096,
-// P*RF subgradients)
+// K-bound limits: 19 (23 with broker weights) B of LDS per broker + 72 (136) B per rack; 32-bit headroom of the priced values:
+// a replica's objective coefficient (role weight + broker weights) x 65536 stays below 2^24, P*RF subgradients.
+// Round 3: RF 5..8 (k_bound<8>) and broker weights are inside the limits.
 bool dual_supported(const kao_topic *t) {
-    if (t->rf > kRFP || t->rf_cur > kRFP) return false;   // K-bound's per-lane subproblem holds 4 replicas
-    if (t->broker_w || t->broker_wl) return false;        // K-bound prices the README rows only
-    if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false) > 160 * 1024) return false;
+    const bool wide = t->rf > kRFP || t->rf_cur > kRFP;
+    const bool hbw = t->broker_w || t->broker_wl;
+    if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false, wide ? 8 : 4, hbw) > 160 * 1024) return false;
     const int64_t n = (int64_t)t->n_partitions * t->rf;
     if (n > 131072) return false;
+    int wmax = 0, bwmax = 0;
     for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j)
-            if (t->w[i][j] < 0 || t->w[i][j] > 255) return false;
-    return true;
+        for (int j = 0; j < 2; ++j) {
+            if (t->w[i][j] < 0) return false;
+            wmax = std::max(wmax, t->w[i][j]);
+        }
+    for (int b = 0; hbw && b < t->n_brokers; ++b)
+        bwmax = std::max(bwmax, (t->broker_w ? t->broker_w[b] : 0) + (t->broker_wl ? t->broker_wl[b] : 0));
+    return wmax + bwmax <= 255;
 }
 
 }  // namespace kao

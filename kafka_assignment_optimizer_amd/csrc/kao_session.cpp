@@ -887,16 +887,17 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     if (s->stream_bound) HIP_TRY(hipStreamSynchronize(s->stream_bound));
     s->h_dual_ids.clear();
     s->h_dual_target.assign((size_t)s->n_topics, -1);
-    int maxB = 0, maxP = 0, maxR = 0;
-    for (int t = 0; t < s->n_topics; ++t) {
-        if (target[t] < 0 || !s->dual_ok[(size_t)t] || s->topic_infeasible[(size_t)t]) continue;
-        if (target[t] > (int64_t)1 << 40) return fail(KAO_ERR_INVALID, "target out of range");
-        s->h_dual_ids.push_back(t);
-        s->h_dual_target[(size_t)t] = target[t];
-        maxB = std::max(maxB, s->pts[(size_t)t].d.B);
-        maxP = std::max(maxP, s->pts[(size_t)t].d.P);
-        maxR = std::max(maxR, s->pts[(size_t)t].d.R);
-    }
+    // two classes of topics, one launch each: RF and current RF <= 4 (k_bound<4>), RF 5..8 (k_bound<8>); ids of the first class first
+    auto wide_slots = [&](int t) { return s->pts[(size_t)t].d.RF > kRFP || s->pts[(size_t)t].d.rf_cur > kRFP; };
+    int n_class[2] = {0, 0};
+    for (int cls = 0; cls < 2; ++cls)
+        for (int t = 0; t < s->n_topics; ++t) {
+            if (target[t] < 0 || !s->dual_ok[(size_t)t] || s->topic_infeasible[(size_t)t] || (int)wide_slots(t) != cls) continue;
+            if (target[t] > (int64_t)1 << 40) return fail(KAO_ERR_INVALID, "target out of range");
+            s->h_dual_ids.push_back(t);
+            s->h_dual_target[(size_t)t] = target[t];
+            n_class[cls]++;
+        }
     if (s->h_dual_ids.empty()) return KAO_OK;
     if (!s->stream_bound) {
         // highest priority: a K-bound launch is a handful of workgroups that should not queue behind a full K-search grid
@@ -925,8 +926,8 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     bp.best_L = reinterpret_cast<long long *>(s->d_dual_rb);
     bp.info = reinterpret_cast<int32_t *>(s->d_dual_rb + (size_t)s->n_topics * 8);
     bp.ext_pool = s->d_ext; bp.rsz_pool = s->d_rsz;
-    bp.iters = iters; bp.maxB = maxB; bp.maxP = maxP; bp.maxR = maxR;
-    bp.cur_in_lds = bound_lds_bytes(maxB, maxP, maxR, true) <= 160 * 1024 ? 1 : 0;
+    bp.iters = iters;
+    bp.bwd_pool = s->any_bw ? s->d_bwd : nullptr;
     // K-search launches already enqueued may still read the half this launch is about to overwrite -- except under kao_solve's
     // deterministic schedule, which starts K-bound only when the enqueued K-search launches read the OTHER half (the launch
     // that read this one has been waited for)
@@ -944,28 +945,43 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
     bp.export_prices = 1;
     if (const char *e = std::getenv("KAO_X_PRICE_SRC")) bp.export_prices = std::atoi(e);  // experiment knob
     s->price_write_last = wh;
-    // lanes own partitions, wavefronts own racks when the pools are rebuilt: enough wavefronts for either, at most 16
-    const int waves = std::min(16, std::max({1, (maxP + 63) / 64, std::min(maxR, 8)}));
-    // topics beyond a few thousand partitions: one iteration per launch, the partitions sliced over several workgroups
-    // (k_bound_step); a launch that holds such a topic runs all its topics that way.  KAO_BOUND_CHUNK = partitions per
-    // slice (test hook: small values slice small topics)
-    int chunk = maxP > 2048 ? 512 : 0;
-    if (const char *e = std::getenv("KAO_BOUND_CHUNK")) chunk = std::max(0, std::atoi(e)) / 64 * 64;
     HIP_TRY(hipEventRecord(s->ev_bound0, s->stream_bound));
-    if (chunk > 0) {
-        s->h_wide_map.clear();
-        for (int t : s->h_dual_ids)
-            for (int sl = 0, n = (s->pts[(size_t)t].d.P + chunk - 1) / chunk; sl < n; ++sl) s->h_wide_map.push_back(make_int2(t, sl));
-        BoundWide wd{};
-        wd.map = reinterpret_cast<const int2 *>(s->d_dual + s->wide_map_i32);
-        wd.cnt_pool = s->d_dual;
-        wd.ctl = reinterpret_cast<long long *>(s->d_dual + s->wide_ctl_i32);
-        wd.chunk = chunk;
-        HIP_TRY(hipMemcpyAsync(s->d_dual + s->wide_map_i32, s->h_wide_map.data(), s->h_wide_map.size() * sizeof(int2), hipMemcpyHostToDevice,
-                               s->stream_bound));
-        launch_bound_wide(bp, wd, (int)s->h_dual_ids.size(), (int)s->h_wide_map.size(), 16, s->stream_bound);
-    } else
-        launch_bound(bp, (int)s->h_dual_ids.size(), waves, s->stream_bound);
+    s->h_wide_map.clear();
+    for (int cls = 0, first = 0; cls < 2; first += n_class[cls], ++cls) {
+        if (!n_class[cls]) continue;
+        int maxB = 0, maxP = 0, maxR = 0;
+        for (int i = first; i < first + n_class[cls]; ++i) {
+            const TopicDev &d = s->pts[(size_t)s->h_dual_ids[(size_t)i]].d;
+            maxB = std::max(maxB, d.B); maxP = std::max(maxP, d.P); maxR = std::max(maxR, d.R);
+        }
+        bp.ids = s->d_dual_ids + first;
+        bp.ne = cls ? 8 : 4;
+        bp.maxB = maxB; bp.maxP = maxP; bp.maxR = maxR;
+        bp.cur_in_lds = bound_lds_bytes(maxB, maxP, maxR, true, bp.ne, bp.bwd_pool != nullptr) <= 160 * 1024 ? 1 : 0;
+        // lanes own partitions, wavefronts own racks when the pools are rebuilt: enough wavefronts for either, at most 16
+        const int waves = std::min(16, std::max({1, (maxP + 63) / 64, std::min(maxR, 8)}));
+        // topics beyond a few thousand partitions: one iteration per launch, the partitions sliced over several workgroups
+        // (k_bound_step); a launch that holds such a topic runs all its topics that way.  KAO_BOUND_CHUNK = partitions per
+        // slice (test hook: small values slice small topics)
+        int chunk = maxP > 2048 ? 512 : 0;
+        if (const char *e = std::getenv("KAO_BOUND_CHUNK")) chunk = std::max(0, std::atoi(e)) / 64 * 64;
+        if (chunk > 0) {
+            const size_t map0 = s->h_wide_map.size();
+            for (int i = first; i < first + n_class[cls]; ++i) {
+                const int t = s->h_dual_ids[(size_t)i];
+                for (int sl = 0, n = (s->pts[(size_t)t].d.P + chunk - 1) / chunk; sl < n; ++sl) s->h_wide_map.push_back(make_int2(t, sl));
+            }
+            BoundWide wd{};
+            wd.map = reinterpret_cast<const int2 *>(s->d_dual + s->wide_map_i32) + map0;
+            wd.cnt_pool = s->d_dual;
+            wd.ctl = reinterpret_cast<long long *>(s->d_dual + s->wide_ctl_i32);
+            wd.chunk = chunk;
+            HIP_TRY(hipMemcpyAsync(s->d_dual + s->wide_map_i32 + 2 * map0, s->h_wide_map.data() + map0, (s->h_wide_map.size() - map0) * sizeof(int2),
+                                   hipMemcpyHostToDevice, s->stream_bound));
+            launch_bound_wide(bp, wd, n_class[cls], (int)(s->h_wide_map.size() - map0), 16, s->stream_bound);
+        } else
+            launch_bound(bp, n_class[cls], waves, s->stream_bound);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_bound1, s->stream_bound));
     s->bound_inflight = true;

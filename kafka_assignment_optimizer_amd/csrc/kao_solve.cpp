@@ -929,12 +929,11 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
         if (rc) break;
         // ---- broker loads over ALL topics (the allreduce(SUM) of a sharded deployment), objective without the weights ----
         std::fill(load.begin(), load.end(), 0);
-        bool all_feasible = true, all_proven = true;
+        bool all_feasible = true;
         int64_t total = 0, total_w = 0;
         for (int i = 0; i < n_topics; ++i) {
             const kao_result &x = res[(size_t)i];
             if (x.status == KAO_STATUS_NO_FEASIBLE || x.status == KAO_STATUS_INFEASIBLE_PROVEN) { all_feasible = false; continue; }
-            all_proven &= x.status == KAO_STATUS_OPTIMAL_PROVEN;
             int64_t wsum = 0;
             for (size_t k = 0; k < buf[(size_t)i].size(); ++k) { const uint16_t b = buf[(size_t)i][k]; load[b]++; wsum += M ? bw[b] : 0; }
             total += x.objective - wsum;
@@ -946,7 +945,9 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
             worst = std::max<int64_t>(worst, load[(size_t)b] - replica_cap[b]);
             priced += (int64_t)mu[(size_t)b] * replica_cap[b];
         }
-        if (all_feasible && all_proven) best_L = std::min(best_L, total_w - (int64_t)M * n_slots + priced);   // L(mu) >= capped optimum
+        // L(mu) <= sum of ANY valid per-topic upper bounds of the weighted topics - M * slots + mu . cap: round 3 -- K-bound now covers
+        // weighted topics, so the per-topic bounds are (nearly) the weighted optima whether or not the search has met them
+        if (all_feasible) best_L = std::min(best_L, total_w - (int64_t)M * n_slots + priced);
         if (all_feasible && worst <= 0 && total > inc_total) {   // respects every cap: a candidate answer
             inc_total = total;
             for (int i = 0; i < n_topics; ++i) {

@@ -785,7 +785,7 @@ static int db_partition_g(const port_topic *t, int p, const int32_t *a, const in
             int in = 0;
             for (int j = 0; j < G.n; ++j) in |= G.b[j] == b;
             if (in) continue;
-            const int32_t fv = db_wcur(t, cur, (unsigned)b, 1) * DB_SCALE - a[b] - g[rb];
+            const int32_t fv = (db_wcur(t, cur, (unsigned)b, 1) + (t->broker_w ? t->broker_w[b] : 0)) * DB_SCALE - a[b] - g[rb];
             if (bb < 0 || fv > bv) { bb = b; bv = fv; }
         }
         if (bb < 0) return -1;
@@ -799,7 +799,8 @@ static int db_partition_g(const port_topic *t, int p, const int32_t *a, const in
     int best_b0 = -1, best_e = -1; int32_t best_v = 0;
     for (int b0 = 0; b0 < B; ++b0) {
         const int r0 = t->rack_of[b0];
-        const int32_t lv = db_wcur(t, cur, (unsigned)b0, 0) * DB_SCALE - a[b0] - g[r0] - l[b0];
+        const int32_t lv = (db_wcur(t, cur, (unsigned)b0, 0) + (t->broker_w ? t->broker_w[b0] : 0) + (t->broker_wl ? t->broker_wl[b0] : 0)) * DB_SCALE
+                           - a[b0] - g[r0] - l[b0];
         int pos = -1;
         for (int j = 0; j < RF; ++j) if (G.b[j] == b0) pos = j;
         int e = -1; int32_t v;

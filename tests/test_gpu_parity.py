@@ -774,6 +774,44 @@ def test_dual_bound_replay_bit_exact(kao, ko, kp, monkeypatch, chunk):
         assert got["bound"] == st.bound >= c["objective"], tag
 
 
+@pytest.mark.parametrize("chunk", [None, "64"])
+def test_dual_bound_replay_high_rf_and_broker_weights(kao, ko, kp, monkeypatch, chunk):
+    """Round 3: K-bound beyond the README's range -- RF 5..8 (k_bound<8>: 8 replica slots per lane, 8 + 9 candidates per rack)
+    and broker weights (plain objective coefficients inside the priced values) -- against the scalar replay, which solves every
+    partition subproblem by brute force over all brokers: identical multipliers, dual value, iteration count, flags; and the
+    certificate never undercuts the HiGHS optimum."""
+    _bound_chunk(monkeypatch, chunk)
+    rng = np.random.default_rng(77)
+    picked = [(c, ko.random_case_rf(c["seed"])) for c in load_golden("random_rf.json")["cases"] if c["status"] == "optimal"][:36]
+    weighted = []
+    for c, t in [(c, t) for c, t in _wide_cases(ko) if c["upper_bound"] != c["objective"]][:16] + picked[:8]:
+        t = ko.random_case_wide(c["seed"]) if "shape" in c else ko.random_case_rf(c["seed"])
+        t.broker_w = rng.integers(0, 6, t.n_brokers).astype(np.int32)
+        t.broker_wl = rng.integers(0, 4, t.n_brokers).astype(np.int32) if len(weighted) % 3 else None
+        weighted.append((None, t))
+    n_rf = n_w = 0
+    for i, (c, ot) in enumerate(picked + weighted):
+        opt = c["objective"] if c is not None else ko.upper_bound_simple(ot) - 3
+        target = max(0, opt - (i % 3 == 2) * 2)
+        iters, launches = (37, 3) if i % 2 else (120, 1)
+        got = kao.dual_bound(to_product_topic(ot), target, iters=iters, launches=launches)
+        st = kp.DualState(ot)
+        for _ in range(launches):
+            st = kp.port_dual_bound(ot, target, iters, st)
+            if st.flags & 7:
+                break
+        tag = (i, ot.n_brokers, ot.n_partitions, ot.rf, ot.rf_cur)
+        assert (got["iters"], got["flags"]) == (st.iters, st.flags), tag
+        assert got["best_dual"] == st.best_L, tag
+        assert got["a"].tolist() == st.a.tolist() and got["l"].tolist() == st.l.tolist() and got["g"].tolist() == st.g[:ot.n_racks].tolist(), tag
+        if c is not None:
+            assert got["bound"] == st.bound >= c["objective"], tag
+            n_rf += ot.rf > 4 or ot.rf_cur > 4
+        else:
+            n_w += 1
+    assert n_rf >= 20 and n_w >= 20
+
+
 @pytest.mark.parametrize("chunk", [None, "0", "64"])
 def test_dual_bound_replay_large_shapes(kao, ko, kp, monkeypatch, chunk):
     """(chunk None: the 20,000-partition shape runs sliced over 40 workgroups, the others persistent; "0": all persistent; "64":
@@ -1023,7 +1061,7 @@ def test_high_rf_golden_optima(kao, ko):
         if c.get("unique"):
             assert kao.canonicalize(to_product_topic(ot), r.assignment).tolist() == ko.canonicalize(ot, np.array(c["assignment"])).tolist(), c["seed"]
             n_unique += 1
-    assert n_opt >= 50 and n_proven >= n_opt // 3
+    assert n_opt >= 50 and n_proven >= n_opt - 2, (n_opt, n_proven)   # round 3: K-bound certifies RF 5..8 (it was n_opt // 3 on the closed-form bound)
 
 
 # ------------------------------------------------------------------------------- broker weights and cluster-wide caps
@@ -1060,14 +1098,15 @@ def test_broker_weights_eval_and_replay_bit_exact(kao, ko, kp):
         t.broker_w = rng.integers(0, 4, t.n_brokers).astype(np.int32)
         t.broker_wl = rng.integers(0, 3, t.n_brokers).astype(np.int32)
     res = kao.solve([to_product_topic(t) for t in small], seed=2, time_limit_s=10, max_launches=16)
-    n = 0
+    n = n_proven = 0
     for t, r in zip(small, res):
         ex = ko.solve_exact(t, 60)
         if ex.status != "optimal":
             continue
         assert r.objective == ex.objective <= r.upper_bound, (t.name, r.objective, ex.objective, r.upper_bound)
         n += 1
-    assert n >= 5
+        n_proven += r.status == "OPTIMAL_PROVEN"
+    assert n >= 5 and n_proven >= n - 1, (n, n_proven)   # round 3: K-bound prices weighted topics too
 
 
 def test_solve_capped_matches_the_exact_joint_optimum_on_toys(kao, ko):
