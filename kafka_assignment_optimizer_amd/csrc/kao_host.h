@@ -92,6 +92,7 @@ struct kao_session {
     std::vector<char> dual_ok;           // per topic: within K-bound's limits
     std::vector<int64_t> h_dual_target;  // staging for kao_session_bound_step
     std::vector<int32_t> h_dual_ids;
+    bool multi_off = false;              // k_bound_multi gave up once in this session (kao_session_bounds): the step kernels from then on
     std::vector<int2> h_wide_map;        // sliced K-bound: {topic, slice} per workgroup (staging, like h_dual_ids)
     uint64_t wide_ctl_i32 = 0, wide_map_i32 = 0;   // int32 offsets of the control blocks / the map inside d_dual
     std::vector<int32_t> dual_flags, dual_iters;

@@ -57,7 +57,8 @@ struct TopicDev {
     int32_t has_bw;              // 1 = the topic carries broker weights (kao_topic.broker_w / broker_wl)
     uint32_t bw_off;             // bw_pool  : packed bw | bwl << 16 per INTERNAL index (u32[Bx])
     uint32_t bwd_off;            // bwd_pool : the same per DENSE index (u32[B]) for K-eval
-    uint32_t cnt_off;            // cnt_pool : NR[B] NL[B] NK[kRackTab] of the sliced K-bound (k_bound_step), zero between steps
+    uint32_t cnt_off;            // cnt_pool : NR[B] NL[B] NK[kRackTab] of the sliced K-bound (k_bound_step), zero between steps; x 3 (the
+                                 //            rotating buffers of k_bound_multi), then its shadow area a[B] l[B] g[kRackTab] ra[B] rl[B] rg[kRackTab]
     int32_t pad_[2];
 };
 
@@ -134,7 +135,7 @@ struct BoundPools {
 struct BoundWide {
     const int2 *map;             // per workgroup: {topic, slice}
     int32_t *cnt_pool;           // subproblem counts meeting in HBM, see TopicDev::cnt_off
-    long long *ctl;              // [n_topics][8] control block: value sum, ticket, bad, stop (see kao_bound.hip)
+    long long *ctl;              // [n_topics][16] control block: value sum, ticket, bad, stop | k_bound_multi's half (see kao_bound.hip)
     int32_t chunk;               // partitions per slice (a multiple of 64)
 };
 
@@ -152,11 +153,12 @@ void launch_gather(const TopicDev *topics, int n_topics, const unsigned long lon
 void launch_adopt_global(unsigned long long *keys, const unsigned long long *glob, int n, void *stream);
 
 // K-bound: Lagrangian dual bound, one workgroup (`waves` wavefronts) per listed topic
-size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds, int ne = 4, bool hbw = false);
+size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds, int ne = 4, bool hbw = false, bool dirs = false);
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream);
 // the same iteration as a sequence of launches: begin, pools.iters x step, the probes, finish (n_blocks = all slices of the
 // n_topics listed topics)
 void launch_bound_wide(const BoundPools &pools, const BoundWide &wide, int n_topics, int n_blocks, int waves, void *stream);
+bool launch_bound_multi(const BoundPools &pools, const BoundWide &wide, int n_topics, int n_blocks, int waves, void *stream);
 
 // canonical tie-break on the device (kao_canonicalize): one wavefront, assignment words in global memory
 size_t canon_lds_bytes(int maxBx);

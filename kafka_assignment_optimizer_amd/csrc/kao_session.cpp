@@ -568,7 +568,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         d.dual_off = (uint32_t)dual_i32;
         dual_i32 += 6 * (uint64_t)d.B + 3 * kRackTab + 8;
         d.cnt_off = (uint32_t)dual_i32;             // counters of the sliced K-bound live in the same pool (zeroed with it)
-        dual_i32 += 2 * (uint64_t)d.B + kRackTab;
+        dual_i32 += 3 * (2 * (uint64_t)d.B + kRackTab) + 4 * (uint64_t)d.B + 2 * kRackTab;   // x 3 + shadow area: k_bound_multi
         wide_slices += (uint64_t)(d.P + 63) / 64;
         s->dual_ok.push_back(dual_supported(&topics[t]) ? 1 : 0);
         // algorithmic bytes: full evaluation = 2*RF*P + 2*rf_cur*P + B per candidate
@@ -682,7 +682,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     s->readback_bytes = s->rb_assign_off + win_u16 * 2;
     // behind the per-topic blocks: control blocks (8 x int64 per topic) and the workgroup map of the sliced K-bound
     dual_i32 = (dual_i32 + 1) & ~(uint64_t)1;
-    s->wide_ctl_i32 = dual_i32; dual_i32 += 16 * (uint64_t)n_topics;
+    s->wide_ctl_i32 = dual_i32; dual_i32 += 32 * (uint64_t)n_topics;
     s->wide_map_i32 = dual_i32; dual_i32 += 2 * wide_slices;
     const size_t dual_b = align_up(dual_i32 * 4), dtarget_b = align_up((size_t)n_topics * 8), dids_b = align_up((size_t)n_topics * 4);
     s->dual_rb_bytes = (size_t)n_topics * 24;
@@ -879,7 +879,11 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     return KAO_OK;
 }
 
-int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters) {
+static int bound_step_impl(kao_session *s, const int64_t *target, int32_t iters, bool force_step);
+int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters) { return bound_step_impl(s, target, iters, false); }
+
+// force_step: the launch repeats one that k_bound_multi gave up on (flag 16): the one-iteration-per-launch kernels, from the same state
+static int bound_step_impl(kao_session *s, const int64_t *target, int32_t iters, bool force_step) {
     if (!s || !target) return fail(KAO_ERR_INVALID, "null argument");
     if (iters < 1) return fail(KAO_ERR_INVALID, "iters < 1");
     HIP_TRY(hipSetDevice(s->device));
@@ -964,7 +968,21 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
         // (k_bound_step); a launch that holds such a topic runs all its topics that way.  KAO_BOUND_CHUNK = partitions per
         // slice (test hook: small values slice small topics)
         int chunk = maxP > 2048 ? 512 : 0;
-        if (const char *e = std::getenv("KAO_BOUND_CHUNK")) chunk = std::max(0, std::atoi(e)) / 64 * 64;
+        // Round 3: the sliced topics run on the PERSISTENT multi-workgroup driver (k_bound_multi) -- and so do topics from 1,024
+        // partitions up, in slices of 256 (a 2,000-partition topic: 52 us per iteration in k_bound's one workgroup).  Its workgroups
+        // wait for each other, so a launch is kept to 96 of them (larger slices otherwise).  KAO_BOUND_MULTI=0: the round-2 drivers.
+        const char *multi_env = std::getenv("KAO_BOUND_MULTI");
+        const bool multi = !(multi_env && multi_env[0] == '0') && !s->multi_off;
+        if (multi && chunk == 0 && maxP >= 1024) chunk = 256;
+        if (const char *e = std::getenv("KAO_BOUND_CHUNK")) { chunk = std::max(0, std::atoi(e)) / 64 * 64; }
+        if (multi && chunk > 0) {   // workgroups that wait for others (topics of more than one slice): at most 96 per launch
+            auto waiting_at = [&](int c) {
+                int64_t nb = 0;
+                for (int i = first; i < first + n_class[cls]; ++i) { const int n = (s->pts[(size_t)s->h_dual_ids[(size_t)i]].d.P + c - 1) / c; nb += n > 1 ? n : 0; }
+                return nb;
+            };
+            while (chunk < (1 << 20) && waiting_at(chunk) > 96) chunk += chunk;
+        }
         if (chunk > 0) {
             const size_t map0 = s->h_wide_map.size();
             for (int i = first; i < first + n_class[cls]; ++i) {
@@ -978,7 +996,9 @@ int kao_session_bound_step(kao_session *s, const int64_t *target, int32_t iters)
             wd.chunk = chunk;
             HIP_TRY(hipMemcpyAsync(s->d_dual + s->wide_map_i32 + 2 * map0, s->h_wide_map.data() + map0, (s->h_wide_map.size() - map0) * sizeof(int2),
                                    hipMemcpyHostToDevice, s->stream_bound));
-            launch_bound_wide(bp, wd, n_class[cls], (int)(s->h_wide_map.size() - map0), 16, s->stream_bound);
+            // (a wavefront per 64 partitions of a slice, 4..16: small workgroups find room beside a K-search launch sooner)
+            if (!(multi && !force_step && launch_bound_multi(bp, wd, n_class[cls], (int)(s->h_wide_map.size() - map0), std::min(16, std::max(4, chunk / 64)), s->stream_bound)))
+                launch_bound_wide(bp, wd, n_class[cls], (int)(s->h_wide_map.size() - map0), 16, s->stream_bound);
         } else
             launch_bound(bp, n_class[cls], waves, s->stream_bound);
     }
@@ -1053,6 +1073,17 @@ int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int
         }
         const int64_t *best = reinterpret_cast<const int64_t *>(rb.data());
         const int32_t *info = reinterpret_cast<const int32_t *>(rb.data() + (size_t)s->n_topics * 8);
+        bool gave_up = false;
+        for (int t = 0; t < s->n_topics; ++t) gave_up |= s->dual_ok[(size_t)t] && (info[t * 4 + 1] & 16);
+        if (gave_up && !s->multi_off) {
+            // k_bound_multi could not get a topic's workgroups resident together and committed nothing: the same launch again on
+            // the kernels that do not wait for each other, and no further use of the persistent driver in this session
+            s->multi_off = true;
+            const std::vector<int64_t> again = s->h_dual_target;
+            int rc = bound_step_impl(s, again.data(), s->bound_iters_last, true);
+            if (rc) return rc;
+            return kao_session_bounds(s, upper_bound, flags, iters);
+        }
         for (int t = 0; t < s->n_topics; ++t) {
             if (!s->dual_ok[(size_t)t]) continue;
             s->dual_iters[(size_t)t] = info[t * 4 + 0];

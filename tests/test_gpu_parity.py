@@ -742,16 +742,22 @@ def _wide_cases(ko, status="optimal"):
 
 
 def _bound_chunk(monkeypatch, chunk):
-    """KAO_BOUND_CHUNK (test hook): None = the library's own choice (one persistent workgroup per topic up to 2048 partitions,
-    k_bound_step with slices of 512 partitions beyond), "0" = always the persistent kernel, "64" / "192" = always k_bound_step
-    with slices that small (several workgroups even for the small families)."""
+    """KAO_BOUND_CHUNK / KAO_BOUND_MULTI (test hooks).  None = the library's own choice (one persistent workgroup per topic below
+    1,024 partitions, k_bound_multi -- persistent, slices of 256 partitions, one barrier per iteration -- beyond), "0" = always
+    k_bound's single workgroup, "64" / "192" = always sliced that small on k_bound_multi (several workgroups even for the small
+    families), "step64" / "step" = the round-2 driver k_bound_step (one kernel launch per iteration), slices of 64 / its own choice."""
+    monkeypatch.delenv("KAO_BOUND_CHUNK", raising=False)
+    monkeypatch.delenv("KAO_BOUND_MULTI", raising=False)
     if chunk is None:
-        monkeypatch.delenv("KAO_BOUND_CHUNK", raising=False)
-    else:
+        return
+    if chunk.startswith("step"):
+        monkeypatch.setenv("KAO_BOUND_MULTI", "0")
+        chunk = chunk[4:]
+    if chunk:
         monkeypatch.setenv("KAO_BOUND_CHUNK", chunk)
 
 
-@pytest.mark.parametrize("chunk", [None, "64", "192"])
+@pytest.mark.parametrize("chunk", [None, "64", "192", "step64"])
 def test_dual_bound_replay_bit_exact(kao, ko, kp, monkeypatch, chunk):
     """K-bound vs its scalar replay (oracle/kao_port.c::kao_port_dual_bound): identical multipliers, best dual value,
     iteration count and stop flags -- one launch, and several launches that continue from the state in HBM.  Both drivers:
@@ -776,7 +782,7 @@ def test_dual_bound_replay_bit_exact(kao, ko, kp, monkeypatch, chunk):
         assert got["bound"] == st.bound >= c["objective"], tag
 
 
-@pytest.mark.parametrize("chunk", [None, "64"])
+@pytest.mark.parametrize("chunk", [None, "64", "step64"])
 def test_dual_bound_replay_high_rf_and_broker_weights(kao, ko, kp, monkeypatch, chunk):
     """Round 3: K-bound beyond the README's range -- RF 5..8 (k_bound<8>: 8 replica slots per lane, 8 + 9 candidates per rack)
     and broker weights (plain objective coefficients inside the priced values) -- against the scalar replay, which solves every
@@ -814,10 +820,11 @@ def test_dual_bound_replay_high_rf_and_broker_weights(kao, ko, kp, monkeypatch, 
     assert n_rf >= 20 and n_w >= 20
 
 
-@pytest.mark.parametrize("chunk", [None, "0", "64"])
+@pytest.mark.parametrize("chunk", [None, "0", "64", "step", "step64"])
 def test_dual_bound_replay_large_shapes(kao, ko, kp, monkeypatch, chunk):
-    """(chunk None: the 20,000-partition shape runs sliced over 40 workgroups, the others persistent; "0": all persistent; "64":
-    all sliced.)  K-bound paths the small families do not reach: the current assignment read from global memory (8 B per
+    """(chunk None: the 20,000-partition shape runs on k_bound_multi sliced over 79 workgroups, the sub-1,024-partition shapes on
+    k_bound's one workgroup; "0": all on one workgroup; "64": all sliced on k_bound_multi; "step" / "step64": k_bound_step, one
+    launch per iteration.)  K-bound paths the small families do not reach: the current assignment read from global memory (8 B per
     partition no longer fits LDS), hundreds of brokers in few racks (long per-rack scans), many racks (rack ranking
     over several 64-lane rounds), RF 4 with an RF change; multipliers and dual value still equal the replay's."""
     shapes = [  # (brokers, racks, partitions, rf, removed, added, new_rf, target offset)
