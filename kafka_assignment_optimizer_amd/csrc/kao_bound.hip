@@ -215,86 +215,95 @@ __device__ __forceinline__ void bound_pools(const BoundLds &L, const BoundTopic 
     using D = BoundDims<NE>;
     constexpr int kTF = D::kTF, kTL = D::kTL;
     const int R = K.R, RF = K.RF;
-    // ---- phase T: per rack, the kTF best followers and kTL best leaders by generic value (one wavefront per rack) ----
-    for (int rr = wave; rr < R; rr += nw) {
-        const int r = __builtin_amdgcn_readfirstlane(rr);
+    // The k-th pick of a ranking by (value descending, id ascending) is the best element strictly BEHIND the (k-1)-th in that
+    // order -- ids are unique, so the order is strict and one (key, id) pair replaces the list of earlier picks.
+    // ---- phase T: per rack, the kTF best followers and kTL best leaders by generic value (one wavefront per rack and ranking) ----
+    for (int uu = wave; uu < 2 * R; uu += nw) {
+        const int u = __builtin_amdgcn_readfirstlane(uu), r = u >> 1;
         const int x0 = L.RO[r], n = L.RO[r + 1] - x0, gr = L.G[r];
-        for (int pass = 0; pass < 2; ++pass) {   // 0: followers (F), 1: leaders (FL = F - l)
+        {
+            const int pass = u & 1;              // 0: followers (F), 1: leaders (FL = F - l)
             const int want = pass == 0 ? RF : RF + 1, stride = pass == 0 ? kTF : kTL;
             int *ob = pass == 0 ? L.TFb + r * kTF : L.TLb + r * kTL, *ov = pass == 0 ? L.TFv + r * kTF : L.TLv + r * kTL;
-            int sel[kTL];
-#pragma unroll
-            for (int i = 0; i < kTL; ++i) sel[i] = -1;
-#pragma unroll
-            for (int k = 0; k < kTL; ++k) {
-                if (k >= stride) continue;
+            uint32_t pk = 0xFFFFFFFFu, pb = 0;   // the previous pick (none yet: every key is below 0xFFFFFFFF -- values stay far from INT_MAX)
+            for (int k = 0; k < stride; ++k) {
                 int selb = -1, selv = 0;
                 if (k < want && k < n) {
                     uint32_t bkey = 0, bb = 0xFFFFFFFFu;
                     for (int jj = lane; jj < n; jj += 64) {
-                        const int b = L.XB[x0 + jj];
-                        const int v = pass ? bound_lval(L, b, gr) : bound_fval(L, b, gr);
+                        const uint32_t b = L.XB[x0 + jj];
+                        const int v = pass ? bound_lval(L, (int)b, gr) : bound_fval(L, (int)b, gr);
                         const uint32_t key = (uint32_t)v + 0x80000000u;
-                        bool ok = true;
-#pragma unroll
-                        for (int i = 0; i < kTL - 1; ++i) ok &= b != sel[i];
-                        if (ok && key > bkey) { bkey = key; bb = (uint32_t)b; }
+                        const bool ok = key < pk || (key == pk && b > pb);
+                        if (ok && key > bkey) { bkey = key; bb = b; }   // members ascend inside a rack: the first of equal keys is the lowest id
                     }
                     uint32_t mx;
                     const int wl_ = wave_argmax(bkey, bb, mx);
                     selb = __builtin_amdgcn_readlane((int)bb, wl_);
                     selv = (int)(mx - 0x80000000u);
-                    sel[k] = selb;
+                    pk = mx; pb = (uint32_t)selb;
                 }
                 if (lane == 0) { ob[k] = selb; ov[k] = selv; }
             }
         }
     }
     __syncthreads();
-    // ---- phase R (wavefront 0): the RF best racks for followers -> pool PF, the RF+1 best racks for leaders -> PL ----
-    if (wave == 0) {
-        for (int pass = 0; pass < 2; ++pass) {
+    // ---- phase R: the RF best racks for followers -> pool PF (wavefront 0), the RF+1 best racks for leaders -> PL (wavefront 1) ----
+    // Up to 64 racks a lane RANKS its rack against all others (independent compares instead of `want` dependent arg-max rounds:
+    // phase R was a quarter of an iteration's fixed cost) and the racks of rank < want write their pool rows; beyond 64 racks the
+    // arg-max rounds remain.  Same strict order (value descending, best broker's id ascending), same pools.
+    if (wave < 2) {
+        for (int pass = wave; pass < 2; pass += nw) {
             const int want = pass == 0 ? RF : RF + 1;
             const int *tb = pass == 0 ? L.TFb : L.TLb, *tv = pass == 0 ? L.TFv : L.TLv;
             const int stride = pass == 0 ? kTF : kTL;
-            int sel[kTL];
-#pragma unroll
-            for (int i = 0; i < kTL; ++i) sel[i] = -1;
-#pragma unroll
-            for (int k = 0; k < kTL; ++k) {
-                if (k >= want) continue;
-                uint32_t bkey = 0, bid = 0xFFFFFFFFu;
-                int brk = -1;
-                for (int r = lane; r < R; r += 64) {
-                    const int b = tb[r * stride];
-                    bool ok = b >= 0;
-#pragma unroll
-                    for (int i = 0; i < kTL - 1; ++i) ok &= r != sel[i];
-                    const uint32_t key = (uint32_t)tv[r * stride] + 0x80000000u;
-                    if (ok && (key > bkey || (key == bkey && (uint32_t)b < bid))) { bkey = key; bid = (uint32_t)b; brk = r; }
+            if (pass == 0) { for (int i = lane; i < D::kPF; i += 64) { L.PFb[i] = -1; L.PFr[i] = -1; L.PFv[i] = 0; } }
+            else if (lane < D::kPL) { L.PLb[lane] = -1; L.PLr[lane] = -1; L.PLv[lane] = 0; }
+            if (R <= 64) {
+                const int myb = lane < R ? tb[lane * stride] : -1;
+                const uint32_t mykey = lane < R ? (uint32_t)tv[lane * stride] + 0x80000000u : 0u;
+                int rank = 0;
+                for (int r2 = 0; r2 < R; ++r2) {
+                    const int b2 = __builtin_amdgcn_readlane(myb, r2);
+                    const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)mykey, r2);
+                    rank += (int)((b2 >= 0) & (k2 > mykey || (k2 == mykey && (uint32_t)b2 < (uint32_t)myb)));
                 }
-                uint32_t mx;
-                int selr = -1;
-                if (__ballot(bkey != 0) != 0ull) {
-                    const int wl_ = wave_argmax(bkey, bid, mx);
-                    selr = __builtin_amdgcn_readlane(brk, wl_);
+                if (myb >= 0 && rank < want) {
+                    if (pass == 0) {
+                        for (int t = 0; t < kTF; ++t) {
+                            const bool have = t < RF;
+                            L.PFb[rank * kTF + t] = have ? L.TFb[lane * kTF + t] : -1;
+                            L.PFr[rank * kTF + t] = lane;
+                            L.PFv[rank * kTF + t] = have ? L.TFv[lane * kTF + t] : 0;
+                        }
+                    } else { L.PLb[rank] = myb; L.PLr[rank] = lane; L.PLv[rank] = tv[lane * stride]; }
                 }
-                sel[k] = selr;
-                if (pass == 0) {
-                    if (lane < kTF) {
-                        const bool have = selr >= 0 && lane < RF;
-                        L.PFb[k * kTF + lane] = have ? L.TFb[selr * kTF + lane] : -1;
-                        L.PFr[k * kTF + lane] = selr;
-                        L.PFv[k * kTF + lane] = have ? L.TFv[selr * kTF + lane] : 0;
+            } else {
+                uint32_t pk = 0xFFFFFFFFu, pb = 0;
+                for (int k = 0; k < want; ++k) {
+                    uint32_t bkey = 0, bid = 0xFFFFFFFFu;
+                    int brk = -1;
+                    for (int r = lane; r < R; r += 64) {
+                        const int b = tb[r * stride];
+                        const uint32_t key = (uint32_t)tv[r * stride] + 0x80000000u;
+                        const bool ok = (b >= 0) & (key < pk || (key == pk && (uint32_t)b > pb));
+                        if (ok && (key > bkey || (key == bkey && (uint32_t)b < bid))) { bkey = key; bid = (uint32_t)b; brk = r; }
                     }
-                } else if (lane == 0) {
-                    L.PLb[k] = selr >= 0 ? L.TLb[selr * kTL] : -1;
-                    L.PLr[k] = selr;
-                    L.PLv[k] = selr >= 0 ? L.TLv[selr * kTL] : 0;
+                    if (__ballot(bkey != 0) == 0ull) break;   // nothing left: no later pick either
+                    uint32_t mx;
+                    const int wl_ = wave_argmax(bkey, bid, mx);
+                    const int selr = __builtin_amdgcn_readlane(brk, wl_);
+                    pk = mx; pb = (uint32_t)__builtin_amdgcn_readlane((int)bid, wl_);
+                    if (pass == 0) {
+                        if (lane < kTF) {
+                            const bool have = lane < RF;
+                            L.PFb[k * kTF + lane] = have ? L.TFb[selr * kTF + lane] : -1;
+                            L.PFr[k * kTF + lane] = selr;
+                            L.PFv[k * kTF + lane] = have ? L.TFv[selr * kTF + lane] : 0;
+                        }
+                    } else if (lane == 0) { L.PLb[k] = L.TLb[selr * kTL]; L.PLr[k] = selr; L.PLv[k] = L.TLv[selr * kTL]; }
                 }
             }
-            if (pass == 0) { for (int k = RF; k < NE; ++k) if (lane < kTF) L.PFb[k * kTF + lane] = -1; }
-            else if (lane == 0) for (int k = RF + 1; k < D::kPL; ++k) L.PLb[k] = -1;
         }
     }
     __syncthreads();
@@ -312,6 +321,11 @@ __device__ __forceinline__ void bound_subproblems(const BoundLds &L, const Bound
     const int w00 = K.w00, w01 = K.w01, w10 = K.w10, w11 = K.w11;
     const int *PFb = L.PFb, *PFr = L.PFr, *PFv = L.PFv, *PLb = L.PLb, *PLr = L.PLr, *PLv = L.PLv, *TLb = L.TLb, *TLv = L.TLv;
     const int *G = L.G;
+    // Of a rack's ranked candidates only the first `pdepth` = min(prack_hi, RF) can enter the follower set (a later one is dominated
+    // by an earlier one of the same rack, and the rack is full once `prack_hi` of them are in), and only the first pdepth + 1
+    // leader candidates matter (at most pdepth of them are set members; all non-members of a rack displace the same element).
+    // With the usual prack_hi = 1 that is 3 + 4 follower candidates per round instead of 12 + 4 -- same picks, same value.
+    const int pdepth = min(phi, RF);
     for (int base = p_begin + wave * 64; base < p_end; base += nw * 64) {
         const int p = base + lane;
         const bool act = p < p_end;
@@ -351,7 +365,8 @@ __device__ __forceinline__ void bound_subproblems(const BoundLds &L, const Bound
                 const bool ok = (b >= 0) & (forced >= 0 ? r == forced : cnt < phi) & !in;
                 if (ok && (f > bf || (f == bf && b < bb))) { bf = f; bb = b; br = r; }
             };
-            for (int i = 0; i < RF * kTF; ++i) consider(PFb[i], PFr[i], PFv[i]);
+            for (int k = 0; k < RF; ++k)
+                for (int i = k * kTF; i < k * kTF + pdepth; ++i) consider(PFb[i], PFr[i], PFv[i]);
 #pragma unroll
             for (int i = 0; i < NE; ++i) consider(cb[i], cr[i], cF[i]);
             if (bb == INT_MAX) { fail = true; bb = -1; bf = 0; }
@@ -394,7 +409,7 @@ __device__ __forceinline__ void bound_subproblems(const BoundLds &L, const Bound
                 if (j >= RF) break;
                 const int b = Gb[j], r = Gr[j];
                 lead(b, r, bound_lval(L, b, G[r]));                               // a set member leads
-                for (int k = 0; k <= RF; ++k) lead(TLb[r * kTL + k], r, TLv[r * kTL + k]);   // best leaders of its rack
+                for (int k = 0; k <= pdepth; ++k) lead(TLb[r * kTL + k], r, TLv[r * kTL + k]);   // best leaders of its rack
             }
 #pragma unroll
             for (int i = 0; i < NE; ++i) lead(cb[i], cr[i], cFL[i]);              // the partition's current brokers
@@ -808,7 +823,7 @@ __global__ __launch_bounds__(256) void k_bound_multi_begin(BoundPools pl, BoundW
 template <int NE>
 __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools pl, BoundWide wd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    __shared__ int s_go;
+    __shared__ int s_go, s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
     const int2 bm = wd.map[blockIdx.x];
     const int topic = bm.x, slice = bm.y;
@@ -851,6 +866,12 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools
     int flags = 0, it = 0, arrivals = 0;
     bool rec = false, parked = false, aborted = false;
     const int n_steps = pl.iters + kDualProbes;
+#ifdef KAO_BOUND_PROFILE   // where an iteration's time goes (slice 0, thread 0; 100 MHz ticks per phase, printed at the end)
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt0 = (long long)wall_clock64();
+#define KAO_PROF_MARK(i) { const long long pt1 = (long long)wall_clock64(); prof[i] += pt1 - pt0; pt0 = pt1; }
+#else
+#define KAO_PROF_MARK(i)
+#endif
     for (int stp = 0; stp < n_steps; ++stp) {
         const int buf = stp % 3;
         const bool probe = stp >= pl.iters;
@@ -876,28 +897,36 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools
             }
             __syncthreads();
         }
+        KAO_PROF_MARK(5)
         bound_pools<NE>(L, K, wave, nw, lane);
+        KAO_PROF_MARK(0)
         long long wsum = 0;
         bool bad = false;
         bound_subproblems<NE, true>(L, K, nullptr, p_begin, p_end, wave, nw, lane, wsum, bad);
         bad = __ballot(bad) != 0ull;
         wsum = wave_sum64(wsum);
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
         if (lane == 0) {
             if (wsum) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[0]), (unsigned long long)wsum);
-            if (bad) atomicOr(&mi[2 + buf], 1);
+            if (bad) { atomicOr(&s_bad, 1); if (n_slices > 1) atomicOr(&mi[2 + buf], 1); }
         }
         __syncthreads();
+        KAO_PROF_MARK(1)
         int *cnt = cnt0 + buf * cstride;
+        // (replicas | leaders << 32 of a broker travel as ONE 64-bit atomic: the HBM atomics of ~60 workgroups on the same 2 B
+        //  addresses are what publish + barrier cost at 1000 brokers x 30,000 partitions -- 17 of 42 us before the packing)
+        unsigned long long *c64 = reinterpret_cast<unsigned long long *>(cnt);
         if (n_slices > 1) {
             for (int b = tid; b < B; b += nt) {
-                const int nr = L.NR[b], nl = L.NL[b];
-                if (nr) atomicAdd(&cnt[b], nr);
-                if (nl) atomicAdd(&cnt[B + b], nl);
+                const unsigned long long v = (unsigned long long)(uint32_t)L.NR[b] | ((unsigned long long)(uint32_t)L.NL[b] << 32);
+                if (v) atomicAdd(&c64[b], v);
             }
             if (tid < R) { const int nk = L.NK[tid]; if (nk) atomicAdd(&cnt[2 * B + tid], nk); }
             if (tid == 0 && acc[0]) atomicAdd(reinterpret_cast<unsigned long long *>(&msum[buf]), (unsigned long long)acc[0]);
             __threadfence();
             __syncthreads();
+            KAO_PROF_MARK(2)
             // ---- the barrier of this evaluation ----
             ++arrivals;
             if (tid == 0) {
@@ -915,11 +944,16 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools
                 s_go = go;
             }
             __syncthreads();
+            KAO_PROF_MARK(3)
             if (!s_go) { aborted = true; break; }
             // totals in; the buffer of the previous evaluation is cleared (its readers have all passed through this barrier)
-            for (int b = tid; b < B; b += nt) { L.NR[b] = ld_agent(&cnt[b]); L.NL[b] = ld_agent(&cnt[B + b]); }
+            for (int b = tid; b < B; b += nt) {
+                const unsigned long long v = __hip_atomic_load(&c64[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.NR[b] = (int)(uint32_t)v; L.NL[b] = (int)(uint32_t)(v >> 32);
+            }
             if (tid < R) L.NK[tid] = ld_agent(&cnt[2 * B + tid]);
             if (tid == 0) acc[0] = __hip_atomic_load(&msum[buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == nt - 1) s_bad = ld_agent(&mi[2 + buf]);
             if (stp > 0) {
                 const int pb = (stp - 1) % 3;
                 int *pc = cnt0 + pb * cstride;
@@ -930,9 +964,9 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools
                 }
             }
             __syncthreads();
+            KAO_PROF_MARK(4)
         }
-        const int any_bad = ld_agent(&mi[2 + buf]);
-        if (any_bad) { if (!probe) flags |= 4; break; }
+        if (s_bad) { if (!probe) flags |= 4; break; }
         long long cL = 0, cN = 0, cD = 0;
         bound_band_terms(L, K, L.DA, L.DL, probe, tid, nt, cL, cN, cD);
         const bool owns = wave * 64 < max(B, R);
@@ -943,6 +977,7 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools
             if (cD) atomicAdd(reinterpret_cast<unsigned long long *>(&acc[2]), (unsigned long long)cD);
         }
         __syncthreads();
+        KAO_PROF_MARK(6)
         // ---- phase C (every workgroup of the topic takes the same decisions) ----
         const long long Lv = acc[0], nrm = acc[1];
         long long dn = acc[2];
@@ -973,6 +1008,11 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools
         bound_take_step(L, K, L.DA, L.DL, reset, step, sh, lv_seq++, tid, nt);
         __syncthreads();
     }
+#ifdef KAO_BOUND_PROFILE
+    if (owner && tid == 0)
+        printf("[k_bound_multi] topic %d P %d B %d slices %d it %d: pools %lld subproblems %lld publish %lld barrier %lld totals %lld band terms %lld step %lld (x 10 ns)\n",
+               topic, P, B, n_slices, it, prof[0], prof[1], prof[2], prof[3], prof[4], prof[6], prof[5]);
+#endif
     if (aborted) {
         if (tid == 0) atomicOr(&pl.info[topic * 4 + 1], 16);
         return;

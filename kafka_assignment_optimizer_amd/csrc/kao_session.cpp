@@ -969,11 +969,11 @@ static int bound_step_impl(kao_session *s, const int64_t *target, int32_t iters,
         // slice (test hook: small values slice small topics)
         int chunk = maxP > 2048 ? 512 : 0;
         // Round 3: the sliced topics run on the PERSISTENT multi-workgroup driver (k_bound_multi) -- and so do topics from 1,024
-        // partitions up, in slices of 256 (a 2,000-partition topic: 52 us per iteration in k_bound's one workgroup).  Its workgroups
+        // partitions up, in slices of 512 (a 2,000-partition topic: 52 us per iteration in k_bound's one workgroup).  Its workgroups
         // wait for each other, so a launch is kept to 96 of them (larger slices otherwise).  KAO_BOUND_MULTI=0: the round-2 drivers.
         const char *multi_env = std::getenv("KAO_BOUND_MULTI");
         const bool multi = !(multi_env && multi_env[0] == '0') && !s->multi_off;
-        if (multi && chunk == 0 && maxP >= 1024) chunk = 256;
+        if (multi && chunk == 0 && maxP >= 1024) chunk = 512;
         if (const char *e = std::getenv("KAO_BOUND_CHUNK")) { chunk = std::max(0, std::atoi(e)) / 64 * 64; }
         if (multi && chunk > 0) {   // workgroups that wait for others (topics of more than one slice): at most 96 per launch
             auto waiting_at = [&](int c) {
@@ -996,8 +996,11 @@ static int bound_step_impl(kao_session *s, const int64_t *target, int32_t iters,
             wd.chunk = chunk;
             HIP_TRY(hipMemcpyAsync(s->d_dual + s->wide_map_i32 + 2 * map0, s->h_wide_map.data() + map0, (s->h_wide_map.size() - map0) * sizeof(int2),
                                    hipMemcpyHostToDevice, s->stream_bound));
-            // (a wavefront per 64 partitions of a slice, 4..16: small workgroups find room beside a K-search launch sooner)
-            if (!(multi && !force_step && launch_bound_multi(bp, wd, n_class[cls], (int)(s->h_wide_map.size() - map0), std::min(16, std::max(4, chunk / 64)), s->stream_bound)))
+            // 16 wavefronts whatever the slice: the O(B) phases every workgroup repeats (pools, totals, band terms, step) are what
+            // an iteration waits for (measured: slices of 256 with 4 wavefronts 32 us, slices of 512 with 8 wavefronts 19 us at 500 x 5,000)
+            int multi_waves = 16;
+            if (const char *e = std::getenv("KAO_BOUND_WAVES")) multi_waves = std::min(16, std::max(1, std::atoi(e)));
+            if (!(multi && !force_step && launch_bound_multi(bp, wd, n_class[cls], (int)(s->h_wide_map.size() - map0), multi_waves, s->stream_bound)))
                 launch_bound_wide(bp, wd, n_class[cls], (int)(s->h_wide_map.size() - map0), 16, s->stream_bound);
         } else
             launch_bound(bp, n_class[cls], waves, s->stream_bound);

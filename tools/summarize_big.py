@@ -14,7 +14,7 @@ def dbs(sub):
 
 
 def short(name):
-    return name.split("(")[0].replace("kao::", "").replace("void ", "").replace("(anonymous namespace)::", "")
+    return name.replace("(anonymous namespace)::", "").split("(")[0].replace("kao::", "").replace("void ", "")
 
 
 steps = {}
@@ -79,9 +79,18 @@ try:
     print(open(os.path.join(out, "solve.json")).read().strip().splitlines()[-1])
 except Exception as e:  # noqa: BLE001
     print("solve json unavailable:", e)
+tot = defaultdict(lambda: [0, 0])
 for db in dbs("solve_trace"):
     c = sqlite3.connect(db)
-    for name, calls, total, avg, pct in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()[:14]:
-        print(f"{short(name)[:58]:58s} calls={calls:6d} total={total / 1e6:9.3f} ms avg={avg / 1e3:10.2f} us {pct:5.1f}%")
+    for name, d in c.execute("select name, duration from kernels"):   # duration in ns
+        e = tot[short(name)[:58]]
+        e[0] += 1
+        e[1] += d
+gpu_ns = sum(e[1] for e in tot.values()) or 1
+solve_share = {}
+for name, (calls, ns) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:16]:
+    solve_share[name] = {"calls": calls, "total_ms": ns / 1e6, "avg_us": ns / calls / 1e3, "share": ns / gpu_ns}
+    print(f"{name:58s} calls={calls:6d} total={ns / 1e6:9.3f} ms avg={ns / calls / 1e3:10.2f} us {100.0 * ns / gpu_ns:5.1f}%")
+const["solve_kernel_share"] = solve_share
 with open(os.path.join(out, "constants.json"), "w") as f:
     json.dump(const, f, indent=1)
