@@ -325,7 +325,8 @@ int kao_rccl_loopback_counts(uint64_t out[2]);
  * delta-evaluated in those launches (kao_stats.delta_candidates, all devices), out[6] = K-bound launches, out[7] = elite
  * exchanges between GPUs (kao_solve_multi), out[8] = K-bound iterations summed over the topics, out[9] = KAO-CX calls,
  * out[10] = KAO-CX calls that improved an incumbent, out[11] = K-search iterations per restart, out[12] = generations started
- * after the first (kao_session_new_generation), out[13..15] reserved (0). */
+ * after the first (kao_session_new_generation), out[13] = KAO-CX runs from further starting points (other restarts' best
+ * snapshots; included in out[9]), out[14..15] reserved (0). */
 int kao_last_solve_timing(double out[16]);
 
 #ifdef __cplusplus

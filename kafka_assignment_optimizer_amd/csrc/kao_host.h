@@ -178,6 +178,9 @@ struct kao_session {
 namespace kao {
 // the topic's winning assignment (dense [P*RF]) as of the last finished launch
 int session_topic_best(kao_session *s, int i, uint16_t *out);
+// every restart's best feasible objective (-1 = none yet) / one restart's best snapshot, as of the last finished launch
+int session_restart_objs(kao_session *s, int i, std::vector<int32_t> &objs);
+int session_restart_best(kao_session *s, int i, int restart, uint16_t *out);
 // an assignment found outside K-search (KAO-CX, another GPU) becomes the topic's incumbent and elite
 int session_adopt_external(kao_session *s, int i, const uint16_t *assign, int64_t objective, uint64_t *key_out);
 }  // namespace kao

@@ -1195,6 +1195,26 @@ int session_topic_best(kao_session *s, int i, uint16_t *out) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     return KAO_OK;
 }
+// every restart's best feasible objective (-1: never feasible) and one restart's best snapshot (dense [P*RF]) as of the last
+// finished launch: the starting points of kao_solve's further KAO-CX runs
+int session_restart_objs(kao_session *s, int i, std::vector<int32_t> &objs) {
+    HIP_TRY(hipSetDevice(s->device));
+    const TopicDev &d = s->pts[(size_t)i].d;
+    std::vector<int32_t> info((size_t)d.n_restarts * 4);
+    HIP_TRY(hipMemcpyAsync(info.data(), s->d_info + (size_t)d.restart_base * 4, info.size() * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    objs.resize((size_t)d.n_restarts);
+    for (int r = 0; r < d.n_restarts; ++r) objs[(size_t)r] = info[(size_t)r * 4];
+    return KAO_OK;
+}
+int session_restart_best(kao_session *s, int i, int restart, uint16_t *out) {
+    HIP_TRY(hipSetDevice(s->device));
+    const TopicDev &d = s->pts[(size_t)i].d;
+    if (restart < 0 || restart >= d.n_restarts) return fail(KAO_ERR_INVALID, "bad restart");
+    HIP_TRY(hipMemcpyAsync(out, s->d_best + d.best_off + (uint64_t)restart * d.P * d.RF, (size_t)d.P * d.RF * 2, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return KAO_OK;
+}
 // a feasible assignment found outside K-search (KAO-CX) becomes the topic's incumbent: winner buffer + packed key with the
 // reserved restart id, exactly as an assignment adopted from another GPU (k_gather leaves it alone, elite launches re-seed from it)
 int session_adopt_external(kao_session *s, int i, const uint16_t *assign, int64_t objective, uint64_t *key_out) {

@@ -84,6 +84,10 @@ struct SolveRun {
     std::vector<uint16_t> cx_buf;
     std::vector<CycleCtx *> cx_ctx;
     int cx_calls = 0, cx_gains = 0;
+    int cx_starts = 0, cx_start_rounds = 16, cx_more = 0;   // further KAO-CX starting points per call (further_starts), rounds each, runs so far
+    std::vector<std::vector<uint64_t>> cx_started;  // per topic: hashes of the assignments KAO-CX has started from in this generation
+    std::vector<int32_t> start_objs;
+    std::vector<int> start_order;
     double cx_slice = 0.1;                        // seconds one KAO-CX call may take (wall-clock schedule only)
     // Deterministic schedule (kao_opts.schedule == 0, the default): every decision of the loop is keyed to COUNTS -- K-search
     // launches and iterations, K-bound iterations, KAO-CX rounds -- never to the clock, so the same seed gives the same answer
@@ -147,6 +151,7 @@ struct SolveRun {
         dkeys.assign((size_t)n, ~0ull); gprev.assign((size_t)n, ~0ull); inc_key.assign((size_t)n, ~0ull); inc_assign.assign((size_t)n, {});
         this->topics = topics;
         t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
+        cx_started.assign((size_t)n, {});
         cx_on = so.use_cycles >= 0;
         { const char *e = std::getenv("KAO_CX_EAGER"); cx_eager = e && e[0] == '1'; }
         cx_ctx.assign((size_t)n, nullptr);
@@ -173,6 +178,10 @@ struct SolveRun {
             if (det) { dual_now = dual_iters = dual_iters > 0 ? (int)env_i("KAO_DET_BOUND_ITERS", dual_iters) : 0; }
             cx_stall_iters = env_i("KAO_DET_CX_STALL", cx_stall_iters); cx_due_iters = env_i("KAO_DET_CX_DUE", cx_due_iters);
             cx_rounds = (int)env_i("KAO_DET_CX_ROUNDS", cx_rounds);
+            // further KAO-CX starting points per call (further_starts): where a round is cheap (closures of (B + 1)^2 entries, <= 512
+            // realisations of P rows) eight more descents cost about as much as the launches between two calls
+            cx_starts = (int)env_i("KAO_DET_CX_STARTS", slots <= 16384 ? 8 : 0);
+            cx_start_rounds = (int)env_i("KAO_DET_CX_START_ROUNDS", 16);
         }
         gens_on = allow_gens && det && cx_on && !has_target;
         { const char *e = std::getenv("KAO_DET_GEN"); if (e && e[0] == '0') gens_on = false; }
@@ -301,7 +310,9 @@ struct SolveRun {
         for (int i = 0; i < n; ++i) {
             if (s->topic_infeasible[(size_t)i] || !gfeasible(i) || (feasible(i) && objective(i) >= s->ub[(size_t)i])) continue;
             if (!cycle_supported(&topics[i])) continue;
-            if ((dkeys[(size_t)i] >> 20) == (cx_seen[(size_t)i] >> 20)) continue;   // same incumbent as the last fixpoint
+            const bool elite_fresh = (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20);   // not the incumbent of the last fixpoint
+            const bool more = det && cx_starts > 0;
+            if (!elite_fresh && !more) continue;
             if (det) {   // counts, not the clock: iterations since the last improvement / since the last call
                 const bool stalled = iters_done - i_improved[(size_t)i] >= cx_stall_iters, due = iters_done - i_cx[(size_t)i] >= cx_due_iters;
                 if (!cx_eager && (!(stalled || due) || iters_done - i_cx[(size_t)i] < cx_stall_iters)) continue;
@@ -311,36 +322,80 @@ struct SolveRun {
             }
             const size_t slots = (size_t)topics[i].n_partitions * topics[i].rf;
             cx_buf.resize(slots);
-            int rc = session_topic_best(s, i, cx_buf.data());
-            if (rc) return rc;
-            int64_t obj = gobjective(i);
-            int32_t st[8];
+            int rc;
             if (!cx_ctx[(size_t)i] && !(cx_ctx[(size_t)i] = cycle_open(&topics[i], &rc))) return rc;
-            // the clock only ends a deterministic call at the solve's own deadline (the stop condition)
-            const double slice_end = det ? deadline : std::min(deadline, now_s() + cx_slice);
-            rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), det ? cx_rounds : 0, slice_end, &obj, st, &SolveRun::poll_bound, this);
-            ++cx_calls;
-            if (rc) return rc;
-            const bool fixpoint = st[0] > st[1];   // the last round found nothing
-            const double t2 = now_s() - t0;
-            t_cx[(size_t)i] = t2;
-            i_cx[(size_t)i] = iters_done;
-            if (obj > gobjective(i)) {
-                uint64_t key = 0;
-                if ((rc = session_adopt_external(s, i, cx_buf.data(), obj, &key))) return rc;
-                dkeys[(size_t)i] = gprev[(size_t)i] = key;
-                t_improved[(size_t)i] = t2;
-                i_improved[(size_t)i] = iters_done;
-                if (key < keys[(size_t)i]) { keys[(size_t)i] = prev[(size_t)i] = key; t_best[(size_t)i] = t_last_improve = t2; }
-                ++cx_gains;
+            if (elite_fresh) {
+                if ((rc = session_topic_best(s, i, cx_buf.data()))) return rc;
+                if (more) cx_started[(size_t)i].push_back(start_hash(cx_buf.data(), slots));
+                if ((rc = cycle_start(i, gobjective(i), det ? cx_rounds : 0, true))) return rc;
             }
-            if (fixpoint) cx_seen[(size_t)i] = dkeys[(size_t)i];
+            if (more && !(feasible(i) && objective(i) >= s->ub[(size_t)i]) && now_s() < deadline && (rc = further_starts(i))) return rc;
             // a context holds ~90 B per broker pair on the device and as much on the host: keep a handful, not one per topic
             int open = 0;
             for (CycleCtx *c : cx_ctx) open += c != nullptr;
             if (open > 8) { cycle_close(cx_ctx[(size_t)i]); cx_ctx[(size_t)i] = nullptr; }
         }
         all_done = check_done();
+        return KAO_OK;
+    }
+    static uint64_t start_hash(const uint16_t *a, size_t n) {   // FNV-1a over the slots
+        uint64_t h = 1469598103934665603ull;
+        for (size_t k = 0; k < n; ++k) { h ^= a[k]; h *= 1099511628211ull; }
+        return h;
+    }
+    // KAO-CX from the assignment in cx_buf (objective obj0) for at most `rounds` rounds; a result better than the generation's
+    // incumbent becomes the topic's incumbent and elite
+    int cycle_start(int i, int64_t obj0, int rounds, bool is_elite) {
+        int64_t obj = obj0;
+        int32_t st[8];
+        // the clock only ends a deterministic call at the solve's own deadline (the stop condition)
+        const double slice_end = det ? deadline : std::min(deadline, now_s() + cx_slice);
+        int rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), rounds, slice_end, &obj, st, &SolveRun::poll_bound, this);
+        ++cx_calls;
+        if (rc) return rc;
+        const bool fixpoint = st[0] > st[1];   // the last round found nothing
+        const double t2 = now_s() - t0;
+        t_cx[(size_t)i] = t2;
+        i_cx[(size_t)i] = iters_done;
+        if (obj > gobjective(i)) {
+            uint64_t key = 0;
+            if ((rc = session_adopt_external(s, i, cx_buf.data(), obj, &key))) return rc;
+            dkeys[(size_t)i] = gprev[(size_t)i] = key;
+            t_improved[(size_t)i] = t2;
+            i_improved[(size_t)i] = iters_done;
+            if (key < keys[(size_t)i]) { keys[(size_t)i] = prev[(size_t)i] = key; t_best[(size_t)i] = t_last_improve = t2; }
+            ++cx_gains;
+            if (fixpoint) cx_seen[(size_t)i] = key;
+        } else if (fixpoint && is_elite) cx_seen[(size_t)i] = dkeys[(size_t)i];   // the incumbent itself is a fixpoint
+        return KAO_OK;
+    }
+    // Further starting points (deterministic schedule): independent descents end a unit or two apart -- which basin KAO-CX
+    // lands in is decided by where it starts (drifted 300 x 2000, scalar replay + oracle: 16 single restarts of 25,600
+    // iterations -> fixpoints 14810..14826, three of them the optimum 14826) -- so besides the elite the best snapshots of the
+    // `cx_starts` best other restarts (by their own best objective, ties to the lower index; an assignment is started from
+    // once per generation) are run to a fixpoint too.  Only a result that beats the incumbent is adopted.
+    int further_starts(int i) {
+        int rc = session_restart_objs(s, i, start_objs);
+        if (rc) return rc;
+        const int nr = (int)start_objs.size();
+        start_order.resize((size_t)nr);
+        for (int r = 0; r < nr; ++r) start_order[(size_t)r] = r;
+        std::stable_sort(start_order.begin(), start_order.end(), [&](int a, int b) { return start_objs[(size_t)a] > start_objs[(size_t)b]; });
+        const size_t slots = (size_t)topics[i].n_partitions * topics[i].rf;
+        int done = 0;
+        for (int q = 0; q < nr && done < cx_starts; ++q) {
+            const int r = start_order[(size_t)q];
+            if (start_objs[(size_t)r] < 0) break;
+            if (feasible(i) && objective(i) >= s->ub[(size_t)i]) break;
+            if (now_s() >= deadline) break;
+            if ((rc = session_restart_best(s, i, r, cx_buf.data()))) return rc;
+            const uint64_t h = start_hash(cx_buf.data(), slots);
+            std::vector<uint64_t> &seen = cx_started[(size_t)i];
+            if (std::find(seen.begin(), seen.end(), h) != seen.end()) continue;
+            seen.push_back(h);
+            ++done; ++cx_more;
+            if ((rc = cycle_start(i, start_objs[(size_t)r], cx_start_rounds, false))) return rc;
+        }
         return KAO_OK;
     }
     // every open topic's population has converged (its best is a fixpoint of KAO-CX and nothing has improved since): bank the
@@ -365,7 +420,7 @@ struct SolveRun {
         if ((rc = kao_session_new_generation(s))) return rc;
         ++generations;
         gen_start = iters_done;
-        for (int i = 0; i < n; ++i) { dkeys[(size_t)i] = gprev[(size_t)i] = ~0ull; i_improved[(size_t)i] = i_cx[(size_t)i] = iters_done; cx_seen[(size_t)i] = ~0ull; }
+        for (int i = 0; i < n; ++i) { dkeys[(size_t)i] = gprev[(size_t)i] = ~0ull; i_improved[(size_t)i] = i_cx[(size_t)i] = iters_done; cx_seen[(size_t)i] = ~0ull; cx_started[(size_t)i].clear(); }
         return KAO_OK;
     }
     int finish(kao_result *results, bool hit_time) {
@@ -469,6 +524,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     g_timing[8] = 0;   // K-bound iterations, summed over the topics
     for (int32_t v : run.s->dual_iters) g_timing[8] += (double)v;
     g_timing[9] = run.cx_calls; g_timing[10] = run.cx_gains; g_timing[11] = (double)run.iters_done; g_timing[12] = run.generations;
+    g_timing[13] = run.cx_more;
     kao_session_destroy(run.s);
     run.s = nullptr;
     g_timing[3] = now_s() - t0;
