@@ -84,7 +84,8 @@ struct SolveRun {
     std::vector<uint16_t> cx_buf;
     std::vector<CycleCtx *> cx_ctx;
     int cx_calls = 0, cx_gains = 0;
-    int cx_starts = 0, cx_start_rounds = 16, cx_more = 0;   // further KAO-CX starting points per call (further_starts), rounds each, runs so far
+    int cx_starts = 0, cx_starts_first = 0, cx_start_rounds = 16, cx_more = 0;   // further KAO-CX starting points per call (further_starts) / in a generation's first call, rounds each, runs so far
+    std::vector<int> start_budget, start_near;      // per topic: starts the next call may run; starts of this generation that ended within a unit of the incumbent
     std::vector<std::vector<uint64_t>> cx_started;  // per topic: hashes of the assignments KAO-CX has started from in this generation
     std::vector<int32_t> start_objs;
     std::vector<int> start_order;
@@ -181,7 +182,9 @@ struct SolveRun {
             // further KAO-CX starting points per call (further_starts): where a round is cheap (closures of (B + 1)^2 entries, <= 512
             // realisations of P rows) eight more descents cost about as much as the launches between two calls
             cx_starts = (int)env_i("KAO_DET_CX_STARTS", slots <= 16384 ? 8 : 0);
+            cx_starts_first = (int)env_i("KAO_DET_CX_STARTS_FIRST", 2 * cx_starts);
             cx_start_rounds = (int)env_i("KAO_DET_CX_START_ROUNDS", 16);
+            start_budget.assign((size_t)n, cx_starts_first); start_near.assign((size_t)n, 0);
         }
         gens_on = allow_gens && det && cx_on && !has_target;
         { const char *e = std::getenv("KAO_DET_GEN"); if (e && e[0] == '0') gens_on = false; }
@@ -345,7 +348,7 @@ struct SolveRun {
     }
     // KAO-CX from the assignment in cx_buf (objective obj0) for at most `rounds` rounds; a result better than the generation's
     // incumbent becomes the topic's incumbent and elite
-    int cycle_start(int i, int64_t obj0, int rounds, bool is_elite) {
+    int cycle_start(int i, int64_t obj0, int rounds, bool is_elite, int64_t *reached = nullptr) {
         int64_t obj = obj0;
         int32_t st[8];
         // the clock only ends a deterministic call at the solve's own deadline (the stop condition)
@@ -353,6 +356,9 @@ struct SolveRun {
         int rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), rounds, slice_end, &obj, st, &SolveRun::poll_bound, this);
         ++cx_calls;
         if (rc) return rc;
+        if (reached) *reached = obj;
+        if (trace) std::fprintf(stderr, "[kao-solve]   KAO-CX topic %d %s start %lld -> %lld in %d rounds (%d improving), incumbent %lld, launch %d\n", i, is_elite ? "elite" : "further",
+                                (long long)obj0, (long long)obj, st[0], st[1], (long long)gobjective(i), launches);
         const bool fixpoint = st[0] > st[1];   // the last round found nothing
         const double t2 = now_s() - t0;
         t_cx[(size_t)i] = t2;
@@ -372,8 +378,12 @@ struct SolveRun {
     // Further starting points (deterministic schedule): independent descents end a unit or two apart -- which basin KAO-CX
     // lands in is decided by where it starts (drifted 300 x 2000, scalar replay + oracle: 16 single restarts of 25,600
     // iterations -> fixpoints 14810..14826, three of them the optimum 14826) -- so besides the elite the best snapshots of the
-    // `cx_starts` best other restarts (by their own best objective, ties to the lower index; an assignment is started from
-    // once per generation) are run to a fixpoint too.  Only a result that beats the incumbent is adopted.
+    // best other restarts (by their own best objective, ties to the lower index; an assignment is started from once per
+    // generation) are run to a fixpoint too.  Only a result that beats the incumbent is adopted.  The first call of a
+    // generation meets the most diverse population (nothing has been re-seeded from a KAO-CX result yet) and gets
+    // `cx_starts_first` starts, later calls `cx_starts`; where the descents end far below the incumbent (slack bands: drifted
+    // 400 x 3000, fixpoints 25-60 units short) they only take time from the search, so a call whose first four starts all end
+    // more than a unit below the incumbent stops there and the next call of the topic gets a quarter of the budget.
     int further_starts(int i) {
         int rc = session_restart_objs(s, i, start_objs);
         if (rc) return rc;
@@ -382,8 +392,10 @@ struct SolveRun {
         for (int r = 0; r < nr; ++r) start_order[(size_t)r] = r;
         std::stable_sort(start_order.begin(), start_order.end(), [&](int a, int b) { return start_objs[(size_t)a] > start_objs[(size_t)b]; });
         const size_t slots = (size_t)topics[i].n_partitions * topics[i].rf;
-        int done = 0;
-        for (int q = 0; q < nr && done < cx_starts; ++q) {
+        const int budget = start_budget[(size_t)i];
+        const int64_t inc0 = gobjective(i);
+        int done = 0, near = 0;
+        for (int q = 0; q < nr && done < budget; ++q) {
             const int r = start_order[(size_t)q];
             if (start_objs[(size_t)r] < 0) break;
             if (feasible(i) && objective(i) >= s->ub[(size_t)i]) break;
@@ -394,7 +406,14 @@ struct SolveRun {
             if (std::find(seen.begin(), seen.end(), h) != seen.end()) continue;
             seen.push_back(h);
             ++done; ++cx_more;
-            if ((rc = cycle_start(i, start_objs[(size_t)r], cx_start_rounds, false))) return rc;
+            int64_t reached = -1;
+            if ((rc = cycle_start(i, start_objs[(size_t)r], cx_start_rounds, false, &reached))) return rc;
+            near += reached >= inc0 - 1;
+            if (done == 4 && near == 0) break;
+        }
+        if (done > 0) {
+            start_near[(size_t)i] += near;
+            start_budget[(size_t)i] = near > 0 ? cx_starts : std::max(1, std::min(budget, cx_starts) / 4);
         }
         return KAO_OK;
     }
@@ -420,7 +439,9 @@ struct SolveRun {
         if ((rc = kao_session_new_generation(s))) return rc;
         ++generations;
         gen_start = iters_done;
-        for (int i = 0; i < n; ++i) { dkeys[(size_t)i] = gprev[(size_t)i] = ~0ull; i_improved[(size_t)i] = i_cx[(size_t)i] = iters_done; cx_seen[(size_t)i] = ~0ull; cx_started[(size_t)i].clear(); }
+        for (int i = 0; i < n; ++i) { dkeys[(size_t)i] = gprev[(size_t)i] = ~0ull; i_improved[(size_t)i] = i_cx[(size_t)i] = iters_done; cx_seen[(size_t)i] = ~0ull; cx_started[(size_t)i].clear();
+            // a topic none of whose further starts came near the incumbent in the generation that ends gets a small first batch
+            start_budget[(size_t)i] = start_near[(size_t)i] > 0 || cx_starts_first <= 4 ? cx_starts_first : 4; start_near[(size_t)i] = 0; }
         return KAO_OK;
     }
     int finish(kao_result *results, bool hit_time) {

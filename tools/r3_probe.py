@@ -39,14 +39,15 @@ def line(tag, B, R, P, dseed, r, dt, tm):
 
 if "family" in what:
     for sched in SCHEDS:
-        proven, gaps = 0, []
-        for (B, R, P) in FAMILY:
-            for dseed in (1, 2):
-                r, dt, tm = run(topic(B, R, P, dseed), seed=3, time_limit_s=budget, schedule=sched)
-                proven += r.status == "OPTIMAL_PROVEN"
-                gaps.append(r.upper_bound - r.objective)
-                print(line(f"family sched{sched}", B, R, P, dseed, r, dt, tm), flush=True)
-        print(f"family sched{sched}: proven {proven}/{len(gaps)}; gaps of the others {sorted(g for g in gaps if g)}", flush=True)
+        for sd in [int(v) for v in os.environ.get("R3_SEEDS", "3").split(",")]:   # solver seeds
+            proven, gaps = 0, []
+            for (B, R, P) in FAMILY:
+                for dseed in (1, 2):
+                    r, dt, tm = run(topic(B, R, P, dseed), seed=sd, time_limit_s=budget, schedule=sched)
+                    proven += r.status == "OPTIMAL_PROVEN"
+                    gaps.append(r.upper_bound - r.objective)
+                    print(line(f"family sched{sched} seed {sd}", B, R, P, dseed, r, dt, tm), flush=True)
+            print(f"family sched{sched} seed {sd}: proven {proven}/{len(gaps)}; gaps of the others {sorted(g for g in gaps if g)}", flush=True)
 
 if "scale" in what:
     for sched in SCHEDS:
