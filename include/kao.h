@@ -299,7 +299,8 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
  * unrolled into slot changes and scored exactly by K-eval; rounds until nothing improves or `max_rounds` (<= 0: no limit).
  * kao_solve calls it for unproven topics whose search has stalled.  stats (may be NULL): [0] rounds, [1] improving rounds,
  * [2] realisations evaluated, [3] improving ones, [4] candidates priced > 0, [5] compounds merged, [6] objective before,
- * [7] objective after.  KAO_ERR_UNSUPPORTED: rf > 4, more than 2047 brokers, or broker weights. */
+ * [7] objective after.  Broker weights (kao_topic.broker_w / broker_wl) enter every edge and seed price.
+ * KAO_ERR_UNSUPPORTED: rf < 2, rf > 8 or more than 2047 brokers. */
 int kao_improve_cycles(const kao_topic *t, uint16_t *assignment, int32_t max_rounds, int64_t *objective, int32_t stats[8]);
 /* Parity hooks of KAO-CX (tests): the cost matrix of `layer` (0 = follower moves, 1 = role swaps) after `level` squarings
  * (0..3) as dist[(B+1)*(B+1)] (node B = slack; 1 << 17 = none), the midpoints mid[(B+1)*(B+1)] (level >= 1; may be NULL) and

@@ -38,7 +38,7 @@ constexpr int kCxBias = 1 << 16;
 constexpr int kCxLevels = 3;
 constexpr int kCxLayers = 3;      // 0 F (follower moves), 1 S (role swaps), 2 L (leader replacements)
 constexpr int kCxMaxEval = 512;
-constexpr int kCxMaxRF = 4;
+constexpr int kCxMaxRF = 8;
 constexpr unsigned long long kNoEdge = ~0ull;
 
 struct CxParams {
@@ -46,17 +46,21 @@ struct CxParams {
     int32_t rep_lo, rep_hi, lead_lo, lead_hi, prack_lo, prack_hi;
     int32_t w00, w01, w10, w11;
     int32_t ncfg;
+    const int32_t *bw, *bwl;   // broker weights by dense index (kao_topic.broker_w / broker_wl), or null
 };
 
-// objective weight of broker b in role nr on a partition whose current replicas are cur[0..rfc) (README.md:145-146)
+// objective weight of broker b in role nr on a partition whose current replicas are cur[0..rfc) (README.md:145-146), plus the
+// broker's own weights when the topic carries them (broker_w on both variables of a broker, broker_wl on the `_l` one)
 __device__ __forceinline__ int cx_wt(const CxParams &q, const uint16_t *cur, int b, int nr) {
     int w = 0;
     for (int k = 0; k < q.rfc; ++k)
         if ((int)cur[k] == b) w = k == 0 ? (nr == 0 ? q.w00 : q.w01) : (nr == 0 ? q.w10 : q.w11);
+    if (q.bw) w += q.bw[b];
+    if (q.bwl && nr == 0) w += q.bwl[b];
     return w;
 }
 
-// C7 (README.md:178-180) of a row made of `base[0..nb)` plus one more broker of rack ry: nb <= 3
+// C7 (README.md:178-180) of a row made of `base[0..nb)` plus one more broker of rack ry: nb <= kCxMaxRF - 1
 struct CxBase {
     int rk[kCxMaxRF];
     int nb, ndef;
@@ -444,6 +448,7 @@ struct Cx {
     kao_eval_plan *plan = nullptr;
     uint16_t *d_A = nullptr, *d_cur = nullptr; uint8_t *d_rack = nullptr;
     int32_t *d_cnt = nullptr;                       // c[B] | l[B]
+    int32_t *d_bw = nullptr;                        // broker weights bw[B] | bwl[B] (topics that carry them)
     unsigned long long *d_E[kCxLayers] = {};
     int32_t *d_D[kCxLayers][kCxLevels + 1] = {};
     uint16_t *d_M[kCxLayers][kCxLevels + 1] = {};
@@ -460,7 +465,7 @@ struct Cx {
     bool have_paths = false;
 
     ~Cx() {
-        (void)hipFree(d_A); (void)hipFree(d_cur); (void)hipFree(d_rack); (void)hipFree(d_cnt); (void)hipFree(d_table);
+        (void)hipFree(d_A); (void)hipFree(d_cur); (void)hipFree(d_rack); (void)hipFree(d_cnt); (void)hipFree(d_bw); (void)hipFree(d_table);
         (void)hipFree(d_cand); (void)hipFree(d_obj); (void)hipFree(d_viol); (void)hipFree(d_pq); (void)hipFree(d_prow);
         for (int l = 0; l < kCxLayers; ++l) {
             (void)hipFree(d_E[l]);
@@ -475,8 +480,8 @@ struct Cx {
         int32_t bd[8];
         int rc = kao_derive_bounds(t, bd);
         if (rc) return rc;
-        if (t->rf > kCxMaxRF || t->rf_cur > 8 || t->n_brokers + 1 > 2048 || t->broker_w || t->broker_wl || t->rf < 2)
-            return api_fail(KAO_ERR_UNSUPPORTED, "KAO-CX: needs 2 <= RF <= 4, at most 2047 brokers and no broker weights");
+        if (t->rf > kCxMaxRF || t->rf_cur > 8 || t->n_brokers + 1 > 2048 || t->rf < 2)
+            return api_fail(KAO_ERR_UNSUPPORTED, "KAO-CX: needs 2 <= RF <= 8 and at most 2047 brokers");
         q.B = t->n_brokers; q.R = t->n_racks; q.P = t->n_partitions; q.RF = t->rf; q.rfc = t->rf_cur;
         q.n = q.B + 1; q.np = (q.n + 63) & ~63;
         q.rep_lo = bd[0]; q.rep_hi = bd[1]; q.lead_lo = bd[2]; q.lead_hi = bd[3]; q.prack_lo = bd[6]; q.prack_hi = bd[7];
@@ -500,6 +505,12 @@ struct Cx {
         }
         CX_TRY(hipMemcpy(d_cur, t->current, (size_t)q.P * q.rfc * 2, hipMemcpyHostToDevice));
         CX_TRY(hipMemcpy(d_rack, t->rack_of, (size_t)q.B, hipMemcpyHostToDevice));
+        if (t->broker_w || t->broker_wl) {   // both arrays in one allocation: bw[B] | bwl[B]
+            CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_bw), (size_t)q.B * 8));
+            CX_TRY(hipMemset(d_bw, 0, (size_t)q.B * 8));
+            if (t->broker_w) { CX_TRY(hipMemcpy(d_bw, t->broker_w, (size_t)q.B * 4, hipMemcpyHostToDevice)); q.bw = d_bw; }
+            if (t->broker_wl) { CX_TRY(hipMemcpy(d_bw + q.B, t->broker_wl, (size_t)q.B * 4, hipMemcpyHostToDevice)); q.bwl = d_bw + q.B; }
+        }
         return KAO_OK;
     }
 
@@ -786,7 +797,7 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
             int nr[kCxMaxRF];
             cx.seed_row(p, cd.b, y, nr);
             const uint16_t *row = &cx.A[(size_t)p * q.RF];
-            int Rm[kCxMaxRF] = {0, 0, 0, 0}, Ad[kCxMaxRF] = {0, 0, 0, 0}, nrm = 0, nad = 0;
+            int Rm[kCxMaxRF] = {}, Ad[kCxMaxRF] = {}, nrm = 0, nad = 0;
             for (int k = 0; k < q.RF; ++k) { bool in = false; for (int j = 0; j < q.RF; ++j) in = in || nr[j] == row[k]; if (!in) Rm[nrm++] = row[k]; }
             for (int k = 0; k < q.RF; ++k) { bool in = false; for (int j = 0; j < q.RF; ++j) in = in || row[j] == nr[k]; if (!in) Ad[nad++] = nr[k]; }
             if (opt) {   // replica imbalance closed through L (and the leader imbalance, when the leader stayed, through S)
@@ -944,7 +955,7 @@ int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, doub
 }
 
 bool cycle_supported(const kao_topic *t) {
-    return t && t->rf >= 2 && t->rf <= kCxMaxRF && t->rf_cur <= 8 && t->n_brokers + 1 <= 2048 && !t->broker_w && !t->broker_wl;
+    return t && t->rf >= 2 && t->rf <= kCxMaxRF && t->rf_cur <= 8 && t->n_brokers + 1 <= 2048;
 }
 
 }  // namespace kao

@@ -35,11 +35,11 @@ NO_SLOT = 0xFFFFFFFF
 NO_EDGE = 0xFFFFFFFFFFFFFFFF
 LEVELS = 3          # squarings: paths of <= 2**LEVELS edges
 MAX_EVAL = 512      # realisations evaluated per round
-MAX_RF = 4
+MAX_RF = 8
 
 
 def supported(t) -> bool:
-    return t.rf <= MAX_RF and t.n_brokers + 1 <= 2048 and getattr(t, "broker_w", None) is None and getattr(t, "broker_wl", None) is None
+    return 2 <= t.rf <= MAX_RF and t.n_brokers + 1 <= 2048
 
 
 def n_cfg(rf: int, rf_cur: int) -> int:
@@ -47,7 +47,8 @@ def n_cfg(rf: int, rf_cur: int) -> int:
 
 
 def _wt_tables(t):
-    """WL[p, b], WF[p, b]: objective weight of broker b as leader / follower of partition p (README.md:145-146)."""
+    """WL[p, b], WF[p, b]: objective weight of broker b as leader / follower of partition p (README.md:145-146), plus the
+    topic's broker weights (kao_topic.broker_w on both variables of a broker, broker_wl on the `_l` one) when it carries them."""
     P, B = t.n_partitions, t.n_brokers
     WL = np.zeros((P, B), dtype=np.int64)
     WF = np.zeros((P, B), dtype=np.int64)
@@ -59,6 +60,11 @@ def _wt_tables(t):
         ps = np.nonzero(ok)[0]
         WL[ps, cur[ps, k]] = w[cr][0]
         WF[ps, cur[ps, k]] = w[cr][1]
+    if getattr(t, "broker_w", None) is not None:
+        WL += np.asarray(t.broker_w, dtype=np.int64)[None, :]
+        WF += np.asarray(t.broker_w, dtype=np.int64)[None, :]
+    if getattr(t, "broker_wl", None) is not None:
+        WL += np.asarray(t.broker_wl, dtype=np.int64)[None, :]
     return WL, WF
 
 

@@ -113,3 +113,54 @@ def test_config_numbering_round_trips(ko, kp):
         for tot, p, cfg, y in rd.seed_candidates()[:50]:
             row = rd.seed_row(p, cfg, y % 4096)
             assert len(set(row)) == t.rf and max(row) < t.n_brokers
+
+
+def _rf_and_weighted_cases(ko, kp, n_rf=10, n_w=10):
+    """RF 5..8 topics (random_case_rf) and wide-family topics carrying broker weights."""
+    rng = np.random.default_rng(77)
+    got_rf = got_w = 0
+    for s in range(200):
+        if got_rf < n_rf:
+            t = ko.random_case_rf(s)
+            if t.rf > 4:
+                a = _incumbent(kp, t, 2, 64)
+                if a is not None:
+                    got_rf += 1
+                    yield "rf", s, t, a
+        if got_w < n_w:
+            t = ko.random_case_wide(s)
+            if 2 <= t.rf <= 4:
+                t.broker_w = rng.integers(0, 6, t.n_brokers).astype(np.int32)
+                t.broker_wl = rng.integers(0, 4, t.n_brokers).astype(np.int32) if s % 3 else None
+                a = _incumbent(kp, t, 2, 64)
+                if a is not None:
+                    got_w += 1
+                    yield "w", s, t, a
+        if got_rf >= n_rf and got_w >= n_w:
+            break
+
+
+def test_high_rf_and_broker_weights(ko, kp):
+    """RF 5..8 and broker weights (round 3): priced candidates are worth exactly their price under the independent verifier,
+    rounds only improve, the result stays feasible."""
+    import kao_cycle as kc
+    seen = {"rf": 0, "w": 0}
+    priced = improved = 0
+    for kind, s, t, a in _rf_and_weighted_cases(ko, kp):
+        assert kc.supported(t)
+        rd = kc.Round(t, a)
+        base, v0 = kc.evaluate(t, rd.A)
+        assert v0 == 0
+        cyc = rd.cycle_candidates()
+        cands = [("c", c) for c in cyc[:10]] if cyc else [("s", c) for c in rd.seed_candidates()[:20]]
+        for k2, c in cands:
+            for i, (X, used) in enumerate(rd.realise_cycle(c) if k2 == "c" else rd.realise_seed(c)):
+                o, _ = kc.evaluate(t, X)   # the second realisation of a two-replica seed pairs the closures the dearer way round
+                assert (o - base == c[0]) if i == 0 else (o - base <= c[0]), (kind, s, c)
+                priced += 1
+        X, hist = kc.improve(t, a, 8)
+        o, v = kc.evaluate(t, X)
+        assert v == 0 and o >= base
+        improved += o > base
+        seen[kind] += 1
+    assert seen["rf"] >= 5 and seen["w"] >= 5 and priced > 0 and improved >= 2

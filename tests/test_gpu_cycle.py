@@ -101,8 +101,48 @@ def test_fixpoint_on_a_1000_partition_topic_is_feasible_and_better(kao, ko, kp):
     assert obj <= load_golden("drift_scale.json")["rows"][0]["milp_objective"]
 
 
+def test_high_rf_and_broker_weights_match_the_oracle(kao, ko, kp):
+    """Round 3: KAO-CX for RF 5..8 (up to 1,863 seed configurations per partition) and for topics with broker weights (they enter
+    every edge and seed price): matrices, midpoints, seed tables, whole rounds and fixpoints bit-exact against the oracle."""
+    import kao_cycle as kc
+    rng = np.random.default_rng(77)
+    n_rf = n_w = n_improved = 0
+    for s in range(200):
+        cases = []
+        t = ko.random_case_rf(s)
+        if t.rf > 4 and n_rf < 12:
+            cases.append(("rf", t))
+        t = ko.random_case_wide(s)
+        if 2 <= t.rf <= 4 and n_w < 12:
+            t.broker_w = rng.integers(0, 6, t.n_brokers).astype(np.int32)
+            t.broker_wl = rng.integers(0, 4, t.n_brokers).astype(np.int32) if s % 3 else None
+            cases.append(("w", t))
+        for kind, t in cases:
+            r = kp.port_search(t, 3, 0, 2, 64)
+            if r["best_obj"] < 0:
+                continue
+            a = r["best"]
+            pt = to_product_topic(t)
+            rd = _same_matrices(kao, kc, pt, t, a)
+            if not rd.cycle_candidates():
+                assert np.array_equal(kao.cycle_seeds(pt, a), rd.seed_table()), (kind, s)
+            Xo, hist = kc.improve(t, a, 64)
+            Xg, obj, st = kao.improve_cycles(pt, a, 64)
+            assert np.array_equal(np.asarray(Xo).reshape(-1), Xg.reshape(-1)), (kind, s)
+            o, v = ko.verify(t, Xg)
+            assert int(np.asarray(v).sum()) == 0 and o == obj == st["objective_after"]
+            n_improved += obj > st["objective_before"]
+            if kind == "rf":
+                n_rf += 1
+            else:
+                n_w += 1
+        if n_rf >= 12 and n_w >= 12:
+            break
+    assert n_rf >= 8 and n_w >= 8 and n_improved >= 3, (n_rf, n_w, n_improved)
+
+
 def test_rejects_what_it_does_not_support(kao, ko, kp):
-    t = next(x for x in (ko.random_case_rf(s) for s in range(200)) if x.rf > 4)
+    t = next(x for x in (ko.random_case_wide(s) for s in range(400)) if x.rf == 1)   # RF 1: no follower to move, no role to swap
     pt = to_product_topic(t)
     a = np.zeros((t.n_partitions, t.rf), dtype=np.uint16)
     with pytest.raises(kao.KaoError):
