@@ -28,7 +28,11 @@ DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
     // 29 / 49 / 43 / 48 / 60 us per iteration; the 200-topic config-4 batch: 1.0 ms and 9.5 us).  Interpolated on a log scale
     // of the largest topic's replica slots and rounded down a little: K-bound finishing early costs it some idle time, K-bound
     // finishing late stalls the search.
-    static const struct { int64_t slots; int iters; } tab[] = {{512, 128}, {3000, 56}, {6000, 80}, {15000, 88}, {30000, 120}, {90000, 136}};
+    // Re-fitted after k_bound_multi (gpurun_out r21, medians of launches without a KAO-CX call, K-bound beside K-search: 1,000 /
+    // 2,000 / 5,000 / 10,000 / 30,000 partitions: K-search launch + sync 1.29 / 3.02 / 3.64 / 5.30 / 9.19 ms, K-bound 30.5 / 41.6 /
+    // 27.6 / 33.3 / 55.6 us per iteration): the two smallest knots made the search wait 0.4 ms per launch, the larger ones left
+    // K-bound idle a quarter of the time.
+    static const struct { int64_t slots; int iters; } tab[] = {{512, 128}, {3000, 40}, {6000, 72}, {15000, 120}, {30000, 152}, {90000, 160}};
     const int nt = (int)(sizeof tab / sizeof tab[0]);
     if (slots <= tab[0].slots) d.bound_iters = tab[0].iters;
     else if (slots >= tab[nt - 1].slots) d.bound_iters = tab[nt - 1].iters;
@@ -394,7 +398,7 @@ struct SolveRun {
         const size_t slots = (size_t)topics[i].n_partitions * topics[i].rf;
         const int budget = start_budget[(size_t)i];
         const int64_t inc0 = gobjective(i);
-        int done = 0, near = 0;
+        int done = 0, near = 0, gains = 0;
         for (int q = 0; q < nr && done < budget; ++q) {
             const int r = start_order[(size_t)q];
             if (start_objs[(size_t)r] < 0) break;
@@ -409,11 +413,14 @@ struct SolveRun {
             int64_t reached = -1;
             if ((rc = cycle_start(i, start_objs[(size_t)r], cx_start_rounds, false, &reached))) return rc;
             near += reached >= inc0 - 1;
+            gains += reached > inc0;
             if (done == 4 && near == 0) break;
         }
         if (done > 0) {
-            start_near[(size_t)i] += near;
-            start_budget[(size_t)i] = near > 0 ? cx_starts : std::max(1, std::min(budget, cx_starts) / 4);
+            // a batch pays when one of its descents beat the incumbent it met (restarts re-seeded from the elite end NEAR it by
+            // construction); one that did not halves the next call's budget
+            start_near[(size_t)i] += gains;
+            start_budget[(size_t)i] = gains > 0 ? cx_starts : std::max(1, std::min(budget, cx_starts) / (near > 0 ? 2 : 4));
         }
         return KAO_OK;
     }
