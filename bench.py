@@ -145,7 +145,11 @@ def load_profile_constants(tag, iters, restarts_total):
 
 def load_big_constants(which):
     """Per-kernel counter figures of the north-star workloads (tools/profile_big.sh -> profiles/r03_big_<which>_constants.json)."""
-    path = os.path.join(ROOT, "profiles", "r03_big_%s_constants.json" % which)
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_big_%s_constants.json" % which)))   # the latest tag wins
+    if not paths:
+        return None
+    path = paths[-1]
     try:
         with open(path) as f:
             c = json.load(f)
@@ -419,7 +423,8 @@ def main():
             probes.append({"brokers": B_, "partitions": P_, "rf": 3, "status": str(r.status), "objective": int(r.objective),
                            "certificate": int(r.upper_bound), "exact_optimum_highs": known, "lp_relaxation_highs": lp,
                            "seconds": time.perf_counter() - t0, "seconds_to_best": float(r.seconds_to_best),
-                           "k_bound_iterations": int(tm["bound_iters"]), "k_bound_launches": int(tm["bound_launches"])})
+                           "k_bound_iterations": int(tm["bound_iters"]), "k_bound_launches": int(tm["bound_launches"]),
+                           "kao_cx_calls": int(tm["cx_calls"]), "kao_cx_further_starts": int(tm["cx_further_starts"]), "generations": int(tm["generations"])})
         out["exactness_probe"] = {"topics": probes,
                                   "note": "one kao_solve call per topic (K-search + K-bound + KAO-CX), 20 % drift, tools/drift_scale.py's "
                                           "instances; exact references from tests/golden/drift_scale.json (HiGHS: MILP optimum where branch-and-"
@@ -474,13 +479,11 @@ def main():
         peak = prof.get("valu_issue_peak_winst_per_s", 671.3e9)
         out["roofline_valu_issue"] = {"kernel": "k_search", "bound": "valu-issue", "insts_per_launch": valu,
                                       "achieved": valu / (avg_ms * 1e-3) / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
-                                      "frac": min(1.0, valu / (avg_ms * 1e-3) / peak),
-                                      "achieved_over_measured_peak": valu / (avg_ms * 1e-3) / peak,
+                                      "frac": valu / (avg_ms * 1e-3) / peak,
                                       "valu_insts_per_neighbour": valu / max(1.0, d_delta / max(1, launches)),
                                       "note": "SQ_INSTS_VALU per launch from " + prof["source"] + "; peak: " + prof.get("valu_issue_peak_note", "")
-                                              + ".  The peak is the best instruction class the microbench measured, not a datasheet figure: "
-                                              "this kernel's own mix can issue a percent faster (achieved_over_measured_peak > 1); frac is "
-                                              "capped at 1 -- the kernel is AT the issue roof, and only fewer instructions make it faster"}
+                                              + ".  The peak is the fastest instruction class the microbench measured at the clock it "
+                                              "measured, not a datasheet figure; frac is not capped.  Only fewer instructions make this kernel faster"}
         if "k_search_lds_insts_per_launch" in prof:
             lds_b = prof["k_search_lds_insts_per_launch"] * 64 * prof.get("lds_bytes_per_lane_avg", 4)
             out["roofline_lds"] = {"kernel": "k_search", "bound": "lds", "achieved": lds_b / (avg_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS,

@@ -3,7 +3,8 @@
 time limit, and always the value of the LP relaxation (an upper bound on the optimum; floor(LP) is what a certificate
 can reach at best).  "parity unpinned": OUR restatement of the README model (README.md:144-185), not lp_solve output.
 
-Run in the build container:  python tests/golden/make_golden_drift_scale.py B R P [milp_time_limit_s] [lp_method]
+Run in the build container:  python tests/golden/make_golden_drift_scale.py B R P [milp_time_limit_s] [lp_method] [drift_seed]
+(drift_seed other than 1: the row goes to "rows_other_seeds"; lp_method "none" skips the LP relaxation)
 (milp_time_limit_s 0 = the LP relaxation only; lp_method "highs-ipm" for the topics the simplex does not finish: 400 x 3000
 took 2,438 s with the interior point method on 8 cores).  Each run merges its row into drift_scale.json.
 """
@@ -32,15 +33,17 @@ def main():
     B, R, P = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     limit = float(sys.argv[4]) if len(sys.argv) > 4 else 3600.0
     lp_method = sys.argv[5] if len(sys.argv) > 5 else "highs"
-    ot = oracle_topic(B, R, P)
-    row = {"B": B, "R": R, "P": P, "rf": 3, "drift": 0.2, "seed": 1,
+    dseed = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    ot = oracle_topic(B, R, P, 0.2, dseed)
+    row = {"B": B, "R": R, "P": P, "rf": 3, "drift": 0.2, "seed": dseed,
            "upper_bound_closed_form": int(min(ko.upper_bound_forced(ot), ko.upper_bound_broker(ot)))}
-    t0 = time.perf_counter()
-    lp = ko.lp_bound(ot, lp_method)
-    row["lp_value"] = lp
-    row["lp_method"] = lp_method
-    row["lp_seconds"] = round(time.perf_counter() - t0, 1)
-    print("LP", lp, row["lp_seconds"], flush=True)
+    if lp_method != "none":
+        t0 = time.perf_counter()
+        lp = ko.lp_bound(ot, lp_method)
+        row["lp_value"] = lp
+        row["lp_method"] = lp_method
+        row["lp_seconds"] = round(time.perf_counter() - t0, 1)
+        print("LP", lp, row["lp_seconds"], flush=True)
     if limit > 0:
         ex = ko.solve_exact(ot, limit)
         row["milp_status"] = ex.status
@@ -54,8 +57,9 @@ def main():
     if os.path.exists(path):
         with open(path) as f:
             doc = json.load(f)
-    doc["rows"] = [r for r in doc["rows"] if (r["B"], r["R"], r["P"]) != (B, R, P)] + [row]
-    doc["rows"].sort(key=lambda r: r["P"])
+    key = "rows" if dseed == 1 else "rows_other_seeds"
+    doc[key] = [r for r in doc.get(key, []) if (r["B"], r["R"], r["P"], r.get("seed", 1)) != (B, R, P, dseed)] + [row]
+    doc[key].sort(key=lambda r: r["P"])
     with open(path, "w") as f:
         json.dump(doc, f, indent=1)
         f.write("\n")

@@ -722,6 +722,26 @@ def test_drift_scale_optima_are_reached_and_proven(kao, ko, B, R, P):
         assert viol[0] == 0 and obj == opt
 
 
+def test_further_kao_cx_starts(kao, ko, monkeypatch):
+    """Round 3: besides the elite, KAO-CX descends from the best snapshots of other restarts (which basin it ends in is decided by
+    where it starts).  The drifted 300 x 2000 topic (MILP optimum 14826; round 2's bench returned 14824) is proven with them,
+    they are counted in the solve's timing record, KAO_DET_CX_STARTS=0 switches them off, and on the second drift seed of the
+    same shape (MILP optimum 14801, drift_scale.json rows_other_seeds) certificate and incumbent stay within two units."""
+    t = _drift_topic(300, 6, 2000)
+    r = kao.solve([t], seed=3, time_limit_s=20.0)[0]
+    tm = kao.last_solve_timing()
+    assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", 14826, 14826)
+    assert 1 <= tm["cx_further_starts"] < tm["cx_calls"]
+    other = load_golden("drift_scale.json")["rows_other_seeds"][0]
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    t2 = sy.drift(sy.make_cluster(other["B"], other["R"], 1, other["P"], 3, [], []), 0.2, other["seed"])[0]
+    r2 = kao.solve([t2], seed=3, time_limit_s=4.0)[0]
+    assert r2.upper_bound == other["milp_objective"] and other["milp_objective"] - 2 <= r2.objective <= other["milp_objective"]
+    monkeypatch.setenv("KAO_DET_CX_STARTS", "0")
+    kao.solve([t], seed=3, time_limit_s=20.0, max_launches=200)
+    assert kao.last_solve_timing()["cx_further_starts"] == 0
+
+
 @pytest.mark.parametrize("B,R,P", [(400, 8, 3000), (250, 5, 4000)])
 def test_drift_scale_certificates_meet_the_lp_value(kao, ko, B, R, P):
     """The larger rows of drift_scale.json (only the LP relaxation finished on the CPU: 2,438 s / hours): within 6 s the device
