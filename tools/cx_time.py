@@ -1,4 +1,4 @@
-"""GPU: KAO-CX alone on a saved incumbent (gpurun_out/inc_<B>_<P>.npy from tools/dump_incumbent.py) -- test tooling."""
+"""GPU: KAO-CX alone on a saved incumbent (an .npy assignment, e.g. extracted from `r3_probe.py dump`) -- test tooling."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -9,7 +9,7 @@ tail -4 gpurun_out/r20_pytest_cycle.log
 tail -6 gpurun_out/r20_pytest_rest.log
 for st in 0 4; do
   for a in "500 10 10000 1" "1000 20 30000 1"; do
-    KAO_DET_CX_STARTS=$st timeout 60 python tools/one_trace.py $a 3.0 2>/dev/null | tail -1 | cut -c1-100
+    KAO_DET_CX_STARTS=$st timeout 60 python tools/r3_probe.py onetrace $a 3.0 2>/dev/null | tail -1 | cut -c1-100
   done
 done > gpurun_out/r20_big_starts.log 2>&1
 cat gpurun_out/r20_big_starts.log

@@ -1,6 +1,10 @@
 """GPU probe of round 3 (test tooling): the drifted families under the deterministic and the wall-clock schedule, a determinism
 check of kao_solve, per-launch timing traces for the schedule constants, and incumbents saved for the offline KAO-CX analysis.
-Usage: r3_probe.py <what>[,<what>...] [budget_s]   what: family | scale | determinism | trace | dump"""
+Usage: r3_probe.py <what>[,<what>...] [budget_s]   what: family | scale | seeds | goldens | determinism | trace | dump
+       r3_probe.py solve B R P drift_seed solver_seeds(csv) [budget_s]     one line per solver seed (KAO_* test hooks from the environment)
+       r3_probe.py onetrace B R P drift_seed [budget_s] [solver_seed]      one solve under KAO_SOLVE_TRACE=1 (per-launch lines on stderr)
+Environment: R3_SCHEDS (schedules, default "0,1"), R3_SEEDS (solver seeds of `family`), R3_HARD=1 (second half of the family).
+(Replaces the one-off probes of rounds 2-3: cx_ab, cx_long, cx_seeds, cx_sweep, drift_family, drift_probe, dump_incumbent, one_big, ...)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +12,9 @@ import kafka_assignment_optimizer_amd as kao
 from kafka_assignment_optimizer_amd import synthetic as sy
 
 what = set((sys.argv[1] if len(sys.argv) > 1 else "family").split(","))
-budget = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+if "onetrace" in what:
+    os.environ["KAO_SOLVE_TRACE"] = "1"
+budget = float(sys.argv[2]) if len(sys.argv) > 2 and not (what & {"solve", "onetrace"}) else 3.0
 SCHEDS = [int(v) for v in os.environ.get("R3_SCHEDS", "0,1").split(",")]
 kao.init(0)
 OUT = "gpurun_out"
@@ -110,3 +116,16 @@ if "dump" in what:
         print(line("dump", B, R, P, dseed, r, dt, tm), flush=True)
         np.savez_compressed(f"{OUT}/incumbents/inc_{B}_{R}_{P}_d{dseed}.npz", assignment=r.assignment, objective=r.objective, upper_bound=r.upper_bound,
                             current=np.asarray(t.current), rack_of=np.asarray(t.rack_of))
+
+if "solve" in what or "onetrace" in what:
+    B, R, P, d = (int(v) for v in sys.argv[2:6])
+    t = topic(B, R, P, d)
+    if "solve" in what:
+        seeds = [int(v) for v in sys.argv[6].split(",")]
+        lim = float(sys.argv[7]) if len(sys.argv) > 7 else 3.0
+    else:
+        lim = float(sys.argv[6]) if len(sys.argv) > 6 else 3.0
+        seeds = [int(sys.argv[7]) if len(sys.argv) > 7 else 3]
+    for sd in seeds:
+        r, dt, tm = run(t, seed=sd, time_limit_s=lim, schedule=SCHEDS[0])
+        print(line(f"solve seed {sd}", B, R, P, d, r, dt, tm), flush=True)
