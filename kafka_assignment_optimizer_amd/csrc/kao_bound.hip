@@ -526,6 +526,60 @@ __device__ __forceinline__ void bound_export_prices(const BoundPools &pl, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_bound_center: the exact line search along the COMMON SHIFT of every family of multipliers, once per launch (round 3)
+// ------------------------------------------------------------------------------------------------
+// Adding c to every multiplier of a family (replicas per broker, leaders per broker, replicas per rack) leaves every subproblem
+// solution alone -- each partition pays c per replica / per leader -- so L(m + c) = const + sum_i (m_i + c) * (m_i + c > 0 ? hi : lo)
+// - c * total is a convex piecewise-linear function of c alone, minimal where k = (total - n * lo) / (hi - lo) multipliers are
+// positive: the (k+1)-th largest becomes 0.  Tight bands (hi == lo) do not depend on the shift.  Subgradient steps are poor at
+// this one direction (its kinks sit at every multiplier's zero crossing): on slack bands -- P * RF not a multiple of the broker
+// count -- the record stalled 12..20 units above the LP value (drifted 270 x 2200, LP optimum 16459: 16474.6 after 20,000
+// iterations in the scalar replay; 16459 after 2,000 with the shift taken once per launch).  One workgroup per topic of the
+// launch, in front of whichever driver runs it; selection by rank counting in LDS (n <= 8192, K-bound's LDS limit on brokers,
+// else straight from global memory); same rule, same integers as oracle/kao_port.c::db_center (idempotent: a launch that is
+// repeated by another driver finds the pivot at 0).
+__device__ __forceinline__ void bound_center_family(int *g_m, int n, int lo, int hi, long long total, int *sm, int *slot, int tid, int nt) {
+    if (hi <= lo || n <= 1) return;                      // uniform over the workgroup
+    long long k = (total - (long long)n * lo) / (hi - lo);
+    if (k < 0) k = 0;
+    if (k >= n) return;
+    const bool in_lds = n <= 8192;
+    const int *src = g_m;
+    if (in_lds) {
+        for (int i = tid; i < n; i += nt) sm[i] = g_m[i];
+        src = sm;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        const int v = src[i];
+        int gt = 0, ge = 0;
+        for (int j = 0; j < n; ++j) { const int w = src[j]; gt += (int)(w > v); ge += (int)(w >= v); }
+        if (gt <= k && k < ge) *slot = v;                // the element of descending rank k (every writer holds the same value)
+    }
+    __syncthreads();
+    const long long pivot = *slot;
+    for (int i = tid; i < n; i += nt) {
+        long long v = (long long)src[i] - pivot;
+        v = v > kDualClamp ? kDualClamp : (v < -kDualClamp ? -kDualClamp : v);
+        g_m[i] = (int)v;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_bound_center(BoundPools pl) {
+    __shared__ int sm[8192];
+    __shared__ int slot;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int topic = pl.ids[blockIdx.x];
+    const TopicDev &T = pl.topics[topic];
+    const int B = T.B, R = T.R;
+    int *gp = pl.dual_pool + T.dual_off;                 // a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab]
+    const long long replicas = (long long)T.P * T.RF;
+    bound_center_family(gp, B, T.rep_lo, T.rep_hi, replicas, sm, &slot, tid, nt);
+    bound_center_family(gp + B, B, T.lead_lo, T.lead_hi, (long long)T.P, sm, &slot, tid, nt);
+    bound_center_family(gp + 4 * B, R, T.rack_lo, T.rack_hi, replicas, sm, &slot, tid, nt);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_bound: one workgroup per topic, persistent over the iterations of a launch
 // ------------------------------------------------------------------------------------------------
 template <int NE>
@@ -1065,6 +1119,10 @@ size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds, int ne, bo
 }
 
 static int g_attr_bound_dev[kAttrDevices][2] = {{0}}, g_attr_step_dev[kAttrDevices][2] = {{0}};
+
+void launch_bound_center(const BoundPools &pools, int n_topics, void *stream) {
+    if (pools.iters > 0) hipLaunchKernelGGL(k_bound_center, dim3(n_topics), dim3(256), 0, static_cast<hipStream_t>(stream), pools);
+}
 
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream) {
     const bool ne8 = pools.ne == 8;

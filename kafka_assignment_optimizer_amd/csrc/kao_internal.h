@@ -154,6 +154,7 @@ void launch_adopt_global(unsigned long long *keys, const unsigned long long *glo
 
 // K-bound: Lagrangian dual bound, one workgroup (`waves` wavefronts) per listed topic
 size_t bound_lds_bytes(int maxB, int maxP, int maxR, bool cur_in_lds, int ne = 4, bool hbw = false, bool dirs = false);
+void launch_bound_center(const BoundPools &pools, int n_topics, void *stream);   // the common shifts, in front of every K-bound launch
 void launch_bound(const BoundPools &pools, int n_blocks, int waves, void *stream);
 // the same iteration as a sequence of launches: begin, pools.iters x step, the probes, finish (n_blocks = all slices of the
 // n_topics listed topics)

@@ -983,6 +983,7 @@ static int bound_step_impl(kao_session *s, const int64_t *target, int32_t iters,
             };
             while (chunk < (1 << 20) && waiting_at(chunk) > 96) chunk += chunk;
         }
+        launch_bound_center(bp, n_class[cls], s->stream_bound);   // exact line search along the common shift of every family
         if (chunk > 0) {
             const size_t map0 = s->h_wide_map.size();
             for (int i = first; i < first + n_class[cls]; ++i) {

@@ -206,16 +206,16 @@ def test_port_dual_bound_is_valid_and_closes_the_gap(ko, kp):
         assert st.bound >= c["objective"], c["seed"]
         closed += st.bound == c["objective"]
         tight_closed_form += c["upper_bound"] == c["objective"]
-        if c["seed"] % 7 == 0:  # a suboptimal incumbent as target: still a valid bound; continuation == one long run
+        if c["seed"] % 7 == 0:  # a suboptimal incumbent as target: still a valid bound; a continued run stays one
             lo = kp.port_dual_bound(t, max(0, c["objective"] - 5), 60)
             assert lo.bound >= c["objective"]
-            one = kp.port_dual_bound(t, c["objective"], 80)
             two = kp.port_dual_bound(t, c["objective"], 30)
             if not two.flags & 3:  # (a rounding probe at the end of the short launch may already have closed the gap)
+                rec = two.best_L
                 two = kp.port_dual_bound(t, c["objective"], 50, two)
-                # same iterate; the extra rounding probes of the split run can only lower the record
-                assert (one.a.tolist(), one.l.tolist(), one.g.tolist()) == (two.a.tolist(), two.l.tolist(), two.g.tolist())
-                assert two.best_L <= one.best_L
+                # (round 3: every launch starts with the exact line search along the common shifts, so a split run is no longer
+                #  the same trajectory as one long launch; the record only ever improves and stays a valid bound)
+                assert two.best_L <= rec and two.bound >= c["objective"] and two.iters <= 80
     assert closed >= len(cases) - 2 and tight_closed_form < len(cases) // 2 + 5, (closed, tight_closed_form, len(cases))
     # an incumbent BELOW the optimum as target (what K-search hands over on hard instances): the level control keeps the
     # certificate close to the optimum anyway (a plain Polyak step stalls 6.5 units above it on average, 25 at worst)
