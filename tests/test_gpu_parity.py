@@ -722,6 +722,23 @@ def test_drift_scale_optima_are_reached_and_proven(kao, ko, B, R, P):
         assert viol[0] == 0 and obj == opt
 
 
+def test_slack_band_certificate_meets_the_lp_value(kao, ko):
+    """Round 3: a topic whose replicas do not divide evenly (6,600 on 270 brokers: bands 24..25 -- every drifted topic of the
+    family above has P * RF a multiple of B).  The dual function is piecewise linear along the common shift of a family of
+    multipliers and subgradient steps crawl there: the certificate stood at 16471 after 3 s against an LP value of 16459
+    (HiGHS interior point, tests/golden/drift_scale.json).  With the exact line search along the shifts at every launch
+    (k_bound_center) it meets the LP value; the incumbent stays a feasible assignment below it."""
+    row = [r for r in load_golden("drift_scale.json")["rows"] if (r["B"], r["R"], r["P"]) == (270, 6, 2200)][0]
+    t = _drift_topic(270, 6, 2200)
+    ot = ko.Topic(name=t.name, broker_ids=np.array(t.broker_ids), rack_of=np.array(t.rack_of), n_racks=t.n_racks,
+                  n_partitions=t.n_partitions, rf=t.rf, current=np.array(t.current), weights=t.weights)
+    r = kao.solve([t], seed=3, time_limit_s=4.0)[0]
+    lp = int(round(row["lp_value"]))
+    assert lp <= r.upper_bound <= lp + 1, (r.upper_bound, lp)
+    obj, viol = ko.verify(ot, r.assignment)
+    assert viol[0] == 0 and obj == r.objective <= lp and lp - r.objective <= 25
+
+
 def test_further_kao_cx_starts(kao, ko, monkeypatch):
     """Round 3: besides the elite, KAO-CX descends from the best snapshots of other restarts (which basin it ends in is decided by
     where it starts).  The drifted 300 x 2000 topic (MILP optimum 14826; round 2's bench returned 14824) is proven with them,
