@@ -208,6 +208,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="timed steps only (what tools/profile.sh wraps in rocprofv3)")
     ap.add_argument("--eval-bench", type=int, default=1, help="also time K-eval alone on a resident batch")
+    ap.add_argument("--in-library", action="store_true",
+                    help="ONE process, --gpus devices, through kao_solve_multi (what kao-cli --gpus N ships: topics dealt LPT, RCCL only "
+                         "when topics < devices) instead of one process per GPU; not the driver's launch mode")
+    ap.add_argument("--devices", type=str, default="", help="--in-library: device list (csv; repeats = logical shards on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -219,7 +223,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if world != args.gpus and not args.in_library:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -246,6 +250,39 @@ def main():
 
     # ---- workload: identical synthetic instance on every rank, topics sharded (LPT) -------------
     topics_all = synthetic.make_config(args.config, n_topics=args.topics or None)
+    if args.in_library:
+        # the in-library multi-GPU path: every timed step is one kao_solve_multi call on a FRESH drifted batch (upload, search to
+        # the proof on every device, read-back) -- whole solves, not single launches, so `value` counts the neighbours evaluated
+        # until every topic was proven per wall second of the whole call
+        if world != 1:
+            raise SystemExit("--in-library runs in ONE process (do not launch it through torch.distributed.run)")
+        devices = [int(v) for v in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        batches = [synthetic.drift(topics_all, 0.2, 1 + i) for i in range(args.warmup + args.steps)]
+        done = []
+        for i, b in enumerate(batches):
+            if i == args.warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            rs = kao.solve_multi(b, devices, seed=0xB0B + i, time_limit_s=20.0)
+            if i >= args.warmup:
+                tm = kao.last_solve_timing()
+                done.append((sum(r.status == "OPTIMAL_PROVEN" for r in rs), tm["delta_candidates"], tm["launches"], tm["elite_exchanges"]))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cand = sum(d[1] for d in done)
+        print(json.dumps({"metric": "candidate assignments/sec (+ time_to_optimal_s), 10k-partition reassign", "value": cand / dt,
+                          "unit": "candidates/s", "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "int32", "data": "synthetic",
+                          "config": {"workload": "BASELINE config %d, 20 %% drift, a fresh batch per step, each step one kao_solve_multi call to the "
+                                                 "proof (upload + search + certificate + read-back)" % args.config,
+                                     "parallelism": "in-library: one process, devices %s, topics dealt LPT" % devices},
+                          "time_to_optimal_s": dt / max(1, args.steps), "topics": len(topics_all),
+                          "topics_proven_per_step": [d[0] for d in done], "launches_per_step": [d[2] for d in done],
+                          "elite_exchanges": sum(d[3] for d in done),
+                          "note": "unmeasured on more than one physical GPU (the driver launches one process per GPU; repeated device ids are "
+                                  "logical shards of one GPU)"}))
+        return
     sizes = [t.n_brokers * t.n_partitions for t in topics_all]
     if len(topics_all) >= world:
         shards = multigpu.shard_topics(sizes, world)
