@@ -1182,8 +1182,8 @@ def test_solve_capped_matches_the_exact_joint_optimum_on_toys(kao, ko):
             np.add.at(load, r.assignment.reshape(-1).astype(int), 1)
         assert (load <= cap).all(), (c["seed"], load.tolist(), cap.tolist())
         assert total <= c["objective"] < c["objective_without_caps"]
-        if lb is not None:
-            assert lb >= c["objective"], (c["seed"], lb, c["objective"])
+        # round 3: K-bound prices weighted topics, so every round yields a Lagrangian bound -- and it meets the exact optimum
+        assert lb is not None and 0 <= lb - c["objective"] <= 1, (c["seed"], lb, c["objective"])
         assert total >= 0.98 * c["objective"], (c["seed"], total, c["objective"])
         equal += total == c["objective"]
-    assert equal >= len(cases) // 2, equal
+    assert equal >= (2 * len(cases)) // 3, equal   # GPU call 32: 4 of 6 (the other two 2 units = 1-1.7 % below), bound == optimum on all
