@@ -164,3 +164,24 @@ def test_high_rf_and_broker_weights(ko, kp):
         improved += o > base
         seen[kind] += 1
     assert seen["rf"] >= 5 and seen["w"] >= 5 and priced > 0 and improved >= 2
+
+
+@pytest.mark.slow
+def test_compound_edges_of_leader_balanced_pairs_improve_a_fixpoint(ko, kp):
+    """oracle/kao_cycle_pairs.py (prototype of the next KAO-CX layer; ~2.5 minutes of pure Python, -m slow): a KAO-CX fixpoint of
+    the drifted 300 x 2000 topic one unit below the MILP optimum 14826 (tests/golden/kao_cx_fixpoint_300x2000_d1.npy, made by
+    the scalar replay of K-search + oracle KAO-CX) is improved to the optimum by a cycle through two compound edges --
+    leader-balanced pairs of leader transfers whose net replica effect is one unit."""
+    import os
+    import kao_cycle as kc
+    import kao_cycle_pairs as kcp
+    t = kcp.drift_topic(300, 6, 2000, 1)
+    X = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kao_cx_fixpoint_300x2000_d1.npy")).reshape(2000, 3)
+    base, v0 = kc.evaluate(t, X)
+    assert (base, v0) == (14825, 0)
+    again, hist = kc.improve(t, X, max_rounds=4)
+    assert kc.evaluate(t, again)[0] == 14825           # a fixpoint of plain KAO-CX
+    Y, objs = kcp.improve_with_pairs(t, X, max_passes=2, verbose=False)
+    obj, viol = ko.verify(t, np.asarray(Y).astype(np.uint16))
+    assert int(np.asarray(viol).sum()) == 0 and obj == objs[-1] == 14826
+    assert [r for r in load_golden("drift_scale.json")["rows"] if (r["B"], r["P"]) == (300, 2000)][0]["milp_objective"] == 14826
