@@ -76,7 +76,8 @@ typedef struct kao_topic {
     /* Optional broker weights (NULL = none): extra objective coefficients on EVERY variable of a broker -- broker_w[b] on
        each replica placed on b (t?b<b>p? and t?b<b>p?_l), broker_wl[b] on each leader (t?b<b>p?_l) -- i.e. plain
        coefficients of the README's `max:` row (README.md:145-146).  0..1023 each.  kao_solve_capped uses them to price
-       cluster-wide per-broker caps; topics with broker weights get no K-bound certificate and are not canonicalised. */
+       cluster-wide per-broker caps; K-bound and KAO-CX take them into their priced values (round 3); weighted topics are
+       not canonicalised. */
     const int32_t *broker_w;    /* [n_brokers] or NULL */
     const int32_t *broker_wl;   /* [n_brokers] or NULL */
 } kao_topic;
@@ -310,6 +311,13 @@ int kao_cycle_matrices(const kao_topic *t, const uint16_t *assignment, int32_t l
 /* The seed table table[P * n_cfg * 2] = (total, completing broker) per partition and configuration (oracle/kao_cycle.py
  * gives the numbering); *n_cfg is always set; table may be NULL to query n_cfg only. */
 int kao_cycle_seeds(const kao_topic *t, const uint16_t *assignment, int32_t *table, int32_t *n_cfg);
+/* Prototype hook of the next KAO-CX layer (host only, no GPU; specification: oracle/kao_cycle_pairs.py): the
+ * COMPOUND EDGES of leader-balanced pairs of leader transfers around a feasible `assignment` -- partition p led by u hands the
+ * leadership to v, partition q led by v hands it to u (half-moves of objective gain >= gmin each; a generic entering follower
+ * may take the broker the partner releases), and a pair whose net replica effect is one unit x -> z is an edge of cost
+ * -(gain of both rows).  cost[B*B] (row x, column z; INT32_MAX = none); stats (may be NULL): [0] half-moves, [1] pairs joined,
+ * [2] edges, [3] pairs with no net replica effect and a positive gain.  Not used by kao_solve yet. */
+int kao_cycle_pair_edges(const kao_topic *t, const uint16_t *assignment, int32_t gmin, int32_t *cost, int64_t stats[4]);
 
 /* Diagnostic: runs the two collectives kao_solve_multi uses (ncclAllReduce(ncclUint64, ncclMin) and ncclBroadcast) on
  * small resident buffers of the listed distinct devices and checks the results.  0 = ok. */

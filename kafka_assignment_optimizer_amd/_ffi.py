@@ -89,6 +89,7 @@ SIGNATURES = {
     "kao_improve_cycles": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int32, _P(C.c_int64), _P(C.c_int32)]),
     "kao_cycle_matrices": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int32, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_uint32)]),
     "kao_cycle_seeds": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), _P(C.c_int32), _P(C.c_int32)]),
+    "kao_cycle_pair_edges": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int32, _P(C.c_int32), _P(C.c_int64)]),
     "kao_last_solve_timing": (C.c_int, [_P(C.c_double)]),
 }
 

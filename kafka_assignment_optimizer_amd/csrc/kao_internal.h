@@ -3,6 +3,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <unordered_map>
+
 #include "../../include/kao.h"
 
 namespace kao {
@@ -178,6 +180,9 @@ int cycle_run(CycleCtx *c, uint16_t *assign, int32_t max_rounds, double deadline
               int (*poll)(void *) = nullptr, void *poll_arg = nullptr);
 void cycle_close(CycleCtx *c);
 // helpers of the host side (kao_solve.cpp) for the device translation units
+// compound edges of leader-balanced pairs (kao_pairs.cpp; host only): the cheapest pair behind every edge x -> z
+struct PairEdge { int32_t cost; int32_t set; int32_t p, q; uint16_t rowp[8], rowq[8]; };
+int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::unordered_map<uint32_t, PairEdge> &edges, int64_t stats[4]);
 int api_fail(int code, const char *msg);
 int api_require_init();
 double api_now_s();

@@ -173,6 +173,19 @@ def cycle_seeds(topic: Topic, assign) -> np.ndarray:
     return tab
 
 
+def cycle_pair_edges(topic: Topic, assign, gmin: int = -2):
+    """Prototype hook (host only): compound edges of leader-balanced pairs of leader transfers (kao_cycle_pair_edges).
+    Returns (cost [B, B] int32 with INT32_MAX = none, dict(half_moves, pairs, edges, closed_improving))."""
+    ct = _CTopics([topic])
+    a = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1)
+    B = topic.n_brokers
+    cost = np.zeros((B, B), dtype=np.int32)
+    st = (C.c_int64 * 4)()
+    _check(_ffi.load().kao_cycle_pair_edges(ct.arr, a.ctypes.data_as(C.POINTER(C.c_uint16)), int(gmin), cost.ctypes.data_as(C.POINTER(C.c_int32)), st),
+           "kao_cycle_pair_edges")
+    return cost, dict(half_moves=int(st[0]), pairs=int(st[1]), edges=int(st[2]), closed_improving=int(st[3]))
+
+
 class EvalPlan:
     """Device-resident K-eval: tables uploaded once; candidates / outputs are device pointers
     (e.g. ``torch.Tensor.data_ptr()``)."""

@@ -141,6 +141,22 @@ def test_high_rf_and_broker_weights_match_the_oracle(kao, ko, kp):
     assert n_rf >= 8 and n_w >= 8 and n_improved >= 3, (n_rf, n_w, n_improved)
 
 
+def test_compound_edge_layer_lifts_the_committed_fixpoint(kao, ko, monkeypatch):
+    """The next KAO-CX layer (test hook KAO_CX_PAIRS=1; specification oracle/kao_cycle_pairs.py): leader-balanced pairs of leader
+    transfers as compound edges of the F graph.  The committed fixpoint of the drifted 300 x 2000 topic (14825, a fixpoint of the
+    plain layers, one unit below the MILP optimum) is lifted to 14826 -- as the oracle prototype does -- and stays feasible."""
+    import os
+    pt, t = _drifted(ko, 300, 6, 2000)
+    X = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kao_cx_fixpoint_300x2000_d1.npy")).reshape(2000, 3)
+    monkeypatch.delenv("KAO_CX_PAIRS", raising=False)
+    X0, obj0, st0 = kao.improve_cycles(pt, X, 0)
+    assert obj0 == st0["objective_before"] == 14825 and np.array_equal(X0.reshape(-1), X.reshape(-1))
+    monkeypatch.setenv("KAO_CX_PAIRS", "1")
+    X1, obj1, st1 = kao.improve_cycles(pt, X, 0)
+    o, v = ko.verify(t, X1)
+    assert int(np.asarray(v).sum()) == 0 and o == obj1 == 14826 and st1["improving_rounds"] >= 1
+
+
 def test_rejects_what_it_does_not_support(kao, ko, kp):
     t = next(x for x in (ko.random_case_wide(s) for s in range(400)) if x.rf == 1)   # RF 1: no follower to move, no role to swap
     pt = to_product_topic(t)

@@ -243,3 +243,46 @@ def test_host_code_under_asan_and_ubsan():
     import subprocess
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh")], cwd=ROOT, capture_output=True, timeout=1800)
     assert out.returncode == 0 and b"sanitised host code: ok" in out.stdout and b"sanitised kao-cli --emit-lp: ok" in out.stdout, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+def test_pair_edges_match_the_oracle_prototype():
+    """kao_cycle_pair_edges (host only: the enumeration of the next KAO-CX layer, kao_pairs.cpp) against oracle/kao_cycle_pairs.py:
+    the same compound-edge cost matrix and the same counts (half-moves, pairs, edges, closed pairs) on drifted topics (rigid and
+    slack bands, RF 2..4), wide-family topics with and without broker weights, and RF 5..8 topics."""
+    import numpy as np
+    import kao_oracle as ko
+    import kao_port as kp
+    import kao_cycle as kc
+    import kao_cycle_pairs as kcp
+    import kafka_assignment_optimizer_amd as kao
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    from conftest import to_product_topic
+    cases = []
+    for (B, R, P, rf) in [(60, 3, 200, 3), (45, 5, 130, 2), (50, 2, 120, 3), (48, 6, 160, 4)]:
+        pt = sy.drift(sy.make_cluster(B, R, 1, P, rf, [], []), 0.2, 1)[0]
+        cases.append(ko.Topic(name=pt.name, broker_ids=np.array(pt.broker_ids), rack_of=np.array(pt.rack_of), n_racks=pt.n_racks,
+                              n_partitions=pt.n_partitions, rf=pt.rf, current=np.array(pt.current), weights=pt.weights))
+    rng = np.random.default_rng(5)
+    for s in range(12):
+        t = ko.random_case_wide(s)
+        if 2 <= t.rf <= 4:
+            if s % 2:
+                t.broker_w = rng.integers(0, 4, t.n_brokers).astype(np.int32)
+            cases.append(t)
+    cases += [t for t in (ko.random_case_rf(s) for s in range(6)) if t.rf > 4]
+    n = n_edges = 0
+    for t in cases:
+        r = kp.port_search(t, 3, 0, 4, 128)
+        if r["best_obj"] < 0:
+            continue
+        X = r["best"]
+        edges, closed = kcp.compound_edges(kc.Round(t, X), verbose=False)
+        want = np.full((t.n_brokers, t.n_brokers), np.iinfo(np.int32).max, dtype=np.int32)
+        for (x, z), (c, _) in edges.items():
+            want[x, z] = c
+        got, st = kao.cycle_pair_edges(to_product_topic(t), X, -2)
+        assert np.array_equal(got, want), t.name
+        assert st["edges"] == len(edges) and st["closed_improving"] == len(closed)
+        n += 1
+        n_edges += len(edges)
+    assert n >= 8 and n_edges > 1000
