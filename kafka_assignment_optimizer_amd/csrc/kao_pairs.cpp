@@ -15,6 +15,8 @@
 // Pure host code, no GPU: the closure of the augmented graph, the unrolling and the exact evaluation (k_cx_square, k_cx_patch,
 // K-eval) are not wired in yet -- this entry point is the parity hook of the enumeration (tests/test_host.py against the oracle).
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
@@ -69,13 +71,18 @@ namespace kao {
 // edges[x * B + z] = the cheapest compound edge x -> z with the two rows behind it (ties: the lower (p, q)); stats as in kao.h
 int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::unordered_map<uint32_t, PairEdge> &edges, int64_t stats[4]) {
     edges.clear();
+    const double t_begin = now_s();
     if (t->rf < 2) return fail(KAO_ERR_UNSUPPORTED, "compound edges need a follower (RF >= 2)");
     int32_t bd[8];
     derive_bounds(t, bd);
     PairCtx cx{t, assignment, t->n_brokers, t->n_racks, t->n_partitions, t->rf, t->rf_cur, bd[6], bd[7]};
     const int B = cx.B, P = cx.P, RF = cx.RF;
+    std::vector<int32_t> best_cost((size_t)B * B, INT32_MAX);   // dense copy of the costs: most offers are dominated and stop here
     auto offer = [&](int x, int z, int cost, int p, const int *rowp, int q, const int *rowq) {
-        PairEdge &e = edges[(uint32_t)x * (uint32_t)B + (uint32_t)z];   // value-initialised: p = q = 0, cost = 0 ...
+        int32_t &bc = best_cost[(size_t)x * B + z];
+        if (cost > bc) return;
+        bc = cost;
+        PairEdge &e = edges[(uint32_t)x * (uint32_t)B + (uint32_t)z];   // value-initialised: set = 0
         if (e.set && (e.cost < cost || (e.cost == cost && (e.p < p || (e.p == p && e.q <= q))))) return;
         e.set = 1; e.cost = cost; e.p = p; e.q = q;
         for (int k = 0; k < RF; ++k) { e.rowp[k] = (uint16_t)rowp[k]; e.rowq[k] = (uint16_t)rowq[k]; }
@@ -151,6 +158,7 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
         }
     }
     int64_t n_pairs = 0, n_closed = 0;
+    const double t_halves = now_s();
     for (const auto &kv : buckets) {
         const int u = (int)(kv.first >> 32), v = (int)(uint32_t)kv.first;
         if (u > v) continue;
@@ -197,11 +205,26 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
                     const int x = outs[0];
                     const int *rowt = ap ? rp : rq, *other = ap ? rq : rp;
                     if (!cx.c7_ok(other)) continue;
+                    // which racks may the generic follower come from?  (the row without it: distinct brokers, no rack above its
+                    // band, at most one rack below it -- and then only that rack completes the row)
+                    int cnt[256] = {0}, ka = -1;
+                    bool fixed_ok = true;
+                    for (int k = 0; k < RF && fixed_ok; ++k) {
+                        if (rowt[k] == kAny) { ka = k; continue; }
+                        for (int j = 0; j < k; ++j) if (rowt[j] == rowt[k]) fixed_ok = false;
+                        ++cnt[t->rack_of[rowt[k]]];
+                    }
+                    int deficient = 0;
+                    for (int r = 0; r < cx.R && fixed_ok; ++r) { if (cnt[r] > cx.phi) fixed_ok = false; deficient += cnt[r] < cx.plo; }
+                    if (!fixed_ok || deficient > 1) continue;
+                    int cand[KAO_MAX_RF];
+                    for (int k = 0; k < RF; ++k) cand[k] = rowt[k];
                     for (int z = 0; z < B; ++z) {
                         if (z == x) continue;
-                        int cand[KAO_MAX_RF];
-                        for (int k = 0; k < RF; ++k) cand[k] = rowt[k] == kAny ? z : rowt[k];
-                        if (!cx.c7_ok(cand)) continue;
+                        const int rz = t->rack_of[z];
+                        if (cnt[rz] + 1 > cx.phi || (deficient == 1 && !(cnt[rz] < cx.plo && cnt[rz] + 1 >= cx.plo))) continue;
+                        if (contains(rowt, RF, z)) continue;
+                        cand[ka] = z;
                         if (ap) offer(x, z, -gain, hp.p, cand, hq.p, rq); else offer(x, z, -gain, hp.p, rp, hq.p, cand);
                     }
                     continue;
@@ -213,6 +236,9 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
         }
     }
     if (stats) { stats[0] = (int64_t)halves.size(); stats[1] = n_pairs; stats[2] = (int64_t)edges.size(); stats[3] = n_closed; }
+    if (std::getenv("KAO_CX_TRACE"))
+        std::fprintf(stderr, "[kao-cx] pairs: %zu half-moves in %.1f ms, %lld pairs -> %zu compound edges in %.1f ms\n", halves.size(),
+                     (t_halves - t_begin) * 1e3, (long long)n_pairs, edges.size(), (now_s() - t_halves) * 1e3);
     return KAO_OK;
 }
 }  // namespace kao
