@@ -13,7 +13,8 @@ slot), evaluated exactly by the independent verifier, and handed back to KAO-CX.
 
 Measured (scalar replay of K-search + oracle KAO-CX to a fixpoint, drifted 300 x 2000, MILP optimum 14826; six fixpoints below
 it): 14825 -> 14826 twice, 14824 -> 14825, 14823 -> 14824, two unchanged (14823, 14825); every gain is "a cycle through 2 compound
-edges".  ~70 s per pass in pure Python (324,000 half-moves, 580,000 pairs, 51,000 compound edges at B = 300): the enumeration is a
+edges"; seven more fixpoints (250 x 2000, optimum 14918: 14917, 14909, 14910; second drift seed of 300 x 2000, optimum 14801: 14797, 14796,
+14798, 14799): 14910 -> 14914 in two passes, 14797 -> 14798, five unchanged.  ~70 s per pass in pure Python (324,000 half-moves, 580,000 pairs, 51,000 compound edges at B = 300): the enumeration is a
 join on (leader, new leader) -- one wavefront per partition pair on the device.
 
 usage: python oracle/kao_cycle_pairs.py B R P drift_seed fixpoint.npy     (the instance of synthetic.drift(make_cluster(B, R, 1, P, 3), 0.2, seed))
