@@ -1025,7 +1025,7 @@ CycleCtx *cycle_open(const kao_topic *t, int *rc_out) {
 void cycle_close(CycleCtx *c) { delete c; }
 
 int cycle_run(CycleCtx *c, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8],
-              int (*poll)(void *), void *poll_arg) {
+              int (*poll)(void *), void *poll_arg, bool pairs) {
     int32_t local[8];
     if (!stats) stats = local;
     for (int i = 0; i < 8; ++i) stats[i] = 0;
@@ -1046,7 +1046,7 @@ int cycle_run(CycleCtx *c, uint16_t *assign, int32_t max_rounds, double deadline
         if (got < 0) return got;   // a KAO_ERR_* code (negative) from cx_round
         if (got == 0) {            // a fixpoint of the plain layers: the compound-edge layer (test hook KAO_CX_PAIRS=1, see cx_pairs_round)
             const char *pe = std::getenv("KAO_CX_PAIRS");   // read at every fixpoint: the tests switch it inside one process
-            if (!(pe && pe[0] == '1')) break;
+            if (!(pairs && pe && pe[0] == '1')) break;
             got = cx_pairs_round(cx, assign, cur, &next, stats);
             if (got < 0) return got;
             if (got == 0) break;

@@ -175,9 +175,11 @@ int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, doub
 // the same with the device buffers kept between calls (kao_solve); the topic must outlive the context
 struct CycleCtx;
 CycleCtx *cycle_open(const kao_topic *t, int *rc_out);
-// `poll` (may be null) is called between rounds: the caller keeps its other streams busy (kao_solve: K-bound)
+// `poll` (may be null) is called between rounds: the caller keeps its other streams busy (kao_solve: K-bound); `pairs`: at a fixpoint
+// of the plain layers the compound-edge layer may take a round (only with KAO_CX_PAIRS=1; kao_solve allows it for the elite's
+// descents, not for the further starting points: a pass costs 0.15 s of host time at 300 x 2000)
 int cycle_run(CycleCtx *c, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8],
-              int (*poll)(void *) = nullptr, void *poll_arg = nullptr);
+              int (*poll)(void *) = nullptr, void *poll_arg = nullptr, bool pairs = true);
 void cycle_close(CycleCtx *c);
 // helpers of the host side (kao_solve.cpp) for the device translation units
 // compound edges of leader-balanced pairs (kao_pairs.cpp; host only): the cheapest pair behind every edge x -> z

@@ -357,7 +357,7 @@ struct SolveRun {
         int32_t st[8];
         // the clock only ends a deterministic call at the solve's own deadline (the stop condition)
         const double slice_end = det ? deadline : std::min(deadline, now_s() + cx_slice);
-        int rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), rounds, slice_end, &obj, st, &SolveRun::poll_bound, this);
+        int rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), rounds, slice_end, &obj, st, &SolveRun::poll_bound, this, is_elite);
         ++cx_calls;
         if (rc) return rc;
         if (reached) *reached = obj;
