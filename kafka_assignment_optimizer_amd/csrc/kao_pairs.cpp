@@ -88,7 +88,7 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
         for (int k = 0; k < RF; ++k) { e.rowp[k] = (uint16_t)rowp[k]; e.rowq[k] = (uint16_t)rowq[k]; }
     };
     std::vector<Half> halves;
-    std::unordered_map<uint64_t, std::vector<int>> buckets;   // (leader, new leader) -> half-moves
+    std::vector<std::vector<std::pair<int, int>>> by_leader((size_t)B);   // leader u -> (new leader v, half-move), sorted by v below
     std::vector<int> ycur;
     for (int p = 0; p < P; ++p) {
         int row[KAO_MAX_RF];
@@ -113,7 +113,7 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
             std::memcpy(h.row, nrow, sizeof(int) * (size_t)RF);
             h.no = (o0 != INT_MIN) + (o1 != INT_MIN); h.outs[0] = o0; h.outs[1] = o1;
             h.ni = (i0 != INT_MIN) + (i1 != INT_MIN); h.ins[0] = i0; h.ins[1] = i1;
-            buckets[((uint64_t)(uint32_t)u << 32) | (uint32_t)v].push_back((int)halves.size());
+            by_leader[(size_t)u].emplace_back(v, (int)halves.size());
             halves.push_back(h);
         };
         int nrow[KAO_MAX_RF];
@@ -159,15 +159,23 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
     }
     int64_t n_pairs = 0, n_closed = 0;
     const double t_halves = now_s();
-    for (const auto &kv : buckets) {
-        const int u = (int)(kv.first >> 32), v = (int)(uint32_t)kv.first;
+    for (auto &lst : by_leader) std::stable_sort(lst.begin(), lst.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+    for (int u = 0; u < B; ++u) {
+      const auto &lu = by_leader[(size_t)u];
+      for (size_t g0 = 0; g0 < lu.size();) {
+        const int v = lu[g0].first;
+        size_t g1 = g0;
+        while (g1 < lu.size() && lu[g1].first == v) ++g1;
+        const size_t gb = g0, ge = g1;
+        g0 = g1;
         if (u > v) continue;
-        const auto rev = buckets.find(((uint64_t)(uint32_t)v << 32) | (uint32_t)u);
-        if (rev == buckets.end()) continue;
-        for (int hi : kv.second) {
-            const Half &hp = halves[(size_t)hi];
-            for (int hj : rev->second) {
-                const Half &hq = halves[(size_t)hj];
+        const auto &lv = by_leader[(size_t)v];   // the half-moves v -> u
+        const auto r0 = std::lower_bound(lv.begin(), lv.end(), std::make_pair(u, INT_MIN)), r1 = std::lower_bound(lv.begin(), lv.end(), std::make_pair(u + 1, INT_MIN));
+        if (r0 == r1) continue;
+        for (size_t gi = gb; gi < ge; ++gi) {
+            const Half &hp = halves[(size_t)lu[gi].second];
+            for (auto rj = r0; rj != r1; ++rj) {
+                const Half &hq = halves[(size_t)rj->second];
                 if (hp.p == hq.p) continue;
                 ++n_pairs;
                 int outs[4], ins[4], no = 0, ni = 0;
@@ -234,6 +242,7 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
                 if (no == 1 && ni == 1) offer(outs[0], ins[0], -gain, hp.p, rp, hq.p, rq);
             }
         }
+      }
     }
     if (stats) { stats[0] = (int64_t)halves.size(); stats[1] = n_pairs; stats[2] = (int64_t)edges.size(); stats[3] = n_closed; }
     if (std::getenv("KAO_CX_TRACE"))
