@@ -130,7 +130,7 @@ JNIEXPORT jintArray JNICALL Java_io_sqooba_kao_Kao_solve(JNIEnv *env, jclass cls
     kao_opts o;
     memset(&o, 0, sizeof o);
     o.seed = (uint64_t)seed; o.time_limit_s = timeLimit; o.stop_at_bound = 1;
-    const int rc = nDev > 1 ? kao_solve_multi(t, nTopics, (const int32_t *)dev, (int32_t)nDev, &o, r) : kao_solve(t, nTopics, &o, r);
+    const int rc = nDev >= 1 ? kao_solve_multi(t, nTopics, (const int32_t *)dev, (int32_t)nDev, &o, r) : kao_solve(t, nTopics, &o, r);
     if (rc) { throw_kao(env, rc); goto done; }
     status = (*env)->NewIntArray(env, nTopics);
     if (!status) goto done;   /* OutOfMemoryError pending */

@@ -294,13 +294,13 @@ int main(int argc, char **argv) {
             if (lp_only) return 0;
         }
         // ---- solve on the GPU ------------------------------------------------------------------
-        int rc = kao_init(device);
+        int rc = kao_init(gpu_list.empty() ? device : gpu_list[0]);
         if (rc) throw std::runtime_error(std::string("kao_init: ") + kao_strerror(rc) + " " + kao_last_error());
         kao_opts opts{};
         opts.seed = seed; opts.time_limit_s = time_limit; opts.stop_at_bound = 0; opts.iters_per_launch = 0;  // 0 = by topic size
         // stop early when every topic is proven optimal; otherwise search until the time limit
         opts.stop_at_bound = 1;
-        if (gpus > 1) {  // devices device .. device+gpus-1 of this node: topics sharded (or, with fewer topics than GPUs, replicated with an
+        if (gpus > 1 || !gpu_list.empty()) {  // (a list of ONE ordinal runs kao_solve on that device, not on --device)  // devices device .. device+gpus-1 of this node: topics sharded (or, with fewer topics than GPUs, replicated with an
                          // RCCL min-allreduce of the global best between them)
             std::vector<int32_t> devs = gpu_list;
             if (devs.empty()) for (int d = 0; d < gpus; ++d) devs.push_back(device + d);

@@ -116,7 +116,11 @@ typedef struct kao_opts {
                                  to stop.  1 = wall-clock adaptive (round-2 behaviour: K-bound merged whenever it has finished,
                                  launch lengths adapted to measured times, KAO-CX in time slices): a few percent more work per
                                  second, answers on large topics vary by a unit or two between runs */
-    int32_t reserved0;        /* must be 0 */
+    int32_t team;             /* topics whose assignment lives in global memory (beyond ~9,000 partitions): wavefronts that search
+                                 ONE restart together (k_team: every wavefront proposes a move per iteration against the same
+                                 state, proposals that share no partition / broker / rack with a lower-numbered wavefront's are
+                                 all applied).  0 = auto (8; 4 for RF 5..8), 1 = one wavefront per restart (the round-3 kernel),
+                                 2..8 = team size.  Deterministic either way; other values are KAO_ERR_INVALID.  (Was reserved0.) */
     const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
                                         objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;

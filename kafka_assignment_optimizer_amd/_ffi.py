@@ -24,7 +24,7 @@ class KaoOpts(C.Structure):
                 ("lam_min", C.c_int32), ("lam_max", C.c_int32), ("period_log2", C.c_int32),
                 ("stop_at_bound", C.c_int32), ("profile", C.c_int32), ("dual_iters", C.c_int32),
                 ("elite_period", C.c_int32), ("use_prices", C.c_int32), ("use_cycles", C.c_int32), ("islands", C.c_int32),
-                ("schedule", C.c_int32), ("reserved0", C.c_int32),
+                ("schedule", C.c_int32), ("team", C.c_int32),
                 ("target_objective", C.POINTER(C.c_int64))]
 
 

@@ -858,8 +858,9 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_step(BoundPools 
 // leaves, flag 16 is reported, and the host repeats the launch with k_bound_step and stops using this driver for the session.
 // Same arithmetic, same order of decisions as the other two drivers: the replay tests hold bit for bit.
 // Control block (BoundWide::ctl + topic * 16 + 8, 8 x int64): [0..2] value sums of the three buffers; as int32 from byte 24:
-// [0] barrier counter, [1] abort, [2..4] "a partition had no solution" per buffer.
+// [0] barrier counter | abort mark (bit 30), [1] unused, [2..4] "a partition had no solution" per buffer.
 constexpr long long kMultiPatience = 30000000;   // ticks of the 100 MHz constant clock: 0.3 s
+constexpr int kMultiAbortBit = 1 << 30;           // in the barrier counter (arrivals stay far below: iterations x slices)
 __device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // zeroes what a launch of k_bound_multi (or a sequence of k_bound_step) expects to be zero: one workgroup per topic
@@ -887,7 +888,7 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools
     BoundLds L = bound_carve<NE>(smem_b, pl.maxB, pl.maxR, pl.bwd_pool != nullptr, true);
     long long *acc = L.acc;
     long long *msum = wd.ctl + (size_t)topic * 16 + 8;
-    int *mi = reinterpret_cast<int *>(msum + 3);   // [0] barrier, [1] abort, [2..4] bad
+    int *mi = reinterpret_cast<int *>(msum + 3);   // [0] barrier | abort mark, [2..4] bad
     const int n_slices = (P + wd.chunk - 1) / wd.chunk;
     const int p_begin = slice * wd.chunk, p_end = min(P, p_begin + wd.chunk);
     const bool owner = slice == 0;
@@ -987,13 +988,18 @@ __global__ __launch_bounds__(NE == 4 ? 1024 : 512) void k_bound_multi(BoundPools
                 atomicAdd(&mi[0], 1);
                 const int goal = arrivals * n_slices;
                 const long long t0 = wall_clock64();
+                // Arrivals and the abort mark live in ONE word, and the mark is set by compare-and-swap on a value that is still
+                // short of the goal: either every workgroup of the topic sees the mark at this barrier (nobody commits, flag 16) or
+                // the mark is never set (with a separate flag a slice could pass the last barrier and commit while
+                // another timed out, and the host's repeat then ran that topic's iterations twice).
                 int go = 1;
-                while (ld_agent(&mi[0]) < goal) {
-                    if (ld_agent(&mi[1])) { go = 0; break; }
+                for (;;) {
+                    const int v = ld_agent(&mi[0]);
+                    if (v & kMultiAbortBit) { go = 0; break; }
+                    if (v >= goal) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if ((long long)wall_clock64() - t0 > kMultiPatience) { st_agent(&mi[1], 1); go = 0; break; }
+                    if ((long long)wall_clock64() - t0 > kMultiPatience && atomicCAS(&mi[0], v, v | kMultiAbortBit) == v) { go = 0; break; }
                 }
-                if (go && ld_agent(&mi[1])) go = 0;
                 __threadfence();
                 s_go = go;
             }

@@ -55,7 +55,7 @@ int64_t upper_bound(const kao_topic *t);
 int64_t upper_bound_w(const kao_topic *t);     // ... of a topic that may carry broker weights
 uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers, int n_partitions);
 int auto_period_log2(int P, int RF);
-bool dual_supported(const kao_topic *t);       // within K-bound's limits
+bool dual_supported(const kao_topic *t, bool session_bw = false);       // within K-bound's limits (session_bw: the session carves broker weights)
 
 }  // namespace kao
 
@@ -105,6 +105,7 @@ struct kao_session {
         int waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
         int nw = kRFP;       // replica words per partition of the group's topics: 4 or 8 (template instantiation)
         bool global_a = false;   // topic too large for LDS: assignment + current words stay in global memory
+        int team = 0;            // > 0 (global_a only): every restart is searched by a TEAM of that many wavefronts (k_team), one workgroup per restart
         bool cur_in_lds = true;  // K-eval stages the current assignment in LDS (false: reads it from global)
         bool eval_coop = false;  // K-eval: one candidate per workgroup, wavefronts cooperating (few large candidates)
         int smap_off = 0, smap_n = 0, emap_off = 0, emap_n = 0;

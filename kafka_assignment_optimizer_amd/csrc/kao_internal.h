@@ -12,6 +12,7 @@ namespace kao {
 constexpr int kRFP = 4;          // replica words per partition of the common case (RF <= 4); topics with 5..8 replicas use 8 (kMaxRF)
 constexpr int kMaxRF = 8;
 constexpr int kWaves = 4;        // wavefronts per K-eval workgroup; K-search uses 4, 2 or 1 (largest that fits LDS)
+constexpr int kTeamMax = 8;      // wavefronts of a K-search team (k_team: several wavefronts on ONE restart, topics in global memory)
 constexpr int kMaxRacks = 255;   // rack ids are u8, 0xFF marks a padding slot
 constexpr int kRackTab = 256;    // entries of the per-rack LDS tables (rack sizes, K, RT)
 constexpr uint32_t kNoneW = 0xFFFFFFFFu;  // empty slot in the LDS word layout (x | rack << 16)
@@ -143,9 +144,10 @@ struct BoundWide {
 
 // per-rack LDS tables of K-search (rack sizes, K, RT): entries for `maxR` racks plus one for the padding marker, rounded to 64
 constexpr int search_rack_tab(int maxR) { return ((maxR < 1 ? 1 : maxR) + 1 + 63) & ~63; }
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4, bool bw = false, int maxR = kRackTab - 1);
+// `team` > 0: the workgroup is a team of that many wavefronts on ONE restart (k_team; topics in global memory), `waves` is ignored
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4, bool bw = false, int maxR = kRackTab - 1, int team = 0);
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne = 4);
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream);
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream, int team = 0);
 void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream);
 // copy every topic's winning snapshot (restart id in its packed key) and violation row into contiguous
 // read-back buffers: one D2H instead of two per topic

@@ -182,6 +182,7 @@ template <int NW> __device__ __forceinline__ int part_rack_viol(const TopicRegs 
 // ------------------------------------------------------------------------------------------------
 // K-search
 // ------------------------------------------------------------------------------------------------
+constexpr int kTeamRec = 12;   // ints per proposal record of a team (search_body, kTeam)
 template <int NW> struct WaveLds {
     Part<NW> *A;  // [P] this restart's assignment, NW words per partition
     uint32_t *C;  // [Bx] replicas | leaders << 16 per broker
@@ -226,15 +227,18 @@ __device__ __forceinline__ uint32_t band_fields(const TopicRegs &T, uint32_t c) 
 }
 constexpr uint32_t kWNoCand = 0x8000u;
 // W[x] for every index of the topic (XR: rack of x, `inv` = padding)
-template <int NW> __device__ __forceinline__ void rebuild_band_state(const TopicRegs &T, const WaveLds<NW> &L, const uint8_t *XR, uint32_t inv, int lane) {
-    for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) L.W[x] = (uint16_t)(XR[x] == inv ? kWNoCand : band_fields(T, L.C[x]));
+// (`lane`, `stride`: a wavefront strides by 64; the wavefronts of a team stride together by the workgroup size)
+template <int NW> __device__ __forceinline__ void rebuild_band_state(const TopicRegs &T, const WaveLds<NW> &L, const uint8_t *XR, uint32_t inv, int lane, int stride = 64) {
+    for (int x = lane; x < ((T.Bx + 63) & ~63); x += stride) L.W[x] = (uint16_t)(XR[x] == inv ? kWNoCand : band_fields(T, L.C[x]));
 }
 
 // rebuild C and K from A (lanes stride partitions; LDS atomics)
-template <int NW> __device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds<NW> &L, int lane, int krt) {
-    for (int x = lane; x < ((T.Bx + 63) & ~63); x += 64) L.C[x] = 0;
-    for (int r = lane; r < krt; r += 64) L.K[r] = 0;
-    for (int p = lane; p < T.P; p += 64) {
+// (a team calls it between two workgroup barriers and zeroes, then counts, with a barrier in between: `stride` > 64)
+template <int NW> __device__ __forceinline__ void recount(const TopicRegs &T, const WaveLds<NW> &L, int lane, int stride, int krt) {
+    for (int x = lane; x < ((T.Bx + 63) & ~63); x += stride) L.C[x] = 0;
+    for (int r = lane; r < krt; r += stride) L.K[r] = 0;
+    if (stride > 64) __syncthreads();
+    for (int p = lane; p < T.P; p += stride) {
         const Part<NW> a = L.A[p];
 #pragma unroll
         for (int k = 0; k < NW; ++k)
@@ -243,10 +247,13 @@ template <int NW> __device__ __forceinline__ void recount(const TopicRegs &T, co
 }
 
 // total violation magnitude and objective of the state in LDS (C, K must be current)
-template <int NW> __device__ __forceinline__ void full_cost(const TopicRegs &T, const WaveLds<NW> &L, const Part<NW> *CUR, const int *RSZ,
-                                                            int lane, int &V, int &obj, const uint32_t *BW = nullptr) {
+// kTeam: the wavefronts of the workgroup split the passes and meet through `TS` (two ints per wavefront); every wavefront
+// returns the totals.  Integer sums: the split changes no result.
+template <int NW, bool kTeam = false> __device__ __forceinline__ void full_cost(const TopicRegs &T, const WaveLds<NW> &L, const Part<NW> *CUR, const int *RSZ,
+                                                            int lane, int stride, int &V, int &obj, const uint32_t *BW = nullptr,
+                                                            int *TS = nullptr, int wave = 0, int n_waves = 1) {
     int v = 0, o = 0;
-    for (int p = lane; p < T.P; p += 64) {
+    for (int p = lane; p < T.P; p += stride) {
         const Part<NW> a = L.A[p];
         const Part<NW> c = CUR[p];
 #pragma unroll
@@ -254,7 +261,7 @@ template <int NW> __device__ __forceinline__ void full_cost(const TopicRegs &T, 
             if (a.w[k] != kNoneW) o += role_w(T, c, a.w[k], k == 0 ? 0 : 1);
         v += part_rack_viol(T, a);
     }
-    for (int x = lane; x < T.Bx; x += 64) {
+    for (int x = lane; x < T.Bx; x += stride) {
         const int r = (int)mulhi((uint32_t)x, T.magic);
         if (x - r * T.m < RSZ[r]) {
             const uint32_t c = L.C[x];
@@ -262,13 +269,22 @@ template <int NW> __device__ __forceinline__ void full_cost(const TopicRegs &T, 
             if (BW) { const uint32_t bw = BW[x]; o += (int)(c & 0xFFFFu) * (int)(bw & 0xFFFFu) + (int)(c >> 16) * (int)(bw >> 16); }
         }
     }
-    for (int r = lane; r < T.R; r += 64) v += band(L.K[r], T.rack_lo, T.rack_hi);
+    for (int r = lane; r < T.R; r += stride) v += band(L.K[r], T.rack_lo, T.rack_hi);
     V = wave_sum(v);
     obj = wave_sum(o);
+    if (kTeam) {
+        __syncthreads();   // (TS may still be read from the previous call)
+        if ((lane & 63) == 0) { TS[2 * wave] = V; TS[2 * wave + 1] = obj; }
+        __syncthreads();
+        int tv = 0, to = 0;
+        if ((lane & 63) < n_waves) { tv = TS[2 * (lane & 63)]; to = TS[2 * (lane & 63) + 1]; }
+        V = wave_sum(tv);
+        obj = wave_sum(to);
+    }
 }
 
-template <int NW> __device__ __forceinline__ void snapshot(const TopicRegs &T, const WaveLds<NW> &L, const uint16_t *ext, uint16_t *best, int lane) {
-    for (int p = lane; p < T.P; p += 64) {
+template <int NW> __device__ __forceinline__ void snapshot(const TopicRegs &T, const WaveLds<NW> &L, const uint16_t *ext, uint16_t *best, int lane, int stride = 64) {
+    for (int p = lane; p < T.P; p += stride) {
         const Part<NW> a = L.A[p];
         uint16_t *o = best + p * T.RF;
 #pragma unroll
@@ -289,11 +305,20 @@ template <int NW> __device__ __forceinline__ void snapshot(const TopicRegs &T, c
 // kWide          : the launch group holds topics of 512 replica slots or more: their tournament scores several slots per lane
 //                   and is issued two slots per trip, the REPLACE scan two rounds per trip (instruction-level parallelism for
 //                   the one-wavefront-per-SIMD regime of large topics; costs registers the small-topic instantiation keeps)
-template <bool kGlobalA, bool kPriced, int NW, bool kWide>
-__global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// kTeam = true  : (topics in global memory only; kernel k_team) the wavefronts of the workgroup are a TEAM on ONE restart: they
+//                   share one set of counters and band states in LDS, every wavefront proposes its own move per iteration against
+//                   the same frozen state, and a proposal is applied iff it is acceptable and shares no partition, broker or
+//                   (when it changes rack totals) rack with an acceptable proposal of a lower-numbered wavefront -- disjoint
+//                   moves commute, so violation and objective deltas add up.  A 30,000-partition topic gets W moves per
+//                   latency-bound iteration instead of one (the depth large topics lack), deterministically (specification:
+//                   oracle/kao_port.c::ls_run with team > 1, replayed bit for bit).
+template <bool kGlobalA, bool kPriced, int NW, bool kWide, bool kTeam>
+__device__ __forceinline__ void search_body(unsigned char *smem, const SearchPools &pl, const SearchParams &prm) {
+    static_assert(!kTeam || kGlobalA, "teams run topics that live in global memory");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = kTeam ? __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6)) : 1;   // team size W
+    const int tid = kTeam ? (int)threadIdx.x : lane, nthr = kTeam ? (int)blockDim.x : 64;   // who strides the O(P) / O(B) passes
     const int2 bm = pl.block_map[blockIdx.x];
     const TopicDev *TD = pl.topics + bm.x;
 
@@ -322,7 +347,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     const int pr_bytes = kPriced ? (hbw ? 2 : 1) * c_bytes + krt * 4 : 0;
     int *PG = reinterpret_cast<int *>(smem + a_bytes + krt * 4 + bx64 + c_bytes);  // [krt] rack prices (kPriced only)
     uint32_t *BW = reinterpret_cast<uint32_t *>(smem + a_bytes + krt * 4 + bx64 + c_bytes + krt * 4);  // [bx64] broker weights (kPriced only)
-    unsigned char *wb = smem + a_bytes + krt * 4 + bx64 + pr_bytes + wave * (a_bytes + c_bytes + c_bytes / 2 + krt * 8);  // blockDim.x / 64 waves
+    // per wave: [A] [C] [W] [K] [RT]; a team shares ONE [C] [W] [K], then one [RT] per wavefront and the proposal records
+    unsigned char *wb = smem + a_bytes + krt * 4 + bx64 + pr_bytes + (kTeam ? 0 : wave * (a_bytes + c_bytes + c_bytes / 2 + krt * 8));
     const Part<NW> *cur_words = reinterpret_cast<const Part<NW> *>(pl.cur_pool + TD->cur_off);  // host-prepared words x | rack << 16 (0xFFFFFFFF = none); cur_off counts words
     const Part<NW> *CUR;
     if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const Part<NW> *>(smem);
@@ -330,7 +356,10 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
     L.W = reinterpret_cast<uint16_t *>(wb + a_bytes + c_bytes);
     L.K = reinterpret_cast<int *>(wb + a_bytes + c_bytes + c_bytes / 2);
-    L.RT = L.K + krt;
+    L.RT = L.K + krt + (kTeam ? wave * krt : 0);
+    // team: proposal records, two buffers (iteration parity) x W x kTeamRec ints, then W partial sums x 2
+    int *TR = L.K + krt + n_waves * krt;
+    int *TS = TR + 2 * 16 * kTeamRec;
 
     // ---- stage the rack sizes / rack-of-index table (and, when it fits, the current-assignment words) ----
     if (!kGlobalA) {
@@ -359,8 +388,8 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     }
     __syncthreads();
 
-    const int rho = bm.y + wave;
-    if (rho >= TD->n_restarts) return;  // no block-level barrier below this point
+    const int rho = bm.y + (kTeam ? 0 : wave);
+    if (rho >= TD->n_restarts) return;  // no block-level barrier below this point (a team is one restart: all or none)
     const int g = TD->restart_base + rho;
     // restart state in HBM: packed 4 x u16 per partition (LDS path, loaded / stored around the launch) or the
     // working words themselves, 16 B per partition, updated in place (global path)
@@ -375,7 +404,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     int best_obj, accepted;
     if (prm.init) {
         // surviving current replicas stay in their slots
-        for (int p = lane; p < T.P; p += 64) {
+        for (int p = tid; p < T.P; p += nthr) {
             Part<NW> c = CUR[p];
 #pragma unroll
             for (int k = 1; k < NW; ++k)
@@ -399,7 +428,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         if (reseed) {
             const uint16_t *ea = pl.elite_assign + TD->win_off;
             const uint16_t *io = pl.int_pool + TD->int_off;
-            for (int p = lane; p < T.P; p += 64) {
+            for (int p = tid; p < T.P; p += nthr) {
                 Part<NW> w;
 #pragma unroll
                 for (int k = 0; k < NW; ++k) w.w[k] = k < T.RF ? to_word(T, io[ea[p * T.RF + k]]) : kNoneW;
@@ -410,12 +439,15 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
         }
     }
     if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own stores visible to every lane's loads
-    recount(T, L, lane, krt);
+    if (kTeam) __syncthreads();
+    recount(T, L, tid, nthr, krt);
+    if (kTeam) __syncthreads();
 
     if (prm.init) {
         // ---- hole filling by best insertion, holes in (p,k) order.  Partitions are inspected 64 at a time (one per
         //      lane); only those with a hole are visited, in ascending order. ----
         // Two passes: leader holes of all partitions first, then follower holes (leaders are the scarcer resource).
+        if (!kTeam || wave == 0)   // (a team: its first wavefront fills the holes, in the same order as a single one)
         for (int pass = 0; pass < 2; ++pass)
         for (int pbase = 0; pbase < T.P; pbase += 64) {
             bool has_hole = false;
@@ -475,16 +507,18 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             }
         }
         if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (kTeam) __syncthreads();
     }
 
     int V, obj;
-    full_cost(T, L, CUR, RSZ, lane, V, obj, hbw ? BW : nullptr);
-    if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
-    rebuild_band_state(T, L, XR, inv, lane);          // W from the counters; kept current by every accepted move below
+    full_cost<NW, kTeam>(T, L, CUR, RSZ, tid, nthr, V, obj, hbw ? BW : nullptr, TS, wave, n_waves);
+    if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, tid, nthr); }
+    rebuild_band_state(T, L, XR, inv, tid, nthr);     // W from the counters; kept current by every accepted move below
     if (lane == 0) L.RT[krt - 1] = 0;                 // the spare entry padding lanes read
+    if (kTeam) __syncthreads();
 
     // ---- per-lane RNG stream of this launch (LCG mod 2^24, re-keyed every launch) ----
-    uint32_t rng = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + prm.launch * 0x85EBCA77u + (uint32_t)lane * 0xC2B2AE3Du));
+    uint32_t rng = fmix32(slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + prm.launch * 0x85EBCA77u + (uint32_t)tid * 0xC2B2AE3Du));   // (team: wavefront w's lanes are streams 64 w .. 64 w + 63)
 
     const int plog = TD->period_log2 + (rho & 3);
     const uint32_t pmask = (1u << plog) - 1u;
@@ -710,11 +744,19 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 // not in a), is the only broker with a non-zero objective weight here: the round it falls into is scored with weights
                 const int li = lane & (NW - 1);
                 const uint32_t ai = sel4(a, li), ci = sel4(c, li);
-                const bool mine = (lane < NW) & (ai != kNoneW);
+                // (a team shares W: nothing may be marked there -- the rounds that hold a broker of the partition take the slow
+                //  path below, like the rounds with a displaced current replica, and drop it by comparison)
+                const bool holds = (lane < NW) & (ai != kNoneW);
                 uint32_t w_keep = 0;
-                if (mine) {
+                if (!kTeam && holds) {
                     w_keep = L.W[ai & 0xFFFFu];
                     L.W[ai & 0xFFFFu] = (uint16_t)(w_keep | kWNoCand);
+                }
+                int ar[NW];
+                {
+                    const int ar_l = (kTeam && holds) ? (int)((ai & 0xFFFFu) >> 6) : -1;
+#pragma unroll
+                    for (int i2 = 0; i2 < NW; ++i2) ar[i2] = __builtin_amdgcn_readlane(ar_l, i2);
                 }
                 const bool hm_l = (lane < NW) & (ci != kNoneW) & !in4(a, ci);
                 const int mr_l = hm_l ? (int)((ci & 0xFFFFu) >> 6) : -1;
@@ -752,18 +794,21 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         const int dVx = wfld(w, kWIncR) + wfldw(w, kWIncL, lw) + rt;
                         dsc = __mul24(lam, dVx) + K0;
                     }
+                    uint32_t member = 0;
                     if (decltype(with_w)::value) {
                         const uint32_t x = (uint32_t)(base + lane);
-                        dsc -= __mul24(S, role_w2(c, x | ((uint32_t)XR[x] << 16), wl, wf));
+                        const uint32_t xw = x | ((uint32_t)XR[x] << 16);
+                        dsc -= __mul24(S, role_w2(c, xw, wl, wf));
+                        if (kTeam && in4(a, xw)) member = 0xFFFF0000u;   // row C5: already in the partition
                     }
                     dsc = min(max(dsc, 0), 2 * kDBias - 2);
                     // a "no candidate" index gets a cost field of 0xFFFF: above every real cost (<= 2 * kDBias - 2) and never accepted
-                    return ((uint32_t)dsc << 16) | (st & 0xFF00u) | (uint32_t)rd | ((uint32_t)w & 0xFFFF0000u);
+                    return ((uint32_t)dsc << 16) | (st & 0xFF00u) | (uint32_t)rd | ((uint32_t)w & 0xFFFF0000u) | member;
                 };
                 auto is_weighted = [&](int rdg) {   // wave-uniform
                     bool wgt = false;
 #pragma unroll
-                    for (int i2 = 0; i2 < NW; ++i2) wgt |= mr[i2] == rdg;
+                    for (int i2 = 0; i2 < NW; ++i2) wgt |= (mr[i2] == rdg) | (kTeam && ar[i2] == rdg);
                     return wgt;
                 };
                 for (int cb = 0; cb < T.Bx; cb += 16384) {
@@ -787,7 +832,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                         bestc = min(bestc, is_weighted((cb >> 6) + rd) ? scan_round(std::true_type{}, base, rd) : scan_round(std::false_type{}, base, rd));
                     if ((bestc >> 8) < (bestA >> 8)) { bestA = bestc; chunkA = cb; }   // strict: ties stay with the earlier round
                 }
-                if (mine) L.W[ai & 0xFFFFu] = (uint16_t)w_keep;
+                if (!kTeam && holds) L.W[ai & 0xFFFFu] = (uint16_t)w_keep;
                 key = bestA >> 8;   // (cost + bias) << 8 | tie: the key format of every other move type
                 kmin = wave_umin(key);
                 const unsigned long long bal = __ballot(key == kmin);
@@ -859,17 +904,46 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 win = __ffsll((long long)bal) - 1;  // ties inside the wave go to the lowest lane
             }
         }
-        if (kmin == kKeyNull) continue;
-        if ((int)(kmin >> 8) - kDBias > 0) continue;  // accept only non-worsening moves (cost under current lam)
+        if (!kTeam) {
+            if (kmin == kKeyNull) continue;
+            if ((int)(kmin >> 8) - kDBias > 0) continue;  // accept only non-worsening moves (cost under current lam)
+        }
+        bool mine = true;   // team: this wavefront's proposal is applied
+        int *rec = TR + ((i & 1u) * 16 + (uint32_t)wave) * kTeamRec;
+        if (kTeam) {
+            // ---- the team's proposals meet: record = {acceptable, p, q, broker out, broker in, rack out, rack in, dV, dObj, applied} ----
+            const bool ok = kmin != kKeyNull && (int)(kmin >> 8) - kDBias <= 0;
+            if (lane == win) {
+                const uint32_t ro_ = uw >> 16, rn_ = vw >> 16;
+                const bool racks = ok && type == 0 && ro_ != rn_;   // only a REPLACE across racks reads and changes rack totals
+                rec[0] = ok ? 1 : 0; rec[1] = p; rec[2] = type == 1 ? q : p;
+                rec[3] = (int)(uw & 0xFFFFu); rec[4] = (int)(vw & 0xFFFFu);
+                rec[5] = racks ? (int)ro_ : 0xFFFF; rec[6] = racks ? (int)rn_ : 0xFFFF;
+                rec[7] = dV; rec[8] = dObj;
+            }
+            __syncthreads();
+            bool clash = false;
+            if (lane < wave) {   // lane l looks at wavefront l's record: only lower-numbered wavefronts can block this one
+                const int *o = TR + ((i & 1u) * 16 + (uint32_t)lane) * kTeamRec;
+                if (o[0]) {
+                    const int mp = rec[1], mq = rec[2], mb0 = rec[3], mb1 = rec[4], mr0 = rec[5], mr1 = rec[6];
+                    clash = (o[1] == mp) | (o[1] == mq) | (o[2] == mp) | (o[2] == mq) | (o[3] == mb0) | (o[3] == mb1) | (o[4] == mb0) | (o[4] == mb1);
+                    if (o[5] != 0xFFFF && mr0 != 0xFFFF) clash |= (o[5] == mr0) | (o[5] == mr1) | (o[6] == mr0) | (o[6] == mr1);
+                }
+            }
+            mine = ok && __ballot(clash) == 0ull;
+        }
 
-        if (lane == win) {  // the winning lane applies its own proposal
+        if (lane == win && mine) {  // the winning lane applies its own proposal
             uint32_t *ap = reinterpret_cast<uint32_t *>(&L.A[p]);
             if (type == 0) {
                 const uint32_t d = (k == 0) ? 0x10001u : 1u;
                 L.C[uw & 0xFFFFu] -= d;
                 L.C[vw & 0xFFFFu] += d;
-                L.K[uw >> 16] -= 1;
-                L.K[vw >> 16] += 1;
+                if (!kTeam || (uw >> 16) != (vw >> 16)) {   // (team: moves inside one rack do not own its total -- two of them may run at once)
+                    L.K[uw >> 16] -= 1;
+                    L.K[vw >> 16] += 1;
+                }
                 ap[k] = vw;
             } else if (type == 1) {
                 uint32_t *bp = reinterpret_cast<uint32_t *>(&L.A[q]);
@@ -887,7 +961,7 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
                 ap[k] = uw;
             }
         }
-        {   // band state of the two brokers whose counters may have changed: lane 0 the old broker, lane 1 the new one
+        if (mine) {   // band state of the two brokers whose counters may have changed: lane 0 the old broker, lane 1 the new one
             const uint32_t xo = (uint32_t)__builtin_amdgcn_readlane((int)uw, win) & 0xFFFFu, xn = (uint32_t)__builtin_amdgcn_readlane((int)vw, win) & 0xFFFFu;
             if (lane < 2) {
                 const uint32_t xx = lane ? xn : xo;
@@ -895,25 +969,52 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
             }
         }
         if (kGlobalA) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the winner's stores before the next loads
-        V += __builtin_amdgcn_readlane(dV, win);
-        obj += __builtin_amdgcn_readlane(dObj, win);
-        accepted++;
-        if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, lane); }
+        if (kTeam) {
+            if (lane == 0) rec[9] = mine ? 1 : 0;
+            __syncthreads();
+            int dVs = 0, dOs = 0, na = 0;
+            if (lane < n_waves) {
+                const int *o = TR + ((i & 1u) * 16 + (uint32_t)lane) * kTeamRec;
+                if (o[9]) { dVs = o[7]; dOs = o[8]; na = 1; }
+            }
+            V += wave_sum(dVs);
+            obj += wave_sum(dOs);
+            accepted += wave_sum(na);
+        } else {
+            V += __builtin_amdgcn_readlane(dV, win);
+            obj += __builtin_amdgcn_readlane(dObj, win);
+            accepted++;
+        }
+        if (V == 0 && obj > best_obj) { best_obj = obj; snapshot(T, L, ext, best, tid, nthr); }
     }
 
     // ---- end of launch: verify the incremental bookkeeping against a from-scratch recount ----
-    recount(T, L, lane, krt);
+    if (kTeam) __syncthreads();
+    recount(T, L, tid, nthr, krt);
+    if (kTeam) __syncthreads();
     int V2, obj2;
-    full_cost(T, L, CUR, RSZ, lane, V2, obj2, hbw ? BW : nullptr);
-    if ((V2 != V || obj2 != obj) && lane == 0) atomicAdd(pl.drift, 1);
+    full_cost<NW, kTeam>(T, L, CUR, RSZ, tid, nthr, V2, obj2, hbw ? BW : nullptr, TS, wave, n_waves);
+    if ((V2 != V || obj2 != obj) && tid == 0) atomicAdd(pl.drift, 1);
     if (!kGlobalA)
         for (int p = lane; p < T.P; p += 64) store_packed<NW>(state_packed, p, L.A[p]);
-    if (lane == 0) {
+    if (tid == 0) {
         pl.restart_info[g * 4 + 0] = best_obj;
         pl.restart_info[g * 4 + 1] = V2;
         pl.restart_info[g * 4 + 2] = obj2;
         pl.restart_info[g * 4 + 3] = accepted;
     }
+}
+
+template <bool kGlobalA, bool kPriced, int NW, bool kWide>
+__global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    search_body<kGlobalA, kPriced, NW, kWide, false>(smem, pl, prm);
+}
+// a team of up to 8 wavefronts per restart (topics in global memory; see search_body)
+template <bool kPriced, int NW>
+__global__ __launch_bounds__(NW == 8 ? 256 : 512) void k_team(SearchPools pl, SearchParams prm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    search_body<true, kPriced, NW, true, true>(smem, pl, prm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1163,9 +1264,9 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
         XR[x] = (x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)kRackTab ? r : 0]) ? (uint8_t)r : (uint8_t)0xFF;
     }
     __syncthreads();
-    recount(T, L, lane, kRackTab);
+    recount(T, L, lane, 64, kRackTab);
     int V, obj;
-    full_cost(T, L, cur_words, RSZ, lane, V, obj);
+    full_cost(T, L, cur_words, RSZ, lane, 64, V, obj);
     if (V != 0) {  // only feasible assignments are polished
         if (lane == 0) { status[0] = 0; status[1] = 0; }
         return;
@@ -1242,9 +1343,12 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw, int maxR) {
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw, int maxR, int team) {
     const size_t a = global_a ? 0 : (size_t)maxP * 4 * (size_t)nw, bx64 = ((size_t)maxBx + 63) & ~(size_t)63, krt = (size_t)search_rack_tab(maxR);
-    return a + krt * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + krt * 4 : 0) + (size_t)waves * (a + bx64 * 6 + krt * 8);
+    const size_t shared = a + krt * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + krt * 4 : 0);
+    if (team > 0)   // one set of counters / band states / rack totals, one RT per wavefront, the proposal records, the partial sums
+        return shared + bx64 * 6 + krt * 4 + (size_t)team * krt * 4 + 2 * 16 * kTeamRec * 4 + 16 * 2 * 4;
+    return shared + (size_t)waves * (a + bx64 * 6 + krt * 8);
 }
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne) {
     const size_t r = ((size_t)maxB + 15) & ~(size_t)15, d = cur_in_lds ? ((size_t)maxP * 2 * (size_t)ne + 15) & ~(size_t)15 : 0;
@@ -1266,13 +1370,26 @@ static void launch_search_w(const SearchPools &pools, const SearchParams &prm, i
     else launch_search_t<kGlobalA, kPriced, NW, kGlobalA>(pools, prm, n_blocks, waves, lds, attr, st);
 }
 
-void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream) {
-    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw, prm.bw != 0, prm.maxR);
+template <bool kPriced, int NW>
+static void launch_team_t(const SearchPools &pools, const SearchParams &prm, int n_blocks, int team, size_t lds, int &attr, hipStream_t st) {
+    if ((int)lds > attr) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_team<kPriced, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_team<kPriced, NW>), dim3(n_blocks), dim3(64 * team), lds, st, pools, prm);
+}
+
+void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream, int team) {
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw, prm.bw != 0, prm.maxR, team);
     // largest dynamic-LDS size each of the instantiations has been enabled for, per device
-    static int attr[kAttrDevices][16] = {{0}};
+    static int attr[kAttrDevices][20] = {{0}};
     const bool wide = prm.wide != 0;
-    int &a = attr[attr_slot()][(wide || global_a ? 8 : 0) + (global_a ? 4 : 0) + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (team > 0) {   // one block per restart, `team` wavefronts each (topics in global memory only)
+        int &ta = attr[attr_slot()][16 + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
+        if (nw == 8) { if (priced) launch_team_t<true, 8>(pools, prm, n_blocks, team, lds, ta, st); else launch_team_t<false, 8>(pools, prm, n_blocks, team, lds, ta, st); }
+        else { if (priced) launch_team_t<true, 4>(pools, prm, n_blocks, team, lds, ta, st); else launch_team_t<false, 4>(pools, prm, n_blocks, team, lds, ta, st); }
+        if ((int)lds > ta) ta = (int)lds;
+        return;
+    }
+    int &a = attr[attr_slot()][(wide || global_a ? 8 : 0) + (global_a ? 4 : 0) + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
     if (nw == 8) {
         if (global_a && priced) launch_search_w<true, true, 8>(pools, prm, n_blocks, waves, lds, a, wide, st);
         else if (global_a) launch_search_w<true, false, 8>(pools, prm, n_blocks, waves, lds, a, wide, st);

@@ -423,10 +423,12 @@ int auto_period_log2(int P, int RF) {
 // K-bound limits: 19 (23 with broker weights) B of LDS per broker + 72 (136) B per rack; 32-bit headroom of the priced values:
 // a replica's objective coefficient (role weight + broker weights) x 65536 stays below 2^24, P*RF subgradients.
 // Round 3: RF 5..8 (k_bound<8>) and broker weights are inside the limits.
-bool dual_supported(const kao_topic *t) {
+// `session_bw`: another topic of the session carries broker weights -- the launch then carves the weight table for every
+// topic of the session (an unweighted 7,100..8,600-broker topic passed here and failed at the launch)
+bool dual_supported(const kao_topic *t, bool session_bw) {
     const bool wide = t->rf > kRFP || t->rf_cur > kRFP;
     const bool hbw = t->broker_w || t->broker_wl;
-    if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false, wide ? 8 : 4, hbw) > 160 * 1024) return false;
+    if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false, wide ? 8 : 4, hbw || session_bw) > 160 * 1024) return false;
     const int64_t n = (int64_t)t->n_partitions * t->rf;
     if (n > 131072) return false;
     int wmax = 0, bwmax = 0;

@@ -480,6 +480,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     const int g_num_cu = num_cu(s->device);
     kao_opts o{};
     if (opts_in) o = *opts_in;
+    if (o.team < 0 || o.team > kTeamMax || o.schedule < 0 || o.schedule > 1) { kao_session_destroy(s); return fail(KAO_ERR_INVALID, "kao_opts: team must be 0..8, schedule 0 or 1"); }
     if (o.iters_per_launch <= 0) o.iters_per_launch = 512;
     if (o.obj_scale <= 0) o.obj_scale = 4;
     if (o.lam_min <= 0) o.lam_min = 1;
@@ -570,7 +571,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         d.cnt_off = (uint32_t)dual_i32;             // counters of the sliced K-bound live in the same pool (zeroed with it)
         dual_i32 += 3 * (2 * (uint64_t)d.B + kRackTab) + 4 * (uint64_t)d.B + 2 * kRackTab;   // x 3 + shadow area: k_bound_multi
         wide_slices += (uint64_t)(d.P + 63) / 64;
-        s->dual_ok.push_back(dual_supported(&topics[t]) ? 1 : 0);
+        s->dual_ok.push_back(dual_supported(&topics[t], s->any_bw) ? 1 : 0);
         // algorithmic bytes: full evaluation = 2*RF*P + 2*rf_cur*P + B per candidate
         s->eval_bytes_per_launch += (uint64_t)o.restarts * (uint64_t)(2 * d.RF * d.P + 2 * d.rf_cur * d.P + d.B);
     }
@@ -618,9 +619,21 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         g.nw = s->pts[(size_t)mem[0]].d.nw;
         g.eval_coop = n_cand <= fill && g.maxP >= 1024;
         if (g.eval_coop) cpb = 1;
-        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR) > 160 * 1024) g.waves /= 2;
+        if (g.global_a) if (const char *e = std::getenv("KAO_GLOBAL_WAVES")) g.waves = std::min(kWaves, std::max(1, std::atoi(e)));  // measurement hook
+        // Topics that live in global memory: a restart is latency-bound (dependent loads of 16-byte assignment words), so ONE
+        // wavefront per restart leaves the restart shallow and the chip empty.  Round 4: a TEAM of wavefronts per restart (k_team):
+        // W proposals per iteration against the same state, the disjoint ones applied.  kao_opts.team = 1 (or KAO_TEAM=1)
+        // keeps one wavefront per restart (the round-3 path, still replayed by the tests), n picks the team size.
+        if (g.global_a) {
+            const int tmax = g.nw > kRFP ? kTeamMax / 2 : kTeamMax;   // (8 replica words per partition: 256 threads keep the kernel out of scratch)
+            int want = o.team == 0 ? tmax : o.team;
+            if (const char *e = std::getenv("KAO_TEAM")) want = std::max(0, std::atoi(e));
+            g.team = want <= 1 ? 0 : std::min(want, tmax);
+            if (g.team > 0) g.waves = 1;   // the block map holds one workgroup per restart
+        }
+        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR, g.team) > 160 * 1024) g.waves /= 2;
         g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true, g.nw) <= 160 * 1024;
-        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
+        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR, g.team) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
             kao_session_destroy(s);
             return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS (about 30,000 padded brokers)");
         }
@@ -768,7 +781,7 @@ int kao_session_step(kao_session *s) {
     for (const kao_session::LaunchGroup &g : s->groups) {
         sp.block_map = s->d_smap + g.smap_off;
         prm.maxP = g.maxP; prm.maxBx = g.maxBx; prm.maxR = g.maxR; prm.wide = g.wide ? 1 : 0;
-        launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, g.nw, s->stream);
+        launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, g.nw, s->stream, g.team);
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
@@ -872,7 +885,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
     for (const kao_session::LaunchGroup &g : s->groups)
-        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw, s->any_bw, g.maxR));
+        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw, s->any_bw, g.maxR, g.team));
     out->launch_groups = (int32_t)s->groups.size();
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));
@@ -1082,8 +1095,13 @@ int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int
         if (gave_up && !s->multi_off) {
             // k_bound_multi could not get a topic's workgroups resident together and committed nothing: the same launch again on
             // the kernels that do not wait for each other, and no further use of the persistent driver in this session
+            // Only the topics that carry flag 16 run again: the others of the launch have committed their iterations (the abort
+            // mark is all-or-nothing per topic, kao_bound.hip).  All drivers share one arithmetic, so the repeated topics end in
+            // the state the persistent driver would have reached: the answer does not depend on whether a launch gave up.
             s->multi_off = true;
-            const std::vector<int64_t> again = s->h_dual_target;
+            std::vector<int64_t> again = s->h_dual_target;
+            for (int t = 0; t < s->n_topics; ++t)
+                if (!(s->dual_ok[(size_t)t] && (info[t * 4 + 1] & 16))) again[(size_t)t] = -1;
             int rc = bound_step_impl(s, again.data(), s->bound_iters_last, true);
             if (rc) return rc;
             return kao_session_bounds(s, upper_bound, flags, iters);

@@ -530,6 +530,7 @@ extern "C" {
 int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results) {
     const double t0 = now_s();
     if (!results) return fail(KAO_ERR_INVALID, "null results");
+    if (opts && (opts->team < 0 || opts->team > kTeamMax || opts->schedule < 0 || opts->schedule > 1)) return fail(KAO_ERR_INVALID, "kao_opts: team must be 0..8, schedule 0 or 1");
     const kao_opts so = solve_defaults(topics, n_topics, opts);
     SolveRun run;
     int rc = run.begin(topics, n_topics, so, opts ? opts->target_objective : nullptr, t0, true, true);
@@ -766,6 +767,7 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
     const double t0 = now_s();
     if (!topics || n_topics < 1 || !results) return fail(KAO_ERR_INVALID, "no topics / null results");
     if (!devices || n_dev < 1 || n_dev > kMaxDevices) return fail(KAO_ERR_INVALID, "bad device list");
+    if (opts && (opts->team < 0 || opts->team > kTeamMax || opts->schedule < 0 || opts->schedule > 1)) return fail(KAO_ERR_INVALID, "kao_opts: team must be 0..8, schedule 0 or 1");
     int n_hw = 0;
     if (hipGetDeviceCount(&n_hw) != hipSuccess || n_hw <= 0) return fail(KAO_ERR_NO_DEVICE, "no HIP device");
     std::vector<int> devs(devices, devices + n_dev);
@@ -775,6 +777,15 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
         for (int j = 0; j < i; ++j) distinct &= devs[(size_t)j] != devs[(size_t)i];
     }
     if (!is_init()) { int rc0 = kao_init(devs[0]); if (rc0) return rc0; }
+    if (n_dev == 1) {   // a list of one device: exactly kao_solve (generations, islands), on THAT device (callers used to
+                        // fall back to the kao_init device and ignore the ordinal they had been given)
+        const int saved = t_device;
+        t_device = devs[0];
+        const int rc1 = kao_solve(topics, n_topics, opts, results);
+        t_device = saved;
+        if (cur_device() >= 0) (void)hipSetDevice(cur_device());
+        return rc1;
+    }
     const kao_opts so = solve_defaults(topics, n_topics, opts);
     const bool replicated = n_topics < n_dev;   // fewer topics than GPUs: every GPU searches every topic, elites are exchanged
     // ---- shards: LPT by brokers x partitions (independent sub-problems, README.md:146-184) ----
@@ -957,7 +968,13 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
         }
     }
     g_timing[2] = now_s() - t0;
-    for (Dev &x : D) if (x.run.s) { t_improve = std::max(t_improve, x.run.t_last_improve); cand += (double)x.run.s->delta_total; bl += (double)x.run.s->bound_launches; }
+    for (int i = 8; i < 16; ++i) g_timing[i] = 0;   // counters of this call, summed over the devices (they kept the previous kao_solve's values)
+    for (Dev &x : D) if (x.run.s) {
+        t_improve = std::max(t_improve, x.run.t_last_improve); cand += (double)x.run.s->delta_total; bl += (double)x.run.s->bound_launches;
+        for (int32_t v : x.run.s->dual_iters) g_timing[8] += (double)v;
+        g_timing[9] += x.run.cx_calls; g_timing[10] += x.run.cx_gains; g_timing[11] += (double)x.run.iters_done;
+        g_timing[12] += x.run.generations; g_timing[13] += x.run.cx_more;
+    }
     for (int d = 0; d < n_dev; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; kao_session_destroy(D[(size_t)d].run.s); D[(size_t)d].run.s = nullptr; }
     cleanup();
     g_timing[1] = t_improve; g_timing[3] = now_s() - t0; g_timing[4] = rounds; g_timing[5] = cand; g_timing[6] = bl; g_timing[7] = (double)exchanges;

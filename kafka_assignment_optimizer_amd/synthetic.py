@@ -138,17 +138,20 @@ def north_star_topic(which: str) -> Topic:
       cfg5one  = config 5 taken literally as ONE topic: 1000 brokers / 20 racks, 100,000 partitions RF 3, 50 brokers replaced
                  (each new broker joins the rack of a removed one: with uneven racks the single-topic rack band would be
                  infeasible, SURVEY.md H5), per-broker cap ceil(avg)+1;
-      drift30k = 1000 brokers / 20 racks x 30,000 partitions after a 20 % drift;   drift5k = 500 / 10 x 5,000 likewise."""
+      drift30k = 1000 brokers / 20 racks x 30,000 partitions after a 20 % drift;   drift5k = 500 / 10 x 5,000 and
+      drift100k = 1000 / 20 x 100,000 likewise."""
     if which == "drift30k":
         return drift(make_cluster(1000, 20, 1, 30000, 3, [], []), 0.2, 1)[0]
     if which == "drift5k":
         return drift(make_cluster(500, 10, 1, 5000, 3, [], []), 0.2, 1)[0]
+    if which == "drift100k":      # the north-star size after a 20 % drift: no balanced start the init could simply keep
+        return drift(make_cluster(1000, 20, 1, 100_000, 3, [], []), 0.2, 1)[0]
     if which == "cfg5one":
         rng = SplitMix64(CONFIG_SEED + 5)
         rm = rng.sample(list(range(1000)), 50)
         add = [(1000 + i, b % 20) for i, b in enumerate(rm)]
         return make_cluster(1000, 20, 1, 100_000, 3, rm, add, bounds_override={"rep_hi": 301})[0]
-    raise ValueError("north_star_topic: drift30k | drift5k | cfg5one")
+    raise ValueError("north_star_topic: drift30k | drift5k | drift100k | cfg5one")
 
 
 def north_star_steps(kao, which: str, launches: int = 6, iters: int = 512, restarts: int = 0) -> dict:

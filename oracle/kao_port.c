@@ -44,6 +44,7 @@ typedef struct {
     int32_t lam_max;
     int32_t period_log2;/* sawtooth period of restart rho = 2^(period_log2 + (rho & 3)) iterations: the first
                            half ramps lam_min -> lam_max, the second half holds lam_max */
+    int32_t team;       /* wavefronts searching the restart together (k_team, kao_opts.team): 0 / 1 = one (k_search) */
 } port_params;
 
 static inline int band(int c, int lo, int hi) {
@@ -427,26 +428,15 @@ static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
  *   LEADER-SWAP : every lane a random partition, all RF-1 swaps (ls_lane).
  * --------------------------------------------------------------------------------------------- */
 
-static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho, uint32_t launch, uint32_t iters) {
-    const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
-    const int P = t->P, RF = t->RF, S = pp->obj_scale;
-    uint32_t rng[LANES];
-    for (uint32_t l = 0; l < LANES; ++l)
-        rng[l] = fmix32(slo ^ fmix32(shi + rho * 0x9E3779B1u + launch * 0x85EBCA77u + l * 0xC2B2AE3Du));
-    ls_recount(t, s);
-    if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
-    const uint32_t plog = (uint32_t)pp->period_log2 + (rho & 3u);
-    const uint32_t pmask = (1u << plog) - 1u;
+/* The proposal of ONE wavefront for iteration `it` (move type `type`, penalty `lam`) against the state *s, which it does not
+ * change: draws from the wavefront's 64 lane streams `rng`, returns the wavefront's smallest key (KEY_NULL: no valid candidate)
+ * and the matching move in *out. */
+static uint32_t ls_propose(const ls_topic *t, ls_state *s, int type, uint32_t it, uint32_t *rng, int lam, int S, proposal *out) {
+    const int P = t->P, RF = t->RF;
     int T = (P * RF) / 4; if (T < 4) T = 4; if (T > LANES) T = LANES; /* tournament size */
     int GA = (P * RF) / 256; if (GA < 1) GA = 1; if (GA > 16) GA = 16; /* slots scored per lane in the tournament */
     const int XW = 8; /* an EXCHANGE scans at most XW rounds of 64 partitions (a random window when P is larger) */
-    for (uint32_t i = 0; i < iters; ++i) {
-        const uint32_t it = launch * iters + i;
-        const int type = move_type(it);
-        const uint32_t ph = it & pmask;
-        int lam = pp->lam_min + (int)((2u * ph * (uint32_t)(pp->lam_max - pp->lam_min + 1)) >> plog);
-        if (lam > pp->lam_max) lam = pp->lam_max;
-        if (s->best_obj < 0) lam = pp->lam_max; /* no oscillation before the restart has been feasible once */
+    {
         uint32_t best_key = KEY_NULL;
         proposal bp; memset(&bp, 0, sizeof bp);
         if (type == 2 || (type == 0 && ((it >> 3) & 1))) { /* per-lane proposals: LEADER SWAP, sampled REPLACE */
@@ -565,10 +555,66 @@ static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32
                     if (lane_key[l] < best_key) { best_key = lane_key[l]; bp.type = 1; bp.p = p; bp.k = k; bp.q = lane_q[l]; bp.j = lane_j[l]; bp.dV = lane_dV[l]; bp.dObj = lane_dO[l]; }
             }
         }
-        if (best_key == KEY_NULL) continue;
-        if ((int)(best_key >> 8) - DBIAS > 0) continue;
-        ls_apply(t, s, &bp);
-        s->n_accept++;
+        *out = bp;
+        return best_key;
+    }
+}
+
+/* One launch.  team = W wavefronts search the restart together (k_team; W = 1: k_search, one wavefront): lane l of wavefront
+ * w draws from stream 64 w + l; in every iteration each wavefront makes its own proposal (ls_propose) against the SAME state;
+ * a proposal is acceptable when its key is not null and its cost is <= 0; it is APPLIED iff it is acceptable and shares no
+ * resource with an acceptable proposal of a lower-numbered wavefront.  Resources of a move: the partitions it rewrites (p, and q
+ * of an EXCHANGE), the two brokers (leaving and entering the slot; an EXCHANGE: the two brokers that trade places), and -- only
+ * for a REPLACE whose brokers sit in different racks -- the two racks.  Moves with disjoint resources commute and their
+ * violation / objective deltas add up; the best-snapshot rule is evaluated once per iteration, after the applied moves. */
+static void ls_run(const ls_topic *t, ls_state *s, const port_params *pp, uint32_t rho, uint32_t launch, uint32_t iters) {
+    const uint32_t slo = (uint32_t)pp->seed, shi = (uint32_t)(pp->seed >> 32);
+    const int S = pp->obj_scale;
+    enum { TEAM_MAX = 16 };
+    const int W = pp->team < 1 ? 1 : (pp->team > TEAM_MAX ? TEAM_MAX : pp->team);
+    static __thread uint32_t rng[TEAM_MAX][LANES];
+    for (int w = 0; w < W; ++w)
+        for (uint32_t l = 0; l < LANES; ++l)
+            rng[w][l] = fmix32(slo ^ fmix32(shi + rho * 0x9E3779B1u + launch * 0x85EBCA77u + ((uint32_t)w * LANES + l) * 0xC2B2AE3Du));
+    ls_recount(t, s);
+    if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
+    const uint32_t plog = (uint32_t)pp->period_log2 + (rho & 3u);
+    const uint32_t pmask = (1u << plog) - 1u;
+    for (uint32_t i = 0; i < iters; ++i) {
+        const uint32_t it = launch * iters + i;
+        const int type = move_type(it);
+        const uint32_t ph = it & pmask;
+        int lam = pp->lam_min + (int)((2u * ph * (uint32_t)(pp->lam_max - pp->lam_min + 1)) >> plog);
+        if (lam > pp->lam_max) lam = pp->lam_max;
+        if (s->best_obj < 0) lam = pp->lam_max; /* no oscillation before the restart has been feasible once */
+        proposal bp[TEAM_MAX];
+        int ok[TEAM_MAX], rp[TEAM_MAX], rq[TEAM_MAX], rb0[TEAM_MAX], rb1[TEAM_MAX], rr0[TEAM_MAX], rr1[TEAM_MAX], applied[TEAM_MAX];
+        for (int w = 0; w < W; ++w) {
+            const uint32_t key = ls_propose(t, s, type, it, rng[w], lam, S, &bp[w]);
+            ok[w] = key != KEY_NULL && (int)(key >> 8) - DBIAS <= 0;
+            if (!ok[w]) continue;
+            const uint16_t *a = s->A + bp[w].p * RFP;
+            rp[w] = bp[w].p; rq[w] = bp[w].type == 1 ? bp[w].q : bp[w].p;
+            rr0[w] = rr1[w] = -1;
+            if (bp[w].type == 0) {
+                rb0[w] = a[bp[w].k]; rb1[w] = (int)bp[w].x;
+                const int ro = rack_of_x(t, (unsigned)rb0[w]), rn = rack_of_x(t, (unsigned)rb1[w]);
+                if (ro != rn) { rr0[w] = ro; rr1[w] = rn; }
+            } else if (bp[w].type == 1) { rb0[w] = a[bp[w].k]; rb1[w] = s->A[bp[w].q * RFP + bp[w].j]; }
+            else { rb0[w] = a[0]; rb1[w] = a[bp[w].k]; }
+        }
+        for (int w = 0; w < W; ++w) {
+            applied[w] = ok[w];
+            for (int v = 0; v < w && applied[w]; ++v) {
+                if (!ok[v]) continue;
+                int clash = rp[v] == rp[w] || rp[v] == rq[w] || rq[v] == rp[w] || rq[v] == rq[w] ||
+                            rb0[v] == rb0[w] || rb0[v] == rb1[w] || rb1[v] == rb0[w] || rb1[v] == rb1[w];
+                if (rr0[v] >= 0 && rr0[w] >= 0) clash = clash || rr0[v] == rr0[w] || rr0[v] == rr1[w] || rr1[v] == rr0[w] || rr1[v] == rr1[w];
+                if (clash) applied[w] = 0;
+            }
+        }
+        for (int w = 0; w < W; ++w)
+            if (applied[w]) { ls_apply(t, s, &bp[w]); s->n_accept++; }
         if (s->V == 0 && s->obj > s->best_obj) { s->best_obj = s->obj; ls_snapshot(t, s); }
     }
 }

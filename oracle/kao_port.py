@@ -25,7 +25,7 @@ class PortTopic(C.Structure):
 
 class PortParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("obj_scale", C.c_int32), ("lam_min", C.c_int32),
-                ("lam_max", C.c_int32), ("period_log2", C.c_int32)]
+                ("lam_max", C.c_int32), ("period_log2", C.c_int32), ("team", C.c_int32)]
 
 
 class PortExtra(C.Structure):
@@ -112,7 +112,7 @@ def port_eval(topic, assign) -> Tuple[int, np.ndarray]:
     return int(obj.value), np.array(list(viol), dtype=np.int64)
 
 
-DEFAULT_PARAMS = dict(obj_scale=4, lam_min=1, lam_max=40, period_log2=None)  # None = by topic size, see below
+DEFAULT_PARAMS = dict(obj_scale=4, lam_min=1, lam_max=40, period_log2=None, team=1)  # period None = by topic size, see below; team = wavefronts per restart (k_team)
 
 
 def auto_period_log2(topic) -> int:
@@ -132,7 +132,7 @@ def port_search(topic, seed: int, rho: int, launches: int, iters: int, **params)
         if pr["period_log2"] is None:
             pr["period_log2"] = auto_period_log2(topic)
         pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
-                        lam_max=pr["lam_max"], period_log2=pr["period_log2"])
+                        lam_max=pr["lam_max"], period_log2=pr["period_log2"], team=pr["team"])
         n = topic.n_partitions * topic.rf
         fin = np.zeros(n, dtype=np.uint16)
         best = np.zeros(n, dtype=np.uint16)
@@ -161,7 +161,7 @@ class PortRun:
         if pr["period_log2"] is None:
             pr["period_log2"] = auto_period_log2(topic)
         self._pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
-                              lam_max=pr["lam_max"], period_log2=pr["period_log2"])
+                              lam_max=pr["lam_max"], period_log2=pr["period_log2"], team=pr["team"])
         self._run = lib().kao_port_run_create(self._h, C.byref(self._pp), rho)
 
     def launch(self, launch: int, iters: int, prices=None, elite=None, gen: int = 0):
@@ -225,7 +225,7 @@ def port_valid_fraction(topic, seed: int, rho: int, launches: int, iters: int, *
         if pr["period_log2"] is None:
             pr["period_log2"] = auto_period_log2(topic)
         pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
-                        lam_max=pr["lam_max"], period_log2=pr["period_log2"])
+                        lam_max=pr["lam_max"], period_log2=pr["period_log2"], team=pr["team"])
         return float(lib().kao_port_valid_fraction(h, C.byref(pp), rho, launches, iters))
     finally:
         lib().kao_port_ls_destroy(h)
@@ -244,7 +244,7 @@ def port_search_throughput(topic, seed: int, n_restarts: int, launches: int, ite
         if pr["period_log2"] is None:
             pr["period_log2"] = auto_period_log2(topic)
         pp = PortParams(seed=seed & 0xFFFFFFFFFFFFFFFF, obj_scale=pr["obj_scale"], lam_min=pr["lam_min"],
-                        lam_max=pr["lam_max"], period_log2=pr["period_log2"])
+                        lam_max=pr["lam_max"], period_log2=pr["period_log2"], team=pr["team"])
         return int(lib().kao_port_search_many(h, C.byref(pp), 0, n_restarts, launches, iters, threads))
     finally:
         lib().kao_port_ls_destroy(h)

@@ -420,7 +420,7 @@ def test_topic_in_global_memory_replay_and_eval(kao, ko, kp):
     pt = synthetic.make_cluster(1000, 20, 1, 6000, 3, [7, 77, 777], [(1000, 7), (1001, 17), (1002, 17)])[0]
     ot = _oracle_topic(ko, pt)
     seed = 2718
-    with kao.Session([pt], seed=seed, restarts=4, iters_per_launch=40) as s:
+    with kao.Session([pt], seed=seed, restarts=4, iters_per_launch=40, team=1) as s:   # team=1: one wavefront per restart (k_search<true>)
         st = s.stats()
         assert st["lds_bytes_search"] < 40 * 1024  # only broker / rack tables in LDS
         s.step(2)
@@ -440,6 +440,52 @@ def test_topic_in_global_memory_replay_and_eval(kao, ko, kp):
     for i in range(len(cands)):
         o, v = kp.port_eval(ob, cands[i])
         assert (int(obj[i]), viol[i].tolist()) == (o, v.tolist())
+
+
+@pytest.mark.parametrize("team", [8, 3])
+def test_team_search_replay_bit_exact(kao, ko, kp, team):
+    """Topics in global memory, round 4: a TEAM of wavefronts searches one restart (k_team) -- every wavefront proposes a move
+    per iteration against the same state, proposals sharing no partition / broker / rack with a lower-numbered wavefront's
+    are all applied.  Same deterministic spec as oracle/kao_port.c::ls_run(team): final state, best snapshot, V, objective and
+    the number of applied moves bit for bit; with host-set prices and an elite launch too."""
+    from kafka_assignment_optimizer_amd import synthetic
+    pt = synthetic.drift(synthetic.make_cluster(1000, 20, 1, 6000, 3, [7, 77, 777], [(1000, 7), (1001, 17), (1002, 17)]), 0.2, 3)[0]
+    ot = _oracle_topic(ko, pt)
+    seed, iters = 1618 + team, 48
+    tseed = seed ^ 0x9E3779B97F4A7C15
+    with kao.Session([pt], seed=seed, restarts=3, iters_per_launch=iters, team=team) as s:
+        assert s.stats()["lds_bytes_search"] < 40 * 1024
+        s.step(3)
+        assert s.stats()["drift"] == 0
+        n_acc = []
+        for rho in range(3):
+            dev = s.restart_state(0, rho)
+            ref = kp.port_search(ot, tseed, rho, 3, iters, team=team)
+            assert np.array_equal(dev["final"], ref["final"]) and np.array_equal(dev["best"], ref["best"]), (team, rho)
+            assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
+            obj, viol = kp.port_eval(ot, dev["final"])
+            assert (obj, int(viol[0])) == (dev["obj"], dev["V"])
+            n_acc.append(dev["n_accept"])
+        single = kp.port_search(ot, tseed, 0, 3, iters)["n_accept"]
+        assert n_acc[0] > 2 * single            # the team applies several moves per iteration
+    # priced instantiation + an elite launch
+    rng = np.random.default_rng(team)
+    prices = ((rng.integers(-8, 9, ot.n_brokers) * 16384).astype(np.int32), (rng.integers(-4, 5, ot.n_brokers) * 16384 + rng.integers(-4800, 4800, ot.n_brokers)).astype(np.int32),
+              (rng.integers(-2, 3, ot.n_racks) * 16384).astype(np.int32))
+    with kao.Session([pt], seed=seed, restarts=3, iters_per_launch=iters, elite_period=2, team=team) as s:
+        s.set_prices(0, *prices)
+        s.step(2)
+        r = s.best()[0]
+        s.step(1)
+        assert s.stats()["drift"] == 0
+        for rho in range(3):
+            run = kp.PortRun(ot, tseed, rho, team=team)
+            run.launch(0, iters, prices=prices); run.launch(1, iters, prices=prices)
+            run.launch(2, iters, prices=prices, elite=(r.assignment, r.objective, r.best_restart) if r.status != "NO_FEASIBLE" else None)
+            ref = run.read()
+            dev = s.restart_state(0, rho)
+            assert np.array_equal(dev["final"], ref["final"]) and np.array_equal(dev["best"], ref["best"]), (team, rho)
+            assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
 
 
 def test_config5_as_one_topic(kao, ko, kp):
