@@ -119,8 +119,9 @@ typedef struct kao_opts {
     int32_t team;             /* topics whose assignment lives in global memory (beyond ~9,000 partitions): wavefronts that search
                                  ONE restart together (k_team: every wavefront proposes a move per iteration against the same
                                  state, proposals that share no partition / broker / rack with a lower-numbered wavefront's are
-                                 all applied).  0 = auto (8; 4 for RF 5..8), 1 = one wavefront per restart (the round-3 kernel),
-                                 2..8 = team size.  Deterministic either way; other values are KAO_ERR_INVALID.  (Was reserved0.) */
+                                 all applied).  0 / 1 = one wavefront per restart (k_search; the default: measured on 1000 x 30000 and
+                                 1000 x 100000, teams bought neither iterations per second nor a better incumbent in 3 s),
+                                 2..8 = team size (4 at most for RF 5..8).  Deterministic either way; other values are KAO_ERR_INVALID.  (Was reserved0.) */
     const int64_t *target_objective; /* kao_solve: optional [n_topics]; a topic counts as done once its feasible
                                         objective reaches this value (e.g. a known optimum); NULL = use the bound */
 } kao_opts;
@@ -305,11 +306,12 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
  * kao_solve calls it for unproven topics whose search has stalled.  stats (may be NULL): [0] rounds, [1] improving rounds,
  * [2] realisations evaluated, [3] improving ones, [4] candidates priced > 0, [5] compounds merged, [6] objective before,
  * [7] objective after.  Broker weights (kao_topic.broker_w / broker_wl) enter every edge and seed price.
- * KAO_ERR_UNSUPPORTED: rf < 2, rf > 8 or more than 2047 brokers. */
+ * KAO_ERR_UNSUPPORTED: rf < 2, rf > 8 or brokers + racks > 2047. */
 int kao_improve_cycles(const kao_topic *t, uint16_t *assignment, int32_t max_rounds, int64_t *objective, int32_t stats[8]);
 /* Parity hooks of KAO-CX (tests): the cost matrix of `layer` (0 = follower moves, 1 = role swaps) after `level` squarings
- * (0..3) as dist[(B+1)*(B+1)] (node B = slack; 1 << 17 = none), the midpoints mid[(B+1)*(B+1)] (level >= 1; may be NULL) and
- * the slot p*rf+k behind every level-0 edge slot[(B+1)*(B+1)] (0xFFFFFFFF = none; may be NULL). */
+ * (0..3) as dist[n*n], n = B + R + 1 (nodes B .. B+R-1 = the racks' slack nodes, B+R = the global slack node; 1 << 17 = none),
+ * the midpoints mid[n*n] (level >= 1; may be NULL) and the slot p*rf+k behind every level-0 edge slot[n*n] (0xFFFFFFFF = none;
+ * may be NULL). */
 int kao_cycle_matrices(const kao_topic *t, const uint16_t *assignment, int32_t layer, int32_t level, int32_t *dist, int32_t *mid,
                        uint32_t *slot);
 /* The seed table table[P * n_cfg * 2] = (total, completing broker) per partition and configuration (oracle/kao_cycle.py

@@ -40,11 +40,14 @@ constexpr int kCxLevels = 3;
 constexpr int kCxLayers = 3;      // 0 F (follower moves), 1 S (role swaps), 2 L (leader replacements)
 constexpr int kCxMaxEval = 512;
 constexpr int kCxMaxRF = 8;
+// The per-partition kernels (k_cx_edges, k_cx_edges_l, k_cx_seeds) keep a row and the rows derived from it in small per-thread
+// arrays indexed at run time; instantiated for MR = 4 (RF <= 4: the arrays stay in registers) and MR = 8 (RF 5..8) like K-search
+// and K-bound -- with one size for all, RF 3 paid for RF 8 (k_cx_edges_l 540 -> 2,109 us at 1000 x 30000).
 constexpr unsigned long long kNoEdge = ~0ull;
 
 struct CxParams {
-    int32_t B, R, P, RF, rfc, n, np;   // n = B + 1 (slack node Z = B), np = row stride of the matrices (multiple of 64)
-    int32_t rep_lo, rep_hi, lead_lo, lead_hi, prack_lo, prack_hi;
+    int32_t B, R, P, RF, rfc, n, np;   // n = B + R + 1 (slack nodes: Z_r = B + r per rack, Z = B + R), np = row stride of the matrices (multiple of 64)
+    int32_t rep_lo, rep_hi, lead_lo, lead_hi, prack_lo, prack_hi, rack_lo, rack_hi;
     int32_t w00, w01, w10, w11;
     int32_t ncfg;
     const int32_t *bw, *bwl;   // broker weights by dense index (kao_topic.broker_w / broker_wl), or null
@@ -61,14 +64,14 @@ __device__ __forceinline__ int cx_wt(const CxParams &q, const uint16_t *cur, int
     return w;
 }
 
-// C7 (README.md:178-180) of a row made of `base[0..nb)` plus one more broker of rack ry: nb <= kCxMaxRF - 1
-struct CxBase {
-    int rk[kCxMaxRF];
+// C7 (README.md:178-180) of a row made of `base[0..nb)` plus one more broker of rack ry: nb <= MR - 1
+template <int MR> struct CxBase {
+    int rk[MR];
     int nb, ndef;
     bool over;
 };
-__device__ __forceinline__ CxBase cx_base(const CxParams &q, const uint8_t *rack, const int *base, int nb) {
-    CxBase o;
+template <int MR> __device__ __forceinline__ CxBase<MR> cx_base(const CxParams &q, const uint8_t *rack, const int *base, int nb) {
+    CxBase<MR> o;
     o.nb = nb; o.over = false;
     int distinct = 0, deficient_present = 0;
     for (int i = 0; i < nb; ++i) o.rk[i] = rack[base[i]];
@@ -81,7 +84,7 @@ __device__ __forceinline__ CxBase cx_base(const CxParams &q, const uint8_t *rack
     o.ndef = q.prack_lo > 0 ? (q.R - distinct) + deficient_present : 0;
     return o;
 }
-__device__ __forceinline__ bool cx_completes(const CxParams &q, const CxBase &b, int ry) {
+template <int MR> __device__ __forceinline__ bool cx_completes(const CxParams &q, const CxBase<MR> &b, int ry) {
     int cnt = 0;
     for (int i = 0; i < b.nb; ++i) cnt += b.rk[i] == ry;
     if (cnt + 1 > q.prack_hi) return false;
@@ -90,18 +93,19 @@ __device__ __forceinline__ bool cx_completes(const CxParams &q, const CxBase &b,
 }
 
 // ---- edges: one wavefront per partition -------------------------------------------------------------------------------
+template <int MR>
 __global__ __launch_bounds__(256) void k_cx_edges(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack,
                                                   unsigned long long *EF, unsigned long long *ES) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= q.P) return;
-    int row[kCxMaxRF];
+    int row[MR];
     for (int k = 0; k < q.RF; ++k) row[k] = A[(size_t)p * q.RF + k];
     const uint16_t *c = cur + (size_t)p * q.rfc;
     for (int k = 1; k < q.RF; ++k) {
         const int u = row[k];
-        int base[kCxMaxRF]; int nb = 0;
+        int base[MR]; int nb = 0;
         for (int j = 0; j < q.RF; ++j) if (j != k) base[nb++] = row[j];
-        const CxBase cb = cx_base(q, rack, base, nb);
+        const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
         if (!cb.over && cb.ndef <= 1) {
             const int wu = cx_wt(q, c, u, 1);
             for (int v = lane; v < q.B; v += 64) {
@@ -141,12 +145,13 @@ __device__ __forceinline__ long long cx_wave_min(long long v) {
     }
     return v;
 }
+template <int MR>
 __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack, const int32_t *DF,
                                                     int plain_only, unsigned long long *EL) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= q.P) return;
     const int RF = q.RF;
-    int row[kCxMaxRF];
+    int row[MR];
     for (int k = 0; k < RF; ++k) row[k] = A[(size_t)p * RF + k];
     const uint16_t *c = cur + (size_t)p * q.rfc;
     const int u = row[0];
@@ -155,9 +160,9 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
     const int wlu = cx_wt(q, c, u, 0), wfu = cx_wt(q, c, u, 1);
     auto inrow = [&](int x) { bool in = false; for (int j = 0; j < RF; ++j) in = in || row[j] == x; return in; };
     {   // 0 plain
-        int base[kCxMaxRF]; int nb = 0;
+        int base[MR]; int nb = 0;
         for (int j = 1; j < RF; ++j) base[nb++] = row[j];
-        const CxBase cb = cx_base(q, rack, base, nb);
+        const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
         if (!cb.over && cb.ndef <= 1)
             for (int v = lane; v < q.B; v += 64) {
                 if (inrow(v) || !cx_completes(q, cb, rack[v])) continue;
@@ -168,13 +173,13 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
     if (plain_only) return;
     for (int k = 1; k < RF; ++k) {
         const int b = row[k];
-        int others[kCxMaxRF], no = 0, osum = 0;
+        int others[MR], no = 0, osum = 0;
         for (int j = 1; j < RF; ++j) if (j != k) { others[no++] = row[j]; osum += cx_wt(q, c, row[j], 1); }
         {   // 1 demote: row' = (v; u, others)
-            int base[kCxMaxRF]; int nb = 0;
+            int base[MR]; int nb = 0;
             base[nb++] = u;
             for (int j = 0; j < no; ++j) base[nb++] = others[j];
-            const CxBase cb = cx_base(q, rack, base, nb);
+            const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
             const int comp = DF[(size_t)u * q.np + b];
             if (!cb.over && cb.ndef <= 1 && comp < kCxInf)
                 for (int v = lane; v < q.B; v += 64) {
@@ -184,10 +189,10 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
                 }
         }
         {   // 2 promote: v = row[k]; row' = (v; y, others), best y
-            int base[kCxMaxRF]; int nb = 0;
+            int base[MR]; int nb = 0;
             base[nb++] = b;
             for (int j = 0; j < no; ++j) base[nb++] = others[j];
-            const CxBase cb = cx_base(q, rack, base, nb);
+            const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
             long long best = LLONG_MAX;
             if (!cb.over && cb.ndef <= 1) {
                 const int wlv = cx_wt(q, c, b, 0);
@@ -212,10 +217,10 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
         for (int ii = 0; ii < q.rfc; ++ii) {
             const int i = c[ii];
             if (i >= q.B || inrow(i)) continue;
-            int base[kCxMaxRF]; int nb = 0;
+            int base[MR]; int nb = 0;
             for (int j = 0; j < no; ++j) base[nb++] = others[j];
             base[nb++] = i;
-            const CxBase cb = cx_base(q, rack, base, nb);
+            const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
             if (cb.over || cb.ndef > 1) continue;
             const int compi = DF[(size_t)i * q.np + b];
             if (compi < kCxInf) {   // (a) y = i, any v
@@ -245,18 +250,32 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
     }
 }
 
-// ---- edge keys -> level-0 cost matrix (with the slack node) -----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cx_dist0(CxParams q, const unsigned long long *E, const int32_t *cnt, int lo, int hi, int shift, int32_t *D) {
+// ---- edge keys -> level-0 cost matrix (with the slack nodes) ----------------------------------------------------------
+// mode 0 (F, replica units): u -> Z_rack(u) when u may take one more replica inside its band, Z_rack(v) -> v when v may give one
+//        up -- a path through Z_r alone leaves every rack total as it is --, Z_r -> Z when rack r may take one more (C6,
+//        README.md:173-175), Z -> Z_r when it may give one up.  Round 4; with ONE slack node a path through it moved a unit
+//        between racks, K-eval rejected the realisation and the rack-conserving path of equal cost was never found: on topics
+//        whose bands have slack (P*RF not a multiple of B) the fixpoints ended 8-21 units below the optimum.
+// mode 1 (S, leader units: they know no racks): u -> Z, Z -> v by the leader band.   mode 2 (L): no slack edges.
+// cnt: c[B] | l[B] | K[R] (replicas, leaders per broker; replicas per rack)
+__global__ __launch_bounds__(256) void k_cx_dist0(CxParams q, const unsigned long long *E, const int32_t *cnt, const uint8_t *rack, int mode, int shift, int32_t *D) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= q.np) return;
     int d = kCxInf;
+    const int B = q.B, Z = q.B + q.R;
     if (i < q.n && j < q.n) {
         if (i == j) d = 0;
-        else if (j == q.B) d = cnt[i] < hi ? 0 : kCxInf;
-        else if (i == q.B) d = cnt[j] > lo ? 0 : kCxInf;
-        else {
+        else if (i < B && j < B) {
             const unsigned long long key = E[(size_t)i * q.np + j];
             d = key == kNoEdge ? kCxInf : (int)(key >> shift) - kCxBias;
+        } else if (mode == 0) {
+            if (i < B && j < Z) d = ((int)rack[i] == j - B && cnt[i] < q.rep_hi) ? 0 : kCxInf;
+            else if (j < B && i < Z) d = ((int)rack[j] == i - B && cnt[j] > q.rep_lo) ? 0 : kCxInf;
+            else if (i >= B && i < Z && j == Z) d = cnt[2 * B + (i - B)] < q.rack_hi ? 0 : kCxInf;
+            else if (i == Z && j >= B && j < Z) d = cnt[2 * B + (j - B)] > q.rack_lo ? 0 : kCxInf;
+        } else if (mode == 1) {
+            if (i < B && j == Z) d = cnt[B + i] < q.lead_hi ? 0 : kCxInf;
+            else if (i == Z && j < B) d = cnt[B + j] > q.lead_lo ? 0 : kCxInf;
         }
     }
     D[(size_t)i * q.np + j] = d;
@@ -321,12 +340,13 @@ __device__ __forceinline__ long long cx_wave_max(long long v) {
     return v;
 }
 
+template <int MR>
 __global__ __launch_bounds__(256) void k_cx_seeds(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack,
                                                   const int32_t *DF, const int32_t *DS, const int32_t *DL, int2 *table) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= q.P) return;
     const int RF = q.RF;
-    int row[kCxMaxRF];
+    int row[MR];
     for (int k = 0; k < RF; ++k) row[k] = A[(size_t)p * RF + k];
     const uint16_t *c = cur + (size_t)p * q.rfc;
     int w0 = cx_wt(q, c, row[0], 0);
@@ -340,7 +360,7 @@ __global__ __launch_bounds__(256) void k_cx_seeds(CxParams q, const uint16_t *A,
     }
     const int n_single = RF, n_pair = RF * (RF - 1) / 2;
     for (int bc = 0; bc < n_single + n_pair * q.rfc; ++bc) {
-        int base[kCxMaxRF], removed[2], nb = 0, nrm = 0, cfg0;
+        int base[MR], removed[2], nb = 0, nrm = 0, cfg0;
         bool valid = true;
         if (bc < n_single) {
             for (int j = 0; j < RF; ++j) { if (j == bc) removed[nrm++] = row[j]; else base[nb++] = row[j]; }
@@ -356,19 +376,19 @@ __global__ __launch_bounds__(256) void k_cx_seeds(CxParams q, const uint16_t *A,
             base[nb++] = valid ? i : 0;
             cfg0 = (RF - 1) + RF * RF + (pi * q.rfc + ii) * RF;
         }
-        const CxBase cb = cx_base(q, rack, base, nb);
+        const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
         valid = valid && !cb.over && cb.ndef <= 1;
         if (!valid) {
             if (lane < RF) out[cfg0 + lane] = make_int2(0, 0);
             continue;
         }
-        int wl_base[kCxMaxRF], wf_sum = 0, cl_base[kCxMaxRF];
+        int wl_base[MR], wf_sum = 0, cl_base[MR];
         for (int i = 0; i < nb; ++i) {
             wl_base[i] = cx_wt(q, c, base[i], 0);
             wf_sum += cx_wt(q, c, base[i], 1);
             cl_base[i] = DS[(size_t)base[i] * q.np + row[0]];
         }
-        long long best[kCxMaxRF];
+        long long best[MR];
         for (int li = 0; li < RF; ++li) best[li] = -1;
         for (int y = lane; y < q.B; y += 64) {
             bool ok = cx_completes(q, cb, rack[y]);
@@ -481,11 +501,11 @@ struct Cx {
         int32_t bd[8];
         int rc = kao_derive_bounds(t, bd);
         if (rc) return rc;
-        if (t->rf > kCxMaxRF || t->rf_cur > 8 || t->n_brokers + 1 > 2048 || t->rf < 2)
-            return api_fail(KAO_ERR_UNSUPPORTED, "KAO-CX: needs 2 <= RF <= 8 and at most 2047 brokers");
+        if (t->rf > kCxMaxRF || t->rf_cur > 8 || t->n_brokers + t->n_racks + 1 > 2048 || t->rf < 2)
+            return api_fail(KAO_ERR_UNSUPPORTED, "KAO-CX: needs 2 <= RF <= 8 and brokers + racks <= 2047");
         q.B = t->n_brokers; q.R = t->n_racks; q.P = t->n_partitions; q.RF = t->rf; q.rfc = t->rf_cur;
-        q.n = q.B + 1; q.np = (q.n + 63) & ~63;
-        q.rep_lo = bd[0]; q.rep_hi = bd[1]; q.lead_lo = bd[2]; q.lead_hi = bd[3]; q.prack_lo = bd[6]; q.prack_hi = bd[7];
+        q.n = q.B + q.R + 1; q.np = (q.n + 63) & ~63;
+        q.rep_lo = bd[0]; q.rep_hi = bd[1]; q.lead_lo = bd[2]; q.lead_hi = bd[3]; q.rack_lo = bd[4]; q.rack_hi = bd[5]; q.prack_lo = bd[6]; q.prack_hi = bd[7];
         q.w00 = t->w[0][0]; q.w01 = t->w[0][1]; q.w10 = t->w[1][0]; q.w11 = t->w[1][1];
         q.ncfg = cx_ncfg(q.RF, q.rfc);
         if ((rc = api_require_init())) return rc;
@@ -495,7 +515,7 @@ struct Cx {
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_A), slots * 2));
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_cur), (size_t)q.P * q.rfc * 2));
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_rack), (size_t)q.B));
-        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_cnt), (size_t)q.B * 8));
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_cnt), ((size_t)q.B * 2 + (size_t)q.R) * 4));
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_table), (size_t)q.P * q.ncfg * sizeof(int2)));
         for (int l = 0; l < kCxLayers; ++l) {
             CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_E[l]), nn * 8));
@@ -519,21 +539,23 @@ struct Cx {
     int build(const uint16_t *assign) {
         const size_t nn = (size_t)q.np * q.np, slots = (size_t)q.P * q.RF;
         A.assign(assign, assign + slots);
-        std::vector<int32_t> cnt((size_t)q.B * 2, 0);
+        std::vector<int32_t> cnt((size_t)q.B * 2 + (size_t)q.R, 0);   // c[B] | l[B] | K[R]
         for (int p = 0; p < q.P; ++p)
             for (int k = 0; k < q.RF; ++k) {
                 const unsigned b = A[(size_t)p * q.RF + k];
                 if (b >= (unsigned)q.B) return api_fail(KAO_ERR_INVALID, "KAO-CX: the assignment has an empty or out-of-range slot");
                 ++cnt[b];
+                ++cnt[(size_t)q.B * 2 + t->rack_of[b]];
                 if (k == 0) ++cnt[(size_t)q.B + b];
             }
         CX_TRY(hipMemcpyAsync(d_A, A.data(), slots * 2, hipMemcpyHostToDevice, stream));
         CX_TRY(hipMemcpyAsync(d_cnt, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, stream));
         for (int l = 0; l < kCxLayers; ++l) CX_TRY(hipMemsetAsync(d_E[l], 0xFF, nn * 8, stream));
-        hipLaunchKernelGGL(k_cx_edges, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_E[0], d_E[1]);
+        if (q.RF <= 4) hipLaunchKernelGGL(k_cx_edges<4>, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_E[0], d_E[1]);
+        else hipLaunchKernelGGL(k_cx_edges<8>, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_E[0], d_E[1]);
         const dim3 g0((q.np + 255) / 256, q.np);
-        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[0], d_cnt, q.rep_lo, q.rep_hi, 32, d_D[0][0]);
-        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[1], d_cnt + q.B, q.lead_lo, q.lead_hi, 32, d_D[1][0]);
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[0], d_cnt, d_rack, 0, 32, d_D[0][0]);
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[1], d_cnt, d_rack, 1, 32, d_D[1][0]);
         const dim3 gs(q.np / 64, q.np / 64);
         for (int v = 1; v <= kCxLevels; ++v)
             for (int l = 0; l < 2; ++l)
@@ -552,8 +574,9 @@ struct Cx {
         // the L graph prices its compensations on the F closure: only when F has no improving cycle of its own
         int f_neg = 0;
         for (size_t i = 0; i < (size_t)kCxLevels * q.B; ++i) f_neg |= diag[i] < 0;
-        hipLaunchKernelGGL(k_cx_edges_l, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], f_neg, d_E[2]);
-        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[2], d_cnt, INT_MAX, INT_MIN, 44, d_D[2][0]);   // L: no slack edges
+        if (q.RF <= 4) hipLaunchKernelGGL(k_cx_edges_l<4>, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], f_neg, d_E[2]);
+        else hipLaunchKernelGGL(k_cx_edges_l<8>, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], f_neg, d_E[2]);
+        hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[2], d_cnt, d_rack, 2, 44, d_D[2][0]);   // L: no slack edges
         for (int v = 1; v <= kCxLevels; ++v)
             hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[2][v - 1], d_D[2][v], d_M[2][v]);
         CX_TRY(hipGetLastError());
@@ -590,7 +613,8 @@ struct Cx {
     }
 
     int seeds() {
-        hipLaunchKernelGGL(k_cx_seeds, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_D[1][kCxLevels], d_D[2][kCxLevels], d_table);
+        if (q.RF <= 4) hipLaunchKernelGGL(k_cx_seeds<4>, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_D[1][kCxLevels], d_D[2][kCxLevels], d_table);
+        else hipLaunchKernelGGL(k_cx_seeds<8>, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_D[1][kCxLevels], d_D[2][kCxLevels], d_table);
         CX_TRY(hipGetLastError());
         table.resize((size_t)q.P * q.ncfg);
         CX_TRY(hipMemcpyAsync(table.data(), d_table, table.size() * sizeof(int2), hipMemcpyDeviceToHost, stream));
@@ -628,7 +652,7 @@ struct Cx {
         for (int d : nodes) {
             const int s0 = s;
             s = d;
-            if (s0 == d || s0 == q.B || d == q.B) continue;
+            if (s0 == d || s0 >= q.B || d >= q.B) continue;   // slack nodes carry no slot
             const unsigned long long key = hE[layer][(size_t)s0 * q.np + d];
             if (key == kNoEdge) return false;
             if (layer == 2) {   // generalised leader transfer: the partition's row changes, then the compensating F path
@@ -971,7 +995,7 @@ int cx_pairs_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int
         for (int d : nodes) {
             const int s0 = s;
             s = d;
-            if (s0 == d || s0 == q.B || d == q.B) continue;
+            if (s0 == d || s0 >= q.B || d >= q.B) continue;   // slack nodes carry no slot
             if (comp[(size_t)s0 * q.np + d]) {
                 const PairEdge &e = edges[(uint32_t)s0 * (uint32_t)q.B + (uint32_t)d];
                 const int ps[2] = {e.p, e.q};
@@ -1069,7 +1093,7 @@ int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, doub
 }
 
 bool cycle_supported(const kao_topic *t) {
-    return t && t->rf >= 2 && t->rf <= kCxMaxRF && t->rf_cur <= 8 && t->n_brokers + 1 <= 2048;
+    return t && t->rf >= 2 && t->rf <= kCxMaxRF && t->rf_cur <= 8 && t->n_brokers + t->n_racks + 1 <= 2048;
 }
 
 }  // namespace kao

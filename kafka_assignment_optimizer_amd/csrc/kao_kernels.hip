@@ -654,11 +654,8 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
             // slot (A[p], then W[x] / K[rack]) are hidden behind the other slot's, not behind other wavefronts
             // (p_o comes in: the lane's first slot is in a random partition, its further slots in the partitions that follow it
             //  cyclically -- on topics that live in HBM the slots of a lane then share two cache lines instead of touching 16)
-            auto score_slot = [&](auto ty, uint32_t &key_o, int p_o, int &k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
+            auto score_words = [&](auto ty, uint32_t &key_o, const Part<NW> &al, const Part<NW> &cl, int k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
                 constexpr int TY = decltype(ty)::value;
-                k_o = (int)rnd24(rng, RF8);
-                const Part<NW> al = L.A[p_o];
-                const Part<NW> cl = CUR[p_o];
                 oldw_o = sel4(al, k_o);
                 const uint32_t rol = oldw_o >> 16;
                 const bool leadl = k_o == 0;
@@ -686,6 +683,12 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
                 }
                 else key_o = make_key(lam, S, sc, -g_o, lane) | tour_off;   // lanes outside the tournament: all ones = kKeyNull
             };
+            auto score_slot = [&](auto ty, uint32_t &key_o, int p_o, int &k_o, uint32_t &oldw_o, int &g_o, int &dvo_o, int &dvr_o) {
+                k_o = (int)rnd24(rng, RF8);
+                const Part<NW> al = L.A[p_o];
+                const Part<NW> cl = CUR[p_o];
+                score_words(ty, key_o, al, cl, k_o, oldw_o, g_o, dvo_o, dvr_o);
+            };
             // large topics: up to 16 slots per lane, the lane keeps its best; two slots per trip.  Draw and comparison order
             // are those of a one-at-a-time loop.
             auto tournament = [&](auto ty) {
@@ -711,7 +714,56 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
                     if (kg < keyA) { keyA = kg; pl_ = pg; kl_ = kk; oldw_l = ow; g_old_l = gg; dvo_l = d1; dvr_l = d2; }
                 }
             };
-            if (type == 0) tournament(std::integral_constant<int, 0>{}); else tournament(std::integral_constant<int, 1>{});
+            // Topics that live in global memory (round 4): every draw of the iteration is independent of what is loaded, so all
+            // of them come first, then ALL the loads of the iteration -- the 2 x 16 tournament words of the lane and, for an
+            // EXCHANGE, the partner words of the first XB rounds -- are issued back to back, and only then scored: one global round
+            // trip per iteration where the slot-by-slot form took 8 for the tournament, one more for the winner's words and one per
+            // partner round (a restart is one wavefront per SIMD: nothing else hides that latency).  The lane's 16 loads of
+            // consecutive partitions also hit the same two or three cache lines while they are still in the L1.  Draw and
+            // comparison order are those of the slot-by-slot loop (same spec, same replay); slots g >= GA of a small topic are
+            // loaded from the lane's first partition and masked out of the comparison.
+            Part<NW> a_l, c_l;   // the words of the lane's best slot: the winner's are broadcast, not re-read
+            constexpr int XB = !kGlobalA ? 1 : ((NW == 4 && !kTeam) ? 8 : 4);   // (a team runs two wavefronts per SIMD: 256 registers each)
+            Part<NW> xb[XB], xcb[XB];
+            int q0 = 0;
+            auto x_partner = [&](int rd, int &qq, bool &okq) {   // partition lane `lane` looks at in partner round rd
+                qq = q0 + rd * 64 + lane; okq = true;
+                if (qq >= T.P) { if (x_windowed) qq -= T.P; else okq = false; }
+                return min(qq, T.P - 1);
+            };
+            auto tournament_global = [&](auto ty) {
+                constexpr int TY = decltype(ty)::value;
+                constexpr int TB = (NW == 4 && !kTeam) ? 16 : 8;   // slots per batch: 2 x NW x TB registers of loads in flight
+                const int p0 = (int)rnd24_wide(rng, (uint32_t)T.P);
+                auto part = [&](int ga) { const int q2 = p0 + ga; return q2 < T.P ? q2 : q2 - T.P; };
+                int kk[16];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { kk[g] = 0; if (g < GA) kk[g] = (int)rnd24(rng, RF8); }
+                if (TY == 1) {
+                    const int q_draw = (int)rnd24_wide(rng, (uint32_t)T.P);   // every lane draws; lane 0's value places the window
+                    q0 = x_windowed ? __builtin_amdgcn_readfirstlane(q_draw) : 0;
+#pragma unroll
+                    for (int r2 = 0; r2 < XB; ++r2) { int qq; bool okq; const int qc = x_partner(r2, qq, okq); xb[r2] = L.A[qc]; xcb[r2] = CUR[qc]; }
+                }
+#pragma unroll
+                for (int g0 = 0; g0 < 16; g0 += TB) {
+                    if (g0 > 0 && g0 >= GA) break;   // wave-uniform
+                    Part<NW> tal[TB], tcl[TB];
+                    int tp[TB];
+#pragma unroll
+                    for (int g = 0; g < TB; ++g) { tp[g] = (g0 + g) < GA ? part(g0 + g) : p0; tal[g] = L.A[tp[g]]; tcl[g] = CUR[tp[g]]; }
+#pragma unroll
+                    for (int g = 0; g < TB; ++g) {
+                        uint32_t kg, ow;
+                        int gg, d1 = 0, d2 = 0;
+                        score_words(ty, kg, tal[g], tcl[g], kk[g0 + g], ow, gg, d1, d2);
+                        if (g0 + g > 0) kg |= (g0 + g) < GA ? 0u : kKeyNull;
+                        if (g0 + g == 0 || kg < keyA) { keyA = kg; pl_ = tp[g]; kl_ = kk[g0 + g]; oldw_l = ow; g_old_l = gg; dvo_l = d1; dvr_l = d2; a_l = tal[g]; c_l = tcl[g]; }
+                    }
+                }
+            };
+            if constexpr (kGlobalA) { if (type == 0) tournament_global(std::integral_constant<int, 0>{}); else tournament_global(std::integral_constant<int, 1>{}); }
+            else if (type == 0) tournament(std::integral_constant<int, 0>{}); else tournament(std::integral_constant<int, 1>{});
             const int wA = (int)(wave_umin(keyA) & 63u);
             p = __builtin_amdgcn_readlane(pl_, wA);
             k = __builtin_amdgcn_readlane(kl_, wA);
@@ -719,8 +771,14 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
             const int g_old = __builtin_amdgcn_readlane(g_old_l, wA);
             const int dV_old = __builtin_amdgcn_readlane(dvo_l, wA);
             const int dV_rack_old = __builtin_amdgcn_readlane(dvr_l, wA);
-            const Part<NW> a = L.A[p];   // same address in every lane: LDS broadcast
-            const Part<NW> c = CUR[p];
+            Part<NW> a, c;
+            if constexpr (kGlobalA) {
+#pragma unroll
+                for (int i2 = 0; i2 < NW; ++i2) { a.w[i2] = (uint32_t)__builtin_amdgcn_readlane((int)a_l.w[i2], wA); c.w[i2] = (uint32_t)__builtin_amdgcn_readlane((int)c_l.w[i2], wA); }
+            } else {
+                a = L.A[p];   // same address in every lane: LDS broadcast
+                c = CUR[p];
+            }
             const bool lead = k == 0;  // wave-uniform
             const uint32_t ro = uw >> 16;
             if (type == 0) {
@@ -855,18 +913,17 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
                 const int pl_u = kPriced ? price_lead(PR[uw & 0xFFFFu]) : 0;
                 const int bwl_u = hbw ? (int)(BW[uw & 0xFFFFu] >> 16) : 0;
                 // every lane draws; lane 0's value places the window when the topic has more than 512 partitions
-                const int q_draw = (int)rnd24_wide(rng, (uint32_t)T.P);
-                const int q0 = x_windowed ? __builtin_amdgcn_readfirstlane(q_draw) : 0;
+                // (topics in global memory: drawn -- at the same place of the stream -- and its first partner words loaded by tournament_global)
+                if (!kGlobalA) {
+                    const int q_draw = (int)rnd24_wide(rng, (uint32_t)T.P);
+                    q0 = x_windowed ? __builtin_amdgcn_readfirstlane(q_draw) : 0;
+                }
                 const int x_rounds = x_windowed ? 8 : x_rounds_full;
-                for (int rd = 0; rd < x_rounds; ++rd) {
+                auto x_round = [&](int rd, const Part<NW> &b, const Part<NW> &cb) {
                     const uint32_t tie0 = lcg24(rng) >> 8;
-                    int qq = q0 + rd * 64 + lane;
-                    bool okq = true;
-                    if (qq >= T.P) { if (x_windowed) qq -= T.P; else okq = false; }
+                    int qq; bool okq;
+                    x_partner(rd, qq, okq);
                     okq = okq & (qq != p);
-                    const int qc = min(qq, T.P - 1);
-                    const Part<NW> b = L.A[qc];
-                    const Part<NW> cb = CUR[qc];
                     const bool u_in_b = in4(b, uw);
                     // independent of the partner slot j: what u would be worth in q, and q's replicas in u's rack
                     const int u_in_q_lead = role_w2(cb, uw, T.w00, T.w10), u_in_q_fol = role_w2(cb, uw, T.w01, T.w11);
@@ -897,6 +954,27 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
                         if (kPriced) keyx = ok ? make_key_tie_p(lam, S, dVx, dObjx, dPx, tie0 + (uint32_t)jj * 0x55u) : kKeyNull;
                         else keyx = ok ? make_key_tie(lam, S, dVx, dObjx, tie0 + (uint32_t)jj * 0x55u) : kKeyNull;
                         if (keyx < key) { key = keyx; vw = v; q = qq; j = jj; dV = dVx; dObj = dObjx; }
+                    }
+                };
+                if constexpr (kGlobalA) {
+#pragma unroll
+                    for (int r2 = 0; r2 < XB; ++r2)
+                        if (r2 < x_rounds) x_round(r2, xb[r2], xcb[r2]);
+                    for (int rb = XB; rb < x_rounds; rb += XB) {   // (8 words per partition: the second half of the rounds)
+                        Part<NW> yb[XB], ycb[XB];
+#pragma unroll
+                        for (int r2 = 0; r2 < XB; ++r2) { int qq; bool okq; const int qc = x_partner(rb + r2, qq, okq); yb[r2] = L.A[qc]; ycb[r2] = CUR[qc]; }
+#pragma unroll
+                        for (int r2 = 0; r2 < XB; ++r2)
+                            if (rb + r2 < x_rounds) x_round(rb + r2, yb[r2], ycb[r2]);
+                    }
+                } else {
+                    for (int rd = 0; rd < x_rounds; ++rd) {
+                        int qq; bool okq;
+                        const int qc = x_partner(rd, qq, okq);
+                        const Part<NW> b = L.A[qc];
+                        const Part<NW> cb = CUR[qc];
+                        x_round(rd, b, cb);
                     }
                 }
                 kmin = wave_umin(key);

@@ -621,12 +621,13 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         if (g.eval_coop) cpb = 1;
         if (g.global_a) if (const char *e = std::getenv("KAO_GLOBAL_WAVES")) g.waves = std::min(kWaves, std::max(1, std::atoi(e)));  // measurement hook
         // Topics that live in global memory: a restart is latency-bound (dependent loads of 16-byte assignment words), so ONE
-        // wavefront per restart leaves the restart shallow and the chip empty.  Round 4: a TEAM of wavefronts per restart (k_team):
-        // W proposals per iteration against the same state, the disjoint ones applied.  kao_opts.team = 1 (or KAO_TEAM=1)
-        // keeps one wavefront per restart (the round-3 path, still replayed by the tests), n picks the team size.
+        // wavefront per restart leaves the restart shallow.  Round 4 tried a TEAM of wavefronts per restart (k_team): W proposals
+        // per iteration against the same state, the disjoint ones applied.  Measured (gpurun_out/r04_c2_*): same iterations per
+        // second per restart at team 2 / 4, fewer at 8, and the 3-s incumbents of 1000 x 30000 / 1000 x 100000 within noise of
+        // one wavefront per restart -- so teams are opt-in (kao_opts.team = n, or KAO_TEAM=n), the default is k_search.
         if (g.global_a) {
             const int tmax = g.nw > kRFP ? kTeamMax / 2 : kTeamMax;   // (8 replica words per partition: 256 threads keep the kernel out of scratch)
-            int want = o.team == 0 ? tmax : o.team;
+            int want = o.team == 0 ? 1 : o.team;
             if (const char *e = std::getenv("KAO_TEAM")) want = std::max(0, std::atoi(e));
             g.team = want <= 1 ? 0 : std::min(want, tmax);
             if (g.team > 0) g.waves = 1;   // the block map holds one workgroup per restart

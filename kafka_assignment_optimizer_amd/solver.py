@@ -148,10 +148,11 @@ def improve_cycles(topic: Topic, assign, max_rounds: int = 0) -> tuple:
 
 
 def cycle_matrices(topic: Topic, assign, layer: int, level: int) -> tuple:
-    """Parity hook of KAO-CX: (dist, mid, slot), each [(B+1), (B+1)], of one layer (0 follower moves, 1 role swaps) and level."""
+    """Parity hook of KAO-CX: (dist, mid, slot), each [n, n] with n = B + R + 1 (brokers, one slack node per rack, the global slack
+    node), of one layer (0 follower moves, 1 role swaps, 2 leader replacements) and level."""
     ct = _CTopics([topic])
     a = np.ascontiguousarray(assign, dtype=np.uint16).reshape(-1)
-    n = len(topic.broker_ids) + 1
+    n = len(topic.broker_ids) + int(topic.n_racks) + 1
     dist = np.zeros((n, n), dtype=np.int32)
     mid = np.zeros((n, n), dtype=np.int32)
     slot = np.zeros((n, n), dtype=np.uint32)

@@ -6,14 +6,20 @@ numbering, candidate order, realisation, merge rule -- is what the HIP kernels a
 Never imported by the product package.
 
 One round, from a FEASIBLE assignment A of one topic (model: README.md:144-185):
-  * two transfer graphs on the brokers plus a slack node Z = B:
+  * transfer graphs on the brokers plus SLACK nodes -- one per rack, Z_r = B + r, and a global one, Z = B + R (round 4; until
+    then a single node Z = B: on topics whose band has slack -- P*RF not a multiple of B, README.md:158-166 with hi > lo -- a
+    path through it moved a replica unit from one rack to another, rows C6 (README.md:173-175) rejected the realisation, and the
+    rack-conserving path of the same cost was never found: fixpoints 8-21 units below the optimum):
       F: edge u -> v = "some follower slot holding u takes v instead" (one replica unit moves u -> v), cheapest slot per pair;
       S: edge u -> v = "a partition led by u with follower v swaps the two roles" (one leader unit moves u -> v);
       L: edge u -> v = "a partition led by u gets leader v" -- nominally a replica unit AND a leader unit move u -> v; five
          variants (plain replacement; v enters and u stays as follower while another follower leaves; a follower is promoted
          and u leaves; role swap; replacement plus one follower replaced), each carrying the cost of the F path that
          compensates the difference between its replica effect and u -> v -- built AFTER the F closure;
-      u -> Z when u may take one more (replica / leader) inside its band, Z -> v when v may give one up;
+      F: u -> Z_rack(u) when u may take one more replica inside its band (C3), Z_rack(v) -> v when v may give one up: a path through
+         Z_r alone leaves every rack total as it is; Z_r -> Z when rack r may take one more inside ITS band (C6), Z -> Z_r when it
+         may give one up;   S: u -> Z when u may lead one more partition (C4), Z -> v when v may give one up (leader units know no
+         racks);   L: no slack edges;
   * bounded-hop closures by three min-plus squarings (paths of <= 8 edges), with the midpoint of every pair;
   * a negative diagonal entry is an improving cyclic exchange by itself; otherwise SEEDS are enumerated -- for every partition
     every new row that replaces at most two replicas (one of them by a current replica of the partition) and picks any
@@ -39,7 +45,7 @@ MAX_RF = 8
 
 
 def supported(t) -> bool:
-    return 2 <= t.rf <= MAX_RF and t.n_brokers + 1 <= 2048
+    return 2 <= t.rf <= MAX_RF and t.n_brokers + t.n_racks + 1 <= 2048
 
 
 def n_cfg(rf: int, rf_cur: int) -> int:
@@ -75,14 +81,15 @@ class Round:
         self.t = t
         self.A = np.asarray(A).astype(np.int64).reshape(t.n_partitions, t.rf)
         self.B, self.P, self.RF, self.R = t.n_brokers, t.n_partitions, t.rf, t.n_racks
-        self.n = self.B + 1
-        self.Z = self.B
+        self.n = self.B + self.R + 1      # brokers, one slack node per rack (B + r), the global slack node
+        self.Z = self.B + self.R
         self.bd = t.bounds()
         self.rack = np.asarray(t.rack_of).astype(np.int64)
         self.cur = np.asarray(t.current).astype(np.int64)
         self.WL, self.WF = _wt_tables(t)
         self.c = np.bincount(self.A.reshape(-1), minlength=self.B)
         self.l = np.bincount(self.A[:, 0], minlength=self.B)
+        self.K = np.bincount(self.rack[self.A.reshape(-1)], minlength=self.R)     # replicas per rack (C6)
         self._edges()
         self._closures()
 
@@ -127,8 +134,13 @@ class Round:
                 if ks < ES[a, v]:
                     ES[a, v] = ks
         zkey = np.uint64((CB << 32) | NO_SLOT)
-        EF[:B, self.Z][self.c < self.bd["rep_hi"]] = zkey
-        EF[self.Z, :B][self.c > self.bd["rep_lo"]] = zkey
+        bs = np.arange(B)
+        up, down = self.c < self.bd["rep_hi"], self.c > self.bd["rep_lo"]
+        EF[bs[up], B + self.rack[up]] = zkey
+        EF[B + self.rack[down], bs[down]] = zkey
+        rs = np.arange(self.R)
+        EF[B + rs[self.K < self.bd["rack_hi"]], self.Z] = zkey
+        EF[self.Z, B + rs[self.K > self.bd["rack_lo"]]] = zkey
         ES[:B, self.Z][self.l < self.bd["lead_hi"]] = zkey
         ES[self.Z, :B][self.l > self.bd["lead_lo"]] = zkey
         self.EF, self.ES, self.EL = EF, ES, EL    # L has no slack edges: it moves two kinds of units at once
@@ -389,7 +401,7 @@ class Round:
         E = (self.EF, self.ES, self.EL)[layer]
         RF = self.RF
         for s, d in zip(pth[:-1], pth[1:]):
-            if s == d or s == self.Z or d == self.Z:
+            if s == d or s >= self.B or d >= self.B:      # slack nodes carry no slot
                 continue
             key = int(E[s, d])
             if key == NO_EDGE:

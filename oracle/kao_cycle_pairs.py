@@ -180,7 +180,7 @@ def find_improvement(t, X, verbose=True):
                 pth = path(b, m, lev - 1) + path(m, b, lev - 1)[1:]
                 Y = rd.A.copy(); used = set(); ok = True
                 for s, d in zip(pth[:-1], pth[1:]):
-                    if s == d or s == rd.Z or d == rd.Z: continue
+                    if s == d or s >= rd.B or d >= rd.B: continue
                     if comp[s, d]:
                         for (p, row) in edges[(s, d)][1]:
                             if p in used: ok = False; break

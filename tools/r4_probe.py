@@ -20,9 +20,10 @@ if mode == "solve":
     for team in [int(v) for v in sys.argv[3].split(",")]:
         os.environ["KAO_TEAM"] = str(team)
         t0 = time.perf_counter()
-        r = kao.solve([t], seed=seed, stop_at_bound=1, time_limit_s=budget)[0]
+        kw = {"restarts": int(os.environ["R4_RESTARTS"])} if os.environ.get("R4_RESTARTS") else {}
+        r = kao.solve([t], seed=seed, stop_at_bound=1, time_limit_s=budget, **kw)[0]
         tm = kao.last_solve_timing()
-        print(json.dumps({"which": which, "team": team, "status": str(r.status), "objective": int(r.objective), "certificate": int(r.upper_bound),
+        print(json.dumps({"which": which, "team": team, "restarts": os.environ.get("R4_RESTARTS", "auto"), "status": str(r.status), "objective": int(r.objective), "certificate": int(r.upper_bound),
                           "gap": int(r.upper_bound - r.objective), "seconds": round(time.perf_counter() - t0, 3),
                           "timing": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in tm.items()}}), flush=True)
 if mode in ("fill", "team"):
