@@ -764,7 +764,20 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
             };
             if constexpr (kGlobalA) { if (type == 0) tournament_global(std::integral_constant<int, 0>{}); else tournament_global(std::integral_constant<int, 1>{}); }
             else if (type == 0) tournament(std::integral_constant<int, 0>{}); else tournament(std::integral_constant<int, 1>{});
-            const int wA = (int)(wave_umin(keyA) & 63u);
+            const int wA1 = (int)(wave_umin(keyA) & 63u);
+            // REPLACE scan (round 4): the slots of the tournament's TWO best lanes are scanned, the winner's first; the better of
+            // the two moves is the proposal (ties: the first slot's).  Loop head, penalty, acceptance and bookkeeping are paid once
+            // for twice the neighbours (they were two thirds of the instruction stream at 500 brokers, docs/notes_r03.md section 6).
+            int wA2 = -1;
+            if (type == 0) {
+                const uint32_t k2 = wave_umin(lane == wA1 ? kKeyNull : keyA);
+                wA2 = k2 == kKeyNull ? -1 : (int)(k2 & 63u);   // (no other lane takes part: one slot)
+            }
+            uint32_t b_kmin = kKeyNull, b_uw = 0, b_vw = 0;
+            int b_win = 0, b_p = 0, b_k = 0, b_dV = 0, b_dObj = 0;
+#pragma nounroll
+            for (int si = 0; si < (wA2 >= 0 ? 2 : 1); ++si) {
+            const int wA = si == 0 ? wA1 : wA2;
             p = __builtin_amdgcn_readlane(pl_, wA);
             k = __builtin_amdgcn_readlane(kl_, wA);
             uw = (uint32_t)__builtin_amdgcn_readlane((int)oldw_l, wA);
@@ -905,6 +918,7 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
                     dV = wfld(ws, kWIncR) + wfldw(ws, kWIncL, lw) + dV_old + (kPriced ? (int)(signed char)(rts & 0xFF) : rts);
                     dObj = -g_old + (has_missing ? role_w2(c, vw, wl, wf) : 0) + (hbw ? bw_of(BW[xs], lead) : 0);
                 }
+                if (si == 0 || kmin < b_kmin) { b_kmin = kmin; b_win = win; b_p = p; b_k = k; b_uw = uw; b_vw = vw; b_dV = dV; b_dObj = dObj; }
             } else {
                 // ---- phase B (EXCHANGE): every partner slot (q,j) for slot (p,k), 64 partitions per round ----
                 const int nrp = lead ? 0 : 1;
@@ -981,6 +995,8 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
                 const unsigned long long bal = __ballot(key == kmin);
                 win = __ffsll((long long)bal) - 1;  // ties inside the wave go to the lowest lane
             }
+            }   // (the two scan slots)
+            if (type == 0) { kmin = b_kmin; win = b_win; p = b_p; k = b_k; uw = b_uw; vw = b_vw; dV = b_dV; dObj = b_dObj; }
         }
         if (!kTeam) {
             if (kmin == kKeyNull) continue;

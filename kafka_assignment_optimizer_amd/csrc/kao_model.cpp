@@ -403,7 +403,7 @@ uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers
     for (uint32_t i = 0; i < iters; ++i) {
         const uint32_t it = it0 + i;
         const int type = pat[it & 7];
-        if (type == 0) n += ((it >> 3) & 1u) ? 256ull : (uint64_t)n_brokers;
+        if (type == 0) n += ((it >> 3) & 1u) ? 256ull : 2ull * (uint64_t)n_brokers;   // a scan covers the slots of the tournament's two best lanes
         else if (type == 1) n += (uint64_t)std::min(n_partitions, n_partitions > 512 ? 512 : n_partitions) * (uint64_t)rf;
         else n += 64ull * (uint64_t)(rf > 1 ? rf - 1 : 0);
     }

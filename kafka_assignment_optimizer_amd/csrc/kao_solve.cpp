@@ -357,7 +357,8 @@ struct SolveRun {
         int32_t st[8];
         // the clock only ends a deterministic call at the solve's own deadline (the stop condition)
         const double slice_end = det ? deadline : std::min(deadline, now_s() + cx_slice);
-        int rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), rounds, slice_end, &obj, st, &SolveRun::poll_bound, this, is_elite);
+        static const bool pairs_all = [] { const char *e = std::getenv("KAO_CX_PAIRS_ALL"); return e && e[0] == '1'; }();   // experiment hook
+        int rc = cycle_run(cx_ctx[(size_t)i], cx_buf.data(), rounds, slice_end, &obj, st, &SolveRun::poll_bound, this, is_elite || pairs_all);
         ++cx_calls;
         if (rc) return rc;
         if (reached) *reached = obj;

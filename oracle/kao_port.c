@@ -417,8 +417,10 @@ static void ls_apply(const ls_topic *t, ls_state *s, const proposal *o) {
 /* ---------------------------------------------------------------------------------------------
  * One launch of KAO-LS.  Move type of iteration `it`: pattern R R X R L R X R.
  *   REPLACE, blocks of 8 iterations alternate between two styles ((it >> 3) & 1):
- *     scan   : a tournament over T random slots (lowest "removal score") picks ONE slot (p,k); every
- *              target broker is then delta-evaluated for it, 64 per round (lane = internal index);
+ *     scan   : a tournament over T random slots (lowest "removal score") picks the slots of its TWO best lanes (round 4; one
+ *              slot until then: the per-iteration overhead -- loop head, penalty, accept, bookkeeping -- is paid once for
+ *              twice the neighbours); for each of them, first the winner's, every target broker is delta-evaluated, 64
+ *              per round (lane = internal index); the better of the two moves is the proposal (ties: the first slot's);
  *     sample : every lane proposes its own random slot and 4 candidate brokers (ls_lane).
  *   EXCHANGE : tournament slot (p,k), then every partner slot (q,j) is scanned (lane = partition q); topics with
  *              more than 512 partitions scan a random window of 512 (8 rounds).
@@ -448,6 +450,8 @@ static uint32_t ls_propose(const ls_topic *t, ls_state *s, int type, uint32_t it
         } else {
             /* ---- phase A: tournament over T random slots, lowest removal score wins ---- */
             uint32_t keyA = KEY_NULL; int p = 0, k = 0;
+            uint32_t lkey[LANES]; int lp[LANES], lk[LANES];   /* every lane's best slot (the second scan slot comes from the second-best LANE) */
+            for (uint32_t l = 0; l < LANES; ++l) { lkey[l] = KEY_NULL; lp[l] = 0; lk[l] = 0; }
             for (uint32_t l = 0; l < LANES; ++l)
               for (int ga = 0, p0 = 0; ga < GA; ++ga) {
                 /* the lane draws ONE partition; its further slots come from the partitions that follow it (cyclically): on topics
@@ -471,7 +475,19 @@ static uint32_t ls_propose(const ls_topic *t, ls_state *s, int type, uint32_t it
                 const int sc = (type == 0) ? dvo + (dvr < 0 ? dvr : 0) : (dv7 < 0 ? dv7 : 0) + (dvl < 0 ? dvl : 0);
                 const uint32_t key = make_key(lam, S, sc, -(type == 0 ? slot_w(t, pl, old, kl == 0 ? 0 : 1) : role_w(t, pl, old, kl == 0 ? 0 : 1)), l, type == 0 ? p_out((int)(co & 0xFFFF), t->rep_lo, t->rep_hi, PAx(s, old)) + (kl == 0 ? p_out((int)(co >> 16), t->lead_lo, t->lead_hi, PLx(s, old)) : 0) : 0);
                 if (key < keyA) { keyA = key; p = pl; k = kl; }
+                if (ga == 0 || key < lkey[l]) { lkey[l] = key; lp[l] = pl; lk[l] = kl; }
               }
+            /* REPLACE scan: the slot of the best lane, then the slot of the best OTHER lane (none when no other lane takes part) */
+            int n_slots = 1, sp[2], sk[2];
+            sp[0] = p; sk[0] = k;
+            if (type == 0) {
+                uint32_t k2 = KEY_NULL; const uint32_t wA = keyA & 63u;
+                for (uint32_t l = 0; l < LANES; ++l)
+                    if (l != wA && lkey[l] < k2) { k2 = lkey[l]; sp[1] = lp[l]; sk[1] = lk[l]; }
+                if (k2 != KEY_NULL) n_slots = 2;
+            }
+            for (int si = 0; si < n_slots; ++si) {
+            p = sp[si]; k = sk[si];
             const uint16_t *a = s->A + p * RFP;
             const unsigned old = a[k];
             const int nr = k == 0 ? 0 : 1;
@@ -553,6 +569,7 @@ static uint32_t ls_propose(const ls_topic *t, ls_state *s, int type, uint32_t it
                     }
                 for (uint32_t l = 0; l < LANES; ++l)
                     if (lane_key[l] < best_key) { best_key = lane_key[l]; bp.type = 1; bp.p = p; bp.k = k; bp.q = lane_q[l]; bp.j = lane_j[l]; bp.dV = lane_dV[l]; bp.dObj = lane_dO[l]; }
+            }
             }
         }
         *out = bp;

@@ -51,7 +51,9 @@ def test_closure_is_the_bounded_shortest_path(ko, kp):
 def test_realised_candidates_are_worth_their_price(ko, kp):
     import kao_cycle as kc
     seen_seed = seen_cycle = 0
-    for s, t, a in _wide_cases(ko, kp, range(60)):
+    import itertools
+    # mature incumbents (after the two-slot REPLACE scan of round 4 most of them are fixpoints already) and immature ones
+    for s, t, a in itertools.chain(_wide_cases(ko, kp, range(60)), _wide_cases(ko, kp, range(60), launches=2, iters=64)):
         rd = kc.Round(t, a)
         base, v0 = kc.evaluate(t, rd.A)
         assert v0 == 0
