@@ -146,7 +146,7 @@ def load_profile_constants(tag, iters, restarts_total):
 def load_big_constants(which):
     """Per-kernel counter figures of the north-star workloads (tools/profile_big.sh -> profiles/r03_big_<which>_constants.json)."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03*_big_%s_constants.json" % which)))   # the latest tag wins
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_big_%s_constants.json" % which)))   # the latest tag wins
     if not paths:
         return None
     path = paths[-1]
@@ -471,8 +471,8 @@ def main():
     #      run there (k_search<true, ...>, the cooperative k_eval) against the HBM peak; traffic from profiles/ (rocprofv3 --pmc) ----
     if not args.no_extras and rank == 0:
         big = []
-        for which in ("drift30k", "cfg5one"):
-            st = synthetic.north_star_steps(kao, which, launches=4)
+        for which in ("drift30k", "drift100k", "cfg5one"):
+            st = synthetic.north_star_steps(kao, which, launches=4)     # automatic restart count: 4 per compute unit (round 4)
             prof_b = load_big_constants(which)
             e = {"workload": which, "brokers": st["brokers"], "partitions": st["partitions"], "restarts": st["restarts"],
                  "iters_per_launch": st["iters_per_launch"], "wall_ms_per_step": st["wall_ms_per_launch"], "drift": st["drift"]}
@@ -489,11 +489,41 @@ def main():
                     r["valu_insts_per_launch"] = pk.get("SQ_INSTS_VALU")
                     r["traffic_note"] = "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 wide-read correction) + WRITE_SIZE per launch, separate passes, " + prof_b["source"]
                 e[kern] = r
+            if which == "drift100k":    # the north-star size after a 20 % drift: one 3-s kao_solve (K-search + K-bound + KAO-CX), gap to the certificate
+                tp = synthetic.north_star_topic(which)
+                kao.solve([tp], seed=1, max_launches=1)
+                t0 = time.perf_counter()
+                r = kao.solve([tp], seed=3, stop_at_bound=1, time_limit_s=3.0)[0]
+                tm = kao.last_solve_timing()
+                e["solve_3s"] = {"status": str(r.status), "objective": int(r.objective), "certificate": int(r.upper_bound),
+                                 "gap": int(r.upper_bound - r.objective), "closed_form_bound": int(kao.upper_bound(tp)),
+                                 "seconds": time.perf_counter() - t0, "seconds_to_best": float(r.seconds_to_best),
+                                 "launches": int(tm["launches"]), "k_bound_iterations": int(tm["bound_iters"]), "kao_cx_calls": int(tm["cx_calls"]),
+                                 "note": "no exact solver reaches this size: the certificate is K-bound's Lagrangian dual value (round 4: "
+                                         "K-bound's limit on P*RF went from 2^17 to 2^20)"}
             big.append(e)
         out["roofline_big_topic"] = {"topics": big,
                                      "note": "K-search + K-eval steps of one session on a single large topic (synthetic.north_star_topic): "
                                              "the assignment words live in HBM/L2 (16 B per partition per restart, updated in place); k_search<true,...> is "
                                              "bound by the latency of dependent global loads at one wavefront per SIMD, not by bandwidth"}
+
+    # ---- cluster-wide per-broker caps (BASELINE config 5 wording; kao_solve_capped) on the medium golden: wall time, plan
+    #      against the exact joint optimum (HiGHS, tests/golden/capped_medium.json: numbers only, nothing of oracle/ runs here) ----
+    if not args.no_extras and rank == 0:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "capped_medium.json")) as f:
+                cases = json.load(f)["cases"]
+            rows = []
+            for c in cases:
+                tps = [kao.Topic.from_dict(d) for d in c["topics"]]
+                t0 = time.perf_counter()
+                res, lb = kao.solve_capped(tps, c["replica_cap"], seed=c["seed"], time_limit_s=10.0, max_rounds=60)
+                rows.append({"topics": len(tps), "brokers": tps[0].n_brokers, "partitions_per_topic": tps[0].n_partitions,
+                             "wall_s": time.perf_counter() - t0, "plan_objective": int(sum(int(r.objective) for r in res)),
+                             "exact_joint_optimum_highs": c["objective"], "lagrangian_bound": lb, "objective_without_caps": c["objective_without_caps"]})
+            out["capped_cluster"] = {"cases": rows, "note": "kao_solve_capped: Lagrangian prices on the capped brokers over independent per-topic solves"}
+        except (OSError, ValueError, KeyError, AttributeError) as ex:
+            out["capped_cluster"] = {"error": repr(ex)}
 
     # ---- roofline of the dominant kernel (K-search), duration from HIP events on the session stream -------
     avg_ms = ms_search / max(1, launches)

@@ -919,9 +919,9 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
         std::memcpy(&assign[(size_t)winner.used[u] * q.RF], &winner.rows[u * q.RF], (size_t)q.RF * 2);
     *new_obj = win_obj;
     if (trace)
-        std::fprintf(stderr, "[kao-cx] %s build %.2f ms, candidates %zu in %.2f ms, paths %.2f ms, %zu realisations %.2f ms, eval+merge %.2f ms: %d -> %d (%d merged)\n",
+        std::fprintf(stderr, "[kao-cx] %s build %.2f ms, candidates %zu in %.2f ms, paths %.2f ms, %zu realisations %.2f ms, eval+merge %.2f ms: %d -> %d (%d merged; %d improving, %zu partition-disjoint)\n",
                      cycles ? "cycles" : "seeds", (tt1 - tt0) * 1e3, cands.size(), (tt2 - tt1) * 1e3, (tt3 - tt2) * 1e3, reals.size(), (tt4 - tt3) * 1e3,
-                     (api_now_s() - tt4) * 1e3, base, win_obj, n_taken);
+                     (api_now_s() - tt4) * 1e3, base, win_obj, n_taken, n_good, chosen.size());
     return 1;
 }
 

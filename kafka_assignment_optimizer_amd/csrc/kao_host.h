@@ -53,7 +53,7 @@ int prepare(const kao_topic *t, uint64_t seed, PreparedTopic &pt);
 std::string infeasible_reason(const kao_topic *t);
 int64_t upper_bound(const kao_topic *t);
 int64_t upper_bound_w(const kao_topic *t);     // ... of a topic that may carry broker weights
-uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers, int n_partitions);
+uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers, int n_partitions, int scan2_max = kScanTwoSlots);
 int auto_period_log2(int P, int RF);
 bool dual_supported(const kao_topic *t, bool session_bw = false);       // within K-bound's limits (session_bw: the session carves broker weights)
 

@@ -24,6 +24,7 @@ constexpr int kDualScale = 1 << kDualLog2; // fixed point of the dual multiplier
                                           // 14831.74 for 110,000 iterations; with 2^16 the same iteration reaches the LP optimum 14826.0)
 constexpr int kDualStage = 100;           // level control: iterations per stage (K-bound)
 constexpr int kDualDeflP = 2048;          // topics with more partitions use the long deflection memory (kao_bound.hip::db_defl)
+constexpr int kScanTwoSlots = 24576;     // REPLACE scan: two tournament slots per iteration up to this many replica slots, one beyond (oracle/kao_port.c SCAN_TWO_SLOTS)
 constexpr int kDualClamp = 1 << 26;       // |multiplier| <= this (32-bit headroom of the priced values)
 constexpr int kDualQuarterLog2 = kDualLog2 - 2;  // kDualScale / 4: the quarter grid of the rounding probes and the search prices
 constexpr int kDualProbes = 2;            // probes per K-bound launch: multipliers rounded to the quarter grid, then the half grid
@@ -76,6 +77,7 @@ struct SearchParams {
     int32_t bw;                  // 1 = topics of this launch carry broker weights (priced instantiation: the weight table is carved)
     uint32_t gen;                // generation of the population: salts the tie-break hash of the initial state (init = 1 with gen > 0 =
                                  //     kao_solve re-initialises every restart after a population converged without a proof)
+    int32_t scan2_max;           // REPLACE scan covers the tournament's TWO best slots on topics of at most this many replica slots (kScanTwoSlots)
     int32_t elite;               // 1 = restarts that trail their topic's best feasible objective may re-seed from it (KAO-LS
                                  //     "elite" rule)
 };

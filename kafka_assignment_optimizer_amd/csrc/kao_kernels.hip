@@ -769,7 +769,7 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
             // the two moves is the proposal (ties: the first slot's).  Loop head, penalty, acceptance and bookkeeping are paid once
             // for twice the neighbours (they were two thirds of the instruction stream at 500 brokers, docs/notes_r03.md section 6).
             int wA2 = -1;
-            if (type == 0) {
+            if (type == 0 && TD->P * TD->RF <= prm.scan2_max) {   // (large topics scan one slot: their iterations are what they are short of)
                 const uint32_t k2 = wave_umin(lane == wA1 ? kKeyNull : keyA);
                 wA2 = k2 == kKeyNull ? -1 : (int)(k2 & 63u);   // (no other lane takes part: one slot)
             }

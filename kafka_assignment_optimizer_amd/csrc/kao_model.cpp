@@ -397,13 +397,14 @@ int64_t upper_bound_w(const kao_topic *t) {
 // move pattern R R X R L R X R; REPLACE scans all B brokers of one slot in even blocks of 8 iterations and
 // samples 64 lanes x 4 brokers in odd blocks; EXCHANGE scans all P*RF partner slots (a window of 512 partitions
 // when P > 512); LEADER-SWAP 64 x (RF-1).
-uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers, int n_partitions) {
+uint64_t neighbours_in_range(uint32_t it0, uint32_t iters, int rf, int n_brokers, int n_partitions, int scan2_max) {
+    const uint64_t scan_slots = (int64_t)n_partitions * rf <= scan2_max ? 2 : 1;
     static const uint8_t pat[8] = {0, 0, 1, 0, 2, 0, 1, 0};
     uint64_t n = 0;
     for (uint32_t i = 0; i < iters; ++i) {
         const uint32_t it = it0 + i;
         const int type = pat[it & 7];
-        if (type == 0) n += ((it >> 3) & 1u) ? 256ull : 2ull * (uint64_t)n_brokers;   // a scan covers the slots of the tournament's two best lanes
+        if (type == 0) n += ((it >> 3) & 1u) ? 256ull : scan_slots * (uint64_t)n_brokers;   // a scan covers the slots of the tournament's two best lanes (one on large topics)
         else if (type == 1) n += (uint64_t)std::min(n_partitions, n_partitions > 512 ? 512 : n_partitions) * (uint64_t)rf;
         else n += 64ull * (uint64_t)(rf > 1 ? rf - 1 : 0);
     }
@@ -430,7 +431,12 @@ bool dual_supported(const kao_topic *t, bool session_bw) {
     const bool hbw = t->broker_w || t->broker_wl;
     if (bound_lds_bytes(t->n_brokers, 0, t->n_racks, false, wide ? 8 : 4, hbw || session_bw) > 160 * 1024) return false;
     const int64_t n = (int64_t)t->n_partitions * t->rf;
-    if (n > 131072) return false;
+    // Round 4: the P*RF <= 2^17 limit of rounds 1-3 was far inside the arithmetic's real headroom (BASELINE config 5 as one
+    // topic is 300,000 slots).  What the integers need: a subgradient entry |s| <= n and a direction |d| <= 64 n in 32 bits
+    // (n <= 2^20); |d|^2 summed over 2 B + R multipliers in 63 bits (4096 n^2 (2 B + R) < 2^62); the level gap in dual fixed
+    // point below 2^42 (bound_step_length: n * weight * 65536, checked with the weights below).
+    if (n > ((int64_t)1 << 20)) return false;
+    if (4096.0 * (double)n * (double)n * (double)(2 * t->n_brokers + t->n_racks) >= 4.0e18) return false;
     int wmax = 0, bwmax = 0;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j) {
@@ -439,7 +445,7 @@ bool dual_supported(const kao_topic *t, bool session_bw) {
         }
     for (int b = 0; hbw && b < t->n_brokers; ++b)
         bwmax = std::max(bwmax, (t->broker_w ? t->broker_w[b] : 0) + (t->broker_wl ? t->broker_wl[b] : 0));
-    return wmax + bwmax <= 255;
+    return wmax + bwmax <= 255 && n * (int64_t)(wmax + bwmax) <= ((int64_t)1 << 25);
 }
 
 }  // namespace kao

@@ -500,15 +500,18 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         // restarts of the largest topic, but never fewer than one restart per compute unit
         int64_t slots = 1;
         for (int t = 0; t < n_topics; ++t) slots = std::max<int64_t>(slots, (int64_t)topics[t].n_partitions * std::max(topics[t].rf, 1));
-        const int cap = (int)std::max<int64_t>(g_num_cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves);
+        // (round 4: four per compute unit where the topic lives in HBM -- a restart is then one wavefront waiting on dependent global
+        //  loads, and 1024 of them take the time of 256: drifted 1000 x 30000 3.98 -> 4.43 ms per launch, profiles/r04_a_fill_probe.txt)
+        const int floor_r = slots >= 32768 ? 4 * g_num_cu : g_num_cu;
+        const int cap = (int)std::max<int64_t>(floor_r, (((int64_t)1 << 22) / slots) / kWaves * kWaves);
         o.restarts = std::min(o.restarts, cap);
     }
     if (o.restarts > (1 << 20) - 2) o.restarts = (1 << 20) - 2;  // id 0xFFFFF is reserved (kExternalRestart)
     {   // huge topics: bound the per-restart state in HBM (16 B of working words + the snapshot per partition):
-        // 1 GB when the count was chosen automatically, 8 GB for an explicit request
+        // 8 GB (of 288; 1 GB for automatic counts until round 4)
         uint64_t per_restart = 0;
         for (int t = 0; t < n_topics; ++t) per_restart += (uint64_t)topics[t].n_partitions * (32 + 2 * (uint64_t)std::max(topics[t].rf, 1));
-        const uint64_t cap = ((auto_restarts ? 1ull : 8ull) << 30) / std::max<uint64_t>(per_restart, 1);
+        const uint64_t cap = (8ull << 30) / std::max<uint64_t>(per_restart, 1);
         if ((uint64_t)o.restarts > cap) o.restarts = (int)std::max<uint64_t>(cap / kWaves * kWaves, kWaves);
     }
     s->opts = o;
@@ -771,6 +774,8 @@ int kao_session_step(kao_session *s) {
     s->reinit = false;
     const int eper = s->opts.elite_period;
     prm.bw = s->any_bw ? 1 : 0;
+    prm.scan2_max = kScanTwoSlots;
+    if (const char *e = std::getenv("KAO_X_SCAN2_MAX")) prm.scan2_max = std::atoi(e);   // experiment knob (the replay tests assume the default)
     prm.elite = (eper > 0 && s->launch > 0 && s->launch % (uint32_t)eper == 0) ? 1 : 0;
     sp.price_pool = s->d_price + (size_t)s->price_read * s->price_half_i32;
     sp.int_pool = s->d_int; sp.elite_assign = s->d_win_assign; sp.elite_key = s->d_keys; sp.bw_pool = s->d_bw;
@@ -798,7 +803,7 @@ int kao_session_step(kao_session *s) {
         HIP_TRY(hipGetLastError());
     }
     for (const PreparedTopic &pt : s->pts) {
-        const uint64_t n = neighbours_in_range(prm.launch * prm.iters, prm.iters, pt.d.RF, pt.d.B, pt.d.P) * (uint64_t)pt.d.n_restarts;
+        const uint64_t n = neighbours_in_range(prm.launch * prm.iters, prm.iters, pt.d.RF, pt.d.B, pt.d.P, prm.scan2_max) * (uint64_t)pt.d.n_restarts;
         s->delta_total += n;
         s->search_bytes_total += n * (uint64_t)(8 * pt.d.RF + 10);
     }

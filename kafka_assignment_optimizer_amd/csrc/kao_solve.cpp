@@ -74,6 +74,16 @@ struct SolveRun {
     std::vector<int64_t> dual_target;
     double t0 = 0, t_last_improve = 0;
     int launches = 0, dual_iters = 0, dual_now = 0;
+    // K-bound back-off (round 4, deterministic schedule, topics beyond kBoundRestSlots replica slots): a K-bound launch beside
+    // K-search costs the search more than half its speed there (1000 x 100,000: a K-search launch 6.8 ms alone, 14-19 ms beside
+    // K-bound; 1000 x 30,000: 4.0 / 8.4) while the certificate of such a topic stops moving after a second (782,651 from 2.0 s
+    // to 10 s with the incumbent still 500 units away).  A topic whose certificate has not moved for kBoundQuiet merged launches
+    // is given to K-bound only every kBoundDuty-th time; any improvement of the certificate ends the rest.  Counts only.
+    std::vector<int64_t> ub_seen;
+    std::vector<int> bound_quiet, bound_turn;
+    std::vector<char> bound_ran;
+    int64_t bound_rest_slots = 32768;
+    int bound_quiet_max = 6, bound_duty = 8;
     bool use_prices = true, all_done = false;
     // KAO-CX (kao_cycle.hip): cyclic-exchange improvement of incumbents K-search has stopped improving
     const kao_topic *topics = nullptr;
@@ -153,6 +163,8 @@ struct SolveRun {
         has_target = tgt != nullptr;
         if (tgt) { target.resize((size_t)n); for (int i = 0; i < n; ++i) target[(size_t)i] = tgt[origin[(size_t)i]]; }
         keys.assign((size_t)n, 0); prev.assign((size_t)n, ~0ull); t_best.assign((size_t)n, 0.0); dual_target.assign((size_t)n, -1);
+        ub_seen.assign((size_t)n, INT64_MAX); bound_quiet.assign((size_t)n, 0); bound_turn.assign((size_t)n, 0); bound_ran.assign((size_t)n, 0);
+        { const char *e = std::getenv("KAO_X_BOUND_REST"); if (e && *e) bound_rest_slots = std::atoll(e); }   // experiment knob: slots beyond which K-bound rests (huge = never)
         dkeys.assign((size_t)n, ~0ull); gprev.assign((size_t)n, ~0ull); inc_key.assign((size_t)n, ~0ull); inc_assign.assign((size_t)n, {});
         this->topics = topics;
         t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
@@ -285,6 +297,11 @@ struct SolveRun {
         if (s->bound_inflight) {
             if ((rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;   // deterministic schedule: waits for the launch
             share_bounds();
+            for (int i = 0; i < n; ++i) {
+                if (!bound_ran[(size_t)i]) continue;
+                if (s->ub[(size_t)i] < ub_seen[(size_t)i]) { ub_seen[(size_t)i] = s->ub[(size_t)i]; bound_quiet[(size_t)i] = 0; }
+                else ++bound_quiet[(size_t)i];
+            }
             // the finished launch's multipliers (rounded to quarters) become the prices of the next K-search launches
             if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
             if (!det && s->bound_ms_last > 0) {
@@ -297,8 +314,13 @@ struct SolveRun {
         for (int i = 0; i < n && !all_done; ++i) {
             const bool want = feasible(i) && objective(i) < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
                               !(s->dual_flags[(size_t)i] & 6);
-            dual_target[(size_t)i] = want ? objective(i) : -1;
-            any |= want;
+            bool rest = false;
+            if (want && det && bound_quiet[(size_t)i] >= bound_quiet_max &&
+                (int64_t)topics[i].n_partitions * topics[i].rf > bound_rest_slots)
+                rest = (++bound_turn[(size_t)i] % bound_duty) != 0;
+            dual_target[(size_t)i] = want && !rest ? objective(i) : -1;
+            bound_ran[(size_t)i] = want && !rest;
+            any |= want && !rest;
         }
         bound_pending = false;
         if (any) {

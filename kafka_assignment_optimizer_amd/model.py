@@ -46,6 +46,19 @@ class Topic:
     def rf_cur(self) -> int:
         return int(self.current.shape[1])
 
+    @classmethod
+    def from_dict(cls, d: dict) -> "Topic":
+        """A topic from its plain-JSON form (the layout of the fixtures under tests/golden/: broker_ids, rack_of, n_racks,
+        n_partitions, rf, current rows, weights, bounds_override, optional broker_w / broker_wl)."""
+        P = int(d["n_partitions"])
+        return cls(name=str(d.get("name", "t")), broker_ids=np.array(d["broker_ids"], dtype=np.int32),
+                   rack_of=np.array(d["rack_of"], dtype=np.uint8), n_racks=int(d["n_racks"]), n_partitions=P, rf=int(d["rf"]),
+                   current=np.array(d["current"], dtype=np.uint16).reshape(P, -1),
+                   weights=tuple(tuple(int(x) for x in w) for w in d.get("weights", DEFAULT_WEIGHTS)),
+                   bounds_override=dict(d.get("bounds_override", {})),
+                   broker_w=None if d.get("broker_w") is None else np.array(d["broker_w"], dtype=np.int32),
+                   broker_wl=None if d.get("broker_wl") is None else np.array(d["broker_wl"], dtype=np.int32))
+
 
 def topics_from_json(doc: dict, broker_list: Sequence[int], racks: Dict, rf: Optional[int] = None,
                      weights=DEFAULT_WEIGHTS) -> List[Topic]:

@@ -310,6 +310,7 @@ static void ls_init(const ls_topic *t, ls_state *s, const port_params *pp, uint3
 typedef struct { int type, p, k, q, j; unsigned x; int dV, dObj; } proposal;
 
 /* move type of global iteration `it` (wave-uniform on the GPU) */
+#define SCAN_TWO_SLOTS 24576 /* REPLACE scan: two tournament slots per iteration on topics of at most this many replica slots (kScanTwoSlots) */
 static inline int move_type(uint32_t it) {
     static const uint8_t pat[8] = {0, 0, 1, 0, 2, 0, 1, 0}; /* 0 replace, 1 exchange, 2 leader swap */
     return pat[it & 7];
@@ -480,7 +481,7 @@ static uint32_t ls_propose(const ls_topic *t, ls_state *s, int type, uint32_t it
             /* REPLACE scan: the slot of the best lane, then the slot of the best OTHER lane (none when no other lane takes part) */
             int n_slots = 1, sp[2], sk[2];
             sp[0] = p; sk[0] = k;
-            if (type == 0) {
+            if (type == 0 && P * RF <= SCAN_TWO_SLOTS) {
                 uint32_t k2 = KEY_NULL; const uint32_t wA = keyA & 63u;
                 for (uint32_t l = 0; l < LANES; ++l)
                     if (l != wA && lkey[l] < k2) { k2 = lkey[l]; sp[1] = lp[l]; sk[1] = lk[l]; }
@@ -950,8 +951,8 @@ static inline int32_t db_move(int32_t m, int64_t step, int sh, int k, int32_t d,
 }
 
 /* Runs up to `iters` dual iterations from the state (a[B], l[B], g[R] multipliers; da[B], dl[B], dg[R] previous
- * direction; lv[4] level-control state and step counter, zeros to start; *best_L), all in/out (zeros and INT64_MAX to start).  Needs P*RF <= 2^17 and P*RF*max(w) <= 2^19 (32-bit
- * headroom of the priced values).  flags: 1 = closed (best_L < (target+1)*DB_SCALE), 2 = zero subgradient (dual optimum reached),
+ * direction; lv[4] level-control state and step counter, zeros to start; *best_L), all in/out (zeros and INT64_MAX to start).  Needs P*RF <= 2^20, 4096 (P*RF)^2 (2B+R) < 2^62 and
+ * P*RF*max(w) <= 2^25 (round 4; rounds 1-3: P*RF <= 2^17 -- the arithmetic below never needed that).  flags: 1 = closed (best_L < (target+1)*DB_SCALE), 2 = zero subgradient (dual optimum reached),
  * 4 = a partition subproblem is infeasible (no bound).  Returns the number of iterations performed. */
 int kao_port_dual_bound_rec(const port_topic *t, int64_t target, int32_t iters, int32_t *a, int32_t *l, int32_t *g,
                             int32_t *da, int32_t *dl, int32_t *dg, int64_t *lv, int64_t *best_L, int32_t *flags,

@@ -514,6 +514,26 @@ def test_config5_as_one_topic(kao, ko, kp):
     assert tm["results_read_back"] < 1.0                                 # north_star: time-to-optimal <= 1 s
 
 
+def test_drifted_north_star_topic_gets_a_dual_certificate(kao, ko, kp):
+    """Round 4: the north-star size after a 20 % drift (1000 brokers x 100,000 partitions: nothing the init could simply keep).
+    K-bound's limit on P * RF moved from 2^17 to 2^20, so the topic gets a Lagrangian certificate instead of the closed-form
+    bound (786,857; first GPU run: 782,651 after 3 s with the incumbent at 782,074).  No exact solver can check the optimum at
+    this size: what is asserted is the sandwich incumbent <= certificate < closed-form bound and that the gap is small."""
+    from kafka_assignment_optimizer_amd import synthetic
+    pt = synthetic.north_star_topic("drift100k")
+    ot = _oracle_topic(ko, pt)
+    closed = kao.upper_bound(pt)
+    kao.solve([pt], seed=1, max_launches=1)   # warm allocation of the big arenas
+    r = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=3.0)[0]
+    tm = kao.last_solve_timing()
+    print(f"drifted 1000 x 100k: {r.status} objective {r.objective} certificate {r.upper_bound} (closed form {closed}) "
+          f"launches {tm['launches']} K-bound iterations {tm['bound_iters']}")
+    obj, viol = kp.port_eval(ot, r.assignment)
+    assert viol[0] == 0 and obj == r.objective <= r.upper_bound
+    assert tm["bound_iters"] > 0 and r.upper_bound < closed - 2000
+    assert r.upper_bound - r.objective <= 0.0015 * r.upper_bound
+
+
 def test_large_topic_fewer_waves_per_workgroup(kao, ko, kp):
     """A 3000-partition topic (9000 replicas, 1000 brokers) does not fit LDS with four restarts per workgroup;
     the same kernel runs it with two, and the scalar replay still matches bit for bit."""
@@ -922,6 +942,7 @@ def test_dual_bound_replay_large_shapes(kao, ko, kp, monkeypatch, chunk):
         (400, 200, 150, 2, [5, 6, 7], [(400, 3)], None, 1),
         (64, 4, 500, 4, [1], [(64, 2), (65, 3)], 3, 3),
         (130, 1, 257, 1, [0, 129], [], 2, 5),
+        (60, 4, 50000, 3, [3], [(60, 1)], None, 60),     # round 4: 150,000 replica slots -- beyond the 2^17 of rounds 1-3 (kao_model.cpp dual_supported)
     ]
     for i, (B, R, P, rf, rm, add, new_rf, off) in enumerate(shapes):
         ot = ko.make_cluster(f"shape{i}", B, R, 1, P, rf, rm, add, new_rf=new_rf).topics[0]
@@ -1230,6 +1251,28 @@ def test_solve_capped_matches_the_exact_joint_optimum_on_toys(kao, ko):
         assert total <= c["objective"] < c["objective_without_caps"]
         # round 3: K-bound prices weighted topics, so every round yields a Lagrangian bound -- and it meets the exact optimum
         assert lb is not None and 0 <= lb - c["objective"] <= 1, (c["seed"], lb, c["objective"])
-        assert total >= 0.98 * c["objective"], (c["seed"], total, c["objective"])
         equal += total == c["objective"]
-    assert equal >= (2 * len(cases)) // 3, equal   # GPU call 32: 4 of 6 (the other two 2 units = 1-1.7 % below), bound == optimum on all
+    assert equal == len(cases), equal   # round 3: 4 of 6 (the other two 2 units below); round 4 (KAO-CX slack nodes per rack): all six
+
+
+def test_solve_capped_on_the_medium_golden(kao, ko):
+    """Round 4: cluster-wide caps beyond toys -- 20 topics x 64 partitions on 60 brokers with 12 capped
+    brokers, and 12 x 48 on 40 (tests/golden/capped_medium.json: exact joint optimum by HiGHS, make_golden_capped_medium.py).
+    The plan respects every cap and every topic's own rows and is sandwiched plan <= exact optimum <= Lagrangian bound; first
+    GPU run: 9165 / 9175 / 9195 and 4093 / 4097 / 4100 (plan / exact / bound) in 0.2 s."""
+    for c in load_golden("capped_medium.json")["cases"]:
+        ots = [ko.topic_from_dict(d) for d in c["topics"]]
+        cap = np.array(c["replica_cap"])
+        res, lb = kao.solve_capped([to_product_topic(t) for t in ots], cap, seed=c["seed"], time_limit_s=20, max_rounds=60)
+        load = np.zeros(len(cap), dtype=int)
+        total = 0
+        for ot, r in zip(ots, res):
+            assert r.status in ("FEASIBLE_BOUND_GAP", "OPTIMAL_PROVEN"), (c["seed"], r.status)
+            obj, viol = ko.verify(ot, r.assignment)
+            assert viol[0] == 0 and obj == r.objective
+            total += obj
+            np.add.at(load, r.assignment.reshape(-1).astype(int), 1)
+        assert (load <= cap).all(), (c["seed"], load.tolist(), cap.tolist())
+        assert total <= c["objective"] < c["objective_without_caps"]
+        assert lb is not None and c["objective"] <= lb <= 1.003 * c["objective"], (c["seed"], lb, c["objective"])
+        assert total >= 0.998 * c["objective"], (c["seed"], total, c["objective"])
