@@ -143,17 +143,21 @@ def load_profile_constants(tag, iters, restarts_total):
     return None
 
 
-def load_big_constants(which):
-    """Per-kernel counter figures of the north-star workloads (tools/profile_big.sh -> profiles/r03_big_<which>_constants.json)."""
+def load_big_constants(which, restarts):
+    """Per-kernel counter figures of the north-star workloads (tools/profile_big.sh -> profiles/r0N_<tag>_big_<which>_constants.json):
+    the latest profile taken with THIS restart count (traffic per launch scales with it), else None (-> traffic: null)."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_big_%s_constants.json" % which)))   # the latest tag wins
-    if not paths:
-        return None
-    path = paths[-1]
-    try:
-        with open(path) as f:
-            c = json.load(f)
-    except (OSError, ValueError):
+    c = path = None
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_big_%s_constants.json" % which)), reverse=True):   # the latest tag first
+        try:
+            with open(cand) as f:
+                cc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if cc.get("steps", {}).get("restarts") == restarts:
+            c, path = cc, cand
+            break
+    if c is None:
         return None
     out = {"source": "profiles/" + os.path.basename(path)}
     for k, v in c.items():
@@ -473,7 +477,7 @@ def main():
         big = []
         for which in ("drift30k", "drift100k", "cfg5one"):
             st = synthetic.north_star_steps(kao, which, launches=4)     # automatic restart count: 4 per compute unit (round 4)
-            prof_b = load_big_constants(which)
+            prof_b = load_big_constants(which, st["restarts"])
             e = {"workload": which, "brokers": st["brokers"], "partitions": st["partitions"], "restarts": st["restarts"],
                  "iters_per_launch": st["iters_per_launch"], "wall_ms_per_step": st["wall_ms_per_launch"], "drift": st["drift"]}
             for kern, ms, algo in (("k_search", st["k_search_ms_per_launch"], st["k_search_algorithmic_bytes_per_launch"]),

@@ -39,6 +39,7 @@ constexpr int kCxBias = 1 << 16;
 constexpr int kCxLevels = 3;
 constexpr int kCxLayers = 3;      // 0 F (follower moves), 1 S (role swaps), 2 L (leader replacements)
 constexpr int kCxMaxEval = 512;
+constexpr int64_t kCxBulkSlots = 131072;   // beyond: cycle candidates are merged before they are scored (cx_round, bulk mode)
 constexpr int kCxMaxRF = 8;
 // The per-partition kernels (k_cx_edges, k_cx_edges_l, k_cx_seeds) keep a row and the rows derived from it in small per-thread
 // arrays indexed at run time; instantiated for MR = 4 (RF <= 4: the arrays stay in registers) and MR = 8 (RF 5..8) like K-search
@@ -92,6 +93,13 @@ template <int MR> __device__ __forceinline__ bool cx_completes(const CxParams &q
     return b.ndef == 1 && cnt < q.prack_lo && cnt + 1 >= q.prack_lo;
 }
 
+// atomicMin behind a plain look (round 4): keys only ever decrease, so a key that does not beat the value read -- however stale --
+// cannot beat the current one either.  At 1000 x 100,000 every partition offered 2,000 keys to a table of 10^6 entries (2e8
+// 64-bit atomics a build); nearly all of them lose to what is already there.  Same table, bit for bit.
+__device__ __forceinline__ void cx_offer(unsigned long long *e, unsigned long long key) {
+    if (key < __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(e, key);   // agent scope: read at L2, where the atomics land
+}
+
 // ---- edges: one wavefront per partition -------------------------------------------------------------------------------
 template <int MR>
 __global__ __launch_bounds__(256) void k_cx_edges(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack,
@@ -114,14 +122,14 @@ __global__ __launch_bounds__(256) void k_cx_edges(CxParams q, const uint16_t *A,
                 if (in || !cx_completes(q, cb, rack[v])) continue;
                 const int cost = wu - cx_wt(q, c, v, 1);
                 const unsigned long long key = ((unsigned long long)(unsigned)(cost + kCxBias) << 32) | (unsigned)(p * q.RF + k);
-                atomicMin(&EF[(size_t)u * q.np + v], key);
+                cx_offer(&EF[(size_t)u * q.np + v], key);
             }
         }
         if (lane == 0) {
             const int a = row[0];
             const int cs = cx_wt(q, c, a, 0) + cx_wt(q, c, u, 1) - cx_wt(q, c, u, 0) - cx_wt(q, c, a, 1);
             const unsigned long long key = ((unsigned long long)(unsigned)(cs + kCxBias) << 32) | (unsigned)(p * q.RF + k);
-            atomicMin(&ES[(size_t)a * q.np + u], key);
+            cx_offer(&ES[(size_t)a * q.np + u], key);
         }
     }
 }
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
             for (int v = lane; v < q.B; v += 64) {
                 if (inrow(v) || !cx_completes(q, cb, rack[v])) continue;
                 const int cost = wlu - cx_wt(q, c, v, 0);
-                if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 0, 0, 0));
+                if (cost < kCxInf / 2) cx_offer(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 0, 0, 0));
             }
     }
     if (plain_only) return;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
                 for (int v = lane; v < q.B; v += 64) {
                     if (inrow(v) || !cx_completes(q, cb, rack[v])) continue;
                     const int cost = w0 - (cx_wt(q, c, v, 0) + wfu + osum) + comp;
-                    if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 1, k, 0));
+                    if (cost < kCxInf / 2) cx_offer(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 1, k, 0));
                 }
         }
         {   // 2 promote: v = row[k]; row' = (v; y, others), best y
@@ -206,12 +214,12 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
             best = cx_wave_min(best);
             if (lane == 0 && best != LLONG_MAX) {
                 const long long cost = best / 4096 - (1ll << 30);
-                if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + b], cx_lkey((int)cost, p, 2, k, (int)(best % 4096)));
+                if (cost < kCxInf / 2) cx_offer(&EL[(size_t)u * q.np + b], cx_lkey((int)cost, p, 2, k, (int)(best % 4096)));
             }
         }
         if (lane == 0) {   // 3 swap
             const int cost = wlu + cx_wt(q, c, b, 1) - cx_wt(q, c, b, 0) - wfu + DF[(size_t)u * q.np + b];
-            if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + b], cx_lkey(cost, p, 3, k, 0));
+            if (cost < kCxInf / 2) cx_offer(&EL[(size_t)u * q.np + b], cx_lkey(cost, p, 3, k, 0));
         }
         // 4 double: new leader v (not in the row) and slot k takes y; v or y is a current replica i of the partition
         for (int ii = 0; ii < q.rfc; ++ii) {
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
                 for (int v = lane; v < q.B; v += 64) {
                     if (inrow(v) || v == i || !cx_completes(q, cb, rack[v])) continue;
                     const int cost = w0 - (cx_wt(q, c, v, 0) + wfi + osum) + compi;
-                    if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 4, k, i));
+                    if (cost < kCxInf / 2) cx_offer(&EL[(size_t)u * q.np + v], cx_lkey(cost, p, 4, k, i));
                 }
             }
             {   // (b) v = i, best y
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
                 best = cx_wave_min(best);
                 if (lane == 0 && best != LLONG_MAX) {
                     const long long cost = best / 4096 - (1ll << 30);
-                    if (cost < kCxInf / 2) atomicMin(&EL[(size_t)u * q.np + i], cx_lkey((int)cost, p, 4, k, (int)(best % 4096)));
+                    if (cost < kCxInf / 2) cx_offer(&EL[(size_t)u * q.np + i], cx_lkey((int)cost, p, 4, k, (int)(best % 4096)));
                 }
             }
         }
@@ -766,19 +774,26 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     if (rc) return rc;
     const double tt1 = api_now_s();
     // ---- candidates ----
-    std::vector<CxCand> cyc;
-    for (int l = 0; l < kCxLayers; ++l)
-        for (int v = 1; v <= kCxLevels; ++v) {
-            const int32_t *dg = &cx.diag[((size_t)l * kCxLevels + (v - 1)) * q.B];
-            bool any = false;
-            for (int b = 0; b < q.B; ++b) if (dg[b] < 0) { cyc.push_back({-dg[b], l, v, b}); any = true; }
-            if (any) break;
-        }
+    const char *bulk_env = std::getenv("KAO_CX_BULK_SLOTS");   // test hook (read every round: tests switch it)
+    const int64_t bulk_slots = bulk_env && *bulk_env ? (int64_t)std::atoll(bulk_env) : kCxBulkSlots;
+    const bool bulk_topic = (int64_t)q.P * q.RF > bulk_slots;
+    auto collect = [&](bool all_levels) {   // the lowest level of every layer that has a negative diagonal entry; every such level in bulk mode
+        std::vector<CxCand> cyc;
+        for (int l = 0; l < kCxLayers; ++l)
+            for (int v = 1; v <= kCxLevels; ++v) {
+                const int32_t *dg = &cx.diag[((size_t)l * kCxLevels + (v - 1)) * q.B];
+                bool any = false;
+                for (int b = 0; b < q.B; ++b) if (dg[b] < 0) { cyc.push_back({-dg[b], l, v, b}); any = true; }
+                if (any && !all_levels) break;
+            }
+        std::sort(cyc.begin(), cyc.end(), [](const CxCand &x, const CxCand &y) {
+            return x.total != y.total ? x.total > y.total : (x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.c < y.c)); });
+        return cyc;
+    };
+    std::vector<CxCand> cyc = collect(bulk_topic);
     std::vector<CxCand> cands;
     const bool cycles = !cyc.empty();
     if (cycles) {
-        std::sort(cyc.begin(), cyc.end(), [](const CxCand &x, const CxCand &y) {
-            return x.total != y.total ? x.total > y.total : (x.a != y.a ? x.a < y.a : x.c < y.c); });
         cands = cyc;
     } else {
         if ((rc = cx.seeds())) return rc;
@@ -807,8 +822,15 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
         for (size_t i : order) { sig.push_back(r.used[i]); for (int k = 0; k < q.RF; ++k) sig.push_back(r.rows[i * q.RF + k]); }
         if (seen.insert(sig).second) reals.push_back(std::move(r));
     };
+    // Bulk mode (round 4; topics beyond kCxBulkSlots replica slots, cycle candidates): every candidate is unrolled, a
+    // partition-disjoint set is taken in candidate order BEFORE any scoring, and only its merges (all, half, a quarter, ... , the
+    // best candidate alone) are scored exactly -- a dozen K-eval candidates instead of 512 (drifted 1000 x 100,000: 512 of 512
+    // realisations improved in nearly every round, scoring them one by one was a quarter of a round).  A round whose merges
+    // all fail falls through to the one-by-one path.
+    const bool bulk = cycles && bulk_topic;
+    const int max_real = bulk ? 8 * kCxMaxEval : kCxMaxEval;
     for (const CxCand &cd : cands) {
-        if ((int)reals.size() >= kCxMaxEval) break;
+        if ((int)reals.size() >= max_real) break;
         if (cycles) {
             const int layer = cd.a, lev = cd.b, b = cd.c;
             const int m = cx.hM[layer][lev][(size_t)b * q.np + b];
@@ -870,6 +892,49 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     stats[2] += (int32_t)reals.size();
     if (reals.empty()) return 0;
     const double tt4 = api_now_s();
+    if (bulk) {
+        std::vector<char> taken((size_t)q.P, 0);
+        std::vector<int> chosen;
+        for (size_t i = 0; i < reals.size(); ++i) {
+            bool clash = false;
+            for (int u : reals[i].used) clash = clash || taken[(size_t)u];
+            if (clash) continue;
+            for (int u : reals[i].used) taken[(size_t)u] = 1;
+            chosen.push_back((int)i);
+        }
+        std::vector<int> sizes;
+        for (int k = (int)chosen.size(); k >= 1; k /= 2) sizes.push_back(k);
+        std::vector<CxReal> merges(sizes.size());
+        std::vector<const CxReal *> ms(sizes.size());
+        for (size_t m = 0; m < sizes.size(); ++m) {
+            for (int c = 0; c < sizes[m]; ++c) {
+                const CxReal &r = reals[(size_t)chosen[(size_t)c]];
+                merges[m].used.insert(merges[m].used.end(), r.used.begin(), r.used.end());
+                merges[m].rows.insert(merges[m].rows.end(), r.rows.begin(), r.rows.end());
+            }
+            ms[m] = &merges[m];
+        }
+        std::vector<int32_t> o1, v1;
+        if ((rc = cx.eval_patched(ms, o1, v1))) return rc;
+        int win = -1;
+        for (size_t m = 0; m < sizes.size(); ++m)
+            if (v1[m * 8] == 0 && o1[m] > base && (win < 0 || o1[m] > o1[(size_t)win])) win = (int)m;
+        if (win >= 0) {
+            const CxReal &winner = merges[(size_t)win];
+            std::memcpy(assign, cx.A.data(), slots * 2);
+            for (size_t u = 0; u < winner.used.size(); ++u)
+                std::memcpy(&assign[(size_t)winner.used[u] * q.RF], &winner.rows[u * q.RF], (size_t)q.RF * 2);
+            *new_obj = o1[(size_t)win];
+            stats[3] += sizes[(size_t)win];
+            if (sizes[(size_t)win] > 1) stats[5] += sizes[(size_t)win];
+            if (trace)
+                std::fprintf(stderr, "[kao-cx] cycles (bulk) build %.2f ms, candidates %zu in %.2f ms, paths %.2f ms, %zu realisations %.2f ms, eval+merge %.2f ms: %d -> %d (%d merged of %zu partition-disjoint)\n",
+                             (tt1 - tt0) * 1e3, cands.size(), (tt2 - tt1) * 1e3, (tt3 - tt2) * 1e3, reals.size(), (tt4 - tt3) * 1e3,
+                             (api_now_s() - tt4) * 1e3, base, *new_obj, sizes[(size_t)win], chosen.size());
+            return 1;
+        }
+        if (reals.size() > (size_t)kCxMaxEval) reals.resize((size_t)kCxMaxEval);   // one by one: the best kCxMaxEval candidates
+    }
     // ---- exact evaluation by K-eval ----
     const size_t n = reals.size();
     std::vector<const CxReal *> rs(n);

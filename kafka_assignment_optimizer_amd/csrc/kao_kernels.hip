@@ -536,11 +536,13 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
     // tuple (the kernarg load) that the allocator spills and restores WHOLE -- three times per iteration, 24 v_readlane
     int lam_lo = prm.lam_min, lam_hi = prm.lam_max;
     uint32_t n_iters = prm.iters, it_base = prm.launch * prm.iters;
+    uint32_t scan_two = TD->P * TD->RF <= prm.scan2_max ? 1u : 0u;   // REPLACE scan over two tournament slots (topics up to kScanTwoSlots replica slots)
     {   // through a VGPR and back: a plain scalar copy is coalesced with the tuple again
-        uint32_t v0 = (uint32_t)lam_lo, v1 = (uint32_t)lam_hi, v2 = n_iters, v3 = it_base;
-        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+        uint32_t v0 = (uint32_t)lam_lo, v1 = (uint32_t)lam_hi, v2 = n_iters, v3 = it_base, v4 = scan_two;
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4));
         lam_lo = (int)__builtin_amdgcn_readfirstlane(v0); lam_hi = (int)__builtin_amdgcn_readfirstlane(v1);
         n_iters = __builtin_amdgcn_readfirstlane(v2); it_base = __builtin_amdgcn_readfirstlane(v3);
+        scan_two = __builtin_amdgcn_readfirstlane(v4);
     }
     for (uint32_t i = 0; i < n_iters; ++i) {
         const uint32_t it = it_base + i;
@@ -769,7 +771,7 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
             // the two moves is the proposal (ties: the first slot's).  Loop head, penalty, acceptance and bookkeeping are paid once
             // for twice the neighbours (they were two thirds of the instruction stream at 500 brokers, docs/notes_r03.md section 6).
             int wA2 = -1;
-            if (type == 0 && TD->P * TD->RF <= prm.scan2_max) {   // (large topics scan one slot: their iterations are what they are short of)
+            if (type == 0 && scan_two) {   // (large topics scan one slot: their iterations are what they are short of)
                 const uint32_t k2 = wave_umin(lane == wA1 ? kKeyNull : keyA);
                 wA2 = k2 == kKeyNull ? -1 : (int)(k2 & 63u);   // (no other lane takes part: one slot)
             }

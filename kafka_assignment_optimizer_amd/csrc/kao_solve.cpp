@@ -55,10 +55,14 @@ DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
     auto env_l = [](const char *name, int64_t dflt) { const char *e = std::getenv(name); return e && *e ? (int64_t)std::atoll(e) : dflt; };
     // Beyond a few thousand partitions a launch takes 5-15 ms and KAO-CX is what carries the incumbent (1000 x 30000, 3 s:
     // 231,529 with a call every 6 / 36 launches, 231,159 with 24 / 144), so the counts shrink with the topic.
-    const int64_t stall_l = slots <= 16384 ? 24 : (slots <= 32768 ? 12 : 6);
+    // Round 4, beyond 131,072 slots: of a 3-s solve of the drifted 1000 x 100,000 topic KAO-CX's 97 rounds (0.93 s) brought ALL of
+    // the 4,275 units gained after the first feasible incumbent, K-search's 126 launches (2 s) none -- there KAO-CX runs after
+    // every launch, up to 48 rounds a call (a call ends at the first round that finds nothing).
+    const bool huge = slots > 131072;
+    const int64_t stall_l = slots <= 16384 ? 24 : (slots <= 32768 ? 12 : (huge ? 1 : 6));
     d.cx_stall_iters = it * env_l("KAO_DET_CX_STALL_L", stall_l);
-    d.cx_due_iters = it * env_l("KAO_DET_CX_DUE_L", 6 * stall_l);
-    d.cx_rounds = slots <= 32768 ? 12 : 6;
+    d.cx_due_iters = it * env_l("KAO_DET_CX_DUE_L", huge ? 1 : 6 * stall_l);
+    d.cx_rounds = (int)env_l("KAO_DET_CX_ROUNDS", slots <= 32768 ? 12 : (huge ? 48 : 6));
     return d;
 }
 
@@ -74,7 +78,7 @@ struct SolveRun {
     std::vector<int64_t> dual_target;
     double t0 = 0, t_last_improve = 0;
     int launches = 0, dual_iters = 0, dual_now = 0;
-    // K-bound back-off (round 4, deterministic schedule, topics beyond kBoundRestSlots replica slots): a K-bound launch beside
+    // K-bound back-off (round 4, deterministic schedule, topics beyond `bound_rest_slots` replica slots): a K-bound launch beside
     // K-search costs the search more than half its speed there (1000 x 100,000: a K-search launch 6.8 ms alone, 14-19 ms beside
     // K-bound; 1000 x 30,000: 4.0 / 8.4) while the certificate of such a topic stops moving after a second (782,651 from 2.0 s
     // to 10 s with the incumbent still 500 units away).  A topic whose certificate has not moved for kBoundQuiet merged launches
@@ -82,7 +86,7 @@ struct SolveRun {
     std::vector<int64_t> ub_seen;
     std::vector<int> bound_quiet, bound_turn;
     std::vector<char> bound_ran;
-    int64_t bound_rest_slots = 32768;
+    int64_t bound_rest_slots = 131072;   // (1000 x 30000, 90,000 slots: the rest costs 20-40 units of incumbent and some certificate; 1000 x 100,000: it gains 100-200)
     int bound_quiet_max = 6, bound_duty = 8;
     bool use_prices = true, all_done = false;
     // KAO-CX (kao_cycle.hip): cyclic-exchange improvement of incumbents K-search has stopped improving
@@ -156,6 +160,18 @@ struct SolveRun {
             int r = std::min(std::max((cu * 32 / n_topics) / kWaves * kWaves, 8), 8192);
             r = std::min<int>(r, (int)std::max<int64_t>(cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves));
             so_x.restarts = std::max((r / k) / kWaves * kWaves, 2 * kWaves);
+        }
+        if (k == 1 && so.restarts <= 0 && user_topics) {
+            // Topics that live in HBM: a session on its own fills the chip with 4 restarts per compute unit (kao_session_create), the
+            // solve keeps one per compute unit -- beside K-bound and KAO-CX depth pays, breadth does not (3-s solves, seeds 3 / 4,
+            // 256 against 1024 restarts: 1000 x 30000 231,530 / 231,522 against 231,511 / 231,522; 1000 x 100,000 with the K-bound
+            // back-off 782,227 / 782,261 against 782,118 / 782,079; profiles/r04_f_large_topic_restarts.txt)
+            int64_t slots = 1;
+            for (int i = 0; i < n_topics; ++i) slots = std::max<int64_t>(slots, (int64_t)user_topics[i].n_partitions * std::max(user_topics[i].rf, 1));
+            if (slots >= 32768 && !require_init()) {
+                const int cu = std::max(num_cu(cur_device()), 1);
+                so_x.restarts = (int)std::max<int64_t>(cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves);
+            }
         }
         n = n_topics = (int)xt.size();
         int rc = kao_session_create(topics, n_topics, &so_x, &s);
@@ -1018,7 +1034,13 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
         if (topics[i].broker_w || topics[i].broker_wl) return fail(KAO_ERR_UNSUPPORTED, "kao_solve_capped: topics with their own broker weights");
         for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) wmax = std::max(wmax, topics[i].w[a][b]);
     }
-    const int mu_max = std::min(1023, 4 * wmax);   // a price above every objective weight already repels every replica
+    // Price granularity F (price units per objective unit).  Quarter units (F = 4: every role weight times 4 inside the per-topic
+    // solves, prices in steps of 1/4) were tried in round 4 and tightened the Lagrangian bound of the medium golden (exact joint
+    // optimum 9175: bound 9195 with whole prices, 9189 with quarters; the 12-topic case 4100 -> 4097 = exact) -- but K-search's
+    // penalty range is tuned to the README's weights 1..4, with weights 4..16 per-topic solves come back infeasible and whole
+    // rounds yield no cap-respecting plan (GPU calls 13-15).  So F = 1; the code below is written for any F.
+    const int F = 1;
+    const int mu_max = std::min(1023, 4 * wmax * F);   // a price above every objective weight already repels every replica
     kao_opts o{};
     if (opts) o = *opts;
     const double limit = o.time_limit_s > 0 ? o.time_limit_s : 10.0;
@@ -1026,18 +1048,32 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
     if (o.max_launches <= 0) o.max_launches = 6;
     o.stop_at_bound = 1;
     o.target_objective = nullptr;
-    std::vector<int32_t> mu((size_t)B, 0), bw((size_t)B, 0);
+    std::vector<int32_t> mu((size_t)B, 0), bw((size_t)B, 0), mu_inc((size_t)B, 0);
     std::vector<kao_topic> tp(topics, topics + n_topics);
+    for (int i = 0; i < n_topics; ++i)
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) tp[(size_t)i].w[a][b] = topics[i].w[a][b] * F;
     std::vector<std::vector<uint16_t>> buf((size_t)n_topics), inc((size_t)n_topics);
     std::vector<kao_result> res((size_t)n_topics), inc_res((size_t)n_topics);
     for (int i = 0; i < n_topics; ++i) buf[(size_t)i].assign((size_t)topics[i].n_partitions * topics[i].rf, (uint16_t)KAO_NONE);
-    int64_t inc_total = -1, best_L = INT64_MAX, n_slots = 0;
+    int64_t inc_total = -1, best_L = INT64_MAX, n_slots = 0;   // inc_total in objective units, best_L = floor(dual value in objective units)
     for (int i = 0; i < n_topics; ++i) n_slots += (int64_t)topics[i].n_partitions * topics[i].rf;
     std::vector<int64_t> load((size_t)B);
-    int rc = KAO_OK, r = 0;
-    for (; r < rounds; ++r) {
+    auto floor_div = [](int64_t a, int64_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    // Rounds 0 .. rounds-1: WHOLE objective units (F price units), the loop of rounds 2-3.  Then up to rounds/2 more: with a
+    // cap-respecting plan in hand, quarter units restarted from THAT plan's prices (with quarter steps from the start -- or from the
+    // last prices -- the medium golden found no cap-respecting plan at all, and a toy lost two units: GPU calls 13 / 14); without
+    // one, prices only rise (every broker over its cap, by its excess) until a plan respects the caps.
+    int rc = KAO_OK, r = 0, fine_from = -1;
+    bool raise_only = false;
+    const int rounds_all = rounds + rounds / 2;
+    for (; r < rounds_all; ++r) {
         const double left = limit - (now_s() - t0);
         if (r > 0 && left <= 0) break;
+        if (r >= rounds && fine_from < 0 && !raise_only) {
+            if (inc_total >= 0 && F > 1) { fine_from = r; mu = mu_inc; }
+            else if (inc_total < 0) raise_only = true;
+            else break;
+        }
         int M = 0;
         for (int b = 0; b < B; ++b) M = std::max(M, mu[(size_t)b]);
         for (int b = 0; b < B; ++b) bw[(size_t)b] = M - mu[(size_t)b];   // weights must be >= 0: a constant M per replica does not change any argmax
@@ -1046,7 +1082,7 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
             res[(size_t)i] = kao_result{};
             res[(size_t)i].assignment = buf[(size_t)i].data();
         }
-        o.time_limit_s = std::max(0.05, left / std::max(1, std::min(rounds - r, 8)));
+        o.time_limit_s = std::max(0.05, left / std::max(1, std::min(rounds_all - r, 8)));
         o.seed = (opts ? opts->seed : 0) + (uint64_t)r * 0x9E3779B97F4A7C15ull;
         rc = (devices && n_dev > 1) ? kao_solve_multi(tp.data(), n_topics, devices, n_dev, &o, res.data())
                                     : kao_solve(tp.data(), n_topics, &o, res.data());
@@ -1054,7 +1090,7 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
         // ---- broker loads over ALL topics (the allreduce(SUM) of a sharded deployment), objective without the weights ----
         std::fill(load.begin(), load.end(), 0);
         bool all_feasible = true;
-        int64_t total = 0, total_w = 0;
+        int64_t total = 0, total_w = 0;   // in 1/F units
         for (int i = 0; i < n_topics; ++i) {
             const kao_result &x = res[(size_t)i];
             if (x.status == KAO_STATUS_NO_FEASIBLE || x.status == KAO_STATUS_INFEASIBLE_PROVEN) { all_feasible = false; continue; }
@@ -1071,32 +1107,98 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
         }
         // L(mu) <= sum of ANY valid per-topic upper bounds of the weighted topics - M * slots + mu . cap: round 3 -- K-bound now covers
         // weighted topics, so the per-topic bounds are (nearly) the weighted optima whether or not the search has met them
-        if (all_feasible) best_L = std::min(best_L, total_w - (int64_t)M * n_slots + priced);
-        if (all_feasible && worst <= 0 && total > inc_total) {   // respects every cap: a candidate answer
-            inc_total = total;
+        if (all_feasible) best_L = std::min(best_L, floor_div(total_w - (int64_t)M * n_slots + priced, F));
+        if (all_feasible && worst <= 0 && total / F > inc_total) {   // respects every cap: a candidate answer
+            inc_total = total / F;
+            mu_inc = mu;
             for (int i = 0; i < n_topics; ++i) {
                 inc[(size_t)i] = buf[(size_t)i];
                 inc_res[(size_t)i] = res[(size_t)i];
                 int64_t wsum = 0;
                 for (uint16_t b : buf[(size_t)i]) wsum += M ? bw[b] : 0;
-                inc_res[(size_t)i].objective = res[(size_t)i].objective - wsum;
+                inc_res[(size_t)i].objective = (res[(size_t)i].objective - wsum) / F;
             }
         }
         if (inc_total >= 0 && best_L != INT64_MAX && inc_total >= best_L) break;   // incumbent meets the Lagrangian bound: optimal
-        // ---- projected subgradient step on the prices, diminishing: alpha = 1 / (1 + r / 3) ----
-        const int den = 1 + r / 3;
+        // ---- projected subgradient step on the prices, diminishing: alpha = 1 / (1 + r / 3) price units of the phase ----
+        const bool fine = fine_from >= 0;
+        const int rr = fine ? r - fine_from : (raise_only ? 0 : r);
+        const int den = 1 + rr / 3;
+        const int unit = fine ? 1 : F;
+        if (raise_only && worst <= 0) break;   // the plan just booked respects every cap
         bool moved = false;
         for (int b = 0; b < B; ++b) {
             if (replica_cap[b] < 0) continue;
             const int64_t ex = load[(size_t)b] - replica_cap[b];
             int d = 0;
-            if (ex > 0) d = (int)std::max<int64_t>(1, ex / den);
-            else if (ex < 0 && mu[(size_t)b] > 0) d = -(int)std::min<int64_t>(mu[(size_t)b], std::max<int64_t>(r >= 6 ? 0 : 1, (-ex) / (2 * den)));
+            if (ex > 0) d = unit * (int)std::max<int64_t>(1, ex / den);
+            else if (ex < 0 && mu[(size_t)b] > 0 && !raise_only)
+                d = -(int)std::min<int64_t>(mu[(size_t)b], unit * std::max<int64_t>(rr >= 6 ? 0 : 1, (-ex) / (2 * den)));
             const int nm = std::min(mu_max, std::max(0, mu[(size_t)b] + d));
             moved |= nm != mu[(size_t)b];
             mu[(size_t)b] = nm;
         }
-        if (!moved) break;   // prices are stationary
+        if (!moved) {   // prices are stationary: the coarse phase hands over (to the fine one or to raise-only), the others end
+            if (fine || raise_only || r >= rounds - 1) break;
+            r = rounds - 1;
+        }
+    }
+    // ---- repair (round 4): one topic at a time from the incumbent plan.  Capped brokers that ended BELOW their cap were priced a
+    // little too high for somebody: every topic in turn is solved again alone with those brokers one price unit cheaper (all
+    // others as in the incumbent's round), and the new plan of that topic is taken when the topic's own objective grows and no
+    // cap breaks.  Passes repeat while one of them gained and the clock allows.
+    int repairs = 0;
+    if (!rc && inc_total >= 0 && !(best_L != INT64_MAX && inc_total >= best_L)) {
+        std::fill(load.begin(), load.end(), 0);
+        for (int i = 0; i < n_topics; ++i) for (uint16_t b : inc[(size_t)i]) load[b]++;
+        std::vector<int32_t> mu_t((size_t)B), bw_t((size_t)B);
+        std::vector<uint16_t> one;
+        bool gained = true;
+        for (int pass = 0; pass < 4 && gained && !rc; ++pass) {
+            gained = false;
+            for (int i = 0; i < n_topics && !rc; ++i) {
+                if (limit - (now_s() - t0) <= 0) break;
+                bool any_slack = false;
+                for (int b = 0; b < B; ++b) {
+                    const bool slack = replica_cap[b] >= 0 && load[(size_t)b] < replica_cap[b] && mu_inc[(size_t)b] > 0;
+                    mu_t[(size_t)b] = slack ? std::max(0, mu_inc[(size_t)b] - (pass % 2 ? 2 : 1)) : mu_inc[(size_t)b];
+                    any_slack |= slack;
+                }
+                if (!any_slack) break;
+                int M = 0;
+                for (int b = 0; b < B; ++b) M = std::max(M, mu_t[(size_t)b]);
+                for (int b = 0; b < B; ++b) bw_t[(size_t)b] = M - mu_t[(size_t)b];
+                kao_topic t1 = tp[(size_t)i];
+                t1.broker_w = M ? bw_t.data() : nullptr;
+                one.assign(inc[(size_t)i].size(), (uint16_t)KAO_NONE);
+                kao_result r1{};
+                r1.assignment = one.data();
+                o.time_limit_s = std::max(0.02, std::min(0.25, limit - (now_s() - t0)));
+                o.seed = (opts ? opts->seed : 0) + 0xD1B54A32D192ED03ull * (uint64_t)(pass * n_topics + i + 1);
+                rc = kao_solve(&t1, 1, &o, &r1);
+                if (rc) break;
+                if (r1.status == KAO_STATUS_NO_FEASIBLE || r1.status == KAO_STATUS_INFEASIBLE_PROVEN) continue;
+                int64_t wsum = 0;
+                for (uint16_t b : one) wsum += M ? bw_t[b] : 0;
+                const int64_t obj1 = (r1.objective - wsum) / F;
+                if (obj1 <= inc_res[(size_t)i].objective) continue;
+                bool ok = true;
+                for (uint16_t b : inc[(size_t)i]) load[b]--;
+                for (uint16_t b : one) load[b]++;
+                for (int b = 0; b < B && ok; ++b) ok = replica_cap[b] < 0 || load[(size_t)b] <= replica_cap[b];
+                if (!ok) {
+                    for (uint16_t b : one) load[b]--;
+                    for (uint16_t b : inc[(size_t)i]) load[b]++;
+                    continue;
+                }
+                inc_total += obj1 - inc_res[(size_t)i].objective;
+                inc[(size_t)i] = one;
+                inc_res[(size_t)i] = r1;
+                inc_res[(size_t)i].objective = obj1;
+                gained = true;
+                ++repairs;
+            }
+        }
     }
     if (!rc) {
         for (int i = 0; i < n_topics; ++i) {
@@ -1114,7 +1216,7 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
         }
         if (lagrangian_bound) *lagrangian_bound = best_L;
     }
-    g_timing[3] = now_s() - t0; g_timing[4] = r;
+    g_timing[3] = now_s() - t0; g_timing[4] = r; (void)repairs;
     return rc;
 }
 

@@ -41,6 +41,7 @@ NO_SLOT = 0xFFFFFFFF
 NO_EDGE = 0xFFFFFFFFFFFFFFFF
 LEVELS = 3          # squarings: paths of <= 2**LEVELS edges
 MAX_EVAL = 512      # realisations evaluated per round
+BULK_SLOTS = 131072  # topics beyond this many replica slots: cycle candidates are merged BEFORE they are scored (round_step, bulk mode)
 MAX_RF = 8
 
 
@@ -271,16 +272,19 @@ class Round:
                             put(u, [i], [int(cy[y])], np.array([int(pb) | (4 << 16) | (k << 12) | y], dtype=np.uint64))
         self.EL = EL
     # ---- candidates ----
-    def cycle_candidates(self) -> List[Tuple[int, int, int, int]]:
-        """(gain, layer, level, b) of the lowest level of each layer that has a negative diagonal entry."""
+    def cycle_candidates(self, all_levels: bool = False) -> List[Tuple[int, int, int, int]]:
+        """(gain, layer, level, b) of the lowest level of each layer that has a negative diagonal entry -- of EVERY level that has
+        one when `all_levels` (bulk mode, round 4: the longer walks of the higher levels often use other partitions than the
+        short ones, and a bulk round keeps whatever is partition-disjoint)."""
         out = []
         for layer, Ds in ((0, self.DF), (1, self.DS), (2, self.DL)):
             for lev in range(1, LEVELS + 1):
                 dg = np.diag(Ds[lev])[: self.B]
                 if (dg < 0).any():
                     out += [(int(-dg[b]), layer, lev, int(b)) for b in np.nonzero(dg < 0)[0]]
-                    break
-        out.sort(key=lambda c: (-c[0], c[1], c[3]))
+                    if not all_levels:
+                        break
+        out.sort(key=lambda c: (-c[0], c[1], c[2], c[3]))
         return out
 
     def row_weight(self, p: int, row) -> int:
@@ -484,9 +488,9 @@ class Round:
                 out.append((X, used))
         return out
 
-    def realisations(self):
-        """Up to MAX_EVAL (assignment, used partitions) in candidate order; duplicates (same used set and rows) dropped."""
-        cyc = self.cycle_candidates()
+    def realisations(self, limit: int = MAX_EVAL, all_levels: bool = False):
+        """Up to `limit` (assignment, used partitions) in candidate order; duplicates (same used set and rows) dropped."""
+        cyc = self.cycle_candidates(all_levels)
         out, seen = [], set()
         cands = [("c", c) for c in cyc] if cyc else [("s", c) for c in self.seed_candidates()]
         for kind, c in cands:
@@ -496,7 +500,7 @@ class Round:
                     continue
                 seen.add(sig)
                 out.append((X, used))
-                if len(out) >= MAX_EVAL:
+                if len(out) >= limit:
                     return out
         return out
 
@@ -507,12 +511,38 @@ def evaluate(t, X) -> Tuple[int, int]:
     return int(obj), int(np.asarray(viol).sum() if np.ndim(viol) else viol)
 
 
-def round_step(t, A, evaluator=evaluate):
-    """One round.  Returns (new assignment or None, info)."""
+def round_step(t, A, evaluator=evaluate, bulk_slots: int = BULK_SLOTS):
+    """One round.  Returns (new assignment or None, info).
+    Bulk mode (round 4; topics of more than `bulk_slots` replica slots whose round has cycle candidates): up to 8 * MAX_EVAL
+    candidates are unrolled, a partition-disjoint set is taken in candidate order BEFORE any scoring, and only its merges -- the
+    first m, m/2, m/4, ..., 1 of them -- are scored; the best feasible improving merge wins (ties: the larger).  A round none of
+    whose merges improves falls through to the one-by-one path on the first MAX_EVAL realisations."""
     rd = Round(t, A)
     base, v0 = evaluator(t, rd.A)
     assert v0 == 0, "KAO-CX starts from a feasible assignment"
-    reals = rd.realisations()
+    bulk = t.n_partitions * t.rf > bulk_slots and bool(rd.cycle_candidates())
+    reals = rd.realisations(8 * MAX_EVAL if bulk else MAX_EVAL, all_levels=bulk)
+    if bulk:
+        chosen, taken = [], set()
+        for X, used in reals:
+            if used & taken:
+                continue
+            chosen.append((X, used))
+            taken |= used
+        win = None
+        k = len(chosen)
+        while k >= 1:
+            merged = rd.A.copy()
+            for X, used in chosen[:k]:
+                for q in used:
+                    merged[q] = X[q]
+            o, v = evaluator(t, merged)
+            if v == 0 and o > base and (win is None or o > win[0]):
+                win = (o, k, merged)
+            k //= 2
+        if win is not None:
+            return win[2].astype(np.uint16), dict(base=base, realisations=len(reals), improving=win[1], objective=win[0], merged=win[1], bulk=True)
+        reals = reals[:MAX_EVAL]
     good = []
     for idx, (X, used) in enumerate(reals):
         o, v = evaluator(t, X)
@@ -548,11 +578,11 @@ def round_step(t, A, evaluator=evaluate):
     return out.astype(np.uint16), info
 
 
-def improve(t, A, max_rounds: int = 64, evaluator=evaluate):
+def improve(t, A, max_rounds: int = 64, evaluator=evaluate, bulk_slots: int = BULK_SLOTS):
     A = np.asarray(A).astype(np.uint16).reshape(t.n_partitions, t.rf)
     hist = []
     for _ in range(max_rounds):
-        X, info = round_step(t, A, evaluator)
+        X, info = round_step(t, A, evaluator, bulk_slots)
         hist.append(info)
         if X is None:
             break

@@ -89,6 +89,30 @@ def test_drifted_topics_match_the_oracle(kao, ko, kp, shape):
     assert int(np.asarray(v).sum()) == 0 and o == obj >= st["objective_before"]
 
 
+@pytest.mark.parametrize("shape", [(60, 3, 200, 3), (45, 5, 130, 2), (48, 6, 160, 4), (100, 5, 1000, 3)])
+def test_bulk_mode_matches_the_oracle(kao, ko, kp, shape, monkeypatch):
+    """Round 4: the bulk mode of a KAO-CX round (topics beyond 131,072 replica slots: cycle candidates are merged before they
+    are scored) forced onto small topics (test hook KAO_CX_BULK_SLOTS=0; oracle round_step(bulk_slots=0)): same assignment
+    after every call, feasible, never worse -- from an immature incumbent, where rounds have many cycle candidates."""
+    import kao_cycle as kc
+    B, R, P, rf = shape
+    pt, t = _drifted(ko, B, R, P, rf)
+    for iters in (128, 512, 2048):              # the first feasible incumbent: plenty of improving cycles left
+        r = kp.port_search(t, 3, 0, 1, iters)
+        if r["best_obj"] >= 0:
+            break
+    assert r["best_obj"] >= 0
+    a = r["best"]
+    monkeypatch.setenv("KAO_CX_BULK_SLOTS", "0")
+    rounds = 64 if P <= 200 else 4              # (the oracle is pure Python)
+    Xo, hist = kc.improve(t, a, rounds, bulk_slots=0)
+    Xg, obj, st = kao.improve_cycles(pt, a, rounds)
+    assert np.array_equal(np.asarray(Xo).reshape(-1), Xg.reshape(-1))
+    assert any(h.get("bulk") for h in hist)
+    o, v = ko.verify(t, Xg)
+    assert int(np.asarray(v).sum()) == 0 and o == obj >= st["objective_before"]
+
+
 def test_fixpoint_on_a_1000_partition_topic_is_feasible_and_better(kao, ko, kp):
     pt, t = _drifted(ko, 100, 5, 1000)
     a = kp.port_search(t, 3, 0, 30, 512)["best"]
@@ -223,4 +247,4 @@ def test_solve_with_eager_cycles_on_the_wide_family(kao, ko, monkeypatch):
         assert viol[0] == 0 and obj == r.objective <= c["objective"], c["seed"]
         n_equal += r.objective == c["objective"]
         n_proven += r.status == "OPTIMAL_PROVEN"
-    assert n_equal >= n_opt - 2 and n_proven >= n_opt - 6, (n_opt, n_equal, n_proven)
+    assert n_equal == n_opt and n_proven >= n_opt - 1, (n_opt, n_equal, n_proven)   # round 4: 175 / 175 / 175 (tools/tol_probe.py, GPU call 14)

@@ -668,7 +668,7 @@ def test_golden_optima_random_medium(kao, ko):
         if c.get("unique"):
             assert kao.canonicalize(pt, r.assignment).tolist() == ko.canonicalize(ot, np.array(c["assignment"])).tolist(), c["seed"]
             n_unique += 1
-    assert n_opt >= 70 and n_unique >= 5 and n_proven >= n_opt // 2
+    assert n_opt >= 70 and n_unique >= 5 and n_proven >= n_opt - 1, (n_opt, n_proven)   # round 4: 77 of 77 proven (tools/tol_probe.py, GPU call 14)
 
 
 @pytest.mark.parametrize("name", ["cfg2.json", "cfg3.json", "cfg4.json"])
@@ -800,9 +800,31 @@ def test_slack_band_certificate_meets_the_lp_value(kao, ko):
                   n_partitions=t.n_partitions, rf=t.rf, current=np.array(t.current), weights=t.weights)
     r = kao.solve([t], seed=3, time_limit_s=4.0)[0]
     lp = int(round(row["lp_value"]))
-    assert lp <= r.upper_bound <= lp + 1, (r.upper_bound, lp)
+    assert r.upper_bound == lp, (r.upper_bound, lp)
     obj, viol = ko.verify(ot, r.assignment)
-    assert viol[0] == 0 and obj == r.objective <= lp and lp - r.objective <= 25
+    # round 4 (KAO-CX with one slack node per rack): 16456 on this seed, proven 16459 on seeds 1 and 2 (round 3: 8-21 units short)
+    assert viol[0] == 0 and obj == r.objective <= lp and lp - r.objective <= 3
+    for seed in (1, 2):
+        r = kao.solve([t], seed=seed, time_limit_s=8.0, stop_at_bound=1)[0]
+        assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", lp, lp), (seed, r.status, r.objective, r.upper_bound)
+
+
+@pytest.mark.parametrize("B,R,P", [(350, 7, 2500), (450, 9, 3500)])
+def test_more_slack_band_topics(kao, ko, B, R, P):
+    """Round 4: the other slack-band topics VERDICT r03 named (incumbents 8-21 units below the LP value then).  350 x 2500 (LP
+    18751): proven optimal for three seeds.  450 x 3500 (LP 26330): the incumbent EQUALS the LP value for three seeds -- it is
+    optimal -- but K-bound's certificate stalls 6-7 units above it (the subgradient method on the kinks of three slack-band
+    families; docs/notes_r04.md section 5), so the status stays TIME_LIMIT."""
+    row = [r for r in load_golden("drift_scale.json")["rows"] if (r["B"], r["R"], r["P"]) == (B, R, P)][0]
+    lp = int(round(row["lp_value"]))
+    t = _drift_topic(B, R, P)
+    for seed in (1, 2, 3):
+        r = kao.solve([t], seed=seed, time_limit_s=4.0 if P > 3000 else 8.0, stop_at_bound=1)[0]
+        assert r.objective == lp, (seed, r.objective, lp)
+        if P > 3000:
+            assert lp <= r.upper_bound <= lp + 8, (seed, r.upper_bound, lp)
+        else:
+            assert (r.status, r.upper_bound) == ("OPTIMAL_PROVEN", lp), (seed, r.status, r.upper_bound)
 
 
 def test_further_kao_cx_starts(kao, ko, monkeypatch):
@@ -818,8 +840,14 @@ def test_further_kao_cx_starts(kao, ko, monkeypatch):
     other = load_golden("drift_scale.json")["rows_other_seeds"][0]
     from kafka_assignment_optimizer_amd import synthetic as sy
     t2 = sy.drift(sy.make_cluster(other["B"], other["R"], 1, other["P"], 3, [], []), 0.2, other["seed"])[0]
-    r2 = kao.solve([t2], seed=3, time_limit_s=4.0)[0]
-    assert r2.upper_bound == other["milp_objective"] and other["milp_objective"] - 2 <= r2.objective <= other["milp_objective"]
+    # round 4 (tools/tol_probe.py, GPU call 14): solver seeds 2 and 5 prove the MILP optimum 14801 inside 4 s, seed 3 inside 8 s;
+    # seeds 1 and 4 end at 14800 / 14799 under the certificate 14801 (round 3: 14799 / 14801 / 14800 for seeds 3 / 4 / 5 in 3 s)
+    for seed in (2, 3, 5):
+        r2 = kao.solve([t2], seed=seed, time_limit_s=14.0, stop_at_bound=1)[0]
+        assert (r2.status, r2.objective, r2.upper_bound) == ("OPTIMAL_PROVEN", other["milp_objective"], other["milp_objective"]), (seed, r2.status, r2.objective)
+    for seed in (1, 4):
+        r2 = kao.solve([t2], seed=seed, time_limit_s=4.0)[0]
+        assert r2.upper_bound == other["milp_objective"] and other["milp_objective"] - 2 <= r2.objective <= other["milp_objective"], (seed, r2.objective)
     monkeypatch.setenv("KAO_DET_CX_STARTS", "0")
     kao.solve([t], seed=3, time_limit_s=20.0, max_launches=200)
     assert kao.last_solve_timing()["cx_further_starts"] == 0
@@ -827,22 +855,16 @@ def test_further_kao_cx_starts(kao, ko, monkeypatch):
 
 @pytest.mark.parametrize("B,R,P", [(400, 8, 3000), (250, 5, 4000)])
 def test_drift_scale_certificates_meet_the_lp_value(kao, ko, B, R, P):
-    """The larger rows of drift_scale.json (only the LP relaxation finished on the CPU: 2,438 s / hours): within 6 s the device
-    certificate equals floor(LP value) and the incumbent is within a few units of it, for three seeds.  (At 3 s the 4,000-partition
-    certificate is sometimes still one unit above -- 29944 against 29943, GPU call 9 of round 3 -- the limit only decides how many
-    launches of the count-keyed schedule fit.)"""
+    """The larger rows of drift_scale.json (only the LP relaxation finished on the CPU: 2,438 s / hours): the device proves the
+    optimum -- incumbent == certificate == floor(LP value) -- for three seeds (round 4; the limit only decides how many launches
+    of the count-keyed schedule fit: all six solves ended inside 6 s on the GPU box)."""
     row = [r for r in load_golden("drift_scale.json")["rows"] if (r["B"], r["R"], r["P"]) == (B, R, P)][0]
     t = _drift_topic(B, R, P)
-    exact = 0
     for seed in (1, 2, 3):
-        r = kao.solve([t], seed=seed, time_limit_s=6.0)[0]
-        # never below floor(LP) (the certificate is a valid bound), at most one unit above it inside the budget: with the common
-        # shifts taken at every launch (k_bound_center) the last half unit of the slack-band 400 x 3000 topic takes longer on
-        # some trajectories (seed 2: 22587 after 6 s, GPU call 28) while its incumbent ends 2-4 below instead of 7-9
-        assert int(row["lp_value"]) <= r.upper_bound <= int(row["lp_value"]) + 1, (seed, r.upper_bound, row["lp_value"])
-        exact += r.upper_bound == int(row["lp_value"])
-        assert r.status in ("OPTIMAL_PROVEN", "TIME_LIMIT") and r.upper_bound - r.objective <= 12, (seed, r.objective, r.upper_bound)
-    assert exact >= 2, exact
+        r = kao.solve([t], seed=seed, time_limit_s=12.0, stop_at_bound=1)[0]
+        # round 4: proven for all three seeds inside 6 s (tools/tol_probe.py, GPU call 14); round 3 accepted a certificate one unit
+        # above floor(LP) and incumbents up to 12 units below it
+        assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", int(row["lp_value"]), int(row["lp_value"])), (seed, r.status, r.objective, r.upper_bound)
 
 
 # ------------------------------------------------------------------------------- K-bound (Lagrangian dual certificate)
