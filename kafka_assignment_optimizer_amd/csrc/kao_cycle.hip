@@ -75,9 +75,12 @@ template <int MR> __device__ __forceinline__ CxBase<MR> cx_base(const CxParams &
     CxBase<MR> o;
     o.nb = nb; o.over = false;
     int distinct = 0, deficient_present = 0;
+#pragma unroll
     for (int i = 0; i < nb; ++i) o.rk[i] = rack[base[i]];
+#pragma unroll
     for (int i = 0; i < nb; ++i) {
         int cnt = 0; bool first = true;
+#pragma unroll
         for (int j = 0; j < nb; ++j) { cnt += o.rk[j] == o.rk[i]; first = first && !(j < i && o.rk[j] == o.rk[i]); }
         if (cnt > q.prack_hi) o.over = true;
         if (first) { ++distinct; deficient_present += cnt < q.prack_lo; }
@@ -87,6 +90,7 @@ template <int MR> __device__ __forceinline__ CxBase<MR> cx_base(const CxParams &
 }
 template <int MR> __device__ __forceinline__ bool cx_completes(const CxParams &q, const CxBase<MR> &b, int ry) {
     int cnt = 0;
+#pragma unroll
     for (int i = 0; i < b.nb; ++i) cnt += b.rk[i] == ry;
     if (cnt + 1 > q.prack_hi) return false;
     if (b.ndef == 0) return true;
@@ -153,22 +157,43 @@ __device__ __forceinline__ long long cx_wave_min(long long v) {
     }
     return v;
 }
-template <int MR>
+// DFt[b][y] = DF[y][b]: k_cx_edges_l reads the compensation DF[y][b] for EVERY entering broker y (lane = y) of a fixed b -- one
+// cache line per lane in DF's row-major layout (3,000 such reads per partition: most of the kernel's time at 1000 x 100,000),
+// consecutive words in the transpose.  64 x 64 tiles through LDS; np is a multiple of 64.
+__global__ __launch_bounds__(256) void k_cx_transpose(int np, const int32_t *__restrict__ D, int32_t *__restrict__ Dt) {
+    __shared__ int32_t tile[64][65];
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = D[(size_t)(by + r) * np + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) Dt[(size_t)(bx + r) * np + by + tx] = tile[tx][r];
+}
+
+// KRF: the replication factor as a compile-time constant (2..4 with MR = 4; 0 = read it from q).  Round 4: with a run-time RF
+// the loops over the row stay rolled, `row[k]`, `others[no++]`, `base[nb++]` are indexed at run time and the arrays live in
+// scratch (32 B per lane even at MR = 4) -- and `inrow`, called for every target broker, reads them from there: 1.74 ms per call
+// at 1000 x 30000, 3.6 ms at 1000 x 100,000.  With RF known every index is a constant and the rows stay in registers.
+template <int MR, int KRF>
 __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *A, const uint16_t *cur, const uint8_t *rack, const int32_t *DF,
-                                                    int plain_only, unsigned long long *EL) {
+                                                    const int32_t *DFt, int plain_only, unsigned long long *EL) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (p >= q.P) return;
-    const int RF = q.RF;
+    const int RF = KRF ? KRF : q.RF;
     int row[MR];
+    #pragma unroll
     for (int k = 0; k < RF; ++k) row[k] = A[(size_t)p * RF + k];
     const uint16_t *c = cur + (size_t)p * q.rfc;
     const int u = row[0];
     int w0 = cx_wt(q, c, u, 0);
+    #pragma unroll
     for (int k = 1; k < RF; ++k) w0 += cx_wt(q, c, row[k], 1);
     const int wlu = cx_wt(q, c, u, 0), wfu = cx_wt(q, c, u, 1);
-    auto inrow = [&](int x) { bool in = false; for (int j = 0; j < RF; ++j) in = in || row[j] == x; return in; };
+    auto inrow = [&](int x) { bool in = false;
+#pragma unroll
+        for (int j = 0; j < RF; ++j) in = in || row[j] == x;
+        return in; };
     {   // 0 plain
         int base[MR]; int nb = 0;
+        #pragma unroll
         for (int j = 1; j < RF; ++j) base[nb++] = row[j];
         const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
         if (!cb.over && cb.ndef <= 1)
@@ -179,13 +204,16 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
             }
     }
     if (plain_only) return;
+    #pragma unroll
     for (int k = 1; k < RF; ++k) {
         const int b = row[k];
         int others[MR], no = 0, osum = 0;
+        #pragma unroll
         for (int j = 1; j < RF; ++j) if (j != k) { others[no++] = row[j]; osum += cx_wt(q, c, row[j], 1); }
         {   // 1 demote: row' = (v; u, others)
             int base[MR]; int nb = 0;
             base[nb++] = u;
+            #pragma unroll
             for (int j = 0; j < no; ++j) base[nb++] = others[j];
             const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
             const int comp = DF[(size_t)u * q.np + b];
@@ -199,6 +227,7 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
         {   // 2 promote: v = row[k]; row' = (v; y, others), best y
             int base[MR]; int nb = 0;
             base[nb++] = b;
+            #pragma unroll
             for (int j = 0; j < no; ++j) base[nb++] = others[j];
             const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
             long long best = LLONG_MAX;
@@ -206,7 +235,7 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
                 const int wlv = cx_wt(q, c, b, 0);
                 for (int y = lane; y < q.B; y += 64) {
                     if (inrow(y) || !cx_completes(q, cb, rack[y])) continue;
-                    const long long cost = (long long)w0 - (wlv + cx_wt(q, c, y, 1) + osum) + DF[(size_t)y * q.np + b];
+                    const long long cost = (long long)w0 - (wlv + cx_wt(q, c, y, 1) + osum) + DFt[(size_t)b * q.np + y];
                     const long long key = (cost + (1ll << 30)) * 4096 + y;
                     best = key < best ? key : best;
                 }
@@ -226,6 +255,7 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
             const int i = c[ii];
             if (i >= q.B || inrow(i)) continue;
             int base[MR]; int nb = 0;
+            #pragma unroll
             for (int j = 0; j < no; ++j) base[nb++] = others[j];
             base[nb++] = i;
             const CxBase<MR> cb = cx_base<MR>(q, rack, base, nb);
@@ -244,7 +274,7 @@ __global__ __launch_bounds__(256) void k_cx_edges_l(CxParams q, const uint16_t *
                 const int wli = cx_wt(q, c, i, 0);
                 for (int y = lane; y < q.B; y += 64) {
                     if (inrow(y) || y == i || !cx_completes(q, cb, rack[y])) continue;
-                    const long long cost = (long long)w0 - (wli + cx_wt(q, c, y, 1) + osum) + DF[(size_t)y * q.np + b];
+                    const long long cost = (long long)w0 - (wli + cx_wt(q, c, y, 1) + osum) + DFt[(size_t)b * q.np + y];
                     const long long key = (cost + (1ll << 30)) * 4096 + y;
                     best = key < best ? key : best;
                 }
@@ -480,6 +510,7 @@ struct Cx {
     int32_t *d_bw = nullptr;                        // broker weights bw[B] | bwl[B] (topics that carry them)
     unsigned long long *d_E[kCxLayers] = {};
     int32_t *d_D[kCxLayers][kCxLevels + 1] = {};
+    int32_t *d_DFt = nullptr;                      // transpose of the level-3 F closure (k_cx_edges_l)
     uint16_t *d_M[kCxLayers][kCxLevels + 1] = {};
     int2 *d_table = nullptr;
     uint16_t *d_cand = nullptr; int32_t *d_obj = nullptr, *d_viol = nullptr;
@@ -495,7 +526,7 @@ struct Cx {
 
     ~Cx() {
         (void)hipFree(d_A); (void)hipFree(d_cur); (void)hipFree(d_rack); (void)hipFree(d_cnt); (void)hipFree(d_bw); (void)hipFree(d_table);
-        (void)hipFree(d_cand); (void)hipFree(d_obj); (void)hipFree(d_viol); (void)hipFree(d_pq); (void)hipFree(d_prow);
+        (void)hipFree(d_DFt); (void)hipFree(d_cand); (void)hipFree(d_obj); (void)hipFree(d_viol); (void)hipFree(d_pq); (void)hipFree(d_prow);
         for (int l = 0; l < kCxLayers; ++l) {
             (void)hipFree(d_E[l]);
             for (int v = 0; v <= kCxLevels; ++v) { (void)hipFree(d_D[l][v]); (void)hipFree(d_M[l][v]); }
@@ -525,6 +556,7 @@ struct Cx {
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_rack), (size_t)q.B));
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_cnt), ((size_t)q.B * 2 + (size_t)q.R) * 4));
         CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_table), (size_t)q.P * q.ncfg * sizeof(int2)));
+        CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_DFt), nn * 4));
         for (int l = 0; l < kCxLayers; ++l) {
             CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_E[l]), nn * 8));
             for (int v = 0; v <= kCxLevels; ++v) {
@@ -582,8 +614,14 @@ struct Cx {
         // the L graph prices its compensations on the F closure: only when F has no improving cycle of its own
         int f_neg = 0;
         for (size_t i = 0; i < (size_t)kCxLevels * q.B; ++i) f_neg |= diag[i] < 0;
-        if (q.RF <= 4) hipLaunchKernelGGL(k_cx_edges_l<4>, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], f_neg, d_E[2]);
-        else hipLaunchKernelGGL(k_cx_edges_l<8>, dim3((q.P + 3) / 4), dim3(256), 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], f_neg, d_E[2]);
+        if (!f_neg) hipLaunchKernelGGL(k_cx_transpose, dim3(q.np / 64, q.np / 64), dim3(256), 0, stream, q.np, d_D[0][kCxLevels], d_DFt);   // (plain_only reads no compensation)
+        {
+            const dim3 gl((q.P + 3) / 4), bl(256);
+            if (q.RF == 2) hipLaunchKernelGGL((k_cx_edges_l<4, 2>), gl, bl, 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_DFt, f_neg, d_E[2]);
+            else if (q.RF == 3) hipLaunchKernelGGL((k_cx_edges_l<4, 3>), gl, bl, 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_DFt, f_neg, d_E[2]);
+            else if (q.RF == 4) hipLaunchKernelGGL((k_cx_edges_l<4, 4>), gl, bl, 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_DFt, f_neg, d_E[2]);
+            else hipLaunchKernelGGL((k_cx_edges_l<8, 0>), gl, bl, 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_DFt, f_neg, d_E[2]);
+        }
         hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[2], d_cnt, d_rack, 2, 44, d_D[2][0]);   // L: no slack edges
         for (int v = 1; v <= kCxLevels; ++v)
             hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[2][v - 1], d_D[2][v], d_M[2][v]);
@@ -790,7 +828,7 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
             return x.total != y.total ? x.total > y.total : (x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.c < y.c)); });
         return cyc;
     };
-    std::vector<CxCand> cyc = collect(bulk_topic);
+    std::vector<CxCand> cyc = collect(bulk_topic);   // (every level on small topics too: hard family 12 / 12 / 12 of 14 against 12 / 11 / 13 -- no gain, GPU call 18)
     std::vector<CxCand> cands;
     const bool cycles = !cyc.empty();
     if (cycles) {

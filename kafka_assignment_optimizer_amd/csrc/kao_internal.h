@@ -63,7 +63,10 @@ struct TopicDev {
     uint32_t bwd_off;            // bwd_pool : the same per DENSE index (u32[B]) for K-eval
     uint32_t cnt_off;            // cnt_pool : NR[B] NL[B] NK[kRackTab] of the sliced K-bound (k_bound_step), zero between steps; x 3 (the
                                  //            rotating buffers of k_bound_multi), then its shadow area a[B] l[B] g[kRackTab] ra[B] rl[B] rg[kRackTab]
-    int32_t pad_[2];
+    uint32_t hole_off;           // cur_pool   : first word of the topic's hole list {n leader holes, n follower holes, partitions with a leader
+                                 //              hole ascending, partitions with a follower hole ascending} (round 4: the init walks it instead of
+                                 //              inspecting every partition twice)
+    int32_t pad_[1];
 };
 
 struct SearchParams {

@@ -447,23 +447,22 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
         // ---- hole filling by best insertion, holes in (p,k) order.  Partitions are inspected 64 at a time (one per
         //      lane); only those with a hole are visited, in ascending order. ----
         // Two passes: leader holes of all partitions first, then follower holes (leaders are the scarcer resource).
+        // Round 4: the partitions that have a hole are listed by the host (TopicDev::hole_off: static, they depend on the current
+        // assignment only) -- inspecting all P partitions twice, 64 per trip with a global load each, was most of the 70-ms first
+        // launch of a 100,000-partition topic, holes or not.  Same holes, same order.
+        const uint32_t *HL = pl.cur_pool + TD->hole_off;
         if (!kTeam || wave == 0)   // (a team: its first wavefront fills the holes, in the same order as a single one)
-        for (int pass = 0; pass < 2; ++pass)
-        for (int pbase = 0; pbase < T.P; pbase += 64) {
-            bool has_hole = false;
-            if (pbase + lane < T.P) {
-                const Part<NW> al = L.A[pbase + lane];
-                bool fh = false;
-#pragma unroll
-                for (int k = 1; k < NW; ++k) fh |= (k < T.RF) & (al.w[k] == kNoneW);
-                has_hole = pass == 0 ? (al.w[0] == kNoneW) : fh;
-            }
-            unsigned long long todo = __ballot(has_hole);
-            while (todo) {
-                const int p = pbase + __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                Part<NW> a = L.A[p];  // same address in every lane: broadcast
-                const Part<NW> c = CUR[p];
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t n_holes = HL[pass], *hl = HL + 2 + (pass ? HL[0] : 0u);
+            // the next hole's rows are loaded while this one is scanned (a pass lists every partition once, so the rows of the next
+            // hole cannot be written by this one): config 5 as one topic has 15,000 holes, each two global round trips apart
+            int p_n = n_holes ? (int)hl[0] : 0;
+            Part<NW> a_n = L.A[p_n], c_n = CUR[p_n];
+            for (uint32_t hi = 0; hi < n_holes; ++hi) {
+                const int p = p_n;
+                Part<NW> a = a_n;  // same address in every lane: broadcast
+                const Part<NW> c = c_n;
+                if (hi + 1 < n_holes) { p_n = (int)hl[hi + 1]; a_n = L.A[p_n]; c_n = CUR[p_n]; }
 #pragma unroll
                 for (int k = 0; k < NW; ++k) {
                     if (k >= T.RF) break;
@@ -473,6 +472,7 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
                     const uint32_t hmix = slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * NW + k) * 0x27D4EB2Fu + 0x5BD1E995u + prm.gen * 0x632BE5ABu);
                     const int wl = k == 0 ? T.w00 : T.w01, wf = k == 0 ? T.w10 : T.w11;
                     uint32_t key = kKeyNull, xw_l = kNoneW;
+#pragma unroll 2
                     for (int base = 0; base < T.Bx; base += 64) {
                         const uint32_t x = (uint32_t)(base + lane);
                         const uint32_t r = XR[x];

@@ -542,6 +542,20 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         while (cur_pool.size() % 4) cur_pool.push_back(kNoneW);   // every topic's words start 16-byte aligned
         d.cur_off = (uint32_t)cur_pool.size();
         for (size_t i = 0; i < (size_t)d.P * d.nw; ++i) cur_pool.push_back(word(pt.cur_int[i]));  // LDS / register form of a replica: internal index | rack << 16
+        {   // the holes best insertion has to fill (slots below RF without a surviving replica): leader holes, then follower holes
+            d.hole_off = (uint32_t)cur_pool.size();
+            const size_t w0 = (size_t)d.cur_off;
+            std::vector<uint32_t> lead, foll;
+            for (int p = 0; p < d.P; ++p) {
+                bool fh = false;
+                for (int k = 1; k < d.RF; ++k) fh |= cur_pool[w0 + (size_t)p * d.nw + k] == kNoneW;
+                if (cur_pool[w0 + (size_t)p * d.nw] == kNoneW) lead.push_back((uint32_t)p);
+                if (fh) foll.push_back((uint32_t)p);
+            }
+            cur_pool.push_back((uint32_t)lead.size()); cur_pool.push_back((uint32_t)foll.size());
+            cur_pool.insert(cur_pool.end(), lead.begin(), lead.end());
+            cur_pool.insert(cur_pool.end(), foll.begin(), foll.end());
+        }
         const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw, s->any_bw, d.R) > 160 * 1024;
         s->topic_global[(size_t)t] = global_a;
         d.ext_off = (uint32_t)ext_pool.size();
