@@ -73,6 +73,14 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
     edges.clear();
     const double t_begin = now_s();
     if (t->rf < 2) return fail(KAO_ERR_UNSUPPORTED, "compound edges need a follower (RF >= 2)");
+    // the enumeration sweeps brokers x slots for every partition and the join is quadratic per leader pair -- 0.05 s
+    // at 300 x 2000, minutes and gigabytes at 1000 x 30000.  Beyond kPairsMaxWork partition-broker pairs the layer reports no
+    // edges (the caller sees a fixpoint), and it stops adding half-moves at kPairsMaxHalves.
+    constexpr int64_t kPairsMaxWork = 4000000, kPairsMaxHalves = 4000000;
+    if ((int64_t)t->n_partitions * t->n_brokers > kPairsMaxWork) {
+        if (stats) { stats[0] = stats[1] = stats[2] = 0; stats[3] = 0; }
+        return KAO_OK;
+    }
     int32_t bd[8];
     derive_bounds(t, bd);
     PairCtx cx{t, assignment, t->n_brokers, t->n_racks, t->n_partitions, t->rf, t->rf_cur, bd[6], bd[7]};
@@ -107,7 +115,7 @@ int pair_edges(const kao_topic *t, const uint16_t *assignment, int gmin, std::un
             int g = cx.wt(p, nrow[0], 0);
             for (int k = 1; k < RF; ++k) if (nrow[k] != kAny) g += cx.wt(p, nrow[k], 1);
             g -= w0;
-            if (g < gmin) return;
+            if (g < gmin || (int64_t)halves.size() >= kPairsMaxHalves) return;
             Half h{};
             h.p = p; h.gain = g;
             std::memcpy(h.row, nrow, sizeof(int) * (size_t)RF);

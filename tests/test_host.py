@@ -286,3 +286,29 @@ def test_pair_edges_match_the_oracle_prototype():
         n += 1
         n_edges += len(edges)
     assert n >= 8 and n_edges > 1000
+
+
+def test_topic_from_dict_reads_the_golden_layout(ko):
+    """The product's Topic.from_dict (what bench.py's capped_cluster leg reads tests/golden/capped_medium.json with) agrees with
+    the oracle's topic_from_dict field by field, and the C-side host helpers give the same bounds for both."""
+    import kafka_assignment_optimizer_amd as kao
+    from conftest import load_golden, to_product_topic
+    c = load_golden("capped_medium.json")["cases"][0]
+    for d in c["topics"][:4]:
+        pt, ot = kao.Topic.from_dict(d), ko.topic_from_dict(d)
+        via = to_product_topic(ot)
+        assert (pt.n_brokers, pt.n_racks, pt.n_partitions, pt.rf, pt.rf_cur) == (via.n_brokers, via.n_racks, via.n_partitions, via.rf, via.rf_cur)
+        assert np.array_equal(pt.current, via.current) and np.array_equal(pt.rack_of, via.rack_of) and np.array_equal(pt.broker_ids, via.broker_ids)
+        assert tuple(map(tuple, pt.weights)) == tuple(map(tuple, via.weights)) and pt.bounds_override == via.bounds_override
+        assert kao.derive_bounds(pt) == kao.derive_bounds(via) and kao.upper_bound(pt) == kao.upper_bound(via)
+
+
+def test_pair_enumeration_refuses_large_topics():
+    """the compound-edge enumeration (kao_pairs.cpp) is quadratic per leader pair; beyond 4,000,000 partition-broker
+    pairs it reports no edges instead of running for minutes (host only, no GPU needed)."""
+    import kafka_assignment_optimizer_amd as kao
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    pt = sy.make_cluster(500, 10, 1, 9000, 3, [], [])[0]          # 4.5e6 pairs, balanced start: a feasible assignment
+    X = np.ascontiguousarray(pt.current[:, :3], dtype=np.uint16)
+    got, st = kao.cycle_pair_edges(pt, X, -2)
+    assert st["half_moves"] == 0 and st["edges"] == 0 and (got == np.iinfo(np.int32).max).all()

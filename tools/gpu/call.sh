@@ -1,11 +1,17 @@
 #!/bin/bash
-# round 4, call 22 (row loads batched behind an acquire fence): k_bound_multi publishes a slice's counts as a row (plain stores) instead of B 64-bit atomics: replay tests on every
-# driver, microseconds per iteration (tools/bound_rate.py), a 3-s solve of 1000 x 30000
+# round 4, final state: whole GPU suite, smoke, bench.py with its extras, PMC passes of the bench (profiles/r04_z_*), hard family,
+# slack-band topics, large solves
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r04_c22
-(time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "dual or bound or certificate or slack or deterministic") > gpurun_out/${T}_pytest.log 2>&1
-tail -4 gpurun_out/${T}_pytest.log | cut -c1-300
-(time BOUND_RATE_SHAPES=300x6x2000,500x10x5000,500x10x10000,1000x20x30000 timeout 300 python tools/bound_rate.py multi:512:16 multi:1024:16) > gpurun_out/${T}_bound_rate.log 2>&1
-cat gpurun_out/${T}_bound_rate.log | cut -c1-300
-for sd in 3 4; do timeout 60 python tools/r4_probe.py solve drift30k 1 3.0 $sd 2>/dev/null | grep '^{' | cut -c1-420; done | tee gpurun_out/${T}_big.log
+T=r04_z
+(time timeout 1200 python -m pytest tests -m gpu -q) > gpurun_out/${T}_pytest.log 2>&1
+tail -6 gpurun_out/${T}_pytest.log | cut -c1-300
+(time timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')") > gpurun_out/${T}_smoke.log 2>&1
+tail -2 gpurun_out/${T}_smoke.log
+(time timeout 900 python bench.py) > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+cut -c1-400 gpurun_out/${T}_bench.json; tail -3 gpurun_out/${T}_bench.err
+(time timeout 600 bash tools/profile.sh r04_z 10) > gpurun_out/${T}_profile.log 2>&1
+tail -12 gpurun_out/${T}_profile.log | cut -c1-300
+(time R3_HARD=1 R3_SEEDS=3,4,5 R3_SCHEDS=0 timeout 400 python tools/r3_probe.py family 3.0) > gpurun_out/${T}_family.log 2>&1
+grep -h "proven [0-9]" gpurun_out/${T}_family.log
+for w in drift30k drift100k; do for lim in 1.0 3.0; do timeout 60 python tools/r4_probe.py solve $w 1 $lim 3 2>/dev/null | grep '^{' | cut -c1-260; done; done | tee gpurun_out/${T}_big.log
