@@ -86,7 +86,9 @@ typedef struct kao_opts {
     uint64_t seed;            /* search is deterministic in (seed, restarts, iters_per_launch) */
     double time_limit_s;      /* kao_solve: wall-clock limit; <= 0 = default 10 s */
     int32_t restarts;         /* parallel restarts (wavefronts) per topic; <= 0 = auto: one round of resident wavefronts
-                                 over all topics, fewer for very large topics (depth over breadth) */
+                                 over all topics, fewer for very large topics (depth over breadth): a session takes four per
+                                 compute unit on a topic whose assignment lives in HBM (>= 32,768 replica slots; that fills
+                                 every SIMD with a wavefront waiting on global loads), kao_solve one per compute unit */
     int32_t iters_per_launch; /* local-search iterations per K-search launch; <= 0 = 512 (sessions) / 128 (kao_solve) */
     int32_t max_launches;     /* kao_solve: stop after this many launches; <= 0 = unlimited */
     int32_t obj_scale;        /* S in cost = lam*violation - S*objective; <= 0 = 4 */

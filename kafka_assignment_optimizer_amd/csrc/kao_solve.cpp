@@ -59,7 +59,12 @@ DetPlan det_plan(int64_t slots, int maxB, int n_topics, int iters_per_launch) {
     // the 4,275 units gained after the first feasible incumbent, K-search's 126 launches (2 s) none -- there KAO-CX runs after
     // every launch, up to 48 rounds a call (a call ends at the first round that finds nothing).
     const bool huge = slots > 131072;
-    const int64_t stall_l = slots <= 16384 ? 24 : (slots <= 32768 ? 12 : (huge ? 1 : 6));
+    // Round 4, up to 16,384 slots: 8 / 48 launches instead of 24 / 144.  Round 3 had found that KAO-CX pays on a MATURE incumbent
+    // (first call after 32 launches: 10 of 24 drifted topics proven, after 144: 15); with the two-slot REPLACE scan and the
+    // per-rack slack nodes that is no longer so: the whole drifted family (24 topics x solver seeds 3 / 4 / 5, 3 s each) ends
+    // 68 of 72 proven in 41 s of wall time with 8 / 48 against 66 of 72 in 58 s with 24 / 144 (GPU call 24; 16 / 96 and 12 / 72
+    // on the hard half: 37 and 36 of 42 against 36 and 38).
+    const int64_t stall_l = slots <= 16384 ? 8 : (slots <= 32768 ? 12 : (huge ? 1 : 6));
     d.cx_stall_iters = it * env_l("KAO_DET_CX_STALL_L", stall_l);
     d.cx_due_iters = it * env_l("KAO_DET_CX_DUE_L", huge ? 1 : 6 * stall_l);
     d.cx_rounds = (int)env_l("KAO_DET_CX_ROUNDS", slots <= 32768 ? 12 : (huge ? 48 : 6));

@@ -531,7 +531,12 @@ def test_drifted_north_star_topic_gets_a_dual_certificate(kao, ko, kp):
     obj, viol = kp.port_eval(ot, r.assignment)
     assert viol[0] == 0 and obj == r.objective <= r.upper_bound
     assert tm["bound_iters"] > 0 and r.upper_bound < closed - 2000
-    assert r.upper_bound - r.objective <= 0.0015 * r.upper_bound
+    # round 4 (KAO-CX after every launch in bulk rounds): gaps 155-183 of 782,6xx after 3 s on four runs, 201-279 after 1 s
+    assert r.upper_bound - r.objective <= 0.0004 * r.upper_bound, (r.objective, r.upper_bound)
+    r1 = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=1.0)[0]          # north_star: what one second buys
+    obj1, viol1 = kp.port_eval(ot, r1.assignment)
+    assert viol1[0] == 0 and obj1 == r1.objective <= r1.upper_bound
+    assert r1.upper_bound - r1.objective <= 0.0006 * r1.upper_bound, (r1.objective, r1.upper_bound)
 
 
 def test_large_topic_fewer_waves_per_workgroup(kao, ko, kp):
@@ -802,7 +807,7 @@ def test_slack_band_certificate_meets_the_lp_value(kao, ko):
     lp = int(round(row["lp_value"]))
     assert r.upper_bound == lp, (r.upper_bound, lp)
     obj, viol = ko.verify(ot, r.assignment)
-    # round 4 (KAO-CX with one slack node per rack): 16456 on this seed, proven 16459 on seeds 1 and 2 (round 3: 8-21 units short)
+    # round 4 (KAO-CX with one slack node per rack): 16457 on this seed after 4 s, proven 16459 on seeds 1 and 2 inside 8 s (round 3: 8-21 units short)
     assert viol[0] == 0 and obj == r.objective <= lp and lp - r.objective <= 3
     for seed in (1, 2):
         r = kao.solve([t], seed=seed, time_limit_s=8.0, stop_at_bound=1)[0]
@@ -840,14 +845,13 @@ def test_further_kao_cx_starts(kao, ko, monkeypatch):
     other = load_golden("drift_scale.json")["rows_other_seeds"][0]
     from kafka_assignment_optimizer_amd import synthetic as sy
     t2 = sy.drift(sy.make_cluster(other["B"], other["R"], 1, other["P"], 3, [], []), 0.2, other["seed"])[0]
-    # round 4 (tools/tol_probe.py, GPU call 14): solver seeds 2 and 5 prove the MILP optimum 14801 inside 4 s, seed 3 inside 8 s;
-    # seeds 1 and 4 end at 14800 / 14799 under the certificate 14801 (round 3: 14799 / 14801 / 14800 for seeds 3 / 4 / 5 in 3 s)
-    for seed in (2, 3, 5):
+    # round 4 (tools/tol_probe.py, GPU call 25, KAO-CX cadence 8 / 48): solver seeds 2, 4 and 5 prove the MILP optimum 14801 inside
+    # 4 s, seed 1 inside 8 s; seed 3 ends at 14800 under the certificate 14801 (round 3: 14799 / 14801 / 14800 for seeds 3 / 4 / 5)
+    for seed in (1, 2, 4, 5):
         r2 = kao.solve([t2], seed=seed, time_limit_s=14.0, stop_at_bound=1)[0]
         assert (r2.status, r2.objective, r2.upper_bound) == ("OPTIMAL_PROVEN", other["milp_objective"], other["milp_objective"]), (seed, r2.status, r2.objective)
-    for seed in (1, 4):
-        r2 = kao.solve([t2], seed=seed, time_limit_s=4.0)[0]
-        assert r2.upper_bound == other["milp_objective"] and other["milp_objective"] - 2 <= r2.objective <= other["milp_objective"], (seed, r2.objective)
+    r2 = kao.solve([t2], seed=3, time_limit_s=4.0)[0]
+    assert r2.upper_bound == other["milp_objective"] and other["milp_objective"] - 1 <= r2.objective <= other["milp_objective"], r2.objective
     monkeypatch.setenv("KAO_DET_CX_STARTS", "0")
     kao.solve([t], seed=3, time_limit_s=20.0, max_launches=200)
     assert kao.last_solve_timing()["cx_further_starts"] == 0
