@@ -187,3 +187,29 @@ def test_compound_edges_of_leader_balanced_pairs_improve_a_fixpoint(ko, kp):
     obj, viol = ko.verify(t, np.asarray(Y).astype(np.uint16))
     assert int(np.asarray(viol).sum()) == 0 and obj == objs[-1] == 14826
     assert [r for r in load_golden("drift_scale.json")["rows"] if (r["B"], r["P"]) == (300, 2000)][0]["milp_objective"] == 14826
+
+
+def test_bulk_rounds_only_improve_and_end_no_lower(ko, kp):
+    """Round 4: the bulk mode of a round (topics beyond 131,072 replica slots: candidates of every level, a partition-disjoint set
+    merged before scoring), forced onto small topics: every round keeps the assignment feasible and strictly improves it, and bulk
+    rounds do occur from immature incumbents (the one-by-one mode runs beside it from the same start: both end feasible)."""
+    import kao_cycle as kc
+    n = n_bulk = 0
+    for s, t, a in _wide_cases(ko, kp, range(60), launches=2, iters=64):
+        base, v0 = kc.evaluate(t, np.asarray(a).reshape(t.n_partitions, t.rf))
+        assert v0 == 0
+        Xb, hist_b = kc.improve(t, a, 64, bulk_slots=0)
+        Xo, hist_o = kc.improve(t, a, 64)
+        prev = base
+        for h in hist_b:
+            if h.get("objective") is not None:
+                assert h["objective"] > prev, s
+                prev = h["objective"]
+            n_bulk += bool(h.get("bulk"))
+        ob, vb = kc.evaluate(t, Xb)
+        oo, vo = kc.evaluate(t, Xo)
+        assert vb == 0 and vo == 0 and ob == prev >= base, s
+        n += 1
+        if n >= 16:
+            break
+    assert n >= 10 and n_bulk >= 3, (n, n_bulk)
