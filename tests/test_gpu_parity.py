@@ -810,7 +810,7 @@ def test_slack_band_certificate_meets_the_lp_value(kao, ko):
     # round 4 (KAO-CX with one slack node per rack): 16457 on this seed after 4 s, proven 16459 on seeds 1 and 2 inside 8 s (round 3: 8-21 units short)
     assert viol[0] == 0 and obj == r.objective <= lp and lp - r.objective <= 3
     for seed in (1, 2):
-        r = kao.solve([t], seed=seed, time_limit_s=8.0, stop_at_bound=1)[0]
+        r = kao.solve([t], seed=seed, time_limit_s=16.0, stop_at_bound=1)[0]   # (proven inside 8 s on the GPU box; the schedule is count-keyed, the limit only has to be generous)
         assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", lp, lp), (seed, r.status, r.objective, r.upper_bound)
 
 
@@ -824,7 +824,7 @@ def test_more_slack_band_topics(kao, ko, B, R, P):
     lp = int(round(row["lp_value"]))
     t = _drift_topic(B, R, P)
     for seed in (1, 2, 3):
-        r = kao.solve([t], seed=seed, time_limit_s=4.0 if P > 3000 else 8.0, stop_at_bound=1)[0]
+        r = kao.solve([t], seed=seed, time_limit_s=4.0 if P > 3000 else 16.0, stop_at_bound=1)[0]   # (350 x 2500: proven inside 8 s; generous limit)
         assert r.objective == lp, (seed, r.objective, lp)
         if P > 3000:
             assert lp <= r.upper_bound <= lp + 8, (seed, r.upper_bound, lp)
@@ -848,7 +848,7 @@ def test_further_kao_cx_starts(kao, ko, monkeypatch):
     # round 4 (tools/tol_probe.py, GPU call 25, KAO-CX cadence 8 / 48): solver seeds 2, 4 and 5 prove the MILP optimum 14801 inside
     # 4 s, seed 1 inside 8 s; seed 3 ends at 14800 under the certificate 14801 (round 3: 14799 / 14801 / 14800 for seeds 3 / 4 / 5)
     for seed in (1, 2, 4, 5):
-        r2 = kao.solve([t2], seed=seed, time_limit_s=14.0, stop_at_bound=1)[0]
+        r2 = kao.solve([t2], seed=seed, time_limit_s=20.0, stop_at_bound=1)[0]
         assert (r2.status, r2.objective, r2.upper_bound) == ("OPTIMAL_PROVEN", other["milp_objective"], other["milp_objective"]), (seed, r2.status, r2.objective)
     r2 = kao.solve([t2], seed=3, time_limit_s=4.0)[0]
     assert r2.upper_bound == other["milp_objective"] and other["milp_objective"] - 1 <= r2.objective <= other["milp_objective"], r2.objective
@@ -865,7 +865,7 @@ def test_drift_scale_certificates_meet_the_lp_value(kao, ko, B, R, P):
     row = [r for r in load_golden("drift_scale.json")["rows"] if (r["B"], r["R"], r["P"]) == (B, R, P)][0]
     t = _drift_topic(B, R, P)
     for seed in (1, 2, 3):
-        r = kao.solve([t], seed=seed, time_limit_s=12.0, stop_at_bound=1)[0]
+        r = kao.solve([t], seed=seed, time_limit_s=16.0, stop_at_bound=1)[0]
         # round 4: proven for all three seeds inside 6 s (tools/tol_probe.py, GPU call 14); round 3 accepted a certificate one unit
         # above floor(LP) and incumbents up to 12 units below it
         assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", int(row["lp_value"]), int(row["lp_value"])), (seed, r.status, r.objective, r.upper_bound)
