@@ -1,16 +1,10 @@
 #!/bin/bash
-# round 4, call 26: KAO-CX cadence 4 / 24 and 6 / 36 on the hard half of the family (adopted: 8 / 48), and on the 500-broker scale rows
+# round 4, last call: whole GPU suite on the committed state; kernel trace of one 3-s solve of the drifted 300 x 2000 (second drift seed:
+# not proven on solver seed 3) and of 500 x 5000: where the GPU time of a medium solve goes (profiles/r04_zz_solve_*)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r04_c26
-for cad in "4 24" "6 36"; do
-  set -- $cad
-  (KAO_DET_CX_STALL_L=$1 KAO_DET_CX_DUE_L=$2 R3_HARD=1 R3_SEEDS=3,4,5 R3_SCHEDS=0 timeout 400 python tools/r3_probe.py family 3.0) > gpurun_out/${T}_family_cx_$1_$2.log 2>&1
-  grep -h "proven [0-9]" gpurun_out/${T}_family_cx_$1_$2.log | sed "s/^/cadence $1 $2: /"
-  for shape in "500 10 5000" "500 10 10000"; do
-    KAO_DET_CX_STALL_L=$1 KAO_DET_CX_DUE_L=$2 timeout 100 python tools/r3_probe.py solve $shape 1 3,4 3.0 2>&1 | grep "solve seed" | cut -c1-110 | sed "s/^/cadence $1 $2: /"
-  done
-done | tee gpurun_out/${T}_summary.log
-for shape in "500 10 5000" "500 10 10000"; do
-  timeout 100 python tools/r3_probe.py solve $shape 1 3,4 3.0 2>&1 | grep "solve seed" | cut -c1-110 | sed "s/^/default: /"
-done | tee -a gpurun_out/${T}_summary.log
+T=r04_zzz
+(time timeout 1200 python -m pytest tests -m gpu -q) > gpurun_out/${T}_pytest.log 2>&1
+tail -5 gpurun_out/${T}_pytest.log | cut -c1-300
+(timeout 200 bash tools/profile_solve.sh r04_zz_500x5000 500 10 5000 3) > gpurun_out/${T}_solve_500.log 2>&1
+tail -20 gpurun_out/${T}_solve_500.log | cut -c1-200

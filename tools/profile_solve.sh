@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/prof_solve_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o solve -- python $REPO/tools/cx_long.py $B $R $P $BUDGET 3 > "$OUT/solve.txt" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o solve -- python $REPO/tools/r3_probe.py solve $B $R $P 1 3 $BUDGET > "$OUT/solve.txt" 2> "$OUT/trace.err"
 cd "$REPO"
 python - "$OUT" <<'PY' > "$OUT/summary.txt" 2>&1
 import glob, os, sqlite3, sys
