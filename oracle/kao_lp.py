@@ -1,0 +1,278 @@
+"""KAO-LP oracle -- TEST INFRASTRUCTURE ONLY (never imported by the product package).
+
+The reference proves its optimum by lp_solve's simplex + branch and bound on the generated model (README.md:135-136,
+README.md:144-185).  The device certifies an incumbent by a Lagrangian dual of the same model (K-bound, oracle/kao_port.c);
+round 5 adds KAO-LP: the multipliers K-bound is evaluated at come from an interior-point solve of the model's LP relaxation
+in COMPACT form.  This module restates that compact LP row by row, solves it exactly with HiGHS (scipy) and restates the
+interior-point iteration with generic sparse algebra (the device runs the same iteration on the block structure).
+
+Compact form.  A variable t?b<b>p<p>[_l] (README.md:146, README.md:182-184) of a broker that does NOT hold partition p today
+has objective coefficient 0 (README.md:145-146: only existing placements carry weight), so within one rack all such brokers
+are interchangeable for p up to the rows of the broker itself.  Their mass is pooled:
+  per partition p:  f[p,j], l[p,j]   follower / leader variable of the j-th CURRENT replica of p (weights w[cur_role][new_role])
+                    yf[p,r], yl[p,r] new follower / leader mass of p in rack r (weight 0)
+  per broker b:     zf[b], zl[b]     new follower / leader mass broker b receives (broker weights, if any, ride here)
+                    n[b], m[b]       replicas / leaders on b above the lower band end (0 .. hi - lo)
+  per rack r:       k[r]             replicas in r above the lower band end
+Rows (README lines of the family they restate):
+  C1[p]   sum_j (f+l) + sum_r (yf+yl) = RF                      README.md:148-151
+  C2[p]   sum_j l + sum_r yl = 1                                README.md:153-156
+  C5[p,j] f + l <= 1                                            README.md:168-171 (only kept when a rack may take two replicas)
+  C7[p,r] plo <= sum_{j in r} (f+l) + yf + yl <= phi            README.md:178-180
+  C3[b]   sum_{(p,j) on b} (f+l) + zf[b] + zl[b] - n[b] = rep_lo        README.md:158-161
+  C4[b]   sum_{(p,j) on b} l + zl[b] - m[b] = lead_lo                   README.md:163-166
+  C6[r]   sum_{b in r} n[b] - k[r] = rack_lo - |r| rep_lo               README.md:173-176
+  NF[r]   sum_p yf[p,r] - sum_{b in r} zf[b] = 0      (pooling)
+  NL[r]   sum_p yl[p,r] - sum_{b in r} zl[b] = 0      (pooling)
+It is a relaxation of the README model's LP (a pooled unit may land on a broker the partition already uses), and where at
+most one replica of a partition fits a rack (phi = 1, the usual case) it loses nothing.  What the certificate rests on is not
+this LP's value but the EXACT Lagrangian dual value at its row duals (oracle/kao_port.c::kao_port_dual_bound) -- valid for any
+multipliers.  Measured (round 5): drifted 450 x 3500, 500 x 5000, 270 x 2200: value = the full LP's value (26330, 37558,
+16459; HiGHS needed 2,876 / 10,008 / 567 s for the full LPs, 14 / 172 / 28 s for the compact ones), exact dual value at the
+compact LP's duals = the same.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+from scipy.optimize import linprog
+
+import kao_oracle as ko
+
+DB_SCALE = 65536
+
+
+@dataclass
+class CompactLP:
+    """min c x,  A x = b,  0 <= x <= u (u = inf where unbounded); the README objective is -c x."""
+    A: sp.csr_matrix
+    b: np.ndarray
+    c: np.ndarray
+    u: np.ndarray
+    rows: Dict[str, np.ndarray]   # row indices by family: C3[B], C4[B], C6[R] (-1 = row absent), NF[R], NL[R]
+    n_local_rows: int
+
+
+def build(t: ko.Topic) -> CompactLP:
+    B, R, P, RF = t.n_brokers, t.n_racks, t.n_partitions, t.rf
+    bd = t.bounds()
+    w = t.weights
+    rack = np.asarray(t.rack_of)
+    rsz = np.bincount(rack, minlength=R)
+    bw = np.zeros(B, dtype=np.int64) if t.broker_w is None else np.asarray(t.broker_w, dtype=np.int64)
+    bwl = np.zeros(B, dtype=np.int64) if t.broker_wl is None else np.asarray(t.broker_wl, dtype=np.int64)
+    lo, hi, llo, lhi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"]
+    rlo, rhi, plo, phi = bd["rack_lo"], bd["rack_hi"], bd["prack_lo"], bd["prack_hi"]
+    has_c5 = phi >= 2
+    ri, ci, vi = [], [], []
+    c, u, b = [], [], []
+
+    def var(cost, ub=np.inf):
+        c.append(-float(cost)); u.append(ub); return len(c) - 1
+
+    def row(rhs):
+        b.append(float(rhs)); return len(b) - 1
+
+    def put(r, v, x=1.0):
+        ri.append(r); ci.append(v); vi.append(x)
+
+    has_n = hi > lo
+    NF = [row(0) for _ in range(R)]
+    NL = [row(0) for _ in range(R)]
+    C6 = [row(rlo - int(rsz[r]) * lo) if has_n else -1 for r in range(R)]
+    C3 = [row(lo) for _ in range(B)]
+    C4 = [row(llo) for _ in range(B)]
+    for b_ in range(B):
+        r = int(rack[b_])
+        zf = var(bw[b_]); zl = var(bw[b_] + bwl[b_])
+        put(C3[b_], zf); put(C3[b_], zl); put(C4[b_], zl); put(NF[r], zf, -1.0); put(NL[r], zl, -1.0)
+        if has_n:
+            n = var(0, hi - lo); put(C3[b_], n, -1.0); put(C6[r], n)
+        if lhi > llo:
+            m = var(0, lhi - llo); put(C4[b_], m, -1.0)
+    if has_n and rhi > rlo:
+        for r in range(R):
+            k = var(0, rhi - rlo); put(C6[r], k, -1.0)
+    n_glob_rows = len(b)
+    for p in range(P):
+        c1 = row(RF); c2 = row(1)
+        c7 = [row(phi) for _ in range(R)]
+        for j in range(t.rf_cur):
+            b_ = int(t.current[p, j])
+            if b_ == ko.NONE or b_ >= B:
+                continue
+            cr = 0 if j == 0 else 1
+            f = var(w[cr][1] + bw[b_]); l = var(w[cr][0] + bw[b_] + bwl[b_])
+            for v in (f, l):
+                put(c1, v); put(C3[b_], v); put(c7[int(rack[b_])], v)
+            put(c2, l); put(C4[b_], l)
+            if has_c5:
+                c5 = row(1); q = var(0); put(c5, f); put(c5, l); put(c5, q)
+        for r in range(R):
+            yf = var(0); yl = var(0)
+            for v in (yf, yl):
+                put(c1, v); put(c7[r], v)
+            put(c2, yl); put(NF[r], yf); put(NL[r], yl)
+            if phi > plo:
+                tt = var(0, phi - plo if plo > 0 else np.inf); put(c7[r], tt)
+    A = sp.csr_matrix((vi, (ri, ci)), shape=(len(b), len(c)))
+    return CompactLP(A=A, b=np.array(b), c=np.array(c), u=np.array(u),
+                     rows=dict(C3=np.array(C3), C4=np.array(C4), C6=np.array(C6), NF=np.array(NF), NL=np.array(NL)),
+                     n_local_rows=len(b) - n_glob_rows)
+
+
+def to_fixed(v: np.ndarray) -> np.ndarray:
+    return np.clip(np.round(np.asarray(v) * DB_SCALE), -(1 << 26), 1 << 26).astype(np.int32)
+
+
+def duals_to_alg(t: ko.Topic, lp: CompactLP, y: np.ndarray):
+    rack = np.asarray(t.rack_of)
+    C6 = lp.rows["C6"]
+    g = np.where(C6 >= 0, -y[np.maximum(C6, 0)], 0.0)
+    a = -y[lp.rows["C3"]] - g[rack]
+    l = -y[lp.rows["C4"]]
+    return to_fixed(a), to_fixed(l), to_fixed(g)
+
+
+def solve_highs(lp: CompactLP, method: str = "highs-ipm"):
+    """Exact reference: HiGHS on the compact LP.  Returns (README-objective value, row duals, x, seconds)."""
+    bounds = [(0.0, None if not np.isfinite(ub) else ub) for ub in lp.u]
+    t0 = time.time()
+    res = linprog(lp.c, A_eq=lp.A, b_eq=lp.b, bounds=bounds, method=method)
+    if res.status != 0:
+        raise RuntimeError(f"HiGHS status {res.status}: {res.message}")
+    return -float(res.fun), np.asarray(res.eqlin.marginals), np.asarray(res.x), time.time() - t0
+
+
+def exact_dual_value(t: ko.Topic, a, l, g) -> float:
+    """The exact Lagrangian dual value (oracle/kao_port.c, one evaluation after the common shifts) at given multipliers."""
+    import kao_port as kp
+    st = kp.DualState(t)
+    st.a[:] = a; st.l[:] = l; st.g[:len(g)] = g
+    kp.port_dual_bound(t, 0, 1, st)
+    return st.best_L / DB_SCALE
+
+
+def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, trace=None):
+    """Mehrotra predictor-corrector on min c x, A x = b, 0 <= x <= u -- the iteration kao_lp.hip runs on the block structure
+    (same starting point, same step rule, same stopping rule), here with generic sparse algebra.  Returns (x, y, iterations,
+    primal objective, dual objective).  `trace`, if a list, receives (mu, pobj, dobj, pinf, dinf) per iteration."""
+    A, b, c, u = lp.A, lp.b, lp.c, lp.u
+    m, n = A.shape
+    U = np.isfinite(u)
+    uu = np.where(U, u, 0.0)
+    nU = int(U.sum())
+    AT = A.T.tocsr()
+
+    def factor(theta):
+        return spl.splu((A @ sp.diags(theta) @ AT).tocsc() + reg * sp.identity(m, format="csc"))
+
+    lu = factor(np.ones(n))
+    x = AT @ lu.solve(b)
+    y = lu.solve(A @ c)
+    s = c - AT @ y
+    x = np.maximum(x, 1.0)
+    x = np.where(U, np.minimum(x, np.maximum(uu * 0.5, 1e-2)), x)
+    w = np.where(U, uu - x, 1.0)
+    s = np.maximum(s, 1.0)
+    v = np.where(U, 1.0, 0.0)
+    nb, nc = 1.0 + np.linalg.norm(b), 1.0 + np.linalg.norm(c)
+    it = 0
+    pobj = dobj = 0.0
+    for it in range(maxit + 1):
+        rp = b - A @ x
+        rd = c - AT @ y - s + v
+        mu = (x @ s + (w * v)[U].sum()) / (n + nU)
+        pobj = float(c @ x); dobj = float(b @ y - (uu * v)[U].sum())
+        pinf, dinf = np.linalg.norm(rp) / nb, np.linalg.norm(rd) / nc
+        if trace is not None:
+            trace.append((mu, pobj, dobj, pinf, dinf))
+        if (abs(pobj - dobj) / (1.0 + abs(pobj)) < tol and pinf < 100 * tol and dinf < tol) or it == maxit:
+            break
+        wU = np.where(U, w, 1.0)
+        theta = 1.0 / (s / x + np.where(U, v / wU, 0.0))
+        lu = factor(theta)
+
+        def direction(rxs, rwv):
+            h = rd - rxs / x + np.where(U, rwv / wU, 0.0)
+            dy = lu.solve(rp + A @ (theta * h))
+            dx = theta * (AT @ dy - h)
+            ds = (rxs - s * dx) / x
+            dv = np.where(U, (rwv + v * dx) / wU, 0.0)
+            return dx, dy, ds, dv
+
+        def maxstep(z, dz, mask=None):
+            neg = dz < 0
+            if mask is not None:
+                neg = neg & mask
+            return min(1.0, float((-z[neg] / dz[neg]).min())) if neg.any() else 1.0
+
+        dx, dy, ds, dv = direction(-x * s, np.where(U, -w * v, 0.0))
+        ap = min(maxstep(x, dx), maxstep(w, -dx, U)); ad = min(maxstep(s, ds), maxstep(v, dv, U))
+        mu_aff = ((x + ap * dx) @ (s + ad * ds) + ((w - ap * dx) * (v + ad * dv))[U].sum()) / (n + nU)
+        sigma = (mu_aff / mu) ** 3
+        dx, dy, ds, dv = direction(sigma * mu - x * s - dx * ds, np.where(U, sigma * mu - w * v + dx * dv, 0.0))
+        ap = min(maxstep(x, dx), maxstep(w, -dx, U)); ad = min(maxstep(s, ds), maxstep(v, dv, U))
+        ap = 0.9995 * ap if ap < 1.0 else 1.0
+        ad = 0.9995 * ad if ad < 1.0 else 1.0
+        x = x + ap * dx; w = np.where(U, uu - x, 1.0)
+        y = y + ad * dy; s = s + ad * ds; v = v + ad * dv
+    return x, y, it, -pobj, -dobj
+
+
+# ---- the block-structured restatement in C (oracle/kao_lp_port.c) ------------------------------------------------
+_PORT = None
+
+
+def _port():
+    global _PORT
+    if _PORT is None:
+        import ctypes as C
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so, src = os.path.join(here, "libkao_lp_port.so"), os.path.join(here, "kao_lp_port.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", here, "libkao_lp_port.so"], stdout=subprocess.DEVNULL)
+        import kao_port as kp
+        _PORT = C.CDLL(so)
+        _PORT.kao_lp_port_solve.argtypes = [C.POINTER(kp.PortTopic), C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double)]
+        _PORT.kao_lp_port_solve.restype = C.c_int
+    return _PORT
+
+
+def port_coupling_order(t: ko.Topic, lp: CompactLP) -> np.ndarray:
+    """Row indices of `lp` in the order oracle/kao_lp_port.c (and the device) number the coupling rows:
+    NF[R], NL[R], C6[R], then C3[b], C4[b] interleaved (-1 = row absent)."""
+    B = t.n_brokers
+    inter = np.empty(2 * B, dtype=np.int64)
+    inter[0::2] = lp.rows["C3"]; inter[1::2] = lp.rows["C4"]
+    return np.concatenate([lp.rows["NF"], lp.rows["NL"], lp.rows["C6"], inter])
+
+
+def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80):
+    """The structured iteration on the CPU.  Returns dict(status, iterations, primal, dual (README objective), y (coupling-row
+    duals in the port's order), a, l, g (fixed-point multipliers), trace [(mu, pobj, dobj, pinf, dinf)])."""
+    import ctypes as C
+    import kao_port as kp
+    ct = kp.CTopic(t)
+    B, R = t.n_brokers, t.n_racks
+    mc = 3 * R + 2 * B
+    y = np.zeros(mc)
+    trace = np.zeros(5 * (maxit + 2))
+    stats = np.zeros(4)
+    pd = C.POINTER(C.c_double)
+    rc = _port().kao_lp_port_solve(C.byref(ct.s), tol, maxit, y.ctypes.data_as(pd), trace.ctypes.data_as(pd), stats.ctypes.data_as(pd))
+    it = int(stats[0])
+    rack = np.asarray(t.rack_of)
+    g = -y[2 * R:3 * R]
+    a = -y[3 * R::2] - g[rack]
+    l = -y[3 * R + 1::2]
+    return dict(status=rc, iterations=it, primal=float(stats[1]), dual=float(stats[2]), y=y, a=to_fixed(a), l=to_fixed(l), g=to_fixed(g),
+                trace=trace[:5 * (it + 1)].reshape(-1, 5))
