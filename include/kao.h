@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KAO_VERSION 101 /* 0.1.1: kao_opts.schedule, kao_session_new_generation, kao_last_solve_timing out[16] */
+#define KAO_VERSION 102 /* 0.1.2: kao_lp_bound, kao_session_set_dual_state (KAO-LP, round 5) */
 #define KAO_NONE 0xFFFFu /* "no broker": replica on a broker outside the target set / empty slot */
 #define KAO_MAX_RF 8     /* replica slots per partition supported by the gfx950 kernels (RF <= 4: one 128-bit word group per
                             partition; 5..8: two) */
@@ -261,6 +261,28 @@ int kao_session_bounds(kao_session *s, int64_t *upper_bound, int32_t *flags, int
 /* Test hook: K-bound state of one topic -- multipliers a[n_brokers], l[n_brokers], g[n_racks] (fixed point, 65536 = 1)
  * and the smallest dual value so far in the same fixed point (INT64_MAX-like before the first iteration). */
 int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l, int32_t *g, int64_t *best_dual);
+/* Test hook / KAO-LP: overwrite K-bound's current multipliers of one topic (a[n_brokers], l[n_brokers], g[n_racks], fixed point
+ * 65536 = 1, each clamped to +-2^26); the direction memory and the level control start afresh, the record dual value and the
+ * certificate stay.  The next kao_session_bound_step evaluates the dual function there (after the common shifts) and goes on
+ * from there.  Waits for a K-bound launch in flight. */
+int kao_session_set_dual_state(kao_session *s, int32_t topic, const int32_t *a, const int32_t *l, const int32_t *g);
+/* KAO-LP: the certificate from the model's LP relaxation (round 5).  lp_solve's proof of optimality rests on the LP relaxation of
+ * the generated model (README.md:135-136, README.md:144-185); K-bound's subgradient iteration approaches that LP's value from
+ * above and stalls short of it on slack-band and on large topics.  kao_lp_bound solves the LP itself on the device -- in compact
+ * form (new placements pooled per partition and rack; oracle/kao_lp.py states the rows) by a block-structured interior-point
+ * method (kao_lp.hip) -- takes its row duals as multipliers, rounds them to K-bound's fixed point and lets K-bound evaluate the
+ * dual function there IN INTEGERS: *bound = floor(that value) is a valid upper bound on the optimum whatever the floating-point
+ * solve did.  multipliers (may be NULL): a[n_brokers], l[n_brokers], g[n_racks]; stats (may be NULL): [0] interior-point
+ * iterations, [1] README objective of the primal iterate, [2] of the dual iterate (the LP value to ~1e-7), [3] 0 converged /
+ * 1 iteration limit / 3 stalled (the last finite iterate was used), [4] mu, [5] / [6] relative primal / dual infeasibility,
+ * [7] milliseconds of the interior-point solve.  tol <= 0: 1e-7; max_iters <= 0: 80.  KAO_ERR_UNSUPPORTED: outside K-bound's
+ * limits or more than ~4,700 brokers. */
+int kao_lp_bound(const kao_topic *t, double tol, int32_t max_iters, int64_t *bound, int64_t *best_dual, int32_t *multipliers, double stats[8]);
+/* Test hook: the interior-point solve alone, with its trace -- trace[5 * i .. 5 * i + 4] = (mu, primal objective, dual objective,
+ * relative primal infeasibility, relative dual infeasibility) of iterate i in the LP's min form (README objective = -value),
+ * room for max_iters + 2 iterates; stats and multipliers as kao_lp_bound (any may be NULL).  The parity tests hold the trace against
+ * oracle/kao_lp_port.c's. */
+int kao_lp_trace(const kao_topic *t, double tol, int32_t max_iters, double *trace, double stats[8], int32_t *multipliers);
 /* One-shot K-bound on one topic: `launches` launches of `iters` iterations towards `target`.
  * *bound = floor(best dual / 65536) (not combined with kao_upper_bound); multipliers, if not NULL, receives
  * a[n_brokers], l[n_brokers], g[n_racks]. */

@@ -77,6 +77,9 @@ SIGNATURES = {
     "kao_session_bound_busy": (C.c_int, [C.c_void_p]),
     "kao_session_bounds": (C.c_int, [C.c_void_p, _P(C.c_int64), _P(C.c_int32), _P(C.c_int32)]),
     "kao_session_dual_state": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32), _P(C.c_int64)]),
+    "kao_session_set_dual_state": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "kao_lp_bound": (C.c_int, [_P(KaoTopic), C.c_double, C.c_int32, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32), _P(C.c_double)]),
+    "kao_lp_trace": (C.c_int, [_P(KaoTopic), C.c_double, C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_int32)]),
     "kao_dual_bound": (C.c_int, [_P(KaoTopic), C.c_int64, C.c_int32, C.c_int32, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32),
                                  _P(C.c_int32), _P(C.c_int32)]),
     "kao_session_destroy": (None, [C.c_void_p]),

@@ -150,6 +150,7 @@ struct kao_session {
     unsigned char *d_dual_rb = nullptr;
     size_t dual_rb_bytes = 0;
     uint64_t bound_launches = 0;
+    bool dual_state_init = false;   // the K-bound state in HBM has been cleared (first launch or kao_session_set_dual_state)
     size_t dual_bytes = 0;
     hipStream_t stream_bound = nullptr;   // K-bound runs beside K-search on its own stream (it occupies one CU per topic)
     hipEvent_t ev_bound0 = nullptr, ev_bound1 = nullptr, ev_search = nullptr;

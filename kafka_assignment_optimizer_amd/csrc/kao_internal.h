@@ -176,6 +176,13 @@ void launch_canon(const TopicDev *topic, const uint32_t *cur_words, const uint16
                   int nw, int32_t *status, void *stream);
 
 
+// ---- KAO-LP (kao_lp.hip): interior-point solve of the compact LP relaxation; its row duals are multipliers for K-bound ----
+struct LpCtx;
+int lp_open(const kao_topic *t, LpCtx **out);
+// multipliers (host): a[B] l[B] g[R] in K-bound's fixed point; stats[8], trace: see kao_lp.hip
+int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace);
+void lp_close(LpCtx *c);
+
 // ---- KAO-CX (kao_cycle.hip): cyclic-exchange improvement of a feasible assignment ----
 bool cycle_supported(const kao_topic *t);
 int cycle_improve(const kao_topic *t, uint16_t *assign, int32_t max_rounds, double deadline, int64_t *objective, int32_t stats[8]);

@@ -1,0 +1,1178 @@
+// kao_lp.hip -- KAO-LP: the LP relaxation of the Kafka partition-assignment model solved on gfx950 by a block-structured
+// interior-point method; its row duals are the multipliers K-bound's exact dual value is taken at (round 5).
+//
+// lp_solve proves the reference's optimum on the generated model (README.md:135-136, README.md:144-185).  K-bound (kao_bound.hip)
+// gives a certificate for ANY multipliers of the rows C3 / C4 / C6, but its subgradient iteration stalls above the LP value on
+// slack-band and on large topics (450 x 3500: 26336 against an LP value of 26330 = the incumbent; 1000 x 30000: 231,562 against
+// 231,532).  Here the multipliers come from the LP itself, in COMPACT form (oracle/kao_lp.py states it row by row): a variable
+// of a broker that does not hold the partition today has objective coefficient 0 (README.md:145-146), so the new placements of
+// a partition are pooled per rack (yf, yl) and handed to the brokers through per-broker inflow variables (zf, zl); the band
+// rows are written on slack variables n, m, k.  What is reported never rests on floating point: the duals are rounded to
+// K-bound's fixed point and the dual value there is computed by K-bound in integers.
+//
+// Iteration: Mehrotra predictor-corrector (oracle/kao_lp.py::ipm, restated on the block structure by oracle/kao_lp_port.c).
+// Normal equations per iteration:
+//   per partition (one lane each): row C5[p,j] is folded into a 2x2 weight of (f_j, l_j); the rows C7[p,r] are then mutually
+//     orthogonal (a diagonal d_r); the dense rows C1[p], C2[p] leave a 2x2 system T (guarded pivots);
+//   coupling rows NF[r] NL[r] C6[r] C3[b] C4[b] (mc = 3R + 2B): Schur complement S = per-partition block-diagonal parts minus
+//     rank-2 terms, GATHERED in a fixed order (one wavefront per broker walks the broker's incidence list, the rack x rack
+//     block is a tiled outer-product sum over fixed chunks): no floating-point atomics, the same bits on every run;
+//   dense blocked Cholesky of S (64 x 64 tiles; pivots that lost all but 1e-12 of their entry pin a dependent row), two
+//     triangular solves per right-hand side.
+// f64 throughout (the Cholesky trailing update is the one GEMM-shaped piece of the whole library).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kao_host.h"
+
+namespace kao {
+namespace {
+
+constexpr double kLpPivotRel = 1e-12;
+constexpr double kLpPivotBig = 1e64;
+constexpr double kLpReg = 1e-10;
+constexpr int kNB = 64;            // Cholesky tile
+constexpr int kRedVals = 8;        // values per reduction record
+constexpr int kRedBlock = 256;
+
+struct LpDev {
+    int P, B, R, NJ, RF, NV, GV, mc, mcp;    // mcp = mc rounded up to the Cholesky tile (padding rows are identity)
+    int has_c5, has_t, t_ub, has_n, has_m, has_k, n_ub, m_ub, k_ub, phi;
+    const uint16_t *cur;        // [P*NJ] dense broker or KAO_NONE
+    const uint8_t *rack;        // [B]
+    const int *inc_off, *inc;   // per broker: its incidences (p << 3 | j), ascending
+    const int *rk_off, *rk_mem; // per rack: member brokers, ascending
+    const double *c;            // [2*NJ][P]: cost (min form) of f_j, l_j
+    const double *cg;           // [GV]
+    const unsigned char *rowc;  // [mc]: 1 = row present, 0 = absent, 2 = pinned (exact dependency)
+    const double *bc;           // [mc] right-hand sides of the coupling rows
+};
+
+// variable numbering inside a partition (SoA: element (v, p) at v*P + p) and among the global variables
+__device__ __host__ __forceinline__ int VF(int j) { return 3 * j; }
+__device__ __host__ __forceinline__ int VL(int j) { return 3 * j + 1; }
+__device__ __host__ __forceinline__ int VQ(int j) { return 3 * j + 2; }
+__device__ __host__ __forceinline__ int VYF(const LpDev &D, int r) { return 3 * D.NJ + 3 * r; }
+__device__ __host__ __forceinline__ int VYL(const LpDev &D, int r) { return 3 * D.NJ + 3 * r + 1; }
+__device__ __host__ __forceinline__ int VT(const LpDev &D, int r) { return 3 * D.NJ + 3 * r + 2; }
+__device__ __host__ __forceinline__ int RNF(const LpDev &, int r) { return r; }
+__device__ __host__ __forceinline__ int RNL(const LpDev &D, int r) { return D.R + r; }
+__device__ __host__ __forceinline__ int RC6(const LpDev &D, int r) { return 2 * D.R + r; }
+__device__ __host__ __forceinline__ int RC3(const LpDev &D, int b) { return 3 * D.R + 2 * b; }
+__device__ __host__ __forceinline__ int RC4(const LpDev &D, int b) { return 3 * D.R + 2 * b + 1; }
+
+__device__ __forceinline__ int cur_b(const LpDev &D, int p, int j) {
+    const unsigned b = D.cur[(size_t)p * D.NJ + j];
+    return (b == KAO_NONE || (int)b >= D.B) ? -1 : (int)b;
+}
+// presence / upper bound / cost of variable v of partition p
+__device__ __forceinline__ bool var_present(const LpDev &D, int v, int p) {
+    if (v < 3 * D.NJ) { const int k = v % 3; return cur_b(D, p, v / 3) >= 0 && (k < 2 || D.has_c5); }
+    const int k = (v - 3 * D.NJ) % 3;
+    return k < 2 || D.has_t;
+}
+__device__ __forceinline__ double var_ub(const LpDev &D, int v) {   // 0 = none
+    return (v >= 3 * D.NJ && (v - 3 * D.NJ) % 3 == 2) ? (double)D.t_ub : 0.0;
+}
+__device__ __forceinline__ double var_cost(const LpDev &D, int v, int p) {
+    if (v >= 3 * D.NJ) return 0.0;
+    const int k = v % 3;
+    return k == 2 ? 0.0 : D.c[(size_t)(2 * (v / 3) + k) * D.P + p];
+}
+__device__ __forceinline__ bool gvar_present(const LpDev &D, int g) {
+    if (g < 2 * D.B) return true;
+    if (g < 3 * D.B) return D.has_n;
+    if (g < 4 * D.B) return D.has_m;
+    return D.has_k;
+}
+__device__ __forceinline__ double gvar_ub(const LpDev &D, int g) {
+    if (g < 2 * D.B) return 0.0;
+    if (g < 3 * D.B) return D.n_ub;
+    if (g < 4 * D.B) return D.m_ub;
+    return D.k_ub;
+}
+
+struct RowVec { double *r1, *r2, *r7, *r5, *rc; };    // one vector over the rows: local C1[P] C2[P] C7[R][P] C5[NJ][P], coupling [mcp]
+struct VarVec { double *z, *zg; };                    // one vector over the variables: [NV][P], [GV]
+
+// (A^T y) of variable v of partition p / of global variable g
+__device__ __forceinline__ double at_val(const LpDev &D, int v, int p, const RowVec &y) {
+    const int P = D.P;
+    if (v < 3 * D.NJ) {
+        const int j = v / 3, k = v % 3, b = cur_b(D, p, j);
+        if (b < 0) return 0.0;
+        const double c5 = D.has_c5 ? y.r5[(size_t)j * P + p] : 0.0;
+        if (k == 2) return c5;
+        double a = y.r1[p] + y.r7[(size_t)D.rack[b] * P + p] + c5 + y.rc[RC3(D, b)];
+        if (k == 1) a += y.r2[p] + y.rc[RC4(D, b)];
+        return a;
+    }
+    const int r = (v - 3 * D.NJ) / 3, k = (v - 3 * D.NJ) % 3;
+    const double c7 = y.r7[(size_t)r * P + p];
+    if (k == 2) return D.has_t ? c7 : 0.0;
+    if (k == 0) return y.r1[p] + c7 + y.rc[RNF(D, r)];
+    return y.r1[p] + y.r2[p] + c7 + y.rc[RNL(D, r)];
+}
+__device__ __forceinline__ double at_val_g(const LpDev &D, int g, const double *yc) {
+    const int B = D.B;
+    if (g < B) return yc[RC3(D, g)] - yc[RNF(D, D.rack[g])];
+    if (g < 2 * B) { const int b = g - B; return yc[RC3(D, b)] + yc[RC4(D, b)] - yc[RNL(D, D.rack[b])]; }
+    if (g < 3 * B) { const int b = g - 2 * B; return D.has_n ? -yc[RC3(D, b)] + yc[RC6(D, D.rack[b])] : 0.0; }
+    if (g < 4 * B) { const int b = g - 3 * B; return D.has_m ? -yc[RC4(D, b)] : 0.0; }
+    return D.has_k ? -yc[RC6(D, g - 4 * B)] : 0.0;
+}
+
+// ---- deterministic block reductions: every block writes one record of kRedVals values, a second kernel adds the records in order
+__device__ __forceinline__ void block_reduce(double *vals, int n, bool is_min, double *out_rec) {   // vals: this thread's n values
+    __shared__ double sh[kRedBlock];
+    for (int k = 0; k < n; ++k) {
+        sh[threadIdx.x] = vals[k];
+        __syncthreads();
+        for (int s = kRedBlock / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) sh[threadIdx.x] = is_min ? fmin(sh[threadIdx.x], sh[threadIdx.x + s]) : sh[threadIdx.x] + sh[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out_rec[k] = sh[0];
+        __syncthreads();
+    }
+}
+__global__ void k_lp_red_final(const double *rec, int nrec, int n, int is_min, double *out) {   // one block of 64; thread k adds value k
+    const int k = threadIdx.x;
+    if (k >= n) return;
+    double a = is_min ? 1.0 : 0.0;
+    for (int i = 0; i < nrec; ++i) a = is_min ? fmin(a, rec[(size_t)i * kRedVals + k]) : a + rec[(size_t)i * kRedVals + k];
+    out[k] = is_min ? fmin(out[k], a) : out[k] + a;
+}
+
+// ---- elementwise over the variables ------------------------------------------------------------------------------
+// theta = 1 / (s / x + v / w); init = 1: theta = 1 on present variables (the starting point's least-squares solves)
+__global__ void k_lp_theta(LpDev D, const double *x, const double *s, const double *v, double *th, int init) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)D.NV * D.P) return;
+    const int vv = (int)(i / D.P), p = (int)(i % D.P);
+    if (!var_present(D, vv, p)) { th[i] = 0.0; return; }
+    if (init) { th[i] = 1.0; return; }
+    const double u = var_ub(D, vv);
+    th[i] = 1.0 / (s[i] / x[i] + (u > 0 ? v[i] / (u - x[i]) : 0.0));
+}
+__global__ void k_lp_theta_g(LpDev D, const double *x, const double *s, const double *v, double *th, int init) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= D.GV) return;
+    if (!gvar_present(D, g)) { th[g] = 0.0; return; }
+    if (init) { th[g] = 1.0; return; }
+    const double u = gvar_ub(D, g);
+    th[g] = 1.0 / (s[g] / x[g] + (u > 0 ? v[g] / (u - x[g]) : 0.0));
+}
+
+// ---- per-partition factor: sig11 sig12 sig22 e5 k1 k2 per replica, d e1 e2 per rack, T^-1 ------------------------------
+__global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double *fr, double *ti) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.P) return;
+    const int P = D.P, R = D.R, NJ = D.NJ;
+    double m11 = 0, m12 = 0, m22 = 0;
+    for (int r = 0; r < R; ++r) {
+        const double cyf = th[(size_t)VYF(D, r) * P + p], cyl = th[(size_t)VYL(D, r) * P + p], ct = D.has_t ? th[(size_t)VT(D, r) * P + p] : 0.0;
+        fr[((size_t)0 * R + r) * P + p] = cyf + cyl + ct + kLpReg;
+        fr[((size_t)1 * R + r) * P + p] = cyf + cyl;
+        fr[((size_t)2 * R + r) * P + p] = cyl;
+        m11 += cyf + cyl; m12 += cyl; m22 += cyl;
+    }
+    for (int j = 0; j < NJ; ++j) {
+        const int b = cur_b(D, p, j);
+        double s11 = 0, s12 = 0, s22 = 0, e5 = 1, k1 = 0, k2 = 0;
+        if (b >= 0) {
+            const double tf = th[(size_t)VF(j) * P + p], tl = th[(size_t)VL(j) * P + p];
+            double a11 = tf, a12 = 0, a22 = tl;
+            if (D.has_c5) {
+                e5 = tf + tl + th[(size_t)VQ(j) * P + p] + kLpReg; k1 = tf + tl; k2 = tl;
+                a11 = tf - tf * tf / e5; a12 = -tf * tl / e5; a22 = tl - tl * tl / e5;
+            }
+            s11 = a11 + 2 * a12 + a22; s12 = a12 + a22; s22 = a22;
+            const int r = D.rack[b];
+            fr[((size_t)0 * R + r) * P + p] += s11;
+            fr[((size_t)1 * R + r) * P + p] += s11;
+            fr[((size_t)2 * R + r) * P + p] += s12;
+            m11 += s11; m12 += s12; m22 += s22;
+        }
+        fj[((size_t)0 * NJ + j) * P + p] = s11; fj[((size_t)1 * NJ + j) * P + p] = s12; fj[((size_t)2 * NJ + j) * P + p] = s22;
+        fj[((size_t)3 * NJ + j) * P + p] = e5; fj[((size_t)4 * NJ + j) * P + p] = k1; fj[((size_t)5 * NJ + j) * P + p] = k2;
+    }
+    m11 += kLpReg; m22 += kLpReg;
+    const double o11 = m11, o22 = m22;
+    for (int r = 0; r < R; ++r) {
+        const double d = fr[((size_t)0 * R + r) * P + p], e1 = fr[((size_t)1 * R + r) * P + p], e2 = fr[((size_t)2 * R + r) * P + p];
+        m11 -= e1 * e1 / d; m12 -= e1 * e2 / d; m22 -= e2 * e2 / d;
+    }
+    double i11, i12, i22;   // guarded pivots: C1 is a dependent row when the C7 rows carry no slack (oracle/kao_lp_port.c)
+    if (!(m11 > kLpPivotRel * o11)) { i11 = 0; i12 = 0; i22 = m22 > kLpPivotRel * o22 ? 1.0 / m22 : 0.0; }
+    else {
+        const double l21 = m12 / m11, p2 = m22 - l21 * m12;
+        if (!(p2 > kLpPivotRel * o22)) { i11 = 1.0 / m11; i12 = 0; i22 = 0; }
+        else { i22 = 1.0 / p2; i12 = -l21 * i22; i11 = 1.0 / m11 + l21 * l21 * i22; }
+    }
+    ti[(size_t)0 * P + p] = i11; ti[(size_t)1 * P + p] = i12; ti[(size_t)2 * P + p] = i22;
+}
+
+// One coupling column of a partition: which row of S, its rack, and (m1, m2, eps, dg) as in oracle/kao_lp_port.c::lp_cols.
+// Column numbering inside a partition: 2j, 2j+1 = C3 / C4 of replica j (j < NJ), then 2NJ + 2r, 2NJ + 2r + 1 = NF[r] / NL[r].
+struct PCol { int col, rk; double m1, m2, eps, dg, v0, v1; };
+__device__ __forceinline__ bool lp_col(const LpDev &D, const double *th, const double *fj, const double *fr, int p, int c, PCol &q) {
+    const int P = D.P, R = D.R, NJ = D.NJ;
+    if (c < 2 * NJ) {
+        const int j = c >> 1, b = cur_b(D, p, j);
+        if (b < 0) return false;
+        const double s11 = fj[((size_t)0 * NJ + j) * P + p], s12 = fj[((size_t)1 * NJ + j) * P + p], s22 = fj[((size_t)2 * NJ + j) * P + p];
+        q.rk = D.rack[b];
+        if (!(c & 1)) { q.col = RC3(D, b); q.m1 = s11; q.m2 = s12; q.eps = s11; q.dg = s11; }
+        else { q.col = RC4(D, b); q.m1 = s12; q.m2 = s22; q.eps = s12; q.dg = s22; }
+    } else {
+        const int r = (c - 2 * NJ) >> 1;
+        if (r >= R) return false;
+        q.rk = r;
+        if (!(c & 1)) { const double cyf = th[(size_t)VYF(D, r) * P + p]; q.col = RNF(D, r); q.m1 = cyf; q.m2 = 0; q.eps = cyf; q.dg = cyf; }
+        else { const double cyl = th[(size_t)VYL(D, r) * P + p]; q.col = RNL(D, r); q.m1 = cyl; q.m2 = cyl; q.eps = cyl; q.dg = cyl; }
+    }
+    const double d = fr[((size_t)0 * R + q.rk) * P + p], e1 = fr[((size_t)1 * R + q.rk) * P + p], e2 = fr[((size_t)2 * R + q.rk) * P + p];
+    q.v0 = q.m1 - e1 * q.eps / d;
+    q.v1 = q.m2 - e2 * q.eps / d;
+    return true;
+}
+
+// ---- Schur complement, broker rows: one wavefront per broker walks the broker's incidences in order -----------------------
+// rows C3[b] and C4[b] are accumulated in LDS (2 x mc doubles per wavefront) and written once (lower triangle)
+__global__ void k_lp_schur_broker(LpDev D, const double *th, const double *thg, const double *fj, const double *fr, const double *ti, double *S) {
+    extern __shared__ double lds_rows[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int b = blockIdx.x * nw + wave;
+    if (b >= D.B) return;
+    const int P = D.P, R = D.R, NJ = D.NJ, mc = D.mc;
+    double *rowA = lds_rows + (size_t)wave * 2 * mc, *rowB = rowA + mc;
+    for (int i = lane; i < 2 * mc; i += 64) rowA[i] = 0.0;
+    const int r0 = D.rack[b], nc = 2 * NJ + 2 * R;
+    for (int e = D.inc_off[b]; e < D.inc_off[b + 1]; ++e) {
+        const int idx = D.inc[e], p = idx >> 3, j0 = idx & 7;
+        const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
+        PCol a3, a4;
+        lp_col(D, th, fj, fr, p, 2 * j0, a3);
+        lp_col(D, th, fj, fr, p, 2 * j0 + 1, a4);
+        const double w30 = i11 * a3.v0 + i12 * a3.v1, w31 = i12 * a3.v0 + i22 * a3.v1;
+        const double w40 = i11 * a4.v0 + i12 * a4.v1, w41 = i12 * a4.v0 + i22 * a4.v1;
+        const double d0 = fr[((size_t)0 * R + r0) * P + p];
+        for (int c = lane; c < nc; c += 64) {
+            PCol q;
+            if (!lp_col(D, th, fj, fr, p, c, q)) continue;
+            double v3 = -(w30 * q.v0 + w31 * q.v1), v4 = -(w40 * q.v0 + w41 * q.v1);
+            if (q.rk == r0) {
+                v3 -= a3.eps * q.eps / d0; v4 -= a4.eps * q.eps / d0;
+                if (c == 2 * j0) { v3 += a3.dg; v4 += a4.m1; }            // (C3, C3) = sig11, (C4, C3) = sig12
+                else if (c == 2 * j0 + 1) { v3 += a4.m1; v4 += a4.dg; }   // (C3, C4) = sig12, (C4, C4) = sig22
+            }
+            rowA[q.col] += v3; rowB[q.col] += v4;
+        }
+    }
+    if (lane == 0) {   // the broker's own global variables
+        const double zf = thg[b], zl = thg[D.B + b], tn = D.has_n ? thg[2 * D.B + b] : 0.0, tm = D.has_m ? thg[3 * D.B + b] : 0.0;
+        rowA[RC3(D, b)] += zf + zl + tn;
+        rowB[RC3(D, b)] += zl;
+        rowB[RC4(D, b)] += zl + tm;
+        rowA[RNF(D, r0)] -= zf; rowA[RNL(D, r0)] -= zl; rowB[RNL(D, r0)] -= zl;
+        if (D.has_n) rowA[RC6(D, r0)] -= tn;
+    }
+    const int ra = RC3(D, b), rb = RC4(D, b);
+    for (int i = lane; i <= ra; i += 64) S[(size_t)ra * D.mcp + i] = rowA[i];
+    for (int i = lane; i <= rb; i += 64) S[(size_t)rb * D.mcp + i] = rowB[i];
+}
+
+// ---- Schur complement, rack x rack block (rows NF, NL against columns NF, NL): tiled outer-product sum over a fixed chunk of
+// partitions per block; partial sums per block, added in block order by k_lp_schur_rack_sum
+__global__ void k_lp_schur_rack(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, int chunk, int tile, double *part) {
+    extern __shared__ double lds_t[];   // per partition of the tile: v0[2R] v1[2R] w0[2R] w1[2R] eps[2R] dg[2R] dinv[R]
+    const int R = D.R, P = D.P, n2 = 2 * R, per = 6 * n2 + R;
+    const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
+    const int ne = n2 * n2;
+    // every thread owns entries e = threadIdx.x + k * blockDim.x; at most 8 per thread are kept in registers per sweep
+    for (int e0 = 0; e0 < ne; e0 += blockDim.x * 8) {
+        double acc[8];
+        for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+        for (int t0 = p0; t0 < p1; t0 += tile) {
+            const int nt = min(tile, p1 - t0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < nt * n2; i += blockDim.x) {
+                const int tp = i / n2, c = i % n2, p = t0 + tp;      // column c: r = c % R, NF if c < R else NL
+                const int r = c % R;
+                const double cy = th[(size_t)(c < R ? VYF(D, r) : VYL(D, r)) * P + p];
+                const double d = fr[((size_t)0 * R + r) * P + p], e1 = fr[((size_t)1 * R + r) * P + p], e2 = fr[((size_t)2 * R + r) * P + p];
+                const double v0 = cy - e1 * cy / d, v1 = (c < R ? 0.0 : cy) - e2 * cy / d;
+                const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
+                double *T = lds_t + (size_t)tp * per;
+                T[c] = v0; T[n2 + c] = v1; T[2 * n2 + c] = i11 * v0 + i12 * v1; T[3 * n2 + c] = i12 * v0 + i22 * v1; T[4 * n2 + c] = cy; T[5 * n2 + c] = cy;
+                if (c < R) T[6 * n2 + c] = 1.0 / d;
+            }
+            __syncthreads();
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + threadIdx.x + k * blockDim.x;
+                if (e >= ne) break;
+                const int a = e / n2, c = e % n2;
+                if (c > a) continue;
+                const int ra = a % R, rc = c % R;
+                double s = 0.0;
+                for (int tp = 0; tp < nt; ++tp) {
+                    const double *T = lds_t + (size_t)tp * per;
+                    double v = -(T[2 * n2 + a] * T[c] + T[3 * n2 + a] * T[n2 + c]);
+                    if (ra == rc) { v -= T[4 * n2 + a] * T[4 * n2 + c] * T[6 * n2 + ra]; if (a == c) v += T[5 * n2 + a]; }
+                    s += v;
+                }
+                acc[k] += s;
+            }
+        }
+        for (int k = 0; k < 8; ++k) {
+            const int e = e0 + threadIdx.x + k * blockDim.x;
+            if (e < ne) part[(size_t)blockIdx.x * ne + e] = acc[k];
+        }
+    }
+}
+__global__ void k_lp_schur_rack_sum(LpDev D, const double *part, int nblk, const double *thg, double *S) {
+    const int n2 = 2 * D.R, ne = n2 * n2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const int a = e / n2, c = e % n2;
+    if (c > a) return;
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += part[(size_t)i * ne + e];
+    if (a == c) {   // the racks' own inflow variables: NF[r] += sum zf, NL[r] += sum zl over the rack's brokers (in order)
+        const int r = a % D.R;
+        for (int i = D.rk_off[r]; i < D.rk_off[r + 1]; ++i) s += thg[(a < D.R ? 0 : D.B) + D.rk_mem[i]];
+    }
+    S[(size_t)a * D.mcp + c] = s;    // rows NF[r] = r, NL[r] = R + r: exactly the numbering of a
+}
+// rows C6[r] (columns NF, NL: none; own diagonal: sum n + k), regularisation, absent / pinned rows, padding; saves the diagonal
+__global__ void k_lp_schur_fix(LpDev D, const double *thg, double *S, double *diag0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.mcp) return;
+    const int R = D.R;
+    if (i >= D.mc) { for (int k = 0; k < i; ++k) S[(size_t)i * D.mcp + k] = 0.0; S[(size_t)i * D.mcp + i] = 1.0; diag0[i] = 1.0; return; }
+    if (i >= 2 * R && i < 3 * R) {
+        for (int k = 0; k < i; ++k) S[(size_t)i * D.mcp + k] = 0.0;
+        double s = 0.0;
+        if (D.has_n) { const int r = i - 2 * R; for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s += thg[2 * D.B + D.rk_mem[e]]; if (D.has_k) s += thg[4 * D.B + r]; }
+        S[(size_t)i * D.mcp + i] = s;
+    }
+    if (D.rowc[i] == 1) { S[(size_t)i * D.mcp + i] += kLpReg; }
+    else {
+        for (int k = 0; k < i; ++k) S[(size_t)i * D.mcp + k] = 0.0;
+        S[(size_t)i * D.mcp + i] = 1.0;
+    }
+    diag0[i] = S[(size_t)i * D.mcp + i];
+}
+// column of an absent / pinned row below the diagonal (only rack rows can be absent or pinned: i < 3R)
+__global__ void k_lp_schur_fix_cols(LpDev D, double *S) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= D.mc) return;
+    for (int i = 0; i < 3 * D.R && i < k; ++i)
+        if (D.rowc[i] != 1) S[(size_t)k * D.mcp + i] = 0.0;
+}
+
+// ---- dense Cholesky of S (lower, row-major, leading dimension n = mcp, 64 x 64 tiles) ----------------------------------
+__global__ void __launch_bounds__(256) k_lp_chol_diag(double *S, int n, int kb, const double *diag0) {
+    __shared__ double T[kNB][kNB + 1];
+    const int t = threadIdx.x, base = kb * kNB;
+    for (int i = t; i < kNB * kNB; i += 256) T[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
+    __syncthreads();
+    for (int j = 0; j < kNB; ++j) {
+        const double a = T[j][j];
+        const double ljj = (a > kLpPivotRel * diag0[base + j]) ? sqrt(a) : kLpPivotBig;
+        __syncthreads();
+        if (t == 0) T[j][j] = ljj;
+        for (int i = j + 1 + t; i < kNB; i += 256) T[i][j] /= ljj;
+        __syncthreads();
+        // trailing update of the lower triangle: pairs (i, k), j < k <= i
+        const int m = kNB - j - 1;
+        for (int e = t; e < m * m; e += 256) {
+            const int i = j + 1 + e / m, k = j + 1 + e % m;
+            if (k <= i) T[i][k] -= T[i][j] * T[k][j];
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < kNB * kNB; i += 256) if (i % kNB <= i / kNB) S[(size_t)(base + i / kNB) * n + base + i % kNB] = T[i / kNB][i % kNB];
+}
+// row tiles below the diagonal tile: X = A L_kk^-T (every thread solves one row by forward substitution)
+__global__ void __launch_bounds__(64) k_lp_chol_trsm(double *S, int n, int kb) {
+    __shared__ double Lk[kNB][kNB + 1];
+    const int t = threadIdx.x, base = kb * kNB, row = (kb + 1 + blockIdx.x) * kNB + t;
+    for (int i = t; i < kNB * kNB; i += 64) Lk[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
+    __syncthreads();
+    double x[kNB];
+    double *Ar = S + (size_t)row * n + base;
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) x[j] = Ar[j];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        double a = x[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) a -= x[k] * Lk[j][k];
+        x[j] = a / Lk[j][j];
+    }
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) Ar[j] = x[j];
+}
+// trailing update A_ij -= L_ik L_jk^T for tile pairs i >= j > kb; 256 threads, 4 x 4 micro-tiles
+__global__ void __launch_bounds__(256) k_lp_chol_update(double *S, int n, int kb, int nrem) {
+    __shared__ double Li[kNB][kNB + 1], Lj[kNB][kNB + 1];
+    // decode the pair: blockIdx.x = i * (i + 1) / 2 + j over 0 <= j <= i < nrem
+    int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
+    while (bi * (bi + 1) / 2 > (int)blockIdx.x) --bi;
+    const int bj = blockIdx.x - bi * (bi + 1) / 2;
+    const int ti_ = kb + 1 + bi, tj = kb + 1 + bj, base = kb * kNB, t = threadIdx.x;
+    for (int i = t; i < kNB * kNB; i += 256) {
+        Li[i / kNB][i % kNB] = S[(size_t)(ti_ * kNB + i / kNB) * n + base + i % kNB];
+        Lj[i / kNB][i % kNB] = S[(size_t)(tj * kNB + i / kNB) * n + base + i % kNB];
+    }
+    __syncthreads();
+    const int r0 = (t / 16) * 4, c0 = (t % 16) * 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k = 0; k < kNB; ++k) {
+        double li[4], lj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { li[a] = Li[r0 + a][k]; lj[a] = Lj[c0 + a][k]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += li[a] * lj[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (bi != bj || c0 + b <= r0 + a) S[(size_t)(ti_ * kNB + r0 + a) * n + tj * kNB + c0 + b] -= acc[a][b];   // diagonal tiles: lower triangle only
+}
+// L z = r then L^T x = z, in place in `r` (length n); one workgroup of 1024, the vector in LDS
+__global__ void __launch_bounds__(1024) k_lp_trsv(const double *S, int n, double *r) {
+    extern __shared__ double xv[];
+    __shared__ double Lk[kNB][kNB + 1];
+    const int t = threadIdx.x, nt = n / kNB;
+    for (int i = t; i < n; i += 1024) xv[i] = r[i];
+    __syncthreads();
+    for (int kb = 0; kb < nt; ++kb) {
+        const int base = kb * kNB;
+        for (int i = t; i < kNB * kNB; i += 1024) Lk[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
+        __syncthreads();
+        if (t < 64) {   // one wavefront: forward substitution inside the tile
+            double mine = xv[base + t];
+            for (int j = 0; j < kNB; ++j) {
+                const double xj = __shfl(mine, j, 64) / Lk[j][j];
+                if (t == j) mine = xj;
+                else if (t > j) mine -= Lk[t][j] * xj;
+            }
+            xv[base + t] = mine;
+        }
+        __syncthreads();
+        for (int i = base + kNB + t; i < n; i += 1024) {
+            const double *Li = S + (size_t)i * n + base;
+            double a = 0.0;
+            for (int k = 0; k < kNB; ++k) a += Li[k] * xv[base + k];
+            xv[i] -= a;
+        }
+        __syncthreads();
+    }
+    for (int kb = nt - 1; kb >= 0; --kb) {
+        const int base = kb * kNB;
+        for (int i = t; i < kNB * kNB; i += 1024) Lk[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
+        __syncthreads();
+        if (t < 64) {
+            double mine = xv[base + t];
+            for (int j = kNB - 1; j >= 0; --j) {
+                const double xj = __shfl(mine, j, 64) / Lk[j][j];
+                if (t == j) mine = xj;
+                else if (t < j) mine -= Lk[j][t] * xj;
+            }
+            xv[base + t] = mine;
+        }
+        __syncthreads();
+        for (int i = t; i < base; i += 1024) {
+            double a = 0.0;
+            for (int k = 0; k < kNB; ++k) a += S[(size_t)(base + k) * n + i] * xv[base + k];
+            xv[i] -= a;
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < n; i += 1024) r[i] = xv[i];
+}
+
+// ---- rows of A z ------------------------------------------------------------------------------------------------------
+// local rows; mode 0: out = A z, 1: out = b - A z, 2: out = A z + add
+__global__ void k_lp_A_local(LpDev D, const double *z, RowVec out, int mode, RowVec add) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.P) return;
+    const int P = D.P, R = D.R, NJ = D.NJ;
+    double a1 = 0, a2 = 0;
+    for (int r = 0; r < R; ++r) {
+        const double yf = z[(size_t)VYF(D, r) * P + p], yl = z[(size_t)VYL(D, r) * P + p], tt = D.has_t ? z[(size_t)VT(D, r) * P + p] : 0.0;
+        a1 += yf + yl; a2 += yl;
+        out.r7[(size_t)r * P + p] = yf + yl + tt;
+    }
+    for (int j = 0; j < NJ; ++j) {
+        const int b = cur_b(D, p, j);
+        double v5 = 0.0;
+        if (b >= 0) {
+            const double f = z[(size_t)VF(j) * P + p], l = z[(size_t)VL(j) * P + p];
+            a1 += f + l; a2 += l;
+            out.r7[(size_t)D.rack[b] * P + p] += f + l;
+            if (D.has_c5) v5 = f + l + z[(size_t)VQ(j) * P + p];
+        }
+        const bool row5 = D.has_c5 && b >= 0;
+        out.r5[(size_t)j * P + p] = mode == 1 ? (row5 ? 1.0 - v5 : 0.0) : (mode == 2 ? v5 + add.r5[(size_t)j * P + p] : v5);
+    }
+    if (mode == 1) { a1 = D.RF - a1; a2 = 1.0 - a2; }
+    if (mode == 2) { a1 += add.r1[p]; a2 += add.r2[p]; }
+    out.r1[p] = a1; out.r2[p] = a2;
+    if (mode)
+        for (int r = 0; r < R; ++r) {
+            const size_t k = (size_t)r * P + p;
+            out.r7[k] = mode == 1 ? D.phi - out.r7[k] : out.r7[k] + add.r7[k];
+        }
+}
+// coupling rows C3[b], C4[b]: one wavefront per broker; `cb` (may be null): extra per-incidence terms [2 NJ][P] of the eliminations
+__global__ void k_lp_A_broker(LpDev D, const double *z, const double *zg, const double *cb, double *rc, int mode, const double *addc) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int b = blockIdx.x * nw + wave;
+    if (b >= D.B) return;
+    const int P = D.P;
+    double s3 = 0, s4 = 0;
+    for (int e = D.inc_off[b] + lane; e < D.inc_off[b + 1]; e += 64) {
+        const int idx = D.inc[e], p = idx >> 3, j = idx & 7;
+        const double f = z[(size_t)VF(j) * P + p], l = z[(size_t)VL(j) * P + p];
+        s3 += f + l; s4 += l;
+        if (cb) { s3 += cb[(size_t)(2 * j) * P + p]; s4 += cb[(size_t)(2 * j + 1) * P + p]; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { s3 += __shfl_xor(s3, o, 64); s4 += __shfl_xor(s4, o, 64); }
+    if (lane) return;
+    s3 += zg[b] + zg[D.B + b] - (D.has_n ? zg[2 * D.B + b] : 0.0);
+    s4 += zg[D.B + b] - (D.has_m ? zg[3 * D.B + b] : 0.0);
+    const int r3 = RC3(D, b), r4 = RC4(D, b);
+    rc[r3] = mode == 1 ? D.bc[r3] - s3 : (mode == 2 ? s3 + addc[r3] : s3);
+    rc[r4] = mode == 1 ? D.bc[r4] - s4 : (mode == 2 ? s4 + addc[r4] : s4);
+}
+// coupling rows NF[r], NL[r] (one block each: a fixed-order sum over the partitions) and C6[r]; `cr`: extra terms [2 R][P]
+__global__ void __launch_bounds__(kRedBlock) k_lp_A_rack(LpDev D, const double *z, const double *zg, const double *cr, double *rc, int mode, const double *addc) {
+    __shared__ double sh[kRedBlock];
+    const int R = D.R, P = D.P, row = blockIdx.x;     // 0..R-1 NF, R..2R-1 NL, 2R..3R-1 C6
+    const int r = row % R, kind = row / R;
+    double s = 0.0;
+    if (kind < 2) {
+        const double *zz = z + (size_t)(kind == 0 ? VYF(D, r) : VYL(D, r)) * P;
+        const double *cc = cr ? cr + (size_t)(2 * r + kind) * P : nullptr;
+        for (int p = threadIdx.x; p < P; p += kRedBlock) s += zz[p] + (cc ? cc[p] : 0.0);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = kRedBlock / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x) return;
+    s = sh[0];
+    if (kind < 2) { for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s -= zg[(kind == 0 ? 0 : D.B) + D.rk_mem[e]]; }
+    else if (D.has_n) { for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s += zg[2 * D.B + D.rk_mem[e]]; if (D.has_k) s -= zg[4 * D.B + r]; }
+    double out = mode == 1 ? D.bc[row] - s : (mode == 2 ? s + addc[row] : s);
+    if (D.rowc[row] != 1) out = 0.0;      // absent / pinned rows carry no residual and no right-hand side
+    rc[row] = out;
+}
+
+// ---- the normal equations' local eliminations (oracle/kao_lp_port.c::lp_solve_normal, first loop): local right-hand sides in
+// place, the terms they send to the coupling rows into cb [2 NJ][P] (C3 / C4 of replica j) and cr [2 R][P] (NF / NL of rack r)
+__global__ void k_lp_elim_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v, double *cb, double *cr) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.P) return;
+    const int P = D.P, R = D.R, NJ = D.NJ;
+    double r1 = v.r1[p], r2 = v.r2[p];
+    for (int j = 0; j < NJ; ++j) { cb[(size_t)(2 * j) * P + p] = 0.0; cb[(size_t)(2 * j + 1) * P + p] = 0.0; }
+    if (D.has_c5)
+        for (int j = 0; j < NJ; ++j) {
+            const int b = cur_b(D, p, j);
+            if (b < 0) continue;
+            const double g5 = v.r5[(size_t)j * P + p] / fj[((size_t)3 * NJ + j) * P + p];
+            const double k1 = fj[((size_t)4 * NJ + j) * P + p], k2 = fj[((size_t)5 * NJ + j) * P + p];
+            r1 -= k1 * g5; v.r7[(size_t)D.rack[b] * P + p] -= k1 * g5; cb[(size_t)(2 * j) * P + p] -= k1 * g5;
+            r2 -= k2 * g5; cb[(size_t)(2 * j + 1) * P + p] -= k2 * g5;
+        }
+    for (int r = 0; r < R; ++r) {
+        const double d = fr[((size_t)0 * R + r) * P + p], e1 = fr[((size_t)1 * R + r) * P + p], e2 = fr[((size_t)2 * R + r) * P + p];
+        const double g7 = v.r7[(size_t)r * P + p] / d;
+        r1 -= e1 * g7; r2 -= e2 * g7;
+        cr[(size_t)(2 * r) * P + p] = -th[(size_t)VYF(D, r) * P + p] * g7;
+        cr[(size_t)(2 * r + 1) * P + p] = -th[(size_t)VYL(D, r) * P + p] * g7;
+    }
+    for (int j = 0; j < NJ; ++j) {
+        const int b = cur_b(D, p, j);
+        if (b < 0) continue;
+        const int r = D.rack[b];
+        const double g7 = v.r7[(size_t)r * P + p] / fr[((size_t)0 * R + r) * P + p];
+        cb[(size_t)(2 * j) * P + p] -= fj[((size_t)0 * NJ + j) * P + p] * g7;        // eps of C3_j = sig11
+        cb[(size_t)(2 * j + 1) * P + p] -= fj[((size_t)1 * NJ + j) * P + p] * g7;    // eps of C4_j = sig12
+    }
+    const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
+    const double g1 = i11 * r1 + i12 * r2, g2 = i12 * r1 + i22 * r2;
+    v.r1[p] = r1; v.r2[p] = r2;
+    const int nc = 2 * NJ + 2 * R;
+    for (int c = 0; c < nc; ++c) {
+        PCol q;
+        if (!lp_col(D, th, fj, fr, p, c, q)) continue;
+        const double tv = q.v0 * g1 + q.v1 * g2;
+        if (c < 2 * NJ) cb[(size_t)c * P + p] -= tv; else cr[(size_t)(c - 2 * NJ) * P + p] -= tv;
+    }
+}
+// back substitution (second loop): dy of the local rows in place, given dy of the coupling rows
+__global__ void k_lp_back_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.P) return;
+    const int P = D.P, R = D.R, NJ = D.NJ, nc = 2 * NJ + 2 * R;
+    double t1 = v.r1[p], t2 = v.r2[p];
+    for (int c = 0; c < nc; ++c) {
+        PCol q;
+        if (!lp_col(D, th, fj, fr, p, c, q)) continue;
+        const double y = v.rc[q.col];
+        t1 -= q.v0 * y; t2 -= q.v1 * y;
+    }
+    const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
+    const double d1 = i11 * t1 + i12 * t2, d2 = i12 * t1 + i22 * t2;
+    v.r1[p] = d1; v.r2[p] = d2;
+    for (int r = 0; r < R; ++r) {
+        const double e1 = fr[((size_t)1 * R + r) * P + p], e2 = fr[((size_t)2 * R + r) * P + p];
+        v.r7[(size_t)r * P + p] -= e1 * d1 + e2 * d2 + th[(size_t)VYF(D, r) * P + p] * v.rc[RNF(D, r)] + th[(size_t)VYL(D, r) * P + p] * v.rc[RNL(D, r)];
+    }
+    for (int j = 0; j < NJ; ++j) {
+        const int b = cur_b(D, p, j);
+        if (b < 0) continue;
+        v.r7[(size_t)D.rack[b] * P + p] -= fj[((size_t)0 * NJ + j) * P + p] * v.rc[RC3(D, b)] + fj[((size_t)1 * NJ + j) * P + p] * v.rc[RC4(D, b)];
+    }
+    for (int r = 0; r < R; ++r) v.r7[(size_t)r * P + p] /= fr[((size_t)0 * R + r) * P + p];
+    for (int j = 0; j < NJ; ++j) {
+        const int b = cur_b(D, p, j);
+        if (!D.has_c5 || b < 0) { v.r5[(size_t)j * P + p] = 0.0; continue; }
+        const double k1 = fj[((size_t)4 * NJ + j) * P + p], k2 = fj[((size_t)5 * NJ + j) * P + p];
+        v.r5[(size_t)j * P + p] = (v.r5[(size_t)j * P + p] - k1 * (d1 + v.r7[(size_t)D.rack[b] * P + p] + v.rc[RC3(D, b)]) - k2 * (d2 + v.rc[RC4(D, b)]))
+                                  / fj[((size_t)3 * NJ + j) * P + p];
+    }
+}
+
+// ---- interior-point vector kernels ------------------------------------------------------------------------------------
+// z = A^T y (only the starting point needs it as a vector)
+__global__ void k_lp_AT(LpDev D, RowVec y, double *z, double *zg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    if (i < nv) z[i] = var_present(D, (int)(i / D.P), (int)(i % D.P)) ? at_val(D, (int)(i / D.P), (int)(i % D.P), y) : 0.0;
+    else if (i < nv + D.GV) { const int g = (int)(i - nv); zg[g] = gvar_present(D, g) ? at_val_g(D, g, y.rc) : 0.0; }
+}
+// starting point: x = max(x~, 1) capped at half the upper bound, s = max(c - A^T y, 1), v = 1 where bounded
+__global__ void k_lp_start(LpDev D, RowVec y, double *x, double *xg, double *s, double *sg, double *v, double *vg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    if (i < nv) {
+        const int vv = (int)(i / D.P), p = (int)(i % D.P);
+        if (!var_present(D, vv, p)) { x[i] = 1; s[i] = 1; v[i] = 0; return; }
+        const double u = var_ub(D, vv);
+        double xx = x[i] > 1.0 ? x[i] : 1.0;
+        if (u > 0) { const double cap = u * 0.5 > 1e-2 ? u * 0.5 : 1e-2; if (xx > cap) xx = cap; }
+        x[i] = xx;
+        const double ss = var_cost(D, vv, p) - at_val(D, vv, p, y);
+        s[i] = ss > 1.0 ? ss : 1.0;
+        v[i] = u > 0 ? 1.0 : 0.0;
+    } else if (i < nv + D.GV) {
+        const int g = (int)(i - nv);
+        if (!gvar_present(D, g)) { xg[g] = 1; sg[g] = 1; vg[g] = 0; return; }
+        const double u = gvar_ub(D, g);
+        double xx = xg[g] > 1.0 ? xg[g] : 1.0;
+        if (u > 0) { const double cap = u * 0.5 > 1e-2 ? u * 0.5 : 1e-2; if (xx > cap) xx = cap; }
+        xg[g] = xx;
+        const double ss = D.cg[g] - at_val_g(D, g, y.rc);
+        sg[g] = ss > 1.0 ? ss : 1.0;
+        vg[g] = u > 0 ? 1.0 : 0.0;
+    }
+}
+// the cost vector as a variable-space vector (A c for the starting point)
+__global__ void k_lp_cost(LpDev D, double *z, double *zg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    if (i < nv) z[i] = var_present(D, (int)(i / D.P), (int)(i % D.P)) ? var_cost(D, (int)(i / D.P), (int)(i % D.P)) : 0.0;
+    else if (i < nv + D.GV) zg[i - nv] = D.cg[i - nv];
+}
+// dual residual rd = c - A^T y - s + v and the sums {|rd|^2, x.s + w.v, c.x, u.v}; one record per block
+__global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVec s, VarVec v, RowVec y, VarVec rd, double *rec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    double a[4] = {0, 0, 0, 0};
+    if (i < nv) {
+        const int vv = (int)(i / D.P), p = (int)(i % D.P);
+        if (var_present(D, vv, p)) {
+            const double u = var_ub(D, vv), c = var_cost(D, vv, p);
+            const double r = c - at_val(D, vv, p, y) - s.z[i] + v.z[i];
+            rd.z[i] = r; a[0] = r * r; a[1] = x.z[i] * s.z[i]; a[2] = c * x.z[i];
+            if (u > 0) { a[1] += (u - x.z[i]) * v.z[i]; a[3] = u * v.z[i]; }
+        } else rd.z[i] = 0.0;
+    } else if (i < nv + D.GV) {
+        const int g = (int)(i - nv);
+        if (gvar_present(D, g)) {
+            const double u = gvar_ub(D, g), c = D.cg[g];
+            const double r = c - at_val_g(D, g, y.rc) - s.zg[g] + v.zg[g];
+            rd.zg[g] = r; a[0] = r * r; a[1] = x.zg[g] * s.zg[g]; a[2] = c * x.zg[g];
+            if (u > 0) { a[1] += (u - x.zg[g]) * v.zg[g]; a[3] = u * v.zg[g]; }
+        } else rd.zg[g] = 0.0;
+    }
+    block_reduce(a, 4, false, rec + (size_t)blockIdx.x * kRedVals);
+}
+// sums over the rows: {|rp|^2 (local rows), b.y (local rows)}; one record per block (thread per partition)
+__global__ void __launch_bounds__(kRedBlock) k_lp_rowsums(LpDev D, RowVec rp, RowVec y, double *rec) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double a[2] = {0, 0};
+    if (p < D.P) {
+        const int P = D.P;
+        a[0] = rp.r1[p] * rp.r1[p] + rp.r2[p] * rp.r2[p];
+        a[1] = D.RF * y.r1[p] + y.r2[p];
+        for (int r = 0; r < D.R; ++r) { const double q = rp.r7[(size_t)r * P + p]; a[0] += q * q; a[1] += D.phi * y.r7[(size_t)r * P + p]; }
+        for (int j = 0; j < D.NJ; ++j) {
+            const double q = rp.r5[(size_t)j * P + p]; a[0] += q * q;
+            if (D.has_c5 && cur_b(D, p, j) >= 0) a[1] += y.r5[(size_t)j * P + p];
+        }
+    }
+    block_reduce(a, 2, false, rec + (size_t)blockIdx.x * kRedVals);
+}
+// the same over the coupling rows (one block)
+__global__ void __launch_bounds__(kRedBlock) k_lp_rowsums_c(LpDev D, const double *rpc, const double *yc, double *out) {
+    double a[2] = {0, 0};
+    for (int i = threadIdx.x; i < D.mc; i += kRedBlock) { a[0] += rpc[i] * rpc[i]; if (D.rowc[i]) a[1] += D.bc[i] * yc[i]; }
+    __shared__ double rec[kRedVals];
+    block_reduce(a, 2, false, rec);
+    if (threadIdx.x == 0) { out[0] += rec[0]; out[1] += rec[1]; }
+}
+// h = rd - rxs / x + rwv / w and g = theta h; rxs, rwv are parked in ds, dv (k_lp_dir turns them into the directions).
+// pass 1 (corrector): rxs = sigma mu - x s - dx_aff ds_aff, rwv = sigma mu - w v + dx_aff dv_aff
+__global__ void k_lp_h(LpDev D, int pass, double sigma_mu, VarVec x, VarVec s, VarVec v, VarVec th, VarVec rd, VarVec dxa, VarVec dsa, VarVec dva,
+                       VarVec h, VarVec g, VarVec ds, VarVec dv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    if (i < nv) {
+        const int vv = (int)(i / D.P), p = (int)(i % D.P);
+        if (!var_present(D, vv, p)) { h.z[i] = 0; g.z[i] = 0; ds.z[i] = 0; dv.z[i] = 0; return; }
+        const double u = var_ub(D, vv), w = u > 0 ? u - x.z[i] : 1.0;
+        double rxs = -x.z[i] * s.z[i], rwv = u > 0 ? -w * v.z[i] : 0.0;
+        if (pass) { rxs += sigma_mu - dxa.z[i] * dsa.z[i]; if (u > 0) rwv += sigma_mu + dxa.z[i] * dva.z[i]; }
+        const double hh = rd.z[i] - rxs / x.z[i] + (u > 0 ? rwv / w : 0.0);
+        h.z[i] = hh; g.z[i] = th.z[i] * hh; ds.z[i] = rxs; dv.z[i] = rwv;
+    } else if (i < nv + D.GV) {
+        const int k = (int)(i - nv);
+        if (!gvar_present(D, k)) { h.zg[k] = 0; g.zg[k] = 0; ds.zg[k] = 0; dv.zg[k] = 0; return; }
+        const double u = gvar_ub(D, k), w = u > 0 ? u - x.zg[k] : 1.0;
+        double rxs = -x.zg[k] * s.zg[k], rwv = u > 0 ? -w * v.zg[k] : 0.0;
+        if (pass) { rxs += sigma_mu - dxa.zg[k] * dsa.zg[k]; if (u > 0) rwv += sigma_mu + dxa.zg[k] * dva.zg[k]; }
+        const double hh = rd.zg[k] - rxs / x.zg[k] + (u > 0 ? rwv / w : 0.0);
+        h.zg[k] = hh; g.zg[k] = th.zg[k] * hh; ds.zg[k] = rxs; dv.zg[k] = rwv;
+    }
+}
+// dx = theta (A^T dy - h), ds = (rxs - s dx) / x, dv = (rwv + v dx) / w; step lengths to the boundary {alpha_p, alpha_d} (min)
+__global__ void __launch_bounds__(kRedBlock) k_lp_dir(LpDev D, VarVec x, VarVec s, VarVec v, VarVec th, VarVec h, RowVec dy, VarVec dx, VarVec ds, VarVec dv, double *rec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    double a[2] = {1.0, 1.0};
+    double xi = 0, si = 0, vi = 0, thi = 0, hi = 0, atv = 0, u = 0, rxs = 0, rwv = 0;
+    bool on = false;
+    if (i < nv) {
+        const int vv = (int)(i / D.P), p = (int)(i % D.P);
+        on = var_present(D, vv, p);
+        if (on) { xi = x.z[i]; si = s.z[i]; vi = v.z[i]; thi = th.z[i]; hi = h.z[i]; atv = at_val(D, vv, p, dy); u = var_ub(D, vv); rxs = ds.z[i]; rwv = dv.z[i]; }
+    } else if (i < nv + D.GV) {
+        const int k = (int)(i - nv);
+        on = gvar_present(D, k);
+        if (on) { xi = x.zg[k]; si = s.zg[k]; vi = v.zg[k]; thi = th.zg[k]; hi = h.zg[k]; atv = at_val_g(D, k, dy.rc); u = gvar_ub(D, k); rxs = ds.zg[k]; rwv = dv.zg[k]; }
+    }
+    double ddx = 0, dds = 0, ddv = 0;
+    if (on) {
+        ddx = thi * (atv - hi);
+        dds = (rxs - si * ddx) / xi;
+        if (ddx < 0) a[0] = fmin(a[0], -xi / ddx);
+        if (dds < 0) a[1] = fmin(a[1], -si / dds);
+        if (u > 0) {
+            const double w = u - xi;
+            ddv = (rwv + vi * ddx) / w;
+            if (ddx > 0) a[0] = fmin(a[0], w / ddx);
+            if (ddv < 0) a[1] = fmin(a[1], -vi / ddv);
+        }
+    }
+    if (i < nv) { dx.z[i] = ddx; ds.z[i] = dds; dv.z[i] = ddv; }
+    else if (i < nv + D.GV) { dx.zg[i - nv] = ddx; ds.zg[i - nv] = dds; dv.zg[i - nv] = ddv; }
+    block_reduce(a, 2, true, rec + (size_t)blockIdx.x * kRedVals);
+}
+// sum (x + ap dx)(s + ad ds) + (w - ap dx)(v + ad dv)
+__global__ void __launch_bounds__(kRedBlock) k_lp_muaff(LpDev D, double ap, double ad, VarVec x, VarVec s, VarVec v, VarVec dx, VarVec ds, VarVec dv, double *rec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    double a[1] = {0};
+    if (i < nv) {
+        const int vv = (int)(i / D.P), p = (int)(i % D.P);
+        if (var_present(D, vv, p)) {
+            const double u = var_ub(D, vv);
+            a[0] = (x.z[i] + ap * dx.z[i]) * (s.z[i] + ad * ds.z[i]);
+            if (u > 0) a[0] += (u - x.z[i] - ap * dx.z[i]) * (v.z[i] + ad * dv.z[i]);
+        }
+    } else if (i < nv + D.GV) {
+        const int k = (int)(i - nv);
+        if (gvar_present(D, k)) {
+            const double u = gvar_ub(D, k);
+            a[0] = (x.zg[k] + ap * dx.zg[k]) * (s.zg[k] + ad * ds.zg[k]);
+            if (u > 0) a[0] += (u - x.zg[k] - ap * dx.zg[k]) * (v.zg[k] + ad * dv.zg[k]);
+        }
+    }
+    block_reduce(a, 1, false, rec + (size_t)blockIdx.x * kRedVals);
+}
+__global__ void k_lp_update(LpDev D, double ap, double ad, VarVec x, VarVec s, VarVec v, VarVec dx, VarVec ds, VarVec dv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    if (i < nv) {
+        if (!var_present(D, (int)(i / D.P), (int)(i % D.P))) return;
+        x.z[i] += ap * dx.z[i]; s.z[i] += ad * ds.z[i];
+        if (var_ub(D, (int)(i / D.P)) > 0) v.z[i] += ad * dv.z[i];
+    } else if (i < nv + D.GV) {
+        const int k = (int)(i - nv);
+        if (!gvar_present(D, k)) return;
+        x.zg[k] += ap * dx.zg[k]; s.zg[k] += ad * ds.zg[k];
+        if (gvar_ub(D, k) > 0) v.zg[k] += ad * dv.zg[k];
+    }
+}
+// y += ad dy over all rows (local rows stored contiguously: r1 r2 r7 r5, then rc)
+__global__ void k_lp_axpy(double a, const double *d, double *y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * d[i];
+}
+// row duals -> K-bound multipliers in its fixed point: g[r] = -y_C6[r], a[b] = -y_C3[b] - g[rack b], l[b] = -y_C4[b]
+__global__ void k_lp_multipliers(LpDev D, const double *yc, int32_t *a, int32_t *l, int32_t *g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    auto fx = [](double v) { v = rint(v * kDualScale); v = fmin(fmax(v, -(double)kDualClamp), (double)kDualClamp); return (int32_t)v; };
+    if (i < D.B) {
+        const double gr = D.rowc[RC6(D, D.rack[i])] == 1 ? -yc[RC6(D, D.rack[i])] : 0.0;
+        a[i] = fx(-yc[RC3(D, i)] - gr);
+        l[i] = fx(-yc[RC4(D, i)]);
+    }
+    if (i < D.R) g[i] = fx(D.rowc[RC6(D, i)] == 1 ? -yc[RC6(D, i)] : 0.0);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Host driver
+struct LpCtx {
+    LpDev D{};
+    int device = 0;
+    hipStream_t st = nullptr;
+    std::vector<void *> bufs;
+    long nvar = 0, nub = 0;
+    double nb = 1, ncn = 1;
+    // vectors
+    VarVec x{}, s{}, v{}, th{}, rd{}, h{}, g{}, d1{}, d2{}, dsa{}, dva{}, ds{}, dv{};
+    RowVec y{}, rp{}, w1{}, w2{};
+    size_t rows_local = 0;     // doubles of the local rows of one RowVec (r1 r2 r7 r5 contiguous)
+    double *fj = nullptr, *fr = nullptr, *ti = nullptr, *S = nullptr, *diag0 = nullptr, *cb = nullptr, *cr = nullptr;
+    double *rec = nullptr, *red = nullptr, *part = nullptr, *ylast = nullptr;
+    int32_t *d_mult = nullptr;
+    int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
+    double *h_red = nullptr;   // pinned
+
+    template <class T> int alloc(T **p, size_t n) {
+        void *q = nullptr;
+        if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return fail(KAO_ERR_NOMEM, "KAO-LP: hipMalloc failed");
+        bufs.push_back(q);
+        *p = static_cast<T *>(q);
+        return KAO_OK;
+    }
+    template <class T> int upload(T **p, const std::vector<T> &hv) {
+        int rc = alloc(p, hv.size());
+        if (rc) return rc;
+        if (!hv.empty()) HIP_TRY(hipMemcpy(*p, hv.data(), hv.size() * sizeof(T), hipMemcpyHostToDevice));
+        return KAO_OK;
+    }
+    int var_vec(VarVec &vv) {
+        int rc = alloc(&vv.z, (size_t)D.NV * D.P + D.GV);
+        vv.zg = vv.z + (size_t)D.NV * D.P;      // contiguous: kernels index the global variables right behind the partition ones
+        return rc;
+    }
+    int row_vec(RowVec &r) {
+        int rc = alloc(&r.r1, rows_local + D.mcp);
+        r.r2 = r.r1 + D.P; r.r7 = r.r2 + D.P; r.r5 = r.r7 + (size_t)D.P * D.R; r.rc = r.r1 + rows_local;
+        return rc;
+    }
+    ~LpCtx() {
+        for (void *p : bufs) (void)hipFree(p);
+        if (h_red) (void)hipHostFree(h_red);
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+namespace {
+
+int lp_reduce(LpCtx &c, int nrec, int n, bool is_min, double *out_host) {
+    // red[0..n) accumulates; the caller has cleared or preset it
+    hipLaunchKernelGGL(k_lp_red_final, dim3(1), dim3(64), 0, c.st, c.rec, nrec, n, is_min ? 1 : 0, c.red);
+    if (out_host) {
+        HIP_TRY(hipMemcpyAsync(c.h_red, c.red, sizeof(double) * kRedVals, hipMemcpyDeviceToHost, c.st));
+        HIP_TRY(hipStreamSynchronize(c.st));
+        std::memcpy(out_host, c.h_red, sizeof(double) * kRedVals);
+    }
+    return KAO_OK;
+}
+int lp_red_preset(LpCtx &c, double v) {
+    double init[kRedVals];
+    for (double &q : init) q = v;
+    HIP_TRY(hipMemcpyAsync(c.red, init, sizeof init, hipMemcpyHostToDevice, c.st));
+    HIP_TRY(hipStreamSynchronize(c.st));   // `init` is a stack buffer
+    return KAO_OK;
+}
+
+// rows of A z into `out` (mode 0 plain, 1 = b - A z, 2 = A z + add), with the optional elimination terms cb / cr
+void lp_A(LpCtx &c, const VarVec &z, const RowVec &out, int mode, const RowVec &add, const double *cb, const double *cr, bool local) {
+    const LpDev &D = c.D;
+    if (local) hipLaunchKernelGGL(k_lp_A_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, z.z, out, mode, add);
+    hipLaunchKernelGGL(k_lp_A_broker, dim3((D.B + 3) / 4), dim3(256), 0, c.st, D, z.z, z.zg, cb, out.rc, mode, add.rc);
+    hipLaunchKernelGGL(k_lp_A_rack, dim3(3 * D.R), dim3(kRedBlock), 0, c.st, D, z.z, z.zg, cr, out.rc, mode, add.rc);
+}
+
+int lp_factor(LpCtx &c) {
+    const LpDev &D = c.D;
+    hipLaunchKernelGGL(k_lp_factor_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti);
+    const size_t lds_b = (size_t)c.broker_waves * 2 * D.mc * sizeof(double);
+    hipLaunchKernelGGL(k_lp_schur_broker, dim3((D.B + c.broker_waves - 1) / c.broker_waves), dim3(64 * c.broker_waves), lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
+    const int n2 = 2 * D.R, per = 6 * n2 + D.R;
+    hipLaunchKernelGGL(k_lp_schur_rack, dim3(c.rack_blocks), dim3(256), (size_t)c.rack_tile * per * sizeof(double), c.st, D, c.th.z, c.fj, c.fr, c.ti, c.rack_chunk, c.rack_tile, c.part);
+    hipLaunchKernelGGL(k_lp_schur_rack_sum, dim3((n2 * n2 + 255) / 256), dim3(256), 0, c.st, D, c.part, c.rack_blocks, c.th.zg, c.S);
+    hipLaunchKernelGGL(k_lp_schur_fix, dim3((D.mcp + 255) / 256), dim3(256), 0, c.st, D, c.th.zg, c.S, c.diag0);
+    hipLaunchKernelGGL(k_lp_schur_fix_cols, dim3((D.mc + 255) / 256), dim3(256), 0, c.st, D, c.S);
+    const int nt = D.mcp / kNB;
+    for (int kb = 0; kb < nt; ++kb) {
+        hipLaunchKernelGGL(k_lp_chol_diag, dim3(1), dim3(256), 0, c.st, c.S, D.mcp, kb, c.diag0);
+        const int nrem = nt - kb - 1;
+        if (nrem <= 0) break;
+        hipLaunchKernelGGL(k_lp_chol_trsm, dim3(nrem), dim3(64), 0, c.st, c.S, D.mcp, kb);
+        hipLaunchKernelGGL(k_lp_chol_update, dim3(nrem * (nrem + 1) / 2), dim3(256), 0, c.st, c.S, D.mcp, kb, nrem);
+    }
+    HIP_TRY(hipGetLastError());
+    return KAO_OK;
+}
+
+// N dy = rho, in place in `v` (local rows + coupling rows)
+int lp_solve_normal(LpCtx &c, const RowVec &v, const VarVec *zsrc, const RowVec *addsrc) {
+    // the coupling right-hand side is GATHERED: rows of A z (z = *zsrc, or nothing) + *addsrc + the elimination terms
+    const LpDev &D = c.D;
+    hipLaunchKernelGGL(k_lp_elim_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, c.cb, c.cr);
+    const VarVec &z = zsrc ? *zsrc : c.g;    // (c.g is zeroed by the caller when there is no source vector)
+    lp_A(c, z, v, addsrc ? 2 : 0, addsrc ? *addsrc : v, c.cb, c.cr, false);
+    hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, c.S, D.mcp, v.rc);
+    hipLaunchKernelGGL(k_lp_back_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v);
+    HIP_TRY(hipGetLastError());
+    return KAO_OK;
+}
+
+}  // namespace
+
+// Builds the device image of one topic's compact LP.
+int lp_open(const kao_topic *t, LpCtx **out) {
+    int rc = require_init();
+    if (rc) return rc;
+    rc = validate(t);
+    if (rc) return rc;
+    int32_t bd[8];
+    derive_bounds(t, bd);
+    const int P = t->n_partitions, B = t->n_brokers, R = t->n_racks, NJ = t->rf_cur;
+    const int mc = 3 * R + 2 * B;
+    if ((size_t)2 * mc * sizeof(double) > 150 * 1024) return fail(KAO_ERR_UNSUPPORTED, "KAO-LP: more than ~4,700 brokers (a Schur row pair must fit LDS)");
+    if (NJ > 8 || P >= (1 << 28)) return fail(KAO_ERR_UNSUPPORTED, "KAO-LP: current RF > 8");
+    LpCtx *c = new LpCtx();
+    c->device = cur_device();
+    LpDev &D = c->D;
+    D.P = P; D.B = B; D.R = R; D.NJ = NJ; D.RF = t->rf; D.NV = 3 * NJ + 3 * R; D.GV = 4 * B + R; D.mc = mc; D.mcp = (mc + kNB - 1) / kNB * kNB;
+    D.phi = bd[7];
+    D.has_c5 = bd[7] >= 2; D.has_t = bd[7] > bd[6]; D.t_ub = (D.has_t && bd[6] > 0) ? bd[7] - bd[6] : 0;
+    D.has_n = bd[1] > bd[0]; D.n_ub = bd[1] - bd[0];
+    D.has_m = bd[3] > bd[2]; D.m_ub = bd[3] - bd[2];
+    D.has_k = D.has_n && bd[5] > bd[4]; D.k_ub = bd[5] - bd[4];
+    auto bail = [&](int code) { delete c; return code; };
+    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) return bail(fail(KAO_ERR_HIP, "KAO-LP: stream"));
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_red), sizeof(double) * kRedVals) != hipSuccess) return bail(fail(KAO_ERR_NOMEM, "KAO-LP: pinned buffer"));
+    // structure
+    std::vector<uint16_t> cur(t->current, t->current + (size_t)P * NJ);
+    std::vector<uint8_t> rack(t->rack_of, t->rack_of + B);
+    std::vector<int> inc_off((size_t)B + 1, 0), rk_off((size_t)R + 1, 0), rsz((size_t)R, 0);
+    for (int p = 0; p < P; ++p)
+        for (int j = 0; j < NJ; ++j) { const unsigned b = cur[(size_t)p * NJ + j]; if (b != KAO_NONE && (int)b < B) inc_off[b + 1]++; }
+    for (int b = 0; b < B; ++b) { inc_off[(size_t)b + 1] += inc_off[(size_t)b]; rsz[rack[(size_t)b]]++; }
+    std::vector<int> inc((size_t)inc_off[(size_t)B]), fill(inc_off.begin(), inc_off.end() - 1);
+    for (int p = 0; p < P; ++p)
+        for (int j = 0; j < NJ; ++j) { const unsigned b = cur[(size_t)p * NJ + j]; if (b != KAO_NONE && (int)b < B) inc[(size_t)fill[b]++] = (p << 3) | j; }
+    for (int r = 0; r < R; ++r) rk_off[(size_t)r + 1] = rk_off[(size_t)r] + rsz[(size_t)r];
+    std::vector<int> rk_mem((size_t)B), rfill(rk_off.begin(), rk_off.end() - 1);
+    for (int b = 0; b < B; ++b) rk_mem[(size_t)rfill[rack[(size_t)b]]++] = b;
+    std::vector<double> cost((size_t)2 * NJ * P, 0.0), cg((size_t)D.GV, 0.0), bc((size_t)mc, 0.0);
+    std::vector<unsigned char> rowc((size_t)mc, 0);
+    double ncn = 0, nbn = 0;
+    long nvar = 0, nub = 0;
+    for (int p = 0; p < P; ++p)
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned b = cur[(size_t)p * NJ + j];
+            if (b == KAO_NONE || (int)b >= B) continue;
+            const int cr = j == 0 ? 0 : 1, bw = t->broker_w ? t->broker_w[b] : 0, bwl = t->broker_wl ? t->broker_wl[b] : 0;
+            const double cf = -(double)(t->w[cr][1] + bw), cl = -(double)(t->w[cr][0] + bw + bwl);
+            cost[(size_t)(2 * j) * P + p] = cf; cost[(size_t)(2 * j + 1) * P + p] = cl;
+            ncn += cf * cf + cl * cl;
+            nvar += 2 + (D.has_c5 ? 1 : 0);
+            if (D.has_c5) nbn += 1.0;
+        }
+    nvar += (long)P * R * (2 + (D.has_t ? 1 : 0));
+    if (D.t_ub) nub += (long)P * R;
+    for (int b = 0; b < B; ++b) {
+        const int bw = t->broker_w ? t->broker_w[b] : 0, bwl = t->broker_wl ? t->broker_wl[b] : 0;
+        cg[(size_t)b] = -(double)bw; cg[(size_t)B + b] = -(double)(bw + bwl);
+        ncn += cg[(size_t)b] * cg[(size_t)b] + cg[(size_t)B + b] * cg[(size_t)B + b];
+        nvar += 2 + (D.has_n ? 1 : 0) + (D.has_m ? 1 : 0);
+        nub += (D.has_n ? 1 : 0) + (D.has_m ? 1 : 0);
+        rowc[(size_t)(3 * R + 2 * b)] = 1; bc[(size_t)(3 * R + 2 * b)] = bd[0];
+        rowc[(size_t)(3 * R + 2 * b + 1)] = 1; bc[(size_t)(3 * R + 2 * b + 1)] = bd[2];
+    }
+    for (int r = 0; r < R; ++r) {
+        if (D.has_k) { nvar++; nub++; }
+        rowc[(size_t)r] = 1; rowc[(size_t)(R + r)] = 1;
+        if (D.has_n) { rowc[(size_t)(2 * R + r)] = 1; bc[(size_t)(2 * R + r)] = (double)bd[4] - (double)rsz[(size_t)r] * bd[0]; }
+    }
+    if (!D.has_n) rowc[0] = 2;                 // exact row dependencies (oracle/kao_lp_port.c): NF[0] / NL[0] pinned
+    if (!D.has_m) rowc[(size_t)R] = 2;
+    nbn += (double)P * t->rf * t->rf + (double)P + (double)P * R * bd[7] * bd[7];
+    for (double q : bc) nbn += q * q;
+    c->nvar = nvar; c->nub = nub; c->nb = 1.0 + std::sqrt(nbn); c->ncn = 1.0 + std::sqrt(ncn);
+    uint16_t *d_cur; uint8_t *d_rack; int *d_io, *d_inc, *d_ro, *d_rm; double *d_c, *d_cg, *d_bc; unsigned char *d_rowc;
+    if ((rc = c->upload(&d_cur, cur)) || (rc = c->upload(&d_rack, rack)) || (rc = c->upload(&d_io, inc_off)) || (rc = c->upload(&d_inc, inc)) ||
+        (rc = c->upload(&d_ro, rk_off)) || (rc = c->upload(&d_rm, rk_mem)) || (rc = c->upload(&d_c, cost)) || (rc = c->upload(&d_cg, cg)) ||
+        (rc = c->upload(&d_bc, bc)) || (rc = c->upload(&d_rowc, rowc)))
+        return bail(rc);
+    D.cur = d_cur; D.rack = d_rack; D.inc_off = d_io; D.inc = d_inc; D.rk_off = d_ro; D.rk_mem = d_rm; D.c = d_c; D.cg = d_cg; D.bc = d_bc; D.rowc = d_rowc;
+    c->rows_local = (size_t)P * (2 + R + NJ);
+    for (VarVec *vv : {&c->x, &c->s, &c->v, &c->th, &c->rd, &c->h, &c->g, &c->d1, &c->d2, &c->dsa, &c->dva, &c->ds, &c->dv})
+        if ((rc = c->var_vec(*vv))) return bail(rc);
+    for (RowVec *rv : {&c->y, &c->rp, &c->w1, &c->w2})
+        if ((rc = c->row_vec(*rv))) return bail(rc);
+    const size_t nvtot = (size_t)D.NV * P + D.GV;
+    c->nblk_var = (int)((nvtot + kRedBlock - 1) / kRedBlock);
+    c->nblk_p = (P + 255) / 256;
+    c->broker_waves = std::max(1, std::min(4, (int)((150 * 1024) / ((size_t)2 * mc * sizeof(double)))));
+    const int n2 = 2 * R, per = 6 * n2 + R;
+    c->rack_tile = std::max(1, std::min(16, (int)((64 * 1024) / ((size_t)per * sizeof(double)))));
+    c->rack_chunk = std::max(c->rack_tile, ((P + 255) / 256 + c->rack_tile - 1) / c->rack_tile * c->rack_tile);   // about 256 blocks
+    c->rack_blocks = (P + c->rack_chunk - 1) / c->rack_chunk;
+    if ((rc = c->alloc(&c->fj, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->fr, (size_t)3 * R * P)) || (rc = c->alloc(&c->ti, (size_t)3 * P)) ||
+        (rc = c->alloc(&c->S, (size_t)D.mcp * D.mcp)) || (rc = c->alloc(&c->diag0, (size_t)D.mcp)) || (rc = c->alloc(&c->cb, (size_t)2 * NJ * P)) ||
+        (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
+        (rc = c->alloc(&c->red, (size_t)kRedVals)) || (rc = c->alloc(&c->part, (size_t)c->rack_blocks * n2 * n2)) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
+        (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)))
+        return bail(rc);
+    // dynamic LDS beyond 64 KiB has to be enabled per kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_rack), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    for (const VarVec *vv : {&c->x, &c->s, &c->v, &c->th, &c->rd, &c->h, &c->g, &c->d1, &c->d2, &c->dsa, &c->dva, &c->ds, &c->dv})
+        HIP_TRY(hipMemsetAsync(vv->z, 0, nvtot * sizeof(double), c->st));
+    for (const RowVec *rv : {&c->y, &c->rp, &c->w1, &c->w2}) HIP_TRY(hipMemsetAsync(rv->r1, 0, (c->rows_local + D.mcp) * sizeof(double), c->st));
+    HIP_TRY(hipMemsetAsync(c->S, 0, (size_t)D.mcp * D.mcp * sizeof(double), c->st));
+    HIP_TRY(hipStreamSynchronize(c->st));
+    *out = c;
+    return KAO_OK;
+}
+
+void lp_close(LpCtx *c) { delete c; }
+
+// The interior-point solve.  multipliers (host, may be null): a[B] l[B] g[R] in K-bound's fixed point; stats[8] = {iterations,
+// README objective of the primal iterate, of the dual iterate, status (0 converged, 1 iteration limit, 3 stalled: the last finite
+// iterate is returned), mu, relative primal infeasibility, relative dual infeasibility, milliseconds}; trace (may be null):
+// 5 doubles per iteration.
+int lp_solve(LpCtx *cp, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace) {
+    LpCtx &c = *cp;
+    const LpDev &D = c.D;
+    HIP_TRY(hipSetDevice(c.device));
+    const double t0 = now_s();
+    const size_t nvtot = (size_t)D.NV * D.P + D.GV;
+    const dim3 gv((unsigned)((nvtot + 255) / 256)), b256(256);
+    int rc;
+    double hr[kRedVals];
+    // ---- starting point: theta = 1; x~ = A^T (A A^T)^-1 b; y = (A A^T)^-1 A c; s = c - A^T y
+    hipLaunchKernelGGL(k_lp_theta, dim3((unsigned)(((size_t)D.NV * D.P + 255) / 256)), b256, 0, c.st, D, c.x.z, c.s.z, c.v.z, c.th.z, 1);
+    hipLaunchKernelGGL(k_lp_theta_g, dim3((D.GV + 255) / 256), b256, 0, c.st, D, c.x.zg, c.s.zg, c.v.zg, c.th.zg, 1);
+    if ((rc = lp_factor(c))) return rc;
+    HIP_TRY(hipMemsetAsync(c.g.z, 0, nvtot * sizeof(double), c.st));
+    lp_A(c, c.g, c.w1, 1, c.w1, nullptr, nullptr, true);                  // w1 = b - A 0 = b (local rows)
+    if ((rc = lp_solve_normal(c, c.w1, nullptr, &c.w1))) return rc;       // coupling rhs = gathered (0 + b_c + eliminations)
+    hipLaunchKernelGGL(k_lp_AT, gv, b256, 0, c.st, D, c.w1, c.x.z, c.x.zg);
+    hipLaunchKernelGGL(k_lp_cost, gv, b256, 0, c.st, D, c.g.z, c.g.zg);
+    lp_A(c, c.g, c.y, 0, c.y, nullptr, nullptr, true);                    // y = A c (local rows; the coupling rows are gathered again below)
+    if ((rc = lp_solve_normal(c, c.y, &c.g, nullptr))) return rc;
+    hipLaunchKernelGGL(k_lp_start, gv, b256, 0, c.st, D, c.y, c.x.z, c.x.zg, c.s.z, c.s.zg, c.v.z, c.v.zg);
+    int status = 1, it = 0;
+    double pobj = 0, dobj = 0, plast = 0, dlast = 0, mu = 0, pinf = 0, dinf = 0;
+    bool have_last = false;
+    for (it = 0;; ++it) {
+        // residuals and the stopping test
+        lp_A(c, c.x, c.rp, 1, c.rp, nullptr, nullptr, true);
+        hipLaunchKernelGGL(k_lp_resid, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, c.x, c.s, c.v, c.y, c.rd, c.rec);
+        if ((rc = lp_red_preset(c, 0.0)) || (rc = lp_reduce(c, c.nblk_var, 4, false, hr))) return rc;
+        const double din = hr[0], xs = hr[1], cx = hr[2], uv = hr[3];
+        hipLaunchKernelGGL(k_lp_rowsums, dim3(c.nblk_p), dim3(kRedBlock), 0, c.st, D, c.rp, c.y, c.rec);
+        if ((rc = lp_red_preset(c, 0.0))) return rc;
+        hipLaunchKernelGGL(k_lp_rowsums_c, dim3(1), dim3(kRedBlock), 0, c.st, D, c.rp.rc, c.y.rc, c.red);
+        if ((rc = lp_reduce(c, c.nblk_p, 2, false, hr))) return rc;
+        pobj = cx; dobj = hr[1] - uv;
+        mu = xs / (double)(c.nvar + c.nub); pinf = std::sqrt(hr[0]) / c.nb; dinf = std::sqrt(din) / c.ncn;
+        if (trace) { trace[5 * it] = mu; trace[5 * it + 1] = pobj; trace[5 * it + 2] = dobj; trace[5 * it + 3] = pinf; trace[5 * it + 4] = dinf; }
+        if (!(mu == mu) || !(pobj == pobj) || !(dobj == dobj) || !std::isfinite(mu) || !std::isfinite(dobj)) { status = 3; break; }
+        HIP_TRY(hipMemcpyAsync(c.ylast, c.y.rc, (size_t)D.mcp * sizeof(double), hipMemcpyDeviceToDevice, c.st));
+        plast = pobj; dlast = dobj; have_last = true;
+        if (std::fabs(pobj - dobj) / (1.0 + std::fabs(pobj)) < tol && pinf < 100 * tol && dinf < tol) { status = 0; break; }
+        if (it >= maxit) { status = 1; break; }
+        hipLaunchKernelGGL(k_lp_theta, dim3((unsigned)(((size_t)D.NV * D.P + 255) / 256)), b256, 0, c.st, D, c.x.z, c.s.z, c.v.z, c.th.z, 0);
+        hipLaunchKernelGGL(k_lp_theta_g, dim3((D.GV + 255) / 256), b256, 0, c.st, D, c.x.zg, c.s.zg, c.v.zg, c.th.zg, 0);
+        if ((rc = lp_factor(c))) return rc;
+        double ap = 1, ad = 1, sigma_mu = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const VarVec &dx = pass ? c.d2 : c.d1, &pds = pass ? c.ds : c.dsa, &pdv = pass ? c.dv : c.dva;
+            const RowVec &dy = pass ? c.w2 : c.w1;
+            hipLaunchKernelGGL(k_lp_h, gv, b256, 0, c.st, D, pass, sigma_mu, c.x, c.s, c.v, c.th, c.rd, c.d1, c.dsa, c.dva, c.h, c.g, pds, pdv);
+            lp_A(c, c.g, dy, 2, c.rp, nullptr, nullptr, true);            // local rows: A (theta h) + rp
+            if ((rc = lp_solve_normal(c, dy, &c.g, &c.rp))) return rc;    // coupling rows gathered with the elimination terms
+            hipLaunchKernelGGL(k_lp_dir, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, c.x, c.s, c.v, c.th, c.h, dy, dx, pds, pdv, c.rec);
+            if ((rc = lp_red_preset(c, 1.0)) || (rc = lp_reduce(c, c.nblk_var, 2, true, hr))) return rc;
+            ap = hr[0]; ad = hr[1];
+            if (pass == 0) {
+                hipLaunchKernelGGL(k_lp_muaff, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, ap, ad, c.x, c.s, c.v, c.d1, c.dsa, c.dva, c.rec);
+                if ((rc = lp_red_preset(c, 0.0)) || (rc = lp_reduce(c, c.nblk_var, 1, false, hr))) return rc;
+                const double ratio = hr[0] / (double)(c.nvar + c.nub) / mu;
+                sigma_mu = ratio * ratio * ratio * mu;
+            }
+        }
+        if (ap < 1.0) ap *= 0.9995;
+        if (ad < 1.0) ad *= 0.9995;
+        hipLaunchKernelGGL(k_lp_update, gv, b256, 0, c.st, D, ap, ad, c.x, c.s, c.v, c.d2, c.ds, c.dv);
+        const size_t nrow = c.rows_local + D.mcp;
+        hipLaunchKernelGGL(k_lp_axpy, dim3((unsigned)((nrow + 255) / 256)), b256, 0, c.st, ad, c.w2.r1, c.y.r1, nrow);
+    }
+    if (!have_last) return fail(KAO_ERR_HIP, "KAO-LP: the starting point is not finite");
+    hipLaunchKernelGGL(k_lp_multipliers, dim3((std::max(D.B, D.R) + 255) / 256), b256, 0, c.st, D, c.ylast, c.d_mult, c.d_mult + D.B, c.d_mult + 2 * D.B);
+    HIP_TRY(hipGetLastError());
+    if (multipliers) HIP_TRY(hipMemcpyAsync(multipliers, c.d_mult, ((size_t)2 * D.B + D.R) * 4, hipMemcpyDeviceToHost, c.st));
+    HIP_TRY(hipStreamSynchronize(c.st));
+    if (stats) {
+        stats[0] = it; stats[1] = -plast; stats[2] = -dlast; stats[3] = status; stats[4] = mu; stats[5] = pinf; stats[6] = dinf;
+        stats[7] = (now_s() - t0) * 1e3;
+    }
+    return KAO_OK;
+}
+
+}  // namespace kao

@@ -947,12 +947,13 @@ static int bound_step_impl(kao_session *s, const int64_t *target, int32_t iters,
     // one K-bound launch in flight at a time (it continues from the state the previous one left in HBM); the session
     // upload was synchronised at creation, K-search and K-bound share read-only tables only
     HIP_TRY(hipStreamSynchronize(s->stream_bound));
-    if (s->bound_launches == 0) {
+    if (!s->dual_state_init) {
         // K-bound state is initialised by the first launch only (most sessions never need K-bound): multipliers and
         // directions 0, best dual value "infinite" (0x7F7F...), info 0
         HIP_TRY(hipMemsetAsync(s->d_dual, 0, s->dual_bytes, s->stream_bound));
         HIP_TRY(hipMemsetAsync(s->d_dual_rb, 0x7F, (size_t)s->n_topics * 8, s->stream_bound));
         HIP_TRY(hipMemsetAsync(s->d_dual_rb + (size_t)s->n_topics * 8, 0, (size_t)s->n_topics * 16, s->stream_bound));
+        s->dual_state_init = true;
     }
     // pageable staging: hipMemcpyAsync returns once the host buffers have been consumed
     HIP_TRY(hipMemcpyAsync(s->d_dual_target, s->h_dual_target.data(), (size_t)s->n_topics * 8, hipMemcpyHostToDevice, s->stream_bound));
@@ -1150,7 +1151,7 @@ int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->stream_bound) HIP_TRY(hipStreamSynchronize(s->stream_bound));
     const int32_t *base = s->d_dual + d.dual_off;
-    if (s->bound_launches == 0) {  // no K-bound launch yet: the initial state
+    if (!s->dual_state_init) {  // no K-bound launch yet: the initial state
         if (a) std::memset(a, 0, (size_t)d.B * 4);
         if (l) std::memset(l, 0, (size_t)d.B * 4);
         if (g) std::memset(g, 0, (size_t)d.R * 4);
@@ -1162,6 +1163,78 @@ int kao_session_dual_state(kao_session *s, int32_t topic, int32_t *a, int32_t *l
     if (g) HIP_TRY(hipMemcpy(g, base + 4 * (size_t)d.B, (size_t)d.R * 4, hipMemcpyDeviceToHost));
     if (best_dual) HIP_TRY(hipMemcpy(best_dual, s->d_dual_rb + (size_t)topic * 8, 8, hipMemcpyDeviceToHost));
     return KAO_OK;
+}
+
+int kao_session_set_dual_state(kao_session *s, int32_t topic, const int32_t *a, const int32_t *l, const int32_t *g) {
+    if (!s || topic < 0 || topic >= s->n_topics || !a || !l || !g) return fail(KAO_ERR_INVALID, "bad argument");
+    if (!s->dual_ok[(size_t)topic]) return fail(KAO_ERR_UNSUPPORTED, "topic outside K-bound's limits");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->stream_bound) {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&s->stream_bound, hipStreamNonBlocking, hi));
+        HIP_TRY(hipEventCreate(&s->ev_bound0));
+        HIP_TRY(hipEventCreate(&s->ev_bound1));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream_bound));
+    if (!s->dual_state_init) {
+        HIP_TRY(hipMemsetAsync(s->d_dual, 0, s->dual_bytes, s->stream_bound));
+        HIP_TRY(hipMemsetAsync(s->d_dual_rb, 0x7F, (size_t)s->n_topics * 8, s->stream_bound));
+        HIP_TRY(hipMemsetAsync(s->d_dual_rb + (size_t)s->n_topics * 8, 0, (size_t)s->n_topics * 16, s->stream_bound));
+        s->dual_state_init = true;
+    }
+    const TopicDev &d = s->pts[(size_t)topic].d;
+    // dual_pool: a[B] l[B] da[B] dl[B] g[kRackTab] dg[kRackTab] lv[8] ...: iterate replaced, direction memory and level control cleared
+    std::vector<int32_t> buf(4 * (size_t)d.B + 2 * kRackTab + 8, 0);
+    auto clampm = [](int32_t v) { return std::max(-kDualClamp, std::min(kDualClamp, v)); };
+    for (int b = 0; b < d.B; ++b) { buf[(size_t)b] = clampm(a[b]); buf[(size_t)d.B + b] = clampm(l[b]); }
+    for (int r = 0; r < d.R; ++r) buf[4 * (size_t)d.B + r] = clampm(g[r]);
+    HIP_TRY(hipMemcpyAsync(s->d_dual + d.dual_off, buf.data(), buf.size() * 4, hipMemcpyHostToDevice, s->stream_bound));
+    HIP_TRY(hipStreamSynchronize(s->stream_bound));
+    return KAO_OK;
+}
+
+int kao_lp_bound(const kao_topic *t, double tol, int32_t max_iters, int64_t *bound, int64_t *best_dual, int32_t *multipliers, double stats[8]) {
+    if (!t) return fail(KAO_ERR_INVALID, "null topic");
+    int rc = require_init();
+    if (rc) return rc;
+    LpCtx *lp = nullptr;
+    if ((rc = lp_open(t, &lp))) return rc;
+    std::vector<int32_t> mult(2 * (size_t)t->n_brokers + (size_t)t->n_racks);
+    rc = lp_solve(lp, tol > 0 ? tol : 1e-7, max_iters > 0 ? max_iters : 80, mult.data(), stats, nullptr);
+    lp_close(lp);
+    if (rc) return rc;
+    if (multipliers) std::memcpy(multipliers, mult.data(), mult.size() * 4);
+    // the dual value at those multipliers, in integers: one K-bound iteration from them
+    kao_opts o{};
+    o.restarts = kWaves;
+    kao_session *s = nullptr;
+    if ((rc = kao_session_create(t, 1, &o, &s))) return rc;
+    if (!s->dual_ok[0]) { kao_session_destroy(s); return fail(KAO_ERR_UNSUPPORTED, "topic outside K-bound's limits"); }
+    rc = kao_session_set_dual_state(s, 0, mult.data(), mult.data() + t->n_brokers, mult.data() + 2 * (size_t)t->n_brokers);
+    const int64_t target = 0;
+    int32_t fl = 0, itn = 0;
+    if (!rc) rc = kao_session_bound_step(s, &target, 1);
+    if (!rc) rc = kao_session_bounds(s, nullptr, &fl, &itn);
+    int64_t bd = 0;
+    if (!rc) rc = kao_session_dual_state(s, 0, nullptr, nullptr, nullptr, &bd);
+    if (!rc) {
+        if (best_dual) *best_dual = bd;
+        if (bound) *bound = (fl & 4) || itn == 0 ? INT64_MAX : (bd >= 0 ? bd / kDualScale : -((-bd + kDualScale - 1) / kDualScale));
+    }
+    kao_session_destroy(s);
+    return rc;
+}
+
+int kao_lp_trace(const kao_topic *t, double tol, int32_t max_iters, double *trace, double stats[8], int32_t *multipliers) {
+    if (!t) return fail(KAO_ERR_INVALID, "null topic");
+    int rc = require_init();
+    if (rc) return rc;
+    LpCtx *lp = nullptr;
+    if ((rc = lp_open(t, &lp))) return rc;
+    rc = lp_solve(lp, tol > 0 ? tol : 1e-7, max_iters > 0 ? max_iters : 80, multipliers, stats, trace);
+    lp_close(lp);
+    return rc;
 }
 
 int kao_dual_bound(const kao_topic *t, int64_t target, int32_t iters, int32_t launches, int64_t *bound, int64_t *best_dual,

@@ -358,6 +358,13 @@ class Session:
                "kao_session_bounds")
         return dict(upper_bound=ub, flags=fl, iters=it)
 
+    def set_dual_state(self, topic: int, a, l, g):
+        """Test hook / KAO-LP: overwrite K-bound's multipliers of one topic (kao_session_set_dual_state)."""
+        a, l, g = (np.ascontiguousarray(v, dtype=np.int32) for v in (a, l, g))
+        p32 = C.POINTER(C.c_int32)
+        _check(_ffi.load().kao_session_set_dual_state(self._h, topic, a.ctypes.data_as(p32), l.ctypes.data_as(p32), g.ctypes.data_as(p32)),
+               "kao_session_set_dual_state")
+
     def dual_state(self, topic: int) -> dict:
         t = self.topics[topic]
         a = np.zeros(t.n_brokers, dtype=np.int32)
@@ -398,6 +405,36 @@ def dual_bound(topic: Topic, target: int, iters: int = 512, launches: int = 1) -
     B = topic.n_brokers
     return dict(bound=int(bound.value), best_dual=int(best.value), iters=int(itn.value), flags=int(fl.value),
                 a=mult[:B].copy(), l=mult[B:2 * B].copy(), g=mult[2 * B:].copy())
+
+
+def lp_bound(topic: Topic, tol: float = 0.0, max_iters: int = 0) -> dict:
+    """KAO-LP (kao_lp_bound): interior-point solve of the compact LP relaxation on the device, its row duals as multipliers,
+    K-bound's exact dual value there.  bound = floor(best_dual / 65536) is a valid upper bound on the optimum."""
+    ct = _CTopics([topic])
+    bound, best = C.c_int64(), C.c_int64()
+    B = topic.n_brokers
+    mult = np.zeros(2 * B + topic.n_racks, dtype=np.int32)
+    st = np.zeros(8)
+    _check(_ffi.load().kao_lp_bound(ct.ptr(0), float(tol), int(max_iters), C.byref(bound), C.byref(best),
+                                    mult.ctypes.data_as(C.POINTER(C.c_int32)), st.ctypes.data_as(C.POINTER(C.c_double))), "kao_lp_bound")
+    return dict(bound=int(bound.value), best_dual=int(best.value), a=mult[:B].copy(), l=mult[B:2 * B].copy(), g=mult[2 * B:].copy(),
+                iterations=int(st[0]), primal=float(st[1]), dual=float(st[2]), status=int(st[3]), mu=float(st[4]), pinf=float(st[5]),
+                dinf=float(st[6]), ms=float(st[7]))
+
+
+def lp_trace(topic: Topic, tol: float = 0.0, max_iters: int = 80) -> dict:
+    """Test hook (kao_lp_trace): the interior-point solve alone and its per-iterate trace (mu, primal, dual, pinf, dinf)."""
+    ct = _CTopics([topic])
+    B = topic.n_brokers
+    mult = np.zeros(2 * B + topic.n_racks, dtype=np.int32)
+    st = np.zeros(8)
+    tr = np.zeros(5 * (max_iters + 2))
+    pd = C.POINTER(C.c_double)
+    _check(_ffi.load().kao_lp_trace(ct.ptr(0), float(tol), int(max_iters), tr.ctypes.data_as(pd), st.ctypes.data_as(pd),
+                                    mult.ctypes.data_as(C.POINTER(C.c_int32))), "kao_lp_trace")
+    it = int(st[0])
+    return dict(a=mult[:B].copy(), l=mult[B:2 * B].copy(), g=mult[2 * B:].copy(), iterations=it, primal=float(st[1]), dual=float(st[2]),
+                status=int(st[3]), ms=float(st[7]), trace=tr[:5 * (it + 1)].reshape(-1, 5))
 
 
 def decode_key(key: int) -> tuple:
