@@ -365,7 +365,7 @@ int kao_rccl_loopback_counts(uint64_t out[2]);
  * exchanges between GPUs (kao_solve_multi), out[8] = K-bound iterations summed over the topics, out[9] = KAO-CX calls,
  * out[10] = KAO-CX calls that improved an incumbent, out[11] = K-search iterations per restart, out[12] = generations started
  * after the first (kao_session_new_generation), out[13] = KAO-CX runs from further starting points (other restarts' best
- * snapshots; included in out[9]), out[14..15] reserved (0). */
+ * snapshots; included in out[9]), out[14] = KAO-LP solves that delivered multipliers, out[15] = their interior-point iterations. */
 int kao_last_solve_timing(double out[16]);
 
 #ifdef __cplusplus

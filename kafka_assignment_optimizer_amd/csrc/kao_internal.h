@@ -180,7 +180,13 @@ void launch_canon(const TopicDev *topic, const uint32_t *cur_words, const uint16
 struct LpCtx;
 int lp_open(const kao_topic *t, LpCtx **out);
 // multipliers (host): a[B] l[B] g[R] in K-bound's fixed point; stats[8], trace: see kao_lp.hip
-int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace);
+int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace);   // one shot
+// incremental (kao_solve runs the iterations beside K-search): begin, enqueue k iterations (asynchronous, no host round trip inside),
+// poll (waits; *status 0 = running, 1 converged, 2 iteration limit, 3 stalled), finish (multipliers of the last finite iterate)
+int lp_begin(LpCtx *c, double tol, int maxit);
+int lp_enqueue(LpCtx *c, int k);
+int lp_poll(LpCtx *c, int *status, int *iterations);
+int lp_finish(LpCtx *c, int32_t *multipliers, double stats[8], double *trace);
 void lp_close(LpCtx *c);
 
 // ---- KAO-CX (kao_cycle.hip): cyclic-exchange improvement of a feasible assignment ----

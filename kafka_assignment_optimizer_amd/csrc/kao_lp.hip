@@ -52,7 +52,13 @@ struct LpDev {
     const double *cg;           // [GV]
     const unsigned char *rowc;  // [mc]: 1 = row present, 0 = absent, 2 = pinned (exact dependency)
     const double *bc;           // [mc] right-hand sides of the coupling rows
+    double *sc;                 // [kScN] the iteration's scalars, resident: no host round trip inside an iteration (see ScIdx)
 };
+// Device-resident scalars.  The kernels of an iteration read the step lengths, sigma mu and the stop flag from here, so any number
+// of iterations can be enqueued without the host looking; once the stop flag is set every later kernel returns at its first line.
+enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (non-finite iterate) */, SC_IT, SC_AP, SC_AD, SC_SIGMU, SC_MU, SC_POBJ, SC_DOBJ,
+             SC_PINF, SC_DINF, SC_PLAST, SC_DLAST, SC_HAVE_LAST, SC_KEEP /* this iterate is finite: copy its duals */, SC_TOL, SC_MAXIT, SC_NVU /* variables + bounded variables */, SC_NB, SC_NCN, kScN = 24 };
+#define LP_STOPPED(D) ((D).sc[SC_STOP] != 0.0)
 
 // variable numbering inside a partition (SoA: element (v, p) at v*P + p) and among the global variables
 __device__ __host__ __forceinline__ int VF(int j) { return 3 * j; }
@@ -142,17 +148,54 @@ __device__ __forceinline__ void block_reduce(double *vals, int n, bool is_min, d
         __syncthreads();
     }
 }
-__global__ void k_lp_red_final(const double *rec, int nrec, int n, int is_min, double *out) {   // one block of 64; thread k adds value k
+__global__ void k_lp_red_final(const double *sc, const double *rec, int nrec, int n, int is_min, double *out) {   // one block of 64; thread k adds value k
     const int k = threadIdx.x;
-    if (k >= n) return;
+    if (k >= n || sc[SC_STOP] != 0.0) return;
     double a = is_min ? 1.0 : 0.0;
     for (int i = 0; i < nrec; ++i) a = is_min ? fmin(a, rec[(size_t)i * kRedVals + k]) : a + rec[(size_t)i * kRedVals + k];
-    out[k] = is_min ? fmin(out[k], a) : out[k] + a;
+    out[k] = a;
+}
+// ---- the scalar steps of an iteration (one thread each) ------------------------------------------------------------------
+// residual sums -> mu, objectives, infeasibilities, trace, the stopping test.  redA = {|rd|^2, x.s + w.v, c.x, u.v},
+// redB = {|rp|^2, b.y} over the local rows, redC = the same over the coupling rows
+__global__ void k_lp_sc_resid(double *sc, const double *redA, const double *redB, const double *redC, double *trace) {
+    if (sc[SC_STOP] != 0.0) return;
+    const double din = redA[0], xs = redA[1], cx = redA[2], uv = redA[3];
+    const double pobj = cx, dobj = redB[1] + redC[1] - uv;
+    const double mu = xs / sc[SC_NVU], pinf = sqrt(redB[0] + redC[0]) / sc[SC_NB], dinf = sqrt(din) / sc[SC_NCN];
+    const int it = (int)sc[SC_IT];
+    if (trace) { trace[5 * it] = mu; trace[5 * it + 1] = pobj; trace[5 * it + 2] = dobj; trace[5 * it + 3] = pinf; trace[5 * it + 4] = dinf; }
+    sc[SC_MU] = mu; sc[SC_POBJ] = pobj; sc[SC_DOBJ] = dobj; sc[SC_PINF] = pinf; sc[SC_DINF] = dinf;
+    const bool finite = isfinite(mu) && isfinite(pobj) && isfinite(dobj);
+    sc[SC_KEEP] = finite ? 1.0 : 0.0;
+    if (!finite) { sc[SC_STOP] = 3.0; return; }
+    sc[SC_PLAST] = pobj; sc[SC_DLAST] = dobj; sc[SC_HAVE_LAST] = 1.0;     // k_lp_keep_last copies y next
+    const double tol = sc[SC_TOL];
+    if (fabs(pobj - dobj) / (1.0 + fabs(pobj)) < tol && pinf < 100 * tol && dinf < tol) sc[SC_STOP] = 1.0;
+    else if (it >= (int)sc[SC_MAXIT]) sc[SC_STOP] = 2.0;
+}
+// the coupling-row duals of the last finite iterate (what the multipliers are read from); runs right after k_lp_sc_resid
+__global__ void k_lp_keep_last(const double *sc, const double *yc, double *ylast, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && sc[SC_KEEP] == 1.0) ylast[i] = yc[i];
+}
+// step lengths to the boundary from the min-reduction; the corrector's are damped (0.9995) and close the iteration count
+__global__ void k_lp_sc_step(double *sc, const double *red, int pass) {
+    if (sc[SC_STOP] != 0.0) return;
+    double ap = red[0], ad = red[1];
+    if (pass) { if (ap < 1.0) ap *= 0.9995; if (ad < 1.0) ad *= 0.9995; sc[SC_IT] += 1.0; }
+    sc[SC_AP] = ap; sc[SC_AD] = ad;
+}
+__global__ void k_lp_sc_sigma(double *sc, const double *red) {
+    if (sc[SC_STOP] != 0.0) return;
+    const double ratio = red[0] / sc[SC_NVU] / sc[SC_MU];
+    sc[SC_SIGMU] = ratio * ratio * ratio * sc[SC_MU];
 }
 
 // ---- elementwise over the variables ------------------------------------------------------------------------------
 // theta = 1 / (s / x + v / w); init = 1: theta = 1 on present variables (the starting point's least-squares solves)
 __global__ void k_lp_theta(LpDev D, const double *x, const double *s, const double *v, double *th, int init) {
+    if (LP_STOPPED(D)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)D.NV * D.P) return;
     const int vv = (int)(i / D.P), p = (int)(i % D.P);
@@ -162,6 +205,7 @@ __global__ void k_lp_theta(LpDev D, const double *x, const double *s, const doub
     th[i] = 1.0 / (s[i] / x[i] + (u > 0 ? v[i] / (u - x[i]) : 0.0));
 }
 __global__ void k_lp_theta_g(LpDev D, const double *x, const double *s, const double *v, double *th, int init) {
+    if (LP_STOPPED(D)) return;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= D.GV) return;
     if (!gvar_present(D, g)) { th[g] = 0.0; return; }
@@ -172,6 +216,7 @@ __global__ void k_lp_theta_g(LpDev D, const double *x, const double *s, const do
 
 // ---- per-partition factor: sig11 sig12 sig22 e5 k1 k2 per replica, d e1 e2 per rack, T^-1 ------------------------------
 __global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double *fr, double *ti) {
+    if (LP_STOPPED(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
     const int P = D.P, R = D.R, NJ = D.NJ;
@@ -247,6 +292,7 @@ __device__ __forceinline__ bool lp_col(const LpDev &D, const double *th, const d
 // ---- Schur complement, broker rows: one wavefront per broker walks the broker's incidences in order -----------------------
 // rows C3[b] and C4[b] are accumulated in LDS (2 x mc doubles per wavefront) and written once (lower triangle)
 __global__ void k_lp_schur_broker(LpDev D, const double *th, const double *thg, const double *fj, const double *fr, const double *ti, double *S) {
+    if (LP_STOPPED(D)) return;
     extern __shared__ double lds_rows[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int b = blockIdx.x * nw + wave;
@@ -292,6 +338,7 @@ __global__ void k_lp_schur_broker(LpDev D, const double *th, const double *thg, 
 // ---- Schur complement, rack x rack block (rows NF, NL against columns NF, NL): tiled outer-product sum over a fixed chunk of
 // partitions per block; partial sums per block, added in block order by k_lp_schur_rack_sum
 __global__ void k_lp_schur_rack(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, int chunk, int tile, double *part) {
+    if (LP_STOPPED(D)) return;
     extern __shared__ double lds_t[];   // per partition of the tile: v0[2R] v1[2R] w0[2R] w1[2R] eps[2R] dg[2R] dinv[R]
     const int R = D.R, P = D.P, n2 = 2 * R, per = 6 * n2 + R;
     const int p0 = blockIdx.x * chunk, p1 = min(P, p0 + chunk);
@@ -338,6 +385,7 @@ __global__ void k_lp_schur_rack(LpDev D, const double *th, const double *fj, con
     }
 }
 __global__ void k_lp_schur_rack_sum(LpDev D, const double *part, int nblk, const double *thg, double *S) {
+    if (LP_STOPPED(D)) return;
     const int n2 = 2 * D.R, ne = n2 * n2;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= ne) return;
@@ -353,6 +401,7 @@ __global__ void k_lp_schur_rack_sum(LpDev D, const double *part, int nblk, const
 }
 // rows C6[r] (columns NF, NL: none; own diagonal: sum n + k), regularisation, absent / pinned rows, padding; saves the diagonal
 __global__ void k_lp_schur_fix(LpDev D, const double *thg, double *S, double *diag0) {
+    if (LP_STOPPED(D)) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.mcp) return;
     const int R = D.R;
@@ -372,6 +421,7 @@ __global__ void k_lp_schur_fix(LpDev D, const double *thg, double *S, double *di
 }
 // column of an absent / pinned row below the diagonal (only rack rows can be absent or pinned: i < 3R)
 __global__ void k_lp_schur_fix_cols(LpDev D, double *S) {
+    if (LP_STOPPED(D)) return;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= D.mc) return;
     for (int i = 0; i < 3 * D.R && i < k; ++i)
@@ -379,7 +429,8 @@ __global__ void k_lp_schur_fix_cols(LpDev D, double *S) {
 }
 
 // ---- dense Cholesky of S (lower, row-major, leading dimension n = mcp, 64 x 64 tiles) ----------------------------------
-__global__ void __launch_bounds__(256) k_lp_chol_diag(double *S, int n, int kb, const double *diag0) {
+__global__ void __launch_bounds__(256) k_lp_chol_diag(const double *sc, double *S, int n, int kb, const double *diag0) {
+    if (sc[SC_STOP] != 0.0) return;
     __shared__ double T[kNB][kNB + 1];
     const int t = threadIdx.x, base = kb * kNB;
     for (int i = t; i < kNB * kNB; i += 256) T[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
@@ -402,7 +453,8 @@ __global__ void __launch_bounds__(256) k_lp_chol_diag(double *S, int n, int kb, 
     for (int i = t; i < kNB * kNB; i += 256) if (i % kNB <= i / kNB) S[(size_t)(base + i / kNB) * n + base + i % kNB] = T[i / kNB][i % kNB];
 }
 // row tiles below the diagonal tile: X = A L_kk^-T (every thread solves one row by forward substitution)
-__global__ void __launch_bounds__(64) k_lp_chol_trsm(double *S, int n, int kb) {
+__global__ void __launch_bounds__(64) k_lp_chol_trsm(const double *sc, double *S, int n, int kb) {
+    if (sc[SC_STOP] != 0.0) return;
     __shared__ double Lk[kNB][kNB + 1];
     const int t = threadIdx.x, base = kb * kNB, row = (kb + 1 + blockIdx.x) * kNB + t;
     for (int i = t; i < kNB * kNB; i += 64) Lk[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
@@ -422,7 +474,8 @@ __global__ void __launch_bounds__(64) k_lp_chol_trsm(double *S, int n, int kb) {
     for (int j = 0; j < kNB; ++j) Ar[j] = x[j];
 }
 // trailing update A_ij -= L_ik L_jk^T for tile pairs i >= j > kb; 256 threads, 4 x 4 micro-tiles
-__global__ void __launch_bounds__(256) k_lp_chol_update(double *S, int n, int kb, int nrem) {
+__global__ void __launch_bounds__(256) k_lp_chol_update(const double *sc, double *S, int n, int kb, int nrem) {
+    if (sc[SC_STOP] != 0.0) return;
     __shared__ double Li[kNB][kNB + 1], Lj[kNB][kNB + 1];
     // decode the pair: blockIdx.x = i * (i + 1) / 2 + j over 0 <= j <= i < nrem
     int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -457,7 +510,8 @@ __global__ void __launch_bounds__(256) k_lp_chol_update(double *S, int n, int kb
             if (bi != bj || c0 + b <= r0 + a) S[(size_t)(ti_ * kNB + r0 + a) * n + tj * kNB + c0 + b] -= acc[a][b];   // diagonal tiles: lower triangle only
 }
 // L z = r then L^T x = z, in place in `r` (length n); one workgroup of 1024, the vector in LDS
-__global__ void __launch_bounds__(1024) k_lp_trsv(const double *S, int n, double *r) {
+__global__ void __launch_bounds__(1024) k_lp_trsv(const double *sc, const double *S, int n, double *r) {
+    if (sc[SC_STOP] != 0.0) return;
     extern __shared__ double xv[];
     __shared__ double Lk[kNB][kNB + 1];
     const int t = threadIdx.x, nt = n / kNB;
@@ -512,6 +566,7 @@ __global__ void __launch_bounds__(1024) k_lp_trsv(const double *S, int n, double
 // ---- rows of A z ------------------------------------------------------------------------------------------------------
 // local rows; mode 0: out = A z, 1: out = b - A z, 2: out = A z + add
 __global__ void k_lp_A_local(LpDev D, const double *z, RowVec out, int mode, RowVec add) {
+    if (LP_STOPPED(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
     const int P = D.P, R = D.R, NJ = D.NJ;
@@ -544,6 +599,7 @@ __global__ void k_lp_A_local(LpDev D, const double *z, RowVec out, int mode, Row
 }
 // coupling rows C3[b], C4[b]: one wavefront per broker; `cb` (may be null): extra per-incidence terms [2 NJ][P] of the eliminations
 __global__ void k_lp_A_broker(LpDev D, const double *z, const double *zg, const double *cb, double *rc, int mode, const double *addc) {
+    if (LP_STOPPED(D)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int b = blockIdx.x * nw + wave;
     if (b >= D.B) return;
@@ -565,6 +621,7 @@ __global__ void k_lp_A_broker(LpDev D, const double *z, const double *zg, const 
 }
 // coupling rows NF[r], NL[r] (one block each: a fixed-order sum over the partitions) and C6[r]; `cr`: extra terms [2 R][P]
 __global__ void __launch_bounds__(kRedBlock) k_lp_A_rack(LpDev D, const double *z, const double *zg, const double *cr, double *rc, int mode, const double *addc) {
+    if (LP_STOPPED(D)) return;
     __shared__ double sh[kRedBlock];
     const int R = D.R, P = D.P, row = blockIdx.x;     // 0..R-1 NF, R..2R-1 NL, 2R..3R-1 C6
     const int r = row % R, kind = row / R;
@@ -589,6 +646,7 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_A_rack(LpDev D, const double *
 // ---- the normal equations' local eliminations (oracle/kao_lp_port.c::lp_solve_normal, first loop): local right-hand sides in
 // place, the terms they send to the coupling rows into cb [2 NJ][P] (C3 / C4 of replica j) and cr [2 R][P] (NF / NL of rack r)
 __global__ void k_lp_elim_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v, double *cb, double *cr) {
+    if (LP_STOPPED(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
     const int P = D.P, R = D.R, NJ = D.NJ;
@@ -631,6 +689,7 @@ __global__ void k_lp_elim_local(LpDev D, const double *th, const double *fj, con
 }
 // back substitution (second loop): dy of the local rows in place, given dy of the coupling rows
 __global__ void k_lp_back_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v) {
+    if (LP_STOPPED(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
     const int P = D.P, R = D.R, NJ = D.NJ, nc = 2 * NJ + 2 * R;
@@ -706,6 +765,7 @@ __global__ void k_lp_cost(LpDev D, double *z, double *zg) {
 }
 // dual residual rd = c - A^T y - s + v and the sums {|rd|^2, x.s + w.v, c.x, u.v}; one record per block
 __global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVec s, VarVec v, RowVec y, VarVec rd, double *rec) {
+    if (LP_STOPPED(D)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nv = (size_t)D.NV * D.P;
     double a[4] = {0, 0, 0, 0};
@@ -730,6 +790,7 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVe
 }
 // sums over the rows: {|rp|^2 (local rows), b.y (local rows)}; one record per block (thread per partition)
 __global__ void __launch_bounds__(kRedBlock) k_lp_rowsums(LpDev D, RowVec rp, RowVec y, double *rec) {
+    if (LP_STOPPED(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double a[2] = {0, 0};
     if (p < D.P) {
@@ -746,18 +807,19 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_rowsums(LpDev D, RowVec rp, Ro
 }
 // the same over the coupling rows (one block)
 __global__ void __launch_bounds__(kRedBlock) k_lp_rowsums_c(LpDev D, const double *rpc, const double *yc, double *out) {
+    if (LP_STOPPED(D)) return;
     double a[2] = {0, 0};
     for (int i = threadIdx.x; i < D.mc; i += kRedBlock) { a[0] += rpc[i] * rpc[i]; if (D.rowc[i]) a[1] += D.bc[i] * yc[i]; }
-    __shared__ double rec[kRedVals];
-    block_reduce(a, 2, false, rec);
-    if (threadIdx.x == 0) { out[0] += rec[0]; out[1] += rec[1]; }
+    block_reduce(a, 2, false, out);
 }
 // h = rd - rxs / x + rwv / w and g = theta h; rxs, rwv are parked in ds, dv (k_lp_dir turns them into the directions).
 // pass 1 (corrector): rxs = sigma mu - x s - dx_aff ds_aff, rwv = sigma mu - w v + dx_aff dv_aff
-__global__ void k_lp_h(LpDev D, int pass, double sigma_mu, VarVec x, VarVec s, VarVec v, VarVec th, VarVec rd, VarVec dxa, VarVec dsa, VarVec dva,
+__global__ void k_lp_h(LpDev D, int pass, VarVec x, VarVec s, VarVec v, VarVec th, VarVec rd, VarVec dxa, VarVec dsa, VarVec dva,
                        VarVec h, VarVec g, VarVec ds, VarVec dv) {
+    if (LP_STOPPED(D)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nv = (size_t)D.NV * D.P;
+    const double sigma_mu = D.sc[SC_SIGMU];
     if (i < nv) {
         const int vv = (int)(i / D.P), p = (int)(i % D.P);
         if (!var_present(D, vv, p)) { h.z[i] = 0; g.z[i] = 0; ds.z[i] = 0; dv.z[i] = 0; return; }
@@ -778,6 +840,7 @@ __global__ void k_lp_h(LpDev D, int pass, double sigma_mu, VarVec x, VarVec s, V
 }
 // dx = theta (A^T dy - h), ds = (rxs - s dx) / x, dv = (rwv + v dx) / w; step lengths to the boundary {alpha_p, alpha_d} (min)
 __global__ void __launch_bounds__(kRedBlock) k_lp_dir(LpDev D, VarVec x, VarVec s, VarVec v, VarVec th, VarVec h, RowVec dy, VarVec dx, VarVec ds, VarVec dv, double *rec) {
+    if (LP_STOPPED(D)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nv = (size_t)D.NV * D.P;
     double a[2] = {1.0, 1.0};
@@ -810,10 +873,12 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_dir(LpDev D, VarVec x, VarVec 
     block_reduce(a, 2, true, rec + (size_t)blockIdx.x * kRedVals);
 }
 // sum (x + ap dx)(s + ad ds) + (w - ap dx)(v + ad dv)
-__global__ void __launch_bounds__(kRedBlock) k_lp_muaff(LpDev D, double ap, double ad, VarVec x, VarVec s, VarVec v, VarVec dx, VarVec ds, VarVec dv, double *rec) {
+__global__ void __launch_bounds__(kRedBlock) k_lp_muaff(LpDev D, VarVec x, VarVec s, VarVec v, VarVec dx, VarVec ds, VarVec dv, double *rec) {
+    if (LP_STOPPED(D)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nv = (size_t)D.NV * D.P;
     double a[1] = {0};
+    const double ap = D.sc[SC_AP], ad = D.sc[SC_AD];
     if (i < nv) {
         const int vv = (int)(i / D.P), p = (int)(i % D.P);
         if (var_present(D, vv, p)) {
@@ -831,9 +896,11 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_muaff(LpDev D, double ap, doub
     }
     block_reduce(a, 1, false, rec + (size_t)blockIdx.x * kRedVals);
 }
-__global__ void k_lp_update(LpDev D, double ap, double ad, VarVec x, VarVec s, VarVec v, VarVec dx, VarVec ds, VarVec dv) {
+__global__ void k_lp_update(LpDev D, VarVec x, VarVec s, VarVec v, VarVec dx, VarVec ds, VarVec dv) {
+    if (LP_STOPPED(D)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nv = (size_t)D.NV * D.P;
+    const double ap = D.sc[SC_AP], ad = D.sc[SC_AD];
     if (i < nv) {
         if (!var_present(D, (int)(i / D.P), (int)(i % D.P))) return;
         x.z[i] += ap * dx.z[i]; s.z[i] += ad * ds.z[i];
@@ -846,9 +913,10 @@ __global__ void k_lp_update(LpDev D, double ap, double ad, VarVec x, VarVec s, V
     }
 }
 // y += ad dy over all rows (local rows stored contiguously: r1 r2 r7 r5, then rc)
-__global__ void k_lp_axpy(double a, const double *d, double *y, size_t n) {
+__global__ void k_lp_axpy(const double *sc, const double *d, double *y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] += a * d[i];
+    if (sc[SC_STOP] != 0.0) return;
+    if (i < n) y[i] += sc[SC_AD] * d[i];
 }
 // row duals -> K-bound multipliers in its fixed point: g[r] = -y_C6[r], a[b] = -y_C3[b] - g[rack b], l[b] = -y_C4[b]
 __global__ void k_lp_multipliers(LpDev D, const double *yc, int32_t *a, int32_t *l, int32_t *g) {
@@ -864,8 +932,10 @@ __global__ void k_lp_multipliers(LpDev D, const double *yc, int32_t *a, int32_t 
 
 }  // namespace
 
+
 // ------------------------------------------------------------------------------------------------------------------------
-// Host driver
+// Host driver.  An iteration is a fixed sequence of kernel launches on the context's stream with no host round trip: the
+// scalars live in LpDev::sc.  The host enqueues iterations in batches and looks at the stop flag in between.
 struct LpCtx {
     LpDev D{};
     int device = 0;
@@ -873,15 +943,17 @@ struct LpCtx {
     std::vector<void *> bufs;
     long nvar = 0, nub = 0;
     double nb = 1, ncn = 1;
-    // vectors
     VarVec x{}, s{}, v{}, th{}, rd{}, h{}, g{}, d1{}, d2{}, dsa{}, dva{}, ds{}, dv{};
     RowVec y{}, rp{}, w1{}, w2{};
     size_t rows_local = 0;     // doubles of the local rows of one RowVec (r1 r2 r7 r5 contiguous)
     double *fj = nullptr, *fr = nullptr, *ti = nullptr, *S = nullptr, *diag0 = nullptr, *cb = nullptr, *cr = nullptr;
-    double *rec = nullptr, *red = nullptr, *part = nullptr, *ylast = nullptr;
+    double *rec = nullptr, *redA = nullptr, *redB = nullptr, *redC = nullptr, *part = nullptr, *ylast = nullptr, *trace = nullptr;
     int32_t *d_mult = nullptr;
     int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
-    double *h_red = nullptr;   // pinned
+    int maxit = 80, trace_cap = 0;
+    double *h_sc = nullptr;    // pinned mirror of the scalars
+    double t_begin = 0;
+    int enqueued = 0;          // iterations enqueued since lp_begin
 
     template <class T> int alloc(T **p, size_t n) {
         void *q = nullptr;
@@ -908,40 +980,28 @@ struct LpCtx {
     }
     ~LpCtx() {
         for (void *p : bufs) (void)hipFree(p);
-        if (h_red) (void)hipHostFree(h_red);
+        if (h_sc) (void)hipHostFree(h_sc);
         if (st) (void)hipStreamDestroy(st);
     }
 };
 
 namespace {
 
-int lp_reduce(LpCtx &c, int nrec, int n, bool is_min, double *out_host) {
-    // red[0..n) accumulates; the caller has cleared or preset it
-    hipLaunchKernelGGL(k_lp_red_final, dim3(1), dim3(64), 0, c.st, c.rec, nrec, n, is_min ? 1 : 0, c.red);
-    if (out_host) {
-        HIP_TRY(hipMemcpyAsync(c.h_red, c.red, sizeof(double) * kRedVals, hipMemcpyDeviceToHost, c.st));
-        HIP_TRY(hipStreamSynchronize(c.st));
-        std::memcpy(out_host, c.h_red, sizeof(double) * kRedVals);
-    }
-    return KAO_OK;
+void lp_reduce(LpCtx &c, int nrec, int n, bool is_min, double *out) {
+    hipLaunchKernelGGL(k_lp_red_final, dim3(1), dim3(64), 0, c.st, c.D.sc, c.rec, nrec, n, is_min ? 1 : 0, out);
 }
-int lp_red_preset(LpCtx &c, double v) {
-    double init[kRedVals];
-    for (double &q : init) q = v;
-    HIP_TRY(hipMemcpyAsync(c.red, init, sizeof init, hipMemcpyHostToDevice, c.st));
-    HIP_TRY(hipStreamSynchronize(c.st));   // `init` is a stack buffer
-    return KAO_OK;
+// local rows of A z into `out` (mode 0 plain, 1 = b - A z, 2 = A z + add)
+void lp_rows_local(LpCtx &c, const VarVec &z, const RowVec &out, int mode, const RowVec &add) {
+    hipLaunchKernelGGL(k_lp_A_local, dim3(c.nblk_p), dim3(256), 0, c.st, c.D, z.z, out, mode, add);
 }
-
-// rows of A z into `out` (mode 0 plain, 1 = b - A z, 2 = A z + add), with the optional elimination terms cb / cr
-void lp_A(LpCtx &c, const VarVec &z, const RowVec &out, int mode, const RowVec &add, const double *cb, const double *cr, bool local) {
+// coupling rows, gathered: rows of A z (+ the elimination terms cb / cr) (+ add)
+void lp_rows_coupling(LpCtx &c, const VarVec &z, double *out_rc, int mode, const double *add_rc, const double *cb, const double *cr) {
     const LpDev &D = c.D;
-    if (local) hipLaunchKernelGGL(k_lp_A_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, z.z, out, mode, add);
-    hipLaunchKernelGGL(k_lp_A_broker, dim3((D.B + 3) / 4), dim3(256), 0, c.st, D, z.z, z.zg, cb, out.rc, mode, add.rc);
-    hipLaunchKernelGGL(k_lp_A_rack, dim3(3 * D.R), dim3(kRedBlock), 0, c.st, D, z.z, z.zg, cr, out.rc, mode, add.rc);
+    hipLaunchKernelGGL(k_lp_A_broker, dim3((D.B + 3) / 4), dim3(256), 0, c.st, D, z.z, z.zg, cb, out_rc, mode, add_rc);
+    hipLaunchKernelGGL(k_lp_A_rack, dim3(3 * D.R), dim3(kRedBlock), 0, c.st, D, z.z, z.zg, cr, out_rc, mode, add_rc);
 }
 
-int lp_factor(LpCtx &c) {
+void lp_factor(LpCtx &c) {
     const LpDev &D = c.D;
     hipLaunchKernelGGL(k_lp_factor_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti);
     const size_t lds_b = (size_t)c.broker_waves * 2 * D.mc * sizeof(double);
@@ -953,27 +1013,35 @@ int lp_factor(LpCtx &c) {
     hipLaunchKernelGGL(k_lp_schur_fix_cols, dim3((D.mc + 255) / 256), dim3(256), 0, c.st, D, c.S);
     const int nt = D.mcp / kNB;
     for (int kb = 0; kb < nt; ++kb) {
-        hipLaunchKernelGGL(k_lp_chol_diag, dim3(1), dim3(256), 0, c.st, c.S, D.mcp, kb, c.diag0);
+        hipLaunchKernelGGL(k_lp_chol_diag, dim3(1), dim3(256), 0, c.st, D.sc, c.S, D.mcp, kb, c.diag0);
         const int nrem = nt - kb - 1;
         if (nrem <= 0) break;
-        hipLaunchKernelGGL(k_lp_chol_trsm, dim3(nrem), dim3(64), 0, c.st, c.S, D.mcp, kb);
-        hipLaunchKernelGGL(k_lp_chol_update, dim3(nrem * (nrem + 1) / 2), dim3(256), 0, c.st, c.S, D.mcp, kb, nrem);
+        hipLaunchKernelGGL(k_lp_chol_trsm, dim3(nrem), dim3(64), 0, c.st, D.sc, c.S, D.mcp, kb);
+        hipLaunchKernelGGL(k_lp_chol_update, dim3(nrem * (nrem + 1) / 2), dim3(256), 0, c.st, D.sc, c.S, D.mcp, kb, nrem);
     }
-    HIP_TRY(hipGetLastError());
-    return KAO_OK;
 }
 
-// N dy = rho, in place in `v` (local rows + coupling rows)
-int lp_solve_normal(LpCtx &c, const RowVec &v, const VarVec *zsrc, const RowVec *addsrc) {
-    // the coupling right-hand side is GATHERED: rows of A z (z = *zsrc, or nothing) + *addsrc + the elimination terms
+// N dy = rho, in place in `v`: v's local rows hold rho; the coupling right-hand side is GATHERED: rows of A z + the elimination terms (+ add)
+void lp_solve_normal(LpCtx &c, const RowVec &v, const VarVec &z, const double *add_rc) {
     const LpDev &D = c.D;
     hipLaunchKernelGGL(k_lp_elim_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, c.cb, c.cr);
-    const VarVec &z = zsrc ? *zsrc : c.g;    // (c.g is zeroed by the caller when there is no source vector)
-    lp_A(c, z, v, addsrc ? 2 : 0, addsrc ? *addsrc : v, c.cb, c.cr, false);
-    hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, c.S, D.mcp, v.rc);
+    lp_rows_coupling(c, z, v.rc, add_rc ? 2 : 0, add_rc, c.cb, c.cr);
+    hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, D.sc, c.S, D.mcp, v.rc);
     hipLaunchKernelGGL(k_lp_back_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v);
-    HIP_TRY(hipGetLastError());
-    return KAO_OK;
+}
+
+// residuals, sums, trace, stopping test of the current iterate
+void lp_enqueue_resid(LpCtx &c) {
+    const LpDev &D = c.D;
+    lp_rows_local(c, c.x, c.rp, 1, c.rp);
+    lp_rows_coupling(c, c.x, c.rp.rc, 1, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_lp_resid, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, c.x, c.s, c.v, c.y, c.rd, c.rec);
+    lp_reduce(c, c.nblk_var, 4, false, c.redA);
+    hipLaunchKernelGGL(k_lp_rowsums, dim3(c.nblk_p), dim3(kRedBlock), 0, c.st, D, c.rp, c.y, c.rec);
+    lp_reduce(c, c.nblk_p, 2, false, c.redB);
+    hipLaunchKernelGGL(k_lp_rowsums_c, dim3(1), dim3(kRedBlock), 0, c.st, D, c.rp.rc, c.y.rc, c.redC);
+    hipLaunchKernelGGL(k_lp_sc_resid, dim3(1), dim3(1), 0, c.st, D.sc, c.redA, c.redB, c.redC, c.trace);
+    hipLaunchKernelGGL(k_lp_keep_last, dim3((D.mcp + 255) / 256), dim3(256), 0, c.st, D.sc, c.y.rc, c.ylast, D.mcp);
 }
 
 }  // namespace
@@ -989,7 +1057,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     const int P = t->n_partitions, B = t->n_brokers, R = t->n_racks, NJ = t->rf_cur;
     const int mc = 3 * R + 2 * B;
     if ((size_t)2 * mc * sizeof(double) > 150 * 1024) return fail(KAO_ERR_UNSUPPORTED, "KAO-LP: more than ~4,700 brokers (a Schur row pair must fit LDS)");
-    if (NJ > 8 || P >= (1 << 28)) return fail(KAO_ERR_UNSUPPORTED, "KAO-LP: current RF > 8");
+    if (NJ > 8 || NJ < 1 || P >= (1 << 28)) return fail(KAO_ERR_UNSUPPORTED, "KAO-LP: current RF outside 1..8");
     LpCtx *c = new LpCtx();
     c->device = cur_device();
     LpDev &D = c->D;
@@ -1001,7 +1069,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     D.has_k = D.has_n && bd[5] > bd[4]; D.k_ub = bd[5] - bd[4];
     auto bail = [&](int code) { delete c; return code; };
     if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) return bail(fail(KAO_ERR_HIP, "KAO-LP: stream"));
-    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_red), sizeof(double) * kRedVals) != hipSuccess) return bail(fail(KAO_ERR_NOMEM, "KAO-LP: pinned buffer"));
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_sc), sizeof(double) * kScN) != hipSuccess) return bail(fail(KAO_ERR_NOMEM, "KAO-LP: pinned buffer"));
     // structure
     std::vector<uint16_t> cur(t->current, t->current + (size_t)P * NJ);
     std::vector<uint8_t> rack(t->rack_of, t->rack_of + B);
@@ -1070,11 +1138,13 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     c->rack_tile = std::max(1, std::min(16, (int)((64 * 1024) / ((size_t)per * sizeof(double)))));
     c->rack_chunk = std::max(c->rack_tile, ((P + 255) / 256 + c->rack_tile - 1) / c->rack_tile * c->rack_tile);   // about 256 blocks
     c->rack_blocks = (P + c->rack_chunk - 1) / c->rack_chunk;
+    c->trace_cap = 512;
     if ((rc = c->alloc(&c->fj, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->fr, (size_t)3 * R * P)) || (rc = c->alloc(&c->ti, (size_t)3 * P)) ||
         (rc = c->alloc(&c->S, (size_t)D.mcp * D.mcp)) || (rc = c->alloc(&c->diag0, (size_t)D.mcp)) || (rc = c->alloc(&c->cb, (size_t)2 * NJ * P)) ||
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
-        (rc = c->alloc(&c->red, (size_t)kRedVals)) || (rc = c->alloc(&c->part, (size_t)c->rack_blocks * n2 * n2)) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
-        (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)))
+        (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
+        (rc = c->alloc(&c->part, (size_t)c->rack_blocks * n2 * n2)) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
+        (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
     // dynamic LDS beyond 64 KiB has to be enabled per kernel
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1084,6 +1154,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
         HIP_TRY(hipMemsetAsync(vv->z, 0, nvtot * sizeof(double), c->st));
     for (const RowVec *rv : {&c->y, &c->rp, &c->w1, &c->w2}) HIP_TRY(hipMemsetAsync(rv->r1, 0, (c->rows_local + D.mcp) * sizeof(double), c->st));
     HIP_TRY(hipMemsetAsync(c->S, 0, (size_t)D.mcp * D.mcp * sizeof(double), c->st));
+    HIP_TRY(hipMemsetAsync(c->ylast, 0, (size_t)D.mcp * sizeof(double), c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
     *out = c;
     return KAO_OK;
@@ -1091,88 +1162,118 @@ int lp_open(const kao_topic *t, LpCtx **out) {
 
 void lp_close(LpCtx *c) { delete c; }
 
-// The interior-point solve.  multipliers (host, may be null): a[B] l[B] g[R] in K-bound's fixed point; stats[8] = {iterations,
-// README objective of the primal iterate, of the dual iterate, status (0 converged, 1 iteration limit, 3 stalled: the last finite
-// iterate is returned), mu, relative primal infeasibility, relative dual infeasibility, milliseconds}; trace (may be null):
-// 5 doubles per iteration.
-int lp_solve(LpCtx *cp, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace) {
+// Enqueues the starting point (theta = 1: x~ = A^T (A A^T)^-1 b, y = (A A^T)^-1 A c, s = c - A^T y, pushed into the interior) and the
+// residuals of iterate 0.  Asynchronous on the context's stream.
+int lp_begin(LpCtx *cp, double tol, int maxit) {
     LpCtx &c = *cp;
     const LpDev &D = c.D;
     HIP_TRY(hipSetDevice(c.device));
-    const double t0 = now_s();
+    c.t_begin = now_s();
+    c.maxit = std::min(maxit, c.trace_cap - 2);
+    c.enqueued = 0;
+    double init[kScN];
+    std::memset(init, 0, sizeof init);
+    init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
+    std::memcpy(c.h_sc, init, sizeof init);
+    HIP_TRY(hipMemcpyAsync(D.sc, c.h_sc, sizeof init, hipMemcpyHostToDevice, c.st));
     const size_t nvtot = (size_t)D.NV * D.P + D.GV;
     const dim3 gv((unsigned)((nvtot + 255) / 256)), b256(256);
-    int rc;
-    double hr[kRedVals];
-    // ---- starting point: theta = 1; x~ = A^T (A A^T)^-1 b; y = (A A^T)^-1 A c; s = c - A^T y
     hipLaunchKernelGGL(k_lp_theta, dim3((unsigned)(((size_t)D.NV * D.P + 255) / 256)), b256, 0, c.st, D, c.x.z, c.s.z, c.v.z, c.th.z, 1);
     hipLaunchKernelGGL(k_lp_theta_g, dim3((D.GV + 255) / 256), b256, 0, c.st, D, c.x.zg, c.s.zg, c.v.zg, c.th.zg, 1);
-    if ((rc = lp_factor(c))) return rc;
+    lp_factor(c);
     HIP_TRY(hipMemsetAsync(c.g.z, 0, nvtot * sizeof(double), c.st));
-    lp_A(c, c.g, c.w1, 1, c.w1, nullptr, nullptr, true);                  // w1 = b - A 0 = b (local rows)
-    if ((rc = lp_solve_normal(c, c.w1, nullptr, &c.w1))) return rc;       // coupling rhs = gathered (0 + b_c + eliminations)
+    lp_rows_local(c, c.g, c.w1, 1, c.w1);                               // w1 = b - A 0 = b
+    lp_rows_coupling(c, c.g, c.w1.rc, 1, nullptr, nullptr, nullptr);
+    lp_solve_normal(c, c.w1, c.g, c.w1.rc);                             // coupling rhs = b_c + the elimination terms (gathered in place)
     hipLaunchKernelGGL(k_lp_AT, gv, b256, 0, c.st, D, c.w1, c.x.z, c.x.zg);
     hipLaunchKernelGGL(k_lp_cost, gv, b256, 0, c.st, D, c.g.z, c.g.zg);
-    lp_A(c, c.g, c.y, 0, c.y, nullptr, nullptr, true);                    // y = A c (local rows; the coupling rows are gathered again below)
-    if ((rc = lp_solve_normal(c, c.y, &c.g, nullptr))) return rc;
+    lp_rows_local(c, c.g, c.y, 0, c.y);                                 // y = A c
+    lp_solve_normal(c, c.y, c.g, nullptr);
     hipLaunchKernelGGL(k_lp_start, gv, b256, 0, c.st, D, c.y, c.x.z, c.x.zg, c.s.z, c.s.zg, c.v.z, c.v.zg);
-    int status = 1, it = 0;
-    double pobj = 0, dobj = 0, plast = 0, dlast = 0, mu = 0, pinf = 0, dinf = 0;
-    bool have_last = false;
-    for (it = 0;; ++it) {
-        // residuals and the stopping test
-        lp_A(c, c.x, c.rp, 1, c.rp, nullptr, nullptr, true);
-        hipLaunchKernelGGL(k_lp_resid, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, c.x, c.s, c.v, c.y, c.rd, c.rec);
-        if ((rc = lp_red_preset(c, 0.0)) || (rc = lp_reduce(c, c.nblk_var, 4, false, hr))) return rc;
-        const double din = hr[0], xs = hr[1], cx = hr[2], uv = hr[3];
-        hipLaunchKernelGGL(k_lp_rowsums, dim3(c.nblk_p), dim3(kRedBlock), 0, c.st, D, c.rp, c.y, c.rec);
-        if ((rc = lp_red_preset(c, 0.0))) return rc;
-        hipLaunchKernelGGL(k_lp_rowsums_c, dim3(1), dim3(kRedBlock), 0, c.st, D, c.rp.rc, c.y.rc, c.red);
-        if ((rc = lp_reduce(c, c.nblk_p, 2, false, hr))) return rc;
-        pobj = cx; dobj = hr[1] - uv;
-        mu = xs / (double)(c.nvar + c.nub); pinf = std::sqrt(hr[0]) / c.nb; dinf = std::sqrt(din) / c.ncn;
-        if (trace) { trace[5 * it] = mu; trace[5 * it + 1] = pobj; trace[5 * it + 2] = dobj; trace[5 * it + 3] = pinf; trace[5 * it + 4] = dinf; }
-        if (!(mu == mu) || !(pobj == pobj) || !(dobj == dobj) || !std::isfinite(mu) || !std::isfinite(dobj)) { status = 3; break; }
-        HIP_TRY(hipMemcpyAsync(c.ylast, c.y.rc, (size_t)D.mcp * sizeof(double), hipMemcpyDeviceToDevice, c.st));
-        plast = pobj; dlast = dobj; have_last = true;
-        if (std::fabs(pobj - dobj) / (1.0 + std::fabs(pobj)) < tol && pinf < 100 * tol && dinf < tol) { status = 0; break; }
-        if (it >= maxit) { status = 1; break; }
+    lp_enqueue_resid(c);
+    HIP_TRY(hipGetLastError());
+    return KAO_OK;
+}
+
+// Enqueues `k` iterations (each: factor, predictor, corrector, update, residuals + stopping test of the new iterate).  Asynchronous;
+// iterations behind the one that sets the stop flag are no-ops.
+int lp_enqueue(LpCtx *cp, int k) {
+    LpCtx &c = *cp;
+    const LpDev &D = c.D;
+    HIP_TRY(hipSetDevice(c.device));
+    const size_t nvtot = (size_t)D.NV * D.P + D.GV;
+    const dim3 gv((unsigned)((nvtot + 255) / 256)), b256(256);
+    for (int q = 0; q < k; ++q) {
         hipLaunchKernelGGL(k_lp_theta, dim3((unsigned)(((size_t)D.NV * D.P + 255) / 256)), b256, 0, c.st, D, c.x.z, c.s.z, c.v.z, c.th.z, 0);
         hipLaunchKernelGGL(k_lp_theta_g, dim3((D.GV + 255) / 256), b256, 0, c.st, D, c.x.zg, c.s.zg, c.v.zg, c.th.zg, 0);
-        if ((rc = lp_factor(c))) return rc;
-        double ap = 1, ad = 1, sigma_mu = 0;
+        lp_factor(c);
         for (int pass = 0; pass < 2; ++pass) {
             const VarVec &dx = pass ? c.d2 : c.d1, &pds = pass ? c.ds : c.dsa, &pdv = pass ? c.dv : c.dva;
             const RowVec &dy = pass ? c.w2 : c.w1;
-            hipLaunchKernelGGL(k_lp_h, gv, b256, 0, c.st, D, pass, sigma_mu, c.x, c.s, c.v, c.th, c.rd, c.d1, c.dsa, c.dva, c.h, c.g, pds, pdv);
-            lp_A(c, c.g, dy, 2, c.rp, nullptr, nullptr, true);            // local rows: A (theta h) + rp
-            if ((rc = lp_solve_normal(c, dy, &c.g, &c.rp))) return rc;    // coupling rows gathered with the elimination terms
+            hipLaunchKernelGGL(k_lp_h, gv, b256, 0, c.st, D, pass, c.x, c.s, c.v, c.th, c.rd, c.d1, c.dsa, c.dva, c.h, c.g, pds, pdv);
+            lp_rows_local(c, c.g, dy, 2, c.rp);                          // local rows: A (theta h) + rp
+            lp_solve_normal(c, dy, c.g, c.rp.rc);                        // coupling rows gathered with the elimination terms + rp
             hipLaunchKernelGGL(k_lp_dir, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, c.x, c.s, c.v, c.th, c.h, dy, dx, pds, pdv, c.rec);
-            if ((rc = lp_red_preset(c, 1.0)) || (rc = lp_reduce(c, c.nblk_var, 2, true, hr))) return rc;
-            ap = hr[0]; ad = hr[1];
+            lp_reduce(c, c.nblk_var, 2, true, c.redA);
+            hipLaunchKernelGGL(k_lp_sc_step, dim3(1), dim3(1), 0, c.st, D.sc, c.redA, pass);
             if (pass == 0) {
-                hipLaunchKernelGGL(k_lp_muaff, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, ap, ad, c.x, c.s, c.v, c.d1, c.dsa, c.dva, c.rec);
-                if ((rc = lp_red_preset(c, 0.0)) || (rc = lp_reduce(c, c.nblk_var, 1, false, hr))) return rc;
-                const double ratio = hr[0] / (double)(c.nvar + c.nub) / mu;
-                sigma_mu = ratio * ratio * ratio * mu;
+                hipLaunchKernelGGL(k_lp_muaff, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, c.x, c.s, c.v, c.d1, c.dsa, c.dva, c.rec);
+                lp_reduce(c, c.nblk_var, 1, false, c.redA);
+                hipLaunchKernelGGL(k_lp_sc_sigma, dim3(1), dim3(1), 0, c.st, D.sc, c.redA);
             }
         }
-        if (ap < 1.0) ap *= 0.9995;
-        if (ad < 1.0) ad *= 0.9995;
-        hipLaunchKernelGGL(k_lp_update, gv, b256, 0, c.st, D, ap, ad, c.x, c.s, c.v, c.d2, c.ds, c.dv);
+        hipLaunchKernelGGL(k_lp_update, gv, b256, 0, c.st, D, c.x, c.s, c.v, c.d2, c.ds, c.dv);
         const size_t nrow = c.rows_local + D.mcp;
-        hipLaunchKernelGGL(k_lp_axpy, dim3((unsigned)((nrow + 255) / 256)), b256, 0, c.st, ad, c.w2.r1, c.y.r1, nrow);
+        hipLaunchKernelGGL(k_lp_axpy, dim3((unsigned)((nrow + 255) / 256)), b256, 0, c.st, D.sc, c.w2.r1, c.y.r1, nrow);
+        lp_enqueue_resid(c);
     }
-    if (!have_last) return fail(KAO_ERR_HIP, "KAO-LP: the starting point is not finite");
-    hipLaunchKernelGGL(k_lp_multipliers, dim3((std::max(D.B, D.R) + 255) / 256), b256, 0, c.st, D, c.ylast, c.d_mult, c.d_mult + D.B, c.d_mult + 2 * D.B);
+    c.enqueued += k;
+    HIP_TRY(hipGetLastError());
+    return KAO_OK;
+}
+
+// Waits for what has been enqueued and reads the scalars: *status = the stop flag (0 = still running), *iterations so far.
+int lp_poll(LpCtx *cp, int *status, int *iterations) {
+    LpCtx &c = *cp;
+    HIP_TRY(hipSetDevice(c.device));
+    HIP_TRY(hipMemcpyAsync(c.h_sc, c.D.sc, sizeof(double) * kScN, hipMemcpyDeviceToHost, c.st));
+    HIP_TRY(hipStreamSynchronize(c.st));
+    if (status) *status = (int)c.h_sc[SC_STOP];
+    if (iterations) *iterations = (int)c.h_sc[SC_IT];
+    return KAO_OK;
+}
+
+// The multipliers of the last finite iterate (host, may be null: a[B] l[B] g[R] in K-bound's fixed point); stats[8] = {iterations,
+// README objective of the primal iterate, of the dual iterate, status (0 converged, 1 iteration limit, 3 stalled: the last finite
+// iterate is returned), mu, relative primal infeasibility, relative dual infeasibility, milliseconds since lp_begin}; trace (may be
+// null): 5 doubles per iterate, iterations + 1 of them.
+int lp_finish(LpCtx *cp, int32_t *multipliers, double stats[8], double *trace) {
+    LpCtx &c = *cp;
+    const LpDev &D = c.D;
+    int st = 0, it = 0;
+    int rc = lp_poll(cp, &st, &it);
+    if (rc) return rc;
+    if (c.h_sc[SC_HAVE_LAST] == 0.0) return fail(KAO_ERR_HIP, "KAO-LP: the starting point is not finite");
+    hipLaunchKernelGGL(k_lp_multipliers, dim3((std::max(D.B, D.R) + 255) / 256), dim3(256), 0, c.st, D, c.ylast, c.d_mult, c.d_mult + D.B, c.d_mult + 2 * D.B);
     HIP_TRY(hipGetLastError());
     if (multipliers) HIP_TRY(hipMemcpyAsync(multipliers, c.d_mult, ((size_t)2 * D.B + D.R) * 4, hipMemcpyDeviceToHost, c.st));
+    if (trace) HIP_TRY(hipMemcpyAsync(trace, c.trace, sizeof(double) * 5 * (size_t)(it + 1), hipMemcpyDeviceToHost, c.st));
     HIP_TRY(hipStreamSynchronize(c.st));
     if (stats) {
-        stats[0] = it; stats[1] = -plast; stats[2] = -dlast; stats[3] = status; stats[4] = mu; stats[5] = pinf; stats[6] = dinf;
-        stats[7] = (now_s() - t0) * 1e3;
+        stats[0] = it; stats[1] = -c.h_sc[SC_PLAST]; stats[2] = -c.h_sc[SC_DLAST]; stats[3] = st == 1 ? 0 : (st == 2 || st == 0 ? 1 : 3);
+        stats[4] = c.h_sc[SC_MU]; stats[5] = c.h_sc[SC_PINF]; stats[6] = c.h_sc[SC_DINF]; stats[7] = (now_s() - c.t_begin) * 1e3;
     }
     return KAO_OK;
+}
+
+// One shot: iterations in batches of four until the stop flag is up.
+int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace) {
+    int rc = lp_begin(c, tol, maxit);
+    if (rc) return rc;
+    for (int st = 0, it = 0; !st;) {
+        if ((rc = lp_enqueue(c, 4)) || (rc = lp_poll(c, &st, &it))) return rc;
+    }
+    return lp_finish(c, multipliers, stats, trace);
 }
 
 }  // namespace kao

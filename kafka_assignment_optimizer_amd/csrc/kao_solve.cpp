@@ -139,8 +139,22 @@ struct SolveRun {
     std::vector<uint64_t> dkeys, gprev;           // packed best keys of the CURRENT generation as the device holds them; their record
     std::vector<uint64_t> inc_key;                // best incumbent of the earlier generations (host copy), ~0 = none
     std::vector<std::vector<uint16_t>> inc_assign;
+    // KAO-LP (round 5, kao_lp.hip): K-bound's subgradient iteration stalls above the LP value on slack-band and on large topics
+    // (450 x 3500: 26336 against 26330 = the incumbent; 1000 x 30000: 231,562 against 231,532).  A feasible topic K-bound has not
+    // closed after `lp_after` merged launches gets the LP relaxation solved by the interior-point kernels: the iterations ride
+    // beside the K-search launches on a stream of their own (`lp_per_launch` per launch, no host round trip inside), and when
+    // the stop flag is up the row duals become K-bound's multipliers, ONE K-bound iteration evaluates the dual function there in
+    // integers (certificate, search prices), and K-bound leaves the topic alone from then on -- it cannot get below the LP
+    // value, and beside K-search it costs the search half its speed on large topics.  Counts only: deterministic.
+    std::vector<LpCtx *> lp_ctx;
+    std::vector<char> lp_state;                   // 0 = not started, 1 = running, 2 = done, 3 = unsupported / failed
+    std::vector<int> bound_merges;                // merged K-bound launches per topic
+    std::vector<int64_t> lp_tgt;
+    int lp_on = 1, lp_per_launch = 2, lp_max_running = 2, lp_solves = 0, lp_iters = 0;
+    int64_t lp_min_slots = 2048;
+    int lp_after_big = 2, lp_after_small = 48;
 
-    ~SolveRun() { for (CycleCtx *c : cx_ctx) cycle_close(c); if (s) kao_session_destroy(s); }
+    ~SolveRun() { for (CycleCtx *c : cx_ctx) cycle_close(c); for (LpCtx *c : lp_ctx) if (c) lp_close(c); if (s) kao_session_destroy(s); }
 
     // `so` is the caller's options with kao_solve's defaults applied; the session is created on the calling thread's device
     int begin(const kao_topic *user_topics, int n_topics, const kao_opts &so, const int64_t *tgt, double t_start, bool allow_islands = false, bool allow_gens = false) {
@@ -190,6 +204,14 @@ struct SolveRun {
         this->topics = topics;
         t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
         cx_started.assign((size_t)n, {});
+        lp_ctx.assign((size_t)n, nullptr); lp_state.assign((size_t)n, 0); bound_merges.assign((size_t)n, 0); lp_tgt.assign((size_t)n, -1);
+        {   // test / experiment hooks: KAO_LP=0 switches KAO-LP off, KAO_LP_AFTER / KAO_LP_PER_LAUNCH / KAO_LP_MIN_SLOTS override the counts
+            auto env_i = [](const char *name, int64_t dflt) { const char *e = std::getenv(name); return e && *e ? (int64_t)std::atoll(e) : dflt; };
+            lp_on = (int)env_i("KAO_LP", 1);
+            lp_after_big = (int)env_i("KAO_LP_AFTER", lp_after_big);
+            lp_per_launch = (int)std::max<int64_t>(1, env_i("KAO_LP_PER_LAUNCH", lp_per_launch));
+            lp_min_slots = env_i("KAO_LP_MIN_SLOTS", lp_min_slots);
+        }
         cx_on = so.use_cycles >= 0;
         { const char *e = std::getenv("KAO_CX_EAGER"); cx_eager = e && e[0] == '1'; }
         cx_ctx.assign((size_t)n, nullptr);
@@ -243,7 +265,61 @@ struct SolveRun {
     int launch() {
         int rc = kao_session_step(s);
         if (!rc && bound_pending) { bound_pending = false; rc = kao_session_bound_step(s, dual_target.data(), dual_now); }
+        for (int i = 0; i < n && !rc; ++i)
+            if (lp_state[(size_t)i] == 1) rc = lp_enqueue(lp_ctx[(size_t)i], lp_per_launch);   // interior-point iterations beside the launch
         return rc;
+    }
+    // KAO-LP: start the LP of topics K-bound has not closed, collect the ones whose stop flag is up
+    int service_lp(bool final_call = false) {
+        if (!lp_on || has_target || dual_iters <= 0) return KAO_OK;
+        int rc, running = 0;
+        for (int i = 0; i < n; ++i) running += lp_state[(size_t)i] == 1;
+        for (int i = 0; i < n; ++i) {
+            if (lp_state[(size_t)i] != 1) continue;
+            int st = 0, it = 0;
+            if ((rc = lp_poll(lp_ctx[(size_t)i], &st, &it))) return rc;
+            const bool open = feasible(i) ? objective(i) < s->ub[(size_t)i] : true;
+            if (!st && open && !final_call) continue;
+            if (!st || !open) { lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; lp_state[(size_t)i] = open ? 0 : 2; --running; continue; }
+            // the row duals as K-bound's multipliers; one K-bound iteration evaluates the dual function there in integers
+            const kao_topic &t = topics[i];
+            std::vector<int32_t> mult(2 * (size_t)t.n_brokers + (size_t)t.n_racks);
+            double st8[8];
+            rc = lp_finish(lp_ctx[(size_t)i], mult.data(), st8, nullptr);
+            lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; --running;
+            if (rc) { lp_state[(size_t)i] = 3; continue; }
+            lp_iters += it; ++lp_solves;
+            if (s->bound_inflight && (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
+            if ((rc = kao_session_set_dual_state(s, i, mult.data(), mult.data() + t.n_brokers, mult.data() + 2 * (size_t)t.n_brokers))) return rc;
+            std::fill(lp_tgt.begin(), lp_tgt.end(), -1);
+            lp_tgt[(size_t)i] = feasible(i) ? objective(i) : 0;
+            if ((rc = kao_session_bound_step(s, lp_tgt.data(), 1)) || (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
+            share_bounds();
+            if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
+            lp_state[(size_t)i] = 2;
+            if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: %d iterations, LP value %.4f, certificate %lld, launch %d\n", i, it, st8[2], (long long)s->ub[(size_t)i], launches);
+        }
+        if (final_call) return KAO_OK;
+        // largest open topics first, at most `lp_max_running` at a time
+        for (;;) {
+            if (running >= lp_max_running) break;
+            int best = -1; int64_t best_slots = 0;
+            for (int i = 0; i < n; ++i) {
+                if (lp_state[(size_t)i] != 0 || !s->dual_ok[(size_t)i] || s->topic_infeasible[(size_t)i] || !feasible(i) || objective(i) >= s->ub[(size_t)i]) continue;
+                const int64_t slots = (int64_t)topics[i].n_partitions * topics[i].rf;
+                if (bound_merges[(size_t)i] < (slots >= lp_min_slots ? lp_after_big : lp_after_small)) continue;
+                if (slots > best_slots) { best = i; best_slots = slots; }
+            }
+            if (best < 0) break;
+            LpCtx *c = nullptr;
+            rc = lp_open(&topics[best], &c);
+            if (rc == KAO_ERR_UNSUPPORTED || rc == KAO_ERR_NOMEM) { lp_state[(size_t)best] = 3; continue; }
+            if (rc) return rc;
+            if ((rc = lp_begin(c, 1e-7, 120))) { lp_close(c); return rc; }
+            lp_ctx[(size_t)best] = c; lp_state[(size_t)best] = 1; ++running;
+        }
+        all_done = check_done();
+        return KAO_OK;
     }
     // keys = the best over all generations (what "done", the K-bound targets and the answer go by); dkeys = this generation's
     bool feasible(int i) const { return (keys[(size_t)i] >> 44) == 0; }
@@ -289,6 +365,7 @@ struct SolveRun {
         all_done = check_done();
         const double t_search = now_s();
         if ((rc = service_bound(false))) return rc;
+        if ((rc = service_lp())) return rc;
         const double t_bound = now_s();
         const int cx0 = cx_calls;
         if (cx_on && !all_done && !has_target && (rc = cycles(t))) return rc;
@@ -320,6 +397,7 @@ struct SolveRun {
             share_bounds();
             for (int i = 0; i < n; ++i) {
                 if (!bound_ran[(size_t)i]) continue;
+                ++bound_merges[(size_t)i];
                 if (s->ub[(size_t)i] < ub_seen[(size_t)i]) { ub_seen[(size_t)i] = s->ub[(size_t)i]; bound_quiet[(size_t)i] = 0; }
                 else ++bound_quiet[(size_t)i];
             }
@@ -334,7 +412,7 @@ struct SolveRun {
         bool any = false;
         for (int i = 0; i < n && !all_done; ++i) {
             const bool want = feasible(i) && objective(i) < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
-                              !(s->dual_flags[(size_t)i] & 6);
+                              !(s->dual_flags[(size_t)i] & 6) && lp_state[(size_t)i] != 2;   // (a topic KAO-LP has certified: K-bound cannot get below the LP value)
             bool rest = false;
             if (want && det && bound_quiet[(size_t)i] >= bound_quiet_max &&
                 (int64_t)topics[i].n_partitions * topics[i].rf > bound_rest_slots)
@@ -498,6 +576,7 @@ struct SolveRun {
     int finish(kao_result *results, bool hit_time) {
         int rc = KAO_OK;
         if (s->bound_inflight && (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;  // last K-bound launch
+        if ((rc = service_lp(true))) return rc;                                                        // an LP whose stop flag is up by now still counts
         share_bounds();
         std::vector<kao_result> rs((size_t)n);
         std::vector<std::vector<uint16_t>> bufs((size_t)n);
@@ -598,6 +677,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     for (int32_t v : run.s->dual_iters) g_timing[8] += (double)v;
     g_timing[9] = run.cx_calls; g_timing[10] = run.cx_gains; g_timing[11] = (double)run.iters_done; g_timing[12] = run.generations;
     g_timing[13] = run.cx_more;
+    g_timing[14] = run.lp_solves; g_timing[15] = run.lp_iters;
     kao_session_destroy(run.s);
     run.s = nullptr;
     g_timing[3] = now_s() - t0;

@@ -518,4 +518,5 @@ def last_solve_timing() -> dict:
     _check(_ffi.load().kao_last_solve_timing(out), "kao_last_solve_timing")
     return dict(session_ready=out[0], time_to_best=out[1], results_read_back=out[2], returned=out[3], launches=int(out[4]),
                 delta_candidates=int(out[5]), bound_launches=int(out[6]), elite_exchanges=int(out[7]), bound_iters=int(out[8]),
-                cx_calls=int(out[9]), cx_gains=int(out[10]), search_iters=int(out[11]), generations=int(out[12]), cx_further_starts=int(out[13]))
+                cx_calls=int(out[9]), cx_gains=int(out[10]), search_iters=int(out[11]), generations=int(out[12]), cx_further_starts=int(out[13]),
+                lp_solves=int(out[14]), lp_iters=int(out[15]))
