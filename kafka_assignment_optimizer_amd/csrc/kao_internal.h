@@ -186,7 +186,10 @@ int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats
 int lp_begin(LpCtx *c, double tol, int maxit);
 int lp_enqueue(LpCtx *c, int k);
 int lp_poll(LpCtx *c, int *status, int *iterations);
+int lp_enqueue_mark(LpCtx *c, int k, int slot);                      // enqueue + a mark (ring slot 0..31) that lp_poll_mark waits for
+int lp_poll_mark(LpCtx *c, int slot, int *status, int *iterations);
 int lp_finish(LpCtx *c, int32_t *multipliers, double stats[8], double *trace);
+void lp_abort(LpCtx *c);   // stop flag up from the host: enqueued iterations turn into no-ops
 void lp_close(LpCtx *c);
 
 // ---- KAO-CX (kao_cycle.hip): cyclic-exchange improvement of a feasible assignment ----

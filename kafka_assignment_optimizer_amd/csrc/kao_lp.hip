@@ -148,12 +148,14 @@ __device__ __forceinline__ void block_reduce(double *vals, int n, bool is_min, d
         __syncthreads();
     }
 }
-__global__ void k_lp_red_final(const double *sc, const double *rec, int nrec, int n, int is_min, double *out) {   // one block of 64; thread k adds value k
-    const int k = threadIdx.x;
-    if (k >= n || sc[SC_STOP] != 0.0) return;
-    double a = is_min ? 1.0 : 0.0;
-    for (int i = 0; i < nrec; ++i) a = is_min ? fmin(a, rec[(size_t)i * kRedVals + k]) : a + rec[(size_t)i * kRedVals + k];
-    out[k] = a;
+__global__ void __launch_bounds__(kRedBlock) k_lp_red_final(const double *sc, const double *rec, int nrec, int n, int is_min, double *out) {
+    // one block: thread t folds records t, t + 256, ... in order, then the fixed tree of block_reduce -- the same bits on every run
+    if (sc[SC_STOP] != 0.0) return;
+    double a[kRedVals];
+    for (int k = 0; k < n; ++k) a[k] = is_min ? 1.0 : 0.0;
+    for (int i = threadIdx.x; i < nrec; i += kRedBlock)
+        for (int k = 0; k < n; ++k) a[k] = is_min ? fmin(a[k], rec[(size_t)i * kRedVals + k]) : a[k] + rec[(size_t)i * kRedVals + k];
+    block_reduce(a, n, is_min != 0, out);
 }
 // ---- the scalar steps of an iteration (one thread each) ------------------------------------------------------------------
 // residual sums -> mu, objectives, infeasibilities, trace, the stopping test.  redA = {|rd|^2, x.s + w.v, c.x, u.v},
@@ -429,49 +431,80 @@ __global__ void k_lp_schur_fix_cols(LpDev D, double *S) {
 }
 
 // ---- dense Cholesky of S (lower, row-major, leading dimension n = mcp, 64 x 64 tiles) ----------------------------------
-__global__ void __launch_bounds__(256) k_lp_chol_diag(const double *sc, double *S, int n, int kb, const double *diag0) {
+// The factor L is kept in the lower triangle; the tiles below the diagonal are ALSO written transposed into the upper triangle
+// (nothing else lives there), so that both triangular solves read rows of S with consecutive lanes on consecutive columns.
+// Diagonal tile: one wavefront, lane = row (Cholesky-Crout by columns; LDS operations of one wavefront execute in order, so no
+// barrier is needed), then the inverse of the 64 x 64 triangle (lane = column), which turns the panel solve below it and the
+// tile steps of the triangular solves into small matrix products.
+__global__ void __launch_bounds__(64) k_lp_chol_diag(const double *sc, double *S, int n, int kb, const double *diag0, double *Linv) {
     if (sc[SC_STOP] != 0.0) return;
     __shared__ double T[kNB][kNB + 1];
-    const int t = threadIdx.x, base = kb * kNB;
-    for (int i = t; i < kNB * kNB; i += 256) T[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
-    __syncthreads();
+    const int lane = threadIdx.x, base = kb * kNB;
+    for (int r = 0; r < kNB; ++r) T[r][lane] = S[(size_t)(base + r) * n + base + lane];
+    // the lane's own row lives in registers (both loops fully unrolled: every index is a constant), row j is broadcast from LDS
+    double row[kNB];
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) row[k] = T[lane][k];
+    double dg[kNB / 64 + 1];
+    dg[0] = diag0[base + lane];
+#pragma unroll
     for (int j = 0; j < kNB; ++j) {
-        const double a = T[j][j];
-        const double ljj = (a > kLpPivotRel * diag0[base + j]) ? sqrt(a) : kLpPivotBig;
-        __syncthreads();
-        if (t == 0) T[j][j] = ljj;
-        for (int i = j + 1 + t; i < kNB; i += 256) T[i][j] /= ljj;
-        __syncthreads();
-        // trailing update of the lower triangle: pairs (i, k), j < k <= i
-        const int m = kNB - j - 1;
-        for (int e = t; e < m * m; e += 256) {
-            const int i = j + 1 + e / m, k = j + 1 + e % m;
-            if (k <= i) T[i][k] -= T[i][j] * T[k][j];
-        }
-        __syncthreads();
+        double a = row[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) a -= row[k] * T[j][k];
+        const double aj = __shfl(a, j, 64), d0 = __shfl(dg[0], j, 64);
+        const double ljj = (aj > kLpPivotRel * d0) ? sqrt(aj) : kLpPivotBig;
+        row[j] = lane == j ? ljj : a / ljj;       // (lanes above the diagonal hold garbage nobody reads)
+        T[lane][j] = row[j];
     }
-    for (int i = t; i < kNB * kNB; i += 256) if (i % kNB <= i / kNB) S[(size_t)(base + i / kNB) * n + base + i % kNB] = T[i / kNB][i % kNB];
-}
-// row tiles below the diagonal tile: X = A L_kk^-T (every thread solves one row by forward substitution)
-__global__ void __launch_bounds__(64) k_lp_chol_trsm(const double *sc, double *S, int n, int kb) {
-    if (sc[SC_STOP] != 0.0) return;
-    __shared__ double Lk[kNB][kNB + 1];
-    const int t = threadIdx.x, base = kb * kNB, row = (kb + 1 + blockIdx.x) * kNB + t;
-    for (int i = t; i < kNB * kNB; i += 64) Lk[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
-    __syncthreads();
+    for (int r = 0; r < kNB; ++r) if (lane <= r) S[(size_t)(base + r) * n + base + lane] = T[r][lane];
+    // X = L^-1, column `lane` in registers: x_c = 1 / L_cc, x_i = -(sum_{c <= k < i} L_ik x_k) / L_ii
     double x[kNB];
-    double *Ar = S + (size_t)row * n + base;
 #pragma unroll
-    for (int j = 0; j < kNB; ++j) x[j] = Ar[j];
+    for (int i = 0; i < kNB; ++i) {
+        double a = i == lane ? 1.0 : 0.0;
 #pragma unroll
-    for (int j = 0; j < kNB; ++j) {
-        double a = x[j];
+        for (int k = 0; k < i; ++k) a -= T[i][k] * x[k];      // (x[k] = 0 for k < lane)
+        x[i] = i < lane ? 0.0 : a / T[i][i];
+    }
+    double *out = Linv + (size_t)kb * kNB * kNB;
 #pragma unroll
-        for (int k = 0; k < j; ++k) a -= x[k] * Lk[j][k];
-        x[j] = a / Lk[j][j];
+    for (int r = 0; r < kNB; ++r) out[r * kNB + lane] = x[r];
+}
+// row tiles below the diagonal tile: X = A L_kk^-T = A Linv^T, a 64 x 64 x 64 product (256 threads, 4 x 4 micro-tiles);
+// written to the lower tile and, transposed, to the upper one
+__global__ void __launch_bounds__(256) k_lp_chol_trsm(const double *sc, double *S, int n, int kb, const double *Linv) {
+    if (sc[SC_STOP] != 0.0) return;
+    __shared__ double Ai[kNB][kNB + 1], Li[kNB][kNB + 1];
+    const int t = threadIdx.x, base = kb * kNB, rt = kb + 1 + blockIdx.x;
+    const double *inv = Linv + (size_t)kb * kNB * kNB;
+    for (int i = t; i < kNB * kNB; i += 256) {
+        Ai[i / kNB][i % kNB] = S[(size_t)(rt * kNB + i / kNB) * n + base + i % kNB];
+        Li[i / kNB][i % kNB] = inv[i];
+    }
+    __syncthreads();
+    const int r0 = (t / 16) * 4, c0 = (t % 16) * 4;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int k = 0; k < kNB; ++k) {
+        double ai[4], li[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { ai[a] = Ai[r0 + a][k]; li[a] = Li[c0 + a][k]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] += ai[a] * li[b];
     }
 #pragma unroll
-    for (int j = 0; j < kNB; ++j) Ar[j] = x[j];
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            S[(size_t)(rt * kNB + r0 + a) * n + base + c0 + b] = acc[a][b];
+            S[(size_t)(base + c0 + b) * n + rt * kNB + r0 + a] = acc[a][b];
+        }
 }
 // trailing update A_ij -= L_ik L_jk^T for tile pairs i >= j > kb; 256 threads, 4 x 4 micro-tiles
 __global__ void __launch_bounds__(256) k_lp_chol_update(const double *sc, double *S, int n, int kb, int nrem) {
@@ -509,55 +542,50 @@ __global__ void __launch_bounds__(256) k_lp_chol_update(const double *sc, double
         for (int b = 0; b < 4; ++b)
             if (bi != bj || c0 + b <= r0 + a) S[(size_t)(ti_ * kNB + r0 + a) * n + tj * kNB + c0 + b] -= acc[a][b];   // diagonal tiles: lower triangle only
 }
-// L z = r then L^T x = z, in place in `r` (length n); one workgroup of 1024, the vector in LDS
-__global__ void __launch_bounds__(1024) k_lp_trsv(const double *sc, const double *S, int n, double *r) {
+// sum_k col[k * n] * xt[k], k < 64: the loads of 16 rows are issued together (written as load phase / multiply phase: left to itself
+// the compiler waits for every load before it issues the next -- 2.1 ms per solve at n = 2112 instead of 0.3)
+__device__ __forceinline__ double trsv_col_dot(const double *__restrict__ col, int n, const double *xt) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < kNB; k += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(col + (size_t)(k + u) * n);
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) { a0 += v[u] * xt[k + u]; a1 += v[u + 1] * xt[k + u + 1]; }
+    }
+    return a0 + a1;
+}
+// L z = r then L^T x = z, in place in `r` (length n); one workgroup of 1024, the vector in LDS.  A tile step is x_tile = Linv r_tile
+// (one wavefront) followed by the update of the rest of the vector, whose reads are rows of S on consecutive lanes in both
+// directions (the upper triangle holds L^T).
+__global__ void __launch_bounds__(1024) k_lp_trsv(const double *sc, const double *S, int n, double *r, const double *Linv) {
     if (sc[SC_STOP] != 0.0) return;
     extern __shared__ double xv[];
-    __shared__ double Lk[kNB][kNB + 1];
+    __shared__ double Lk[kNB][kNB + 1], xt[kNB];
     const int t = threadIdx.x, nt = n / kNB;
     for (int i = t; i < n; i += 1024) xv[i] = r[i];
     __syncthreads();
     for (int kb = 0; kb < nt; ++kb) {
         const int base = kb * kNB;
-        for (int i = t; i < kNB * kNB; i += 1024) Lk[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
+        const double *inv = Linv + (size_t)kb * kNB * kNB;
+        for (int i = t; i < kNB * kNB; i += 1024) Lk[i / kNB][i % kNB] = inv[i];
         __syncthreads();
-        if (t < 64) {   // one wavefront: forward substitution inside the tile
-            double mine = xv[base + t];
-            for (int j = 0; j < kNB; ++j) {
-                const double xj = __shfl(mine, j, 64) / Lk[j][j];
-                if (t == j) mine = xj;
-                else if (t > j) mine -= Lk[t][j] * xj;
-            }
-            xv[base + t] = mine;
-        }
+        if (t < kNB) { double a = 0.0; for (int k = 0; k <= t; ++k) a += Lk[t][k] * xv[base + k]; xt[t] = a; }
         __syncthreads();
-        for (int i = base + kNB + t; i < n; i += 1024) {
-            const double *Li = S + (size_t)i * n + base;
-            double a = 0.0;
-            for (int k = 0; k < kNB; ++k) a += Li[k] * xv[base + k];
-            xv[i] -= a;
-        }
+        if (t < kNB) xv[base + t] = xt[t];
+        for (int i = base + kNB + t; i < n; i += 1024) xv[i] -= trsv_col_dot(S + (size_t)base * n + i, n, xt);
         __syncthreads();
     }
     for (int kb = nt - 1; kb >= 0; --kb) {
         const int base = kb * kNB;
-        for (int i = t; i < kNB * kNB; i += 1024) Lk[i / kNB][i % kNB] = S[(size_t)(base + i / kNB) * n + base + i % kNB];
+        const double *inv = Linv + (size_t)kb * kNB * kNB;
+        for (int i = t; i < kNB * kNB; i += 1024) Lk[i / kNB][i % kNB] = inv[i];
         __syncthreads();
-        if (t < 64) {
-            double mine = xv[base + t];
-            for (int j = kNB - 1; j >= 0; --j) {
-                const double xj = __shfl(mine, j, 64) / Lk[j][j];
-                if (t == j) mine = xj;
-                else if (t < j) mine -= Lk[j][t] * xj;
-            }
-            xv[base + t] = mine;
-        }
+        if (t < kNB) { double a = 0.0; for (int k = t; k < kNB; ++k) a += Lk[k][t] * xv[base + k]; xt[t] = a; }
         __syncthreads();
-        for (int i = t; i < base; i += 1024) {
-            double a = 0.0;
-            for (int k = 0; k < kNB; ++k) a += S[(size_t)(base + k) * n + i] * xv[base + k];
-            xv[i] -= a;
-        }
+        if (t < kNB) xv[base + t] = xt[t];
+        for (int i = t; i < base; i += 1024) xv[i] -= trsv_col_dot(S + (size_t)base * n + i, n, xt);
         __syncthreads();
     }
     for (int i = t; i < n; i += 1024) r[i] = xv[i];
@@ -946,12 +974,15 @@ struct LpCtx {
     VarVec x{}, s{}, v{}, th{}, rd{}, h{}, g{}, d1{}, d2{}, dsa{}, dva{}, ds{}, dv{};
     RowVec y{}, rp{}, w1{}, w2{};
     size_t rows_local = 0;     // doubles of the local rows of one RowVec (r1 r2 r7 r5 contiguous)
-    double *fj = nullptr, *fr = nullptr, *ti = nullptr, *S = nullptr, *diag0 = nullptr, *cb = nullptr, *cr = nullptr;
+    double *fj = nullptr, *fr = nullptr, *ti = nullptr, *S = nullptr, *Linv = nullptr, *diag0 = nullptr, *cb = nullptr, *cr = nullptr;
     double *rec = nullptr, *redA = nullptr, *redB = nullptr, *redC = nullptr, *part = nullptr, *ylast = nullptr, *trace = nullptr;
     int32_t *d_mult = nullptr;
     int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
     int maxit = 80, trace_cap = 0;
-    double *h_sc = nullptr;    // pinned mirror of the scalars
+    double *h_sc = nullptr;    // pinned mirror of the scalars: slot 0 for lp_poll / lp_begin, slots 1..kLpRing for the marks of lp_enqueue_mark
+    hipEvent_t ev[32] = {};
+    hipGraphExec_t graph = nullptr;   // one iteration, captured once: a launch instead of ~250 (every kernel argument is fixed for the context's lifetime)
+    bool graph_tried = false;
     double t_begin = 0;
     int enqueued = 0;          // iterations enqueued since lp_begin
 
@@ -981,6 +1012,8 @@ struct LpCtx {
     ~LpCtx() {
         for (void *p : bufs) (void)hipFree(p);
         if (h_sc) (void)hipHostFree(h_sc);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+        if (graph) (void)hipGraphExecDestroy(graph);
         if (st) (void)hipStreamDestroy(st);
     }
 };
@@ -988,7 +1021,7 @@ struct LpCtx {
 namespace {
 
 void lp_reduce(LpCtx &c, int nrec, int n, bool is_min, double *out) {
-    hipLaunchKernelGGL(k_lp_red_final, dim3(1), dim3(64), 0, c.st, c.D.sc, c.rec, nrec, n, is_min ? 1 : 0, out);
+    hipLaunchKernelGGL(k_lp_red_final, dim3(1), dim3(kRedBlock), 0, c.st, c.D.sc, c.rec, nrec, n, is_min ? 1 : 0, out);
 }
 // local rows of A z into `out` (mode 0 plain, 1 = b - A z, 2 = A z + add)
 void lp_rows_local(LpCtx &c, const VarVec &z, const RowVec &out, int mode, const RowVec &add) {
@@ -1013,10 +1046,10 @@ void lp_factor(LpCtx &c) {
     hipLaunchKernelGGL(k_lp_schur_fix_cols, dim3((D.mc + 255) / 256), dim3(256), 0, c.st, D, c.S);
     const int nt = D.mcp / kNB;
     for (int kb = 0; kb < nt; ++kb) {
-        hipLaunchKernelGGL(k_lp_chol_diag, dim3(1), dim3(256), 0, c.st, D.sc, c.S, D.mcp, kb, c.diag0);
+        hipLaunchKernelGGL(k_lp_chol_diag, dim3(1), dim3(64), 0, c.st, D.sc, c.S, D.mcp, kb, c.diag0, c.Linv);
         const int nrem = nt - kb - 1;
         if (nrem <= 0) break;
-        hipLaunchKernelGGL(k_lp_chol_trsm, dim3(nrem), dim3(64), 0, c.st, D.sc, c.S, D.mcp, kb);
+        hipLaunchKernelGGL(k_lp_chol_trsm, dim3(nrem), dim3(256), 0, c.st, D.sc, c.S, D.mcp, kb, c.Linv);
         hipLaunchKernelGGL(k_lp_chol_update, dim3(nrem * (nrem + 1) / 2), dim3(256), 0, c.st, D.sc, c.S, D.mcp, kb, nrem);
     }
 }
@@ -1026,7 +1059,7 @@ void lp_solve_normal(LpCtx &c, const RowVec &v, const VarVec &z, const double *a
     const LpDev &D = c.D;
     hipLaunchKernelGGL(k_lp_elim_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, c.cb, c.cr);
     lp_rows_coupling(c, z, v.rc, add_rc ? 2 : 0, add_rc, c.cb, c.cr);
-    hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, D.sc, c.S, D.mcp, v.rc);
+    hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, D.sc, c.S, D.mcp, v.rc, c.Linv);
     hipLaunchKernelGGL(k_lp_back_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v);
 }
 
@@ -1068,8 +1101,14 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     D.has_m = bd[3] > bd[2]; D.m_ub = bd[3] - bd[2];
     D.has_k = D.has_n && bd[5] > bd[4]; D.k_ub = bd[5] - bd[4];
     auto bail = [&](int code) { delete c; return code; };
-    if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess) return bail(fail(KAO_ERR_HIP, "KAO-LP: stream"));
-    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_sc), sizeof(double) * kScN) != hipSuccess) return bail(fail(KAO_ERR_NOMEM, "KAO-LP: pinned buffer"));
+    {   // highest priority: an iteration is a chain of ~250 small dependent kernels; behind a full K-search grid at normal priority
+        // every one of them queues (measured on the drifted 1000 x 100,000 topic: 4 iterations in 280 ms beside K-search, 38 ms alone)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&c->st, hipStreamNonBlocking, hi) != hipSuccess)
+            return bail(fail(KAO_ERR_HIP, "KAO-LP: stream"));
+    }
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_sc), sizeof(double) * kScN * 33) != hipSuccess) return bail(fail(KAO_ERR_NOMEM, "KAO-LP: pinned buffer"));
+    for (hipEvent_t &e : c->ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(KAO_ERR_HIP, "KAO-LP: event"));
     // structure
     std::vector<uint16_t> cur(t->current, t->current + (size_t)P * NJ);
     std::vector<uint8_t> rack(t->rack_of, t->rack_of + B);
@@ -1140,7 +1179,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     c->rack_blocks = (P + c->rack_chunk - 1) / c->rack_chunk;
     c->trace_cap = 512;
     if ((rc = c->alloc(&c->fj, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->fr, (size_t)3 * R * P)) || (rc = c->alloc(&c->ti, (size_t)3 * P)) ||
-        (rc = c->alloc(&c->S, (size_t)D.mcp * D.mcp)) || (rc = c->alloc(&c->diag0, (size_t)D.mcp)) || (rc = c->alloc(&c->cb, (size_t)2 * NJ * P)) ||
+        (rc = c->alloc(&c->S, (size_t)D.mcp * D.mcp)) || (rc = c->alloc(&c->Linv, (size_t)D.mcp * kNB)) || (rc = c->alloc(&c->diag0, (size_t)D.mcp)) || (rc = c->alloc(&c->cb, (size_t)2 * NJ * P)) ||
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
         (rc = c->alloc(&c->part, (size_t)c->rack_blocks * n2 * n2)) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
@@ -1160,6 +1199,14 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     return KAO_OK;
 }
 
+// Raises the stop flag from the host: whatever is still enqueued turns into no-ops (a context that is closed with work in flight
+// would otherwise wait for all of it).
+void lp_abort(LpCtx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    const double two = 2.0;
+    (void)hipMemcpy(c->D.sc + SC_STOP, &two, sizeof two, hipMemcpyHostToDevice);
+}
 void lp_close(LpCtx *c) { delete c; }
 
 // Enqueues the starting point (theta = 1: x~ = A^T (A A^T)^-1 b, y = (A A^T)^-1 A c, s = c - A^T y, pushed into the interior) and the
@@ -1197,13 +1244,11 @@ int lp_begin(LpCtx *cp, double tol, int maxit) {
 
 // Enqueues `k` iterations (each: factor, predictor, corrector, update, residuals + stopping test of the new iterate).  Asynchronous;
 // iterations behind the one that sets the stop flag are no-ops.
-int lp_enqueue(LpCtx *cp, int k) {
-    LpCtx &c = *cp;
+static void lp_enqueue_one(LpCtx &c) {
     const LpDev &D = c.D;
-    HIP_TRY(hipSetDevice(c.device));
     const size_t nvtot = (size_t)D.NV * D.P + D.GV;
     const dim3 gv((unsigned)((nvtot + 255) / 256)), b256(256);
-    for (int q = 0; q < k; ++q) {
+    {
         hipLaunchKernelGGL(k_lp_theta, dim3((unsigned)(((size_t)D.NV * D.P + 255) / 256)), b256, 0, c.st, D, c.x.z, c.s.z, c.v.z, c.th.z, 0);
         hipLaunchKernelGGL(k_lp_theta_g, dim3((D.GV + 255) / 256), b256, 0, c.st, D, c.x.zg, c.s.zg, c.v.zg, c.th.zg, 0);
         lp_factor(c);
@@ -1227,8 +1272,50 @@ int lp_enqueue(LpCtx *cp, int k) {
         hipLaunchKernelGGL(k_lp_axpy, dim3((unsigned)((nrow + 255) / 256)), b256, 0, c.st, D.sc, c.w2.r1, c.y.r1, nrow);
         lp_enqueue_resid(c);
     }
+}
+int lp_enqueue(LpCtx *cp, int k) {
+    LpCtx &c = *cp;
+    HIP_TRY(hipSetDevice(c.device));
+    if (!c.graph_tried) {   // capture one iteration (KAO_LP_GRAPH=0: plain launches)
+        c.graph_tried = true;
+        const char *e = std::getenv("KAO_LP_GRAPH");
+        if (!(e && e[0] == '0') && hipStreamBeginCapture(c.st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            lp_enqueue_one(c);
+            hipGraph_t g = nullptr;
+            if (hipStreamEndCapture(c.st, &g) == hipSuccess && g) {
+                if (hipGraphInstantiate(&c.graph, g, nullptr, nullptr, 0) != hipSuccess) c.graph = nullptr;
+                (void)hipGraphDestroy(g);
+            }
+            (void)hipGetLastError();
+        }
+    }
+    for (int q = 0; q < k; ++q) {
+        if (c.graph) HIP_TRY(hipGraphLaunch(c.graph, c.st));
+        else lp_enqueue_one(c);
+    }
     c.enqueued += k;
     HIP_TRY(hipGetLastError());
+    return KAO_OK;
+}
+
+// lp_enqueue + a MARK: behind the k iterations the scalars are copied to ring slot `slot` (0..31) and an event is recorded.  lp_poll_mark
+// waits for exactly that mark -- not for whatever was enqueued after it -- so a caller that keeps a few marks in flight (kao_solve: one per
+// K-search launch, read three launches later) hardly ever blocks and still sees the state of a fixed iteration count: deterministic.
+int lp_enqueue_mark(LpCtx *cp, int k, int slot) {
+    int rc = lp_enqueue(cp, k);
+    if (rc) return rc;
+    LpCtx &c = *cp;
+    HIP_TRY(hipMemcpyAsync(c.h_sc + (size_t)(1 + (slot & 31)) * kScN, c.D.sc, sizeof(double) * kScN, hipMemcpyDeviceToHost, c.st));
+    HIP_TRY(hipEventRecord(c.ev[slot & 7], c.st));
+    return KAO_OK;
+}
+int lp_poll_mark(LpCtx *cp, int slot, int *status, int *iterations) {
+    LpCtx &c = *cp;
+    HIP_TRY(hipSetDevice(c.device));
+    HIP_TRY(hipEventSynchronize(c.ev[slot & 7]));
+    const double *h = c.h_sc + (size_t)(1 + (slot & 31)) * kScN;
+    if (status) *status = (int)h[SC_STOP];
+    if (iterations) *iterations = (int)h[SC_IT];
     return KAO_OK;
 }
 

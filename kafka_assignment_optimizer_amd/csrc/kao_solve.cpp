@@ -140,21 +140,44 @@ struct SolveRun {
     std::vector<uint64_t> inc_key;                // best incumbent of the earlier generations (host copy), ~0 = none
     std::vector<std::vector<uint16_t>> inc_assign;
     // KAO-LP (round 5, kao_lp.hip): K-bound's subgradient iteration stalls above the LP value on slack-band and on large topics
-    // (450 x 3500: 26336 against 26330 = the incumbent; 1000 x 30000: 231,562 against 231,532).  A feasible topic K-bound has not
-    // closed after `lp_after` merged launches gets the LP relaxation solved by the interior-point kernels: the iterations ride
-    // beside the K-search launches on a stream of their own (`lp_per_launch` per launch, no host round trip inside), and when
-    // the stop flag is up the row duals become K-bound's multipliers, ONE K-bound iteration evaluates the dual function there in
-    // integers (certificate, search prices), and K-bound leaves the topic alone from then on -- it cannot get below the LP
-    // value, and beside K-search it costs the search half its speed on large topics.  Counts only: deterministic.
+    // (450 x 3500: 26336 against 26330 = the incumbent; 1000 x 30000: 231,562 against 231,532; drifted 1000 x 100,000: 782,627
+    // against 782,512).  A topic of at least `lp_min_slots` replica slots that the first launch has not closed gets the LP
+    // relaxation solved by the interior-point kernels right away (it needs no incumbent; 11-16 iterations = 25-60 ms up to 5,000
+    // partitions, where K-bound needs 0.2 s to several seconds or never arrives); a smaller one only after K-bound has had
+    // `lp_after_small` merged launches without closing it.  The iterations ride beside the K-search launches on a stream of their
+    // own (`lp_per_launch` per launch, no host round trip inside), and when the stop flag is up the row duals become K-bound's
+    // multipliers, ONE K-bound iteration evaluates the dual function there in integers (certificate, search prices), and K-bound
+    // leaves the topic alone from then on -- it cannot get below the LP value, and beside K-search it costs the search half its
+    // speed on large topics.  Counts only: deterministic.
     std::vector<LpCtx *> lp_ctx;
     std::vector<char> lp_state;                   // 0 = not started, 1 = running, 2 = done, 3 = unsupported / failed
     std::vector<int> bound_merges;                // merged K-bound launches per topic
     std::vector<int64_t> lp_tgt;
+    std::vector<int> lp_marks, lp_read;           // per topic: marks enqueued / marks read (a mark is read `lp_lag` launches after it was enqueued)
+    int lp_lag = 3;
+    // Beyond `lp_huge_slots` replica slots (the north-star regime) the pieces do not share the GPU well: K-search there is a grid of
+    // dependent random 16-byte reads that saturates the memory system, and beside it the interior point's chain of ~250 small kernels
+    // per iteration crawls (drifted 1000 x 100,000: 4 iterations in 250-280 ms beside K-search, 38 ms alone, whatever the stream
+    // priority; KAO-CX beside the LP: 20 ms a round instead of 8) -- while K-search itself brings nothing once the topic is feasible
+    // (round 4: 0 of 4,275 units; KAO-CX all).  The pieces add up to the same wall time in any order (first feasible incumbent 0.16 s,
+    // KAO-CX to its fixpoint 0.8 s, LP 0.53 s), so they run one after the other, the primal side first:
+    //   until the first feasible incumbent: K-search;
+    //   then KAO-CX to its fixpoint with K-bound beside it (a certificate for whoever stops early), no K-search launches;
+    //   then the LP, all its iterations enqueued at once (marks of four), nothing beside it;
+    //   then K-search again, under the LP's prices, K-bound retired.
+    int64_t lp_huge_slots = 131072;
+    std::vector<char> lp_all;                     // per topic: every iteration is enqueued already
+    bool huge(int i) const { return (int64_t)topics[i].n_partitions * topics[i].rf > lp_huge_slots; }
+    bool lp_possible(int i) const { return lp_on && !has_target && dual_iters > 0 && s->dual_ok[(size_t)i] && lp_state[(size_t)i] < 2; }
+    bool search_paused() const {   // a huge topic between its first feasible incumbent and the end of its LP
+        for (int i = 0; i < n; ++i) if (huge(i) && lp_possible(i) && feasible(i) && !topic_done(i)) return true;
+        return false;
+    }
     int lp_on = 1, lp_per_launch = 2, lp_max_running = 2, lp_solves = 0, lp_iters = 0;
     int64_t lp_min_slots = 2048;
-    int lp_after_big = 2, lp_after_small = 48;
+    int lp_after_small = 48;
 
-    ~SolveRun() { for (CycleCtx *c : cx_ctx) cycle_close(c); for (LpCtx *c : lp_ctx) if (c) lp_close(c); if (s) kao_session_destroy(s); }
+    ~SolveRun() { for (CycleCtx *c : cx_ctx) cycle_close(c); for (LpCtx *c : lp_ctx) if (c) { lp_abort(c); lp_close(c); } if (s) kao_session_destroy(s); }
 
     // `so` is the caller's options with kao_solve's defaults applied; the session is created on the calling thread's device
     int begin(const kao_topic *user_topics, int n_topics, const kao_opts &so, const int64_t *tgt, double t_start, bool allow_islands = false, bool allow_gens = false) {
@@ -204,11 +227,11 @@ struct SolveRun {
         this->topics = topics;
         t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
         cx_started.assign((size_t)n, {});
-        lp_ctx.assign((size_t)n, nullptr); lp_state.assign((size_t)n, 0); bound_merges.assign((size_t)n, 0); lp_tgt.assign((size_t)n, -1);
+        lp_ctx.assign((size_t)n, nullptr); lp_marks.assign((size_t)n, 0); lp_read.assign((size_t)n, 0); lp_all.assign((size_t)n, 0); lp_state.assign((size_t)n, 0); bound_merges.assign((size_t)n, 0); lp_tgt.assign((size_t)n, -1);
         {   // test / experiment hooks: KAO_LP=0 switches KAO-LP off, KAO_LP_AFTER / KAO_LP_PER_LAUNCH / KAO_LP_MIN_SLOTS override the counts
             auto env_i = [](const char *name, int64_t dflt) { const char *e = std::getenv(name); return e && *e ? (int64_t)std::atoll(e) : dflt; };
             lp_on = (int)env_i("KAO_LP", 1);
-            lp_after_big = (int)env_i("KAO_LP_AFTER", lp_after_big);
+            lp_after_small = (int)env_i("KAO_LP_AFTER", lp_after_small);
             lp_per_launch = (int)std::max<int64_t>(1, env_i("KAO_LP_PER_LAUNCH", lp_per_launch));
             lp_min_slots = env_i("KAO_LP_MIN_SLOTS", lp_min_slots);
         }
@@ -263,24 +286,37 @@ struct SolveRun {
     // now, behind the new K-search launch -- enqueueing up to 176 step kernels takes the host about a millisecond, which
     // the search stream no longer spends idle
     int launch() {
-        int rc = kao_session_step(s);
+        int rc = KAO_OK;
+        if (!search_paused()) rc = kao_session_step(s);
         if (!rc && bound_pending) { bound_pending = false; rc = kao_session_bound_step(s, dual_target.data(), dual_now); }
         for (int i = 0; i < n && !rc; ++i)
-            if (lp_state[(size_t)i] == 1) rc = lp_enqueue(lp_ctx[(size_t)i], lp_per_launch);   // interior-point iterations beside the launch
+            if (lp_state[(size_t)i] == 1 && !lp_all[(size_t)i]) rc = lp_enqueue_mark(lp_ctx[(size_t)i], lp_per_launch, lp_marks[(size_t)i]++);   // interior-point iterations beside the launch
         return rc;
     }
     // KAO-LP: start the LP of topics K-bound has not closed, collect the ones whose stop flag is up
     int service_lp(bool final_call = false) {
         if (!lp_on || has_target || dual_iters <= 0) return KAO_OK;
+        const double tsl0 = now_s();
+        struct Tr { bool on; double t0; int l; ~Tr() { if (on && now_s() - t0 > 2e-3) std::fprintf(stderr, "[kao-solve]   service_lp took %.3f ms at launch %d\n", (now_s() - t0) * 1e3, l); } } tr_{trace, tsl0, launches};
         int rc, running = 0;
         for (int i = 0; i < n; ++i) running += lp_state[(size_t)i] == 1;
         for (int i = 0; i < n; ++i) {
             if (lp_state[(size_t)i] != 1) continue;
             int st = 0, it = 0;
-            if ((rc = lp_poll(lp_ctx[(size_t)i], &st, &it))) return rc;
+            // the mark of `lp_lag` launches ago (the interior-point stream runs on while the host goes about K-search, K-bound and KAO-CX:
+            // it is hardly ever waited for); at the end of the solve the newest one
+            if (final_call) {   // the newest mark of an LP that rides beside the launches; of one enqueued as a whole only the next (a bounded wait)
+                const int m = lp_all[(size_t)i] ? lp_read[(size_t)i] : lp_marks[(size_t)i] - 1;
+                if (m >= 0 && m < lp_marks[(size_t)i] && (rc = lp_poll_mark(lp_ctx[(size_t)i], m, &st, &it))) return rc;
+                if (!st) lp_abort(lp_ctx[(size_t)i]);
+            } else if (lp_read[(size_t)i] < lp_marks[(size_t)i] && lp_marks[(size_t)i] - lp_read[(size_t)i] > (lp_all[(size_t)i] ? 0 : lp_lag)) {
+                const double tp0 = now_s();
+                if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it))) return rc;
+                if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: mark %d of %d read in %.3f ms: %d iterations, stop %d\n", i, lp_read[(size_t)i] - 1, lp_marks[(size_t)i], (now_s() - tp0) * 1e3, it, st);
+            }
             const bool open = feasible(i) ? objective(i) < s->ub[(size_t)i] : true;
             if (!st && open && !final_call) continue;
-            if (!st || !open) { lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; lp_state[(size_t)i] = open ? 0 : 2; --running; continue; }
+            if (!st || !open) { lp_abort(lp_ctx[(size_t)i]); lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; lp_state[(size_t)i] = open ? 0 : 2; --running; continue; }
             // the row duals as K-bound's multipliers; one K-bound iteration evaluates the dual function there in integers
             const kao_topic &t = topics[i];
             std::vector<int32_t> mult(2 * (size_t)t.n_brokers + (size_t)t.n_racks);
@@ -305,9 +341,13 @@ struct SolveRun {
             if (running >= lp_max_running) break;
             int best = -1; int64_t best_slots = 0;
             for (int i = 0; i < n; ++i) {
-                if (lp_state[(size_t)i] != 0 || !s->dual_ok[(size_t)i] || s->topic_infeasible[(size_t)i] || !feasible(i) || objective(i) >= s->ub[(size_t)i]) continue;
+                if (lp_state[(size_t)i] != 0 || !s->dual_ok[(size_t)i] || s->topic_infeasible[(size_t)i] || (feasible(i) && objective(i) >= s->ub[(size_t)i])) continue;
+                if (huge(i)) {   // ... once KAO-CX has run the incumbent to a fixpoint (or cannot run)
+                    const bool cx_can = cx_on && cycle_supported(&topics[i]);
+                    if (!feasible(i) || (cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20))) continue;
+                }
                 const int64_t slots = (int64_t)topics[i].n_partitions * topics[i].rf;
-                if (bound_merges[(size_t)i] < (slots >= lp_min_slots ? lp_after_big : lp_after_small)) continue;
+                if (slots < lp_min_slots && (!feasible(i) || bound_merges[(size_t)i] < lp_after_small)) continue;
                 if (slots > best_slots) { best = i; best_slots = slots; }
             }
             if (best < 0) break;
@@ -316,7 +356,11 @@ struct SolveRun {
             if (rc == KAO_ERR_UNSUPPORTED || rc == KAO_ERR_NOMEM) { lp_state[(size_t)best] = 3; continue; }
             if (rc) return rc;
             if ((rc = lp_begin(c, 1e-7, 120))) { lp_close(c); return rc; }
-            lp_ctx[(size_t)best] = c; lp_state[(size_t)best] = 1; ++running;
+            lp_ctx[(size_t)best] = c; lp_state[(size_t)best] = 1; lp_marks[(size_t)best] = lp_read[(size_t)best] = 0; lp_all[(size_t)best] = 0; ++running;
+            if (huge(best)) {   // the whole solve at once: 30 marks of four iterations (those behind the stop flag are no-ops)
+                for (int m = 0; m < 30; ++m) if ((rc = lp_enqueue_mark(c, 4, lp_marks[(size_t)best]++))) return rc;
+                lp_all[(size_t)best] = 1;
+            }
         }
         all_done = check_done();
         return KAO_OK;
@@ -365,6 +409,7 @@ struct SolveRun {
         all_done = check_done();
         const double t_search = now_s();
         if ((rc = service_bound(false))) return rc;
+        if (trace && now_s() - t_search > 2e-3) std::fprintf(stderr, "[kao-solve]   service_bound took %.3f ms\n", (now_s() - t_search) * 1e3);
         if ((rc = service_lp())) return rc;
         const double t_bound = now_s();
         const int cx0 = cx_calls;
@@ -412,7 +457,8 @@ struct SolveRun {
         bool any = false;
         for (int i = 0; i < n && !all_done; ++i) {
             const bool want = feasible(i) && objective(i) < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
-                              !(s->dual_flags[(size_t)i] & 6) && lp_state[(size_t)i] != 2;   // (a topic KAO-LP has certified: K-bound cannot get below the LP value)
+                              !(s->dual_flags[(size_t)i] & 6) && lp_state[(size_t)i] != 2 &&   // (a topic KAO-LP has certified: K-bound cannot get below the LP value)
+                              !(lp_state[(size_t)i] == 1 && lp_all[(size_t)i]);                // (a huge topic while its LP runs: the search is paused, prices have no reader)
             bool rest = false;
             if (want && det && bound_quiet[(size_t)i] >= bound_quiet_max &&
                 (int64_t)topics[i].n_partitions * topics[i].rf > bound_rest_slots)

@@ -11,9 +11,15 @@ def otopic(pt):
     return ko.Topic(name=pt.name, broker_ids=np.array(pt.broker_ids), rack_of=np.array(pt.rack_of), n_racks=pt.n_racks,
                     n_partitions=pt.n_partitions, rf=pt.rf, current=np.array(pt.current), weights=pt.weights,
                     bounds_override=dict(pt.bounds_override))
-shapes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(100, 5, 1000), (130, 5, 1000), (450, 9, 3500)]
-for B, R, P in shapes:
-    pt = sy.drift(sy.make_cluster(B, R, 1, P, 3, [], []), 0.2, 1)[0]
+args = sys.argv[1:] or ["100x5x1000", "130x5x1000", "450x9x3500"]
+for arg in args:
+    if "x" in arg and arg[0].isdigit():
+        B, R, P = (int(x) for x in arg.split("x"))
+        pt = sy.drift(sy.make_cluster(B, R, 1, P, 3, [], []), 0.2, 1)[0]
+    else:                                   # a named north-star workload (synthetic.north_star_topic): drift100k, cfg5one, drift30k
+        pt = sy.north_star_topic(arg)
+        B, R, P = pt.n_brokers, pt.n_racks, pt.n_partitions
+        kao.lp_trace(pt, max_iters=1)       # allocation warm-up
     t0 = time.perf_counter(); d = kao.lp_trace(pt); dt = time.perf_counter() - t0
     print(f"{B}x{P}: device status {d['status']} it {d['iterations']} primal {d['primal']:.6f} dual {d['dual']:.6f} ipm {d['ms']:.1f} ms (call {dt*1e3:.1f} ms)", flush=True)
     if P <= 6000:
