@@ -141,8 +141,10 @@ typedef struct kao_result {
 typedef struct kao_stats {
     uint64_t launches;          /* K-search launches */
     uint64_t delta_candidates;  /* neighbours delta-evaluated by K-search, per restart and iteration: REPLACE = all B
-                                   brokers of one slot (scan blocks) or 64 lanes x 4 (sample blocks), EXCHANGE = all
-                                   P*rf partner slots, LEADER-SWAP = 64 x (rf-1) */
+                                   brokers of one slot (scan blocks; of TWO slots on topics of at most 24,576 replica slots --
+                                   counted as 2 B although the second slot is scanned only when a second lane takes part in
+                                   the tournament: an upper bound on small tournaments) or 64 lanes x 4 (sample blocks),
+                                   EXCHANGE = all P*rf partner slots, LEADER-SWAP = 64 x (rf-1) */
     uint64_t full_candidates;   /* complete candidates fully evaluated by K-eval */
     double ms_search;           /* HIP-event time of K-search launches (profile=1) */
     double ms_eval;             /* HIP-event time of K-eval launches (profile=1) */
@@ -317,7 +319,8 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
  * the caps (status FEASIBLE_BOUND_GAP / NO_FEASIBLE; objective = README objective without the weights);
  * *lagrangian_bound (may be NULL) = smallest Lagrangian dual value seen (an upper bound on the capped optimum when every
  * topic's priced sub-problem was proven optimal in that round, else INT64_MAX).  devices / n_dev as kao_solve_multi
- * (NULL / 0 = the current device). */
+ * (NULL / 0 = the current device).  When the `max_rounds` price rounds end without a cap-respecting plan, up to max_rounds / 2 further
+ * rounds only RAISE prices until a round in which every topic is feasible respects every cap. */
 int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *replica_cap, const int32_t *devices, int32_t n_dev,
                      const kao_opts *opts, int32_t max_rounds, kao_result *results, int64_t *lagrangian_bound);
 /* ---- KAO-CX: cyclic-exchange improvement of a feasible assignment --------------------------------
@@ -367,6 +370,13 @@ int kao_rccl_loopback_counts(uint64_t out[2]);
  * after the first (kao_session_new_generation), out[13] = KAO-CX runs from further starting points (other restarts' best
  * snapshots; included in out[9]), out[14] = KAO-LP solves that delivered multipliers, out[15] = their interior-point iterations. */
 int kao_last_solve_timing(double out[16]);
+/* K-search as THIS thread's last kao_solve ran it (only when that solve had kao_opts.profile = 1: every K-search / K-eval launch is
+ * then bracketed by HIP events on the session's stream): out[0] = HIP-event milliseconds of all K-search launches, out[1] = of all
+ * K-eval launches, out[2] = K-search launches (turns of the loop that launched none -- a huge topic while KAO-CX / KAO-LP have the GPU
+ * -- are not counted), out[3] = restarts, out[4] = algorithmic bytes of those launches (neighbours x (8 RF + 10)),
+ * out[5] = neighbours delta-evaluated, out[6] = dynamic LDS per K-search workgroup, out[7] = workgroups per launch.  All zero when
+ * the solve was not profiled. */
+int kao_last_solve_profile(double out[8]);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,8 @@ int num_cu(int device);
 int require_init();               // kao_init on first use, then hipSetDevice(cur_device())
 bool is_init();
 extern thread_local int t_device; // per-thread override: kao_solve_multi drives several devices from one process
-extern thread_local double g_timing[16];   // wall-clock breakdown of the last solve (kao_last_solve_timing)
+extern thread_local double g_timing[16];
+extern thread_local double g_profile[8];  // K-search as the last profiled kao_solve ran it (kao_last_solve_profile)   // wall-clock breakdown of the last solve (kao_last_solve_timing)
 
 // ---- the model on the host (kao_model.cpp) ----
 int validate(const kao_topic *t);

@@ -17,6 +17,7 @@ namespace kao {
 
 thread_local int t_device = -1;
 thread_local double g_timing[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_profile[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace {
 thread_local std::string g_err;
@@ -508,10 +509,14 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     }
     if (o.restarts > (1 << 20) - 2) o.restarts = (1 << 20) - 2;  // id 0xFFFFF is reserved (kExternalRestart)
     {   // huge topics: bound the per-restart state in HBM (16 B of working words + the snapshot per partition):
-        // 8 GB (of 288; 1 GB for automatic counts until round 4)
+        // at most 8 GB and at most a quarter of what the device has free right now (the constant assumed the 288 GB
+        // device with nothing beside the session; multi-GPU replicas and capped rounds hold several sessions)
         uint64_t per_restart = 0;
         for (int t = 0; t < n_topics; ++t) per_restart += (uint64_t)topics[t].n_partitions * (32 + 2 * (uint64_t)std::max(topics[t].rf, 1));
-        const uint64_t cap = (8ull << 30) / std::max<uint64_t>(per_restart, 1);
+        size_t free_b = 0, total_b = 0;
+        uint64_t budget = 8ull << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, std::max<uint64_t>(free_b / 4, 256ull << 20));
+        const uint64_t cap = budget / std::max<uint64_t>(per_restart, 1);
         if ((uint64_t)o.restarts > cap) o.restarts = (int)std::max<uint64_t>(cap / kWaves * kWaves, kWaves);
     }
     s->opts = o;

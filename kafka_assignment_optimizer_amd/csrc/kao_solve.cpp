@@ -211,8 +211,11 @@ struct SolveRun {
             int64_t slots = 1;
             for (int i = 0; i < n_topics; ++i) slots = std::max<int64_t>(slots, (int64_t)user_topics[i].n_partitions * std::max(user_topics[i].rf, 1));
             if (slots >= 32768 && !require_init()) {
+                // never more than the session's own automatic count (with many topics beside a large one the override
+                // multiplied the wavefronts per launch: 100 topics of 11,000 partitions went from 80 to 256 restarts each)
                 const int cu = std::max(num_cu(cur_device()), 1);
-                so_x.restarts = (int)std::max<int64_t>(cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves);
+                const int64_t auto_r = std::min(std::max((cu * 32 / std::max(n_topics, 1)) / kWaves * kWaves, 8), 8192);
+                so_x.restarts = (int)std::min<int64_t>(auto_r, std::max<int64_t>(cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves));
             }
         }
         n = n_topics = (int)xt.size();
@@ -724,6 +727,14 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     g_timing[9] = run.cx_calls; g_timing[10] = run.cx_gains; g_timing[11] = (double)run.iters_done; g_timing[12] = run.generations;
     g_timing[13] = run.cx_more;
     g_timing[14] = run.lp_solves; g_timing[15] = run.lp_iters;
+    for (double &q : g_profile) q = 0;
+    if (o.profile) {
+        kao_stats st{};
+        if (kao_session_stats(run.s, &st) == KAO_OK) {
+            g_profile[0] = st.ms_search; g_profile[1] = st.ms_eval; g_profile[2] = (double)st.launches; g_profile[3] = st.n_restarts_total;
+            g_profile[4] = (double)st.search_bytes_algo; g_profile[5] = (double)st.delta_candidates; g_profile[6] = st.lds_bytes_search; g_profile[7] = st.blocks_search;
+        }
+    }
     kao_session_destroy(run.s);
     run.s = nullptr;
     g_timing[3] = now_s() - t0;
@@ -1256,7 +1267,7 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
         const int rr = fine ? r - fine_from : (raise_only ? 0 : r);
         const int den = 1 + rr / 3;
         const int unit = fine ? 1 : F;
-        if (raise_only && worst <= 0) break;   // the plan just booked respects every cap
+        if (raise_only && all_feasible && worst <= 0) break;   // the plan just booked respects every cap (loads are counted over feasible topics only: ADVICE r04)
         bool moved = false;
         for (int b = 0; b < B; ++b) {
             if (replica_cap[b] < 0) continue;
@@ -1360,6 +1371,12 @@ int kao_rccl_loopback_counts(uint64_t out[2]) {
 int kao_last_solve_timing(double out[16]) {
     if (!out) return fail(KAO_ERR_INVALID, "null out");
     for (int i = 0; i < 16; ++i) out[i] = g_timing[i];
+    return KAO_OK;
+}
+
+int kao_last_solve_profile(double out[8]) {
+    if (!out) return fail(KAO_ERR_INVALID, "null out");
+    for (int i = 0; i < 8; ++i) out[i] = g_profile[i];
     return KAO_OK;
 }
 

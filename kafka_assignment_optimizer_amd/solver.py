@@ -520,3 +520,11 @@ def last_solve_timing() -> dict:
                 delta_candidates=int(out[5]), bound_launches=int(out[6]), elite_exchanges=int(out[7]), bound_iters=int(out[8]),
                 cx_calls=int(out[9]), cx_gains=int(out[10]), search_iters=int(out[11]), generations=int(out[12]), cx_further_starts=int(out[13]),
                 lp_solves=int(out[14]), lp_iters=int(out[15]))
+
+
+def last_solve_profile() -> dict:
+    """K-search as the last kao_solve ran it (kao_last_solve_profile; needs profile=1 in that solve's options)."""
+    out = (C.c_double * 8)()
+    _check(_ffi.load().kao_last_solve_profile(out), "kao_last_solve_profile")
+    return dict(ms_search=out[0], ms_eval=out[1], search_launches=int(out[2]), restarts=int(out[3]), search_bytes_algo=int(out[4]),
+                delta_candidates=int(out[5]), lds_bytes_search=int(out[6]), blocks_search=int(out[7]))
