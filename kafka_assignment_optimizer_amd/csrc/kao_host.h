@@ -89,6 +89,7 @@ struct kao_session {
     std::vector<kao_topic> topics;  // shallow copies (pointers not retained for device work)
     std::vector<int64_t> ub;
     std::vector<char> topic_global;  // per topic: runs with its assignment in global memory
+    std::vector<char> topic_curg;    // per topic: working assignment in LDS, current assignment from global memory (k_search_curg)
     std::vector<char> topic_infeasible;  // per topic: proven infeasible by counting (kao_check_infeasible)
     std::vector<char> dual_ok;           // per topic: within K-bound's limits
     std::vector<int64_t> h_dual_target;  // staging for kao_session_bound_step
@@ -106,6 +107,7 @@ struct kao_session {
         int waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
         int nw = kRFP;       // replica words per partition of the group's topics: 4 or 8 (template instantiation)
         bool global_a = false;   // topic too large for LDS: assignment + current words stay in global memory
+        bool cur_global = false; // (round 5) only the current-assignment words stay in global memory / L2, the working words are in LDS (~4,900 .. 9,800 partitions)
         int team = 0;            // > 0 (global_a only): every restart is searched by a TEAM of that many wavefronts (k_team), one workgroup per restart
         bool cur_in_lds = true;  // K-eval stages the current assignment in LDS (false: reads it from global)
         bool eval_coop = false;  // K-eval: one candidate per workgroup, wavefronts cooperating (few large candidates)

@@ -81,6 +81,7 @@ struct SearchParams {
     uint32_t gen;                // generation of the population: salts the tie-break hash of the initial state (init = 1 with gen > 0 =
                                  //     kao_solve re-initialises every restart after a population converged without a proof)
     int32_t scan2_max;           // REPLACE scan covers the tournament's TWO best slots on topics of at most this many replica slots (kScanTwoSlots)
+    int32_t cur_global;          // 1 = the launch group keeps only the working assignment in LDS (k_search_curg): the current assignment is read from global memory
     int32_t elite;               // 1 = restarts that trail their topic's best feasible objective may re-seed from it (KAO-LS
                                  //     "elite" rule)
 };
@@ -150,7 +151,8 @@ struct BoundWide {
 // per-rack LDS tables of K-search (rack sizes, K, RT): entries for `maxR` racks plus one for the padding marker, rounded to 64
 constexpr int search_rack_tab(int maxR) { return ((maxR < 1 ? 1 : maxR) + 1 + 63) & ~63; }
 // `team` > 0: the workgroup is a team of that many wavefronts on ONE restart (k_team; topics in global memory), `waves` is ignored
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4, bool bw = false, int maxR = kRackTab - 1, int team = 0);
+// cur_global: only the working assignment in LDS, the current assignment read from global memory (k_search_curg, round 5)
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4, bool bw = false, int maxR = kRackTab - 1, int team = 0, bool cur_global = false);
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne = 4);
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream, int team = 0);
 void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream);

@@ -298,6 +298,10 @@ template <int NW> __device__ __forceinline__ void snapshot(const TopicRegs &T, c
 // kGlobalA = true : they stay in global memory (HBM / L2) -- 16 B per partition per restart, updated in place --
 //                   and only the broker / rack tables live in LDS.  Same algorithm, same results; this is what
 //                   lets a single 100k-partition topic run.
+// kCurG = true  : (kGlobalA = false only; round 5) the restart's WORKING assignment words live in LDS, the topic's CURRENT-assignment
+//                   words are read from global memory (one copy per topic, shared by every restart: it sits in L2).  Holding both in LDS
+//                   costs 2 x 16 B per partition, so a restart fitted 160 KiB only up to ~4,900 partitions and 500 x 5000 ran the HBM
+//                   path at 4.8 ms a launch; with the working words alone the limit is ~9,800.  Same arithmetic: the replay holds.
 // kPriced = true : the cost of a move also carries Lagrangian PRICES of the coupling rows (K-bound's multipliers: replicas
 //                   per broker / rack, leaders per broker) -- an augmented-Lagrangian search: with near-optimal prices the
 //                   chain steps an improvement needs (objective down a little, violation unchanged) become neutral moves.
@@ -312,9 +316,10 @@ template <int NW> __device__ __forceinline__ void snapshot(const TopicRegs &T, c
 //                   moves commute, so violation and objective deltas add up.  A 30,000-partition topic gets W moves per
 //                   latency-bound iteration instead of one (the depth large topics lack), deterministically (specification:
 //                   oracle/kao_port.c::ls_run with team > 1, replayed bit for bit).
-template <bool kGlobalA, bool kPriced, int NW, bool kWide, bool kTeam>
+template <bool kGlobalA, bool kPriced, int NW, bool kWide, bool kTeam, bool kCurG = false>
 __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPools &pl, const SearchParams &prm) {
     static_assert(!kTeam || kGlobalA, "teams run topics that live in global memory");
+    static_assert(!kCurG || !kGlobalA, "kCurG: the working assignment is in LDS");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_waves = kTeam ? __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6)) : 1;   // team size W
@@ -335,23 +340,24 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
     // ---- LDS carve: [CUR uint4[maxP]]* [RSZ int[krt]] [XR u8[Bx rounded to 64]] then per wave
     //      [A uint4[maxP]]* [C u32[Bx rounded to 64]] [W u16[same]] [K int[krt]] [RT int[krt]]        (* only when !kGlobalA)
     //      krt = search_rack_tab(largest rack count of the launch group): the racks plus one entry for the padding marker
-    const int a_bytes = kGlobalA ? 0 : prm.maxP * NW * 4;
+    const int a_bytes = kGlobalA ? 0 : prm.maxP * NW * 4;              // a restart's working words (per wave)
+    const int cur_bytes = (kGlobalA || kCurG) ? 0 : prm.maxP * NW * 4;  // the topic's current-assignment words (shared by the workgroup)
     const int bx64 = (prm.maxBx + 63) & ~63;
     const int c_bytes = bx64 * 4;
     const int krt = search_rack_tab(prm.maxR);
-    int *RSZ = reinterpret_cast<int *>(smem + a_bytes);
-    uint8_t *XR = smem + a_bytes + krt * 4;  // rack of internal index x, inv = krt - 1 (never a rack) = padding slot / beyond Bx
+    int *RSZ = reinterpret_cast<int *>(smem + cur_bytes);
+    uint8_t *XR = smem + cur_bytes + krt * 4;  // rack of internal index x, inv = krt - 1 (never a rack) = padding slot / beyond Bx
     const uint32_t inv = (uint32_t)krt - 1u;
-    uint32_t *PR = reinterpret_cast<uint32_t *>(smem + a_bytes + krt * 4 + bx64);  // [bx64] packed prices (kPriced only)
+    uint32_t *PR = reinterpret_cast<uint32_t *>(smem + cur_bytes + krt * 4 + bx64);  // [bx64] packed prices (kPriced only)
     const bool hbw = kPriced && prm.bw != 0;   // the launch group carries broker weights (their table is carved only then)
     const int pr_bytes = kPriced ? (hbw ? 2 : 1) * c_bytes + krt * 4 : 0;
-    int *PG = reinterpret_cast<int *>(smem + a_bytes + krt * 4 + bx64 + c_bytes);  // [krt] rack prices (kPriced only)
-    uint32_t *BW = reinterpret_cast<uint32_t *>(smem + a_bytes + krt * 4 + bx64 + c_bytes + krt * 4);  // [bx64] broker weights (kPriced only)
+    int *PG = reinterpret_cast<int *>(smem + cur_bytes + krt * 4 + bx64 + c_bytes);  // [krt] rack prices (kPriced only)
+    uint32_t *BW = reinterpret_cast<uint32_t *>(smem + cur_bytes + krt * 4 + bx64 + c_bytes + krt * 4);  // [bx64] broker weights (kPriced only)
     // per wave: [A] [C] [W] [K] [RT]; a team shares ONE [C] [W] [K], then one [RT] per wavefront and the proposal records
-    unsigned char *wb = smem + a_bytes + krt * 4 + bx64 + pr_bytes + (kTeam ? 0 : wave * (a_bytes + c_bytes + c_bytes / 2 + krt * 8));
+    unsigned char *wb = smem + cur_bytes + krt * 4 + bx64 + pr_bytes + (kTeam ? 0 : wave * (a_bytes + c_bytes + c_bytes / 2 + krt * 8));
     const Part<NW> *cur_words = reinterpret_cast<const Part<NW> *>(pl.cur_pool + TD->cur_off);  // host-prepared words x | rack << 16 (0xFFFFFFFF = none); cur_off counts words
     const Part<NW> *CUR;
-    if (kGlobalA) CUR = cur_words; else CUR = reinterpret_cast<const Part<NW> *>(smem);
+    if (kGlobalA || kCurG) CUR = cur_words; else CUR = reinterpret_cast<const Part<NW> *>(smem);
     WaveLds<NW> L;
     L.C = reinterpret_cast<uint32_t *>(wb + a_bytes);
     L.W = reinterpret_cast<uint16_t *>(wb + a_bytes + c_bytes);
@@ -362,7 +368,7 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
     int *TS = TR + 2 * 16 * kTeamRec;
 
     // ---- stage the rack sizes / rack-of-index table (and, when it fits, the current-assignment words) ----
-    if (!kGlobalA) {
+    if (!kGlobalA && !kCurG) {
         Part<NW> *cur_lds = reinterpret_cast<Part<NW> *>(smem);
         for (int p = threadIdx.x; p < T.P; p += blockDim.x) cur_lds[p] = cur_words[p];
     }
@@ -1106,6 +1112,12 @@ __global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     search_body<kGlobalA, kPriced, NW, kWide, false>(smem, pl, prm);
 }
+// working assignment in LDS, current assignment from global memory / L2 (kCurG; ~4,900 .. 9,800 partitions: always wide)
+template <bool kPriced, int NW>
+__global__ __launch_bounds__(256) void k_search_curg(SearchPools pl, SearchParams prm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    search_body<false, kPriced, NW, true, false, true>(smem, pl, prm);
+}
 // a team of up to 8 wavefronts per restart (topics in global memory; see search_body)
 template <bool kPriced, int NW>
 __global__ __launch_bounds__(NW == 8 ? 256 : 512) void k_team(SearchPools pl, SearchParams prm) {
@@ -1439,9 +1451,9 @@ __global__ __launch_bounds__(64) void k_canon(const TopicDev *TD, const Part<NW>
 // ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw, int maxR, int team) {
+size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced, int nw, bool bw, int maxR, int team, bool cur_global) {
     const size_t a = global_a ? 0 : (size_t)maxP * 4 * (size_t)nw, bx64 = ((size_t)maxBx + 63) & ~(size_t)63, krt = (size_t)search_rack_tab(maxR);
-    const size_t shared = a + krt * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + krt * 4 : 0);
+    const size_t shared = (cur_global ? 0 : a) + krt * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + krt * 4 : 0);
     if (team > 0)   // one set of counters / band states / rack totals, one RT per wavefront, the proposal records, the partial sums
         return shared + bx64 * 6 + krt * 4 + (size_t)team * krt * 4 + 2 * 16 * kTeamRec * 4 + 16 * 2 * 4;
     return shared + (size_t)waves * (a + bx64 * 6 + krt * 8);
@@ -1473,11 +1485,21 @@ static void launch_team_t(const SearchPools &pools, const SearchParams &prm, int
 }
 
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream, int team) {
-    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw, prm.bw != 0, prm.maxR, team);
+    const bool curg = prm.cur_global != 0 && !global_a;
+    const size_t lds = search_lds_bytes(prm.maxP, prm.maxBx, waves, global_a, priced, nw, prm.bw != 0, prm.maxR, team, curg);
     // largest dynamic-LDS size each of the instantiations has been enabled for, per device
-    static int attr[kAttrDevices][20] = {{0}};
+    static int attr[kAttrDevices][24] = {{0}};
     const bool wide = prm.wide != 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (curg) {   // working assignment in LDS, current assignment from L2
+        int &ca = attr[attr_slot()][20 + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
+        const void *fn = nw == 8 ? (priced ? reinterpret_cast<const void *>(k_search_curg<true, 8>) : reinterpret_cast<const void *>(k_search_curg<false, 8>))
+                                 : (priced ? reinterpret_cast<const void *>(k_search_curg<true, 4>) : reinterpret_cast<const void *>(k_search_curg<false, 4>));
+        if ((int)lds > ca) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); ca = (int)lds; }
+        if (nw == 8) { if (priced) hipLaunchKernelGGL((k_search_curg<true, 8>), dim3(n_blocks), dim3(64 * waves), lds, st, pools, prm); else hipLaunchKernelGGL((k_search_curg<false, 8>), dim3(n_blocks), dim3(64 * waves), lds, st, pools, prm); }
+        else { if (priced) hipLaunchKernelGGL((k_search_curg<true, 4>), dim3(n_blocks), dim3(64 * waves), lds, st, pools, prm); else hipLaunchKernelGGL((k_search_curg<false, 4>), dim3(n_blocks), dim3(64 * waves), lds, st, pools, prm); }
+        return;
+    }
     if (team > 0) {   // one block per restart, `team` wavefronts each (topics in global memory only)
         int &ta = attr[attr_slot()][16 + (priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
         if (nw == 8) { if (priced) launch_team_t<true, 8>(pools, prm, n_blocks, team, lds, ta, st); else launch_team_t<false, 8>(pools, prm, n_blocks, team, lds, ta, st); }

@@ -529,6 +529,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     std::vector<uint8_t> rackof_pool;
     uint64_t state_bytes = 0, best_u16 = 0, win_u16 = 0, dual_i32 = 0, wide_slices = 0;
     s->topic_global.assign((size_t)n_topics, 0);
+    s->topic_curg.assign((size_t)n_topics, 0);
     for (int t = 0; t < n_topics; ++t) s->any_bw |= topics[t].broker_w || topics[t].broker_wl;
     int restart_base = 0;
     for (int t = 0; t < n_topics; ++t) {
@@ -561,8 +562,19 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
             cur_pool.insert(cur_pool.end(), lead.begin(), lead.end());
             cur_pool.insert(cur_pool.end(), foll.begin(), foll.end());
         }
-        const bool global_a = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw, s->any_bw, d.R) > 160 * 1024;
+        // both assignments in LDS when they fit (one wavefront per workgroup at least); else the working one alone, the current one read
+        // from global memory / L2 (round 5: ~4,900 .. 9,800 partitions; KAO_CUR_GLOBAL=0: the HBM path as before); else everything in HBM
+        const bool both_fit = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw, s->any_bw, d.R) <= 160 * 1024;
+        static const bool curg_on = [] { const char *e = std::getenv("KAO_CUR_GLOBAL"); return !(e && e[0] == '0'); }();
+        // (one workgroup of ONE wavefront per restart and compute unit: with more restarts than compute units the workgroups run in rounds
+        // and the HBM path, four wavefronts per workgroup, is the faster one -- 500 x 5000: 3.1 against 3.9 ms a launch at 256 restarts,
+        // 12.4 against 4.2 at 1,024; teams (kao_opts.team) are a global-memory mode)
+        static const bool team_env = [] { const char *e = std::getenv("KAO_TEAM"); return e && std::atoi(e) > 1; }();
+        const bool curg = !both_fit && curg_on && o.team <= 1 && !team_env && o.restarts <= std::max(num_cu(s->device), 1) &&
+                          search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw, s->any_bw, d.R, 0, true) <= 160 * 1024;
+        const bool global_a = !both_fit && !curg;
         s->topic_global[(size_t)t] = global_a;
+        s->topic_curg[(size_t)t] = curg;
         d.ext_off = (uint32_t)ext_pool.size();
         ext_pool.insert(ext_pool.end(), pt.ext_of.begin(), pt.ext_of.end());
         d.rsz_off = (uint32_t)rsz_pool.size();
@@ -604,7 +616,8 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     auto need1 = [&](int t) {  // topics kept in global memory sort last (their LDS need is tiny but they form their own groups)
         const TopicDev &d = s->pts[(size_t)t].d;
         const bool ga = s->topic_global[(size_t)t] != 0;
-        return (ga ? ((size_t)1 << 40) : 0) + (d.nw > kRFP ? ((size_t)1 << 41) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true, d.nw, s->any_bw, d.R);
+        const bool cg = s->topic_curg[(size_t)t] != 0;
+        return (ga ? ((size_t)1 << 40) : 0) + (cg ? ((size_t)1 << 39) : 0) + (d.nw > kRFP ? ((size_t)1 << 41) : 0) + search_lds_bytes(d.P, d.Bx, 1, ga, true, d.nw, s->any_bw, d.R, 0, cg);
     };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return need1(x) < need1(y); });
     std::vector<std::vector<int>> members;
@@ -612,7 +625,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
     // K-search / K-eval are instantiated per (assignment words in HBM or LDS, words per partition): a launch group must be
     // homogeneous in both, whatever the LDS sizes say -- so a change of either ALWAYS starts a group; the
     // "at most 8 groups" cap only limits the splits by LDS footprint
-    auto kind = [&](int t) { return (s->topic_global[(size_t)t] ? 1 : 0) | (s->pts[(size_t)t].d.nw > kRFP ? 2 : 0); };
+    auto kind = [&](int t) { return (s->topic_global[(size_t)t] ? 1 : 0) | (s->pts[(size_t)t].d.nw > kRFP ? 2 : 0) | (s->topic_curg[(size_t)t] ? 4 : 0); };
     int lds_groups = 0, group_kind = -1;
     for (int t : order) {
         const bool new_kind = members.empty() || kind(t) != group_kind;
@@ -638,6 +651,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
             g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B); g.maxR = std::max(g.maxR, d.R); g.wide = g.wide || (int64_t)d.P * d.RF >= 512;
         }
         g.global_a = s->topic_global[(size_t)mem[0]] != 0;
+        g.cur_global = s->topic_curg[(size_t)mem[0]] != 0;
         g.nw = s->pts[(size_t)mem[0]].d.nw;
         g.eval_coop = n_cand <= fill && g.maxP >= 1024;
         if (g.eval_coop) cpb = 1;
@@ -654,9 +668,9 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
             g.team = want <= 1 ? 0 : std::min(want, tmax);
             if (g.team > 0) g.waves = 1;   // the block map holds one workgroup per restart
         }
-        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR, g.team) > 160 * 1024) g.waves /= 2;
+        while (g.waves > 1 && search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR, g.team, g.cur_global) > 160 * 1024) g.waves /= 2;
         g.cur_in_lds = eval_lds_bytes(g.maxP, g.maxB, true, g.nw) <= 160 * 1024;
-        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR, g.team) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
+        if (search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, true, g.nw, s->any_bw, g.maxR, g.team, g.cur_global) > 160 * 1024 || eval_lds_bytes(g.maxP, g.maxB, g.cur_in_lds, g.nw) > 160 * 1024) {
             kao_session_destroy(s);
             return fail(KAO_ERR_UNSUPPORTED, "broker tables exceed 160 KiB of LDS (about 30,000 padded brokers)");
         }
@@ -805,7 +819,7 @@ int kao_session_step(kao_session *s) {
     if (prof) HIP_TRY(hipEventRecord(e[0], s->stream));
     for (const kao_session::LaunchGroup &g : s->groups) {
         sp.block_map = s->d_smap + g.smap_off;
-        prm.maxP = g.maxP; prm.maxBx = g.maxBx; prm.maxR = g.maxR; prm.wide = g.wide ? 1 : 0;
+        prm.maxP = g.maxP; prm.maxBx = g.maxBx; prm.maxR = g.maxR; prm.wide = g.wide ? 1 : 0; prm.cur_global = g.cur_global ? 1 : 0;
         launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, g.nw, s->stream, g.team);
         HIP_TRY(hipGetLastError());
     }
@@ -910,7 +924,7 @@ int kao_session_stats(kao_session *s, kao_stats *out) {
     out->eval_bytes_algo = s->eval_bytes_per_launch * s->launch;
     out->n_restarts_total = s->total_restarts;
     for (const kao_session::LaunchGroup &g : s->groups)
-        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw, s->any_bw, g.maxR, g.team));
+        out->lds_bytes_search = std::max(out->lds_bytes_search, (int32_t)search_lds_bytes(g.maxP, g.maxBx, g.waves, g.global_a, s->priced, g.nw, s->any_bw, g.maxR, g.team, g.cur_global));
     out->launch_groups = (int32_t)s->groups.size();
     out->blocks_search = s->blocks_search;
     HIP_TRY(hipMemcpy(&out->drift, s->d_drift, 4, hipMemcpyDeviceToHost));
