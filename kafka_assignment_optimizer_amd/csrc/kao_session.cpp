@@ -565,7 +565,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         // both assignments in LDS when they fit (one wavefront per workgroup at least); else the working one alone, the current one read
         // from global memory / L2 (round 5: ~4,900 .. 9,800 partitions; KAO_CUR_GLOBAL=0: the HBM path as before); else everything in HBM
         const bool both_fit = search_lds_bytes(d.P, d.Bx, 1, false, true, d.nw, s->any_bw, d.R) <= 160 * 1024;
-        static const bool curg_on = [] { const char *e = std::getenv("KAO_CUR_GLOBAL"); return !(e && e[0] == '0'); }();
+        const bool curg_on = [] { const char *e = std::getenv("KAO_CUR_GLOBAL"); return !(e && e[0] == '0'); }();   // (read per session: a test hook)
         // (one workgroup of ONE wavefront per restart and compute unit: with more restarts than compute units the workgroups run in rounds
         // and the HBM path, four wavefronts per workgroup, is the faster one -- 500 x 5000: 3.1 against 3.9 ms a launch at 256 restarts,
         // 12.4 against 4.2 at 1,024; teams (kao_opts.team) are a global-memory mode)

@@ -1165,8 +1165,11 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
 // ------------------------------------------------------------------------------------------------
 // kao_solve_capped: cluster-wide per-broker load caps, priced (Lagrangian) over independent per-topic solves
 // ------------------------------------------------------------------------------------------------
-int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *replica_cap, const int32_t *devices, int32_t n_dev,
-                     const kao_opts *opts, int32_t max_rounds, kao_result *results, int64_t *lagrangian_bound) {
+}  // extern "C"
+
+// One run of the price loop at ONE price granularity F (price units per objective unit); kao_solve_capped below runs a portfolio of them.
+static int capped_once(const kao_topic *topics, int32_t n_topics, const int32_t *replica_cap, const int32_t *devices, int32_t n_dev,
+                       const kao_opts *opts, int32_t max_rounds, kao_result *results, int64_t *lagrangian_bound, const int F) {
     const double t0 = now_s();
     if (!topics || n_topics < 1 || !replica_cap || !results) return fail(KAO_ERR_INVALID, "null argument");
     const int B = topics[0].n_brokers;
@@ -1179,15 +1182,17 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
     // Price granularity F (price units per objective unit).  Quarter units (F = 4: every role weight times 4 inside the per-topic
     // solves, prices in steps of 1/4) were tried in round 4 and tightened the Lagrangian bound of the medium golden (exact joint
     // optimum 9175: bound 9195 with whole prices, 9189 with quarters; the 12-topic case 4100 -> 4097 = exact) -- but K-search's
-    // penalty range is tuned to the README's weights 1..4, with weights 4..16 per-topic solves come back infeasible and whole
-    // rounds yield no cap-respecting plan (GPU calls 13-15).  So F = 1; the code below is written for any F.
-    const int F = 1;
+    // penalty range is tuned to the README's weights 1..4, with weights 4..16 per-topic solves came back infeasible and whole
+    // rounds yielded no cap-respecting plan (round 4, GPU calls 13-15).  Round 5: the penalty range of the per-topic solves is scaled by
+    // F as well (lam_min / lam_max times F: the ratio penalty : objective stays what K-search is tuned to) and the solves are
+    // feasible again: medium golden bound 9195 (F = 1) -> 9178 (2) -> 9176 (4) against the exact 9175, the 12-topic case 4100 -> 4097 = exact.
     const int mu_max = std::min(1023, 4 * wmax * F);   // a price above every objective weight already repels every replica
     kao_opts o{};
     if (opts) o = *opts;
     const double limit = o.time_limit_s > 0 ? o.time_limit_s : 10.0;
     const int rounds = max_rounds > 0 ? max_rounds : 40;
     if (o.max_launches <= 0) o.max_launches = 6;
+    if (F > 1) { o.lam_min = (o.lam_min > 0 ? o.lam_min : 1) * F; o.lam_max = (o.lam_max > 0 ? o.lam_max : 40) * F; }
     o.stop_at_bound = 1;
     o.target_objective = nullptr;
     std::vector<int32_t> mu((size_t)B, 0), bw((size_t)B, 0), mu_inc((size_t)B, 0);
@@ -1359,6 +1364,66 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
         if (lagrangian_bound) *lagrangian_bound = best_L;
     }
     g_timing[3] = now_s() - t0; g_timing[4] = r; (void)repairs;
+    return rc;
+}
+
+extern "C" {
+
+// A portfolio over the price granularity (round 5): quarter units give the tightest Lagrangian bound (and prices between the whole
+// units, which is where the exact joint optimum's prices often lie), half and whole units different plans -- which granularity finds
+// the best cap-respecting plan varies by instance (medium golden: plan 9169 / 9175 / 9169 with F = 4 / 2 / 1, the 12-topic case 4095 /
+// 4093 / 4097).  The runs share the time limit; the best plan and the smallest bound of all runs are returned, and the portfolio ends as
+// soon as they meet.  KAO_CAP_F=<n> (test hook): one run at that granularity.
+int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *replica_cap, const int32_t *devices, int32_t n_dev,
+                     const kao_opts *opts, int32_t max_rounds, kao_result *results, int64_t *lagrangian_bound) {
+    const double t0 = now_s();
+    if (!topics || n_topics < 1 || !replica_cap || !results) return fail(KAO_ERR_INVALID, "null argument");
+    int wmax = 1;
+    for (int i = 0; i < n_topics; ++i) for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) wmax = std::max(wmax, topics[i].w[a][b]);
+    std::vector<int> fs;
+    if (const char *e = std::getenv("KAO_CAP_F")) fs.push_back(std::max(1, std::min(8, std::atoi(e))));
+    else for (int f : {4, 2, 1}) if (wmax * f <= 255) fs.push_back(f);
+    kao_opts o{};
+    if (opts) o = *opts;
+    const double limit = o.time_limit_s > 0 ? o.time_limit_s : 10.0;
+    std::vector<std::vector<uint16_t>> buf((size_t)n_topics);
+    std::vector<kao_result> res((size_t)n_topics);
+    for (int i = 0; i < n_topics; ++i) buf[(size_t)i].assign((size_t)topics[i].n_partitions * topics[i].rf, (uint16_t)KAO_NONE);
+    int64_t best_total = -1, best_L = INT64_MAX;
+    int rc = KAO_OK;
+    double rounds_total = 0;
+    for (size_t k = 0; k < fs.size() && !rc; ++k) {
+        const double left = limit - (now_s() - t0);
+        if (k > 0 && left <= 0.05) break;
+        for (int i = 0; i < n_topics; ++i) { res[(size_t)i] = kao_result{}; res[(size_t)i].assignment = buf[(size_t)i].data(); }
+        o.time_limit_s = std::max(0.05, left / (double)(fs.size() - k));
+        int64_t L = INT64_MAX;
+        rc = capped_once(topics, n_topics, replica_cap, devices, n_dev, &o, max_rounds, res.data(), &L, fs[k]);
+        if (rc) break;
+        rounds_total += g_timing[4];
+        best_L = std::min(best_L, L);
+        int64_t total = 0;
+        bool ok = true;
+        for (int i = 0; i < n_topics; ++i) { ok = ok && res[(size_t)i].status != KAO_STATUS_NO_FEASIBLE; total += res[(size_t)i].objective; }
+        if ((ok && total > best_total) || (best_total < 0 && k + 1 == fs.size())) {
+            if (ok) best_total = total;
+            for (int i = 0; i < n_topics; ++i) {
+                uint16_t *dst = results[i].assignment;
+                results[i] = res[(size_t)i];
+                results[i].assignment = dst;
+                if (dst) std::memcpy(dst, buf[(size_t)i].data(), buf[(size_t)i].size() * 2);
+            }
+        }
+        if (best_total >= 0 && best_L != INT64_MAX && best_total >= best_L) break;
+    }
+    if (!rc) {
+        for (int i = 0; i < n_topics && best_total >= 0; ++i) {
+            results[i].status = (best_L != INT64_MAX && best_total >= best_L) ? KAO_STATUS_OPTIMAL_PROVEN : KAO_STATUS_FEASIBLE_BOUND_GAP;
+            results[i].upper_bound = best_L;
+        }
+        if (lagrangian_bound) *lagrangian_bound = best_L;
+    }
+    g_timing[3] = now_s() - t0; g_timing[4] = rounds_total;
     return rc;
 }
 

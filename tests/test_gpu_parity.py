@@ -448,10 +448,12 @@ def _oracle_topic(ko, pt):
                     rf=pt.rf, current=pt.current, weights=pt.weights, bounds_override=dict(pt.bounds_override))
 
 
-def test_topic_in_global_memory_replay_and_eval(kao, ko, kp):
-    """6000 partitions x 1000 brokers does not fit LDS even with one restart per workgroup: the kernel keeps the
-    assignment words in global memory (k_search<true>).  Same spec: bit-exact against the scalar replay; K-eval
-    on 12000 x 3 = 36000 replicas (> 32767: unpacked wave sums) bit-exact against the C evaluator."""
+def test_topic_in_global_memory_replay_and_eval(kao, ko, kp, monkeypatch):
+    """6000 partitions x 1000 brokers does not fit LDS with both assignments even with one restart per workgroup: the kernel keeps the
+    assignment words in global memory (k_search<true>; KAO_CUR_GLOBAL=0 keeps round 5's k_search_curg, which would take this size, out
+    of the way -- it has its own replay test).  Same spec: bit-exact against the scalar replay; K-eval on 12000 x 3 = 36000 replicas
+    (> 32767: unpacked wave sums) bit-exact against the C evaluator."""
+    monkeypatch.setenv("KAO_CUR_GLOBAL", "0")
     from kafka_assignment_optimizer_amd import synthetic
     pt = synthetic.make_cluster(1000, 20, 1, 6000, 3, [7, 77, 777], [(1000, 7), (1001, 17), (1002, 17)])[0]
     ot = _oracle_topic(ko, pt)
@@ -1321,8 +1323,9 @@ def test_solve_capped_matches_the_exact_joint_optimum_on_toys(kao, ko):
 def test_solve_capped_on_the_medium_golden(kao, ko):
     """Round 4: cluster-wide caps beyond toys -- 20 topics x 64 partitions on 60 brokers with 12 capped
     brokers, and 12 x 48 on 40 (tests/golden/capped_medium.json: exact joint optimum by HiGHS, make_golden_capped_medium.py).
-    The plan respects every cap and every topic's own rows and is sandwiched plan <= exact optimum <= Lagrangian bound; first
-    GPU run: 9165 / 9175 / 9195 and 4093 / 4097 / 4100 (plan / exact / bound) in 0.2 s."""
+    The plan respects every cap and every topic's own rows and is sandwiched plan <= exact optimum <= Lagrangian bound; round 4's
+    first GPU run: 9165 / 9175 / 9195 and 4093 / 4097 / 4100 (plan / exact / bound) in 0.2 s; round 5: 9175 / 9175 / 9176 in 1.5 s and
+    4097 / 4097 / 4097 in 0.7 s."""
     for c in load_golden("capped_medium.json")["cases"]:
         ots = [ko.topic_from_dict(d) for d in c["topics"]]
         cap = np.array(c["replica_cap"])
@@ -1337,5 +1340,8 @@ def test_solve_capped_on_the_medium_golden(kao, ko):
             np.add.at(load, r.assignment.reshape(-1).astype(int), 1)
         assert (load <= cap).all(), (c["seed"], load.tolist(), cap.tolist())
         assert total <= c["objective"] < c["objective_without_caps"]
-        assert lb is not None and c["objective"] <= lb <= 1.003 * c["objective"], (c["seed"], lb, c["objective"])
-        assert total >= 0.998 * c["objective"], (c["seed"], total, c["objective"])
+        # round 5 (a portfolio over the price granularity -- quarter, half, whole units -- with K-search's penalty range scaled with the
+        # weights): plan = the exact joint optimum on both cases, bound one unit above it on the first, equal (OPTIMAL_PROVEN) on the second
+        # (round 4, whole units only: 9169 / 9175 / 9195 and 4097 / 4097 / 4100)
+        assert lb is not None and c["objective"] <= lb <= c["objective"] + 1, (c["seed"], lb, c["objective"])
+        assert total == c["objective"], (c["seed"], total, c["objective"])
