@@ -168,9 +168,10 @@ struct SolveRun {
     int64_t lp_huge_slots = 131072;
     std::vector<char> lp_all;                     // per topic: every iteration is enqueued already
     bool huge(int i) const { return (int64_t)topics[i].n_partitions * topics[i].rf > lp_huge_slots; }
+    bool lp_huge_first = false;   // experiment hook KAO_LP_HUGE_FIRST=1: huge topics get their LP before anything else (the search waits for its prices)
     bool lp_possible(int i) const { return lp_on && !has_target && dual_iters > 0 && s->dual_ok[(size_t)i] && lp_state[(size_t)i] < 2; }
     bool search_paused() const {   // a huge topic between its first feasible incumbent and the end of its LP
-        for (int i = 0; i < n; ++i) if (huge(i) && lp_possible(i) && feasible(i) && !topic_done(i)) return true;
+        for (int i = 0; i < n; ++i) if (huge(i) && lp_possible(i) && (feasible(i) || (lp_huge_first && launches >= 1)) && !topic_done(i)) return true;
         return false;
     }
     int lp_on = 1, lp_per_launch = 2, lp_max_running = 2, lp_solves = 0, lp_iters = 0;
@@ -237,6 +238,7 @@ struct SolveRun {
             lp_after_small = (int)env_i("KAO_LP_AFTER", lp_after_small);
             lp_per_launch = (int)std::max<int64_t>(1, env_i("KAO_LP_PER_LAUNCH", lp_per_launch));
             lp_min_slots = env_i("KAO_LP_MIN_SLOTS", lp_min_slots);
+            lp_huge_first = env_i("KAO_LP_HUGE_FIRST", 0) != 0;
         }
         cx_on = so.use_cycles >= 0;
         { const char *e = std::getenv("KAO_CX_EAGER"); cx_eager = e && e[0] == '1'; }
@@ -345,7 +347,7 @@ struct SolveRun {
             int best = -1; int64_t best_slots = 0;
             for (int i = 0; i < n; ++i) {
                 if (lp_state[(size_t)i] != 0 || !s->dual_ok[(size_t)i] || s->topic_infeasible[(size_t)i] || (feasible(i) && objective(i) >= s->ub[(size_t)i])) continue;
-                if (huge(i)) {   // ... once KAO-CX has run the incumbent to a fixpoint (or cannot run)
+                if (huge(i) && !lp_huge_first) {   // ... once KAO-CX has run the incumbent to a fixpoint (or cannot run)
                     const bool cx_can = cx_on && cycle_supported(&topics[i]);
                     if (!feasible(i) || (cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20))) continue;
                 }

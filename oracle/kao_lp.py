@@ -244,6 +244,8 @@ def _port():
         _PORT.kao_lp_port_solve.argtypes = [C.POINTER(kp.PortTopic), C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                             C.POINTER(C.c_double)]
         _PORT.kao_lp_port_solve.restype = C.c_int
+        _PORT.kao_lp_port_solve_x.argtypes = _PORT.kao_lp_port_solve.argtypes + [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _PORT.kao_lp_port_solve_x.restype = C.c_int
     return _PORT
 
 
@@ -256,7 +258,7 @@ def port_coupling_order(t: ko.Topic, lp: CompactLP) -> np.ndarray:
     return np.concatenate([lp.rows["NF"], lp.rows["NL"], lp.rows["C6"], inter])
 
 
-def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80):
+def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80, primal: bool = False):
     """The structured iteration on the CPU.  Returns dict(status, iterations, primal, dual (README objective), y (coupling-row
     duals in the port's order), a, l, g (fixed-point multipliers), trace [(mu, pobj, dobj, pinf, dinf)])."""
     import ctypes as C
@@ -268,11 +270,18 @@ def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80):
     trace = np.zeros(5 * (maxit + 2))
     stats = np.zeros(4)
     pd = C.POINTER(C.c_double)
-    rc = _port().kao_lp_port_solve(C.byref(ct.s), tol, maxit, y.ctypes.data_as(pd), trace.ctypes.data_as(pd), stats.ctypes.data_as(pd))
+    x = np.zeros((3 * t.rf_cur + 3 * R) * t.n_partitions) if primal else None
+    xg = np.zeros(4 * B + R) if primal else None
+    rc = _port().kao_lp_port_solve_x(C.byref(ct.s), tol, maxit, y.ctypes.data_as(pd), trace.ctypes.data_as(pd), stats.ctypes.data_as(pd),
+                                     x.ctypes.data_as(pd) if primal else None, xg.ctypes.data_as(pd) if primal else None)
     it = int(stats[0])
     rack = np.asarray(t.rack_of)
     g = -y[2 * R:3 * R]
     a = -y[3 * R::2] - g[rack]
     l = -y[3 * R + 1::2]
-    return dict(status=rc, iterations=it, primal=float(stats[1]), dual=float(stats[2]), y=y, a=to_fixed(a), l=to_fixed(l), g=to_fixed(g),
-                trace=trace[:5 * (it + 1)].reshape(-1, 5))
+    out = dict(status=rc, iterations=it, primal=float(stats[1]), dual=float(stats[2]), y=y, a=to_fixed(a), l=to_fixed(l), g=to_fixed(g),
+               trace=trace[:5 * (it + 1)].reshape(-1, 5))
+    if primal:   # x[v, p]: v = 3 j + {0 f, 1 l, 2 q} for current replica j, then 3 NJ + 3 r + {0 yf, 1 yl, 2 t}; xg: zf[B] zl[B] n[B] m[B] k[R]
+        out["x"] = x.reshape(3 * t.rf_cur + 3 * R, t.n_partitions)
+        out["xg"] = xg
+    return out

@@ -425,11 +425,67 @@ static void vec_free(lp_vec *v) { free(v->z); free(v->zg); free(v->r1); free(v->
 /* Interior-point solve.  out_y[mc] = coupling-row duals (order NF[R] NL[R] C6[R] then C3[b], C4[b] interleaved),
  * trace[5 * (iterations + 1)] = (mu, pobj, dobj, pinf, dinf) per iteration (may be NULL), stats = {iterations, README
  * objective of the primal iterate, of the dual iterate, status (0 converged, 1 iteration limit, 2 Cholesky failed, 3 stalled)}. */
+/* ---- multiple centrality correctors (Gondzio): after the predictor-corrector direction, the step lengths are enlarged by `MCC_DELTA`,
+ * the complementarity products of that trial point are projected onto [MCC_BMIN, MCC_BMAX] x (sigma mu), and the difference is the
+ * right-hand side of one more solve with the same factor; the corrected direction is kept when it lengthens a step. ---- */
+#define MCC_DELTA 0.3
+#define MCC_BMIN 0.1
+#define MCC_BMAX 10.0
+static void mcc_build(size_t n, const unsigned char *pres, const unsigned char *ub, const double *uu, const double *x, const double *s, const double *v,
+                      const double *th, const double *dx, const double *ds, const double *dv, double apt, double adt, double mut,
+                      double *h, double *g, double *rxs_out, double *rwv_out) {
+    for (size_t i = 0; i < n; ++i) {
+        if (!pres[i]) { h[i] = 0; g[i] = 0; rxs_out[i] = 0; rwv_out[i] = 0; continue; }
+        double pr = (x[i] + apt * dx[i]) * (s[i] + adt * ds[i]);
+        double tg = pr < MCC_BMIN * mut ? MCC_BMIN * mut : (pr > MCC_BMAX * mut ? MCC_BMAX * mut : pr);
+        double rxs = tg - pr; if (rxs < -MCC_BMAX * mut) rxs = -MCC_BMAX * mut;
+        double rwv = 0, w = 1;
+        if (ub[i]) {
+            w = uu[i] - x[i];
+            pr = (w - apt * dx[i]) * (v[i] + adt * dv[i]);
+            tg = pr < MCC_BMIN * mut ? MCC_BMIN * mut : (pr > MCC_BMAX * mut ? MCC_BMAX * mut : pr);
+            rwv = tg - pr; if (rwv < -MCC_BMAX * mut) rwv = -MCC_BMAX * mut;
+        }
+        h[i] = -rxs / x[i] + (ub[i] ? rwv / w : 0.0);
+        g[i] = th[i] * h[i];
+        rxs_out[i] = rxs; rwv_out[i] = rwv;
+    }
+}
+/* correction direction from A^T dy (in z) and the parked right-hand sides; then the step lengths of direction + correction */
+static void mcc_finish(size_t n, const unsigned char *pres, const unsigned char *ub, const double *uu, const double *x, const double *s, const double *v,
+                       const double *th, const double *h, double *z, double *dsc, double *dvc, const double *dx, const double *ds, const double *dv,
+                       double *ap, double *ad) {
+    for (size_t i = 0; i < n; ++i) {
+        if (!pres[i]) { z[i] = 0; dsc[i] = 0; dvc[i] = 0; continue; }
+        const double dxc = th[i] * (z[i] - h[i]);
+        const double dss = (dsc[i] - s[i] * dxc) / x[i];
+        z[i] = dxc; dsc[i] = dss;
+        const double tx = dx[i] + dxc, ts = ds[i] + dss;
+        if (tx < 0) { const double a = -x[i] / tx; if (a < *ap) *ap = a; }
+        if (ts < 0) { const double a = -s[i] / ts; if (a < *ad) *ad = a; }
+        if (ub[i]) {
+            const double w = uu[i] - x[i], dvv = (dvc[i] + v[i] * dxc) / w;
+            dvc[i] = dvv;
+            const double tv = dv[i] + dvv;
+            if (tx > 0) { const double a = w / tx; if (a < *ap) *ap = a; }
+            if (tv < 0) { const double a = -v[i] / tv; if (a < *ad) *ad = a; }
+        } else dvc[i] = 0;
+    }
+}
+
+/* the same, also returning the primal iterate: out_x[(3 NJ + 3 R) * P] (variable-major: f_j l_j q_j per current replica, then yf_r yl_r t_r
+ * per rack) and out_xg[4 B + R] (zf zl n m per broker, k per rack); either may be NULL */
+int kao_lp_port_solve_x(const port_topic *t, double tol, int maxit, double *out_y, double *trace, double stats[4], double *out_x, double *out_xg);
 int kao_lp_port_solve(const port_topic *t, double tol, int maxit, double *out_y, double *trace, double stats[4]) {
+    return kao_lp_port_solve_x(t, tol, maxit, out_y, trace, stats, NULL, NULL);
+}
+int kao_lp_port_solve_x(const port_topic *t, double tol, int maxit, double *out_y, double *trace, double stats[4], double *out_x, double *out_xg) {
     lp_t *L = lp_create(t);
     const int P = L->P, R = L->R, NJ = L->NJ, mc = L->mc, GV = L->GV;
     const size_t nv = (size_t)L->NV * P;
-    lp_vec rp = vec_new(L), rd = vec_new(L), h = vec_new(L), d1 = vec_new(L), d2 = vec_new(L), tmp = vec_new(L);
+    lp_vec rp = vec_new(L), rd = vec_new(L), h = vec_new(L), d1 = vec_new(L), d2 = vec_new(L), tmp = vec_new(L), dc = vec_new(L);
+    double *dsc = (double *)zalloc(8 * nv), *dscg = (double *)zalloc(8 * (size_t)L->GV), *dvc = (double *)zalloc(8 * nv), *dvcg = (double *)zalloc(8 * (size_t)L->GV);
+    int n_mcc = 0;
     double *dsa = (double *)zalloc(8 * nv), *dsag = (double *)zalloc(8 * (size_t)GV), *dva = (double *)zalloc(8 * nv), *dvag = (double *)zalloc(8 * (size_t)GV);
     double *ds = (double *)zalloc(8 * nv), *dsg = (double *)zalloc(8 * (size_t)GV), *dv = (double *)zalloc(8 * nv), *dvg = (double *)zalloc(8 * (size_t)GV);
     int status = 1, it = 0;
@@ -598,6 +654,32 @@ int kao_lp_port_solve(const port_topic *t, double tol, int maxit, double *out_y,
                 sigma_mu = ratio * ratio * ratio * mu;
             }
         }
+        {   /* EXPERIMENT hook KAO_LP_MCC=<k>: up to k centrality correctors per iteration */
+            const char *e = getenv("KAO_LP_MCC");
+            const int kmax = e ? atoi(e) : 0;
+            for (int k = 0; k < kmax && (ap < 1.0 || ad < 1.0); ++k) {
+                const double apt = ap + MCC_DELTA < 1.0 ? ap + MCC_DELTA : 1.0, adt = ad + MCC_DELTA < 1.0 ? ad + MCC_DELTA : 1.0;
+                mcc_build(nv, L->pres, L->ub, L->uu, L->x, L->s, L->v, L->th, d2.z, ds, dv, apt, adt, sigma_mu, h.z, tmp.z, dsc, dvc);
+                mcc_build((size_t)GV, L->presg, L->ubg, L->uug, L->xg, L->sg, L->vg, L->thg, d2.zg, dsg, dvg, apt, adt, sigma_mu, h.zg, tmp.zg, dscg, dvcg);
+                lp_A(L, tmp.z, tmp.zg, dc.r1, dc.r2, dc.r7, dc.r5, dc.rc);
+                lp_solve_normal(L, dc.r1, dc.r2, dc.r7, dc.r5, dc.rc);
+                lp_AT(L, dc.r1, dc.r2, dc.r7, dc.r5, dc.rc, dc.z, dc.zg);
+                double ap2 = 1, ad2 = 1;
+                mcc_finish(nv, L->pres, L->ub, L->uu, L->x, L->s, L->v, L->th, h.z, dc.z, dsc, dvc, d2.z, ds, dv, &ap2, &ad2);
+                mcc_finish((size_t)GV, L->presg, L->ubg, L->uug, L->xg, L->sg, L->vg, L->thg, h.zg, dc.zg, dscg, dvcg, d2.zg, dsg, dvg, &ap2, &ad2);
+                if (!(ap2 >= ap + 0.01 * MCC_DELTA || ad2 >= ad + 0.01 * MCC_DELTA) || ap2 < 0.9 * ap || ad2 < 0.9 * ad) break;
+                for (size_t i = 0; i < nv; ++i) { d2.z[i] += dc.z[i]; ds[i] += dsc[i]; dv[i] += dvc[i]; }
+                for (int i = 0; i < GV; ++i) { d2.zg[i] += dc.zg[i]; dsg[i] += dscg[i]; dvg[i] += dvcg[i]; }
+                for (int p = 0; p < P; ++p) {
+                    d2.r1[p] += dc.r1[p]; d2.r2[p] += dc.r2[p];
+                    for (int r = 0; r < R; ++r) d2.r7[(size_t)r * P + p] += dc.r7[(size_t)r * P + p];
+                    for (int j = 0; j < NJ; ++j) d2.r5[(size_t)j * P + p] += dc.r5[(size_t)j * P + p];
+                }
+                for (int i = 0; i < mc; ++i) d2.rc[i] += dc.rc[i];
+                ap = ap2; ad = ad2;
+                ++n_mcc;
+            }
+        }
         if (ap < 1.0) ap *= 0.9995;
         if (ad < 1.0) ad *= 0.9995;
         for (size_t i = 0; i < nv; ++i) { if (!L->pres[i]) continue; L->x[i] += ap * d2.z[i]; L->s[i] += ad * ds[i]; if (L->ub[i]) L->v[i] += ad * dv[i]; }
@@ -611,10 +693,14 @@ int kao_lp_port_solve(const port_topic *t, double tol, int maxit, double *out_y,
     }
 done:
     if (out_y) memcpy(out_y, ylast, 8 * (size_t)mc);
+    if (out_x) memcpy(out_x, L->x, 8 * nv);
+    if (out_xg) memcpy(out_xg, L->xg, 8 * (size_t)GV);
     if (stats) { stats[0] = it; stats[1] = -plast; stats[2] = -dlast; stats[3] = status; }
     free(ylast);
     free(dsa); free(dsag); free(dva); free(dvag); free(ds); free(dsg); free(dv); free(dvg);
-    vec_free(&rp); vec_free(&rd); vec_free(&h); vec_free(&d1); vec_free(&d2); vec_free(&tmp);
+    if (getenv("KAO_LP_MCC")) fprintf(stderr, "[kao_lp_port] %d centrality correctors accepted in %d iterations\n", n_mcc, it);
+    free(dsc); free(dscg); free(dvc); free(dvcg);
+    vec_free(&rp); vec_free(&rd); vec_free(&h); vec_free(&d1); vec_free(&d2); vec_free(&tmp); vec_free(&dc);
     lp_destroy(L);
     return status;
 }
