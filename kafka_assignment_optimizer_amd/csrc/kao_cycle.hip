@@ -576,7 +576,12 @@ struct Cx {
     }
 
     // edges, closures (device); diagonals to the host
-    int build(const uint16_t *assign) {
+    // lazy (round 5; plain rounds only -- a bulk round takes the cycles of EVERY level): a layer is squared only up to its first
+    // level with a negative diagonal entry, the one cx_round takes its cycles from (drifted 500 x 5000, round 4: 5,814 squarings for 646
+    // builds, 17 % of a solve's GPU time, nine per build whether level 1 had found something or not); the matrices of the levels above
+    // stay stale and are not read (the L layer prices its compensations on the F closure only when F has NO cycle, i.e. when every F
+    // level was computed; the seeds are looked at only when no layer has a cycle).  Same candidates as the eager build.
+    int build(const uint16_t *assign, bool lazy = false) {
         const size_t nn = (size_t)q.np * q.np, slots = (size_t)q.P * q.RF;
         A.assign(assign, assign + slots);
         std::vector<int32_t> cnt((size_t)q.B * 2 + (size_t)q.R, 0);   // c[B] | l[B] | K[R]
@@ -597,20 +602,34 @@ struct Cx {
         hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[0], d_cnt, d_rack, 0, 32, d_D[0][0]);
         hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[1], d_cnt, d_rack, 1, 32, d_D[1][0]);
         const dim3 gs(q.np / 64, q.np / 64);
-        for (int v = 1; v <= kCxLevels; ++v)
-            for (int l = 0; l < 2; ++l)
-                hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[l][v - 1], d_D[l][v], d_M[l][v]);
-        CX_TRY(hipGetLastError());
         diag.assign((size_t)kCxLayers * kCxLevels * q.B, 0);
-        auto fetch_diag = [&](int l) -> int {
-            for (int v = 1; v <= kCxLevels; ++v)
-                CX_TRY(hipMemcpy2DAsync(&diag[((size_t)l * kCxLevels + (v - 1)) * q.B], 4, d_D[l][v], ((size_t)q.np + 1) * 4, 4, (size_t)q.B,
-                                        hipMemcpyDeviceToHost, stream));
+        auto fetch_level = [&](int l, int v) -> int {
+            CX_TRY(hipMemcpy2DAsync(&diag[((size_t)l * kCxLevels + (v - 1)) * q.B], 4, d_D[l][v], ((size_t)q.np + 1) * 4, 4, (size_t)q.B,
+                                    hipMemcpyDeviceToHost, stream));
             return KAO_OK;
         };
+        auto level_neg = [&](int l, int v) { const int32_t *dg = &diag[((size_t)l * kCxLevels + (v - 1)) * q.B]; for (int b = 0; b < q.B; ++b) if (dg[b] < 0) return true; return false; };
         int rc;
-        if ((rc = fetch_diag(0)) || (rc = fetch_diag(1))) return rc;
-        CX_TRY(hipStreamSynchronize(stream));
+        if (!lazy) {
+            for (int v = 1; v <= kCxLevels; ++v)
+                for (int l = 0; l < 2; ++l)
+                    hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[l][v - 1], d_D[l][v], d_M[l][v]);
+            CX_TRY(hipGetLastError());
+            for (int l = 0; l < 2; ++l) for (int v = 1; v <= kCxLevels; ++v) if ((rc = fetch_level(l, v))) return rc;
+            CX_TRY(hipStreamSynchronize(stream));
+        } else {
+            bool found[2] = {false, false};
+            for (int v = 1; v <= kCxLevels && !(found[0] && found[1]); ++v) {
+                for (int l = 0; l < 2; ++l) {
+                    if (found[l]) continue;
+                    hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[l][v - 1], d_D[l][v], d_M[l][v]);
+                    if ((rc = fetch_level(l, v))) return rc;
+                }
+                CX_TRY(hipGetLastError());
+                CX_TRY(hipStreamSynchronize(stream));
+                for (int l = 0; l < 2; ++l) if (!found[l]) found[l] = level_neg(l, v);
+            }
+        }
         // the L graph prices its compensations on the F closure: only when F has no improving cycle of its own
         int f_neg = 0;
         for (size_t i = 0; i < (size_t)kCxLevels * q.B; ++i) f_neg |= diag[i] < 0;
@@ -623,10 +642,12 @@ struct Cx {
             else hipLaunchKernelGGL((k_cx_edges_l<8, 0>), gl, bl, 0, stream, q, d_A, d_cur, d_rack, d_D[0][kCxLevels], d_DFt, f_neg, d_E[2]);
         }
         hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[2], d_cnt, d_rack, 2, 44, d_D[2][0]);   // L: no slack edges
-        for (int v = 1; v <= kCxLevels; ++v)
+        for (int v = 1; v <= kCxLevels; ++v) {
             hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[2][v - 1], d_D[2][v], d_M[2][v]);
+            if ((rc = fetch_level(2, v))) return rc;
+            if (lazy) { CX_TRY(hipStreamSynchronize(stream)); if (level_neg(2, v)) break; }
+        }
         CX_TRY(hipGetLastError());
-        if ((rc = fetch_diag(2))) return rc;
         CX_TRY(hipStreamSynchronize(stream));
         have_paths = false;
         return KAO_OK;
@@ -808,13 +829,14 @@ int cx_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int32_t s
     const CxParams &q = cx.q;
     static const bool trace = std::getenv("KAO_CX_TRACE") != nullptr;
     const double tt0 = api_now_s();
-    int rc = cx.build(assign);
-    if (rc) return rc;
-    const double tt1 = api_now_s();
-    // ---- candidates ----
     const char *bulk_env = std::getenv("KAO_CX_BULK_SLOTS");   // test hook (read every round: tests switch it)
     const int64_t bulk_slots = bulk_env && *bulk_env ? (int64_t)std::atoll(bulk_env) : kCxBulkSlots;
     const bool bulk_topic = (int64_t)q.P * q.RF > bulk_slots;
+    static const bool lazy_on = [] { const char *e = std::getenv("KAO_CX_LAZY"); return !(e && e[0] == '0'); }();   // KAO_CX_LAZY=0: every level in every build
+    int rc = cx.build(assign, lazy_on && !bulk_topic);
+    if (rc) return rc;
+    const double tt1 = api_now_s();
+    // ---- candidates ----
     auto collect = [&](bool all_levels) {   // the lowest level of every layer that has a negative diagonal entry; every such level in bulk mode
         std::vector<CxCand> cyc;
         for (int l = 0; l < kCxLayers; ++l)
