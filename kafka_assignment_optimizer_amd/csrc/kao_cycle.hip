@@ -365,6 +365,57 @@ __global__ __launch_bounds__(256) void k_cx_square(int np, const int32_t *__rest
         }
 }
 
+// The same squaring for SMALL matrices, split over the midpoints (round 5): (np / 64)^2 workgroups are 81 at 500 brokers -- a third of
+// the compute units, each walking all np midpoints behind two barriers per 16 (0.11 ms a squaring, 37 % of the GPU time of a 3-s solve of
+// 500 x 5000).  Here blockIdx.z takes a slice of the midpoints and the composite keys meet by atomicMin (the minimum does not depend on the
+// order: the same winner, the same matrices, bit for bit); k_cx_square_fin decodes them.
+__global__ __launch_bounds__(256) void k_cx_square_part(int np, int kchunk, const int32_t *__restrict__ D, uint32_t *__restrict__ keys) {
+    __shared__ int32_t sa[64][17];
+    __shared__ int32_t sb[16][64];
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    const int kbeg = blockIdx.z * kchunk, kend = min(np, kbeg + kchunk);
+    const int tr = (threadIdx.x >> 4) * 4, tc = (threadIdx.x & 15) * 4;
+    uint32_t best[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) best[a][b] = 0xFFFFFFFFu;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int r = e >> 4, kk = e & 15;
+            sa[r][kk] = D[(size_t)(i0 + r) * np + k0 + kk];
+        }
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int kk = e >> 6, c = e & 63;
+            sb[kk][c] = D[(size_t)(k0 + kk) * np + j0 + c];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = k0 + kk;
+            int bv[4];
+            for (int b = 0; b < 4; ++b) bv[b] = sb[kk][tc + b];
+            for (int a = 0; a < 4; ++a) {
+                const int av = sa[tr + a][kk] + (1 << 18);
+                const uint32_t prio = (k == i0 + tr + a) ? 0u : (uint32_t)(k + 1);
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t key = ((uint32_t)(av + bv[b]) << 12) | prio;
+                    best[a][b] = key < best[a][b] ? key : best[a][b];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) atomicMin(&keys[(size_t)(i0 + tr + a) * np + j0 + tc + b], best[a][b]);
+}
+__global__ void k_cx_square_fin(int np, const uint32_t *__restrict__ keys, int32_t *__restrict__ Dn, uint16_t *__restrict__ mid) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)np * np) return;
+    const uint32_t key = keys[e];
+    const int sum = (int)(key >> 12) - (1 << 18);
+    const uint32_t prio = key & 0xFFFu;
+    Dn[e] = sum < kCxInf ? sum : kCxInf;
+    mid[e] = (uint16_t)(prio == 0 ? (int)(e / (size_t)np) : (int)prio - 1);
+}
+
 // ---- seeds: one wavefront per partition -------------------------------------------------------------------------------
 // table[p][cfg] = (total, y) of the best completion of configuration cfg (total <= 0: none).  Configuration numbering:
 //   [0, RF-1)                                      role swap with follower slot cfg + 1
@@ -511,6 +562,7 @@ struct Cx {
     unsigned long long *d_E[kCxLayers] = {};
     int32_t *d_D[kCxLayers][kCxLevels + 1] = {};
     int32_t *d_DFt = nullptr;                      // transpose of the level-3 F closure (k_cx_edges_l)
+    uint32_t *d_sqkey = nullptr;                   // composite keys of a squaring split over the midpoints (k_cx_square_part)
     uint16_t *d_M[kCxLayers][kCxLevels + 1] = {};
     int2 *d_table = nullptr;
     uint16_t *d_cand = nullptr; int32_t *d_obj = nullptr, *d_viol = nullptr;
@@ -530,6 +582,7 @@ struct Cx {
         for (int l = 0; l < kCxLayers; ++l) {
             (void)hipFree(d_E[l]);
             for (int v = 0; v <= kCxLevels; ++v) { (void)hipFree(d_D[l][v]); (void)hipFree(d_M[l][v]); }
+        if (d_sqkey) { (void)hipFree(d_sqkey); d_sqkey = nullptr; }
         }
         if (stream) (void)hipStreamDestroy(stream);
         kao_eval_plan_destroy(plan);
@@ -576,6 +629,21 @@ struct Cx {
     }
 
     // edges, closures (device); diagonals to the host
+    // one min-plus squaring; small matrices are split over the midpoints so that the launch fills the chip (KAO_CX_SPLITK=0: never)
+    int square(const int32_t *Din, int32_t *Dout, uint16_t *Mout) {
+        const int nt = q.np / 64, tiles = nt * nt;
+        static const bool split_on = [] { const char *e = std::getenv("KAO_CX_SPLITK"); return !(e && e[0] == '0'); }();
+        int ks = split_on && tiles < 200 ? std::min(8, std::max(2, (512 + tiles - 1) / tiles)) : 1;
+        const int kchunk = ((q.np + ks - 1) / ks + 15) / 16 * 16;
+        ks = (q.np + kchunk - 1) / kchunk;
+        if (ks <= 1) { hipLaunchKernelGGL(k_cx_square, dim3(nt, nt), dim3(256), 0, stream, q.np, Din, Dout, Mout); return KAO_OK; }
+        const size_t nn = (size_t)q.np * q.np;
+        if (!d_sqkey) CX_TRY(hipMalloc(reinterpret_cast<void **>(&d_sqkey), nn * 4));
+        CX_TRY(hipMemsetAsync(d_sqkey, 0xFF, nn * 4, stream));
+        hipLaunchKernelGGL(k_cx_square_part, dim3(nt, nt, ks), dim3(256), 0, stream, q.np, kchunk, Din, d_sqkey);
+        hipLaunchKernelGGL(k_cx_square_fin, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, stream, q.np, d_sqkey, Dout, Mout);
+        return KAO_OK;
+    }
     // lazy (round 5; plain rounds only -- a bulk round takes the cycles of EVERY level): a layer is squared only up to its first
     // level with a negative diagonal entry, the one cx_round takes its cycles from (drifted 500 x 5000, round 4: 5,814 squarings for 646
     // builds, 17 % of a solve's GPU time, nine per build whether level 1 had found something or not); the matrices of the levels above
@@ -613,7 +681,7 @@ struct Cx {
         if (!lazy) {
             for (int v = 1; v <= kCxLevels; ++v)
                 for (int l = 0; l < 2; ++l)
-                    hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[l][v - 1], d_D[l][v], d_M[l][v]);
+                    if ((rc = square(d_D[l][v - 1], d_D[l][v], d_M[l][v]))) return rc;
             CX_TRY(hipGetLastError());
             for (int l = 0; l < 2; ++l) for (int v = 1; v <= kCxLevels; ++v) if ((rc = fetch_level(l, v))) return rc;
             CX_TRY(hipStreamSynchronize(stream));
@@ -622,7 +690,7 @@ struct Cx {
             for (int v = 1; v <= kCxLevels && !(found[0] && found[1]); ++v) {
                 for (int l = 0; l < 2; ++l) {
                     if (found[l]) continue;
-                    hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[l][v - 1], d_D[l][v], d_M[l][v]);
+                    if ((rc = square(d_D[l][v - 1], d_D[l][v], d_M[l][v]))) return rc;
                     if ((rc = fetch_level(l, v))) return rc;
                 }
                 CX_TRY(hipGetLastError());
@@ -643,7 +711,7 @@ struct Cx {
         }
         hipLaunchKernelGGL(k_cx_dist0, g0, dim3(256), 0, stream, q, d_E[2], d_cnt, d_rack, 2, 44, d_D[2][0]);   // L: no slack edges
         for (int v = 1; v <= kCxLevels; ++v) {
-            hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, stream, q.np, d_D[2][v - 1], d_D[2][v], d_M[2][v]);
+            if ((rc = square(d_D[2][v - 1], d_D[2][v], d_M[2][v]))) return rc;
             if ((rc = fetch_level(2, v))) return rc;
             if (lazy) { CX_TRY(hipStreamSynchronize(stream)); if (level_neg(2, v)) break; }
         }
@@ -1084,7 +1152,7 @@ int cx_pairs_round(Cx &cx, uint16_t *assign, int32_t base, int32_t *new_obj, int
     CX_TRY(hipMemcpyAsync(cx.d_D[0][0], D0.data(), nn * 4, hipMemcpyHostToDevice, cx.stream));
     const dim3 gs(q.np / 64, q.np / 64);
     for (int v = 1; v <= kCxLevels; ++v)
-        hipLaunchKernelGGL(k_cx_square, gs, dim3(256), 0, cx.stream, q.np, cx.d_D[0][v - 1], cx.d_D[0][v], cx.d_M[0][v]);
+        if ((rc = cx.square(cx.d_D[0][v - 1], cx.d_D[0][v], cx.d_M[0][v]))) return rc;
     CX_TRY(hipGetLastError());
     std::vector<int32_t> dg((size_t)kCxLevels * q.B);
     for (int v = 1; v <= kCxLevels; ++v)

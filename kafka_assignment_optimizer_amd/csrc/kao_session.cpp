@@ -506,6 +506,19 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         const int floor_r = slots >= 32768 ? 4 * g_num_cu : g_num_cu;
         const int cap = (int)std::max<int64_t>(floor_r, (((int64_t)1 << 22) / slots) / kWaves * kWaves);
         o.restarts = std::min(o.restarts, cap);
+        // a single topic whose WORKING assignment alone fits LDS (k_search_curg, ~4,900 .. 9,800 partitions): one wavefront per workgroup
+        // and compute unit, so a count a little above the compute units (2^22 / slots = 276 at 5,000 partitions) would pay a whole second
+        // round of workgroups for 20 restarts
+        if (n_topics == 1 && o.restarts > g_num_cu && o.restarts <= g_num_cu + g_num_cu / 4 && o.team <= 1) {
+            const kao_topic &t0 = topics[0];
+            std::vector<int> rs((size_t)std::max(t0.n_racks, 1), 0);
+            for (int b = 0; b < t0.n_brokers; ++b) if (t0.rack_of[b] < rs.size()) rs[t0.rack_of[b]]++;
+            const int bx = *std::max_element(rs.begin(), rs.end()) * t0.n_racks, nw0 = (t0.rf > kRFP || t0.rf_cur > kRFP) ? 2 * kRFP : kRFP;
+            const bool hbw = t0.broker_w || t0.broker_wl;
+            if (search_lds_bytes(t0.n_partitions, bx, 1, false, true, nw0, hbw, t0.n_racks) > 160 * 1024 &&
+                search_lds_bytes(t0.n_partitions, bx, 1, false, true, nw0, hbw, t0.n_racks, 0, true) <= 160 * 1024)
+                o.restarts = g_num_cu / kWaves * kWaves;
+        }
     }
     if (o.restarts > (1 << 20) - 2) o.restarts = (1 << 20) - 2;  // id 0xFFFFF is reserved (kExternalRestart)
     {   // huge topics: bound the per-restart state in HBM (16 B of working words + the snapshot per partition):

@@ -1,19 +1,11 @@
 #!/bin/bash
-# round 5, call 20 ("final"): whole GPU suite, smoke, bench with extras, tools/profile.sh r05_z (kernel trace + PMC passes of the bench), KAO-LP and a 3-s solve under rocprofv3
+# round 5, call 23: min-plus squarings of small matrices split over the midpoints (atomicMin of the composite keys): parity tests, family, kernel trace of a 500 x 5000 solve
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r05_z
-(time timeout 1500 python -m pytest tests -m gpu -q) > gpurun_out/${T}_pytest.log 2>&1
-tail -6 gpurun_out/${T}_pytest.log | cut -c1-300
-(timeout 300 python -c "import __graft_entry__ as g; g.smoke()") > gpurun_out/${T}_smoke.log 2>&1
-tail -2 gpurun_out/${T}_smoke.log | cut -c1-300
-(time timeout 600 python bench.py) > gpurun_out/${T}_bench.log 2> gpurun_out/${T}_bench.err
-tail -1 gpurun_out/${T}_bench.log > gpurun_out/${T}_bench.json
-python -c "
-import json; d=json.load(open('gpurun_out/r05_z_bench.json')); print({k:d[k] for k in ('value','ms_per_step','time_to_optimal_s')}); print(d['roofline']['frac'], d['roofline']['avg_launch_ms'], d.get('roofline_valu_issue',{}).get('frac'))"
-(timeout 900 bash tools/profile.sh r05_z 10) > gpurun_out/${T}_profile.log 2>&1
-tail -40 gpurun_out/${T}_profile.log | cut -c1-220
-(timeout 200 bash tools/profile_lp.sh r05_z_30k 1000 20 30000) > gpurun_out/${T}_prof_lp.log 2>&1
-tail -27 gpurun_out/${T}_prof_lp.log | head -10 | cut -c1-200
-(timeout 200 bash tools/profile_solve.sh r05_z_1000x30000 1000 20 30000 3) > gpurun_out/${T}_prof_solve.log 2>&1
-tail -18 gpurun_out/${T}_prof_solve.log | cut -c1-200
+T=r05_c23
+(time timeout 900 python -m pytest tests/test_gpu_cycle.py tests/test_gpu_parity.py -q -x -k "cycle or oracle or bulk or cx or kao_cx or deterministic or fixpoint or working_words") > gpurun_out/${T}_pytest.log 2>&1
+tail -3 gpurun_out/${T}_pytest.log | cut -c1-300
+(time R3_SCHEDS=0 R3_SEEDS=3,4,5 timeout 900 python tools/r3_probe.py family 3) > gpurun_out/${T}_family.log 2>&1
+grep "proven\|real" gpurun_out/${T}_family.log | cut -c1-250
+(timeout 200 bash tools/profile_solve.sh r05_c23_500x5000 500 10 5000 3) > gpurun_out/${T}_prof_solve.log 2>&1
+head -12 gpurun_out/prof_solve_r05_c23_500x5000/summary.txt | cut -c1-200
