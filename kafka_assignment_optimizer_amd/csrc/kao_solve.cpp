@@ -205,18 +205,26 @@ struct SolveRun {
             so_x.restarts = std::max((r / k) / kWaves * kWaves, 2 * kWaves);
         }
         if (k == 1 && so.restarts <= 0 && user_topics) {
-            // Topics that live in HBM: a session on its own fills the chip with 4 restarts per compute unit (kao_session_create), the
-            // solve keeps one per compute unit -- beside K-bound and KAO-CX depth pays, breadth does not (3-s solves, seeds 3 / 4,
-            // 256 against 1024 restarts: 1000 x 30000 231,530 / 231,522 against 231,511 / 231,522; 1000 x 100,000 with the K-bound
-            // back-off 782,227 / 782,261 against 782,118 / 782,079; profiles/r04_f_large_topic_restarts.txt)
+            // Topics that live in HBM (not even the working assignment of one restart fits LDS): a session on its own fills the chip with 4
+            // restarts per compute unit (kao_session_create); the solve keeps TWO per compute unit.  Round 4 kept one -- beside K-bound depth
+            // paid, breadth did not (256 against 1024 restarts: 1000 x 30000 231,530 / 231,522 against 231,511 / 231,522) -- but since round 5
+            // K-bound retires as soon as KAO-LP has certified the topic, and a launch of 512 restarts takes hardly longer than one of 256
+            // (1000 x 30000, 4 s, seeds 3 / 4 / 5: 231,527 / 231,516 / 231,532 PROVEN with 512; 231,522 / 231,516 / 231,518 with 256; 231,511 /
+            // 231,516 / 231,518 with 1,024; 500 x 10000: 76,351 / 76,352 / 76,354 proven against 76,345 / 76,352 / 76,351; GPU call 24).
             int64_t slots = 1;
-            for (int i = 0; i < n_topics; ++i) slots = std::max<int64_t>(slots, (int64_t)user_topics[i].n_partitions * std::max(user_topics[i].rf, 1));
-            if (slots >= 32768 && !require_init()) {
+            bool hbm = false;
+            for (int i = 0; i < n_topics; ++i) {
+                const kao_topic &t = user_topics[i];
+                slots = std::max<int64_t>(slots, (int64_t)t.n_partitions * std::max(t.rf, 1));
+                const int nw = (t.rf > kRFP || t.rf_cur > kRFP) ? 2 * kRFP : kRFP;
+                hbm = hbm || (int64_t)t.n_partitions * nw * 4 + 8 * 1024 > 160 * 1024;
+            }
+            if (hbm && !require_init()) {
                 // never more than the session's own automatic count (with many topics beside a large one the override
                 // multiplied the wavefronts per launch: 100 topics of 11,000 partitions went from 80 to 256 restarts each)
                 const int cu = std::max(num_cu(cur_device()), 1);
                 const int64_t auto_r = std::min(std::max((cu * 32 / std::max(n_topics, 1)) / kWaves * kWaves, 8), 8192);
-                so_x.restarts = (int)std::min<int64_t>(auto_r, std::max<int64_t>(cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves));
+                so_x.restarts = (int)std::min<int64_t>(auto_r, std::max<int64_t>(2 * cu, (((int64_t)1 << 22) / slots) / kWaves * kWaves));
             }
         }
         n = n_topics = (int)xt.size();

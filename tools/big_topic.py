@@ -27,7 +27,8 @@ if __name__ == "__main__":
         budget = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0
         kao.solve([t], seed=1, max_launches=1)          # arenas, code objects
         t0 = time.perf_counter()
-        r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=budget)[0]
+        extra = {"restarts": int(os.environ["RESTARTS"])} if os.environ.get("RESTARTS") else {}
+        r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=budget, **extra)[0]
         tm = kao.last_solve_timing()
         print(json.dumps({"workload": which, "status": str(r.status), "objective": int(r.objective), "certificate": int(r.upper_bound),
                           "seconds": time.perf_counter() - t0, "timing": tm}))

@@ -1,11 +1,10 @@
 #!/bin/bash
-# round 5, call 23: min-plus squarings of small matrices split over the midpoints (atomicMin of the composite keys): parity tests, family, kernel trace of a 500 x 5000 solve
+# round 5, call 25: two restarts per compute unit on HBM topics as kao_solve's default: scale rows, drifted north-star topic, the tests that touch it
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r05_c23
-(time timeout 900 python -m pytest tests/test_gpu_cycle.py tests/test_gpu_parity.py -q -x -k "cycle or oracle or bulk or cx or kao_cx or deterministic or fixpoint or working_words") > gpurun_out/${T}_pytest.log 2>&1
+T=r05_c25
+(SEEDS=1,2,3,4,5 BUDGET=4 timeout 600 python tools/r5_solve_probe.py 1000x20x30000 500x10x10000) > gpurun_out/${T}_solve.log 2>&1
+cut -c1-215 gpurun_out/${T}_solve.log
+for B in 1 3; do (timeout 300 python tools/big_topic.py solve drift100k $B) 2>&1 | grep workload | cut -c1-330; done
+(time timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "north_star or config5 or deterministic or large_topic or global_memory") > gpurun_out/${T}_pytest.log 2>&1
 tail -3 gpurun_out/${T}_pytest.log | cut -c1-300
-(time R3_SCHEDS=0 R3_SEEDS=3,4,5 timeout 900 python tools/r3_probe.py family 3) > gpurun_out/${T}_family.log 2>&1
-grep "proven\|real" gpurun_out/${T}_family.log | cut -c1-250
-(timeout 200 bash tools/profile_solve.sh r05_c23_500x5000 500 10 5000 3) > gpurun_out/${T}_prof_solve.log 2>&1
-head -12 gpurun_out/prof_solve_r05_c23_500x5000/summary.txt | cut -c1-200

@@ -12,7 +12,8 @@ for B, R, P in shapes:
     t = sy.drift(sy.make_cluster(B, R, 1, P, 3, [], []), 0.2, int(os.environ.get("DSEED", "1")))[0]
     for seed in seeds:
         t0 = time.perf_counter()
-        r = kao.solve([t], seed=seed, stop_at_bound=1, time_limit_s=budget)[0]
+        extra = {"restarts": int(os.environ["RESTARTS"])} if os.environ.get("RESTARTS") else {}
+        r = kao.solve([t], seed=seed, stop_at_bound=1, time_limit_s=budget, **extra)[0]
         dt = time.perf_counter() - t0
         tm = kao.last_solve_timing()
         print(f"{B}x{P} seed {seed}: {r.status} objective {r.objective} certificate {r.upper_bound} gap {r.upper_bound - r.objective} t_best {tm['time_to_best']:.3f}s total {dt:.3f}s "
