@@ -907,8 +907,31 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
                             }
                         }
                     }
-                    for (; base < cend; base += 64, ++rd)
-                        bestc = min(bestc, is_weighted((cb >> 6) + rd) ? scan_round(std::true_type{}, base, rd) : scan_round(std::false_type{}, base, rd));
+                    if (kWide || kTeam) {
+                        for (; base < cend; base += 64, ++rd)
+                            bestc = min(bestc, is_weighted((cb >> 6) + rd) ? scan_round(std::true_type{}, base, rd) : scan_round(std::false_type{}, base, rd));
+                    } else {
+                        // Round 5: the rounds between two weighted ones run in a loop of their own.  Asking every round
+                        // "is it one of the NW weighted ones" was 11 of its 22 scalar instructions -- and the two-way
+                        // body cost two register copies of the generator state and an address add per round on top of
+                        // the 12 vector instructions a candidate round needs.  Same rounds, same order, same draws.
+                        const int n_rd = (cend - cb + 63) >> 6, rd0 = cb >> 6;
+                        while (rd < n_rd) {
+                            int nxt = n_rd;   // the next weighted round of this chunk at or after rd
+#pragma unroll
+                            for (int i2 = 0; i2 < NW; ++i2) {
+                                const int m = mr[i2] - rd0;
+                                if (m >= rd) nxt = min(nxt, m);
+                            }
+                            for (; rd + 1 < nxt; rd += 2, base += 128) {   // two rounds share the address arithmetic and one v_min3_u32
+                                const uint32_t k0 = scan_round(std::false_type{}, base, rd);
+                                const uint32_t k1 = scan_round(std::false_type{}, base + 64, rd + 1);
+                                bestc = min(bestc, min(k0, k1));
+                            }
+                            if (rd < nxt) { bestc = min(bestc, scan_round(std::false_type{}, base, rd)); ++rd; base += 64; }
+                            if (rd < n_rd) { bestc = min(bestc, scan_round(std::true_type{}, base, rd)); ++rd; base += 64; }
+                        }
+                    }
                     if ((bestc >> 8) < (bestA >> 8)) { bestA = bestc; chunkA = cb; }   // strict: ties stay with the earlier round
                 }
                 if (!kTeam && holds) L.W[ai & 0xFFFFu] = (uint16_t)w_keep;
@@ -1107,8 +1130,15 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
     }
 }
 
+#ifndef KAO_WPE_SMALL
+#define KAO_WPE_SMALL 6
+#endif
+#ifndef KAO_WPE_WIDE
+#define KAO_WPE_WIDE 6
+#endif
+template <bool kGlobalA, bool kPriced, int NW, bool kWide> constexpr int search_min_waves() { return kGlobalA ? 1 : (kWide ? KAO_WPE_WIDE : KAO_WPE_SMALL); }
 template <bool kGlobalA, bool kPriced, int NW, bool kWide>
-__global__ __launch_bounds__(256) void k_search(SearchPools pl, SearchParams prm) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(search_min_waves<kGlobalA, kPriced, NW, kWide>(), 8))) void k_search(SearchPools pl, SearchParams prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     search_body<kGlobalA, kPriced, NW, kWide, false>(smem, pl, prm);
 }
