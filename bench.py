@@ -590,7 +590,12 @@ def main():
                                       "valu_insts_per_neighbour": valu / max(1.0, d_delta / max(1, launches)),
                                       "note": "SQ_INSTS_VALU per launch from " + prof["source"] + "; peak: " + prof.get("valu_issue_peak_note", "")
                                               + ".  The peak is the fastest instruction class the microbench measured at the clock it "
-                                              "measured, not a datasheet figure; frac is not capped.  Only fewer instructions make this kernel faster"}
+                                              "measured, not a datasheet figure; frac is not capped.  Until round 5 the kernel held 97 VGPRs = 4 wavefronts per "
+                                              "SIMD and was bound by latency, not by issue (3.7 % fewer VALU instructions changed nothing, "
+                                              "profiles/r05_c28_scan_loop_ab.txt); with the register allocator held to 6 wavefronts per SIMD "
+                                              "(amdgpu_waves_per_eu, 17-20 VGPRs spilled outside the loop) the same instruction stream runs "
+                                              "11 % faster and fewer instructions pay again (profiles/r05_c29 / c30 / c31)",
+                                      "occupancy": {"waves_per_simd": 6, "vgprs": 80}}
         if "k_search_lds_insts_per_launch" in prof:
             lds_b = prof["k_search_lds_insts_per_launch"] * 64 * prof.get("lds_bytes_per_lane_avg", 4)
             out["roofline_lds"] = {"kernel": "k_search", "bound": "lds", "achieved": lds_b / (avg_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS,
