@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KAO_VERSION 102 /* 0.1.2: kao_lp_bound, kao_session_set_dual_state (KAO-LP, round 5) */
+#define KAO_VERSION 103 /* 0.1.3: kao_lp_round (KAO-LP's primal side); 0.1.2: kao_lp_bound, kao_session_set_dual_state (KAO-LP, round 5) */
 #define KAO_NONE 0xFFFFu /* "no broker": replica on a broker outside the target set / empty slot */
 #define KAO_MAX_RF 8     /* replica slots per partition supported by the gfx950 kernels (RF <= 4: one 128-bit word group per
                             partition; 5..8: two) */
@@ -285,6 +285,21 @@ int kao_lp_bound(const kao_topic *t, double tol, int32_t max_iters, int64_t *bou
  * room for max_iters + 2 iterates; stats and multipliers as kao_lp_bound (any may be NULL).  The parity tests hold the trace against
  * oracle/kao_lp_port.c's. */
 int kao_lp_trace(const kao_topic *t, double tol, int32_t max_iters, double *trace, double stats[8], int32_t *multipliers);
+/* KAO-LP, the primal side (round 5): an assignment from the LP relaxation.  lp_solve returns the optimum of the generated model
+ * (README.md:135-136); on every topic measured the model's LP (README.md:144-185, all rows relaxed to [0, 1]) has INTEGRAL optimal
+ * vertices that attain it -- but its optimal face is huge (ties everywhere) and an interior-point iterate ends at the face's
+ * analytic centre, fractional in most partitions.  kao_lp_round perturbs the costs by pert * h(variable, salt), h in [0, 1) a
+ * hash, which leaves (generically) one optimal vertex; the iterate converges to it, is rounded on the host (new replicas of a rack
+ * handed to that rack's brokers by their inflows; specification oracle/kao_lp.py round_primal) and evaluated exactly by K-eval.
+ * assignment [P*rf] (dense broker indices, leader first) is overwritten: on entry it may hold a FALLBACK -- the rows that partitions
+ * with fractional variables keep (use_fallback != 0; e.g. an incumbent) --, otherwise such partitions take their heaviest options.
+ * The result can violate band rows when partitions were fractional: violations[8] as kao_evaluate (violations[0] = total).
+ * pert <= 0: min(1e-2, 100 / (P * rf)); tol <= 0: 1e-8; max_iters <= 0: 150.  stats (may be NULL): [0] interior-point iterations,
+ * [1] status (0 converged / 1 iteration limit / 3 stalled), [2] fractional partitions, [3] replicas placed beyond a broker's
+ * inflow, [4] rows taken from the fallback, [5] milliseconds of the interior-point solve, [6] milliseconds of the rounding,
+ * [7] the perturbation used.  An optimality proof needs kao_lp_bound's certificate beside it (objective == bound). */
+int kao_lp_round(const kao_topic *t, double pert, uint32_t salt, double tol, int32_t max_iters, int32_t use_fallback, uint16_t *assignment,
+                 int64_t *objective, int32_t violations[8], double stats[8]);
 /* One-shot K-bound on one topic: `launches` launches of `iters` iterations towards `target`.
  * *bound = floor(best dual / 65536) (not combined with kao_upper_bound); multipliers, if not NULL, receives
  * a[n_brokers], l[n_brokers], g[n_racks]. */

@@ -182,15 +182,20 @@ void launch_canon(const TopicDev *topic, const uint32_t *cur_words, const uint16
 struct LpCtx;
 int lp_open(const kao_topic *t, LpCtx **out);
 // multipliers (host): a[B] l[B] g[R] in K-bound's fixed point; stats[8], trace: see kao_lp.hip
-int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace);   // one shot
+int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace, double pert = 0.0, uint32_t salt = 0);   // one shot
 // incremental (kao_solve runs the iterations beside K-search): begin, enqueue k iterations (asynchronous, no host round trip inside),
 // poll (waits; *status 0 = running, 1 converged, 2 iteration limit, 3 stalled), finish (multipliers of the last finite iterate)
-int lp_begin(LpCtx *c, double tol, int maxit);
+int lp_begin(LpCtx *c, double tol, int maxit, double pert = 0.0, uint32_t salt = 0);   // pert > 0: costs + pert * hash(variable, salt) (the primal side)
 int lp_enqueue(LpCtx *c, int k);
 int lp_poll(LpCtx *c, int *status, int *iterations);
 int lp_enqueue_mark(LpCtx *c, int k, int slot);                      // enqueue + a mark (ring slot 0..31) that lp_poll_mark waits for
 int lp_poll_mark(LpCtx *c, int slot, int *status, int *iterations);
 int lp_finish(LpCtx *c, int32_t *multipliers, double stats[8], double *trace);
+inline double lp_default_pert(const kao_topic *t) { const double e = 100.0 / ((double)t->n_partitions * t->rf); return e < 1e-2 ? e : 1e-2; }   // oracle/kao_lp.py default_pert
+int lp_primal(LpCtx *c, uint8_t *q, int32_t *zq);   // quantised primal iterate: q[(2 rf_cur + 2 R) * P] centi-units, zq[2 B] inflows (host memory)
+// q / zq -> an assignment (kao_round.cpp; specification oracle/kao_lp.py round_primal).  fallback (dense indices, may be null): the rows
+// fractional partitions keep.  rep[4] = {fractional partitions, over-inflow placements, unplaced, rows taken from fallback}
+int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq, const uint16_t *fallback, uint16_t *out, int32_t rep[4]);
 void lp_abort(LpCtx *c);   // stop flag up from the host: enqueued iterations turn into no-ops
 void lp_close(LpCtx *c);
 

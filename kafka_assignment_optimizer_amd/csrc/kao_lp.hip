@@ -57,7 +57,8 @@ struct LpDev {
 // Device-resident scalars.  The kernels of an iteration read the step lengths, sigma mu and the stop flag from here, so any number
 // of iterations can be enqueued without the host looking; once the stop flag is set every later kernel returns at its first line.
 enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (non-finite iterate) */, SC_IT, SC_AP, SC_AD, SC_SIGMU, SC_MU, SC_POBJ, SC_DOBJ,
-             SC_PINF, SC_DINF, SC_PLAST, SC_DLAST, SC_HAVE_LAST, SC_KEEP /* this iterate is finite: copy its duals */, SC_TOL, SC_MAXIT, SC_NVU /* variables + bounded variables */, SC_NB, SC_NCN, kScN = 24 };
+             SC_PINF, SC_DINF, SC_PLAST, SC_DLAST, SC_HAVE_LAST, SC_KEEP /* this iterate is finite: copy its duals */, SC_TOL, SC_MAXIT, SC_NVU /* variables + bounded variables */, SC_NB, SC_NCN,
+             SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT, kScN = 24 };
 #define LP_STOPPED(D) ((D).sc[SC_STOP] != 0.0)
 
 // variable numbering inside a partition (SoA: element (v, p) at v*P + p) and among the global variables
@@ -86,11 +87,25 @@ __device__ __forceinline__ bool var_present(const LpDev &D, int v, int p) {
 __device__ __forceinline__ double var_ub(const LpDev &D, int v) {   // 0 = none
     return (v >= 3 * D.NJ && (v - 3 * D.NJ) % 3 == 2) ? (double)D.t_ub : 0.0;
 }
-__device__ __forceinline__ double var_cost(const LpDev &D, int v, int p) {
-    if (v >= 3 * D.NJ) return 0.0;
-    const int k = v % 3;
-    return k == 2 ? 0.0 : D.c[(size_t)(2 * (v / 3) + k) * D.P + p];
+// Cost perturbation (the primal side, round 5; oracle/kao_lp_port.c pert_hash): eps * h(i) on every present variable, h in [0, 1) a
+// hash of the variable's index (v * P + p; 0x80000000 + g for the global ones) and a salt.  eps and salt live with the other scalars, so
+// the captured iteration graph serves both the model's own LP (eps = 0) and the perturbed one.
+__device__ __forceinline__ double pert_hash(uint32_t i, uint32_t salt) {
+    uint32_t h = (i ^ salt) * 0x9E3779B1u + 0x85EBCA6Bu;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (double)(h >> 8) / 16777216.0;
 }
+__device__ __forceinline__ double pert_term(const LpDev &D, uint32_t i) {
+    const double eps = D.sc[SC_PERT];
+    return eps > 0.0 ? eps * pert_hash(i, (uint32_t)D.sc[SC_SALT]) : 0.0;
+}
+__device__ __forceinline__ double var_cost(const LpDev &D, int v, int p) {   // of a PRESENT variable
+    const double pt = pert_term(D, (uint32_t)((size_t)v * D.P + p));
+    if (v >= 3 * D.NJ) return pt;
+    const int k = v % 3;
+    return (k == 2 ? 0.0 : D.c[(size_t)(2 * (v / 3) + k) * D.P + p]) + pt;
+}
+__device__ __forceinline__ double gvar_cost(const LpDev &D, int g) { return D.cg[g] + pert_term(D, 0x80000000u + (uint32_t)g); }   // of a present one
 __device__ __forceinline__ bool gvar_present(const LpDev &D, int g) {
     if (g < 2 * D.B) return true;
     if (g < 3 * D.B) return D.has_n;
@@ -779,7 +794,7 @@ __global__ void k_lp_start(LpDev D, RowVec y, double *x, double *xg, double *s, 
         double xx = xg[g] > 1.0 ? xg[g] : 1.0;
         if (u > 0) { const double cap = u * 0.5 > 1e-2 ? u * 0.5 : 1e-2; if (xx > cap) xx = cap; }
         xg[g] = xx;
-        const double ss = D.cg[g] - at_val_g(D, g, y.rc);
+        const double ss = gvar_cost(D, g) - at_val_g(D, g, y.rc);
         sg[g] = ss > 1.0 ? ss : 1.0;
         vg[g] = u > 0 ? 1.0 : 0.0;
     }
@@ -789,7 +804,7 @@ __global__ void k_lp_cost(LpDev D, double *z, double *zg) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nv = (size_t)D.NV * D.P;
     if (i < nv) z[i] = var_present(D, (int)(i / D.P), (int)(i % D.P)) ? var_cost(D, (int)(i / D.P), (int)(i % D.P)) : 0.0;
-    else if (i < nv + D.GV) zg[i - nv] = D.cg[i - nv];
+    else if (i < nv + D.GV) zg[i - nv] = gvar_present(D, (int)(i - nv)) ? gvar_cost(D, (int)(i - nv)) : 0.0;
 }
 // dual residual rd = c - A^T y - s + v and the sums {|rd|^2, x.s + w.v, c.x, u.v}; one record per block
 __global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVec s, VarVec v, RowVec y, VarVec rd, double *rec) {
@@ -808,7 +823,7 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVe
     } else if (i < nv + D.GV) {
         const int g = (int)(i - nv);
         if (gvar_present(D, g)) {
-            const double u = gvar_ub(D, g), c = D.cg[g];
+            const double u = gvar_ub(D, g), c = gvar_cost(D, g);
             const double r = c - at_val_g(D, g, y.rc) - s.zg[g] + v.zg[g];
             rd.zg[g] = r; a[0] = r * r; a[1] = x.zg[g] * s.zg[g]; a[2] = c * x.zg[g];
             if (u > 0) { a[1] += (u - x.zg[g]) * v.zg[g]; a[3] = u * v.zg[g]; }
@@ -947,6 +962,24 @@ __global__ void k_lp_axpy(const double *sc, const double *d, double *y, size_t n
     if (i < n) y[i] += sc[SC_AD] * d[i];
 }
 // row duals -> K-bound multipliers in its fixed point: g[r] = -y_C6[r], a[b] = -y_C3[b] - g[rack b], l[b] = -y_C4[b]
+// The primal iterate in centi-units for the rounding on the host (lp_round_assignment; specification oracle/kao_lp.py round_primal):
+// q[k * P + p] = min(250, rint(100 x)), k = j (f_j), NJ + j (l_j), 2 NJ + r (yf_r), 2 NJ + R + r (yl_r); absent variables 0;
+// zq[b] = rint(zf_b), zq[B + b] = rint(zl_b)
+__global__ void k_lp_round(LpDev D, const double *x, const double *xg, uint8_t *q, int32_t *zq) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = 2 * D.NJ + 2 * D.R;
+    if (i < (size_t)K * D.P) {
+        const int k = (int)(i / D.P), p = (int)(i % D.P);
+        const int v = k < D.NJ ? VF(k) : (k < 2 * D.NJ ? VL(k - D.NJ) : (k < 2 * D.NJ + D.R ? VYF(D, k - 2 * D.NJ) : VYL(D, k - 2 * D.NJ - D.R)));
+        double c = 0.0;
+        if (var_present(D, v, p)) c = fmin(250.0, fmax(0.0, rint(100.0 * x[(size_t)v * D.P + p])));
+        q[i] = (uint8_t)(c == c ? c : 255.0);   // a non-finite iterate: 255 (never an integer: the partition is fractional)
+    } else if (i < (size_t)K * D.P + 2 * (size_t)D.B) {
+        const int g = (int)(i - (size_t)K * D.P);
+        const double z = rint(xg[g]);
+        zq[g] = (z == z && fabs(z) < 1e9) ? (int32_t)z : 0;
+    }
+}
 __global__ void k_lp_multipliers(LpDev D, const double *yc, int32_t *a, int32_t *l, int32_t *g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     auto fx = [](double v) { v = rint(v * kDualScale); v = fmin(fmax(v, -(double)kDualClamp), (double)kDualClamp); return (int32_t)v; };
@@ -976,7 +1009,8 @@ struct LpCtx {
     size_t rows_local = 0;     // doubles of the local rows of one RowVec (r1 r2 r7 r5 contiguous)
     double *fj = nullptr, *fr = nullptr, *ti = nullptr, *S = nullptr, *Linv = nullptr, *diag0 = nullptr, *cb = nullptr, *cr = nullptr;
     double *rec = nullptr, *redA = nullptr, *redB = nullptr, *redC = nullptr, *part = nullptr, *ylast = nullptr, *trace = nullptr;
-    int32_t *d_mult = nullptr;
+    int32_t *d_mult = nullptr, *d_zq = nullptr;
+    uint8_t *d_q = nullptr;   // quantised primal iterate (lp_primal)
     int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
     int maxit = 80, trace_cap = 0;
     double *h_sc = nullptr;    // pinned mirror of the scalars: slot 0 for lp_poll / lp_begin, slots 1..kLpRing for the marks of lp_enqueue_mark
@@ -985,6 +1019,7 @@ struct LpCtx {
     bool graph_tried = false;
     double t_begin = 0;
     int enqueued = 0;          // iterations enqueued since lp_begin
+    bool used = false;         // lp_begin has run on this context before
 
     template <class T> int alloc(T **p, size_t n) {
         void *q = nullptr;
@@ -1211,16 +1246,26 @@ void lp_close(LpCtx *c) { delete c; }
 
 // Enqueues the starting point (theta = 1: x~ = A^T (A A^T)^-1 b, y = (A A^T)^-1 A c, s = c - A^T y, pushed into the interior) and the
 // residuals of iterate 0.  Asynchronous on the context's stream.
-int lp_begin(LpCtx *cp, double tol, int maxit) {
+int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
     LpCtx &c = *cp;
     const LpDev &D = c.D;
     HIP_TRY(hipSetDevice(c.device));
     c.t_begin = now_s();
     c.maxit = std::min(maxit, c.trace_cap - 2);
     c.enqueued = 0;
+    if (c.used) {   // a second solve on the context (kao_solve: the perturbed LP after the certificate's): everything lp_open zeroed
+        const size_t nv0 = (size_t)D.NV * D.P + D.GV;
+        for (const VarVec *vv : {&c.x, &c.s, &c.v, &c.th, &c.rd, &c.h, &c.g, &c.d1, &c.d2, &c.dsa, &c.dva, &c.ds, &c.dv})
+            HIP_TRY(hipMemsetAsync(vv->z, 0, nv0 * sizeof(double), c.st));
+        for (const RowVec *rv : {&c.y, &c.rp, &c.w1, &c.w2}) HIP_TRY(hipMemsetAsync(rv->r1, 0, (c.rows_local + D.mcp) * sizeof(double), c.st));
+        HIP_TRY(hipMemsetAsync(c.S, 0, (size_t)D.mcp * D.mcp * sizeof(double), c.st));
+        HIP_TRY(hipMemsetAsync(c.ylast, 0, (size_t)D.mcp * sizeof(double), c.st));
+    }
+    c.used = true;
     double init[kScN];
     std::memset(init, 0, sizeof init);
     init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
+    init[SC_PERT] = pert > 0.0 ? pert : 0.0; init[SC_SALT] = (double)salt;
     std::memcpy(c.h_sc, init, sizeof init);
     HIP_TRY(hipMemcpyAsync(D.sc, c.h_sc, sizeof init, hipMemcpyHostToDevice, c.st));
     const size_t nvtot = (size_t)D.NV * D.P + D.GV;
@@ -1353,9 +1398,25 @@ int lp_finish(LpCtx *cp, int32_t *multipliers, double stats[8], double *trace) {
     return KAO_OK;
 }
 
+// The primal iterate, quantised (k_lp_round): q[(2 NJ + 2 R) * P] bytes, zq[2 B] ints, both host memory.  After lp_finish / once the
+// stop flag is up (the iterate does not move behind it).
+int lp_primal(LpCtx *cp, uint8_t *q, int32_t *zq) {
+    LpCtx &c = *cp;
+    const LpDev &D = c.D;
+    HIP_TRY(hipSetDevice(c.device));
+    const size_t nq = (size_t)(2 * D.NJ + 2 * D.R) * D.P;
+    if (!c.d_q) { int rc = c.alloc(&c.d_q, nq); if (rc) return rc; rc = c.alloc(&c.d_zq, (size_t)2 * D.B); if (rc) return rc; }
+    hipLaunchKernelGGL(k_lp_round, dim3((unsigned)((nq + 2 * (size_t)D.B + 255) / 256)), dim3(256), 0, c.st, D, c.x.z, c.x.zg, c.d_q, c.d_zq);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(q, c.d_q, nq, hipMemcpyDeviceToHost, c.st));
+    HIP_TRY(hipMemcpyAsync(zq, c.d_zq, (size_t)2 * D.B * 4, hipMemcpyDeviceToHost, c.st));
+    HIP_TRY(hipStreamSynchronize(c.st));
+    return KAO_OK;
+}
+
 // One shot: iterations in batches of four until the stop flag is up.
-int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace) {
-    int rc = lp_begin(c, tol, maxit);
+int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace, double pert, uint32_t salt) {
+    int rc = lp_begin(c, tol, maxit, pert, salt);
     if (rc) return rc;
     for (int st = 0, it = 0; !st;) {
         if ((rc = lp_enqueue(c, 4)) || (rc = lp_poll(c, &st, &it))) return rc;

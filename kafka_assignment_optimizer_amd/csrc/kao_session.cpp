@@ -1258,6 +1258,37 @@ int kao_lp_bound(const kao_topic *t, double tol, int32_t max_iters, int64_t *bou
     return rc;
 }
 
+int kao_lp_round(const kao_topic *t, double pert, uint32_t salt, double tol, int32_t max_iters, int32_t use_fallback, uint16_t *assignment,
+                 int64_t *objective, int32_t violations[8], double stats[8]) {
+    if (!t || !assignment) return fail(KAO_ERR_INVALID, "null topic / assignment");
+    int rc = require_init();
+    if (rc) return rc;
+    LpCtx *lp = nullptr;
+    if ((rc = lp_open(t, &lp))) return rc;
+    const size_t slots = (size_t)t->n_partitions * t->rf;
+    const double eps = pert > 0 ? pert : lp_default_pert(t);
+    double st[8] = {0};
+    rc = lp_solve(lp, tol > 0 ? tol : 1e-8, max_iters > 0 ? max_iters : 150, nullptr, st, nullptr, eps, salt);
+    std::vector<uint8_t> q((size_t)(2 * t->rf_cur + 2 * t->n_racks) * t->n_partitions);
+    std::vector<int32_t> zq(2 * (size_t)t->n_brokers);
+    if (!rc) rc = lp_primal(lp, q.data(), zq.data());
+    lp_close(lp);
+    if (rc) return rc;
+    const double t0 = now_s();
+    std::vector<uint16_t> fb;
+    if (use_fallback) fb.assign(assignment, assignment + slots);
+    int32_t rep[4] = {0, 0, 0, 0};
+    if ((rc = lp_round_assignment(t, q.data(), zq.data(), use_fallback ? fb.data() : nullptr, assignment, rep))) return rc;
+    const double t1 = now_s();
+    int64_t obj = 0;
+    int32_t viol[8] = {0};
+    if ((rc = kao_evaluate(t, assignment, &obj, viol))) return rc;
+    if (objective) *objective = obj;
+    if (violations) std::memcpy(violations, viol, sizeof viol);
+    if (stats) { stats[0] = st[0]; stats[1] = st[3]; stats[2] = rep[0]; stats[3] = rep[1] + rep[2]; stats[4] = rep[3]; stats[5] = st[7]; stats[6] = (t1 - t0) * 1e3; stats[7] = eps; }
+    return KAO_OK;
+}
+
 int kao_lp_trace(const kao_topic *t, double tol, int32_t max_iters, double *trace, double stats[8], int32_t *multipliers) {
     if (!t) return fail(KAO_ERR_INVALID, "null topic");
     int rc = require_init();

@@ -422,6 +422,24 @@ def lp_bound(topic: Topic, tol: float = 0.0, max_iters: int = 0) -> dict:
                 dinf=float(st[6]), ms=float(st[7]))
 
 
+def lp_round(topic: Topic, pert: float = 0.0, salt: int = 0, tol: float = 0.0, max_iters: int = 0, fallback=None) -> dict:
+    """KAO-LP's primal side (kao_lp_round): the interior-point iterate of the LP with perturbed costs, rounded into an assignment and
+    evaluated exactly.  `fallback` ([P, rf] dense indices): the rows partitions with fractional variables keep."""
+    ct = _CTopics([topic])
+    n = topic.n_partitions * topic.rf
+    a = np.zeros(n, dtype=np.uint16) if fallback is None else np.ascontiguousarray(np.asarray(fallback).reshape(-1), dtype=np.uint16).copy()
+    if a.shape != (n,):
+        raise ValueError("fallback: [P, rf] expected")
+    obj = C.c_int64()
+    viol = (C.c_int32 * 8)()
+    st = np.zeros(8)
+    _check(_ffi.load().kao_lp_round(ct.ptr(0), float(pert), int(salt) & 0xFFFFFFFF, float(tol), int(max_iters), 0 if fallback is None else 1,
+                                    a.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(obj), viol, st.ctypes.data_as(C.POINTER(C.c_double))), "kao_lp_round")
+    return dict(assignment=a.reshape(topic.n_partitions, topic.rf), objective=int(obj.value), violations=[int(v) for v in viol],
+                iterations=int(st[0]), status=int(st[1]), fractional=int(st[2]), over_inflow=int(st[3]), from_fallback=int(st[4]),
+                ms_lp=float(st[5]), ms_round=float(st[6]), pert=float(st[7]))
+
+
 def lp_trace(topic: Topic, tol: float = 0.0, max_iters: int = 80) -> dict:
     """Test hook (kao_lp_trace): the interior-point solve alone and its per-iterate trace (mu, primal, dual, pinf, dinf)."""
     ct = _CTopics([topic])

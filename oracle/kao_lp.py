@@ -246,6 +246,8 @@ def _port():
         _PORT.kao_lp_port_solve.restype = C.c_int
         _PORT.kao_lp_port_solve_x.argtypes = _PORT.kao_lp_port_solve.argtypes + [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _PORT.kao_lp_port_solve_x.restype = C.c_int
+        _PORT.kao_lp_port_solve_p.argtypes = [C.POINTER(kp.PortTopic), C.c_double, C.c_int, C.c_double, C.c_uint32] + [C.POINTER(C.c_double)] * 5
+        _PORT.kao_lp_port_solve_p.restype = C.c_int
     return _PORT
 
 
@@ -258,7 +260,7 @@ def port_coupling_order(t: ko.Topic, lp: CompactLP) -> np.ndarray:
     return np.concatenate([lp.rows["NF"], lp.rows["NL"], lp.rows["C6"], inter])
 
 
-def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80, primal: bool = False):
+def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80, primal: bool = False, pert: float = 0.0, salt: int = 0):
     """The structured iteration on the CPU.  Returns dict(status, iterations, primal, dual (README objective), y (coupling-row
     duals in the port's order), a, l, g (fixed-point multipliers), trace [(mu, pobj, dobj, pinf, dinf)])."""
     import ctypes as C
@@ -272,8 +274,8 @@ def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80, primal: bool = F
     pd = C.POINTER(C.c_double)
     x = np.zeros((3 * t.rf_cur + 3 * R) * t.n_partitions) if primal else None
     xg = np.zeros(4 * B + R) if primal else None
-    rc = _port().kao_lp_port_solve_x(C.byref(ct.s), tol, maxit, y.ctypes.data_as(pd), trace.ctypes.data_as(pd), stats.ctypes.data_as(pd),
-                                     x.ctypes.data_as(pd) if primal else None, xg.ctypes.data_as(pd) if primal else None)
+    rc = _port().kao_lp_port_solve_p(C.byref(ct.s), tol, maxit, float(pert), int(salt) & 0xFFFFFFFF, y.ctypes.data_as(pd), trace.ctypes.data_as(pd),
+                                     stats.ctypes.data_as(pd), x.ctypes.data_as(pd) if primal else None, xg.ctypes.data_as(pd) if primal else None)
     it = int(stats[0])
     rack = np.asarray(t.rack_of)
     g = -y[2 * R:3 * R]
@@ -285,3 +287,126 @@ def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80, primal: bool = F
         out["x"] = x.reshape(3 * t.rf_cur + 3 * R, t.n_partitions)
         out["xg"] = xg
     return out
+
+
+# ---- the primal side (round 5): from the iterate of the PERTURBED LP to an assignment ------------------------------------------
+# Specification of kao_lp_round (include/kao.h) / lp_round_assignment (kao_round.cpp): same quantisation, same order, same ties.
+
+ROUND_TOL_C = 30       # a variable farther than 0.30 from an integer makes its partition "fractional"
+PERT_SLOTS = 100.0     # default perturbation: eps = min(1e-2, PERT_SLOTS / (partitions * rf))
+
+
+def default_pert(t: ko.Topic) -> float:
+    return min(1e-2, PERT_SLOTS / (t.n_partitions * t.rf))
+
+
+def quantise(x) -> np.ndarray:
+    """centi-units as the device packs them: min(250, rint(100 x)), negative values 0"""
+    return np.minimum(250, np.maximum(0, np.rint(100.0 * np.asarray(x, dtype=np.float64)))).astype(np.int64)
+
+
+def primal_blocks(t: ko.Topic, x: np.ndarray, xg: np.ndarray):
+    """(F, L [P][rf_cur], YF, YL [P][R], ZF, ZL [B]) in centi-units from port_solve(primal=True)'s x / xg."""
+    NJ, R, B = t.rf_cur, t.n_racks, t.n_brokers
+    F = quantise(np.stack([x[3 * j] for j in range(NJ)], axis=1)); L = quantise(np.stack([x[3 * j + 1] for j in range(NJ)], axis=1))
+    YF = quantise(np.stack([x[3 * NJ + 3 * r] for r in range(R)], axis=1)); YL = quantise(np.stack([x[3 * NJ + 3 * r + 1] for r in range(R)], axis=1))
+    return F, L, YF, YL, np.rint(xg[:B]).astype(np.int64), np.rint(xg[B:2 * B]).astype(np.int64)
+
+
+def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = ROUND_TOL_C):
+    """The compact LP pools the NEW replicas of a partition per rack (yf, yl) and counts what every broker receives (zf, zl): an
+    integral solution still has to hand the new replicas of a rack to that rack's brokers.  Any way that respects the inflows and
+    puts no broker twice into a partition (row C5, README.md:168-171) is as good as any other -- the objective (README.md:145-146)
+    only sees current replicas -- so: partitions in ascending order; kept current replicas first (leader: the lowest j with l_j = 1);
+    then racks in ascending order, the new leader of a rack before its new followers; a new replica goes to the broker of the rack
+    with the LARGEST remaining inflow that is not in the row yet (ties: the lowest index), to the lowest-index broker not in the row
+    when none has inflow left (`over_inflow`).  A partition with a variable farther than tolc / 100 from an integer, or whose row
+    comes out incomplete, is FRACTIONAL: it keeps its row of `fallback` (the incumbent) when there is one, else its heaviest options
+    (leader: the largest l_j, then the largest yl_r; followers by decreasing mass, current replicas before racks on ties).
+    Returns (A [P][RF] dense broker indices, leader first; report dict)."""
+    B, R, P, RF, NJ = t.n_brokers, t.n_racks, t.n_partitions, t.rf, t.rf_cur
+    phi = t.bounds()["prack_hi"]
+    rack = np.asarray(t.rack_of)
+    members = [[int(b) for b in np.nonzero(rack == r)[0]] for r in range(R)]
+    capf = [int(v) for v in ZF]; capl = [int(v) for v in ZL]
+    A = np.zeros((P, RF), dtype=np.int64)
+    rep = dict(fractional=0, over_inflow=0, unplaced=0, from_fallback=0)
+
+    def frac(c):
+        return abs(int(c) - 100 * ((int(c) + 50) // 100)) > tolc
+
+    def take(r, cap, used):
+        best = -1
+        for b in members[r]:
+            if cap[b] > 0 and b not in used and (best < 0 or cap[b] > cap[best]):
+                best = b
+        if best >= 0:
+            cap[best] -= 1
+            return best
+        for b in members[r]:
+            if b not in used:
+                rep["over_inflow"] += 1
+                return b
+        rep["unplaced"] += 1
+        return -1
+
+    pending = []
+    for p in range(P):
+        cur = [int(b) if (int(b) != ko.NONE and int(b) < B) else -1 for b in t.current[p]]
+        vals = [F[p, j] for j in range(NJ) if cur[j] >= 0] + [L[p, j] for j in range(NJ) if cur[j] >= 0] + list(YF[p]) + list(YL[p])
+        if any(frac(c) for c in vals):
+            pending.append(p); continue
+        lead = -1; row = []
+        for j in range(NJ):
+            if cur[j] < 0: continue
+            if lead < 0 and (int(L[p, j]) + 50) // 100 >= 1: lead = cur[j]
+            elif (int(F[p, j]) + 50) // 100 >= 1: row.append(cur[j])
+        used = set(row) | ({lead} if lead >= 0 else set())
+        # (a snapshot of the inflows: an incomplete row gives back what it took)
+        sf, sl, so, su = list(capf), list(capl), rep["over_inflow"], rep["unplaced"]
+        for r in range(R):
+            if lead < 0 and (int(YL[p, r]) + 50) // 100 >= 1:
+                b = take(r, capl, used)
+                if b >= 0: lead = b; used.add(b)
+            for _ in range((int(YF[p, r]) + 50) // 100):
+                if len(row) >= RF - 1: break
+                b = take(r, capf, used)
+                if b >= 0: row.append(b); used.add(b)
+        if lead < 0 or len(row) != RF - 1:
+            capf[:], capl[:] = sf, sl
+            rep["over_inflow"], rep["unplaced"] = so, su
+            pending.append(p); continue
+        A[p, 0] = lead; A[p, 1:] = row
+    rep["fractional"] = len(pending)
+    for p in pending:
+        if fallback is not None:
+            A[p] = np.asarray(fallback[p]); rep["from_fallback"] += 1
+            continue
+        cur = [int(b) if (int(b) != ko.NONE and int(b) < B) else -1 for b in t.current[p]]
+        # leader: the heaviest option
+        opts = [(-int(L[p, j]), 0, j) for j in range(NJ) if cur[j] >= 0] + [(-int(YL[p, r]), 1, r) for r in range(R)]
+        opts.sort()
+        used = set(); lead = -1; per_rack = [0] * R
+        for m, kind, k in opts:
+            b = cur[k] if kind == 0 else take(k, capl, used)
+            if b >= 0:
+                lead = b; used.add(b); per_rack[int(rack[b])] += 1; break
+        opts = [(-int(F[p, j]), 0, j) for j in range(NJ) if cur[j] >= 0] + [(-int(YF[p, r]), 1, r) for r in range(R)]
+        opts.sort()
+        row = []
+        for rnd in range(2):    # second pass: anything that fits (all masses may sit on options already taken)
+            for m, kind, k in opts:
+                if len(row) >= RF - 1: break
+                if kind == 0:
+                    b = cur[k]
+                    if b in used or per_rack[int(rack[b])] >= phi: continue
+                else:
+                    if per_rack[k] >= phi: continue
+                    b = take(k, capf, used)
+                    if b < 0: continue
+                row.append(b); used.add(b); per_rack[int(rack[b])] += 1
+        while len(row) < RF - 1:   # (cannot happen on a feasible model: R * phi >= RF)
+            row.append(next(b for b in range(B) if b not in used)); used.add(row[-1])
+        A[p, 0] = lead if lead >= 0 else next(b for b in range(B) if b not in used)
+        A[p, 1:] = row
+    return A, rep

@@ -81,6 +81,18 @@ static inline int cur_b(const lp_t *L, int p, int j) {
 
 static void *zalloc(size_t n) { void *p = calloc(n ? n : 1, 1); if (!p) abort(); return p; }
 
+/* Cost perturbation (round 5, KAO-LP's primal side).  The optimal face of the model's LP is huge -- ties everywhere -- and the
+ * interior-point iterate converges to its analytic centre: fractional in most partitions.  Adding eps * h(i) to the cost of every
+ * variable i, h in [0, 1) a hash of the variable's index and a salt, leaves (generically) ONE optimal vertex, the iterate converges
+ * to it, and on every topic tried that vertex is integral in all but a handful of partitions: rounding it (oracle/kao_lp.py
+ * round_primal) gives an assignment whose objective equals the LP value of the unperturbed model -- the optimum -- on 300 x 2000,
+ * 450 x 3500, 500 x 5000, 500 x 10000 (docs/notes_r05.md section 6).  Index: v * P + p for the partition variables, 0x80000000 + g for
+ * the global ones.  The stopping rule keeps the norm of the UNPERTURBED costs. */
+static double pert_hash(uint32_t i, uint32_t salt) {
+    uint32_t h = (i ^ salt) * 0x9E3779B1u + 0x85EBCA6Bu;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (double)(h >> 8) / 16777216.0;
+}
 static lp_t *lp_create(const port_topic *t) {
     lp_t *L = (lp_t *)zalloc(sizeof(lp_t));
     const int P = L->P = t->n_partitions, B = L->B = t->n_brokers, R = L->R = t->n_racks;
@@ -475,11 +487,15 @@ static void mcc_finish(size_t n, const unsigned char *pres, const unsigned char 
 
 /* the same, also returning the primal iterate: out_x[(3 NJ + 3 R) * P] (variable-major: f_j l_j q_j per current replica, then yf_r yl_r t_r
  * per rack) and out_xg[4 B + R] (zf zl n m per broker, k per rack); either may be NULL */
-int kao_lp_port_solve_x(const port_topic *t, double tol, int maxit, double *out_y, double *trace, double stats[4], double *out_x, double *out_xg);
-int kao_lp_port_solve(const port_topic *t, double tol, int maxit, double *out_y, double *trace, double stats[4]) {
-    return kao_lp_port_solve_x(t, tol, maxit, out_y, trace, stats, NULL, NULL);
-}
+int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, uint32_t salt, double *out_y, double *trace, double stats[4], double *out_x, double *out_xg);
 int kao_lp_port_solve_x(const port_topic *t, double tol, int maxit, double *out_y, double *trace, double stats[4], double *out_x, double *out_xg) {
+    return kao_lp_port_solve_p(t, tol, maxit, 0.0, 0u, out_y, trace, stats, out_x, out_xg);
+}
+int kao_lp_port_solve(const port_topic *t, double tol, int maxit, double *out_y, double *trace, double stats[4]) {
+    return kao_lp_port_solve_p(t, tol, maxit, 0.0, 0u, out_y, trace, stats, NULL, NULL);
+}
+/* the same with perturbed costs: c_i + eps * pert_hash(i, salt) on every present variable (eps = 0: the model's own LP) */
+int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, uint32_t salt, double *out_y, double *trace, double stats[4], double *out_x, double *out_xg) {
     lp_t *L = lp_create(t);
     const int P = L->P, R = L->R, NJ = L->NJ, mc = L->mc, GV = L->GV;
     const size_t nv = (size_t)L->NV * P;
@@ -501,6 +517,10 @@ int kao_lp_port_solve_x(const port_topic *t, double tol, int maxit, double *out_
     for (size_t i = 0; i < nv; ++i) ncn += L->c[i] * L->c[i];
     for (int i = 0; i < GV; ++i) ncn += L->cg[i] * L->cg[i];
     nb = 1.0 + sqrt(nb); ncn = 1.0 + sqrt(ncn);
+    if (eps > 0) {
+        for (size_t i = 0; i < nv; ++i) if (L->pres[i]) L->c[i] += eps * pert_hash((uint32_t)i, salt);
+        for (int i = 0; i < GV; ++i) if (L->presg[i]) L->cg[i] += eps * pert_hash(0x80000000u + (uint32_t)i, salt);
+    }
 #define RHS_B(V) do { for (int p_ = 0; p_ < P; ++p_) { (V).r1[p_] = L->RF; (V).r2[p_] = 1; for (int r_ = 0; r_ < R; ++r_) (V).r7[(size_t)r_ * P + p_] = t->prack_hi; \
         for (int j_ = 0; j_ < NJ; ++j_) (V).r5[(size_t)j_ * P + p_] = (L->has_c5 && cur_b(L, p_, j_) >= 0) ? 1.0 : 0.0; } memcpy((V).rc, L->bc, 8 * (size_t)mc); } while (0)
     /* starting point: theta = 1 */

@@ -1036,6 +1036,7 @@ def test_dual_bound_is_valid_and_closes_wide_family(kao, ko):
         got = kao.dual_bound(to_product_topic(ot), c["objective"], iters=1500)
         assert not got["flags"] & 4 and got["bound"] >= c["objective"], c["seed"]
         closed += got["bound"] == c["objective"]
+    print("wide family: closed", closed, "of", len(cases))
     assert closed >= len(cases) - 4, (closed, len(cases))
 
 
@@ -1245,6 +1246,7 @@ def test_high_rf_golden_optima(kao, ko):
         if c.get("unique"):
             assert kao.canonicalize(to_product_topic(ot), r.assignment).tolist() == ko.canonicalize(ot, np.array(c["assignment"])).tolist(), c["seed"]
             n_unique += 1
+    print("high RF goldens: proven", n_proven, "of", n_opt)
     assert n_opt >= 50 and n_proven >= n_opt - 2, (n_opt, n_proven)   # round 3: K-bound certifies RF 5..8 (it was n_opt // 3 on the closed-form bound)
 
 
@@ -1290,6 +1292,7 @@ def test_broker_weights_eval_and_replay_bit_exact(kao, ko, kp):
         assert r.objective == ex.objective <= r.upper_bound, (t.name, r.objective, ex.objective, r.upper_bound)
         n += 1
         n_proven += r.status == "OPTIMAL_PROVEN"
+    print("broker-weight topics: proven", n_proven, "of", n)
     assert n >= 5 and n_proven >= n - 1, (n, n_proven)   # round 3: K-bound prices weighted topics too
 
 
