@@ -385,6 +385,10 @@ int kao_rccl_loopback_counts(uint64_t out[2]);
  * after the first (kao_session_new_generation), out[13] = KAO-CX runs from further starting points (other restarts' best
  * snapshots; included in out[9]), out[14] = KAO-LP solves that delivered multipliers, out[15] = their interior-point iterations. */
 int kao_last_solve_timing(double out[16]);
+/* KAO-LP in this thread's last kao_solve: out[0] solves that delivered multipliers, out[1] their interior-point iterations, out[2] iterates
+ * rounded into an assignment (kao_lp_round's primal side inside the solve), out[3] of those adopted as a topic's incumbent, out[4]
+ * partitions with fractional variables summed over the rounded iterates; out[5..7] reserved (0). */
+int kao_last_solve_lp(double out[8]);
 /* K-search as THIS thread's last kao_solve ran it (only when that solve had kao_opts.profile = 1: every K-search / K-eval launch is
  * then bracketed by HIP events on the session's stream): out[0] = HIP-event milliseconds of all K-search launches, out[1] = of all
  * K-eval launches, out[2] = K-search launches (turns of the loop that launched none -- a huge topic while KAO-CX / KAO-LP have the GPU

@@ -96,6 +96,7 @@ SIGNATURES = {
     "kao_cycle_pair_edges": (C.c_int, [_P(KaoTopic), _P(C.c_uint16), C.c_int32, _P(C.c_int32), _P(C.c_int64)]),
     "kao_last_solve_timing": (C.c_int, [_P(C.c_double)]),
     "kao_last_solve_profile": (C.c_int, [_P(C.c_double)]),
+    "kao_last_solve_lp": (C.c_int, [_P(C.c_double)]),
 }
 
 _lib = None

@@ -34,6 +34,7 @@ int require_init();               // kao_init on first use, then hipSetDevice(cu
 bool is_init();
 extern thread_local int t_device; // per-thread override: kao_solve_multi drives several devices from one process
 extern thread_local double g_timing[16];
+extern thread_local double g_lp[8];       // KAO-LP in the last kao_solve (kao_last_solve_lp)
 extern thread_local double g_profile[8];  // K-search as the last profiled kao_solve ran it (kao_last_solve_profile)   // wall-clock breakdown of the last solve (kao_last_solve_timing)
 
 // ---- the model on the host (kao_model.cpp) ----

@@ -18,6 +18,7 @@ namespace kao {
 thread_local int t_device = -1;
 thread_local double g_timing[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 thread_local double g_profile[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local double g_lp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 namespace {
 thread_local std::string g_err;

@@ -168,6 +168,21 @@ struct SolveRun {
     int64_t lp_huge_slots = 131072;
     std::vector<char> lp_all;                     // per topic: every iteration is enqueued already
     bool huge(int i) const { return (int64_t)topics[i].n_partitions * topics[i].rf > lp_huge_slots; }
+    // KAO-LP's primal side (round 5, second half): the LP is solved with PERTURBED costs (kao_lp.hip pert_term) -- small enough that
+    // the dual function at its row duals still floors to the LP value (the certificate), large enough that the iterate converges to ONE
+    // vertex, which rounds to an assignment (lp_round_assignment).  One solve gives the certificate and, nearly always, the optimum.
+    bool lp_round_on = true;      // KAO_LP_ROUND=0: certificate only (the unperturbed LP, as in the first half of round 5)
+    double lp_pert_env = -1.0;    // KAO_LP_PERT=<eps>: the perturbation (default min(1e-4, 1.5 / slots))
+    double lp_first_s = 1.8;      // huge topics: with at least this much time the LP runs straight after the first feasible incumbent
+    int lp_rounded = 0, lp_round_adopted = 0, lp_round_fractional = 0;
+    std::vector<uint8_t> lp_q;
+    std::vector<int32_t> lp_zq;
+    std::vector<uint16_t> lp_buf, lp_fb;
+    double lp_pert_of(int i) const {
+        if (!lp_round_on) return 0.0;
+        if (lp_pert_env >= 0) return lp_pert_env;
+        return std::min(1e-4, 1.5 / ((double)topics[i].n_partitions * topics[i].rf));
+    }
     bool lp_huge_first = false;   // experiment hook KAO_LP_HUGE_FIRST=1: huge topics get their LP before anything else (the search waits for its prices)
     bool lp_possible(int i) const { return lp_on && !has_target && dual_iters > 0 && s->dual_ok[(size_t)i] && lp_state[(size_t)i] < 2; }
     bool search_paused() const {   // a huge topic between its first feasible incumbent and the end of its LP
@@ -247,6 +262,9 @@ struct SolveRun {
             lp_per_launch = (int)std::max<int64_t>(1, env_i("KAO_LP_PER_LAUNCH", lp_per_launch));
             lp_min_slots = env_i("KAO_LP_MIN_SLOTS", lp_min_slots);
             lp_huge_first = env_i("KAO_LP_HUGE_FIRST", 0) != 0;
+            lp_round_on = env_i("KAO_LP_ROUND", 1) != 0;
+            if (const char *e = std::getenv("KAO_LP_PERT")) lp_pert_env = std::atof(e);
+            if (const char *e = std::getenv("KAO_LP_FIRST_S")) lp_first_s = std::atof(e);
         }
         cx_on = so.use_cycles >= 0;
         { const char *e = std::getenv("KAO_CX_EAGER"); cx_eager = e && e[0] == '1'; }
@@ -335,6 +353,11 @@ struct SolveRun {
             std::vector<int32_t> mult(2 * (size_t)t.n_brokers + (size_t)t.n_racks);
             double st8[8];
             rc = lp_finish(lp_ctx[(size_t)i], mult.data(), st8, nullptr);
+            bool have_primal = false;
+            if (!rc && lp_round_on && st8[3] != 3.0) {   // the quantised iterate (not of a stalled solve: its last iterate is not finite)
+                lp_q.resize((size_t)(2 * t.rf_cur + 2 * t.n_racks) * t.n_partitions); lp_zq.resize(2 * (size_t)t.n_brokers);
+                have_primal = lp_primal(lp_ctx[(size_t)i], lp_q.data(), lp_zq.data()) == KAO_OK;
+            }
             lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; --running;
             if (rc) { lp_state[(size_t)i] = 3; continue; }
             lp_iters += it; ++lp_solves;
@@ -347,6 +370,7 @@ struct SolveRun {
             if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
             lp_state[(size_t)i] = 2;
             if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: %d iterations, LP value %.4f, certificate %lld, launch %d\n", i, it, st8[2], (long long)s->ub[(size_t)i], launches);
+            if (have_primal && (rc = lp_round_and_adopt(i))) return rc;
         }
         if (final_call) return KAO_OK;
         // largest open topics first, at most `lp_max_running` at a time
@@ -355,9 +379,12 @@ struct SolveRun {
             int best = -1; int64_t best_slots = 0;
             for (int i = 0; i < n; ++i) {
                 if (lp_state[(size_t)i] != 0 || !s->dual_ok[(size_t)i] || s->topic_infeasible[(size_t)i] || (feasible(i) && objective(i) >= s->ub[(size_t)i])) continue;
-                if (huge(i) && !lp_huge_first) {   // ... once KAO-CX has run the incumbent to a fixpoint (or cannot run)
+                if (huge(i) && !lp_huge_first) {   // ... once KAO-CX has run the incumbent to a fixpoint (or cannot run) -- or, when the time
+                    // limit leaves room for it (a limit is an input, not the clock), straight after the first feasible incumbent: its
+                    // primal side makes the fixpoint unnecessary
                     const bool cx_can = cx_on && cycle_supported(&topics[i]);
-                    if (!feasible(i) || (cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20))) continue;
+                    const bool lp_now = lp_round_on && deadline - t0 >= lp_first_s;
+                    if (!feasible(i) || (!lp_now && cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20))) continue;
                 }
                 const int64_t slots = (int64_t)topics[i].n_partitions * topics[i].rf;
                 if (slots < lp_min_slots && (!feasible(i) || bound_merges[(size_t)i] < lp_after_small)) continue;
@@ -368,14 +395,45 @@ struct SolveRun {
             rc = lp_open(&topics[best], &c);
             if (rc == KAO_ERR_UNSUPPORTED || rc == KAO_ERR_NOMEM) { lp_state[(size_t)best] = 3; continue; }
             if (rc) return rc;
-            if ((rc = lp_begin(c, 1e-7, 120))) { lp_close(c); return rc; }
+            const double pert = lp_pert_of(best);
+            if ((rc = lp_begin(c, pert > 0 ? 1e-10 : 1e-7, pert > 0 ? 200 : 120, pert, 0u))) { lp_close(c); return rc; }
             lp_ctx[(size_t)best] = c; lp_state[(size_t)best] = 1; lp_marks[(size_t)best] = lp_read[(size_t)best] = 0; lp_all[(size_t)best] = 0; ++running;
             if (huge(best)) {   // the whole solve at once: 30 marks of four iterations (those behind the stop flag are no-ops)
-                for (int m = 0; m < 30; ++m) if ((rc = lp_enqueue_mark(c, 4, lp_marks[(size_t)best]++))) return rc;
+                for (int m = 0; m < (pert > 0 ? 50 : 30); ++m) if ((rc = lp_enqueue_mark(c, 4, lp_marks[(size_t)best]++))) return rc;
                 lp_all[(size_t)best] = 1;
             }
         }
         all_done = check_done();
+        return KAO_OK;
+    }
+    // the quantised iterate in lp_q / lp_zq -> an assignment (fractional partitions keep the incumbent's rows), scored exactly; a feasible
+    // one that beats the incumbent becomes the incumbent and the elite (as a KAO-CX result does)
+    int lp_round_and_adopt(int i) {
+        const kao_topic &t = topics[i];
+        const size_t slots = (size_t)t.n_partitions * t.rf;
+        const double tr0 = now_s();
+        lp_buf.resize(slots);
+        const uint16_t *fb = nullptr;
+        int rc;
+        if (gfeasible(i)) { lp_fb.resize(slots); if ((rc = session_topic_best(s, i, lp_fb.data()))) return rc; fb = lp_fb.data(); }
+        int32_t rep[4] = {0, 0, 0, 0};
+        if ((rc = lp_round_assignment(&t, lp_q.data(), lp_zq.data(), fb, lp_buf.data(), rep))) return rc;
+        int64_t obj = 0;
+        int32_t viol[8] = {0};
+        if ((rc = kao_evaluate(&t, lp_buf.data(), &obj, viol))) return rc;
+        ++lp_rounded; lp_round_fractional += rep[0];
+        const bool better = viol[0] == 0 && (!gfeasible(i) || obj > gobjective(i));
+        if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: rounded iterate: objective %lld violations %d (%d fractional partitions, %d beyond an inflow, %d rows from the incumbent) in %.3f ms%s\n",
+                                i, (long long)obj, viol[0], rep[0], rep[1] + rep[2], rep[3], (now_s() - tr0) * 1e3, better ? ": adopted" : "");
+        if (!better) return KAO_OK;
+        uint64_t key = 0;
+        if ((rc = session_adopt_external(s, i, lp_buf.data(), obj, &key))) return rc;
+        const double t2 = now_s() - t0;
+        dkeys[(size_t)i] = gprev[(size_t)i] = key;
+        t_improved[(size_t)i] = t2;
+        i_improved[(size_t)i] = iters_done;
+        if (key < keys[(size_t)i]) { keys[(size_t)i] = prev[(size_t)i] = key; t_best[(size_t)i] = t_last_improve = t2; }
+        ++lp_round_adopted;
         return KAO_OK;
     }
     // keys = the best over all generations (what "done", the K-bound targets and the answer go by); dkeys = this generation's
@@ -497,6 +555,7 @@ struct SolveRun {
         for (int i = 0; i < n; ++i) {
             if (s->topic_infeasible[(size_t)i] || !gfeasible(i) || (feasible(i) && objective(i) >= s->ub[(size_t)i])) continue;
             if (!cycle_supported(&topics[i])) continue;
+            if (lp_state[(size_t)i] == 1 && lp_all[(size_t)i]) continue;   // a huge topic's LP has the GPU to itself (beside it a round takes 20 ms instead of 8)
             const bool elite_fresh = (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20);   // not the incumbent of the last fixpoint
             const bool more = det && cx_starts > 0;
             if (!elite_fresh && !more) continue;
@@ -737,6 +796,7 @@ int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, k
     g_timing[9] = run.cx_calls; g_timing[10] = run.cx_gains; g_timing[11] = (double)run.iters_done; g_timing[12] = run.generations;
     g_timing[13] = run.cx_more;
     g_timing[14] = run.lp_solves; g_timing[15] = run.lp_iters;
+    g_lp[0] = run.lp_solves; g_lp[1] = run.lp_iters; g_lp[2] = run.lp_rounded; g_lp[3] = run.lp_round_adopted; g_lp[4] = run.lp_round_fractional;
     for (double &q : g_profile) q = 0;
     if (o.profile) {
         kao_stats st{};
@@ -1443,6 +1503,11 @@ int kao_rccl_loopback_counts(uint64_t out[2]) {
     return KAO_OK;
 }
 
+int kao_last_solve_lp(double out[8]) {
+    if (!out) return fail(KAO_ERR_INVALID, "null out");
+    for (int i = 0; i < 8; ++i) out[i] = g_lp[i];
+    return KAO_OK;
+}
 int kao_last_solve_timing(double out[16]) {
     if (!out) return fail(KAO_ERR_INVALID, "null out");
     for (int i = 0; i < 16; ++i) out[i] = g_timing[i];

@@ -540,6 +540,13 @@ def last_solve_timing() -> dict:
                 lp_solves=int(out[14]), lp_iters=int(out[15]))
 
 
+def last_solve_lp() -> dict:
+    """KAO-LP in this thread's last solve (kao_last_solve_lp)."""
+    out = (C.c_double * 8)()
+    _check(_ffi.load().kao_last_solve_lp(out), "kao_last_solve_lp")
+    return dict(solves=int(out[0]), iterations=int(out[1]), rounded=int(out[2]), adopted=int(out[3]), fractional_partitions=int(out[4]))
+
+
 def last_solve_profile() -> dict:
     """K-search as the last kao_solve ran it (kao_last_solve_profile; needs profile=1 in that solve's options)."""
     out = (C.c_double * 8)()

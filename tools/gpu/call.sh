@@ -1,19 +1,22 @@
 #!/bin/bash
-# round 5, call 32: KAO-LP's primal side on the device for the first time: perturbed LP + rounding against the certificate
+# round 5, call 34: kao_solve with the perturbed LP (certificate + rounded iterate from one solve)
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r05_c32
-SALTS=0,1 timeout 900 python tools/r5_round_probe.py 300x6x2000 300x6x2000:2 270x6x2200 450x9x3500 500x10x5000 500x10x10000 1000x20x30000 > gpurun_out/${T}_round.log 2>&1
-timeout 600 python - >> gpurun_out/${T}_round.log 2>&1 <<'P'
+T=r05_c34
+SEEDS=1,2,3 BUDGET=4 timeout 900 python tools/r5_solve_probe.py 300x6x2000 270x6x2200 450x9x3500 500x10x5000 500x10x10000 1000x20x30000 > gpurun_out/${T}_solve.log 2>&1
+DSEED=2 SEEDS=1,2,3,4,5 BUDGET=4 timeout 600 python tools/r5_solve_probe.py 300x6x2000 >> gpurun_out/${T}_solve.log 2>&1
+KAO_SOLVE_TRACE=1 timeout 600 python - >> gpurun_out/${T}_solve.log 2> gpurun_out/${T}_trace100k.log <<'P'
 import sys, time
 sys.path.insert(0, '.')
 import kafka_assignment_optimizer_amd as kao
 from kafka_assignment_optimizer_amd import synthetic as sy
 kao.init(0)
 t = sy.north_star_topic('drift100k')
-lb = kao.lp_bound(t)
-for salt in (0, 1):
-    t0 = time.perf_counter(); r = kao.lp_round(t, salt=salt); w = time.perf_counter() - t0
-    print(f"1000x100000 salt {salt} pert {r['pert']:.2e}: objective {r['objective']} violations {r['violations'][0]} certificate {lb['bound']} | perturbed LP {r['iterations']} it status {r['status']} {r['ms_lp']:.0f} ms, rounding {r['ms_round']:.1f} ms, fractional {r['fractional']}, over inflow {r['over_inflow']}, wall {w:.2f} s", flush=True)
+kao.solve([t], seed=1, max_launches=1)
+for budget in (3.0, 1.0):
+    t0 = time.perf_counter(); r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=budget)[0]; dt = time.perf_counter() - t0
+    tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
+    print(f"drift100k limit {budget}: {r.status} objective {r.objective} certificate {r.upper_bound} gap {r.upper_bound - r.objective} t_best {tm['time_to_best']:.3f}s total {dt:.3f}s launches {tm['launches']} cx {tm['cx_calls']} lp {lp}", flush=True)
 P
-cat gpurun_out/${T}_round.log
+grep -v "^\[kao-solve\] launch\|generation" gpurun_out/${T}_trace100k.log | grep "KAO-LP\|KAO-CX" | head -20 >> gpurun_out/${T}_solve.log
+cat gpurun_out/${T}_solve.log | cut -c1-330

@@ -15,7 +15,7 @@ for B, R, P in shapes:
         extra = {"restarts": int(os.environ["RESTARTS"])} if os.environ.get("RESTARTS") else {}
         r = kao.solve([t], seed=seed, stop_at_bound=1, time_limit_s=budget, **extra)[0]
         dt = time.perf_counter() - t0
-        tm = kao.last_solve_timing()
+        tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
         print(f"{B}x{P} seed {seed}: {r.status} objective {r.objective} certificate {r.upper_bound} gap {r.upper_bound - r.objective} t_best {tm['time_to_best']:.3f}s total {dt:.3f}s "
               f"launches {tm['launches']} bound launches {tm['bound_launches']} / {tm['bound_iters']} it, cx {tm['cx_calls']} ({tm['cx_gains']} gains), gens {tm['generations']}, "
-              f"lp {tm['lp_solves']} solves / {tm['lp_iters']} it", flush=True)
+              f"lp {tm['lp_solves']} solves / {tm['lp_iters']} it, rounded {lp['rounded']} adopted {lp['adopted']} fractional {lp['fractional_partitions']}", flush=True)
