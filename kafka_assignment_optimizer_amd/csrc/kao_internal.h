@@ -189,7 +189,7 @@ int lp_begin(LpCtx *c, double tol, int maxit, double pert = 0.0, uint32_t salt =
 int lp_enqueue(LpCtx *c, int k);
 int lp_poll(LpCtx *c, int *status, int *iterations);
 int lp_enqueue_mark(LpCtx *c, int k, int slot);                      // enqueue + a mark (ring slot 0..31) that lp_poll_mark waits for
-int lp_poll_mark(LpCtx *c, int slot, int *status, int *iterations);
+int lp_poll_mark(LpCtx *c, int slot, int *status, int *iterations, double deadline = 0);   // deadline (now_s() clock, 0 = none): past it the solve is aborted instead of waited for
 int lp_finish(LpCtx *c, int32_t *multipliers, double stats[8], double *trace);
 inline double lp_default_pert(const kao_topic *t) { const double e = 100.0 / ((double)t->n_partitions * t->rf); return e < 1e-2 ? e : 1e-2; }   // oracle/kao_lp.py default_pert
 int lp_primal(LpCtx *c, uint8_t *q, int32_t *zq);   // quantised primal iterate: q[(2 rf_cur + 2 R) * P] centi-units, zq[2 B] inflows (host memory)

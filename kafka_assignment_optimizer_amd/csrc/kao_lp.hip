@@ -27,6 +27,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "kao_host.h"
@@ -464,9 +466,14 @@ __global__ void __launch_bounds__(64) k_lp_chol_diag(const double *sc, double *S
     dg[0] = diag0[base + lane];
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
-        double a = row[j];
+        // (four partial sums: the dot product is a chain of up to 63 dependent f64 FMAs otherwise -- the tile is latency, not work)
+        double a = row[j], a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int k = 0; k < j; ++k) a -= row[k] * T[j][k];
+        for (int k = 0; k < j; ++k) {
+            const double pr = row[k] * T[j][k];
+            if ((k & 3) == 0) a -= pr; else if ((k & 3) == 1) a1 -= pr; else if ((k & 3) == 2) a2 -= pr; else a3 -= pr;
+        }
+        a += (a1 + a2) + a3;
         const double aj = __shfl(a, j, 64), d0 = __shfl(dg[0], j, 64);
         const double ljj = (aj > kLpPivotRel * d0) ? sqrt(aj) : kLpPivotBig;
         row[j] = lane == j ? ljj : a / ljj;       // (lanes above the diagonal hold garbage nobody reads)
@@ -477,9 +484,13 @@ __global__ void __launch_bounds__(64) k_lp_chol_diag(const double *sc, double *S
     double x[kNB];
 #pragma unroll
     for (int i = 0; i < kNB; ++i) {
-        double a = i == lane ? 1.0 : 0.0;
+        double a = i == lane ? 1.0 : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int k = 0; k < i; ++k) a -= T[i][k] * x[k];      // (x[k] = 0 for k < lane)
+        for (int k = 0; k < i; ++k) {      // (x[k] = 0 for k < lane)
+            const double pr = T[i][k] * x[k];
+            if ((k & 3) == 0) a -= pr; else if ((k & 3) == 1) a1 -= pr; else if ((k & 3) == 2) a2 -= pr; else a3 -= pr;
+        }
+        a += (a1 + a2) + a3;
         x[i] = i < lane ? 0.0 : a / T[i][i];
     }
     double *out = Linv + (size_t)kb * kNB * kNB;
@@ -1354,9 +1365,17 @@ int lp_enqueue_mark(LpCtx *cp, int k, int slot) {
     HIP_TRY(hipEventRecord(c.ev[slot & 7], c.st));
     return KAO_OK;
 }
-int lp_poll_mark(LpCtx *cp, int slot, int *status, int *iterations) {
+int lp_poll_mark(LpCtx *cp, int slot, int *status, int *iterations, double deadline) {
     LpCtx &c = *cp;
     HIP_TRY(hipSetDevice(c.device));
+    if (deadline > 0) {   // a bounded wait: past the deadline the stop flag goes up (what is still enqueued turns into no-ops) and the mark arrives at once
+        bool aborted = false;
+        while (hipEventQuery(c.ev[slot & 7]) == hipErrorNotReady) {
+            if (!aborted && now_s() >= deadline) { lp_abort(cp); aborted = true; }
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+        (void)hipGetLastError();
+    }
     HIP_TRY(hipEventSynchronize(c.ev[slot & 7]));
     const double *h = c.h_sc + (size_t)(1 + (slot & 31)) * kScN;
     if (status) *status = (int)h[SC_STOP];

@@ -173,8 +173,12 @@ struct SolveRun {
     // vertex, which rounds to an assignment (lp_round_assignment).  One solve gives the certificate and, nearly always, the optimum.
     bool lp_round_on = true;      // KAO_LP_ROUND=0: certificate only (the unperturbed LP, as in the first half of round 5)
     double lp_pert_env = -1.0;    // KAO_LP_PERT=<eps>: the perturbation (default min(1e-4, 1.5 / slots))
-    double lp_first_s = 1.8;      // huge topics: with at least this much time the LP runs straight after the first feasible incumbent
+    double lp_first_s = 1.8;      // huge topics: with at least this much time the LP runs straight after the first feasible incumbent,
+    double lp_alone_s = 2.5;      // with this much before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
     int lp_rounded = 0, lp_round_adopted = 0, lp_round_fractional = 0;
+    std::vector<char> lp_try, lp_certified;   // per topic: LP solves finished; the LP's certificate is in place (K-bound leaves the topic alone)
+    int lp_max_tries = 3;         // a rounded iterate that is not the optimum: up to two more solves, larger perturbation, other salts, primal side only
+    bool lp_retry_test = false;   // test hook KAO_LP_RETRY_TEST=1: the first rounded iterate is discarded
     std::vector<uint8_t> lp_q;
     std::vector<int32_t> lp_zq;
     std::vector<uint16_t> lp_buf, lp_fb;
@@ -185,8 +189,9 @@ struct SolveRun {
     }
     bool lp_huge_first = false;   // experiment hook KAO_LP_HUGE_FIRST=1: huge topics get their LP before anything else (the search waits for its prices)
     bool lp_possible(int i) const { return lp_on && !has_target && dual_iters > 0 && s->dual_ok[(size_t)i] && lp_state[(size_t)i] < 2; }
-    bool search_paused() const {   // a huge topic between its first feasible incumbent and the end of its LP
-        for (int i = 0; i < n; ++i) if (huge(i) && lp_possible(i) && (feasible(i) || (lp_huge_first && launches >= 1)) && !topic_done(i)) return true;
+    bool lp_alone() const { return lp_round_on && deadline - t0 >= lp_alone_s; }   // (a limit is an input, not the clock)
+    bool search_paused() const {   // a huge topic between its first feasible incumbent and the end of its LP -- from the start when the limit leaves room for the LP alone
+        for (int i = 0; i < n; ++i) if (huge(i) && lp_possible(i) && (feasible(i) || (lp_huge_first && launches >= 1) || lp_alone()) && !topic_done(i)) return true;
         return false;
     }
     int lp_on = 1, lp_per_launch = 2, lp_max_running = 2, lp_solves = 0, lp_iters = 0;
@@ -254,7 +259,7 @@ struct SolveRun {
         this->topics = topics;
         t_improved.assign((size_t)n, 0.0); t_cx.assign((size_t)n, 0.0); cx_seen.assign((size_t)n, ~0ull);
         cx_started.assign((size_t)n, {});
-        lp_ctx.assign((size_t)n, nullptr); lp_marks.assign((size_t)n, 0); lp_read.assign((size_t)n, 0); lp_all.assign((size_t)n, 0); lp_state.assign((size_t)n, 0); bound_merges.assign((size_t)n, 0); lp_tgt.assign((size_t)n, -1);
+        lp_ctx.assign((size_t)n, nullptr); lp_marks.assign((size_t)n, 0); lp_read.assign((size_t)n, 0); lp_all.assign((size_t)n, 0); lp_state.assign((size_t)n, 0); lp_try.assign((size_t)n, 0); lp_certified.assign((size_t)n, 0); bound_merges.assign((size_t)n, 0); lp_tgt.assign((size_t)n, -1);
         {   // test / experiment hooks: KAO_LP=0 switches KAO-LP off, KAO_LP_AFTER / KAO_LP_PER_LAUNCH / KAO_LP_MIN_SLOTS override the counts
             auto env_i = [](const char *name, int64_t dflt) { const char *e = std::getenv(name); return e && *e ? (int64_t)std::atoll(e) : dflt; };
             lp_on = (int)env_i("KAO_LP", 1);
@@ -263,8 +268,11 @@ struct SolveRun {
             lp_min_slots = env_i("KAO_LP_MIN_SLOTS", lp_min_slots);
             lp_huge_first = env_i("KAO_LP_HUGE_FIRST", 0) != 0;
             lp_round_on = env_i("KAO_LP_ROUND", 1) != 0;
+            lp_max_tries = env_i("KAO_LP_TRIES", 3);
+            lp_retry_test = env_i("KAO_LP_RETRY_TEST", 0) != 0;
             if (const char *e = std::getenv("KAO_LP_PERT")) lp_pert_env = std::atof(e);
             if (const char *e = std::getenv("KAO_LP_FIRST_S")) lp_first_s = std::atof(e);
+            if (const char *e = std::getenv("KAO_LP_ALONE_S")) lp_alone_s = std::atof(e);
         }
         cx_on = so.use_cycles >= 0;
         { const char *e = std::getenv("KAO_CX_EAGER"); cx_eager = e && e[0] == '1'; }
@@ -338,11 +346,11 @@ struct SolveRun {
             // it is hardly ever waited for); at the end of the solve the newest one
             if (final_call) {   // the newest mark of an LP that rides beside the launches; of one enqueued as a whole only the next (a bounded wait)
                 const int m = lp_all[(size_t)i] ? lp_read[(size_t)i] : lp_marks[(size_t)i] - 1;
-                if (m >= 0 && m < lp_marks[(size_t)i] && (rc = lp_poll_mark(lp_ctx[(size_t)i], m, &st, &it))) return rc;
+                if (m >= 0 && m < lp_marks[(size_t)i] && (rc = lp_poll_mark(lp_ctx[(size_t)i], m, &st, &it, deadline))) return rc;
                 if (!st) lp_abort(lp_ctx[(size_t)i]);
             } else if (lp_read[(size_t)i] < lp_marks[(size_t)i] && lp_marks[(size_t)i] - lp_read[(size_t)i] > (lp_all[(size_t)i] ? 0 : lp_lag)) {
                 const double tp0 = now_s();
-                if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it))) return rc;
+                if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it, lp_all[(size_t)i] ? deadline : 0.0))) return rc;   // (a huge topic's LP is enqueued as a whole: the wait ends at the deadline)
                 if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: mark %d of %d read in %.3f ms: %d iterations, stop %d\n", i, lp_read[(size_t)i] - 1, lp_marks[(size_t)i], (now_s() - tp0) * 1e3, it, st);
             }
             const bool open = feasible(i) ? objective(i) < s->ub[(size_t)i] : true;
@@ -361,6 +369,14 @@ struct SolveRun {
             lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; --running;
             if (rc) { lp_state[(size_t)i] = 3; continue; }
             lp_iters += it; ++lp_solves;
+            const bool primal_only = lp_try[(size_t)i]++ > 0;   // a retry: the certificate and the prices of the first solve stay
+            if (primal_only) {
+                lp_state[(size_t)i] = 2;
+                if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: solve %d (primal side only): %d iterations, launch %d\n", i, (int)lp_try[(size_t)i], it, launches);
+                if (have_primal && (rc = lp_round_and_adopt(i))) return rc;
+                if (!topic_done(i) && lp_try[(size_t)i] < (huge(i) ? std::min(2, lp_max_tries) : lp_max_tries)) lp_state[(size_t)i] = 0;
+                continue;
+            }
             if (s->bound_inflight && (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
             if ((rc = kao_session_set_dual_state(s, i, mult.data(), mult.data() + t.n_brokers, mult.data() + 2 * (size_t)t.n_brokers))) return rc;
             std::fill(lp_tgt.begin(), lp_tgt.end(), -1);
@@ -368,9 +384,10 @@ struct SolveRun {
             if ((rc = kao_session_bound_step(s, lp_tgt.data(), 1)) || (rc = kao_session_bounds(s, nullptr, nullptr, nullptr))) return rc;
             share_bounds();
             if (use_prices && (rc = kao_session_adopt_prices(s))) return rc;
-            lp_state[(size_t)i] = 2;
+            lp_state[(size_t)i] = 2; lp_certified[(size_t)i] = 1;
             if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: %d iterations, LP value %.4f, certificate %lld, launch %d\n", i, it, st8[2], (long long)s->ub[(size_t)i], launches);
-            if (have_primal && (rc = lp_round_and_adopt(i))) return rc;
+            if (have_primal && !(lp_retry_test && lp_try[(size_t)i] == 1) && (rc = lp_round_and_adopt(i))) return rc;
+            if (lp_round_on && !topic_done(i) && lp_try[(size_t)i] < (huge(i) ? std::min(2, lp_max_tries) : lp_max_tries)) lp_state[(size_t)i] = 0;   // not the optimum: once more, primal side only (huge topics: once; the search waits meanwhile)
         }
         if (final_call) return KAO_OK;
         // largest open topics first, at most `lp_max_running` at a time
@@ -384,10 +401,10 @@ struct SolveRun {
                     // primal side makes the fixpoint unnecessary
                     const bool cx_can = cx_on && cycle_supported(&topics[i]);
                     const bool lp_now = lp_round_on && deadline - t0 >= lp_first_s;
-                    if (!feasible(i) || (!lp_now && cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20))) continue;
+                    if (!lp_alone() && (!feasible(i) || (!lp_now && cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20)))) continue;
                 }
                 const int64_t slots = (int64_t)topics[i].n_partitions * topics[i].rf;
-                if (slots < lp_min_slots && (!feasible(i) || bound_merges[(size_t)i] < lp_after_small)) continue;
+                if (slots < lp_min_slots && !lp_try[(size_t)i] && (!feasible(i) || bound_merges[(size_t)i] < lp_after_small)) continue;
                 if (slots > best_slots) { best = i; best_slots = slots; }
             }
             if (best < 0) break;
@@ -395,8 +412,9 @@ struct SolveRun {
             rc = lp_open(&topics[best], &c);
             if (rc == KAO_ERR_UNSUPPORTED || rc == KAO_ERR_NOMEM) { lp_state[(size_t)best] = 3; continue; }
             if (rc) return rc;
-            const double pert = lp_pert_of(best);
-            if ((rc = lp_begin(c, pert > 0 ? 1e-10 : 1e-7, pert > 0 ? 200 : 120, pert, 0u))) { lp_close(c); return rc; }
+            const bool retry = lp_try[(size_t)best] > 0;   // primal side only: the larger perturbation of kao_lp_round, another salt
+            const double pert = retry ? lp_default_pert(&topics[best]) : lp_pert_of(best);
+            if ((rc = lp_begin(c, retry ? 1e-8 : (pert > 0 ? 1e-10 : 1e-7), pert > 0 ? 200 : 120, pert, (uint32_t)lp_try[(size_t)best]))) { lp_close(c); return rc; }
             lp_ctx[(size_t)best] = c; lp_state[(size_t)best] = 1; lp_marks[(size_t)best] = lp_read[(size_t)best] = 0; lp_all[(size_t)best] = 0; ++running;
             if (huge(best)) {   // the whole solve at once: 30 marks of four iterations (those behind the stop flag are no-ops)
                 for (int m = 0; m < (pert > 0 ? 50 : 30); ++m) if ((rc = lp_enqueue_mark(c, 4, lp_marks[(size_t)best]++))) return rc;
@@ -416,11 +434,16 @@ struct SolveRun {
         const uint16_t *fb = nullptr;
         int rc;
         if (gfeasible(i)) { lp_fb.resize(slots); if ((rc = session_topic_best(s, i, lp_fb.data()))) return rc; fb = lp_fb.data(); }
+        // fractional partitions take their heaviest options first (they follow the LP's mass and the inflows that are left); only when
+        // that breaks a band row do they keep the incumbent's rows instead (an incumbent far from the LP's vertex fits the inflows worse:
+        // drifted 1000 x 100,000, 9 fractional partitions: optimal with the options, 5 violations with the rows of the first feasible incumbent)
         int32_t rep[4] = {0, 0, 0, 0};
-        if ((rc = lp_round_assignment(&t, lp_q.data(), lp_zq.data(), fb, lp_buf.data(), rep))) return rc;
         int64_t obj = 0;
         int32_t viol[8] = {0};
-        if ((rc = kao_evaluate(&t, lp_buf.data(), &obj, viol))) return rc;
+        if ((rc = lp_round_assignment(&t, lp_q.data(), lp_zq.data(), nullptr, lp_buf.data(), rep)) || (rc = kao_evaluate(&t, lp_buf.data(), &obj, viol))) return rc;
+        if (viol[0] != 0 && fb && rep[0] > 0) {
+            if ((rc = lp_round_assignment(&t, lp_q.data(), lp_zq.data(), fb, lp_buf.data(), rep)) || (rc = kao_evaluate(&t, lp_buf.data(), &obj, viol))) return rc;
+        }
         ++lp_rounded; lp_round_fractional += rep[0];
         const bool better = viol[0] == 0 && (!gfeasible(i) || obj > gobjective(i));
         if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: rounded iterate: objective %lld violations %d (%d fractional partitions, %d beyond an inflow, %d rows from the incumbent) in %.3f ms%s\n",
@@ -528,7 +551,7 @@ struct SolveRun {
         bool any = false;
         for (int i = 0; i < n && !all_done; ++i) {
             const bool want = feasible(i) && objective(i) < s->ub[(size_t)i] && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i] &&
-                              !(s->dual_flags[(size_t)i] & 6) && lp_state[(size_t)i] != 2 &&   // (a topic KAO-LP has certified: K-bound cannot get below the LP value)
+                              !(s->dual_flags[(size_t)i] & 6) && !lp_certified[(size_t)i] &&   // (a topic KAO-LP has certified: K-bound cannot get below the LP value)
                               !(lp_state[(size_t)i] == 1 && lp_all[(size_t)i]);                // (a huge topic while its LP runs: the search is paused, prices have no reader)
             bool rest = false;
             if (want && det && bound_quiet[(size_t)i] >= bound_quiet_max &&

@@ -204,7 +204,10 @@ def test_solve_with_cycles_proves_the_drifted_1000_partition_topic(kao, ko):
             assert r.objective == want == r.upper_bound
 
 
-def test_solve_with_cycles_beats_plain_search_on_a_large_drifted_topic(kao, ko):
+def test_solve_with_cycles_beats_plain_search_on_a_large_drifted_topic(kao, ko, monkeypatch):
+    """(The search engines alone, KAO_LP_ROUND=0: since round 5 the rounded iterate of KAO-LP proves this topic in 0.25 s before
+    either of them matters -- tests/test_gpu_lp.py.)"""
+    monkeypatch.setenv("KAO_LP_ROUND", "0")
     pt, t = _drifted(ko, 500, 10, 10000)
     with_cx = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=2.0)[0]
     without = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=2.0, use_cycles=-1)[0]

@@ -569,9 +569,12 @@ def test_drifted_north_star_topic_gets_a_dual_certificate(kao, ko, kp):
     obj, viol = kp.port_eval(ot, r.assignment)
     assert viol[0] == 0 and obj == r.objective <= r.upper_bound
     assert tm["bound_iters"] > 0 and r.upper_bound < closed - 2000
-    # round 4 (KAO-CX after every launch in bulk rounds): gaps 155-183 of 782,6xx after 3 s on four runs, 201-279 after 1 s
-    assert r.upper_bound - r.objective <= 0.0004 * r.upper_bound, (r.objective, r.upper_bound)
-    r1 = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=1.0)[0]          # north_star: what one second buys
+    # round 4 (KAO-CX after every launch in bulk rounds): gaps 155-183 of 782,6xx after 3 s on four runs, 201-279 after 1 s.
+    # Round 5: with room for it (limit >= 1.8 s) the perturbed LP runs straight after the first feasible incumbent; its row duals give
+    # the certificate 782,512 and its rounded iterate an assignment of exactly that value: PROVEN in 1.65 s (GPU call 34)
+    assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", 782512, 782512), (r.status, r.objective, r.upper_bound)
+    assert kao.last_solve_lp()["adopted"] == 1 and tm["results_read_back"] < 2.5
+    r1 = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=1.0)[0]          # north_star: what one second buys (the LP alone needs 1.35 s: K-search, KAO-CX and K-bound as in round 4)
     obj1, viol1 = kp.port_eval(ot, r1.assignment)
     assert viol1[0] == 0 and obj1 == r1.objective <= r1.upper_bound
     assert r1.upper_bound - r1.objective <= 0.0006 * r1.upper_bound, (r1.objective, r1.upper_bound)
@@ -875,22 +878,21 @@ def test_further_kao_cx_starts(kao, ko, monkeypatch):
     they are counted in the solve's timing record, KAO_DET_CX_STARTS=0 switches them off, and on the second drift seed of the
     same shape (MILP optimum 14801, drift_scale.json rows_other_seeds) certificate and incumbent stay within two units."""
     t = _drift_topic(300, 6, 2000)
+    monkeypatch.setenv("KAO_LP_ROUND", "0")     # the search engines alone (with KAO-LP's rounded iterate the topic is proven before KAO-CX is called)
     r = kao.solve([t], seed=3, time_limit_s=20.0)[0]
     tm = kao.last_solve_timing()
     assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", 14826, 14826)
     assert 1 <= tm["cx_further_starts"] < tm["cx_calls"]
+    monkeypatch.delenv("KAO_LP_ROUND")
     other = load_golden("drift_scale.json")["rows_other_seeds"][0]
     from kafka_assignment_optimizer_amd import synthetic as sy
     t2 = sy.drift(sy.make_cluster(other["B"], other["R"], 1, other["P"], 3, [], []), 0.2, other["seed"])[0]
-    # round 5 (KAO-LP: the certificate 14801 after 11 interior-point iterations): every solver seed ends at 14801 or 14800 under the
-    # certificate 14801 inside 8 s, three to four of the five PROVEN (round 4: four, seed 3 a unit short; round 3: 14799 / 14801 / 14800)
-    n_proven = 0
+    # round 5, second half: the rounded iterate of the perturbed LP IS the optimum -- every solver seed proves 14801 (rounds 3-5 with the
+    # search engines alone: three to four seeds of five, the others a unit short after 8 s: VERDICT r04's open item)
     for seed in (1, 2, 3, 4, 5):
         r2 = kao.solve([t2], seed=seed, time_limit_s=8.0, stop_at_bound=1)[0]
-        assert r2.upper_bound == other["milp_objective"] and other["milp_objective"] - 1 <= r2.objective <= other["milp_objective"], (seed, r2.objective)
-        n_proven += r2.status == "OPTIMAL_PROVEN"
-    assert n_proven >= 3, n_proven   # (which seeds miss moves with every change of the schedule: 1, 2, 3, 5 proven with the LP after two K-bound merges,
-                                     #  three of five with the LP from the first launch; VERDICT r04's item -- one seed of five a unit short -- is still open)
+        assert (r2.status, r2.objective, r2.upper_bound) == ("OPTIMAL_PROVEN", other["milp_objective"], other["milp_objective"]), (seed, r2.status, r2.objective)
+    monkeypatch.setenv("KAO_LP_ROUND", "0")
     monkeypatch.setenv("KAO_DET_CX_STARTS", "0")
     kao.solve([t], seed=3, time_limit_s=20.0, max_launches=200)
     assert kao.last_solve_timing()["cx_further_starts"] == 0
@@ -1037,7 +1039,7 @@ def test_dual_bound_is_valid_and_closes_wide_family(kao, ko):
         assert not got["flags"] & 4 and got["bound"] >= c["objective"], c["seed"]
         closed += got["bound"] == c["objective"]
     print("wide family: closed", closed, "of", len(cases))
-    assert closed >= len(cases) - 4, (closed, len(cases))
+    assert closed >= len(cases) - 1, (closed, len(cases))   # 174 of 175 (round 5, GPU call 36)
 
 
 def test_solve_proves_wide_family(kao, ko):
@@ -1247,7 +1249,7 @@ def test_high_rf_golden_optima(kao, ko):
             assert kao.canonicalize(to_product_topic(ot), r.assignment).tolist() == ko.canonicalize(ot, np.array(c["assignment"])).tolist(), c["seed"]
             n_unique += 1
     print("high RF goldens: proven", n_proven, "of", n_opt)
-    assert n_opt >= 50 and n_proven >= n_opt - 2, (n_opt, n_proven)   # round 3: K-bound certifies RF 5..8 (it was n_opt // 3 on the closed-form bound)
+    assert n_opt >= 50 and n_proven == n_opt, (n_opt, n_proven)   # 62 of 62 (round 5, GPU call 36)   # round 3: K-bound certifies RF 5..8 (it was n_opt // 3 on the closed-form bound)
 
 
 # ------------------------------------------------------------------------------- broker weights and cluster-wide caps
@@ -1293,7 +1295,7 @@ def test_broker_weights_eval_and_replay_bit_exact(kao, ko, kp):
         n += 1
         n_proven += r.status == "OPTIMAL_PROVEN"
     print("broker-weight topics: proven", n_proven, "of", n)
-    assert n >= 5 and n_proven >= n - 1, (n, n_proven)   # round 3: K-bound prices weighted topics too
+    assert n >= 5 and n_proven == n, (n, n_proven)   # 10 of 10 (round 5, GPU call 36)   # round 3: K-bound prices weighted topics too
 
 
 def test_solve_capped_matches_the_exact_joint_optimum_on_toys(kao, ko):

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     declared -= {"kao_init(device", "kao_strerror"} - {"kao_strerror"}
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     lib = _ffi.load()  # raises if the .so is missing or lacks a symbol
-    assert lib.kao_version() == 102
+    assert lib.kao_version() == 103
     assert lib.kao_strerror(-3).decode().startswith("no usable HIP device")
 
 

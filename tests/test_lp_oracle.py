@@ -83,3 +83,47 @@ def test_structured_iteration_on_the_golden_families(ko, kp):
         assert b >= c["objective"], c["seed"]
         n += 1; exact += b == c["objective"]
     assert n >= 60 and exact >= n - 2, (n, exact)
+
+
+@pytest.mark.parametrize("B,R,P,dseed,optimum", [(100, 5, 1000, 1, 7430), (300, 6, 2000, 1, 14826), (300, 6, 2000, 2, 14801)])
+def test_perturbed_lp_rounds_to_the_milp_optimum(ko, kp, B, R, P, dseed, optimum):
+    """KAO-LP's primal side (round 5).  The optimal face of the model's LP (README.md:144-185 relaxed) is huge and the
+    interior-point iterate ends at its centre; with costs perturbed by eps * hash(variable) the iterate converges to ONE vertex,
+    and that vertex rounds (oracle/kao_lp.py round_primal) to an assignment the README's rows accept (ko.verify) whose objective
+    is the HiGHS MILP optimum of tests/golden/drift_scale.json (7430, 14826) / the second drift seed's (14801, the one K-search +
+    KAO-CX miss on one solver seed in five) -- for two salts.  A SMALL perturbation (what kao_solve uses) also keeps the
+    certificate: the exact dual value at its row duals still floors to the optimum."""
+    import kao_lp as kl
+    t = _drift_topic(ko, B, R, P, dseed)
+    for salt in (0, 1):
+        r = kl.port_solve(t, tol=1e-8, maxit=150, primal=True, pert=kl.default_pert(t), salt=salt)
+        assert r["status"] == 0
+        A, rep = kl.round_primal(t, *kl.primal_blocks(t, r["x"], r["xg"]))
+        obj, viol = ko.verify(t, A)
+        assert int(np.asarray(viol).sum()) == 0 and obj == optimum, (salt, obj, rep)
+        assert rep["over_inflow"] == 0 and rep["unplaced"] == 0
+    eps = min(1e-4, 1.5 / (P * 3))
+    r = kl.port_solve(t, tol=1e-10, maxit=200, primal=True, pert=eps)
+    assert r["status"] == 0 and math.floor(kl.exact_dual_value(t, r["a"], r["l"], r["g"]) + 1e-9) == optimum
+    A, rep = kl.round_primal(t, *kl.primal_blocks(t, r["x"], r["xg"]))
+    obj, viol = ko.verify(t, A)
+    assert int(np.asarray(viol).sum()) == 0 and obj == optimum, (obj, rep)
+
+
+def test_round_primal_without_a_vertex(ko, kp):
+    """An iterate far from a vertex (six iterations): most partitions are fractional.  Without a fallback they take their heaviest
+    options -- every row complete, leader first, no broker twice, one replica per rack where the model says so (rows C1, C2, C5,
+    C7 of README.md:148-180 hold; the band rows need not) --, with one they keep the fallback's rows."""
+    import kao_lp as kl
+    t = _drift_topic(ko, 100, 5, 1000)
+    r = kl.port_solve(t, tol=1e-8, maxit=6, primal=True, pert=kl.default_pert(t))
+    blocks = kl.primal_blocks(t, r["x"], r["xg"])
+    A, rep = kl.round_primal(t, *blocks)
+    assert rep["fractional"] > 100
+    _, viol = ko.verify(t, A)
+    v = [int(x) for x in np.asarray(viol)]
+    assert v[1] == 0 and v[2] == 0 and v[5] == 0 and v[7] == 0, v     # C1, C2, C5, C7
+    fb = np.tile(np.arange(3), (1000, 1))
+    A2, rep2 = kl.round_primal(t, *blocks, fallback=fb)
+    assert rep2["from_fallback"] == rep2["fractional"] == rep["fractional"]
+    assert int((A2 == fb).all(axis=1).sum()) >= rep2["fractional"]
