@@ -1362,7 +1362,7 @@ int lp_enqueue_mark(LpCtx *cp, int k, int slot) {
     if (rc) return rc;
     LpCtx &c = *cp;
     HIP_TRY(hipMemcpyAsync(c.h_sc + (size_t)(1 + (slot & 31)) * kScN, c.D.sc, sizeof(double) * kScN, hipMemcpyDeviceToHost, c.st));
-    HIP_TRY(hipEventRecord(c.ev[slot & 7], c.st));
+    HIP_TRY(hipEventRecord(c.ev[slot & 31], c.st));
     return KAO_OK;
 }
 int lp_poll_mark(LpCtx *cp, int slot, int *status, int *iterations, double deadline) {
@@ -1370,13 +1370,13 @@ int lp_poll_mark(LpCtx *cp, int slot, int *status, int *iterations, double deadl
     HIP_TRY(hipSetDevice(c.device));
     if (deadline > 0) {   // a bounded wait: past the deadline the stop flag goes up (what is still enqueued turns into no-ops) and the mark arrives at once
         bool aborted = false;
-        while (hipEventQuery(c.ev[slot & 7]) == hipErrorNotReady) {
+        while (hipEventQuery(c.ev[slot & 31]) == hipErrorNotReady) {
             if (!aborted && now_s() >= deadline) { lp_abort(cp); aborted = true; }
             std::this_thread::sleep_for(std::chrono::microseconds(100));
         }
         (void)hipGetLastError();
     }
-    HIP_TRY(hipEventSynchronize(c.ev[slot & 7]));
+    HIP_TRY(hipEventSynchronize(c.ev[slot & 31]));
     const double *h = c.h_sc + (size_t)(1 + (slot & 31)) * kScN;
     if (status) *status = (int)h[SC_STOP];
     if (iterations) *iterations = (int)h[SC_IT];

@@ -174,9 +174,11 @@ struct SolveRun {
     bool lp_round_on = true;      // KAO_LP_ROUND=0: certificate only (the unperturbed LP, as in the first half of round 5)
     double lp_pert_env = -1.0;    // KAO_LP_PERT=<eps>: the perturbation (default min(1e-4, 1.5 / slots))
     double lp_first_s = 1.8;      // huge topics: with at least this much time the LP runs straight after the first feasible incumbent,
+    double lp_solo_s = 1.0; int64_t lp_solo_slots = 32768;
     double lp_alone_s = 2.5;      // with this much before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
     int lp_rounded = 0, lp_round_adopted = 0, lp_round_fractional = 0;
     std::vector<char> lp_try, lp_certified;   // per topic: LP solves finished; the LP's certificate is in place (K-bound leaves the topic alone)
+    int lp_ahead = 4;             // huge topics: marks (of four iterations) kept enqueued ahead of the one being waited for
     int lp_max_tries = 3;         // a rounded iterate that is not the optimum: up to two more solves, larger perturbation, other salts, primal side only
     bool lp_retry_test = false;   // test hook KAO_LP_RETRY_TEST=1: the first rounded iterate is discarded
     std::vector<uint8_t> lp_q;
@@ -189,9 +191,13 @@ struct SolveRun {
     }
     bool lp_huge_first = false;   // experiment hook KAO_LP_HUGE_FIRST=1: huge topics get their LP before anything else (the search waits for its prices)
     bool lp_possible(int i) const { return lp_on && !has_target && dual_iters > 0 && s->dual_ok[(size_t)i] && lp_state[(size_t)i] < 2; }
-    bool lp_alone() const { return lp_round_on && deadline - t0 >= lp_alone_s; }   // (a limit is an input, not the clock)
+    // the LP alone on the GPU, before any K-search launch: huge topics when the limit leaves room for ~1.3 s of it, topics from
+    // lp_solo_slots replica slots (1000 x 30000: 0.56 s alone, 1.0 s two iterations per K-search launch) when it is at least a second
+    // (a limit is an input, not the clock: the schedule stays count-keyed)
+    bool solo(int i) const { return !huge(i) && (int64_t)topics[i].n_partitions * topics[i].rf >= lp_solo_slots; }
+    bool lp_alone(int i) const { return lp_round_on && ((huge(i) && deadline - t0 >= lp_alone_s) || (solo(i) && deadline - t0 >= lp_solo_s)); }
     bool search_paused() const {   // a huge topic between its first feasible incumbent and the end of its LP -- from the start when the limit leaves room for the LP alone
-        for (int i = 0; i < n; ++i) if (huge(i) && lp_possible(i) && (feasible(i) || (lp_huge_first && launches >= 1) || lp_alone()) && !topic_done(i)) return true;
+        for (int i = 0; i < n; ++i) if (lp_possible(i) && !topic_done(i) && ((huge(i) && (feasible(i) || (lp_huge_first && launches >= 1))) || lp_alone(i))) return true;
         return false;
     }
     int lp_on = 1, lp_per_launch = 2, lp_max_running = 2, lp_solves = 0, lp_iters = 0;
@@ -273,6 +279,8 @@ struct SolveRun {
             if (const char *e = std::getenv("KAO_LP_PERT")) lp_pert_env = std::atof(e);
             if (const char *e = std::getenv("KAO_LP_FIRST_S")) lp_first_s = std::atof(e);
             if (const char *e = std::getenv("KAO_LP_ALONE_S")) lp_alone_s = std::atof(e);
+            if (const char *e = std::getenv("KAO_LP_SOLO_S")) lp_solo_s = std::atof(e);
+            lp_solo_slots = env_i("KAO_LP_SOLO_SLOTS", 32768);
         }
         cx_on = so.use_cycles >= 0;
         { const char *e = std::getenv("KAO_CX_EAGER"); cx_eager = e && e[0] == '1'; }
@@ -350,7 +358,8 @@ struct SolveRun {
                 if (!st) lp_abort(lp_ctx[(size_t)i]);
             } else if (lp_read[(size_t)i] < lp_marks[(size_t)i] && lp_marks[(size_t)i] - lp_read[(size_t)i] > (lp_all[(size_t)i] ? 0 : lp_lag)) {
                 const double tp0 = now_s();
-                if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it, lp_all[(size_t)i] ? deadline : 0.0))) return rc;   // (a huge topic's LP is enqueued as a whole: the wait ends at the deadline)
+                if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it, lp_all[(size_t)i] ? deadline : 0.0))) return rc;   // (a huge topic's LP is waited for: the wait ends at the deadline)
+                if (lp_all[(size_t)i] && !st && lp_marks[(size_t)i] < 64 && (rc = lp_enqueue_mark(lp_ctx[(size_t)i], 4, lp_marks[(size_t)i]++))) return rc;
                 if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: mark %d of %d read in %.3f ms: %d iterations, stop %d\n", i, lp_read[(size_t)i] - 1, lp_marks[(size_t)i], (now_s() - tp0) * 1e3, it, st);
             }
             const bool open = feasible(i) ? objective(i) < s->ub[(size_t)i] : true;
@@ -401,7 +410,7 @@ struct SolveRun {
                     // primal side makes the fixpoint unnecessary
                     const bool cx_can = cx_on && cycle_supported(&topics[i]);
                     const bool lp_now = lp_round_on && deadline - t0 >= lp_first_s;
-                    if (!lp_alone() && (!feasible(i) || (!lp_now && cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20)))) continue;
+                    if (!lp_alone(i) && (!feasible(i) || (!lp_now && cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20)))) continue;
                 }
                 const int64_t slots = (int64_t)topics[i].n_partitions * topics[i].rf;
                 if (slots < lp_min_slots && !lp_try[(size_t)i] && (!feasible(i) || bound_merges[(size_t)i] < lp_after_small)) continue;
@@ -416,8 +425,9 @@ struct SolveRun {
             const double pert = retry ? lp_default_pert(&topics[best]) : lp_pert_of(best);
             if ((rc = lp_begin(c, retry ? 1e-8 : (pert > 0 ? 1e-10 : 1e-7), pert > 0 ? 200 : 120, pert, (uint32_t)lp_try[(size_t)best]))) { lp_close(c); return rc; }
             lp_ctx[(size_t)best] = c; lp_state[(size_t)best] = 1; lp_marks[(size_t)best] = lp_read[(size_t)best] = 0; lp_all[(size_t)best] = 0; ++running;
-            if (huge(best)) {   // the whole solve at once: 30 marks of four iterations (those behind the stop flag are no-ops)
-                for (int m = 0; m < (pert > 0 ? 50 : 30); ++m) if ((rc = lp_enqueue_mark(c, 4, lp_marks[(size_t)best]++))) return rc;
+            if (huge(best) || lp_alone(best)) {   // alone on the GPU and driven from here: a few marks of four iterations ahead, one more whenever one is read (iterations
+                // behind the stop flag are no-ops, but ~250 empty kernels each: enqueueing the whole solve left 0.1 s of them behind an early stop)
+                for (int m = 0; m < lp_ahead; ++m) if ((rc = lp_enqueue_mark(c, 4, lp_marks[(size_t)best]++))) return rc;
                 lp_all[(size_t)best] = 1;
             }
         }
