@@ -583,8 +583,11 @@ def main():
             "algorithmic_lds_served": {"bytes_per_launch": algo_per_launch, "gbps": algo_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
                                        "note": "SURVEY.md 8(d) algorithmic bytes = neighbours x (8*RF+10) B; they are served from LDS (the "
                                                "restart state is LDS-resident), NOT from HBM, so they are not priced against the HBM peak"},
-            "note": "achieved = HBM bytes per launch from the PMC counters / HIP-event launch time: the kernel touches HBM only to load and "
-                    "store restart states; it is bound by VALU issue (see roofline_valu_issue), not by HBM"}
+            "note": "achieved = HBM bytes per launch from the PMC counters / HIP-event launch time: the kernel touches HBM to load and store "
+                    "restart states (25 MB read x2 correction + 23 MB written per launch) and, since round 5's occupancy floor (80 VGPRs for 6 "
+                    "wavefronts per SIMD), to park ~20 VGPRs per lane in scratch around the iteration loop (+156 MB written per launch = 2.05 M "
+                    "lanes x 20 x 4 B; read back mostly from L2): 230 MB in 11.9 ms = 19 GB/s.  It is bound by VALU issue (see roofline_valu_issue), "
+                    "not by HBM"}
     if prof:
         roof["traffic"] = prof["k_search_hbm_bytes_per_launch"]
         roof["achieved"] = prof["k_search_hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9

@@ -1,25 +1,22 @@
 #!/bin/bash
-# round 5, call 39: north-star solves under limits of 3 / 2 / 1.5 / 1 s with the LP driven a few marks ahead; determinism + LP solve tests
+# round 5, call 40 (final evidence): whole suite, smoke, tools/profile.sh r05_zz (kernel trace + PMC passes of the bench), constants merged, bench with extras
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r05_c39
-timeout 600 python - > gpurun_out/${T}_solve.log 2>&1 <<'P'
-import sys, time
-sys.path.insert(0, '.')
-import kafka_assignment_optimizer_amd as kao
-from kafka_assignment_optimizer_amd import synthetic as sy
-kao.init(0)
-t = sy.north_star_topic('drift100k')
-kao.solve([t], seed=1, max_launches=1)
-for budget in (3.0, 2.0, 1.5, 1.0):
-    t0 = time.perf_counter(); r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=budget)[0]; dt = time.perf_counter() - t0
-    tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
-    print(f"drift100k limit {budget}: {r.status} objective {r.objective} certificate {r.upper_bound} gap {r.upper_bound - r.objective} t_best {tm['time_to_best']:.3f}s read back {tm['results_read_back']:.3f}s total {dt:.3f}s launches {tm['launches']} cx {tm['cx_calls']} lp {lp}", flush=True)
-t = sy.north_star_topic('drift30k')
-for budget in (3.0,):
-    t0 = time.perf_counter(); r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=budget)[0]; dt = time.perf_counter() - t0
-    tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
-    print(f"drift30k limit {budget}: {r.status} objective {r.objective} certificate {r.upper_bound} gap {r.upper_bound - r.objective} t_best {tm['time_to_best']:.3f}s read back {tm['results_read_back']:.3f}s total {dt:.3f}s launches {tm['launches']} cx {tm['cx_calls']} lp {lp}", flush=True)
+T=r05_zz
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/${T}_pytest.log; cat gpurun_out/${T}_pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/${T}_smoke.log
+timeout 1200 bash tools/profile.sh $T 10 > gpurun_out/${T}_profile_stdout.log 2>&1
+cp gpurun_out/prof_$T/summary.txt gpurun_out/${T}_final_rocprof_summary.txt
+python tools/merge_pmc.py $T | tee gpurun_out/${T}_merge.log
+cp profiles/pmc_constants.json gpurun_out/${T}_pmc_constants.json
+timeout 1500 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err; tail -c 600 gpurun_out/${T}_bench.err
+python - <<'P'
+import json
+b = json.load(open('gpurun_out/r05_zz_bench.json'))
+print({k: b[k] for k in ('value', 'ms_per_step', 'time_to_optimal_s')})
+print(b['roofline_valu_issue']['frac'], b['roofline_valu_issue']['valu_insts_per_neighbour'], b['roofline']['traffic'])
+for t in b['lp_certificate']['topics']: print(t['workload'], t['certificate'], round(t['interior_point_ms']), t['rounded_iterate'])
+for t in b['exactness_probe']['topics']: print({k: t[k] for k in t if k in ('brokers', 'partitions', 'status', 'objective', 'certificate', 'seconds', 'seconds_to_proof', 'budget_s')})
+for t in b['roofline_big_topic']['topics']: print(t['workload'], t.get('solve_3s'))
 P
-cat gpurun_out/${T}_solve.log | cut -c1-330
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_lp.py -m gpu -q -k "deterministic or north_star or solve_proves or retries" 2>&1 | tail -3
+find gpurun_out/prof_$T -name "*.db" -size +3M -delete; find gpurun_out/prof_$T -name "*.csv" -size +3M -delete
