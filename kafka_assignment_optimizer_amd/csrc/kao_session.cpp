@@ -1290,6 +1290,15 @@ int kao_lp_round(const kao_topic *t, double pert, uint32_t salt, double tol, int
     return KAO_OK;
 }
 
+int kao_lp_round_host(const kao_topic *t, const uint8_t *q, const int32_t *zq, int32_t use_fallback, uint16_t *assignment, int32_t rep[4]) {
+    if (!t || !q || !zq || !assignment) return fail(KAO_ERR_INVALID, "null argument");
+    int rc = validate(t);
+    if (rc) return rc;
+    std::vector<uint16_t> fb;
+    if (use_fallback) fb.assign(assignment, assignment + (size_t)t->n_partitions * t->rf);
+    return lp_round_assignment(t, q, zq, use_fallback ? fb.data() : nullptr, assignment, rep);
+}
+
 int kao_lp_trace(const kao_topic *t, double tol, int32_t max_iters, double *trace, double stats[8], int32_t *multipliers) {
     if (!t) return fail(KAO_ERR_INVALID, "null topic");
     int rc = require_init();

@@ -440,6 +440,18 @@ def lp_round(topic: Topic, pert: float = 0.0, salt: int = 0, tol: float = 0.0, m
                 ms_lp=float(st[5]), ms_round=float(st[6]), pert=float(st[7]))
 
 
+def lp_round_host(topic: Topic, q, zq, fallback=None) -> dict:
+    """Test hook (kao_lp_round_host): the host half of lp_round from a quantised iterate q [(2 rf_cur + 2 R), P] uint8, zq [2 B] int32."""
+    ct = _CTopics([topic])
+    n = topic.n_partitions * topic.rf
+    q = np.ascontiguousarray(q, dtype=np.uint8); zq = np.ascontiguousarray(zq, dtype=np.int32)
+    a = np.zeros(n, dtype=np.uint16) if fallback is None else np.ascontiguousarray(np.asarray(fallback).reshape(-1), dtype=np.uint16).copy()
+    rep = (C.c_int32 * 4)()
+    _check(_ffi.load().kao_lp_round_host(ct.ptr(0), q.ctypes.data_as(C.POINTER(C.c_uint8)), zq.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         0 if fallback is None else 1, a.ctypes.data_as(C.POINTER(C.c_uint16)), rep), "kao_lp_round_host")
+    return dict(assignment=a.reshape(topic.n_partitions, topic.rf), fractional=int(rep[0]), over_inflow=int(rep[1]), unplaced=int(rep[2]), from_fallback=int(rep[3]))
+
+
 def lp_trace(topic: Topic, tol: float = 0.0, max_iters: int = 80) -> dict:
     """Test hook (kao_lp_trace): the interior-point solve alone and its per-iterate trace (mu, primal, dual, pinf, dinf)."""
     ct = _CTopics([topic])

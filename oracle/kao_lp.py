@@ -292,6 +292,7 @@ def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80, primal: bool = F
 # ---- the primal side (round 5): from the iterate of the PERTURBED LP to an assignment ------------------------------------------
 # Specification of kao_lp_round (include/kao.h) / lp_round_assignment (kao_round.cpp): same quantisation, same order, same ties.
 
+MAX_SEARCH = 64        # more fractional partitions than this: no search over their rows (the iterate is far from a vertex)
 ROUND_TOL_C = 30       # a variable farther than 0.30 from an integer makes its partition "fractional"
 PERT_SLOTS = 100.0     # default perturbation: eps = min(1e-2, PERT_SLOTS / (partitions * rf))
 
@@ -317,40 +318,62 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
     """The compact LP pools the NEW replicas of a partition per rack (yf, yl) and counts what every broker receives (zf, zl): an
     integral solution still has to hand the new replicas of a rack to that rack's brokers.  Any way that respects the inflows and
     puts no broker twice into a partition (row C5, README.md:168-171) is as good as any other -- the objective (README.md:145-146)
-    only sees current replicas -- so: partitions in ascending order; kept current replicas first (leader: the lowest j with l_j = 1);
-    then racks in ascending order, the new leader of a rack before its new followers; a new replica goes to the broker of the rack
-    with the LARGEST remaining inflow that is not in the row yet (ties: the lowest index), to the lowest-index broker not in the row
-    when none has inflow left (`over_inflow`).  A partition with a variable farther than tolc / 100 from an integer, or whose row
-    comes out incomplete, is FRACTIONAL: it keeps its row of `fallback` (the incumbent) when there is one, else its heaviest options
-    (leader: the largest l_j, then the largest yl_r; followers by decreasing mass, current replicas before racks on ties).
+    only sees current replicas -- so:
+      * partitions in ascending order; kept current replicas first (leader: the lowest j with l_j = 1); then racks in ascending
+        order, the new leader of a rack before its new followers; a new replica goes to the broker of the rack with the LARGEST
+        remaining inflow that is not in the row yet (ties: the lowest index);
+      * when every broker with inflow left is in the row already, ONE swap is tried: an earlier partition of the rack that holds a
+        new replica of the same kind on a broker b' outside this row moves it to a broker with inflow left that is outside ITS row,
+        and b' goes to this partition (the first such b' in index order, the earliest such partition); failing that the replica goes
+        to the lowest-index broker of the rack outside the row (`over_inflow`);
+      * a partition with a variable farther than tolc / 100 from an integer, or whose row comes out incomplete, is FRACTIONAL: it
+        keeps its row of `fallback` (the incumbent) when there is one; else, after all others, it takes the row that fits the band
+        rows best given what the others left (README.md:158-166): candidates are its current replicas with any mass and, per rack
+        with new mass, the two brokers that need replicas most; rows over them are scored (broker over its band: -1000 each,
+        broker below its band / leader below the leader band: +10 each, centi-mass of the options / 100) and the best row wins
+        (ties: the first in enumeration order: leader candidates in candidate order, follower combinations lexicographic).
     Returns (A [P][RF] dense broker indices, leader first; report dict)."""
+    import itertools
     B, R, P, RF, NJ = t.n_brokers, t.n_racks, t.n_partitions, t.rf, t.rf_cur
-    phi = t.bounds()["prack_hi"]
-    rack = np.asarray(t.rack_of)
-    members = [[int(b) for b in np.nonzero(rack == r)[0]] for r in range(R)]
+    bd = t.bounds()
+    phi = bd["prack_hi"]
+    rack = [int(r) for r in np.asarray(t.rack_of)]
+    members = [[b for b in range(B) if rack[b] == r] for r in range(R)]
     capf = [int(v) for v in ZF]; capl = [int(v) for v in ZL]
     A = np.zeros((P, RF), dtype=np.int64)
-    rep = dict(fractional=0, over_inflow=0, unplaced=0, from_fallback=0)
+    rep = dict(fractional=0, over_inflow=0, unplaced=0, from_fallback=0, swaps=0)
+    placed = [[[], []] for _ in range(R)]      # per rack, per kind (0 follower, 1 leader): (partition, slot) of new replicas handed out
 
     def frac(c):
         return abs(int(c) - 100 * ((int(c) + 50) // 100)) > tolc
 
-    def take(r, cap, used):
+    def take(p, slot, r, kind, used):
+        cap = capl if kind else capf
         best = -1
         for b in members[r]:
             if cap[b] > 0 and b not in used and (best < 0 or cap[b] > cap[best]):
                 best = b
         if best >= 0:
             cap[best] -= 1
-            return best
+            return best, True
+        for b1 in members[r]:          # one swap
+            if b1 in used: continue
+            for (q, sq) in placed[r][kind]:
+                if int(A[q, sq]) != b1: continue
+                rowq = [int(x) for x in A[q]]
+                for b2 in members[r]:
+                    if cap[b2] > 0 and b2 not in rowq:
+                        cap[b2] -= 1; A[q, sq] = b2; rep["swaps"] += 1; swaps_now.append((q, sq, b1))
+                        return b1, True
         for b in members[r]:
             if b not in used:
                 rep["over_inflow"] += 1
-                return b
+                return b, False
         rep["unplaced"] += 1
-        return -1
+        return -1, False
 
     pending = []
+    swaps_now = []
     for p in range(P):
         cur = [int(b) if (int(b) != ko.NONE and int(b) < B) else -1 for b in t.current[p]]
         vals = [F[p, j] for j in range(NJ) if cur[j] >= 0] + [L[p, j] for j in range(NJ) if cur[j] >= 0] + list(YF[p]) + list(YL[p])
@@ -361,52 +384,137 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
             if cur[j] < 0: continue
             if lead < 0 and (int(L[p, j]) + 50) // 100 >= 1: lead = cur[j]
             elif (int(F[p, j]) + 50) // 100 >= 1: row.append(cur[j])
+        n_kept = len(row)
         used = set(row) | ({lead} if lead >= 0 else set())
-        # (a snapshot of the inflows: an incomplete row gives back what it took)
-        sf, sl, so, su = list(capf), list(capl), rep["over_inflow"], rep["unplaced"]
+        # the row is built in A[p] itself (a swap reads the rows of earlier partitions there); an incomplete row gives back what it took
+        sf, sl, so, su, ss = list(capf), list(capl), rep["over_inflow"], rep["unplaced"], rep["swaps"]
+        del swaps_now[:]
+        new_slots = []
+        ok = len(used) <= RF and len(row) <= RF - 1
+        A[p] = -1
         for r in range(R):
+            if not ok: break
             if lead < 0 and (int(YL[p, r]) + 50) // 100 >= 1:
-                b = take(r, capl, used)
-                if b >= 0: lead = b; used.add(b)
+                b, within = take(p, 0, r, 1, used)
+                if b >= 0:
+                    lead = b; used.add(b); A[p, 0] = b
+                    if within: new_slots.append((r, 1, 0))
             for _ in range((int(YF[p, r]) + 50) // 100):
                 if len(row) >= RF - 1: break
-                b = take(r, capf, used)
-                if b >= 0: row.append(b); used.add(b)
-        if lead < 0 or len(row) != RF - 1:
+                b, within = take(p, 1 + len(row), r, 0, used)
+                if b >= 0:
+                    row.append(b); used.add(b); A[p, len(row)] = b
+                    if within: new_slots.append((r, 0, len(row)))
+        if not ok or lead < 0 or len(row) != RF - 1:
             capf[:], capl[:] = sf, sl
-            rep["over_inflow"], rep["unplaced"] = so, su
+            for (q, sq, b1) in reversed(swaps_now): A[q, sq] = b1      # (the swaps made for this row are undone with it)
+            rep["over_inflow"], rep["unplaced"], rep["swaps"] = so, su, ss
             pending.append(p); continue
         A[p, 0] = lead; A[p, 1:] = row
+        for (r, kind, slot) in new_slots: placed[r][kind].append((p, slot))
     rep["fractional"] = len(pending)
-    for p in pending:
-        if fallback is not None:
+    done = np.ones(P, dtype=bool); done[pending] = False
+    load = np.zeros(B, dtype=np.int64); lead_load = np.zeros(B, dtype=np.int64)
+    for p in range(P):
+        if done[p]:
+            for k in range(RF): load[int(A[p, k])] += 1
+            lead_load[int(A[p, 0])] += 1
+    lo, hi, llo, lhi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"]
+    if fallback is not None:
+        for p in pending:
             A[p] = np.asarray(fallback[p]); rep["from_fallback"] += 1
-            continue
+        return A, rep
+    # ---- the fractional partitions, together: candidate rows from their support, chosen by a bounded depth-first search so that the
+    #      band rows (README.md:158-166) come out right given what the other partitions hold ----
+    w = t.weights
+    bwv = np.zeros(B, dtype=np.int64) if getattr(t, "broker_w", None) is None else np.asarray(t.broker_w, dtype=np.int64)
+    bwlv = np.zeros(B, dtype=np.int64) if getattr(t, "broker_wl", None) is None else np.asarray(t.broker_wl, dtype=np.int64)
+    rows_of = []
+    for p in pending:
         cur = [int(b) if (int(b) != ko.NONE and int(b) < B) else -1 for b in t.current[p]]
-        # leader: the heaviest option
-        opts = [(-int(L[p, j]), 0, j) for j in range(NJ) if cur[j] >= 0] + [(-int(YL[p, r]), 1, r) for r in range(R)]
-        opts.sort()
-        used = set(); lead = -1; per_rack = [0] * R
-        for m, kind, k in opts:
-            b = cur[k] if kind == 0 else take(k, capl, used)
-            if b >= 0:
-                lead = b; used.add(b); per_rack[int(rack[b])] += 1; break
-        opts = [(-int(F[p, j]), 0, j) for j in range(NJ) if cur[j] >= 0] + [(-int(YF[p, r]), 1, r) for r in range(R)]
-        opts.sort()
-        row = []
-        for rnd in range(2):    # second pass: anything that fits (all masses may sit on options already taken)
-            for m, kind, k in opts:
-                if len(row) >= RF - 1: break
-                if kind == 0:
-                    b = cur[k]
-                    if b in used or per_rack[int(rack[b])] >= phi: continue
-                else:
-                    if per_rack[k] >= phi: continue
-                    b = take(k, capf, used)
-                    if b < 0: continue
-                row.append(b); used.add(b); per_rack[int(rack[b])] += 1
-        while len(row) < RF - 1:   # (cannot happen on a feasible model: R * phi >= RF)
-            row.append(next(b for b in range(B) if b not in used)); used.add(row[-1])
-        A[p, 0] = lead if lead >= 0 else next(b for b in range(B) if b not in used)
-        A[p, 1:] = row
+        cand = []
+        for j in range(NJ):
+            if cur[j] >= 0 and (int(F[p, j]) > 0 or int(L[p, j]) > 0): cand.append(cur[j])
+        for r in range(R):
+            if int(YF[p, r]) > 0 or int(YL[p, r]) > 0:
+                best = sorted((b for b in members[r] if b not in cand and load[b] < hi), key=lambda b: (-(lo - int(load[b])), -(llo - int(lead_load[b])), b))[:3]
+                cand += best
+        cand = cand[:12]
+        if len(cand) < RF:      # (mass on too few options: the brokers that need replicas most)
+            for b in sorted((b for b in range(B) if b not in cand), key=lambda b: (-(lo - int(load[b])), b)):
+                cand.append(b)
+                if len(cand) >= RF + 2: break
+        wl = {}; wf = {}
+        for b in cand:
+            wf[b] = int(bwv[b]); wl[b] = int(bwv[b]) + int(bwlv[b])
+        for j, b in enumerate(cur):
+            if b >= 0 and b in wl: wl[b] += w[0 if j == 0 else 1][0]; wf[b] += w[0 if j == 0 else 1][1]
+        rows = []
+        for ld in cand:
+            others = [b for b in cand if b != ld]
+            for fol in itertools.combinations(others, RF - 1):
+                rowb = (ld,) + fol
+                cnt = {}
+                for b in rowb: cnt[rack[b]] = cnt.get(rack[b], 0) + 1
+                if max(cnt.values()) > phi: continue
+                rows.append((wl.get(ld, 0) + sum(wf.get(b, 0) for b in fol), rowb))
+        rows.sort(key=lambda x: -x[0])       # (stable: equal weights keep the enumeration order)
+        rows_of.append(rows[:64])
+    best = dict(viol=None, obj=None, pick=None); nodes = [0]
+    pick = [None] * len(pending)
+
+    def leaf_viol():
+        return int(np.maximum(lo - load, 0).sum() + np.maximum(llo - lead_load, 0).sum())
+
+    def dfs(i, obj):
+        if nodes[0] > 200000: return
+        nodes[0] += 1
+        if i == len(pending):
+            v = leaf_viol()
+            if best["viol"] is None or (v, -obj) < (best["viol"], -best["obj"]):
+                best.update(viol=v, obj=obj, pick=list(pick))
+            return
+        any_row = False
+        for wv, rowb in rows_of[i]:
+            if any(load[b] >= hi for b in rowb) or lead_load[rowb[0]] >= lhi: continue
+            any_row = True
+            for b in rowb: load[b] += 1
+            lead_load[rowb[0]] += 1
+            pick[i] = rowb
+            dfs(i + 1, obj + wv)
+            for b in rowb: load[b] -= 1
+            lead_load[rowb[0]] -= 1
+            if best["viol"] == 0 and nodes[0] > 20000: return
+        if not any_row and not rows_of[i]:
+            pick[i] = None
+            dfs(i + 1, obj)
+        if not any_row and rows_of[i]:      # every row breaks an upper band end: take the first, the violation is counted by K-eval
+            wv, rowb = rows_of[i][0]
+            for b in rowb: load[b] += 1
+            lead_load[rowb[0]] += 1
+            pick[i] = rowb
+            dfs(i + 1, obj + wv)
+            for b in rowb: load[b] -= 1
+            lead_load[rowb[0]] -= 1
+
+    if len(pending) > MAX_SEARCH:     # far from a vertex: no search, the first admissible row of every partition in turn
+        best["pick"] = []
+        for i in range(len(pending)):
+            ri = 0
+            for k, (wv, rowb) in enumerate(rows_of[i]):
+                if not (any(load[b] >= hi for b in rowb) or lead_load[rowb[0]] >= lhi):
+                    ri = k; break
+            if rows_of[i]:
+                rowb = rows_of[i][ri][1]
+                for b in rowb: load[b] += 1
+                lead_load[rowb[0]] += 1
+                best["pick"].append(rowb)
+            else:
+                best["pick"].append(None)
+    else:
+        dfs(0, 0)
+    rep["dfs_nodes"] = nodes[0]
+    for i, p in enumerate(pending):
+        rowb = best["pick"][i] if best["pick"] is not None and best["pick"][i] is not None else (rows_of[i][0][1] if rows_of[i] else tuple(range(RF)))
+        A[p] = rowb
     return A, rep

@@ -127,3 +127,40 @@ def test_round_primal_without_a_vertex(ko, kp):
     A2, rep2 = kl.round_primal(t, *blocks, fallback=fb)
     assert rep2["from_fallback"] == rep2["fractional"] == rep["fractional"]
     assert int((A2 == fb).all(axis=1).sum()) >= rep2["fractional"]
+
+
+def _pack(F, L, YF, YL, ZF, ZL):
+    return np.concatenate([F.T, L.T, YF.T, YL.T], axis=0).astype(np.uint8), np.concatenate([ZF, ZL]).astype(np.int32)
+
+
+def test_host_rounding_matches_the_specification(ko, kp):
+    """The product's host half of kao_lp_round (kao_round.cpp, reached through the test hook kao_lp_round_host: no device involved)
+    against the specification (oracle/kao_lp.py round_primal) on the scalar restatement's iterate: the same assignment, the same
+    counts -- RF 5..8 (two replicas per rack: C5 rows), the medium family, a drifted 1,000-partition topic; at a vertex (swaps, the
+    bounded search over the fractional partitions) and after five iterations (hundreds of fractional partitions: the greedy pass;
+    with and without fallback rows)."""
+    import kao_lp as kl
+    import kafka_assignment_optimizer_amd as kao
+    from conftest import to_product_topic
+    cases = [ko.random_case_rf(c["seed"]) for c in load_golden("random_rf.json")["cases"] if c["status"] == "optimal"][::2]
+    cases += [ko.topic_from_dict(c["topic"]) for c in load_golden("random_medium.json")["cases"] if c["status"] == "optimal"][::2]
+    cases.append(_drift_topic(ko, 100, 5, 1000))
+    n = n_search = n_swaps = 0
+    for t in cases:
+        for maxit in (150, 5):
+            r = kl.port_solve(t, tol=1e-8, maxit=maxit, primal=True, pert=kl.default_pert(t))
+            blocks = kl.primal_blocks(t, r["x"], r["xg"])
+            A, rep = kl.round_primal(t, *blocks)
+            q, zq = _pack(*blocks)
+            d = kao.lp_round_host(to_product_topic(t), q, zq)
+            assert d["assignment"].tolist() == A.tolist(), (t.name, maxit, rep)
+            assert (d["fractional"], d["over_inflow"], d["unplaced"]) == (rep["fractional"], rep["over_inflow"], rep["unplaced"])
+            n += 1; n_search += 0 < rep["fractional"] <= kl.MAX_SEARCH; n_swaps += rep["swaps"] > 0
+    t = cases[-1]
+    r = kl.port_solve(t, tol=1e-8, maxit=5, primal=True, pert=kl.default_pert(t))
+    blocks = kl.primal_blocks(t, r["x"], r["xg"])
+    fb = np.tile(np.array([97, 98, 99]), (t.n_partitions, 1))
+    A, rep = kl.round_primal(t, *blocks, fallback=fb)
+    d = kao.lp_round_host(to_product_topic(t), *_pack(*blocks), fallback=fb)
+    assert d["assignment"].tolist() == A.tolist() and d["from_fallback"] == rep["from_fallback"] == rep["fractional"] > 100
+    assert n >= 130 and n_search >= 5 and n_swaps >= 3, (n, n_search, n_swaps)
