@@ -16,10 +16,9 @@ namespace kao {
 
 namespace {
 constexpr int kTolC = 30;          // a variable farther than 0.30 from an integer makes its partition fractional
-constexpr int kMaxCand = 12;       // candidate brokers of a fractional partition
-constexpr int kMaxRows = 64;       // candidate rows kept per fractional partition (by objective weight)
-constexpr long kMaxNodes = 200000; // search nodes over the fractional partitions
-constexpr long kEnoughNodes = 20000;
+constexpr int kMaxCand = 16;       // candidate brokers of a fractional partition
+constexpr int kMaxRows = 256;      // candidate rows kept per fractional partition (by objective weight)
+constexpr long kMaxNodes = 100000; // search nodes over the fractional partitions
 constexpr int kMaxSearch = 64;     // more fractional partitions than this: the iterate is far from a vertex, no search
 constexpr uint16_t kUnset = 0xFFFFu;
 
@@ -167,7 +166,10 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                 if (la != lb) return la > lb;
                 return a < b;
             });
-            for (size_t k = 0; k < order.size() && k < 3; ++k) cand.push_back(order[k]);
+            size_t n_short = 0;
+            for (int b : order) n_short += load[(size_t)b] < lo;
+            const size_t keep = std::max<size_t>(2, std::min<size_t>(8, n_short));   // every broker of the rack that is below its band (up to 8), two at least
+            for (size_t k = 0; k < order.size() && k < keep; ++k) cand.push_back(order[k]);
         }
         if ((int)cand.size() > kMaxCand) cand.resize(kMaxCand);
         if ((int)cand.size() < RF) {   // (mass on too few options: the brokers that need replicas most)
@@ -239,11 +241,36 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
         }
         have_best = true;
     } else {
+        // cover[i][b] / lcover[i][b]: how many of the partitions i.. can still put a replica / their leader on broker b -- a deficit beyond
+        // that stays whatever the rest of the search does; wmax[i]: the most the partitions i.. can add to the objective
+        std::vector<int> shortb, lshortb;
+        for (int b = 0; b < B; ++b) { if (load[(size_t)b] < lo) shortb.push_back(b); if (lead_load[(size_t)b] < llo) lshortb.push_back(b); }
+        std::vector<std::vector<int>> cover(np + 1, std::vector<int>((size_t)B, 0)), lcover(np + 1, std::vector<int>((size_t)B, 0));
+        std::vector<long> wmax(np + 1, 0);
+        {
+            std::vector<char> seen((size_t)B), seenl((size_t)B);
+            for (size_t i = np; i-- > 0;) {
+                cover[i] = cover[i + 1]; lcover[i] = lcover[i + 1];
+                std::fill(seen.begin(), seen.end(), 0); std::fill(seenl.begin(), seenl.end(), 0);
+                for (const Row &rw : rows_of[i]) {
+                    for (int k = 0; k < rw.n; ++k) if (!seen[(size_t)rw.b[k]]) { seen[(size_t)rw.b[k]] = 1; cover[i][(size_t)rw.b[k]]++; }
+                    if (!seenl[(size_t)rw.b[0]]) { seenl[(size_t)rw.b[0]] = 1; lcover[i][(size_t)rw.b[0]]++; }
+                }
+                wmax[i] = wmax[i + 1] + (rows_of[i].empty() ? 0 : rows_of[i][0].w);
+            }
+        }
+        auto lower_bound = [&](size_t i) {
+            long v = 0;
+            for (int b : shortb) { const int d = lo - load[(size_t)b] - cover[i][(size_t)b]; if (d > 0) v += d; }
+            for (int b : lshortb) { const int d = llo - lead_load[(size_t)b] - lcover[i][(size_t)b]; if (d > 0) v += d; }
+            return v;
+        };
         auto leaf_viol = [&]() {
             long v = 0;
             for (int b = 0; b < B; ++b) { v += std::max(lo - load[(size_t)b], 0); v += std::max(llo - lead_load[(size_t)b], 0); }
             return v;
         };
+        bool perfect = false;
         std::function<void(size_t, long)> dfs = [&](size_t i, long obj) {
             if (nodes > kMaxNodes) return;
             ++nodes;
@@ -252,6 +279,9 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                 if (!have_best || v < best_viol || (v == best_viol && obj > best_obj)) { have_best = true; best_viol = v; best_obj = obj; best_pick = pick; }
                 return;
             }
+            const long lb = lower_bound(i);
+            if (perfect && lb > 0) return;   // (first pass: only completions that leave no broker below its band)
+            if (have_best && (lb > best_viol || (lb == best_viol && obj + wmax[i] <= best_obj))) return;   // cannot beat the best so far
             const std::vector<Row> &rows = rows_of[i];
             bool any = false;
             for (size_t k = 0; k < rows.size(); ++k) {
@@ -261,7 +291,6 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                 pick[i] = (int)k;
                 dfs(i + 1, obj + rows[k].w);
                 apply(rows[k], -1);
-                if (have_best && best_viol == 0 && nodes > kEnoughNodes) return;
             }
             if (!any && !rows.empty()) {   // every row breaks an upper band end: take the first, K-eval counts the violation
                 apply(rows[0], +1);
@@ -270,7 +299,12 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                 apply(rows[0], -1);
             } else if (!any) { pick[i] = -1; dfs(i + 1, obj); }
         };
+        perfect = true;
         dfs(0, 0);
+        if (!have_best || best_viol > 0) {   // no completion without a violation among the candidate rows (or not found in time): the least violated one
+            perfect = false; nodes = 0;
+            dfs(0, 0);
+        }
     }
     for (size_t i = 0; i < np; ++i) {
         const int p = pending[i];

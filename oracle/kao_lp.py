@@ -292,6 +292,9 @@ def port_solve(t: ko.Topic, tol: float = 1e-7, maxit: int = 80, primal: bool = F
 # ---- the primal side (round 5): from the iterate of the PERTURBED LP to an assignment ------------------------------------------
 # Specification of kao_lp_round (include/kao.h) / lp_round_assignment (kao_round.cpp): same quantisation, same order, same ties.
 
+MAX_CAND = 16          # candidate brokers of a fractional partition
+MAX_ROWS = 256         # candidate rows kept per fractional partition (by objective weight)
+MAX_NODES = 100000     # search nodes over the fractional partitions
 MAX_SEARCH = 64        # more fractional partitions than this: no search over their rows (the iterate is far from a vertex)
 ROUND_TOL_C = 30       # a variable farther than 0.30 from an integer makes its partition "fractional"
 PERT_SLOTS = 100.0     # default perturbation: eps = min(1e-2, PERT_SLOTS / (partitions * rf))
@@ -437,9 +440,10 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
             if cur[j] >= 0 and (int(F[p, j]) > 0 or int(L[p, j]) > 0): cand.append(cur[j])
         for r in range(R):
             if int(YF[p, r]) > 0 or int(YL[p, r]) > 0:
-                best = sorted((b for b in members[r] if b not in cand and load[b] < hi), key=lambda b: (-(lo - int(load[b])), -(llo - int(lead_load[b])), b))[:3]
-                cand += best
-        cand = cand[:12]
+                best = sorted((b for b in members[r] if b not in cand and load[b] < hi), key=lambda b: (-(lo - int(load[b])), -(llo - int(lead_load[b])), b))
+                n_short = sum(1 for b in best if load[b] < lo)
+                cand += best[:max(2, min(8, n_short))]      # every broker of the rack that is below its band (up to 8), two at least
+        cand = cand[:MAX_CAND]
         if len(cand) < RF:      # (mass on too few options: the brokers that need replicas most)
             for b in sorted((b for b in range(B) if b not in cand), key=lambda b: (-(lo - int(load[b])), b)):
                 cand.append(b)
@@ -459,21 +463,53 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
                 if max(cnt.values()) > phi: continue
                 rows.append((wl.get(ld, 0) + sum(wf.get(b, 0) for b in fol), rowb))
         rows.sort(key=lambda x: -x[0])       # (stable: equal weights keep the enumeration order)
-        rows_of.append(rows[:64])
-    best = dict(viol=None, obj=None, pick=None); nodes = [0]
+        rows_of.append(rows[:MAX_ROWS])
+    best = dict(viol=None, obj=None, pick=None); nodes = [0]; perfect = [False]
     pick = [None] * len(pending)
+    # cover[i][b] / lcover[i][b]: how many of the partitions i.. can still put a replica / their leader on broker b -- a deficit beyond that
+    # stays whatever the rest of the search does (the bound that keeps the search small on rigid bands)
+    npend = len(pending)
+    short = [b for b in range(B) if load[b] < lo]; lshort = [b for b in range(B) if lead_load[b] < llo]
+    cover = [dict.fromkeys(short, 0) for _ in range(npend + 1)]; lcover = [dict.fromkeys(lshort, 0) for _ in range(npend + 1)]
+    if npend <= MAX_SEARCH:
+        for i in range(npend - 1, -1, -1):
+            cover[i] = dict(cover[i + 1]); lcover[i] = dict(lcover[i + 1])
+            inrow = set(); leads = set()
+            for wv, rowb in rows_of[i]:
+                inrow.update(rowb); leads.add(rowb[0])
+            for b in inrow:
+                if b in cover[i]: cover[i][b] += 1
+            for b in leads:
+                if b in lcover[i]: lcover[i][b] += 1
+
+    wmax = [0] * (npend + 1)      # the most the partitions i.. can add to the objective
+    for i in range(npend - 1, -1, -1):
+        wmax[i] = wmax[i + 1] + (rows_of[i][0][0] if rows_of[i] else 0)
+
+    def lower_bound(i):
+        v = 0
+        for b in short:
+            d = lo - int(load[b]) - cover[i][b]
+            if d > 0: v += d
+        for b in lshort:
+            d = llo - int(lead_load[b]) - lcover[i][b]
+            if d > 0: v += d
+        return v
 
     def leaf_viol():
         return int(np.maximum(lo - load, 0).sum() + np.maximum(llo - lead_load, 0).sum())
 
     def dfs(i, obj):
-        if nodes[0] > 200000: return
+        if nodes[0] > MAX_NODES: return
         nodes[0] += 1
         if i == len(pending):
             v = leaf_viol()
             if best["viol"] is None or (v, -obj) < (best["viol"], -best["obj"]):
                 best.update(viol=v, obj=obj, pick=list(pick))
             return
+        lb = lower_bound(i)
+        if perfect[0] and lb > 0: return                  # (first pass: only completions that leave no broker below its band)
+        if best["viol"] is not None and (lb > best["viol"] or (lb == best["viol"] and obj + wmax[i] <= best["obj"])): return      # cannot beat the best so far
         any_row = False
         for wv, rowb in rows_of[i]:
             if any(load[b] >= hi for b in rowb) or lead_load[rowb[0]] >= lhi: continue
@@ -484,7 +520,6 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
             dfs(i + 1, obj + wv)
             for b in rowb: load[b] -= 1
             lead_load[rowb[0]] -= 1
-            if best["viol"] == 0 and nodes[0] > 20000: return
         if not any_row and not rows_of[i]:
             pick[i] = None
             dfs(i + 1, obj)
@@ -512,7 +547,11 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
             else:
                 best["pick"].append(None)
     else:
+        perfect[0] = True
         dfs(0, 0)
+        if best["viol"] is None or best["viol"] > 0:      # no completion without a violation among the candidate rows (or not found in time): the least violated one
+            perfect[0] = False; nodes[0] = 0
+            dfs(0, 0)
     rep["dfs_nodes"] = nodes[0]
     for i, p in enumerate(pending):
         rowb = best["pick"][i] if best["pick"] is not None and best["pick"][i] is not None else (rows_of[i][0][1] if rows_of[i] else tuple(range(RF)))

@@ -1,22 +1,20 @@
 #!/bin/bash
-# round 5, call 40 (final evidence): whole suite, smoke, tools/profile.sh r05_zz (kernel trace + PMC passes of the bench), constants merged, bench with extras
+# round 5, call 41: rounding v2 on the device's own iterates (north-star topic, three salts), LP tests, solve tests
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r05_zz
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/${T}_pytest.log; cat gpurun_out/${T}_pytest.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee gpurun_out/${T}_smoke.log
-timeout 1200 bash tools/profile.sh $T 10 > gpurun_out/${T}_profile_stdout.log 2>&1
-cp gpurun_out/prof_$T/summary.txt gpurun_out/${T}_final_rocprof_summary.txt
-python tools/merge_pmc.py $T | tee gpurun_out/${T}_merge.log
-cp profiles/pmc_constants.json gpurun_out/${T}_pmc_constants.json
-timeout 1500 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err; tail -c 600 gpurun_out/${T}_bench.err
-python - <<'P'
-import json
-b = json.load(open('gpurun_out/r05_zz_bench.json'))
-print({k: b[k] for k in ('value', 'ms_per_step', 'time_to_optimal_s')})
-print(b['roofline_valu_issue']['frac'], b['roofline_valu_issue']['valu_insts_per_neighbour'], b['roofline']['traffic'])
-for t in b['lp_certificate']['topics']: print(t['workload'], t['certificate'], round(t['interior_point_ms']), t['rounded_iterate'])
-for t in b['exactness_probe']['topics']: print({k: t[k] for k in t if k in ('brokers', 'partitions', 'status', 'objective', 'certificate', 'seconds', 'seconds_to_proof', 'budget_s')})
-for t in b['roofline_big_topic']['topics']: print(t['workload'], t.get('solve_3s'))
+T=r05_c41
+timeout 600 python - > gpurun_out/${T}_round.log 2>&1 <<'P'
+import sys, time
+sys.path.insert(0, '.')
+import kafka_assignment_optimizer_amd as kao
+from kafka_assignment_optimizer_amd import synthetic as sy
+kao.init(0)
+for which in ('drift100k', 'drift30k'):
+    t = sy.north_star_topic(which)
+    for salt in (0, 1, 2):
+        t0 = time.perf_counter(); r = kao.lp_round(t, salt=salt); w = time.perf_counter() - t0
+        print(f"{which} salt {salt} pert {r['pert']:.2e}: objective {r['objective']} violations {r['violations']} | {r['iterations']} it status {r['status']} {r['ms_lp']:.0f} ms, rounding {r['ms_round']:.1f} ms, fractional {r['fractional']}, over inflow {r['over_inflow']}, wall {w:.2f} s", flush=True)
 P
-find gpurun_out/prof_$T -name "*.db" -size +3M -delete; find gpurun_out/prof_$T -name "*.csv" -size +3M -delete
+cat gpurun_out/${T}_round.log | cut -c1-250
+SALTS=0,1,2 timeout 600 python tools/r5_round_probe.py 500x10x5000 500x10x10000 450x9x3500 >> gpurun_out/${T}_round.log 2>&1; tail -9 gpurun_out/${T}_round.log | cut -c1-250
+timeout 900 python -m pytest tests/test_gpu_lp.py -m gpu -q -s 2>&1 | grep -E "passed|failed|FAILED|golden families"
