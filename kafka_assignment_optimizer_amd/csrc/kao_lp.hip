@@ -617,6 +617,81 @@ __global__ void __launch_bounds__(1024) k_lp_trsv(const double *sc, const double
     for (int i = t; i < n; i += 1024) r[i] = xv[i];
 }
 
+// The same two solves by one workgroup PER ROW TILE (round 5, second half).  The single workgroup above pulls the whole factor (17 MB at
+// 2,060 rows) through one compute unit's memory path: 0.93 ms, 21 % of an iteration at 100,000 partitions.  Here workgroup i owns row tile
+// i: forward it subtracts L_ij x_j for j = 0 .. i-1 as the x_j are PUBLISHED by their owners (a flag per tile, release / acquire at agent
+// scope; the tile L_ij is loaded into registers before the flag is waited for), then x_i = Linv_ii acc is published; backward the same
+// with j = nt-1 .. i+1 on the tiles of L^T.  The critical path is 2 nt steps of two register-resident 64 x 64 products; everything else
+// runs beside it.  All nt workgroups are resident at once (nt <= 160); a workgroup only ever waits for workgroups that were dispatched
+// before it (forward: lower indices; backward: everyone has started).  Every sum has a fixed order: the same bits on every run.
+// flags[2 nt] are zeroed by a memset in front of the launch; ztmp[n] carries the forward result.
+__global__ void __launch_bounds__(256) k_lp_trsv_mw(const double *sc, const double *S, int n, double *r, const double *Linv, double *ztmp, int *flags) {
+    if (sc[SC_STOP] != 0.0) return;
+    __shared__ double acc[kNB], xj[kNB], part[4][kNB];
+    const int t = threadIdx.x, a = t & 63, kq = t >> 6, i = blockIdx.x, nt = n / kNB;
+    const double *inv = Linv + (size_t)i * kNB * kNB;
+    auto wait_flag = [&](int *f) {
+        if (t == 0) while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    };
+    auto publish = [&](int *f) {   // (the values were written and fenced by the first wavefront; every thread passes the barrier first)
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(f, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // one tile step: acc[a] -= sum_k tile(a, k) * x[k], this thread's quarter of the k range, tile element (a, k) at base + k * ks + a * as
+    auto tile_load = [&](const double *base, size_t ks, size_t as, double v[16]) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(base + (size_t)(kq * 16 + u) * ks + (size_t)a * as);
+    };
+    auto tile_apply = [&](const double v[16], bool subtract) {
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) { p0 += v[u] * xj[kq * 16 + u]; p1 += v[u + 1] * xj[kq * 16 + u + 1]; }
+        part[kq][a] = p0 + p1;
+        __syncthreads();
+        if (t < kNB) { const double sum = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]); acc[t] = subtract ? acc[t] - sum : sum; }
+        __syncthreads();
+    };
+    // ---- forward: L z = r ----
+    if (t < kNB) acc[t] = r[(size_t)i * kNB + t];
+    __syncthreads();
+    for (int j = 0; j < i; ++j) {
+        double v[16];
+        tile_load(S + (size_t)j * kNB * n + (size_t)i * kNB, (size_t)n, 1, v);        // L[i*64 + a][j*64 + k] from the upper copy: consecutive lanes, consecutive a
+        wait_flag(flags + j);
+        if (t < kNB) xj[t] = __hip_atomic_load(ztmp + (size_t)j * kNB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        tile_apply(v, true);
+    }
+    {
+        double v[16];
+        tile_load(inv, 1, (size_t)kNB, v);                                             // Linv[a][k] (lower triangular: zeros above the diagonal)
+        if (t < kNB) xj[t] = acc[t];
+        __syncthreads();
+        tile_apply(v, false);
+        if (t < kNB) { ztmp[(size_t)i * kNB + t] = acc[t]; __threadfence(); }
+        publish(flags + i);
+    }
+    // ---- backward: L^T x = z ----  (acc holds z_i)
+    for (int j = nt - 1; j > i; --j) {
+        double v[16];
+        tile_load(S + (size_t)j * kNB * n + (size_t)i * kNB, (size_t)n, 1, v);        // L^T[i*64 + a][j*64 + k] = L[j*64 + k][i*64 + a]: the lower triangle itself
+        wait_flag(flags + nt + j);
+        if (t < kNB) xj[t] = __hip_atomic_load(r + (size_t)j * kNB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        tile_apply(v, true);
+    }
+    {
+        double v[16];
+        tile_load(inv, (size_t)kNB, 1, v);                                             // Linv^T[a][k] = Linv[k][a]
+        if (t < kNB) xj[t] = acc[t];
+        __syncthreads();
+        tile_apply(v, false);
+        if (t < kNB) { r[(size_t)i * kNB + t] = acc[t]; __threadfence(); }
+        publish(flags + nt + i);
+    }
+}
+
 // ---- rows of A z ------------------------------------------------------------------------------------------------------
 // local rows; mode 0: out = A z, 1: out = b - A z, 2: out = A z + add
 __global__ void k_lp_A_local(LpDev D, const double *z, RowVec out, int mode, RowVec add) {
@@ -1021,6 +1096,7 @@ struct LpCtx {
     double *fj = nullptr, *fr = nullptr, *ti = nullptr, *S = nullptr, *Linv = nullptr, *diag0 = nullptr, *cb = nullptr, *cr = nullptr;
     double *rec = nullptr, *redA = nullptr, *redB = nullptr, *redC = nullptr, *part = nullptr, *ylast = nullptr, *trace = nullptr;
     int32_t *d_mult = nullptr, *d_zq = nullptr;
+    int *trsv_flags = nullptr; double *trsv_z = nullptr; bool trsv_mw = true;   // the triangular solves by one workgroup per row tile (KAO_LP_TRSV_MW=0: by one workgroup)
     uint8_t *d_q = nullptr;   // quantised primal iterate (lp_primal)
     int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
     int maxit = 80, trace_cap = 0;
@@ -1105,7 +1181,11 @@ void lp_solve_normal(LpCtx &c, const RowVec &v, const VarVec &z, const double *a
     const LpDev &D = c.D;
     hipLaunchKernelGGL(k_lp_elim_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, c.cb, c.cr);
     lp_rows_coupling(c, z, v.rc, add_rc ? 2 : 0, add_rc, c.cb, c.cr);
-    hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, D.sc, c.S, D.mcp, v.rc, c.Linv);
+    if (c.trsv_mw) {
+        (void)hipMemsetAsync(c.trsv_flags, 0, sizeof(int) * 2 * (size_t)(D.mcp / kNB), c.st);
+        hipLaunchKernelGGL(k_lp_trsv_mw, dim3(D.mcp / kNB), dim3(256), 0, c.st, D.sc, c.S, D.mcp, v.rc, c.Linv, c.trsv_z, c.trsv_flags);
+    } else
+        hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, D.sc, c.S, D.mcp, v.rc, c.Linv);
     hipLaunchKernelGGL(k_lp_back_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v);
 }
 
@@ -1229,8 +1309,10 @@ int lp_open(const kao_topic *t, LpCtx **out) {
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
         (rc = c->alloc(&c->part, (size_t)c->rack_blocks * n2 * n2)) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
+        (rc = c->alloc(&c->trsv_flags, (size_t)2 * (D.mcp / kNB))) || (rc = c->alloc(&c->trsv_z, (size_t)D.mcp)) ||
         (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
+    { const char *e = std::getenv("KAO_LP_TRSV_MW"); c->trsv_mw = !(e && e[0] == '0') && D.mcp / kNB <= 160; }
     // dynamic LDS beyond 64 KiB has to be enabled per kernel
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_rack), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
