@@ -320,6 +320,41 @@ __global__ void k_lp_schur_broker(LpDev D, const double *th, const double *thg, 
     double *rowA = lds_rows + (size_t)wave * 2 * mc, *rowB = rowA + mc;
     for (int i = lane; i < 2 * mc; i += 64) rowA[i] = 0.0;
     const int r0 = D.rack[b], nc = 2 * NJ + 2 * R;
+    if (nc <= 64) {
+        // Every lane owns one column of an incidence; FOUR incidences are fetched before the first is added to the rows (round 5, second
+        // half): an incidence is a chain of three dependent global round trips (the incidence word, the partition's factors, the column's
+        // factors) and a broker has ~300 of them at 100,000 partitions -- 1.37 ms of an 8.8-ms iteration with one chain in flight.  The adds
+        // reach every column in incidence order as before: the same bits.
+        struct Inc { bool ok; int col; double v3, v4; };
+        auto fetch = [&](int e, Inc &o) {
+            const int idx = D.inc[e], p = idx >> 3, j0 = idx & 7;
+            const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
+            PCol a3, a4, q;
+            lp_col(D, th, fj, fr, p, 2 * j0, a3);
+            lp_col(D, th, fj, fr, p, 2 * j0 + 1, a4);
+            const double w30 = i11 * a3.v0 + i12 * a3.v1, w31 = i12 * a3.v0 + i22 * a3.v1;
+            const double w40 = i11 * a4.v0 + i12 * a4.v1, w41 = i12 * a4.v0 + i22 * a4.v1;
+            const double d0 = fr[((size_t)0 * R + r0) * P + p];
+            const int c = lane;
+            o.ok = c < nc && lp_col(D, th, fj, fr, p, c, q);
+            if (!o.ok) return;
+            double v3 = -(w30 * q.v0 + w31 * q.v1), v4 = -(w40 * q.v0 + w41 * q.v1);
+            if (q.rk == r0) {
+                v3 -= a3.eps * q.eps / d0; v4 -= a4.eps * q.eps / d0;
+                if (c == 2 * j0) { v3 += a3.dg; v4 += a4.m1; }
+                else if (c == 2 * j0 + 1) { v3 += a4.m1; v4 += a4.dg; }
+            }
+            o.col = q.col; o.v3 = v3; o.v4 = v4;
+        };
+        const int e1 = D.inc_off[b + 1];
+        for (int e = D.inc_off[b]; e < e1; e += 4) {
+            Inc q4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { q4[u].ok = false; if (e + u < e1) fetch(e + u, q4[u]); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (q4[u].ok) { rowA[q4[u].col] += q4[u].v3; rowB[q4[u].col] += q4[u].v4; }
+        }
+    } else
     for (int e = D.inc_off[b]; e < D.inc_off[b + 1]; ++e) {
         const int idx = D.inc[e], p = idx >> 3, j0 = idx & 7;
         const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];

@@ -315,6 +315,83 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     }
     if (rep) { rep[1] = over; rep[2] = unplaced; rep[3] = from_fb; }
     (void)swaps;
+    // ---- what the completion of a half-integral vertex leaves: a few brokers one replica (or one leadership) over their band, as many
+    //      under it.  Moves that cost nothing put that right (specification: oracle/kao_lp.py repair_bands) ----
+    {
+        std::fill(load.begin(), load.end(), 0); std::fill(lead_load.begin(), lead_load.end(), 0);
+        for (int p = 0; p < P; ++p) { for (int k = 0; k < RF; ++k) load[out[(size_t)p * RF + k]]++; lead_load[out[(size_t)p * RF]]++; }
+        bool fine = true;
+        for (int b = 0; b < B && fine; ++b) fine = load[(size_t)b] >= lo && load[(size_t)b] <= hi && lead_load[(size_t)b] >= llo && lead_load[(size_t)b] <= lhi;
+        if (!fine) {
+            auto wts = [&](int p, int b, int &wlo, int &wfo) {
+                wlo = (t->broker_w ? t->broker_w[b] : 0) + (t->broker_wl ? t->broker_wl[b] : 0); wfo = t->broker_w ? t->broker_w[b] : 0;
+                for (int j = 0; j < NJ; ++j)
+                    if ((int)t->current[(size_t)p * NJ + j] == b) { wlo += t->w[j == 0 ? 0 : 1][0]; wfo += t->w[j == 0 ? 0 : 1][1]; }
+            };
+            std::vector<int> overb;
+            bool any_under = false;
+            for (int b = 0; b < B; ++b) { if (load[(size_t)b] > hi) overb.push_back(b); any_under |= load[(size_t)b] < lo; }
+            if (!overb.empty() || any_under) {
+                std::vector<char> is_src((size_t)B, 0);
+                for (int b : overb) is_src[(size_t)b] = 1;
+                std::vector<std::vector<std::pair<int, int>>> holds((size_t)B);
+                for (int p = 0; p < P; ++p)
+                    for (int k = 1; k < RF; ++k) { const int b = out[(size_t)p * RF + k]; if (is_src[(size_t)b]) holds[(size_t)b].emplace_back(p, k); }
+                std::vector<int> targets;
+                for (int b1 : overb) {
+                    while (load[(size_t)b1] > hi) {
+                        bool moved = false;
+                        targets.clear();
+                        for (int b = 0; b < B; ++b) if (load[(size_t)b] < lo) targets.push_back(b);
+                        if (targets.empty()) for (int b = 0; b < B; ++b) if (load[(size_t)b] < hi && b != b1) targets.push_back(b);
+                        std::stable_sort(targets.begin(), targets.end(), [&](int a, int b) {
+                            const bool oa = t->rack_of[a] != t->rack_of[b1], ob = t->rack_of[b] != t->rack_of[b1];
+                            return oa != ob ? !oa : a < b;
+                        });
+                        for (int b2 : targets) {
+                            for (auto &h : holds[(size_t)b1]) {
+                                const int p = h.first, k = h.second;
+                                if (out[(size_t)p * RF + k] != (uint16_t)b1) continue;
+                                if (in_row(p, b2)) continue;
+                                int wl1, wf1, wl2, wf2; wts(p, b1, wl1, wf1); wts(p, b2, wl2, wf2);
+                                if (wf1 != wf2) continue;
+                                if (t->rack_of[b2] != t->rack_of[b1]) {
+                                    int cnt = 0;
+                                    for (int m = 0; m < RF; ++m) cnt += t->rack_of[out[(size_t)p * RF + m]] == t->rack_of[b2];
+                                    if (cnt >= phi) continue;
+                                }
+                                out[(size_t)p * RF + k] = (uint16_t)b2; load[(size_t)b1]--; load[(size_t)b2]++; moved = true;
+                                break;
+                            }
+                            if (moved) break;
+                        }
+                        if (!moved) break;
+                    }
+                }
+            }
+            std::vector<int> overl;
+            for (int b = 0; b < B; ++b) if (lead_load[(size_t)b] > lhi) overl.push_back(b);
+            for (int b1 : overl) {
+                while (lead_load[(size_t)b1] > lhi) {
+                    bool moved = false, under = false;
+                    for (int b = 0; b < B && !under; ++b) under = lead_load[(size_t)b] < llo;
+                    const int cap2 = under ? llo : lhi;   // the taker is below its band when anyone is, else below the upper end
+                    for (int p = 0; p < P && !moved; ++p) {
+                        if (out[(size_t)p * RF] != (uint16_t)b1) continue;
+                        for (int k = 1; k < RF; ++k) {
+                            const int b2 = out[(size_t)p * RF + k];
+                            if (lead_load[(size_t)b2] >= cap2) continue;
+                            int wl1, wf1, wl2, wf2; wts(p, b1, wl1, wf1); wts(p, b2, wl2, wf2);
+                            if (wl1 + wf2 != wl2 + wf1) continue;
+                            out[(size_t)p * RF] = (uint16_t)b2; out[(size_t)p * RF + k] = (uint16_t)b1; lead_load[(size_t)b1]--; lead_load[(size_t)b2]++; moved = true;
+                            break;
+                        }
+                    }
+                    if (!moved) break;
+                }
+            }
+        }
+    }
     return KAO_OK;
 }
 

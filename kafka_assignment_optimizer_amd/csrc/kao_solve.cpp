@@ -173,11 +173,12 @@ struct SolveRun {
     // vertex, which rounds to an assignment (lp_round_assignment).  One solve gives the certificate and, nearly always, the optimum.
     bool lp_round_on = true;      // KAO_LP_ROUND=0: certificate only (the unperturbed LP, as in the first half of round 5)
     double lp_pert_env = -1.0;    // KAO_LP_PERT=<eps>: the perturbation (default min(1e-4, 1.5 / slots))
-    double lp_first_s = 1.8;      // huge topics: with at least this much time the LP runs straight after the first feasible incumbent,
+    double lp_first_s = 1.3;      // huge topics: with at least this much time the LP runs straight after the first feasible incumbent,
     double lp_solo_s = 1.0; int64_t lp_solo_slots = 32768;
-    double lp_alone_s = 2.5;      // with this much before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
+    double lp_alone_s = 1.5;      // with this much before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
     int lp_rounded = 0, lp_round_adopted = 0, lp_round_fractional = 0;
     std::vector<char> lp_try, lp_certified;   // per topic: LP solves finished; the LP's certificate is in place (K-bound leaves the topic alone)
+    double lp_tol = 1e-10;        // stopping tolerance of the perturbed solve (KAO_LP_TOL)
     int lp_ahead = 4;             // huge topics: marks (of four iterations) kept enqueued ahead of the one being waited for
     int lp_max_tries = 3;         // a rounded iterate that is not the optimum: up to two more solves, larger perturbation, other salts, primal side only
     bool lp_retry_test = false;   // test hook KAO_LP_RETRY_TEST=1: the first rounded iterate is discarded
@@ -275,6 +276,7 @@ struct SolveRun {
             lp_huge_first = env_i("KAO_LP_HUGE_FIRST", 0) != 0;
             lp_round_on = env_i("KAO_LP_ROUND", 1) != 0;
             lp_max_tries = env_i("KAO_LP_TRIES", 3);
+            if (const char *e = std::getenv("KAO_LP_TOL")) lp_tol = std::atof(e);
             lp_retry_test = env_i("KAO_LP_RETRY_TEST", 0) != 0;
             if (const char *e = std::getenv("KAO_LP_PERT")) lp_pert_env = std::atof(e);
             if (const char *e = std::getenv("KAO_LP_FIRST_S")) lp_first_s = std::atof(e);
@@ -423,7 +425,7 @@ struct SolveRun {
             if (rc) return rc;
             const bool retry = lp_try[(size_t)best] > 0;   // primal side only: the larger perturbation of kao_lp_round, another salt
             const double pert = retry ? lp_default_pert(&topics[best]) : lp_pert_of(best);
-            if ((rc = lp_begin(c, retry ? 1e-8 : (pert > 0 ? 1e-10 : 1e-7), pert > 0 ? 200 : 120, pert, (uint32_t)lp_try[(size_t)best]))) { lp_close(c); return rc; }
+            if ((rc = lp_begin(c, retry ? 1e-8 : (pert > 0 ? lp_tol : 1e-7), pert > 0 ? 200 : 120, pert, (uint32_t)lp_try[(size_t)best]))) { lp_close(c); return rc; }
             lp_ctx[(size_t)best] = c; lp_state[(size_t)best] = 1; lp_marks[(size_t)best] = lp_read[(size_t)best] = 0; lp_all[(size_t)best] = 0; ++running;
             if (huge(best) || lp_alone(best)) {   // alone on the GPU and driven from here: a few marks of four iterations ahead, one more whenever one is read (iterations
                 // behind the stop flag are no-ops, but ~250 empty kernels each: enqueueing the whole solve left 0.1 s of them behind an early stop)
@@ -467,6 +469,14 @@ struct SolveRun {
         i_improved[(size_t)i] = iters_done;
         if (key < keys[(size_t)i]) { keys[(size_t)i] = prev[(size_t)i] = key; t_best[(size_t)i] = t_last_improve = t2; }
         ++lp_round_adopted;
+        // a rounded iterate that is feasible but a few units under the certificate (a half-integral vertex: the completion of its
+        // fractional partitions is feasible, not optimal) is local work for KAO-CX -- a descent from it costs a few rounds, another
+        // interior-point solve a second at 100,000 partitions
+        if (cx_on && !has_target && !topic_done(i) && cycle_supported(&t) && now_s() < deadline) {
+            cx_buf.assign(lp_buf.begin(), lp_buf.end());
+            if (!cx_ctx[(size_t)i] && !(cx_ctx[(size_t)i] = cycle_open(&topics[i], &rc))) return rc;
+            if ((rc = cycle_start(i, gobjective(i), det ? 2 * cx_rounds : 0, true))) return rc;
+        }
         return KAO_OK;
     }
     // keys = the best over all generations (what "done", the K-bound targets and the answer go by); dkeys = this generation's

@@ -556,4 +556,74 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
     for i, p in enumerate(pending):
         rowb = best["pick"][i] if best["pick"] is not None and best["pick"][i] is not None else (rows_of[i][0][1] if rows_of[i] else tuple(range(RF)))
         A[p] = rowb
+    rep["repaired"] = repair_bands(t, A)
     return A, rep
+
+
+def repair_bands(t: ko.Topic, A) -> int:
+    """What the completion of a half-integral vertex leaves: a few brokers one replica (or one leadership) over their band, as many
+    under it (README.md:158-166).  Moves that cost nothing put that right: a follower replica that carries no weight (its broker is
+    not a current replica of the partition, README.md:145-146) goes from the lowest over-loaded broker to the lowest under-loaded one
+    that is not in the row -- same rack first, another rack only if the partition's count there stays within its band (README.md:
+    178-180); a leader whose swap with a follower of its row changes no weight hands over its role.  Partitions in ascending order,
+    first fit.  In place; returns the number of moves."""
+    B, R, P, RF = t.n_brokers, t.n_racks, t.n_partitions, t.rf
+    bd = t.bounds()
+    lo, hi, llo, lhi, phi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"], bd["prack_hi"]
+    rack = [int(r) for r in np.asarray(t.rack_of)]
+    load = [0] * B; lead = [0] * B
+    for p in range(P):
+        for k in range(RF): load[int(A[p, k])] += 1
+        lead[int(A[p, 0])] += 1
+    if all(lo <= load[b] <= hi and llo <= lead[b] <= lhi for b in range(B)):
+        return 0
+    bwv = np.zeros(B, dtype=np.int64) if getattr(t, "broker_w", None) is None else np.asarray(t.broker_w, dtype=np.int64)
+    bwlv = np.zeros(B, dtype=np.int64) if getattr(t, "broker_wl", None) is None else np.asarray(t.broker_wl, dtype=np.int64)
+    w = t.weights
+
+    def wts(p, b):        # (leader weight, follower weight) of broker b on partition p
+        wl = int(bwv[b]) + int(bwlv[b]); wf = int(bwv[b])
+        for j in range(t.rf_cur):
+            if int(t.current[p, j]) == b:
+                wl += w[0 if j == 0 else 1][0]; wf += w[0 if j == 0 else 1][1]
+        return wl, wf
+
+    moves = 0
+    over = [b for b in range(B) if load[b] > hi]
+    if over or any(load[b] < lo for b in range(B)):
+        holds = [[] for _ in range(B)]
+        srcs = set(over) if over else set()
+        for p in range(P):
+            for k in range(1, RF):
+                if int(A[p, k]) in srcs: holds[int(A[p, k])].append((p, k))
+        for b1 in over:
+            while load[b1] > hi:
+                moved = False
+                targets = [b for b in range(B) if load[b] < lo] or [b for b in range(B) if load[b] < hi and b != b1]
+                targets.sort(key=lambda b: (rack[b] != rack[b1], b))
+                for b2 in targets:
+                    for (p, k) in holds[b1]:
+                        if int(A[p, k]) != b1: continue
+                        row = [int(x) for x in A[p]]
+                        if b2 in row or wts(p, b1)[1] != wts(p, b2)[1]: continue
+                        if rack[b2] != rack[b1] and sum(1 for x in row if rack[x] == rack[b2]) >= phi: continue
+                        A[p, k] = b2; load[b1] -= 1; load[b2] += 1; moves += 1; moved = True
+                        break
+                    if moved: break
+                if not moved: break
+    for b1 in [b for b in range(B) if lead[b] > lhi]:
+        while lead[b1] > lhi:
+            moved = False
+            cap2 = llo if any(lead[b] < llo for b in range(B)) else lhi      # the taker is below its band when anyone is, else below the upper end
+            for p in range(P):
+                if int(A[p, 0]) != b1: continue
+                for k in range(1, RF):
+                    b2 = int(A[p, k])
+                    if lead[b2] >= cap2: continue
+                    wl1, wf1 = wts(p, b1); wl2, wf2 = wts(p, b2)
+                    if wl1 + wf2 != wl2 + wf1: continue
+                    A[p, 0], A[p, k] = b2, b1; lead[b1] -= 1; lead[b2] += 1; moves += 1; moved = True
+                    break
+                if moved: break
+            if not moved: break
+    return moves

@@ -1,22 +1,29 @@
 #!/bin/bash
-# round 5, call 44: the triangular solves by one workgroup per row tile: LP tests (trace against the restatement), time per iteration, A/B against the single workgroup
+# round 5, call 47: other huge instances: 1000 x 100,000 with drift seeds 2 / 3 and 40 % drift, 2000 x 100,000, 1000 x 200,000, config 5 as one topic, RF 4
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r05_c44
-timeout 900 python -m pytest tests/test_gpu_lp.py -m gpu -q 2>&1 | grep -E "passed|failed|FAILED|Error" | head -5
-for mw in 1 0; do
-KAO_LP_TRSV_MW=$mw timeout 600 python - >> gpurun_out/${T}_lp.log 2>&1 <<'P'
+T=r05_c47
+timeout 900 python - > gpurun_out/${T}_huge.log 2>&1 <<'P'
 import sys, time, os
 sys.path.insert(0, '.')
 import kafka_assignment_optimizer_amd as kao
 from kafka_assignment_optimizer_amd import synthetic as sy
 kao.init(0)
-for which in ('drift30k', 'drift100k'):
-    t = sy.north_star_topic(which)
-    kao.lp_trace(t, max_iters=1)
-    b = kao.lp_bound(t)
-    r = kao.lp_round(t, salt=1)
-    print('KAO_LP_TRSV_MW=' + os.environ['KAO_LP_TRSV_MW'], which, 'certificate', b['bound'], b['iterations'], 'it', round(b['ms'], 1), 'ms =', round(b['ms'] / b['iterations'], 2), 'ms / it | rounded', r['objective'], r['violations'][0], r['iterations'], 'it', round(r['ms_lp']), 'ms', flush=True)
+cases = [('1000x100000 drift 0.2 seed 2', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 100000, 3, [], []), 0.2, 2)[0]),
+         ('1000x100000 drift 0.2 seed 3', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 100000, 3, [], []), 0.2, 3)[0]),
+         ('1000x100000 drift 0.4 seed 1', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 100000, 3, [], []), 0.4, 1)[0]),
+         ('2000x100000 drift 0.2 seed 1', lambda: sy.drift(sy.make_cluster(2000, 20, 1, 100000, 3, [], []), 0.2, 1)[0]),
+         ('1000x200000 drift 0.2 seed 1', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 200000, 3, [], []), 0.2, 1)[0]),
+         ('1000x50000 rf4 drift 0.2 seed 1', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 50000, 4, [], []), 0.2, 1)[0]),
+         ('cfg5one', lambda: sy.north_star_topic('cfg5one'))]
+for name, mk in cases:
+    try:
+        t = mk()
+        kao.solve([t], seed=1, max_launches=1)
+        t0 = time.perf_counter(); r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=6.0)[0]; dt = time.perf_counter() - t0
+        tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
+        print(f"{name}: {r.status} objective {r.objective} certificate {r.upper_bound} gap {r.upper_bound - r.objective} read back {tm['results_read_back']:.3f}s launches {tm['launches']} cx {tm['cx_calls']} lp {lp}", flush=True)
+    except Exception as e:
+        print(name, 'ERROR', repr(e)[:200], flush=True)
 P
-done
-cat gpurun_out/${T}_lp.log
+cat gpurun_out/${T}_huge.log | cut -c1-300
