@@ -368,6 +368,37 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                         if (!moved) break;
                     }
                 }
+                // what is left costs weight: the cheapest follower move of every broker still over its band (first minimal loss in (p, k), target order)
+                for (int b1 : overb) {
+                    while (load[(size_t)b1] > hi) {
+                        targets.clear();
+                        for (int b = 0; b < B; ++b) if (load[(size_t)b] < lo) targets.push_back(b);
+                        if (targets.empty()) for (int b = 0; b < B; ++b) if (load[(size_t)b] < hi && b != b1) targets.push_back(b);
+                        std::stable_sort(targets.begin(), targets.end(), [&](int a, int b) {
+                            const bool oa = t->rack_of[a] != t->rack_of[b1], ob = t->rack_of[b] != t->rack_of[b1];
+                            return oa != ob ? !oa : a < b;
+                        });
+                        bool have = false; int bl = 0, bp = 0, bk = 0, bb = 0;
+                        for (auto &h : holds[(size_t)b1]) {
+                            const int p = h.first, k = h.second;
+                            if (out[(size_t)p * RF + k] != (uint16_t)b1) continue;
+                            int wl1, wf1; wts(p, b1, wl1, wf1);
+                            for (int b2 : targets) {
+                                if (in_row(p, b2)) continue;
+                                if (t->rack_of[b2] != t->rack_of[b1]) {
+                                    int cnt = 0;
+                                    for (int m = 0; m < RF; ++m) cnt += t->rack_of[out[(size_t)p * RF + m]] == t->rack_of[b2];
+                                    if (cnt >= phi) continue;
+                                }
+                                int wl2, wf2; wts(p, b2, wl2, wf2);
+                                const int loss = wf1 - wf2;
+                                if (!have || loss < bl) { have = true; bl = loss; bp = p; bk = k; bb = b2; }
+                            }
+                        }
+                        if (!have) break;
+                        out[(size_t)bp * RF + bk] = (uint16_t)bb; load[(size_t)b1]--; load[(size_t)bb]++;
+                    }
+                }
             }
             std::vector<int> overl;
             for (int b = 0; b < B; ++b) if (lead_load[(size_t)b] > lhi) overl.push_back(b);
@@ -388,6 +419,29 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                         }
                     }
                     if (!moved) break;
+                }
+            }
+            overl.clear();
+            for (int b = 0; b < B; ++b) if (lead_load[(size_t)b] > lhi) overl.push_back(b);
+            for (int b1 : overl) {   // and the cheapest role swap of every broker still leading too many
+                while (lead_load[(size_t)b1] > lhi) {
+                    bool under = false;
+                    for (int b = 0; b < B && !under; ++b) under = lead_load[(size_t)b] < llo;
+                    const int cap2 = under ? llo : lhi;
+                    bool have = false; int bl = 0, bp = 0, bk = 0, bb = 0;
+                    for (int p = 0; p < P; ++p) {
+                        if (out[(size_t)p * RF] != (uint16_t)b1) continue;
+                        int wl1, wf1; wts(p, b1, wl1, wf1);
+                        for (int k = 1; k < RF; ++k) {
+                            const int b2 = out[(size_t)p * RF + k];
+                            if (lead_load[(size_t)b2] >= cap2) continue;
+                            int wl2, wf2; wts(p, b2, wl2, wf2);
+                            const int loss = (wl1 + wf2) - (wl2 + wf1);
+                            if (!have || loss < bl) { have = true; bl = loss; bp = p; bk = k; bb = b2; }
+                        }
+                    }
+                    if (!have) break;
+                    out[(size_t)bp * RF] = (uint16_t)bb; out[(size_t)bp * RF + bk] = (uint16_t)b1; lead_load[(size_t)b1]--; lead_load[(size_t)bb]++;
                 }
             }
         }

@@ -611,6 +611,24 @@ def repair_bands(t: ko.Topic, A) -> int:
                         break
                     if moved: break
                 if not moved: break
+        # what is left costs weight: the cheapest follower move of every broker still over its band (first minimal loss in (p, k), target order)
+        for b1 in over:
+            while load[b1] > hi:
+                targets = [b for b in range(B) if load[b] < lo] or [b for b in range(B) if load[b] < hi and b != b1]
+                targets.sort(key=lambda b: (rack[b] != rack[b1], b))
+                bestm = None
+                for (p, k) in holds[b1]:
+                    if int(A[p, k]) != b1: continue
+                    row = [int(x) for x in A[p]]
+                    w1 = wts(p, b1)[1]
+                    for b2 in targets:
+                        if b2 in row: continue
+                        if rack[b2] != rack[b1] and sum(1 for x in row if rack[x] == rack[b2]) >= phi: continue
+                        loss = w1 - wts(p, b2)[1]
+                        if bestm is None or loss < bestm[0]: bestm = (loss, p, k, b2)
+                if bestm is None: break
+                _, p, k, b2 = bestm
+                A[p, k] = b2; load[b1] -= 1; load[b2] += 1; moves += 1
     for b1 in [b for b in range(B) if lead[b] > lhi]:
         while lead[b1] > lhi:
             moved = False
@@ -626,4 +644,20 @@ def repair_bands(t: ko.Topic, A) -> int:
                     break
                 if moved: break
             if not moved: break
+    for b1 in [b for b in range(B) if lead[b] > lhi]:      # and the cheapest role swap of every broker still leading too many
+        while lead[b1] > lhi:
+            cap2 = llo if any(lead[b] < llo for b in range(B)) else lhi
+            bestm = None
+            for p in range(P):
+                if int(A[p, 0]) != b1: continue
+                wl1, wf1 = wts(p, b1)
+                for k in range(1, RF):
+                    b2 = int(A[p, k])
+                    if lead[b2] >= cap2: continue
+                    wl2, wf2 = wts(p, b2)
+                    loss = (wl1 + wf2) - (wl2 + wf1)
+                    if bestm is None or loss < bestm[0]: bestm = (loss, p, k, b2)
+            if bestm is None: break
+            _, p, k, b2 = bestm
+            A[p, 0], A[p, k] = b2, b1; lead[b1] -= 1; lead[b2] += 1; moves += 1
     return moves
