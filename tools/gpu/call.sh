@@ -1,23 +1,31 @@
 #!/bin/bash
-# round 5, call 49: what the rounded iterates of 2000 x 100,000 and of the 40 % drift violate
+# round 5, call 50: the huge instances with the two-phase band repair; LP tests
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
-T=r05_c49
-timeout 900 python - > gpurun_out/${T}_viol.log 2>&1 <<'P'
+T=r05_c50
+timeout 900 python -m pytest tests/test_gpu_lp.py -m gpu -q -s 2>&1 | grep -E "passed|failed|FAILED|golden families"
+timeout 900 python - > gpurun_out/${T}_huge.log 2>&1 <<'P'
 import sys, time, os
-import numpy as np
 sys.path.insert(0, '.')
 import kafka_assignment_optimizer_amd as kao
 from kafka_assignment_optimizer_amd import synthetic as sy
 kao.init(0)
-for name, t in (('2000x100000', sy.drift(sy.make_cluster(2000, 20, 1, 100000, 3, [], []), 0.2, 1)[0]), ('1000x100000 drift 0.4', sy.drift(sy.make_cluster(1000, 20, 1, 100000, 3, [], []), 0.4, 1)[0])):
-    b = kao.lp_bound(t)
-    print(name, 'certificate', b['bound'], b['iterations'], 'it', round(b['ms']), 'ms', flush=True)
-    for pert, salt, tol in ((1.5 / (t.n_partitions * 3), 0, 1e-10), (0.0, 1, 0.0)):
-        r = kao.lp_round(t, pert=pert, salt=salt, tol=tol, max_iters=200)
-        A = r['assignment']
-        B = t.n_brokers
-        load = np.bincount(A.reshape(-1), minlength=B); lead = np.bincount(A[:, 0], minlength=B)
-        print(f"  pert {r['pert']:.1e} salt {salt}: objective {r['objective']} violations {r['violations']} | {r['iterations']} it status {r['status']} {r['ms_lp']:.0f} ms, rounding {r['ms_round']:.1f} ms, fractional {r['fractional']}, over inflow {r['over_inflow']}; replica loads min {load.min()} max {load.max()} leaders min {lead.min()} max {lead.max()}", flush=True)
+cases = [('1000x100000 drift 0.2 seed 1', lambda: sy.north_star_topic('drift100k')),
+         ('1000x100000 drift 0.2 seed 2', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 100000, 3, [], []), 0.2, 2)[0]),
+         ('1000x100000 drift 0.2 seed 3', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 100000, 3, [], []), 0.2, 3)[0]),
+         ('1000x100000 drift 0.4 seed 1', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 100000, 3, [], []), 0.4, 1)[0]),
+         ('2000x100000 drift 0.2 seed 1', lambda: sy.drift(sy.make_cluster(2000, 20, 1, 100000, 3, [], []), 0.2, 1)[0]),
+         ('1000x200000 drift 0.2 seed 1', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 200000, 3, [], []), 0.2, 1)[0]),
+         ('1000x30000 drift 0.2 seed 2', lambda: sy.drift(sy.make_cluster(1000, 20, 1, 30000, 3, [], []), 0.2, 2)[0]),
+         ('500x10000 drift 0.3 seed 4', lambda: sy.drift(sy.make_cluster(500, 10, 1, 10000, 3, [], []), 0.3, 4)[0])]
+for name, mk in cases:
+    try:
+        t = mk()
+        kao.solve([t], seed=1, max_launches=1)
+        t0 = time.perf_counter(); r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=6.0)[0]; dt = time.perf_counter() - t0
+        tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
+        print(f"{name}: {r.status} objective {r.objective} certificate {r.upper_bound} gap {r.upper_bound - r.objective} read back {tm['results_read_back']:.3f}s launches {tm['launches']} cx {tm['cx_calls']} lp {lp}", flush=True)
+    except Exception as e:
+        print(name, 'ERROR', repr(e)[:200], flush=True)
 P
-cat gpurun_out/${T}_viol.log | cut -c1-300
+cat gpurun_out/${T}_huge.log | cut -c1-300
