@@ -444,6 +444,51 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                     out[(size_t)bp * RF] = (uint16_t)bb; out[(size_t)bp * RF + bk] = (uint16_t)b1; lead_load[(size_t)b1]--; lead_load[(size_t)bb]++;
                 }
             }
+            // a broker that still leads too many and shares no partition with one that may take a leadership (2,000 brokers: the usual
+            // case): a CHAIN of role swaps, breadth first over "u leads p, v follows in p" (partitions ascending, slots ascending),
+            // weight-neutral swaps only in the first attempt, any swap in the second; every broker between the ends keeps its count
+            overl.clear();
+            for (int b = 0; b < B; ++b) if (lead_load[(size_t)b] > lhi) overl.push_back(b);
+            struct Par { int u, p, k; };
+            std::vector<Par> parent((size_t)B);
+            std::vector<char> seen((size_t)B);
+            std::vector<int> queue;
+            std::vector<std::vector<int>> leads_of((size_t)B);
+            for (int b1 : overl) {
+                while (lead_load[(size_t)b1] > lhi) {
+                    bool under = false;
+                    for (int b = 0; b < B && !under; ++b) under = lead_load[(size_t)b] < llo;
+                    const int cap2 = under ? llo : lhi;
+                    int end = -1;
+                    for (int attempt = 0; attempt < 2 && end < 0; ++attempt) {
+                        const bool neutral_only = attempt == 0;
+                        for (auto &v : leads_of) v.clear();
+                        for (int p = 0; p < P; ++p) leads_of[out[(size_t)p * RF]].push_back(p);
+                        std::fill(seen.begin(), seen.end(), 0);
+                        queue.clear(); queue.push_back(b1); seen[(size_t)b1] = 1; parent[(size_t)b1] = {-1, -1, -1};
+                        for (size_t qi = 0; qi < queue.size() && end < 0; ++qi) {
+                            const int u = queue[qi];
+                            for (int p : leads_of[(size_t)u]) {
+                                int wl1, wf1; wts(p, u, wl1, wf1);
+                                for (int k = 1; k < RF; ++k) {
+                                    const int v = out[(size_t)p * RF + k];
+                                    if (seen[(size_t)v]) continue;
+                                    if (neutral_only) { int wl2, wf2; wts(p, v, wl2, wf2); if (wl1 + wf2 != wl2 + wf1) continue; }
+                                    seen[(size_t)v] = 1; parent[(size_t)v] = {u, p, k}; queue.push_back(v);
+                                    if (lead_load[(size_t)v] < cap2) { end = v; break; }
+                                }
+                                if (end >= 0) break;
+                            }
+                        }
+                    }
+                    if (end < 0) break;
+                    for (int v = end; parent[(size_t)v].u >= 0; v = parent[(size_t)v].u) {
+                        const Par &e = parent[(size_t)v];
+                        out[(size_t)e.p * RF] = (uint16_t)v; out[(size_t)e.p * RF + e.k] = (uint16_t)e.u;
+                    }
+                    lead_load[(size_t)b1]--; lead_load[(size_t)end]++;
+                }
+            }
         }
     }
     return KAO_OK;

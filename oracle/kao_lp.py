@@ -660,4 +660,38 @@ def repair_bands(t: ko.Topic, A) -> int:
             if bestm is None: break
             _, p, k, b2 = bestm
             A[p, 0], A[p, k] = b2, b1; lead[b1] -= 1; lead[b2] += 1; moves += 1
+    # a broker that still leads too many and shares no partition with one that may take a leadership (2,000 brokers: the usual case):
+    # a CHAIN of role swaps, breadth first over "u leads p, v follows in p" (partitions ascending, slots ascending), weight-neutral swaps
+    # only in the first attempt, any swap in the second; every broker between the ends keeps its count
+    for b1 in [b for b in range(B) if lead[b] > lhi]:
+        while lead[b1] > lhi:
+            cap2 = llo if any(lead[b] < llo for b in range(B)) else lhi
+            path = None
+            for neutral_only in (True, False):
+                leads_of = [[] for _ in range(B)]
+                for p in range(P): leads_of[int(A[p, 0])].append(p)
+                parent = {b1: None}; queue = [b1]; end = None; qi = 0
+                while qi < len(queue) and end is None:
+                    u = queue[qi]; qi += 1
+                    for p in leads_of[u]:
+                        wl1, wf1 = wts(p, u)
+                        for k in range(1, RF):
+                            v = int(A[p, k])
+                            if v in parent: continue
+                            if neutral_only:
+                                wl2, wf2 = wts(p, v)
+                                if wl1 + wf2 != wl2 + wf1: continue
+                            parent[v] = (u, p, k); queue.append(v)
+                            if lead[v] < cap2: end = v; break
+                        if end is not None: break
+                if end is not None:
+                    path = []
+                    v = end
+                    while parent[v] is not None:
+                        path.append((parent[v][0], parent[v][1], parent[v][2], v)); v = parent[v][0]
+                    break
+            if path is None: break
+            for (u, p, k, v) in path:
+                A[p, 0], A[p, k] = v, u; moves += 1
+            lead[b1] -= 1; lead[path[0][3]] += 1
     return moves
