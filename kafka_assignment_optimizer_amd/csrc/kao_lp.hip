@@ -325,34 +325,75 @@ __global__ void k_lp_schur_broker(LpDev D, const double *th, const double *thg, 
         // half): an incidence is a chain of three dependent global round trips (the incidence word, the partition's factors, the column's
         // factors) and a broker has ~300 of them at 100,000 partitions -- 1.37 ms of an 8.8-ms iteration with one chain in flight.  The adds
         // reach every column in incidence order as before: the same bits.
-        struct Inc { bool ok; int col; double v3, v4; };
-        auto fetch = [&](int e, Inc &o) {
-            const int idx = D.inc[e], p = idx >> 3, j0 = idx & 7;
-            const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
-            PCol a3, a4, q;
-            lp_col(D, th, fj, fr, p, 2 * j0, a3);
-            lp_col(D, th, fj, fr, p, 2 * j0 + 1, a4);
-            const double w30 = i11 * a3.v0 + i12 * a3.v1, w31 = i12 * a3.v0 + i22 * a3.v1;
-            const double w40 = i11 * a4.v0 + i12 * a4.v1, w41 = i12 * a4.v0 + i22 * a4.v1;
-            const double d0 = fr[((size_t)0 * R + r0) * P + p];
-            const int c = lane;
-            o.ok = c < nc && lp_col(D, th, fj, fr, p, c, q);
-            if (!o.ok) return;
-            double v3 = -(w30 * q.v0 + w31 * q.v1), v4 = -(w40 * q.v0 + w41 * q.v1);
-            if (q.rk == r0) {
-                v3 -= a3.eps * q.eps / d0; v4 -= a4.eps * q.eps / d0;
-                if (c == 2 * j0) { v3 += a3.dg; v4 += a4.m1; }
-                else if (c == 2 * j0 + 1) { v3 += a4.m1; v4 += a4.dg; }
-            }
-            o.col = q.col; o.v3 = v3; o.v4 = v4;
-        };
+        // Straight-line code, level by level over the four incidences (no branch between the loads of one level: the compiler keeps
+        // them in flight together): incidence word -> partition's factors and current replicas -> rack of the column's broker -> rack factors.
+        constexpr int U = 4;
         const int e1 = D.inc_off[b + 1];
-        for (int e = D.inc_off[b]; e < e1; e += 4) {
-            Inc q4[4];
+        const int c = lane;
+        const bool is_cur = c < 2 * NJ, has_col = c < nc;
+        const int jc = is_cur ? (c >> 1) : 0, rc_ = is_cur ? 0 : min((c - 2 * NJ) >> 1, R - 1), odd = c & 1;
+        for (int e = D.inc_off[b]; e < e1; e += U) {
+            int pp[U], j0[U]; bool live[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { q4[u].ok = false; if (e + u < e1) fetch(e + u, q4[u]); }
+            for (int u = 0; u < U; ++u) { live[u] = e + u < e1; const int idx = D.inc[min(e + u, e1 - 1)]; pp[u] = idx >> 3; j0[u] = idx & 7; }
+            // level 2: everything that needs only p
+            double i11[U], i12[U], i22[U], f3[U][3], cs[U][3], cy[U], d0[U];
+            int bc[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (q4[u].ok) { rowA[q4[u].col] += q4[u].v3; rowB[q4[u].col] += q4[u].v4; }
+            for (int u = 0; u < U; ++u) {
+                const int p = pp[u];
+                i11[u] = ti[(size_t)0 * P + p]; i12[u] = ti[(size_t)1 * P + p]; i22[u] = ti[(size_t)2 * P + p];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { f3[u][m] = fj[((size_t)m * NJ + j0[u]) * P + p]; cs[u][m] = fj[((size_t)m * NJ + jc) * P + p]; }
+                cy[u] = th[(size_t)(odd ? VYL(D, rc_) : VYF(D, rc_)) * P + p];
+                d0[u] = fr[((size_t)0 * R + r0) * P + p];
+                bc[u] = D.cur[(size_t)p * NJ + jc];
+            }
+            // level 3: the rack of the column's broker (current-replica columns) -- the incidence's own broker is b, rack r0
+            int rk[U]; bool okc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool cur_ok = bc[u] != KAO_NONE && bc[u] < D.B;
+                okc[u] = live[u] && has_col && (is_cur ? cur_ok : true);
+                rk[u] = is_cur ? (int)D.rack[cur_ok ? bc[u] : 0] : rc_;
+            }
+            // level 4: rack factors of the column and of the incidence's rows
+            double dq[U], e1q[U], e2q[U], e1a[U], e2a[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int p = pp[u];
+                dq[u] = fr[((size_t)0 * R + rk[u]) * P + p]; e1q[u] = fr[((size_t)1 * R + rk[u]) * P + p]; e2q[u] = fr[((size_t)2 * R + rk[u]) * P + p];
+                e1a[u] = fr[((size_t)1 * R + r0) * P + p]; e2a[u] = fr[((size_t)2 * R + r0) * P + p];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!okc[u]) continue;
+                // the incidence's two rows (lp_col for columns 2 j0 and 2 j0 + 1): C3 row a3, C4 row a4
+                const double s11 = f3[u][0], s12 = f3[u][1], s22 = f3[u][2];
+                const double a3v0 = s11 - e1a[u] * s11 / d0[u], a3v1 = s12 - e2a[u] * s11 / d0[u];
+                const double a4v0 = s12 - e1a[u] * s12 / d0[u], a4v1 = s22 - e2a[u] * s12 / d0[u];
+                const double w30 = i11[u] * a3v0 + i12[u] * a3v1, w31 = i12[u] * a3v0 + i22[u] * a3v1;
+                const double w40 = i11[u] * a4v0 + i12[u] * a4v1, w41 = i12[u] * a4v0 + i22[u] * a4v1;
+                // this lane's column (lp_col for column c)
+                double m1, m2, eps, dg; int col;
+                if (is_cur) {
+                    const double q11 = cs[u][0], q12 = cs[u][1], q22 = cs[u][2];
+                    if (!odd) { col = RC3(D, bc[u]); m1 = q11; m2 = q12; eps = q11; dg = q11; }
+                    else { col = RC4(D, bc[u]); m1 = q12; m2 = q22; eps = q12; dg = q22; }
+                } else {
+                    if (!odd) { col = RNF(D, rc_); m1 = cy[u]; m2 = 0; eps = cy[u]; dg = cy[u]; }
+                    else { col = RNL(D, rc_); m1 = cy[u]; m2 = cy[u]; eps = cy[u]; dg = cy[u]; }
+                }
+                (void)dg;
+                const double qv0 = m1 - e1q[u] * eps / dq[u], qv1 = m2 - e2q[u] * eps / dq[u];
+                double v3 = -(w30 * qv0 + w31 * qv1), v4 = -(w40 * qv0 + w41 * qv1);
+                if (rk[u] == r0) {
+                    v3 -= s11 * eps / d0[u]; v4 -= s12 * eps / d0[u];           // a3.eps = s11, a4.eps = s12
+                    if (c == 2 * j0[u]) { v3 += s11; v4 += s12; }                // (C3, C3) = sig11, (C4, C3) = sig12
+                    else if (c == 2 * j0[u] + 1) { v3 += s12; v4 += s22; }       // (C3, C4) = sig12, (C4, C4) = sig22
+                }
+                rowA[col] += v3; rowB[col] += v4;
+            }
         }
     } else
     for (int e = D.inc_off[b]; e < D.inc_off[b + 1]; ++e) {
