@@ -316,7 +316,12 @@ int kao_session_restart_state(kao_session *s, int32_t topic, int32_t restart, ui
                               uint16_t *best_state, int32_t info[4]);
 void kao_session_destroy(kao_session *s);
 
-/* Whole job: create, step until target/time limit, read back, destroy. */
+/* Whole job: create, step until target/time limit, read back, destroy.  What runs inside (round 5): K-search + K-eval on every topic;
+ * K-bound beside them (the certificate of small topics); KAO-CX on stalled incumbents; and for every topic of at least 2,048 replica
+ * slots that is not closed at once ONE interior-point solve of the model's LP with slightly perturbed costs (KAO-LP): its row duals
+ * become the certificate (and the search prices), its iterate -- rounded as kao_lp_round does -- the incumbent; status OPTIMAL_PROVEN means
+ * objective == certificate.  Topics from 32,768 slots get that solve before any K-search launch when time_limit_s >= 1 (huge ones: 1.5).
+ * The schedule is keyed to counts, not to the clock (kao_opts.schedule = 0): same input, same seed, same answer. */
 int kao_solve(const kao_topic *topics, int32_t n_topics, const kao_opts *opts, kao_result *results);
 /* Whole job on several GPUs of ONE process (one host thread drives all of them; launches of every device are enqueued
  * before any is waited for).  devices[n_dev] = HIP device ordinals.
