@@ -196,7 +196,11 @@ struct SolveRun {
     // lp_solo_slots replica slots (1000 x 30000: 0.56 s alone, 1.0 s two iterations per K-search launch) when it is at least a second
     // (a limit is an input, not the clock: the schedule stays count-keyed)
     bool solo(int i) const { return !huge(i) && (int64_t)topics[i].n_partitions * topics[i].rf >= lp_solo_slots; }
-    bool lp_alone(int i) const { return lp_round_on && ((huge(i) && deadline - t0 >= lp_alone_s) || (solo(i) && deadline - t0 >= lp_solo_s)); }
+    bool only_open(int i) const {   // no other topic still waits for the search (a paused K-search would starve it)
+        for (int j = 0; j < n; ++j) if (j != i && !topic_done(j)) return false;
+        return true;
+    }
+    bool lp_alone(int i) const { return lp_round_on && ((huge(i) && deadline - t0 >= lp_alone_s) || (solo(i) && deadline - t0 >= lp_solo_s && only_open(i))); }
     bool search_paused() const {   // a huge topic between its first feasible incumbent and the end of its LP -- from the start when the limit leaves room for the LP alone
         for (int i = 0; i < n; ++i) if (lp_possible(i) && !topic_done(i) && ((huge(i) && (feasible(i) || (lp_huge_first && launches >= 1))) || lp_alone(i))) return true;
         return false;

@@ -27,6 +27,12 @@ def _drift(ko, B, R, P, dseed=1):
     return pt, ot
 
 
+def _otopic(ko, pt):
+    return ko.Topic(name=pt.name, broker_ids=np.array(pt.broker_ids), rack_of=np.array(pt.rack_of), n_racks=pt.n_racks,
+                    n_partitions=pt.n_partitions, rf=pt.rf, current=np.array(pt.current), weights=pt.weights,
+                    bounds_override=dict(pt.bounds_override))
+
+
 def _trace_close(dev, ref, rel=1e-7):
     """mu, primal and dual objective of every iterate agree to `rel` while mu >= 1e-6 (afterwards both are at the optimum and
     the last digits are rounding); the iteration counts differ by at most one."""
@@ -243,3 +249,18 @@ def test_solve_retries_a_rounded_iterate_that_is_not_the_optimum(kao, ko, kp, mo
     lp = kao.last_solve_lp()
     assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", 14801, 14801), (r.status, r.objective, r.upper_bound, lp)
     assert lp["solves"] == 2 and lp["rounded"] == 1 and lp["adopted"] == 1, lp
+
+
+def test_solve_mixed_topics_keeps_the_search_running(kao, ko, kp):
+    """One topic large enough for the LP-alone schedule (36,000 replica slots) among small ones: the LP must not get the GPU to itself
+    while other topics still wait for K-search (it rides beside the launches instead); every topic ends OPTIMAL_PROVEN, the large one by
+    its rounded iterate."""
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    big = sy.drift(sy.make_cluster(600, 12, 1, 12000, 3, [], []), 0.2, 1)[0]
+    small = sy.drift(sy.make_cluster(100, 5, 6, 200, 3, [], []), 0.2, 2)
+    res = kao.solve([big] + list(small), seed=5, stop_at_bound=1, time_limit_s=20.0)
+    lp = kao.last_solve_lp()
+    assert all(r.status == "OPTIMAL_PROVEN" for r in res), [r.status for r in res]
+    assert lp["adopted"] >= 1 and res[0].objective == res[0].upper_bound
+    obj, viol = kp.port_eval(_otopic(ko, big), res[0].assignment)
+    assert viol[0] == 0 and obj == res[0].objective
