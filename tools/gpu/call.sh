@@ -1,8 +1,15 @@
 #!/bin/bash
-# round 5: rocprofv3 kernel trace of ONE kao_solve of the drifted north-star topic (plain LP launches: the tool crashes in the graph capture at this size)
+# round 5: the whole drifted family (24 topics x solver seeds 3 / 4 / 5, 3-s limit each) on the final state
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
 T=r05_zz
-KAO_LP_GRAPH=0 timeout 600 bash tools/profile_solve.sh ${T}_100k 1000 20 100000 3 > /dev/null 2>&1
-cp gpurun_out/prof_solve_${T}_100k/summary.txt gpurun_out/${T}_solve_1000x100000_rocprof_summary.txt; head -22 gpurun_out/${T}_solve_1000x100000_rocprof_summary.txt | cut -c1-200
-find gpurun_out/prof_solve_${T}_100k -name "*.db" -size +5M -delete; find gpurun_out/prof_solve_${T}_100k -name "*.csv" -size +5M -delete
+R3_SCHEDS=0 R3_SEEDS=3,4,5 timeout 600 python tools/r3_probe.py family 3 > gpurun_out/${T}_drift_family.txt 2>&1
+grep "proven" gpurun_out/${T}_drift_family.txt | cut -c1-200
+python - <<'P'
+import re
+t = 0.0; n = 0
+for l in open('gpurun_out/r05_zz_drift_family.txt'):
+    m = re.search(r' ([0-9.]+)s t_best', l)
+    if m: t += float(m.group(1)); n += 1
+print('solves', n, 'sum of solve seconds', round(t, 2))
+P
