@@ -303,8 +303,9 @@ int kao_lp_round(const kao_topic *t, double pert, uint32_t salt, double tol, int
 /* Test hook: the host half of kao_lp_round alone -- from a quantised iterate to an assignment (no device needed).  q[(2 rf_cur + 2 R) * P]:
  * centi-units min(250, rint(100 x)) of f_j (row j), l_j (row rf_cur + j), yf_r (row 2 rf_cur + r), yl_r (row 2 rf_cur + R + r), each row P
  * long; zq[2 B]: rint(zf_b), rint(zl_b).  assignment / use_fallback as kao_lp_round; rep[4] = {fractional partitions, placements beyond
- * an inflow, unplaced, rows taken from the fallback}.  The parity tests hold it against oracle/kao_lp.py round_primal on the scalar
- * restatement's iterate. */
+ * an inflow, unplaced, rows taken from the fallback}.  use_fallback == 2: only the band repair at the end of the rounding, on the complete
+ * assignment passed in (q, zq unused, may be NULL).  The parity tests hold it against oracle/kao_lp.py round_primal / repair_bands on the
+ * scalar restatement's iterate. */
 int kao_lp_round_host(const kao_topic *t, const uint8_t *q, const int32_t *zq, int32_t use_fallback, uint16_t *assignment, int32_t rep[4]);
 /* One-shot K-bound on one topic: `launches` launches of `iters` iterations towards `target`.
  * *bound = floor(best dual / 65536) (not combined with kao_upper_bound); multipliers, if not NULL, receives

@@ -30,6 +30,10 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     int32_t bd[8];
     derive_bounds(t, bd);
     const int lo = bd[0], hi = bd[1], llo = bd[2], lhi = bd[3], phi = bd[7];
+    std::vector<int> load((size_t)B, 0), lead_load((size_t)B, 0);
+    auto in_row = [&](int p, int b) { for (int k = 0; k < RF; ++k) if (out[(size_t)p * RF + k] == (uint16_t)b) return true; return false; };
+    do {   // (q == nullptr: `out` holds a complete assignment already and only the band repair at the end runs -- the test hook's mode 2)
+    if (!q) break;
     std::vector<std::vector<int>> members((size_t)R);
     for (int b = 0; b < B; ++b) members[t->rack_of[b]].push_back(b);
     std::vector<int> cap[2] = {std::vector<int>(zq, zq + B), std::vector<int>(zq + B, zq + 2 * B)};   // [0] follower inflow, [1] leader inflow
@@ -41,7 +45,6 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     auto unit = [&](int c) { return (c + 50) / 100; };
     int used[2 * KAO_MAX_RF + 2]; int n_used = 0;
     auto is_used = [&](int b) { for (int i = 0; i < n_used; ++i) if (used[i] == b) return true; return false; };
-    auto in_row = [&](int p, int b) { for (int k = 0; k < RF; ++k) if (out[(size_t)p * RF + k] == (uint16_t)b) return true; return false; };
     struct Swap { int q, sq, b1; };
     std::vector<Swap> swaps_now;
     // a new replica of kind `kind` in rack r for the row under construction (brokers in `used`): (broker, inside the inflows?)
@@ -139,7 +142,6 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     //      band rows (README.md:158-166) come out right given what the other partitions hold ----
     std::vector<char> is_pending((size_t)P, 0);
     for (int p : pending) is_pending[(size_t)p] = 1;
-    std::vector<int> load((size_t)B, 0), lead_load((size_t)B, 0);
     for (int p = 0; p < P; ++p) {
         if (is_pending[(size_t)p]) continue;
         for (int k = 0; k < RF; ++k) load[out[(size_t)p * RF + k]]++;
@@ -315,6 +317,7 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     }
     if (rep) { rep[1] = over; rep[2] = unplaced; rep[3] = from_fb; }
     (void)swaps;
+    } while (0);
     // ---- what the completion of a half-integral vertex leaves: a few brokers one replica (or one leadership) over their band, as many
     //      under it.  Moves that cost nothing put that right (specification: oracle/kao_lp.py repair_bands) ----
     {

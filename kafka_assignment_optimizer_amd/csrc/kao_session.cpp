@@ -1291,9 +1291,15 @@ int kao_lp_round(const kao_topic *t, double pert, uint32_t salt, double tol, int
 }
 
 int kao_lp_round_host(const kao_topic *t, const uint8_t *q, const int32_t *zq, int32_t use_fallback, uint16_t *assignment, int32_t rep[4]) {
-    if (!t || !q || !zq || !assignment) return fail(KAO_ERR_INVALID, "null argument");
+    if (!t || !assignment || (use_fallback != 2 && (!q || !zq))) return fail(KAO_ERR_INVALID, "null argument");
     int rc = validate(t);
     if (rc) return rc;
+    if (use_fallback == 2) {   // the band repair alone on the assignment passed in
+        if (rep) rep[0] = rep[1] = rep[2] = rep[3] = 0;
+        for (size_t i = 0, n = (size_t)t->n_partitions * t->rf; i < n; ++i)
+            if (assignment[i] >= t->n_brokers) return fail(KAO_ERR_INVALID, "repair: a complete assignment expected");
+        return lp_round_assignment(t, nullptr, zq, nullptr, assignment, rep);
+    }
     std::vector<uint16_t> fb;
     if (use_fallback) fb.assign(assignment, assignment + (size_t)t->n_partitions * t->rf);
     return lp_round_assignment(t, q, zq, use_fallback ? fb.data() : nullptr, assignment, rep);

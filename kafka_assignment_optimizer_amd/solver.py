@@ -452,6 +452,15 @@ def lp_round_host(topic: Topic, q, zq, fallback=None) -> dict:
     return dict(assignment=a.reshape(topic.n_partitions, topic.rf), fractional=int(rep[0]), over_inflow=int(rep[1]), unplaced=int(rep[2]), from_fallback=int(rep[3]))
 
 
+def lp_repair_host(topic: Topic, assignment) -> np.ndarray:
+    """Test hook (kao_lp_round_host, mode 2): the band repair of the rounding alone, on a complete assignment [P, rf]."""
+    ct = _CTopics([topic])
+    a = np.ascontiguousarray(np.asarray(assignment).reshape(-1), dtype=np.uint16).copy()
+    rep = (C.c_int32 * 4)()
+    _check(_ffi.load().kao_lp_round_host(ct.ptr(0), None, None, 2, a.ctypes.data_as(C.POINTER(C.c_uint16)), rep), "kao_lp_round_host")
+    return a.reshape(topic.n_partitions, topic.rf)
+
+
 def lp_trace(topic: Topic, tol: float = 0.0, max_iters: int = 80) -> dict:
     """Test hook (kao_lp_trace): the interior-point solve alone and its per-iterate trace (mu, primal, dual, pinf, dinf)."""
     ct = _CTopics([topic])

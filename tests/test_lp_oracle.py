@@ -164,3 +164,96 @@ def test_host_rounding_matches_the_specification(ko, kp):
     d = kao.lp_round_host(to_product_topic(t), *_pack(*blocks), fallback=fb)
     assert d["assignment"].tolist() == A.tolist() and d["from_fallback"] == rep["from_fallback"] == rep["fractional"] > 100
     assert n >= 130 and n_search >= 5 and n_swaps >= 3, (n, n_search, n_swaps)
+
+
+def test_band_repair_matches_the_specification(ko, kp):
+    """The band repair at the end of the rounding (kao_round.cpp against oracle/kao_lp.py repair_bands, through kao_lp_round_host mode 2),
+    on imbalances built from an optimal assignment of a drifted 100-broker topic: (a) weightless follower replicas piled onto two
+    brokers (zero-cost moves, same rack first), (b) kept current replicas given up elsewhere and re-added on another broker (only
+    costly moves are left), (c) leaderships shifted between brokers of the same partitions (role swaps) and (d) between brokers that
+    share no partition (a chain of role swaps).  Same assignment from both, and the README's band rows hold again (ko.verify)."""
+    import kao_lp as kl
+    import kafka_assignment_optimizer_amd as kao
+    from conftest import to_product_topic
+    t = _drift_topic(ko, 100, 5, 1000)
+    r = kl.port_solve(t, tol=1e-8, maxit=150, primal=True, pert=kl.default_pert(t))
+    A0, _ = kl.round_primal(t, *kl.primal_blocks(t, r["x"], r["xg"]))
+    obj0, v0 = ko.verify(t, A0)
+    assert int(np.asarray(v0)[0]) == 0
+    pt = to_product_topic(t)
+    rack = np.asarray(t.rack_of)
+    cur = np.asarray(t.current)
+    rng = np.random.default_rng(11)
+
+    def check(A, what, expect_feasible=True):
+        ref = A.copy()
+        moves = kl.repair_bands(t, ref)
+        got = kao.lp_repair_host(pt, A)
+        assert got.tolist() == ref.tolist(), what
+        o, v = ko.verify(t, ref)
+        if expect_feasible:
+            assert int(np.asarray(v)[0]) == 0 and moves > 0, (what, [int(x) for x in np.asarray(v)], moves)
+        return o
+
+    # (a) weightless followers piled onto a broker of the same rack
+    A = A0.copy(); n = 0
+    for p in range(t.n_partitions):
+        for k in (1, 2):
+            b = int(A[p, k])
+            if b in cur[p]: continue
+            tgt = next((x for x in range(t.n_brokers) if rack[x] == rack[b] and x != b and x not in A[p] and x not in cur[p]), None)
+            if tgt is not None and n < 3: A[p, k] = tgt; n += 1
+        if n >= 3: break
+    assert check(A, "weightless followers") == obj0
+    # (b) kept current followers moved to brokers that are not current replicas: the repair has to pay for moving others, or move them on
+    A = A0.copy(); n = 0
+    for p in range(t.n_partitions):
+        for k in (1, 2):
+            b = int(A[p, k])
+            if b not in cur[p]: continue
+            tgt = next((x for x in range(t.n_brokers) if rack[x] == rack[b] and x != b and x not in A[p] and x not in cur[p]), None)
+            if tgt is not None and n < 2: A[p, k] = tgt; n += 1
+        if n >= 2: break
+    assert check(A, "costly followers") <= obj0
+    # (c) role swaps inside partitions whose two brokers carry no weight there
+    A = A0.copy(); n = 0
+    for p in range(t.n_partitions):
+        if n >= 2: break
+        for k in (1, 2):
+            if int(A[p, 0]) not in cur[p] and int(A[p, k]) not in cur[p]:
+                A[p, 0], A[p, k] = A[p, k], A[p, 0]; n += 1; break
+    check(A, "role swaps")
+    # (d) a leadership moved between two brokers that share no partition (300 brokers: most pairs do not): only a chain of role swaps
+    #     brings it back -- u's leadership of p goes to v, v's leadership of another partition q goes on to w
+    t2 = _drift_topic(ko, 300, 6, 2000)
+    r2 = kl.port_solve(t2, tol=1e-8, maxit=150, primal=True, pert=kl.default_pert(t2))
+    B0, _ = kl.round_primal(t2, *kl.primal_blocks(t2, r2["x"], r2["xg"]))
+    assert int(np.asarray(ko.verify(t2, B0)[1])[0]) == 0
+    pt2 = to_product_topic(t2)
+    lead_of = {}
+    for p in range(t2.n_partitions): lead_of.setdefault(int(B0[p, 0]), []).append(p)
+    holds = [set() for _ in range(t2.n_brokers)]
+    for p in range(t2.n_partitions):
+        for b in B0[p]: holds[int(b)].add(p)
+    nlead = np.bincount(B0[:, 0], minlength=t2.n_brokers)
+    llo2, lhi2 = t2.bounds()["lead_lo"], t2.bounds()["lead_hi"]      # u drops below the band, w rises above it
+    A = None
+    for p in range(t2.n_partitions):
+        for k in (1, 2):
+            u, v = int(B0[p, 0]), int(B0[p, k])
+            for q in lead_of.get(v, []):
+                for k2 in (1, 2):
+                    w = int(B0[q, k2])
+                    if q == p or w == u or holds[u] & holds[w] or nlead[u] != llo2 or nlead[w] != lhi2: continue
+                    A = B0.copy()
+                    A[p, 0], A[p, k] = v, u
+                    A[q, 0], A[q, k2] = w, v
+                    break
+                if A is not None: break
+            if A is not None: break
+        if A is not None: break
+    assert A is not None
+    ref = A.copy()
+    assert kl.repair_bands(t2, ref) >= 2                     # at least two swaps: a chain
+    assert kao.lp_repair_host(pt2, A).tolist() == ref.tolist()
+    assert int(np.asarray(ko.verify(t2, ref)[1])[0]) == 0
