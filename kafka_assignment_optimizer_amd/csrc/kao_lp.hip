@@ -60,7 +60,8 @@ struct LpDev {
 // of iterations can be enqueued without the host looking; once the stop flag is set every later kernel returns at its first line.
 enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (non-finite iterate) */, SC_IT, SC_AP, SC_AD, SC_SIGMU, SC_MU, SC_POBJ, SC_DOBJ,
              SC_PINF, SC_DINF, SC_PLAST, SC_DLAST, SC_HAVE_LAST, SC_KEEP /* this iterate is finite: copy its duals */, SC_TOL, SC_MAXIT, SC_NVU /* variables + bounded variables */, SC_NB, SC_NCN,
-             SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT, kScN = 24 };
+             SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT,
+             SC_MCC_GO /* centrality correctors: the next one is still wanted */, SC_MCC_ACC /* the last one was accepted */, kScN = 24 };
 #define LP_STOPPED(D) ((D).sc[SC_STOP] != 0.0)
 
 // variable numbering inside a partition (SoA: element (v, p) at v*P + p) and among the global variables
@@ -201,9 +202,30 @@ __global__ void k_lp_keep_last(const double *sc, const double *yc, double *ylast
 // step lengths to the boundary from the min-reduction; the corrector's are damped (0.9995) and close the iteration count
 __global__ void k_lp_sc_step(double *sc, const double *red, int pass) {
     if (sc[SC_STOP] != 0.0) return;
-    double ap = red[0], ad = red[1];
-    if (pass) { if (ap < 1.0) ap *= 0.9995; if (ad < 1.0) ad *= 0.9995; sc[SC_IT] += 1.0; }
+    const double ap = red[0], ad = red[1];
     sc[SC_AP] = ap; sc[SC_AD] = ad;
+    if (pass) { sc[SC_MCC_GO] = (ap < 1.0 || ad < 1.0) ? 1.0 : 0.0; sc[SC_MCC_ACC] = 0.0; }
+}
+// after the correctors: the step stops short of the boundary, the iteration is counted
+__global__ void k_lp_sc_final(double *sc) {
+    if (sc[SC_STOP] != 0.0) return;
+    if (sc[SC_AP] < 1.0) sc[SC_AP] *= 0.9995;
+    if (sc[SC_AD] < 1.0) sc[SC_AD] *= 0.9995;
+    sc[SC_IT] += 1.0;
+}
+// ---- Gondzio's multiple centrality correctors (round 5, last; oracle/kao_lp_port.c mcc_build / mcc_finish): the step lengths of the
+// predictor-corrector direction are enlarged by kMccDelta, the complementarity products of that trial point are projected onto
+// [kMccBmin, kMccBmax] x sigma mu, and the direction that moves them there is added when it lengthens the step.  The graph of an iteration
+// is static: both correctors are always enqueued and turn into no-ops through SC_MCC_GO / SC_MCC_ACC.
+constexpr double kMccDelta = 0.3, kMccBmin = 0.1, kMccBmax = 10.0;
+__global__ void k_lp_sc_mcc(double *sc, const double *red) {
+    if (sc[SC_STOP] != 0.0) return;
+    if (sc[SC_MCC_GO] == 0.0) { sc[SC_MCC_ACC] = 0.0; return; }
+    const double ap = sc[SC_AP], ad = sc[SC_AD], ap2 = red[0], ad2 = red[1];
+    const bool bad = !(ap2 >= ap + 0.01 * kMccDelta || ad2 >= ad + 0.01 * kMccDelta) || ap2 < 0.9 * ap || ad2 < 0.9 * ad;
+    if (bad) { sc[SC_MCC_ACC] = 0.0; sc[SC_MCC_GO] = 0.0; return; }
+    sc[SC_MCC_ACC] = 1.0; sc[SC_AP] = ap2; sc[SC_AD] = ad2;
+    if (!(ap2 < 1.0 || ad2 < 1.0)) sc[SC_MCC_GO] = 0.0;
 }
 __global__ void k_lp_sc_sigma(double *sc, const double *red) {
     if (sc[SC_STOP] != 0.0) return;
@@ -1077,6 +1099,75 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_dir(LpDev D, VarVec x, VarVec 
     else if (i < nv + D.GV) { dx.zg[i - nv] = ddx; ds.zg[i - nv] = dds; dv.zg[i - nv] = ddv; }
     block_reduce(a, 2, true, rec + (size_t)blockIdx.x * kRedVals);
 }
+// corrector right-hand side: h, g = theta h and the parked targets (rxs -> dsc, rwv -> dvc) from the trial point of the direction (dx, ds, dv)
+__global__ void k_lp_mcc_h(LpDev D, VarVec x, VarVec s, VarVec v, VarVec th, VarVec dx, VarVec ds, VarVec dv, VarVec h, VarVec g, VarVec dsc, VarVec dvc) {
+    if (LP_STOPPED(D) || D.sc[SC_MCC_GO] == 0.0) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    if (i >= nv + D.GV) return;
+    const double ap = D.sc[SC_AP], ad = D.sc[SC_AD], mut = D.sc[SC_SIGMU];
+    const double apt = ap + kMccDelta < 1.0 ? ap + kMccDelta : 1.0, adt = ad + kMccDelta < 1.0 ? ad + kMccDelta : 1.0;
+    bool on; double u;
+    if (i < nv) { const int vv = (int)(i / D.P), p = (int)(i % D.P); on = var_present(D, vv, p); u = var_ub(D, vv); }
+    else { const int k = (int)(i - nv); on = gvar_present(D, k); u = gvar_ub(D, k); }
+    if (!on) { h.z[i] = 0; g.z[i] = 0; dsc.z[i] = 0; dvc.z[i] = 0; return; }   // (the global variables sit right behind the partition ones)
+    const double xi = x.z[i], si = s.z[i], vi = v.z[i];
+    double pr = (xi + apt * dx.z[i]) * (si + adt * ds.z[i]);
+    double tg = pr < kMccBmin * mut ? kMccBmin * mut : (pr > kMccBmax * mut ? kMccBmax * mut : pr);
+    double rxs = tg - pr; if (rxs < -kMccBmax * mut) rxs = -kMccBmax * mut;
+    double rwv = 0.0, w = 1.0;
+    if (u > 0) {
+        w = u - xi;
+        pr = (w - apt * dx.z[i]) * (vi + adt * dv.z[i]);
+        tg = pr < kMccBmin * mut ? kMccBmin * mut : (pr > kMccBmax * mut ? kMccBmax * mut : pr);
+        rwv = tg - pr; if (rwv < -kMccBmax * mut) rwv = -kMccBmax * mut;
+    }
+    const double hh = -rxs / xi + (u > 0 ? rwv / w : 0.0);
+    h.z[i] = hh; g.z[i] = th.z[i] * hh; dsc.z[i] = rxs; dvc.z[i] = rwv;
+}
+// correction direction (dxc, dsc, dvc) from dy and the parked targets; step lengths of direction + correction {alpha_p, alpha_d} (min)
+__global__ void __launch_bounds__(kRedBlock) k_lp_mcc_dir(LpDev D, VarVec x, VarVec s, VarVec v, VarVec th, VarVec h, RowVec dy, VarVec dxc, VarVec dsc, VarVec dvc,
+                                                            VarVec dx, VarVec ds, VarVec dv, double *rec) {
+    if (LP_STOPPED(D) || D.sc[SC_MCC_GO] == 0.0) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nv = (size_t)D.NV * D.P;
+    double a[2] = {1.0, 1.0};
+    bool on = false; double u = 0, atv = 0;
+    if (i < nv) { const int vv = (int)(i / D.P), p = (int)(i % D.P); on = var_present(D, vv, p); if (on) { u = var_ub(D, vv); atv = at_val(D, vv, p, dy); } }
+    else if (i < nv + D.GV) { const int k = (int)(i - nv); on = gvar_present(D, k); if (on) { u = gvar_ub(D, k); atv = at_val_g(D, k, dy.rc); } }
+    if (i < nv + D.GV) {
+        double c1 = 0, c2 = 0, c3 = 0;
+        if (on) {
+            const double xi = x.z[i], si = s.z[i], vi = v.z[i];
+            c1 = th.z[i] * (atv - h.z[i]);
+            c2 = (dsc.z[i] - si * c1) / xi;
+            const double tx = dx.z[i] + c1, ts = ds.z[i] + c2;
+            if (tx < 0) a[0] = fmin(a[0], -xi / tx);
+            if (ts < 0) a[1] = fmin(a[1], -si / ts);
+            if (u > 0) {
+                const double w = u - xi;
+                c3 = (dvc.z[i] + vi * c1) / w;
+                const double tv = dv.z[i] + c3;
+                if (tx > 0) a[0] = fmin(a[0], w / tx);
+                if (tv < 0) a[1] = fmin(a[1], -vi / tv);
+            }
+        }
+        dxc.z[i] = c1; dsc.z[i] = c2; dvc.z[i] = c3;
+    }
+    block_reduce(a, 2, true, rec + (size_t)blockIdx.x * kRedVals);
+}
+// an accepted corrector joins the direction: variables, then rows
+__global__ void k_lp_mcc_acc(LpDev D, VarVec dx, VarVec ds, VarVec dv, VarVec dxc, VarVec dsc, VarVec dvc) {
+    if (LP_STOPPED(D) || D.sc[SC_MCC_ACC] == 0.0) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)D.NV * D.P + D.GV) return;
+    dx.z[i] += dxc.z[i]; ds.z[i] += dsc.z[i]; dv.z[i] += dvc.z[i];
+}
+__global__ void k_lp_mcc_acc_rows(const double *sc, const double *d, double *y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sc[SC_STOP] != 0.0 || sc[SC_MCC_ACC] == 0.0) return;
+    if (i < n) y[i] += d[i];
+}
 // sum (x + ap dx)(s + ad ds) + (w - ap dx)(v + ad dv)
 __global__ void __launch_bounds__(kRedBlock) k_lp_muaff(LpDev D, VarVec x, VarVec s, VarVec v, VarVec dx, VarVec ds, VarVec dv, double *rec) {
     if (LP_STOPPED(D)) return;
@@ -1172,6 +1263,7 @@ struct LpCtx {
     double *fj = nullptr, *fr = nullptr, *ti = nullptr, *S = nullptr, *Linv = nullptr, *diag0 = nullptr, *cb = nullptr, *cr = nullptr;
     double *rec = nullptr, *redA = nullptr, *redB = nullptr, *redC = nullptr, *part = nullptr, *ylast = nullptr, *trace = nullptr;
     int32_t *d_mult = nullptr, *d_zq = nullptr;
+    VarVec dc{}; RowVec wc{}; int mcc = 2;   // centrality correctors per iteration (KAO_LP_MCC; 0: none) and their direction / row vector
     int *trsv_flags = nullptr; double *trsv_z = nullptr; bool trsv_mw = true;   // the triangular solves by one workgroup per row tile (KAO_LP_TRSV_MW=0: by one workgroup)
     uint8_t *d_q = nullptr;   // quantised primal iterate (lp_primal)
     int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
@@ -1369,8 +1461,10 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     c->rows_local = (size_t)P * (2 + R + NJ);
     for (VarVec *vv : {&c->x, &c->s, &c->v, &c->th, &c->rd, &c->h, &c->g, &c->d1, &c->d2, &c->dsa, &c->dva, &c->ds, &c->dv})
         if ((rc = c->var_vec(*vv))) return bail(rc);
-    for (RowVec *rv : {&c->y, &c->rp, &c->w1, &c->w2})
+    for (RowVec *rv : {&c->y, &c->rp, &c->w1, &c->w2, &c->wc})
         if ((rc = c->row_vec(*rv))) return bail(rc);
+    if ((rc = c->var_vec(c->dc))) return bail(rc);
+    { const char *e = std::getenv("KAO_LP_MCC"); c->mcc = e ? std::max(0, std::min(4, std::atoi(e))) : 2; }
     const size_t nvtot = (size_t)D.NV * P + D.GV;
     c->nblk_var = (int)((nvtot + kRedBlock - 1) / kRedBlock);
     c->nblk_p = (P + 255) / 256;
@@ -1393,9 +1487,9 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_rack), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    for (const VarVec *vv : {&c->x, &c->s, &c->v, &c->th, &c->rd, &c->h, &c->g, &c->d1, &c->d2, &c->dsa, &c->dva, &c->ds, &c->dv})
+    for (const VarVec *vv : {&c->x, &c->s, &c->v, &c->th, &c->rd, &c->h, &c->g, &c->d1, &c->d2, &c->dsa, &c->dva, &c->ds, &c->dv, &c->dc})
         HIP_TRY(hipMemsetAsync(vv->z, 0, nvtot * sizeof(double), c->st));
-    for (const RowVec *rv : {&c->y, &c->rp, &c->w1, &c->w2}) HIP_TRY(hipMemsetAsync(rv->r1, 0, (c->rows_local + D.mcp) * sizeof(double), c->st));
+    for (const RowVec *rv : {&c->y, &c->rp, &c->w1, &c->w2, &c->wc}) HIP_TRY(hipMemsetAsync(rv->r1, 0, (c->rows_local + D.mcp) * sizeof(double), c->st));
     HIP_TRY(hipMemsetAsync(c->S, 0, (size_t)D.mcp * D.mcp * sizeof(double), c->st));
     HIP_TRY(hipMemsetAsync(c->ylast, 0, (size_t)D.mcp * sizeof(double), c->st));
     HIP_TRY(hipStreamSynchronize(c->st));
@@ -1424,9 +1518,9 @@ int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
     c.enqueued = 0;
     if (c.used) {   // a second solve on the context (kao_solve: the perturbed LP after the certificate's): everything lp_open zeroed
         const size_t nv0 = (size_t)D.NV * D.P + D.GV;
-        for (const VarVec *vv : {&c.x, &c.s, &c.v, &c.th, &c.rd, &c.h, &c.g, &c.d1, &c.d2, &c.dsa, &c.dva, &c.ds, &c.dv})
+        for (const VarVec *vv : {&c.x, &c.s, &c.v, &c.th, &c.rd, &c.h, &c.g, &c.d1, &c.d2, &c.dsa, &c.dva, &c.ds, &c.dv, &c.dc})
             HIP_TRY(hipMemsetAsync(vv->z, 0, nv0 * sizeof(double), c.st));
-        for (const RowVec *rv : {&c.y, &c.rp, &c.w1, &c.w2}) HIP_TRY(hipMemsetAsync(rv->r1, 0, (c.rows_local + D.mcp) * sizeof(double), c.st));
+        for (const RowVec *rv : {&c.y, &c.rp, &c.w1, &c.w2, &c.wc}) HIP_TRY(hipMemsetAsync(rv->r1, 0, (c.rows_local + D.mcp) * sizeof(double), c.st));
         HIP_TRY(hipMemsetAsync(c.S, 0, (size_t)D.mcp * D.mcp * sizeof(double), c.st));
         HIP_TRY(hipMemsetAsync(c.ylast, 0, (size_t)D.mcp * sizeof(double), c.st));
     }
@@ -1481,8 +1575,19 @@ static void lp_enqueue_one(LpCtx &c) {
                 hipLaunchKernelGGL(k_lp_sc_sigma, dim3(1), dim3(1), 0, c.st, D.sc, c.redA);
             }
         }
-        hipLaunchKernelGGL(k_lp_update, gv, b256, 0, c.st, D, c.x, c.s, c.v, c.d2, c.ds, c.dv);
         const size_t nrow = c.rows_local + D.mcp;
+        for (int k = 0; k < c.mcc; ++k) {   // centrality correctors (no-ops once one was rejected or the step is full)
+            hipLaunchKernelGGL(k_lp_mcc_h, gv, b256, 0, c.st, D, c.x, c.s, c.v, c.th, c.d2, c.ds, c.dv, c.h, c.g, c.dsa, c.dva);
+            lp_rows_local(c, c.g, c.wc, 0, c.wc);                        // local rows: A (theta h)
+            lp_solve_normal(c, c.wc, c.g, nullptr);
+            hipLaunchKernelGGL(k_lp_mcc_dir, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, c.x, c.s, c.v, c.th, c.h, c.wc, c.dc, c.dsa, c.dva, c.d2, c.ds, c.dv, c.rec);
+            lp_reduce(c, c.nblk_var, 2, true, c.redA);
+            hipLaunchKernelGGL(k_lp_sc_mcc, dim3(1), dim3(1), 0, c.st, D.sc, c.redA);
+            hipLaunchKernelGGL(k_lp_mcc_acc, gv, b256, 0, c.st, D, c.d2, c.ds, c.dv, c.dc, c.dsa, c.dva);
+            hipLaunchKernelGGL(k_lp_mcc_acc_rows, dim3((unsigned)((nrow + 255) / 256)), b256, 0, c.st, D.sc, c.wc.r1, c.w2.r1, nrow);
+        }
+        hipLaunchKernelGGL(k_lp_sc_final, dim3(1), dim3(1), 0, c.st, D.sc);
+        hipLaunchKernelGGL(k_lp_update, gv, b256, 0, c.st, D, c.x, c.s, c.v, c.d2, c.ds, c.dv);
         hipLaunchKernelGGL(k_lp_axpy, dim3((unsigned)((nrow + 255) / 256)), b256, 0, c.st, D.sc, c.w2.r1, c.y.r1, nrow);
         lp_enqueue_resid(c);
     }

@@ -674,9 +674,9 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
                 sigma_mu = ratio * ratio * ratio * mu;
             }
         }
-        {   /* EXPERIMENT hook KAO_LP_MCC=<k>: up to k centrality correctors per iteration */
+        {   /* up to two centrality correctors per iteration (the device enqueues exactly as many: KAO_LP_MCC=<k> overrides both sides, 0 = none) */
             const char *e = getenv("KAO_LP_MCC");
-            const int kmax = e ? atoi(e) : 0;
+            const int kmax = e ? atoi(e) : 2;
             for (int k = 0; k < kmax && (ap < 1.0 || ad < 1.0); ++k) {
                 const double apt = ap + MCC_DELTA < 1.0 ? ap + MCC_DELTA : 1.0, adt = ad + MCC_DELTA < 1.0 ? ad + MCC_DELTA : 1.0;
                 mcc_build(nv, L->pres, L->ub, L->uu, L->x, L->s, L->v, L->th, d2.z, ds, dv, apt, adt, sigma_mu, h.z, tmp.z, dsc, dvc);
@@ -718,7 +718,7 @@ done:
     if (stats) { stats[0] = it; stats[1] = -plast; stats[2] = -dlast; stats[3] = status; }
     free(ylast);
     free(dsa); free(dsag); free(dva); free(dvag); free(ds); free(dsg); free(dv); free(dvg);
-    if (getenv("KAO_LP_MCC")) fprintf(stderr, "[kao_lp_port] %d centrality correctors accepted in %d iterations\n", n_mcc, it);
+    if (getenv("KAO_LP_MCC_TRACE")) fprintf(stderr, "[kao_lp_port] %d centrality correctors accepted in %d iterations\n", n_mcc, it);
     free(dsc); free(dscg); free(dvc); free(dvcg);
     vec_free(&rp); vec_free(&rd); vec_free(&h); vec_free(&d1); vec_free(&d2); vec_free(&tmp); vec_free(&dc);
     lp_destroy(L);
