@@ -317,6 +317,41 @@ def primal_blocks(t: ko.Topic, x: np.ndarray, xg: np.ndarray):
     return F, L, YF, YL, np.rint(xg[:B]).astype(np.int64), np.rint(xg[B:2 * B]).astype(np.int64)
 
 
+def compact_index(t: ko.Topic) -> dict:
+    """Variable indices of build(t), by replaying its loops: zf[B], zl[B], f[P][rf_cur], l[P][rf_cur] (-1 = absent), yf[P][R], yl[P][R], n."""
+    B, R, P = t.n_brokers, t.n_racks, t.n_partitions
+    bd = t.bounds()
+    lo, hi, llo, lhi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"]
+    rlo, rhi, plo, phi = bd["rack_lo"], bd["rack_hi"], bd["prack_lo"], bd["prack_hi"]
+    has_c5, has_n = phi >= 2, hi > lo
+    n = 0
+    zf = np.zeros(B, dtype=np.int64); zl = np.zeros(B, dtype=np.int64)
+    for b in range(B):
+        zf[b] = n; zl[b] = n + 1; n += 2
+        if has_n: n += 1
+        if lhi > llo: n += 1
+    if has_n and rhi > rlo: n += R
+    f = -np.ones((P, t.rf_cur), dtype=np.int64); l = -np.ones((P, t.rf_cur), dtype=np.int64)
+    yf = np.zeros((P, R), dtype=np.int64); yl = np.zeros((P, R), dtype=np.int64)
+    for p in range(P):
+        for j in range(t.rf_cur):
+            b = int(t.current[p, j])
+            if b == ko.NONE or b >= B: continue
+            f[p, j] = n; l[p, j] = n + 1; n += 2
+            if has_c5: n += 1
+        for r in range(R):
+            yf[p, r] = n; yl[p, r] = n + 1; n += 2
+            if phi > plo: n += 1
+    return dict(zf=zf, zl=zl, f=f, l=l, yf=yf, yl=yl, n=n)
+
+
+def blocks_from_compact(t: ko.Topic, x: np.ndarray):
+    """(F, L, YF, YL, ZF, ZL) in centi-units / rounded inflows from a solution vector of build(t) (solve_highs's x)."""
+    ix = compact_index(t)
+    g = lambda idx: np.where(idx >= 0, x[np.maximum(idx, 0)], 0.0)
+    return quantise(g(ix["f"])), quantise(g(ix["l"])), quantise(g(ix["yf"])), quantise(g(ix["yl"])), np.rint(g(ix["zf"])).astype(np.int64), np.rint(g(ix["zl"])).astype(np.int64)
+
+
 def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = ROUND_TOL_C):
     """The compact LP pools the NEW replicas of a partition per rack (yf, yl) and counts what every broker receives (zf, zl): an
     integral solution still has to hand the new replicas of a rack to that rack's brokers.  Any way that respects the inflows and
