@@ -158,10 +158,16 @@ def exact_dual_value(t: ko.Topic, a, l, g) -> float:
     return st.best_L / DB_SCALE
 
 
-def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, trace=None):
+MCC_DELTA, MCC_BMIN, MCC_BMAX = 0.3, 0.1, 10.0      # Gondzio's centrality correctors (oracle/kao_lp_port.c, kao_lp.hip)
+
+
+def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, trace=None, mcc: int = 2):
     """Mehrotra predictor-corrector on min c x, A x = b, 0 <= x <= u -- the iteration kao_lp.hip runs on the block structure
     (same starting point, same step rule, same stopping rule), here with generic sparse algebra.  Returns (x, y, iterations,
-    primal objective, dual objective).  `trace`, if a list, receives (mu, pobj, dobj, pinf, dinf) per iteration."""
+    primal objective, dual objective).  `trace`, if a list, receives (mu, pobj, dobj, pinf, dinf) per iteration.  Up to `mcc`
+    centrality correctors per iteration: the step lengths of the predictor-corrector direction are enlarged by MCC_DELTA, the
+    complementarity products of that trial point are projected onto [MCC_BMIN, MCC_BMAX] x sigma mu, the direction that moves them
+    there is added when it lengthens a step by at least a hundredth of MCC_DELTA and shortens neither by more than a tenth."""
     A, b, c, u = lp.A, lp.b, lp.c, lp.u
     m, n = A.shape
     U = np.isfinite(u)
@@ -218,6 +224,24 @@ def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, t
         sigma = (mu_aff / mu) ** 3
         dx, dy, ds, dv = direction(sigma * mu - x * s - dx * ds, np.where(U, sigma * mu - w * v + dx * dv, 0.0))
         ap = min(maxstep(x, dx), maxstep(w, -dx, U)); ad = min(maxstep(s, ds), maxstep(v, dv, U))
+        mut = sigma * mu
+        for _ in range(mcc):
+            if not (ap < 1.0 or ad < 1.0):
+                break
+            apt, adt = min(1.0, ap + MCC_DELTA), min(1.0, ad + MCC_DELTA)
+            pr = (x + apt * dx) * (s + adt * ds)
+            rxs = np.maximum(np.clip(pr, MCC_BMIN * mut, MCC_BMAX * mut) - pr, -MCC_BMAX * mut)
+            pr2 = (w - apt * dx) * (v + adt * dv)
+            rwv = np.where(U, np.maximum(np.clip(pr2, MCC_BMIN * mut, MCC_BMAX * mut) - pr2, -MCC_BMAX * mut), 0.0)
+            hc = -rxs / x + np.where(U, rwv / wU, 0.0)
+            dyc = lu.solve(A @ (theta * hc))
+            dxc = theta * (AT @ dyc - hc)
+            dsc = (rxs - s * dxc) / x
+            dvc = np.where(U, (rwv + v * dxc) / wU, 0.0)
+            ap2 = min(maxstep(x, dx + dxc), maxstep(w, -(dx + dxc), U)); ad2 = min(maxstep(s, ds + dsc), maxstep(v, dv + dvc, U))
+            if not (ap2 >= ap + 0.01 * MCC_DELTA or ad2 >= ad + 0.01 * MCC_DELTA) or ap2 < 0.9 * ap or ad2 < 0.9 * ad:
+                break
+            dx, dy, ds, dv, ap, ad = dx + dxc, dy + dyc, ds + dsc, dv + dvc, ap2, ad2
         ap = 0.9995 * ap if ap < 1.0 else 1.0
         ad = 0.9995 * ad if ad < 1.0 else 1.0
         x = x + ap * dx; w = np.where(U, uu - x, 1.0)

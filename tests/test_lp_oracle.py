@@ -33,13 +33,12 @@ def test_kat1_compact_lp(ko, kp):
 
 
 @pytest.mark.parametrize("B,R,P", [(100, 5, 1000), (130, 5, 1000)])
-def test_structured_iteration_matches_the_generic_one(ko, kp, B, R, P, monkeypatch):
+def test_structured_iteration_matches_the_generic_one(ko, kp, B, R, P):
     """Rigid bands (100 x 1000: two exactly dependent coupling rows are pinned) and slack bands (130 x 1000): the block
     elimination of oracle/kao_lp_port.c follows the generic-sparse iteration of oracle/kao_lp.py iterate by iterate
     (mu, primal and dual objective to 1e-6 relative while mu >= 1e-6), both end at the HiGHS value, and the exact dual value
     at the structured iteration's duals is floor-equal to it (tests/golden/drift_scale.json: 100 x 1000 -> 7430)."""
     import kao_lp as kl
-    monkeypatch.setenv("KAO_LP_MCC", "0")     # (the generic restatement has no centrality correctors: plain predictor-corrector on both sides)
     t = _drift_topic(ko, B, R, P)
     lp = kl.build(t)
     val, _, _, _ = kl.solve_highs(lp)
