@@ -19,6 +19,8 @@ constexpr int kTolC = 30;          // a variable farther than 0.30 from an integ
 constexpr int kMaxCand = 16;       // candidate brokers of a fractional partition
 constexpr int kMaxRows = 256;      // candidate rows kept per fractional partition (by objective weight)
 constexpr long kMaxNodes = 100000; // search nodes over the fractional partitions
+constexpr int kPatMaxParts = 24;   // pattern completion: fractional partitions at most
+constexpr long kPatMaxNodes = 60000;    // ... nodes of the pattern search and of all its leaf matchings together
 constexpr int kMaxSearch = 64;     // more fractional partitions than this: the iterate is far from a vertex, no search
 constexpr uint16_t kUnset = 0xFFFFu;
 
@@ -148,6 +150,189 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
         lead_load[out[(size_t)p * RF]]++;
     }
     const size_t np = pending.size();
+    // ---- first attempt: PATTERNS (specification: oracle/kao_lp.py complete_by_patterns).  The weight of a completion comes from the
+    //      current replicas a partition keeps; the new replicas are weightless and interchangeable.  Per partition the patterns (leader:
+    //      a current replica or a new one; followers: a subset of the other current replicas; kept brokers in distinct racks), heaviest
+    //      first; depth first with the sum of the best remaining patterns as the bound; at a leaf the new slots are matched to the
+    //      brokers still below their band (leader slots first).  Only the plain case; the result is checked before it is taken.
+    bool by_patterns = false;
+    if (phi == 1 && RF <= 4 && np > 0 && np <= (size_t)kPatMaxParts && !t->broker_w && !t->broker_wl) {
+        struct Pat { int obj, lead, nf, f[KAO_MAX_RF]; };
+        std::vector<std::vector<Pat>> pats(np);
+        for (size_t i = 0; i < np; ++i) {
+            const int p = pending[i];
+            int cb[KAO_MAX_RF], cwl[KAO_MAX_RF], cwf[KAO_MAX_RF], nc = 0;
+            for (int j = 0; j < NJ; ++j) {
+                const unsigned b = t->current[(size_t)p * NJ + j];
+                if (b == KAO_NONE || (int)b >= B) continue;
+                bool dup = false;
+                for (int k = 0; k < nc; ++k) dup |= cb[k] == (int)b;
+                if (dup) continue;
+                cb[nc] = (int)b; cwl[nc] = t->w[j == 0 ? 0 : 1][0]; cwf[nc] = t->w[j == 0 ? 0 : 1][1]; ++nc;
+            }
+            std::vector<Pat> &lst = pats[i];
+            for (int li = -1; li < nc; ++li) {
+                int others[KAO_MAX_RF], no = 0;
+                for (int k = 0; k < nc; ++k) if (k != li) others[no++] = k;
+                for (int sz = 0; sz <= std::min(RF - 1, no); ++sz) {
+                    int idx[KAO_MAX_RF];
+                    for (int k = 0; k < sz; ++k) idx[k] = k;
+                    for (;;) {
+                        Pat pt; pt.lead = li >= 0 ? cb[li] : -1; pt.nf = sz; pt.obj = li >= 0 ? cwl[li] : 0;
+                        bool distinct = true;
+                        int racks[KAO_MAX_RF + 1], nr = 0;
+                        if (li >= 0) racks[nr++] = t->rack_of[cb[li]];
+                        for (int k = 0; k < sz; ++k) {
+                            const int c = others[idx[k]];
+                            pt.f[k] = cb[c]; pt.obj += cwf[c];
+                            const int rr = t->rack_of[cb[c]];
+                            for (int m = 0; m < nr; ++m) distinct &= racks[m] != rr;
+                            racks[nr++] = rr;
+                        }
+                        if (distinct) lst.push_back(pt);
+                        int k = sz - 1;
+                        while (k >= 0 && idx[k] == no - sz + k) --k;
+                        if (k < 0) break;
+                        ++idx[k];
+                        for (int m = k + 1; m < sz; ++m) idx[m] = idx[m - 1] + 1;
+                    }
+                }
+            }
+            std::stable_sort(lst.begin(), lst.end(), [](const Pat &a, const Pat &b) { return a.obj > b.obj; });
+        }
+        std::vector<long> wmax(np + 1, 0);
+        for (size_t i = np; i-- > 0;) wmax[i] = wmax[i + 1] + (pats[i].empty() ? 0 : pats[i][0].obj);
+        // the weight the iterate itself gives these partitions bounds what a completion can reach beside the rows already set
+        long target_c = 0;
+        for (int p : pending)
+            for (int j = 0; j < NJ; ++j) {
+                const unsigned b = t->current[(size_t)p * NJ + j];
+                if (b == KAO_NONE || (int)b >= B) continue;
+                target_c += (long)t->w[j == 0 ? 0 : 1][1] * Q(j, p) + (long)t->w[j == 0 ? 0 : 1][0] * Q(NJ + j, p);
+            }
+        const long target = (target_c + 25) / 100;
+        long nodes = 0, best_obj = -1, cap = kPatMaxNodes;
+        std::vector<std::vector<int>> best_rows, rows(np);
+        std::vector<const Pat *> choice(np, nullptr);
+        std::vector<int> pl = load, pd = lead_load;   // working counts
+        std::vector<std::pair<int, int>> slots;
+        std::vector<int> short_r, short_l, cands;
+        std::function<bool(size_t)> place = [&](size_t si) -> bool {
+            if (nodes > cap) return false;
+            ++nodes;
+            if (si == slots.size()) {
+                for (int b = 0; b < B; ++b) if (pl[(size_t)b] < lo || pd[(size_t)b] < llo) return false;
+                return true;
+            }
+            long left_l = 0, need_l = 0, need_r = 0;
+            for (size_t q = si; q < slots.size(); ++q) left_l += slots[q].second == 0;
+            for (int b : short_l) need_l += std::max(0, llo - pd[(size_t)b]);
+            if (need_l > left_l) return false;
+            for (int b : short_r) need_r += std::max(0, lo - pl[(size_t)b]);
+            if (need_r > (long)(slots.size() - si)) return false;
+            const int i = slots[si].first, k = slots[si].second;
+            std::vector<int> &row = rows[(size_t)i];
+            std::vector<int> cs;
+            for (int b = 0; b < B; ++b) {
+                if (pl[(size_t)b] >= hi) continue;
+                // (a follower more must leave the broker room for the leaders it is still short of, as in dfsp below)
+                if (k == 0 ? pd[(size_t)b] >= lhi : llo - pd[(size_t)b] > hi - pl[(size_t)b] - 1) continue;
+                bool clash = false;
+                for (int x : row) if (x >= 0 && (x == b || t->rack_of[x] == t->rack_of[b])) { clash = true; break; }
+                if (!clash) cs.push_back(b);
+            }
+            std::stable_sort(cs.begin(), cs.end(), [&](int a, int b) {
+                const int la = k == 0 ? std::max(0, llo - pd[(size_t)a]) : 0, lb = k == 0 ? std::max(0, llo - pd[(size_t)b]) : 0;
+                if (la != lb) return la > lb;
+                const int ra = std::max(0, lo - pl[(size_t)a]), rb = std::max(0, lo - pl[(size_t)b]);
+                if (ra != rb) return ra > rb;
+                return a < b;
+            });
+            if (cs.size() > 12) cs.resize(12);
+            for (int b : cs) {
+                row[(size_t)k] = b; pl[(size_t)b]++; if (k == 0) pd[(size_t)b]++;
+                if (place(si + 1)) return true;
+                row[(size_t)k] = -1; pl[(size_t)b]--; if (k == 0) pd[(size_t)b]--;
+            }
+            return false;
+        };
+        auto fill = [&]() -> bool {   // on success `rows` holds the complete rows and the placements are undone in the counts
+            slots.clear();
+            for (size_t i = 0; i < np; ++i) {
+                const Pat &c = *choice[i];
+                rows[i].assign(1, c.lead);
+                for (int k = 0; k < c.nf; ++k) rows[i].push_back(c.f[k]);
+            }
+            for (size_t i = 0; i < np; ++i) if (rows[i][0] < 0) slots.emplace_back((int)i, 0);
+            for (size_t i = 0; i < np; ++i)
+                for (int k = (int)rows[i].size(); k < RF; ++k) { slots.emplace_back((int)i, k); rows[i].push_back(-1); }
+            short_r.clear(); short_l.clear();
+            for (int b = 0; b < B; ++b) { if (pl[(size_t)b] < lo) short_r.push_back(b); if (pd[(size_t)b] < llo) short_l.push_back(b); }
+            // most constrained first: leader slots, then follower slots, each group by the number of brokers below their band the slot may take
+            std::vector<int> nopt(slots.size());
+            std::vector<size_t> ord(slots.size());
+            for (size_t q = 0; q < slots.size(); ++q) {
+                const std::vector<int> &row = rows[(size_t)slots[q].first];
+                int n = 0;
+                for (int b : (slots[q].second == 0 ? short_l : short_r)) {
+                    bool clash = false;
+                    for (int x : row) if (x >= 0 && (x == b || t->rack_of[x] == t->rack_of[b])) { clash = true; break; }
+                    n += !clash;
+                }
+                nopt[q] = n; ord[q] = q;
+            }
+            std::stable_sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+                const bool fx = slots[x].second != 0, fy = slots[y].second != 0;
+                if (fx != fy) return !fx;
+                return nopt[x] < nopt[y];
+            });
+            { std::vector<std::pair<int, int>> s2(slots.size()); for (size_t q = 0; q < ord.size(); ++q) s2[q] = slots[ord[q]]; slots.swap(s2); }
+            if (!place(0)) return false;
+            for (auto &sl : slots) { const int b = rows[(size_t)sl.first][(size_t)sl.second]; pl[(size_t)b]--; if (sl.second == 0) pd[(size_t)b]--; }
+            return true;
+        };
+        std::function<void(size_t, long)> dfsp = [&](size_t i, long obj) {
+            if (nodes > cap) return;
+            ++nodes;
+            if (obj + wmax[i] <= best_obj) return;
+            if (i == np) { if (fill()) { best_obj = obj; best_rows = rows; if (obj >= target) cap = -1; } return; }   // (target met: all open calls return)
+            for (const Pat &pt : pats[i]) {
+                bool bad = pt.lead >= 0 && (pl[(size_t)pt.lead] >= hi || pd[(size_t)pt.lead] >= lhi);
+                for (int k = 0; k < pt.nf && !bad; ++k) bad = pl[(size_t)pt.f[k]] >= hi;
+                if (bad) continue;
+                if (pt.lead >= 0) { pl[(size_t)pt.lead]++; pd[(size_t)pt.lead]++; }
+                for (int k = 0; k < pt.nf; ++k) pl[(size_t)pt.f[k]]++;
+                // every leader a broker is still short of takes a replica of its band too: once its followers leave no room for them no
+                // completion exists (loads only grow from here)
+                bool room = true;
+                for (int k = 0; k < pt.nf && room; ++k) room = llo - pd[(size_t)pt.f[k]] <= hi - pl[(size_t)pt.f[k]];
+                if (room) { choice[i] = &pt; dfsp(i + 1, obj + pt.obj); }
+                if (pt.lead >= 0) { pl[(size_t)pt.lead]--; pd[(size_t)pt.lead]--; }
+                for (int k = 0; k < pt.nf; ++k) pl[(size_t)pt.f[k]]--;
+            }
+        };
+        dfsp(0, 0);
+        if (best_obj >= 0) {   // the result against the rows of the model it must satisfy
+            bool okr = true;
+            std::vector<int> l2 = load, d2 = lead_load;
+            for (size_t i = 0; i < np && okr; ++i) {
+                const std::vector<int> &r = best_rows[i];
+                okr = (int)r.size() == RF;
+                for (int a = 0; a < RF && okr; ++a) {
+                    okr = r[(size_t)a] >= 0;
+                    for (int b2 = 0; b2 < a && okr; ++b2) okr = r[(size_t)a] != r[(size_t)b2] && t->rack_of[r[(size_t)a]] != t->rack_of[r[(size_t)b2]];
+                }
+                if (okr) { for (int b : r) l2[(size_t)b]++; d2[(size_t)r[0]]++; }
+            }
+            for (int b = 0; b < B && okr; ++b) okr = l2[(size_t)b] >= lo && l2[(size_t)b] <= hi && d2[(size_t)b] >= llo && d2[(size_t)b] <= lhi;
+            if (okr) {
+                for (size_t i = 0; i < np; ++i)
+                    for (int k = 0; k < RF; ++k) out[(size_t)pending[i] * RF + k] = (uint16_t)best_rows[i][(size_t)k];
+                by_patterns = true;
+            }
+        }
+    }
+    if (!by_patterns) {
     std::vector<std::vector<Row>> rows_of(np);
     std::vector<int> cand, wl((size_t)B, 0), wf((size_t)B, 0), order;
     for (size_t i = 0; i < np; ++i) {
@@ -315,6 +500,7 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
         if (rows.empty()) { for (int k = 0; k < RF; ++k) out[(size_t)p * RF + k] = (uint16_t)k; continue; }
         for (int k = 0; k < RF; ++k) out[(size_t)p * RF + k] = (uint16_t)rows[(size_t)ri].b[k];
     }
+    }   // (!by_patterns)
     if (rep) { rep[1] = over; rep[2] = unplaced; rep[3] = from_fb; }
     (void)swaps;
     } while (0);

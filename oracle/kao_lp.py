@@ -486,6 +486,25 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
         for p in pending:
             A[p] = np.asarray(fallback[p]); rep["from_fallback"] += 1
         return A, rep
+    # ---- first attempt: PATTERNS.  The weight of a completion comes from the current replicas a partition keeps (README.md:145-146);
+    #      the new replicas are weightless and interchangeable.  So: per partition the patterns (leader: a current replica or a new one;
+    #      followers: a subset of the other current replicas; kept brokers in distinct racks), heaviest first; depth first over the
+    #      partitions with the sum of the best remaining patterns as the bound; at a leaf the new slots are matched to the brokers still
+    #      below their band (leader slots first).  Only the plain case (one replica per rack, no broker weights, few partitions); the
+    #      result is checked against the band rows before it is taken -- otherwise the search over candidate rows below runs as before.
+    #      The weight the iterate itself gives these partitions bounds what a completion can reach beside the rows already set, so the
+    #      search stops as soon as it is met.
+    target_c = 0
+    for p in pending:
+        for j in range(NJ):
+            b = int(t.current[p, j])
+            if b != ko.NONE and b < B:
+                target_c += t.weights[0 if j == 0 else 1][1] * int(F[p, j]) + t.weights[0 if j == 0 else 1][0] * int(L[p, j])
+    got = complete_by_patterns(t, A, pending, load, lead_load, (target_c + 25) // 100)
+    rep["patterns"] = int(got)
+    if got:
+        rep["repaired"] = repair_bands(t, A)
+        return A, rep
     # ---- the fractional partitions, together: candidate rows from their support, chosen by a bounded depth-first search so that the
     #      band rows (README.md:158-166) come out right given what the other partitions hold ----
     w = t.weights
@@ -617,6 +636,136 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
         A[p] = rowb
     rep["repaired"] = repair_bands(t, A)
     return A, rep
+
+
+PAT_MAX_PARTS = 24       # pattern completion: fractional partitions at most
+PAT_MAX_NODES = 60000    # ... nodes of the pattern search and of all its leaf matchings together
+
+
+def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> bool:
+    """See round_primal.  On success the rows of `pending` in A are set and every broker is inside its bands; else A is untouched."""
+    import itertools
+    B, R, P, RF, NJ = t.n_brokers, t.n_racks, t.n_partitions, t.rf, t.rf_cur
+    bd = t.bounds()
+    lo, hi, llo, lhi, phi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"], bd["prack_hi"]
+    if phi != 1 or RF > 4 or not pending or len(pending) > PAT_MAX_PARTS: return False
+    if getattr(t, "broker_w", None) is not None or getattr(t, "broker_wl", None) is not None: return False
+    rack = [int(r) for r in np.asarray(t.rack_of)]
+    w = t.weights
+    load = [int(v) for v in load0]; lead = [int(v) for v in lead0]
+    npd = len(pending)
+    pats = []
+    for p in pending:
+        cur = []
+        for j in range(NJ):
+            b = int(t.current[p, j])
+            if b != ko.NONE and b < B and b not in [c[0] for c in cur]: cur.append((b, w[0 if j == 0 else 1][0], w[0 if j == 0 else 1][1]))
+        lst = []
+        for li in [-1] + list(range(len(cur))):
+            others = [k for k in range(len(cur)) if k != li]
+            for sz in range(0, min(RF - 1, len(others)) + 1):
+                for fs in itertools.combinations(others, sz):
+                    kept = ([cur[li][0]] if li >= 0 else []) + [cur[k][0] for k in fs]
+                    if len({rack[b] for b in kept}) != len(kept): continue
+                    obj = (cur[li][1] if li >= 0 else 0) + sum(cur[k][2] for k in fs)
+                    lst.append((obj, cur[li][0] if li >= 0 else -1, tuple(cur[k][0] for k in fs)))
+        lst.sort(key=lambda x: -x[0])
+        pats.append(lst)
+    wmax = [0] * (npd + 1)
+    for i in range(npd - 1, -1, -1): wmax[i] = wmax[i + 1] + (pats[i][0][0] if pats[i] else 0)
+    nodes = [0]; cap = [PAT_MAX_NODES]
+    best = dict(obj=-1, rows=None)
+    choice = [None] * npd
+
+    def fill():
+        # the new slots of every partition: a new leader where the pattern keeps none, then the new followers
+        rows = [[c[1]] + list(c[2]) if c[1] >= 0 else [-1] + list(c[2]) for c in choice]
+        slots = []
+        for i in range(npd):
+            if rows[i][0] < 0: slots.append((i, 0))
+        for i in range(npd):
+            for k in range(len(rows[i]), RF): slots.append((i, k)); rows[i].append(-1)
+
+        def place(si):
+            if nodes[0] > cap[0]: return False
+            nodes[0] += 1
+            if si == len(slots):
+                return all(load[b] >= lo for b in range(B)) and all(lead[b] >= llo for b in range(B))
+            # what is left must still be able to lift every broker to its band
+            left_l = sum(1 for (i2, k2) in slots[si:] if k2 == 0)
+            # (the slots are sorted: leader slots first)
+            if sum(max(0, llo - lead[b]) for b in short_l) > left_l: return False
+            if sum(max(0, lo - load[b]) for b in short_r) > len(slots) - si: return False
+            i, k = slots[si]
+            used = [b for b in rows[i] if b >= 0]
+            racks = {rack[b] for b in used}
+            # (a follower more must leave the broker room for the leaders it is still short of, as in dfs below)
+            cands = [b for b in range(B) if load[b] < hi and (lead[b] < lhi if k == 0 else llo - lead[b] <= hi - load[b] - 1)
+                     and b not in used and rack[b] not in racks]
+            cands.sort(key=lambda b: (-(max(0, llo - lead[b]) if k == 0 else 0), -max(0, lo - load[b]), b))
+            for b in cands[:12]:
+                rows[i][k] = b; load[b] += 1
+                if k == 0: lead[b] += 1
+                ok = place(si + 1)
+                if ok: return True
+                rows[i][k] = -1; load[b] -= 1
+                if k == 0: lead[b] -= 1
+            return False
+
+        short_r = [b for b in range(B) if load[b] < lo]; short_l = [b for b in range(B) if lead[b] < llo]
+        # most constrained first: leader slots, then follower slots, each group by the number of brokers below their band the slot may take
+        def n_opts(sl):
+            i, k = sl
+            used = [b for b in rows[i] if b >= 0]; racks = {rack[b] for b in used}
+            pool = short_l if k == 0 else short_r
+            return sum(1 for b in pool if b not in used and rack[b] not in racks)
+        slots.sort(key=lambda sl: (sl[1] != 0, n_opts(sl)))
+        ok = place(0)
+        if ok:
+            out = [list(r) for r in rows]
+            # undo the placements (the caller keeps searching for a heavier choice of patterns)
+            for (i, k) in slots:
+                b = rows[i][k]; load[b] -= 1
+                if k == 0: lead[b] -= 1
+            return out
+        return None
+
+    def dfs(i, obj):
+        if nodes[0] > cap[0]: return
+        nodes[0] += 1
+        if obj + wmax[i] <= best["obj"]: return
+        if i == npd:
+            rows = fill()
+            if rows is not None:
+                best.update(obj=obj, rows=rows)
+                if obj >= target: cap[0] = -1          # nothing heavier to find: every call still open returns at once
+            return
+        for (o, ld, fs) in pats[i]:
+            kept = ([ld] if ld >= 0 else []) + list(fs)
+            if any(load[b] >= hi for b in kept) or (ld >= 0 and lead[ld] >= lhi): continue
+            for b in kept: load[b] += 1
+            if ld >= 0: lead[ld] += 1
+            # every leader a broker is still short of takes a replica of its band too: once its followers leave no room for them no
+            # completion exists (loads only grow from here)
+            if all(llo - lead[b] <= hi - load[b] for b in fs):
+                choice[i] = (o, ld, fs)
+                dfs(i + 1, obj + o)
+            for b in kept: load[b] -= 1
+            if ld >= 0: lead[ld] -= 1
+
+    dfs(0, 0)
+    if best["rows"] is None: return False
+    # the result against the rows of the model it must satisfy: complete rows, distinct brokers and racks, every broker inside its bands
+    for i, p in enumerate(pending):
+        r = best["rows"][i]
+        if len(r) != RF or min(r) < 0 or len(set(r)) != RF or len({rack[b] for b in r}) != RF: return False
+    l2 = [int(v) for v in load0]; d2 = [int(v) for v in lead0]
+    for r in best["rows"]:
+        for b in r: l2[b] += 1
+        d2[r[0]] += 1
+    if any(l2[b] < lo or l2[b] > hi or d2[b] < llo or d2[b] > lhi for b in range(B)): return False
+    for i, p in enumerate(pending): A[p] = best["rows"][i]
+    return True
 
 
 def repair_bands(t: ko.Topic, A) -> int:

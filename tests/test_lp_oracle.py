@@ -166,6 +166,31 @@ def test_host_rounding_matches_the_specification(ko, kp):
     assert n >= 130 and n_search >= 5 and n_swaps >= 3, (n, n_search, n_swaps)
 
 
+@pytest.mark.parametrize("B,R,P,dseed,salt,fractional", [(60, 6, 400, 1, 1, 14), (100, 10, 1000, 2, 2, 9), (300, 10, 2000, 1, 3, 13)])
+def test_half_integral_vertex_is_completed_by_patterns(ko, kp, B, R, P, dseed, salt, fractional):
+    """Perturbed LPs whose vertex is half-integral in 9..14 partitions (rigid bands: every broker's band is a single value).  The
+    pattern completion (oracle/kao_lp.py complete_by_patterns: which current replicas each of these partitions keeps, heaviest
+    first; the new replicas matched to the brokers still below their band) gives an assignment the README's rows accept
+    (README.md:148-180, ko.verify) whose weight IS the certificate, floor of the exact dual value at the unperturbed LP's row
+    duals -- optimal, proven.  The search over candidate rows it replaced ended 2..12 below on the same iterates (docs/notes_r05.md
+    section 6).  The product's host half (kao_round.cpp) returns the same rows."""
+    import kao_lp as kl
+    import kafka_assignment_optimizer_amd as kao
+    from conftest import to_product_topic
+    t = _drift_topic(ko, B, R, P, dseed)
+    r0 = kl.port_solve(t)
+    bound = math.floor(kl.exact_dual_value(t, r0["a"], r0["l"], r0["g"]) + 1e-9)
+    r = kl.port_solve(t, tol=1e-8, maxit=200, primal=True, pert=min(1e-2, 100.0 / (P * 3)), salt=salt)
+    assert r["status"] == 0
+    blocks = kl.primal_blocks(t, r["x"], r["xg"])
+    A, rep = kl.round_primal(t, *blocks)
+    obj, viol = ko.verify(t, A)
+    assert rep["fractional"] == fractional and rep["patterns"] == 1, rep
+    assert int(np.asarray(viol).sum()) == 0 and obj == bound, (obj, bound, rep)
+    d = kao.lp_round_host(to_product_topic(t), *_pack(*blocks))
+    assert d["assignment"].tolist() == A.tolist() and d["fractional"] == fractional
+
+
 def test_band_repair_matches_the_specification(ko, kp):
     """The band repair at the end of the rounding (kao_round.cpp against oracle/kao_lp.py repair_bands, through kao_lp_round_host mode 2),
     on imbalances built from an optimal assignment of a drifted 100-broker topic: (a) weightless follower replicas piled onto two
