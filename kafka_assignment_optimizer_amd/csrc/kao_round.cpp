@@ -158,7 +158,9 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     bool by_patterns = false;
     if (phi == 1 && RF <= 4 && np > 0 && np <= (size_t)kPatMaxParts && !t->broker_w && !t->broker_wl) {
         struct Pat { int obj, lead, nf, f[KAO_MAX_RF]; };
+        struct Item { int b, wl, wf; };   // a current replica: weight kept as leader / as follower
         std::vector<std::vector<Pat>> pats(np);
+        std::vector<std::vector<Item>> items(np);
         for (size_t i = 0; i < np; ++i) {
             const int p = pending[i];
             int cb[KAO_MAX_RF], cwl[KAO_MAX_RF], cwf[KAO_MAX_RF], nc = 0;
@@ -170,6 +172,7 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                 if (dup) continue;
                 cb[nc] = (int)b; cwl[nc] = t->w[j == 0 ? 0 : 1][0]; cwf[nc] = t->w[j == 0 ? 0 : 1][1]; ++nc;
             }
+            for (int k = 0; k < nc; ++k) items[i].push_back({cb[k], cwl[k], cwf[k]});
             std::vector<Pat> &lst = pats[i];
             for (int li = -1; li < nc; ++li) {
                 int others[KAO_MAX_RF], no = 0;
@@ -189,6 +192,9 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                             for (int m = 0; m < nr; ++m) distinct &= racks[m] != rr;
                             racks[nr++] = rr;
                         }
+                        // (no room even now: the broker's band or leader band is full before any of these partitions is set)
+                        if (li >= 0 && (load[(size_t)cb[li]] >= hi || lead_load[(size_t)cb[li]] >= lhi)) distinct = false;
+                        for (int k = 0; k < sz && distinct; ++k) distinct = load[(size_t)pt.f[k]] < hi;
                         if (distinct) lst.push_back(pt);
                         int k = sz - 1;
                         while (k >= 0 && idx[k] == no - sz + k) --k;
@@ -216,12 +222,13 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
         std::vector<const Pat *> choice(np, nullptr);
         std::vector<int> pl = load, pd = lead_load;   // working counts
         std::vector<std::pair<int, int>> slots;
-        std::vector<int> short_r, short_l, cands;
+        std::vector<int> short_r, short_l, open_b;
         std::function<bool(size_t)> place = [&](size_t si) -> bool {
             if (nodes > cap) return false;
             ++nodes;
-            if (si == slots.size()) {
-                for (int b = 0; b < B; ++b) if (pl[(size_t)b] < lo || pd[(size_t)b] < llo) return false;
+            if (si == slots.size()) {   // (only the brokers short when the matching began can still be short: counts only grow)
+                for (int b : short_r) if (pl[(size_t)b] < lo) return false;
+                for (int b : short_l) if (pd[(size_t)b] < llo) return false;
                 return true;
             }
             long left_l = 0, need_l = 0, need_r = 0;
@@ -233,7 +240,7 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
             const int i = slots[si].first, k = slots[si].second;
             std::vector<int> &row = rows[(size_t)i];
             std::vector<int> cs;
-            for (int b = 0; b < B; ++b) {
+            for (int b : open_b) {   // (ascending; the brokers with room when the matching began)
                 if (pl[(size_t)b] >= hi) continue;
                 // (a follower more must leave the broker room for the leaders it is still short of, as in dfsp below)
                 if (k == 0 ? pd[(size_t)b] >= lhi : llo - pd[(size_t)b] > hi - pl[(size_t)b] - 1) continue;
@@ -266,8 +273,12 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
             for (size_t i = 0; i < np; ++i) if (rows[i][0] < 0) slots.emplace_back((int)i, 0);
             for (size_t i = 0; i < np; ++i)
                 for (int k = (int)rows[i].size(); k < RF; ++k) { slots.emplace_back((int)i, k); rows[i].push_back(-1); }
-            short_r.clear(); short_l.clear();
-            for (int b = 0; b < B; ++b) { if (pl[(size_t)b] < lo) short_r.push_back(b); if (pd[(size_t)b] < llo) short_l.push_back(b); }
+            short_r.clear(); short_l.clear(); open_b.clear();
+            for (int b = 0; b < B; ++b) {
+                if (pl[(size_t)b] < lo) short_r.push_back(b);
+                if (pd[(size_t)b] < llo) short_l.push_back(b);
+                if (pl[(size_t)b] < hi) open_b.push_back(b);
+            }
             // most constrained first: leader slots, then follower slots, each group by the number of brokers below their band the slot may take
             std::vector<int> nopt(slots.size());
             std::vector<size_t> ord(slots.size());
@@ -291,10 +302,26 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
             for (auto &sl : slots) { const int b = rows[(size_t)sl.first][(size_t)sl.second]; pl[(size_t)b]--; if (sl.second == 0) pd[(size_t)b]--; }
             return true;
         };
+        // second bound on what partitions i.. can still add: a broker keeps at most as many of their current replicas as its band has
+        // room for, the heaviest ones (the one-leader-per-partition row dropped)
+        std::vector<std::pair<int, int>> per;
+        auto room_bound = [&](size_t i) {
+            per.clear();
+            for (size_t q = i; q < np; ++q)
+                for (const Item &it : items[q]) per.emplace_back(it.b, -std::max(pd[(size_t)it.b] < lhi ? it.wl : 0, it.wf));
+            std::sort(per.begin(), per.end());
+            long tot = 0; int last = -1, left = 0;
+            for (auto &e : per) {
+                if (e.first != last) { last = e.first; left = hi - pl[(size_t)e.first]; }
+                if (left > 0) { tot -= e.second; --left; }
+            }
+            return tot;
+        };
         std::function<void(size_t, long)> dfsp = [&](size_t i, long obj) {
             if (nodes > cap) return;
             ++nodes;
             if (obj + wmax[i] <= best_obj) return;
+            if (best_obj >= 0 && obj + room_bound(i) <= best_obj) return;
             if (i == np) { if (fill()) { best_obj = obj; best_rows = rows; if (obj >= target) cap = -1; } return; }   // (target met: all open calls return)
             for (const Pat &pt : pats[i]) {
                 bool bad = pt.lead >= 0 && (pl[(size_t)pt.lead] >= hi || pd[(size_t)pt.lead] >= lhi);

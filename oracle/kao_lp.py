@@ -655,11 +655,13 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> 
     load = [int(v) for v in load0]; lead = [int(v) for v in lead0]
     npd = len(pending)
     pats = []
+    items = []       # per partition: (current replica, weight kept as leader, weight kept as follower)
     for p in pending:
         cur = []
         for j in range(NJ):
             b = int(t.current[p, j])
             if b != ko.NONE and b < B and b not in [c[0] for c in cur]: cur.append((b, w[0 if j == 0 else 1][0], w[0 if j == 0 else 1][1]))
+        items.append(cur)
         lst = []
         for li in [-1] + list(range(len(cur))):
             others = [k for k in range(len(cur)) if k != li]
@@ -667,6 +669,7 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> 
                 for fs in itertools.combinations(others, sz):
                     kept = ([cur[li][0]] if li >= 0 else []) + [cur[k][0] for k in fs]
                     if len({rack[b] for b in kept}) != len(kept): continue
+                    if any(load[b] >= hi for b in kept) or (li >= 0 and lead[cur[li][0]] >= lhi): continue   # no room even now
                     obj = (cur[li][1] if li >= 0 else 0) + sum(cur[k][2] for k in fs)
                     lst.append((obj, cur[li][0] if li >= 0 else -1, tuple(cur[k][0] for k in fs)))
         lst.sort(key=lambda x: -x[0])
@@ -690,7 +693,7 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> 
             if nodes[0] > cap[0]: return False
             nodes[0] += 1
             if si == len(slots):
-                return all(load[b] >= lo for b in range(B)) and all(lead[b] >= llo for b in range(B))
+                return all(load[b] >= lo for b in short_r) and all(lead[b] >= llo for b in short_l)   # (counts only grow: nobody else can be short)
             # what is left must still be able to lift every broker to its band
             left_l = sum(1 for (i2, k2) in slots[si:] if k2 == 0)
             # (the slots are sorted: leader slots first)
@@ -700,7 +703,7 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> 
             used = [b for b in rows[i] if b >= 0]
             racks = {rack[b] for b in used}
             # (a follower more must leave the broker room for the leaders it is still short of, as in dfs below)
-            cands = [b for b in range(B) if load[b] < hi and (lead[b] < lhi if k == 0 else llo - lead[b] <= hi - load[b] - 1)
+            cands = [b for b in open_b if load[b] < hi and (lead[b] < lhi if k == 0 else llo - lead[b] <= hi - load[b] - 1)
                      and b not in used and rack[b] not in racks]
             cands.sort(key=lambda b: (-(max(0, llo - lead[b]) if k == 0 else 0), -max(0, lo - load[b]), b))
             for b in cands[:12]:
@@ -713,6 +716,7 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> 
             return False
 
         short_r = [b for b in range(B) if load[b] < lo]; short_l = [b for b in range(B) if lead[b] < llo]
+        open_b = [b for b in range(B) if load[b] < hi]      # the brokers with room when the matching begins (ascending)
         # most constrained first: leader slots, then follower slots, each group by the number of brokers below their band the slot may take
         def n_opts(sl):
             i, k = sl
@@ -730,10 +734,21 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> 
             return out
         return None
 
+    def room_bound(i):
+        # second bound on what partitions i.. can still add: a broker keeps at most as many of their current replicas as its band has
+        # room for, the heaviest ones (the one-leader-per-partition row dropped)
+        per = sorted((b, -max(wl if lead[b] < lhi else 0, wf)) for q in range(i, npd) for (b, wl, wf) in items[q])
+        tot = 0; last = -1; left = 0
+        for (b, nw) in per:
+            if b != last: last = b; left = hi - load[b]
+            if left > 0: tot -= nw; left -= 1
+        return tot
+
     def dfs(i, obj):
         if nodes[0] > cap[0]: return
         nodes[0] += 1
         if obj + wmax[i] <= best["obj"]: return
+        if best["obj"] >= 0 and obj + room_bound(i) <= best["obj"]: return
         if i == npd:
             rows = fill()
             if rows is not None:

@@ -166,11 +166,13 @@ def test_host_rounding_matches_the_specification(ko, kp):
     assert n >= 130 and n_search >= 5 and n_swaps >= 3, (n, n_search, n_swaps)
 
 
-@pytest.mark.parametrize("B,R,P,dseed,salt,fractional", [(60, 6, 400, 1, 1, 14), (100, 10, 1000, 2, 2, 9), (300, 10, 2000, 1, 3, 13)])
+@pytest.mark.parametrize("B,R,P,dseed,salt,fractional", [(60, 6, 400, 1, 1, 14), (100, 10, 1000, 2, 2, 9), (300, 10, 2000, 1, 3, 13),
+                                                         (300, 10, 2000, 2, 4, 19)])
 def test_half_integral_vertex_is_completed_by_patterns(ko, kp, B, R, P, dseed, salt, fractional):
-    """Perturbed LPs whose vertex is half-integral in 9..14 partitions (rigid bands: every broker's band is a single value).  The
+    """Perturbed LPs whose vertex is half-integral in 9..19 partitions (rigid bands: every broker's band is a single value).  The
     pattern completion (oracle/kao_lp.py complete_by_patterns: which current replicas each of these partitions keeps, heaviest
-    first; the new replicas matched to the brokers still below their band) gives an assignment the README's rows accept
+    first, bounded by the best remaining patterns and by the room the brokers' bands have left -- the 19-partition case needs the
+    second bound: 126 nodes instead of 218,000; the new replicas matched to the brokers still below their band) gives an assignment the README's rows accept
     (README.md:148-180, ko.verify) whose weight IS the certificate, floor of the exact dual value at the unperturbed LP's row
     duals -- optimal, proven.  The search over candidate rows it replaced ended 2..12 below on the same iterates (docs/notes_r05.md
     section 6).  The product's host half (kao_round.cpp) returns the same rows."""
