@@ -157,20 +157,20 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     //      brokers still below their band (leader slots first).  Only the plain case; the result is checked before it is taken.
     bool by_patterns = false;
     if (phi == 1 && RF <= 4 && np > 0 && np <= (size_t)kPatMaxParts && !t->broker_w && !t->broker_wl) {
-        struct Pat { int obj, lead, nf, f[KAO_MAX_RF]; };
+        struct Pat { int obj, lead, nf, f[KAO_MAX_RF], mass; };   // (mass: what the iterate itself keeps of the pattern, centi-units)
         struct Item { int b, wl, wf; };   // a current replica: weight kept as leader / as follower
         std::vector<std::vector<Pat>> pats(np);
         std::vector<std::vector<Item>> items(np);
         for (size_t i = 0; i < np; ++i) {
             const int p = pending[i];
-            int cb[KAO_MAX_RF], cwl[KAO_MAX_RF], cwf[KAO_MAX_RF], nc = 0;
+            int cb[KAO_MAX_RF], cwl[KAO_MAX_RF], cwf[KAO_MAX_RF], cml[KAO_MAX_RF], cmf[KAO_MAX_RF], nc = 0;
             for (int j = 0; j < NJ; ++j) {
                 const unsigned b = t->current[(size_t)p * NJ + j];
                 if (b == KAO_NONE || (int)b >= B) continue;
                 bool dup = false;
                 for (int k = 0; k < nc; ++k) dup |= cb[k] == (int)b;
                 if (dup) continue;
-                cb[nc] = (int)b; cwl[nc] = t->w[j == 0 ? 0 : 1][0]; cwf[nc] = t->w[j == 0 ? 0 : 1][1]; ++nc;
+                cb[nc] = (int)b; cwl[nc] = t->w[j == 0 ? 0 : 1][0]; cwf[nc] = t->w[j == 0 ? 0 : 1][1]; cml[nc] = Q(NJ + j, p); cmf[nc] = Q(j, p); ++nc;
             }
             for (int k = 0; k < nc; ++k) items[i].push_back({cb[k], cwl[k], cwf[k]});
             std::vector<Pat> &lst = pats[i];
@@ -181,13 +181,13 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                     int idx[KAO_MAX_RF];
                     for (int k = 0; k < sz; ++k) idx[k] = k;
                     for (;;) {
-                        Pat pt; pt.lead = li >= 0 ? cb[li] : -1; pt.nf = sz; pt.obj = li >= 0 ? cwl[li] : 0;
+                        Pat pt; pt.lead = li >= 0 ? cb[li] : -1; pt.nf = sz; pt.obj = li >= 0 ? cwl[li] : 0; pt.mass = li >= 0 ? cml[li] : 0;
                         bool distinct = true;
                         int racks[KAO_MAX_RF + 1], nr = 0;
                         if (li >= 0) racks[nr++] = t->rack_of[cb[li]];
                         for (int k = 0; k < sz; ++k) {
                             const int c = others[idx[k]];
-                            pt.f[k] = cb[c]; pt.obj += cwf[c];
+                            pt.f[k] = cb[c]; pt.obj += cwf[c]; pt.mass += cmf[c];
                             const int rr = t->rack_of[cb[c]];
                             for (int m = 0; m < nr; ++m) distinct &= racks[m] != rr;
                             racks[nr++] = rr;
@@ -204,7 +204,8 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                     }
                 }
             }
-            std::stable_sort(lst.begin(), lst.end(), [](const Pat &a, const Pat &b) { return a.obj > b.obj; });
+            // heaviest first; among equals the one the iterate leans to
+            std::stable_sort(lst.begin(), lst.end(), [](const Pat &a, const Pat &b) { return a.obj != b.obj ? a.obj > b.obj : a.mass > b.mass; });
         }
         std::vector<long> wmax(np + 1, 0);
         for (size_t i = np; i-- > 0;) wmax[i] = wmax[i + 1] + (pats[i].empty() ? 0 : pats[i][0].obj);

@@ -500,7 +500,7 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
             b = int(t.current[p, j])
             if b != ko.NONE and b < B:
                 target_c += t.weights[0 if j == 0 else 1][1] * int(F[p, j]) + t.weights[0 if j == 0 else 1][0] * int(L[p, j])
-    got = complete_by_patterns(t, A, pending, load, lead_load, (target_c + 25) // 100)
+    got = complete_by_patterns(t, A, pending, load, lead_load, (target_c + 25) // 100, F, L)
     rep["patterns"] = int(got)
     if got:
         rep["repaired"] = repair_bands(t, A)
@@ -642,7 +642,7 @@ PAT_MAX_PARTS = 24       # pattern completion: fractional partitions at most
 PAT_MAX_NODES = 60000    # ... nodes of the pattern search and of all its leaf matchings together
 
 
-def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> bool:
+def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int, F, L) -> bool:
     """See round_primal.  On success the rows of `pending` in A are set and every broker is inside its bands; else A is untouched."""
     import itertools
     B, R, P, RF, NJ = t.n_brokers, t.n_racks, t.n_partitions, t.rf, t.rf_cur
@@ -660,8 +660,9 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> 
         cur = []
         for j in range(NJ):
             b = int(t.current[p, j])
-            if b != ko.NONE and b < B and b not in [c[0] for c in cur]: cur.append((b, w[0 if j == 0 else 1][0], w[0 if j == 0 else 1][1]))
-        items.append(cur)
+            if b != ko.NONE and b < B and b not in [c[0] for c in cur]:
+                cur.append((b, w[0 if j == 0 else 1][0], w[0 if j == 0 else 1][1], int(L[p, j]), int(F[p, j])))
+        items.append([c[:3] for c in cur])
         lst = []
         for li in [-1] + list(range(len(cur))):
             others = [k for k in range(len(cur)) if k != li]
@@ -671,9 +672,10 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int) -> 
                     if len({rack[b] for b in kept}) != len(kept): continue
                     if any(load[b] >= hi for b in kept) or (li >= 0 and lead[cur[li][0]] >= lhi): continue   # no room even now
                     obj = (cur[li][1] if li >= 0 else 0) + sum(cur[k][2] for k in fs)
-                    lst.append((obj, cur[li][0] if li >= 0 else -1, tuple(cur[k][0] for k in fs)))
-        lst.sort(key=lambda x: -x[0])
-        pats.append(lst)
+                    mass = (cur[li][3] if li >= 0 else 0) + sum(cur[k][4] for k in fs)     # what the iterate itself keeps of this pattern
+                    lst.append((obj, cur[li][0] if li >= 0 else -1, tuple(cur[k][0] for k in fs), mass))
+        lst.sort(key=lambda x: (-x[0], -x[3]))      # heaviest first; among equals the one the iterate leans to
+        pats.append([x[:3] for x in lst])
     wmax = [0] * (npd + 1)
     for i in range(npd - 1, -1, -1): wmax[i] = wmax[i + 1] + (pats[i][0][0] if pats[i] else 0)
     nodes = [0]; cap = [PAT_MAX_NODES]
