@@ -19,7 +19,7 @@ constexpr int kTolC = 30;          // a variable farther than 0.30 from an integ
 constexpr int kMaxCand = 16;       // candidate brokers of a fractional partition
 constexpr int kMaxRows = 256;      // candidate rows kept per fractional partition (by objective weight)
 constexpr long kMaxNodes = 100000; // search nodes over the fractional partitions
-constexpr int kPatMaxParts = 24;   // pattern completion: fractional partitions at most
+constexpr int kPatMaxParts = 32;   // pattern completion: fractional partitions at most
 constexpr long kPatMaxNodes = 60000;    // ... nodes of the pattern search and of all its leaf matchings together
 constexpr int kMaxSearch = 64;     // more fractional partitions than this: the iterate is far from a vertex, no search
 constexpr uint16_t kUnset = 0xFFFFu;
@@ -75,7 +75,7 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
         ++unplaced;
         return -1;
     };
-    std::vector<int> pending, cur((size_t)NJ), row;
+    std::vector<int> pending, overp, cur((size_t)NJ), row;
     std::vector<std::tuple<int, int, int>> undo;          // (kind, broker, units) taken by the row under construction
     std::vector<std::tuple<int, int, int>> new_slots;     // (rack, kind, slot)
     for (int p = 0; p < P; ++p) {
@@ -133,6 +133,13 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
         out[(size_t)p * RF] = (uint16_t)lead;
         for (int k = 1; k < RF; ++k) out[(size_t)p * RF + k] = (uint16_t)row[(size_t)k - 1];
         for (auto &ns : new_slots) placed[std::get<1>(ns)][(size_t)std::get<0>(ns)].emplace_back(p, std::get<2>(ns));
+        if (over > over0) overp.push_back(p);
+    }
+    // rows that took a replica outside the inflows (its broker ends over its band) are given up again when the pattern completion can
+    // take them along: it sees the bands, not the inflows
+    if (!overp.empty() && phi == 1 && RF <= 4 && pending.size() + overp.size() <= (size_t)kPatMaxParts && !t->broker_w && !t->broker_wl) {
+        pending.insert(pending.end(), overp.begin(), overp.end());
+        std::sort(pending.begin(), pending.end());
     }
     if (rep) { rep[0] = (int32_t)pending.size(); }
     if (fallback) {
@@ -152,9 +159,11 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     const size_t np = pending.size();
     // ---- first attempt: PATTERNS (specification: oracle/kao_lp.py complete_by_patterns).  The weight of a completion comes from the
     //      current replicas a partition keeps; the new replicas are weightless and interchangeable.  Per partition the patterns (leader:
-    //      a current replica or a new one; followers: a subset of the other current replicas; kept brokers in distinct racks), heaviest
-    //      first; depth first with the sum of the best remaining patterns as the bound; at a leaf the new slots are matched to the
-    //      brokers still below their band (leader slots first).  Only the plain case; the result is checked before it is taken.
+    //      a current replica or a new one; followers: a subset of the other current replicas; kept brokers in distinct racks, with room
+    //      in their bands), heaviest first, ties by the iterate's own mass on the kept replicas; depth first, bounded by the sum of the
+    //      best remaining patterns and by the room left in the brokers' bands; at a leaf the new slots are matched to the brokers still
+    //      below their band (most constrained slot first).  Done when the weight the iterate gives these partitions is met.  Only the
+    //      plain case; the result is checked before it is taken.
     bool by_patterns = false;
     if (phi == 1 && RF <= 4 && np > 0 && np <= (size_t)kPatMaxParts && !t->broker_w && !t->broker_wl) {
         struct Pat { int obj, lead, nf, f[KAO_MAX_RF], mass; };   // (mass: what the iterate itself keeps of the pattern, centi-units)

@@ -435,6 +435,7 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
         return -1, False
 
     pending = []
+    overp = []
     swaps_now = []
     for p in range(P):
         cur = [int(b) if (int(b) != ko.NONE and int(b) < B) else -1 for b in t.current[p]]
@@ -474,6 +475,12 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
             pending.append(p); continue
         A[p, 0] = lead; A[p, 1:] = row
         for (r, kind, slot) in new_slots: placed[r][kind].append((p, slot))
+        if rep["over_inflow"] > so: overp.append(p)
+    # rows that took a replica outside the inflows (its broker ends over its band) are given up again when the pattern completion
+    # can take them along: it sees the bands, not the inflows
+    if overp and phi == 1 and RF <= 4 and len(pending) + len(overp) <= PAT_MAX_PARTS \
+            and getattr(t, "broker_w", None) is None and getattr(t, "broker_wl", None) is None:
+        pending = sorted(pending + overp)
     rep["fractional"] = len(pending)
     done = np.ones(P, dtype=bool); done[pending] = False
     load = np.zeros(B, dtype=np.int64); lead_load = np.zeros(B, dtype=np.int64)
@@ -638,7 +645,7 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
     return A, rep
 
 
-PAT_MAX_PARTS = 24       # pattern completion: fractional partitions at most
+PAT_MAX_PARTS = 32       # pattern completion: fractional partitions at most
 PAT_MAX_NODES = 60000    # ... nodes of the pattern search and of all its leaf matchings together
 
 

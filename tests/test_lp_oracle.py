@@ -193,6 +193,28 @@ def test_half_integral_vertex_is_completed_by_patterns(ko, kp, B, R, P, dseed, s
     assert d["assignment"].tolist() == A.tolist() and d["fractional"] == fractional
 
 
+def test_rows_outside_the_inflows_join_the_pattern_completion(ko, kp):
+    """400 x 6000, second drift seed, tolerance 1e-6: three fractional partitions and ONE row of the integral pass that found no
+    broker with inflow left in its rack (`over_inflow` 1: broker 0 ends a replica over its band, ten brokers one under it with nine
+    slots to give -- no completion can be perfect, and the band repair that followed cost nine units).  That row is given up and
+    completed with the fractional ones: the certificate (45366, floor of the exact dual value at the unperturbed LP's row duals),
+    no violation, no repair; the product's host half returns the same rows and counts."""
+    import kao_lp as kl
+    import kafka_assignment_optimizer_amd as kao
+    from conftest import to_product_topic
+    t = _drift_topic(ko, 400, 8, 6000, 2)
+    r0 = kl.port_solve(t)
+    bound = math.floor(kl.exact_dual_value(t, r0["a"], r0["l"], r0["g"]) + 1e-9)
+    r = kl.port_solve(t, tol=1e-6, maxit=200, primal=True, pert=min(1e-2, 100.0 / (6000 * 3)), salt=2)
+    blocks = kl.primal_blocks(t, r["x"], r["xg"])
+    A, rep = kl.round_primal(t, *blocks)
+    obj, viol = ko.verify(t, A)
+    assert (rep["fractional"], rep["over_inflow"], rep["patterns"], rep["repaired"]) == (4, 1, 1, 0), rep
+    assert int(np.asarray(viol).sum()) == 0 and obj == bound == 45366, (obj, bound)
+    d = kao.lp_round_host(to_product_topic(t), *_pack(*blocks))
+    assert d["assignment"].tolist() == A.tolist() and (d["fractional"], d["over_inflow"]) == (4, 1)
+
+
 def test_band_repair_matches_the_specification(ko, kp):
     """The band repair at the end of the rounding (kao_round.cpp against oracle/kao_lp.py repair_bands, through kao_lp_round_host mode 2),
     on imbalances built from an optimal assignment of a drifted 100-broker topic: (a) weightless follower replicas piled onto two
