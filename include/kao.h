@@ -292,7 +292,8 @@ int kao_lp_trace(const kao_topic *t, double tol, int32_t max_iters, double *trac
  * hash, which leaves (generically) one optimal vertex; the iterate converges to it, is rounded on the host (new replicas of a rack
  * handed to that rack's brokers by their inflows; specification oracle/kao_lp.py round_primal) and evaluated exactly by K-eval.
  * assignment [P*rf] (dense broker indices, leader first) is overwritten: on entry it may hold a FALLBACK -- the rows that partitions
- * with fractional variables keep (use_fallback != 0; e.g. an incumbent) --, otherwise such partitions take their heaviest options.
+ * with fractional variables keep (use_fallback != 0; e.g. an incumbent) --, otherwise such partitions are completed together (a search
+ * over which current replicas they keep, DESIGN.md section 4b''; far from a vertex: their heaviest options).
  * The result can violate band rows when partitions were fractional: violations[8] as kao_evaluate (violations[0] = total).
  * pert <= 0: min(1e-2, 100 / (P * rf)); tol <= 0: 1e-8; max_iters <= 0: 150.  stats (may be NULL): [0] interior-point iterations,
  * [1] status (0 converged / 1 iteration limit / 3 stalled), [2] fractional partitions, [3] replicas placed beyond a broker's

@@ -19,7 +19,7 @@ constexpr int kTolC = 30;          // a variable farther than 0.30 from an integ
 constexpr int kMaxCand = 16;       // candidate brokers of a fractional partition
 constexpr int kMaxRows = 256;      // candidate rows kept per fractional partition (by objective weight)
 constexpr long kMaxNodes = 100000; // search nodes over the fractional partitions
-constexpr int kPatMaxParts = 32;   // pattern completion: fractional partitions at most
+constexpr int kPatMaxParts = 64;   // pattern completion: fractional partitions at most
 constexpr long kPatMaxNodes = 60000;    // ... nodes of the pattern search and of all its leaf matchings together
 constexpr int kMaxSearch = 64;     // more fractional partitions than this: the iterate is far from a vertex, no search
 constexpr uint16_t kUnset = 0xFFFFu;
@@ -165,7 +165,16 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     //      below their band (most constrained slot first).  Done when the weight the iterate gives these partitions is met.  Only the
     //      plain case; the result is checked before it is taken.
     bool by_patterns = false;
-    if (phi == 1 && RF <= 4 && np > 0 && np <= (size_t)kPatMaxParts && !t->broker_w && !t->broker_wl) {
+    bool can = phi == 1 && RF <= 4 && np > 0 && np <= (size_t)kPatMaxParts && !t->broker_w && !t->broker_wl;
+    if (can) {   // no completion can be perfect when the rows already set put a broker over a band or leave more to fill than these partitions have
+        long need_r = 0, need_l = 0;
+        for (int b = 0; b < B && can; ++b) {
+            can = load[(size_t)b] <= hi && lead_load[(size_t)b] <= lhi;
+            need_r += std::max(0, lo - load[(size_t)b]); need_l += std::max(0, llo - lead_load[(size_t)b]);
+        }
+        can = can && need_r <= (long)RF * (long)np && need_l <= (long)np;
+    }
+    if (can) {
         struct Pat { int obj, lead, nf, f[KAO_MAX_RF], mass; };   // (mass: what the iterate itself keeps of the pattern, centi-units)
         struct Item { int b, wl, wf; };   // a current replica: weight kept as leader / as follower
         std::vector<std::vector<Pat>> pats(np);

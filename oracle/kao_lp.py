@@ -645,7 +645,7 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
     return A, rep
 
 
-PAT_MAX_PARTS = 32       # pattern completion: fractional partitions at most
+PAT_MAX_PARTS = 64       # pattern completion: fractional partitions at most
 PAT_MAX_NODES = 60000    # ... nodes of the pattern search and of all its leaf matchings together
 
 
@@ -661,6 +661,9 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int, F, 
     w = t.weights
     load = [int(v) for v in load0]; lead = [int(v) for v in lead0]
     npd = len(pending)
+    # no completion can be perfect when the rows already set put a broker over a band or leave more to fill than these partitions have
+    if any(load[b] > hi or lead[b] > lhi for b in range(B)): return False
+    if sum(max(0, lo - load[b]) for b in range(B)) > RF * npd or sum(max(0, llo - lead[b]) for b in range(B)) > npd: return False
     pats = []
     items = []       # per partition: (current replica, weight kept as leader, weight kept as follower)
     for p in pending:
