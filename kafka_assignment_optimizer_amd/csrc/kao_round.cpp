@@ -137,9 +137,47 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     }
     // rows that took a replica outside the inflows (its broker ends over its band) are given up again when the pattern completion can
     // take them along: it sees the bands, not the inflows
-    if (!overp.empty() && phi == 1 && RF <= 4 && pending.size() + overp.size() <= (size_t)kPatMaxParts && !t->broker_w && !t->broker_wl) {
+    const bool plain = phi == 1 && RF <= 4 && !t->broker_w && !t->broker_wl;
+    if (!overp.empty() && plain && pending.size() + overp.size() <= (size_t)kPatMaxParts) {
         pending.insert(pending.end(), overp.begin(), overp.end());
         std::sort(pending.begin(), pending.end());
+    }
+    std::vector<char> is_pending((size_t)P, 0);
+    for (int p : pending) is_pending[(size_t)p] = 1;
+    for (int p = 0; p < P; ++p) {
+        if (is_pending[(size_t)p]) continue;
+        for (int k = 0; k < RF; ++k) load[out[(size_t)p * RF + k]]++;
+        lead_load[out[(size_t)p * RF]]++;
+    }
+    // likewise a broker the rows now set put over a band (inflows of an iterate that has not converged need not add up to the bands):
+    // the last rows that hold it are given up, one per unit of excess (as a new replica first: weightless), while the set stays small
+    auto n_over = [&]() { int n = 0; for (int b = 0; b < B; ++b) n += (load[(size_t)b] > hi) + (lead_load[(size_t)b] > lhi); return n; };
+    if (plain && !pending.empty() && pending.size() < (size_t)kPatMaxParts && n_over() > 0) {
+        int excess = n_over();
+        size_t n_extra = 0;
+        auto is_cur = [&](int p, int b) { for (int j = 0; j < NJ; ++j) if (t->current[(size_t)p * NJ + j] == (unsigned)b) return true; return false; };
+        for (int want = 0; want < 3; ++want)   // 0: the broker sits there as a new replica; 1: as a kept follower; 2: as the leader it was
+            for (int p = P - 1; p >= 0; --p) {
+                if (pending.size() + n_extra >= (size_t)kPatMaxParts || excess == 0) break;
+                if (is_pending[(size_t)p]) continue;
+                const uint16_t *row = out + (size_t)p * RF;
+                bool hit = false;
+                if (want == 0) {
+                    for (int k = 0; k < RF && !hit; ++k) hit = load[row[k]] > hi && !is_cur(p, row[k]);
+                    hit = hit || (lead_load[row[0]] > lhi && !is_cur(p, row[0]));
+                } else if (want == 1) {
+                    for (int k = 1; k < RF && !hit; ++k) hit = load[row[k]] > hi;
+                } else hit = load[row[0]] > hi || lead_load[row[0]] > lhi;
+                if (!hit) continue;
+                is_pending[(size_t)p] = 1; ++n_extra;
+                for (int k = 0; k < RF; ++k) load[row[k]]--;
+                lead_load[row[0]]--;
+                excess = n_over();
+            }
+        if (n_extra) {
+            pending.clear();
+            for (int p = 0; p < P; ++p) if (is_pending[(size_t)p]) pending.push_back(p);
+        }
     }
     if (rep) { rep[0] = (int32_t)pending.size(); }
     if (fallback) {
@@ -149,13 +187,6 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     }
     // ---- the fractional partitions, together: candidate rows from their support, chosen by a bounded depth-first search so that the
     //      band rows (README.md:158-166) come out right given what the other partitions hold ----
-    std::vector<char> is_pending((size_t)P, 0);
-    for (int p : pending) is_pending[(size_t)p] = 1;
-    for (int p = 0; p < P; ++p) {
-        if (is_pending[(size_t)p]) continue;
-        for (int k = 0; k < RF; ++k) load[out[(size_t)p * RF + k]]++;
-        lead_load[out[(size_t)p * RF]]++;
-    }
     const size_t np = pending.size();
     // ---- first attempt: PATTERNS (specification: oracle/kao_lp.py complete_by_patterns).  The weight of a completion comes from the
     //      current replicas a partition keeps; the new replicas are weightless and interchangeable.  Per partition the patterns (leader:

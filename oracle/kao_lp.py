@@ -478,8 +478,8 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
         if rep["over_inflow"] > so: overp.append(p)
     # rows that took a replica outside the inflows (its broker ends over its band) are given up again when the pattern completion
     # can take them along: it sees the bands, not the inflows
-    if overp and phi == 1 and RF <= 4 and len(pending) + len(overp) <= PAT_MAX_PARTS \
-            and getattr(t, "broker_w", None) is None and getattr(t, "broker_wl", None) is None:
+    plain = phi == 1 and RF <= 4 and getattr(t, "broker_w", None) is None and getattr(t, "broker_wl", None) is None
+    if overp and plain and len(pending) + len(overp) <= PAT_MAX_PARTS:
         pending = sorted(pending + overp)
     rep["fractional"] = len(pending)
     done = np.ones(P, dtype=bool); done[pending] = False
@@ -489,6 +489,25 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
             for k in range(RF): load[int(A[p, k])] += 1
             lead_load[int(A[p, 0])] += 1
     lo, hi, llo, lhi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"]
+    # likewise a broker the rows now set put over a band (inflows of an iterate that has not converged need not add up to the bands):
+    # the last rows that hold it are given up, one per unit of excess (as a new replica first: weightless), while the set stays small
+    if plain and 0 < len(pending) < PAT_MAX_PARTS and (bool((load > hi).any()) or bool((lead_load > lhi).any())):
+        extra = []
+        for want in (0, 1, 2):       # 0: the broker sits there as a new replica; 1: as a kept follower; 2: as the leader it was
+            for p in range(P - 1, -1, -1):
+                if len(pending) + len(extra) >= PAT_MAX_PARTS or not (bool((load > hi).any()) or bool((lead_load > lhi).any())): break
+                if not done[p]: continue
+                row = [int(x) for x in A[p]]
+                curp = [int(x) for x in t.current[p]]
+                if want == 0: hit = any(load[b] > hi and b not in curp for b in row) or (lead_load[row[0]] > lhi and row[0] not in curp)
+                elif want == 1: hit = any(load[b] > hi for b in row[1:])
+                else: hit = load[row[0]] > hi or lead_load[row[0]] > lhi
+                if hit:
+                    extra.append(p); done[p] = False
+                    for b in row: load[b] -= 1
+                    lead_load[row[0]] -= 1
+        pending = sorted(pending + extra)
+        rep["fractional"] = len(pending)
     if fallback is not None:
         for p in pending:
             A[p] = np.asarray(fallback[p]); rep["from_fallback"] += 1

@@ -193,7 +193,7 @@ def test_half_integral_vertex_is_completed_by_patterns(ko, kp, B, R, P, dseed, s
     assert d["assignment"].tolist() == A.tolist() and d["fractional"] == fractional
 
 
-def test_rows_outside_the_inflows_join_the_pattern_completion(ko, kp):
+def test_rows_outside_the_inflows_or_over_a_band_join_the_pattern_completion(ko, kp):
     """400 x 6000, second drift seed, tolerance 1e-6: three fractional partitions and ONE row of the integral pass that found no
     broker with inflow left in its rack (`over_inflow` 1: broker 0 ends a replica over its band, ten brokers one under it with nine
     slots to give -- no completion can be perfect, and the band repair that followed cost nine units).  That row is given up and
@@ -213,6 +213,17 @@ def test_rows_outside_the_inflows_join_the_pattern_completion(ko, kp):
     assert int(np.asarray(viol).sum()) == 0 and obj == bound == 45366, (obj, bound)
     d = kao.lp_round_host(to_product_topic(t), *_pack(*blocks))
     assert d["assignment"].tolist() == A.tolist() and (d["fractional"], d["over_inflow"]) == (4, 1)
+    # the same topic stopped at tolerance 1e-5: 46 fractional partitions, and the rows already set hold one broker 46 times (band:
+    # 45) although every replica stayed inside the inflows -- 139 places to fill with 138 slots.  The last row holding that broker
+    # joins the completion (47 partitions): two under the certificate without a violation or a repair (candidate rows + repair: 50).
+    r = kl.port_solve(t, tol=1e-5, maxit=200, primal=True, pert=min(1e-2, 100.0 / (6000 * 3)), salt=2)
+    blocks = kl.primal_blocks(t, r["x"], r["xg"])
+    A, rep = kl.round_primal(t, *blocks)
+    obj, viol = ko.verify(t, A)
+    assert (rep["fractional"], rep["over_inflow"], rep["patterns"], rep["repaired"]) == (47, 0, 1, 0), rep
+    assert int(np.asarray(viol).sum()) == 0 and bound - 2 <= obj <= bound, (obj, bound)
+    d = kao.lp_round_host(to_product_topic(t), *_pack(*blocks))
+    assert d["assignment"].tolist() == A.tolist() and d["fractional"] == 47
 
 
 def test_band_repair_matches_the_specification(ko, kp):
