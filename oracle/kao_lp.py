@@ -389,11 +389,16 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
         and b' goes to this partition (the first such b' in index order, the earliest such partition); failing that the replica goes
         to the lowest-index broker of the rack outside the row (`over_inflow`);
       * a partition with a variable farther than tolc / 100 from an integer, or whose row comes out incomplete, is FRACTIONAL: it
-        keeps its row of `fallback` (the incumbent) when there is one; else, after all others, it takes the row that fits the band
-        rows best given what the others left (README.md:158-166): candidates are its current replicas with any mass and, per rack
-        with new mass, the two brokers that need replicas most; rows over them are scored (broker over its band: -1000 each,
-        broker below its band / leader below the leader band: +10 each, centi-mass of the options / 100) and the best row wins
-        (ties: the first in enumeration order: leader candidates in candidate order, follower combinations lexicographic).
+        keeps its row of `fallback` (the incumbent) when there is one; else the fractional partitions are completed TOGETHER after
+        all others.  In the plain case (one replica per rack and partition, RF <= 4, no broker weights) rows that had to leave the
+        inflows, and the last rows of a broker the pass left over a band, are given up and join them while the set stays within
+        PAT_MAX_PARTS partitions; then `complete_by_patterns` (below: which current replicas every partition keeps, the new
+        replicas matched to the brokers still below their band) -- taken only if every band row holds afterwards;
+      * otherwise, up to MAX_SEARCH partitions: candidate rows from each partition's support plus the brokers of its racks that are
+        below their band, chosen by a bounded two-pass branch and bound (first only completions that leave no broker below its
+        band, then the least violated one); more than MAX_SEARCH (the iterate is far from a vertex): the first admissible row of
+        every partition in turn;
+      * what that leaves outside the bands is put right by `repair_bands`.
     Returns (A [P][RF] dense broker indices, leader first; report dict)."""
     import itertools
     B, R, P, RF, NJ = t.n_brokers, t.n_racks, t.n_partitions, t.rf, t.rf_cur
