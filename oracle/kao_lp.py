@@ -674,7 +674,27 @@ PAT_MAX_NODES = 60000    # ... nodes of the pattern search and of all its leaf m
 
 
 def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int, F, L) -> bool:
-    """See round_primal.  On success the rows of `pending` in A are set and every broker is inside its bands; else A is untouched."""
+    """Specification of the pattern completion (product: kao_round.cpp, the block marked PATTERNS).  The weight of a completion comes
+    from the current replicas a partition keeps (README.md:145-146: w[cur_role][new_role]); new replicas are weightless and
+    interchangeable.  `load0` / `lead0`: replica and leader counts of the rows already set; `target`: the weight the iterate gives
+    the pending partitions (floor of the centi-sum + 0.25), F / L its centi-masses.
+      * Not tried when a broker is already over a band, or when more is missing below the bands than the partitions have slots.
+      * Patterns of a partition: leader = one of its current replicas or a new one, followers = a subset of the others, kept brokers
+        in distinct racks and with room in their bands even now; order: weight descending, then the iterate's mass on the kept
+        replicas descending, then enumeration order (leader: new, then current j ascending; subsets by size, lexicographic).
+      * Depth first over the partitions in ascending order.  Bounds: weight so far + the best patterns of the remaining partitions;
+        and, once a completion is known, + per broker the heaviest kept replicas of the remaining partitions its band still has room
+        for.  A pattern is skipped when a kept broker has no room, or when a follower it keeps leaves its broker fewer free places
+        than that broker is still short of leaders (llo - lead > hi - load: loads only grow down the tree).
+      * Leaf: the new slots (a new leader where the pattern keeps none; the new followers) are matched to brokers depth first, leader
+        slots first, within a group the slot with the fewest admissible brokers below their band first; candidates of a slot: brokers
+        with room when the matching began, not in the row, rack not in the row, leader slot: below lead_hi, follower slot: still
+        leaving room for the leaders the broker is short of; ordered by leaders short (leader slots), replicas short, index; the
+        first 12.  A matching succeeds when every broker that was short ends inside its bands.
+      * The first completion whose weight reaches `target` ends the search; otherwise PAT_MAX_NODES nodes (pattern nodes and matching
+        nodes together) and the best completion found.  The result is checked against rows C1-C8 as they apply here (complete rows,
+        distinct brokers and racks, every band) before A is touched.
+    On success the rows of `pending` in A are set and every broker is inside its bands; else A is untouched."""
     import itertools
     B, R, P, RF, NJ = t.n_brokers, t.n_racks, t.n_partitions, t.rf, t.rf_cur
     bd = t.bounds()
