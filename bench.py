@@ -36,6 +36,65 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 G
 LDS_PEAK_GBS = 256 * 128 * 2.4   # 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s for ds_read_b128-class accesses (guide, LDS table)
 
 
+FINAL_LINE_LIMIT = 4096   # the driver keeps a bounded tail of stdout: the result line must stay far below it
+
+
+def _num(d, keys):
+    """{k: d[k]} for the keys that are present and are numbers / short strings / None (no prose in the result line)."""
+    o = {}
+    for k in keys:
+        if isinstance(d, dict) and k in d:
+            v = d[k]
+            if v is None or isinstance(v, (bool, int, float)) or (isinstance(v, str) and len(v) <= 96):
+                o[k] = v
+    return o
+
+
+def compact_line(out):
+    """The ONE result line: numbers only, < FINAL_LINE_LIMIT bytes.  Everything else (notes, probes, per-topic rows) goes to
+    gpurun_out/bench_extras.json (emit())."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+           "dtype", "data", "value_non_null", "delta_candidates_per_s", "full_candidates_per_s", "time_to_optimal_s")
+    line = _num(out, top)
+    cfg = out.get("config", {})
+    line["config"] = {"workload": cfg.get("workload", "")[:200]}
+    line["config"].update(_num(cfg, ("topics_total", "restarts_per_topic_rank0", "iters_per_launch", "parallelism")))
+    roof_keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                 "traffic_source", "peak_source")
+    for k in ("roofline", "roofline_valu_issue", "roofline_lds", "roofline_eval_stream", "roofline_lp"):
+        if k in out:
+            line[k] = _num(out[k], roof_keys + ("valu_insts_per_neighbour", "ms_per_iteration", "iterations", "hbm_frac", "f64_frac",
+                                                "hbm_bytes_per_iteration", "f64_flops_per_iteration", "chol_ms_per_iteration"))
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _num(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "value_one_thread", "non_null_fraction",
+                                                          "exact_solver", "exact_topics_solved", "exact_topics_total",
+                                                          "exact_seconds_per_topic", "exact_wall_seconds"))
+    if "north_star" in out:
+        line["north_star"] = _num(out["north_star"], ("workload", "time_limit_s", "seconds", "status", "objective", "certificate",
+                                                      "kao_lp_iterations", "seconds_unlimited", "status_unlimited"))
+    if "extras_file" in out:
+        line["extras_file"] = out["extras_file"]
+    return line
+
+
+def emit(out):
+    """Write the full record to gpurun_out/bench_extras.json (scratch on the GPU box, merged back by gpurun) and print the compact
+    result line LAST on stdout."""
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "bench_extras.json")
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        out["extras_file"] = "gpurun_out/bench_extras.json"
+    except OSError as ex:
+        print("bench.py: could not write the extras file: %r" % (ex,), file=sys.stderr)
+    line = json.dumps(compact_line(out))
+    assert len(line) < FINAL_LINE_LIMIT, len(line)
+    sys.stdout.flush()
+    print(line, flush=True)
+
+
 def host_cores() -> int:
     """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box with 256 hardware
     threads may grant the container 16 CPUs' worth of time)."""
@@ -118,10 +177,12 @@ def cpu_baseline(topics, restarts, iters, budget_s=12.0, exact_budget_s=45.0):
         pool.terminate()
     exact_wall = time.perf_counter() - te
     return {"value": n_eval / dt, "unit": "candidates/s", "cores": cores, "kind": "port",
-            "sample": f"{done_topics} topic passes (of the {len(ots)}-topic list, repeated) x {per_call} restarts x {iters} iterations, "
-                      f"oracle/kao_port.c scalar replay of the same search on {cores} native host threads, {dt:.1f} s",
+            "sample": f"{done_topics} topic passes x {per_call} restarts x {iters} iters, {dt:.1f} s",
+            "sample_detail": f"{done_topics} topic passes (of the {len(ots)}-topic list, repeated) x {per_call} restarts x {iters} iterations, "
+                             f"oracle/kao_port.c scalar replay of the same search on {cores} native host threads, {dt:.1f} s",
             "value_one_thread": rate1, "non_null_fraction": non_null,
-            "exact_solver": "HiGHS (scipy.optimize.milp) on the README model; lp_solve 5.5 not installed",
+            "exact_solver": "HiGHS (scipy milp) on the README model; lp_solve 5.5 not installed",
+            "exact_seconds_per_topic": (sum(secs) / n_done) if n_done else None,
             "exact_topics_solved": n_done, "exact_topics_total": len(ots), "exact_pool_processes": min(cores, len(ots)),
             "exact_wall_seconds": exact_wall, "exact_cpu_seconds_sum": sum(secs),
             "exact_cpu_seconds_per_topic_mean": (sum(secs) / n_done) if n_done else None,
@@ -579,7 +640,7 @@ def main():
     algo_per_launch = sb // max(1, launches)
     prof = load_profile_constants("cfg%d-drift-fresh" % args.config, args.iters, restarts_total)
     roof = {"kernel": "k_search", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": avg_ms,
-            "achieved": None, "frac": None, "traffic": None,
+            "achieved": None, "frac": None, "traffic": None, "algorithmic_bytes_per_launch": algo_per_launch,
             "algorithmic_lds_served": {"bytes_per_launch": algo_per_launch, "gbps": algo_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
                                        "note": "SURVEY.md 8(d) algorithmic bytes = neighbours x (8*RF+10) B; they are served from LDS (the "
                                                "restart state is LDS-resident), NOT from HBM, so they are not priced against the HBM peak"},
@@ -592,13 +653,14 @@ def main():
         roof["traffic"] = prof["k_search_hbm_bytes_per_launch"]
         roof["achieved"] = prof["k_search_hbm_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["traffic_source"] = prof["source"].split(" ")[0]
         roof["traffic_note"] = ("rocprofv3 --pmc FETCH_SIZE (x2 gfx950 wide-read correction) + WRITE_SIZE per launch, separate passes, from "
                                 + prof["source"])
         valu = prof["k_search_valu_insts_per_launch"]
         peak = prof.get("valu_issue_peak_winst_per_s", 671.3e9)
         out["roofline_valu_issue"] = {"kernel": "k_search", "bound": "valu-issue", "insts_per_launch": valu,
                                       "achieved": valu / (avg_ms * 1e-3) / 1e9, "peak": peak / 1e9, "unit": "G wave-instructions/s",
-                                      "frac": valu / (avg_ms * 1e-3) / peak,
+                                      "frac": valu / (avg_ms * 1e-3) / peak, "peak_source": "builder microbench (tools/microbench/valu_rate.hip), not datasheet",
                                       "valu_insts_per_neighbour": valu / max(1.0, d_delta / max(1, launches)),
                                       "note": "SQ_INSTS_VALU per launch from " + prof["source"] + "; peak: " + prof.get("valu_issue_peak_note", "")
                                               + ".  The peak is the fastest instruction class the microbench measured at the clock it "
@@ -653,7 +715,7 @@ def main():
         objs = [o for o in cb.pop("exact_objectives") if o is not None]
         if tto and objs and len(objs) == len(topics):   # the exact solver finished every topic: the certified optimum agrees
             out["time_to_optimal_detail"]["objective_sum_exact_cpu"] = sum(objs)
-    print(json.dumps(out))
+    emit(out)
     if world > 1:
         dist.destroy_process_group()
 

@@ -312,3 +312,30 @@ def test_pair_enumeration_refuses_large_topics():
     X = np.ascontiguousarray(pt.current[:, :3], dtype=np.uint16)
     got, st = kao.cycle_pair_edges(pt, X, -2)
     assert st["half_moves"] == 0 and st["edges"] == 0 and (got == np.iinfo(np.int32).max).all()
+
+
+def test_bench_result_line_is_short_and_strict_json():
+    """The driver parses the LAST stdout line of bench.py and keeps a bounded tail (round 5's 21 KB line was not parsed): the
+    compact line built from the fattest record we have committed stays under 4 KB, is strict JSON, and keeps the contract's keys."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "r05_zz_bench.json")) as f:
+        fat = json.load(f)
+    fat["north_star"] = {"workload": "drift100k", "time_limit_s": 1.0, "seconds": 0.9, "status": "OPTIMAL_PROVEN", "objective": 782512,
+                         "certificate": 782512, "note": "x" * 5000}
+    fat["roofline_lp"] = {"kernel": "k_lp_*", "bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": 1,
+                          "ms_per_iteration": 4.0, "note": "y" * 5000}
+    line = json.dumps(bench.compact_line(fat))
+    assert len(line) < bench.FINAL_LINE_LIMIT <= 4096
+    back = json.loads(line, parse_constant=lambda c: pytest.fail("non-strict JSON constant " + c))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in back, k
+    assert "workload" in back["config"] and back["config"]["workload"].startswith("cfg4")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in back["roofline"], k
+    for k in ("value", "unit", "cores", "kind"):
+        assert k in back["cpu_baseline"], k
+    assert all(not isinstance(v, str) or len(v) <= 200 for d in back.values() if isinstance(d, dict) for v in d.values())
