@@ -308,6 +308,11 @@ int kao_lp_round(const kao_topic *t, double pert, uint32_t salt, double tol, int
  * assignment passed in (q, zq unused, may be NULL).  The parity tests hold it against oracle/kao_lp.py round_primal / repair_bands on the
  * scalar restatement's iterate. */
 int kao_lp_round_host(const kao_topic *t, const uint8_t *q, const int32_t *zq, int32_t use_fallback, uint16_t *assignment, int32_t rep[4]);
+/* Test hook: KAO-LP's dense kernels alone (kao_chol.hip) on the caller's symmetric positive definite matrix A[n][n] (row-major, the lower
+ * triangle is read; n a multiple of 64, at most 10,240): factor[n][n] = L in the lower triangle and L^T tile-wise in the upper one, linv[n / 64]
+ * [64][64] = the inverses of L's diagonal tiles, x[n] = the solution of A x = rhs (rhs NULL: all ones), ms[2] = HIP-event milliseconds of
+ * the factorisation and of the two triangular solves (second of two runs).  Any output may be NULL. */
+int kao_dense_spd_test(const double *A, int32_t n, const double *rhs, double *factor, double *linv, double *x, double ms[2]);
 /* One-shot K-bound on one topic: `launches` launches of `iters` iterations towards `target`.
  * *bound = floor(best dual / 65536) (not combined with kao_upper_bound); multipliers, if not NULL, receives
  * a[n_brokers], l[n_brokers], g[n_racks]. */

@@ -198,6 +198,11 @@ int lp_primal(LpCtx *c, uint8_t *q, int32_t *zq);   // quantised primal iterate:
 int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq, const uint16_t *fallback, uint16_t *out, int32_t rep[4]);
 void lp_abort(LpCtx *c);   // stop flag up from the host: enqueued iterations turn into no-ops
 void lp_close(LpCtx *c);
+// the dense piece (kao_chol.hip): Cholesky of the n x n matrix in the lower triangle of S (row-major, n a multiple of 64, diag0 its
+// diagonal) -> L below, L^T above, Linv[n / 64][64][64] the inverses of the diagonal tiles; then S x = r in place (xz[2 n]: scratch).
+// stop / gate: device scalars (may be null): every kernel returns at once when *stop != 0 / when *gate == 0.  `stream` is a hipStream_t.
+void chol_enqueue(void *stream, const double *stop, double *S, int n, const double *diag0, double *Linv);
+void trsv_enqueue(void *stream, double *stop, const double *gate, const double *S, int n, double *r, const double *Linv, double *xz);
 
 // ---- KAO-CX (kao_cycle.hip): cyclic-exchange improvement of a feasible assignment ----
 bool cycle_supported(const kao_topic *t);

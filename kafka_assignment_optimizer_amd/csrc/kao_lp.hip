@@ -63,6 +63,8 @@ enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (no
              SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT,
              SC_MCC_GO /* centrality correctors: the next one is still wanted */, SC_MCC_ACC /* the last one was accepted */, kScN = 24 };
 #define LP_STOPPED(D) ((D).sc[SC_STOP] != 0.0)
+// kernels of a centrality corrector carry gated = 1: once no further corrector is wanted they return at their first line
+#define LP_GATED_OFF(D, gated) ((gated) && (D).sc[SC_MCC_GO] == 0.0)
 
 // variable numbering inside a partition (SoA: element (v, p) at v*P + p) and among the global variables
 __device__ __host__ __forceinline__ int VF(int j) { return 3 * j; }
@@ -332,11 +334,15 @@ __device__ __forceinline__ bool lp_col(const LpDev &D, const double *th, const d
 
 // ---- Schur complement, broker rows: one wavefront per broker walks the broker's incidences in order -----------------------
 // rows C3[b] and C4[b] are accumulated in LDS (2 x mc doubles per wavefront) and written once (lower triangle)
-__global__ void k_lp_schur_broker(LpDev D, const double *th, const double *thg, const double *fj, const double *fr, const double *ti, double *S) {
+template <int U>
+__global__ void __launch_bounds__(256) k_lp_schur_broker(LpDev D, const double *__restrict__ th, const double *__restrict__ thg, const double *__restrict__ fj,
+                                                          const double *__restrict__ fr, const double *__restrict__ ti, double *__restrict__ S) {
     if (LP_STOPPED(D)) return;
     extern __shared__ double lds_rows[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    const int b = blockIdx.x * nw + wave;
+    // (the broker is the same for the whole wavefront: said so, the incidence words, the partition's factors and the incidence's own rows travel
+    // through the scalar cache -- nine of the seventeen loads of an incidence)
+    const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * nw + wave);
     if (b >= D.B) return;
     const int P = D.P, R = D.R, NJ = D.NJ, mc = D.mc;
     double *rowA = lds_rows + (size_t)wave * 2 * mc, *rowB = rowA + mc;
@@ -349,7 +355,6 @@ __global__ void k_lp_schur_broker(LpDev D, const double *th, const double *thg, 
         // reach every column in incidence order as before: the same bits.
         // Straight-line code, level by level over the four incidences (no branch between the loads of one level: the compiler keeps
         // them in flight together): incidence word -> partition's factors and current replicas -> rack of the column's broker -> rack factors.
-        constexpr int U = 4;
         const int e1 = D.inc_off[b + 1];
         const int c = lane;
         const bool is_cur = c < 2 * NJ, has_col = c < nc;
@@ -792,8 +797,8 @@ __global__ void __launch_bounds__(256) k_lp_trsv_mw(const double *sc, const doub
 
 // ---- rows of A z ------------------------------------------------------------------------------------------------------
 // local rows; mode 0: out = A z, 1: out = b - A z, 2: out = A z + add
-__global__ void k_lp_A_local(LpDev D, const double *z, RowVec out, int mode, RowVec add) {
-    if (LP_STOPPED(D)) return;
+__global__ void k_lp_A_local(LpDev D, const double *z, RowVec out, int mode, RowVec add, int gated) {
+    if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
     const int P = D.P, R = D.R, NJ = D.NJ;
@@ -825,8 +830,8 @@ __global__ void k_lp_A_local(LpDev D, const double *z, RowVec out, int mode, Row
         }
 }
 // coupling rows C3[b], C4[b]: one wavefront per broker; `cb` (may be null): extra per-incidence terms [2 NJ][P] of the eliminations
-__global__ void k_lp_A_broker(LpDev D, const double *z, const double *zg, const double *cb, double *rc, int mode, const double *addc) {
-    if (LP_STOPPED(D)) return;
+__global__ void k_lp_A_broker(LpDev D, const double *z, const double *zg, const double *cb, double *rc, int mode, const double *addc, int gated) {
+    if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int b = blockIdx.x * nw + wave;
     if (b >= D.B) return;
@@ -847,8 +852,8 @@ __global__ void k_lp_A_broker(LpDev D, const double *z, const double *zg, const 
     rc[r4] = mode == 1 ? D.bc[r4] - s4 : (mode == 2 ? s4 + addc[r4] : s4);
 }
 // coupling rows NF[r], NL[r] (one block each: a fixed-order sum over the partitions) and C6[r]; `cr`: extra terms [2 R][P]
-__global__ void __launch_bounds__(kRedBlock) k_lp_A_rack(LpDev D, const double *z, const double *zg, const double *cr, double *rc, int mode, const double *addc) {
-    if (LP_STOPPED(D)) return;
+__global__ void __launch_bounds__(kRedBlock) k_lp_A_rack(LpDev D, const double *z, const double *zg, const double *cr, double *rc, int mode, const double *addc, int gated) {
+    if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
     __shared__ double sh[kRedBlock];
     const int R = D.R, P = D.P, row = blockIdx.x;     // 0..R-1 NF, R..2R-1 NL, 2R..3R-1 C6
     const int r = row % R, kind = row / R;
@@ -872,8 +877,8 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_A_rack(LpDev D, const double *
 
 // ---- the normal equations' local eliminations (oracle/kao_lp_port.c::lp_solve_normal, first loop): local right-hand sides in
 // place, the terms they send to the coupling rows into cb [2 NJ][P] (C3 / C4 of replica j) and cr [2 R][P] (NF / NL of rack r)
-__global__ void k_lp_elim_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v, double *cb, double *cr) {
-    if (LP_STOPPED(D)) return;
+__global__ void k_lp_elim_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v, double *cb, double *cr, int gated) {
+    if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
     const int P = D.P, R = D.R, NJ = D.NJ;
@@ -915,8 +920,8 @@ __global__ void k_lp_elim_local(LpDev D, const double *th, const double *fj, con
     }
 }
 // back substitution (second loop): dy of the local rows in place, given dy of the coupling rows
-__global__ void k_lp_back_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v) {
-    if (LP_STOPPED(D)) return;
+__global__ void k_lp_back_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v, int gated) {
+    if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
     const int P = D.P, R = D.R, NJ = D.NJ, nc = 2 * NJ + 2 * R;
@@ -1264,6 +1269,8 @@ struct LpCtx {
     double *rec = nullptr, *redA = nullptr, *redB = nullptr, *redC = nullptr, *part = nullptr, *ylast = nullptr, *trace = nullptr;
     int32_t *d_mult = nullptr, *d_zq = nullptr;
     VarVec dc{}; RowVec wc{}; int mcc = 2;   // centrality correctors per iteration (KAO_LP_MCC; 0: none) and their direction / row vector
+    int broker_u = 8;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
+    double *xz = nullptr; bool dense_new = true;   // kao_chol.hip (KAO_LP_DENSE=old: round 5's kernels below, for A/B runs)
     int *trsv_flags = nullptr; double *trsv_z = nullptr; bool trsv_mw = true;   // the triangular solves by one workgroup per row tile (KAO_LP_TRSV_MW=0: by one workgroup)
     uint8_t *d_q = nullptr;   // quantised primal iterate (lp_primal)
     int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
@@ -1314,26 +1321,30 @@ void lp_reduce(LpCtx &c, int nrec, int n, bool is_min, double *out) {
     hipLaunchKernelGGL(k_lp_red_final, dim3(1), dim3(kRedBlock), 0, c.st, c.D.sc, c.rec, nrec, n, is_min ? 1 : 0, out);
 }
 // local rows of A z into `out` (mode 0 plain, 1 = b - A z, 2 = A z + add)
-void lp_rows_local(LpCtx &c, const VarVec &z, const RowVec &out, int mode, const RowVec &add) {
-    hipLaunchKernelGGL(k_lp_A_local, dim3(c.nblk_p), dim3(256), 0, c.st, c.D, z.z, out, mode, add);
+void lp_rows_local(LpCtx &c, const VarVec &z, const RowVec &out, int mode, const RowVec &add, int gated = 0) {
+    hipLaunchKernelGGL(k_lp_A_local, dim3(c.nblk_p), dim3(256), 0, c.st, c.D, z.z, out, mode, add, gated);
 }
 // coupling rows, gathered: rows of A z (+ the elimination terms cb / cr) (+ add)
-void lp_rows_coupling(LpCtx &c, const VarVec &z, double *out_rc, int mode, const double *add_rc, const double *cb, const double *cr) {
+void lp_rows_coupling(LpCtx &c, const VarVec &z, double *out_rc, int mode, const double *add_rc, const double *cb, const double *cr, int gated = 0) {
     const LpDev &D = c.D;
-    hipLaunchKernelGGL(k_lp_A_broker, dim3((D.B + 3) / 4), dim3(256), 0, c.st, D, z.z, z.zg, cb, out_rc, mode, add_rc);
-    hipLaunchKernelGGL(k_lp_A_rack, dim3(3 * D.R), dim3(kRedBlock), 0, c.st, D, z.z, z.zg, cr, out_rc, mode, add_rc);
+    hipLaunchKernelGGL(k_lp_A_broker, dim3((D.B + 3) / 4), dim3(256), 0, c.st, D, z.z, z.zg, cb, out_rc, mode, add_rc, gated);
+    hipLaunchKernelGGL(k_lp_A_rack, dim3(3 * D.R), dim3(kRedBlock), 0, c.st, D, z.z, z.zg, cr, out_rc, mode, add_rc, gated);
 }
 
 void lp_factor(LpCtx &c) {
     const LpDev &D = c.D;
     hipLaunchKernelGGL(k_lp_factor_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti);
     const size_t lds_b = (size_t)c.broker_waves * 2 * D.mc * sizeof(double);
-    hipLaunchKernelGGL(k_lp_schur_broker, dim3((D.B + c.broker_waves - 1) / c.broker_waves), dim3(64 * c.broker_waves), lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
+    const dim3 bg((D.B + c.broker_waves - 1) / c.broker_waves), bb(64 * c.broker_waves);
+    if (c.broker_u >= 16) hipLaunchKernelGGL(k_lp_schur_broker<16>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
+    else if (c.broker_u >= 8) hipLaunchKernelGGL(k_lp_schur_broker<8>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
+    else hipLaunchKernelGGL(k_lp_schur_broker<4>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
     const int n2 = 2 * D.R, per = 6 * n2 + D.R;
     hipLaunchKernelGGL(k_lp_schur_rack, dim3(c.rack_blocks), dim3(256), (size_t)c.rack_tile * per * sizeof(double), c.st, D, c.th.z, c.fj, c.fr, c.ti, c.rack_chunk, c.rack_tile, c.part);
     hipLaunchKernelGGL(k_lp_schur_rack_sum, dim3((n2 * n2 + 255) / 256), dim3(256), 0, c.st, D, c.part, c.rack_blocks, c.th.zg, c.S);
     hipLaunchKernelGGL(k_lp_schur_fix, dim3((D.mcp + 255) / 256), dim3(256), 0, c.st, D, c.th.zg, c.S, c.diag0);
     hipLaunchKernelGGL(k_lp_schur_fix_cols, dim3((D.mc + 255) / 256), dim3(256), 0, c.st, D, c.S);
+    if (c.dense_new) { chol_enqueue(c.st, D.sc + SC_STOP, c.S, D.mcp, c.diag0, c.Linv); return; }
     const int nt = D.mcp / kNB;
     for (int kb = 0; kb < nt; ++kb) {
         hipLaunchKernelGGL(k_lp_chol_diag, dim3(1), dim3(64), 0, c.st, D.sc, c.S, D.mcp, kb, c.diag0, c.Linv);
@@ -1345,16 +1356,17 @@ void lp_factor(LpCtx &c) {
 }
 
 // N dy = rho, in place in `v`: v's local rows hold rho; the coupling right-hand side is GATHERED: rows of A z + the elimination terms (+ add)
-void lp_solve_normal(LpCtx &c, const RowVec &v, const VarVec &z, const double *add_rc) {
+void lp_solve_normal(LpCtx &c, const RowVec &v, const VarVec &z, const double *add_rc, int gated = 0) {
     const LpDev &D = c.D;
-    hipLaunchKernelGGL(k_lp_elim_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, c.cb, c.cr);
-    lp_rows_coupling(c, z, v.rc, add_rc ? 2 : 0, add_rc, c.cb, c.cr);
-    if (c.trsv_mw) {
+    hipLaunchKernelGGL(k_lp_elim_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, c.cb, c.cr, gated);
+    lp_rows_coupling(c, z, v.rc, add_rc ? 2 : 0, add_rc, c.cb, c.cr, gated);
+    if (c.dense_new) trsv_enqueue(c.st, D.sc + SC_STOP, gated ? D.sc + SC_MCC_GO : nullptr, c.S, D.mcp, v.rc, c.Linv, c.xz);
+    else if (c.trsv_mw) {
         (void)hipMemsetAsync(c.trsv_flags, 0, sizeof(int) * 2 * (size_t)(D.mcp / kNB), c.st);
         hipLaunchKernelGGL(k_lp_trsv_mw, dim3(D.mcp / kNB), dim3(256), 0, c.st, D.sc, c.S, D.mcp, v.rc, c.Linv, c.trsv_z, c.trsv_flags);
     } else
         hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, D.sc, c.S, D.mcp, v.rc, c.Linv);
-    hipLaunchKernelGGL(k_lp_back_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v);
+    hipLaunchKernelGGL(k_lp_back_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, gated);
 }
 
 // residuals, sums, trace, stopping test of the current iterate
@@ -1479,12 +1491,16 @@ int lp_open(const kao_topic *t, LpCtx **out) {
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
         (rc = c->alloc(&c->part, (size_t)c->rack_blocks * n2 * n2)) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
-        (rc = c->alloc(&c->trsv_flags, (size_t)2 * (D.mcp / kNB))) || (rc = c->alloc(&c->trsv_z, (size_t)D.mcp)) ||
+        (rc = c->alloc(&c->trsv_flags, (size_t)2 * (D.mcp / kNB))) || (rc = c->alloc(&c->trsv_z, (size_t)D.mcp)) || (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) ||
         (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
     { const char *e = std::getenv("KAO_LP_TRSV_MW"); c->trsv_mw = !(e && e[0] == '0') && D.mcp / kNB <= 160; }
+    { const char *e = std::getenv("KAO_LP_DENSE"); c->dense_new = !(e && e[0] == 'o') && D.mcp / kNB <= 160; }
     // dynamic LDS beyond 64 KiB has to be enabled per kernel
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    { const char *e = std::getenv("KAO_LP_BROKER_U"); c->broker_u = e ? std::atoi(e) : 8; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_rack), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     for (const VarVec *vv : {&c->x, &c->s, &c->v, &c->th, &c->rd, &c->h, &c->g, &c->d1, &c->d2, &c->dsa, &c->dva, &c->ds, &c->dv, &c->dc})
@@ -1578,8 +1594,8 @@ static void lp_enqueue_one(LpCtx &c) {
         const size_t nrow = c.rows_local + D.mcp;
         for (int k = 0; k < c.mcc; ++k) {   // centrality correctors (no-ops once one was rejected or the step is full)
             hipLaunchKernelGGL(k_lp_mcc_h, gv, b256, 0, c.st, D, c.x, c.s, c.v, c.th, c.d2, c.ds, c.dv, c.h, c.g, c.dsa, c.dva);
-            lp_rows_local(c, c.g, c.wc, 0, c.wc);                        // local rows: A (theta h)
-            lp_solve_normal(c, c.wc, c.g, nullptr);
+            lp_rows_local(c, c.g, c.wc, 0, c.wc, 1);                     // local rows: A (theta h)
+            lp_solve_normal(c, c.wc, c.g, nullptr, 1);
             hipLaunchKernelGGL(k_lp_mcc_dir, dim3(c.nblk_var), dim3(kRedBlock), 0, c.st, D, c.x, c.s, c.v, c.th, c.h, c.wc, c.dc, c.dsa, c.dva, c.d2, c.ds, c.dv, c.rec);
             lp_reduce(c, c.nblk_var, 2, true, c.redA);
             hipLaunchKernelGGL(k_lp_sc_mcc, dim3(1), dim3(1), 0, c.st, D.sc, c.redA);

@@ -467,6 +467,7 @@ def lp_trace(topic: Topic, tol: float = 0.0, max_iters: int = 80) -> dict:
     B = topic.n_brokers
     mult = np.zeros(2 * B + topic.n_racks, dtype=np.int32)
     st = np.zeros(8)
+    max_iters = int(max_iters) if int(max_iters) > 0 else 80      # the C side reads <= 0 as 80: size the trace for what it will write
     tr = np.zeros(5 * (max_iters + 2))
     pd = C.POINTER(C.c_double)
     _check(_ffi.load().kao_lp_trace(ct.ptr(0), float(tol), int(max_iters), tr.ctypes.data_as(pd), st.ctypes.data_as(pd),
@@ -474,6 +475,20 @@ def lp_trace(topic: Topic, tol: float = 0.0, max_iters: int = 80) -> dict:
     it = int(st[0])
     return dict(a=mult[:B].copy(), l=mult[B:2 * B].copy(), g=mult[2 * B:].copy(), iterations=it, primal=float(st[1]), dual=float(st[2]),
                 status=int(st[3]), ms=float(st[7]), trace=tr[:5 * (it + 1)].reshape(-1, 5))
+
+
+def dense_spd_test(A: np.ndarray, rhs: Optional[np.ndarray] = None) -> dict:
+    """Test hook (kao_dense_spd_test): KAO-LP's dense kernels (kao_chol.hip) alone on a symmetric positive definite matrix whose order
+    is a multiple of 64: the factor (L below, L^T tile-wise above), the inverses of L's diagonal tiles, the solution of A x = rhs."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    n = A.shape[0]
+    assert A.shape == (n, n)
+    f = np.zeros((n, n)); li = np.zeros((n // 64, 64, 64)); x = np.zeros(n); ms = np.zeros(2)
+    pd = C.POINTER(C.c_double)
+    r = None if rhs is None else np.ascontiguousarray(rhs, dtype=np.float64)
+    _check(_ffi.load().kao_dense_spd_test(A.ctypes.data_as(pd), n, None if r is None else r.ctypes.data_as(pd), f.ctypes.data_as(pd),
+                                          li.ctypes.data_as(pd), x.ctypes.data_as(pd), ms.ctypes.data_as(pd)), "kao_dense_spd_test")
+    return dict(factor=f, linv=li, x=x, ms_factor=float(ms[0]), ms_solve=float(ms[1]))
 
 
 def decode_key(key: int) -> tuple:
