@@ -582,8 +582,8 @@ struct Cx {
         for (int l = 0; l < kCxLayers; ++l) {
             (void)hipFree(d_E[l]);
             for (int v = 0; v <= kCxLevels; ++v) { (void)hipFree(d_D[l][v]); (void)hipFree(d_M[l][v]); }
-        if (d_sqkey) { (void)hipFree(d_sqkey); d_sqkey = nullptr; }
         }
+        if (d_sqkey) { (void)hipFree(d_sqkey); d_sqkey = nullptr; }
         if (stream) (void)hipStreamDestroy(stream);
         kao_eval_plan_destroy(plan);
     }

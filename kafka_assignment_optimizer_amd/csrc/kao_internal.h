@@ -189,13 +189,15 @@ int lp_begin(LpCtx *c, double tol, int maxit, double pert = 0.0, uint32_t salt =
 int lp_enqueue(LpCtx *c, int k);
 int lp_poll(LpCtx *c, int *status, int *iterations);
 int lp_enqueue_mark(LpCtx *c, int k, int slot);                      // enqueue + a mark (ring slot 0..31) that lp_poll_mark waits for
-int lp_poll_mark(LpCtx *c, int slot, int *status, int *iterations, double deadline = 0);   // deadline (now_s() clock, 0 = none): past it the solve is aborted instead of waited for
+int lp_poll_mark(LpCtx *c, int slot, int *status, int *iterations, double deadline = 0);   // deadline (now_s() clock, 0 = none): past it the solve is aborted instead of waited for (*status = 4)
 int lp_finish(LpCtx *c, int32_t *multipliers, double stats[8], double *trace);
 inline double lp_default_pert(const kao_topic *t) { const double e = 100.0 / ((double)t->n_partitions * t->rf); return e < 1e-2 ? e : 1e-2; }   // oracle/kao_lp.py default_pert
 int lp_primal(LpCtx *c, uint8_t *q, int32_t *zq);   // quantised primal iterate: q[(2 rf_cur + 2 R) * P] centi-units, zq[2 B] inflows (host memory)
 // q / zq -> an assignment (kao_round.cpp; specification oracle/kao_lp.py round_primal).  fallback (dense indices, may be null): the rows
 // fractional partitions keep.  rep[4] = {fractional partitions, over-inflow placements, unplaced, rows taken from fallback}
-int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq, const uint16_t *fallback, uint16_t *out, int32_t rep[4]);
+// max_free: without a fallback, more fractional partitions than this are not completed at all (the completion costs ~0.1 ms a partition):
+// rep[0] = their number, rep[3] = -1, `out` is left incomplete
+int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq, const uint16_t *fallback, uint16_t *out, int32_t rep[4], int max_free = 1 << 30);
 void lp_abort(LpCtx *c);   // stop flag up from the host: enqueued iterations turn into no-ops
 void lp_close(LpCtx *c);
 // the dense piece (kao_chol.hip): Cholesky of the n x n matrix in the lower triangle of S (row-major, n a multiple of 64, diag0 its

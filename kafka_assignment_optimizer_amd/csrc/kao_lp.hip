@@ -42,6 +42,7 @@ constexpr double kLpReg = 1e-10;
 constexpr int kNB = 64;            // Cholesky tile
 constexpr int kRedVals = 8;        // values per reduction record
 constexpr int kRedBlock = 256;
+constexpr int kVarBlocks = 2048;   // workgroups (= records) of the reductions over the variables: every thread walks its elements with the grid's stride
 
 struct LpDev {
     int P, B, R, NJ, RF, NV, GV, mc, mcp;    // mcp = mc rounded up to the Cholesky tile (padding rows are identity)
@@ -58,7 +59,7 @@ struct LpDev {
 };
 // Device-resident scalars.  The kernels of an iteration read the step lengths, sigma mu and the stop flag from here, so any number
 // of iterations can be enqueued without the host looking; once the stop flag is set every later kernel returns at its first line.
-enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (non-finite iterate) */, SC_IT, SC_AP, SC_AD, SC_SIGMU, SC_MU, SC_POBJ, SC_DOBJ,
+enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (non-finite iterate), 4 aborted by the host (lp_abort) */, SC_IT, SC_AP, SC_AD, SC_SIGMU, SC_MU, SC_POBJ, SC_DOBJ,
              SC_PINF, SC_DINF, SC_PLAST, SC_DLAST, SC_HAVE_LAST, SC_KEEP /* this iterate is finite: copy its duals */, SC_TOL, SC_MAXIT, SC_NVU /* variables + bounded variables */, SC_NB, SC_NCN,
              SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT,
              SC_MCC_GO /* centrality correctors: the next one is still wanted */, SC_MCC_ACC /* the last one was accepted */, kScN = 24 };
@@ -521,6 +522,115 @@ __global__ void k_lp_schur_rack_sum(LpDev D, const double *part, int nblk, const
     }
     S[(size_t)a * D.mcp + c] = s;    // rows NF[r] = r, NL[r] = R + r: exactly the numbering of a
 }
+// The same block on the matrix cores (round 6; 2R <= 64).  The block is a sum over the partitions of outer products,
+//   S[a][c] = sum_p -(w0_a v0_c + w1_a v1_c) - [rack a == rack c] (cy_a / d) cy_c + [a == c] cy_a,      a, c in NF[0..R) NL[0..R),
+// i.e. two (three with the same-rack term, masked afterwards) 2R x P x 2R products: v_mfma_f64_16x16x4_f64 with the partitions as the
+// k index.  Lane (m, q) of a wavefront holds column 16 t + m of partition p0 + q for every 16-column tile t, which is at once the A operand
+// of tile row t and the B operand of tile column t.  Every wavefront walks a fixed slice of the partitions, the four wavefronts of a
+// workgroup are added in order through LDS, the workgroups' partial blocks by k_lp_schur_rack_sum2 in order: the same bits on every run.
+typedef double lp_v4d __attribute__((ext_vector_type(4)));
+constexpr int kRackMfmaBlocks = 256;
+template <int T16>
+__global__ void __launch_bounds__(256) k_lp_schur_rack_mfma(LpDev D, const double *__restrict__ th, const double *__restrict__ fr, const double *__restrict__ ti, double *__restrict__ part) {
+    if (LP_STOPPED(D)) return;
+    constexpr int NP = T16 * (T16 + 1) / 2;                 // tile pairs (row tile >= column tile)
+    constexpr int NE = 2 * NP * 256 + T16 * 16;             // doubles of one partial record: C tiles, same-rack tiles, column sums
+    __shared__ double comb[NE];
+    const int R = D.R, P = D.P, n2 = 2 * R;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lm = lane & 15, lq = lane >> 4;
+    const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + w;
+    const int chunk = ((P + nwaves - 1) / nwaves + 3) / 4 * 4;
+    const int pb = min(P, gw * chunk), pe = min(P, pb + chunk);
+    int vy[T16], rr[T16]; bool on[T16], nl[T16];
+#pragma unroll
+    for (int t = 0; t < T16; ++t) {
+        const int a = 16 * t + lm;
+        on[t] = a < n2; nl[t] = a >= R;
+        rr[t] = on[t] ? a % R : 0;
+        vy[t] = nl[t] ? VYL(D, rr[t]) : VYF(D, rr[t]);
+    }
+    lp_v4d C[NP], G[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { C[k] = lp_v4d{0.0, 0.0, 0.0, 0.0}; G[k] = lp_v4d{0.0, 0.0, 0.0, 0.0}; }
+    double dsum[T16];
+#pragma unroll
+    for (int t = 0; t < T16; ++t) dsum[t] = 0.0;
+    for (int p0 = pb; p0 < pe; p0 += 4) {
+        const int p = p0 + lq;
+        const bool live = p < pe;
+        const int pc = live ? p : pb;
+        const double i11 = ti[(size_t)0 * P + pc], i12 = ti[(size_t)1 * P + pc], i22 = ti[(size_t)2 * P + pc];
+        double v0[T16], v1[T16], w0[T16], w1[T16], cy[T16], g[T16];
+#pragma unroll
+        for (int t = 0; t < T16; ++t) {
+            const double c = th[(size_t)vy[t] * P + pc], d = fr[((size_t)0 * R + rr[t]) * P + pc], e1 = fr[((size_t)1 * R + rr[t]) * P + pc], e2 = fr[((size_t)2 * R + rr[t]) * P + pc];
+            const bool use = live && on[t];
+            cy[t] = use ? c : 0.0;
+            g[t] = use ? c / d : 0.0;
+            v0[t] = use ? c - e1 * c / d : 0.0;
+            v1[t] = use ? (nl[t] ? c : 0.0) - e2 * c / d : 0.0;
+            w0[t] = i11 * v0[t] + i12 * v1[t]; w1[t] = i12 * v0[t] + i22 * v1[t];
+            dsum[t] += cy[t];
+        }
+#pragma unroll
+        for (int ta = 0; ta < T16; ++ta)
+#pragma unroll
+            for (int tc = 0; tc <= ta; ++tc) {
+                const int k = ta * (ta + 1) / 2 + tc;
+                C[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w0[ta], v0[tc], C[k], 0, 0, 0);
+                C[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w1[ta], v1[tc], C[k], 0, 0, 0);
+                G[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-g[ta], cy[tc], G[k], 0, 0, 0);
+            }
+    }
+    // column sums: the four q-lanes of a column, in order
+#pragma unroll
+    for (int t = 0; t < T16; ++t) {
+        const double s1 = __shfl(dsum[t], lm + 16, 64), s2 = __shfl(dsum[t], lm + 32, 64), s3 = __shfl(dsum[t], lm + 48, 64);
+        dsum[t] = ((dsum[t] + s1) + s2) + s3;       // (meaningful on lanes 0..15)
+    }
+    for (int ww = 0; ww < 4; ++ww) {               // the workgroup's four wavefronts, added in order
+        if (w == ww) {
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = (k * 4 + r) * 64 + lane;
+                    comb[e] = ww ? comb[e] + C[k][r] : C[k][r];
+                    comb[NP * 256 + e] = ww ? comb[NP * 256 + e] + G[k][r] : G[k][r];
+                }
+            if (lane < 16)
+#pragma unroll
+                for (int t = 0; t < T16; ++t) comb[2 * NP * 256 + 16 * t + lane] = ww ? comb[2 * NP * 256 + 16 * t + lane] + dsum[t] : dsum[t];
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < NE; e += 256) part[(size_t)blockIdx.x * NE + e] = comb[e];
+}
+template <int T16>
+__global__ void k_lp_schur_rack_sum2(LpDev D, const double *part, int nblk, const double *thg, double *S) {
+    if (LP_STOPPED(D)) return;
+    constexpr int NP = T16 * (T16 + 1) / 2, NE = 2 * NP * 256 + T16 * 16;
+    const int n2 = 2 * D.R, ne = n2 * n2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    const int a = e / n2, c = e % n2;
+    if (c > a) return;
+    const int ta = a >> 4, tc = c >> 4, k = ta * (ta + 1) / 2 + tc, row = a & 15, col = c & 15;
+    const int idx = (k * 4 + (row >> 2)) * 64 + (row & 3) * 16 + col;      // accumulator layout: row = (lane >> 4) + 4 reg, col = lane & 15
+    const bool same = a % D.R == c % D.R;
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) {
+        const double *rec = part + (size_t)i * NE;
+        double v = rec[idx];
+        if (same) { v += rec[NP * 256 + idx]; if (a == c) v += rec[2 * NP * 256 + a]; }
+        s += v;
+    }
+    if (a == c) {   // the racks' own inflow variables: NF[r] += sum zf, NL[r] += sum zl over the rack's brokers (in order)
+        const int r = a % D.R;
+        for (int i = D.rk_off[r]; i < D.rk_off[r + 1]; ++i) s += thg[(a < D.R ? 0 : D.B) + D.rk_mem[i]];
+    }
+    S[(size_t)a * D.mcp + c] = s;
+}
 // rows C6[r] (columns NF, NL: none; own diagonal: sum n + k), regularisation, absent / pinned rows, padding; saves the diagonal
 __global__ void k_lp_schur_fix(LpDev D, const double *thg, double *S, double *diag0) {
     if (LP_STOPPED(D)) return;
@@ -851,25 +961,35 @@ __global__ void k_lp_A_broker(LpDev D, const double *z, const double *zg, const 
     rc[r3] = mode == 1 ? D.bc[r3] - s3 : (mode == 2 ? s3 + addc[r3] : s3);
     rc[r4] = mode == 1 ? D.bc[r4] - s4 : (mode == 2 ? s4 + addc[r4] : s4);
 }
-// coupling rows NF[r], NL[r] (one block each: a fixed-order sum over the partitions) and C6[r]; `cr`: extra terms [2 R][P]
-__global__ void __launch_bounds__(kRedBlock) k_lp_A_rack(LpDev D, const double *z, const double *zg, const double *cr, double *rc, int mode, const double *addc, int gated) {
+// coupling rows NF[r], NL[r] and C6[r]; `cr`: extra terms [2 R][P].  Two stages (round 6): kRackChunks workgroups per row sum a fixed
+// slice of the partitions each (one workgroup per row walked 100,000 partitions with 256 threads: 0.12 ms, five times an iteration), one
+// thread per row adds the slices in order and the row's global variables.
+constexpr int kRackChunks = 16;
+__global__ void __launch_bounds__(kRedBlock) k_lp_A_rack_part(LpDev D, const double *z, const double *cr, double *part, int gated) {
     if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
     __shared__ double sh[kRedBlock];
-    const int R = D.R, P = D.P, row = blockIdx.x;     // 0..R-1 NF, R..2R-1 NL, 2R..3R-1 C6
+    const int R = D.R, P = D.P, row = blockIdx.x / kRackChunks, chunk = blockIdx.x % kRackChunks;     // row: 0..R-1 NF, R..2R-1 NL
     const int r = row % R, kind = row / R;
+    const int per = (P + kRackChunks - 1) / kRackChunks, p0 = chunk * per, p1 = min(P, p0 + per);
+    const double *zz = z + (size_t)(kind == 0 ? VYF(D, r) : VYL(D, r)) * P;
+    const double *cc = cr ? cr + (size_t)(2 * r + kind) * P : nullptr;
     double s = 0.0;
-    if (kind < 2) {
-        const double *zz = z + (size_t)(kind == 0 ? VYF(D, r) : VYL(D, r)) * P;
-        const double *cc = cr ? cr + (size_t)(2 * r + kind) * P : nullptr;
-        for (int p = threadIdx.x; p < P; p += kRedBlock) s += zz[p] + (cc ? cc[p] : 0.0);
-    }
+    for (int p = p0 + threadIdx.x; p < p1; p += kRedBlock) s += zz[p] + (cc ? cc[p] : 0.0);
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = kRedBlock / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x) return;
-    s = sh[0];
-    if (kind < 2) { for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s -= zg[(kind == 0 ? 0 : D.B) + D.rk_mem[e]]; }
-    else if (D.has_n) { for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s += zg[2 * D.B + D.rk_mem[e]]; if (D.has_k) s -= zg[4 * D.B + r]; }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ void k_lp_A_rack_fin(LpDev D, const double *part, const double *zg, double *rc, int mode, const double *addc, int gated) {
+    if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
+    const int R = D.R, row = blockIdx.x * blockDim.x + threadIdx.x;     // 0..R-1 NF, R..2R-1 NL, 2R..3R-1 C6
+    if (row >= 3 * R) return;
+    const int r = row % R, kind = row / R;
+    double s = 0.0;
+    if (kind < 2) {
+        for (int k = 0; k < kRackChunks; ++k) s += part[row * kRackChunks + k];
+        for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s -= zg[(kind == 0 ? 0 : D.B) + D.rk_mem[e]];
+    } else if (D.has_n) { for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s += zg[2 * D.B + D.rk_mem[e]]; if (D.has_k) s -= zg[4 * D.B + r]; }
     double out = mode == 1 ? D.bc[row] - s : (mode == 2 ? s + addc[row] : s);
     if (D.rowc[row] != 1) out = 0.0;      // absent / pinned rows carry no residual and no right-hand side
     rc[row] = out;
@@ -998,25 +1118,26 @@ __global__ void k_lp_cost(LpDev D, double *z, double *zg) {
 // dual residual rd = c - A^T y - s + v and the sums {|rd|^2, x.s + w.v, c.x, u.v}; one record per block
 __global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVec s, VarVec v, RowVec y, VarVec rd, double *rec) {
     if (LP_STOPPED(D)) return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nv = (size_t)D.NV * D.P;
+    const size_t nv = (size_t)D.NV * D.P, stride = (size_t)gridDim.x * blockDim.x;
     double a[4] = {0, 0, 0, 0};
-    if (i < nv) {
-        const int vv = (int)(i / D.P), p = (int)(i % D.P);
-        if (var_present(D, vv, p)) {
-            const double u = var_ub(D, vv), c = var_cost(D, vv, p);
-            const double r = c - at_val(D, vv, p, y) - s.z[i] + v.z[i];
-            rd.z[i] = r; a[0] = r * r; a[1] = x.z[i] * s.z[i]; a[2] = c * x.z[i];
-            if (u > 0) { a[1] += (u - x.z[i]) * v.z[i]; a[3] = u * v.z[i]; }
-        } else rd.z[i] = 0.0;
-    } else if (i < nv + D.GV) {
-        const int g = (int)(i - nv);
-        if (gvar_present(D, g)) {
-            const double u = gvar_ub(D, g), c = gvar_cost(D, g);
-            const double r = c - at_val_g(D, g, y.rc) - s.zg[g] + v.zg[g];
-            rd.zg[g] = r; a[0] = r * r; a[1] = x.zg[g] * s.zg[g]; a[2] = c * x.zg[g];
-            if (u > 0) { a[1] += (u - x.zg[g]) * v.zg[g]; a[3] = u * v.zg[g]; }
-        } else rd.zg[g] = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv + D.GV; i += stride) {
+        if (i < nv) {
+            const int vv = (int)(i / D.P), p = (int)(i % D.P);
+            if (var_present(D, vv, p)) {
+                const double u = var_ub(D, vv), c = var_cost(D, vv, p);
+                const double r = c - at_val(D, vv, p, y) - s.z[i] + v.z[i];
+                rd.z[i] = r; a[0] += r * r; a[1] += x.z[i] * s.z[i]; a[2] += c * x.z[i];
+                if (u > 0) { a[1] += (u - x.z[i]) * v.z[i]; a[3] += u * v.z[i]; }
+            } else rd.z[i] = 0.0;
+        } else {
+            const int g = (int)(i - nv);
+            if (gvar_present(D, g)) {
+                const double u = gvar_ub(D, g), c = gvar_cost(D, g);
+                const double r = c - at_val_g(D, g, y.rc) - s.zg[g] + v.zg[g];
+                rd.zg[g] = r; a[0] += r * r; a[1] += x.zg[g] * s.zg[g]; a[2] += c * x.zg[g];
+                if (u > 0) { a[1] += (u - x.zg[g]) * v.zg[g]; a[3] += u * v.zg[g]; }
+            } else rd.zg[g] = 0.0;
+        }
     }
     block_reduce(a, 4, false, rec + (size_t)blockIdx.x * kRedVals);
 }
@@ -1073,35 +1194,35 @@ __global__ void k_lp_h(LpDev D, int pass, VarVec x, VarVec s, VarVec v, VarVec t
 // dx = theta (A^T dy - h), ds = (rxs - s dx) / x, dv = (rwv + v dx) / w; step lengths to the boundary {alpha_p, alpha_d} (min)
 __global__ void __launch_bounds__(kRedBlock) k_lp_dir(LpDev D, VarVec x, VarVec s, VarVec v, VarVec th, VarVec h, RowVec dy, VarVec dx, VarVec ds, VarVec dv, double *rec) {
     if (LP_STOPPED(D)) return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nv = (size_t)D.NV * D.P;
+    const size_t nv = (size_t)D.NV * D.P, stride = (size_t)gridDim.x * blockDim.x;
     double a[2] = {1.0, 1.0};
-    double xi = 0, si = 0, vi = 0, thi = 0, hi = 0, atv = 0, u = 0, rxs = 0, rwv = 0;
-    bool on = false;
-    if (i < nv) {
-        const int vv = (int)(i / D.P), p = (int)(i % D.P);
-        on = var_present(D, vv, p);
-        if (on) { xi = x.z[i]; si = s.z[i]; vi = v.z[i]; thi = th.z[i]; hi = h.z[i]; atv = at_val(D, vv, p, dy); u = var_ub(D, vv); rxs = ds.z[i]; rwv = dv.z[i]; }
-    } else if (i < nv + D.GV) {
-        const int k = (int)(i - nv);
-        on = gvar_present(D, k);
-        if (on) { xi = x.zg[k]; si = s.zg[k]; vi = v.zg[k]; thi = th.zg[k]; hi = h.zg[k]; atv = at_val_g(D, k, dy.rc); u = gvar_ub(D, k); rxs = ds.zg[k]; rwv = dv.zg[k]; }
-    }
-    double ddx = 0, dds = 0, ddv = 0;
-    if (on) {
-        ddx = thi * (atv - hi);
-        dds = (rxs - si * ddx) / xi;
-        if (ddx < 0) a[0] = fmin(a[0], -xi / ddx);
-        if (dds < 0) a[1] = fmin(a[1], -si / dds);
-        if (u > 0) {
-            const double w = u - xi;
-            ddv = (rwv + vi * ddx) / w;
-            if (ddx > 0) a[0] = fmin(a[0], w / ddx);
-            if (ddv < 0) a[1] = fmin(a[1], -vi / ddv);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv + D.GV; i += stride) {
+        double xi = 0, si = 0, vi = 0, thi = 0, hi = 0, atv = 0, u = 0, rxs = 0, rwv = 0;
+        bool on = false;
+        if (i < nv) {
+            const int vv = (int)(i / D.P), p = (int)(i % D.P);
+            on = var_present(D, vv, p);
+            if (on) { xi = x.z[i]; si = s.z[i]; vi = v.z[i]; thi = th.z[i]; hi = h.z[i]; atv = at_val(D, vv, p, dy); u = var_ub(D, vv); rxs = ds.z[i]; rwv = dv.z[i]; }
+        } else {
+            const int k = (int)(i - nv);
+            on = gvar_present(D, k);
+            if (on) { xi = x.zg[k]; si = s.zg[k]; vi = v.zg[k]; thi = th.zg[k]; hi = h.zg[k]; atv = at_val_g(D, k, dy.rc); u = gvar_ub(D, k); rxs = ds.zg[k]; rwv = dv.zg[k]; }
         }
+        double ddx = 0, dds = 0, ddv = 0;
+        if (on) {
+            ddx = thi * (atv - hi);
+            dds = (rxs - si * ddx) / xi;
+            if (ddx < 0) a[0] = fmin(a[0], -xi / ddx);
+            if (dds < 0) a[1] = fmin(a[1], -si / dds);
+            if (u > 0) {
+                const double w = u - xi;
+                ddv = (rwv + vi * ddx) / w;
+                if (ddx > 0) a[0] = fmin(a[0], w / ddx);
+                if (ddv < 0) a[1] = fmin(a[1], -vi / ddv);
+            }
+        }
+        dx.z[i] = ddx; ds.z[i] = dds; dv.z[i] = ddv;       // (the global variables sit right behind the partition ones)
     }
-    if (i < nv) { dx.z[i] = ddx; ds.z[i] = dds; dv.z[i] = ddv; }
-    else if (i < nv + D.GV) { dx.zg[i - nv] = ddx; ds.zg[i - nv] = dds; dv.zg[i - nv] = ddv; }
     block_reduce(a, 2, true, rec + (size_t)blockIdx.x * kRedVals);
 }
 // corrector right-hand side: h, g = theta h and the parked targets (rxs -> dsc, rwv -> dvc) from the trial point of the direction (dx, ds, dv)
@@ -1134,13 +1255,12 @@ __global__ void k_lp_mcc_h(LpDev D, VarVec x, VarVec s, VarVec v, VarVec th, Var
 __global__ void __launch_bounds__(kRedBlock) k_lp_mcc_dir(LpDev D, VarVec x, VarVec s, VarVec v, VarVec th, VarVec h, RowVec dy, VarVec dxc, VarVec dsc, VarVec dvc,
                                                             VarVec dx, VarVec ds, VarVec dv, double *rec) {
     if (LP_STOPPED(D) || D.sc[SC_MCC_GO] == 0.0) return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nv = (size_t)D.NV * D.P;
+    const size_t nv = (size_t)D.NV * D.P, stride = (size_t)gridDim.x * blockDim.x;
     double a[2] = {1.0, 1.0};
-    bool on = false; double u = 0, atv = 0;
-    if (i < nv) { const int vv = (int)(i / D.P), p = (int)(i % D.P); on = var_present(D, vv, p); if (on) { u = var_ub(D, vv); atv = at_val(D, vv, p, dy); } }
-    else if (i < nv + D.GV) { const int k = (int)(i - nv); on = gvar_present(D, k); if (on) { u = gvar_ub(D, k); atv = at_val_g(D, k, dy.rc); } }
-    if (i < nv + D.GV) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv + D.GV; i += stride) {
+        bool on = false; double u = 0, atv = 0;
+        if (i < nv) { const int vv = (int)(i / D.P), p = (int)(i % D.P); on = var_present(D, vv, p); if (on) { u = var_ub(D, vv); atv = at_val(D, vv, p, dy); } }
+        else { const int k = (int)(i - nv); on = gvar_present(D, k); if (on) { u = gvar_ub(D, k); atv = at_val_g(D, k, dy.rc); } }
         double c1 = 0, c2 = 0, c3 = 0;
         if (on) {
             const double xi = x.z[i], si = s.z[i], vi = v.z[i];
@@ -1176,24 +1296,16 @@ __global__ void k_lp_mcc_acc_rows(const double *sc, const double *d, double *y, 
 // sum (x + ap dx)(s + ad ds) + (w - ap dx)(v + ad dv)
 __global__ void __launch_bounds__(kRedBlock) k_lp_muaff(LpDev D, VarVec x, VarVec s, VarVec v, VarVec dx, VarVec ds, VarVec dv, double *rec) {
     if (LP_STOPPED(D)) return;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nv = (size_t)D.NV * D.P;
+    const size_t nv = (size_t)D.NV * D.P, stride = (size_t)gridDim.x * blockDim.x;
     double a[1] = {0};
     const double ap = D.sc[SC_AP], ad = D.sc[SC_AD];
-    if (i < nv) {
-        const int vv = (int)(i / D.P), p = (int)(i % D.P);
-        if (var_present(D, vv, p)) {
-            const double u = var_ub(D, vv);
-            a[0] = (x.z[i] + ap * dx.z[i]) * (s.z[i] + ad * ds.z[i]);
-            if (u > 0) a[0] += (u - x.z[i] - ap * dx.z[i]) * (v.z[i] + ad * dv.z[i]);
-        }
-    } else if (i < nv + D.GV) {
-        const int k = (int)(i - nv);
-        if (gvar_present(D, k)) {
-            const double u = gvar_ub(D, k);
-            a[0] = (x.zg[k] + ap * dx.zg[k]) * (s.zg[k] + ad * ds.zg[k]);
-            if (u > 0) a[0] += (u - x.zg[k] - ap * dx.zg[k]) * (v.zg[k] + ad * dv.zg[k]);
-        }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv + D.GV; i += stride) {
+        bool on; double u;
+        if (i < nv) { const int vv = (int)(i / D.P), p = (int)(i % D.P); on = var_present(D, vv, p); u = var_ub(D, vv); }
+        else { const int k = (int)(i - nv); on = gvar_present(D, k); u = gvar_ub(D, k); }
+        if (!on) continue;
+        a[0] += (x.z[i] + ap * dx.z[i]) * (s.z[i] + ad * ds.z[i]);
+        if (u > 0) a[0] += (u - x.z[i] - ap * dx.z[i]) * (v.z[i] + ad * dv.z[i]);
     }
     block_reduce(a, 1, false, rec + (size_t)blockIdx.x * kRedVals);
 }
@@ -1269,6 +1381,8 @@ struct LpCtx {
     double *rec = nullptr, *redA = nullptr, *redB = nullptr, *redC = nullptr, *part = nullptr, *ylast = nullptr, *trace = nullptr;
     int32_t *d_mult = nullptr, *d_zq = nullptr;
     VarVec dc{}; RowVec wc{}; int mcc = 2;   // centrality correctors per iteration (KAO_LP_MCC; 0: none) and their direction / row vector
+    bool rack_mfma = true;         // the rack x rack block of the Schur complement on the matrix cores (2R <= 64; KAO_LP_RACK=old: the LDS-tiled kernel)
+    double *rack_part = nullptr;   // [2 R][kRackChunks] slice sums of the rack rows
     int broker_u = 8;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
     double *xz = nullptr; bool dense_new = true;   // kao_chol.hip (KAO_LP_DENSE=old: round 5's kernels below, for A/B runs)
     int *trsv_flags = nullptr; double *trsv_z = nullptr; bool trsv_mw = true;   // the triangular solves by one workgroup per row tile (KAO_LP_TRSV_MW=0: by one workgroup)
@@ -1328,7 +1442,8 @@ void lp_rows_local(LpCtx &c, const VarVec &z, const RowVec &out, int mode, const
 void lp_rows_coupling(LpCtx &c, const VarVec &z, double *out_rc, int mode, const double *add_rc, const double *cb, const double *cr, int gated = 0) {
     const LpDev &D = c.D;
     hipLaunchKernelGGL(k_lp_A_broker, dim3((D.B + 3) / 4), dim3(256), 0, c.st, D, z.z, z.zg, cb, out_rc, mode, add_rc, gated);
-    hipLaunchKernelGGL(k_lp_A_rack, dim3(3 * D.R), dim3(kRedBlock), 0, c.st, D, z.z, z.zg, cr, out_rc, mode, add_rc, gated);
+    hipLaunchKernelGGL(k_lp_A_rack_part, dim3(2 * D.R * kRackChunks), dim3(kRedBlock), 0, c.st, D, z.z, cr, c.rack_part, gated);
+    hipLaunchKernelGGL(k_lp_A_rack_fin, dim3((3 * D.R + 63) / 64), dim3(64), 0, c.st, D, c.rack_part, z.zg, out_rc, mode, add_rc, gated);
 }
 
 void lp_factor(LpCtx &c) {
@@ -1339,9 +1454,19 @@ void lp_factor(LpCtx &c) {
     if (c.broker_u >= 16) hipLaunchKernelGGL(k_lp_schur_broker<16>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
     else if (c.broker_u >= 8) hipLaunchKernelGGL(k_lp_schur_broker<8>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
     else hipLaunchKernelGGL(k_lp_schur_broker<4>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
-    const int n2 = 2 * D.R, per = 6 * n2 + D.R;
-    hipLaunchKernelGGL(k_lp_schur_rack, dim3(c.rack_blocks), dim3(256), (size_t)c.rack_tile * per * sizeof(double), c.st, D, c.th.z, c.fj, c.fr, c.ti, c.rack_chunk, c.rack_tile, c.part);
-    hipLaunchKernelGGL(k_lp_schur_rack_sum, dim3((n2 * n2 + 255) / 256), dim3(256), 0, c.st, D, c.part, c.rack_blocks, c.th.zg, c.S);
+    const int n2 = 2 * D.R, per = 6 * n2 + D.R, t16 = (n2 + 15) / 16;
+    const dim3 sg((n2 * n2 + 255) / 256), sb(256);
+#define KAO_RACK_MFMA(T) do { hipLaunchKernelGGL(k_lp_schur_rack_mfma<T>, dim3(kRackMfmaBlocks), dim3(256), 0, c.st, D, c.th.z, c.fr, c.ti, c.part); \
+                              hipLaunchKernelGGL(k_lp_schur_rack_sum2<T>, sg, sb, 0, c.st, D, c.part, kRackMfmaBlocks, c.th.zg, c.S); } while (0)
+    if (c.rack_mfma && t16 == 1) KAO_RACK_MFMA(1);
+    else if (c.rack_mfma && t16 == 2) KAO_RACK_MFMA(2);
+    else if (c.rack_mfma && t16 == 3) KAO_RACK_MFMA(3);
+    else if (c.rack_mfma && t16 == 4) KAO_RACK_MFMA(4);
+    else {
+        hipLaunchKernelGGL(k_lp_schur_rack, dim3(c.rack_blocks), dim3(256), (size_t)c.rack_tile * per * sizeof(double), c.st, D, c.th.z, c.fj, c.fr, c.ti, c.rack_chunk, c.rack_tile, c.part);
+        hipLaunchKernelGGL(k_lp_schur_rack_sum, sg, sb, 0, c.st, D, c.part, c.rack_blocks, c.th.zg, c.S);
+    }
+#undef KAO_RACK_MFMA
     hipLaunchKernelGGL(k_lp_schur_fix, dim3((D.mcp + 255) / 256), dim3(256), 0, c.st, D, c.th.zg, c.S, c.diag0);
     hipLaunchKernelGGL(k_lp_schur_fix_cols, dim3((D.mc + 255) / 256), dim3(256), 0, c.st, D, c.S);
     if (c.dense_new) { chol_enqueue(c.st, D.sc + SC_STOP, c.S, D.mcp, c.diag0, c.Linv); return; }
@@ -1478,7 +1603,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     if ((rc = c->var_vec(c->dc))) return bail(rc);
     { const char *e = std::getenv("KAO_LP_MCC"); c->mcc = e ? std::max(0, std::min(4, std::atoi(e))) : 2; }
     const size_t nvtot = (size_t)D.NV * P + D.GV;
-    c->nblk_var = (int)((nvtot + kRedBlock - 1) / kRedBlock);
+    c->nblk_var = (int)std::min<size_t>((nvtot + kRedBlock - 1) / kRedBlock, (size_t)kVarBlocks);
     c->nblk_p = (P + 255) / 256;
     c->broker_waves = std::max(1, std::min(4, (int)((150 * 1024) / ((size_t)2 * mc * sizeof(double)))));
     const int n2 = 2 * R, per = 6 * n2 + R;
@@ -1490,8 +1615,8 @@ int lp_open(const kao_topic *t, LpCtx **out) {
         (rc = c->alloc(&c->S, (size_t)D.mcp * D.mcp)) || (rc = c->alloc(&c->Linv, (size_t)D.mcp * kNB)) || (rc = c->alloc(&c->diag0, (size_t)D.mcp)) || (rc = c->alloc(&c->cb, (size_t)2 * NJ * P)) ||
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
-        (rc = c->alloc(&c->part, (size_t)c->rack_blocks * n2 * n2)) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
-        (rc = c->alloc(&c->trsv_flags, (size_t)2 * (D.mcp / kNB))) || (rc = c->alloc(&c->trsv_z, (size_t)D.mcp)) || (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) ||
+        (rc = c->alloc(&c->part, std::max((size_t)c->rack_blocks * n2 * n2, (size_t)kRackMfmaBlocks * (2 * 10 * 256 + 64)))) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
+        (rc = c->alloc(&c->trsv_flags, (size_t)2 * (D.mcp / kNB))) || (rc = c->alloc(&c->trsv_z, (size_t)D.mcp)) || (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
         (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
     { const char *e = std::getenv("KAO_LP_TRSV_MW"); c->trsv_mw = !(e && e[0] == '0') && D.mcp / kNB <= 160; }
@@ -1500,6 +1625,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    { const char *e = std::getenv("KAO_LP_RACK"); c->rack_mfma = !(e && e[0] == 'o'); }
     { const char *e = std::getenv("KAO_LP_BROKER_U"); c->broker_u = e ? std::atoi(e) : 8; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_rack), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -1518,8 +1644,8 @@ int lp_open(const kao_topic *t, LpCtx **out) {
 void lp_abort(LpCtx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    const double two = 2.0;
-    (void)hipMemcpy(c->D.sc + SC_STOP, &two, sizeof two, hipMemcpyHostToDevice);
+    const double four = 4.0;   // its own value: an aborted solve's iterate is mid-way, nobody may take it for a finished one
+    (void)hipMemcpy(c->D.sc + SC_STOP, &four, sizeof four, hipMemcpyHostToDevice);
 }
 void lp_close(LpCtx *c) { delete c; }
 
@@ -1690,7 +1816,7 @@ int lp_finish(LpCtx *cp, int32_t *multipliers, double stats[8], double *trace) {
     if (trace) HIP_TRY(hipMemcpyAsync(trace, c.trace, sizeof(double) * 5 * (size_t)(it + 1), hipMemcpyDeviceToHost, c.st));
     HIP_TRY(hipStreamSynchronize(c.st));
     if (stats) {
-        stats[0] = it; stats[1] = -c.h_sc[SC_PLAST]; stats[2] = -c.h_sc[SC_DLAST]; stats[3] = st == 1 ? 0 : (st == 2 || st == 0 ? 1 : 3);
+        stats[0] = it; stats[1] = -c.h_sc[SC_PLAST]; stats[2] = -c.h_sc[SC_DLAST]; stats[3] = st == 1 ? 0 : (st == 2 || st == 0 || st == 4 ? 1 : 3);
         stats[4] = c.h_sc[SC_MU]; stats[5] = c.h_sc[SC_PINF]; stats[6] = c.h_sc[SC_DINF]; stats[7] = (now_s() - c.t_begin) * 1e3;
     }
     return KAO_OK;

@@ -27,7 +27,7 @@ constexpr uint16_t kUnset = 0xFFFFu;
 struct Row { int w; int n; int b[KAO_MAX_RF]; };
 }  // namespace
 
-int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq, const uint16_t *fallback, uint16_t *out, int32_t rep[4]) {
+int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq, const uint16_t *fallback, uint16_t *out, int32_t rep[4], int max_free) {
     const int P = t->n_partitions, B = t->n_brokers, R = t->n_racks, RF = t->rf, NJ = t->rf_cur;
     int32_t bd[8];
     derive_bounds(t, bd);
@@ -188,6 +188,10 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     // ---- the fractional partitions, together: candidate rows from their support, chosen by a bounded depth-first search so that the
     //      band rows (README.md:158-166) come out right given what the other partitions hold ----
     const size_t np = pending.size();
+    if (np > (size_t)std::max(max_free, 0)) {   // an iterate far from a vertex (an aborted or stalled solve): the caller decides what the rows are worth
+        if (rep) { rep[1] = over; rep[2] = unplaced; rep[3] = -1; }
+        return KAO_OK;
+    }
     // ---- first attempt: PATTERNS (specification: oracle/kao_lp.py complete_by_patterns).  The weight of a completion comes from the
     //      current replicas a partition keeps; the new replicas are weightless and interchangeable.  Per partition the patterns (leader:
     //      a current replica or a new one; followers: a subset of the other current replicas; kept brokers in distinct racks, with room

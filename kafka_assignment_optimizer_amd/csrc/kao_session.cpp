@@ -529,7 +529,9 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         for (int t = 0; t < n_topics; ++t) per_restart += (uint64_t)topics[t].n_partitions * (32 + 2 * (uint64_t)std::max(topics[t].rf, 1));
         size_t free_b = 0, total_b = 0;
         uint64_t budget = 8ull << 30;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, std::max<uint64_t>(free_b / 4, 256ull << 20));
+        // keyed to the device's TOTAL memory, not to what happens to be free (same input, same seed, same answer whatever else
+        // occupies the device; an allocation that does not fit fails loudly with KAO_ERR_NOMEM instead of changing the search)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) budget = std::min<uint64_t>(budget, std::max<uint64_t>(total_b / 8, 256ull << 20));
         const uint64_t cap = budget / std::max<uint64_t>(per_restart, 1);
         if ((uint64_t)o.restarts > cap) o.restarts = (int)std::max<uint64_t>(cap / kWaves * kWaves, kWaves);
     }

@@ -177,6 +177,7 @@ struct SolveRun {
     double lp_solo_s = 1.0; int64_t lp_solo_slots = 32768;
     double lp_alone_s = 1.5;      // with this much before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
     int lp_rounded = 0, lp_round_adopted = 0, lp_round_fractional = 0;
+    int lp_round_max_free = 512;  // fractional partitions completed without the incumbent's rows (about 0.1 ms each: 100,000 of a mid-way iterate took 8 s)
     std::vector<char> lp_try, lp_certified;   // per topic: LP solves finished; the LP's certificate is in place (K-bound leaves the topic alone)
     double lp_tol = 1e-10;        // stopping tolerance of the perturbed solve (KAO_LP_TOL)
     int lp_ahead = 4;             // huge topics: marks (of four iterations) kept enqueued ahead of the one being waited for
@@ -201,9 +202,19 @@ struct SolveRun {
         return true;
     }
     bool lp_alone(int i) const { return lp_round_on && ((huge(i) && deadline - t0 >= lp_alone_s) || (solo(i) && deadline - t0 >= lp_solo_s && only_open(i))); }
-    bool search_paused() const {   // a huge topic between its first feasible incumbent and the end of its LP -- from the start when the limit leaves room for the LP alone
-        for (int i = 0; i < n; ++i) if (lp_possible(i) && !topic_done(i) && ((huge(i) && (feasible(i) || (lp_huge_first && launches >= 1))) || lp_alone(i))) return true;
-        return false;
+    // a huge topic between its first feasible incumbent and the end of its LP -- from the start when the limit leaves room for the LP alone
+    bool pause_wanted(int i) const { return lp_possible(i) && ((huge(i) && (feasible(i) || (lp_huge_first && launches >= 1))) || lp_alone(i)); }
+    bool search_paused() const {
+        //  never when the caller counts K-search launches (max_launches: it gets them), and never while some other open topic
+        // still needs the search: a pause is for solves whose every open topic is waiting for its LP
+        if (s->opts.max_launches > 0) return false;
+        bool any = false;
+        for (int i = 0; i < n; ++i) {
+            if (topic_done(i)) continue;
+            if (!pause_wanted(i)) return false;
+            any = true;
+        }
+        return any;
     }
     int lp_on = 1, lp_per_launch = 2, lp_max_running = 2, lp_solves = 0, lp_iters = 0;
     int64_t lp_min_slots = 2048;
@@ -338,9 +349,12 @@ struct SolveRun {
     // asynchronous.  Deterministic schedule: the K-bound launch decided after the previous K-search launch is enqueued only
     // now, behind the new K-search launch -- enqueueing up to 176 step kernels takes the host about a millisecond, which
     // the search stream no longer spends idle
+    bool stepped = false;     // the last turn launched K-search (a paused turn does not count as a launch)
+    int turns = 0;
     int launch() {
         int rc = KAO_OK;
-        if (!search_paused()) rc = kao_session_step(s);
+        stepped = !search_paused();
+        if (stepped) rc = kao_session_step(s);
         if (!rc && bound_pending) { bound_pending = false; rc = kao_session_bound_step(s, dual_target.data(), dual_now); }
         for (int i = 0; i < n && !rc; ++i)
             if (lp_state[(size_t)i] == 1 && !lp_all[(size_t)i]) rc = lp_enqueue_mark(lp_ctx[(size_t)i], lp_per_launch, lp_marks[(size_t)i]++);   // interior-point iterations beside the launch
@@ -361,10 +375,15 @@ struct SolveRun {
             if (final_call) {   // the newest mark of an LP that rides beside the launches; of one enqueued as a whole only the next (a bounded wait)
                 const int m = lp_all[(size_t)i] ? lp_read[(size_t)i] : lp_marks[(size_t)i] - 1;
                 if (m >= 0 && m < lp_marks[(size_t)i] && (rc = lp_poll_mark(lp_ctx[(size_t)i], m, &st, &it, deadline))) return rc;
+                if (st == 4) st = 0;   // aborted at the deadline: a mid-way iterate, not a result
                 if (!st) lp_abort(lp_ctx[(size_t)i]);
             } else if (lp_read[(size_t)i] < lp_marks[(size_t)i] && lp_marks[(size_t)i] - lp_read[(size_t)i] > (lp_all[(size_t)i] ? 0 : lp_lag)) {
                 const double tp0 = now_s();
                 if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it, lp_all[(size_t)i] ? deadline : 0.0))) return rc;   // (a huge topic's LP is waited for: the wait ends at the deadline)
+                if (st == 4) {   // aborted at the deadline: no certificate, no rounding of a mid-way iterate; the main loop ends on the clock
+                    lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; lp_state[(size_t)i] = 3; --running;
+                    continue;
+                }
                 if (lp_all[(size_t)i] && !st && lp_marks[(size_t)i] < 64 && (rc = lp_enqueue_mark(lp_ctx[(size_t)i], 4, lp_marks[(size_t)i]++))) return rc;
                 if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: mark %d of %d read in %.3f ms: %d iterations, stop %d\n", i, lp_read[(size_t)i] - 1, lp_marks[(size_t)i], (now_s() - tp0) * 1e3, it, st);
             }
@@ -407,7 +426,7 @@ struct SolveRun {
         if (final_call) return KAO_OK;
         // largest open topics first, at most `lp_max_running` at a time
         for (;;) {
-            if (running >= lp_max_running) break;
+            if (running >= lp_max_running || now_s() >= deadline) break;
             int best = -1; int64_t best_slots = 0;
             for (int i = 0; i < n; ++i) {
                 if (lp_state[(size_t)i] != 0 || !s->dual_ok[(size_t)i] || s->topic_infeasible[(size_t)i] || (feasible(i) && objective(i) >= s->ub[(size_t)i])) continue;
@@ -456,8 +475,14 @@ struct SolveRun {
         int32_t rep[4] = {0, 0, 0, 0};
         int64_t obj = 0;
         int32_t viol[8] = {0};
-        if ((rc = lp_round_assignment(&t, lp_q.data(), lp_zq.data(), nullptr, lp_buf.data(), rep)) || (rc = kao_evaluate(&t, lp_buf.data(), &obj, viol))) return rc;
-        if (viol[0] != 0 && fb && rep[0] > 0) {
+        if (now_s() >= deadline) return KAO_OK;
+        if ((rc = lp_round_assignment(&t, lp_q.data(), lp_zq.data(), nullptr, lp_buf.data(), rep, lp_round_max_free))) return rc;
+        if (rep[3] < 0) {   // far from a vertex: too many fractional partitions to complete freely -- the incumbent's rows, or nothing
+            if (!fb) { ++lp_rounded; lp_round_fractional += rep[0]; return KAO_OK; }
+            if ((rc = lp_round_assignment(&t, lp_q.data(), lp_zq.data(), fb, lp_buf.data(), rep))) return rc;
+        }
+        if ((rc = kao_evaluate(&t, lp_buf.data(), &obj, viol))) return rc;
+        if (viol[0] != 0 && fb && rep[0] > 0 && rep[3] == 0) {
             if ((rc = lp_round_assignment(&t, lp_q.data(), lp_zq.data(), fb, lp_buf.data(), rep)) || (rc = kao_evaluate(&t, lp_buf.data(), &obj, viol))) return rc;
         }
         ++lp_rounded; lp_round_fractional += rep[0];
@@ -516,8 +541,8 @@ struct SolveRun {
     int after_launch() {
         int rc = kao_session_best_keys(s, dkeys.data());
         if (rc) return rc;
-        ++launches;
-        iters_done += s->opts.iters_per_launch;
+        ++turns;
+        if (stepped) { ++launches; iters_done += s->opts.iters_per_launch; }
         const double t = now_s() - t0;
         for (int i = 0; i < n; ++i) {
             if (dkeys[(size_t)i] < gprev[(size_t)i]) { gprev[(size_t)i] = dkeys[(size_t)i]; t_improved[(size_t)i] = t; i_improved[(size_t)i] = iters_done; }
@@ -1499,7 +1524,7 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
     for (int i = 0; i < n_topics; ++i) for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) wmax = std::max(wmax, topics[i].w[a][b]);
     std::vector<int> fs;
     if (const char *e = std::getenv("KAO_CAP_F")) fs.push_back(std::max(1, std::min(8, std::atoi(e))));
-    else for (int f : {4, 2, 1}) if (wmax * f <= 255) fs.push_back(f);
+    else for (int f : {4, 2, 1}) if (f == 1 || wmax * f <= 255) fs.push_back(f);   // F = 1 always runs (weights up to 1023 are valid; only the scaled runs need room)
     kao_opts o{};
     if (opts) o = *opts;
     const double limit = o.time_limit_s > 0 ? o.time_limit_s : 10.0;
@@ -1509,6 +1534,14 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
     int64_t best_total = -1, best_L = INT64_MAX;
     int rc = KAO_OK;
     double rounds_total = 0;
+    auto copy_out = [&]() {
+        for (int i = 0; i < n_topics; ++i) {
+            uint16_t *dst = results[i].assignment;
+            results[i] = res[(size_t)i];
+            results[i].assignment = dst;
+            if (dst) std::memcpy(dst, buf[(size_t)i].data(), buf[(size_t)i].size() * 2);
+        }
+    };
     for (size_t k = 0; k < fs.size() && !rc; ++k) {
         const double left = limit - (now_s() - t0);
         if (k > 0 && left <= 0.05) break;
@@ -1522,14 +1555,9 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
         int64_t total = 0;
         bool ok = true;
         for (int i = 0; i < n_topics; ++i) { ok = ok && res[(size_t)i].status != KAO_STATUS_NO_FEASIBLE; total += res[(size_t)i].objective; }
-        if ((ok && total > best_total) || (best_total < 0 && k + 1 == fs.size())) {
+        if ((ok && total > best_total) || best_total < 0) {   // (no cap-respecting plan yet: the last run's report -- NO_FEASIBLE -- stands until one is found)
             if (ok) best_total = total;
-            for (int i = 0; i < n_topics; ++i) {
-                uint16_t *dst = results[i].assignment;
-                results[i] = res[(size_t)i];
-                results[i].assignment = dst;
-                if (dst) std::memcpy(dst, buf[(size_t)i].data(), buf[(size_t)i].size() * 2);
-            }
+            copy_out();
         }
         if (best_total >= 0 && best_L != INT64_MAX && best_total >= best_L) break;
     }

@@ -37,7 +37,7 @@ def run(pt, tag):
     kao.lp_trace(pt, max_iters=1)
     out = {}
     for mode in ("old", "new"):
-        os.environ["KAO_LP_DENSE"] = mode
+        os.environ["KAO_LP_DENSE"] = mode; os.environ["KAO_LP_RACK"] = mode; os.environ["KAO_LP_BROKER_U"] = "4" if mode == "old" else "8"
         t0 = time.perf_counter(); d = kao.lp_trace(pt, max_iters=200); dt = time.perf_counter() - t0
         out[mode] = d
         print(f"{tag} dense={mode}: status {d['status']} it {d['iterations']} primal {d['primal']:.6f} dual {d['dual']:.6f} ipm {d['ms']:.1f} ms = {d['ms']/max(1,d['iterations']):.3f} ms/it (call {dt*1e3:.0f} ms)", flush=True)
@@ -48,6 +48,15 @@ def run(pt, tag):
             worst = max(worst, abs(a[i][0] - b[i][0]) / a[i][0], abs(a[i][1] - b[i][1]) / max(1, abs(a[i][1])), abs(a[i][2] - b[i][2]) / max(1, abs(a[i][2])))
     print(f"   worst relative trace deviation new vs old while mu > 1e-6: {worst:.2e}; multipliers max diff {np.abs(out['old']['a'].astype(np.int64) - out['new']['a']).max()}", flush=True)
     os.environ["KAO_LP_DENSE"] = "new"
+    if pt.n_partitions >= 30000:
+        for u in ("4", "16"):
+            os.environ["KAO_LP_BROKER_U"] = u
+            d = kao.lp_trace(pt, max_iters=200)
+            print(f"   broker U={u}: it {d['iterations']} ipm {d['ms']:.1f} ms = {d['ms']/max(1,d['iterations']):.3f} ms/it", flush=True)
+        os.environ["KAO_LP_BROKER_U"] = "8"; os.environ["KAO_LP_RACK"] = "old"
+        d = kao.lp_trace(pt, max_iters=200)
+        print(f"   rack block by the LDS-tiled kernel: it {d['iterations']} ipm {d['ms']:.1f} ms = {d['ms']/max(1,d['iterations']):.3f} ms/it", flush=True)
+        os.environ["KAO_LP_RACK"] = "new"
     b1 = kao.lp_bound(pt); b2 = kao.lp_bound(pt)
     print(f"   lp_bound x2 (new): certificate {b1['bound']} / {b2['bound']}, same bits: {np.array_equal(b1['a'], b2['a']) and b1['best_dual'] == b2['best_dual']}", flush=True)
 
