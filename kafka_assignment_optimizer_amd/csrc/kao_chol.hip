@@ -26,6 +26,8 @@
 // bits on every run.  f64 throughout.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -64,43 +66,62 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
 // 16 x 16 diagonal block at c0 of the factored tile -> its inverse into V (lanes 0..15 of one wavefront: lane = column)
 __device__ __forceinline__ void dinv_block(const double *T, double *V, const double *rinv_s, int c0, int lane) {
     if (lane >= 16) return;
-    double x[16];
+    // column `lane` of the inverse, right-looking: once x_k is final every later row's sum takes L_ik x_k -- the dependent chain is one
+    // multiply and one fused multiply-add per row instead of a dot product per row
+    double s[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        double s = 0.0;
+    for (int i = 0; i < 16; ++i) s[i] = i == lane ? -1.0 : 0.0;     // x_i = -s_i / L_ii: the unit right-hand side enters as s_lane = -1
 #pragma unroll
-        for (int k = 0; k < i; ++k) s = fma(T[(c0 + i) * LD + c0 + k], x[k], s);     // (x[k] = 0 above the lane's column)
-        const double ri = rinv_s[c0 + i];
-        x[i] = i == lane ? ri : (i < lane ? 0.0 : -s * ri);
+    for (int k = 0; k < 16; ++k) {
+        const double xk = k < lane ? 0.0 : -s[k] * rinv_s[c0 + k];
+        s[k] = xk;
+#pragma unroll
+        for (int i = k + 1; i < 16; ++i) s[i] = fma(T[(c0 + i) * LD + c0 + k], xk, s[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) V[(c0 + i) * LD + c0 + lane] = x[i];
+    for (int i = 0; i < 16; ++i) V[(c0 + i) * LD + c0 + lane] = s[i];
 }
 
 // All kStepThreads threads of the workgroup call this.  d0s[64]: the tile's diagonal before the factorisation (pivot test).
-__device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, double *rinv_s, int tid) {
+__device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, double *rinv_s, int tid, long long *dbg = nullptr) {
     const int w = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
+    int dn = 0;
+#define KAO_TICK() do { if (dbg && tid == 0) dbg[dn] = (long long)__builtin_amdgcn_s_memtime(); ++dn; } while (0)
+    KAO_TICK();
     for (int e = tid; e < NB * LD; e += kStepThreads) V[e] = 0.0;
     __syncthreads();
     for (int p = 0; p < 4; ++p) {
         const int c0 = 16 * p;
         if (w == 0) {
             // the panel: lane = row, the panel's 16 columns in registers; rows above the panel's diagonal block carry garbage nobody reads
+            // The pivots run ahead on wave-uniform values: pivot j+1 = d - (u r2) u with u = the entry below pivot j, d = the diagonal
+            // entry behind it (both read BEFORE column j is scaled, while 1 / sqrt(pivot j) is still being refined) and r2 = 1 / pivot j
+            // -- twelve dependent operations a column; the scaling of the column and the updates of the panel's other columns,
+            // a[c] -= (a[j] r2) u_c with the unscaled u_c, depend on r2 only and fill the issue slots beside the chain.
             double a[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = T[lane * LD + c0 + c];
             const double d0l = d0s[lane];
+            double piv = readlane_d(a[0], c0);
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int pr = c0 + j;
-                const double piv = readlane_d(a[j], pr), thr = kPivotRel * readlane_d(d0l, pr);
-                const bool ok = piv > thr;
-                const double rinv = ok ? rsqrt_nr(piv) : kPivotBigInv;
-                const double ljj = ok ? piv * rinv : kPivotBig;
+                double u[16];
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) u[c] = readlane_d(a[j], c0 + c);          // unscaled entries of column j, rows of the panel's diagonal block
+                const double dnext = j + 1 < 16 ? readlane_d(a[j + 1], pr + 1) : 0.0;
+                const double thr = kPivotRel * readlane_d(d0l, pr);
+                const double pj = piv;
+                const bool ok = pj > thr;
+                const double rinv = ok ? rsqrt_nr(pj) : kPivotBigInv;
+                const double r2 = rinv * rinv;
+                if (j + 1 < 16) piv = fma(-(u[j + 1] * r2), u[j + 1], dnext);               // (the same operations lane pr + 1 applies to its own entry below)
+                const double t = a[j] * r2;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) a[c] = fma(-t, u[c], a[c]);
+                const double ljj = ok ? pj * rinv : kPivotBig;
                 a[j] = lane == pr ? ljj : a[j] * rinv;
                 if (lane == pr) rinv_s[pr] = rinv;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) a[c] = fma(-a[j], readlane_d(a[j], c0 + c), a[c]);
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c)
@@ -108,7 +129,9 @@ __device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, d
         } else if (w == 7 && p > 0) {
             dinv_block(T, V, rinv_s, c0 - 16, lane);      // the previous panel's diagonal block, beside the chain
         }
+        KAO_TICK();
         __syncthreads();
+        KAO_TICK();
         // trailing 16 x 16 blocks (mb, nb), p < nb <= mb <= 3: -= panel(mb) panel(nb)^T
         const int rel = 3 - p;
         if (w < rel * (rel + 1) / 2) {
@@ -124,9 +147,11 @@ __device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, d
             for (int r = 0; r < 4; ++r) T[(16 * mb + lq + 4 * r) * LD + 16 * nb + lm] = acc[r];
         }
         __syncthreads();
+        KAO_TICK();
     }
     if (w == 7) dinv_block(T, V, rinv_s, 48, lane);
     __syncthreads();
+    KAO_TICK();
     // the blocks of the inverse below the diagonal, by distance d from it: X_ij = -Dinv_i sum_{j <= k < i} L_ik X_kj
     for (int d = 1; d <= 3; ++d) {
         const bool act = w <= 3 - d;
@@ -151,34 +176,63 @@ __device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, d
             for (int r = 0; r < 4; ++r) V[(16 * i + lq + 4 * r) * LD + 16 * j + lm] = acc[r];
         }
         __syncthreads();
+        KAO_TICK();
     }
+#undef KAO_TICK
 }
 // the factored tile and its inverse leave LDS: L into the lower triangle of S's diagonal tile, L^-1 (zeros above the diagonal) into Linv
 __device__ __forceinline__ void diag_out(const double *T, const double *V, double *S, int n, int base, double *inv, int tid) {
-    for (int e = tid; e < NB * NB; e += kStepThreads) {
-        const int r = e >> 6, c = e & 63;
+#pragma unroll
+    for (int u = 0; u < NB * NB / kStepThreads; ++u) {
+        const int e = tid + kStepThreads * u, r = e >> 6, c = e & 63;
         inv[e] = c <= r ? V[r * LD + c] : 0.0;
         if (c <= r) S[(size_t)(base + r) * n + base + c] = T[r * LD + c];
     }
 }
 
+// workgroup index -> (bi, bj), 0 <= bj <= bi: index = bi (bi + 1) / 2 + bj
+__device__ __forceinline__ void pair_of(int idx, int &bi, int &bj) {
+    bi = (int)((sqrtf(8.0f * (float)idx + 1.0f) - 1.0f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= idx) ++bi;
+    while (bi * (bi + 1) / 2 > idx) --bi;
+    bj = idx - bi * (bi + 1) / 2;
+}
+// a 64 x 64 tile of S (row-major, leading dimension n) -> LDS (leading dimension LD): all eight loads of a thread are issued before the
+// first LDS write (written as a loop the compiler waits for every load in turn: 8 x 2 dependent round trips, half of a step's time)
+__device__ __forceinline__ void tile_to_lds(const double *__restrict__ src, int n, double *dst, int tid) {
+    double v[NB * NB / kStepThreads];
+#pragma unroll
+    for (int u = 0; u < NB * NB / kStepThreads; ++u) { const int e = tid + kStepThreads * u; v[u] = src[(size_t)(e >> 6) * n + (e & 63)]; }
+#pragma unroll
+    for (int u = 0; u < NB * NB / kStepThreads; ++u) { const int e = tid + kStepThreads * u; dst[(e >> 6) * LD + (e & 63)] = v[u]; }
+}
+__device__ __forceinline__ void tile_pair_to_lds(const double *__restrict__ srcA, const double *__restrict__ srcB, int n, double *dstA, double *dstB, int tid) {
+    double va[NB * NB / kStepThreads], vb[NB * NB / kStepThreads];
+#pragma unroll
+    for (int u = 0; u < NB * NB / kStepThreads; ++u) { const int e = tid + kStepThreads * u; va[u] = srcA[(size_t)(e >> 6) * n + (e & 63)]; vb[u] = srcB[(size_t)(e >> 6) * n + (e & 63)]; }
+#pragma unroll
+    for (int u = 0; u < NB * NB / kStepThreads; ++u) { const int e = tid + kStepThreads * u; dstA[(e >> 6) * LD + (e & 63)] = va[u]; dstB[(e >> 6) * LD + (e & 63)] = vb[u]; }
+}
+
 // tile (0, 0)
-__global__ void __launch_bounds__(kStepThreads) k_chol_first(const double *stop, double *S, int n, const double *diag0, double *Linv) {
+__global__ void __launch_bounds__(kStepThreads) k_chol_first(const double *stop, double *S, int n, const double *diag0, double *Linv, long long *dbg = nullptr) {
     if (stop && *stop != 0.0) return;
     extern __shared__ double lds[];
     double *T = lds, *V = lds + NB * LD, *Wb = V + NB * LD, *d0s = Wb + 3 * 16 * kWbLd, *rinv_s = d0s + NB;
     const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += kStepThreads) T[(e >> 6) * LD + (e & 63)] = S[(size_t)(e >> 6) * n + (e & 63)];
+    tile_to_lds(S, n, T, tid);
     if (tid < NB) d0s[tid] = diag0[tid];
     __syncthreads();
-    potrf_inv(T, V, Wb, d0s, rinv_s, tid);
+    if (dbg && tid == 0) dbg[30] = (long long)__builtin_amdgcn_s_memtime();
+    potrf_inv(T, V, Wb, d0s, rinv_s, tid, dbg);
     diag_out(T, V, S, n, 0, Linv, tid);
+    if (dbg && tid == 0) dbg[31] = (long long)__builtin_amdgcn_s_memtime();
 }
 
 // The two wavefronts of a 16-row band of the tile share its four 16-column blocks as {0, 3} and {1, 2}: the triangular product
 // with Linv^T needs 4 (nb + 1) k-steps for column block nb, so both get 20.
-template <int NB0, int NB1>
-__device__ __forceinline__ void step_products(const double *Lk, double *bufA, double *bufB, bool diag, bool first, bool write_upper, double *S, int n, int k, int ti, int tj,
+template <int NB0, int NB1, bool diag>
+__device__ __forceinline__ void step_products(const double *__restrict__ Lk, double *bufA, double *bufB, bool first, bool write_upper, double *S, int n, int k, int ti, int tj,
                                               int tid, v4d c[2]) {
     const int w = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4, mb = w >> 1;
     constexpr int nbs[2] = {NB0, NB1};
@@ -207,8 +261,13 @@ __device__ __forceinline__ void step_products(const double *Lk, double *bufA, do
             if (!diag) bufB[(16 * mb + lq + 4 * r) * LD + 16 * nbs[t] + lm] = lj[t][r];
         }
     __syncthreads();
-    if (write_upper)           // L_ik^T into the upper triangle: element (c, m) of tile (k, ti)
-        for (int e = tid; e < NB * NB; e += kStepThreads) S[(size_t)(k * NB + (e >> 6)) * n + ti * NB + (e & 63)] = bufA[(e & 63) * LD + (e >> 6)];
+    if (write_upper) {         // L_ik^T into the upper triangle: element (c, m) of tile (k, ti)
+#pragma unroll
+        for (int u = 0; u < NB * NB / kStepThreads; ++u) {
+            const int e = tid + kStepThreads * u;
+            S[(size_t)(k * NB + (e >> 6)) * n + ti * NB + (e & 63)] = bufA[(e & 63) * LD + (e >> 6)];
+        }
+    }
     const double *bufY = diag ? bufA : bufB;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -240,10 +299,8 @@ __global__ void __launch_bounds__(kStepThreads) k_chol_step(const double *stop, 
     if (stop && *stop != 0.0) return;
     extern __shared__ double lds[];
     double *bufA = lds, *bufB = lds + NB * LD, *Wb = bufB + NB * LD, *d0s = Wb + 3 * 16 * kWbLd, *rinv_s = d0s + NB;
-    int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
-    while (bi * (bi + 1) / 2 > (int)blockIdx.x) --bi;
-    const int bj = blockIdx.x - bi * (bi + 1) / 2;
+    int bi, bj;
+    pair_of((int)blockIdx.x, bi, bj);
     const int ti = k + 1 + bi, tj = k + 1 + bj, tid = threadIdx.x;
     const bool diag = bi == bj, first = blockIdx.x == 0;
     const int w = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4, mb = w >> 1;
@@ -259,16 +316,18 @@ __global__ void __launch_bounds__(kStepThreads) k_chol_step(const double *stop, 
             c[t][r] = (!diag || col <= row) ? S[(size_t)(ti * NB + row) * n + tj * NB + col] : 0.0;
         }
     }
-    for (int e = tid; e < NB * NB; e += kStepThreads) {
-        const int r = e >> 6, cc = e & 63;
-        bufA[r * LD + cc] = S[(size_t)(ti * NB + r) * n + k * NB + cc];
-        if (!diag) bufB[r * LD + cc] = S[(size_t)(tj * NB + r) * n + k * NB + cc];
-    }
+    if (diag) tile_to_lds(S + (size_t)ti * NB * n + (size_t)k * NB, n, bufA, tid);
+    else tile_pair_to_lds(S + (size_t)ti * NB * n + (size_t)k * NB, S + (size_t)tj * NB * n + (size_t)k * NB, n, bufA, bufB, tid);
     if (first && tid < NB) d0s[tid] = diag0[(k + 1) * NB + tid];
     __syncthreads();
     const double *Lk = Linv + (size_t)k * NB * NB;
-    if (w & 1) step_products<1, 2>(Lk, bufA, bufB, diag, first, bj == 0, S, n, k, ti, tj, tid, c);
-    else step_products<0, 3>(Lk, bufA, bufB, diag, first, bj == 0, S, n, k, ti, tj, tid, c);
+    if (diag) {
+        if (w & 1) step_products<1, 2, true>(Lk, bufA, bufB, first, bj == 0, S, n, k, ti, tj, tid, c);
+        else step_products<0, 3, true>(Lk, bufA, bufB, first, bj == 0, S, n, k, ti, tj, tid, c);
+    } else {
+        if (w & 1) step_products<1, 2, false>(Lk, bufA, bufB, first, bj == 0, S, n, k, ti, tj, tid, c);
+        else step_products<0, 3, false>(Lk, bufA, bufB, first, bj == 0, S, n, k, ti, tj, tid, c);
+    }
     if (!first) return;
     __syncthreads();
     potrf_inv(bufA, bufB, Wb, d0s, rinv_s, tid);
@@ -279,13 +338,17 @@ __global__ void __launch_bounds__(kStepThreads) k_chol_step(const double *stop, 
 __global__ void __launch_bounds__(256) k_chol_mirror(const double *stop, double *S, int n) {
     if (stop && *stop != 0.0) return;
     __shared__ double Ts[NB * LD];
-    int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
-    while (bi * (bi + 1) / 2 > (int)blockIdx.x) --bi;
-    const int bj = blockIdx.x - bi * (bi + 1) / 2, i = bi + 1, j = bj;       // 0 <= j < i
-    for (int e = threadIdx.x; e < NB * NB; e += 256) Ts[(e >> 6) * LD + (e & 63)] = S[(size_t)(j * NB + (e >> 6)) * n + i * NB + (e & 63)];
+    int bi, bj;
+    pair_of((int)blockIdx.x, bi, bj);
+    const int i = bi + 1, j = bj;       // 0 <= j < i
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int e = threadIdx.x + 256 * u; v[u] = S[(size_t)(j * NB + (e >> 6)) * n + i * NB + (e & 63)]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int e = threadIdx.x + 256 * u; Ts[(e >> 6) * LD + (e & 63)] = v[u]; }
     __syncthreads();
-    for (int e = threadIdx.x; e < NB * NB; e += 256) S[(size_t)(i * NB + (e >> 6)) * n + j * NB + (e & 63)] = Ts[(e & 63) * LD + (e >> 6)];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int e = threadIdx.x + 256 * u; S[(size_t)(i * NB + (e >> 6)) * n + j * NB + (e & 63)] = Ts[(e & 63) * LD + (e >> 6)]; }
 }
 
 // ---- L z = r then L^T x = z, in place in r: one workgroup per row tile -------------------------------------------------------------
@@ -327,6 +390,10 @@ __global__ void __launch_bounds__(256) k_trsv(double *stop, const double *gate, 
         if (t < NB) { const double sum = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]); acc[t] = subtract ? acc[t] - sum : sum; }
         __syncthreads();
     };
+    // the diagonal tile's inverse in both orientations, fetched now: nothing but the polled value is waited for on the critical path
+    double vf[16], vb[16];
+    tile_load(inv, 1, (size_t)NB, vf);                                              // Linv[a][k]
+    tile_load(inv, (size_t)NB, 1, vb);                                              // Linv^T[a][k] = Linv[k][a]
     if (t < NB) acc[t] = r[(size_t)i * NB + t];
     __syncthreads();
     for (int j = 0; j < i; ++j) {
@@ -336,11 +403,9 @@ __global__ void __launch_bounds__(256) k_trsv(double *stop, const double *gate, 
         tile_apply(v, true);
     }
     {
-        double v[16];
-        tile_load(inv, 1, (size_t)NB, v);                                           // Linv[a][k]
         if (t < NB) xj[t] = acc[t];
         __syncthreads();
-        tile_apply(v, false);
+        tile_apply(vf, false);
         if (t < NB) __hip_atomic_store(xz + (size_t)i * NB + t, acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int j = nt - 1; j > i; --j) {
@@ -350,11 +415,9 @@ __global__ void __launch_bounds__(256) k_trsv(double *stop, const double *gate, 
         tile_apply(v, true);
     }
     {
-        double v[16];
-        tile_load(inv, (size_t)NB, 1, v);                                           // Linv^T[a][k] = Linv[k][a]
         if (t < NB) xj[t] = acc[t];
         __syncthreads();
-        tile_apply(v, false);
+        tile_apply(vb, false);
         if (t < NB) {
             __hip_atomic_store(xz + (size_t)n + (size_t)i * NB + t, acc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             r[(size_t)i * NB + t] = acc[t];
@@ -380,7 +443,7 @@ void chol_enqueue(void *stream, const double *stop, double *S, int n, const doub
     set_attrs();
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nt = n / NB;
-    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(kStepThreads), kStepLds, st, stop, S, n, diag0, Linv);
+    hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(kStepThreads), kStepLds, st, stop, S, n, diag0, Linv, (long long *)nullptr);
     for (int k = 0; k + 1 < nt; ++k) {
         const int nrem = nt - k - 1;
         hipLaunchKernelGGL(k_chol_step, dim3(nrem * (nrem + 1) / 2), dim3(kStepThreads), kStepLds, st, stop, S, n, k, diag0, Linv);
@@ -430,6 +493,20 @@ extern "C" int kao_dense_spd_test(const double *A, int32_t n, const double *rhs,
         SPD_TRY(hipEventRecord(ev[2], st));
         SPD_TRY(hipStreamSynchronize(st));
         SPD_TRY(hipGetLastError());
+    }
+    if (std::getenv("KAO_CHOL_DEBUG")) {     // clock ticks (s_memtime) of the diagonal tile's phases, to stderr
+        long long *dbgd = nullptr, hd[32] = {0};
+        SPD_TRY(hipMalloc(&dbgd, sizeof hd));
+        SPD_TRY(hipMemset(dbgd, 0, sizeof hd));
+        SPD_TRY(hipMemcpyAsync(dS, dA, nn * 8, hipMemcpyDeviceToDevice, st));
+        set_attrs();
+        hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(kStepThreads), kStepLds, st, (const double *)nullptr, dS, n, dd, dL, dbgd);
+        SPD_TRY(hipStreamSynchronize(st));
+        SPD_TRY(hipMemcpy(hd, dbgd, sizeof hd, hipMemcpyDeviceToHost));
+        (void)hipFree(dbgd);
+        std::fprintf(stderr, "[kao-chol] diagonal tile, ticks since entry (s_memtime, 100 MHz):");
+        for (int q = 0; q < 30 && (q == 0 || hd[q]); ++q) std::fprintf(stderr, " %lld", hd[q] - hd[30]);
+        std::fprintf(stderr, " | whole kernel body %lld\n", hd[31] - hd[30]);
     }
     float m0 = 0, m1 = 0;
     SPD_TRY(hipEventElapsedTime(&m0, ev[0], ev[1])); SPD_TRY(hipEventElapsedTime(&m1, ev[1], ev[2]));

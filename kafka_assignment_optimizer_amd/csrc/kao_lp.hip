@@ -297,6 +297,9 @@ __global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double 
     for (int r = 0; r < R; ++r) {
         const double d = fr[((size_t)0 * R + r) * P + p], e1 = fr[((size_t)1 * R + r) * P + p], e2 = fr[((size_t)2 * R + r) * P + p];
         m11 -= e1 * e1 / d; m12 -= e1 * e2 / d; m22 -= e2 * e2 / d;
+        // 1 / d, e1 / d, e2 / d for the eliminations and back substitutions of the iteration's solves (two to four of each: no division there)
+        const double id = 1.0 / d;
+        fr[((size_t)3 * R + r) * P + p] = id; fr[((size_t)4 * R + r) * P + p] = e1 * id; fr[((size_t)5 * R + r) * P + p] = e2 * id;
     }
     double i11, i12, i22;   // guarded pivots: C1 is a dependent row when the C7 rows carry no slack (oracle/kao_lp_port.c)
     if (!(m11 > kLpPivotRel * o11)) { i11 = 0; i12 = 0; i22 = m22 > kLpPivotRel * o22 ? 1.0 / m22 : 0.0; }
@@ -619,11 +622,16 @@ __global__ void k_lp_schur_rack_sum2(LpDev D, const double *part, int nblk, cons
     const int idx = (k * 4 + (row >> 2)) * 64 + (row & 3) * 16 + col;      // accumulator layout: row = (lane >> 4) + 4 reg, col = lane & 15
     const bool same = a % D.R == c % D.R;
     double s = 0.0;
-    for (int i = 0; i < nblk; ++i) {
-        const double *rec = part + (size_t)i * NE;
-        double v = rec[idx];
-        if (same) { v += rec[NP * 256 + idx]; if (a == c) v += rec[2 * NP * 256 + a]; }
-        s += v;
+    for (int i0 = 0; i0 < nblk; i0 += 8) {      // eight records' loads in flight, added in record order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double *rec = part + (size_t)min(i0 + u, nblk - 1) * NE;
+            v[u] = rec[idx];
+            if (same) { v[u] += rec[NP * 256 + idx]; if (a == c) v[u] += rec[2 * NP * 256 + a]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i0 + u < nblk) s += v[u];
     }
     if (a == c) {   // the racks' own inflow variables: NF[r] += sum zf, NL[r] += sum zl over the rack's brokers (in order)
         const int r = a % D.R;
@@ -907,7 +915,7 @@ __global__ void __launch_bounds__(256) k_lp_trsv_mw(const double *sc, const doub
 
 // ---- rows of A z ------------------------------------------------------------------------------------------------------
 // local rows; mode 0: out = A z, 1: out = b - A z, 2: out = A z + add
-__global__ void k_lp_A_local(LpDev D, const double *z, RowVec out, int mode, RowVec add, int gated) {
+__global__ void k_lp_A_local(LpDev D, const double *__restrict__ z, RowVec out, int mode, RowVec add, int gated) {
     if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
@@ -980,16 +988,21 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_A_rack_part(LpDev D, const dou
     for (int o = kRedBlock / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
-__global__ void k_lp_A_rack_fin(LpDev D, const double *part, const double *zg, double *rc, int mode, const double *addc, int gated) {
+__global__ void __launch_bounds__(64) k_lp_A_rack_fin(LpDev D, const double *part, const double *zg, double *rc, int mode, const double *addc, int gated) {
     if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
-    const int R = D.R, row = blockIdx.x * blockDim.x + threadIdx.x;     // 0..R-1 NF, R..2R-1 NL, 2R..3R-1 C6
-    if (row >= 3 * R) return;
+    // one wavefront per row (0..R-1 NF, R..2R-1 NL, 2R..3R-1 C6): the lanes share the slices and the rack's brokers, fixed butterfly
+    const int R = D.R, row = blockIdx.x, lane = threadIdx.x;
     const int r = row % R, kind = row / R;
     double s = 0.0;
     if (kind < 2) {
-        for (int k = 0; k < kRackChunks; ++k) s += part[row * kRackChunks + k];
-        for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s -= zg[(kind == 0 ? 0 : D.B) + D.rk_mem[e]];
-    } else if (D.has_n) { for (int e = D.rk_off[r]; e < D.rk_off[r + 1]; ++e) s += zg[2 * D.B + D.rk_mem[e]]; if (D.has_k) s -= zg[4 * D.B + r]; }
+        if (lane < kRackChunks) s = part[row * kRackChunks + lane];
+        for (int e = D.rk_off[r] + lane; e < D.rk_off[r + 1]; e += 64) s -= zg[(kind == 0 ? 0 : D.B) + D.rk_mem[e]];
+    } else if (D.has_n) {
+        for (int e = D.rk_off[r] + lane; e < D.rk_off[r + 1]; e += 64) s += zg[2 * D.B + D.rk_mem[e]];
+        if (D.has_k && lane == 0) s -= zg[4 * D.B + r];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane) return;
     double out = mode == 1 ? D.bc[row] - s : (mode == 2 ? s + addc[row] : s);
     if (D.rowc[row] != 1) out = 0.0;      // absent / pinned rows carry no residual and no right-hand side
     rc[row] = out;
@@ -997,74 +1010,98 @@ __global__ void k_lp_A_rack_fin(LpDev D, const double *part, const double *zg, d
 
 // ---- the normal equations' local eliminations (oracle/kao_lp_port.c::lp_solve_normal, first loop): local right-hand sides in
 // place, the terms they send to the coupling rows into cb [2 NJ][P] (C3 / C4 of replica j) and cr [2 R][P] (NF / NL of rack r)
-__global__ void k_lp_elim_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v, double *cb, double *cr, int gated) {
+__global__ void k_lp_elim_local(LpDev D, const double *__restrict__ th, const double *__restrict__ fj, const double *__restrict__ fr, const double *__restrict__ ti, RowVec v,
+                                double *__restrict__ cb, double *__restrict__ cr, int gated) {
     if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
     const int P = D.P, R = D.R, NJ = D.NJ;
+    const double *__restrict__ ID = fr + (size_t)3 * R * P, *__restrict__ F1 = fr + (size_t)4 * R * P, *__restrict__ F2 = fr + (size_t)5 * R * P, *__restrict__ E1 = fr + (size_t)1 * R * P, *__restrict__ E2 = fr + (size_t)2 * R * P;
     double r1 = v.r1[p], r2 = v.r2[p];
-    for (int j = 0; j < NJ; ++j) { cb[(size_t)(2 * j) * P + p] = 0.0; cb[(size_t)(2 * j + 1) * P + p] = 0.0; }
     if (D.has_c5)
         for (int j = 0; j < NJ; ++j) {
             const int b = cur_b(D, p, j);
-            if (b < 0) continue;
-            const double g5 = v.r5[(size_t)j * P + p] / fj[((size_t)3 * NJ + j) * P + p];
-            const double k1 = fj[((size_t)4 * NJ + j) * P + p], k2 = fj[((size_t)5 * NJ + j) * P + p];
-            r1 -= k1 * g5; v.r7[(size_t)D.rack[b] * P + p] -= k1 * g5; cb[(size_t)(2 * j) * P + p] -= k1 * g5;
-            r2 -= k2 * g5; cb[(size_t)(2 * j + 1) * P + p] -= k2 * g5;
+            double c3 = 0.0, c4 = 0.0;
+            if (b >= 0) {
+                const double g5 = v.r5[(size_t)j * P + p] / fj[((size_t)3 * NJ + j) * P + p];
+                const double k1 = fj[((size_t)4 * NJ + j) * P + p], k2 = fj[((size_t)5 * NJ + j) * P + p];
+                r1 -= k1 * g5; v.r7[(size_t)D.rack[b] * P + p] -= k1 * g5; c3 = -k1 * g5;
+                r2 -= k2 * g5; c4 = -k2 * g5;
+            }
+            cb[(size_t)(2 * j) * P + p] = c3; cb[(size_t)(2 * j + 1) * P + p] = c4;
         }
+    // (round 6) With q_r = r7_r / d_r - (e1_r g1 + e2_r g2) / d_r the terms a partition sends to the coupling rows are
+    //   NF[r]: -cyf (q_r + g1)    NL[r]: -cyl (q_r + g1 + g2)    C3_j: -sig11 (q_rk + g1) - sig12 g2    C4_j: -sig12 (q_rk + g1) - sig22 g2
+    // (rk the rack of replica j's broker) -- the same sums as lp_col's columns give, regrouped: two passes over the racks with
+    // independent loads, no division, no read-modify-write of cb / cr.
+#pragma unroll 4
     for (int r = 0; r < R; ++r) {
-        const double d = fr[((size_t)0 * R + r) * P + p], e1 = fr[((size_t)1 * R + r) * P + p], e2 = fr[((size_t)2 * R + r) * P + p];
-        const double g7 = v.r7[(size_t)r * P + p] / d;
-        r1 -= e1 * g7; r2 -= e2 * g7;
-        cr[(size_t)(2 * r) * P + p] = -th[(size_t)VYF(D, r) * P + p] * g7;
-        cr[(size_t)(2 * r + 1) * P + p] = -th[(size_t)VYL(D, r) * P + p] * g7;
+        const double g7 = v.r7[(size_t)r * P + p] * ID[(size_t)r * P + p];
+        r1 -= E1[(size_t)r * P + p] * g7; r2 -= E2[(size_t)r * P + p] * g7;
+    }
+    const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
+    const double g1 = i11 * r1 + i12 * r2, g2 = i12 * r1 + i22 * r2;
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) {
+        const size_t k = (size_t)r * P + p;
+        const double q = v.r7[k] * ID[k] - (F1[k] * g1 + F2[k] * g2);
+        cr[(size_t)(2 * r) * P + p] = -th[(size_t)VYF(D, r) * P + p] * (q + g1);
+        cr[(size_t)(2 * r + 1) * P + p] = -th[(size_t)VYL(D, r) * P + p] * (q + g1 + g2);
+    }
+    for (int j = 0; j < NJ; ++j) {
+        const int b = cur_b(D, p, j);
+        double c3 = 0.0, c4 = 0.0;
+        if (b >= 0) {
+            const size_t k = (size_t)D.rack[b] * P + p;
+            const double q = v.r7[k] * ID[k] - (F1[k] * g1 + F2[k] * g2);
+            const double s11 = fj[((size_t)0 * NJ + j) * P + p], s12 = fj[((size_t)1 * NJ + j) * P + p], s22 = fj[((size_t)2 * NJ + j) * P + p];
+            c3 = -s11 * (q + g1) - s12 * g2; c4 = -s12 * (q + g1) - s22 * g2;
+            if (D.has_c5) { c3 += cb[(size_t)(2 * j) * P + p]; c4 += cb[(size_t)(2 * j + 1) * P + p]; }
+        }
+        cb[(size_t)(2 * j) * P + p] = c3; cb[(size_t)(2 * j + 1) * P + p] = c4;
+    }
+    v.r1[p] = r1; v.r2[p] = r2;
+}
+// back substitution (second loop): dy of the local rows in place, given dy of the coupling rows
+__global__ void k_lp_back_local(LpDev D, const double *__restrict__ th, const double *__restrict__ fj, const double *__restrict__ fr, const double *__restrict__ ti, RowVec v, int gated) {
+    if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.P) return;
+    const int P = D.P, R = D.R, NJ = D.NJ;
+    const double *__restrict__ ID = fr + (size_t)3 * R * P, *__restrict__ F1 = fr + (size_t)4 * R * P, *__restrict__ F2 = fr + (size_t)5 * R * P;
+    // (round 6) E = sum of eps_c y_c over a rack's columns (NF, NL: cyf y_NF + cyl y_NL; a replica's C3 / C4: sig11 y3 + sig12 y4):
+    //   t1 = r1 - sum E (1 - e1 / d),   t2 = r2 - sum (m2 . y) + sum E e2 / d,   dy7_r = (r7_r - E_r) / d_r - (e1_r d1 + e2_r d2) / d_r
+    // -- lp_col's columns regrouped by rack: independent loads, no division.
+    double t1 = v.r1[p], t2 = v.r2[p];
+#pragma unroll 4
+    for (int r = 0; r < R; ++r) {
+        const size_t k = (size_t)r * P + p;
+        const double yl = th[(size_t)VYL(D, r) * P + p] * v.rc[RNL(D, r)], E = th[(size_t)VYF(D, r) * P + p] * v.rc[RNF(D, r)] + yl;
+        t1 -= E - F1[k] * E; t2 -= yl - F2[k] * E;
     }
     for (int j = 0; j < NJ; ++j) {
         const int b = cur_b(D, p, j);
         if (b < 0) continue;
-        const int r = D.rack[b];
-        const double g7 = v.r7[(size_t)r * P + p] / fr[((size_t)0 * R + r) * P + p];
-        cb[(size_t)(2 * j) * P + p] -= fj[((size_t)0 * NJ + j) * P + p] * g7;        // eps of C3_j = sig11
-        cb[(size_t)(2 * j + 1) * P + p] -= fj[((size_t)1 * NJ + j) * P + p] * g7;    // eps of C4_j = sig12
-    }
-    const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
-    const double g1 = i11 * r1 + i12 * r2, g2 = i12 * r1 + i22 * r2;
-    v.r1[p] = r1; v.r2[p] = r2;
-    const int nc = 2 * NJ + 2 * R;
-    for (int c = 0; c < nc; ++c) {
-        PCol q;
-        if (!lp_col(D, th, fj, fr, p, c, q)) continue;
-        const double tv = q.v0 * g1 + q.v1 * g2;
-        if (c < 2 * NJ) cb[(size_t)c * P + p] -= tv; else cr[(size_t)(c - 2 * NJ) * P + p] -= tv;
-    }
-}
-// back substitution (second loop): dy of the local rows in place, given dy of the coupling rows
-__global__ void k_lp_back_local(LpDev D, const double *th, const double *fj, const double *fr, const double *ti, RowVec v, int gated) {
-    if (LP_STOPPED(D) || LP_GATED_OFF(D, gated)) return;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= D.P) return;
-    const int P = D.P, R = D.R, NJ = D.NJ, nc = 2 * NJ + 2 * R;
-    double t1 = v.r1[p], t2 = v.r2[p];
-    for (int c = 0; c < nc; ++c) {
-        PCol q;
-        if (!lp_col(D, th, fj, fr, p, c, q)) continue;
-        const double y = v.rc[q.col];
-        t1 -= q.v0 * y; t2 -= q.v1 * y;
+        const size_t k = (size_t)D.rack[b] * P + p;
+        const double s11 = fj[((size_t)0 * NJ + j) * P + p], s12 = fj[((size_t)1 * NJ + j) * P + p], s22 = fj[((size_t)2 * NJ + j) * P + p];
+        const double y3 = v.rc[RC3(D, b)], y4 = v.rc[RC4(D, b)], E = s11 * y3 + s12 * y4;
+        t1 -= E - F1[k] * E; t2 -= (s12 * y3 + s22 * y4) - F2[k] * E;
     }
     const double i11 = ti[(size_t)0 * P + p], i12 = ti[(size_t)1 * P + p], i22 = ti[(size_t)2 * P + p];
     const double d1 = i11 * t1 + i12 * t2, d2 = i12 * t1 + i22 * t2;
     v.r1[p] = d1; v.r2[p] = d2;
+#pragma unroll 4
     for (int r = 0; r < R; ++r) {
-        const double e1 = fr[((size_t)1 * R + r) * P + p], e2 = fr[((size_t)2 * R + r) * P + p];
-        v.r7[(size_t)r * P + p] -= e1 * d1 + e2 * d2 + th[(size_t)VYF(D, r) * P + p] * v.rc[RNF(D, r)] + th[(size_t)VYL(D, r) * P + p] * v.rc[RNL(D, r)];
+        const size_t k = (size_t)r * P + p;
+        const double E = th[(size_t)VYF(D, r) * P + p] * v.rc[RNF(D, r)] + th[(size_t)VYL(D, r) * P + p] * v.rc[RNL(D, r)];
+        v.r7[k] = (v.r7[k] - E) * ID[k] - (F1[k] * d1 + F2[k] * d2);
     }
     for (int j = 0; j < NJ; ++j) {
         const int b = cur_b(D, p, j);
         if (b < 0) continue;
-        v.r7[(size_t)D.rack[b] * P + p] -= fj[((size_t)0 * NJ + j) * P + p] * v.rc[RC3(D, b)] + fj[((size_t)1 * NJ + j) * P + p] * v.rc[RC4(D, b)];
+        const size_t k = (size_t)D.rack[b] * P + p;
+        v.r7[k] -= (fj[((size_t)0 * NJ + j) * P + p] * v.rc[RC3(D, b)] + fj[((size_t)1 * NJ + j) * P + p] * v.rc[RC4(D, b)]) * ID[k];
     }
-    for (int r = 0; r < R; ++r) v.r7[(size_t)r * P + p] /= fr[((size_t)0 * R + r) * P + p];
     for (int j = 0; j < NJ; ++j) {
         const int b = cur_b(D, p, j);
         if (!D.has_c5 || b < 0) { v.r5[(size_t)j * P + p] = 0.0; continue; }
@@ -1443,7 +1480,7 @@ void lp_rows_coupling(LpCtx &c, const VarVec &z, double *out_rc, int mode, const
     const LpDev &D = c.D;
     hipLaunchKernelGGL(k_lp_A_broker, dim3((D.B + 3) / 4), dim3(256), 0, c.st, D, z.z, z.zg, cb, out_rc, mode, add_rc, gated);
     hipLaunchKernelGGL(k_lp_A_rack_part, dim3(2 * D.R * kRackChunks), dim3(kRedBlock), 0, c.st, D, z.z, cr, c.rack_part, gated);
-    hipLaunchKernelGGL(k_lp_A_rack_fin, dim3((3 * D.R + 63) / 64), dim3(64), 0, c.st, D, c.rack_part, z.zg, out_rc, mode, add_rc, gated);
+    hipLaunchKernelGGL(k_lp_A_rack_fin, dim3(3 * D.R), dim3(64), 0, c.st, D, c.rack_part, z.zg, out_rc, mode, add_rc, gated);
 }
 
 void lp_factor(LpCtx &c) {
@@ -1611,7 +1648,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     c->rack_chunk = std::max(c->rack_tile, ((P + 255) / 256 + c->rack_tile - 1) / c->rack_tile * c->rack_tile);   // about 256 blocks
     c->rack_blocks = (P + c->rack_chunk - 1) / c->rack_chunk;
     c->trace_cap = 512;
-    if ((rc = c->alloc(&c->fj, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->fr, (size_t)3 * R * P)) || (rc = c->alloc(&c->ti, (size_t)3 * P)) ||
+    if ((rc = c->alloc(&c->fj, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->fr, (size_t)6 * R * P)) || (rc = c->alloc(&c->ti, (size_t)3 * P)) ||
         (rc = c->alloc(&c->S, (size_t)D.mcp * D.mcp)) || (rc = c->alloc(&c->Linv, (size_t)D.mcp * kNB)) || (rc = c->alloc(&c->diag0, (size_t)D.mcp)) || (rc = c->alloc(&c->cb, (size_t)2 * NJ * P)) ||
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||

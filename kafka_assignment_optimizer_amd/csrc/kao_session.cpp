@@ -1313,7 +1313,9 @@ int kao_lp_trace(const kao_topic *t, double tol, int32_t max_iters, double *trac
     if (rc) return rc;
     LpCtx *lp = nullptr;
     if ((rc = lp_open(t, &lp))) return rc;
-    rc = lp_solve(lp, tol > 0 ? tol : 1e-7, max_iters > 0 ? max_iters : 80, multipliers, stats, trace);
+    double pert = 0.0;       // experiment hook KAO_LP_TRACE_PERT=<eps> (-1: the solve's own default): the trace of the PERTURBED solve
+    if (const char *e = std::getenv("KAO_LP_TRACE_PERT")) { pert = std::atof(e); if (pert < 0) pert = std::min(1e-4, 1.5 / ((double)t->n_partitions * t->rf)); }
+    rc = lp_solve(lp, tol > 0 ? tol : 1e-7, max_iters > 0 ? max_iters : 80, multipliers, stats, trace, pert, 0);
     lp_close(lp);
     return rc;
 }

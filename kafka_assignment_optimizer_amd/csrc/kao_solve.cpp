@@ -173,9 +173,9 @@ struct SolveRun {
     // vertex, which rounds to an assignment (lp_round_assignment).  One solve gives the certificate and, nearly always, the optimum.
     bool lp_round_on = true;      // KAO_LP_ROUND=0: certificate only (the unperturbed LP, as in the first half of round 5)
     double lp_pert_env = -1.0;    // KAO_LP_PERT=<eps>: the perturbation (default min(1e-4, 1.5 / slots))
-    double lp_first_s = 1.3;      // huge topics: with at least this much time the LP runs straight after the first feasible incumbent,
+    double lp_first_s = 0.0;      // (KAO_LP_FIRST_S=<s>: fixed rule) huge topics: when the LP fits behind the ~0.2 s to the first feasible incumbent it runs straight after it,
     double lp_solo_s = 1.0; int64_t lp_solo_slots = 32768;
-    double lp_alone_s = 1.5;      // with this much before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
+    double lp_alone_s = 0.0;      // (KAO_LP_ALONE_S=<s>: fixed rule) when the LP's predicted time fits the limit it runs before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
     int lp_rounded = 0, lp_round_adopted = 0, lp_round_fractional = 0;
     int lp_round_max_free = 512;  // fractional partitions completed without the incumbent's rows (about 0.1 ms each: 100,000 of a mid-way iterate took 8 s)
     std::vector<char> lp_try, lp_certified;   // per topic: LP solves finished; the LP's certificate is in place (K-bound leaves the topic alone)
@@ -201,7 +201,27 @@ struct SolveRun {
         for (int j = 0; j < n; ++j) if (j != i && !topic_done(j)) return false;
         return true;
     }
-    bool lp_alone(int i) const { return lp_round_on && ((huge(i) && deadline - t0 >= lp_alone_s) || (solo(i) && deadline - t0 >= lp_solo_s && only_open(i))); }
+    // Predicted seconds of ONE perturbed interior-point solve of topic i alone on the device, from counts (the choice of
+    // algorithm was keyed on fixed limits, 1.5 / 1.3 s, so a 1-second caller never got the LP).  An iteration costs lp_ms_base +
+    // lp_ms_tile per 64-row tile of the Schur complement (3R + 2B rows: the Cholesky and the triangular solves walk the tiles one after
+    // the other) + lp_ms_kpart per 1,000 partitions (everything else streams the partitions); the perturbed solve takes ~105-150
+    // iterations at tolerance 1e-10 on drifted topics of 30,000-200,000 partitions (lp_iters_est), plus lp_s_fixed for the context, the
+    // starting point, the read-back and the rounding.  Constants measured on one MI355X (round 6, profiles/r06_*); a limit is an input,
+    // not the clock: the schedule stays count-keyed.
+    double lp_ms_base = 0.55, lp_ms_tile = 0.055, lp_ms_kpart = 0.022, lp_iters_est = 125.0, lp_s_fixed = 0.12, lp_fit = 0.8;
+    double lp_reserve_s = 0.2;    // an LP that runs before there is any incumbent is given up this long before the deadline: K-search needs ~0.16 s to a first feasible plan at 100,000 partitions
+    double lp_wait_until(int i) const { return feasible(i) ? deadline : deadline - lp_reserve_s; }
+    double lp_est_s(int i) const {
+        const kao_topic &t = topics[i];
+        const int nt = (3 * t.n_racks + 2 * t.n_brokers + 63) / 64;
+        return lp_s_fixed + 1e-3 * lp_iters_est * (lp_ms_base + lp_ms_tile * nt + lp_ms_kpart * t.n_partitions / 1000.0);
+    }
+    bool lp_fits(int i, double extra_s = 0.0) const { return lp_est_s(i) + extra_s <= lp_fit * (deadline - t0); }
+    bool lp_alone(int i) const {
+        if (!lp_round_on) return false;
+        const bool huge_ok = lp_alone_s > 0 ? deadline - t0 >= lp_alone_s : lp_fits(i);      // (KAO_LP_ALONE_S=<s>: the fixed rule, for experiments)
+        return (huge(i) && huge_ok) || (solo(i) && deadline - t0 >= lp_solo_s && only_open(i));
+    }
     // a huge topic between its first feasible incumbent and the end of its LP -- from the start when the limit leaves room for the LP alone
     bool pause_wanted(int i) const { return lp_possible(i) && ((huge(i) && (feasible(i) || (lp_huge_first && launches >= 1))) || lp_alone(i)); }
     bool search_paused() const {
@@ -379,7 +399,7 @@ struct SolveRun {
                 if (!st) lp_abort(lp_ctx[(size_t)i]);
             } else if (lp_read[(size_t)i] < lp_marks[(size_t)i] && lp_marks[(size_t)i] - lp_read[(size_t)i] > (lp_all[(size_t)i] ? 0 : lp_lag)) {
                 const double tp0 = now_s();
-                if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it, lp_all[(size_t)i] ? deadline : 0.0))) return rc;   // (a huge topic's LP is waited for: the wait ends at the deadline)
+                if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it, lp_all[(size_t)i] ? lp_wait_until(i) : 0.0))) return rc;   // (a huge topic's LP is waited for: the wait ends at the deadline)
                 if (st == 4) {   // aborted at the deadline: no certificate, no rounding of a mid-way iterate; the main loop ends on the clock
                     lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; lp_state[(size_t)i] = 3; --running;
                     continue;
@@ -434,7 +454,7 @@ struct SolveRun {
                     // limit leaves room for it (a limit is an input, not the clock), straight after the first feasible incumbent: its
                     // primal side makes the fixpoint unnecessary
                     const bool cx_can = cx_on && cycle_supported(&topics[i]);
-                    const bool lp_now = lp_round_on && deadline - t0 >= lp_first_s;
+                    const bool lp_now = lp_round_on && (lp_first_s > 0 ? deadline - t0 >= lp_first_s : lp_fits(i, 0.2));
                     if (!lp_alone(i) && (!feasible(i) || (!lp_now && cx_can && (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20)))) continue;
                 }
                 const int64_t slots = (int64_t)topics[i].n_partitions * topics[i].rf;
