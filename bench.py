@@ -32,6 +32,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+ROUND_TAG = "r06"        # counter constants are taken from profiles/ of THIS round only: the kernels change between rounds
+F64_PEAK_TFLOPS = 78.6   # MI355X f64 (vector = matrix) datasheet peak; the microarch guide has no f64 row
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 LDS_PEAK_GBS = 256 * 128 * 2.4   # 128 B/clk/CU x 256 CUs x 2.4 GHz = 78.6 TB/s for ds_read_b128-class accesses (guide, LDS table)
 
@@ -209,7 +211,7 @@ def load_big_constants(which, restarts):
     the latest profile taken with THIS restart count (traffic per launch scales with it), else None (-> traffic: null)."""
     import glob
     c = path = None
-    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_big_%s_constants.json" % which)), reverse=True):   # the latest tag first
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", ROUND_TAG + "*_big_%s_constants.json" % which)), reverse=True):   # this round's, the latest tag first
         try:
             with open(cand) as f:
                 cc = json.load(f)
@@ -225,6 +227,22 @@ def load_big_constants(which, restarts):
         if isinstance(v, dict) and "hbm_bytes" in v:
             out["k_search" if k.startswith("k_search") else ("k_eval" if k.startswith("k_eval") else k)] = v
     return out
+
+
+def load_lp_constants(workload):
+    """Per-iteration counter figures of KAO-LP (tools/profile_lp_pmc.sh -> profiles/<round tag>*_lp_pmc_constants.json), this round's
+    latest for the workload, else None (-> traffic: null)."""
+    import glob
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", ROUND_TAG + "*_lp_pmc_constants.json")), reverse=True):
+        try:
+            with open(cand) as f:
+                c = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if c.get("workload") == workload:
+            c["file"] = "profiles/" + os.path.basename(cand)
+            return c
+    return None
 
 
 def write_cli_inputs(topics, path_prefix):
@@ -564,6 +582,41 @@ def main():
                                          "equals the certificate it IS an optimum of the model, found without a search",
                                  "reference": "HiGHS on the full model needed 2,876 s (450 x 3500, LP 26330) and 10,008 s (500 x 5000, LP 37558): tests/golden/drift_scale.json"}
 
+    # ---- the north-star solve under the north-star's own budget, and the roofline of what decides it: a KAO-LP iteration ----
+    if not args.no_extras and rank == 0:
+        tp = synthetic.north_star_topic("drift100k")
+        kao.solve([tp], seed=1, max_launches=1)               # arenas / code objects
+        t0 = time.perf_counter()
+        r = kao.solve([tp], seed=3, stop_at_bound=1, time_limit_s=1.0)[0]
+        wall = time.perf_counter() - t0
+        tm = kao.last_solve_timing(); lpi = kao.last_solve_lp()
+        out["north_star"] = {"workload": "drift100k: 1000 brokers x 100,000 partitions RF 3, 20 % drift, one topic", "time_limit_s": 1.0,
+                             "seconds": tm["results_read_back"], "python_wall_s": wall, "status": str(r.status), "objective": int(r.objective),
+                             "certificate": int(r.upper_bound), "kao_lp_iterations": int(lpi["iterations"]), "kao_lp_solves": int(lpi["solves"]),
+                             "fractional_partitions": int(lpi["fractional_partitions"]), "k_search_launches": int(tm["launches"]), "kao_cx_calls": int(tm["cx_calls"])}
+        t0 = time.perf_counter()
+        r3 = kao.solve([tp], seed=3, stop_at_bound=1, time_limit_s=3.0)[0]
+        out["north_star"]["seconds_unlimited"] = kao.last_solve_timing()["results_read_back"]
+        out["north_star"]["status_unlimited"] = str(r3.status)
+        kao.lp_trace(tp, max_iters=1)
+        b = kao.lp_bound(tp)
+        ms_it = b["ms"] / max(1, b["iterations"])
+        lc = load_lp_constants("drift100k")
+        rl = {"kernel": "KAO-LP iteration (k_lp_*, k_chol_*, k_trsv)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "ms_per_iteration": ms_it,
+              "iterations": b["iterations"], "achieved": None, "frac": None, "traffic": None, "hbm_frac": None, "f64_frac": None,
+              "note": "one interior-point iteration of the certificate's LP at 100,000 partitions, HIP-event time of the whole solve / iterations (captured graph); "
+                      "bytes and counted f64 flops per iteration from this round's rocprofv3 passes (plain launches)"}
+        if lc:
+            rl.update(traffic=lc["hbm_bytes_per_iteration"], hbm_bytes_per_iteration=lc["hbm_bytes_per_iteration"],
+                      f64_flops_per_iteration=lc["f64_flops_per_iteration_counted"], traffic_source=lc["file"],
+                      kernel_ms_per_iteration_in_the_profile=lc["kernel_ms_per_iteration"])
+            rl["achieved"] = lc["hbm_bytes_per_iteration"] / (ms_it * 1e-3) / 1e9
+            rl["frac"] = rl["hbm_frac"] = rl["achieved"] / HBM_PEAK_GBS
+            rl["f64_frac"] = lc["f64_flops_per_iteration_counted"] / (ms_it * 1e-3) / 1e12 / F64_PEAK_TFLOPS
+            ks = lc.get("kernels_ms_per_iteration", {})
+            rl["chol_ms_per_iteration"] = sum(v for k, v in ks.items() if k.startswith("k_chol"))
+        out["roofline_lp"] = rl
+
     # ---- the north-star regime (BASELINE config 5): one LARGE topic, assignment words in HBM/L2 -- the kernel variants that
     #      run there (k_search<true, ...>, the cooperative k_eval) against the HBM peak; traffic from profiles/ (rocprofv3 --pmc) ----
     if not args.no_extras and rank == 0:
@@ -600,7 +653,7 @@ def main():
                                                  "algorithmic_gbps": pf["search_bytes_algo"] / (pf["ms_search"] * 1e-3) / 1e9,
                                                  "algorithmic_frac_of_hbm_peak": pf["search_bytes_algo"] / (pf["ms_search"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                  "note": "HIP-event time of every K-search launch of the 3-s kao_solve below (kao_opts.profile, kao_last_solve_profile): the "
-                                                         "solve keeps one restart per compute unit on topics that live in HBM and launches K-search beside K-bound / KAO-LP, so "
+                                                         "solve keeps two restarts per compute unit on topics that live in HBM and launches K-search beside K-bound / KAO-LP, so "
                                                          "this -- not the session figure above (4 restarts per compute unit, nothing beside it) -- is what the product's solve "
                                                          "path runs.  Beyond 131,072 slots K-search is not launched at all between the first feasible incumbent and the end of the LP"}
                 e["solve_3s"] = {"status": str(r.status), "objective": int(r.objective), "certificate": int(r.upper_bound),

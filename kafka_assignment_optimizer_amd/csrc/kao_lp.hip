@@ -609,30 +609,37 @@ __global__ void __launch_bounds__(256) k_lp_schur_rack_mfma(LpDev D, const doubl
     }
     for (int e = threadIdx.x; e < NE; e += 256) part[(size_t)blockIdx.x * NE + e] = comb[e];
 }
+// 16 entries x 16 slices of the partial records per workgroup: a thread adds its slice in record order, the slices are added in order
+// through LDS (one thread per entry walking all 256 records took 0.16 ms: 25 wavefronts of dependent loads)
 template <int T16>
-__global__ void k_lp_schur_rack_sum2(LpDev D, const double *part, int nblk, const double *thg, double *S) {
+__global__ void __launch_bounds__(256) k_lp_schur_rack_sum2(LpDev D, const double *__restrict__ part, int nblk, const double *__restrict__ thg, double *__restrict__ S) {
     if (LP_STOPPED(D)) return;
     constexpr int NP = T16 * (T16 + 1) / 2, NE = 2 * NP * 256 + T16 * 16;
+    __shared__ double sl[16][17];
     const int n2 = 2 * D.R, ne = n2 * n2;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ne) return;
-    const int a = e / n2, c = e % n2;
-    if (c > a) return;
+    const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const bool live = e < ne;
+    const int a = live ? e / n2 : 0, c = live ? e % n2 : 0;
+    const bool lower = live && c <= a;
     const int ta = a >> 4, tc = c >> 4, k = ta * (ta + 1) / 2 + tc, row = a & 15, col = c & 15;
     const int idx = (k * 4 + (row >> 2)) * 64 + (row & 3) * 16 + col;      // accumulator layout: row = (lane >> 4) + 4 reg, col = lane & 15
     const bool same = a % D.R == c % D.R;
+    const int per = (nblk + 15) / 16, i0 = slice * per, i1 = min(nblk, i0 + per);
     double s = 0.0;
-    for (int i0 = 0; i0 < nblk; i0 += 8) {      // eight records' loads in flight, added in record order
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double *rec = part + (size_t)min(i0 + u, nblk - 1) * NE;
-            v[u] = rec[idx];
-            if (same) { v[u] += rec[NP * 256 + idx]; if (a == c) v[u] += rec[2 * NP * 256 + a]; }
+    if (lower)
+        for (int i = i0; i < i1; ++i) {
+            const double *rec = part + (size_t)i * NE;
+            double v = rec[idx];
+            if (same) { v += rec[NP * 256 + idx]; if (a == c) v += rec[2 * NP * 256 + a]; }
+            s += v;
         }
+    sl[el][slice] = s;
+    __syncthreads();
+    if (slice || !lower) return;
+    s = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (i0 + u < nblk) s += v[u];
-    }
+    for (int q = 0; q < 16; ++q) s += sl[el][q];
     if (a == c) {   // the racks' own inflow variables: NF[r] += sum zf, NL[r] += sum zl over the rack's brokers (in order)
         const int r = a % D.R;
         for (int i = D.rk_off[r]; i < D.rk_off[r + 1]; ++i) s += thg[(a < D.R ? 0 : D.B) + D.rk_mem[i]];
@@ -1492,9 +1499,9 @@ void lp_factor(LpCtx &c) {
     else if (c.broker_u >= 8) hipLaunchKernelGGL(k_lp_schur_broker<8>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
     else hipLaunchKernelGGL(k_lp_schur_broker<4>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
     const int n2 = 2 * D.R, per = 6 * n2 + D.R, t16 = (n2 + 15) / 16;
-    const dim3 sg((n2 * n2 + 255) / 256), sb(256);
+    const dim3 sg((n2 * n2 + 255) / 256), sb(256), sg2((n2 * n2 + 15) / 16);
 #define KAO_RACK_MFMA(T) do { hipLaunchKernelGGL(k_lp_schur_rack_mfma<T>, dim3(kRackMfmaBlocks), dim3(256), 0, c.st, D, c.th.z, c.fr, c.ti, c.part); \
-                              hipLaunchKernelGGL(k_lp_schur_rack_sum2<T>, sg, sb, 0, c.st, D, c.part, kRackMfmaBlocks, c.th.zg, c.S); } while (0)
+                              hipLaunchKernelGGL(k_lp_schur_rack_sum2<T>, sg2, sb, 0, c.st, D, c.part, kRackMfmaBlocks, c.th.zg, c.S); } while (0)
     if (c.rack_mfma && t16 == 1) KAO_RACK_MFMA(1);
     else if (c.rack_mfma && t16 == 2) KAO_RACK_MFMA(2);
     else if (c.rack_mfma && t16 == 3) KAO_RACK_MFMA(3);

