@@ -42,7 +42,7 @@ constexpr int kStepThreads = 512;      // eight wavefronts
 constexpr double kPivotRel = 1e-12, kPivotBig = 1e64, kPivotBigInv = 1e-64;
 constexpr int kWbLd = 17;
 // LDS carve of k_chol_step / k_chol_first: two tiles, three 16 x 17 scratch blocks, the tile's original diagonal, the pivots' 1 / sqrt
-constexpr size_t kStepLds = sizeof(double) * (2 * (size_t)NB * LD + 3 * 16 * kWbLd + 2 * NB);
+constexpr size_t kStepLds = sizeof(double) * (2 * (size_t)NB * LD + 3 * 16 * kWbLd + 2 * NB + 2 * NB);   // (+ two column buffers of the panel factor)
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -59,6 +59,14 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
         const double e = fma(-(p * y), 0.5 * y, 0.5);
         y = fma(y, e, y);
     }
+    return y;
+}
+
+// 1 / p, p > 0: the hardware estimate and two Newton steps y <- y + y (1 - p y)
+__device__ __forceinline__ double rcp_nr(double p) {
+    double y = __builtin_amdgcn_rcp(p);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) y = fma(y, fma(-p, y, 1.0), y);
     return y;
 }
 
@@ -83,13 +91,15 @@ __device__ __forceinline__ void dinv_block(const double *T, double *V, const dou
 }
 
 // All kStepThreads threads of the workgroup call this.  d0s[64]: the tile's diagonal before the factorisation (pivot test).
-__device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, double *rinv_s, int tid, long long *dbg = nullptr) {
+__device__ __forceinline__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, double *rinv_s, double *colb, int tid, long long *dbg = nullptr) {
     const int w = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
     int dn = 0;
 #define KAO_TICK() do { if (dbg && tid == 0) dbg[dn] = (long long)__builtin_amdgcn_s_memtime(); ++dn; } while (0)
     KAO_TICK();
-    for (int e = tid; e < NB * LD; e += kStepThreads) V[e] = 0.0;
-    __syncthreads();
+    for (int e = tid; e < 6 * 256; e += kStepThreads) {      // the six 16 x 16 blocks above the diagonal (the rest of V is written below)
+        const int blk = e >> 8, bi = blk < 3 ? 0 : (blk < 5 ? 1 : 2), bj = blk < 3 ? blk + 1 : (blk < 5 ? blk - 1 : 3);
+        V[(16 * bi + ((e >> 4) & 15)) * LD + 16 * bj + (e & 15)] = 0.0;
+    }
     for (int p = 0; p < 4; ++p) {
         const int c0 = 16 * p;
         if (w == 0) {
@@ -98,6 +108,9 @@ __device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, d
             // entry behind it (both read BEFORE column j is scaled, while 1 / sqrt(pivot j) is still being refined) and r2 = 1 / pivot j
             // -- twelve dependent operations a column; the scaling of the column and the updates of the panel's other columns,
             // a[c] -= (a[j] r2) u_c with the unscaled u_c, depend on r2 only and fill the issue slots beside the chain.
+            // The other columns' multipliers u_c (the unscaled entries of column j in the rows of the panel's diagonal block) reach the lanes
+            // through LDS: the column is written once (64 lanes, one ds_write_b64) and every u_c is a broadcast read -- a v_readlane pair per
+            // multiplier made the column 70 vector instructions, 500 cycles; only the chain's own u_{j+1} still travels by v_readlane.
             double a[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = T[lane * LD + c0 + c];
@@ -106,19 +119,20 @@ __device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, d
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int pr = c0 + j;
-                double u[16];
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) u[c] = readlane_d(a[j], c0 + c);          // unscaled entries of column j, rows of the panel's diagonal block
+                double *cb = colb + (j & 1) * NB;
+                cb[lane] = a[j];
+                const double unext = j + 1 < 16 ? readlane_d(a[j], pr + 1) : 0.0;
                 const double dnext = j + 1 < 16 ? readlane_d(a[j + 1], pr + 1) : 0.0;
                 const double thr = kPivotRel * readlane_d(d0l, pr);
                 const double pj = piv;
                 const bool ok = pj > thr;
+                // 1 / pivot for the updates (on the chain: five dependent operations), 1 / sqrt(pivot) for the column's own entries (beside it)
+                const double r2 = ok ? rcp_nr(pj) : kPivotBigInv * kPivotBigInv;
                 const double rinv = ok ? rsqrt_nr(pj) : kPivotBigInv;
-                const double r2 = rinv * rinv;
-                if (j + 1 < 16) piv = fma(-(u[j + 1] * r2), u[j + 1], dnext);               // (the same operations lane pr + 1 applies to its own entry below)
+                if (j + 1 < 16) piv = fma(-(unext * r2), unext, dnext);                     // (the same operations lane pr + 1 applies to its own entry below)
                 const double t = a[j] * r2;
 #pragma unroll
-                for (int c = j + 1; c < 16; ++c) a[c] = fma(-t, u[c], a[c]);
+                for (int c = j + 1; c < 16; ++c) a[c] = fma(-t, cb[c0 + c], a[c]);
                 const double ljj = ok ? pj * rinv : kPivotBig;
                 a[j] = lane == pr ? ljj : a[j] * rinv;
                 if (lane == pr) rinv_s[pr] = rinv;
@@ -149,14 +163,13 @@ __device__ void potrf_inv(double *T, double *V, double *Wb, const double *d0s, d
         __syncthreads();
         KAO_TICK();
     }
-    if (w == 7) dinv_block(T, V, rinv_s, 48, lane);
-    __syncthreads();
-    KAO_TICK();
     // the blocks of the inverse below the diagonal, by distance d from it: X_ij = -Dinv_i sum_{j <= k < i} L_ik X_kj
+    // (the last diagonal block's inverse is computed beside the first products, which do not need it)
     for (int d = 1; d <= 3; ++d) {
         const bool act = w <= 3 - d;
         const int j = w, i = w + d;
         double *wb = Wb + (w < 3 ? w : 0) * 16 * kWbLd;
+        if (d == 1 && w == 7) dinv_block(T, V, rinv_s, 48, lane);
         if (act) {
             v4d acc = {0.0, 0.0, 0.0, 0.0};
             for (int k = j; k < i; ++k)
@@ -218,13 +231,13 @@ __device__ __forceinline__ void tile_pair_to_lds(const double *__restrict__ srcA
 __global__ void __launch_bounds__(kStepThreads) k_chol_first(const double *stop, double *S, int n, const double *diag0, double *Linv, long long *dbg = nullptr) {
     if (stop && *stop != 0.0) return;
     extern __shared__ double lds[];
-    double *T = lds, *V = lds + NB * LD, *Wb = V + NB * LD, *d0s = Wb + 3 * 16 * kWbLd, *rinv_s = d0s + NB;
+    double *T = lds, *V = lds + NB * LD, *Wb = V + NB * LD, *d0s = Wb + 3 * 16 * kWbLd, *rinv_s = d0s + NB, *colb = rinv_s + NB;
     const int tid = threadIdx.x;
     tile_to_lds(S, n, T, tid);
     if (tid < NB) d0s[tid] = diag0[tid];
     __syncthreads();
     if (dbg && tid == 0) dbg[30] = (long long)__builtin_amdgcn_s_memtime();
-    potrf_inv(T, V, Wb, d0s, rinv_s, tid, dbg);
+    potrf_inv(T, V, Wb, d0s, rinv_s, colb, tid, dbg);
     diag_out(T, V, S, n, 0, Linv, tid);
     if (dbg && tid == 0) dbg[31] = (long long)__builtin_amdgcn_s_memtime();
 }
@@ -298,7 +311,7 @@ __device__ __forceinline__ void step_products(const double *__restrict__ Lk, dou
 __global__ void __launch_bounds__(kStepThreads) k_chol_step(const double *stop, double *S, int n, int k, const double *diag0, double *Linv) {
     if (stop && *stop != 0.0) return;
     extern __shared__ double lds[];
-    double *bufA = lds, *bufB = lds + NB * LD, *Wb = bufB + NB * LD, *d0s = Wb + 3 * 16 * kWbLd, *rinv_s = d0s + NB;
+    double *bufA = lds, *bufB = lds + NB * LD, *Wb = bufB + NB * LD, *d0s = Wb + 3 * 16 * kWbLd, *rinv_s = d0s + NB, *colb = rinv_s + NB;
     int bi, bj;
     pair_of((int)blockIdx.x, bi, bj);
     const int ti = k + 1 + bi, tj = k + 1 + bj, tid = threadIdx.x;
@@ -330,7 +343,7 @@ __global__ void __launch_bounds__(kStepThreads) k_chol_step(const double *stop, 
     }
     if (!first) return;
     __syncthreads();
-    potrf_inv(bufA, bufB, Wb, d0s, rinv_s, tid);
+    potrf_inv(bufA, bufB, Wb, d0s, rinv_s, colb, tid);
     diag_out(bufA, bufB, S, n, (k + 1) * NB, Linv + (size_t)(k + 1) * NB * NB, tid);
 }
 

@@ -259,7 +259,10 @@ __global__ void k_lp_theta_g(LpDev D, const double *x, const double *s, const do
 }
 
 // ---- per-partition factor: sig11 sig12 sig22 e5 k1 k2 per replica, d e1 e2 per rack, T^-1 ------------------------------
-__global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double *fr, double *ti) {
+// qd[3][2 NJ][P], qc[2 NJ][P], wr[4][NJ][P]: the replica columns of the partition as k_lp_schur_broker needs them (round 6) -- per column
+// 2j (C3 of replica j) / 2j + 1 (C4): v0, v1, eps / d and row | rack << 16 (-1: the replica's broker is not in the target set); and the two
+// rows of replica j premultiplied by T^-1.  The broker kernel used to derive them per incidence through four dependent global round trips.
+__global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double *fr, double *ti, double *__restrict__ qd, int *__restrict__ qc, double *__restrict__ wr) {
     if (LP_STOPPED(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
@@ -309,6 +312,25 @@ __global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double 
         else { i22 = 1.0 / p2; i12 = -l21 * i22; i11 = 1.0 / m11 + l21 * l21 * i22; }
     }
     ti[(size_t)0 * P + p] = i11; ti[(size_t)1 * P + p] = i12; ti[(size_t)2 * P + p] = i22;
+    const size_t cs = (size_t)2 * NJ * P;      // stride between the three planes of qd
+    for (int j = 0; j < NJ; ++j) {
+        const int b = cur_b(D, p, j);
+        const size_t k3 = (size_t)(2 * j) * P + p, k4 = (size_t)(2 * j + 1) * P + p;
+        if (b < 0) {
+            qc[k3] = -1; qc[k4] = -1;
+            qd[k3] = 0.0; qd[cs + k3] = 0.0; qd[2 * cs + k3] = 0.0; qd[k4] = 0.0; qd[cs + k4] = 0.0; qd[2 * cs + k4] = 0.0;
+            for (int m = 0; m < 4; ++m) wr[((size_t)m * NJ + j) * P + p] = 0.0;
+            continue;
+        }
+        const int rk = D.rack[b];
+        const double s11 = fj[((size_t)0 * NJ + j) * P + p], s12 = fj[((size_t)1 * NJ + j) * P + p], s22 = fj[((size_t)2 * NJ + j) * P + p];
+        const double d = fr[((size_t)0 * R + rk) * P + p], e1 = fr[((size_t)1 * R + rk) * P + p], e2 = fr[((size_t)2 * R + rk) * P + p];
+        const double a3v0 = s11 - e1 * s11 / d, a3v1 = s12 - e2 * s11 / d, a4v0 = s12 - e1 * s12 / d, a4v1 = s22 - e2 * s12 / d;
+        qd[k3] = a3v0; qd[cs + k3] = a3v1; qd[2 * cs + k3] = s11 / d; qc[k3] = RC3(D, b) | (rk << 16);
+        qd[k4] = a4v0; qd[cs + k4] = a4v1; qd[2 * cs + k4] = s12 / d; qc[k4] = RC4(D, b) | (rk << 16);
+        wr[((size_t)0 * NJ + j) * P + p] = i11 * a3v0 + i12 * a3v1; wr[((size_t)1 * NJ + j) * P + p] = i12 * a3v0 + i22 * a3v1;
+        wr[((size_t)2 * NJ + j) * P + p] = i11 * a4v0 + i12 * a4v1; wr[((size_t)3 * NJ + j) * P + p] = i12 * a4v0 + i22 * a4v1;
+    }
 }
 
 // One coupling column of a partition: which row of S, its rack, and (m1, m2, eps, dg) as in oracle/kao_lp_port.c::lp_cols.
@@ -340,7 +362,8 @@ __device__ __forceinline__ bool lp_col(const LpDev &D, const double *th, const d
 // rows C3[b] and C4[b] are accumulated in LDS (2 x mc doubles per wavefront) and written once (lower triangle)
 template <int U>
 __global__ void __launch_bounds__(256) k_lp_schur_broker(LpDev D, const double *__restrict__ th, const double *__restrict__ thg, const double *__restrict__ fj,
-                                                          const double *__restrict__ fr, const double *__restrict__ ti, double *__restrict__ S) {
+                                                          const double *__restrict__ fr, const double *__restrict__ ti, const double *__restrict__ qd, const int *__restrict__ qc,
+                                                          const double *__restrict__ wr, double *__restrict__ S) {
     if (LP_STOPPED(D)) return;
     extern __shared__ double lds_rows[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -353,77 +376,54 @@ __global__ void __launch_bounds__(256) k_lp_schur_broker(LpDev D, const double *
     for (int i = lane; i < 2 * mc; i += 64) rowA[i] = 0.0;
     const int r0 = D.rack[b], nc = 2 * NJ + 2 * R;
     if (nc <= 64) {
-        // Every lane owns one column of an incidence; FOUR incidences are fetched before the first is added to the rows (round 5, second
-        // half): an incidence is a chain of three dependent global round trips (the incidence word, the partition's factors, the column's
-        // factors) and a broker has ~300 of them at 100,000 partitions -- 1.37 ms of an 8.8-ms iteration with one chain in flight.  The adds
-        // reach every column in incidence order as before: the same bits.
-        // Straight-line code, level by level over the four incidences (no branch between the loads of one level: the compiler keeps
-        // them in flight together): incidence word -> partition's factors and current replicas -> rack of the column's broker -> rack factors.
+        // Every lane owns one column of an incidence; U incidences are in flight.  An incidence is TWO dependent round trips (round 6): the
+        // incidence word (scalar), then everything else, which depends on the partition only -- the incidence's own rows premultiplied by
+        // T^-1 and the replica columns come precomputed from k_lp_factor_local (wr, qd, qc), the rack columns are two products away from
+        // theta and the reciprocal rack factors.  (Round 5 walked incidence word -> partition's factors -> rack of the column's broker ->
+        // rack factors: four trips, 1.07 ms at 100,000 partitions with one wavefront per SIMD.)  The adds reach every column in incidence
+        // order: the same bits on every run.
         const int e1 = D.inc_off[b + 1];
         const int c = lane;
         const bool is_cur = c < 2 * NJ, has_col = c < nc;
-        const int jc = is_cur ? (c >> 1) : 0, rc_ = is_cur ? 0 : min((c - 2 * NJ) >> 1, R - 1), odd = c & 1;
+        const int rc_ = is_cur ? 0 : min((c - 2 * NJ) >> 1, R - 1), odd = c & 1;
+        const size_t cs = (size_t)2 * NJ * P;
+        const double *__restrict__ cyp = th + (size_t)(odd ? VYL(D, rc_) : VYF(D, rc_)) * P;
+        const double *__restrict__ idp = fr + ((size_t)3 * R + rc_) * P, *__restrict__ f1p = fr + ((size_t)4 * R + rc_) * P, *__restrict__ f2p = fr + ((size_t)5 * R + rc_) * P;
+        const int ccl = is_cur ? c : 0;
+        const int rcol = odd ? RNL(D, rc_) : RNF(D, rc_);
         for (int e = D.inc_off[b]; e < e1; e += U) {
             int pp[U], j0[U]; bool live[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { live[u] = e + u < e1; const int idx = D.inc[min(e + u, e1 - 1)]; pp[u] = idx >> 3; j0[u] = idx & 7; }
-            // level 2: everything that needs only p
-            double i11[U], i12[U], i22[U], f3[U][3], cs[U][3], cy[U], d0[U];
-            int bc[U];
+            double w30[U], w31[U], w40[U], w41[U], s11[U], s12[U], s22[U], q0[U], q1[U], qe[U];
+            int col[U], rk[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int p = pp[u];
-                i11[u] = ti[(size_t)0 * P + p]; i12[u] = ti[(size_t)1 * P + p]; i22[u] = ti[(size_t)2 * P + p];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) { f3[u][m] = fj[((size_t)m * NJ + j0[u]) * P + p]; cs[u][m] = fj[((size_t)m * NJ + jc) * P + p]; }
-                cy[u] = th[(size_t)(odd ? VYL(D, rc_) : VYF(D, rc_)) * P + p];
-                d0[u] = fr[((size_t)0 * R + r0) * P + p];
-                bc[u] = D.cur[(size_t)p * NJ + jc];
-            }
-            // level 3: the rack of the column's broker (current-replica columns) -- the incidence's own broker is b, rack r0
-            int rk[U]; bool okc[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool cur_ok = bc[u] != KAO_NONE && bc[u] < D.B;
-                okc[u] = live[u] && has_col && (is_cur ? cur_ok : true);
-                rk[u] = is_cur ? (int)D.rack[cur_ok ? bc[u] : 0] : rc_;
-            }
-            // level 4: rack factors of the column and of the incidence's rows
-            double dq[U], e1q[U], e2q[U], e1a[U], e2a[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int p = pp[u];
-                dq[u] = fr[((size_t)0 * R + rk[u]) * P + p]; e1q[u] = fr[((size_t)1 * R + rk[u]) * P + p]; e2q[u] = fr[((size_t)2 * R + rk[u]) * P + p];
-                e1a[u] = fr[((size_t)1 * R + r0) * P + p]; e2a[u] = fr[((size_t)2 * R + r0) * P + p];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!okc[u]) continue;
-                // the incidence's two rows (lp_col for columns 2 j0 and 2 j0 + 1): C3 row a3, C4 row a4
-                const double s11 = f3[u][0], s12 = f3[u][1], s22 = f3[u][2];
-                const double a3v0 = s11 - e1a[u] * s11 / d0[u], a3v1 = s12 - e2a[u] * s11 / d0[u];
-                const double a4v0 = s12 - e1a[u] * s12 / d0[u], a4v1 = s22 - e2a[u] * s12 / d0[u];
-                const double w30 = i11[u] * a3v0 + i12[u] * a3v1, w31 = i12[u] * a3v0 + i22[u] * a3v1;
-                const double w40 = i11[u] * a4v0 + i12[u] * a4v1, w41 = i12[u] * a4v0 + i22[u] * a4v1;
-                // this lane's column (lp_col for column c)
-                double m1, m2, eps, dg; int col;
+                w30[u] = wr[((size_t)0 * NJ + j0[u]) * P + p]; w31[u] = wr[((size_t)1 * NJ + j0[u]) * P + p];
+                w40[u] = wr[((size_t)2 * NJ + j0[u]) * P + p]; w41[u] = wr[((size_t)3 * NJ + j0[u]) * P + p];
+                s11[u] = fj[((size_t)0 * NJ + j0[u]) * P + p]; s12[u] = fj[((size_t)1 * NJ + j0[u]) * P + p]; s22[u] = fj[((size_t)2 * NJ + j0[u]) * P + p];
                 if (is_cur) {
-                    const double q11 = cs[u][0], q12 = cs[u][1], q22 = cs[u][2];
-                    if (!odd) { col = RC3(D, bc[u]); m1 = q11; m2 = q12; eps = q11; dg = q11; }
-                    else { col = RC4(D, bc[u]); m1 = q12; m2 = q22; eps = q12; dg = q22; }
+                    const size_t k = (size_t)ccl * P + p;
+                    q0[u] = qd[k]; q1[u] = qd[cs + k]; qe[u] = qd[2 * cs + k];
+                    const int w = qc[k];
+                    col[u] = w < 0 ? -1 : (w & 0xFFFF); rk[u] = w < 0 ? -1 : (w >> 16);
                 } else {
-                    if (!odd) { col = RNF(D, rc_); m1 = cy[u]; m2 = 0; eps = cy[u]; dg = cy[u]; }
-                    else { col = RNL(D, rc_); m1 = cy[u]; m2 = cy[u]; eps = cy[u]; dg = cy[u]; }
+                    const double cy = cyp[p];
+                    q0[u] = cy - cy * f1p[p]; q1[u] = (odd ? cy : 0.0) - cy * f2p[p]; qe[u] = cy * idp[p];
+                    col[u] = has_col ? rcol : -1; rk[u] = rc_;
                 }
-                (void)dg;
-                const double qv0 = m1 - e1q[u] * eps / dq[u], qv1 = m2 - e2q[u] * eps / dq[u];
-                double v3 = -(w30 * qv0 + w31 * qv1), v4 = -(w40 * qv0 + w41 * qv1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!live[u] || col[u] < 0) continue;
+                double v3 = -(w30[u] * q0[u] + w31[u] * q1[u]), v4 = -(w40[u] * q0[u] + w41[u] * q1[u]);
                 if (rk[u] == r0) {
-                    v3 -= s11 * eps / d0[u]; v4 -= s12 * eps / d0[u];           // a3.eps = s11, a4.eps = s12
-                    if (c == 2 * j0[u]) { v3 += s11; v4 += s12; }                // (C3, C3) = sig11, (C4, C3) = sig12
-                    else if (c == 2 * j0[u] + 1) { v3 += s12; v4 += s22; }       // (C3, C4) = sig12, (C4, C4) = sig22
+                    v3 -= s11[u] * qe[u]; v4 -= s12[u] * qe[u];                   // a3.eps = s11, a4.eps = s12
+                    if (c == 2 * j0[u]) { v3 += s11[u]; v4 += s12[u]; }          // (C3, C3) = sig11, (C4, C3) = sig12
+                    else if (c == 2 * j0[u] + 1) { v3 += s12[u]; v4 += s22[u]; } // (C3, C4) = sig12, (C4, C4) = sig22
                 }
-                rowA[col] += v3; rowB[col] += v4;
+                rowA[col[u]] += v3; rowB[col[u]] += v4;
             }
         }
     } else
@@ -1426,8 +1426,9 @@ struct LpCtx {
     int32_t *d_mult = nullptr, *d_zq = nullptr;
     VarVec dc{}; RowVec wc{}; int mcc = 2;   // centrality correctors per iteration (KAO_LP_MCC; 0: none) and their direction / row vector
     bool rack_mfma = true;         // the rack x rack block of the Schur complement on the matrix cores (2R <= 64; KAO_LP_RACK=old: the LDS-tiled kernel)
+    double *qd = nullptr, *wr = nullptr; int *qc = nullptr;   // replica columns / rows of the partitions for k_lp_schur_broker (k_lp_factor_local)
     double *rack_part = nullptr;   // [2 R][kRackChunks] slice sums of the rack rows
-    int broker_u = 8;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
+    int broker_u = 4;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
     double *xz = nullptr; bool dense_new = true;   // kao_chol.hip (KAO_LP_DENSE=old: round 5's kernels below, for A/B runs)
     int *trsv_flags = nullptr; double *trsv_z = nullptr; bool trsv_mw = true;   // the triangular solves by one workgroup per row tile (KAO_LP_TRSV_MW=0: by one workgroup)
     uint8_t *d_q = nullptr;   // quantised primal iterate (lp_primal)
@@ -1492,12 +1493,12 @@ void lp_rows_coupling(LpCtx &c, const VarVec &z, double *out_rc, int mode, const
 
 void lp_factor(LpCtx &c) {
     const LpDev &D = c.D;
-    hipLaunchKernelGGL(k_lp_factor_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti);
+    hipLaunchKernelGGL(k_lp_factor_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr);
     const size_t lds_b = (size_t)c.broker_waves * 2 * D.mc * sizeof(double);
     const dim3 bg((D.B + c.broker_waves - 1) / c.broker_waves), bb(64 * c.broker_waves);
-    if (c.broker_u >= 16) hipLaunchKernelGGL(k_lp_schur_broker<16>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
-    else if (c.broker_u >= 8) hipLaunchKernelGGL(k_lp_schur_broker<8>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
-    else hipLaunchKernelGGL(k_lp_schur_broker<4>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.S);
+    if (c.broker_u >= 16) hipLaunchKernelGGL(k_lp_schur_broker<16>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
+    else if (c.broker_u >= 8) hipLaunchKernelGGL(k_lp_schur_broker<8>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
+    else hipLaunchKernelGGL(k_lp_schur_broker<4>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
     const int n2 = 2 * D.R, per = 6 * n2 + D.R, t16 = (n2 + 15) / 16;
     const dim3 sg((n2 * n2 + 255) / 256), sb(256), sg2((n2 * n2 + 15) / 16);
 #define KAO_RACK_MFMA(T) do { hipLaunchKernelGGL(k_lp_schur_rack_mfma<T>, dim3(kRackMfmaBlocks), dim3(256), 0, c.st, D, c.th.z, c.fr, c.ti, c.part); \
@@ -1660,7 +1661,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
         (rc = c->alloc(&c->part, std::max((size_t)c->rack_blocks * n2 * n2, (size_t)kRackMfmaBlocks * (2 * 10 * 256 + 64)))) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
-        (rc = c->alloc(&c->trsv_flags, (size_t)2 * (D.mcp / kNB))) || (rc = c->alloc(&c->trsv_z, (size_t)D.mcp)) || (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
+        (rc = c->alloc(&c->trsv_flags, (size_t)2 * (D.mcp / kNB))) || (rc = c->alloc(&c->trsv_z, (size_t)D.mcp)) || (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->qd, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->qc, (size_t)2 * NJ * P)) || (rc = c->alloc(&c->wr, (size_t)4 * NJ * P)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
         (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
     { const char *e = std::getenv("KAO_LP_TRSV_MW"); c->trsv_mw = !(e && e[0] == '0') && D.mcp / kNB <= 160; }
@@ -1670,7 +1671,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     { const char *e = std::getenv("KAO_LP_RACK"); c->rack_mfma = !(e && e[0] == 'o'); }
-    { const char *e = std::getenv("KAO_LP_BROKER_U"); c->broker_u = e ? std::atoi(e) : 8; }
+    { const char *e = std::getenv("KAO_LP_BROKER_U"); c->broker_u = e ? std::atoi(e) : 4; }   // (round 6, measured at 100,000 partitions: 4.10 / 4.29 / 4.41 ms an iteration with 4 / 8 / 16)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_rack), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     for (const VarVec *vv : {&c->x, &c->s, &c->v, &c->th, &c->rd, &c->h, &c->g, &c->d1, &c->d2, &c->dsa, &c->dva, &c->ds, &c->dv, &c->dc})
