@@ -209,7 +209,7 @@ struct SolveRun {
     // iterations at tolerance 1e-10 on drifted topics of 30,000-200,000 partitions (lp_iters_est), plus lp_s_fixed for the context, the
     // starting point, the read-back and the rounding.  Constants measured on one MI355X (round 6, profiles/r06_*); a limit is an input,
     // not the clock: the schedule stays count-keyed.
-    double lp_ms_base = 0.55, lp_ms_tile = 0.055, lp_ms_kpart = 0.022, lp_iters_est = 125.0, lp_s_fixed = 0.12, lp_fit = 0.8;
+    double lp_ms_base = 0.50, lp_ms_tile = 0.05, lp_ms_kpart = 0.020, lp_iters_est = 125.0, lp_s_fixed = 0.12, lp_fit = 0.8;
     double lp_reserve_s = 0.2;    // an LP that runs before there is any incumbent is given up this long before the deadline: K-search needs ~0.16 s to a first feasible plan at 100,000 partitions
     double lp_wait_until(int i) const { return feasible(i) ? deadline : deadline - lp_reserve_s; }
     double lp_est_s(int i) const {
