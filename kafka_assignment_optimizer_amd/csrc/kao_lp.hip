@@ -62,7 +62,14 @@ struct LpDev {
 enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (non-finite iterate), 4 aborted by the host (lp_abort) */, SC_IT, SC_AP, SC_AD, SC_SIGMU, SC_MU, SC_POBJ, SC_DOBJ,
              SC_PINF, SC_DINF, SC_PLAST, SC_DLAST, SC_HAVE_LAST, SC_KEEP /* this iterate is finite: copy its duals */, SC_TOL, SC_MAXIT, SC_NVU /* variables + bounded variables */, SC_NB, SC_NCN,
              SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT,
-             SC_MCC_GO /* centrality correctors: the next one is still wanted */, SC_MCC_ACC /* the last one was accepted */, kScN = 24 };
+             SC_MCC_GO /* centrality correctors: the next one is still wanted */, SC_MCC_ACC /* the last one was accepted */,
+             SC_MU_REF, SC_IT_REF /* the stall test's reference iterate */, kScN = 32 };
+// Stalled at the numerical floor (round 6): some perturbed solves reach a relative gap of 5e-10 .. 1e-9 after ~110 iterations and then
+// stand still -- step lengths ~0, mu unchanged for the remaining 90 iterations of their cap (profiles/r06_c09_stalled_solves.txt).  An
+// iterate within kLpStallGap tolerances of the optimum whose mu has not fallen by a tenth in kLpStallWindow iterations counts as converged:
+// its duals go through K-bound's integer evaluation like any others, its primal side through the rounding.
+constexpr int kLpStallWindow = 8;
+constexpr double kLpStallGap = 100.0, kLpStallMu = 0.9;
 #define LP_STOPPED(D) ((D).sc[SC_STOP] != 0.0)
 // kernels of a centrality corrector carry gated = 1: once no further corrector is wanted they return at their first line
 #define LP_GATED_OFF(D, gated) ((gated) && (D).sc[SC_MCC_GO] == 0.0)
@@ -194,8 +201,13 @@ __global__ void k_lp_sc_resid(double *sc, const double *redA, const double *redB
     if (!finite) { sc[SC_STOP] = 3.0; return; }
     sc[SC_PLAST] = pobj; sc[SC_DLAST] = dobj; sc[SC_HAVE_LAST] = 1.0;     // k_lp_keep_last copies y next
     const double tol = sc[SC_TOL];
-    if (fabs(pobj - dobj) / (1.0 + fabs(pobj)) < tol && pinf < 100 * tol && dinf < tol) sc[SC_STOP] = 1.0;
-    else if (it >= (int)sc[SC_MAXIT]) sc[SC_STOP] = 2.0;
+    const double gap = fabs(pobj - dobj) / (1.0 + fabs(pobj));
+    if (gap < tol && pinf < 100 * tol && dinf < tol) { sc[SC_STOP] = 1.0; return; }
+    if (it - (int)sc[SC_IT_REF] >= kLpStallWindow) {
+        if (gap < kLpStallGap * tol && pinf < 100 * tol && dinf < tol && mu > kLpStallMu * sc[SC_MU_REF]) { sc[SC_STOP] = 1.0; return; }
+        sc[SC_MU_REF] = mu; sc[SC_IT_REF] = (double)it;
+    }
+    if (it >= (int)sc[SC_MAXIT]) sc[SC_STOP] = 2.0;
 }
 // the coupling-row duals of the last finite iterate (what the multipliers are read from); runs right after k_lp_sc_resid
 __global__ void k_lp_keep_last(const double *sc, const double *yc, double *ylast, int n) {
@@ -1716,6 +1728,7 @@ int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
     std::memset(init, 0, sizeof init);
     init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
     init[SC_PERT] = pert > 0.0 ? pert : 0.0; init[SC_SALT] = (double)salt;
+    init[SC_MU_REF] = 1e300; init[SC_IT_REF] = 0.0;
     std::memcpy(c.h_sc, init, sizeof init);
     HIP_TRY(hipMemcpyAsync(D.sc, c.h_sc, sizeof init, hipMemcpyHostToDevice, c.st));
     const size_t nvtot = (size_t)D.NV * D.P + D.GV;
