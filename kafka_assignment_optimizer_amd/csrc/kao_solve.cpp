@@ -1325,7 +1325,10 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
         for (int32_t v : x.run.s->dual_iters) g_timing[8] += (double)v;
         g_timing[9] += x.run.cx_calls; g_timing[10] += x.run.cx_gains; g_timing[11] += (double)x.run.iters_done;
         g_timing[12] += x.run.generations; g_timing[13] += x.run.cx_more;
+        g_timing[14] += x.run.lp_solves; g_timing[15] += x.run.lp_iters;
     }
+    for (double &q : g_lp) q = 0;     // KAO-LP over all devices (a replicated topic in the LP's regime is a race: every device runs its own solve)
+    for (Dev &x : D) if (x.run.s) { g_lp[0] += x.run.lp_solves; g_lp[1] += x.run.lp_iters; g_lp[2] += x.run.lp_rounded; g_lp[3] += x.run.lp_round_adopted; g_lp[4] += x.run.lp_round_fractional; }
     for (int d = 0; d < n_dev; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; kao_session_destroy(D[(size_t)d].run.s); D[(size_t)d].run.s = nullptr; }
     cleanup();
     g_timing[1] = t_improve; g_timing[3] = now_s() - t0; g_timing[4] = rounds; g_timing[5] = cand; g_timing[6] = bl; g_timing[7] = (double)exchanges;

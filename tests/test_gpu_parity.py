@@ -1156,6 +1156,24 @@ def test_solve_multi_replicated_runs_the_grouped_collectives(kao, ko, monkeypatc
     assert (r2.status, r2.objective, r2.assignment.tolist()) == (r.status, r.objective, r.assignment.tolist())
 
 
+def test_solve_multi_races_the_lp_on_a_replicated_large_topic(kao, ko, kp, monkeypatch):
+    """Round 6: a replicated topic in the LP's regime (>= 32,768 replica slots) is a RACE -- every (logical) device runs the perturbed
+    interior-point solve with its own salt, the first proof ends the solve for all, certificates and incumbents are shared through the
+    grouped collectives as before.  Two ranks on device 0 (loop-back table): the proven optimum equals the single-device one, the answer
+    satisfies every row under the scalar evaluator, and more than one LP was started."""
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    monkeypatch.setenv("KAO_RCCL_LOOPBACK", "1")
+    pt = sy.drift(sy.make_cluster(600, 12, 1, 12000, 3, [], []), 0.2, 1)[0]
+    ot = _oracle_topic(ko, pt)
+    one = kao.solve([pt], seed=5, stop_at_bound=1, time_limit_s=20.0)[0]
+    two = kao.solve_multi([pt], [0, 0], seed=5, stop_at_bound=1, time_limit_s=20.0)[0]
+    lp = kao.last_solve_lp()
+    assert one.status == two.status == "OPTIMAL_PROVEN" and one.objective == two.objective == two.upper_bound, (one.status, two.status, one.objective, two.objective)
+    obj, viol = kp.port_eval(ot, two.assignment)
+    assert viol[0] == 0 and obj == two.objective
+    assert lp["solves"] >= 1 and lp["adopted"] >= 1, lp
+
+
 def test_rccl_collectives_on_the_resident_buffers(kao):
     """The RCCL path of kao_solve_multi (librccl.so opened on first use, ncclCommInitAll, ncclAllReduce(ncclUint64, ncclMin),
     ncclBroadcast) on the devices this box has -- one here, so a world of one; the same entry point checks 8 on a full node."""
