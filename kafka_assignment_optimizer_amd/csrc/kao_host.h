@@ -107,6 +107,7 @@ struct kao_session {
         bool wide = false;   // some topic of the group has 512 replica slots or more (several tournament slots per lane)
         int waves = kWaves;  // restarts per K-search workgroup: 4, 2 or 1 -- the largest whose LDS carve fits 160 KiB
         int nw = kRFP;       // replica words per partition of the group's topics: 4 or 8 (template instantiation)
+        int rf_uniform = -1; // the RF all topics of the group share (0: mixed; -1: no topic yet)
         bool global_a = false;   // topic too large for LDS: assignment + current words stay in global memory
         bool cur_global = false; // (round 5) only the current-assignment words stay in global memory / L2, the working words are in LDS (~4,900 .. 9,800 partitions)
         int team = 0;            // > 0 (global_a only): every restart is searched by a TEAM of that many wavefronts (k_team), one workgroup per restart

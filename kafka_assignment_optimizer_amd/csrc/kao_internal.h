@@ -118,6 +118,7 @@ struct EvalPools {
     const uint32_t *bwd_pool;    // broker weights per dense index (topics with has_bw)
     int32_t *overflow;           // [1] or nullptr: set when a candidate puts more than 65,535 replicas on one broker (the 16-bit
                                  //     halves of the per-broker counters would carry; only possible when P*RF > 65535)
+    int32_t rf_uniform;          // the replication factor every topic of the launch has, or 0 (mixed): RF 3 runs an instantiation whose slot loops have no guards
 };
 
 struct BoundPools {

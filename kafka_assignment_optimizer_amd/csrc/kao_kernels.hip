@@ -1164,8 +1164,11 @@ __global__ __launch_bounds__(NW == 8 ? 256 : 512) void k_team(SearchPools pl, Se
 //                of LDS counters -- few large candidates (a 30,000-partition topic has 256 restarts; KAO-CX scores <= 513
 //                realisations): one wavefront per candidate left 3 of 4 SIMDs idle and took 469 dependent trips per candidate.
 //                All sums are integers, so the split changes no result.
-template <int NE, bool kCoop>
+// RFT > 0 (round 6): every topic of the launch has replication factor RFT -- the slot loops run RFT times without the `k >= RF` guards and the
+//                C7 compare square is RFT x RFT instead of NE x NE (RF 3 in four slots: 9 of 16); RFT = 0: RF is read per topic.
+template <int NE, bool kCoop, int RFT = 0>
 __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
+    constexpr int RFE = RFT ? RFT : NE;      // slots the loops visit
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     unsigned long long *wave_key = reinterpret_cast<unsigned long long *>(smem_all);  // [kWaves], 32 B
     unsigned char *smem = smem_all + 32;
@@ -1173,7 +1176,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int4 bm = pl.block_map[blockIdx.x];
     const TopicDev *TD = pl.topics + bm.x;
-    const int B = TD->B, R = TD->R, P = TD->P, RF = TD->RF, rf_cur = TD->rf_cur;
+    const int B = TD->B, R = TD->R, P = TD->P, RF = RFT ? RFT : TD->RF, rf_cur = TD->rf_cur;
     const int rep_lo = TD->rep_lo, rep_hi = TD->rep_hi, lead_lo = TD->lead_lo, lead_hi = TD->lead_hi;
     const int rack_lo = TD->rack_lo, rack_hi = TD->rack_hi, prack_lo = TD->prack_lo, prack_hi = TD->prack_hi;
     const int w00 = TD->w00, w01 = TD->w01, w10 = TD->w10, w11 = TD->w11;
@@ -1213,7 +1216,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     for (int ci = bm.y + (kCoop ? 0 : wave); ci < bm.y + bm.z; ci += (kCoop ? 1 : kWaves)) {
         const uint16_t *cand = pl.cand + TD->best_off + (uint64_t)ci * P * RF;
         for (int b4 = tid; b4 < nB4; b4 += tstride) reinterpret_cast<uint4 *>(C)[b4] = make_uint4(0, 0, 0, 0);
-        for (int r = tid; r < kRackTab; r += tstride) K[r] = 0;
+        for (int r = tid; r < (k4 ? 4 * KR : KR); r += tstride) K[r] = 0;      // (only the entries the atomics below and the C6 pass touch)
         if (kCoop) __syncthreads();
         // Broker band violations are accumulated from the value each LDS atomic RETURNS: adding a replica to a
         // broker whose count was c changes band(c) by (c >= hi) - (c < lo), and sum_b band(0) = B*lo, so
@@ -1240,8 +1243,8 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             }
             int missing = 0;
 #pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                if (k >= RF) break;
+            for (int k = 0; k < RFE; ++k) {
+                if (!RFT && k >= RF) break;
                 const uint32_t b = bk[k];
                 if (b >= (uint32_t)B) { ++missing; continue; }   // empty / out-of-range slot
                 rk[k] = RACK[b];
@@ -1267,11 +1270,11 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             // C7: replicas per partition per rack, over all R racks (each rack counted at its first slot)
             int touched = 0, s7 = 0;
 #pragma unroll
-            for (int k = 0; k < NE; ++k) {
+            for (int k = 0; k < RFE; ++k) {
                 bool first = rk[k] != 0xFFu;
                 int cnt = 0;
 #pragma unroll
-                for (int j = 0; j < NE; ++j) { cnt += (int)(rk[j] == rk[k]); if (j < k) first &= rk[j] != rk[k]; }
+                for (int j = 0; j < RFE; ++j) { cnt += (int)(rk[j] == rk[k]); if (j < k) first &= rk[j] != rk[k]; }
                 if (first) { s7 += band(cnt, prack_lo, prack_hi); touched++; }
             }
             s57 += (uint32_t)(s7 + (R - touched) * prack_lo) << 16;
@@ -1557,6 +1560,7 @@ void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream) {
     int &g_attr_eval = g_attr_eval_dev[attr_slot()];
     if ((int)lds > g_attr_eval) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<4, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_eval<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1568,6 +1572,7 @@ void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream) {
         else hipLaunchKernelGGL((k_eval<4, true>), dim3(n_blocks), dim3(256), lds, st, pools);
     } else {
         if (ne == 8) hipLaunchKernelGGL((k_eval<8, false>), dim3(n_blocks), dim3(256), lds, st, pools);
+        else if (pools.rf_uniform == 3) hipLaunchKernelGGL((k_eval<4, false, 3>), dim3(n_blocks), dim3(256), lds, st, pools);
         else hipLaunchKernelGGL((k_eval<4, false>), dim3(n_blocks), dim3(256), lds, st, pools);
     }
 }

@@ -291,7 +291,7 @@ int kao_eval_plan_run(kao_eval_plan *p, const void *d_candidates, int64_t n, voi
     pl.objective = static_cast<int32_t *>(d_objective);
     pl.violations = static_cast<int32_t *>(d_violations);
     pl.best_key = static_cast<unsigned long long *>(d_best_key);
-    pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B; pl.cur_in_lds = p->cur_in_lds ? 1 : 0; pl.coop = p->coop ? 1 : 0;
+    pl.maxP = p->pt.d.P; pl.maxB = p->pt.d.B; pl.cur_in_lds = p->cur_in_lds ? 1 : 0; pl.coop = p->coop ? 1 : 0; pl.rf_uniform = p->pt.d.RF;
     pl.overflow = p->d_overflow; pl.bwd_pool = p->d_bwd;
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     launch_eval(pl, p->map_blocks, p->pt.d.nw, p->stream);
@@ -664,6 +664,7 @@ int kao_session_create(const kao_topic *topics, int32_t n_topics, const kao_opts
         if (n_cand < fill * 32) cpb = (int)std::min<int64_t>(32, std::max<int64_t>(kWaves, ((n_cand + fill - 1) / fill + kWaves - 1) / kWaves * kWaves));
         for (int t : mem) {
             const TopicDev &d = s->pts[(size_t)t].d;
+            g.rf_uniform = g.rf_uniform < 0 ? d.RF : (g.rf_uniform == d.RF ? d.RF : 0);
             g.maxP = std::max(g.maxP, d.P); g.maxBx = std::max(g.maxBx, d.Bx); g.maxB = std::max(g.maxB, d.B); g.maxR = std::max(g.maxR, d.R); g.wide = g.wide || (int64_t)d.P * d.RF >= 512;
         }
         g.global_a = s->topic_global[(size_t)mem[0]] != 0;
@@ -842,7 +843,7 @@ int kao_session_step(kao_session *s) {
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));
     for (const kao_session::LaunchGroup &g : s->groups) {
         ep.block_map = s->d_emap + g.emap_off;
-        ep.maxP = g.maxP; ep.maxB = g.maxB; ep.cur_in_lds = g.cur_in_lds ? 1 : 0; ep.coop = g.eval_coop ? 1 : 0;
+        ep.maxP = g.maxP; ep.maxB = g.maxB; ep.cur_in_lds = g.cur_in_lds ? 1 : 0; ep.coop = g.eval_coop ? 1 : 0; ep.rf_uniform = std::max(g.rf_uniform, 0);
         launch_eval(ep, g.emap_n, g.nw, s->stream);
         HIP_TRY(hipGetLastError());
     }
