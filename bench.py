@@ -61,6 +61,8 @@ def compact_line(out):
     cfg = out.get("config", {})
     line["config"] = {"workload": cfg.get("workload", "")[:200]}
     line["config"].update(_num(cfg, ("topics_total", "restarts_per_topic_rank0", "iters_per_launch", "parallelism")))
+    if isinstance(cfg.get("topics_per_rank"), list) and len(cfg["topics_per_rank"]) <= 16:
+        line["config"]["topics_per_rank"] = cfg["topics_per_rank"]          # (tools/summarize_prof.py keys the counter constants on it)
     roof_keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
                  "traffic_source", "peak_source")
     for k in ("roofline", "roofline_valu_issue", "roofline_lds", "roofline_eval_stream", "roofline_lp"):

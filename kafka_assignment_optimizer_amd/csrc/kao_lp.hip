@@ -17,9 +17,10 @@
 //   coupling rows NF[r] NL[r] C6[r] C3[b] C4[b] (mc = 3R + 2B): Schur complement S = per-partition block-diagonal parts minus
 //     rank-2 terms, GATHERED in a fixed order (one wavefront per broker walks the broker's incidence list, the rack x rack
 //     block is a tiled outer-product sum over fixed chunks): no floating-point atomics, the same bits on every run;
-//   dense blocked Cholesky of S (64 x 64 tiles; pivots that lost all but 1e-12 of their entry pin a dependent row), two
-//     triangular solves per right-hand side.
-// f64 throughout (the Cholesky trailing update is the one GEMM-shaped piece of the whole library).
+//   dense Cholesky of S and two triangular solves per right-hand side: kao_chol.hip (round 6: v_mfma_f64_16x16x4_f64, one launch per
+//     64-row tile column; pivots that lost all but 1e-12 of their entry pin a dependent row).
+// f64 throughout.  The dense contractions of the path -- the Cholesky and the rack x rack block of S -- run on the f64 matrix cores;
+// everything else is gathers and per-partition streams.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -37,7 +38,6 @@ namespace kao {
 namespace {
 
 constexpr double kLpPivotRel = 1e-12;
-constexpr double kLpPivotBig = 1e64;
 constexpr double kLpReg = 1e-10;
 constexpr int kNB = 64;            // Cholesky tile
 constexpr int kRedVals = 8;        // values per reduction record
@@ -687,251 +687,6 @@ __global__ void k_lp_schur_fix_cols(LpDev D, double *S) {
         if (D.rowc[i] != 1) S[(size_t)k * D.mcp + i] = 0.0;
 }
 
-// ---- dense Cholesky of S (lower, row-major, leading dimension n = mcp, 64 x 64 tiles) ----------------------------------
-// The factor L is kept in the lower triangle; the tiles below the diagonal are ALSO written transposed into the upper triangle
-// (nothing else lives there), so that both triangular solves read rows of S with consecutive lanes on consecutive columns.
-// Diagonal tile: one wavefront, lane = row (Cholesky-Crout by columns; LDS operations of one wavefront execute in order, so no
-// barrier is needed), then the inverse of the 64 x 64 triangle (lane = column), which turns the panel solve below it and the
-// tile steps of the triangular solves into small matrix products.
-__global__ void __launch_bounds__(64) k_lp_chol_diag(const double *sc, double *S, int n, int kb, const double *diag0, double *Linv) {
-    if (sc[SC_STOP] != 0.0) return;
-    __shared__ double T[kNB][kNB + 1];
-    const int lane = threadIdx.x, base = kb * kNB;
-    for (int r = 0; r < kNB; ++r) T[r][lane] = S[(size_t)(base + r) * n + base + lane];
-    // the lane's own row lives in registers (both loops fully unrolled: every index is a constant), row j is broadcast from LDS
-    double row[kNB];
-#pragma unroll
-    for (int k = 0; k < kNB; ++k) row[k] = T[lane][k];
-    double dg[kNB / 64 + 1];
-    dg[0] = diag0[base + lane];
-#pragma unroll
-    for (int j = 0; j < kNB; ++j) {
-        // (four partial sums: the dot product is a chain of up to 63 dependent f64 FMAs otherwise -- the tile is latency, not work)
-        double a = row[j], a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-        for (int k = 0; k < j; ++k) {
-            const double pr = row[k] * T[j][k];
-            if ((k & 3) == 0) a -= pr; else if ((k & 3) == 1) a1 -= pr; else if ((k & 3) == 2) a2 -= pr; else a3 -= pr;
-        }
-        a += (a1 + a2) + a3;
-        const double aj = __shfl(a, j, 64), d0 = __shfl(dg[0], j, 64);
-        const double ljj = (aj > kLpPivotRel * d0) ? sqrt(aj) : kLpPivotBig;
-        row[j] = lane == j ? ljj : a / ljj;       // (lanes above the diagonal hold garbage nobody reads)
-        T[lane][j] = row[j];
-    }
-    for (int r = 0; r < kNB; ++r) if (lane <= r) S[(size_t)(base + r) * n + base + lane] = T[r][lane];
-    // X = L^-1, column `lane` in registers: x_c = 1 / L_cc, x_i = -(sum_{c <= k < i} L_ik x_k) / L_ii
-    double x[kNB];
-#pragma unroll
-    for (int i = 0; i < kNB; ++i) {
-        double a = i == lane ? 1.0 : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-#pragma unroll
-        for (int k = 0; k < i; ++k) {      // (x[k] = 0 for k < lane)
-            const double pr = T[i][k] * x[k];
-            if ((k & 3) == 0) a -= pr; else if ((k & 3) == 1) a1 -= pr; else if ((k & 3) == 2) a2 -= pr; else a3 -= pr;
-        }
-        a += (a1 + a2) + a3;
-        x[i] = i < lane ? 0.0 : a / T[i][i];
-    }
-    double *out = Linv + (size_t)kb * kNB * kNB;
-#pragma unroll
-    for (int r = 0; r < kNB; ++r) out[r * kNB + lane] = x[r];
-}
-// row tiles below the diagonal tile: X = A L_kk^-T = A Linv^T, a 64 x 64 x 64 product (256 threads, 4 x 4 micro-tiles);
-// written to the lower tile and, transposed, to the upper one
-__global__ void __launch_bounds__(256) k_lp_chol_trsm(const double *sc, double *S, int n, int kb, const double *Linv) {
-    if (sc[SC_STOP] != 0.0) return;
-    __shared__ double Ai[kNB][kNB + 1], Li[kNB][kNB + 1];
-    const int t = threadIdx.x, base = kb * kNB, rt = kb + 1 + blockIdx.x;
-    const double *inv = Linv + (size_t)kb * kNB * kNB;
-    for (int i = t; i < kNB * kNB; i += 256) {
-        Ai[i / kNB][i % kNB] = S[(size_t)(rt * kNB + i / kNB) * n + base + i % kNB];
-        Li[i / kNB][i % kNB] = inv[i];
-    }
-    __syncthreads();
-    const int r0 = (t / 16) * 4, c0 = (t % 16) * 4;
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k = 0; k < kNB; ++k) {
-        double ai[4], li[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { ai[a] = Ai[r0 + a][k]; li[a] = Li[c0 + a][k]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += ai[a] * li[b];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            S[(size_t)(rt * kNB + r0 + a) * n + base + c0 + b] = acc[a][b];
-            S[(size_t)(base + c0 + b) * n + rt * kNB + r0 + a] = acc[a][b];
-        }
-}
-// trailing update A_ij -= L_ik L_jk^T for tile pairs i >= j > kb; 256 threads, 4 x 4 micro-tiles
-__global__ void __launch_bounds__(256) k_lp_chol_update(const double *sc, double *S, int n, int kb, int nrem) {
-    if (sc[SC_STOP] != 0.0) return;
-    __shared__ double Li[kNB][kNB + 1], Lj[kNB][kNB + 1];
-    // decode the pair: blockIdx.x = i * (i + 1) / 2 + j over 0 <= j <= i < nrem
-    int bi = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((bi + 1) * (bi + 2) / 2 <= (int)blockIdx.x) ++bi;
-    while (bi * (bi + 1) / 2 > (int)blockIdx.x) --bi;
-    const int bj = blockIdx.x - bi * (bi + 1) / 2;
-    const int ti_ = kb + 1 + bi, tj = kb + 1 + bj, base = kb * kNB, t = threadIdx.x;
-    for (int i = t; i < kNB * kNB; i += 256) {
-        Li[i / kNB][i % kNB] = S[(size_t)(ti_ * kNB + i / kNB) * n + base + i % kNB];
-        Lj[i / kNB][i % kNB] = S[(size_t)(tj * kNB + i / kNB) * n + base + i % kNB];
-    }
-    __syncthreads();
-    const int r0 = (t / 16) * 4, c0 = (t % 16) * 4;
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k = 0; k < kNB; ++k) {
-        double li[4], lj[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { li[a] = Li[r0 + a][k]; lj[a] = Lj[c0 + a][k]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] += li[a] * lj[b];
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (bi != bj || c0 + b <= r0 + a) S[(size_t)(ti_ * kNB + r0 + a) * n + tj * kNB + c0 + b] -= acc[a][b];   // diagonal tiles: lower triangle only
-}
-// sum_k col[k * n] * xt[k], k < 64: the loads of 16 rows are issued together (written as load phase / multiply phase: left to itself
-// the compiler waits for every load before it issues the next -- 2.1 ms per solve at n = 2112 instead of 0.3)
-__device__ __forceinline__ double trsv_col_dot(const double *__restrict__ col, int n, const double *xt) {
-    double a0 = 0.0, a1 = 0.0;
-#pragma unroll 1
-    for (int k = 0; k < kNB; k += 16) {
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(col + (size_t)(k + u) * n);
-#pragma unroll
-        for (int u = 0; u < 16; u += 2) { a0 += v[u] * xt[k + u]; a1 += v[u + 1] * xt[k + u + 1]; }
-    }
-    return a0 + a1;
-}
-// L z = r then L^T x = z, in place in `r` (length n); one workgroup of 1024, the vector in LDS.  A tile step is x_tile = Linv r_tile
-// (one wavefront) followed by the update of the rest of the vector, whose reads are rows of S on consecutive lanes in both
-// directions (the upper triangle holds L^T).
-__global__ void __launch_bounds__(1024) k_lp_trsv(const double *sc, const double *S, int n, double *r, const double *Linv) {
-    if (sc[SC_STOP] != 0.0) return;
-    extern __shared__ double xv[];
-    __shared__ double Lk[kNB][kNB + 1], xt[kNB];
-    const int t = threadIdx.x, nt = n / kNB;
-    for (int i = t; i < n; i += 1024) xv[i] = r[i];
-    __syncthreads();
-    for (int kb = 0; kb < nt; ++kb) {
-        const int base = kb * kNB;
-        const double *inv = Linv + (size_t)kb * kNB * kNB;
-        for (int i = t; i < kNB * kNB; i += 1024) Lk[i / kNB][i % kNB] = inv[i];
-        __syncthreads();
-        if (t < kNB) { double a = 0.0; for (int k = 0; k <= t; ++k) a += Lk[t][k] * xv[base + k]; xt[t] = a; }
-        __syncthreads();
-        if (t < kNB) xv[base + t] = xt[t];
-        for (int i = base + kNB + t; i < n; i += 1024) xv[i] -= trsv_col_dot(S + (size_t)base * n + i, n, xt);
-        __syncthreads();
-    }
-    for (int kb = nt - 1; kb >= 0; --kb) {
-        const int base = kb * kNB;
-        const double *inv = Linv + (size_t)kb * kNB * kNB;
-        for (int i = t; i < kNB * kNB; i += 1024) Lk[i / kNB][i % kNB] = inv[i];
-        __syncthreads();
-        if (t < kNB) { double a = 0.0; for (int k = t; k < kNB; ++k) a += Lk[k][t] * xv[base + k]; xt[t] = a; }
-        __syncthreads();
-        if (t < kNB) xv[base + t] = xt[t];
-        for (int i = t; i < base; i += 1024) xv[i] -= trsv_col_dot(S + (size_t)base * n + i, n, xt);
-        __syncthreads();
-    }
-    for (int i = t; i < n; i += 1024) r[i] = xv[i];
-}
-
-// The same two solves by one workgroup PER ROW TILE (round 5, second half).  The single workgroup above pulls the whole factor (17 MB at
-// 2,060 rows) through one compute unit's memory path: 0.93 ms, 21 % of an iteration at 100,000 partitions.  Here workgroup i owns row tile
-// i: forward it subtracts L_ij x_j for j = 0 .. i-1 as the x_j are PUBLISHED by their owners (a flag per tile, release / acquire at agent
-// scope; the tile L_ij is loaded into registers before the flag is waited for), then x_i = Linv_ii acc is published; backward the same
-// with j = nt-1 .. i+1 on the tiles of L^T.  The critical path is 2 nt steps of two register-resident 64 x 64 products; everything else
-// runs beside it.  All nt workgroups are resident at once (nt <= 160); a workgroup only ever waits for workgroups that were dispatched
-// before it (forward: lower indices; backward: everyone has started).  Every sum has a fixed order: the same bits on every run.
-// flags[2 nt] are zeroed by a memset in front of the launch; ztmp[n] carries the forward result.
-__global__ void __launch_bounds__(256) k_lp_trsv_mw(const double *sc, const double *S, int n, double *r, const double *Linv, double *ztmp, int *flags) {
-    if (sc[SC_STOP] != 0.0) return;
-    __shared__ double acc[kNB], xj[kNB], part[4][kNB];
-    const int t = threadIdx.x, a = t & 63, kq = t >> 6, i = blockIdx.x, nt = n / kNB;
-    const double *inv = Linv + (size_t)i * kNB * kNB;
-    auto wait_flag = [&](int *f) {
-        if (t == 0) while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
-        __syncthreads();
-    };
-    auto publish = [&](int *f) {   // (the values were written and fenced by the first wavefront; every thread passes the barrier first)
-        __syncthreads();
-        if (t == 0) __hip_atomic_store(f, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    // one tile step: acc[a] -= sum_k tile(a, k) * x[k], this thread's quarter of the k range, tile element (a, k) at base + k * ks + a * as
-    auto tile_load = [&](const double *base, size_t ks, size_t as, double v[16]) {
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(base + (size_t)(kq * 16 + u) * ks + (size_t)a * as);
-    };
-    auto tile_apply = [&](const double v[16], bool subtract) {
-        double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-        for (int u = 0; u < 16; u += 2) { p0 += v[u] * xj[kq * 16 + u]; p1 += v[u + 1] * xj[kq * 16 + u + 1]; }
-        part[kq][a] = p0 + p1;
-        __syncthreads();
-        if (t < kNB) { const double sum = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]); acc[t] = subtract ? acc[t] - sum : sum; }
-        __syncthreads();
-    };
-    // ---- forward: L z = r ----
-    if (t < kNB) acc[t] = r[(size_t)i * kNB + t];
-    __syncthreads();
-    for (int j = 0; j < i; ++j) {
-        double v[16];
-        tile_load(S + (size_t)j * kNB * n + (size_t)i * kNB, (size_t)n, 1, v);        // L[i*64 + a][j*64 + k] from the upper copy: consecutive lanes, consecutive a
-        wait_flag(flags + j);
-        if (t < kNB) xj[t] = __hip_atomic_load(ztmp + (size_t)j * kNB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        tile_apply(v, true);
-    }
-    {
-        double v[16];
-        tile_load(inv, 1, (size_t)kNB, v);                                             // Linv[a][k] (lower triangular: zeros above the diagonal)
-        if (t < kNB) xj[t] = acc[t];
-        __syncthreads();
-        tile_apply(v, false);
-        if (t < kNB) { ztmp[(size_t)i * kNB + t] = acc[t]; __threadfence(); }
-        publish(flags + i);
-    }
-    // ---- backward: L^T x = z ----  (acc holds z_i)
-    for (int j = nt - 1; j > i; --j) {
-        double v[16];
-        tile_load(S + (size_t)j * kNB * n + (size_t)i * kNB, (size_t)n, 1, v);        // L^T[i*64 + a][j*64 + k] = L[j*64 + k][i*64 + a]: the lower triangle itself
-        wait_flag(flags + nt + j);
-        if (t < kNB) xj[t] = __hip_atomic_load(r + (size_t)j * kNB + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        tile_apply(v, true);
-    }
-    {
-        double v[16];
-        tile_load(inv, (size_t)kNB, 1, v);                                             // Linv^T[a][k] = Linv[k][a]
-        if (t < kNB) xj[t] = acc[t];
-        __syncthreads();
-        tile_apply(v, false);
-        if (t < kNB) { r[(size_t)i * kNB + t] = acc[t]; __threadfence(); }
-        publish(flags + nt + i);
-    }
-}
-
 // ---- rows of A z ------------------------------------------------------------------------------------------------------
 // local rows; mode 0: out = A z, 1: out = b - A z, 2: out = A z + add
 __global__ void k_lp_A_local(LpDev D, const double *__restrict__ z, RowVec out, int mode, RowVec add, int gated) {
@@ -1441,8 +1196,7 @@ struct LpCtx {
     double *qd = nullptr, *wr = nullptr; int *qc = nullptr;   // replica columns / rows of the partitions for k_lp_schur_broker (k_lp_factor_local)
     double *rack_part = nullptr;   // [2 R][kRackChunks] slice sums of the rack rows
     int broker_u = 4;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
-    double *xz = nullptr; bool dense_new = true;   // kao_chol.hip (KAO_LP_DENSE=old: round 5's kernels below, for A/B runs)
-    int *trsv_flags = nullptr; double *trsv_z = nullptr; bool trsv_mw = true;   // the triangular solves by one workgroup per row tile (KAO_LP_TRSV_MW=0: by one workgroup)
+    double *xz = nullptr;      // exchange vectors of the triangular solves (kao_chol.hip)
     uint8_t *d_q = nullptr;   // quantised primal iterate (lp_primal)
     int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
     int maxit = 80, trace_cap = 0;
@@ -1526,15 +1280,7 @@ void lp_factor(LpCtx &c) {
 #undef KAO_RACK_MFMA
     hipLaunchKernelGGL(k_lp_schur_fix, dim3((D.mcp + 255) / 256), dim3(256), 0, c.st, D, c.th.zg, c.S, c.diag0);
     hipLaunchKernelGGL(k_lp_schur_fix_cols, dim3((D.mc + 255) / 256), dim3(256), 0, c.st, D, c.S);
-    if (c.dense_new) { chol_enqueue(c.st, D.sc + SC_STOP, c.S, D.mcp, c.diag0, c.Linv); return; }
-    const int nt = D.mcp / kNB;
-    for (int kb = 0; kb < nt; ++kb) {
-        hipLaunchKernelGGL(k_lp_chol_diag, dim3(1), dim3(64), 0, c.st, D.sc, c.S, D.mcp, kb, c.diag0, c.Linv);
-        const int nrem = nt - kb - 1;
-        if (nrem <= 0) break;
-        hipLaunchKernelGGL(k_lp_chol_trsm, dim3(nrem), dim3(256), 0, c.st, D.sc, c.S, D.mcp, kb, c.Linv);
-        hipLaunchKernelGGL(k_lp_chol_update, dim3(nrem * (nrem + 1) / 2), dim3(256), 0, c.st, D.sc, c.S, D.mcp, kb, nrem);
-    }
+    chol_enqueue(c.st, D.sc + SC_STOP, c.S, D.mcp, c.diag0, c.Linv);      // kao_chol.hip
 }
 
 // N dy = rho, in place in `v`: v's local rows hold rho; the coupling right-hand side is GATHERED: rows of A z + the elimination terms (+ add)
@@ -1542,12 +1288,7 @@ void lp_solve_normal(LpCtx &c, const RowVec &v, const VarVec &z, const double *a
     const LpDev &D = c.D;
     hipLaunchKernelGGL(k_lp_elim_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, c.cb, c.cr, gated);
     lp_rows_coupling(c, z, v.rc, add_rc ? 2 : 0, add_rc, c.cb, c.cr, gated);
-    if (c.dense_new) trsv_enqueue(c.st, D.sc + SC_STOP, gated ? D.sc + SC_MCC_GO : nullptr, c.S, D.mcp, v.rc, c.Linv, c.xz);
-    else if (c.trsv_mw) {
-        (void)hipMemsetAsync(c.trsv_flags, 0, sizeof(int) * 2 * (size_t)(D.mcp / kNB), c.st);
-        hipLaunchKernelGGL(k_lp_trsv_mw, dim3(D.mcp / kNB), dim3(256), 0, c.st, D.sc, c.S, D.mcp, v.rc, c.Linv, c.trsv_z, c.trsv_flags);
-    } else
-        hipLaunchKernelGGL(k_lp_trsv, dim3(1), dim3(1024), (size_t)D.mcp * sizeof(double), c.st, D.sc, c.S, D.mcp, v.rc, c.Linv);
+    trsv_enqueue(c.st, D.sc + SC_STOP, gated ? D.sc + SC_MCC_GO : nullptr, c.S, D.mcp, v.rc, c.Linv, c.xz);      // kao_chol.hip
     hipLaunchKernelGGL(k_lp_back_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, v, gated);
 }
 
@@ -1673,11 +1414,9 @@ int lp_open(const kao_topic *t, LpCtx **out) {
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
         (rc = c->alloc(&c->part, std::max((size_t)c->rack_blocks * n2 * n2, (size_t)kRackMfmaBlocks * (2 * 10 * 256 + 64)))) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
-        (rc = c->alloc(&c->trsv_flags, (size_t)2 * (D.mcp / kNB))) || (rc = c->alloc(&c->trsv_z, (size_t)D.mcp)) || (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->qd, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->qc, (size_t)2 * NJ * P)) || (rc = c->alloc(&c->wr, (size_t)4 * NJ * P)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
+        (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->qd, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->qc, (size_t)2 * NJ * P)) || (rc = c->alloc(&c->wr, (size_t)4 * NJ * P)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
         (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
-    { const char *e = std::getenv("KAO_LP_TRSV_MW"); c->trsv_mw = !(e && e[0] == '0') && D.mcp / kNB <= 160; }
-    { const char *e = std::getenv("KAO_LP_DENSE"); c->dense_new = !(e && e[0] == 'o') && D.mcp / kNB <= 160; }
     // dynamic LDS beyond 64 KiB has to be enabled per kernel
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1685,7 +1424,6 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     { const char *e = std::getenv("KAO_LP_RACK"); c->rack_mfma = !(e && e[0] == 'o'); }
     { const char *e = std::getenv("KAO_LP_BROKER_U"); c->broker_u = e ? std::atoi(e) : 4; }   // (round 6, measured at 100,000 partitions: 4.10 / 4.29 / 4.41 ms an iteration with 4 / 8 / 16)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_rack), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_trsv), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     for (const VarVec *vv : {&c->x, &c->s, &c->v, &c->th, &c->rd, &c->h, &c->g, &c->d1, &c->d2, &c->dsa, &c->dva, &c->ds, &c->dv, &c->dc})
         HIP_TRY(hipMemsetAsync(vv->z, 0, nvtot * sizeof(double), c->st));
     for (const RowVec *rv : {&c->y, &c->rp, &c->w1, &c->w2, &c->wc}) HIP_TRY(hipMemsetAsync(rv->r1, 0, (c->rows_local + D.mcp) * sizeof(double), c->st));

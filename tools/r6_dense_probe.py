@@ -1,5 +1,7 @@
 """GPU (round 6): KAO-LP's dense kernels (kao_chol.hip) through the kao_dense_spd_test hook against numpy: factor, diagonal-tile
-inverses, solution; then the interior point with the new kernels against round 5's (KAO_LP_DENSE=old) on drifted topics."""
+inverses, solution; then the interior point on drifted topics with the rack block / broker rows switched between their variants
+(KAO_LP_RACK, KAO_LP_BROKER_U).  (Until commit "remove round 5's dense kernels" the "old" mode also ran round 5's Cholesky and
+triangular solves, KAO_LP_DENSE=old: profiles/r06_c01 / r06_c02 hold those A/B runs.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
