@@ -271,10 +271,12 @@ __global__ void k_lp_theta_g(LpDev D, const double *x, const double *s, const do
 }
 
 // ---- per-partition factor: sig11 sig12 sig22 e5 k1 k2 per replica, d e1 e2 per rack, T^-1 ------------------------------
-// qd[3][2 NJ][P], qc[2 NJ][P], wr[4][NJ][P]: the replica columns of the partition as k_lp_schur_broker needs them (round 6) -- per column
-// 2j (C3 of replica j) / 2j + 1 (C4): v0, v1, eps / d and row | rack << 16 (-1: the replica's broker is not in the target set); and the two
-// rows of replica j premultiplied by T^-1.  The broker kernel used to derive them per incidence through four dependent global round trips.
-__global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double *fr, double *ti, double *__restrict__ qd, int *__restrict__ qc, double *__restrict__ wr) {
+// qd[3][P][ncp], qc[P][ncp], wr[4][NJ][P] (ncp = 0: not wanted): every coupling column of the partition as k_lp_schur_broker needs it
+// (round 6) -- per column c (2j = C3 of replica j, 2j + 1 = C4, then NF[r], NL[r]): v0, v1, eps / d and row | rack << 16 (-1: the replica's
+// broker is not in the target set) -- PARTITION-major, so that the 2 NJ + 2 R lanes of a broker's wavefront read one contiguous run per
+// incidence (the kernel used to derive them per incidence through four dependent round trips of 8-byte gathers: 2.5 GB per launch at
+// 100,000 partitions, each partition three times); and the two rows of replica j premultiplied by T^-1.
+__global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double *fr, double *ti, double *__restrict__ qd, int *__restrict__ qc, double *__restrict__ wr, int ncp) {
     if (LP_STOPPED(D)) return;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.P) return;
@@ -315,6 +317,12 @@ __global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double 
         // 1 / d, e1 / d, e2 / d for the eliminations and back substitutions of the iteration's solves (two to four of each: no division there)
         const double id = 1.0 / d;
         fr[((size_t)3 * R + r) * P + p] = id; fr[((size_t)4 * R + r) * P + p] = e1 * id; fr[((size_t)5 * R + r) * P + p] = e2 * id;
+        if (ncp) {   // the rack's two columns NF[r], NL[r]
+            const double cyf = th[(size_t)VYF(D, r) * P + p], cyl = th[(size_t)VYL(D, r) * P + p];
+            const size_t pn = (size_t)P * ncp, kf = (size_t)p * ncp + 2 * NJ + 2 * r, kl = kf + 1;
+            qd[kf] = cyf - cyf * (e1 * id); qd[pn + kf] = 0.0 - cyf * (e2 * id); qd[2 * pn + kf] = cyf * id; qc[kf] = RNF(D, r) | (r << 16);
+            qd[kl] = cyl - cyl * (e1 * id); qd[pn + kl] = cyl - cyl * (e2 * id); qd[2 * pn + kl] = cyl * id; qc[kl] = RNL(D, r) | (r << 16);
+        }
     }
     double i11, i12, i22;   // guarded pivots: C1 is a dependent row when the C7 rows carry no slack (oracle/kao_lp_port.c)
     if (!(m11 > kLpPivotRel * o11)) { i11 = 0; i12 = 0; i22 = m22 > kLpPivotRel * o22 ? 1.0 / m22 : 0.0; }
@@ -324,10 +332,11 @@ __global__ void k_lp_factor_local(LpDev D, const double *th, double *fj, double 
         else { i22 = 1.0 / p2; i12 = -l21 * i22; i11 = 1.0 / m11 + l21 * l21 * i22; }
     }
     ti[(size_t)0 * P + p] = i11; ti[(size_t)1 * P + p] = i12; ti[(size_t)2 * P + p] = i22;
-    const size_t cs = (size_t)2 * NJ * P;      // stride between the three planes of qd
+    if (!ncp) return;
+    const size_t cs = (size_t)P * ncp;      // stride between the three planes of qd
     for (int j = 0; j < NJ; ++j) {
         const int b = cur_b(D, p, j);
-        const size_t k3 = (size_t)(2 * j) * P + p, k4 = (size_t)(2 * j + 1) * P + p;
+        const size_t k3 = (size_t)p * ncp + 2 * j, k4 = k3 + 1;
         if (b < 0) {
             qc[k3] = -1; qc[k4] = -1;
             qd[k3] = 0.0; qd[cs + k3] = 0.0; qd[2 * cs + k3] = 0.0; qd[k4] = 0.0; qd[cs + k4] = 0.0; qd[2 * cs + k4] = 0.0;
@@ -396,13 +405,9 @@ __global__ void __launch_bounds__(256) k_lp_schur_broker(LpDev D, const double *
         // order: the same bits on every run.
         const int e1 = D.inc_off[b + 1];
         const int c = lane;
-        const bool is_cur = c < 2 * NJ, has_col = c < nc;
-        const int rc_ = is_cur ? 0 : min((c - 2 * NJ) >> 1, R - 1), odd = c & 1;
-        const size_t cs = (size_t)2 * NJ * P;
-        const double *__restrict__ cyp = th + (size_t)(odd ? VYL(D, rc_) : VYF(D, rc_)) * P;
-        const double *__restrict__ idp = fr + ((size_t)3 * R + rc_) * P, *__restrict__ f1p = fr + ((size_t)4 * R + rc_) * P, *__restrict__ f2p = fr + ((size_t)5 * R + rc_) * P;
-        const int ccl = is_cur ? c : 0;
-        const int rcol = odd ? RNL(D, rc_) : RNF(D, rc_);
+        const bool has_col = c < nc;
+        const int ncp = (nc + 7) & ~7, cl = has_col ? c : 0;
+        const size_t cs = (size_t)P * ncp;
         for (int e = D.inc_off[b]; e < e1; e += U) {
             int pp[U], j0[U]; bool live[U];
 #pragma unroll
@@ -415,16 +420,10 @@ __global__ void __launch_bounds__(256) k_lp_schur_broker(LpDev D, const double *
                 w30[u] = wr[((size_t)0 * NJ + j0[u]) * P + p]; w31[u] = wr[((size_t)1 * NJ + j0[u]) * P + p];
                 w40[u] = wr[((size_t)2 * NJ + j0[u]) * P + p]; w41[u] = wr[((size_t)3 * NJ + j0[u]) * P + p];
                 s11[u] = fj[((size_t)0 * NJ + j0[u]) * P + p]; s12[u] = fj[((size_t)1 * NJ + j0[u]) * P + p]; s22[u] = fj[((size_t)2 * NJ + j0[u]) * P + p];
-                if (is_cur) {
-                    const size_t k = (size_t)ccl * P + p;
-                    q0[u] = qd[k]; q1[u] = qd[cs + k]; qe[u] = qd[2 * cs + k];
-                    const int w = qc[k];
-                    col[u] = w < 0 ? -1 : (w & 0xFFFF); rk[u] = w < 0 ? -1 : (w >> 16);
-                } else {
-                    const double cy = cyp[p];
-                    q0[u] = cy - cy * f1p[p]; q1[u] = (odd ? cy : 0.0) - cy * f2p[p]; qe[u] = cy * idp[p];
-                    col[u] = has_col ? rcol : -1; rk[u] = rc_;
-                }
+                const size_t k = (size_t)p * ncp + cl;      // consecutive lanes, consecutive columns of the partition
+                q0[u] = qd[k]; q1[u] = qd[cs + k]; qe[u] = qd[2 * cs + k];
+                const int w = qc[k];
+                col[u] = (w < 0 || !has_col) ? -1 : (w & 0xFFFF); rk[u] = w < 0 ? -1 : (w >> 16);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1193,7 +1192,7 @@ struct LpCtx {
     int32_t *d_mult = nullptr, *d_zq = nullptr;
     VarVec dc{}; RowVec wc{}; int mcc = 2;   // centrality correctors per iteration (KAO_LP_MCC; 0: none) and their direction / row vector
     bool rack_mfma = true;         // the rack x rack block of the Schur complement on the matrix cores (2R <= 64; KAO_LP_RACK=old: the LDS-tiled kernel)
-    double *qd = nullptr, *wr = nullptr; int *qc = nullptr;   // replica columns / rows of the partitions for k_lp_schur_broker (k_lp_factor_local)
+    double *qd = nullptr, *wr = nullptr; int *qc = nullptr; int ncp = 0;   // the partitions' coupling columns / replica rows for k_lp_schur_broker (k_lp_factor_local); ncp = columns per partition, padded (0: more than 64, not kept)
     double *rack_part = nullptr;   // [2 R][kRackChunks] slice sums of the rack rows
     int broker_u = 4;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
     double *xz = nullptr;      // exchange vectors of the triangular solves (kao_chol.hip)
@@ -1259,7 +1258,7 @@ void lp_rows_coupling(LpCtx &c, const VarVec &z, double *out_rc, int mode, const
 
 void lp_factor(LpCtx &c) {
     const LpDev &D = c.D;
-    hipLaunchKernelGGL(k_lp_factor_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr);
+    hipLaunchKernelGGL(k_lp_factor_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.ncp);
     const size_t lds_b = (size_t)c.broker_waves * 2 * D.mc * sizeof(double);
     const dim3 bg((D.B + c.broker_waves - 1) / c.broker_waves), bb(64 * c.broker_waves);
     if (c.broker_u >= 16) hipLaunchKernelGGL(k_lp_schur_broker<16>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
@@ -1409,12 +1408,13 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     c->rack_chunk = std::max(c->rack_tile, ((P + 255) / 256 + c->rack_tile - 1) / c->rack_tile * c->rack_tile);   // about 256 blocks
     c->rack_blocks = (P + c->rack_chunk - 1) / c->rack_chunk;
     c->trace_cap = 512;
+    c->ncp = 2 * NJ + 2 * R <= 64 ? (2 * NJ + 2 * R + 7) & ~7 : 0;
     if ((rc = c->alloc(&c->fj, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->fr, (size_t)6 * R * P)) || (rc = c->alloc(&c->ti, (size_t)3 * P)) ||
         (rc = c->alloc(&c->S, (size_t)D.mcp * D.mcp)) || (rc = c->alloc(&c->Linv, (size_t)D.mcp * kNB)) || (rc = c->alloc(&c->diag0, (size_t)D.mcp)) || (rc = c->alloc(&c->cb, (size_t)2 * NJ * P)) ||
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
         (rc = c->alloc(&c->part, std::max((size_t)c->rack_blocks * n2 * n2, (size_t)kRackMfmaBlocks * (2 * 10 * 256 + 64)))) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
-        (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->qd, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->qc, (size_t)2 * NJ * P)) || (rc = c->alloc(&c->wr, (size_t)4 * NJ * P)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
+        (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->qd, (size_t)3 * c->ncp * P)) || (rc = c->alloc(&c->qc, (size_t)c->ncp * P)) || (rc = c->alloc(&c->wr, (size_t)4 * NJ * P)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
         (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
     // dynamic LDS beyond 64 KiB has to be enabled per kernel
