@@ -313,6 +313,17 @@ int kao_lp_round_host(const kao_topic *t, const uint8_t *q, const int32_t *zq, i
  * [64][64] = the inverses of L's diagonal tiles, x[n] = the solution of A x = rhs (rhs NULL: all ones), ms[2] = HIP-event milliseconds of
  * the factorisation and of the two triangular solves (second of two runs).  Any output may be NULL. */
 int kao_dense_spd_test(const double *A, int32_t n, const double *rhs, double *factor, double *linv, double *x, double ms[2]);
+/* Test hook (round 6): the LP of ONE topic solved by n_dev SHARDS -- shard r holds the partitions [P r / n_dev, P (r + 1) / n_dev) with their
+ * variables and local rows; the 3R + 2B coupling rows and the global variables are replicated; per interior-point iteration the shards'
+ * parts of the Schur complement meet in one all-reduce (f64 sum), the coupling right-hand sides in one per solve, the scalar records of the
+ * reductions in one each; the Cholesky and the triangular solves run replicated.  `devices` may repeat a device with KAO_RCCL_LOOPBACK=1
+ * (logical shards through the loop-back table); distinct devices go through RCCL.  pert as kao_lp_round (0: its default; < 0: the model's
+ * own LP).  *bound = the certificate (K-bound's integer dual value at the common row duals), assignment / objective / violations = the
+ * rounded iterate as kao_lp_round (assignment may be NULL), stats[8] = {iterations, status, fractional partitions, collectives issued,
+ * README objective of the dual iterate, milliseconds of the solve, milliseconds of certificate + rounding, perturbation}.
+ * NOT scheduled by kao_solve_multi (which races whole solves on a replicated large topic) and unmeasured on more than one GPU. */
+int kao_lp_sharded_test(const kao_topic *t, const int32_t *devices, int32_t n_dev, double pert, uint32_t salt, double tol, int32_t max_iters,
+                        int64_t *bound, uint16_t *assignment, int64_t *objective, int32_t violations[8], double stats[8]);
 /* One-shot K-bound on one topic: `launches` launches of `iters` iterations towards `target`.
  * *bound = floor(best dual / 65536) (not combined with kao_upper_bound); multipliers, if not NULL, receives
  * a[n_brokers], l[n_brokers], g[n_racks]. */

@@ -82,6 +82,8 @@ SIGNATURES = {
     "kao_lp_round": (C.c_int, [_P(KaoTopic), C.c_double, C.c_uint32, C.c_double, C.c_int32, C.c_int32, _P(C.c_uint16), _P(C.c_int64), _P(C.c_int32), _P(C.c_double)]),
     "kao_lp_round_host": (C.c_int, [_P(KaoTopic), _P(C.c_uint8), _P(C.c_int32), C.c_int32, _P(C.c_uint16), _P(C.c_int32)]),
     "kao_dense_spd_test": (C.c_int, [_P(C.c_double), C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    "kao_lp_sharded_test": (C.c_int, [_P(KaoTopic), _P(C.c_int32), C.c_int32, C.c_double, C.c_uint32, C.c_double, C.c_int32, _P(C.c_int64), _P(C.c_uint16),
+                                      _P(C.c_int64), _P(C.c_int32), _P(C.c_double)]),
     "kao_lp_trace": (C.c_int, [_P(KaoTopic), C.c_double, C.c_int32, _P(C.c_double), _P(C.c_double), _P(C.c_int32)]),
     "kao_dual_bound": (C.c_int, [_P(KaoTopic), C.c_int64, C.c_int32, C.c_int32, _P(C.c_int64), _P(C.c_int64), _P(C.c_int32),
                                  _P(C.c_int32), _P(C.c_int32)]),

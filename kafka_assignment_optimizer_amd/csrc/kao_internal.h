@@ -181,7 +181,17 @@ void launch_canon(const TopicDev *topic, const uint32_t *cur_words, const uint16
 
 // ---- KAO-LP (kao_lp.hip): interior-point solve of the compact LP relaxation; its row duals are multipliers for K-bound ----
 struct LpCtx;
-int lp_open(const kao_topic *t, LpCtx **out);
+// One LP over several devices (round 6): every shard holds a contiguous range of the topic's partitions; the coupling rows and the global
+// variables are replicated.  The sums over the partitions meet through `coll` at fixed points of the iteration (the Schur complement once
+// per factorisation, the coupling right-hand side once per solve, the scalar records of the reductions): every shard calls allreduce with
+// its own rank, buffer and stream; the call returns once the collective is ENQUEUED on every shard's stream (kao_solve.cpp: RCCL, or the
+// loop-back table on logical shards).  Sums are taken in rank order, so all shards hold the same bits afterwards.
+struct LpColl {
+    virtual int allreduce(int rank, double *buf, size_t n, bool is_min, void *stream) = 0;
+    virtual ~LpColl() {}
+};
+struct LpShard { int p0, p1, rank; LpColl *coll; };
+int lp_open(const kao_topic *t, LpCtx **out, const LpShard *shard = nullptr);
 // multipliers (host): a[B] l[B] g[R] in K-bound's fixed point; stats[8], trace: see kao_lp.hip
 int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace, double pert = 0.0, uint32_t salt = 0);   // one shot
 // incremental (kao_solve runs the iterations beside K-search): begin, enqueue k iterations (asynchronous, no host round trip inside),

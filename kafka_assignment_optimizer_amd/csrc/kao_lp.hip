@@ -46,6 +46,10 @@ constexpr int kVarBlocks = 2048;   // workgroups (= records) of the reductions o
 
 struct LpDev {
     int P, B, R, NJ, RF, NV, GV, mc, mcp;    // mcp = mc rounded up to the Cholesky tile (padding rows are identity)
+    // A SHARD of one LP (round 6, lp_open with an LpShard): the context holds the partitions p0 .. p0 + P - 1 of a topic of Pg partitions;
+    // the coupling rows and the global variables are replicated on every shard, their own terms are counted by shard 0 only, and the
+    // sums over the partitions meet through LpColl::allreduce.  A whole topic is the shard (p0 = 0, Pg = P, shard = 0).
+    int Pg, p0, shard;
     int has_c5, has_t, t_ub, has_n, has_m, has_k, n_ub, m_ub, k_ub, phi;
     const uint16_t *cur;        // [P*NJ] dense broker or KAO_NONE
     const uint8_t *rack;        // [B]
@@ -113,7 +117,7 @@ __device__ __forceinline__ double pert_term(const LpDev &D, uint32_t i) {
     return eps > 0.0 ? eps * pert_hash(i, (uint32_t)D.sc[SC_SALT]) : 0.0;
 }
 __device__ __forceinline__ double var_cost(const LpDev &D, int v, int p) {   // of a PRESENT variable
-    const double pt = pert_term(D, (uint32_t)((size_t)v * D.P + p));
+    const double pt = pert_term(D, (uint32_t)((size_t)v * D.Pg + D.p0 + p));
     if (v >= 3 * D.NJ) return pt;
     const int k = v % 3;
     return (k == 2 ? 0.0 : D.c[(size_t)(2 * (v / 3) + k) * D.P + p]) + pt;
@@ -459,7 +463,7 @@ __global__ void __launch_bounds__(256) k_lp_schur_broker(LpDev D, const double *
             rowA[q.col] += v3; rowB[q.col] += v4;
         }
     }
-    if (lane == 0) {   // the broker's own global variables
+    if (lane == 0 && D.shard == 0) {   // the broker's own global variables
         const double zf = thg[b], zl = thg[D.B + b], tn = D.has_n ? thg[2 * D.B + b] : 0.0, tm = D.has_m ? thg[3 * D.B + b] : 0.0;
         rowA[RC3(D, b)] += zf + zl + tn;
         rowB[RC3(D, b)] += zl;
@@ -530,7 +534,7 @@ __global__ void k_lp_schur_rack_sum(LpDev D, const double *part, int nblk, const
     if (c > a) return;
     double s = 0.0;
     for (int i = 0; i < nblk; ++i) s += part[(size_t)i * ne + e];
-    if (a == c) {   // the racks' own inflow variables: NF[r] += sum zf, NL[r] += sum zl over the rack's brokers (in order)
+    if (a == c && D.shard == 0) {   // the racks' own inflow variables: NF[r] += sum zf, NL[r] += sum zl over the rack's brokers (in order)
         const int r = a % D.R;
         for (int i = D.rk_off[r]; i < D.rk_off[r + 1]; ++i) s += thg[(a < D.R ? 0 : D.B) + D.rk_mem[i]];
     }
@@ -651,11 +655,24 @@ __global__ void __launch_bounds__(256) k_lp_schur_rack_sum2(LpDev D, const doubl
     s = 0.0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += sl[el][q];
-    if (a == c) {   // the racks' own inflow variables: NF[r] += sum zf, NL[r] += sum zl over the rack's brokers (in order)
+    if (a == c && D.shard == 0) {   // the racks' own inflow variables: NF[r] += sum zf, NL[r] += sum zl over the rack's brokers (in order)
         const int r = a % D.R;
         for (int i = D.rk_off[r]; i < D.rk_off[r + 1]; ++i) s += thg[(a < D.R ? 0 : D.B) + D.rk_mem[i]];
     }
     S[(size_t)a * D.mcp + c] = s;
+}
+// A shard's part of S travels PACKED (round 6): the rows 0 .. mc-1 of the lower triangle, row i at offset i (i + 1) / 2 -- half the bytes of the
+// square the all-reduce would otherwise carry (17 instead of 34 MB at 2,060 rows).  multigpu.py tri_pack / tri_unpack restate the index map.
+__global__ void k_lp_tri_pack(LpDev D, const double *S, double *tri, int unpack, double *S_out) {
+    if (LP_STOPPED(D)) return;
+    const size_t n = (size_t)D.mc * (D.mc + 1) / 2;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        size_t i = (size_t)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= e) ++i;
+        while (i * (i + 1) / 2 > e) --i;
+        const size_t j = e - i * (i + 1) / 2;
+        if (unpack) S_out[i * D.mcp + j] = tri[e]; else tri[e] = S[i * D.mcp + j];
+    }
 }
 // rows C6[r] (columns NF, NL: none; own diagonal: sum n + k), regularisation, absent / pinned rows, padding; saves the diagonal
 __global__ void k_lp_schur_fix(LpDev D, const double *thg, double *S, double *diag0) {
@@ -736,9 +753,13 @@ __global__ void k_lp_A_broker(LpDev D, const double *z, const double *zg, const 
     }
     for (int o = 32; o > 0; o >>= 1) { s3 += __shfl_xor(s3, o, 64); s4 += __shfl_xor(s4, o, 64); }
     if (lane) return;
+    const int r3 = RC3(D, b), r4 = RC4(D, b);
+    if (D.shard != 0) {   // a further shard contributes its partitions' sums only (sign of mode 1); shard 0 carries the global variables and the affine parts
+        rc[r3] = mode == 1 ? -s3 : s3; rc[r4] = mode == 1 ? -s4 : s4;
+        return;
+    }
     s3 += zg[b] + zg[D.B + b] - (D.has_n ? zg[2 * D.B + b] : 0.0);
     s4 += zg[D.B + b] - (D.has_m ? zg[3 * D.B + b] : 0.0);
-    const int r3 = RC3(D, b), r4 = RC4(D, b);
     rc[r3] = mode == 1 ? D.bc[r3] - s3 : (mode == 2 ? s3 + addc[r3] : s3);
     rc[r4] = mode == 1 ? D.bc[r4] - s4 : (mode == 2 ? s4 + addc[r4] : s4);
 }
@@ -767,16 +788,17 @@ __global__ void __launch_bounds__(64) k_lp_A_rack_fin(LpDev D, const double *par
     const int R = D.R, row = blockIdx.x, lane = threadIdx.x;
     const int r = row % R, kind = row / R;
     double s = 0.0;
+    const bool own = D.shard == 0;
     if (kind < 2) {
         if (lane < kRackChunks) s = part[row * kRackChunks + lane];
-        for (int e = D.rk_off[r] + lane; e < D.rk_off[r + 1]; e += 64) s -= zg[(kind == 0 ? 0 : D.B) + D.rk_mem[e]];
-    } else if (D.has_n) {
+        if (own) for (int e = D.rk_off[r] + lane; e < D.rk_off[r + 1]; e += 64) s -= zg[(kind == 0 ? 0 : D.B) + D.rk_mem[e]];
+    } else if (D.has_n && own) {
         for (int e = D.rk_off[r] + lane; e < D.rk_off[r + 1]; e += 64) s += zg[2 * D.B + D.rk_mem[e]];
         if (D.has_k && lane == 0) s -= zg[4 * D.B + r];
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane) return;
-    double out = mode == 1 ? D.bc[row] - s : (mode == 2 ? s + addc[row] : s);
+    double out = own ? (mode == 1 ? D.bc[row] - s : (mode == 2 ? s + addc[row] : s)) : (mode == 1 ? -s : s);
     if (D.rowc[row] != 1) out = 0.0;      // absent / pinned rows carry no residual and no right-hand side
     rc[row] = out;
 }
@@ -944,8 +966,11 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVe
             if (gvar_present(D, g)) {
                 const double u = gvar_ub(D, g), c = gvar_cost(D, g);
                 const double r = c - at_val_g(D, g, y.rc) - s.zg[g] + v.zg[g];
-                rd.zg[g] = r; a[0] += r * r; a[1] += x.zg[g] * s.zg[g]; a[2] += c * x.zg[g];
-                if (u > 0) { a[1] += (u - x.zg[g]) * v.zg[g]; a[3] += u * v.zg[g]; }
+                rd.zg[g] = r;
+                if (D.shard == 0) {
+                    a[0] += r * r; a[1] += x.zg[g] * s.zg[g]; a[2] += c * x.zg[g];
+                    if (u > 0) { a[1] += (u - x.zg[g]) * v.zg[g]; a[3] += u * v.zg[g]; }
+                }
             } else rd.zg[g] = 0.0;
         }
     }
@@ -1112,7 +1137,7 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_muaff(LpDev D, VarVec x, VarVe
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv + D.GV; i += stride) {
         bool on; double u;
         if (i < nv) { const int vv = (int)(i / D.P), p = (int)(i % D.P); on = var_present(D, vv, p); u = var_ub(D, vv); }
-        else { const int k = (int)(i - nv); on = gvar_present(D, k); u = gvar_ub(D, k); }
+        else { const int k = (int)(i - nv); on = gvar_present(D, k) && D.shard == 0; u = gvar_ub(D, k); }
         if (!on) continue;
         a[0] += (x.z[i] + ap * dx.z[i]) * (s.z[i] + ad * ds.z[i]);
         if (u > 0) a[0] += (u - x.z[i] - ap * dx.z[i]) * (v.z[i] + ad * dv.z[i]);
@@ -1196,6 +1221,11 @@ struct LpCtx {
     double *rack_part = nullptr;   // [2 R][kRackChunks] slice sums of the rack rows
     int broker_u = 4;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
     double *xz = nullptr;      // exchange vectors of the triangular solves (kao_chol.hip)
+    double *tri = nullptr;     // a shard's packed lower triangle of S for the all-reduce
+    LpColl *coll = nullptr; int rank = 0;   // a shard of one LP over several devices (kao_internal.h LpShard); null: the whole topic
+    int coll_rc = KAO_OK;      // first failure of a collective (checked by lp_enqueue / lp_begin)
+    void all_sum(double *buf, size_t n) { if (coll && !coll_rc) coll_rc = coll->allreduce(rank, buf, n, false, st); }
+    void all_min(double *buf, size_t n) { if (coll && !coll_rc) coll_rc = coll->allreduce(rank, buf, n, true, st); }
     uint8_t *d_q = nullptr;   // quantised primal iterate (lp_primal)
     int nblk_var = 0, nblk_p = 0, rack_chunk = 0, rack_tile = 0, rack_blocks = 0, broker_waves = 0;
     int maxit = 80, trace_cap = 0;
@@ -1243,6 +1273,7 @@ namespace {
 
 void lp_reduce(LpCtx &c, int nrec, int n, bool is_min, double *out) {
     hipLaunchKernelGGL(k_lp_red_final, dim3(1), dim3(kRedBlock), 0, c.st, c.D.sc, c.rec, nrec, n, is_min ? 1 : 0, out);
+    if (is_min) c.all_min(out, (size_t)n); else c.all_sum(out, (size_t)n);
 }
 // local rows of A z into `out` (mode 0 plain, 1 = b - A z, 2 = A z + add)
 void lp_rows_local(LpCtx &c, const VarVec &z, const RowVec &out, int mode, const RowVec &add, int gated = 0) {
@@ -1254,6 +1285,7 @@ void lp_rows_coupling(LpCtx &c, const VarVec &z, double *out_rc, int mode, const
     hipLaunchKernelGGL(k_lp_A_broker, dim3((D.B + 3) / 4), dim3(256), 0, c.st, D, z.z, z.zg, cb, out_rc, mode, add_rc, gated);
     hipLaunchKernelGGL(k_lp_A_rack_part, dim3(2 * D.R * kRackChunks), dim3(kRedBlock), 0, c.st, D, z.z, cr, c.rack_part, gated);
     hipLaunchKernelGGL(k_lp_A_rack_fin, dim3(3 * D.R), dim3(64), 0, c.st, D, c.rack_part, z.zg, out_rc, mode, add_rc, gated);
+    c.all_sum(out_rc, (size_t)D.mc);
 }
 
 void lp_factor(LpCtx &c) {
@@ -1277,6 +1309,12 @@ void lp_factor(LpCtx &c) {
         hipLaunchKernelGGL(k_lp_schur_rack_sum, sg, sb, 0, c.st, D, c.part, c.rack_blocks, c.th.zg, c.S);
     }
 #undef KAO_RACK_MFMA
+    if (c.coll) {   // shards: every shard gathered its own partitions' part of the lower triangle; the parts meet packed
+        const size_t ntri = (size_t)D.mc * (D.mc + 1) / 2;
+        hipLaunchKernelGGL(k_lp_tri_pack, dim3(1024), dim3(256), 0, c.st, D, c.S, c.tri, 0, c.S);
+        c.all_sum(c.tri, ntri);
+        hipLaunchKernelGGL(k_lp_tri_pack, dim3(1024), dim3(256), 0, c.st, D, c.S, c.tri, 1, c.S);
+    }
     hipLaunchKernelGGL(k_lp_schur_fix, dim3((D.mcp + 255) / 256), dim3(256), 0, c.st, D, c.th.zg, c.S, c.diag0);
     hipLaunchKernelGGL(k_lp_schur_fix_cols, dim3((D.mc + 255) / 256), dim3(256), 0, c.st, D, c.S);
     chol_enqueue(c.st, D.sc + SC_STOP, c.S, D.mcp, c.diag0, c.Linv);      // kao_chol.hip
@@ -1308,20 +1346,24 @@ void lp_enqueue_resid(LpCtx &c) {
 }  // namespace
 
 // Builds the device image of one topic's compact LP.
-int lp_open(const kao_topic *t, LpCtx **out) {
+int lp_open(const kao_topic *t, LpCtx **out, const LpShard *shard) {
     int rc = require_init();
     if (rc) return rc;
     rc = validate(t);
     if (rc) return rc;
     int32_t bd[8];
     derive_bounds(t, bd);
-    const int P = t->n_partitions, B = t->n_brokers, R = t->n_racks, NJ = t->rf_cur;
+    const int Pg = t->n_partitions, p0 = shard ? shard->p0 : 0, P = shard ? shard->p1 - shard->p0 : Pg;   // this context's partitions: p0 .. p0 + P - 1
+    if (shard && (p0 < 0 || P < 1 || shard->p1 > Pg || !shard->coll)) return fail(KAO_ERR_INVALID, "KAO-LP: bad shard");
+    const int B = t->n_brokers, R = t->n_racks, NJ = t->rf_cur;
     const int mc = 3 * R + 2 * B;
     if ((size_t)2 * mc * sizeof(double) > 150 * 1024) return fail(KAO_ERR_UNSUPPORTED, "KAO-LP: more than ~4,700 brokers (a Schur row pair must fit LDS)");
     if (NJ > 8 || NJ < 1 || P >= (1 << 28)) return fail(KAO_ERR_UNSUPPORTED, "KAO-LP: current RF outside 1..8");
     LpCtx *c = new LpCtx();
     c->device = cur_device();
     LpDev &D = c->D;
+    D.Pg = Pg; D.p0 = p0; D.shard = shard ? shard->rank : 0;
+    c->coll = shard ? shard->coll : nullptr; c->rank = shard ? shard->rank : 0;
     D.P = P; D.B = B; D.R = R; D.NJ = NJ; D.RF = t->rf; D.NV = 3 * NJ + 3 * R; D.GV = 4 * B + R; D.mc = mc; D.mcp = (mc + kNB - 1) / kNB * kNB;
     D.phi = bd[7];
     D.has_c5 = bd[7] >= 2; D.has_t = bd[7] > bd[6]; D.t_ub = (D.has_t && bd[6] > 0) ? bd[7] - bd[6] : 0;
@@ -1338,7 +1380,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_sc), sizeof(double) * kScN * 33) != hipSuccess) return bail(fail(KAO_ERR_NOMEM, "KAO-LP: pinned buffer"));
     for (hipEvent_t &e : c->ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(fail(KAO_ERR_HIP, "KAO-LP: event"));
     // structure
-    std::vector<uint16_t> cur(t->current, t->current + (size_t)P * NJ);
+    std::vector<uint16_t> cur(t->current + (size_t)p0 * NJ, t->current + (size_t)(p0 + P) * NJ);
     std::vector<uint8_t> rack(t->rack_of, t->rack_of + B);
     std::vector<int> inc_off((size_t)B + 1, 0), rk_off((size_t)R + 1, 0), rsz((size_t)R, 0);
     for (int p = 0; p < P; ++p)
@@ -1361,12 +1403,19 @@ int lp_open(const kao_topic *t, LpCtx **out) {
             const int cr = j == 0 ? 0 : 1, bw = t->broker_w ? t->broker_w[b] : 0, bwl = t->broker_wl ? t->broker_wl[b] : 0;
             const double cf = -(double)(t->w[cr][1] + bw), cl = -(double)(t->w[cr][0] + bw + bwl);
             cost[(size_t)(2 * j) * P + p] = cf; cost[(size_t)(2 * j + 1) * P + p] = cl;
+        }
+    for (int p = 0; p < Pg; ++p)      // the normalisers of the stopping test count the WHOLE topic (a shard stops when the topic's solve does)
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned b = t->current[(size_t)p * NJ + j];
+            if (b == KAO_NONE || (int)b >= B) continue;
+            const int cr = j == 0 ? 0 : 1, bw = t->broker_w ? t->broker_w[b] : 0, bwl = t->broker_wl ? t->broker_wl[b] : 0;
+            const double cf = -(double)(t->w[cr][1] + bw), cl = -(double)(t->w[cr][0] + bw + bwl);
             ncn += cf * cf + cl * cl;
             nvar += 2 + (D.has_c5 ? 1 : 0);
             if (D.has_c5) nbn += 1.0;
         }
-    nvar += (long)P * R * (2 + (D.has_t ? 1 : 0));
-    if (D.t_ub) nub += (long)P * R;
+    nvar += (long)Pg * R * (2 + (D.has_t ? 1 : 0));
+    if (D.t_ub) nub += (long)Pg * R;
     for (int b = 0; b < B; ++b) {
         const int bw = t->broker_w ? t->broker_w[b] : 0, bwl = t->broker_wl ? t->broker_wl[b] : 0;
         cg[(size_t)b] = -(double)bw; cg[(size_t)B + b] = -(double)(bw + bwl);
@@ -1383,7 +1432,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
     }
     if (!D.has_n) rowc[0] = 2;                 // exact row dependencies (oracle/kao_lp_port.c): NF[0] / NL[0] pinned
     if (!D.has_m) rowc[(size_t)R] = 2;
-    nbn += (double)P * t->rf * t->rf + (double)P + (double)P * R * bd[7] * bd[7];
+    nbn += (double)Pg * t->rf * t->rf + (double)Pg + (double)Pg * R * bd[7] * bd[7];
     for (double q : bc) nbn += q * q;
     c->nvar = nvar; c->nub = nub; c->nb = 1.0 + std::sqrt(nbn); c->ncn = 1.0 + std::sqrt(ncn);
     uint16_t *d_cur; uint8_t *d_rack; int *d_io, *d_inc, *d_ro, *d_rm; double *d_c, *d_cg, *d_bc; unsigned char *d_rowc;
@@ -1414,7 +1463,7 @@ int lp_open(const kao_topic *t, LpCtx **out) {
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
         (rc = c->alloc(&c->part, std::max((size_t)c->rack_blocks * n2 * n2, (size_t)kRackMfmaBlocks * (2 * 10 * 256 + 64)))) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
-        (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->qd, (size_t)3 * c->ncp * P)) || (rc = c->alloc(&c->qc, (size_t)c->ncp * P)) || (rc = c->alloc(&c->wr, (size_t)4 * NJ * P)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
+        (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->tri, shard ? (size_t)mc * (mc + 1) / 2 : 1)) || (rc = c->alloc(&c->qd, (size_t)3 * c->ncp * P)) || (rc = c->alloc(&c->qc, (size_t)c->ncp * P)) || (rc = c->alloc(&c->wr, (size_t)4 * NJ * P)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
         (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
     // dynamic LDS beyond 64 KiB has to be enabled per kernel
@@ -1485,7 +1534,7 @@ int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
     hipLaunchKernelGGL(k_lp_start, gv, b256, 0, c.st, D, c.y, c.x.z, c.x.zg, c.s.z, c.s.zg, c.v.z, c.v.zg);
     lp_enqueue_resid(c);
     HIP_TRY(hipGetLastError());
-    return KAO_OK;
+    return c.coll_rc;
 }
 
 // Enqueues `k` iterations (each: factor, predictor, corrector, update, residuals + stopping test of the new iterate).  Asynchronous;
@@ -1536,7 +1585,7 @@ int lp_enqueue(LpCtx *cp, int k) {
     if (!c.graph_tried) {   // capture one iteration (KAO_LP_GRAPH=0: plain launches)
         c.graph_tried = true;
         const char *e = std::getenv("KAO_LP_GRAPH");
-        if (!(e && e[0] == '0') && hipStreamBeginCapture(c.st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        if (!(e && e[0] == '0') && !c.coll && hipStreamBeginCapture(c.st, hipStreamCaptureModeThreadLocal) == hipSuccess) {   // (a shard's iteration holds collectives: plain launches)
             lp_enqueue_one(c);
             hipGraph_t g = nullptr;
             if (hipStreamEndCapture(c.st, &g) == hipSuccess && g) {
@@ -1552,7 +1601,7 @@ int lp_enqueue(LpCtx *cp, int k) {
     }
     c.enqueued += k;
     HIP_TRY(hipGetLastError());
-    return KAO_OK;
+    return c.coll_rc;
 }
 
 // lp_enqueue + a MARK: behind the k iterations the scalars are copied to ring slot `slot` (0..31) and an event is recorded.  lp_poll_mark

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 #include "kao_host.h"
 
@@ -961,11 +963,11 @@ struct Rccl {
 // box that has one GPU (the grouped sequence had never executed with more than one rank).  Never used unless the
 // environment asks for it; results are those RCCL would deliver.
 struct LoopComm { int rank, nranks, device; };
-struct LoopOp { int kind; const void *send; void *recv; size_t count; int dtype, root; LoopComm *comm; hipStream_t st; };
+struct LoopOp { int kind; const void *send; void *recv; size_t count; int dtype, root; LoopComm *comm; hipStream_t st; int op; };
 thread_local std::vector<LoopOp> t_loop_ops;
 thread_local int t_loop_depth = 0;
 uint64_t g_loop_allreduces = 0, g_loop_broadcasts = 0;   // collectives completed (test hook kao_rccl_loopback_counts)
-size_t loop_elem(int dtype) { return dtype == ncclUint64 || dtype == ncclInt64 ? 8 : (dtype == ncclUint8 || dtype == ncclInt8 ? 1 : 4); }
+size_t loop_elem(int dtype) { return dtype == ncclUint64 || dtype == ncclInt64 || dtype == ncclDouble ? 8 : (dtype == ncclUint8 || dtype == ncclInt8 ? 1 : 4); }
 ncclResult_t loop_run() {
     std::vector<LoopOp> ops;
     ops.swap(t_loop_ops);
@@ -974,14 +976,24 @@ ncclResult_t loop_run() {
     if ((int)ops.size() != n) return ncclInvalidUsage;            // every rank of the communicator must take part
     std::vector<const LoopOp *> by_rank((size_t)n, nullptr);
     for (const LoopOp &o : ops) {
-        if (o.kind != ops[0].kind || o.count != ops[0].count || o.dtype != ops[0].dtype || o.root != ops[0].root || o.comm->nranks != n) return ncclInvalidUsage;
+        if (o.kind != ops[0].kind || o.count != ops[0].count || o.dtype != ops[0].dtype || o.root != ops[0].root || o.op != ops[0].op || o.comm->nranks != n) return ncclInvalidUsage;
         if (o.comm->rank < 0 || o.comm->rank >= n || by_rank[(size_t)o.comm->rank]) return ncclInvalidUsage;
         by_rank[(size_t)o.comm->rank] = &o;
     }
     const size_t bytes = ops[0].count * loop_elem(ops[0].dtype);
     for (const LoopOp &o : ops)   // a collective is ordered behind the work already enqueued on each rank's stream
         if (hipSetDevice(o.comm->device) != hipSuccess || hipStreamSynchronize(o.st) != hipSuccess) return ncclUnhandledCudaError;
-    if (ops[0].kind == 0) {   // all-reduce: uint64 / min is the only combination the solver uses
+    if (ops[0].kind == 0 && ops[0].dtype == ncclDouble) {   // f64 sum / min (KAO-LP's shards): added in RANK order, every rank gets the same bits
+        std::vector<double> acc(ops[0].count), tmp(ops[0].count);
+        for (int r = 0; r < n; ++r) {
+            const LoopOp &o = *by_rank[(size_t)r];
+            if (hipSetDevice(o.comm->device) != hipSuccess || hipMemcpy(r ? tmp.data() : acc.data(), o.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+            if (r) for (size_t i = 0; i < acc.size(); ++i) acc[i] = ops[0].op == (int)ncclMin ? std::min(acc[i], tmp[i]) : acc[i] + tmp[i];
+        }
+        for (const LoopOp &o : ops)
+            if (hipSetDevice(o.comm->device) != hipSuccess || hipMemcpy(o.recv, acc.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        ++g_loop_allreduces;
+    } else if (ops[0].kind == 0) {   // all-reduce: uint64 / min (the elite exchange)
         if (ops[0].dtype != ncclUint64) return ncclInvalidArgument;
         std::vector<uint64_t> acc(ops[0].count, ~0ull), tmp(ops[0].count);
         for (const LoopOp &o : ops) {
@@ -1011,12 +1023,12 @@ const char *loop_GetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no 
 ncclResult_t loop_GroupStart() { ++t_loop_depth; return ncclSuccess; }
 ncclResult_t loop_GroupEnd() { if (t_loop_depth <= 0) return ncclInvalidUsage; return --t_loop_depth == 0 ? loop_run() : ncclSuccess; }
 ncclResult_t loop_AllReduce(const void *send, void *recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t c, hipStream_t st) {
-    if (op != ncclMin) return ncclInvalidArgument;
-    t_loop_ops.push_back(LoopOp{0, send, recv, count, (int)dt, 0, reinterpret_cast<LoopComm *>(c), st});
+    if (!((dt == ncclUint64 && op == ncclMin) || (dt == ncclDouble && (op == ncclMin || op == ncclSum)))) return ncclInvalidArgument;
+    t_loop_ops.push_back(LoopOp{0, send, recv, count, (int)dt, 0, reinterpret_cast<LoopComm *>(c), st, (int)op});
     return t_loop_depth == 0 ? loop_run() : ncclSuccess;
 }
 ncclResult_t loop_Broadcast(const void *send, void *recv, size_t count, ncclDataType_t dt, int root, ncclComm_t c, hipStream_t st) {
-    t_loop_ops.push_back(LoopOp{1, send, recv, count, (int)dt, root, reinterpret_cast<LoopComm *>(c), st});
+    t_loop_ops.push_back(LoopOp{1, send, recv, count, (int)dt, root, reinterpret_cast<LoopComm *>(c), st, 0});
     return t_loop_depth == 0 ? loop_run() : ncclSuccess;
 }
 struct LoopTable : Rccl {
@@ -1601,6 +1613,145 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
     }
     g_timing[3] = now_s() - t0; g_timing[4] = rounds_total;
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ONE LP over several devices (round 6): the collective side of kao_lp.hip's shards, and a test hook
+// ------------------------------------------------------------------------------------------------
+namespace {
+// Every shard's host thread walks the same sequence of launches; where the sequence holds a collective each thread hands in its buffer
+// and stream and waits; the LAST one to arrive issues the grouped ncclAllReduce(ncclDouble, ncclSum | ncclMin) for every rank -- the
+// single-process, one-thread-per-group calling pattern kao_solve_multi's elite exchange uses, served by RCCL on distinct devices and by
+// the loop-back table on logical shards -- and releases the others.  A thread that fails raises `failed`: nobody waits for it.
+struct LpGroup : LpColl {
+    int n = 0;
+    std::vector<ncclComm_t> comms;
+    const Rccl *api = nullptr;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0, rc = KAO_OK;
+    uint64_t gen = 0, collectives = 0;
+    bool failed = false;
+    struct Op { double *buf; size_t n; bool is_min; hipStream_t st; };
+    std::vector<Op> ops;
+    int issue() {
+        for (int r = 1; r < n; ++r)
+            if (ops[(size_t)r].n != ops[0].n || ops[(size_t)r].is_min != ops[0].is_min) return fail(KAO_ERR_HIP, "KAO-LP shards: the ranks disagree about a collective");
+        ncclResult_t nr = api->GroupStart();
+        for (int r = 0; r < n && nr == ncclSuccess; ++r) {
+            const Op &o = ops[(size_t)r];
+            nr = api->AllReduce(o.buf, o.buf, o.n, ncclDouble, o.is_min ? ncclMin : ncclSum, comms[(size_t)r], o.st);
+        }
+        if (nr == ncclSuccess) nr = api->GroupEnd();
+        ++collectives;
+        return nr == ncclSuccess ? KAO_OK : fail(KAO_ERR_HIP, std::string("KAO-LP shards: all-reduce: ") + api->GetErrorString(nr));
+    }
+    int allreduce(int rank, double *buf, size_t cnt, bool is_min, void *stream) override {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed) return rc ? rc : KAO_ERR_HIP;
+        ops[(size_t)rank] = Op{buf, cnt, is_min, static_cast<hipStream_t>(stream)};
+        const uint64_t my = gen;
+        if (++arrived == n) {
+            const int r = issue();
+            arrived = 0; ++gen;
+            if (r) { failed = true; rc = r; }
+            cv.notify_all();
+            return r;
+        }
+        cv.wait(lk, [&] { return gen != my || failed; });
+        return failed ? (rc ? rc : KAO_ERR_HIP) : KAO_OK;
+    }
+    void give_up(int code) { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; rc = code; } cv.notify_all(); }
+};
+}  // namespace
+
+// Test hook (include/kao.h): the LP of ONE topic solved by n_dev shards (contiguous partition ranges; devices may repeat with
+// KAO_RCCL_LOOPBACK=1: logical shards), then the same certificate evaluation and rounding as kao_lp_bound / kao_lp_round.
+int kao_lp_sharded_test(const kao_topic *t, const int32_t *devices, int32_t n_dev, double pert, uint32_t salt, double tol, int32_t max_iters,
+                        int64_t *bound, uint16_t *assignment, int64_t *objective, int32_t violations[8], double stats[8]) {
+    if (!t || !devices || n_dev < 1 || n_dev > kMaxDevices) return fail(KAO_ERR_INVALID, "kao_lp_sharded_test: bad arguments");
+    int rc = require_init();
+    if (rc) return rc;
+    if ((rc = validate(t))) return rc;
+    if (t->n_partitions < n_dev) return fail(KAO_ERR_INVALID, "kao_lp_sharded_test: fewer partitions than shards");
+    std::vector<int> devs(devices, devices + n_dev);
+    bool distinct = true;
+    for (int i = 0; i < n_dev; ++i) for (int j = 0; j < i; ++j) distinct &= devs[(size_t)i] != devs[(size_t)j];
+    if (!distinct && !loopback_wanted()) return fail(KAO_ERR_INVALID, "kao_lp_sharded_test: repeated devices are logical shards: set KAO_RCCL_LOOPBACK=1");
+    LpGroup g;
+    g.n = n_dev; g.ops.resize((size_t)n_dev);
+    if ((rc = comms_for(devs, g.comms, &g.api))) return rc;
+    const int P = t->n_partitions, K = 2 * t->rf_cur + 2 * t->n_racks;
+    std::vector<LpCtx *> ctx((size_t)n_dev, nullptr);
+    std::vector<int> rcs((size_t)n_dev, KAO_OK), p0s((size_t)n_dev + 1, 0);
+    for (int r = 0; r <= n_dev; ++r) p0s[(size_t)r] = (int)((int64_t)P * r / n_dev);
+    std::vector<std::vector<uint8_t>> qs((size_t)n_dev);
+    std::vector<int32_t> zq(2 * (size_t)t->n_brokers), mult(2 * (size_t)t->n_brokers + (size_t)t->n_racks);
+    double st8[8] = {0};
+    const double eps = pert > 0 ? pert : (pert < 0 ? 0.0 : lp_default_pert(t));       // pert < 0: the model's own LP (certificate only)
+    const double t0 = now_s();
+    auto work = [&](int r) {
+        t_device = devs[(size_t)r];
+        int e = hipSetDevice(t_device) == hipSuccess ? KAO_OK : fail(KAO_ERR_NO_DEVICE, "hipSetDevice");
+        LpShard sh{p0s[(size_t)r], p0s[(size_t)r + 1], r, &g};
+        if (!e) e = lp_open(t, &ctx[(size_t)r], &sh);
+        double stl[8] = {0};
+        if (!e) e = lp_solve(ctx[(size_t)r], tol > 0 ? tol : 1e-8, max_iters > 0 ? max_iters : 150, r == 0 ? mult.data() : nullptr, stl, nullptr, eps, salt);
+        if (!e) {
+            qs[(size_t)r].resize((size_t)K * (size_t)(p0s[(size_t)r + 1] - p0s[(size_t)r]));
+            std::vector<int32_t> zl(2 * (size_t)t->n_brokers);
+            e = lp_primal(ctx[(size_t)r], qs[(size_t)r].data(), zl.data());
+            if (!e && r == 0) { zq = zl; std::memcpy(st8, stl, sizeof stl); }
+        }
+        if (e) g.give_up(e);
+        rcs[(size_t)r] = e;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int r = 1; r < n_dev; ++r) th.emplace_back(work, r);
+        const int saved = t_device;
+        work(0);
+        for (std::thread &x : th) x.join();
+        t_device = saved;
+        if (cur_device() >= 0) (void)hipSetDevice(cur_device());
+    }
+    for (LpCtx *c : ctx) if (c) lp_close(c);
+    for (int e : rcs) if (e) return e;
+    const double t_lp = now_s();
+    // the shards' quantised iterates side by side: row k of the whole topic = the shards' rows k, in partition order
+    std::vector<uint8_t> q((size_t)K * P);
+    for (int r = 0; r < n_dev; ++r) {
+        const int pa = p0s[(size_t)r], pn = p0s[(size_t)r + 1] - pa;
+        for (int k = 0; k < K; ++k) std::memcpy(q.data() + (size_t)k * P + pa, qs[(size_t)r].data() + (size_t)k * pn, (size_t)pn);
+    }
+    if (bound) {   // the dual value at the shards' common multipliers, in integers: one K-bound iteration from them (as kao_lp_bound)
+        kao_opts o{};
+        o.restarts = kWaves;
+        kao_session *s = nullptr;
+        if ((rc = kao_session_create(t, 1, &o, &s))) return rc;
+        if (!s->dual_ok[0]) { kao_session_destroy(s); return fail(KAO_ERR_UNSUPPORTED, "topic outside K-bound's limits"); }
+        rc = kao_session_set_dual_state(s, 0, mult.data(), mult.data() + t->n_brokers, mult.data() + 2 * (size_t)t->n_brokers);
+        const int64_t target = 0;
+        int32_t fl = 0, itn = 0;
+        int64_t bd = 0;
+        if (!rc) rc = kao_session_bound_step(s, &target, 1);
+        if (!rc) rc = kao_session_bounds(s, nullptr, &fl, &itn);
+        if (!rc) rc = kao_session_dual_state(s, 0, nullptr, nullptr, nullptr, &bd);
+        if (!rc) *bound = (fl & 4) || itn == 0 ? INT64_MAX : (bd >= 0 ? bd / kDualScale : -((-bd + kDualScale - 1) / kDualScale));
+        kao_session_destroy(s);
+        if (rc) return rc;
+    }
+    int32_t rep[4] = {0, 0, 0, 0};
+    if (assignment) {
+        if ((rc = lp_round_assignment(t, q.data(), zq.data(), nullptr, assignment, rep))) return rc;
+        int64_t obj = 0;
+        int32_t viol[8] = {0};
+        if ((rc = kao_evaluate(t, assignment, &obj, viol))) return rc;
+        if (objective) *objective = obj;
+        if (violations) std::memcpy(violations, viol, sizeof viol);
+    }
+    if (stats) { stats[0] = st8[0]; stats[1] = st8[3]; stats[2] = rep[0]; stats[3] = (double)g.collectives; stats[4] = st8[2]; stats[5] = (t_lp - t0) * 1e3; stats[6] = (now_s() - t_lp) * 1e3; stats[7] = eps; }
+    return KAO_OK;
 }
 
 int kao_rccl_loopback_counts(uint64_t out[2]) {

@@ -142,3 +142,31 @@ def gather_assignments(best: np.ndarray, owned: Sequence[int], local_assignments
     for d in gathered:
         merged.update(d)
     return [merged.get(t) for t in range(len(best))]
+
+
+# ---- KAO-LP sharded by partition range (round 6): what the shards exchange per factorisation -------------------------------------
+def tri_pack(S: np.ndarray, mc: int) -> np.ndarray:
+    """A shard's part of the Schur complement for the all-reduce: rows 0 .. mc-1 of the lower triangle of S [mcp, mcp], row i at offset
+    i (i + 1) / 2 -- the index map of k_lp_tri_pack (kao_lp.hip): half the bytes of the square."""
+    i, j = np.tril_indices(mc)
+    return np.ascontiguousarray(S[i, j], dtype=np.float64)
+
+
+def tri_unpack(tri: np.ndarray, mc: int, mcp: int, out: np.ndarray = None) -> np.ndarray:
+    """Inverse of tri_pack into the lower triangle of an [mcp, mcp] matrix (everything else untouched / zero)."""
+    S = np.zeros((mcp, mcp)) if out is None else out
+    i, j = np.tril_indices(mc)
+    S[i, j] = tri
+    return S
+
+
+def allreduce_schur(S_local: np.ndarray, mc: int, device=None) -> np.ndarray:
+    """One process per GPU: the shards' lower triangles summed (f64) over the process group, packed; every rank gets the same matrix.
+    (Inside one process the library does this itself: kao_lp_sharded_test, LpGroup in kao_solve.cpp.)"""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(tri_pack(S_local, mc))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return tri_unpack(t.cpu().numpy(), mc, S_local.shape[0])

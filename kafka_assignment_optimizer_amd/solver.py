@@ -477,6 +477,21 @@ def lp_trace(topic: Topic, tol: float = 0.0, max_iters: int = 80) -> dict:
                 status=int(st[3]), ms=float(st[7]), trace=tr[:5 * (it + 1)].reshape(-1, 5))
 
 
+def lp_sharded(topic: Topic, devices: Sequence[int], pert: float = 0.0, salt: int = 0, tol: float = 0.0, max_iters: int = 0) -> dict:
+    """Test hook (kao_lp_sharded_test): one topic's LP solved by len(devices) shards of its partitions (repeated devices = logical shards,
+    KAO_RCCL_LOOPBACK=1); certificate + rounded iterate as lp_bound / lp_round."""
+    ct = _CTopics([topic])
+    dv = np.asarray(list(devices), dtype=np.int32)
+    A = np.full((topic.n_partitions, topic.rf), 0xFFFF, dtype=np.uint16)
+    bound = C.c_int64(0); obj = C.c_int64(0)
+    viol = np.zeros(8, dtype=np.int32); st = np.zeros(8)
+    _check(_ffi.load().kao_lp_sharded_test(ct.ptr(0), dv.ctypes.data_as(C.POINTER(C.c_int32)), len(dv), float(pert), int(salt), float(tol), int(max_iters),
+                                           C.byref(bound), A.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(obj), viol.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           st.ctypes.data_as(C.POINTER(C.c_double))), "kao_lp_sharded_test")
+    return dict(bound=int(bound.value), assignment=A, objective=int(obj.value), violations=viol.tolist(), iterations=int(st[0]), status=int(st[1]),
+                fractional=int(st[2]), collectives=int(st[3]), dual=float(st[4]), ms_lp=float(st[5]), ms_rest=float(st[6]), pert=float(st[7]))
+
+
 def dense_spd_test(A: np.ndarray, rhs: Optional[np.ndarray] = None) -> dict:
     """Test hook (kao_dense_spd_test): KAO-LP's dense kernels (kao_chol.hip) alone on a symmetric positive definite matrix whose order
     is a multiple of 64: the factor (L below, L^T tile-wise above), the inverses of L's diagonal tiles, the solution of A x = rhs."""

@@ -88,3 +88,56 @@ def test_allreduce_best_gloo_world2():
         assert got0[t] == [[10 * owner + t] * 2] * 2
     assert dec[4] == (0, 501, 7, 1)  # replicated topic: the better objective (rank 1) wins
     assert got0[4] == [[14, 14], [14, 14]] and got0 == got1
+
+
+def _schur_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mc, mcp = 70, 128
+        rng = np.random.default_rng(100 + rank)
+        S = np.zeros((mcp, mcp))
+        S[:mc, :mc] = np.tril(rng.standard_normal((mc, mc)))       # this shard's partitions' part of the lower triangle
+        S[mc:, :] = 7.0 + rank                                     # padding rows: not part of the exchange
+        out = mg.allreduce_schur(S, mc)
+        q.put((rank, S[:mc, :mc].tolist(), out.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tri_packing_matches_the_kernel_index_map():
+    """Row i of the lower triangle at offset i (i + 1) / 2 (k_lp_tri_pack), round trip, nothing outside the triangle travels."""
+    mc, mcp = 9, 64
+    S = np.arange(mcp * mcp, dtype=np.float64).reshape(mcp, mcp)
+    t = mg.tri_pack(S, mc)
+    assert t.shape == (mc * (mc + 1) // 2,)
+    for i in range(mc):
+        for j in range(i + 1):
+            assert t[i * (i + 1) // 2 + j] == S[i, j]
+    back = mg.tri_unpack(t, mc, mcp)
+    assert np.array_equal(np.tril(back[:mc, :mc]), np.tril(S[:mc, :mc])) and back[mc:].sum() == 0 and np.triu(back, 1).sum() == 0
+
+
+def test_schur_allreduce_gloo_world2():
+    """KAO-LP sharded by partition range: the shards' parts of the Schur complement summed over a world of two (gloo), packed -- every
+    rank ends with the dense sum of the lower triangles, bit for bit the same on both."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_schur_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, part0, out0), (_, part1, out1) = res
+    want = np.array(part0) + np.array(part1)
+    assert np.array_equal(np.array(out0), np.array(out1))
+    assert np.array_equal(np.array(out0)[:70, :70], want) and np.array(out0)[70:].sum() == 0

@@ -300,3 +300,26 @@ def test_another_north_star_seed_is_proven_by_its_rounded_iterate(kao, ko, kp):
     obj, viol = kp.port_eval(ot, r.assignment)
     assert viol[0] == 0 and obj == r.objective
     assert r.status == "OPTIMAL_PROVEN" and r.objective == r.upper_bound and lp["adopted"] >= 1, (r.status, r.objective, r.upper_bound, lp)
+
+
+@pytest.mark.parametrize("B,R,P,shards", [(100, 5, 1000, 2), (300, 6, 2000, 3)])
+def test_one_lp_sharded_over_logical_devices(kao, ko, kp, monkeypatch, B, R, P, shards):
+    """Round 6: ONE topic's LP solved by several shards of its partitions (kao_lp_sharded_test) -- local variables and rows per shard,
+    coupling rows and global variables replicated, the Schur complement / the coupling right-hand sides / the reductions' records summed
+    by all-reduces (loop-back table: logical shards on device 0, rank-ordered sums).  The sharded solve must give what the whole one gives:
+    the same certificate (= the HiGHS optimum), the same iteration count (+- 2: the sums over the partitions are added in another order),
+    a rounded iterate that satisfies every row and whose objective equals the certificate; and it must have issued collectives."""
+    monkeypatch.setenv("KAO_RCCL_LOOPBACK", "1")
+    pt, ot = _drift(ko, B, R, P)
+    row = [r for r in load_golden("drift_scale.json")["rows"] if (r["B"], r["R"], r["P"]) == (B, R, P)][0]
+    eps = min(1e-4, 1.5 / (P * 3))          # kao_solve's perturbation: small enough that the row duals still floor to the LP value
+    whole = kao.lp_round(pt, pert=eps, tol=1e-10, max_iters=200)
+    cert = kao.lp_bound(pt)["bound"]
+    sh = kao.lp_sharded(pt, [0] * shards, pert=eps, tol=1e-10, max_iters=200)
+    print(f"{B}x{P} in {shards} shards: certificate {sh['bound']} rounded {sh['objective']} ({sh['violations'][0]} violations) {sh['iterations']} iterations, "
+          f"{sh['collectives']} collectives, {sh['ms_lp']:.0f} ms; whole topic: {whole['objective']} in {whole['iterations']} iterations")
+    assert sh["status"] == 0 and abs(sh["iterations"] - whole["iterations"]) <= 2
+    assert sh["bound"] == cert == row["milp_objective"]
+    obj, viol = kp.port_eval(ot, sh["assignment"])
+    assert viol[0] == 0 and obj == sh["objective"] == cert
+    assert sh["collectives"] >= 10 * sh["iterations"]
