@@ -321,7 +321,8 @@ int kao_dense_spd_test(const double *A, int32_t n, const double *rhs, double *fa
  * own LP).  *bound = the certificate (K-bound's integer dual value at the common row duals), assignment / objective / violations = the
  * rounded iterate as kao_lp_round (assignment may be NULL), stats[8] = {iterations, status, fractional partitions, collectives issued,
  * README objective of the dual iterate, milliseconds of the solve, milliseconds of certificate + rounding, perturbation}.
- * NOT scheduled by kao_solve_multi (which races whole solves on a replicated large topic) and unmeasured on more than one GPU. */
+ * kao_solve_multi races whole solves on a replicated large topic by default and runs this sharded solve instead with KAO_MULTI_LP=shard;
+ * unmeasured on more than one GPU. */
 int kao_lp_sharded_test(const kao_topic *t, const int32_t *devices, int32_t n_dev, double pert, uint32_t salt, double tol, int32_t max_iters,
                         int64_t *bound, uint16_t *assignment, int64_t *objective, int32_t violations[8], double stats[8]);
 /* One-shot K-bound on one topic: `launches` launches of `iters` iterations towards `target`.

@@ -191,6 +191,21 @@ struct LpColl {
     virtual ~LpColl() {}
 };
 struct LpShard { int p0, p1, rank; LpColl *coll; };
+// A set of shard contexts driven as ONE solve (kao_solve.cpp LpFanImpl): lp_open_fan returns shard 0's context, whose lp_begin /
+// lp_enqueue_mark / lp_poll_mark / lp_finish / lp_primal / lp_abort / lp_close forward here -- the caller (kao_solve's loop) sees one LP.
+struct LpFan {
+    virtual int begin(double tol, int maxit, double pert, uint32_t salt) = 0;
+    virtual int enqueue_mark(int k, int slot) = 0;
+    virtual int poll_mark(int slot, int *status, int *iterations, double deadline) = 0;
+    virtual int finish(int32_t *multipliers, double stats[8], double *trace) = 0;
+    virtual int primal(uint8_t *q, int32_t *zq) = 0;
+    virtual void abort() = 0;
+    virtual void close() = 0;        // closes every shard (the forwarding context included) and the fan itself
+    virtual ~LpFan() {}
+};
+extern thread_local bool t_lp_inner;   // set while the fan itself calls the lp_* functions on its shards (no forwarding then)
+void lp_set_fan(LpCtx *c, LpFan *fan);
+int lp_open_fan(const kao_topic *t, const int *devices, int n_dev, LpCtx **out);   // kao_solve.cpp
 int lp_open(const kao_topic *t, LpCtx **out, const LpShard *shard = nullptr);
 // multipliers (host): a[B] l[B] g[R] in K-bound's fixed point; stats[8], trace: see kao_lp.hip
 int lp_solve(LpCtx *c, double tol, int maxit, int32_t *multipliers, double stats[8], double *trace, double pert = 0.0, uint32_t salt = 0);   // one shot

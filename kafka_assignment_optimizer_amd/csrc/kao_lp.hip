@@ -1221,6 +1221,7 @@ struct LpCtx {
     double *rack_part = nullptr;   // [2 R][kRackChunks] slice sums of the rack rows
     int broker_u = 4;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
     double *xz = nullptr;      // exchange vectors of the triangular solves (kao_chol.hip)
+    LpFan *fan = nullptr;      // shard 0 of a fan (kao_internal.h): the lp_* entry points forward to it
     double *tri = nullptr;     // a shard's packed lower triangle of S for the all-reduce
     LpColl *coll = nullptr; int rank = 0;   // a shard of one LP over several devices (kao_internal.h LpShard); null: the whole topic
     int coll_rc = KAO_OK;      // first failure of a collective (checked by lp_enqueue / lp_begin)
@@ -1485,17 +1486,24 @@ int lp_open(const kao_topic *t, LpCtx **out, const LpShard *shard) {
 
 // Raises the stop flag from the host: whatever is still enqueued turns into no-ops (a context that is closed with work in flight
 // would otherwise wait for all of it).
+thread_local bool t_lp_inner = false;
+void lp_set_fan(LpCtx *c, LpFan *fan) { c->fan = fan; }
 void lp_abort(LpCtx *c) {
     if (!c) return;
+    if (c->fan && !t_lp_inner) { c->fan->abort(); return; }
     (void)hipSetDevice(c->device);
     const double four = 4.0;   // its own value: an aborted solve's iterate is mid-way, nobody may take it for a finished one
     (void)hipMemcpy(c->D.sc + SC_STOP, &four, sizeof four, hipMemcpyHostToDevice);
 }
-void lp_close(LpCtx *c) { delete c; }
+void lp_close(LpCtx *c) {
+    if (c && c->fan && !t_lp_inner) { c->fan->close(); return; }
+    delete c;
+}
 
 // Enqueues the starting point (theta = 1: x~ = A^T (A A^T)^-1 b, y = (A A^T)^-1 A c, s = c - A^T y, pushed into the interior) and the
 // residuals of iterate 0.  Asynchronous on the context's stream.
 int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
+    if (cp->fan && !t_lp_inner) return cp->fan->begin(tol, maxit, pert, salt);
     LpCtx &c = *cp;
     const LpDev &D = c.D;
     HIP_TRY(hipSetDevice(c.device));
@@ -1608,6 +1616,7 @@ int lp_enqueue(LpCtx *cp, int k) {
 // waits for exactly that mark -- not for whatever was enqueued after it -- so a caller that keeps a few marks in flight (kao_solve: one per
 // K-search launch, read three launches later) hardly ever blocks and still sees the state of a fixed iteration count: deterministic.
 int lp_enqueue_mark(LpCtx *cp, int k, int slot) {
+    if (cp->fan && !t_lp_inner) return cp->fan->enqueue_mark(k, slot);
     int rc = lp_enqueue(cp, k);
     if (rc) return rc;
     LpCtx &c = *cp;
@@ -1616,6 +1625,7 @@ int lp_enqueue_mark(LpCtx *cp, int k, int slot) {
     return KAO_OK;
 }
 int lp_poll_mark(LpCtx *cp, int slot, int *status, int *iterations, double deadline) {
+    if (cp->fan && !t_lp_inner) return cp->fan->poll_mark(slot, status, iterations, deadline);
     LpCtx &c = *cp;
     HIP_TRY(hipSetDevice(c.device));
     if (deadline > 0) {   // a bounded wait: past the deadline the stop flag goes up (what is still enqueued turns into no-ops) and the mark arrives at once
@@ -1649,6 +1659,7 @@ int lp_poll(LpCtx *cp, int *status, int *iterations) {
 // iterate is returned), mu, relative primal infeasibility, relative dual infeasibility, milliseconds since lp_begin}; trace (may be
 // null): 5 doubles per iterate, iterations + 1 of them.
 int lp_finish(LpCtx *cp, int32_t *multipliers, double stats[8], double *trace) {
+    if (cp->fan && !t_lp_inner) return cp->fan->finish(multipliers, stats, trace);
     LpCtx &c = *cp;
     const LpDev &D = c.D;
     int st = 0, it = 0;
@@ -1670,6 +1681,7 @@ int lp_finish(LpCtx *cp, int32_t *multipliers, double stats[8], double *trace) {
 // The primal iterate, quantised (k_lp_round): q[(2 NJ + 2 R) * P] bytes, zq[2 B] ints, both host memory.  After lp_finish / once the
 // stop flag is up (the iterate does not move behind it).
 int lp_primal(LpCtx *cp, uint8_t *q, int32_t *zq) {
+    if (cp->fan && !t_lp_inner) return cp->fan->primal(q, zq);
     LpCtx &c = *cp;
     const LpDev &D = c.D;
     HIP_TRY(hipSetDevice(c.device));

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -179,6 +180,8 @@ struct SolveRun {
     double lp_solo_s = 1.0; int64_t lp_solo_slots = 32768;
     double lp_alone_s = 0.0;      // (KAO_LP_ALONE_S=<s>: fixed rule) when the LP's predicted time fits the limit it runs before any K-search launch (its rounded iterate needs no incumbent; K-search takes over if it fails)
     int lp_rounded = 0, lp_round_adopted = 0, lp_round_fractional = 0;
+    std::vector<int> lp_fan_devs; // kao_solve_multi, KAO_MULTI_LP=shard: the devices ONE sharded LP of a large replicated topic runs on (lp_open_fan); empty: this device alone
+    const bool *ext_pause = nullptr;   // ... and the other devices' runs: no K-search launches while the shards of that LP have the GPUs
     int lp_salt0 = 0;             // kao_solve_multi, replicated topics: the device's rank -- every device perturbs the LP with its own salt (a race)
     int lp_round_max_free = 512;  // fractional partitions completed without the incumbent's rows (about 0.1 ms each: 100,000 of a mid-way iterate took 8 s)
     std::vector<char> lp_try, lp_certified;   // per topic: LP solves finished; the LP's certificate is in place (K-bound leaves the topic alone)
@@ -231,6 +234,7 @@ struct SolveRun {
         //  never when the caller counts K-search launches (max_launches: it gets them), and never while some other open topic
         // still needs the search: a pause is for solves whose every open topic is waiting for its LP
         if (s->opts.max_launches > 0) return false;
+        if (ext_pause && *ext_pause) return true;
         bool any = false;
         for (int i = 0; i < n; ++i) {
             if (topic_done(i)) continue;
@@ -466,7 +470,8 @@ struct SolveRun {
             }
             if (best < 0) break;
             LpCtx *c = nullptr;
-            rc = lp_open(&topics[best], &c);
+            if (!lp_fan_devs.empty() && (huge(best) || solo(best))) rc = lp_open_fan(&topics[best], lp_fan_devs.data(), (int)lp_fan_devs.size(), &c);   // one LP over all devices
+            else rc = lp_open(&topics[best], &c);
             if (rc == KAO_ERR_UNSUPPORTED || rc == KAO_ERR_NOMEM) { lp_state[(size_t)best] = 3; continue; }
             if (rc) return rc;
             const bool retry = lp_try[(size_t)best] > 0;   // primal side only: the larger perturbation of kao_lp_round, another salt
@@ -1146,6 +1151,11 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
     const bool replicated = n_topics < n_dev;   // fewer topics than GPUs: every GPU searches every topic, elites are exchanged
     bool race = false;
     for (int i = 0; replicated && i < n_topics; ++i) race |= (int64_t)topics[i].n_partitions * topics[i].rf >= 32768;
+    // KAO_MULTI_LP=shard (opt-in, round 6): instead of racing whole solves, ONE LP of such a topic runs sharded by partition range over all
+    // devices (driven by device 0's solve loop through lp_open_fan; the other devices' loops launch no K-search while it has the GPUs).
+    // Exercised on logical shards only (tests/test_gpu_parity.py); the race stays the default until a multi-GPU node has timed both.
+    bool shard_lp = false, lp_pause = false;
+    { const char *e = std::getenv("KAO_MULTI_LP"); shard_lp = race && e && e[0] == 's' && (distinct || loopback_wanted()); }
     // ---- shards: LPT by brokers x partitions (independent sub-problems, README.md:146-184) ----
     std::vector<std::vector<int>> shard((size_t)n_dev);
     if (replicated) for (auto &sh : shard) for (int i = 0; i < n_topics; ++i) sh.push_back(i);
@@ -1184,8 +1194,9 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
         // slots or more is solved by ONE perturbed interior-point solve whose iteration count is heavy-tailed (105 .. 200 at 100,000
         // partitions, depending on the perturbation's salt and on rounding noise) -- there every device runs the solve with its own salt and
         // the first proof ends the solve for all (certificates and incumbents are shared as before): a race, not a split of the work
-        if (replicated && d > 0 && !race) o.dual_iters = -1;
+        if (replicated && d > 0 && (!race || shard_lp)) o.dual_iters = -1;
         x.run.lp_salt0 = replicated ? d : 0;
+        if (shard_lp) { if (d == 0) x.run.lp_fan_devs = devs; else x.run.ext_pause = &lp_pause; }
         t_device = devs[(size_t)d];
         if (hipSetDevice(t_device) != hipSuccess) { rc = fail(KAO_ERR_NO_DEVICE, "hipSetDevice"); break; }
         rc = x.run.begin(x.tp.data(), (int)x.tp.size(), o, x.tgt.empty() ? nullptr : x.tgt.data(), t0);
@@ -1199,6 +1210,7 @@ int kao_solve_multi(const kao_topic *topics, int32_t n_topics, const int32_t *de
     std::vector<uint64_t> gmin((size_t)n_topics);
     std::vector<int> root((size_t)n_topics);
     for (;;) {
+        if (shard_lp && D[0].run.s) lp_pause = D[0].run.search_paused();
         for (int d = 0; d < n_dev && !rc; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; rc = D[(size_t)d].run.launch(); }
         for (int d = 0; d < n_dev && !rc; ++d) if (D[(size_t)d].run.s) { t_device = devs[(size_t)d]; rc = D[(size_t)d].run.after_launch(); }
         if (rc) break;
@@ -1615,6 +1627,8 @@ int kao_solve_capped(const kao_topic *topics, int32_t n_topics, const int32_t *r
     return rc;
 }
 
+}  // extern "C"
+
 // ------------------------------------------------------------------------------------------------
 // ONE LP over several devices (round 6): the collective side of kao_lp.hip's shards, and a test hook
 // ------------------------------------------------------------------------------------------------
@@ -1663,7 +1677,119 @@ struct LpGroup : LpColl {
     }
     void give_up(int code) { std::lock_guard<std::mutex> lk(mu); if (!failed) { failed = true; rc = code; } cv.notify_all(); }
 };
+
+// N shard contexts behind ONE LpCtx-shaped front (kao_internal.h LpFan): one persistent host thread per shard (its device current, the
+// collectives of LpGroup between them); a call of the front runs the same lp_* function on every shard's thread and returns when all have
+// ENQUEUED their part.  Marks are read from shard 0 (the scalars are replicated); an abort reaches every shard.
+struct LpFanImpl : LpFan {
+    const kao_topic *t = nullptr;
+    std::vector<int> devs, p0s;
+    LpGroup group;
+    std::vector<LpCtx *> ctx;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<int(int)> job;
+    uint64_t job_gen = 0;
+    int pending = 0;
+    std::vector<int> rcs;
+    bool quit = false;
+    void worker(int r) {
+        t_device = devs[(size_t)r];
+        (void)hipSetDevice(t_device);
+        t_lp_inner = true;
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<int(int)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return quit || job_gen != seen; });
+                if (quit) return;
+                seen = job_gen; f = job;
+            }
+            const int e = f(r);
+            if (e) group.give_up(e);
+            std::lock_guard<std::mutex> lk(mu);
+            rcs[(size_t)r] = e;
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    int run(std::function<int(int)> f) {     // f(rank) on every shard's thread; first failure
+        std::unique_lock<std::mutex> lk(mu);
+        job = std::move(f); ++job_gen; pending = (int)devs.size();
+        std::fill(rcs.begin(), rcs.end(), KAO_OK);
+        cv_go.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+        for (int e : rcs) if (e) return e;
+        return KAO_OK;
+    }
+    int open(const kao_topic *topic, const int *devices, int n) {
+        t = topic;
+        devs.assign(devices, devices + n);
+        group.n = n; group.ops.resize((size_t)n);
+        int rc = comms_for(devs, group.comms, &group.api);
+        if (rc) return rc;
+        p0s.resize((size_t)n + 1);
+        for (int r = 0; r <= n; ++r) p0s[(size_t)r] = (int)((int64_t)t->n_partitions * r / n);
+        ctx.assign((size_t)n, nullptr); rcs.assign((size_t)n, KAO_OK);
+        for (int r = 0; r < n; ++r) th.emplace_back(&LpFanImpl::worker, this, r);
+        return run([&](int r) { LpShard sh{p0s[(size_t)r], p0s[(size_t)r + 1], r, &group}; return lp_open(t, &ctx[(size_t)r], &sh); });
+    }
+    int begin(double tol, int maxit, double pert, uint32_t salt) override { return run([&](int r) { return lp_begin(ctx[(size_t)r], tol, maxit, pert, salt); }); }
+    int enqueue_mark(int k, int slot) override { return run([&](int r) { return lp_enqueue_mark(ctx[(size_t)r], k, slot); }); }
+    struct Inner { bool saved; Inner() : saved(t_lp_inner) { t_lp_inner = true; } ~Inner() { t_lp_inner = saved; } };
+    int poll_mark(int slot, int *status, int *iterations, double deadline) override {
+        Inner in;
+        int st = 0, it = 0;
+        const int rc = lp_poll_mark(ctx[0], slot, &st, &it, deadline);
+        if (!rc && st == 4) for (size_t r = 1; r < ctx.size(); ++r) lp_abort(ctx[r]);     // the deadline passed: shard 0 raised its flag, the others follow
+        if (status) *status = st;
+        if (iterations) *iterations = it;
+        if (cur_device() >= 0) (void)hipSetDevice(cur_device());
+        return rc;
+    }
+    int finish(int32_t *multipliers, double stats[8], double *trace) override {
+        return run([&](int r) { return lp_finish(ctx[(size_t)r], r == 0 ? multipliers : nullptr, r == 0 ? stats : nullptr, r == 0 ? trace : nullptr); });
+    }
+    int primal(uint8_t *q, int32_t *zq) override {     // the shards' quantised rows side by side
+        const int P = t->n_partitions, K = 2 * t->rf_cur + 2 * t->n_racks;
+        std::vector<std::vector<uint8_t>> qs(ctx.size());
+        std::vector<std::vector<int32_t>> zs(ctx.size(), std::vector<int32_t>(2 * (size_t)t->n_brokers));
+        const int rc = run([&](int r) { qs[(size_t)r].resize((size_t)K * (size_t)(p0s[(size_t)r + 1] - p0s[(size_t)r])); return lp_primal(ctx[(size_t)r], qs[(size_t)r].data(), zs[(size_t)r].data()); });
+        if (rc) return rc;
+        for (size_t r = 0; r < ctx.size(); ++r) {
+            const int pa = p0s[r], pn = p0s[r + 1] - pa;
+            for (int k = 0; k < K; ++k) std::memcpy(q + (size_t)k * P + pa, qs[r].data() + (size_t)k * pn, (size_t)pn);
+        }
+        std::memcpy(zq, zs[0].data(), zs[0].size() * 4);
+        return KAO_OK;
+    }
+    void abort() override { Inner in; for (LpCtx *c : ctx) if (c) lp_abort(c); if (cur_device() >= 0) (void)hipSetDevice(cur_device()); }
+    void shutdown() {
+        if (!th.empty()) {
+            (void)run([&](int r) { if (ctx[(size_t)r]) { lp_abort(ctx[(size_t)r]); lp_close(ctx[(size_t)r]); ctx[(size_t)r] = nullptr; } return KAO_OK; });
+            { std::lock_guard<std::mutex> lk(mu); quit = true; }
+            cv_go.notify_all();
+            for (std::thread &x : th) x.join();
+            th.clear();
+        }
+        if (cur_device() >= 0) (void)hipSetDevice(cur_device());
+    }
+    void close() override { shutdown(); delete this; }
+    ~LpFanImpl() override { shutdown(); }
+};
 }  // namespace
+
+int kao::lp_open_fan(const kao_topic *t, const int *devices, int n_dev, LpCtx **out) {
+    LpFanImpl *f = new LpFanImpl();
+    const int rc = f->open(t, devices, n_dev);
+    if (rc) { delete f; return rc; }
+    lp_set_fan(f->ctx[0], f);
+    *out = f->ctx[0];
+    return KAO_OK;
+}
+
+extern "C" {
 
 // Test hook (include/kao.h): the LP of ONE topic solved by n_dev shards (contiguous partition ranges; devices may repeat with
 // KAO_RCCL_LOOPBACK=1: logical shards), then the same certificate evaluation and rounding as kao_lp_bound / kao_lp_round.

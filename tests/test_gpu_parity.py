@@ -1174,6 +1174,28 @@ def test_solve_multi_races_the_lp_on_a_replicated_large_topic(kao, ko, kp, monke
     assert lp["solves"] >= 1 and lp["adopted"] >= 1, lp
 
 
+def test_solve_multi_shards_one_lp_over_the_devices(kao, ko, kp, monkeypatch):
+    """Round 6, opt-in (KAO_MULTI_LP=shard): on a replicated topic in the LP's regime ONE interior-point solve runs sharded by partition
+    range over all (logical) devices -- device 0's solve loop drives it through lp_open_fan, the shards' sums meet in grouped f64
+    all-reduces (loop-back table here), the other devices' loops launch no K-search meanwhile.  Same proven optimum as one device, every
+    row satisfied, and the collectives were really issued (hundreds of all-reduces: ~13 per iteration)."""
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    monkeypatch.setenv("KAO_RCCL_LOOPBACK", "1")
+    monkeypatch.setenv("KAO_MULTI_LP", "shard")
+    pt = sy.drift(sy.make_cluster(600, 12, 1, 12000, 3, [], []), 0.2, 1)[0]
+    ot = _oracle_topic(ko, pt)
+    one = kao.solve([pt], seed=5, stop_at_bound=1, time_limit_s=20.0)[0]
+    ar0, _ = kao.rccl_loopback_counts()
+    two = kao.solve_multi([pt], [0, 0], seed=5, stop_at_bound=1, time_limit_s=30.0)[0]
+    lp = kao.last_solve_lp()
+    ar1, _ = kao.rccl_loopback_counts()
+    print(f"sharded LP inside kao_solve_multi: {two.status} {two.objective} / {two.upper_bound}, {int(lp['iterations'])} iterations, {ar1 - ar0} all-reduces")
+    assert one.status == two.status == "OPTIMAL_PROVEN" and one.objective == two.objective == two.upper_bound, (one.status, two.status, one.objective, two.objective)
+    obj, viol = kp.port_eval(ot, two.assignment)
+    assert viol[0] == 0 and obj == two.objective
+    assert lp["solves"] >= 1 and lp["adopted"] >= 1 and ar1 - ar0 >= 10 * lp["iterations"], (lp, ar1 - ar0)
+
+
 def test_rccl_collectives_on_the_resident_buffers(kao):
     """The RCCL path of kao_solve_multi (librccl.so opened on first use, ncclCommInitAll, ncclAllReduce(ncclUint64, ncclMin),
     ncclBroadcast) on the devices this box has -- one here, so a world of one; the same entry point checks 8 on a full node."""
