@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVe
                 const double r = c - at_val(D, vv, p, y) - s.z[i] + v.z[i];
                 rd.z[i] = r; a[0] += r * r; a[1] += x.z[i] * s.z[i]; a[2] += c * x.z[i];
                 if (u > 0) { a[1] += (u - x.z[i]) * v.z[i]; a[3] += u * v.z[i]; }
-            } else rd.z[i] = 0.0;
+            }
         } else {
             const int g = (int)(i - nv);
             if (gvar_present(D, g)) {
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_resid(LpDev D, VarVec x, VarVe
                     a[0] += r * r; a[1] += x.zg[g] * s.zg[g]; a[2] += c * x.zg[g];
                     if (u > 0) { a[1] += (u - x.zg[g]) * v.zg[g]; a[3] += u * v.zg[g]; }
                 }
-            } else rd.zg[g] = 0.0;
+            }
         }
     }
     block_reduce(a, 4, false, rec + (size_t)blockIdx.x * kRedVals);
@@ -1010,7 +1010,7 @@ __global__ void k_lp_h(LpDev D, int pass, VarVec x, VarVec s, VarVec v, VarVec t
     const double sigma_mu = D.sc[SC_SIGMU];
     if (i < nv) {
         const int vv = (int)(i / D.P), p = (int)(i % D.P);
-        if (!var_present(D, vv, p)) { h.z[i] = 0; g.z[i] = 0; ds.z[i] = 0; dv.z[i] = 0; return; }
+        if (!var_present(D, vv, p)) return;      // (absent variables' entries of every direction / right-hand-side vector are zero from lp_begin's memset on: nobody ever stores anything else there)
         const double u = var_ub(D, vv), w = u > 0 ? u - x.z[i] : 1.0;
         double rxs = -x.z[i] * s.z[i], rwv = u > 0 ? -w * v.z[i] : 0.0;
         if (pass) { rxs += sigma_mu - dxa.z[i] * dsa.z[i]; if (u > 0) rwv += sigma_mu + dxa.z[i] * dva.z[i]; }
@@ -1018,7 +1018,7 @@ __global__ void k_lp_h(LpDev D, int pass, VarVec x, VarVec s, VarVec v, VarVec t
         h.z[i] = hh; g.z[i] = th.z[i] * hh; ds.z[i] = rxs; dv.z[i] = rwv;
     } else if (i < nv + D.GV) {
         const int k = (int)(i - nv);
-        if (!gvar_present(D, k)) { h.zg[k] = 0; g.zg[k] = 0; ds.zg[k] = 0; dv.zg[k] = 0; return; }
+        if (!gvar_present(D, k)) return;
         const double u = gvar_ub(D, k), w = u > 0 ? u - x.zg[k] : 1.0;
         double rxs = -x.zg[k] * s.zg[k], rwv = u > 0 ? -w * v.zg[k] : 0.0;
         if (pass) { rxs += sigma_mu - dxa.zg[k] * dsa.zg[k]; if (u > 0) rwv += sigma_mu + dxa.zg[k] * dva.zg[k]; }
@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_dir(LpDev D, VarVec x, VarVec 
                 if (ddv < 0) a[1] = fmin(a[1], -vi / ddv);
             }
         }
-        dx.z[i] = ddx; ds.z[i] = dds; dv.z[i] = ddv;       // (the global variables sit right behind the partition ones)
+        if (on) { dx.z[i] = ddx; ds.z[i] = dds; dv.z[i] = ddv; }       // (the global variables sit right behind the partition ones; absent entries stay zero)
     }
     block_reduce(a, 2, true, rec + (size_t)blockIdx.x * kRedVals);
 }
@@ -1071,7 +1071,7 @@ __global__ void k_lp_mcc_h(LpDev D, VarVec x, VarVec s, VarVec v, VarVec th, Var
     bool on; double u;
     if (i < nv) { const int vv = (int)(i / D.P), p = (int)(i % D.P); on = var_present(D, vv, p); u = var_ub(D, vv); }
     else { const int k = (int)(i - nv); on = gvar_present(D, k); u = gvar_ub(D, k); }
-    if (!on) { h.z[i] = 0; g.z[i] = 0; dsc.z[i] = 0; dvc.z[i] = 0; return; }   // (the global variables sit right behind the partition ones)
+    if (!on) return;   // (the global variables sit right behind the partition ones; absent entries stay zero)
     const double xi = x.z[i], si = s.z[i], vi = v.z[i];
     double pr = (xi + apt * dx.z[i]) * (si + adt * ds.z[i]);
     double tg = pr < kMccBmin * mut ? kMccBmin * mut : (pr > kMccBmax * mut ? kMccBmax * mut : pr);
@@ -1112,7 +1112,7 @@ __global__ void __launch_bounds__(kRedBlock) k_lp_mcc_dir(LpDev D, VarVec x, Var
                 if (tv < 0) a[1] = fmin(a[1], -vi / tv);
             }
         }
-        dxc.z[i] = c1; dsc.z[i] = c2; dvc.z[i] = c3;
+        if (on) { dxc.z[i] = c1; dsc.z[i] = c2; dvc.z[i] = c3; }
     }
     block_reduce(a, 2, true, rec + (size_t)blockIdx.x * kRedVals);
 }
