@@ -75,7 +75,7 @@ struct SearchParams {
     int32_t wide;                // 1 = the group holds a topic of >= 512 replica slots (k_search<..., kWide = true>)
     uint32_t launch;             // launch number (global iteration = launch*iters + i)
     uint32_t iters;
-    int32_t init;                // 1 = build the initial state of every restart first
+    int32_t init;                // 1 = build the initial state of every restart first; 2 = K-init has built it (launch_init), the rest of an initialising launch remains
     int32_t maxP, maxBx;         // LDS carve sizes
     int32_t bw;                  // 1 = topics of this launch carry broker weights (priced instantiation: the weight table is carved)
     uint32_t gen;                // generation of the population: salts the tie-break hash of the initial state (init = 1 with gen > 0 =
@@ -156,6 +156,7 @@ constexpr int search_rack_tab(int maxR) { return ((maxR < 1 ? 1 : maxR) + 1 + 63
 size_t search_lds_bytes(int maxP, int maxBx, int waves, bool global_a, bool priced = false, int nw = 4, bool bw = false, int maxR = kRackTab - 1, int team = 0, bool cur_global = false);
 size_t eval_lds_bytes(int maxP, int maxB, bool cur_in_lds, int ne = 4);
 void launch_search(const SearchPools &pools, const SearchParams &prm, int n_blocks, int waves, bool global_a, bool priced, int nw, void *stream, int team = 0);
+bool launch_init(const SearchPools &pools, const SearchParams &prm, int n_blocks, int per_block, bool priced, int nw, void *stream);   // K-init (topics in global memory)
 void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream);
 // copy every topic's winning snapshot (restart id in its packed key) and violation row into contiguous
 // read-back buffers: one D2H instead of two per topic

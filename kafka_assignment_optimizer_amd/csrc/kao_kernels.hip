@@ -409,7 +409,8 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
 
     int best_obj, accepted;
     if (prm.init) {
-        // surviving current replicas stay in their slots
+        // surviving current replicas stay in their slots (init == 2: k_init has seeded the state and filled its holes)
+        if (prm.init == 1)
         for (int p = tid; p < T.P; p += nthr) {
             Part<NW> c = CUR[p];
 #pragma unroll
@@ -449,7 +450,7 @@ __device__ __forceinline__ void search_body(unsigned char *smem, const SearchPoo
     recount(T, L, tid, nthr, krt);
     if (kTeam) __syncthreads();
 
-    if (prm.init) {
+    if (prm.init == 1) {
         // ---- hole filling by best insertion, holes in (p,k) order.  Partitions are inspected 64 at a time (one per
         //      lane); only those with a hole are visited, in ascending order. ----
         // Two passes: leader holes of all partitions first, then follower holes (leaders are the scarcer resource).
@@ -1156,6 +1157,184 @@ __global__ __launch_bounds__(NW == 8 ? 256 : 512) void k_team(SearchPools pl, Se
 }
 
 // ------------------------------------------------------------------------------------------------
+// K-init (round 6): the hole filling of an initialising launch, one WORKGROUP per restart -- topics in global memory only
+// ------------------------------------------------------------------------------------------------
+// search_body fills the holes with ONE wavefront per restart: every hole scans all Bx brokers, 64 per round, and the holes are a chain
+// (each insertion moves the counters the next one reads) -- 15,000 holes x 16 rounds = 70 ms for config 5 as one topic, on a quarter
+// of the chip's SIMDs at best.  Here the rounds of a hole are dealt to the W wavefronts of the workgroup (round j to wavefront j mod W);
+// every wavefront reduces its rounds to one record (key, lane, round, word), the records meet in LDS behind ONE workgroup barrier per hole
+// and every wavefront takes the same minimum in the order of the single-wavefront scan: lowest key, then lowest lane, then -- inside a
+// lane -- the earliest round.  Same holes, same order, same winners -- the replays (oracle/kao_port.c::ls_init) hold bit for bit; k_search / k_team
+// then run with prm.init = 2 (state seeded and filled, everything else as in an initialising launch).
+constexpr int kInitWaves = 16;
+size_t init_lds_bytes(int maxBx, int maxR, bool priced, bool bw) {
+    const size_t bx64 = (size_t)((maxBx + 63) & ~63), krt = (size_t)search_rack_tab(maxR);
+    return krt * 4 + bx64 + (priced ? (bw ? 2 : 1) * bx64 * 4 + krt * 4 : 0) + bx64 * 4 + krt * 4 + (size_t)kInitWaves * krt * 4 + 3 * 8;
+}
+template <bool kPriced, int NW>
+__global__ __launch_bounds__(64 * kInitWaves) void k_init(SearchPools pl, SearchParams prm, int per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_waves = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    const int2 bm = pl.block_map[blockIdx.x / (unsigned)per_block];
+    const TopicDev *TD = pl.topics + bm.x;
+    const int rho = bm.y + (int)(blockIdx.x % (unsigned)per_block);
+    if (rho >= TD->n_restarts) return;   // (the whole workgroup)
+
+    TopicRegs T;
+    T.P = TD->P; T.RF = TD->RF; T.R = TD->R; T.m = TD->m; T.Bx = TD->Bx; T.magic = TD->magic;
+    T.rep_lo = TD->rep_lo; T.rep_hi = TD->rep_hi; T.lead_lo = TD->lead_lo; T.lead_hi = TD->lead_hi;
+    T.rack_lo = TD->rack_lo; T.rack_hi = TD->rack_hi; T.prack_lo = TD->prack_lo; T.prack_hi = TD->prack_hi;
+    T.w00 = TD->w00; T.w01 = TD->w01; T.w10 = TD->w10; T.w11 = TD->w11;
+
+    // LDS: [RSZ int[krt]] [XR u8[bx64]] ([PR u32[bx64]] [PG int[krt]] ([BW u32[bx64]])) [C u32[bx64]] [K int[krt]] [KW int[W][krt]] [BEST u64[3]]
+    const int bx64 = (prm.maxBx + 63) & ~63, krt = search_rack_tab(prm.maxR);
+    const bool hbw = kPriced && prm.bw != 0;
+    const uint32_t inv = (uint32_t)krt - 1u;
+    unsigned char *q = smem;
+    int *RSZ = reinterpret_cast<int *>(q); q += krt * 4;
+    uint8_t *XR = q; q += bx64;
+    uint32_t *PR = reinterpret_cast<uint32_t *>(q); if (kPriced) q += bx64 * 4;
+    int *PG = reinterpret_cast<int *>(q); if (kPriced) q += krt * 4;
+    uint32_t *BW = reinterpret_cast<uint32_t *>(q); if (hbw) q += bx64 * 4;
+    WaveLds<NW> L;
+    L.C = reinterpret_cast<uint32_t *>(q); q += bx64 * 4;
+    L.K = reinterpret_cast<int *>(q); q += krt * 4;
+    L.W = nullptr; L.RT = nullptr;
+    int *KW = reinterpret_cast<int *>(q); q += kInitWaves * krt * 4;   // every wavefront's own copy of the rack counts
+    unsigned long long *BEST = reinterpret_cast<unsigned long long *>(q);   // the hole's winner over the wavefronts (LDS atomic min), three in rotation
+
+    for (int r = tid; r < krt; r += nthr) {
+        RSZ[r] = r < T.R ? pl.rsz_pool[TD->rsz_off + r] : 0;
+        if (kPriced) PG[r] = r < T.R ? price_units(pl.price_pool[TD->price_off + 2 * TD->B + r], prm.obj_scale) : 0;
+    }
+    __syncthreads();
+    for (int x = tid; x < ((T.Bx + 63) & ~63); x += nthr) {
+        const uint32_t r = mulhi((uint32_t)x, T.magic);
+        const bool valid = x < T.Bx && (int)((uint32_t)x - r * (uint32_t)T.m) < RSZ[r < (uint32_t)krt ? r : 0];
+        XR[x] = valid ? (uint8_t)r : (uint8_t)inv;
+        if (kPriced) {
+            uint32_t pr = 0;
+            if (valid) {
+                const int32_t *pp = pl.price_pool + TD->price_off;
+                const int b = pl.ext_pool[TD->ext_off + x];
+                pr = ((uint32_t)price_units(pp[b], prm.obj_scale) & 0xFFFFu) | ((uint32_t)price_units(pp[TD->B + b], prm.obj_scale) << 16);
+            }
+            PR[x] = pr;
+            if (hbw) BW[x] = (valid && TD->has_bw) ? pl.bw_pool[TD->bw_off + x] : 0u;
+        }
+    }
+    const Part<NW> *CUR = reinterpret_cast<const Part<NW> *>(pl.cur_pool + TD->cur_off);
+    L.A = reinterpret_cast<Part<NW> *>(pl.state_pool + TD->state_off) + (uint64_t)rho * T.P;
+    const uint32_t slo = TD->seed_lo, shi = TD->seed_hi;
+    const int S = prm.obj_scale;
+    for (int p = tid; p < T.P; p += nthr) {   // surviving current replicas stay in their slots
+        Part<NW> c = CUR[p];
+#pragma unroll
+        for (int k = 1; k < NW; ++k)
+            if (k >= T.RF) c.w[k] = kNoneW;
+        L.A[p] = c;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __syncthreads();
+    recount(T, L, tid, nthr, krt);
+    __syncthreads();
+    // Who reads what during the fill: C[x] only the wavefront that scans x's round, K[r] every wavefront.  So the winner's C entry is
+    // bumped by the wavefront that owns it, the rack counts live in one copy per wavefront, and a hole costs ONE workgroup barrier.
+    if (n_waves > 1) {
+        for (int r = lane; r < krt; r += 64) KW[wave * krt + r] = L.K[r];
+        L.K = KW + wave * krt;
+        if (tid < 3) BEST[tid] = ~0ull;
+        __syncthreads();
+    }
+
+    const uint32_t *HL = pl.cur_pool + TD->hole_off;
+    const int n_rounds = (T.Bx + 63) >> 6;
+    int par = 0;   // which BEST this hole uses
+    for (int pass = 0; pass < 2; ++pass) {   // leader holes of all partitions first, then follower holes
+        const uint32_t n_holes = HL[pass], *hl = HL + 2 + (pass ? HL[0] : 0u);
+        // The rows of 64 holes are fetched at once, one hole per lane, and handed out by v_readlane: a pass lists every partition once, so
+        // no row of the batch is written before its turn.  (Fetching them one hole ahead left two dependent global round trips, list entry
+        // then row, per hole: 1.5 us, the whole fill once the scan was spread over the workgroup.)
+        for (uint32_t h0 = 0; h0 < n_holes; h0 += 64) {
+          const uint32_t nb = min(64u, n_holes - h0);
+          const uint32_t p_l = hl[h0 + ((uint32_t)lane < nb ? (uint32_t)lane : 0u)];
+          const Part<NW> a_l = L.A[p_l], c_l = CUR[p_l];
+          for (uint32_t hi = 0; hi < nb; ++hi) {
+            const int p = __builtin_amdgcn_readlane((int)p_l, (int)hi);
+            Part<NW> a, c;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                a.w[w] = (uint32_t)__builtin_amdgcn_readlane((int)a_l.w[w], (int)hi);
+                c.w[w] = (uint32_t)__builtin_amdgcn_readlane((int)c_l.w[w], (int)hi);
+            }
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                if (k >= T.RF) break;
+                if ((k == 0) != (pass == 0)) continue;
+                if (a.w[k] != kNoneW) continue;   // uniform over the workgroup
+                const uint32_t hmix = slo ^ fmix32(shi + (uint32_t)rho * 0x9E3779B1u + (uint32_t)(p * NW + k) * 0x27D4EB2Fu + 0x5BD1E995u + prm.gen * 0x632BE5ABu);
+                const int wl = k == 0 ? T.w00 : T.w01, wf = k == 0 ? T.w10 : T.w11;
+                uint32_t key = kKeyNull, xw_l = kNoneW;
+                for (int j = wave; j < n_rounds; j += n_waves) {
+                    const uint32_t x = (uint32_t)(j * 64 + lane);
+                    const uint32_t r = XR[x];
+                    const uint32_t xw = x | (r << 16);
+                    const bool okx = (r != inv) & !in4(a, xw);
+                    const uint32_t cn = L.C[x];
+                    int dV = dinc((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi) + dinc(L.K[r], T.rack_lo, T.rack_hi) +
+                             dinc(cnt4(a, r), T.prack_lo, T.prack_hi);
+                    if (k == 0) dV += dinc((int)(cn >> 16), T.lead_lo, T.lead_hi);
+                    const uint32_t tie = fmix32(hmix + x * 0x165667B1u) >> 24;
+                    uint32_t keyx;
+                    if (kPriced) {
+                        const uint32_t prx = PR[x];
+                        int dP = p_in((int)(cn & 0xFFFFu), T.rep_lo, T.rep_hi, price_rep(prx)) + p_in(L.K[r], T.rack_lo, T.rack_hi, PG[r]);
+                        if (k == 0) dP += p_in((int)(cn >> 16), T.lead_lo, T.lead_hi, price_lead(prx));
+                        keyx = okx ? make_key_tie_p(prm.lam_max, S, dV, role_w2(c, xw, wl, wf) + (hbw ? bw_of(BW[x], k == 0) : 0), dP, tie) : kKeyNull;
+                    }
+                    else keyx = okx ? make_key_tie(prm.lam_max, S, dV, role_w2(c, xw, wl, wf), tie) : kKeyNull;
+                    if (keyx < key) { key = keyx; xw_l = xw; }   // (equal keys: the earlier round stays)
+                }
+                // this wavefront's winner: lowest key, then lowest lane (then, inside the lane, the earliest round: above)
+                uint32_t kmin = wave_umin(key);
+                const unsigned long long bal = __ballot(key == kmin);
+                const int l_win = __ffsll((long long)bal) - 1;
+                uint32_t xw_win = (uint32_t)__builtin_amdgcn_readlane((int)xw_l, l_win);
+                if (n_waves > 1) {
+                    // across the wavefronts the same order, (key, lane, round), packed with the rack into one 64-bit word: LDS atomic min.
+                    // Three words in rotation: the one two holes ahead is reset behind this hole's barrier (everybody has read it before).
+                    if (lane == 0) atomicMin(&BEST[par], ((unsigned long long)kmin << 32) | ((unsigned long long)l_win << 24) | ((unsigned long long)((xw_win & 0xFFFFu) >> 6) << 8) | (xw_win >> 16 & 0xFFu));
+                    // LDS traffic only is ordered here: __syncthreads() would also wait for the winner's global store of the previous hole
+                    // (vmcnt(0): a round trip to L2 per hole, ~1 us -- it was most of the fill); nobody reads those rows before the pass ends
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    const unsigned long long bw = BEST[par];
+                    const int nxt = par == 2 ? 0 : par + 1;
+                    if (tid == 0) BEST[nxt == 2 ? 0 : nxt + 1] = ~0ull;
+                    par = nxt;
+                    const uint32_t lo = (uint32_t)bw;
+                    xw_win = (((lo >> 8) & 0xFFFFu) << 6 | (lo >> 24)) | ((lo & 0xFFu) << 16);
+                }
+                a.w[k] = xw_win;
+                if (lane == 0) {
+                    const int owner = (int)(((xw_win & 0xFFFFu) >> 6) & (uint32_t)(n_waves - 1));   // (W is a power of two)
+                    if (wave == owner) {
+                        reinterpret_cast<uint32_t *>(&L.A[p])[k] = xw_win;
+                        L.C[xw_win & 0xFFFFu] += (k == 0) ? 0x10001u : 1u;
+                    }
+                    L.K[xw_win >> 16] += 1;   // own copy
+                }
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // pass 1 reads the rows pass 0 wrote
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K-eval
 // ------------------------------------------------------------------------------------------------
 // NE = replica slots handled per partition: 4 (RF and current RF <= 4) or 8.
@@ -1553,6 +1732,28 @@ void launch_search(const SearchPools &pools, const SearchParams &prm, int n_bloc
         else launch_search_w<false, false, 4>(pools, prm, n_blocks, waves, lds, a, wide, st);
     }
     if ((int)lds > a) a = (int)lds;
+}
+
+// K-init for one launch group of topics in global memory: `n_blocks` block-map entries of `per_block` restarts each.  False when the
+// tables do not fit (the caller leaves prm.init = 1: k_search fills the holes itself).
+bool launch_init(const SearchPools &pools, const SearchParams &prm, int n_blocks, int per_block, bool priced, int nw, void *stream) {
+    const size_t lds = init_lds_bytes(prm.maxBx, prm.maxR, priced, prm.bw != 0);
+    if (lds > 160 * 1024) return false;
+    static int attr[kAttrDevices][4] = {{0}};
+    int &a = attr[attr_slot()][(priced ? 2 : 0) + (nw == 8 ? 1 : 0)];
+    const void *fn = nw == 8 ? (priced ? reinterpret_cast<const void *>(k_init<true, 8>) : reinterpret_cast<const void *>(k_init<false, 8>))
+                             : (priced ? reinterpret_cast<const void *>(k_init<true, 4>) : reinterpret_cast<const void *>(k_init<false, 4>));
+    if ((int)lds > a && lds > 64 * 1024) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a = (int)lds; }
+    // (config 5 as one topic, 15,000 holes x 16 rounds, per K-init: 59.2 / 21.8 / 17.3 / 18.0 ms with 1 / 4 / 8 / 16 wavefronts -- beyond two rounds
+    // per wavefront the hole's fixed part, ~200 instructions of reduce / exchange / update behind one another, is what is left)
+    int waves = std::min(8, std::max(1, (prm.maxBx + 63) / 64));
+    if (const char *e = std::getenv("KAO_INIT_WAVES")) waves = std::min(kInitWaves, std::max(1, std::atoi(e)));   // measurement hook (0: see kao_session_step)
+    while (waves & (waves - 1)) waves &= waves - 1;   // a power of two (the kernel's owner-of-a-round mask)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(n_blocks * per_block)), block((unsigned)(64 * waves));
+    if (nw == 8) { if (priced) hipLaunchKernelGGL((k_init<true, 8>), grid, block, lds, st, pools, prm, per_block); else hipLaunchKernelGGL((k_init<false, 8>), grid, block, lds, st, pools, prm, per_block); }
+    else { if (priced) hipLaunchKernelGGL((k_init<true, 4>), grid, block, lds, st, pools, prm, per_block); else hipLaunchKernelGGL((k_init<false, 4>), grid, block, lds, st, pools, prm, per_block); }
+    return true;
 }
 
 void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream) {

@@ -837,7 +837,13 @@ int kao_session_step(kao_session *s) {
     for (const kao_session::LaunchGroup &g : s->groups) {
         sp.block_map = s->d_smap + g.smap_off;
         prm.maxP = g.maxP; prm.maxBx = g.maxBx; prm.maxR = g.maxR; prm.wide = g.wide ? 1 : 0; prm.cur_global = g.cur_global ? 1 : 0;
-        launch_search(sp, prm, g.smap_n, g.waves, g.global_a, s->priced, g.nw, s->stream, g.team);
+        SearchParams gp = prm;
+        if (gp.init && g.global_a) {   // topics in global memory: the holes are filled by a workgroup per restart (K-init), not by one wavefront
+            const char *e = std::getenv("KAO_INIT_WAVES");
+            if (!(e && e[0] == '0') && launch_init(sp, gp, g.smap_n, g.team > 0 ? 1 : g.waves, s->priced, g.nw, s->stream)) gp.init = 2;
+            HIP_TRY(hipGetLastError());
+        }
+        launch_search(sp, gp, g.smap_n, g.waves, g.global_a, s->priced, g.nw, s->stream, g.team);
         HIP_TRY(hipGetLastError());
     }
     if (prof) HIP_TRY(hipEventRecord(e[1], s->stream));

@@ -526,6 +526,42 @@ def test_team_search_replay_bit_exact(kao, ko, kp, team):
             assert (dev["best_obj"], dev["V"], dev["obj"], dev["n_accept"]) == (ref["best_obj"], ref["V"], ref["obj"], ref["n_accept"])
 
 
+@pytest.mark.parametrize("shape", ["rf3", "rf6", "rf3_priced_team"])
+def test_k_init_fills_the_holes_like_one_wavefront(kao, ko, kp, monkeypatch, shape):
+    """Round 6: topics in global memory get their holes filled by K-init, one WORKGROUP per restart (the rounds of a hole dealt to its
+    wavefronts, one LDS atomic min and one barrier per hole), instead of one wavefront inside k_search.  Same holes, same order, same
+    winners: the restart states after the first launches are those of KAO_INIT_WAVES=0 (the old fill) for every team size, for the
+    8-word instantiation (RF 6) and with host-set prices behind a re-initialisation; and they are the scalar replay's (kao_port.c)."""
+    from kafka_assignment_optimizer_amd import synthetic
+    rf = 6 if shape == "rf6" else 3
+    gone = [3, 33, 133, 233, 333, 433, 533, 633, 733, 833]
+    pt = synthetic.make_cluster(1000, 20, 1, 6000, rf, gone, [(1000 + i, (7 * i) % 20) for i in range(8)])[0]
+    ot = _oracle_topic(ko, pt)
+    seed, iters, team = 4242, 24, (4 if shape.endswith("team") else 1)
+    rng = np.random.default_rng(6)
+    prices = ((rng.integers(-8, 9, ot.n_brokers) * 16384).astype(np.int32), (rng.integers(-4, 5, ot.n_brokers) * 16384).astype(np.int32),
+              (rng.integers(-2, 3, ot.n_racks) * 16384).astype(np.int32)) if "priced" in shape else None
+    monkeypatch.setenv("KAO_CUR_GLOBAL", "0")
+    sigs = {}
+    for waves in ("0", "1", "2", "8", "16", None):
+        if waves is None: monkeypatch.delenv("KAO_INIT_WAVES", raising=False)
+        else: monkeypatch.setenv("KAO_INIT_WAVES", waves)
+        with kao.Session([pt], seed=seed, restarts=3, iters_per_launch=iters, team=team) as s:
+            assert s.stats()["lds_bytes_search"] < 48 * 1024            # the global-memory path
+            if prices is not None: s.set_prices(0, *prices)
+            s.step(2)
+            st = [s.restart_state(0, rho) for rho in range(3)]
+        sigs[waves] = [(d["final"].tobytes(), d["best"].tobytes(), d["best_obj"], d["V"], d["obj"], d["n_accept"]) for d in st]
+        if waves is None:
+            tseed = seed ^ 0x9E3779B97F4A7C15
+            for rho in (0, 2):
+                run = kp.PortRun(ot, tseed, rho, team=team)
+                run.launch(0, iters, prices=prices); run.launch(1, iters, prices=prices)
+                ref = run.read()
+                assert np.array_equal(st[rho]["final"], ref["final"]) and (st[rho]["V"], st[rho]["obj"], st[rho]["n_accept"]) == (ref["V"], ref["obj"], ref["n_accept"])
+    assert all(v == sigs["0"] for v in sigs.values()), [k for k, v in sigs.items() if v != sigs["0"]]
+
+
 def test_config5_as_one_topic(kao, ko, kp):
     """BASELINE config 5 taken literally as ONE topic: 1000 brokers, 20 racks, 100,000 partitions, RF 3, 50 brokers
     replaced, per-broker cap ceil(avg)+1 (north_star: time-to-optimal <= 1 s).  The topic (1.6 MB of assignment words
