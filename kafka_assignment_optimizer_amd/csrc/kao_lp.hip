@@ -385,7 +385,8 @@ __device__ __forceinline__ bool lp_col(const LpDev &D, const double *th, const d
 
 // ---- Schur complement, broker rows: one wavefront per broker walks the broker's incidences in order -----------------------
 // rows C3[b] and C4[b] are accumulated in LDS (2 x mc doubles per wavefront) and written once (lower triangle)
-template <int U>
+// NCL = columns per lane: 1 (up to 64 coupling columns per partition, 2 RF + 2 R: 29 racks at RF 3) or 2 (up to 128: 61 racks)
+template <int U, int NCL = 1>
 __global__ void __launch_bounds__(256) k_lp_schur_broker(LpDev D, const double *__restrict__ th, const double *__restrict__ thg, const double *__restrict__ fj,
                                                           const double *__restrict__ fr, const double *__restrict__ ti, const double *__restrict__ qd, const int *__restrict__ qc,
                                                           const double *__restrict__ wr, double *__restrict__ S) {
@@ -400,46 +401,53 @@ __global__ void __launch_bounds__(256) k_lp_schur_broker(LpDev D, const double *
     double *rowA = lds_rows + (size_t)wave * 2 * mc, *rowB = rowA + mc;
     for (int i = lane; i < 2 * mc; i += 64) rowA[i] = 0.0;
     const int r0 = D.rack[b], nc = 2 * NJ + 2 * R;
-    if (nc <= 64) {
-        // Every lane owns one column of an incidence; U incidences are in flight.  An incidence is TWO dependent round trips (round 6): the
+    if (nc <= 64 * NCL) {
+        // Every lane owns one column (NCL = 2: two) of an incidence; U incidences are in flight.  An incidence is TWO dependent round trips (round 6): the
         // incidence word (scalar), then everything else, which depends on the partition only -- the incidence's own rows premultiplied by
         // T^-1 and the replica columns come precomputed from k_lp_factor_local (wr, qd, qc), the rack columns are two products away from
         // theta and the reciprocal rack factors.  (Round 5 walked incidence word -> partition's factors -> rack of the column's broker ->
         // rack factors: four trips, 1.07 ms at 100,000 partitions with one wavefront per SIMD.)  The adds reach every column in incidence
         // order: the same bits on every run.
         const int e1 = D.inc_off[b + 1];
-        const int c = lane;
-        const bool has_col = c < nc;
-        const int ncp = (nc + 7) & ~7, cl = has_col ? c : 0;
+        bool has_col[NCL]; int cl[NCL];
+#pragma unroll
+        for (int n = 0; n < NCL; ++n) { has_col[n] = lane + 64 * n < nc; cl[n] = has_col[n] ? lane + 64 * n : 0; }
+        const int ncp = (nc + 7) & ~7;
         const size_t cs = (size_t)P * ncp;
         for (int e = D.inc_off[b]; e < e1; e += U) {
             int pp[U], j0[U]; bool live[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { live[u] = e + u < e1; const int idx = D.inc[min(e + u, e1 - 1)]; pp[u] = idx >> 3; j0[u] = idx & 7; }
-            double w30[U], w31[U], w40[U], w41[U], s11[U], s12[U], s22[U], q0[U], q1[U], qe[U];
-            int col[U], rk[U];
+            double w30[U], w31[U], w40[U], w41[U], s11[U], s12[U], s22[U], q0[U][NCL], q1[U][NCL], qe[U][NCL];
+            int col[U][NCL], rk[U][NCL];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int p = pp[u];
                 w30[u] = wr[((size_t)0 * NJ + j0[u]) * P + p]; w31[u] = wr[((size_t)1 * NJ + j0[u]) * P + p];
                 w40[u] = wr[((size_t)2 * NJ + j0[u]) * P + p]; w41[u] = wr[((size_t)3 * NJ + j0[u]) * P + p];
                 s11[u] = fj[((size_t)0 * NJ + j0[u]) * P + p]; s12[u] = fj[((size_t)1 * NJ + j0[u]) * P + p]; s22[u] = fj[((size_t)2 * NJ + j0[u]) * P + p];
-                const size_t k = (size_t)p * ncp + cl;      // consecutive lanes, consecutive columns of the partition
-                q0[u] = qd[k]; q1[u] = qd[cs + k]; qe[u] = qd[2 * cs + k];
-                const int w = qc[k];
-                col[u] = (w < 0 || !has_col) ? -1 : (w & 0xFFFF); rk[u] = w < 0 ? -1 : (w >> 16);
+#pragma unroll
+                for (int n = 0; n < NCL; ++n) {
+                    const size_t k = (size_t)p * ncp + cl[n];      // consecutive lanes, consecutive columns of the partition
+                    q0[u][n] = qd[k]; q1[u][n] = qd[cs + k]; qe[u][n] = qd[2 * cs + k];
+                    const int w = qc[k];
+                    col[u][n] = (w < 0 || !has_col[n]) ? -1 : (w & 0xFFFF); rk[u][n] = w < 0 ? -1 : (w >> 16);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!live[u] || col[u] < 0) continue;
-                double v3 = -(w30[u] * q0[u] + w31[u] * q1[u]), v4 = -(w40[u] * q0[u] + w41[u] * q1[u]);
-                if (rk[u] == r0) {
-                    v3 -= s11[u] * qe[u]; v4 -= s12[u] * qe[u];                   // a3.eps = s11, a4.eps = s12
-                    if (c == 2 * j0[u]) { v3 += s11[u]; v4 += s12[u]; }          // (C3, C3) = sig11, (C4, C3) = sig12
-                    else if (c == 2 * j0[u] + 1) { v3 += s12[u]; v4 += s22[u]; } // (C3, C4) = sig12, (C4, C4) = sig22
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int n = 0; n < NCL; ++n) {
+                    if (!live[u] || col[u][n] < 0) continue;
+                    const int c = lane + 64 * n;
+                    double v3 = -(w30[u] * q0[u][n] + w31[u] * q1[u][n]), v4 = -(w40[u] * q0[u][n] + w41[u] * q1[u][n]);
+                    if (rk[u][n] == r0) {
+                        v3 -= s11[u] * qe[u][n]; v4 -= s12[u] * qe[u][n];                   // a3.eps = s11, a4.eps = s12
+                        if (c == 2 * j0[u]) { v3 += s11[u]; v4 += s12[u]; }          // (C3, C3) = sig11, (C4, C3) = sig12
+                        else if (c == 2 * j0[u] + 1) { v3 += s12[u]; v4 += s22[u]; } // (C3, C4) = sig12, (C4, C4) = sig22
+                    }
+                    rowA[col[u][n]] += v3; rowB[col[u][n]] += v4;
                 }
-                rowA[col[u]] += v3; rowB[col[u]] += v4;
-            }
         }
     } else
     for (int e = D.inc_off[b]; e < D.inc_off[b + 1]; ++e) {
@@ -540,7 +548,7 @@ __global__ void k_lp_schur_rack_sum(LpDev D, const double *part, int nblk, const
     }
     S[(size_t)a * D.mcp + c] = s;    // rows NF[r] = r, NL[r] = R + r: exactly the numbering of a
 }
-// The same block on the matrix cores (round 6; 2R <= 64).  The block is a sum over the partitions of outer products,
+// The same block on the matrix cores (round 6; 2R <= 128).  The block is a sum over the partitions of outer products,
 //   S[a][c] = sum_p -(w0_a v0_c + w1_a v1_c) - [rack a == rack c] (cy_a / d) cy_c + [a == c] cy_a,      a, c in NF[0..R) NL[0..R),
 // i.e. two (three with the same-rack term, masked afterwards) 2R x P x 2R products: v_mfma_f64_16x16x4_f64 with the partitions as the
 // k index.  Lane (m, q) of a wavefront holds column 16 t + m of partition p0 + q for every 16-column tile t, which is at once the A operand
@@ -548,20 +556,25 @@ __global__ void k_lp_schur_rack_sum(LpDev D, const double *part, int nblk, const
 // workgroup are added in order through LDS, the workgroups' partial blocks by k_lp_schur_rack_sum2 in order: the same bits on every run.
 typedef double lp_v4d __attribute__((ext_vector_type(4)));
 constexpr int kRackMfmaBlocks = 256;
-template <int T16>
-__global__ void __launch_bounds__(256) k_lp_schur_rack_mfma(LpDev D, const double *__restrict__ th, const double *__restrict__ fr, const double *__restrict__ ti, double *__restrict__ part) {
-    if (LP_STOPPED(D)) return;
-    constexpr int NP = T16 * (T16 + 1) / 2;                 // tile pairs (row tile >= column tile)
-    constexpr int NE = 2 * NP * 256 + T16 * 16;             // doubles of one partial record: C tiles, same-rack tiles, column sums
-    __shared__ double comb[NE];
+constexpr int kRackMfmaT16Max = 8;                          // 2R <= 128
+constexpr int rack_mfma_record(int t16) { return 2 * (t16 * (t16 + 1) / 2) * 256 + t16 * 16; }   // doubles of one partial record: C tiles, same-rack tiles, column sums
+// One workgroup's share: the tile rows TA0 .. TA1-1 (against the tile columns 0 .. ta) of the block.  Up to 64 columns (T16 <= 4) that is the
+// whole lower triangle, ten tile pairs in 160 accumulator registers; up to 128 columns (33 .. 64 racks) the rows are dealt to four groups
+// of workgroups (blockIdx.y: rows 0-3, 4-5, 6, 7 = 10, 11, 7, 8 pairs), every group walking all the partitions: the operands of the
+// columns left of a group's rows are formed again by it (25 tile operands instead of 8 per four partitions; they are a quarter of a GB).
+template <int T16, int TA0, int TA1>
+__device__ __forceinline__ void rack_mfma_rows(const LpDev &D, const double *__restrict__ th, const double *__restrict__ fr, const double *__restrict__ ti, double *__restrict__ part, double *comb) {
+    constexpr int NPALL = T16 * (T16 + 1) / 2;              // tile pairs (row tile >= column tile) of the whole block: the record's numbering
+    constexpr int NE = rack_mfma_record(T16);
+    constexpr int K0 = TA0 * (TA0 + 1) / 2, NP = TA1 * (TA1 + 1) / 2 - K0;   // this share's pairs: K0 .. K0 + NP - 1
     const int R = D.R, P = D.P, n2 = 2 * R;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lm = lane & 15, lq = lane >> 4;
     const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + w;
     const int chunk = ((P + nwaves - 1) / nwaves + 3) / 4 * 4;
     const int pb = min(P, gw * chunk), pe = min(P, pb + chunk);
-    int vy[T16], rr[T16]; bool on[T16], nl[T16];
+    int vy[TA1], rr[TA1]; bool on[TA1], nl[TA1];
 #pragma unroll
-    for (int t = 0; t < T16; ++t) {
+    for (int t = 0; t < TA1; ++t) {
         const int a = 16 * t + lm;
         on[t] = a < n2; nl[t] = a >= R;
         rr[t] = on[t] ? a % R : 0;
@@ -570,42 +583,45 @@ __global__ void __launch_bounds__(256) k_lp_schur_rack_mfma(LpDev D, const doubl
     lp_v4d C[NP], G[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) { C[k] = lp_v4d{0.0, 0.0, 0.0, 0.0}; G[k] = lp_v4d{0.0, 0.0, 0.0, 0.0}; }
-    double dsum[T16];
+    double dsum[TA1 - TA0];
 #pragma unroll
-    for (int t = 0; t < T16; ++t) dsum[t] = 0.0;
+    for (int t = 0; t < TA1 - TA0; ++t) dsum[t] = 0.0;
     for (int p0 = pb; p0 < pe; p0 += 4) {
         const int p = p0 + lq;
         const bool live = p < pe;
         const int pc = live ? p : pb;
         const double i11 = ti[(size_t)0 * P + pc], i12 = ti[(size_t)1 * P + pc], i22 = ti[(size_t)2 * P + pc];
-        double v0[T16], v1[T16], w0[T16], w1[T16], cy[T16], g[T16];
+        double v0[TA1], v1[TA1], w0[TA1 - TA0], w1[TA1 - TA0], cy[TA1], g[TA1 - TA0];
 #pragma unroll
-        for (int t = 0; t < T16; ++t) {
+        for (int t = 0; t < TA1; ++t) {
             const double c = th[(size_t)vy[t] * P + pc], d = fr[((size_t)0 * R + rr[t]) * P + pc], e1 = fr[((size_t)1 * R + rr[t]) * P + pc], e2 = fr[((size_t)2 * R + rr[t]) * P + pc];
             const bool use = live && on[t];
             cy[t] = use ? c : 0.0;
-            g[t] = use ? c / d : 0.0;
             v0[t] = use ? c - e1 * c / d : 0.0;
             v1[t] = use ? (nl[t] ? c : 0.0) - e2 * c / d : 0.0;
-            w0[t] = i11 * v0[t] + i12 * v1[t]; w1[t] = i12 * v0[t] + i22 * v1[t];
-            dsum[t] += cy[t];
+            if (t >= TA0) {
+                g[t - TA0] = use ? c / d : 0.0;
+                w0[t - TA0] = i11 * v0[t] + i12 * v1[t]; w1[t - TA0] = i12 * v0[t] + i22 * v1[t];
+                dsum[t - TA0] += cy[t];
+            }
         }
 #pragma unroll
-        for (int ta = 0; ta < T16; ++ta)
+        for (int ta = TA0; ta < TA1; ++ta)
 #pragma unroll
             for (int tc = 0; tc <= ta; ++tc) {
-                const int k = ta * (ta + 1) / 2 + tc;
-                C[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w0[ta], v0[tc], C[k], 0, 0, 0);
-                C[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w1[ta], v1[tc], C[k], 0, 0, 0);
-                G[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-g[ta], cy[tc], G[k], 0, 0, 0);
+                const int k = ta * (ta + 1) / 2 + tc - K0;
+                C[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w0[ta - TA0], v0[tc], C[k], 0, 0, 0);
+                C[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-w1[ta - TA0], v1[tc], C[k], 0, 0, 0);
+                G[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-g[ta - TA0], cy[tc], G[k], 0, 0, 0);
             }
     }
     // column sums: the four q-lanes of a column, in order
 #pragma unroll
-    for (int t = 0; t < T16; ++t) {
+    for (int t = 0; t < TA1 - TA0; ++t) {
         const double s1 = __shfl(dsum[t], lm + 16, 64), s2 = __shfl(dsum[t], lm + 32, 64), s3 = __shfl(dsum[t], lm + 48, 64);
         dsum[t] = ((dsum[t] + s1) + s2) + s3;       // (meaningful on lanes 0..15)
     }
+    // comb: [NP pairs x 256] C, [NP x 256] G, [(TA1 - TA0) x 16] column sums
     for (int ww = 0; ww < 4; ++ww) {               // the workgroup's four wavefronts, added in order
         if (w == ww) {
 #pragma unroll
@@ -618,18 +634,36 @@ __global__ void __launch_bounds__(256) k_lp_schur_rack_mfma(LpDev D, const doubl
                 }
             if (lane < 16)
 #pragma unroll
-                for (int t = 0; t < T16; ++t) comb[2 * NP * 256 + 16 * t + lane] = ww ? comb[2 * NP * 256 + 16 * t + lane] + dsum[t] : dsum[t];
+                for (int t = 0; t < TA1 - TA0; ++t) comb[2 * NP * 256 + 16 * t + lane] = ww ? comb[2 * NP * 256 + 16 * t + lane] + dsum[t] : dsum[t];
         }
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < NE; e += 256) part[(size_t)blockIdx.x * NE + e] = comb[e];
+    double *rec = part + (size_t)blockIdx.x * NE;   // the record keeps the whole block's numbering: this share fills its own entries
+    for (int e = threadIdx.x; e < NP * 256; e += 256) { rec[K0 * 256 + e] = comb[e]; rec[NPALL * 256 + K0 * 256 + e] = comb[NP * 256 + e]; }
+    for (int e = threadIdx.x; e < (TA1 - TA0) * 16; e += 256) rec[2 * NPALL * 256 + TA0 * 16 + e] = comb[2 * NP * 256 + e];
 }
+constexpr int kRackMfmaComb = 2 * 11 * 256 + 4 * 16;        // the largest share: 11 pairs (rows 4-5 of eight), four tile rows of column sums
+template <int T16>
+__global__ void __launch_bounds__(256) k_lp_schur_rack_mfma(LpDev D, const double *__restrict__ th, const double *__restrict__ fr, const double *__restrict__ ti, double *__restrict__ part) {
+    if (LP_STOPPED(D)) return;
+    __shared__ double comb[T16 <= 4 ? 2 * (T16 * (T16 + 1) / 2) * 256 + T16 * 16 : kRackMfmaComb];
+    if constexpr (T16 <= 4) rack_mfma_rows<T16, 0, T16>(D, th, fr, ti, part, comb);
+    else {   // (blockIdx.y is uniform: one share per workgroup)
+        if (blockIdx.y == 0) rack_mfma_rows<T16, 0, 4>(D, th, fr, ti, part, comb);
+        else if (blockIdx.y == 1) rack_mfma_rows<T16, 4, (T16 < 6 ? T16 : 6)>(D, th, fr, ti, part, comb);
+        else if constexpr (T16 >= 7) {
+            if (blockIdx.y == 2) rack_mfma_rows<T16, 6, 7>(D, th, fr, ti, part, comb);
+            else if constexpr (T16 >= 8) rack_mfma_rows<T16, 7, 8>(D, th, fr, ti, part, comb);
+        }
+    }
+}
+constexpr int rack_mfma_shares(int t16) { return t16 <= 4 ? 1 : t16 <= 6 ? 2 : t16 == 7 ? 3 : 4; }
 // 16 entries x 16 slices of the partial records per workgroup: a thread adds its slice in record order, the slices are added in order
 // through LDS (one thread per entry walking all 256 records took 0.16 ms: 25 wavefronts of dependent loads)
 template <int T16>
 __global__ void __launch_bounds__(256) k_lp_schur_rack_sum2(LpDev D, const double *__restrict__ part, int nblk, const double *__restrict__ thg, double *__restrict__ S) {
     if (LP_STOPPED(D)) return;
-    constexpr int NP = T16 * (T16 + 1) / 2, NE = 2 * NP * 256 + T16 * 16;
+    constexpr int NP = T16 * (T16 + 1) / 2, NE = rack_mfma_record(T16);
     __shared__ double sl[16][17];
     const int n2 = 2 * D.R, ne = n2 * n2;
     const int el = threadIdx.x & 15, slice = threadIdx.x >> 4;
@@ -1216,8 +1250,8 @@ struct LpCtx {
     double *rec = nullptr, *redA = nullptr, *redB = nullptr, *redC = nullptr, *part = nullptr, *ylast = nullptr, *trace = nullptr;
     int32_t *d_mult = nullptr, *d_zq = nullptr;
     VarVec dc{}; RowVec wc{}; int mcc = 2;   // centrality correctors per iteration (KAO_LP_MCC; 0: none) and their direction / row vector
-    bool rack_mfma = true;         // the rack x rack block of the Schur complement on the matrix cores (2R <= 64; KAO_LP_RACK=old: the LDS-tiled kernel)
-    double *qd = nullptr, *wr = nullptr; int *qc = nullptr; int ncp = 0;   // the partitions' coupling columns / replica rows for k_lp_schur_broker (k_lp_factor_local); ncp = columns per partition, padded (0: more than 64, not kept)
+    bool rack_mfma = true;         // the rack x rack block of the Schur complement on the matrix cores (2R <= 128; KAO_LP_RACK=old: the LDS-tiled kernel)
+    double *qd = nullptr, *wr = nullptr; int *qc = nullptr; int ncp = 0;   // the partitions' coupling columns / replica rows for k_lp_schur_broker (k_lp_factor_local); ncp = columns per partition, padded (0: more than 128, not kept)
     double *rack_part = nullptr;   // [2 R][kRackChunks] slice sums of the rack rows
     int broker_u = 4;          // incidences in flight per wavefront in k_lp_schur_broker (KAO_LP_BROKER_U: 4 / 8 / 16)
     double *xz = nullptr;      // exchange vectors of the triangular solves (kao_chol.hip)
@@ -1294,17 +1328,22 @@ void lp_factor(LpCtx &c) {
     hipLaunchKernelGGL(k_lp_factor_local, dim3(c.nblk_p), dim3(256), 0, c.st, D, c.th.z, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.ncp);
     const size_t lds_b = (size_t)c.broker_waves * 2 * D.mc * sizeof(double);
     const dim3 bg((D.B + c.broker_waves - 1) / c.broker_waves), bb(64 * c.broker_waves);
-    if (c.broker_u >= 16) hipLaunchKernelGGL(k_lp_schur_broker<16>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
+    if (2 * D.NJ + 2 * D.R > 64) hipLaunchKernelGGL((k_lp_schur_broker<4, 2>), bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
+    else if (c.broker_u >= 16) hipLaunchKernelGGL(k_lp_schur_broker<16>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
     else if (c.broker_u >= 8) hipLaunchKernelGGL(k_lp_schur_broker<8>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
     else hipLaunchKernelGGL(k_lp_schur_broker<4>, bg, bb, lds_b, c.st, D, c.th.z, c.th.zg, c.fj, c.fr, c.ti, c.qd, c.qc, c.wr, c.S);
     const int n2 = 2 * D.R, per = 6 * n2 + D.R, t16 = (n2 + 15) / 16;
     const dim3 sg((n2 * n2 + 255) / 256), sb(256), sg2((n2 * n2 + 15) / 16);
-#define KAO_RACK_MFMA(T) do { hipLaunchKernelGGL(k_lp_schur_rack_mfma<T>, dim3(kRackMfmaBlocks), dim3(256), 0, c.st, D, c.th.z, c.fr, c.ti, c.part); \
+#define KAO_RACK_MFMA(T) do { hipLaunchKernelGGL(k_lp_schur_rack_mfma<T>, dim3(kRackMfmaBlocks, rack_mfma_shares(T)), dim3(256), 0, c.st, D, c.th.z, c.fr, c.ti, c.part); \
                               hipLaunchKernelGGL(k_lp_schur_rack_sum2<T>, sg2, sb, 0, c.st, D, c.part, kRackMfmaBlocks, c.th.zg, c.S); } while (0)
     if (c.rack_mfma && t16 == 1) KAO_RACK_MFMA(1);
     else if (c.rack_mfma && t16 == 2) KAO_RACK_MFMA(2);
     else if (c.rack_mfma && t16 == 3) KAO_RACK_MFMA(3);
     else if (c.rack_mfma && t16 == 4) KAO_RACK_MFMA(4);
+    else if (c.rack_mfma && t16 == 5) KAO_RACK_MFMA(5);
+    else if (c.rack_mfma && t16 == 6) KAO_RACK_MFMA(6);
+    else if (c.rack_mfma && t16 == 7) KAO_RACK_MFMA(7);
+    else if (c.rack_mfma && t16 == 8) KAO_RACK_MFMA(8);
     else {
         hipLaunchKernelGGL(k_lp_schur_rack, dim3(c.rack_blocks), dim3(256), (size_t)c.rack_tile * per * sizeof(double), c.st, D, c.th.z, c.fj, c.fr, c.ti, c.rack_chunk, c.rack_tile, c.part);
         hipLaunchKernelGGL(k_lp_schur_rack_sum, sg, sb, 0, c.st, D, c.part, c.rack_blocks, c.th.zg, c.S);
@@ -1458,12 +1497,12 @@ int lp_open(const kao_topic *t, LpCtx **out, const LpShard *shard) {
     c->rack_chunk = std::max(c->rack_tile, ((P + 255) / 256 + c->rack_tile - 1) / c->rack_tile * c->rack_tile);   // about 256 blocks
     c->rack_blocks = (P + c->rack_chunk - 1) / c->rack_chunk;
     c->trace_cap = 512;
-    c->ncp = 2 * NJ + 2 * R <= 64 ? (2 * NJ + 2 * R + 7) & ~7 : 0;
+    c->ncp = 2 * NJ + 2 * R <= 128 ? (2 * NJ + 2 * R + 7) & ~7 : 0;   // (k_lp_schur_broker: one or two columns per lane)
     if ((rc = c->alloc(&c->fj, (size_t)6 * NJ * P)) || (rc = c->alloc(&c->fr, (size_t)6 * R * P)) || (rc = c->alloc(&c->ti, (size_t)3 * P)) ||
         (rc = c->alloc(&c->S, (size_t)D.mcp * D.mcp)) || (rc = c->alloc(&c->Linv, (size_t)D.mcp * kNB)) || (rc = c->alloc(&c->diag0, (size_t)D.mcp)) || (rc = c->alloc(&c->cb, (size_t)2 * NJ * P)) ||
         (rc = c->alloc(&c->cr, (size_t)2 * R * P)) || (rc = c->alloc(&c->rec, (size_t)std::max(c->nblk_var, c->nblk_p) * kRedVals)) ||
         (rc = c->alloc(&c->redA, (size_t)kRedVals)) || (rc = c->alloc(&c->redB, (size_t)kRedVals)) || (rc = c->alloc(&c->redC, (size_t)kRedVals)) ||
-        (rc = c->alloc(&c->part, std::max((size_t)c->rack_blocks * n2 * n2, (size_t)kRackMfmaBlocks * (2 * 10 * 256 + 64)))) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
+        (rc = c->alloc(&c->part, std::max((size_t)c->rack_blocks * n2 * n2, (size_t)kRackMfmaBlocks * rack_mfma_record(std::min(kRackMfmaT16Max, (n2 + 15) / 16))))) || (rc = c->alloc(&c->ylast, (size_t)D.mcp)) ||
         (rc = c->alloc(&c->xz, (size_t)2 * D.mcp)) || (rc = c->alloc(&c->tri, shard ? (size_t)mc * (mc + 1) / 2 : 1)) || (rc = c->alloc(&c->qd, (size_t)3 * c->ncp * P)) || (rc = c->alloc(&c->qc, (size_t)c->ncp * P)) || (rc = c->alloc(&c->wr, (size_t)4 * NJ * P)) || (rc = c->alloc(&c->rack_part, (size_t)2 * R * kRackChunks)) ||
         (rc = c->alloc(&c->d_mult, (size_t)2 * B + R)) || (rc = c->alloc(&D.sc, (size_t)kScN)) || (rc = c->alloc(&c->trace, (size_t)5 * c->trace_cap)))
         return bail(rc);
@@ -1471,6 +1510,7 @@ int lp_open(const kao_topic *t, LpCtx **out, const LpShard *shard) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_broker<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     { const char *e = std::getenv("KAO_LP_RACK"); c->rack_mfma = !(e && e[0] == 'o'); }
     { const char *e = std::getenv("KAO_LP_BROKER_U"); c->broker_u = e ? std::atoi(e) : 4; }   // (round 6, measured at 100,000 partitions: 4.10 / 4.29 / 4.41 ms an iteration with 4 / 8 / 16)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_lp_schur_rack), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

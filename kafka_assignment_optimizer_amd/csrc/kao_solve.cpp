@@ -215,12 +215,16 @@ struct SolveRun {
     // starting point, the read-back and the rounding.  Constants measured on one MI355X (round 6, profiles/r06_*); a limit is an input,
     // not the clock: the schedule stays count-keyed.
     double lp_ms_base = 0.50, lp_ms_tile = 0.05, lp_ms_kpart = 0.020, lp_iters_est = 125.0, lp_s_fixed = 0.12, lp_fit = 0.8;
+    // beyond 20 racks both grow (1000 x 100,000 at 30 / 40 / 50 racks: 4.9 / 5.9 / 6.7 ms an iteration against 4.0, 120-190 iterations): the
+    // per-partition rack work of the eliminations and of the Schur rows, and a slower approach to the vertex
+    double lp_ms_kpart_rack = 0.0009, lp_iters_rack = 2.0;
     double lp_reserve_s = 0.2;    // an LP that runs before there is any incumbent is given up this long before the deadline: K-search needs ~0.16 s to a first feasible plan at 100,000 partitions
     double lp_wait_until(int i) const { return feasible(i) ? deadline : deadline - lp_reserve_s; }
     double lp_est_s(int i) const {
         const kao_topic &t = topics[i];
         const int nt = (3 * t.n_racks + 2 * t.n_brokers + 63) / 64;
-        return lp_s_fixed + 1e-3 * lp_iters_est * (lp_ms_base + lp_ms_tile * nt + lp_ms_kpart * t.n_partitions / 1000.0);
+        const double xr = std::max(0, t.n_racks - 20);
+        return lp_s_fixed + 1e-3 * (lp_iters_est + lp_iters_rack * xr) * (lp_ms_base + lp_ms_tile * nt + (lp_ms_kpart + lp_ms_kpart_rack * xr) * t.n_partitions / 1000.0);
     }
     bool lp_fits(int i, double extra_s = 0.0) const { return lp_est_s(i) + extra_s <= lp_fit * (deadline - t0); }
     bool lp_alone(int i) const {

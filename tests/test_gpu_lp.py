@@ -57,9 +57,11 @@ def test_lp_kat1(kao, ko, kp):
     assert b["bound"] == 58 and abs(b["dual"] - 58.0) < 1e-4
 
 
-@pytest.mark.parametrize("B,R,P", [(100, 5, 1000), (130, 5, 1000)])
+@pytest.mark.parametrize("B,R,P", [(100, 5, 1000), (130, 5, 1000), (120, 30, 800), (160, 40, 800), (200, 50, 900), (256, 64, 1000)])
 def test_lp_trace_matches_the_restatement(kao, ko, kp, B, R, P):
-    """Rigid bands (two pinned coupling rows) and slack bands: device trace == scalar restatement to 1e-7 relative, both end at
+    """Rigid bands (two pinned coupling rows) and slack bands; 30 / 40 / 50 / 64 racks: 66 .. 134 coupling columns per partition (two per lane
+    in k_lp_schur_broker up to 128, its one-column walk beyond) and a rack block of 4 / 5 / 7 / 8 tiles of 16 (k_lp_schur_rack_mfma in one
+    to four shares of tile rows).  Device trace == scalar restatement to 1e-7 relative, both end at
     the HiGHS value of the compact LP, the multipliers agree to a few hundredths, and the dual value K-bound
     computes at the device's multipliers equals the restatement's exact evaluation (oracle/kao_port.c) at the same multipliers
     bit for bit."""
