@@ -761,6 +761,66 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
             }
         }
     }
+    // ---- and the racks (round 6): with a rigid rack band (15,000 replicas per rack exactly) and loose broker bands the completion may leave
+    //      one rack a replica over its band and another one under it -- 100 brokers added to 1,000: two of the first four perturbed solves
+    //      rounded to the optimum's value with 2 or 4 units of C6 (README.md:173-176) and nothing else, and K-search took three seconds
+    //      over them.  A follower replica moves from a rack over (else: above the lower end of) its band to one under (else: below the upper
+    //      end of) it, within the broker bands and the partition's per-rack band; weight-neutral moves first (first fit: source rack,
+    //      target rack, partition, slot, target broker ascending), then the cheapest.  Specification: oracle/kao_lp.py repair_racks. ----
+    {
+        const int rlo = bd[4], rhi = bd[5], plo = bd[6];
+        std::vector<int> tot((size_t)R, 0);
+        std::fill(load.begin(), load.end(), 0);
+        for (int p = 0; p < P; ++p) for (int k = 0; k < RF; ++k) { const int b = out[(size_t)p * RF + k]; load[(size_t)b]++; tot[t->rack_of[b]]++; }
+        bool fine = true;
+        for (int r = 0; r < R && fine; ++r) fine = tot[(size_t)r] >= rlo && tot[(size_t)r] <= rhi;
+        if (!fine) {
+            auto wf_of = [&](int p, int b) {
+                int wfo = t->broker_w ? t->broker_w[b] : 0;
+                for (int j = 0; j < NJ; ++j) if ((int)t->current[(size_t)p * NJ + j] == b) wfo += t->w[j == 0 ? 0 : 1][1];
+                return wfo;
+            };
+            std::vector<std::vector<int>> members((size_t)R);
+            for (int b = 0; b < B; ++b) members[t->rack_of[b]].push_back(b);
+            std::vector<char> is_src((size_t)R), is_dst((size_t)R);
+            for (int guard = 0; guard < 4 * R + 64; ++guard) {
+                bool any_over = false, any_under = false;
+                for (int r = 0; r < R; ++r) { any_over |= tot[(size_t)r] > rhi; any_under |= tot[(size_t)r] < rlo; }
+                if (!any_over && !any_under) break;
+                for (int r = 0; r < R; ++r) {
+                    is_src[(size_t)r] = any_over ? tot[(size_t)r] > rhi : tot[(size_t)r] > rlo;
+                    is_dst[(size_t)r] = any_under ? tot[(size_t)r] < rlo : tot[(size_t)r] < rhi;
+                }
+                bool have = false, neutral = false; int bl = 0, bp = 0, bk = 0, bb = 0;
+                for (int r1 = 0; r1 < R && !neutral; ++r1) {
+                    if (!is_src[(size_t)r1]) continue;
+                    for (int r2 = 0; r2 < R && !neutral; ++r2) {
+                        if (!is_dst[(size_t)r2] || r2 == r1) continue;
+                        for (int p = 0; p < P && !neutral; ++p) {
+                            int c1 = 0, c2 = 0;
+                            for (int m = 0; m < RF; ++m) { const int rm = t->rack_of[out[(size_t)p * RF + m]]; c1 += rm == r1; c2 += rm == r2; }
+                            if (c1 == 0 || c1 - 1 < plo || c2 >= phi) continue;
+                            for (int k = 1; k < RF && !neutral; ++k) {
+                                const int b1 = out[(size_t)p * RF + k];
+                                if (t->rack_of[b1] != r1 || load[(size_t)b1] - 1 < lo) continue;
+                                const int w1 = wf_of(p, b1);
+                                for (int b2 : members[(size_t)r2]) {
+                                    if (load[(size_t)b2] + 1 > hi || in_row(p, b2)) continue;
+                                    const int loss = w1 - wf_of(p, b2);
+                                    if (!have || loss < bl) { have = true; bl = loss; bp = p; bk = k; bb = b2; }
+                                    if (loss <= 0) { neutral = true; break; }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (!have) break;
+                const int b1 = out[(size_t)bp * RF + bk];
+                out[(size_t)bp * RF + bk] = (uint16_t)bb;
+                load[(size_t)b1]--; load[(size_t)bb]++; tot[t->rack_of[b1]]--; tot[t->rack_of[bb]]++;
+            }
+        }
+    }
     return KAO_OK;
 }
 

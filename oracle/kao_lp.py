@@ -840,6 +840,12 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int, F, 
 
 
 def repair_bands(t: ko.Topic, A) -> int:
+    """The repairs after the completion, in place: the broker bands (repair_broker_bands), then the rack bands (repair_racks).  Returns the
+    number of moves."""
+    return repair_broker_bands(t, A) + repair_racks(t, A)
+
+
+def repair_broker_bands(t: ko.Topic, A) -> int:
     """What the completion of a half-integral vertex leaves: a few brokers one replica (or one leadership) over their band, as many
     under it (README.md:158-166).  Moves that cost nothing put that right: a follower replica that carries no weight (its broker is
     not a current replica of the partition, README.md:145-146) goes from the lowest over-loaded broker to the lowest under-loaded one
@@ -973,4 +979,64 @@ def repair_bands(t: ko.Topic, A) -> int:
             for (u, p, k, v) in path:
                 A[p, 0], A[p, k] = v, u; moves += 1
             lead[b1] -= 1; lead[path[0][3]] += 1
+    return moves
+
+
+def repair_racks(t: ko.Topic, A) -> int:
+    """With a rigid rack band and loose broker bands the completion may leave one rack a replica over its band and another one under it
+    (README.md:173-176).  A follower replica moves from a rack over (else: above the lower end of) its band to one under (else: below the
+    upper end of) it, within the broker bands (README.md:158-166) and the partition's per-rack band (README.md:178-180): the first move that
+    loses no weight in the order source rack, target rack, partition, slot, target broker (all ascending), else the cheapest seen in that
+    order.  In place; returns the number of moves.  (kao_round.cpp, the last block of lp_round_assignment.)"""
+    B, R, P, RF = t.n_brokers, t.n_racks, t.n_partitions, t.rf
+    bd = t.bounds()
+    lo, hi, rlo, rhi, plo, phi = bd["rep_lo"], bd["rep_hi"], bd["rack_lo"], bd["rack_hi"], bd["prack_lo"], bd["prack_hi"]
+    rack = [int(r) for r in np.asarray(t.rack_of)]
+    load = [0] * B; tot = [0] * R
+    for p in range(P):
+        for k in range(RF):
+            b = int(A[p, k]); load[b] += 1; tot[rack[b]] += 1
+    if all(rlo <= tot[r] <= rhi for r in range(R)):
+        return 0
+    bwv = np.zeros(B, dtype=np.int64) if getattr(t, "broker_w", None) is None else np.asarray(t.broker_w, dtype=np.int64)
+    w = t.weights
+    members = [[b for b in range(B) if rack[b] == r] for r in range(R)]
+
+    def wf_of(p, b):
+        wf = int(bwv[b])
+        for j in range(t.rf_cur):
+            if int(t.current[p, j]) == b: wf += w[0 if j == 0 else 1][1]
+        return wf
+
+    moves = 0
+    for _ in range(4 * R + 64):
+        any_over = any(tot[r] > rhi for r in range(R)); any_under = any(tot[r] < rlo for r in range(R))
+        if not any_over and not any_under: break
+        src = [r for r in range(R) if (tot[r] > rhi if any_over else tot[r] > rlo)]
+        dst = [r for r in range(R) if (tot[r] < rlo if any_under else tot[r] < rhi)]
+        best = None; neutral = False
+        for r1 in src:
+            for r2 in dst:
+                if r2 == r1: continue
+                for p in range(P):
+                    row = [int(x) for x in A[p]]
+                    c1 = sum(1 for x in row if rack[x] == r1); c2 = sum(1 for x in row if rack[x] == r2)
+                    if c1 == 0 or c1 - 1 < plo or c2 >= phi: continue
+                    for k in range(1, RF):
+                        b1 = row[k]
+                        if rack[b1] != r1 or load[b1] - 1 < lo: continue
+                        w1 = wf_of(p, b1)
+                        for b2 in members[r2]:
+                            if load[b2] + 1 > hi or b2 in row: continue
+                            loss = w1 - wf_of(p, b2)
+                            if best is None or loss < best[0]: best = (loss, p, k, b2)
+                            if loss <= 0: neutral = True; break
+                        if neutral: break
+                    if neutral: break
+                if neutral: break
+            if neutral: break
+        if best is None: break
+        _, p, k, b2 = best
+        b1 = int(A[p, k]); A[p, k] = b2
+        load[b1] -= 1; load[b2] += 1; tot[rack[b1]] -= 1; tot[rack[b2]] += 1; moves += 1
     return moves

@@ -304,6 +304,30 @@ def test_another_north_star_seed_is_proven_by_its_rounded_iterate(kao, ko, kp):
     assert r.status == "OPTIMAL_PROVEN" and r.objective == r.upper_bound and lp["adopted"] >= 1, (r.status, r.objective, r.upper_bound, lp)
 
 
+def test_expansion_is_proven_by_one_rounded_iterate(kao, ko, kp):
+    """Round 6, found by tools/r6_scenarios.py: 100 brokers (5 per rack) join 1,000 under a 100,000-partition topic.  The broker bands are
+    loose (272..273 replicas), the rack band rigid (15,000): the perturbed LP's rounded iterate had the optimum's value and one rack a
+    replica over, another one under its band (C6 = 2 or 4, README.md:173-176) -- not adopted, and the solve took 3.4 s of KAO-CX and
+    K-search over it.  The rounding now repairs the racks too (kao_round.cpp; oracle/kao_lp.py repair_racks): ONE LP solve, its iterate
+    adopted, proven.  Counts, not the clock."""
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    add = [(1000 + 5 * r + i, r) for r in range(20) for i in range(5)]
+    pt = sy.drift(sy.make_cluster(1000, 20, 1, 100_000, 3, [], add), 0.2, 1)[0]
+    bd = kao.derive_bounds(pt)
+    assert bd["rep_lo"] < bd["rep_hi"] and bd["rack_lo"] == bd["rack_hi"]
+    for salt in (0, 1):   # the two salts whose rounded iterates used to carry 2 and 4 units of C6
+        rr = kao.lp_round(pt, pert=min(1e-4, 1.5 / (pt.n_partitions * pt.rf)), salt=salt, tol=1e-10, max_iters=250)
+        assert rr["violations"][0] == 0, (salt, rr["violations"])
+    ot = _otopic(ko, pt)
+    kao.solve([pt], seed=1, max_launches=1)
+    r = kao.solve([pt], seed=3, stop_at_bound=1, time_limit_s=3.0)[0]
+    lp, tm = kao.last_solve_lp(), kao.last_solve_timing()
+    print(f"expansion: {r.status} objective {r.objective} certificate {r.upper_bound} in {tm['results_read_back']:.3f} s, {int(lp['solves'])} LP solve(s), {int(lp['iterations'])} iterations")
+    obj, viol = kp.port_eval(ot, r.assignment)
+    assert viol[0] == 0 and obj == r.objective
+    assert r.status == "OPTIMAL_PROVEN" and r.objective == r.upper_bound and lp["solves"] == 1 and lp["adopted"] == 1 and tm["launches"] == 1, (r.status, lp, tm)
+
+
 @pytest.mark.parametrize("B,R,P,shards", [(100, 5, 1000, 2), (300, 6, 2000, 3)])
 def test_one_lp_sharded_over_logical_devices(kao, ko, kp, monkeypatch, B, R, P, shards):
     """Round 6: ONE topic's LP solved by several shards of its partitions (kao_lp_sharded_test) -- local variables and rows per shard,

@@ -317,6 +317,38 @@ def test_band_repair_matches_the_specification(ko, kp):
     assert kl.repair_bands(t2, ref) >= 2                     # at least two swaps: a chain
     assert kao.lp_repair_host(pt2, A).tolist() == ref.tolist()
     assert int(np.asarray(ko.verify(t2, ref)[1])[0]) == 0
+    # (e) round 6: a rigid rack band under loose broker bands (130 brokers, 5 racks: 23..24 replicas a broker, 600 a rack exactly) --
+    #     followers moved to another rack leave the broker bands alone and two racks one replica off: the rack repair (repair_racks) moves one back
+    t3 = _drift_topic(ko, 130, 5, 1000)
+    bd3 = t3.bounds()
+    assert bd3["rep_lo"] < bd3["rep_hi"] and bd3["rack_lo"] == bd3["rack_hi"]
+    r3 = kl.port_solve(t3, tol=1e-8, maxit=150, primal=True, pert=kl.default_pert(t3))
+    C0, _ = kl.round_primal(t3, *kl.primal_blocks(t3, r3["x"], r3["xg"]))
+    obj3, v3 = ko.verify(t3, C0)
+    assert int(np.asarray(v3)[0]) == 0
+    pt3 = to_product_topic(t3)
+    rack3 = np.asarray(t3.rack_of); cur3 = np.asarray(t3.current)
+    for n_moves in (1, 2):
+        A = C0.copy(); n = 0
+        load3 = np.bincount(A.reshape(-1), minlength=t3.n_brokers)
+        for p in range(t3.n_partitions):
+            if n >= n_moves: break
+            for k in (1, 2):
+                b = int(A[p, k])
+                if load3[b] <= bd3["rep_lo"]: continue
+                tgt = next((x for x in range(t3.n_brokers) if rack3[x] != rack3[b] and load3[x] < bd3["rep_hi"] and x not in A[p] and x not in cur3[p]
+                            and sum(1 for y in A[p] if rack3[y] == rack3[x]) < bd3["prack_hi"]), None)
+                if tgt is None: continue
+                A[p, k] = tgt; load3[b] -= 1; load3[tgt] += 1; n += 1
+                break
+        assert n == n_moves
+        vb = np.asarray(ko.verify(t3, A)[1])
+        assert int(vb[0]) == int(vb[6]) > 0, [int(x) for x in vb]      # rack rows (C6) only
+        ref = A.copy()
+        assert kl.repair_bands(t3, ref) == kl.repair_racks(t3, A.copy()) >= 1
+        assert kao.lp_repair_host(pt3, A).tolist() == ref.tolist()
+        o3, v3 = ko.verify(t3, ref)
+        assert int(np.asarray(v3)[0]) == 0 and o3 <= obj3
 
 
 def test_simplex_vertex_of_the_compact_lp_rounds_to_the_milp_optimum(ko, kp):
