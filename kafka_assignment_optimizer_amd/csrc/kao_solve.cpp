@@ -247,7 +247,8 @@ struct SolveRun {
         }
         return any;
     }
-    int lp_on = 1, lp_per_launch = 2, lp_max_running = 2, lp_solves = 0, lp_iters = 0;
+    int lp_on = 1, lp_per_launch = 2, lp_per_turn_max = 48, lp_max_running = 4, lp_solves = 0, lp_iters = 0;
+    int64_t lp_mid_slots = 8192;   // from here on the LP is what proves a drifted topic: more iterations per turn, KAO-CX behind it
     int64_t lp_min_slots = 2048;
     int lp_after_small = 48;
 
@@ -382,13 +383,37 @@ struct SolveRun {
     // the search stream no longer spends idle
     bool stepped = false;     // the last turn launched K-search (a paused turn does not count as a launch)
     int turns = 0;
+    double t_turn = 0, turn_s = 0;   // when the previous turn began; how long the turns take (smoothed)
+    // Interior-point iterations enqueued beside one launch.  Two (lp_per_launch) suit launches of a few milliseconds; twenty topics of 5,000
+    // partitions or ten of 12,000 turn every ~0.2 s, and at two iterations a turn an LP of a hundred iterations took fifty turns (round 6,
+    // tools/r6_scenarios2.py: 5 of 20 topics proven in 10 s, four LP solves finished).  So the count follows the clock: what the LP's own
+    // estimate says fits one turn, shared by the solves in flight; the deterministic schedule goes by the topic's size (8 iterations a turn from
+    // lp_mid_slots replica slots on, 16 from 32,768), up to four solves in flight, and KAO-CX leaves such a topic alone until its LP has spoken:
+    // the one turn in which every stalled topic got its KAO-CX calls was 8.5 s of that solve, with the LP streams idle.
+    int lp_iters_this_turn(int i, int running) const {
+        if (det || turn_s <= 0) {   // counts: a pure function of the topic's size (a launch over topics of 8,192+ slots takes tens of milliseconds)
+            const int64_t slots = (int64_t)topics[i].n_partitions * topics[i].rf;
+            return slots >= 32768 ? std::max(lp_per_launch, 16) : (slots >= lp_mid_slots ? std::max(lp_per_launch, 8) : lp_per_launch);
+        }
+        const kao_topic &t = topics[i];
+        const int nt = (3 * t.n_racks + 2 * t.n_brokers + 63) / 64;
+        const double xr = std::max(0, t.n_racks - 20);
+        const double ms = lp_ms_base + lp_ms_tile * nt + (lp_ms_kpart + lp_ms_kpart_rack * xr) * t.n_partitions / 1000.0;
+        return (int)std::min<double>(lp_per_turn_max, std::max<double>(lp_per_launch, turn_s * 1e3 / (ms * std::max(1, running))));
+    }
+    int lp_lag_now() const { return (!det && turn_s > 0.02) ? 1 : lp_lag; }   // (a mark is a turn's worth of iterations then: read a turn later)
     int launch() {
         int rc = KAO_OK;
+        const double tn = now_s();
+        if (t_turn > 0) turn_s = turn_s > 0 ? 0.5 * turn_s + 0.5 * (tn - t_turn) : tn - t_turn;
+        t_turn = tn;
         stepped = !search_paused();
         if (stepped) rc = kao_session_step(s);
         if (!rc && bound_pending) { bound_pending = false; rc = kao_session_bound_step(s, dual_target.data(), dual_now); }
+        int running = 0;
+        for (int i = 0; i < n; ++i) running += lp_state[(size_t)i] == 1 && !lp_all[(size_t)i];
         for (int i = 0; i < n && !rc; ++i)
-            if (lp_state[(size_t)i] == 1 && !lp_all[(size_t)i]) rc = lp_enqueue_mark(lp_ctx[(size_t)i], lp_per_launch, lp_marks[(size_t)i]++);   // interior-point iterations beside the launch
+            if (lp_state[(size_t)i] == 1 && !lp_all[(size_t)i]) rc = lp_enqueue_mark(lp_ctx[(size_t)i], lp_iters_this_turn(i, running), lp_marks[(size_t)i]++);   // interior-point iterations beside the launch
         return rc;
     }
     // KAO-LP: start the LP of topics K-bound has not closed, collect the ones whose stop flag is up
@@ -408,7 +433,7 @@ struct SolveRun {
                 if (m >= 0 && m < lp_marks[(size_t)i] && (rc = lp_poll_mark(lp_ctx[(size_t)i], m, &st, &it, deadline))) return rc;
                 if (st == 4) st = 0;   // aborted at the deadline: a mid-way iterate, not a result
                 if (!st) lp_abort(lp_ctx[(size_t)i]);
-            } else if (lp_read[(size_t)i] < lp_marks[(size_t)i] && lp_marks[(size_t)i] - lp_read[(size_t)i] > (lp_all[(size_t)i] ? 0 : lp_lag)) {
+            } else if (lp_read[(size_t)i] < lp_marks[(size_t)i] && lp_marks[(size_t)i] - lp_read[(size_t)i] > (lp_all[(size_t)i] ? 0 : lp_lag_now())) {
                 const double tp0 = now_s();
                 if ((rc = lp_poll_mark(lp_ctx[(size_t)i], lp_read[(size_t)i]++, &st, &it, lp_all[(size_t)i] ? lp_wait_until(i) : 0.0))) return rc;   // (a huge topic's LP is waited for: the wait ends at the deadline)
                 if (st == 4) {   // aborted at the deadline: no certificate, no rounding of a mid-way iterate; the main loop ends on the clock
@@ -660,6 +685,7 @@ struct SolveRun {
             if (s->topic_infeasible[(size_t)i] || !gfeasible(i) || (feasible(i) && objective(i) >= s->ub[(size_t)i])) continue;
             if (!cycle_supported(&topics[i])) continue;
             if (lp_state[(size_t)i] == 1 && lp_all[(size_t)i]) continue;   // a huge topic's LP has the GPU to itself (beside it a round takes 20 ms instead of 8)
+            if (lp_round_on && lp_possible(i) && !lp_try[(size_t)i] && (int64_t)topics[i].n_partitions * topics[i].rf >= lp_mid_slots) continue;   // (round 6) its first LP is waiting or running: the rounded iterate comes first
             const bool elite_fresh = (dkeys[(size_t)i] >> 20) != (cx_seen[(size_t)i] >> 20);   // not the incumbent of the last fixpoint
             const bool more = det && cx_starts > 0;
             if (!elite_fresh && !more) continue;

@@ -304,6 +304,24 @@ def test_another_north_star_seed_is_proven_by_its_rounded_iterate(kao, ko, kp):
     assert r.status == "OPTIMAL_PROVEN" and r.objective == r.upper_bound and lp["adopted"] >= 1, (r.status, r.objective, r.upper_bound, lp)
 
 
+def test_several_mid_size_topics_are_proven_by_their_lps(kao, ko, kp):
+    """Round 6, found by tools/r6_scenarios2.py: twenty drifted topics of 5,000 partitions in ONE call ended 5 of 20 proven in 10 s -- the LP
+    rode beside the launches at two iterations a turn (a hundred iterations: fifty turns of 32 ms), two solves in flight, and one turn gave
+    every stalled topic its KAO-CX calls: 8.5 s.  The deterministic schedule now gives a topic of 8,192+ replica slots eight iterations a
+    turn (sixteen from 32,768), four solves in flight, and keeps KAO-CX off it until its first LP has spoken.  Eight topics here: every one
+    proven, by its own LP's rounded iterate, without a KAO-CX call before it.  Counts, not the clock."""
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    ts = sy.drift(sy.make_cluster(500, 10, 8, 5000, 3, [], []), 0.2, 1)
+    kao.solve(ts, seed=1, max_launches=1)
+    rs = kao.solve(ts, seed=3, stop_at_bound=1, time_limit_s=10.0)
+    lp, tm = kao.last_solve_lp(), kao.last_solve_timing()
+    print(f"8 x 5,000: {[r.status for r in rs]} in {tm['results_read_back']:.3f} s, {tm['launches']} launches, {int(lp['solves'])} LP solves, {int(lp['adopted'])} adopted, {tm['cx_calls']} KAO-CX calls")
+    for t, r in zip(ts, rs):
+        obj, viol = kp.port_eval(_otopic(ko, t), r.assignment)
+        assert viol[0] == 0 and obj == r.objective == r.upper_bound and r.status == "OPTIMAL_PROVEN", (t.name, r.status, r.objective, r.upper_bound)
+    assert lp["solves"] >= 8 and lp["adopted"] >= 8 and tm["launches"] <= 40, (lp, tm)
+
+
 def test_expansion_is_proven_by_one_rounded_iterate(kao, ko, kp):
     """Round 6, found by tools/r6_scenarios.py: 100 brokers (5 per rack) join 1,000 under a 100,000-partition topic.  The broker bands are
     loose (272..273 replicas), the rack band rigid (15,000): the perturbed LP's rounded iterate had the optimum's value and one rack a
