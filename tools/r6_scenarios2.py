@@ -27,7 +27,7 @@ for name, ts, lim in cases:
     try:
         kao.solve(ts, seed=1, max_launches=1)
         t0 = time.perf_counter()
-        rs = kao.solve(ts, seed=3, stop_at_bound=1, time_limit_s=lim)
+        rs = kao.solve(ts, seed=3, stop_at_bound=1, time_limit_s=lim, schedule=int(os.environ.get("SCHEDULE", "0")))
         dt = time.perf_counter() - t0
         tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
         st = Counter(r.status for r in rs)
