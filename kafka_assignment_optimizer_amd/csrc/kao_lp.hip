@@ -1394,6 +1394,16 @@ int lp_open(const kao_topic *t, LpCtx **out, const LpShard *shard) {
     int32_t bd[8];
     derive_bounds(t, bd);
     const int Pg = t->n_partitions, p0 = shard ? shard->p0 : 0, P = shard ? shard->p1 - shard->p0 : Pg;   // this context's partitions: p0 .. p0 + P - 1
+    {   // the bands' implied ends (round 6; oracle/kao_lp.py lp_bands): when the brokers' lower ends add up to all the replicas nobody can be above
+        // its lower end -- the band is a point and its slack column is left out (likewise from above; likewise leaders and racks).  Same feasible
+        // set.  With config 5's "cap + 1" on a cluster whose average is whole (300 .. 301 at 1000 x 100,000) every feasible point pinned the slack
+        // at zero: an LP without interior, 200 iterations without converging, a certificate 2,481 above the optimum the rounding had found.
+        const long long tot = (long long)Pg * t->rf;
+        const long long nb = t->n_brokers, nr = t->n_racks;
+        if (nb * bd[0] == tot) bd[1] = bd[0]; else if (nb * bd[1] == tot) bd[0] = bd[1];
+        if (nb * bd[2] == Pg) bd[3] = bd[2]; else if (nb * bd[3] == Pg) bd[2] = bd[3];
+        if (nr * bd[4] == tot) bd[5] = bd[4]; else if (nr * bd[5] == tot) bd[4] = bd[5];
+    }
     if (shard && (p0 < 0 || P < 1 || shard->p1 > Pg || !shard->coll)) return fail(KAO_ERR_INVALID, "KAO-LP: bad shard");
     const int B = t->n_brokers, R = t->n_racks, NJ = t->rf_cur;
     const int mc = 3 * R + 2 * B;

@@ -58,9 +58,23 @@ class CompactLP:
     n_local_rows: int
 
 
+def lp_bands(t: ko.Topic) -> dict:
+    """The bands the LP is built on: t.bounds() (README.md:158-176) with the implied ends -- when the brokers' lower ends already add up to all
+    the replicas (B rep_lo = P RF) no broker can be above its lower end, so the band is the point rep_lo and its slack column is left out (and
+    likewise from above; likewise leaders and racks).  Same feasible set; without it such a band (config 5's "cap + 1" on a cluster whose
+    average is whole) has a slack that every feasible point pins at zero, the LP has no interior and the iteration crawls.  (round 6;
+    kao_lp.hip lp_open and kao_lp_port.c lp_setup do the same.)"""
+    bd = dict(t.bounds())
+    B, R, P, RF = t.n_brokers, t.n_racks, t.n_partitions, t.rf
+    for lo, hi, n, tot in (("rep_lo", "rep_hi", B, P * RF), ("lead_lo", "lead_hi", B, P), ("rack_lo", "rack_hi", R, P * RF)):
+        if n * bd[lo] == tot: bd[hi] = bd[lo]
+        elif n * bd[hi] == tot: bd[lo] = bd[hi]
+    return bd
+
+
 def build(t: ko.Topic) -> CompactLP:
     B, R, P, RF = t.n_brokers, t.n_racks, t.n_partitions, t.rf
-    bd = t.bounds()
+    bd = lp_bands(t)
     w = t.weights
     rack = np.asarray(t.rack_of)
     rsz = np.bincount(rack, minlength=R)
@@ -344,7 +358,7 @@ def primal_blocks(t: ko.Topic, x: np.ndarray, xg: np.ndarray):
 def compact_index(t: ko.Topic) -> dict:
     """Variable indices of build(t), by replaying its loops: zf[B], zl[B], f[P][rf_cur], l[P][rf_cur] (-1 = absent), yf[P][R], yl[P][R], n."""
     B, R, P = t.n_brokers, t.n_racks, t.n_partitions
-    bd = t.bounds()
+    bd = lp_bands(t)
     lo, hi, llo, lhi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"]
     rlo, rhi, plo, phi = bd["rack_lo"], bd["rack_hi"], bd["prack_lo"], bd["prack_hi"]
     has_c5, has_n = phi >= 2, hi > lo

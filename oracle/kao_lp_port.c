@@ -102,9 +102,17 @@ static lp_t *lp_create(const port_topic *t) {
     L->has_c5 = t->prack_hi >= 2;
     L->has_t = t->prack_hi > t->prack_lo;
     L->t_ub = (L->has_t && t->prack_lo > 0) ? t->prack_hi - t->prack_lo : 0;
-    L->has_n = t->rep_hi > t->rep_lo; L->n_ub = t->rep_hi - t->rep_lo;
-    L->has_m = t->lead_hi > t->lead_lo; L->m_ub = t->lead_hi - t->lead_lo;
-    L->has_k = L->has_n && t->rack_hi > t->rack_lo; L->k_ub = t->rack_hi - t->rack_lo;
+    /* the bands with their implied ends (oracle/kao_lp.py lp_bands; kao_lp.hip lp_open): B rep_lo = P RF pins every broker at rep_lo, ... */
+    int32_t rep_lo = t->rep_lo, rep_hi = t->rep_hi, lead_lo = t->lead_lo, lead_hi = t->lead_hi, rack_lo = t->rack_lo, rack_hi = t->rack_hi;
+    {
+        const long long tot = (long long)P * t->rf;
+        if ((long long)B * rep_lo == tot) rep_hi = rep_lo; else if ((long long)B * rep_hi == tot) rep_lo = rep_hi;
+        if ((long long)B * lead_lo == P) lead_hi = lead_lo; else if ((long long)B * lead_hi == P) lead_lo = lead_hi;
+        if ((long long)R * rack_lo == tot) rack_hi = rack_lo; else if ((long long)R * rack_hi == tot) rack_lo = rack_hi;
+    }
+    L->has_n = rep_hi > rep_lo; L->n_ub = rep_hi - rep_lo;
+    L->has_m = lead_hi > lead_lo; L->m_ub = lead_hi - lead_lo;
+    L->has_k = L->has_n && rack_hi > rack_lo; L->k_ub = rack_hi - rack_lo;
     L->rsz = (int *)zalloc(sizeof(int) * (size_t)R);
     for (int b = 0; b < B; ++b) L->rsz[t->rack_of[b]]++;
     const size_t nv = (size_t)L->NV * P;
@@ -134,13 +142,13 @@ static lp_t *lp_create(const port_topic *t) {
         L->presg[GZL(b)] = 1; L->cg[GZL(b)] = -(double)(bw + bwl);
         if (L->has_n) { L->presg[GN(b)] = 1; L->ubg[GN(b)] = 1; L->uug[GN(b)] = L->n_ub; }
         if (L->has_m) { L->presg[GM(b)] = 1; L->ubg[GM(b)] = 1; L->uug[GM(b)] = L->m_ub; }
-        L->rowc[RC3(b)] = 1; L->bc[RC3(b)] = t->rep_lo;
-        L->rowc[RC4(b)] = 1; L->bc[RC4(b)] = t->lead_lo;
+        L->rowc[RC3(b)] = 1; L->bc[RC3(b)] = rep_lo;
+        L->rowc[RC4(b)] = 1; L->bc[RC4(b)] = lead_lo;
     }
     for (int r = 0; r < R; ++r) {
         if (L->has_k) { L->presg[GK(r)] = 1; L->ubg[GK(r)] = 1; L->uug[GK(r)] = L->k_ub; }
         L->rowc[RNF(r)] = 1; L->rowc[RNL(r)] = 1;
-        if (L->has_n) { L->rowc[RC6(r)] = 1; L->bc[RC6(r)] = (double)t->rack_lo - (double)L->rsz[r] * t->rep_lo; }
+        if (L->has_n) { L->rowc[RC6(r)] = 1; L->bc[RC6(r)] = (double)rack_lo - (double)L->rsz[r] * rep_lo; }
     }
     /* Exact row dependencies: without n (replicas per broker fixed) sum C1 = sum C3 + sum NF + sum NL, without m (leaders per
      * broker fixed) sum C2 = sum C4 + sum NL.  One row of each is redundant: NF[0] / NL[0] are pinned (dy = 0). */

@@ -304,6 +304,28 @@ def test_another_north_star_seed_is_proven_by_its_rounded_iterate(kao, ko, kp):
     assert r.status == "OPTIMAL_PROVEN" and r.objective == r.upper_bound and lp["adopted"] >= 1, (r.status, r.objective, r.upper_bound, lp)
 
 
+def test_a_band_whose_slack_is_pinned_does_not_stall_the_lp(kao, ko, kp):
+    """Round 6, found by tools/r6_scenarios3.py: config 5's "cap + 1" rule (rep_hi = average + 1) on a cluster whose average is whole -- 300..301
+    replicas a broker with 1000 x 300 = all of them, so every feasible point has every broker at 300 and the band's slack at zero.  The LP had
+    no interior: 200 iterations without converging at 1000 x 100,000, a certificate 2,481 above the optimum the rounding had already found,
+    TIME_LIMIT.  lp_open (and the restatements) now build the LP on the bands' implied ends.  Small: same trace as the restatement, the
+    certificate of the plain band; large: proven by one LP solve."""
+    import kao_lp as kl
+    from kafka_assignment_optimizer_amd import synthetic as sy
+    pt = sy.drift(sy.make_cluster(100, 5, 1, 1000, 3, [], [], bounds_override={"rep_hi": 31}), 0.2, 1)[0]
+    ot = _otopic(ko, pt)
+    assert ot.bounds()["rep_hi"] == 31 and kl.lp_bands(ot)["rep_hi"] == 30
+    d, r = kao.lp_trace(pt), kl.port_solve(ot)
+    _trace_close(d["trace"], r["trace"])
+    assert kao.lp_bound(pt)["bound"] == 7430           # tests/golden/drift_scale.json, the plain band's optimum
+    big = sy.drift(sy.make_cluster(1000, 20, 1, 100_000, 3, [], [], bounds_override={"rep_hi": 301}), 0.2, 1)[0]
+    kao.solve([big], seed=1, max_launches=1)
+    res = kao.solve([big], seed=3, stop_at_bound=1, time_limit_s=3.0)[0]
+    lp, tm = kao.last_solve_lp(), kao.last_solve_timing()
+    print(f"cap + 1 at 1000 x 100,000: {res.status} objective {res.objective} certificate {res.upper_bound} in {tm['results_read_back']:.3f} s, {int(lp['solves'])} LP solve(s), {int(lp['iterations'])} iterations")
+    assert res.status == "OPTIMAL_PROVEN" and res.objective == res.upper_bound == 782512 and lp["solves"] == 1, (res.status, res.objective, res.upper_bound, lp)
+
+
 def test_several_mid_size_topics_are_proven_by_their_lps(kao, ko, kp):
     """Round 6, found by tools/r6_scenarios2.py: twenty drifted topics of 5,000 partitions in ONE call ended 5 of 20 proven in 10 s -- the LP
     rode beside the launches at two iterations a turn (a hundred iterations: fifty turns of 32 ms), two solves in flight, and one turn gave
