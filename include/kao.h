@@ -233,7 +233,7 @@ int kao_session_stats(kao_session *s, kao_stats *out);
  * optimum, so floor(min dual) is a certificate whatever the multipliers.
  * One launch runs up to `iters` iterations for every topic i with target[i] >= 0 (the incumbent objective the
  * step length aims at; pass -1 to skip a topic).  Topics outside K-bound's limits (broker and rack tables
- * beyond 160 KiB of LDS: about 8,000 brokers; n_partitions*rf > 2^20 (round 4; 2^17 before), or n_partitions*rf*(largest weight) > 2^25; a weight outside 0..255) are skipped.  Asynchronous, on a stream of its own: K-bound
+ * beyond 160 KiB of LDS: about 8,000 brokers; n_partitions*rf > 2^21 (round 6; 2^20 in rounds 4-5, 2^17 before), or n_partitions*rf*(largest weight) > 2^25; a weight outside 0..255) are skipped.  Asynchronous, on a stream of its own: K-bound
  * occupies one compute unit per topic -- one per 512 partitions when a launch holds a topic of more than 2,048 partitions
  * (then every iteration is a kernel launch of its own, see kao_bound.hip) -- and runs beside K-search (kao_session_step); a
  * new launch first waits for the

@@ -435,8 +435,15 @@ bool dual_supported(const kao_topic *t, bool session_bw) {
     // topic is 300,000 slots).  What the integers need: a subgradient entry |s| <= n and a direction |d| <= 64 n in 32 bits
     // (n <= 2^20); |d|^2 summed over 2 B + R multipliers in 63 bits (4096 n^2 (2 B + R) < 2^62); the level gap in dual fixed
     // point below 2^42 (bound_step_length: n * weight * 65536, checked with the weights below).
-    if (n > ((int64_t)1 << 20)) return false;
-    if (4096.0 * (double)n * (double)n * (double)(2 * t->n_brokers + t->n_racks) >= 4.0e18) return false;
+    // Round 6 (1000 x 500,000 = 1.5 M slots had no certificate and no LP): the 63-bit test above priced |d|^2 as (64 n)^2 per multiplier.  A
+    // family's subgradient has |s|_inf <= max(n, 65535) and |s|_1 <= n + 65535 * (entries) (counts add up to n, band ends are 16-bit), the
+    // deflected direction is 64 x a convex combination of such vectors, and sum d^2 <= |d|_inf |d|_1: three families stay below 2^62 up to
+    // 2^21 slots with 8,000 brokers.  |s| and 64 |s| in 32 bits need n < 2^25; the level gap n * weight * 65536 < 2^42 is the last line.
+    if (n > ((int64_t)1 << 21)) return false;
+    {
+        const double sinf = (double)std::max<int64_t>(n, 65535), s1 = (double)n + 65535.0 * (double)std::max(t->n_brokers, t->n_racks);
+        if (3.0 * 64.0 * sinf * 64.0 * s1 >= 4.0e18) return false;
+    }
     int wmax = 0, bwmax = 0;
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j) {
