@@ -247,7 +247,7 @@ struct SolveRun {
         }
         return any;
     }
-    int lp_on = 1, lp_per_launch = 2, lp_per_turn_max = 48, lp_max_running = 4, lp_solves = 0, lp_iters = 0;
+    int lp_on = 1, lp_per_launch = 2, lp_per_turn_max = 48, lp_max_running = 8, lp_solves = 0, lp_iters = 0;
     int64_t lp_mid_slots = 8192;   // from here on the LP is what proves a drifted topic: more iterations per turn, KAO-CX behind it
     int64_t lp_min_slots = 2048;
     int lp_after_small = 48;
@@ -323,6 +323,7 @@ struct SolveRun {
             lp_huge_first = env_i("KAO_LP_HUGE_FIRST", 0) != 0;
             lp_round_on = env_i("KAO_LP_ROUND", 1) != 0;
             lp_max_tries = env_i("KAO_LP_TRIES", 3);
+            lp_max_running = (int)std::max<int64_t>(1, env_i("KAO_LP_MAX_RUNNING", lp_max_running));
             if (const char *e = std::getenv("KAO_LP_TOL")) lp_tol = std::atof(e);
             lp_retry_test = env_i("KAO_LP_RETRY_TEST", 0) != 0;
             if (const char *e = std::getenv("KAO_LP_PERT")) lp_pert_env = std::atof(e);
@@ -388,7 +389,7 @@ struct SolveRun {
     // partitions or ten of 12,000 turn every ~0.2 s, and at two iterations a turn an LP of a hundred iterations took fifty turns (round 6,
     // tools/r6_scenarios2.py: 5 of 20 topics proven in 10 s, four LP solves finished).  So the count follows the clock: what the LP's own
     // estimate says fits one turn, shared by the solves in flight; the deterministic schedule goes by the topic's size (8 iterations a turn from
-    // lp_mid_slots replica slots on, 16 from 32,768), up to four solves in flight, and KAO-CX leaves such a topic alone until its LP has spoken:
+    // lp_mid_slots replica slots on, 16 from 32,768), up to eight solves in flight (2 / 4 / 8 / 16: 2.8 / 2.2 / 1.9 / 1.7 s on twenty topics of 5,000 partitions), and KAO-CX leaves such a topic alone until its LP has spoken:
     // the one turn in which every stalled topic got its KAO-CX calls was 8.5 s of that solve, with the LP streams idle.
     int lp_iters_this_turn(int i, int running) const {
         if (det || turn_s <= 0) {   // counts: a pure function of the topic's size (a launch over topics of 8,192+ slots takes tens of milliseconds)
