@@ -67,13 +67,19 @@ enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (no
              SC_PINF, SC_DINF, SC_PLAST, SC_DLAST, SC_HAVE_LAST, SC_KEEP /* this iterate is finite: copy its duals */, SC_TOL, SC_MAXIT, SC_NVU /* variables + bounded variables */, SC_NB, SC_NCN,
              SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT,
              SC_MCC_GO /* centrality correctors: the next one is still wanted */, SC_MCC_ACC /* the last one was accepted */,
-             SC_MU_REF, SC_IT_REF /* the stall test's reference iterate */, kScN = 32 };
+             SC_MU_REF, SC_IT_REF /* the stall test's reference iterate */, SC_PINF_BEST /* smallest primal infeasibility among the near-optimal iterates */, kScN = 32 };
 // Stalled at the numerical floor (round 6): some perturbed solves reach a relative gap of 5e-10 .. 1e-9 after ~110 iterations and then
 // stand still -- step lengths ~0, mu unchanged for the remaining 90 iterations of their cap (profiles/r06_c09_stalled_solves.txt).  An
 // iterate within kLpStallGap tolerances of the optimum whose mu has not fallen by a tenth in kLpStallWindow iterations counts as converged:
 // its duals go through K-bound's integer evaluation like any others, its primal side through the rounding.
 constexpr int kLpStallWindow = 8;
 constexpr double kLpStallGap = 100.0, kLpStallMu = 0.9;
+// Past the floor (round 6, later): on two racks (RF 3: every partition splits 1 + 2) the normal equations lose their conditioning once mu is
+// ~1e-9 -- 600 x 50,000: relative gap 9e-10 and primal infeasibility 3e-9 at iteration 70, then the infeasibility jumps to 6e-5 and stays
+// there for the remaining 130 iterations of the cap (the duals no longer move; 600 x 10,000 ends non-finite).  A solve that has been within
+// kLpStallGap tolerances of the optimum and whose primal infeasibility is now kLpFloorJump times its smallest value there (and beyond what
+// the stopping test accepts) stops as converged: later iterates are no better, and that one rounds like the one 130 iterations on.
+constexpr double kLpFloorJump = 1e3;
 #define LP_STOPPED(D) ((D).sc[SC_STOP] != 0.0)
 // kernels of a centrality corrector carry gated = 1: once no further corrector is wanted they return at their first line
 #define LP_GATED_OFF(D, gated) ((gated) && (D).sc[SC_MCC_GO] == 0.0)
@@ -207,6 +213,8 @@ __global__ void k_lp_sc_resid(double *sc, const double *redA, const double *redB
     const double tol = sc[SC_TOL];
     const double gap = fabs(pobj - dobj) / (1.0 + fabs(pobj));
     if (gap < tol && pinf < 100 * tol && dinf < tol) { sc[SC_STOP] = 1.0; return; }
+    if (gap < kLpStallGap * tol && dinf < tol && pinf < sc[SC_PINF_BEST]) sc[SC_PINF_BEST] = pinf;
+    if (sc[SC_PINF_BEST] < 100 * tol && pinf > 100 * tol && pinf > kLpFloorJump * sc[SC_PINF_BEST] && dinf < tol) { sc[SC_STOP] = 1.0; return; }
     if (it - (int)sc[SC_IT_REF] >= kLpStallWindow) {
         if (gap < kLpStallGap * tol && pinf < 100 * tol && dinf < tol && mu > kLpStallMu * sc[SC_MU_REF]) { sc[SC_STOP] = 1.0; return; }
         sc[SC_MU_REF] = mu; sc[SC_IT_REF] = (double)it;
@@ -1573,7 +1581,7 @@ int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
     std::memset(init, 0, sizeof init);
     init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
     init[SC_PERT] = pert > 0.0 ? pert : 0.0; init[SC_SALT] = (double)salt;
-    init[SC_MU_REF] = 1e300; init[SC_IT_REF] = 0.0;
+    init[SC_MU_REF] = 1e300; init[SC_IT_REF] = 0.0; init[SC_PINF_BEST] = 1e300;
     std::memcpy(c.h_sc, init, sizeof init);
     HIP_TRY(hipMemcpyAsync(D.sc, c.h_sc, sizeof init, hipMemcpyHostToDevice, c.st));
     const size_t nvtot = (size_t)D.NV * D.P + D.GV;

@@ -561,7 +561,7 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
         L->sg[i] = s > 1.0 ? s : 1.0;
         L->vg[i] = L->ubg[i] ? 1.0 : 0.0;
     }
-    double mu_ref = 1e300;
+    double mu_ref = 1e300, pinf_best = 1e300;
     int it_ref = 0;
     for (it = 0;; ++it) {
         /* residuals */
@@ -604,6 +604,10 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
         if (gap < tol && pinf < 100 * tol && dinf < tol) { status = 0; break; }
         /* stalled at the numerical floor (kao_lp.hip k_lp_sc_resid, round 6): within 100 tolerances of the optimum and mu has not fallen
          * by a tenth in 8 iterations -> converged */
+        /* past the floor (kao_lp.hip kLpFloorJump): it has been within 100 tolerances and its primal infeasibility is now 1000 x its smallest
+         * value there -> converged */
+        if (gap < 100.0 * tol && dinf < tol && pinf < pinf_best) pinf_best = pinf;
+        if (pinf_best < 100 * tol && pinf > 100 * tol && pinf > 1e3 * pinf_best && dinf < tol) { status = 0; break; }
         if (it - it_ref >= 8) {
             if (gap < 100.0 * tol && pinf < 100 * tol && dinf < tol && mu > 0.9 * mu_ref) { status = 0; break; }
             mu_ref = mu; it_ref = it;

@@ -330,7 +330,7 @@ def test_several_mid_size_topics_are_proven_by_their_lps(kao, ko, kp):
     """Round 6, found by tools/r6_scenarios2.py: twenty drifted topics of 5,000 partitions in ONE call ended 5 of 20 proven in 10 s -- the LP
     rode beside the launches at two iterations a turn (a hundred iterations: fifty turns of 32 ms), two solves in flight, and one turn gave
     every stalled topic its KAO-CX calls: 8.5 s.  The deterministic schedule now gives a topic of 8,192+ replica slots eight iterations a
-    turn (sixteen from 32,768), four solves in flight, and keeps KAO-CX off it until its first LP has spoken.  Eight topics here: every one
+    turn (sixteen from 32,768), eight solves in flight, and keeps KAO-CX off it until its first LP has spoken.  Eight topics here: every one
     proven, by its own LP's rounded iterate, without a KAO-CX call before it.  Counts, not the clock."""
     from kafka_assignment_optimizer_amd import synthetic as sy
     ts = sy.drift(sy.make_cluster(500, 10, 8, 5000, 3, [], []), 0.2, 1)
