@@ -765,16 +765,20 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     //      one rack a replica over its band and another one under it -- 100 brokers added to 1,000: two of the first four perturbed solves
     //      rounded to the optimum's value with 2 or 4 units of C6 (README.md:173-176) and nothing else, and K-search took three seconds
     //      over them.  A follower replica moves from a rack over (else: above the lower end of) its band to one under (else: below the upper
-    //      end of) it, within the broker bands and the partition's per-rack band; weight-neutral moves first (first fit: source rack,
-    //      target rack, partition, slot, target broker ascending), then the cheapest.  Specification: oracle/kao_lp.py repair_racks. ----
+    //      end of) it, within the broker bands and the partition's per-rack band.  Rack pairs (source, target) in ascending order; the first
+    //      pair that offers a move at all decides: its first move that loses no weight (partition, slot, target broker ascending), else its
+    //      cheapest.  Bounded: nothing is tried when the racks are more than kRackRepairMax replicas off (that is not what a completion
+    //      leaves; the search takes it), one move costs at most a pass over the partitions per pair.  Specification: oracle/kao_lp.py
+    //      repair_racks. ----
     {
         const int rlo = bd[4], rhi = bd[5], plo = bd[6];
         std::vector<int> tot((size_t)R, 0);
         std::fill(load.begin(), load.end(), 0);
         for (int p = 0; p < P; ++p) for (int k = 0; k < RF; ++k) { const int b = out[(size_t)p * RF + k]; load[(size_t)b]++; tot[t->rack_of[b]]++; }
-        bool fine = true;
-        for (int r = 0; r < R && fine; ++r) fine = tot[(size_t)r] >= rlo && tot[(size_t)r] <= rhi;
-        if (!fine) {
+        constexpr int kRackRepairMax = 32;
+        int off = 0;
+        for (int r = 0; r < R; ++r) off += std::max(0, tot[(size_t)r] - rhi) + std::max(0, rlo - tot[(size_t)r]);
+        if (off > 0 && off <= kRackRepairMax) {
             auto wf_of = [&](int p, int b) {
                 int wfo = t->broker_w ? t->broker_w[b] : 0;
                 for (int j = 0; j < NJ; ++j) if ((int)t->current[(size_t)p * NJ + j] == b) wfo += t->w[j == 0 ? 0 : 1][1];
@@ -783,7 +787,7 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
             std::vector<std::vector<int>> members((size_t)R);
             for (int b = 0; b < B; ++b) members[t->rack_of[b]].push_back(b);
             std::vector<char> is_src((size_t)R), is_dst((size_t)R);
-            for (int guard = 0; guard < 4 * R + 64; ++guard) {
+            for (int guard = 0; guard < 2 * kRackRepairMax; ++guard) {
                 bool any_over = false, any_under = false;
                 for (int r = 0; r < R; ++r) { any_over |= tot[(size_t)r] > rhi; any_under |= tot[(size_t)r] < rlo; }
                 if (!any_over && !any_under) break;
@@ -792,9 +796,9 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
                     is_dst[(size_t)r] = any_under ? tot[(size_t)r] < rlo : tot[(size_t)r] < rhi;
                 }
                 bool have = false, neutral = false; int bl = 0, bp = 0, bk = 0, bb = 0;
-                for (int r1 = 0; r1 < R && !neutral; ++r1) {
+                for (int r1 = 0; r1 < R && !have; ++r1) {
                     if (!is_src[(size_t)r1]) continue;
-                    for (int r2 = 0; r2 < R && !neutral; ++r2) {
+                    for (int r2 = 0; r2 < R && !have; ++r2) {
                         if (!is_dst[(size_t)r2] || r2 == r1) continue;
                         for (int p = 0; p < P && !neutral; ++p) {
                             int c1 = 0, c2 = 0;

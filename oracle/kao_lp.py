@@ -996,12 +996,16 @@ def repair_broker_bands(t: ko.Topic, A) -> int:
     return moves
 
 
+RACK_REPAIR_MAX = 32     # replicas the racks may be off for repair_racks to try at all
+
+
 def repair_racks(t: ko.Topic, A) -> int:
     """With a rigid rack band and loose broker bands the completion may leave one rack a replica over its band and another one under it
     (README.md:173-176).  A follower replica moves from a rack over (else: above the lower end of) its band to one under (else: below the
-    upper end of) it, within the broker bands (README.md:158-166) and the partition's per-rack band (README.md:178-180): the first move that
-    loses no weight in the order source rack, target rack, partition, slot, target broker (all ascending), else the cheapest seen in that
-    order.  In place; returns the number of moves.  (kao_round.cpp, the last block of lp_round_assignment.)"""
+    upper end of) it, within the broker bands (README.md:158-166) and the partition's per-rack band (README.md:178-180).  Rack pairs (source,
+    target) ascending; the first pair that offers a move at all decides: its first move that loses no weight (partition, slot, target broker
+    ascending), else its cheapest.  Nothing is tried when the racks are more than RACK_REPAIR_MAX replicas off.  In place; returns the number
+    of moves.  (kao_round.cpp, the last block of lp_round_assignment.)"""
     B, R, P, RF = t.n_brokers, t.n_racks, t.n_partitions, t.rf
     bd = t.bounds()
     lo, hi, rlo, rhi, plo, phi = bd["rep_lo"], bd["rep_hi"], bd["rack_lo"], bd["rack_hi"], bd["prack_lo"], bd["prack_hi"]
@@ -1010,7 +1014,8 @@ def repair_racks(t: ko.Topic, A) -> int:
     for p in range(P):
         for k in range(RF):
             b = int(A[p, k]); load[b] += 1; tot[rack[b]] += 1
-    if all(rlo <= tot[r] <= rhi for r in range(R)):
+    off = sum(max(0, tot[r] - rhi) + max(0, rlo - tot[r]) for r in range(R))
+    if off == 0 or off > RACK_REPAIR_MAX:
         return 0
     bwv = np.zeros(B, dtype=np.int64) if getattr(t, "broker_w", None) is None else np.asarray(t.broker_w, dtype=np.int64)
     w = t.weights
@@ -1023,7 +1028,7 @@ def repair_racks(t: ko.Topic, A) -> int:
         return wf
 
     moves = 0
-    for _ in range(4 * R + 64):
+    for _ in range(2 * RACK_REPAIR_MAX):
         any_over = any(tot[r] > rhi for r in range(R)); any_under = any(tot[r] < rlo for r in range(R))
         if not any_over and not any_under: break
         src = [r for r in range(R) if (tot[r] > rhi if any_over else tot[r] > rlo)]
@@ -1047,8 +1052,8 @@ def repair_racks(t: ko.Topic, A) -> int:
                             if loss <= 0: neutral = True; break
                         if neutral: break
                     if neutral: break
-                if neutral: break
-            if neutral: break
+                if best is not None: break
+            if best is not None: break
         if best is None: break
         _, p, k, b2 = best
         b1 = int(A[p, k]); A[p, k] = b2
