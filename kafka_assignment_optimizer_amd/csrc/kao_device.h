@@ -34,6 +34,42 @@ __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
+// Six wavefront sums at once (round 6; K-eval folded its six partial sums one wave_sum after the other: ~100 of a small candidate's
+// ~450 instructions).  v_permlane32_swap / v_permlane16_swap (gfx950) exchange the upper half / the odd rows of one register with the
+// lower half / the even rows of another, so a swap and an add fold two values into one register whose halves (rows) hold the two
+// partial sums: six values -> three -> two registers, and the rows of 16 are then summed by the fused DPP butterfly of wave_sum, both
+// registers in one block (a DPP read wants two wait states behind the write of its source: the other chain's add is one of them).
+// Totals come back wave-uniform in v[0..5].  33 instructions against 96.
+__device__ __forceinline__ int fold_halves(int a, int b) {   // lanes 0..31: a[l] + a[l + 32]; lanes 32..63: b[l - 32] + b[l]
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    return (int)(r[0] + r[1]);
+}
+__device__ __forceinline__ int fold_rows(int a, int b) {     // rows 0 / 2: a's row + the row above it; rows 1 / 3: b's row below + its own
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    return (int)(r[0] + r[1]);
+}
+__device__ __forceinline__ void wave_sum6(int (&v)[6]) {
+    const int w0 = fold_halves(v[0], v[3]), w1 = fold_halves(v[1], v[4]), w2 = fold_halves(v[2], v[5]);
+    int u0 = fold_rows(w0, w1);      // rows: v0 v1 v3 v4
+    int u1 = fold_rows(w2, 0);       // rows: v2 0 v5 0
+    asm("s_nop 1\n\t"
+        "v_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(u0), "+v"(u1));
+    v[0] = __builtin_amdgcn_readlane(u0, 0); v[1] = __builtin_amdgcn_readlane(u0, 16);
+    v[3] = __builtin_amdgcn_readlane(u0, 32); v[4] = __builtin_amdgcn_readlane(u0, 48);
+    v[2] = __builtin_amdgcn_readlane(u1, 0); v[5] = __builtin_amdgcn_readlane(u1, 32);
+}
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v) { return ~wave_umin(~v); }
 __device__ __forceinline__ long long wave_sum64(long long v) {
 #pragma unroll

@@ -1348,6 +1348,7 @@ __global__ __launch_bounds__(64 * kInitWaves) void k_init(SearchPools pl, Search
 template <int NE, bool kCoop, int RFT = 0>
 __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     constexpr int RFE = RFT ? RFT : NE;      // slots the loops visit
+    constexpr bool kLds = RFT > 0;           // the RF-uniform instantiation is launched only with the current assignment staged in LDS (launch_eval)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     unsigned long long *wave_key = reinterpret_cast<unsigned long long *>(smem_all);  // [kWaves], 32 B
     unsigned char *smem = smem_all + 32;
@@ -1359,10 +1360,15 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     const int rep_lo = TD->rep_lo, rep_hi = TD->rep_hi, lead_lo = TD->lead_lo, lead_hi = TD->lead_hi;
     const int rack_lo = TD->rack_lo, rack_hi = TD->rack_hi, prack_lo = TD->prack_lo, prack_hi = TD->prack_hi;
     const int w00 = TD->w00, w01 = TD->w01, w10 = TD->w10, w11 = TD->w11;
+    const bool cur_lds = kLds || pl.cur_in_lds != 0;
+    // C7 of a partition whose three replicas sit on one / two / three racks (RFT == 3)
+    const int c7_one = band(3, prack_lo, prack_hi) + (R - 1) * prack_lo;
+    const int c7_two = band(2, prack_lo, prack_hi) + band(1, prack_lo, prack_hi) + (R - 2) * prack_lo;
+    const int c7_three = 3 * band(1, prack_lo, prack_hi) + (R - 3) * prack_lo;
 
     // ---- LDS carve: [wave_key 32 B] [RACK u8[maxB~]] [CURD u16[maxP][NE]] then per wave [C u32[maxB~]] [K int[256]]
     const int r_bytes = (pl.maxB + 15) & ~15;
-    const int d_bytes = pl.cur_in_lds ? pl.maxP * NE * 2 : 0;  // huge topics read the current assignment from global memory
+    const int d_bytes = cur_lds ? pl.maxP * NE * 2 : 0;  // huge topics read the current assignment from global memory
     const int c_bytes = (pl.maxB * 4 + 15) & ~15;
     uint8_t *RACK = smem;
     uint16_t *CURD = reinterpret_cast<uint16_t *>(smem + r_bytes);
@@ -1376,7 +1382,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     for (int b = threadIdx.x; b < B; b += 256) RACK[b] = pl.rackof_pool[TD->rackof_off + b];
     const uint16_t *curd = pl.curd_pool + TD->curd_off;
     const uint32_t *bwd = TD->has_bw ? pl.bwd_pool + TD->bwd_off : nullptr;   // broker weights, dense index (global memory / L2)
-    if (pl.cur_in_lds)
+    if (cur_lds)
         for (int i = threadIdx.x; i < P * NE; i += 256) {
             const int p = i / NE, k = i - p * NE;
             CURD[i] = k < rf_cur ? curd[(size_t)p * rf_cur + k] : (uint16_t)0xFFFFu;
@@ -1409,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             const uint16_t *ap = cand + (size_t)p * RF;  // a wavefront reads 64*RF consecutive u16: coalesced
             uint32_t bk[NE], rk[NE], ck[NE];
             uint32_t cw[NE / 2];   // the partition's current replicas, two u16 per word: one ds_read_b64 / b128 when staged in LDS
-            if (pl.cur_in_lds) {
+            if (cur_lds) {
                 if (NE == 4) { const uint2 v = reinterpret_cast<const uint2 *>(CURD)[p]; cw[0] = v.x; cw[1] = v.y; }
                 else { const uint4 v = reinterpret_cast<const uint4 *>(CURD)[p]; cw[0] = v.x; cw[1] = v.y; cw[2 % (NE / 2)] = v.z; cw[3 % (NE / 2)] = v.w; }
             }
@@ -1417,7 +1423,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             for (int k = 0; k < NE; ++k) {
                 bk[k] = k < RF ? (uint32_t)ap[k < RF ? k : 0] : 0xFFFFu;
                 rk[k] = 0xFFu;
-                ck[k] = pl.cur_in_lds ? ((k & 1) ? cw[k >> 1] >> 16 : cw[k >> 1] & 0xFFFFu)
+                ck[k] = cur_lds ? ((k & 1) ? cw[k >> 1] >> 16 : cw[k >> 1] & 0xFFFFu)
                                       : (k < rf_cur ? (uint32_t)curd[(size_t)p * rf_cur + (k < rf_cur ? k : 0)] : 0xFFFFu);
             }
             int missing = 0;
@@ -1447,16 +1453,23 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             }
             s12 += (uint32_t)missing + ((uint32_t)(bk[0] >= (uint32_t)B) << 16);  // C1: sum_b (f+l) = RF ; C2: exactly one leader
             // C7: replicas per partition per rack, over all R racks (each rack counted at its first slot)
-            int touched = 0, s7 = 0;
+            if (RFT == 3 && __ballot(missing != 0) == 0ull) {
+                // three filled slots (no lane of this trip has an empty one: wave-uniform) fall on one, two or three racks -- the row's value
+                // in each case is a constant of the topic (c7_one / c7_two / c7_three: the sums the general loop below would form)
+                const bool e01 = rk[0] == rk[1], e02 = rk[0] == rk[2], e12 = rk[1] == rk[2];
+                s57 += (uint32_t)((e01 & e12) ? c7_one : ((e01 | e02 | e12) ? c7_two : c7_three)) << 16;
+            } else {
+                int touched = 0, s7 = 0;
 #pragma unroll
-            for (int k = 0; k < RFE; ++k) {
-                bool first = rk[k] != 0xFFu;
-                int cnt = 0;
+                for (int k = 0; k < RFE; ++k) {
+                    bool first = rk[k] != 0xFFu;
+                    int cnt = 0;
 #pragma unroll
-                for (int j = 0; j < RFE; ++j) { cnt += (int)(rk[j] == rk[k]); if (j < k) first &= rk[j] != rk[k]; }
-                if (first) { s7 += band(cnt, prack_lo, prack_hi); touched++; }
+                    for (int j = 0; j < RFE; ++j) { cnt += (int)(rk[j] == rk[k]); if (j < k) first &= rk[j] != rk[k]; }
+                    if (first) { s7 += band(cnt, prack_lo, prack_hi); touched++; }
+                }
+                s57 += (uint32_t)(s7 + (R - touched) * prack_lo) << 16;
             }
-            s57 += (uint32_t)(s7 + (R - touched) * prack_lo) << 16;
         }
         // C6 from the rack totals (the wavefront's own LDS operations complete in order: no barrier needed; the cooperating
         // wavefronts of kCoop meet at one)
@@ -1467,22 +1480,24 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
             s6 += band(tot, rack_lo, rack_hi);
         }
         if (big && __ballot(ovf) != 0ull && pl.overflow && lane == 0) atomicOr(pl.overflow, 1);
-        obj = wave_sum(obj);
         int v1, v2, v3, v4, v5, v6, v7;   // (v3, v4 without their constants B * lo until the partial sums have met)
-        if (P * RF <= 32767) {  // packed halves cannot carry: every count is at most P*RF
-            const uint32_t t12 = (uint32_t)wave_sum((int)s12), t3 = (uint32_t)wave_sum((int)s3), t4 = (uint32_t)wave_sum((int)s4);
-            const uint32_t t57 = (uint32_t)wave_sum((int)s57);
+        if (P * RF <= 32767) {  // packed halves cannot carry: every count is at most P*RF -- the six words are summed in one go (wave_sum6)
+            int t[6] = {obj, (int)s12, (int)s3, (int)s4, (int)s57, s6};
+            wave_sum6(t);
+            const uint32_t t12 = (uint32_t)t[1], t3 = (uint32_t)t[2], t4 = (uint32_t)t[3], t57 = (uint32_t)t[4];
+            obj = t[0]; v6 = t[5];
             v1 = (int)(t12 & 0xFFFFu); v2 = (int)(t12 >> 16);
             v3 = (int)(t3 & 0xFFFFu) - (int)(t3 >> 16);
             v4 = (int)(t4 & 0xFFFFu) - (int)(t4 >> 16);
             v5 = (int)(t57 & 0xFFFFu); v7 = (int)(t57 >> 16);
         } else {  // huge topic: per-lane halves still fit 16 bits, the wavefront totals do not -> sum them unpacked
+            obj = wave_sum(obj);
             v1 = wave_sum((int)(s12 & 0xFFFFu)); v2 = wave_sum((int)(s12 >> 16));
             v3 = wave_sum((int)(s3 & 0xFFFFu)) - wave_sum((int)(s3 >> 16));
             v4 = wave_sum((int)(s4 & 0xFFFFu)) - wave_sum((int)(s4 >> 16));
             v5 = wave_sum((int)(s57 & 0xFFFFu)); v7 = wave_sum((int)(s57 >> 16));
+            v6 = wave_sum(s6);
         }
-        v6 = wave_sum(s6);
         if (kCoop) {   // the four wavefronts' partial sums meet in LDS; every wavefront reads the totals
             if (lane == 0) { int *q = red + wave * 8; q[0] = obj; q[1] = v1; q[2] = v2; q[3] = v3; q[4] = v4; q[5] = v5; q[6] = v6; q[7] = v7; }
             __syncthreads();
@@ -1773,7 +1788,7 @@ void launch_eval(const EvalPools &pools, int n_blocks, int ne, void *stream) {
         else hipLaunchKernelGGL((k_eval<4, true>), dim3(n_blocks), dim3(256), lds, st, pools);
     } else {
         if (ne == 8) hipLaunchKernelGGL((k_eval<8, false>), dim3(n_blocks), dim3(256), lds, st, pools);
-        else if (pools.rf_uniform == 3) hipLaunchKernelGGL((k_eval<4, false, 3>), dim3(n_blocks), dim3(256), lds, st, pools);
+        else if (pools.rf_uniform == 3 && pools.cur_in_lds) hipLaunchKernelGGL((k_eval<4, false, 3>), dim3(n_blocks), dim3(256), lds, st, pools);
         else hipLaunchKernelGGL((k_eval<4, false>), dim3(n_blocks), dim3(256), lds, st, pools);
     }
 }
