@@ -41,6 +41,7 @@ constexpr int LD = 65;                 // leading dimension of a tile in LDS (od
 constexpr int kStepThreads = 512;      // eight wavefronts
 constexpr double kPivotRel = 1e-12, kPivotBig = 1e64, kPivotBigInv = 1e-64;
 constexpr int kWbLd = 17;
+constexpr bool kPanelBlocked = true;   // the diagonal tile's panels in register-blocked halves (false: round 6's column-by-column panel, kept for A/B)
 // LDS carve of k_chol_step / k_chol_first: two tiles, three 16 x 17 scratch blocks, the tile's original diagonal, the pivots' 1 / sqrt
 constexpr size_t kStepLds = sizeof(double) * (2 * (size_t)NB * LD + 3 * 16 * kWbLd + 2 * NB + 2 * NB);   // (+ two column buffers of the panel factor)
 
@@ -60,6 +61,14 @@ __device__ __forceinline__ double rsqrt_nr(double p) {
         y = fma(y, e, y);
     }
     return y;
+}
+
+// 1 / sqrt(p), p > 0: the hardware estimate (2^-23 relative) and ONE third-order step: with e = 1 - p y^2, 1 / sqrt(p) = y (1 + e / 2 + 3 e^2 / 8 + O(e^3))
+// -- five operations, four deep, against eight and six for the two Newton steps (the blocked panel's chain is this function)
+__device__ __forceinline__ double rsqrt_h3(double p) {
+    const double y = __builtin_amdgcn_rsq(p);
+    const double e = fma(-(p * y), y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 // 1 / p, p > 0: the hardware estimate and two Newton steps y <- y + y (1 - p y)
@@ -102,7 +111,81 @@ __device__ __forceinline__ void potrf_inv(double *T, double *V, double *Wb, cons
     }
     for (int p = 0; p < 4; ++p) {
         const int c0 = 16 * p;
-        if (w == 0) {
+        if (w == 0 && kPanelBlocked) {
+            // The panel in two halves of eight columns (round 6, last).  The chain of the column-by-column panel below -- pivot, 1 / pivot, the
+            // column through LDS to the other lanes, their multiply-add, the next pivot by v_readlane -- cost ~430 cycles a column whatever its
+            // instruction count.  Here EVERY lane factors the half's 8 x 8 diagonal block for itself, in registers (36 entries, read from LDS as
+            // broadcasts): the chain is 1 / sqrt(pivot) -> column entry -> next pivot with no cross-lane step in it, and the redundant work (120
+            // multiply-adds) fills the issue slots beside it.  With the block's factor in registers a lane's own row is a forward substitution
+            // of 36 operations; the second half's columns then take the first half's rank-8 update lane by lane (the block of the factor they
+            // need, rows cc + 8 .. cc + 15, comes back from LDS as broadcasts).  Pinned pivots as before: L_jj = 1e64, the column scaled by 1e-64.
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = c0 + 8 * h;
+                const double *Tc = T + cc * LD + cc;          // the half's diagonal block
+                double d[36], ri[8], thr[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) d[i * (i + 1) / 2 + j] = Tc[i * LD + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) thr[j] = d0s[cc + j];          // (kPanelBlocked: d0s holds the thresholds, kPivotRel x the original diagonal)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int jj = j * (j + 1) / 2 + j;
+                    // a pivot under its threshold is replaced by 1e128: 1 / sqrt = 1e-64 and L_jj = 1e64 come out of the same operations (one
+                    // select, no branch around the chain)
+                    const double pj = d[jj] > thr[j] ? d[jj] : kPivotBig * kPivotBig;
+                    const double rinv = rsqrt_h3(pj);
+                    d[jj] = pj * rinv;
+                    ri[j] = rinv;
+#pragma unroll
+                    for (int i = j + 1; i < 8; ++i) d[i * (i + 1) / 2 + j] *= rinv;
+#pragma unroll
+                    for (int i = j + 1; i < 8; ++i)
+#pragma unroll
+                        for (int k = j + 1; k <= i; ++k) d[i * (i + 1) / 2 + k] = fma(-d[i * (i + 1) / 2 + j], d[k * (k + 1) / 2 + j], d[i * (i + 1) / 2 + k]);
+                }
+                // this lane's row of the half: x L^T = a (right-looking); the rows of the diagonal block itself take the pivot entry from the factor
+                double a[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[c] = T[lane * LD + cc + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double x = a[j] * ri[j];
+                    a[j] = lane == cc + j ? d[j * (j + 1) / 2 + j] : x;
+#pragma unroll
+                    for (int i = j + 1; i < 8; ++i) a[i] = fma(-x, d[i * (i + 1) / 2 + j], a[i]);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (lane >= cc + c) T[lane * LD + cc + c] = a[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (lane == cc + j) rinv_s[cc + j] = ri[j];
+                if (h == 0) {
+                    // the second half's columns, rows cc + 8 and below: a2[c] -= sum_k a[k] L[cc + 8 + c][cc + k] (this wavefront's own LDS writes
+                    // above are in order with the reads below: one wavefront, one LDS queue)
+                    // On the matrix core: per block of 16 rows two k-steps of v_mfma_f64_16x16x4_f64 (columns 8..15 of the product are not
+                    // stored); ~12 instructions a row block against ~110 for the lane-by-lane form.  What lands above the diagonal of the second
+                    // half's block, or in rows above the panel, is never read.
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const double b0 = lm < 8 ? T[(cc + 8 + lm) * LD + cc + lq] : 0.0, b1 = lm < 8 ? T[(cc + 8 + lm) * LD + cc + 4 + lq] : 0.0;
+                    for (int mb = p; mb < 4; ++mb) {
+                        v4d acc;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = T[(16 * mb + lq + 4 * r) * LD + cc + 8 + (lm & 7)];
+                        acc = mfma(-T[(16 * mb + lm) * LD + cc + lq], b0, acc);
+                        acc = mfma(-T[(16 * mb + lm) * LD + cc + 4 + lq], b1, acc);
+                        if (lm < 8) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) T[(16 * mb + lq + 4 * r) * LD + cc + 8 + lm] = acc[r];
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        } else if (w == 0) {
             // the panel: lane = row, the panel's 16 columns in registers; rows above the panel's diagonal block carry garbage nobody reads
             // The pivots run ahead on wave-uniform values: pivot j+1 = d - (u r2) u with u = the entry below pivot j, d = the diagonal
             // entry behind it (both read BEFORE column j is scaled, while 1 / sqrt(pivot j) is still being refined) and r2 = 1 / pivot j
@@ -234,7 +317,7 @@ __global__ void __launch_bounds__(kStepThreads) k_chol_first(const double *stop,
     double *T = lds, *V = lds + NB * LD, *Wb = V + NB * LD, *d0s = Wb + 3 * 16 * kWbLd, *rinv_s = d0s + NB, *colb = rinv_s + NB;
     const int tid = threadIdx.x;
     tile_to_lds(S, n, T, tid);
-    if (tid < NB) d0s[tid] = diag0[tid];
+    if (tid < NB) d0s[tid] = (kPanelBlocked ? kPivotRel : 1.0) * diag0[tid];
     __syncthreads();
     if (dbg && tid == 0) dbg[30] = (long long)__builtin_amdgcn_s_memtime();
     potrf_inv(T, V, Wb, d0s, rinv_s, colb, tid, dbg);
@@ -331,7 +414,7 @@ __global__ void __launch_bounds__(kStepThreads) k_chol_step(const double *stop, 
     }
     if (diag) tile_to_lds(S + (size_t)ti * NB * n + (size_t)k * NB, n, bufA, tid);
     else tile_pair_to_lds(S + (size_t)ti * NB * n + (size_t)k * NB, S + (size_t)tj * NB * n + (size_t)k * NB, n, bufA, bufB, tid);
-    if (first && tid < NB) d0s[tid] = diag0[(k + 1) * NB + tid];
+    if (first && tid < NB) d0s[tid] = (kPanelBlocked ? kPivotRel : 1.0) * diag0[(k + 1) * NB + tid];
     __syncthreads();
     const double *Lk = Linv + (size_t)k * NB * NB;
     if (diag) {

@@ -389,3 +389,37 @@ def test_one_lp_sharded_over_logical_devices(kao, ko, kp, monkeypatch, B, R, P, 
     obj, viol = kp.port_eval(ot, sh["assignment"])
     assert viol[0] == 0 and obj == sh["objective"] == cert
     assert sh["collectives"] >= 10 * sh["iterations"]
+
+
+@pytest.mark.parametrize("n", [64, 192, 704])
+def test_dense_kernels_against_numpy(kao, n):
+    """kao_chol.hip alone (kao_dense_spd_test): the Cholesky factor of a badly scaled SPD matrix, the inverses of its diagonal tiles and the
+    solution agree with numpy to rounding; f64 throughout, so the tolerance is a few thousand ulps at condition 1e7..1e8."""
+    rng = np.random.default_rng(100 + n)
+    G = rng.standard_normal((n, n + 32))
+    sc = 10.0 ** rng.uniform(-1.5, 1.5, n)
+    A = (G @ G.T) * np.outer(sc, sc) + 1e-6 * np.diag(sc * sc)
+    A = (A + A.T) / 2
+    rhs = rng.standard_normal(n)
+    d = kao.dense_spd_test(A, rhs)
+    L = np.linalg.cholesky(A)
+    assert np.abs(np.tril(d["factor"]) - L).max() <= 1e-12 * np.abs(L).max()
+    for k in range(n // 64):
+        Lk = L[k * 64:(k + 1) * 64, k * 64:(k + 1) * 64]
+        assert np.abs(d["linv"][k] @ Lk - np.eye(64)).max() <= 1e-11
+        assert np.abs(np.triu(d["linv"][k], 1)).max() == 0.0
+    x = np.linalg.solve(A, rhs)
+    assert np.abs(d["x"] - x).max() <= 1e-9 * np.abs(x).max()
+
+
+def test_dense_kernels_pin_a_dependent_row(kao):
+    """A row that repeats an earlier one loses its pivot: the factor pins it (L_jj = 1e64), the solve stays finite and leaves that
+    component at ~0 -- the rule KAO-LP's Schur complement relies on for rigid bands."""
+    rng = np.random.default_rng(7)
+    n = 128
+    G = rng.standard_normal((n, n))
+    A = G @ G.T + np.eye(n)
+    A[70, :] = A[3, :]; A[:, 70] = A[:, 3]; A[70, 70] = A[3, 3]
+    d = kao.dense_spd_test(A)
+    assert abs(d["factor"][70, 70] / 1e64 - 1.0) < 1e-12
+    assert np.isfinite(d["x"]).all() and abs(d["x"][70]) < 1e-100
