@@ -95,7 +95,9 @@ try:
     except Exception as e:  # noqa: BLE001
         print("bench json unavailable:", e)
     const.update(meta)
-    const["source"] = "profiles/" + os.path.basename(out.rstrip("/")) + " (tools/profile.sh)"
+    tag = os.path.basename(out.rstrip("/"))
+    tag = tag[len("prof_"):] if tag.startswith("prof_") else tag
+    const["source"] = "profiles/%s_final_rocprof_summary.txt (tools/profile.sh %s; summary.txt of gpurun_out/prof_%s, copied)" % (tag, tag, tag)
     print("== constants ==")
     print(json.dumps(const))
     with open(os.path.join(out, "pmc_constants.json"), "w") as f:
