@@ -234,6 +234,15 @@ struct SolveRun {
     }
     // a huge topic between its first feasible incumbent and the end of its LP -- from the start when the limit leaves room for the LP alone
     bool pause_wanted(int i) const { return lp_possible(i) && ((huge(i) && (feasible(i) || (lp_huge_first && launches >= 1))) || lp_alone(i)); }
+    static constexpr int kFirstShortIters = 32;
+    int iters_last = 0;           // iterations of the launch just enqueued
+    bool first_launch_short() const {
+        if (s->opts.max_launches > 0 || !lp_on || has_target || dual_iters <= 0) return false;
+        { const char *e = std::getenv("KAO_FIRST_SHORT"); if (e && e[0] == '0') return false; }   // measurement hook
+        for (int i = 0; i < n; ++i)
+            if (!(huge(i) && lp_alone(i) && s->dual_ok[(size_t)i] && !s->topic_infeasible[(size_t)i])) return false;
+        return n > 0;
+    }
     bool search_paused() const {
         //  never when the caller counts K-search launches (max_launches: it gets them), and never while some other open topic
         // still needs the search: a pause is for solves whose every open topic is waiting for its LP
@@ -409,7 +418,17 @@ struct SolveRun {
         if (t_turn > 0) turn_s = turn_s > 0 ? 0.5 * turn_s + 0.5 * (tn - t_turn) : tn - t_turn;
         t_turn = tn;
         stepped = !search_paused();
-        if (stepped) rc = kao_session_step(s);
+        if (stepped) {
+            // The first launch of a solve whose every topic gets its LP without waiting for an incumbent (huge, and the LP's predicted time fits
+            // the limit) is K-init + kFirstShortIters iterations instead of a whole launch: on a drifted 100,000-partition topic the 512
+            // iterations (17 ms) end without a feasible plan anyway and the LP's kernels find no free compute unit until they have drained; a
+            // balanced start is proven by K-init's plan either way.  A count, not the clock.
+            const int ipl = s->opts.iters_per_launch;
+            if (turns == 0 && first_launch_short()) s->opts.iters_per_launch = std::min(ipl, kFirstShortIters);
+            rc = kao_session_step(s);
+            iters_last = s->opts.iters_per_launch;
+            s->opts.iters_per_launch = ipl;
+        }
         if (!rc && bound_pending) { bound_pending = false; rc = kao_session_bound_step(s, dual_target.data(), dual_now); }
         int running = 0;
         for (int i = 0; i < n; ++i) running += lp_state[(size_t)i] == 1 && !lp_all[(size_t)i];
@@ -600,7 +619,7 @@ struct SolveRun {
         int rc = kao_session_best_keys(s, dkeys.data());
         if (rc) return rc;
         ++turns;
-        if (stepped) { ++launches; iters_done += s->opts.iters_per_launch; }
+        if (stepped) { ++launches; iters_done += iters_last; }
         const double t = now_s() - t0;
         for (int i = 0; i < n; ++i) {
             if (dkeys[(size_t)i] < gprev[(size_t)i]) { gprev[(size_t)i] = dkeys[(size_t)i]; t_improved[(size_t)i] = t; i_improved[(size_t)i] = iters_done; }
