@@ -470,13 +470,17 @@ struct SolveRun {
             const kao_topic &t = topics[i];
             std::vector<int32_t> mult(2 * (size_t)t.n_brokers + (size_t)t.n_racks);
             double st8[8];
+            const double tf0 = now_s();
             rc = lp_finish(lp_ctx[(size_t)i], mult.data(), st8, nullptr);
+            const double tf1 = now_s();
             bool have_primal = false;
             if (!rc && lp_round_on && st8[3] != 3.0) {   // the quantised iterate (not of a stalled solve: its last iterate is not finite)
                 lp_q.resize((size_t)(2 * t.rf_cur + 2 * t.n_racks) * t.n_partitions); lp_zq.resize(2 * (size_t)t.n_brokers);
                 have_primal = lp_primal(lp_ctx[(size_t)i], lp_q.data(), lp_zq.data()) == KAO_OK;
             }
+            const double tf2 = now_s();
             lp_close(lp_ctx[(size_t)i]); lp_ctx[(size_t)i] = nullptr; --running;
+            if (trace) std::fprintf(stderr, "[kao-solve]   KAO-LP topic %d: lp_finish %.3f ms, lp_primal %.3f ms, lp_close %.3f ms\n", i, (tf1 - tf0) * 1e3, (tf2 - tf1) * 1e3, (now_s() - tf2) * 1e3);
             if (rc) { lp_state[(size_t)i] = 3; continue; }
             lp_iters += it; ++lp_solves;
             const bool primal_only = lp_try[(size_t)i]++ > 0;   // a retry: the certificate and the prices of the first solve stay
