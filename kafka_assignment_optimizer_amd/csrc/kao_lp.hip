@@ -67,7 +67,8 @@ enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (no
              SC_PINF, SC_DINF, SC_PLAST, SC_DLAST, SC_HAVE_LAST, SC_KEEP /* this iterate is finite: copy its duals */, SC_TOL, SC_MAXIT, SC_NVU /* variables + bounded variables */, SC_NB, SC_NCN,
              SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT,
              SC_MCC_GO /* centrality correctors: the next one is still wanted */, SC_MCC_ACC /* the last one was accepted */,
-             SC_MU_REF, SC_IT_REF /* the stall test's reference iterate */, SC_PINF_BEST /* smallest primal infeasibility among the near-optimal iterates */, kScN = 32 };
+             SC_MU_REF, SC_IT_REF /* the stall test's reference iterate */, SC_PINF_BEST /* smallest primal infeasibility among the near-optimal iterates */,
+             SC_GAMMA /* the fraction of the way to the boundary a blocked step takes */, kScN = 32 };
 // Stalled at the numerical floor (round 6): some perturbed solves reach a relative gap of 5e-10 .. 1e-9 after ~110 iterations and then
 // stand still -- step lengths ~0, mu unchanged for the remaining 90 iterations of their cap (profiles/r06_c09_stalled_solves.txt).  An
 // iterate within kLpStallGap tolerances of the optimum whose mu has not fallen by a tenth in kLpStallWindow iterations counts as converged:
@@ -226,7 +227,7 @@ __global__ void k_lp_keep_last(const double *sc, const double *yc, double *ylast
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && sc[SC_KEEP] == 1.0) ylast[i] = yc[i];
 }
-// step lengths to the boundary from the min-reduction; the corrector's are damped (0.9995) and close the iteration count
+// step lengths to the boundary from the min-reduction; the last ones are damped (kLpGamma) and close the iteration count
 __global__ void k_lp_sc_step(double *sc, const double *red, int pass) {
     if (sc[SC_STOP] != 0.0) return;
     const double ap = red[0], ad = red[1];
@@ -234,10 +235,18 @@ __global__ void k_lp_sc_step(double *sc, const double *red, int pass) {
     if (pass) { sc[SC_MCC_GO] = (ap < 1.0 || ad < 1.0) ? 1.0 : 0.0; sc[SC_MCC_ACC] = 0.0; }
 }
 // after the correctors: the step stops short of the boundary, the iteration is counted
+// A blocked step of length a goes min(kLpGammaMax, max(kLpGamma, a)) of the way to the boundary.  0.9995 throughout until late in round 6; a short
+// step that stops a tenth short leaves the blocking pair a tenth of its value instead of a two-thousandth, and the next iteration is not
+// blocked by the same pair again -- 16 drift seeds of the 1000 x 100,000 topic: fewer iterations of the perturbed solve on every one
+// (profiles/r06_c30_step_fraction.txt); nearly full steps stay nearly full, so the last iterations converge as before.
+// SC_GAMMA > 0 (KAO_LP_GAMMA, measurement hook): that fixed fraction instead.
+constexpr double kLpGamma = 0.9, kLpGammaMax = 0.9995;
+static double lp_gamma() { const char *e = std::getenv("KAO_LP_GAMMA"); const double g = e ? std::atof(e) : 0.0; return g > 0.5 && g < 1.0 ? g : 0.0; }
+__device__ __forceinline__ double lp_step_fraction(double a, double fixed) { return fixed > 0.0 ? fixed : (a > kLpGammaMax ? kLpGammaMax : (a < kLpGamma ? kLpGamma : a)); }
 __global__ void k_lp_sc_final(double *sc) {
     if (sc[SC_STOP] != 0.0) return;
-    if (sc[SC_AP] < 1.0) sc[SC_AP] *= 0.9995;
-    if (sc[SC_AD] < 1.0) sc[SC_AD] *= 0.9995;
+    if (sc[SC_AP] < 1.0) sc[SC_AP] *= lp_step_fraction(sc[SC_AP], sc[SC_GAMMA]);
+    if (sc[SC_AD] < 1.0) sc[SC_AD] *= lp_step_fraction(sc[SC_AD], sc[SC_GAMMA]);
     sc[SC_IT] += 1.0;
 }
 // ---- Gondzio's multiple centrality correctors (round 5, last; oracle/kao_lp_port.c mcc_build / mcc_finish): the step lengths of the
@@ -1593,7 +1602,7 @@ int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
     c.used = true;
     double init[kScN];
     std::memset(init, 0, sizeof init);
-    init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
+    init[SC_GAMMA] = lp_gamma(); init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
     init[SC_PERT] = pert > 0.0 ? pert : 0.0; init[SC_SALT] = (double)salt;
     init[SC_MU_REF] = 1e300; init[SC_IT_REF] = 0.0; init[SC_PINF_BEST] = 1e300;
     std::memcpy(c.h_sc, init, sizeof init);

@@ -173,6 +173,7 @@ def exact_dual_value(t: ko.Topic, a, l, g) -> float:
 
 
 MCC_DELTA, MCC_BMIN, MCC_BMAX = 0.3, 0.1, 10.0      # Gondzio's centrality correctors (oracle/kao_lp_port.c, kao_lp.hip)
+STEP_FRACTION, STEP_FRACTION_MAX = 0.9, 0.9995      # a blocked step of length a goes min(MAX, max(FRACTION, a)) of the way to the boundary (kao_lp.hip k_lp_sc_final; 0.9995 throughout until late in round 6)
 
 
 def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, trace=None, mcc: int = 2):
@@ -256,8 +257,8 @@ def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, t
             if not (ap2 >= ap + 0.01 * MCC_DELTA or ad2 >= ad + 0.01 * MCC_DELTA) or ap2 < 0.9 * ap or ad2 < 0.9 * ad:
                 break
             dx, dy, ds, dv, ap, ad = dx + dxc, dy + dyc, ds + dsc, dv + dvc, ap2, ad2
-        ap = 0.9995 * ap if ap < 1.0 else 1.0
-        ad = 0.9995 * ad if ad < 1.0 else 1.0
+        ap = min(STEP_FRACTION_MAX, max(STEP_FRACTION, ap)) * ap if ap < 1.0 else 1.0
+        ad = min(STEP_FRACTION_MAX, max(STEP_FRACTION, ad)) * ad if ad < 1.0 else 1.0
         x = x + ap * dx; w = np.where(U, uu - x, 1.0)
         y = y + ad * dy; s = s + ad * ds; v = v + ad * dv
     return x, y, it, -pobj, -dobj

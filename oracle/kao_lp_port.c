@@ -448,6 +448,8 @@ static void vec_free(lp_vec *v) { free(v->z); free(v->zg); free(v->r1); free(v->
 /* ---- multiple centrality correctors (Gondzio): after the predictor-corrector direction, the step lengths are enlarged by `MCC_DELTA`,
  * the complementarity products of that trial point are projected onto [MCC_BMIN, MCC_BMAX] x (sigma mu), and the difference is the
  * right-hand side of one more solve with the same factor; the corrected direction is kept when it lengthens a step. ---- */
+#define STEP_FRACTION 0.9
+#define STEP_FRACTION_MAX 0.9995
 #define MCC_DELTA 0.3
 #define MCC_BMIN 0.1
 #define MCC_BMAX 10.0
@@ -651,20 +653,27 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
             lp_solve_normal(L, D->r1, D->r2, D->r7, D->r5, D->rc);       /* dy */
             lp_AT(L, D->r1, D->r2, D->r7, D->r5, D->rc, D->z, D->zg);
             ap = 1; ad = 1;
+            long blk_p = -1, blk_d = -1; int blk_pk = 0, blk_dk = 0;
             for (size_t i = 0; i < nv; ++i) {
                 if (!L->pres[i]) { D->z[i] = 0; pds[i] = 0; pdv[i] = 0; continue; }
                 const double dx = L->th[i] * (D->z[i] - h.z[i]);
                 const double dss = (pds[i] - L->s[i] * dx) / L->x[i];
                 D->z[i] = dx; pds[i] = dss;
-                if (dx < 0) { const double a = -L->x[i] / dx; if (a < ap) ap = a; }
-                if (dss < 0) { const double a = -L->s[i] / dss; if (a < ad) ad = a; }
+                if (dx < 0) { const double a = -L->x[i] / dx; if (a < ap) { ap = a; blk_p = (long)i; blk_pk = 0; } }
+                if (dss < 0) { const double a = -L->s[i] / dss; if (a < ad) { ad = a; blk_d = (long)i; blk_dk = 0; } }
                 if (L->ub[i]) {
                     const double w = L->uu[i] - L->x[i], dvv = (pdv[i] + L->v[i] * dx) / w;
                     pdv[i] = dvv;
-                    if (dx > 0) { const double a = w / dx; if (a < ap) ap = a; }
-                    if (dvv < 0) { const double a = -L->v[i] / dvv; if (a < ad) ad = a; }
+                    if (dx > 0) { const double a = w / dx; if (a < ap) { ap = a; blk_p = (long)i; blk_pk = 1; } }
+                    if (dvv < 0) { const double a = -L->v[i] / dvv; if (a < ad) { ad = a; blk_d = (long)i; blk_dk = 1; } }
                 } else pdv[i] = 0;
             }
+            if (getenv("KAO_LP_STEP_TRACE") && pass == 1) {
+                fprintf(stderr, "[kao_lp_port]   local blockers: primal var class %ld (%s) x %.3e s %.3e ap %.4f | dual class %ld (%s) x %.3e s %.3e ad %.4f\n",
+                        blk_p < 0 ? -1 : blk_p / P, blk_pk ? "w" : "x", blk_p < 0 ? 0 : L->x[blk_p], blk_p < 0 ? 0 : L->s[blk_p], ap,
+                        blk_d < 0 ? -1 : blk_d / P, blk_dk ? "v" : "s", blk_d < 0 ? 0 : L->x[blk_d], blk_d < 0 ? 0 : L->s[blk_d], ad);
+            }
+            const double ap_loc = ap, ad_loc = ad;
             for (int i = 0; i < GV; ++i) {
                 if (!L->presg[i]) { D->zg[i] = 0; pdsg[i] = 0; pdvg[i] = 0; continue; }
                 const double dx = L->thg[i] * (D->zg[i] - h.zg[i]);
@@ -679,6 +688,8 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
                     if (dvv < 0) { const double a = -L->vg[i] / dvv; if (a < ad) ad = a; }
                 } else pdvg[i] = 0;
             }
+            if (getenv("KAO_LP_STEP_TRACE") && pass == 1 && (ap < ap_loc || ad < ad_loc)) fprintf(stderr, "[kao_lp_port]   global variables block: ap %.4f (local %.4f) ad %.4f (local %.4f)\n", ap, ap_loc, ad, ad_loc);
+            (void)ap_loc; (void)ad_loc;
             if (pass == 0) {
                 double xs2 = 0;
                 for (size_t i = 0; i < nv; ++i) {
@@ -721,8 +732,15 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
                 ++n_mcc;
             }
         }
-        if (ap < 1.0) ap *= 0.9995;
-        if (ad < 1.0) ad *= 0.9995;
+        {   /* a blocked step goes a fraction min(STEP_FRACTION_MAX, max(STEP_FRACTION, alpha)) of the way to the boundary: short steps leave the
+             * blocking pair a tenth of its value, nearly full ones stay nearly full (kao_lp.hip k_lp_sc_final; KAO_LP_GAMMA is the same
+             * measurement hook: a fixed fraction) */
+            const char *e = getenv("KAO_LP_GAMMA");
+            const double gfix = e ? atof(e) : 0.0;
+            if (ap < 1.0) ap *= (gfix > 0.5 && gfix < 1.0) ? gfix : (ap > STEP_FRACTION_MAX ? STEP_FRACTION_MAX : (ap < STEP_FRACTION ? STEP_FRACTION : ap));
+            if (ad < 1.0) ad *= (gfix > 0.5 && gfix < 1.0) ? gfix : (ad > STEP_FRACTION_MAX ? STEP_FRACTION_MAX : (ad < STEP_FRACTION ? STEP_FRACTION : ad));
+        }
+        if (getenv("KAO_LP_STEP_TRACE")) fprintf(stderr, "[kao_lp_port] it %d mu %.3e sigma %.3e ap %.4f ad %.4f\n", it, mu, sigma_mu / mu, ap, ad);
         for (size_t i = 0; i < nv; ++i) { if (!L->pres[i]) continue; L->x[i] += ap * d2.z[i]; L->s[i] += ad * ds[i]; if (L->ub[i]) L->v[i] += ad * dv[i]; }
         for (int i = 0; i < GV; ++i) { if (!L->presg[i]) continue; L->xg[i] += ap * d2.zg[i]; L->sg[i] += ad * dsg[i]; if (L->ubg[i]) L->vg[i] += ad * dvg[i]; }
         for (int p = 0; p < P; ++p) {

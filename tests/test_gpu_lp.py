@@ -71,7 +71,10 @@ def test_lp_trace_matches_the_restatement(kao, ko, kp, B, R, P):
     r = kl.port_solve(ot)
     _trace_close(d["trace"], r["trace"])
     val, _, _, _ = kl.solve_highs(kl.build(ot))
-    assert abs(d["dual"] - val) < 1e-3 and abs(d["primal"] - val) < 1e-2
+    # (the primal value of the LAST iterate is the looser one: with 50 racks the solve ends past its numerical floor -- mu ~1e-11, primal
+    # infeasibility back up to ~1e-5 -- and the primal objective there is off by 0.01 .. 0.02 on the device and in the restatement alike;
+    # the certificate is the dual side)
+    assert abs(d["dual"] - val) < 1e-3 and abs(d["primal"] - val) < 3e-2
     for k in ("a", "l", "g"):   # the optimal duals are a face, not a point: the last iterates (mu ~ 1e-9) drift along it by ~1e-3
         assert np.abs(d[k].astype(np.int64) - r[k]).max() <= 2048, k
     b = kao.lp_bound(pt)

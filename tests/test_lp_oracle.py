@@ -168,7 +168,7 @@ def test_host_rounding_matches_the_specification(ko, kp):
 
 @pytest.mark.parametrize("B,R,P,dseed,salt,fractional", [(60, 6, 400, 1, 1, 14), (100, 10, 1000, 2, 2, 9), (300, 10, 2000, 1, 3, 13),
                                                          (300, 10, 2000, 2, 4, 19)])
-def test_half_integral_vertex_is_completed_by_patterns(ko, kp, B, R, P, dseed, salt, fractional):
+def test_half_integral_vertex_is_completed_by_patterns(ko, kp, monkeypatch, B, R, P, dseed, salt, fractional):
     """Perturbed LPs whose vertex is half-integral in 9..19 partitions (rigid bands: every broker's band is a single value).  The
     pattern completion (oracle/kao_lp.py complete_by_patterns: which current replicas each of these partitions keeps, heaviest
     first, bounded by the best remaining patterns and by the room the brokers' bands have left -- the 19-partition case needs the
@@ -179,6 +179,9 @@ def test_half_integral_vertex_is_completed_by_patterns(ko, kp, B, R, P, dseed, s
     import kao_lp as kl
     import kafka_assignment_optimizer_amd as kao
     from conftest import to_product_topic
+    # the iterates are this test's INPUT (picked because they end half-integral): they were produced with the step fraction 0.9995; with
+    # today's 0.9 the same solves stop on iterates that round without a fractional partition.  The hook keeps the pinned inputs.
+    monkeypatch.setenv("KAO_LP_GAMMA", "0.9995")
     t = _drift_topic(ko, B, R, P, dseed)
     r0 = kl.port_solve(t)
     bound = math.floor(kl.exact_dual_value(t, r0["a"], r0["l"], r0["g"]) + 1e-9)
@@ -193,7 +196,7 @@ def test_half_integral_vertex_is_completed_by_patterns(ko, kp, B, R, P, dseed, s
     assert d["assignment"].tolist() == A.tolist() and d["fractional"] == fractional
 
 
-def test_rows_outside_the_inflows_or_over_a_band_join_the_pattern_completion(ko, kp):
+def test_rows_outside_the_inflows_or_over_a_band_join_the_pattern_completion(ko, kp, monkeypatch):
     """400 x 6000, second drift seed, tolerance 1e-6: three fractional partitions and ONE row of the integral pass that found no
     broker with inflow left in its rack (`over_inflow` 1: broker 0 ends a replica over its band, ten brokers one under it with nine
     slots to give -- no completion can be perfect, and the band repair that followed cost nine units).  That row is given up and
@@ -202,6 +205,7 @@ def test_rows_outside_the_inflows_or_over_a_band_join_the_pattern_completion(ko,
     import kao_lp as kl
     import kafka_assignment_optimizer_amd as kao
     from conftest import to_product_topic
+    monkeypatch.setenv("KAO_LP_GAMMA", "0.9995")     # pinned input iterates (see test_half_integral_vertex_is_completed_by_patterns)
     t = _drift_topic(ko, 400, 8, 6000, 2)
     r0 = kl.port_solve(t)
     bound = math.floor(kl.exact_dual_value(t, r0["a"], r0["l"], r0["g"]) + 1e-9)
