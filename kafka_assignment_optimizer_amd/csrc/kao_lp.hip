@@ -68,7 +68,7 @@ enum ScIdx { SC_STOP = 0 /* 0 run, 1 converged, 2 iteration limit, 3 stalled (no
              SC_PERT /* cost perturbation eps (0: the model's own LP) */, SC_SALT,
              SC_MCC_GO /* centrality correctors: the next one is still wanted */, SC_MCC_ACC /* the last one was accepted */,
              SC_MU_REF, SC_IT_REF /* the stall test's reference iterate */, SC_PINF_BEST /* smallest primal infeasibility among the near-optimal iterates */,
-             SC_GAMMA /* the fraction of the way to the boundary a blocked step takes */, kScN = 32 };
+             SC_GAMMA /* the fraction of the way to the boundary a blocked step takes */, SC_SIGEXP /* sigma = (mu_aff / mu)^this */, kScN = 32 };
 // Stalled at the numerical floor (round 6): some perturbed solves reach a relative gap of 5e-10 .. 1e-9 after ~110 iterations and then
 // stand still -- step lengths ~0, mu unchanged for the remaining 90 iterations of their cap (profiles/r06_c09_stalled_solves.txt).  An
 // iterate within kLpStallGap tolerances of the optimum whose mu has not fallen by a tenth in kLpStallWindow iterations counts as converged:
@@ -241,6 +241,12 @@ __global__ void k_lp_sc_step(double *sc, const double *red, int pass) {
 // (profiles/r06_c30_step_fraction.txt); nearly full steps stay nearly full, so the last iterations converge as before.
 // SC_GAMMA > 0 (KAO_LP_GAMMA, measurement hook): that fixed fraction instead.
 constexpr double kLpGamma = 0.9, kLpGammaMax = 0.9995;
+// sigma = (mu_aff / mu)^kLpSigmaExp.  Mehrotra's exponent 3 until late in round 6: on these LPs the predictor's step is short (0.1 .. 0.3: one pair blocks
+// it) while the corrected step is not, so the cube asked for sigma = 0.5 .. 0.7 and mu fell by a tenth an iteration.  Exponent 10 keeps sigma
+// near 1 only where the predictor achieves nothing: the perturbed solve of the drifted 1000 x 100,000 topic takes 66 iterations instead of
+// 88, the certificate's LP 26 instead of 42 (profiles/r06_c31_sigma_exponent.txt; 6 / 8 / 10 / 12 / 16 / 24 / 32 tried: 24 stalled once).
+constexpr int kLpSigmaExp = 10;
+static double lp_sigexp() { const char *e = std::getenv("KAO_LP_SIGEXP"); const int k = e ? std::atoi(e) : kLpSigmaExp; return k >= 1 && k <= 64 ? k : kLpSigmaExp; }   // (measurement hook)
 static double lp_gamma() { const char *e = std::getenv("KAO_LP_GAMMA"); const double g = e ? std::atof(e) : 0.0; return g > 0.5 && g < 1.0 ? g : 0.0; }
 __device__ __forceinline__ double lp_step_fraction(double a, double fixed) { return fixed > 0.0 ? fixed : (a > kLpGammaMax ? kLpGammaMax : (a < kLpGamma ? kLpGamma : a)); }
 __global__ void k_lp_sc_final(double *sc) {
@@ -266,7 +272,9 @@ __global__ void k_lp_sc_mcc(double *sc, const double *red) {
 __global__ void k_lp_sc_sigma(double *sc, const double *red) {
     if (sc[SC_STOP] != 0.0) return;
     const double ratio = red[0] / sc[SC_NVU] / sc[SC_MU];
-    sc[SC_SIGMU] = ratio * ratio * ratio * sc[SC_MU];
+    double sg = ratio;
+    for (int k = 1; k < (int)sc[SC_SIGEXP]; ++k) sg *= ratio;
+    sc[SC_SIGMU] = sg * sc[SC_MU];
 }
 
 // ---- elementwise over the variables ------------------------------------------------------------------------------
@@ -1602,7 +1610,7 @@ int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
     c.used = true;
     double init[kScN];
     std::memset(init, 0, sizeof init);
-    init[SC_GAMMA] = lp_gamma(); init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
+    init[SC_GAMMA] = lp_gamma(); init[SC_SIGEXP] = lp_sigexp(); init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
     init[SC_PERT] = pert > 0.0 ? pert : 0.0; init[SC_SALT] = (double)salt;
     init[SC_MU_REF] = 1e300; init[SC_IT_REF] = 0.0; init[SC_PINF_BEST] = 1e300;
     std::memcpy(c.h_sc, init, sizeof init);

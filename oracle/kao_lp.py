@@ -173,6 +173,7 @@ def exact_dual_value(t: ko.Topic, a, l, g) -> float:
 
 
 MCC_DELTA, MCC_BMIN, MCC_BMAX = 0.3, 0.1, 10.0      # Gondzio's centrality correctors (oracle/kao_lp_port.c, kao_lp.hip)
+SIGMA_EXP = 10                                      # sigma = (mu_aff / mu)^SIGMA_EXP (Mehrotra's 3 until late in round 6: docs/notes_r06.md section 24)
 STEP_FRACTION, STEP_FRACTION_MAX = 0.9, 0.9995      # a blocked step of length a goes min(MAX, max(FRACTION, a)) of the way to the boundary (kao_lp.hip k_lp_sc_final; 0.9995 throughout until late in round 6)
 
 
@@ -236,7 +237,9 @@ def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, t
         dx, dy, ds, dv = direction(-x * s, np.where(U, -w * v, 0.0))
         ap = min(maxstep(x, dx), maxstep(w, -dx, U)); ad = min(maxstep(s, ds), maxstep(v, dv, U))
         mu_aff = ((x + ap * dx) @ (s + ad * ds) + ((w - ap * dx) * (v + ad * dv))[U].sum()) / (n + nU)
-        sigma = (mu_aff / mu) ** 3
+        sigma = mu_aff / mu
+        for _ in range(SIGMA_EXP - 1):      # the powers multiplied up one by one, as the restatement and the device do
+            sigma *= mu_aff / mu
         dx, dy, ds, dv = direction(sigma * mu - x * s - dx * ds, np.where(U, sigma * mu - w * v + dx * dv, 0.0))
         ap = min(maxstep(x, dx), maxstep(w, -dx, U)); ad = min(maxstep(s, ds), maxstep(v, dv, U))
         mut = sigma * mu

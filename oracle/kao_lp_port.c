@@ -448,6 +448,7 @@ static void vec_free(lp_vec *v) { free(v->z); free(v->zg); free(v->r1); free(v->
 /* ---- multiple centrality correctors (Gondzio): after the predictor-corrector direction, the step lengths are enlarged by `MCC_DELTA`,
  * the complementarity products of that trial point are projected onto [MCC_BMIN, MCC_BMAX] x (sigma mu), and the difference is the
  * right-hand side of one more solve with the same factor; the corrected direction is kept when it lengthens a step. ---- */
+#define SIGMA_EXP 10
 #define STEP_FRACTION 0.9
 #define STEP_FRACTION_MAX 0.9995
 #define MCC_DELTA 0.3
@@ -703,7 +704,14 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
                     if (L->ubg[i]) xs2 += (L->uug[i] - L->xg[i] - ap * d1.zg[i]) * (L->vg[i] + ad * dvag[i]);
                 }
                 const double mu_aff = xs2 / (double)(nvar + nub), ratio = mu_aff / mu;
-                sigma_mu = ratio * ratio * ratio * mu;
+                {   /* sigma = (mu_aff / mu)^SIGMA_EXP, the powers multiplied up one by one (kao_lp.hip k_lp_sc_sigma; KAO_LP_SIGEXP: same hook) */
+                    const char *e = getenv("KAO_LP_SIGEXP");
+                    int ke = e ? atoi(e) : SIGMA_EXP;
+                    if (ke < 1 || ke > 64) ke = SIGMA_EXP;
+                    double sg = ratio;
+                    for (int k = 1; k < ke; ++k) sg *= ratio;
+                    sigma_mu = sg * mu;
+                }
             }
         }
         {   /* up to two centrality correctors per iteration (the device enqueues exactly as many: KAO_LP_MCC=<k> overrides both sides, 0 = none) */

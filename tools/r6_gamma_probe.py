@@ -13,7 +13,7 @@ kao.solve([topics[0][1]], seed=1, max_launches=1)
 for name, t in topics:
     kao.solve([t], seed=1, max_launches=1)
     for g in gammas:
-        os.environ["KAO_LP_GAMMA"] = g
+        os.environ[os.environ.get("HOOK", "KAO_LP_GAMMA")] = g
         r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=1.0)[0]
         tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
         print(f"{name} gamma {g}: {r.status} objective {r.objective} certificate {r.upper_bound} read back {tm['results_read_back']:.3f}s "
