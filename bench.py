@@ -64,7 +64,7 @@ def compact_line(out):
     if isinstance(cfg.get("topics_per_rank"), list) and len(cfg["topics_per_rank"]) <= 16:
         line["config"]["topics_per_rank"] = cfg["topics_per_rank"]          # (tools/summarize_prof.py keys the counter constants on it)
     roof_keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
-                 "traffic_source", "peak_source")
+                 "traffic_source", "peak_source", "binding_bound", "binding_frac", "algorithmic_gbps")
     for k in ("roofline", "roofline_valu_issue", "roofline_lds", "roofline_eval_stream", "roofline_lp"):
         if k in out:
             line[k] = _num(out[k], roof_keys + ("valu_insts_per_neighbour", "ms_per_iteration", "iterations", "hbm_frac", "f64_frac",
@@ -730,6 +730,10 @@ def main():
             out["roofline_lds"] = {"kernel": "k_search", "bound": "lds", "achieved": lds_b / (avg_ms * 1e-3) / 1e9, "peak": LDS_PEAK_GBS,
                                    "unit": "GB/s", "frac": lds_b / (avg_ms * 1e-3) / 1e9 / LDS_PEAK_GBS,
                                    "note": "SQ_INSTS_LDS x 64 lanes x average access width; peak 128 B/clk/CU"}
+    # the HBM figure above is the contract's; the roof that binds this LDS-resident kernel is VALU issue: both in the one block (numbers only)
+    roof["algorithmic_gbps"] = roof["algorithmic_lds_served"]["gbps"]
+    if "roofline_valu_issue" in out:
+        roof["binding_bound"] = "valu-issue"; roof["binding_frac"] = out["roofline_valu_issue"]["frac"]
     out["roofline"] = roof
     ach_e = eb / (ms_eval * 1e-3) / 1e9 if ms_eval > 0 else None
     out["roofline_eval_in_step"] = {"kernel": "k_eval", "achieved": ach_e, "unit": "GB/s", "avg_launch_ms": ms_eval / max(1, launches),
