@@ -173,6 +173,7 @@ def exact_dual_value(t: ko.Topic, a, l, g) -> float:
 
 
 MCC_DELTA, MCC_BMIN, MCC_BMAX = 0.3, 0.1, 10.0      # Gondzio's centrality correctors (oracle/kao_lp_port.c, kao_lp.hip)
+START_X_FLOOR = 0.1                                 # the starting point's x = max(x~, this), capped at half the upper bound (1.0 until late in round 6: notes section 25)
 SIGMA_EXP = 10                                      # sigma = (mu_aff / mu)^SIGMA_EXP (Mehrotra's 3 until late in round 6: docs/notes_r06.md section 24)
 STEP_FRACTION, STEP_FRACTION_MAX = 0.9, 0.9995      # a blocked step of length a goes min(MAX, max(FRACTION, a)) of the way to the boundary (kao_lp.hip k_lp_sc_final; 0.9995 throughout until late in round 6)
 
@@ -198,7 +199,7 @@ def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, t
     x = AT @ lu.solve(b)
     y = lu.solve(A @ c)
     s = c - AT @ y
-    x = np.maximum(x, 1.0)
+    x = np.maximum(x, START_X_FLOOR)
     x = np.where(U, np.minimum(x, np.maximum(uu * 0.5, 1e-2)), x)
     w = np.where(U, uu - x, 1.0)
     s = np.maximum(s, 1.0)

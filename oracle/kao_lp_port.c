@@ -449,6 +449,7 @@ static void vec_free(lp_vec *v) { free(v->z); free(v->zg); free(v->r1); free(v->
  * the complementarity products of that trial point are projected onto [MCC_BMIN, MCC_BMAX] x (sigma mu), and the difference is the
  * right-hand side of one more solve with the same factor; the corrected direction is kept when it lengthens a step. ---- */
 #define SIGMA_EXP 10
+#define START_X_FLOOR 0.1
 #define STEP_FRACTION 0.9
 #define STEP_FRACTION_MAX 0.9995
 #define MCC_DELTA 0.3
@@ -534,7 +535,9 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
     }
 #define RHS_B(V) do { for (int p_ = 0; p_ < P; ++p_) { (V).r1[p_] = L->RF; (V).r2[p_] = 1; for (int r_ = 0; r_ < R; ++r_) (V).r7[(size_t)r_ * P + p_] = t->prack_hi; \
         for (int j_ = 0; j_ < NJ; ++j_) (V).r5[(size_t)j_ * P + p_] = (L->has_c5 && cur_b(L, p_, j_) >= 0) ? 1.0 : 0.0; } memcpy((V).rc, L->bc, 8 * (size_t)mc); } while (0)
-    /* starting point: theta = 1 */
+    /* starting point: theta = 1; x = max(x~, START_X_FLOOR) capped at half the upper bound (kao_lp.hip k_lp_start; KAO_LP_XFLOOR: same hook) */
+    double xfloor = getenv("KAO_LP_XFLOOR") ? atof(getenv("KAO_LP_XFLOOR")) : START_X_FLOOR;
+    if (!(xfloor > 0.0 && xfloor <= 10.0)) xfloor = START_X_FLOOR;
     for (size_t i = 0; i < nv; ++i) L->th[i] = L->pres[i] ? 1.0 : 0.0;
     for (int i = 0; i < GV; ++i) L->thg[i] = L->presg[i] ? 1.0 : 0.0;
     if (lp_factor(L)) { status = 2; goto done; }
@@ -548,7 +551,7 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
     lp_AT(L, L->y1, L->y2, L->y7, L->y5, L->yc, tmp.z, tmp.zg);
     for (size_t i = 0; i < nv; ++i) {
         if (!L->pres[i]) { L->x[i] = 1; L->s[i] = 1; L->v[i] = 0; continue; }
-        double x = L->x[i] > 1.0 ? L->x[i] : 1.0;
+        double x = L->x[i] > xfloor ? L->x[i] : xfloor;
         if (L->ub[i]) { const double cap = L->uu[i] * 0.5 > 1e-2 ? L->uu[i] * 0.5 : 1e-2; if (x > cap) x = cap; }
         L->x[i] = x;
         const double s = L->c[i] - tmp.z[i];
@@ -557,7 +560,7 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
     }
     for (int i = 0; i < GV; ++i) {
         if (!L->presg[i]) { L->xg[i] = 1; L->sg[i] = 1; L->vg[i] = 0; continue; }
-        double x = L->xg[i] > 1.0 ? L->xg[i] : 1.0;
+        double x = L->xg[i] > xfloor ? L->xg[i] : xfloor;
         if (L->ubg[i]) { const double cap = L->uug[i] * 0.5 > 1e-2 ? L->uug[i] * 0.5 : 1e-2; if (x > cap) x = cap; }
         L->xg[i] = x;
         const double s = L->cg[i] - tmp.zg[i];

@@ -181,7 +181,7 @@ def test_half_integral_vertex_is_completed_by_patterns(ko, kp, monkeypatch, B, R
     from conftest import to_product_topic
     # the iterates are this test's INPUT (picked because they end half-integral): they were produced with the step fraction 0.9995; with
     # today's 0.9 the same solves stop on iterates that round without a fractional partition.  The hook keeps the pinned inputs.
-    monkeypatch.setenv("KAO_LP_GAMMA", "0.9995"); monkeypatch.setenv("KAO_LP_SIGEXP", "3")      # (likewise the centering exponent: 3 then, 10 today)
+    monkeypatch.setenv("KAO_LP_GAMMA", "0.9995"); monkeypatch.setenv("KAO_LP_SIGEXP", "3"); monkeypatch.setenv("KAO_LP_XFLOOR", "1")      # (likewise the centering exponent, 3 then, 10 today, and the starting point's floor, 1 then, 0.1 today)
     t = _drift_topic(ko, B, R, P, dseed)
     r0 = kl.port_solve(t)
     bound = math.floor(kl.exact_dual_value(t, r0["a"], r0["l"], r0["g"]) + 1e-9)
@@ -205,7 +205,7 @@ def test_rows_outside_the_inflows_or_over_a_band_join_the_pattern_completion(ko,
     import kao_lp as kl
     import kafka_assignment_optimizer_amd as kao
     from conftest import to_product_topic
-    monkeypatch.setenv("KAO_LP_GAMMA", "0.9995"); monkeypatch.setenv("KAO_LP_SIGEXP", "3")     # pinned input iterates (see test_half_integral_vertex_is_completed_by_patterns)
+    monkeypatch.setenv("KAO_LP_GAMMA", "0.9995"); monkeypatch.setenv("KAO_LP_SIGEXP", "3"); monkeypatch.setenv("KAO_LP_XFLOOR", "1")     # pinned input iterates (see test_half_integral_vertex_is_completed_by_patterns)
     t = _drift_topic(ko, 400, 8, 6000, 2)
     r0 = kl.port_solve(t)
     bound = math.floor(kl.exact_dual_value(t, r0["a"], r0["l"], r0["g"]) + 1e-9)
