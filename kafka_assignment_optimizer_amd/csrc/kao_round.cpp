@@ -31,6 +31,14 @@ int lp_round_assignment(const kao_topic *t, const uint8_t *q, const int32_t *zq,
     const int P = t->n_partitions, B = t->n_brokers, R = t->n_racks, RF = t->rf, NJ = t->rf_cur;
     int32_t bd[8];
     derive_bounds(t, bd);
+    {   // the bands' implied ends, as the LP is built on them (kao_lp.hip lp_open; oracle/kao_lp.py lp_bands): when the brokers' lower ends add up to
+        // all the replicas nobody can be above its lower end (likewise from above; likewise leaders and racks).  Same feasible set; without it the
+        // completion of config 5's "cap + 1" topic used room no feasible assignment has and ended under the certificate (a second solve).
+        const long long tot = (long long)P * RF;
+        if ((long long)B * bd[0] == tot) bd[1] = bd[0]; else if ((long long)B * bd[1] == tot) bd[0] = bd[1];
+        if ((long long)B * bd[2] == P) bd[3] = bd[2]; else if ((long long)B * bd[3] == P) bd[2] = bd[3];
+        if ((long long)R * bd[4] == tot) bd[5] = bd[4]; else if ((long long)R * bd[5] == tot) bd[4] = bd[5];
+    }
     const int lo = bd[0], hi = bd[1], llo = bd[2], lhi = bd[3], phi = bd[7];
     std::vector<int> load((size_t)B, 0), lead_load((size_t)B, 0);
     auto in_row = [&](int p, int b) { for (int k = 0; k < RF; ++k) if (out[(size_t)p * RF + k] == (uint16_t)b) return true; return false; };

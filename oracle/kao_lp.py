@@ -421,7 +421,7 @@ def round_primal(t: ko.Topic, F, L, YF, YL, ZF, ZL, fallback=None, tolc: int = R
     Returns (A [P][RF] dense broker indices, leader first; report dict)."""
     import itertools
     B, R, P, RF, NJ = t.n_brokers, t.n_racks, t.n_partitions, t.rf, t.rf_cur
-    bd = t.bounds()
+    bd = lp_bands(t)      # the implied ends: same feasible set (kao_round.cpp does the same)
     phi = bd["prack_hi"]
     rack = [int(r) for r in np.asarray(t.rack_of)]
     members = [[b for b in range(B) if rack[b] == r] for r in range(R)]
@@ -716,7 +716,7 @@ def complete_by_patterns(t: ko.Topic, A, pending, load0, lead0, target: int, F, 
     On success the rows of `pending` in A are set and every broker is inside its bands; else A is untouched."""
     import itertools
     B, R, P, RF, NJ = t.n_brokers, t.n_racks, t.n_partitions, t.rf, t.rf_cur
-    bd = t.bounds()
+    bd = lp_bands(t)      # the implied ends: same feasible set (kao_round.cpp does the same)
     lo, hi, llo, lhi, phi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"], bd["prack_hi"]
     if phi != 1 or RF > 4 or not pending or len(pending) > PAT_MAX_PARTS: return False
     if getattr(t, "broker_w", None) is not None or getattr(t, "broker_wl", None) is not None: return False
@@ -872,7 +872,7 @@ def repair_broker_bands(t: ko.Topic, A) -> int:
     178-180); a leader whose swap with a follower of its row changes no weight hands over its role.  Partitions in ascending order,
     first fit.  In place; returns the number of moves."""
     B, R, P, RF = t.n_brokers, t.n_racks, t.n_partitions, t.rf
-    bd = t.bounds()
+    bd = lp_bands(t)      # the implied ends: same feasible set (kao_round.cpp does the same)
     lo, hi, llo, lhi, phi = bd["rep_lo"], bd["rep_hi"], bd["lead_lo"], bd["lead_hi"], bd["prack_hi"]
     rack = [int(r) for r in np.asarray(t.rack_of)]
     load = [0] * B; lead = [0] * B
@@ -1012,7 +1012,7 @@ def repair_racks(t: ko.Topic, A) -> int:
     ascending), else its cheapest.  Nothing is tried when the racks are more than RACK_REPAIR_MAX replicas off.  In place; returns the number
     of moves.  (kao_round.cpp, the last block of lp_round_assignment.)"""
     B, R, P, RF = t.n_brokers, t.n_racks, t.n_partitions, t.rf
-    bd = t.bounds()
+    bd = lp_bands(t)      # the implied ends: same feasible set (kao_round.cpp does the same)
     lo, hi, rlo, rhi, plo, phi = bd["rep_lo"], bd["rep_hi"], bd["rack_lo"], bd["rack_hi"], bd["prack_lo"], bd["prack_hi"]
     rack = [int(r) for r in np.asarray(t.rack_of)]
     load = [0] * B; tot = [0] * R
