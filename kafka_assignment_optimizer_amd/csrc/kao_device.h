@@ -70,6 +70,20 @@ __device__ __forceinline__ void wave_sum6(int (&v)[6]) {
     v[3] = __builtin_amdgcn_readlane(u0, 32); v[4] = __builtin_amdgcn_readlane(u0, 48);
     v[2] = __builtin_amdgcn_readlane(u1, 0); v[5] = __builtin_amdgcn_readlane(u1, 32);
 }
+// Four wavefront sums at once: two half folds, one row fold (rows: v0 v1 v2 v3), one DPP block, four v_readlane -- 19 instructions.
+__device__ __forceinline__ void wave_sum4(int (&v)[4]) {
+    int u = fold_rows(fold_halves(v[0], v[2]), fold_halves(v[1], v[3]));
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(u));
+    v[0] = __builtin_amdgcn_readlane(u, 0); v[1] = __builtin_amdgcn_readlane(u, 16);
+    v[2] = __builtin_amdgcn_readlane(u, 32); v[3] = __builtin_amdgcn_readlane(u, 48);
+}
+// lanes of the wavefront (active ones) on which `c` holds: v_cmp into a scalar pair + s_bcnt1 -- a count that needs no vector register, no reduction
+__device__ __forceinline__ int wave_count(bool c) { return __builtin_popcountll(__ballot(c)); }
 __device__ __forceinline__ uint32_t wave_umax(uint32_t v) { return ~wave_umin(~v); }
 __device__ __forceinline__ long long wave_sum64(long long v) {
 #pragma unroll

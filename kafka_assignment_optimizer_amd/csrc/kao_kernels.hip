@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
     const int KR = (R + 15) & ~15;
     const int kcopy = 4 * KR <= kRackTab ? (lane >> 4) * KR : 0;
     const bool k4 = 4 * KR <= kRackTab;
-    const bool big = P * RF > 65535;   // only then can a 16-bit per-broker counter overflow
+    const bool big = !kLds && P * RF > 65535;   // only then can a 16-bit per-broker counter overflow (the RF-3 instantiation runs with the current assignment in LDS: at most 20,480 partitions x 3)
     for (int ci = bm.y + (kCoop ? 0 : wave); ci < bm.y + bm.z; ci += (kCoop ? 1 : kWaves)) {
         const uint16_t *cand = pl.cand + TD->best_off + (uint64_t)ci * P * RF;
         for (int b4 = tid; b4 < nB4; b4 += tstride) reinterpret_cast<uint4 *>(C)[b4] = make_uint4(0, 0, 0, 0);
@@ -1408,7 +1408,10 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
         // no pass over all brokers is needed.  Packed partial sums: low half = #(old >= hi), high = #(old < lo).
         int obj = 0;
         uint32_t s12 = 0;  // v1 | v2 << 16
-        uint32_t s3 = 0, s4 = 0;
+        // C3 / C4 are COUNTS of lanes (old count at or above the upper end, below the lower end): each is a compare into a scalar pair and a
+        // population count, accumulated in scalar registers -- no per-lane sum, no wavefront reduction (round 6, last: they were two of the six
+        // words of wave_sum6 and five vector instructions per slot)
+        int n3hi = 0, n3lo = 0, n4hi = 0, n4lo = 0;
         uint32_t s57 = 0;  // v5 | v7 << 16
         bool ovf = false;
         for (int p = tid; p < P; p += tstride) {
@@ -1427,33 +1430,60 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
                                       : (k < rf_cur ? (uint32_t)curd[(size_t)p * rf_cur + (k < rf_cur ? k : 0)] : 0xFFFFu);
             }
             int missing = 0;
+            // One slot of the trip (KAO_EVAL_SLOT).  VALID is the lane's own "this slot holds a broker", or the literal true when every lane of
+            // the trip has one (the usual case, tested once per trip with a ballot): the body then has no per-lane branch and the counts sit in
+            // wave-uniform control flow.  Otherwise the counts are taken where the lanes have met again -- the scalar accumulators live in every
+            // lane's copy of the loop state, and a lane that sat out a slot would miss its counts (lane 0, whose copy is read in the end, is in
+            // every trip: partitions ascend with the lane).
+#define KAO_EVAL_SLOT(VALID) do { \
+                uint32_t oc = 0; \
+                if (!(VALID)) ++missing; \
+                else { \
+                    rk[k] = RACK[b]; \
+                    oc = atomicAdd(&C[b], k == 0 ? 0x10001u : 1u); \
+                    __hip_atomic_fetch_add(&K[kcopy + rk[k]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+                    if (big) ovf |= (oc & 0xFFFFu) == 0xFFFFu; \
+                    bool fol = false, dup = false; \
+                    _Pragma("unroll") for (int j = 1; j < NE; ++j) fol |= ck[j] == b; \
+                    _Pragma("unroll") for (int j = 0; j < k; ++j) dup |= bk[j] == b; \
+                    obj += (ck[0] == b) ? (k == 0 ? w00 : w01) : (fol ? (k == 0 ? w10 : w11) : 0); \
+                    if (bwd) { const uint32_t bw = bwd[b]; obj += (int)(bw & 0xFFFFu) + (k == 0 ? (int)(bw >> 16) : 0); } \
+                    s57 += (uint32_t)dup;  /* C5: f+l <= 1 (an earlier slot holds the same broker) */ \
+                } \
+                const int cr = (int)(oc & 0xFFFFu); \
+                n3hi += wave_count((VALID) & (cr >= rep_hi)); n3lo += wave_count((VALID) & (cr < rep_lo));         /* C3 */ \
+                if (k == 0) { \
+                    const int cl = (int)(oc >> 16); \
+                    n4hi += wave_count((VALID) & (cl >= lead_hi)); n4lo += wave_count((VALID) & (cl < lead_lo));   /* C4 */ \
+                } \
+            } while (0)
+            bool any_empty = false;
 #pragma unroll
             for (int k = 0; k < RFE; ++k) {
                 if (!RFT && k >= RF) break;
-                const uint32_t b = bk[k];
-                if (b >= (uint32_t)B) { ++missing; continue; }   // empty / out-of-range slot
-                rk[k] = RACK[b];
-                const uint32_t oc = atomicAdd(&C[b], k == 0 ? 0x10001u : 1u);
-                __hip_atomic_fetch_add(&K[kcopy + rk[k]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const int cr = (int)(oc & 0xFFFFu);
-                s3 += (uint32_t)(cr >= rep_hi) + ((uint32_t)(cr < rep_lo) << 16);         // C3
-                if (k == 0) {
-                    const int cl = (int)(oc >> 16);
-                    s4 += (uint32_t)(cl >= lead_hi) + ((uint32_t)(cl < lead_lo) << 16);   // C4
-                }
-                if (big) ovf |= cr == 0xFFFF;
-                bool fol = false, dup = false;
-#pragma unroll
-                for (int j = 1; j < NE; ++j) fol |= ck[j] == b;
-#pragma unroll
-                for (int j = 0; j < k; ++j) dup |= bk[j] == b;
-                obj += (ck[0] == b) ? (k == 0 ? w00 : w01) : (fol ? (k == 0 ? w10 : w11) : 0);
-                if (bwd) { const uint32_t bw = bwd[b]; obj += (int)(bw & 0xFFFFu) + (k == 0 ? (int)(bw >> 16) : 0); }
-                s57 += (uint32_t)dup;  // C5: f+l <= 1 (an earlier slot holds the same broker)
+                any_empty |= bk[k] >= (uint32_t)B;
             }
+            const bool trip_full = __ballot(any_empty) == 0ull;      // wave-uniform: no lane of this trip has an empty / out-of-range slot
+            if (trip_full) {
+#pragma unroll
+                for (int k = 0; k < RFE; ++k) {
+                    if (!RFT && k >= RF) break;
+                    const uint32_t b = bk[k];
+                    KAO_EVAL_SLOT(true);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RFE; ++k) {
+                    if (!RFT && k >= RF) break;
+                    const uint32_t b = bk[k];
+                    const bool valid = b < (uint32_t)B;
+                    KAO_EVAL_SLOT(valid);
+                }
+            }
+#undef KAO_EVAL_SLOT
             s12 += (uint32_t)missing + ((uint32_t)(bk[0] >= (uint32_t)B) << 16);  // C1: sum_b (f+l) = RF ; C2: exactly one leader
             // C7: replicas per partition per rack, over all R racks (each rack counted at its first slot)
-            if (RFT == 3 && __ballot(missing != 0) == 0ull) {
+            if (RFT == 3 && trip_full) {
                 // three filled slots (no lane of this trip has an empty one: wave-uniform) fall on one, two or three racks -- the row's value
                 // in each case is a constant of the topic (c7_one / c7_two / c7_three: the sums the general loop below would form)
                 const bool e01 = rk[0] == rk[1], e02 = rk[0] == rk[2], e12 = rk[1] == rk[2];
@@ -1481,20 +1511,17 @@ __global__ __launch_bounds__(256) void k_eval(EvalPools pl) {
         }
         if (big && __ballot(ovf) != 0ull && pl.overflow && lane == 0) atomicOr(pl.overflow, 1);
         int v1, v2, v3, v4, v5, v6, v7;   // (v3, v4 without their constants B * lo until the partial sums have met)
-        if (P * RF <= 32767) {  // packed halves cannot carry: every count is at most P*RF -- the six words are summed in one go (wave_sum6)
-            int t[6] = {obj, (int)s12, (int)s3, (int)s4, (int)s57, s6};
-            wave_sum6(t);
-            const uint32_t t12 = (uint32_t)t[1], t3 = (uint32_t)t[2], t4 = (uint32_t)t[3], t57 = (uint32_t)t[4];
-            obj = t[0]; v6 = t[5];
+        v3 = __builtin_amdgcn_readfirstlane(n3hi - n3lo); v4 = __builtin_amdgcn_readfirstlane(n4hi - n4lo);      // lane 0's copy (see above): wave-uniform from here on
+        if (P * RF <= 32767) {  // packed halves cannot carry: every count is at most P*RF -- the four words are summed in one go (wave_sum4)
+            int t[4] = {obj, (int)s12, (int)s57, s6};
+            wave_sum4(t);
+            const uint32_t t12 = (uint32_t)t[1], t57 = (uint32_t)t[2];
+            obj = t[0]; v6 = t[3];
             v1 = (int)(t12 & 0xFFFFu); v2 = (int)(t12 >> 16);
-            v3 = (int)(t3 & 0xFFFFu) - (int)(t3 >> 16);
-            v4 = (int)(t4 & 0xFFFFu) - (int)(t4 >> 16);
             v5 = (int)(t57 & 0xFFFFu); v7 = (int)(t57 >> 16);
         } else {  // huge topic: per-lane halves still fit 16 bits, the wavefront totals do not -> sum them unpacked
             obj = wave_sum(obj);
             v1 = wave_sum((int)(s12 & 0xFFFFu)); v2 = wave_sum((int)(s12 >> 16));
-            v3 = wave_sum((int)(s3 & 0xFFFFu)) - wave_sum((int)(s3 >> 16));
-            v4 = wave_sum((int)(s4 & 0xFFFFu)) - wave_sum((int)(s4 >> 16));
             v5 = wave_sum((int)(s57 & 0xFFFFu)); v7 = wave_sum((int)(s57 >> 16));
             v6 = wave_sum(s6);
         }
