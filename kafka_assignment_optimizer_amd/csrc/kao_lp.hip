@@ -251,7 +251,17 @@ constexpr int kLpSigmaExp = 10;
 // iterations instead of 527 (0.3: 487, 0.03: 538; profiles/r06_c32_start_floor.txt).
 constexpr double kLpXFloor = 0.1;
 static double lp_xfloor() { const char *e = std::getenv("KAO_LP_XFLOOR"); const double f = e ? std::atof(e) : kLpXFloor; return f > 0.0 && f <= 10.0 ? f : kLpXFloor; }   // (measurement hook)
-static double lp_sigexp() { const char *e = std::getenv("KAO_LP_SIGEXP"); const int k = e ? std::atoi(e) : kLpSigmaExp; return k >= 1 && k <= 64 ? k : kLpSigmaExp; }   // (measurement hook)
+// Topics of more than kLpSigmaHugeSlots replica slots (the ones kao_solve gives their LP alone) take kLpSigmaExpHuge: with the starting point's floor at
+// 0.1 the iteration count keeps falling up to ~24 there (13 drifted 100,000-partition topics: 761 iterations at 10, 663 at 14, 554 at 20, 508 at 24,
+// 503-525 at 32-64; profiles/r06_c36_sigma_exponent_huge.txt) -- but on the small goldens 24 leaves 11 rounded iterates outside a band row instead of 4,
+// so smaller topics keep 10.
+constexpr int kLpSigmaExpHuge = 24;
+constexpr long long kLpSigmaHugeSlots = 131072;
+static double lp_sigexp(long long slots) {
+    const int dflt = slots > kLpSigmaHugeSlots ? kLpSigmaExpHuge : kLpSigmaExp;
+    const char *e = std::getenv("KAO_LP_SIGEXP"); const int k = e ? std::atoi(e) : dflt;      // (measurement hook)
+    return k >= 1 && k <= 64 ? k : dflt;
+}
 static double lp_gamma() { const char *e = std::getenv("KAO_LP_GAMMA"); const double g = e ? std::atof(e) : 0.0; return g > 0.5 && g < 1.0 ? g : 0.0; }
 __device__ __forceinline__ double lp_step_fraction(double a, double fixed) { return fixed > 0.0 ? fixed : (a > kLpGammaMax ? kLpGammaMax : (a < kLpGamma ? kLpGamma : a)); }
 __global__ void k_lp_sc_final(double *sc) {
@@ -1615,7 +1625,7 @@ int lp_begin(LpCtx *cp, double tol, int maxit, double pert, uint32_t salt) {
     c.used = true;
     double init[kScN];
     std::memset(init, 0, sizeof init);
-    init[SC_GAMMA] = lp_gamma(); init[SC_SIGEXP] = lp_sigexp(); init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
+    init[SC_GAMMA] = lp_gamma(); init[SC_SIGEXP] = lp_sigexp((long long)c.D.Pg * c.D.RF); init[SC_TOL] = tol; init[SC_MAXIT] = c.maxit; init[SC_NVU] = (double)(c.nvar + c.nub); init[SC_NB] = c.nb; init[SC_NCN] = c.ncn;
     init[SC_PERT] = pert > 0.0 ? pert : 0.0; init[SC_SALT] = (double)salt;
     init[SC_MU_REF] = 1e300; init[SC_IT_REF] = 0.0; init[SC_PINF_BEST] = 1e300;
     std::memcpy(c.h_sc, init, sizeof init);

@@ -210,12 +210,12 @@ struct SolveRun {
     // Predicted seconds of ONE perturbed interior-point solve of topic i alone on the device, from counts (the choice of
     // algorithm was keyed on fixed limits, 1.5 / 1.3 s, so a 1-second caller never got the LP).  An iteration costs lp_ms_base +
     // lp_ms_tile per 64-row tile of the Schur complement (3R + 2B rows: the Cholesky and the triangular solves walk the tiles one after
-    // the other) + lp_ms_kpart per 1,000 partitions (everything else streams the partitions); the perturbed solve takes 55-80
-    // iterations at tolerance 1e-10 on drifted topics of 30,000-200,000 partitions (lp_iters_est; 105-150 before the centering exponent 10, the
+    // the other) + lp_ms_kpart per 1,000 partitions (everything else streams the partitions); the perturbed solve takes 35-55
+    // iterations at tolerance 1e-10 on drifted topics of 30,000-300,000 partitions (lp_iters_est; 105-150 before the centering exponent 10, the
     // step fraction and the starting point's floor, docs/notes_r06.md sections 23-25), plus lp_s_fixed + lp_s_kpart per 1,000 partitions for the context, the
     // starting point, the read-back and the rounding (0.12 s at 100,000 partitions).  Constants measured on one MI355X (round 6, profiles/r06_*); a limit is an input,
     // not the clock: the schedule stays count-keyed.
-    double lp_ms_base = 0.50, lp_ms_tile = 0.05, lp_ms_kpart = 0.020, lp_iters_est = 80.0, lp_s_fixed = 0.06, lp_s_kpart = 0.0006, lp_fit = 0.8;
+    double lp_ms_base = 0.50, lp_ms_tile = 0.05, lp_ms_kpart = 0.020, lp_iters_est = 60.0, lp_s_fixed = 0.06, lp_s_kpart = 0.0006, lp_fit = 0.8;
     // beyond 20 racks both grow (1000 x 100,000 at 30 / 40 / 50 racks: 4.9 / 5.9 / 6.7 ms an iteration against 4.0; 74 iterations at 40 racks against 66 at 20): the
     // per-partition rack work of the eliminations and of the Schur rows, and a slower approach to the vertex
     double lp_ms_kpart_rack = 0.0009, lp_iters_rack = 0.5;

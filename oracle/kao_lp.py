@@ -175,10 +175,11 @@ def exact_dual_value(t: ko.Topic, a, l, g) -> float:
 MCC_DELTA, MCC_BMIN, MCC_BMAX = 0.3, 0.1, 10.0      # Gondzio's centrality correctors (oracle/kao_lp_port.c, kao_lp.hip)
 START_X_FLOOR = 0.1                                 # the starting point's x = max(x~, this), capped at half the upper bound (1.0 until late in round 6: notes section 25)
 SIGMA_EXP = 10                                      # sigma = (mu_aff / mu)^SIGMA_EXP (Mehrotra's 3 until late in round 6: docs/notes_r06.md section 24)
+SIGMA_EXP_HUGE, SIGMA_HUGE_SLOTS = 24, 131072       # ... and ^SIGMA_EXP_HUGE on topics of more than SIGMA_HUGE_SLOTS replica slots (section 29; ipm's `sigma_exp`)
 STEP_FRACTION, STEP_FRACTION_MAX = 0.9, 0.9995      # a blocked step of length a goes min(MAX, max(FRACTION, a)) of the way to the boundary (kao_lp.hip k_lp_sc_final; 0.9995 throughout until late in round 6)
 
 
-def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, trace=None, mcc: int = 2):
+def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, trace=None, mcc: int = 2, sigma_exp: int = SIGMA_EXP):
     """Mehrotra predictor-corrector on min c x, A x = b, 0 <= x <= u -- the iteration kao_lp.hip runs on the block structure
     (same starting point, same step rule, same stopping rule), here with generic sparse algebra.  Returns (x, y, iterations,
     primal objective, dual objective).  `trace`, if a list, receives (mu, pobj, dobj, pinf, dinf) per iteration.  Up to `mcc`
@@ -239,7 +240,7 @@ def ipm(lp: CompactLP, tol: float = 1e-7, maxit: int = 80, reg: float = 1e-10, t
         ap = min(maxstep(x, dx), maxstep(w, -dx, U)); ad = min(maxstep(s, ds), maxstep(v, dv, U))
         mu_aff = ((x + ap * dx) @ (s + ad * ds) + ((w - ap * dx) * (v + ad * dv))[U].sum()) / (n + nU)
         sigma = mu_aff / mu
-        for _ in range(SIGMA_EXP - 1):      # the powers multiplied up one by one, as the restatement and the device do
+        for _ in range(sigma_exp - 1):      # the powers multiplied up one by one, as the restatement and the device do
             sigma *= mu_aff / mu
         dx, dy, ds, dv = direction(sigma * mu - x * s - dx * ds, np.where(U, sigma * mu - w * v + dx * dv, 0.0))
         ap = min(maxstep(x, dx), maxstep(w, -dx, U)); ad = min(maxstep(s, ds), maxstep(v, dv, U))

@@ -449,6 +449,8 @@ static void vec_free(lp_vec *v) { free(v->z); free(v->zg); free(v->r1); free(v->
  * the complementarity products of that trial point are projected onto [MCC_BMIN, MCC_BMAX] x (sigma mu), and the difference is the
  * right-hand side of one more solve with the same factor; the corrected direction is kept when it lengthens a step. ---- */
 #define SIGMA_EXP 10
+#define SIGMA_EXP_HUGE 24          /* topics of more than SIGMA_HUGE_SLOTS replica slots (kao_lp.hip lp_sigexp) */
+#define SIGMA_HUGE_SLOTS 131072
 #define START_X_FLOOR 0.1
 #define STEP_FRACTION 0.9
 #define STEP_FRACTION_MAX 0.9995
@@ -709,8 +711,9 @@ int kao_lp_port_solve_p(const port_topic *t, double tol, int maxit, double eps, 
                 const double mu_aff = xs2 / (double)(nvar + nub), ratio = mu_aff / mu;
                 {   /* sigma = (mu_aff / mu)^SIGMA_EXP, the powers multiplied up one by one (kao_lp.hip k_lp_sc_sigma; KAO_LP_SIGEXP: same hook) */
                     const char *e = getenv("KAO_LP_SIGEXP");
-                    int ke = e ? atoi(e) : SIGMA_EXP;
-                    if (ke < 1 || ke > 64) ke = SIGMA_EXP;
+                    const int dflt = (long long)t->n_partitions * t->rf > SIGMA_HUGE_SLOTS ? SIGMA_EXP_HUGE : SIGMA_EXP;
+                    int ke = e ? atoi(e) : dflt;
+                    if (ke < 1 || ke > 64) ke = dflt;
                     double sg = ratio;
                     for (int k = 1; k < ke; ++k) sg *= ratio;
                     sigma_mu = sg * mu;

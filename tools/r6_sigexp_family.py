@@ -20,7 +20,8 @@ for (name, B, R, P, RF, dr, ds, bo) in cases:
     t = sy.drift(sy.make_cluster(B, R, 1, P, RF, [], [], **({"bounds_override": bo} if bo else {})), dr, ds)[0]
     kao.solve([t], seed=1, max_launches=1)
     for e in exps:
-        os.environ["KAO_LP_SIGEXP"] = e
+        if e == "default": os.environ.pop("KAO_LP_SIGEXP", None)      # the shipped rule (10; 24 on topics of more than 131,072 slots)
+        else: os.environ["KAO_LP_SIGEXP"] = e
         r = kao.solve([t], seed=3, stop_at_bound=1, time_limit_s=float(os.environ.get('LIMIT', '3.0')))[0]
         tm = kao.last_solve_timing(); lp = kao.last_solve_lp()
         tot[e][0] += r.status == "OPTIMAL_PROVEN"; tot[e][1] += tm["results_read_back"]; tot[e][2] += int(lp["solves"]); tot[e][3] += int(lp["iterations"])
